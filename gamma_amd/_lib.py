@@ -1,0 +1,106 @@
+"""ctypes loader for libgamma_hip.so (the C ABI in include/gamma_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or a call fails, an exception is
+raised.  The oracle under oracle/ is never imported from here.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgamma_hip.so")
+
+f32p = C.POINTER(C.c_float)
+i64p = C.POINTER(C.c_int64)
+i32p = C.POINTER(C.c_int32)
+u8p = C.POINTER(C.c_uint8)
+
+NUM_STAGES = 6
+STAGE_NAMES = ["coarse", "tables", "scan", "select", "rerank", "flat"]
+
+
+class RangeFilter(C.Structure):
+    _fields_ = [("bitmap", u8p), ("bitmap_bytes", C.c_int64), ("min_doc", C.c_int32),
+                ("max_doc", C.c_int32), ("min_aligned", C.c_int32), ("b_not_in", C.c_int32)]
+
+
+class SearchParams(C.Structure):
+    _fields_ = [("metric", C.c_int32), ("nprobe", C.c_int32), ("recall_num", C.c_int32),
+                ("has_rank", C.c_int32), ("min_score", C.c_float), ("max_score", C.c_float),
+                ("coarse_mode", C.c_int32), ("has_range", C.c_int32), ("n_range", C.c_int32),
+                ("range", C.POINTER(RangeFilter))]
+
+
+# name -> (restype, argtypes); every symbol include/gamma_hip.h declares
+SYMBOLS = {
+    "gamma_hip_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "gamma_hip_destroy": (C.c_int, [C.c_void_p]),
+    "gamma_hip_strerror": (C.c_char_p, [C.c_int]),
+    "gamma_hip_last_error": (C.c_char_p, [C.c_void_p]),
+    "gamma_hip_stream": (C.c_void_p, [C.c_void_p]),
+    "gamma_hip_synchronize": (C.c_int, [C.c_void_p]),
+    "gamma_hip_raw_init": (C.c_int, [C.c_void_p, C.c_int]),
+    "gamma_hip_raw_append": (C.c_int, [C.c_void_p, C.c_int64, f32p]),
+    "gamma_hip_raw_update": (C.c_int, [C.c_void_p, C.c_int64, f32p]),
+    "gamma_hip_raw_count": (C.c_int64, [C.c_void_p]),
+    "gamma_hip_bitmap_upload": (C.c_int, [C.c_void_p, u8p, C.c_int64]),
+    "gamma_hip_bitmap_set": (C.c_int, [C.c_void_p, i64p, C.c_int64, C.c_int]),
+    "gamma_hip_ivfpq_init": (C.c_int, [C.c_void_p] + [C.c_int] * 7),
+    "gamma_hip_ivfpq_set_trained": (C.c_int, [C.c_void_p, f32p, f32p, f32p]),
+    "gamma_hip_ivfpq_get_precomputed_table": (C.c_int, [C.c_void_p, f32p]),
+    "gamma_hip_ivfpq_add_keys": (C.c_int, [C.c_void_p, C.c_int, C.c_int, i64p, u8p]),
+    "gamma_hip_ivfpq_add_keys_batch": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p, i64p, u8p]),
+    "gamma_hip_ivfpq_update": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, u8p]),
+    "gamma_hip_ivfpq_delete": (C.c_int, [C.c_void_p, i64p, C.c_int]),
+    "gamma_hip_ivfpq_compact_if_need": (C.c_int, [C.c_void_p]),
+    "gamma_hip_ivfpq_list_size": (C.c_int64, [C.c_void_p, C.c_int]),
+    "gamma_hip_ivfpq_list_capacity": (C.c_int64, [C.c_void_p, C.c_int]),
+    "gamma_hip_ivfpq_get_list": (C.c_int, [C.c_void_p, C.c_int, i64p, u8p]),
+    "gamma_hip_ivfpq_set_list_mask": (C.c_int, [C.c_void_p, u8p]),
+    "gamma_hip_ivfpq_add": (C.c_int, [C.c_void_p, C.c_int64, f32p, C.c_int64]),
+    "gamma_hip_ivfpq_encode": (C.c_int, [C.c_void_p, C.c_int64, f32p, i64p, u8p]),
+    "gamma_hip_ivfpq_search": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int, f32p, C.c_int,
+                                         f32p, i64p]),
+    "gamma_hip_ivfpq_search_device": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int,
+                                                C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "gamma_hip_ivfpq_last_stages": (C.c_int, [C.c_void_p, f32p, i64p, f32p, i64p]),
+    "gamma_hip_ivfpq_search_shard": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int,
+                                               C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "gamma_hip_ivfpq_merge_rerank": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int, C.c_int,
+                                               C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                               C.c_int, C.c_void_p, C.c_void_p]),
+    "gamma_hip_flat_search": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int, f32p, C.c_int,
+                                        f32p, i64p]),
+    "gamma_hip_flat_search_device": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int,
+                                               C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "gamma_hip_total_mem_bytes": (C.c_int64, [C.c_void_p]),
+    "gamma_hip_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "gamma_hip_profile_reset": (C.c_int, [C.c_void_p]),
+    "gamma_hip_profile_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double),
+                                        C.POINTER(C.c_int64)]),
+    "gamma_hip_profile_scan_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64),
+                                               C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+
+
+class GammaHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libgamma_hip.so and bind every symbol of the C ABI.  Raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GammaHipError(
+                "libgamma_hip.so not found at %s -- build it with `python -c 'import "
+                "__graft_entry__ as g; g.build()'` or `make -C gamma_amd/csrc` (no CPU fallback)"
+                % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib

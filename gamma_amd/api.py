@@ -1,0 +1,281 @@
+"""Thin Python face of the libgamma_hip.so C ABI (include/gamma_hip.h), used by the tests,
+bench.py and the multi-GPU driver.  numpy in / numpy out for host calls; raw device
+pointers (ints) for the *_device entry points.  All compute happens in the HIP library.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import GammaHipError, RangeFilter, SearchParams
+
+METRIC_IP = 0
+METRIC_L2 = 1
+
+FLT_TINY = float(np.finfo(np.float32).tiny)
+FLT_MAX = float(np.finfo(np.float32).max)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+def make_range_filter(docids, b_not_in=False):
+    """RangeQueryResult-shaped filter (table/range_query_result.h:96-125) from matching docids.
+    Returns (RangeFilter, keepalive array)."""
+    docids = np.asarray(sorted(set(int(x) for x in docids)), dtype=np.int64)
+    mn, mx = (int(docids[0]), int(docids[-1])) if len(docids) else (0, 0)
+    min_aligned = (mn // 8) * 8
+    max_aligned = (mx // 8 + 1) * 8 - 1
+    bm = np.zeros(((max_aligned - min_aligned + 1) >> 3) + 1, dtype=np.uint8)
+    rel = docids - min_aligned
+    np.bitwise_or.at(bm, rel >> 3, (1 << (rel & 7)).astype(np.uint8))
+    rf = RangeFilter(_p(bm, _lib.u8p), bm.size, mn, mx, min_aligned, 1 if b_not_in else 0)
+    return rf, bm
+
+
+class SearchArgs:
+    """Builds a gamma_hip_search_params; keeps the filter buffers alive."""
+
+    def __init__(self, metric=METRIC_L2, nprobe=1, recall_num=100, has_rank=True, min_score=None,
+                 max_score=None, coarse_mode=-1, range_filters=None):
+        p = SearchParams()
+        p.metric = metric
+        p.nprobe = nprobe
+        p.recall_num = recall_num
+        p.has_rank = 1 if has_rank else 0
+        # GammaSearchCondition defaults (common/gamma_common_data.h:50-51)
+        p.min_score = FLT_TINY if min_score is None else min_score
+        p.max_score = FLT_MAX if max_score is None else max_score
+        p.coarse_mode = coarse_mode
+        self._keep = []
+        if range_filters is not None:
+            p.has_range = 1
+            p.n_range = len(range_filters)
+            arr = (RangeFilter * max(1, len(range_filters)))()
+            for i, (rf, ka) in enumerate(range_filters):
+                arr[i] = rf
+                self._keep.append(ka)
+            p.range = C.cast(arr, C.POINTER(RangeFilter))
+            self._keep.append(arr)
+        self.p = p
+
+    def ref(self):
+        return C.byref(self.p)
+
+
+class GammaHip:
+    """One handle = one GPU (or one shard)."""
+
+    def __init__(self, device=0):
+        self.L = _lib.load()
+        h = C.c_void_p()
+        rc = self.L.gamma_hip_create(device, C.byref(h))
+        if rc != 0:
+            raise GammaHipError("gamma_hip_create(device=%d): %s" % (
+                device, self.L.gamma_hip_strerror(rc).decode()))
+        self.h = h
+        self.d = None
+        self.M = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.gamma_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise GammaHipError("%s: %s (%s)" % (
+                what, self.L.gamma_hip_strerror(rc).decode(),
+                self.L.gamma_hip_last_error(self.h).decode()))
+
+    # ---- raw store / bitmap ----
+    def raw_init(self, d):
+        self._ck(self.L.gamma_hip_raw_init(self.h, d), "raw_init")
+        self.raw_d = d
+
+    def raw_append(self, vecs):
+        vecs = _f32(vecs)
+        self._ck(self.L.gamma_hip_raw_append(self.h, vecs.shape[0], _p(vecs, _lib.f32p)), "raw_append")
+
+    def raw_update(self, vid, vec):
+        vec = _f32(vec)
+        self._ck(self.L.gamma_hip_raw_update(self.h, vid, _p(vec, _lib.f32p)), "raw_update")
+
+    def raw_count(self):
+        return self.L.gamma_hip_raw_count(self.h)
+
+    def bitmap_upload(self, bitmap, nbits):
+        bitmap = np.ascontiguousarray(bitmap, dtype=np.uint8)
+        self._ck(self.L.gamma_hip_bitmap_upload(self.h, _p(bitmap, _lib.u8p), nbits), "bitmap_upload")
+
+    def bitmap_set(self, docids, value=1):
+        docids = np.ascontiguousarray(docids, dtype=np.int64)
+        self._ck(self.L.gamma_hip_bitmap_set(self.h, _p(docids, _lib.i64p), len(docids), value),
+                 "bitmap_set")
+
+    # ---- ivfpq model ----
+    def ivfpq_init(self, d, nlist, M, nbits=8, metric=METRIC_L2, bucket_init_size=1000,
+                   bucket_max_size=1280000):
+        self._ck(self.L.gamma_hip_ivfpq_init(self.h, d, nlist, M, nbits, metric, bucket_init_size,
+                                             bucket_max_size), "ivfpq_init")
+        self.d, self.nlist, self.M = d, nlist, M
+
+    def ivfpq_set_trained(self, coarse_centroids, pq_centroids, table=None):
+        cc, pq = _f32(coarse_centroids), _f32(pq_centroids)
+        t = _f32(table) if table is not None else None
+        self._ck(self.L.gamma_hip_ivfpq_set_trained(self.h, _p(cc, _lib.f32p), _p(pq, _lib.f32p),
+                                                    _p(t, _lib.f32p)), "ivfpq_set_trained")
+
+    def ivfpq_table(self):
+        out = np.empty((self.nlist, self.M, 256), dtype=np.float32)
+        self._ck(self.L.gamma_hip_ivfpq_get_precomputed_table(self.h, _p(out, _lib.f32p)), "get_table")
+        return out
+
+    def add_keys(self, list_no, vids, codes):
+        vids = np.ascontiguousarray(vids, dtype=np.int64)
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        self._ck(self.L.gamma_hip_ivfpq_add_keys(self.h, list_no, len(vids), _p(vids, _lib.i64p),
+                                                 _p(codes, _lib.u8p)), "add_keys")
+
+    def add_keys_batch(self, list_nos, counts, vids, codes):
+        list_nos = np.ascontiguousarray(list_nos, dtype=np.int32)
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
+        vids = np.ascontiguousarray(vids, dtype=np.int64)
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        self._ck(self.L.gamma_hip_ivfpq_add_keys_batch(
+            self.h, len(list_nos), _p(list_nos, _lib.i32p), _p(counts, _lib.i32p),
+            _p(vids, _lib.i64p), _p(codes, _lib.u8p)), "add_keys_batch")
+
+    def add_encoded(self, list_nos, codes, first_vid=0):
+        """Add pre-encoded vectors (vid = first_vid + row), grouped by list in ascending list
+        order like GammaIVFPQIndex::Add's std::map (gamma_index_ivfpq.cc:428-494)."""
+        list_nos = np.asarray(list_nos, dtype=np.int64)
+        order = np.argsort(list_nos, kind="stable")
+        lists, counts = np.unique(list_nos, return_counts=True)
+        self.add_keys_batch(lists, counts, first_vid + order, np.asarray(codes)[order])
+
+    def update(self, list_no, vid, code):
+        code = np.ascontiguousarray(code, dtype=np.uint8)
+        self._ck(self.L.gamma_hip_ivfpq_update(self.h, list_no, vid, _p(code, _lib.u8p)), "update")
+
+    def delete(self, vids):
+        vids = np.ascontiguousarray(vids, dtype=np.int64)
+        self._ck(self.L.gamma_hip_ivfpq_delete(self.h, _p(vids, _lib.i64p), len(vids)), "delete")
+
+    def compact_if_need(self):
+        self._ck(self.L.gamma_hip_ivfpq_compact_if_need(self.h), "compact_if_need")
+
+    def list_size(self, l):
+        return self.L.gamma_hip_ivfpq_list_size(self.h, l)
+
+    def list_capacity(self, l):
+        return self.L.gamma_hip_ivfpq_list_capacity(self.h, l)
+
+    def get_list(self, l):
+        n = self.list_size(l)
+        ids = np.empty(n, dtype=np.int64)
+        codes = np.empty((n, self.M), dtype=np.uint8)
+        self._ck(self.L.gamma_hip_ivfpq_get_list(self.h, l, _p(ids, _lib.i64p), _p(codes, _lib.u8p)),
+                 "get_list")
+        return ids, codes
+
+    def set_list_mask(self, owned):
+        owned = np.ascontiguousarray(owned, dtype=np.uint8) if owned is not None else None
+        self._ck(self.L.gamma_hip_ivfpq_set_list_mask(self.h, _p(owned, _lib.u8p)), "set_list_mask")
+
+    def add(self, vecs, first_vid):
+        vecs = _f32(vecs)
+        self._ck(self.L.gamma_hip_ivfpq_add(self.h, vecs.shape[0], _p(vecs, _lib.f32p), first_vid), "add")
+
+    def encode(self, vecs):
+        vecs = _f32(vecs)
+        n = vecs.shape[0]
+        lno = np.empty(n, dtype=np.int64)
+        codes = np.empty((n, self.M), dtype=np.uint8)
+        self._ck(self.L.gamma_hip_ivfpq_encode(self.h, n, _p(vecs, _lib.f32p), _p(lno, _lib.i64p),
+                                               _p(codes, _lib.u8p)), "encode")
+        return lno, codes
+
+    # ---- search (host buffers) ----
+    def ivfpq_search(self, x, k, args):
+        x = _f32(x)
+        nq = x.shape[0]
+        D = np.empty((nq, max(k, 0)), dtype=np.float32)
+        I = np.empty((nq, max(k, 0)), dtype=np.int64)
+        self._ck(self.L.gamma_hip_ivfpq_search(self.h, args.ref(), nq, _p(x, _lib.f32p), k,
+                                               _p(D, _lib.f32p), _p(I, _lib.i64p)), "ivfpq_search")
+        return D, I
+
+    def last_stages(self, nq, nprobe, R):
+        cd = np.empty((nq, nprobe), dtype=np.float32)
+        ci = np.empty((nq, nprobe), dtype=np.int64)
+        rd = np.empty((nq, R), dtype=np.float32)
+        ri = np.empty((nq, R), dtype=np.int64)
+        self._ck(self.L.gamma_hip_ivfpq_last_stages(self.h, _p(cd, _lib.f32p), _p(ci, _lib.i64p),
+                                                    _p(rd, _lib.f32p), _p(ri, _lib.i64p)), "last_stages")
+        return dict(coarse_dis=cd, coarse_idx=ci, recall_dis=rd, recall_ids=ri)
+
+    def flat_search(self, x, k, args):
+        x = _f32(x)
+        nq = x.shape[0]
+        D = np.empty((nq, max(k, 0)), dtype=np.float32)
+        I = np.empty((nq, max(k, 0)), dtype=np.int64)
+        self._ck(self.L.gamma_hip_flat_search(self.h, args.ref(), nq, _p(x, _lib.f32p), k,
+                                              _p(D, _lib.f32p), _p(I, _lib.i64p)), "flat_search")
+        return D, I
+
+    # ---- search (device pointers, async on the handle's stream) ----
+    def ivfpq_search_device(self, d_x, nq, k, args, d_D, d_I):
+        self._ck(self.L.gamma_hip_ivfpq_search_device(self.h, args.ref(), nq, d_x, k, d_D, d_I),
+                 "ivfpq_search_device")
+
+    def flat_search_device(self, d_x, nq, k, args, d_D, d_I):
+        self._ck(self.L.gamma_hip_flat_search_device(self.h, args.ref(), nq, d_x, k, d_D, d_I),
+                 "flat_search_device")
+
+    def ivfpq_search_shard(self, d_x, nq, k, args, d_rdis, d_rids):
+        self._ck(self.L.gamma_hip_ivfpq_search_shard(self.h, args.ref(), nq, d_x, k, d_rdis, d_rids),
+                 "ivfpq_search_shard")
+
+    def ivfpq_merge_rerank(self, nshards, nq, d_x, k, args, d_all_dis, d_all_ids, q0, nq_local, d_D, d_I):
+        self._ck(self.L.gamma_hip_ivfpq_merge_rerank(self.h, args.ref(), nshards, nq, d_x, k, d_all_dis,
+                                                     d_all_ids, q0, nq_local, d_D, d_I), "merge_rerank")
+
+    # ---- misc ----
+    def stream(self):
+        return self.L.gamma_hip_stream(self.h)
+
+    def synchronize(self):
+        self._ck(self.L.gamma_hip_synchronize(self.h), "synchronize")
+
+    def total_mem_bytes(self):
+        return self.L.gamma_hip_total_mem_bytes(self.h)
+
+    def profile_enable(self, on=True):
+        self._ck(self.L.gamma_hip_profile_enable(self.h, 1 if on else 0), "profile_enable")
+
+    def profile_reset(self):
+        self._ck(self.L.gamma_hip_profile_reset(self.h), "profile_reset")
+
+    def profile(self):
+        out = {}
+        for i, name in enumerate(_lib.STAGE_NAMES):
+            ms, n = C.c_double(), C.c_int64()
+            self._ck(self.L.gamma_hip_profile_get(self.h, i, C.byref(ms), C.byref(n)), "profile_get")
+            out[name] = (ms.value, n.value)
+        b, pr = C.c_int64(), C.c_int64()
+        self._ck(self.L.gamma_hip_profile_scan_bytes(self.h, C.byref(b), C.byref(pr)), "scan_bytes")
+        out["scan_bytes"] = b.value
+        out["scan_pairs"] = pr.value
+        return out

@@ -1,0 +1,1205 @@
+// gamma_hip.cpp -- host side of libgamma_hip.so: the handle, HBM-resident state
+// (coarse centroids, PQ codebooks, precomputed table, realtime inverted-list arena, raw
+// vectors, delete bitmap), workspace management and the search pipelines, behind the
+// C ABI declared in include/gamma_hip.h.  No CPU fallback: every entry point either runs
+// the HIP kernels of kernels.hip or returns an error.
+#include "../../include/gamma_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace {
+
+constexpr double kPI = 3.14159265;  // realtime/realtime_mem_data.h:24
+constexpr int64_t kDelMask = (int64_t)(1ULL << 63);
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) {
+            hipError_t e = hipFree(p);
+            if (e != hipSuccess) return e;
+            p = nullptr;
+            cap = 0;
+        }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return e;
+        }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T>
+    T* as() const {
+        return reinterpret_cast<T*>(p);
+    }
+};
+
+struct StageEvent {
+    int stage;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct gamma_hip_index {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::string err;
+
+    // raw vector store
+    int raw_d = 0;
+    float* d_raw = nullptr;
+    int64_t nraw = 0, raw_cap = 0;
+
+    // delete bitmap
+    uint8_t* d_bitmap = nullptr;
+    int64_t bitmap_bits = 0;
+    size_t bitmap_cap_bytes = 0;
+    std::vector<uint8_t> h_bitmap;
+
+    // IVFPQ model
+    bool ivf_init = false, trained = false;
+    int d = 0, nlist = 0, M = 0, ksub = 256, dsub = 0, code_size = 0, metric = GAMMA_HIP_METRIC_L2;
+    int bucket_init = 1000, bucket_max = 1280000;
+    float *d_cc = nullptr, *d_cc_norms = nullptr, *d_pqc = nullptr, *d_T2 = nullptr;
+
+    // inverted-list arena
+    uint8_t* d_codes = nullptr;
+    int64_t* d_ids = nullptr;
+    int64_t arena_cap = 0, arena_used = 0, arena_waste = 0;
+    std::vector<int64_t> h_list_off;
+    std::vector<int> h_list_len, h_list_cap, h_deleted;
+    std::vector<uint8_t> h_extend_time;
+    int64_t* d_list_off = nullptr;
+    int* d_list_len = nullptr;
+    uint8_t* d_list_mask = nullptr;
+    std::vector<uint8_t> h_list_mask;
+    std::vector<int64_t> vid_pos;
+    int max_list_len = 0;
+    int64_t ntotal = 0;
+
+    // workspace
+    DevBuf w_mat, w_coarse_dis, w_probe, w_xn, w_st2, w_pair_off, w_qtotal, w_dist, w_cand_dis,
+            w_cand_pos, w_cand_ids, w_exact, w_selv, w_selp, w_x, w_outd, w_outl, w_stage, w_filter,
+            w_m_dis, w_m_ids, w_part_v, w_part_i, w_assign, w_codes_tmp;
+    unsigned long long* d_scan_codes = nullptr;
+    size_t dist_budget_bytes = (size_t)2 << 30;
+
+    // last-search stage info
+    int last_nq = 0, last_P = 0, last_R = 0;
+
+    // profiling
+    bool profile = false;
+    std::vector<StageEvent> events;
+    double stage_ms[GAMMA_HIP_NUM_STAGES] = {0};
+    int64_t stage_n[GAMMA_HIP_NUM_STAGES] = {0};
+    int64_t scan_pairs = 0;
+};
+
+namespace {
+
+using H = gamma_hip_index;
+
+#define GH_CHECK(h, expr)                                                                  \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                  \
+            return e_ == hipErrorOutOfMemory ? GAMMA_HIP_ENOMEM : GAMMA_HIP_EDEVICE;       \
+        }                                                                                  \
+    } while (0)
+
+#define GH_TRY(expr)                   \
+    do {                               \
+        int rc_ = (expr);              \
+        if (rc_ != GAMMA_HIP_OK) return rc_; \
+    } while (0)
+
+int fail(H* h, int code, const char* msg) {
+    h->err = msg;
+    return code;
+}
+
+struct StageScope {
+    H* h;
+    int stage;
+    hipEvent_t a = nullptr, b = nullptr;
+    StageScope(H* h_, int st) : h(h_), stage(st) {
+        if (h->profile) {
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+                a = b = nullptr;
+                return;
+            }
+            (void)hipEventRecord(a, h->stream);
+        }
+    }
+    ~StageScope() {
+        if (a && b) {
+            (void)hipEventRecord(b, h->stream);
+            h->events.push_back({stage, a, b});
+        }
+    }
+};
+
+int drain_events(H* h) {
+    if (h->events.empty()) return GAMMA_HIP_OK;
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    for (auto& e : h->events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            h->stage_ms[e.stage] += ms;
+            h->stage_n[e.stage] += 1;
+        }
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    h->events.clear();
+    return GAMMA_HIP_OK;
+}
+
+double extend_coefficient(uint8_t t) { return 1.1 + kPI / 2 - atan((double)t); }
+
+// ---- arena ---------------------------------------------------------------------------
+int arena_reserve(H* h, int64_t need_entries) {
+    if (h->arena_used + need_entries <= h->arena_cap) return GAMMA_HIP_OK;
+    int64_t ncap = std::max<int64_t>(h->arena_cap * 2, h->arena_used + need_entries);
+    ncap += ncap / 8;
+    uint8_t* nc = nullptr;
+    int64_t* ni = nullptr;
+    GH_CHECK(h, hipMalloc((void**)&nc, (size_t)ncap * h->code_size));
+    GH_CHECK(h, hipMalloc((void**)&ni, (size_t)ncap * sizeof(int64_t)));
+    if (h->arena_used > 0) {
+        GH_CHECK(h, hipMemcpyAsync(nc, h->d_codes, (size_t)h->arena_used * h->code_size,
+                                   hipMemcpyDeviceToDevice, h->stream));
+        GH_CHECK(h, hipMemcpyAsync(ni, h->d_ids, (size_t)h->arena_used * sizeof(int64_t),
+                                   hipMemcpyDeviceToDevice, h->stream));
+    }
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    if (h->d_codes) GH_CHECK(h, hipFree(h->d_codes));
+    if (h->d_ids) GH_CHECK(h, hipFree(h->d_ids));
+    h->d_codes = nc;
+    h->d_ids = ni;
+    h->arena_cap = ncap;
+    return GAMMA_HIP_OK;
+}
+
+// RealTimeMemData::ExtendBucketIfNeed + RTInvertBucketData::ExtendBucketMem
+// (realtime_mem_data.cc:383-421,152-188): same growth law, region moved inside the arena.
+int list_ensure(H* h, int l, int add) {
+    const int len = h->h_list_len[l], cap = h->h_list_cap[l];
+    if ((int64_t)len + add <= cap) return GAMMA_HIP_OK;
+    if ((int64_t)cap * 2 >= h->bucket_max) return fail(h, GAMMA_HIP_EFULL, "exceed the max bucket keys");
+    const int least = len + add;
+    double coef = extend_coefficient(++h->h_extend_time[l]);
+    int ext = (int)(cap * coef);
+    while (ext < least) {
+        coef = extend_coefficient(++h->h_extend_time[l]);
+        ext = (int)(ext * coef);
+    }
+    GH_TRY(arena_reserve(h, ext));
+    const int64_t noff = h->arena_used;
+    if (len > 0) {
+        GH_CHECK(h, hipMemcpyAsync(h->d_codes + noff * h->code_size,
+                                   h->d_codes + h->h_list_off[l] * h->code_size,
+                                   (size_t)len * h->code_size, hipMemcpyDeviceToDevice, h->stream));
+        GH_CHECK(h, hipMemcpyAsync(h->d_ids + noff, h->d_ids + h->h_list_off[l],
+                                   (size_t)len * sizeof(int64_t), hipMemcpyDeviceToDevice, h->stream));
+    }
+    h->arena_waste += cap;
+    h->arena_used += ext;
+    h->h_list_off[l] = noff;
+    h->h_list_cap[l] = ext;
+    GH_CHECK(h, hipMemcpyAsync(h->d_list_off + l, &h->h_list_off[l], sizeof(int64_t),
+                               hipMemcpyHostToDevice, h->stream));
+    return GAMMA_HIP_OK;
+}
+
+int publish_len(H* h, int l) {
+    GH_CHECK(h, hipMemcpyAsync(h->d_list_len + l, &h->h_list_len[l], sizeof(int), hipMemcpyHostToDevice,
+                               h->stream));
+    if (h->h_list_len[l] > h->max_list_len) h->max_list_len = h->h_list_len[l];
+    return GAMMA_HIP_OK;
+}
+
+int add_keys_locked(H* h, int l, int n, const int64_t* vids, const uint8_t* codes) {
+    if (l < 0 || l >= h->nlist || n < 0) return fail(h, GAMMA_HIP_EINVAL, "bad list_no");
+    if (n == 0) return GAMMA_HIP_OK;
+    GH_TRY(list_ensure(h, l, n));
+    const int64_t pos = h->h_list_off[l] + h->h_list_len[l];
+    GH_CHECK(h, hipMemcpyAsync(h->d_ids + pos, vids, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice,
+                               h->stream));
+    GH_CHECK(h, hipMemcpyAsync(h->d_codes + pos * h->code_size, codes, (size_t)n * h->code_size,
+                               hipMemcpyHostToDevice, h->stream));
+    // the host buffers may be reused by the caller as soon as we return
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n; i++) {
+        const int64_t v = vids[i];
+        if (v < 0) continue;
+        if ((size_t)v >= h->vid_pos.size()) h->vid_pos.resize(std::max<size_t>(h->vid_pos.size() * 2, v + 1), -1);
+        h->vid_pos[v] = ((int64_t)l << 32) | (int64_t)(h->h_list_len[l] + i);
+        if (h->bitmap_bits > v && !h->h_bitmap.empty() && ((h->h_bitmap[v >> 3] >> (v & 7)) & 1))
+            h->h_deleted[l]++;  // realtime_mem_data.cc:293-296
+    }
+    h->h_list_len[l] += n;  // publish after the copies (realtime_mem_data.cc:299-300)
+    h->ntotal += n;
+    return publish_len(h, l);
+}
+
+int build_filter(H* h, const gamma_hip_search_params* p, gh::FilterDesc* f) {
+    memset(f, 0, sizeof(*f));
+    f->del_bitmap = h->d_bitmap;
+    f->del_bits = h->d_bitmap ? h->bitmap_bits : 0;
+    f->has_range = p->has_range ? 1 : 0;
+    f->n_range = p->has_range ? p->n_range : 0;
+    if (f->n_range > gh::kMaxRange) return fail(h, GAMMA_HIP_EINVAL, "too many range filters");
+    if (f->n_range > 0) {
+        size_t tot = 0;
+        for (int i = 0; i < f->n_range; i++) tot += ((size_t)p->range[i].bitmap_bytes + 15) & ~(size_t)15;
+        GH_CHECK(h, h->w_filter.ensure(tot));
+        size_t off = 0;
+        for (int i = 0; i < f->n_range; i++) {
+            const gamma_hip_range_filter& r = p->range[i];
+            uint8_t* dst = h->w_filter.as<uint8_t>() + off;
+            GH_CHECK(h, hipMemcpyAsync(dst, r.bitmap, (size_t)r.bitmap_bytes, hipMemcpyHostToDevice,
+                                       h->stream));
+            f->range[i].bitmap = dst;
+            f->range[i].min_doc = r.min_doc;
+            f->range[i].max_doc = r.max_doc;
+            f->range[i].min_aligned = r.min_aligned;
+            f->range[i].b_not_in = r.b_not_in;
+            off += ((size_t)r.bitmap_bytes + 15) & ~(size_t)15;
+        }
+    }
+    return GAMMA_HIP_OK;
+}
+
+int check_params(H* h, const gamma_hip_search_params* p, int nq, int k) {
+    if (!p) return fail(h, GAMMA_HIP_EINVAL, "null params");
+    if (nq < 0) return fail(h, GAMMA_HIP_EINVAL, "nq < 0");
+    if (p->metric != GAMMA_HIP_METRIC_IP && p->metric != GAMMA_HIP_METRIC_L2)
+        return fail(h, GAMMA_HIP_EINVAL, "bad metric");
+    if (k > 4096) return fail(h, GAMMA_HIP_EINVAL, "k > 4096 unsupported");
+    return GAMMA_HIP_OK;
+}
+
+// ---- IVFPQ stage A: coarse + tables + scan + top-R + ids ------------------------------
+// results: w_cand_dis [nq*R] (ADC distance, best first, sentinel pad), w_cand_ids [nq*R]
+int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& filt, int nq,
+                  const float* d_x, int R) {
+    const int P = p->nprobe, d = h->d, M = h->M, nlist = h->nlist;
+    const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
+    hipStream_t s = h->stream;
+    GH_CHECK(h, h->w_mat.ensure((size_t)nq * nlist * sizeof(float)));
+    GH_CHECK(h, h->w_coarse_dis.ensure((size_t)nq * P * sizeof(float)));
+    GH_CHECK(h, h->w_probe.ensure((size_t)nq * P * sizeof(int)));
+    GH_CHECK(h, h->w_st2.ensure((size_t)nq * M * 256 * sizeof(float)));
+    GH_CHECK(h, h->w_pair_off.ensure((size_t)nq * (P + 1) * sizeof(int)));
+    GH_CHECK(h, h->w_qtotal.ensure((size_t)nq * sizeof(int)));
+    GH_CHECK(h, h->w_cand_dis.ensure((size_t)nq * R * sizeof(float)));
+    GH_CHECK(h, h->w_cand_pos.ensure((size_t)nq * R * sizeof(int)));
+    GH_CHECK(h, h->w_cand_ids.ensure((size_t)nq * R * sizeof(int64_t)));
+    int mode = p->coarse_mode;
+    if (mode < 0) mode = nq < 20 ? 0 : 1;  // faiss:utils/distances.cpp:303,346
+    {
+        StageScope t(h, GAMMA_HIP_STAGE_COARSE);
+        if (mode == 0) {
+            gh::launch_pairwise(s, true, d_x, nq, d, h->d_cc, nlist, h->w_mat.as<float>(), nlist);
+        } else {
+            GH_CHECK(h, h->w_xn.ensure((size_t)nq * sizeof(float)));
+            gh::launch_row_norms(s, d_x, nq, d, h->w_xn.as<float>());
+            gh::launch_l2_gemmform(s, d_x, nq, d, h->d_cc, nlist, h->w_xn.as<float>(), h->d_cc_norms,
+                                   h->w_mat.as<float>(), nlist, true);
+        }
+        gh::launch_select_topk(s, true, h->w_mat.as<float>(), nlist, nullptr, nlist, nq, P,
+                               h->w_coarse_dis.as<float>(), h->w_probe.as<int>());
+    }
+    {
+        StageScope t(h, GAMMA_HIP_STAGE_TABLES);
+        gh::launch_pq_ip_table(s, d_x, nq, d, M, h->d_pqc, h->w_st2.as<float>());
+        gh::launch_pair_offsets(s, h->w_probe.as<int>(), nq, P, h->d_list_len, h->d_list_mask, nlist,
+                                h->w_pair_off.as<int>(), h->w_qtotal.as<int>(), h->d_scan_codes);
+    }
+    const int64_t q_stride = std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len));
+    GH_CHECK(h, h->w_dist.ensure((size_t)nq * q_stride * sizeof(float)));
+    {
+        StageScope t(h, GAMMA_HIP_STAGE_SCAN);
+        gh::launch_ivfpq_scan_pair(s, l2, d_x, nq, d, M, P, h->w_probe.as<int>(),
+                                   h->w_coarse_dis.as<float>(), h->d_cc, h->w_st2.as<float>(), h->d_T2,
+                                   h->d_list_off, h->d_list_len, h->d_list_mask, nlist, h->d_codes,
+                                   h->d_ids, h->w_pair_off.as<int>(), q_stride, h->w_dist.as<float>(),
+                                   filt);
+    }
+    h->scan_pairs += (int64_t)nq * P;
+    {
+        StageScope t(h, GAMMA_HIP_STAGE_SELECT);
+        gh::launch_select_topk(s, l2, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), 0, nq, R,
+                               h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>());
+        gh::launch_map_candidates(s, h->w_cand_pos.as<int>(), nq, R, P, h->w_probe.as<int>(),
+                                  h->w_pair_off.as<int>(), h->d_list_off, h->d_ids,
+                                  h->w_cand_ids.as<int64_t>());
+    }
+    GH_CHECK(h, hipGetLastError());
+    return GAMMA_HIP_OK;
+}
+
+// ---- stage B: compute_dis (gamma_index_ivfpq.cc:642-697) ------------------------------
+int ivfpq_stage_b(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, int R, int k,
+                  const float* cand_dis, const int64_t* cand_ids, float* d_distances,
+                  int64_t* d_labels) {
+    const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
+    const float neutral = l2 ? 3.402823466e+38f : -3.402823466e+38f;
+    hipStream_t s = h->stream;
+    StageScope t(h, GAMMA_HIP_STAGE_RERANK);
+    if (p->has_rank) {
+        if (!h->d_raw || h->raw_d != h->d) return fail(h, GAMMA_HIP_EINVAL, "has_rank needs the raw store");
+        GH_CHECK(h, h->w_exact.ensure((size_t)nq * R * sizeof(float)));
+        GH_CHECK(h, h->w_selv.ensure((size_t)nq * k * sizeof(float)));
+        GH_CHECK(h, h->w_selp.ensure((size_t)nq * k * sizeof(int)));
+        gh::launch_rerank_dist(s, l2, d_x, nq, h->d, h->d_raw, h->nraw, cand_ids, R, p->min_score,
+                               p->max_score, h->w_exact.as<float>());
+        gh::launch_select_topk(s, l2, h->w_exact.as<float>(), R, nullptr, R, nq, k,
+                               h->w_selv.as<float>(), h->w_selp.as<int>());
+        gh::launch_finalize_topk(s, h->w_selv.as<float>(), h->w_selp.as<int>(), nq, k, cand_ids, R, 0,
+                                 neutral, d_distances, d_labels);
+    } else {
+        gh::launch_finalize_norank(s, cand_dis, cand_ids, nq, R, k, p->min_score, p->max_score, neutral,
+                                   d_distances, d_labels);
+    }
+    GH_CHECK(h, hipGetLastError());
+    return GAMMA_HIP_OK;
+}
+
+int ivfpq_check(H* h, const gamma_hip_search_params* p, int nq, int k) {
+    GH_TRY(check_params(h, p, nq, k));
+    if (!h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
+    if (!h->trained) return fail(h, GAMMA_HIP_ENOTTRAINED, "ivfpq not trained");
+    if (p->nprobe <= 0 || p->nprobe > h->nlist) return fail(h, GAMMA_HIP_EINVAL, "nprobe out of range");
+    if (std::max(p->recall_num, k) > 4096) return fail(h, GAMMA_HIP_EINVAL, "recall_num > 4096 unsupported");
+    return GAMMA_HIP_OK;
+}
+
+int query_chunk(H* h, int nq, int P) {
+    const int64_t q_stride = std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len));
+    int64_t by_dist = (int64_t)(h->dist_budget_bytes / (q_stride * sizeof(float)));
+    int64_t by_mat = (int64_t)(h->dist_budget_bytes / ((size_t)h->nlist * sizeof(float)));
+    int64_t c = std::min<int64_t>(by_dist, by_mat);
+    c = std::max<int64_t>(1, std::min<int64_t>(c, nq));
+    return (int)c;
+}
+
+int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, int k,
+                               float* d_distances, int64_t* d_labels) {
+    GH_TRY(ivfpq_check(h, p, nq, k));
+    if (k <= 0 || nq == 0) return GAMMA_HIP_OK;  // gamma_index_ivfpq.cc:753-756
+    GH_CHECK(h, hipSetDevice(h->device));
+    const int R = std::max(p->recall_num, k);
+    gh::FilterDesc filt;
+    GH_TRY(build_filter(h, p, &filt));
+    const int chunk = query_chunk(h, nq, p->nprobe);
+    for (int q0 = 0; q0 < nq; q0 += chunk) {
+        const int nc = std::min(chunk, nq - q0);
+        GH_TRY(ivfpq_stage_a(h, p, filt, nc, d_x + (size_t)q0 * h->d, R));
+        GH_TRY(ivfpq_stage_b(h, p, nc, d_x + (size_t)q0 * h->d, R, k, h->w_cand_dis.as<float>(),
+                             h->w_cand_ids.as<int64_t>(), d_distances + (size_t)q0 * k,
+                             d_labels + (size_t)q0 * k));
+        h->last_nq = nc;
+    }
+    h->last_P = p->nprobe;
+    h->last_R = R;
+    return GAMMA_HIP_OK;
+}
+
+// ---- flat ------------------------------------------------------------------------------
+int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, int k,
+                              float* d_distances, int64_t* d_labels) {
+    GH_TRY(check_params(h, p, nq, k));
+    if (!h->d_raw && h->nraw > 0) return fail(h, GAMMA_HIP_EINVAL, "raw store not initialised");
+    if (h->raw_d <= 0) return fail(h, GAMMA_HIP_EINVAL, "raw store not initialised");
+    if (k <= 0 || nq == 0) return GAMMA_HIP_OK;
+    GH_CHECK(h, hipSetDevice(h->device));
+    const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
+    const float neutral = l2 ? 3.402823466e+38f : -3.402823466e+38f;
+    const float sentinel = l2 ? INFINITY : -INFINITY;
+    const int d = h->raw_d;
+    const int64_t N = h->nraw;
+    hipStream_t s = h->stream;
+    gh::FilterDesc filt;
+    GH_TRY(build_filter(h, p, &filt));
+    // query chunks x row chunks so the distance slab stays inside the budget
+    int64_t rows_chunk = std::max<int64_t>(256, std::min<int64_t>(N, (int64_t)1 << 16));
+    rows_chunk = (rows_chunk + 255) / 256 * 256;
+    int qc = (int)std::max<int64_t>(1, std::min<int64_t>(nq, (int64_t)(h->dist_budget_bytes / (rows_chunk * sizeof(float)))));
+    const int nchunks = (int)std::max<int64_t>(1, (N + rows_chunk - 1) / rows_chunk);
+    GH_CHECK(h, h->w_dist.ensure((size_t)qc * rows_chunk * sizeof(float)));
+    GH_CHECK(h, h->w_part_v.ensure((size_t)qc * nchunks * k * sizeof(float)));
+    GH_CHECK(h, h->w_part_i.ensure((size_t)qc * nchunks * k * sizeof(int64_t)));
+    GH_CHECK(h, h->w_selv.ensure((size_t)qc * k * sizeof(float)));
+    GH_CHECK(h, h->w_selp.ensure((size_t)qc * k * sizeof(int)));
+    GH_CHECK(h, h->w_cand_pos.ensure((size_t)qc * k * sizeof(int)));
+    GH_CHECK(h, h->w_cand_dis.ensure((size_t)qc * k * sizeof(float)));
+    StageScope t(h, GAMMA_HIP_STAGE_FLAT);
+    for (int q0 = 0; q0 < nq; q0 += qc) {
+        const int nc = std::min(qc, nq - q0);
+        const float* xq = d_x + (size_t)q0 * d;
+        if (N == 0) {
+            // nothing to scan: all-empty result
+            GH_CHECK(h, hipMemsetAsync(h->w_selp.p, 0xff, (size_t)nc * k * sizeof(int), s));
+            gh::launch_finalize_topk(s, h->w_selv.as<float>(), h->w_selp.as<int>(), nc, k, nullptr, 0, 0,
+                                     neutral, d_distances + (size_t)q0 * k, d_labels + (size_t)q0 * k);
+            continue;
+        }
+        for (int c = 0; c < nchunks; c++) {
+            const int64_t r0 = (int64_t)c * rows_chunk;
+            const int64_t nr = std::min<int64_t>(rows_chunk, N - r0);
+            gh::launch_pairwise_filtered(s, l2, xq, nc, d, h->d_raw + r0 * d, nr, h->w_dist.as<float>(),
+                                         rows_chunk, filt, p->min_score, p->max_score, r0);
+            // per-chunk top-k: values + positions relative to the chunk
+            gh::launch_select_topk(s, l2, h->w_dist.as<float>(), rows_chunk, nullptr, (int)nr, nc, k,
+                                   h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>());
+            // scatter into the partial table [q][chunk][k] with global ids
+            // (reuse finalize_topk: labels = pos, then offset by r0 on the fly below)
+            gh::launch_finalize_topk(s, h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>(), nc, k, nullptr,
+                                     0, r0, sentinel, h->w_selv.as<float>(),
+                                     h->w_part_i.as<int64_t>() + (size_t)c * nc * k);
+            GH_CHECK(h, hipMemcpyAsync(h->w_part_v.as<float>() + (size_t)c * nc * k, h->w_selv.p,
+                                       (size_t)nc * k * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
+        // merge: layout [chunk][q][k] == the sharded layout [shard][nq][R]
+        GH_CHECK(h, h->w_m_dis.ensure((size_t)nc * nchunks * k * sizeof(float)));
+        GH_CHECK(h, h->w_m_ids.ensure((size_t)nc * nchunks * k * sizeof(int64_t)));
+        gh::launch_gather_shards(s, h->w_part_v.as<float>(), h->w_part_i.as<int64_t>(), nchunks, nc, k,
+                                 h->w_m_dis.as<float>(), h->w_m_ids.as<int64_t>(), sentinel);
+        gh::launch_select_topk(s, l2, h->w_m_dis.as<float>(), (int64_t)nchunks * k, nullptr, nchunks * k,
+                               nc, k, h->w_selv.as<float>(), h->w_selp.as<int>());
+        gh::launch_finalize_topk(s, h->w_selv.as<float>(), h->w_selp.as<int>(), nc, k,
+                                 h->w_m_ids.as<int64_t>(), (int64_t)nchunks * k, 0, neutral,
+                                 d_distances + (size_t)q0 * k, d_labels + (size_t)q0 * k);
+    }
+    GH_CHECK(h, hipGetLastError());
+    return GAMMA_HIP_OK;
+}
+
+// host-pointer wrapper shared by ivfpq / flat
+template <typename F>
+int host_search(H* h, int nq, int d, const float* x, int k, float* distances, int64_t* labels, F&& f) {
+    if (nq <= 0 || k <= 0) return f(nullptr, nullptr, nullptr);
+    GH_CHECK(h, hipSetDevice(h->device));
+    GH_CHECK(h, h->w_x.ensure((size_t)nq * d * sizeof(float)));
+    GH_CHECK(h, h->w_outd.ensure((size_t)nq * k * sizeof(float)));
+    GH_CHECK(h, h->w_outl.ensure((size_t)nq * k * sizeof(int64_t)));
+    GH_CHECK(h, hipMemcpyAsync(h->w_x.p, x, (size_t)nq * d * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    GH_TRY(f(h->w_x.as<float>(), h->w_outd.as<float>(), h->w_outl.as<int64_t>()));
+    GH_CHECK(h, hipMemcpyAsync(distances, h->w_outd.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    GH_CHECK(h, hipMemcpyAsync(labels, h->w_outl.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    return GAMMA_HIP_OK;
+}
+
+}  // namespace
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+extern "C" {
+
+const char* gamma_hip_strerror(int code) {
+    switch (code) {
+        case GAMMA_HIP_OK: return "ok";
+        case GAMMA_HIP_EINVAL: return "invalid argument";
+        case GAMMA_HIP_ENOTTRAINED: return "index not trained";
+        case GAMMA_HIP_EDEVICE: return "HIP runtime error";
+        case GAMMA_HIP_ENOMEM: return "out of memory";
+        case GAMMA_HIP_EFULL: return "inverted list full";
+        default: return "unknown error";
+    }
+}
+
+int gamma_hip_create(int device, gamma_hip_index** out) {
+    if (!out) return GAMMA_HIP_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GAMMA_HIP_EDEVICE;
+    if (device < 0 || device >= ndev) return GAMMA_HIP_EINVAL;
+    if (hipSetDevice(device) != hipSuccess) return GAMMA_HIP_EDEVICE;
+    H* h = new (std::nothrow) H();
+    if (!h) return GAMMA_HIP_ENOMEM;
+    h->device = device;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return GAMMA_HIP_EDEVICE;
+    }
+    if (hipMalloc((void**)&h->d_scan_codes, sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(h->d_scan_codes, 0, sizeof(unsigned long long)) != hipSuccess) {
+        (void)hipStreamDestroy(h->stream);
+        delete h;
+        return GAMMA_HIP_EDEVICE;
+    }
+    *out = h;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_destroy(gamma_hip_index* h) {
+    if (!h) return GAMMA_HIP_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (auto& e : h->events) {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    void* ptrs[] = {h->d_raw, h->d_bitmap, h->d_cc, h->d_cc_norms, h->d_pqc, h->d_T2, h->d_codes,
+                    h->d_ids, h->d_list_off, h->d_list_len, h->d_list_mask, h->d_scan_codes};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    DevBuf* bufs[] = {&h->w_mat, &h->w_coarse_dis, &h->w_probe, &h->w_xn, &h->w_st2, &h->w_pair_off,
+                      &h->w_qtotal, &h->w_dist, &h->w_cand_dis, &h->w_cand_pos, &h->w_cand_ids,
+                      &h->w_exact, &h->w_selv, &h->w_selp, &h->w_x, &h->w_outd, &h->w_outl, &h->w_stage,
+                      &h->w_filter, &h->w_m_dis, &h->w_m_ids, &h->w_part_v, &h->w_part_i, &h->w_assign,
+                      &h->w_codes_tmp};
+    for (DevBuf* b : bufs) b->release();
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+    return GAMMA_HIP_OK;
+}
+
+const char* gamma_hip_last_error(gamma_hip_index* h) { return h ? h->err.c_str() : "null handle"; }
+void* gamma_hip_stream(gamma_hip_index* h) { return h ? (void*)h->stream : nullptr; }
+
+int gamma_hip_synchronize(gamma_hip_index* h) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    GH_CHECK(h, hipSetDevice(h->device));
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    return GAMMA_HIP_OK;
+}
+
+/* ---- raw store ---------------------------------------------------------------------- */
+int gamma_hip_raw_init(gamma_hip_index* h, int d) {
+    if (!h || d <= 0) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->raw_d != 0 && h->raw_d != d) return fail(h, GAMMA_HIP_EINVAL, "raw store dimension mismatch");
+    h->raw_d = d;
+    return GAMMA_HIP_OK;
+}
+
+static int raw_reserve(H* h, int64_t need) {
+    if (need <= h->raw_cap) return GAMMA_HIP_OK;
+    int64_t ncap = std::max<int64_t>(need, h->raw_cap + h->raw_cap / 2);
+    ncap = std::max<int64_t>(ncap, 1024);
+    float* np = nullptr;
+    GH_CHECK(h, hipMalloc((void**)&np, (size_t)ncap * h->raw_d * sizeof(float)));
+    if (h->nraw > 0)
+        GH_CHECK(h, hipMemcpyAsync(np, h->d_raw, (size_t)h->nraw * h->raw_d * sizeof(float),
+                                   hipMemcpyDeviceToDevice, h->stream));
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    if (h->d_raw) GH_CHECK(h, hipFree(h->d_raw));
+    h->d_raw = np;
+    h->raw_cap = ncap;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_raw_append(gamma_hip_index* h, int64_t n, const float* vecs) {
+    if (!h || n < 0 || (n > 0 && !vecs)) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->raw_d <= 0) return fail(h, GAMMA_HIP_EINVAL, "raw store not initialised");
+    if (n == 0) return GAMMA_HIP_OK;
+    GH_CHECK(h, hipSetDevice(h->device));
+    GH_TRY(raw_reserve(h, h->nraw + n));
+    GH_CHECK(h, hipMemcpyAsync(h->d_raw + h->nraw * h->raw_d, vecs, (size_t)n * h->raw_d * sizeof(float),
+                               hipMemcpyHostToDevice, h->stream));
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    h->nraw += n;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_raw_update(gamma_hip_index* h, int64_t vid, const float* vec) {
+    if (!h || !vec) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (vid < 0 || vid >= h->nraw) return fail(h, GAMMA_HIP_EINVAL, "vid out of range");
+    GH_CHECK(h, hipSetDevice(h->device));
+    GH_CHECK(h, hipMemcpyAsync(h->d_raw + vid * h->raw_d, vec, (size_t)h->raw_d * sizeof(float),
+                               hipMemcpyHostToDevice, h->stream));
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    return GAMMA_HIP_OK;
+}
+
+int64_t gamma_hip_raw_count(gamma_hip_index* h) { return h ? h->nraw : -1; }
+
+/* ---- delete bitmap ------------------------------------------------------------------- */
+static int bitmap_reserve(H* h, int64_t nbits) {
+    size_t bytes = (((size_t)nbits >> 3) + 1 + 3) & ~(size_t)3;
+    if (bytes <= h->bitmap_cap_bytes) return GAMMA_HIP_OK;
+    size_t ncap = std::max(bytes, h->bitmap_cap_bytes * 2);
+    uint8_t* np = nullptr;
+    GH_CHECK(h, hipMalloc((void**)&np, ncap));
+    GH_CHECK(h, hipMemsetAsync(np, 0, ncap, h->stream));
+    if (h->d_bitmap)
+        GH_CHECK(h, hipMemcpyAsync(np, h->d_bitmap, h->bitmap_cap_bytes, hipMemcpyDeviceToDevice, h->stream));
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    if (h->d_bitmap) GH_CHECK(h, hipFree(h->d_bitmap));
+    h->d_bitmap = np;
+    h->bitmap_cap_bytes = ncap;
+    h->h_bitmap.resize(ncap, 0);
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_bitmap_upload(gamma_hip_index* h, const uint8_t* bitmap, int64_t nbits) {
+    if (!h || nbits < 0 || (nbits > 0 && !bitmap)) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    GH_CHECK(h, hipSetDevice(h->device));
+    GH_TRY(bitmap_reserve(h, nbits));
+    size_t bytes = ((size_t)nbits >> 3) + 1;  // bitmap::create, util/bitmap.cc:15-23
+    GH_CHECK(h, hipMemsetAsync(h->d_bitmap, 0, h->bitmap_cap_bytes, h->stream));
+    GH_CHECK(h, hipMemcpyAsync(h->d_bitmap, bitmap, bytes, hipMemcpyHostToDevice, h->stream));
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    std::fill(h->h_bitmap.begin(), h->h_bitmap.end(), 0);
+    memcpy(h->h_bitmap.data(), bitmap, bytes);
+    h->bitmap_bits = nbits;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_bitmap_set(gamma_hip_index* h, const int64_t* docids, int64_t n, int value) {
+    if (!h || n < 0 || (n > 0 && !docids)) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (n == 0) return GAMMA_HIP_OK;
+    GH_CHECK(h, hipSetDevice(h->device));
+    int64_t mx = 0;
+    for (int64_t i = 0; i < n; i++) mx = std::max(mx, docids[i]);
+    if (mx >= h->bitmap_bits) {
+        GH_TRY(bitmap_reserve(h, mx + 1));
+        h->bitmap_bits = std::max<int64_t>(h->bitmap_bits, mx + 1);
+    }
+    GH_CHECK(h, h->w_stage.ensure((size_t)n * sizeof(int64_t)));
+    GH_CHECK(h, hipMemcpyAsync(h->w_stage.p, docids, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    gh::launch_bitmap_set(h->stream, h->d_bitmap, h->w_stage.as<int64_t>(), n, h->bitmap_bits, value);
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    for (int64_t i = 0; i < n; i++) {
+        int64_t id = docids[i];
+        if (id < 0) continue;
+        if (value) h->h_bitmap[id >> 3] |= (uint8_t)(1u << (id & 7));
+        else h->h_bitmap[id >> 3] &= (uint8_t)~(1u << (id & 7));
+    }
+    return GAMMA_HIP_OK;
+}
+
+/* ---- IVFPQ model ---------------------------------------------------------------------- */
+int gamma_hip_ivfpq_init(gamma_hip_index* h, int d, int nlist, int M, int nbits, int metric,
+                         int bucket_init_size, int bucket_max_size) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "already initialised");
+    if (d <= 0 || nlist <= 0 || M <= 0) return fail(h, GAMMA_HIP_EINVAL, "bad d/nlist/M");
+    if (nbits != 8) return fail(h, GAMMA_HIP_EINVAL, "only nbits_per_idx == 8 is supported on device");
+    if (d % M != 0) return fail(h, GAMMA_HIP_EINVAL, "d must be divisible by nsubvector");
+    if (d / M > 64) return fail(h, GAMMA_HIP_EINVAL, "dsub > 64 unsupported");
+    if (M > 64) return fail(h, GAMMA_HIP_EINVAL, "nsubvector > 64 unsupported (LUT must fit 64 KiB LDS)");
+    if (metric != GAMMA_HIP_METRIC_IP && metric != GAMMA_HIP_METRIC_L2) return fail(h, GAMMA_HIP_EINVAL, "bad metric");
+    GH_CHECK(h, hipSetDevice(h->device));
+    h->d = d;
+    h->nlist = nlist;
+    h->M = M;
+    h->dsub = d / M;
+    h->code_size = M;
+    h->metric = metric;
+    h->bucket_init = bucket_init_size > 0 ? bucket_init_size : 1000;
+    h->bucket_max = bucket_max_size > 0 ? bucket_max_size : 1280000;
+    GH_CHECK(h, hipMalloc((void**)&h->d_cc, (size_t)nlist * d * sizeof(float)));
+    GH_CHECK(h, hipMalloc((void**)&h->d_cc_norms, (size_t)nlist * sizeof(float)));
+    GH_CHECK(h, hipMalloc((void**)&h->d_pqc, (size_t)M * 256 * h->dsub * sizeof(float)));
+    GH_CHECK(h, hipMalloc((void**)&h->d_T2, (size_t)nlist * M * 256 * sizeof(float)));
+    GH_CHECK(h, hipMalloc((void**)&h->d_list_off, (size_t)nlist * sizeof(int64_t)));
+    GH_CHECK(h, hipMalloc((void**)&h->d_list_len, (size_t)nlist * sizeof(int)));
+    // RTInvertBucketData::Init (realtime_mem_data.cc:57-96): bucket_init entries per list
+    h->h_list_off.resize(nlist);
+    h->h_list_len.assign(nlist, 0);
+    h->h_list_cap.assign(nlist, h->bucket_init);
+    h->h_deleted.assign(nlist, 0);
+    h->h_extend_time.assign(nlist, 0);
+    for (int l = 0; l < nlist; l++) h->h_list_off[l] = (int64_t)l * h->bucket_init;
+    h->arena_used = 0;
+    GH_TRY(arena_reserve(h, (int64_t)nlist * h->bucket_init));
+    h->arena_used = (int64_t)nlist * h->bucket_init;
+    GH_CHECK(h, hipMemcpyAsync(h->d_list_off, h->h_list_off.data(), (size_t)nlist * sizeof(int64_t),
+                               hipMemcpyHostToDevice, h->stream));
+    GH_CHECK(h, hipMemsetAsync(h->d_list_len, 0, (size_t)nlist * sizeof(int), h->stream));
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    h->vid_pos.assign((size_t)nlist * h->bucket_init, -1);
+    h->ivf_init = true;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_set_trained(gamma_hip_index* h, const float* cc, const float* pqc, const float* table) {
+    if (!h || !cc || !pqc) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
+    GH_CHECK(h, hipSetDevice(h->device));
+    const size_t ncc = (size_t)h->nlist * h->d, npq = (size_t)h->M * 256 * h->dsub;
+    const size_t nt = (size_t)h->nlist * h->M * 256;
+    GH_CHECK(h, hipMemcpyAsync(h->d_cc, cc, ncc * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    GH_CHECK(h, hipMemcpyAsync(h->d_pqc, pqc, npq * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    gh::launch_row_norms(h->stream, h->d_cc, h->nlist, h->d, h->d_cc_norms);
+    if (table)
+        GH_CHECK(h, hipMemcpyAsync(h->d_T2, table, nt * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    else
+        gh::launch_precompute_table(h->stream, h->d_cc, h->nlist, h->d, h->M, h->d_pqc, h->d_T2);
+    GH_CHECK(h, hipGetLastError());
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    h->trained = true;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_get_precomputed_table(gamma_hip_index* h, float* out) {
+    if (!h || !out) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!h->trained) return fail(h, GAMMA_HIP_ENOTTRAINED, "not trained");
+    GH_CHECK(h, hipSetDevice(h->device));
+    GH_CHECK(h, hipMemcpyAsync(out, h->d_T2, (size_t)h->nlist * h->M * 256 * sizeof(float),
+                               hipMemcpyDeviceToHost, h->stream));
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    return GAMMA_HIP_OK;
+}
+
+/* ---- realtime lists ------------------------------------------------------------------- */
+int gamma_hip_ivfpq_add_keys(gamma_hip_index* h, int list_no, int n, const int64_t* vids, const uint8_t* codes) {
+    if (!h || (n > 0 && (!vids || !codes))) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
+    GH_CHECK(h, hipSetDevice(h->device));
+    return add_keys_locked(h, list_no, n, vids, codes);
+}
+
+int gamma_hip_ivfpq_add_keys_batch(gamma_hip_index* h, int nlists, const int32_t* list_nos,
+                                   const int32_t* counts, const int64_t* vids, const uint8_t* codes) {
+    if (!h || nlists < 0 || (nlists > 0 && (!list_nos || !counts || !vids || !codes))) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
+    GH_CHECK(h, hipSetDevice(h->device));
+    int64_t off = 0;
+    // grow first so that no copy below races with an arena move
+    for (int i = 0; i < nlists; i++) {
+        if (list_nos[i] < 0 || list_nos[i] >= h->nlist || counts[i] < 0) return fail(h, GAMMA_HIP_EINVAL, "bad list_no");
+        GH_TRY(list_ensure(h, list_nos[i], counts[i]));
+    }
+    for (int i = 0; i < nlists; i++) {
+        const int l = list_nos[i], n = counts[i];
+        if (n == 0) continue;
+        const int64_t pos = h->h_list_off[l] + h->h_list_len[l];
+        GH_CHECK(h, hipMemcpyAsync(h->d_ids + pos, vids + off, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+        GH_CHECK(h, hipMemcpyAsync(h->d_codes + pos * h->code_size, codes + off * h->code_size,
+                                   (size_t)n * h->code_size, hipMemcpyHostToDevice, h->stream));
+        for (int j = 0; j < n; j++) {
+            const int64_t v = vids[off + j];
+            if (v < 0) continue;
+            if ((size_t)v >= h->vid_pos.size()) h->vid_pos.resize(std::max<size_t>(h->vid_pos.size() * 2, v + 1), -1);
+            h->vid_pos[v] = ((int64_t)l << 32) | (int64_t)(h->h_list_len[l] + j);
+            if (h->bitmap_bits > v && !h->h_bitmap.empty() && ((h->h_bitmap[v >> 3] >> (v & 7)) & 1)) h->h_deleted[l]++;
+        }
+        h->h_list_len[l] += n;
+        h->ntotal += n;
+        if (h->h_list_len[l] > h->max_list_len) h->max_list_len = h->h_list_len[l];
+        off += n;
+    }
+    // publish all lengths after the copies, in stream order
+    GH_CHECK(h, hipMemcpyAsync(h->d_list_len, h->h_list_len.data(), (size_t)h->nlist * sizeof(int),
+                               hipMemcpyHostToDevice, h->stream));
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_update(gamma_hip_index* h, int list_no, int64_t vid, const uint8_t* code) {
+    if (!h || !code) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!h->ivf_init || list_no < 0 || list_no >= h->nlist) return fail(h, GAMMA_HIP_EINVAL, "bad list_no");
+    if (vid < 0 || (size_t)vid >= h->vid_pos.size()) return GAMMA_HIP_OK;  // realtime_mem_data.cc:307
+    const int64_t bp = h->vid_pos[vid];
+    if (bp == -1) return GAMMA_HIP_OK;
+    GH_CHECK(h, hipSetDevice(h->device));
+    const int ob = (int)(bp >> 32), op = (int)(bp & 0xffffffff);
+    if (ob == list_no) {
+        GH_CHECK(h, hipMemcpyAsync(h->d_codes + (h->h_list_off[ob] + op) * h->code_size, code, h->code_size,
+                                   hipMemcpyHostToDevice, h->stream));
+        GH_CHECK(h, hipStreamSynchronize(h->stream));
+        return GAMMA_HIP_OK;
+    }
+    gh::launch_mark_moved(h->stream, h->d_ids, h->h_list_off[ob] + op);
+    h->h_deleted[ob]++;
+    h->ntotal -= 1;  // add_keys_locked re-counts it
+    return add_keys_locked(h, list_no, 1, &vid, code);
+}
+
+int gamma_hip_ivfpq_delete(gamma_hip_index* h, const int64_t* vids, int n) {
+    if (!h || (n > 0 && !vids)) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    for (int i = 0; i < n; i++) {
+        if (vids[i] < 0 || (size_t)vids[i] >= h->vid_pos.size()) continue;
+        const int64_t bp = h->vid_pos[vids[i]];
+        if (bp == -1) continue;
+        h->h_deleted[bp >> 32]++;
+    }
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_compact_if_need(gamma_hip_index* h) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
+    GH_CHECK(h, hipSetDevice(h->device));
+    std::vector<int64_t> ids;
+    std::vector<uint8_t> codes;
+    bool changed = false;
+    for (int l = 0; l < h->nlist; l++) {
+        const int len = h->h_list_len[l];
+        if (!((float)h->h_deleted[l] / len >= 0.3f)) continue;  // Compactable, :373-377
+        ids.resize(len);
+        codes.resize((size_t)len * h->code_size);
+        GH_CHECK(h, hipMemcpyAsync(ids.data(), h->d_ids + h->h_list_off[l], (size_t)len * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+        GH_CHECK(h, hipMemcpyAsync(codes.data(), h->d_codes + h->h_list_off[l] * h->code_size, (size_t)len * h->code_size, hipMemcpyDeviceToHost, h->stream));
+        GH_CHECK(h, hipStreamSynchronize(h->stream));
+        int pos = 0;
+        for (int i = 0; i < len; i++) {  // CompactOne, :98-112
+            const int64_t id = ids[i];
+            const int64_t v = id & ~kDelMask;
+            const bool deleted = (v < h->bitmap_bits) && ((h->h_bitmap[v >> 3] >> (v & 7)) & 1);
+            if (!(id & kDelMask) && !deleted) {
+                ids[pos] = id;
+                memmove(codes.data() + (size_t)pos * h->code_size, codes.data() + (size_t)i * h->code_size, h->code_size);
+                h->vid_pos[id] = ((int64_t)l << 32) | pos;
+                pos++;
+            }
+        }
+        // new region of the same capacity (copy-on-write swap, :426-474)
+        GH_TRY(arena_reserve(h, h->h_list_cap[l]));
+        const int64_t noff = h->arena_used;
+        h->arena_used += h->h_list_cap[l];
+        h->arena_waste += h->h_list_cap[l];
+        if (pos > 0) {
+            GH_CHECK(h, hipMemcpyAsync(h->d_ids + noff, ids.data(), (size_t)pos * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+            GH_CHECK(h, hipMemcpyAsync(h->d_codes + noff * h->code_size, codes.data(), (size_t)pos * h->code_size, hipMemcpyHostToDevice, h->stream));
+        }
+        h->h_list_off[l] = noff;
+        h->ntotal -= (len - pos);
+        h->h_list_len[l] = pos;
+        h->h_deleted[l] = 0;
+        GH_CHECK(h, hipMemcpyAsync(h->d_list_off + l, &h->h_list_off[l], sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+        GH_CHECK(h, hipMemcpyAsync(h->d_list_len + l, &h->h_list_len[l], sizeof(int), hipMemcpyHostToDevice, h->stream));
+        GH_CHECK(h, hipStreamSynchronize(h->stream));
+        changed = true;
+    }
+    if (changed) {
+        h->max_list_len = 0;
+        for (int l = 0; l < h->nlist; l++) h->max_list_len = std::max(h->max_list_len, h->h_list_len[l]);
+    }
+    return GAMMA_HIP_OK;
+}
+
+int64_t gamma_hip_ivfpq_list_size(gamma_hip_index* h, int l) {
+    if (!h || !h->ivf_init || l < 0 || l >= h->nlist) return -1;
+    return h->h_list_len[l];
+}
+int64_t gamma_hip_ivfpq_list_capacity(gamma_hip_index* h, int l) {
+    if (!h || !h->ivf_init || l < 0 || l >= h->nlist) return -1;
+    return h->h_list_cap[l];
+}
+
+int gamma_hip_ivfpq_get_list(gamma_hip_index* h, int l, int64_t* vids, uint8_t* codes) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!h->ivf_init || l < 0 || l >= h->nlist) return fail(h, GAMMA_HIP_EINVAL, "bad list_no");
+    const int len = h->h_list_len[l];
+    if (len == 0) return GAMMA_HIP_OK;
+    GH_CHECK(h, hipSetDevice(h->device));
+    if (vids) GH_CHECK(h, hipMemcpyAsync(vids, h->d_ids + h->h_list_off[l], (size_t)len * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    if (codes) GH_CHECK(h, hipMemcpyAsync(codes, h->d_codes + h->h_list_off[l] * h->code_size, (size_t)len * h->code_size, hipMemcpyDeviceToHost, h->stream));
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_set_list_mask(gamma_hip_index* h, const uint8_t* owned) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
+    GH_CHECK(h, hipSetDevice(h->device));
+    if (!owned) {
+        if (h->d_list_mask) GH_CHECK(h, hipFree(h->d_list_mask));
+        h->d_list_mask = nullptr;
+        h->h_list_mask.clear();
+        return GAMMA_HIP_OK;
+    }
+    if (!h->d_list_mask) GH_CHECK(h, hipMalloc((void**)&h->d_list_mask, (size_t)h->nlist));
+    h->h_list_mask.assign(owned, owned + h->nlist);
+    GH_CHECK(h, hipMemcpyAsync(h->d_list_mask, owned, (size_t)h->nlist, hipMemcpyHostToDevice, h->stream));
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    return GAMMA_HIP_OK;
+}
+
+/* ---- device-side encode / add ----------------------------------------------------------- */
+static int encode_locked(H* h, int64_t n, const float* d_vecs, int* d_assign, uint8_t* d_codes_out) {
+    // quantizer->assign == search with k = 1 (faiss rule for the arithmetic form)
+    hipStream_t s = h->stream;
+    const int d = h->d, nlist = h->nlist;
+    GH_CHECK(h, h->w_mat.ensure((size_t)n * nlist * sizeof(float)));
+    GH_CHECK(h, h->w_coarse_dis.ensure((size_t)n * sizeof(float)));
+    if (n < 20) {
+        gh::launch_pairwise(s, true, d_vecs, (int)n, d, h->d_cc, nlist, h->w_mat.as<float>(), nlist);
+    } else {
+        GH_CHECK(h, h->w_xn.ensure((size_t)n * sizeof(float)));
+        gh::launch_row_norms(s, d_vecs, n, d, h->w_xn.as<float>());
+        gh::launch_l2_gemmform(s, d_vecs, (int)n, d, h->d_cc, nlist, h->w_xn.as<float>(), h->d_cc_norms,
+                               h->w_mat.as<float>(), nlist, true);
+    }
+    gh::launch_select_topk(s, true, h->w_mat.as<float>(), nlist, nullptr, nlist, (int)n, 1,
+                           h->w_coarse_dis.as<float>(), d_assign);
+    gh::launch_pq_encode(s, d_vecs, n, d, h->M, d_assign, h->d_cc, h->d_pqc, d_codes_out);
+    GH_CHECK(h, hipGetLastError());
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_encode(gamma_hip_index* h, int64_t n, const float* vecs, int64_t* list_nos, uint8_t* codes) {
+    if (!h || n < 0 || (n > 0 && (!vecs || !list_nos || !codes))) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!h->trained) return fail(h, GAMMA_HIP_ENOTTRAINED, "not trained");
+    if (n == 0) return GAMMA_HIP_OK;
+    GH_CHECK(h, hipSetDevice(h->device));
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(h->dist_budget_bytes / ((size_t)h->nlist * sizeof(float)))));
+    std::vector<int> assign(chunk);
+    for (int64_t i0 = 0; i0 < n; i0 += chunk) {
+        const int64_t nc = std::min(chunk, n - i0);
+        GH_CHECK(h, h->w_x.ensure((size_t)nc * h->d * sizeof(float)));
+        GH_CHECK(h, h->w_assign.ensure((size_t)nc * sizeof(int)));
+        GH_CHECK(h, h->w_codes_tmp.ensure((size_t)nc * h->code_size));
+        GH_CHECK(h, hipMemcpyAsync(h->w_x.p, vecs + i0 * h->d, (size_t)nc * h->d * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        GH_TRY(encode_locked(h, nc, h->w_x.as<float>(), h->w_assign.as<int>(), h->w_codes_tmp.as<uint8_t>()));
+        GH_CHECK(h, hipMemcpyAsync(assign.data(), h->w_assign.p, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        GH_CHECK(h, hipMemcpyAsync(codes + i0 * h->code_size, h->w_codes_tmp.p, (size_t)nc * h->code_size, hipMemcpyDeviceToHost, h->stream));
+        GH_CHECK(h, hipStreamSynchronize(h->stream));
+        for (int64_t i = 0; i < nc; i++) list_nos[i0 + i] = assign[i];
+    }
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_add(gamma_hip_index* h, int64_t n, const float* vecs, int64_t first_vid) {
+    if (!h || n < 0 || (n > 0 && !vecs)) return GAMMA_HIP_EINVAL;
+    if (n == 0) return GAMMA_HIP_OK;
+    std::vector<int64_t> lno(n);
+    std::vector<uint8_t> codes;
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        if (!h->trained) return fail(h, GAMMA_HIP_ENOTTRAINED, "not trained");
+        codes.resize((size_t)n * h->code_size);
+    }
+    GH_TRY(gamma_hip_ivfpq_encode(h, n, vecs, lno.data(), codes.data()));
+    // group by list in ascending list order (std::map in gamma_index_ivfpq.cc:428-494)
+    const int cs = h->code_size;
+    std::vector<int64_t> order(n);
+    for (int64_t i = 0; i < n; i++) {
+        if (lno[i] < 0) lno[i] = (first_vid + i) % h->nlist;
+        order[i] = i;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return lno[a] < lno[b]; });
+    std::vector<int32_t> lists, counts;
+    std::vector<int64_t> vids(n);
+    std::vector<uint8_t> gcodes((size_t)n * cs);
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t src = order[i];
+        vids[i] = first_vid + src;
+        memcpy(gcodes.data() + (size_t)i * cs, codes.data() + (size_t)src * cs, cs);
+        if (lists.empty() || lists.back() != (int32_t)lno[src]) {
+            lists.push_back((int32_t)lno[src]);
+            counts.push_back(0);
+        }
+        counts.back()++;
+    }
+    return gamma_hip_ivfpq_add_keys_batch(h, (int)lists.size(), lists.data(), counts.data(), vids.data(), gcodes.data());
+}
+
+/* ---- search ----------------------------------------------------------------------------- */
+int gamma_hip_ivfpq_search_device(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
+                                  const float* d_x, int k, float* d_distances, int64_t* d_labels) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    return ivfpq_search_device_locked(h, p, nq, d_x, k, d_distances, d_labels);
+}
+
+int gamma_hip_ivfpq_search(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x,
+                           int k, float* distances, int64_t* labels) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    GH_TRY(ivfpq_check(h, p, nq, k));
+    if (nq > 0 && k > 0 && (!x || !distances || !labels)) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
+    return host_search(h, nq, h->d, x, k, distances, labels, [&](const float* dx, float* dd, int64_t* dl) {
+        return ivfpq_search_device_locked(h, p, nq, dx, k, dd, dl);
+    });
+}
+
+int gamma_hip_ivfpq_last_stages(gamma_hip_index* h, float* coarse_dis, int64_t* coarse_idx,
+                                float* recall_dis, int64_t* recall_ids) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    const int nq = h->last_nq, P = h->last_P, R = h->last_R;
+    if (nq <= 0) return fail(h, GAMMA_HIP_EINVAL, "no previous search");
+    GH_CHECK(h, hipSetDevice(h->device));
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    if (coarse_dis) GH_CHECK(h, hipMemcpy(coarse_dis, h->w_coarse_dis.p, (size_t)nq * P * sizeof(float), hipMemcpyDeviceToHost));
+    if (coarse_idx) {
+        std::vector<int> tmp((size_t)nq * P);
+        GH_CHECK(h, hipMemcpy(tmp.data(), h->w_probe.p, tmp.size() * sizeof(int), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < tmp.size(); i++) coarse_idx[i] = tmp[i];
+    }
+    if (recall_dis) GH_CHECK(h, hipMemcpy(recall_dis, h->w_cand_dis.p, (size_t)nq * R * sizeof(float), hipMemcpyDeviceToHost));
+    if (recall_ids) GH_CHECK(h, hipMemcpy(recall_ids, h->w_cand_ids.p, (size_t)nq * R * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_search_shard(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
+                                 const float* d_x, int k, float* d_recall_dis, int64_t* d_recall_ids) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    GH_TRY(ivfpq_check(h, p, nq, k));
+    if (k <= 0 || nq == 0) return GAMMA_HIP_OK;
+    GH_CHECK(h, hipSetDevice(h->device));
+    const int R = std::max(p->recall_num, k);
+    gh::FilterDesc filt;
+    GH_TRY(build_filter(h, p, &filt));
+    const int chunk = query_chunk(h, nq, p->nprobe);
+    for (int q0 = 0; q0 < nq; q0 += chunk) {
+        const int nc = std::min(chunk, nq - q0);
+        GH_TRY(ivfpq_stage_a(h, p, filt, nc, d_x + (size_t)q0 * h->d, R));
+        GH_CHECK(h, hipMemcpyAsync(d_recall_dis + (size_t)q0 * R, h->w_cand_dis.p, (size_t)nc * R * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        GH_CHECK(h, hipMemcpyAsync(d_recall_ids + (size_t)q0 * R, h->w_cand_ids.p, (size_t)nc * R * sizeof(int64_t), hipMemcpyDeviceToDevice, h->stream));
+        h->last_nq = nc;
+    }
+    h->last_P = p->nprobe;
+    h->last_R = R;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_merge_rerank(gamma_hip_index* h, const gamma_hip_search_params* p, int nshards, int nq,
+                                 const float* d_x, int k, const float* d_all_dis, const int64_t* d_all_ids,
+                                 int q0, int nq_local, float* d_distances, int64_t* d_labels) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    GH_TRY(ivfpq_check(h, p, nq, k));
+    if (nshards <= 0 || q0 < 0 || nq_local < 0 || q0 + nq_local > nq) return fail(h, GAMMA_HIP_EINVAL, "bad shard/query range");
+    if (k <= 0 || nq_local == 0) return GAMMA_HIP_OK;
+    GH_CHECK(h, hipSetDevice(h->device));
+    const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
+    const int R = std::max(p->recall_num, k);
+    if ((int64_t)nshards * R > (int64_t)1 << 24) return fail(h, GAMMA_HIP_EINVAL, "too many candidates");
+    hipStream_t s = h->stream;
+    GH_CHECK(h, h->w_m_dis.ensure((size_t)nq * nshards * R * sizeof(float)));
+    GH_CHECK(h, h->w_m_ids.ensure((size_t)nq * nshards * R * sizeof(int64_t)));
+    GH_CHECK(h, h->w_cand_dis.ensure((size_t)nq_local * R * sizeof(float)));
+    GH_CHECK(h, h->w_cand_pos.ensure((size_t)nq_local * R * sizeof(int)));
+    GH_CHECK(h, h->w_cand_ids.ensure((size_t)nq_local * R * sizeof(int64_t)));
+    {
+        StageScope t(h, GAMMA_HIP_STAGE_SELECT);
+        gh::launch_gather_shards(s, d_all_dis, d_all_ids, nshards, nq, R, h->w_m_dis.as<float>(),
+                                 h->w_m_ids.as<int64_t>(), l2 ? INFINITY : -INFINITY);
+        const int64_t stride = (int64_t)nshards * R;
+        gh::launch_select_topk(s, l2, h->w_m_dis.as<float>() + (size_t)q0 * stride, stride, nullptr,
+                               (int)stride, nq_local, R, h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>());
+        gh::launch_take_ids(s, h->w_cand_pos.as<int>(), h->w_m_ids.as<int64_t>() + (size_t)q0 * stride, stride,
+                            nq_local, R, h->w_cand_ids.as<int64_t>());
+    }
+    return ivfpq_stage_b(h, p, nq_local, d_x + (size_t)q0 * h->d, R, k, h->w_cand_dis.as<float>(),
+                         h->w_cand_ids.as<int64_t>(), d_distances, d_labels);
+}
+
+int gamma_hip_flat_search_device(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
+                                 const float* d_x, int k, float* d_distances, int64_t* d_labels) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    return flat_search_device_locked(h, p, nq, d_x, k, d_distances, d_labels);
+}
+
+int gamma_hip_flat_search(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x,
+                          int k, float* distances, int64_t* labels) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    GH_TRY(check_params(h, p, nq, k));
+    if (h->raw_d <= 0) return fail(h, GAMMA_HIP_EINVAL, "raw store not initialised");
+    if (nq > 0 && k > 0 && (!x || !distances || !labels)) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
+    return host_search(h, nq, h->raw_d, x, k, distances, labels, [&](const float* dx, float* dd, int64_t* dl) {
+        return flat_search_device_locked(h, p, nq, dx, k, dd, dl);
+    });
+}
+
+/* ---- accounting ----------------------------------------------------------------------------- */
+int64_t gamma_hip_total_mem_bytes(gamma_hip_index* h) {
+    if (!h) return -1;
+    std::lock_guard<std::mutex> g(h->mu);
+    int64_t b = 0;
+    b += h->raw_cap * h->raw_d * (int64_t)sizeof(float);
+    b += (int64_t)h->bitmap_cap_bytes;
+    if (h->ivf_init) {
+        b += (int64_t)h->nlist * h->d * 4 + (int64_t)h->nlist * 4 + (int64_t)h->M * 256 * h->dsub * 4;
+        b += (int64_t)h->nlist * h->M * 256 * 4;
+        b += h->arena_cap * (h->code_size + (int64_t)sizeof(int64_t));
+        b += (int64_t)h->nlist * 12;
+    }
+    return b;
+}
+
+int gamma_hip_profile_enable(gamma_hip_index* h, int on) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    h->profile = on != 0;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_profile_reset(gamma_hip_index* h) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    GH_CHECK(h, hipSetDevice(h->device));
+    GH_TRY(drain_events(h));
+    for (int i = 0; i < GAMMA_HIP_NUM_STAGES; i++) {
+        h->stage_ms[i] = 0;
+        h->stage_n[i] = 0;
+    }
+    h->scan_pairs = 0;
+    GH_CHECK(h, hipMemsetAsync(h->d_scan_codes, 0, sizeof(unsigned long long), h->stream));
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_profile_get(gamma_hip_index* h, int stage, double* total_ms, int64_t* launches) {
+    if (!h || stage < 0 || stage >= GAMMA_HIP_NUM_STAGES) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    GH_CHECK(h, hipSetDevice(h->device));
+    GH_TRY(drain_events(h));
+    if (total_ms) *total_ms = h->stage_ms[stage];
+    if (launches) *launches = h->stage_n[stage];
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_profile_scan_bytes(gamma_hip_index* h, int64_t* bytes, int64_t* pairs) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    GH_CHECK(h, hipSetDevice(h->device));
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    unsigned long long codes = 0;
+    GH_CHECK(h, hipMemcpy(&codes, h->d_scan_codes, sizeof(codes), hipMemcpyDeviceToHost));
+    if (bytes) *bytes = (int64_t)codes * h->code_size;
+    if (pairs) *pairs = h->scan_pairs;
+    return GAMMA_HIP_OK;
+}
+
+}  // extern "C"

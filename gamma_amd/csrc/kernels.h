@@ -1,0 +1,74 @@
+// kernels.h -- launch wrappers of the gfx950 kernels in kernels.hip (internal to
+// libgamma_hip.so; the public surface is include/gamma_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gh {
+
+constexpr int kMaxRange = 8;
+
+// RangeQueryResult on device (table/range_query_result.h:53-67)
+struct RangeDesc {
+    const uint8_t* bitmap;
+    int32_t min_doc, max_doc, min_aligned, b_not_in;
+};
+
+// everything GammaSearchCondition::IsValid reads (common/gamma_common_data.h:99-108)
+struct FilterDesc {
+    const uint8_t* del_bitmap;
+    int64_t del_bits;
+    int32_t has_range, n_range;
+    RangeDesc range[kMaxRange];
+};
+
+void launch_pairwise(hipStream_t s, bool l2, const float* x, int nq, int d, const float* y,
+                     int64_t ny, float* out, int64_t ld_out);
+void launch_pairwise_filtered(hipStream_t s, bool l2, const float* x, int nq, int d,
+                              const float* y, int64_t ny, float* out, int64_t ld_out,
+                              const FilterDesc& filt, float min_score, float max_score,
+                              int64_t row_base);
+void launch_row_norms(hipStream_t s, const float* y, int64_t n, int d, float* out);
+void launch_l2_gemmform(hipStream_t s, const float* x, int nq, int d, const float* y, int64_t ny,
+                        const float* xn, const float* yn, float* out, int64_t ld_out,
+                        bool use_mfma);
+void launch_pq_ip_table(hipStream_t s, const float* x, int nq, int d, int M, const float* pqc,
+                        float* out);
+void launch_precompute_table(hipStream_t s, const float* cc, int nlist, int d, int M,
+                             const float* pqc, float* out);
+void launch_pair_offsets(hipStream_t s, const int* probe_list, int nq, int P, const int* list_len,
+                         const uint8_t* list_mask, int nlist, int* pair_off, int* q_total,
+                         unsigned long long* scan_codes);
+void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int d, int M, int P,
+                            const int* probe_list, const float* coarse_dis, const float* cc,
+                            const float* st2, const float* T2, const int64_t* list_off,
+                            const int* list_len, const uint8_t* list_mask, int nlist,
+                            const uint8_t* codes, const int64_t* ids, const int* pair_off,
+                            int64_t q_stride, float* out, const FilterDesc& filt);
+int select_kpad(int K);
+void launch_select_topk(hipStream_t s, bool smallest, const float* vals, int64_t seg_stride,
+                        const int* seg_len, int fixed_len, int nseg, int K, float* out_vals,
+                        int* out_pos);
+void launch_map_candidates(hipStream_t s, const int* pos, int nq, int R, int P,
+                           const int* probe_list, const int* pair_off, const int64_t* list_off,
+                           const int64_t* ids, int64_t* cand_ids);
+void launch_rerank_dist(hipStream_t s, bool l2, const float* x, int nq, int d, const float* raw,
+                        int64_t nraw, const int64_t* cand_ids, int R, float min_score,
+                        float max_score, float* out);
+void launch_finalize_topk(hipStream_t s, const float* sel_vals, const int* sel_pos, int nq, int k,
+                          const int64_t* src_ids, int64_t src_stride, int64_t id_base,
+                          float neutral, float* distances, int64_t* labels);
+void launch_finalize_norank(hipStream_t s, const float* cand_dis, const int64_t* cand_ids, int nq,
+                            int R, int k, float min_score, float max_score, float neutral,
+                            float* distances, int64_t* labels);
+void launch_gather_shards(hipStream_t s, const float* all_dis, const int64_t* all_ids, int nshards,
+                          int nq, int R, float* dis, int64_t* ids, float sentinel);
+void launch_take_ids(hipStream_t s, const int* pos, const int64_t* src_ids, int64_t src_stride,
+                     int nq, int R, int64_t* out);
+void launch_bitmap_set(hipStream_t s, uint8_t* bm, const int64_t* docids, int64_t n, int64_t nbits,
+                       int value);
+void launch_mark_moved(hipStream_t s, int64_t* ids, int64_t pos);
+void launch_pq_encode(hipStream_t s, const float* x, int64_t n, int d, int M, const int* assign,
+                      const float* cc, const float* pqc, uint8_t* codes);
+
+}  // namespace gh

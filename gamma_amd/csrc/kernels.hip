@@ -1,0 +1,996 @@
+// kernels.hip -- hand-written gfx950 (MI355X, wave64) kernels for the Gamma retrieval
+// hot path: exact pairwise distances, PQ lookup-table build, IVFPQ inverted-list scan with
+// the LUT in LDS, radix/bitonic k-selection, exact re-rank.  Arithmetic order follows
+// device_math.h so distances are bit-identical to the reference's faiss-CPU path.
+//
+// Reference stages: a2 coarse quantizer, a4 LUT build, a5/a6 list scan,
+// a7 top-k, a8 validity, a9 re-rank, a10 flat.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_math.h"
+#include "kernels.h"
+
+namespace gh {
+
+// ------------------------------------------------------------------------------------
+// small block-level helpers (256 threads = 4 waves of 64)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int y = __shfl_up(v, off, 64);
+        if (lane >= off) v += y;
+    }
+    return v;
+}
+
+// exclusive scan of one int per thread over a 256-thread block; `total` = block sum.
+// s_w: 4 ints of LDS scratch.  Contains two barriers.
+__device__ __forceinline__ int block_excl_scan256(int v, int* s_w, int& total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int incl = wave_incl_scan(v);
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int t = s_w[i];
+        if (i < w) base += t;
+    }
+    total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __syncthreads();
+    return base + incl - v;
+}
+
+// ------------------------------------------------------------------------------------
+// validity predicate (GammaSearchCondition::IsValid, common/gamma_common_data.h:99-108)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ bool bm_test(const uint8_t* bm, int64_t id) {
+    return (bm[id >> 3] >> (id & 7)) & 1;
+}
+
+__device__ __forceinline__ bool is_valid_doc(const FilterDesc& f, int64_t vid) {
+    const int doc = (int)vid;
+    if (f.has_range) {
+        if (f.n_range == 0) return false;  // MultiRangeQueryResults::Has on empty set
+        for (int i = 0; i < f.n_range; i++) {
+            const RangeDesc& r = f.range[i];
+            bool has;
+            if (r.b_not_in) {
+                has = (doc < r.min_doc || doc > r.max_doc) ? true
+                                                           : !bm_test(r.bitmap, doc - r.min_aligned);
+            } else {
+                has = (doc < r.min_doc || doc > r.max_doc) ? false
+                                                           : bm_test(r.bitmap, doc - r.min_aligned);
+            }
+            if (!has) return false;
+        }
+    }
+    if (f.del_bitmap && doc >= 0 && (int64_t)doc < f.del_bits && bm_test(f.del_bitmap, doc))
+        return false;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------
+// a2/a10: exact pairwise distances, one database row per thread held in registers.
+//   out[q][row] = fvec_L2sqr / fvec_inner_product (x_q, y_row), reference op order.
+// The row (D floats) is read from HBM once per block and reused for every query of the
+// block's query range; the query vector is wave-uniform and comes in through scalar
+// loads.  grid = (ceil(ny/256), ceil(nq/q_per_block)).
+// ------------------------------------------------------------------------------------
+template <bool L2, int D, bool FILTER>
+__global__ __launch_bounds__(256) void k_pairwise_rowreg(const float* __restrict__ x, int nq,
+                                                         const float* __restrict__ y, int64_t ny,
+                                                         float* __restrict__ out, int64_t ld_out,
+                                                         int q_per_block, FilterDesc filt,
+                                                         float min_score, float max_score,
+                                                         float sentinel, int64_t row_base) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int q0 = blockIdx.y * q_per_block;
+    const int q1 = min(nq, q0 + q_per_block);
+    float yr[D];
+    const bool live = row < ny;
+    if (live) {
+        const float4* yp = reinterpret_cast<const float4*>(y + row * D);
+#pragma unroll
+        for (int i = 0; i < D / 4; i++) {
+            float4 v = yp[i];
+            yr[4 * i + 0] = v.x;
+            yr[4 * i + 1] = v.y;
+            yr[4 * i + 2] = v.z;
+            yr[4 * i + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < D; i++) yr[i] = 0.f;
+    }
+    bool valid = live;
+    if (FILTER && live) valid = is_valid_doc(filt, row_base + row);
+    for (int q = q0; q < q1; q++) {
+        const float* xq = x + (int64_t)q * D;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < D; i += 8) {
+#pragma unroll
+            for (int l = 0; l < 8; l++) {
+                if (L2) {
+                    float t = xq[i + l] - yr[i + l];
+                    acc[l] = __builtin_fmaf(t, t, acc[l]);
+                } else {
+                    acc[l] = __builtin_fmaf(xq[i + l], yr[i + l], acc[l]);
+                }
+            }
+        }
+        float dis = hsum4(acc[4] + acc[0], acc[5] + acc[1], acc[6] + acc[2], acc[7] + acc[3]);
+        if (FILTER) {
+            if (!valid || !(dis <= max_score && dis >= min_score)) dis = sentinel;
+        }
+        if (live) out[(int64_t)q * ld_out + row] = dis;
+    }
+}
+
+// generic-d fallback: same contract, row streamed from memory per query.
+template <bool L2, bool FILTER>
+__global__ __launch_bounds__(256) void k_pairwise_generic(const float* __restrict__ x, int nq, int d,
+                                                          const float* __restrict__ y, int64_t ny,
+                                                          float* __restrict__ out, int64_t ld_out,
+                                                          int q_per_block, FilterDesc filt,
+                                                          float min_score, float max_score,
+                                                          float sentinel, int64_t row_base) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= ny) return;
+    const int q0 = blockIdx.y * q_per_block;
+    const int q1 = min(nq, q0 + q_per_block);
+    const float* yr = y + row * d;
+    bool valid = true;
+    if (FILTER) valid = is_valid_doc(filt, row_base + row);
+    for (int q = q0; q < q1; q++) {
+        float dis = fvec_dist<L2>(x + (int64_t)q * d, yr, d);
+        if (FILTER) {
+            if (!valid || !(dis <= max_score && dis >= min_score)) dis = sentinel;
+        }
+        out[(int64_t)q * ld_out + row] = dis;
+    }
+}
+
+template <bool L2, bool FILTER>
+static void launch_pairwise_t(hipStream_t s, const float* x, int nq, int d, const float* y,
+                              int64_t ny, float* out, int64_t ld_out, const FilterDesc& filt,
+                              float min_score, float max_score, float sentinel,
+                              int64_t row_base) {
+    if (ny <= 0 || nq <= 0) return;
+    const int64_t row_blocks = (ny + 255) / 256;
+    // enough blocks to fill 256 CUs a few times over; rows stay in registers across the
+    // block's whole query range
+    int q_per_block = nq;
+    const int64_t want_blocks = 2048;
+    if (row_blocks < want_blocks) {
+        int splits = (int)((want_blocks + row_blocks - 1) / row_blocks);
+        q_per_block = (nq + splits - 1) / splits;
+        if (q_per_block < 8) q_per_block = nq < 8 ? nq : 8;
+    }
+    dim3 grid((unsigned)row_blocks, (unsigned)((nq + q_per_block - 1) / q_per_block));
+#define GH_ROWREG(DD)                                                                        \
+    hipLaunchKernelGGL((k_pairwise_rowreg<L2, DD, FILTER>), grid, dim3(256), 0, s, x, nq, y, ny, \
+                       out, ld_out, q_per_block, filt, min_score, max_score, sentinel, row_base)
+    switch (d) {
+        case 128: GH_ROWREG(128); break;
+        case 96: GH_ROWREG(96); break;
+        case 64: GH_ROWREG(64); break;
+        case 32: GH_ROWREG(32); break;
+        case 16: GH_ROWREG(16); break;
+        default:
+            hipLaunchKernelGGL((k_pairwise_generic<L2, FILTER>), grid, dim3(256), 0, s, x, nq, d, y,
+                               ny, out, ld_out, q_per_block, filt, min_score, max_score, sentinel,
+                               row_base);
+    }
+#undef GH_ROWREG
+}
+
+void launch_pairwise(hipStream_t s, bool l2, const float* x, int nq, int d, const float* y,
+                     int64_t ny, float* out, int64_t ld_out) {
+    FilterDesc f{};
+    if (l2)
+        launch_pairwise_t<true, false>(s, x, nq, d, y, ny, out, ld_out, f, 0, 0, 0, 0);
+    else
+        launch_pairwise_t<false, false>(s, x, nq, d, y, ny, out, ld_out, f, 0, 0, 0, 0);
+}
+
+void launch_pairwise_filtered(hipStream_t s, bool l2, const float* x, int nq, int d,
+                              const float* y, int64_t ny, float* out, int64_t ld_out,
+                              const FilterDesc& filt, float min_score, float max_score,
+                              int64_t row_base) {
+    if (l2)
+        launch_pairwise_t<true, true>(s, x, nq, d, y, ny, out, ld_out, filt, min_score, max_score,
+                                      INFINITY, row_base);
+    else
+        launch_pairwise_t<false, true>(s, x, nq, d, y, ny, out, ld_out, filt, min_score, max_score,
+                                       -INFINITY, row_base);
+}
+
+// ------------------------------------------------------------------------------------
+// a2 (GEMM form, faiss:utils/distances.cpp:215-296): squared norms in the SSE order.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_row_norms(const float* __restrict__ y, int64_t n, int d,
+                                                   float* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = fvec_norm_L2sqr(y + i * d, d);
+}
+void launch_row_norms(hipStream_t s, const float* y, int64_t n, int d, float* out) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, n, d, out);
+}
+
+// dis = (xn + yn) - 2*ip, clamped at 0; ip = k-ordered single-accumulator fmaf chain.
+// This is the exact value the fp32 MFMA path produces (v_mfma_f32_*_f32 accumulates as a
+// k-ordered fmaf chain); this VALU kernel is the correctness reference for it and the
+// fallback for shapes the MFMA kernel does not tile.
+__global__ __launch_bounds__(256) void k_l2_gemmform_valu(const float* __restrict__ x, int nq, int d,
+                                                          const float* __restrict__ y, int64_t ny,
+                                                          const float* __restrict__ xn,
+                                                          const float* __restrict__ yn,
+                                                          float* __restrict__ out, int64_t ld_out,
+                                                          int q_per_block) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= ny) return;
+    const int q0 = blockIdx.y * q_per_block;
+    const int q1 = min(nq, q0 + q_per_block);
+    const float* yr = y + row * d;
+    const float ynr = yn[row];
+    for (int q = q0; q < q1; q++) {
+        const float* xq = x + (int64_t)q * d;
+        float ip = 0.f;
+        for (int t = 0; t < d; t++) ip = __builtin_fmaf(xq[t], yr[t], ip);
+        float dis = (xn[q] + ynr) - 2.f * ip;
+        if (dis < 0.f) dis = 0.f;
+        out[(int64_t)q * ld_out + row] = dis;
+    }
+}
+
+// MFMA version: C[q][c] tile 64x64 per wave-quad; v_mfma_f32_32x32x2_f32 (exact fp32,
+// k-ordered fmaf chain => bit-identical to k_l2_gemmform_valu).  Block = 256 threads =
+// 4 waves, each wave owns a 32x32 output tile of a 64x64 block tile; A (queries) and B
+// (centroids) k-slabs of 32 are staged through LDS.
+// lane l holds A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]; C/D: col = l&31,
+// row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void k_l2_gemmform_mfma(const float* __restrict__ x, int nq, int d,
+                                                          const float* __restrict__ y, int ny,
+                                                          const float* __restrict__ xn,
+                                                          const float* __restrict__ yn,
+                                                          float* __restrict__ out, int64_t ld_out) {
+    constexpr int BK = 32;
+    // +1 padding: the fragment reads walk rows (stride BK+1 dwords) -> conflict-free
+    __shared__ float sA[64][BK + 1];
+    __shared__ float sB[64][BK + 1];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wq = w >> 1, wc = w & 1;
+    const int q_base = blockIdx.y * 64, c_base = blockIdx.x * 64;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.f;
+    for (int k0 = 0; k0 < d; k0 += BK) {
+        // stage 64 x 32 of A and of B: 2048 floats each, 8 per thread
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            int e = it * 256 + tid;
+            int r = e >> 5, c = e & 31;
+            int q = q_base + r, cc = c_base + r, kk = k0 + c;
+            sA[r][c] = (q < nq && kk < d) ? x[(int64_t)q * d + kk] : 0.f;
+            sB[r][c] = (cc < ny && kk < d) ? y[(int64_t)cc * d + kk] : 0.f;
+        }
+        __syncthreads();
+        const int kmax = min(BK, d - k0);
+        // K must advance in order: each MFMA consumes k, k+1 (lane>>5 selects which)
+        for (int kk = 0; kk < kmax; kk += 2) {
+            float a = sA[wq * 32 + (lane & 31)][kk + (lane >> 5)];
+            float b = sB[wc * 32 + (lane & 31)][kk + (lane >> 5)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // epilogue: dis = (xn + yn) - 2*ip, clamp
+    const int col = c_base + wc * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        int row = q_base + wq * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < nq && col < ny) {
+            float dis = (xn[row] + yn[col]) - 2.f * acc[r];
+            if (dis < 0.f) dis = 0.f;
+            out[(int64_t)row * ld_out + col] = dis;
+        }
+    }
+}
+
+void launch_l2_gemmform(hipStream_t s, const float* x, int nq, int d, const float* y, int64_t ny,
+                        const float* xn, const float* yn, float* out, int64_t ld_out,
+                        bool use_mfma) {
+    if (nq <= 0 || ny <= 0) return;
+    // the 32x32x2 MFMA consumes k in pairs with a zero pad for odd d: fma(0,0,acc) == acc
+    // exactly, so any d is bit-safe
+    if (use_mfma) {
+        dim3 grid((unsigned)((ny + 63) / 64), (unsigned)((nq + 63) / 64));
+        hipLaunchKernelGGL(k_l2_gemmform_mfma, grid, dim3(256), 0, s, x, nq, d, y, (int)ny, xn, yn,
+                           out, ld_out);
+    } else {
+        const int64_t row_blocks = (ny + 255) / 256;
+        int q_per_block = 8;
+        dim3 grid((unsigned)row_blocks, (unsigned)((nq + q_per_block - 1) / q_per_block));
+        hipLaunchKernelGGL(k_l2_gemmform_valu, grid, dim3(256), 0, s, x, nq, d, y, ny, xn, yn, out,
+                           ld_out, q_per_block);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// a4: per-query inner-product table  st2[q][m][j] = <x_q,m , c_mj>
+// (ProductQuantizer::compute_inner_prod_table, faiss:impl/ProductQuantizer.cpp:518-531)
+// block = 256 threads = the 256 centroids of one sub-quantizer; grid = (M, nq).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pq_ip_table(const float* __restrict__ x, int d, int M,
+                                                     int dsub, const float* __restrict__ pqc,
+                                                     float* __restrict__ out) {
+    const int m = blockIdx.x, q = blockIdx.y, j = threadIdx.x;
+    const float* xs = x + (int64_t)q * d + m * dsub;                 // wave-uniform
+    const float* c = pqc + ((int64_t)m * 256 + j) * dsub;            // per-lane row
+    out[((int64_t)q * M + m) * 256 + j] = fvec_ny_row<false>(xs, c, dsub);
+}
+void launch_pq_ip_table(hipStream_t s, const float* x, int nq, int d, int M, const float* pqc,
+                        float* out) {
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(k_pq_ip_table, dim3(M, nq), dim3(256), 0, s, x, d, M, d / M, pqc, out);
+}
+
+// precomputed table T2[l][m][j] = ||c_mj||^2 + 2 <centroid_l,m , c_mj>
+// (faiss:IndexIVFPQ.cpp:453-479: r_norms via fvec_norm_L2sqr, fvec_madd with bf = 2)
+__global__ __launch_bounds__(256) void k_precompute_table(const float* __restrict__ cc, int d, int M,
+                                                          int dsub, const float* __restrict__ pqc,
+                                                          float* __restrict__ out) {
+    const int m = blockIdx.x, l = blockIdx.y, j = threadIdx.x;
+    const float* xs = cc + (int64_t)l * d + m * dsub;
+    const float* c = pqc + ((int64_t)m * 256 + j) * dsub;
+    float ip = fvec_ny_row<false>(xs, c, dsub);
+    float rn = fvec_norm_L2sqr(c, dsub);
+    out[((int64_t)l * M + m) * 256 + j] = __builtin_fmaf(2.0f, ip, rn);
+}
+void launch_precompute_table(hipStream_t s, const float* cc, int nlist, int d, int M,
+                             const float* pqc, float* out) {
+    hipLaunchKernelGGL(k_precompute_table, dim3(M, nlist), dim3(256), 0, s, cc, d, M, d / M, pqc, out);
+}
+
+// ------------------------------------------------------------------------------------
+// per-query exclusive prefix of probed-list lengths -> where each (query, probe) pair
+// writes its distances.  grid = nq, block = 256.  Also masks lists not owned by this
+// shard (length 0) and accumulates the algorithmic scan-byte counter.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pair_offsets(const int* __restrict__ probe_list, int P,
+                                                      const int* __restrict__ list_len,
+                                                      const uint8_t* __restrict__ list_mask,
+                                                      int nlist, int* __restrict__ pair_off,
+                                                      int* __restrict__ q_total,
+                                                      unsigned long long* __restrict__ scan_codes) {
+    __shared__ int s_w[4];
+    const int q = blockIdx.x;
+    int running = 0;
+    for (int p0 = 0; p0 < P; p0 += 256) {
+        int p = p0 + threadIdx.x;
+        int len = 0;
+        if (p < P) {
+            int l = probe_list[(int64_t)q * P + p];
+            if (l >= 0 && l < nlist && (!list_mask || list_mask[l])) len = list_len[l];
+        }
+        int tot;
+        int ex = block_excl_scan256(len, s_w, tot);
+        if (p < P) pair_off[(int64_t)q * (P + 1) + p] = running + ex;
+        running += tot;
+    }
+    if (threadIdx.x == 0) {
+        pair_off[(int64_t)q * (P + 1) + P] = running;
+        q_total[q] = running;
+        if (scan_codes) atomicAdd(scan_codes, (unsigned long long)running);
+    }
+}
+void launch_pair_offsets(hipStream_t s, const int* probe_list, int nq, int P, const int* list_len,
+                         const uint8_t* list_mask, int nlist, int* pair_off, int* q_total,
+                         unsigned long long* scan_codes) {
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(k_pair_offsets, dim3(nq), dim3(256), 0, s, probe_list, P, list_len, list_mask,
+                       nlist, pair_off, q_total, scan_codes);
+}
+
+// ------------------------------------------------------------------------------------
+// a4+a5+a6+a8: IVFPQ list scan, one workgroup per (query, probe) pair.
+//   LUT (M x 256 fp32) built in LDS:  L2: lut = T2[list] + (-2) * st2[q]  (fvec_madd)
+//                                     IP: lut = st2[q]
+//   dis0: L2 = coarse distance; IP = <x_q, centroid> in fvec_inner_product order.
+//   per code j:  skip if ids[j] bit 63 / !IsValid;  dis = dis0; for m: dis += lut[m][code[m]]
+//   (sequential fp32 adds, gamma_index_ivfpq.h:591-597).  Distances go to the pair's slot
+//   range in out; filtered entries get the sentinel.
+// Codes are AoS [len][M] exactly as the reference stores them; a 16-byte code is one
+// dwordx4 load per lane, so a wave reads 1 KiB contiguous.
+// ------------------------------------------------------------------------------------
+template <bool L2, int MT>
+__global__ __launch_bounds__(256) void k_ivfpq_scan_pair(
+        const float* __restrict__ x, int d, int M, int P, const int* __restrict__ probe_list,
+        const float* __restrict__ coarse_dis, const float* __restrict__ cc,
+        const float* __restrict__ st2, const float* __restrict__ T2,
+        const int64_t* __restrict__ list_off, const int* __restrict__ list_len,
+        const uint8_t* __restrict__ list_mask, int nlist, const uint8_t* __restrict__ codes,
+        const int64_t* __restrict__ ids, const int* __restrict__ pair_off, int64_t q_stride,
+        float* __restrict__ out, FilterDesc filt, float sentinel) {
+    extern __shared__ float s_lut[];  // M*256
+    __shared__ float s_acc[8];
+    const int pair = blockIdx.x;
+    const int q = pair / P, p = pair - q * P;
+    const int l = probe_list[pair];
+    if (l < 0 || l >= nlist) return;
+    if (list_mask && !list_mask[l]) return;
+    const int len = list_len[l];
+    if (len == 0) return;
+    const int tid = threadIdx.x;
+    const int msz = M * 256;
+    const float* st2q = st2 + (int64_t)q * msz;
+    if (L2) {
+        const float* t2 = T2 + (int64_t)l * msz;
+        for (int e = tid; e < msz; e += 256) s_lut[e] = __builtin_fmaf(-2.0f, st2q[e], t2[e]);
+    } else {
+        for (int e = tid; e < msz; e += 256) s_lut[e] = st2q[e];
+        // dis0 = fvec_inner_product(x_q, centroid_l): 8 lane accumulators by 8 threads
+        if (tid < 8) {
+            const float* xq = x + (int64_t)q * d;
+            const float* c = cc + (int64_t)l * d;
+            float a = 0.f;
+            for (int i = tid; i + (7 - tid) < d; i += 8) a = __builtin_fmaf(xq[i], c[i], a);
+            s_acc[tid] = a;
+        }
+    }
+    __syncthreads();
+    float dis0;
+    if (L2) {
+        dis0 = coarse_dis[pair];
+    } else {
+        const float* xq = x + (int64_t)q * d;
+        const float* c = cc + (int64_t)l * d;
+        float s0 = s_acc[4] + s_acc[0], s1 = s_acc[5] + s_acc[1], s2 = s_acc[6] + s_acc[2],
+              s3 = s_acc[7] + s_acc[3];
+        int i = d & ~7, rem = d & 7;
+        if (rem >= 4) {
+            s0 = __builtin_fmaf(xq[i], c[i], s0);
+            s1 = __builtin_fmaf(xq[i + 1], c[i + 1], s1);
+            s2 = __builtin_fmaf(xq[i + 2], c[i + 2], s2);
+            s3 = __builtin_fmaf(xq[i + 3], c[i + 3], s3);
+            i += 4;
+            rem -= 4;
+        }
+        if (rem > 0) s0 = __builtin_fmaf(xq[i], c[i], s0);
+        if (rem > 1) s1 = __builtin_fmaf(xq[i + 1], c[i + 1], s1);
+        if (rem > 2) s2 = __builtin_fmaf(xq[i + 2], c[i + 2], s2);
+        dis0 = hsum4(s0, s1, s2, s3);
+    }
+    const int64_t off = list_off[l];
+    const uint8_t* lc = codes + off * M;
+    const int64_t* lid = ids + off;
+    float* o = out + (int64_t)q * q_stride + pair_off[(int64_t)q * (P + 1) + p];
+    for (int j = tid; j < len; j += 256) {
+        const int64_t id = lid[j];
+        bool ok = id >= 0;  // bit 63 = kDelIdxMask (realtime_mem_data.h:26)
+        if (ok) ok = is_valid_doc(filt, id);
+        float dis = dis0;
+        if (MT == 16) {
+            const uint4 cv = *reinterpret_cast<const uint4*>(lc + (int64_t)j * 16);
+            const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+            for (int m = 0; m < 16; m++) dis += s_lut[m * 256 + ((cw[m >> 2] >> ((m & 3) * 8)) & 255)];
+        } else if (MT == 32) {
+            const uint4* cp = reinterpret_cast<const uint4*>(lc + (int64_t)j * 32);
+            const uint4 c0 = cp[0], c1 = cp[1];
+            const uint32_t cw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+            for (int m = 0; m < 32; m++) dis += s_lut[m * 256 + ((cw[m >> 2] >> ((m & 3) * 8)) & 255)];
+        } else {
+            const uint8_t* cj = lc + (int64_t)j * M;
+            for (int m = 0; m < M; m++) dis += s_lut[m * 256 + cj[m]];
+        }
+        o[j] = ok ? dis : sentinel;
+    }
+}
+
+void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int d, int M, int P,
+                            const int* probe_list, const float* coarse_dis, const float* cc,
+                            const float* st2, const float* T2, const int64_t* list_off,
+                            const int* list_len, const uint8_t* list_mask, int nlist,
+                            const uint8_t* codes, const int64_t* ids, const int* pair_off,
+                            int64_t q_stride, float* out, const FilterDesc& filt) {
+    if (nq <= 0) return;
+    const size_t lds = (size_t)M * 256 * sizeof(float);
+    dim3 grid((unsigned)((int64_t)nq * P));
+#define GH_SCAN(LL, MT)                                                                        \
+    hipLaunchKernelGGL((k_ivfpq_scan_pair<LL, MT>), grid, dim3(256), lds, s, x, d, M, P, probe_list, \
+                       coarse_dis, cc, st2, T2, list_off, list_len, list_mask, nlist, codes, ids,  \
+                       pair_off, q_stride, out, filt, LL ? INFINITY : -INFINITY)
+    if (l2) {
+        if (M == 16) GH_SCAN(true, 16);
+        else if (M == 32) GH_SCAN(true, 32);
+        else GH_SCAN(true, 0);
+    } else {
+        if (M == 16) GH_SCAN(false, 16);
+        else if (M == 32) GH_SCAN(false, 32);
+        else GH_SCAN(false, 0);
+    }
+#undef GH_SCAN
+}
+
+// ------------------------------------------------------------------------------------
+// a7: k-selection.  One workgroup per row segment.  MSB-first radix select (4 passes of
+// 8 bits over order-preserving keys) finds the K-th key; the survivors (key < T, plus the
+// first few == T in scan order) are gathered into LDS and sorted by a bitonic network on
+// 64-bit (key, position) items, so equal distances come out in scan order -- the
+// deterministic counterpart of the reference's heap (faiss:utils/Heap.h), which keeps the
+// same multiset and differs only in the order inside exact ties.
+// SMALLEST=true keeps the K smallest (CMax heap, L2); false the K largest (CMin heap, IP).
+// Sentinel values (+inf / -inf) mark filtered entries and are returned as pos = -1.
+// ------------------------------------------------------------------------------------
+template <bool SMALLEST>
+__device__ __forceinline__ uint32_t sel_key(float v) {
+    uint32_t k = f2key(v);
+    return SMALLEST ? k : ~k;
+}
+
+template <bool SMALLEST>
+__global__ __launch_bounds__(256) void k_select_topk(const float* __restrict__ vals,
+                                                     int64_t seg_stride,
+                                                     const int* __restrict__ seg_len,
+                                                     int fixed_len, int K, int Kpad,
+                                                     float* __restrict__ out_vals,
+                                                     int* __restrict__ out_pos) {
+    extern __shared__ unsigned long long s_items[];  // Kpad
+    __shared__ int s_hist[256];
+    __shared__ int s_w[4];
+    __shared__ int s_misc[8];
+    const int tid = threadIdx.x;
+    const int seg = blockIdx.x;
+    const int n = seg_len ? seg_len[seg] : fixed_len;
+    const float* v = vals + (int64_t)seg * seg_stride;
+    for (int i = tid; i < Kpad; i += 256) s_items[i] = ~0ull;
+    __syncthreads();
+    if (n <= K) {
+        for (int i = tid; i < n; i += 256)
+            s_items[i] = ((unsigned long long)sel_key<SMALLEST>(v[i]) << 32) | (unsigned)i;
+    } else {
+        uint32_t prefix = 0, mask = 0;
+        int kk = K;
+        int cnt_eq = 0;
+        for (int pass = 0; pass < 4; pass++) {
+            const int shift = 24 - 8 * pass;
+            s_hist[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += 256) {
+                uint32_t key = sel_key<SMALLEST>(v[i]);
+                if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255], 1);
+            }
+            __syncthreads();
+            const int c = s_hist[tid];
+            int tot;
+            const int ex = block_excl_scan256(c, s_w, tot);
+            if (ex < kk && kk <= ex + c) {
+                s_misc[0] = tid;
+                s_misc[1] = ex;
+                s_misc[2] = c;
+            }
+            __syncthreads();
+            prefix |= (uint32_t)s_misc[0] << shift;
+            mask |= 255u << shift;
+            kk -= s_misc[1];
+            cnt_eq = s_misc[2];
+            __syncthreads();
+        }
+        const uint32_t T = prefix;
+        const int n_less = K - kk;
+        if (tid == 0) {
+            s_misc[3] = 0;
+            s_misc[4] = 0;
+        }
+        __syncthreads();
+        if (cnt_eq == kk) {
+            for (int i = tid; i < n; i += 256) {
+                uint32_t key = sel_key<SMALLEST>(v[i]);
+                if (key < T) {
+                    int slot = atomicAdd(&s_misc[3], 1);
+                    s_items[slot] = ((unsigned long long)key << 32) | (unsigned)i;
+                } else if (key == T) {
+                    int slot = n_less + atomicAdd(&s_misc[4], 1);
+                    s_items[slot] = ((unsigned long long)key << 32) | (unsigned)i;
+                }
+            }
+        } else {
+            // ties straddle the K boundary: keep the first kk in scan order
+            int running = 0;
+            for (int i0 = 0; i0 < n; i0 += 256) {
+                const int i = i0 + tid;
+                uint32_t key = 0xffffffffu;
+                bool in = i < n;
+                if (in) key = sel_key<SMALLEST>(v[i]);
+                if (in && key < T) {
+                    int slot = atomicAdd(&s_misc[3], 1);
+                    s_items[slot] = ((unsigned long long)key << 32) | (unsigned)i;
+                }
+                const int flag = (in && key == T) ? 1 : 0;
+                int tot;
+                const int ex = block_excl_scan256(flag, s_w, tot);
+                const int rank = running + ex;
+                if (flag && rank < kk) s_items[n_less + rank] = ((unsigned long long)key << 32) | (unsigned)i;
+                running += tot;
+            }
+        }
+    }
+    // bitonic sort, ascending
+    for (int size = 2; size <= Kpad; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = tid; t < (Kpad >> 1); t += 256) {
+                const int lo = ((t / stride) * stride << 1) + (t % stride);
+                const int hi = lo + stride;
+                const bool asc = (lo & size) == 0;
+                unsigned long long a = s_items[lo], b = s_items[hi];
+                if ((a > b) == asc) {
+                    s_items[lo] = b;
+                    s_items[hi] = a;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const float sentinel = SMALLEST ? INFINITY : -INFINITY;
+    for (int r = tid; r < K; r += 256) {
+        const unsigned long long it = s_items[r];
+        float val = sentinel;
+        int pos = -1;
+        if (it != ~0ull) {
+            pos = (int)(uint32_t)it;
+            val = v[pos];
+            if (val == sentinel) pos = -1;
+        }
+        out_vals[(int64_t)seg * K + r] = val;
+        out_pos[(int64_t)seg * K + r] = pos;
+    }
+}
+
+int select_kpad(int K) {
+    int p = 2;
+    while (p < K) p <<= 1;
+    return p;
+}
+
+void launch_select_topk(hipStream_t s, bool smallest, const float* vals, int64_t seg_stride,
+                        const int* seg_len, int fixed_len, int nseg, int K, float* out_vals,
+                        int* out_pos) {
+    if (nseg <= 0 || K <= 0) return;
+    const int Kpad = select_kpad(K);
+    const size_t lds = (size_t)Kpad * sizeof(unsigned long long);
+    if (smallest)
+        hipLaunchKernelGGL((k_select_topk<true>), dim3(nseg), dim3(256), lds, s, vals, seg_stride,
+                           seg_len, fixed_len, K, Kpad, out_vals, out_pos);
+    else
+        hipLaunchKernelGGL((k_select_topk<false>), dim3(nseg), dim3(256), lds, s, vals, seg_stride,
+                           seg_len, fixed_len, K, Kpad, out_vals, out_pos);
+}
+
+// ------------------------------------------------------------------------------------
+// positions in a query's candidate segment -> vector ids (KnnSearchResults::add stores
+// ids[j], gamma_index_ivfpq.h:363-369).  grid = nq.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_map_candidates(const int* __restrict__ pos, int R, int P,
+                                                        const int* __restrict__ probe_list,
+                                                        const int* __restrict__ pair_off,
+                                                        const int64_t* __restrict__ list_off,
+                                                        const int64_t* __restrict__ ids,
+                                                        int64_t* __restrict__ cand_ids) {
+    const int q = blockIdx.x;
+    const int* off = pair_off + (int64_t)q * (P + 1);
+    for (int r = threadIdx.x; r < R; r += 256) {
+        const int ps = pos[(int64_t)q * R + r];
+        int64_t id = -1;
+        if (ps >= 0) {
+            // last p with off[p] <= ps
+            int lo = 0, hi = P - 1;
+            while (lo < hi) {
+                int mid = (lo + hi + 1) >> 1;
+                if (off[mid] <= ps) lo = mid; else hi = mid - 1;
+            }
+            const int l = probe_list[(int64_t)q * P + lo];
+            id = ids[list_off[l] + (ps - off[lo])] & 0x7fffffffffffffffLL;
+        }
+        cand_ids[(int64_t)q * R + r] = id;
+    }
+}
+void launch_map_candidates(hipStream_t s, const int* pos, int nq, int R, int P,
+                           const int* probe_list, const int* pair_off, const int64_t* list_off,
+                           const int64_t* ids, int64_t* cand_ids) {
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(k_map_candidates, dim3(nq), dim3(256), 0, s, pos, R, P, probe_list, pair_off,
+                       list_off, ids, cand_ids);
+}
+
+// ------------------------------------------------------------------------------------
+// a9: exact re-rank distances (compute_dis, gamma_index_ivfpq.cc:642-680).  8 threads
+// per candidate = the 8 lane accumulators of fvec_L2sqr / fvec_inner_product; the
+// cross-lane reduction mirrors extractf128 + add + 2x haddps.  grid = nq, block = 256
+// (32 candidates in flight).  Out-of-window scores and empty slots get the sentinel.
+// ------------------------------------------------------------------------------------
+template <bool L2>
+__global__ __launch_bounds__(256) void k_rerank_dist(const float* __restrict__ x, int d,
+                                                     const float* __restrict__ raw, int64_t nraw,
+                                                     const int64_t* __restrict__ cand_ids, int R,
+                                                     float min_score, float max_score,
+                                                     float* __restrict__ out) {
+    const int q = blockIdx.x;
+    const int l = threadIdx.x & 7, g = threadIdx.x >> 3;
+    const float* xq = x + (int64_t)q * d;
+    const float sentinel = L2 ? INFINITY : -INFINITY;
+    for (int r0 = 0; r0 < R; r0 += 32) {
+        const int r = r0 + g;
+        int64_t id = -1;
+        if (r < R) id = cand_ids[(int64_t)q * R + r];
+        const bool live = id >= 0 && id < nraw;
+        const float* v = raw + (live ? id : 0) * d;
+        float a = 0.f;
+        const int d8 = d & ~7;
+        if (live) {
+            for (int i = l; i < d8; i += 8) {
+                if (L2) {
+                    float t = xq[i] - v[i];
+                    a = __builtin_fmaf(t, t, a);
+                } else {
+                    a = __builtin_fmaf(xq[i], v[i], a);
+                }
+            }
+        }
+        // s[l] = acc[l+4] + acc[l] for l < 4
+        float s = __shfl_down(a, 4, 8) + a;
+        int rem = d - d8;
+        int i = d8;
+        if (live && rem >= 4) {
+            if (l < 4) {
+                if (L2) {
+                    float t = xq[i + l] - v[i + l];
+                    s = __builtin_fmaf(t, t, s);
+                } else {
+                    s = __builtin_fmaf(xq[i + l], v[i + l], s);
+                }
+            }
+            i += 4;
+            rem -= 4;
+        }
+        if (live && l < rem) {
+            if (L2) {
+                float t = xq[i + l] - v[i + l];
+                s = __builtin_fmaf(t, t, s);
+            } else {
+                s = __builtin_fmaf(xq[i + l], v[i + l], s);
+            }
+        }
+        float t01 = s + __shfl_down(s, 1, 8);      // lane0: s0+s1, lane2: s2+s3
+        float dis = t01 + __shfl_down(t01, 2, 8);  // lane0: (s0+s1)+(s2+s3)
+        if (l == 0 && r < R) {
+            if (!live || !(dis <= max_score && dis >= min_score)) dis = sentinel;
+            out[(int64_t)q * R + r] = dis;
+        }
+    }
+}
+void launch_rerank_dist(hipStream_t s, bool l2, const float* x, int nq, int d, const float* raw,
+                        int64_t nraw, const int64_t* cand_ids, int R, float min_score,
+                        float max_score, float* out) {
+    if (nq <= 0) return;
+    if (l2)
+        hipLaunchKernelGGL((k_rerank_dist<true>), dim3(nq), dim3(256), 0, s, x, d, raw, nraw, cand_ids,
+                           R, min_score, max_score, out);
+    else
+        hipLaunchKernelGGL((k_rerank_dist<false>), dim3(nq), dim3(256), 0, s, x, d, raw, nraw,
+                           cand_ids, R, min_score, max_score, out);
+}
+
+// final outputs from a top-k selection over re-ranked (or flat) candidates:
+//   labels = src_ids ? src_ids[q][pos] : id_base + pos ; empty -> -1 / heap neutral
+__global__ __launch_bounds__(256) void k_finalize_topk(const float* __restrict__ sel_vals,
+                                                       const int* __restrict__ sel_pos, int k,
+                                                       const int64_t* __restrict__ src_ids,
+                                                       int64_t src_stride, int64_t id_base,
+                                                       float neutral,
+                                                       float* __restrict__ distances,
+                                                       int64_t* __restrict__ labels, int n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)n * k) return;
+    const int q = (int)(i / k);
+    const int ps = sel_pos[i];
+    if (ps < 0) {
+        distances[i] = neutral;
+        labels[i] = -1;
+    } else {
+        distances[i] = sel_vals[i];
+        labels[i] = src_ids ? src_ids[(int64_t)q * src_stride + ps] : id_base + (int64_t)ps;
+    }
+}
+void launch_finalize_topk(hipStream_t s, const float* sel_vals, const int* sel_pos, int nq, int k,
+                          const int64_t* src_ids, int64_t src_stride, int64_t id_base,
+                          float neutral, float* distances, int64_t* labels) {
+    if (nq <= 0 || k <= 0) return;
+    int64_t tot = (int64_t)nq * k;
+    hipLaunchKernelGGL(k_finalize_topk, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, sel_vals,
+                       sel_pos, k, src_ids, src_stride, id_base, neutral, distances, labels, nq);
+}
+
+// has_rank == false (gamma_index_ivfpq.cc:681-696): candidates are already sorted by ADC
+// distance; copy the first k whose score is inside the window.  grid = nq.
+__global__ __launch_bounds__(256) void k_finalize_norank(const float* __restrict__ cand_dis,
+                                                         const int64_t* __restrict__ cand_ids, int R,
+                                                         int k, float min_score, float max_score,
+                                                         float neutral, float* __restrict__ distances,
+                                                         int64_t* __restrict__ labels) {
+    __shared__ int s_w[4];
+    const int q = blockIdx.x;
+    int running = 0;
+    for (int r0 = 0; r0 < R && running < k; r0 += 256) {
+        const int r = r0 + threadIdx.x;
+        float dis = 0.f;
+        int64_t id = -1;
+        if (r < R) {
+            dis = cand_dis[(int64_t)q * R + r];
+            id = cand_ids[(int64_t)q * R + r];
+        }
+        const int flag = (id != -1 && dis <= max_score && dis >= min_score) ? 1 : 0;
+        int tot;
+        const int ex = block_excl_scan256(flag, s_w, tot);
+        const int slot = running + ex;
+        if (flag && slot < k) {
+            distances[(int64_t)q * k + slot] = dis;
+            labels[(int64_t)q * k + slot] = id;
+        }
+        running += tot;
+    }
+    for (int i = min(running, k) + threadIdx.x; i < k; i += 256) {
+        distances[(int64_t)q * k + i] = neutral;
+        labels[(int64_t)q * k + i] = -1;
+    }
+}
+void launch_finalize_norank(hipStream_t s, const float* cand_dis, const int64_t* cand_ids, int nq,
+                            int R, int k, float min_score, float max_score, float neutral,
+                            float* distances, int64_t* labels) {
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(k_finalize_norank, dim3(nq), dim3(256), 0, s, cand_dis, cand_ids, R, k,
+                       min_score, max_score, neutral, distances, labels);
+}
+
+// ------------------------------------------------------------------------------------
+// small utility kernels
+// ------------------------------------------------------------------------------------
+__global__ void k_pos_to_i32(const int* __restrict__ pos, int* __restrict__ out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = pos[i];
+}
+
+// [shard][nq][R] -> [nq][shard*R] for the sharded merge
+__global__ __launch_bounds__(256) void k_gather_shards(const float* __restrict__ all_dis,
+                                                       const int64_t* __restrict__ all_ids,
+                                                       int nshards, int nq, int R,
+                                                       float* __restrict__ dis,
+                                                       int64_t* __restrict__ ids, float sentinel) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t tot = (int64_t)nshards * nq * R;
+    if (i >= tot) return;
+    const int r = (int)(i % R);
+    const int64_t t = i / R;
+    const int q = (int)(t % nq);
+    const int sh = (int)(t / nq);
+    const int64_t id = all_ids[i];
+    const int64_t o = ((int64_t)q * nshards + sh) * R + r;
+    dis[o] = id < 0 ? sentinel : all_dis[i];
+    ids[o] = id;
+}
+void launch_gather_shards(hipStream_t s, const float* all_dis, const int64_t* all_ids, int nshards,
+                          int nq, int R, float* dis, int64_t* ids, float sentinel) {
+    int64_t tot = (int64_t)nshards * nq * R;
+    if (tot <= 0) return;
+    hipLaunchKernelGGL(k_gather_shards, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, all_dis,
+                       all_ids, nshards, nq, R, dis, ids, sentinel);
+}
+
+// out_ids[q][r] = pos<0 ? -1 : src_ids[q][pos]
+__global__ __launch_bounds__(256) void k_take_ids(const int* __restrict__ pos,
+                                                  const int64_t* __restrict__ src_ids,
+                                                  int64_t src_stride, int R, int64_t n,
+                                                  int64_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t q = i / R;
+    const int ps = pos[i];
+    out[i] = ps < 0 ? -1 : src_ids[q * src_stride + ps];
+}
+void launch_take_ids(hipStream_t s, const int* pos, const int64_t* src_ids, int64_t src_stride,
+                     int nq, int R, int64_t* out) {
+    int64_t n = (int64_t)nq * R;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_take_ids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pos, src_ids,
+                       src_stride, R, n, out);
+}
+
+// coarse result packing: selected positions are the centroid ids
+__global__ void k_i32_copy_check(const int* __restrict__ in, int* __restrict__ out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+
+// set / clear bits of the delete bitmap
+__global__ void k_bitmap_set(uint8_t* __restrict__ bm, const int64_t* __restrict__ docids, int64_t n,
+                             int64_t nbits, int value) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int64_t id = docids[i];
+    if (id < 0 || id >= nbits) return;
+    unsigned int* w = reinterpret_cast<unsigned int*>(bm) + (id >> 5);
+    unsigned int m = 1u << (id & 31);  // little-endian: bit (id&7) of byte id>>3
+    if (value) atomicOr(w, m); else atomicAnd(w, ~m);
+}
+void launch_bitmap_set(hipStream_t s, uint8_t* bm, const int64_t* docids, int64_t n, int64_t nbits,
+                       int value) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_bitmap_set, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, bm, docids, n,
+                       nbits, value);
+}
+
+// mark an inverted-list entry as superseded (ids[pos] |= kDelIdxMask)
+__global__ void k_mark_moved(int64_t* __restrict__ ids, int64_t pos) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) ids[pos] |= (int64_t)(1ULL << 63);
+}
+void launch_mark_moved(hipStream_t s, int64_t* ids, int64_t pos) {
+    hipLaunchKernelGGL(k_mark_moved, dim3(1), dim3(64), 0, s, ids, pos);
+}
+
+// ------------------------------------------------------------------------------------
+// a12 (Add path): residual + PQ encode.  assign comes from the coarse kernels + select.
+//   code[m] = argmin_j fvec_L2sqr_ny(residual_m, c_mj)   (strict <, first minimum,
+//   faiss:impl/ProductQuantizer.cpp:321-348).  grid = (M, n), block = 256 = ksub.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pq_encode(const float* __restrict__ x, int d, int M, int dsub,
+                                                   const int* __restrict__ assign,
+                                                   const float* __restrict__ cc,
+                                                   const float* __restrict__ pqc,
+                                                   uint8_t* __restrict__ codes) {
+    __shared__ float s_res[64];
+    __shared__ unsigned long long s_best[4];
+    const int m = blockIdx.x, i = blockIdx.y, j = threadIdx.x;
+    const int l = assign[i];
+    if (j < dsub) {
+        float xv = x[(int64_t)i * d + m * dsub + j];
+        s_res[j] = l < 0 ? 0.f : xv - cc[(int64_t)l * d + m * dsub + j];
+    }
+    __syncthreads();
+    const float* c = pqc + ((int64_t)m * 256 + j) * dsub;
+    float dis = fvec_ny_row<true>(s_res, c, dsub);
+    if (!(dis < 1e20f)) dis = INFINITY;  // reference never picks dis >= 1e20 (mindis init)
+    // argmin with first-index tie rule: min over (key(dis), j)
+    unsigned long long item = ((unsigned long long)f2key(dis) << 32) | (unsigned)j;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long o = __shfl_down(item, off, 64);
+        if (o < item) item = o;
+    }
+    if ((j & 63) == 0) s_best[j >> 6] = item;
+    __syncthreads();
+    if (j == 0) {
+        unsigned long long b = s_best[0];
+        for (int w = 1; w < 4; w++) if (s_best[w] < b) b = s_best[w];
+        int best = (int)(uint32_t)b;
+        if (key2f((uint32_t)(b >> 32)) == INFINITY) best = 0;  // idxm initial value
+        codes[(int64_t)i * M + m] = (uint8_t)best;
+    }
+}
+void launch_pq_encode(hipStream_t s, const float* x, int64_t n, int d, int M, const int* assign,
+                      const float* cc, const float* pqc, uint8_t* codes) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_pq_encode, dim3(M, (unsigned)n), dim3(256), 0, s, x, d, M, d / M, assign, cc,
+                       pqc, codes);
+}
+
+}  // namespace gh

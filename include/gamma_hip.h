@@ -1,0 +1,182 @@
+/*
+ * gamma_hip.h -- C ABI of libgamma_hip.so, the MI355X (gfx950) device shim behind Gamma's
+ * RetrievalModel plugin boundary.
+ *
+ * The only callers are the plugin classes in gamma_amd/host/ (GammaIVFPQHIPIndex,
+ * GammaFLATHIPIndex -- REGISTER_MODEL(HIPIVFPQ / HIPFLAT)), i.e. what a Gamma maintainer
+ * compiles into libgamma next to index/impl/gamma_index_ivfpq.cc, and
+ * the ctypes binding used by this repo's tests and bench.  Everything is extern "C", plain
+ * pointers and sizes, caller-owned buffers, int return codes (0 = ok, <0 = error, see
+ * gamma_hip_strerror); no C++/torch types, no exceptions cross this line.
+ *
+ * Each entry point names the reference interface it stands in for (paths relative to the
+ * reference tree; "faiss:" = third_party/faiss-1.7.1.tar.gz, faiss-1.7.1/faiss/).
+ *
+ * Threading: one handle owns one device and one HIP stream.  Calls on a handle are
+ * serialised by an internal mutex (search + single writer, retrieval contract
+ * SURVEY.md §8b "Threading"); use one handle per GPU / per shard.
+ */
+#ifndef GAMMA_HIP_H_
+#define GAMMA_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GAMMA_HIP_METRIC_IP 0 /* DistanceComputeType::INNER_PRODUCT, index/retrieval_model.h:20 */
+#define GAMMA_HIP_METRIC_L2 1 /* DistanceComputeType::L2 */
+
+/* error codes */
+#define GAMMA_HIP_OK 0
+#define GAMMA_HIP_EINVAL (-1)     /* bad argument / unsupported parameter */
+#define GAMMA_HIP_ENOTTRAINED (-2)/* search before centroids/codebooks were set */
+#define GAMMA_HIP_EDEVICE (-3)    /* a HIP runtime call failed (hipGetLastError text kept) */
+#define GAMMA_HIP_ENOMEM (-4)     /* device or host allocation failed */
+#define GAMMA_HIP_EFULL (-5)      /* list would exceed bucket_max_size (AddKeys returns false) */
+
+typedef struct gamma_hip_index gamma_hip_index;
+
+/* RangeQueryResult as the scan sees it (table/range_query_result.h:53-67,96-109): a bitmap
+ * relative to min_aligned plus [min,max] and the NOT flag.  Host memory; copied per call. */
+typedef struct {
+    const uint8_t* bitmap;
+    int64_t bitmap_bytes;
+    int32_t min_doc, max_doc, min_aligned;
+    int32_t b_not_in;
+} gamma_hip_range_filter;
+
+/* What GammaSearchCondition + IVFPQRetrievalParameters carry into Search()
+ * (common/gamma_common_data.h:39-124, index/impl/gamma_index_ivfpq.h:629-673). */
+typedef struct {
+    int32_t metric;       /* per-request DistanceComputeType (gamma_index_ivfpq.cc:744-750) */
+    int32_t nprobe;       /* resolved by the caller as gamma_index_ivfpq.cc:539-545 does */
+    int32_t recall_num;   /* raised to k inside (gamma_index_ivfpq.cc:762-765) */
+    int32_t has_rank;     /* GammaSearchCondition::has_rank: exact re-rank of recall_num */
+    float min_score;      /* IsSimilarScoreValid window (gamma_common_data.h:95-97) */
+    float max_score;
+    int32_t coarse_mode;  /* -1: faiss rule nq<20 -> exact per-pair, else GEMM form
+                             (faiss:utils/distances.cpp:303,346); 0 exact; 1 GEMM (MFMA) */
+    int32_t has_range;    /* range_query_result != nullptr */
+    int32_t n_range;      /* number of RangeQueryResult; 0 with has_range => nothing valid */
+    const gamma_hip_range_filter* range;
+} gamma_hip_search_params;
+
+/* ---- lifecycle ------------------------------------------------------------------- */
+/* replaces: new GammaIVFPQIndex / GammaFLATIndex + Init (gamma_index_ivfpq.cc:119-214,
+ * gamma_index_flat.cc:62-76).  One handle = one device. */
+int gamma_hip_create(int device, gamma_hip_index** out);
+int gamma_hip_destroy(gamma_hip_index* h);
+const char* gamma_hip_strerror(int code);
+const char* gamma_hip_last_error(gamma_hip_index* h);
+/* hipStream_t the handle launches on (for event timing / overlap by the caller) */
+void* gamma_hip_stream(gamma_hip_index* h);
+int gamma_hip_synchronize(gamma_hip_index* h);
+
+/* ---- raw vector store (VectorReader::Gets / MemoryRawVector, vector/raw_vector.cc:99-109,
+ *      vector/memory_raw_vector.cc:90-142): device mirror, vid = row ------------------- */
+int gamma_hip_raw_init(gamma_hip_index* h, int d);
+int gamma_hip_raw_append(gamma_hip_index* h, int64_t n, const float* vecs);
+int gamma_hip_raw_update(gamma_hip_index* h, int64_t vid, const float* vec);
+int64_t gamma_hip_raw_count(gamma_hip_index* h);
+
+/* ---- delete bitmap (bitmap::BitmapManager, util/bitmap_manager.cc:171-192): bit = docid,
+ *      byte docid>>3, mask 1<<(docid&7) --------------------------------------------------- */
+int gamma_hip_bitmap_upload(gamma_hip_index* h, const uint8_t* bitmap, int64_t nbits);
+int gamma_hip_bitmap_set(gamma_hip_index* h, const int64_t* docids, int64_t n, int value);
+
+/* ---- IVFPQ model state (faiss::IndexIVFPQ members the scanner reads) --------------- */
+/* replaces GammaIVFPQIndex::Init's parameter checks (gamma_index_ivfpq.cc:119-214);
+ * nbits must be 8, d % M == 0 (OPQ / HNSW quantizer / padding are rejected: EINVAL) */
+int gamma_hip_ivfpq_init(gamma_hip_index* h, int d, int nlist, int M, int nbits, int metric,
+                         int bucket_init_size, int bucket_max_size);
+/* quantizer->xb (nlist*d), pq.centroids (M*ksub*dsub), and the precomputed table
+ * (faiss:IndexIVFPQ.cpp:412-479; NULL => computed on device with identical arithmetic) */
+int gamma_hip_ivfpq_set_trained(gamma_hip_index* h, const float* coarse_centroids,
+                                const float* pq_centroids, const float* precomputed_table);
+int gamma_hip_ivfpq_get_precomputed_table(gamma_hip_index* h, float* out);
+
+/* ---- realtime inverted lists (realtime::RTInvertIndex, realtime/realtime_invert_index.h)
+ *      resident in HBM ----------------------------------------------------------------- */
+/* RTInvertIndex::AddKeys for one bucket (realtime_mem_data.cc:264-303) */
+int gamma_hip_ivfpq_add_keys(gamma_hip_index* h, int list_no, int n, const int64_t* vids,
+                             const uint8_t* codes);
+/* many buckets at once: vids/codes grouped by list, list_nos[i] has counts[i] entries */
+int gamma_hip_ivfpq_add_keys_batch(gamma_hip_index* h, int nlists, const int32_t* list_nos,
+                                   const int32_t* counts, const int64_t* vids,
+                                   const uint8_t* codes);
+/* RTInvertIndex::Update (realtime_mem_data.cc:305-327) */
+int gamma_hip_ivfpq_update(gamma_hip_index* h, int list_no, int64_t vid, const uint8_t* code);
+/* RTInvertIndex::Delete (realtime_mem_data.cc:329-335,190-199): counter only */
+int gamma_hip_ivfpq_delete(gamma_hip_index* h, const int64_t* vids, int n);
+/* RTInvertIndex::CompactIfNeed (realtime_mem_data.cc:354-381,119-150); needs the delete
+ * bitmap the handle mirrors */
+int gamma_hip_ivfpq_compact_if_need(gamma_hip_index* h);
+int64_t gamma_hip_ivfpq_list_size(gamma_hip_index* h, int list_no);
+int64_t gamma_hip_ivfpq_list_capacity(gamma_hip_index* h, int list_no);
+/* RealTimeMemData::RetrieveCodes ("for unit test", realtime_mem_data.h:95-96) */
+int gamma_hip_ivfpq_get_list(gamma_hip_index* h, int list_no, int64_t* vids, uint8_t* codes);
+/* restrict the scan to the lists a shard owns (multi-GPU list sharding): owner[l] != 0 */
+int gamma_hip_ivfpq_set_list_mask(gamma_hip_index* h, const uint8_t* owned);
+
+/* device-side Add path (gamma_index_ivfpq.cc:424-512): assign + residual + PQ encode +
+ * AddKeys for n vectors with consecutive vids starting at first_vid. */
+int gamma_hip_ivfpq_add(gamma_hip_index* h, int64_t n, const float* vecs, int64_t first_vid);
+int gamma_hip_ivfpq_encode(gamma_hip_index* h, int64_t n, const float* vecs, int64_t* list_nos,
+                           uint8_t* codes);
+
+/* ---- search ------------------------------------------------------------------------ */
+/* replaces GammaIVFPQIndex::Search (gamma_index_ivfpq.cc:514-566 + search_preassigned
+ * :701-890).  x: nq*d fp32 host; distances/labels: nq*k host, best first, unused slots
+ * label -1 / distance = heap neutral (FLT_MAX for L2, -FLT_MAX for IP). */
+int gamma_hip_ivfpq_search(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
+                           const float* x, int k, float* distances, int64_t* labels);
+/* same, all pointers in device memory, enqueued on the handle's stream, no sync */
+int gamma_hip_ivfpq_search_device(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
+                                  const float* d_x, int k, float* d_distances, int64_t* d_labels);
+/* stage outputs of the LAST search for parity tests / sharded merge (device->host):
+ * coarse_dis/idx [nq*nprobe], recall_dis/ids [nq*recall_num] (sorted best first, -1 pad) */
+int gamma_hip_ivfpq_last_stages(gamma_hip_index* h, float* coarse_dis, int64_t* coarse_idx,
+                                float* recall_dis, int64_t* recall_ids);
+/* sharded search, stage 1: coarse + owned-list scan + local top-recall_num, results left in
+ * device buffers d_recall_dis/d_recall_ids [nq*recall_num] for the all-gather */
+int gamma_hip_ivfpq_search_shard(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
+                                 const float* d_x, int k, float* d_recall_dis,
+                                 int64_t* d_recall_ids);
+/* sharded search, stage 2: merge nshards*recall_num candidates per query (layout
+ * [shard][nq][recall_num]) into the global top-recall_num, then compute_dis (re-rank or
+ * truncate, gamma_index_ivfpq.cc:642-697) for queries [q0, q0+nq_local) */
+int gamma_hip_ivfpq_merge_rerank(gamma_hip_index* h, const gamma_hip_search_params* p,
+                                 int nshards, int nq, const float* d_x, int k,
+                                 const float* d_all_dis, const int64_t* d_all_ids, int q0,
+                                 int nq_local, float* d_distances, int64_t* d_labels);
+
+/* replaces GammaFLATIndex::Search (gamma_index_flat.cc:118-300) over the raw store */
+int gamma_hip_flat_search(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
+                          const float* x, int k, float* distances, int64_t* labels);
+int gamma_hip_flat_search_device(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
+                                 const float* d_x, int k, float* d_distances, int64_t* d_labels);
+
+/* ---- accounting (GetTotalMemBytes, index/retrieval_model.h:287; PerfTool :23-50) ------ */
+int64_t gamma_hip_total_mem_bytes(gamma_hip_index* h);
+/* per-stage HIP-event timing of the kernels launched by search calls */
+#define GAMMA_HIP_STAGE_COARSE 0
+#define GAMMA_HIP_STAGE_TABLES 1
+#define GAMMA_HIP_STAGE_SCAN 2
+#define GAMMA_HIP_STAGE_SELECT 3
+#define GAMMA_HIP_STAGE_RERANK 4
+#define GAMMA_HIP_STAGE_FLAT 5
+#define GAMMA_HIP_NUM_STAGES 6
+int gamma_hip_profile_enable(gamma_hip_index* h, int on);
+int gamma_hip_profile_reset(gamma_hip_index* h);
+/* total milliseconds and number of timed launches of a stage since the last reset;
+ * scan_bytes = algorithmic list-scan bytes (sum over probed pairs of len*code_size) */
+int gamma_hip_profile_get(gamma_hip_index* h, int stage, double* total_ms, int64_t* launches);
+int gamma_hip_profile_scan_bytes(gamma_hip_index* h, int64_t* bytes, int64_t* pairs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAMMA_HIP_H_ */

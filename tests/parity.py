@@ -1,0 +1,41 @@
+"""Tie-aware comparison of (distances, ids) result tables.
+
+Bar (BASELINE.json north_star): ids/ranks bit-exact, distances within 1e-4.  Our kernels
+reproduce the reference's fp32 operation order, so the tests demand MORE: distances must be
+bit-identical position by position.  Ids must be identical wherever the distance order
+determines them; inside a group of exactly equal distances the reference's order is an
+artefact of its binary-heap mechanics (faiss:utils/Heap.h), so there the id SETS must match,
+and a tie group cut by the k boundary may keep different members."""
+import numpy as np
+
+
+def compare_topk(D_ref, I_ref, D_got, I_got):
+    """Returns dict(n_tie_queries=..., n_boundary=...).  Raises AssertionError on mismatch."""
+    D_ref = np.ascontiguousarray(D_ref, dtype=np.float32)
+    D_got = np.ascontiguousarray(D_got, dtype=np.float32)
+    assert D_ref.shape == D_got.shape and I_ref.shape == I_got.shape
+    a, b = D_ref.view(np.uint32), D_got.view(np.uint32)
+    if not np.array_equal(a, b):
+        bad = np.argwhere(a != b)
+        q, r = bad[0]
+        raise AssertionError("distance bits differ at %d entries, first (q=%d, rank=%d): ref=%r got=%r"
+                             % (len(bad), q, r, D_ref[q, r], D_got[q, r]))
+    n_tie = n_boundary = 0
+    nq, k = D_ref.shape
+    for q in np.argwhere((I_ref != I_got).any(axis=1)).ravel():
+        n_tie += 1
+        d = D_ref[q]
+        start = 0
+        while start < k:
+            end = start + 1
+            while end < k and d[end] == d[start]:
+                end += 1
+            ref_set, got_set = set(I_ref[q, start:end].tolist()), set(I_got[q, start:end].tolist())
+            if ref_set != got_set:
+                if end == k and I_ref[q, k - 1] != -1:
+                    n_boundary += 1  # tie group truncated by k: membership may differ
+                else:
+                    raise AssertionError("ids differ outside ties: q=%d ranks[%d:%d] ref=%s got=%s"
+                                         % (q, start, end, sorted(ref_set), sorted(got_set)))
+            start = end
+    return dict(n_tie_queries=n_tie, n_boundary=n_boundary)
