@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""bench.py -- QPS of the MI355X-native Gamma IVFPQ search path.
+
+Workload (BASELINE.json metric, configs[2] "C3"): IVFPQ nlist=4096 m=16 nbits=8 over 1M x 128
+SIFT1M-shaped synthetic vectors, nprobe=32, recall_num=200 + exact re-rank (the operating point
+that reaches recall@10 >= 0.95 on this data), k=10, L2.  One "step" = one
+Search call over a batch of `--nq` synthetic queries already resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W          (N=1 default)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N>1: the index is sharded by IVF list across the ranks (gamma_amd/dist.py), per-shard top-k
+merged after an RCCL all-gather; the index size is fixed, so scaling is "strong".
+Rank 0 prints ONE JSON line (plus diagnostics on stderr).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--nq", type=int, default=1024, help="queries per Search call (one step)")
+    ap.add_argument("--n", type=int, default=1000000)
+    ap.add_argument("--d", type=int, default=128)
+    ap.add_argument("--nlist", type=int, default=4096)
+    ap.add_argument("--m", type=int, default=16)
+    ap.add_argument("--nprobe", type=int, default=32)
+    ap.add_argument("--recall-num", type=int, default=200)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--no-rank", action="store_true")
+    ap.add_argument("--coarse-mode", type=int, default=-1)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--recall-queries", type=int, default=1000)
+    ap.add_argument("--pmc-traffic", type=float, default=None,
+                    help="HBM bytes per scan launch from a separate rocprofv3 --pmc pass")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from gamma_amd import api, synth, train
+    from gamma_amd import dist as gdist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        log("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (a.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    t0 = time.time()
+    N, d, nlist, M = a.n, a.d, a.nlist, a.m
+    base = synth.sift_like(N, d=d, seed=1234)
+    nbatches = 8
+    queries = synth.sift_like(a.nq * nbatches, d=d, seed=4321)
+    log("[rank %d] data %.1fs" % (rank, time.time() - t0))
+
+    g = api.GammaHip(local_rank)
+    g.ivfpq_init(d, nlist, M, 8, api.METRIC_L2, bucket_init_size=max(1000, int(2.5 * N / nlist)))
+
+    # ---- training + encoding (setup, untimed): rank 0 trains, everyone gets the same state ----
+    t0 = time.time()
+    ntrain = min(N, nlist * 64)
+    if rank == 0:
+        cc, pq = train.train_ivfpq(base[:ntrain], nlist, M, niter=10, pq_niter=25, seed=1234,
+                                   device=str(dev))
+        state = [torch.from_numpy(cc).to(dev), torch.from_numpy(pq).to(dev)]
+    else:
+        state = [torch.empty((nlist, d), dtype=torch.float32, device=dev),
+                 torch.empty((M, 256, d // M), dtype=torch.float32, device=dev)]
+    if world > 1:
+        for t in state:
+            dist.broadcast(t, 0)
+    cc, pq = state[0].cpu().numpy(), state[1].cpu().numpy()
+    g.ivfpq_set_trained(cc, pq, None)  # precomputed table built on device
+    if rank == 0:
+        lno, codes = g.encode(base)     # device assign + residual + PQ encode
+        enc = [torch.from_numpy(lno).to(dev), torch.from_numpy(codes).to(dev)]
+    else:
+        enc = [torch.empty(N, dtype=torch.int64, device=dev),
+               torch.empty((N, M), dtype=torch.uint8, device=dev)]
+    if world > 1:
+        for t in enc:
+            dist.broadcast(t, 0)
+    lno, codes = enc[0].cpu().numpy(), enc[1].cpu().numpy()
+    del enc, state
+    list_sizes = np.bincount(lno, minlength=nlist)
+    owner = gdist.balance_lists(list_sizes, world)
+    mine = owner[lno] == rank
+    vids = np.nonzero(mine)[0].astype(np.int64)
+    order = np.argsort(lno[vids], kind="stable")
+    lists, counts = np.unique(lno[vids], return_counts=True)
+    g.add_keys_batch(lists, counts, vids[order], codes[vids][order])
+    g.raw_init(d)
+    for i0 in range(0, N, 1 << 18):
+        g.raw_append(base[i0:i0 + (1 << 18)])
+    log("[rank %d] train+encode+load %.1fs; lists mean %.1f max %d; device bytes %.0f MB" % (
+        rank, time.time() - t0, list_sizes.mean(), list_sizes.max(), g.total_mem_bytes() / 1e6))
+
+    k, R = a.k, max(a.recall_num, a.k)
+    args = api.SearchArgs(metric=api.METRIC_L2, nprobe=a.nprobe, recall_num=a.recall_num,
+                          has_rank=not a.no_rank, min_score=0.0, max_score=1e30,
+                          coarse_mode=a.coarse_mode)
+    d_q = torch.from_numpy(queries).to(dev)
+    d_D = torch.empty((a.nq, k), dtype=torch.float32, device=dev)
+    d_I = torch.empty((a.nq, k), dtype=torch.int64, device=dev)
+    backend = gdist.HipShardBackend(g, local_rank) if world > 1 else None
+
+    def step(i):
+        xb = d_q[(i % nbatches) * a.nq:(i % nbatches + 1) * a.nq]
+        if world == 1:
+            g.ivfpq_search_device(xb.data_ptr(), a.nq, k, args, d_D.data_ptr(), d_I.data_ptr())
+            return d_D, d_I
+        return gdist.sharded_search(backend, xb, k, args)
+
+    # ---- recall@10 against exact flat search on the GPU (rank 0 data is complete: raw replicated)
+    recall = None
+    nrq = min(a.recall_queries, a.nq)
+    if nrq > 0:
+        Dg, Ig = step(0)
+        torch.cuda.synchronize()
+        Ig = Ig[:nrq].cpu().numpy()
+        fargs = api.SearchArgs(metric=api.METRIC_L2, min_score=0.0, max_score=1e30)
+        Df, If = g.flat_search(queries[:nrq], k, fargs)
+        hits = sum(len(set(Ig[i].tolist()) & set(If[i].tolist())) for i in range(nrq))
+        recall = hits / float(nrq * k)
+        log("[rank %d] recall@%d = %.4f over %d queries" % (rank, k, recall, nrq))
+
+    # ---- timed region ----
+    for i in range(a.warmup):
+        step(i)
+    g.profile_enable(True)
+    g.profile_reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    prof = g.profile()
+    g.profile_enable(False)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    qps = a.nq * a.steps / dt
+    scan_ms, scan_n = prof["scan"]
+    bytes_per_launch = prof["scan_bytes"] / max(1, scan_n)
+    avg_s = (scan_ms / 1e3) / max(1, scan_n)
+    achieved = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
+    peak = 8000.0
+    stages = {n: round(prof[n][0] / max(1, prof[n][1]) * 1e3, 2) for n in
+              ("coarse", "tables", "scan", "select", "rerank") if prof[n][1]}
+    log("stage avg us per launch:", stages, "scan bytes/launch %.0f" % bytes_per_launch)
+
+    cpu = None
+    if world == 1 and a.cpu_seconds > 0:
+        cpu = cpu_baseline(a, base, queries, cc, pq, g, lno, codes, list_sizes)
+
+    out = {
+        "metric": "queries/sec @ recall@10>=0.95, IVFPQ nlist=4096 nprobe=32",
+        "value": round(qps, 1),
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": round(dt / a.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "C3: IVFPQ nlist=%d m=%d nbits=8, %dx%d SIFT1M-shaped synthetic, nprobe=%d, "
+                        "recall_num=%d, has_rank=%s, k=%d, L2, batch=%d queries/step" % (
+                            nlist, M, N, d, a.nprobe, a.recall_num, str(not a.no_rank).lower(), k, a.nq),
+            "recall_at_10": None if recall is None else round(recall, 4),
+            "parallelism": "list-shard x%d + RCCL all-gather" % world if world > 1 else "single GPU",
+            "stage_us": stages,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "k_ivfpq_scan_pair",
+            "achieved": round(achieved, 1),
+            "peak": peak,
+            "unit": "GB/s",
+            "frac": round(achieved / peak, 4),
+            "traffic": a.pmc_traffic,
+            "algorithmic_bytes_per_launch": round(bytes_per_launch),
+            "avg_launch_us": round(avg_s * 1e6, 2),
+        },
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a, base, queries, cc, pq, g, lno, codes, list_sizes):
+    """The oracle (CPU restatement of the reference's faiss-CPU path, kind "port") timed on the
+    host cores of this box on a bounded sample of the same workload."""
+    from oracle import binding as B
+    t0 = time.time()
+    o = B.OracleIVFPQ(a.d, a.nlist, a.m, 8, B.METRIC_L2,
+                      bucket_init_size=max(1000, int(list_sizes.max()) + 1))
+    o.set_trained(cc, pq, g.ivfpq_table())
+    order = np.argsort(lno, kind="stable")
+    starts = np.concatenate([[0], np.cumsum(list_sizes)])
+    for l in range(a.nlist):
+        if list_sizes[l]:
+            sl = order[starts[l]:starts[l + 1]]
+            o.add_keys(l, sl.astype(np.int64), codes[sl])
+    o.set_raw(base)
+    ctx = B.make_ctx(min_score=0.0, max_score=1e30)
+    cores = B.lib().go_num_threads()
+    log("cpu baseline: oracle index built in %.1fs, %d threads" % (time.time() - t0, cores))
+    nb = queries.shape[0] // a.nq
+    o.search(queries[:a.nq], a.k, a.nprobe, recall_num=a.recall_num, has_rank=not a.no_rank,
+             metric=B.METRIC_L2, ctx=ctx, coarse_mode=0)  # warm-up
+    done, t0 = 0, time.perf_counter()
+    i = 0
+    while True:
+        xb = queries[(i % nb) * a.nq:(i % nb + 1) * a.nq]
+        o.search(xb, a.k, a.nprobe, recall_num=a.recall_num, has_rank=not a.no_rank,
+                 metric=B.METRIC_L2, ctx=ctx, coarse_mode=0)
+        done += a.nq
+        i += 1
+        el = time.perf_counter() - t0
+        if el >= a.cpu_seconds:
+            break
+    return {
+        "value": round(done / el, 1),
+        "unit": "queries/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d Search calls of %d queries (same index, same parameters, OpenMP over queries, "
+                  "exact sequential coarse path) in %.1fs" % (i, a.nq, el),
+    }
+
+
+if __name__ == "__main__":
+    main()
