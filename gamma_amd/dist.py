@@ -80,10 +80,13 @@ def sharded_search(backend, x, k, args, group=None, gather_results=True):
     stream_ctx = torch.cuda.stream(backend.stream) if hasattr(backend, "stream") else _Null()
     with stream_ctx:
         rdis, rids = backend.search_shard(x, k, args)
-        all_dis = backend.empty((world,) + tuple(rdis.shape), rdis.dtype)
-        all_ids = backend.empty((world,) + tuple(rids.shape), rids.dtype)
+        # concatenation along dim 0 == [shard][nq][R] row-major (the layout merge_rerank reads)
+        all_dis = backend.empty((world * nq, rdis.shape[1]), rdis.dtype)
+        all_ids = backend.empty((world * nq, rids.shape[1]), rids.dtype)
         dist.all_gather_into_tensor(all_dis, rdis, group=group)
         dist.all_gather_into_tensor(all_ids, rids, group=group)
+        all_dis = all_dis.view(world, nq, -1)
+        all_ids = all_ids.view(world, nq, -1)
         q0, q1, per = query_slice(nq, rank, world)
         D, I = backend.merge_rerank(all_dis, all_ids, x, k, args, q0, q1 - q0, per)
         if not gather_results:

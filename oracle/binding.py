@@ -89,6 +89,8 @@ def lib():
         L.go_ivfpq_set_trained.argtypes = [C.c_void_p, _f32p, _f32p, _f32p]
         L.go_ivfpq_table.restype = _f32p
         L.go_ivfpq_table.argtypes = [C.c_void_p]
+        L.go_ivfpq_set_docids_bitmap.restype = None
+        L.go_ivfpq_set_docids_bitmap.argtypes = [C.c_void_p, _u8p, C.c_int64]
         L.go_ivfpq_set_raw.restype = None
         L.go_ivfpq_set_raw.argtypes = [C.c_void_p, _f32p, C.c_int64]
         L.go_ivfpq_add.restype = C.c_int
@@ -99,6 +101,8 @@ def lib():
         L.go_ivfpq_add_keys.argtypes = [C.c_void_p, C.c_int, C.c_int, _i64p, _u8p]
         L.go_ivfpq_update.restype = C.c_int
         L.go_ivfpq_update.argtypes = [C.c_void_p, C.c_int64, _f32p]
+        L.go_ivfpq_update_code.restype = C.c_int
+        L.go_ivfpq_update_code.argtypes = [C.c_void_p, C.c_int, C.c_int64, _u8p]
         L.go_ivfpq_delete.restype = C.c_int
         L.go_ivfpq_delete.argtypes = [C.c_void_p, _i64p, C.c_int, _u8p]
         L.go_ivfpq_compact_if_need.restype = C.c_int
@@ -208,6 +212,11 @@ class OracleIVFPQ:
         n = self.nlist * self.M * self.ksub
         p = self.L.go_ivfpq_table(self.h)
         return np.ctypeslib.as_array(p, shape=(n,)).reshape(self.nlist, self.M, self.ksub).copy()
+
+    def set_docids_bitmap(self, bm):
+        """bm: np.uint8 array kept alive by the caller's reference here (may be mutated later)."""
+        self._bm = bm
+        self.L.go_ivfpq_set_docids_bitmap(self.h, _up(bm), bm.size * 8)
 
     def set_raw(self, raw):
         self._raw = _f32(raw)

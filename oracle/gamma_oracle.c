@@ -485,6 +485,8 @@ struct go_ivfpq {
     const float* raw;
     int64_t nraw;
     int64_t indexed_vec_count;
+    const uint8_t* docids_bitmap; /* borrowed; RTInvertBucketData::docids_bitmap_ */
+    int64_t docids_bits;
 };
 
 go_ivfpq* go_ivfpq_new(int d, int nlist, int M, int nbits, int metric, int bucket_init_size,
@@ -550,6 +552,11 @@ void go_ivfpq_set_trained(go_ivfpq* ix, const float* cc, const float* pqc, const
 
 const float* go_ivfpq_table(go_ivfpq* ix) { return ix->table; }
 
+void go_ivfpq_set_docids_bitmap(go_ivfpq* ix, const uint8_t* bm, int64_t nbits) {
+    ix->docids_bitmap = bm;
+    ix->docids_bits = nbits;
+}
+
 void go_ivfpq_set_raw(go_ivfpq* ix, const float* raw, int64_t n) {
     ix->raw = raw;
     ix->nraw = n;
@@ -611,6 +618,10 @@ int go_ivfpq_add_keys(go_ivfpq* ix, int list_no, int n, const int64_t* keys, con
         while (keys[i] >= ix->nids) ids_extend(ix);
         ix->vid_pos[keys[i]] = ((int64_t)list_no << 32) | pos;
         pos++;
+        /* :293-296: a key whose doc is already deleted counts as deleted at once */
+        if (ix->docids_bitmap && keys[i] >= 0 && keys[i] < ix->docids_bits &&
+            bm_test(ix->docids_bitmap, keys[i]))
+            b->deleted++;
     }
     b->size = pos; /* publish after the copies */
     return 1;
@@ -691,22 +702,26 @@ int go_ivfpq_add(go_ivfpq* ix, int64_t n, const float* x) {
 
 /* GammaIVFPQIndex::Update -> RealTimeMemData::Update (gamma_index_ivfpq.cc:375-422,
  * realtime_mem_data.cc:305-327) */
+/* RealTimeMemData::Update(bucket_no, vid, codes), realtime_mem_data.cc:305-327 */
+int go_ivfpq_update_code(go_ivfpq* ix, int list_no, int64_t vid, const uint8_t* code) {
+    if (vid < 0 || vid >= ix->nids) return 0;
+    int64_t bp = ix->vid_pos[vid];
+    if (bp == -1) return 0;
+    int old_b = (int)(bp >> 32), old_pos = (int)(bp & 0xffffffff);
+    if (old_b == list_no) {
+        memcpy(ix->b[old_b].codes + (size_t)old_pos * ix->code_size, code, ix->code_size);
+        return 0;
+    }
+    ix->b[old_b].ids[old_pos] |= GO_DEL_MASK;
+    ix->b[old_b].deleted++;
+    return go_ivfpq_add_keys(ix, list_no, 1, &vid, code);
+}
+
 int go_ivfpq_update(go_ivfpq* ix, int64_t vid, const float* x) {
     int64_t lno;
     uint8_t* code = (uint8_t*)malloc(ix->code_size);
     encode_impl(ix, 0, 1, x, &lno, code);
-    int ret = 0;
-    if (vid < ix->nids && ix->vid_pos[vid] != -1) {
-        int64_t bp = ix->vid_pos[vid];
-        int old_b = (int)(bp >> 32), old_pos = (int)(bp & 0xffffffff);
-        if (old_b == (int)lno) {
-            memcpy(ix->b[old_b].codes + (size_t)old_pos * ix->code_size, code, ix->code_size);
-        } else {
-            ix->b[old_b].ids[old_pos] |= GO_DEL_MASK;
-            ix->b[old_b].deleted++;
-            ret = go_ivfpq_add_keys(ix, (int)lno, 1, &vid, code);
-        }
-    }
+    int ret = go_ivfpq_update_code(ix, (int)lno, vid, code);
     free(code);
     return ret;
 }
@@ -725,6 +740,7 @@ int go_ivfpq_delete(go_ivfpq* ix, const int64_t* vids, int n, const uint8_t* doc
 
 /* CompactIfNeed / CompactBucket, :354-381,119-150 */
 int go_ivfpq_compact_if_need(go_ivfpq* ix, const uint8_t* docids_bitmap) {
+    if (!docids_bitmap) docids_bitmap = ix->docids_bitmap;
     for (int l = 0; l < ix->nlist; l++) {
         go_bucket* b = &ix->b[l];
         if (!((float)b->deleted / b->size >= 0.3f)) continue;

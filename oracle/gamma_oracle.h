@@ -107,6 +107,8 @@ void go_ivfpq_free(go_ivfpq* ix);
 void go_ivfpq_set_trained(go_ivfpq* ix, const float* coarse_centroids, const float* pq_centroids,
                           const float* table);
 const float* go_ivfpq_table(go_ivfpq* ix);
+/* delete bitmap the list writer consults (AddKeys, CompactBucket); borrowed pointer */
+void go_ivfpq_set_docids_bitmap(go_ivfpq* ix, const uint8_t* bm, int64_t nbits);
 /* raw vector store for re-rank (VectorReader::Gets): pointer is borrowed */
 void go_ivfpq_set_raw(go_ivfpq* ix, const float* raw, int64_t n);
 /* Add path (gamma_index_ivfpq.cc:424-512): assign + residual + encode + AddKeys; vids are
@@ -119,6 +121,7 @@ void go_ivfpq_encode(go_ivfpq* ix, int64_t n, const float* x, int64_t* list_nos,
 /* realtime list writer side */
 int go_ivfpq_add_keys(go_ivfpq* ix, int list_no, int n, const int64_t* keys, const uint8_t* codes);
 int go_ivfpq_update(go_ivfpq* ix, int64_t vid, const float* x);
+int go_ivfpq_update_code(go_ivfpq* ix, int list_no, int64_t vid, const uint8_t* code);
 int go_ivfpq_delete(go_ivfpq* ix, const int64_t* vids, int n, const uint8_t* docids_bitmap);
 int go_ivfpq_compact_if_need(go_ivfpq* ix, const uint8_t* docids_bitmap);
 int64_t go_ivfpq_list_size(go_ivfpq* ix, int list_no);

@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the REAL reference arithmetic: faiss 1.7.1 built from the
+reference's vendored tarball and the reference's own realtime/ sources (oracle/_ref, built by
+oracle/Makefile.ref -- only possible in the container that has /root/reference).
+
+The fixtures are data only (inputs + expected outputs); the oracle, and on the GPU box the HIP
+path, are checked against them.  Re-run:  python tests/gen_golden.py
+Determinism: faiss::distance_compute_blas_threshold is raised so the coarse quantizer takes the
+exact per-pair path (no BLAS summation order), OMP threads do not affect results.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("MKL_THREADING_LAYER", "GNU")
+
+from gamma_amd import synth  # noqa: E402
+from oracle import binding as B  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def gen_prims(R):
+    rng = np.random.default_rng(7)
+    out = {}
+    dims = [1, 2, 3, 4, 5, 7, 8, 12, 15, 16, 17, 31, 32, 33, 64, 100, 128, 129, 768]
+    out["dims"] = np.array(dims)
+    for d in dims:
+        x = (rng.standard_normal((6, d)) * rng.uniform(0.1, 100, size=(6, 1))).astype(np.float32)
+        y = (rng.standard_normal((6, d)) * 3).astype(np.float32)
+        res = np.zeros((6, 3), dtype=np.float32)
+        for i in range(6):
+            res[i, 0] = R.ref_fvec_L2sqr(B._fp(x[i]), B._fp(y[i]), d)
+            res[i, 1] = R.ref_fvec_inner_product(B._fp(x[i]), B._fp(y[i]), d)
+            res[i, 2] = R.ref_fvec_norm_L2sqr(B._fp(x[i]), d)
+        out["x_%d" % d], out["y_%d" % d], out["res_%d" % d] = x, y, res
+    nyd = [1, 2, 4, 8, 12, 3, 6, 16]
+    out["ny_dims"] = np.array(nyd)
+    for d in nyd:
+        ny = 256
+        x = rng.standard_normal(d).astype(np.float32)
+        y = rng.standard_normal((ny, d)).astype(np.float32)
+        ip = np.empty(ny, np.float32)
+        l2 = np.empty(ny, np.float32)
+        R.ref_fvec_inner_products_ny(B._fp(ip), B._fp(x), B._fp(y), d, ny)
+        R.ref_fvec_L2sqr_ny(B._fp(l2), B._fp(x), B._fp(y), d, ny)
+        out["nyx_%d" % d], out["nyy_%d" % d], out["nyip_%d" % d], out["nyl2_%d" % d] = x, y, ip, l2
+    a = rng.standard_normal(512).astype(np.float32)
+    b = rng.standard_normal(512).astype(np.float32)
+    c = np.empty(512, np.float32)
+    R.ref_fvec_madd(512, B._fp(a), -2.0, B._fp(b), B._fp(c))
+    out["madd_a"], out["madd_b"], out["madd_c"] = a, b, c
+    np.savez_compressed(os.path.join(OUT, "prims.npz"), **out)
+
+
+def gen_heap(R):
+    rng = np.random.default_rng(11)
+    out = {}
+    cases = []
+    for ks in (0, 1):
+        for k in (1, 3, 10, 100):
+            for n in (0, 5, 300):
+                cases.append((ks, k, n))
+    out["cases"] = np.array(cases)
+    for ci, (ks, k, n) in enumerate(cases):
+        vals = rng.integers(0, 25, size=n).astype(np.float32)  # many exact ties
+        ids = np.arange(n, dtype=np.int64)
+        hv, hi = np.empty(k, np.float32), np.empty(k, np.int64)
+        sv, si = np.empty(k, np.float32), np.empty(k, np.int64)
+        pv, pi = np.empty(k, np.float32), np.empty(k, np.int64)
+        R.ref_heap_stream(ks, k, n, B._fp(vals), B._ip(ids), B._fp(hv), B._ip(hi), B._fp(sv), B._ip(si))
+        R.ref_heap_pop_push_stream(ks, k, n, B._fp(vals), B._ip(ids), B._fp(pv), B._ip(pi))
+        out["vals_%d" % ci] = vals
+        for nm, arr in (("hv", hv), ("hi", hi), ("sv", sv), ("si", si), ("pv", pv), ("pi", pi)):
+            out["%s_%d" % (nm, ci)] = arr
+    np.savez_compressed(os.path.join(OUT, "heap.npz"), **out)
+
+
+def gen_ivfpq(R, name, d, nlist, M, N, nq, metric, nprobe, Rk, normalize=False):
+    base = synth.sift_like(N, d=d, seed=1234)
+    q = synth.sift_like(nq, d=d, seed=4321)
+    if normalize:
+        base = (base / np.linalg.norm(base, axis=1, keepdims=True)).astype(np.float32)
+        q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    r = B.RefIVFPQ(d, nlist, M, 8, metric)
+    r.train(base[:min(N, nlist * 64)])
+    r.add(base)
+    assert r.use_precomputed_table() == 1
+    out = dict(d=d, nlist=nlist, M=M, N=N, nq=nq, metric=metric, nprobe=nprobe, R=Rk,
+               normalize=int(normalize), q=q,
+               cc=r.coarse_centroids(), pq=r.pq_centroids(), table=r.precomputed_table())
+    # base is regenerated from the portable generator (not stored): only its checksum
+    out["base_sum"] = np.array([base.astype(np.float64).sum()])
+    sizes, ids, codes = [], [], []
+    for l in range(nlist):
+        i, c = r.get_list(l)
+        sizes.append(len(i))
+        ids.append(i)
+        codes.append(c)
+    out["list_sizes"] = np.array(sizes, dtype=np.int64)
+    out["list_ids"] = np.concatenate(ids)
+    out["list_codes"] = np.concatenate(codes)
+    lno, cds = r.encode(base[:500])
+    out["enc_lno"], out["enc_codes"] = lno, cds
+    cd, ci = r.coarse(q, nprobe)
+    out["coarse_dis"], out["coarse_idx"] = cd, ci
+    for m, tag in ((B.METRIC_L2, "l2"), (B.METRIC_IP, "ip")):
+        r.set_metric(m)
+        D, I = r.search(q, Rk, nprobe)
+        out["rdis_" + tag], out["rids_" + tag] = D, I
+    r.set_metric(metric)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+
+
+def gen_realtime():
+    """Drive the reference's real RTInvertIndex through a scripted sequence of AddKeys /
+    Update / Delete / CompactIfNeed and record the observable state after each phase."""
+    import ctypes as C
+    RT = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libgamma_rt_ref.so"))
+    RT.ref_rt_new.restype = C.c_void_p
+    RT.ref_rt_new.argtypes = [C.c_int] * 5
+    RT.ref_rt_add_keys.argtypes = [C.c_void_p, C.c_int, C.c_int, B._i64p, B._u8p]
+    RT.ref_rt_update.argtypes = [C.c_void_p, C.c_int, C.c_int, B._u8p]
+    RT.ref_rt_delete.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
+    RT.ref_rt_bitmap_set.argtypes = [C.c_void_p, C.c_int]
+    RT.ref_rt_compact_if_need.argtypes = [C.c_void_p]
+    RT.ref_rt_list_size.restype = C.c_int64
+    RT.ref_rt_list_size.argtypes = [C.c_void_p, C.c_int]
+    RT.ref_rt_list_capacity.restype = C.c_int64
+    RT.ref_rt_list_capacity.argtypes = [C.c_void_p, C.c_int]
+    RT.ref_rt_get_list.argtypes = [C.c_void_p, C.c_int, B._i64p, B._u8p]
+    RT.ref_rt_vid_pos.restype = C.c_int64
+    RT.ref_rt_vid_pos.argtypes = [C.c_void_p, C.c_int64]
+    nlist, cs, binit, bmax, nbits = 8, 4, 16, 4096, 8192
+    h = RT.ref_rt_new(nlist, cs, binit, bmax, nbits)
+    rng = np.random.default_rng(5)
+    ops = []      # (op, a, b, payload) script the test replays
+    snaps = []
+    next_vid = 0
+    live = []
+
+    def snapshot():
+        st = {}
+        for l in range(nlist):
+            n = RT.ref_rt_list_size(h, l)
+            ids = np.empty(n, np.int64)
+            codes = np.empty((n, cs), np.uint8)
+            if n:
+                RT.ref_rt_get_list(h, l, B._ip(ids), B._up(codes))
+            st[l] = (ids, codes, RT.ref_rt_list_capacity(h, l))
+        vp = np.array([RT.ref_rt_vid_pos(h, v) for v in range(next_vid)], dtype=np.int64)
+        return st, vp
+
+    script = []
+    for phase in range(6):
+        # adds of varying size (forces several extensions)
+        for _ in range(12):
+            l = int(rng.integers(0, nlist))
+            n = int(rng.integers(1, 40))
+            keys = np.arange(next_vid, next_vid + n, dtype=np.int64)
+            codes = rng.integers(0, 256, size=(n, cs)).astype(np.uint8)
+            ok = RT.ref_rt_add_keys(h, l, n, B._ip(keys), B._up(codes))
+            script.append(("add", l, n, codes.copy(), ok))
+            if ok:
+                next_vid += n
+                live.extend(keys.tolist())
+        # updates: some stay in list, some move
+        for _ in range(10):
+            vid = int(rng.choice(live))
+            l = int(rng.integers(0, nlist))
+            code = rng.integers(0, 256, size=cs).astype(np.uint8)
+            RT.ref_rt_update(h, l, vid, B._up(code))
+            script.append(("update", l, vid, code.copy(), 1))
+        # deletes: set bitmap bit then Delete (search/gamma_engine.cc:810-812 order)
+        dels = rng.choice(live, size=min(len(live), 25), replace=False).astype(np.int32)
+        for v in dels:
+            RT.ref_rt_bitmap_set(h, int(v))
+        arr = (C.c_int * len(dels))(*[int(v) for v in dels])
+        RT.ref_rt_delete(h, arr, len(dels))
+        script.append(("delete", 0, 0, dels.astype(np.int64), 1))
+        RT.ref_rt_compact_if_need(h)
+        script.append(("compact", 0, 0, np.zeros(0, np.uint8), 1))
+        snaps.append(snapshot())
+    out = dict(nlist=nlist, cs=cs, binit=binit, bmax=bmax, nbits=nbits, nops=len(script),
+               nsnaps=len(snaps))
+    for i, (op, a, b, payload, ok) in enumerate(script):
+        out["op_%d" % i] = np.array([{"add": 0, "update": 1, "delete": 2, "compact": 3}[op], a, b, ok])
+        out["pl_%d" % i] = payload
+    snap_after = [i for i, s in enumerate(script) if s[0] == "compact"]
+    out["snap_after"] = np.array(snap_after)
+    for si, (st, vp) in enumerate(snaps):
+        out["vp_%d" % si] = vp
+        for l in range(nlist):
+            out["ids_%d_%d" % (si, l)] = st[l][0]
+            out["codes_%d_%d" % (si, l)] = st[l][1]
+        out["caps_%d" % si] = np.array([st[l][2] for l in range(nlist)], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "realtime.npz"), **out)
+
+
+def main():
+    if not B.have_ref():
+        raise SystemExit("oracle/_ref/libgamma_ref.so missing: run make -f oracle/Makefile.ref")
+    os.makedirs(OUT, exist_ok=True)
+    R = B.ref()
+    R.ref_set_blas_threshold(1 << 30)
+    gen_prims(R)
+    gen_heap(R)
+    gen_ivfpq(R, "ivfpq_l2_d32", 32, 32, 8, 6000, 40, B.METRIC_L2, 6, 64)        # dsub 4
+    gen_ivfpq(R, "ivfpq_l2_d64", 64, 32, 8, 6000, 40, B.METRIC_L2, 8, 100)       # dsub 8
+    gen_ivfpq(R, "ivfpq_ip_d48", 48, 16, 4, 4000, 30, B.METRIC_IP, 4, 50, True)  # dsub 12
+    gen_realtime()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
