@@ -39,3 +39,21 @@ def compare_topk(D_ref, I_ref, D_got, I_got):
                                          % (q, start, end, sorted(ref_set), sorted(got_set)))
             start = end
     return dict(n_tie_queries=n_tie, n_boundary=n_boundary)
+
+
+def compare_search(D, I, st, Dg, Ig, sg):
+    """Final (D, I) vs (Dg, Ig) given the recall-stage tables st / sg (dicts with recall_dis,
+    recall_ids).  The recall stage must agree (bit-identical distances, ids up to ties).  A query
+    whose recall-stage id SET differs -- possible only when equal ADC distances straddle the
+    recall_num boundary, where the reference keeps whichever tied entries its heap happens to hold
+    -- is excluded from the final comparison (its re-rank input legitimately differs).
+    Returns the number of such queries."""
+    rd_o, rd_g = st["recall_dis"].copy(), sg["recall_dis"].copy()
+    rd_o[st["recall_ids"] == -1] = 0      # oracle pads with FLT_MAX, device with +-inf
+    rd_g[sg["recall_ids"] == -1] = 0
+    compare_topk(rd_o, st["recall_ids"], rd_g, sg["recall_ids"])
+    same = np.array([set(a.tolist()) == set(b.tolist())
+                     for a, b in zip(st["recall_ids"], sg["recall_ids"])])
+    if same.any():
+        compare_topk(D[same], I[same], Dg[same], Ig[same])
+    return int((~same).sum())

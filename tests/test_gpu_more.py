@@ -1,0 +1,361 @@
+"""GPU parity tests, part 2: filters, flat, edge cases, golden vectors from real faiss, device
+realtime lists, device encode, and full-size (1M) properties.  Everything goes through the
+C ABI (gamma_amd.api -> libgamma_hip.so)."""
+import os
+
+import numpy as np
+import pytest
+
+from gamma_amd import api, synth
+from oracle import binding as B
+from tests import fixtures
+from tests.parity import compare_search, compare_topk
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+WIDE = dict(min_score=-3e38, max_score=3e38)
+
+
+def run_both(case, g, q, k, nprobe, R, metric, has_rank, coarse_mode=0, ctx_kw=None, range_docs=None,
+             del_bitmap=None, b_not_in=False):
+    ctx_kw = ctx_kw or WIDE
+    rf_o = rf_g = None
+    if range_docs is not None:
+        rf_o = [B.make_range_filter(r, b_not_in=b_not_in) for r in range_docs]
+        rf_g = [api.make_range_filter(r, b_not_in=b_not_in) for r in range_docs]
+    ctx = B.make_ctx(docids_bitmap=del_bitmap, range_filters=rf_o, **ctx_kw)
+    D, I, st = case["oracle"].search(q, k, nprobe, recall_num=R, has_rank=has_rank, metric=metric,
+                                     ctx=ctx, coarse_mode=coarse_mode, want_stages=True)
+    args = api.SearchArgs(metric=metric, nprobe=nprobe, recall_num=R, has_rank=has_rank,
+                          coarse_mode=coarse_mode, range_filters=rf_g, **ctx_kw)
+    Dg, Ig = g.ivfpq_search(q, k, args)
+    return (D, I, st), (Dg, Ig)
+
+
+# --------------------------------------------------------------------------- filters / windows
+@pytest.fixture(scope="module")
+def case():
+    return fixtures.trained_case(d=32, nlist=64, M=8, N=20000, nq=64, metric=B.METRIC_L2)
+
+
+@pytest.fixture(scope="module")
+def hip(case):
+    g = fixtures.load_hip(case)
+    yield g
+    g.close()
+
+
+@pytest.mark.parametrize("has_rank", [True, False])
+def test_delete_bitmap_and_range_filters(case, hip, has_rank):
+    rng = np.random.default_rng(1)
+    N = case["N"]
+    deleted = rng.choice(N, size=N // 5, replace=False)
+    bm = np.zeros((N >> 3) + 1, dtype=np.uint8)
+    np.bitwise_or.at(bm, deleted >> 3, (1 << (deleted & 7)).astype(np.uint8))
+    hip.bitmap_upload(bm, N)
+    try:
+        r1 = rng.choice(N, size=N // 2, replace=False)           # ~50 % selectivity
+        r2 = np.arange(1000, 15000)                               # a contiguous docid range
+        for ranges, not_in in (([r1], False), ([r1, r2], False), ([r2], True), ([], False)):
+            (D, I, _), (Dg, Ig) = run_both(case, hip, case["q"], 10, 8, 100, B.METRIC_L2, has_rank,
+                                           range_docs=ranges, del_bitmap=bm, b_not_in=not_in)
+            compare_topk(D, I, Dg, Ig)
+            live = Ig[Ig >= 0]
+            assert not np.isin(live, deleted).any()
+            if ranges == []:
+                assert (Ig == -1).all()   # MultiRangeQueryResults::Has on an empty set is false
+    finally:
+        hip.bitmap_upload(np.zeros(1, dtype=np.uint8), 0)
+
+
+@pytest.mark.parametrize("metric", [B.METRIC_L2, B.METRIC_IP])
+def test_score_window(case, hip, metric):
+    # default GammaSearchCondition window: min = FLT_MIN (tiny), max = FLT_MAX
+    (D, I, _), (Dg, Ig) = run_both(case, hip, case["q"], 10, 8, 100, metric, True,
+                                   ctx_kw=dict(min_score=None, max_score=None))
+    compare_topk(D, I, Dg, Ig)
+    lo, hi = (20000.0, 60000.0) if metric == B.METRIC_L2 else (1e5, 4e5)
+    for has_rank in (True, False):
+        (D, I, _), (Dg, Ig) = run_both(case, hip, case["q"], 10, 8, 100, metric, has_rank,
+                                       ctx_kw=dict(min_score=lo, max_score=hi))
+        compare_topk(D, I, Dg, Ig)
+        ok = Ig >= 0
+        assert (Dg[ok] >= lo).all() and (Dg[ok] <= hi).all()
+
+
+def test_edge_shapes(case, hip):
+    q = case["q"]
+    # nq = 1 (exact coarse rule), k = 1, recall_num < k is raised to k, nprobe = nlist
+    for nq, k, nprobe, R in ((1, 1, 1, 1), (1, 10, 64, 5), (3, 200, 2, 50), (64, 10, 64, 300)):
+        (D, I, _), (Dg, Ig) = run_both(case, hip, q[:nq], k, nprobe, R, B.METRIC_L2, True, coarse_mode=-1)
+        compare_topk(D, I, Dg, Ig)
+    # k <= 0 leaves the outputs alone and succeeds (gamma_index_ivfpq.cc:753-756)
+    args = api.SearchArgs(metric=api.METRIC_L2, nprobe=4)
+    Dg, Ig = hip.ivfpq_search(q[:2], 0, args)
+    assert Dg.shape == (2, 0)
+    # bad nprobe is rejected loudly
+    with pytest.raises(api.GammaHipError):
+        hip.ivfpq_search(q[:2], 5, api.SearchArgs(metric=api.METRIC_L2, nprobe=65))
+
+
+def test_not_trained_and_missing_raw_fail_loudly():
+    g = api.GammaHip(0)
+    try:
+        g.ivfpq_init(16, 8, 4)
+        with pytest.raises(api.GammaHipError):
+            g.ivfpq_search(np.zeros((1, 16), np.float32), 3, api.SearchArgs(nprobe=2))
+        with pytest.raises(api.GammaHipError):
+            g.flat_search(np.zeros((1, 16), np.float32), 3, api.SearchArgs())
+        with pytest.raises(api.GammaHipError):
+            g2 = api.GammaHip(0)
+            g2.ivfpq_init(16, 8, 4, nbits=4)     # only nbits == 8 on device
+    finally:
+        g.close()
+
+
+# --------------------------------------------------------------------------- other shapes
+@pytest.mark.parametrize("cfg", [
+    dict(d=128, nlist=32, M=16, N=12000),          # dsub 8, 16-byte codes (uint4 path)
+    dict(d=128, nlist=32, M=32, N=12000),          # dsub 4, 32-byte codes
+    dict(d=96, nlist=16, M=8, N=8000),             # dsub 12
+    dict(d=20, nlist=16, M=4, N=6000),             # dsub 5 (generic), d % 8 != 0
+    dict(d=64, nlist=16, M=4, N=6000),             # dsub 16 (generic AVX order)
+    dict(d=24, nlist=300, M=12, N=2000),           # dsub 2, many empty lists
+])
+@pytest.mark.parametrize("metric", [B.METRIC_L2, B.METRIC_IP])
+def test_other_shapes(cfg, metric):
+    case = fixtures.trained_case(nq=24, metric=B.METRIC_L2, **cfg)
+    g = fixtures.load_hip(case)
+    try:
+        assert g.ivfpq_table().tobytes() == case["oracle"].table().tobytes()
+        for has_rank in (True, False):
+            for cm in (0, 1):
+                (D, I, st), (Dg, Ig) = run_both(case, g, case["q"], 7, min(6, cfg["nlist"]), 40, metric,
+                                                has_rank, coarse_mode=cm)
+                sg = g.last_stages(len(case["q"]), min(6, cfg["nlist"]), 40)
+                assert sg["coarse_dis"].tobytes() == st["coarse_dis"].tobytes()
+                compare_search(D, I, st, Dg, Ig, sg)
+    finally:
+        g.close()
+
+
+# --------------------------------------------------------------------------- flat
+@pytest.mark.parametrize("metric", [B.METRIC_L2, B.METRIC_IP])
+@pytest.mark.parametrize("d", [128, 32, 20])
+def test_flat_parity(metric, d):
+    N, nq, k = 70000, 16, 100            # > one 65536-row chunk: exercises the chunk merge
+    base = synth.sift_like(N, d=d, seed=21)
+    q = synth.sift_like(nq, d=d, seed=22)
+    rng = np.random.default_rng(2)
+    deleted = rng.choice(N, size=N // 10, replace=False)
+    bm = np.zeros((N >> 3) + 1, dtype=np.uint8)
+    np.bitwise_or.at(bm, deleted >> 3, (1 << (deleted & 7)).astype(np.uint8))
+    g = api.GammaHip(0)
+    try:
+        g.raw_init(d)
+        g.raw_append(base[:30000])
+        g.raw_append(base[30000:])
+        g.bitmap_upload(bm, N)
+        keep = rng.choice(N, size=N // 3, replace=False)
+        for ranges in (None, [keep]):
+            rf_o = [B.make_range_filter(r) for r in ranges] if ranges else None
+            rf_g = [api.make_range_filter(r) for r in ranges] if ranges else None
+            ctx = B.make_ctx(docids_bitmap=bm, range_filters=rf_o, **WIDE)
+            D, I = B.flat_search(base, q, k, metric, ctx)
+            Dg, Ig = g.flat_search(q, k, api.SearchArgs(metric=metric, range_filters=rf_g, **WIDE))
+            compare_topk(D, I, Dg, Ig)
+    finally:
+        g.close()
+
+
+def test_flat_small_and_empty():
+    g = api.GammaHip(0)
+    try:
+        g.raw_init(16)
+        q = synth.sift_like(3, d=16, seed=1)
+        Dg, Ig = g.flat_search(q, 5, api.SearchArgs(metric=api.METRIC_L2, **WIDE))
+        assert (Ig == -1).all() and (Dg == np.finfo(np.float32).max).all()
+        base = synth.sift_like(3, d=16, seed=2)
+        g.raw_append(base)
+        D, I = B.flat_search(base, q, 5, B.METRIC_L2, B.make_ctx(**WIDE))
+        Dg, Ig = g.flat_search(q, 5, api.SearchArgs(metric=api.METRIC_L2, **WIDE))
+        compare_topk(D, I, Dg, Ig)      # k > N: -1 / FLT_MAX padding
+    finally:
+        g.close()
+
+
+# --------------------------------------------------------------------------- golden (real faiss)
+@pytest.mark.parametrize("name", ["ivfpq_l2_d32", "ivfpq_l2_d64", "ivfpq_ip_d48"])
+def test_golden_vectors_from_real_faiss(name):
+    z = np.load(os.path.join(G, name + ".npz"))
+    d, nlist, M, N = int(z["d"]), int(z["nlist"]), int(z["M"]), int(z["N"])
+    nprobe, R = int(z["nprobe"]), int(z["R"])
+    g = api.GammaHip(0)
+    try:
+        g.ivfpq_init(d, nlist, M, 8, int(z["metric"]))
+        g.ivfpq_set_trained(z["cc"], z["pq"], None)
+        assert g.ivfpq_table().tobytes() == z["table"].tobytes()   # faiss precompute_table
+        sizes = z["list_sizes"]
+        nz = np.nonzero(sizes)[0]
+        g.add_keys_batch(nz, sizes[nz], z["list_ids"], z["list_codes"])
+        for m, tag in ((api.METRIC_L2, "l2"), (api.METRIC_IP, "ip")):
+            args = api.SearchArgs(metric=m, nprobe=nprobe, recall_num=R, has_rank=False, coarse_mode=0, **WIDE)
+            Dg, Ig = g.ivfpq_search(z["q"], 5, args)
+            sg = g.last_stages(len(z["q"]), nprobe, R)
+            assert sg["coarse_dis"].tobytes() == z["coarse_dis"].tobytes()
+            assert np.array_equal(sg["coarse_idx"], z["coarse_idx"])
+            compare_topk(z["rdis_" + tag], z["rids_" + tag], sg["recall_dis"], sg["recall_ids"])
+            compare_topk(z["rdis_" + tag][:, :5], z["rids_" + tag][:, :5], Dg, Ig)
+    finally:
+        g.close()
+
+
+def test_golden_realtime_replay_on_device():
+    """The reference's real RTInvertIndex script (AddKeys / Update / Delete / CompactIfNeed)
+    replayed on the HBM-resident lists: same contents, same capacities."""
+    z = np.load(os.path.join(G, "realtime.npz"))
+    nlist, cs = int(z["nlist"]), int(z["cs"])
+    g = api.GammaHip(0)
+    try:
+        g.ivfpq_init(cs, nlist, cs, 8, api.METRIC_L2, int(z["binit"]), int(z["bmax"]))
+        g.bitmap_upload(np.zeros(int(z["nbits"]) // 8 + 1, dtype=np.uint8), int(z["nbits"]))
+        next_vid, snap = 0, 0
+        snap_after = set(int(x) for x in z["snap_after"])
+        for i in range(int(z["nops"])):
+            op, a, b, ok = [int(x) for x in z["op_%d" % i]]
+            pl = z["pl_%d" % i]
+            if op == 0:
+                keys = np.arange(next_vid, next_vid + b, dtype=np.int64)
+                try:
+                    g.add_keys(a, keys, pl)
+                    got = 1
+                except api.GammaHipError:
+                    got = 0
+                assert got == ok
+                if ok:
+                    next_vid += b
+            elif op == 1:
+                g.update(a, b, pl)
+            elif op == 2:
+                g.bitmap_set(pl.astype(np.int64), 1)
+                g.delete(pl.astype(np.int64))
+            elif op == 3:
+                g.compact_if_need()
+            if i in snap_after:
+                for l in range(nlist):
+                    ids, codes = g.get_list(l)
+                    assert np.array_equal(ids, z["ids_%d_%d" % (snap, l)]), (snap, l)
+                    assert np.array_equal(codes, z["codes_%d_%d" % (snap, l)]), (snap, l)
+                caps = np.array([g.list_capacity(l) for l in range(nlist)])
+                assert np.array_equal(caps, z["caps_%d" % snap]), snap
+                snap += 1
+    finally:
+        g.close()
+
+
+def test_moved_entries_are_skipped(case):
+    """Update that moves a vector marks the old slot with bit 63 (kDelIdxMask); the scan must skip
+    it (gamma_index_ivfpq.h:579-582) on both sides."""
+    g = fixtures.load_hip(case)
+    o = B.OracleIVFPQ(case["d"], case["nlist"], case["M"], 8, case["metric"])
+    o.set_trained(case["cc"], case["pq"], None)
+    for l in range(case["nlist"]):
+        ids, codes = case["oracle"].get_list(l)
+        if len(ids):
+            o.add_keys(l, ids, codes)
+    o.set_raw(case["base"])
+    try:
+        rng = np.random.default_rng(4)
+        for vid in rng.choice(case["N"], size=200, replace=False):
+            newl = int(rng.integers(0, case["nlist"]))
+            code = rng.integers(0, 256, size=case["M"]).astype(np.uint8)
+            B.lib().go_ivfpq_update_code(o.h, newl, int(vid), B._up(code))
+            g.update(newl, int(vid), code)
+        c2 = dict(case, oracle=o)
+        for has_rank in (True, False):
+            (D, I, _), (Dg, Ig) = run_both(c2, g, case["q"], 10, 16, 100, B.METRIC_L2, has_rank)
+            compare_topk(D, I, Dg, Ig)
+    finally:
+        g.close()
+
+
+def test_device_encode_matches_oracle(case, hip):
+    """Add path on device (assign + residual + PQ argmin) == oracle == real faiss (golden)."""
+    x = case["base"][:3000]
+    for mode, n in ((0, 7), (1, 3000)):      # faiss rule: n < 20 exact, else GEMM form
+        B.lib().go_set_assign_mode(mode)
+        lo, co = case["oracle"].encode(x[:n])
+        lg, cg = hip.encode(x[:n])
+        assert np.array_equal(lo, lg) and np.array_equal(co, cg)
+    B.lib().go_set_assign_mode(0)
+
+
+# --------------------------------------------------------------------------- full size (C3)
+@pytest.fixture(scope="module")
+def c3():
+    """BASELINE.json configs[2]: 1M x 128, nlist 4096, M 16; trained on the GPU, encoded on the
+    GPU; the oracle is loaded with the same lists for sampled parity."""
+    import torch
+    from gamma_amd import train
+    N, d, nlist, M = 1000000, 128, 4096, 16
+    base = synth.sift_like(N, d=d, seed=1234)
+    cc, pq = train.train_ivfpq(base[:nlist * 64], nlist, M, niter=10, pq_niter=25, seed=1234,
+                               device="cuda" if torch.cuda.is_available() else "cpu")
+    g = api.GammaHip(0)
+    g.ivfpq_init(d, nlist, M, 8, api.METRIC_L2, bucket_init_size=1000)
+    g.ivfpq_set_trained(cc, pq, None)
+    for i0 in range(0, N, 250000):          # Add path in batches: exercises list growth
+        g.add(base[i0:i0 + 250000], i0)
+    g.raw_init(d)
+    g.raw_append(base)
+    yield dict(N=N, d=d, nlist=nlist, M=M, base=base, cc=cc, pq=pq, g=g)
+    g.close()
+
+
+def test_c3_properties(c3):
+    g, base, N = c3["g"], c3["base"], c3["N"]
+    assert sum(g.list_size(l) for l in range(c3["nlist"])) == N
+    q = synth.sift_like(1024, d=128, seed=4321)
+    args = api.SearchArgs(metric=api.METRIC_L2, nprobe=32, recall_num=200, has_rank=True,
+                          min_score=0.0, max_score=1e30, coarse_mode=1)
+    D, I = g.ivfpq_search(q, 10, args)
+    # sorted, unique, in range
+    assert (np.diff(D, axis=1) >= 0).all()
+    assert (I >= 0).all() and (I < N).all()
+    assert all(len(set(r.tolist())) == 10 for r in I)
+    # idempotent
+    D2, I2 = g.ivfpq_search(q, 10, args)
+    assert D.tobytes() == D2.tobytes() and np.array_equal(I, I2)
+    # batch split invariance (per-query results do not depend on the batch composition)
+    parts = [g.ivfpq_search(q[i:i + 256], 10, args) for i in range(0, 1024, 256)]
+    assert np.concatenate([p[0] for p in parts]).tobytes() == D.tobytes()
+    assert np.array_equal(np.concatenate([p[1] for p in parts]), I)
+    # re-ranked distances are the exact ones
+    ex = ((base[I[:50].ravel()] - np.repeat(q[:50], 10, axis=0)) ** 2).sum(1).reshape(50, 10)
+    assert np.array_equal(ex.astype(np.float32), D[:50])     # integer-valued data: exact in fp32
+    # self-queries come back first with distance 0
+    Ds, Is = g.ivfpq_search(base[5000:5064], 10, args)
+    assert (Is[:, 0] == np.arange(5000, 5064)).mean() > 0.95 and (Ds[Is[:, 0] == np.arange(5000, 5064), 0] == 0).all()
+    # recall@10 >= 0.95 against exact flat search on the GPU
+    Df, If = g.flat_search(q[:200], 10, api.SearchArgs(metric=api.METRIC_L2, min_score=0.0, max_score=1e30))
+    rec = np.mean([len(set(I[i].tolist()) & set(If[i].tolist())) / 10.0 for i in range(200)])
+    assert rec >= 0.95, rec
+
+
+def test_c3_sampled_oracle_parity(c3):
+    g = c3["g"]
+    o = B.OracleIVFPQ(c3["d"], c3["nlist"], c3["M"], 8, B.METRIC_L2, bucket_init_size=4000)
+    o.set_trained(c3["cc"], c3["pq"], g.ivfpq_table())
+    for l in range(c3["nlist"]):
+        ids, codes = g.get_list(l)
+        if len(ids):
+            o.add_keys(l, ids, codes)
+    o.set_raw(c3["base"])
+    q = synth.sift_like(96, d=128, seed=999)
+    case = dict(oracle=o)
+    for has_rank, cm in ((True, 1), (False, 1), (True, 0)):
+        (D, I, st), (Dg, Ig) = run_both(case, g, q, 10, 32, 200, B.METRIC_L2, has_rank, coarse_mode=cm,
+                                        ctx_kw=dict(min_score=0.0, max_score=1e30))
+        sg = g.last_stages(len(q), 32, 200)
+        assert sg["coarse_dis"].tobytes() == st["coarse_dis"].tobytes()
+        compare_topk(D, I, Dg, Ig)
