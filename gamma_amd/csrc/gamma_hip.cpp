@@ -324,19 +324,19 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
         if (mode == 0) {
             gh::launch_pairwise(s, true, d_x, nq, d, h->d_cc, nlist, h->w_mat.as<float>(), nlist);
         } else {
-            GH_CHECK(h, h->w_xn.ensure((size_t)nq * sizeof(float)));
-            gh::launch_row_norms(s, d_x, nq, d, h->w_xn.as<float>());
-            gh::launch_l2_gemmform(s, d_x, nq, d, h->d_cc, nlist, h->w_xn.as<float>(), h->d_cc_norms,
+            // query norms are fused into the MFMA kernel (xn = nullptr)
+            gh::launch_l2_gemmform(s, d_x, nq, d, h->d_cc, nlist, nullptr, h->d_cc_norms,
                                    h->w_mat.as<float>(), nlist, true);
         }
-        gh::launch_select_topk(s, true, h->w_mat.as<float>(), nlist, nullptr, nlist, nq, P,
+        gh::launch_select_topk(s, true, h->w_mat.as<float>(), nlist, nullptr, nlist, nlist, nq, P,
                                h->w_coarse_dis.as<float>(), h->w_probe.as<int>());
     }
     {
         StageScope t(h, GAMMA_HIP_STAGE_TABLES);
         gh::launch_pq_ip_table(s, d_x, nq, d, M, h->d_pqc, h->w_st2.as<float>());
         gh::launch_pair_offsets(s, h->w_probe.as<int>(), nq, P, h->d_list_len, h->d_list_mask, nlist,
-                                h->w_pair_off.as<int>(), h->w_qtotal.as<int>(), h->d_scan_codes);
+                                h->w_pair_off.as<int>(), h->w_qtotal.as<int>(),
+                                h->profile ? h->d_scan_codes : nullptr);
     }
     const int64_t q_stride = std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len));
     GH_CHECK(h, h->w_dist.ensure((size_t)nq * q_stride * sizeof(float)));
@@ -351,7 +351,8 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
     h->scan_pairs += (int64_t)nq * P;
     {
         StageScope t(h, GAMMA_HIP_STAGE_SELECT);
-        gh::launch_select_topk(s, l2, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), 0, nq, R,
+        gh::launch_select_topk(s, l2, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), 0,
+                               (int)std::min<int64_t>(q_stride, 1 << 30), nq, R,
                                h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>());
         gh::launch_map_candidates(s, h->w_cand_pos.as<int>(), nq, R, P, h->w_probe.as<int>(),
                                   h->w_pair_off.as<int>(), h->d_list_off, h->d_ids,
@@ -376,7 +377,7 @@ int ivfpq_stage_b(H* h, const gamma_hip_search_params* p, int nq, const float* d
         GH_CHECK(h, h->w_selp.ensure((size_t)nq * k * sizeof(int)));
         gh::launch_rerank_dist(s, l2, d_x, nq, h->d, h->d_raw, h->nraw, cand_ids, R, p->min_score,
                                p->max_score, h->w_exact.as<float>());
-        gh::launch_select_topk(s, l2, h->w_exact.as<float>(), R, nullptr, R, nq, k,
+        gh::launch_select_topk(s, l2, h->w_exact.as<float>(), R, nullptr, R, R, nq, k,
                                h->w_selv.as<float>(), h->w_selp.as<int>());
         gh::launch_finalize_topk(s, h->w_selv.as<float>(), h->w_selp.as<int>(), nq, k, cand_ids, R, 0,
                                  neutral, d_distances, d_labels);
@@ -473,7 +474,7 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
             gh::launch_pairwise_filtered(s, l2, xq, nc, d, h->d_raw + r0 * d, nr, h->w_dist.as<float>(),
                                          rows_chunk, filt, p->min_score, p->max_score, r0);
             // per-chunk top-k: values + positions relative to the chunk
-            gh::launch_select_topk(s, l2, h->w_dist.as<float>(), rows_chunk, nullptr, (int)nr, nc, k,
+            gh::launch_select_topk(s, l2, h->w_dist.as<float>(), rows_chunk, nullptr, (int)nr, (int)nr, nc, k,
                                    h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>());
             // scatter into the partial table [q][chunk][k] with global ids
             // (reuse finalize_topk: labels = pos, then offset by r0 on the fly below)
@@ -489,7 +490,7 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
         gh::launch_gather_shards(s, h->w_part_v.as<float>(), h->w_part_i.as<int64_t>(), nchunks, nc, k,
                                  h->w_m_dis.as<float>(), h->w_m_ids.as<int64_t>(), sentinel);
         gh::launch_select_topk(s, l2, h->w_m_dis.as<float>(), (int64_t)nchunks * k, nullptr, nchunks * k,
-                               nc, k, h->w_selv.as<float>(), h->w_selp.as<int>());
+                               nchunks * k, nc, k, h->w_selv.as<float>(), h->w_selp.as<int>());
         gh::launch_finalize_topk(s, h->w_selv.as<float>(), h->w_selp.as<int>(), nc, k,
                                  h->w_m_ids.as<int64_t>(), (int64_t)nchunks * k, 0, neutral,
                                  d_distances + (size_t)q0 * k, d_labels + (size_t)q0 * k);
@@ -960,12 +961,10 @@ static int encode_locked(H* h, int64_t n, const float* d_vecs, int* d_assign, ui
     if (n < 20) {
         gh::launch_pairwise(s, true, d_vecs, (int)n, d, h->d_cc, nlist, h->w_mat.as<float>(), nlist);
     } else {
-        GH_CHECK(h, h->w_xn.ensure((size_t)n * sizeof(float)));
-        gh::launch_row_norms(s, d_vecs, n, d, h->w_xn.as<float>());
-        gh::launch_l2_gemmform(s, d_vecs, (int)n, d, h->d_cc, nlist, h->w_xn.as<float>(), h->d_cc_norms,
+        gh::launch_l2_gemmform(s, d_vecs, (int)n, d, h->d_cc, nlist, nullptr, h->d_cc_norms,
                                h->w_mat.as<float>(), nlist, true);
     }
-    gh::launch_select_topk(s, true, h->w_mat.as<float>(), nlist, nullptr, nlist, (int)n, 1,
+    gh::launch_select_topk(s, true, h->w_mat.as<float>(), nlist, nullptr, nlist, nlist, (int)n, 1,
                            h->w_coarse_dis.as<float>(), d_assign);
     gh::launch_pq_encode(s, d_vecs, n, d, h->M, d_assign, h->d_cc, h->d_pqc, d_codes_out);
     GH_CHECK(h, hipGetLastError());
@@ -1115,7 +1114,7 @@ int gamma_hip_ivfpq_merge_rerank(gamma_hip_index* h, const gamma_hip_search_para
                                  h->w_m_ids.as<int64_t>(), l2 ? INFINITY : -INFINITY);
         const int64_t stride = (int64_t)nshards * R;
         gh::launch_select_topk(s, l2, h->w_m_dis.as<float>() + (size_t)q0 * stride, stride, nullptr,
-                               (int)stride, nq_local, R, h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>());
+                               (int)stride, (int)stride, nq_local, R, h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>());
         gh::launch_take_ids(s, h->w_cand_pos.as<int>(), h->w_m_ids.as<int64_t>() + (size_t)q0 * stride, stride,
                             nq_local, R, h->w_cand_ids.as<int64_t>());
     }

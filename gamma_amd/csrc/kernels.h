@@ -47,8 +47,8 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
                             int64_t q_stride, float* out, const FilterDesc& filt);
 int select_kpad(int K);
 void launch_select_topk(hipStream_t s, bool smallest, const float* vals, int64_t seg_stride,
-                        const int* seg_len, int fixed_len, int nseg, int K, float* out_vals,
-                        int* out_pos);
+                        const int* seg_len, int fixed_len, int max_len, int nseg, int K,
+                        float* out_vals, int* out_pos);
 void launch_map_candidates(hipStream_t s, const int* pos, int nq, int R, int P,
                            const int* probe_list, const int* pair_off, const int64_t* list_off,
                            const int64_t* ids, int64_t* cand_ids);

@@ -8,41 +8,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "block_utils.h"
 #include "device_math.h"
 #include "kernels.h"
 
 namespace gh {
-
-// ------------------------------------------------------------------------------------
-// small block-level helpers (256 threads = 4 waves of 64)
-// ------------------------------------------------------------------------------------
-__device__ __forceinline__ int wave_incl_scan(int v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int y = __shfl_up(v, off, 64);
-        if (lane >= off) v += y;
-    }
-    return v;
-}
-
-// exclusive scan of one int per thread over a 256-thread block; `total` = block sum.
-// s_w: 4 ints of LDS scratch.  Contains two barriers.
-__device__ __forceinline__ int block_excl_scan256(int v, int* s_w, int& total) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int incl = wave_incl_scan(v);
-    if (lane == 63) s_w[w] = incl;
-    __syncthreads();
-    int base = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        int t = s_w[i];
-        if (i < w) base += t;
-    }
-    total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-    __syncthreads();
-    return base + incl - v;
-}
 
 // ------------------------------------------------------------------------------------
 // validity predicate (GammaSearchCondition::IsValid, common/gamma_common_data.h:99-108)
@@ -262,43 +232,109 @@ __global__ __launch_bounds__(256) void k_l2_gemmform_mfma(const float* __restric
                                                           const float* __restrict__ xn,
                                                           const float* __restrict__ yn,
                                                           float* __restrict__ out, int64_t ld_out) {
-    constexpr int BK = 32;
-    // +1 padding: the fragment reads walk rows (stride BK+1 dwords) -> conflict-free
-    __shared__ float sA[64][BK + 1];
-    __shared__ float sB[64][BK + 1];
+    // Whole-K slabs of 128 in LDS (2 x 64 x 129 floats = 66 KB, 2 blocks / CU): all global
+    // loads of a slab are issued back to back (float4, 16 per thread and operand), then each
+    // wave runs 64 dependent MFMAs uninterrupted.  Row stride 129 dwords: the fragment reads
+    // (row = lane & 31, fixed k) hit 32 distinct banks.
+    constexpr int KS = 128, LD = KS + 1;
+    extern __shared__ float s_gemm[];
+    float* sA = s_gemm;            // [64][LD]
+    float* sB = s_gemm + 64 * LD;  // [64][LD]
+    __shared__ float s_xn[64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wq = w >> 1, wc = w & 1;
     const int q_base = blockIdx.y * 64, c_base = blockIdx.x * 64;
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = 0.f;
-    for (int k0 = 0; k0 < d; k0 += BK) {
-        // stage 64 x 32 of A and of B: 2048 floats each, 8 per thread
+    // fused query norms (fvec_norm_L2sqr order): thread (row = tid >> 2, lane4 = tid & 3)
+    float nacc = 0.f;
+    const bool vec4 = (d & 3) == 0;
+    for (int k0 = 0; k0 < d; k0 += KS) {
+        const int kw = min(KS, d - k0);
+        if (vec4) {
+            // 64 rows x 32 float4 per operand = 2048 float4, 8 per thread.  Loads are
+            // UNCONDITIONAL on clamped addresses (a branch per load would make hipcc wait for
+            // each one); out-of-range lanes are zeroed afterwards.  All 16 are in flight
+            // before the first LDS write.
+            float4 va[8], vb[8];
 #pragma unroll
-        for (int it = 0; it < 8; it++) {
-            int e = it * 256 + tid;
-            int r = e >> 5, c = e & 31;
-            int q = q_base + r, cc = c_base + r, kk = k0 + c;
-            sA[r][c] = (q < nq && kk < d) ? x[(int64_t)q * d + kk] : 0.f;
-            sB[r][c] = (cc < ny && kk < d) ? y[(int64_t)cc * d + kk] : 0.f;
+            for (int it = 0; it < 8; it++) {
+                const int e = it * 256 + tid;
+                const int r = e >> 5, c4 = (e & 31) * 4;
+                const int q = min(q_base + r, nq - 1), cc = min(c_base + r, ny - 1);
+                const int c4c = min(c4, kw - 4);
+                va[it] = *reinterpret_cast<const float4*>(x + (int64_t)q * d + k0 + c4c);
+                vb[it] = *reinterpret_cast<const float4*>(y + (int64_t)cc * d + k0 + c4c);
+            }
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                const int e = it * 256 + tid;
+                const int r = e >> 5, c4 = (e & 31) * 4;
+                const bool oka = c4 < kw && q_base + r < nq, okb = c4 < kw && c_base + r < ny;
+                float* pa = sA + r * LD + c4;
+                float* pb = sB + r * LD + c4;
+                pa[0] = oka ? va[it].x : 0.f; pa[1] = oka ? va[it].y : 0.f;
+                pa[2] = oka ? va[it].z : 0.f; pa[3] = oka ? va[it].w : 0.f;
+                pb[0] = okb ? vb[it].x : 0.f; pb[1] = okb ? vb[it].y : 0.f;
+                pb[2] = okb ? vb[it].z : 0.f; pb[3] = okb ? vb[it].w : 0.f;
+            }
+        } else {
+            for (int it = 0; it < 32; it++) {
+                const int e = it * 256 + tid;
+                const int r = e >> 7, c = e & 127;
+                const int q = q_base + r, cc = c_base + r;
+                sA[r * LD + c] = (q < nq && c < kw) ? x[(int64_t)q * d + k0 + c] : 0.f;
+                sB[r * LD + c] = (cc < ny && c < kw) ? y[(int64_t)cc * d + k0 + c] : 0.f;
+            }
         }
         __syncthreads();
-        const int kmax = min(BK, d - k0);
-        // K must advance in order: each MFMA consumes k, k+1 (lane>>5 selects which)
-        for (int kk = 0; kk < kmax; kk += 2) {
-            float a = sA[wq * 32 + (lane & 31)][kk + (lane >> 5)];
-            float b = sB[wc * 32 + (lane & 31)][kk + (lane >> 5)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        if (!xn) {
+            const float* row = sA + (tid >> 2) * LD;
+            const int l4 = tid & 3;
+            for (int i = 0; i < kw; i += 4) {
+                const float xv = row[i + l4];
+                // full 4-blocks are fused; the masked tail block is mul + add (as built)
+                if (k0 + i + 4 <= d) nacc = __builtin_fmaf(xv, xv, nacc);
+                else nacc = nacc + xv * xv;
+            }
         }
+        // K advances in order: each MFMA consumes k, k+1 (lane >> 5 selects which); the zero
+        // pad beyond d contributes fma(0, 0, acc) == acc
+        const float* fa = sA + (wq * 32 + (lane & 31)) * LD + (lane >> 5);
+        const float* fb = sB + (wc * 32 + (lane & 31)) * LD + (lane >> 5);
+        // chunks of 16 k = 8 MFMAs: 16 fragment reads are issued first, then the dependent
+        // MFMA chain runs while the next chunk's reads are in flight
+        const int nch = (kw + 15) >> 4;
+        for (int ch = 0; ch < nch; ch++) {
+            float a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                a[u] = fa[ch * 16 + 2 * u];
+                b[u] = fb[ch * 16 + 2 * u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    if (!xn) {
+        // (a0 + a1) + (a2 + a3) inside each 4-lane group
+        const float t01 = nacc + __shfl_down(nacc, 1, 4);
+        const float nn = t01 + __shfl_down(t01, 2, 4);
+        if ((tid & 3) == 0) s_xn[tid >> 2] = nn;
         __syncthreads();
     }
     // epilogue: dis = (xn + yn) - 2*ip, clamp
     const int col = c_base + wc * 32 + (lane & 31);
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-        int row = q_base + wq * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int lr = wq * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int row = q_base + lr;
         if (row < nq && col < ny) {
-            float dis = (xn[row] + yn[col]) - 2.f * acc[r];
+            const float xnr = xn ? xn[row] : s_xn[lr];
+            float dis = (xnr + yn[col]) - 2.f * acc[r];
             if (dis < 0.f) dis = 0.f;
             out[(int64_t)row * ld_out + col] = dis;
         }
@@ -313,7 +349,15 @@ void launch_l2_gemmform(hipStream_t s, const float* x, int nq, int d, const floa
     // exactly, so any d is bit-safe
     if (use_mfma) {
         dim3 grid((unsigned)((ny + 63) / 64), (unsigned)((nq + 63) / 64));
-        hipLaunchKernelGGL(k_l2_gemmform_mfma, grid, dim3(256), 0, s, x, nq, d, y, (int)ny, xn, yn,
+        constexpr size_t lds = 2 * 64 * 129 * sizeof(float);  // 66 KB > the 64 KB default cap
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_l2_gemmform_mfma),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        // xn == nullptr: query norms are computed inside the kernel from the staged tile
+        hipLaunchKernelGGL(k_l2_gemmform_mfma, grid, dim3(256), lds, s, x, nq, d, y, (int)ny, xn, yn,
                            out, ld_out);
     } else {
         const int64_t row_blocks = (ny + 255) / 256;
@@ -365,39 +409,53 @@ void launch_precompute_table(hipStream_t s, const float* cc, int nlist, int d, i
 // writes its distances.  grid = nq, block = 256.  Also masks lists not owned by this
 // shard (length 0) and accumulates the algorithmic scan-byte counter.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pair_offsets(const int* __restrict__ probe_list, int P,
+__global__ __launch_bounds__(256) void k_pair_offsets(const int* __restrict__ probe_list, int nq, int P,
                                                       const int* __restrict__ list_len,
                                                       const uint8_t* __restrict__ list_mask,
                                                       int nlist, int* __restrict__ pair_off,
                                                       int* __restrict__ q_total,
                                                       unsigned long long* __restrict__ scan_codes) {
-    __shared__ int s_w[4];
-    const int q = blockIdx.x;
+    // one wave per query: the scan is a wave-shuffle prefix sum, no barriers
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (q >= nq) return;
     int running = 0;
-    for (int p0 = 0; p0 < P; p0 += 256) {
-        int p = p0 + threadIdx.x;
+    for (int p0 = 0; p0 < P; p0 += 64) {
+        const int p = p0 + lane;
         int len = 0;
         if (p < P) {
-            int l = probe_list[(int64_t)q * P + p];
+            const int l = probe_list[(int64_t)q * P + p];
             if (l >= 0 && l < nlist && (!list_mask || list_mask[l])) len = list_len[l];
         }
-        int tot;
-        int ex = block_excl_scan256(len, s_w, tot);
-        if (p < P) pair_off[(int64_t)q * (P + 1) + p] = running + ex;
-        running += tot;
+        const int incl = wave_incl_scan(len);
+        if (p < P) pair_off[(int64_t)q * (P + 1) + p] = running + incl - len;
+        running += __shfl(incl, 63, 64);
     }
-    if (threadIdx.x == 0) {
+    if (lane == 0) {
         pair_off[(int64_t)q * (P + 1) + P] = running;
         q_total[q] = running;
-        if (scan_codes) atomicAdd(scan_codes, (unsigned long long)running);
     }
+}
+
+// profiling only: algorithmic scan volume of a batch = sum of the per-query candidate counts
+__global__ __launch_bounds__(256) void k_sum_totals(const int* __restrict__ q_total, int nq,
+                                                    unsigned long long* __restrict__ acc) {
+    __shared__ unsigned long long s_part[4];
+    unsigned long long t = 0;
+    for (int i = threadIdx.x; i < nq; i += 256) t += (unsigned long long)q_total[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
 }
 void launch_pair_offsets(hipStream_t s, const int* probe_list, int nq, int P, const int* list_len,
                          const uint8_t* list_mask, int nlist, int* pair_off, int* q_total,
                          unsigned long long* scan_codes) {
     if (nq <= 0) return;
-    hipLaunchKernelGGL(k_pair_offsets, dim3(nq), dim3(256), 0, s, probe_list, P, list_len, list_mask,
-                       nlist, pair_off, q_total, scan_codes);
+    hipLaunchKernelGGL(k_pair_offsets, dim3((nq + 3) / 4), dim3(256), 0, s, probe_list, nq, P, list_len,
+                       list_mask, nlist, pair_off, q_total, scan_codes);
+    if (scan_codes) hipLaunchKernelGGL(k_sum_totals, dim3(1), dim3(256), 0, s, q_total, nq, scan_codes);
 }
 
 // ------------------------------------------------------------------------------------
@@ -433,8 +491,31 @@ __global__ __launch_bounds__(256) void k_ivfpq_scan_pair(
     const int msz = M * 256;
     const float* st2q = st2 + (int64_t)q * msz;
     if (L2) {
-        const float* t2 = T2 + (int64_t)l * msz;
-        for (int e = tid; e < msz; e += 256) s_lut[e] = __builtin_fmaf(-2.0f, st2q[e], t2[e]);
+        // float4 loads, 4 per operand in flight before the first use (msz % 1024 == 0)
+        const float4* t2 = reinterpret_cast<const float4*>(T2 + (int64_t)l * msz);
+        const float4* s2 = reinterpret_cast<const float4*>(st2q);
+        float4* lut4 = reinterpret_cast<float4*>(s_lut);
+        if (msz & 4095) {  // M not a multiple of 16: plain loop
+            for (int e = tid; e < msz; e += 256)
+                s_lut[e] = __builtin_fmaf(-2.0f, st2q[e], T2[(int64_t)l * msz + e]);
+        } else
+        for (int e0 = tid; e0 < msz / 4; e0 += 1024) {
+            float4 a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                a[u] = t2[e0 + u * 256];
+                b[u] = s2[e0 + u * 256];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                float4 r;
+                r.x = __builtin_fmaf(-2.0f, b[u].x, a[u].x);
+                r.y = __builtin_fmaf(-2.0f, b[u].y, a[u].y);
+                r.z = __builtin_fmaf(-2.0f, b[u].z, a[u].z);
+                r.w = __builtin_fmaf(-2.0f, b[u].w, a[u].w);
+                lut4[e0 + u * 256] = r;
+            }
+        }
     } else {
         for (int e = tid; e < msz; e += 256) s_lut[e] = st2q[e];
         // dis0 = fvec_inner_product(x_q, centroid_l): 8 lane accumulators by 8 threads
@@ -523,161 +604,6 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
 }
 
 // ------------------------------------------------------------------------------------
-// a7: k-selection.  One workgroup per row segment.  MSB-first radix select (4 passes of
-// 8 bits over order-preserving keys) finds the K-th key; the survivors (key < T, plus the
-// first few == T in scan order) are gathered into LDS and sorted by a bitonic network on
-// 64-bit (key, position) items, so equal distances come out in scan order -- the
-// deterministic counterpart of the reference's heap (faiss:utils/Heap.h), which keeps the
-// same multiset and differs only in the order inside exact ties.
-// SMALLEST=true keeps the K smallest (CMax heap, L2); false the K largest (CMin heap, IP).
-// Sentinel values (+inf / -inf) mark filtered entries and are returned as pos = -1.
-// ------------------------------------------------------------------------------------
-template <bool SMALLEST>
-__device__ __forceinline__ uint32_t sel_key(float v) {
-    uint32_t k = f2key(v);
-    return SMALLEST ? k : ~k;
-}
-
-template <bool SMALLEST>
-__global__ __launch_bounds__(256) void k_select_topk(const float* __restrict__ vals,
-                                                     int64_t seg_stride,
-                                                     const int* __restrict__ seg_len,
-                                                     int fixed_len, int K, int Kpad,
-                                                     float* __restrict__ out_vals,
-                                                     int* __restrict__ out_pos) {
-    extern __shared__ unsigned long long s_items[];  // Kpad
-    __shared__ int s_hist[256];
-    __shared__ int s_w[4];
-    __shared__ int s_misc[8];
-    const int tid = threadIdx.x;
-    const int seg = blockIdx.x;
-    const int n = seg_len ? seg_len[seg] : fixed_len;
-    const float* v = vals + (int64_t)seg * seg_stride;
-    for (int i = tid; i < Kpad; i += 256) s_items[i] = ~0ull;
-    __syncthreads();
-    if (n <= K) {
-        for (int i = tid; i < n; i += 256)
-            s_items[i] = ((unsigned long long)sel_key<SMALLEST>(v[i]) << 32) | (unsigned)i;
-    } else {
-        uint32_t prefix = 0, mask = 0;
-        int kk = K;
-        int cnt_eq = 0;
-        for (int pass = 0; pass < 4; pass++) {
-            const int shift = 24 - 8 * pass;
-            s_hist[tid] = 0;
-            __syncthreads();
-            for (int i = tid; i < n; i += 256) {
-                uint32_t key = sel_key<SMALLEST>(v[i]);
-                if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255], 1);
-            }
-            __syncthreads();
-            const int c = s_hist[tid];
-            int tot;
-            const int ex = block_excl_scan256(c, s_w, tot);
-            if (ex < kk && kk <= ex + c) {
-                s_misc[0] = tid;
-                s_misc[1] = ex;
-                s_misc[2] = c;
-            }
-            __syncthreads();
-            prefix |= (uint32_t)s_misc[0] << shift;
-            mask |= 255u << shift;
-            kk -= s_misc[1];
-            cnt_eq = s_misc[2];
-            __syncthreads();
-        }
-        const uint32_t T = prefix;
-        const int n_less = K - kk;
-        if (tid == 0) {
-            s_misc[3] = 0;
-            s_misc[4] = 0;
-        }
-        __syncthreads();
-        if (cnt_eq == kk) {
-            for (int i = tid; i < n; i += 256) {
-                uint32_t key = sel_key<SMALLEST>(v[i]);
-                if (key < T) {
-                    int slot = atomicAdd(&s_misc[3], 1);
-                    s_items[slot] = ((unsigned long long)key << 32) | (unsigned)i;
-                } else if (key == T) {
-                    int slot = n_less + atomicAdd(&s_misc[4], 1);
-                    s_items[slot] = ((unsigned long long)key << 32) | (unsigned)i;
-                }
-            }
-        } else {
-            // ties straddle the K boundary: keep the first kk in scan order
-            int running = 0;
-            for (int i0 = 0; i0 < n; i0 += 256) {
-                const int i = i0 + tid;
-                uint32_t key = 0xffffffffu;
-                bool in = i < n;
-                if (in) key = sel_key<SMALLEST>(v[i]);
-                if (in && key < T) {
-                    int slot = atomicAdd(&s_misc[3], 1);
-                    s_items[slot] = ((unsigned long long)key << 32) | (unsigned)i;
-                }
-                const int flag = (in && key == T) ? 1 : 0;
-                int tot;
-                const int ex = block_excl_scan256(flag, s_w, tot);
-                const int rank = running + ex;
-                if (flag && rank < kk) s_items[n_less + rank] = ((unsigned long long)key << 32) | (unsigned)i;
-                running += tot;
-            }
-        }
-    }
-    // bitonic sort, ascending
-    for (int size = 2; size <= Kpad; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
-            for (int t = tid; t < (Kpad >> 1); t += 256) {
-                const int lo = ((t / stride) * stride << 1) + (t % stride);
-                const int hi = lo + stride;
-                const bool asc = (lo & size) == 0;
-                unsigned long long a = s_items[lo], b = s_items[hi];
-                if ((a > b) == asc) {
-                    s_items[lo] = b;
-                    s_items[hi] = a;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const float sentinel = SMALLEST ? INFINITY : -INFINITY;
-    for (int r = tid; r < K; r += 256) {
-        const unsigned long long it = s_items[r];
-        float val = sentinel;
-        int pos = -1;
-        if (it != ~0ull) {
-            pos = (int)(uint32_t)it;
-            val = v[pos];
-            if (val == sentinel) pos = -1;
-        }
-        out_vals[(int64_t)seg * K + r] = val;
-        out_pos[(int64_t)seg * K + r] = pos;
-    }
-}
-
-int select_kpad(int K) {
-    int p = 2;
-    while (p < K) p <<= 1;
-    return p;
-}
-
-void launch_select_topk(hipStream_t s, bool smallest, const float* vals, int64_t seg_stride,
-                        const int* seg_len, int fixed_len, int nseg, int K, float* out_vals,
-                        int* out_pos) {
-    if (nseg <= 0 || K <= 0) return;
-    const int Kpad = select_kpad(K);
-    const size_t lds = (size_t)Kpad * sizeof(unsigned long long);
-    if (smallest)
-        hipLaunchKernelGGL((k_select_topk<true>), dim3(nseg), dim3(256), lds, s, vals, seg_stride,
-                           seg_len, fixed_len, K, Kpad, out_vals, out_pos);
-    else
-        hipLaunchKernelGGL((k_select_topk<false>), dim3(nseg), dim3(256), lds, s, vals, seg_stride,
-                           seg_len, fixed_len, K, Kpad, out_vals, out_pos);
-}
-
-// ------------------------------------------------------------------------------------
 // positions in a query's candidate segment -> vector ids (KnnSearchResults::add stores
 // ids[j], gamma_index_ivfpq.h:363-369).  grid = nq.
 // ------------------------------------------------------------------------------------
@@ -729,7 +655,7 @@ __global__ __launch_bounds__(256) void k_rerank_dist(const float* __restrict__ x
     const int l = threadIdx.x & 7, g = threadIdx.x >> 3;
     const float* xq = x + (int64_t)q * d;
     const float sentinel = L2 ? INFINITY : -INFINITY;
-    for (int r0 = 0; r0 < R; r0 += 32) {
+    for (int r0 = blockIdx.y * 32; r0 < R; r0 += gridDim.y * 32) {
         const int r = r0 + g;
         int64_t id = -1;
         if (r < R) id = cand_ids[(int64_t)q * R + r];
@@ -783,11 +709,12 @@ void launch_rerank_dist(hipStream_t s, bool l2, const float* x, int nq, int d, c
                         int64_t nraw, const int64_t* cand_ids, int R, float min_score,
                         float max_score, float* out) {
     if (nq <= 0) return;
+    const int gy = (R + 31) / 32;   // 32 candidates (8 lanes each) per workgroup
     if (l2)
-        hipLaunchKernelGGL((k_rerank_dist<true>), dim3(nq), dim3(256), 0, s, x, d, raw, nraw, cand_ids,
+        hipLaunchKernelGGL((k_rerank_dist<true>), dim3(nq, gy), dim3(256), 0, s, x, d, raw, nraw, cand_ids,
                            R, min_score, max_score, out);
     else
-        hipLaunchKernelGGL((k_rerank_dist<false>), dim3(nq), dim3(256), 0, s, x, d, raw, nraw,
+        hipLaunchKernelGGL((k_rerank_dist<false>), dim3(nq, gy), dim3(256), 0, s, x, d, raw, nraw,
                            cand_ids, R, min_score, max_score, out);
 }
 
