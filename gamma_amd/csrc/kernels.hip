@@ -7,41 +7,16 @@
 // a7 top-k, a8 validity, a9 re-rank, a10 flat.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <algorithm>
 
 #include "block_utils.h"
 #include "device_math.h"
+#include "filter_dev.h"
 #include "kernels.h"
 
 namespace gh {
-
-// ------------------------------------------------------------------------------------
-// validity predicate (GammaSearchCondition::IsValid, common/gamma_common_data.h:99-108)
-// ------------------------------------------------------------------------------------
-__device__ __forceinline__ bool bm_test(const uint8_t* bm, int64_t id) {
-    return (bm[id >> 3] >> (id & 7)) & 1;
-}
-
-__device__ __forceinline__ bool is_valid_doc(const FilterDesc& f, int64_t vid) {
-    const int doc = (int)vid;
-    if (f.has_range) {
-        if (f.n_range == 0) return false;  // MultiRangeQueryResults::Has on empty set
-        for (int i = 0; i < f.n_range; i++) {
-            const RangeDesc& r = f.range[i];
-            bool has;
-            if (r.b_not_in) {
-                has = (doc < r.min_doc || doc > r.max_doc) ? true
-                                                           : !bm_test(r.bitmap, doc - r.min_aligned);
-            } else {
-                has = (doc < r.min_doc || doc > r.max_doc) ? false
-                                                           : bm_test(r.bitmap, doc - r.min_aligned);
-            }
-            if (!has) return false;
-        }
-    }
-    if (f.del_bitmap && doc >= 0 && (int64_t)doc < f.del_bits && bm_test(f.del_bitmap, doc))
-        return false;
-    return true;
-}
 
 // ------------------------------------------------------------------------------------
 // a2/a10: exact pairwise distances, one database row per thread held in registers.
@@ -457,6 +432,9 @@ void launch_pair_offsets(hipStream_t s, const int* probe_list, int nq, int P, co
                        list_mask, nlist, pair_off, q_total, scan_codes);
     if (scan_codes) hipLaunchKernelGGL(k_sum_totals, dim3(1), dim3(256), 0, s, q_total, nq, scan_codes);
 }
+void launch_sum_totals(hipStream_t s, const int* q_total, int nq, unsigned long long* acc) {
+    if (nq > 0 && acc) hipLaunchKernelGGL(k_sum_totals, dim3(1), dim3(256), 0, s, q_total, nq, acc);
+}
 
 // ------------------------------------------------------------------------------------
 // a4+a5+a6+a8: IVFPQ list scan, one workgroup per (query, probe) pair.
@@ -471,110 +449,121 @@ void launch_pair_offsets(hipStream_t s, const int* probe_list, int nq, int P, co
 // ------------------------------------------------------------------------------------
 template <bool L2, int MT>
 __global__ __launch_bounds__(256) void k_ivfpq_scan_pair(
-        const float* __restrict__ x, int d, int M, int P, const int* __restrict__ probe_list,
+        const float* __restrict__ x, int d, int M, int P, int G, const int* __restrict__ probe_list,
         const float* __restrict__ coarse_dis, const float* __restrict__ cc,
         const float* __restrict__ st2, const float* __restrict__ T2,
         const int64_t* __restrict__ list_off, const int* __restrict__ list_len,
         const uint8_t* __restrict__ list_mask, int nlist, const uint8_t* __restrict__ codes,
         const int64_t* __restrict__ ids, const int* __restrict__ pair_off, int64_t q_stride,
-        float* __restrict__ out, FilterDesc filt, float sentinel) {
+        float* __restrict__ out, FilterDesc filt, int need_ids, float sentinel) {
+    // One workgroup scans G consecutive probes of one query: the query's 16 KB table st2 is
+    // read ONCE into registers (MT per thread) and reused for the G list-specific LUTs, so
+    // the per-pair table traffic drops from 2 x M KB to (1 + 1/G) x M KB.
     extern __shared__ float s_lut[];  // M*256
     __shared__ float s_acc[8];
-    const int pair = blockIdx.x;
-    const int q = pair / P, p = pair - q * P;
-    const int l = probe_list[pair];
-    if (l < 0 || l >= nlist) return;
-    if (list_mask && !list_mask[l]) return;
-    const int len = list_len[l];
-    if (len == 0) return;
+    const int PGN = (P + G - 1) / G;
+    const int q = blockIdx.x / PGN, pg = blockIdx.x - q * PGN;
+    const int p_begin = pg * G, p_end = min(P, p_begin + G);
     const int tid = threadIdx.x;
     const int msz = M * 256;
     const float* st2q = st2 + (int64_t)q * msz;
-    if (L2) {
-        // float4 loads, 4 per operand in flight before the first use (msz % 1024 == 0)
-        const float4* t2 = reinterpret_cast<const float4*>(T2 + (int64_t)l * msz);
-        const float4* s2 = reinterpret_cast<const float4*>(st2q);
-        float4* lut4 = reinterpret_cast<float4*>(s_lut);
-        if (msz & 4095) {  // M not a multiple of 16: plain loop
-            for (int e = tid; e < msz; e += 256)
-                s_lut[e] = __builtin_fmaf(-2.0f, st2q[e], T2[(int64_t)l * msz + e]);
-        } else
-        for (int e0 = tid; e0 < msz / 4; e0 += 1024) {
-            float4 a[4], b[4];
+    float s2r[MT > 0 ? MT : 1];
+    if (MT > 0) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                a[u] = t2[e0 + u * 256];
-                b[u] = s2[e0 + u * 256];
-            }
+        for (int i = 0; i < MT; i++) s2r[i] = st2q[tid + 256 * i];
+    }
+    if (!L2) {   // inner product: the LUT is the query table itself, list independent
+        if (MT > 0) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                float4 r;
-                r.x = __builtin_fmaf(-2.0f, b[u].x, a[u].x);
-                r.y = __builtin_fmaf(-2.0f, b[u].y, a[u].y);
-                r.z = __builtin_fmaf(-2.0f, b[u].z, a[u].z);
-                r.w = __builtin_fmaf(-2.0f, b[u].w, a[u].w);
-                lut4[e0 + u * 256] = r;
-            }
+            for (int i = 0; i < MT; i++) s_lut[tid + 256 * i] = s2r[i];
+        } else {
+            for (int e = tid; e < msz; e += 256) s_lut[e] = st2q[e];
         }
-    } else {
-        for (int e = tid; e < msz; e += 256) s_lut[e] = st2q[e];
-        // dis0 = fvec_inner_product(x_q, centroid_l): 8 lane accumulators by 8 threads
-        if (tid < 8) {
+    }
+    for (int p = p_begin; p < p_end; p++) {
+        const int pair = q * P + p;
+        const int l = probe_list[pair];
+        if (l < 0 || l >= nlist) continue;            // uniform
+        if (list_mask && !list_mask[l]) continue;
+        const int len = list_len[l];
+        if (len == 0) continue;
+        __syncthreads();   // the previous list's gathers (and s_acc reads) are finished
+        if (L2) {
+            const float* t2 = T2 + (int64_t)l * msz;
+            if (MT > 0) {
+                float tv[MT > 0 ? MT : 1];
+#pragma unroll
+                for (int i = 0; i < MT; i++) tv[i] = t2[tid + 256 * i];   // MT loads in flight
+#pragma unroll
+                for (int i = 0; i < MT; i++) s_lut[tid + 256 * i] = __builtin_fmaf(-2.0f, s2r[i], tv[i]);
+            } else {
+                for (int e = tid; e < msz; e += 256) s_lut[e] = __builtin_fmaf(-2.0f, st2q[e], t2[e]);
+            }
+        } else if (tid < 8) {
+            // dis0 = fvec_inner_product(x_q, centroid_l): 8 lane accumulators by 8 threads
             const float* xq = x + (int64_t)q * d;
             const float* c = cc + (int64_t)l * d;
             float a = 0.f;
             for (int i = tid; i + (7 - tid) < d; i += 8) a = __builtin_fmaf(xq[i], c[i], a);
             s_acc[tid] = a;
         }
-    }
-    __syncthreads();
-    float dis0;
-    if (L2) {
-        dis0 = coarse_dis[pair];
-    } else {
-        const float* xq = x + (int64_t)q * d;
-        const float* c = cc + (int64_t)l * d;
-        float s0 = s_acc[4] + s_acc[0], s1 = s_acc[5] + s_acc[1], s2 = s_acc[6] + s_acc[2],
-              s3 = s_acc[7] + s_acc[3];
-        int i = d & ~7, rem = d & 7;
-        if (rem >= 4) {
-            s0 = __builtin_fmaf(xq[i], c[i], s0);
-            s1 = __builtin_fmaf(xq[i + 1], c[i + 1], s1);
-            s2 = __builtin_fmaf(xq[i + 2], c[i + 2], s2);
-            s3 = __builtin_fmaf(xq[i + 3], c[i + 3], s3);
-            i += 4;
-            rem -= 4;
-        }
-        if (rem > 0) s0 = __builtin_fmaf(xq[i], c[i], s0);
-        if (rem > 1) s1 = __builtin_fmaf(xq[i + 1], c[i + 1], s1);
-        if (rem > 2) s2 = __builtin_fmaf(xq[i + 2], c[i + 2], s2);
-        dis0 = hsum4(s0, s1, s2, s3);
-    }
-    const int64_t off = list_off[l];
-    const uint8_t* lc = codes + off * M;
-    const int64_t* lid = ids + off;
-    float* o = out + (int64_t)q * q_stride + pair_off[(int64_t)q * (P + 1) + p];
-    for (int j = tid; j < len; j += 256) {
-        const int64_t id = lid[j];
-        bool ok = id >= 0;  // bit 63 = kDelIdxMask (realtime_mem_data.h:26)
-        if (ok) ok = is_valid_doc(filt, id);
-        float dis = dis0;
-        if (MT == 16) {
-            const uint4 cv = *reinterpret_cast<const uint4*>(lc + (int64_t)j * 16);
-            const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w};
-#pragma unroll
-            for (int m = 0; m < 16; m++) dis += s_lut[m * 256 + ((cw[m >> 2] >> ((m & 3) * 8)) & 255)];
-        } else if (MT == 32) {
-            const uint4* cp = reinterpret_cast<const uint4*>(lc + (int64_t)j * 32);
-            const uint4 c0 = cp[0], c1 = cp[1];
-            const uint32_t cw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-#pragma unroll
-            for (int m = 0; m < 32; m++) dis += s_lut[m * 256 + ((cw[m >> 2] >> ((m & 3) * 8)) & 255)];
+        __syncthreads();
+        float dis0;
+        if (L2) {
+            dis0 = coarse_dis[pair];
         } else {
-            const uint8_t* cj = lc + (int64_t)j * M;
-            for (int m = 0; m < M; m++) dis += s_lut[m * 256 + cj[m]];
+            const float* xq = x + (int64_t)q * d;
+            const float* c = cc + (int64_t)l * d;
+            float s0 = s_acc[4] + s_acc[0], s1 = s_acc[5] + s_acc[1], s2 = s_acc[6] + s_acc[2],
+                  s3 = s_acc[7] + s_acc[3];
+            int i = d & ~7, rem = d & 7;
+            if (rem >= 4) {
+                s0 = __builtin_fmaf(xq[i], c[i], s0);
+                s1 = __builtin_fmaf(xq[i + 1], c[i + 1], s1);
+                s2 = __builtin_fmaf(xq[i + 2], c[i + 2], s2);
+                s3 = __builtin_fmaf(xq[i + 3], c[i + 3], s3);
+                i += 4;
+                rem -= 4;
+            }
+            if (rem > 0) s0 = __builtin_fmaf(xq[i], c[i], s0);
+            if (rem > 1) s1 = __builtin_fmaf(xq[i + 1], c[i + 1], s1);
+            if (rem > 2) s2 = __builtin_fmaf(xq[i + 2], c[i + 2], s2);
+            dis0 = hsum4(s0, s1, s2, s3);
         }
-        o[j] = ok ? dis : sentinel;
+        const int64_t off = list_off[l];
+        const uint8_t* lc = codes + off * M;
+        const int64_t* lid = ids + off;
+        float* o = out + (int64_t)q * q_stride + pair_off[(int64_t)q * (P + 1) + p];
+        for (int j = tid; j < len; j += 256) {
+            // ids are read only when something can reject an entry (delete bit, range filter,
+            // superseded slot); otherwise 8 of the 28 bytes per candidate stay in HBM
+            bool ok = true;
+            if (need_ids) {
+                const int64_t id = lid[j];
+                ok = id >= 0;  // bit 63 = kDelIdxMask (realtime_mem_data.h:26)
+                if (ok) ok = is_valid_doc(filt, id);
+            }
+            float dis = dis0;
+            if (MT == 16 || MT == 32) {
+                uint32_t cw[MT > 0 ? MT / 4 : 1];
+                const uint4* cp = reinterpret_cast<const uint4*>(lc + (int64_t)j * MT);
+#pragma unroll
+                for (int u = 0; u < MT / 16; u++) {
+                    const uint4 cv = cp[u];
+                    cw[4 * u] = cv.x; cw[4 * u + 1] = cv.y; cw[4 * u + 2] = cv.z; cw[4 * u + 3] = cv.w;
+                }
+                float t[MT > 0 ? MT : 1];
+#pragma unroll
+                for (int m = 0; m < MT; m++) t[m] = s_lut[m * 256 + ((cw[m >> 2] >> ((m & 3) * 8)) & 255)];
+                __builtin_amdgcn_sched_barrier(0);   // all gathers in flight before the add chain
+#pragma unroll
+                for (int m = 0; m < MT; m++) dis += t[m];   // sequential, reference order
+            } else {
+                const uint8_t* cj = lc + (int64_t)j * M;
+                for (int m = 0; m < M; m++) dis += s_lut[m * 256 + cj[m]];
+            }
+            o[j] = ok ? dis : sentinel;
+        }
     }
 }
 
@@ -583,14 +572,19 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
                             const float* st2, const float* T2, const int64_t* list_off,
                             const int* list_len, const uint8_t* list_mask, int nlist,
                             const uint8_t* codes, const int64_t* ids, const int* pair_off,
-                            int64_t q_stride, float* out, const FilterDesc& filt) {
+                            int64_t q_stride, float* out, const FilterDesc& filt, int need_ids) {
     if (nq <= 0) return;
     const size_t lds = (size_t)M * 256 * sizeof(float);
-    dim3 grid((unsigned)((int64_t)nq * P));
+    // probes per workgroup: amortise the query table, but keep >= ~4096 workgroups in flight
+    static const int g_env = getenv("GAMMA_HIP_SCAN_G") ? atoi(getenv("GAMMA_HIP_SCAN_G")) : 0;
+    int G = g_env > 0 ? g_env : 4;
+    while (G > 1 && (int64_t)nq * ((P + G - 1) / G) < 4096) G >>= 1;
+    G = std::max(1, std::min(G, P));
+    dim3 grid((unsigned)((int64_t)nq * ((P + G - 1) / G)));
 #define GH_SCAN(LL, MT)                                                                        \
-    hipLaunchKernelGGL((k_ivfpq_scan_pair<LL, MT>), grid, dim3(256), lds, s, x, d, M, P, probe_list, \
+    hipLaunchKernelGGL((k_ivfpq_scan_pair<LL, MT>), grid, dim3(256), lds, s, x, d, M, P, G, probe_list, \
                        coarse_dis, cc, st2, T2, list_off, list_len, list_mask, nlist, codes, ids,  \
-                       pair_off, q_stride, out, filt, LL ? INFINITY : -INFINITY)
+                       pair_off, q_stride, out, filt, need_ids, LL ? INFINITY : -INFINITY)
     if (l2) {
         if (M == 16) GH_SCAN(true, 16);
         else if (M == 32) GH_SCAN(true, 32);
