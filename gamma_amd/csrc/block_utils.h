@@ -50,4 +50,48 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return v;
 }
 
+// Sort a[0..n) (64-bit items, all distinct except ~0 padding) ascending in place with a
+// 256-thread block: every thread ranks its items by counting smaller ones (broadcast LDS
+// reads, no bank conflicts), one barrier, then scatters.  O(n^2/256) compares but only two
+// barriers -- much faster than a barrier-per-stage bitonic network for n <= ~1024.
+// The n items must be pairwise distinct (ours are (key, position) pairs); n <= MAXI * NTHREADS.
+template <int NTHREADS, int MAXI>
+__device__ __forceinline__ void block_rank_sort(unsigned long long* a, int n) {
+    unsigned long long it[MAXI];
+    int rk[MAXI];
+    const int nu = (n + NTHREADS - 1) / NTHREADS;   // items per thread actually in use (uniform)
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < MAXI; u++) {
+        const int i = threadIdx.x + NTHREADS * u;
+        it[u] = i < n ? a[i] : ~0ull;
+        rk[u] = 0;
+    }
+    // broadcast reads (same address in every lane), 8 issued before the first compare: hipcc
+    // does not pipeline this loop by itself and it would pay one LDS latency per item
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {
+        unsigned long long x[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) x[e] = a[j + e];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+#pragma unroll
+            for (int u = 0; u < MAXI; u++)
+                if (u < nu) rk[u] += (x[e] < it[u]) ? 1 : 0;
+        }
+    }
+    for (; j < n; j++) {
+        const unsigned long long x = a[j];
+#pragma unroll
+        for (int u = 0; u < MAXI; u++)
+            if (u < nu) rk[u] += (x < it[u]) ? 1 : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < MAXI; u++)
+        if (threadIdx.x + NTHREADS * u < n) a[rk[u]] = it[u];
+    __syncthreads();
+}
+
 }  // namespace gh

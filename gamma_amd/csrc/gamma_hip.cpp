@@ -388,7 +388,8 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
                                 h->w_pair_off.as<int>(), h->w_qtotal.as<int>(),
                                 h->profile ? h->d_scan_codes : nullptr);
     }
-    const int64_t q_stride = std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len));
+    // per-query slab of the distance buffer; multiple of 4 floats so rows are 16-byte aligned
+    const int64_t q_stride = (std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len)) + 3) & ~(int64_t)3;
     GH_CHECK(h, h->w_dist.ensure((size_t)nq * q_stride * sizeof(float)));
     {
         StageScope t(h, GAMMA_HIP_STAGE_SCAN);

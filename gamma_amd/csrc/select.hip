@@ -18,6 +18,10 @@
 // Sentinels (+inf / -inf) mark filtered entries and come back as pos = -1.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <vector>
 
 #include "block_utils.h"
 #include "device_math.h"
@@ -191,9 +195,7 @@ __global__ __launch_bounds__(256) void k_select2(const float* __restrict__ vals,
             if (cnt == kk) {
                 for (int i = tid; i < cnt; i += 256) s_items[n_less + i] = s_cand[i];
             } else {
-                int cpad = 2;
-                while (cpad < cnt) cpad <<= 1;
-                bitonic_sort_lds(s_cand, cpad);
+                block_rank_sort<256, 4>(s_cand, cnt);   // cnt <= CAP distinct items
                 for (int i = tid; i < kk; i += 256) s_items[n_less + i] = s_cand[i];
             }
         } else {
@@ -219,10 +221,232 @@ __global__ __launch_bounds__(256) void k_select2(const float* __restrict__ vals,
         }
     }
     __syncthreads();
-    bitonic_sort_lds(s_items, Kpad);
+    {
+        const int nres = n < K ? n : K;               // s_items[0..nres) hold distinct items
+        if (nres <= 2048) {
+            block_rank_sort<256, 8>(s_items, nres);   // slots >= nres stay ~0
+        } else {
+            bitonic_sort_lds(s_items, Kpad);
+        }
+    }
     const float sentinel = SMALLEST ? INFINITY : -INFINITY;
     for (int r = tid; r < K; r += 256) {
         const unsigned long long it = s_items[r];
+        float val = sentinel;
+        int pos = -1;
+        if (it != ~0ull) {
+            pos = (int)(uint32_t)it;
+            val = v[pos];
+            if (val == sentinel) pos = -1;
+        }
+        out_vals[(int64_t)seg * K + r] = val;
+        out_pos[(int64_t)seg * K + r] = pos;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Streaming variant for long rows (n > 4096, K <= 1024): ONE pass over the row.  Elements
+// are visited in chunks of 2048; an element is kept only if it beats the running threshold
+// tau (the K-th best seen so far), survivors go to an LDS buffer by wave-aggregated atomics,
+// and the buffer is compacted (bucket select, keeps the K best, tightens tau) whenever the
+// next chunk could overflow it.  The first chunk -- the closest probed lists, which hold most
+// of the final result -- acts as the sample that sets tau.  Same result as k_select2:
+// the K smallest (key, position) pairs, sorted.
+// ------------------------------------------------------------------------------------
+namespace {
+constexpr int ST_CAPS = 2048;          // survivor buffer entries (16 KB -> 6 workgroups / CU)
+constexpr int ST_CHUNK = 1024;         // elements per threshold check
+constexpr int ST_IPT = ST_CAPS / 256;  // buffer items per thread during compaction
+
+// keep the K smallest items of buf[0..n) in buf[0..K); returns the largest kept key
+__device__ uint32_t st_compact(unsigned long long* buf, int n, int K, int* s_hist, int* s_w,
+                               uint32_t* s_red, int* s_misc) {
+    const int tid = threadIdx.x;
+    unsigned long long it[ST_IPT];
+    uint32_t mn = 0xffffffffu, mx = 0u;
+#pragma unroll
+    for (int j = 0; j < ST_IPT; j++) {
+        const int i = tid + 256 * j;
+        it[j] = i < n ? buf[i] : ~0ull;
+        if (i < n) {
+            const uint32_t key = (uint32_t)(it[j] >> 32);
+            mn = key < mn ? key : mn;
+            mx = key > mx ? key : mx;
+        }
+    }
+    mn = wave_min_u32(mn);
+    mx = wave_max_u32(mx);
+    if ((tid & 63) == 0) {
+        s_red[tid >> 6] = mn;
+        s_red[4 + (tid >> 6)] = mx;
+    }
+    for (int i = tid; i < NB; i += 256) s_hist[i] = 0;
+    if (tid < 8) s_misc[tid] = 0;
+    __syncthreads();
+    mn = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+    mx = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+    const uint32_t range = mx - mn;
+    const int s = range >= (uint32_t)NB ? (32 - __clz((int)range)) - 11 : 0;
+#pragma unroll
+    for (int j = 0; j < ST_IPT; j++)
+        if (tid + 256 * j < n) atomicAdd(&s_hist[((uint32_t)(it[j] >> 32) - mn) >> s], 1);
+    __syncthreads();
+    int c8 = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) c8 += s_hist[tid * 8 + j];
+    int tot;
+    const int ex = block_excl_scan256(c8, s_w, tot);
+    if (ex < K && K <= ex + c8) {
+        int run = ex;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int c = s_hist[tid * 8 + j];
+            if (run < K && K <= run + c) {
+                s_misc[0] = tid * 8 + j;
+                s_misc[1] = run;
+                s_misc[2] = c;
+            }
+            run += c;
+        }
+    }
+    __syncthreads();
+    const uint32_t B = (uint32_t)s_misc[0];
+    const int below = s_misc[1], cnt = s_misc[2];
+    const int need = K - below;
+    if (cnt == need) {
+#pragma unroll
+        for (int j = 0; j < ST_IPT; j++)
+            if (tid + 256 * j < n && (((uint32_t)(it[j] >> 32) - mn) >> s) <= B)
+                buf[atomicAdd(&s_misc[3], 1)] = it[j];
+        __syncthreads();
+    } else if (cnt <= 1024) {
+        int cpad = 2;
+        while (cpad < cnt) cpad <<= 1;
+        unsigned long long* cand = buf + (ST_CAPS - cpad);   // disjoint from [0, below): K <= 1024
+#pragma unroll
+        for (int j = 0; j < ST_IPT; j++) {
+            if (tid + 256 * j < n) {
+                const uint32_t b = ((uint32_t)(it[j] >> 32) - mn) >> s;
+                if (b < B) buf[atomicAdd(&s_misc[3], 1)] = it[j];
+                else if (b == B) cand[atomicAdd(&s_misc[4], 1)] = it[j];
+            }
+        }
+        block_rank_sort<256, 4>(cand, cnt);
+        for (int i = tid; i < need; i += 256) buf[below + i] = cand[i];
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int j = 0; j < ST_IPT; j++) buf[tid + 256 * j] = it[j];
+        bitonic_sort_lds(buf, ST_CAPS);
+    }
+    uint32_t kmx = 0u;
+    for (int i = tid; i < K; i += 256) {
+        const uint32_t key = (uint32_t)(buf[i] >> 32);
+        kmx = key > kmx ? key : kmx;
+    }
+    kmx = wave_max_u32(kmx);
+    __syncthreads();
+    if ((tid & 63) == 0) s_red[tid >> 6] = kmx;
+    __syncthreads();
+    return max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+}
+}  // namespace
+
+template <bool SMALLEST>
+__global__ __launch_bounds__(256) void k_select_stream(const float* __restrict__ vals, int64_t seg_stride,
+                                                       const int* __restrict__ seg_len, int fixed_len,
+                                                       int K, int Kpad, float* __restrict__ out_vals,
+                                                       int* __restrict__ out_pos,
+                                                       unsigned long long* __restrict__ dbg) {
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+    auto TICK = [&](int slot) {
+        if (dbg) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            tacc[slot] += now - tlast;
+            tlast = now;
+        }
+    };
+    if (dbg) tlast = __builtin_amdgcn_s_memtime();
+    __shared__ unsigned long long s_buf[ST_CAPS];
+    __shared__ int s_hist[NB];
+    __shared__ int s_w[4];
+    __shared__ uint32_t s_red[8];
+    __shared__ int s_misc[8];
+    __shared__ int s_cnt;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int seg = blockIdx.x;
+    const int n = seg_len ? seg_len[seg] : fixed_len;
+    const float* v = vals + (int64_t)seg * seg_stride;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    uint32_t tau = 0xffffffffu;
+    // 16-byte loads: lane holds 4 consecutive elements, 2 float4 per thread and chunk of 2048
+    // (the row base is 16-byte aligned: seg_stride % 4 == 0 is required by the launcher).
+    // Reads past n inside the last float4 group are masked by the i < n test; reads past the
+    // row are avoided by clamping the group index.
+    const float4* v4 = reinterpret_cast<const float4*>(v);
+    const int n4 = (n + 3) >> 2;               // float4 groups that contain an element
+    // two chunks (of 1024 = 256 lanes x float4) are kept in flight ahead of the one in use
+    float4 t4[3];
+#pragma unroll
+    for (int u = 0; u < 3; u++) t4[u] = v4[min(tid + 256 * u, n4 - 1)];
+    for (int base = 0; base < n; base += ST_CHUNK) {
+        const float4 cur = t4[0];
+        t4[0] = t4[1];
+        t4[1] = t4[2];
+        if (base + 3 * ST_CHUNK < n) t4[2] = v4[min((base + 3 * ST_CHUNK) / 4 + tid, n4 - 1)];
+        if (dbg) { asm volatile("" :: "v"(cur.x), "v"(cur.w)); TICK(0); }   // load wait
+        // one LDS atomic per wave per chunk: ballots of the 4 slots are prefix-summed in SGPRs
+        const float t[4] = {cur.x, cur.y, cur.z, cur.w};
+        uint32_t key[4];
+        unsigned long long bal[4];
+        int wtot = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = base + 4 * tid + u;
+            key[u] = sel_key<SMALLEST>(t[u]);
+            bal[u] = __ballot(i < n && key[u] <= tau);
+            wtot += __popcll(bal[u]);
+        }
+        if (wtot) {
+            int b0 = 0;
+            if (lane == 0) b0 = atomicAdd(&s_cnt, wtot);
+            b0 = __shfl(b0, 0, 64);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if ((bal[u] >> lane) & 1ull)
+                    s_buf[b0 + __popcll(bal[u] & ((1ull << lane) - 1ull))] =
+                            ((unsigned long long)key[u] << 32) | (unsigned)(base + 4 * tid + u);
+                b0 += __popcll(bal[u]);
+            }
+        }
+        TICK(1);   // filter + append
+        __syncthreads();
+        const int cnt = s_cnt;
+        __syncthreads();
+        TICK(2);   // barriers
+        if (cnt > ST_CAPS - ST_CHUNK && cnt > K) {     // uniform
+            tau = st_compact(s_buf, cnt, K, s_hist, s_w, s_red, s_misc);
+            if (tid == 0) s_cnt = K;
+            __syncthreads();
+            TICK(3);   // compaction
+        }
+    }
+    int cnt = s_cnt;
+    if (cnt > K) {
+        (void)st_compact(s_buf, cnt, K, s_hist, s_w, s_red, s_misc);
+        cnt = K;
+    }
+    __syncthreads();
+    TICK(3);
+    block_rank_sort<256, 4>(s_buf, cnt);           // cnt <= K <= 1024 distinct items
+    for (int i = cnt + tid; i < K; i += 256) s_buf[i] = ~0ull;
+    __syncthreads();
+    TICK(4);   // final sort
+    if (dbg && tid == 0) for (int i = 0; i < 6; i++) dbg[(size_t)blockIdx.x * 6 + i] = tacc[i];
+    const float sentinel = SMALLEST ? INFINITY : -INFINITY;
+    for (int r = tid; r < K; r += 256) {
+        const unsigned long long it = s_buf[r];
         float val = sentinel;
         int pos = -1;
         if (it != ~0ull) {
@@ -251,6 +475,27 @@ static void launch_sel(hipStream_t s, const float* vals, int64_t seg_stride, con
                        seg_len, fixed_len, K, Kpad, out_vals, out_pos)
     if (max_len <= 256 * 4) GH_SEL(4);
     else if (max_len <= 256 * 16) GH_SEL(16);
+    else if (K <= 1024 && (seg_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(vals) & 15) == 0 &&
+             !getenv("GAMMA_HIP_NO_STREAM_SELECT"))
+    {
+        static unsigned long long* dbg_buf = nullptr;
+        static const bool dbg_on = getenv("GAMMA_HIP_SELECT_DBG") != nullptr;
+        static int shown = 0;
+        if (dbg_on && !dbg_buf) (void)hipMalloc((void**)&dbg_buf, 6 * 8 * 65536);
+        hipLaunchKernelGGL((k_select_stream<SMALLEST>), dim3(nseg), dim3(256), 0, s, vals, seg_stride,
+                           seg_len, fixed_len, K, Kpad, out_vals, out_pos, dbg_on ? dbg_buf : nullptr);
+        if (dbg_on && shown++ == 8 && nseg <= 65536) {
+            (void)hipStreamSynchronize(s);
+            std::vector<unsigned long long> hb((size_t)nseg * 6);
+            (void)hipMemcpy(hb.data(), dbg_buf, hb.size() * 8, hipMemcpyDeviceToHost);
+            const char* nm[6] = {"load-wait", "filter+append", "barriers", "compact", "final-sort", "-"};
+            for (int i = 0; i < 5; i++) {
+                double sum = 0;
+                for (int w = 0; w < nseg; w++) sum += (double)hb[(size_t)w * 6 + i];
+                fprintf(stderr, "select phase %-14s avg %.0f ticks per workgroup\n", nm[i], sum / nseg);
+            }
+        }
+    }
     else GH_SEL(0);
 #undef GH_SEL
 }
