@@ -449,7 +449,7 @@ void launch_sum_totals(hipStream_t s, const int* q_total, int nq, unsigned long 
 // ------------------------------------------------------------------------------------
 template <bool L2, int MT>
 __global__ __launch_bounds__(256) void k_ivfpq_scan_pair(
-        const float* __restrict__ x, int d, int M, int P, int G, const int* __restrict__ probe_list,
+        const float* __restrict__ x, int nq, int d, int M, int P, int G, const int* __restrict__ probe_list,
         const float* __restrict__ coarse_dis, const float* __restrict__ cc,
         const float* __restrict__ st2, const float* __restrict__ T2,
         const int64_t* __restrict__ list_off, const int* __restrict__ list_len,
@@ -462,7 +462,12 @@ __global__ __launch_bounds__(256) void k_ivfpq_scan_pair(
     extern __shared__ float s_lut[];  // M*256
     __shared__ float s_acc[8];
     const int PGN = (P + G - 1) / G;
-    const int q = blockIdx.x / PGN, pg = blockIdx.x - q * PGN;
+    // XCD-aware placement (speed only): block b runs on XCD b % 8 with its own L2, so all PGN
+    // workgroups of one query are given block ids with the same residue -- the query's table
+    // st2[q] is then fetched from HBM/MALL once per XCD and served from that L2 afterwards.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q = (slot / PGN) * 8 + xcd, pg = slot % PGN;
+    if (q >= nq) return;
     const int p_begin = pg * G, p_end = min(P, p_begin + G);
     const int tid = threadIdx.x;
     const int msz = M * 256;
@@ -580,9 +585,9 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
     int G = g_env > 0 ? g_env : 4;
     while (G > 1 && (int64_t)nq * ((P + G - 1) / G) < 4096) G >>= 1;
     G = std::max(1, std::min(G, P));
-    dim3 grid((unsigned)((int64_t)nq * ((P + G - 1) / G)));
+    dim3 grid((unsigned)(8 * (int64_t)((nq + 7) / 8) * ((P + G - 1) / G)));
 #define GH_SCAN(LL, MT)                                                                        \
-    hipLaunchKernelGGL((k_ivfpq_scan_pair<LL, MT>), grid, dim3(256), lds, s, x, d, M, P, G, probe_list, \
+    hipLaunchKernelGGL((k_ivfpq_scan_pair<LL, MT>), grid, dim3(256), lds, s, x, nq, d, M, P, G, probe_list, \
                        coarse_dis, cc, st2, T2, list_off, list_len, list_mask, nlist, codes, ids,  \
                        pair_off, q_stride, out, filt, need_ids, LL ? INFINITY : -INFINITY)
     if (l2) {
