@@ -422,6 +422,13 @@ int ivfpq_stage_b(H* h, const gamma_hip_search_params* p, int nq, const float* d
     StageScope t(h, GAMMA_HIP_STAGE_RERANK);
     if (p->has_rank) {
         if (!h->d_raw || h->raw_d != h->d) return fail(h, GAMMA_HIP_EINVAL, "has_rank needs the raw store");
+        if (R <= 1024 && nq >= 256) {
+            // one fused kernel: exact distances + top-k + output
+            gh::launch_rerank_topk(s, l2, d_x, nq, h->d, h->d_raw, h->nraw, cand_ids, R, k, p->min_score,
+                                   p->max_score, neutral, d_distances, d_labels);
+            GH_CHECK(h, hipGetLastError());
+            return GAMMA_HIP_OK;
+        }
         GH_CHECK(h, h->w_exact.ensure((size_t)nq * R * sizeof(float)));
         GH_CHECK(h, h->w_selv.ensure((size_t)nq * k * sizeof(float)));
         GH_CHECK(h, h->w_selp.ensure((size_t)nq * k * sizeof(int)));

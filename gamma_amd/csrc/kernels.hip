@@ -663,7 +663,26 @@ __global__ __launch_bounds__(256) void k_rerank_dist(const float* __restrict__ x
         float a = 0.f;
         const int d8 = d & ~7;
         if (live) {
-            for (int i = l; i < d8; i += 8) {
+            // 16 row elements (and 16 query elements) are requested before the dependent fma
+            // chain starts: the chain is sequential by construction, the loads need not be
+            int i = l;
+            for (; i + 15 * 8 < d8; i += 16 * 8) {
+                float vv[16], xx[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) vv[u] = v[i + 8 * u];
+#pragma unroll
+                for (int u = 0; u < 16; u++) xx[u] = xq[i + 8 * u];
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    if (L2) {
+                        float t = xx[u] - vv[u];
+                        a = __builtin_fmaf(t, t, a);
+                    } else {
+                        a = __builtin_fmaf(xx[u], vv[u], a);
+                    }
+                }
+            }
+            for (; i < d8; i += 8) {
                 if (L2) {
                     float t = xq[i] - v[i];
                     a = __builtin_fmaf(t, t, a);
@@ -715,6 +734,119 @@ void launch_rerank_dist(hipStream_t s, bool l2, const float* x, int nq, int d, c
     else
         hipLaunchKernelGGL((k_rerank_dist<false>), dim3(nq, gy), dim3(256), 0, s, x, d, raw, nraw,
                            cand_ids, R, min_score, max_score, out);
+}
+
+// ------------------------------------------------------------------------------------
+// a9, fused: exact re-rank distances + top-k + output in ONE kernel (compute_dis with
+// has_rank, gamma_index_ivfpq.cc:646-680).  One workgroup per query: the R exact distances
+// become (key, candidate rank) items in LDS, a block rank sort orders them -- equal exact
+// distances keep the ADC order of the candidates -- and the first k go out with their ids
+// (empty slots: -1 / heap neutral).  R <= 1024.
+// ------------------------------------------------------------------------------------
+template <bool L2>
+__global__ __launch_bounds__(256) void k_rerank_topk(const float* __restrict__ x, int d,
+                                                     const float* __restrict__ raw, int64_t nraw,
+                                                     const int64_t* __restrict__ cand_ids, int R, int k,
+                                                     float min_score, float max_score, float neutral,
+                                                     float* __restrict__ distances,
+                                                     int64_t* __restrict__ labels) {
+    __shared__ unsigned long long s_it[1024];
+    const int q = blockIdx.x;
+    const int l = threadIdx.x & 7, g = threadIdx.x >> 3;
+    const float* xq = x + (int64_t)q * d;
+    const float sentinel = L2 ? INFINITY : -INFINITY;
+    const int d8 = d & ~7;
+    for (int r0 = 0; r0 < R; r0 += 32) {
+        const int r = r0 + g;
+        int64_t id = -1;
+        if (r < R) id = cand_ids[(int64_t)q * R + r];
+        const bool live = id >= 0 && id < nraw;
+        const float* v = raw + (live ? id : 0) * d;
+        float a = 0.f;
+        if (live) {
+            int i = l;
+            for (; i + 15 * 8 < d8; i += 16 * 8) {
+                float vv[16], xx[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) vv[u] = v[i + 8 * u];
+#pragma unroll
+                for (int u = 0; u < 16; u++) xx[u] = xq[i + 8 * u];
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    if (L2) {
+                        float t = xx[u] - vv[u];
+                        a = __builtin_fmaf(t, t, a);
+                    } else {
+                        a = __builtin_fmaf(xx[u], vv[u], a);
+                    }
+                }
+            }
+            for (; i < d8; i += 8) {
+                if (L2) {
+                    float t = xq[i] - v[i];
+                    a = __builtin_fmaf(t, t, a);
+                } else {
+                    a = __builtin_fmaf(xq[i], v[i], a);
+                }
+            }
+        }
+        float s = __shfl_down(a, 4, 8) + a;   // s[l] = acc[l+4] + acc[l]
+        int rem = d - d8, i = d8;
+        if (live && rem >= 4) {
+            if (l < 4) {
+                if (L2) {
+                    float t = xq[i + l] - v[i + l];
+                    s = __builtin_fmaf(t, t, s);
+                } else {
+                    s = __builtin_fmaf(xq[i + l], v[i + l], s);
+                }
+            }
+            i += 4;
+            rem -= 4;
+        }
+        if (live && l < rem) {
+            if (L2) {
+                float t = xq[i + l] - v[i + l];
+                s = __builtin_fmaf(t, t, s);
+            } else {
+                s = __builtin_fmaf(xq[i + l], v[i + l], s);
+            }
+        }
+        const float t01 = s + __shfl_down(s, 1, 8);
+        float dis = t01 + __shfl_down(t01, 2, 8);
+        if (l == 0 && r < R) {
+            if (!live || !(dis <= max_score && dis >= min_score)) dis = sentinel;
+            const uint32_t key = L2 ? f2key(dis) : ~f2key(dis);
+            s_it[r] = ((unsigned long long)key << 32) | (unsigned)r;
+        }
+    }
+    block_rank_sort<256, 4>(s_it, R);   // R distinct items (the rank field differs)
+    for (int i = threadIdx.x; i < k; i += 256) {
+        float val = neutral;
+        int64_t id = -1;
+        if (i < R) {
+            const unsigned long long it = s_it[i];
+            const uint32_t key = (uint32_t)(it >> 32);
+            const float dv = key2f(L2 ? key : ~key);
+            if (dv != sentinel) {
+                val = dv;
+                id = cand_ids[(int64_t)q * R + (uint32_t)it];
+            }
+        }
+        distances[(int64_t)q * k + i] = val;
+        labels[(int64_t)q * k + i] = id;
+    }
+}
+void launch_rerank_topk(hipStream_t s, bool l2, const float* x, int nq, int d, const float* raw,
+                        int64_t nraw, const int64_t* cand_ids, int R, int k, float min_score,
+                        float max_score, float neutral, float* distances, int64_t* labels) {
+    if (nq <= 0) return;
+    if (l2)
+        hipLaunchKernelGGL((k_rerank_topk<true>), dim3(nq), dim3(256), 0, s, x, d, raw, nraw, cand_ids,
+                           R, k, min_score, max_score, neutral, distances, labels);
+    else
+        hipLaunchKernelGGL((k_rerank_topk<false>), dim3(nq), dim3(256), 0, s, x, d, raw, nraw, cand_ids,
+                           R, k, min_score, max_score, neutral, distances, labels);
 }
 
 // final outputs from a top-k selection over re-ranked (or flat) candidates:
