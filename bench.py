@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--nq", type=int, default=1024, help="queries per Search call (one step)")
+    ap.add_argument("--nq", type=int, default=8192, help="queries per Search call (one step)")
     ap.add_argument("--n", type=int, default=1000000)
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--nlist", type=int, default=4096)
@@ -70,7 +70,7 @@ def main():
     t0 = time.time()
     N, d, nlist, M = a.n, a.d, a.nlist, a.m
     base = synth.sift_like(N, d=d, seed=1234)
-    nbatches = 8
+    nbatches = 4
     queries = synth.sift_like(a.nq * nbatches, d=d, seed=4321)
     log("[rank %d] data %.1fs" % (rank, time.time() - t0))
 

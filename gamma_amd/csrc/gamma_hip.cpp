@@ -1055,6 +1055,38 @@ int gamma_hip_ivfpq_encode(gamma_hip_index* h, int64_t n, const float* vecs, int
     return GAMMA_HIP_OK;
 }
 
+int gamma_hip_assign(gamma_hip_index* h, int d, int64_t n, const float* x, int k, const float* centroids,
+                     int32_t* assign, float* dis) {
+    if (!h || d <= 0 || n < 0 || k <= 0 || (n > 0 && (!x || !centroids || !assign))) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (n == 0) return GAMMA_HIP_OK;
+    GH_CHECK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    // centroids + their norms live in the (otherwise unused here) partial-result buffers
+    GH_CHECK(h, h->w_part_v.ensure((size_t)k * d * sizeof(float)));
+    GH_CHECK(h, h->w_xn.ensure((size_t)k * sizeof(float)));
+    GH_CHECK(h, hipMemcpyAsync(h->w_part_v.p, centroids, (size_t)k * d * sizeof(float), hipMemcpyHostToDevice, s));
+    gh::launch_row_norms(s, h->w_part_v.as<float>(), k, d, h->w_xn.as<float>());
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(h->dist_budget_bytes / ((size_t)k * sizeof(float)))));
+    for (int64_t i0 = 0; i0 < n; i0 += chunk) {
+        const int64_t nc = std::min(chunk, n - i0);
+        GH_CHECK(h, h->w_x.ensure((size_t)nc * d * sizeof(float)));
+        GH_CHECK(h, h->w_mat.ensure((size_t)nc * k * sizeof(float)));
+        GH_CHECK(h, h->w_assign.ensure((size_t)nc * sizeof(int)));
+        GH_CHECK(h, h->w_coarse_dis.ensure((size_t)nc * sizeof(float)));
+        GH_CHECK(h, hipMemcpyAsync(h->w_x.p, x + i0 * d, (size_t)nc * d * sizeof(float), hipMemcpyHostToDevice, s));
+        gh::launch_l2_gemmform(s, h->w_x.as<float>(), (int)nc, d, h->w_part_v.as<float>(), k, nullptr,
+                               h->w_xn.as<float>(), h->w_mat.as<float>(), k, true);
+        gh::launch_select_topk(s, true, h->w_mat.as<float>(), k, nullptr, k, k, (int)nc, 1,
+                               h->w_coarse_dis.as<float>(), h->w_assign.as<int>());
+        GH_CHECK(h, hipGetLastError());
+        GH_CHECK(h, hipMemcpyAsync(assign + i0, h->w_assign.p, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, s));
+        if (dis) GH_CHECK(h, hipMemcpyAsync(dis + i0, h->w_coarse_dis.p, (size_t)nc * sizeof(float), hipMemcpyDeviceToHost, s));
+        GH_CHECK(h, hipStreamSynchronize(s));
+    }
+    return GAMMA_HIP_OK;
+}
+
 int gamma_hip_ivfpq_add(gamma_hip_index* h, int64_t n, const float* vecs, int64_t first_vid) {
     if (!h || n < 0 || (n > 0 && !vecs)) return GAMMA_HIP_EINVAL;
     if (n == 0) return GAMMA_HIP_OK;

@@ -1,0 +1,117 @@
+// GammaFLATHIPIndex -- see gamma_index_flat_hip.h
+#include "gamma_index_flat_hip.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+
+#include <algorithm>
+#include <limits>
+
+namespace tig_gamma {
+
+REGISTER_MODEL(HIPFLAT, GammaFLATHIPIndex);
+
+GammaFLATHIPIndex::~GammaFLATHIPIndex() {
+  if (h_) gamma_hip_destroy(h_);
+}
+
+int GammaFLATHIPIndex::Init(const std::string &model_parameters, int indexing_size) {
+  indexing_size_ = indexing_size;
+  if (!vector_) return -1;
+  if (model_parameters != "") {   // FLATModelParams::Parse, gamma_index_flat.cc:34-55
+    utils::JsonParser jp;
+    if (jp.Parse(model_parameters.c_str())) return -1;
+    std::string mt;
+    if (!jp.GetString("metric_type", mt)) {
+      if (strcasecmp("L2", mt.c_str()) && strcasecmp("InnerProduct", mt.c_str())) return -1;
+      metric_type_ = !strcasecmp("L2", mt.c_str()) ? DistanceComputeType::L2 : DistanceComputeType::INNER_PRODUCT;
+    }
+  }
+  d_ = vector_->MetaInfo()->Dimension();
+  const char *dev = getenv("GAMMA_HIP_DEVICE");
+  if (gamma_hip_create(dev ? atoi(dev) : 0, &h_)) return -1;
+  return gamma_hip_raw_init(h_, d_) ? -1 : 0;
+}
+
+RetrievalParameters *GammaFLATHIPIndex::Parse(const std::string &parameters) {
+  if (parameters == "") return new FlatRetrievalParameters(metric_type_);
+  utils::JsonParser jp;
+  if (jp.Parse(parameters.c_str())) return nullptr;
+  DistanceComputeType type = metric_type_;
+  std::string mt;
+  if (!jp.GetString("metric_type", mt))
+    type = !strcasecmp("L2", mt.c_str()) ? DistanceComputeType::L2 : DistanceComputeType::INNER_PRODUCT;
+  int poq = 1;
+  jp.GetInt("parallel_on_queries", poq);
+  return new FlatRetrievalParameters(poq != 0, type);
+}
+
+bool GammaFLATHIPIndex::Add(int n, const uint8_t *vec) {
+  // the CPU model reads vector_ at search time; the device keeps a mirror, fed in vid order
+  if (gamma_hip_raw_append(h_, n, reinterpret_cast<const float *>(vec))) return false;
+  uploaded_ += n;
+  return true;
+}
+
+int GammaFLATHIPIndex::Update(const std::vector<int64_t> &ids, const std::vector<const uint8_t *> &vecs) {
+  for (size_t i = 0; i < ids.size(); i++)
+    if (ids[i] < uploaded_ && gamma_hip_raw_update(h_, ids[i], reinterpret_cast<const float *>(vecs[i]))) return -1;
+  return 0;
+}
+
+int GammaFLATHIPIndex::Delete(const std::vector<int64_t> &ids) {
+  if (ids.empty()) return 0;
+  return gamma_hip_bitmap_set(h_, ids.data(), (int64_t)ids.size(), 1) ? -1 : 0;
+}
+
+int GammaFLATHIPIndex::Load(const std::string &dir) {
+  const int64_t nvec = (int64_t)vector_->MetaInfo()->Size();
+  for (int64_t i0 = uploaded_; i0 < nvec; i0 += 65536) {
+    const int64_t nb = std::min<int64_t>(65536, nvec - i0);
+    std::vector<int64_t> vids(nb);
+    for (int64_t i = 0; i < nb; i++) vids[i] = i0 + i;
+    ScopeVectors sv;
+    if (vector_->Gets(vids, sv)) return -1;
+    std::vector<float> buf((size_t)nb * d_);
+    for (int64_t i = 0; i < nb; i++) memcpy(&buf[(size_t)i * d_], sv.Get((int)i), sizeof(float) * d_);
+    if (gamma_hip_raw_append(h_, nb, buf.data())) return -1;
+    uploaded_ += nb;
+  }
+  return (int)uploaded_;
+}
+
+int GammaFLATHIPIndex::Search(RetrievalContext *retrieval_context, int n, const uint8_t *x, int k,
+                              float *distances, int64_t *ids) {
+  FlatRetrievalParameters *rp = dynamic_cast<FlatRetrievalParameters *>(retrieval_context->RetrievalParams());
+  FlatRetrievalParameters defaults(true, DistanceComputeType::L2);   // gamma_index_flat.cc:125-128
+  if (rp == nullptr) rp = &defaults;
+  if (x == nullptr) return -1;
+  GammaSearchCondition *cond = dynamic_cast<GammaSearchCondition *>(retrieval_context);
+  gamma_hip_search_params p;
+  memset(&p, 0, sizeof(p));
+  p.metric = rp->GetDistanceComputeType() == DistanceComputeType::INNER_PRODUCT ? GAMMA_HIP_METRIC_IP
+                                                                                : GAMMA_HIP_METRIC_L2;
+  p.min_score = cond ? cond->min_score : std::numeric_limits<float>::min();
+  p.max_score = cond ? cond->max_score : std::numeric_limits<float>::max();
+  std::vector<gamma_hip_range_filter> rf;
+  if (cond && cond->range_query_result) {
+    p.has_range = 1;
+    for (auto &r : cond->range_query_result->GetAllResult()) {
+      gamma_hip_range_filter f;
+      f.bitmap = reinterpret_cast<const uint8_t *>(r.bitmap_);
+      f.bitmap_bytes = r.bytes_;
+      f.min_doc = r.min_;
+      f.max_doc = r.max_;
+      f.min_aligned = r.min_aligned_;
+      f.b_not_in = r.b_not_in_ ? 1 : 0;
+      rf.push_back(f);
+    }
+    p.n_range = (int)rf.size();
+    p.range = rf.data();
+  }
+  return gamma_hip_flat_search(h_, &p, n, reinterpret_cast<const float *>(x), k, distances, ids);
+}
+
+}  // namespace tig_gamma

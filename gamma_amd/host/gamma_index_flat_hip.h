@@ -1,0 +1,49 @@
+// GammaFLATHIPIndex -- RetrievalModel plugin "HIPFLAT": Gamma's brute-force model
+// (reference index/impl/gamma_index_flat.{h,cc}) on an MI355X.  Same JSON keys
+// (metric_type, parallel_on_queries), same Search contract.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/gamma_hip.h"
+#include "json_lite.h"
+#include "retrieval_model.h"
+
+namespace tig_gamma {
+
+class FlatRetrievalParameters : public RetrievalParameters {
+ public:
+  FlatRetrievalParameters() : RetrievalParameters(), parallel_on_queries_(true) {}
+  FlatRetrievalParameters(bool parallel_on_queries, enum DistanceComputeType type)
+      : RetrievalParameters(type), parallel_on_queries_(parallel_on_queries) {}
+  FlatRetrievalParameters(enum DistanceComputeType type) : RetrievalParameters(type), parallel_on_queries_(true) {}
+  bool ParallelOnQueries() { return parallel_on_queries_; }
+
+ private:
+  bool parallel_on_queries_;   // accepted for compatibility; the device path is always batched
+};
+
+class GammaFLATHIPIndex : public RetrievalModel {
+ public:
+  GammaFLATHIPIndex() {}
+  ~GammaFLATHIPIndex() override;
+  int Init(const std::string &model_parameters, int indexing_size) override;
+  RetrievalParameters *Parse(const std::string &parameters) override;
+  int Indexing() override { return 0; }
+  bool Add(int n, const uint8_t *vec) override;
+  int Update(const std::vector<int64_t> &ids, const std::vector<const uint8_t *> &vecs) override;
+  int Delete(const std::vector<int64_t> &ids) override;
+  int Search(RetrievalContext *retrieval_context, int n, const uint8_t *x, int k, float *distances,
+             int64_t *ids) override;
+  long GetTotalMemBytes() override { return h_ ? (long)gamma_hip_total_mem_bytes(h_) : 0; }
+  int Dump(const std::string &dir) override { return 0; }
+  int Load(const std::string &dir) override;
+  DistanceComputeType metric_type_ = DistanceComputeType::INNER_PRODUCT;
+
+ private:
+  gamma_hip_index *h_ = nullptr;
+  int d_ = 0;
+  int64_t uploaded_ = 0;
+};
+
+}  // namespace tig_gamma

@@ -1,0 +1,429 @@
+// GammaIVFPQHIPIndex -- see gamma_index_ivfpq_hip.h.  Host side only: parameter handling,
+// training driver, bookkeeping; every distance / scan / selection runs in libgamma_hip.so.
+#include "gamma_index_ivfpq_hip.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+
+#include <algorithm>
+#include <random>
+
+namespace tig_gamma {
+
+REGISTER_MODEL(HIPIVFPQ, GammaIVFPQHIPIndex);
+
+#define HLOG(...)                      \
+  do {                                 \
+    fprintf(stderr, "[HIPIVFPQ] ");    \
+    fprintf(stderr, __VA_ARGS__);      \
+    fprintf(stderr, "\n");             \
+  } while (0)
+
+int IVFPQModelParams::Parse(const char *str) {
+  utils::JsonParser jp;
+  if (jp.Parse(str)) {
+    HLOG("parse IVFPQ retrieval parameters error: %s", str);
+    return -1;
+  }
+  int v;
+  if (!jp.GetInt("ncentroids", v)) {
+    if (v < -1) return -1;
+    if (v > 0) ncentroids = v;
+  } else {
+    HLOG("cannot get ncentroids for ivfpq, set it when create space");
+    return -1;
+  }
+  if (!jp.GetInt("nsubvector", v)) {
+    if (v < -1) return -1;
+    if (v > 0) nsubvector = v;
+  } else {
+    HLOG("cannot get nsubvector for ivfpq, set it when create space");
+    return -1;
+  }
+  if (!jp.GetInt("nbits_per_idx", v)) {
+    if (v < -1) return -1;
+    if (v > 0) nbits_per_idx = v;
+  }
+  if (!jp.GetInt("nprobe", v)) {
+    if (v < -1) return -1;
+    if (v > 0) nprobe = v;
+    if (nprobe > ncentroids) {
+      HLOG("nprobe should less than ncentroids");
+      return -1;
+    }
+  }
+  if (!jp.GetInt("support_indivisible_nsubvector", v)) support_indivisible_nsubvector = v != 0;
+  if (!jp.GetInt("bucket_init_size", v)) {
+    if (v < -1) return -1;
+    if (v > 0) bucket_init_size = v;
+  }
+  if (!jp.GetInt("bucket_max_size", v)) {
+    if (v < -1) return -1;
+    if (v > 0) bucket_max_size = v;
+  }
+  std::string mt;
+  if (!jp.GetString("metric_type", mt)) {
+    if (strcasecmp("L2", mt.c_str()) && strcasecmp("InnerProduct", mt.c_str())) {
+      HLOG("invalid metric_type = %s", mt.c_str());
+      return -1;
+    }
+    metric_type = !strcasecmp("L2", mt.c_str()) ? DistanceComputeType::L2 : DistanceComputeType::INNER_PRODUCT;
+  }
+  utils::JsonParser sub;
+  has_hnsw = !jp.GetObject("hnsw", sub);
+  has_opq = !jp.GetObject("opq", sub);
+  if (ncentroids <= 0 || nsubvector <= 0 || nbits_per_idx <= 0) return -1;
+  return 0;
+}
+
+GammaIVFPQHIPIndex::GammaIVFPQHIPIndex() {}
+
+GammaIVFPQHIPIndex::~GammaIVFPQHIPIndex() {
+  if (h_) gamma_hip_destroy(h_);
+  delete model_param_;
+}
+
+int GammaIVFPQHIPIndex::Init(const std::string &model_parameters, int indexing_size) {
+  indexing_size_ = indexing_size;
+  model_param_ = new IVFPQModelParams();
+  IVFPQModelParams &pa = *model_param_;
+  if (model_parameters != "" && pa.Parse(model_parameters.c_str())) return -1;
+  if (!vector_) {
+    HLOG("vector_ must be set before Init");
+    return -1;
+  }
+  d_ = vector_->MetaInfo()->Dimension();
+  if (d_ % pa.nsubvector != 0) {
+    HLOG("Dimension [%d] cannot divide by nsubvector [%d] (support_indivisible_nsubvector is not "
+         "available on the HIP path)", d_, pa.nsubvector);
+    return -2;
+  }
+  if (pa.has_hnsw || pa.has_opq || pa.support_indivisible_nsubvector || pa.nbits_per_idx != 8) {
+    HLOG("hnsw / opq / padded dimensions / nbits_per_idx != 8 are not supported by HIPIVFPQ");
+    return -2;
+  }
+  nlist_ = pa.ncentroids;
+  M_ = pa.nsubvector;
+  metric_type_ = pa.metric_type;
+  nprobe_ = pa.nprobe;
+  const char *dev = getenv("GAMMA_HIP_DEVICE");
+  int rc = gamma_hip_create(dev ? atoi(dev) : 0, &h_);
+  if (rc) {
+    HLOG("gamma_hip_create failed: %s", gamma_hip_strerror(rc));
+    return -1;
+  }
+  rc = gamma_hip_ivfpq_init(h_, d_, nlist_, M_, 8,
+                            metric_type_ == DistanceComputeType::L2 ? GAMMA_HIP_METRIC_L2 : GAMMA_HIP_METRIC_IP,
+                            pa.bucket_init_size, pa.bucket_max_size);
+  if (!rc) rc = gamma_hip_raw_init(h_, d_);
+  if (rc) {
+    HLOG("device init failed: %s (%s)", gamma_hip_strerror(rc), gamma_hip_last_error(h_));
+    return -1;
+  }
+  return 0;
+}
+
+RetrievalParameters *GammaIVFPQHIPIndex::Parse(const std::string &parameters) {
+  if (parameters == "") return new IVFPQRetrievalParameters(metric_type_);
+  utils::JsonParser jp;
+  if (jp.Parse(parameters.c_str())) {
+    HLOG("parse retrieval parameters error: %s", parameters.c_str());
+    return nullptr;
+  }
+  IVFPQRetrievalParameters *rp = new IVFPQRetrievalParameters();
+  std::string mt;
+  if (!jp.GetString("metric_type", mt)) {
+    rp->SetDistanceComputeType(!strcasecmp("L2", mt.c_str()) ? DistanceComputeType::L2
+                                                              : DistanceComputeType::INNER_PRODUCT);
+  } else {
+    rp->SetDistanceComputeType(metric_type_);
+  }
+  int v;
+  if (!jp.GetInt("recall_num", v) && v > 0) rp->SetRecallNum(v);
+  if (!jp.GetInt("nprobe", v) && v > 0) rp->SetNprobe(v);
+  if (!jp.GetInt("parallel_on_queries", v)) rp->SetParallelOnQueries(v != 0);
+  return rp;
+}
+
+// Lloyd k-means; the assignment step runs on the device (gamma_hip_assign), the centroid
+// update on the host.  Deterministic for a given seed.
+static int kmeans_device(gamma_hip_index *h, int d, size_t n, const float *x, int k, int niter,
+                         unsigned seed, std::vector<float> &centroids) {
+  centroids.resize((size_t)k * d);
+  std::mt19937_64 rng(seed);
+  std::vector<size_t> perm(n);
+  for (size_t i = 0; i < n; i++) perm[i] = i;
+  for (size_t i = 0; i < (size_t)k && i < n; i++) {
+    size_t j = i + rng() % (n - i);
+    std::swap(perm[i], perm[j]);
+    memcpy(&centroids[i * d], x + perm[i] * d, sizeof(float) * d);
+  }
+  std::vector<int32_t> assign(n);
+  std::vector<double> sums((size_t)k * d);
+  std::vector<int64_t> cnt(k);
+  for (int it = 0; it < niter; it++) {
+    int rc = gamma_hip_assign(h, d, (int64_t)n, x, k, centroids.data(), assign.data(), nullptr);
+    if (rc) return rc;
+    std::fill(sums.begin(), sums.end(), 0.0);
+    std::fill(cnt.begin(), cnt.end(), 0);
+    for (size_t i = 0; i < n; i++) {
+      const int a = assign[i];
+      if (a < 0 || a >= k) continue;
+      cnt[a]++;
+      double *s = &sums[(size_t)a * d];
+      const float *xi = x + i * d;
+      for (int t = 0; t < d; t++) s[t] += xi[t];
+    }
+    for (int c = 0; c < k; c++) {
+      if (cnt[c] == 0) {  // re-seed an empty cluster from a random point
+        memcpy(&centroids[(size_t)c * d], x + (rng() % n) * d, sizeof(float) * d);
+        continue;
+      }
+      for (int t = 0; t < d; t++) centroids[(size_t)c * d + t] = (float)(sums[(size_t)c * d + t] / cnt[c]);
+    }
+  }
+  return 0;
+}
+
+int GammaIVFPQHIPIndex::TrainOnHost(size_t num, const float *xt) {
+  // coarse quantizer: cp.niter = 10 (gamma_index_ivfpq.cc:175)
+  int rc = kmeans_device(h_, d_, num, xt, nlist_, 10, 1234, coarse_centroids_);
+  if (rc) return rc;
+  // residuals of the training set (by_residual = true, :179)
+  std::vector<int32_t> assign(num);
+  rc = gamma_hip_assign(h_, d_, (int64_t)num, xt, nlist_, coarse_centroids_.data(), assign.data(), nullptr);
+  if (rc) return rc;
+  const size_t nsub = std::min<size_t>(num, 256 * 256);  // max_points_per_centroid * ksub
+  const int dsub = d_ / M_;
+  std::vector<float> sub(nsub * dsub);
+  pq_centroids_.resize((size_t)M_ * 256 * dsub);
+  for (int m = 0; m < M_; m++) {
+    for (size_t i = 0; i < nsub; i++) {
+      const float *xi = xt + i * d_ + m * dsub;
+      const float *c = &coarse_centroids_[(size_t)assign[i] * d_ + m * dsub];
+      for (int t = 0; t < dsub; t++) sub[i * dsub + t] = xi[t] - c[t];
+    }
+    std::vector<float> cm;
+    rc = kmeans_device(h_, dsub, nsub, sub.data(), 256, 25, 1235 + m, cm);
+    if (rc) return rc;
+    memcpy(&pq_centroids_[(size_t)m * 256 * dsub], cm.data(), sizeof(float) * 256 * dsub);
+  }
+  return 0;
+}
+
+int GammaIVFPQHIPIndex::Indexing() {
+  if (is_trained_) {
+    HLOG("already trained, skip indexing");
+    return 0;
+  }
+  const size_t vectors_count = vector_->MetaInfo()->Size();
+  // training-set size rule of gamma_index_ivfpq.cc:280-301
+  size_t num;
+  if ((size_t)indexing_size_ < (size_t)nlist_) num = (size_t)nlist_ * 39;
+  else if ((size_t)indexing_size_ <= (size_t)nlist_ * 256) num = (size_t)indexing_size_;
+  else num = (size_t)nlist_ * 256;
+  if (num > vectors_count) {
+    HLOG("vector total count [%zu] less then index_size[%zu], failed!", vectors_count, num);
+    return -1;
+  }
+  std::vector<int64_t> vids(num);
+  for (size_t i = 0; i < num; i++) vids[i] = (int64_t)i;
+  ScopeVectors sv;
+  if (vector_->Gets(vids, sv)) return -1;
+  std::vector<float> xt(num * d_);
+  for (size_t i = 0; i < num; i++) memcpy(&xt[i * d_], sv.Get((int)i), sizeof(float) * d_);
+  int rc = TrainOnHost(num, xt.data());
+  if (!rc) rc = gamma_hip_ivfpq_set_trained(h_, coarse_centroids_.data(), pq_centroids_.data(), nullptr);
+  if (rc) {
+    HLOG("training failed: %s (%s)", gamma_hip_strerror(rc), gamma_hip_last_error(h_));
+    return -1;
+  }
+  is_trained_ = true;
+  return 0;
+}
+
+bool GammaIVFPQHIPIndex::Add(int n, const uint8_t *vec) {
+  // vids are consecutive from indexed_vec_count_ (gamma_index_ivfpq.cc:475-489); the raw
+  // vectors are mirrored to HBM for the exact re-rank (VectorReader::Gets on the CPU path)
+  const float *v = reinterpret_cast<const float *>(vec);
+  const int64_t end = (int64_t)indexed_vec_count_ + n;
+  if (raw_uploaded_ < indexed_vec_count_ && EnsureRaw(indexed_vec_count_)) return false;
+  if (raw_uploaded_ < end) {   // the part of this batch a brute-force search has not mirrored yet
+    const int64_t skip = raw_uploaded_ - indexed_vec_count_;
+    if (gamma_hip_raw_append(h_, end - raw_uploaded_, v + skip * d_)) return false;
+    raw_uploaded_ = end;
+  }
+  int rc = gamma_hip_ivfpq_add(h_, n, v, indexed_vec_count_);
+  if (rc) {
+    HLOG("add failed: %s (%s)", gamma_hip_strerror(rc), gamma_hip_last_error(h_));
+    return false;
+  }
+  indexed_vec_count_ += n;
+  return true;
+}
+
+int GammaIVFPQHIPIndex::Update(const std::vector<int64_t> &ids, const std::vector<const uint8_t *> &vecs) {
+  for (size_t i = 0; i < ids.size(); i++) {
+    const float *v = reinterpret_cast<const float *>(vecs[i]);
+    int64_t lno = -1;
+    std::vector<uint8_t> code(M_);
+    if (gamma_hip_ivfpq_encode(h_, 1, v, &lno, code.data())) return -1;
+    if (gamma_hip_ivfpq_update(h_, (int)lno, ids[i], code.data())) return -1;
+    if (ids[i] < raw_uploaded_ && gamma_hip_raw_update(h_, ids[i], v)) return -1;
+  }
+  gamma_hip_ivfpq_compact_if_need(h_);   // gamma_index_ivfpq.cc:420
+  return 0;
+}
+
+int GammaIVFPQHIPIndex::Delete(const std::vector<int64_t> &ids) {
+  // the engine sets the doc bit in its BitmapManager (search/gamma_engine.cc:810-812); the
+  // device keeps a mirror of that bitmap, fed from here (vid == docid for single-vector docs)
+  if (ids.empty()) return 0;
+  if (gamma_hip_bitmap_set(h_, ids.data(), (int64_t)ids.size(), 1)) return -1;
+  return gamma_hip_ivfpq_delete(h_, ids.data(), (int)ids.size()) ? -1 : 0;
+}
+
+int GammaIVFPQHIPIndex::Search(RetrievalContext *retrieval_context, int n, const uint8_t *x, int k,
+                               float *distances, int64_t *ids) {
+  IVFPQRetrievalParameters *rp = dynamic_cast<IVFPQRetrievalParameters *>(retrieval_context->RetrievalParams());
+  IVFPQRetrievalParameters defaults;
+  if (rp == nullptr) rp = &defaults;
+  GammaSearchCondition *cond = dynamic_cast<GammaSearchCondition *>(retrieval_context);
+  gamma_hip_search_params p;
+  memset(&p, 0, sizeof(p));
+  p.metric = rp->GetDistanceComputeType() == DistanceComputeType::INNER_PRODUCT ? GAMMA_HIP_METRIC_IP
+                                                                                : GAMMA_HIP_METRIC_L2;
+  p.recall_num = rp->RecallNum();
+  p.has_rank = cond ? (cond->has_rank ? 1 : 0) : 1;
+  p.min_score = cond ? cond->min_score : std::numeric_limits<float>::min();
+  p.max_score = cond ? cond->max_score : std::numeric_limits<float>::max();
+  p.coarse_mode = -1;
+  std::vector<gamma_hip_range_filter> rf;
+  if (cond && cond->range_query_result) {
+    p.has_range = 1;
+    for (auto &r : cond->range_query_result->GetAllResult()) {
+      gamma_hip_range_filter f;
+      f.bitmap = reinterpret_cast<const uint8_t *>(r.bitmap_);
+      f.bitmap_bytes = r.bytes_;
+      f.min_doc = r.min_;
+      f.max_doc = r.max_;
+      f.min_aligned = r.min_aligned_;
+      f.b_not_in = r.b_not_in_ ? 1 : 0;
+      rf.push_back(f);
+    }
+    p.n_range = (int)rf.size();
+    p.range = rf.data();
+  }
+  const float *xq = reinterpret_cast<const float *>(x);
+  int rc;
+  if ((cond && cond->brute_force_search) || !is_trained_) {
+    if (EnsureRaw((int64_t)vector_->MetaInfo()->Size())) return -1;
+    rc = gamma_hip_flat_search(h_, &p, n, xq, k, distances, ids);   // gamma_index_ivfpq.cc:529-537
+  } else {
+    // nprobe rule of gamma_index_ivfpq.cc:539-545
+    p.nprobe = (rp->Nprobe() > 0 && rp->Nprobe() <= nlist_) ? rp->Nprobe() : nprobe_;
+    rc = gamma_hip_ivfpq_search(h_, &p, n, xq, k, distances, ids);
+  }
+  if (rc) {
+    HLOG("search failed: %s (%s)", gamma_hip_strerror(rc), gamma_hip_last_error(h_));
+    return rc;
+  }
+  return 0;
+}
+
+// mirror vids [raw_uploaded_, upto) of the engine's vector store into HBM
+int GammaIVFPQHIPIndex::EnsureRaw(int64_t upto) {
+  const int64_t step = 65536;
+  for (int64_t i0 = raw_uploaded_; i0 < upto; i0 += step) {
+    const int64_t nb = std::min(step, upto - i0);
+    std::vector<int64_t> vids(nb);
+    for (int64_t i = 0; i < nb; i++) vids[i] = i0 + i;
+    ScopeVectors sv;
+    if (vector_->Gets(vids, sv)) return -1;
+    std::vector<float> buf((size_t)nb * d_);
+    for (int64_t i = 0; i < nb; i++) memcpy(&buf[(size_t)i * d_], sv.Get((int)i), sizeof(float) * d_);
+    if (gamma_hip_raw_append(h_, nb, buf.data())) return -1;
+    raw_uploaded_ += nb;
+  }
+  return 0;
+}
+
+int GammaIVFPQHIPIndex::SetTrained(const float *coarse, const float *pq) {
+  coarse_centroids_.assign(coarse, coarse + (size_t)nlist_ * d_);
+  pq_centroids_.assign(pq, pq + (size_t)M_ * 256 * (d_ / M_));
+  if (gamma_hip_ivfpq_set_trained(h_, coarse_centroids_.data(), pq_centroids_.data(), nullptr)) return -1;
+  is_trained_ = true;
+  return 0;
+}
+
+long GammaIVFPQHIPIndex::GetTotalMemBytes() { return h_ ? (long)gamma_hip_total_mem_bytes(h_) : 0; }
+
+// Own container for the trained state + lists ("HIPQ").  Compatibility with the reference's
+// IwPQ dump (index/gamma_index_io.cc:113-192) is a later scope item.
+int GammaIVFPQHIPIndex::Dump(const std::string &dir) {
+  if (!is_trained_) return 0;
+  const std::string path = dir + "/hipivfpq.index";
+  FILE *f = fopen(path.c_str(), "wb");
+  if (!f) return -1;
+  const int32_t hdr[6] = {0x51504948, d_, nlist_, M_, (int32_t)metric_type_, indexed_vec_count_};
+  fwrite(hdr, sizeof(hdr), 1, f);
+  fwrite(coarse_centroids_.data(), sizeof(float), coarse_centroids_.size(), f);
+  fwrite(pq_centroids_.data(), sizeof(float), pq_centroids_.size(), f);
+  std::vector<int64_t> ids;
+  std::vector<uint8_t> codes;
+  for (int l = 0; l < nlist_; l++) {
+    int64_t len = gamma_hip_ivfpq_list_size(h_, l);
+    fwrite(&len, sizeof(len), 1, f);
+    if (len <= 0) continue;
+    ids.resize(len);
+    codes.resize((size_t)len * M_);
+    if (gamma_hip_ivfpq_get_list(h_, l, ids.data(), codes.data())) {
+      fclose(f);
+      return -1;
+    }
+    fwrite(ids.data(), sizeof(int64_t), len, f);
+    fwrite(codes.data(), 1, codes.size(), f);
+  }
+  fclose(f);
+  return 0;
+}
+
+int GammaIVFPQHIPIndex::Load(const std::string &dir) {
+  const std::string path = dir + "/hipivfpq.index";
+  FILE *f = fopen(path.c_str(), "rb");
+  if (!f) return 0;   // nothing dumped: zero vectors loaded
+  int32_t hdr[6];
+  if (fread(hdr, sizeof(hdr), 1, f) != 1 || hdr[0] != 0x51504948 || hdr[1] != d_ || hdr[2] != nlist_ ||
+      hdr[3] != M_) {
+    fclose(f);
+    return -1;
+  }
+  coarse_centroids_.resize((size_t)nlist_ * d_);
+  pq_centroids_.resize((size_t)M_ * 256 * (d_ / M_));
+  bool ok = fread(coarse_centroids_.data(), sizeof(float), coarse_centroids_.size(), f) == coarse_centroids_.size() &&
+            fread(pq_centroids_.data(), sizeof(float), pq_centroids_.size(), f) == pq_centroids_.size();
+  if (ok) ok = gamma_hip_ivfpq_set_trained(h_, coarse_centroids_.data(), pq_centroids_.data(), nullptr) == 0;
+  std::vector<int64_t> ids;
+  std::vector<uint8_t> codes;
+  for (int l = 0; ok && l < nlist_; l++) {
+    int64_t len = 0;
+    ok = fread(&len, sizeof(len), 1, f) == 1;
+    if (!ok || len <= 0) continue;
+    ids.resize(len);
+    codes.resize((size_t)len * M_);
+    ok = fread(ids.data(), sizeof(int64_t), len, f) == (size_t)len &&
+         fread(codes.data(), 1, codes.size(), f) == codes.size() &&
+         gamma_hip_ivfpq_add_keys(h_, l, (int)len, ids.data(), codes.data()) == 0;
+  }
+  fclose(f);
+  if (!ok) return -1;
+  is_trained_ = true;
+  indexed_vec_count_ = hdr[5];
+  // raw vectors for the re-rank come back from the engine's vector store
+  if (EnsureRaw(std::min<int64_t>(indexed_vec_count_, (int64_t)vector_->MetaInfo()->Size()))) return -1;
+  return indexed_vec_count_;
+}
+
+}  // namespace tig_gamma

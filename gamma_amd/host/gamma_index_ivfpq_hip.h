@@ -1,0 +1,85 @@
+// GammaIVFPQHIPIndex -- RetrievalModel plugin "HIPIVFPQ": Gamma's IVFPQ model with the whole
+// search path (coarse quantizer, LUT, list scan, filters, top-k, re-rank) and the Add-path
+// encoding on an MI355X through the C ABI of include/gamma_hip.h.
+//
+// Mirrors GammaIVFPQIndex (reference index/impl/gamma_index_ivfpq.{h,cc}): same JSON keys and
+// defaults (IVFPQModelParams :675-887, IVFPQRetrievalParameters :629-673), same return codes,
+// same Search contract.  Unsupported on device and rejected in Init like any bad parameter:
+// hnsw quantizer, opq, support_indivisible_nsubvector, nbits_per_idx != 8.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/gamma_hip.h"
+#include "json_lite.h"
+#include "retrieval_model.h"
+
+namespace tig_gamma {
+
+class IVFPQRetrievalParameters : public RetrievalParameters {
+ public:
+  IVFPQRetrievalParameters() : RetrievalParameters(), parallel_on_queries_(true), recall_num_(100), nprobe_(-1) {}
+  IVFPQRetrievalParameters(enum DistanceComputeType type)
+      : RetrievalParameters(type), parallel_on_queries_(true), recall_num_(100), nprobe_(-1) {}
+  int RecallNum() { return recall_num_; }
+  void SetRecallNum(int recall_num) { recall_num_ = recall_num; }
+  int Nprobe() { return nprobe_; }
+  void SetNprobe(int nprobe) { nprobe_ = nprobe; }
+  bool ParallelOnQueries() { return parallel_on_queries_; }
+  void SetParallelOnQueries(bool p) { parallel_on_queries_ = p; }
+
+ protected:
+  bool parallel_on_queries_;   // accepted for compatibility; the device path is always batched
+  int recall_num_;
+  int nprobe_;
+};
+
+struct IVFPQModelParams {
+  int ncentroids = 2048;
+  int nsubvector = 64;
+  bool support_indivisible_nsubvector = false;
+  int nbits_per_idx = 8;
+  int nprobe = 80;
+  DistanceComputeType metric_type = DistanceComputeType::INNER_PRODUCT;
+  bool has_hnsw = false;
+  bool has_opq = false;
+  int bucket_init_size = 1000;
+  int bucket_max_size = 1280000;
+  int Parse(const char *str);   // 0 ok, -1 bad (same rules as gamma_index_ivfpq.h:708-851)
+};
+
+class GammaIVFPQHIPIndex : public RetrievalModel {
+ public:
+  GammaIVFPQHIPIndex();
+  ~GammaIVFPQHIPIndex() override;
+  int Init(const std::string &model_parameters, int indexing_size) override;
+  RetrievalParameters *Parse(const std::string &parameters) override;
+  int Indexing() override;
+  bool Add(int n, const uint8_t *vec) override;
+  int Update(const std::vector<int64_t> &ids, const std::vector<const uint8_t *> &vecs) override;
+  int Delete(const std::vector<int64_t> &ids) override;
+  int Search(RetrievalContext *retrieval_context, int n, const uint8_t *x, int k, float *distances,
+             int64_t *ids) override;
+  long GetTotalMemBytes() override;
+  int Dump(const std::string &dir) override;
+  int Load(const std::string &dir) override;
+
+  // install an externally trained quantizer (tests: same centroids as the oracle)
+  int SetTrained(const float *coarse_centroids, const float *pq_centroids);
+
+  // exposed for the harness / tests
+  bool is_trained_ = false;
+  int d_ = 0, nlist_ = 0, M_ = 0, nprobe_ = 80;
+  DistanceComputeType metric_type_ = DistanceComputeType::INNER_PRODUCT;
+  int indexed_vec_count_ = 0;
+  std::vector<float> coarse_centroids_, pq_centroids_;
+
+ private:
+  int TrainOnHost(size_t num, const float *xt);
+  int EnsureRaw(int64_t upto);
+  gamma_hip_index *h_ = nullptr;
+  IVFPQModelParams *model_param_ = nullptr;
+  int64_t raw_uploaded_ = 0;
+};
+
+}  // namespace tig_gamma

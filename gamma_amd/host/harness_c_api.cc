@@ -1,0 +1,145 @@
+// harness_c_api.cc -- extern "C" test harness that drives the RetrievalModel plugins the way
+// VectorManager does (vector/vector_manager.cc:161-192,305-349,433-491): create by name through
+// the reflector, set vector_, Init, Add, Indexing, Parse + Search with a GammaSearchCondition.
+// Used by the Python tests through ctypes; not part of the product surface.
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "gamma_index_ivfpq_hip.h"
+#include "retrieval_model.h"
+
+using namespace tig_gamma;
+
+namespace {
+// MemoryRawVector stand-in: the engine-owned raw vector store the model reads through VectorReader
+class MemVectorReader : public VectorReader {
+ public:
+  MemVectorReader(int d) : VectorReader(new VectorMetaInfo("vec", d, VectorValueType::FLOAT)), d_(d) {}
+  int Gets(const std::vector<int64_t> &vids, ScopeVectors &vecs) const override {
+    for (auto v : vids) {
+      if (v < 0 || (size_t)v >= data_.size() / d_) return -1;
+      vecs.Add(reinterpret_cast<const uint8_t *>(&data_[(size_t)v * d_]), false);
+    }
+    return 0;
+  }
+  void Append(int n, const float *x) {
+    data_.insert(data_.end(), x, x + (size_t)n * d_);
+    meta_info_->size_ += n;
+  }
+  int d_;
+  std::vector<float> data_;
+};
+
+struct Host {
+  MemVectorReader *store;
+  RetrievalModel *model;
+};
+}  // namespace
+
+extern "C" {
+
+void *gh_host_new(const char *retrieval_type, int d) {
+  RetrievalModel *m = reflector().GetNewModel(retrieval_type);
+  if (!m) return nullptr;
+  Host *h = new Host{new MemVectorReader(d), m};
+  m->vector_ = h->store;
+  return h;
+}
+void gh_host_free(void *hp) {
+  Host *h = (Host *)hp;
+  delete h->model;
+  delete h->store;
+  delete h;
+}
+int gh_host_init(void *hp, const char *retrieval_param, int indexing_size) {
+  return ((Host *)hp)->model->Init(retrieval_param, indexing_size);
+}
+// AddToStore (raw vector append) without indexing: what happens before the index is trained
+void gh_host_store(void *hp, int n, const float *x) { ((Host *)hp)->store->Append(n, x); }
+int gh_host_indexing(void *hp) { return ((Host *)hp)->model->Indexing(); }
+// model->Add for vectors already in the store (AddRTVecsToIndex)
+int gh_host_add(void *hp, int n, const float *x) {
+  Host *h = (Host *)hp;
+  bool ok = h->model->Add(n, reinterpret_cast<const uint8_t *>(x));
+  if (ok) h->model->indexed_count_ += n;
+  return ok ? 1 : 0;
+}
+int gh_host_update(void *hp, int64_t vid, const float *x) {
+  Host *h = (Host *)hp;
+  memcpy(&h->store->data_[(size_t)vid * h->store->d_], x, sizeof(float) * h->store->d_);
+  std::vector<int64_t> ids{vid};
+  std::vector<const uint8_t *> vecs{reinterpret_cast<const uint8_t *>(x)};
+  return h->model->Update(ids, vecs);
+}
+int gh_host_delete(void *hp, const int64_t *vids, int n) {
+  std::vector<int64_t> ids(vids, vids + n);
+  return ((Host *)hp)->model->Delete(ids);
+}
+int gh_host_search(void *hp, const char *retrieval_params, int has_rank, int brute_force, float min_score,
+                   float max_score, int n, const float *x, int k, float *distances, int64_t *ids) {
+  Host *h = (Host *)hp;
+  PerfTool perf;
+  GammaSearchCondition cond(&perf);
+  cond.topn = k;
+  cond.has_rank = has_rank != 0;
+  cond.brute_force_search = brute_force != 0;
+  cond.min_score = min_score;
+  cond.max_score = max_score;
+  cond.retrieval_params_ = h->model->Parse(retrieval_params);   // owned by the context
+  if (!cond.retrieval_params_) return -100;
+  return h->model->Search(&cond, n, reinterpret_cast<const uint8_t *>(x), k, distances, ids);
+}
+int gh_host_dump(void *hp, const char *dir) { return ((Host *)hp)->model->Dump(dir); }
+int gh_host_load(void *hp, const char *dir) { return ((Host *)hp)->model->Load(dir); }
+long gh_host_mem_bytes(void *hp) { return ((Host *)hp)->model->GetTotalMemBytes(); }
+// trained state of a HIPIVFPQ model (for parity checks against the oracle)
+int gh_host_ivfpq_state(void *hp, float *cc, float *pq) {
+  GammaIVFPQHIPIndex *m = dynamic_cast<GammaIVFPQHIPIndex *>(((Host *)hp)->model);
+  if (!m || !m->is_trained_) return -1;
+  if (cc) memcpy(cc, m->coarse_centroids_.data(), sizeof(float) * m->coarse_centroids_.size());
+  if (pq) memcpy(pq, m->pq_centroids_.data(), sizeof(float) * m->pq_centroids_.size());
+  return 0;
+}
+
+int gh_host_ivfpq_set_trained(void *hp, const float *cc, const float *pq) {
+  GammaIVFPQHIPIndex *m = dynamic_cast<GammaIVFPQHIPIndex *>(((Host *)hp)->model);
+  return m ? m->SetTrained(cc, pq) : -1;
+}
+// IVFPQModelParams::Parse for host-logic tests: out = {rc, ncentroids, nsubvector, nbits_per_idx,
+// nprobe, metric(0 IP / 1 L2), bucket_init_size, bucket_max_size, has_hnsw, has_opq}
+void gh_parse_ivfpq_model_params(const char *str, int *out) {
+  IVFPQModelParams p;
+  out[0] = p.Parse(str);
+  out[1] = p.ncentroids;
+  out[2] = p.nsubvector;
+  out[3] = p.nbits_per_idx;
+  out[4] = p.nprobe;
+  out[5] = (int)p.metric_type;
+  out[6] = p.bucket_init_size;
+  out[7] = p.bucket_max_size;
+  out[8] = p.has_hnsw;
+  out[9] = p.has_opq;
+}
+// IVFPQRetrievalParameters via Parse on an un-Init'ed model: out = {rc, metric, recall_num, nprobe}
+void gh_parse_ivfpq_retrieval_params(const char *str, int *out) {
+  GammaIVFPQHIPIndex m;
+  RetrievalParameters *rp = m.Parse(str);
+  IVFPQRetrievalParameters *ip = dynamic_cast<IVFPQRetrievalParameters *>(rp);
+  out[0] = ip ? 0 : -1;
+  if (ip) {
+    out[1] = (int)ip->GetDistanceComputeType();
+    out[2] = ip->RecallNum();
+    out[3] = ip->Nprobe();
+  }
+  delete rp;
+}
+int gh_model_registered(const char *name) {
+  RetrievalModel *m = reflector().GetNewModel(name);
+  if (!m) return 0;
+  delete m;
+  return 1;
+}
+
+}  // extern "C"

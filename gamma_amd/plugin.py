@@ -1,0 +1,148 @@
+"""ctypes driver for libgamma_host.so: the RetrievalModel plugins (HIPIVFPQ / HIPFLAT) driven
+the way Gamma's VectorManager drives a model (gamma_amd/host/harness_c_api.cc).
+
+Test/bench convenience only; the product boundary is the C++ RetrievalModel interface in
+gamma_amd/host/retrieval_model.h on top of the C ABI in include/gamma_hip.h.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+
+HOST_LIB_PATH = os.path.join(_lib.HERE, "libgamma_host.so")
+f32p, i64p = _lib.f32p, _lib.i64p
+
+HOST_SYMBOLS = {
+    "gh_host_new": (C.c_void_p, [C.c_char_p, C.c_int]),
+    "gh_host_free": (None, [C.c_void_p]),
+    "gh_host_init": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "gh_host_store": (None, [C.c_void_p, C.c_int, f32p]),
+    "gh_host_indexing": (C.c_int, [C.c_void_p]),
+    "gh_host_add": (C.c_int, [C.c_void_p, C.c_int, f32p]),
+    "gh_host_update": (C.c_int, [C.c_void_p, C.c_int64, f32p]),
+    "gh_host_delete": (C.c_int, [C.c_void_p, i64p, C.c_int]),
+    "gh_host_search": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_float, C.c_float,
+                                 C.c_int, f32p, C.c_int, f32p, i64p]),
+    "gh_host_dump": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "gh_host_load": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "gh_host_mem_bytes": (C.c_long, [C.c_void_p]),
+    "gh_host_ivfpq_state": (C.c_int, [C.c_void_p, f32p, f32p]),
+    "gh_host_ivfpq_set_trained": (C.c_int, [C.c_void_p, f32p, f32p]),
+    "gh_parse_ivfpq_model_params": (None, [C.c_char_p, C.POINTER(C.c_int)]),
+    "gh_parse_ivfpq_retrieval_params": (None, [C.c_char_p, C.POINTER(C.c_int)]),
+    "gh_model_registered": (C.c_int, [C.c_char_p]),
+}
+
+_host = None
+FLT_MIN = float(np.finfo(np.float32).tiny)
+FLT_MAX = float(np.finfo(np.float32).max)
+
+
+def load_host():
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise _lib.GammaHipError("libgamma_host.so not found at %s -- run `make -C gamma_amd/host`"
+                                     % HOST_LIB_PATH)
+        L = C.CDLL(HOST_LIB_PATH)
+        for name, (res, args) in HOST_SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _host = L
+    return _host
+
+
+def _f(a):
+    return a.ctypes.data_as(f32p)
+
+
+def parse_model_params(s):
+    out = (C.c_int * 10)()
+    load_host().gh_parse_ivfpq_model_params(s.encode(), out)
+    keys = ["rc", "ncentroids", "nsubvector", "nbits_per_idx", "nprobe", "metric", "bucket_init_size",
+            "bucket_max_size", "has_hnsw", "has_opq"]
+    return dict(zip(keys, list(out)))
+
+
+def parse_retrieval_params(s):
+    out = (C.c_int * 4)()
+    load_host().gh_parse_ivfpq_retrieval_params(s.encode(), out)
+    return dict(zip(["rc", "metric", "recall_num", "nprobe"], list(out)))
+
+
+class PluginModel:
+    """One RetrievalModel instance plus the in-memory vector store it reads."""
+
+    def __init__(self, retrieval_type, d, retrieval_param="", indexing_size=0):
+        self.L = load_host()
+        self.d = d
+        self.h = self.L.gh_host_new(retrieval_type.encode(), d)
+        if not self.h:
+            raise _lib.GammaHipError("model %r is not registered" % retrieval_type)
+        rc = self.L.gh_host_init(self.h, retrieval_param.encode(), indexing_size)
+        if rc:
+            self.close()
+            raise _lib.GammaHipError("Init(%r) returned %d" % (retrieval_param, rc))
+
+    def close(self):
+        if self.h:
+            self.L.gh_host_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def store(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        self.L.gh_host_store(self.h, x.shape[0], _f(x))
+
+    def indexing(self):
+        return self.L.gh_host_indexing(self.h)
+
+    def add(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        return self.L.gh_host_add(self.h, x.shape[0], _f(x)) == 1
+
+    def update(self, vid, x):
+        x = np.ascontiguousarray(x, np.float32)
+        return self.L.gh_host_update(self.h, vid, _f(x))
+
+    def delete(self, vids):
+        v = np.ascontiguousarray(vids, np.int64)
+        return self.L.gh_host_delete(self.h, v.ctypes.data_as(i64p), v.size)
+
+    def search(self, xq, k, retrieval_params="", has_rank=True, brute_force=False, min_score=FLT_MIN,
+               max_score=FLT_MAX):
+        xq = np.ascontiguousarray(xq, np.float32)
+        n = xq.shape[0]
+        D = np.empty((n, k), np.float32)
+        I = np.empty((n, k), np.int64)
+        rc = self.L.gh_host_search(self.h, retrieval_params.encode(), int(has_rank), int(brute_force),
+                                   min_score, max_score, n, _f(xq), k, _f(D), I.ctypes.data_as(i64p))
+        if rc:
+            raise _lib.GammaHipError("Search returned %d" % rc)
+        return D, I
+
+    def dump(self, d):
+        return self.L.gh_host_dump(self.h, d.encode())
+
+    def load(self, d):
+        return self.L.gh_host_load(self.h, d.encode())
+
+    def mem_bytes(self):
+        return self.L.gh_host_mem_bytes(self.h)
+
+    def set_trained(self, coarse, pq):
+        coarse = np.ascontiguousarray(coarse, np.float32)
+        pq = np.ascontiguousarray(pq, np.float32)
+        return self.L.gh_host_ivfpq_set_trained(self.h, _f(coarse), _f(pq))
+
+    def trained_state(self, nlist, M):
+        cc = np.empty((nlist, self.d), np.float32)
+        pq = np.empty((M, 256, self.d // M), np.float32)
+        if self.L.gh_host_ivfpq_state(self.h, _f(cc), _f(pq)):
+            return None
+        return cc, pq

@@ -127,6 +127,12 @@ int gamma_hip_ivfpq_add(gamma_hip_index* h, int64_t n, const float* vecs, int64_
 int gamma_hip_ivfpq_encode(gamma_hip_index* h, int64_t n, const float* vecs, int64_t* list_nos,
                            uint8_t* codes);
 
+/* Training helper (GammaIVFPQIndex::Indexing -> faiss::Clustering's assignment step,
+ * gamma_index_ivfpq.cc:272-354): nearest of k centroids (squared L2, GEMM form on MFMA) for n
+ * host vectors of dimension d; the Lloyd update stays on the host.  dis may be NULL. */
+int gamma_hip_assign(gamma_hip_index* h, int d, int64_t n, const float* x, int k,
+                     const float* centroids, int32_t* assign, float* dis);
+
 /* ---- search ------------------------------------------------------------------------ */
 /* replaces GammaIVFPQIndex::Search (gamma_index_ivfpq.cc:514-566 + search_preassigned
  * :701-890).  x: nq*d fp32 host; distances/labels: nq*k host, best first, unused slots

@@ -1,0 +1,159 @@
+"""GPU tests of the RetrievalModel plugins (HIPIVFPQ / HIPFLAT) driven like VectorManager drives
+a model: reflector -> Init(json) -> Add -> Indexing -> Parse(json) + Search(GammaSearchCondition).
+Parity against the CPU oracle with the same trained state; end-to-end recall with the plugin's
+own device-side training."""
+import numpy as np
+import pytest
+
+from oracle import binding as B
+from tests import fixtures
+from tests.parity import compare_topk
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def case():
+    return fixtures.trained_case(d=32, nlist=64, M=8, N=20000, nq=64, metric=B.METRIC_L2)
+
+
+def _ivfpq_plugin(case, metric="L2"):
+    from gamma_amd import plugin
+    m = plugin.PluginModel("HIPIVFPQ", case["d"],
+                           '{"ncentroids": %d, "nsubvector": %d, "nprobe": 8, "metric_type": "%s"}'
+                           % (case["nlist"], case["M"], metric), indexing_size=5000)
+    return m
+
+
+def test_ivfpq_plugin_matches_oracle(case):
+    m = _ivfpq_plugin(case)
+    base, q, o = case["base"], case["q"], case["oracle"]
+    m.store(base)
+    assert m.set_trained(case["cc"], case["pq"]) == 0
+    # Add in engine-sized batches (GammaIVFPQIndex::Add, n >= 20 -> faiss BLAS assign rule)
+    B.lib().go_set_assign_mode(1)
+    o2 = B.OracleIVFPQ(case["d"], case["nlist"], case["M"], 8, B.METRIC_L2)
+    o2.set_trained(case["cc"], case["pq"], None)
+    for i0 in range(0, len(base), 5000):
+        assert m.add(base[i0:i0 + 5000])
+        assert o2.add(base[i0:i0 + 5000])
+    B.lib().go_set_assign_mode(0)
+    o2.set_raw(base)
+    for has_rank in (True, False):
+        for n in (len(q), 7):           # nq >= 20 -> GEMM-form coarse, else exact
+            D, I = o2.search(q[:n], 10, 8, recall_num=100, has_rank=has_rank, metric=B.METRIC_L2,
+                             ctx=B.make_ctx(), coarse_mode=-1)
+            Dg, Ig = m.search(q[:n], 10, '{"metric_type": "L2", "recall_num": 100, "nprobe": 8}',
+                              has_rank=has_rank)
+            compare_topk(D, I, Dg, Ig)
+    # retrieval_params "" -> model defaults (nprobe from Init, recall_num 100)
+    D, I = o2.search(q, 10, 8, recall_num=100, has_rank=True, metric=B.METRIC_L2, ctx=B.make_ctx(),
+                     coarse_mode=-1)
+    Dg, Ig = m.search(q, 10, "")
+    compare_topk(D, I, Dg, Ig)
+    # brute_force_search -> flat scan over the raw vectors
+    Df, If = B.flat_search(base, q, 10, B.METRIC_L2, B.make_ctx())
+    Dg, Ig = m.search(q, 10, '{"metric_type": "L2"}', brute_force=True)
+    compare_topk(Df, If, Dg, Ig)
+    # Delete: doc bits set + list entries flagged
+    dead = np.unique(I[:, 0])
+    dead = dead[dead >= 0]
+    assert m.delete(dead) == 0
+    bm = np.zeros((len(base) + 7) // 8, np.uint8)
+    for v in dead:
+        bm[v >> 3] |= 1 << (v & 7)
+    o2.set_docids_bitmap(bm)
+    o2.delete(dead)
+    D, I = o2.search(q, 10, 8, recall_num=100, has_rank=True, metric=B.METRIC_L2,
+                     ctx=B.make_ctx(docids_bitmap=bm), coarse_mode=-1)
+    Dg, Ig = m.search(q, 10, "")
+    compare_topk(D, I, Dg, Ig)
+    assert not np.isin(Ig, dead).any()
+    # Update: re-encode + move
+    vid = int(I[0, 0])
+    newv = base[(vid + 17) % len(base)].copy()
+    assert m.update(vid, newv) == 0
+    base2 = base.copy()
+    base2[vid] = newv
+    o2.set_raw(base2)
+    B.lib().go_set_assign_mode(0)
+    o2.update(vid, newv)
+    D, I = o2.search(q, 10, 8, recall_num=100, has_rank=True, metric=B.METRIC_L2,
+                     ctx=B.make_ctx(docids_bitmap=bm), coarse_mode=-1)
+    Dg, Ig = m.search(q, 10, "")
+    compare_topk(D, I, Dg, Ig)
+    assert m.mem_bytes() > 0
+    m.close()
+
+
+def test_ivfpq_plugin_trains_and_recalls(case, tmp_path):
+    """Indexing() with the plugin's own k-means (device assignment) + Dump/Load round trip."""
+    from gamma_amd import plugin
+    base, q = case["base"], case["q"]
+    m = _ivfpq_plugin(case)
+    m.store(base)
+    # untrained model: Search falls back to brute force (gamma_index_ivfpq.cc:529-537)
+    Df, If = B.flat_search(base, q, 10, B.METRIC_L2, B.make_ctx())
+    Dg, Ig = m.search(q, 10, '{"metric_type": "L2"}')
+    compare_topk(Df, If, Dg, Ig)
+    assert m.indexing() == 0
+    assert m.indexing() == 0          # second call is a no-op
+    assert m.add(base)
+    D1, I1 = m.search(q, 10, '{"metric_type": "L2", "recall_num": 200, "nprobe": 16}')
+    recall = np.mean([len(set(I1[i]) & set(If[i])) / 10.0 for i in range(len(q))])
+    assert recall > 0.8, recall
+    # exact distances of what came back (has_rank re-rank reads the HBM mirror of the store)
+    for i in range(0, len(q), 9):
+        assert (I1[i] >= 0).all()
+        De, _ = B.flat_search(base[I1[i]], q[i:i + 1], 10, B.METRIC_L2, B.make_ctx())
+        assert De[0].tobytes() == D1[i].tobytes()
+    cc, pq = m.trained_state(case["nlist"], case["M"])
+    assert m.dump(str(tmp_path)) == 0
+    m2 = _ivfpq_plugin(case)
+    m2.store(base)
+    assert m2.load(str(tmp_path)) == len(base)
+    cc2, pq2 = m2.trained_state(case["nlist"], case["M"])
+    assert cc.tobytes() == cc2.tobytes() and pq.tobytes() == pq2.tobytes()
+    D2, I2 = m2.search(q, 10, '{"metric_type": "L2", "recall_num": 200, "nprobe": 16}')
+    assert D1.tobytes() == D2.tobytes() and np.array_equal(I1, I2)
+    m.close()
+    m2.close()
+
+
+def test_ivfpq_plugin_rejects_unsupported(case):
+    from gamma_amd import _lib, plugin
+    with pytest.raises(_lib.GammaHipError):
+        plugin.PluginModel("HIPIVFPQ", 32, '{"ncentroids": 64, "nsubvector": 8, "hnsw": {"nlinks": 32}}')
+    with pytest.raises(_lib.GammaHipError):
+        plugin.PluginModel("HIPIVFPQ", 30, '{"ncentroids": 64, "nsubvector": 8}')   # 30 % 8 != 0
+    with pytest.raises(_lib.GammaHipError):
+        plugin.PluginModel("HIPIVFPQ", 32, '{"nsubvector": 8}')
+
+
+@pytest.mark.parametrize("metric", ["L2", "InnerProduct"])
+def test_flat_plugin_matches_oracle(case, metric):
+    from gamma_amd import plugin
+    base, q = case["base"][:7000], case["q"]
+    mt = B.METRIC_L2 if metric == "L2" else B.METRIC_IP
+    m = plugin.PluginModel("HIPFLAT", case["d"], '{"metric_type": "%s"}' % metric)
+    m.store(base)
+    for i0 in range(0, len(base), 3000):
+        assert m.add(base[i0:i0 + 3000])
+    Df, If = B.flat_search(base, q, 10, mt, B.make_ctx())
+    Dg, Ig = m.search(q, 10, "")
+    compare_topk(Df, If, Dg, Ig)
+    dead = np.unique(If[:, :2])
+    assert m.delete(dead) == 0
+    bm = np.zeros((len(base) + 7) // 8, np.uint8)
+    for v in dead:
+        bm[v >> 3] |= 1 << (v & 7)
+    Df, If = B.flat_search(base, q, 10, mt, B.make_ctx(docids_bitmap=bm))
+    Dg, Ig = m.search(q, 10, '{"metric_type": "%s"}' % metric)
+    compare_topk(Df, If, Dg, Ig)
+    # score window (GammaSearchCondition::IsSimilarScoreValid)
+    lo, hi = float(np.median(Df[:, 2])), float(np.median(Df[:, 8]))
+    lo, hi = min(lo, hi), max(lo, hi)
+    Df, If = B.flat_search(base, q, 10, mt, B.make_ctx(docids_bitmap=bm, min_score=lo, max_score=hi))
+    Dg, Ig = m.search(q, 10, "", min_score=lo, max_score=hi)
+    compare_topk(Df, If, Dg, Ig)
+    m.close()
