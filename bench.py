@@ -182,6 +182,17 @@ def main():
               ("coarse", "tables", "scan", "select", "rerank") if prof[n][1]}
     log("stage avg us per launch:", stages, "scan bytes/launch %.0f" % bytes_per_launch)
 
+    # host-buffer entry point (what the RetrievalModel boundary hands over): H2D queries + D2H
+    # results included.  Reported for DESIGN.md; never `value`.
+    host_qps = None
+    if world == 1:
+        qh = queries[:a.nq]
+        g.ivfpq_search(qh, k, args)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            g.ivfpq_search(qh, k, args)
+        host_qps = 5 * a.nq / (time.perf_counter() - t1)
+
     cpu = None
     if world == 1 and a.cpu_seconds > 0:
         cpu = cpu_baseline(a, base, queries, cc, pq, g, lno, codes, list_sizes)
@@ -206,6 +217,7 @@ def main():
             "recall_at_10": None if recall is None else round(recall, 4),
             "parallelism": "list-shard x%d + RCCL all-gather" % world if world > 1 else "single GPU",
             "stage_us": stages,
+            "pcie_inclusive_qps": None if host_qps is None else round(host_qps, 1),
         },
         "roofline": {
             "bound": "hbm",

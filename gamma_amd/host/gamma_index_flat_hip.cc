@@ -1,6 +1,8 @@
 // GammaFLATHIPIndex -- see gamma_index_flat_hip.h
 #include "gamma_index_flat_hip.h"
 
+#include "filter_bridge.h"
+
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -96,21 +98,7 @@ int GammaFLATHIPIndex::Search(RetrievalContext *retrieval_context, int n, const 
   p.min_score = cond ? cond->min_score : std::numeric_limits<float>::min();
   p.max_score = cond ? cond->max_score : std::numeric_limits<float>::max();
   std::vector<gamma_hip_range_filter> rf;
-  if (cond && cond->range_query_result) {
-    p.has_range = 1;
-    for (auto &r : cond->range_query_result->GetAllResult()) {
-      gamma_hip_range_filter f;
-      f.bitmap = reinterpret_cast<const uint8_t *>(r.bitmap_);
-      f.bitmap_bytes = r.bytes_;
-      f.min_doc = r.min_;
-      f.max_doc = r.max_;
-      f.min_aligned = r.min_aligned_;
-      f.b_not_in = r.b_not_in_ ? 1 : 0;
-      rf.push_back(f);
-    }
-    p.n_range = (int)rf.size();
-    p.range = rf.data();
-  }
+  FillRangeFilters(cond, p, rf);
   return gamma_hip_flat_search(h_, &p, n, reinterpret_cast<const float *>(x), k, distances, ids);
 }
 

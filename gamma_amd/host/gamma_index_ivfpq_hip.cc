@@ -2,6 +2,8 @@
 // training driver, bookkeeping; every distance / scan / selection runs in libgamma_hip.so.
 #include "gamma_index_ivfpq_hip.h"
 
+#include "filter_bridge.h"
+
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -301,21 +303,7 @@ int GammaIVFPQHIPIndex::Search(RetrievalContext *retrieval_context, int n, const
   p.max_score = cond ? cond->max_score : std::numeric_limits<float>::max();
   p.coarse_mode = -1;
   std::vector<gamma_hip_range_filter> rf;
-  if (cond && cond->range_query_result) {
-    p.has_range = 1;
-    for (auto &r : cond->range_query_result->GetAllResult()) {
-      gamma_hip_range_filter f;
-      f.bitmap = reinterpret_cast<const uint8_t *>(r.bitmap_);
-      f.bitmap_bytes = r.bytes_;
-      f.min_doc = r.min_;
-      f.max_doc = r.max_;
-      f.min_aligned = r.min_aligned_;
-      f.b_not_in = r.b_not_in_ ? 1 : 0;
-      rf.push_back(f);
-    }
-    p.n_range = (int)rf.size();
-    p.range = rf.data();
-  }
+  FillRangeFilters(cond, p, rf);
   const float *xq = reinterpret_cast<const float *>(x);
   int rc;
   if ((cond && cond->brute_force_search) || !is_trained_) {

@@ -11,8 +11,7 @@
 #include <vector>
 
 #include "../../include/gamma_hip.h"
-#include "json_lite.h"
-#include "retrieval_model.h"
+#include "plugin_includes.h"
 
 namespace tig_gamma {
 

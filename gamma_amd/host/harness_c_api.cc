@@ -91,6 +91,41 @@ int gh_host_search(void *hp, const char *retrieval_params, int has_rank, int bru
   if (!cond.retrieval_params_) return -100;
   return h->model->Search(&cond, n, reinterpret_cast<const uint8_t *>(x), k, distances, ids);
 }
+// Search with a scalar filter: range clause i matches docids[off_i .. off_i+counts[i]) (not_in[i]
+// inverts it); the MultiRangeQueryResults is built the way field_range_index.cc fills one
+// (SetRange over the matching ids, Resize, Set(doc - MinAligned)).
+int gh_host_search_filtered(void *hp, const char *retrieval_params, int has_rank, int brute_force,
+                            float min_score, float max_score, int n, const float *x, int k, float *distances,
+                            int64_t *ids, int n_range, const int64_t *docids, const int *counts,
+                            const int *not_in) {
+  Host *h = (Host *)hp;
+  PerfTool perf;
+  GammaSearchCondition cond(&perf);
+  MultiRangeQueryResults mr;
+  size_t off = 0;
+  for (int i = 0; i < n_range; i++) {
+    RangeQueryResult r;
+    if (counts[i] > 0) {
+      for (int j = 0; j < counts[i]; j++) r.SetRange((int)docids[off + j], (int)docids[off + j]);
+    } else {
+      r.SetRange(0, 0);
+    }
+    r.Resize();
+    for (int j = 0; j < counts[i]; j++) r.Set((int)docids[off + j] - r.MinAligned());
+    r.SetNotIn(not_in[i] != 0);
+    off += counts[i];
+    mr.Add(std::move(r));
+  }
+  cond.range_query_result = &mr;
+  cond.topn = k;
+  cond.has_rank = has_rank != 0;
+  cond.brute_force_search = brute_force != 0;
+  cond.min_score = min_score;
+  cond.max_score = max_score;
+  cond.retrieval_params_ = h->model->Parse(retrieval_params);
+  if (!cond.retrieval_params_) return -100;
+  return h->model->Search(&cond, n, reinterpret_cast<const uint8_t *>(x), k, distances, ids);
+}
 int gh_host_dump(void *hp, const char *dir) { return ((Host *)hp)->model->Dump(dir); }
 int gh_host_load(void *hp, const char *dir) { return ((Host *)hp)->model->Load(dir); }
 long gh_host_mem_bytes(void *hp) { return ((Host *)hp)->model->GetTotalMemBytes(); }

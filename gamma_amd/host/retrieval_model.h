@@ -13,7 +13,9 @@
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
+#include <algorithm>
 #include <deque>
 #include <iostream>
 #include <limits>
@@ -215,7 +217,16 @@ namespace tig_gamma {
 
 class RangeQueryResult {
  public:
-  RangeQueryResult() : min_(0), max_(0), min_aligned_(0), bitmap_(nullptr), bytes_(0), b_not_in_(false) {}
+  RangeQueryResult() : min_(std::numeric_limits<int>::max()), max_(0), min_aligned_(0), max_aligned_(0),
+                       bitmap_(nullptr), b_not_in_(false) {}
+  RangeQueryResult(RangeQueryResult &&o) { bitmap_ = nullptr; *this = std::move(o); }
+  RangeQueryResult &operator=(RangeQueryResult &&o) {
+    min_ = o.min_; max_ = o.max_; min_aligned_ = o.min_aligned_; max_aligned_ = o.max_aligned_;
+    free(bitmap_);
+    bitmap_ = o.bitmap_; o.bitmap_ = nullptr; b_not_in_ = o.b_not_in_;
+    return *this;
+  }
+  ~RangeQueryResult() { free(bitmap_); }
   bool Has(int doc) const {
     if (b_not_in_) {
       if (doc < min_ || doc > max_) return true;
@@ -226,14 +237,29 @@ class RangeQueryResult {
     doc -= min_aligned_;
     return (bitmap_[doc >> 3] >> (doc & 7)) & 1;
   }
+  void SetRange(int x, int y) {
+    min_ = std::min(min_, x);
+    max_ = std::max(max_, y);
+    min_aligned_ = (min_ / 8) * 8;
+    max_aligned_ = (max_ / 8 + 1) * 8 - 1;
+  }
+  void Resize() {   // bitmap::create: (n >> 3) + 1 zeroed bytes (util/bitmap.cc:15-23)
+    int n = max_aligned_ - min_aligned_ + 1;
+    free(bitmap_);
+    bitmap_ = (char *)calloc((n >> 3) + 1, 1);
+  }
+  void Set(int pos) { bitmap_[pos >> 3] |= (char)(1 << (pos & 7)); }
   int Min() const { return min_; }
   int Max() const { return max_; }
   int MinAligned() { return min_aligned_; }
+  int MaxAligned() { return max_aligned_; }
   char *&Ref() { return bitmap_; }
+  void SetNotIn(bool b) { b_not_in_ = b; }
   bool NotIn() { return b_not_in_; }
-  int min_, max_, min_aligned_;
-  char *bitmap_;   // not owned in this mirror
-  int64_t bytes_;
+
+ private:
+  int min_, max_, min_aligned_, max_aligned_;
+  char *bitmap_;
   bool b_not_in_;
 };
 
@@ -246,7 +272,10 @@ class MultiRangeQueryResults {
     return true;
   }
   size_t Size() { return all_results_.size(); }
-  const std::vector<RangeQueryResult> &GetAllResult() const { return all_results_; }
+  void Add(RangeQueryResult &&result) { all_results_.emplace_back(std::move(result)); }
+  const RangeQueryResult *GetAllResult() const { return &all_results_[0]; }
+
+ private:
   std::vector<RangeQueryResult> all_results_;
 };
 

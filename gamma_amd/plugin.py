@@ -25,6 +25,9 @@ HOST_SYMBOLS = {
     "gh_host_delete": (C.c_int, [C.c_void_p, i64p, C.c_int]),
     "gh_host_search": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_float, C.c_float,
                                  C.c_int, f32p, C.c_int, f32p, i64p]),
+    "gh_host_search_filtered": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_float, C.c_float,
+                                          C.c_int, f32p, C.c_int, f32p, i64p, C.c_int, i64p,
+                                          C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gh_host_dump": (C.c_int, [C.c_void_p, C.c_char_p]),
     "gh_host_load": (C.c_int, [C.c_void_p, C.c_char_p]),
     "gh_host_mem_bytes": (C.c_long, [C.c_void_p]),
@@ -115,11 +118,23 @@ class PluginModel:
         return self.L.gh_host_delete(self.h, v.ctypes.data_as(i64p), v.size)
 
     def search(self, xq, k, retrieval_params="", has_rank=True, brute_force=False, min_score=FLT_MIN,
-               max_score=FLT_MAX):
+               max_score=FLT_MAX, range_filters=None):
+        """range_filters: None, or a list of (matching docids, not_in) clauses (AND-ed)."""
         xq = np.ascontiguousarray(xq, np.float32)
         n = xq.shape[0]
         D = np.empty((n, k), np.float32)
         I = np.empty((n, k), np.int64)
+        if range_filters is not None:
+            docs = [np.unique(np.asarray(d, np.int64)) for d, _ in range_filters]
+            flat = np.ascontiguousarray(np.concatenate(docs) if docs else np.zeros(0, np.int64))
+            counts = (C.c_int * max(1, len(docs)))(*[len(d) for d in docs])
+            notin = (C.c_int * max(1, len(docs)))(*[int(bool(ni)) for _, ni in range_filters])
+            rc = self.L.gh_host_search_filtered(
+                self.h, retrieval_params.encode(), int(has_rank), int(brute_force), min_score, max_score, n,
+                _f(xq), k, _f(D), I.ctypes.data_as(i64p), len(docs), flat.ctypes.data_as(i64p), counts, notin)
+            if rc:
+                raise _lib.GammaHipError("Search returned %d" % rc)
+            return D, I
         rc = self.L.gh_host_search(self.h, retrieval_params.encode(), int(has_rank), int(brute_force),
                                    min_score, max_score, n, _f(xq), k, _f(D), I.ctypes.data_as(i64p))
         if rc:

@@ -157,3 +157,35 @@ def test_flat_plugin_matches_oracle(case, metric):
     Dg, Ig = m.search(q, 10, "", min_score=lo, max_score=hi)
     compare_topk(Df, If, Dg, Ig)
     m.close()
+
+
+def test_plugin_range_filters(case):
+    """GammaSearchCondition::range_query_result -> gamma_hip_range_filter[] (filter_bridge.h)."""
+    m = _ivfpq_plugin(case)
+    base, q = case["base"], case["q"]
+    m.store(base)
+    assert m.set_trained(case["cc"], case["pq"]) == 0
+    B.lib().go_set_assign_mode(1)
+    o2 = B.OracleIVFPQ(case["d"], case["nlist"], case["M"], 8, B.METRIC_L2)
+    o2.set_trained(case["cc"], case["pq"], None)
+    assert m.add(base) and o2.add(base)
+    B.lib().go_set_assign_mode(0)
+    o2.set_raw(base)
+    rng = np.random.RandomState(5)
+    N = len(base)
+    clauses = [
+        [(rng.choice(N, N // 2, replace=False), False)],
+        [(np.arange(1000, 9000), False), (rng.choice(N, N // 3, replace=False), True)],
+        [(np.zeros(0, np.int64), False)],                        # empty clause: nothing matches
+        [],                                                      # zero clauses: Has() == false
+    ]
+    for cl in clauses:
+        rfs = [B.make_range_filter(d, b_not_in=ni) for d, ni in cl]
+        ctx = B.make_ctx(range_filters=rfs)
+        D, I = o2.search(q, 10, 8, recall_num=100, has_rank=True, metric=B.METRIC_L2, ctx=ctx, coarse_mode=-1)
+        Dg, Ig = m.search(q, 10, "", range_filters=cl)
+        compare_topk(D, I, Dg, Ig)
+        Df, If = B.flat_search(base, q[:16], 10, B.METRIC_L2, ctx)
+        Dg, Ig = m.search(q[:16], 10, "", brute_force=True, range_filters=cl)
+        compare_topk(Df, If, Dg, Ig)
+    m.close()
