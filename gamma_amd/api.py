@@ -248,6 +248,15 @@ class GammaHip:
         self._ck(self.L.gamma_hip_ivfpq_search_shard(self.h, args.ref(), nq, d_x, k, d_rdis, d_rids),
                  "ivfpq_search_shard")
 
+    def ivfpq_coarse_device(self, d_x, nq, args, d_cdis, d_probe):
+        self._ck(self.L.gamma_hip_ivfpq_coarse_device(self.h, args.ref(), nq, d_x, d_cdis, d_probe),
+                 "ivfpq_coarse_device")
+
+    def ivfpq_search_shard_preassigned(self, d_x, nq, d_cdis, d_probe, k, args, d_rdis, d_rids):
+        self._ck(self.L.gamma_hip_ivfpq_search_shard_preassigned(self.h, args.ref(), nq, d_x, d_cdis,
+                                                                  d_probe, k, d_rdis, d_rids),
+                 "ivfpq_search_shard_preassigned")
+
     def ivfpq_merge_rerank(self, nshards, nq, d_x, k, args, d_all_dis, d_all_ids, q0, nq_local, d_D, d_I):
         self._ck(self.L.gamma_hip_ivfpq_merge_rerank(self.h, args.ref(), nshards, nq, d_x, k, d_all_dis,
                                                      d_all_ids, q0, nq_local, d_D, d_I), "merge_rerank")

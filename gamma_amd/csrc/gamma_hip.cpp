@@ -84,6 +84,8 @@ struct gamma_hip_index {
     int d = 0, nlist = 0, M = 0, ksub = 256, dsub = 0, code_size = 0, metric = GAMMA_HIP_METRIC_L2;
     int bucket_init = 1000, bucket_max = 1280000;
     float *d_cc = nullptr, *d_cc_norms = nullptr, *d_pqc = nullptr, *d_T2 = nullptr;
+    int* d_list_rank = nullptr;   // spatial order of the coarse centroids (scan locality only)
+    bool sort_queries = getenv("GAMMA_HIP_NO_QUERY_SORT") == nullptr;
 
     // inverted-list arena
     uint8_t* d_codes = nullptr;
@@ -103,7 +105,7 @@ struct gamma_hip_index {
     // workspace
     DevBuf w_mat, w_coarse_dis, w_probe, w_xn, w_st2, w_pair_off, w_qtotal, w_dist, w_cand_dis,
             w_cand_pos, w_cand_ids, w_exact, w_selv, w_selp, w_x, w_outd, w_outl, w_stage, w_filter,
-            w_m_dis, w_m_ids, w_part_v, w_part_i, w_assign, w_codes_tmp;
+            w_m_dis, w_m_ids, w_part_v, w_part_i, w_assign, w_codes_tmp, w_qperm;
     unsigned long long* d_scan_codes = nullptr;
     size_t dist_budget_bytes = (size_t)2 << 30;
     // EXPERIMENTAL fused scan+select kernel (qscan.hip): parity-green but, at one workgroup
@@ -298,6 +300,66 @@ int build_filter(H* h, const gamma_hip_search_params* p, gh::FilterDesc* f) {
     return GAMMA_HIP_OK;
 }
 
+// Spatial order of the coarse centroids by recursive principal-axis bisection: split the set at
+// the median of its projection on the dominant direction (a few power iterations), recurse.
+// Neighbouring ranks = neighbouring centroids.  Used only to order queries for cache locality.
+void centroid_order_rec(const float* cc, int d, std::vector<int>& idx, int lo, int hi, std::vector<float>& proj,
+                        std::vector<double>& mean, std::vector<double>& dir, std::vector<double>& tmp) {
+    const int n = hi - lo;
+    if (n <= 2) return;
+    for (int t = 0; t < d; t++) mean[t] = 0;
+    for (int i = lo; i < hi; i++) {
+        const float* c = cc + (size_t)idx[i] * d;
+        for (int t = 0; t < d; t++) mean[t] += c[t];
+    }
+    for (int t = 0; t < d; t++) mean[t] /= n;
+    // start from the direction to the point farthest from the mean (never orthogonal to the data)
+    double best = -1;
+    int far = lo;
+    for (int i = lo; i < hi; i++) {
+        const float* c = cc + (size_t)idx[i] * d;
+        double s = 0;
+        for (int t = 0; t < d; t++) s += (c[t] - mean[t]) * (c[t] - mean[t]);
+        if (s > best) { best = s; far = i; }
+    }
+    for (int t = 0; t < d; t++) dir[t] = cc[(size_t)idx[far] * d + t] - mean[t];
+    for (int it = 0; it < 6; it++) {
+        for (int t = 0; t < d; t++) tmp[t] = 0;
+        for (int i = lo; i < hi; i++) {
+            const float* c = cc + (size_t)idx[i] * d;
+            double pr = 0;
+            for (int t = 0; t < d; t++) pr += (c[t] - mean[t]) * dir[t];
+            for (int t = 0; t < d; t++) tmp[t] += pr * (c[t] - mean[t]);
+        }
+        double nrm = 0;
+        for (int t = 0; t < d; t++) nrm += tmp[t] * tmp[t];
+        if (nrm <= 0) break;
+        nrm = std::sqrt(nrm);
+        for (int t = 0; t < d; t++) dir[t] = tmp[t] / nrm;
+    }
+    for (int i = lo; i < hi; i++) {
+        const float* c = cc + (size_t)idx[i] * d;
+        double pr = 0;
+        for (int t = 0; t < d; t++) pr += (c[t] - mean[t]) * dir[t];
+        proj[idx[i]] = (float)pr;
+    }
+    const int mid = lo + n / 2;
+    std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi,
+                     [&](int a, int b) { return proj[a] < proj[b] || (proj[a] == proj[b] && a < b); });
+    centroid_order_rec(cc, d, idx, lo, mid, proj, mean, dir, tmp);
+    centroid_order_rec(cc, d, idx, mid, hi, proj, mean, dir, tmp);
+}
+
+std::vector<int> centroid_rank(const float* cc, int nlist, int d) {
+    std::vector<int> idx(nlist), rank(nlist);
+    for (int i = 0; i < nlist; i++) idx[i] = i;
+    std::vector<float> proj(nlist);
+    std::vector<double> mean(d), dir(d), tmp(d);
+    centroid_order_rec(cc, d, idx, 0, nlist, proj, mean, dir, tmp);
+    for (int i = 0; i < nlist; i++) rank[idx[i]] = i;
+    return rank;
+}
+
 int check_params(H* h, const gamma_hip_search_params* p, int nq, int k) {
     if (!p) return fail(h, GAMMA_HIP_EINVAL, "null params");
     if (nq < 0) return fail(h, GAMMA_HIP_EINVAL, "nq < 0");
@@ -309,12 +371,34 @@ int check_params(H* h, const gamma_hip_search_params* p, int nq, int k) {
 
 // ---- IVFPQ stage A: coarse + tables + scan + top-R + ids ------------------------------
 // results: w_cand_dis [nq*R] (ADC distance, best first, sentinel pad), w_cand_ids [nq*R]
+int ivfpq_coarse(H* h, const gamma_hip_search_params* p, int nq, const float* d_x) {
+    const int P = p->nprobe, d = h->d, nlist = h->nlist;
+    hipStream_t s = h->stream;
+    GH_CHECK(h, h->w_mat.ensure((size_t)nq * nlist * sizeof(float)));
+    GH_CHECK(h, h->w_coarse_dis.ensure((size_t)nq * P * sizeof(float)));
+    GH_CHECK(h, h->w_probe.ensure((size_t)nq * P * sizeof(int)));
+    int mode = p->coarse_mode;
+    if (mode < 0) mode = nq < 20 ? 0 : 1;  // faiss:utils/distances.cpp:303,346
+    StageScope t(h, GAMMA_HIP_STAGE_COARSE);
+    if (mode == 0) {
+        gh::launch_pairwise(s, true, d_x, nq, d, h->d_cc, nlist, h->w_mat.as<float>(), nlist);
+    } else {
+        // query norms are fused into the MFMA kernel (xn = nullptr)
+        gh::launch_l2_gemmform(s, d_x, nq, d, h->d_cc, nlist, nullptr, h->d_cc_norms,
+                               h->w_mat.as<float>(), nlist, true);
+    }
+    gh::launch_select_topk(s, true, h->w_mat.as<float>(), nlist, nullptr, nlist, nlist, nq, P,
+                           h->w_coarse_dis.as<float>(), h->w_probe.as<int>());
+    return GAMMA_HIP_OK;
+}
+
+// pre_dis / pre_probe: coarse assignment computed elsewhere (sharded search: the rank owning the
+// query slice), device pointers [nq*nprobe]; nullptr = run the coarse quantizer here
 int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& filt, int nq,
-                  const float* d_x, int R) {
+                  const float* d_x, int R, const float* pre_dis = nullptr, const int* pre_probe = nullptr) {
     const int P = p->nprobe, d = h->d, M = h->M, nlist = h->nlist;
     const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
     hipStream_t s = h->stream;
-    GH_CHECK(h, h->w_mat.ensure((size_t)nq * nlist * sizeof(float)));
     GH_CHECK(h, h->w_coarse_dis.ensure((size_t)nq * P * sizeof(float)));
     GH_CHECK(h, h->w_probe.ensure((size_t)nq * P * sizeof(int)));
     GH_CHECK(h, h->w_st2.ensure((size_t)nq * M * 256 * sizeof(float)));
@@ -323,19 +407,13 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
     GH_CHECK(h, h->w_cand_dis.ensure((size_t)nq * R * sizeof(float)));
     GH_CHECK(h, h->w_cand_pos.ensure((size_t)nq * R * sizeof(int)));
     GH_CHECK(h, h->w_cand_ids.ensure((size_t)nq * R * sizeof(int64_t)));
-    int mode = p->coarse_mode;
-    if (mode < 0) mode = nq < 20 ? 0 : 1;  // faiss:utils/distances.cpp:303,346
-    {
-        StageScope t(h, GAMMA_HIP_STAGE_COARSE);
-        if (mode == 0) {
-            gh::launch_pairwise(s, true, d_x, nq, d, h->d_cc, nlist, h->w_mat.as<float>(), nlist);
-        } else {
-            // query norms are fused into the MFMA kernel (xn = nullptr)
-            gh::launch_l2_gemmform(s, d_x, nq, d, h->d_cc, nlist, nullptr, h->d_cc_norms,
-                                   h->w_mat.as<float>(), nlist, true);
-        }
-        gh::launch_select_topk(s, true, h->w_mat.as<float>(), nlist, nullptr, nlist, nlist, nq, P,
-                               h->w_coarse_dis.as<float>(), h->w_probe.as<int>());
+    if (pre_dis && pre_probe) {
+        GH_CHECK(h, hipMemcpyAsync(h->w_coarse_dis.p, pre_dis, (size_t)nq * P * sizeof(float),
+                                   hipMemcpyDeviceToDevice, s));
+        GH_CHECK(h, hipMemcpyAsync(h->w_probe.p, pre_probe, (size_t)nq * P * sizeof(int),
+                                   hipMemcpyDeviceToDevice, s));
+    } else {
+        GH_TRY(ivfpq_coarse(h, p, nq, d_x));
     }
     h->scan_pairs += (int64_t)nq * P;
     // ids are only read during the scan when something can reject an entry: a delete bit,
@@ -381,12 +459,20 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
         GH_CHECK(h, hipGetLastError());
         return GAMMA_HIP_OK;
     }
+    const int* qperm = nullptr;
     {
         StageScope t(h, GAMMA_HIP_STAGE_TABLES);
         gh::launch_pq_ip_table(s, d_x, nq, d, M, h->d_pqc, h->w_st2.as<float>());
         gh::launch_pair_offsets(s, h->w_probe.as<int>(), nq, P, h->d_list_len, h->d_list_mask, nlist,
                                 h->w_pair_off.as<int>(), h->w_qtotal.as<int>(),
                                 h->profile ? h->d_scan_codes : nullptr);
+        // enough queries that L2 capacity matters: run them in spatial order (kernels.hip)
+        if (h->sort_queries && h->d_list_rank && nq >= 256) {
+            GH_CHECK(h, h->w_qperm.ensure((size_t)2 * nq * sizeof(int)));
+            gh::launch_query_order(s, h->w_probe.as<int>(), nq, P, h->d_list_rank, nlist,
+                                   h->w_qperm.as<int>() + nq, h->w_qperm.as<int>());
+            qperm = h->w_qperm.as<int>();
+        }
     }
     // per-query slab of the distance buffer; multiple of 4 floats so rows are 16-byte aligned
     const int64_t q_stride = (std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len)) + 3) & ~(int64_t)3;
@@ -397,7 +483,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
                                    h->w_coarse_dis.as<float>(), h->d_cc, h->w_st2.as<float>(), h->d_T2,
                                    h->d_list_off, h->d_list_len, h->d_list_mask, nlist, h->d_codes,
                                    h->d_ids, h->w_pair_off.as<int>(), q_stride, h->w_dist.as<float>(),
-                                   filt, need_ids);
+                                   filt, need_ids, qperm);
     }
     {
         StageScope t(h, GAMMA_HIP_STAGE_SELECT);
@@ -623,7 +709,7 @@ int gamma_hip_destroy(gamma_hip_index* h) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
     }
-    void* ptrs[] = {h->d_raw, h->d_bitmap, h->d_cc, h->d_cc_norms, h->d_pqc, h->d_T2, h->d_codes,
+    void* ptrs[] = {h->d_list_rank, h->d_raw, h->d_bitmap, h->d_cc, h->d_cc_norms, h->d_pqc, h->d_T2, h->d_codes,
                     h->d_ids, h->d_list_off, h->d_list_len, h->d_list_mask, h->d_scan_codes};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -631,7 +717,7 @@ int gamma_hip_destroy(gamma_hip_index* h) {
                       &h->w_qtotal, &h->w_dist, &h->w_cand_dis, &h->w_cand_pos, &h->w_cand_ids,
                       &h->w_exact, &h->w_selv, &h->w_selp, &h->w_x, &h->w_outd, &h->w_outl, &h->w_stage,
                       &h->w_filter, &h->w_m_dis, &h->w_m_ids, &h->w_part_v, &h->w_part_i, &h->w_assign,
-                      &h->w_codes_tmp};
+                      &h->w_codes_tmp, &h->w_qperm};
     for (DevBuf* b : bufs) b->release();
     (void)hipStreamDestroy(h->stream);
     delete h;
@@ -821,6 +907,13 @@ int gamma_hip_ivfpq_set_trained(gamma_hip_index* h, const float* cc, const float
         GH_CHECK(h, hipMemcpyAsync(h->d_T2, table, nt * sizeof(float), hipMemcpyHostToDevice, h->stream));
     else
         gh::launch_precompute_table(h->stream, h->d_cc, h->nlist, h->d, h->M, h->d_pqc, h->d_T2);
+    {
+        std::vector<int> rank = centroid_rank(cc, h->nlist, h->d);
+        if (!h->d_list_rank) GH_CHECK(h, hipMalloc((void**)&h->d_list_rank, (size_t)h->nlist * sizeof(int)));
+        GH_CHECK(h, hipMemcpyAsync(h->d_list_rank, rank.data(), (size_t)h->nlist * sizeof(int),
+                                   hipMemcpyHostToDevice, h->stream));
+        GH_CHECK(h, hipStreamSynchronize(h->stream));   // rank is a local
+    }
     GH_CHECK(h, hipGetLastError());
     GH_CHECK(h, hipStreamSynchronize(h->stream));
     h->trained = true;
@@ -1179,6 +1272,53 @@ int gamma_hip_ivfpq_search_shard(gamma_hip_index* h, const gamma_hip_search_para
         h->last_nq = nc;
     }
     h->last_P = p->nprobe;
+    h->last_R = R;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_coarse_device(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
+                                  const float* d_x, float* d_coarse_dis, int32_t* d_probe) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    GH_TRY(ivfpq_check(h, p, nq, 1));
+    if (nq == 0) return GAMMA_HIP_OK;
+    if (!d_x || !d_coarse_dis || !d_probe) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
+    GH_CHECK(h, hipSetDevice(h->device));
+    const int P = p->nprobe;
+    const int chunk = query_chunk(h, nq, P);
+    for (int q0 = 0; q0 < nq; q0 += chunk) {
+        const int nc = std::min(chunk, nq - q0);
+        GH_TRY(ivfpq_coarse(h, p, nc, d_x + (size_t)q0 * h->d));
+        GH_CHECK(h, hipMemcpyAsync(d_coarse_dis + (size_t)q0 * P, h->w_coarse_dis.p, (size_t)nc * P * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        GH_CHECK(h, hipMemcpyAsync(d_probe + (size_t)q0 * P, h->w_probe.p, (size_t)nc * P * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+    }
+    GH_CHECK(h, hipGetLastError());
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_search_shard_preassigned(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
+                                             const float* d_x, const float* d_coarse_dis,
+                                             const int32_t* d_probe, int k, float* d_recall_dis,
+                                             int64_t* d_recall_ids) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    GH_TRY(ivfpq_check(h, p, nq, k));
+    if (k <= 0 || nq == 0) return GAMMA_HIP_OK;
+    if (!d_coarse_dis || !d_probe) return fail(h, GAMMA_HIP_EINVAL, "null coarse assignment");
+    GH_CHECK(h, hipSetDevice(h->device));
+    const int R = std::max(p->recall_num, k), P = p->nprobe;
+    gh::FilterDesc filt;
+    GH_TRY(build_filter(h, p, &filt));
+    const int chunk = query_chunk(h, nq, P);
+    for (int q0 = 0; q0 < nq; q0 += chunk) {
+        const int nc = std::min(chunk, nq - q0);
+        GH_TRY(ivfpq_stage_a(h, p, filt, nc, d_x + (size_t)q0 * h->d, R, d_coarse_dis + (size_t)q0 * P,
+                             d_probe + (size_t)q0 * P));
+        GH_CHECK(h, hipMemcpyAsync(d_recall_dis + (size_t)q0 * R, h->w_cand_dis.p, (size_t)nc * R * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        GH_CHECK(h, hipMemcpyAsync(d_recall_ids + (size_t)q0 * R, h->w_cand_ids.p, (size_t)nc * R * sizeof(int64_t), hipMemcpyDeviceToDevice, h->stream));
+        h->last_nq = nc;
+    }
+    h->last_P = P;
     h->last_R = R;
     return GAMMA_HIP_OK;
 }

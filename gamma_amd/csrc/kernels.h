@@ -44,7 +44,10 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
                             const float* st2, const float* T2, const int64_t* list_off,
                             const int* list_len, const uint8_t* list_mask, int nlist,
                             const uint8_t* codes, const int64_t* ids, const int* pair_off,
-                            int64_t q_stride, float* out, const FilterDesc& filt, int need_ids);
+                            int64_t q_stride, float* out, const FilterDesc& filt, int need_ids,
+                            const int* qperm);
+void launch_query_order(hipStream_t s, const int* probe_list, int nq, int P, const int* list_rank,
+                        int nlist, int* qkey, int* qperm);
 void launch_sum_totals(hipStream_t s, const int* q_total, int nq, unsigned long long* acc);
 // fused scan + select (qscan.hip)
 bool qscan_supported(int d, int M, int R, int P);

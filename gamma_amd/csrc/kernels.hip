@@ -437,6 +437,84 @@ void launch_sum_totals(hipStream_t s, const int* q_total, int nq, unsigned long 
 }
 
 // ------------------------------------------------------------------------------------
+// Query order for the scan (speed only, results do not depend on it): counting sort of the
+// queries by list_rank[nearest list] scaled to QO_BINS bins.  list_rank is a spatial order
+// of the coarse centroids (recursive principal-axis bisection, host side).  One workgroup;
+// keys are fetched QO_BATCH at a time so the strided loads overlap.
+// ------------------------------------------------------------------------------------
+constexpr int QO_BINS = 4096, QO_BATCH = 8;
+__global__ __launch_bounds__(1024) void k_query_order(const int* __restrict__ probe_list, int nq, int P,
+                                                      const int* __restrict__ list_rank, int nlist,
+                                                      int* __restrict__ qkey, int* __restrict__ qperm) {
+    __shared__ int s_bin[QO_BINS];
+    __shared__ int s_part[1024];
+    const int tid = threadIdx.x;
+    for (int b = tid; b < QO_BINS; b += 1024) s_bin[b] = 0;
+    __syncthreads();
+    for (int q0 = 0; q0 < nq; q0 += 1024 * QO_BATCH) {
+        int l[QO_BATCH], r[QO_BATCH];
+#pragma unroll
+        for (int u = 0; u < QO_BATCH; u++) {
+            const int q = q0 + u * 1024 + tid;
+            l[u] = q < nq ? probe_list[(int64_t)q * P] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < QO_BATCH; u++) r[u] = (l[u] >= 0 && l[u] < nlist) ? list_rank[l[u]] : 0;
+#pragma unroll
+        for (int u = 0; u < QO_BATCH; u++) {
+            const int q = q0 + u * 1024 + tid;
+            if (q < nq) {
+                const int key = (int)((int64_t)r[u] * QO_BINS / nlist);
+                qkey[q] = key;
+                atomicAdd(&s_bin[key], 1);
+            }
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the bins: QO_BINS / 1024 bins per thread
+    int v[QO_BINS / 1024], sum = 0;
+#pragma unroll
+    for (int u = 0; u < QO_BINS / 1024; u++) {
+        v[u] = s_bin[tid * (QO_BINS / 1024) + u];
+        sum += v[u];
+    }
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int t = tid >= off ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += t;
+        __syncthreads();
+    }
+    int run = s_part[tid] - sum;
+#pragma unroll
+    for (int u = 0; u < QO_BINS / 1024; u++) {
+        s_bin[tid * (QO_BINS / 1024) + u] = run;
+        run += v[u];
+    }
+    __syncthreads();
+    for (int q0 = 0; q0 < nq; q0 += 1024 * QO_BATCH) {
+        int key[QO_BATCH];
+#pragma unroll
+        for (int u = 0; u < QO_BATCH; u++) {
+            const int q = q0 + u * 1024 + tid;
+            key[u] = q < nq ? qkey[q] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < QO_BATCH; u++) {
+            const int q = q0 + u * 1024 + tid;
+            if (q < nq) qperm[atomicAdd(&s_bin[key[u]], 1)] = q;
+        }
+    }
+}
+void launch_query_order(hipStream_t s, const int* probe_list, int nq, int P, const int* list_rank,
+                        int nlist, int* qkey, int* qperm) {
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(k_query_order, dim3(1), dim3(1024), 0, s, probe_list, nq, P, list_rank, nlist, qkey,
+                       qperm);
+}
+
+// ------------------------------------------------------------------------------------
 // a4+a5+a6+a8: IVFPQ list scan, one workgroup per (query, probe) pair.
 //   LUT (M x 256 fp32) built in LDS:  L2: lut = T2[list] + (-2) * st2[q]  (fvec_madd)
 //                                     IP: lut = st2[q]
@@ -455,7 +533,8 @@ __global__ __launch_bounds__(256) void k_ivfpq_scan_pair(
         const int64_t* __restrict__ list_off, const int* __restrict__ list_len,
         const uint8_t* __restrict__ list_mask, int nlist, const uint8_t* __restrict__ codes,
         const int64_t* __restrict__ ids, const int* __restrict__ pair_off, int64_t q_stride,
-        float* __restrict__ out, FilterDesc filt, int need_ids, float sentinel) {
+        float* __restrict__ out, FilterDesc filt, int need_ids, float sentinel,
+        const int* __restrict__ qperm) {
     // One workgroup scans G consecutive probes of one query: the query's 16 KB table st2 is
     // read ONCE into registers (MT per thread) and reused for the G list-specific LUTs, so
     // the per-pair table traffic drops from 2 x M KB to (1 + 1/G) x M KB.
@@ -465,9 +544,20 @@ __global__ __launch_bounds__(256) void k_ivfpq_scan_pair(
     // XCD-aware placement (speed only): block b runs on XCD b % 8 with its own L2, so all PGN
     // workgroups of one query are given block ids with the same residue -- the query's table
     // st2[q] is then fetched from HBM/MALL once per XCD and served from that L2 afterwards.
+    // With qperm (queries sorted by the spatial rank of their nearest list, k_query_order) XCD x
+    // takes the x-th contiguous eighth of that order, in order: concurrently running queries
+    // probe overlapping lists, so the 16 KB T2 rows they stream are mostly L2 hits as well.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int q = (slot / PGN) * 8 + xcd, pg = slot % PGN;
-    if (q >= nq) return;
+    const int pg = slot % PGN;
+    int q;
+    if (qperm) {
+        const int qi = xcd * ((nq + 7) >> 3) + slot / PGN;
+        if (qi >= nq) return;
+        q = qperm[qi];
+    } else {
+        q = (slot / PGN) * 8 + xcd;
+        if (q >= nq) return;
+    }
     const int p_begin = pg * G, p_end = min(P, p_begin + G);
     const int tid = threadIdx.x;
     const int msz = M * 256;
@@ -577,7 +667,8 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
                             const float* st2, const float* T2, const int64_t* list_off,
                             const int* list_len, const uint8_t* list_mask, int nlist,
                             const uint8_t* codes, const int64_t* ids, const int* pair_off,
-                            int64_t q_stride, float* out, const FilterDesc& filt, int need_ids) {
+                            int64_t q_stride, float* out, const FilterDesc& filt, int need_ids,
+                            const int* qperm) {
     if (nq <= 0) return;
     const size_t lds = (size_t)M * 256 * sizeof(float);
     // probes per workgroup: amortise the query table, but keep >= ~4096 workgroups in flight
@@ -589,7 +680,7 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
 #define GH_SCAN(LL, MT)                                                                        \
     hipLaunchKernelGGL((k_ivfpq_scan_pair<LL, MT>), grid, dim3(256), lds, s, x, nq, d, M, P, G, probe_list, \
                        coarse_dis, cc, st2, T2, list_off, list_len, list_mask, nlist, codes, ids,  \
-                       pair_off, q_stride, out, filt, need_ids, LL ? INFINITY : -INFINITY)
+                       pair_off, q_stride, out, filt, need_ids, LL ? INFINITY : -INFINITY, qperm)
     if (l2) {
         if (M == 16) GH_SCAN(true, 16);
         else if (M == 32) GH_SCAN(true, 32);

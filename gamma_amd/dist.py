@@ -1,16 +1,20 @@
 """List-sharded multi-GPU IVFPQ search.
 
 One process per GPU.  Every rank holds the replicated small state (coarse centroids, PQ
-codebooks, delete bitmap, raw vectors for the re-rank) and the inverted lists it OWNS.  A
-search batch runs in three steps:
+codebooks, delete bitmap, raw vectors for the re-rank) and the inverted lists it OWNS.  The
+batch of nq queries is also split into one contiguous slice per rank ("its" queries).  A search
+runs in four steps:
 
-  1. every rank: coarse quantizer for the whole batch (cheap, replicated), scan of the owned
-     probed lists only, local top-recall_num per query            (gamma_hip_ivfpq_search_shard)
-  2. RCCL all-gather over xGMI of the per-shard (distance, id) tables, nq*R*(4+8) bytes per GPU
-     -- the one real exchange step of the path
-  3. every rank merges the gathered tables into the global top-recall_num and runs compute_dis
-     (re-rank / truncate) for ITS slice of the queries             (gamma_hip_ivfpq_merge_rerank)
-     followed by a small all-gather of the [nq_slice, k] results.
+  0. every rank: coarse quantizer for ITS query slice                (gamma_hip_ivfpq_coarse_device)
+     + all-gather of the (distance, list) assignment, nq*nprobe*8 bytes in total
+  1. every rank: query tables for the whole batch, scan of the owned probed lists only, local
+     top-recall_num per query                            (gamma_hip_ivfpq_search_shard_preassigned)
+  2. the one real exchange of the path: every rank sends each peer the candidates of the PEER'S
+     query slice -- an RCCL all-to-all over xGMI, (nq/W)*R*(4+8) bytes per pair of GPUs, each
+     pair on its own direct link (an all-gather of everything would move W times as much)
+  3. every rank merges the W candidate tables of its slice into the global top-recall_num and
+     runs compute_dis (re-rank / truncate)                           (gamma_hip_ivfpq_merge_rerank)
+     followed by a small all-gather of the [nq/W, k] results.
 
 The global top-recall_num of the union equals the single-GPU top-recall_num (same ADC
 distances, disjoint lists), so results are identical to one GPU up to the order inside exact
@@ -53,22 +57,22 @@ class HipShardBackend:
     def empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, device=self.device)
 
-    def search_shard(self, x, k, args):
-        nq = x.shape[0]
-        R = max(args.p.recall_num, k)
-        rdis = self.empty((nq, R), torch.float32)
-        rids = self.empty((nq, R), torch.int64)
-        self.g.ivfpq_search_shard(x.data_ptr(), nq, k, args, rdis.data_ptr(), rids.data_ptr())
-        return rdis, rids
+    def coarse(self, x, args, cdis, probe):
+        """coarse assignment of the rows of x into the preallocated cdis/probe [n, nprobe]"""
+        if x.shape[0]:
+            self.g.ivfpq_coarse_device(x.data_ptr(), x.shape[0], args, cdis.data_ptr(), probe.data_ptr())
 
-    def merge_rerank(self, all_dis, all_ids, x, k, args, q0, nql, out_rows):
-        W, nq = all_dis.shape[0], all_dis.shape[1]
-        D = self.empty((out_rows, k), torch.float32)
-        I = self.empty((out_rows, k), torch.int64)
+    def search_shard(self, x, cdis, probe, k, args, rdis, rids):
+        """local top-R over the owned lists for all rows of x into rdis/rids [n, R]"""
+        self.g.ivfpq_search_shard_preassigned(x.data_ptr(), x.shape[0], cdis.data_ptr(), probe.data_ptr(),
+                                              k, args, rdis.data_ptr(), rids.data_ptr())
+
+    def merge_rerank(self, all_dis, all_ids, x, k, args, nql, D, I):
+        """all_dis/all_ids [W, per, R]: candidates of this rank's slice from every shard"""
+        W, per = all_dis.shape[0], all_dis.shape[1]
         if nql > 0:
-            self.g.ivfpq_merge_rerank(W, nq, x.data_ptr(), k, args, all_dis.data_ptr(),
-                                      all_ids.data_ptr(), q0, nql, D.data_ptr(), I.data_ptr())
-        return D, I
+            self.g.ivfpq_merge_rerank(W, per, x.data_ptr(), k, args, all_dis.data_ptr(),
+                                      all_ids.data_ptr(), 0, nql, D.data_ptr(), I.data_ptr())
 
 
 def sharded_search(backend, x, k, args, group=None, gather_results=True):
@@ -77,20 +81,45 @@ def sharded_search(backend, x, k, args, group=None, gather_results=True):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     nq = x.shape[0]
+    P = args.p.nprobe
+    R = max(args.p.recall_num, k)
+    q0, q1, per = query_slice(nq, rank, world)
+    nql = q1 - q0
     stream_ctx = torch.cuda.stream(backend.stream) if hasattr(backend, "stream") else _Null()
     with stream_ctx:
-        rdis, rids = backend.search_shard(x, k, args)
-        # concatenation along dim 0 == [shard][nq][R] row-major (the layout merge_rerank reads)
-        all_dis = backend.empty((world * nq, rdis.shape[1]), rdis.dtype)
-        all_ids = backend.empty((world * nq, rids.shape[1]), rids.dtype)
-        dist.all_gather_into_tensor(all_dis, rdis, group=group)
-        dist.all_gather_into_tensor(all_ids, rids, group=group)
-        all_dis = all_dis.view(world, nq, -1)
-        all_ids = all_ids.view(world, nq, -1)
-        q0, q1, per = query_slice(nq, rank, world)
-        D, I = backend.merge_rerank(all_dis, all_ids, x, k, args, q0, q1 - q0, per)
+        # 0. coarse quantizer on the own slice, assignment all-gathered (rows padded to W*per)
+        cdis_l = backend.empty((per, P), torch.float32)
+        probe_l = backend.empty((per, P), torch.int32)
+        if nql < per:            # padding rows: no valid list
+            cdis_l.zero_()
+            probe_l.fill_(-1)
+        backend.coarse(x[q0:q1], args, cdis_l, probe_l)
+        cdis = backend.empty((world * per, P), torch.float32)
+        probe = backend.empty((world * per, P), torch.int32)
+        dist.all_gather_into_tensor(cdis, cdis_l, group=group)
+        dist.all_gather_into_tensor(probe, probe_l, group=group)
+        # 1. local top-R of every query over the owned lists, laid out [dest rank][per][R]
+        rdis = backend.empty((world * per, R), torch.float32)
+        rids = backend.empty((world * per, R), torch.int64)
+        if nq < world * per:     # padding rows carry no candidates
+            rdis[nq:].zero_()
+            rids[nq:].fill_(-1)
+        backend.search_shard(x, cdis[:nq], probe[:nq], k, args, rdis[:nq], rids[:nq])
+        # 2. all-to-all: block r of rdis goes to rank r; block s of all_dis came from shard s
+        all_dis = backend.empty((world * per, R), torch.float32)
+        all_ids = backend.empty((world * per, R), torch.int64)
+        dist.all_to_all_single(all_dis, rdis, group=group)
+        dist.all_to_all_single(all_ids, rids, group=group)
+        # 3. merge + compute_dis for the own slice
+        D = backend.empty((per, k), torch.float32)
+        I = backend.empty((per, k), torch.int64)
+        if nql < per:
+            D.zero_()
+            I.fill_(-1)
+        backend.merge_rerank(all_dis.view(world, per, R), all_ids.view(world, per, R), x[q0:q1], k, args,
+                             nql, D, I)
         if not gather_results:
-            return D[:q1 - q0], I[:q1 - q0]
+            return D[:nql], I[:nql]
         Dall = backend.empty((world * per, k), D.dtype)
         Iall = backend.empty((world * per, k), I.dtype)
         dist.all_gather_into_tensor(Dall, D, group=group)

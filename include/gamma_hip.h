@@ -151,6 +151,17 @@ int gamma_hip_ivfpq_last_stages(gamma_hip_index* h, float* coarse_dis, int64_t* 
 int gamma_hip_ivfpq_search_shard(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
                                  const float* d_x, int k, float* d_recall_dis,
                                  int64_t* d_recall_ids);
+/* sharded search with the query batch split over the ranks: stage 0 = the coarse quantizer alone
+ * (IndexFlatL2::search, faiss:IndexFlat.cpp:35-55) for this rank's slice of the queries; outputs
+ * [nq*nprobe] in device memory, exchanged with an all-gather */
+int gamma_hip_ivfpq_coarse_device(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
+                                  const float* d_x, float* d_coarse_dis, int32_t* d_probe);
+/* stage 1 with the coarse assignment supplied = search_preassigned restricted to the owned lists
+ * (gamma_index_ivfpq.cc:701-890): tables + scan + local top-recall_num */
+int gamma_hip_ivfpq_search_shard_preassigned(gamma_hip_index* h, const gamma_hip_search_params* p,
+                                             int nq, const float* d_x, const float* d_coarse_dis,
+                                             const int32_t* d_probe, int k, float* d_recall_dis,
+                                             int64_t* d_recall_ids);
 /* sharded search, stage 2: merge nshards*recall_num candidates per query (layout
  * [shard][nq][recall_num]) into the global top-recall_num, then compute_dis (re-rank or
  * truncate, gamma_index_ivfpq.cc:642-697) for queries [q0, q0+nq_local) */

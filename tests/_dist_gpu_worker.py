@@ -1,0 +1,63 @@
+"""RCCL worker (one process per GPU): gamma_amd.dist.sharded_search with the HIP backend against
+the unsharded device search of a handle that holds every list."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from gamma_amd import api  # noqa: E402
+from gamma_amd import dist as gdist  # noqa: E402
+from oracle import binding as B  # noqa: E402
+from tests import fixtures  # noqa: E402
+from tests.parity import compare_topk  # noqa: E402
+
+
+def main():
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group("nccl", device_id=dev)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    case = fixtures.trained_case(d=32, nlist=64, M=8, N=20000, nq=64, metric=B.METRIC_L2)
+    sizes = np.array([case["oracle"].list_size(l) for l in range(case["nlist"])])
+    owner = gdist.balance_lists(sizes, world)
+    full = fixtures.load_hip(case, device=local)
+    g = api.GammaHip(local)
+    g.ivfpq_init(case["d"], case["nlist"], case["M"], 8, case["metric"], 1000)
+    g.ivfpq_set_trained(case["cc"], case["pq"], None)
+    lists, counts, vids, codes = [], [], [], []
+    for l in range(case["nlist"]):
+        if owner[l] == rank:
+            ids, cds = case["oracle"].get_list(l)
+            if len(ids):
+                lists.append(l)
+                counts.append(len(ids))
+                vids.append(ids)
+                codes.append(cds)
+    g.add_keys_batch(lists, counts, np.concatenate(vids), np.concatenate(codes))
+    g.raw_init(case["d"])
+    g.raw_append(case["base"])
+    be = gdist.HipShardBackend(g, local)
+    k, P, R, nq = 10, 8, 100, 61
+    args = api.SearchArgs(metric=api.METRIC_L2, nprobe=P, recall_num=R, has_rank=True, min_score=-3e38,
+                          max_score=3e38, coarse_mode=1)
+    x = torch.from_numpy(case["q"][:nq]).to(dev)
+    for _ in range(2):      # second call reuses workspaces
+        D, I = gdist.sharded_search(be, x, k, args)
+    torch.cuda.synchronize()
+    Dref = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    Iref = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    full.ivfpq_search_device(x.data_ptr(), nq, k, args, Dref.data_ptr(), Iref.data_ptr())
+    full.synchronize()
+    compare_topk(Dref.cpu().numpy(), Iref.cpu().numpy(), D.cpu().numpy(), I.cpu().numpy())
+    dist.destroy_process_group()
+    print("rank %d ok" % rank)
+
+
+if __name__ == "__main__":
+    main()

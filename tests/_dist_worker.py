@@ -33,32 +33,41 @@ class OracleShardBackend:
     def empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype)
 
-    def search_shard(self, x, k, args):
+    def coarse(self, x, args, cdis, probe):
+        if x.shape[0] == 0:
+            return
         p = args.p
-        R = max(p.recall_num, k)
+        Dc, Ic = B.knn_L2sqr(x.numpy(), self.case["cc"], p.nprobe, mode=0)
+        cdis[:x.shape[0]] = torch.from_numpy(Dc)
+        probe[:x.shape[0]] = torch.from_numpy(Ic.astype(np.int32))
+
+    def search_shard(self, x, cdis, probe, k, args, rdis, rids):
+        p = args.p
         ctx = B.make_ctx(min_score=p.min_score, max_score=p.max_score)
         _, _, st = self.o.search(x.numpy(), k, p.nprobe, recall_num=p.recall_num, has_rank=False,
                                  metric=p.metric, ctx=ctx, coarse_mode=0, want_stages=True)
-        return torch.from_numpy(st["recall_dis"]), torch.from_numpy(st["recall_ids"])
+        # the oracle recomputes the (deterministic) coarse assignment: it must be what the
+        # owning ranks computed and the all-gather delivered
+        assert np.array_equal(st["coarse_idx"], probe.numpy().astype(np.int64))
+        assert st["coarse_dis"].tobytes() == cdis.numpy().tobytes()
+        rdis[:] = torch.from_numpy(st["recall_dis"])
+        rids[:] = torch.from_numpy(st["recall_ids"])
 
-    def merge_rerank(self, all_dis, all_ids, x, k, args, q0, nql, out_rows):
+    def merge_rerank(self, all_dis, all_ids, x, k, args, nql, D, I):
         p = args.p
         R = max(p.recall_num, k)
         ks = 1 if p.metric == B.METRIC_L2 else 0
         L = B.lib()
-        D = torch.zeros((out_rows, k), dtype=torch.float32)
-        I = torch.full((out_rows, k), -1, dtype=torch.int64)
         ad, ai = all_dis.numpy(), all_ids.numpy()
         base, d = self.case["base"], self.case["d"]
         for qi in range(nql):
-            q = q0 + qi
-            dis = ad[:, q, :].reshape(-1)
-            ids = ai[:, q, :].reshape(-1)
+            dis = ad[:, qi, :].reshape(-1)
+            ids = ai[:, qi, :].reshape(-1)
             keep = ids >= 0
             dis, ids = dis[keep], ids[keep]
             order = np.argsort(dis if ks else -dis, kind="stable")[:R]
             ids = ids[order]
-            xq = np.ascontiguousarray(x[q].numpy())
+            xq = np.ascontiguousarray(x[qi].numpy())
             fn = L.go_fvec_L2sqr if ks else L.go_fvec_inner_product
             ex = np.array([fn(B._fp(xq), B._fp(np.ascontiguousarray(base[i])), d) for i in ids],
                           dtype=np.float32)
@@ -67,7 +76,6 @@ class OracleShardBackend:
             L.go_heap_pop_push_stream(ks, k, len(ids), B._fp(ex), B._ip(ids), B._fp(ov), B._ip(oi))
             D[qi] = torch.from_numpy(ov)
             I[qi] = torch.from_numpy(oi)
-        return D, I
 
 
 def main():
