@@ -459,6 +459,164 @@ __global__ __launch_bounds__(256) void k_select_stream(const float* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Wave-per-row variant for small K (K <= 64: the coarse quantizer's top-nprobe, 1-NN
+// assignment).  No workgroup barriers: a 256-thread workgroup is four independent waves, one
+// row each.  A row is visited in chunks of 64 lanes x SW_NPL registers:
+//   1. every lane takes the minimum of its SW_NPL keys; the K-th smallest of the 64 lane minima
+//      is an upper bound tau of the chunk's K-th smallest key (K lanes hold a key <= tau)
+//   2. keys <= tau (about 1.4 K of them on unstructured data) are appended to a per-wave LDS
+//      list behind the running top-K, lane offsets from a wave prefix sum
+//   3. wave rank sort of the list on (key, position), first K kept
+// If the bound is loose (structured rows, mass ties) the list would overflow; the chunk's
+// top-K is then extracted exactly from the registers, K rounds of wave arg-min.
+// Same result as k_select2: the K smallest (key, position) pairs, sorted.
+// ------------------------------------------------------------------------------------
+namespace {
+constexpr int SW_CAP = 512;   // list entries per wave (4 KB)
+constexpr int SW_NPL = 64;    // keys per lane and chunk (chunk = 64 * SW_NPL elements)
+
+// buf[0..c) distinct items -> the min(c, K) smallest, sorted, in buf[0..); wave-synchronous
+__device__ __forceinline__ void wave_rank_take(unsigned long long* buf, int c, int K) {
+    const int lane = threadIdx.x & 63;
+    constexpr int MAXI = SW_CAP / 64;
+    unsigned long long it[MAXI];
+    int rk[MAXI];
+    const int nu = (c + 63) >> 6;   // uniform
+#pragma unroll
+    for (int u = 0; u < MAXI; u++) {
+        const int i = lane + 64 * u;
+        it[u] = i < c ? buf[i] : ~0ull;
+        rk[u] = 0;
+    }
+    int j = 0;
+    for (; j + 8 <= c; j += 8) {
+        unsigned long long x[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) x[e] = buf[j + e];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+#pragma unroll
+            for (int u = 0; u < MAXI; u++)
+                if (u < nu) rk[u] += (x[e] < it[u]) ? 1 : 0;
+        }
+    }
+    for (; j < c; j++) {
+        const unsigned long long x = buf[j];
+#pragma unroll
+        for (int u = 0; u < MAXI; u++)
+            if (u < nu) rk[u] += (x < it[u]) ? 1 : 0;
+    }
+    __builtin_amdgcn_wave_barrier();   // every read above is issued before the scatter below
+#pragma unroll
+    for (int u = 0; u < MAXI; u++)
+        if (lane + 64 * u < c && rk[u] < K) buf[rk[u]] = it[u];
+    __builtin_amdgcn_wave_barrier();
+}
+}  // namespace
+
+template <bool SMALLEST>
+__global__ __launch_bounds__(256) void k_select_wave(const float* __restrict__ vals, int64_t seg_stride,
+                                                     const int* __restrict__ seg_len, int fixed_len,
+                                                     int nseg, int K, float* __restrict__ out_vals,
+                                                     int* __restrict__ out_pos) {
+    __shared__ unsigned long long s_buf[4][SW_CAP];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int seg = blockIdx.x * 4 + w;
+    if (seg >= nseg) return;   // whole wave; the kernel has no workgroup barrier
+    const int n = seg_len ? seg_len[seg] : fixed_len;
+    const float* v = vals + (int64_t)seg * seg_stride;
+    unsigned long long* buf = s_buf[w];
+    int run = 0;               // buf[0..run): running top, sorted
+    for (int base = 0; base < n; base += 64 * SW_NPL) {
+        uint32_t key[SW_NPL];
+        unsigned long long inval = 0;   // bit j: slot j is past the end of the row
+#pragma unroll
+        for (int j0 = 0; j0 < SW_NPL; j0 += 16) {   // 16 unconditional loads in flight per lane
+            float t[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) t[u] = v[min(base + (j0 + u) * 64 + lane, n - 1)];
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const bool ok = base + (j0 + u) * 64 + lane < n;
+                key[j0 + u] = ok ? sel_key<SMALLEST>(t[u]) : 0xffffffffu;
+                if (!ok) inval |= 1ull << (j0 + u);
+            }
+        }
+        uint32_t m = key[0];
+#pragma unroll
+        for (int j = 1; j < SW_NPL; j++) m = key[j] < m ? key[j] : m;
+        // rank of this lane's minimum among the 64 (ties by lane): K-th smallest = tau
+        int rk = 0;
+#pragma unroll
+        for (int l = 0; l < 64; l++) {
+            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)m, l);
+            rk += (o < m || (o == m && l < lane)) ? 1 : 0;
+        }
+        const unsigned long long who = __ballot(rk == K - 1);
+        uint32_t tau = (uint32_t)__shfl((int)m, (int)__ffsll((long long)who) - 1, 64);
+        if (run == K) {
+            const uint32_t kth = (uint32_t)(buf[K - 1] >> 32);
+            tau = kth < tau ? kth : tau;
+        }
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < SW_NPL; j++) c += (key[j] <= tau && !((inval >> j) & 1ull)) ? 1 : 0;
+        const int incl = wave_incl_scan(c);
+        const int tot = __shfl(incl, 63, 64);
+        if (run + tot <= SW_CAP) {
+            int off = run + incl - c;
+#pragma unroll
+            for (int j = 0; j < SW_NPL; j++)
+                if (key[j] <= tau && !((inval >> j) & 1ull))
+                    buf[off++] = ((unsigned long long)key[j] << 32) | (unsigned)(base + j * 64 + lane);
+            __builtin_amdgcn_wave_barrier();
+            wave_rank_take(buf, run + tot, K);
+            run = min(run + tot, K);
+        } else {
+            // exact extraction from the registers: K rounds of (lane arg-min, wave arg-min)
+            unsigned long long rm = inval;
+            int got = 0;
+            for (; got < K; got++) {
+                uint32_t bk = 0xffffffffu;
+                int bj = -1;
+#pragma unroll
+                for (int j = 0; j < SW_NPL; j++) {
+                    const bool ok = !((rm >> j) & 1ull) && (bj < 0 || key[j] < bk);
+                    bk = ok ? key[j] : bk;
+                    bj = ok ? j : bj;
+                }
+                unsigned long long item = bj < 0 ? ~0ull
+                                                 : (((unsigned long long)bk << 32) | (unsigned)(base + bj * 64 + lane));
+                unsigned long long best = item;
+#pragma unroll
+                for (int off2 = 32; off2 > 0; off2 >>= 1) {
+                    const unsigned long long o = __shfl_xor(best, off2, 64);
+                    best = o < best ? o : best;
+                }
+                if (best == ~0ull) break;          // chunk exhausted (uniform)
+                if (item == best) rm |= 1ull << bj; // positions are distinct: one lane
+                if (lane == 0) buf[run + got] = best;
+            }
+            __builtin_amdgcn_wave_barrier();
+            wave_rank_take(buf, run + got, K);
+            run = min(run + got, K);
+        }
+    }
+    const float sentinel = SMALLEST ? INFINITY : -INFINITY;
+    for (int r = lane; r < K; r += 64) {
+        float val = sentinel;
+        int pos = -1;
+        if (r < run) {
+            pos = (int)(uint32_t)buf[r];
+            val = v[pos];
+            if (val == sentinel) pos = -1;
+        }
+        out_vals[(int64_t)seg * K + r] = val;
+        out_pos[(int64_t)seg * K + r] = pos;
+    }
+}
+
 int select_kpad(int K) {
     int p = 2;
     while (p < K) p <<= 1;
@@ -473,7 +631,11 @@ static void launch_sel(hipStream_t s, const float* vals, int64_t seg_stride, con
 #define GH_SEL(NPT)                                                                              \
     hipLaunchKernelGGL((k_select2<SMALLEST, NPT>), dim3(nseg), dim3(256), lds, s, vals, seg_stride, \
                        seg_len, fixed_len, K, Kpad, out_vals, out_pos)
-    if (max_len <= 256 * 4) GH_SEL(4);
+    static const bool no_wave = getenv("GAMMA_HIP_NO_WAVE_SELECT") != nullptr;
+    if (K <= 64 && !no_wave)
+        hipLaunchKernelGGL((k_select_wave<SMALLEST>), dim3((nseg + 3) / 4), dim3(256), 0, s, vals, seg_stride,
+                           seg_len, fixed_len, nseg, K, out_vals, out_pos);
+    else if (max_len <= 256 * 4) GH_SEL(4);
     else if (max_len <= 256 * 16) GH_SEL(16);
     else if (K <= 1024 && (seg_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(vals) & 15) == 0 &&
              !getenv("GAMMA_HIP_NO_STREAM_SELECT"))

@@ -168,6 +168,38 @@ def test_flat_parity(metric, d):
         g.close()
 
 
+@pytest.mark.parametrize("k", [1, 10, 64])
+@pytest.mark.parametrize("layout", ["random", "one_lane", "ties"])
+def test_small_k_selection_paths(k, layout):
+    """k <= 64 goes through the wave-per-row selection (select.hip): multi-chunk rows, the
+    exact-extraction path (all near neighbours at positions = 5 mod 64, so the lane-minimum
+    bound is useless) and rows that are one big tie."""
+    d, N, nq = 16, 9000, 12
+    rng = np.random.default_rng(7)
+    base = synth.sift_like(N, d=d, seed=31)
+    q = synth.sift_like(nq, d=d, seed=32)
+    if layout == "one_lane":
+        base = base + 400.0                       # everything far away ...
+        near = np.arange(5, N, 64)
+        base[near] = q[rng.integers(0, nq, size=len(near))] + rng.integers(0, 3, size=(len(near), d))
+        base = base.astype(np.float32)
+    elif layout == "ties":
+        base[:] = base[0]                         # every distance equal: order = position
+        base[100:140] = base[1]
+    g = api.GammaHip(0)
+    try:
+        g.raw_init(d)
+        g.raw_append(base)
+        for metric in (B.METRIC_L2, B.METRIC_IP):
+            D, I = B.flat_search(base, q, k, metric, B.make_ctx(**WIDE))
+            Dg, Ig = g.flat_search(q, k, api.SearchArgs(metric=metric, **WIDE))
+            compare_topk(D, I, Dg, Ig)
+            if layout == "ties":
+                assert Dg.tobytes() == D.tobytes()
+    finally:
+        g.close()
+
+
 def test_flat_small_and_empty():
     g = api.GammaHip(0)
     try:
