@@ -530,17 +530,21 @@ __global__ __launch_bounds__(256) void k_select_wave(const float* __restrict__ v
     int run = 0;               // buf[0..run): running top, sorted
     for (int base = 0; base < n; base += 64 * SW_NPL) {
         uint32_t key[SW_NPL];
-        unsigned long long inval = 0;   // bit j: slot j is past the end of the row
+        // slot j of this lane is element base + j*64 + lane; it exists iff j*64 < nrem
+        const int nrem = n - base - lane;
+        if (base + 64 * SW_NPL <= n) {      // full chunk (uniform): one base address, constant offsets
+            const float* pv = v + base + lane;
 #pragma unroll
-        for (int j0 = 0; j0 < SW_NPL; j0 += 16) {   // 16 unconditional loads in flight per lane
-            float t[16];
+            for (int j = 0; j < SW_NPL; j++) key[j] = sel_key<SMALLEST>(pv[j * 64]);
+        } else {
 #pragma unroll
-            for (int u = 0; u < 16; u++) t[u] = v[min(base + (j0 + u) * 64 + lane, n - 1)];
+            for (int j0 = 0; j0 < SW_NPL; j0 += 16) {   // 16 unconditional (clamped) loads in flight
+                float t[16];
 #pragma unroll
-            for (int u = 0; u < 16; u++) {
-                const bool ok = base + (j0 + u) * 64 + lane < n;
-                key[j0 + u] = ok ? sel_key<SMALLEST>(t[u]) : 0xffffffffu;
-                if (!ok) inval |= 1ull << (j0 + u);
+                for (int u = 0; u < 16; u++) t[u] = v[min(base + (j0 + u) * 64 + lane, n - 1)];
+#pragma unroll
+                for (int u = 0; u < 16; u++)
+                    key[j0 + u] = (j0 + u) * 64 < nrem ? sel_key<SMALLEST>(t[u]) : 0xffffffffu;
             }
         }
         uint32_t m = key[0];
@@ -561,28 +565,28 @@ __global__ __launch_bounds__(256) void k_select_wave(const float* __restrict__ v
         }
         int c = 0;
 #pragma unroll
-        for (int j = 0; j < SW_NPL; j++) c += (key[j] <= tau && !((inval >> j) & 1ull)) ? 1 : 0;
+        for (int j = 0; j < SW_NPL; j++) c += (key[j] <= tau && j * 64 < nrem) ? 1 : 0;
         const int incl = wave_incl_scan(c);
         const int tot = __shfl(incl, 63, 64);
         if (run + tot <= SW_CAP) {
             int off = run + incl - c;
 #pragma unroll
             for (int j = 0; j < SW_NPL; j++)
-                if (key[j] <= tau && !((inval >> j) & 1ull))
+                if (key[j] <= tau && j * 64 < nrem)
                     buf[off++] = ((unsigned long long)key[j] << 32) | (unsigned)(base + j * 64 + lane);
             __builtin_amdgcn_wave_barrier();
             wave_rank_take(buf, run + tot, K);
             run = min(run + tot, K);
         } else {
             // exact extraction from the registers: K rounds of (lane arg-min, wave arg-min)
-            unsigned long long rm = inval;
+            unsigned long long rm = 0;   // bit j: slot j already taken
             int got = 0;
             for (; got < K; got++) {
                 uint32_t bk = 0xffffffffu;
                 int bj = -1;
 #pragma unroll
                 for (int j = 0; j < SW_NPL; j++) {
-                    const bool ok = !((rm >> j) & 1ull) && (bj < 0 || key[j] < bk);
+                    const bool ok = !((rm >> j) & 1ull) && j * 64 < nrem && (bj < 0 || key[j] < bk);
                     bk = ok ? key[j] : bk;
                     bj = ok ? j : bj;
                 }
