@@ -316,6 +316,148 @@ __global__ __launch_bounds__(256) void k_l2_gemmform_mfma(const float* __restric
     }
 }
 
+// Strip variant for d <= 128 (one K slab): a workgroup keeps its 64-query tile in LDS and walks
+// over `tps` consecutive 64-centroid tiles.  The next centroid tile is fetched into registers
+// while the current one feeds the MFMAs, so global latency is paid once per workgroup instead
+// of once per tile, and the query tile (and its norms) is loaded once per strip.  Per output
+// element the accumulation is the same k-ascending fma chain as above.
+__global__ __launch_bounds__(256) void k_l2_gemmform_strip(const float* __restrict__ x, int nq, int d,
+                                                           const float* __restrict__ y, int ny,
+                                                           const float* __restrict__ xn,
+                                                           const float* __restrict__ yn,
+                                                           float* __restrict__ out, int64_t ld_out,
+                                                           int tps) {
+    constexpr int KS = 128, LD = KS + 1;
+    extern __shared__ float s_gemm[];
+    float* sA = s_gemm;            // [64][LD]
+    float* sB = s_gemm + 64 * LD;  // [64][LD]
+    __shared__ float s_xn[64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wq = w >> 1, wc = w & 1;
+    const int q_base = blockIdx.y * 64;
+    const int ntiles = (ny + 63) >> 6;
+    const int t0 = blockIdx.x * tps, t1 = min(ntiles, t0 + tps);
+    const int kw = d;   // <= KS, multiple of 4
+    // thread's 8 float4 slots of a 64 x 128 tile.  One wave instruction covers 8 rows x 32
+    // floats (8 lanes per 128-byte row segment, coalesced); with row stride 129 the four scalar
+    // LDS stores of such an instruction hit 32 distinct banks per half wave (a whole row per
+    // instruction would be 4-way conflicted).  combo = w*8 + it: row block combo>>2, segment combo&3
+    auto slot_r = [&](int it) { return (((w * 8 + it) >> 2) << 3) + (lane >> 3); };
+    auto slot_c = [&](int it) { return (((w * 8 + it) & 3) << 5) + ((lane & 7) << 2); };
+    float4 va[8], vb[8];
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int r = slot_r(it), c4c = min(slot_c(it), kw - 4);
+        va[it] = *reinterpret_cast<const float4*>(x + (int64_t)min(q_base + r, nq - 1) * d + c4c);
+        vb[it] = *reinterpret_cast<const float4*>(y + (int64_t)min(t0 * 64 + r, ny - 1) * d + c4c);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int r = slot_r(it), c4 = slot_c(it);
+        const bool oka = c4 < kw && q_base + r < nq, okb = c4 < kw && t0 * 64 + r < ny;
+        float* pa = sA + r * LD + c4;
+        float* pb = sB + r * LD + c4;
+        pa[0] = oka ? va[it].x : 0.f; pa[1] = oka ? va[it].y : 0.f;
+        pa[2] = oka ? va[it].z : 0.f; pa[3] = oka ? va[it].w : 0.f;
+        pb[0] = okb ? vb[it].x : 0.f; pb[1] = okb ? vb[it].y : 0.f;
+        pb[2] = okb ? vb[it].z : 0.f; pb[3] = okb ? vb[it].w : 0.f;
+    }
+    __syncthreads();
+    if (!xn) {
+        // fused query norms (fvec_norm_L2sqr order): thread (row = tid >> 2, lane4 = tid & 3);
+        // d % 4 == 0 here, so every 4-block is a fused one
+        const float* row = sA + (tid >> 2) * LD;
+        const int l4 = tid & 3;
+        float nacc = 0.f;
+        for (int i = 0; i < kw; i += 4) {
+            const float xv = row[i + l4];
+            nacc = __builtin_fmaf(xv, xv, nacc);
+        }
+        const float t01 = nacc + __shfl_down(nacc, 1, 4);
+        const float nn = t01 + __shfl_down(t01, 2, 4);
+        if ((tid & 3) == 0) s_xn[tid >> 2] = nn;
+        __syncthreads();
+    }
+    float xnr[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int lr = wq * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        xnr[r] = xn ? xn[min(q_base + lr, nq - 1)] : s_xn[lr];
+    }
+    const float* fa = sA + (wq * 32 + (lane & 31)) * LD + (lane >> 5);
+    const float* fb = sB + (wc * 32 + (lane & 31)) * LD + (lane >> 5);
+    const int nch = (kw + 15) >> 4;
+    for (int t = t0; t < t1; t++) {
+        const bool more = t + 1 < t1;   // uniform
+        if (more) {
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                const int r = slot_r(it), c4c = min(slot_c(it), kw - 4);
+                vb[it] = *reinterpret_cast<const float4*>(y + (int64_t)min((t + 1) * 64 + r, ny - 1) * d + c4c);
+            }
+        }
+        const int col = t * 64 + wc * 32 + (lane & 31);
+        const float ync = yn[min(col, ny - 1)];
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[i] = 0.f;
+        // fragment reads of chunk ch+1 are issued before the 8 dependent MFMAs of chunk ch
+        float a0[8], b0[8], a1[8], b1[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            a0[u] = fa[2 * u];
+            b0[u] = fb[2 * u];
+        }
+        for (int ch = 0; ch < nch; ch += 2) {
+            if (ch + 1 < nch) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    a1[u] = fa[(ch + 1) * 16 + 2 * u];
+                    b1[u] = fb[(ch + 1) * 16 + 2 * u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc, 0, 0, 0);
+            if (ch + 2 < nch) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    a0[u] = fa[(ch + 2) * 16 + 2 * u];
+                    b0[u] = fb[(ch + 2) * 16 + 2 * u];
+                }
+            }
+            if (ch + 1 < nch) {
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc, 0, 0, 0);
+            }
+        }
+        // epilogue: dis = (xn + yn) - 2*ip, clamp
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int lr = wq * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int row = q_base + lr;
+            if (row < nq && col < ny) {
+                float dis = (xnr[r] + ync) - 2.f * acc[r];
+                if (dis < 0.f) dis = 0.f;
+                out[(int64_t)row * ld_out + col] = dis;
+            }
+        }
+        if (more) {
+            __syncthreads();   // every wave is done with sB
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                const int r = slot_r(it), c4 = slot_c(it);
+                const bool okb = c4 < kw && (t + 1) * 64 + r < ny;
+                float* pb = sB + r * LD + c4;
+                pb[0] = okb ? vb[it].x : 0.f; pb[1] = okb ? vb[it].y : 0.f;
+                pb[2] = okb ? vb[it].z : 0.f; pb[3] = okb ? vb[it].w : 0.f;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 void launch_l2_gemmform(hipStream_t s, const float* x, int nq, int d, const float* y, int64_t ny,
                         const float* xn, const float* yn, float* out, int64_t ld_out,
                         bool use_mfma) {
@@ -330,6 +472,24 @@ void launch_l2_gemmform(hipStream_t s, const float* x, int nq, int d, const floa
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_l2_gemmform_mfma),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
+        }
+        static const bool no_strip = getenv("GAMMA_HIP_NO_GEMM_STRIP") != nullptr;
+        if (d <= 128 && (d & 3) == 0 && !no_strip) {
+            static bool attr2 = false;
+            if (!attr2) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_l2_gemmform_strip),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr2 = true;
+            }
+            // tiles per strip: amortise the query tile, but keep >= 512 workgroups
+            const int ntiles = (int)((ny + 63) / 64);
+            static const int tps_env = getenv("GAMMA_HIP_GEMM_TPS") ? atoi(getenv("GAMMA_HIP_GEMM_TPS")) : 0;
+            int tps = tps_env > 0 ? tps_env : 8;
+            while (tps > 1 && (int64_t)grid.y * ((ntiles + tps - 1) / tps) < 512) tps >>= 1;
+            dim3 g2((unsigned)((ntiles + tps - 1) / tps), grid.y);
+            hipLaunchKernelGGL(k_l2_gemmform_strip, g2, dim3(256), lds, s, x, nq, d, y, (int)ny, xn, yn, out,
+                               ld_out, tps);
+            return;
         }
         // xn == nullptr: query norms are computed inside the kernel from the staged tile
         hipLaunchKernelGGL(k_l2_gemmform_mfma, grid, dim3(256), lds, s, x, nq, d, y, (int)ny, xn, yn,
