@@ -1,0 +1,152 @@
+"""GPU parity tests shaped like BASELINE.json configs[3] and configs[4] at sizes the oracle and a
+single test run can afford: the same code paths (M = 32 scan template, nlist = 16384 coarse,
+nprobe = 64; d = 768 inner product with dsub = 12 codebooks, range-filter bitmaps, inserts and
+updates interleaved with searches), checked against the CPU oracle on the same inputs."""
+import numpy as np
+import pytest
+
+from gamma_amd import api, synth, train
+from oracle import binding as B
+from tests.parity import compare_search, compare_topk
+
+pytestmark = pytest.mark.gpu
+WIDE = dict(min_score=-3e38, max_score=3e38)
+
+
+def _oracle_from_device(g, d, nlist, M, metric, cc, pq, base, bucket=4000):
+    o = B.OracleIVFPQ(d, nlist, M, 8, metric, bucket_init_size=bucket)
+    o.set_trained(cc, pq, g.ivfpq_table())
+    for l in range(nlist):
+        ids, codes = g.get_list(l)
+        if len(ids):
+            o.add_keys(l, ids, codes)
+    o.set_raw(base)
+    return o
+
+
+def test_c4_shape_m32_nlist16384_nprobe64():
+    import torch
+    N, d, nlist, M, P = 1500000, 128, 16384, 32, 64
+    base = synth.sift_like(N, d=d, seed=1234)
+    cc, pq = train.train_ivfpq(base[:nlist * 40], nlist, M, niter=6, pq_niter=10, seed=3,
+                               device="cuda" if torch.cuda.is_available() else "cpu")
+    g = api.GammaHip(0)
+    try:
+        g.ivfpq_init(d, nlist, M, 8, api.METRIC_L2, bucket_init_size=200)
+        g.ivfpq_set_trained(cc, pq, None)
+        for i0 in range(0, N, 500000):
+            g.add(base[i0:i0 + 500000], i0)
+        g.raw_init(d)
+        g.raw_append(base)
+        assert sum(g.list_size(l) for l in range(nlist)) == N
+        q = synth.sift_like(512, d=d, seed=4321)
+        args = api.SearchArgs(metric=api.METRIC_L2, nprobe=P, recall_num=100, has_rank=True, coarse_mode=1,
+                              min_score=0.0, max_score=1e30)
+        D, I = g.ivfpq_search(q, 10, args)
+        assert (np.diff(D, axis=1) >= 0).all() and (I >= 0).all() and (I < N).all()
+        ex = ((base[I[:50].ravel()] - np.repeat(q[:50], 10, axis=0)) ** 2).sum(1).reshape(50, 10)
+        assert np.array_equal(ex.astype(np.float32), D[:50])
+        Df, If = g.flat_search(q[:100], 10, api.SearchArgs(metric=api.METRIC_L2, min_score=0.0, max_score=1e30))
+        rec = np.mean([len(set(I[i].tolist()) & set(If[i].tolist())) / 10.0 for i in range(100)])
+        assert rec > 0.85, rec
+        # sampled bit parity against the oracle holding the same lists
+        o = _oracle_from_device(g, d, nlist, M, B.METRIC_L2, cc, pq, base)
+        qs = q[:48]
+        for has_rank in (True, False):
+            ctx = B.make_ctx(min_score=0.0, max_score=1e30)
+            Do, Io, st = o.search(qs, 10, P, recall_num=100, has_rank=has_rank, metric=B.METRIC_L2, ctx=ctx,
+                                  coarse_mode=1, want_stages=True)
+            a2 = api.SearchArgs(metric=api.METRIC_L2, nprobe=P, recall_num=100, has_rank=has_rank,
+                                coarse_mode=1, min_score=0.0, max_score=1e30)
+            Dg, Ig = g.ivfpq_search(qs, 10, a2)
+            sg = g.last_stages(len(qs), P, 100)
+            assert sg["coarse_dis"].tobytes() == st["coarse_dis"].tobytes()
+            assert np.array_equal(sg["coarse_idx"], st["coarse_idx"])
+            compare_search(Do, Io, st, Dg, Ig, sg)
+    finally:
+        g.close()
+
+
+def test_c5_shape_d768_ip_filters_and_realtime_inserts():
+    import torch
+    N, d, nlist, M, P = 60000, 768, 1024, 64, 32
+    rng = np.random.default_rng(11)
+    # unit-normalised Gaussian mixture (embedding-shaped)
+    centres = rng.standard_normal((256, d)).astype(np.float32)
+    lab = rng.integers(0, 256, size=N + 3000)
+    allv = centres[lab] + 0.6 * rng.standard_normal((N + 3000, d)).astype(np.float32)
+    allv /= np.linalg.norm(allv, axis=1, keepdims=True)
+    allv = np.ascontiguousarray(allv, dtype=np.float32)
+    base, pool = allv[:N], allv[N:]
+    q = pool[-64:]
+    scalar = rng.integers(0, 1000000, size=N + 3000)          # the int field range filters select on
+    cc, pq = train.train_ivfpq(base[:nlist * 40], nlist, M, niter=6, pq_niter=8, seed=5,
+                               device="cuda" if torch.cuda.is_available() else "cpu")
+    g = api.GammaHip(0)
+    o = B.OracleIVFPQ(d, nlist, M, 8, B.METRIC_IP, bucket_init_size=100)
+    o.set_trained(cc, pq, None)
+    try:
+        g.ivfpq_init(d, nlist, M, 8, api.METRIC_IP, bucket_init_size=100)
+        g.ivfpq_set_trained(cc, pq, None)
+        assert g.ivfpq_table().tobytes() == o.table().tobytes()
+        g.raw_init(d)
+        # engine-sized Add batches (<= 1000 vectors, vector/vector_manager.cc:305-349), device encode
+        B.lib().go_set_assign_mode(1)
+        n_added = 0
+
+        def add(x):
+            nonlocal n_added
+            g.raw_append(x)
+            g.add(x, n_added)
+            assert o.add(x)
+            n_added += len(x)
+
+        for i0 in range(0, N, 1000):
+            add(base[i0:i0 + 1000])
+        for l in range(0, nlist, 37):
+            ids, codes = o.get_list(l)
+            gi, gc = g.get_list(l)
+            assert np.array_equal(ids, gi) and np.array_equal(codes, gc)
+
+        def check(nvec, del_bm=None):
+            o.set_raw(allv[:nvec])
+            for sel in (None, 0.01, 0.10, 0.50):
+                rf_o = rf_g = None
+                if sel is not None:
+                    docs = np.nonzero(scalar[:nvec] < int(sel * 1000000))[0]
+                    rf_o = [B.make_range_filter(docs)]
+                    rf_g = [api.make_range_filter(docs)]
+                for has_rank in (True, False):
+                    ctx = B.make_ctx(docids_bitmap=del_bm, range_filters=rf_o, **WIDE)
+                    Do, Io, st = o.search(q, 10, P, recall_num=100, has_rank=has_rank, metric=B.METRIC_IP,
+                                          ctx=ctx, coarse_mode=1, want_stages=True)
+                    a = api.SearchArgs(metric=api.METRIC_IP, nprobe=P, recall_num=100, has_rank=has_rank,
+                                       coarse_mode=1, range_filters=rf_g, **WIDE)
+                    Dg, Ig = g.ivfpq_search(q, 10, a)
+                    sg = g.last_stages(len(q), P, 100)
+                    compare_search(Do, Io, st, Dg, Ig, sg)
+
+        check(N)
+        # realtime inserts between searches, then deletes + updates
+        for b in range(2):
+            add(pool[b * 1000:(b + 1) * 1000])
+            check(n_added)
+        dead = rng.choice(n_added, size=500, replace=False)
+        bm = np.zeros((n_added >> 3) + 1, dtype=np.uint8)
+        np.bitwise_or.at(bm, dead >> 3, (1 << (dead & 7)).astype(np.uint8))
+        g.bitmap_upload(bm, n_added)
+        g.delete(dead)
+        o.set_docids_bitmap(bm)
+        o.delete(dead)
+        B.lib().go_set_assign_mode(0)
+        for vid in rng.choice(n_added, size=40, replace=False):
+            newv = pool[2000 + int(vid) % 900]
+            lno, code = g.encode(newv[None, :])
+            g.update(int(lno[0]), int(vid), code[0])
+            g.raw_update(int(vid), newv)
+            allv[vid] = newv
+            o.update(int(vid), newv)
+        check(n_added, del_bm=bm)
+    finally:
+        B.lib().go_set_assign_mode(0)
+        g.close()
