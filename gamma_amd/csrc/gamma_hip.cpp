@@ -261,7 +261,11 @@ int add_keys_locked(H* h, int l, int n, const int64_t* vids, const uint8_t* code
     GH_CHECK(h, hipStreamSynchronize(h->stream));
     for (int i = 0; i < n; i++) {
         const int64_t v = vids[i];
-        if (v < 0) continue;
+        if (v < 0) {   // superseded slot restored from a dump (ReadInvertedLists, gamma_index_io.cc:186-189)
+            h->h_deleted[l]++;
+            h->n_moved++;
+            continue;
+        }
         if ((size_t)v >= h->vid_pos.size()) h->vid_pos.resize(std::max<size_t>(h->vid_pos.size() * 2, v + 1), -1);
         h->vid_pos[v] = ((int64_t)l << 32) | (int64_t)(h->h_list_len[l] + i);
         if (h->bitmap_bits > v && !h->h_bitmap.empty() && ((h->h_bitmap[v >> 3] >> (v & 7)) & 1))

@@ -3,11 +3,14 @@
 #include "gamma_index_ivfpq_hip.h"
 
 #include "filter_bridge.h"
+#include "iwpq_io.h"
 
+#include <errno.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <strings.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <random>
@@ -348,67 +351,79 @@ int GammaIVFPQHIPIndex::SetTrained(const float *coarse, const float *pq) {
 
 long GammaIVFPQHIPIndex::GetTotalMemBytes() { return h_ ? (long)gamma_hip_total_mem_bytes(h_) : 0; }
 
-// Own container for the trained state + lists ("HIPQ").  Compatibility with the reference's
-// IwPQ dump (index/gamma_index_io.cc:113-192) is a later scope item.
+// Dump / Load in the reference's own file format (gamma_index_ivfpq.cc:958-1048): an index dumped by
+// the CPU "IVFPQ" model loads here and the other way round (iwpq_io.h for the record layout).
 int GammaIVFPQHIPIndex::Dump(const std::string &dir) {
-  if (!is_trained_) return 0;
-  const std::string path = dir + "/hipivfpq.index";
-  FILE *f = fopen(path.c_str(), "wb");
-  if (!f) return -1;
-  const int32_t hdr[6] = {0x51504948, d_, nlist_, M_, (int32_t)metric_type_, indexed_vec_count_};
-  fwrite(hdr, sizeof(hdr), 1, f);
-  fwrite(coarse_centroids_.data(), sizeof(float), coarse_centroids_.size(), f);
-  fwrite(pq_centroids_.data(), sizeof(float), pq_centroids_.size(), f);
-  std::vector<int64_t> ids;
-  std::vector<uint8_t> codes;
-  for (int l = 0; l < nlist_; l++) {
-    int64_t len = gamma_hip_ivfpq_list_size(h_, l);
-    fwrite(&len, sizeof(len), 1, f);
-    if (len <= 0) continue;
-    ids.resize(len);
-    codes.resize((size_t)len * M_);
-    if (gamma_hip_ivfpq_get_list(h_, l, ids.data(), codes.data())) {
-      fclose(f);
-      return -1;
-    }
-    fwrite(ids.data(), sizeof(int64_t), len, f);
-    fwrite(codes.data(), 1, codes.size(), f);
+  if (!is_trained_) {
+    HLOG("index is not trained, skip dumping");
+    return 0;
   }
-  fclose(f);
+  const std::string index_dir = dir + "/" + vector_->MetaInfo()->AbsoluteName();
+  if (mkdir(index_dir.c_str(), 0755) && errno != EEXIST) {
+    HLOG("mkdir error, index dir=%s", index_dir.c_str());
+    return -1;
+  }
+  IwPQFile f;
+  f.d = d_;
+  f.ntotal = 0;   // GammaIVFPQIndex never advances faiss's ntotal; its dumps carry 0
+  f.metric = metric_type_ == DistanceComputeType::INNER_PRODUCT ? 0 : 1;
+  f.nlist = (size_t)nlist_;
+  f.nprobe = (size_t)nprobe_;
+  f.coarse = coarse_centroids_;
+  f.by_residual = true;
+  f.code_size = (size_t)M_;
+  f.M = (size_t)M_;
+  f.nbits = 8;
+  f.pq = pq_centroids_;
+  f.sizes.resize(nlist_);
+  f.codes.resize(nlist_);
+  f.ids.resize(nlist_);
+  for (int l = 0; l < nlist_; l++) {
+    const int64_t len = gamma_hip_ivfpq_list_size(h_, l);
+    if (len < 0) return -1;
+    f.sizes[l] = (size_t)len;
+    if (len == 0) continue;
+    f.ids[l].resize(len);
+    f.codes[l].resize((size_t)len * M_);
+    if (gamma_hip_ivfpq_get_list(h_, l, f.ids[l].data(), f.codes[l].data())) return -1;
+  }
+  if (WriteIwPQ(index_dir + "/ivfpq.index", f)) {
+    HLOG("write error, index dir=%s", index_dir.c_str());
+    return -1;
+  }
   return 0;
 }
 
 int GammaIVFPQHIPIndex::Load(const std::string &dir) {
-  const std::string path = dir + "/hipivfpq.index";
-  FILE *f = fopen(path.c_str(), "rb");
-  if (!f) return 0;   // nothing dumped: zero vectors loaded
-  int32_t hdr[6];
-  if (fread(hdr, sizeof(hdr), 1, f) != 1 || hdr[0] != 0x51504948 || hdr[1] != d_ || hdr[2] != nlist_ ||
-      hdr[3] != M_) {
-    fclose(f);
+  const std::string path = dir + "/" + vector_->MetaInfo()->AbsoluteName() + "/ivfpq.index";
+  FILE *probe = fopen(path.c_str(), "rb");
+  if (!probe) {
+    HLOG("%s isn't existed, skip loading", path.c_str());
+    return 0;   // it should train again after load
+  }
+  fclose(probe);
+  IwPQFile f;
+  const int rc = ReadIwPQ(path, &f);
+  if (rc) {
+    HLOG("cannot read %s (%d)", path.c_str(), rc);
     return -1;
   }
-  coarse_centroids_.resize((size_t)nlist_ * d_);
-  pq_centroids_.resize((size_t)M_ * 256 * (d_ / M_));
-  bool ok = fread(coarse_centroids_.data(), sizeof(float), coarse_centroids_.size(), f) == coarse_centroids_.size() &&
-            fread(pq_centroids_.data(), sizeof(float), pq_centroids_.size(), f) == pq_centroids_.size();
-  if (ok) ok = gamma_hip_ivfpq_set_trained(h_, coarse_centroids_.data(), pq_centroids_.data(), nullptr) == 0;
-  std::vector<int64_t> ids;
-  std::vector<uint8_t> codes;
-  for (int l = 0; ok && l < nlist_; l++) {
-    int64_t len = 0;
-    ok = fread(&len, sizeof(len), 1, f) == 1;
-    if (!ok || len <= 0) continue;
-    ids.resize(len);
-    codes.resize((size_t)len * M_);
-    ok = fread(ids.data(), sizeof(int64_t), len, f) == (size_t)len &&
-         fread(codes.data(), 1, codes.size(), f) == codes.size() &&
-         gamma_hip_ivfpq_add_keys(h_, l, (int)len, ids.data(), codes.data()) == 0;
+  if (f.d != d_ || (int)f.nlist != nlist_ || (int)f.M != M_ || f.nbits != 8 || (int)f.code_size != M_ ||
+      !f.by_residual || f.pq.size() != (size_t)M_ * 256 * (d_ / M_)) {
+    HLOG("index file does not match the table's retrieval_param");
+    return -1;
   }
-  fclose(f);
-  if (!ok) return -1;
-  is_trained_ = true;
-  indexed_vec_count_ = hdr[5];
+  if (SetTrained(f.coarse.data(), f.pq.data())) return -1;   // T2 is recomputed, as in the reference
+  metric_type_ = f.metric == 0 ? DistanceComputeType::INNER_PRODUCT : DistanceComputeType::L2;
+  int64_t count = 0;
+  for (int l = 0; l < nlist_; l++) {
+    const size_t n = f.sizes[l];
+    if (n == 0) continue;
+    if (gamma_hip_ivfpq_add_keys(h_, l, (int)n, f.ids[l].data(), f.codes[l].data())) return -1;
+    for (size_t i = 0; i < n; i++)
+      if (f.ids[l][i] >= 0) count++;   // bit 63 = superseded by an Update (gamma_index_io.cc:186-189)
+  }
+  indexed_vec_count_ = (int)count;
   // raw vectors for the re-rank come back from the engine's vector store
   if (EnsureRaw(std::min<int64_t>(indexed_vec_count_, (int64_t)vector_->MetaInfo()->Size()))) return -1;
   return indexed_vec_count_;

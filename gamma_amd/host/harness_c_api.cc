@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "gamma_index_ivfpq_hip.h"
+#include "iwpq_io.h"
 #include "retrieval_model.h"
 
 using namespace tig_gamma;
@@ -170,6 +171,58 @@ void gh_parse_ivfpq_retrieval_params(const char *str, int *out) {
   }
   delete rp;
 }
+// ---- IwPQ file IO (host only) ----
+int gh_iwpq_write(const char *path, int d, int64_t ntotal, int metric, int nlist, int nprobe, const float *cc,
+                  int M, const float *pqc, const int64_t *sizes, const uint8_t *codes, const int64_t *ids) {
+  IwPQFile f;
+  f.d = d;
+  f.ntotal = ntotal;
+  f.metric = metric;
+  f.nlist = nlist;
+  f.nprobe = nprobe;
+  f.coarse.assign(cc, cc + (size_t)nlist * d);
+  f.code_size = f.M = M;
+  f.pq.assign(pqc, pqc + (size_t)M * 256 * (d / M));
+  f.sizes.resize(nlist);
+  f.codes.resize(nlist);
+  f.ids.resize(nlist);
+  size_t off = 0;
+  for (int l = 0; l < nlist; l++) {
+    const size_t n = (size_t)sizes[l];
+    f.sizes[l] = n;
+    f.codes[l].assign(codes + off * M, codes + (off + n) * M);
+    f.ids[l].assign(ids + off, ids + off + n);
+    off += n;
+  }
+  return WriteIwPQ(path, f);
+}
+// pass 1 (cc == NULL): hdr = {d, ntotal, metric, nlist, nprobe, M, nbits, code_size, by_residual, sum sizes};
+// pass 2: fills cc, pqc, sizes[nlist], codes and ids (concatenated in list order)
+int gh_iwpq_read(const char *path, int64_t *hdr, float *cc, float *pqc, int64_t *sizes, uint8_t *codes,
+                 int64_t *ids) {
+  IwPQFile f;
+  const int rc = ReadIwPQ(path, &f);
+  if (rc) return rc;
+  size_t tot = 0;
+  for (size_t l = 0; l < f.nlist; l++) tot += f.sizes[l];
+  const int64_t h[10] = {f.d, f.ntotal, f.metric, (int64_t)f.nlist, (int64_t)f.nprobe, (int64_t)f.M,
+                         (int64_t)f.nbits, (int64_t)f.code_size, f.by_residual ? 1 : 0, (int64_t)tot};
+  memcpy(hdr, h, sizeof(h));
+  if (!cc) return 0;
+  memcpy(cc, f.coarse.data(), sizeof(float) * f.coarse.size());
+  memcpy(pqc, f.pq.data(), sizeof(float) * f.pq.size());
+  size_t off = 0;
+  for (size_t l = 0; l < f.nlist; l++) {
+    sizes[l] = (int64_t)f.sizes[l];
+    if (f.sizes[l]) {
+      memcpy(codes + off * f.code_size, f.codes[l].data(), f.codes[l].size());
+      memcpy(ids + off, f.ids[l].data(), sizeof(int64_t) * f.ids[l].size());
+    }
+    off += f.sizes[l];
+  }
+  return 0;
+}
+
 int gh_model_registered(const char *name) {
   RetrievalModel *m = reflector().GetNewModel(name);
   if (!m) return 0;

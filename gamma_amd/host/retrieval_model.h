@@ -124,6 +124,11 @@ class VectorMetaInfo {
   size_t Size() { return size_; }
   long MemBytes() { return mem_bytes_; }
   int DataSize() { return data_size_; }
+  std::string AbsoluteName() {
+    char v[4];
+    snprintf(v, sizeof(v), "%03d", version_);
+    return name_ + "." + v;
+  }
   std::string name_;
   int dimension_;
   VectorValueType data_type_;

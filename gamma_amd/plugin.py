@@ -36,6 +36,9 @@ HOST_SYMBOLS = {
     "gh_parse_ivfpq_model_params": (None, [C.c_char_p, C.POINTER(C.c_int)]),
     "gh_parse_ivfpq_retrieval_params": (None, [C.c_char_p, C.POINTER(C.c_int)]),
     "gh_model_registered": (C.c_int, [C.c_char_p]),
+    "gh_iwpq_write": (C.c_int, [C.c_char_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p,
+                                i64p, _lib.u8p, i64p]),
+    "gh_iwpq_read": (C.c_int, [C.c_char_p, i64p, f32p, f32p, i64p, _lib.u8p, i64p]),
 }
 
 _host = None
@@ -74,6 +77,40 @@ def parse_retrieval_params(s):
     out = (C.c_int * 4)()
     load_host().gh_parse_ivfpq_retrieval_params(s.encode(), out)
     return dict(zip(["rc", "metric", "recall_num", "nprobe"], list(out)))
+
+
+def iwpq_write(path, d, ntotal, metric, nprobe, cc, pq, list_sizes, list_codes, list_ids):
+    """Write the reference's ivfpq.index ("IwPQ") file; metric 0 = inner product, 1 = L2."""
+    cc = np.ascontiguousarray(cc, np.float32)
+    pq = np.ascontiguousarray(pq, np.float32)
+    sizes = np.ascontiguousarray(list_sizes, np.int64)
+    codes = np.ascontiguousarray(list_codes, np.uint8)
+    ids = np.ascontiguousarray(list_ids, np.int64)
+    M = pq.shape[0]
+    return load_host().gh_iwpq_write(path.encode(), d, ntotal, metric, cc.shape[0], nprobe, _f(cc), M, _f(pq),
+                                     sizes.ctypes.data_as(i64p), codes.ctypes.data_as(_lib.u8p),
+                                     ids.ctypes.data_as(i64p))
+
+
+def iwpq_read(path):
+    L = load_host()
+    hdr = np.zeros(10, np.int64)
+    rc = L.gh_iwpq_read(path.encode(), hdr.ctypes.data_as(i64p), None, None, None, None, None)
+    if rc:
+        raise _lib.GammaHipError("cannot read %s (%d)" % (path, rc))
+    d, ntotal, metric, nlist, nprobe, M, nbits, code_size, by_res, tot = [int(v) for v in hdr]
+    cc = np.empty((nlist, d), np.float32)
+    pq = np.empty((M, 1 << nbits, d // M), np.float32)
+    sizes = np.empty(nlist, np.int64)
+    codes = np.empty((tot, code_size), np.uint8)
+    ids = np.empty(tot, np.int64)
+    rc = L.gh_iwpq_read(path.encode(), hdr.ctypes.data_as(i64p), _f(cc), _f(pq), sizes.ctypes.data_as(i64p),
+                        codes.ctypes.data_as(_lib.u8p), ids.ctypes.data_as(i64p))
+    if rc:
+        raise _lib.GammaHipError("cannot read %s (%d)" % (path, rc))
+    return dict(d=d, ntotal=ntotal, metric=metric, nlist=nlist, nprobe=nprobe, M=M, nbits=nbits,
+                code_size=code_size, by_residual=by_res, cc=cc, pq=pq, list_sizes=sizes, list_codes=codes,
+                list_ids=ids)
 
 
 class PluginModel:

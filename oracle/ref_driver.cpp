@@ -9,6 +9,7 @@
 #include <faiss/IndexFlat.h>
 #include <faiss/IndexIVFPQ.h>
 #include <faiss/impl/ProductQuantizer.h>
+#include <faiss/index_io.h>
 #include <faiss/invlists/InvertedLists.h>
 #include <faiss/utils/Heap.h>
 #include <faiss/utils/distances.h>
@@ -158,6 +159,11 @@ int ref_ivfpq_use_precomputed_table(void* h) {
 void ref_ivfpq_set_metric(void* h, int metric_ip) {
     ((RefIVFPQ*)h)->index->metric_type =
             metric_ip ? faiss::METRIC_INNER_PRODUCT : faiss::METRIC_L2;
+}
+// faiss's own "IwPQ" writer (faiss:impl/index_write.cpp): the byte layout Gamma's Dump mirrors
+// (index/gamma_index_io.cc:16-192, index/impl/gamma_index_ivfpq.cc:958-992)
+void ref_ivfpq_write_index(void* h, const char* path) {
+    faiss::write_index(((RefIVFPQ*)h)->index, path);
 }
 void ref_ivfpq_set_nprobe(void* h, int nprobe) {
     ((RefIVFPQ*)h)->index->nprobe = nprobe;

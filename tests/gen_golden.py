@@ -200,7 +200,39 @@ def gen_realtime():
     np.savez_compressed(os.path.join(OUT, "realtime.npz"), **out)
 
 
+def gen_iwpq(R):
+    """A small index trained and filled by real faiss, and the bytes faiss::write_index produces
+    for it: the "IwPQ" layout GammaIVFPQIndex::Dump mirrors (index/gamma_index_io.cc:16-192)."""
+    import ctypes as C
+    import tempfile
+    d, nlist, M, N = 16, 8, 4, 700
+    base = synth.sift_like(N, d=d, seed=1234)
+    r = B.RefIVFPQ(d, nlist, M, 8, B.METRIC_L2)
+    r.train(base)
+    r.add(base)
+    R.ref_ivfpq_set_nprobe.argtypes = [C.c_void_p, C.c_int]
+    R.ref_ivfpq_write_index.argtypes = [C.c_void_p, C.c_char_p]
+    R.ref_ivfpq_set_nprobe(r.h, 5)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "ivfpq.index")
+        R.ref_ivfpq_write_index(r.h, path.encode())
+        blob = np.frombuffer(open(path, "rb").read(), dtype=np.uint8).copy()
+    sizes, ids, codes = [], [], []
+    for l in range(nlist):
+        i, c = r.get_list(l)
+        sizes.append(len(i))
+        ids.append(i)
+        codes.append(c)
+    np.savez_compressed(os.path.join(OUT, "iwpq_small.npz"), d=d, nlist=nlist, M=M, N=N, nprobe=5,
+                        cc=r.coarse_centroids(), pq=r.pq_centroids(),
+                        list_sizes=np.array(sizes, dtype=np.int64), list_ids=np.concatenate(ids),
+                        list_codes=np.concatenate(codes), file_bytes=blob)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "iwpq":     # add one fixture, leave the others alone
+        gen_iwpq(B.ref())
+        return
     if not B.have_ref():
         raise SystemExit("oracle/_ref/libgamma_ref.so missing: run make -f oracle/Makefile.ref")
     os.makedirs(OUT, exist_ok=True)

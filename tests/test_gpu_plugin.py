@@ -189,3 +189,43 @@ def test_plugin_range_filters(case):
         Dg, Ig = m.search(q[:16], 10, "", brute_force=True, range_filters=cl)
         compare_topk(Df, If, Dg, Ig)
     m.close()
+
+
+def test_plugin_loads_an_index_dumped_by_the_reference(tmp_path):
+    """Load() of an ivfpq.index whose bytes were written by real faiss in the layout
+    GammaIVFPQIndex::Dump uses (tests/golden/iwpq_small.npz), then Dump() reproduces the file
+    (up to ntotal, which Gamma leaves at 0) and searches match the oracle on the same lists."""
+    import os
+    from gamma_amd import plugin, synth
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "iwpq_small.npz"))
+    d, nlist, M, N = int(z["d"]), int(z["nlist"]), int(z["M"]), int(z["N"])
+    base = synth.sift_like(N, d=d, seed=1234)
+    os.makedirs(tmp_path / "vec.000")
+    open(tmp_path / "vec.000" / "ivfpq.index", "wb").write(z["file_bytes"].tobytes())
+    m = plugin.PluginModel("HIPIVFPQ", d, '{"ncentroids": %d, "nsubvector": %d, "nprobe": 5, "metric_type": "L2"}'
+                           % (nlist, M), indexing_size=N)
+    m.store(base)
+    assert m.load(str(tmp_path)) == N
+    o = B.OracleIVFPQ(d, nlist, M, 8, B.METRIC_L2)
+    o.set_trained(z["cc"], z["pq"], None)
+    off = 0
+    for l in range(nlist):
+        n = int(z["list_sizes"][l])
+        if n:
+            o.add_keys(l, z["list_ids"][off:off + n], z["list_codes"][off:off + n])
+        off += n
+    o.set_raw(base)
+    q = synth.sift_like(40, d=d, seed=4321)
+    for has_rank in (True, False):
+        D, I = o.search(q, 10, 5, recall_num=50, has_rank=has_rank, metric=B.METRIC_L2, ctx=B.make_ctx(),
+                        coarse_mode=-1)
+        Dg, Ig = m.search(q, 10, '{"metric_type": "L2", "recall_num": 50}', has_rank=has_rank)
+        compare_topk(D, I, Dg, Ig)
+    out = tmp_path / "redump"
+    os.makedirs(out)
+    assert m.dump(str(out)) == 0
+    got = plugin.iwpq_read(str(out / "vec.000" / "ivfpq.index"))
+    assert got["ntotal"] == 0 and got["nprobe"] == 5
+    assert got["cc"].tobytes() == z["cc"].tobytes() and got["pq"].tobytes() == z["pq"].tobytes()
+    assert np.array_equal(got["list_ids"], z["list_ids"]) and np.array_equal(got["list_codes"], z["list_codes"])
+    m.close()

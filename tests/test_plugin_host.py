@@ -68,3 +68,55 @@ def test_retrieval_params():
 def test_unknown_model_name():
     L = plugin.load_host()
     assert not L.gh_host_new(b"NOPE", 8)
+
+
+# ---- ivfpq.index ("IwPQ") file format, pinned on bytes written by real faiss (tests/gen_golden.py) ----
+def _golden_iwpq():
+    import numpy as np
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "iwpq_small.npz"))
+
+
+def test_iwpq_writer_matches_faiss_bytes(tmp_path):
+    z = _golden_iwpq()
+    path = str(tmp_path / "ivfpq.index")
+    rc = plugin.iwpq_write(path, int(z["d"]), int(z["N"]), 1, int(z["nprobe"]), z["cc"], z["pq"],
+                           z["list_sizes"], z["list_codes"], z["list_ids"])
+    assert rc == 0
+    got = open(path, "rb").read()
+    assert got == z["file_bytes"].tobytes()
+
+
+def test_iwpq_reader_on_faiss_file(tmp_path):
+    import numpy as np
+    z = _golden_iwpq()
+    path = str(tmp_path / "ref.index")
+    open(path, "wb").write(z["file_bytes"].tobytes())
+    f = plugin.iwpq_read(path)
+    assert (f["d"], f["nlist"], f["M"], f["nbits"], f["code_size"], f["metric"], f["by_residual"]) == (
+        int(z["d"]), int(z["nlist"]), int(z["M"]), 8, int(z["M"]), 1, 1)
+    assert f["ntotal"] == int(z["N"]) and f["nprobe"] == int(z["nprobe"])
+    assert f["cc"].tobytes() == z["cc"].tobytes() and f["pq"].tobytes() == z["pq"].tobytes()
+    assert np.array_equal(f["list_sizes"], z["list_sizes"])
+    assert np.array_equal(f["list_ids"], z["list_ids"]) and np.array_equal(f["list_codes"], z["list_codes"])
+
+
+def test_iwpq_superseded_ids_and_bad_files(tmp_path):
+    import numpy as np
+    z = _golden_iwpq()
+    ids = z["list_ids"].copy()
+    ids[3] |= np.int64(-2 ** 63)                 # bit 63: slot superseded by an Update
+    path = str(tmp_path / "moved.index")
+    assert plugin.iwpq_write(path, int(z["d"]), 0, 0, 7, z["cc"], z["pq"], z["list_sizes"], z["list_codes"],
+                             ids) == 0
+    f = plugin.iwpq_read(path)
+    assert f["ntotal"] == 0 and f["metric"] == 0 and f["nprobe"] == 7
+    assert np.array_equal(f["list_ids"], ids)
+    bad = str(tmp_path / "bad.index")
+    open(bad, "wb").write(b"IxF2" + bytes(100))
+    with pytest.raises(Exception):
+        plugin.iwpq_read(bad)
+    open(bad, "wb").write(z["file_bytes"].tobytes()[:5000])      # truncated
+    with pytest.raises(Exception):
+        plugin.iwpq_read(bad)
+    with pytest.raises(Exception):
+        plugin.iwpq_read(str(tmp_path / "missing.index"))
