@@ -506,20 +506,28 @@ void launch_l2_gemmform(hipStream_t s, const float* x, int nq, int d, const floa
 // ------------------------------------------------------------------------------------
 // a4: per-query inner-product table  st2[q][m][j] = <x_q,m , c_mj>
 // (ProductQuantizer::compute_inner_prod_table, faiss:impl/ProductQuantizer.cpp:518-531)
-// block = 256 threads = the 256 centroids of one sub-quantizer; grid = (M, nq).
+// block = 256 threads = the 256 centroids of one sub-quantizer; grid = (M, nq / IPT_QB).
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pq_ip_table(const float* __restrict__ x, int d, int M,
+constexpr int IPT_QB = 8;   // queries per workgroup: the centroid row stays in registers
+__global__ __launch_bounds__(256) void k_pq_ip_table(const float* __restrict__ x, int nq, int d, int M,
                                                      int dsub, const float* __restrict__ pqc,
                                                      float* __restrict__ out) {
-    const int m = blockIdx.x, q = blockIdx.y, j = threadIdx.x;
-    const float* xs = x + (int64_t)q * d + m * dsub;                 // wave-uniform
+    const int m = blockIdx.x, q0 = blockIdx.y * IPT_QB, j = threadIdx.x;
     const float* c = pqc + ((int64_t)m * 256 + j) * dsub;            // per-lane row
-    out[((int64_t)q * M + m) * 256 + j] = fvec_ny_row<false>(xs, c, dsub);
+#pragma unroll
+    for (int u = 0; u < IPT_QB; u++) {
+        const int q = q0 + u;
+        if (q < nq) {                                                // uniform
+            const float* xs = x + (int64_t)q * d + m * dsub;         // wave-uniform
+            out[((int64_t)q * M + m) * 256 + j] = fvec_ny_row<false>(xs, c, dsub);
+        }
+    }
 }
 void launch_pq_ip_table(hipStream_t s, const float* x, int nq, int d, int M, const float* pqc,
                         float* out) {
     if (nq <= 0) return;
-    hipLaunchKernelGGL(k_pq_ip_table, dim3(M, nq), dim3(256), 0, s, x, d, M, d / M, pqc, out);
+    hipLaunchKernelGGL(k_pq_ip_table, dim3(M, (nq + IPT_QB - 1) / IPT_QB), dim3(256), 0, s, x, nq, d, M,
+                       d / M, pqc, out);
 }
 
 // precomputed table T2[l][m][j] = ||c_mj||^2 + 2 <centroid_l,m , c_mj>
