@@ -108,9 +108,6 @@ struct gamma_hip_index {
             w_m_dis, w_m_ids, w_part_v, w_part_i, w_assign, w_codes_tmp, w_qperm;
     unsigned long long* d_scan_codes = nullptr;
     size_t dist_budget_bytes = (size_t)2 << 30;
-    // EXPERIMENTAL fused scan+select kernel (qscan.hip): parity-green but, at one workgroup
-    // per CU, slower than the unfused chain on MI355X -- opt-in only
-    bool use_qscan = getenv("GAMMA_HIP_ENABLE_QSCAN") != nullptr;
 
     // last-search stage info
     int last_nq = 0, last_P = 0, last_R = 0;
@@ -423,46 +420,6 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
     // ids are only read during the scan when something can reject an entry: a delete bit,
     // a range filter, or a superseded (bit 63) slot left behind by Update
     const int need_ids = (filt.has_range || (filt.del_bitmap && h->bitmap_any) || h->n_moved > 0) ? 1 : 0;
-    if (h->use_qscan && gh::qscan_supported(d, M, R, P)) {
-        // fused path: LUT recomputed from registers, scan + top-R in one kernel (qscan.hip)
-        const float* dis0 = h->w_coarse_dis.as<float>();
-        if (!l2) {
-            StageScope t(h, GAMMA_HIP_STAGE_TABLES);
-            GH_CHECK(h, h->w_st2.ensure((size_t)nq * P * sizeof(float)));
-            gh::launch_ip_dis0(s, d_x, nq, d, P, h->w_probe.as<int>(), h->d_cc, nlist, h->w_st2.as<float>());
-            dis0 = h->w_st2.as<float>();
-        }
-        // enough workgroups to fill the chip when the batch is small: split the probes
-        int PG = 1;
-        if (nq < 512) PG = std::max(1, std::min(P, 512 / std::max(1, nq)));
-        if (PG == 1) {
-            StageScope t(h, GAMMA_HIP_STAGE_SCAN);
-            gh::launch_ivfpq_qscan(s, l2, d_x, nq, d, M, P, 1, h->w_probe.as<int>(), dis0, h->d_cc,
-                                   h->d_pqc, h->d_list_off, h->d_list_len, h->d_list_mask, nlist,
-                                   h->d_codes, h->d_ids, filt, need_ids, R, h->w_cand_dis.as<float>(),
-                                   h->w_cand_ids.as<int64_t>(), h->w_qtotal.as<int>());
-        } else {
-            GH_CHECK(h, h->w_m_dis.ensure((size_t)nq * PG * R * sizeof(float)));
-            GH_CHECK(h, h->w_m_ids.ensure((size_t)nq * PG * R * sizeof(int64_t)));
-            {
-                StageScope t(h, GAMMA_HIP_STAGE_SCAN);
-                gh::launch_ivfpq_qscan(s, l2, d_x, nq, d, M, P, PG, h->w_probe.as<int>(), dis0, h->d_cc,
-                                       h->d_pqc, h->d_list_off, h->d_list_len, h->d_list_mask, nlist,
-                                       h->d_codes, h->d_ids, filt, need_ids, R, h->w_m_dis.as<float>(),
-                                       h->w_m_ids.as<int64_t>(), h->w_qtotal.as<int>());
-            }
-            StageScope t(h, GAMMA_HIP_STAGE_SELECT);
-            // partial lists cover contiguous probe ranges and are sorted on (distance, scan
-            // position), so index order inside [q][PG*R] is scan order among equal distances
-            gh::launch_select_topk(s, l2, h->w_m_dis.as<float>(), (int64_t)PG * R, nullptr, PG * R, PG * R,
-                                   nq, R, h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>());
-            gh::launch_take_ids(s, h->w_cand_pos.as<int>(), h->w_m_ids.as<int64_t>(), (int64_t)PG * R, nq, R,
-                                h->w_cand_ids.as<int64_t>());
-        }
-        if (h->profile) gh::launch_sum_totals(s, h->w_qtotal.as<int>(), nq, h->d_scan_codes);
-        GH_CHECK(h, hipGetLastError());
-        return GAMMA_HIP_OK;
-    }
     const int* qperm = nullptr;
     {
         StageScope t(h, GAMMA_HIP_STAGE_TABLES);

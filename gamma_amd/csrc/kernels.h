@@ -49,15 +49,6 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
 void launch_query_order(hipStream_t s, const int* probe_list, int nq, int P, const int* list_rank,
                         int nlist, int* qkey, int* qperm);
 void launch_sum_totals(hipStream_t s, const int* q_total, int nq, unsigned long long* acc);
-// fused scan + select (qscan.hip)
-bool qscan_supported(int d, int M, int R, int P);
-void launch_ip_dis0(hipStream_t s, const float* x, int nq, int d, int P, const int* probe_list,
-                    const float* cc, int nlist, float* out);
-void launch_ivfpq_qscan(hipStream_t s, bool l2, const float* x, int nq, int d, int M, int P, int PG,
-                        const int* probe_list, const float* dis0, const float* cc, const float* pqc,
-                        const int64_t* list_off, const int* list_len, const uint8_t* list_mask,
-                        int nlist, const uint8_t* codes, const int64_t* ids, const FilterDesc& filt,
-                        int need_ids, int R, float* out_dis, int64_t* out_ids, int* q_total);
 int select_kpad(int K);
 void launch_select_topk(hipStream_t s, bool smallest, const float* vals, int64_t seg_stride,
                         const int* seg_len, int fixed_len, int max_len, int nseg, int K,
