@@ -56,6 +56,7 @@ struct DevBuf {
 struct StageEvent {
     int stage;
     hipEvent_t a, b;
+    bool count;
 };
 
 }  // namespace
@@ -86,6 +87,7 @@ struct gamma_hip_index {
     float *d_cc = nullptr, *d_cc_norms = nullptr, *d_pqc = nullptr, *d_T2 = nullptr;
     int* d_list_rank = nullptr;   // spatial order of the coarse centroids (scan locality only)
     bool sort_queries = getenv("GAMMA_HIP_NO_QUERY_SORT") == nullptr;
+    bool scan_bound = getenv("GAMMA_HIP_NO_SCAN_BOUND") == nullptr;
 
     // inverted-list arena
     uint8_t* d_codes = nullptr;
@@ -105,7 +107,7 @@ struct gamma_hip_index {
     // workspace
     DevBuf w_mat, w_coarse_dis, w_probe, w_xn, w_st2, w_pair_off, w_qtotal, w_dist, w_cand_dis,
             w_cand_pos, w_cand_ids, w_exact, w_selv, w_selp, w_x, w_outd, w_outl, w_stage, w_filter,
-            w_m_dis, w_m_ids, w_part_v, w_part_i, w_assign, w_codes_tmp, w_qperm;
+            w_m_dis, w_m_ids, w_part_v, w_part_i, w_assign, w_codes_tmp, w_qperm, w_tau, w_scnt, w_sflag, w_surv;
     unsigned long long* d_scan_codes = nullptr;
     size_t dist_budget_bytes = (size_t)2 << 30;
 
@@ -147,8 +149,9 @@ int fail(H* h, int code, const char* msg) {
 struct StageScope {
     H* h;
     int stage;
+    bool count;   // false: add the time to the stage but do not count a new invocation
     hipEvent_t a = nullptr, b = nullptr;
-    StageScope(H* h_, int st) : h(h_), stage(st) {
+    StageScope(H* h_, int st, bool count_ = true) : h(h_), stage(st), count(count_) {
         if (h->profile) {
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
                 a = b = nullptr;
@@ -160,7 +163,7 @@ struct StageScope {
     ~StageScope() {
         if (a && b) {
             (void)hipEventRecord(b, h->stream);
-            h->events.push_back({stage, a, b});
+            h->events.push_back({stage, a, b, count});
         }
     }
 };
@@ -172,7 +175,7 @@ int drain_events(H* h) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
             h->stage_ms[e.stage] += ms;
-            h->stage_n[e.stage] += 1;
+            h->stage_n[e.stage] += e.count ? 1 : 0;
         }
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -396,7 +399,8 @@ int ivfpq_coarse(H* h, const gamma_hip_search_params* p, int nq, const float* d_
 // pre_dis / pre_probe: coarse assignment computed elsewhere (sharded search: the rank owning the
 // query slice), device pointers [nq*nprobe]; nullptr = run the coarse quantizer here
 int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& filt, int nq,
-                  const float* d_x, int R, const float* pre_dis = nullptr, const int* pre_probe = nullptr) {
+                  const float* d_x, int R, const float* pre_dis = nullptr, const int* pre_probe = nullptr,
+                  bool allow_bound = true) {
     const int P = p->nprobe, d = h->d, M = h->M, nlist = h->nlist;
     const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
     hipStream_t s = h->stream;
@@ -438,19 +442,66 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
     // per-query slab of the distance buffer; multiple of 4 floats so rows are 16-byte aligned
     const int64_t q_stride = (std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len)) + 3) & ~(int64_t)3;
     GH_CHECK(h, h->w_dist.ensure((size_t)nq * q_stride * sizeof(float)));
-    {
-        StageScope t(h, GAMMA_HIP_STAGE_SCAN);
+    const int G = gh::scan_group_size(nq, P), PGN = (P + G - 1) / G;
+    auto scan = [&](int gsz, int pg_lo, int pg_cnt, const gh::ScanBound* bound, bool count) {
+        StageScope t(h, GAMMA_HIP_STAGE_SCAN, count);
         gh::launch_ivfpq_scan_pair(s, l2, d_x, nq, d, M, P, h->w_probe.as<int>(),
                                    h->w_coarse_dis.as<float>(), h->d_cc, h->w_st2.as<float>(), h->d_T2,
                                    h->d_list_off, h->d_list_len, h->d_list_mask, nlist, h->d_codes,
                                    h->d_ids, h->w_pair_off.as<int>(), q_stride, h->w_dist.as<float>(),
-                                   filt, need_ids, qperm);
-    }
-    {
+                                   filt, need_ids, qperm, gsz, pg_lo, pg_cnt, bound);
+    };
+    // Threshold pre-filter: scan the nearest probe group first, bound each query's R-th best
+    // distance from it, and let the scan of the remaining groups keep a short survivor list per
+    // query; the exact top-R then comes from a few hundred survivors instead of ~10^4 candidates
+    // (select.hip).  Queries without a usable bound fall back to the unfiltered selection.
+    const bool bounded = allow_bound && h->scan_bound && R <= 256 && PGN >= 2;
+    if (!bounded) {
+        scan(G, 0, PGN, nullptr, true);
         StageScope t(h, GAMMA_HIP_STAGE_SELECT);
         gh::launch_select_topk(s, l2, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), 0,
                                (int)std::min<int64_t>(q_stride, 1 << 30), nq, R,
                                h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>());
+        gh::launch_map_candidates(s, h->w_cand_pos.as<int>(), nq, R, P, h->w_probe.as<int>(),
+                                  h->w_pair_off.as<int>(), h->d_list_off, h->d_ids,
+                                  h->w_cand_ids.as<int64_t>());
+    } else {
+        const int caps = gh::scan_bound_caps();
+        GH_CHECK(h, h->w_scnt.ensure((size_t)nq * (sizeof(unsigned long long) + sizeof(int))));   // ready[nq] | cnt[nq]
+        GH_CHECK(h, h->w_sflag.ensure((size_t)nq));
+        GH_CHECK(h, h->w_surv.ensure((size_t)nq * caps * sizeof(unsigned long long)));
+        GH_CHECK(h, hipMemsetAsync(h->w_scnt.p, 0, (size_t)nq * (sizeof(unsigned long long) + sizeof(int)), s));
+        gh::ScanBound sb;
+        sb.ready = h->w_scnt.as<unsigned long long>();
+        sb.surv = h->w_surv.as<unsigned long long>();
+        sb.cnt = reinterpret_cast<int*>(h->w_scnt.as<unsigned long long>() + nq);
+        sb.caps = caps;
+        sb.K = R;
+        scan(G, 0, PGN, &sb, true);
+        static const bool dbg = getenv("GAMMA_HIP_BOUND_DBG") != nullptr;
+        static int shown = 0;
+        StageScope t(h, GAMMA_HIP_STAGE_SELECT);
+        gh::launch_select_final(s, l2, sb.surv, sb.cnt, sb.ready, h->w_dist.as<float>(), q_stride,
+                                h->w_pair_off.as<int>(), P, G, nq, R, h->w_sflag.as<uint8_t>(),
+                                h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>());
+        gh::launch_select_topk(s, l2, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), 0,
+                               (int)std::min<int64_t>(q_stride, 1 << 30), nq, R,
+                               h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>(), h->w_sflag.as<uint8_t>());
+        if (dbg && shown++ == 8) {
+            std::vector<uint8_t> hf(nq);
+            std::vector<int> hc(nq);
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(hf.data(), h->w_sflag.p, nq, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(hc.data(), sb.cnt, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost);
+            int64_t nf = 0, tot = 0, mx = 0;
+            for (int i = 0; i < nq; i++) {
+                nf += hf[i];
+                tot += hc[i];
+                mx = std::max<int64_t>(mx, hc[i]);
+            }
+            fprintf(stderr, "scan bound: %lld of %d queries unfiltered, survivors mean %.1f max %lld\n",
+                    (long long)nf, nq, (double)tot / nq, (long long)mx);
+        }
         gh::launch_map_candidates(s, h->w_cand_pos.as<int>(), nq, R, P, h->w_probe.as<int>(),
                                   h->w_pair_off.as<int>(), h->d_list_off, h->d_ids,
                                   h->w_cand_ids.as<int64_t>());
@@ -678,7 +729,7 @@ int gamma_hip_destroy(gamma_hip_index* h) {
                       &h->w_qtotal, &h->w_dist, &h->w_cand_dis, &h->w_cand_pos, &h->w_cand_ids,
                       &h->w_exact, &h->w_selv, &h->w_selp, &h->w_x, &h->w_outd, &h->w_outl, &h->w_stage,
                       &h->w_filter, &h->w_m_dis, &h->w_m_ids, &h->w_part_v, &h->w_part_i, &h->w_assign,
-                      &h->w_codes_tmp, &h->w_qperm};
+                      &h->w_codes_tmp, &h->w_qperm, &h->w_tau, &h->w_scnt, &h->w_sflag, &h->w_surv};
     for (DevBuf* b : bufs) b->release();
     (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1227,7 +1278,7 @@ int gamma_hip_ivfpq_search_shard(gamma_hip_index* h, const gamma_hip_search_para
     const int chunk = query_chunk(h, nq, p->nprobe);
     for (int q0 = 0; q0 < nq; q0 += chunk) {
         const int nc = std::min(chunk, nq - q0);
-        GH_TRY(ivfpq_stage_a(h, p, filt, nc, d_x + (size_t)q0 * h->d, R));
+        GH_TRY(ivfpq_stage_a(h, p, filt, nc, d_x + (size_t)q0 * h->d, R, nullptr, nullptr, /*allow_bound=*/false));
         GH_CHECK(h, hipMemcpyAsync(d_recall_dis + (size_t)q0 * R, h->w_cand_dis.p, (size_t)nc * R * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
         GH_CHECK(h, hipMemcpyAsync(d_recall_ids + (size_t)q0 * R, h->w_cand_ids.p, (size_t)nc * R * sizeof(int64_t), hipMemcpyDeviceToDevice, h->stream));
         h->last_nq = nc;
@@ -1273,8 +1324,10 @@ int gamma_hip_ivfpq_search_shard_preassigned(gamma_hip_index* h, const gamma_hip
     const int chunk = query_chunk(h, nq, P);
     for (int q0 = 0; q0 < nq; q0 += chunk) {
         const int nc = std::min(chunk, nq - q0);
+        // a shard owns ~1/W of the probed lists: the first probe group is usually empty here, so
+        // there is nothing to bound from
         GH_TRY(ivfpq_stage_a(h, p, filt, nc, d_x + (size_t)q0 * h->d, R, d_coarse_dis + (size_t)q0 * P,
-                             d_probe + (size_t)q0 * P));
+                             d_probe + (size_t)q0 * P, /*allow_bound=*/false));
         GH_CHECK(h, hipMemcpyAsync(d_recall_dis + (size_t)q0 * R, h->w_cand_dis.p, (size_t)nc * R * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
         GH_CHECK(h, hipMemcpyAsync(d_recall_ids + (size_t)q0 * R, h->w_cand_ids.p, (size_t)nc * R * sizeof(int64_t), hipMemcpyDeviceToDevice, h->stream));
         h->last_nq = nc;

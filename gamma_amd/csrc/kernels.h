@@ -39,20 +39,37 @@ void launch_precompute_table(hipStream_t s, const float* cc, int nlist, int d, i
 void launch_pair_offsets(hipStream_t s, const int* probe_list, int nq, int P, const int* list_len,
                          const uint8_t* list_mask, int nlist, int* pair_off, int* q_total,
                          unsigned long long* scan_codes);
+// threshold pre-filter of the scan (kernels.hip, k_ivfpq_scan_pair<.., FILT>)
+struct ScanBound {
+    unsigned long long* ready;  // [nq] 0 = not yet published; (1 << 32 | key bound) = bound valid;
+                                // (2 << 32) = no bound (unfiltered selection); zeroed per launch
+    unsigned long long* surv;   // [nq][caps] survivors as (key << 32 | position in the query's segment)
+    int* cnt;                   // [nq] survivors appended (may exceed caps: overflow -> unfiltered selection); zeroed per launch
+    int caps;
+    int K;                      // recall_num
+};
+int scan_group_size(int nq, int P);
 void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int d, int M, int P,
                             const int* probe_list, const float* coarse_dis, const float* cc,
                             const float* st2, const float* T2, const int64_t* list_off,
                             const int* list_len, const uint8_t* list_mask, int nlist,
                             const uint8_t* codes, const int64_t* ids, const int* pair_off,
                             int64_t q_stride, float* out, const FilterDesc& filt, int need_ids,
-                            const int* qperm);
+                            const int* qperm, int G, int pg_lo, int pg_cnt, const ScanBound* bound);
 void launch_query_order(hipStream_t s, const int* probe_list, int nq, int P, const int* list_rank,
                         int nlist, int* qkey, int* qperm);
 void launch_sum_totals(hipStream_t s, const int* q_total, int nq, unsigned long long* acc);
 int select_kpad(int K);
 void launch_select_topk(hipStream_t s, bool smallest, const float* vals, int64_t seg_stride,
                         const int* seg_len, int fixed_len, int max_len, int nseg, int K,
-                        float* out_vals, int* out_pos);
+                        float* out_vals, int* out_pos, const uint8_t* only = nullptr);
+// threshold pre-filter of the scan: exact top-K from the survivor lists (select.hip); rows that end
+// with flag != 0 are left to launch_select_topk(..., only = flag)
+int scan_bound_caps();
+void launch_select_final(hipStream_t s, bool smallest, const unsigned long long* surv, const int* cnt,
+                         const unsigned long long* ready, const float* vals, int64_t seg_stride,
+                         const int* pair_off, int P, int G, int nq, int K, uint8_t* flag, float* out_vals,
+                         int* out_pos);
 void launch_map_candidates(hipStream_t s, const int* pos, int nq, int R, int P,
                            const int* probe_list, const int* pair_off, const int64_t* list_off,
                            const int64_t* ids, int64_t* cand_ids);

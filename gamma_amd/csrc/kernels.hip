@@ -693,8 +693,19 @@ void launch_query_order(hipStream_t s, const int* probe_list, int nq, int P, con
 // Codes are AoS [len][M] exactly as the reference stores them; a 16-byte code is one
 // dwordx4 load per lane, so a wave reads 1 KiB contiguous.
 // ------------------------------------------------------------------------------------
-template <bool L2, int MT>
-__global__ __launch_bounds__(256) void k_ivfpq_scan_pair(
+// order-preserving key of a distance in "smaller is better" form (the selection kernels' key)
+template <bool L2>
+__device__ __forceinline__ uint32_t dis_key(float v) {
+    const uint32_t k = f2key(v);
+    return L2 ? k : ~k;
+}
+constexpr uint32_t KEY_SENTINEL = 0xff800000u;   // key of the filtered-entry marker (+inf / -inf)
+constexpr int SCAN_STAGE = 256;                  // survivors staged in LDS per workgroup
+
+// amdgpu_num_sgpr(96): 8 waves per SIMD need <= 96 SGPRs each (800 per SIMD); the FILT variant
+// would otherwise take 100 and lose one of the eight resident workgroups per CU
+template <bool L2, int MT, bool FILT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_ivfpq_scan_pair(
         const float* __restrict__ x, int nq, int d, int M, int P, int G, const int* __restrict__ probe_list,
         const float* __restrict__ coarse_dis, const float* __restrict__ cc,
         const float* __restrict__ st2, const float* __restrict__ T2,
@@ -702,30 +713,120 @@ __global__ __launch_bounds__(256) void k_ivfpq_scan_pair(
         const uint8_t* __restrict__ list_mask, int nlist, const uint8_t* __restrict__ codes,
         const int64_t* __restrict__ ids, const int* __restrict__ pair_off, int64_t q_stride,
         float* __restrict__ out, FilterDesc filt, int need_ids, float sentinel,
-        const int* __restrict__ qperm) {
+        const int* __restrict__ qperm, int pg_lo, int pg_cnt, ScanBound sb) {
+    // This launch covers probe groups [pg_lo, pg_lo + pg_cnt) of every query.
+    // FILT (pg_lo = 0, pg_cnt >= 2): threshold pre-filter.  The workgroup of a query's FIRST probe
+    // group (its nearest lists) ends by bounding the query's recall_num-th best distance from above
+    // with the candidates it has just scored, and publishes that bound; the workgroups of the other
+    // groups append every candidate within the bound, as a (key, position) item, to the query's
+    // short survivor list.  The exact top-recall_num is then selected from the first group's
+    // candidates within the bound plus a few hundred survivors, instead of all ~10^4 candidates
+    // (select.hip, k_select_final).
     // One workgroup scans G consecutive probes of one query: the query's 16 KB table st2 is
     // read ONCE into registers (MT per thread) and reused for the G list-specific LUTs, so
     // the per-pair table traffic drops from 2 x M KB to (1 + 1/G) x M KB.
     extern __shared__ float s_lut[];  // M*256
     __shared__ float s_acc[8];
-    const int PGN = (P + G - 1) / G;
     // XCD-aware placement (speed only): block b runs on XCD b % 8 with its own L2, so all PGN
     // workgroups of one query are given block ids with the same residue -- the query's table
     // st2[q] is then fetched from HBM/MALL once per XCD and served from that L2 afterwards.
     // With qperm (queries sorted by the spatial rank of their nearest list, k_query_order) XCD x
     // takes the x-th contiguous eighth of that order, in order: concurrently running queries
     // probe overlapping lists, so the 16 KB T2 rows they stream are mostly L2 hits as well.
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int pg = slot % PGN;
+    const int xcd = blockIdx.x & 7;
+    int slot = blockIdx.x >> 3, pg, qslot;
+    if (FILT) {
+        // block ids: first the group-0 workgroup of EVERY query (they publish the bounds), then
+        // the other groups.  Workgroups are dispatched in id order, so a consumer only ever waits
+        // for a producer that is already resident or finished.
+        const int nq8 = (nq + 7) >> 3;
+        if (slot < nq8) {
+            pg = 0;
+            qslot = slot;
+        } else {
+            slot -= nq8;
+            pg = 1 + slot % (pg_cnt - 1);
+            qslot = slot / (pg_cnt - 1);
+        }
+    } else {
+        pg = pg_lo + slot % pg_cnt;
+        qslot = slot / pg_cnt;
+    }
     int q;
     if (qperm) {
-        const int qi = xcd * ((nq + 7) >> 3) + slot / PGN;
+        const int qi = xcd * ((nq + 7) >> 3) + qslot;
         if (qi >= nq) return;
         q = qperm[qi];
     } else {
-        q = (slot / PGN) * 8 + xcd;
+        q = qslot * 8 + xcd;
         if (q >= nq) return;
     }
+    const int lane = threadIdx.x & 63;
+    // Survivors are staged in LDS (one LDS atomic per wave and iteration) and flushed to the
+    // query's list with ONE global atomic per workgroup; a returning global atomic per wave
+    // iteration would put ~1 us of latency into the scan loop.  All lanes of a wave call append().
+    __shared__ unsigned long long s_stage[SCAN_STAGE];
+    __shared__ int s_nstage, s_gbase;
+    __shared__ uint32_t s_tau;
+    uint32_t tauq = 0xffffffffu;
+    bool bound_on = false;
+    if (FILT) {
+        if (threadIdx.x == 0) {
+            s_nstage = 0;
+            if (pg > 0) {   // wait for this query's bound (published by its group-0 workgroup)
+                // ONE relaxed 64-bit word carries (state << 32 | bound): no acquire/release fence is
+                // needed (nothing else the producer wrote is read here), and agent-scope fences
+                // would write back / invalidate the L2 this kernel lives on
+                int spins = 0;
+                unsigned long long word;
+                while ((word = __hip_atomic_load(&sb.ready[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0ull &&
+                       ++spins < (1 << 20))
+                    __builtin_amdgcn_s_sleep(16);
+                if (word != 0ull) {
+                    s_tau = (word >> 32) == 1ull ? (uint32_t)word : 0xffffffffu;
+                } else {   // never expected: give the query to the unfiltered selection instead of hanging
+                    s_tau = 0xffffffffu;
+                    atomicAdd(&sb.cnt[q], sb.caps + 1);
+                }
+            }
+        }
+        __syncthreads();
+        if (pg > 0) {
+            tauq = s_tau;
+            bound_on = tauq < KEY_SENTINEL;   // otherwise the query takes the unfiltered selection
+        }
+    }
+    uint32_t g_mn = 0xffffffffu, g_mx = 0u;   // producer (pg == 0): range and count of its valid keys
+    int g_nv = 0;
+    auto append = [&](bool keep, uint32_t key, int pos) {
+        const unsigned long long bal = __ballot(keep);
+        if (bal) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_nstage, __popcll(bal));
+            base = __shfl(base, 0, 64);
+            if (keep) {
+                const int at = base + __popcll(bal & ((1ull << lane) - 1ull));
+                const unsigned long long item = ((unsigned long long)key << 32) | (unsigned)pos;
+                if (at < SCAN_STAGE) {
+                    s_stage[at] = item;
+                } else {   // staging full (rare): straight to the list
+                    const int g = atomicAdd(&sb.cnt[q], 1);
+                    if (g < sb.caps) sb.surv[(int64_t)q * sb.caps + g] = item;
+                }
+            }
+        }
+    };
+    auto flush = [&]() {   // whole workgroup
+        __syncthreads();
+        const int n = min(s_nstage, SCAN_STAGE);
+        if (n > 0) {
+            if (threadIdx.x == 0) s_gbase = atomicAdd(&sb.cnt[q], n);
+            __syncthreads();
+            const int g0 = s_gbase;
+            for (int i = threadIdx.x; i < n; i += 256)
+                if (g0 + i < sb.caps) sb.surv[(int64_t)q * sb.caps + g0 + i] = s_stage[i];
+        }
+    };
     const int p_begin = pg * G, p_end = min(P, p_begin + G);
     const int tid = threadIdx.x;
     const int msz = M * 256;
@@ -796,8 +897,12 @@ __global__ __launch_bounds__(256) void k_ivfpq_scan_pair(
         const int64_t off = list_off[l];
         const uint8_t* lc = codes + off * M;
         const int64_t* lid = ids + off;
-        float* o = out + (int64_t)q * q_stride + pair_off[(int64_t)q * (P + 1) + p];
-        for (int j = tid; j < len; j += 256) {
+        const int pbase = pair_off[(int64_t)q * (P + 1) + p];
+        float* o = out + (int64_t)q * q_stride + pbase;
+        for (int j0 = 0; j0 < len; j0 += 256) {     // uniform trip count: append() ballots
+            const int j = j0 + tid;
+            uint32_t key = 0xffffffffu;
+            if (j < len) {
             // ids are read only when something can reject an entry (delete bit, range filter,
             // superseded slot); otherwise 8 of the 28 bytes per candidate stay in HBM
             bool ok = true;
@@ -825,9 +930,97 @@ __global__ __launch_bounds__(256) void k_ivfpq_scan_pair(
                 const uint8_t* cj = lc + (int64_t)j * M;
                 for (int m = 0; m < M; m++) dis += s_lut[m * 256 + cj[m]];
             }
-            o[j] = ok ? dis : sentinel;
+            const float val = ok ? dis : sentinel;
+            o[j] = val;
+            if (FILT) {
+                key = dis_key<L2>(val);
+                if (pg == 0 && key < KEY_SENTINEL) {
+                    g_mn = key < g_mn ? key : g_mn;
+                    g_mx = key > g_mx ? key : g_mx;
+                    g_nv++;
+                }
+            }
+            }
+            if (FILT && bound_on) append(key <= tauq, key, pbase + j);
         }
     }
+    if (FILT && pg > 0 && bound_on) flush();
+    if (FILT && pg == 0) {
+        // ---- producer: bound of this query's K-th best from its first probe group ----
+        // 256-bin histogram of the group's valid keys over [min, max]; tau = upper edge of the bin
+        // holding the K-th smallest.  At least K candidates are <= tau, hence the whole final top-K.
+        __syncthreads();   // this workgroup's distance stores are visible to all its threads
+        int* hist = reinterpret_cast<int*>(s_stage);   // staging has not been used yet
+        __shared__ uint32_t s_red[12];
+        const int n0 = pair_off[(int64_t)q * (P + 1) + min(G, P)];
+        const float* o0 = out + (int64_t)q * q_stride;
+        uint32_t mn = g_mn, mx = g_mx;
+        int nv = g_nv;
+        mn = wave_min_u32(mn);
+        mx = wave_max_u32(mx);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nv += __shfl_xor(nv, off, 64);
+        if (lane == 0) {
+            s_red[threadIdx.x >> 6] = mn;
+            s_red[4 + (threadIdx.x >> 6)] = mx;
+            s_red[8 + (threadIdx.x >> 6)] = (uint32_t)nv;
+        }
+        hist[threadIdx.x] = 0;
+        __syncthreads();
+        mn = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+        mx = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+        nv = (int)(s_red[8] + s_red[9] + s_red[10] + s_red[11]);
+        uint32_t tau = 0xffffffffu;
+        if (nv >= sb.K) {   // uniform
+            const uint32_t range = mx - mn;
+            const int sh = range >= 256u ? (32 - __clz((int)range)) - 8 : 0;   // (range >> sh) < 256
+            for (int i0 = 0; i0 < n0; i0 += 256 * 8) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) t[u] = o0[min(i0 + u * 256 + (int)threadIdx.x, n0 - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t key = dis_key<L2>(t[u]);
+                    if (i0 + u * 256 + (int)threadIdx.x < n0 && key < KEY_SENTINEL)
+                        atomicAdd(&hist[(key - mn) >> sh], 1);
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < 64) {   // wave 0: scan of the 256 bins, 4 per lane
+                int c[4], c4 = 0;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    c[u] = hist[lane * 4 + u];
+                    c4 += c[u];
+                }
+                const int incl = wave_incl_scan(c4);
+                int run = incl - c4;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (run < sb.K && sb.K <= run + c[u]) {
+                        unsigned long long edge = (unsigned long long)mn +
+                                                  (((unsigned long long)(lane * 4 + u) + 1ull) << sh) - 1ull;
+                        if (edge > (unsigned long long)mx) edge = mx;
+                        s_tau = (uint32_t)edge;
+                    }
+                    run += c[u];
+                }
+            }
+            __syncthreads();
+            tau = s_tau;
+        }
+        if (threadIdx.x == 0)
+            __hip_atomic_store(&sb.ready[q], tau < KEY_SENTINEL ? ((1ull << 32) | tau) : (2ull << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+int scan_group_size(int nq, int P) {
+    // probes per workgroup: amortise the query table, but keep >= ~4096 workgroups in flight
+    static const int g_env = getenv("GAMMA_HIP_SCAN_G") ? atoi(getenv("GAMMA_HIP_SCAN_G")) : 0;
+    int G = g_env > 0 ? g_env : 4;
+    while (G > 1 && (int64_t)nq * ((P + G - 1) / G) < 4096) G >>= 1;
+    return std::max(1, std::min(G, P));
 }
 
 void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int d, int M, int P,
@@ -836,28 +1029,31 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
                             const int* list_len, const uint8_t* list_mask, int nlist,
                             const uint8_t* codes, const int64_t* ids, const int* pair_off,
                             int64_t q_stride, float* out, const FilterDesc& filt, int need_ids,
-                            const int* qperm) {
-    if (nq <= 0) return;
+                            const int* qperm, int G, int pg_lo, int pg_cnt, const ScanBound* bound) {
+    if (nq <= 0 || pg_cnt <= 0) return;
     const size_t lds = (size_t)M * 256 * sizeof(float);
-    // probes per workgroup: amortise the query table, but keep >= ~4096 workgroups in flight
-    static const int g_env = getenv("GAMMA_HIP_SCAN_G") ? atoi(getenv("GAMMA_HIP_SCAN_G")) : 0;
-    int G = g_env > 0 ? g_env : 4;
-    while (G > 1 && (int64_t)nq * ((P + G - 1) / G) < 4096) G >>= 1;
-    G = std::max(1, std::min(G, P));
-    dim3 grid((unsigned)(8 * (int64_t)((nq + 7) / 8) * ((P + G - 1) / G)));
-#define GH_SCAN(LL, MT)                                                                        \
-    hipLaunchKernelGGL((k_ivfpq_scan_pair<LL, MT>), grid, dim3(256), lds, s, x, nq, d, M, P, G, probe_list, \
-                       coarse_dis, cc, st2, T2, list_off, list_len, list_mask, nlist, codes, ids,  \
-                       pair_off, q_stride, out, filt, need_ids, LL ? INFINITY : -INFINITY, qperm)
-    if (l2) {
-        if (M == 16) GH_SCAN(true, 16);
-        else if (M == 32) GH_SCAN(true, 32);
-        else GH_SCAN(true, 0);
+    dim3 grid((unsigned)(8 * (int64_t)((nq + 7) / 8) * pg_cnt));
+    ScanBound sb = {nullptr, nullptr, nullptr, 0, 0};
+    if (bound) sb = *bound;
+#define GH_SCAN(LL, MT, FF)                                                                       \
+    hipLaunchKernelGGL((k_ivfpq_scan_pair<LL, MT, FF>), grid, dim3(256), lds, s, x, nq, d, M, P, G,     \
+                       probe_list, coarse_dis, cc, st2, T2, list_off, list_len, list_mask, nlist, codes, \
+                       ids, pair_off, q_stride, out, filt, need_ids, LL ? INFINITY : -INFINITY, qperm,   \
+                       pg_lo, pg_cnt, sb)
+#define GH_SCAN_M(LL, FF)                       \
+    do {                                        \
+        if (M == 16) GH_SCAN(LL, 16, FF);       \
+        else if (M == 32) GH_SCAN(LL, 32, FF);  \
+        else GH_SCAN(LL, 0, FF);                \
+    } while (0)
+    if (bound) {
+        if (l2) GH_SCAN_M(true, true);
+        else GH_SCAN_M(false, true);
     } else {
-        if (M == 16) GH_SCAN(false, 16);
-        else if (M == 32) GH_SCAN(false, 32);
-        else GH_SCAN(false, 0);
+        if (l2) GH_SCAN_M(true, false);
+        else GH_SCAN_M(false, false);
     }
+#undef GH_SCAN_M
 #undef GH_SCAN
 }
 

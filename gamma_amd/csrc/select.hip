@@ -63,7 +63,9 @@ template <bool SMALLEST, int NPT>
 __global__ __launch_bounds__(256) void k_select2(const float* __restrict__ vals, int64_t seg_stride,
                                                  const int* __restrict__ seg_len, int fixed_len, int K,
                                                  int Kpad, float* __restrict__ out_vals,
-                                                 int* __restrict__ out_pos) {
+                                                 int* __restrict__ out_pos,
+                                                 const uint8_t* __restrict__ only) {
+    if (only && !only[blockIdx.x]) return;         // rows another kernel has already selected
     extern __shared__ unsigned long long s_dyn[];  // items[Kpad] | cand[CAP]
     unsigned long long* s_items = s_dyn;
     unsigned long long* s_cand = s_dyn + Kpad;
@@ -357,7 +359,9 @@ __global__ __launch_bounds__(256) void k_select_stream(const float* __restrict__
                                                        const int* __restrict__ seg_len, int fixed_len,
                                                        int K, int Kpad, float* __restrict__ out_vals,
                                                        int* __restrict__ out_pos,
-                                                       unsigned long long* __restrict__ dbg) {
+                                                       unsigned long long* __restrict__ dbg,
+                                                       const uint8_t* __restrict__ only) {
+    if (only && !only[blockIdx.x]) return;         // rows another kernel has already selected
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
     auto TICK = [&](int slot) {
         if (dbg) {
@@ -621,6 +625,211 @@ __global__ __launch_bounds__(256) void k_select_wave(const float* __restrict__ v
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Threshold pre-filter of the list scan (kernels.hip, k_ivfpq_scan_pair<.., FILT>).
+//
+// The bound itself is computed inside the scan kernel by the workgroup of each query's first probe
+// group (kernels.hip); ready[q] = 1 when a bound exists, 2 when the group held fewer than K valid
+// candidates (that query then takes the unfiltered selection kernel).
+//
+// k_select_final: one wave per query turns the survivor list written by the filtered scan
+// (a few hundred (key, position) items) into the sorted top-K: histogram cut down to <= 256
+// items, four 64-item bitonic sorts in registers (wave shuffles), rank merge by binary search.
+// Lists that overflowed, or cuts that cannot get below 256 items (mass ties), set flag = 1.
+// ------------------------------------------------------------------------------------
+namespace {
+constexpr int SF_CAPS = 2048;           // survivor list entries per query (probe groups 1..)
+
+// ascending bitonic sort of 64 items, one per lane
+__device__ __forceinline__ unsigned long long wave_sort64(unsigned long long x) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const unsigned long long y = __shfl_xor(x, stride, 64);
+            const bool keep_min = ((lane & stride) == 0) == ((lane & size) == 0);
+            x = ((x < y) == keep_min) ? x : y;
+        }
+    }
+    return x;
+}
+}  // namespace
+
+template <bool SMALLEST>
+__global__ __launch_bounds__(256) void k_select_final(const unsigned long long* __restrict__ surv,
+                                                      const int* __restrict__ cnt,
+                                                      const unsigned long long* __restrict__ ready,
+                                                      int caps, const float* __restrict__ vals,
+                                                      int64_t seg_stride, const int* __restrict__ pair_off,
+                                                      int P, int G, int nq, int K,
+                                                      uint8_t* __restrict__ flag,
+                                                      float* __restrict__ out_vals,
+                                                      int* __restrict__ out_pos) {
+    __shared__ int s_hist[4][256];
+    __shared__ unsigned long long s_run[4][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + w;
+    if (q >= nq) return;
+    const int c_list = cnt[q];
+    const unsigned long long word = ready[q];
+    if ((word >> 32) != 1ull || c_list > caps) {   // no bound, or the list overflowed
+        if (lane == 0) flag[q] = 1;                // left to the unfiltered selection kernel
+        return;
+    }
+    int* hist = s_hist[w];
+    unsigned long long* runs = s_run[w];
+    const uint32_t tauq = (uint32_t)word;
+    const int n0 = pair_off[(int64_t)q * (P + 1) + min(G, P)];
+    const float* v = vals + (int64_t)q * seg_stride;
+    const unsigned long long* src = surv + (int64_t)q * caps;
+    // The candidate set = the first probe group's distances within the bound (read straight from
+    // the distance buffer) + the survivors appended by the other groups.  It is streamed, never
+    // held: every pass calls body(valid, key, item) with a wave-uniform trip count.
+    auto for_each = [&](auto&& body) {
+        for (int i0 = 0; i0 < n0; i0 += 64 * 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) t[u] = v[min(i0 + u * 64 + lane, n0 - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int idx = i0 + u * 64 + lane;
+                const uint32_t key = sel_key<SMALLEST>(t[u]);
+                body(idx < n0 && key <= tauq, key, ((unsigned long long)key << 32) | (unsigned)idx);
+            }
+        }
+        for (int i0 = 0; i0 < c_list; i0 += 64 * 4) {
+            unsigned long long t[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) t[u] = src[min(i0 + u * 64 + lane, c_list - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; u++) body(i0 + u * 64 + lane < c_list, (uint32_t)(t[u] >> 32), t[u]);
+        }
+    };
+    // ---- pass 1: size and key range ----
+    uint32_t mn = 0xffffffffu, mx = 0u;
+    int c = 0;
+    for_each([&](bool ok, uint32_t key, unsigned long long) {
+        if (ok) {
+            mn = key < mn ? key : mn;
+            mx = key > mx ? key : mx;
+            c++;
+        }
+    });
+    mn = wave_min_u32(mn);
+    mx = wave_max_u32(mx);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    // ---- cut to <= 256 items: keep keys <= cutoff, cutoff from (nested) 256-bin histograms ----
+    uint32_t cutoff = 0xffffffffu;
+    if (c > 256) {
+        uint32_t lo = mn;
+        const uint32_t range = mx - mn;
+        int s = range >= 256u ? (32 - __clz((int)range)) - 8 : 0;
+        int below = 0;                   // items with key < lo (all kept)
+        for (;;) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) hist[lane * 4 + u] = 0;
+            __builtin_amdgcn_wave_barrier();
+            for_each([&](bool ok, uint32_t key, unsigned long long) {
+                if (ok && key >= lo && ((key - lo) >> s) < 256u) atomicAdd(&hist[(key - lo) >> s], 1);
+            });
+            __builtin_amdgcn_wave_barrier();
+            int cc[4], c4 = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                cc[u] = hist[lane * 4 + u];
+                c4 += cc[u];
+            }
+            const int incl = wave_incl_scan(c4);
+            int run = below + incl - c4, b = -1, kept = 0, before = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (b < 0 && run < K && K <= run + cc[u]) {
+                    b = lane * 4 + u;
+                    before = run;
+                    kept = run + cc[u];
+                }
+                run += cc[u];
+            }
+            const unsigned long long who = __ballot(b >= 0);
+            const int src_lane = (int)__ffsll((long long)who) - 1;
+            b = __shfl(b, src_lane, 64);
+            kept = __shfl(kept, src_lane, 64);
+            before = __shfl(before, src_lane, 64);
+            __builtin_amdgcn_wave_barrier();
+            if (kept <= 256 || s == 0) {
+                if (kept > 256) {        // > 256 copies of one key around the K-th: rare, unfiltered path
+                    if (lane == 0) flag[q] = 1;
+                    return;
+                }
+                const unsigned long long edge = (unsigned long long)lo + (((unsigned long long)b + 1ull) << s) - 1ull;
+                cutoff = edge > 0xffffffffull ? 0xffffffffu : (uint32_t)edge;
+                break;
+            }
+            below = before;
+            lo += (uint32_t)b << s;
+            s = s > 8 ? s - 8 : 0;
+        }
+    }
+    if (lane == 0) flag[q] = 0;
+    // ---- compact the kept items into runs[0..m), m <= 256 ----
+    int m = 0;
+    for_each([&](bool ok, uint32_t key, unsigned long long item) {
+        const bool keep = ok && key <= cutoff;
+        const unsigned long long bal = __ballot(keep);
+        if (keep) runs[m + __popcll(bal & ((1ull << lane) - 1ull))] = item;
+        m += __popcll(bal);
+    });
+    __builtin_amdgcn_wave_barrier();
+    // ---- four sorted runs of 64, then rank merge ----
+    unsigned long long x[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) x[r] = (r * 64 + lane < m) ? runs[r * 64 + lane] : ~0ull;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; r++) x[r] = wave_sort64(x[r]);
+#pragma unroll
+    for (int r = 0; r < 4; r++) runs[r * 64 + lane] = x[r];
+    __builtin_amdgcn_wave_barrier();
+    const float sentinel = SMALLEST ? INFINITY : -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (x[r] == ~0ull) continue;
+        int rank = lane;
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            if (o == r) continue;
+            // number of items of run o smaller than x[r]
+            const unsigned long long* ro = runs + o * 64;
+            int lo2 = 0, n2 = 64;
+#pragma unroll
+            for (int st = 0; st < 7; st++) {
+                if (n2 > 0) {
+                    const int half = n2 >> 1;
+                    if (ro[lo2 + half] < x[r]) {
+                        lo2 += half + 1;
+                        n2 -= half + 1;
+                    } else {
+                        n2 = half;
+                    }
+                }
+            }
+            rank += lo2;
+        }
+        if (rank < K) {
+            const uint32_t key = (uint32_t)(x[r] >> 32);
+            const float val = key2f(SMALLEST ? key : ~key);
+            out_vals[(int64_t)q * K + rank] = val;
+            out_pos[(int64_t)q * K + rank] = val == sentinel ? -1 : (int)(uint32_t)x[r];
+        }
+    }
+    for (int r = m + lane; r < K; r += 64) {   // fewer than K survivors cannot happen with a bound; be safe
+        out_vals[(int64_t)q * K + r] = sentinel;
+        out_pos[(int64_t)q * K + r] = -1;
+    }
+}
+
 int select_kpad(int K) {
     int p = 2;
     while (p < K) p <<= 1;
@@ -629,14 +838,15 @@ int select_kpad(int K) {
 
 template <bool SMALLEST>
 static void launch_sel(hipStream_t s, const float* vals, int64_t seg_stride, const int* seg_len,
-                       int fixed_len, int max_len, int nseg, int K, float* out_vals, int* out_pos) {
+                       int fixed_len, int max_len, int nseg, int K, float* out_vals, int* out_pos,
+                       const uint8_t* only) {
     const int Kpad = select_kpad(K);
     const size_t lds = (size_t)(Kpad + CAP) * sizeof(unsigned long long);
 #define GH_SEL(NPT)                                                                              \
     hipLaunchKernelGGL((k_select2<SMALLEST, NPT>), dim3(nseg), dim3(256), lds, s, vals, seg_stride, \
-                       seg_len, fixed_len, K, Kpad, out_vals, out_pos)
+                       seg_len, fixed_len, K, Kpad, out_vals, out_pos, only)
     static const bool no_wave = getenv("GAMMA_HIP_NO_WAVE_SELECT") != nullptr;
-    if (K <= 64 && !no_wave)
+    if (K <= 64 && !no_wave && !only)
         hipLaunchKernelGGL((k_select_wave<SMALLEST>), dim3((nseg + 3) / 4), dim3(256), 0, s, vals, seg_stride,
                            seg_len, fixed_len, nseg, K, out_vals, out_pos);
     else if (max_len <= 256 * 4) GH_SEL(4);
@@ -649,7 +859,7 @@ static void launch_sel(hipStream_t s, const float* vals, int64_t seg_stride, con
         static int shown = 0;
         if (dbg_on && !dbg_buf) (void)hipMalloc((void**)&dbg_buf, 6 * 8 * 65536);
         hipLaunchKernelGGL((k_select_stream<SMALLEST>), dim3(nseg), dim3(256), 0, s, vals, seg_stride,
-                           seg_len, fixed_len, K, Kpad, out_vals, out_pos, dbg_on ? dbg_buf : nullptr);
+                           seg_len, fixed_len, K, Kpad, out_vals, out_pos, dbg_on ? dbg_buf : nullptr, only);
         if (dbg_on && shown++ == 8 && nseg <= 65536) {
             (void)hipStreamSynchronize(s);
             std::vector<unsigned long long> hb((size_t)nseg * 6);
@@ -668,12 +878,27 @@ static void launch_sel(hipStream_t s, const float* vals, int64_t seg_stride, con
 
 void launch_select_topk(hipStream_t s, bool smallest, const float* vals, int64_t seg_stride,
                         const int* seg_len, int fixed_len, int max_len, int nseg, int K,
-                        float* out_vals, int* out_pos) {
+                        float* out_vals, int* out_pos, const uint8_t* only) {
     if (nseg <= 0 || K <= 0) return;
     if (smallest)
-        launch_sel<true>(s, vals, seg_stride, seg_len, fixed_len, max_len, nseg, K, out_vals, out_pos);
+        launch_sel<true>(s, vals, seg_stride, seg_len, fixed_len, max_len, nseg, K, out_vals, out_pos, only);
     else
-        launch_sel<false>(s, vals, seg_stride, seg_len, fixed_len, max_len, nseg, K, out_vals, out_pos);
+        launch_sel<false>(s, vals, seg_stride, seg_len, fixed_len, max_len, nseg, K, out_vals, out_pos, only);
+}
+
+int scan_bound_caps() { return SF_CAPS; }
+
+void launch_select_final(hipStream_t s, bool smallest, const unsigned long long* surv, const int* cnt,
+                         const unsigned long long* ready, const float* vals, int64_t seg_stride,
+                         const int* pair_off, int P, int G, int nq, int K, uint8_t* flag, float* out_vals,
+                         int* out_pos) {
+    if (nq <= 0) return;
+    if (smallest)
+        hipLaunchKernelGGL((k_select_final<true>), dim3((nq + 3) / 4), dim3(256), 0, s, surv, cnt, ready, SF_CAPS,
+                           vals, seg_stride, pair_off, P, G, nq, K, flag, out_vals, out_pos);
+    else
+        hipLaunchKernelGGL((k_select_final<false>), dim3((nq + 3) / 4), dim3(256), 0, s, surv, cnt, ready, SF_CAPS,
+                           vals, seg_stride, pair_off, P, G, nq, K, flag, out_vals, out_pos);
 }
 
 }  // namespace gh
