@@ -455,7 +455,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
     // distance from it, and let the scan of the remaining groups keep a short survivor list per
     // query; the exact top-R then comes from a few hundred survivors instead of ~10^4 candidates
     // (select.hip).  Queries without a usable bound fall back to the unfiltered selection.
-    const bool bounded = allow_bound && h->scan_bound && R <= 256 && PGN >= 2;
+    const bool bounded = allow_bound && h->scan_bound && R <= 256 && PGN >= 2 && PGN <= 65;
     if (!bounded) {
         scan(G, 0, PGN, nullptr, true);
         StageScope t(h, GAMMA_HIP_STAGE_SELECT);
@@ -466,22 +466,22 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
                                   h->w_pair_off.as<int>(), h->d_list_off, h->d_ids,
                                   h->w_cand_ids.as<int64_t>());
     } else {
-        const int caps = gh::scan_bound_caps();
-        GH_CHECK(h, h->w_scnt.ensure((size_t)nq * (sizeof(unsigned long long) + sizeof(int))));   // ready[nq] | cnt[nq]
+        const int cap = gh::scan_slice_cap(), nsl = PGN - 1;
+        GH_CHECK(h, h->w_scnt.ensure((size_t)nq * (sizeof(unsigned long long) + (size_t)nsl * sizeof(int))));   // ready[nq] | gcnt[nq][nsl]
         GH_CHECK(h, h->w_sflag.ensure((size_t)nq));
-        GH_CHECK(h, h->w_surv.ensure((size_t)nq * caps * sizeof(unsigned long long)));
-        GH_CHECK(h, hipMemsetAsync(h->w_scnt.p, 0, (size_t)nq * (sizeof(unsigned long long) + sizeof(int)), s));
+        GH_CHECK(h, h->w_surv.ensure((size_t)nq * nsl * cap * sizeof(unsigned long long)));
+        GH_CHECK(h, hipMemsetAsync(h->w_scnt.p, 0, (size_t)nq * sizeof(unsigned long long), s));
         gh::ScanBound sb;
         sb.ready = h->w_scnt.as<unsigned long long>();
         sb.surv = h->w_surv.as<unsigned long long>();
-        sb.cnt = reinterpret_cast<int*>(h->w_scnt.as<unsigned long long>() + nq);
-        sb.caps = caps;
-        sb.K = R;
+        sb.gcnt = reinterpret_cast<int*>(h->w_scnt.as<unsigned long long>() + nq);
+        static const bool bound_off = getenv("GAMMA_HIP_BOUND_OFF") != nullptr;   // experiment: nobody gets a bound
+        sb.K = bound_off ? (1 << 30) : R;
         scan(G, 0, PGN, &sb, true);
         static const bool dbg = getenv("GAMMA_HIP_BOUND_DBG") != nullptr;
         static int shown = 0;
         StageScope t(h, GAMMA_HIP_STAGE_SELECT);
-        gh::launch_select_final(s, l2, sb.surv, sb.cnt, sb.ready, h->w_dist.as<float>(), q_stride,
+        gh::launch_select_final(s, l2, sb.surv, sb.gcnt, nsl, cap, sb.ready, h->w_dist.as<float>(), q_stride,
                                 h->w_pair_off.as<int>(), P, G, nq, R, h->w_sflag.as<uint8_t>(),
                                 h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>());
         gh::launch_select_topk(s, l2, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), 0,
@@ -489,17 +489,17 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
                                h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>(), h->w_sflag.as<uint8_t>());
         if (dbg && shown++ == 8) {
             std::vector<uint8_t> hf(nq);
-            std::vector<int> hc(nq);
+            std::vector<int> hc((size_t)nq * nsl);
             (void)hipStreamSynchronize(s);
             (void)hipMemcpy(hf.data(), h->w_sflag.p, nq, hipMemcpyDeviceToHost);
-            (void)hipMemcpy(hc.data(), sb.cnt, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(hc.data(), sb.gcnt, hc.size() * sizeof(int), hipMemcpyDeviceToHost);
             int64_t nf = 0, tot = 0, mx = 0;
-            for (int i = 0; i < nq; i++) {
-                nf += hf[i];
+            for (int i = 0; i < nq; i++) nf += hf[i];
+            for (size_t i = 0; i < hc.size(); i++) {
                 tot += hc[i];
                 mx = std::max<int64_t>(mx, hc[i]);
             }
-            fprintf(stderr, "scan bound: %lld of %d queries unfiltered, survivors mean %.1f max %lld\n",
+            fprintf(stderr, "scan bound: %lld of %d queries unfiltered, survivors per query mean %.1f, per slice max %lld\n",
                     (long long)nf, nq, (double)tot / nq, (long long)mx);
         }
         gh::launch_map_candidates(s, h->w_cand_pos.as<int>(), nq, R, P, h->w_probe.as<int>(),

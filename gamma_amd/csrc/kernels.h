@@ -43,11 +43,12 @@ void launch_pair_offsets(hipStream_t s, const int* probe_list, int nq, int P, co
 struct ScanBound {
     unsigned long long* ready;  // [nq] 0 = not yet published; (1 << 32 | key bound) = bound valid;
                                 // (2 << 32) = no bound (unfiltered selection); zeroed per launch
-    unsigned long long* surv;   // [nq][caps] survivors as (key << 32 | position in the query's segment)
-    int* cnt;                   // [nq] survivors appended (may exceed caps: overflow -> unfiltered selection); zeroed per launch
-    int caps;
+    unsigned long long* surv;   // [nq][groups - 1][scan_slice_cap()] survivors of each consumer workgroup,
+                                // as (key << 32 | position in the query's segment)
+    int* gcnt;                  // [nq][groups - 1] survivors per slice; > scan_slice_cap() = overflowed
     int K;                      // recall_num
 };
+int scan_slice_cap();
 int scan_group_size(int nq, int P);
 void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int d, int M, int P,
                             const int* probe_list, const float* coarse_dis, const float* cc,
@@ -65,9 +66,9 @@ void launch_select_topk(hipStream_t s, bool smallest, const float* vals, int64_t
                         float* out_vals, int* out_pos, const uint8_t* only = nullptr);
 // threshold pre-filter of the scan: exact top-K from the survivor lists (select.hip); rows that end
 // with flag != 0 are left to launch_select_topk(..., only = flag)
-int scan_bound_caps();
-void launch_select_final(hipStream_t s, bool smallest, const unsigned long long* surv, const int* cnt,
-                         const unsigned long long* ready, const float* vals, int64_t seg_stride,
+void launch_select_final(hipStream_t s, bool smallest, const unsigned long long* surv, const int* gcnt,
+                         int nslices, int slice_cap, const unsigned long long* ready, const float* vals,
+                         int64_t seg_stride,
                          const int* pair_off, int P, int G, int nq, int K, uint8_t* flag, float* out_vals,
                          int* out_pos);
 void launch_map_candidates(hipStream_t s, const int* pos, int nq, int R, int P,

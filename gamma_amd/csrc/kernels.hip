@@ -701,6 +701,8 @@ __device__ __forceinline__ uint32_t dis_key(float v) {
 }
 constexpr uint32_t KEY_SENTINEL = 0xff800000u;   // key of the filtered-entry marker (+inf / -inf)
 constexpr int SCAN_STAGE = 256;                  // survivors staged in LDS per workgroup
+constexpr int SCAN_SLICE = 512;                  // survivor slice of one consumer workgroup (global)
+constexpr int SCAN_BATCH = 64;                   // queries per XCD by which producers run ahead
 
 // amdgpu_num_sgpr(96): 8 waves per SIMD need <= 96 SGPRs each (800 per SIMD); the FILT variant
 // would otherwise take 100 and lose one of the eight resident workgroups per CU
@@ -736,18 +738,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
     const int xcd = blockIdx.x & 7;
     int slot = blockIdx.x >> 3, pg, qslot;
     if (FILT) {
-        // block ids: first the group-0 workgroup of EVERY query (they publish the bounds), then
-        // the other groups.  Workgroups are dispatched in id order, so a consumer only ever waits
-        // for a producer that is already resident or finished.
+        // Block order inside an XCD (slot = XCD-local index): producers (group 0, they publish
+        // the bounds) run one batch of SCAN_BATCH queries AHEAD of the consumers (other groups):
+        //   P(0) | P(1) C(0) | P(2) C(1) | ...
+        // Workgroups are dispatched in id order, so a consumer only ever waits for a producer that
+        // is already resident or finished -- and it starts >= SCAN_BATCH * pg_cnt dispatches after
+        // its producer, by when the bound is normally there.  The query's table st2[q] is still in
+        // this XCD's L2 when its consumers arrive.
         const int nq8 = (nq + 7) >> 3;
-        if (slot < nq8) {
+        if (slot < SCAN_BATCH) {
             pg = 0;
             qslot = slot;
         } else {
-            slot -= nq8;
-            pg = 1 + slot % (pg_cnt - 1);
-            qslot = slot / (pg_cnt - 1);
+            const int s2 = slot - SCAN_BATCH, period = SCAN_BATCH * pg_cnt;
+            const int t = s2 / period, r = s2 % period;
+            if (r < SCAN_BATCH) {
+                pg = 0;
+                qslot = (t + 1) * SCAN_BATCH + r;
+            } else {
+                const int i = r - SCAN_BATCH;
+                pg = 1 + i % (pg_cnt - 1);
+                qslot = t * SCAN_BATCH + i / (pg_cnt - 1);
+            }
         }
+        if (qslot >= nq8) return;
     } else {
         pg = pg_lo + slot % pg_cnt;
         qslot = slot / pg_cnt;
@@ -766,36 +780,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
     // query's list with ONE global atomic per workgroup; a returning global atomic per wave
     // iteration would put ~1 us of latency into the scan loop.  All lanes of a wave call append().
     __shared__ unsigned long long s_stage[SCAN_STAGE];
-    __shared__ int s_nstage, s_gbase;
+    __shared__ int s_nstage;
     __shared__ uint32_t s_tau;
     uint32_t tauq = 0xffffffffu;
     bool bound_on = false;
-    if (FILT) {
-        if (threadIdx.x == 0) {
-            s_nstage = 0;
-            if (pg > 0) {   // wait for this query's bound (published by its group-0 workgroup)
-                // ONE relaxed 64-bit word carries (state << 32 | bound): no acquire/release fence is
-                // needed (nothing else the producer wrote is read here), and agent-scope fences
-                // would write back / invalidate the L2 this kernel lives on
-                int spins = 0;
-                unsigned long long word;
-                while ((word = __hip_atomic_load(&sb.ready[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0ull &&
-                       ++spins < (1 << 20))
-                    __builtin_amdgcn_s_sleep(16);
-                if (word != 0ull) {
-                    s_tau = (word >> 32) == 1ull ? (uint32_t)word : 0xffffffffu;
-                } else {   // never expected: give the query to the unfiltered selection instead of hanging
-                    s_tau = 0xffffffffu;
-                    atomicAdd(&sb.cnt[q], sb.caps + 1);
-                }
-            }
-        }
-        __syncthreads();
-        if (pg > 0) {
-            tauq = s_tau;
-            bound_on = tauq < KEY_SENTINEL;   // otherwise the query takes the unfiltered selection
-        }
-    }
     uint32_t g_mn = 0xffffffffu, g_mx = 0u;   // producer (pg == 0): range and count of its valid keys
     int g_nv = 0;
     auto append = [&](bool keep, uint32_t key, int pos) {
@@ -807,25 +795,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
             if (keep) {
                 const int at = base + __popcll(bal & ((1ull << lane) - 1ull));
                 const unsigned long long item = ((unsigned long long)key << 32) | (unsigned)pos;
-                if (at < SCAN_STAGE) {
-                    s_stage[at] = item;
-                } else {   // staging full (rare): straight to the list
-                    const int g = atomicAdd(&sb.cnt[q], 1);
-                    if (g < sb.caps) sb.surv[(int64_t)q * sb.caps + g] = item;
-                }
+                if (at < SCAN_STAGE) s_stage[at] = item;
+                else if (at < SCAN_SLICE)   // staging full (rare): the slot number is already unique
+                    sb.surv[((int64_t)q * (pg_cnt - 1) + (pg - 1)) * SCAN_SLICE + at] = item;
             }
         }
     };
+    // every consumer workgroup owns one fixed slice of its query's survivor list: no global
+    // atomics, the count (> SCAN_SLICE = overflowed) is a plain store
     auto flush = [&]() {   // whole workgroup
         __syncthreads();
-        const int n = min(s_nstage, SCAN_STAGE);
-        if (n > 0) {
-            if (threadIdx.x == 0) s_gbase = atomicAdd(&sb.cnt[q], n);
-            __syncthreads();
-            const int g0 = s_gbase;
-            for (int i = threadIdx.x; i < n; i += 256)
-                if (g0 + i < sb.caps) sb.surv[(int64_t)q * sb.caps + g0 + i] = s_stage[i];
-        }
+        const int n = s_nstage;
+        const int64_t slice = (int64_t)q * (pg_cnt - 1) + (pg - 1);
+        if (threadIdx.x == 0) sb.gcnt[slice] = n;
+        for (int i = threadIdx.x; i < min(n, SCAN_STAGE); i += 256) sb.surv[slice * SCAN_SLICE + i] = s_stage[i];
     };
     const int p_begin = pg * G, p_end = min(P, p_begin + G);
     const int tid = threadIdx.x;
@@ -842,6 +825,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
             for (int i = 0; i < MT; i++) s_lut[tid + 256 * i] = s2r[i];
         } else {
             for (int e = tid; e < msz; e += 256) s_lut[e] = st2q[e];
+        }
+    }
+    if (FILT) {   // placed after the table loads were issued: their latency and this one overlap
+        if (threadIdx.x == 0) {
+            s_nstage = 0;
+            if (pg > 0) {   // wait for this query's bound (published by its group-0 workgroup)
+                // ONE relaxed 64-bit word carries (state << 32 | bound): no acquire/release fence is
+                // needed (nothing else the producer wrote is read here), and agent-scope fences
+                // would write back / invalidate the L2 this kernel lives on
+                int spins = 0;
+                unsigned long long word;
+                while ((word = __hip_atomic_load(&sb.ready[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0ull &&
+                       ++spins < (1 << 20))
+                    __builtin_amdgcn_s_sleep(16);
+                if (word != 0ull) {
+                    s_tau = (word >> 32) == 1ull ? (uint32_t)word : 0xffffffffu;
+                } else {   // never expected: give the query to the unfiltered selection instead of hanging
+                    s_tau = 0xffffffffu;
+                    s_nstage = SCAN_SLICE + 1;
+                }
+            }
+        }
+        __syncthreads();
+        if (pg > 0) {
+            tauq = s_tau;
+            bound_on = tauq < KEY_SENTINEL;   // otherwise the query takes the unfiltered selection
         }
     }
     for (int p = p_begin; p < p_end; p++) {
@@ -944,7 +953,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
             if (FILT && bound_on) append(key <= tauq, key, pbase + j);
         }
     }
-    if (FILT && pg > 0 && bound_on) flush();
+    if (FILT && pg > 0) flush();   // also without a bound: the slice count must be written (0)
     if (FILT && pg == 0) {
         // ---- producer: bound of this query's K-th best from its first probe group ----
         // 256-bin histogram of the group's valid keys over [min, max]; tau = upper edge of the bin
@@ -1015,6 +1024,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
     }
 }
 
+int scan_slice_cap() { return SCAN_SLICE; }
+
 int scan_group_size(int nq, int P) {
     // probes per workgroup: amortise the query table, but keep >= ~4096 workgroups in flight
     static const int g_env = getenv("GAMMA_HIP_SCAN_G") ? atoi(getenv("GAMMA_HIP_SCAN_G")) : 0;
@@ -1033,7 +1044,11 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
     if (nq <= 0 || pg_cnt <= 0) return;
     const size_t lds = (size_t)M * 256 * sizeof(float);
     dim3 grid((unsigned)(8 * (int64_t)((nq + 7) / 8) * pg_cnt));
-    ScanBound sb = {nullptr, nullptr, nullptr, 0, 0};
+    if (bound) {   // P(0) | P(t+1) C(t) ...: whole batches, see the kernel
+        const int64_t nq8 = (nq + 7) / 8, nb = (nq8 + SCAN_BATCH - 1) / SCAN_BATCH;
+        grid.x = (unsigned)(8 * (SCAN_BATCH + nb * SCAN_BATCH * pg_cnt));
+    }
+    ScanBound sb = {nullptr, nullptr, nullptr, 0};
     if (bound) sb = *bound;
 #define GH_SCAN(LL, MT, FF)                                                                       \
     hipLaunchKernelGGL((k_ivfpq_scan_pair<LL, MT, FF>), grid, dim3(256), lds, s, x, nq, d, M, P, G,     \

@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256) void k_select_wave(const float* __restrict__ v
 // Lists that overflowed, or cuts that cannot get below 256 items (mass ties), set flag = 1.
 // ------------------------------------------------------------------------------------
 namespace {
-constexpr int SF_CAPS = 2048;           // survivor list entries per query (probe groups 1..)
+
 
 // ascending bitonic sort of 64 items, one per lane
 __device__ __forceinline__ unsigned long long wave_sort64(unsigned long long x) {
@@ -658,9 +658,10 @@ __device__ __forceinline__ unsigned long long wave_sort64(unsigned long long x) 
 
 template <bool SMALLEST>
 __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* __restrict__ surv,
-                                                      const int* __restrict__ cnt,
+                                                      const int* __restrict__ gcnt, int nslices,
+                                                      int slice_cap,
                                                       const unsigned long long* __restrict__ ready,
-                                                      int caps, const float* __restrict__ vals,
+                                                      const float* __restrict__ vals,
                                                       int64_t seg_stride, const int* __restrict__ pair_off,
                                                       int P, int G, int nq, int K,
                                                       uint8_t* __restrict__ flag,
@@ -671,10 +672,11 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + w;
     if (q >= nq) return;
-    const int c_list = cnt[q];
     const unsigned long long word = ready[q];
-    if ((word >> 32) != 1ull || c_list > caps) {   // no bound, or the list overflowed
-        if (lane == 0) flag[q] = 1;                // left to the unfiltered selection kernel
+    // slice counts of the consumer workgroups (nslices <= 64: one per lane)
+    const int my_cnt = lane < nslices ? gcnt[(int64_t)q * nslices + lane] : 0;
+    if ((word >> 32) != 1ull || __ballot(my_cnt > slice_cap)) {   // no bound, or a slice overflowed
+        if (lane == 0) flag[q] = 1;                                // left to the unfiltered selection kernel
         return;
     }
     int* hist = s_hist[w];
@@ -682,7 +684,7 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
     const uint32_t tauq = (uint32_t)word;
     const int n0 = pair_off[(int64_t)q * (P + 1) + min(G, P)];
     const float* v = vals + (int64_t)q * seg_stride;
-    const unsigned long long* src = surv + (int64_t)q * caps;
+    const unsigned long long* src = surv + (int64_t)q * nslices * slice_cap;
     // The candidate set = the first probe group's distances within the bound (read straight from
     // the distance buffer) + the survivors appended by the other groups.  It is streamed, never
     // held: every pass calls body(valid, key, item) with a wave-uniform trip count.
@@ -698,12 +700,13 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
                 body(idx < n0 && key <= tauq, key, ((unsigned long long)key << 32) | (unsigned)idx);
             }
         }
-        for (int i0 = 0; i0 < c_list; i0 += 64 * 4) {
-            unsigned long long t[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) t[u] = src[min(i0 + u * 64 + lane, c_list - 1)];
-#pragma unroll
-            for (int u = 0; u < 4; u++) body(i0 + u * 64 + lane < c_list, (uint32_t)(t[u] >> 32), t[u]);
+        for (int g = 0; g < nslices; g++) {
+            const int cg = __shfl(my_cnt, g, 64);
+            const unsigned long long* sg = src + (int64_t)g * slice_cap;
+            for (int i0 = 0; i0 < cg; i0 += 64) {
+                const unsigned long long t = sg[min(i0 + lane, cg - 1)];
+                body(i0 + lane < cg, (uint32_t)(t >> 32), t);
+            }
         }
     };
     // ---- pass 1: size and key range ----
@@ -886,19 +889,17 @@ void launch_select_topk(hipStream_t s, bool smallest, const float* vals, int64_t
         launch_sel<false>(s, vals, seg_stride, seg_len, fixed_len, max_len, nseg, K, out_vals, out_pos, only);
 }
 
-int scan_bound_caps() { return SF_CAPS; }
-
-void launch_select_final(hipStream_t s, bool smallest, const unsigned long long* surv, const int* cnt,
-                         const unsigned long long* ready, const float* vals, int64_t seg_stride,
-                         const int* pair_off, int P, int G, int nq, int K, uint8_t* flag, float* out_vals,
-                         int* out_pos) {
+void launch_select_final(hipStream_t s, bool smallest, const unsigned long long* surv, const int* gcnt,
+                         int nslices, int slice_cap, const unsigned long long* ready, const float* vals,
+                         int64_t seg_stride, const int* pair_off, int P, int G, int nq, int K, uint8_t* flag,
+                         float* out_vals, int* out_pos) {
     if (nq <= 0) return;
     if (smallest)
-        hipLaunchKernelGGL((k_select_final<true>), dim3((nq + 3) / 4), dim3(256), 0, s, surv, cnt, ready, SF_CAPS,
-                           vals, seg_stride, pair_off, P, G, nq, K, flag, out_vals, out_pos);
+        hipLaunchKernelGGL((k_select_final<true>), dim3((nq + 3) / 4), dim3(256), 0, s, surv, gcnt, nslices,
+                           slice_cap, ready, vals, seg_stride, pair_off, P, G, nq, K, flag, out_vals, out_pos);
     else
-        hipLaunchKernelGGL((k_select_final<false>), dim3((nq + 3) / 4), dim3(256), 0, s, surv, cnt, ready, SF_CAPS,
-                           vals, seg_stride, pair_off, P, G, nq, K, flag, out_vals, out_pos);
+        hipLaunchKernelGGL((k_select_final<false>), dim3((nq + 3) / 4), dim3(256), 0, s, surv, gcnt, nslices,
+                           slice_cap, ready, vals, seg_stride, pair_off, P, G, nq, K, flag, out_vals, out_pos);
 }
 
 }  // namespace gh
