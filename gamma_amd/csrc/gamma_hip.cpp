@@ -455,7 +455,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
     // distance from it, and let the scan of the remaining groups keep a short survivor list per
     // query; the exact top-R then comes from a few hundred survivors instead of ~10^4 candidates
     // (select.hip).  Queries without a usable bound fall back to the unfiltered selection.
-    const bool bounded = allow_bound && h->scan_bound && R <= 256 && PGN >= 2 && PGN <= 65;
+    const bool bounded = allow_bound && h->scan_bound && R <= 256 && PGN >= 2 && P <= 64;
     if (!bounded) {
         scan(G, 0, PGN, nullptr, true);
         StageScope t(h, GAMMA_HIP_STAGE_SELECT);
@@ -482,8 +482,9 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
         static int shown = 0;
         StageScope t(h, GAMMA_HIP_STAGE_SELECT);
         gh::launch_select_final(s, l2, sb.surv, sb.gcnt, nsl, cap, sb.ready, h->w_dist.as<float>(), q_stride,
-                                h->w_pair_off.as<int>(), P, G, nq, R, h->w_sflag.as<uint8_t>(),
-                                h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>());
+                                h->w_pair_off.as<int>(), P, G, nq, R, h->w_probe.as<int>(), h->d_list_off,
+                                h->d_ids, h->w_sflag.as<uint8_t>(), h->w_cand_dis.as<float>(),
+                                h->w_cand_pos.as<int>(), h->w_cand_ids.as<int64_t>());
         gh::launch_select_topk(s, l2, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), 0,
                                (int)std::min<int64_t>(q_stride, 1 << 30), nq, R,
                                h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>(), h->w_sflag.as<uint8_t>());
@@ -504,7 +505,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
         }
         gh::launch_map_candidates(s, h->w_cand_pos.as<int>(), nq, R, P, h->w_probe.as<int>(),
                                   h->w_pair_off.as<int>(), h->d_list_off, h->d_ids,
-                                  h->w_cand_ids.as<int64_t>());
+                                  h->w_cand_ids.as<int64_t>(), h->w_sflag.as<uint8_t>());
     }
     GH_CHECK(h, hipGetLastError());
     return GAMMA_HIP_OK;

@@ -68,12 +68,12 @@ void launch_select_topk(hipStream_t s, bool smallest, const float* vals, int64_t
 // with flag != 0 are left to launch_select_topk(..., only = flag)
 void launch_select_final(hipStream_t s, bool smallest, const unsigned long long* surv, const int* gcnt,
                          int nslices, int slice_cap, const unsigned long long* ready, const float* vals,
-                         int64_t seg_stride,
-                         const int* pair_off, int P, int G, int nq, int K, uint8_t* flag, float* out_vals,
-                         int* out_pos);
+                         int64_t seg_stride, const int* pair_off, int P, int G, int nq, int K,
+                         const int* probe_list, const int64_t* list_off, const int64_t* ids, uint8_t* flag,
+                         float* out_vals, int* out_pos, int64_t* out_ids);
 void launch_map_candidates(hipStream_t s, const int* pos, int nq, int R, int P,
                            const int* probe_list, const int* pair_off, const int64_t* list_off,
-                           const int64_t* ids, int64_t* cand_ids);
+                           const int64_t* ids, int64_t* cand_ids, const uint8_t* only = nullptr);
 void launch_rerank_dist(hipStream_t s, bool l2, const float* x, int nq, int d, const float* raw,
                         int64_t nraw, const int64_t* cand_ids, int R, float min_score,
                         float max_score, float* out);

@@ -1081,8 +1081,10 @@ __global__ __launch_bounds__(256) void k_map_candidates(const int* __restrict__ 
                                                         const int* __restrict__ pair_off,
                                                         const int64_t* __restrict__ list_off,
                                                         const int64_t* __restrict__ ids,
-                                                        int64_t* __restrict__ cand_ids) {
+                                                        int64_t* __restrict__ cand_ids,
+                                                        const uint8_t* __restrict__ only) {
     const int q = blockIdx.x;
+    if (only && !only[q]) return;   // rows k_select_final has already mapped
     const int* off = pair_off + (int64_t)q * (P + 1);
     for (int r = threadIdx.x; r < R; r += 256) {
         const int ps = pos[(int64_t)q * R + r];
@@ -1102,10 +1104,10 @@ __global__ __launch_bounds__(256) void k_map_candidates(const int* __restrict__ 
 }
 void launch_map_candidates(hipStream_t s, const int* pos, int nq, int R, int P,
                            const int* probe_list, const int* pair_off, const int64_t* list_off,
-                           const int64_t* ids, int64_t* cand_ids) {
+                           const int64_t* ids, int64_t* cand_ids, const uint8_t* only) {
     if (nq <= 0) return;
     hipLaunchKernelGGL(k_map_candidates, dim3(nq), dim3(256), 0, s, pos, R, P, probe_list, pair_off,
-                       list_off, ids, cand_ids);
+                       list_off, ids, cand_ids, only);
 }
 
 // ------------------------------------------------------------------------------------

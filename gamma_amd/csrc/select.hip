@@ -656,6 +656,10 @@ __device__ __forceinline__ unsigned long long wave_sort64(unsigned long long x) 
 }
 }  // namespace
 
+namespace {
+constexpr int SF_CAND = 512;   // candidates of one query held in LDS (first group within the bound + slices)
+}
+
 template <bool SMALLEST>
 __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* __restrict__ surv,
                                                       const int* __restrict__ gcnt, int nslices,
@@ -664,11 +668,16 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
                                                       const float* __restrict__ vals,
                                                       int64_t seg_stride, const int* __restrict__ pair_off,
                                                       int P, int G, int nq, int K,
+                                                      const int* __restrict__ probe_list,
+                                                      const int64_t* __restrict__ list_off,
+                                                      const int64_t* __restrict__ ids,
                                                       uint8_t* __restrict__ flag,
                                                       float* __restrict__ out_vals,
-                                                      int* __restrict__ out_pos) {
+                                                      int* __restrict__ out_pos,
+                                                      int64_t* __restrict__ out_ids) {
     __shared__ int s_hist[4][256];
-    __shared__ unsigned long long s_run[4][256];
+    __shared__ unsigned long long s_cand[4][SF_CAND];   // candidates, later the <= 256 kept ones (in place)
+    __shared__ int s_off[4][72];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + w;
     if (q >= nq) return;
@@ -680,15 +689,75 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
         return;
     }
     int* hist = s_hist[w];
-    unsigned long long* runs = s_run[w];
+    unsigned long long* cand = s_cand[w];
+    unsigned long long* runs = cand;
     const uint32_t tauq = (uint32_t)word;
-    const int n0 = pair_off[(int64_t)q * (P + 1) + min(G, P)];
+    const int* goff = pair_off + (int64_t)q * (P + 1);
+    int* off = s_off[w];        // this query's pair offsets (P + 1 <= 65 entries, see the launcher)
+    for (int i = lane; i <= P; i += 64) off[i] = goff[i];
+    const int n0 = goff[min(G, P)];
     const float* v = vals + (int64_t)q * seg_stride;
+    // ---- gather the candidate set into LDS: the first probe group's distances within the bound
+    //      (straight from the distance buffer) + the survivors the other groups appended ----
+    int c = 0;
+    uint32_t mn = 0xffffffffu, mx = 0u;
+    for (int i0 = 0; i0 < n0; i0 += 64 * 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) t[u] = v[min(i0 + u * 64 + lane, n0 - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int idx = i0 + u * 64 + lane;
+            const uint32_t key = sel_key<SMALLEST>(t[u]);
+            const bool keep = idx < n0 && key <= tauq;
+            const unsigned long long bal = __ballot(keep);
+            if (keep) {
+                const int at = c + __popcll(bal & ((1ull << lane) - 1ull));
+                if (at < SF_CAND) cand[at] = ((unsigned long long)key << 32) | (unsigned)idx;
+                mn = key < mn ? key : mn;
+                mx = key > mx ? key : mx;
+            }
+            c += __popcll(bal);
+        }
+    }
     const unsigned long long* src = surv + (int64_t)q * nslices * slice_cap;
-    // The candidate set = the first probe group's distances within the bound (read straight from
-    // the distance buffer) + the survivors appended by the other groups.  It is streamed, never
-    // held: every pass calls body(valid, key, item) with a wave-uniform trip count.
+    for (int g0 = 0; g0 < nslices; g0 += 8) {   // the first 64 items of 8 slices in flight at once
+        int cg[8];
+        unsigned long long t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            cg[u] = g0 + u < nslices ? __shfl(my_cnt, min(g0 + u, 63), 64) : 0;
+            const unsigned long long* sg = src + (int64_t)min(g0 + u, nslices - 1) * slice_cap;
+            t[u] = sg[min(lane, max(cg[u] - 1, 0))];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const unsigned long long* sg = src + (int64_t)min(g0 + u, nslices - 1) * slice_cap;
+            for (int i0 = 0; i0 < cg[u]; i0 += 64) {
+                if (i0 + lane < cg[u]) {
+                    const unsigned long long item = i0 == 0 ? t[u] : sg[i0 + lane];
+                    const uint32_t key = (uint32_t)(item >> 32);
+                    if (c + i0 + lane < SF_CAND) cand[c + i0 + lane] = item;
+                    mn = key < mn ? key : mn;
+                    mx = key > mx ? key : mx;
+                }
+            }
+            c += cg[u];
+        }
+    }
+    mn = wave_min_u32(mn);
+    mx = wave_max_u32(mx);
+    __builtin_amdgcn_wave_barrier();
+    // later passes visit the candidates in LDS, or -- when they did not fit (loose bound, rare) --
+    // stream them again from memory; body(valid, key, item) is called with a uniform trip count
     auto for_each = [&](auto&& body) {
+        if (c <= SF_CAND) {
+            for (int i0 = 0; i0 < c; i0 += 64) {
+                const unsigned long long item = i0 + lane < c ? cand[i0 + lane] : ~0ull;
+                body(i0 + lane < c, (uint32_t)(item >> 32), item);
+            }
+            return;
+        }
         for (int i0 = 0; i0 < n0; i0 += 64 * 8) {
             float t[8];
 #pragma unroll
@@ -704,25 +773,11 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
             const int cg = __shfl(my_cnt, g, 64);
             const unsigned long long* sg = src + (int64_t)g * slice_cap;
             for (int i0 = 0; i0 < cg; i0 += 64) {
-                const unsigned long long t = sg[min(i0 + lane, cg - 1)];
-                body(i0 + lane < cg, (uint32_t)(t >> 32), t);
+                const unsigned long long item = sg[min(i0 + lane, cg - 1)];
+                body(i0 + lane < cg, (uint32_t)(item >> 32), item);
             }
         }
     };
-    // ---- pass 1: size and key range ----
-    uint32_t mn = 0xffffffffu, mx = 0u;
-    int c = 0;
-    for_each([&](bool ok, uint32_t key, unsigned long long) {
-        if (ok) {
-            mn = key < mn ? key : mn;
-            mx = key > mx ? key : mx;
-            c++;
-        }
-    });
-    mn = wave_min_u32(mn);
-    mx = wave_max_u32(mx);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
     // ---- cut to <= 256 items: keep keys <= cutoff, cutoff from (nested) 256-bin histograms ----
     uint32_t cutoff = 0xffffffffu;
     if (c > 256) {
@@ -777,10 +832,13 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
     }
     if (lane == 0) flag[q] = 0;
     // ---- compact the kept items into runs[0..m), m <= 256 ----
+    // (in place when the candidates sit in LDS: each lane holds its item before the wave writes,
+    //  and the write index never passes the read index)
     int m = 0;
     for_each([&](bool ok, uint32_t key, unsigned long long item) {
         const bool keep = ok && key <= cutoff;
         const unsigned long long bal = __ballot(keep);
+        __builtin_amdgcn_wave_barrier();
         if (keep) runs[m + __popcll(bal & ((1ull << lane) - 1ull))] = item;
         m += __popcll(bal);
     });
@@ -796,9 +854,9 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
     for (int r = 0; r < 4; r++) runs[r * 64 + lane] = x[r];
     __builtin_amdgcn_wave_barrier();
     const float sentinel = SMALLEST ? INFINITY : -INFINITY;
+    int rk[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        if (x[r] == ~0ull) continue;
         int rank = lane;
 #pragma unroll
         for (int o = 0; o < 4; o++) {
@@ -820,16 +878,41 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
             }
             rank += lo2;
         }
-        if (rank < K) {
+        rk[r] = rank;
+    }
+    // position in the query's segment -> vector id (as k_map_candidates): last p with off[p] <= ps.
+    // Unconditional on clamped values so the four dependent load chains run side by side.
+    int ps[4], pp[4], ll[4];
+    int64_t lo64[4], idv[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        ps[r] = x[r] == ~0ull ? 0 : (int)(uint32_t)x[r];
+        int plo = 0, phi = P - 1;
+        while (plo < phi) {
+            const int mid = (plo + phi + 1) >> 1;
+            if (off[mid] <= ps[r]) plo = mid; else phi = mid - 1;
+        }
+        pp[r] = plo;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) ll[r] = probe_list[(int64_t)q * P + pp[r]];
+#pragma unroll
+    for (int r = 0; r < 4; r++) lo64[r] = list_off[max(ll[r], 0)];
+#pragma unroll
+    for (int r = 0; r < 4; r++) idv[r] = ids[lo64[r] + (ps[r] - off[pp[r]])];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (x[r] != ~0ull && rk[r] < K) {
             const uint32_t key = (uint32_t)(x[r] >> 32);
-            const float val = key2f(SMALLEST ? key : ~key);
-            out_vals[(int64_t)q * K + rank] = val;
-            out_pos[(int64_t)q * K + rank] = val == sentinel ? -1 : (int)(uint32_t)x[r];
+            out_vals[(int64_t)q * K + rk[r]] = key2f(SMALLEST ? key : ~key);
+            out_pos[(int64_t)q * K + rk[r]] = ps[r];
+            out_ids[(int64_t)q * K + rk[r]] = idv[r] & 0x7fffffffffffffffLL;
         }
     }
     for (int r = m + lane; r < K; r += 64) {   // fewer than K survivors cannot happen with a bound; be safe
         out_vals[(int64_t)q * K + r] = sentinel;
         out_pos[(int64_t)q * K + r] = -1;
+        out_ids[(int64_t)q * K + r] = -1;
     }
 }
 
@@ -891,15 +974,18 @@ void launch_select_topk(hipStream_t s, bool smallest, const float* vals, int64_t
 
 void launch_select_final(hipStream_t s, bool smallest, const unsigned long long* surv, const int* gcnt,
                          int nslices, int slice_cap, const unsigned long long* ready, const float* vals,
-                         int64_t seg_stride, const int* pair_off, int P, int G, int nq, int K, uint8_t* flag,
-                         float* out_vals, int* out_pos) {
+                         int64_t seg_stride, const int* pair_off, int P, int G, int nq, int K,
+                         const int* probe_list, const int64_t* list_off, const int64_t* ids, uint8_t* flag,
+                         float* out_vals, int* out_pos, int64_t* out_ids) {
     if (nq <= 0) return;
     if (smallest)
         hipLaunchKernelGGL((k_select_final<true>), dim3((nq + 3) / 4), dim3(256), 0, s, surv, gcnt, nslices,
-                           slice_cap, ready, vals, seg_stride, pair_off, P, G, nq, K, flag, out_vals, out_pos);
+                           slice_cap, ready, vals, seg_stride, pair_off, P, G, nq, K, probe_list, list_off, ids,
+                           flag, out_vals, out_pos, out_ids);
     else
         hipLaunchKernelGGL((k_select_final<false>), dim3((nq + 3) / 4), dim3(256), 0, s, surv, gcnt, nslices,
-                           slice_cap, ready, vals, seg_stride, pair_off, P, G, nq, K, flag, out_vals, out_pos);
+                           slice_cap, ready, vals, seg_stride, pair_off, P, G, nq, K, probe_list, list_off, ids,
+                           flag, out_vals, out_pos, out_ids);
 }
 
 }  // namespace gh
