@@ -422,3 +422,46 @@ def test_c2_flat_full_size(c3):
     Di, Ii = g.flat_search(q[:6], 100, argi)
     Do, Io = B.flat_search(base, q[:6], 100, B.METRIC_IP, B.make_ctx(**WIDE))
     compare_topk(Do, Io, Di, Ii)
+
+
+def test_scan_bound_fallback_paths():
+    """The threshold pre-filter of the scan must hand a query over to the unfiltered selection when
+    it has no usable bound: (a) mass ties -- every candidate within the bound, survivor slices
+    overflow; (b) a first probe group with fewer than recall_num valid candidates (90% deleted)."""
+    d, nlist, M, N = 32, 16, 8, 24000
+    rng = np.random.default_rng(3)
+    distinct = synth.sift_like(60, d=d, seed=77)
+    base = distinct[rng.integers(0, 60, size=N)].copy()          # 60 distinct vectors, 400 copies each
+    base[:2000] = synth.sift_like(2000, d=d, seed=78)            # plus some ordinary ones
+    q = np.concatenate([distinct[:20], synth.sift_like(20, d=d, seed=79)])
+    from gamma_amd import train
+    cc, pq = train.train_ivfpq(base[:6000], nlist, M, niter=6, pq_niter=8, seed=9, device="cpu")
+    o = B.OracleIVFPQ(d, nlist, M, 8, B.METRIC_L2, bucket_init_size=4000)
+    o.set_trained(cc, pq, None)
+    B.lib().go_set_assign_mode(1)
+    assert o.add(base)
+    B.lib().go_set_assign_mode(0)
+    o.set_raw(base)
+    g = api.GammaHip(0)
+    try:
+        g.ivfpq_init(d, nlist, M, 8, api.METRIC_L2, 4000)
+        g.ivfpq_set_trained(cc, pq, None)
+        g.add(base, 0)
+        g.raw_init(d)
+        g.raw_append(base)
+        case = dict(oracle=o)
+        dead = rng.choice(N, size=int(N * 0.9), replace=False)
+        bm = np.zeros((N >> 3) + 1, dtype=np.uint8)
+        np.bitwise_or.at(bm, dead >> 3, (1 << (dead & 7)).astype(np.uint8))
+        for del_bm in (None, bm):
+            if del_bm is not None:
+                g.bitmap_upload(del_bm, N)
+                o.set_docids_bitmap(del_bm)
+            for has_rank in (True, False):
+                for metric in (B.METRIC_L2, B.METRIC_IP):
+                    (D, I, st), (Dg, Ig) = run_both(case, g, q, 10, 8, 120, metric, has_rank, coarse_mode=1,
+                                                    del_bitmap=del_bm)
+                    sg = g.last_stages(len(q), 8, 120)
+                    compare_search(D, I, st, Dg, Ig, sg)
+    finally:
+        g.close()
