@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void k_sum_totals(const int* __restrict__ q_to
                                                     unsigned long long* __restrict__ acc) {
     __shared__ unsigned long long s_part[4];
     unsigned long long t = 0;
-    for (int i = threadIdx.x; i < nq; i += 256) t += (unsigned long long)q_total[i];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nq; i += gridDim.x * 256) t += (unsigned long long)q_total[i];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = t;
@@ -598,10 +598,13 @@ void launch_pair_offsets(hipStream_t s, const int* probe_list, int nq, int P, co
     if (nq <= 0) return;
     hipLaunchKernelGGL(k_pair_offsets, dim3((nq + 3) / 4), dim3(256), 0, s, probe_list, nq, P, list_len,
                        list_mask, nlist, pair_off, q_total, scan_codes);
-    if (scan_codes) hipLaunchKernelGGL(k_sum_totals, dim3(1), dim3(256), 0, s, q_total, nq, scan_codes);
+    if (scan_codes)
+        hipLaunchKernelGGL(k_sum_totals, dim3(std::min(64, (nq + 255) / 256)), dim3(256), 0, s, q_total, nq,
+                           scan_codes);
 }
 void launch_sum_totals(hipStream_t s, const int* q_total, int nq, unsigned long long* acc) {
-    if (nq > 0 && acc) hipLaunchKernelGGL(k_sum_totals, dim3(1), dim3(256), 0, s, q_total, nq, acc);
+    if (nq > 0 && acc)
+        hipLaunchKernelGGL(k_sum_totals, dim3(std::min(64, (nq + 255) / 256)), dim3(256), 0, s, q_total, nq, acc);
 }
 
 // ------------------------------------------------------------------------------------
