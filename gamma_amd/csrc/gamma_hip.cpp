@@ -400,7 +400,7 @@ int ivfpq_coarse(H* h, const gamma_hip_search_params* p, int nq, const float* d_
 // query slice), device pointers [nq*nprobe]; nullptr = run the coarse quantizer here
 int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& filt, int nq,
                   const float* d_x, int R, const float* pre_dis = nullptr, const int* pre_probe = nullptr,
-                  bool allow_bound = true) {
+                  bool shard = false) {
     const int P = p->nprobe, d = h->d, M = h->M, nlist = h->nlist;
     const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
     hipStream_t s = h->stream;
@@ -413,10 +413,16 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
     GH_CHECK(h, h->w_cand_pos.ensure((size_t)nq * R * sizeof(int)));
     GH_CHECK(h, h->w_cand_ids.ensure((size_t)nq * R * sizeof(int64_t)));
     if (pre_dis && pre_probe) {
-        GH_CHECK(h, hipMemcpyAsync(h->w_coarse_dis.p, pre_dis, (size_t)nq * P * sizeof(float),
-                                   hipMemcpyDeviceToDevice, s));
-        GH_CHECK(h, hipMemcpyAsync(h->w_probe.p, pre_probe, (size_t)nq * P * sizeof(int),
-                                   hipMemcpyDeviceToDevice, s));
+        if (shard && P <= 64) {
+            // dense probe groups for the owned lists (kernels.hip, k_compact_probes)
+            gh::launch_compact_probes(s, pre_probe, pre_dis, nq, P, h->d_list_len, h->d_list_mask, nlist,
+                                      h->w_probe.as<int>(), h->w_coarse_dis.as<float>());
+        } else {
+            GH_CHECK(h, hipMemcpyAsync(h->w_coarse_dis.p, pre_dis, (size_t)nq * P * sizeof(float),
+                                       hipMemcpyDeviceToDevice, s));
+            GH_CHECK(h, hipMemcpyAsync(h->w_probe.p, pre_probe, (size_t)nq * P * sizeof(int),
+                                       hipMemcpyDeviceToDevice, s));
+        }
     } else {
         GH_TRY(ivfpq_coarse(h, p, nq, d_x));
     }
@@ -449,13 +455,14 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
                                    h->w_coarse_dis.as<float>(), h->d_cc, h->w_st2.as<float>(), h->d_T2,
                                    h->d_list_off, h->d_list_len, h->d_list_mask, nlist, h->d_codes,
                                    h->d_ids, h->w_pair_off.as<int>(), q_stride, h->w_dist.as<float>(),
-                                   filt, need_ids, qperm, gsz, pg_lo, pg_cnt, bound);
+                                   filt, need_ids, qperm, gsz, pg_lo, pg_cnt, shard ? 1 : 0, bound);
     };
     // Threshold pre-filter: scan the nearest probe group first, bound each query's R-th best
     // distance from it, and let the scan of the remaining groups keep a short survivor list per
     // query; the exact top-R then comes from a few hundred survivors instead of ~10^4 candidates
     // (select.hip).  Queries without a usable bound fall back to the unfiltered selection.
-    const bool bounded = allow_bound && h->scan_bound && R <= 256 && PGN >= 2 && P <= 64;
+    // (sharded without a supplied assignment: probe groups are sparse, nothing to bound from)
+    const bool bounded = (!shard || (pre_probe && P <= 64)) && h->scan_bound && R <= 256 && PGN >= 2 && P <= 64;
     if (!bounded) {
         scan(G, 0, PGN, nullptr, true);
         StageScope t(h, GAMMA_HIP_STAGE_SELECT);
@@ -1279,7 +1286,7 @@ int gamma_hip_ivfpq_search_shard(gamma_hip_index* h, const gamma_hip_search_para
     const int chunk = query_chunk(h, nq, p->nprobe);
     for (int q0 = 0; q0 < nq; q0 += chunk) {
         const int nc = std::min(chunk, nq - q0);
-        GH_TRY(ivfpq_stage_a(h, p, filt, nc, d_x + (size_t)q0 * h->d, R, nullptr, nullptr, /*allow_bound=*/false));
+        GH_TRY(ivfpq_stage_a(h, p, filt, nc, d_x + (size_t)q0 * h->d, R, nullptr, nullptr, /*shard=*/true));
         GH_CHECK(h, hipMemcpyAsync(d_recall_dis + (size_t)q0 * R, h->w_cand_dis.p, (size_t)nc * R * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
         GH_CHECK(h, hipMemcpyAsync(d_recall_ids + (size_t)q0 * R, h->w_cand_ids.p, (size_t)nc * R * sizeof(int64_t), hipMemcpyDeviceToDevice, h->stream));
         h->last_nq = nc;
@@ -1325,10 +1332,8 @@ int gamma_hip_ivfpq_search_shard_preassigned(gamma_hip_index* h, const gamma_hip
     const int chunk = query_chunk(h, nq, P);
     for (int q0 = 0; q0 < nq; q0 += chunk) {
         const int nc = std::min(chunk, nq - q0);
-        // a shard owns ~1/W of the probed lists: the first probe group is usually empty here, so
-        // there is nothing to bound from
         GH_TRY(ivfpq_stage_a(h, p, filt, nc, d_x + (size_t)q0 * h->d, R, d_coarse_dis + (size_t)q0 * P,
-                             d_probe + (size_t)q0 * P, /*allow_bound=*/false));
+                             d_probe + (size_t)q0 * P, /*shard=*/true));
         GH_CHECK(h, hipMemcpyAsync(d_recall_dis + (size_t)q0 * R, h->w_cand_dis.p, (size_t)nc * R * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
         GH_CHECK(h, hipMemcpyAsync(d_recall_ids + (size_t)q0 * R, h->w_cand_ids.p, (size_t)nc * R * sizeof(int64_t), hipMemcpyDeviceToDevice, h->stream));
         h->last_nq = nc;

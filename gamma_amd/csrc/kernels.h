@@ -39,6 +39,9 @@ void launch_precompute_table(hipStream_t s, const float* cc, int nlist, int d, i
 void launch_pair_offsets(hipStream_t s, const int* probe_list, int nq, int P, const int* list_len,
                          const uint8_t* list_mask, int nlist, int* pair_off, int* q_total,
                          unsigned long long* scan_codes);
+void launch_compact_probes(hipStream_t s, const int* probe_in, const float* cdis_in, int nq, int P,
+                           const int* list_len, const uint8_t* list_mask, int nlist, int* probe_out,
+                           float* cdis_out);
 // threshold pre-filter of the scan (kernels.hip, k_ivfpq_scan_pair<.., FILT>)
 struct ScanBound {
     unsigned long long* ready;  // [nq] 0 = not yet published; (1 << 32 | key bound) = bound valid;
@@ -56,7 +59,7 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
                             const int* list_len, const uint8_t* list_mask, int nlist,
                             const uint8_t* codes, const int64_t* ids, const int* pair_off,
                             int64_t q_stride, float* out, const FilterDesc& filt, int need_ids,
-                            const int* qperm, int G, int pg_lo, int pg_cnt, const ScanBound* bound);
+                            const int* qperm, int G, int pg_lo, int pg_cnt, int sparse, const ScanBound* bound);
 void launch_query_order(hipStream_t s, const int* probe_list, int nq, int P, const int* list_rank,
                         int nlist, int* qkey, int* qperm);
 void launch_sum_totals(hipStream_t s, const int* q_total, int nq, unsigned long long* acc);

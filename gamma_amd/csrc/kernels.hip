@@ -580,6 +580,46 @@ __global__ __launch_bounds__(256) void k_pair_offsets(const int* __restrict__ pr
     }
 }
 
+// Sharded search: a shard owns ~1/W of a query's probed lists.  Move the owned, non-empty ones to
+// the front of the query's probe list (stable, coarse distances move along) so that the scan's
+// probe groups are dense again and the first group can bound the local top-recall_num.
+// One wave per query, P <= 64.  Entries behind the owned ones become -1.
+__global__ __launch_bounds__(256) void k_compact_probes(const int* __restrict__ probe_in,
+                                                        const float* __restrict__ cdis_in, int nq, int P,
+                                                        const int* __restrict__ list_len,
+                                                        const uint8_t* __restrict__ list_mask, int nlist,
+                                                        int* __restrict__ probe_out,
+                                                        float* __restrict__ cdis_out) {
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    int l = -1;
+    float cd = 0.f;
+    if (lane < P) {
+        l = probe_in[(int64_t)q * P + lane];
+        cd = cdis_in[(int64_t)q * P + lane];
+    }
+    const bool own = lane < P && l >= 0 && l < nlist && (!list_mask || list_mask[l]) && list_len[l] > 0;
+    const unsigned long long bal = __ballot(own);
+    const int nown = __popcll(bal);
+    if (own) {
+        const int at = __popcll(bal & ((1ull << lane) - 1ull));
+        probe_out[(int64_t)q * P + at] = l;
+        cdis_out[(int64_t)q * P + at] = cd;
+    }
+    if (lane >= nown && lane < P) {
+        probe_out[(int64_t)q * P + lane] = -1;
+        cdis_out[(int64_t)q * P + lane] = 0.f;
+    }
+}
+void launch_compact_probes(hipStream_t s, const int* probe_in, const float* cdis_in, int nq, int P,
+                           const int* list_len, const uint8_t* list_mask, int nlist, int* probe_out,
+                           float* cdis_out) {
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(k_compact_probes, dim3((nq + 3) / 4), dim3(256), 0, s, probe_in, cdis_in, nq, P, list_len,
+                       list_mask, nlist, probe_out, cdis_out);
+}
+
 // profiling only: algorithmic scan volume of a batch = sum of the per-query candidate counts
 __global__ __launch_bounds__(256) void k_sum_totals(const int* __restrict__ q_total, int nq,
                                                     unsigned long long* __restrict__ acc) {
@@ -718,7 +758,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
         const uint8_t* __restrict__ list_mask, int nlist, const uint8_t* __restrict__ codes,
         const int64_t* __restrict__ ids, const int* __restrict__ pair_off, int64_t q_stride,
         float* __restrict__ out, FilterDesc filt, int need_ids, float sentinel,
-        const int* __restrict__ qperm, int pg_lo, int pg_cnt, ScanBound sb) {
+        const int* __restrict__ qperm, int pg_lo, int pg_cnt, int sparse, ScanBound sb) {
     // This launch covers probe groups [pg_lo, pg_lo + pg_cnt) of every query.
     // FILT (pg_lo = 0, pg_cnt >= 2): threshold pre-filter.  The workgroup of a query's FIRST probe
     // group (its nearest lists) ends by bounding the query's recall_num-th best distance from above
@@ -816,6 +856,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
     const int p_begin = pg * G, p_end = min(P, p_begin + G);
     const int tid = threadIdx.x;
     const int msz = M * 256;
+    // nothing to scan in this group (a shard owns ~1/W of the probed lists): leave before the
+    // 16 KB query table is fetched (sparse = sharded search only: the check costs two dependent
+    // scalar loads per probe).  Producers always go on: they must publish.
+    if (sparse && (!FILT || pg > 0)) {
+        bool any = false;
+        for (int p = p_begin; p < p_end; p++) {
+            const int l = probe_list[q * P + p];
+            if (l >= 0 && l < nlist && (!list_mask || list_mask[l]) && list_len[l] > 0) any = true;
+        }
+        if (!any) {   // uniform
+            if (FILT && threadIdx.x == 0) sb.gcnt[(int64_t)q * (pg_cnt - 1) + (pg - 1)] = 0;
+            return;
+        }
+    }
     const float* st2q = st2 + (int64_t)q * msz;
     float s2r[MT > 0 ? MT : 1];
     if (MT > 0) {
@@ -1043,7 +1097,7 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
                             const int* list_len, const uint8_t* list_mask, int nlist,
                             const uint8_t* codes, const int64_t* ids, const int* pair_off,
                             int64_t q_stride, float* out, const FilterDesc& filt, int need_ids,
-                            const int* qperm, int G, int pg_lo, int pg_cnt, const ScanBound* bound) {
+                            const int* qperm, int G, int pg_lo, int pg_cnt, int sparse, const ScanBound* bound) {
     if (nq <= 0 || pg_cnt <= 0) return;
     const size_t lds = (size_t)M * 256 * sizeof(float);
     dim3 grid((unsigned)(8 * (int64_t)((nq + 7) / 8) * pg_cnt));
@@ -1057,7 +1111,7 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
     hipLaunchKernelGGL((k_ivfpq_scan_pair<LL, MT, FF>), grid, dim3(256), lds, s, x, nq, d, M, P, G,     \
                        probe_list, coarse_dis, cc, st2, T2, list_off, list_len, list_mask, nlist, codes, \
                        ids, pair_off, q_stride, out, filt, need_ids, LL ? INFINITY : -INFINITY, qperm,   \
-                       pg_lo, pg_cnt, sb)
+                       pg_lo, pg_cnt, sparse, sb)
 #define GH_SCAN_M(LL, FF)                       \
     do {                                        \
         if (M == 16) GH_SCAN(LL, 16, FF);       \

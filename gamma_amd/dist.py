@@ -75,9 +75,29 @@ class HipShardBackend:
                                       all_ids.data_ptr(), 0, nql, D.data_ptr(), I.data_ptr())
 
 
+def _buffers(backend, world, per, P, R, k):
+    """Exchange buffers, allocated once per shape and kept on the backend (a search step enqueues
+    ~25 kernels and 6 collectives: per-step allocations would leave the GPU waiting for the host)."""
+    cache = backend.__dict__.setdefault("_xbuf", {})
+    key = (world, per, P, R, k)
+    b = cache.get(key)
+    if b is None:
+        f32, i32, i64 = torch.float32, torch.int32, torch.int64
+        b = dict(cdis_l=backend.empty((per, P), f32), probe_l=backend.empty((per, P), i32),
+                 cdis=backend.empty((world * per, P), f32), probe=backend.empty((world * per, P), i32),
+                 rdis=backend.empty((world * per, R), f32), rids=backend.empty((world * per, R), i64),
+                 all_dis=backend.empty((world * per, R), f32), all_ids=backend.empty((world * per, R), i64),
+                 D=backend.empty((per, k), f32), I=backend.empty((per, k), i64),
+                 Dall=backend.empty((world * per, k), f32), Iall=backend.empty((world * per, k), i64))
+        cache.clear()          # one shape at a time
+        cache[key] = b
+    return b
+
+
 def sharded_search(backend, x, k, args, group=None, gather_results=True):
     """x: [nq, d] tensor on the backend's device (same on every rank).  Returns (D, I) for all nq
-    queries on every rank when gather_results, else this rank's slice."""
+    queries on every rank when gather_results, else this rank's slice.  The returned tensors are
+    views of buffers that the next call with the same shape overwrites."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     nq = x.shape[0]
@@ -87,32 +107,28 @@ def sharded_search(backend, x, k, args, group=None, gather_results=True):
     nql = q1 - q0
     stream_ctx = torch.cuda.stream(backend.stream) if hasattr(backend, "stream") else _Null()
     with stream_ctx:
+        b = _buffers(backend, world, per, P, R, k)
         # 0. coarse quantizer on the own slice, assignment all-gathered (rows padded to W*per)
-        cdis_l = backend.empty((per, P), torch.float32)
-        probe_l = backend.empty((per, P), torch.int32)
+        cdis_l, probe_l = b["cdis_l"], b["probe_l"]
         if nql < per:            # padding rows: no valid list
             cdis_l.zero_()
             probe_l.fill_(-1)
         backend.coarse(x[q0:q1], args, cdis_l, probe_l)
-        cdis = backend.empty((world * per, P), torch.float32)
-        probe = backend.empty((world * per, P), torch.int32)
+        cdis, probe = b["cdis"], b["probe"]
         dist.all_gather_into_tensor(cdis, cdis_l, group=group)
         dist.all_gather_into_tensor(probe, probe_l, group=group)
         # 1. local top-R of every query over the owned lists, laid out [dest rank][per][R]
-        rdis = backend.empty((world * per, R), torch.float32)
-        rids = backend.empty((world * per, R), torch.int64)
+        rdis, rids = b["rdis"], b["rids"]
         if nq < world * per:     # padding rows carry no candidates
             rdis[nq:].zero_()
             rids[nq:].fill_(-1)
         backend.search_shard(x, cdis[:nq], probe[:nq], k, args, rdis[:nq], rids[:nq])
         # 2. all-to-all: block r of rdis goes to rank r; block s of all_dis came from shard s
-        all_dis = backend.empty((world * per, R), torch.float32)
-        all_ids = backend.empty((world * per, R), torch.int64)
+        all_dis, all_ids = b["all_dis"], b["all_ids"]
         dist.all_to_all_single(all_dis, rdis, group=group)
         dist.all_to_all_single(all_ids, rids, group=group)
         # 3. merge + compute_dis for the own slice
-        D = backend.empty((per, k), torch.float32)
-        I = backend.empty((per, k), torch.int64)
+        D, I = b["D"], b["I"]
         if nql < per:
             D.zero_()
             I.fill_(-1)
@@ -120,8 +136,7 @@ def sharded_search(backend, x, k, args, group=None, gather_results=True):
                              nql, D, I)
         if not gather_results:
             return D[:nql], I[:nql]
-        Dall = backend.empty((world * per, k), D.dtype)
-        Iall = backend.empty((world * per, k), I.dtype)
+        Dall, Iall = b["Dall"], b["Iall"]
         dist.all_gather_into_tensor(Dall, D, group=group)
         dist.all_gather_into_tensor(Iall, I, group=group)
     return Dall[:nq], Iall[:nq]

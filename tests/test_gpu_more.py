@@ -465,3 +465,52 @@ def test_scan_bound_fallback_paths():
                     compare_search(D, I, st, Dg, Ig, sg)
     finally:
         g.close()
+
+
+def test_concurrent_search_and_add_on_one_handle(case):
+    """Search is re-entrant for the engine's client threads while the indexing thread appends
+    (SURVEY §8b threading): calls serialise on the handle, results stay exact."""
+    import threading
+    g = api.GammaHip(0)
+    o = case["oracle"]
+    try:
+        g.ivfpq_init(case["d"], case["nlist"], case["M"], 8, case["metric"], 1000)
+        g.ivfpq_set_trained(case["cc"], case["pq"], None)
+        g.raw_init(case["d"])
+        base, q = case["base"], case["q"]
+        half = len(base) // 2
+        g.raw_append(base[:half])
+        g.add(base[:half], 0)
+        args = api.SearchArgs(metric=api.METRIC_L2, nprobe=8, recall_num=100, has_rank=True, coarse_mode=0, **WIDE)
+        errors, results = [], {}
+
+        def searcher(t):
+            try:
+                for it in range(6):
+                    D, I = g.ivfpq_search(q, 10, args)
+                    assert (np.diff(D, axis=1) >= 0).all() and (I < len(base)).all()
+                    results[t] = (D, I)
+            except Exception as e:   # noqa: BLE001
+                errors.append(e)
+
+        def adder():
+            try:
+                for i0 in range(half, len(base), 1000):
+                    g.raw_append(base[i0:i0 + 1000])
+                    g.add(base[i0:i0 + 1000], i0)
+            except Exception as e:   # noqa: BLE001
+                errors.append(e)
+
+        th = [threading.Thread(target=searcher, args=(t,)) for t in range(4)] + [threading.Thread(target=adder)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errors, errors
+        # everything is in: the final state answers exactly like the oracle that holds the same lists
+        D, I = o.search(q, 10, 8, recall_num=100, has_rank=True, metric=B.METRIC_L2, ctx=B.make_ctx(**WIDE),
+                        coarse_mode=0)
+        Dg, Ig = g.ivfpq_search(q, 10, args)
+        compare_topk(D, I, Dg, Ig)
+    finally:
+        g.close()
