@@ -482,8 +482,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
         sb.ready = h->w_scnt.as<unsigned long long>();
         sb.surv = h->w_surv.as<unsigned long long>();
         sb.gcnt = reinterpret_cast<int*>(h->w_scnt.as<unsigned long long>() + nq);
-        static const bool bound_off = getenv("GAMMA_HIP_BOUND_OFF") != nullptr;   // experiment: nobody gets a bound
-        sb.K = bound_off ? (1 << 30) : R;
+        sb.K = R;
         scan(G, 0, PGN, &sb, true);
         static const bool dbg = getenv("GAMMA_HIP_BOUND_DBG") != nullptr;
         static int shown = 0;

@@ -483,8 +483,7 @@ void launch_l2_gemmform(hipStream_t s, const float* x, int nq, int d, const floa
             }
             // tiles per strip: amortise the query tile, but keep >= 512 workgroups
             const int ntiles = (int)((ny + 63) / 64);
-            static const int tps_env = getenv("GAMMA_HIP_GEMM_TPS") ? atoi(getenv("GAMMA_HIP_GEMM_TPS")) : 0;
-            int tps = tps_env > 0 ? tps_env : 8;
+            int tps = 8;
             while (tps > 1 && (int64_t)grid.y * ((ntiles + tps - 1) / tps) < 512) tps >>= 1;
             dim3 g2((unsigned)((ntiles + tps - 1) / tps), grid.y);
             hipLaunchKernelGGL(k_l2_gemmform_strip, g2, dim3(256), lds, s, x, nq, d, y, (int)ny, xn, yn, out,

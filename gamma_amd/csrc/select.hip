@@ -359,18 +359,8 @@ __global__ __launch_bounds__(256) void k_select_stream(const float* __restrict__
                                                        const int* __restrict__ seg_len, int fixed_len,
                                                        int K, int Kpad, float* __restrict__ out_vals,
                                                        int* __restrict__ out_pos,
-                                                       unsigned long long* __restrict__ dbg,
                                                        const uint8_t* __restrict__ only) {
     if (only && !only[blockIdx.x]) return;         // rows another kernel has already selected
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
-    auto TICK = [&](int slot) {
-        if (dbg) {
-            const unsigned long long now = __builtin_amdgcn_s_memtime();
-            tacc[slot] += now - tlast;
-            tlast = now;
-        }
-    };
-    if (dbg) tlast = __builtin_amdgcn_s_memtime();
     __shared__ unsigned long long s_buf[ST_CAPS];
     __shared__ int s_hist[NB];
     __shared__ int s_w[4];
@@ -399,7 +389,6 @@ __global__ __launch_bounds__(256) void k_select_stream(const float* __restrict__
         t4[0] = t4[1];
         t4[1] = t4[2];
         if (base + 3 * ST_CHUNK < n) t4[2] = v4[min((base + 3 * ST_CHUNK) / 4 + tid, n4 - 1)];
-        if (dbg) { asm volatile("" :: "v"(cur.x), "v"(cur.w)); TICK(0); }   // load wait
         // one LDS atomic per wave per chunk: ballots of the 4 slots are prefix-summed in SGPRs
         const float t[4] = {cur.x, cur.y, cur.z, cur.w};
         uint32_t key[4];
@@ -424,16 +413,13 @@ __global__ __launch_bounds__(256) void k_select_stream(const float* __restrict__
                 b0 += __popcll(bal[u]);
             }
         }
-        TICK(1);   // filter + append
         __syncthreads();
         const int cnt = s_cnt;
         __syncthreads();
-        TICK(2);   // barriers
         if (cnt > ST_CAPS - ST_CHUNK && cnt > K) {     // uniform
             tau = st_compact(s_buf, cnt, K, s_hist, s_w, s_red, s_misc);
             if (tid == 0) s_cnt = K;
             __syncthreads();
-            TICK(3);   // compaction
         }
     }
     int cnt = s_cnt;
@@ -442,12 +428,9 @@ __global__ __launch_bounds__(256) void k_select_stream(const float* __restrict__
         cnt = K;
     }
     __syncthreads();
-    TICK(3);
     block_rank_sort<256, 4>(s_buf, cnt);           // cnt <= K <= 1024 distinct items
     for (int i = cnt + tid; i < K; i += 256) s_buf[i] = ~0ull;
     __syncthreads();
-    TICK(4);   // final sort
-    if (dbg && tid == 0) for (int i = 0; i < 6; i++) dbg[(size_t)blockIdx.x * 6 + i] = tacc[i];
     const float sentinel = SMALLEST ? INFINITY : -INFINITY;
     for (int r = tid; r < K; r += 256) {
         const unsigned long long it = s_buf[r];
@@ -939,25 +922,8 @@ static void launch_sel(hipStream_t s, const float* vals, int64_t seg_stride, con
     else if (max_len <= 256 * 16) GH_SEL(16);
     else if (K <= 1024 && (seg_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(vals) & 15) == 0 &&
              !getenv("GAMMA_HIP_NO_STREAM_SELECT"))
-    {
-        static unsigned long long* dbg_buf = nullptr;
-        static const bool dbg_on = getenv("GAMMA_HIP_SELECT_DBG") != nullptr;
-        static int shown = 0;
-        if (dbg_on && !dbg_buf) (void)hipMalloc((void**)&dbg_buf, 6 * 8 * 65536);
         hipLaunchKernelGGL((k_select_stream<SMALLEST>), dim3(nseg), dim3(256), 0, s, vals, seg_stride,
-                           seg_len, fixed_len, K, Kpad, out_vals, out_pos, dbg_on ? dbg_buf : nullptr, only);
-        if (dbg_on && shown++ == 8 && nseg <= 65536) {
-            (void)hipStreamSynchronize(s);
-            std::vector<unsigned long long> hb((size_t)nseg * 6);
-            (void)hipMemcpy(hb.data(), dbg_buf, hb.size() * 8, hipMemcpyDeviceToHost);
-            const char* nm[6] = {"load-wait", "filter+append", "barriers", "compact", "final-sort", "-"};
-            for (int i = 0; i < 5; i++) {
-                double sum = 0;
-                for (int w = 0; w < nseg; w++) sum += (double)hb[(size_t)w * 6 + i];
-                fprintf(stderr, "select phase %-14s avg %.0f ticks per workgroup\n", nm[i], sum / nseg);
-            }
-        }
-    }
+                           seg_len, fixed_len, K, Kpad, out_vals, out_pos, only);
     else GH_SEL(0);
 #undef GH_SEL
 }
