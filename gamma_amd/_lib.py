@@ -23,11 +23,18 @@ class RangeFilter(C.Structure):
                 ("max_doc", C.c_int32), ("min_aligned", C.c_int32), ("b_not_in", C.c_int32)]
 
 
+class FieldFilter(C.Structure):
+    _fields_ = [("field_id", C.c_int32), ("include_lower", C.c_int32), ("include_upper", C.c_int32),
+                ("reserved", C.c_int32), ("lower_i", C.c_int64), ("upper_i", C.c_int64),
+                ("lower_f", C.c_double), ("upper_f", C.c_double)]
+
+
 class SearchParams(C.Structure):
     _fields_ = [("metric", C.c_int32), ("nprobe", C.c_int32), ("recall_num", C.c_int32),
                 ("has_rank", C.c_int32), ("min_score", C.c_float), ("max_score", C.c_float),
                 ("coarse_mode", C.c_int32), ("has_range", C.c_int32), ("n_range", C.c_int32),
-                ("range", C.POINTER(RangeFilter))]
+                ("range", C.POINTER(RangeFilter)), ("n_field", C.c_int32), ("reserved", C.c_int32),
+                ("field", C.POINTER(FieldFilter))]
 
 
 # name -> (restype, argtypes); every symbol include/gamma_hip.h declares
@@ -38,6 +45,9 @@ SYMBOLS = {
     "gamma_hip_last_error": (C.c_char_p, [C.c_void_p]),
     "gamma_hip_stream": (C.c_void_p, [C.c_void_p]),
     "gamma_hip_synchronize": (C.c_int, [C.c_void_p]),
+    "gamma_hip_field_append": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
+    "gamma_hip_field_update": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
+    "gamma_hip_field_count": (C.c_int64, [C.c_void_p, C.c_int]),
     "gamma_hip_raw_init": (C.c_int, [C.c_void_p, C.c_int]),
     "gamma_hip_raw_append": (C.c_int, [C.c_void_p, C.c_int64, f32p]),
     "gamma_hip_raw_update": (C.c_int, [C.c_void_p, C.c_int64, f32p]),

@@ -42,7 +42,9 @@ class SearchArgs:
     """Builds a gamma_hip_search_params; keeps the filter buffers alive."""
 
     def __init__(self, metric=METRIC_L2, nprobe=1, recall_num=100, has_rank=True, min_score=None,
-                 max_score=None, coarse_mode=-1, range_filters=None):
+                 max_score=None, coarse_mode=-1, range_filters=None, field_filters=None):
+        """field_filters: list of (field_id, lower, upper, include_lower, include_upper) evaluated on
+        the device against columns loaded with GammaHip.field_append."""
         p = SearchParams()
         p.metric = metric
         p.nprobe = nprobe
@@ -62,6 +64,16 @@ class SearchArgs:
                 self._keep.append(ka)
             p.range = C.cast(arr, C.POINTER(RangeFilter))
             self._keep.append(arr)
+        if field_filters:
+            fa = (_lib.FieldFilter * len(field_filters))()
+            for i, (fid, lo, hi, il, iu) in enumerate(field_filters):
+                fa[i].field_id = fid
+                fa[i].include_lower, fa[i].include_upper = int(bool(il)), int(bool(iu))
+                fa[i].lower_i, fa[i].upper_i = int(lo), int(hi)
+                fa[i].lower_f, fa[i].upper_f = float(lo), float(hi)
+            p.n_field = len(field_filters)
+            p.field = C.cast(fa, C.POINTER(_lib.FieldFilter))
+            self._keep.append(fa)
         self.p = p
 
     def ref(self):
@@ -260,6 +272,23 @@ class GammaHip:
     def ivfpq_merge_rerank(self, nshards, nq, d_x, k, args, d_all_dis, d_all_ids, q0, nq_local, d_D, d_I):
         self._ck(self.L.gamma_hip_ivfpq_merge_rerank(self.h, args.ref(), nshards, nq, d_x, k, d_all_dis,
                                                      d_all_ids, q0, nq_local, d_D, d_I), "merge_rerank")
+
+    # ---- numeric columns for on-device range filters ----
+    _FIELD_DTYPES = {np.dtype(np.int32): 0, np.dtype(np.int64): 1, np.dtype(np.float32): 2,
+                     np.dtype(np.float64): 3}
+
+    def field_append(self, field_id, values):
+        values = np.ascontiguousarray(values)
+        dt = self._FIELD_DTYPES[values.dtype]
+        self._ck(self.L.gamma_hip_field_append(self.h, field_id, dt, values.size, values.ctypes.data),
+                 "field_append")
+
+    def field_update(self, field_id, docid, value):
+        value = np.ascontiguousarray(value)
+        self._ck(self.L.gamma_hip_field_update(self.h, field_id, docid, value.ctypes.data), "field_update")
+
+    def field_count(self, field_id):
+        return self.L.gamma_hip_field_count(self.h, field_id)
 
     # ---- misc ----
     def stream(self):

@@ -1,6 +1,6 @@
 // filter_dev.h -- device-side validity predicate (GammaSearchCondition::IsValid,
 // common/gamma_common_data.h:99-108): range bitmaps (table/range_query_result.h:53-67,
-// 169-179) AND NOT delete bitmap (util/bitmap_manager.cc:187-192).
+// 169-179) AND numeric column predicates AND NOT delete bitmap (util/bitmap_manager.cc:187-192).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,6 +29,24 @@ __device__ __forceinline__ bool is_valid_doc(const FilterDesc& f, int64_t vid) {
             }
             if (!has) return false;
         }
+    }
+    for (int i = 0; i < f.n_field; i++) {
+        const FieldDesc& c = f.field[i];
+        if (doc < 0 || (int64_t)doc >= c.n) return false;
+        bool in;
+        if (c.dtype <= 1) {
+            const int64_t v = c.dtype == 0 ? (int64_t) reinterpret_cast<const int32_t*>(c.col)[doc]
+                                           : reinterpret_cast<const int64_t*>(c.col)[doc];
+            in = ((c.incl & 1) ? v >= c.lo_i : v > c.lo_i) && ((c.incl & 2) ? v <= c.hi_i : v < c.hi_i);
+        } else if (c.dtype == 2) {
+            const float v = reinterpret_cast<const float*>(c.col)[doc];
+            const float lo = (float)c.lo_f, hi = (float)c.hi_f;
+            in = ((c.incl & 1) ? v >= lo : v > lo) && ((c.incl & 2) ? v <= hi : v < hi);
+        } else {
+            const double v = reinterpret_cast<const double*>(c.col)[doc];
+            in = ((c.incl & 1) ? v >= c.lo_f : v > c.lo_f) && ((c.incl & 2) ? v <= c.hi_f : v < c.hi_f);
+        }
+        if (!in) return false;
     }
     if (f.del_bitmap && doc >= 0 && (int64_t)doc < f.del_bits && bm_test(f.del_bitmap, doc))
         return false;

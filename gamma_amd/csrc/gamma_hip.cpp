@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -71,6 +72,14 @@ struct gamma_hip_index {
     int raw_d = 0;
     float* d_raw = nullptr;
     int64_t nraw = 0, raw_cap = 0;
+
+    // numeric scalar columns (on-device range filters)
+    struct Column {
+        int dtype = 0;
+        uint8_t* d = nullptr;
+        int64_t n = 0, cap = 0;
+    };
+    std::map<int, Column> fields;
 
     // delete bitmap
     uint8_t* d_bitmap = nullptr;
@@ -301,6 +310,23 @@ int build_filter(H* h, const gamma_hip_search_params* p, gh::FilterDesc* f) {
             off += ((size_t)r.bitmap_bytes + 15) & ~(size_t)15;
         }
     }
+    f->n_field = p->n_field;
+    if (p->n_field < 0 || p->n_field > gh::kMaxField || (p->n_field > 0 && !p->field))
+        return fail(h, GAMMA_HIP_EINVAL, "bad field filters");
+    for (int i = 0; i < p->n_field; i++) {
+        const gamma_hip_field_filter& ff = p->field[i];
+        auto it = h->fields.find(ff.field_id);
+        if (it == h->fields.end()) return fail(h, GAMMA_HIP_EINVAL, "field filter on an unknown column");
+        gh::FieldDesc& fd = f->field[i];
+        fd.col = it->second.d;
+        fd.n = it->second.n;
+        fd.dtype = it->second.dtype;
+        fd.incl = (ff.include_lower ? 1 : 0) | (ff.include_upper ? 2 : 0);
+        fd.lo_i = ff.lower_i;
+        fd.hi_i = ff.upper_i;
+        fd.lo_f = ff.lower_f;
+        fd.hi_f = ff.upper_f;
+    }
     return GAMMA_HIP_OK;
 }
 
@@ -429,7 +455,8 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
     h->scan_pairs += (int64_t)nq * P;
     // ids are only read during the scan when something can reject an entry: a delete bit,
     // a range filter, or a superseded (bit 63) slot left behind by Update
-    const int need_ids = (filt.has_range || (filt.del_bitmap && h->bitmap_any) || h->n_moved > 0) ? 1 : 0;
+    const int need_ids =
+            (filt.has_range || filt.n_field > 0 || (filt.del_bitmap && h->bitmap_any) || h->n_moved > 0) ? 1 : 0;
     const int* qperm = nullptr;
     {
         StageScope t(h, GAMMA_HIP_STAGE_TABLES);
@@ -732,6 +759,8 @@ int gamma_hip_destroy(gamma_hip_index* h) {
                     h->d_ids, h->d_list_off, h->d_list_len, h->d_list_mask, h->d_scan_codes};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    for (auto& kv : h->fields)
+        if (kv.second.d) (void)hipFree(kv.second.d);
     DevBuf* bufs[] = {&h->w_mat, &h->w_coarse_dis, &h->w_probe, &h->w_xn, &h->w_st2, &h->w_pair_off,
                       &h->w_qtotal, &h->w_dist, &h->w_cand_dis, &h->w_cand_pos, &h->w_cand_ids,
                       &h->w_exact, &h->w_selv, &h->w_selp, &h->w_x, &h->w_outd, &h->w_outl, &h->w_stage,
@@ -755,6 +784,59 @@ int gamma_hip_synchronize(gamma_hip_index* h) {
 }
 
 /* ---- raw store ---------------------------------------------------------------------- */
+namespace {
+size_t field_elem_size(int dtype) {
+    return dtype == GAMMA_HIP_FIELD_INT || dtype == GAMMA_HIP_FIELD_FLOAT ? 4 : 8;
+}
+}  // namespace
+
+int gamma_hip_field_append(gamma_hip_index* h, int field_id, int dtype, int64_t n, const void* values) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (dtype < GAMMA_HIP_FIELD_INT || dtype > GAMMA_HIP_FIELD_DOUBLE || n < 0 || (n > 0 && !values))
+        return fail(h, GAMMA_HIP_EINVAL, "bad column append");
+    GH_CHECK(h, hipSetDevice(h->device));
+    auto& c = h->fields[field_id];
+    if (c.n == 0 && c.cap == 0) c.dtype = dtype;
+    if (c.dtype != dtype) return fail(h, GAMMA_HIP_EINVAL, "column dtype mismatch");
+    const size_t es = field_elem_size(dtype);
+    if (c.n + n > c.cap) {
+        const int64_t ncap = std::max<int64_t>(c.n + n, std::max<int64_t>(1 << 16, c.cap * 2));
+        uint8_t* nd = nullptr;
+        GH_CHECK(h, hipMalloc((void**)&nd, (size_t)ncap * es));
+        if (c.n) GH_CHECK(h, hipMemcpyAsync(nd, c.d, (size_t)c.n * es, hipMemcpyDeviceToDevice, h->stream));
+        GH_CHECK(h, hipStreamSynchronize(h->stream));
+        if (c.d) (void)hipFree(c.d);
+        c.d = nd;
+        c.cap = ncap;
+    }
+    if (n) {
+        GH_CHECK(h, hipMemcpyAsync(c.d + (size_t)c.n * es, values, (size_t)n * es, hipMemcpyHostToDevice, h->stream));
+        GH_CHECK(h, hipStreamSynchronize(h->stream));
+    }
+    c.n += n;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_field_update(gamma_hip_index* h, int field_id, int64_t docid, const void* value) {
+    if (!h || !value) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    auto it = h->fields.find(field_id);
+    if (it == h->fields.end() || docid < 0 || docid >= it->second.n) return fail(h, GAMMA_HIP_EINVAL, "bad column update");
+    GH_CHECK(h, hipSetDevice(h->device));
+    const size_t es = field_elem_size(it->second.dtype);
+    GH_CHECK(h, hipMemcpyAsync(it->second.d + (size_t)docid * es, value, es, hipMemcpyHostToDevice, h->stream));
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    return GAMMA_HIP_OK;
+}
+
+int64_t gamma_hip_field_count(gamma_hip_index* h, int field_id) {
+    if (!h) return -1;
+    std::lock_guard<std::mutex> g(h->mu);
+    auto it = h->fields.find(field_id);
+    return it == h->fields.end() ? 0 : it->second.n;
+}
+
 int gamma_hip_raw_init(gamma_hip_index* h, int d) {
     if (!h || d <= 0) return GAMMA_HIP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
@@ -1400,6 +1482,7 @@ int64_t gamma_hip_total_mem_bytes(gamma_hip_index* h) {
     int64_t b = 0;
     b += h->raw_cap * h->raw_d * (int64_t)sizeof(float);
     b += (int64_t)h->bitmap_cap_bytes;
+    for (auto& kv : h->fields) b += kv.second.cap * (int64_t)field_elem_size(kv.second.dtype);
     if (h->ivf_init) {
         b += (int64_t)h->nlist * h->d * 4 + (int64_t)h->nlist * 4 + (int64_t)h->M * 256 * h->dsub * 4;
         b += (int64_t)h->nlist * h->M * 256 * 4;

@@ -14,12 +14,24 @@ struct RangeDesc {
     int32_t min_doc, max_doc, min_aligned, b_not_in;
 };
 
+// numeric column predicate (IsInRange<T>, index/impl/gpu/gamma_index_ivfpq_gpu.cc:685-727)
+constexpr int kMaxField = 4;
+struct FieldDesc {
+    const void* col;
+    int64_t n;
+    int32_t dtype, incl;   // incl: bit 0 include_lower, bit 1 include_upper
+    int64_t lo_i, hi_i;
+    double lo_f, hi_f;
+};
+
 // everything GammaSearchCondition::IsValid reads (common/gamma_common_data.h:99-108)
 struct FilterDesc {
     const uint8_t* del_bitmap;
     int64_t del_bits;
     int32_t has_range, n_range;
     RangeDesc range[kMaxRange];
+    int32_t n_field, pad;
+    FieldDesc field[kMaxField];
 };
 
 void launch_pairwise(hipStream_t s, bool l2, const float* x, int nq, int d, const float* y,

@@ -48,6 +48,27 @@ typedef struct {
     int32_t b_not_in;
 } gamma_hip_range_filter;
 
+/* Scalar range filter evaluated ON the device against a numeric column that lives in HBM
+ * (gamma_hip_field_append).  Stands in for the per-request docid bitmap that
+ * MultiFieldsRangeIndex::Search produces on the host (table/field_range_index.cc:1015-1200)
+ * and for the per-doc check the reference's own GPU model makes through Table
+ * (IsInRange<T>, index/impl/gpu/gamma_index_ivfpq_gpu.cc:685-727): same comparison, same
+ * include_lower / include_upper rules; several filters are AND-ed; a doc beyond the end of
+ * the column does not match.  INT / LONG columns compare lower_i / upper_i, FLOAT / DOUBLE
+ * columns lower_f / upper_f (FLOAT in float). */
+#define GAMMA_HIP_FIELD_INT 0
+#define GAMMA_HIP_FIELD_LONG 1
+#define GAMMA_HIP_FIELD_FLOAT 2
+#define GAMMA_HIP_FIELD_DOUBLE 3
+#define GAMMA_HIP_MAX_FIELD_FILTERS 4
+typedef struct {
+    int32_t field_id;
+    int32_t include_lower, include_upper;
+    int32_t reserved;
+    int64_t lower_i, upper_i;
+    double lower_f, upper_f;
+} gamma_hip_field_filter;
+
 /* What GammaSearchCondition + IVFPQRetrievalParameters carry into Search()
  * (common/gamma_common_data.h:39-124, index/impl/gamma_index_ivfpq.h:629-673). */
 typedef struct {
@@ -62,6 +83,9 @@ typedef struct {
     int32_t has_range;    /* range_query_result != nullptr */
     int32_t n_range;      /* number of RangeQueryResult; 0 with has_range => nothing valid */
     const gamma_hip_range_filter* range;
+    int32_t n_field;      /* GammaSearchCondition::range_filters evaluated on device columns */
+    int32_t reserved;
+    const gamma_hip_field_filter* field;
 } gamma_hip_search_params;
 
 /* ---- lifecycle ------------------------------------------------------------------- */
@@ -74,6 +98,12 @@ const char* gamma_hip_last_error(gamma_hip_index* h);
 /* hipStream_t the handle launches on (for event timing / overlap by the caller) */
 void* gamma_hip_stream(gamma_hip_index* h);
 int gamma_hip_synchronize(gamma_hip_index* h);
+
+/* ---- numeric scalar columns for on-device range filters (docid = row).  The engine side
+ *      appends a doc's value when the doc is added (Table::Add, table/table.cc) ----------- */
+int gamma_hip_field_append(gamma_hip_index* h, int field_id, int dtype, int64_t n, const void* values);
+int gamma_hip_field_update(gamma_hip_index* h, int field_id, int64_t docid, const void* value);
+int64_t gamma_hip_field_count(gamma_hip_index* h, int field_id);
 
 /* ---- raw vector store (VectorReader::Gets / MemoryRawVector, vector/raw_vector.cc:99-109,
  *      vector/memory_raw_vector.cc:90-142): device mirror, vid = row ------------------- */

@@ -514,3 +514,52 @@ def test_concurrent_search_and_add_on_one_handle(case):
         compare_topk(D, I, Dg, Ig)
     finally:
         g.close()
+
+
+def test_field_filters_on_device(case):
+    """Scalar range filters evaluated on device columns == the same selection handed over as a
+    host-built RangeQueryResult bitmap (reference semantics: IsInRange<T>, AND of the clauses,
+    include_lower / include_upper, docs beyond the column do not match)."""
+    N = case["N"]
+    rng = np.random.default_rng(17)
+    price = rng.integers(0, 1000, size=N).astype(np.int64)
+    score = rng.random(N - 500)                      # float64, 500 docs short
+    stock = rng.integers(-5, 5, size=N).astype(np.int32)
+    weight = rng.random(N).astype(np.float32)
+    g = fixtures.load_hip(case)       # own handle: no delete bitmap left over from other tests
+    g.field_append(1, price[:N // 2])
+    g.field_append(1, price[N // 2:])                # grows
+    g.field_append(2, score)
+    g.field_append(3, stock)
+    g.field_append(4, weight)
+    assert g.field_count(1) == N and g.field_count(2) == N - 500
+    g.field_update(1, 7, np.array([price[7] + 1000], dtype=np.int64))
+    price[7] += 1000
+    sc = np.concatenate([score, np.full(500, np.nan)])
+    w_lo, w_hi = np.float32(0.25), np.float32(0.75)
+    cases = [
+        ([(1, 100, 300, True, True)], (price >= 100) & (price <= 300)),
+        ([(1, 100, 300, False, False)], (price > 100) & (price < 300)),
+        ([(1, 100, 300, True, False), (2, 0.2, 0.9, False, True)],
+         (price >= 100) & (price < 300) & (sc > 0.2) & (sc <= 0.9)),
+        ([(3, -2, 2, True, True), (4, float(w_lo), float(w_hi), True, False)],
+         (stock >= -2) & (stock <= 2) & (weight >= w_lo) & (weight < w_hi)),
+        ([(1, 5000, 6000, True, True)], np.zeros(N, bool)),
+    ]
+    q = case["q"]
+    for filters, mask in cases:
+        docs = np.nonzero(mask)[0]
+        for has_rank in (True, False):
+            (D, I, st), _ = run_both(case, g, q, 10, 8, 100, B.METRIC_L2, has_rank, range_docs=[docs])
+            args = api.SearchArgs(metric=api.METRIC_L2, nprobe=8, recall_num=100, has_rank=has_rank,
+                                  coarse_mode=0, field_filters=filters, **WIDE)
+            Dg, Ig = g.ivfpq_search(q, 10, args)
+            compare_topk(D, I, Dg, Ig)
+        Df, If = B.flat_search(case["base"], q[:8], 10, B.METRIC_L2,
+                               B.make_ctx(range_filters=[B.make_range_filter(docs)], **WIDE))
+        Dg, Ig = g.flat_search(q[:8], 10, api.SearchArgs(metric=api.METRIC_L2, field_filters=filters, **WIDE))
+        compare_topk(Df, If, Dg, Ig)
+    with pytest.raises(api.GammaHipError):      # unknown column
+        g.ivfpq_search(q, 10, api.SearchArgs(metric=api.METRIC_L2, nprobe=8, field_filters=[(99, 0, 1, True, True)],
+                                             **WIDE))
+    g.close()
