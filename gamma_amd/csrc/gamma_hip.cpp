@@ -489,7 +489,10 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
     // query; the exact top-R then comes from a few hundred survivors instead of ~10^4 candidates
     // (select.hip).  Queries without a usable bound fall back to the unfiltered selection.
     // (sharded without a supplied assignment: probe groups are sparse, nothing to bound from)
-    const bool bounded = (!shard || (pre_probe && P <= 64)) && h->scan_bound && R <= 256 && PGN >= 2 && P <= 64;
+    // small batches: one probe per workgroup, a single list rarely holds R candidates, and the
+    // unfiltered selection is latency-bound anyway
+    const bool bounded = (!shard || (pre_probe && P <= 64)) && h->scan_bound && R <= 256 && PGN >= 2 && P <= 64 &&
+                         G >= 4;
     if (!bounded) {
         scan(G, 0, PGN, nullptr, true);
         StageScope t(h, GAMMA_HIP_STAGE_SELECT);

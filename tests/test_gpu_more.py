@@ -424,16 +424,45 @@ def test_c2_flat_full_size(c3):
     compare_topk(Do, Io, Di, Ii)
 
 
+def test_scan_bound_parity_at_batch_size(case):
+    """512+ queries x 32 probes switch the threshold pre-filter on (4 probes per workgroup): full
+    parity against the oracle, with and without filters, both metrics, re-rank on and off."""
+    g = fixtures.load_hip(case)
+    try:
+        q = synth.sift_like(530, d=case["d"], seed=4242)
+        N = case["N"]
+        rng = np.random.default_rng(8)
+        dead = rng.choice(N, size=N // 4, replace=False)
+        bm = np.zeros((N >> 3) + 1, dtype=np.uint8)
+        np.bitwise_or.at(bm, dead >> 3, (1 << (dead & 7)).astype(np.uint8))
+        keep = rng.choice(N, size=N // 2, replace=False)
+        for del_bm, rdocs in ((None, None), (bm, [keep])):
+            if del_bm is not None:
+                g.bitmap_upload(del_bm, N)
+                case["oracle"].set_docids_bitmap(del_bm)
+            for metric in (B.METRIC_L2, B.METRIC_IP):
+                for has_rank in (True, False):
+                    (D, I, st), (Dg, Ig) = run_both(case, g, q, 10, 32, 100, metric, has_rank, coarse_mode=1,
+                                                    del_bitmap=del_bm, range_docs=rdocs)
+                    sg = g.last_stages(len(q), 32, 100)
+                    assert sg["coarse_dis"].tobytes() == st["coarse_dis"].tobytes()
+                    compare_search(D, I, st, Dg, Ig, sg)
+    finally:
+        case["oracle"].set_docids_bitmap(np.zeros((case["N"] >> 3) + 1, dtype=np.uint8))
+        g.close()
+
+
 def test_scan_bound_fallback_paths():
     """The threshold pre-filter of the scan must hand a query over to the unfiltered selection when
     it has no usable bound: (a) mass ties -- every candidate within the bound, survivor slices
     overflow; (b) a first probe group with fewer than recall_num valid candidates (90% deleted)."""
-    d, nlist, M, N = 32, 16, 8, 24000
+    d, nlist, M, N = 32, 64, 8, 24000
     rng = np.random.default_rng(3)
     distinct = synth.sift_like(60, d=d, seed=77)
     base = distinct[rng.integers(0, 60, size=N)].copy()          # 60 distinct vectors, 400 copies each
     base[:2000] = synth.sift_like(2000, d=d, seed=78)            # plus some ordinary ones
-    q = np.concatenate([distinct[:20], synth.sift_like(20, d=d, seed=79)])
+    # 520 queries x 32 probes: enough workgroups for 4 probes per group, i.e. the pre-filter is on
+    q = np.concatenate([distinct[:60], synth.sift_like(460, d=d, seed=79)])
     from gamma_amd import train
     cc, pq = train.train_ivfpq(base[:6000], nlist, M, niter=6, pq_niter=8, seed=9, device="cpu")
     o = B.OracleIVFPQ(d, nlist, M, 8, B.METRIC_L2, bucket_init_size=4000)
@@ -459,9 +488,9 @@ def test_scan_bound_fallback_paths():
                 o.set_docids_bitmap(del_bm)
             for has_rank in (True, False):
                 for metric in (B.METRIC_L2, B.METRIC_IP):
-                    (D, I, st), (Dg, Ig) = run_both(case, g, q, 10, 8, 120, metric, has_rank, coarse_mode=1,
+                    (D, I, st), (Dg, Ig) = run_both(case, g, q, 10, 32, 120, metric, has_rank, coarse_mode=1,
                                                     del_bitmap=del_bm)
-                    sg = g.last_stages(len(q), 8, 120)
+                    sg = g.last_stages(len(q), 32, 120)
                     compare_search(D, I, st, Dg, Ig, sg)
     finally:
         g.close()
