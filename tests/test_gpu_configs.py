@@ -51,7 +51,7 @@ def test_c4_shape_m32_nlist16384_nprobe64():
         assert rec > 0.85, rec
         # sampled bit parity against the oracle holding the same lists
         o = _oracle_from_device(g, d, nlist, M, B.METRIC_L2, cc, pq, base)
-        qs = q[:48]
+        qs = q                       # all 512: 4 probes per scan workgroup, threshold pre-filter on
         for has_rank in (True, False):
             ctx = B.make_ctx(min_score=0.0, max_score=1e30)
             Do, Io, st = o.search(qs, 10, P, recall_num=100, has_rank=has_rank, metric=B.METRIC_L2, ctx=ctx,
@@ -61,7 +61,7 @@ def test_c4_shape_m32_nlist16384_nprobe64():
             Dg, Ig = g.ivfpq_search(qs, 10, a2)
             sg = g.last_stages(len(qs), P, 100)
             assert sg["coarse_dis"].tobytes() == st["coarse_dis"].tobytes()
-            assert np.array_equal(sg["coarse_idx"], st["coarse_idx"])
+            compare_topk(st["coarse_dis"], st["coarse_idx"], sg["coarse_dis"], sg["coarse_idx"])   # tie-aware
             compare_search(Do, Io, st, Dg, Ig, sg)
     finally:
         g.close()
@@ -147,6 +147,18 @@ def test_c5_shape_d768_ip_filters_and_realtime_inserts():
             allv[vid] = newv
             o.update(int(vid), newv)
         check(n_added, del_bm=bm)
+        # a batch large enough for the scan's threshold pre-filter (generic M = 64 kernel, inner product)
+        qb = np.ascontiguousarray(allv[rng.choice(n_added, size=520, replace=False)] * np.float32(0.999))
+        o.set_raw(allv[:n_added])
+        for has_rank in (True, False):
+            ctx = B.make_ctx(docids_bitmap=bm, **WIDE)
+            Do, Io, st = o.search(qb, 10, P, recall_num=100, has_rank=has_rank, metric=B.METRIC_IP, ctx=ctx,
+                                  coarse_mode=1, want_stages=True)
+            a = api.SearchArgs(metric=api.METRIC_IP, nprobe=P, recall_num=100, has_rank=has_rank, coarse_mode=1,
+                               **WIDE)
+            Dg, Ig = g.ivfpq_search(qb, 10, a)
+            sg = g.last_stages(len(qb), P, 100)
+            compare_search(Do, Io, st, Dg, Ig, sg)
     finally:
         B.lib().go_set_assign_mode(0)
         g.close()
