@@ -524,20 +524,26 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
         gh::launch_select_topk(s, l2, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), 0,
                                (int)std::min<int64_t>(q_stride, 1 << 30), nq, R,
                                h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>(), h->w_sflag.as<uint8_t>());
-        if (dbg && shown++ == 8) {
+        if (dbg && shown++ >= 8 && shown <= 13) {
             std::vector<uint8_t> hf(nq);
             std::vector<int> hc((size_t)nq * nsl);
             (void)hipStreamSynchronize(s);
             (void)hipMemcpy(hf.data(), h->w_sflag.p, nq, hipMemcpyDeviceToHost);
             (void)hipMemcpy(hc.data(), sb.gcnt, hc.size() * sizeof(int), hipMemcpyDeviceToHost);
-            int64_t nf = 0, tot = 0, mx = 0;
-            for (int i = 0; i < nq; i++) nf += hf[i];
+            std::vector<unsigned long long> hr(nq);
+            (void)hipMemcpy(hr.data(), sb.ready, (size_t)nq * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            int64_t nf = 0, tot = 0, mx = 0, nobound = 0;
+            for (int i = 0; i < nq; i++) {
+                nf += hf[i];
+                nobound += (hr[i] >> 32) != 1ull;
+            }
             for (size_t i = 0; i < hc.size(); i++) {
                 tot += hc[i];
                 mx = std::max<int64_t>(mx, hc[i]);
             }
-            fprintf(stderr, "scan bound: %lld of %d queries unfiltered, survivors per query mean %.1f, per slice max %lld\n",
-                    (long long)nf, nq, (double)tot / nq, (long long)mx);
+            fprintf(stderr, "scan bound: %lld of %d queries unfiltered (%lld without a bound), survivors per query mean %.1f, "
+                    "per slice max %lld\n",
+                    (long long)nf, nq, (long long)nobound, (double)tot / nq, (long long)mx);
         }
         gh::launch_map_candidates(s, h->w_cand_pos.as<int>(), nq, R, P, h->w_probe.as<int>(),
                                   h->w_pair_off.as<int>(), h->d_list_off, h->d_ids,
