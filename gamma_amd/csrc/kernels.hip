@@ -741,6 +741,7 @@ __device__ __forceinline__ uint32_t dis_key(float v) {
     const uint32_t k = f2key(v);
     return L2 ? k : ~k;
 }
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr uint32_t KEY_SENTINEL = 0xff800000u;   // key of the filtered-entry marker (+inf / -inf)
 constexpr int SCAN_STAGE = 256;                  // survivors staged in LDS per workgroup
 constexpr int SCAN_SLICE = 512;                  // survivor slice of one consumer workgroup (global)
@@ -916,6 +917,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
         if (list_mask && !list_mask[l]) continue;
         const int len = list_len[l];
         if (len == 0) continue;
+        const int64_t off = list_off[l];
+        const uint8_t* lc = codes + off * M;
+        // the first 256 codes are requested BEFORE the T2 row: both latencies overlap, and lists of
+        // up to 256 codes (most of them) never wait for their codes after the LUT is ready
+        constexpr bool PRE = MT == 16 || MT == 32;
+        // (issued as inline asm: hipcc sinks an ordinary load down to its first use, behind both
+        // barriers; the matching s_waitcnt is placed by hand where the codes are consumed)
+        u32x4 cfirst[PRE ? MT / 16 : 1];
+        if (PRE) {
+            const uint8_t* cp0 = lc + (int64_t)min(tid, len - 1) * (PRE ? MT : 16);
+#pragma unroll
+            for (int u = 0; u < (PRE ? MT / 16 : 1); u++) {
+                const uint8_t* a = cp0 + 16 * u;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(cfirst[u]) : "v"(a) : "memory");
+            }
+        }
         __syncthreads();   // the previous list's gathers (and s_acc reads) are finished
         if (L2) {
             const float* t2 = T2 + (int64_t)l * msz;
@@ -959,15 +976,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
             if (rem > 2) s2 = __builtin_fmaf(xq[i + 2], c[i + 2], s2);
             dis0 = hsum4(s0, s1, s2, s3);
         }
-        const int64_t off = list_off[l];
-        const uint8_t* lc = codes + off * M;
         const int64_t* lid = ids + off;
         const int pbase = pair_off[(int64_t)q * (P + 1) + p];
         float* o = out + (int64_t)q * q_stride + pbase;
-        for (int j0 = 0; j0 < len; j0 += 256) {     // uniform trip count: append() ballots
-            const int j = j0 + tid;
-            uint32_t key = 0xffffffffu;
-            if (j < len) {
+        // one code: validity, ADC (gathers issued together, adds in reference order), store
+        auto do_code = [&](int j, const uint32_t* cw) -> uint32_t {
             // ids are read only when something can reject an entry (delete bit, range filter,
             // superseded slot); otherwise 8 of the 28 bytes per candidate stay in HBM
             bool ok = true;
@@ -977,26 +990,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
                 if (ok) ok = is_valid_doc(filt, id);
             }
             float dis = dis0;
-            if (MT == 16 || MT == 32) {
-                uint32_t cw[MT > 0 ? MT / 4 : 1];
-                const uint4* cp = reinterpret_cast<const uint4*>(lc + (int64_t)j * MT);
+            if (PRE) {
+                float t[PRE ? MT : 1];
 #pragma unroll
-                for (int u = 0; u < MT / 16; u++) {
-                    const uint4 cv = cp[u];
-                    cw[4 * u] = cv.x; cw[4 * u + 1] = cv.y; cw[4 * u + 2] = cv.z; cw[4 * u + 3] = cv.w;
-                }
-                float t[MT > 0 ? MT : 1];
-#pragma unroll
-                for (int m = 0; m < MT; m++) t[m] = s_lut[m * 256 + ((cw[m >> 2] >> ((m & 3) * 8)) & 255)];
+                for (int m = 0; m < (PRE ? MT : 1); m++) t[m] = s_lut[m * 256 + ((cw[m >> 2] >> ((m & 3) * 8)) & 255)];
                 __builtin_amdgcn_sched_barrier(0);   // all gathers in flight before the add chain
 #pragma unroll
-                for (int m = 0; m < MT; m++) dis += t[m];   // sequential, reference order
+                for (int m = 0; m < (PRE ? MT : 1); m++) dis += t[m];   // sequential, reference order
             } else {
                 const uint8_t* cj = lc + (int64_t)j * M;
                 for (int m = 0; m < M; m++) dis += s_lut[m * 256 + cj[m]];
             }
             const float val = ok ? dis : sentinel;
             o[j] = val;
+            uint32_t key = 0xffffffffu;
             if (FILT) {
                 key = dis_key<L2>(val);
                 if (pg == 0 && key < KEY_SENTINEL) {
@@ -1005,6 +1012,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
                     g_nv++;
                 }
             }
+            return key;
+        };
+        // uniform trip counts: append() ballots.  First 256 codes: already in registers.
+        if (PRE) {
+#pragma unroll
+            for (int u = 0; u < (PRE ? MT / 16 : 1); u++)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(cfirst[u]) : : "memory");
+        }
+        {
+            uint32_t key = 0xffffffffu;
+            if (tid < len) {
+                uint32_t cw[PRE ? MT / 4 : 1];
+                if (PRE) {
+#pragma unroll
+                    for (int u = 0; u < MT / 16; u++) {
+                        cw[4 * u] = cfirst[u].x; cw[4 * u + 1] = cfirst[u].y;
+                        cw[4 * u + 2] = cfirst[u].z; cw[4 * u + 3] = cfirst[u].w;
+                    }
+                }
+                key = do_code(tid, cw);
+            }
+            if (FILT && bound_on) append(key <= tauq, key, pbase + tid);
+        }
+        for (int j0 = 256; j0 < len; j0 += 256) {
+            const int j = j0 + tid;
+            uint32_t key = 0xffffffffu;
+            if (j < len) {
+                uint32_t cw[PRE ? MT / 4 : 1];
+                if (PRE) {
+                    const uint4* cp = reinterpret_cast<const uint4*>(lc + (int64_t)j * (PRE ? MT : 16));
+#pragma unroll
+                    for (int u = 0; u < MT / 16; u++) {
+                        const uint4 cv = cp[u];
+                        cw[4 * u] = cv.x; cw[4 * u + 1] = cv.y; cw[4 * u + 2] = cv.z; cw[4 * u + 3] = cv.w;
+                    }
+                }
+                key = do_code(j, cw);
             }
             if (FILT && bound_on) append(key <= tauq, key, pbase + j);
         }
