@@ -33,7 +33,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--nq", type=int, default=8192, help="queries per Search call (one step)")
     ap.add_argument("--n", type=int, default=1000000)
     ap.add_argument("--d", type=int, default=128)

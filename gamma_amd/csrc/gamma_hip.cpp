@@ -126,6 +126,7 @@ struct gamma_hip_index {
     // profiling
     bool profile = false;
     std::vector<StageEvent> events;
+    std::vector<hipEvent_t> event_pool;
     double stage_ms[GAMMA_HIP_NUM_STAGES] = {0};
     int64_t stage_n[GAMMA_HIP_NUM_STAGES] = {0};
     int64_t scan_pairs = 0;
@@ -162,7 +163,20 @@ struct StageScope {
     hipEvent_t a = nullptr, b = nullptr;
     StageScope(H* h_, int st, bool count_ = true) : h(h_), stage(st), count(count_) {
         if (h->profile) {
-            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+            // events are recycled: creating / destroying two per stage and step costs the host
+            // more than the stages' launches
+            auto take = [&]() -> hipEvent_t {
+                if (!h->event_pool.empty()) {
+                    hipEvent_t e = h->event_pool.back();
+                    h->event_pool.pop_back();
+                    return e;
+                }
+                hipEvent_t e = nullptr;
+                return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+            };
+            a = take();
+            b = take();
+            if (!a || !b) {
                 a = b = nullptr;
                 return;
             }
@@ -186,8 +200,8 @@ int drain_events(H* h) {
             h->stage_ms[e.stage] += ms;
             h->stage_n[e.stage] += e.count ? 1 : 0;
         }
-        (void)hipEventDestroy(e.a);
-        (void)hipEventDestroy(e.b);
+        h->event_pool.push_back(e.a);
+        h->event_pool.push_back(e.b);
     }
     h->events.clear();
     return GAMMA_HIP_OK;
@@ -770,6 +784,7 @@ int gamma_hip_destroy(gamma_hip_index* h) {
         if (p) (void)hipFree(p);
     for (auto& kv : h->fields)
         if (kv.second.d) (void)hipFree(kv.second.d);
+    for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&h->w_mat, &h->w_coarse_dis, &h->w_probe, &h->w_xn, &h->w_st2, &h->w_pair_off,
                       &h->w_qtotal, &h->w_dist, &h->w_cand_dis, &h->w_cand_pos, &h->w_cand_ids,
                       &h->w_exact, &h->w_selv, &h->w_selp, &h->w_x, &h->w_outd, &h->w_outl, &h->w_stage,
