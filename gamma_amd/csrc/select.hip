@@ -863,19 +863,29 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
         }
         rk[r] = rank;
     }
+    // the K winners in rank order (LDS), then one coalesced pass: rank r = lane + 64 i
+    __builtin_amdgcn_wave_barrier();   // all binary searches have read the runs
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        if (x[r] != ~0ull && rk[r] < 256) runs[rk[r]] = x[r];   // ranks are a permutation of 0..m-1
+    __builtin_amdgcn_wave_barrier();
     // position in the query's segment -> vector id (as k_map_candidates): last p with off[p] <= ps.
-    // Unconditional on clamped values so the four dependent load chains run side by side.
+    // Branch-free on clamped values so the four dependent load chains run side by side.
+    const int nres = min(m, K);
+    unsigned long long it[4];
     int ps[4], pp[4], ll[4];
     int64_t lo64[4], idv[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        ps[r] = x[r] == ~0ull ? 0 : (int)(uint32_t)x[r];
-        int plo = 0, phi = P - 1;
-        while (plo < phi) {
-            const int mid = (plo + phi + 1) >> 1;
-            if (off[mid] <= ps[r]) plo = mid; else phi = mid - 1;
+        it[r] = runs[min(lane + 64 * r, max(nres - 1, 0))];
+        ps[r] = (int)(uint32_t)it[r];
+        int lo = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {   // P <= 64
+            const int mid = lo + step;
+            if (mid < P && off[min(mid, P)] <= ps[r]) lo = mid;
         }
-        pp[r] = plo;
+        pp[r] = lo;
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) ll[r] = probe_list[(int64_t)q * P + pp[r]];
@@ -885,11 +895,12 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
     for (int r = 0; r < 4; r++) idv[r] = ids[lo64[r] + (ps[r] - off[pp[r]])];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        if (x[r] != ~0ull && rk[r] < K) {
-            const uint32_t key = (uint32_t)(x[r] >> 32);
-            out_vals[(int64_t)q * K + rk[r]] = key2f(SMALLEST ? key : ~key);
-            out_pos[(int64_t)q * K + rk[r]] = ps[r];
-            out_ids[(int64_t)q * K + rk[r]] = idv[r] & 0x7fffffffffffffffLL;
+        const int rank = lane + 64 * r;
+        if (rank < nres) {
+            const uint32_t key = (uint32_t)(it[r] >> 32);
+            out_vals[(int64_t)q * K + rank] = key2f(SMALLEST ? key : ~key);
+            out_pos[(int64_t)q * K + rank] = ps[r];
+            out_ids[(int64_t)q * K + rank] = idv[r] & 0x7fffffffffffffffLL;
         }
     }
     for (int r = m + lane; r < K; r += 64) {   // fewer than K survivors cannot happen with a bound; be safe
