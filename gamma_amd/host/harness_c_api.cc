@@ -9,7 +9,7 @@
 
 #include "gamma_index_ivfpq_hip.h"
 #include "iwpq_io.h"
-#include "retrieval_model.h"
+#include "plugin_api.h"
 
 using namespace tig_gamma;
 

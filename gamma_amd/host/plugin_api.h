@@ -1,4 +1,4 @@
-// retrieval_model.h -- this repository's own restatement of Gamma's plugin interface
+// plugin_api.h -- this repository's own restatement of Gamma's plugin interface
 // (reference: index/retrieval_model.h:18-310, index/reflector.h:15-80, the parts of
 // common/gamma_common_data.h:39-124 and table/range_query_result.h:25-200 a plugin reads).
 //

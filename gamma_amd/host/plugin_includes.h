@@ -9,5 +9,5 @@
 #include "util/utils.h"
 #else
 #include "json_lite.h"
-#include "retrieval_model.h"
+#include "plugin_api.h"
 #endif

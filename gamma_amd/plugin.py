@@ -2,7 +2,7 @@
 the way Gamma's VectorManager drives a model (gamma_amd/host/harness_c_api.cc).
 
 Test/bench convenience only; the product boundary is the C++ RetrievalModel interface in
-gamma_amd/host/retrieval_model.h on top of the C ABI in include/gamma_hip.h.
+gamma_amd/host/plugin_api.h on top of the C ABI in include/gamma_hip.h.
 """
 import ctypes as C
 import os
