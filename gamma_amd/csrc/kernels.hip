@@ -657,7 +657,7 @@ __global__ __launch_bounds__(1024) void k_query_order(const int* __restrict__ pr
                                                       const int* __restrict__ list_rank, int nlist,
                                                       int* __restrict__ qkey, int* __restrict__ qperm) {
     __shared__ int s_bin[QO_BINS];
-    __shared__ int s_part[1024];
+    __shared__ int s_part[32];
     const int tid = threadIdx.x;
     for (int b = tid; b < QO_BINS; b += 1024) s_bin[b] = 0;
     __syncthreads();
@@ -688,15 +688,17 @@ __global__ __launch_bounds__(1024) void k_query_order(const int* __restrict__ pr
         v[u] = s_bin[tid * (QO_BINS / 1024) + u];
         sum += v[u];
     }
-    s_part[tid] = sum;
+    // block-wide exclusive prefix of `sum`: wave scans + one scan of the 16 wave totals
+    const int incl = wave_incl_scan(sum);
+    if ((tid & 63) == 63) s_part[tid >> 6] = incl;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int t = tid >= off ? s_part[tid - off] : 0;
-        __syncthreads();
-        s_part[tid] += t;
-        __syncthreads();
+    if (tid < 64) {
+        const int t = tid < 16 ? s_part[tid] : 0;
+        const int ti = wave_incl_scan(t);
+        if (tid < 16) s_part[16 + tid] = ti - t;   // exclusive prefix of the wave totals
     }
-    int run = s_part[tid] - sum;
+    __syncthreads();
+    int run = s_part[16 + (tid >> 6)] + incl - sum;
 #pragma unroll
     for (int u = 0; u < QO_BINS / 1024; u++) {
         s_bin[tid * (QO_BINS / 1024) + u] = run;
