@@ -1325,15 +1325,20 @@ __global__ __launch_bounds__(256) void k_rerank_topk(const float* __restrict__ x
                                                      float* __restrict__ distances,
                                                      int64_t* __restrict__ labels) {
     __shared__ unsigned long long s_it[1024];
+    __shared__ int64_t s_id[1024];
     const int q = blockIdx.x;
     const int l = threadIdx.x & 7, g = threadIdx.x >> 3;
     const float* xq = x + (int64_t)q * d;
     const float sentinel = L2 ? INFINITY : -INFINITY;
     const int d8 = d & ~7;
+    // all candidate ids first (one coalesced pass): the row gathers below then start without a
+    // dependent id load in front of each of them
+    for (int r = threadIdx.x; r < R; r += 256) s_id[r] = cand_ids[(int64_t)q * R + r];
+    __syncthreads();
     for (int r0 = 0; r0 < R; r0 += 32) {
         const int r = r0 + g;
         int64_t id = -1;
-        if (r < R) id = cand_ids[(int64_t)q * R + r];
+        if (r < R) id = s_id[r];
         const bool live = id >= 0 && id < nraw;
         const float* v = raw + (live ? id : 0) * d;
         float a = 0.f;
@@ -1404,7 +1409,7 @@ __global__ __launch_bounds__(256) void k_rerank_topk(const float* __restrict__ x
             const float dv = key2f(L2 ? key : ~key);
             if (dv != sentinel) {
                 val = dv;
-                id = cand_ids[(int64_t)q * R + (uint32_t)it];
+                id = s_id[(uint32_t)it];
             }
         }
         distances[(int64_t)q * k + i] = val;
