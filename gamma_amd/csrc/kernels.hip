@@ -76,6 +76,89 @@ __global__ __launch_bounds__(256) void k_pairwise_rowreg(const float* __restrict
     }
 }
 
+// Same contract, queries staged in LDS and broadcast (one ds_read_b128 feeds a whole wave), packed
+// fp32 math.  k_pairwise_rowreg pulls every query vector through the scalar cache once per wave
+// (512 B per wave and query at d = 128) and that path, not the VALU, is its limit; here a tile of
+// PW_QT queries is read once per workgroup and the sub / fma pairs run as v_pk_add_f32 /
+// v_pk_fma_f32 on two of the eight lane accumulators at a time (IEEE per component: same bits).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int PW_QT = 32;
+template <bool L2, int D, bool FILTER>
+__global__ __launch_bounds__(256) void k_pairwise_lds(const float* __restrict__ x, int nq,
+                                                      const float* __restrict__ y, int64_t ny,
+                                                      float* __restrict__ out, int64_t ld_out,
+                                                      int q_per_block, FilterDesc filt, float min_score,
+                                                      float max_score, float sentinel, int64_t row_base) {
+    // Two threads per database row: the even one owns AVX lanes 0-3 (elements 8i .. 8i+3), the odd
+    // one lanes 4-7, D/2 row values each -- half the registers of a whole row per thread, so
+    // several waves fit per SIMD.  Per lane the accumulation order is untouched; the pair's sums
+    // meet in s[l] = acc[l+4] + acc[l] through one shuffle.
+    __shared__ float4 s_x[PW_QT * D / 4];
+    const int half = threadIdx.x & 1;
+    const int64_t row = (int64_t)blockIdx.x * 128 + (threadIdx.x >> 1);
+    const int q0 = blockIdx.y * q_per_block;
+    const int q1 = min(nq, q0 + q_per_block);
+    f32x2 yr[D / 4];
+    const bool live = row < ny;
+    {
+        const float4* yp = reinterpret_cast<const float4*>(y + (live ? row : 0) * D) + half;
+#pragma unroll
+        for (int i = 0; i < D / 8; i++) {
+            const float4 v = yp[2 * i];
+            yr[2 * i] = f32x2{v.x, v.y};
+            yr[2 * i + 1] = f32x2{v.z, v.w};
+        }
+    }
+    bool valid = live;
+    if (FILTER && live) valid = is_valid_doc(filt, row_base + row);
+    for (int qt = q0; qt < q1; qt += PW_QT) {
+        const int nqt = min(PW_QT, q1 - qt);
+        __syncthreads();   // the previous tile has been consumed
+        for (int e = threadIdx.x; e < nqt * (D / 4); e += 256)
+            s_x[e] = reinterpret_cast<const float4*>(x + (int64_t)qt * D)[e];
+        __syncthreads();
+        for (int qi = 0; qi < nqt; qi++) {
+            const float4* xq = s_x + qi * (D / 4) + half;
+            f32x2 acc[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+#pragma unroll
+            for (int i0 = 0; i0 < D / 8; i0 += 8) {
+                // 8 reads (two distinct addresses per wave: broadcast), then 16 packed sub/fma pairs;
+                // the barrier keeps hipcc from hoisting every read of the query to the top
+                float4 xa[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) xa[u] = (i0 + u) < D / 8 ? xq[2 * (i0 + u)] : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = i0 + u;
+                    if (i < D / 8) {
+                        const f32x2 xv[2] = {f32x2{xa[u].x, xa[u].y}, f32x2{xa[u].z, xa[u].w}};
+#pragma unroll
+                        for (int l = 0; l < 2; l++) {
+                            if (L2) {
+                                const f32x2 t = xv[l] - yr[2 * i + l];
+                                acc[l] = __builtin_elementwise_fma(t, t, acc[l]);
+                            } else {
+                                acc[l] = __builtin_elementwise_fma(xv[l], yr[2 * i + l], acc[l]);
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // even thread: lanes 0..3, odd thread: lanes 4..7;  s[l] = acc[l+4] + acc[l]
+            const float s0 = __shfl_xor(acc[0].x, 1, 64) + acc[0].x;
+            const float s1 = __shfl_xor(acc[0].y, 1, 64) + acc[0].y;
+            const float s2 = __shfl_xor(acc[1].x, 1, 64) + acc[1].x;
+            const float s3 = __shfl_xor(acc[1].y, 1, 64) + acc[1].y;
+            float dis = hsum4(s0, s1, s2, s3);
+            if (FILTER) {
+                if (!valid || !(dis <= max_score && dis >= min_score)) dis = sentinel;
+            }
+            if (live && half == 0) out[(int64_t)(qt + qi) * ld_out + row] = dis;
+        }
+    }
+}
+
 // generic-d fallback: same contract, row streamed from memory per query.
 template <bool L2, bool FILTER>
 __global__ __launch_bounds__(256) void k_pairwise_generic(const float* __restrict__ x, int nq, int d,
@@ -117,9 +200,19 @@ static void launch_pairwise_t(hipStream_t s, const float* x, int nq, int d, cons
         if (q_per_block < 8) q_per_block = nq < 8 ? nq : 8;
     }
     dim3 grid((unsigned)row_blocks, (unsigned)((nq + q_per_block - 1) / q_per_block));
-#define GH_ROWREG(DD)                                                                        \
-    hipLaunchKernelGGL((k_pairwise_rowreg<L2, DD, FILTER>), grid, dim3(256), 0, s, x, nq, y, ny, \
-                       out, ld_out, q_per_block, filt, min_score, max_score, sentinel, row_base)
+    static const bool no_lds = getenv("GAMMA_HIP_NO_PAIRWISE_LDS") != nullptr;
+    // a workgroup that sees fewer than a few queries gains nothing from staging them
+    const bool use_lds = !no_lds && q_per_block >= 8;
+#define GH_ROWREG(DD)                                                                                  \
+    do {                                                                                               \
+        if (use_lds)                                                                                   \
+            hipLaunchKernelGGL((k_pairwise_lds<L2, DD, FILTER>), dim3((unsigned)((ny + 127) / 128), grid.y), \
+                               dim3(256), 0, s, x, nq, y, ny, out, ld_out, q_per_block, filt, min_score, \
+                               max_score, sentinel, row_base);                                         \
+        else                                                                                           \
+            hipLaunchKernelGGL((k_pairwise_rowreg<L2, DD, FILTER>), grid, dim3(256), 0, s, x, nq, y, ny, \
+                               out, ld_out, q_per_block, filt, min_score, max_score, sentinel, row_base); \
+    } while (0)
     switch (d) {
         case 128: GH_ROWREG(128); break;
         case 96: GH_ROWREG(96); break;

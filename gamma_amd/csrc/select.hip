@@ -926,7 +926,7 @@ static void launch_sel(hipStream_t s, const float* vals, int64_t seg_stride, con
     hipLaunchKernelGGL((k_select2<SMALLEST, NPT>), dim3(nseg), dim3(256), lds, s, vals, seg_stride, \
                        seg_len, fixed_len, K, Kpad, out_vals, out_pos, only)
     static const bool no_wave = getenv("GAMMA_HIP_NO_WAVE_SELECT") != nullptr;
-    if (K <= 64 && !no_wave && !only)
+    if (K <= 64 && max_len <= 16384 && !no_wave && !only)   // longer rows: the streaming kernel wins
         hipLaunchKernelGGL((k_select_wave<SMALLEST>), dim3((nseg + 3) / 4), dim3(256), 0, s, vals, seg_stride,
                            seg_len, fixed_len, nseg, K, out_vals, out_pos);
     else if (max_len <= 256 * 4) GH_SEL(4);
