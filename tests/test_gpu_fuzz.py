@@ -1,0 +1,85 @@
+"""Differential fuzz: random index shapes / search parameters / filters, device vs oracle.
+Fixed seeds; every configuration goes through training, the Add path and several searches."""
+import numpy as np
+import pytest
+
+from gamma_amd import api, synth, train
+from oracle import binding as B
+from tests.parity import compare_search
+
+pytestmark = pytest.mark.gpu
+WIDE = dict(min_score=-3e38, max_score=3e38)
+
+
+def _config(rng):
+    dsub = int(rng.choice([2, 4, 8, 12, 16]))
+    M = int(rng.choice([4, 8, 16, 32]))
+    d = dsub * M
+    if d > 256:
+        M = 8
+        d = dsub * M
+    nlist = int(rng.choice([8, 24, 64, 100]))
+    N = int(rng.integers(nlist * 45, nlist * 300))
+    return d, M, nlist, min(N, 26000)
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_configuration(seed):
+    rng = np.random.default_rng(1000 + seed)
+    d, M, nlist, N = _config(rng)
+    metric = B.METRIC_L2 if rng.random() < 0.6 else B.METRIC_IP
+    base = synth.sift_like(N, d=d, seed=50 + seed)
+    if metric == B.METRIC_IP:
+        base = (base / np.maximum(np.linalg.norm(base, axis=1, keepdims=True), 1e-9)).astype(np.float32)
+    cc, pq = train.train_ivfpq(base[:max(nlist * 40, 3000)], nlist, M, niter=4, pq_niter=5, seed=seed, device="cpu")
+    bucket = int(rng.choice([50, 1000]))
+    o = B.OracleIVFPQ(d, nlist, M, 8, metric, bucket_init_size=bucket)
+    o.set_trained(cc, pq, None)
+    g = api.GammaHip(0)
+    try:
+        g.ivfpq_init(d, nlist, M, 8, metric, bucket)
+        g.ivfpq_set_trained(cc, pq, None)
+        g.raw_init(d)
+        B.lib().go_set_assign_mode(1)
+        step = int(rng.choice([700, 5000]))
+        for i0 in range(0, N, step):          # Add path on both sides (device encode)
+            xb = base[i0:i0 + step]
+            g.raw_append(xb)
+            g.add(xb, i0)
+            assert o.add(xb)
+        B.lib().go_set_assign_mode(0)
+        o.set_raw(base)
+        dead = rng.choice(N, size=int(N * rng.choice([0.0, 0.05, 0.6])), replace=False)
+        bm = None
+        if len(dead):
+            bm = np.zeros((N >> 3) + 1, dtype=np.uint8)
+            np.bitwise_or.at(bm, dead >> 3, (1 << (dead & 7)).astype(np.uint8))
+            g.bitmap_upload(bm, N)
+            g.delete(dead)
+            o.set_docids_bitmap(bm)
+            o.delete(dead)
+        for nq in (1, 23, int(rng.choice([300, 700]))):
+            q = synth.sift_like(nq, d=d, seed=900 + seed)
+            if metric == B.METRIC_IP:
+                q = (q / np.maximum(np.linalg.norm(q, axis=1, keepdims=True), 1e-9)).astype(np.float32)
+            P = int(rng.choice([1, 4, min(32, nlist), min(64, nlist)]))
+            R = int(rng.choice([10, 64, 100, 200, 300]))
+            k = int(rng.choice([1, 10, 50]))
+            has_rank = bool(rng.random() < 0.6)
+            sm = B.METRIC_L2 if rng.random() < 0.7 else B.METRIC_IP      # per-request metric
+            rdocs = None
+            if rng.random() < 0.4:
+                rdocs = [rng.choice(N, size=int(N * rng.choice([0.02, 0.5])), replace=False)]
+            rf_o = [B.make_range_filter(r) for r in rdocs] if rdocs else None
+            rf_g = [api.make_range_filter(r) for r in rdocs] if rdocs else None
+            ctx = B.make_ctx(docids_bitmap=bm, range_filters=rf_o, **WIDE)
+            Do, Io, st = o.search(q, k, P, recall_num=R, has_rank=has_rank, metric=sm, ctx=ctx, coarse_mode=-1,
+                                  want_stages=True)
+            a = api.SearchArgs(metric=sm, nprobe=P, recall_num=R, has_rank=has_rank, coarse_mode=-1,
+                               range_filters=rf_g, **WIDE)
+            Dg, Ig = g.ivfpq_search(q, k, a)
+            sg = g.last_stages(nq, P, max(R, k))
+            compare_search(Do, Io, st, Dg, Ig, sg)
+    finally:
+        B.lib().go_set_assign_mode(0)
+        g.close()
