@@ -37,23 +37,28 @@ def _shard_handle(case, owner, s):
     return g
 
 
-@pytest.mark.parametrize("metric,has_rank", [(B.METRIC_L2, True), (B.METRIC_L2, False), (B.METRIC_IP, True)])
-def test_two_shards_on_one_gpu(metric, has_rank):
+@pytest.mark.parametrize("metric,has_rank,W,nq,P", [
+    (B.METRIC_L2, True, 2, 61, 8), (B.METRIC_L2, False, 2, 61, 8), (B.METRIC_IP, True, 2, 61, 8),
+    # enough queries x probes for 4 probes per scan workgroup: compacted probe lists + threshold
+    # pre-filter inside every shard
+    (B.METRIC_L2, True, 4, 603, 32), (B.METRIC_L2, False, 3, 603, 32), (B.METRIC_IP, True, 4, 603, 32),
+])
+def test_shards_on_one_gpu(metric, has_rank, W, nq, P):
     import torch
     from gamma_amd import api
     from gamma_amd import dist as gdist
     case = fixtures.trained_case(d=32, nlist=64, M=8, N=20000, nq=64, metric=B.METRIC_L2)
     sizes = np.array([case["oracle"].list_size(l) for l in range(case["nlist"])])
-    W = 2
     owner = gdist.balance_lists(sizes, W)
     full = fixtures.load_hip(case)
     shards = [_shard_handle(case, owner, s) for s in range(W)]
-    k, P, R = 10, 8, 100
-    nq = 61                                   # not a multiple of W: padded slice
+    k, R = 10, 100                            # nq is not a multiple of W: padded slices
     args = api.SearchArgs(metric=metric, nprobe=P, recall_num=R, has_rank=has_rank, min_score=-3e38,
                           max_score=3e38, coarse_mode=1)
     dev = torch.device("cuda", 0)
-    x = torch.from_numpy(case["q"][:nq]).to(dev)
+    from gamma_amd import synth
+    qh = case["q"][:nq] if nq <= len(case["q"]) else synth.sift_like(nq, d=case["d"], seed=777)
+    x = torch.from_numpy(qh).to(dev)
     Dref = torch.empty((nq, k), dtype=torch.float32, device=dev)
     Iref = torch.empty((nq, k), dtype=torch.int64, device=dev)
     full.ivfpq_search_device(x.data_ptr(), nq, k, args, Dref.data_ptr(), Iref.data_ptr())
