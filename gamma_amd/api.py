@@ -273,6 +273,9 @@ class GammaHip:
         self._ck(self.L.gamma_hip_ivfpq_merge_rerank(self.h, args.ref(), nshards, nq, d_x, k, d_all_dis,
                                                      d_all_ids, q0, nq_local, d_D, d_I), "merge_rerank")
 
+    def set_dist_budget(self, nbytes):
+        self._ck(self.L.gamma_hip_set_workspace_budget(self.h, int(nbytes)), "set_workspace_budget")
+
     # ---- numeric columns for on-device range filters ----
     _FIELD_DTYPES = {np.dtype(np.int32): 0, np.dtype(np.int64): 1, np.dtype(np.float32): 2,
                      np.dtype(np.float64): 3}

@@ -118,7 +118,7 @@ struct gamma_hip_index {
             w_cand_pos, w_cand_ids, w_exact, w_selv, w_selp, w_x, w_outd, w_outl, w_stage, w_filter,
             w_m_dis, w_m_ids, w_part_v, w_part_i, w_assign, w_codes_tmp, w_qperm, w_tau, w_scnt, w_sflag, w_surv;
     unsigned long long* d_scan_codes = nullptr;
-    size_t dist_budget_bytes = (size_t)2 << 30;
+    size_t dist_budget_bytes = (size_t)8 << 30;   // per-chunk ADC distance buffer (288 GB of HBM per GPU)
 
     // last-search stage info
     int last_nq = 0, last_P = 0, last_R = 0;
@@ -627,6 +627,11 @@ int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, c
     const int R = std::max(p->recall_num, k);
     gh::FilterDesc filt;
     GH_TRY(build_filter(h, p, &filt));
+    // faiss picks the coarse path from the size of the WHOLE call (faiss:utils/distances.cpp:346);
+    // the internal chunks must not re-decide it
+    gamma_hip_search_params pp = *p;
+    if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;
+    p = &pp;
     const int chunk = query_chunk(h, nq, p->nprobe);
     for (int q0 = 0; q0 < nq; q0 += chunk) {
         const int nc = std::min(chunk, nq - q0);
@@ -813,6 +818,13 @@ size_t field_elem_size(int dtype) {
     return dtype == GAMMA_HIP_FIELD_INT || dtype == GAMMA_HIP_FIELD_FLOAT ? 4 : 8;
 }
 }  // namespace
+
+int gamma_hip_set_workspace_budget(gamma_hip_index* h, int64_t bytes) {
+    if (!h || bytes <= 0) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    h->dist_budget_bytes = (size_t)bytes;
+    return GAMMA_HIP_OK;
+}
 
 int gamma_hip_field_append(gamma_hip_index* h, int field_id, int dtype, int64_t n, const void* values) {
     if (!h) return GAMMA_HIP_EINVAL;
@@ -1388,6 +1400,9 @@ int gamma_hip_ivfpq_search_shard(gamma_hip_index* h, const gamma_hip_search_para
     const int R = std::max(p->recall_num, k);
     gh::FilterDesc filt;
     GH_TRY(build_filter(h, p, &filt));
+    gamma_hip_search_params pp = *p;
+    if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;   // decided on the whole call, not per chunk
+    p = &pp;
     const int chunk = query_chunk(h, nq, p->nprobe);
     for (int q0 = 0; q0 < nq; q0 += chunk) {
         const int nc = std::min(chunk, nq - q0);
@@ -1410,6 +1425,9 @@ int gamma_hip_ivfpq_coarse_device(gamma_hip_index* h, const gamma_hip_search_par
     if (!d_x || !d_coarse_dis || !d_probe) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
     GH_CHECK(h, hipSetDevice(h->device));
     const int P = p->nprobe;
+    gamma_hip_search_params pp = *p;   // the caller resolves -1 on the size of the whole batch; a slice
+    if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;   // that arrives unresolved decides by itself
+    p = &pp;
     const int chunk = query_chunk(h, nq, P);
     for (int q0 = 0; q0 < nq; q0 += chunk) {
         const int nc = std::min(chunk, nq - q0);

@@ -105,6 +105,9 @@ def sharded_search(backend, x, k, args, group=None, gather_results=True):
     R = max(args.p.recall_num, k)
     q0, q1, per = query_slice(nq, rank, world)
     nql = q1 - q0
+    if args.p.coarse_mode < 0:
+        # faiss chooses the coarse path from the size of the whole batch: the slices must agree
+        args.p.coarse_mode = 0 if nq < 20 else 1
     stream_ctx = torch.cuda.stream(backend.stream) if hasattr(backend, "stream") else _Null()
     with stream_ctx:
         b = _buffers(backend, world, per, P, R, k)

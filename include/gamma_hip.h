@@ -99,6 +99,10 @@ const char* gamma_hip_last_error(gamma_hip_index* h);
 void* gamma_hip_stream(gamma_hip_index* h);
 int gamma_hip_synchronize(gamma_hip_index* h);
 
+/* Upper bound in bytes of the per-chunk workspaces (coarse distance matrix, ADC distance buffer);
+ * larger calls are processed in chunks of queries.  Default 8 GiB. */
+int gamma_hip_set_workspace_budget(gamma_hip_index* h, int64_t bytes);
+
 /* ---- numeric scalar columns for on-device range filters (docid = row).  The engine side
  *      appends a doc's value when the doc is added (Table::Add, table/table.cc) ----------- */
 int gamma_hip_field_append(gamma_hip_index* h, int field_id, int dtype, int64_t n, const void* values);

@@ -592,3 +592,19 @@ def test_field_filters_on_device(case):
         g.ivfpq_search(q, 10, api.SearchArgs(metric=api.METRIC_L2, nprobe=8, field_filters=[(99, 0, 1, True, True)],
                                              **WIDE))
     g.close()
+
+
+def test_internal_chunking_keeps_the_whole_call_semantics(case):
+    """Large calls are processed in chunks (ADC buffer budget).  faiss chooses the coarse path from the
+    size of the whole call, so a trailing chunk of < 20 queries must still take the GEMM form."""
+    g = fixtures.load_hip(case)
+    try:
+        q = synth.sift_like(45, d=case["d"], seed=31337)
+        g.set_dist_budget(case["nlist"] * 4 * 20)        # room for 20 rows of the coarse matrix: chunks of 20, 20, 5
+        (D, I, st), (Dg, Ig) = run_both(case, g, q, 10, 8, 100, B.METRIC_L2, True, coarse_mode=-1)
+        compare_topk(D, I, Dg, Ig)
+        g.set_dist_budget(8 << 30)
+        D2, I2 = g.ivfpq_search(q, 10, api.SearchArgs(metric=api.METRIC_L2, nprobe=8, recall_num=100, **WIDE))
+        assert D2.tobytes() == Dg.tobytes() and np.array_equal(I2, Ig)
+    finally:
+        g.close()
