@@ -1243,13 +1243,14 @@ int gamma_hip_ivfpq_set_list_mask(gamma_hip_index* h, const uint8_t* owned) {
 }
 
 /* ---- device-side encode / add ----------------------------------------------------------- */
-static int encode_locked(H* h, int64_t n, const float* d_vecs, int* d_assign, uint8_t* d_codes_out) {
+// exact: the arithmetic form faiss picks from the size of the WHOLE assign() call (n < 20), not of a chunk
+static int encode_locked(H* h, int64_t n, const float* d_vecs, int* d_assign, uint8_t* d_codes_out, bool exact) {
     // quantizer->assign == search with k = 1 (faiss rule for the arithmetic form)
     hipStream_t s = h->stream;
     const int d = h->d, nlist = h->nlist;
     GH_CHECK(h, h->w_mat.ensure((size_t)n * nlist * sizeof(float)));
     GH_CHECK(h, h->w_coarse_dis.ensure((size_t)n * sizeof(float)));
-    if (n < 20) {
+    if (exact) {
         gh::launch_pairwise(s, true, d_vecs, (int)n, d, h->d_cc, nlist, h->w_mat.as<float>(), nlist);
     } else {
         gh::launch_l2_gemmform(s, d_vecs, (int)n, d, h->d_cc, nlist, nullptr, h->d_cc_norms,
@@ -1276,7 +1277,7 @@ int gamma_hip_ivfpq_encode(gamma_hip_index* h, int64_t n, const float* vecs, int
         GH_CHECK(h, h->w_assign.ensure((size_t)nc * sizeof(int)));
         GH_CHECK(h, h->w_codes_tmp.ensure((size_t)nc * h->code_size));
         GH_CHECK(h, hipMemcpyAsync(h->w_x.p, vecs + i0 * h->d, (size_t)nc * h->d * sizeof(float), hipMemcpyHostToDevice, h->stream));
-        GH_TRY(encode_locked(h, nc, h->w_x.as<float>(), h->w_assign.as<int>(), h->w_codes_tmp.as<uint8_t>()));
+        GH_TRY(encode_locked(h, nc, h->w_x.as<float>(), h->w_assign.as<int>(), h->w_codes_tmp.as<uint8_t>(), n < 20));
         GH_CHECK(h, hipMemcpyAsync(assign.data(), h->w_assign.p, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         GH_CHECK(h, hipMemcpyAsync(codes + i0 * h->code_size, h->w_codes_tmp.p, (size_t)nc * h->code_size, hipMemcpyDeviceToHost, h->stream));
         GH_CHECK(h, hipStreamSynchronize(h->stream));

@@ -603,6 +603,13 @@ def test_internal_chunking_keeps_the_whole_call_semantics(case):
         g.set_dist_budget(case["nlist"] * 4 * 20)        # room for 20 rows of the coarse matrix: chunks of 20, 20, 5
         (D, I, st), (Dg, Ig) = run_both(case, g, q, 10, 8, 100, B.METRIC_L2, True, coarse_mode=-1)
         compare_topk(D, I, Dg, Ig)
+        # same for the Add path's quantizer->assign: 45 vectors in chunks of 20, 20, 5
+        xs = case["base"][100:145]
+        B.lib().go_set_assign_mode(1)
+        lo, co = case["oracle"].encode(xs)
+        B.lib().go_set_assign_mode(0)
+        lg, cg = g.encode(xs)
+        assert np.array_equal(lo, lg) and np.array_equal(co, cg)
         g.set_dist_budget(8 << 30)
         D2, I2 = g.ivfpq_search(q, 10, api.SearchArgs(metric=api.METRIC_L2, nprobe=8, recall_num=100, **WIDE))
         assert D2.tobytes() == Dg.tobytes() and np.array_equal(I2, Ig)
