@@ -615,3 +615,37 @@ def test_internal_chunking_keeps_the_whole_call_semantics(case):
         assert D2.tobytes() == Dg.tobytes() and np.array_equal(I2, Ig)
     finally:
         g.close()
+
+
+def test_list_full_at_bucket_max_size(case):
+    """A list cannot grow past bucket_max_size (RealTimeMemData::ExtendBucketIfNeed,
+    realtime/realtime_mem_data.cc:383-474): AddKeys fails at the same batch on both sides and
+    leaves the same list behind."""
+    d, nlist, M = case["d"], case["nlist"], case["M"]
+    o = B.OracleIVFPQ(d, nlist, M, 8, B.METRIC_L2, bucket_init_size=8, bucket_max_size=40)
+    o.set_trained(case["cc"], case["pq"], None)
+    g = api.GammaHip(0)
+    try:
+        g.ivfpq_init(d, nlist, M, 8, api.METRIC_L2, 8, 40)
+        g.ivfpq_set_trained(case["cc"], case["pq"], None)
+        rng = np.random.default_rng(12)
+        failed_o = failed_g = None
+        for b in range(12):
+            keys = np.arange(b * 7, b * 7 + 7, dtype=np.int64)
+            codes = rng.integers(0, 256, size=(7, M)).astype(np.uint8)
+            ok_o = o.add_keys(3, keys, codes)
+            try:
+                g.add_keys(3, keys, codes)
+                ok_g = True
+            except api.GammaHipError:
+                ok_g = False
+            assert ok_o == ok_g, b
+            if not ok_o and failed_o is None:
+                failed_o = failed_g = b
+        assert failed_o is not None and failed_o == failed_g
+        io, co = o.get_list(3)
+        ig, cg = g.get_list(3)
+        assert np.array_equal(io, ig) and np.array_equal(co, cg)
+        assert o.list_capacity(3) == g.list_capacity(3) and len(io) <= 40
+    finally:
+        g.close()
