@@ -83,3 +83,36 @@ def test_random_configuration(seed):
     finally:
         B.lib().go_set_assign_mode(0)
         g.close()
+
+
+def test_many_probes_and_large_batch():
+    """nprobe > 64 (no pre-filter, no probe compaction) at a batch size that would otherwise enable them."""
+    d, M, nlist, N = 32, 8, 128, 30000
+    base = synth.sift_like(N, d=d, seed=5)
+    cc, pq = train.train_ivfpq(base[:6000], nlist, M, niter=4, pq_niter=5, seed=2, device="cpu")
+    o = B.OracleIVFPQ(d, nlist, M, 8, B.METRIC_L2)
+    o.set_trained(cc, pq, None)
+    g = api.GammaHip(0)
+    try:
+        g.ivfpq_init(d, nlist, M, 8, api.METRIC_L2, 1000)
+        g.ivfpq_set_trained(cc, pq, None)
+        g.raw_init(d)
+        g.raw_append(base)
+        B.lib().go_set_assign_mode(1)
+        g.add(base, 0)
+        assert o.add(base)
+        B.lib().go_set_assign_mode(0)
+        o.set_raw(base)
+        q = synth.sift_like(300, d=d, seed=6)
+        for P, R, k in ((100, 150, 10), (128, 64, 64), (65, 200, 1)):
+            for has_rank in (True, False):
+                ctx = B.make_ctx(**WIDE)
+                Do, Io, st = o.search(q, k, P, recall_num=R, has_rank=has_rank, metric=B.METRIC_L2, ctx=ctx,
+                                      coarse_mode=-1, want_stages=True)
+                a = api.SearchArgs(metric=api.METRIC_L2, nprobe=P, recall_num=R, has_rank=has_rank, **WIDE)
+                Dg, Ig = g.ivfpq_search(q, k, a)
+                sg = g.last_stages(len(q), P, max(R, k))
+                compare_search(Do, Io, st, Dg, Ig, sg)
+    finally:
+        B.lib().go_set_assign_mode(0)
+        g.close()
