@@ -116,7 +116,7 @@ struct gamma_hip_index {
     // workspace
     DevBuf w_mat, w_coarse_dis, w_probe, w_xn, w_st2, w_pair_off, w_qtotal, w_dist, w_cand_dis,
             w_cand_pos, w_cand_ids, w_exact, w_selv, w_selp, w_x, w_outd, w_outl, w_stage, w_filter,
-            w_m_dis, w_m_ids, w_part_v, w_part_i, w_assign, w_codes_tmp, w_qperm, w_scnt, w_sflag, w_surv;
+            w_m_dis, w_m_ids, w_part_v, w_part_i, w_assign, w_codes_tmp, w_qperm, w_scnt, w_sflag, w_surv, w_pair_base;
     unsigned long long* d_scan_codes = nullptr;
     size_t dist_budget_bytes = (size_t)8 << 30;   // per-chunk ADC distance buffer (288 GB of HBM per GPU)
 
@@ -448,6 +448,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
     GH_CHECK(h, h->w_probe.ensure((size_t)nq * P * sizeof(int)));
     GH_CHECK(h, h->w_st2.ensure((size_t)nq * M * 256 * sizeof(float)));
     GH_CHECK(h, h->w_pair_off.ensure((size_t)nq * (P + 1) * sizeof(int)));
+    GH_CHECK(h, h->w_pair_base.ensure((size_t)nq * P * sizeof(int64_t)));
     GH_CHECK(h, h->w_qtotal.ensure((size_t)nq * sizeof(int)));
     GH_CHECK(h, h->w_cand_dis.ensure((size_t)nq * R * sizeof(float)));
     GH_CHECK(h, h->w_cand_pos.ensure((size_t)nq * R * sizeof(int)));
@@ -477,7 +478,8 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
         gh::launch_pq_ip_table(s, d_x, nq, d, M, h->d_pqc, h->w_st2.as<float>());
         gh::launch_pair_offsets(s, h->w_probe.as<int>(), nq, P, h->d_list_len, h->d_list_mask, nlist,
                                 h->w_pair_off.as<int>(), h->w_qtotal.as<int>(),
-                                h->profile ? h->d_scan_codes : nullptr);
+                                h->profile ? h->d_scan_codes : nullptr, h->d_list_off,
+                                h->w_pair_base.as<int64_t>());
         // enough queries that L2 capacity matters: run them in spatial order (kernels.hip)
         if (h->sort_queries && h->d_list_rank && nq >= 256) {
             GH_CHECK(h, h->w_qperm.ensure((size_t)2 * nq * sizeof(int)));
@@ -532,8 +534,8 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
         static int shown = 0;
         StageScope t(h, GAMMA_HIP_STAGE_SELECT);
         gh::launch_select_final(s, l2, sb.surv, sb.gcnt, nsl, cap, sb.ready, h->w_dist.as<float>(), q_stride,
-                                h->w_pair_off.as<int>(), P, G, nq, R, h->w_probe.as<int>(), h->d_list_off,
-                                h->d_ids, h->w_sflag.as<uint8_t>(), h->w_cand_dis.as<float>(),
+                                h->w_pair_off.as<int>(), P, G, nq, R, h->w_pair_base.as<int64_t>(), h->d_ids,
+                                h->w_sflag.as<uint8_t>(), h->w_cand_dis.as<float>(),
                                 h->w_cand_pos.as<int>(), h->w_cand_ids.as<int64_t>());
         gh::launch_select_topk(s, l2, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), 0,
                                (int)std::min<int64_t>(q_stride, 1 << 30), nq, R,
@@ -794,7 +796,7 @@ int gamma_hip_destroy(gamma_hip_index* h) {
                       &h->w_qtotal, &h->w_dist, &h->w_cand_dis, &h->w_cand_pos, &h->w_cand_ids,
                       &h->w_exact, &h->w_selv, &h->w_selp, &h->w_x, &h->w_outd, &h->w_outl, &h->w_stage,
                       &h->w_filter, &h->w_m_dis, &h->w_m_ids, &h->w_part_v, &h->w_part_i, &h->w_assign,
-                      &h->w_codes_tmp, &h->w_qperm, &h->w_scnt, &h->w_sflag, &h->w_surv};
+                      &h->w_codes_tmp, &h->w_qperm, &h->w_scnt, &h->w_sflag, &h->w_surv, &h->w_pair_base};
     for (DevBuf* b : bufs) b->release();
     (void)hipStreamDestroy(h->stream);
     delete h;

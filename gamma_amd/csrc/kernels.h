@@ -50,7 +50,8 @@ void launch_precompute_table(hipStream_t s, const float* cc, int nlist, int d, i
                              const float* pqc, float* out);
 void launch_pair_offsets(hipStream_t s, const int* probe_list, int nq, int P, const int* list_len,
                          const uint8_t* list_mask, int nlist, int* pair_off, int* q_total,
-                         unsigned long long* scan_codes);
+                         unsigned long long* scan_codes, const int64_t* list_off = nullptr,
+                         int64_t* pair_base = nullptr);
 void launch_compact_probes(hipStream_t s, const int* probe_in, const float* cdis_in, int nq, int P,
                            const int* list_len, const uint8_t* list_mask, int nlist, int* probe_out,
                            float* cdis_out);
@@ -84,8 +85,8 @@ void launch_select_topk(hipStream_t s, bool smallest, const float* vals, int64_t
 void launch_select_final(hipStream_t s, bool smallest, const unsigned long long* surv, const int* gcnt,
                          int nslices, int slice_cap, const unsigned long long* ready, const float* vals,
                          int64_t seg_stride, const int* pair_off, int P, int G, int nq, int K,
-                         const int* probe_list, const int64_t* list_off, const int64_t* ids, uint8_t* flag,
-                         float* out_vals, int* out_pos, int64_t* out_ids);
+                         const int64_t* pair_base, const int64_t* ids, uint8_t* flag, float* out_vals,
+                         int* out_pos, int64_t* out_ids);
 void launch_map_candidates(hipStream_t s, const int* pos, int nq, int R, int P,
                            const int* probe_list, const int* pair_off, const int64_t* list_off,
                            const int64_t* ids, int64_t* cand_ids, const uint8_t* only = nullptr);

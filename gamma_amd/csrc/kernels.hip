@@ -649,7 +649,9 @@ __global__ __launch_bounds__(256) void k_pair_offsets(const int* __restrict__ pr
                                                       const uint8_t* __restrict__ list_mask,
                                                       int nlist, int* __restrict__ pair_off,
                                                       int* __restrict__ q_total,
-                                                      unsigned long long* __restrict__ scan_codes) {
+                                                      unsigned long long* __restrict__ scan_codes,
+                                                      const int64_t* __restrict__ list_off,
+                                                      int64_t* __restrict__ pair_base) {
     // one wave per query: the scan is a wave-shuffle prefix sum, no barriers
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -658,12 +660,19 @@ __global__ __launch_bounds__(256) void k_pair_offsets(const int* __restrict__ pr
     for (int p0 = 0; p0 < P; p0 += 64) {
         const int p = p0 + lane;
         int len = 0;
+        int64_t lbase = 0;
         if (p < P) {
             const int l = probe_list[(int64_t)q * P + p];
-            if (l >= 0 && l < nlist && (!list_mask || list_mask[l])) len = list_len[l];
+            if (l >= 0 && l < nlist && (!list_mask || list_mask[l])) {
+                len = list_len[l];
+                lbase = list_off[l];
+            }
         }
         const int incl = wave_incl_scan(len);
-        if (p < P) pair_off[(int64_t)q * (P + 1) + p] = running + incl - len;
+        if (p < P) {
+            pair_off[(int64_t)q * (P + 1) + p] = running + incl - len;
+            if (pair_base) pair_base[(int64_t)q * P + p] = lbase;   // arena offset of the pair's list
+        }
         running += __shfl(incl, 63, 64);
     }
     if (lane == 0) {
@@ -726,10 +735,10 @@ __global__ __launch_bounds__(256) void k_sum_totals(const int* __restrict__ q_to
 }
 void launch_pair_offsets(hipStream_t s, const int* probe_list, int nq, int P, const int* list_len,
                          const uint8_t* list_mask, int nlist, int* pair_off, int* q_total,
-                         unsigned long long* scan_codes) {
+                         unsigned long long* scan_codes, const int64_t* list_off, int64_t* pair_base) {
     if (nq <= 0) return;
     hipLaunchKernelGGL(k_pair_offsets, dim3((nq + 3) / 4), dim3(256), 0, s, probe_list, nq, P, list_len,
-                       list_mask, nlist, pair_off, q_total, scan_codes);
+                       list_mask, nlist, pair_off, q_total, scan_codes, list_off, pair_base);
     if (scan_codes)
         hipLaunchKernelGGL(k_sum_totals, dim3(std::min(64, (nq + 255) / 256)), dim3(256), 0, s, q_total, nq,
                            scan_codes);

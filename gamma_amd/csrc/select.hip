@@ -640,7 +640,8 @@ __device__ __forceinline__ unsigned long long wave_sort64(unsigned long long x) 
 }  // namespace
 
 namespace {
-constexpr int SF_CAND = 512;   // candidates of one query held in LDS (first group within the bound + slices)
+constexpr int SF_CAND = 384;   // candidates of one query held in LDS (first group within the bound + slices);
+                               // sized so that 8 workgroups (= all 2048 of an 8192-query batch) are resident per CU
 }
 
 template <bool SMALLEST>
@@ -651,8 +652,7 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
                                                       const float* __restrict__ vals,
                                                       int64_t seg_stride, const int* __restrict__ pair_off,
                                                       int P, int G, int nq, int K,
-                                                      const int* __restrict__ probe_list,
-                                                      const int64_t* __restrict__ list_off,
+                                                      const int64_t* __restrict__ pair_base,
                                                       const int64_t* __restrict__ ids,
                                                       uint8_t* __restrict__ flag,
                                                       float* __restrict__ out_vals,
@@ -661,6 +661,7 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
     __shared__ int s_hist[4][256];
     __shared__ unsigned long long s_cand[4][SF_CAND];   // candidates, later the <= 256 kept ones (in place)
     __shared__ int s_off[4][72];
+    __shared__ int64_t s_base[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + w;
     if (q >= nq) return;
@@ -678,6 +679,8 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
     const int* goff = pair_off + (int64_t)q * (P + 1);
     int* off = s_off[w];        // this query's pair offsets (P + 1 <= 65 entries, see the launcher)
     for (int i = lane; i <= P; i += 64) off[i] = goff[i];
+    int64_t* lbase = s_base[w];   // arena offset of each probed list (k_pair_offsets): no probe_list ->
+    if (lane < P) lbase[lane] = pair_base[(int64_t)q * P + lane];   // list_off chain at the end
     const int n0 = goff[min(G, P)];
     const float* v = vals + (int64_t)q * seg_stride;
     // ---- gather the candidate set into LDS: the first probe group's distances within the bound
@@ -873,8 +876,8 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
     // Branch-free on clamped values so the four dependent load chains run side by side.
     const int nres = min(m, K);
     unsigned long long it[4];
-    int ps[4], pp[4], ll[4];
-    int64_t lo64[4], idv[4];
+    int ps[4], pp[4];
+    int64_t idv[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         it[r] = runs[min(lane + 64 * r, max(nres - 1, 0))];
@@ -888,11 +891,7 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
         pp[r] = lo;
     }
 #pragma unroll
-    for (int r = 0; r < 4; r++) ll[r] = probe_list[(int64_t)q * P + pp[r]];
-#pragma unroll
-    for (int r = 0; r < 4; r++) lo64[r] = list_off[max(ll[r], 0)];
-#pragma unroll
-    for (int r = 0; r < 4; r++) idv[r] = ids[lo64[r] + (ps[r] - off[pp[r]])];
+    for (int r = 0; r < 4; r++) idv[r] = ids[lbase[pp[r]] + (ps[r] - off[pp[r]])];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int rank = lane + 64 * r;
@@ -952,17 +951,17 @@ void launch_select_topk(hipStream_t s, bool smallest, const float* vals, int64_t
 void launch_select_final(hipStream_t s, bool smallest, const unsigned long long* surv, const int* gcnt,
                          int nslices, int slice_cap, const unsigned long long* ready, const float* vals,
                          int64_t seg_stride, const int* pair_off, int P, int G, int nq, int K,
-                         const int* probe_list, const int64_t* list_off, const int64_t* ids, uint8_t* flag,
-                         float* out_vals, int* out_pos, int64_t* out_ids) {
+                         const int64_t* pair_base, const int64_t* ids, uint8_t* flag, float* out_vals,
+                         int* out_pos, int64_t* out_ids) {
     if (nq <= 0) return;
     if (smallest)
         hipLaunchKernelGGL((k_select_final<true>), dim3((nq + 3) / 4), dim3(256), 0, s, surv, gcnt, nslices,
-                           slice_cap, ready, vals, seg_stride, pair_off, P, G, nq, K, probe_list, list_off, ids,
-                           flag, out_vals, out_pos, out_ids);
+                           slice_cap, ready, vals, seg_stride, pair_off, P, G, nq, K, pair_base, ids, flag,
+                           out_vals, out_pos, out_ids);
     else
         hipLaunchKernelGGL((k_select_final<false>), dim3((nq + 3) / 4), dim3(256), 0, s, surv, gcnt, nslices,
-                           slice_cap, ready, vals, seg_stride, pair_off, P, G, nq, K, probe_list, list_off, ids,
-                           flag, out_vals, out_pos, out_ids);
+                           slice_cap, ready, vals, seg_stride, pair_off, P, G, nq, K, pair_base, ids, flag,
+                           out_vals, out_pos, out_ids);
 }
 
 }  // namespace gh
