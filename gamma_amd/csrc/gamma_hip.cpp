@@ -473,9 +473,39 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
     const int need_ids =
             (filt.has_range || filt.n_field > 0 || (filt.del_bitmap && h->bitmap_any) || h->n_moved > 0) ? 1 : 0;
     const int* qperm = nullptr;
+    // Probes per workgroup.  Sharded search with a compacted assignment: a query keeps ~P/W probes on
+    // this shard, all in its first group(s) -- the other P/G - 1 workgroups of the query would start only
+    // to find nothing to do (at W = 8 that was half of the scan time).  When the expected candidate
+    // count per query is small, ONE workgroup takes all of a query's probes (G = P): it bounds the
+    // R-th best itself (producer path of the pre-filter, no consumers), and computes the query's PQ
+    // table on the fly instead of reading it back from HBM (IPF, kernels.hip).
+    int G0 = 4;
+    const bool compacted = shard && pre_dis && pre_probe && P <= 64;
+    if (compacted && h->scan_bound && R <= 256) {
+        int64_t owned = 0;
+        for (int l = 0; l < nlist; l++)
+            owned += h->h_list_len[l] > 0 && (h->h_list_mask.empty() || h->h_list_mask[l]);
+        const double exp_probes = (double)P * (double)owned / std::max(1, nlist);
+        const double exp_cand = exp_probes * (owned ? (double)h->ntotal / (double)owned : 0.0);
+        if (exp_cand <= 16384.0) {
+            G0 = 1;
+            while (G0 < P) G0 <<= 1;
+        }
+    }
+    const int G = gh::scan_group_size(nq, P, G0), PGN = (P + G - 1) / G;
+    // Threshold pre-filter: scan the nearest probe group first, bound each query's R-th best
+    // distance from it, and let the scan of the remaining groups keep a short survivor list per
+    // query; the exact top-R then comes from a few hundred survivors instead of ~10^4 candidates
+    // (select.hip).  Queries without a usable bound fall back to the unfiltered selection.
+    // (sharded without a supplied assignment: probe groups are sparse, nothing to bound from)
+    // small batches: one probe per workgroup, a single list rarely holds R candidates, and the
+    // unfiltered selection is latency-bound anyway
+    const bool bounded = (!shard || compacted) && h->scan_bound && R <= 256 && P <= 64 && G >= 4 &&
+                         (PGN >= 2 || compacted);
+    const bool fuse_ip = bounded && PGN == 1 && (M == 16 || M == 32) && !getenv("GAMMA_HIP_NO_FUSED_IP");
     {
         StageScope t(h, GAMMA_HIP_STAGE_TABLES);
-        gh::launch_pq_ip_table(s, d_x, nq, d, M, h->d_pqc, h->w_st2.as<float>());
+        if (!fuse_ip) gh::launch_pq_ip_table(s, d_x, nq, d, M, h->d_pqc, h->w_st2.as<float>());
         gh::launch_pair_offsets(s, h->w_probe.as<int>(), nq, P, h->d_list_len, h->d_list_mask, nlist,
                                 h->w_pair_off.as<int>(), h->w_qtotal.as<int>(),
                                 h->profile ? h->d_scan_codes : nullptr, h->d_list_off,
@@ -491,24 +521,15 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
     // per-query slab of the distance buffer; multiple of 4 floats so rows are 16-byte aligned
     const int64_t q_stride = (std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len)) + 3) & ~(int64_t)3;
     GH_CHECK(h, h->w_dist.ensure((size_t)nq * q_stride * sizeof(float)));
-    const int G = gh::scan_group_size(nq, P), PGN = (P + G - 1) / G;
     auto scan = [&](int gsz, int pg_lo, int pg_cnt, const gh::ScanBound* bound, bool count) {
         StageScope t(h, GAMMA_HIP_STAGE_SCAN, count);
         gh::launch_ivfpq_scan_pair(s, l2, d_x, nq, d, M, P, h->w_probe.as<int>(),
                                    h->w_coarse_dis.as<float>(), h->d_cc, h->w_st2.as<float>(), h->d_T2,
                                    h->d_list_off, h->d_list_len, h->d_list_mask, nlist, h->d_codes,
                                    h->d_ids, h->w_pair_off.as<int>(), q_stride, h->w_dist.as<float>(),
-                                   filt, need_ids, qperm, gsz, pg_lo, pg_cnt, shard ? 1 : 0, bound);
+                                   filt, need_ids, qperm, gsz, pg_lo, pg_cnt, shard ? 1 : 0, bound,
+                                   fuse_ip ? h->d_pqc : nullptr);
     };
-    // Threshold pre-filter: scan the nearest probe group first, bound each query's R-th best
-    // distance from it, and let the scan of the remaining groups keep a short survivor list per
-    // query; the exact top-R then comes from a few hundred survivors instead of ~10^4 candidates
-    // (select.hip).  Queries without a usable bound fall back to the unfiltered selection.
-    // (sharded without a supplied assignment: probe groups are sparse, nothing to bound from)
-    // small batches: one probe per workgroup, a single list rarely holds R candidates, and the
-    // unfiltered selection is latency-bound anyway
-    const bool bounded = (!shard || (pre_probe && P <= 64)) && h->scan_bound && R <= 256 && PGN >= 2 && P <= 64 &&
-                         G >= 4;
     if (!bounded) {
         scan(G, 0, PGN, nullptr, true);
         StageScope t(h, GAMMA_HIP_STAGE_SELECT);
@@ -1482,20 +1503,28 @@ int gamma_hip_ivfpq_merge_rerank(gamma_hip_index* h, const gamma_hip_search_para
     const int R = std::max(p->recall_num, k);
     if ((int64_t)nshards * R > (int64_t)1 << 24) return fail(h, GAMMA_HIP_EINVAL, "too many candidates");
     hipStream_t s = h->stream;
-    GH_CHECK(h, h->w_m_dis.ensure((size_t)nq * nshards * R * sizeof(float)));
-    GH_CHECK(h, h->w_m_ids.ensure((size_t)nq * nshards * R * sizeof(int64_t)));
     GH_CHECK(h, h->w_cand_dis.ensure((size_t)nq_local * R * sizeof(float)));
-    GH_CHECK(h, h->w_cand_pos.ensure((size_t)nq_local * R * sizeof(int)));
     GH_CHECK(h, h->w_cand_ids.ensure((size_t)nq_local * R * sizeof(int64_t)));
     {
         StageScope t(h, GAMMA_HIP_STAGE_SELECT);
-        gh::launch_gather_shards(s, d_all_dis, d_all_ids, nshards, nq, R, h->w_m_dis.as<float>(),
-                                 h->w_m_ids.as<int64_t>(), l2 ? INFINITY : -INFINITY);
-        const int64_t stride = (int64_t)nshards * R;
-        gh::launch_select_topk(s, l2, h->w_m_dis.as<float>() + (size_t)q0 * stride, stride, nullptr,
-                               (int)stride, (int)stride, nq_local, R, h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>());
-        gh::launch_take_ids(s, h->w_cand_pos.as<int>(), h->w_m_ids.as<int64_t>() + (size_t)q0 * stride, stride,
-                            nq_local, R, h->w_cand_ids.as<int64_t>());
+        static const bool no_merge_kernel = getenv("GAMMA_HIP_NO_MERGE_KERNEL") != nullptr;
+        if (no_merge_kernel ||
+            !gh::launch_merge_shards(s, l2, d_all_dis, d_all_ids, nshards, nq, R, q0, nq_local,
+                                     h->w_cand_dis.as<float>(), h->w_cand_ids.as<int64_t>())) {
+            // general shapes: transpose to [nq][W * R], select, translate positions to ids
+            GH_CHECK(h, h->w_m_dis.ensure((size_t)nq * nshards * R * sizeof(float)));
+            GH_CHECK(h, h->w_m_ids.ensure((size_t)nq * nshards * R * sizeof(int64_t)));
+            GH_CHECK(h, h->w_cand_pos.ensure((size_t)nq_local * R * sizeof(int)));
+            gh::launch_gather_shards(s, d_all_dis, d_all_ids, nshards, nq, R, h->w_m_dis.as<float>(),
+                                     h->w_m_ids.as<int64_t>(), l2 ? INFINITY : -INFINITY);
+            const int64_t stride = (int64_t)nshards * R;
+            gh::launch_select_topk(s, l2, h->w_m_dis.as<float>() + (size_t)q0 * stride, stride, nullptr,
+                                   (int)stride, (int)stride, nq_local, R, h->w_cand_dis.as<float>(),
+                                   h->w_cand_pos.as<int>());
+            gh::launch_take_ids(s, h->w_cand_pos.as<int>(), h->w_m_ids.as<int64_t>() + (size_t)q0 * stride, stride,
+                                nq_local, R, h->w_cand_ids.as<int64_t>());
+        }
+        GH_CHECK(h, hipGetLastError());
     }
     return ivfpq_stage_b(h, p, nq_local, d_x + (size_t)q0 * h->d, R, k, h->w_cand_dis.as<float>(),
                          h->w_cand_ids.as<int64_t>(), d_distances, d_labels);

@@ -65,14 +65,15 @@ struct ScanBound {
     int K;                      // recall_num
 };
 int scan_slice_cap();
-int scan_group_size(int nq, int P);
+int scan_group_size(int nq, int P, int G0 = 4);   // G0: probes per workgroup to start from (power of two)
 void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int d, int M, int P,
                             const int* probe_list, const float* coarse_dis, const float* cc,
                             const float* st2, const float* T2, const int64_t* list_off,
                             const int* list_len, const uint8_t* list_mask, int nlist,
                             const uint8_t* codes, const int64_t* ids, const int* pair_off,
                             int64_t q_stride, float* out, const FilterDesc& filt, int need_ids,
-                            const int* qperm, int G, int pg_lo, int pg_cnt, int sparse, const ScanBound* bound);
+                            const int* qperm, int G, int pg_lo, int pg_cnt, int sparse, const ScanBound* bound,
+                            const float* pqc_fused = nullptr);   // != nullptr: query table computed in the kernel
 void launch_query_order(hipStream_t s, const int* probe_list, int nq, int P, const int* list_rank,
                         int nlist, int* qkey, int* qperm);
 void launch_sum_totals(hipStream_t s, const int* q_total, int nq, unsigned long long* acc);
@@ -104,6 +105,10 @@ void launch_finalize_norank(hipStream_t s, const float* cand_dis, const int64_t*
                             float* distances, int64_t* labels);
 void launch_gather_shards(hipStream_t s, const float* all_dis, const int64_t* all_ids, int nshards,
                           int nq, int R, float* dis, int64_t* ids, float sentinel);
+// one-kernel merge of the shard tables [W][nq][R] for queries [q0, q0 + nql) -> [nql][R]; false = shape
+// not covered (R > 256 or W * R > 2048), use launch_gather_shards + launch_select_topk + launch_take_ids
+bool launch_merge_shards(hipStream_t s, bool smallest, const float* all_dis, const int64_t* all_ids, int W,
+                         int nq, int R, int q0, int nql, float* out_dis, int64_t* out_ids);
 void launch_take_ids(hipStream_t s, const int* pos, const int64_t* src_ids, int64_t src_stride,
                      int nq, int R, int64_t* out);
 void launch_bitmap_set(hipStream_t s, uint8_t* bm, const int64_t* docids, int64_t n, int64_t nbits,

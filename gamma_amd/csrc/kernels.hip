@@ -853,7 +853,11 @@ constexpr int SCAN_BATCH = 64;                   // queries per XCD by which pro
 
 // amdgpu_num_sgpr(96): 8 waves per SIMD need <= 96 SGPRs each (800 per SIMD); the FILT variant
 // would otherwise take 100 and lose one of the eight resident workgroups per CU
-template <bool L2, int MT, bool FILT>
+// IPF (sharded search with every probe of a query in ONE workgroup): the query's table <x_q,m , c_mj> is
+// computed here from the PQ codebook (128 KB, L2 resident; `st2` then points at it) instead of being
+// written to HBM by k_pq_ip_table and read back -- with W shards that table is W x 16 KB per query of
+// traffic that does not shrink with the shard, and each of its entries would be read exactly once.
+template <bool L2, int MT, bool FILT, bool IPF = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_ivfpq_scan_pair(
         const float* __restrict__ x, int nq, int d, int M, int P, int G, const int* __restrict__ probe_list,
         const float* __restrict__ coarse_dis, const float* __restrict__ cc,
@@ -976,7 +980,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
     }
     const float* st2q = st2 + (int64_t)q * msz;
     float s2r[MT > 0 ? MT : 1];
-    if (MT > 0) {
+    if (IPF && MT > 0) {
+        // same arithmetic as k_pq_ip_table: one fvec_inner_products_ny row per (m, code word)
+        const int dsub = d / M;
+        const float* xq = x + (int64_t)q * d;
+#pragma unroll
+        for (int i = 0; i < MT; i++) s2r[i] = fvec_ny_row<false>(xq + i * dsub, st2 + ((int64_t)i * 256 + tid) * dsub, dsub);
+    } else if (MT > 0) {
 #pragma unroll
         for (int i = 0; i < MT; i++) s2r[i] = st2q[tid + 256 * i];
     }
@@ -1230,10 +1240,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
 
 int scan_slice_cap() { return SCAN_SLICE; }
 
-int scan_group_size(int nq, int P) {
+int scan_group_size(int nq, int P, int G0) {
     // probes per workgroup: amortise the query table, but keep >= ~4096 workgroups in flight
     static const int g_env = getenv("GAMMA_HIP_SCAN_G") ? atoi(getenv("GAMMA_HIP_SCAN_G")) : 0;
-    int G = g_env > 0 ? g_env : 4;
+    int G = g_env > 0 ? g_env : G0;
     while (G > 1 && (int64_t)nq * ((P + G - 1) / G) < 4096) G >>= 1;
     return std::max(1, std::min(G, P));
 }
@@ -1244,8 +1254,13 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
                             const int* list_len, const uint8_t* list_mask, int nlist,
                             const uint8_t* codes, const int64_t* ids, const int* pair_off,
                             int64_t q_stride, float* out, const FilterDesc& filt, int need_ids,
-                            const int* qperm, int G, int pg_lo, int pg_cnt, int sparse, const ScanBound* bound) {
+                            const int* qperm, int G, int pg_lo, int pg_cnt, int sparse, const ScanBound* bound,
+                            const float* pqc_fused) {
     if (nq <= 0 || pg_cnt <= 0) return;
+    if (pqc_fused) {   // the table is computed inside the kernel (IPF): one workgroup per query, M 16 / 32
+        if (!bound || pg_cnt != 1 || (M != 16 && M != 32)) abort();
+        st2 = pqc_fused;
+    }
     const size_t lds = (size_t)M * 256 * sizeof(float);
     dim3 grid((unsigned)(8 * (int64_t)((nq + 7) / 8) * pg_cnt));
     if (bound) {   // P(0) | P(t+1) C(t) ...: whole batches, see the kernel
@@ -1255,7 +1270,9 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
     ScanBound sb = {nullptr, nullptr, nullptr, 0};
     if (bound) sb = *bound;
 #define GH_SCAN(LL, MT, FF)                                                                       \
-    hipLaunchKernelGGL((k_ivfpq_scan_pair<LL, MT, FF>), grid, dim3(256), lds, s, x, nq, d, M, P, G,     \
+    GH_SCAN4(LL, MT, FF, false)
+#define GH_SCAN4(LL, MT, FF, II)                                                                       \
+    hipLaunchKernelGGL((k_ivfpq_scan_pair<LL, MT, FF, II>), grid, dim3(256), lds, s, x, nq, d, M, P, G,     \
                        probe_list, coarse_dis, cc, st2, T2, list_off, list_len, list_mask, nlist, codes, \
                        ids, pair_off, q_stride, out, filt, need_ids, LL ? INFINITY : -INFINITY, qperm,   \
                        pg_lo, pg_cnt, sparse, sb)
@@ -1265,7 +1282,12 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
         else if (M == 32) GH_SCAN(LL, 32, FF);  \
         else GH_SCAN(LL, 0, FF);                \
     } while (0)
-    if (bound) {
+    if (pqc_fused) {
+        if (l2 && M == 16) GH_SCAN4(true, 16, true, true);
+        else if (l2) GH_SCAN4(true, 32, true, true);
+        else if (M == 16) GH_SCAN4(false, 16, true, true);
+        else GH_SCAN4(false, 32, true, true);
+    } else if (bound) {
         if (l2) GH_SCAN_M(true, true);
         else GH_SCAN_M(false, true);
     } else {
@@ -1274,6 +1296,7 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
     }
 #undef GH_SCAN_M
 #undef GH_SCAN
+#undef GH_SCAN4
 }
 
 // ------------------------------------------------------------------------------------

@@ -909,6 +909,179 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Merge of the per-shard candidate tables (list-sharded search, gamma_hip_ivfpq_merge_rerank):
+// all_dis / all_ids [W][nq][R] -> the K = R best of each query's W*R candidates, ordered by
+// (distance, shard, rank inside the shard) -- what selecting from the gathered [nq][W*R] row gives.
+// One wave per query, the row's keys live in registers (NPL per lane):
+//   1. K-th smallest key by bisection on the key value (count = compare + popcount, no memory)
+//   2. keys below it, and the first few equal to it in index order, are compacted into LDS (<= 256)
+//   3. four 64-item bitonic sorts in registers + rank merge (as k_select_final)
+// Nothing is assumed about the order inside a shard's row.  Entries with id < 0 (padding: a shard
+// with fewer than R candidates) or a sentinel distance are invalid and come out as (sentinel, -1).
+// ------------------------------------------------------------------------------------
+template <bool SMALLEST, int NPL>
+__global__ __launch_bounds__(256) void k_merge_shards(const float* __restrict__ all_dis,
+                                                      const int64_t* __restrict__ all_ids, int W, int nq,
+                                                      int R, int q0, int nql, float* __restrict__ out_dis,
+                                                      int64_t* __restrict__ out_ids) {
+    __shared__ unsigned long long s_run[4][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + w;
+    if (q >= nql) return;
+    constexpr uint32_t KEYSENT = 0xff800000u;   // key of +inf (SMALLEST) / -inf (largest)
+    const int n = W * R, K = R;
+    const int64_t row = (int64_t)(q0 + q) * R, blk = (int64_t)nq * R;
+    // element e = j * 64 + lane sits at shard e / R, rank e % R: walked incrementally
+    const int q64 = 64 / R, m64 = 64 % R;
+    uint32_t key[NPL];
+    {
+        float dv[NPL];
+        int32_t iv[NPL];   // sign word of the id (little endian): all that is needed here
+        const int32_t* idw = reinterpret_cast<const int32_t*>(all_ids);
+        int sh = lane / R, r = lane % R;
+#pragma unroll
+        for (int j = 0; j < NPL; j++) {
+            const bool in = j * 64 + lane < n;
+            const int64_t at = in ? (int64_t)sh * blk + row + r : row;
+            dv[j] = all_dis[at];
+            iv[j] = idw[2 * at + 1];
+            sh += q64;
+            r += m64;
+            if (r >= R) {
+                r -= R;
+                sh++;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NPL; j++) {
+            const bool in = j * 64 + lane < n;
+            uint32_t kk = sel_key<SMALLEST>(dv[j]);
+            if (iv[j] < 0 || kk > KEYSENT) kk = KEYSENT;
+            key[j] = in ? kk : 0xffffffffu;
+        }
+    }
+    const int Kq = min(K, n);
+    // smallest v with #(key <= v) >= Kq
+    uint32_t lo = 0u, hi = KEYSENT;   // every real key is <= KEYSENT and there are n >= Kq of them
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < NPL; j++) c += key[j] <= mid ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+        if (c >= Kq) hi = mid;
+        else lo = mid + 1u;
+    }
+    const uint32_t vstar = lo;
+    int below = 0;
+#pragma unroll
+    for (int j = 0; j < NPL; j++) below += key[j] < vstar ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) below += __shfl_xor(below, off, 64);
+    const int need_eq = Kq - below;   // >= 1
+    unsigned long long* runs = s_run[w];
+    int m = 0, eq_seen = 0;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+        const bool is_eq = key[j] == vstar;
+        const unsigned long long eqb = __ballot(is_eq);
+        const bool take = key[j] < vstar || (is_eq && eq_seen + __popcll(eqb & lt_mask) < need_eq);
+        const unsigned long long tb = __ballot(take);
+        if (take) runs[m + __popcll(tb & lt_mask)] = ((unsigned long long)key[j] << 32) | (unsigned)(j * 64 + lane);
+        m += __popcll(tb);
+        eq_seen += __popcll(eqb);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // m == Kq <= 256 items: four sorted runs of 64, then rank merge
+    unsigned long long x[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) x[r] = (r * 64 + lane < m) ? runs[r * 64 + lane] : ~0ull;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; r++) x[r] = wave_sort64(x[r]);
+#pragma unroll
+    for (int r = 0; r < 4; r++) runs[r * 64 + lane] = x[r];
+    __builtin_amdgcn_wave_barrier();
+    int rk[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        int rank = lane;
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            if (o == r) continue;
+            const unsigned long long* ro = runs + o * 64;
+            int lo2 = 0, n2 = 64;
+#pragma unroll
+            for (int st = 0; st < 7; st++) {
+                if (n2 > 0) {
+                    const int half = n2 >> 1;
+                    if (ro[lo2 + half] < x[r]) {
+                        lo2 += half + 1;
+                        n2 -= half + 1;
+                    } else {
+                        n2 = half;
+                    }
+                }
+            }
+            rank += lo2;
+        }
+        rk[r] = rank;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        if (x[r] != ~0ull && rk[r] < 256) runs[rk[r]] = x[r];
+    __builtin_amdgcn_wave_barrier();
+    const float sentinel = SMALLEST ? INFINITY : -INFINITY;
+    unsigned long long it[4];
+    int64_t idv[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        it[r] = runs[min(lane + 64 * r, max(m - 1, 0))];
+        const int e = (int)(uint32_t)it[r];
+        const int sh = e / R;
+        idv[r] = all_ids[(int64_t)sh * blk + row + (e - sh * R)];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int rank = lane + 64 * r;
+        if (rank < m) {
+            const uint32_t kk = (uint32_t)(it[r] >> 32);
+            const bool valid = kk < KEYSENT && idv[r] >= 0;
+            out_dis[(int64_t)q * K + rank] = valid ? key2f(SMALLEST ? kk : ~kk) : sentinel;
+            out_ids[(int64_t)q * K + rank] = valid ? idv[r] : -1;
+        }
+    }
+    for (int r = m + lane; r < K; r += 64) {
+        out_dis[(int64_t)q * K + r] = sentinel;
+        out_ids[(int64_t)q * K + r] = -1;
+    }
+}
+
+bool launch_merge_shards(hipStream_t s, bool smallest, const float* all_dis, const int64_t* all_ids, int W,
+                         int nq, int R, int q0, int nql, float* out_dis, int64_t* out_ids) {
+    const int64_t n = (int64_t)W * R;
+    if (R > 256 || n > 64 * 32 || nql <= 0) return false;
+    const dim3 grid((nql + 3) / 4), block(256);
+#define GH_MERGE(SM, NPL)                                                                                \
+    hipLaunchKernelGGL((k_merge_shards<SM, NPL>), grid, block, 0, s, all_dis, all_ids, W, nq, R, q0, nql, \
+                       out_dis, out_ids)
+#define GH_MERGE_N(SM)                         \
+    do {                                       \
+        if (n <= 64 * 8) GH_MERGE(SM, 8);      \
+        else if (n <= 64 * 16) GH_MERGE(SM, 16); \
+        else GH_MERGE(SM, 32);                 \
+    } while (0)
+    if (smallest) GH_MERGE_N(true);
+    else GH_MERGE_N(false);
+#undef GH_MERGE_N
+#undef GH_MERGE
+    return true;
+}
+
 int select_kpad(int K) {
     int p = 2;
     while (p < K) p <<= 1;

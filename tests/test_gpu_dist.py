@@ -37,17 +37,22 @@ def _shard_handle(case, owner, s):
     return g
 
 
-@pytest.mark.parametrize("metric,has_rank,W,nq,P", [
-    (B.METRIC_L2, True, 2, 61, 8), (B.METRIC_L2, False, 2, 61, 8), (B.METRIC_IP, True, 2, 61, 8),
+@pytest.mark.parametrize("metric,has_rank,W,nq,P,d,M", [
+    (B.METRIC_L2, True, 2, 61, 8, 32, 8), (B.METRIC_L2, False, 2, 61, 8, 32, 8), (B.METRIC_IP, True, 2, 61, 8, 32, 8),
     # enough queries x probes for 4 probes per scan workgroup: compacted probe lists + threshold
     # pre-filter inside every shard
-    (B.METRIC_L2, True, 4, 603, 32), (B.METRIC_L2, False, 3, 603, 32), (B.METRIC_IP, True, 4, 603, 32),
+    (B.METRIC_L2, True, 4, 603, 32, 32, 8), (B.METRIC_L2, False, 3, 603, 32, 32, 8),
+    (B.METRIC_IP, True, 4, 603, 32, 32, 8),
+    # enough queries that ONE workgroup takes all of a query's probes on the shard (bound from its own
+    # candidates, no consumers); with M = 16 / 32 the query table is computed inside the scan
+    (B.METRIC_L2, True, 4, 4200, 32, 64, 16), (B.METRIC_IP, True, 3, 4200, 32, 64, 16),
+    (B.METRIC_L2, False, 4, 4200, 32, 64, 32), (B.METRIC_L2, True, 2, 4200, 16, 32, 8),
 ])
-def test_shards_on_one_gpu(metric, has_rank, W, nq, P):
+def test_shards_on_one_gpu(metric, has_rank, W, nq, P, d, M):
     import torch
     from gamma_amd import api
     from gamma_amd import dist as gdist
-    case = fixtures.trained_case(d=32, nlist=64, M=8, N=20000, nq=64, metric=B.METRIC_L2)
+    case = fixtures.trained_case(d=d, nlist=64, M=M, N=20000, nq=64, metric=B.METRIC_L2)
     sizes = np.array([case["oracle"].list_size(l) for l in range(case["nlist"])])
     owner = gdist.balance_lists(sizes, W)
     full = fixtures.load_hip(case)
@@ -101,3 +106,51 @@ def test_sharded_search_over_rccl_world1():
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "rank 0 ok" in r.stdout
+
+
+@pytest.mark.parametrize("metric,W,R,nql", [
+    (B.METRIC_L2, 8, 200, 37), (B.METRIC_IP, 7, 100, 64), (B.METRIC_L2, 2, 256, 5), (B.METRIC_L2, 3, 33, 129),
+    (B.METRIC_L2, 16, 200, 9),       # W * R > 2048: the general gather + select path
+])
+def test_merge_of_shard_tables(metric, W, R, nql):
+    """gamma_hip_ivfpq_merge_rerank without re-rank and k = R returns the merged table itself: the R best
+    of W*R in (distance, shard, rank) order; rows unsorted, with ties, padding and rows of padding only."""
+    import torch
+    from gamma_amd import api
+    case = fixtures.trained_case(d=32, nlist=64, M=8, N=20000, nq=64, metric=B.METRIC_L2)
+    g = fixtures.load_hip(case)
+    rng = np.random.default_rng(W * 1000 + R)
+    nq, q0 = nql + 11, 7                       # a slice inside a longer batch
+    l2 = metric == B.METRIC_L2
+    dis = rng.standard_normal((W, nq, R)).astype(np.float32)
+    dis = (np.round(dis * 8) / 8 + 0.0).astype(np.float32) if R > 100 else dis   # many exact ties (+ 0.0: no -0.0, which
+                                                                                 # the device key orders before +0.0)
+    ids = rng.integers(0, 1 << 40, size=(W, nq, R)).astype(np.int64)
+    pad = rng.random((W, nq, R)) < 0.15
+    pad[:, q0 + 1] = True                      # a query nobody has candidates for
+    pad[0, q0 + 2] = True
+    ids[pad] = -1
+    dev = torch.device("cuda", 0)
+    d_dis, d_ids = torch.from_numpy(dis).to(dev), torch.from_numpy(ids).to(dev)
+    x = torch.zeros((nq, case["d"]), dtype=torch.float32, device=dev)
+    D = torch.empty((nql, R), dtype=torch.float32, device=dev)
+    I = torch.empty((nql, R), dtype=torch.int64, device=dev)
+    args = api.SearchArgs(metric=metric, nprobe=8, recall_num=R, has_rank=False, min_score=-3e38, max_score=3e38)
+    g.ivfpq_merge_rerank(W, nq, x.data_ptr(), R, args, d_dis.data_ptr(), d_ids.data_ptr(), q0, nql, D.data_ptr(),
+                         I.data_ptr())
+    g.synchronize()
+    D, I = D.cpu().numpy(), I.cpu().numpy()
+    for i in range(nql):
+        q = q0 + i
+        dv = dis[:, q].reshape(-1)
+        iv = ids[:, q].reshape(-1)
+        e = np.arange(W * R)
+        ok = iv >= 0
+        order = np.lexsort((e[ok], dv[ok] if l2 else -dv[ok]))[:R]
+        want_i = iv[ok][order]
+        want_d = dv[ok][order]
+        m = len(order)
+        assert np.array_equal(I[i, :m], want_i), (i, m)
+        assert np.array_equal(D[i, :m], want_d)
+        assert np.all(I[i, m:] == -1)
+    g.close()
