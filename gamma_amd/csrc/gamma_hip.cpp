@@ -440,19 +440,26 @@ int ivfpq_coarse(H* h, const gamma_hip_search_params* p, int nq, const float* d_
 // query slice), device pointers [nq*nprobe]; nullptr = run the coarse quantizer here
 int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& filt, int nq,
                   const float* d_x, int R, const float* pre_dis = nullptr, const int* pre_probe = nullptr,
-                  bool shard = false) {
+                  bool shard = false, float* out_dis = nullptr, int64_t* out_ids = nullptr) {
     const int P = p->nprobe, d = h->d, M = h->M, nlist = h->nlist;
     const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
     hipStream_t s = h->stream;
     GH_CHECK(h, h->w_coarse_dis.ensure((size_t)nq * P * sizeof(float)));
     GH_CHECK(h, h->w_probe.ensure((size_t)nq * P * sizeof(int)));
-    GH_CHECK(h, h->w_st2.ensure((size_t)nq * M * 256 * sizeof(float)));
     GH_CHECK(h, h->w_pair_off.ensure((size_t)nq * (P + 1) * sizeof(int)));
     GH_CHECK(h, h->w_pair_base.ensure((size_t)nq * P * sizeof(int64_t)));
     GH_CHECK(h, h->w_qtotal.ensure((size_t)nq * sizeof(int)));
-    GH_CHECK(h, h->w_cand_dis.ensure((size_t)nq * R * sizeof(float)));
     GH_CHECK(h, h->w_cand_pos.ensure((size_t)nq * R * sizeof(int)));
-    GH_CHECK(h, h->w_cand_ids.ensure((size_t)nq * R * sizeof(int64_t)));
+    // the top-R table goes to the workspace (stage B reads it there) or straight into the caller's
+    // buffers (sharded search: 12 B x R per query would otherwise be copied once more)
+    if (!out_dis) {
+        GH_CHECK(h, h->w_cand_dis.ensure((size_t)nq * R * sizeof(float)));
+        out_dis = h->w_cand_dis.as<float>();
+    }
+    if (!out_ids) {
+        GH_CHECK(h, h->w_cand_ids.ensure((size_t)nq * R * sizeof(int64_t)));
+        out_ids = h->w_cand_ids.as<int64_t>();
+    }
     if (pre_dis && pre_probe) {
         if (shard && P <= 64) {
             // dense probe groups for the owned lists (kernels.hip, k_compact_probes)
@@ -480,11 +487,13 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
     // R-th best itself (producer path of the pre-filter, no consumers), and computes the query's PQ
     // table on the fly instead of reading it back from HBM (IPF, kernels.hip).
     int G0 = 4;
+    int64_t t2_bytes = (int64_t)nlist * M * 256 * sizeof(float);
     const bool compacted = shard && pre_dis && pre_probe && P <= 64;
     if (compacted && h->scan_bound && R <= 256) {
         int64_t owned = 0;
         for (int l = 0; l < nlist; l++)
             owned += h->h_list_len[l] > 0 && (h->h_list_mask.empty() || h->h_list_mask[l]);
+        t2_bytes = owned * M * 256 * (int64_t)sizeof(float);
         const double exp_probes = (double)P * (double)owned / std::max(1, nlist);
         const double exp_cand = exp_probes * (owned ? (double)h->ntotal / (double)owned : 0.0);
         if (exp_cand <= 16384.0) {
@@ -505,13 +514,17 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
     const bool fuse_ip = bounded && PGN == 1 && (M == 16 || M == 32) && !getenv("GAMMA_HIP_NO_FUSED_IP");
     {
         StageScope t(h, GAMMA_HIP_STAGE_TABLES);
-        if (!fuse_ip) gh::launch_pq_ip_table(s, d_x, nq, d, M, h->d_pqc, h->w_st2.as<float>());
+        if (!fuse_ip) {
+            GH_CHECK(h, h->w_st2.ensure((size_t)nq * M * 256 * sizeof(float)));
+            gh::launch_pq_ip_table(s, d_x, nq, d, M, h->d_pqc, h->w_st2.as<float>());
+        }
         gh::launch_pair_offsets(s, h->w_probe.as<int>(), nq, P, h->d_list_len, h->d_list_mask, nlist,
                                 h->w_pair_off.as<int>(), h->w_qtotal.as<int>(),
                                 h->profile ? h->d_scan_codes : nullptr, h->d_list_off,
                                 h->w_pair_base.as<int64_t>());
         // enough queries that L2 capacity matters: run them in spatial order (kernels.hip)
-        if (h->sort_queries && h->d_list_rank && nq >= 256) {
+        // (not when the T2 rows of the lists scanned here fit the L2s anyway: a shard of a small index)
+        if (h->sort_queries && h->d_list_rank && nq >= 256 && t2_bytes > ((int64_t)8 << 20)) {
             GH_CHECK(h, h->w_qperm.ensure((size_t)2 * nq * sizeof(int)));
             gh::launch_query_order(s, h->w_probe.as<int>(), nq, P, h->d_list_rank, nlist,
                                    h->w_qperm.as<int>() + nq, h->w_qperm.as<int>());
@@ -535,10 +548,10 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
         StageScope t(h, GAMMA_HIP_STAGE_SELECT);
         gh::launch_select_topk(s, l2, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), 0,
                                (int)std::min<int64_t>(q_stride, 1 << 30), nq, R,
-                               h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>());
+                               out_dis, h->w_cand_pos.as<int>());
         gh::launch_map_candidates(s, h->w_cand_pos.as<int>(), nq, R, P, h->w_probe.as<int>(),
                                   h->w_pair_off.as<int>(), h->d_list_off, h->d_ids,
-                                  h->w_cand_ids.as<int64_t>());
+                                  out_ids);
     } else {
         const int cap = gh::scan_slice_cap(), nsl = PGN - 1;
         GH_CHECK(h, h->w_scnt.ensure((size_t)nq * (sizeof(unsigned long long) + (size_t)nsl * sizeof(int))));   // ready[nq] | gcnt[nq][nsl]
@@ -556,11 +569,11 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
         StageScope t(h, GAMMA_HIP_STAGE_SELECT);
         gh::launch_select_final(s, l2, sb.surv, sb.gcnt, nsl, cap, sb.ready, h->w_dist.as<float>(), q_stride,
                                 h->w_pair_off.as<int>(), P, G, nq, R, h->w_pair_base.as<int64_t>(), h->d_ids,
-                                h->w_sflag.as<uint8_t>(), h->w_cand_dis.as<float>(),
-                                h->w_cand_pos.as<int>(), h->w_cand_ids.as<int64_t>());
+                                h->w_sflag.as<uint8_t>(), out_dis,
+                                h->w_cand_pos.as<int>(), out_ids);
         gh::launch_select_topk(s, l2, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), 0,
                                (int)std::min<int64_t>(q_stride, 1 << 30), nq, R,
-                               h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>(), h->w_sflag.as<uint8_t>());
+                               out_dis, h->w_cand_pos.as<int>(), h->w_sflag.as<uint8_t>());
         if (dbg && shown++ >= 8 && shown <= 13) {
             std::vector<uint8_t> hf(nq);
             std::vector<int> hc((size_t)nq * nsl);
@@ -584,7 +597,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
         }
         gh::launch_map_candidates(s, h->w_cand_pos.as<int>(), nq, R, P, h->w_probe.as<int>(),
                                   h->w_pair_off.as<int>(), h->d_list_off, h->d_ids,
-                                  h->w_cand_ids.as<int64_t>(), h->w_sflag.as<uint8_t>());
+                                  out_ids, h->w_sflag.as<uint8_t>());
     }
     GH_CHECK(h, hipGetLastError());
     return GAMMA_HIP_OK;
@@ -1420,6 +1433,7 @@ int gamma_hip_ivfpq_search_shard(gamma_hip_index* h, const gamma_hip_search_para
     std::lock_guard<std::mutex> g(h->mu);
     GH_TRY(ivfpq_check(h, p, nq, k));
     if (k <= 0 || nq == 0) return GAMMA_HIP_OK;
+    if (!d_x || !d_recall_dis || !d_recall_ids) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
     GH_CHECK(h, hipSetDevice(h->device));
     const int R = std::max(p->recall_num, k);
     gh::FilterDesc filt;
@@ -1430,9 +1444,8 @@ int gamma_hip_ivfpq_search_shard(gamma_hip_index* h, const gamma_hip_search_para
     const int chunk = query_chunk(h, nq, p->nprobe);
     for (int q0 = 0; q0 < nq; q0 += chunk) {
         const int nc = std::min(chunk, nq - q0);
-        GH_TRY(ivfpq_stage_a(h, p, filt, nc, d_x + (size_t)q0 * h->d, R, nullptr, nullptr, /*shard=*/true));
-        GH_CHECK(h, hipMemcpyAsync(d_recall_dis + (size_t)q0 * R, h->w_cand_dis.p, (size_t)nc * R * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-        GH_CHECK(h, hipMemcpyAsync(d_recall_ids + (size_t)q0 * R, h->w_cand_ids.p, (size_t)nc * R * sizeof(int64_t), hipMemcpyDeviceToDevice, h->stream));
+        GH_TRY(ivfpq_stage_a(h, p, filt, nc, d_x + (size_t)q0 * h->d, R, nullptr, nullptr, /*shard=*/true,
+                             d_recall_dis + (size_t)q0 * R, d_recall_ids + (size_t)q0 * R));
         h->last_nq = nc;
     }
     h->last_P = p->nprobe;
@@ -1472,6 +1485,7 @@ int gamma_hip_ivfpq_search_shard_preassigned(gamma_hip_index* h, const gamma_hip
     GH_TRY(ivfpq_check(h, p, nq, k));
     if (k <= 0 || nq == 0) return GAMMA_HIP_OK;
     if (!d_coarse_dis || !d_probe) return fail(h, GAMMA_HIP_EINVAL, "null coarse assignment");
+    if (!d_x || !d_recall_dis || !d_recall_ids) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
     GH_CHECK(h, hipSetDevice(h->device));
     const int R = std::max(p->recall_num, k), P = p->nprobe;
     gh::FilterDesc filt;
@@ -1480,9 +1494,8 @@ int gamma_hip_ivfpq_search_shard_preassigned(gamma_hip_index* h, const gamma_hip
     for (int q0 = 0; q0 < nq; q0 += chunk) {
         const int nc = std::min(chunk, nq - q0);
         GH_TRY(ivfpq_stage_a(h, p, filt, nc, d_x + (size_t)q0 * h->d, R, d_coarse_dis + (size_t)q0 * P,
-                             d_probe + (size_t)q0 * P, /*shard=*/true));
-        GH_CHECK(h, hipMemcpyAsync(d_recall_dis + (size_t)q0 * R, h->w_cand_dis.p, (size_t)nc * R * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-        GH_CHECK(h, hipMemcpyAsync(d_recall_ids + (size_t)q0 * R, h->w_cand_ids.p, (size_t)nc * R * sizeof(int64_t), hipMemcpyDeviceToDevice, h->stream));
+                             d_probe + (size_t)q0 * P, /*shard=*/true, d_recall_dis + (size_t)q0 * R,
+                             d_recall_ids + (size_t)q0 * R));
         h->last_nq = nc;
     }
     h->last_P = P;
