@@ -165,10 +165,12 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(a.warmup + i)
+    t_enq = time.perf_counter() - t0     # host time to enqueue the steps (log only)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    log("[rank %d] host enqueue %.3f ms/step of %.3f ms/step" % (rank, t_enq / a.steps * 1e3, dt / a.steps * 1e3))
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

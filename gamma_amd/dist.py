@@ -16,11 +16,16 @@ runs in four steps:
      runs compute_dis (re-rank / truncate)                           (gamma_hip_ivfpq_merge_rerank)
      followed by a small all-gather of the [nq/W, k] results.
 
+Large batches run as two interleaved sub-batches with every collective asynchronous, so the
+all-to-all of one overlaps the scan / merge of the other (sharded_search).
+
 The global top-recall_num of the union equals the single-GPU top-recall_num (same ADC
 distances, disjoint lists), so results are identical to one GPU up to the order inside exact
 ties.  The orchestration is backend-agnostic so the world_size-2 gloo test on CPU exercises
 the same code with an oracle-based backend (tests/test_dist_cpu.py).
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -75,73 +80,138 @@ class HipShardBackend:
                                       all_ids.data_ptr(), 0, nql, D.data_ptr(), I.data_ptr())
 
 
-def _buffers(backend, world, per, P, R, k):
+MIN_SUB = 2048   # queries per rank and sub-batch below which a batch is not split for overlap
+
+
+def _buffers(backend, world, pers, P, R, k):
     """Exchange buffers, allocated once per shape and kept on the backend (a search step enqueues
-    ~25 kernels and 6 collectives: per-step allocations would leave the GPU waiting for the host)."""
+    ~25 kernels and 3 collectives per sub-batch: per-step allocations would leave the GPU waiting
+    for the host).  One set per sub-batch; the gathered results of all sub-batches share one
+    [rows, k] table.  What travels together is packed: (coarse distance | list) of the assignment
+    and (labels | distances) of the result are halves of ONE gathered buffer each."""
     cache = backend.__dict__.setdefault("_xbuf", {})
-    key = (world, per, P, R, k)
+    key = (world, tuple(pers), P, R, k)
     b = cache.get(key)
     if b is None:
-        f32, i32, i64 = torch.float32, torch.int32, torch.int64
-        b = dict(cdis_l=backend.empty((per, P), f32), probe_l=backend.empty((per, P), i32),
-                 cdis=backend.empty((world * per, P), f32), probe=backend.empty((world * per, P), i32),
-                 rdis=backend.empty((world * per, R), f32), rids=backend.empty((world * per, R), i64),
-                 all_dis=backend.empty((world * per, R), f32), all_ids=backend.empty((world * per, R), i64),
-                 D=backend.empty((per, k), f32), I=backend.empty((per, k), i64),
-                 Dall=backend.empty((world * per, k), f32), Iall=backend.empty((world * per, k), i64))
+        f32, i32, i64, u8 = torch.float32, torch.int32, torch.int64, torch.uint8
+        rows = world * sum(pers)
+        b = dict(Dall=backend.empty((rows, k), f32), Iall=backend.empty((rows, k), i64), sub=[])
+        for per in pers:
+            cp_l = backend.empty((2, per, P), i32)
+            nres = per * k
+            res_bytes = (nres * 12 + 7) // 8 * 8          # labels (8 B) first: both halves stay aligned
+            res_l = backend.empty((res_bytes,), u8)
+            b["sub"].append(dict(
+                cp_l=cp_l, cdis_l=cp_l[0].view(f32), probe_l=cp_l[1],
+                cp=backend.empty((world, 2, per, P), i32),
+                cdis=backend.empty((world * per, P), f32), probe=backend.empty((world * per, P), i32),
+                rdis=backend.empty((world * per, R), f32), rids=backend.empty((world * per, R), i64),
+                all_dis=backend.empty((world * per, R), f32), all_ids=backend.empty((world * per, R), i64),
+                res_l=res_l, I=res_l[:nres * 8].view(i64).view(per, k),
+                D=res_l[nres * 8:nres * 12].view(f32).view(per, k),
+                res=backend.empty((world, res_bytes), u8)))
         cache.clear()          # one shape at a time
         cache[key] = b
     return b
 
 
-def sharded_search(backend, x, k, args, group=None, gather_results=True):
+def _exchange(rdis, rids, all_dis, all_ids, group):
+    """The all-to-all of the path: block r of (rdis, rids) goes to rank r, block s of (all_dis, all_ids)
+    comes from shard s.  Two plain all-to-alls, issued back to back on the communication stream."""
+    return [dist.all_to_all_single(all_dis, rdis, group=group, async_op=True),
+            dist.all_to_all_single(all_ids, rids, group=group, async_op=True)]
+
+
+def plan_sub_batches(nq, world, nsub):
+    """[(first query, end query)] of the contiguous sub-batches.  All but the last hold a multiple of
+    `world` queries, so their gathered result rows carry no padding and the whole result stays one
+    contiguous [nq, k] table."""
+    nsub = max(1, min(nsub, nq // max(1, world)))
+    bounds = [0]
+    for j in range(nsub - 1):
+        left = nq - bounds[-1]
+        size = -(-left // (nsub - j))
+        size = -(-size // world) * world
+        bounds.append(min(nq, bounds[-1] + size))
+    bounds.append(nq)
+    return [(bounds[j], bounds[j + 1]) for j in range(len(bounds) - 1) if bounds[j + 1] > bounds[j] or j == 0]
+
+
+def sharded_search(backend, x, k, args, group=None, pipeline=None):
     """x: [nq, d] tensor on the backend's device (same on every rank).  Returns (D, I) for all nq
-    queries on every rank when gather_results, else this rank's slice.  The returned tensors are
-    views of buffers that the next call with the same shape overwrites."""
+    queries on every rank.  The returned tensors are views of buffers that the next call with the
+    same shape overwrites.
+
+    A large batch is cut into two sub-batches whose steps are interleaved, every collective issued
+    asynchronously: the all-to-all of one sub-batch (the only exchange whose volume matters,
+    nq*R*12 bytes) runs over xGMI while the other sub-batch is being scanned or merged.
+    `pipeline` overrides the number of sub-batches."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     nq = x.shape[0]
     P = args.p.nprobe
     R = max(args.p.recall_num, k)
-    q0, q1, per = query_slice(nq, rank, world)
-    nql = q1 - q0
     if args.p.coarse_mode < 0:
-        # faiss chooses the coarse path from the size of the whole batch: the slices must agree
+        # faiss chooses the coarse path from the size of the whole batch: slices and sub-batches must agree
         args.p.coarse_mode = 0 if nq < 20 else 1
+    nsub = pipeline or int(os.environ.get("GAMMA_DIST_PIPELINE", "0")) or (2 if world > 1 and nq >= 2 * world * MIN_SUB else 1)
+    plan = plan_sub_batches(nq, world, nsub)
+    pers = [max(1, -(-(e - s) // world)) for s, e in plan]
     stream_ctx = torch.cuda.stream(backend.stream) if hasattr(backend, "stream") else _Null()
     with stream_ctx:
-        b = _buffers(backend, world, per, P, R, k)
+        bufs = _buffers(backend, world, pers, P, R, k)
+        Dall, Iall = bufs["Dall"], bufs["Iall"]
+        subs = []
+        row = 0
+        for (s0, s1), per, b in zip(plan, pers, bufs["sub"]):
+            n = s1 - s0
+            q0, q1, _ = query_slice(n, rank, world)
+            subs.append(dict(x=x[s0:s1], n=n, per=per, q0=q0, q1=q1, nql=q1 - q0, b=b, row=row))
+            row += world * per
         # 0. coarse quantizer on the own slice, assignment all-gathered (rows padded to W*per)
-        cdis_l, probe_l = b["cdis_l"], b["probe_l"]
-        if nql < per:            # padding rows: no valid list
-            cdis_l.zero_()
-            probe_l.fill_(-1)
-        backend.coarse(x[q0:q1], args, cdis_l, probe_l)
-        cdis, probe = b["cdis"], b["probe"]
-        dist.all_gather_into_tensor(cdis, cdis_l, group=group)
-        dist.all_gather_into_tensor(probe, probe_l, group=group)
-        # 1. local top-R of every query over the owned lists, laid out [dest rank][per][R]
-        rdis, rids = b["rdis"], b["rids"]
-        if nq < world * per:     # padding rows carry no candidates
-            rdis[nq:].zero_()
-            rids[nq:].fill_(-1)
-        backend.search_shard(x, cdis[:nq], probe[:nq], k, args, rdis[:nq], rids[:nq])
+        for sb in subs:
+            b, per, nql = sb["b"], sb["per"], sb["nql"]
+            cdis_l, probe_l = b["cdis_l"], b["probe_l"]
+            if nql < per:            # padding rows: no valid list
+                cdis_l.zero_()
+                probe_l.fill_(-1)
+            backend.coarse(sb["x"][sb["q0"]:sb["q1"]], args, cdis_l, probe_l)
+            sb["w"] = [dist.all_gather_into_tensor(b["cp"].view(-1), b["cp_l"].view(-1), group=group, async_op=True)]
+        # 1. local top-R of every query over the owned lists, laid out [dest rank][per][R];
         # 2. all-to-all: block r of rdis goes to rank r; block s of all_dis came from shard s
-        all_dis, all_ids = b["all_dis"], b["all_ids"]
-        dist.all_to_all_single(all_dis, rdis, group=group)
-        dist.all_to_all_single(all_ids, rids, group=group)
-        # 3. merge + compute_dis for the own slice
-        D, I = b["D"], b["I"]
-        if nql < per:
-            D.zero_()
-            I.fill_(-1)
-        backend.merge_rerank(all_dis.view(world, per, R), all_ids.view(world, per, R), x[q0:q1], k, args,
-                             nql, D, I)
-        if not gather_results:
-            return D[:nql], I[:nql]
-        Dall, Iall = b["Dall"], b["Iall"]
-        dist.all_gather_into_tensor(Dall, D, group=group)
-        dist.all_gather_into_tensor(Iall, I, group=group)
+        for sb in subs:
+            b, per, n = sb["b"], sb["per"], sb["n"]
+            for w in sb["w"]:
+                w.wait()
+            # unpack [W][2][per][P] into the two contiguous [W*per, P] tables the shard search reads
+            b["cdis"].view(world, per, P).copy_(b["cp"][:, 0].view(torch.float32))
+            b["probe"].view(world, per, P).copy_(b["cp"][:, 1])
+            rdis, rids = b["rdis"], b["rids"]
+            if n < world * per:     # padding rows carry no candidates
+                rdis[n:].zero_()
+                rids[n:].fill_(-1)
+            backend.search_shard(sb["x"], b["cdis"][:n], b["probe"][:n], k, args, rdis[:n], rids[:n])
+            sb["w"] = _exchange(rdis, rids, b["all_dis"], b["all_ids"], group)
+        # 3. merge + compute_dis for the own slice, results all-gathered into the common table
+        pending = []
+        for sb in subs:
+            b, per, nql = sb["b"], sb["per"], sb["nql"]
+            for w in sb["w"]:
+                w.wait()
+            D, I = b["D"], b["I"]
+            if nql < per:
+                D.zero_()
+                I.fill_(-1)
+            backend.merge_rerank(b["all_dis"].view(world, per, R), b["all_ids"].view(world, per, R),
+                                 sb["x"][sb["q0"]:sb["q1"]], k, args, nql, D, I)
+            pending.append((sb, dist.all_gather_into_tensor(b["res"].view(-1), b["res_l"], group=group, async_op=True)))
+        for sb, w in pending:
+            w.wait()
+            b, per = sb["b"], sb["per"]
+            rows = slice(sb["row"], sb["row"] + world * per)
+            nres = per * k
+            Iall[rows].view(world, per, k).copy_(b["res"][:, :nres * 8].view(torch.int64).view(world, per, k))
+            Dall[rows].view(world, per, k).copy_(b["res"][:, nres * 8:nres * 12].view(torch.float32).view(world, per, k))
     return Dall[:nq], Iall[:nq]
 
 

@@ -47,14 +47,15 @@ def main():
     args = api.SearchArgs(metric=api.METRIC_L2, nprobe=P, recall_num=R, has_rank=True, min_score=-3e38,
                           max_score=3e38, coarse_mode=1)
     x = torch.from_numpy(case["q"][:nq]).to(dev)
-    for _ in range(2):      # second call reuses workspaces
-        D, I = gdist.sharded_search(be, x, k, args)
-    torch.cuda.synchronize()
     Dref = torch.empty((nq, k), dtype=torch.float32, device=dev)
     Iref = torch.empty((nq, k), dtype=torch.int64, device=dev)
     full.ivfpq_search_device(x.data_ptr(), nq, k, args, Dref.data_ptr(), Iref.data_ptr())
     full.synchronize()
-    compare_topk(Dref.cpu().numpy(), Iref.cpu().numpy(), D.cpu().numpy(), I.cpu().numpy())
+    # single pass (twice: the second call reuses workspaces), then 2 and 3 interleaved sub-batches
+    for pipeline in (None, None, 2, 3, 2):
+        D, I = gdist.sharded_search(be, x, k, args, pipeline=pipeline)
+        torch.cuda.synchronize()
+        compare_topk(Dref.cpu().numpy(), Iref.cpu().numpy(), D.cpu().numpy(), I.cpu().numpy())
     dist.destroy_process_group()
     print("rank %d ok" % rank)
 

@@ -89,11 +89,14 @@ def main():
     args = api.SearchArgs(metric=api.METRIC_L2, nprobe=nprobe, recall_num=R, has_rank=True,
                           min_score=-3e38, max_score=3e38, coarse_mode=0)
     x = torch.from_numpy(case["q"])
-    D, I = gdist.sharded_search(be, x, k, args)
     ctx = B.make_ctx(min_score=-3e38, max_score=3e38)
     Dr, Ir = case["oracle"].search(case["q"], k, nprobe, recall_num=R, has_rank=True,
                                    metric=B.METRIC_L2, ctx=ctx, coarse_mode=0)
-    compare_topk(Dr, Ir, D.numpy(), I.numpy())
+    # two and three interleaved sub-batches (asynchronous collectives, padded last slices), then the
+    # plain single pass
+    for pipeline in (2, 3, None):
+        D, I = gdist.sharded_search(be, x, k, args, pipeline=pipeline)
+        compare_topk(Dr, Ir, D.numpy(), I.numpy())
     # every rank holds the full, identical result
     gathered = [torch.empty_like(I) for _ in range(world)]
     dist.all_gather(gathered, I)
