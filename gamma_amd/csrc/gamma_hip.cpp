@@ -116,7 +116,8 @@ struct gamma_hip_index {
     // workspace
     DevBuf w_mat, w_coarse_dis, w_probe, w_xn, w_st2, w_pair_off, w_qtotal, w_dist, w_cand_dis,
             w_cand_pos, w_cand_ids, w_exact, w_selv, w_selp, w_x, w_outd, w_outl, w_stage, w_filter,
-            w_m_dis, w_m_ids, w_part_v, w_part_i, w_assign, w_codes_tmp, w_qperm, w_scnt, w_sflag, w_surv, w_pair_base;
+            w_m_dis, w_m_ids, w_part_v, w_part_i, w_assign, w_codes_tmp, w_qperm, w_scnt, w_sflag, w_surv, w_pair_base,
+            w_pair_ip;
     unsigned long long* d_scan_codes = nullptr;
     size_t dist_budget_bytes = (size_t)8 << 30;   // per-chunk ADC distance buffer (288 GB of HBM per GPU)
 
@@ -534,10 +535,18 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
     // per-query slab of the distance buffer; multiple of 4 floats so rows are 16-byte aligned
     const int64_t q_stride = (std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len)) + 3) & ~(int64_t)3;
     GH_CHECK(h, h->w_dist.ensure((size_t)nq * q_stride * sizeof(float)));
+    // dis0 of every (query, probe) pair: the coarse distance (L2) or <x_q, centroid> (inner product)
+    const float* dis0 = h->w_coarse_dis.as<float>();
+    if (!l2) {
+        StageScope t(h, GAMMA_HIP_STAGE_TABLES, false);
+        GH_CHECK(h, h->w_pair_ip.ensure((size_t)nq * P * sizeof(float)));
+        gh::launch_pair_ip(s, d_x, h->d_cc, h->w_probe.as<int>(), nq, P, d, nlist, h->w_pair_ip.as<float>());
+        dis0 = h->w_pair_ip.as<float>();
+    }
     auto scan = [&](int gsz, int pg_lo, int pg_cnt, const gh::ScanBound* bound, bool count) {
         StageScope t(h, GAMMA_HIP_STAGE_SCAN, count);
         gh::launch_ivfpq_scan_pair(s, l2, d_x, nq, d, M, P, h->w_probe.as<int>(),
-                                   h->w_coarse_dis.as<float>(), h->d_cc, h->w_st2.as<float>(), h->d_T2,
+                                   dis0, h->d_cc, h->w_st2.as<float>(), h->d_T2,
                                    h->d_list_off, h->d_list_len, h->d_list_mask, nlist, h->d_codes,
                                    h->d_ids, h->w_pair_off.as<int>(), q_stride, h->w_dist.as<float>(),
                                    filt, need_ids, qperm, gsz, pg_lo, pg_cnt, shard ? 1 : 0, bound,
@@ -830,7 +839,8 @@ int gamma_hip_destroy(gamma_hip_index* h) {
                       &h->w_qtotal, &h->w_dist, &h->w_cand_dis, &h->w_cand_pos, &h->w_cand_ids,
                       &h->w_exact, &h->w_selv, &h->w_selp, &h->w_x, &h->w_outd, &h->w_outl, &h->w_stage,
                       &h->w_filter, &h->w_m_dis, &h->w_m_ids, &h->w_part_v, &h->w_part_i, &h->w_assign,
-                      &h->w_codes_tmp, &h->w_qperm, &h->w_scnt, &h->w_sflag, &h->w_surv, &h->w_pair_base};
+                      &h->w_codes_tmp, &h->w_qperm, &h->w_scnt, &h->w_sflag, &h->w_surv, &h->w_pair_base,
+                      &h->w_pair_ip};
     for (DevBuf* b : bufs) b->release();
     (void)hipStreamDestroy(h->stream);
     delete h;

@@ -55,6 +55,10 @@ void launch_pair_offsets(hipStream_t s, const int* probe_list, int nq, int P, co
 void launch_compact_probes(hipStream_t s, const int* probe_in, const float* cdis_in, int nq, int P,
                            const int* list_len, const uint8_t* list_mask, int nlist, int* probe_out,
                            float* cdis_out);
+// inner-product scan: dis0[q][p] = <x_q, centroid of probe p> (fvec_inner_product order); the scan takes it
+// through its coarse_dis argument
+void launch_pair_ip(hipStream_t s, const float* x, const float* cc, const int* probe_list, int nq, int P, int d,
+                    int nlist, float* out);
 // threshold pre-filter of the scan (kernels.hip, k_ivfpq_scan_pair<.., FILT>)
 struct ScanBound {
     unsigned long long* ready;  // [nq] 0 = not yet published; (1 << 32 | key bound) = bound valid;

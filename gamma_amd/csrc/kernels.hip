@@ -829,6 +829,60 @@ void launch_query_order(hipStream_t s, const int* probe_list, int nq, int P, con
 }
 
 // ------------------------------------------------------------------------------------
+// dis0 of the inner-product scan: <x_q, centroid_l> for every (query, probe) pair, in
+// fvec_inner_product order (gamma_index_ivfpq.h:216-230; device_math.h fvec_dist<false>): eight
+// threads per pair play the eight AVX lanes, each a k-ascending fma chain over its elements,
+// then s[j] = acc[j+4] + acc[j], the 4-lane and masked tails, (s0+s1)+(s2+s3).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pair_ip(const float* __restrict__ x, const float* __restrict__ cc,
+                                                 const int* __restrict__ probe_list, int64_t npairs, int P,
+                                                 int d, int nlist, float* __restrict__ out) {
+    const int64_t pair = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int l8 = threadIdx.x & 7, l4 = l8 & 3;
+    if (pair >= npairs) return;   // groups of 8 lanes leave together
+    const int l = probe_list[pair];
+    float res = 0.f;
+    if (l >= 0 && l < nlist) {    // uniform inside the group
+        const float* xq = x + (pair / P) * d;
+        const float* c = cc + (int64_t)l * d;
+        const int nblk = d >> 3;
+        float a = 0.f;
+        int b = 0;
+        for (; b + 8 <= nblk; b += 8) {   // 16 loads in flight, then the chain
+            float xv[8], cv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                xv[u] = xq[(b + u) * 8 + l8];
+                cv[u] = c[(b + u) * 8 + l8];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) a = __builtin_fmaf(xv[u], cv[u], a);
+        }
+        for (; b < nblk; b++) a = __builtin_fmaf(xq[b * 8 + l8], c[b * 8 + l8], a);
+        const int base = (threadIdx.x & 63) & ~7;
+        float sv = __shfl(a, base + l4 + 4, 64) + __shfl(a, base + l4, 64);   // s[l4], on lanes l4 and l4 + 4
+        int i0 = nblk * 8, rem = d - i0;
+        if (rem >= 4) {
+            sv = __builtin_fmaf(xq[i0 + l4], c[i0 + l4], sv);
+            i0 += 4;
+            rem -= 4;
+        }
+        if (l4 < rem) sv = __builtin_fmaf(xq[i0 + l4], c[i0 + l4], sv);   // rem <= 3
+        const float s0 = __shfl(sv, base, 64), s1 = __shfl(sv, base + 1, 64), s2 = __shfl(sv, base + 2, 64),
+                    s3 = __shfl(sv, base + 3, 64);
+        res = hsum4(s0, s1, s2, s3);
+    }
+    if (l8 == 0) out[pair] = res;
+}
+void launch_pair_ip(hipStream_t s, const float* x, const float* cc, const int* probe_list, int nq, int P, int d,
+                    int nlist, float* out) {
+    const int64_t npairs = (int64_t)nq * P;
+    if (npairs <= 0) return;
+    hipLaunchKernelGGL(k_pair_ip, dim3((unsigned)((npairs + 31) / 32)), dim3(256), 0, s, x, cc, probe_list, npairs,
+                       P, d, nlist, out);
+}
+
+// ------------------------------------------------------------------------------------
 // a4+a5+a6+a8: IVFPQ list scan, one workgroup per (query, probe) pair.
 //   LUT (M x 256 fp32) built in LDS:  L2: lut = T2[list] + (-2) * st2[q]  (fvec_madd)
 //                                     IP: lut = st2[q]
@@ -879,7 +933,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
     // read ONCE into registers (MT per thread) and reused for the G list-specific LUTs, so
     // the per-pair table traffic drops from 2 x M KB to (1 + 1/G) x M KB.
     extern __shared__ float s_lut[];  // M*256
-    __shared__ float s_acc[8];
     // XCD-aware placement (speed only): block b runs on XCD b % 8 with its own L2, so all PGN
     // workgroups of one query are given block ids with the same residue -- the query's table
     // st2[q] is then fetched from HBM/MALL once per XCD and served from that L2 afterwards.
@@ -1024,6 +1077,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
             bound_on = tauq < KEY_SENTINEL;   // otherwise the query takes the unfiltered selection
         }
     }
+    if (!L2) __syncthreads();   // the LUT (written once per query) is complete; L2 rebuilds it per list
     for (int p = p_begin; p < p_end; p++) {
         const int pair = q * P + p;
         const int l = probe_list[pair];
@@ -1035,7 +1089,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
         const uint8_t* lc = codes + off * M;
         // the first 256 codes are requested BEFORE the T2 row: both latencies overlap, and lists of
         // up to 256 codes (most of them) never wait for their codes after the LUT is ready
-        constexpr bool PRE = MT == 16 || MT == 32;
+        constexpr bool PRE = MT == 16 || MT == 32 || MT == 64;
         // (issued as inline asm: hipcc sinks an ordinary load down to its first use, behind both
         // barriers; the matching s_waitcnt is placed by hand where the codes are consumed)
         u32x4 cfirst[PRE ? MT / 16 : 1];
@@ -1047,8 +1101,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(cfirst[u]) : "v"(a) : "memory");
             }
         }
-        __syncthreads();   // the previous list's gathers (and s_acc reads) are finished
         if (L2) {
+            __syncthreads();   // the previous list's gathers are finished
             const float* t2 = T2 + (int64_t)l * msz;
             if (MT > 0) {
                 float tv[MT > 0 ? MT : 1];
@@ -1059,40 +1113,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
             } else {
                 for (int e = tid; e < msz; e += 256) s_lut[e] = __builtin_fmaf(-2.0f, st2q[e], t2[e]);
             }
-        } else if (tid < 8) {
-            // dis0 = fvec_inner_product(x_q, centroid_l): 8 lane accumulators by 8 threads
-            const float* xq = x + (int64_t)q * d;
-            const float* c = cc + (int64_t)l * d;
-            float a = 0.f;
-            for (int i = tid; i + (7 - tid) < d; i += 8) a = __builtin_fmaf(xq[i], c[i], a);
-            s_acc[tid] = a;
+            __syncthreads();
         }
-        __syncthreads();
-        float dis0;
-        if (L2) {
-            dis0 = coarse_dis[pair];
-        } else {
-            const float* xq = x + (int64_t)q * d;
-            const float* c = cc + (int64_t)l * d;
-            float s0 = s_acc[4] + s_acc[0], s1 = s_acc[5] + s_acc[1], s2 = s_acc[6] + s_acc[2],
-                  s3 = s_acc[7] + s_acc[3];
-            int i = d & ~7, rem = d & 7;
-            if (rem >= 4) {
-                s0 = __builtin_fmaf(xq[i], c[i], s0);
-                s1 = __builtin_fmaf(xq[i + 1], c[i + 1], s1);
-                s2 = __builtin_fmaf(xq[i + 2], c[i + 2], s2);
-                s3 = __builtin_fmaf(xq[i + 3], c[i + 3], s3);
-                i += 4;
-                rem -= 4;
-            }
-            if (rem > 0) s0 = __builtin_fmaf(xq[i], c[i], s0);
-            if (rem > 1) s1 = __builtin_fmaf(xq[i + 1], c[i + 1], s1);
-            if (rem > 2) s2 = __builtin_fmaf(xq[i + 2], c[i + 2], s2);
-            dis0 = hsum4(s0, s1, s2, s3);
-        }
+        // L2: the coarse distance; IP: <x_q, centroid_l>, computed per pair by k_pair_ip (a chain of d/8
+        // dependent fmas per AVX lane has no place inside this loop)
+        const float dis0 = coarse_dis[pair];
         const int64_t* lid = ids + off;
         const int pbase = pair_off[(int64_t)q * (P + 1) + p];
         float* o = out + (int64_t)q * q_stride + pbase;
+        // store + what the pre-filter tracks about a scored code
+        auto finish = [&](int j, bool ok, float dis) -> uint32_t {
+            const float val = ok ? dis : sentinel;
+            o[j] = val;
+            uint32_t key = 0xffffffffu;
+            if (FILT) {
+                key = dis_key<L2>(val);
+                if (pg == 0 && key < KEY_SENTINEL) {
+                    g_mn = key < g_mn ? key : g_mn;
+                    g_mx = key > g_mx ? key : g_mx;
+                    g_nv++;
+                }
+            }
+            return key;
+        };
         // one code: validity, ADC (gathers issued together, adds in reference order), store
         auto do_code = [&](int j, const uint32_t* cw) -> uint32_t {
             // ids are read only when something can reject an entry (delete bit, range filter,
@@ -1115,18 +1158,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
                 const uint8_t* cj = lc + (int64_t)j * M;
                 for (int m = 0; m < M; m++) dis += s_lut[m * 256 + cj[m]];
             }
-            const float val = ok ? dis : sentinel;
-            o[j] = val;
-            uint32_t key = 0xffffffffu;
-            if (FILT) {
-                key = dis_key<L2>(val);
-                if (pg == 0 && key < KEY_SENTINEL) {
-                    g_mn = key < g_mn ? key : g_mn;
-                    g_mx = key > g_mx ? key : g_mx;
-                    g_nv++;
-                }
-            }
-            return key;
+            return finish(j, ok, dis);
         };
         // uniform trip counts: append() ballots.  First 256 codes: already in registers.
         if (PRE) {
@@ -1149,24 +1181,87 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
             }
             if (FILT && bound_on) append(key <= tauq, key, pbase + tid);
         }
-        for (int j0 = 256; j0 < len; j0 += 256) {
-            const int j = j0 + tid;
-            uint32_t key = 0xffffffffu;
-            if (j < len) {
-                uint32_t cw[PRE ? MT / 4 : 1];
-                if (PRE) {
-                    const uint4* cp = reinterpret_cast<const uint4*>(lc + (int64_t)j * (PRE ? MT : 16));
+        if constexpr (MT == 64) {
+            // 64-byte codes: the 64 KB LUT leaves two workgroups per CU (2 waves per SIMD), so each
+            // thread scores TWO codes per iteration -- 128 LDS gathers in flight, two independent
+            // add chains -- instead of relying on other waves to cover its latency
+            int j0 = 256;
+            for (; j0 + 256 < len; j0 += 512) {   // both halves hold codes (uniform)
+                const int ja = j0 + tid, jb = ja + 256;
+                const bool ina = true, inb = jb < len;
+                uint32_t cwa[16], cwb[16];
+                {
+                    const uint4* pa = reinterpret_cast<const uint4*>(lc + (int64_t)min(ja, len - 1) * 64);
+                    const uint4* pb = reinterpret_cast<const uint4*>(lc + (int64_t)min(jb, len - 1) * 64);
 #pragma unroll
-                    for (int u = 0; u < MT / 16; u++) {
+                    for (int u = 0; u < 4; u++) {
+                        const uint4 a = pa[u], b = pb[u];
+                        cwa[4 * u] = a.x; cwa[4 * u + 1] = a.y; cwa[4 * u + 2] = a.z; cwa[4 * u + 3] = a.w;
+                        cwb[4 * u] = b.x; cwb[4 * u + 1] = b.y; cwb[4 * u + 2] = b.z; cwb[4 * u + 3] = b.w;
+                    }
+                }
+                bool oka = true, okb = true;
+                if (need_ids) {
+                    const int64_t ida = lid[min(ja, len - 1)], idb = lid[min(jb, len - 1)];
+                    oka = ida >= 0;
+                    if (oka) oka = is_valid_doc(filt, ida);
+                    okb = idb >= 0;
+                    if (okb) okb = is_valid_doc(filt, idb);
+                }
+                float ta[64], tb[64];
+#pragma unroll
+                for (int m = 0; m < 64; m++) ta[m] = s_lut[m * 256 + ((cwa[m >> 2] >> ((m & 3) * 8)) & 255)];
+#pragma unroll
+                for (int m = 0; m < 64; m++) tb[m] = s_lut[m * 256 + ((cwb[m >> 2] >> ((m & 3) * 8)) & 255)];
+                __builtin_amdgcn_sched_barrier(0);   // all gathers in flight before the add chains
+                float da = dis0, db = dis0;
+#pragma unroll
+                for (int m = 0; m < 64; m++) {       // each chain sequential, reference order
+                    da += ta[m];
+                    db += tb[m];
+                }
+                const uint32_t keya = ina ? finish(ja, oka, da) : 0xffffffffu;
+                const uint32_t keyb = inb ? finish(jb, okb, db) : 0xffffffffu;
+                if (FILT && bound_on) {
+                    append(keya <= tauq, keya, pbase + ja);
+                    append(keyb <= tauq, keyb, pbase + jb);
+                }
+            }
+            if (j0 < len) {   // at most 256 codes left: one per thread
+                const int j = j0 + tid;
+                uint32_t key = 0xffffffffu;
+                if (j < len) {
+                    uint32_t cw[16];
+                    const uint4* cp = reinterpret_cast<const uint4*>(lc + (int64_t)j * 64);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
                         const uint4 cv = cp[u];
                         cw[4 * u] = cv.x; cw[4 * u + 1] = cv.y; cw[4 * u + 2] = cv.z; cw[4 * u + 3] = cv.w;
                     }
+                    key = do_code(j, cw);
                 }
-                key = do_code(j, cw);
+                if (FILT && bound_on) append(key <= tauq, key, pbase + j);
             }
-            if (FILT && bound_on) append(key <= tauq, key, pbase + j);
+        } else {
+            for (int j0 = 256; j0 < len; j0 += 256) {
+                const int j = j0 + tid;
+                uint32_t key = 0xffffffffu;
+                if (j < len) {
+                    uint32_t cw[PRE ? MT / 4 : 1];
+                    if (PRE) {
+                        const uint4* cp = reinterpret_cast<const uint4*>(lc + (int64_t)j * (PRE ? MT : 16));
+    #pragma unroll
+                        for (int u = 0; u < MT / 16; u++) {
+                            const uint4 cv = cp[u];
+                            cw[4 * u] = cv.x; cw[4 * u + 1] = cv.y; cw[4 * u + 2] = cv.z; cw[4 * u + 3] = cv.w;
+                        }
+                    }
+                    key = do_code(j, cw);
+                }
+                if (FILT && bound_on) append(key <= tauq, key, pbase + j);
+            }
         }
-    }
+        }
     if (FILT && pg > 0) flush();   // also without a bound: the slice count must be written (0)
     if (FILT && pg == 0) {
         // ---- producer: bound of this query's K-th best from its first probe group ----
@@ -1280,6 +1375,7 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
     do {                                        \
         if (M == 16) GH_SCAN(LL, 16, FF);       \
         else if (M == 32) GH_SCAN(LL, 32, FF);  \
+        else if (M == 64) GH_SCAN(LL, 64, FF);  \
         else GH_SCAN(LL, 0, FF);                \
     } while (0)
     if (pqc_fused) {

@@ -121,6 +121,7 @@ def test_not_trained_and_missing_raw_fail_loudly():
     dict(d=20, nlist=16, M=4, N=6000),             # dsub 5 (generic), d % 8 != 0
     dict(d=64, nlist=16, M=4, N=6000),             # dsub 16 (generic AVX order)
     dict(d=24, nlist=300, M=12, N=2000),           # dsub 2, many empty lists
+    dict(d=128, nlist=8, M=64, N=12000),           # dsub 2, 64-byte codes: two codes per thread, lists of ~1500
 ])
 @pytest.mark.parametrize("metric", [B.METRIC_L2, B.METRIC_IP])
 def test_other_shapes(cfg, metric):
@@ -424,9 +425,13 @@ def test_c2_flat_full_size(c3):
     compare_topk(Do, Io, Di, Ii)
 
 
-def test_scan_bound_parity_at_batch_size(case):
+@pytest.mark.parametrize("shape", ["m8", "m64"])
+def test_scan_bound_parity_at_batch_size(case, shape):
     """512+ queries x 32 probes switch the threshold pre-filter on (4 probes per workgroup): full
-    parity against the oracle, with and without filters, both metrics, re-rank on and off."""
+    parity against the oracle, with and without filters, both metrics, re-rank on and off.
+    m64: the 64-byte-code variant of the scan (two codes per thread), lists of ~600."""
+    if shape == "m64":
+        case = fixtures.trained_case(d=128, nlist=32, M=64, N=20000, nq=24, metric=B.METRIC_L2)
     g = fixtures.load_hip(case)
     try:
         q = synth.sift_like(530, d=case["d"], seed=4242)

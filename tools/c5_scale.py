@@ -1,0 +1,68 @@
+"""C5-shaped run on one GPU: d=768 unit-normalised embedding-shaped vectors, inner product, nlist 4096, M 64
+(dsub 12), nprobe 64, recall_num 100, N vectors (default 2M) added in 100k chunks, with and without a 10 %
+range filter on an int column (device-side field filter).  Reports build time, QPS at 4096-query steps,
+recall@10 against the exact flat search, stage times."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from gamma_amd import api, train
+N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 2000000
+d, nlist, M, P, R, k, nq = 768, 4096, 64, 64, 100, 10, 4096
+dev = torch.device("cuda", 0)
+CH = 100000
+gen = torch.Generator(device=dev); gen.manual_seed(99)
+centres = torch.randn((4096, d), device=dev, generator=gen)
+
+
+def chunk(n, seed):
+    g2 = torch.Generator(device=dev); g2.manual_seed(seed)
+    lab = torch.randint(0, 4096, (n,), device=dev, generator=g2)
+    v = centres[lab] + 0.7 * torch.randn((n, d), device=dev, generator=g2)
+    return torch.nn.functional.normalize(v, dim=1).cpu().numpy()
+
+
+t0 = time.time()
+first = chunk(max(CH, nlist * 40), 1000)
+cc, pq = train.train_ivfpq(first[:nlist * 40], nlist, M, niter=8, pq_niter=12, seed=5, device=str(dev))
+print("train %.1fs" % (time.time() - t0)); t0 = time.time()
+g = api.GammaHip(0)
+g.ivfpq_init(d, nlist, M, 8, api.METRIC_IP, bucket_init_size=max(200, int(1.5 * N / nlist)))
+g.ivfpq_set_trained(cc, pq, None)
+g.raw_init(d)
+rng = np.random.default_rng(3)
+done = 0
+c = 0
+while done < N:
+    n = min(CH, N - done)
+    xb = chunk(n, 2000 + c)
+    g.raw_append(xb)
+    g.add(xb, done)
+    g.field_append(0, rng.integers(0, 1000000, size=n).astype(np.int64))
+    done += n
+    c += 1
+print("generate + add %d vectors %.1fs, device bytes %.1f GB" % (N, time.time() - t0, g.total_mem_bytes() / 1e9))
+q = chunk(nq * 2, 777)
+dq = torch.from_numpy(q).to(dev)
+D = torch.empty((nq, k), dtype=torch.float32, device=dev)
+I = torch.empty((nq, k), dtype=torch.int64, device=dev)
+for name, ff in (("no filter", None), ("10% range filter", [(0, 0, 99999, True, True)])):
+    args = api.SearchArgs(metric=api.METRIC_IP, nprobe=P, recall_num=R, has_rank=True, min_score=-1e30, max_score=1e30,
+                          field_filters=ff)
+    for i in range(3):
+        g.ivfpq_search_device(dq[(i % 2) * nq:].data_ptr(), nq, k, args, D.data_ptr(), I.data_ptr())
+    g.synchronize()
+    g.profile_enable(True); g.profile_reset()
+    steps = 10
+    t0 = time.perf_counter()
+    for i in range(steps):
+        g.ivfpq_search_device(dq[(i % 2) * nq:].data_ptr(), nq, k, args, D.data_ptr(), I.data_ptr())
+    g.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    prof = g.profile()
+    print("%s: %.2f ms per %d queries = %.0f queries/s" % (name, dt * 1e3, nq, nq / dt))
+    print("   stage ms per step:", {n: round(prof[n][0] / steps, 3) for n in ("coarse", "tables", "scan", "select", "rerank")},
+          "scan GB/step %.2f -> %.2f TB/s" % (prof["scan_bytes"] / steps / 1e9, prof["scan_bytes"] / steps / 1e9 / max(1e-9, prof["scan"][0] / steps)))
+    Ih = I[:64].cpu().numpy()
+    Df, If = g.flat_search(q[(steps - 1) % 2 * nq:][:64], k, api.SearchArgs(metric=api.METRIC_IP, min_score=-1e30, max_score=1e30, field_filters=ff))
+    rec = np.mean([len(set(Ih[i].tolist()) & set(If[i].tolist()) - {-1}) / float(max(1, (If[i] >= 0).sum())) for i in range(64)])
+    print("   recall@10 vs flat on 64 queries: %.3f" % rec)
