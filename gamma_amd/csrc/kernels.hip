@@ -1089,16 +1089,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
         const uint8_t* lc = codes + off * M;
         // the first 256 codes are requested BEFORE the T2 row: both latencies overlap, and lists of
         // up to 256 codes (most of them) never wait for their codes after the LUT is ready
-        constexpr bool PRE = MT == 16 || MT == 32 || MT == 64;
+        // compiled code widths: any multiple of 8 bytes up to 64; a code is NLD loads of LW dwords
+        constexpr bool PRE = MT > 0 && MT % 8 == 0 && MT <= 64;
+        constexpr int LW = (MT % 16 == 0) ? 4 : 2, NLD = PRE ? MT / (4 * LW) : 1;
+        typedef uint32_t cvec_t __attribute__((ext_vector_type(LW)));
         // (issued as inline asm: hipcc sinks an ordinary load down to its first use, behind both
         // barriers; the matching s_waitcnt is placed by hand where the codes are consumed)
-        u32x4 cfirst[PRE ? MT / 16 : 1];
+        cvec_t cfirst[NLD];
         if (PRE) {
             const uint8_t* cp0 = lc + (int64_t)min(tid, len - 1) * (PRE ? MT : 16);
 #pragma unroll
-            for (int u = 0; u < (PRE ? MT / 16 : 1); u++) {
-                const uint8_t* a = cp0 + 16 * u;
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(cfirst[u]) : "v"(a) : "memory");
+            for (int u = 0; u < NLD; u++) {
+                const uint8_t* a = cp0 + 4 * LW * u;
+                if constexpr (LW == 4) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(cfirst[u]) : "v"(a) : "memory");
+                else asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(cfirst[u]) : "v"(a) : "memory");
             }
         }
         if (L2) {
@@ -1163,8 +1167,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
         // uniform trip counts: append() ballots.  First 256 codes: already in registers.
         if (PRE) {
 #pragma unroll
-            for (int u = 0; u < (PRE ? MT / 16 : 1); u++)
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(cfirst[u]) : : "memory");
+            for (int u = 0; u < NLD; u++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(cfirst[u]) : : "memory");
         }
         {
             uint32_t key = 0xffffffffu;
@@ -1172,10 +1175,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
                 uint32_t cw[PRE ? MT / 4 : 1];
                 if (PRE) {
 #pragma unroll
-                    for (int u = 0; u < MT / 16; u++) {
-                        cw[4 * u] = cfirst[u].x; cw[4 * u + 1] = cfirst[u].y;
-                        cw[4 * u + 2] = cfirst[u].z; cw[4 * u + 3] = cfirst[u].w;
-                    }
+                    for (int u = 0; u < NLD; u++)
+#pragma unroll
+                        for (int i = 0; i < LW; i++) cw[LW * u + i] = cfirst[u][i];
                 }
                 key = do_code(tid, cw);
             }
@@ -1249,11 +1251,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
                 if (j < len) {
                     uint32_t cw[PRE ? MT / 4 : 1];
                     if (PRE) {
-                        const uint4* cp = reinterpret_cast<const uint4*>(lc + (int64_t)j * (PRE ? MT : 16));
-    #pragma unroll
-                        for (int u = 0; u < MT / 16; u++) {
-                            const uint4 cv = cp[u];
-                            cw[4 * u] = cv.x; cw[4 * u + 1] = cv.y; cw[4 * u + 2] = cv.z; cw[4 * u + 3] = cv.w;
+                        const cvec_t* cp = reinterpret_cast<const cvec_t*>(lc + (int64_t)j * (PRE ? MT : 16));
+#pragma unroll
+                        for (int u = 0; u < NLD; u++) {
+                            const cvec_t cv = cp[u];
+#pragma unroll
+                            for (int i = 0; i < LW; i++) cw[LW * u + i] = cv[i];
                         }
                     }
                     key = do_code(j, cw);
@@ -1261,7 +1264,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
                 if (FILT && bound_on) append(key <= tauq, key, pbase + j);
             }
         }
-        }
+    }
     if (FILT && pg > 0) flush();   // also without a bound: the slice count must be written (0)
     if (FILT && pg == 0) {
         // ---- producer: bound of this query's K-th best from its first probe group ----
@@ -1376,6 +1379,9 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
         if (M == 16) GH_SCAN(LL, 16, FF);       \
         else if (M == 32) GH_SCAN(LL, 32, FF);  \
         else if (M == 64) GH_SCAN(LL, 64, FF);  \
+        else if (M == 8) GH_SCAN(LL, 8, FF);    \
+        else if (M == 24) GH_SCAN(LL, 24, FF);  \
+        else if (M == 48) GH_SCAN(LL, 48, FF);  \
         else GH_SCAN(LL, 0, FF);                \
     } while (0)
     if (pqc_fused) {
