@@ -462,7 +462,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
         out_ids = h->w_cand_ids.as<int64_t>();
     }
     if (pre_dis && pre_probe) {
-        if (shard && P <= 64) {
+        if (shard) {
             // dense probe groups for the owned lists (kernels.hip, k_compact_probes)
             gh::launch_compact_probes(s, pre_probe, pre_dis, nq, P, h->d_list_len, h->d_list_mask, nlist,
                                       h->w_probe.as<int>(), h->w_coarse_dis.as<float>());
@@ -489,7 +489,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
     // table on the fly instead of reading it back from HBM (IPF, kernels.hip).
     int G0 = 4;
     int64_t t2_bytes = (int64_t)nlist * M * 256 * sizeof(float);
-    const bool compacted = shard && pre_dis && pre_probe && P <= 64;
+    const bool compacted = shard && pre_dis && pre_probe;
     if (compacted && h->scan_bound && R <= 256) {
         int64_t owned = 0;
         for (int l = 0; l < nlist; l++)
@@ -510,7 +510,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
     // (sharded without a supplied assignment: probe groups are sparse, nothing to bound from)
     // small batches: one probe per workgroup, a single list rarely holds R candidates, and the
     // unfiltered selection is latency-bound anyway
-    const bool bounded = (!shard || compacted) && h->scan_bound && R <= 256 && P <= 64 && G >= 4 &&
+    const bool bounded = (!shard || compacted) && h->scan_bound && R <= 256 && P <= 128 && G >= 4 &&
                          (PGN >= 2 || compacted);
     const bool fuse_ip = bounded && PGN == 1 && (M == 16 || M == 32) && !getenv("GAMMA_HIP_NO_FUSED_IP");
     {

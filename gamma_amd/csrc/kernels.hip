@@ -684,7 +684,7 @@ __global__ __launch_bounds__(256) void k_pair_offsets(const int* __restrict__ pr
 // Sharded search: a shard owns ~1/W of a query's probed lists.  Move the owned, non-empty ones to
 // the front of the query's probe list (stable, coarse distances move along) so that the scan's
 // probe groups are dense again and the first group can bound the local top-recall_num.
-// One wave per query, P <= 64.  Entries behind the owned ones become -1.
+// One wave per query, 64 probes per pass.  Entries behind the owned ones become -1.
 __global__ __launch_bounds__(256) void k_compact_probes(const int* __restrict__ probe_in,
                                                         const float* __restrict__ cdis_in, int nq, int P,
                                                         const int* __restrict__ list_len,
@@ -694,23 +694,27 @@ __global__ __launch_bounds__(256) void k_compact_probes(const int* __restrict__ 
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (q >= nq) return;
-    int l = -1;
-    float cd = 0.f;
-    if (lane < P) {
-        l = probe_in[(int64_t)q * P + lane];
-        cd = cdis_in[(int64_t)q * P + lane];
+    int nown = 0;
+    for (int p0 = 0; p0 < P; p0 += 64) {
+        const int p = p0 + lane;
+        int l = -1;
+        float cd = 0.f;
+        if (p < P) {
+            l = probe_in[(int64_t)q * P + p];
+            cd = cdis_in[(int64_t)q * P + p];
+        }
+        const bool own = p < P && l >= 0 && l < nlist && (!list_mask || list_mask[l]) && list_len[l] > 0;
+        const unsigned long long bal = __ballot(own);
+        if (own) {
+            const int at = nown + __popcll(bal & ((1ull << lane) - 1ull));
+            probe_out[(int64_t)q * P + at] = l;
+            cdis_out[(int64_t)q * P + at] = cd;
+        }
+        nown += __popcll(bal);
     }
-    const bool own = lane < P && l >= 0 && l < nlist && (!list_mask || list_mask[l]) && list_len[l] > 0;
-    const unsigned long long bal = __ballot(own);
-    const int nown = __popcll(bal);
-    if (own) {
-        const int at = __popcll(bal & ((1ull << lane) - 1ull));
-        probe_out[(int64_t)q * P + at] = l;
-        cdis_out[(int64_t)q * P + at] = cd;
-    }
-    if (lane >= nown && lane < P) {
-        probe_out[(int64_t)q * P + lane] = -1;
-        cdis_out[(int64_t)q * P + lane] = 0.f;
+    for (int p = nown + lane; p < P; p += 64) {
+        probe_out[(int64_t)q * P + p] = -1;
+        cdis_out[(int64_t)q * P + p] = 0.f;
     }
 }
 void launch_compact_probes(hipStream_t s, const int* probe_in, const float* cdis_in, int nq, int P,

@@ -644,7 +644,7 @@ constexpr int SF_CAND = 384;   // candidates of one query held in LDS (first gro
                                // sized so that 8 workgroups (= all 2048 of an 8192-query batch) are resident per CU
 }
 
-template <bool SMALLEST>
+template <bool SMALLEST, int PMAX>   // PMAX: 64 or 128 probes per query
 __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* __restrict__ surv,
                                                       const int* __restrict__ gcnt, int nslices,
                                                       int slice_cap,
@@ -660,8 +660,8 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
                                                       int64_t* __restrict__ out_ids) {
     __shared__ int s_hist[4][256];
     __shared__ unsigned long long s_cand[4][SF_CAND];   // candidates, later the <= 256 kept ones (in place)
-    __shared__ int s_off[4][72];
-    __shared__ int64_t s_base[4][64];
+    __shared__ int s_off[4][PMAX + 8];
+    __shared__ int64_t s_base[4][PMAX];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + w;
     if (q >= nq) return;
@@ -677,10 +677,10 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
     unsigned long long* runs = cand;
     const uint32_t tauq = (uint32_t)word;
     const int* goff = pair_off + (int64_t)q * (P + 1);
-    int* off = s_off[w];        // this query's pair offsets (P + 1 <= 65 entries, see the launcher)
+    int* off = s_off[w];        // this query's pair offsets (P + 1 <= PMAX + 1 entries, see the launcher)
     for (int i = lane; i <= P; i += 64) off[i] = goff[i];
     int64_t* lbase = s_base[w];   // arena offset of each probed list (k_pair_offsets): no probe_list ->
-    if (lane < P) lbase[lane] = pair_base[(int64_t)q * P + lane];   // list_off chain at the end
+    for (int i = lane; i < P; i += 64) lbase[i] = pair_base[(int64_t)q * P + i];   // list_off chain at the end
     const int n0 = goff[min(G, P)];
     const float* v = vals + (int64_t)q * seg_stride;
     // ---- gather the candidate set into LDS: the first probe group's distances within the bound
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
         ps[r] = (int)(uint32_t)it[r];
         int lo = 0;
 #pragma unroll
-        for (int step = 32; step >= 1; step >>= 1) {   // P <= 64
+        for (int step = PMAX / 2; step >= 1; step >>= 1) {   // P <= PMAX
             const int mid = lo + step;
             if (mid < P && off[min(mid, P)] <= ps[r]) lo = mid;
         }
@@ -1127,14 +1127,19 @@ void launch_select_final(hipStream_t s, bool smallest, const unsigned long long*
                          const int64_t* pair_base, const int64_t* ids, uint8_t* flag, float* out_vals,
                          int* out_pos, int64_t* out_ids) {
     if (nq <= 0) return;
-    if (smallest)
-        hipLaunchKernelGGL((k_select_final<true>), dim3((nq + 3) / 4), dim3(256), 0, s, surv, gcnt, nslices,
-                           slice_cap, ready, vals, seg_stride, pair_off, P, G, nq, K, pair_base, ids, flag,
-                           out_vals, out_pos, out_ids);
-    else
-        hipLaunchKernelGGL((k_select_final<false>), dim3((nq + 3) / 4), dim3(256), 0, s, surv, gcnt, nslices,
-                           slice_cap, ready, vals, seg_stride, pair_off, P, G, nq, K, pair_base, ids, flag,
-                           out_vals, out_pos, out_ids);
+    if (P > 128 || nslices > 64) abort();   // callers gate on this (gamma_hip.cpp, ivfpq_stage_a)
+#define GH_SF(SM, PM)                                                                                        \
+    hipLaunchKernelGGL((k_select_final<SM, PM>), dim3((nq + 3) / 4), dim3(256), 0, s, surv, gcnt, nslices,   \
+                       slice_cap, ready, vals, seg_stride, pair_off, P, G, nq, K, pair_base, ids, flag,      \
+                       out_vals, out_pos, out_ids)
+    if (smallest) {
+        if (P <= 64) GH_SF(true, 64);
+        else GH_SF(true, 128);
+    } else {
+        if (P <= 64) GH_SF(false, 64);
+        else GH_SF(false, 128);
+    }
+#undef GH_SF
 }
 
 }  // namespace gh

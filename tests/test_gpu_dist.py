@@ -47,12 +47,14 @@ def _shard_handle(case, owner, s):
     # candidates, no consumers); with M = 16 / 32 the query table is computed inside the scan
     (B.METRIC_L2, True, 4, 4200, 32, 64, 16), (B.METRIC_IP, True, 3, 4200, 32, 64, 16),
     (B.METRIC_L2, False, 4, 4200, 32, 64, 32), (B.METRIC_L2, True, 2, 4200, 16, 32, 8),
+    # the reference's default nprobe (80) and beyond 128 probes (no pre-filter)
+    (B.METRIC_L2, True, 4, 700, 80, 32, 8), (B.METRIC_IP, True, 2, 4200, 80, 32, 8), (B.METRIC_L2, True, 3, 300, 150, 32, 8),
 ])
 def test_shards_on_one_gpu(metric, has_rank, W, nq, P, d, M):
     import torch
     from gamma_amd import api
     from gamma_amd import dist as gdist
-    case = fixtures.trained_case(d=d, nlist=64, M=M, N=20000, nq=64, metric=B.METRIC_L2)
+    case = fixtures.trained_case(d=d, nlist=64 if P <= 64 else 160, M=M, N=20000, nq=64, metric=B.METRIC_L2)
     sizes = np.array([case["oracle"].list_size(l) for l in range(case["nlist"])])
     owner = gdist.balance_lists(sizes, W)
     full = fixtures.load_hip(case)

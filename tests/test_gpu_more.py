@@ -457,6 +457,24 @@ def test_scan_bound_parity_at_batch_size(case, shape):
         g.close()
 
 
+@pytest.mark.parametrize("P", [80, 128])
+def test_scan_bound_with_more_than_64_probes(P):
+    """nprobe 80 is the reference's default (gamma_index_ivfpq.h:629-673): the threshold pre-filter and its
+    selection kernel cover up to 128 probes per query."""
+    case = fixtures.trained_case(d=32, nlist=160, M=8, N=30000, nq=24, metric=B.METRIC_L2)
+    g = fixtures.load_hip(case)
+    try:
+        q = synth.sift_like(300, d=case["d"], seed=99)
+        for metric in (B.METRIC_L2, B.METRIC_IP):
+            for has_rank in (True, False):
+                (D, I, st), (Dg, Ig) = run_both(case, g, q, 10, P, 100, metric, has_rank, coarse_mode=1)
+                sg = g.last_stages(len(q), P, 100)
+                assert sg["coarse_dis"].tobytes() == st["coarse_dis"].tobytes()
+                compare_search(D, I, st, Dg, Ig, sg)
+    finally:
+        g.close()
+
+
 def test_scan_bound_fallback_paths():
     """The threshold pre-filter of the scan must hand a query over to the unfiltered selection when
     it has no usable bound: (a) mass ties -- every candidate within the bound, survivor slices
