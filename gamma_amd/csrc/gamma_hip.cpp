@@ -117,7 +117,7 @@ struct gamma_hip_index {
     DevBuf w_mat, w_coarse_dis, w_probe, w_xn, w_st2, w_pair_off, w_qtotal, w_dist, w_cand_dis,
             w_cand_pos, w_cand_ids, w_exact, w_selv, w_selp, w_x, w_outd, w_outl, w_stage, w_filter,
             w_m_dis, w_m_ids, w_part_v, w_part_i, w_assign, w_codes_tmp, w_qperm, w_scnt, w_sflag, w_surv, w_pair_base,
-            w_pair_ip;
+            w_pair_ip, w_flat_cand, w_flat_meta;
     unsigned long long* d_scan_codes = nullptr;
     size_t dist_budget_bytes = (size_t)8 << 30;   // per-chunk ADC distance buffer (288 GB of HBM per GPU)
 
@@ -720,16 +720,10 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
     GH_CHECK(h, h->w_cand_pos.ensure((size_t)qc * k * sizeof(int)));
     GH_CHECK(h, h->w_cand_dis.ensure((size_t)qc * k * sizeof(float)));
     StageScope t(h, GAMMA_HIP_STAGE_FLAT);
-    for (int q0 = 0; q0 < nq; q0 += qc) {
-        const int nc = std::min(qc, nq - q0);
+    // the reference's loop: every row, one query at a time, a k-heap (gamma_index_flat.cc:118-300).
+    // Here: distance slab of one row chunk -> per-chunk top-k -> merge of the chunks' tables.
+    auto unbounded = [&](int q0, int nc) -> int {
         const float* xq = d_x + (size_t)q0 * d;
-        if (N == 0) {
-            // nothing to scan: all-empty result
-            GH_CHECK(h, hipMemsetAsync(h->w_selp.p, 0xff, (size_t)nc * k * sizeof(int), s));
-            gh::launch_finalize_topk(s, h->w_selv.as<float>(), h->w_selp.as<int>(), nc, k, nullptr, 0, 0,
-                                     neutral, d_distances + (size_t)q0 * k, d_labels + (size_t)q0 * k);
-            continue;
-        }
         for (int c = 0; c < nchunks; c++) {
             const int64_t r0 = (int64_t)c * rows_chunk;
             const int64_t nr = std::min<int64_t>(rows_chunk, N - r0);
@@ -756,6 +750,57 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
         gh::launch_finalize_topk(s, h->w_selv.as<float>(), h->w_selp.as<int>(), nc, k,
                                  h->w_m_ids.as<int64_t>(), (int64_t)nchunks * k, 0, neutral,
                                  d_distances + (size_t)q0 * k, d_labels + (size_t)q0 * k);
+        return GAMMA_HIP_OK;
+    };
+    // Running bound: only the first chunk goes through a distance slab.  Its k-th best bounds the
+    // answer; the remaining rows are scored in passes that double the rows seen so far, each pass
+    // appending only the distances within the current bound to the query's candidate list (about k
+    // per pass and query) and ending with a compaction that tightens the bound.  The k smallest
+    // (distance, row id) items are the same either way.  A list that overflows (rows arriving in
+    // improving order) is detected and the call redone without a bound.
+    const int cap = gh::flat_list_cap();
+    auto bounded = [&](int q0, int nc, bool* redo) -> int {
+        const float* xq = d_x + (size_t)q0 * d;
+        GH_CHECK(h, h->w_flat_cand.ensure((size_t)nc * cap * sizeof(unsigned long long)));
+        GH_CHECK(h, h->w_flat_meta.ensure((size_t)(2 * nc + 1) * sizeof(int)));   // tau[nc] | cnt[nc] | overflow
+        uint32_t* tau = h->w_flat_meta.as<uint32_t>();
+        int* cnt = h->w_flat_meta.as<int>() + nc;
+        int* over = cnt + nc;
+        gh::FlatEmit em{tau, h->w_flat_cand.as<unsigned long long>(), cnt, cap};
+        GH_CHECK(h, hipMemsetAsync(over, 0, sizeof(int), s));
+        gh::launch_pairwise_filtered(s, l2, xq, nc, d, h->d_raw, rows_chunk, h->w_dist.as<float>(), rows_chunk, filt,
+                                     p->min_score, p->max_score, 0);
+        gh::launch_select_topk(s, l2, h->w_dist.as<float>(), rows_chunk, nullptr, (int)rows_chunk, (int)rows_chunk,
+                               nc, k, h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>());
+        gh::launch_flat_init(s, l2, h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>(), nc, k, 0, em, tau);
+        for (int64_t r = rows_chunk; r < N;) {
+            const int64_t nr = std::min<int64_t>(r, N - r);
+            gh::launch_pairwise_emit(s, l2, xq, nc, d, h->d_raw + r * d, nr, filt, p->min_score, p->max_score, r, em);
+            gh::launch_flat_compact(s, nc, k, em, tau, over);
+            r += nr;
+        }
+        gh::launch_flat_final(s, l2, nc, k, em, neutral, d_distances + (size_t)q0 * k, d_labels + (size_t)q0 * k);
+        GH_CHECK(h, hipGetLastError());
+        int h_over = 0;
+        GH_CHECK(h, hipMemcpyAsync(&h_over, over, sizeof(int), hipMemcpyDeviceToHost, s));
+        GH_CHECK(h, hipStreamSynchronize(s));
+        *redo = h_over != 0;
+        return GAMMA_HIP_OK;
+    };
+    for (int q0 = 0; q0 < nq; q0 += qc) {
+        const int nc = std::min(qc, nq - q0);
+        if (N == 0) {
+            // nothing to scan: all-empty result
+            GH_CHECK(h, hipMemsetAsync(h->w_selp.p, 0xff, (size_t)nc * k * sizeof(int), s));
+            gh::launch_finalize_topk(s, h->w_selv.as<float>(), h->w_selp.as<int>(), nc, k, nullptr, 0, 0,
+                                     neutral, d_distances + (size_t)q0 * k, d_labels + (size_t)q0 * k);
+            continue;
+        }
+        bool redo = true;
+        if (k <= 256 && N > rows_chunk && N < ((int64_t)1 << 32) &&
+            gh::pairwise_can_emit(nc, d, N - rows_chunk))
+            GH_TRY(bounded(q0, nc, &redo));
+        if (redo) GH_TRY(unbounded(q0, nc));
     }
     GH_CHECK(h, hipGetLastError());
     return GAMMA_HIP_OK;
@@ -840,7 +885,7 @@ int gamma_hip_destroy(gamma_hip_index* h) {
                       &h->w_exact, &h->w_selv, &h->w_selp, &h->w_x, &h->w_outd, &h->w_outl, &h->w_stage,
                       &h->w_filter, &h->w_m_dis, &h->w_m_ids, &h->w_part_v, &h->w_part_i, &h->w_assign,
                       &h->w_codes_tmp, &h->w_qperm, &h->w_scnt, &h->w_sflag, &h->w_surv, &h->w_pair_base,
-                      &h->w_pair_ip};
+                      &h->w_pair_ip, &h->w_flat_cand, &h->w_flat_meta};
     for (DevBuf* b : bufs) b->release();
     (void)hipStreamDestroy(h->stream);
     delete h;

@@ -40,6 +40,26 @@ void launch_pairwise_filtered(hipStream_t s, bool l2, const float* x, int nq, in
                               const float* y, int64_t ny, float* out, int64_t ld_out,
                               const FilterDesc& filt, float min_score, float max_score,
                               int64_t row_base);
+// Flat search with a running bound: candidate lists of the queries of one call
+struct FlatEmit {
+    const uint32_t* tau;        // [nq] key bound per query (0xff7fffff = anything valid)
+    unsigned long long* cand;   // [nq][cap] (key << 32 | row id)
+    int* cnt;                   // [nq] items appended (may exceed cap: overflow)
+    int cap;
+};
+bool pairwise_can_emit(int nq, int d, int64_t ny);
+int flat_list_cap();
+void launch_pairwise_emit(hipStream_t s, bool l2, const float* x, int nq, int d, const float* y, int64_t ny,
+                          const FilterDesc& filt, float min_score, float max_score, int64_t row_base,
+                          const FlatEmit& em);
+// candidate lists from the first chunk's top-k (vals / positions inside the chunk starting at row r0)
+void launch_flat_init(hipStream_t s, bool l2, const float* vals, const int* pos, int nq, int k, int64_t r0,
+                      const FlatEmit& em, uint32_t* tau);
+// per query: keep the k best of its list (sorted), set the new bound; lists that overflowed set *overflow
+void launch_flat_compact(hipStream_t s, int nq, int k, const FlatEmit& em, uint32_t* tau, int* overflow);
+// sorted lists -> distances / labels (neutral / -1 padded)
+void launch_flat_final(hipStream_t s, bool l2, int nq, int k, const FlatEmit& em, float neutral, float* distances,
+                       int64_t* labels);
 void launch_row_norms(hipStream_t s, const float* y, int64_t n, int d, float* out);
 void launch_l2_gemmform(hipStream_t s, const float* x, int nq, int d, const float* y, int64_t ny,
                         const float* xn, const float* yn, float* out, int64_t ld_out,

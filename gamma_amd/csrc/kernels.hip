@@ -83,17 +83,23 @@ __global__ __launch_bounds__(256) void k_pairwise_rowreg(const float* __restrict
 // v_pk_fma_f32 on two of the eight lane accumulators at a time (IEEE per component: same bits).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int PW_QT = 32;
-template <bool L2, int D, bool FILTER>
+// EMIT (flat search with a running bound, gamma_hip.cpp flat_search_device_locked): instead of writing
+// the nq x ny distance slab, append (key << 32 | row id) of every distance within the query's current
+// bound tau[q] to the query's candidate list (cand[q][cap], cnt[q]; an atomic per survivor, and there
+// are about k per query and chunk).  Keys order like the distances ("smaller is better").
+template <bool L2, int D, bool FILTER, bool EMIT = false>
 __global__ __launch_bounds__(256) void k_pairwise_lds(const float* __restrict__ x, int nq,
                                                       const float* __restrict__ y, int64_t ny,
                                                       float* __restrict__ out, int64_t ld_out,
                                                       int q_per_block, FilterDesc filt, float min_score,
-                                                      float max_score, float sentinel, int64_t row_base) {
+                                                      float max_score, float sentinel, int64_t row_base,
+                                                      FlatEmit em) {
     // Two threads per database row: the even one owns AVX lanes 0-3 (elements 8i .. 8i+3), the odd
     // one lanes 4-7, D/2 row values each -- half the registers of a whole row per thread, so
     // several waves fit per SIMD.  Per lane the accumulation order is untouched; the pair's sums
     // meet in s[l] = acc[l+4] + acc[l] through one shuffle.
     __shared__ float4 s_x[PW_QT * D / 4];
+    __shared__ uint32_t s_tau[PW_QT];
     const int half = threadIdx.x & 1;
     const int64_t row = (int64_t)blockIdx.x * 128 + (threadIdx.x >> 1);
     const int q0 = blockIdx.y * q_per_block;
@@ -116,6 +122,7 @@ __global__ __launch_bounds__(256) void k_pairwise_lds(const float* __restrict__ 
         __syncthreads();   // the previous tile has been consumed
         for (int e = threadIdx.x; e < nqt * (D / 4); e += 256)
             s_x[e] = reinterpret_cast<const float4*>(x + (int64_t)qt * D)[e];
+        if (EMIT && threadIdx.x < nqt) s_tau[threadIdx.x] = em.tau[qt + threadIdx.x];
         __syncthreads();
         for (int qi = 0; qi < nqt; qi++) {
             const float4* xq = s_x + qi * (D / 4) + half;
@@ -154,7 +161,20 @@ __global__ __launch_bounds__(256) void k_pairwise_lds(const float* __restrict__ 
             if (FILTER) {
                 if (!valid || !(dis <= max_score && dis >= min_score)) dis = sentinel;
             }
-            if (live && half == 0) out[(int64_t)(qt + qi) * ld_out + row] = dis;
+            if (EMIT) {
+                if (live && half == 0) {
+                    const uint32_t kk = f2key(dis);
+                    const uint32_t key = L2 ? kk : ~kk;
+                    if (key <= s_tau[qi] && key < 0xff800000u) {   // 0xff800000: key of the sentinel
+                        const int slot = atomicAdd(&em.cnt[qt + qi], 1);
+                        if (slot < em.cap)
+                            em.cand[(int64_t)(qt + qi) * em.cap + slot] =
+                                    ((unsigned long long)key << 32) | (unsigned)(row_base + row);
+                    }
+                }
+            } else {
+                if (live && half == 0) out[(int64_t)(qt + qi) * ld_out + row] = dis;
+            }
         }
     }
 }
@@ -183,15 +203,17 @@ __global__ __launch_bounds__(256) void k_pairwise_generic(const float* __restric
     }
 }
 
-template <bool L2, bool FILTER>
-static void launch_pairwise_t(hipStream_t s, const float* x, int nq, int d, const float* y,
-                              int64_t ny, float* out, int64_t ld_out, const FilterDesc& filt,
-                              float min_score, float max_score, float sentinel,
-                              int64_t row_base) {
-    if (ny <= 0 || nq <= 0) return;
-    const int64_t row_blocks = (ny + 255) / 256;
-    // enough blocks to fill 256 CUs a few times over; rows stay in registers across the
-    // block's whole query range
+// which shapes the EMIT variant covers (the others keep the distance slab)
+bool pairwise_can_emit(int nq, int d, int64_t ny) {
+    static const bool no_lds = getenv("GAMMA_HIP_NO_PAIRWISE_LDS") != nullptr;
+    static const bool no_emit = getenv("GAMMA_HIP_NO_FLAT_BOUND") != nullptr;
+    if (no_lds || no_emit || nq < 8 || ny < 1024) return false;
+    return d == 128 || d == 96 || d == 64 || d == 32 || d == 16;
+}
+
+// queries per workgroup: enough workgroups to fill 256 CUs a few times over; a workgroup's rows stay
+// in registers across its whole query range
+static int pairwise_q_per_block(int nq, int64_t row_blocks) {
     int q_per_block = nq;
     const int64_t want_blocks = 2048;
     if (row_blocks < want_blocks) {
@@ -199,6 +221,45 @@ static void launch_pairwise_t(hipStream_t s, const float* x, int nq, int d, cons
         q_per_block = (nq + splits - 1) / splits;
         if (q_per_block < 8) q_per_block = nq < 8 ? nq : 8;
     }
+    return q_per_block;
+}
+
+template <bool L2>
+static void launch_pairwise_emit_t(hipStream_t s, const float* x, int nq, int d, const float* y, int64_t ny,
+                                   const FilterDesc& filt, float min_score, float max_score, float sentinel,
+                                   int64_t row_base, const FlatEmit& em) {
+    const int q_per_block = pairwise_q_per_block(nq, (ny + 255) / 256);
+    const dim3 grid((unsigned)((ny + 127) / 128), (unsigned)((nq + q_per_block - 1) / q_per_block));
+#define GH_EMIT(DD)                                                                                         \
+    hipLaunchKernelGGL((k_pairwise_lds<L2, DD, true, true>), grid, dim3(256), 0, s, x, nq, y, ny, nullptr, 0, \
+                       q_per_block, filt, min_score, max_score, sentinel, row_base, em)
+    switch (d) {
+        case 128: GH_EMIT(128); break;
+        case 96: GH_EMIT(96); break;
+        case 64: GH_EMIT(64); break;
+        case 32: GH_EMIT(32); break;
+        case 16: GH_EMIT(16); break;
+        default: abort();   // pairwise_can_emit
+    }
+#undef GH_EMIT
+}
+
+void launch_pairwise_emit(hipStream_t s, bool l2, const float* x, int nq, int d, const float* y, int64_t ny,
+                          const FilterDesc& filt, float min_score, float max_score, int64_t row_base,
+                          const FlatEmit& em) {
+    if (ny <= 0 || nq <= 0) return;
+    if (l2) launch_pairwise_emit_t<true>(s, x, nq, d, y, ny, filt, min_score, max_score, INFINITY, row_base, em);
+    else launch_pairwise_emit_t<false>(s, x, nq, d, y, ny, filt, min_score, max_score, -INFINITY, row_base, em);
+}
+
+template <bool L2, bool FILTER>
+static void launch_pairwise_t(hipStream_t s, const float* x, int nq, int d, const float* y,
+                              int64_t ny, float* out, int64_t ld_out, const FilterDesc& filt,
+                              float min_score, float max_score, float sentinel,
+                              int64_t row_base) {
+    if (ny <= 0 || nq <= 0) return;
+    const int64_t row_blocks = (ny + 255) / 256;
+    const int q_per_block = pairwise_q_per_block(nq, row_blocks);
     dim3 grid((unsigned)row_blocks, (unsigned)((nq + q_per_block - 1) / q_per_block));
     static const bool no_lds = getenv("GAMMA_HIP_NO_PAIRWISE_LDS") != nullptr;
     // a workgroup that sees fewer than a few queries gains nothing from staging them
@@ -208,7 +269,7 @@ static void launch_pairwise_t(hipStream_t s, const float* x, int nq, int d, cons
         if (use_lds)                                                                                   \
             hipLaunchKernelGGL((k_pairwise_lds<L2, DD, FILTER>), dim3((unsigned)((ny + 127) / 128), grid.y), \
                                dim3(256), 0, s, x, nq, y, ny, out, ld_out, q_per_block, filt, min_score, \
-                               max_score, sentinel, row_base);                                         \
+                               max_score, sentinel, row_base, FlatEmit{});                             \
         else                                                                                           \
             hipLaunchKernelGGL((k_pairwise_rowreg<L2, DD, FILTER>), grid, dim3(256), 0, s, x, nq, y, ny, \
                                out, ld_out, q_per_block, filt, min_score, max_score, sentinel, row_base); \

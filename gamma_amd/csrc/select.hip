@@ -1082,6 +1082,156 @@ bool launch_merge_shards(hipStream_t s, bool smallest, const float* all_dis, con
     return true;
 }
 
+// ------------------------------------------------------------------------------------
+// Flat search with a running bound (gamma_hip.cpp, flat_search_device_locked; the emitting
+// distance kernel is k_pairwise_lds<.., EMIT> in kernels.hip).  A query's candidate list holds
+// (key << 32 | row id) items: ascending 64-bit order = (distance, row id) order, the order the
+// reference's scan + heap leaves behind up to the membership inside exact ties.
+// ------------------------------------------------------------------------------------
+constexpr uint32_t FLAT_ANY = 0xff7fffffu;   // bound that admits every non-sentinel key
+constexpr int FLAT_CAP = 2048;               // items per query list (k_flat_compact holds them in registers)
+
+__global__ __launch_bounds__(256) void k_flat_init(const float* __restrict__ vals, const int* __restrict__ pos,
+                                                   int k, int64_t r0, bool smallest, FlatEmit em,
+                                                   uint32_t* __restrict__ tau) {
+    // first chunk's top-k (sorted on (value, position), invalid entries behind with pos = -1)
+    const int q = blockIdx.x;
+    __shared__ int s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int i = threadIdx.x; i < k; i += 256) {
+        const int ps = pos[(int64_t)q * k + i];
+        if (ps >= 0) {
+            const uint32_t kk = f2key(vals[(int64_t)q * k + i]);
+            em.cand[(int64_t)q * em.cap + i] = ((unsigned long long)(smallest ? kk : ~kk) << 32) | (unsigned)(r0 + ps);
+            mine++;
+        }
+    }
+    if (mine) atomicAdd(&s_n, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int n = s_n;
+        em.cnt[q] = n;
+        tau[q] = n == k ? (uint32_t)(em.cand[(int64_t)q * em.cap + k - 1] >> 32) : FLAT_ANY;
+    }
+}
+
+// one wave per query: keep the k smallest items of the list, sorted; new bound = key of the k-th
+__global__ __launch_bounds__(256) void k_flat_compact(int nq, int k, FlatEmit em, uint32_t* __restrict__ tau,
+                                                      int* __restrict__ overflow) {
+    constexpr int NPL = FLAT_CAP / 64;
+    __shared__ unsigned long long s_run[4][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + w;
+    if (q >= nq) return;
+    const int cnt = em.cnt[q];
+    if (cnt > em.cap) {   // more survivors than the list holds: the caller redoes the call without a bound
+        if (lane == 0) *overflow = 1;
+        return;
+    }
+    if (cnt == 0) return;
+    unsigned long long* list = em.cand + (int64_t)q * em.cap;
+    unsigned long long it[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; j++) it[j] = j * 64 + lane < cnt ? list[j * 64 + lane] : ~0ull;
+    const int m = min(cnt, k);
+    // smallest V with #(item <= V) >= m; items are distinct, so exactly m items are <= V
+    unsigned long long lo = 0ull, hi = ~0ull - 1ull;
+    while (lo < hi) {
+        const unsigned long long mid = lo + ((hi - lo) >> 1);
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < NPL; j++) c += it[j] <= mid ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+        if (c >= m) hi = mid;
+        else lo = mid + 1ull;
+    }
+    const unsigned long long V = lo;
+    unsigned long long* runs = s_run[w];
+    int at = 0;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+        const bool take = it[j] <= V;
+        const unsigned long long tb = __ballot(take);
+        if (take) runs[at + __popcll(tb & lt_mask)] = it[j];
+        at += __popcll(tb);
+    }
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long x[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) x[r] = (r * 64 + lane < m) ? runs[r * 64 + lane] : ~0ull;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; r++) x[r] = wave_sort64(x[r]);
+#pragma unroll
+    for (int r = 0; r < 4; r++) runs[r * 64 + lane] = x[r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        int rank = lane;
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            if (o == r) continue;
+            const unsigned long long* ro = runs + o * 64;
+            int lo2 = 0, n2 = 64;
+#pragma unroll
+            for (int st = 0; st < 7; st++) {
+                if (n2 > 0) {
+                    const int half = n2 >> 1;
+                    if (ro[lo2 + half] < x[r]) {
+                        lo2 += half + 1;
+                        n2 -= half + 1;
+                    } else {
+                        n2 = half;
+                    }
+                }
+            }
+            rank += lo2;
+        }
+        if (x[r] != ~0ull) list[rank] = x[r];   // ranks are a permutation of 0..m-1
+    }
+    if (lane == 0) {
+        em.cnt[q] = m;
+        tau[q] = m == k ? (uint32_t)(V >> 32) : FLAT_ANY;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_flat_final(int k, bool smallest, FlatEmit em, float neutral,
+                                                    float* __restrict__ distances, int64_t* __restrict__ labels) {
+    const int q = blockIdx.x;
+    const int m = min(em.cnt[q], k);
+    for (int i = threadIdx.x; i < k; i += 256) {
+        float dv = neutral;
+        int64_t id = -1;
+        if (i < m) {
+            const unsigned long long item = em.cand[(int64_t)q * em.cap + i];
+            const uint32_t key = (uint32_t)(item >> 32);
+            dv = key2f(smallest ? key : ~key);
+            id = (int64_t)(uint32_t)item;
+        }
+        distances[(int64_t)q * k + i] = dv;
+        labels[(int64_t)q * k + i] = id;
+    }
+}
+
+int flat_list_cap() { return FLAT_CAP; }
+
+void launch_flat_init(hipStream_t s, bool l2, const float* vals, const int* pos, int nq, int k, int64_t r0,
+                      const FlatEmit& em, uint32_t* tau) {
+    if (nq > 0) hipLaunchKernelGGL(k_flat_init, dim3(nq), dim3(256), 0, s, vals, pos, k, r0, l2, em, tau);
+}
+void launch_flat_compact(hipStream_t s, int nq, int k, const FlatEmit& em, uint32_t* tau, int* overflow) {
+    if (k > 256 || em.cap != FLAT_CAP) abort();   // callers gate on this
+    if (nq > 0) hipLaunchKernelGGL(k_flat_compact, dim3((nq + 3) / 4), dim3(256), 0, s, nq, k, em, tau, overflow);
+}
+void launch_flat_final(hipStream_t s, bool l2, int nq, int k, const FlatEmit& em, float neutral, float* distances,
+                       int64_t* labels) {
+    if (nq > 0) hipLaunchKernelGGL(k_flat_final, dim3(nq), dim3(256), 0, s, k, l2, em, neutral, distances, labels);
+}
+
 int select_kpad(int K) {
     int p = 2;
     while (p < K) p <<= 1;

@@ -169,6 +169,48 @@ def test_flat_parity(metric, d):
         g.close()
 
 
+@pytest.mark.parametrize("order", ["random", "improving", "ties"])
+def test_flat_running_bound(order):
+    """Beyond the first 65536 rows the flat search keeps per-query candidate lists under a running bound
+    (row passes that double the rows seen).  random: the normal case; improving: rows sorted so that every
+    pass beats the bound of the rows before it -- the lists overflow and the call is redone without a bound;
+    ties: few distinct vectors, the k-th distance is shared by thousands of rows (membership by row id)."""
+    N, d, nq = 300000, 32, 24
+    base = synth.sift_like(N, d=d, seed=31)
+    q = synth.sift_like(nq, d=d, seed=32)
+    if order == "improving":
+        dist0 = ((base - q[0]) ** 2).sum(1)
+        base = np.ascontiguousarray(base[np.argsort(-dist0, kind="stable")])
+    elif order == "ties":
+        base = np.ascontiguousarray(base[np.random.default_rng(5).integers(0, 40, size=N)])
+    rng = np.random.default_rng(3)
+    deleted = rng.choice(N, size=N // 10, replace=False)
+    bm = np.zeros((N >> 3) + 1, dtype=np.uint8)
+    np.bitwise_or.at(bm, deleted >> 3, (1 << (deleted & 7)).astype(np.uint8))
+    g = api.GammaHip(0)
+    try:
+        g.raw_init(d)
+        g.raw_append(base)
+        g.bitmap_upload(bm, N)
+        for metric, k, win in ((B.METRIC_L2, 100, WIDE), (B.METRIC_IP, 10, WIDE), (B.METRIC_L2, 256, WIDE),
+                               (B.METRIC_L2, 300, WIDE), (B.METRIC_L2, 100, dict(min_score=30000.0, max_score=1e30))):
+            ctx = B.make_ctx(docids_bitmap=bm, **win)
+            D, I = B.flat_search(base, q, k, metric, ctx)
+            Dg, Ig = g.flat_search(q, k, api.SearchArgs(metric=metric, **win))
+            if order == "ties":
+                # same distances; ids may differ inside exact ties only (heap vs (distance, row id) order)
+                assert np.array_equal(D, Dg)
+                for i in range(nq):
+                    ok = Ig[i] >= 0
+                    dd = ((base[Ig[i][ok]] - q[i]) ** 2).sum(1) if metric == B.METRIC_L2 else (base[Ig[i][ok]] * q[i]).sum(1)
+                    assert np.allclose(dd, Dg[i][ok], rtol=1e-5)
+                    assert len(set(Ig[i][ok].tolist())) == ok.sum()
+            else:
+                compare_topk(D, I, Dg, Ig)
+    finally:
+        g.close()
+
+
 @pytest.mark.parametrize("k", [1, 10, 64])
 @pytest.mark.parametrize("layout", ["random", "one_lane", "ties"])
 def test_small_k_selection_paths(k, layout):
