@@ -117,7 +117,7 @@ struct gamma_hip_index {
     DevBuf w_mat, w_coarse_dis, w_probe, w_xn, w_st2, w_pair_off, w_qtotal, w_dist, w_cand_dis,
             w_cand_pos, w_cand_ids, w_exact, w_selv, w_selp, w_x, w_outd, w_outl, w_stage, w_filter,
             w_m_dis, w_m_ids, w_part_v, w_part_i, w_assign, w_codes_tmp, w_qperm, w_scnt, w_sflag, w_surv, w_pair_base,
-            w_pair_ip, w_flat_cand, w_flat_meta;
+            w_pair_ip, w_flat_cand, w_flat_meta, w_full_cdis, w_full_probe;
     unsigned long long* d_scan_codes = nullptr;
     size_t dist_budget_bytes = (size_t)8 << 30;   // per-chunk ADC distance buffer (288 GB of HBM per GPU)
 
@@ -416,12 +416,17 @@ int check_params(H* h, const gamma_hip_search_params* p, int nq, int k) {
 
 // ---- IVFPQ stage A: coarse + tables + scan + top-R + ids ------------------------------
 // results: w_cand_dis [nq*R] (ADC distance, best first, sentinel pad), w_cand_ids [nq*R]
-int ivfpq_coarse(H* h, const gamma_hip_search_params* p, int nq, const float* d_x) {
+int ivfpq_coarse(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, float* out_dis = nullptr,
+                 int* out_probe = nullptr) {
     const int P = p->nprobe, d = h->d, nlist = h->nlist;
     hipStream_t s = h->stream;
     GH_CHECK(h, h->w_mat.ensure((size_t)nq * nlist * sizeof(float)));
-    GH_CHECK(h, h->w_coarse_dis.ensure((size_t)nq * P * sizeof(float)));
-    GH_CHECK(h, h->w_probe.ensure((size_t)nq * P * sizeof(int)));
+    if (!out_dis || !out_probe) {   // the workspace the scan reads
+        GH_CHECK(h, h->w_coarse_dis.ensure((size_t)nq * P * sizeof(float)));
+        GH_CHECK(h, h->w_probe.ensure((size_t)nq * P * sizeof(int)));
+        out_dis = h->w_coarse_dis.as<float>();
+        out_probe = h->w_probe.as<int>();
+    }
     int mode = p->coarse_mode;
     if (mode < 0) mode = nq < 20 ? 0 : 1;  // faiss:utils/distances.cpp:303,346
     StageScope t(h, GAMMA_HIP_STAGE_COARSE);
@@ -432,8 +437,7 @@ int ivfpq_coarse(H* h, const gamma_hip_search_params* p, int nq, const float* d_
         gh::launch_l2_gemmform(s, d_x, nq, d, h->d_cc, nlist, nullptr, h->d_cc_norms,
                                h->w_mat.as<float>(), nlist, true);
     }
-    gh::launch_select_topk(s, true, h->w_mat.as<float>(), nlist, nullptr, nlist, nlist, nq, P,
-                           h->w_coarse_dis.as<float>(), h->w_probe.as<int>());
+    gh::launch_select_topk(s, true, h->w_mat.as<float>(), nlist, nullptr, nlist, nlist, nq, P, out_dis, out_probe);
     return GAMMA_HIP_OK;
 }
 
@@ -562,7 +566,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
                                   h->w_pair_off.as<int>(), h->d_list_off, h->d_ids,
                                   out_ids);
     } else {
-        const int cap = gh::scan_slice_cap(), nsl = PGN - 1;
+        const int cap = gh::scan_slice_cap(), nsl = PGN;   // one survivor slice per probe group (slice 0: the producer's own)
         GH_CHECK(h, h->w_scnt.ensure((size_t)nq * (sizeof(unsigned long long) + (size_t)nsl * sizeof(int))));   // ready[nq] | gcnt[nq][nsl]
         GH_CHECK(h, h->w_sflag.ensure((size_t)nq));
         GH_CHECK(h, h->w_surv.ensure((size_t)nq * nsl * cap * sizeof(unsigned long long)));
@@ -655,14 +659,18 @@ int ivfpq_check(H* h, const gamma_hip_search_params* p, int nq, int k) {
     return GAMMA_HIP_OK;
 }
 
-int query_chunk(H* h, int nq, int P) {
-    const int64_t q_stride = std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len));
-    int64_t by_dist = (int64_t)(h->dist_budget_bytes / (q_stride * sizeof(float)));
-    int64_t by_mat = (int64_t)(h->dist_budget_bytes / ((size_t)h->nlist * sizeof(float)));
-    int64_t c = std::min<int64_t>(by_dist, by_mat);
-    c = std::max<int64_t>(1, std::min<int64_t>(c, nq));
-    return (int)c;
+// queries per internal chunk: the coarse distance matrix (nlist floats per query) and the ADC distance
+// slab (nprobe x longest list floats per query) each stay inside the workspace budget
+int coarse_chunk(H* h, int nq) {
+    const int64_t by_mat = (int64_t)(h->dist_budget_bytes / ((size_t)h->nlist * sizeof(float)));
+    return (int)std::max<int64_t>(1, std::min<int64_t>(by_mat, nq));
 }
+int scan_chunk(H* h, int nq, int P) {
+    const int64_t q_stride = std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len));
+    const int64_t by_dist = (int64_t)(h->dist_budget_bytes / (q_stride * sizeof(float)));
+    return (int)std::max<int64_t>(1, std::min<int64_t>(by_dist, nq));
+}
+int query_chunk(H* h, int nq, int P) { return std::min(coarse_chunk(h, nq), scan_chunk(h, nq, P)); }
 
 int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, int k,
                                float* d_distances, int64_t* d_labels) {
@@ -677,10 +685,25 @@ int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, c
     gamma_hip_search_params pp = *p;
     if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;
     p = &pp;
-    const int chunk = query_chunk(h, nq, p->nprobe);
+    const int chunk = scan_chunk(h, nq, p->nprobe), P = p->nprobe;
+    // long lists (C4: 64 probes x lists of tens of thousands) make the ADC slab the limit: the coarse
+    // quantizer then still runs over the whole call (one GEMM instead of one per slab chunk)
+    const bool coarse_first = chunk < nq;
+    if (coarse_first) {
+        GH_CHECK(h, h->w_full_cdis.ensure((size_t)nq * P * sizeof(float)));
+        GH_CHECK(h, h->w_full_probe.ensure((size_t)nq * P * sizeof(int)));
+        const int cc = coarse_chunk(h, nq);
+        for (int q0 = 0; q0 < nq; q0 += cc)
+            GH_TRY(ivfpq_coarse(h, p, std::min(cc, nq - q0), d_x + (size_t)q0 * h->d,
+                                h->w_full_cdis.as<float>() + (size_t)q0 * P, h->w_full_probe.as<int>() + (size_t)q0 * P));
+    }
     for (int q0 = 0; q0 < nq; q0 += chunk) {
         const int nc = std::min(chunk, nq - q0);
-        GH_TRY(ivfpq_stage_a(h, p, filt, nc, d_x + (size_t)q0 * h->d, R));
+        if (coarse_first)
+            GH_TRY(ivfpq_stage_a(h, p, filt, nc, d_x + (size_t)q0 * h->d, R, h->w_full_cdis.as<float>() + (size_t)q0 * P,
+                                 h->w_full_probe.as<int>() + (size_t)q0 * P));
+        else
+            GH_TRY(ivfpq_stage_a(h, p, filt, nc, d_x + (size_t)q0 * h->d, R));
         GH_TRY(ivfpq_stage_b(h, p, nc, d_x + (size_t)q0 * h->d, R, k, h->w_cand_dis.as<float>(),
                              h->w_cand_ids.as<int64_t>(), d_distances + (size_t)q0 * k,
                              d_labels + (size_t)q0 * k));
@@ -861,6 +884,11 @@ int gamma_hip_create(int device, gamma_hip_index** out) {
         delete h;
         return GAMMA_HIP_EDEVICE;
     }
+    // workspace budget of the chunked buffers: an eighth of the device memory, 1..32 GiB (36 GB -> 32 GiB
+    // on a 288 GB MI355X); gamma_hip_set_workspace_budget overrides
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0)
+        h->dist_budget_bytes = std::min<size_t>((size_t)32 << 30, std::max<size_t>((size_t)1 << 30, total_b / 8));
     *out = h;
     return GAMMA_HIP_OK;
 }
@@ -885,7 +913,8 @@ int gamma_hip_destroy(gamma_hip_index* h) {
                       &h->w_exact, &h->w_selv, &h->w_selp, &h->w_x, &h->w_outd, &h->w_outl, &h->w_stage,
                       &h->w_filter, &h->w_m_dis, &h->w_m_ids, &h->w_part_v, &h->w_part_i, &h->w_assign,
                       &h->w_codes_tmp, &h->w_qperm, &h->w_scnt, &h->w_sflag, &h->w_surv, &h->w_pair_base,
-                      &h->w_pair_ip, &h->w_flat_cand, &h->w_flat_meta};
+                      &h->w_pair_ip, &h->w_flat_cand, &h->w_flat_meta, &h->w_full_cdis,
+                      &h->w_full_probe};
     for (DevBuf* b : bufs) b->release();
     (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1520,13 +1549,10 @@ int gamma_hip_ivfpq_coarse_device(gamma_hip_index* h, const gamma_hip_search_par
     gamma_hip_search_params pp = *p;   // the caller resolves -1 on the size of the whole batch; a slice
     if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;   // that arrives unresolved decides by itself
     p = &pp;
-    const int chunk = query_chunk(h, nq, P);
-    for (int q0 = 0; q0 < nq; q0 += chunk) {
-        const int nc = std::min(chunk, nq - q0);
-        GH_TRY(ivfpq_coarse(h, p, nc, d_x + (size_t)q0 * h->d));
-        GH_CHECK(h, hipMemcpyAsync(d_coarse_dis + (size_t)q0 * P, h->w_coarse_dis.p, (size_t)nc * P * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-        GH_CHECK(h, hipMemcpyAsync(d_probe + (size_t)q0 * P, h->w_probe.p, (size_t)nc * P * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
-    }
+    const int chunk = coarse_chunk(h, nq);
+    for (int q0 = 0; q0 < nq; q0 += chunk)
+        GH_TRY(ivfpq_coarse(h, p, std::min(chunk, nq - q0), d_x + (size_t)q0 * h->d, d_coarse_dis + (size_t)q0 * P,
+                            d_probe + (size_t)q0 * P));
     GH_CHECK(h, hipGetLastError());
     return GAMMA_HIP_OK;
 }

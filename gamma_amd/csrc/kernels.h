@@ -83,9 +83,9 @@ void launch_pair_ip(hipStream_t s, const float* x, const float* cc, const int* p
 struct ScanBound {
     unsigned long long* ready;  // [nq] 0 = not yet published; (1 << 32 | key bound) = bound valid;
                                 // (2 << 32) = no bound (unfiltered selection); zeroed per launch
-    unsigned long long* surv;   // [nq][groups - 1][scan_slice_cap()] survivors of each consumer workgroup,
+    unsigned long long* surv;   // [nq][groups][scan_slice_cap()] candidates within the bound, per workgroup,
                                 // as (key << 32 | position in the query's segment)
-    int* gcnt;                  // [nq][groups - 1] survivors per slice; > scan_slice_cap() = overflowed
+    int* gcnt;                  // [nq][groups] items per slice; > scan_slice_cap() = overflowed
     int K;                      // recall_num
 };
 int scan_slice_cap();

@@ -967,7 +967,7 @@ __device__ __forceinline__ uint32_t dis_key(float v) {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr uint32_t KEY_SENTINEL = 0xff800000u;   // key of the filtered-entry marker (+inf / -inf)
 constexpr int SCAN_STAGE = 256;                  // survivors staged in LDS per workgroup
-constexpr int SCAN_SLICE = 512;                  // survivor slice of one consumer workgroup (global)
+constexpr int SCAN_SLICE = 1024;                 // candidate slice of one workgroup (global); a producer needs recall_num + one histogram bin
 constexpr int SCAN_BATCH = 64;                   // queries per XCD by which producers run ahead
 
 // amdgpu_num_sgpr(96): 8 waves per SIMD need <= 96 SGPRs each (800 per SIMD); the FILT variant
@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
                 const unsigned long long item = ((unsigned long long)key << 32) | (unsigned)pos;
                 if (at < SCAN_STAGE) s_stage[at] = item;
                 else if (at < SCAN_SLICE)   // staging full (rare): the slot number is already unique
-                    sb.surv[((int64_t)q * (pg_cnt - 1) + (pg - 1)) * SCAN_SLICE + at] = item;
+                    sb.surv[((int64_t)q * pg_cnt + pg) * SCAN_SLICE + at] = item;
             }
         }
     };
@@ -1075,7 +1075,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
     auto flush = [&]() {   // whole workgroup
         __syncthreads();
         const int n = s_nstage;
-        const int64_t slice = (int64_t)q * (pg_cnt - 1) + (pg - 1);
+        const int64_t slice = (int64_t)q * pg_cnt + pg;
         if (threadIdx.x == 0) sb.gcnt[slice] = n;
         for (int i = threadIdx.x; i < min(n, SCAN_STAGE); i += 256) sb.surv[slice * SCAN_SLICE + i] = s_stage[i];
     };
@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
             if (l >= 0 && l < nlist && (!list_mask || list_mask[l]) && list_len[l] > 0) any = true;
         }
         if (!any) {   // uniform
-            if (FILT && threadIdx.x == 0) sb.gcnt[(int64_t)q * (pg_cnt - 1) + (pg - 1)] = 0;
+            if (FILT && threadIdx.x == 0) sb.gcnt[(int64_t)q * pg_cnt + pg] = 0;
             return;
         }
     }
@@ -1398,6 +1398,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
         if (threadIdx.x == 0)
             __hip_atomic_store(&sb.ready[q], tau < KEY_SENTINEL ? ((1ull << 32) | tau) : (2ull << 32),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the group's own candidates within the bound become its survivor slice (slice 0), like a
+        // consumer's: k_select_final then reads a few hundred items per query and never the distance
+        // buffer (one wave walking a long first group -- 24 k candidates at C4 -- was the slow part)
+        if (tau < KEY_SENTINEL) {   // uniform
+            __syncthreads();        // the histogram (aliasing the staging area) has been read
+            for (int i0 = 0; i0 < n0; i0 += 256 * 8) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) t[u] = o0[min(i0 + u * 256 + (int)threadIdx.x, n0 - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int idx = i0 + u * 256 + (int)threadIdx.x;
+                    const uint32_t key = dis_key<L2>(t[u]);
+                    append(idx < n0 && key <= tau, key, idx);
+                }
+            }
+        }
+        flush();   // without a bound: count 0
     }
 }
 

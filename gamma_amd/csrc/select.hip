@@ -675,37 +675,15 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
     int* hist = s_hist[w];
     unsigned long long* cand = s_cand[w];
     unsigned long long* runs = cand;
-    const uint32_t tauq = (uint32_t)word;
     const int* goff = pair_off + (int64_t)q * (P + 1);
     int* off = s_off[w];        // this query's pair offsets (P + 1 <= PMAX + 1 entries, see the launcher)
     for (int i = lane; i <= P; i += 64) off[i] = goff[i];
     int64_t* lbase = s_base[w];   // arena offset of each probed list (k_pair_offsets): no probe_list ->
     for (int i = lane; i < P; i += 64) lbase[i] = pair_base[(int64_t)q * P + i];   // list_off chain at the end
-    const int n0 = goff[min(G, P)];
-    const float* v = vals + (int64_t)q * seg_stride;
-    // ---- gather the candidate set into LDS: the first probe group's distances within the bound
-    //      (straight from the distance buffer) + the survivors the other groups appended ----
+    // ---- gather the candidate set into LDS: the survivor slices (slice 0 = the first probe group's own
+    //      candidates within the bound, appended by its producer workgroup) ----
     int c = 0;
     uint32_t mn = 0xffffffffu, mx = 0u;
-    for (int i0 = 0; i0 < n0; i0 += 64 * 8) {
-        float t[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) t[u] = v[min(i0 + u * 64 + lane, n0 - 1)];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int idx = i0 + u * 64 + lane;
-            const uint32_t key = sel_key<SMALLEST>(t[u]);
-            const bool keep = idx < n0 && key <= tauq;
-            const unsigned long long bal = __ballot(keep);
-            if (keep) {
-                const int at = c + __popcll(bal & ((1ull << lane) - 1ull));
-                if (at < SF_CAND) cand[at] = ((unsigned long long)key << 32) | (unsigned)idx;
-                mn = key < mn ? key : mn;
-                mx = key > mx ? key : mx;
-            }
-            c += __popcll(bal);
-        }
-    }
     const unsigned long long* src = surv + (int64_t)q * nslices * slice_cap;
     for (int g0 = 0; g0 < nslices; g0 += 8) {   // the first 64 items of 8 slices in flight at once
         int cg[8];
@@ -743,17 +721,6 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
                 body(i0 + lane < c, (uint32_t)(item >> 32), item);
             }
             return;
-        }
-        for (int i0 = 0; i0 < n0; i0 += 64 * 8) {
-            float t[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) t[u] = v[min(i0 + u * 64 + lane, n0 - 1)];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int idx = i0 + u * 64 + lane;
-                const uint32_t key = sel_key<SMALLEST>(t[u]);
-                body(idx < n0 && key <= tauq, key, ((unsigned long long)key << 32) | (unsigned)idx);
-            }
         }
         for (int g = 0; g < nslices; g++) {
             const int cg = __shfl(my_cnt, g, 64);

@@ -100,7 +100,7 @@ void* gamma_hip_stream(gamma_hip_index* h);
 int gamma_hip_synchronize(gamma_hip_index* h);
 
 /* Upper bound in bytes of the per-chunk workspaces (coarse distance matrix, ADC distance buffer);
- * larger calls are processed in chunks of queries.  Default 8 GiB. */
+ * larger calls are processed in chunks of queries.  Default: an eighth of the device memory, 1 to 32 GiB. */
 int gamma_hip_set_workspace_budget(gamma_hip_index* h, int64_t bytes);
 
 /* ---- numeric scalar columns for on-device range filters (docid = row).  The engine side
