@@ -12,8 +12,12 @@
 
 #include <algorithm>
 #include <map>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.h"
@@ -123,6 +127,28 @@ struct gamma_hip_index {
 
     // last-search stage info
     int last_nq = 0, last_P = 0, last_R = 0;
+
+    // request combining of small concurrent host-buffer searches (gamma_hip_ivfpq_search)
+    struct Waiter {
+        const gamma_hip_search_params* p;
+        int nq, k, mode;   // mode: coarse path resolved from THIS request's size
+        const float* x;
+        float* D;
+        int64_t* I;
+        int rc = 0;
+        bool done = false;
+        std::condition_variable cv;   // woken when done
+    };
+    std::mutex comb_mu;
+    std::condition_variable comb_wcv;   // the worker waits here
+    std::deque<Waiter*> comb_q;
+    bool comb_busy = false;             // a batch (or a direct call) is in flight
+    bool comb_stop = false;
+    std::thread comb_thread;
+    bool combine = getenv("GAMMA_HIP_NO_COMBINE") == nullptr;
+    // pinned staging of the combined batches, two sets (only the worker touches them)
+    void* comb_pin[2] = {nullptr, nullptr};
+    size_t comb_pin_bytes[2] = {0, 0};
 
     // profiling
     bool profile = false;
@@ -830,8 +856,10 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
 }
 
 // host-pointer wrapper shared by ivfpq / flat
+// sync = false: everything is only enqueued (pinned host buffers); the caller synchronises the stream
 template <typename F>
-int host_search(H* h, int nq, int d, const float* x, int k, float* distances, int64_t* labels, F&& f) {
+int host_search(H* h, int nq, int d, const float* x, int k, float* distances, int64_t* labels, F&& f,
+                bool sync = true) {
     if (nq <= 0 || k <= 0) return f(nullptr, nullptr, nullptr);
     GH_CHECK(h, hipSetDevice(h->device));
     GH_CHECK(h, h->w_x.ensure((size_t)nq * d * sizeof(float)));
@@ -841,7 +869,7 @@ int host_search(H* h, int nq, int d, const float* x, int k, float* distances, in
     GH_TRY(f(h->w_x.as<float>(), h->w_outd.as<float>(), h->w_outl.as<int64_t>()));
     GH_CHECK(h, hipMemcpyAsync(distances, h->w_outd.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     GH_CHECK(h, hipMemcpyAsync(labels, h->w_outl.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    if (sync) GH_CHECK(h, hipStreamSynchronize(h->stream));
     return GAMMA_HIP_OK;
 }
 
@@ -895,6 +923,12 @@ int gamma_hip_create(int device, gamma_hip_index** out) {
 
 int gamma_hip_destroy(gamma_hip_index* h) {
     if (!h) return GAMMA_HIP_OK;
+    {
+        std::unique_lock<std::mutex> lk(h->comb_mu);
+        h->comb_stop = true;
+        h->comb_wcv.notify_all();
+    }
+    if (h->comb_thread.joinable()) h->comb_thread.join();
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (auto& e : h->events) {
@@ -908,6 +942,8 @@ int gamma_hip_destroy(gamma_hip_index* h) {
     for (auto& kv : h->fields)
         if (kv.second.d) (void)hipFree(kv.second.d);
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
+    for (void* pp : h->comb_pin)
+        if (pp) (void)hipHostFree(pp);
     DevBuf* bufs[] = {&h->w_mat, &h->w_coarse_dis, &h->w_probe, &h->w_xn, &h->w_st2, &h->w_pair_off,
                       &h->w_qtotal, &h->w_dist, &h->w_cand_dis, &h->w_cand_pos, &h->w_cand_ids,
                       &h->w_exact, &h->w_selv, &h->w_selp, &h->w_x, &h->w_outd, &h->w_outl, &h->w_stage,
@@ -1481,15 +1517,177 @@ int gamma_hip_ivfpq_search_device(gamma_hip_index* h, const gamma_hip_search_par
     return ivfpq_search_device_locked(h, p, nq, d_x, k, d_distances, d_labels);
 }
 
-int gamma_hip_ivfpq_search(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x,
-                           int k, float* distances, int64_t* labels) {
-    if (!h) return GAMMA_HIP_EINVAL;
+static int ivfpq_search_host_locked(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x,
+                                   int k, float* distances, int64_t* labels) {
     std::lock_guard<std::mutex> g(h->mu);
     GH_TRY(ivfpq_check(h, p, nq, k));
     if (nq > 0 && k > 0 && (!x || !distances || !labels)) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
     return host_search(h, nq, h->d, x, k, distances, labels, [&](const float* dx, float* dd, int64_t* dl) {
         return ivfpq_search_device_locked(h, p, nq, dx, k, dd, dl);
     });
+}
+
+// Search is re-entrant in the reference and is called from many client threads at once, typically with
+// one query each (tools/perf.cc).  One GPU stream serves one call at a time, so small calls
+// that arrive while another is in flight are COMBINED: they queue, and a worker thread of the handle
+// (the reference's GPU model funnels its searches through one thread as well) takes every queued
+// request with the same parameters, runs them as one batch and hands the results back.  A call that
+// finds the handle idle runs directly on the caller's thread.
+// Results are those of the separate calls: rows are independent, and the coarse path (exact below 20
+// queries, GEMM form from 20 on, faiss:utils/distances.cpp:346) is the one each request's OWN size
+// selects -- requests only share a batch with requests that resolve to the same path.
+constexpr int COMB_MAX_NQ = 256, COMB_MAX_TOTAL = 4096;
+
+static void combine_worker(gamma_hip_index* h) {
+    using W = gamma_hip_index::Waiter;
+    auto same = [](const W* a, const W* b) {
+        return a->k == b->k && a->mode == b->mode && a->p->metric == b->p->metric && a->p->nprobe == b->p->nprobe &&
+               a->p->recall_num == b->p->recall_num && a->p->has_rank == b->p->has_rank &&
+               a->p->min_score == b->p->min_score && a->p->max_score == b->p->max_score;
+    };
+    // a batch in flight: its requests, where its results land, whether the stream still has to be awaited
+    struct Batch {
+        std::vector<W*> grp;
+        int rc = GAMMA_HIP_OK, total = 0, kk = 0;
+        float* sd = nullptr;
+        int64_t* si = nullptr;
+        bool enqueued = false;
+    };
+    // results -> callers, wake them (no lock needed for the copies: the callers are blocked)
+    auto deliver = [&](Batch& b, std::unique_lock<std::mutex>& lk) {
+        if (b.grp.empty()) return;
+        if (b.rc == GAMMA_HIP_OK && b.sd) {
+            size_t at = 0;
+            for (W* g : b.grp) {
+                std::memcpy(g->D, b.sd + at * b.kk, (size_t)g->nq * b.kk * sizeof(float));
+                std::memcpy(g->I, b.si + at * b.kk, (size_t)g->nq * b.kk * sizeof(int64_t));
+                at += g->nq;
+            }
+        }
+        lk.lock();
+        for (W* g : b.grp) {
+            g->rc = b.rc;
+            g->done = true;
+            g->cv.notify_one();
+        }
+        lk.unlock();
+        b.grp.clear();
+    };
+    Batch prev, cur;
+    int set = 0;
+    std::unique_lock<std::mutex> lk(h->comb_mu);
+    for (;;) {
+        h->comb_wcv.wait(lk, [&] { return h->comb_stop || (!h->comb_busy && !h->comb_q.empty()); });
+        if (h->comb_stop) break;
+        h->comb_busy = true;
+        // Pipeline: while batch N runs on the GPU its predecessor's results are copied out and its callers
+        // woken (64 futex wakes cost as much as the batch itself); the handle stays busy until the queue
+        // is drained.
+        for (;;) {
+            cur = Batch();
+            if (!h->comb_q.empty()) {   // one group: the oldest request and everything compatible with it
+                W* first = h->comb_q.front();
+                for (auto it = h->comb_q.begin(); it != h->comb_q.end();) {
+                    if (same(first, *it) && (cur.grp.empty() || cur.total + (*it)->nq <= COMB_MAX_TOTAL)) {
+                        cur.total += (*it)->nq;
+                        cur.grp.push_back(*it);
+                        it = h->comb_q.erase(it);
+                    } else {
+                        ++it;
+                    }
+                }
+            }
+            lk.unlock();
+            if (!cur.grp.empty()) {
+                W* first = cur.grp.front();
+                gamma_hip_search_params pp = *first->p;
+                pp.coarse_mode = first->mode;
+                const int d = h->d, kk = first->k, total = cur.total;
+                cur.kk = kk;
+                const size_t bx = (size_t)total * d * sizeof(float), bd = (size_t)total * kk * sizeof(float),
+                             bi = (size_t)total * kk * sizeof(int64_t);
+                const size_t off_i = (bx + 15) & ~(size_t)15, off_d = off_i + ((bi + 15) & ~(size_t)15),
+                             need = off_d + bd;
+                if (need > h->comb_pin_bytes[set]) {
+                    if (h->comb_pin[set]) (void)hipHostFree(h->comb_pin[set]);
+                    h->comb_pin[set] = nullptr;
+                    h->comb_pin_bytes[set] = 0;
+                    if (hipSetDevice(h->device) == hipSuccess &&
+                        hipHostMalloc(&h->comb_pin[set], need * 2, hipHostMallocDefault) == hipSuccess)
+                        h->comb_pin_bytes[set] = need * 2;
+                    else
+                        cur.rc = GAMMA_HIP_ENOMEM;
+                }
+                if (cur.rc == GAMMA_HIP_OK) {
+                    char* base = static_cast<char*>(h->comb_pin[set]);
+                    float* sx = reinterpret_cast<float*>(base);
+                    cur.si = reinterpret_cast<int64_t*>(base + off_i);
+                    cur.sd = reinterpret_cast<float*>(base + off_d);
+                    size_t at = 0;
+                    for (W* g : cur.grp) {
+                        std::memcpy(sx + at * d, g->x, (size_t)g->nq * d * sizeof(float));
+                        at += g->nq;
+                    }
+                    h->mu.lock();   // held until the batch has been awaited (below)
+                    cur.rc = ivfpq_check(h, &pp, total, kk);
+                    if (cur.rc == GAMMA_HIP_OK)
+                        cur.rc = host_search(h, total, d, sx, kk, cur.sd, cur.si,
+                                             [&](const float* dx, float* dd, int64_t* dl) {
+                                                 return ivfpq_search_device_locked(h, &pp, total, dx, kk, dd, dl);
+                                             },
+                                             /*sync=*/false);
+                    cur.enqueued = true;
+                }
+                set ^= 1;
+            }
+            deliver(prev, lk);   // overlaps with cur on the GPU
+            if (cur.enqueued) {
+                if (hipStreamSynchronize(h->stream) != hipSuccess && cur.rc == GAMMA_HIP_OK) cur.rc = GAMMA_HIP_EDEVICE;
+                h->mu.unlock();
+                cur.enqueued = false;
+            }
+            prev = std::move(cur);
+            lk.lock();
+            if (h->comb_q.empty()) break;
+        }
+        lk.unlock();
+        deliver(prev, lk);
+        lk.lock();
+        h->comb_busy = false;
+    }
+}
+
+static int combined_search(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x, int k,
+                           float* distances, int64_t* labels) {
+    gamma_hip_index::Waiter w;
+    w.p = p; w.nq = nq; w.k = k; w.x = x; w.D = distances; w.I = labels;
+    w.mode = p->coarse_mode < 0 ? (nq < 20 ? 0 : 1) : p->coarse_mode;
+    std::unique_lock<std::mutex> lk(h->comb_mu);
+    if (!h->comb_busy && h->comb_q.empty()) {   // idle handle: run on this thread, no hop
+        h->comb_busy = true;
+        lk.unlock();
+        gamma_hip_search_params pp = *p;
+        pp.coarse_mode = w.mode;
+        const int rc = ivfpq_search_host_locked(h, &pp, nq, x, k, distances, labels);
+        lk.lock();
+        h->comb_busy = false;
+        if (!h->comb_q.empty()) h->comb_wcv.notify_one();
+        return rc;
+    }
+    if (!h->comb_thread.joinable()) h->comb_thread = std::thread(combine_worker, h);
+    h->comb_q.push_back(&w);
+    h->comb_wcv.notify_one();
+    w.cv.wait(lk, [&] { return w.done; });
+    return w.rc;
+}
+
+int gamma_hip_ivfpq_search(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x,
+                           int k, float* distances, int64_t* labels) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    if (h->combine && p && nq > 0 && nq <= COMB_MAX_NQ && k > 0 && x && distances && labels && !p->has_range &&
+        p->n_range == 0 && p->n_field == 0 && h->ivf_init && h->d > 0)
+        return combined_search(h, p, nq, x, k, distances, labels);
+    return ivfpq_search_host_locked(h, p, nq, x, k, distances, labels);
 }
 
 int gamma_hip_ivfpq_last_stages(gamma_hip_index* h, float* coarse_dis, int64_t* coarse_idx,

@@ -5,6 +5,9 @@
 #include <string.h>
 
 #include <string>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "gamma_index_ivfpq_hip.h"
@@ -126,6 +129,33 @@ int gh_host_search_filtered(void *hp, const char *retrieval_params, int has_rank
   cond.retrieval_params_ = h->model->Parse(retrieval_params);
   if (!cond.retrieval_params_) return -100;
   return h->model->Search(&cond, n, reinterpret_cast<const uint8_t *>(x), k, distances, ids);
+}
+// Closed-loop clients, the pattern of the reference's tools/perf.cc: `nthreads` threads, each issuing
+// `calls` Search calls of `nq_call` queries taken round-robin from a pool of `npool` queries.  Returns the
+// wall time in seconds (< 0 on error); lat_us[nthreads * calls] receives every call's latency.
+double gh_host_concurrent_clients(void *hp, const char *retrieval_params, int has_rank, int nthreads, int calls,
+                                  int nq_call, const float *pool, int npool, int d, int k, float *lat_us) {
+  std::vector<std::thread> th;
+  std::atomic<int> failed(0);
+  auto t0 = std::chrono::steady_clock::now();
+  for (int t = 0; t < nthreads; t++) {
+    th.emplace_back([=, &failed]() {
+      std::vector<float> D((size_t)nq_call * k);
+      std::vector<int64_t> I((size_t)nq_call * k);
+      for (int i = 0; i < calls; i++) {
+        const int at = (int)(((int64_t)(t * calls + i) * nq_call) % std::max(1, npool - nq_call + 1));
+        auto a = std::chrono::steady_clock::now();
+        int rc = gh_host_search(hp, retrieval_params, has_rank, 0, -1e30f, 1e30f, nq_call, pool + (size_t)at * d, k,
+                                D.data(), I.data());
+        auto b = std::chrono::steady_clock::now();
+        if (rc) failed++;
+        if (lat_us) lat_us[(size_t)t * calls + i] = std::chrono::duration<float, std::micro>(b - a).count();
+      }
+    });
+  }
+  for (auto &x : th) x.join();
+  double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return failed.load() ? -1.0 : dt;
 }
 int gh_host_dump(void *hp, const char *dir) { return ((Host *)hp)->model->Dump(dir); }
 int gh_host_load(void *hp, const char *dir) { return ((Host *)hp)->model->Load(dir); }

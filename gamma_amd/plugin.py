@@ -28,6 +28,8 @@ HOST_SYMBOLS = {
     "gh_host_search_filtered": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_float, C.c_float,
                                           C.c_int, f32p, C.c_int, f32p, i64p, C.c_int, i64p,
                                           C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gh_host_concurrent_clients": (C.c_double, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, f32p,
+                                                C.c_int, C.c_int, C.c_int, f32p]),
     "gh_host_dump": (C.c_int, [C.c_void_p, C.c_char_p]),
     "gh_host_load": (C.c_int, [C.c_void_p, C.c_char_p]),
     "gh_host_mem_bytes": (C.c_long, [C.c_void_p]),
@@ -177,6 +179,16 @@ class PluginModel:
         if rc:
             raise _lib.GammaHipError("Search returned %d" % rc)
         return D, I
+
+    def concurrent_clients(self, pool, retrieval_params, nthreads, calls, nq_call=1, k=10, has_rank=True):
+        """closed-loop client threads (C++ threads, no GIL): returns (wall seconds, latencies in us)"""
+        pool = np.ascontiguousarray(pool, dtype=np.float32)
+        lat = np.empty(nthreads * calls, dtype=np.float32)
+        dt = self.L.gh_host_concurrent_clients(self.h, retrieval_params.encode(), int(has_rank), nthreads, calls,
+                                               nq_call, _f(pool), pool.shape[0], pool.shape[1], k, _f(lat))
+        if dt < 0:
+            raise _lib.GammaHipError("a Search call failed")
+        return dt, lat
 
     def dump(self, d):
         return self.L.gh_host_dump(self.h, d.encode())

@@ -610,6 +610,46 @@ def test_concurrent_search_and_add_on_one_handle(case):
         g.close()
 
 
+def test_concurrent_small_searches_are_combined_and_exact(case, hip):
+    """Many client threads with one or a few queries each (the engine's serving pattern): requests that
+    arrive while the GPU is busy share a batch.  Every result must be bit-identical to the same call made
+    alone -- including the coarse path, which each request's OWN size selects (exact below 20 queries)."""
+    import threading
+    q = synth.sift_like(480, d=case["d"], seed=515)
+    variants = [
+        (1, api.SearchArgs(metric=api.METRIC_L2, nprobe=8, recall_num=100, has_rank=True, **WIDE), 10),
+        (3, api.SearchArgs(metric=api.METRIC_L2, nprobe=8, recall_num=100, has_rank=True, **WIDE), 10),
+        (1, api.SearchArgs(metric=api.METRIC_IP, nprobe=12, recall_num=60, has_rank=False, **WIDE), 5),
+        (24, api.SearchArgs(metric=api.METRIC_L2, nprobe=8, recall_num=100, has_rank=True, **WIDE), 10),   # GEMM-form coarse
+    ]
+    # the answers of the calls made one at a time
+    want = {}
+    for v, (n, args, k) in enumerate(variants):
+        for i0 in range(0, 480 - n + 1, n):
+            want[(v, i0)] = hip.ivfpq_search(q[i0:i0 + n], k, args)
+    errors = []
+
+    def client(t):
+        try:
+            rng = np.random.default_rng(t)
+            for it in range(60):
+                v = int(rng.integers(0, len(variants)))
+                n, args, k = variants[v]
+                i0 = int(rng.integers(0, (480 - n) // n + 1)) * n
+                D, I = hip.ivfpq_search(q[i0:i0 + n], k, args)
+                Dw, Iw = want[(v, i0)]
+                assert D.tobytes() == Dw.tobytes() and np.array_equal(I, Iw), (t, it, v, i0)
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=client, args=(t,)) for t in range(16)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:3]
+
+
 def test_field_filters_on_device(case):
     """Scalar range filters evaluated on device columns == the same selection handed over as a
     host-built RangeQueryResult bitmap (reference semantics: IsInRange<T>, AND of the clauses,
