@@ -606,8 +606,8 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
         static const bool dbg = getenv("GAMMA_HIP_BOUND_DBG") != nullptr;
         static int shown = 0;
         StageScope t(h, GAMMA_HIP_STAGE_SELECT);
-        gh::launch_select_final(s, l2, sb.surv, sb.gcnt, nsl, cap, sb.ready, h->w_dist.as<float>(), q_stride,
-                                h->w_pair_off.as<int>(), P, G, nq, R, h->w_pair_base.as<int64_t>(), h->d_ids,
+        gh::launch_select_final(s, l2, sb.surv, sb.gcnt, nsl, cap, sb.ready, h->w_pair_off.as<int>(), P, nq, R,
+                                h->w_pair_base.as<int64_t>(), h->d_ids,
                                 h->w_sflag.as<uint8_t>(), out_dis,
                                 h->w_cand_pos.as<int>(), out_ids);
         gh::launch_select_topk(s, l2, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), 0,

@@ -108,9 +108,8 @@ void launch_select_topk(hipStream_t s, bool smallest, const float* vals, int64_t
 // threshold pre-filter of the scan: exact top-K from the survivor lists (select.hip); rows that end
 // with flag != 0 are left to launch_select_topk(..., only = flag)
 void launch_select_final(hipStream_t s, bool smallest, const unsigned long long* surv, const int* gcnt,
-                         int nslices, int slice_cap, const unsigned long long* ready, const float* vals,
-                         int64_t seg_stride, const int* pair_off, int P, int G, int nq, int K,
-                         const int64_t* pair_base, const int64_t* ids, uint8_t* flag, float* out_vals,
+                         int nslices, int slice_cap, const unsigned long long* ready, const int* pair_off, int P,
+                         int nq, int K, const int64_t* pair_base, const int64_t* ids, uint8_t* flag, float* out_vals,
                          int* out_pos, int64_t* out_ids);
 void launch_map_candidates(hipStream_t s, const int* pos, int nq, int R, int P,
                            const int* probe_list, const int* pair_off, const int64_t* list_off,

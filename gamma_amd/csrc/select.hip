@@ -649,9 +649,7 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
                                                       const int* __restrict__ gcnt, int nslices,
                                                       int slice_cap,
                                                       const unsigned long long* __restrict__ ready,
-                                                      const float* __restrict__ vals,
-                                                      int64_t seg_stride, const int* __restrict__ pair_off,
-                                                      int P, int G, int nq, int K,
+                                                      const int* __restrict__ pair_off, int P, int nq, int K,
                                                       const int64_t* __restrict__ pair_base,
                                                       const int64_t* __restrict__ ids,
                                                       uint8_t* __restrict__ flag,
@@ -1239,15 +1237,14 @@ void launch_select_topk(hipStream_t s, bool smallest, const float* vals, int64_t
 }
 
 void launch_select_final(hipStream_t s, bool smallest, const unsigned long long* surv, const int* gcnt,
-                         int nslices, int slice_cap, const unsigned long long* ready, const float* vals,
-                         int64_t seg_stride, const int* pair_off, int P, int G, int nq, int K,
-                         const int64_t* pair_base, const int64_t* ids, uint8_t* flag, float* out_vals,
+                         int nslices, int slice_cap, const unsigned long long* ready, const int* pair_off, int P,
+                         int nq, int K, const int64_t* pair_base, const int64_t* ids, uint8_t* flag, float* out_vals,
                          int* out_pos, int64_t* out_ids) {
     if (nq <= 0) return;
     if (P > 128 || nslices > 64) abort();   // callers gate on this (gamma_hip.cpp, ivfpq_stage_a)
 #define GH_SF(SM, PM)                                                                                        \
     hipLaunchKernelGGL((k_select_final<SM, PM>), dim3((nq + 3) / 4), dim3(256), 0, s, surv, gcnt, nslices,   \
-                       slice_cap, ready, vals, seg_stride, pair_off, P, G, nq, K, pair_base, ids, flag,      \
+                       slice_cap, ready, pair_off, P, nq, K, pair_base, ids, flag,                           \
                        out_vals, out_pos, out_ids)
     if (smallest) {
         if (P <= 64) GH_SF(true, 64);
