@@ -1492,11 +1492,24 @@ int gamma_hip_ivfpq_add(gamma_hip_index* h, int64_t n, const float* vecs, int64_
         if (lno[i] < 0) lno[i] = (first_vid + i) % h->nlist;
         order[i] = i;
     }
+    // list-sharded index: every shard is handed the same batch and keeps the vectors whose list it owns
+    // (realtime inserts route to the owner of the assigned list) -- no exchange needed
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        if (!h->h_list_mask.empty()) {
+            int64_t m = 0;
+            for (int64_t i = 0; i < n; i++)
+                if (h->h_list_mask[lno[i]]) order[m++] = i;
+            order.resize(m);
+        }
+    }
+    const int64_t nkeep = (int64_t)order.size();
+    if (nkeep == 0) return GAMMA_HIP_OK;
     std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return lno[a] < lno[b]; });
     std::vector<int32_t> lists, counts;
-    std::vector<int64_t> vids(n);
-    std::vector<uint8_t> gcodes((size_t)n * cs);
-    for (int64_t i = 0; i < n; i++) {
+    std::vector<int64_t> vids(nkeep);
+    std::vector<uint8_t> gcodes((size_t)nkeep * cs);
+    for (int64_t i = 0; i < nkeep; i++) {
         const int64_t src = order[i];
         vids[i] = first_vid + src;
         memcpy(gcodes.data() + (size_t)i * cs, codes.data() + (size_t)src * cs, cs);

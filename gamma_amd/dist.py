@@ -62,6 +62,15 @@ class HipShardBackend:
     def empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, device=self.device)
 
+    def add(self, vecs, first_vid):
+        """Realtime insert on a list-sharded index: EVERY rank calls this with the same batch (host
+        array [n, d], vids first_vid ..).  The raw store is replicated; the handle, whose list mask
+        says which lists this rank owns (GammaHip.set_list_mask), encodes the batch and keeps only
+        the vectors assigned to its own lists -- the insert reaches the owner of the list without
+        any exchange."""
+        self.g.raw_append(vecs)
+        self.g.add(vecs, first_vid)
+
     def coarse(self, x, args, cdis, probe):
         """coarse assignment of the rows of x into the preallocated cdis/probe [n, nprobe]"""
         if x.shape[0]:

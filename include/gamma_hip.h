@@ -152,7 +152,9 @@ int64_t gamma_hip_ivfpq_list_size(gamma_hip_index* h, int list_no);
 int64_t gamma_hip_ivfpq_list_capacity(gamma_hip_index* h, int list_no);
 /* RealTimeMemData::RetrieveCodes ("for unit test", realtime_mem_data.h:95-96) */
 int gamma_hip_ivfpq_get_list(gamma_hip_index* h, int list_no, int64_t* vids, uint8_t* codes);
-/* restrict the scan to the lists a shard owns (multi-GPU list sharding): owner[l] != 0 */
+/* restrict the scan to the lists a shard owns (multi-GPU list sharding): owner[l] != 0.  With a mask
+ * set, gamma_hip_ivfpq_add keeps only the vectors assigned to owned lists: every shard is handed the same
+ * batch, which routes realtime inserts to the owner of the list without any exchange. */
 int gamma_hip_ivfpq_set_list_mask(gamma_hip_index* h, const uint8_t* owned);
 
 /* device-side Add path (gamma_index_ivfpq.cc:424-512): assign + residual + PQ encode +

@@ -37,28 +37,10 @@ def _shard_handle(case, owner, s):
     return g
 
 
-@pytest.mark.parametrize("metric,has_rank,W,nq,P,d,M", [
-    (B.METRIC_L2, True, 2, 61, 8, 32, 8), (B.METRIC_L2, False, 2, 61, 8, 32, 8), (B.METRIC_IP, True, 2, 61, 8, 32, 8),
-    # enough queries x probes for 4 probes per scan workgroup: compacted probe lists + threshold
-    # pre-filter inside every shard
-    (B.METRIC_L2, True, 4, 603, 32, 32, 8), (B.METRIC_L2, False, 3, 603, 32, 32, 8),
-    (B.METRIC_IP, True, 4, 603, 32, 32, 8),
-    # enough queries that ONE workgroup takes all of a query's probes on the shard (bound from its own
-    # candidates, no consumers); with M = 16 / 32 the query table is computed inside the scan
-    (B.METRIC_L2, True, 4, 4200, 32, 64, 16), (B.METRIC_IP, True, 3, 4200, 32, 64, 16),
-    (B.METRIC_L2, False, 4, 4200, 32, 64, 32), (B.METRIC_L2, True, 2, 4200, 16, 32, 8),
-    # the reference's default nprobe (80) and beyond 128 probes (no pre-filter)
-    (B.METRIC_L2, True, 4, 700, 80, 32, 8), (B.METRIC_IP, True, 2, 4200, 80, 32, 8), (B.METRIC_L2, True, 3, 300, 150, 32, 8),
-])
-def test_shards_on_one_gpu(metric, has_rank, W, nq, P, d, M):
+def _sharded_vs_full(case, shards, full, metric, has_rank, W, nq, P):
     import torch
     from gamma_amd import api
     from gamma_amd import dist as gdist
-    case = fixtures.trained_case(d=d, nlist=64 if P <= 64 else 160, M=M, N=20000, nq=64, metric=B.METRIC_L2)
-    sizes = np.array([case["oracle"].list_size(l) for l in range(case["nlist"])])
-    owner = gdist.balance_lists(sizes, W)
-    full = fixtures.load_hip(case)
-    shards = [_shard_handle(case, owner, s) for s in range(W)]
     k, R = 10, 100                            # nq is not a multiple of W: padded slices
     args = api.SearchArgs(metric=metric, nprobe=P, recall_num=R, has_rank=has_rank, min_score=-3e38,
                           max_score=3e38, coarse_mode=1)
@@ -96,6 +78,31 @@ def test_shards_on_one_gpu(metric, has_rank, W, nq, P, d, M):
                               I[r * per:(r + 1) * per])
         shards[r].synchronize()
     compare_topk(Dref.cpu().numpy(), Iref.cpu().numpy(), D[:nq].cpu().numpy(), I[:nq].cpu().numpy())
+
+
+@pytest.mark.parametrize("metric,has_rank,W,nq,P,d,M", [
+    (B.METRIC_L2, True, 2, 61, 8, 32, 8), (B.METRIC_L2, False, 2, 61, 8, 32, 8), (B.METRIC_IP, True, 2, 61, 8, 32, 8),
+    # enough queries x probes for 4 probes per scan workgroup: compacted probe lists + threshold
+    # pre-filter inside every shard
+    (B.METRIC_L2, True, 4, 603, 32, 32, 8), (B.METRIC_L2, False, 3, 603, 32, 32, 8),
+    (B.METRIC_IP, True, 4, 603, 32, 32, 8),
+    # enough queries that ONE workgroup takes all of a query's probes on the shard (bound from its own
+    # candidates, no consumers); with M = 16 / 32 the query table is computed inside the scan
+    (B.METRIC_L2, True, 4, 4200, 32, 64, 16), (B.METRIC_IP, True, 3, 4200, 32, 64, 16),
+    (B.METRIC_L2, False, 4, 4200, 32, 64, 32), (B.METRIC_L2, True, 2, 4200, 16, 32, 8),
+    # the reference's default nprobe (80) and beyond 128 probes (no pre-filter)
+    (B.METRIC_L2, True, 4, 700, 80, 32, 8), (B.METRIC_IP, True, 2, 4200, 80, 32, 8), (B.METRIC_L2, True, 3, 300, 150, 32, 8),
+])
+def test_shards_on_one_gpu(metric, has_rank, W, nq, P, d, M):
+    import torch
+    from gamma_amd import api
+    from gamma_amd import dist as gdist
+    case = fixtures.trained_case(d=d, nlist=64 if P <= 64 else 160, M=M, N=20000, nq=64, metric=B.METRIC_L2)
+    sizes = np.array([case["oracle"].list_size(l) for l in range(case["nlist"])])
+    owner = gdist.balance_lists(sizes, W)
+    full = fixtures.load_hip(case)
+    shards = [_shard_handle(case, owner, s) for s in range(W)]
+    _sharded_vs_full(case, shards, full, metric, has_rank, W, nq, P)
     for g in shards + [full]:
         g.close()
 
@@ -156,3 +163,44 @@ def test_merge_of_shard_tables(metric, W, R, nql):
         assert np.array_equal(D[i, :m], want_d)
         assert np.all(I[i, m:] == -1)
     g.close()
+
+
+def test_sharded_realtime_inserts_route_to_the_list_owner():
+    """realtime inserts go to the GPU that owns the assigned list.  Every shard is handed the same
+    Add batches (engine-sized, 1000 vectors) and keeps what it owns (list mask): its lists must equal those of
+    an unsharded handle fed the same batches, the other lists stay empty, and the sharded search agrees."""
+    from gamma_amd import api
+    from gamma_amd import dist as gdist
+    case = fixtures.trained_case(d=32, nlist=64, M=8, N=20000, nq=64, metric=B.METRIC_L2)
+    W = 3
+    sizes = np.array([case["oracle"].list_size(l) for l in range(case["nlist"])])
+    owner = gdist.balance_lists(sizes, W)
+    base = case["base"]
+
+    def build(mask):
+        g = api.GammaHip(0)
+        g.ivfpq_init(case["d"], case["nlist"], case["M"], 8, case["metric"], 1000)
+        g.ivfpq_set_trained(case["cc"], case["pq"], None)
+        if mask is not None:
+            g.set_list_mask(mask)
+        g.raw_init(case["d"])
+        for i0 in range(0, len(base), 1000):
+            g.raw_append(base[i0:i0 + 1000])
+            g.add(base[i0:i0 + 1000], i0)
+        return g
+
+    full = build(None)
+    shards = [build((owner == s).astype(np.uint8)) for s in range(W)]
+    try:
+        for l in range(case["nlist"]):
+            ids, codes = full.get_list(l)
+            for s in range(W):
+                if owner[l] == s:
+                    gi, gc = shards[s].get_list(l)
+                    assert np.array_equal(ids, gi) and np.array_equal(codes, gc)
+                else:
+                    assert shards[s].list_size(l) == 0
+        _sharded_vs_full(case, shards, full, B.METRIC_L2, True, W, 603, 32)
+    finally:
+        for g in shards + [full]:
+            g.close()
