@@ -121,9 +121,14 @@ struct gamma_hip_index {
     DevBuf w_mat, w_coarse_dis, w_probe, w_xn, w_st2, w_pair_off, w_qtotal, w_dist, w_cand_dis,
             w_cand_pos, w_cand_ids, w_exact, w_selv, w_selp, w_x, w_outd, w_outl, w_stage, w_filter,
             w_m_dis, w_m_ids, w_part_v, w_part_i, w_assign, w_codes_tmp, w_qperm, w_scnt, w_sflag, w_surv, w_pair_base,
-            w_pair_ip, w_flat_cand, w_flat_meta, w_full_cdis, w_full_probe;
+            w_pair_ip, w_flat_cand, w_flat_meta, w_full_cdis, w_full_probe, w_ftab, w_qfil;
     unsigned long long* d_scan_codes = nullptr;
     size_t dist_budget_bytes = (size_t)8 << 30;   // per-chunk ADC distance buffer (288 GB of HBM per GPU)
+
+    // device copy of the filter table of the running call (entry 0 = the call's own descriptor) and the
+    // host image of what entry 0 holds, so an unchanged descriptor is not uploaded again
+    gh::FilterDesc ftab_shadow;
+    bool ftab_valid = false;
 
     // last-search stage info
     int last_nq = 0, last_P = 0, last_R = 0;
@@ -326,7 +331,9 @@ int add_keys_locked(H* h, int l, int n, const int64_t* vids, const uint8_t* code
     return publish_len(h, l);
 }
 
-int build_filter(H* h, const gamma_hip_search_params* p, gh::FilterDesc* f) {
+// off != nullptr: the range bitmaps go to w_filter at *off (advanced; the caller has sized w_filter for all
+// the requests of a combined batch); nullptr: a call of its own, bitmaps from offset 0
+int build_filter(H* h, const gamma_hip_search_params* p, gh::FilterDesc* f, size_t* off_io = nullptr) {
     memset(f, 0, sizeof(*f));
     f->del_bitmap = h->d_bitmap;
     f->del_bits = h->d_bitmap ? h->bitmap_bits : 0;
@@ -336,8 +343,8 @@ int build_filter(H* h, const gamma_hip_search_params* p, gh::FilterDesc* f) {
     if (f->n_range > 0) {
         size_t tot = 0;
         for (int i = 0; i < f->n_range; i++) tot += ((size_t)p->range[i].bitmap_bytes + 15) & ~(size_t)15;
-        GH_CHECK(h, h->w_filter.ensure(tot));
-        size_t off = 0;
+        if (!off_io) GH_CHECK(h, h->w_filter.ensure(tot));
+        size_t off = off_io ? *off_io : 0;
         for (int i = 0; i < f->n_range; i++) {
             const gamma_hip_range_filter& r = p->range[i];
             uint8_t* dst = h->w_filter.as<uint8_t>() + off;
@@ -350,6 +357,7 @@ int build_filter(H* h, const gamma_hip_search_params* p, gh::FilterDesc* f) {
             f->range[i].b_not_in = r.b_not_in;
             off += ((size_t)r.bitmap_bytes + 15) & ~(size_t)15;
         }
+        if (off_io) *off_io = off;
     }
     f->n_field = p->n_field;
     if (p->n_field < 0 || p->n_field > gh::kMaxField || (p->n_field > 0 && !p->field))
@@ -368,6 +376,34 @@ int build_filter(H* h, const gamma_hip_search_params* p, gh::FilterDesc* f) {
         fd.lo_f = ff.lower_f;
         fd.hi_f = ff.upper_f;
     }
+    return GAMMA_HIP_OK;
+}
+
+// What the scan needs to know about the validity predicates of a call: the device filter table, the
+// optional query -> entry map (combined batches of requests with their own filters), and whether
+// anything but the delete bitmap can reject an entry.
+struct FiltCtx {
+    const gh::FilterDesc* d_tab = nullptr;
+    const int* d_qf = nullptr;
+    bool any_clause = false;
+    FiltCtx at(int q0) const {   // the same context for the queries from q0 on
+        FiltCtx c = *this;
+        if (c.d_qf) c.d_qf += q0;
+        return c;
+    }
+};
+
+int filt_ctx_single(H* h, const gh::FilterDesc& f, FiltCtx* c) {
+    GH_CHECK(h, h->w_ftab.ensure(sizeof(gh::FilterDesc)));
+    if (!h->ftab_valid || memcmp(&h->ftab_shadow, &f, sizeof(f)) != 0) {
+        // the stream may still be reading the previous image: the copy is ordered behind it
+        h->ftab_shadow = f;
+        h->ftab_valid = true;
+        GH_CHECK(h, hipMemcpyAsync(h->w_ftab.p, &h->ftab_shadow, sizeof(f), hipMemcpyHostToDevice, h->stream));
+    }
+    c->d_tab = h->w_ftab.as<gh::FilterDesc>();
+    c->d_qf = nullptr;
+    c->any_clause = f.has_range || f.n_field > 0;
     return GAMMA_HIP_OK;
 }
 
@@ -469,7 +505,7 @@ int ivfpq_coarse(H* h, const gamma_hip_search_params* p, int nq, const float* d_
 
 // pre_dis / pre_probe: coarse assignment computed elsewhere (sharded search: the rank owning the
 // query slice), device pointers [nq*nprobe]; nullptr = run the coarse quantizer here
-int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& filt, int nq,
+int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int nq,
                   const float* d_x, int R, const float* pre_dis = nullptr, const int* pre_probe = nullptr,
                   bool shard = false, float* out_dis = nullptr, int64_t* out_ids = nullptr) {
     const int P = p->nprobe, d = h->d, M = h->M, nlist = h->nlist;
@@ -509,7 +545,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
     // ids are only read during the scan when something can reject an entry: a delete bit,
     // a range filter, or a superseded (bit 63) slot left behind by Update
     const int need_ids =
-            (filt.has_range || filt.n_field > 0 || (filt.del_bitmap && h->bitmap_any) || h->n_moved > 0) ? 1 : 0;
+            (fc.any_clause || (h->d_bitmap && h->bitmap_any) || h->n_moved > 0) ? 1 : 0;
     const int* qperm = nullptr;
     // Probes per workgroup.  Sharded search with a compacted assignment: a query keeps ~P/W probes on
     // this shard, all in its first group(s) -- the other P/G - 1 workgroups of the query would start only
@@ -579,7 +615,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const gh::FilterDesc& 
                                    dis0, h->d_cc, h->w_st2.as<float>(), h->d_T2,
                                    h->d_list_off, h->d_list_len, h->d_list_mask, nlist, h->d_codes,
                                    h->d_ids, h->w_pair_off.as<int>(), q_stride, h->w_dist.as<float>(),
-                                   filt, need_ids, qperm, gsz, pg_lo, pg_cnt, shard ? 1 : 0, bound,
+                                   fc.d_tab, fc.d_qf, need_ids, qperm, gsz, pg_lo, pg_cnt, shard ? 1 : 0, bound,
                                    fuse_ip ? h->d_pqc : nullptr);
     };
     if (!bounded) {
@@ -698,14 +734,21 @@ int scan_chunk(H* h, int nq, int P) {
 }
 int query_chunk(H* h, int nq, int P) { return std::min(coarse_chunk(h, nq), scan_chunk(h, nq, P)); }
 
+// given != nullptr: the filter context of a combined batch (p's own filter clauses are ignored)
 int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, int k,
-                               float* d_distances, int64_t* d_labels) {
+                               float* d_distances, int64_t* d_labels, const FiltCtx* given = nullptr) {
     GH_TRY(ivfpq_check(h, p, nq, k));
     if (k <= 0 || nq == 0) return GAMMA_HIP_OK;  // gamma_index_ivfpq.cc:753-756
     GH_CHECK(h, hipSetDevice(h->device));
     const int R = std::max(p->recall_num, k);
-    gh::FilterDesc filt;
-    GH_TRY(build_filter(h, p, &filt));
+    FiltCtx fc;
+    if (given) {
+        fc = *given;
+    } else {
+        gh::FilterDesc filt;
+        GH_TRY(build_filter(h, p, &filt));
+        GH_TRY(filt_ctx_single(h, filt, &fc));
+    }
     // faiss picks the coarse path from the size of the WHOLE call (faiss:utils/distances.cpp:346);
     // the internal chunks must not re-decide it
     gamma_hip_search_params pp = *p;
@@ -726,10 +769,10 @@ int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, c
     for (int q0 = 0; q0 < nq; q0 += chunk) {
         const int nc = std::min(chunk, nq - q0);
         if (coarse_first)
-            GH_TRY(ivfpq_stage_a(h, p, filt, nc, d_x + (size_t)q0 * h->d, R, h->w_full_cdis.as<float>() + (size_t)q0 * P,
-                                 h->w_full_probe.as<int>() + (size_t)q0 * P));
+            GH_TRY(ivfpq_stage_a(h, p, fc.at(q0), nc, d_x + (size_t)q0 * h->d, R,
+                                 h->w_full_cdis.as<float>() + (size_t)q0 * P, h->w_full_probe.as<int>() + (size_t)q0 * P));
         else
-            GH_TRY(ivfpq_stage_a(h, p, filt, nc, d_x + (size_t)q0 * h->d, R));
+            GH_TRY(ivfpq_stage_a(h, p, fc.at(q0), nc, d_x + (size_t)q0 * h->d, R));
         GH_TRY(ivfpq_stage_b(h, p, nc, d_x + (size_t)q0 * h->d, R, k, h->w_cand_dis.as<float>(),
                              h->w_cand_ids.as<int64_t>(), d_distances + (size_t)q0 * k,
                              d_labels + (size_t)q0 * k));
@@ -950,7 +993,7 @@ int gamma_hip_destroy(gamma_hip_index* h) {
                       &h->w_filter, &h->w_m_dis, &h->w_m_ids, &h->w_part_v, &h->w_part_i, &h->w_assign,
                       &h->w_codes_tmp, &h->w_qperm, &h->w_scnt, &h->w_sflag, &h->w_surv, &h->w_pair_base,
                       &h->w_pair_ip, &h->w_flat_cand, &h->w_flat_meta, &h->w_full_cdis,
-                      &h->w_full_probe};
+                      &h->w_full_probe, &h->w_ftab, &h->w_qfil};
     for (DevBuf* b : bufs) b->release();
     (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1733,13 +1776,15 @@ int gamma_hip_ivfpq_search_shard(gamma_hip_index* h, const gamma_hip_search_para
     const int R = std::max(p->recall_num, k);
     gh::FilterDesc filt;
     GH_TRY(build_filter(h, p, &filt));
+    FiltCtx fc;
+    GH_TRY(filt_ctx_single(h, filt, &fc));
     gamma_hip_search_params pp = *p;
     if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;   // decided on the whole call, not per chunk
     p = &pp;
     const int chunk = query_chunk(h, nq, p->nprobe);
     for (int q0 = 0; q0 < nq; q0 += chunk) {
         const int nc = std::min(chunk, nq - q0);
-        GH_TRY(ivfpq_stage_a(h, p, filt, nc, d_x + (size_t)q0 * h->d, R, nullptr, nullptr, /*shard=*/true,
+        GH_TRY(ivfpq_stage_a(h, p, fc.at(q0), nc, d_x + (size_t)q0 * h->d, R, nullptr, nullptr, /*shard=*/true,
                              d_recall_dis + (size_t)q0 * R, d_recall_ids + (size_t)q0 * R));
         h->last_nq = nc;
     }
@@ -1782,10 +1827,12 @@ int gamma_hip_ivfpq_search_shard_preassigned(gamma_hip_index* h, const gamma_hip
     const int R = std::max(p->recall_num, k), P = p->nprobe;
     gh::FilterDesc filt;
     GH_TRY(build_filter(h, p, &filt));
+    FiltCtx fc;
+    GH_TRY(filt_ctx_single(h, filt, &fc));
     const int chunk = query_chunk(h, nq, P);
     for (int q0 = 0; q0 < nq; q0 += chunk) {
         const int nc = std::min(chunk, nq - q0);
-        GH_TRY(ivfpq_stage_a(h, p, filt, nc, d_x + (size_t)q0 * h->d, R, d_coarse_dis + (size_t)q0 * P,
+        GH_TRY(ivfpq_stage_a(h, p, fc.at(q0), nc, d_x + (size_t)q0 * h->d, R, d_coarse_dis + (size_t)q0 * P,
                              d_probe + (size_t)q0 * P, /*shard=*/true, d_recall_dis + (size_t)q0 * R,
                              d_recall_ids + (size_t)q0 * R));
         h->last_nq = nc;

@@ -95,7 +95,8 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
                             const float* st2, const float* T2, const int64_t* list_off,
                             const int* list_len, const uint8_t* list_mask, int nlist,
                             const uint8_t* codes, const int64_t* ids, const int* pair_off,
-                            int64_t q_stride, float* out, const FilterDesc& filt, int need_ids,
+                            int64_t q_stride, float* out, const FilterDesc* ftab /* device */, const int* qfil /* device, may be null */,
+                            int need_ids,
                             const int* qperm, int G, int pg_lo, int pg_cnt, int sparse, const ScanBound* bound,
                             const float* pqc_fused = nullptr);   // != nullptr: query table computed in the kernel
 void launch_query_order(hipStream_t s, const int* probe_list, int nq, int P, const int* list_rank,

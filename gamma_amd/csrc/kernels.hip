@@ -984,8 +984,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
         const int64_t* __restrict__ list_off, const int* __restrict__ list_len,
         const uint8_t* __restrict__ list_mask, int nlist, const uint8_t* __restrict__ codes,
         const int64_t* __restrict__ ids, const int* __restrict__ pair_off, int64_t q_stride,
-        float* __restrict__ out, FilterDesc filt, int need_ids, float sentinel,
-        const int* __restrict__ qperm, int pg_lo, int pg_cnt, int sparse, ScanBound sb) {
+        float* __restrict__ out, const FilterDesc* __restrict__ ftab, const int* __restrict__ qfil, int need_ids,
+        float sentinel, const int* __restrict__ qperm, int pg_lo, int pg_cnt, int sparse, ScanBound sb) {
     // This launch covers probe groups [pg_lo, pg_lo + pg_cnt) of every query.
     // FILT (pg_lo = 0, pg_cnt >= 2): threshold pre-filter.  The workgroup of a query's FIRST probe
     // group (its nearest lists) ends by bounding the query's recall_num-th best distance from above
@@ -1044,6 +1044,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
         q = qslot * 8 + xcd;
         if (q >= nq) return;
     }
+    // validity predicates of THIS query: entry qfil[q] of the call's filter table (one entry unless the
+    // call is a combined batch of requests with their own filters); only read when need_ids
+    const FilterDesc& filt = ftab[(need_ids && qfil) ? qfil[q] : 0];
     const int lane = threadIdx.x & 63;
     // Survivors are staged in LDS (one LDS atomic per wave and iteration) and flushed to the
     // query's list with ONE global atomic per workgroup; a returning global atomic per wave
@@ -1434,7 +1437,7 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
                             const float* st2, const float* T2, const int64_t* list_off,
                             const int* list_len, const uint8_t* list_mask, int nlist,
                             const uint8_t* codes, const int64_t* ids, const int* pair_off,
-                            int64_t q_stride, float* out, const FilterDesc& filt, int need_ids,
+                            int64_t q_stride, float* out, const FilterDesc* ftab, const int* qfil, int need_ids,
                             const int* qperm, int G, int pg_lo, int pg_cnt, int sparse, const ScanBound* bound,
                             const float* pqc_fused) {
     if (nq <= 0 || pg_cnt <= 0) return;
@@ -1455,7 +1458,7 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
 #define GH_SCAN4(LL, MT, FF, II)                                                                       \
     hipLaunchKernelGGL((k_ivfpq_scan_pair<LL, MT, FF, II>), grid, dim3(256), lds, s, x, nq, d, M, P, G,     \
                        probe_list, coarse_dis, cc, st2, T2, list_off, list_len, list_mask, nlist, codes, \
-                       ids, pair_off, q_stride, out, filt, need_ids, LL ? INFINITY : -INFINITY, qperm,   \
+                       ids, pair_off, q_stride, out, ftab, qfil, need_ids, LL ? INFINITY : -INFINITY, qperm,   \
                        pg_lo, pg_cnt, sparse, sb)
 #define GH_SCAN_M(LL, FF)                       \
     do {                                        \
