@@ -1594,6 +1594,34 @@ static int ivfpq_search_host_locked(gamma_hip_index* h, const gamma_hip_search_p
 // selects -- requests only share a batch with requests that resolve to the same path.
 constexpr int COMB_MAX_NQ = 256, COMB_MAX_TOTAL = 4096;
 
+// filter table of a combined batch (h->mu held): entry i = request i's clauses + the delete bitmap
+static int build_group_filters(gamma_hip_index* h, const std::vector<gamma_hip_index::Waiter*>& grp, int total,
+                               std::vector<gh::FilterDesc>& tab, std::vector<int>& qf, FiltCtx* fc) {
+    GH_CHECK(h, hipSetDevice(h->device));
+    size_t tot = 0;
+    for (auto* g : grp)
+        if (g->p->has_range)
+            for (int i = 0; i < g->p->n_range; i++) tot += ((size_t)g->p->range[i].bitmap_bytes + 15) & ~(size_t)15;
+    GH_CHECK(h, h->w_filter.ensure(std::max<size_t>(tot, 16)));
+    tab.resize(grp.size());
+    qf.resize(total);
+    size_t off = 0;
+    int at = 0;
+    for (size_t i = 0; i < grp.size(); i++) {
+        GH_TRY(build_filter(h, grp[i]->p, &tab[i], &off));
+        for (int j = 0; j < grp[i]->nq; j++) qf[at++] = (int)i;
+    }
+    GH_CHECK(h, h->w_ftab.ensure(tab.size() * sizeof(gh::FilterDesc)));
+    GH_CHECK(h, h->w_qfil.ensure(qf.size() * sizeof(int)));
+    h->ftab_valid = false;   // entry 0 no longer holds a single call's descriptor
+    GH_CHECK(h, hipMemcpyAsync(h->w_ftab.p, tab.data(), tab.size() * sizeof(gh::FilterDesc), hipMemcpyHostToDevice, h->stream));
+    GH_CHECK(h, hipMemcpyAsync(h->w_qfil.p, qf.data(), qf.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    fc->d_tab = h->w_ftab.as<gh::FilterDesc>();
+    fc->d_qf = h->w_qfil.as<int>();
+    fc->any_clause = true;
+    return GAMMA_HIP_OK;
+}
+
 static void combine_worker(gamma_hip_index* h) {
     using W = gamma_hip_index::Waiter;
     auto same = [](const W* a, const W* b) {
@@ -1608,6 +1636,9 @@ static void combine_worker(gamma_hip_index* h) {
         float* sd = nullptr;
         int64_t* si = nullptr;
         bool enqueued = false;
+        std::vector<gh::FilterDesc> ftab;   // host images of the uploads, alive until the batch is awaited
+        std::vector<int> qf;
+        std::vector<int> rcs;               // per-request codes when the batch had to be redone one by one
     };
     // results -> callers, wake them (no lock needed for the copies: the callers are blocked)
     auto deliver = [&](Batch& b, std::unique_lock<std::mutex>& lk) {
@@ -1621,8 +1652,9 @@ static void combine_worker(gamma_hip_index* h) {
             }
         }
         lk.lock();
-        for (W* g : b.grp) {
-            g->rc = b.rc;
+        for (size_t i = 0; i < b.grp.size(); i++) {
+            W* g = b.grp[i];
+            g->rc = b.rcs.empty() ? b.rc : b.rcs[i];
             g->done = true;
             g->cv.notify_one();
         }
@@ -1686,10 +1718,17 @@ static void combine_worker(gamma_hip_index* h) {
                     }
                     h->mu.lock();   // held until the batch has been awaited (below)
                     cur.rc = ivfpq_check(h, &pp, total, kk);
+                    // requests with their own filter clauses: one table entry per request, a query -> entry map
+                    FiltCtx fc;
+                    bool any_filter = false;
+                    for (W* g : cur.grp) any_filter |= g->p->has_range || g->p->n_field > 0;
+                    const bool multi = any_filter && cur.grp.size() > 1;
+                    if (cur.rc == GAMMA_HIP_OK && multi) cur.rc = build_group_filters(h, cur.grp, total, cur.ftab, cur.qf, &fc);
                     if (cur.rc == GAMMA_HIP_OK)
                         cur.rc = host_search(h, total, d, sx, kk, cur.sd, cur.si,
                                              [&](const float* dx, float* dd, int64_t* dl) {
-                                                 return ivfpq_search_device_locked(h, &pp, total, dx, kk, dd, dl);
+                                                 return ivfpq_search_device_locked(h, &pp, total, dx, kk, dd, dl,
+                                                                                   multi ? &fc : nullptr);
                                              },
                                              /*sync=*/false);
                     cur.enqueued = true;
@@ -1701,6 +1740,17 @@ static void combine_worker(gamma_hip_index* h) {
                 if (hipStreamSynchronize(h->stream) != hipSuccess && cur.rc == GAMMA_HIP_OK) cur.rc = GAMMA_HIP_EDEVICE;
                 h->mu.unlock();
                 cur.enqueued = false;
+                if (cur.rc != GAMMA_HIP_OK && cur.grp.size() > 1) {
+                    // one request's parameters may be at fault (a filter on an unknown column, ...): every
+                    // request gets the outcome of its own call
+                    for (W* g : cur.grp) {
+                        gamma_hip_search_params pg = *g->p;
+                        pg.coarse_mode = g->mode;
+                        cur.rcs.push_back(ivfpq_search_host_locked(h, &pg, g->nq, g->x, g->k, g->D, g->I));
+                    }
+                    cur.sd = nullptr;   // results are already in the callers' buffers
+                    cur.rc = GAMMA_HIP_OK;
+                }
             }
             prev = std::move(cur);
             lk.lock();
@@ -1740,8 +1790,9 @@ static int combined_search(gamma_hip_index* h, const gamma_hip_search_params* p,
 int gamma_hip_ivfpq_search(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x,
                            int k, float* distances, int64_t* labels) {
     if (!h) return GAMMA_HIP_EINVAL;
-    if (h->combine && p && nq > 0 && nq <= COMB_MAX_NQ && k > 0 && x && distances && labels && !p->has_range &&
-        p->n_range == 0 && p->n_field == 0 && h->ivf_init && h->d > 0)
+    if (h->combine && p && nq > 0 && nq <= COMB_MAX_NQ && k > 0 && x && distances && labels && h->ivf_init && h->d > 0 &&
+        (!p->has_range || (p->n_range >= 0 && p->n_range <= gh::kMaxRange && (p->n_range == 0 || p->range))) &&
+        p->n_field >= 0 && p->n_field <= gh::kMaxField && (p->n_field == 0 || p->field))
         return combined_search(h, p, nq, x, k, distances, labels);
     return ivfpq_search_host_locked(h, p, nq, x, k, distances, labels);
 }

@@ -157,6 +157,49 @@ double gh_host_concurrent_clients(void *hp, const char *retrieval_params, int ha
   double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return failed.load() ? -1.0 : dt;
 }
+// Same clients, each with its OWN scalar filter (client t admits docids [t*stride, t*stride + span), every
+// other client a NOT-IN clause), results checked: the calls are repeated one at a time afterwards and
+// must be bit-identical.  Returns the number of calls whose concurrent result differed (< 0: a call
+// failed); *seconds receives the wall time of the concurrent phase.
+int gh_host_concurrent_filtered_check(void *hp, const char *retrieval_params, int has_rank, int nthreads, int calls,
+                                      const float *pool, int npool, int d, int k, int stride, int span,
+                                      double *seconds) {
+  std::vector<std::vector<float>> Dc(nthreads);
+  std::vector<std::vector<int64_t>> Ic(nthreads);
+  std::atomic<int> failed(0);
+  auto one = [&](int t, int i, float *D, int64_t *I) -> int {
+    std::vector<int64_t> docs(span);
+    for (int j = 0; j < span; j++) docs[j] = (int64_t)t * stride + j;
+    int cnt = span, not_in = t & 1;
+    const int at = (int)(((int64_t)t * calls + i) % npool);
+    return gh_host_search_filtered(hp, retrieval_params, has_rank, 0, -1e30f, 1e30f, 1, pool + (size_t)at * d, k, D, I,
+                                   1, docs.data(), &cnt, &not_in);
+  };
+  std::vector<std::thread> th;
+  auto t0 = std::chrono::steady_clock::now();
+  for (int t = 0; t < nthreads; t++) {
+    Dc[t].resize((size_t)calls * k);
+    Ic[t].resize((size_t)calls * k);
+    th.emplace_back([&, t]() {
+      for (int i = 0; i < calls; i++)
+        if (one(t, i, Dc[t].data() + (size_t)i * k, Ic[t].data() + (size_t)i * k)) failed++;
+    });
+  }
+  for (auto &x : th) x.join();
+  if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (failed.load()) return -1;
+  int bad = 0;
+  std::vector<float> D(k);
+  std::vector<int64_t> I(k);
+  for (int t = 0; t < nthreads; t++)
+    for (int i = 0; i < calls; i++) {
+      if (one(t, i, D.data(), I.data())) return -1;
+      if (memcmp(D.data(), Dc[t].data() + (size_t)i * k, sizeof(float) * k) ||
+          memcmp(I.data(), Ic[t].data() + (size_t)i * k, sizeof(int64_t) * k))
+        bad++;
+    }
+  return bad;
+}
 int gh_host_dump(void *hp, const char *dir) { return ((Host *)hp)->model->Dump(dir); }
 int gh_host_load(void *hp, const char *dir) { return ((Host *)hp)->model->Load(dir); }
 long gh_host_mem_bytes(void *hp) { return ((Host *)hp)->model->GetTotalMemBytes(); }

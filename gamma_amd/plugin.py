@@ -30,6 +30,8 @@ HOST_SYMBOLS = {
                                           C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gh_host_concurrent_clients": (C.c_double, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, f32p,
                                                 C.c_int, C.c_int, C.c_int, f32p]),
+    "gh_host_concurrent_filtered_check": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, f32p, C.c_int,
+                                                    C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "gh_host_dump": (C.c_int, [C.c_void_p, C.c_char_p]),
     "gh_host_load": (C.c_int, [C.c_void_p, C.c_char_p]),
     "gh_host_mem_bytes": (C.c_long, [C.c_void_p]),
@@ -189,6 +191,18 @@ class PluginModel:
         if dt < 0:
             raise _lib.GammaHipError("a Search call failed")
         return dt, lat
+
+    def concurrent_filtered_check(self, pool, retrieval_params, nthreads, calls, stride, span, k=10, has_rank=True):
+        """client threads with one query and their own range filter each; returns (calls whose result differs
+        from the same call made alone, wall seconds of the concurrent phase)"""
+        pool = np.ascontiguousarray(pool, dtype=np.float32)
+        sec = C.c_double(0)
+        bad = self.L.gh_host_concurrent_filtered_check(self.h, retrieval_params.encode(), int(has_rank), nthreads, calls,
+                                                       _f(pool), pool.shape[0], pool.shape[1], k, stride, span,
+                                                       C.byref(sec))
+        if bad < 0:
+            raise _lib.GammaHipError("a Search call failed")
+        return bad, sec.value
 
     def dump(self, d):
         return self.L.gh_host_dump(self.h, d.encode())

@@ -622,6 +622,16 @@ def test_concurrent_small_searches_are_combined_and_exact(case, hip):
         (1, api.SearchArgs(metric=api.METRIC_IP, nprobe=12, recall_num=60, has_rank=False, **WIDE), 5),
         (24, api.SearchArgs(metric=api.METRIC_L2, nprobe=8, recall_num=100, has_rank=True, **WIDE), 10),   # GEMM-form coarse
     ]
+    # requests with their OWN range filters share batches too (one filter-table entry per request)
+    frng = np.random.default_rng(77)
+    N = case["N"]
+    for sel, not_in in ((0.5, False), (0.1, False), (0.3, True)):
+        docs = np.sort(frng.choice(N, size=int(N * sel), replace=False))
+        variants.append((1, api.SearchArgs(metric=api.METRIC_L2, nprobe=8, recall_num=100, has_rank=True,
+                                           range_filters=[api.make_range_filter(docs, b_not_in=not_in)], **WIDE), 10))
+    variants.append((2, api.SearchArgs(metric=api.METRIC_L2, nprobe=8, recall_num=100, has_rank=True,
+                                       range_filters=[api.make_range_filter(np.arange(100, 9000)),
+                                                      api.make_range_filter(np.arange(5000, 19000))], **WIDE), 10))
     # the answers of the calls made one at a time
     want = {}
     for v, (n, args, k) in enumerate(variants):

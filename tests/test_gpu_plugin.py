@@ -8,6 +8,7 @@ import pytest
 from oracle import binding as B
 from tests import fixtures
 from tests.parity import compare_topk
+from gamma_amd import synth
 
 pytestmark = pytest.mark.gpu
 
@@ -228,4 +229,21 @@ def test_plugin_loads_an_index_dumped_by_the_reference(tmp_path):
     assert got["ntotal"] == 0 and got["nprobe"] == 5
     assert got["cc"].tobytes() == z["cc"].tobytes() and got["pq"].tobytes() == z["pq"].tobytes()
     assert np.array_equal(got["list_ids"], z["list_ids"]) and np.array_equal(got["list_codes"], z["list_codes"])
+    m.close()
+
+
+def test_plugin_concurrent_clients_with_their_own_filters(case):
+    """32 client threads (C++), one query and one range filter each (every other one a NOT-IN clause), through
+    RetrievalModel::Search: requests that meet in the queue share a device batch with one filter-table entry
+    per request; every result must be bit-identical to the same call made alone."""
+    m = _ivfpq_plugin(case)
+    base = case["base"]
+    m.store(base)
+    assert m.set_trained(case["cc"], case["pq"]) == 0
+    assert m.add(base)
+    pool = synth.sift_like(512, d=case["d"], seed=91)
+    N = len(base)
+    bad, sec = m.concurrent_filtered_check(pool, '{"recall_num": 100, "nprobe": 8}', nthreads=32, calls=40,
+                                           stride=N // 40, span=N // 4)
+    assert bad == 0
     m.close()

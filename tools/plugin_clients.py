@@ -22,3 +22,8 @@ for T in (1, 8, 32, 128, 512):
     lat = np.sort(lat)
     print("%3d client threads x 1 query per call: %8.0f queries/s, latency median %.0f us, p99 %.0f us" % (
         T, T * calls / dt, np.median(lat), lat[int(0.99 * len(lat))]), flush=True)
+N0 = N
+for T in (8, 32, 128):
+    bad, sec = m.concurrent_filtered_check(q, params, T, max(50, 4000 // T), N0 // (T + 4), N0 // 4)
+    print("%3d client threads x 1 query, each with its own range filter: %8.0f queries/s (%d results differ from the call made alone)" % (
+        T, T * max(50, 4000 // T) / sec, bad), flush=True)
