@@ -137,6 +137,7 @@ struct gamma_hip_index {
     struct Waiter {
         const gamma_hip_search_params* p;
         int nq, k, mode;   // mode: coarse path resolved from THIS request's size
+        int kind = 0;      // 0: IVFPQ search, 1: flat search
         const float* x;
         float* D;
         int64_t* I;
@@ -1573,6 +1574,17 @@ int gamma_hip_ivfpq_search_device(gamma_hip_index* h, const gamma_hip_search_par
     return ivfpq_search_device_locked(h, p, nq, d_x, k, d_distances, d_labels);
 }
 
+static int flat_search_host_locked(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x, int k,
+                                  float* distances, int64_t* labels) {
+    std::lock_guard<std::mutex> g(h->mu);
+    GH_TRY(check_params(h, p, nq, k));
+    if (h->raw_d <= 0) return fail(h, GAMMA_HIP_EINVAL, "raw store not initialised");
+    if (nq > 0 && k > 0 && (!x || !distances || !labels)) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
+    return host_search(h, nq, h->raw_d, x, k, distances, labels, [&](const float* dx, float* dd, int64_t* dl) {
+        return flat_search_device_locked(h, p, nq, dx, k, dd, dl);
+    });
+}
+
 static int ivfpq_search_host_locked(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x,
                                    int k, float* distances, int64_t* labels) {
     std::lock_guard<std::mutex> g(h->mu);
@@ -1625,7 +1637,8 @@ static int build_group_filters(gamma_hip_index* h, const std::vector<gamma_hip_i
 static void combine_worker(gamma_hip_index* h) {
     using W = gamma_hip_index::Waiter;
     auto same = [](const W* a, const W* b) {
-        return a->k == b->k && a->mode == b->mode && a->p->metric == b->p->metric && a->p->nprobe == b->p->nprobe &&
+        return a->kind == b->kind && a->k == b->k && a->mode == b->mode && a->p->metric == b->p->metric &&
+               a->p->nprobe == b->p->nprobe &&
                a->p->recall_num == b->p->recall_num && a->p->has_rank == b->p->has_rank &&
                a->p->min_score == b->p->min_score && a->p->max_score == b->p->max_score;
     };
@@ -1690,7 +1703,8 @@ static void combine_worker(gamma_hip_index* h) {
                 W* first = cur.grp.front();
                 gamma_hip_search_params pp = *first->p;
                 pp.coarse_mode = first->mode;
-                const int d = h->d, kk = first->k, total = cur.total;
+                const bool flat = first->kind == 1;
+                const int d = flat ? h->raw_d : h->d, kk = first->k, total = cur.total;
                 cur.kk = kk;
                 const size_t bx = (size_t)total * d * sizeof(float), bd = (size_t)total * kk * sizeof(float),
                              bi = (size_t)total * kk * sizeof(int64_t);
@@ -1717,16 +1731,18 @@ static void combine_worker(gamma_hip_index* h) {
                         at += g->nq;
                     }
                     h->mu.lock();   // held until the batch has been awaited (below)
-                    cur.rc = ivfpq_check(h, &pp, total, kk);
+                    cur.rc = flat ? check_params(h, &pp, total, kk) : ivfpq_check(h, &pp, total, kk);
                     // requests with their own filter clauses: one table entry per request, a query -> entry map
+                    // (IVFPQ only: filtered flat requests are not combined)
                     FiltCtx fc;
                     bool any_filter = false;
                     for (W* g : cur.grp) any_filter |= g->p->has_range || g->p->n_field > 0;
-                    const bool multi = any_filter && cur.grp.size() > 1;
+                    const bool multi = !flat && any_filter && cur.grp.size() > 1;
                     if (cur.rc == GAMMA_HIP_OK && multi) cur.rc = build_group_filters(h, cur.grp, total, cur.ftab, cur.qf, &fc);
                     if (cur.rc == GAMMA_HIP_OK)
                         cur.rc = host_search(h, total, d, sx, kk, cur.sd, cur.si,
                                              [&](const float* dx, float* dd, int64_t* dl) {
+                                                 if (flat) return flat_search_device_locked(h, &pp, total, dx, kk, dd, dl);
                                                  return ivfpq_search_device_locked(h, &pp, total, dx, kk, dd, dl,
                                                                                    multi ? &fc : nullptr);
                                              },
@@ -1746,7 +1762,8 @@ static void combine_worker(gamma_hip_index* h) {
                     for (W* g : cur.grp) {
                         gamma_hip_search_params pg = *g->p;
                         pg.coarse_mode = g->mode;
-                        cur.rcs.push_back(ivfpq_search_host_locked(h, &pg, g->nq, g->x, g->k, g->D, g->I));
+                        cur.rcs.push_back(g->kind == 1 ? flat_search_host_locked(h, &pg, g->nq, g->x, g->k, g->D, g->I)
+                                                       : ivfpq_search_host_locked(h, &pg, g->nq, g->x, g->k, g->D, g->I));
                     }
                     cur.sd = nullptr;   // results are already in the callers' buffers
                     cur.rc = GAMMA_HIP_OK;
@@ -1764,17 +1781,19 @@ static void combine_worker(gamma_hip_index* h) {
 }
 
 static int combined_search(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x, int k,
-                           float* distances, int64_t* labels) {
+                           float* distances, int64_t* labels, int kind = 0) {
     gamma_hip_index::Waiter w;
     w.p = p; w.nq = nq; w.k = k; w.x = x; w.D = distances; w.I = labels;
-    w.mode = p->coarse_mode < 0 ? (nq < 20 ? 0 : 1) : p->coarse_mode;
+    w.kind = kind;
+    w.mode = kind == 1 ? 0 : (p->coarse_mode < 0 ? (nq < 20 ? 0 : 1) : p->coarse_mode);
     std::unique_lock<std::mutex> lk(h->comb_mu);
     if (!h->comb_busy && h->comb_q.empty()) {   // idle handle: run on this thread, no hop
         h->comb_busy = true;
         lk.unlock();
         gamma_hip_search_params pp = *p;
         pp.coarse_mode = w.mode;
-        const int rc = ivfpq_search_host_locked(h, &pp, nq, x, k, distances, labels);
+        const int rc = kind == 1 ? flat_search_host_locked(h, &pp, nq, x, k, distances, labels)
+                                 : ivfpq_search_host_locked(h, &pp, nq, x, k, distances, labels);
         lk.lock();
         h->comb_busy = false;
         if (!h->comb_q.empty()) h->comb_wcv.notify_one();
@@ -1943,13 +1962,11 @@ int gamma_hip_flat_search_device(gamma_hip_index* h, const gamma_hip_search_para
 int gamma_hip_flat_search(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x,
                           int k, float* distances, int64_t* labels) {
     if (!h) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
-    GH_TRY(check_params(h, p, nq, k));
-    if (h->raw_d <= 0) return fail(h, GAMMA_HIP_EINVAL, "raw store not initialised");
-    if (nq > 0 && k > 0 && (!x || !distances || !labels)) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
-    return host_search(h, nq, h->raw_d, x, k, distances, labels, [&](const float* dx, float* dd, int64_t* dl) {
-        return flat_search_device_locked(h, p, nq, dx, k, dd, dl);
-    });
+    // small unfiltered calls from concurrent client threads share device batches (see gamma_hip_ivfpq_search)
+    if (h->combine && p && nq > 0 && nq <= COMB_MAX_NQ && k > 0 && x && distances && labels && h->raw_d > 0 &&
+        !p->has_range && p->n_range == 0 && p->n_field == 0)
+        return combined_search(h, p, nq, x, k, distances, labels, /*kind=*/1);
+    return flat_search_host_locked(h, p, nq, x, k, distances, labels);
 }
 
 /* ---- accounting ----------------------------------------------------------------------------- */

@@ -632,11 +632,19 @@ def test_concurrent_small_searches_are_combined_and_exact(case, hip):
     variants.append((2, api.SearchArgs(metric=api.METRIC_L2, nprobe=8, recall_num=100, has_rank=True,
                                        range_filters=[api.make_range_filter(np.arange(100, 9000)),
                                                       api.make_range_filter(np.arange(5000, 19000))], **WIDE), 10))
+    # flat searches (the brute-force fallback of the plugins) from the same clients
+    flat_variants = {len(variants): True, len(variants) + 1: True}
+    variants.append((1, api.SearchArgs(metric=api.METRIC_L2, **WIDE), 10))
+    variants.append((2, api.SearchArgs(metric=api.METRIC_IP, **WIDE), 7))
+
+    def call(v, xb, k, args):
+        return hip.flat_search(xb, k, args) if v in flat_variants else hip.ivfpq_search(xb, k, args)
+
     # the answers of the calls made one at a time
     want = {}
     for v, (n, args, k) in enumerate(variants):
         for i0 in range(0, 480 - n + 1, n):
-            want[(v, i0)] = hip.ivfpq_search(q[i0:i0 + n], k, args)
+            want[(v, i0)] = call(v, q[i0:i0 + n], k, args)
     errors = []
 
     def client(t):
@@ -646,7 +654,7 @@ def test_concurrent_small_searches_are_combined_and_exact(case, hip):
                 v = int(rng.integers(0, len(variants)))
                 n, args, k = variants[v]
                 i0 = int(rng.integers(0, (480 - n) // n + 1)) * n
-                D, I = hip.ivfpq_search(q[i0:i0 + n], k, args)
+                D, I = call(v, q[i0:i0 + n], k, args)
                 Dw, Iw = want[(v, i0)]
                 assert D.tobytes() == Dw.tobytes() and np.array_equal(I, Iw), (t, it, v, i0)
         except Exception as e:   # noqa: BLE001
