@@ -593,9 +593,9 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         // enough queries that L2 capacity matters: run them in spatial order (kernels.hip)
         // (not when the T2 rows of the lists scanned here fit the L2s anyway: a shard of a small index)
         if (h->sort_queries && h->d_list_rank && nq >= 256 && t2_bytes > ((int64_t)8 << 20)) {
-            GH_CHECK(h, h->w_qperm.ensure((size_t)2 * nq * sizeof(int)));
+            GH_CHECK(h, h->w_qperm.ensure(((size_t)2 * nq + gh::query_order_bins()) * sizeof(int)));   // qperm | qkey | bins
             gh::launch_query_order(s, h->w_probe.as<int>(), nq, P, h->d_list_rank, nlist,
-                                   h->w_qperm.as<int>() + nq, h->w_qperm.as<int>());
+                                   h->w_qperm.as<int>() + nq, h->w_qperm.as<int>(), h->w_qperm.as<int>() + 2 * (size_t)nq);
             qperm = h->w_qperm.as<int>();
         }
     }

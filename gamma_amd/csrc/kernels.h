@@ -99,8 +99,10 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
                             int need_ids,
                             const int* qperm, int G, int pg_lo, int pg_cnt, int sparse, const ScanBound* bound,
                             const float* pqc_fused = nullptr);   // != nullptr: query table computed in the kernel
+int query_order_bins();
+// bins: query_order_bins() ints of scratch (large batches sort over the whole grid); may be null
 void launch_query_order(hipStream_t s, const int* probe_list, int nq, int P, const int* list_rank,
-                        int nlist, int* qkey, int* qperm);
+                        int nlist, int* qkey, int* qperm, int* bins = nullptr);
 void launch_sum_totals(hipStream_t s, const int* q_total, int nq, unsigned long long* acc);
 int select_kpad(int K);
 void launch_select_topk(hipStream_t s, bool smallest, const float* vals, int64_t seg_stride,
