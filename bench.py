@@ -9,9 +9,10 @@ Search call over a batch of `--nq` synthetic queries already resident in HBM.
   python bench.py --gpus N --steps K --warmup W          (N=1 default)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N>1: the index is sharded by IVF list across the ranks (gamma_amd/dist.py), per-shard top-k
-merged after an RCCL all-gather; the index size is fixed, so scaling is "strong".
-Rank 0 prints ONE JSON line (plus diagnostics on stderr).
+N>1: the index is sharded by IVF list across the ranks (gamma_amd/dist.py): every rank scans the
+lists it owns for the whole batch, an RCCL all-to-all hands each rank the candidates of its query
+slice, merge + re-rank there.  A step then holds N x nq queries (per-GPU scan work constant:
+"weak" scaling).  Rank 0 prints ONE JSON line (plus diagnostics on stderr).
 """
 import argparse
 import json
@@ -34,7 +35,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--nq", type=int, default=8192, help="queries per Search call (one step)")
+    ap.add_argument("--nq", type=int, default=16384, help="queries per Search call (one step)")
     ap.add_argument("--n", type=int, default=1000000)
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--nlist", type=int, default=4096)
