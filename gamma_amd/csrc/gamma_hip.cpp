@@ -11,7 +11,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -1649,43 +1651,73 @@ static void combine_worker(gamma_hip_index* h) {
         float* sd = nullptr;
         int64_t* si = nullptr;
         bool enqueued = false;
+        int set = -1;                       // pinned staging set holding its inputs / results
         std::vector<gh::FilterDesc> ftab;   // host images of the uploads, alive until the batch is awaited
         std::vector<int> qf;
         std::vector<int> rcs;               // per-request codes when the batch had to be redone one by one
     };
-    // results -> callers, wake them (no lock needed for the copies: the callers are blocked)
-    auto deliver = [&](Batch& b, std::unique_lock<std::mutex>& lk) {
-        if (b.grp.empty()) return;
-        if (b.rc == GAMMA_HIP_OK && b.sd) {
-            size_t at = 0;
-            for (W* g : b.grp) {
-                std::memcpy(g->D, b.sd + at * b.kk, (size_t)g->nq * b.kk * sizeof(float));
-                std::memcpy(g->I, b.si + at * b.kk, (size_t)g->nq * b.kk * sizeof(int64_t));
-                at += g->nq;
+    // Results -> callers: a helper thread copies them out of the pinned staging set and wakes the callers
+    // (one futex wake per request costs the worker more than launching the next batch), so the worker only
+    // forms, launches and awaits batches.  A staging set is reused once its batch has been delivered.
+    std::mutex n_mu;
+    std::condition_variable n_cv;
+    std::deque<Batch> n_q;
+    bool n_stop = false;
+    std::atomic<bool> set_busy[2];
+    set_busy[0] = false;
+    set_busy[1] = false;
+    std::thread notifier([&]() {
+        std::unique_lock<std::mutex> nl(n_mu);
+        for (;;) {
+            n_cv.wait(nl, [&] { return n_stop || !n_q.empty(); });
+            if (n_q.empty()) break;   // stop requested and nothing left
+            Batch b = std::move(n_q.front());
+            n_q.pop_front();
+            nl.unlock();
+            if (b.rc == GAMMA_HIP_OK && b.sd) {   // no lock needed for the copies: the callers are blocked
+                size_t at = 0;
+                for (W* g : b.grp) {
+                    std::memcpy(g->D, b.sd + at * b.kk, (size_t)g->nq * b.kk * sizeof(float));
+                    std::memcpy(g->I, b.si + at * b.kk, (size_t)g->nq * b.kk * sizeof(int64_t));
+                    at += g->nq;
+                }
             }
+            if (b.set >= 0) set_busy[b.set].store(false, std::memory_order_release);
+            {
+                std::lock_guard<std::mutex> cl(h->comb_mu);
+                for (size_t i = 0; i < b.grp.size(); i++) {
+                    W* g = b.grp[i];
+                    g->rc = b.rcs.empty() ? b.rc : b.rcs[i];
+                    g->done = true;
+                    g->cv.notify_one();
+                }
+            }
+            nl.lock();
         }
-        lk.lock();
-        for (size_t i = 0; i < b.grp.size(); i++) {
-            W* g = b.grp[i];
-            g->rc = b.rcs.empty() ? b.rc : b.rcs[i];
-            g->done = true;
-            g->cv.notify_one();
+    });
+    auto post = [&](Batch&& b) {
+        if (b.grp.empty()) return;
+        {
+            std::lock_guard<std::mutex> nl(n_mu);
+            n_q.push_back(std::move(b));
         }
-        lk.unlock();
-        b.grp.clear();
+        n_cv.notify_one();
     };
-    Batch prev, cur;
+    Batch cur;
     int set = 0;
+    static const bool dbg = getenv("GAMMA_HIP_COMB_DBG") != nullptr;   // phase times of the worker, printed at exit
+    double us_stage = 0, us_deliver = 0, us_sync = 0;
+    long n_batches = 0, n_reqs = 0;
     std::unique_lock<std::mutex> lk(h->comb_mu);
     for (;;) {
         h->comb_wcv.wait(lk, [&] { return h->comb_stop || (!h->comb_busy && !h->comb_q.empty()); });
         if (h->comb_stop) break;
         h->comb_busy = true;
-        // Pipeline: while batch N runs on the GPU its predecessor's results are copied out and its callers
-        // woken (64 futex wakes cost as much as the batch itself); the handle stays busy until the queue
-        // is drained.
+        // the handle stays busy until the queue is drained; delivery of batch N overlaps with forming and
+        // launching batch N+1
         for (;;) {
             cur = Batch();
+            const auto t_a = std::chrono::steady_clock::now();
             if (!h->comb_q.empty()) {   // one group: the oldest request and everything compatible with it
                 W* first = h->comb_q.front();
                 for (auto it = h->comb_q.begin(); it != h->comb_q.end();) {
@@ -1710,6 +1742,7 @@ static void combine_worker(gamma_hip_index* h) {
                              bi = (size_t)total * kk * sizeof(int64_t);
                 const size_t off_i = (bx + 15) & ~(size_t)15, off_d = off_i + ((bi + 15) & ~(size_t)15),
                              need = off_d + bd;
+                while (set_busy[set].load(std::memory_order_acquire)) std::this_thread::yield();   // its last batch is being delivered
                 if (need > h->comb_pin_bytes[set]) {
                     if (h->comb_pin[set]) (void)hipHostFree(h->comb_pin[set]);
                     h->comb_pin[set] = nullptr;
@@ -1730,6 +1763,8 @@ static void combine_worker(gamma_hip_index* h) {
                         std::memcpy(sx + at * d, g->x, (size_t)g->nq * d * sizeof(float));
                         at += g->nq;
                     }
+                    cur.set = set;
+                    set_busy[set].store(true, std::memory_order_release);
                     h->mu.lock();   // held until the batch has been awaited (below)
                     cur.rc = flat ? check_params(h, &pp, total, kk) : ivfpq_check(h, &pp, total, kk);
                     // requests with their own filter clauses: one table entry per request, a query -> entry map
@@ -1751,7 +1786,8 @@ static void combine_worker(gamma_hip_index* h) {
                 }
                 set ^= 1;
             }
-            deliver(prev, lk);   // overlaps with cur on the GPU
+            const auto t_b = std::chrono::steady_clock::now();
+            const auto t_c = t_b;
             if (cur.enqueued) {
                 if (hipStreamSynchronize(h->stream) != hipSuccess && cur.rc == GAMMA_HIP_OK) cur.rc = GAMMA_HIP_EDEVICE;
                 h->mu.unlock();
@@ -1769,15 +1805,31 @@ static void combine_worker(gamma_hip_index* h) {
                     cur.rc = GAMMA_HIP_OK;
                 }
             }
-            prev = std::move(cur);
+            if (dbg) {
+                const auto t_d = std::chrono::steady_clock::now();
+                us_stage += std::chrono::duration<double, std::micro>(t_b - t_a).count();
+                us_deliver += std::chrono::duration<double, std::micro>(t_c - t_b).count();
+                us_sync += std::chrono::duration<double, std::micro>(t_d - t_c).count();
+                n_batches++;
+                n_reqs += (long)cur.grp.size();
+            }
+            post(std::move(cur));
             lk.lock();
             if (h->comb_q.empty()) break;
         }
-        lk.unlock();
-        deliver(prev, lk);
-        lk.lock();
         h->comb_busy = false;
     }
+    lk.unlock();
+    {
+        std::lock_guard<std::mutex> nl(n_mu);
+        n_stop = true;
+    }
+    n_cv.notify_one();
+    notifier.join();
+    if (dbg && n_batches)
+        fprintf(stderr, "combine worker: %ld batches, %.1f requests each; per batch: group+stage+enqueue %.1f us, deliver previous %.1f us, "
+                "wait for the GPU %.1f us\n", n_batches, (double)n_reqs / n_batches, us_stage / n_batches, us_deliver / n_batches,
+                us_sync / n_batches);
 }
 
 static int combined_search(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x, int k,
