@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from gamma_amd import api, train
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 2000000
-d, nlist, M, P, R, k, nq = 768, 4096, 64, 64, 100, 10, 4096
+d, nlist, M, P, R, k, nq = 768, (int(sys.argv[2]) if len(sys.argv) > 2 else 4096), 64, 64, 100, 10, 4096
 dev = torch.device("cuda", 0)
 CH = 100000
 gen = torch.Generator(device=dev); gen.manual_seed(99)
