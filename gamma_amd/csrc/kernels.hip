@@ -379,23 +379,27 @@ __global__ __launch_bounds__(256) void k_l2_gemmform_mfma(const float* __restric
     // fused query norms (fvec_norm_L2sqr order): thread (row = tid >> 2, lane4 = tid & 3)
     float nacc = 0.f;
     const bool vec4 = (d & 3) == 0;
+    // 64 rows x 32 float4 per operand = 2048 float4, 8 per thread.  Loads are UNCONDITIONAL on clamped
+    // addresses (a branch per load would make hipcc wait for each one); out-of-range lanes are zeroed
+    // when the slab is written to LDS.  The NEXT slab is requested before the MFMAs of the current one
+    // (d = 768: six slabs per tile, their global latency used to be exposed once per slab).
+    float4 va[8], vb[8];
+    auto gload = [&](int k0) {
+        const int kw = min(KS, d - k0);
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int e = it * 256 + tid;
+            const int r = e >> 5, c4 = (e & 31) * 4;
+            const int q = min(q_base + r, nq - 1), cc = min(c_base + r, ny - 1);
+            const int c4c = min(c4, kw - 4);
+            va[it] = *reinterpret_cast<const float4*>(x + (int64_t)q * d + k0 + c4c);
+            vb[it] = *reinterpret_cast<const float4*>(y + (int64_t)cc * d + k0 + c4c);
+        }
+    };
+    if (vec4) gload(0);
     for (int k0 = 0; k0 < d; k0 += KS) {
         const int kw = min(KS, d - k0);
         if (vec4) {
-            // 64 rows x 32 float4 per operand = 2048 float4, 8 per thread.  Loads are
-            // UNCONDITIONAL on clamped addresses (a branch per load would make hipcc wait for
-            // each one); out-of-range lanes are zeroed afterwards.  All 16 are in flight
-            // before the first LDS write.
-            float4 va[8], vb[8];
-#pragma unroll
-            for (int it = 0; it < 8; it++) {
-                const int e = it * 256 + tid;
-                const int r = e >> 5, c4 = (e & 31) * 4;
-                const int q = min(q_base + r, nq - 1), cc = min(c_base + r, ny - 1);
-                const int c4c = min(c4, kw - 4);
-                va[it] = *reinterpret_cast<const float4*>(x + (int64_t)q * d + k0 + c4c);
-                vb[it] = *reinterpret_cast<const float4*>(y + (int64_t)cc * d + k0 + c4c);
-            }
 #pragma unroll
             for (int it = 0; it < 8; it++) {
                 const int e = it * 256 + tid;
@@ -418,6 +422,7 @@ __global__ __launch_bounds__(256) void k_l2_gemmform_mfma(const float* __restric
             }
         }
         __syncthreads();
+        if (vec4 && k0 + KS < d) gload(k0 + KS);   // uniform
         if (!xn) {
             const float* row = sA + (tid >> 2) * LD;
             const int l4 = tid & 3;
