@@ -134,6 +134,7 @@ struct gamma_hip_index {
 
     // last-search stage info
     int last_nq = 0, last_P = 0, last_R = 0;
+    const int* last_qperm = nullptr;   // query order of the last stage A (null: arrival order)
 
     // request combining of small concurrent host-buffer searches (gamma_hip_ivfpq_search)
     struct Waiter {
@@ -600,6 +601,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
                                    h->w_qperm.as<int>() + nq, h->w_qperm.as<int>(), h->w_qperm.as<int>() + 2 * (size_t)nq);
             qperm = h->w_qperm.as<int>();
         }
+        h->last_qperm = qperm;   // stage B runs the re-rank in the same order
     }
     // per-query slab of the distance buffer; multiple of 4 floats so rows are 16-byte aligned
     const int64_t q_stride = (std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len)) + 3) & ~(int64_t)3;
@@ -684,7 +686,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
 // ---- stage B: compute_dis (gamma_index_ivfpq.cc:642-697) ------------------------------
 int ivfpq_stage_b(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, int R, int k,
                   const float* cand_dis, const int64_t* cand_ids, float* d_distances,
-                  int64_t* d_labels) {
+                  int64_t* d_labels, const int* qperm = nullptr) {
     const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
     const float neutral = l2 ? 3.402823466e+38f : -3.402823466e+38f;
     hipStream_t s = h->stream;
@@ -694,7 +696,7 @@ int ivfpq_stage_b(H* h, const gamma_hip_search_params* p, int nq, const float* d
         if (R <= 1024 && nq >= 256) {
             // one fused kernel: exact distances + top-k + output
             gh::launch_rerank_topk(s, l2, d_x, nq, h->d, h->d_raw, h->nraw, cand_ids, R, k, p->min_score,
-                                   p->max_score, neutral, d_distances, d_labels);
+                                   p->max_score, neutral, d_distances, d_labels, qperm);
             GH_CHECK(h, hipGetLastError());
             return GAMMA_HIP_OK;
         }
@@ -778,7 +780,7 @@ int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, c
             GH_TRY(ivfpq_stage_a(h, p, fc.at(q0), nc, d_x + (size_t)q0 * h->d, R));
         GH_TRY(ivfpq_stage_b(h, p, nc, d_x + (size_t)q0 * h->d, R, k, h->w_cand_dis.as<float>(),
                              h->w_cand_ids.as<int64_t>(), d_distances + (size_t)q0 * k,
-                             d_labels + (size_t)q0 * k));
+                             d_labels + (size_t)q0 * k, getenv("GAMMA_HIP_NO_RERANK_ORDER") ? nullptr : h->last_qperm));
         h->last_nq = nc;
     }
     h->last_P = p->nprobe;

@@ -122,7 +122,8 @@ void launch_rerank_dist(hipStream_t s, bool l2, const float* x, int nq, int d, c
                         float max_score, float* out);
 void launch_rerank_topk(hipStream_t s, bool l2, const float* x, int nq, int d, const float* raw,
                         int64_t nraw, const int64_t* cand_ids, int R, int k, float min_score,
-                        float max_score, float neutral, float* distances, int64_t* labels);
+                        float max_score, float neutral, float* distances, int64_t* labels,
+                        const int* qperm = nullptr);   // qperm: run the queries in this order (speed only)
 void launch_finalize_topk(hipStream_t s, const float* sel_vals, const int* sel_pos, int nq, int k,
                           const int64_t* src_ids, int64_t src_stride, int64_t id_base,
                           float neutral, float* distances, int64_t* labels);

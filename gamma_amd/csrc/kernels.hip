@@ -1693,10 +1693,21 @@ __global__ __launch_bounds__(256) void k_rerank_topk(const float* __restrict__ x
                                                      const int64_t* __restrict__ cand_ids, int R, int k,
                                                      float min_score, float max_score, float neutral,
                                                      float* __restrict__ distances,
-                                                     int64_t* __restrict__ labels) {
+                                                     int64_t* __restrict__ labels, int nq,
+                                                     const int* __restrict__ qperm) {
     __shared__ unsigned long long s_it[1024];
     __shared__ int64_t s_id[1024];
-    const int q = blockIdx.x;
+    // With the scan's query order (qperm: queries sorted by the spatial rank of their nearest list) XCD x takes
+    // the x-th eighth of that order: queries running together share candidates (a batch references every raw
+    // row ~3 times), so their rows are served by that XCD's L2 instead of HBM.  Results do not depend on it.
+    int q = blockIdx.x;
+    if (qperm) {
+        const int qi = (blockIdx.x & 7) * ((nq + 7) >> 3) + (blockIdx.x >> 3);
+        if (qi >= nq) return;
+        q = qperm[qi];
+    } else if (q >= nq) {
+        return;
+    }
     const int l = threadIdx.x & 7, g = threadIdx.x >> 3;
     const float* xq = x + (int64_t)q * d;
     const float sentinel = L2 ? INFINITY : -INFINITY;
@@ -1788,14 +1799,15 @@ __global__ __launch_bounds__(256) void k_rerank_topk(const float* __restrict__ x
 }
 void launch_rerank_topk(hipStream_t s, bool l2, const float* x, int nq, int d, const float* raw,
                         int64_t nraw, const int64_t* cand_ids, int R, int k, float min_score,
-                        float max_score, float neutral, float* distances, int64_t* labels) {
+                        float max_score, float neutral, float* distances, int64_t* labels, const int* qperm) {
     if (nq <= 0) return;
+    const dim3 grid((unsigned)(8 * ((nq + 7) / 8)));
     if (l2)
-        hipLaunchKernelGGL((k_rerank_topk<true>), dim3(nq), dim3(256), 0, s, x, d, raw, nraw, cand_ids,
-                           R, k, min_score, max_score, neutral, distances, labels);
+        hipLaunchKernelGGL((k_rerank_topk<true>), grid, dim3(256), 0, s, x, d, raw, nraw, cand_ids,
+                           R, k, min_score, max_score, neutral, distances, labels, nq, qperm);
     else
-        hipLaunchKernelGGL((k_rerank_topk<false>), dim3(nq), dim3(256), 0, s, x, d, raw, nraw, cand_ids,
-                           R, k, min_score, max_score, neutral, distances, labels);
+        hipLaunchKernelGGL((k_rerank_topk<false>), grid, dim3(256), 0, s, x, d, raw, nraw, cand_ids,
+                           R, k, min_score, max_score, neutral, distances, labels, nq, qperm);
 }
 
 // final outputs from a top-k selection over re-ranked (or flat) candidates:
