@@ -12,18 +12,22 @@ WIDE = dict(min_score=-3e38, max_score=3e38)
 
 
 def _config(rng):
-    dsub = int(rng.choice([2, 4, 8, 12, 16]))
-    M = int(rng.choice([4, 8, 16, 32]))
+    M = int(rng.choice([4, 8, 16, 24, 32, 48, 64, 12]))        # compiled code widths and the generic byte loop (12)
+    dsub = int(rng.choice([x for x in (1, 2, 4, 8, 12, 16) if x * M <= 256]))
     d = dsub * M
-    if d > 256:
-        M = 8
-        d = dsub * M
     nlist = int(rng.choice([8, 24, 64, 100]))
     N = int(rng.integers(nlist * 45, nlist * 300))
     return d, M, nlist, min(N, 26000)
 
 
-@pytest.mark.parametrize("seed", list(range(24)))
+import os
+_SEEDS = list(range(24))
+if os.environ.get("GAMMA_FUZZ_SEEDS"):          # e.g. "100:160": an extended one-off run
+    _a, _b = os.environ["GAMMA_FUZZ_SEEDS"].split(":")
+    _SEEDS = list(range(int(_a), int(_b)))
+
+
+@pytest.mark.parametrize("seed", _SEEDS)
 def test_random_configuration(seed):
     rng = np.random.default_rng(1000 + seed)
     d, M, nlist, N = _config(rng)
