@@ -89,7 +89,7 @@ struct ScanBound {
     int K;                      // recall_num
 };
 int scan_slice_cap();
-int scan_group_size(int nq, int P, int G0 = 4);   // G0: probes per workgroup to start from (power of two)
+int scan_group_size(int nq, int P, int G0 = 8);   // G0: probes per workgroup to start from (power of two)
 void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int d, int M, int P,
                             const int* probe_list, const float* coarse_dis, const float* cc,
                             const float* st2, const float* T2, const int64_t* list_off,
