@@ -580,8 +580,8 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     // (sharded without a supplied assignment: probe groups are sparse, nothing to bound from)
     // small batches: one probe per workgroup, a single list rarely holds R candidates, and the
     // unfiltered selection is latency-bound anyway
-    const bool bounded = (!shard || compacted) && h->scan_bound && R <= 256 && P <= 128 && G >= 4 &&
-                         (PGN >= 2 || compacted);
+    // (one group per query -- few probes, or a shard -- is fine: the producer bounds and compacts its own candidates)
+    const bool bounded = (!shard || compacted) && h->scan_bound && R <= 256 && P <= 128 && G >= 4;
     const bool fuse_ip = bounded && PGN == 1 && (M == 16 || M == 32) && !getenv("GAMMA_HIP_NO_FUSED_IP");
     {
         StageScope t(h, GAMMA_HIP_STAGE_TABLES);
