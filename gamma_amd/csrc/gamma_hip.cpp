@@ -557,7 +557,9 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     // count per query is small, ONE workgroup takes all of a query's probes (G = P): it bounds the
     // R-th best itself (producer path of the pre-filter, no consumers), and computes the query's PQ
     // table on the fly instead of reading it back from HBM (IPF, kernels.hip).
-    int G0 = 8;
+    // 8 probes per workgroup pay off with short lists (half the query-table re-reads, a tighter bound from a
+    // first group of 8 lists); long lists or many probes balance better with 4 (tools/shape_sweep.py)
+    int G0 = ((double)h->ntotal / std::max(1, nlist) <= 700.0 && P <= 64) ? 8 : 4;
     int64_t t2_bytes = (int64_t)nlist * M * 256 * sizeof(float);
     const bool compacted = shard && pre_dis && pre_probe;
     if (compacted && h->scan_bound && R <= 256) {
