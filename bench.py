@@ -49,6 +49,10 @@ def main():
     ap.add_argument("--recall-queries", type=int, default=1000)
     ap.add_argument("--force-dist", action="store_true",
                     help="run the sharded orchestration (gamma_amd.dist) even on one GPU")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend; 'gloo' with --one-gpu runs all ranks on GPU 0 (functional "
+                         "check of the multi-rank path on a single-GPU box, not a measurement)")
+    ap.add_argument("--one-gpu", action="store_true", help="every rank uses cuda:0")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per scan launch from a separate rocprofv3 --pmc pass")
     a = ap.parse_args()
@@ -61,7 +65,7 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if a.one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         log("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (a.gpus, world))
     torch.cuda.set_device(local_rank)
@@ -72,7 +76,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29711")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
 
     t0 = time.time()
     N, d, nlist, M = a.n, a.d, a.nlist, a.m

@@ -18,10 +18,16 @@ from tests.parity import compare_topk  # noqa: E402
 
 
 def main():
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("GAMMA_TEST_BACKEND", "nccl")
+    # gloo: several ranks share GPU 0 (RCCL refuses that) -- the multi-rank path with real exchanges on a
+    # single-GPU box; the collectives then run through gloo on the same CUDA tensors
+    local = int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist.init_process_group("nccl", device_id=dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
     rank, world = dist.get_rank(), dist.get_world_size()
     case = fixtures.trained_case(d=32, nlist=64, M=8, N=20000, nq=64, metric=B.METRIC_L2)
     sizes = np.array([case["oracle"].list_size(l) for l in range(case["nlist"])])

@@ -107,6 +107,21 @@ def test_shards_on_one_gpu(metric, has_rank, W, nq, P, d, M):
         g.close()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_search_real_ranks_sharing_one_gpu(world):
+    """The orchestration with REAL ranks (separate processes, each owning a shard, every exchange a real
+    collective) on a single-GPU box: the ranks share GPU 0 and the collectives go through gloo on the CUDA
+    tensors (RCCL refuses two ranks on one device)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", GAMMA_TEST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
+                        "--master-addr", "127.0.0.1", "--master-port", str(29680 + world),
+                        os.path.join(ROOT, "tests", "_dist_gpu_worker.py")],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for rk in range(world):
+        assert "rank %d ok" % rk in r.stdout
+
+
 def test_sharded_search_over_rccl_world1():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
