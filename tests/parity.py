@@ -51,9 +51,20 @@ def compare_search(D, I, st, Dg, Ig, sg):
     rd_o, rd_g = st["recall_dis"].copy(), sg["recall_dis"].copy()
     rd_o[st["recall_ids"] == -1] = 0      # oracle pads with FLT_MAX, device with +-inf
     rd_g[sg["recall_ids"] == -1] = 0
-    compare_topk(rd_o, st["recall_ids"], rd_g, sg["recall_ids"])
-    same = np.array([set(a.tolist()) == set(b.tolist())
-                     for a, b in zip(st["recall_ids"], sg["recall_ids"])])
+    # The same one stage earlier: two centroids at exactly the same fp32 distance straddling the nprobe
+    # boundary (about 1e-5 of the queries on fp32 data).  The reference probes whichever of them its
+    # heap happens to hold, the device the one with the lower list number; the sorted coarse distances
+    # are identical, the probed SET differs, and everything downstream legitimately does too.
+    keep = np.ones(len(rd_o), dtype=bool)
+    if "coarse_idx" in st and "coarse_idx" in sg and st["coarse_idx"].shape == sg["coarse_idx"].shape:
+        for qi, (a, b) in enumerate(zip(st["coarse_idx"], sg["coarse_idx"])):
+            if set(a.tolist()) != set(b.tolist()):
+                assert st["coarse_dis"][qi].tobytes() == sg["coarse_dis"][qi].tobytes(), \
+                    "probed lists differ without a tie in the coarse distances (q=%d)" % qi
+                keep[qi] = False
+    compare_topk(rd_o[keep], st["recall_ids"][keep], rd_g[keep], sg["recall_ids"][keep])
+    same = keep & np.array([set(a.tolist()) == set(b.tolist())
+                            for a, b in zip(st["recall_ids"], sg["recall_ids"])])
     if same.any():
         compare_topk(D[same], I[same], Dg[same], Ig[same])
     return int((~same).sum())
