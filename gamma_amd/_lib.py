@@ -46,6 +46,7 @@ SYMBOLS = {
     "gamma_hip_stream": (C.c_void_p, [C.c_void_p]),
     "gamma_hip_synchronize": (C.c_int, [C.c_void_p]),
     "gamma_hip_set_workspace_budget": (C.c_int, [C.c_void_p, C.c_int64]),
+    "gamma_hip_set_exact_ties": (C.c_int, [C.c_void_p, C.c_int]),
     "gamma_hip_field_append": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     "gamma_hip_field_update": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     "gamma_hip_field_count": (C.c_int64, [C.c_void_p, C.c_int]),

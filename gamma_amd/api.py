@@ -276,6 +276,10 @@ class GammaHip:
     def set_dist_budget(self, nbytes):
         self._ck(self.L.gamma_hip_set_workspace_budget(self.h, int(nbytes)), "set_workspace_budget")
 
+    def set_exact_ties(self, on=True):
+        """probe exactly the lists the reference's heap keeps when coarse distances tie at the nprobe boundary"""
+        self._ck(self.L.gamma_hip_set_exact_ties(self.h, 1 if on else 0), "set_exact_ties")
+
     # ---- numeric columns for on-device range filters ----
     _FIELD_DTYPES = {np.dtype(np.int32): 0, np.dtype(np.int64): 1, np.dtype(np.float32): 2,
                      np.dtype(np.float64): 3}

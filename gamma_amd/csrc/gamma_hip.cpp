@@ -123,7 +123,7 @@ struct gamma_hip_index {
     DevBuf w_mat, w_coarse_dis, w_probe, w_xn, w_st2, w_pair_off, w_qtotal, w_dist, w_cand_dis,
             w_cand_pos, w_cand_ids, w_exact, w_selv, w_selp, w_x, w_outd, w_outl, w_stage, w_filter,
             w_m_dis, w_m_ids, w_part_v, w_part_i, w_assign, w_codes_tmp, w_qperm, w_scnt, w_sflag, w_surv, w_pair_base,
-            w_pair_ip, w_flat_cand, w_flat_meta, w_full_cdis, w_full_probe, w_ftab, w_qfil;
+            w_pair_ip, w_flat_cand, w_flat_meta, w_full_cdis, w_full_probe, w_ftab, w_qfil, w_tieflag;
     unsigned long long* d_scan_codes = nullptr;
     size_t dist_budget_bytes = (size_t)8 << 30;   // per-chunk ADC distance buffer (288 GB of HBM per GPU)
 
@@ -131,6 +131,8 @@ struct gamma_hip_index {
     // host image of what entry 0 holds, so an unchanged descriptor is not uploaded again
     gh::FilterDesc ftab_shadow;
     bool ftab_valid = false;
+
+    bool exact_ties = false;   // gamma_hip_set_exact_ties
 
     // last-search stage info
     int last_nq = 0, last_P = 0, last_R = 0;
@@ -503,7 +505,9 @@ int ivfpq_coarse(H* h, const gamma_hip_search_params* p, int nq, const float* d_
         gh::launch_l2_gemmform(s, d_x, nq, d, h->d_cc, nlist, nullptr, h->d_cc_norms,
                                h->w_mat.as<float>(), nlist, true);
     }
-    gh::launch_select_topk(s, true, h->w_mat.as<float>(), nlist, nullptr, nlist, nlist, nq, P, out_dis, out_probe);
+    if (h->exact_ties) GH_CHECK(h, h->w_tieflag.ensure((size_t)nq));
+    gh::launch_coarse_select(s, h->w_mat.as<float>(), nlist, nq, P, out_dis, out_probe,
+                             h->exact_ties ? h->w_tieflag.as<uint8_t>() : nullptr);
     return GAMMA_HIP_OK;
 }
 
@@ -1000,7 +1004,7 @@ int gamma_hip_destroy(gamma_hip_index* h) {
                       &h->w_filter, &h->w_m_dis, &h->w_m_ids, &h->w_part_v, &h->w_part_i, &h->w_assign,
                       &h->w_codes_tmp, &h->w_qperm, &h->w_scnt, &h->w_sflag, &h->w_surv, &h->w_pair_base,
                       &h->w_pair_ip, &h->w_flat_cand, &h->w_flat_meta, &h->w_full_cdis,
-                      &h->w_full_probe, &h->w_ftab, &h->w_qfil};
+                      &h->w_full_probe, &h->w_ftab, &h->w_qfil, &h->w_tieflag};
     for (DevBuf* b : bufs) b->release();
     (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1024,6 +1028,13 @@ size_t field_elem_size(int dtype) {
     return dtype == GAMMA_HIP_FIELD_INT || dtype == GAMMA_HIP_FIELD_FLOAT ? 4 : 8;
 }
 }  // namespace
+
+int gamma_hip_set_exact_ties(gamma_hip_index* h, int on) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    h->exact_ties = on != 0;
+    return GAMMA_HIP_OK;
+}
 
 int gamma_hip_set_workspace_budget(gamma_hip_index* h, int64_t bytes) {
     if (!h || bytes <= 0) return GAMMA_HIP_EINVAL;

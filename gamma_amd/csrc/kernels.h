@@ -105,6 +105,9 @@ void launch_query_order(hipStream_t s, const int* probe_list, int nq, int P, con
                         int nlist, int* qkey, int* qperm, int* bins = nullptr);
 void launch_sum_totals(hipStream_t s, const int* q_total, int nq, unsigned long long* acc);
 int select_kpad(int K);
+// coarse quantizer selection (ties at the K-th distance resolved like the reference's heap); tie_flag: nq bytes
+void launch_coarse_select(hipStream_t s, const float* mat, int nlist, int nq, int K, float* out_vals, int* out_pos,
+                          uint8_t* tie_flag);
 void launch_select_topk(hipStream_t s, bool smallest, const float* vals, int64_t seg_stride,
                         const int* seg_len, int fixed_len, int max_len, int nseg, int K,
                         float* out_vals, int* out_pos, const uint8_t* only = nullptr);

@@ -506,7 +506,8 @@ template <bool SMALLEST>
 __global__ __launch_bounds__(256) void k_select_wave(const float* __restrict__ vals, int64_t seg_stride,
                                                      const int* __restrict__ seg_len, int fixed_len,
                                                      int nseg, int K, float* __restrict__ out_vals,
-                                                     int* __restrict__ out_pos) {
+                                                     int* __restrict__ out_pos,
+                                                     uint8_t* __restrict__ tie_flag = nullptr) {
     __shared__ unsigned long long s_buf[4][SW_CAP];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int seg = blockIdx.x * 4 + w;
@@ -562,9 +563,16 @@ __global__ __launch_bounds__(256) void k_select_wave(const float* __restrict__ v
                 if (key[j] <= tau && j * 64 < nrem)
                     buf[off++] = ((unsigned long long)key[j] << 32) | (unsigned)(base + j * 64 + lane);
             __builtin_amdgcn_wave_barrier();
-            wave_rank_take(buf, run + tot, K);
+            // tie_flag (coarse quantizer, rows of one chunk): one rank more is kept -- is the (K+1)-th key equal
+            // to the K-th?  Then WHICH of the tied entries the reference keeps is decided by its heap
+            // (k_coarse_heap_fix redoes the row the way the heap does).
+            const bool want_flag = tie_flag && base == 0 && n <= 64 * SW_NPL;
+            wave_rank_take(buf, run + tot, want_flag ? K + 1 : K);
+            if (want_flag && lane == 0)
+                tie_flag[seg] = (run + tot > K && (uint32_t)(buf[K] >> 32) == (uint32_t)(buf[K - 1] >> 32)) ? 1 : 0;
             run = min(run + tot, K);
         } else {
+            if (tie_flag && base == 0 && n <= 64 * SW_NPL && lane == 0) tie_flag[seg] = 1;   // not known here: redo the row
             // exact extraction from the registers: K rounds of (lane arg-min, wave arg-min)
             unsigned long long rm = 0;   // bit j: slot j already taken
             int got = 0;
@@ -1195,6 +1203,126 @@ void launch_flat_compact(hipStream_t s, int nq, int k, const FlatEmit& em, uint3
 void launch_flat_final(hipStream_t s, bool l2, int nq, int k, const FlatEmit& em, float neutral, float* distances,
                        int64_t* labels) {
     if (nq > 0) hipLaunchKernelGGL(k_flat_final, dim3(nq), dim3(256), 0, s, k, l2, em, neutral, distances, labels);
+}
+
+// ------------------------------------------------------------------------------------
+// Coarse quantizer, rows whose K-th distance is tied with an entry left outside (flag from
+// k_select_wave): redo the row exactly as faiss's HeapResultHandler does (faiss:utils/Heap.h:103-131,
+// faiss:impl/ResultHandler.h:112-117; knn_L2sqr uses it below 100 results) -- a max-heap of K
+// (FLT_MAX, -1) entries, entries visited in index order, `if (top > dis) replace_top`, then
+// heap_reorder -- so that the SAME tied lists are probed.  One wave per flagged row: the 64 lanes find
+// the next entry that beats the heap's top, lane 0 sifts it in.  ~1e-5 of the rows on fp32 data.
+// ------------------------------------------------------------------------------------
+// The heap lives in registers, node i (1-based) in lane i - 1: every index of the sift is wave-uniform, so
+// nodes are read with v_readlane and written with a lane-select move (a few cycles) instead of LDS round trips.
+// (the lane index is forced into an SGPR: with an index the compiler cannot prove uniform it would wrap every
+//  v_readlane in a waterfall loop, ~100 cycles each)
+__device__ __forceinline__ float rl_f(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_amdgcn_readfirstlane(l)));
+}
+__device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l)); }
+__device__ __forceinline__ void wl_f(float& v, int l, float x) { v = (int)(threadIdx.x & 63) == l ? x : v; }
+__device__ __forceinline__ void wl_i(int& v, int l, int x) { v = (int)(threadIdx.x & 63) == l ? x : v; }
+
+// 1-based sift of faiss's heap_pop / heap_replace_top (CMax: cmp(a, b) = a > b), heap of k nodes
+__device__ __forceinline__ void heap_sift_down(int k, float& hv, int& hi, float val, int id) {
+    int i = 1;
+    for (;;) {
+        const int i1 = i << 1, i2 = i1 + 1;
+        if (i1 > k) break;
+        const float v1 = rl_f(hv, i1 - 1);
+        const float v2 = i2 <= k ? rl_f(hv, i2 - 1) : 0.f;
+        if (i2 == k + 1 || v1 > v2) {
+            if (val > v1) break;
+            wl_f(hv, i - 1, v1);
+            wl_i(hi, i - 1, rl_i(hi, i1 - 1));
+            i = i1;
+        } else {
+            if (val > v2) break;
+            wl_f(hv, i - 1, v2);
+            wl_i(hi, i - 1, rl_i(hi, i2 - 1));
+            i = i2;
+        }
+    }
+    wl_f(hv, i - 1, val);
+    wl_i(hi, i - 1, id);
+}
+
+__global__ __launch_bounds__(256) void k_coarse_heap_fix(const float* __restrict__ mat, int64_t ld, int n, int K,
+                                                         int nq, const uint8_t* __restrict__ flag,
+                                                         float* __restrict__ out_vals, int* __restrict__ out_pos) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + w;
+    if (q >= nq || !flag[q]) return;   // whole wave
+    float hv = 3.402823466e+38f;       // heap_heapify: (FLT_MAX, -1) everywhere
+    int hi = -1;
+    const float* v = mat + (int64_t)q * ld;
+    // the whole row (n <= 4096) goes to LDS first, 16 loads in flight per lane: one global round trip per
+    // 64-entry block of the sequential walk below would cost more than the walk itself
+    __shared__ float s_row[4][64 * SW_NPL];
+    float* row = s_row[w];
+    for (int i0 = 0; i0 < n; i0 += 64 * 16) {
+        float t[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) t[u] = v[min(i0 + u * 64 + lane, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+            if (i0 + u * 64 + lane < n) row[i0 + u * 64 + lane] = t[u];
+    }
+    __builtin_amdgcn_wave_barrier();
+    float top = 3.402823466e+38f;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + lane;
+        const float dv = j < n ? row[j] : 3.402823466e+38f;
+        int from = 0;
+        for (;;) {
+            unsigned long long m = __ballot(j < n && top > dv);
+            m &= from >= 64 ? 0ull : (~0ull << from);
+            if (m == 0ull) break;
+            const int l = (int)__ffsll((long long)m) - 1;
+            heap_sift_down(K, hv, hi, rl_f(dv, l), j0 + l);
+            top = rl_f(hv, 0);
+            from = l + 1;
+        }
+    }
+    // heap_reorder (faiss:utils/Heap.h:300-330), as written: K pops, real entries packed from the back
+    float ov = INFINITY;
+    int oi = -1;
+    int ii = 0;
+    for (int i = 0; i < K; i++) {
+        const float val = rl_f(hv, 0);
+        const int id = rl_i(hi, 0);
+        const int kk = K - i;
+        heap_sift_down(kk, hv, hi, rl_f(hv, kk - 1), rl_i(hi, kk - 1));   // heap_pop
+        wl_f(ov, K - ii - 1, val);
+        wl_i(oi, K - ii - 1, id);
+        if (id != -1) ii++;
+    }
+    // real entries sit in lanes [K - ii, K): move to the front, pad with (+inf, -1)
+    const float rv = __shfl(ov, min(lane + K - ii, 63), 64);
+    const int ri = __shfl(oi, min(lane + K - ii, 63), 64);
+    if (lane < K) {
+        out_vals[(int64_t)q * K + lane] = lane < ii ? rv : INFINITY;
+        out_pos[(int64_t)q * K + lane] = lane < ii ? ri : -1;
+    }
+}
+
+// top-K nearest centroids of every row of the coarse distance matrix.  tie_flag != nullptr (nq bytes of
+// scratch; gamma_hip_set_exact_ties): with the reference's choice among entries tied at the K-th distance
+// (K <= 64, rows of <= 4096 entries; other shapes keep the (distance, index) order).  A flagged row is a
+// sequential walk of one wave, ~0.17 ms, and about 3 rows in 10^4 are flagged on fp32 data -- hence opt-in.
+void launch_coarse_select(hipStream_t s, const float* mat, int nlist, int nq, int K, float* out_vals, int* out_pos,
+                          uint8_t* tie_flag) {
+    static const bool off = getenv("GAMMA_HIP_NO_WAVE_SELECT") != nullptr;
+    if (nq <= 0) return;
+    if (off || !tie_flag || K > 64 || nlist > 64 * SW_NPL) {
+        launch_select_topk(s, true, mat, nlist, nullptr, nlist, nlist, nq, K, out_vals, out_pos);
+        return;
+    }
+    hipLaunchKernelGGL((k_select_wave<true>), dim3((nq + 3) / 4), dim3(256), 0, s, mat, (int64_t)nlist, nullptr, nlist, nq,
+                       K, out_vals, out_pos, tie_flag);
+    hipLaunchKernelGGL(k_coarse_heap_fix, dim3((nq + 3) / 4), dim3(256), 0, s, mat, (int64_t)nlist, nlist, K, nq, tie_flag,
+                       out_vals, out_pos);
 }
 
 int select_kpad(int K) {

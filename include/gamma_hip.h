@@ -102,6 +102,12 @@ int gamma_hip_synchronize(gamma_hip_index* h);
 /* Upper bound in bytes of the per-chunk workspaces (coarse distance matrix, ADC distance buffer);
  * larger calls are processed in chunks of queries.  Default: an eighth of the device memory, 1 to 32 GiB. */
 int gamma_hip_set_workspace_budget(gamma_hip_index* h, int64_t bytes);
+/* Coarse quantizer ties.  Two centroids at exactly the same fp32 distance can straddle the nprobe boundary
+ * (about 3 queries in 10^4 on fp32 data); faiss probes whichever of them its binary heap happens to hold
+ * (HeapResultHandler, faiss:impl/ResultHandler.h:112-117, faiss:utils/Heap.h:103-131), the device by default
+ * the one with the lower list number.  on != 0: such rows are redone exactly as the heap does (nprobe <= 64,
+ * nlist <= 4096), so the probed lists are the reference's; costs ~0.17 ms per batch containing such a row. */
+int gamma_hip_set_exact_ties(gamma_hip_index* h, int on);
 
 /* ---- numeric scalar columns for on-device range filters (docid = row).  The engine side
  *      appends a doc's value when the doc is added (Table::Add, table/table.cc) ----------- */

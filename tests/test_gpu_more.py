@@ -517,6 +517,49 @@ def test_scan_bound_with_more_than_64_probes(P):
         g.close()
 
 
+def test_coarse_ties_at_the_nprobe_boundary_follow_the_reference_heap():
+    """Centroids duplicated in pairs: with an odd nprobe the nprobe-th and the next coarse distance are always
+    equal, and WHICH of the two lists is probed is decided by faiss's heap (HeapResultHandler).  The device
+    redoes such rows the way the heap does (k_coarse_heap_fix): the probed sets must be identical, for the
+    exact (nq < 20) and the GEMM-form coarse path, and the searches must agree downstream."""
+    case = fixtures.trained_case(d=32, nlist=64, M=8, N=20000, nq=64, metric=B.METRIC_L2)
+    cc = case["cc"].copy()
+    cc[1::2] = cc[0::2]
+    base = case["base"][:8000]
+    o = B.OracleIVFPQ(case["d"], case["nlist"], case["M"], 8, B.METRIC_L2)
+    o.set_trained(cc, case["pq"], None)
+    g = api.GammaHip(0)
+    try:
+        g.ivfpq_init(case["d"], case["nlist"], case["M"], 8, api.METRIC_L2, 1000)
+        g.ivfpq_set_trained(cc, case["pq"], None)
+        g.set_exact_ties(True)          # opt-in: a flagged row is a sequential walk (DESIGN §4)
+        g.raw_init(case["d"])
+        g.raw_append(base)
+        B.lib().go_set_assign_mode(1)
+        g.add(base, 0)
+        assert o.add(base)
+        B.lib().go_set_assign_mode(0)
+        o.set_raw(base)
+        q = synth.sift_like(300, d=case["d"], seed=4)
+        n_split = 0
+        for nq, P in ((5, 7), (24, 7), (300, 7), (300, 31), (24, 32), (300, 64)):
+            ctx = B.make_ctx(**WIDE)
+            D, I, st = o.search(q[:nq], 10, P, recall_num=60, has_rank=True, metric=B.METRIC_L2, ctx=ctx,
+                                coarse_mode=-1, want_stages=True)
+            Dg, Ig = g.ivfpq_search(q[:nq], 10, api.SearchArgs(metric=api.METRIC_L2, nprobe=P, recall_num=60,
+                                                              has_rank=True, coarse_mode=-1, **WIDE))
+            sg = g.last_stages(nq, P, 60)
+            assert sg["coarse_dis"].tobytes() == st["coarse_dis"].tobytes()
+            for a, b in zip(st["coarse_idx"], sg["coarse_idx"]):
+                assert set(a.tolist()) == set(b.tolist())
+                n_split += (a[-1] ^ 1) not in a.tolist() if P < 64 else 0
+            compare_search(D, I, st, Dg, Ig, sg)
+        assert n_split > 100          # the boundary really did split pairs
+    finally:
+        B.lib().go_set_assign_mode(0)
+        g.close()
+
+
 def test_scan_bound_fallback_paths():
     """The threshold pre-filter of the scan must hand a query over to the unfiltered selection when
     it has no usable bound: (a) mass ties -- every candidate within the bound, survivor slices
