@@ -57,6 +57,15 @@ def main():
                     help="HBM bytes per scan launch from a separate rocprofv3 --pmc pass")
     a = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher: this process only starts the N ranks (one fresh process per
+    # GPU, RCCL rendezvous on 127.0.0.1) -- BEFORE anything here touches the GPU -- and waits for them; rank 0
+    # prints the line.  Under torchrun (WORLD_SIZE set) the world size must BE --gpus.
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:
+        log("error: --gpus %d but WORLD_SIZE=%s" % (a.gpus, os.environ.get("WORLD_SIZE")))
+        sys.exit(2)
+
     import torch
     import torch.distributed as dist
 
@@ -66,8 +75,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = 0 if a.one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        log("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (a.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or a.force_dist
@@ -80,6 +87,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(a.backend)
+        if dist.get_world_size() != a.gpus:
+            log("error: process group of %d ranks for --gpus %d" % (dist.get_world_size(), a.gpus))
+            sys.exit(2)
 
     t0 = time.time()
     N, d, nlist, M = a.n, a.d, a.nlist, a.m
@@ -271,6 +281,35 @@ def main():
     print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def spawn_ranks(n):
+    """Start n copies of this script as ranks 0..n-1 of one job (what `torch.distributed.run --nnodes=1
+    --nproc-per-node n` would do) and return the worst exit code.  Children inherit stdout / stderr."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while rc == 0 and any(p.poll() is None for p in procs):
+            time.sleep(0.2)
+            rc = max(abs(p.returncode) for p in procs if p.returncode is not None) if any(
+                p.returncode is not None for p in procs) else 0
+        rc = max([rc] + [abs(p.returncode) for p in procs if p.returncode is not None])
+    finally:
+        for p in procs:                 # a rank died: the others would wait in a collective forever
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def cpu_baseline(a, base, queries, cc, pq, g, lno, codes, list_sizes):

@@ -120,6 +120,10 @@ class GammaHip:
         vecs = _f32(vecs)
         self._ck(self.L.gamma_hip_raw_append(self.h, vecs.shape[0], _p(vecs, _lib.f32p)), "raw_append")
 
+    def raw_write(self, first_vid, vecs):
+        vecs = _f32(vecs)
+        self._ck(self.L.gamma_hip_raw_write(self.h, first_vid, vecs.shape[0], _p(vecs, _lib.f32p)), "raw_write")
+
     def raw_update(self, vid, vec):
         vec = _f32(vec)
         self._ck(self.L.gamma_hip_raw_update(self.h, vid, _p(vec, _lib.f32p)), "raw_update")
@@ -187,6 +191,14 @@ class GammaHip:
 
     def compact_if_need(self):
         self._ck(self.L.gamma_hip_ivfpq_compact_if_need(self.h), "compact_if_need")
+
+    def arena_stats(self):
+        out = np.zeros(4, np.int64)
+        self._ck(self.L.gamma_hip_ivfpq_arena_stats(self.h, _p(out, _lib.i64p)), "arena_stats")
+        return dict(zip(["cap", "used", "waste", "repacks"], [int(v) for v in out]))
+
+    def set_repack_threshold(self, min_waste_entries):
+        self._ck(self.L.gamma_hip_ivfpq_set_repack_threshold(self.h, min_waste_entries), "set_repack_threshold")
 
     def list_size(self, l):
         return self.L.gamma_hip_ivfpq_list_size(self.h, l)

@@ -107,7 +107,9 @@ struct gamma_hip_index {
     // inverted-list arena
     uint8_t* d_codes = nullptr;
     int64_t* d_ids = nullptr;
-    int64_t arena_cap = 0, arena_used = 0, arena_waste = 0;
+    int64_t arena_cap = 0, arena_used = 0, arena_waste = 0;   // entries; waste = abandoned extents inside used
+    int64_t repack_min_entries = 1 << 16;                     // no repack for less waste than this
+    int64_t n_repacks = 0;
     std::vector<int64_t> h_list_off;
     std::vector<int> h_list_len, h_list_cap, h_deleted;
     std::vector<uint8_t> h_extend_time;
@@ -271,6 +273,48 @@ int arena_reserve(H* h, int64_t need_entries) {
     return GAMMA_HIP_OK;
 }
 
+// The reference frees a bucket's old memory after a grow / compact swap (delayed by 1 s,
+// realtime_mem_data.cc:457-466).  Here grown and compacted extents are abandoned inside the arena
+// (arena_waste); once they are more than half of what is in use -- and worth at least a megabyte of codes --
+// every list moves into a fresh, tight arena: one kernel, offsets re-published in stream order.
+int arena_repack(H* h) {
+    int64_t total = 0;
+    std::vector<int64_t> noff(h->nlist);
+    for (int l = 0; l < h->nlist; l++) {
+        noff[l] = total;
+        total += h->h_list_cap[l];
+    }
+    const int64_t ncap = total + total / 8 + 1024;
+    uint8_t* nc = nullptr;
+    int64_t* ni = nullptr;
+    GH_CHECK(h, hipMalloc((void**)&nc, (size_t)ncap * h->code_size));
+    if (hipMalloc((void**)&ni, (size_t)ncap * sizeof(int64_t)) != hipSuccess) {
+        (void)hipFree(nc);
+        return fail(h, GAMMA_HIP_ENOMEM, "arena repack: out of memory");
+    }
+    GH_CHECK(h, h->w_stage.ensure((size_t)h->nlist * sizeof(int64_t)));
+    GH_CHECK(h, hipMemcpyAsync(h->w_stage.p, noff.data(), (size_t)h->nlist * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    gh::launch_repack_lists(h->stream, h->d_codes, h->d_ids, nc, ni, h->d_list_off, h->w_stage.as<int64_t>(),
+                            h->d_list_len, h->nlist, h->code_size, h->max_list_len);
+    GH_CHECK(h, hipMemcpyAsync(h->d_list_off, noff.data(), (size_t)h->nlist * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    GH_CHECK(h, hipStreamSynchronize(h->stream));   // noff is a local; the old arrays are free to go
+    GH_CHECK(h, hipFree(h->d_codes));
+    GH_CHECK(h, hipFree(h->d_ids));
+    h->d_codes = nc;
+    h->d_ids = ni;
+    h->arena_cap = ncap;
+    h->arena_used = total;
+    h->arena_waste = 0;
+    h->h_list_off = noff;
+    h->n_repacks++;
+    return GAMMA_HIP_OK;
+}
+int arena_repack_if_need(H* h) {
+    const int64_t min_waste = std::max<int64_t>(h->repack_min_entries, 1);
+    if (h->arena_waste < min_waste || h->arena_waste * 2 < h->arena_used) return GAMMA_HIP_OK;
+    return arena_repack(h);
+}
+
 // RealTimeMemData::ExtendBucketIfNeed + RTInvertBucketData::ExtendBucketMem
 // (realtime_mem_data.cc:383-421,152-188): same growth law, region moved inside the arena.
 int list_ensure(H* h, int l, int add) {
@@ -334,7 +378,8 @@ int add_keys_locked(H* h, int l, int n, const int64_t* vids, const uint8_t* code
     }
     h->h_list_len[l] += n;  // publish after the copies (realtime_mem_data.cc:299-300)
     h->ntotal += n;
-    return publish_len(h, l);
+    GH_TRY(publish_len(h, l));
+    return arena_repack_if_need(h);
 }
 
 // off != nullptr: the range bitmaps go to w_filter at *off (advanced; the caller has sized w_filter for all
@@ -1128,6 +1173,21 @@ int gamma_hip_raw_append(gamma_hip_index* h, int64_t n, const float* vecs) {
     return GAMMA_HIP_OK;
 }
 
+int gamma_hip_raw_write(gamma_hip_index* h, int64_t first_vid, int64_t n, const float* vecs) {
+    if (!h || n < 0 || first_vid < 0 || (n > 0 && !vecs)) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->raw_d <= 0) return fail(h, GAMMA_HIP_EINVAL, "raw store not initialised");
+    if (first_vid > h->nraw) return fail(h, GAMMA_HIP_EINVAL, "raw write would leave a gap");
+    if (n == 0) return GAMMA_HIP_OK;
+    GH_CHECK(h, hipSetDevice(h->device));
+    GH_TRY(raw_reserve(h, first_vid + n));
+    GH_CHECK(h, hipMemcpyAsync(h->d_raw + first_vid * h->raw_d, vecs, (size_t)n * h->raw_d * sizeof(float),
+                               hipMemcpyHostToDevice, h->stream));
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    h->nraw = std::max(h->nraw, first_vid + n);
+    return GAMMA_HIP_OK;
+}
+
 int gamma_hip_raw_update(gamma_hip_index* h, int64_t vid, const float* vec) {
     if (!h || !vec) return GAMMA_HIP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
@@ -1301,10 +1361,17 @@ int gamma_hip_ivfpq_add_keys_batch(gamma_hip_index* h, int nlists, const int32_t
     if (!h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
     GH_CHECK(h, hipSetDevice(h->device));
     int64_t off = 0;
-    // grow first so that no copy below races with an arena move
-    for (int i = 0; i < nlists; i++) {
-        if (list_nos[i] < 0 || list_nos[i] >= h->nlist || counts[i] < 0) return fail(h, GAMMA_HIP_EINVAL, "bad list_no");
-        GH_TRY(list_ensure(h, list_nos[i], counts[i]));
+    // grow first so that no copy below races with an arena move; a list named twice reserves for the sum
+    {
+        std::map<int, int64_t> per_list;
+        for (int i = 0; i < nlists; i++) {
+            if (list_nos[i] < 0 || list_nos[i] >= h->nlist || counts[i] < 0) return fail(h, GAMMA_HIP_EINVAL, "bad list_no");
+            per_list[list_nos[i]] += counts[i];
+        }
+        for (auto& kv : per_list) {
+            if (kv.second > h->bucket_max) return fail(h, GAMMA_HIP_EFULL, "exceed the max bucket keys");
+            GH_TRY(list_ensure(h, kv.first, (int)kv.second));
+        }
     }
     for (int i = 0; i < nlists; i++) {
         const int l = list_nos[i], n = counts[i];
@@ -1315,7 +1382,11 @@ int gamma_hip_ivfpq_add_keys_batch(gamma_hip_index* h, int nlists, const int32_t
                                    (size_t)n * h->code_size, hipMemcpyHostToDevice, h->stream));
         for (int j = 0; j < n; j++) {
             const int64_t v = vids[off + j];
-            if (v < 0) continue;
+            if (v < 0) {   // superseded slot restored from a dump: same accounting as add_keys_locked, so that
+                h->h_deleted[l]++;   // the scan reads the ids (n_moved) and never returns the slot
+                h->n_moved++;
+                continue;
+            }
             if ((size_t)v >= h->vid_pos.size()) h->vid_pos.resize(std::max<size_t>(h->vid_pos.size() * 2, v + 1), -1);
             h->vid_pos[v] = ((int64_t)l << 32) | (int64_t)(h->h_list_len[l] + j);
             if (h->bitmap_bits > v && !h->h_bitmap.empty() && ((h->h_bitmap[v >> 3] >> (v & 7)) & 1)) h->h_deleted[l]++;
@@ -1329,7 +1400,7 @@ int gamma_hip_ivfpq_add_keys_batch(gamma_hip_index* h, int nlists, const int32_t
     GH_CHECK(h, hipMemcpyAsync(h->d_list_len, h->h_list_len.data(), (size_t)h->nlist * sizeof(int),
                                hipMemcpyHostToDevice, h->stream));
     GH_CHECK(h, hipStreamSynchronize(h->stream));
-    return GAMMA_HIP_OK;
+    return arena_repack_if_need(h);
 }
 
 int gamma_hip_ivfpq_update(gamma_hip_index* h, int list_no, int64_t vid, const uint8_t* code) {
@@ -1415,8 +1486,28 @@ int gamma_hip_ivfpq_compact_if_need(gamma_hip_index* h) {
     if (changed) {
         h->max_list_len = 0;
         for (int l = 0; l < h->nlist; l++) h->max_list_len = std::max(h->max_list_len, h->h_list_len[l]);
+        GH_TRY(arena_repack_if_need(h));
     }
     return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_arena_stats(gamma_hip_index* h, int64_t* out4) {
+    if (!h || !out4) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    out4[0] = h->arena_cap;
+    out4[1] = h->arena_used;
+    out4[2] = h->arena_waste;
+    out4[3] = h->n_repacks;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_set_repack_threshold(gamma_hip_index* h, int64_t min_waste_entries) {
+    if (!h || min_waste_entries < 0) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
+    GH_CHECK(h, hipSetDevice(h->device));
+    h->repack_min_entries = min_waste_entries;
+    return arena_repack_if_need(h);
 }
 
 int64_t gamma_hip_ivfpq_list_size(gamma_hip_index* h, int l) {

@@ -1966,6 +1966,35 @@ void launch_mark_moved(hipStream_t s, int64_t* ids, int64_t pos) {
     hipLaunchKernelGGL(k_mark_moved, dim3(1), dim3(64), 0, s, ids, pos);
 }
 
+// Arena repack (gamma_hip.cpp, arena_repack): every list's live entries move from (old arrays, old offset)
+// to (new arrays, new offset).  grid = (nlist, chunks); the code bytes move as dwords when M % 4 == 0.
+__global__ __launch_bounds__(256) void k_repack_lists(const uint8_t* __restrict__ oc, const int64_t* __restrict__ oi,
+                                                      uint8_t* __restrict__ nc, int64_t* __restrict__ ni,
+                                                      const int64_t* __restrict__ old_off,
+                                                      const int64_t* __restrict__ new_off,
+                                                      const int* __restrict__ len, int M) {
+    const int l = blockIdx.x;
+    const int n = len[l];
+    const int64_t a = old_off[l], b = new_off[l];
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) ni[b + i] = oi[a + i];
+    if ((M & 3) == 0) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(oc + a * M);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(nc + b * M);
+        const int64_t nw = (int64_t)n * (M >> 2);
+        for (int64_t i = blockIdx.y * 256 + threadIdx.x; i < nw; i += gridDim.y * 256) dst[i] = src[i];
+    } else {
+        const int64_t nb = (int64_t)n * M;
+        for (int64_t i = blockIdx.y * 256 + threadIdx.x; i < nb; i += gridDim.y * 256) nc[b * M + i] = oc[a * M + i];
+    }
+}
+void launch_repack_lists(hipStream_t s, const uint8_t* oc, const int64_t* oi, uint8_t* nc, int64_t* ni,
+                         const int64_t* old_off, const int64_t* new_off, const int* len, int nlist, int M,
+                         int max_len) {
+    if (nlist <= 0) return;
+    const int chunks = std::max(1, std::min(64, (max_len + 1023) / 1024));
+    hipLaunchKernelGGL(k_repack_lists, dim3(nlist, chunks), dim3(256), 0, s, oc, oi, nc, ni, old_off, new_off, len, M);
+}
+
 // ------------------------------------------------------------------------------------
 // a12 (Add path): residual + PQ encode.  assign comes from the coarse kernels + select.
 //   code[m] = argmin_j fvec_L2sqr_ny(residual_m, c_mj)   (strict <, first minimum,

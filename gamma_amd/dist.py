@@ -155,14 +155,24 @@ def sharded_search(backend, x, k, args, group=None, pipeline=None):
     asynchronously: the all-to-all of one sub-batch (the only exchange whose volume matters,
     nq*R*12 bytes) runs over xGMI while the other sub-batch is being scanned or merged.
     `pipeline` overrides the number of sub-batches."""
+    # faiss chooses the coarse path from the size of the whole batch: slices and sub-batches must agree.  The
+    # resolved mode lives in the caller's parameter block only for the duration of this call -- a SearchArgs
+    # reused for a batch on the other side of the 20-query rule must resolve again.
+    saved_mode = args.p.coarse_mode
+    if saved_mode < 0:
+        args.p.coarse_mode = 0 if x.shape[0] < 20 else 1
+    try:
+        return _sharded_search(backend, x, k, args, group, pipeline)
+    finally:
+        args.p.coarse_mode = saved_mode
+
+
+def _sharded_search(backend, x, k, args, group, pipeline):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     nq = x.shape[0]
     P = args.p.nprobe
     R = max(args.p.recall_num, k)
-    if args.p.coarse_mode < 0:
-        # faiss chooses the coarse path from the size of the whole batch: slices and sub-batches must agree
-        args.p.coarse_mode = 0 if nq < 20 else 1
     nsub = pipeline or int(os.environ.get("GAMMA_DIST_PIPELINE", "0")) or (2 if world > 1 and nq >= 2 * world * MIN_SUB else 1)
     plan = plan_sub_batches(nq, world, nsub)
     pers = [max(1, -(-(e - s) // world)) for s, e in plan]

@@ -38,7 +38,7 @@ int GammaFLATHIPIndex::Init(const std::string &model_parameters, int indexing_si
 }
 
 RetrievalParameters *GammaFLATHIPIndex::Parse(const std::string &parameters) {
-  if (parameters == "") return new FlatRetrievalParameters(metric_type_);
+  if (parameters == "") return new HIPFlatRetrievalParameters(metric_type_);
   utils::JsonParser jp;
   if (jp.Parse(parameters.c_str())) return nullptr;
   DistanceComputeType type = metric_type_;
@@ -47,17 +47,19 @@ RetrievalParameters *GammaFLATHIPIndex::Parse(const std::string &parameters) {
     type = !strcasecmp("L2", mt.c_str()) ? DistanceComputeType::L2 : DistanceComputeType::INNER_PRODUCT;
   int poq = 1;
   jp.GetInt("parallel_on_queries", poq);
-  return new FlatRetrievalParameters(poq != 0, type);
+  return new HIPFlatRetrievalParameters(poq != 0, type);
 }
 
 bool GammaFLATHIPIndex::Add(int n, const uint8_t *vec) {
-  // the CPU model reads vector_ at search time; the device keeps a mirror, fed in vid order
-  if (gamma_hip_raw_append(h_, n, reinterpret_cast<const float *>(vec))) return false;
+  // the CPU model reads vector_ at search time; the device keeps a mirror, fed in vid order at explicit rows
+  std::lock_guard<std::mutex> g(raw_mu_);
+  if (gamma_hip_raw_write(h_, uploaded_, n, reinterpret_cast<const float *>(vec))) return false;
   uploaded_ += n;
   return true;
 }
 
 int GammaFLATHIPIndex::Update(const std::vector<int64_t> &ids, const std::vector<const uint8_t *> &vecs) {
+  std::lock_guard<std::mutex> g(raw_mu_);
   for (size_t i = 0; i < ids.size(); i++)
     if (ids[i] < uploaded_ && gamma_hip_raw_update(h_, ids[i], reinterpret_cast<const float *>(vecs[i]))) return -1;
   return 0;
@@ -69,6 +71,14 @@ int GammaFLATHIPIndex::Delete(const std::vector<int64_t> &ids) {
 }
 
 int GammaFLATHIPIndex::Load(const std::string &dir) {
+  // deletes made before the restart: the engine has loaded its bitmap file already (vector_ is a RawVector)
+  if (RawVector *rv = dynamic_cast<RawVector *>(vector_)) {
+    if (rv->Bitmap() && rv->Bitmap()->BitSize() > 0 &&
+        gamma_hip_bitmap_upload(h_, reinterpret_cast<const uint8_t *>(rv->Bitmap()->Bitmap()),
+                                (int64_t)rv->Bitmap()->BitSize()))
+      return -1;
+  }
+  std::lock_guard<std::mutex> g(raw_mu_);
   const int64_t nvec = (int64_t)vector_->MetaInfo()->Size();
   for (int64_t i0 = uploaded_; i0 < nvec; i0 += 65536) {
     const int64_t nb = std::min<int64_t>(65536, nvec - i0);
@@ -78,16 +88,16 @@ int GammaFLATHIPIndex::Load(const std::string &dir) {
     if (vector_->Gets(vids, sv)) return -1;
     std::vector<float> buf((size_t)nb * d_);
     for (int64_t i = 0; i < nb; i++) memcpy(&buf[(size_t)i * d_], sv.Get((int)i), sizeof(float) * d_);
-    if (gamma_hip_raw_append(h_, nb, buf.data())) return -1;
-    uploaded_ += nb;
+    if (gamma_hip_raw_write(h_, i0, nb, buf.data())) return -1;
+    uploaded_ = i0 + nb;
   }
   return (int)uploaded_;
 }
 
 int GammaFLATHIPIndex::Search(RetrievalContext *retrieval_context, int n, const uint8_t *x, int k,
                               float *distances, int64_t *ids) {
-  FlatRetrievalParameters *rp = dynamic_cast<FlatRetrievalParameters *>(retrieval_context->RetrievalParams());
-  FlatRetrievalParameters defaults(true, DistanceComputeType::L2);   // gamma_index_flat.cc:125-128
+  HIPFlatRetrievalParameters *rp = dynamic_cast<HIPFlatRetrievalParameters *>(retrieval_context->RetrievalParams());
+  HIPFlatRetrievalParameters defaults(true, DistanceComputeType::L2);   // gamma_index_flat.cc:125-128
   if (rp == nullptr) rp = &defaults;
   if (x == nullptr) return -1;
   GammaSearchCondition *cond = dynamic_cast<GammaSearchCondition *>(retrieval_context);

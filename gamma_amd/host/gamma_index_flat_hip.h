@@ -2,6 +2,7 @@
 // (reference index/impl/gamma_index_flat.{h,cc}) on an MI355X.  Same JSON keys
 // (metric_type, parallel_on_queries), same Search contract.
 #pragma once
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -10,12 +11,12 @@
 
 namespace tig_gamma {
 
-class FlatRetrievalParameters : public RetrievalParameters {
+class HIPFlatRetrievalParameters : public RetrievalParameters {
  public:
-  FlatRetrievalParameters() : RetrievalParameters(), parallel_on_queries_(true) {}
-  FlatRetrievalParameters(bool parallel_on_queries, enum DistanceComputeType type)
+  HIPFlatRetrievalParameters() : RetrievalParameters(), parallel_on_queries_(true) {}
+  HIPFlatRetrievalParameters(bool parallel_on_queries, enum DistanceComputeType type)
       : RetrievalParameters(type), parallel_on_queries_(parallel_on_queries) {}
-  FlatRetrievalParameters(enum DistanceComputeType type) : RetrievalParameters(type), parallel_on_queries_(true) {}
+  HIPFlatRetrievalParameters(enum DistanceComputeType type) : RetrievalParameters(type), parallel_on_queries_(true) {}
   bool ParallelOnQueries() { return parallel_on_queries_; }
 
  private:
@@ -43,6 +44,7 @@ class GammaFLATHIPIndex : public RetrievalModel {
   gamma_hip_index *h_ = nullptr;
   int d_ = 0;
   int64_t uploaded_ = 0;
+  std::mutex raw_mu_;   // uploaded_ + the mirror writes
 };
 
 }  // namespace tig_gamma

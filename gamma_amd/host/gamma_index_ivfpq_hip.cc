@@ -26,7 +26,7 @@ REGISTER_MODEL(HIPIVFPQ, GammaIVFPQHIPIndex);
     fprintf(stderr, "\n");             \
   } while (0)
 
-int IVFPQModelParams::Parse(const char *str) {
+int HIPIVFPQModelParams::Parse(const char *str) {
   utils::JsonParser jp;
   if (jp.Parse(str)) {
     HLOG("parse IVFPQ retrieval parameters error: %s", str);
@@ -92,8 +92,8 @@ GammaIVFPQHIPIndex::~GammaIVFPQHIPIndex() {
 
 int GammaIVFPQHIPIndex::Init(const std::string &model_parameters, int indexing_size) {
   indexing_size_ = indexing_size;
-  model_param_ = new IVFPQModelParams();
-  IVFPQModelParams &pa = *model_param_;
+  model_param_ = new HIPIVFPQModelParams();
+  HIPIVFPQModelParams &pa = *model_param_;
   if (model_parameters != "" && pa.Parse(model_parameters.c_str())) return -1;
   if (!vector_) {
     HLOG("vector_ must be set before Init");
@@ -131,13 +131,13 @@ int GammaIVFPQHIPIndex::Init(const std::string &model_parameters, int indexing_s
 }
 
 RetrievalParameters *GammaIVFPQHIPIndex::Parse(const std::string &parameters) {
-  if (parameters == "") return new IVFPQRetrievalParameters(metric_type_);
+  if (parameters == "") return new HIPIVFPQRetrievalParameters(metric_type_);
   utils::JsonParser jp;
   if (jp.Parse(parameters.c_str())) {
     HLOG("parse retrieval parameters error: %s", parameters.c_str());
     return nullptr;
   }
-  IVFPQRetrievalParameters *rp = new IVFPQRetrievalParameters();
+  HIPIVFPQRetrievalParameters *rp = new HIPIVFPQRetrievalParameters();
   std::string mt;
   if (!jp.GetString("metric_type", mt)) {
     rp->SetDistanceComputeType(!strcasecmp("L2", mt.c_str()) ? DistanceComputeType::L2
@@ -251,14 +251,16 @@ int GammaIVFPQHIPIndex::Indexing() {
 
 bool GammaIVFPQHIPIndex::Add(int n, const uint8_t *vec) {
   // vids are consecutive from indexed_vec_count_ (gamma_index_ivfpq.cc:475-489); the raw
-  // vectors are mirrored to HBM for the exact re-rank (VectorReader::Gets on the CPU path)
+  // vectors are mirrored to HBM for the exact re-rank (VectorReader::Gets on the CPU path).
+  // The mirror is written at explicit rows (gamma_hip_raw_write): a brute-force Search that mirrors the
+  // same rows at the same time (EnsureRaw) rewrites identical bytes instead of appending them twice.
   const float *v = reinterpret_cast<const float *>(vec);
   const int64_t end = (int64_t)indexed_vec_count_ + n;
-  if (raw_uploaded_ < indexed_vec_count_ && EnsureRaw(indexed_vec_count_)) return false;
-  if (raw_uploaded_ < end) {   // the part of this batch a brute-force search has not mirrored yet
-    const int64_t skip = raw_uploaded_ - indexed_vec_count_;
-    if (gamma_hip_raw_append(h_, end - raw_uploaded_, v + skip * d_)) return false;
-    raw_uploaded_ = end;
+  if (EnsureRaw(indexed_vec_count_)) return false;
+  {
+    std::lock_guard<std::mutex> g(raw_mu_);
+    if (gamma_hip_raw_write(h_, indexed_vec_count_, n, v)) return false;
+    raw_uploaded_ = std::max(raw_uploaded_, end);
   }
   int rc = gamma_hip_ivfpq_add(h_, n, v, indexed_vec_count_);
   if (rc) {
@@ -276,6 +278,7 @@ int GammaIVFPQHIPIndex::Update(const std::vector<int64_t> &ids, const std::vecto
     std::vector<uint8_t> code(M_);
     if (gamma_hip_ivfpq_encode(h_, 1, v, &lno, code.data())) return -1;
     if (gamma_hip_ivfpq_update(h_, (int)lno, ids[i], code.data())) return -1;
+    std::lock_guard<std::mutex> g(raw_mu_);
     if (ids[i] < raw_uploaded_ && gamma_hip_raw_update(h_, ids[i], v)) return -1;
   }
   gamma_hip_ivfpq_compact_if_need(h_);   // gamma_index_ivfpq.cc:420
@@ -292,8 +295,8 @@ int GammaIVFPQHIPIndex::Delete(const std::vector<int64_t> &ids) {
 
 int GammaIVFPQHIPIndex::Search(RetrievalContext *retrieval_context, int n, const uint8_t *x, int k,
                                float *distances, int64_t *ids) {
-  IVFPQRetrievalParameters *rp = dynamic_cast<IVFPQRetrievalParameters *>(retrieval_context->RetrievalParams());
-  IVFPQRetrievalParameters defaults;
+  HIPIVFPQRetrievalParameters *rp = dynamic_cast<HIPIVFPQRetrievalParameters *>(retrieval_context->RetrievalParams());
+  HIPIVFPQRetrievalParameters defaults;
   if (rp == nullptr) rp = &defaults;
   GammaSearchCondition *cond = dynamic_cast<GammaSearchCondition *>(retrieval_context);
   gamma_hip_search_params p;
@@ -324,8 +327,11 @@ int GammaIVFPQHIPIndex::Search(RetrievalContext *retrieval_context, int n, const
   return 0;
 }
 
-// mirror vids [raw_uploaded_, upto) of the engine's vector store into HBM
+// mirror vids [raw_uploaded_, upto) of the engine's vector store into HBM.  Called from Search (any number of
+// client threads: brute force before training), from Add (the indexing thread) and from Load: raw_mu_ makes
+// "read the watermark, copy, advance it" one step, and the rows go to their own positions.
 int GammaIVFPQHIPIndex::EnsureRaw(int64_t upto) {
+  std::lock_guard<std::mutex> g(raw_mu_);
   const int64_t step = 65536;
   for (int64_t i0 = raw_uploaded_; i0 < upto; i0 += step) {
     const int64_t nb = std::min(step, upto - i0);
@@ -335,10 +341,19 @@ int GammaIVFPQHIPIndex::EnsureRaw(int64_t upto) {
     if (vector_->Gets(vids, sv)) return -1;
     std::vector<float> buf((size_t)nb * d_);
     for (int64_t i = 0; i < nb; i++) memcpy(&buf[(size_t)i * d_], sv.Get((int)i), sizeof(float) * d_);
-    if (gamma_hip_raw_append(h_, nb, buf.data())) return -1;
-    raw_uploaded_ += nb;
+    if (gamma_hip_raw_write(h_, i0, nb, buf.data())) return -1;
+    raw_uploaded_ = i0 + nb;
   }
   return 0;
+}
+
+// the engine's delete bitmap -> the device mirror (after a restart the engine has loaded its bitmap file
+// before it calls Load on the models, util/bitmap_manager.cc:96-161; vector_ is a RawVector, raw_vector.h:171)
+int GammaIVFPQHIPIndex::UploadEngineBitmap() {
+  RawVector *rv = dynamic_cast<RawVector *>(vector_);
+  if (!rv || !rv->Bitmap() || rv->Bitmap()->BitSize() == 0) return 0;
+  return gamma_hip_bitmap_upload(h_, reinterpret_cast<const uint8_t *>(rv->Bitmap()->Bitmap()),
+                                 (int64_t)rv->Bitmap()->BitSize());
 }
 
 int GammaIVFPQHIPIndex::SetTrained(const float *coarse, const float *pq) {
@@ -414,6 +429,9 @@ int GammaIVFPQHIPIndex::Load(const std::string &dir) {
     return -1;
   }
   if (SetTrained(f.coarse.data(), f.pq.data())) return -1;   // T2 is recomputed, as in the reference
+  // deletes that happened before the restart: the bitmap must be in place BEFORE the lists come back, so that
+  // AddKeys counts the deleted entries per list as the reference does (realtime_mem_data.cc:293-296)
+  if (UploadEngineBitmap()) return -1;
   metric_type_ = f.metric == 0 ? DistanceComputeType::INNER_PRODUCT : DistanceComputeType::L2;
   int64_t count = 0;
   for (int l = 0; l < nlist_; l++) {

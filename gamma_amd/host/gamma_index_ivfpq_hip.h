@@ -3,10 +3,13 @@
 // encoding on an MI355X through the C ABI of include/gamma_hip.h.
 //
 // Mirrors GammaIVFPQIndex (reference index/impl/gamma_index_ivfpq.{h,cc}): same JSON keys and
-// defaults (IVFPQModelParams :675-887, IVFPQRetrievalParameters :629-673), same return codes,
-// same Search contract.  Unsupported on device and rejected in Init like any bad parameter:
+// defaults (the reference's IVFPQModelParams :675-887 and IVFPQRetrievalParameters :629-673), same
+// return codes, same Search contract.  The parameter classes carry a HIP prefix: the plugin is compiled
+// INTO libgamma next to the reference's own IVFPQ model, where a second
+// tig_gamma::IVFPQModelParams with another layout would be an ODR violation.  Unsupported on device and rejected in Init like any bad parameter:
 // hnsw quantizer, opq, support_indivisible_nsubvector, nbits_per_idx != 8.
 #pragma once
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -15,10 +18,10 @@
 
 namespace tig_gamma {
 
-class IVFPQRetrievalParameters : public RetrievalParameters {
+class HIPIVFPQRetrievalParameters : public RetrievalParameters {
  public:
-  IVFPQRetrievalParameters() : RetrievalParameters(), parallel_on_queries_(true), recall_num_(100), nprobe_(-1) {}
-  IVFPQRetrievalParameters(enum DistanceComputeType type)
+  HIPIVFPQRetrievalParameters() : RetrievalParameters(), parallel_on_queries_(true), recall_num_(100), nprobe_(-1) {}
+  HIPIVFPQRetrievalParameters(enum DistanceComputeType type)
       : RetrievalParameters(type), parallel_on_queries_(true), recall_num_(100), nprobe_(-1) {}
   int RecallNum() { return recall_num_; }
   void SetRecallNum(int recall_num) { recall_num_ = recall_num; }
@@ -33,7 +36,7 @@ class IVFPQRetrievalParameters : public RetrievalParameters {
   int nprobe_;
 };
 
-struct IVFPQModelParams {
+struct HIPIVFPQModelParams {
   int ncentroids = 2048;
   int nsubvector = 64;
   bool support_indivisible_nsubvector = false;
@@ -76,8 +79,10 @@ class GammaIVFPQHIPIndex : public RetrievalModel {
  private:
   int TrainOnHost(size_t num, const float *xt);
   int EnsureRaw(int64_t upto);
+  int UploadEngineBitmap();
+  std::mutex raw_mu_;   // raw_uploaded_ + the mirror writes (Search threads, the indexing thread, Load)
   gamma_hip_index *h_ = nullptr;
-  IVFPQModelParams *model_param_ = nullptr;
+  HIPIVFPQModelParams *model_param_ = nullptr;
   int64_t raw_uploaded_ = 0;
 };
 

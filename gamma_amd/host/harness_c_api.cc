@@ -4,6 +4,8 @@
 // Used by the Python tests through ctypes; not part of the product surface.
 #include <string.h>
 
+#include <algorithm>
+#include <mutex>
 #include <string>
 #include <atomic>
 #include <chrono>
@@ -17,23 +19,34 @@
 using namespace tig_gamma;
 
 namespace {
-// MemoryRawVector stand-in: the engine-owned raw vector store the model reads through VectorReader
-class MemVectorReader : public VectorReader {
+// MemoryRawVector stand-in: the engine-owned raw vector store the model reads through VectorReader, with the
+// engine's delete bitmap behind RawVector::Bitmap() (vector/raw_vector.h:171; GammaEngine owns the manager,
+// search/gamma_engine.cc:255)
+class MemVectorReader : public RawVector {
  public:
-  MemVectorReader(int d) : VectorReader(new VectorMetaInfo("vec", d, VectorValueType::FLOAT)), d_(d) {}
+  MemVectorReader(int d) : RawVector(new VectorMetaInfo("vec", d, VectorValueType::FLOAT), &bitmap_), d_(d) {
+    bitmap_.Init(1 << 22);
+  }
   int Gets(const std::vector<int64_t> &vids, ScopeVectors &vecs) const override {
+    std::lock_guard<std::mutex> g(mu_);
     for (auto v : vids) {
       if (v < 0 || (size_t)v >= data_.size() / d_) return -1;
-      vecs.Add(reinterpret_cast<const uint8_t *>(&data_[(size_t)v * d_]), false);
+      // a copy the ScopeVectors owns: the store may grow (and move) while a model still reads the rows
+      uint8_t *c = new uint8_t[sizeof(float) * d_];
+      memcpy(c, &data_[(size_t)v * d_], sizeof(float) * d_);
+      vecs.Add(c, true);
     }
     return 0;
   }
   void Append(int n, const float *x) {
+    std::lock_guard<std::mutex> g(mu_);
     data_.insert(data_.end(), x, x + (size_t)n * d_);
     meta_info_->size_ += n;
   }
   int d_;
   std::vector<float> data_;
+  bitmap::BitmapManager bitmap_;
+  mutable std::mutex mu_;
 };
 
 struct Host {
@@ -77,9 +90,48 @@ int gh_host_update(void *hp, int64_t vid, const float *x) {
   std::vector<const uint8_t *> vecs{reinterpret_cast<const uint8_t *>(x)};
   return h->model->Update(ids, vecs);
 }
+// GammaEngine::Delete (search/gamma_engine.cc:802-824): the doc bit in the engine's bitmap, then the models
 int gh_host_delete(void *hp, const int64_t *vids, int n) {
+  Host *h = (Host *)hp;
+  for (int i = 0; i < n; i++) h->store->bitmap_.Set((uint32_t)vids[i]);
   std::vector<int64_t> ids(vids, vids + n);
-  return ((Host *)hp)->model->Delete(ids);
+  return h->model->Delete(ids);
+}
+// the engine's bitmap alone (what BitmapManager::Load restores after a restart, before the models' Load)
+void gh_host_engine_bitmap_set(void *hp, const int64_t *vids, int n) {
+  Host *h = (Host *)hp;
+  for (int i = 0; i < n; i++) h->store->bitmap_.Set((uint32_t)vids[i]);
+}
+int gh_host_search(void *hp, const char *retrieval_params, int has_rank, int brute_force, float min_score,
+                   float max_score, int n, const float *x, int k, float *distances, int64_t *ids);
+// Brute-force Search calls from `nthreads` client threads WHILE the indexing thread adds `n` vectors in
+// batches of `batch` (the model is untrained or brute_force_search is set: both paths mirror the vector
+// store on demand).  Returns the number of failed calls; afterwards the mirror must hold exactly n rows.
+int gh_host_search_during_add(void *hp, const char *retrieval_params, int nthreads, int n, int batch,
+                              const float *x, int d, const float *q, int nq, int k) {
+  Host *h = (Host *)hp;
+  std::atomic<int> failed(0), stop(0);
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthreads; t++)
+    th.emplace_back([&, t]() {
+      std::vector<float> D((size_t)k);
+      std::vector<int64_t> I((size_t)k);
+      int i = t;
+      while (!stop.load()) {
+        if (gh_host_search(hp, retrieval_params, 1, 1, -1e30f, 1e30f, 1, q + (size_t)(i % nq) * d, k, D.data(), I.data()))
+          failed++;
+        i += nthreads;
+      }
+    });
+  for (int i0 = 0; i0 < n; i0 += batch) {
+    const int nb = std::min(batch, n - i0);
+    h->store->Append(nb, x + (size_t)i0 * d);
+    if (!h->model->Add(nb, reinterpret_cast<const uint8_t *>(x + (size_t)i0 * d))) failed++;
+    else h->model->indexed_count_ += nb;
+  }
+  stop = 1;
+  for (auto &t : th) t.join();
+  return failed.load();
 }
 int gh_host_search(void *hp, const char *retrieval_params, int has_rank, int brute_force, float min_score,
                    float max_score, int n, const float *x, int k, float *distances, int64_t *ids) {
@@ -216,10 +268,10 @@ int gh_host_ivfpq_set_trained(void *hp, const float *cc, const float *pq) {
   GammaIVFPQHIPIndex *m = dynamic_cast<GammaIVFPQHIPIndex *>(((Host *)hp)->model);
   return m ? m->SetTrained(cc, pq) : -1;
 }
-// IVFPQModelParams::Parse for host-logic tests: out = {rc, ncentroids, nsubvector, nbits_per_idx,
+// HIPIVFPQModelParams::Parse for host-logic tests: out = {rc, ncentroids, nsubvector, nbits_per_idx,
 // nprobe, metric(0 IP / 1 L2), bucket_init_size, bucket_max_size, has_hnsw, has_opq}
 void gh_parse_ivfpq_model_params(const char *str, int *out) {
-  IVFPQModelParams p;
+  HIPIVFPQModelParams p;
   out[0] = p.Parse(str);
   out[1] = p.ncentroids;
   out[2] = p.nsubvector;
@@ -231,11 +283,11 @@ void gh_parse_ivfpq_model_params(const char *str, int *out) {
   out[8] = p.has_hnsw;
   out[9] = p.has_opq;
 }
-// IVFPQRetrievalParameters via Parse on an un-Init'ed model: out = {rc, metric, recall_num, nprobe}
+// HIPIVFPQRetrievalParameters via Parse on an un-Init'ed model: out = {rc, metric, recall_num, nprobe}
 void gh_parse_ivfpq_retrieval_params(const char *str, int *out) {
   GammaIVFPQHIPIndex m;
   RetrievalParameters *rp = m.Parse(str);
-  IVFPQRetrievalParameters *ip = dynamic_cast<IVFPQRetrievalParameters *>(rp);
+  HIPIVFPQRetrievalParameters *ip = dynamic_cast<HIPIVFPQRetrievalParameters *>(rp);
   out[0] = ip ? 0 : -1;
   if (ip) {
     out[1] = (int)ip->GetDistanceComputeType();

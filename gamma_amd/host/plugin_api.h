@@ -169,6 +169,49 @@ class VectorReader {
   VectorMetaInfo *meta_info_;
 };
 
+// bitmap::BitmapManager (util/bitmap_manager.h:13-52), in-memory part: bit i <-> byte i>>3, mask 1<<(i&7)
+namespace bitmap {
+class BitmapManager {
+ public:
+  BitmapManager() : size_(0) {}
+  int Init(uint32_t bit_size) {
+    size_ = bit_size;
+    bytes_.assign((bit_size >> 3) + 1, 0);
+    return 0;
+  }
+  int Set(uint32_t bit_id) {
+    if (bit_id >= size_) return -1;
+    bytes_[bit_id >> 3] |= (char)(1 << (bit_id & 7));
+    return 0;
+  }
+  int Unset(uint32_t bit_id) {
+    if (bit_id >= size_) return -1;
+    bytes_[bit_id >> 3] &= (char)~(1 << (bit_id & 7));
+    return 0;
+  }
+  bool Test(uint32_t bit_id) { return bit_id < size_ && ((bytes_[bit_id >> 3] >> (bit_id & 7)) & 1); }
+  uint32_t BitSize() { return size_; }
+  char *Bitmap() { return bytes_.data(); }
+  uint32_t BytesSize() { return (size_ >> 3) + 1; }
+
+ private:
+  std::vector<char> bytes_;
+  uint32_t size_;
+};
+}  // namespace bitmap
+
+// RawVector (vector/raw_vector.h:70-216), the one member a model reads besides VectorReader's: the engine's
+// delete bitmap (:171)
+class RawVector : public VectorReader {
+ public:
+  RawVector(VectorMetaInfo *meta_info, bitmap::BitmapManager *docids_bitmap)
+      : VectorReader(meta_info), docids_bitmap_(docids_bitmap) {}
+  bitmap::BitmapManager *Bitmap() { return docids_bitmap_; }
+
+ protected:
+  bitmap::BitmapManager *docids_bitmap_;
+};
+
 // stand-in for tbb::concurrent_bounded_queue<int> (see header comment)
 class UpdatedVidQueue {
  public:

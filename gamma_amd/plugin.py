@@ -23,6 +23,9 @@ HOST_SYMBOLS = {
     "gh_host_add": (C.c_int, [C.c_void_p, C.c_int, f32p]),
     "gh_host_update": (C.c_int, [C.c_void_p, C.c_int64, f32p]),
     "gh_host_delete": (C.c_int, [C.c_void_p, i64p, C.c_int]),
+    "gh_host_engine_bitmap_set": (None, [C.c_void_p, i64p, C.c_int]),
+    "gh_host_search_during_add": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p,
+                                            C.c_int, C.c_int]),
     "gh_host_search": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_float, C.c_float,
                                  C.c_int, f32p, C.c_int, f32p, i64p]),
     "gh_host_search_filtered": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_float, C.c_float,
@@ -157,6 +160,18 @@ class PluginModel:
     def delete(self, vids):
         v = np.ascontiguousarray(vids, np.int64)
         return self.L.gh_host_delete(self.h, v.ctypes.data_as(i64p), v.size)
+
+    def engine_bitmap_set(self, vids):
+        """set doc bits in the ENGINE's delete bitmap only (the state BitmapManager::Load restores)"""
+        v = np.ascontiguousarray(vids, np.int64)
+        self.L.gh_host_engine_bitmap_set(self.h, v.ctypes.data_as(i64p), v.size)
+
+    def search_during_add(self, x, q, k, nthreads=4, batch=500, retrieval_params=""):
+        """brute-force client threads running while the vectors are stored + added; returns failed calls"""
+        x = np.ascontiguousarray(x, np.float32)
+        q = np.ascontiguousarray(q, np.float32)
+        return self.L.gh_host_search_during_add(self.h, retrieval_params.encode(), nthreads, x.shape[0], batch, _f(x),
+                                                x.shape[1], _f(q), q.shape[0], k)
 
     def search(self, xq, k, retrieval_params="", has_rank=True, brute_force=False, min_score=FLT_MIN,
                max_score=FLT_MAX, range_filters=None):

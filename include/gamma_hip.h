@@ -120,6 +120,11 @@ int64_t gamma_hip_field_count(gamma_hip_index* h, int field_id);
 int gamma_hip_raw_init(gamma_hip_index* h, int d);
 int gamma_hip_raw_append(gamma_hip_index* h, int64_t n, const float* vecs);
 int gamma_hip_raw_update(gamma_hip_index* h, int64_t vid, const float* vec);
+/* rows [first_vid, first_vid + n) written at their own position: idempotent (a repeated or overlapping
+ * call rewrites the same rows with the same bytes), the row count only ever grows to first_vid + n.
+ * first_vid may not leave a gap (first_vid <= gamma_hip_raw_count).  This is what a mirror of the engine's
+ * vector store needs when Search (brute force before training) and the indexing thread's Add race. */
+int gamma_hip_raw_write(gamma_hip_index* h, int64_t first_vid, int64_t n, const float* vecs);
 int64_t gamma_hip_raw_count(gamma_hip_index* h);
 
 /* ---- delete bitmap (bitmap::BitmapManager, util/bitmap_manager.cc:171-192): bit = docid,
@@ -154,6 +159,12 @@ int gamma_hip_ivfpq_delete(gamma_hip_index* h, const int64_t* vids, int n);
 /* RTInvertIndex::CompactIfNeed (realtime_mem_data.cc:354-381,119-150); needs the delete
  * bitmap the handle mirrors */
 int gamma_hip_ivfpq_compact_if_need(gamma_hip_index* h);
+/* Extents abandoned by list growth and compaction (the reference frees them 1 s after the swap,
+ * realtime_mem_data.cc:457-466) stay inside the arena until they exceed half of what is in use and
+ * `min_waste_entries` (default 65536): then every list moves into a fresh tight arena.  out4 = {capacity, in use,
+ * abandoned, repacks so far}, in list entries (code_size + 8 bytes each).  Setting the threshold re-checks at once. */
+int gamma_hip_ivfpq_arena_stats(gamma_hip_index* h, int64_t* out4);
+int gamma_hip_ivfpq_set_repack_threshold(gamma_hip_index* h, int64_t min_waste_entries);
 int64_t gamma_hip_ivfpq_list_size(gamma_hip_index* h, int list_no);
 int64_t gamma_hip_ivfpq_list_capacity(gamma_hip_index* h, int list_no);
 /* RealTimeMemData::RetrieveCodes ("for unit test", realtime_mem_data.h:95-96) */

@@ -815,3 +815,108 @@ def test_list_full_at_bucket_max_size(case):
         assert o.list_capacity(3) == g.list_capacity(3) and len(io) <= 40
     finally:
         g.close()
+
+
+def test_raw_write_is_idempotent():
+    """gamma_hip_raw_write: rows at explicit positions; repeating or overlapping a write changes nothing, the
+    count only grows, and a write that would leave a gap is refused."""
+    from gamma_amd import api
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((3000, 32)).astype(np.float32)
+    g = api.GammaHip(0)
+    g.raw_init(32)
+    g.raw_write(0, x[:1000])
+    g.raw_write(500, x[500:2000])      # overlaps and extends
+    g.raw_write(0, x[:1000])           # repeated
+    assert g.raw_count() == 2000
+    with pytest.raises(api.GammaHipError):
+        g.raw_write(2500, x[2500:])    # gap
+    g.raw_write(2000, x[2000:])
+    assert g.raw_count() == 3000
+    q = x[::97].copy()
+    args = api.SearchArgs(metric=api.METRIC_L2, min_score=-1e30, max_score=1e30)
+    D, I = g.flat_search(q, 1, args)
+    assert np.array_equal(I[:, 0], np.arange(0, 3000, 97)) and (D == 0).all()
+    g.close()
+
+
+def test_arena_repack_reclaims_abandoned_extents(case):
+    """list growth and compaction abandon their old extents inside the arena; once the
+    waste passes the threshold every list moves into a tight arena.  Contents, capacities and search results
+    are unchanged by the move."""
+    from gamma_amd import api
+    o = case["oracle"]
+    g = api.GammaHip(0)
+    nlist, M = case["nlist"], case["M"]
+    g.ivfpq_init(case["d"], nlist, M, 8, case["metric"], 16)   # tiny buckets: every list grows many times
+    g.ivfpq_set_trained(case["cc"], case["pq"], None)
+    g.set_repack_threshold(1 << 40)                             # off for now
+    lists = [o.get_list(l) for l in range(nlist)]
+    for rnd in range(4):                                        # interleaved appends: repeated growth
+        for l in range(nlist):
+            ids, cds = lists[l]
+            lo, hi = len(ids) * rnd // 4, len(ids) * (rnd + 1) // 4
+            if hi > lo:
+                g.add_keys(l, ids[lo:hi], cds[lo:hi])
+    st = g.arena_stats()
+    assert st["waste"] > 0 and st["repacks"] == 0
+    caps = [g.list_capacity(l) for l in range(nlist)]
+    g.raw_init(case["d"])
+    g.raw_append(case["base"])
+    args = api.SearchArgs(metric=case["metric"], nprobe=8, recall_num=100, has_rank=True, min_score=-1e30,
+                          max_score=1e30, coarse_mode=0)
+    D0, I0 = g.ivfpq_search(case["q"], 10, args)
+    g.set_repack_threshold(1)                                   # re-checks at once
+    st2 = g.arena_stats()
+    assert st2["repacks"] == 1 and st2["waste"] == 0 and st2["used"] == sum(caps)
+    assert st2["cap"] < st["cap"] or st2["used"] < st["used"]
+    for l in range(nlist):
+        ids, cds = g.get_list(l)
+        assert np.array_equal(ids, lists[l][0]) and np.array_equal(cds, lists[l][1])
+        assert g.list_capacity(l) == caps[l]
+    D1, I1 = g.ivfpq_search(case["q"], 10, args)
+    assert D0.tobytes() == D1.tobytes() and np.array_equal(I0, I1)
+    # appends after the move land in the new arena
+    g.add_keys(0, np.array([10 ** 6], np.int64), lists[1][1][:1])
+    ids, _ = g.get_list(0)
+    assert ids[-1] == 10 ** 6 and len(ids) == len(lists[0][0]) + 1
+    g.close()
+
+
+def test_add_keys_batch_counts_superseded_slots(case):
+    """ids with bit 63 (slots superseded by an Update, as a dump holds them) loaded through
+    the batch entry point must make the scan read the ids -- such a slot is never returned."""
+    from gamma_amd import api
+    o = case["oracle"]
+    g = api.GammaHip(0)
+    g.ivfpq_init(case["d"], case["nlist"], case["M"], 8, case["metric"], 1000)
+    g.ivfpq_set_trained(case["cc"], case["pq"], None)
+    lists, counts, vids, codes = [], [], [], []
+    moved = []
+    for l in range(case["nlist"]):
+        ids, cds = o.get_list(l)
+        if len(ids) == 0:
+            continue
+        ids = ids.copy()
+        if len(ids) > 3:
+            moved.append(int(ids[1]))
+            ids[1] |= np.int64(-2 ** 63)
+        lists.append(l); counts.append(len(ids)); vids.append(ids); codes.append(cds)
+    g.add_keys_batch(lists, counts, np.concatenate(vids), np.concatenate(codes))
+    g.raw_init(case["d"])
+    g.raw_append(case["base"])
+    args = api.SearchArgs(metric=case["metric"], nprobe=16, recall_num=100, has_rank=False, min_score=-1e30,
+                          max_score=1e30, coarse_mode=0)
+    D, I = g.ivfpq_search(case["q"], 20, args)
+    assert (I >= -1).all() and not np.isin(I, moved).any()
+    # a list named twice in one batch reserves for the sum of its parts
+    g2 = api.GammaHip(0)
+    g2.ivfpq_init(case["d"], case["nlist"], case["M"], 8, case["metric"], 8)
+    g2.ivfpq_set_trained(case["cc"], case["pq"], None)
+    ids, cds = o.get_list(lists[0])
+    n = len(ids)
+    g2.add_keys_batch([lists[0], lists[0]], [n // 2, n - n // 2], ids, cds)
+    gi, gc = g2.get_list(lists[0])
+    assert np.array_equal(gi, ids) and np.array_equal(gc, cds)
+    g.close()
+    g2.close()

@@ -247,3 +247,65 @@ def test_plugin_concurrent_clients_with_their_own_filters(case):
                                            stride=N // 40, span=N // 4)
     assert bad == 0
     m.close()
+
+
+def test_bruteforce_search_during_add_keeps_the_mirror_exact(case):
+    """Search is re-entrant; in the brute-force / untrained branch it mirrors the engine's
+    vector store into HBM on demand (EnsureRaw) while the indexing thread's Add mirrors the same rows.  Rows
+    are now written at their own position (gamma_hip_raw_write) under a plugin mutex: whatever the
+    interleaving, row == vid afterwards, so flat labels and re-rank distances stay right."""
+    base, q = case["base"][:12000], case["q"]
+    m = _ivfpq_plugin(case)
+    assert m.set_trained(case["cc"], case["pq"]) == 0
+    failed = m.search_during_add(base, q, 10, nthreads=6, batch=400,
+                                 retrieval_params='{"metric_type": "L2"}')
+    assert failed == 0
+    Df, If = B.flat_search(base, q, 10, B.METRIC_L2, B.make_ctx())
+    Dg, Ig = m.search(q, 10, '{"metric_type": "L2"}', brute_force=True)
+    compare_topk(Df, If, Dg, Ig)
+    # the re-rank reads the same mirror
+    D1, I1 = m.search(q, 10, '{"metric_type": "L2", "recall_num": 100, "nprobe": 8}')
+    for i in range(0, len(q), 7):
+        ok = I1[i] >= 0
+        De, _ = B.flat_search(base[I1[i][ok]], q[i:i + 1], int(ok.sum()), B.METRIC_L2, B.make_ctx())
+        assert De[0].tobytes() == D1[i][ok].tobytes()
+    m.close()
+
+
+@pytest.mark.parametrize("model", ["HIPIVFPQ", "HIPFLAT"])
+def test_load_restores_the_delete_bitmap(case, tmp_path, model):
+    """deletes made before a restart.  The engine reloads its bitmap file, then calls
+    Load() on the models (util/bitmap_manager.cc:96-161); the device mirror must pick the bitmap up there --
+    Delete() is never called again for those docs."""
+    from gamma_amd import plugin
+    base, q = case["base"], case["q"]
+
+    def make():
+        if model == "HIPIVFPQ":
+            return _ivfpq_plugin(case)
+        return plugin.PluginModel("HIPFLAT", case["d"], '{"metric_type": "L2"}')
+
+    m = make()
+    m.store(base)
+    if model == "HIPIVFPQ":
+        assert m.set_trained(case["cc"], case["pq"]) == 0
+    assert m.add(base)
+    params = '{"metric_type": "L2", "recall_num": 100, "nprobe": 8}'
+    D0, I0 = m.search(q, 10, params)
+    dead = np.unique(I0[:, :3])
+    dead = dead[dead >= 0]
+    assert m.delete(dead) == 0
+    D1, I1 = m.search(q, 10, params)
+    assert not np.isin(I1, dead).any()
+    assert m.dump(str(tmp_path)) == 0
+    m.close()
+    # "restart": a new model over the same store; the engine's bitmap holds the deletes
+    m2 = make()
+    m2.store(base)
+    m2.engine_bitmap_set(dead)
+    n = m2.load(str(tmp_path))
+    assert n == len(base)
+    D2, I2 = m2.search(q, 10, params)
+    assert not np.isin(I2, dead).any()
+    assert D1.tobytes() == D2.tobytes() and np.array_equal(I1, I2)
+    m2.close()
