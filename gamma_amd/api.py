@@ -288,6 +288,11 @@ class GammaHip:
     def set_dist_budget(self, nbytes):
         self._ck(self.L.gamma_hip_set_workspace_budget(self.h, int(nbytes)), "set_workspace_budget")
 
+    def tie_stats(self, reset=False):
+        out = np.zeros(3, np.int64)
+        self._ck(self.L.gamma_hip_tie_stats(self.h, _p(out, _lib.i64p), 1 if reset else 0), "tie_stats")
+        return dict(coarse_rows=int(out[0]), cut_ties=int(out[1]), replayed=int(out[2]))
+
     def set_exact_ties(self, on=True):
         """probe exactly the lists the reference's heap keeps when coarse distances tie at the nprobe boundary"""
         self._ck(self.L.gamma_hip_set_exact_ties(self.h, 1 if on else 0), "set_exact_ties")

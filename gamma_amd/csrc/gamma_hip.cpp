@@ -125,7 +125,7 @@ struct gamma_hip_index {
     DevBuf w_mat, w_coarse_dis, w_probe, w_xn, w_st2, w_pair_off, w_qtotal, w_dist, w_cand_dis,
             w_cand_pos, w_cand_ids, w_exact, w_selv, w_selp, w_x, w_outd, w_outl, w_stage, w_filter,
             w_m_dis, w_m_ids, w_part_v, w_part_i, w_assign, w_codes_tmp, w_qperm, w_scnt, w_sflag, w_surv, w_pair_base,
-            w_pair_ip, w_flat_cand, w_flat_meta, w_full_cdis, w_full_probe, w_ftab, w_qfil, w_tieflag;
+            w_pair_ip, w_flat_cand, w_flat_meta, w_full_cdis, w_full_probe, w_ftab, w_qfil, w_tieflag, w_tcut, w_tlist;
     unsigned long long* d_scan_codes = nullptr;
     size_t dist_budget_bytes = (size_t)8 << 30;   // per-chunk ADC distance buffer (288 GB of HBM per GPU)
 
@@ -135,6 +135,13 @@ struct gamma_hip_index {
     bool ftab_valid = false;
 
     bool exact_ties = false;   // gamma_hip_set_exact_ties
+    unsigned long long* d_tie_stats = nullptr;   // {coarse rows redone, top-R cuts through a tie, queries replayed}
+    // what stage A leaves for the tie replay of stage B (ties.hip)
+    struct TieCtx {
+        bool on = false, bounded = false;
+        int G = 0, nsl = 0, cap = 0;
+        int64_t q_stride = 0;
+    } tie;
 
     // last-search stage info
     int last_nq = 0, last_P = 0, last_R = 0;
@@ -552,7 +559,7 @@ int ivfpq_coarse(H* h, const gamma_hip_search_params* p, int nq, const float* d_
     }
     if (h->exact_ties) GH_CHECK(h, h->w_tieflag.ensure((size_t)nq));
     gh::launch_coarse_select(s, h->w_mat.as<float>(), nlist, nq, P, out_dis, out_probe,
-                             h->exact_ties ? h->w_tieflag.as<uint8_t>() : nullptr);
+                             h->exact_ties ? h->w_tieflag.as<uint8_t>() : nullptr, h->d_tie_stats);
     return GAMMA_HIP_OK;
 }
 
@@ -624,6 +631,16 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         }
     }
     const int G = gh::scan_group_size(nq, P, G0), PGN = (P + G - 1) / G;
+    // exact ties (ties.hip): queries whose top-R cut goes through a group of equal ADC distances are marked here
+    // and redone by the replay at the end of stage B
+    h->tie = H::TieCtx();
+    h->tie.on = h->exact_ties && !shard && R <= gh::tie_replay_max_k() && P <= gh::tie_replay_max_probes();
+    if (h->tie.on) {
+        GH_CHECK(h, h->w_tcut.ensure((size_t)nq));
+        GH_CHECK(h, h->w_tlist.ensure(((size_t)nq + 1) * sizeof(int)));   // count | list[nq]
+        GH_CHECK(h, hipMemsetAsync(h->w_tcut.p, 0, (size_t)nq, s));
+        GH_CHECK(h, hipMemsetAsync(h->w_tlist.p, 0, sizeof(int), s));
+    }
     // Threshold pre-filter: scan the nearest probe group first, bound each query's R-th best
     // distance from it, and let the scan of the remaining groups keep a short survivor list per
     // query; the exact top-R then comes from a few hundred survivors instead of ~10^4 candidates
@@ -683,6 +700,9 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         gh::launch_map_candidates(s, h->w_cand_pos.as<int>(), nq, R, P, h->w_probe.as<int>(),
                                   h->w_pair_off.as<int>(), h->d_list_off, h->d_ids,
                                   out_ids);
+        if (h->tie.on)
+            gh::launch_flag_cut_ties(s, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), nq, R, out_dis,
+                                     h->w_cand_pos.as<int>(), nullptr, h->w_tcut.as<uint8_t>());
     } else {
         const int cap = gh::scan_slice_cap(), nsl = PGN;   // one survivor slice per probe group (slice 0: the producer's own)
         GH_CHECK(h, h->w_scnt.ensure((size_t)nq * (sizeof(unsigned long long) + (size_t)nsl * sizeof(int))));   // ready[nq] | gcnt[nq][nsl]
@@ -701,10 +721,18 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         gh::launch_select_final(s, l2, sb.surv, sb.gcnt, nsl, cap, sb.ready, h->w_pair_off.as<int>(), P, nq, R,
                                 h->w_pair_base.as<int64_t>(), h->d_ids,
                                 h->w_sflag.as<uint8_t>(), out_dis,
-                                h->w_cand_pos.as<int>(), out_ids);
+                                h->w_cand_pos.as<int>(), out_ids, h->tie.on ? h->w_tcut.as<uint8_t>() : nullptr,
+                                h->d_tie_stats);
         gh::launch_select_topk(s, l2, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), 0,
                                (int)std::min<int64_t>(q_stride, 1 << 30), nq, R,
                                out_dis, h->w_cand_pos.as<int>(), h->w_sflag.as<uint8_t>());
+        if (h->tie.on) {
+            gh::launch_flag_cut_ties(s, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), nq, R, out_dis,
+                                     h->w_cand_pos.as<int>(), h->w_sflag.as<uint8_t>(), h->w_tcut.as<uint8_t>());
+            h->tie.bounded = true;
+            h->tie.nsl = nsl;
+            h->tie.cap = cap;
+        }
         if (dbg && shown++ >= 8 && shown <= 13) {
             std::vector<uint8_t> hf(nq);
             std::vector<int> hc((size_t)nq * nsl);
@@ -730,6 +758,8 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
                                   h->w_pair_off.as<int>(), h->d_list_off, h->d_ids,
                                   out_ids, h->w_sflag.as<uint8_t>());
     }
+    h->tie.G = G;
+    h->tie.q_stride = q_stride;
     GH_CHECK(h, hipGetLastError());
     return GAMMA_HIP_OK;
 }
@@ -737,17 +767,61 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
 // ---- stage B: compute_dis (gamma_index_ivfpq.cc:642-697) ------------------------------
 int ivfpq_stage_b(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, int R, int k,
                   const float* cand_dis, const int64_t* cand_ids, float* d_distances,
-                  int64_t* d_labels, const int* qperm = nullptr) {
+                  int64_t* d_labels, const int* qperm = nullptr, bool tie_replay = false) {
     const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
     const float neutral = l2 ? 3.402823466e+38f : -3.402823466e+38f;
     hipStream_t s = h->stream;
     StageScope t(h, GAMMA_HIP_STAGE_RERANK);
+    // exact ties: the final-stage kernel lists the queries with a tie among their first k+1 distances (or with a
+    // tied top-R cut, stage A) and k_tie_replay redoes those the way the reference's heaps do (ties.hip)
+    const bool ties = tie_replay && h->tie.on;
+    gh::TieFlags tf;
+    if (ties) {
+        tf.cut = h->w_tcut.as<uint8_t>();
+        tf.count = h->w_tlist.as<int>();
+        tf.list = h->w_tlist.as<int>() + 1;
+        tf.stats = h->d_tie_stats;
+    }
+    auto replay = [&]() {
+        gh::TieReplayArgs a;
+        a.list = tf.list;
+        a.count = tf.count;
+        a.nq = nq;
+        a.slab = h->w_dist.as<float>();
+        a.q_stride = h->tie.q_stride;
+        a.pair_off = h->w_pair_off.as<int>();
+        a.pair_base = h->w_pair_base.as<int64_t>();
+        a.ids = h->d_ids;
+        a.P = p->nprobe;
+        a.G = h->tie.G;
+        a.ready = h->tie.bounded ? h->w_scnt.as<unsigned long long>() : nullptr;
+        a.surv = h->w_surv.as<unsigned long long>();
+        a.gcnt = reinterpret_cast<int*>(h->w_scnt.as<unsigned long long>() + nq);
+        a.nsl = h->tie.nsl;
+        a.slice_cap = h->tie.cap;
+        a.x = d_x;
+        a.d = h->d;
+        a.raw = h->d_raw;
+        a.nraw = h->nraw;
+        a.R = R;
+        a.k = k;
+        a.has_rank = p->has_rank ? 1 : 0;
+        a.min_score = p->min_score;
+        a.max_score = p->max_score;
+        a.neutral = neutral;
+        a.cand_dis = const_cast<float*>(cand_dis);
+        a.cand_ids = const_cast<int64_t*>(cand_ids);
+        a.distances = d_distances;
+        a.labels = d_labels;
+        gh::launch_tie_replay(s, l2, a);
+    };
     if (p->has_rank) {
         if (!h->d_raw || h->raw_d != h->d) return fail(h, GAMMA_HIP_EINVAL, "has_rank needs the raw store");
-        if (R <= 1024 && nq >= 256) {
+        if (R <= 1024 && (nq >= 256 || ties)) {
             // one fused kernel: exact distances + top-k + output
             gh::launch_rerank_topk(s, l2, d_x, nq, h->d, h->d_raw, h->nraw, cand_ids, R, k, p->min_score,
-                                   p->max_score, neutral, d_distances, d_labels, qperm);
+                                   p->max_score, neutral, d_distances, d_labels, qperm, ties ? &tf : nullptr);
+            if (ties) replay();
             GH_CHECK(h, hipGetLastError());
             return GAMMA_HIP_OK;
         }
@@ -762,7 +836,8 @@ int ivfpq_stage_b(H* h, const gamma_hip_search_params* p, int nq, const float* d
                                  neutral, d_distances, d_labels);
     } else {
         gh::launch_finalize_norank(s, cand_dis, cand_ids, nq, R, k, p->min_score, p->max_score, neutral,
-                                   d_distances, d_labels);
+                                   d_distances, d_labels, ties ? &tf : nullptr);
+        if (ties) replay();
     }
     GH_CHECK(h, hipGetLastError());
     return GAMMA_HIP_OK;
@@ -831,7 +906,8 @@ int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, c
             GH_TRY(ivfpq_stage_a(h, p, fc.at(q0), nc, d_x + (size_t)q0 * h->d, R));
         GH_TRY(ivfpq_stage_b(h, p, nc, d_x + (size_t)q0 * h->d, R, k, h->w_cand_dis.as<float>(),
                              h->w_cand_ids.as<int64_t>(), d_distances + (size_t)q0 * k,
-                             d_labels + (size_t)q0 * k, getenv("GAMMA_HIP_NO_RERANK_ORDER") ? nullptr : h->last_qperm));
+                             d_labels + (size_t)q0 * k, getenv("GAMMA_HIP_NO_RERANK_ORDER") ? nullptr : h->last_qperm,
+                             /*tie_replay=*/true));
         h->last_nq = nc;
     }
     h->last_P = p->nprobe;
@@ -1006,7 +1082,9 @@ int gamma_hip_create(int device, gamma_hip_index** out) {
         return GAMMA_HIP_EDEVICE;
     }
     if (hipMalloc((void**)&h->d_scan_codes, sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(h->d_scan_codes, 0, sizeof(unsigned long long)) != hipSuccess) {
+        hipMemset(h->d_scan_codes, 0, sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void**)&h->d_tie_stats, 3 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(h->d_tie_stats, 0, 3 * sizeof(unsigned long long)) != hipSuccess) {
         (void)hipStreamDestroy(h->stream);
         delete h;
         return GAMMA_HIP_EDEVICE;
@@ -1035,7 +1113,7 @@ int gamma_hip_destroy(gamma_hip_index* h) {
         (void)hipEventDestroy(e.b);
     }
     void* ptrs[] = {h->d_list_rank, h->d_raw, h->d_bitmap, h->d_cc, h->d_cc_norms, h->d_pqc, h->d_T2, h->d_codes,
-                    h->d_ids, h->d_list_off, h->d_list_len, h->d_list_mask, h->d_scan_codes};
+                    h->d_ids, h->d_list_off, h->d_list_len, h->d_list_mask, h->d_scan_codes, h->d_tie_stats};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& kv : h->fields)
@@ -1049,7 +1127,7 @@ int gamma_hip_destroy(gamma_hip_index* h) {
                       &h->w_filter, &h->w_m_dis, &h->w_m_ids, &h->w_part_v, &h->w_part_i, &h->w_assign,
                       &h->w_codes_tmp, &h->w_qperm, &h->w_scnt, &h->w_sflag, &h->w_surv, &h->w_pair_base,
                       &h->w_pair_ip, &h->w_flat_cand, &h->w_flat_meta, &h->w_full_cdis,
-                      &h->w_full_probe, &h->w_ftab, &h->w_qfil, &h->w_tieflag};
+                      &h->w_full_probe, &h->w_ftab, &h->w_qfil, &h->w_tieflag, &h->w_tcut, &h->w_tlist};
     for (DevBuf* b : bufs) b->release();
     (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1078,6 +1156,18 @@ int gamma_hip_set_exact_ties(gamma_hip_index* h, int on) {
     if (!h) return GAMMA_HIP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
     h->exact_ties = on != 0;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_tie_stats(gamma_hip_index* h, int64_t* out3, int reset) {
+    if (!h || !out3) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    GH_CHECK(h, hipSetDevice(h->device));
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    unsigned long long v[3];
+    GH_CHECK(h, hipMemcpy(v, h->d_tie_stats, sizeof(v), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 3; i++) out3[i] = (int64_t)v[i];
+    if (reset) GH_CHECK(h, hipMemset(h->d_tie_stats, 0, sizeof(v)));
     return GAMMA_HIP_OK;
 }
 

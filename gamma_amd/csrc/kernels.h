@@ -107,7 +107,7 @@ void launch_sum_totals(hipStream_t s, const int* q_total, int nq, unsigned long 
 int select_kpad(int K);
 // coarse quantizer selection (ties at the K-th distance resolved like the reference's heap); tie_flag: nq bytes
 void launch_coarse_select(hipStream_t s, const float* mat, int nlist, int nq, int K, float* out_vals, int* out_pos,
-                          uint8_t* tie_flag);
+                          uint8_t* tie_flag, unsigned long long* tie_stats = nullptr);
 void launch_select_topk(hipStream_t s, bool smallest, const float* vals, int64_t seg_stride,
                         const int* seg_len, int fixed_len, int max_len, int nseg, int K,
                         float* out_vals, int* out_pos, const uint8_t* only = nullptr);
@@ -116,23 +116,67 @@ void launch_select_topk(hipStream_t s, bool smallest, const float* vals, int64_t
 void launch_select_final(hipStream_t s, bool smallest, const unsigned long long* surv, const int* gcnt,
                          int nslices, int slice_cap, const unsigned long long* ready, const int* pair_off, int P,
                          int nq, int K, const int64_t* pair_base, const int64_t* ids, uint8_t* flag, float* out_vals,
-                         int* out_pos, int64_t* out_ids);
+                         int* out_pos, int64_t* out_ids, uint8_t* cut_tie = nullptr,
+                         unsigned long long* tie_stats = nullptr);   // cut_tie[q] = 1: the K-th and (K+1)-th keys are equal
 void launch_map_candidates(hipStream_t s, const int* pos, int nq, int R, int P,
                            const int* probe_list, const int* pair_off, const int64_t* list_off,
                            const int64_t* ids, int64_t* cand_ids, const uint8_t* only = nullptr);
 void launch_rerank_dist(hipStream_t s, bool l2, const float* x, int nq, int d, const float* raw,
                         int64_t nraw, const int64_t* cand_ids, int R, float min_score,
                         float max_score, float* out);
+// Exact-tie bookkeeping (ties.hip, gamma_hip_set_exact_ties).  cut[q] != 0: the top-recall_num cut of query q
+// went through a group of equal ADC distances (set by the selection kernels).  The final-stage kernels add
+// their own condition -- two of the first k+1 final distances equal -- and append every query either one
+// holds for to list[*count]; launch_tie_replay then redoes those queries the way the reference's heaps do.
+// stats: device counters {coarse rows redone, cut ties, queries replayed}, accumulated over calls.
+struct TieFlags {
+    const uint8_t* cut = nullptr;
+    int* list = nullptr;     // nullptr: exact ties off
+    int* count = nullptr;
+    unsigned long long* stats = nullptr;
+};
 void launch_rerank_topk(hipStream_t s, bool l2, const float* x, int nq, int d, const float* raw,
                         int64_t nraw, const int64_t* cand_ids, int R, int k, float min_score,
                         float max_score, float neutral, float* distances, int64_t* labels,
-                        const int* qperm = nullptr);   // qperm: run the queries in this order (speed only)
+                        const int* qperm = nullptr,   // qperm: run the queries in this order (speed only)
+                        const TieFlags* ties = nullptr);
+// what k_tie_replay needs to redo one query (ties.hip)
+struct TieReplayArgs {
+    const int* list;              // flagged queries, *count of them
+    const int* count;
+    int nq;
+    const float* slab;            // ADC distances [nq][q_stride] in scan order, +-inf = filtered entry
+    int64_t q_stride;
+    const int* pair_off;          // [nq][P + 1]
+    const int64_t* pair_base;     // [nq][P] arena offset of each probed list
+    const int64_t* ids;           // list arena
+    int P, G;                     // probes per query; probes of the first group (bounded scan)
+    const unsigned long long* ready;   // bounded scan (may be null): bound word, survivor slices, counts
+    const unsigned long long* surv;
+    const int* gcnt;
+    int nsl, slice_cap;
+    const float* x;               // queries [nq][d]
+    int d;
+    const float* raw;             // raw vectors (has_rank)
+    int64_t nraw;
+    int R, k, has_rank;
+    float min_score, max_score, neutral;
+    float* cand_dis;              // [nq][R] recall-stage table, rewritten for the replayed queries
+    int64_t* cand_ids;
+    float* distances;             // [nq][k]
+    int64_t* labels;
+};
+int tie_replay_max_k();
+int tie_replay_max_probes();
+void launch_tie_replay(hipStream_t s, bool l2, const TieReplayArgs& a);
+void launch_flag_cut_ties(hipStream_t s, const float* slab, int64_t q_stride, const int* q_total, int nq, int K,
+                          const float* sel_vals, const int* sel_pos, const uint8_t* only, uint8_t* tflag);
 void launch_finalize_topk(hipStream_t s, const float* sel_vals, const int* sel_pos, int nq, int k,
                           const int64_t* src_ids, int64_t src_stride, int64_t id_base,
                           float neutral, float* distances, int64_t* labels);
 void launch_finalize_norank(hipStream_t s, const float* cand_dis, const int64_t* cand_ids, int nq,
                             int R, int k, float min_score, float max_score, float neutral,
-                            float* distances, int64_t* labels);
+                            float* distances, int64_t* labels, const TieFlags* ties = nullptr);
 void launch_gather_shards(hipStream_t s, const float* all_dis, const int64_t* all_ids, int nshards,
                           int nq, int R, float* dis, int64_t* ids, float sentinel);
 // one-kernel merge of the shard tables [W][nq][R] for queries [q0, q0 + nql) -> [nql][R]; false = shape

@@ -15,6 +15,7 @@
 #include "device_math.h"
 #include "filter_dev.h"
 #include "kernels.h"
+#include "rerank_dev.h"
 
 namespace gh {
 
@@ -1603,64 +1604,7 @@ __global__ __launch_bounds__(256) void k_rerank_dist(const float* __restrict__ x
         int64_t id = -1;
         if (r < R) id = cand_ids[(int64_t)q * R + r];
         const bool live = id >= 0 && id < nraw;
-        const float* v = raw + (live ? id : 0) * d;
-        float a = 0.f;
-        const int d8 = d & ~7;
-        if (live) {
-            // 16 row elements (and 16 query elements) are requested before the dependent fma
-            // chain starts: the chain is sequential by construction, the loads need not be
-            int i = l;
-            for (; i + 15 * 8 < d8; i += 16 * 8) {
-                float vv[16], xx[16];
-#pragma unroll
-                for (int u = 0; u < 16; u++) vv[u] = v[i + 8 * u];
-#pragma unroll
-                for (int u = 0; u < 16; u++) xx[u] = xq[i + 8 * u];
-#pragma unroll
-                for (int u = 0; u < 16; u++) {
-                    if (L2) {
-                        float t = xx[u] - vv[u];
-                        a = __builtin_fmaf(t, t, a);
-                    } else {
-                        a = __builtin_fmaf(xx[u], vv[u], a);
-                    }
-                }
-            }
-            for (; i < d8; i += 8) {
-                if (L2) {
-                    float t = xq[i] - v[i];
-                    a = __builtin_fmaf(t, t, a);
-                } else {
-                    a = __builtin_fmaf(xq[i], v[i], a);
-                }
-            }
-        }
-        // s[l] = acc[l+4] + acc[l] for l < 4
-        float s = __shfl_down(a, 4, 8) + a;
-        int rem = d - d8;
-        int i = d8;
-        if (live && rem >= 4) {
-            if (l < 4) {
-                if (L2) {
-                    float t = xq[i + l] - v[i + l];
-                    s = __builtin_fmaf(t, t, s);
-                } else {
-                    s = __builtin_fmaf(xq[i + l], v[i + l], s);
-                }
-            }
-            i += 4;
-            rem -= 4;
-        }
-        if (live && l < rem) {
-            if (L2) {
-                float t = xq[i + l] - v[i + l];
-                s = __builtin_fmaf(t, t, s);
-            } else {
-                s = __builtin_fmaf(xq[i + l], v[i + l], s);
-            }
-        }
-        float t01 = s + __shfl_down(s, 1, 8);      // lane0: s0+s1, lane2: s2+s3
-        float dis = t01 + __shfl_down(t01, 2, 8);  // lane0: (s0+s1)+(s2+s3)
+        float dis = rerank_dist8<L2>(xq, raw + (live ? id : 0) * d, d, l, live);
         if (l == 0 && r < R) {
             if (!live || !(dis <= max_score && dis >= min_score)) dis = sentinel;
             out[(int64_t)q * R + r] = dis;
@@ -1694,9 +1638,10 @@ __global__ __launch_bounds__(256) void k_rerank_topk(const float* __restrict__ x
                                                      float min_score, float max_score, float neutral,
                                                      float* __restrict__ distances,
                                                      int64_t* __restrict__ labels, int nq,
-                                                     const int* __restrict__ qperm) {
+                                                     const int* __restrict__ qperm, TieFlags tf) {
     __shared__ unsigned long long s_it[1024];
     __shared__ int64_t s_id[1024];
+    __shared__ int s_tie;
     // With the scan's query order (qperm: queries sorted by the spatial rank of their nearest list) XCD x takes
     // the x-th eighth of that order: queries running together share candidates (a batch references every raw
     // row ~3 times), so their rows are served by that XCD's L2 instead of HBM.  Results do not depend on it.
@@ -1711,7 +1656,6 @@ __global__ __launch_bounds__(256) void k_rerank_topk(const float* __restrict__ x
     const int l = threadIdx.x & 7, g = threadIdx.x >> 3;
     const float* xq = x + (int64_t)q * d;
     const float sentinel = L2 ? INFINITY : -INFINITY;
-    const int d8 = d & ~7;
     // all candidate ids first (one coalesced pass): the row gathers below then start without a
     // dependent id load in front of each of them
     for (int r = threadIdx.x; r < R; r += 256) s_id[r] = cand_ids[(int64_t)q * R + r];
@@ -1721,66 +1665,28 @@ __global__ __launch_bounds__(256) void k_rerank_topk(const float* __restrict__ x
         int64_t id = -1;
         if (r < R) id = s_id[r];
         const bool live = id >= 0 && id < nraw;
-        const float* v = raw + (live ? id : 0) * d;
-        float a = 0.f;
-        if (live) {
-            int i = l;
-            for (; i + 15 * 8 < d8; i += 16 * 8) {
-                float vv[16], xx[16];
-#pragma unroll
-                for (int u = 0; u < 16; u++) vv[u] = v[i + 8 * u];
-#pragma unroll
-                for (int u = 0; u < 16; u++) xx[u] = xq[i + 8 * u];
-#pragma unroll
-                for (int u = 0; u < 16; u++) {
-                    if (L2) {
-                        float t = xx[u] - vv[u];
-                        a = __builtin_fmaf(t, t, a);
-                    } else {
-                        a = __builtin_fmaf(xx[u], vv[u], a);
-                    }
-                }
-            }
-            for (; i < d8; i += 8) {
-                if (L2) {
-                    float t = xq[i] - v[i];
-                    a = __builtin_fmaf(t, t, a);
-                } else {
-                    a = __builtin_fmaf(xq[i], v[i], a);
-                }
-            }
-        }
-        float s = __shfl_down(a, 4, 8) + a;   // s[l] = acc[l+4] + acc[l]
-        int rem = d - d8, i = d8;
-        if (live && rem >= 4) {
-            if (l < 4) {
-                if (L2) {
-                    float t = xq[i + l] - v[i + l];
-                    s = __builtin_fmaf(t, t, s);
-                } else {
-                    s = __builtin_fmaf(xq[i + l], v[i + l], s);
-                }
-            }
-            i += 4;
-            rem -= 4;
-        }
-        if (live && l < rem) {
-            if (L2) {
-                float t = xq[i + l] - v[i + l];
-                s = __builtin_fmaf(t, t, s);
-            } else {
-                s = __builtin_fmaf(xq[i + l], v[i + l], s);
-            }
-        }
-        const float t01 = s + __shfl_down(s, 1, 8);
-        float dis = t01 + __shfl_down(t01, 2, 8);
+        float dis = rerank_dist8<L2>(xq, raw + (live ? id : 0) * d, d, l, live);
         if (l == 0 && r < R) {
             if (!live || !(dis <= max_score && dis >= min_score)) dis = sentinel;
             const uint32_t key = L2 ? f2key(dis) : ~f2key(dis);
             s_it[r] = ((unsigned long long)key << 32) | (unsigned)r;
         }
     }
+    if (tf.list && threadIdx.x == 0) s_tie = tf.cut ? tf.cut[q] : 0;
     block_rank_sort<256, 4>(s_it, R);   // R distinct items (the rank field differs)
+    if (tf.list) {
+        // exact ties (ties.hip): two of the first k+1 exact distances equal -- their order, or which of them
+        // stays inside the k, is decided by the reference's heaps -- or the top-R cut went through a tie
+        for (int i = threadIdx.x; i < k && i + 1 < R; i += 256) {
+            const uint32_t ka = (uint32_t)(s_it[i] >> 32), kb = (uint32_t)(s_it[i + 1] >> 32);
+            if (ka == kb && ka != (L2 ? f2key(sentinel) : ~f2key(sentinel))) s_tie = 1;   // benign race: same value
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && s_tie) {
+            tf.list[atomicAdd(tf.count, 1)] = q;
+            if (tf.stats) atomicAdd(tf.stats + 2, 1ull);
+        }
+    }
     for (int i = threadIdx.x; i < k; i += 256) {
         float val = neutral;
         int64_t id = -1;
@@ -1799,15 +1705,17 @@ __global__ __launch_bounds__(256) void k_rerank_topk(const float* __restrict__ x
 }
 void launch_rerank_topk(hipStream_t s, bool l2, const float* x, int nq, int d, const float* raw,
                         int64_t nraw, const int64_t* cand_ids, int R, int k, float min_score,
-                        float max_score, float neutral, float* distances, int64_t* labels, const int* qperm) {
+                        float max_score, float neutral, float* distances, int64_t* labels, const int* qperm,
+                        const TieFlags* ties) {
     if (nq <= 0) return;
     const dim3 grid((unsigned)(8 * ((nq + 7) / 8)));
+    const TieFlags tf = ties ? *ties : TieFlags{};
     if (l2)
         hipLaunchKernelGGL((k_rerank_topk<true>), grid, dim3(256), 0, s, x, d, raw, nraw, cand_ids,
-                           R, k, min_score, max_score, neutral, distances, labels, nq, qperm);
+                           R, k, min_score, max_score, neutral, distances, labels, nq, qperm, tf);
     else
         hipLaunchKernelGGL((k_rerank_topk<false>), grid, dim3(256), 0, s, x, d, raw, nraw, cand_ids,
-                           R, k, min_score, max_score, neutral, distances, labels, nq, qperm);
+                           R, k, min_score, max_score, neutral, distances, labels, nq, qperm, tf);
 }
 
 // final outputs from a top-k selection over re-ranked (or flat) candidates:
@@ -1846,10 +1754,12 @@ __global__ __launch_bounds__(256) void k_finalize_norank(const float* __restrict
                                                          const int64_t* __restrict__ cand_ids, int R,
                                                          int k, float min_score, float max_score,
                                                          float neutral, float* __restrict__ distances,
-                                                         int64_t* __restrict__ labels) {
+                                                         int64_t* __restrict__ labels, TieFlags tf) {
     __shared__ int s_w[4];
+    __shared__ int s_tie;
     const int q = blockIdx.x;
     int running = 0;
+    if (tf.list && threadIdx.x == 0) s_tie = tf.cut ? tf.cut[q] : 0;
     for (int r0 = 0; r0 < R && running < k; r0 += 256) {
         const int r = r0 + threadIdx.x;
         float dis = 0.f;
@@ -1865,8 +1775,20 @@ __global__ __launch_bounds__(256) void k_finalize_norank(const float* __restrict
         if (flag && slot < k) {
             distances[(int64_t)q * k + slot] = dis;
             labels[(int64_t)q * k + slot] = id;
+            // exact ties (ties.hip): an entry that is taken and its successor at the same ADC distance -- their
+            // order, or which of them is the k-th, is whatever heap_reorder of the reference's R-heap leaves
+            if (tf.list && r + 1 < R && cand_ids[(int64_t)q * R + r + 1] != -1 &&
+                cand_dis[(int64_t)q * R + r + 1] == dis)
+                s_tie = 1;
         }
         running += tot;
+    }
+    if (tf.list) {
+        __syncthreads();
+        if (threadIdx.x == 0 && s_tie) {
+            tf.list[atomicAdd(tf.count, 1)] = q;
+            if (tf.stats) atomicAdd(tf.stats + 2, 1ull);
+        }
     }
     for (int i = min(running, k) + threadIdx.x; i < k; i += 256) {
         distances[(int64_t)q * k + i] = neutral;
@@ -1875,10 +1797,10 @@ __global__ __launch_bounds__(256) void k_finalize_norank(const float* __restrict
 }
 void launch_finalize_norank(hipStream_t s, const float* cand_dis, const int64_t* cand_ids, int nq,
                             int R, int k, float min_score, float max_score, float neutral,
-                            float* distances, int64_t* labels) {
+                            float* distances, int64_t* labels, const TieFlags* ties) {
     if (nq <= 0) return;
     hipLaunchKernelGGL(k_finalize_norank, dim3(nq), dim3(256), 0, s, cand_dis, cand_ids, R, k,
-                       min_score, max_score, neutral, distances, labels);
+                       min_score, max_score, neutral, distances, labels, ties ? *ties : TieFlags{});
 }
 
 // ------------------------------------------------------------------------------------

@@ -568,8 +568,16 @@ __global__ __launch_bounds__(256) void k_select_wave(const float* __restrict__ v
             // (k_coarse_heap_fix redoes the row the way the heap does).
             const bool want_flag = tie_flag && base == 0 && n <= 64 * SW_NPL;
             wave_rank_take(buf, run + tot, want_flag ? K + 1 : K);
-            if (want_flag && lane == 0)
-                tie_flag[seg] = (run + tot > K && (uint32_t)(buf[K] >> 32) == (uint32_t)(buf[K - 1] >> 32)) ? 1 : 0;
+            if (want_flag) {
+                // two equal keys among the K + 1 smallest: which of them is probed (tie at the cut), or in which
+                // order their lists are scanned (tie inside), is the heap's doing
+                const int have = min(run + tot, K + 1);
+                bool eq = false;
+                for (int i = lane; i + 1 < have; i += 64)
+                    eq |= (uint32_t)(buf[i] >> 32) == (uint32_t)(buf[i + 1] >> 32);
+                const unsigned long long any = __ballot(eq);
+                if (lane == 0) tie_flag[seg] = any ? 1 : 0;
+            }
             run = min(run + tot, K);
         } else {
             if (tie_flag && base == 0 && n <= 64 * SW_NPL && lane == 0) tie_flag[seg] = 1;   // not known here: redo the row
@@ -663,7 +671,9 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
                                                       uint8_t* __restrict__ flag,
                                                       float* __restrict__ out_vals,
                                                       int* __restrict__ out_pos,
-                                                      int64_t* __restrict__ out_ids) {
+                                                      int64_t* __restrict__ out_ids,
+                                                      uint8_t* __restrict__ cut_tie,
+                                                      unsigned long long* __restrict__ tie_stats) {
     __shared__ int s_hist[4][256];
     __shared__ unsigned long long s_cand[4][SF_CAND];   // candidates, later the <= 256 kept ones (in place)
     __shared__ int s_off[4][PMAX + 8];
@@ -845,6 +855,13 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
     for (int r = 0; r < 4; r++)
         if (x[r] != ~0ull && rk[r] < 256) runs[rk[r]] = x[r];   // ranks are a permutation of 0..m-1
     __builtin_amdgcn_wave_barrier();
+    // exact ties: every candidate at the K-th key is among the m kept items (key <= cutoff), so the cut went
+    // through a tie group iff the item of rank K carries the key of rank K - 1
+    if (cut_tie && lane == 0) {
+        const bool tie = m > K && (uint32_t)(runs[K] >> 32) == (uint32_t)(runs[K - 1] >> 32);
+        cut_tie[q] = tie ? 1 : 0;
+        if (tie && tie_stats) atomicAdd(tie_stats + 1, 1ull);
+    }
     // position in the query's segment -> vector id (as k_map_candidates): last p with off[p] <= ps.
     // Branch-free on clamped values so the four dependent load chains run side by side.
     const int nres = min(m, K);
@@ -1250,10 +1267,12 @@ __device__ __forceinline__ void heap_sift_down(int k, float& hv, int& hi, float 
 
 __global__ __launch_bounds__(256) void k_coarse_heap_fix(const float* __restrict__ mat, int64_t ld, int n, int K,
                                                          int nq, const uint8_t* __restrict__ flag,
-                                                         float* __restrict__ out_vals, int* __restrict__ out_pos) {
+                                                         float* __restrict__ out_vals, int* __restrict__ out_pos,
+                                                         unsigned long long* __restrict__ tie_stats) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + w;
     if (q >= nq || !flag[q]) return;   // whole wave
+    if (tie_stats && lane == 0) atomicAdd(tie_stats, 1ull);
     float hv = 3.402823466e+38f;       // heap_heapify: (FLT_MAX, -1) everywhere
     int hi = -1;
     const float* v = mat + (int64_t)q * ld;
@@ -1312,7 +1331,7 @@ __global__ __launch_bounds__(256) void k_coarse_heap_fix(const float* __restrict
 // (K <= 64, rows of <= 4096 entries; other shapes keep the (distance, index) order).  A flagged row is a
 // sequential walk of one wave, ~0.17 ms, and about 3 rows in 10^4 are flagged on fp32 data -- hence opt-in.
 void launch_coarse_select(hipStream_t s, const float* mat, int nlist, int nq, int K, float* out_vals, int* out_pos,
-                          uint8_t* tie_flag) {
+                          uint8_t* tie_flag, unsigned long long* tie_stats) {
     static const bool off = getenv("GAMMA_HIP_NO_WAVE_SELECT") != nullptr;
     if (nq <= 0) return;
     if (off || !tie_flag || K > 64 || nlist > 64 * SW_NPL) {
@@ -1322,7 +1341,7 @@ void launch_coarse_select(hipStream_t s, const float* mat, int nlist, int nq, in
     hipLaunchKernelGGL((k_select_wave<true>), dim3((nq + 3) / 4), dim3(256), 0, s, mat, (int64_t)nlist, nullptr, nlist, nq,
                        K, out_vals, out_pos, tie_flag);
     hipLaunchKernelGGL(k_coarse_heap_fix, dim3((nq + 3) / 4), dim3(256), 0, s, mat, (int64_t)nlist, nlist, K, nq, tie_flag,
-                       out_vals, out_pos);
+                       out_vals, out_pos, tie_stats);
 }
 
 int select_kpad(int K) {
@@ -1367,13 +1386,13 @@ void launch_select_topk(hipStream_t s, bool smallest, const float* vals, int64_t
 void launch_select_final(hipStream_t s, bool smallest, const unsigned long long* surv, const int* gcnt,
                          int nslices, int slice_cap, const unsigned long long* ready, const int* pair_off, int P,
                          int nq, int K, const int64_t* pair_base, const int64_t* ids, uint8_t* flag, float* out_vals,
-                         int* out_pos, int64_t* out_ids) {
+                         int* out_pos, int64_t* out_ids, uint8_t* cut_tie, unsigned long long* tie_stats) {
     if (nq <= 0) return;
     if (P > 128 || nslices > 64) abort();   // callers gate on this (gamma_hip.cpp, ivfpq_stage_a)
 #define GH_SF(SM, PM)                                                                                        \
     hipLaunchKernelGGL((k_select_final<SM, PM>), dim3((nq + 3) / 4), dim3(256), 0, s, surv, gcnt, nslices,   \
                        slice_cap, ready, pair_off, P, nq, K, pair_base, ids, flag,                           \
-                       out_vals, out_pos, out_ids)
+                       out_vals, out_pos, out_ids, cut_tie, tie_stats)
     if (smallest) {
         if (P <= 64) GH_SF(true, 64);
         else GH_SF(true, 128);

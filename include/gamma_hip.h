@@ -102,12 +102,21 @@ int gamma_hip_synchronize(gamma_hip_index* h);
 /* Upper bound in bytes of the per-chunk workspaces (coarse distance matrix, ADC distance buffer);
  * larger calls are processed in chunks of queries.  Default: an eighth of the device memory, 1 to 32 GiB. */
 int gamma_hip_set_workspace_budget(gamma_hip_index* h, int64_t bytes);
-/* Coarse quantizer ties.  Two centroids at exactly the same fp32 distance can straddle the nprobe boundary
- * (about 3 queries in 10^4 on fp32 data); faiss probes whichever of them its binary heap happens to hold
- * (HeapResultHandler, faiss:impl/ResultHandler.h:112-117, faiss:utils/Heap.h:103-131), the device by default
- * the one with the lower list number.  on != 0: such rows are redone exactly as the heap does (nprobe <= 64,
- * nlist <= 4096), so the probed lists are the reference's; costs ~0.17 ms per batch containing such a row. */
+/* Exact distance ties.  By default a top-k here is "the k smallest (distance, scan position) pairs".  The
+ * reference keeps candidates in faiss binary heaps (faiss:utils/Heap.h:46-131): WHICH of several candidates at
+ * exactly the same fp32 distance survive a cut, and the order equal distances come out in, is what the heap's
+ * sift order leaves -- at the nprobe cut of the coarse quantizer (HeapResultHandler,
+ * faiss:impl/ResultHandler.h:112-117), at the recall_num cut of the list scan (KnnSearchResults::add,
+ * index/impl/gamma_index_ivfpq.h:363-369) and in compute_dis, which feeds the k-heap in the ARRAY order of the
+ * unsorted recall heap (index/impl/gamma_index_ivfpq.cc:646-680).  on != 0: rows / queries in which such a tie
+ * can change the result are detected by the regular kernels and redone by replaying the reference's heaps
+ * (csrc/ties.hip), so labels and ranks are the reference's, ties included.  Covers single-GPU IVFPQ search with
+ * nprobe <= 64 on <= 4096 lists for the coarse cut, recall_num <= 256 and nprobe <= 256 otherwise; other shapes
+ * and the sharded search keep the (distance, position) order. */
 int gamma_hip_set_exact_ties(gamma_hip_index* h, int on);
+/* out3 = {coarse rows redone, queries whose recall_num cut went through a tie, queries replayed} since creation
+ * or the last reset; meaningful with exact ties on */
+int gamma_hip_tie_stats(gamma_hip_index* h, int64_t* out3, int reset);
 
 /* ---- numeric scalar columns for on-device range filters (docid = row).  The engine side
  *      appends a doc's value when the doc is added (Table::Add, table/table.cc) ----------- */

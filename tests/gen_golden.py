@@ -115,6 +115,91 @@ def gen_ivfpq(R, name, d, nlist, M, N, nq, metric, nprobe, Rk, normalize=False):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
 
 
+def gen_ivfpq_ties(R, name, d, nlist, M, N0, N, nq, nprobe, Rk, k):
+    """Tie-heavy case: every base vector occurs ~N/N0 times (integer data), so equal codes share a list and
+    equal ADC distances straddle every cut; exact distances tie as well.  Expected outputs, all from the real
+    library: the recall-stage table (faiss IndexIVFPQ::search with k = recall_num) and the FINAL results of
+    compute_dis for has_rank on / off, rebuilt here step by step -- candidate stream in scan order (real
+    inner-product table, real fvec_madd, float32 adds in code order), real heap_replace_top stream
+    (ref_heap_stream, which also returns the heap's ARRAY), real fvec_L2sqr / fvec_inner_product on the array
+    order, real heap_pop + heap_push stream + heap_reorder (index/impl/gamma_index_ivfpq.cc:642-697)."""
+    rng = np.random.default_rng(23)
+    b0 = synth.sift_like(N0, d=d, seed=1234)
+    pick = rng.integers(0, N0, size=N).astype(np.int32)
+    base = np.ascontiguousarray(b0[pick])
+    q = synth.sift_like(nq, d=d, seed=4321)
+    q[: nq // 4] = b0[rng.integers(0, N0, size=nq // 4)]          # some queries ARE base vectors
+    out = dict(d=d, nlist=nlist, M=M, N0=N0, N=N, nq=nq, nprobe=nprobe, R=Rk, k=k, pick=pick, q=q)
+    for metric, tag in ((B.METRIC_L2, "l2"), (B.METRIC_IP, "ip")):
+        r = B.RefIVFPQ(d, nlist, M, 8, metric)
+        r.train(b0)
+        r.add(base)
+        assert r.use_precomputed_table() == 1 or metric == B.METRIC_IP
+        cc, pq = r.coarse_centroids(), r.pq_centroids()
+        out["cc_" + tag], out["pq_" + tag] = cc, pq
+        sizes, ids, codes = [], [], []
+        for l in range(nlist):
+            i, c = r.get_list(l)
+            sizes.append(len(i)); ids.append(i); codes.append(c)
+        out["list_sizes_" + tag] = np.array(sizes, dtype=np.int64)
+        out["list_ids_" + tag] = np.concatenate(ids)
+        out["list_codes_" + tag] = np.concatenate(codes)
+        cd, ci = r.coarse(q, nprobe)
+        out["coarse_dis_" + tag], out["coarse_idx_" + tag] = cd, ci
+        Dr, Ir = r.search(q, Rk, nprobe)
+        out["rdis_" + tag], out["rids_" + tag] = Dr, Ir
+        table = r.precomputed_table() if metric == B.METRIC_L2 else None
+        ks = 1 if metric == B.METRIC_L2 else 0
+        tsz = M * 256
+        fin = {True: (np.empty((nq, k), np.float32), np.empty((nq, k), np.int64)),
+               False: (np.empty((nq, k), np.float32), np.empty((nq, k), np.int64))}
+        ntie_cut = 0
+        for qi in range(nq):
+            xq = np.ascontiguousarray(q[qi])
+            st2 = r.inner_prod_table(xq).reshape(-1)
+            sv, si = [], []
+            for ik in range(nprobe):
+                l = int(ci[qi, ik])
+                if l < 0 or sizes[l] == 0:
+                    continue
+                if metric == B.METRIC_L2:
+                    tab = np.empty(tsz, np.float32)
+                    R.ref_fvec_madd(tsz, B._fp(np.ascontiguousarray(table[l].reshape(-1))), -2.0, B._fp(st2), B._fp(tab))
+                    dis = np.full(sizes[l], cd[qi, ik], np.float32)
+                else:
+                    tab = st2
+                    dis = np.full(sizes[l], R.ref_fvec_inner_product(B._fp(xq), B._fp(np.ascontiguousarray(cc[l])), d),
+                                  np.float32)
+                tab = tab.reshape(M, 256)
+                for m in range(M):                      # dis += tab[m][code[m]], m ascending, float32
+                    dis = (dis + tab[m][codes[l][:, m]]).astype(np.float32)
+                sv.append(dis); si.append(ids[l])
+            sv, si = np.ascontiguousarray(np.concatenate(sv)), np.ascontiguousarray(np.concatenate(si))
+            n = len(sv)
+            hv, hi = np.empty(Rk, np.float32), np.empty(Rk, np.int64)
+            so, sio = np.empty(Rk, np.float32), np.empty(Rk, np.int64)
+            R.ref_heap_stream(ks, Rk, n, B._fp(sv), B._ip(si), B._fp(hv), B._ip(hi), B._fp(so), B._ip(sio))
+            # the rebuilt stream IS what faiss scanned: its own search returns the same sorted table
+            assert so.tobytes() == Dr[qi].tobytes() and np.array_equal(sio, Ir[qi]), (tag, qi)
+            kth = so[Rk - 1]
+            ntie_cut += int((sv == kth).sum() > (so == kth).sum())
+            # has_rank: exact distances in ARRAY order through the k-heap
+            live = hi >= 0
+            ex = np.array([(R.ref_fvec_L2sqr if ks else R.ref_fvec_inner_product)(
+                B._fp(xq), B._fp(np.ascontiguousarray(base[i])), d) for i in hi[live]], dtype=np.float32)
+            pv, pi = np.empty(k, np.float32), np.empty(k, np.int64)
+            R.ref_heap_pop_push_stream(ks, k, len(ex), B._fp(ex), B._ip(np.ascontiguousarray(hi[live])), B._fp(pv),
+                                       B._ip(pi))
+            fin[True][0][qi], fin[True][1][qi] = pv, pi
+            # without rank: heap_reorder'ed table, first k (score window wide open)
+            fin[False][0][qi], fin[False][1][qi] = so[:k], sio[:k]
+        out["D_rank_" + tag], out["I_rank_" + tag] = fin[True]
+        out["D_norank_" + tag], out["I_norank_" + tag] = fin[False]
+        out["ncut_" + tag] = np.array([ntie_cut])
+        print(name, tag, "queries with a tie at the recall_num cut:", ntie_cut, "of", nq)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+
+
 def gen_realtime():
     """Drive the reference's real RTInvertIndex through a scripted sequence of AddKeys /
     Update / Delete / CompactIfNeed and record the observable state after each phase."""
@@ -233,6 +318,11 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "iwpq":     # add one fixture, leave the others alone
         gen_iwpq(B.ref())
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "ties":
+        R = B.ref()
+        R.ref_set_blas_threshold(1 << 30)
+        gen_ivfpq_ties(R, "ivfpq_ties_d32", 32, 16, 8, 1500, 6000, 48, 6, 60, 10)
+        return
     if not B.have_ref():
         raise SystemExit("oracle/_ref/libgamma_ref.so missing: run make -f oracle/Makefile.ref")
     os.makedirs(OUT, exist_ok=True)
@@ -243,6 +333,7 @@ def main():
     gen_ivfpq(R, "ivfpq_l2_d32", 32, 32, 8, 6000, 40, B.METRIC_L2, 6, 64)        # dsub 4
     gen_ivfpq(R, "ivfpq_l2_d64", 64, 32, 8, 6000, 40, B.METRIC_L2, 8, 100)       # dsub 8
     gen_ivfpq(R, "ivfpq_ip_d48", 48, 16, 4, 4000, 30, B.METRIC_IP, 4, 50, True)  # dsub 12
+    gen_ivfpq_ties(R, "ivfpq_ties_d32", 32, 16, 8, 1500, 6000, 48, 6, 60, 10)
     gen_realtime()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -68,3 +68,24 @@ def compare_search(D, I, st, Dg, Ig, sg):
     if same.any():
         compare_topk(D[same], I[same], Dg[same], Ig[same])
     return int((~same).sum())
+
+
+def compare_exact(D_ref, I_ref, D_got, I_got):
+    """Strict form (exact-ties mode, gamma_hip_set_exact_ties): distances bit-identical AND labels identical
+    at every rank -- the order inside groups of equal distances, and which members of a group cut by k or
+    recall_num survive, must be the reference heap's."""
+    D_ref = np.ascontiguousarray(D_ref, dtype=np.float32)
+    D_got = np.ascontiguousarray(D_got, dtype=np.float32)
+    assert D_ref.shape == D_got.shape and I_ref.shape == I_got.shape
+    a, b = D_ref.view(np.uint32), D_got.view(np.uint32)
+    pad = (I_ref == -1) & (I_got == -1)      # the reference pads with +-FLT_MAX; either padding value is fine
+    if not np.array_equal(a[~pad], b[~pad]):
+        bad = np.argwhere((a != b) & ~pad)
+        q, r = bad[0]
+        raise AssertionError("distance bits differ at %d entries, first (q=%d, rank=%d): ref=%r got=%r"
+                             % (len(bad), q, r, D_ref[q, r], D_got[q, r]))
+    if not np.array_equal(I_ref, I_got):
+        bad = np.argwhere(I_ref != I_got)
+        q, r = bad[0]
+        raise AssertionError("labels differ at %d entries (%d queries), first (q=%d, rank=%d): ref=%s got=%s"
+                             % (len(bad), len(set(bad[:, 0].tolist())), q, r, I_ref[q].tolist(), I_got[q].tolist()))

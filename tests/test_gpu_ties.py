@@ -1,0 +1,118 @@
+"""GPU: exact-ties mode (gamma_hip_set_exact_ties, csrc/ties.hip).  With it on, labels must be the reference's
+at EVERY rank -- which members of a group of equal distances survive the nprobe / recall_num / k cuts and the
+order equal distances come out in -- checked with tests/parity.compare_exact (no tie tolerance, no excluded
+queries) against the tie-heavy golden built with the real faiss heaps and against the pinned oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from gamma_amd import api, synth
+from oracle import binding as B
+from tests import fixtures
+from tests.parity import compare_exact
+from tests.test_oracle_golden import load_ties
+
+pytestmark = pytest.mark.gpu
+WIDE = dict(min_score=-3e38, max_score=3e38)
+
+
+def _device_for(z, tag, base, metric):
+    d, nlist, M = int(z["d"]), int(z["nlist"]), int(z["M"])
+    g = api.GammaHip(0)
+    g.ivfpq_init(d, nlist, M, 8, metric)
+    g.ivfpq_set_trained(z["cc_" + tag], z["pq_" + tag], None)
+    sizes = z["list_sizes_" + tag]
+    nz = np.nonzero(sizes)[0]
+    g.add_keys_batch(nz, sizes[nz], z["list_ids_" + tag], z["list_codes_" + tag])
+    g.raw_init(d)
+    g.raw_append(base)
+    g.set_exact_ties(True)
+    return g
+
+
+@pytest.mark.parametrize("tag", ["l2", "ip"])
+def test_tie_heavy_golden_on_device(tag):
+    """tests/golden/ivfpq_ties_d32.npz: most queries have equal ADC distances across the recall_num cut and
+    equal exact distances across the k cut.  Small call: the unfiltered selection path flags, the replay redoes."""
+    z, o, base, metric = load_ties(tag)
+    nprobe, R, k = int(z["nprobe"]), int(z["R"]), int(z["k"])
+    g = _device_for(z, tag, base, metric)
+    try:
+        for has_rank, nm in ((True, "rank"), (False, "norank")):
+            g.tie_stats(reset=True)
+            args = api.SearchArgs(metric=metric, nprobe=nprobe, recall_num=R, has_rank=has_rank, coarse_mode=0, **WIDE)
+            Dg, Ig = g.ivfpq_search(z["q"], k, args)
+            sg = g.last_stages(len(z["q"]), nprobe, R)
+            assert sg["coarse_dis"].tobytes() == z["coarse_dis_" + tag].tobytes()
+            assert np.array_equal(sg["coarse_idx"], z["coarse_idx_" + tag])
+            compare_exact(z["D_%s_%s" % (nm, tag)], z["I_%s_%s" % (nm, tag)], Dg, Ig)
+            st = g.tie_stats()
+            assert st["replayed"] >= int(z["ncut_" + tag][0])
+            if not has_rank:     # the replay leaves the recall-stage table in heap_reorder order
+                rows = np.array([i for i in range(len(z["q"]))])
+                compare_exact(z["rdis_" + tag][rows], z["rids_" + tag][rows], sg["recall_dis"][rows],
+                              sg["recall_ids"][rows])
+        # without the mode the same call is only tie-tolerantly equal -- the test data really needs the replay
+        g.set_exact_ties(False)
+        Dg, Ig = g.ivfpq_search(z["q"], k, api.SearchArgs(metric=metric, nprobe=nprobe, recall_num=R,
+                                                         has_rank=True, coarse_mode=0, **WIDE))
+        assert not np.array_equal(Ig, z["I_rank_" + tag])
+    finally:
+        g.close()
+
+
+@pytest.mark.parametrize("tag,nprobe,R,k,reps", [("l2", 12, 60, 10, 100), ("ip", 12, 60, 10, 100),
+                                                  ("l2", 16, 200, 10, 90), ("l2", 6, 40, 40, 100)])
+def test_tie_heavy_batches_take_the_bounded_scan(tag, nprobe, R, k, reps):
+    """The same tie-heavy index at batch size: thousands of queries go through the scan with the threshold
+    pre-filter (survivor slices, k_select_final flags the cut ties); the replay then rebuilds the candidate stream
+    from the first probe group's distances + the slices.  Expected: the pinned oracle, strictly."""
+    z, o, base, metric = load_ties(tag)
+    q = np.tile(z["q"], (reps, 1))
+    q[len(z["q"]):] += np.float32(0)    # exact copies: identical answers, different rows
+    g = _device_for(z, tag, base, metric)
+    try:
+        ctx = B.make_ctx(**WIDE)
+        for has_rank in (True, False):
+            D, I, st = o.search(z["q"], k, nprobe, recall_num=R, has_rank=has_rank, metric=metric, ctx=ctx,
+                                coarse_mode=0, want_stages=True)
+            args = api.SearchArgs(metric=metric, nprobe=nprobe, recall_num=R, has_rank=has_rank, coarse_mode=0, **WIDE)
+            g.tie_stats(reset=True)
+            Dg, Ig = g.ivfpq_search(q, k, args)
+            compare_exact(np.tile(D, (reps, 1)), np.tile(I, (reps, 1)), Dg, Ig)
+            assert g.tie_stats()["replayed"] > 0
+    finally:
+        g.close()
+
+
+def test_ties_with_filters_and_score_window():
+    """Deleted docs and a range filter remove candidates BEFORE the heaps (the reference `continue`s), the score
+    window applies at the k-heap: the replay must see the same stream."""
+    z, o, base, metric = load_ties("l2")
+    nprobe, R, k = 8, 50, 10
+    N = len(base)
+    rng = np.random.default_rng(3)
+    dead = rng.choice(N, size=N // 10, replace=False)
+    bm = np.zeros(N // 8 + 1, np.uint8)
+    for v in dead:
+        bm[v >> 3] |= 1 << (v & 7)
+    allowed = np.nonzero(rng.random(N) < 0.6)[0]
+    g = _device_for(z, "l2", base, metric)
+    try:
+        g.bitmap_upload(bm, N)
+        o.set_docids_bitmap(bm)
+        rf = B.make_range_filter(allowed)
+        q = np.tile(z["q"], (12, 1))
+        for has_rank in (True, False):
+            for win in (dict(min_score=-3e38, max_score=3e38), dict(min_score=2000.0, max_score=60000.0)):
+                ctx = B.make_ctx(docids_bitmap=bm, range_filters=[rf], **win)
+                D, I = o.search(z["q"], k, nprobe, recall_num=R, has_rank=has_rank, metric=metric, ctx=ctx,
+                                coarse_mode=0)
+                args = api.SearchArgs(metric=metric, nprobe=nprobe, recall_num=R, has_rank=has_rank, coarse_mode=0,
+                                      range_filters=[api.make_range_filter(allowed)], **win)
+                for qq, rep in ((z["q"], 1), (q, 12)):
+                    Dg, Ig = g.ivfpq_search(qq, k, args)
+                    compare_exact(np.tile(D, (rep, 1)), np.tile(I, (rep, 1)), Dg, Ig)
+    finally:
+        g.close()

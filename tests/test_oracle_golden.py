@@ -165,3 +165,42 @@ def test_flat_matches_knn():
     Dk, Ik = B.knn_L2sqr(q, base, 10, mode=0)
     # same distances; heap_pop+heap_push vs heap_replace_top only reorder exact ties
     compare_topk(Dk, Ik, D, I)
+
+
+def load_ties(tag):
+    """tests/golden/ivfpq_ties_d32.npz (gen_golden.gen_ivfpq_ties): duplicated integer base vectors, every
+    expected table built with the real faiss primitives and heaps."""
+    z = np.load(os.path.join(G, "ivfpq_ties_d32.npz"))
+    d, nlist, M = int(z["d"]), int(z["nlist"]), int(z["M"])
+    b0 = synth.sift_like(int(z["N0"]), d=d, seed=1234)
+    base = np.ascontiguousarray(b0[z["pick"]])
+    metric = B.METRIC_L2 if tag == "l2" else B.METRIC_IP
+    o = B.OracleIVFPQ(d, nlist, M, 8, metric)
+    o.set_trained(z["cc_" + tag], z["pq_" + tag], None)
+    sizes = z["list_sizes_" + tag]
+    off = 0
+    for l in range(nlist):
+        n = int(sizes[l])
+        if n:
+            o.add_keys(l, z["list_ids_" + tag][off:off + n], z["list_codes_" + tag][off:off + n])
+        off += n
+    o.set_raw(base)
+    return z, o, base, metric
+
+
+@pytest.mark.parametrize("tag", ["l2", "ip"])
+def test_tie_heavy_golden_labels_and_ranks_exact(tag):
+    """Equal ADC distances straddle the recall_num cut in most queries, equal exact distances the k cut: the
+    oracle's heaps must leave exactly what the real library's heaps leave -- labels at every rank."""
+    from tests.parity import compare_exact
+    z, o, base, metric = load_ties(tag)
+    nprobe, R, k = int(z["nprobe"]), int(z["R"]), int(z["k"])
+    assert int(z["ncut_" + tag][0]) > 10
+    ctx = B.make_ctx(min_score=-3e38, max_score=3e38)
+    for has_rank, nm in ((True, "rank"), (False, "norank")):
+        D, I, st = o.search(z["q"], k, nprobe, recall_num=R, has_rank=has_rank, metric=metric, ctx=ctx,
+                            coarse_mode=0, want_stages=True)
+        assert st["coarse_dis"].tobytes() == z["coarse_dis_" + tag].tobytes()
+        assert np.array_equal(st["coarse_idx"], z["coarse_idx_" + tag])
+        compare_exact(z["rdis_" + tag], z["rids_" + tag], st["recall_dis"], st["recall_ids"])
+        compare_exact(z["D_%s_%s" % (nm, tag)], z["I_%s_%s" % (nm, tag)], D, I)
