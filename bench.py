@@ -53,6 +53,10 @@ def main():
                     help="torch.distributed backend; 'gloo' with --one-gpu runs all ranks on GPU 0 (functional "
                          "check of the multi-rank path on a single-GPU box, not a measurement)")
     ap.add_argument("--one-gpu", action="store_true", help="every rank uses cuda:0")
+    ap.add_argument("--exact-ties", action="store_true",
+                    help="run the timed region with gamma_hip_set_exact_ties on (reference heap order inside ties)")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the extra legs (exact ties, batch sizes 1/32/1024, coarse_mode 0, C2 flat)")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per scan launch from a separate rocprofv3 --pmc pass")
     a = ap.parse_args()
@@ -151,6 +155,8 @@ def main():
     d_D = torch.empty((gnq, k), dtype=torch.float32, device=dev)
     d_I = torch.empty((gnq, k), dtype=torch.int64, device=dev)
     backend = gdist.HipShardBackend(g, local_rank) if use_dist else None
+    if a.exact_ties:
+        g.set_exact_ties(True)
 
     def step(i):
         xb = d_q[(i % nbatches) * gnq:(i % nbatches + 1) * gnq]
@@ -222,6 +228,61 @@ def main():
             g.ivfpq_search(qh, k, args)
         host_qps = 5 * a.nq / (time.perf_counter() - t1)
 
+    # ---- the other operating points BASELINE.md / SURVEY 8d name, each a short bounded leg on the same index
+    #      (single GPU only; none of them is `value`) ----
+    extra = {}
+    if world == 1 and not a.no_extra:
+        def timed(fn, n, warm=3):
+            for _ in range(warm):
+                fn()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / n
+
+        # (a) exact ties on: the queries whose result a tie can change are replayed with the reference's heaps
+        g.set_exact_ties(True)
+        sec = timed(lambda: g.ivfpq_search_device(d_q.data_ptr(), gnq, k, args, d_D.data_ptr(), d_I.data_ptr()), 2, 3)
+        g.tie_stats(reset=True)
+        nst = 10
+        sec = timed(lambda: g.ivfpq_search_device(d_q.data_ptr(), gnq, k, args, d_D.data_ptr(), d_I.data_ptr()), nst, 0)
+        ts = g.tie_stats()
+        g.set_exact_ties(a.exact_ties)
+        extra["exact_ties"] = {"qps": round(gnq / sec, 1), "ms_per_step": round(sec * 1e3, 4),
+                               "flagged_per_batch": {"coarse_rows_redone": round(ts["coarse_rows"] / nst, 1),
+                                                     "recall_num_cut_ties": round(ts["cut_ties"] / nst, 1),
+                                                     "queries_replayed": round(ts["replayed"] / nst, 1)},
+                               "batch": gnq}
+        # (b) batch sizes of the BASELINE.md protocol: one Search call of nq queries, device buffers
+        byb = {}
+        for nqb in (1, 32, 1024):
+            sec = timed(lambda: g.ivfpq_search_device(d_q.data_ptr(), nqb, k, args, d_D.data_ptr(), d_I.data_ptr()),
+                        200 if nqb < 1024 else 100, 10)
+            byb[str(nqb)] = {"qps": round(nqb / sec, 1), "us_per_call": round(sec * 1e6, 1)}
+        extra["qps_by_batch"] = byb
+        # (c) the coarse path that is bit-identical to the compiled reference at every batch size (exact
+        #     fvec_L2sqr per pair instead of the GEMM form; faiss itself switches to sgemm at 20 queries)
+        args0 = api.SearchArgs(metric=api.METRIC_L2, nprobe=a.nprobe, recall_num=a.recall_num,
+                               has_rank=not a.no_rank, min_score=0.0, max_score=1e30, coarse_mode=0)
+        sec = timed(lambda: g.ivfpq_search_device(d_q.data_ptr(), gnq, k, args0, d_D.data_ptr(), d_I.data_ptr()), 10, 3)
+        extra["coarse_mode_0"] = {"qps": round(gnq / sec, 1), "ms_per_step": round(sec * 1e3, 4)}
+        # (d) C2: flat L2 over the same 1M x 128 raw vectors, 1024 queries per call, k = 100, exact
+        #     fvec_L2sqr operation order (1 sub + 1 fma per element pair = 3 flops): bound by the fp32 vector rate
+        if N * d * 4 <= (2 << 30):
+            fk, fnq = 100, 1024
+            fD = torch.empty((fnq, fk), dtype=torch.float32, device=dev)
+            fI = torch.empty((fnq, fk), dtype=torch.int64, device=dev)
+            fargs = api.SearchArgs(metric=api.METRIC_L2, min_score=0.0, max_score=1e30)
+            sec = timed(lambda: g.flat_search_device(d_q.data_ptr(), fnq, fk, fargs, fD.data_ptr(), fI.data_ptr()), 5, 2)
+            flops = 3.0 * fnq * N * d
+            extra["c2_flat"] = {"workload": "C2: flat L2, %dx%d, %d queries/call, k=%d" % (N, d, fnq, fk),
+                                "ms_per_call": round(sec * 1e3, 3), "qps": round(fnq / sec, 1),
+                                "roofline": {"bound": "valu_fp32", "achieved": round(flops / sec / 1e12, 2),
+                                             "peak": 157.3, "unit": "TFLOP/s",
+                                             "frac": round(flops / sec / 157.3e12, 4)}}
+
     cpu = None
     if world == 1 and a.cpu_seconds > 0:
         cpu = cpu_baseline(a, base, queries, cc, pq, g, lno, codes, list_sizes)
@@ -264,6 +325,7 @@ def main():
                             "top-k" % (world, world)) if world > 1 else "single GPU",
             "stage_us": stages,
             "pcie_inclusive_qps": None if host_qps is None else round(host_qps, 1),
+            **extra,
         },
         "roofline": {
             "bound": "hbm",

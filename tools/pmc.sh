@@ -3,7 +3,7 @@
 tag=$1; ctrs=$2; kern=$3; shift 3
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --cpu-seconds 0 --recall-queries 0 "$@" > $out.log 2>&1
+rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --cpu-seconds 0 --recall-queries 0 --no-extra "$@" > $out.log 2>&1
 python3 - "$out" "$kern" <<'PY'
 import csv, glob, sys, collections
 d, kern = sys.argv[1], sys.argv[2]

@@ -9,7 +9,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/calib_$c -o pmc -- python3 $root/tools/pmc_calib.py > $out/calib_$c.log 2>&1
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/bench_$c -o pmc -- python3 $root/bench.py --steps 6 --warmup 2 --cpu-seconds 0 --recall-queries 0 "$@" > $out/bench_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/bench_$c -o pmc -- python3 $root/bench.py --steps 6 --warmup 2 --cpu-seconds 0 --recall-queries 0 --no-extra "$@" > $out/bench_$c.log 2>&1
 done
 python3 - "$out" <<'PY' | tee $out/summary.txt
 import csv, glob, sys, collections, json
