@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--one-gpu", action="store_true", help="every rank uses cuda:0")
     ap.add_argument("--exact-ties", action="store_true",
                     help="run the timed region with gamma_hip_set_exact_ties on (reference heap order inside ties)")
+    ap.add_argument("--dup-queries", type=int, default=0,
+                    help="experiment: every batch repeats its first N queries (the lists they probe stay cache "
+                         "resident: what the scan costs without its table traffic)")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the extra legs (exact ties, batch sizes 1/32/1024, coarse_mode 0, C2 flat)")
     ap.add_argument("--pmc-traffic", type=float, default=None,
@@ -103,6 +106,8 @@ def main():
     # lists (scan work) are split, so per-GPU scan work per step is constant
     gnq = a.nq * world
     queries = synth.sift_like(gnq * nbatches, d=d, seed=4321)
+    if a.dup_queries > 0:
+        queries = np.ascontiguousarray(np.tile(queries[:a.dup_queries], (queries.shape[0] // a.dup_queries + 1, 1))[:queries.shape[0]])
     log("[rank %d] data %.1fs" % (rank, time.time() - t0))
 
     g = api.GammaHip(local_rank)

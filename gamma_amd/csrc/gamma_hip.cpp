@@ -705,15 +705,22 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
                                      h->w_cand_pos.as<int>(), nullptr, h->w_tcut.as<uint8_t>());
     } else {
         const int cap = gh::scan_slice_cap(), nsl = PGN;   // one survivor slice per probe group (slice 0: the producer's own)
-        GH_CHECK(h, h->w_scnt.ensure((size_t)nq * (sizeof(unsigned long long) + (size_t)nsl * sizeof(int))));   // ready[nq] | gcnt[nq][nsl]
+        // rq | ready[nq] | gcnt[nq][nsl]   (rq: count + list of the queries that need the repair launch, 8-byte aligned)
+        const size_t rq_bytes = (((size_t)nq + 1) * sizeof(int) + 7) & ~(size_t)7;
+        GH_CHECK(h, h->w_scnt.ensure(rq_bytes + (size_t)nq * (sizeof(unsigned long long) + (size_t)nsl * sizeof(int))));
         GH_CHECK(h, h->w_sflag.ensure((size_t)nq));
         GH_CHECK(h, h->w_surv.ensure((size_t)nq * nsl * cap * sizeof(unsigned long long)));
-        GH_CHECK(h, hipMemsetAsync(h->w_scnt.p, 0, (size_t)nq * sizeof(unsigned long long), s));
+        unsigned long long* ready = reinterpret_cast<unsigned long long*>(h->w_scnt.as<char>() + rq_bytes);
+        GH_CHECK(h, hipMemsetAsync(h->w_scnt.p, 0, sizeof(int), s));
+        GH_CHECK(h, hipMemsetAsync(ready, 0, (size_t)nq * sizeof(unsigned long long), s));
         gh::ScanBound sb;
-        sb.ready = h->w_scnt.as<unsigned long long>();
+        sb.ready = ready;
         sb.surv = h->w_surv.as<unsigned long long>();
-        sb.gcnt = reinterpret_cast<int*>(h->w_scnt.as<unsigned long long>() + nq);
+        sb.gcnt = reinterpret_cast<int*>(ready + nq);
         sb.K = R;
+        sb.store_all = h->tie.on ? 1 : 0;
+        sb.rq_count = h->w_scnt.as<int>();
+        sb.rq_list = h->w_scnt.as<int>() + 1;
         scan(G, 0, PGN, &sb, true);
         static const bool dbg = getenv("GAMMA_HIP_BOUND_DBG") != nullptr;
         static int shown = 0;
@@ -722,7 +729,16 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
                                 h->w_pair_base.as<int64_t>(), h->d_ids,
                                 h->w_sflag.as<uint8_t>(), out_dis,
                                 h->w_cand_pos.as<int>(), out_ids, h->tie.on ? h->w_tcut.as<uint8_t>() : nullptr,
-                                h->d_tie_stats);
+                                h->d_tie_stats, sb.rq_list, sb.rq_count);
+        if (PGN > 1 && !sb.store_all) {
+            // queries the slices could not answer: their consumer groups are scored again, distances stored
+            StageScope t2(h, GAMMA_HIP_STAGE_SCAN, false);
+            gh::launch_ivfpq_scan_pair(s, l2, d_x, nq, d, M, P, h->w_probe.as<int>(), dis0, h->d_cc,
+                                       h->w_st2.as<float>(), h->d_T2, h->d_list_off, h->d_list_len, h->d_list_mask,
+                                       nlist, h->d_codes, h->d_ids, h->w_pair_off.as<int>(), q_stride,
+                                       h->w_dist.as<float>(), fc.d_tab, fc.d_qf, need_ids, nullptr, G, 1, PGN - 1,
+                                       shard ? 1 : 0, nullptr, nullptr, sb.rq_list, sb.rq_count);
+        }
         gh::launch_select_topk(s, l2, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), 0,
                                (int)std::min<int64_t>(q_stride, 1 << 30), nq, R,
                                out_dis, h->w_cand_pos.as<int>(), h->w_sflag.as<uint8_t>());
@@ -794,9 +810,11 @@ int ivfpq_stage_b(H* h, const gamma_hip_search_params* p, int nq, const float* d
         a.ids = h->d_ids;
         a.P = p->nprobe;
         a.G = h->tie.G;
-        a.ready = h->tie.bounded ? h->w_scnt.as<unsigned long long>() : nullptr;
+        const size_t rq_bytes = (((size_t)nq + 1) * sizeof(int) + 7) & ~(size_t)7;
+        unsigned long long* ready = reinterpret_cast<unsigned long long*>(h->w_scnt.as<char>() + rq_bytes);
+        a.ready = h->tie.bounded ? ready : nullptr;
         a.surv = h->w_surv.as<unsigned long long>();
-        a.gcnt = reinterpret_cast<int*>(h->w_scnt.as<unsigned long long>() + nq);
+        a.gcnt = reinterpret_cast<int*>(ready + nq);
         a.nsl = h->tie.nsl;
         a.slice_cap = h->tie.cap;
         a.x = d_x;

@@ -87,6 +87,9 @@ struct ScanBound {
                                 // as (key << 32 | position in the query's segment)
     int* gcnt;                  // [nq][groups] items per slice; > scan_slice_cap() = overflowed
     int K;                      // recall_num
+    int store_all;              // != 0: consumer groups store their distances even with a bound (exact-ties replay)
+    int* rq_list;               // queries k_select_final could not finish from the slices (launch_ivfpq_scan_repair)
+    int* rq_count;
 };
 int scan_slice_cap();
 int scan_group_size(int nq, int P, int G0 = 8);   // G0: probes per workgroup to start from (power of two)
@@ -98,7 +101,8 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
                             int64_t q_stride, float* out, const FilterDesc* ftab /* device */, const int* qfil /* device, may be null */,
                             int need_ids,
                             const int* qperm, int G, int pg_lo, int pg_cnt, int sparse, const ScanBound* bound,
-                            const float* pqc_fused = nullptr);   // != nullptr: query table computed in the kernel
+                            const float* pqc_fused = nullptr,   // != nullptr: query table computed in the kernel
+                            const int* rq_list = nullptr, const int* rq_count = nullptr);   // repair launch (kernels.hip)
 int query_order_bins();
 // bins: query_order_bins() ints of scratch (large batches sort over the whole grid); may be null
 void launch_query_order(hipStream_t s, const int* probe_list, int nq, int P, const int* list_rank,
@@ -117,7 +121,7 @@ void launch_select_final(hipStream_t s, bool smallest, const unsigned long long*
                          int nslices, int slice_cap, const unsigned long long* ready, const int* pair_off, int P,
                          int nq, int K, const int64_t* pair_base, const int64_t* ids, uint8_t* flag, float* out_vals,
                          int* out_pos, int64_t* out_ids, uint8_t* cut_tie = nullptr,
-                         unsigned long long* tie_stats = nullptr);   // cut_tie[q] = 1: the K-th and (K+1)-th keys are equal
+                         unsigned long long* tie_stats = nullptr, int* rq_list = nullptr, int* rq_count = nullptr);   // cut_tie[q] = 1: the K-th and (K+1)-th keys are equal
 void launch_map_candidates(hipStream_t s, const int* pos, int nq, int R, int P,
                            const int* probe_list, const int* pair_off, const int64_t* list_off,
                            const int64_t* ids, int64_t* cand_ids, const uint8_t* only = nullptr);

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <utility>
 
 #include "block_utils.h"
 #include "device_math.h"
@@ -1028,6 +1029,47 @@ constexpr int SCAN_STAGE = 256;                  // survivors staged in LDS per 
 constexpr int SCAN_SLICE = 1024;                 // candidate slice of one workgroup (global); a producer needs recall_num + one histogram bin
 constexpr int SCAN_BATCH = 64;                   // queries per XCD by which producers run ahead
 
+// LDS byte address of LUT entry (m, code byte k of w): (byte << 2) + 1024 * m with the LUT at LDS address 0.
+// One SDWA shift selects the byte and scales it (hipcc emits an extract and a shift-add: two VALU ops per
+// look-up, a third of the scan loop's VALU work); the row offset rides in the ds_read's immediate.
+__device__ __forceinline__ float lut_gather(uint32_t w, int k, int m) {
+    uint32_t a;
+    switch (k) {   // constant after unrolling
+        case 0: asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(a) : "v"(w)); break;
+        case 1: asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(a) : "v"(w)); break;
+        case 2: asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(a) : "v"(w)); break;
+        default: asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(a) : "v"(w)); break;
+    }
+    return *reinterpret_cast<const __attribute__((address_space(3))) float*>((uintptr_t)(a + 1024u * (uint32_t)m));
+}
+
+// LUT entry e = tid + 256 * i goes to LDS with ds_write_addtid_b32: address = M0 + offset + 4 * lane, no address
+// VGPR, 2 LDS cycles per wave instruction instead of the 4 of ds_write_b32 (MI355X_MICROARCH.md, LDS table).
+// M0 = LDS address of the wave's 256-byte segment of table row 0 (lut_store_begin, once per LUT: an SALU write
+// of M0 needs a wait state before an LDS add-TID instruction and the hazard recogniser does not look inside
+// asm statements, hence the s_nop); row i rides in the 16-bit offset field, 1024 * i, i <= 63.  The stores are
+// invisible to the compiler's wait counters, hence the explicit wait before the barrier (lut_store_done).
+// Nothing else in these kernels touches M0 (no LDS-DMA, no movrel): check `grep m0` on the disassembly when
+// the toolchain changes.
+__device__ __forceinline__ void lut_store_begin(uint32_t m0_base) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(m0_base) : "memory");
+}
+template <int MT, int I>
+__device__ __forceinline__ void lut_store_one(float v) {
+    if constexpr (MT >= 64) {   // a 64 KB LUT reaches past the 16 bits of M0 / the offset field
+        extern __shared__ float s_lut_plain[];
+        s_lut_plain[threadIdx.x + 256 * I] = v;
+    } else {
+        asm volatile("ds_write_addtid_b32 %0 offset:%1" : : "v"(v), "n"(1024 * I) : "memory");
+    }
+}
+// rows 0 .. MT-1 of one LUT: f(i) is the entry of row i for this thread
+template <int MT, typename F, int... I>
+__device__ __forceinline__ void lut_store_rows(F&& f, std::integer_sequence<int, I...>) {
+    (lut_store_one<MT, I>(f(I)), ...);
+}
+__device__ __forceinline__ void lut_store_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // amdgpu_num_sgpr(96): 8 waves per SIMD need <= 96 SGPRs each (800 per SIMD); the FILT variant
 // would otherwise take 100 and lose one of the eight resident workgroups per CU
 // IPF (sharded search with every probe of a query in ONE workgroup): the query's table <x_q,m , c_mj> is
@@ -1043,7 +1085,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
         const uint8_t* __restrict__ list_mask, int nlist, const uint8_t* __restrict__ codes,
         const int64_t* __restrict__ ids, const int* __restrict__ pair_off, int64_t q_stride,
         float* __restrict__ out, const FilterDesc* __restrict__ ftab, const int* __restrict__ qfil, int need_ids,
-        float sentinel, const int* __restrict__ qperm, int pg_lo, int pg_cnt, int sparse, ScanBound sb) {
+        float sentinel, const int* __restrict__ qperm, int pg_lo, int pg_cnt, int sparse, ScanBound sb,
+        const int* __restrict__ rq_list, const int* __restrict__ rq_count) {
     // This launch covers probe groups [pg_lo, pg_lo + pg_cnt) of every query.
     // FILT (pg_lo = 0, pg_cnt >= 2): threshold pre-filter.  The workgroup of a query's FIRST probe
     // group (its nearest lists) ends by bounding the query's recall_num-th best distance from above
@@ -1093,8 +1136,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
         pg = pg_lo + slot % pg_cnt;
         qslot = slot / pg_cnt;
     }
-    int q;
-    if (qperm) {
+    const bool repair = !FILT && rq_list != nullptr;
+    int q = 0;
+    if (repair) {
+        // repair launch (launch_ivfpq_scan_repair): a fixed grid walks the (query, probe group) items of the
+        // queries k_select_final could not finish from their survivor slices -- consumer groups with a bound
+        // do not store distances (finish() below) -- and scores those groups again, storing everything
+    } else if (qperm) {
         const int qi = xcd * ((nq + 7) >> 3) + qslot;
         if (qi >= nq) return;
         q = qperm[qi];
@@ -1102,6 +1150,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
         q = qslot * 8 + xcd;
         if (q >= nq) return;
     }
+    // ALL of the kernel's LDS is the dynamic buffer, the LUT first: its LDS address is then the constant 0 and a
+    // gather address is just (code byte << 2) + an immediate offset (one VALU op per look-up instead of two)
+    unsigned long long* s_stage = reinterpret_cast<unsigned long long*>(s_lut + M * 256);   // [SCAN_STAGE]
+    int& s_nstage = *reinterpret_cast<int*>(s_stage + SCAN_STAGE);
+    uint32_t& s_tau = *(reinterpret_cast<uint32_t*>(s_stage + SCAN_STAGE) + 1);
+    uint32_t* s_red = reinterpret_cast<uint32_t*>(s_stage + SCAN_STAGE) + 2;                  // [12]
+    auto body = [&](const int q, const int pg) {
     // validity predicates of THIS query: entry qfil[q] of the call's filter table (one entry unless the
     // call is a combined batch of requests with their own filters); only read when need_ids
     const FilterDesc& filt = ftab[(need_ids && qfil) ? qfil[q] : 0];
@@ -1109,14 +1164,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
     // Survivors are staged in LDS (one LDS atomic per wave and iteration) and flushed to the
     // query's list with ONE global atomic per workgroup; a returning global atomic per wave
     // iteration would put ~1 us of latency into the scan loop.  All lanes of a wave call append().
-    __shared__ unsigned long long s_stage[SCAN_STAGE];
-    __shared__ int s_nstage;
-    __shared__ uint32_t s_tau;
     uint32_t tauq = 0xffffffffu;
+    float tau_f = sentinel;   // the bound as a distance: a candidate survives iff it is not worse than tau_f
     bool bound_on = false;
-    uint32_t g_mn = 0xffffffffu, g_mx = 0u;   // producer (pg == 0): range and count of its valid keys
+    // producer (pg == 0): range and count of its valid distances.  Kept as floats (one min, one max per code
+    // instead of a key conversion and two compare-selects), turned into keys once at the end.
+    float g_fmn = INFINITY, g_fmx = -INFINITY;
     int g_nv = 0;
-    auto append = [&](bool keep, uint32_t key, int pos) {
+    auto within = [&](float val) -> bool { return L2 ? val <= tau_f : val >= tau_f; };
+    auto append = [&](bool keep, float val, int pos) {
         const unsigned long long bal = __ballot(keep);
         if (bal) {
             int base = 0;
@@ -1124,7 +1180,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
             base = __shfl(base, 0, 64);
             if (keep) {
                 const int at = base + __popcll(bal & ((1ull << lane) - 1ull));
-                const unsigned long long item = ((unsigned long long)key << 32) | (unsigned)pos;
+                const unsigned long long item = ((unsigned long long)dis_key<L2>(val) << 32) | (unsigned)pos;
                 if (at < SCAN_STAGE) s_stage[at] = item;
                 else if (at < SCAN_SLICE)   // staging full (rare): the slot number is already unique
                     sb.surv[((int64_t)q * pg_cnt + pg) * SCAN_SLICE + at] = item;
@@ -1143,6 +1199,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
     const int p_begin = pg * G, p_end = min(P, p_begin + G);
     const int tid = threadIdx.x;
     const int msz = M * 256;
+    // LDS byte address of this wave's 256-byte segment of a LUT row (lut_store)
+    const uint32_t lut_m0 = __builtin_amdgcn_readfirstlane(
+            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)s_lut + 256u * (uint32_t)(tid >> 6));
     // nothing to scan in this group (a shard owns ~1/W of the probed lists): leave before the
     // 16 KB query table is fetched (sparse = sharded search only: the check costs two dependent
     // scalar loads per probe).  Producers always go on: they must publish.
@@ -1171,8 +1230,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
     }
     if (!L2) {   // inner product: the LUT is the query table itself, list independent
         if (MT > 0) {
-#pragma unroll
-            for (int i = 0; i < MT; i++) s_lut[tid + 256 * i] = s2r[i];
+            lut_store_begin(lut_m0);
+            lut_store_rows<MT>([&](int i) { return s2r[i]; }, std::make_integer_sequence<int, (MT > 0 ? MT : 1)>{});
+            lut_store_done();
         } else {
             for (int e = tid; e < msz; e += 256) s_lut[e] = st2q[e];
         }
@@ -1186,8 +1246,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
                 // would write back / invalidate the L2 this kernel lives on
                 int spins = 0;
                 unsigned long long word;
+                // (bounded: dispatch order is not a contract -- if the producer has not published within ~2e6
+                //  cycles the group goes on without a bound and the query takes the unfiltered selection)
                 while ((word = __hip_atomic_load(&sb.ready[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0ull &&
-                       ++spins < (1 << 20))
+                       ++spins < (1 << 11))
                     __builtin_amdgcn_s_sleep(16);
                 if (word != 0ull) {
                     s_tau = (word >> 32) == 1ull ? (uint32_t)word : 0xffffffffu;
@@ -1201,6 +1263,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
         if (pg > 0) {
             tauq = s_tau;
             bound_on = tauq < KEY_SENTINEL;   // otherwise the query takes the unfiltered selection
+            tau_f = key2f(L2 ? tauq : ~tauq);
         }
     }
     if (!L2) __syncthreads();   // the LUT (written once per query) is complete; L2 rebuilds it per list
@@ -1238,8 +1301,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
                 float tv[MT > 0 ? MT : 1];
 #pragma unroll
                 for (int i = 0; i < MT; i++) tv[i] = t2[tid + 256 * i];   // MT loads in flight
-#pragma unroll
-                for (int i = 0; i < MT; i++) s_lut[tid + 256 * i] = __builtin_fmaf(-2.0f, s2r[i], tv[i]);
+                lut_store_begin(lut_m0);
+                lut_store_rows<MT>([&](int i) { return __builtin_fmaf(-2.0f, s2r[i], tv[i]); },
+                                   std::make_integer_sequence<int, (MT > 0 ? MT : 1)>{});
+                lut_store_done();
             } else {
                 for (int e = tid; e < msz; e += 256) s_lut[e] = __builtin_fmaf(-2.0f, st2q[e], t2[e]);
             }
@@ -1252,22 +1317,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
         const int pbase = pair_off[(int64_t)q * (P + 1) + p];
         float* o = out + (int64_t)q * q_stride + pbase;
         // store + what the pre-filter tracks about a scored code
-        auto finish = [&](int j, bool ok, float dis) -> uint32_t {
+        // Distances are stored where something reads them: the first group's (its producer's histogram, the
+        // unfiltered selection, the tie replay) and those of a group without a bound.  A consumer with a bound
+        // keeps only its survivors; if k_select_final cannot finish the query from the slices (a slice
+        // overflowed, > 256 equal keys at the cut) the repair launch scores the group again with stores.
+        const bool store = !FILT || pg == 0 || !bound_on || sb.store_all;
+        auto finish = [&](int j, bool ok, float dis) -> float {
             const float val = ok ? dis : sentinel;
-            o[j] = val;
-            uint32_t key = 0xffffffffu;
-            if (FILT) {
-                key = dis_key<L2>(val);
-                if (pg == 0 && key < KEY_SENTINEL) {
-                    g_mn = key < g_mn ? key : g_mn;
-                    g_mx = key > g_mx ? key : g_mx;
-                    g_nv++;
-                }
+            if (store) o[j] = val;
+            if (FILT && pg == 0) {
+                const bool valid = val != sentinel;
+                g_fmn = fminf(g_fmn, valid ? val : INFINITY);
+                g_fmx = fmaxf(g_fmx, valid ? val : -INFINITY);
+                g_nv += valid ? 1 : 0;
             }
-            return key;
+            return val;
         };
         // one code: validity, ADC (gathers issued together, adds in reference order), store
-        auto do_code = [&](int j, const uint32_t* cw) -> uint32_t {
+        auto do_code = [&](int j, const uint32_t* cw) -> float {
             // ids are read only when something can reject an entry (delete bit, range filter,
             // superseded slot); otherwise 8 of the 28 bytes per candidate stay in HBM
             bool ok = true;
@@ -1280,7 +1347,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
             if (PRE) {
                 float t[PRE ? MT : 1];
 #pragma unroll
-                for (int m = 0; m < (PRE ? MT : 1); m++) t[m] = s_lut[m * 256 + ((cw[m >> 2] >> ((m & 3) * 8)) & 255)];
+                for (int m = 0; m < (PRE ? MT : 1); m++) t[m] = lut_gather(cw[m >> 2], m & 3, m);
                 __builtin_amdgcn_sched_barrier(0);   // all gathers in flight before the add chain
 #pragma unroll
                 for (int m = 0; m < (PRE ? MT : 1); m++) dis += t[m];   // sequential, reference order
@@ -1296,7 +1363,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
             for (int u = 0; u < NLD; u++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(cfirst[u]) : : "memory");
         }
         {
-            uint32_t key = 0xffffffffu;
+            float val = sentinel;
             if (tid < len) {
                 uint32_t cw[PRE ? MT / 4 : 1];
                 if (PRE) {
@@ -1305,9 +1372,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
 #pragma unroll
                         for (int i = 0; i < LW; i++) cw[LW * u + i] = cfirst[u][i];
                 }
-                key = do_code(tid, cw);
+                val = do_code(tid, cw);
             }
-            if (FILT && bound_on) append(key <= tauq, key, pbase + tid);
+            if (FILT && bound_on) append(within(val), val, pbase + tid);
         }
         if constexpr (MT == 64) {
             // 64-byte codes: the 64 KB LUT leaves two workgroups per CU (2 waves per SIMD), so each
@@ -1338,9 +1405,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
                 }
                 float ta[64], tb[64];
 #pragma unroll
-                for (int m = 0; m < 64; m++) ta[m] = s_lut[m * 256 + ((cwa[m >> 2] >> ((m & 3) * 8)) & 255)];
+                for (int m = 0; m < 64; m++) ta[m] = lut_gather(cwa[m >> 2], m & 3, m);
 #pragma unroll
-                for (int m = 0; m < 64; m++) tb[m] = s_lut[m * 256 + ((cwb[m >> 2] >> ((m & 3) * 8)) & 255)];
+                for (int m = 0; m < 64; m++) tb[m] = lut_gather(cwb[m >> 2], m & 3, m);
                 __builtin_amdgcn_sched_barrier(0);   // all gathers in flight before the add chains
                 float da = dis0, db = dis0;
 #pragma unroll
@@ -1348,16 +1415,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
                     da += ta[m];
                     db += tb[m];
                 }
-                const uint32_t keya = ina ? finish(ja, oka, da) : 0xffffffffu;
-                const uint32_t keyb = inb ? finish(jb, okb, db) : 0xffffffffu;
+                const float vala = ina ? finish(ja, oka, da) : sentinel;
+                const float valb = inb ? finish(jb, okb, db) : sentinel;
                 if (FILT && bound_on) {
-                    append(keya <= tauq, keya, pbase + ja);
-                    append(keyb <= tauq, keyb, pbase + jb);
+                    append(within(vala), vala, pbase + ja);
+                    append(within(valb), valb, pbase + jb);
                 }
             }
             if (j0 < len) {   // at most 256 codes left: one per thread
                 const int j = j0 + tid;
-                uint32_t key = 0xffffffffu;
+                float val = sentinel;
                 if (j < len) {
                     uint32_t cw[16];
                     const uint4* cp = reinterpret_cast<const uint4*>(lc + (int64_t)j * 64);
@@ -1366,14 +1433,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
                         const uint4 cv = cp[u];
                         cw[4 * u] = cv.x; cw[4 * u + 1] = cv.y; cw[4 * u + 2] = cv.z; cw[4 * u + 3] = cv.w;
                     }
-                    key = do_code(j, cw);
+                    val = do_code(j, cw);
                 }
-                if (FILT && bound_on) append(key <= tauq, key, pbase + j);
+                if (FILT && bound_on) append(within(val), val, pbase + j);
             }
         } else {
             for (int j0 = 256; j0 < len; j0 += 256) {
                 const int j = j0 + tid;
-                uint32_t key = 0xffffffffu;
+                float val = sentinel;
                 if (j < len) {
                     uint32_t cw[PRE ? MT / 4 : 1];
                     if (PRE) {
@@ -1385,9 +1452,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
                             for (int i = 0; i < LW; i++) cw[LW * u + i] = cv[i];
                         }
                     }
-                    key = do_code(j, cw);
+                    val = do_code(j, cw);
                 }
-                if (FILT && bound_on) append(key <= tauq, key, pbase + j);
+                if (FILT && bound_on) append(within(val), val, pbase + j);
             }
         }
     }
@@ -1398,10 +1465,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
         // holding the K-th smallest.  At least K candidates are <= tau, hence the whole final top-K.
         __syncthreads();   // this workgroup's distance stores are visible to all its threads
         int* hist = reinterpret_cast<int*>(s_stage);   // staging has not been used yet
-        __shared__ uint32_t s_red[12];
         const int n0 = pair_off[(int64_t)q * (P + 1) + min(G, P)];
         const float* o0 = out + (int64_t)q * q_stride;
-        uint32_t mn = g_mn, mx = g_mx;
+        // float range -> key range (a zero may carry either sign: take the widest pair of keys)
+        const float fmn = g_fmn == 0.f ? -0.f : g_fmn, fmx = g_fmx == 0.f ? 0.f : g_fmx;
+        uint32_t mn = g_nv ? (L2 ? dis_key<L2>(fmn) : dis_key<L2>(fmx)) : 0xffffffffu;
+        uint32_t mx = g_nv ? (L2 ? dis_key<L2>(fmx) : dis_key<L2>(fmn)) : 0u;
         int nv = g_nv;
         mn = wave_min_u32(mn);
         mx = wave_max_u32(mx);
@@ -1471,12 +1540,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const int idx = i0 + u * 256 + (int)threadIdx.x;
-                    const uint32_t key = dis_key<L2>(t[u]);
-                    append(idx < n0 && key <= tau, key, idx);
+                    append(idx < n0 && dis_key<L2>(t[u]) <= tau, t[u], idx);
                 }
             }
         }
         flush();   // without a bound: count 0
+    }
+    };   // body
+    if (!repair) {
+        body(q, pg);
+    } else {
+        const int nrq = *rq_count;
+        for (int w = blockIdx.x; w / pg_cnt < nrq; w += gridDim.x) {
+            body(rq_list[w / pg_cnt], pg_lo + w % pg_cnt);
+            __syncthreads();   // the LUT of this item has been consumed
+        }
     }
 }
 
@@ -1497,27 +1575,32 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
                             const uint8_t* codes, const int64_t* ids, const int* pair_off,
                             int64_t q_stride, float* out, const FilterDesc* ftab, const int* qfil, int need_ids,
                             const int* qperm, int G, int pg_lo, int pg_cnt, int sparse, const ScanBound* bound,
-                            const float* pqc_fused) {
+                            const float* pqc_fused, const int* rq_list, const int* rq_count) {
     if (nq <= 0 || pg_cnt <= 0) return;
     if (pqc_fused) {   // the table is computed inside the kernel (IPF): one workgroup per query, M 16 / 32
         if (!bound || pg_cnt != 1 || (M != 16 && M != 32)) abort();
         st2 = pqc_fused;
     }
-    const size_t lds = (size_t)M * 256 * sizeof(float);
+    // LUT | survivor staging | a few words (see the kernel)
+    const size_t lds = (size_t)M * 256 * sizeof(float) + SCAN_STAGE * sizeof(unsigned long long) + 16 * sizeof(int);
     dim3 grid((unsigned)(8 * (int64_t)((nq + 7) / 8) * pg_cnt));
     if (bound) {   // P(0) | P(t+1) C(t) ...: whole batches, see the kernel
         const int64_t nq8 = (nq + 7) / 8, nb = (nq8 + SCAN_BATCH - 1) / SCAN_BATCH;
         grid.x = (unsigned)(8 * (SCAN_BATCH + nb * SCAN_BATCH * pg_cnt));
     }
-    ScanBound sb = {nullptr, nullptr, nullptr, 0};
+    ScanBound sb = {nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr};
     if (bound) sb = *bound;
+    if (rq_list) {   // repair launch: a fixed grid loops over the flagged (query, group) items
+        if (bound || pqc_fused) abort();
+        grid.x = (unsigned)std::min<int64_t>((int64_t)nq * pg_cnt, 2048);
+    }
 #define GH_SCAN(LL, MT, FF)                                                                       \
     GH_SCAN4(LL, MT, FF, false)
 #define GH_SCAN4(LL, MT, FF, II)                                                                       \
     hipLaunchKernelGGL((k_ivfpq_scan_pair<LL, MT, FF, II>), grid, dim3(256), lds, s, x, nq, d, M, P, G,     \
                        probe_list, coarse_dis, cc, st2, T2, list_off, list_len, list_mask, nlist, codes, \
                        ids, pair_off, q_stride, out, ftab, qfil, need_ids, LL ? INFINITY : -INFINITY, qperm,   \
-                       pg_lo, pg_cnt, sparse, sb)
+                       pg_lo, pg_cnt, sparse, sb, rq_list, rq_count)
 #define GH_SCAN_M(LL, FF)                       \
     do {                                        \
         if (M == 16) GH_SCAN(LL, 16, FF);       \

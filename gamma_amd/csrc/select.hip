@@ -673,7 +673,8 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
                                                       int* __restrict__ out_pos,
                                                       int64_t* __restrict__ out_ids,
                                                       uint8_t* __restrict__ cut_tie,
-                                                      unsigned long long* __restrict__ tie_stats) {
+                                                      unsigned long long* __restrict__ tie_stats,
+                                                      int* __restrict__ rq_list, int* __restrict__ rq_count) {
     __shared__ int s_hist[4][256];
     __shared__ unsigned long long s_cand[4][SF_CAND];   // candidates, later the <= 256 kept ones (in place)
     __shared__ int s_off[4][PMAX + 8];
@@ -684,8 +685,17 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
     const unsigned long long word = ready[q];
     // slice counts of the consumer workgroups (nslices <= 64: one per lane)
     const int my_cnt = lane < nslices ? gcnt[(int64_t)q * nslices + lane] : 0;
-    if ((word >> 32) != 1ull || __ballot(my_cnt > slice_cap)) {   // no bound, or a slice overflowed
-        if (lane == 0) flag[q] = 1;                                // left to the unfiltered selection kernel
+    // left to the unfiltered selection kernel: no bound (every group stored its distances), or a slice overflowed
+    // (groups with a bound did not store: the repair launch scores them again first, rq_list)
+    if ((word >> 32) != 1ull) {
+        if (lane == 0) flag[q] = 1;
+        return;
+    }
+    if (__ballot(my_cnt > slice_cap)) {
+        if (lane == 0) {
+            flag[q] = 1;
+            if (rq_list) rq_list[atomicAdd(rq_count, 1)] = q;
+        }
         return;
     }
     int* hist = s_hist[w];
@@ -787,7 +797,10 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
             __builtin_amdgcn_wave_barrier();
             if (kept <= 256 || s == 0) {
                 if (kept > 256) {        // > 256 copies of one key around the K-th: rare, unfiltered path
-                    if (lane == 0) flag[q] = 1;
+                    if (lane == 0) {
+                        flag[q] = 1;
+                        if (rq_list) rq_list[atomicAdd(rq_count, 1)] = q;
+                    }
                     return;
                 }
                 const unsigned long long edge = (unsigned long long)lo + (((unsigned long long)b + 1ull) << s) - 1ull;
@@ -1386,13 +1399,14 @@ void launch_select_topk(hipStream_t s, bool smallest, const float* vals, int64_t
 void launch_select_final(hipStream_t s, bool smallest, const unsigned long long* surv, const int* gcnt,
                          int nslices, int slice_cap, const unsigned long long* ready, const int* pair_off, int P,
                          int nq, int K, const int64_t* pair_base, const int64_t* ids, uint8_t* flag, float* out_vals,
-                         int* out_pos, int64_t* out_ids, uint8_t* cut_tie, unsigned long long* tie_stats) {
+                         int* out_pos, int64_t* out_ids, uint8_t* cut_tie, unsigned long long* tie_stats,
+                         int* rq_list, int* rq_count) {
     if (nq <= 0) return;
     if (P > 128 || nslices > 64) abort();   // callers gate on this (gamma_hip.cpp, ivfpq_stage_a)
 #define GH_SF(SM, PM)                                                                                        \
     hipLaunchKernelGGL((k_select_final<SM, PM>), dim3((nq + 3) / 4), dim3(256), 0, s, surv, gcnt, nslices,   \
                        slice_cap, ready, pair_off, P, nq, K, pair_base, ids, flag,                           \
-                       out_vals, out_pos, out_ids, cut_tie, tie_stats)
+                       out_vals, out_pos, out_ids, cut_tie, tie_stats, rq_list, rq_count)
     if (smallest) {
         if (P <= 64) GH_SF(true, 64);
         else GH_SF(true, 128);
