@@ -288,6 +288,9 @@ class GammaHip:
     def set_dist_budget(self, nbytes):
         self._ck(self.L.gamma_hip_set_workspace_budget(self.h, int(nbytes)), "set_workspace_budget")
 
+    def set_list_major(self, on=True):
+        self._ck(self.L.gamma_hip_set_list_major(self.h, 1 if on else 0), "set_list_major")
+
     def tie_stats(self, reset=False):
         out = np.zeros(3, np.int64)
         self._ck(self.L.gamma_hip_tie_stats(self.h, _p(out, _lib.i64p), 1 if reset else 0), "tie_stats")

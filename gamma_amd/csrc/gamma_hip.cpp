@@ -125,7 +125,7 @@ struct gamma_hip_index {
     DevBuf w_mat, w_coarse_dis, w_probe, w_xn, w_st2, w_pair_off, w_qtotal, w_dist, w_cand_dis,
             w_cand_pos, w_cand_ids, w_exact, w_selv, w_selp, w_x, w_outd, w_outl, w_stage, w_filter,
             w_m_dis, w_m_ids, w_part_v, w_part_i, w_assign, w_codes_tmp, w_qperm, w_scnt, w_sflag, w_surv, w_pair_base,
-            w_pair_ip, w_flat_cand, w_flat_meta, w_full_cdis, w_full_probe, w_ftab, w_qfil, w_tieflag, w_tcut, w_tlist;
+            w_pair_ip, w_flat_cand, w_flat_meta, w_full_cdis, w_full_probe, w_ftab, w_qfil, w_tieflag, w_tcut, w_tlist, w_survc, w_lm_units, w_lm_cnt;
     unsigned long long* d_scan_codes = nullptr;
     size_t dist_budget_bytes = (size_t)8 << 30;   // per-chunk ADC distance buffer (288 GB of HBM per GPU)
 
@@ -135,6 +135,7 @@ struct gamma_hip_index {
     bool ftab_valid = false;
 
     bool exact_ties = false;   // gamma_hip_set_exact_ties
+    bool list_major = false;   // gamma_hip_set_list_major
     unsigned long long* d_tie_stats = nullptr;   // {coarse rows redone, top-R cuts through a tie, queries replayed}
     // what stage A leaves for the tie replay of stage B (ties.hip)
     struct TieCtx {
@@ -704,12 +705,25 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
             gh::launch_flag_cut_ties(s, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), nq, R, out_dis,
                                      h->w_cand_pos.as<int>(), nullptr, h->w_tcut.as<uint8_t>());
     } else {
-        const int cap = gh::scan_slice_cap(), nsl = PGN;   // one survivor slice per probe group (slice 0: the producer's own)
+        // List-major consumer scan (scan_lm.hip) for large batches: the producers run alone, then every other probe
+        // is scored two queries per list pass.  Gated on what k_scan_lm covers; results are the same either way.
+        // Measured at C3 (16384 queries): 233 k units for 393 k consumer pairs, 58 % of the query-major kernel's
+        // vector instructions and 84 % of its LDS cycles -- but 1069 us against ~700 us for the same pairs: two
+        // 16 KB query-table rows per unit instead of one per eight pairs (11 GB through the L2 per launch), four
+        // workgroups per CU behind a 32 KB LUT2, and ds_read_b64 gathers that conflict more than ds_read_b32.
+        // Lists of a few hundred codes are too short to pay for it; it stays OFF unless asked for
+        // (gamma_hip_set_list_major, GAMMA_HIP_LM=1), kept for long-list shapes and covered by a parity test.
+        static const bool env_lm = getenv("GAMMA_HIP_LM") != nullptr;
+        const bool lm = (env_lm || h->list_major) && !shard && PGN > 1 && M == 16 && nq >= 2048 && 1 + (P - G) <= 64 &&
+                        !fc.d_qf && h->d_list_mask == nullptr;
+        const int cap = gh::scan_slice_cap();
+        // one survivor slice per probe group (slice 0: the producer's own) -- or, list-major, per consumer PAIR
+        const int nsl = lm ? 1 + (P - G) : PGN;
         // rq | ready[nq] | gcnt[nq][nsl]   (rq: count + list of the queries that need the repair launch, 8-byte aligned)
         const size_t rq_bytes = (((size_t)nq + 1) * sizeof(int) + 7) & ~(size_t)7;
         GH_CHECK(h, h->w_scnt.ensure(rq_bytes + (size_t)nq * (sizeof(unsigned long long) + (size_t)nsl * sizeof(int))));
         GH_CHECK(h, h->w_sflag.ensure((size_t)nq));
-        GH_CHECK(h, h->w_surv.ensure((size_t)nq * nsl * cap * sizeof(unsigned long long)));
+        GH_CHECK(h, h->w_surv.ensure((size_t)nq * (lm ? 1 : nsl) * cap * sizeof(unsigned long long)));
         unsigned long long* ready = reinterpret_cast<unsigned long long*>(h->w_scnt.as<char>() + rq_bytes);
         GH_CHECK(h, hipMemsetAsync(h->w_scnt.p, 0, sizeof(int), s));
         GH_CHECK(h, hipMemsetAsync(ready, 0, (size_t)nq * sizeof(unsigned long long), s));
@@ -718,10 +732,56 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         sb.surv = h->w_surv.as<unsigned long long>();
         sb.gcnt = reinterpret_cast<int*>(ready + nq);
         sb.K = R;
+        sb.cnt_stride = nsl;
         sb.store_all = h->tie.on ? 1 : 0;
         sb.rq_count = h->w_scnt.as<int>();
         sb.rq_list = h->w_scnt.as<int>() + 1;
-        scan(G, 0, PGN, &sb, true);
+        const unsigned long long* surv_c = nullptr;
+        if (!lm) {
+            scan(G, 0, PGN, &sb, true);
+        } else {
+            const int PC = P - G, B = gh::lm_block_queries(P, G), nblk = (nq + B - 1) / B;
+            GH_CHECK(h, h->w_survc.ensure((size_t)nq * PC * gh::lm_pair_cap() * sizeof(unsigned long long)));
+            GH_CHECK(h, h->w_lm_units.ensure((size_t)nblk * gh::lm_units_per_block() * 16 * sizeof(int)));
+            GH_CHECK(h, h->w_lm_cnt.ensure((size_t)nblk * sizeof(int)));
+            GH_CHECK(h, hipMemsetAsync(sb.gcnt, 0, (size_t)nq * nsl * sizeof(int), s));   // pairs never scored: 0 survivors
+            scan(G, 0, 1, &sb, true);   // producers: first probe group, bound, own survivors (slice 0)
+            StageScope t2(h, GAMMA_HIP_STAGE_SCAN, false);
+            gh::launch_lm_units(s, h->w_probe.as<int>(), dis0, h->w_pair_off.as<int>(), h->d_list_off, h->d_list_len,
+                                h->d_list_mask, nlist, qperm, ready, nq, P, G, B, h->w_lm_units.as<int>(),
+                                h->w_lm_cnt.as<int>());
+            gh::LmScanArgs la;
+            la.units = h->w_lm_units.as<int>();
+            la.ucount = h->w_lm_cnt.as<int>();
+            la.nq = nq;
+            la.B = B;
+            la.st2 = h->w_st2.as<float>();
+            la.T2 = h->d_T2;
+            la.codes = h->d_codes;
+            la.ids = h->d_ids;
+            la.out = h->w_dist.as<float>();
+            la.q_stride = q_stride;
+            la.surv = h->w_survc.as<unsigned long long>();
+            la.cnt = sb.gcnt;
+            la.nslc = PC;
+            la.cnt_stride = nsl;
+            la.store_all = sb.store_all;
+            la.need_ids = need_ids;
+            la.ftab = fc.d_tab;
+            gh::launch_scan_lm(s, l2, M, la);
+            surv_c = h->w_survc.as<unsigned long long>();
+            static const bool lm_dbg = getenv("GAMMA_HIP_LM_DBG") != nullptr;
+            static int lm_shown = 0;
+            if (lm_dbg && lm_shown++ < 2) {
+                std::vector<int> uc(nblk);
+                (void)hipStreamSynchronize(s);
+                (void)hipMemcpy(uc.data(), h->w_lm_cnt.p, (size_t)nblk * sizeof(int), hipMemcpyDeviceToHost);
+                int64_t tot = 0;
+                for (int v : uc) tot += v;
+                fprintf(stderr, "list-major scan: %d blocks of %d queries, %lld units for %lld consumer pairs\n", nblk, B,
+                        (long long)tot, (long long)nq * PC);
+            }
+        }
         static const bool dbg = getenv("GAMMA_HIP_BOUND_DBG") != nullptr;
         static int shown = 0;
         StageScope t(h, GAMMA_HIP_STAGE_SELECT);
@@ -729,7 +789,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
                                 h->w_pair_base.as<int64_t>(), h->d_ids,
                                 h->w_sflag.as<uint8_t>(), out_dis,
                                 h->w_cand_pos.as<int>(), out_ids, h->tie.on ? h->w_tcut.as<uint8_t>() : nullptr,
-                                h->d_tie_stats, sb.rq_list, sb.rq_count);
+                                h->d_tie_stats, sb.rq_list, sb.rq_count, surv_c, gh::lm_pair_cap());
         if (PGN > 1 && !sb.store_all) {
             // queries the slices could not answer: their consumer groups are scored again, distances stored
             StageScope t2(h, GAMMA_HIP_STAGE_SCAN, false);
@@ -745,7 +805,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         if (h->tie.on) {
             gh::launch_flag_cut_ties(s, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), nq, R, out_dis,
                                      h->w_cand_pos.as<int>(), h->w_sflag.as<uint8_t>(), h->w_tcut.as<uint8_t>());
-            h->tie.bounded = true;
+            h->tie.bounded = !lm;   // list-major: the replay walks the whole slab (everything is stored with exact ties on)
             h->tie.nsl = nsl;
             h->tie.cap = cap;
         }
@@ -1145,7 +1205,7 @@ int gamma_hip_destroy(gamma_hip_index* h) {
                       &h->w_filter, &h->w_m_dis, &h->w_m_ids, &h->w_part_v, &h->w_part_i, &h->w_assign,
                       &h->w_codes_tmp, &h->w_qperm, &h->w_scnt, &h->w_sflag, &h->w_surv, &h->w_pair_base,
                       &h->w_pair_ip, &h->w_flat_cand, &h->w_flat_meta, &h->w_full_cdis,
-                      &h->w_full_probe, &h->w_ftab, &h->w_qfil, &h->w_tieflag, &h->w_tcut, &h->w_tlist};
+                      &h->w_full_probe, &h->w_ftab, &h->w_qfil, &h->w_tieflag, &h->w_tcut, &h->w_tlist, &h->w_survc, &h->w_lm_units, &h->w_lm_cnt};
     for (DevBuf* b : bufs) b->release();
     (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1174,6 +1234,13 @@ int gamma_hip_set_exact_ties(gamma_hip_index* h, int on) {
     if (!h) return GAMMA_HIP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
     h->exact_ties = on != 0;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_set_list_major(gamma_hip_index* h, int on) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    h->list_major = on != 0;
     return GAMMA_HIP_OK;
 }
 

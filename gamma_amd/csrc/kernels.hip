@@ -17,6 +17,7 @@
 #include "filter_dev.h"
 #include "kernels.h"
 #include "rerank_dev.h"
+#include "scan_dev.h"
 
 namespace gh {
 
@@ -1017,58 +1018,10 @@ void launch_pair_ip(hipStream_t s, const float* x, const float* cc, const int* p
 // Codes are AoS [len][M] exactly as the reference stores them; a 16-byte code is one
 // dwordx4 load per lane, so a wave reads 1 KiB contiguous.
 // ------------------------------------------------------------------------------------
-// order-preserving key of a distance in "smaller is better" form (the selection kernels' key)
-template <bool L2>
-__device__ __forceinline__ uint32_t dis_key(float v) {
-    const uint32_t k = f2key(v);
-    return L2 ? k : ~k;
-}
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-constexpr uint32_t KEY_SENTINEL = 0xff800000u;   // key of the filtered-entry marker (+inf / -inf)
 constexpr int SCAN_STAGE = 256;                  // survivors staged in LDS per workgroup
 constexpr int SCAN_SLICE = 1024;                 // candidate slice of one workgroup (global); a producer needs recall_num + one histogram bin
 constexpr int SCAN_BATCH = 64;                   // queries per XCD by which producers run ahead
-
-// LDS byte address of LUT entry (m, code byte k of w): (byte << 2) + 1024 * m with the LUT at LDS address 0.
-// One SDWA shift selects the byte and scales it (hipcc emits an extract and a shift-add: two VALU ops per
-// look-up, a third of the scan loop's VALU work); the row offset rides in the ds_read's immediate.
-__device__ __forceinline__ float lut_gather(uint32_t w, int k, int m) {
-    uint32_t a;
-    switch (k) {   // constant after unrolling
-        case 0: asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(a) : "v"(w)); break;
-        case 1: asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(a) : "v"(w)); break;
-        case 2: asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(a) : "v"(w)); break;
-        default: asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(a) : "v"(w)); break;
-    }
-    return *reinterpret_cast<const __attribute__((address_space(3))) float*>((uintptr_t)(a + 1024u * (uint32_t)m));
-}
-
-// LUT entry e = tid + 256 * i goes to LDS with ds_write_addtid_b32: address = M0 + offset + 4 * lane, no address
-// VGPR, 2 LDS cycles per wave instruction instead of the 4 of ds_write_b32 (MI355X_MICROARCH.md, LDS table).
-// M0 = LDS address of the wave's 256-byte segment of table row 0 (lut_store_begin, once per LUT: an SALU write
-// of M0 needs a wait state before an LDS add-TID instruction and the hazard recogniser does not look inside
-// asm statements, hence the s_nop); row i rides in the 16-bit offset field, 1024 * i, i <= 63.  The stores are
-// invisible to the compiler's wait counters, hence the explicit wait before the barrier (lut_store_done).
-// Nothing else in these kernels touches M0 (no LDS-DMA, no movrel): check `grep m0` on the disassembly when
-// the toolchain changes.
-__device__ __forceinline__ void lut_store_begin(uint32_t m0_base) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(m0_base) : "memory");
-}
-template <int MT, int I>
-__device__ __forceinline__ void lut_store_one(float v) {
-    if constexpr (MT >= 64) {   // a 64 KB LUT reaches past the 16 bits of M0 / the offset field
-        extern __shared__ float s_lut_plain[];
-        s_lut_plain[threadIdx.x + 256 * I] = v;
-    } else {
-        asm volatile("ds_write_addtid_b32 %0 offset:%1" : : "v"(v), "n"(1024 * I) : "memory");
-    }
-}
-// rows 0 .. MT-1 of one LUT: f(i) is the entry of row i for this thread
-template <int MT, typename F, int... I>
-__device__ __forceinline__ void lut_store_rows(F&& f, std::integer_sequence<int, I...>) {
-    (lut_store_one<MT, I>(f(I)), ...);
-}
-__device__ __forceinline__ void lut_store_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // amdgpu_num_sgpr(96): 8 waves per SIMD need <= 96 SGPRs each (800 per SIMD); the FILT variant
 // would otherwise take 100 and lose one of the eight resident workgroups per CU
@@ -1193,7 +1146,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
         __syncthreads();
         const int n = s_nstage;
         const int64_t slice = (int64_t)q * pg_cnt + pg;
-        if (threadIdx.x == 0) sb.gcnt[slice] = n;
+        if (threadIdx.x == 0) sb.gcnt[(int64_t)q * sb.cnt_stride + pg] = n;
         for (int i = threadIdx.x; i < min(n, SCAN_STAGE); i += 256) sb.surv[slice * SCAN_SLICE + i] = s_stage[i];
     };
     const int p_begin = pg * G, p_end = min(P, p_begin + G);
@@ -1212,7 +1165,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
             if (l >= 0 && l < nlist && (!list_mask || list_mask[l]) && list_len[l] > 0) any = true;
         }
         if (!any) {   // uniform
-            if (FILT && threadIdx.x == 0) sb.gcnt[(int64_t)q * pg_cnt + pg] = 0;
+            if (FILT && threadIdx.x == 0) sb.gcnt[(int64_t)q * sb.cnt_stride + pg] = 0;
             return;
         }
     }
@@ -1588,7 +1541,7 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
         const int64_t nq8 = (nq + 7) / 8, nb = (nq8 + SCAN_BATCH - 1) / SCAN_BATCH;
         grid.x = (unsigned)(8 * (SCAN_BATCH + nb * SCAN_BATCH * pg_cnt));
     }
-    ScanBound sb = {nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr};
+    ScanBound sb = {nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr};
     if (bound) sb = *bound;
     if (rq_list) {   // repair launch: a fixed grid loops over the flagged (query, group) items
         if (bound || pqc_fused) abort();

@@ -114,6 +114,10 @@ int gamma_hip_set_workspace_budget(gamma_hip_index* h, int64_t bytes);
  * nprobe <= 64 on <= 4096 lists for the coarse cut, recall_num <= 256 and nprobe <= 256 otherwise; other shapes
  * and the sharded search keep the (distance, position) order. */
 int gamma_hip_set_exact_ties(gamma_hip_index* h, int on);
+/* Experimental scan schedule for large batches (csrc/scan_lm.hip): the probes behind a query's first group are
+ * scored list-major, two queries per pass over a list.  Same results; slower than the default at C3-sized
+ * lists, off by default.  Covers nsubvector 16, >= 2048 queries per call, no per-request filters. */
+int gamma_hip_set_list_major(gamma_hip_index* h, int on);
 /* out3 = {coarse rows redone, queries whose recall_num cut went through a tie, queries replayed} since creation
  * or the last reset; meaningful with exact ties on */
 int gamma_hip_tie_stats(gamma_hip_index* h, int64_t* out3, int reset);
