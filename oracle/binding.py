@@ -370,6 +370,9 @@ def ref():
         R.ref_ivfpq_get_list.argtypes = [C.c_void_p, C.c_int64, _i64p, _u8p]
         R.ref_ivfpq_search.argtypes = [C.c_void_p, C.c_int64, _f32p, C.c_int64, C.c_int, _f32p,
                                        _i64p]
+        if hasattr(R, "ref_ivfpq_search_rerank"):   # a prebuilt oracle/_ref from before this entry point: bench skips it
+            R.ref_ivfpq_search_rerank.argtypes = [C.c_void_p, C.c_int64, _f32p, C.c_int, C.c_int, C.c_int, _f32p,
+                                                  _f32p, _i64p]
         R.ref_ivfpq_coarse.argtypes = [C.c_void_p, C.c_int64, _f32p, C.c_int, _f32p, _i64p]
         R.ref_ivfpq_search_preassigned.argtypes = [C.c_void_p, C.c_int64, _f32p, C.c_int64, C.c_int,
                                                    _i64p, _f32p, _f32p, _i64p]
@@ -435,6 +438,15 @@ class RefIVFPQ:
         D = np.empty((x.shape[0], k), dtype=np.float32)
         I = np.empty((x.shape[0], k), dtype=np.int64)
         self.R.ref_ivfpq_search(self.h, x.shape[0], _fp(x), k, nprobe, _fp(D), _ip(I))
+        return D, I
+
+    def search_rerank(self, x, k, recall_num, nprobe, raw):
+        """GammaIVFPQIndex::Search with has_rank on the real library (ref_driver.cpp)"""
+        x = _f32(x)
+        raw = _f32(raw)
+        D = np.empty((x.shape[0], k), dtype=np.float32)
+        I = np.empty((x.shape[0], k), dtype=np.int64)
+        self.R.ref_ivfpq_search_rerank(self.h, x.shape[0], _fp(x), k, recall_num, nprobe, _fp(raw), _fp(D), _ip(I))
         return D, I
 
     def coarse(self, x, nprobe):

@@ -10,6 +10,7 @@
 #include "gamma_oracle.h"
 
 #include <float.h>
+#include <immintrin.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -305,7 +306,7 @@ void go_heap_pop_push_stream(int ks, size_t k, size_t n, const float* vals, cons
  * mode 0 = exhaustive_L2sqr_seq (:130-155); mode 1 = exhaustive_L2sqr_blas (:215-296)
  * with sgemm_ restated as a k-sequential single-accumulator fmaf chain.
  * =================================================================================== */
-static float dot_seq(const float* x, const float* y, size_t d) {
+__attribute__((unused)) static float dot_seq(const float* x, const float* y, size_t d) {
     float ip = 0.f;
     for (size_t t = 0; t < d; t++) ip = fmaf(x[t], y[t], ip);
     return ip;
@@ -314,10 +315,23 @@ static float dot_seq(const float* x, const float* y, size_t d) {
 void go_knn_L2sqr(int mode, const float* x, const float* y, size_t d, size_t nx, size_t ny,
                   size_t k, float* D, int64_t* I) {
     float* yn = NULL;
+    float* yT = NULL; /* mode 1: centroids in blocks of 8, transposed: yT[b][t][8] */
+    const size_t nb = (ny + 7) / 8;
     if (mode == 1) {
         yn = (float*)malloc(sizeof(float) * (ny ? ny : 1));
 #pragma omp parallel for
         for (int64_t j = 0; j < (int64_t)ny; j++) yn[j] = go_fvec_norm_L2sqr(y + j * d, d);
+        /* The GEMM form's inner product is ONE k-ascending fmaf chain per (query, centroid) -- what an
+         * fp32 MFMA computes and the stand-in for sgemm_.  Eight centroids run side by side in
+         * the eight AVX lanes, each lane its own chain: same bits as dot_seq, 8x fewer dependent steps. */
+        yT = (float*)aligned_alloc(32, sizeof(float) * 8 * d * (nb ? nb : 1));
+#pragma omp parallel for
+        for (int64_t b = 0; b < (int64_t)nb; b++)
+            for (size_t t = 0; t < d; t++)
+                for (int l = 0; l < 8; l++) {
+                    size_t j = (size_t)b * 8 + l;
+                    yT[((size_t)b * d + t) * 8 + l] = j < ny ? y[j * d + t] : 0.f;
+                }
     }
 #pragma omp parallel for schedule(dynamic)
     for (int64_t i = 0; i < (int64_t)nx; i++) {
@@ -325,21 +339,32 @@ void go_knn_L2sqr(int mode, const float* x, const float* y, size_t d, size_t nx,
         float* hd = D + i * k;
         int64_t* hi = I + i * k;
         go_heap_heapify(1, k, hd, hi);
-        float xn = mode == 1 ? go_fvec_norm_L2sqr(xi, d) : 0.f;
-        for (size_t j = 0; j < ny; j++) {
-            float dis;
-            if (mode == 0) {
-                dis = go_fvec_L2sqr(xi, y + j * d, d);
-            } else {
-                float ip = dot_seq(xi, y + j * d, d);
-                dis = (xn + yn[j]) - 2 * ip;
-                if (dis < 0) dis = 0;
+        if (mode == 0) {
+            for (size_t j = 0; j < ny; j++) {
+                float dis = go_fvec_L2sqr(xi, y + j * d, d);
+                if (hd[0] > dis) go_heap_replace_top(1, k, hd, hi, dis, (int64_t)j);
             }
-            if (hd[0] > dis) go_heap_replace_top(1, k, hd, hi, dis, (int64_t)j);
+        } else {
+            float xn = go_fvec_norm_L2sqr(xi, d);
+            for (size_t b = 0; b < nb; b++) {
+                const float* yb = yT + b * d * 8;
+                __m256 acc = _mm256_setzero_ps();
+                for (size_t t = 0; t < d; t++)
+                    acc = _mm256_fmadd_ps(_mm256_broadcast_ss(xi + t), _mm256_load_ps(yb + t * 8), acc);
+                float ip[8];
+                _mm256_storeu_ps(ip, acc);
+                for (int l = 0; l < 8 && b * 8 + l < ny; l++) {
+                    size_t j = b * 8 + l;
+                    float dis = (xn + yn[j]) - 2 * ip[l];
+                    if (dis < 0) dis = 0;
+                    if (hd[0] > dis) go_heap_replace_top(1, k, hd, hi, dis, (int64_t)j);
+                }
+            }
         }
         go_heap_reorder(1, k, hd, hi);
     }
     free(yn);
+    free(yT);
 }
 
 void go_knn_inner_product(const float* x, const float* y, size_t d, size_t nx, size_t ny,

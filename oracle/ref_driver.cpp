@@ -232,6 +232,50 @@ void ref_ivfpq_encode(void* h, int64_t n, const float* x, int64_t* list_nos,
     }
     r->index->pq.compute_codes(residuals.data(), codes, n);
 }
+// The whole search the way GammaIVFPQIndex::Search runs it (index/impl/gamma_index_ivfpq.cc:514-566,
+// 701-890), on the real library: coarse quantizer + list scan with recall_num results (faiss's own
+// IndexIVFPQ::search: the same quantizer->search + search_preassigned pair, OpenMP over queries), then
+// compute_dis with has_rank (:646-680): exact fvec_L2sqr / fvec_inner_product against the raw vectors and a
+// k-heap fed with heap_pop + heap_push, heap_reorder.  Used as the timed CPU baseline of bench.py
+// (cpu_baseline.kind = "reference"); the recall-stage candidates arrive sorted here instead of in heap-array
+// order, which changes nothing about the work done.
+void ref_ivfpq_search_rerank(void* h, int64_t nq, const float* x, int k, int recall_num, int nprobe,
+                             const float* raw, float* D, int64_t* I) {
+    RefIVFPQ* r = (RefIVFPQ*)h;
+    const int d = r->index->d;
+    const bool ip = r->index->metric_type == faiss::METRIC_INNER_PRODUCT;
+    r->index->nprobe = nprobe;
+    std::vector<float> rd((size_t)nq * recall_num);
+    std::vector<idx_t> ri((size_t)nq * recall_num);
+    r->index->search(nq, x, recall_num, rd.data(), ri.data());
+#pragma omp parallel for schedule(dynamic)
+    for (int64_t q = 0; q < nq; q++) {
+        float* simi = D + q * k;
+        idx_t* idxi = (idx_t*)I + q * k;
+        const float* xi = x + q * d;
+        if (ip) faiss::heap_heapify<faiss::CMin<float, idx_t>>(k, simi, idxi);
+        else faiss::heap_heapify<faiss::CMax<float, idx_t>>(k, simi, idxi);
+        for (int j = 0; j < recall_num; j++) {
+            const idx_t id = ri[q * recall_num + j];
+            if (id < 0) continue;
+            if (ip) {
+                const float dis = faiss::fvec_inner_product(xi, raw + id * d, d);
+                if (faiss::CMin<float, idx_t>::cmp(simi[0], dis)) {
+                    faiss::heap_pop<faiss::CMin<float, idx_t>>(k, simi, idxi);
+                    faiss::heap_push<faiss::CMin<float, idx_t>>(k, simi, idxi, dis, id);
+                }
+            } else {
+                const float dis = faiss::fvec_L2sqr(xi, raw + id * d, d);
+                if (faiss::CMax<float, idx_t>::cmp(simi[0], dis)) {
+                    faiss::heap_pop<faiss::CMax<float, idx_t>>(k, simi, idxi);
+                    faiss::heap_push<faiss::CMax<float, idx_t>>(k, simi, idxi, dis, id);
+                }
+            }
+        }
+        if (ip) faiss::heap_reorder<faiss::CMin<float, idx_t>>(k, simi, idxi);
+        else faiss::heap_reorder<faiss::CMax<float, idx_t>>(k, simi, idxi);
+    }
+}
 void ref_ivfpq_inner_prod_table(void* h, const float* x, float* table) {
     ((RefIVFPQ*)h)->index->pq.compute_inner_prod_table(x, table);
 }

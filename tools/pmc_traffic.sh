@@ -27,9 +27,15 @@ res = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     cal, ncal = per_dispatch("calib_" + c, "elementwise", c)
     res[c] = {"calib_counter_per_launch": cal, "calib_launches": ncal, "calib_true_bytes": 1 << 30}
-    for kern in ("k_ivfpq_scan_pair", "k_select_stream", "k_rerank_topk", "k_l2_gemmform_mfma", "k_pq_ip_table"):
+    # FETCH_SIZE / WRITE_SIZE are in KB.  Correction of MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE
+    # reports half of the bytes of a wide coalesced read -> x2; WRITE_SIZE as is.  The box's own calibration
+    # (a kernel that moves exactly 2^30 bytes each way) is kept next to it.
+    guide = 2.0 if c == "FETCH_SIZE" else 1.0
+    for kern in ("k_ivfpq_scan_pair<true, 16, true", "k_ivfpq_scan_pair<true, 16, false", "k_select_final", "k_rerank_topk",
+                 "k_l2_gemmform_strip", "k_pq_ip_table"):
         v, n = per_dispatch("bench_" + c, kern, c)
         res[c][kern] = {"counter_per_launch": v, "launches": n,
+                        "bytes_per_launch_guide": (v * 1024.0 * guide) if v is not None else None,
                         "bytes_per_launch_calibrated": (v * (1 << 30) / cal) if (v is not None and cal) else None}
 print(json.dumps(res, indent=1))
 PY
