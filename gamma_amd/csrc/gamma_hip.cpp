@@ -68,10 +68,35 @@ struct StageEvent {
 
 }  // namespace
 
+struct WriteLock;
+
 struct gamma_hip_index {
     int device = 0;
-    hipStream_t stream = nullptr;
-    std::mutex mu;
+    // Concurrency (SURVEY 8b "Threading": Search from any number of client threads while ONE indexing thread adds
+    // and API threads delete; the reference's lists are lock-free for readers, realtime_mem_data.cc:279-300):
+    //   stream / search_mu : searches.  One at a time (they share the workspaces); search_mu is held for a whole
+    //                        call, mu only while the call reads the handle's state and enqueues its kernels.
+    //   wstream / writer_mu: writers (list appends, encode, raw / bitmap / column updates) on their own stream, so
+    //                        they neither wait for the searches in flight nor hold them up; mu while they work.
+    //   list meta versions : a search's kernels read the (offset, length) table of the VERSION that was current
+    //                        when it was enqueued; a writer publishes a new version after its copies (the
+    //                        reference publishes retrieve_idx_pos_ after the copy, realtime_mem_data.cc:299-300).
+    //                        Old extents stay intact inside the arena, so a search in flight keeps reading a
+    //                        consistent prefix of the insert log.
+    //   reallocation       : growing the arena / raw store / bitmap frees memory a search in flight may read --
+    //                        the writer then takes search_mu too and drains both streams first (WriteLock::exclusive).
+    // Lock order: writer_mu -> search_mu -> mu.
+    hipStream_t stream = nullptr, wstream = nullptr;
+    std::mutex mu, search_mu, writer_mu;
+    WriteLock* wl = nullptr;   // the writer holding mu (for exclusive() deep inside the arena code)
+    static constexpr int NVER = 4;
+    int64_t* d_ver_off[NVER] = {nullptr, nullptr, nullptr, nullptr};
+    int* d_ver_len[NVER] = {nullptr, nullptr, nullptr, nullptr};
+    void* pin_ver[NVER] = {nullptr, nullptr, nullptr, nullptr};   // pinned staging of a version's tables
+    hipEvent_t ver_ev[NVER] = {nullptr, nullptr, nullptr, nullptr};   // wstream: the version's tables are in place
+    hipEvent_t rd_ev[NVER] = {nullptr, nullptr, nullptr, nullptr};    // stream: the last search reading it is past its list kernels
+    bool rd_set[NVER] = {false, false, false, false};
+    int cur_ver = 0;
     std::string err;
 
     // raw vector store
@@ -125,7 +150,8 @@ struct gamma_hip_index {
     DevBuf w_mat, w_coarse_dis, w_probe, w_xn, w_st2, w_pair_off, w_qtotal, w_dist, w_cand_dis,
             w_cand_pos, w_cand_ids, w_exact, w_selv, w_selp, w_x, w_outd, w_outl, w_stage, w_filter,
             w_m_dis, w_m_ids, w_part_v, w_part_i, w_assign, w_codes_tmp, w_qperm, w_scnt, w_sflag, w_surv, w_pair_base,
-            w_pair_ip, w_flat_cand, w_flat_meta, w_full_cdis, w_full_probe, w_ftab, w_qfil, w_tieflag, w_tcut, w_tlist, w_survc, w_lm_units, w_lm_cnt;
+            w_pair_ip, w_flat_cand, w_flat_meta, w_full_cdis, w_full_probe, w_ftab, w_qfil, w_tieflag, w_tcut, w_tlist, w_survc, w_lm_units, w_lm_cnt,
+            we_mat, we_cdis, we_x, we_assign, we_codes, we_stage;   // writer side (encode, bitmap_set): never shared with a search
     unsigned long long* d_scan_codes = nullptr;
     size_t dist_budget_bytes = (size_t)8 << 30;   // per-chunk ADC distance buffer (288 GB of HBM per GPU)
 
@@ -180,9 +206,37 @@ struct gamma_hip_index {
     int64_t scan_pairs = 0;
 };
 
+// a writer call: writer_mu (one writer at a time) + mu; exclusive() before memory that a search in flight may be
+// reading is freed or moved: search_mu as well (no search can start), both streams drained
+struct WriteLock {
+    gamma_hip_index* h;
+    std::unique_lock<std::mutex> w, s, m;
+    explicit WriteLock(gamma_hip_index* h_) : h(h_), w(h_->writer_mu), s(h_->search_mu, std::defer_lock), m(h_->mu) { h->wl = this; }
+    ~WriteLock() { h->wl = nullptr; }
+    hipError_t exclusive() {
+        if (!s.owns_lock()) {
+            m.unlock();
+            s.lock();
+            m.lock();
+        }
+        hipError_t e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->wstream);
+        return e;
+    }
+};
+
 namespace {
 
 using H = gamma_hip_index;
+
+// a search-type call: search_mu for the whole call, mu while it reads the handle and enqueues
+struct SearchLock {
+    std::unique_lock<std::mutex> s, m;
+    explicit SearchLock(H* h) : s(h->search_mu), m(h->mu) {}
+    void enqueued() {   // everything is on the stream: writers may go on while the call waits for the GPU
+        if (m.owns_lock()) m.unlock();
+    }
+};
 
 #define GH_CHECK(h, expr)                                                                  \
     do {                                                                                   \
@@ -257,6 +311,31 @@ int drain_events(H* h) {
 
 double extend_coefficient(uint8_t t) { return 1.1 + kPI / 2 - atan((double)t); }
 
+// A new version of the lists' (offset, length) tables: what the host mirror holds, copied through the
+// version's pinned staging on the writer stream -- behind the data copies of the writer that calls this, so a
+// search that uses the version finds the entries in place (publish after write, realtime_mem_data.cc:299-300).
+// The slot that is overwritten was current NVER - 1 versions ago; the last search that read it is awaited first.
+int publish_meta(H* h) {
+    const int v = (h->cur_ver + 1) % H::NVER;
+    if (h->rd_set[v]) GH_CHECK(h, hipStreamWaitEvent(h->wstream, h->rd_ev[v], 0));
+    // the staging itself: free once the copies of the version's previous use are done (the writer stream is
+    // drained at the end of every writer call, so they are)
+    int64_t* po = reinterpret_cast<int64_t*>(h->pin_ver[v]);
+    int* pl = reinterpret_cast<int*>(po + h->nlist);
+    memcpy(po, h->h_list_off.data(), (size_t)h->nlist * sizeof(int64_t));
+    memcpy(pl, h->h_list_len.data(), (size_t)h->nlist * sizeof(int));
+    GH_CHECK(h, hipMemcpyAsync(h->d_ver_off[v], po, (size_t)h->nlist * sizeof(int64_t), hipMemcpyHostToDevice, h->wstream));
+    GH_CHECK(h, hipMemcpyAsync(h->d_ver_len[v], pl, (size_t)h->nlist * sizeof(int), hipMemcpyHostToDevice, h->wstream));
+    GH_CHECK(h, hipEventRecord(h->ver_ev[v], h->wstream));
+    h->cur_ver = v;
+    h->d_list_off = h->d_ver_off[v];
+    h->d_list_len = h->d_ver_len[v];
+    int mx = 0;
+    for (int l = 0; l < h->nlist; l++) mx = std::max(mx, h->h_list_len[l]);
+    h->max_list_len = mx;
+    return GAMMA_HIP_OK;
+}
+
 // ---- arena ---------------------------------------------------------------------------
 int arena_reserve(H* h, int64_t need_entries) {
     if (h->arena_used + need_entries <= h->arena_cap) return GAMMA_HIP_OK;
@@ -264,15 +343,16 @@ int arena_reserve(H* h, int64_t need_entries) {
     ncap += ncap / 8;
     uint8_t* nc = nullptr;
     int64_t* ni = nullptr;
+    if (h->wl) GH_CHECK(h, h->wl->exclusive());   // the old arrays are freed below: no search may be reading them
     GH_CHECK(h, hipMalloc((void**)&nc, (size_t)ncap * h->code_size));
     GH_CHECK(h, hipMalloc((void**)&ni, (size_t)ncap * sizeof(int64_t)));
     if (h->arena_used > 0) {
         GH_CHECK(h, hipMemcpyAsync(nc, h->d_codes, (size_t)h->arena_used * h->code_size,
-                                   hipMemcpyDeviceToDevice, h->stream));
+                                   hipMemcpyDeviceToDevice, h->wstream));
         GH_CHECK(h, hipMemcpyAsync(ni, h->d_ids, (size_t)h->arena_used * sizeof(int64_t),
-                                   hipMemcpyDeviceToDevice, h->stream));
+                                   hipMemcpyDeviceToDevice, h->wstream));
     }
-    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
     if (h->d_codes) GH_CHECK(h, hipFree(h->d_codes));
     if (h->d_ids) GH_CHECK(h, hipFree(h->d_ids));
     h->d_codes = nc;
@@ -295,17 +375,18 @@ int arena_repack(H* h) {
     const int64_t ncap = total + total / 8 + 1024;
     uint8_t* nc = nullptr;
     int64_t* ni = nullptr;
+    if (h->wl) GH_CHECK(h, h->wl->exclusive());   // every list moves and the old arrays are freed
+    GH_TRY(publish_meta(h));                      // the device tables the kernel below reads = the host mirror
     GH_CHECK(h, hipMalloc((void**)&nc, (size_t)ncap * h->code_size));
     if (hipMalloc((void**)&ni, (size_t)ncap * sizeof(int64_t)) != hipSuccess) {
         (void)hipFree(nc);
         return fail(h, GAMMA_HIP_ENOMEM, "arena repack: out of memory");
     }
-    GH_CHECK(h, h->w_stage.ensure((size_t)h->nlist * sizeof(int64_t)));
-    GH_CHECK(h, hipMemcpyAsync(h->w_stage.p, noff.data(), (size_t)h->nlist * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
-    gh::launch_repack_lists(h->stream, h->d_codes, h->d_ids, nc, ni, h->d_list_off, h->w_stage.as<int64_t>(),
+    GH_CHECK(h, h->we_stage.ensure((size_t)h->nlist * sizeof(int64_t)));
+    GH_CHECK(h, hipMemcpyAsync(h->we_stage.p, noff.data(), (size_t)h->nlist * sizeof(int64_t), hipMemcpyHostToDevice, h->wstream));
+    gh::launch_repack_lists(h->wstream, h->d_codes, h->d_ids, nc, ni, h->d_list_off, h->we_stage.as<int64_t>(),
                             h->d_list_len, h->nlist, h->code_size, h->max_list_len);
-    GH_CHECK(h, hipMemcpyAsync(h->d_list_off, noff.data(), (size_t)h->nlist * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
-    GH_CHECK(h, hipStreamSynchronize(h->stream));   // noff is a local; the old arrays are free to go
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));   // noff is a local; the old arrays are free to go
     GH_CHECK(h, hipFree(h->d_codes));
     GH_CHECK(h, hipFree(h->d_ids));
     h->d_codes = nc;
@@ -315,7 +396,7 @@ int arena_repack(H* h) {
     h->arena_waste = 0;
     h->h_list_off = noff;
     h->n_repacks++;
-    return GAMMA_HIP_OK;
+    return publish_meta(h);
 }
 int arena_repack_if_need(H* h) {
     const int64_t min_waste = std::max<int64_t>(h->repack_min_entries, 1);
@@ -341,23 +422,14 @@ int list_ensure(H* h, int l, int add) {
     if (len > 0) {
         GH_CHECK(h, hipMemcpyAsync(h->d_codes + noff * h->code_size,
                                    h->d_codes + h->h_list_off[l] * h->code_size,
-                                   (size_t)len * h->code_size, hipMemcpyDeviceToDevice, h->stream));
+                                   (size_t)len * h->code_size, hipMemcpyDeviceToDevice, h->wstream));
         GH_CHECK(h, hipMemcpyAsync(h->d_ids + noff, h->d_ids + h->h_list_off[l],
-                                   (size_t)len * sizeof(int64_t), hipMemcpyDeviceToDevice, h->stream));
+                                   (size_t)len * sizeof(int64_t), hipMemcpyDeviceToDevice, h->wstream));
     }
     h->arena_waste += cap;
     h->arena_used += ext;
-    h->h_list_off[l] = noff;
+    h->h_list_off[l] = noff;   // the old extent stays intact: searches in flight read it through their version
     h->h_list_cap[l] = ext;
-    GH_CHECK(h, hipMemcpyAsync(h->d_list_off + l, &h->h_list_off[l], sizeof(int64_t),
-                               hipMemcpyHostToDevice, h->stream));
-    return GAMMA_HIP_OK;
-}
-
-int publish_len(H* h, int l) {
-    GH_CHECK(h, hipMemcpyAsync(h->d_list_len + l, &h->h_list_len[l], sizeof(int), hipMemcpyHostToDevice,
-                               h->stream));
-    if (h->h_list_len[l] > h->max_list_len) h->max_list_len = h->h_list_len[l];
     return GAMMA_HIP_OK;
 }
 
@@ -367,11 +439,9 @@ int add_keys_locked(H* h, int l, int n, const int64_t* vids, const uint8_t* code
     GH_TRY(list_ensure(h, l, n));
     const int64_t pos = h->h_list_off[l] + h->h_list_len[l];
     GH_CHECK(h, hipMemcpyAsync(h->d_ids + pos, vids, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice,
-                               h->stream));
+                               h->wstream));
     GH_CHECK(h, hipMemcpyAsync(h->d_codes + pos * h->code_size, codes, (size_t)n * h->code_size,
-                               hipMemcpyHostToDevice, h->stream));
-    // the host buffers may be reused by the caller as soon as we return
-    GH_CHECK(h, hipStreamSynchronize(h->stream));
+                               hipMemcpyHostToDevice, h->wstream));
     for (int i = 0; i < n; i++) {
         const int64_t v = vids[i];
         if (v < 0) {   // superseded slot restored from a dump (ReadInvertedLists, gamma_index_io.cc:186-189)
@@ -386,7 +456,9 @@ int add_keys_locked(H* h, int l, int n, const int64_t* vids, const uint8_t* code
     }
     h->h_list_len[l] += n;  // publish after the copies (realtime_mem_data.cc:299-300)
     h->ntotal += n;
-    GH_TRY(publish_len(h, l));
+    GH_TRY(publish_meta(h));
+    // the host buffers may be reused by the caller as soon as we return
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
     return arena_repack_if_need(h);
 }
 
@@ -572,6 +644,10 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     const int P = p->nprobe, d = h->d, M = h->M, nlist = h->nlist;
     const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
     hipStream_t s = h->stream;
+    // this call reads the lists through the version of their (offset, length) tables that is current now:
+    // behind the writer's copies (ver_ev), and the version is not reused before the kernels below are done (rd_ev)
+    const int ver = h->cur_ver;
+    GH_CHECK(h, hipStreamWaitEvent(s, h->ver_ev[ver], 0));
     GH_CHECK(h, h->w_coarse_dis.ensure((size_t)nq * P * sizeof(float)));
     GH_CHECK(h, h->w_probe.ensure((size_t)nq * P * sizeof(int)));
     GH_CHECK(h, h->w_pair_off.ensure((size_t)nq * (P + 1) * sizeof(int)));
@@ -836,6 +912,8 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     }
     h->tie.G = G;
     h->tie.q_stride = q_stride;
+    GH_CHECK(h, hipEventRecord(h->rd_ev[ver], s));
+    h->rd_set[ver] = true;
     GH_CHECK(h, hipGetLastError());
     return GAMMA_HIP_OK;
 }
@@ -1110,9 +1188,11 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
 
 // host-pointer wrapper shared by ivfpq / flat
 // sync = false: everything is only enqueued (pinned host buffers); the caller synchronises the stream
+// lk != nullptr: the caller's SearchLock; its mu is released once everything is enqueued, so writers go on while
+// this call waits for the GPU (search_mu stays: the workspaces are in use)
 template <typename F>
 int host_search(H* h, int nq, int d, const float* x, int k, float* distances, int64_t* labels, F&& f,
-                bool sync = true) {
+                bool sync = true, SearchLock* lk = nullptr) {
     if (nq <= 0 || k <= 0) return f(nullptr, nullptr, nullptr);
     GH_CHECK(h, hipSetDevice(h->device));
     GH_CHECK(h, h->w_x.ensure((size_t)nq * d * sizeof(float)));
@@ -1122,6 +1202,7 @@ int host_search(H* h, int nq, int d, const float* x, int k, float* distances, in
     GH_TRY(f(h->w_x.as<float>(), h->w_outd.as<float>(), h->w_outl.as<int64_t>()));
     GH_CHECK(h, hipMemcpyAsync(distances, h->w_outd.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     GH_CHECK(h, hipMemcpyAsync(labels, h->w_outl.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    if (lk) lk->enqueued();
     if (sync) GH_CHECK(h, hipStreamSynchronize(h->stream));
     return GAMMA_HIP_OK;
 }
@@ -1155,10 +1236,17 @@ int gamma_hip_create(int device, gamma_hip_index** out) {
     H* h = new (std::nothrow) H();
     if (!h) return GAMMA_HIP_ENOMEM;
     h->device = device;
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->wstream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return GAMMA_HIP_EDEVICE;
     }
+    for (int v = 0; v < H::NVER; v++)
+        if (hipEventCreateWithFlags(&h->ver_ev[v], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->rd_ev[v], hipEventDisableTiming) != hipSuccess) {
+            delete h;
+            return GAMMA_HIP_EDEVICE;
+        }
     if (hipMalloc((void**)&h->d_scan_codes, sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(h->d_scan_codes, 0, sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void**)&h->d_tie_stats, 3 * sizeof(unsigned long long)) != hipSuccess ||
@@ -1186,12 +1274,20 @@ int gamma_hip_destroy(gamma_hip_index* h) {
     if (h->comb_thread.joinable()) h->comb_thread.join();
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    (void)hipStreamSynchronize(h->wstream);
+    for (int v = 0; v < H::NVER; v++) {
+        if (h->ver_ev[v]) (void)hipEventDestroy(h->ver_ev[v]);
+        if (h->rd_ev[v]) (void)hipEventDestroy(h->rd_ev[v]);
+        if (h->d_ver_off[v]) (void)hipFree(h->d_ver_off[v]);
+        if (h->d_ver_len[v]) (void)hipFree(h->d_ver_len[v]);
+        if (h->pin_ver[v]) (void)hipHostFree(h->pin_ver[v]);
+    }
     for (auto& e : h->events) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
     }
     void* ptrs[] = {h->d_list_rank, h->d_raw, h->d_bitmap, h->d_cc, h->d_cc_norms, h->d_pqc, h->d_T2, h->d_codes,
-                    h->d_ids, h->d_list_off, h->d_list_len, h->d_list_mask, h->d_scan_codes, h->d_tie_stats};
+                    h->d_ids, h->d_list_mask, h->d_scan_codes, h->d_tie_stats};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& kv : h->fields)
@@ -1205,9 +1301,11 @@ int gamma_hip_destroy(gamma_hip_index* h) {
                       &h->w_filter, &h->w_m_dis, &h->w_m_ids, &h->w_part_v, &h->w_part_i, &h->w_assign,
                       &h->w_codes_tmp, &h->w_qperm, &h->w_scnt, &h->w_sflag, &h->w_surv, &h->w_pair_base,
                       &h->w_pair_ip, &h->w_flat_cand, &h->w_flat_meta, &h->w_full_cdis,
-                      &h->w_full_probe, &h->w_ftab, &h->w_qfil, &h->w_tieflag, &h->w_tcut, &h->w_tlist, &h->w_survc, &h->w_lm_units, &h->w_lm_cnt};
+                      &h->w_full_probe, &h->w_ftab, &h->w_qfil, &h->w_tieflag, &h->w_tcut, &h->w_tlist, &h->w_survc, &h->w_lm_units, &h->w_lm_cnt,
+                      &h->we_mat, &h->we_cdis, &h->we_x, &h->we_assign, &h->we_codes, &h->we_stage};
     for (DevBuf* b : bufs) b->release();
     (void)hipStreamDestroy(h->stream);
+    (void)hipStreamDestroy(h->wstream);
     delete h;
     return GAMMA_HIP_OK;
 }
@@ -1217,9 +1315,10 @@ void* gamma_hip_stream(gamma_hip_index* h) { return h ? (void*)h->stream : nullp
 
 int gamma_hip_synchronize(gamma_hip_index* h) {
     if (!h) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    SearchLock lk(h);
     GH_CHECK(h, hipSetDevice(h->device));
     GH_CHECK(h, hipStreamSynchronize(h->stream));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
     return GAMMA_HIP_OK;
 }
 
@@ -1232,21 +1331,21 @@ size_t field_elem_size(int dtype) {
 
 int gamma_hip_set_exact_ties(gamma_hip_index* h, int on) {
     if (!h) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    SearchLock lk(h);
     h->exact_ties = on != 0;
     return GAMMA_HIP_OK;
 }
 
 int gamma_hip_set_list_major(gamma_hip_index* h, int on) {
     if (!h) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    SearchLock lk(h);
     h->list_major = on != 0;
     return GAMMA_HIP_OK;
 }
 
 int gamma_hip_tie_stats(gamma_hip_index* h, int64_t* out3, int reset) {
     if (!h || !out3) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    SearchLock lk(h);
     GH_CHECK(h, hipSetDevice(h->device));
     GH_CHECK(h, hipStreamSynchronize(h->stream));
     unsigned long long v[3];
@@ -1258,14 +1357,14 @@ int gamma_hip_tie_stats(gamma_hip_index* h, int64_t* out3, int reset) {
 
 int gamma_hip_set_workspace_budget(gamma_hip_index* h, int64_t bytes) {
     if (!h || bytes <= 0) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    SearchLock lk(h);
     h->dist_budget_bytes = (size_t)bytes;
     return GAMMA_HIP_OK;
 }
 
 int gamma_hip_field_append(gamma_hip_index* h, int field_id, int dtype, int64_t n, const void* values) {
     if (!h) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    WriteLock lk(h);
     if (dtype < GAMMA_HIP_FIELD_INT || dtype > GAMMA_HIP_FIELD_DOUBLE || n < 0 || (n > 0 && !values))
         return fail(h, GAMMA_HIP_EINVAL, "bad column append");
     GH_CHECK(h, hipSetDevice(h->device));
@@ -1276,16 +1375,17 @@ int gamma_hip_field_append(gamma_hip_index* h, int field_id, int dtype, int64_t 
     if (c.n + n > c.cap) {
         const int64_t ncap = std::max<int64_t>(c.n + n, std::max<int64_t>(1 << 16, c.cap * 2));
         uint8_t* nd = nullptr;
+        GH_CHECK(h, lk.exclusive());   // the old column is freed below
         GH_CHECK(h, hipMalloc((void**)&nd, (size_t)ncap * es));
-        if (c.n) GH_CHECK(h, hipMemcpyAsync(nd, c.d, (size_t)c.n * es, hipMemcpyDeviceToDevice, h->stream));
-        GH_CHECK(h, hipStreamSynchronize(h->stream));
+        if (c.n) GH_CHECK(h, hipMemcpyAsync(nd, c.d, (size_t)c.n * es, hipMemcpyDeviceToDevice, h->wstream));
+        GH_CHECK(h, hipStreamSynchronize(h->wstream));
         if (c.d) (void)hipFree(c.d);
         c.d = nd;
         c.cap = ncap;
     }
     if (n) {
-        GH_CHECK(h, hipMemcpyAsync(c.d + (size_t)c.n * es, values, (size_t)n * es, hipMemcpyHostToDevice, h->stream));
-        GH_CHECK(h, hipStreamSynchronize(h->stream));
+        GH_CHECK(h, hipMemcpyAsync(c.d + (size_t)c.n * es, values, (size_t)n * es, hipMemcpyHostToDevice, h->wstream));
+        GH_CHECK(h, hipStreamSynchronize(h->wstream));
     }
     c.n += n;
     return GAMMA_HIP_OK;
@@ -1293,13 +1393,13 @@ int gamma_hip_field_append(gamma_hip_index* h, int field_id, int dtype, int64_t 
 
 int gamma_hip_field_update(gamma_hip_index* h, int field_id, int64_t docid, const void* value) {
     if (!h || !value) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    WriteLock lk(h);
     auto it = h->fields.find(field_id);
     if (it == h->fields.end() || docid < 0 || docid >= it->second.n) return fail(h, GAMMA_HIP_EINVAL, "bad column update");
     GH_CHECK(h, hipSetDevice(h->device));
     const size_t es = field_elem_size(it->second.dtype);
-    GH_CHECK(h, hipMemcpyAsync(it->second.d + (size_t)docid * es, value, es, hipMemcpyHostToDevice, h->stream));
-    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    GH_CHECK(h, hipMemcpyAsync(it->second.d + (size_t)docid * es, value, es, hipMemcpyHostToDevice, h->wstream));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
     return GAMMA_HIP_OK;
 }
 
@@ -1312,7 +1412,7 @@ int64_t gamma_hip_field_count(gamma_hip_index* h, int field_id) {
 
 int gamma_hip_raw_init(gamma_hip_index* h, int d) {
     if (!h || d <= 0) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    WriteLock lk(h);
     if (h->raw_d != 0 && h->raw_d != d) return fail(h, GAMMA_HIP_EINVAL, "raw store dimension mismatch");
     h->raw_d = d;
     return GAMMA_HIP_OK;
@@ -1323,11 +1423,12 @@ static int raw_reserve(H* h, int64_t need) {
     int64_t ncap = std::max<int64_t>(need, h->raw_cap + h->raw_cap / 2);
     ncap = std::max<int64_t>(ncap, 1024);
     float* np = nullptr;
+    if (h->wl) GH_CHECK(h, h->wl->exclusive());   // the old store is freed below
     GH_CHECK(h, hipMalloc((void**)&np, (size_t)ncap * h->raw_d * sizeof(float)));
     if (h->nraw > 0)
         GH_CHECK(h, hipMemcpyAsync(np, h->d_raw, (size_t)h->nraw * h->raw_d * sizeof(float),
-                                   hipMemcpyDeviceToDevice, h->stream));
-    GH_CHECK(h, hipStreamSynchronize(h->stream));
+                                   hipMemcpyDeviceToDevice, h->wstream));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
     if (h->d_raw) GH_CHECK(h, hipFree(h->d_raw));
     h->d_raw = np;
     h->raw_cap = ncap;
@@ -1336,41 +1437,41 @@ static int raw_reserve(H* h, int64_t need) {
 
 int gamma_hip_raw_append(gamma_hip_index* h, int64_t n, const float* vecs) {
     if (!h || n < 0 || (n > 0 && !vecs)) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    WriteLock lk(h);
     if (h->raw_d <= 0) return fail(h, GAMMA_HIP_EINVAL, "raw store not initialised");
     if (n == 0) return GAMMA_HIP_OK;
     GH_CHECK(h, hipSetDevice(h->device));
     GH_TRY(raw_reserve(h, h->nraw + n));
     GH_CHECK(h, hipMemcpyAsync(h->d_raw + h->nraw * h->raw_d, vecs, (size_t)n * h->raw_d * sizeof(float),
-                               hipMemcpyHostToDevice, h->stream));
-    GH_CHECK(h, hipStreamSynchronize(h->stream));
+                               hipMemcpyHostToDevice, h->wstream));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
     h->nraw += n;
     return GAMMA_HIP_OK;
 }
 
 int gamma_hip_raw_write(gamma_hip_index* h, int64_t first_vid, int64_t n, const float* vecs) {
     if (!h || n < 0 || first_vid < 0 || (n > 0 && !vecs)) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    WriteLock lk(h);
     if (h->raw_d <= 0) return fail(h, GAMMA_HIP_EINVAL, "raw store not initialised");
     if (first_vid > h->nraw) return fail(h, GAMMA_HIP_EINVAL, "raw write would leave a gap");
     if (n == 0) return GAMMA_HIP_OK;
     GH_CHECK(h, hipSetDevice(h->device));
     GH_TRY(raw_reserve(h, first_vid + n));
     GH_CHECK(h, hipMemcpyAsync(h->d_raw + first_vid * h->raw_d, vecs, (size_t)n * h->raw_d * sizeof(float),
-                               hipMemcpyHostToDevice, h->stream));
-    GH_CHECK(h, hipStreamSynchronize(h->stream));
+                               hipMemcpyHostToDevice, h->wstream));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
     h->nraw = std::max(h->nraw, first_vid + n);
     return GAMMA_HIP_OK;
 }
 
 int gamma_hip_raw_update(gamma_hip_index* h, int64_t vid, const float* vec) {
     if (!h || !vec) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    WriteLock lk(h);
     if (vid < 0 || vid >= h->nraw) return fail(h, GAMMA_HIP_EINVAL, "vid out of range");
     GH_CHECK(h, hipSetDevice(h->device));
     GH_CHECK(h, hipMemcpyAsync(h->d_raw + vid * h->raw_d, vec, (size_t)h->raw_d * sizeof(float),
-                               hipMemcpyHostToDevice, h->stream));
-    GH_CHECK(h, hipStreamSynchronize(h->stream));
+                               hipMemcpyHostToDevice, h->wstream));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
     return GAMMA_HIP_OK;
 }
 
@@ -1382,11 +1483,12 @@ static int bitmap_reserve(H* h, int64_t nbits) {
     if (bytes <= h->bitmap_cap_bytes) return GAMMA_HIP_OK;
     size_t ncap = std::max(bytes, h->bitmap_cap_bytes * 2);
     uint8_t* np = nullptr;
+    if (h->wl) GH_CHECK(h, h->wl->exclusive());   // the old bitmap is freed below
     GH_CHECK(h, hipMalloc((void**)&np, ncap));
-    GH_CHECK(h, hipMemsetAsync(np, 0, ncap, h->stream));
+    GH_CHECK(h, hipMemsetAsync(np, 0, ncap, h->wstream));
     if (h->d_bitmap)
-        GH_CHECK(h, hipMemcpyAsync(np, h->d_bitmap, h->bitmap_cap_bytes, hipMemcpyDeviceToDevice, h->stream));
-    GH_CHECK(h, hipStreamSynchronize(h->stream));
+        GH_CHECK(h, hipMemcpyAsync(np, h->d_bitmap, h->bitmap_cap_bytes, hipMemcpyDeviceToDevice, h->wstream));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
     if (h->d_bitmap) GH_CHECK(h, hipFree(h->d_bitmap));
     h->d_bitmap = np;
     h->bitmap_cap_bytes = ncap;
@@ -1396,13 +1498,13 @@ static int bitmap_reserve(H* h, int64_t nbits) {
 
 int gamma_hip_bitmap_upload(gamma_hip_index* h, const uint8_t* bitmap, int64_t nbits) {
     if (!h || nbits < 0 || (nbits > 0 && !bitmap)) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    WriteLock lk(h);
     GH_CHECK(h, hipSetDevice(h->device));
     GH_TRY(bitmap_reserve(h, nbits));
     size_t bytes = ((size_t)nbits >> 3) + 1;  // bitmap::create, util/bitmap.cc:15-23
-    GH_CHECK(h, hipMemsetAsync(h->d_bitmap, 0, h->bitmap_cap_bytes, h->stream));
-    GH_CHECK(h, hipMemcpyAsync(h->d_bitmap, bitmap, bytes, hipMemcpyHostToDevice, h->stream));
-    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    GH_CHECK(h, hipMemsetAsync(h->d_bitmap, 0, h->bitmap_cap_bytes, h->wstream));
+    GH_CHECK(h, hipMemcpyAsync(h->d_bitmap, bitmap, bytes, hipMemcpyHostToDevice, h->wstream));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
     std::fill(h->h_bitmap.begin(), h->h_bitmap.end(), 0);
     memcpy(h->h_bitmap.data(), bitmap, bytes);
     h->bitmap_bits = nbits;
@@ -1413,7 +1515,7 @@ int gamma_hip_bitmap_upload(gamma_hip_index* h, const uint8_t* bitmap, int64_t n
 
 int gamma_hip_bitmap_set(gamma_hip_index* h, const int64_t* docids, int64_t n, int value) {
     if (!h || n < 0 || (n > 0 && !docids)) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    WriteLock lk(h);
     if (n == 0) return GAMMA_HIP_OK;
     GH_CHECK(h, hipSetDevice(h->device));
     int64_t mx = 0;
@@ -1422,10 +1524,10 @@ int gamma_hip_bitmap_set(gamma_hip_index* h, const int64_t* docids, int64_t n, i
         GH_TRY(bitmap_reserve(h, mx + 1));
         h->bitmap_bits = std::max<int64_t>(h->bitmap_bits, mx + 1);
     }
-    GH_CHECK(h, h->w_stage.ensure((size_t)n * sizeof(int64_t)));
-    GH_CHECK(h, hipMemcpyAsync(h->w_stage.p, docids, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
-    gh::launch_bitmap_set(h->stream, h->d_bitmap, h->w_stage.as<int64_t>(), n, h->bitmap_bits, value);
-    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    GH_CHECK(h, h->we_stage.ensure((size_t)n * sizeof(int64_t)));
+    GH_CHECK(h, hipMemcpyAsync(h->we_stage.p, docids, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, h->wstream));
+    gh::launch_bitmap_set(h->wstream, h->d_bitmap, h->we_stage.as<int64_t>(), n, h->bitmap_bits, value);
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
     for (int64_t i = 0; i < n; i++) {
         int64_t id = docids[i];
         if (id < 0) continue;
@@ -1440,7 +1542,7 @@ int gamma_hip_bitmap_set(gamma_hip_index* h, const int64_t* docids, int64_t n, i
 int gamma_hip_ivfpq_init(gamma_hip_index* h, int d, int nlist, int M, int nbits, int metric,
                          int bucket_init_size, int bucket_max_size) {
     if (!h) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    WriteLock lk(h);
     if (h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "already initialised");
     if (d <= 0 || nlist <= 0 || M <= 0) return fail(h, GAMMA_HIP_EINVAL, "bad d/nlist/M");
     if (nbits != 8) return fail(h, GAMMA_HIP_EINVAL, "only nbits_per_idx == 8 is supported on device");
@@ -1461,8 +1563,13 @@ int gamma_hip_ivfpq_init(gamma_hip_index* h, int d, int nlist, int M, int nbits,
     GH_CHECK(h, hipMalloc((void**)&h->d_cc_norms, (size_t)nlist * sizeof(float)));
     GH_CHECK(h, hipMalloc((void**)&h->d_pqc, (size_t)M * 256 * h->dsub * sizeof(float)));
     GH_CHECK(h, hipMalloc((void**)&h->d_T2, (size_t)nlist * M * 256 * sizeof(float)));
-    GH_CHECK(h, hipMalloc((void**)&h->d_list_off, (size_t)nlist * sizeof(int64_t)));
-    GH_CHECK(h, hipMalloc((void**)&h->d_list_len, (size_t)nlist * sizeof(int)));
+    for (int v = 0; v < H::NVER; v++) {
+        GH_CHECK(h, hipMalloc((void**)&h->d_ver_off[v], (size_t)nlist * sizeof(int64_t)));
+        GH_CHECK(h, hipMalloc((void**)&h->d_ver_len[v], (size_t)nlist * sizeof(int)));
+        GH_CHECK(h, hipHostMalloc(&h->pin_ver[v], (size_t)nlist * (sizeof(int64_t) + sizeof(int)), hipHostMallocDefault));
+    }
+    h->d_list_off = h->d_ver_off[0];
+    h->d_list_len = h->d_ver_len[0];
     // RTInvertBucketData::Init (realtime_mem_data.cc:57-96): bucket_init entries per list
     h->h_list_off.resize(nlist);
     h->h_list_len.assign(nlist, 0);
@@ -1473,10 +1580,8 @@ int gamma_hip_ivfpq_init(gamma_hip_index* h, int d, int nlist, int M, int nbits,
     h->arena_used = 0;
     GH_TRY(arena_reserve(h, (int64_t)nlist * h->bucket_init));
     h->arena_used = (int64_t)nlist * h->bucket_init;
-    GH_CHECK(h, hipMemcpyAsync(h->d_list_off, h->h_list_off.data(), (size_t)nlist * sizeof(int64_t),
-                               hipMemcpyHostToDevice, h->stream));
-    GH_CHECK(h, hipMemsetAsync(h->d_list_len, 0, (size_t)nlist * sizeof(int), h->stream));
-    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    GH_TRY(publish_meta(h));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
     h->vid_pos.assign((size_t)nlist * h->bucket_init, -1);
     h->ivf_init = true;
     return GAMMA_HIP_OK;
@@ -1484,46 +1589,46 @@ int gamma_hip_ivfpq_init(gamma_hip_index* h, int d, int nlist, int M, int nbits,
 
 int gamma_hip_ivfpq_set_trained(gamma_hip_index* h, const float* cc, const float* pqc, const float* table) {
     if (!h || !cc || !pqc) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    WriteLock lk(h);
     if (!h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
     GH_CHECK(h, hipSetDevice(h->device));
     const size_t ncc = (size_t)h->nlist * h->d, npq = (size_t)h->M * 256 * h->dsub;
     const size_t nt = (size_t)h->nlist * h->M * 256;
-    GH_CHECK(h, hipMemcpyAsync(h->d_cc, cc, ncc * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    GH_CHECK(h, hipMemcpyAsync(h->d_pqc, pqc, npq * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    gh::launch_row_norms(h->stream, h->d_cc, h->nlist, h->d, h->d_cc_norms);
+    GH_CHECK(h, hipMemcpyAsync(h->d_cc, cc, ncc * sizeof(float), hipMemcpyHostToDevice, h->wstream));
+    GH_CHECK(h, hipMemcpyAsync(h->d_pqc, pqc, npq * sizeof(float), hipMemcpyHostToDevice, h->wstream));
+    gh::launch_row_norms(h->wstream, h->d_cc, h->nlist, h->d, h->d_cc_norms);
     if (table)
-        GH_CHECK(h, hipMemcpyAsync(h->d_T2, table, nt * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        GH_CHECK(h, hipMemcpyAsync(h->d_T2, table, nt * sizeof(float), hipMemcpyHostToDevice, h->wstream));
     else
-        gh::launch_precompute_table(h->stream, h->d_cc, h->nlist, h->d, h->M, h->d_pqc, h->d_T2);
+        gh::launch_precompute_table(h->wstream, h->d_cc, h->nlist, h->d, h->M, h->d_pqc, h->d_T2);
     {
         std::vector<int> rank = centroid_rank(cc, h->nlist, h->d);
         if (!h->d_list_rank) GH_CHECK(h, hipMalloc((void**)&h->d_list_rank, (size_t)h->nlist * sizeof(int)));
         GH_CHECK(h, hipMemcpyAsync(h->d_list_rank, rank.data(), (size_t)h->nlist * sizeof(int),
-                                   hipMemcpyHostToDevice, h->stream));
-        GH_CHECK(h, hipStreamSynchronize(h->stream));   // rank is a local
+                                   hipMemcpyHostToDevice, h->wstream));
+        GH_CHECK(h, hipStreamSynchronize(h->wstream));   // rank is a local
     }
     GH_CHECK(h, hipGetLastError());
-    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
     h->trained = true;
     return GAMMA_HIP_OK;
 }
 
 int gamma_hip_ivfpq_get_precomputed_table(gamma_hip_index* h, float* out) {
     if (!h || !out) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    WriteLock lk(h);
     if (!h->trained) return fail(h, GAMMA_HIP_ENOTTRAINED, "not trained");
     GH_CHECK(h, hipSetDevice(h->device));
     GH_CHECK(h, hipMemcpyAsync(out, h->d_T2, (size_t)h->nlist * h->M * 256 * sizeof(float),
-                               hipMemcpyDeviceToHost, h->stream));
-    GH_CHECK(h, hipStreamSynchronize(h->stream));
+                               hipMemcpyDeviceToHost, h->wstream));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
     return GAMMA_HIP_OK;
 }
 
 /* ---- realtime lists ------------------------------------------------------------------- */
 int gamma_hip_ivfpq_add_keys(gamma_hip_index* h, int list_no, int n, const int64_t* vids, const uint8_t* codes) {
     if (!h || (n > 0 && (!vids || !codes))) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    WriteLock lk(h);
     if (!h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
     GH_CHECK(h, hipSetDevice(h->device));
     return add_keys_locked(h, list_no, n, vids, codes);
@@ -1532,7 +1637,7 @@ int gamma_hip_ivfpq_add_keys(gamma_hip_index* h, int list_no, int n, const int64
 int gamma_hip_ivfpq_add_keys_batch(gamma_hip_index* h, int nlists, const int32_t* list_nos,
                                    const int32_t* counts, const int64_t* vids, const uint8_t* codes) {
     if (!h || nlists < 0 || (nlists > 0 && (!list_nos || !counts || !vids || !codes))) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    WriteLock lk(h);
     if (!h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
     GH_CHECK(h, hipSetDevice(h->device));
     int64_t off = 0;
@@ -1552,9 +1657,9 @@ int gamma_hip_ivfpq_add_keys_batch(gamma_hip_index* h, int nlists, const int32_t
         const int l = list_nos[i], n = counts[i];
         if (n == 0) continue;
         const int64_t pos = h->h_list_off[l] + h->h_list_len[l];
-        GH_CHECK(h, hipMemcpyAsync(h->d_ids + pos, vids + off, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+        GH_CHECK(h, hipMemcpyAsync(h->d_ids + pos, vids + off, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, h->wstream));
         GH_CHECK(h, hipMemcpyAsync(h->d_codes + pos * h->code_size, codes + off * h->code_size,
-                                   (size_t)n * h->code_size, hipMemcpyHostToDevice, h->stream));
+                                   (size_t)n * h->code_size, hipMemcpyHostToDevice, h->wstream));
         for (int j = 0; j < n; j++) {
             const int64_t v = vids[off + j];
             if (v < 0) {   // superseded slot restored from a dump: same accounting as add_keys_locked, so that
@@ -1571,16 +1676,15 @@ int gamma_hip_ivfpq_add_keys_batch(gamma_hip_index* h, int nlists, const int32_t
         if (h->h_list_len[l] > h->max_list_len) h->max_list_len = h->h_list_len[l];
         off += n;
     }
-    // publish all lengths after the copies, in stream order
-    GH_CHECK(h, hipMemcpyAsync(h->d_list_len, h->h_list_len.data(), (size_t)h->nlist * sizeof(int),
-                               hipMemcpyHostToDevice, h->stream));
-    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    // publish the new lengths (and moved extents) after the copies, in stream order
+    GH_TRY(publish_meta(h));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
     return arena_repack_if_need(h);
 }
 
 int gamma_hip_ivfpq_update(gamma_hip_index* h, int list_no, int64_t vid, const uint8_t* code) {
     if (!h || !code) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    WriteLock lk(h);
     if (!h->ivf_init || list_no < 0 || list_no >= h->nlist) return fail(h, GAMMA_HIP_EINVAL, "bad list_no");
     if (vid < 0 || (size_t)vid >= h->vid_pos.size()) return GAMMA_HIP_OK;  // realtime_mem_data.cc:307
     const int64_t bp = h->vid_pos[vid];
@@ -1589,11 +1693,11 @@ int gamma_hip_ivfpq_update(gamma_hip_index* h, int list_no, int64_t vid, const u
     const int ob = (int)(bp >> 32), op = (int)(bp & 0xffffffff);
     if (ob == list_no) {
         GH_CHECK(h, hipMemcpyAsync(h->d_codes + (h->h_list_off[ob] + op) * h->code_size, code, h->code_size,
-                                   hipMemcpyHostToDevice, h->stream));
-        GH_CHECK(h, hipStreamSynchronize(h->stream));
+                                   hipMemcpyHostToDevice, h->wstream));
+        GH_CHECK(h, hipStreamSynchronize(h->wstream));
         return GAMMA_HIP_OK;
     }
-    gh::launch_mark_moved(h->stream, h->d_ids, h->h_list_off[ob] + op);
+    gh::launch_mark_moved(h->wstream, h->d_ids, h->h_list_off[ob] + op);
     h->h_deleted[ob]++;
     h->n_moved++;
     h->ntotal -= 1;  // add_keys_locked re-counts it
@@ -1602,7 +1706,7 @@ int gamma_hip_ivfpq_update(gamma_hip_index* h, int list_no, int64_t vid, const u
 
 int gamma_hip_ivfpq_delete(gamma_hip_index* h, const int64_t* vids, int n) {
     if (!h || (n > 0 && !vids)) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    WriteLock lk(h);
     for (int i = 0; i < n; i++) {
         if (vids[i] < 0 || (size_t)vids[i] >= h->vid_pos.size()) continue;
         const int64_t bp = h->vid_pos[vids[i]];
@@ -1614,7 +1718,7 @@ int gamma_hip_ivfpq_delete(gamma_hip_index* h, const int64_t* vids, int n) {
 
 int gamma_hip_ivfpq_compact_if_need(gamma_hip_index* h) {
     if (!h) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    WriteLock lk(h);
     if (!h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
     GH_CHECK(h, hipSetDevice(h->device));
     std::vector<int64_t> ids;
@@ -1625,9 +1729,9 @@ int gamma_hip_ivfpq_compact_if_need(gamma_hip_index* h) {
         if (!((float)h->h_deleted[l] / len >= 0.3f)) continue;  // Compactable, :373-377
         ids.resize(len);
         codes.resize((size_t)len * h->code_size);
-        GH_CHECK(h, hipMemcpyAsync(ids.data(), h->d_ids + h->h_list_off[l], (size_t)len * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-        GH_CHECK(h, hipMemcpyAsync(codes.data(), h->d_codes + h->h_list_off[l] * h->code_size, (size_t)len * h->code_size, hipMemcpyDeviceToHost, h->stream));
-        GH_CHECK(h, hipStreamSynchronize(h->stream));
+        GH_CHECK(h, hipMemcpyAsync(ids.data(), h->d_ids + h->h_list_off[l], (size_t)len * sizeof(int64_t), hipMemcpyDeviceToHost, h->wstream));
+        GH_CHECK(h, hipMemcpyAsync(codes.data(), h->d_codes + h->h_list_off[l] * h->code_size, (size_t)len * h->code_size, hipMemcpyDeviceToHost, h->wstream));
+        GH_CHECK(h, hipStreamSynchronize(h->wstream));
         int pos = 0;
         for (int i = 0; i < len; i++) {  // CompactOne, :98-112
             const int64_t id = ids[i];
@@ -1646,21 +1750,19 @@ int gamma_hip_ivfpq_compact_if_need(gamma_hip_index* h) {
         h->arena_used += h->h_list_cap[l];
         h->arena_waste += h->h_list_cap[l];
         if (pos > 0) {
-            GH_CHECK(h, hipMemcpyAsync(h->d_ids + noff, ids.data(), (size_t)pos * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
-            GH_CHECK(h, hipMemcpyAsync(h->d_codes + noff * h->code_size, codes.data(), (size_t)pos * h->code_size, hipMemcpyHostToDevice, h->stream));
+            GH_CHECK(h, hipMemcpyAsync(h->d_ids + noff, ids.data(), (size_t)pos * sizeof(int64_t), hipMemcpyHostToDevice, h->wstream));
+            GH_CHECK(h, hipMemcpyAsync(h->d_codes + noff * h->code_size, codes.data(), (size_t)pos * h->code_size, hipMemcpyHostToDevice, h->wstream));
         }
         h->h_list_off[l] = noff;
         h->ntotal -= (len - pos);
         h->h_list_len[l] = pos;
         h->h_deleted[l] = 0;
-        GH_CHECK(h, hipMemcpyAsync(h->d_list_off + l, &h->h_list_off[l], sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
-        GH_CHECK(h, hipMemcpyAsync(h->d_list_len + l, &h->h_list_len[l], sizeof(int), hipMemcpyHostToDevice, h->stream));
-        GH_CHECK(h, hipStreamSynchronize(h->stream));
+        GH_CHECK(h, hipStreamSynchronize(h->wstream));   // ids / codes are locals of this loop
         changed = true;
     }
     if (changed) {
-        h->max_list_len = 0;
-        for (int l = 0; l < h->nlist; l++) h->max_list_len = std::max(h->max_list_len, h->h_list_len[l]);
+        GH_TRY(publish_meta(h));
+        GH_CHECK(h, hipStreamSynchronize(h->wstream));
         GH_TRY(arena_repack_if_need(h));
     }
     return GAMMA_HIP_OK;
@@ -1678,7 +1780,7 @@ int gamma_hip_ivfpq_arena_stats(gamma_hip_index* h, int64_t* out4) {
 
 int gamma_hip_ivfpq_set_repack_threshold(gamma_hip_index* h, int64_t min_waste_entries) {
     if (!h || min_waste_entries < 0) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    WriteLock lk(h);
     if (!h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
     GH_CHECK(h, hipSetDevice(h->device));
     h->repack_min_entries = min_waste_entries;
@@ -1696,22 +1798,23 @@ int64_t gamma_hip_ivfpq_list_capacity(gamma_hip_index* h, int l) {
 
 int gamma_hip_ivfpq_get_list(gamma_hip_index* h, int l, int64_t* vids, uint8_t* codes) {
     if (!h) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    WriteLock lk(h);
     if (!h->ivf_init || l < 0 || l >= h->nlist) return fail(h, GAMMA_HIP_EINVAL, "bad list_no");
     const int len = h->h_list_len[l];
     if (len == 0) return GAMMA_HIP_OK;
     GH_CHECK(h, hipSetDevice(h->device));
-    if (vids) GH_CHECK(h, hipMemcpyAsync(vids, h->d_ids + h->h_list_off[l], (size_t)len * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-    if (codes) GH_CHECK(h, hipMemcpyAsync(codes, h->d_codes + h->h_list_off[l] * h->code_size, (size_t)len * h->code_size, hipMemcpyDeviceToHost, h->stream));
-    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    if (vids) GH_CHECK(h, hipMemcpyAsync(vids, h->d_ids + h->h_list_off[l], (size_t)len * sizeof(int64_t), hipMemcpyDeviceToHost, h->wstream));
+    if (codes) GH_CHECK(h, hipMemcpyAsync(codes, h->d_codes + h->h_list_off[l] * h->code_size, (size_t)len * h->code_size, hipMemcpyDeviceToHost, h->wstream));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
     return GAMMA_HIP_OK;
 }
 
 int gamma_hip_ivfpq_set_list_mask(gamma_hip_index* h, const uint8_t* owned) {
     if (!h) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    WriteLock lk(h);
     if (!h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
     GH_CHECK(h, hipSetDevice(h->device));
+    GH_CHECK(h, lk.exclusive());
     if (!owned) {
         if (h->d_list_mask) GH_CHECK(h, hipFree(h->d_list_mask));
         h->d_list_mask = nullptr;
@@ -1720,8 +1823,8 @@ int gamma_hip_ivfpq_set_list_mask(gamma_hip_index* h, const uint8_t* owned) {
     }
     if (!h->d_list_mask) GH_CHECK(h, hipMalloc((void**)&h->d_list_mask, (size_t)h->nlist));
     h->h_list_mask.assign(owned, owned + h->nlist);
-    GH_CHECK(h, hipMemcpyAsync(h->d_list_mask, owned, (size_t)h->nlist, hipMemcpyHostToDevice, h->stream));
-    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    GH_CHECK(h, hipMemcpyAsync(h->d_list_mask, owned, (size_t)h->nlist, hipMemcpyHostToDevice, h->wstream));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
     return GAMMA_HIP_OK;
 }
 
@@ -1729,18 +1832,18 @@ int gamma_hip_ivfpq_set_list_mask(gamma_hip_index* h, const uint8_t* owned) {
 // exact: the arithmetic form faiss picks from the size of the WHOLE assign() call (n < 20), not of a chunk
 static int encode_locked(H* h, int64_t n, const float* d_vecs, int* d_assign, uint8_t* d_codes_out, bool exact) {
     // quantizer->assign == search with k = 1 (faiss rule for the arithmetic form)
-    hipStream_t s = h->stream;
+    hipStream_t s = h->wstream;   // own stream and own workspace: runs beside the searches
     const int d = h->d, nlist = h->nlist;
-    GH_CHECK(h, h->w_mat.ensure((size_t)n * nlist * sizeof(float)));
-    GH_CHECK(h, h->w_coarse_dis.ensure((size_t)n * sizeof(float)));
+    GH_CHECK(h, h->we_mat.ensure((size_t)n * nlist * sizeof(float)));
+    GH_CHECK(h, h->we_cdis.ensure((size_t)n * sizeof(float)));
     if (exact) {
-        gh::launch_pairwise(s, true, d_vecs, (int)n, d, h->d_cc, nlist, h->w_mat.as<float>(), nlist);
+        gh::launch_pairwise(s, true, d_vecs, (int)n, d, h->d_cc, nlist, h->we_mat.as<float>(), nlist);
     } else {
         gh::launch_l2_gemmform(s, d_vecs, (int)n, d, h->d_cc, nlist, nullptr, h->d_cc_norms,
-                               h->w_mat.as<float>(), nlist, true);
+                               h->we_mat.as<float>(), nlist, true);
     }
-    gh::launch_select_topk(s, true, h->w_mat.as<float>(), nlist, nullptr, nlist, nlist, (int)n, 1,
-                           h->w_coarse_dis.as<float>(), d_assign);
+    gh::launch_select_topk(s, true, h->we_mat.as<float>(), nlist, nullptr, nlist, nlist, (int)n, 1,
+                           h->we_cdis.as<float>(), d_assign);
     gh::launch_pq_encode(s, d_vecs, n, d, h->M, d_assign, h->d_cc, h->d_pqc, d_codes_out);
     GH_CHECK(h, hipGetLastError());
     return GAMMA_HIP_OK;
@@ -1748,22 +1851,22 @@ static int encode_locked(H* h, int64_t n, const float* d_vecs, int* d_assign, ui
 
 int gamma_hip_ivfpq_encode(gamma_hip_index* h, int64_t n, const float* vecs, int64_t* list_nos, uint8_t* codes) {
     if (!h || n < 0 || (n > 0 && (!vecs || !list_nos || !codes))) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    WriteLock lk(h);
     if (!h->trained) return fail(h, GAMMA_HIP_ENOTTRAINED, "not trained");
     if (n == 0) return GAMMA_HIP_OK;
     GH_CHECK(h, hipSetDevice(h->device));
-    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(h->dist_budget_bytes / ((size_t)h->nlist * sizeof(float)))));
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n, 65536), (int64_t)(h->dist_budget_bytes / ((size_t)h->nlist * sizeof(float)))));
     std::vector<int> assign(chunk);
     for (int64_t i0 = 0; i0 < n; i0 += chunk) {
         const int64_t nc = std::min(chunk, n - i0);
-        GH_CHECK(h, h->w_x.ensure((size_t)nc * h->d * sizeof(float)));
-        GH_CHECK(h, h->w_assign.ensure((size_t)nc * sizeof(int)));
-        GH_CHECK(h, h->w_codes_tmp.ensure((size_t)nc * h->code_size));
-        GH_CHECK(h, hipMemcpyAsync(h->w_x.p, vecs + i0 * h->d, (size_t)nc * h->d * sizeof(float), hipMemcpyHostToDevice, h->stream));
-        GH_TRY(encode_locked(h, nc, h->w_x.as<float>(), h->w_assign.as<int>(), h->w_codes_tmp.as<uint8_t>(), n < 20));
-        GH_CHECK(h, hipMemcpyAsync(assign.data(), h->w_assign.p, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        GH_CHECK(h, hipMemcpyAsync(codes + i0 * h->code_size, h->w_codes_tmp.p, (size_t)nc * h->code_size, hipMemcpyDeviceToHost, h->stream));
-        GH_CHECK(h, hipStreamSynchronize(h->stream));
+        GH_CHECK(h, h->we_x.ensure((size_t)nc * h->d * sizeof(float)));
+        GH_CHECK(h, h->we_assign.ensure((size_t)nc * sizeof(int)));
+        GH_CHECK(h, h->we_codes.ensure((size_t)nc * h->code_size));
+        GH_CHECK(h, hipMemcpyAsync(h->we_x.p, vecs + i0 * h->d, (size_t)nc * h->d * sizeof(float), hipMemcpyHostToDevice, h->wstream));
+        GH_TRY(encode_locked(h, nc, h->we_x.as<float>(), h->we_assign.as<int>(), h->we_codes.as<uint8_t>(), n < 20));
+        GH_CHECK(h, hipMemcpyAsync(assign.data(), h->we_assign.p, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, h->wstream));
+        GH_CHECK(h, hipMemcpyAsync(codes + i0 * h->code_size, h->we_codes.p, (size_t)nc * h->code_size, hipMemcpyDeviceToHost, h->wstream));
+        GH_CHECK(h, hipStreamSynchronize(h->wstream));
         for (int64_t i = 0; i < nc; i++) list_nos[i0 + i] = assign[i];
     }
     return GAMMA_HIP_OK;
@@ -1772,7 +1875,7 @@ int gamma_hip_ivfpq_encode(gamma_hip_index* h, int64_t n, const float* vecs, int
 int gamma_hip_assign(gamma_hip_index* h, int d, int64_t n, const float* x, int k, const float* centroids,
                      int32_t* assign, float* dis) {
     if (!h || d <= 0 || n < 0 || k <= 0 || (n > 0 && (!x || !centroids || !assign))) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    SearchLock lk(h);
     if (n == 0) return GAMMA_HIP_OK;
     GH_CHECK(h, hipSetDevice(h->device));
     hipStream_t s = h->stream;
@@ -1853,29 +1956,29 @@ int gamma_hip_ivfpq_add(gamma_hip_index* h, int64_t n, const float* vecs, int64_
 int gamma_hip_ivfpq_search_device(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
                                   const float* d_x, int k, float* d_distances, int64_t* d_labels) {
     if (!h) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    SearchLock lk(h);
     return ivfpq_search_device_locked(h, p, nq, d_x, k, d_distances, d_labels);
 }
 
 static int flat_search_host_locked(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x, int k,
                                   float* distances, int64_t* labels) {
-    std::lock_guard<std::mutex> g(h->mu);
+    SearchLock lk(h);
     GH_TRY(check_params(h, p, nq, k));
     if (h->raw_d <= 0) return fail(h, GAMMA_HIP_EINVAL, "raw store not initialised");
     if (nq > 0 && k > 0 && (!x || !distances || !labels)) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
     return host_search(h, nq, h->raw_d, x, k, distances, labels, [&](const float* dx, float* dd, int64_t* dl) {
         return flat_search_device_locked(h, p, nq, dx, k, dd, dl);
-    });
+    }, true, &lk);
 }
 
 static int ivfpq_search_host_locked(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x,
                                    int k, float* distances, int64_t* labels) {
-    std::lock_guard<std::mutex> g(h->mu);
+    SearchLock lk(h);
     GH_TRY(ivfpq_check(h, p, nq, k));
     if (nq > 0 && k > 0 && (!x || !distances || !labels)) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
     return host_search(h, nq, h->d, x, k, distances, labels, [&](const float* dx, float* dd, int64_t* dl) {
         return ivfpq_search_device_locked(h, p, nq, dx, k, dd, dl);
-    });
+    }, true, &lk);
 }
 
 // Search is re-entrant in the reference and is called from many client threads at once, typically with
@@ -2046,7 +2149,8 @@ static void combine_worker(gamma_hip_index* h) {
                     }
                     cur.set = set;
                     set_busy[set].store(true, std::memory_order_release);
-                    h->mu.lock();   // held until the batch has been awaited (below)
+                    h->search_mu.lock();   // held until the batch has been awaited (below)
+                    h->mu.lock();          // while the batch reads the handle and is enqueued
                     cur.rc = flat ? check_params(h, &pp, total, kk) : ivfpq_check(h, &pp, total, kk);
                     // requests with their own filter clauses: one table entry per request, a query -> entry map
                     // (IVFPQ only: filtered flat requests are not combined)
@@ -2063,6 +2167,7 @@ static void combine_worker(gamma_hip_index* h) {
                                                                                    multi ? &fc : nullptr);
                                              },
                                              /*sync=*/false);
+                    h->mu.unlock();
                     cur.enqueued = true;
                 }
                 set ^= 1;
@@ -2071,7 +2176,7 @@ static void combine_worker(gamma_hip_index* h) {
             const auto t_c = t_b;
             if (cur.enqueued) {
                 if (hipStreamSynchronize(h->stream) != hipSuccess && cur.rc == GAMMA_HIP_OK) cur.rc = GAMMA_HIP_EDEVICE;
-                h->mu.unlock();
+                h->search_mu.unlock();
                 cur.enqueued = false;
                 if (cur.rc != GAMMA_HIP_OK && cur.grp.size() > 1) {
                     // one request's parameters may be at fault (a filter on an unknown column, ...): every
@@ -2152,7 +2257,7 @@ int gamma_hip_ivfpq_search(gamma_hip_index* h, const gamma_hip_search_params* p,
 int gamma_hip_ivfpq_last_stages(gamma_hip_index* h, float* coarse_dis, int64_t* coarse_idx,
                                 float* recall_dis, int64_t* recall_ids) {
     if (!h) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    SearchLock lk(h);
     const int nq = h->last_nq, P = h->last_P, R = h->last_R;
     if (nq <= 0) return fail(h, GAMMA_HIP_EINVAL, "no previous search");
     GH_CHECK(h, hipSetDevice(h->device));
@@ -2171,7 +2276,7 @@ int gamma_hip_ivfpq_last_stages(gamma_hip_index* h, float* coarse_dis, int64_t* 
 int gamma_hip_ivfpq_search_shard(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
                                  const float* d_x, int k, float* d_recall_dis, int64_t* d_recall_ids) {
     if (!h) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    SearchLock lk(h);
     GH_TRY(ivfpq_check(h, p, nq, k));
     if (k <= 0 || nq == 0) return GAMMA_HIP_OK;
     if (!d_x || !d_recall_dis || !d_recall_ids) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
@@ -2199,7 +2304,7 @@ int gamma_hip_ivfpq_search_shard(gamma_hip_index* h, const gamma_hip_search_para
 int gamma_hip_ivfpq_coarse_device(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
                                   const float* d_x, float* d_coarse_dis, int32_t* d_probe) {
     if (!h) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    SearchLock lk(h);
     GH_TRY(ivfpq_check(h, p, nq, 1));
     if (nq == 0) return GAMMA_HIP_OK;
     if (!d_x || !d_coarse_dis || !d_probe) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
@@ -2221,7 +2326,7 @@ int gamma_hip_ivfpq_search_shard_preassigned(gamma_hip_index* h, const gamma_hip
                                              const int32_t* d_probe, int k, float* d_recall_dis,
                                              int64_t* d_recall_ids) {
     if (!h) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    SearchLock lk(h);
     GH_TRY(ivfpq_check(h, p, nq, k));
     if (k <= 0 || nq == 0) return GAMMA_HIP_OK;
     if (!d_coarse_dis || !d_probe) return fail(h, GAMMA_HIP_EINVAL, "null coarse assignment");
@@ -2249,7 +2354,7 @@ int gamma_hip_ivfpq_merge_rerank(gamma_hip_index* h, const gamma_hip_search_para
                                  const float* d_x, int k, const float* d_all_dis, const int64_t* d_all_ids,
                                  int q0, int nq_local, float* d_distances, int64_t* d_labels) {
     if (!h) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    SearchLock lk(h);
     GH_TRY(ivfpq_check(h, p, nq, k));
     if (nshards <= 0 || q0 < 0 || nq_local < 0 || q0 + nq_local > nq) return fail(h, GAMMA_HIP_EINVAL, "bad shard/query range");
     if (k <= 0 || nq_local == 0) return GAMMA_HIP_OK;
@@ -2288,7 +2393,7 @@ int gamma_hip_ivfpq_merge_rerank(gamma_hip_index* h, const gamma_hip_search_para
 int gamma_hip_flat_search_device(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
                                  const float* d_x, int k, float* d_distances, int64_t* d_labels) {
     if (!h) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    SearchLock lk(h);
     return flat_search_device_locked(h, p, nq, d_x, k, d_distances, d_labels);
 }
 
@@ -2321,14 +2426,14 @@ int64_t gamma_hip_total_mem_bytes(gamma_hip_index* h) {
 
 int gamma_hip_profile_enable(gamma_hip_index* h, int on) {
     if (!h) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    SearchLock lk(h);
     h->profile = on != 0;
     return GAMMA_HIP_OK;
 }
 
 int gamma_hip_profile_reset(gamma_hip_index* h) {
     if (!h) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    SearchLock lk(h);
     GH_CHECK(h, hipSetDevice(h->device));
     GH_TRY(drain_events(h));
     for (int i = 0; i < GAMMA_HIP_NUM_STAGES; i++) {
@@ -2343,7 +2448,7 @@ int gamma_hip_profile_reset(gamma_hip_index* h) {
 
 int gamma_hip_profile_get(gamma_hip_index* h, int stage, double* total_ms, int64_t* launches) {
     if (!h || stage < 0 || stage >= GAMMA_HIP_NUM_STAGES) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    SearchLock lk(h);
     GH_CHECK(h, hipSetDevice(h->device));
     GH_TRY(drain_events(h));
     if (total_ms) *total_ms = h->stage_ms[stage];
@@ -2353,7 +2458,7 @@ int gamma_hip_profile_get(gamma_hip_index* h, int stage, double* total_ms, int64
 
 int gamma_hip_profile_scan_bytes(gamma_hip_index* h, int64_t* bytes, int64_t* pairs) {
     if (!h) return GAMMA_HIP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    SearchLock lk(h);
     GH_CHECK(h, hipSetDevice(h->device));
     GH_CHECK(h, hipStreamSynchronize(h->stream));
     unsigned long long codes = 0;

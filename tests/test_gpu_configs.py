@@ -162,3 +162,33 @@ def test_c5_shape_d768_ip_filters_and_realtime_inserts():
     finally:
         B.lib().go_set_assign_mode(0)
         g.close()
+
+
+def test_c1_flat_l2_10k_128_k10_through_the_plugin_boundary():
+    """BASELINE.json configs[0] at its exact shape: Flat L2, 10 000 x 128 float32, k = 10, driven the way the
+    engine drives a model (reflector -> HIPFLAT -> Init / Add in engine-sized batches / Parse + Search with a
+    GammaSearchCondition, gamma_amd/host/harness_c_api.cc), 1000 queries as in SURVEY 8d -- against the CPU
+    restatement of GammaFLATIndex::Search.  Also the engine's default score window (tests/test.h:584-585)."""
+    from gamma_amd import plugin
+    from oracle import binding as B
+    from tests.parity import compare_topk
+    N, d, k, nq = 10000, 128, 10, 1000
+    base = synth.sift_like(N, d=d, seed=1234)
+    q = synth.sift_like(nq, d=d, seed=4321)
+    m = plugin.PluginModel("HIPFLAT", d, '{"metric_type": "L2"}')
+    m.store(base)
+    for i0 in range(0, N, 1000):              # AddRTVecsToIndex: batches of <= 1000 (vector_manager.cc:305-349)
+        assert m.add(base[i0:i0 + 1000])
+    Df, If = B.flat_search(base, q, k, B.METRIC_L2, B.make_ctx())
+    Dg, Ig = m.search(q, k, '{"metric_type": "L2"}')
+    compare_topk(Df, If, Dg, Ig)
+    assert (Ig >= 0).all() and (np.diff(Dg, axis=1) >= 0).all()
+    Df, If = B.flat_search(base, q, k, B.METRIC_L2, B.make_ctx(min_score=0.0, max_score=10000.0))
+    Dg, Ig = m.search(q, k, '{"metric_type": "L2"}', min_score=0.0, max_score=10000.0)
+    compare_topk(Df, If, Dg, Ig)
+    # one query at a time, as tests/test.h issues them
+    for i in range(0, 40):
+        D1, I1 = m.search(q[i:i + 1], k, "")
+        compare_topk(Df[i:i + 1] * 0 + B.flat_search(base, q[i:i + 1], k, B.METRIC_L2, B.make_ctx())[0],
+                     B.flat_search(base, q[i:i + 1], k, B.METRIC_L2, B.make_ctx())[1], D1, I1)
+    m.close()
