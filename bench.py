@@ -289,6 +289,36 @@ def main():
                                              "peak": 157.3, "unit": "TFLOP/s",
                                              "frac": round(flops / sec / 157.3e12, 4)}}
 
+        # (e) C5's other half: realtime inserts at 10 k vectors/s WHILE searching (writers run on their own stream
+        #     and publish versioned list tables; tests/test_gpu_concurrent.py checks that every search sees a prefix)
+        import threading
+        ins = synth.sift_like(20000, d=d, seed=777)
+        sstream = torch.cuda.ExternalStream(g.stream(), device=dev)
+        done = {"t": None}
+
+        def writer():
+            t1 = time.perf_counter()
+            for b in range(20):
+                lo = b * 1000
+                g.raw_append(ins[lo:lo + 1000])
+                g.add(ins[lo:lo + 1000], N + lo)
+                pause = t1 + (b + 1) * 0.1 - time.perf_counter()    # 1000 vectors every 0.1 s
+                if pause > 0:
+                    time.sleep(pause)
+            done["t"] = time.perf_counter() - t1
+
+        wt = threading.Thread(target=writer)
+        nsteps, t1 = 0, time.perf_counter()
+        wt.start()
+        while wt.is_alive():
+            g.ivfpq_search_device(d_q.data_ptr(), gnq, k, args, d_D.data_ptr(), d_I.data_ptr())
+            sstream.synchronize()
+            nsteps += 1
+        el = time.perf_counter() - t1
+        wt.join()
+        extra["search_during_inserts"] = {"qps": round(gnq * nsteps / el, 1), "insert_rate_vectors_per_s": round(20000 / done["t"], 1),
+                                          "inserted": 20000, "batch": gnq, "steps": nsteps}
+
     cpu = None
     if world == 1 and a.cpu_seconds > 0:
         cpu = cpu_baseline(a, base, queries, cc, pq, g, lno, codes, list_sizes)

@@ -1,0 +1,105 @@
+"""GPU: search concurrent with realtime inserts (BASELINE configs[4]: 768-d inner product, inserts at 10 k
+vectors/s DURING search).  The reference's lists are lock-free for readers: a writer appends, then publishes the
+new length (realtime/realtime_mem_data.cc:279-300).  Here writers run on their own stream and publish a new
+VERSION of the lists' (offset, length) tables; a search reads the version current when it was enqueued.  Checked:
+every Search call made while the writer runs equals the oracle at SOME prefix of the insert log -- never a torn
+state -- prefixes never go backwards within a client thread, and the writer sustains the rate while clients search."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from gamma_amd import api, synth, train
+from oracle import binding as B
+from tests.parity import compare_topk
+
+pytestmark = pytest.mark.gpu
+WIDE = dict(min_score=-3e38, max_score=3e38)
+
+
+def _norm(x):
+    return (x / np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-9)).astype(np.float32)
+
+
+def test_search_during_inserts_sees_a_prefix_of_the_log():
+    d, nlist, M, N0, nb, bs = 768, 64, 64, 6000, 16, 1000
+    rng = np.random.default_rng(11)
+    base = _norm(rng.standard_normal((N0 + nb * bs, d)).astype(np.float32) + 0.3 * rng.standard_normal((1, d)).astype(np.float32))
+    q = _norm(rng.standard_normal((8, d)).astype(np.float32))
+    cc, pq = train.train_ivfpq(base[:4000], nlist, M, niter=4, pq_niter=4, seed=3, device="cpu")
+    k, nprobe, R = 10, 8, 60
+    # the oracle at every prefix of the insert log (Add in the engine's batches: n >= 20 -> GEMM-form assignment)
+    B.lib().go_set_assign_mode(1)
+    o = B.OracleIVFPQ(d, nlist, M, 8, B.METRIC_IP, bucket_init_size=100)
+    o.set_trained(cc, pq, None)
+    assert o.add(base[:N0])
+    ctx = B.make_ctx(**WIDE)
+    expect = []
+    for b in range(nb + 1):
+        if b:
+            assert o.add(base[N0 + (b - 1) * bs:N0 + b * bs])
+        o.set_raw(base[:N0 + b * bs])
+        expect.append(o.search(q, k, nprobe, recall_num=R, has_rank=True, metric=B.METRIC_IP, ctx=ctx, coarse_mode=0))
+    B.lib().go_set_assign_mode(0)
+    assert any(not np.array_equal(expect[b][1], expect[b + 1][1]) for b in range(nb))   # the log changes the answers
+
+    g = api.GammaHip(0)
+    try:
+        g.ivfpq_init(d, nlist, M, 8, api.METRIC_IP, 100)     # small buckets: lists grow (extents move) while searched
+        g.ivfpq_set_trained(cc, pq, None)
+        g.raw_init(d)
+        g.raw_append(base[:N0])
+        g.add(base[:N0], 0)
+        args = api.SearchArgs(metric=api.METRIC_IP, nprobe=nprobe, recall_num=R, has_rank=True, coarse_mode=0, **WIDE)
+        stop = threading.Event()
+        results = [[] for _ in range(3)]
+        errors = []
+
+        def client(slot):
+            try:
+                while not stop.is_set():
+                    results[slot].append(g.ivfpq_search(q, k, args))
+            except Exception as e:     # noqa: BLE001
+                errors.append(e)
+
+        th = [threading.Thread(target=client, args=(i,)) for i in range(3)]
+        for t in th:
+            t.start()
+        time.sleep(0.05)
+        t0 = time.perf_counter()
+        for b in range(nb):            # the indexing thread: store first (re-rank reads it), then the index
+            lo = N0 + b * bs
+            g.raw_append(base[lo:lo + bs])
+            g.add(base[lo:lo + bs], lo)
+        dt = time.perf_counter() - t0
+        time.sleep(0.05)
+        stop.set()
+        for t in th:
+            t.join()
+        assert not errors, errors
+        rate = nb * bs / dt
+        assert rate >= 10000, "insert rate %.0f vectors/s" % rate
+        nsearch = sum(len(r) for r in results)
+        assert nsearch >= 30
+        seen = set()
+        for slot in range(3):
+            last = 0
+            for D, I in results[slot]:
+                hit = None
+                for b in range(last, nb + 1):
+                    try:
+                        compare_topk(expect[b][0], expect[b][1], D, I)
+                        hit = b
+                        break
+                    except AssertionError:
+                        continue
+                assert hit is not None, "a search saw a state that is no prefix of the insert log (after prefix %d)" % last
+                last = hit
+                seen.add(hit)
+        assert len(seen) >= 2, seen            # searches really ran while the index was growing
+        # and the final state is the whole log
+        D, I = g.ivfpq_search(q, k, args)
+        compare_topk(expect[nb][0], expect[nb][1], D, I)
+    finally:
+        g.close()
