@@ -29,12 +29,16 @@ class FieldFilter(C.Structure):
                 ("lower_f", C.c_double), ("upper_f", C.c_double)]
 
 
+class TermFilter(C.Structure):
+    _fields_ = [("field_id", C.c_int32), ("op", C.c_int32), ("n_items", C.c_int32), ("items", C.c_int32 * 8)]
+
+
 class SearchParams(C.Structure):
     _fields_ = [("metric", C.c_int32), ("nprobe", C.c_int32), ("recall_num", C.c_int32),
                 ("has_rank", C.c_int32), ("min_score", C.c_float), ("max_score", C.c_float),
                 ("coarse_mode", C.c_int32), ("has_range", C.c_int32), ("n_range", C.c_int32),
-                ("range", C.POINTER(RangeFilter)), ("n_field", C.c_int32), ("reserved", C.c_int32),
-                ("field", C.POINTER(FieldFilter))]
+                ("range", C.POINTER(RangeFilter)), ("n_field", C.c_int32), ("n_term", C.c_int32),
+                ("field", C.POINTER(FieldFilter)), ("term", C.POINTER(TermFilter))]
 
 
 # name -> (restype, argtypes); every symbol include/gamma_hip.h declares
@@ -50,6 +54,8 @@ SYMBOLS = {
     "gamma_hip_field_append": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     "gamma_hip_field_update": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     "gamma_hip_field_count": (C.c_int64, [C.c_void_p, C.c_int]),
+    "gamma_hip_term_append": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "gamma_hip_term_count": (C.c_int64, [C.c_void_p, C.c_int]),
     "gamma_hip_raw_init": (C.c_int, [C.c_void_p, C.c_int]),
     "gamma_hip_raw_append": (C.c_int, [C.c_void_p, C.c_int64, f32p]),
     "gamma_hip_raw_update": (C.c_int, [C.c_void_p, C.c_int64, f32p]),

@@ -42,9 +42,11 @@ class SearchArgs:
     """Builds a gamma_hip_search_params; keeps the filter buffers alive."""
 
     def __init__(self, metric=METRIC_L2, nprobe=1, recall_num=100, has_rank=True, min_score=None,
-                 max_score=None, coarse_mode=-1, range_filters=None, field_filters=None):
+                 max_score=None, coarse_mode=-1, range_filters=None, field_filters=None, term_filters=None):
         """field_filters: list of (field_id, lower, upper, include_lower, include_upper) evaluated on
-        the device against columns loaded with GammaHip.field_append."""
+        the device against columns loaded with GammaHip.field_append.
+        term_filters: list of (field_id, op, item ids) -- op 0 And / 1 Or / 2 Not -- against columns loaded with
+        GammaHip.term_append."""
         p = SearchParams()
         p.metric = metric
         p.nprobe = nprobe
@@ -74,6 +76,15 @@ class SearchArgs:
             p.n_field = len(field_filters)
             p.field = C.cast(fa, C.POINTER(_lib.FieldFilter))
             self._keep.append(fa)
+        if term_filters:
+            ta = (_lib.TermFilter * len(term_filters))()
+            for i, (fid, op, items) in enumerate(term_filters):
+                ta[i].field_id, ta[i].op, ta[i].n_items = fid, op, len(items)
+                for j, it in enumerate(items):
+                    ta[i].items[j] = int(it)
+            p.n_term = len(term_filters)
+            p.term = C.cast(ta, C.POINTER(_lib.TermFilter))
+            self._keep.append(ta)
         self.p = p
 
     def ref(self):
@@ -313,6 +324,16 @@ class GammaHip:
     def field_update(self, field_id, docid, value):
         value = np.ascontiguousarray(value)
         self._ck(self.L.gamma_hip_field_update(self.h, field_id, docid, value.ctypes.data), "field_update")
+
+    def term_append(self, field_id, docs_items):
+        """docs_items: one sequence of dictionary-encoded item ids per doc (docid = row)"""
+        counts = np.ascontiguousarray([len(d) for d in docs_items], dtype=np.int32)
+        flat = np.ascontiguousarray([t for d in docs_items for t in d], dtype=np.int32)
+        self._ck(self.L.gamma_hip_term_append(self.h, field_id, len(counts), counts.ctypes.data_as(C.POINTER(C.c_int32)),
+                                              flat.ctypes.data_as(C.POINTER(C.c_int32))), "term_append")
+
+    def term_count(self, field_id):
+        return self.L.gamma_hip_term_count(self.h, field_id)
 
     def field_count(self, field_id):
         return self.L.gamma_hip_field_count(self.h, field_id)

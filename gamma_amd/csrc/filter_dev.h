@@ -48,6 +48,21 @@ __device__ __forceinline__ bool is_valid_doc(const FilterDesc& f, int64_t vid) {
         }
         if (!in) return false;
     }
+    for (int i = 0; i < f.n_term; i++) {
+        const TermDesc& t = f.term[i];
+        if (doc < 0 || (int64_t)doc >= t.n) return false;
+        const int64_t b = t.off[doc], e = t.off[doc + 1];
+        // Or: any term item among the doc's items; And: all of them (as the reference's GPU model); Not: none
+        bool any = false, all = true;
+        for (int k = 0; k < t.n_items; k++) {
+            bool in = false;
+            for (int64_t j = b; j < e && !in; j++) in = t.tok[j] == t.items[k];
+            any |= in;
+            all &= in;
+        }
+        const bool pass = t.op == 1 ? any : (t.op == 2 ? !any : all);
+        if (!pass) return false;
+    }
     if (f.del_bitmap && doc >= 0 && (int64_t)doc < f.del_bits && bm_test(f.del_bitmap, doc))
         return false;
     return true;

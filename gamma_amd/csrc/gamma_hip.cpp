@@ -111,6 +111,13 @@ struct gamma_hip_index {
         int64_t n = 0, cap = 0;
     };
     std::map<int, Column> fields;
+    // STRING columns as dictionary-encoded item lists (on-device term filters): doc i = tok[off[i] .. off[i + 1])
+    struct TermColumn {
+        int64_t* d_off = nullptr;
+        int32_t* d_tok = nullptr;
+        int64_t ndocs = 0, cap_docs = 0, ntok = 0, cap_tok = 0;
+    };
+    std::map<int, TermColumn> terms;
 
     // delete bitmap
     uint8_t* d_bitmap = nullptr;
@@ -507,6 +514,23 @@ int build_filter(H* h, const gamma_hip_search_params* p, gh::FilterDesc* f, size
         fd.lo_f = ff.lower_f;
         fd.hi_f = ff.upper_f;
     }
+    f->n_term = p->n_term;
+    if (p->n_term < 0 || p->n_term > gh::kMaxTerm || (p->n_term > 0 && !p->term))
+        return fail(h, GAMMA_HIP_EINVAL, "bad term filters");
+    for (int i = 0; i < p->n_term; i++) {
+        const gamma_hip_term_filter& tf = p->term[i];
+        auto it = h->terms.find(tf.field_id);
+        if (it == h->terms.end()) return fail(h, GAMMA_HIP_EINVAL, "term filter on an unknown column");
+        if (tf.n_items < 0 || tf.n_items > gh::kMaxTermItems || tf.op < 0 || tf.op > 2)
+            return fail(h, GAMMA_HIP_EINVAL, "bad term filter");
+        gh::TermDesc& td = f->term[i];
+        td.off = it->second.d_off;
+        td.tok = it->second.d_tok;
+        td.n = it->second.ndocs;
+        td.op = tf.op;
+        td.n_items = tf.n_items;
+        for (int k = 0; k < tf.n_items; k++) td.items[k] = tf.items[k];
+    }
     return GAMMA_HIP_OK;
 }
 
@@ -534,7 +558,7 @@ int filt_ctx_single(H* h, const gh::FilterDesc& f, FiltCtx* c) {
     }
     c->d_tab = h->w_ftab.as<gh::FilterDesc>();
     c->d_qf = nullptr;
-    c->any_clause = f.has_range || f.n_field > 0;
+    c->any_clause = f.has_range || f.n_field > 0 || f.n_term > 0;
     return GAMMA_HIP_OK;
 }
 
@@ -1292,6 +1316,10 @@ int gamma_hip_destroy(gamma_hip_index* h) {
         if (p) (void)hipFree(p);
     for (auto& kv : h->fields)
         if (kv.second.d) (void)hipFree(kv.second.d);
+    for (auto& kv : h->terms) {
+        if (kv.second.d_off) (void)hipFree(kv.second.d_off);
+        if (kv.second.d_tok) (void)hipFree(kv.second.d_tok);
+    }
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
     for (void* pp : h->comb_pin)
         if (pp) (void)hipHostFree(pp);
@@ -1408,6 +1436,64 @@ int64_t gamma_hip_field_count(gamma_hip_index* h, int field_id) {
     std::lock_guard<std::mutex> g(h->mu);
     auto it = h->fields.find(field_id);
     return it == h->fields.end() ? 0 : it->second.n;
+}
+
+int gamma_hip_term_append(gamma_hip_index* h, int field_id, int64_t n_docs, const int32_t* counts,
+                          const int32_t* items) {
+    if (!h || n_docs < 0 || (n_docs > 0 && !counts)) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    GH_CHECK(h, hipSetDevice(h->device));
+    auto& c = h->terms[field_id];
+    int64_t add_tok = 0;
+    for (int64_t i = 0; i < n_docs; i++) {
+        if (counts[i] < 0) return fail(h, GAMMA_HIP_EINVAL, "negative item count");
+        add_tok += counts[i];
+    }
+    if (add_tok > 0 && !items) return fail(h, GAMMA_HIP_EINVAL, "null items");
+    if (c.ndocs + n_docs + 1 > c.cap_docs || c.ntok + add_tok > c.cap_tok || !c.d_off) {
+        // growth frees the old arrays: no search may be reading them
+        GH_CHECK(h, lk.exclusive());
+        const int64_t nd = std::max<int64_t>(c.ndocs + n_docs + 1, std::max<int64_t>(1 << 16, c.cap_docs * 2));
+        const int64_t nt = std::max<int64_t>(c.ntok + add_tok, std::max<int64_t>(1 << 16, c.cap_tok * 2));
+        int64_t* no = nullptr;
+        int32_t* ntk = nullptr;
+        GH_CHECK(h, hipMalloc((void**)&no, (size_t)nd * sizeof(int64_t)));
+        GH_CHECK(h, hipMalloc((void**)&ntk, (size_t)nt * sizeof(int32_t)));
+        if (c.d_off) {
+            GH_CHECK(h, hipMemcpyAsync(no, c.d_off, (size_t)(c.ndocs + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, h->wstream));
+            if (c.ntok) GH_CHECK(h, hipMemcpyAsync(ntk, c.d_tok, (size_t)c.ntok * sizeof(int32_t), hipMemcpyDeviceToDevice, h->wstream));
+        } else {
+            GH_CHECK(h, hipMemsetAsync(no, 0, sizeof(int64_t), h->wstream));   // off[0] = 0
+        }
+        GH_CHECK(h, hipStreamSynchronize(h->wstream));
+        if (c.d_off) (void)hipFree(c.d_off);
+        if (c.d_tok) (void)hipFree(c.d_tok);
+        c.d_off = no;
+        c.d_tok = ntk;
+        c.cap_docs = nd;
+        c.cap_tok = nt;
+    }
+    if (n_docs > 0) {
+        std::vector<int64_t> off(n_docs);
+        int64_t run = c.ntok;
+        for (int64_t i = 0; i < n_docs; i++) {
+            run += counts[i];
+            off[i] = run;
+        }
+        if (add_tok) GH_CHECK(h, hipMemcpyAsync(c.d_tok + c.ntok, items, (size_t)add_tok * sizeof(int32_t), hipMemcpyHostToDevice, h->wstream));
+        GH_CHECK(h, hipMemcpyAsync(c.d_off + c.ndocs + 1, off.data(), (size_t)n_docs * sizeof(int64_t), hipMemcpyHostToDevice, h->wstream));
+        GH_CHECK(h, hipStreamSynchronize(h->wstream));
+        c.ntok += add_tok;
+        c.ndocs += n_docs;   // published last: a search enqueued before sees the shorter column
+    }
+    return GAMMA_HIP_OK;
+}
+
+int64_t gamma_hip_term_count(gamma_hip_index* h, int field_id) {
+    if (!h) return -1;
+    std::lock_guard<std::mutex> g(h->mu);
+    auto it = h->terms.find(field_id);
+    return it == h->terms.end() ? 0 : it->second.ndocs;
 }
 
 int gamma_hip_raw_init(gamma_hip_index* h, int d) {
@@ -2156,7 +2242,7 @@ static void combine_worker(gamma_hip_index* h) {
                     // (IVFPQ only: filtered flat requests are not combined)
                     FiltCtx fc;
                     bool any_filter = false;
-                    for (W* g : cur.grp) any_filter |= g->p->has_range || g->p->n_field > 0;
+                    for (W* g : cur.grp) any_filter |= g->p->has_range || g->p->n_field > 0 || g->p->n_term > 0;
                     const bool multi = !flat && any_filter && cur.grp.size() > 1;
                     if (cur.rc == GAMMA_HIP_OK && multi) cur.rc = build_group_filters(h, cur.grp, total, cur.ftab, cur.qf, &fc);
                     if (cur.rc == GAMMA_HIP_OK)
@@ -2249,7 +2335,8 @@ int gamma_hip_ivfpq_search(gamma_hip_index* h, const gamma_hip_search_params* p,
     if (!h) return GAMMA_HIP_EINVAL;
     if (h->combine && p && nq > 0 && nq <= COMB_MAX_NQ && k > 0 && x && distances && labels && h->ivf_init && h->d > 0 &&
         (!p->has_range || (p->n_range >= 0 && p->n_range <= gh::kMaxRange && (p->n_range == 0 || p->range))) &&
-        p->n_field >= 0 && p->n_field <= gh::kMaxField && (p->n_field == 0 || p->field))
+        p->n_field >= 0 && p->n_field <= gh::kMaxField && (p->n_field == 0 || p->field) &&
+        p->n_term >= 0 && p->n_term <= gh::kMaxTerm && (p->n_term == 0 || p->term))
         return combined_search(h, p, nq, x, k, distances, labels);
     return ivfpq_search_host_locked(h, p, nq, x, k, distances, labels);
 }
@@ -2402,7 +2489,7 @@ int gamma_hip_flat_search(gamma_hip_index* h, const gamma_hip_search_params* p, 
     if (!h) return GAMMA_HIP_EINVAL;
     // small unfiltered calls from concurrent client threads share device batches (see gamma_hip_ivfpq_search)
     if (h->combine && p && nq > 0 && nq <= COMB_MAX_NQ && k > 0 && x && distances && labels && h->raw_d > 0 &&
-        !p->has_range && p->n_range == 0 && p->n_field == 0)
+        !p->has_range && p->n_range == 0 && p->n_field == 0 && p->n_term == 0)
         return combined_search(h, p, nq, x, k, distances, labels, /*kind=*/1);
     return flat_search_host_locked(h, p, nq, x, k, distances, labels);
 }
@@ -2415,6 +2502,7 @@ int64_t gamma_hip_total_mem_bytes(gamma_hip_index* h) {
     b += h->raw_cap * h->raw_d * (int64_t)sizeof(float);
     b += (int64_t)h->bitmap_cap_bytes;
     for (auto& kv : h->fields) b += kv.second.cap * (int64_t)field_elem_size(kv.second.dtype);
+    for (auto& kv : h->terms) b += kv.second.cap_docs * 8 + kv.second.cap_tok * 4;
     if (h->ivf_init) {
         b += (int64_t)h->nlist * h->d * 4 + (int64_t)h->nlist * 4 + (int64_t)h->M * 256 * h->dsub * 4;
         b += (int64_t)h->nlist * h->M * 256 * 4;

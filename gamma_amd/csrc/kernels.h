@@ -24,14 +24,26 @@ struct FieldDesc {
     double lo_f, hi_f;
 };
 
+// term filter on a STRING field (FilteredByTermFilter, index/impl/gpu/gamma_index_ivfpq_gpu.cc:727-762): the
+// field's items (split at \001) are dictionary-encoded on the host; doc i holds tok[off[i] .. off[i + 1])
+constexpr int kMaxTerm = 4, kMaxTermItems = 8;
+struct TermDesc {
+    const int64_t* off;
+    const int32_t* tok;
+    int64_t n;              // docs in the column
+    int32_t op, n_items;    // FilterOperator (table/field_range_index.h:23): 0 And, 1 Or, 2 Not
+    int32_t items[kMaxTermItems];   // -1: an item no doc has
+};
+
 // everything GammaSearchCondition::IsValid reads (common/gamma_common_data.h:99-108)
 struct FilterDesc {
     const uint8_t* del_bitmap;
     int64_t del_bits;
     int32_t has_range, n_range;
     RangeDesc range[kMaxRange];
-    int32_t n_field, pad;
+    int32_t n_field, n_term;
     FieldDesc field[kMaxField];
+    TermDesc term[kMaxTerm];
 };
 
 void launch_pairwise(hipStream_t s, bool l2, const float* x, int nq, int d, const float* y,

@@ -1,5 +1,11 @@
 // filter_bridge.h -- GammaSearchCondition's range filter -> gamma_hip_range_filter[]
 #pragma once
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <string>
 #include <vector>
 
 #include "../../include/gamma_hip.h"
@@ -8,7 +14,7 @@
 namespace tig_gamma {
 // translate the engine's per-request filter (table/range_query_result.h) into the C ABI's POD
 // descriptors; the bitmaps stay owned by the MultiRangeQueryResults
-static void FillRangeFilters(GammaSearchCondition *cond, gamma_hip_search_params &p,
+inline void FillRangeFilters(GammaSearchCondition *cond, gamma_hip_search_params &p,
                              std::vector<gamma_hip_range_filter> &rf) {
   if (!cond || !cond->range_query_result) return;
   p.has_range = 1;
@@ -29,5 +35,141 @@ static void FillRangeFilters(GammaSearchCondition *cond, gamma_hip_search_params
   p.n_range = (int)rf.size();
   p.range = rf.data();
 }
+
+// ---- scalar filters evaluated ON the device (retrieval_param "device_filters": 1) ------------------------------
+// The engine hands every request its filters twice: flattened into docid bitmaps (range_query_result, what the
+// CPU models test per scanned code) and as the client sent them -- range_filters, term_filters, table
+// (search/gamma_engine.cc:355-357; the reference's own GPU model evaluates those per candidate against the
+// Table, index/impl/gpu/gamma_index_ivfpq_gpu.cc:646-762).  DeviceColumns keeps a mirror of the filtered
+// fields in HBM -- numeric columns as they are, STRING columns as dictionary-encoded item lists -- and turns a
+// request's filters into the C ABI's clauses; the scan then evaluates them per code with the reference GPU
+// model's rules, and nothing docs/8 bytes long is uploaded per request.
+// The mirror is fed lazily: a field is read from the Table (GetFieldRawValue) up to the current doc count the
+// first time a filter names it, and extended by the docs added since on every later request.  Field values
+// rewritten in place by a doc update are not re-read (the reference's GPU model reads the Table per candidate).
+class DeviceColumns {
+ public:
+  // false: this request cannot take the device path (no table, too many clauses, unknown field, ...): use the bitmaps
+  bool Prepare(gamma_hip_index *h, GammaSearchCondition *cond, int64_t ndocs, gamma_hip_search_params &p,
+               std::vector<gamma_hip_field_filter> &ff, std::vector<gamma_hip_term_filter> &tf) {
+    if (!cond || !cond->table) return false;
+    if (cond->range_filters.empty() && cond->term_filters.empty()) return false;
+    if (cond->range_filters.size() > GAMMA_HIP_MAX_FIELD_FILTERS || cond->term_filters.size() > GAMMA_HIP_MAX_TERM_FILTERS)
+      return false;
+    std::lock_guard<std::mutex> g(mu_);
+    Table *t = cond->table;
+    for (auto &r : cond->range_filters) {
+      DataType type;
+      if (t->GetFieldType(r.field, type) || type == DataType::STRING || type == DataType::VECTOR) return false;
+      const int fid = t->GetAttrIdx(r.field);
+      if (fid < 0 || Sync(h, t, fid, type, ndocs)) return false;
+      gamma_hip_field_filter f;
+      memset(&f, 0, sizeof(f));
+      f.field_id = fid;
+      f.include_lower = r.include_lower ? 1 : 0;
+      f.include_upper = r.include_upper ? 1 : 0;
+      if (type == DataType::INT) {
+        int lo = 0, hi = 0;
+        memcpy(&lo, r.lower_value.data(), std::min(sizeof(lo), r.lower_value.size()));
+        memcpy(&hi, r.upper_value.data(), std::min(sizeof(hi), r.upper_value.size()));
+        f.lower_i = lo;
+        f.upper_i = hi;
+      } else if (type == DataType::LONG) {
+        memcpy(&f.lower_i, r.lower_value.data(), std::min(sizeof(f.lower_i), r.lower_value.size()));
+        memcpy(&f.upper_i, r.upper_value.data(), std::min(sizeof(f.upper_i), r.upper_value.size()));
+      } else if (type == DataType::FLOAT) {
+        float lo = 0, hi = 0;
+        memcpy(&lo, r.lower_value.data(), std::min(sizeof(lo), r.lower_value.size()));
+        memcpy(&hi, r.upper_value.data(), std::min(sizeof(hi), r.upper_value.size()));
+        f.lower_f = lo;
+        f.upper_f = hi;
+      } else {
+        memcpy(&f.lower_f, r.lower_value.data(), std::min(sizeof(f.lower_f), r.lower_value.size()));
+        memcpy(&f.upper_f, r.upper_value.data(), std::min(sizeof(f.upper_f), r.upper_value.size()));
+      }
+      ff.push_back(f);
+    }
+    for (auto &tm : cond->term_filters) {
+      DataType type;
+      if (t->GetFieldType(tm.field, type) || type != DataType::STRING) return false;
+      const int fid = t->GetAttrIdx(tm.field);
+      if (fid < 0 || Sync(h, t, fid, type, ndocs)) return false;
+      std::vector<std::string> items = Split(tm.value);
+      if (items.size() > GAMMA_HIP_MAX_TERM_ITEMS) return false;
+      gamma_hip_term_filter f;
+      memset(&f, 0, sizeof(f));
+      f.field_id = fid;
+      f.op = tm.is_union;
+      f.n_items = (int)items.size();
+      auto &dict = fields_[fid].dict;
+      for (size_t k = 0; k < items.size(); k++) {
+        auto it = dict.find(items[k]);
+        f.items[k] = it == dict.end() ? -1 : it->second;   // an item no doc carries
+      }
+      tf.push_back(f);
+    }
+    p.has_range = 0;   // the clauses replace the request's docid bitmaps
+    p.n_range = 0;
+    p.range = nullptr;
+    p.n_field = (int)ff.size();
+    p.field = ff.empty() ? nullptr : ff.data();
+    p.n_term = (int)tf.size();
+    p.term = tf.empty() ? nullptr : tf.data();
+    return true;
+  }
+
+ private:
+  struct Field {
+    int64_t synced = 0;
+    std::map<std::string, int> dict;   // STRING fields: item -> id
+  };
+  static std::vector<std::string> Split(const std::string &v) {   // utils::split(v, "\001") of the reference
+    std::vector<std::string> out;
+    size_t a = 0;
+    while (a <= v.size()) {
+      size_t b = v.find('\001', a);
+      if (b == std::string::npos) b = v.size();
+      if (b > a) out.push_back(v.substr(a, b - a));
+      a = b + 1;
+    }
+    return out;
+  }
+  int Sync(gamma_hip_index *h, Table *t, int fid, DataType type, int64_t ndocs) {
+    Field &f = fields_[fid];
+    if (f.synced >= ndocs) return 0;
+    const int64_t n = ndocs - f.synced;
+    std::string raw;
+    if (type == DataType::STRING) {
+      std::vector<int32_t> counts(n), items;
+      for (int64_t i = 0; i < n; i++) {
+        raw.clear();
+        t->GetFieldRawValue((int)(f.synced + i), fid, raw);
+        std::vector<std::string> its = Split(raw);
+        counts[i] = (int32_t)its.size();
+        for (auto &s : its) {
+          auto it = f.dict.find(s);
+          if (it == f.dict.end()) it = f.dict.emplace(s, (int)f.dict.size()).first;
+          items.push_back(it->second);
+        }
+      }
+      if (gamma_hip_term_append(h, fid, n, counts.data(), items.data())) return -1;
+    } else {
+      const int dt = type == DataType::INT ? GAMMA_HIP_FIELD_INT : type == DataType::LONG ? GAMMA_HIP_FIELD_LONG
+                   : type == DataType::FLOAT ? GAMMA_HIP_FIELD_FLOAT : GAMMA_HIP_FIELD_DOUBLE;
+      const size_t es = (dt == GAMMA_HIP_FIELD_INT || dt == GAMMA_HIP_FIELD_FLOAT) ? 4 : 8;
+      std::vector<uint8_t> buf((size_t)n * es, 0);
+      for (int64_t i = 0; i < n; i++) {
+        raw.clear();
+        t->GetFieldRawValue((int)(f.synced + i), fid, raw);
+        memcpy(&buf[(size_t)i * es], raw.data(), std::min(es, raw.size()));
+      }
+      if (gamma_hip_field_append(h, fid, dt, n, buf.data())) return -1;
+    }
+    f.synced = ndocs;
+    return 0;
+  }
+  std::mutex mu_;
+  std::map<int, Field> fields_;
+};
 
 }  // namespace tig_gamma

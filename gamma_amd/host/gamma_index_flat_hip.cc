@@ -30,6 +30,8 @@ int GammaFLATHIPIndex::Init(const std::string &model_parameters, int indexing_si
       if (strcasecmp("L2", mt.c_str()) && strcasecmp("InnerProduct", mt.c_str())) return -1;
       metric_type_ = !strcasecmp("L2", mt.c_str()) ? DistanceComputeType::L2 : DistanceComputeType::INNER_PRODUCT;
     }
+    int v = 0;
+    if (!jp.GetInt("device_filters", v)) device_filters_ = v != 0;   // HIP only, see filter_bridge.h
   }
   d_ = vector_->MetaInfo()->Dimension();
   const char *dev = getenv("GAMMA_HIP_DEVICE");
@@ -108,7 +110,10 @@ int GammaFLATHIPIndex::Search(RetrievalContext *retrieval_context, int n, const 
   p.min_score = cond ? cond->min_score : std::numeric_limits<float>::min();
   p.max_score = cond ? cond->max_score : std::numeric_limits<float>::max();
   std::vector<gamma_hip_range_filter> rf;
-  FillRangeFilters(cond, p, rf);
+  std::vector<gamma_hip_field_filter> ff;
+  std::vector<gamma_hip_term_filter> tf;
+  if (!(device_filters_ && columns_.Prepare(h_, cond, (int64_t)vector_->MetaInfo()->Size(), p, ff, tf)))
+    FillRangeFilters(cond, p, rf);
   return gamma_hip_flat_search(h_, &p, n, reinterpret_cast<const float *>(x), k, distances, ids);
 }
 

@@ -8,6 +8,7 @@
 
 #include "../../include/gamma_hip.h"
 #include "plugin_includes.h"
+#include "filter_bridge.h"
 
 namespace tig_gamma {
 
@@ -45,6 +46,8 @@ class GammaFLATHIPIndex : public RetrievalModel {
   int d_ = 0;
   int64_t uploaded_ = 0;
   std::mutex raw_mu_;   // uploaded_ + the mirror writes
+  bool device_filters_ = false;
+  DeviceColumns columns_;
 };
 
 }  // namespace tig_gamma

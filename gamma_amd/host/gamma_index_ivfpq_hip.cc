@@ -2,7 +2,6 @@
 // training driver, bookkeeping; every distance / scan / selection runs in libgamma_hip.so.
 #include "gamma_index_ivfpq_hip.h"
 
-#include "filter_bridge.h"
 #include "iwpq_io.h"
 
 #include <errno.h>
@@ -60,6 +59,7 @@ int HIPIVFPQModelParams::Parse(const char *str) {
     }
   }
   if (!jp.GetInt("support_indivisible_nsubvector", v)) support_indivisible_nsubvector = v != 0;
+  if (!jp.GetInt("device_filters", v)) device_filters = v != 0;
   if (!jp.GetInt("bucket_init_size", v)) {
     if (v < -1) return -1;
     if (v > 0) bucket_init_size = v;
@@ -309,7 +309,13 @@ int GammaIVFPQHIPIndex::Search(RetrievalContext *retrieval_context, int n, const
   p.max_score = cond ? cond->max_score : std::numeric_limits<float>::max();
   p.coarse_mode = -1;
   std::vector<gamma_hip_range_filter> rf;
-  FillRangeFilters(cond, p, rf);
+  std::vector<gamma_hip_field_filter> ff;
+  std::vector<gamma_hip_term_filter> tf;
+  // scalar filters: on the device against mirrored columns when asked for and possible, else the request's
+  // flattened docid bitmaps as the CPU models take them
+  if (!(model_param_ && model_param_->device_filters &&
+        columns_.Prepare(h_, cond, (int64_t)vector_->MetaInfo()->Size(), p, ff, tf)))
+    FillRangeFilters(cond, p, rf);
   const float *xq = reinterpret_cast<const float *>(x);
   int rc;
   if ((cond && cond->brute_force_search) || !is_trained_) {

@@ -15,6 +15,7 @@
 
 #include "../../include/gamma_hip.h"
 #include "plugin_includes.h"
+#include "filter_bridge.h"
 
 namespace tig_gamma {
 
@@ -47,6 +48,7 @@ struct HIPIVFPQModelParams {
   bool has_opq = false;
   int bucket_init_size = 1000;
   int bucket_max_size = 1280000;
+  bool device_filters = false;   // HIP only: evaluate range / term filters on device-resident columns (filter_bridge.h)
   int Parse(const char *str);   // 0 ok, -1 bad (same rules as gamma_index_ivfpq.h:708-851)
 };
 
@@ -81,6 +83,7 @@ class GammaIVFPQHIPIndex : public RetrievalModel {
   int EnsureRaw(int64_t upto);
   int UploadEngineBitmap();
   std::mutex raw_mu_;   // raw_uploaded_ + the mirror writes (Search threads, the indexing thread, Load)
+  DeviceColumns columns_;
   gamma_hip_index *h_ = nullptr;
   HIPIVFPQModelParams *model_param_ = nullptr;
   int64_t raw_uploaded_ = 0;

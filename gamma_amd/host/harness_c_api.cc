@@ -52,6 +52,7 @@ class MemVectorReader : public RawVector {
 struct Host {
   MemVectorReader *store;
   RetrievalModel *model;
+  Table table;   // the scalar fields of the docs (device filters read it through GammaSearchCondition::table)
 };
 }  // namespace
 
@@ -60,7 +61,7 @@ extern "C" {
 void *gh_host_new(const char *retrieval_type, int d) {
   RetrievalModel *m = reflector().GetNewModel(retrieval_type);
   if (!m) return nullptr;
-  Host *h = new Host{new MemVectorReader(d), m};
+  Host *h = new Host{new MemVectorReader(d), m, Table()};
   m->vector_ = h->store;
   return h;
 }
@@ -251,6 +252,51 @@ int gh_host_concurrent_filtered_check(void *hp, const char *retrieval_params, in
         bad++;
     }
   return bad;
+}
+// ---- scalar fields + requests that carry their filters as the client sent them ----
+int gh_host_table_add_field(void *hp, const char *name, int data_type) {
+  return ((Host *)hp)->table.AddField(name, (DataType)data_type);
+}
+// n more docs' raw values of one field: numeric = n * elem bytes; STRING = concatenated, lens[i] bytes each
+void gh_host_table_append(void *hp, int field_id, int n, const uint8_t *raw, int elem, const int *lens) {
+  Host *h = (Host *)hp;
+  size_t off = 0;
+  for (int i = 0; i < n; i++) {
+    const int len = lens ? lens[i] : elem;
+    h->table.AppendValue(field_id, std::string(reinterpret_cast<const char *>(raw) + off, (size_t)len));
+    off += (size_t)len;
+  }
+}
+struct HRange {
+  const char *field;
+  const uint8_t *lower, *upper;
+  int nbytes, include_lower, include_upper;
+};
+struct HTerm {
+  const char *field, *value;
+  int value_len, is_union;
+};
+int gh_host_search_scalar(void *hp, const char *retrieval_params, int has_rank, int brute_force, int n, const float *x,
+                          int k, float *distances, int64_t *ids, int n_range, const HRange *rg, int n_term,
+                          const HTerm *tm) {
+  Host *h = (Host *)hp;
+  PerfTool perf;
+  GammaSearchCondition cond(&perf);
+  cond.topn = k;
+  cond.has_rank = has_rank != 0;
+  cond.brute_force_search = brute_force != 0;
+  cond.min_score = -1e30f;
+  cond.max_score = 1e30f;
+  cond.table = &h->table;
+  for (int i = 0; i < n_range; i++)
+    cond.range_filters.push_back(RangeFilter{rg[i].field, std::string((const char *)rg[i].lower, rg[i].nbytes),
+                                             std::string((const char *)rg[i].upper, rg[i].nbytes),
+                                             rg[i].include_lower != 0, rg[i].include_upper != 0});
+  for (int i = 0; i < n_term; i++)
+    cond.term_filters.push_back(TermFilter{tm[i].field, std::string(tm[i].value, tm[i].value_len), tm[i].is_union});
+  cond.retrieval_params_ = h->model->Parse(retrieval_params);
+  if (!cond.retrieval_params_) return -100;
+  return h->model->Search(&cond, n, reinterpret_cast<const uint8_t *>(x), k, distances, ids);
 }
 int gh_host_dump(void *hp, const char *dir) { return ((Host *)hp)->model->Dump(dir); }
 int gh_host_load(void *hp, const char *dir) { return ((Host *)hp)->model->Load(dir); }

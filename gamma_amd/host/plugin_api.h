@@ -327,6 +327,65 @@ class MultiRangeQueryResults {
   std::vector<RangeQueryResult> all_results_;
 };
 
+}  // namespace tig_gamma
+
+// ---- scalar side of a request: the filters as the client sent them + the table they refer to -----------------
+// (c_api/api_data/gamma_table.h:20-27, common/common_query_data.h:9-21, table/table.h:100-120).  The engine fills
+// these next to range_query_result for every request (search/gamma_engine.cc:355-357); the reference's GPU model
+// and the HIP plugins' device filters (filter_bridge.h) read them.
+enum class DataType : std::uint16_t { INT = 0, LONG, FLOAT, DOUBLE, STRING, VECTOR };
+
+namespace tig_gamma {
+
+struct TermFilter {
+  std::string field;
+  std::string value;   // items separated by \001
+  int is_union;        // FilterOperator: 0 And, 1 Or, 2 Not (table/field_range_index.h:23)
+};
+
+struct RangeFilter {
+  std::string field;
+  std::string lower_value;   // raw bytes of the field's type
+  std::string upper_value;
+  bool include_lower;
+  bool include_upper;
+};
+
+// Table, the three accessors a model may use (table/table.h:105-120); in-memory stand-in for the standalone build
+class Table {
+ public:
+  int AddField(const std::string &name, DataType type) {
+    names_.push_back(name);
+    types_.push_back(type);
+    values_.emplace_back();
+    return (int)names_.size() - 1;
+  }
+  void AppendValue(int field_id, const std::string &raw) { values_[field_id].push_back(raw); }
+  int GetFieldType(const std::string &field, DataType &type) {
+    const int i = GetAttrIdx(field);
+    if (i < 0) return -1;
+    type = types_[i];
+    return 0;
+  }
+  int GetAttrIdx(const std::string &field) const {
+    for (size_t i = 0; i < names_.size(); i++)
+      if (names_[i] == field) return (int)i;
+    return -1;
+  }
+  int GetFieldRawValue(int docid, int field_id, std::string &value, const uint8_t *doc_v = nullptr) {
+    (void)doc_v;
+    if (field_id < 0 || (size_t)field_id >= values_.size() || docid < 0 || (size_t)docid >= values_[field_id].size())
+      return -1;
+    value = values_[field_id][docid];
+    return 0;
+  }
+
+ private:
+  std::vector<std::string> names_;
+  std::vector<DataType> types_;
+  std::vector<std::vector<std::string>> values_;
+};
+
 // GammaSearchCondition (common/gamma_common_data.h:39-124), boundary members only
 class GammaSearchCondition : public RetrievalContext {
  public:
@@ -340,6 +399,7 @@ class GammaSearchCondition : public RetrievalContext {
     perf_tool_ = perf_tool;
     docids_bitmap = nullptr;
     docids_bitmap_bits = 0;
+    table = nullptr;
   }
   bool IsSimilarScoreValid(float score) const override { return (score <= max_score) && (score >= min_score); }
   bool IsValid(int id) const override {
@@ -349,6 +409,9 @@ class GammaSearchCondition : public RetrievalContext {
     return true;
   }
   MultiRangeQueryResults *range_query_result;
+  std::vector<struct RangeFilter> range_filters;
+  std::vector<struct TermFilter> term_filters;
+  Table *table;
   int topn;
   bool brute_force_search;
   bool has_rank;

@@ -35,6 +35,10 @@ HOST_SYMBOLS = {
                                                 C.c_int, C.c_int, C.c_int, f32p]),
     "gh_host_concurrent_filtered_check": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, f32p, C.c_int,
                                                     C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "gh_host_table_add_field": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "gh_host_table_append": (None, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "gh_host_search_scalar": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p, i64p,
+                                        C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "gh_host_dump": (C.c_int, [C.c_void_p, C.c_char_p]),
     "gh_host_load": (C.c_int, [C.c_void_p, C.c_char_p]),
     "gh_host_mem_bytes": (C.c_long, [C.c_void_p]),
@@ -193,6 +197,59 @@ class PluginModel:
             return D, I
         rc = self.L.gh_host_search(self.h, retrieval_params.encode(), int(has_rank), int(brute_force),
                                    min_score, max_score, n, _f(xq), k, _f(D), I.ctypes.data_as(i64p))
+        if rc:
+            raise _lib.GammaHipError("Search returned %d" % rc)
+        return D, I
+
+    # ---- scalar fields + filters as the client sends them (GammaSearchCondition::range_filters / term_filters) ----
+    DT = {"int": 0, "long": 1, "float": 2, "double": 3, "string": 4}
+    _NP = {0: np.int32, 1: np.int64, 2: np.float32, 3: np.float64}
+
+    def table_add_field(self, name, dtype):
+        fid = self.L.gh_host_table_add_field(self.h, name.encode(), self.DT[dtype])
+        self.__dict__.setdefault("_ftypes", {})[name] = (fid, self.DT[dtype])
+        return fid
+
+    def table_append(self, name, values):
+        """numeric: array of the field's type; string: list of lists of items (joined with \\001 as the engine does)"""
+        fid, dt = self._ftypes[name]
+        if dt == 4:
+            raws = [b"\x01".join(s.encode() for s in items) for items in values]
+            lens = (C.c_int * len(raws))(*[len(r) for r in raws])
+            blob = b"".join(raws)
+            self.L.gh_host_table_append(self.h, fid, len(raws), C.c_char_p(blob), 0, lens)
+        else:
+            v = np.ascontiguousarray(values, dtype=self._NP[dt])
+            self.L.gh_host_table_append(self.h, fid, v.size, v.ctypes.data, v.itemsize, None)
+
+    def search_scalar(self, xq, k, retrieval_params="", has_rank=True, brute_force=False, ranges=(), terms=()):
+        """ranges: (field, lower, upper, include_lower, include_upper); terms: (field, [items], op 0 And / 1 Or / 2 Not)"""
+        class HRange(C.Structure):
+            _fields_ = [("field", C.c_char_p), ("lower", C.c_void_p), ("upper", C.c_void_p), ("nbytes", C.c_int),
+                        ("include_lower", C.c_int), ("include_upper", C.c_int)]
+
+        class HTerm(C.Structure):
+            _fields_ = [("field", C.c_char_p), ("value", C.c_char_p), ("value_len", C.c_int), ("is_union", C.c_int)]
+
+        keep = []
+        ra = (HRange * max(1, len(ranges)))()
+        for i, (f, lo, hi, il, iu) in enumerate(ranges):
+            npt = self._NP[self._ftypes[f][1]]
+            lo_a, hi_a = np.array([lo], dtype=npt), np.array([hi], dtype=npt)
+            keep += [lo_a, hi_a]
+            ra[i] = HRange(f.encode(), lo_a.ctypes.data, hi_a.ctypes.data, lo_a.itemsize, int(il), int(iu))
+        ta = (HTerm * max(1, len(terms)))()
+        for i, (f, items, op) in enumerate(terms):
+            v = b"\x01".join(s.encode() for s in items)
+            keep.append(v)
+            ta[i] = HTerm(f.encode(), v, len(v), op)
+        xq = np.ascontiguousarray(xq, np.float32)
+        n = xq.shape[0]
+        D = np.empty((n, k), np.float32)
+        I = np.empty((n, k), np.int64)
+        rc = self.L.gh_host_search_scalar(self.h, retrieval_params.encode(), int(has_rank), int(brute_force), n, _f(xq), k,
+                                          _f(D), I.ctypes.data_as(i64p), len(ranges), C.cast(ra, C.c_void_p),
+                                          len(terms), C.cast(ta, C.c_void_p))
         if rc:
             raise _lib.GammaHipError("Search returned %d" % rc)
         return D, I

@@ -69,6 +69,24 @@ typedef struct {
     double lower_f, upper_f;
 } gamma_hip_field_filter;
 
+/* Term filter on a STRING field evaluated on the device (GammaSearchCondition::term_filters; semantics of
+ * FilteredByTermFilter, index/impl/gpu/gamma_index_ivfpq_gpu.cc:727-762: the field value and the filter value
+ * are lists of items separated by \001; is_union Or = any filter item among the doc's items, And = all of
+ * them; Not (FilterOperator::Not, table/field_range_index.h:23) = none).  Items are dictionary-encoded by the
+ * caller (the plugin keeps the dictionary, gamma_amd/host/filter_bridge.h); an item the dictionary does not
+ * know is passed as -1.  The doc's items live in HBM (gamma_hip_term_append). */
+#define GAMMA_HIP_MAX_TERM_FILTERS 4
+#define GAMMA_HIP_MAX_TERM_ITEMS 8
+#define GAMMA_HIP_TERM_AND 0
+#define GAMMA_HIP_TERM_OR 1
+#define GAMMA_HIP_TERM_NOT 2
+typedef struct {
+    int32_t field_id;
+    int32_t op;        /* TermFilter::is_union as the reference passes it: 0 And, 1 Or, 2 Not */
+    int32_t n_items;
+    int32_t items[GAMMA_HIP_MAX_TERM_ITEMS];
+} gamma_hip_term_filter;
+
 /* What GammaSearchCondition + IVFPQRetrievalParameters carry into Search()
  * (common/gamma_common_data.h:39-124, index/impl/gamma_index_ivfpq.h:629-673). */
 typedef struct {
@@ -84,8 +102,9 @@ typedef struct {
     int32_t n_range;      /* number of RangeQueryResult; 0 with has_range => nothing valid */
     const gamma_hip_range_filter* range;
     int32_t n_field;      /* GammaSearchCondition::range_filters evaluated on device columns */
-    int32_t reserved;
+    int32_t n_term;       /* GammaSearchCondition::term_filters evaluated on device columns */
     const gamma_hip_field_filter* field;
+    const gamma_hip_term_filter* term;
 } gamma_hip_search_params;
 
 /* ---- lifecycle ------------------------------------------------------------------- */
@@ -127,6 +146,11 @@ int gamma_hip_tie_stats(gamma_hip_index* h, int64_t* out3, int reset);
 int gamma_hip_field_append(gamma_hip_index* h, int field_id, int dtype, int64_t n, const void* values);
 int gamma_hip_field_update(gamma_hip_index* h, int field_id, int64_t docid, const void* value);
 int64_t gamma_hip_field_count(gamma_hip_index* h, int field_id);
+/* STRING columns for on-device term filters: n more docs (docid = row), doc i with counts[i] dictionary-encoded
+ * items, all items concatenated in `items` (Table::Add -> the plugin's dictionary, filter_bridge.h) */
+int gamma_hip_term_append(gamma_hip_index* h, int field_id, int64_t n_docs, const int32_t* counts,
+                          const int32_t* items);
+int64_t gamma_hip_term_count(gamma_hip_index* h, int field_id);
 
 /* ---- raw vector store (VectorReader::Gets / MemoryRawVector, vector/raw_vector.cc:99-109,
  *      vector/memory_raw_vector.cc:90-142): device mirror, vid = row ------------------- */

@@ -955,3 +955,67 @@ def test_list_major_scan_matches_the_default_schedule(metric):
             g.bitmap_set(dead, 1)     # second round: ids are read, deleted docs filtered
     finally:
         g.close()
+
+
+def _term_mask(doc_items, items, op):
+    want = set(items)
+    if op == 1:
+        return np.array([bool(want & set(d)) for d in doc_items])
+    if op == 2:
+        return np.array([not (want & set(d)) for d in doc_items])
+    return np.array([want <= set(d) for d in doc_items])
+
+
+def test_term_filters_on_device(case):
+    """Term (tag) filters over dictionary-encoded item lists in HBM == the same selection handed over as a
+    docid bitmap.  And = every item present (index/impl/gpu/gamma_index_ivfpq_gpu.cc:728-760), Or = any,
+    Not = none of them (table/field_range_index.cc:1052-1056, SetNotIn); an item no doc carries is -1;
+    docs beyond the column match no clause (as for numeric columns); clauses AND with each other and with numeric clauses."""
+    N = case["N"]
+    rng = np.random.default_rng(23)
+    n_tags = 12
+    counts = rng.integers(0, 4, size=N - 300).astype(np.int32)      # 300 docs short
+    items = rng.integers(0, n_tags, size=int(counts.sum())).astype(np.int32)
+    price = rng.integers(0, 1000, size=N).astype(np.int64)
+    g = fixtures.load_hip(case)
+    off = np.concatenate([[0], np.cumsum(counts)])
+    doc_items = [items[off[i]:off[i + 1]].tolist() for i in range(N - 300)]
+    half = (N - 300) // 2
+    g.term_append(5, doc_items[:half])
+    g.term_append(5, doc_items[half:])                               # grows
+    g.field_append(1, price)
+    assert g.term_count(5) == N - 300
+    doc_items += [[] for _ in range(300)]
+    cases = [
+        ([(5, 1, [3])], []),
+        ([(5, 0, [3, 7])], []),
+        ([(5, 1, [1, 2, 9])], []),
+        ([(5, 2, [0, 4])], []),
+        ([(5, 1, [2, -1])], []),                                   # -1: an item no doc carries
+        ([(5, 0, [2, -1])], []),                                   # And with an unknown item: nothing
+        ([(5, 1, [6]), (5, 2, [8])], []),
+        ([(5, 1, [1, 5])], [(1, 200, 700, True, False)]),
+    ]
+    q = case["q"]
+    for terms, fields in cases:
+        mask = np.ones(N, bool)
+        for fid, op, its in terms:
+            mask &= _term_mask(doc_items, its, op)
+            mask[N - 300:] = False          # beyond the column: no clause matches, Not included
+        for fid, lo, hi, il, iu in fields:
+            mask &= (price >= lo) & (price < hi)
+        docs = np.nonzero(mask)[0]
+        for has_rank in (True, False):
+            (D, I, st), _ = run_both(case, g, q, 10, 8, 100, B.METRIC_L2, has_rank, range_docs=[docs])
+            args = api.SearchArgs(metric=api.METRIC_L2, nprobe=8, recall_num=100, has_rank=has_rank, coarse_mode=0,
+                                  term_filters=terms, field_filters=fields or None, **WIDE)
+            Dg, Ig = g.ivfpq_search(q, 10, args)
+            compare_topk(D, I, Dg, Ig)
+        Df, If = B.flat_search(case["base"], q[:8], 10, B.METRIC_L2,
+                               B.make_ctx(range_filters=[B.make_range_filter(docs)], **WIDE))
+        Dg, Ig = g.flat_search(q[:8], 10, api.SearchArgs(metric=api.METRIC_L2, term_filters=terms,
+                                                         field_filters=fields or None, **WIDE))
+        compare_topk(Df, If, Dg, Ig)
+    with pytest.raises(api.GammaHipError):      # unknown column
+        g.ivfpq_search(q, 10, api.SearchArgs(metric=api.METRIC_L2, nprobe=8, term_filters=[(77, 1, [1])], **WIDE))
+    g.close()

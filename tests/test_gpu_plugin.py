@@ -309,3 +309,86 @@ def test_load_restores_the_delete_bitmap(case, tmp_path, model):
     assert not np.isin(I2, dead).any()
     assert D1.tobytes() == D2.tobytes() and np.array_equal(I1, I2)
     m2.close()
+
+
+@pytest.mark.parametrize("model", ["HIPIVFPQ", "HIPFLAT"])
+def test_plugin_device_filters_from_the_table(case, model):
+    """"device_filters": 1 -- the request's range_filters / term_filters are evaluated per scanned code against
+    HBM mirrors of the Table's fields (filter_bridge.h DeviceColumns; the reference's GPU model reads the Table
+    per candidate, index/impl/gpu/gamma_index_ivfpq_gpu.cc:646-762).  Same results as the docid-bitmap form of
+    the same selection; the mirror follows docs added later."""
+    from gamma_amd import plugin
+    base, q = case["base"], case["q"]
+    N = len(base)
+    if model == "HIPIVFPQ":
+        m = plugin.PluginModel("HIPIVFPQ", case["d"],
+                               '{"ncentroids": %d, "nsubvector": %d, "nprobe": 8, "metric_type": "L2", '
+                               '"device_filters": 1}' % (case["nlist"], case["M"]), indexing_size=5000)
+    else:
+        m = plugin.PluginModel("HIPFLAT", case["d"], '{"metric_type": "L2", "device_filters": 1}')
+    rng = np.random.default_rng(41)
+    price = rng.integers(0, 1000, size=N).astype(np.int32)
+    weight = rng.random(N)
+    tags = ["red", "green", "blue", "cyan", "pink", "grey"]
+    doc_tags = [list(rng.choice(tags, size=int(rng.integers(0, 4)), replace=False)) for _ in range(N)]
+    m.table_add_field("price", "int")
+    m.table_add_field("weight", "double")
+    m.table_add_field("tags", "string")
+    first = N // 2
+
+    def feed(a, b):
+        m.table_append("price", price[a:b])
+        m.table_append("weight", weight[a:b])
+        m.table_append("tags", doc_tags[a:b])
+
+    o2 = None
+    if model == "HIPIVFPQ":
+        assert m.set_trained(case["cc"], case["pq"]) == 0
+        o2 = B.OracleIVFPQ(case["d"], case["nlist"], case["M"], 8, B.METRIC_L2)
+        o2.set_trained(case["cc"], case["pq"], None)
+    sel = [
+        dict(ranges=[("price", 100, 600, True, False)], terms=[]),
+        dict(ranges=[], terms=[("tags", ["red", "blue"], 1)]),
+        dict(ranges=[("weight", 0.1, 0.8, False, True)], terms=[("tags", ["green"], 0), ("tags", ["pink"], 2)]),
+        dict(ranges=[], terms=[("tags", ["red", "mauve"], 1)]),       # an item no doc carries
+        dict(ranges=[], terms=[("tags", ["red", "mauve"], 0)]),       # And with it: nothing matches
+    ]
+
+    def mask_of(s, n):
+        mk = np.ones(n, bool)
+        for f, lo, hi, il, iu in s["ranges"]:
+            v = price[:n] if f == "price" else weight[:n]
+            mk &= (v >= lo if il else v > lo) & (v <= hi if iu else v < hi)
+        for f, items, op in s["terms"]:
+            want = set(items)
+            if op == 1:
+                mk &= np.array([bool(want & set(d)) for d in doc_tags[:n]])
+            elif op == 2:
+                mk &= np.array([not (want & set(d)) for d in doc_tags[:n]])
+            else:
+                mk &= np.array([want <= set(d) for d in doc_tags[:n]])
+        return np.nonzero(mk)[0]
+
+    B.lib().go_set_assign_mode(1)
+    for a, b in ((0, first), (first, N)):           # second pass: the mirror grows with the docs
+        m.store(base[a:b])
+        feed(a, b)
+        assert m.add(base[a:b])
+        if o2 is not None:
+            assert o2.add(base[a:b])
+            o2.set_raw(base[:b])
+        for s in sel:
+            docs = mask_of(s, b)
+            ctx = B.make_ctx(range_filters=[B.make_range_filter(docs)])
+            if o2 is not None:
+                B.lib().go_set_assign_mode(0)
+                D, I = o2.search(q, 10, 8, recall_num=100, has_rank=True, metric=B.METRIC_L2, ctx=ctx, coarse_mode=-1)
+                B.lib().go_set_assign_mode(1)
+                Dg, Ig = m.search_scalar(q, 10, "", ranges=s["ranges"], terms=s["terms"])
+                compare_topk(D, I, Dg, Ig)
+            Df, If = B.flat_search(base[:b], q[:16], 10, B.METRIC_L2, ctx)
+            Dg, Ig = m.search_scalar(q[:16], 10, '{"metric_type": "L2"}', brute_force=(model == "HIPIVFPQ"),
+                                     ranges=s["ranges"], terms=s["terms"])
+            compare_topk(Df, If, Dg, Ig)
+    B.lib().go_set_assign_mode(0)
+    m.close()
