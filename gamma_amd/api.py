@@ -196,6 +196,15 @@ class GammaHip:
         code = np.ascontiguousarray(code, dtype=np.uint8)
         self._ck(self.L.gamma_hip_ivfpq_update(self.h, list_no, vid, _p(code, _lib.u8p)), "update")
 
+    def has_vid(self, vids):
+        vids = np.ascontiguousarray(vids, dtype=np.int64)
+        out = np.zeros(len(vids), dtype=np.uint8)
+        self._ck(self.L.gamma_hip_ivfpq_has_vid(self.h, _p(vids, _lib.i64p), len(vids), _p(out, _lib.u8p)), "has_vid")
+        return out
+
+    def remove(self, vid):
+        self._ck(self.L.gamma_hip_ivfpq_remove(self.h, int(vid)), "remove")
+
     def delete(self, vids):
         vids = np.ascontiguousarray(vids, dtype=np.int64)
         self._ck(self.L.gamma_hip_ivfpq_delete(self.h, _p(vids, _lib.i64p), len(vids)), "delete")

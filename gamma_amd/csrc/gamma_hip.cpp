@@ -1790,6 +1790,32 @@ int gamma_hip_ivfpq_update(gamma_hip_index* h, int list_no, int64_t vid, const u
     return add_keys_locked(h, list_no, 1, &vid, code);
 }
 
+int gamma_hip_ivfpq_has_vid(gamma_hip_index* h, const int64_t* vids, int n, uint8_t* out) {
+    if (!h || n < 0 || (n > 0 && (!vids || !out))) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    for (int i = 0; i < n; i++)
+        out[i] = vids[i] >= 0 && (size_t)vids[i] < h->vid_pos.size() && h->vid_pos[vids[i]] != -1;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_remove(gamma_hip_index* h, int64_t vid) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    if (!h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
+    if (vid < 0 || (size_t)vid >= h->vid_pos.size()) return GAMMA_HIP_OK;
+    const int64_t bp = h->vid_pos[vid];
+    if (bp == -1) return GAMMA_HIP_OK;
+    GH_CHECK(h, hipSetDevice(h->device));
+    const int ob = (int)(bp >> 32), op = (int)(bp & 0xffffffff);
+    gh::launch_mark_moved(h->wstream, h->d_ids, h->h_list_off[ob] + op);
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    h->h_deleted[ob]++;
+    h->n_moved++;
+    h->ntotal -= 1;
+    h->vid_pos[vid] = -1;
+    return GAMMA_HIP_OK;
+}
+
 int gamma_hip_ivfpq_delete(gamma_hip_index* h, const int64_t* vids, int n) {
     if (!h || (n > 0 && !vids)) return GAMMA_HIP_EINVAL;
     WriteLock lk(h);

@@ -71,6 +71,18 @@ class HipShardBackend:
         self.g.raw_append(vecs)
         self.g.add(vecs, first_vid)
 
+    def has_vid(self, vids):
+        return torch.from_numpy(self.g.has_vid(vids)).to(self.device)
+
+    def update_one(self, vid, vec, owned, held_somewhere):
+        """One step of sharded_update on this shard; owned = the list mask handed to GammaHip.set_list_mask."""
+        self.g.raw_write(vid, vec[None])                     # the raw store is replicated
+        lno, code = self.g.encode(vec[None])                 # n = 1: the exact assign, as GammaIVFPQIndex::Update
+        route_update(self.g, int(lno[0]), vid, code[0], owned, held_somewhere)
+
+    def compact_if_need(self):
+        self.g.compact_if_need()
+
     def coarse(self, x, args, cdis, probe):
         """coarse assignment of the rows of x into the preallocated cdis/probe [n, nprobe]"""
         if x.shape[0]:
@@ -87,6 +99,38 @@ class HipShardBackend:
         if nql > 0:
             self.g.ivfpq_merge_rerank(W, per, x.data_ptr(), k, args, all_dis.data_ptr(),
                                       all_ids.data_ptr(), 0, nql, D.data_ptr(), I.data_ptr())
+
+
+def route_update(store, lno, vid, code, owned, held_somewhere):
+    """RealTimeMemData::Update (realtime_mem_data.cc:305-327) when the list the vector leaves and the list it joins
+    may belong to different shards.  store: has_vid / update / remove / add_keys of THIS shard."""
+    held = bool(store.has_vid([vid])[0])
+    if held and owned[lno]:
+        store.update(lno, vid, code)          # both halves here: rewrite in place or move between two owned lists
+    elif held:
+        store.remove(vid)                     # leaves this shard: flag the old entry, the new owner appends
+    elif owned[lno] and held_somewhere:
+        store.add_keys(lno, np.array([vid], dtype=np.int64), np.asarray(code, dtype=np.uint8)[None])
+    # a vid no shard holds is ignored (:307-311)
+
+
+def sharded_update(backend, vids, vecs, owned, group=None):
+    """GammaIVFPQIndex::Update (gamma_index_ivfpq.cc:375-422) on a list-sharded index.  EVERY rank calls this with the
+    same (vids [n], vecs [n, d] host arrays) and its own list mask.  Each rank encodes the vector itself (the
+    coarse centroids and codebooks are replicated), so all ranks agree on the new list without exchanging it; the
+    rank holding the old entry flags it, the owner of the new list appends.  The only exchange is n bytes of
+    "somebody holds this vid" (Update ignores vids that were never added), all-reduced once per call."""
+    vids = np.ascontiguousarray(vids, dtype=np.int64)
+    vecs = np.ascontiguousarray(vecs, dtype=np.float32)
+    held = backend.has_vid(vids)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(held, op=dist.ReduceOp.MAX, group=group)
+    held = held.cpu().numpy()
+    for i in range(len(vids)):
+        if not held[i]:
+            continue                          # never added: Update ignores it (:307-311)
+        backend.update_one(int(vids[i]), vecs[i], owned, bool(held[i]))
+    backend.compact_if_need()                 # gamma_index_ivfpq.cc:420
 
 
 MIN_SUB = 2048   # queries per rank and sub-batch below which a batch is not split for overlap

@@ -191,6 +191,12 @@ int gamma_hip_ivfpq_add_keys_batch(gamma_hip_index* h, int nlists, const int32_t
                                    const uint8_t* codes);
 /* RTInvertIndex::Update (realtime_mem_data.cc:305-327) */
 int gamma_hip_ivfpq_update(gamma_hip_index* h, int list_no, int64_t vid, const uint8_t* code);
+/* The two halves of Update for a list-sharded index, where the list a vector leaves and the list it joins may
+ * live on different shards (gamma_amd/dist.py sharded_update): _has_vid: out[i] = 1 when this handle holds a live
+ * entry of vids[i]; _remove: the first half of RealTimeMemData::Update (:318-321) alone -- the entry is flagged
+ * as moved away and counted as deleted; unknown vids are ignored like Update ignores them (:307-311). */
+int gamma_hip_ivfpq_has_vid(gamma_hip_index* h, const int64_t* vids, int n, uint8_t* out);
+int gamma_hip_ivfpq_remove(gamma_hip_index* h, int64_t vid);
 /* RTInvertIndex::Delete (realtime_mem_data.cc:329-335,190-199): counter only */
 int gamma_hip_ivfpq_delete(gamma_hip_index* h, const int64_t* vids, int n);
 /* RTInvertIndex::CompactIfNeed (realtime_mem_data.cc:354-381,119-150); needs the delete

@@ -103,6 +103,10 @@ def lib():
         L.go_ivfpq_update.argtypes = [C.c_void_p, C.c_int64, _f32p]
         L.go_ivfpq_update_code.restype = C.c_int
         L.go_ivfpq_update_code.argtypes = [C.c_void_p, C.c_int, C.c_int64, _u8p]
+        L.go_ivfpq_has_vid.restype = C.c_int
+        L.go_ivfpq_has_vid.argtypes = [C.c_void_p, C.c_int64]
+        L.go_ivfpq_remove.restype = C.c_int
+        L.go_ivfpq_remove.argtypes = [C.c_void_p, C.c_int64]
         L.go_ivfpq_delete.restype = C.c_int
         L.go_ivfpq_delete.argtypes = [C.c_void_p, _i64p, C.c_int, _u8p]
         L.go_ivfpq_compact_if_need.restype = C.c_int
@@ -242,6 +246,16 @@ class OracleIVFPQ:
     def update(self, vid, x):
         x = _f32(x)
         return self.L.go_ivfpq_update(self.h, vid, _fp(x))
+
+    def update_code(self, list_no, vid, code):
+        code = np.ascontiguousarray(code, dtype=np.uint8)
+        return self.L.go_ivfpq_update_code(self.h, int(list_no), int(vid), _up(code))
+
+    def has_vid(self, vids):
+        return np.array([self.L.go_ivfpq_has_vid(self.h, int(v)) for v in vids], dtype=np.uint8)
+
+    def remove(self, vid):
+        return self.L.go_ivfpq_remove(self.h, int(vid))
 
     def delete(self, vids):
         vids = np.ascontiguousarray(vids, dtype=np.int64)

@@ -742,6 +742,23 @@ int go_ivfpq_update_code(go_ivfpq* ix, int list_no, int64_t vid, const uint8_t* 
     return go_ivfpq_add_keys(ix, list_no, 1, &vid, code);
 }
 
+/* Helpers of the list-sharded Update test (gamma_amd/dist.py sharded_update): whether this index holds a live
+ * entry of vid, and the first half of RealTimeMemData::Update alone (:318-321: flag the old entry, count it). */
+int go_ivfpq_has_vid(go_ivfpq* ix, int64_t vid) {
+    return vid >= 0 && vid < ix->nids && ix->vid_pos[vid] != -1;
+}
+
+int go_ivfpq_remove(go_ivfpq* ix, int64_t vid) {
+    if (vid < 0 || vid >= ix->nids) return 0;
+    int64_t bp = ix->vid_pos[vid];
+    if (bp == -1) return 0;
+    int old_b = (int)(bp >> 32), old_pos = (int)(bp & 0xffffffff);
+    ix->b[old_b].ids[old_pos] |= GO_DEL_MASK;
+    ix->b[old_b].deleted++;
+    ix->vid_pos[vid] = -1;
+    return 0;
+}
+
 int go_ivfpq_update(go_ivfpq* ix, int64_t vid, const float* x) {
     int64_t lno;
     uint8_t* code = (uint8_t*)malloc(ix->code_size);

@@ -122,6 +122,8 @@ void go_ivfpq_encode(go_ivfpq* ix, int64_t n, const float* x, int64_t* list_nos,
 int go_ivfpq_add_keys(go_ivfpq* ix, int list_no, int n, const int64_t* keys, const uint8_t* codes);
 int go_ivfpq_update(go_ivfpq* ix, int64_t vid, const float* x);
 int go_ivfpq_update_code(go_ivfpq* ix, int list_no, int64_t vid, const uint8_t* code);
+int go_ivfpq_has_vid(go_ivfpq* ix, int64_t vid);
+int go_ivfpq_remove(go_ivfpq* ix, int64_t vid);
 int go_ivfpq_delete(go_ivfpq* ix, const int64_t* vids, int n, const uint8_t* docids_bitmap);
 int go_ivfpq_compact_if_need(go_ivfpq* ix, const uint8_t* docids_bitmap);
 int64_t go_ivfpq_list_size(go_ivfpq* ix, int list_no);

@@ -27,11 +27,32 @@ class OracleShardBackend:
                 ids, codes = case["oracle"].get_list(l)
                 if len(ids):
                     o.add_keys(l, ids, codes)
-        o.set_raw(case["base"])
+        self.raw = case["base"].copy()
+        o.set_raw(self.raw)
         self.o = o
 
     def empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype)
+
+    # ---- sharded_update ----
+    class _Store:
+        def __init__(self, o):
+            self.o = o
+            self.has_vid, self.remove, self.add_keys = o.has_vid, o.remove, o.add_keys
+
+        def update(self, lno, vid, code):
+            self.o.update_code(lno, vid, code)
+
+    def has_vid(self, vids):
+        return torch.from_numpy(self.o.has_vid(vids))
+
+    def update_one(self, vid, vec, owned, held_somewhere):
+        self.raw[vid] = vec
+        lno, code = self.o.encode(vec[None])
+        gdist.route_update(self._Store(self.o), int(lno[0]), vid, code[0], owned, held_somewhere)
+
+    def compact_if_need(self):
+        self.o.compact_if_need()
 
     def coarse(self, x, args, cdis, probe):
         if x.shape[0] == 0:
@@ -59,7 +80,7 @@ class OracleShardBackend:
         ks = 1 if p.metric == B.METRIC_L2 else 0
         L = B.lib()
         ad, ai = all_dis.numpy(), all_ids.numpy()
-        base, d = self.case["base"], self.case["d"]
+        d = self.case["d"]
         for qi in range(nql):
             dis = ad[:, qi, :].reshape(-1)
             ids = ai[:, qi, :].reshape(-1)
@@ -69,7 +90,7 @@ class OracleShardBackend:
             ids = ids[order]
             xq = np.ascontiguousarray(x[qi].numpy())
             fn = L.go_fvec_L2sqr if ks else L.go_fvec_inner_product
-            ex = np.array([fn(B._fp(xq), B._fp(np.ascontiguousarray(base[i])), d) for i in ids],
+            ex = np.array([fn(B._fp(xq), B._fp(np.ascontiguousarray(self.raw[i])), d) for i in ids],
                           dtype=np.float32)
             ov, oi = np.empty(k, np.float32), np.empty(k, np.int64)
             ids = np.ascontiguousarray(ids)
@@ -92,6 +113,7 @@ def main():
     ctx = B.make_ctx(min_score=-3e38, max_score=3e38)
     Dr, Ir = case["oracle"].search(case["q"], k, nprobe, recall_num=R, has_rank=True,
                                    metric=B.METRIC_L2, ctx=ctx, coarse_mode=0)
+    Dr0 = Dr.copy()
     # two and three interleaved sub-batches (asynchronous collectives, padded last slices), then the
     # plain single pass
     for pipeline in (2, 3, None):
@@ -102,6 +124,35 @@ def main():
     dist.all_gather(gathered, I)
     for g in gathered:
         assert torch.equal(g, I)
+    # Update across shards: every rank is handed the same (vids, vectors); most of them change list, many change
+    # shard; one vid is updated twice in the batch, one was never added (ignored, realtime_mem_data.cc:307-311)
+    rng = np.random.default_rng(99)
+    N = len(case["base"])
+    vids = rng.choice(N, 300, replace=False)
+    vids = np.concatenate([vids, vids[:1], [N + 5]])
+    newv = case["base"][rng.integers(0, N, len(vids))] + rng.integers(-3, 4, (len(vids), case["d"])).astype(np.float32)
+    owned = (owner == rank).astype(np.uint8)
+    gdist.sharded_update(be, vids, newv, owned)
+    ref = B.OracleIVFPQ(case["d"], case["nlist"], case["M"], 8, case["metric"])
+    ref.set_trained(case["cc"], case["pq"], None)
+    for l in range(case["nlist"]):
+        ids, codes = case["oracle"].get_list(l)
+        if len(ids):
+            ref.add_keys(l, ids, codes)
+    raw2 = case["base"].copy()
+    for v, nv in zip(vids, newv):
+        if v < N:
+            raw2[v] = nv
+        ref.update(int(v), nv)
+    ref.set_raw(raw2)
+    live = sum(int(be.o.has_vid([v])[0]) for v in range(N))
+    tot = torch.tensor([live])
+    dist.all_reduce(tot)
+    assert int(tot) == N, int(tot)            # every vid lives on exactly one shard afterwards
+    Dr, Ir = ref.search(case["q"], k, nprobe, recall_num=R, has_rank=True, metric=B.METRIC_L2, ctx=ctx, coarse_mode=0)
+    assert not np.array_equal(Dr, Dr0)        # the updates are visible
+    D, I = gdist.sharded_search(be, x, k, args)
+    compare_topk(Dr, Ir, D.numpy(), I.numpy())
     dist.destroy_process_group()
     print("rank %d ok" % rank)
 

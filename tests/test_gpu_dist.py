@@ -219,3 +219,55 @@ def test_sharded_realtime_inserts_route_to_the_list_owner():
     finally:
         for g in shards + [full]:
             g.close()
+
+
+def test_update_across_shards():
+    """GammaIVFPQIndex::Update on a list-sharded index (gamma_amd/dist.py sharded_update / route_update): every shard
+    is handed the same (vid, vector); the holder of the old entry flags it, the owner of the new list appends.
+    Owned lists must equal an unsharded handle's after the same updates, entry for entry, and searches agree."""
+    from gamma_amd import api
+    from gamma_amd import dist as gdist
+    case = fixtures.trained_case(d=32, nlist=64, M=8, N=20000, nq=64, metric=B.METRIC_L2)
+    W = 3
+    sizes = np.array([case["oracle"].list_size(l) for l in range(case["nlist"])])
+    owner = gdist.balance_lists(sizes, W)
+    full = fixtures.load_hip(case)
+    shards = [_shard_handle(case, owner, s) for s in range(W)]
+    backs = [gdist.HipShardBackend(g, 0) for g in shards]
+    masks = [(owner == s).astype(np.uint8) for s in range(W)]
+    rng = np.random.default_rng(5)
+    N = len(case["base"])
+    vids = rng.choice(N, 400, replace=False)
+    vids = np.concatenate([vids, vids[:2], [N + 9]])          # two vids twice, one never added
+    newv = (case["base"][rng.integers(0, N, len(vids))] + rng.integers(-3, 4, (len(vids), case["d"]))).astype(np.float32)
+    try:
+        moved_shard = 0
+        for v, x in zip(vids, newv):
+            lno, code = full.encode(x[None])
+            before = [int(g.has_vid([v])[0]) for g in shards]
+            held = any(before)
+            if held:
+                full.raw_write(int(v), x[None])
+                full.update(int(lno[0]), int(v), code[0])
+                for s in range(W):
+                    backs[s].update_one(int(v), x, masks[s], True)
+                after = [int(g.has_vid([v])[0]) for g in shards]
+                assert sum(after) == 1 and after[owner[lno[0]]] == 1
+                moved_shard += before != after
+            else:
+                assert v >= N
+        assert moved_shard > 50
+        for g in shards + [full]:
+            g.compact_if_need()
+        for l in range(case["nlist"]):
+            ids, codes = full.get_list(l)
+            for s in range(W):
+                if owner[l] == s:
+                    gi, gc = shards[s].get_list(l)
+                    assert np.array_equal(ids, gi) and np.array_equal(codes, gc), l
+                else:
+                    assert shards[s].list_size(l) == 0
+        _sharded_vs_full(case, shards, full, B.METRIC_L2, True, W, 603, 32)
+    finally:
+        for g in shards + [full]:
+            g.close()
