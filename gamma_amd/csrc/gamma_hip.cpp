@@ -169,6 +169,8 @@ struct gamma_hip_index {
 
     bool exact_ties = false;   // gamma_hip_set_exact_ties
     bool list_major = false;   // gamma_hip_set_list_major
+    bool coarse_fused = true;  // gamma_hip_set_coarse_fused
+    int coarse_cap = gh::kCoarseCap;
     unsigned long long* d_tie_stats = nullptr;   // {coarse rows redone, top-R cuts through a tie, queries replayed}
     // what stage A leaves for the tie replay of stage B (ties.hip)
     struct TieCtx {
@@ -637,16 +639,28 @@ int ivfpq_coarse(H* h, const gamma_hip_search_params* p, int nq, const float* d_
                  int* out_probe = nullptr) {
     const int P = p->nprobe, d = h->d, nlist = h->nlist;
     hipStream_t s = h->stream;
-    GH_CHECK(h, h->w_mat.ensure((size_t)nq * nlist * sizeof(float)));
+    int mode = p->coarse_mode;
+    if (mode < 0) mode = nq < 20 ? 0 : 1;  // faiss:utils/distances.cpp:303,346
+    // large batches: no distance matrix (coarse.hip); exact ties replay rows of the matrix, so they keep it
+    const bool fused = mode == 1 && h->coarse_fused && !h->exact_ties && gh::coarse_fused_supported(nq, d, nlist, P);
+    gh::CoarseFusedPlan plan;
+    if (fused) {
+        plan = gh::coarse_fused_plan(nq, nlist, P, h->coarse_cap);
+        GH_CHECK(h, h->w_mat.ensure(plan.bytes));
+    } else {
+        GH_CHECK(h, h->w_mat.ensure((size_t)nq * nlist * sizeof(float)));
+    }
     if (!out_dis || !out_probe) {   // the workspace the scan reads
         GH_CHECK(h, h->w_coarse_dis.ensure((size_t)nq * P * sizeof(float)));
         GH_CHECK(h, h->w_probe.ensure((size_t)nq * P * sizeof(int)));
         out_dis = h->w_coarse_dis.as<float>();
         out_probe = h->w_probe.as<int>();
     }
-    int mode = p->coarse_mode;
-    if (mode < 0) mode = nq < 20 ? 0 : 1;  // faiss:utils/distances.cpp:303,346
     StageScope t(h, GAMMA_HIP_STAGE_COARSE);
+    if (fused) {
+        gh::launch_coarse_fused(s, plan, h->w_mat.p, d_x, nq, d, h->d_cc, nlist, h->d_cc_norms, P, out_dis, out_probe);
+        return GAMMA_HIP_OK;
+    }
     if (mode == 0) {
         gh::launch_pairwise(s, true, d_x, nq, d, h->d_cc, nlist, h->w_mat.as<float>(), nlist);
     } else {
@@ -1361,6 +1375,14 @@ int gamma_hip_set_exact_ties(gamma_hip_index* h, int on) {
     if (!h) return GAMMA_HIP_EINVAL;
     SearchLock lk(h);
     h->exact_ties = on != 0;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_set_coarse_fused(gamma_hip_index* h, int on, int list_cap) {
+    if (!h || list_cap < 1 || list_cap > gh::kCoarseCap) return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    h->coarse_fused = on != 0;
+    h->coarse_cap = list_cap;
     return GAMMA_HIP_OK;
 }
 

@@ -149,6 +149,17 @@ void launch_query_order(hipStream_t s, const int* probe_list, int nq, int P, con
 void launch_sum_totals(hipStream_t s, const int* q_total, int nq, unsigned long long* acc);
 int select_kpad(int K);
 // coarse quantizer selection (ties at the K-th distance resolved like the reference's heap); tie_flag: nq bytes
+// coarse.hip: coarse quantizer of a large batch without the distance matrix (sample -> bound -> filtered GEMM
+// epilogue -> merge; see the file header).  ws: pl.bytes of scratch.
+constexpr int kCoarseCap = 128, kCoarseRepairGrid = 64;
+struct CoarseFusedPlan {
+    int sample, nseg, tiles_per_strip, cap, cap_stride;
+    size_t off_mat, off_tau, off_cand, off_cnt, off_ovf, off_scratch, bytes;
+};
+bool coarse_fused_supported(int nq, int d, int nlist, int P);
+CoarseFusedPlan coarse_fused_plan(int nq, int nlist, int P, int cap);
+void launch_coarse_fused(hipStream_t s, const CoarseFusedPlan& pl, void* ws, const float* x, int nq, int d,
+                         const float* y, int nlist, const float* yn, int P, float* out_dis, int* out_idx);
 void launch_coarse_select(hipStream_t s, const float* mat, int nlist, int nq, int K, float* out_vals, int* out_pos,
                           uint8_t* tie_flag, unsigned long long* tie_stats = nullptr);
 void launch_select_topk(hipStream_t s, bool smallest, const float* vals, int64_t seg_stride,

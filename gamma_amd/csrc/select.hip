@@ -502,7 +502,7 @@ __device__ __forceinline__ void wave_rank_take(unsigned long long* buf, int c, i
 }
 }  // namespace
 
-template <bool SMALLEST>
+template <bool SMALLEST, int NPL>
 __global__ __launch_bounds__(256) void k_select_wave(const float* __restrict__ vals, int64_t seg_stride,
                                                      const int* __restrict__ seg_len, int fixed_len,
                                                      int nseg, int K, float* __restrict__ out_vals,
@@ -516,28 +516,29 @@ __global__ __launch_bounds__(256) void k_select_wave(const float* __restrict__ v
     const float* v = vals + (int64_t)seg * seg_stride;
     unsigned long long* buf = s_buf[w];
     int run = 0;               // buf[0..run): running top, sorted
-    for (int base = 0; base < n; base += 64 * SW_NPL) {
-        uint32_t key[SW_NPL];
+    for (int base = 0; base < n; base += 64 * NPL) {
+        uint32_t key[NPL];
         // slot j of this lane is element base + j*64 + lane; it exists iff j*64 < nrem
         const int nrem = n - base - lane;
-        if (base + 64 * SW_NPL <= n) {      // full chunk (uniform): one base address, constant offsets
+        if (base + 64 * NPL <= n) {      // full chunk (uniform): one base address, constant offsets
             const float* pv = v + base + lane;
 #pragma unroll
-            for (int j = 0; j < SW_NPL; j++) key[j] = sel_key<SMALLEST>(pv[j * 64]);
+            for (int j = 0; j < NPL; j++) key[j] = sel_key<SMALLEST>(pv[j * 64]);
         } else {
+            constexpr int LB = NPL < 16 ? NPL : 16;
 #pragma unroll
-            for (int j0 = 0; j0 < SW_NPL; j0 += 16) {   // 16 unconditional (clamped) loads in flight
-                float t[16];
+            for (int j0 = 0; j0 < NPL; j0 += LB) {   // LB unconditional (clamped) loads in flight
+                float t[LB];
 #pragma unroll
-                for (int u = 0; u < 16; u++) t[u] = v[min(base + (j0 + u) * 64 + lane, n - 1)];
+                for (int u = 0; u < LB; u++) t[u] = v[min(base + (j0 + u) * 64 + lane, n - 1)];
 #pragma unroll
-                for (int u = 0; u < 16; u++)
+                for (int u = 0; u < LB; u++)
                     key[j0 + u] = (j0 + u) * 64 < nrem ? sel_key<SMALLEST>(t[u]) : 0xffffffffu;
             }
         }
         uint32_t m = key[0];
 #pragma unroll
-        for (int j = 1; j < SW_NPL; j++) m = key[j] < m ? key[j] : m;
+        for (int j = 1; j < NPL; j++) m = key[j] < m ? key[j] : m;
         // rank of this lane's minimum among the 64 (ties by lane): K-th smallest = tau
         int rk = 0;
 #pragma unroll
@@ -553,20 +554,20 @@ __global__ __launch_bounds__(256) void k_select_wave(const float* __restrict__ v
         }
         int c = 0;
 #pragma unroll
-        for (int j = 0; j < SW_NPL; j++) c += (key[j] <= tau && j * 64 < nrem) ? 1 : 0;
+        for (int j = 0; j < NPL; j++) c += (key[j] <= tau && j * 64 < nrem) ? 1 : 0;
         const int incl = wave_incl_scan(c);
         const int tot = __shfl(incl, 63, 64);
         if (run + tot <= SW_CAP) {
             int off = run + incl - c;
 #pragma unroll
-            for (int j = 0; j < SW_NPL; j++)
+            for (int j = 0; j < NPL; j++)
                 if (key[j] <= tau && j * 64 < nrem)
                     buf[off++] = ((unsigned long long)key[j] << 32) | (unsigned)(base + j * 64 + lane);
             __builtin_amdgcn_wave_barrier();
             // tie_flag (coarse quantizer, rows of one chunk): one rank more is kept -- is the (K+1)-th key equal
             // to the K-th?  Then WHICH of the tied entries the reference keeps is decided by its heap
             // (k_coarse_heap_fix redoes the row the way the heap does).
-            const bool want_flag = tie_flag && base == 0 && n <= 64 * SW_NPL;
+            const bool want_flag = tie_flag && base == 0 && n <= 64 * NPL;
             wave_rank_take(buf, run + tot, want_flag ? K + 1 : K);
             if (want_flag) {
                 // two equal keys among the K + 1 smallest: which of them is probed (tie at the cut), or in which
@@ -580,7 +581,7 @@ __global__ __launch_bounds__(256) void k_select_wave(const float* __restrict__ v
             }
             run = min(run + tot, K);
         } else {
-            if (tie_flag && base == 0 && n <= 64 * SW_NPL && lane == 0) tie_flag[seg] = 1;   // not known here: redo the row
+            if (tie_flag && base == 0 && n <= 64 * NPL && lane == 0) tie_flag[seg] = 1;   // not known here: redo the row
             // exact extraction from the registers: K rounds of (lane arg-min, wave arg-min)
             unsigned long long rm = 0;   // bit j: slot j already taken
             int got = 0;
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(256) void k_select_wave(const float* __restrict__ v
                 uint32_t bk = 0xffffffffu;
                 int bj = -1;
 #pragma unroll
-                for (int j = 0; j < SW_NPL; j++) {
+                for (int j = 0; j < NPL; j++) {
                     const bool ok = !((rm >> j) & 1ull) && j * 64 < nrem && (bj < 0 || key[j] < bk);
                     bk = ok ? key[j] : bk;
                     bj = ok ? j : bj;
@@ -1357,7 +1358,7 @@ void launch_coarse_select(hipStream_t s, const float* mat, int nlist, int nq, in
         launch_select_topk(s, true, mat, nlist, nullptr, nlist, nlist, nq, K, out_vals, out_pos);
         return;
     }
-    hipLaunchKernelGGL((k_select_wave<true>), dim3((nq + 3) / 4), dim3(256), 0, s, mat, (int64_t)nlist, nullptr, nlist, nq,
+    hipLaunchKernelGGL((k_select_wave<true, SW_NPL>), dim3((nq + 3) / 4), dim3(256), 0, s, mat, (int64_t)nlist, nullptr, nlist, nq,
                        K, out_vals, out_pos, tie_flag);
     hipLaunchKernelGGL(k_coarse_heap_fix, dim3((nq + 3) / 4), dim3(256), 0, s, mat, (int64_t)nlist, nlist, K, nq, tie_flag,
                        out_vals, out_pos, tie_stats);
@@ -1379,9 +1380,12 @@ static void launch_sel(hipStream_t s, const float* vals, int64_t seg_stride, con
     hipLaunchKernelGGL((k_select2<SMALLEST, NPT>), dim3(nseg), dim3(256), lds, s, vals, seg_stride, \
                        seg_len, fixed_len, K, Kpad, out_vals, out_pos, only)
     static const bool no_wave = getenv("GAMMA_HIP_NO_WAVE_SELECT") != nullptr;
-    if (K <= 64 && max_len <= 16384 && !no_wave && !only)   // longer rows: the streaming kernel wins
-        hipLaunchKernelGGL((k_select_wave<SMALLEST>), dim3((nseg + 3) / 4), dim3(256), 0, s, vals, seg_stride,
-                           seg_len, fixed_len, nseg, K, out_vals, out_pos);
+    if (K <= 64 && max_len <= 512 && !no_wave && !only)    // short rows (the coarse sample): 8 keys per lane
+        hipLaunchKernelGGL((k_select_wave<SMALLEST, 8>), dim3((nseg + 3) / 4), dim3(256), 0, s, vals, seg_stride,
+                           seg_len, fixed_len, nseg, K, out_vals, out_pos, nullptr);
+    else if (K <= 64 && max_len <= 16384 && !no_wave && !only)   // longer rows: the streaming kernel wins
+        hipLaunchKernelGGL((k_select_wave<SMALLEST, SW_NPL>), dim3((nseg + 3) / 4), dim3(256), 0, s, vals, seg_stride,
+                           seg_len, fixed_len, nseg, K, out_vals, out_pos, nullptr);
     else if (max_len <= 256 * 4) GH_SEL(4);
     else if (max_len <= 256 * 16) GH_SEL(16);
     else if (K <= 1024 && (seg_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(vals) & 15) == 0 &&

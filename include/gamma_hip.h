@@ -137,6 +137,11 @@ int gamma_hip_set_exact_ties(gamma_hip_index* h, int on);
  * scored list-major, two queries per pass over a list.  Same results; slower than the default at C3-sized
  * lists, off by default.  Covers nsubvector 16, >= 2048 queries per call, no per-request filters. */
 int gamma_hip_set_list_major(gamma_hip_index* h, int on);
+/* Coarse quantizer of large batches (>= 4096 queries, >= 2048 lists, d in {32, 64, 96, 128}, nprobe <= 64) without
+ * the [nq][nlist] distance matrix (csrc/coarse.hip).  on: 1 = automatic (default), 0 = always the matrix path.
+ * list_cap: capacity of a query's per-strip survivor list, 1..128 (default 128); a query that overflows it is redone
+ * by the repair kernel -- tests shrink it to force that path.  Results are identical either way. */
+int gamma_hip_set_coarse_fused(gamma_hip_index* h, int on, int list_cap);
 /* out3 = {coarse rows redone, queries whose recall_num cut went through a tie, queries replayed} since creation
  * or the last reset; meaningful with exact ties on */
 int gamma_hip_tie_stats(gamma_hip_index* h, int64_t* out3, int reset);

@@ -1019,3 +1019,46 @@ def test_term_filters_on_device(case):
     with pytest.raises(api.GammaHipError):      # unknown column
         g.ivfpq_search(q, 10, api.SearchArgs(metric=api.METRIC_L2, nprobe=8, term_filters=[(77, 1, [1])], **WIDE))
     g.close()
+
+
+@pytest.mark.parametrize("d,nlist,P,nq", [(128, 4096, 32, 4500), (32, 2048, 8, 4100), (64, 4100, 64, 4200),
+                                          (96, 2304, 20, 8200), (128, 4096, 1, 4096)])
+def test_fused_coarse_matches_matrix_path_and_oracle(d, nlist, P, nq):
+    """csrc/coarse.hip (sample -> bound -> filtered GEMM epilogue -> merge) == the distance-matrix path, bit for
+    bit, also when survivor lists overflow and queries go through the repair kernel (list_cap 1: every query;
+    40: some), and == the oracle's GEMM-form knn_L2sqr (faiss:utils/distances.cpp:215-296) up to ties."""
+    import torch
+    rng = np.random.default_rng(d + nlist + P)
+    cc = (rng.standard_normal((nlist, d)) * 20).astype(np.float32)
+    cc[5] = cc[600]                                   # equal distances: (distance, list number) order in both paths
+    cc[nlist - 1] = cc[700]
+    x = cc[rng.integers(0, nlist, nq)] + (rng.standard_normal((nq, d)) * 12).astype(np.float32)
+    x[3] = cc[5]                                      # distance 0 twice
+    M = d // 8
+    pq = rng.standard_normal((M, 256, d // M)).astype(np.float32)
+    g = api.GammaHip(0)
+    g.ivfpq_init(d, nlist, M, 8, api.METRIC_L2, 100)
+    g.ivfpq_set_trained(cc, pq, None)
+    dev = torch.device("cuda", 0)
+    dx = torch.from_numpy(x).to(dev)
+    args = api.SearchArgs(metric=api.METRIC_L2, nprobe=P, coarse_mode=1, **WIDE)
+
+    def run():
+        cd = torch.empty((nq, P), dtype=torch.float32, device=dev)
+        ci = torch.empty((nq, P), dtype=torch.int32, device=dev)
+        g.ivfpq_coarse_device(dx.data_ptr(), nq, args, cd.data_ptr(), ci.data_ptr())
+        g.synchronize()
+        return cd.cpu().numpy(), ci.cpu().numpy()
+
+    try:
+        g.set_coarse_fused(False)
+        D0, I0 = run()
+        for cap in (128, 40, 1):
+            g.set_coarse_fused(True, cap)
+            D1, I1 = run()
+            assert D0.tobytes() == D1.tobytes(), cap
+            assert np.array_equal(I0, I1), cap
+        Do, Io = B.knn_L2sqr(x[:600], cc, P, mode=1)
+        compare_topk(Do, Io, D0[:600], I0[:600].astype(np.int64))
+    finally:
+        g.close()
