@@ -311,6 +311,9 @@ class GammaHip:
     def set_coarse_fused(self, on=True, list_cap=128):
         self._ck(self.L.gamma_hip_set_coarse_fused(self.h, 1 if on else 0, list_cap), "set_coarse_fused")
 
+    def set_small_path(self, on=True):
+        self._ck(self.L.gamma_hip_set_small_path(self.h, 1 if on else 0), "set_small_path")
+
     def set_list_major(self, on=True):
         self._ck(self.L.gamma_hip_set_list_major(self.h, 1 if on else 0), "set_list_major")
 

@@ -69,7 +69,8 @@ __device__ __forceinline__ void block_rank_sort(unsigned long long* a, int n) {
     }
     // broadcast reads (same address in every lane), 8 issued before the first compare: hipcc
     // does not pipeline this loop by itself and it would pay one LDS latency per item
-    int j = 0;
+    // a wave whose first thread holds no item has nothing to rank (n << NTHREADS: most of a 1024-thread block)
+    int j = (int)(threadIdx.x & ~63u) < n ? 0 : n;
     for (; j + 8 <= n; j += 8) {
         unsigned long long x[8];
 #pragma unroll

@@ -170,6 +170,7 @@ struct gamma_hip_index {
     bool exact_ties = false;   // gamma_hip_set_exact_ties
     bool list_major = false;   // gamma_hip_set_list_major
     bool coarse_fused = true;  // gamma_hip_set_coarse_fused
+    bool small_path = true;    // gamma_hip_set_small_path
     int coarse_cap = gh::kCoarseCap;
     unsigned long long* d_tie_stats = nullptr;   // {coarse rows redone, top-R cuts through a tie, queries replayed}
     // what stage A leaves for the tie replay of stage B (ties.hip)
@@ -1037,6 +1038,66 @@ int ivfpq_stage_b(H* h, const gamma_hip_search_params* p, int nq, const float* d
     return GAMMA_HIP_OK;
 }
 
+// ---- small batches (nq <= 16): the same search in four launches instead of eleven ---------------------------------
+// exact coarse distances + query tables | top-nprobe + slab offsets | scan | top-recall_num + ids + re-rank + top-k
+// (kernels.hip k_small_coarse_ip, select.hip k_small_coarse_select / k_small_tail).  Each launch of the regular
+// chain costs ~4 us of launch + drain at this size, whatever it computes.
+bool ivfpq_small_ok(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int nq, int R) {
+    static const bool off = getenv("GAMMA_HIP_NO_SMALL_PATH") != nullptr;
+    const int d = h->d;
+    return !off && h->small_path && nq >= 1 && nq <= 16 && p->metric == GAMMA_HIP_METRIC_L2 && p->coarse_mode == 0 &&
+           p->nprobe <= 64 && R <= 1024 && !h->exact_ties && !h->profile && !fc.d_qf && !h->d_list_mask &&
+           (d == 16 || d == 32 || d == 64 || d == 96 || d == 128) && h->nlist <= 16384 &&
+           (int64_t)p->nprobe * std::max(1, h->max_list_len) <= (1 << 22) && (!p->has_rank || (h->d_raw && h->raw_d == h->d));
+}
+
+int ivfpq_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int nq, const float* d_x, int R, int k,
+                float* d_distances, int64_t* d_labels) {
+    const int P = p->nprobe, d = h->d, M = h->M, nlist = h->nlist;
+    hipStream_t s = h->stream;
+    const int ver = h->cur_ver;
+    GH_CHECK(h, hipStreamWaitEvent(s, h->ver_ev[ver], 0));
+    GH_CHECK(h, h->w_mat.ensure((size_t)nq * nlist * sizeof(float)));
+    GH_CHECK(h, h->w_st2.ensure((size_t)nq * M * 256 * sizeof(float)));
+    GH_CHECK(h, h->w_coarse_dis.ensure((size_t)nq * P * sizeof(float)));
+    GH_CHECK(h, h->w_probe.ensure((size_t)nq * P * sizeof(int)));
+    GH_CHECK(h, h->w_pair_off.ensure((size_t)nq * (P + 1) * sizeof(int)));
+    GH_CHECK(h, h->w_pair_base.ensure((size_t)nq * P * sizeof(int64_t)));
+    GH_CHECK(h, h->w_qtotal.ensure((size_t)nq * sizeof(int)));
+    GH_CHECK(h, h->w_cand_pos.ensure((size_t)nq * R * sizeof(int)));
+    GH_CHECK(h, h->w_cand_dis.ensure((size_t)nq * R * sizeof(float)));
+    GH_CHECK(h, h->w_cand_ids.ensure((size_t)nq * R * sizeof(int64_t)));
+    const int64_t q_stride = (std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len)) + 3) & ~(int64_t)3;
+    GH_CHECK(h, h->w_dist.ensure((size_t)nq * q_stride * sizeof(float)));
+    // (folding the selection into the first launch -- last workgroup done selects -- was tried: the device-scope
+    // release / acquire it needs costs more than the launch it saves, 24 us against 4 + 8: the XCDs' L2s are
+    // written back and invalidated either way)
+    if (!gh::launch_small_coarse_ip(s, d_x, nq, d, h->d_cc, nlist, h->w_mat.as<float>(), M, h->d_pqc, h->w_st2.as<float>()))
+        return fail(h, GAMMA_HIP_EINVAL, "small path: shape not covered");   // ivfpq_small_ok gates on the same shapes
+    gh::launch_small_coarse_select(s, h->w_mat.as<float>(), nlist, nq, P, h->w_coarse_dis.as<float>(), h->w_probe.as<int>(),
+                                   h->d_list_len, h->d_list_mask, h->d_list_off, h->w_pair_off.as<int>(),
+                                   h->w_qtotal.as<int>(), h->w_pair_base.as<int64_t>());
+    h->scan_pairs += (int64_t)nq * P;
+    const int need_ids = (fc.any_clause || (h->d_bitmap && h->bitmap_any) || h->n_moved > 0) ? 1 : 0;
+    gh::launch_ivfpq_scan_pair(s, true, d_x, nq, d, M, P, h->w_probe.as<int>(), h->w_coarse_dis.as<float>(), h->d_cc,
+                               h->w_st2.as<float>(), h->d_T2, h->d_list_off, h->d_list_len, h->d_list_mask, nlist,
+                               h->d_codes, h->d_ids, h->w_pair_off.as<int>(), q_stride, h->w_dist.as<float>(), fc.d_tab,
+                               fc.d_qf, need_ids, nullptr, 1, 0, P, 0, nullptr, nullptr);
+    const float neutral = 3.402823466e+38f;
+    gh::launch_small_tail(s, true, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), nq, R, P, h->w_probe.as<int>(),
+                          h->w_pair_off.as<int>(), h->d_list_off, h->d_ids, h->w_cand_dis.as<float>(),
+                          h->w_cand_pos.as<int>(), h->w_cand_ids.as<int64_t>(), p->has_rank ? 1 : 0, d_x, d, h->d_raw,
+                          h->nraw, k, p->min_score, p->max_score, neutral, d_distances, d_labels);
+    h->tie = H::TieCtx();
+    h->tie.G = 1;
+    h->tie.q_stride = q_stride;
+    h->last_qperm = nullptr;
+    GH_CHECK(h, hipEventRecord(h->rd_ev[ver], s));
+    h->rd_set[ver] = true;
+    GH_CHECK(h, hipGetLastError());
+    return GAMMA_HIP_OK;
+}
+
 int ivfpq_check(H* h, const gamma_hip_search_params* p, int nq, int k) {
     GH_TRY(check_params(h, p, nq, k));
     if (!h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
@@ -1079,6 +1140,13 @@ int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, c
     gamma_hip_search_params pp = *p;
     if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;
     p = &pp;
+    if (ivfpq_small_ok(h, p, fc, nq, R)) {
+        GH_TRY(ivfpq_small(h, p, fc, nq, d_x, R, k, d_distances, d_labels));
+        h->last_nq = nq;
+        h->last_P = p->nprobe;
+        h->last_R = R;
+        return GAMMA_HIP_OK;
+    }
     const int chunk = scan_chunk(h, nq, p->nprobe), P = p->nprobe;
     // long lists (C4: 64 probes x lists of tens of thousands) make the ADC slab the limit: the coarse
     // quantizer then still runs over the whole call (one GEMM instead of one per slab chunk)
@@ -1383,6 +1451,13 @@ int gamma_hip_set_coarse_fused(gamma_hip_index* h, int on, int list_cap) {
     SearchLock lk(h);
     h->coarse_fused = on != 0;
     h->coarse_cap = list_cap;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_set_small_path(gamma_hip_index* h, int on) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    h->small_path = on != 0;
     return GAMMA_HIP_OK;
 }
 

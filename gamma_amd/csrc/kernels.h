@@ -160,6 +160,20 @@ bool coarse_fused_supported(int nq, int d, int nlist, int P);
 CoarseFusedPlan coarse_fused_plan(int nq, int nlist, int P, int cap);
 void launch_coarse_fused(hipStream_t s, const CoarseFusedPlan& pl, void* ws, const float* x, int nq, int d,
                          const float* y, int nlist, const float* yn, int P, float* out_dis, int* out_idx);
+// small batches: exact coarse distances [nq][nlist] + inner-product tables [nq][M][256] in one launch; false = shape
+// not covered (d not in {16, 32, 64, 96, 128} or nq > 16), nothing launched
+bool launch_small_coarse_ip(hipStream_t s, const float* x, int nq, int d, const float* cc, int nlist, float* mat, int M,
+                            const float* pqc, float* st2);
+// small batches (select.hip): coarse top-nprobe + slab offsets in one kernel; ADC top-recall_num + ids + exact
+// re-rank + top-k + output in one kernel.  P <= 64, R <= 1024.
+void launch_small_coarse_select(hipStream_t s, const float* mat, int nlist, int nq, int P, float* out_vals, int* out_pos,
+                                const int* list_len, const uint8_t* list_mask, const int64_t* list_off, int* pair_off,
+                                int* q_total, int64_t* pair_base);
+void launch_small_tail(hipStream_t s, bool l2, const float* slab, int64_t q_stride, const int* q_total, int nq, int R, int P,
+                       const int* probe_list, const int* pair_off, const int64_t* list_off, const int64_t* ids,
+                       float* cand_dis, int* cand_pos, int64_t* cand_ids, int has_rank, const float* x, int d,
+                       const float* raw, int64_t nraw, int k, float min_score, float max_score, float neutral,
+                       float* distances, int64_t* labels);
 void launch_coarse_select(hipStream_t s, const float* mat, int nlist, int nq, int K, float* out_vals, int* out_pos,
                           uint8_t* tie_flag, unsigned long long* tie_stats = nullptr);
 void launch_select_topk(hipStream_t s, bool smallest, const float* vals, int64_t seg_stride,

@@ -29,14 +29,14 @@ namespace gh {
 // loads.  grid = (ceil(ny/256), ceil(nq/q_per_block)).
 // ------------------------------------------------------------------------------------
 template <bool L2, int D, bool FILTER>
-__global__ __launch_bounds__(256) void k_pairwise_rowreg(const float* __restrict__ x, int nq,
-                                                         const float* __restrict__ y, int64_t ny,
-                                                         float* __restrict__ out, int64_t ld_out,
-                                                         int q_per_block, FilterDesc filt,
-                                                         float min_score, float max_score,
-                                                         float sentinel, int64_t row_base) {
-    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int q0 = blockIdx.y * q_per_block;
+__device__ __forceinline__ void pairwise_rowreg_body(int bx, int by, const float* __restrict__ x, int nq,
+                                                     const float* __restrict__ y, int64_t ny,
+                                                     float* __restrict__ out, int64_t ld_out,
+                                                     int q_per_block, const FilterDesc& filt,
+                                                     float min_score, float max_score,
+                                                     float sentinel, int64_t row_base) {
+    const int64_t row = (int64_t)bx * 256 + threadIdx.x;
+    const int q0 = by * q_per_block;
     const int q1 = min(nq, q0 + q_per_block);
     float yr[D];
     const bool live = row < ny;
@@ -77,6 +77,16 @@ __global__ __launch_bounds__(256) void k_pairwise_rowreg(const float* __restrict
         }
         if (live) out[(int64_t)q * ld_out + row] = dis;
     }
+}
+template <bool L2, int D, bool FILTER>
+__global__ __launch_bounds__(256) void k_pairwise_rowreg(const float* __restrict__ x, int nq,
+                                                         const float* __restrict__ y, int64_t ny,
+                                                         float* __restrict__ out, int64_t ld_out,
+                                                         int q_per_block, FilterDesc filt,
+                                                         float min_score, float max_score,
+                                                         float sentinel, int64_t row_base) {
+    pairwise_rowreg_body<L2, D, FILTER>(blockIdx.x, blockIdx.y, x, nq, y, ny, out, ld_out, q_per_block, filt, min_score,
+                                        max_score, sentinel, row_base);
 }
 
 // Same contract, queries staged in LDS and broadcast (one ds_read_b128 feeds a whole wave), packed
@@ -670,10 +680,9 @@ void launch_l2_gemmform(hipStream_t s, const float* x, int nq, int d, const floa
 // block = 256 threads = the 256 centroids of one sub-quantizer; grid = (M, nq / IPT_QB).
 // ------------------------------------------------------------------------------------
 constexpr int IPT_QB = 8;   // queries per workgroup: the centroid row stays in registers
-__global__ __launch_bounds__(256) void k_pq_ip_table(const float* __restrict__ x, int nq, int d, int M,
-                                                     int dsub, const float* __restrict__ pqc,
-                                                     float* __restrict__ out) {
-    const int m = blockIdx.x, q0 = blockIdx.y * IPT_QB, j = threadIdx.x;
+__device__ __forceinline__ void pq_ip_table_body(int m, int q0, const float* __restrict__ x, int nq, int d, int M,
+                                                 int dsub, const float* __restrict__ pqc, float* __restrict__ out) {
+    const int j = threadIdx.x;
     const float* c = pqc + ((int64_t)m * 256 + j) * dsub;            // per-lane row
 #pragma unroll
     for (int u = 0; u < IPT_QB; u++) {
@@ -683,6 +692,48 @@ __global__ __launch_bounds__(256) void k_pq_ip_table(const float* __restrict__ x
             out[((int64_t)q * M + m) * 256 + j] = fvec_ny_row<false>(xs, c, dsub);
         }
     }
+}
+__global__ __launch_bounds__(256) void k_pq_ip_table(const float* __restrict__ x, int nq, int d, int M,
+                                                     int dsub, const float* __restrict__ pqc,
+                                                     float* __restrict__ out) {
+    pq_ip_table_body(blockIdx.x, blockIdx.y * IPT_QB, x, nq, d, M, dsub, pqc, out);
+}
+// Small batches (nq <= 16): the exact coarse distances (k_pairwise_rowreg, one query range) and the queries'
+// inner-product tables are independent of each other and each is a dozen workgroups: one launch, roles by block.
+template <int D>
+__global__ __launch_bounds__(256) void k_small_coarse_ip(const float* __restrict__ x, int nq, const float* __restrict__ cc,
+                                                         int nlist, float* __restrict__ mat, int row_blocks, int M,
+                                                         const float* __restrict__ pqc, float* __restrict__ st2) {
+    if ((int)blockIdx.x < row_blocks) {
+        // eight threads per centroid = the eight AVX lane accumulators of fvec_L2sqr (rerank_dev.h): 32 centroids per
+        // workgroup, coalesced 32-byte pieces, 128 workgroups at nlist 4096 instead of 16 threads-per-row ones
+        const int l = threadIdx.x & 7, row = (int)blockIdx.x * 32 + (threadIdx.x >> 3);
+        const bool live = row < nlist;
+        const float* yr = cc + (int64_t)(live ? row : 0) * D;
+        for (int q = 0; q < nq; q++) {
+            const float dis = rerank_dist8<true>(x + (int64_t)q * D, yr, D, l, live);
+            if (l == 0 && live) mat[(int64_t)q * nlist + row] = dis;
+        }
+    } else {
+        for (int q0 = 0; q0 < nq; q0 += IPT_QB) pq_ip_table_body((int)blockIdx.x - row_blocks, q0, x, nq, D, M, D / M, pqc, st2);
+    }
+}
+bool launch_small_coarse_ip(hipStream_t s, const float* x, int nq, int d, const float* cc, int nlist, float* mat, int M,
+                            const float* pqc, float* st2) {
+    if (nq <= 0 || nq > 2 * IPT_QB) return false;
+    const int rb = (nlist + 31) / 32;
+#define GH_SC(DD)                                                                                                 \
+    hipLaunchKernelGGL((k_small_coarse_ip<DD>), dim3(rb + M), dim3(256), 0, s, x, nq, cc, nlist, mat, rb, M, pqc, st2)
+    switch (d) {
+        case 128: GH_SC(128); break;
+        case 96: GH_SC(96); break;
+        case 64: GH_SC(64); break;
+        case 32: GH_SC(32); break;
+        case 16: GH_SC(16); break;
+        default: return false;
+    }
+#undef GH_SC
+    return true;
 }
 void launch_pq_ip_table(hipStream_t s, const float* x, int nq, int d, int M, const float* pqc,
                         float* out) {

@@ -502,19 +502,11 @@ __device__ __forceinline__ void wave_rank_take(unsigned long long* buf, int c, i
 }
 }  // namespace
 
+// the K smallest (key, position) of v[0..n) -> buf[0..return value), sorted; one wave, buf: SW_CAP items of LDS
 template <bool SMALLEST, int NPL>
-__global__ __launch_bounds__(256) void k_select_wave(const float* __restrict__ vals, int64_t seg_stride,
-                                                     const int* __restrict__ seg_len, int fixed_len,
-                                                     int nseg, int K, float* __restrict__ out_vals,
-                                                     int* __restrict__ out_pos,
-                                                     uint8_t* __restrict__ tie_flag = nullptr) {
-    __shared__ unsigned long long s_buf[4][SW_CAP];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int seg = blockIdx.x * 4 + w;
-    if (seg >= nseg) return;   // whole wave; the kernel has no workgroup barrier
-    const int n = seg_len ? seg_len[seg] : fixed_len;
-    const float* v = vals + (int64_t)seg * seg_stride;
-    unsigned long long* buf = s_buf[w];
+__device__ __forceinline__ int wave_select_row(const float* __restrict__ v, int n, int K, unsigned long long* buf,
+                                               uint8_t* __restrict__ tie_flag, int seg) {
+    const int lane = threadIdx.x & 63;
     int run = 0;               // buf[0..run): running top, sorted
     for (int base = 0; base < n; base += 64 * NPL) {
         uint32_t key[NPL];
@@ -611,6 +603,23 @@ __global__ __launch_bounds__(256) void k_select_wave(const float* __restrict__ v
             run = min(run + got, K);
         }
     }
+    return run;
+}
+
+template <bool SMALLEST, int NPL>
+__global__ __launch_bounds__(256) void k_select_wave(const float* __restrict__ vals, int64_t seg_stride,
+                                                     const int* __restrict__ seg_len, int fixed_len,
+                                                     int nseg, int K, float* __restrict__ out_vals,
+                                                     int* __restrict__ out_pos,
+                                                     uint8_t* __restrict__ tie_flag = nullptr) {
+    __shared__ unsigned long long s_buf[4][SW_CAP];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int seg = blockIdx.x * 4 + w;
+    if (seg >= nseg) return;   // whole wave; the kernel has no workgroup barrier
+    const int n = seg_len ? seg_len[seg] : fixed_len;
+    const float* v = vals + (int64_t)seg * seg_stride;
+    unsigned long long* buf = s_buf[w];
+    const int run = wave_select_row<SMALLEST, NPL>(v, n, K, buf, tie_flag, seg);
     const float sentinel = SMALLEST ? INFINITY : -INFINITY;
     for (int r = lane; r < K; r += 64) {
         float val = sentinel;
@@ -1425,6 +1434,526 @@ void launch_select_final(hipStream_t s, bool smallest, const unsigned long long*
         else GH_SF(false, 128);
     }
 #undef GH_SF
+}
+
+// ====================================================================================
+// Small batches (nq <= 16): a search is a chain of dependent, nearly empty kernels, each of which costs ~4 us of
+// launch + drain on this chip whatever it does, and a lone wave runs dependent instructions at ~10 cycles each.
+// These two kernels fold seven launches into two, 16 waves per query:
+//   k_small_coarse_select = top-nprobe of the coarse distances + the pairs' slab offsets (k_select_wave + k_pair_offsets)
+//   k_small_tail          = top-recall_num of the ADC slab + ids + exact re-rank + top-k + output
+//                           (k_select_stream + k_map_candidates + k_rerank_dist + k_select_wave + k_finalize_topk)
+// One workgroup per query; same (key, position) orders, same arithmetic (rerank_dev.h) as the kernels they replace.
+// ====================================================================================
+}  // namespace gh
+#include "rerank_dev.h"
+namespace gh {
+namespace {
+constexpr int SM_NT = 1024, SM_NW = SM_NT / 64, SM_BINS = 2048;
+
+// exclusive scan of one int per thread over the 1024-thread block; s_w: SM_NW ints.  Two barriers.
+__device__ __forceinline__ int block_excl_scan_sm(int v, int* s_w, int& total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int incl = wave_incl_scan(v);
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < SM_NW; i++) {
+        const int t = s_w[i];
+        if (i < w) base += t;
+        tot += t;
+    }
+    total = tot;
+    __syncthreads();
+    return base + incl - v;
+}
+
+// Rank sort of a[0..n) (distinct 64-bit items) by the 16 waves of the block: item group g = 64 items, and the j range
+// of the comparisons is cut into slices so that every wave has work (block_rank_sort leaves 12 of 16 waves idle at
+// n = 200 and the other four walk all of a[]).  s_rank: n ints of scratch.
+__device__ __forceinline__ void block_rank_sort_sm(unsigned long long* a, int n, int* s_rank) {
+    if (n > SM_NT) {   // uniform
+        block_rank_sort<SM_NT, 2>(a, n);
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ngroups = (n + 63) >> 6;
+    int lg = 0;
+    while ((1 << lg) < ngroups) lg++;
+    const int slices = SM_NW >> lg;
+    for (int i = tid; i < n; i += SM_NT) s_rank[i] = 0;
+    __syncthreads();
+    const int g = w & ((1 << lg) - 1), sl = w >> lg;
+    const int i = g * 64 + lane;
+    const unsigned long long item = i < n ? a[i] : ~0ull;
+    if (g < ngroups) {   // uniform per wave
+        const int j0 = (int)((int64_t)sl * n / slices), j1 = (int)((int64_t)(sl + 1) * n / slices);
+        int rk = 0, j = j0;
+        for (; j + 8 <= j1; j += 8) {
+            unsigned long long x[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) x[e] = a[j + e];
+#pragma unroll
+            for (int e = 0; e < 8; e++) rk += x[e] < item ? 1 : 0;
+        }
+        for (; j < j1; j++) rk += a[j] < item ? 1 : 0;
+        if (i < n && rk) atomicAdd(&s_rank[i], rk);
+    }
+    __syncthreads();
+    if (sl == 0 && i < n) a[s_rank[i]] = item;
+    __syncthreads();
+}
+
+// The K smallest (key, position) items of v[0..n) into s_it[0..min(n, K)), unsorted.  The K-th key is found exactly
+// by histogram passes over [smallest key, largest key] cut into <= 2048 equal bins, then over the bin holding the
+// K-th, and so on (2 passes for distances spread over ~2^22 key values); a radix pass on raw float bits would put a
+// whole row into three or four bins and serialise its LDS atomics.  Items below the K-th key are all taken, items AT
+// it in position order (every thread owns a contiguous range of the row).
+template <bool SMALLEST>
+__device__ __forceinline__ int block_select_items(const float* __restrict__ v, int n, int K, unsigned long long* s_it,
+                                                  int* s_hist, int* s_w, uint32_t* s_pick) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (n <= K) {
+        for (int i = tid; i < n; i += SM_NT) s_it[i] = ((unsigned long long)sel_key<SMALLEST>(v[i]) << 32) | (unsigned)i;
+        return n;
+    }
+    uint32_t kmin = 0xffffffffu, kmax = 0u;
+    for (int i = tid; i < n; i += SM_NT) {
+        const uint32_t key = sel_key<SMALLEST>(v[i]);
+        kmin = key < kmin ? key : kmin;
+        kmax = key > kmax ? key : kmax;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t a = (uint32_t)__shfl_xor((int)kmin, o, 64), b = (uint32_t)__shfl_xor((int)kmax, o, 64);
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+    }
+    if (lane == 0) {
+        s_w[w] = (int)kmin;
+        s_w[SM_NW + w] = (int)kmax;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SM_NW; i++) {
+        const uint32_t a = (uint32_t)s_w[i], b = (uint32_t)s_w[SM_NW + i];
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+    }
+    __syncthreads();
+    uint32_t lo = kmin, range = kmax - kmin;   // keys of interest: lo .. lo + range
+    int need = K;
+    for (;;) {
+        const int bits = 32 - __clz((int)range | 0) - (range == 0 ? 0 : 0);
+        const int nbits = range == 0 ? 0 : bits;
+        const int shift = nbits > 11 ? nbits - 11 : 0;
+        for (int i = tid; i < SM_BINS; i += SM_NT) s_hist[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += SM_NT) {
+            const uint32_t off = sel_key<SMALLEST>(v[i]) - lo;   // wraps above range for keys below lo
+            if (off <= range) atomicAdd(&s_hist[off >> shift], 1);
+        }
+        __syncthreads();
+        constexpr int PER = SM_BINS / SM_NT;
+        int loc = 0;
+#pragma unroll
+        for (int u = 0; u < PER; u++) loc += s_hist[tid * PER + u];
+        int tot;
+        const int ex = block_excl_scan_sm(loc, s_w, tot);
+        if (ex < need && need <= ex + loc) {
+            int run = ex;
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const int hcur = s_hist[tid * PER + u];
+                if (run < need && need <= run + hcur) {
+                    s_pick[0] = (uint32_t)(tid * PER + u);
+                    s_pick[1] = (uint32_t)(need - run);
+                }
+                run += hcur;
+            }
+        }
+        __syncthreads();
+        const uint32_t b = s_pick[0];
+        need = (int)s_pick[1];
+        const uint32_t sub = b << shift;
+        lo += sub;
+        const uint32_t rest = range - sub;
+        range = shift == 0 ? 0u : (rest < ((1u << shift) - 1u) ? rest : ((1u << shift) - 1u));
+        __syncthreads();
+        if (shift == 0) break;
+    }
+    const uint32_t kth = lo;
+    const int c = (n + SM_NT - 1) / SM_NT;
+    const int i0 = min(n, tid * c), i1 = min(n, i0 + c);
+    int nl = 0, ne = 0;
+    for (int i = i0; i < i1; i++) {
+        const uint32_t key = sel_key<SMALLEST>(v[i]);
+        nl += key < kth ? 1 : 0;
+        ne += key == kth ? 1 : 0;
+    }
+    int tl, te;
+    int ol = block_excl_scan_sm(nl, s_w, tl);
+    int oe = block_excl_scan_sm(ne, s_w, te);
+    const int eq_base = K - need;   // == tl
+    for (int i = i0; i < i1; i++) {
+        const uint32_t key = sel_key<SMALLEST>(v[i]);
+        const unsigned long long item = ((unsigned long long)key << 32) | (unsigned)i;
+        if (key < kth) s_it[ol++] = item;
+        else if (key == kth) {
+            if (oe < need) s_it[eq_base + oe] = item;
+            oe++;
+        }
+    }
+    return K;
+}
+
+// The min(n, K) smallest (key, position) items of v[0..n), SORTED, in s_it (capacity MAXI * 1024 items).
+// One pass: the row's keys stay in registers (NREG per thread when the row fits), one histogram over [min, max]
+// finds the bin holding the K-th smallest; everything up to and including that bin -- K plus a handful -- is appended
+// and rank-sorted.  Only when that bin is crowded (mass ties) does block_select_items refine it pass by pass.
+template <bool SMALLEST, int NREG, int MAXI>
+__device__ __forceinline__ int block_select_sorted(const float* __restrict__ v, int n, int K, unsigned long long* s_it,
+                                                   int* s_hist, int* s_w, uint32_t* s_pick) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (n <= K) {
+        for (int i = tid; i < n; i += SM_NT) s_it[i] = ((unsigned long long)sel_key<SMALLEST>(v[i]) << 32) | (unsigned)i;
+        block_rank_sort_sm(s_it, n, s_hist);
+        return n;
+    }
+    const bool inreg = n <= NREG * SM_NT;   // uniform
+    uint32_t kreg[NREG];
+    uint32_t kmin = 0xffffffffu, kmax = 0u;
+    if (inreg) {
+#pragma unroll
+        for (int u = 0; u < NREG; u++) {
+            const int i = tid + SM_NT * u;
+            kreg[u] = i < n ? sel_key<SMALLEST>(v[i]) : 0xffffffffu;
+            if (i < n) {
+                kmin = kreg[u] < kmin ? kreg[u] : kmin;
+                kmax = kreg[u] > kmax ? kreg[u] : kmax;
+            }
+        }
+    } else {
+        for (int i = tid; i < n; i += SM_NT) {
+            const uint32_t key = sel_key<SMALLEST>(v[i]);
+            kmin = key < kmin ? key : kmin;
+            kmax = key > kmax ? key : kmax;
+        }
+    }
+    kmin = __reduce_min_sync(~0ull, kmin);   // DPP row operations, not LDS shuffles
+    kmax = __reduce_max_sync(~0ull, kmax);
+    for (int i = tid; i < SM_BINS; i += SM_NT) s_hist[i] = 0;
+    if (lane == 0) {
+        s_w[w] = (int)kmin;
+        s_w[SM_NW + w] = (int)kmax;
+    }
+    if (tid == 0) s_pick[2] = 0;   // append counter
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SM_NW; i++) {
+        const uint32_t a = (uint32_t)s_w[i], b = (uint32_t)s_w[SM_NW + i];
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+    }
+    const uint32_t range = kmax - kmin;
+    const int nbits = range == 0 ? 0 : 32 - __clz((int)range);
+    const int shift = nbits > 11 ? nbits - 11 : 0;
+    if (inreg) {
+#pragma unroll
+        for (int u = 0; u < NREG; u++)
+            if (tid + SM_NT * u < n) atomicAdd(&s_hist[(kreg[u] - kmin) >> shift], 1);
+    } else {
+        for (int i = tid; i < n; i += SM_NT) atomicAdd(&s_hist[(sel_key<SMALLEST>(v[i]) - kmin) >> shift], 1);
+    }
+    __syncthreads();
+    constexpr int PER = SM_BINS / SM_NT;
+    int loc = 0;
+#pragma unroll
+    for (int u = 0; u < PER; u++) loc += s_hist[tid * PER + u];
+    int tot;
+    const int ex = block_excl_scan_sm(loc, s_w, tot);
+    if (ex < K && K <= ex + loc) {
+        int run = ex;
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int hcur = s_hist[tid * PER + u];
+            if (run < K && K <= run + hcur) {
+                s_pick[0] = (uint32_t)(tid * PER + u);
+                s_pick[1] = (uint32_t)(run + hcur);   // items up to and including the bin
+            }
+            run += hcur;
+        }
+    }
+    __syncthreads();
+    const uint32_t b = s_pick[0];
+    const int T = (int)s_pick[1];
+    if (T > MAXI * SM_NT) {   // uniform: the boundary bin is crowded
+        __syncthreads();
+        block_select_items<SMALLEST>(v, n, K, s_it, s_hist, s_w, s_pick);
+        block_rank_sort_sm(s_it, K, s_hist);
+        return K;
+    }
+    auto append = [&](uint32_t key, int i, bool live) {
+        const bool take = live && ((key - kmin) >> shift) <= b;
+        const unsigned long long mask = __ballot(take);
+        if (mask) {   // uniform
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s_pick[2], (uint32_t)__popcll(mask));
+            base = (uint32_t)__shfl((int)base, 0, 64);
+            if (take) s_it[base + __popcll(mask & ((1ull << lane) - 1ull))] = ((unsigned long long)key << 32) | (unsigned)i;
+        }
+    };
+    if (inreg) {
+#pragma unroll
+        for (int u = 0; u < NREG; u++) append(kreg[u], tid + SM_NT * u, tid + SM_NT * u < n);
+    } else {
+        for (int i0 = 0; i0 < n; i0 += SM_NT) {
+            const int i = i0 + tid;
+            append(i < n ? sel_key<SMALLEST>(v[i]) : 0u, i, i < n);
+        }
+    }
+    block_rank_sort_sm(s_it, T, s_hist);   // the histogram is done with
+    return K;
+}
+}  // namespace
+
+struct SmallSelectArgs {
+    const float* mat;
+    int nlist, K;
+    float* out_vals;
+    int* out_pos;
+    const int* list_len;
+    const uint8_t* list_mask;
+    const int64_t* list_off;
+    int* pair_off;
+    int* q_total;
+    int64_t* pair_base;
+};
+__device__ __forceinline__ void small_coarse_select_body(int q, const SmallSelectArgs& A) {
+    const float* __restrict__ mat = A.mat;
+    const int nlist = A.nlist, K = A.K;
+    float* __restrict__ out_vals = A.out_vals;
+    int* __restrict__ out_pos = A.out_pos;
+    const int* __restrict__ list_len = A.list_len;
+    const uint8_t* __restrict__ list_mask = A.list_mask;
+    const int64_t* __restrict__ list_off = A.list_off;
+    int* __restrict__ pair_off = A.pair_off;
+    int* __restrict__ q_total = A.q_total;
+    int64_t* __restrict__ pair_base = A.pair_base;
+    __shared__ int s_hist[SM_BINS];
+    __shared__ unsigned long long s_it[SM_NT];
+    __shared__ int s_w[2 * SM_NW];
+    __shared__ uint32_t s_pick[3];
+    __shared__ int s_probe[64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const float* v = mat + (int64_t)q * nlist;
+    const int cnt = block_select_sorted<true, 4, 1>(v, nlist, K, s_it, s_hist, s_w, s_pick);   // trailing barrier inside
+    if (tid < 64) {   // cnt <= K <= 64
+        const unsigned long long mine = tid < cnt ? s_it[tid] : ~0ull;
+        const int rk = tid;
+        int pos = -1;
+        float val = INFINITY;
+        if (tid < cnt) {
+            pos = (int)(uint32_t)mine;
+            val = v[pos];
+            if (val == INFINITY) pos = -1;
+        }
+        s_probe[tid] = -1;
+        __builtin_amdgcn_wave_barrier();
+        if (tid < cnt) {
+            out_vals[(int64_t)q * K + rk] = val;
+            out_pos[(int64_t)q * K + rk] = pos;
+            s_probe[rk] = pos;
+        } else if (tid < K) {
+            out_vals[(int64_t)q * K + tid] = INFINITY;
+            out_pos[(int64_t)q * K + tid] = -1;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // k_pair_offsets for this query (K <= 64 probes: one pass)
+        int len = 0;
+        int64_t lbase = 0;
+        if (lane < K) {
+            const int l = s_probe[lane];
+            if (l >= 0 && l < nlist && (!list_mask || list_mask[l])) {
+                len = list_len[l];
+                lbase = list_off[l];
+            }
+        }
+        const int incl = wave_incl_scan(len);
+        if (lane < K) {
+            pair_off[(int64_t)q * (K + 1) + lane] = incl - len;
+            if (pair_base) pair_base[(int64_t)q * K + lane] = lbase;
+        }
+        const int tot = __shfl(incl, 63, 64);
+        if (lane == 0) {
+            pair_off[(int64_t)q * (K + 1) + K] = tot;
+            q_total[q] = tot;
+        }
+    }
+}
+
+__global__ __launch_bounds__(SM_NT) void k_small_coarse_select(SmallSelectArgs A) { small_coarse_select_body(blockIdx.x, A); }
+
+void launch_small_coarse_select(hipStream_t s, const float* mat, int nlist, int nq, int P, float* out_vals, int* out_pos,
+                                const int* list_len, const uint8_t* list_mask, const int64_t* list_off, int* pair_off,
+                                int* q_total, int64_t* pair_base) {
+    if (nq <= 0) return;
+    if (P > 64) abort();   // callers gate on this
+    const SmallSelectArgs A{mat, nlist, P, out_vals, out_pos, list_len, list_mask, list_off, pair_off, q_total, pair_base};
+    hipLaunchKernelGGL(k_small_coarse_select, dim3(nq), dim3(SM_NT), 0, s, A);
+}
+
+template <bool L2>
+__global__ __launch_bounds__(SM_NT) void k_small_tail(const float* __restrict__ slab, int64_t q_stride,
+                                                      const int* __restrict__ q_total, int R, int P,
+                                                      const int* __restrict__ probe_list,
+                                                      const int* __restrict__ pair_off,
+                                                      const int64_t* __restrict__ list_off,
+                                                      const int64_t* __restrict__ ids, float* __restrict__ cand_dis,
+                                                      int* __restrict__ cand_pos, int64_t* __restrict__ cand_ids,
+                                                      int has_rank, const float* __restrict__ x, int d,
+                                                      const float* __restrict__ raw, int64_t nraw, int k,
+                                                      float min_score, float max_score, float neutral,
+                                                      float* __restrict__ distances, int64_t* __restrict__ labels,
+                                                      unsigned long long* __restrict__ dbg) {
+#define GH_T(i) do { if (dbg && threadIdx.x == 0 && blockIdx.x == 0) dbg[i] = wall_clock64(); } while (0)
+    __shared__ int s_hist[SM_BINS];
+    __shared__ unsigned long long s_it[2 * SM_NT];
+    __shared__ int64_t s_id[1024];
+    __shared__ float s_val[1024];
+    __shared__ int s_w[2 * SM_NW];
+    __shared__ uint32_t s_pick[3];
+    __shared__ int s_off[65];
+    __shared__ int64_t s_lbase[64];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const float* v = slab + (int64_t)q * q_stride;
+    const int n = q_total[q];
+    const float sentinel = L2 ? INFINITY : -INFINITY;
+    // the pairs' slab offsets and list bases: loaded while the selection runs, read from LDS by the id look-up
+    GH_T(0);
+    if (tid <= P) s_off[tid] = pair_off[(int64_t)q * (P + 1) + tid];
+    if (tid < P) {
+        const int l = probe_list[(int64_t)q * P + tid];
+        s_lbase[tid] = l >= 0 ? list_off[l] : 0;
+    }
+    const int cnt = block_select_sorted<L2, 16, 2>(v, n, R, s_it, s_hist, s_w, s_pick);   // barriers inside
+    GH_T(1);
+    // top-R table of the query: ADC distance, slab position, vector id (k_map_candidates)
+    const int* off = s_off;
+    for (int r = tid; r < R; r += SM_NT) {
+        float val = sentinel;
+        int pos = -1;
+        int64_t id = -1;
+        if (r < cnt) {
+            pos = (int)(uint32_t)s_it[r];
+            val = v[pos];
+            if (val == sentinel) pos = -1;
+        }
+        if (pos >= 0) {
+            int lo = 0, hi = P - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (off[mid] <= pos) lo = mid; else hi = mid - 1;
+            }
+            id = ids[s_lbase[lo] + (pos - off[lo])] & 0x7fffffffffffffffLL;
+        }
+        cand_dis[(int64_t)q * R + r] = val;
+        cand_pos[(int64_t)q * R + r] = pos;
+        cand_ids[(int64_t)q * R + r] = id;
+        s_id[r] = id;
+        s_val[r] = val;
+    }
+    __syncthreads();
+    GH_T(2);
+    if (has_rank) {   // k_rerank_topk, 128 candidates in flight
+        const int l = tid & 7, g = tid >> 3;
+        const float* xq = x + (int64_t)q * d;
+        for (int r0 = 0; r0 < R; r0 += SM_NT / 8) {
+            const int r = r0 + g;
+            int64_t id = -1;
+            if (r < R) id = s_id[r];
+            const bool live = id >= 0 && id < nraw;
+            float dis = rerank_dist8<L2>(xq, raw + (live ? id : 0) * d, d, l, live);
+            if (l == 0 && r < R) {
+                if (!live || !(dis <= max_score && dis >= min_score)) dis = sentinel;
+                const uint32_t key = L2 ? f2key(dis) : ~f2key(dis);
+                s_it[r] = ((unsigned long long)key << 32) | (unsigned)r;
+            }
+        }
+        GH_T(3);
+        block_rank_sort_sm(s_it, R, s_hist);
+        GH_T(4);
+        for (int i = tid; i < k; i += SM_NT) {
+            float val = neutral;
+            int64_t id = -1;
+            if (i < R) {
+                const unsigned long long it = s_it[i];
+                const uint32_t key = (uint32_t)(it >> 32);
+                const float dv = key2f(L2 ? key : ~key);
+                if (dv != sentinel) {
+                    val = dv;
+                    id = s_id[(uint32_t)it];
+                }
+            }
+            distances[(int64_t)q * k + i] = val;
+            labels[(int64_t)q * k + i] = id;
+        }
+        GH_T(5);
+    } else {          // k_finalize_norank
+        int running = 0;
+        for (int r0 = 0; r0 < R && running < k; r0 += SM_NT) {
+            const int r = r0 + tid;
+            float dis = 0.f;
+            int64_t id = -1;
+            if (r < R) {
+                dis = s_val[r];
+                id = s_id[r];
+            }
+            const int flag = (id != -1 && dis <= max_score && dis >= min_score) ? 1 : 0;
+            int tot;
+            const int ex = block_excl_scan_sm(flag, s_w, tot);
+            const int slot = running + ex;
+            if (flag && slot < k) {
+                distances[(int64_t)q * k + slot] = dis;
+                labels[(int64_t)q * k + slot] = id;
+            }
+            running += tot;
+        }
+        for (int i = min(running, k) + tid; i < k; i += SM_NT) {
+            distances[(int64_t)q * k + i] = neutral;
+            labels[(int64_t)q * k + i] = -1;
+        }
+    }
+}
+
+void launch_small_tail(hipStream_t s, bool l2, const float* slab, int64_t q_stride, const int* q_total, int nq, int R, int P,
+                       const int* probe_list, const int* pair_off, const int64_t* list_off, const int64_t* ids,
+                       float* cand_dis, int* cand_pos, int64_t* cand_ids, int has_rank, const float* x, int d,
+                       const float* raw, int64_t nraw, int k, float min_score, float max_score, float neutral,
+                       float* distances, int64_t* labels) {
+    if (nq <= 0) return;
+    if (R > 1024) abort();   // callers gate on this
+    static unsigned long long* dbg = nullptr;
+    static int shown = 0;
+    if (getenv("GAMMA_HIP_SM_DBG")) {
+        if (!dbg) (void)hipMalloc((void**)&dbg, 64);
+        if (shown++ % 10 == 9) {
+            unsigned long long h[6];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+            fprintf(stderr, "small tail (10 ns ticks): select %llu map %llu rerank %llu sort %llu out %llu\n", h[1] - h[0], h[2] - h[1],
+                    h[3] - h[2], h[4] - h[3], h[5] - h[4]);
+        }
+    }
+    if (l2)
+        hipLaunchKernelGGL((k_small_tail<true>), dim3(nq), dim3(SM_NT), 0, s, slab, q_stride, q_total, R, P, probe_list,
+                           pair_off, list_off, ids, cand_dis, cand_pos, cand_ids, has_rank, x, d, raw, nraw, k, min_score,
+                           max_score, neutral, distances, labels, dbg);
+    else
+        hipLaunchKernelGGL((k_small_tail<false>), dim3(nq), dim3(SM_NT), 0, s, slab, q_stride, q_total, R, P, probe_list,
+                           pair_off, list_off, ids, cand_dis, cand_pos, cand_ids, has_rank, x, d, raw, nraw, k, min_score,
+                           max_score, neutral, distances, labels, dbg);
 }
 
 }  // namespace gh

@@ -1062,3 +1062,45 @@ def test_fused_coarse_matches_matrix_path_and_oracle(d, nlist, P, nq):
         compare_topk(Do, Io, D0[:600], I0[:600].astype(np.int64))
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("d,M,nlist", [(32, 8, 64), (128, 16, 256), (64, 32, 64)])
+def test_small_batch_path_is_the_regular_chain(d, M, nlist):
+    """Calls of 1..16 queries run as four fused kernels (gamma_hip.cpp ivfpq_small); every output and every stage
+    table must equal the regular chain's, byte for byte: with / without re-rank, recall_num above and below the
+    candidate count, k > candidates, deleted docs, a score window, and the oracle for good measure."""
+    case = fixtures.trained_case(d=d, nlist=nlist, M=M, N=20000, nq=64, metric=B.METRIC_L2)
+    g = fixtures.load_hip(case)
+    rng = np.random.default_rng(d + M)
+    N = case["N"]
+    dead = rng.choice(N, N // 10, replace=False)
+    try:
+        for step in range(2):
+            if step == 1:
+                bm = np.zeros((N >> 3) + 1, dtype=np.uint8)
+                np.bitwise_or.at(bm, dead >> 3, (1 << (dead & 7)).astype(np.uint8))
+                g.bitmap_upload(bm, N)
+            for nq in (1, 2, 5, 8, 13, 16):
+                q = case["q"][7:7 + nq]
+                for has_rank in (True, False):
+                    for P, R, k, win in ((8, 100, 10, None), (1, 50, 10, None), (32, 1000, 100, None),
+                                         (4, 20, 30, None), (16, 200, 10, (2e4, 9e4))):
+                        kw = dict(WIDE)
+                        if win:
+                            kw = dict(min_score=win[0], max_score=win[1])
+                        args = api.SearchArgs(metric=api.METRIC_L2, nprobe=P, recall_num=R, has_rank=has_rank, **kw)
+                        g.set_small_path(False)
+                        D0, I0 = g.ivfpq_search(q, k, args)
+                        s0 = g.last_stages(nq, P, max(R, k))
+                        g.set_small_path(True)
+                        D1, I1 = g.ivfpq_search(q, k, args)
+                        s1 = g.last_stages(nq, P, max(R, k))
+                        tag = (step, nq, has_rank, P, R, k)
+                        assert D0.tobytes() == D1.tobytes() and np.array_equal(I0, I1), tag
+                        for key in s0:
+                            assert s0[key].tobytes() == s1[key].tobytes(), (tag, key)
+            if step == 0:
+                (D, I, st), (Dg, Ig) = run_both(case, g, case["q"][:3], 10, 8, 100, B.METRIC_L2, True)
+                compare_topk(D, I, Dg, Ig)
+    finally:
+        g.close()
