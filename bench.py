@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--dup-queries", type=int, default=0,
                     help="experiment: every batch repeats its first N queries (the lists they probe stay cache "
                          "resident: what the scan costs without its table traffic)")
+    ap.add_argument("--batches", default="1,32,1024", help="batch sizes of the qps_by_batch leg (BASELINE.md protocol)")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the extra legs (exact ties, batch sizes 1/32/1024, coarse_mode 0, C2 flat)")
     ap.add_argument("--pmc-traffic", type=float, default=None,
@@ -263,7 +264,7 @@ def main():
                                "batch": gnq}
         # (b) batch sizes of the BASELINE.md protocol: one Search call of nq queries, device buffers
         byb = {}
-        for nqb in (1, 32, 1024):
+        for nqb in [int(v) for v in a.batches.split(",")]:
             sec = timed(lambda: g.ivfpq_search_device(d_q.data_ptr(), nqb, k, args, d_D.data_ptr(), d_I.data_ptr()),
                         200 if nqb < 1024 else 100, 10)
             byb[str(nqb)] = {"qps": round(nqb / sec, 1), "us_per_call": round(sec * 1e6, 1)}

@@ -1038,14 +1038,18 @@ int ivfpq_stage_b(H* h, const gamma_hip_search_params* p, int nq, const float* d
     return GAMMA_HIP_OK;
 }
 
-// ---- small batches (nq <= 16): the same search in four launches instead of eleven ---------------------------------
+// ---- small batches (nq <= 512; measured cross-over with the regular chain ~1000): four or five launches instead of eleven ---------------------------------
 // exact coarse distances + query tables | top-nprobe + slab offsets | scan | top-recall_num + ids + re-rank + top-k
 // (kernels.hip k_small_coarse_ip, select.hip k_small_coarse_select / k_small_tail).  Each launch of the regular
 // chain costs ~4 us of launch + drain at this size, whatever it computes.
 bool ivfpq_small_ok(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int nq, int R) {
     static const bool off = getenv("GAMMA_HIP_NO_SMALL_PATH") != nullptr;
     const int d = h->d;
-    return !off && h->small_path && nq >= 1 && nq <= 16 && p->metric == GAMMA_HIP_METRIC_L2 && p->coarse_mode == 0 &&
+    static const int max_nq = getenv("GAMMA_HIP_SMALL_MAX") ? atoi(getenv("GAMMA_HIP_SMALL_MAX")) : 512;
+    // exact coarse distances (faiss below 20 queries) come from the fused first kernel, which covers 16 queries; the
+    // GEMM form (20 queries and more) from the regular matrix kernel
+    return !off && h->small_path && nq >= 1 && nq <= max_nq && (p->coarse_mode == 1 || nq <= 16) &&
+           p->metric == GAMMA_HIP_METRIC_L2 &&
            p->nprobe <= 64 && R <= 1024 && !h->exact_ties && !h->profile && !fc.d_qf && !h->d_list_mask &&
            (d == 16 || d == 32 || d == 64 || d == 96 || d == 128) && h->nlist <= 16384 &&
            (int64_t)p->nprobe * std::max(1, h->max_list_len) <= (1 << 22) && (!p->has_rank || (h->d_raw && h->raw_d == h->d));
@@ -1072,8 +1076,13 @@ int ivfpq_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int n
     // (folding the selection into the first launch -- last workgroup done selects -- was tried: the device-scope
     // release / acquire it needs costs more than the launch it saves, 24 us against 4 + 8: the XCDs' L2s are
     // written back and invalidated either way)
-    if (!gh::launch_small_coarse_ip(s, d_x, nq, d, h->d_cc, nlist, h->w_mat.as<float>(), M, h->d_pqc, h->w_st2.as<float>()))
+    if (p->coarse_mode == 1) {
+        gh::launch_l2_gemmform(s, d_x, nq, d, h->d_cc, nlist, nullptr, h->d_cc_norms, h->w_mat.as<float>(), nlist, true);
+        gh::launch_pq_ip_table(s, d_x, nq, d, M, h->d_pqc, h->w_st2.as<float>());
+    } else if (!gh::launch_small_coarse_ip(s, d_x, nq, d, h->d_cc, nlist, h->w_mat.as<float>(), M, h->d_pqc,
+                                           h->w_st2.as<float>())) {
         return fail(h, GAMMA_HIP_EINVAL, "small path: shape not covered");   // ivfpq_small_ok gates on the same shapes
+    }
     gh::launch_small_coarse_select(s, h->w_mat.as<float>(), nlist, nq, P, h->w_coarse_dis.as<float>(), h->w_probe.as<int>(),
                                    h->d_list_len, h->d_list_mask, h->d_list_off, h->w_pair_off.as<int>(),
                                    h->w_qtotal.as<int>(), h->w_pair_base.as<int64_t>());

@@ -1066,7 +1066,7 @@ def test_fused_coarse_matches_matrix_path_and_oracle(d, nlist, P, nq):
 
 @pytest.mark.parametrize("d,M,nlist", [(32, 8, 64), (128, 16, 256), (64, 32, 64)])
 def test_small_batch_path_is_the_regular_chain(d, M, nlist):
-    """Calls of 1..16 queries run as four fused kernels (gamma_hip.cpp ivfpq_small); every output and every stage
+    """Calls of up to 512 queries run as four or five fused kernels (gamma_hip.cpp ivfpq_small); every output and every stage
     table must equal the regular chain's, byte for byte: with / without re-rank, recall_num above and below the
     candidate count, k > candidates, deleted docs, a score window, and the oracle for good measure."""
     case = fixtures.trained_case(d=d, nlist=nlist, M=M, N=20000, nq=64, metric=B.METRIC_L2)
@@ -1080,8 +1080,9 @@ def test_small_batch_path_is_the_regular_chain(d, M, nlist):
                 bm = np.zeros((N >> 3) + 1, dtype=np.uint8)
                 np.bitwise_or.at(bm, dead >> 3, (1 << (dead & 7)).astype(np.uint8))
                 g.bitmap_upload(bm, N)
-            for nq in (1, 2, 5, 8, 13, 16):
-                q = case["q"][7:7 + nq]
+            big = synth.sift_like(300, d=d, seed=4242)
+            for nq in (1, 2, 5, 8, 13, 16, 20, 37, 64, 300):
+                q = case["q"][:nq] if nq <= 64 else big
                 for has_rank in (True, False):
                     for P, R, k, win in ((8, 100, 10, None), (1, 50, 10, None), (32, 1000, 100, None),
                                          (4, 20, 30, None), (16, 200, 10, (2e4, 9e4))):
