@@ -1105,3 +1105,37 @@ def test_small_batch_path_is_the_regular_chain(d, M, nlist):
                 compare_topk(D, I, Dg, Ig)
     finally:
         g.close()
+
+
+def test_large_batch_search_with_fused_coarse_matches_oracle():
+    """A whole search at a size where the coarse quantizer runs without the distance matrix (csrc/coarse.hip:
+    >= 4096 queries, >= 2048 lists): stage tables and results against the oracle (GEMM-form coarse, as faiss above
+    20 queries).  Random codebooks stand in for training: parity does not care how good they are."""
+    d, nlist, M, N, nq = 32, 2048, 8, 40000, 4200
+    rng = np.random.default_rng(7)
+    base = synth.sift_like(N, d=d, seed=11)
+    q = synth.sift_like(nq, d=d, seed=12)
+    cc = base[rng.choice(N, nlist, replace=False)].copy()
+    pq = (rng.standard_normal((M, 256, d // M)) * 20).astype(np.float32)
+    o = B.OracleIVFPQ(d, nlist, M, 8, B.METRIC_L2, bucket_init_size=100)
+    o.set_trained(cc, pq, None)
+    B.lib().go_set_assign_mode(0)
+    assert o.add(base)
+    o.set_raw(base)
+    case = dict(d=d, nlist=nlist, M=M, N=N, nq=nq, metric=B.METRIC_L2, base=base, q=q, cc=cc, pq=pq, oracle=o)
+    g = fixtures.load_hip(case, bucket_init_size=100)
+    try:
+        for has_rank in (True, False):
+            (D, I, st), (Dg, Ig) = run_both(case, g, q, 10, 16, 100, B.METRIC_L2, has_rank, coarse_mode=1)
+            sg = g.last_stages(nq, 16, 100)
+            assert st["coarse_dis"].tobytes() == sg["coarse_dis"].tobytes()
+            excluded = compare_search(D, I, st, Dg, Ig, sg)
+            assert excluded <= nq // 100
+        g.set_coarse_fused(False)      # and the matrix path gives the same bytes
+        args = api.SearchArgs(metric=api.METRIC_L2, nprobe=16, recall_num=100, has_rank=True, coarse_mode=1, **WIDE)
+        D0, I0 = g.ivfpq_search(q, 10, args)
+        g.set_coarse_fused(True)
+        D1, I1 = g.ivfpq_search(q, 10, args)
+        assert D0.tobytes() == D1.tobytes() and np.array_equal(I0, I1)
+    finally:
+        g.close()
