@@ -504,9 +504,18 @@ __device__ __forceinline__ void wave_rank_take(unsigned long long* buf, int c, i
 
 // the K smallest (key, position) of v[0..n) -> buf[0..return value), sorted; one wave, buf: SW_CAP items of LDS
 template <bool SMALLEST, int NPL>
-__device__ __forceinline__ int wave_select_row(const float* __restrict__ v, int n, int K, unsigned long long* buf,
-                                               uint8_t* __restrict__ tie_flag, int seg) {
-    const int lane = threadIdx.x & 63;
+__global__ __launch_bounds__(256) void k_select_wave(const float* __restrict__ vals, int64_t seg_stride,
+                                                     const int* __restrict__ seg_len, int fixed_len,
+                                                     int nseg, int K, float* __restrict__ out_vals,
+                                                     int* __restrict__ out_pos,
+                                                     uint8_t* __restrict__ tie_flag = nullptr) {
+    __shared__ unsigned long long s_buf[4][SW_CAP];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int seg = blockIdx.x * 4 + w;
+    if (seg >= nseg) return;   // whole wave; the kernel has no workgroup barrier
+    const int n = seg_len ? seg_len[seg] : fixed_len;
+    const float* v = vals + (int64_t)seg * seg_stride;
+    unsigned long long* buf = s_buf[w];
     int run = 0;               // buf[0..run): running top, sorted
     for (int base = 0; base < n; base += 64 * NPL) {
         uint32_t key[NPL];
@@ -603,23 +612,6 @@ __device__ __forceinline__ int wave_select_row(const float* __restrict__ v, int 
             run = min(run + got, K);
         }
     }
-    return run;
-}
-
-template <bool SMALLEST, int NPL>
-__global__ __launch_bounds__(256) void k_select_wave(const float* __restrict__ vals, int64_t seg_stride,
-                                                     const int* __restrict__ seg_len, int fixed_len,
-                                                     int nseg, int K, float* __restrict__ out_vals,
-                                                     int* __restrict__ out_pos,
-                                                     uint8_t* __restrict__ tie_flag = nullptr) {
-    __shared__ unsigned long long s_buf[4][SW_CAP];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int seg = blockIdx.x * 4 + w;
-    if (seg >= nseg) return;   // whole wave; the kernel has no workgroup barrier
-    const int n = seg_len ? seg_len[seg] : fixed_len;
-    const float* v = vals + (int64_t)seg * seg_stride;
-    unsigned long long* buf = s_buf[w];
-    const int run = wave_select_row<SMALLEST, NPL>(v, n, K, buf, tie_flag, seg);
     const float sentinel = SMALLEST ? INFINITY : -INFINITY;
     for (int r = lane; r < K; r += 64) {
         float val = sentinel;
