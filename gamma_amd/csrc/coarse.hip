@@ -6,8 +6,9 @@
 //      dis(q, c) = max(0, (|x_q|^2 + |y_c|^2) - 2 <x_q, y_c>),   <.,.> one k-ascending fp32 fma chain.
 // Writing all of them (268 MB per 16 384 queries at nlist 4096) and reading them back costs more than computing
 // them.  Here:
-//   A. the distances to a SAMPLE of the centroids (the first 512 columns; 1024 for nprobe > 32) go through the
-//      matrix kernel; k_coarse_bound derives from them an upper bound tau_q of the final nprobe-th smallest;
+//   A. the distances to a SAMPLE of the centroids (the first 512 columns; 1024 for nprobe > 32) are written out
+//      (k_coarse_fused<.., STORE>); k_coarse_bound derives from them an upper bound tau_q of the final nprobe-th
+//      smallest;
 //   B. k_coarse_fused computes the other columns with the same MFMA chain and keeps only entries <= tau_q
 //      (about nprobe * (nlist / sample) of them): per (query, column strip) list in HBM, slots handed out by
 //      counters in registers (the 32 rows of a wave belong to it alone: ballot + popcount, no atomics);
@@ -49,7 +50,9 @@ __device__ __forceinline__ int wave_incl_scan_i(int v) {
 }
 }  // namespace
 
-template <int NCH>   // d = 16 * NCH
+// STORE: no filter -- every distance of columns [col0, ny) goes to mat[row * ld + (col - col0)] (the sample columns
+// the bound is derived from); tau / cand / cand_cnt unused, cap_stride = ld.
+template <int NCH, bool STORE = false>   // d = 16 * NCH
 __global__ __launch_bounds__(256, 2) void k_coarse_fused(const float* __restrict__ x, int nq,
                                                          const float* __restrict__ y, int ny, int col0,
                                                          const float* __restrict__ yn,
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void k_coarse_fused(const float* __restrict
     }
     __syncthreads();
     // (|x|^2, tau) of the 128 rows stay in LDS: the epilogue reads the pair of its row per element
-    if (tid < 128) s_xt[tid] = make_float2(s_xn[tid], q_base + tid < nq ? tau[q_base + tid] : -INFINITY);
+    if (tid < 128) s_xt[tid] = make_float2(s_xn[tid], (!STORE && q_base + tid < nq) ? tau[q_base + tid] : -INFINITY);
     // ---- centroid tiles ----
     auto gload = [&](int t) {
 #pragma unroll
@@ -126,15 +129,19 @@ __global__ __launch_bounds__(256, 2) void k_coarse_fused(const float* __restrict
 #pragma unroll
     for (int r = 0; r < 16; r++) cnt[r] = 0;
     const uint32_t lt_mask = (1u << (lane & 31)) - 1u;
-    const unsigned row_stride = (unsigned)nseg * (unsigned)cap_stride;   // list entries between consecutive queries
-    const unsigned lane_row = ((unsigned)((q_base + w * 32 + 4 * (lane >> 5)) * nseg + seg)) * (unsigned)cap_stride;
+    // list entries (STORE: matrix elements) between consecutive queries, and the first row of this lane
+    const unsigned row_stride = STORE ? (unsigned)cap_stride : (unsigned)nseg * (unsigned)cap_stride;
+    const unsigned lane_row = STORE ? (unsigned)(q_base + w * 32 + 4 * (lane >> 5)) * (unsigned)cap_stride
+                                    : ((unsigned)((q_base + w * 32 + 4 * (lane >> 5)) * nseg + seg)) * (unsigned)cap_stride;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        cand, 0, (int)min((int64_t)nq * nseg * cap_stride * 8, (int64_t)0x7fffffff), 0x00020000);
+        cand, 0,
+        (int)min(STORE ? (int64_t)nq * cap_stride * 4 : (int64_t)nq * nseg * cap_stride * 8, (int64_t)0x7fffffff),
+        0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     const int sh = lane & 32;
     int rs[16];   // byte offset of row slot r's list from the lane's first row: uniform, rides in the store's soffset
 #pragma unroll
-    for (int r = 0; r < 16; r++) rs[r] = ((r & 3) + 8 * (r >> 2)) * (int)row_stride * 8;
+    for (int r = 0; r < 16; r++) rs[r] = ((r & 3) + 8 * (r >> 2)) * (int)row_stride * (STORE ? 4 : 8);
     const float2* xt_row = s_xt + w * 32 + 4 * (lane >> 5);
     // One element of the epilogue: row slot r of a 32-column block, accumulators o.  f32 MFMAs run at the vector
     // FP32 rate and do not overlap with VALU work of the same SIMD (measured: the epilogue's cycles add to the
@@ -145,6 +152,14 @@ __global__ __launch_bounds__(256, 2) void k_coarse_fused(const float* __restrict
     //   one of the row's list: that query's count says "overflowed" and its list is never read.
     auto epi = [&](const f32x16& o, int r, unsigned colv, float ync, int rsoff) {
         const float2 xt = xt_row[(r & 3) + 8 * (r >> 2)];
+        if constexpr (STORE) {
+            float dis = __builtin_fmaf(-2.f, o[r], xt.x + ync);
+            if (dis < 0.f) dis = 0.f;
+            // a row beyond nq falls outside the descriptor, a column beyond ny is steered there
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dis), rsrc,
+                                                  (int)colv < ny ? (lane_row + (colv - (unsigned)col0)) * 4u : OOB, rsoff, 0);
+            return;
+        }
         const float dis = __builtin_fmaf(-2.f, o[r], xt.x + ync);
         const bool pass = dis <= xt.y;
         const unsigned long long mask = __ballot(pass);
@@ -205,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void k_coarse_fused(const float* __restrict
         __syncthreads();
     }
     if (t0 < t1) step(no, yes, acc0, s_co, acc1, col0 + (t1 - 1) * 64 + 32);
-    if ((lane & 31) == 0) {
+    if (!STORE && (lane & 31) == 0) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int row = q_base + w * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -449,12 +464,33 @@ void launch_coarse_fused(hipStream_t s, const CoarseFusedPlan& pl, void* ws, con
     int* ovf = reinterpret_cast<int*>(b + pl.off_ovf);
     uint32_t* scratch = reinterpret_cast<uint32_t*>(b + pl.off_scratch);
     (void)hipMemsetAsync(ovf, 0, sizeof(int), s);
-    // A: sample columns through the matrix kernels
-    launch_l2_gemmform(s, x, nq, d, y, pl.sample, nullptr, yn, mat, pl.sample, true);
+    // A: the sample columns, every distance stored (two strips: the 128 queries' fragments are loaded once per strip)
+    const size_t lds = (size_t)2 * 64 * (d + 1) * sizeof(float);
+    {
+        const int stiles = pl.sample / 64, sstrips = 4, tps = (stiles + sstrips - 1) / sstrips;
+        dim3 sgrid((unsigned)sstrips, (unsigned)((nq + 127) / 128));
+#define GH_CS(NCH)                                                                                                      \
+    do {                                                                                                                \
+        static bool attr = false;                                                                                       \
+        if (!attr) {                                                                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_coarse_fused<NCH, true>),                         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (16 * NCH + 1) * 4);         \
+            attr = true;                                                                                                \
+        }                                                                                                               \
+        hipLaunchKernelGGL((k_coarse_fused<NCH, true>), sgrid, dim3(256), lds, s, x, nq, y, pl.sample, 0, yn, nullptr, \
+                           tps, 0, pl.sample, reinterpret_cast<unsigned long long*>(mat), nullptr, sstrips);           \
+    } while (0)
+        switch (d) {
+            case 32: GH_CS(2); break;
+            case 64: GH_CS(4); break;
+            case 96: GH_CS(6); break;
+            default: GH_CS(8); break;
+        }
+#undef GH_CS
+    }
     if (pl.sample == 512) hipLaunchKernelGGL(k_coarse_bound<8>, dim3((nq + 3) / 4), dim3(256), 0, s, mat, nq, P, tau);
     else hipLaunchKernelGGL(k_coarse_bound<16>, dim3((nq + 3) / 4), dim3(256), 0, s, mat, nq, P, tau);
     // B: the other columns, filtered
-    const size_t lds = (size_t)2 * 64 * (d + 1) * sizeof(float);
     dim3 grid((unsigned)pl.nseg, (unsigned)((nq + 127) / 128));
 #define GH_CF(NCH)                                                                                                      \
     do {                                                                                                                \
