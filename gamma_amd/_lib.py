@@ -75,6 +75,11 @@ SYMBOLS = {
     "gamma_hip_ivfpq_add_keys": (C.c_int, [C.c_void_p, C.c_int, C.c_int, i64p, u8p]),
     "gamma_hip_ivfpq_add_keys_batch": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p, i64p, u8p]),
     "gamma_hip_ivfpq_update": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, u8p]),
+    "gamma_hip_ivfflat_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "gamma_hip_ivfflat_set_trained": (C.c_int, [C.c_void_p, f32p]),
+    "gamma_hip_ivfflat_search": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int, f32p, C.c_int, f32p, i64p]),
+    "gamma_hip_ivfflat_search_device": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int, C.c_void_p, C.c_int,
+                                                  C.c_void_p, C.c_void_p]),
     "gamma_hip_ivfpq_has_vid": (C.c_int, [C.c_void_p, i64p, C.c_int, u8p]),
     "gamma_hip_ivfpq_remove": (C.c_int, [C.c_void_p, C.c_int64]),
     "gamma_hip_ivfpq_delete": (C.c_int, [C.c_void_p, i64p, C.c_int]),

@@ -261,6 +261,27 @@ class GammaHip:
                                                _p(D, _lib.f32p), _p(I, _lib.i64p)), "ivfpq_search")
         return D, I
 
+    # ---- IVFFLAT ----
+    def ivfflat_init(self, d, nlist, metric=METRIC_L2, bucket_init_size=1000, bucket_max_size=1280000):
+        self._ck(self.L.gamma_hip_ivfflat_init(self.h, d, nlist, metric, bucket_init_size, bucket_max_size), "ivfflat_init")
+        self.d, self.nlist, self.M = d, nlist, 1
+
+    def ivfflat_set_trained(self, coarse_centroids):
+        cc = _f32(coarse_centroids)
+        self._ck(self.L.gamma_hip_ivfflat_set_trained(self.h, _p(cc, _lib.f32p)), "ivfflat_set_trained")
+
+    def ivfflat_search(self, x, k, args):
+        x = _f32(x)
+        nq = x.shape[0]
+        D = np.empty((nq, max(k, 0)), dtype=np.float32)
+        I = np.empty((nq, max(k, 0)), dtype=np.int64)
+        self._ck(self.L.gamma_hip_ivfflat_search(self.h, args.ref(), nq, _p(x, _lib.f32p), k, _p(D, _lib.f32p),
+                                                 _p(I, _lib.i64p)), "ivfflat_search")
+        return D, I
+
+    def ivfflat_search_device(self, d_x, nq, k, args, d_D, d_I):
+        self._ck(self.L.gamma_hip_ivfflat_search_device(self.h, args.ref(), nq, d_x, k, d_D, d_I), "ivfflat_search_device")
+
     def last_stages(self, nq, nprobe, R):
         cd = np.empty((nq, nprobe), dtype=np.float32)
         ci = np.empty((nq, nprobe), dtype=np.int64)

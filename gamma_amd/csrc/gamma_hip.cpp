@@ -171,6 +171,7 @@ struct gamma_hip_index {
     bool list_major = false;   // gamma_hip_set_list_major
     bool coarse_fused = true;  // gamma_hip_set_coarse_fused
     bool small_path = true;    // gamma_hip_set_small_path
+    bool ivfflat = false;      // gamma_hip_ivfflat_init: lists of vector ids (1 dummy code byte), rows from the raw store
     int coarse_cap = gh::kCoarseCap;
     unsigned long long* d_tie_stats = nullptr;   // {coarse rows redone, top-R cuts through a tie, queries replayed}
     // what stage A leaves for the tie replay of stage B (ties.hip)
@@ -1109,7 +1110,7 @@ int ivfpq_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int n
 
 int ivfpq_check(H* h, const gamma_hip_search_params* p, int nq, int k) {
     GH_TRY(check_params(h, p, nq, k));
-    if (!h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
+    if (!h->ivf_init || h->ivfflat) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
     if (!h->trained) return fail(h, GAMMA_HIP_ENOTTRAINED, "ivfpq not trained");
     if (p->nprobe <= 0 || p->nprobe > h->nlist) return fail(h, GAMMA_HIP_EINVAL, "nprobe out of range");
     if (std::max(p->recall_num, k) > 4096) return fail(h, GAMMA_HIP_EINVAL, "recall_num > 4096 unsupported");
@@ -1183,6 +1184,75 @@ int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, c
     }
     h->last_P = p->nprobe;
     h->last_R = R;
+    return GAMMA_HIP_OK;
+}
+
+// ---- IVFFLAT (index/impl/gamma_index_ivfflat.cc:392-567) ------------------------------------------------------
+// coarse quantizer (the IVFPQ one) -> slab offsets -> exact distance of every entry of the probed lists
+// (k_ivfflat_scan) -> top-k of the slab in (distance, scan position) order -> ids.  The reference's k-heap keeps
+// the same k entries (up to its order inside exact ties).
+int ivfflat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, int k,
+                                 float* d_distances, int64_t* d_labels) {
+    GH_TRY(check_params(h, p, nq, k));
+    if (!h->ivf_init || !h->ivfflat) return fail(h, GAMMA_HIP_EINVAL, "ivfflat not initialised");
+    if (!h->trained) return fail(h, GAMMA_HIP_ENOTTRAINED, "ivfflat not trained");
+    if (p->nprobe <= 0 || p->nprobe > h->nlist) return fail(h, GAMMA_HIP_EINVAL, "nprobe out of range");
+    if (!h->d_raw || h->raw_d != h->d) return fail(h, GAMMA_HIP_EINVAL, "ivfflat needs the raw store");
+    if (k <= 0 || nq == 0) return GAMMA_HIP_OK;
+    GH_CHECK(h, hipSetDevice(h->device));
+    const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
+    const float neutral = l2 ? 3.402823466e+38f : -3.402823466e+38f;
+    gh::FilterDesc filt;
+    GH_TRY(build_filter(h, p, &filt));
+    FiltCtx fc;
+    GH_TRY(filt_ctx_single(h, filt, &fc));
+    gamma_hip_search_params pp = *p;
+    if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;   // faiss:utils/distances.cpp:303,346, whole call
+    const int P = pp.nprobe, nlist = h->nlist;
+    hipStream_t s = h->stream;
+    const int chunk = scan_chunk(h, nq, P);
+    const int need_filter = (fc.any_clause || (h->d_bitmap && h->bitmap_any)) ? 1 : 0;
+    for (int q0 = 0; q0 < nq; q0 += chunk) {
+        const int nc = std::min(chunk, nq - q0);
+        const float* xq = d_x + (size_t)q0 * h->d;
+        const int ver = h->cur_ver;
+        GH_CHECK(h, hipStreamWaitEvent(s, h->ver_ev[ver], 0));
+        GH_CHECK(h, h->w_pair_off.ensure((size_t)nc * (P + 1) * sizeof(int)));
+        GH_CHECK(h, h->w_pair_base.ensure((size_t)nc * P * sizeof(int64_t)));
+        GH_CHECK(h, h->w_qtotal.ensure((size_t)nc * sizeof(int)));
+        GH_CHECK(h, h->w_cand_pos.ensure((size_t)nc * k * sizeof(int)));
+        GH_CHECK(h, h->w_cand_dis.ensure((size_t)nc * k * sizeof(float)));
+        GH_CHECK(h, h->w_cand_ids.ensure((size_t)nc * k * sizeof(int64_t)));
+        GH_TRY(ivfpq_coarse(h, &pp, nc, xq));
+        gh::launch_pair_offsets(s, h->w_probe.as<int>(), nc, P, h->d_list_len, h->d_list_mask, nlist,
+                                h->w_pair_off.as<int>(), h->w_qtotal.as<int>(), nullptr, h->d_list_off,
+                                h->w_pair_base.as<int64_t>());
+        const int64_t q_stride = (std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len)) + 3) & ~(int64_t)3;
+        GH_CHECK(h, h->w_dist.ensure((size_t)nc * q_stride * sizeof(float)));
+        {
+            StageScope t(h, GAMMA_HIP_STAGE_SCAN);
+            gh::launch_ivfflat_scan(s, l2, xq, nc, h->d, P, h->w_pair_off.as<int>(), h->w_pair_base.as<int64_t>(), h->d_ids,
+                                    h->d_raw, h->nraw, q_stride, h->w_dist.as<float>(), fc.d_tab, need_filter, p->min_score,
+                                    p->max_score);
+        }
+        {
+            StageScope t(h, GAMMA_HIP_STAGE_SELECT);
+            gh::launch_select_topk(s, l2, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), 0,
+                                   (int)std::min<int64_t>(q_stride, 1 << 30), nc, k, h->w_cand_dis.as<float>(),
+                                   h->w_cand_pos.as<int>());
+            gh::launch_map_candidates(s, h->w_cand_pos.as<int>(), nc, k, P, h->w_probe.as<int>(), h->w_pair_off.as<int>(),
+                                      h->d_list_off, h->d_ids, h->w_cand_ids.as<int64_t>());
+            gh::launch_finalize_norank(s, h->w_cand_dis.as<float>(), h->w_cand_ids.as<int64_t>(), nc, k, k, p->min_score,
+                                       p->max_score, neutral, d_distances + (size_t)q0 * k, d_labels + (size_t)q0 * k,
+                                       nullptr);
+        }
+        GH_CHECK(h, hipEventRecord(h->rd_ev[ver], s));
+        h->rd_set[ver] = true;
+        h->last_nq = nc;
+    }
+    h->last_P = P;
+    h->last_R = k;
+    GH_CHECK(h, hipGetLastError());
     return GAMMA_HIP_OK;
 }
 
@@ -1730,7 +1800,9 @@ int gamma_hip_bitmap_set(gamma_hip_index* h, const int64_t* docids, int64_t n, i
     return GAMMA_HIP_OK;
 }
 
-/* ---- IVFPQ model ---------------------------------------------------------------------- */
+/* ---- IVFPQ / IVFFLAT models ----------------------------------------------------------- */
+static int ivf_init_locked(gamma_hip_index* h, int d, int nlist, int M, int metric, int bucket_init_size,
+                           int bucket_max_size, bool flat);
 int gamma_hip_ivfpq_init(gamma_hip_index* h, int d, int nlist, int M, int nbits, int metric,
                          int bucket_init_size, int bucket_max_size) {
     if (!h) return GAMMA_HIP_EINVAL;
@@ -1741,20 +1813,26 @@ int gamma_hip_ivfpq_init(gamma_hip_index* h, int d, int nlist, int M, int nbits,
     if (d % M != 0) return fail(h, GAMMA_HIP_EINVAL, "d must be divisible by nsubvector");
     if (d / M > 64) return fail(h, GAMMA_HIP_EINVAL, "dsub > 64 unsupported");
     if (M > 64) return fail(h, GAMMA_HIP_EINVAL, "nsubvector > 64 unsupported (LUT must fit 64 KiB LDS)");
+    return ivf_init_locked(h, d, nlist, M, metric, bucket_init_size, bucket_max_size, false);
+}
+
+static int ivf_init_locked(gamma_hip_index* h, int d, int nlist, int M, int metric, int bucket_init_size,
+                           int bucket_max_size, bool flat) {
     if (metric != GAMMA_HIP_METRIC_IP && metric != GAMMA_HIP_METRIC_L2) return fail(h, GAMMA_HIP_EINVAL, "bad metric");
     GH_CHECK(h, hipSetDevice(h->device));
+    h->ivfflat = flat;
     h->d = d;
     h->nlist = nlist;
     h->M = M;
     h->dsub = d / M;
-    h->code_size = M;
+    h->code_size = M;   // IVFFLAT: M = 1, one dummy byte per entry (the arena code keeps its shape)
     h->metric = metric;
     h->bucket_init = bucket_init_size > 0 ? bucket_init_size : 1000;
     h->bucket_max = bucket_max_size > 0 ? bucket_max_size : 1280000;
     GH_CHECK(h, hipMalloc((void**)&h->d_cc, (size_t)nlist * d * sizeof(float)));
     GH_CHECK(h, hipMalloc((void**)&h->d_cc_norms, (size_t)nlist * sizeof(float)));
-    GH_CHECK(h, hipMalloc((void**)&h->d_pqc, (size_t)M * 256 * h->dsub * sizeof(float)));
-    GH_CHECK(h, hipMalloc((void**)&h->d_T2, (size_t)nlist * M * 256 * sizeof(float)));
+    GH_CHECK(h, hipMalloc((void**)&h->d_pqc, flat ? 256 : (size_t)M * 256 * h->dsub * sizeof(float)));
+    GH_CHECK(h, hipMalloc((void**)&h->d_T2, flat ? 256 : (size_t)nlist * M * 256 * sizeof(float)));
     for (int v = 0; v < H::NVER; v++) {
         GH_CHECK(h, hipMalloc((void**)&h->d_ver_off[v], (size_t)nlist * sizeof(int64_t)));
         GH_CHECK(h, hipMalloc((void**)&h->d_ver_len[v], (size_t)nlist * sizeof(int)));
@@ -1779,10 +1857,31 @@ int gamma_hip_ivfpq_init(gamma_hip_index* h, int d, int nlist, int M, int nbits,
     return GAMMA_HIP_OK;
 }
 
+int gamma_hip_ivfflat_init(gamma_hip_index* h, int d, int nlist, int metric, int bucket_init_size, int bucket_max_size) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    if (h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "already initialised");
+    if (d <= 0 || nlist <= 0) return fail(h, GAMMA_HIP_EINVAL, "bad d/nlist");
+    return ivf_init_locked(h, d, nlist, 1, metric, bucket_init_size, bucket_max_size, true);
+}
+
+int gamma_hip_ivfflat_set_trained(gamma_hip_index* h, const float* cc) {
+    if (!h || !cc) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    if (!h->ivf_init || !h->ivfflat) return fail(h, GAMMA_HIP_EINVAL, "ivfflat not initialised");
+    GH_CHECK(h, hipSetDevice(h->device));
+    GH_CHECK(h, hipMemcpyAsync(h->d_cc, cc, (size_t)h->nlist * h->d * sizeof(float), hipMemcpyHostToDevice, h->wstream));
+    gh::launch_row_norms(h->wstream, h->d_cc, h->nlist, h->d, h->d_cc_norms);
+    GH_CHECK(h, hipGetLastError());
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    h->trained = true;
+    return GAMMA_HIP_OK;
+}
+
 int gamma_hip_ivfpq_set_trained(gamma_hip_index* h, const float* cc, const float* pqc, const float* table) {
     if (!h || !cc || !pqc) return GAMMA_HIP_EINVAL;
     WriteLock lk(h);
-    if (!h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
+    if (!h->ivf_init || h->ivfflat) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
     GH_CHECK(h, hipSetDevice(h->device));
     const size_t ncc = (size_t)h->nlist * h->d, npq = (size_t)h->M * 256 * h->dsub;
     const size_t nt = (size_t)h->nlist * h->M * 256;
@@ -2062,7 +2161,8 @@ static int encode_locked(H* h, int64_t n, const float* d_vecs, int* d_assign, ui
     }
     gh::launch_select_topk(s, true, h->we_mat.as<float>(), nlist, nullptr, nlist, nlist, (int)n, 1,
                            h->we_cdis.as<float>(), d_assign);
-    gh::launch_pq_encode(s, d_vecs, n, d, h->M, d_assign, h->d_cc, h->d_pqc, d_codes_out);
+    if (h->ivfflat) GH_CHECK(h, hipMemsetAsync(d_codes_out, 0, (size_t)n, s));   // the dummy byte of every entry
+    else gh::launch_pq_encode(s, d_vecs, n, d, h->M, d_assign, h->d_cc, h->d_pqc, d_codes_out);
     GH_CHECK(h, hipGetLastError());
     return GAMMA_HIP_OK;
 }
@@ -2176,6 +2276,25 @@ int gamma_hip_ivfpq_search_device(gamma_hip_index* h, const gamma_hip_search_par
     if (!h) return GAMMA_HIP_EINVAL;
     SearchLock lk(h);
     return ivfpq_search_device_locked(h, p, nq, d_x, k, d_distances, d_labels);
+}
+
+int gamma_hip_ivfflat_search_device(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* d_x,
+                                    int k, float* d_distances, int64_t* d_labels) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    return ivfflat_search_device_locked(h, p, nq, d_x, k, d_distances, d_labels);
+}
+
+int gamma_hip_ivfflat_search(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x, int k,
+                             float* distances, int64_t* labels) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    GH_TRY(check_params(h, p, nq, k));
+    if (!h->ivf_init || !h->ivfflat) return fail(h, GAMMA_HIP_EINVAL, "ivfflat not initialised");
+    if (nq > 0 && k > 0 && (!x || !distances || !labels)) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
+    return host_search(h, nq, h->d, x, k, distances, labels, [&](const float* dx, float* dd, int64_t* dl) {
+        return ivfflat_search_device_locked(h, p, nq, dx, k, dd, dl);
+    }, true, &lk);
 }
 
 static int flat_search_host_locked(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x, int k,

@@ -174,6 +174,10 @@ void launch_small_tail(hipStream_t s, bool l2, const float* slab, int64_t q_stri
                        float* cand_dis, int* cand_pos, int64_t* cand_ids, int has_rank, const float* x, int d,
                        const float* raw, int64_t nraw, int k, float min_score, float max_score, float neutral,
                        float* distances, int64_t* labels);
+// IVFFLAT: exact distances of every entry of the probed lists (rows from the raw store) into the query's slab
+void launch_ivfflat_scan(hipStream_t s, bool l2, const float* x, int nq, int d, int P, const int* pair_off,
+                         const int64_t* pair_base, const int64_t* ids, const float* raw, int64_t nraw, int64_t q_stride,
+                         float* out, const FilterDesc* ftab, int need_filter, float min_score, float max_score);
 void launch_coarse_select(hipStream_t s, const float* mat, int nlist, int nq, int K, float* out_vals, int* out_pos,
                           uint8_t* tie_flag, unsigned long long* tie_stats = nullptr);
 void launch_select_topk(hipStream_t s, bool smallest, const float* vals, int64_t seg_stride,

@@ -1805,6 +1805,55 @@ void launch_rerank_topk(hipStream_t s, bool l2, const float* x, int nq, int d, c
                            R, k, min_score, max_score, neutral, distances, labels, nq, qperm, tf);
 }
 
+// ------------------------------------------------------------------------------------
+// IVFFLAT list scan (GammaIVFFlatScanner1::scan_codes, index/impl/gamma_index_ivfflat.h:52-75): the reference's
+// lists hold the vectors themselves; here a list holds vector ids and the rows come from the raw store (the same
+// floats).  One workgroup per (query, probe) pair, eight threads per list entry = the eight AVX lane accumulators
+// of fvec_L2sqr / fvec_inner_product (rerank_dev.h).  Entries with bit 63, filtered docs and scores outside the
+// window get the sentinel; one fp32 per entry into the query's slab at the pair's offset.
+// ------------------------------------------------------------------------------------
+template <bool L2>
+__global__ __launch_bounds__(256) void k_ivfflat_scan(const float* __restrict__ x, int d, int P,
+                                                      const int* __restrict__ pair_off,
+                                                      const int64_t* __restrict__ pair_base,
+                                                      const int64_t* __restrict__ ids,
+                                                      const float* __restrict__ raw, int64_t nraw, int64_t q_stride,
+                                                      float* __restrict__ out, const FilterDesc* __restrict__ ftab,
+                                                      int need_filter, float min_score, float max_score) {
+    const int q = blockIdx.x / P, p = blockIdx.x - q * P;
+    const int off = pair_off[(int64_t)q * (P + 1) + p], len = pair_off[(int64_t)q * (P + 1) + p + 1] - off;
+    if (len <= 0) return;   // uniform
+    const int64_t base = pair_base[(int64_t)q * P + p];
+    const float* xq = x + (int64_t)q * d;
+    const int l8 = threadIdx.x & 7, g = threadIdx.x >> 3;
+    const float sentinel = L2 ? INFINITY : -INFINITY;
+    for (int j0 = 0; j0 < len; j0 += 32) {
+        const int j = j0 + g;
+        int64_t id = -1;
+        if (j < len) id = ids[base + j];
+        const int64_t vid = id & 0x7fffffffffffffffLL;
+        bool live = j < len && id >= 0 && vid < nraw;   // id < 0: bit 63, superseded by an Update
+        if (need_filter && live) live = is_valid_doc(ftab[0], vid);
+        float dis = rerank_dist8<L2>(xq, raw + (live ? vid : 0) * d, d, l8, live);
+        if (l8 == 0 && j < len) {
+            if (!live || !(dis <= max_score && dis >= min_score)) dis = sentinel;
+            out[(int64_t)q * q_stride + off + j] = dis;
+        }
+    }
+}
+void launch_ivfflat_scan(hipStream_t s, bool l2, const float* x, int nq, int d, int P, const int* pair_off,
+                         const int64_t* pair_base, const int64_t* ids, const float* raw, int64_t nraw, int64_t q_stride,
+                         float* out, const FilterDesc* ftab, int need_filter, float min_score, float max_score) {
+    if (nq <= 0 || P <= 0) return;
+    const dim3 grid((unsigned)((int64_t)nq * P));
+    if (l2)
+        hipLaunchKernelGGL((k_ivfflat_scan<true>), grid, dim3(256), 0, s, x, d, P, pair_off, pair_base, ids, raw, nraw,
+                           q_stride, out, ftab, need_filter, min_score, max_score);
+    else
+        hipLaunchKernelGGL((k_ivfflat_scan<false>), grid, dim3(256), 0, s, x, d, P, pair_off, pair_base, ids, raw, nraw,
+                           q_stride, out, ftab, need_filter, min_score, max_score);
+}
+
 // final outputs from a top-k selection over re-ranked (or flat) candidates:
 //   labels = src_ids ? src_ids[q][pos] : id_base + pos ; empty -> -1 / heap neutral
 __global__ __launch_bounds__(256) void k_finalize_topk(const float* __restrict__ sel_vals,

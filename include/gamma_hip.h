@@ -238,6 +238,25 @@ int gamma_hip_ivfpq_encode(gamma_hip_index* h, int64_t n, const float* vecs, int
 int gamma_hip_assign(gamma_hip_index* h, int d, int64_t n, const float* x, int k,
                      const float* centroids, int32_t* assign, float* dis);
 
+/* ---- IVFFLAT (index/impl/gamma_index_ivfflat.{h,cc}) ----------------------------------------
+ * The reference's IVFFLAT lists carry the vectors themselves (code_size = 4 d, gamma_index_ivfflat.cc:155); here a
+ * list carries vector ids (plus one dummy code byte so that the realtime-list code is shared) and the rows come
+ * from the raw store (gamma_hip_raw_*), which must hold every indexed vector.  After _init the list entry points
+ * above serve the handle unchanged: gamma_hip_ivfpq_add (= GammaIndexIVFFlat::Add :305-355: assign + AddKeys),
+ * _encode (list_nos = quantizer->assign; codes = dummy bytes), _add_keys / _update / _delete /
+ * _compact_if_need / _get_list / _list_size.  nprobe, metric, filters and the score window come from
+ * gamma_hip_search_params (recall_num / has_rank are ignored: every scanned entry gets its exact distance). */
+int gamma_hip_ivfflat_init(gamma_hip_index* h, int d, int nlist, int metric, int bucket_init_size,
+                           int bucket_max_size);
+/* quantizer->xb (nlist*d): IndexIVFFlat::train == the coarse k-means only */
+int gamma_hip_ivfflat_set_trained(gamma_hip_index* h, const float* coarse_centroids);
+/* replaces GammaIndexIVFFlat::Search (gamma_index_ivfflat.cc:392-421 + search_preassigned :423-612, pmode 0):
+ * x nq*d fp32 host; distances/labels nq*k host, best first, -1 / heap neutral padded */
+int gamma_hip_ivfflat_search(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x, int k,
+                             float* distances, int64_t* labels);
+int gamma_hip_ivfflat_search_device(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* d_x,
+                                    int k, float* d_distances, int64_t* d_labels);
+
 /* ---- search ------------------------------------------------------------------------ */
 /* replaces GammaIVFPQIndex::Search (gamma_index_ivfpq.cc:514-566 + search_preassigned
  * :701-890).  x: nq*d fp32 host; distances/labels: nq*k host, best first, unused slots

@@ -103,6 +103,11 @@ def lib():
         L.go_ivfpq_update.argtypes = [C.c_void_p, C.c_int64, _f32p]
         L.go_ivfpq_update_code.restype = C.c_int
         L.go_ivfpq_update_code.argtypes = [C.c_void_p, C.c_int, C.c_int64, _u8p]
+        L.go_ivfflat_search.restype = C.c_int
+        L.go_ivfflat_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, C.c_int,
+                                        _f32p, _i64p, _f32p, _i64p]
+        L.go_ivfflat_assign.restype = None
+        L.go_ivfflat_assign.argtypes = [C.c_void_p, C.c_int64, _f32p, _i64p]
         L.go_ivfpq_has_vid.restype = C.c_int
         L.go_ivfpq_has_vid.argtypes = [C.c_void_p, C.c_int64]
         L.go_ivfpq_remove.restype = C.c_int
@@ -304,6 +309,30 @@ class OracleIVFPQ:
         if want_stages:
             return D, I, dict(coarse_dis=cd, coarse_idx=ci, recall_dis=rd, recall_ids=ri)
         return D, I
+
+
+def ivfflat_search(o, x, k, nprobe, metric=METRIC_L2, ctx=None, coarse_mode=-1, want_stages=False):
+    """GammaIndexIVFFlat::Search over the lists (ids) and raw store of the OracleIVFPQ `o`"""
+    x = _f32(x)
+    nq = x.shape[0]
+    D = np.empty((nq, k), dtype=np.float32)
+    I = np.empty((nq, k), dtype=np.int64)
+    cd = np.empty((nq, nprobe), dtype=np.float32)
+    ci = np.empty((nq, nprobe), dtype=np.int64)
+    rc = lib().go_ivfflat_search(o.h, C.byref(ctx) if ctx is not None else None, metric, nprobe, coarse_mode, nq,
+                                 _fp(x), k, _fp(D), _ip(I), _fp(cd), _ip(ci))
+    if rc != 0:
+        raise RuntimeError("go_ivfflat_search rc=%d" % rc)
+    if want_stages:
+        return D, I, dict(coarse_dis=cd, coarse_idx=ci)
+    return D, I
+
+
+def ivfflat_assign(o, x):
+    x = _f32(x)
+    out = np.empty(x.shape[0], dtype=np.int64)
+    lib().go_ivfflat_assign(o.h, x.shape[0], _fp(x), _ip(out))
+    return out
 
 
 def flat_search(raw, x, k, metric=METRIC_L2, ctx=None):

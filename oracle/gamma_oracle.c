@@ -962,6 +962,67 @@ int go_flat_search(const float* raw, int64_t n, int d, const go_search_ctx* ctx,
     return 0;
 }
 
+/* ===================================================================================
+ * IVFFLAT (index/impl/gamma_index_ivfflat.{h,cc}): the lists hold the vectors themselves
+ * (code_size = 4 d, gamma_index_ivfflat.cc:155); a search scans the probed lists in probe order with
+ * GammaIVFFlatScanner1::scan_codes (gamma_index_ivfflat.h:52-75): bit 63, IsValid, exact
+ * fvec_L2sqr / fvec_inner_product, score window, heap_pop + heap_push into the k-heap; then heap_reorder
+ * (search_preassigned pmode 0, gamma_index_ivfflat.cc:539-567).  Here the lists of a go_ivfpq (ids only are
+ * used) stand for the RTInvertIndex and the raw store for the list payload: the same floats.
+ * =================================================================================== */
+int go_ivfflat_search(go_ivfpq* ix, const go_search_ctx* ctx, int metric, int nprobe, int coarse_mode,
+                      int nq, const float* x, int k, float* distances, int64_t* labels,
+                      float* coarse_dis_out, int64_t* coarse_idx_out) {
+    if (k <= 0) return 0;
+    if (nprobe <= 0 || nprobe > ix->nlist || !ix->raw) return -1;
+    const int d = ix->d;
+    const int ks = metric == GO_METRIC_IP ? 0 : 1;
+    float* coarse_dis = (float*)malloc(sizeof(float) * (size_t)nq * nprobe);
+    int64_t* idx = (int64_t*)malloc(sizeof(int64_t) * (size_t)nq * nprobe);
+    int mode = coarse_mode < 0 ? (nq < 20 ? 0 : 1) : coarse_mode; /* quantizer->search, :413 */
+    go_knn_L2sqr(mode, x, ix->cc, d, nq, ix->nlist, nprobe, coarse_dis, idx);
+    if (coarse_dis_out) memcpy(coarse_dis_out, coarse_dis, sizeof(float) * (size_t)nq * nprobe);
+    if (coarse_idx_out) memcpy(coarse_idx_out, idx, sizeof(int64_t) * (size_t)nq * nprobe);
+#pragma omp parallel for schedule(dynamic)
+    for (int i = 0; i < nq; i++) {
+        const float* xi = x + (size_t)i * d;
+        float* simi = distances + (size_t)i * k;
+        int64_t* idxi = labels + (size_t)i * k;
+        go_heap_heapify(ks, k, simi, idxi);
+        for (int ik = 0; ik < nprobe; ik++) {
+            int64_t key = idx[(size_t)i * nprobe + ik];
+            if (key < 0 || key >= ix->nlist) continue; /* scan_one_list, :490-503 */
+            const go_bucket* b = &ix->b[key];
+            for (int64_t j = 0; j < b->size; j++) {
+                int64_t id = b->ids[j];
+                if (id & GO_DEL_MASK) continue;
+                int64_t vid = id & GO_RECOVER_MASK;
+                if (!ctx_is_valid(ctx, vid)) continue;
+                if (vid >= ix->nraw) continue; /* not in the store: cannot happen through Add */
+                const float* yj = ix->raw + vid * d;
+                float dis = metric == GO_METRIC_IP ? go_fvec_inner_product(xi, yj, d) : go_fvec_L2sqr(xi, yj, d);
+                if (ctx_score_valid(ctx, dis) && hcmp(ks, simi[0], dis)) {
+                    go_heap_pop(ks, k, simi, idxi);
+                    go_heap_push(ks, k, simi, idxi, dis, vid);
+                }
+            }
+        }
+        go_heap_reorder(ks, k, simi, idxi);
+    }
+    free(coarse_dis);
+    free(idx);
+    return 0;
+}
+
+/* GammaIndexIVFFlat::Add / Update (gamma_index_ivfflat.cc:305-374): quantizer->assign, AddKeys / Update with the
+ * vector as the code.  list_nos out: the assignment (n >= 20 takes the BLAS form unless go_set_assign_mode). */
+void go_ivfflat_assign(go_ivfpq* ix, int64_t n, const float* x, int64_t* list_nos) {
+    int mode = g_assign_mode < 0 ? (n < 20 ? 0 : 1) : g_assign_mode;
+    float* dis = (float*)malloc(sizeof(float) * (size_t)n);
+    go_knn_L2sqr(mode, x, ix->cc, ix->d, n, ix->nlist, 1, dis, list_nos);
+    free(dis);
+}
+
 int go_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

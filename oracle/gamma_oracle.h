@@ -140,6 +140,10 @@ int go_ivfpq_search(go_ivfpq* ix, const go_search_ctx* ctx, int metric, int npro
                     int64_t* coarse_idx_out, float* recall_dis_out, int64_t* recall_ids_out);
 
 /* GammaFLATIndex::Search over a raw vector store [n][d] */
+int go_ivfflat_search(go_ivfpq* ix, const go_search_ctx* ctx, int metric, int nprobe, int coarse_mode,
+                      int nq, const float* x, int k, float* distances, int64_t* labels,
+                      float* coarse_dis_out, int64_t* coarse_idx_out);
+void go_ivfflat_assign(go_ivfpq* ix, int64_t n, const float* x, int64_t* list_nos);
 int go_flat_search(const float* raw, int64_t n, int d, const go_search_ctx* ctx, int metric,
                    int nq, const float* x, int k, float* distances, int64_t* labels);
 
