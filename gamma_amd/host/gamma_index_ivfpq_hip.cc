@@ -192,9 +192,13 @@ static int kmeans_device(gamma_hip_index *h, int d, size_t n, const float *x, in
   return 0;
 }
 
+int GammaIVFPQHIPIndex::TrainCoarse(size_t num, const float *xt) {
+  // coarse quantizer: cp.niter = 10 (gamma_index_ivfpq.cc:175; faiss's default for IndexIVFFlat::train as well)
+  return kmeans_device(h_, d_, num, xt, nlist_, 10, 1234, coarse_centroids_);
+}
+
 int GammaIVFPQHIPIndex::TrainOnHost(size_t num, const float *xt) {
-  // coarse quantizer: cp.niter = 10 (gamma_index_ivfpq.cc:175)
-  int rc = kmeans_device(h_, d_, num, xt, nlist_, 10, 1234, coarse_centroids_);
+  int rc = TrainCoarse(num, xt);
   if (rc) return rc;
   // residuals of the training set (by_residual = true, :179)
   std::vector<int32_t> assign(num);
@@ -223,9 +227,22 @@ int GammaIVFPQHIPIndex::Indexing() {
     HLOG("already trained, skip indexing");
     return 0;
   }
+  std::vector<float> xt;
+  size_t num = 0;
+  if (TrainingSet(xt, num)) return -1;
+  int rc = TrainOnHost(num, xt.data());
+  if (!rc) rc = gamma_hip_ivfpq_set_trained(h_, coarse_centroids_.data(), pq_centroids_.data(), nullptr);
+  if (rc) {
+    HLOG("training failed: %s (%s)", gamma_hip_strerror(rc), gamma_hip_last_error(h_));
+    return -1;
+  }
+  is_trained_ = true;
+  return 0;
+}
+
+// the first `num` vectors of the store, num by the rule of gamma_index_ivfpq.cc:280-301 (= gamma_index_ivfflat.cc:252-276)
+int GammaIVFPQHIPIndex::TrainingSet(std::vector<float> &xt, size_t &num) {
   const size_t vectors_count = vector_->MetaInfo()->Size();
-  // training-set size rule of gamma_index_ivfpq.cc:280-301
-  size_t num;
   if ((size_t)indexing_size_ < (size_t)nlist_) num = (size_t)nlist_ * 39;
   else if ((size_t)indexing_size_ <= (size_t)nlist_ * 256) num = (size_t)indexing_size_;
   else num = (size_t)nlist_ * 256;
@@ -237,15 +254,8 @@ int GammaIVFPQHIPIndex::Indexing() {
   for (size_t i = 0; i < num; i++) vids[i] = (int64_t)i;
   ScopeVectors sv;
   if (vector_->Gets(vids, sv)) return -1;
-  std::vector<float> xt(num * d_);
+  xt.resize(num * d_);
   for (size_t i = 0; i < num; i++) memcpy(&xt[i * d_], sv.Get((int)i), sizeof(float) * d_);
-  int rc = TrainOnHost(num, xt.data());
-  if (!rc) rc = gamma_hip_ivfpq_set_trained(h_, coarse_centroids_.data(), pq_centroids_.data(), nullptr);
-  if (rc) {
-    HLOG("training failed: %s (%s)", gamma_hip_strerror(rc), gamma_hip_last_error(h_));
-    return -1;
-  }
-  is_trained_ = true;
   return 0;
 }
 
@@ -449,6 +459,195 @@ int GammaIVFPQHIPIndex::Load(const std::string &dir) {
   }
   indexed_vec_count_ = (int)count;
   // raw vectors for the re-rank come back from the engine's vector store
+  if (EnsureRaw(std::min<int64_t>(indexed_vec_count_, (int64_t)vector_->MetaInfo()->Size()))) return -1;
+  return indexed_vec_count_;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// HIPIVFFLAT (gamma_index_ivfflat.{h,cc})
+// ------------------------------------------------------------------------------------------------------------
+REGISTER_MODEL(HIPIVFFLAT, GammaIVFFlatHIPIndex);
+
+int GammaIVFFlatHIPIndex::Init(const std::string &model_parameters, int indexing_size) {
+  indexing_size_ = indexing_size;
+  model_param_ = new HIPIVFPQModelParams();   // ncentroids / nprobe / metric_type / bucket sizes / device_filters
+  HIPIVFPQModelParams &pa = *model_param_;
+  // IVFFlatModelParams::Parse (gamma_index_ivfflat.cc:41-101): ncentroids default 2048, nprobe 80, metric InnerProduct
+  utils::JsonParser jp;
+  if (model_parameters != "" && jp.Parse(model_parameters.c_str())) return -1;
+  int v = 0;
+  if (jp.Contains("ncentroids")) {
+    if (jp.GetInt("ncentroids", v)) return -1;
+    if (v > 0) pa.ncentroids = v;
+    else if (v != -1) return -1;
+  }
+  if (!jp.GetInt("nprobe", v)) {
+    if (v < -1) return -1;
+    if (v > 0) pa.nprobe = v;
+    if (pa.nprobe > pa.ncentroids) return -1;
+  }
+  std::string mt;
+  if (!jp.GetString("metric_type", mt)) {
+    if (strcasecmp("L2", mt.c_str()) && strcasecmp("InnerProduct", mt.c_str())) return -1;
+    pa.metric_type = !strcasecmp("L2", mt.c_str()) ? DistanceComputeType::L2 : DistanceComputeType::INNER_PRODUCT;
+  }
+  if (!jp.GetInt("device_filters", v)) pa.device_filters = v != 0;
+  if (!jp.GetInt("bucket_init_size", v) && v > 0) pa.bucket_init_size = v;
+  if (!jp.GetInt("bucket_max_size", v) && v > 0) pa.bucket_max_size = v;
+  if (!vector_) {
+    HLOG("vector_ must be set before Init");
+    return -1;
+  }
+  d_ = vector_->MetaInfo()->Dimension();
+  nlist_ = pa.ncentroids;
+  M_ = 1;   // one dummy code byte per list entry (include/gamma_hip.h, IVFFLAT)
+  metric_type_ = pa.metric_type;
+  nprobe_ = pa.nprobe;
+  const char *dev = getenv("GAMMA_HIP_DEVICE");
+  int rc = gamma_hip_create(dev ? atoi(dev) : 0, &h_);
+  if (rc) return -1;
+  rc = gamma_hip_ivfflat_init(h_, d_, nlist_, metric_type_ == DistanceComputeType::L2 ? GAMMA_HIP_METRIC_L2 : GAMMA_HIP_METRIC_IP,
+                              pa.bucket_init_size, pa.bucket_max_size);
+  if (!rc) rc = gamma_hip_raw_init(h_, d_);
+  if (rc) {
+    HLOG("device init failed: %s (%s)", gamma_hip_strerror(rc), gamma_hip_last_error(h_));
+    return -1;
+  }
+  return 0;
+}
+
+RetrievalParameters *GammaIVFFlatHIPIndex::Parse(const std::string &parameters) {   // gamma_index_ivfflat.cc:188-242
+  if (parameters == "") return new HIPIVFFlatRetrievalParameters(metric_type_);
+  utils::JsonParser jp;
+  if (jp.Parse(parameters.c_str())) {
+    HLOG("parse retrieval parameters error: %s", parameters.c_str());
+    return nullptr;
+  }
+  HIPIVFFlatRetrievalParameters *rp = new HIPIVFFlatRetrievalParameters();
+  std::string mt;
+  if (!jp.GetString("metric_type", mt)) {
+    if (!strcasecmp("L2", mt.c_str())) rp->SetDistanceComputeType(DistanceComputeType::L2);
+    else if (!strcasecmp("InnerProduct", mt.c_str())) rp->SetDistanceComputeType(DistanceComputeType::INNER_PRODUCT);
+    else rp->SetDistanceComputeType(metric_type_);
+  } else {
+    rp->SetDistanceComputeType(metric_type_);
+  }
+  int v;
+  if (!jp.GetInt("nprobe", v) && v > 0) rp->SetNprobe(v);
+  if (!jp.GetInt("parallel_on_queries", v)) rp->SetParallelOnQueries(v != 0);
+  return rp;
+}
+
+int GammaIVFFlatHIPIndex::SetTrainedCoarse(const float *coarse) {
+  coarse_centroids_.assign(coarse, coarse + (size_t)nlist_ * d_);
+  if (gamma_hip_ivfflat_set_trained(h_, coarse_centroids_.data())) return -1;
+  is_trained_ = true;
+  return 0;
+}
+
+int GammaIVFFlatHIPIndex::Indexing() {   // IndexIVFFlat::train == the coarse k-means (gamma_index_ivfflat.cc:244-303)
+  if (is_trained_) return 0;
+  std::vector<float> xt;
+  size_t num = 0;
+  if (TrainingSet(xt, num)) return -1;
+  if (TrainCoarse(num, xt.data())) return -1;
+  return gamma_hip_ivfflat_set_trained(h_, coarse_centroids_.data()) ? -1 : (is_trained_ = true, 0);
+}
+
+int GammaIVFFlatHIPIndex::Search(RetrievalContext *retrieval_context, int n, const uint8_t *x, int k, float *distances,
+                                 int64_t *ids) {
+  HIPIVFFlatRetrievalParameters *rp = dynamic_cast<HIPIVFFlatRetrievalParameters *>(retrieval_context->RetrievalParams());
+  HIPIVFFlatRetrievalParameters defaults(metric_type_);
+  if (rp == nullptr) rp = &defaults;
+  GammaSearchCondition *cond = dynamic_cast<GammaSearchCondition *>(retrieval_context);
+  gamma_hip_search_params p;
+  memset(&p, 0, sizeof(p));
+  p.metric = rp->GetDistanceComputeType() == DistanceComputeType::INNER_PRODUCT ? GAMMA_HIP_METRIC_IP : GAMMA_HIP_METRIC_L2;
+  p.min_score = cond ? cond->min_score : std::numeric_limits<float>::min();
+  p.max_score = cond ? cond->max_score : std::numeric_limits<float>::max();
+  p.coarse_mode = -1;
+  std::vector<gamma_hip_range_filter> rf;
+  std::vector<gamma_hip_field_filter> ff;
+  std::vector<gamma_hip_term_filter> tf;
+  if (!(model_param_ && model_param_->device_filters &&
+        columns_.Prepare(h_, cond, (int64_t)vector_->MetaInfo()->Size(), p, ff, tf)))
+    FillRangeFilters(cond, p, rf);
+  const float *xq = reinterpret_cast<const float *>(x);
+  int rc;
+  if ((cond && cond->brute_force_search) || !is_trained_) {
+    // (the reference's IVFFLAT has no brute-force branch; an untrained model would crash there.  Same service as HIPIVFPQ.)
+    if (EnsureRaw((int64_t)vector_->MetaInfo()->Size())) return -1;
+    rc = gamma_hip_flat_search(h_, &p, n, xq, k, distances, ids);
+  } else {
+    // the reference takes retrieval_params->Nprobe() as it is (-1 when the request did not set it: a negative
+    // allocation there, gamma_index_ivfflat.cc:405-410); the model's nprobe is the sane reading
+    p.nprobe = (rp->Nprobe() > 0 && rp->Nprobe() <= nlist_) ? rp->Nprobe() : nprobe_;
+    rc = gamma_hip_ivfflat_search(h_, &p, n, xq, k, distances, ids);
+  }
+  if (rc) {
+    HLOG("search failed: %s (%s)", gamma_hip_strerror(rc), gamma_hip_last_error(h_));
+    return rc;
+  }
+  return 0;
+}
+
+// "ivfflat.index" in the reference's layout (gamma_index_ivfflat.cc:620-690; iwpq_io.h): a list's codes are its vectors
+int GammaIVFFlatHIPIndex::Dump(const std::string &dir) {
+  if (!is_trained_) return 0;
+  const std::string index_dir = dir + "/" + vector_->MetaInfo()->AbsoluteName();
+  if (mkdir(index_dir.c_str(), 0755) && errno != EEXIST) return -1;
+  IwPQFile f;
+  f.d = d_;
+  f.ntotal = 0;
+  f.metric = metric_type_ == DistanceComputeType::INNER_PRODUCT ? 0 : 1;
+  f.nlist = (size_t)nlist_;
+  f.nprobe = (size_t)nprobe_;
+  f.coarse = coarse_centroids_;
+  f.code_size = sizeof(float) * (size_t)d_;
+  f.sizes.resize(nlist_);
+  f.codes.resize(nlist_);
+  f.ids.resize(nlist_);
+  std::vector<uint8_t> dummy;
+  for (int l = 0; l < nlist_; l++) {
+    const int64_t len = gamma_hip_ivfpq_list_size(h_, l);
+    if (len < 0) return -1;
+    f.sizes[l] = (size_t)len;
+    if (len == 0) continue;
+    f.ids[l].resize(len);
+    dummy.resize(len);
+    if (gamma_hip_ivfpq_get_list(h_, l, f.ids[l].data(), dummy.data())) return -1;
+    // the vectors of the list, from the engine's store (what the reference's lists hold)
+    std::vector<int64_t> vids(len);
+    for (int64_t i = 0; i < len; i++) vids[i] = f.ids[l][i] & 0x7fffffffffffffffLL;
+    ScopeVectors sv;
+    if (vector_->Gets(vids, sv)) return -1;
+    f.codes[l].resize((size_t)len * f.code_size);
+    for (int64_t i = 0; i < len; i++) memcpy(&f.codes[l][(size_t)i * f.code_size], sv.Get((int)i), f.code_size);
+  }
+  return WriteIvFl(index_dir + "/ivfflat.index", f, indexed_vec_count_) ? -1 : 0;
+}
+
+int GammaIVFFlatHIPIndex::Load(const std::string &dir) {
+  const std::string path = dir + "/" + vector_->MetaInfo()->AbsoluteName() + "/ivfflat.index";
+  FILE *probe = fopen(path.c_str(), "rb");
+  if (!probe) return 0;   // it should train again after load
+  fclose(probe);
+  IwPQFile f;
+  int indexed = 0;
+  if (ReadIvFl(path, &f, &indexed)) return -1;
+  if (f.d != d_ || (int)f.nlist != nlist_ || indexed < 0 || indexed > (int)vector_->MetaInfo()->Size()) return -1;
+  if (SetTrainedCoarse(f.coarse.data())) return -1;
+  if (UploadEngineBitmap()) return -1;
+  metric_type_ = f.metric == 0 ? DistanceComputeType::INNER_PRODUCT : DistanceComputeType::L2;
+  std::vector<uint8_t> dummy;
+  for (int l = 0; l < nlist_; l++) {
+    const size_t n = f.sizes[l];
+    if (n == 0) continue;
+    dummy.assign(n, 0);
+    if (gamma_hip_ivfpq_add_keys(h_, l, (int)n, f.ids[l].data(), dummy.data())) return -1;
+  }
+  indexed_vec_count_ = indexed;
   if (EnsureRaw(std::min<int64_t>(indexed_vec_count_, (int64_t)vector_->MetaInfo()->Size()))) return -1;
   return indexed_vec_count_;
 }

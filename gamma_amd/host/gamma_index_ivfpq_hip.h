@@ -78,8 +78,10 @@ class GammaIVFPQHIPIndex : public RetrievalModel {
   int indexed_vec_count_ = 0;
   std::vector<float> coarse_centroids_, pq_centroids_;
 
- private:
+ protected:
   int TrainOnHost(size_t num, const float *xt);
+  int TrainCoarse(size_t num, const float *xt);
+  int TrainingSet(std::vector<float> &xt, size_t &num);
   int EnsureRaw(int64_t upto);
   int UploadEngineBitmap();
   std::mutex raw_mu_;   // raw_uploaded_ + the mirror writes (Search threads, the indexing thread, Load)
@@ -87,6 +89,39 @@ class GammaIVFPQHIPIndex : public RetrievalModel {
   gamma_hip_index *h_ = nullptr;
   HIPIVFPQModelParams *model_param_ = nullptr;
   int64_t raw_uploaded_ = 0;
+};
+
+// "HIPIVFFLAT": the reference's IVFFLAT model (index/impl/gamma_index_ivfflat.{h,cc}) on the device.  Same JSON
+// keys (ncentroids, nprobe, metric_type; retrieval: metric_type, nprobe, parallel_on_queries), same Search
+// contract.  The reference keeps the vectors inside the inverted lists; here the lists hold vector ids and the rows
+// come from the HBM mirror of the vector store the IVFPQ plugin already keeps for its re-rank, so Add / Update /
+// Delete and the raw mirror are inherited; Init, Indexing (coarse k-means only), Search, Dump / Load ("IvFl" file,
+// iwpq_io.h) differ.
+class HIPIVFFlatRetrievalParameters : public RetrievalParameters {
+ public:
+  HIPIVFFlatRetrievalParameters() : RetrievalParameters(), parallel_on_queries_(true), nprobe_(-1) {}
+  HIPIVFFlatRetrievalParameters(enum DistanceComputeType type)
+      : RetrievalParameters(type), parallel_on_queries_(true), nprobe_(-1) {}
+  int Nprobe() { return nprobe_; }
+  void SetNprobe(int nprobe) { nprobe_ = nprobe; }
+  bool ParallelOnQueries() { return parallel_on_queries_; }
+  void SetParallelOnQueries(bool p) { parallel_on_queries_ = p; }
+
+ protected:
+  bool parallel_on_queries_;   // accepted for compatibility; the device path is always batched
+  int nprobe_;
+};
+
+class GammaIVFFlatHIPIndex : public GammaIVFPQHIPIndex {
+ public:
+  int Init(const std::string &model_parameters, int indexing_size) override;
+  RetrievalParameters *Parse(const std::string &parameters) override;
+  int Indexing() override;
+  int Search(RetrievalContext *retrieval_context, int n, const uint8_t *x, int k, float *distances,
+             int64_t *ids) override;
+  int Dump(const std::string &dir) override;
+  int Load(const std::string &dir) override;
+  int SetTrainedCoarse(const float *coarse_centroids);
 };
 
 }  // namespace tig_gamma

@@ -312,6 +312,7 @@ int gh_host_ivfpq_state(void *hp, float *cc, float *pq) {
 
 int gh_host_ivfpq_set_trained(void *hp, const float *cc, const float *pq) {
   GammaIVFPQHIPIndex *m = dynamic_cast<GammaIVFPQHIPIndex *>(((Host *)hp)->model);
+  if (GammaIVFFlatHIPIndex *fl = dynamic_cast<GammaIVFFlatHIPIndex *>(((Host *)hp)->model)) return fl->SetTrainedCoarse(cc);
   return m ? m->SetTrained(cc, pq) : -1;
 }
 // HIPIVFPQModelParams::Parse for host-logic tests: out = {rc, ncentroids, nsubvector, nbits_per_idx,

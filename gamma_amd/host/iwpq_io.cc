@@ -76,14 +76,14 @@ bool read_index_header(In &in, int &d, int64_t &ntotal, int &metric) {
 }
 }  // namespace
 
-int WriteIwPQ(const std::string &path, const IwPQFile &x) {
+static int write_file(const std::string &path, const IwPQFile &x, bool flat, int indexed_count) {
   if (x.coarse.size() != x.nlist * (size_t)x.d || x.sizes.size() != x.nlist || x.codes.size() != x.nlist ||
       x.ids.size() != x.nlist)
     return -2;
   FILE *fp = fopen(path.c_str(), "wb");
   if (!fp) return -1;
   Out o(fp);
-  o.one<uint32_t>(fourcc("IwPQ"));
+  o.one<uint32_t>(fourcc(flat ? "IvFl" : "IwPQ"));
   write_index_header(o, x.d, x.ntotal, x.metric);
   o.one<size_t>(x.nlist);
   o.one<size_t>(x.nprobe);
@@ -92,12 +92,14 @@ int WriteIwPQ(const std::string &path, const IwPQFile &x) {
   o.vec(x.coarse);
   o.one<uint8_t>(0);                 // DirectMap::NoMap
   o.one<size_t>(0);
-  o.one<uint8_t>(x.by_residual ? 1 : 0);
-  o.one<size_t>(x.code_size);
-  o.one<size_t>((size_t)x.d);
-  o.one<size_t>(x.M);
-  o.one<size_t>(x.nbits);
-  o.vec(x.pq);
+  if (!flat) {
+    o.one<uint8_t>(x.by_residual ? 1 : 0);
+    o.one<size_t>(x.code_size);
+    o.one<size_t>((size_t)x.d);
+    o.one<size_t>(x.M);
+    o.one<size_t>(x.nbits);
+    o.vec(x.pq);
+  }
   o.one<uint32_t>(fourcc("ilar"));
   o.one<size_t>(x.nlist);
   o.one<size_t>(x.code_size);
@@ -113,11 +115,15 @@ int WriteIwPQ(const std::string &path, const IwPQFile &x) {
     o.raw(x.codes[l].data(), n * x.code_size);
     o.raw(x.ids[l].data(), n);
   }
+  if (flat) o.one<int>(indexed_count);   // GammaIndexIVFFlat::Dump, gamma_index_ivfflat.cc:645
   const bool ok = o.ok;
   return (fclose(fp) == 0 && ok) ? 0 : -1;
 }
 
-int ReadIwPQ(const std::string &path, IwPQFile *x) {
+int WriteIwPQ(const std::string &path, const IwPQFile &x) { return write_file(path, x, false, 0); }
+int WriteIvFl(const std::string &path, const IwPQFile &x, int indexed_count) { return write_file(path, x, true, indexed_count); }
+
+static int read_file(const std::string &path, IwPQFile *x, bool flat, int *indexed_count) {
   FILE *fp = fopen(path.c_str(), "rb");
   if (!fp) return -1;
   In in(fp);
@@ -126,7 +132,7 @@ int ReadIwPQ(const std::string &path, IwPQFile *x) {
   do {
     uint32_t h = 0;
     in.one(h);
-    if (!in.ok || h != fourcc("IwPQ")) { rc = -2; break; }
+    if (!in.ok || h != fourcc(flat ? "IvFl" : "IwPQ")) { rc = -2; break; }
     if (!read_index_header(in, x->d, x->ntotal, x->metric)) break;
     in.one(x->nlist);
     in.one(x->nprobe);
@@ -142,16 +148,20 @@ int ReadIwPQ(const std::string &path, IwPQFile *x) {
     std::vector<int64_t> dmap;
     in.vec(dmap, kMax);
     if (!in.ok || dm == 2) { rc = -2; break; }   // hashtable direct maps are not produced by Gamma
-    uint8_t br = 1;
-    in.one(br);
-    x->by_residual = br != 0;
-    in.one(x->code_size);
-    size_t pd = 0;
-    in.one(pd);
-    in.one(x->M);
-    in.one(x->nbits);
-    in.vec(x->pq, kMax);
-    if (!in.ok || pd != (size_t)x->d) { rc = -2; break; }
+    if (!flat) {
+      uint8_t br = 1;
+      in.one(br);
+      x->by_residual = br != 0;
+      in.one(x->code_size);
+      size_t pd = 0;
+      in.one(pd);
+      in.one(x->M);
+      in.one(x->nbits);
+      in.vec(x->pq, kMax);
+      if (!in.ok || pd != (size_t)x->d) { rc = -2; break; }
+    } else {
+      x->code_size = sizeof(float) * (size_t)x->d;
+    }
     in.one(h);
     if (!in.ok || h != fourcc("ilar")) { rc = -2; break; }   // an opq record would sit here: unsupported
     size_t nl = 0, cs = 0;
@@ -186,10 +196,14 @@ int ReadIwPQ(const std::string &path, IwPQFile *x) {
       in.raw(x->codes[l].data(), n * x->code_size);
       in.raw(x->ids[l].data(), n);
     }
+    if (flat && indexed_count) in.one(*indexed_count);
   } while (0);
   if (rc == 0 && !in.ok) rc = -1;
   fclose(fp);
   return rc;
 }
+
+int ReadIwPQ(const std::string &path, IwPQFile *x) { return read_file(path, x, false, nullptr); }
+int ReadIvFl(const std::string &path, IwPQFile *x, int *indexed_count) { return read_file(path, x, true, indexed_count); }
 
 }  // namespace tig_gamma

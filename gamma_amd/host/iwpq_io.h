@@ -38,5 +38,10 @@ struct IwPQFile {
 // 0 ok; -1 cannot open / short write or read; -2 not an IwPQ file or unsupported sub-record
 int WriteIwPQ(const std::string &path, const IwPQFile &f);
 int ReadIwPQ(const std::string &path, IwPQFile *f);
+// The IVFFLAT model's "ivfflat.index" (GammaIndexIVFFlat::Dump/Load, index/impl/gamma_index_ivfflat.cc:620-690):
+//   u32 "IvFl" | the same ivf header | the same inverted lists with code_size = 4 d (a list's codes are its vectors)
+//   | int indexed_count.  by_residual / code_size / the product quantizer are absent; f.pq stays empty.
+int WriteIvFl(const std::string &path, const IwPQFile &f, int indexed_count);
+int ReadIvFl(const std::string &path, IwPQFile *f, int *indexed_count);
 
 }  // namespace tig_gamma

@@ -392,3 +392,75 @@ def test_plugin_device_filters_from_the_table(case, model):
             compare_topk(Df, If, Dg, Ig)
     B.lib().go_set_assign_mode(0)
     m.close()
+
+
+def test_ivfflat_plugin_matches_oracle(case, tmp_path):
+    """HIPIVFFLAT driven like VectorManager drives a model (gamma_index_ivfflat.cc): Init / Add in engine-sized
+    batches / Parse + Search / Delete / Update / Dump + Load of the reference's "IvFl" file, against the oracle's
+    restatement of GammaIndexIVFFlat::Search over the same lists; and its own Indexing() for recall."""
+    from gamma_amd import plugin
+    base, q, d, nlist = case["base"], case["q"], case["d"], case["nlist"]
+    N = len(base)
+    m = plugin.PluginModel("HIPIVFFLAT", d, '{"ncentroids": %d, "nprobe": 8, "metric_type": "L2"}' % nlist, indexing_size=5000)
+    m.store(base)
+    assert m.set_trained(case["cc"], case["pq"]) == 0
+    o = B.OracleIVFPQ(d, nlist, case["M"], 8, B.METRIC_L2)
+    o.set_trained(case["cc"], case["pq"], None)
+    B.lib().go_set_assign_mode(-1)
+    try:
+        for i0 in range(0, N, 5000):
+            xb = base[i0:i0 + 5000]
+            assert m.add(xb)
+            lno = B.ivfflat_assign(o, xb)
+            order = np.argsort(lno, kind="stable")
+            for l in np.unique(lno):
+                sel = order[lno[order] == l]
+                o.add_keys(int(l), i0 + sel, np.zeros((len(sel), case["M"]), np.uint8))
+        raw = base.copy()
+        o.set_raw(raw)
+        for n in (len(q), 5):
+            D, I = B.ivfflat_search(o, q[:n], 10, 8, B.METRIC_L2, B.make_ctx())
+            Dg, Ig = m.search(q[:n], 10, '{"metric_type": "L2", "nprobe": 8}')
+            compare_topk(D, I, Dg, Ig)
+        D, I = B.ivfflat_search(o, q, 10, 8, B.METRIC_L2, B.make_ctx())
+        Dg, Ig = m.search(q, 10, "")                      # nprobe from Init
+        compare_topk(D, I, Dg, Ig)
+        # Delete + Update
+        dead = np.unique(I[:, 0])
+        assert m.delete(dead) == 0
+        bm = np.zeros((N + 7) // 8, np.uint8)
+        for v in dead:
+            bm[v >> 3] |= 1 << (v & 7)
+        o.delete(dead)
+        vid = int(I[3, 1])
+        newv = base[(vid + 31) % N].copy()
+        assert m.update(vid, newv) == 0
+        raw[vid] = newv
+        o.update_code(int(B.ivfflat_assign(o, newv[None])[0]), vid, np.zeros(case["M"], np.uint8))
+        D, I = B.ivfflat_search(o, q, 10, 8, B.METRIC_L2, B.make_ctx(docids_bitmap=bm))
+        Dg, Ig = m.search(q, 10, "")
+        compare_topk(D, I, Dg, Ig)
+        # Dump -> a fresh model loads the reference-format file and answers the same
+        assert m.dump(str(tmp_path)) == 0
+        m2 = plugin.PluginModel("HIPIVFFLAT", d, '{"ncentroids": %d, "nprobe": 8, "metric_type": "L2"}' % nlist,
+                                indexing_size=5000)
+        m2.store(raw)
+        m2.engine_bitmap_set(dead)
+        assert m2.load(str(tmp_path)) == N
+        Dg2, Ig2 = m2.search(q, 10, "")
+        assert Dg.tobytes() == Dg2.tobytes() and np.array_equal(Ig, Ig2)
+        m2.close()
+    finally:
+        B.lib().go_set_assign_mode(0)
+        m.close()
+    # own training: recall against the exact search
+    m3 = plugin.PluginModel("HIPIVFFLAT", d, '{"ncentroids": %d, "nprobe": 16, "metric_type": "L2"}' % nlist, indexing_size=5000)
+    m3.store(base)
+    assert m3.indexing() == 0
+    for i0 in range(0, N, 5000):
+        assert m3.add(base[i0:i0 + 5000])
+    Df, If = B.flat_search(base, q, 10, B.METRIC_L2, B.make_ctx())
+    Dg, Ig = m3.search(q, 10, "")
+    hit = np.mean([len(set(a) & set(b)) / 10.0 for a, b in zip(If, Ig)])
+    assert hit > 0.9, hit
+    m3.close()
