@@ -290,6 +290,23 @@ def main():
                                              "peak": 157.3, "unit": "TFLOP/s",
                                              "frac": round(flops / sec / 157.3e12, 4)}}
 
+        # (d2) the IVFFLAT model (f4) on the same vectors, centroids and nprobe: exact distances of every entry of the
+        #      probed lists, rows gathered from the raw store
+        if N * d * 4 <= (2 << 30):
+            gf = api.GammaHip(local_rank)
+            gf.ivfflat_init(d, nlist, api.METRIC_L2, bucket_init_size=max(1000, int(2.5 * N / nlist)))
+            gf.ivfflat_set_trained(cc)
+            gf.raw_init(d)
+            for i0 in range(0, N, 1 << 16):
+                gf.raw_append(base[i0:i0 + (1 << 16)])
+                gf.add(base[i0:i0 + (1 << 16)], i0)
+            vnq = 4096
+            vargs = api.SearchArgs(metric=api.METRIC_L2, nprobe=a.nprobe, min_score=0.0, max_score=1e30)
+            sec = timed(lambda: gf.ivfflat_search_device(d_q.data_ptr(), vnq, k, vargs, d_D.data_ptr(), d_I.data_ptr()), 5, 2)
+            extra["ivfflat"] = {"workload": "IVFFLAT nlist=%d nprobe=%d, %dx%d, %d queries/call, k=%d" % (nlist, a.nprobe, N, d, vnq, k),
+                                "ms_per_call": round(sec * 1e3, 3), "qps": round(vnq / sec, 1)}
+            gf.close()
+
         # (e) C5's other half: realtime inserts at 10 k vectors/s WHILE searching (writers run on their own stream
         #     and publish versioned list tables; tests/test_gpu_concurrent.py checks that every search sees a prefix)
         import threading
