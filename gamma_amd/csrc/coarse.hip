@@ -246,7 +246,9 @@ __device__ __forceinline__ uint32_t wave_kth_smallest(uint32_t m, int K) {
 // value <= tau_q, so tau_q bounds the P-th smallest distance of the row from above, and with 8 values per lane it
 // sits at the same quantile (about 1.3 P / sample) a full selection would reach -- at a tenth of its cost.
 template <int NPL>   // sample = 64 * NPL columns
-__global__ __launch_bounds__(256) void k_coarse_bound(const float* __restrict__ mat, int nq, int P, float* __restrict__ tau) {
+__global__ __launch_bounds__(256) void k_coarse_bound(const float* __restrict__ mat, int nq, int P, float* __restrict__ tau,
+                                                      int* __restrict__ ovf) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) ovf[0] = 0;   // the overflow list of this call starts empty (k_coarse_final appends)
     const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= nq) return;
     const float* v = mat + (int64_t)q * (64 * NPL) + lane;
@@ -463,7 +465,6 @@ void launch_coarse_fused(hipStream_t s, const CoarseFusedPlan& pl, void* ws, con
     int* cnt = reinterpret_cast<int*>(b + pl.off_cnt);
     int* ovf = reinterpret_cast<int*>(b + pl.off_ovf);
     uint32_t* scratch = reinterpret_cast<uint32_t*>(b + pl.off_scratch);
-    (void)hipMemsetAsync(ovf, 0, sizeof(int), s);
     // A: the sample columns, every distance stored (two strips: the 128 queries' fragments are loaded once per strip)
     const size_t lds = (size_t)2 * 64 * (d + 1) * sizeof(float);
     {
@@ -488,8 +489,8 @@ void launch_coarse_fused(hipStream_t s, const CoarseFusedPlan& pl, void* ws, con
         }
 #undef GH_CS
     }
-    if (pl.sample == 512) hipLaunchKernelGGL(k_coarse_bound<8>, dim3((nq + 3) / 4), dim3(256), 0, s, mat, nq, P, tau);
-    else hipLaunchKernelGGL(k_coarse_bound<16>, dim3((nq + 3) / 4), dim3(256), 0, s, mat, nq, P, tau);
+    if (pl.sample == 512) hipLaunchKernelGGL(k_coarse_bound<8>, dim3((nq + 3) / 4), dim3(256), 0, s, mat, nq, P, tau, ovf);
+    else hipLaunchKernelGGL(k_coarse_bound<16>, dim3((nq + 3) / 4), dim3(256), 0, s, mat, nq, P, tau, ovf);
     // B: the other columns, filtered
     dim3 grid((unsigned)pl.nseg, (unsigned)((nq + 127) / 128));
 #define GH_CF(NCH)                                                                                                      \
