@@ -849,7 +849,10 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         sb.gcnt = reinterpret_cast<int*>(ready + nq);
         sb.K = R;
         sb.cnt_stride = nsl;
-        sb.store_all = h->tie.on ? 1 : 0;
+        // exact ties: the replay reads a bounded query's candidates from slab group 0 + the survivor slices, and an
+        // unbounded one's from the slab the repair launch below fills -- nothing else needs the consumers' distances
+        // (the list-major variant has no repair launch: it stores everything)
+        sb.store_all = (h->tie.on && lm) ? 1 : 0;
         sb.rq_count = h->w_scnt.as<int>();
         sb.rq_list = h->w_scnt.as<int>() + 1;
         const unsigned long long* surv_c = nullptr;
