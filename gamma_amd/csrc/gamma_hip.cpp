@@ -1234,9 +1234,19 @@ int ivfflat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq,
         GH_CHECK(h, h->w_dist.ensure((size_t)nc * q_stride * sizeof(float)));
         {
             StageScope t(h, GAMMA_HIP_STAGE_SCAN);
-            gh::launch_ivfflat_scan(s, l2, xq, nc, h->d, P, h->w_pair_off.as<int>(), h->w_pair_base.as<int64_t>(), h->d_ids,
-                                    h->d_raw, h->nraw, q_stride, h->w_dist.as<float>(), fc.d_tab, need_filter, p->min_score,
-                                    p->max_score);
+            // enough (query, probe) pairs that lists are shared: list-major (ivfflat.hip), a list's rows are read once
+            // for all the queries probing it; else one workgroup per pair
+            static const bool no_lm = getenv("GAMMA_HIP_NO_IVFFLAT_LM") != nullptr;
+            if (!no_lm && gh::ivfflat_lm_supported(h->d) && (int64_t)nc * P >= 2 * (int64_t)nlist && !h->d_list_mask) {
+                GH_CHECK(h, h->w_lm_units.ensure(gh::ivfflat_lm_scratch_bytes(nc, P, nlist)));
+                gh::launch_ivfflat_lm(s, l2, xq, nc, h->d, P, h->w_probe.as<int>(), h->w_pair_off.as<int>(), h->d_list_off,
+                                      h->d_list_len, nlist, h->d_ids, h->d_raw, h->nraw, q_stride, h->w_dist.as<float>(),
+                                      fc.d_tab, need_filter, p->min_score, p->max_score, h->w_lm_units.p);
+            } else {
+                gh::launch_ivfflat_scan(s, l2, xq, nc, h->d, P, h->w_pair_off.as<int>(), h->w_pair_base.as<int64_t>(),
+                                        h->d_ids, h->d_raw, h->nraw, q_stride, h->w_dist.as<float>(), fc.d_tab, need_filter,
+                                        p->min_score, p->max_score);
+            }
         }
         {
             StageScope t(h, GAMMA_HIP_STAGE_SELECT);

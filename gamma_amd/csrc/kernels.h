@@ -178,6 +178,13 @@ void launch_small_tail(hipStream_t s, bool l2, const float* slab, int64_t q_stri
 void launch_ivfflat_scan(hipStream_t s, bool l2, const float* x, int nq, int d, int P, const int* pair_off,
                          const int64_t* pair_base, const int64_t* ids, const float* raw, int64_t nraw, int64_t q_stride,
                          float* out, const FilterDesc* ftab, int need_filter, float min_score, float max_score);
+// IVFFLAT, list-major (ivfflat.hip): one workgroup per list, every query probing it run past the list's rows
+bool ivfflat_lm_supported(int d);
+size_t ivfflat_lm_scratch_bytes(int nq, int P, int nlist);
+void launch_ivfflat_lm(hipStream_t s, bool l2, const float* x, int nq, int d, int P, const int* probe, const int* pair_off,
+                       const int64_t* list_off, const int* list_len, int nlist, const int64_t* ids, const float* raw,
+                       int64_t nraw, int64_t q_stride, float* out, const FilterDesc* ftab, int need_filter, float min_score,
+                       float max_score, void* scratch);
 void launch_coarse_select(hipStream_t s, const float* mat, int nlist, int nq, int K, float* out_vals, int* out_pos,
                           uint8_t* tie_flag, unsigned long long* tie_stats = nullptr);
 void launch_select_topk(hipStream_t s, bool smallest, const float* vals, int64_t seg_stride,
