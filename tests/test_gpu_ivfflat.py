@@ -33,8 +33,10 @@ def _load(case, metric):
     return g
 
 
-@pytest.mark.parametrize("metric,d", [(B.METRIC_L2, 32), (B.METRIC_IP, 32), (B.METRIC_L2, 100)])
+@pytest.mark.parametrize("metric,d", [(B.METRIC_L2, 32), (B.METRIC_IP, 32), (B.METRIC_L2, 100), (B.METRIC_L2, 128),
+                                      (B.METRIC_IP, 64), (B.METRIC_L2, 16), (B.METRIC_IP, 96)])
 def test_ivfflat_search_matches_oracle(metric, d):
+    # d = 100 has no list-major variant: the (query, probe) pair kernel; the others run list-major from 16 queries x 8 probes
     case = fixtures.trained_case(d=d, nlist=64, M=d // 4, N=20000, nq=64, metric=B.METRIC_L2)
     o = case["oracle"]
     g = _load(case, metric)
