@@ -75,6 +75,8 @@ SYMBOLS = {
     "gamma_hip_ivfpq_add_keys": (C.c_int, [C.c_void_p, C.c_int, C.c_int, i64p, u8p]),
     "gamma_hip_ivfpq_add_keys_batch": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p, i64p, u8p]),
     "gamma_hip_ivfpq_update": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, u8p]),
+    "gamma_hip_vid2docid_append": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]),
+    "gamma_hip_vid2docid_count": (C.c_int64, [C.c_void_p]),
     "gamma_hip_ivfflat_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "gamma_hip_ivfflat_set_trained": (C.c_int, [C.c_void_p, f32p]),
     "gamma_hip_ivfflat_search": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int, f32p, C.c_int, f32p, i64p]),

@@ -261,6 +261,14 @@ class GammaHip:
                                                _p(D, _lib.f32p), _p(I, _lib.i64p)), "ivfpq_search")
         return D, I
 
+    def vid2docid_append(self, docids):
+        """docid of the next vids (multi-vector documents); never called = docid == vid"""
+        m = np.ascontiguousarray(docids, dtype=np.int32)
+        self._ck(self.L.gamma_hip_vid2docid_append(self.h, m.size, m.ctypes.data_as(C.POINTER(C.c_int32))), "vid2docid_append")
+
+    def vid2docid_count(self):
+        return self.L.gamma_hip_vid2docid_count(self.h)
+
     # ---- IVFFLAT ----
     def ivfflat_init(self, d, nlist, metric=METRIC_L2, bucket_init_size=1000, bucket_max_size=1280000):
         self._ck(self.L.gamma_hip_ivfflat_init(self.h, d, nlist, metric, bucket_init_size, bucket_max_size), "ivfflat_init")

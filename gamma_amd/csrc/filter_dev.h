@@ -14,7 +14,8 @@ __device__ __forceinline__ bool bm_test(const uint8_t* bm, int64_t id) {
 }
 
 __device__ __forceinline__ bool is_valid_doc(const FilterDesc& f, int64_t vid) {
-    const int doc = (int)vid;
+    // GammaSearchCondition::IsValid: docid = raw_vec->VidMgr()->VID2DocID(id) (common/gamma_common_data.h:100)
+    const int doc = (f.vid2doc && vid >= 0 && vid < f.n_vid2doc) ? f.vid2doc[vid] : (int)vid;
     if (f.has_range) {
         if (f.n_range == 0) return false;  // MultiRangeQueryResults::Has on empty set
         for (int i = 0; i < f.n_range; i++) {

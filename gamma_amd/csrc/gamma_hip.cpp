@@ -171,6 +171,16 @@ struct gamma_hip_index {
     bool list_major = false;   // gamma_hip_set_list_major
     bool coarse_fused = true;  // gamma_hip_set_coarse_fused
     bool small_path = true;    // gamma_hip_set_small_path
+    // multi-vector documents (VIDMgr::VID2DocID, vector/raw_vector_common.h:90-95): docid of every vid, host + device;
+    // empty = single-vector documents, docid == vid.  Every delete-bitmap / filter test goes through it.
+    std::vector<int32_t> h_v2d;
+    int32_t* d_v2d = nullptr;
+    int64_t v2d_cap = 0;
+    int64_t doc_of(int64_t v) const { return (v >= 0 && (size_t)v < h_v2d.size()) ? (int64_t)h_v2d[v] : v; }
+    bool doc_deleted(int64_t v) const {
+        const int64_t dd = doc_of(v);
+        return dd >= 0 && dd < bitmap_bits && !h_bitmap.empty() && ((h_bitmap[dd >> 3] >> (dd & 7)) & 1);
+    }
     bool ivfflat = false;      // gamma_hip_ivfflat_init: lists of vector ids (1 dummy code byte), rows from the raw store
     int coarse_cap = gh::kCoarseCap;
     unsigned long long* d_tie_stats = nullptr;   // {coarse rows redone, top-R cuts through a tie, queries replayed}
@@ -462,8 +472,7 @@ int add_keys_locked(H* h, int l, int n, const int64_t* vids, const uint8_t* code
         }
         if ((size_t)v >= h->vid_pos.size()) h->vid_pos.resize(std::max<size_t>(h->vid_pos.size() * 2, v + 1), -1);
         h->vid_pos[v] = ((int64_t)l << 32) | (int64_t)(h->h_list_len[l] + i);
-        if (h->bitmap_bits > v && !h->h_bitmap.empty() && ((h->h_bitmap[v >> 3] >> (v & 7)) & 1))
-            h->h_deleted[l]++;  // realtime_mem_data.cc:293-296
+        if (h->doc_deleted(v)) h->h_deleted[l]++;  // realtime_mem_data.cc:293-296
     }
     h->h_list_len[l] += n;  // publish after the copies (realtime_mem_data.cc:299-300)
     h->ntotal += n;
@@ -479,6 +488,8 @@ int build_filter(H* h, const gamma_hip_search_params* p, gh::FilterDesc* f, size
     memset(f, 0, sizeof(*f));
     f->del_bitmap = h->d_bitmap;
     f->del_bits = h->d_bitmap ? h->bitmap_bits : 0;
+    f->vid2doc = h->h_v2d.empty() ? nullptr : h->d_v2d;
+    f->n_vid2doc = (int64_t)h->h_v2d.size();
     f->has_range = p->has_range ? 1 : 0;
     f->n_range = p->has_range ? p->n_range : 0;
     if (f->n_range > gh::kMaxRange) return fail(h, GAMMA_HIP_EINVAL, "too many range filters");
@@ -1485,7 +1496,7 @@ int gamma_hip_destroy(gamma_hip_index* h) {
         (void)hipEventDestroy(e.b);
     }
     void* ptrs[] = {h->d_list_rank, h->d_raw, h->d_bitmap, h->d_cc, h->d_cc_norms, h->d_pqc, h->d_T2, h->d_codes,
-                    h->d_ids, h->d_list_mask, h->d_scan_codes, h->d_tie_stats};
+                    h->d_ids, h->d_list_mask, h->d_scan_codes, h->d_tie_stats, h->d_v2d};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& kv : h->fields)
@@ -1618,6 +1629,36 @@ int gamma_hip_field_update(gamma_hip_index* h, int field_id, int64_t docid, cons
     GH_CHECK(h, hipMemcpyAsync(it->second.d + (size_t)docid * es, value, es, hipMemcpyHostToDevice, h->wstream));
     GH_CHECK(h, hipStreamSynchronize(h->wstream));
     return GAMMA_HIP_OK;
+}
+
+int gamma_hip_vid2docid_append(gamma_hip_index* h, int64_t n, const int32_t* docids) {
+    if (!h || n < 0 || (n > 0 && !docids)) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    GH_CHECK(h, hipSetDevice(h->device));
+    const int64_t have = (int64_t)h->h_v2d.size();
+    if (have + n > h->v2d_cap) {
+        const int64_t ncap = std::max<int64_t>(have + n, std::max<int64_t>(1 << 16, h->v2d_cap * 2));
+        int32_t* nd = nullptr;
+        GH_CHECK(h, lk.exclusive());   // the old array is freed below
+        GH_CHECK(h, hipMalloc((void**)&nd, (size_t)ncap * sizeof(int32_t)));
+        if (have) GH_CHECK(h, hipMemcpyAsync(nd, h->d_v2d, (size_t)have * sizeof(int32_t), hipMemcpyDeviceToDevice, h->wstream));
+        GH_CHECK(h, hipStreamSynchronize(h->wstream));
+        if (h->d_v2d) (void)hipFree(h->d_v2d);
+        h->d_v2d = nd;
+        h->v2d_cap = ncap;
+    }
+    if (n) {
+        GH_CHECK(h, hipMemcpyAsync(h->d_v2d + have, docids, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, h->wstream));
+        GH_CHECK(h, hipStreamSynchronize(h->wstream));
+        h->h_v2d.insert(h->h_v2d.end(), docids, docids + n);   // published last: searches enqueued before see the shorter map
+    }
+    return GAMMA_HIP_OK;
+}
+
+int64_t gamma_hip_vid2docid_count(gamma_hip_index* h) {
+    if (!h) return -1;
+    std::lock_guard<std::mutex> g(h->mu);
+    return (int64_t)h->h_v2d.size();
 }
 
 int64_t gamma_hip_field_count(gamma_hip_index* h, int field_id) {
@@ -1973,7 +2014,7 @@ int gamma_hip_ivfpq_add_keys_batch(gamma_hip_index* h, int nlists, const int32_t
             }
             if ((size_t)v >= h->vid_pos.size()) h->vid_pos.resize(std::max<size_t>(h->vid_pos.size() * 2, v + 1), -1);
             h->vid_pos[v] = ((int64_t)l << 32) | (int64_t)(h->h_list_len[l] + j);
-            if (h->bitmap_bits > v && !h->h_bitmap.empty() && ((h->h_bitmap[v >> 3] >> (v & 7)) & 1)) h->h_deleted[l]++;
+            if (h->doc_deleted(v)) h->h_deleted[l]++;
         }
         h->h_list_len[l] += n;
         h->ntotal += n;
@@ -2066,7 +2107,7 @@ int gamma_hip_ivfpq_compact_if_need(gamma_hip_index* h) {
         for (int i = 0; i < len; i++) {  // CompactOne, :98-112
             const int64_t id = ids[i];
             const int64_t v = id & ~kDelMask;
-            const bool deleted = (v < h->bitmap_bits) && ((h->h_bitmap[v >> 3] >> (v & 7)) & 1);
+            const bool deleted = h->doc_deleted(v);
             if (!(id & kDelMask) && !deleted) {
                 ids[pos] = id;
                 memmove(codes.data() + (size_t)pos * h->code_size, codes.data() + (size_t)i * h->code_size, h->code_size);

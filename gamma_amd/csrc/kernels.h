@@ -39,6 +39,8 @@ struct TermDesc {
 struct FilterDesc {
     const uint8_t* del_bitmap;
     int64_t del_bits;
+    const int* vid2doc;      // VIDMgr::VID2DocID of multi-vector documents; nullptr: docid == vid
+    int64_t n_vid2doc;
     int32_t has_range, n_range;
     RangeDesc range[kMaxRange];
     int32_t n_field, n_term;

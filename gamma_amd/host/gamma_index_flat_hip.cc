@@ -57,7 +57,19 @@ bool GammaFLATHIPIndex::Add(int n, const uint8_t *vec) {
   std::lock_guard<std::mutex> g(raw_mu_);
   if (gamma_hip_raw_write(h_, uploaded_, n, reinterpret_cast<const float *>(vec))) return false;
   uploaded_ += n;
-  return true;
+  return SyncVid2DocID(uploaded_) == 0;
+}
+
+// multi-vector documents: docids of the mirrored vids to the device (filters and the delete bitmap are on DOC ids)
+int GammaFLATHIPIndex::SyncVid2DocID(int64_t upto) {
+  RawVector *rv = dynamic_cast<RawVector *>(vector_);
+  if (!rv || !rv->VidMgr() || !rv->VidMgr()->MultiVids()) return 0;
+  const int64_t have = gamma_hip_vid2docid_count(h_);
+  if (have < 0) return -1;
+  if (upto <= have) return 0;
+  std::vector<int32_t> m((size_t)(upto - have));
+  for (int64_t v = have; v < upto; v++) m[(size_t)(v - have)] = rv->VidMgr()->VID2DocID((int)v);
+  return gamma_hip_vid2docid_append(h_, (int64_t)m.size(), m.data());
 }
 
 int GammaFLATHIPIndex::Update(const std::vector<int64_t> &ids, const std::vector<const uint8_t *> &vecs) {
@@ -69,7 +81,11 @@ int GammaFLATHIPIndex::Update(const std::vector<int64_t> &ids, const std::vector
 
 int GammaFLATHIPIndex::Delete(const std::vector<int64_t> &ids) {
   if (ids.empty()) return 0;
-  return gamma_hip_bitmap_set(h_, ids.data(), (int64_t)ids.size(), 1) ? -1 : 0;
+  std::vector<int64_t> docs(ids);   // the bitmap is on DOC ids (VIDMgr::VID2DocID; identity for single-vector documents)
+  RawVector *rv = dynamic_cast<RawVector *>(vector_);
+  if (rv && rv->VidMgr() && rv->VidMgr()->MultiVids())
+    for (size_t i = 0; i < docs.size(); i++) docs[i] = rv->VidMgr()->VID2DocID((int)ids[i]);
+  return gamma_hip_bitmap_set(h_, docs.data(), (int64_t)docs.size(), 1) ? -1 : 0;
 }
 
 int GammaFLATHIPIndex::Load(const std::string &dir) {
@@ -93,6 +109,7 @@ int GammaFLATHIPIndex::Load(const std::string &dir) {
     if (gamma_hip_raw_write(h_, i0, nb, buf.data())) return -1;
     uploaded_ = i0 + nb;
   }
+  if (SyncVid2DocID(uploaded_)) return -1;
   return (int)uploaded_;
 }
 

@@ -45,6 +45,7 @@ class GammaFLATHIPIndex : public RetrievalModel {
   gamma_hip_index *h_ = nullptr;
   int d_ = 0;
   int64_t uploaded_ = 0;
+  int SyncVid2DocID(int64_t upto);
   std::mutex raw_mu_;   // uploaded_ + the mirror writes
   bool device_filters_ = false;
   DeviceColumns columns_;

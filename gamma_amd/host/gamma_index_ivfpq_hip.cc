@@ -272,6 +272,7 @@ bool GammaIVFPQHIPIndex::Add(int n, const uint8_t *vec) {
     if (gamma_hip_raw_write(h_, indexed_vec_count_, n, v)) return false;
     raw_uploaded_ = std::max(raw_uploaded_, end);
   }
+  if (SyncVid2DocID(end)) return false;   // before AddKeys: it counts vectors of deleted DOCS (realtime_mem_data.cc:294)
   int rc = gamma_hip_ivfpq_add(h_, n, v, indexed_vec_count_);
   if (rc) {
     HLOG("add failed: %s (%s)", gamma_hip_strerror(rc), gamma_hip_last_error(h_));
@@ -299,7 +300,12 @@ int GammaIVFPQHIPIndex::Delete(const std::vector<int64_t> &ids) {
   // the engine sets the doc bit in its BitmapManager (search/gamma_engine.cc:810-812); the
   // device keeps a mirror of that bitmap, fed from here (vid == docid for single-vector docs)
   if (ids.empty()) return 0;
-  if (gamma_hip_bitmap_set(h_, ids.data(), (int64_t)ids.size(), 1)) return -1;
+  // the bitmap is on DOC ids (VIDMgr::VID2DocID; the identity for single-vector documents)
+  std::vector<int64_t> docs(ids);
+  RawVector *rv = dynamic_cast<RawVector *>(vector_);
+  if (rv && rv->VidMgr() && rv->VidMgr()->MultiVids())
+    for (size_t i = 0; i < docs.size(); i++) docs[i] = rv->VidMgr()->VID2DocID((int)ids[i]);
+  if (gamma_hip_bitmap_set(h_, docs.data(), (int64_t)docs.size(), 1)) return -1;
   return gamma_hip_ivfpq_delete(h_, ids.data(), (int)ids.size()) ? -1 : 0;
 }
 
@@ -365,6 +371,19 @@ int GammaIVFPQHIPIndex::EnsureRaw(int64_t upto) {
 
 // the engine's delete bitmap -> the device mirror (after a restart the engine has loaded its bitmap file
 // before it calls Load on the models, util/bitmap_manager.cc:96-161; vector_ is a RawVector, raw_vector.h:171)
+// multi-vector documents: the device tests the delete bitmap and every filter on the DOC id of a scanned vector
+// (include/gamma_hip.h gamma_hip_vid2docid_append); the mapping is the engine's VIDMgr
+int GammaIVFPQHIPIndex::SyncVid2DocID(int64_t upto) {
+  RawVector *rv = dynamic_cast<RawVector *>(vector_);
+  if (!rv || !rv->VidMgr() || !rv->VidMgr()->MultiVids()) return 0;
+  const int64_t have = gamma_hip_vid2docid_count(h_);
+  if (have < 0) return -1;
+  if (upto <= have) return 0;
+  std::vector<int32_t> m((size_t)(upto - have));
+  for (int64_t v = have; v < upto; v++) m[(size_t)(v - have)] = rv->VidMgr()->VID2DocID((int)v);
+  return gamma_hip_vid2docid_append(h_, (int64_t)m.size(), m.data());
+}
+
 int GammaIVFPQHIPIndex::UploadEngineBitmap() {
   RawVector *rv = dynamic_cast<RawVector *>(vector_);
   if (!rv || !rv->Bitmap() || rv->Bitmap()->BitSize() == 0) return 0;
@@ -448,6 +467,7 @@ int GammaIVFPQHIPIndex::Load(const std::string &dir) {
   // deletes that happened before the restart: the bitmap must be in place BEFORE the lists come back, so that
   // AddKeys counts the deleted entries per list as the reference does (realtime_mem_data.cc:293-296)
   if (UploadEngineBitmap()) return -1;
+  if (SyncVid2DocID((int64_t)vector_->MetaInfo()->Size())) return -1;
   metric_type_ = f.metric == 0 ? DistanceComputeType::INNER_PRODUCT : DistanceComputeType::L2;
   int64_t count = 0;
   for (int l = 0; l < nlist_; l++) {
@@ -639,6 +659,7 @@ int GammaIVFFlatHIPIndex::Load(const std::string &dir) {
   if (f.d != d_ || (int)f.nlist != nlist_ || indexed < 0 || indexed > (int)vector_->MetaInfo()->Size()) return -1;
   if (SetTrainedCoarse(f.coarse.data())) return -1;
   if (UploadEngineBitmap()) return -1;
+  if (SyncVid2DocID((int64_t)vector_->MetaInfo()->Size())) return -1;
   metric_type_ = f.metric == 0 ? DistanceComputeType::INNER_PRODUCT : DistanceComputeType::L2;
   std::vector<uint8_t> dummy;
   for (int l = 0; l < nlist_; l++) {

@@ -84,6 +84,7 @@ class GammaIVFPQHIPIndex : public RetrievalModel {
   int TrainingSet(std::vector<float> &xt, size_t &num);
   int EnsureRaw(int64_t upto);
   int UploadEngineBitmap();
+  int SyncVid2DocID(int64_t upto);   // multi-vector documents: docids of vids [0, upto) to the device (VIDMgr)
   std::mutex raw_mu_;   // raw_uploaded_ + the mirror writes (Search threads, the indexing thread, Load)
   DeviceColumns columns_;
   gamma_hip_index *h_ = nullptr;

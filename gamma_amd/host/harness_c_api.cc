@@ -27,6 +27,9 @@ class MemVectorReader : public RawVector {
   MemVectorReader(int d) : RawVector(new VectorMetaInfo("vec", d, VectorValueType::FLOAT), &bitmap_), d_(d) {
     bitmap_.Init(1 << 22);
   }
+  // documents with several vectors: docid of every vid appended from now on (tests)
+  void SetMultiVids() { vid_mgr_ = &vids_; }
+  VIDMgr vids_{true};
   int Gets(const std::vector<int64_t> &vids, ScopeVectors &vecs) const override {
     std::lock_guard<std::mutex> g(mu_);
     for (auto v : vids) {
@@ -76,6 +79,12 @@ int gh_host_init(void *hp, const char *retrieval_param, int indexing_size) {
 }
 // AddToStore (raw vector append) without indexing: what happens before the index is trained
 void gh_host_store(void *hp, int n, const float *x) { ((Host *)hp)->store->Append(n, x); }
+// multi-vector documents: docid of vids [first, first + n)
+void gh_host_set_vid2docid(void *hp, int first, int n, const int *docids) {
+  Host *h = (Host *)hp;
+  h->store->SetMultiVids();
+  for (int i = 0; i < n; i++) h->store->vids_.Add(first + i, docids[i]);
+}
 int gh_host_indexing(void *hp) { return ((Host *)hp)->model->Indexing(); }
 // model->Add for vectors already in the store (AddRTVecsToIndex)
 int gh_host_add(void *hp, int n, const float *x) {
@@ -94,7 +103,9 @@ int gh_host_update(void *hp, int64_t vid, const float *x) {
 // GammaEngine::Delete (search/gamma_engine.cc:802-824): the doc bit in the engine's bitmap, then the models
 int gh_host_delete(void *hp, const int64_t *vids, int n) {
   Host *h = (Host *)hp;
-  for (int i = 0; i < n; i++) h->store->bitmap_.Set((uint32_t)vids[i]);
+  // GammaEngine::Delete sets the DOC bit, then hands the doc's vids to the model (search/gamma_engine.cc:802-824)
+  for (int i = 0; i < n; i++)
+    h->store->bitmap_.Set((uint32_t)(h->store->VidMgr() ? h->store->VidMgr()->VID2DocID((int)vids[i]) : vids[i]));
   std::vector<int64_t> ids(vids, vids + n);
   return h->model->Delete(ids);
 }

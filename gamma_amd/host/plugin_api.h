@@ -202,14 +202,35 @@ class BitmapManager {
 
 // RawVector (vector/raw_vector.h:70-216), the one member a model reads besides VectorReader's: the engine's
 // delete bitmap (:171)
+// VIDMgr (vector/raw_vector_common.h:36-110): vid -> docid of tables whose documents carry several vectors
+class VIDMgr {
+ public:
+  explicit VIDMgr(bool multi_vids) : multi_vids_(multi_vids) {}
+  bool MultiVids() { return multi_vids_; }
+  int VID2DocID(int vid) {
+    if (!multi_vids_) return vid;
+    return (size_t)vid < vid2docid_.size() ? vid2docid_[vid] : -1;
+  }
+  void Add(int vid, int docid) {   // standalone stand-in for VIDMgr::Add(vid, docid)
+    if ((size_t)vid >= vid2docid_.size()) vid2docid_.resize(vid + 1, -1);
+    vid2docid_[vid] = docid;
+  }
+
+ private:
+  bool multi_vids_;
+  std::vector<int> vid2docid_;
+};
+
 class RawVector : public VectorReader {
  public:
   RawVector(VectorMetaInfo *meta_info, bitmap::BitmapManager *docids_bitmap)
-      : VectorReader(meta_info), docids_bitmap_(docids_bitmap) {}
+      : VectorReader(meta_info), docids_bitmap_(docids_bitmap), vid_mgr_(nullptr) {}
   bitmap::BitmapManager *Bitmap() { return docids_bitmap_; }
+  VIDMgr *VidMgr() const { return vid_mgr_; }   // raw_vector.h:169
 
  protected:
   bitmap::BitmapManager *docids_bitmap_;
+  VIDMgr *vid_mgr_;
 };
 
 // stand-in for tbb::concurrent_bounded_queue<int> (see header comment)

@@ -35,6 +35,7 @@ HOST_SYMBOLS = {
                                                 C.c_int, C.c_int, C.c_int, f32p]),
     "gh_host_concurrent_filtered_check": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, f32p, C.c_int,
                                                     C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "gh_host_set_vid2docid": (None, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "gh_host_table_add_field": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "gh_host_table_append": (None, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "gh_host_search_scalar": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p, i64p,
@@ -149,6 +150,11 @@ class PluginModel:
     def store(self, x):
         x = np.ascontiguousarray(x, np.float32)
         self.L.gh_host_store(self.h, x.shape[0], _f(x))
+
+    def set_vid2docid(self, first, docids):
+        """documents with several vectors: the engine's VIDMgr mapping for vids [first, first + len)"""
+        m = np.ascontiguousarray(docids, dtype=np.int32)
+        self.L.gh_host_set_vid2docid(self.h, first, m.size, m.ctypes.data_as(C.POINTER(C.c_int)))
 
     def indexing(self):
         return self.L.gh_host_indexing(self.h)

@@ -238,6 +238,15 @@ int gamma_hip_ivfpq_encode(gamma_hip_index* h, int64_t n, const float* vecs, int
 int gamma_hip_assign(gamma_hip_index* h, int d, int64_t n, const float* x, int k,
                      const float* centroids, int32_t* assign, float* dis);
 
+/* ---- multi-vector documents (VIDMgr, vector/raw_vector_common.h:36-110) -------------------------
+ * A table whose documents carry several vectors per field has vid != docid; every validity test of the path --
+ * the delete bitmap, the per-request range bitmaps, the device columns (GammaSearchCondition::IsValid,
+ * common/gamma_common_data.h:99-108) and the realtime lists' delete accounting (realtime_mem_data.cc:102,294) --
+ * is on the DOC id.  Append the docid of vids [count, count + n) in vid order; never called = single-vector
+ * documents (docid == vid).  Labels returned by the searches stay vector ids, as in the reference. */
+int gamma_hip_vid2docid_append(gamma_hip_index* h, int64_t n, const int32_t* docids);
+int64_t gamma_hip_vid2docid_count(gamma_hip_index* h);
+
 /* ---- IVFFLAT (index/impl/gamma_index_ivfflat.{h,cc}) ----------------------------------------
  * The reference's IVFFLAT lists carry the vectors themselves (code_size = 4 d, gamma_index_ivfflat.cc:155); here a
  * list carries vector ids (plus one dummy code byte so that the realtime-list code is shared) and the rows come

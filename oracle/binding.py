@@ -108,6 +108,8 @@ def lib():
                                         _f32p, _i64p, _f32p, _i64p]
         L.go_ivfflat_assign.restype = None
         L.go_ivfflat_assign.argtypes = [C.c_void_p, C.c_int64, _f32p, _i64p]
+        L.go_ivfpq_set_vid2docid.restype = None
+        L.go_ivfpq_set_vid2docid.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int64]
         L.go_ivfpq_has_vid.restype = C.c_int
         L.go_ivfpq_has_vid.argtypes = [C.c_void_p, C.c_int64]
         L.go_ivfpq_remove.restype = C.c_int
@@ -147,7 +149,7 @@ class SearchCtx(C.Structure):
     _fields_ = [("docids_bitmap", _u8p), ("docids_bitmap_bits", C.c_int64),
                 ("has_range", C.c_int32), ("n_range", C.c_int32),
                 ("range", C.POINTER(RangeFilter)), ("min_score", C.c_float),
-                ("max_score", C.c_float)]
+                ("max_score", C.c_float), ("vid2docid", C.POINTER(C.c_int32)), ("n_vid2docid", C.c_int64)]
 
 
 def make_range_filter(docids, n_total=None, b_not_in=False):
@@ -168,7 +170,7 @@ def make_range_filter(docids, n_total=None, b_not_in=False):
     return rf, bm
 
 
-def make_ctx(docids_bitmap=None, range_filters=None, min_score=None, max_score=None):
+def make_ctx(docids_bitmap=None, range_filters=None, min_score=None, max_score=None, vid2docid=None):
     """docids_bitmap: np.uint8 delete bitmap (bit set = deleted) or None.
     range_filters: None (no range_query_result) or list of (RangeFilter, keepalive)."""
     ctx = SearchCtx()
@@ -190,6 +192,11 @@ def make_ctx(docids_bitmap=None, range_filters=None, min_score=None, max_score=N
     # GammaSearchCondition defaults (common/gamma_common_data.h:50-51)
     ctx.min_score = np.finfo(np.float32).tiny if min_score is None else min_score
     ctx.max_score = np.finfo(np.float32).max if max_score is None else max_score
+    if vid2docid is not None:
+        vid2docid = np.ascontiguousarray(vid2docid, dtype=np.int32)
+        ctx.vid2docid = vid2docid.ctypes.data_as(C.POINTER(C.c_int32))
+        ctx.n_vid2docid = vid2docid.size
+        keep.append(vid2docid)
     ctx._keep = keep
     return ctx
 
@@ -226,6 +233,10 @@ class OracleIVFPQ:
         """bm: np.uint8 array kept alive by the caller's reference here (may be mutated later)."""
         self._bm = bm
         self.L.go_ivfpq_set_docids_bitmap(self.h, _up(bm), bm.size * 8)
+
+    def set_vid2docid(self, m):
+        self._v2d = np.ascontiguousarray(m, dtype=np.int32)
+        self.L.go_ivfpq_set_vid2docid(self.h, self._v2d.ctypes.data_as(C.POINTER(C.c_int32)), self._v2d.size)
 
     def set_raw(self, raw):
         self._raw = _f32(raw)

@@ -462,7 +462,7 @@ static inline int range_has(const go_range_filter* r, int doc) {
 
 static inline int ctx_is_valid(const go_search_ctx* c, int64_t vid) {
     if (!c) return 1;
-    int docid = (int)vid; /* VIDMgr::VID2DocID is the identity for single-vector docs */
+    int docid = (c->vid2docid && vid >= 0 && vid < c->n_vid2docid) ? c->vid2docid[vid] : (int)vid; /* VIDMgr::VID2DocID */
     if (c->has_range) {
         /* MultiRangeQueryResults::Has, :169-179: empty => false */
         if (c->n_range == 0) return 0;
@@ -512,6 +512,8 @@ struct go_ivfpq {
     int64_t indexed_vec_count;
     const uint8_t* docids_bitmap; /* borrowed; RTInvertBucketData::docids_bitmap_ */
     int64_t docids_bits;
+    const int32_t* vid2docid; /* borrowed; vid_mgr_->VID2DocID, NULL = identity */
+    int64_t n_vid2docid;
 };
 
 go_ivfpq* go_ivfpq_new(int d, int nlist, int M, int nbits, int metric, int bucket_init_size,
@@ -582,6 +584,14 @@ void go_ivfpq_set_docids_bitmap(go_ivfpq* ix, const uint8_t* bm, int64_t nbits) 
     ix->docids_bits = nbits;
 }
 
+void go_ivfpq_set_vid2docid(go_ivfpq* ix, const int32_t* map, int64_t n) {
+    ix->vid2docid = map;
+    ix->n_vid2docid = n;
+}
+static inline int64_t ix_docid(const go_ivfpq* ix, int64_t vid) {
+    return (ix->vid2docid && vid >= 0 && vid < ix->n_vid2docid) ? ix->vid2docid[vid] : vid;
+}
+
 void go_ivfpq_set_raw(go_ivfpq* ix, const float* raw, int64_t n) {
     ix->raw = raw;
     ix->nraw = n;
@@ -644,8 +654,8 @@ int go_ivfpq_add_keys(go_ivfpq* ix, int list_no, int n, const int64_t* keys, con
         ix->vid_pos[keys[i]] = ((int64_t)list_no << 32) | pos;
         pos++;
         /* :293-296: a key whose doc is already deleted counts as deleted at once */
-        if (ix->docids_bitmap && keys[i] >= 0 && keys[i] < ix->docids_bits &&
-            bm_test(ix->docids_bitmap, keys[i]))
+        if (ix->docids_bitmap && keys[i] >= 0 && ix_docid(ix, keys[i]) < ix->docids_bits &&
+            bm_test(ix->docids_bitmap, ix_docid(ix, keys[i])))
             b->deleted++;
     }
     b->size = pos; /* publish after the copies */
@@ -792,7 +802,7 @@ int go_ivfpq_compact_if_need(go_ivfpq* ix, const uint8_t* docids_bitmap) {
         for (int64_t i = 0; i < b->size; i++) {
             int64_t id = b->ids[i];
             if (!(id & GO_DEL_MASK) &&
-                !(docids_bitmap && bm_test(docids_bitmap, id & GO_RECOVER_MASK))) {
+                !(docids_bitmap && bm_test(docids_bitmap, ix_docid(ix, id & GO_RECOVER_MASK)))) {
                 ni[pos] = id;
                 memcpy(nc + (size_t)pos * ix->code_size, b->codes + (size_t)i * ix->code_size,
                        ix->code_size);

@@ -95,6 +95,9 @@ typedef struct {
     int32_t n_range;            /* number of RangeQueryResult (0 => Has() is false) */
     const go_range_filter* range;
     float min_score, max_score;
+    /* VIDMgr::VID2DocID (vector/raw_vector_common.h:90-95): NULL = single-vector documents, docid == vid */
+    const int32_t* vid2docid;
+    int64_t n_vid2docid;
 } go_search_ctx;
 
 /* ---- index objects --------------------------------------------------------------- */
@@ -109,6 +112,8 @@ void go_ivfpq_set_trained(go_ivfpq* ix, const float* coarse_centroids, const flo
 const float* go_ivfpq_table(go_ivfpq* ix);
 /* delete bitmap the list writer consults (AddKeys, CompactBucket); borrowed pointer */
 void go_ivfpq_set_docids_bitmap(go_ivfpq* ix, const uint8_t* bm, int64_t nbits);
+/* vid -> docid of multi-vector documents for the list writer's delete tests (realtime_mem_data.cc:102,294); borrowed */
+void go_ivfpq_set_vid2docid(go_ivfpq* ix, const int32_t* map, int64_t n);
 /* raw vector store for re-rank (VectorReader::Gets): pointer is borrowed */
 void go_ivfpq_set_raw(go_ivfpq* ix, const float* raw, int64_t n);
 /* Add path (gamma_index_ivfpq.cc:424-512): assign + residual + encode + AddKeys; vids are

@@ -1139,3 +1139,51 @@ def test_large_batch_search_with_fused_coarse_matches_oracle():
         assert D0.tobytes() == D1.tobytes() and np.array_equal(I0, I1)
     finally:
         g.close()
+
+
+def test_multi_vector_documents(case):
+    """Documents with several vectors (VIDMgr::VID2DocID, vector/raw_vector_common.h:90-95): the delete bitmap, the
+    request's range bitmaps and the device columns are tested on the DOC id of a scanned vector
+    (GammaSearchCondition::IsValid, common/gamma_common_data.h:99-108); labels stay vector ids."""
+    N, q = case["N"], case["q"]
+    rng = np.random.default_rng(77)
+    per_doc = rng.integers(1, 4, size=N)                       # 1..3 vectors per document
+    v2d = np.repeat(np.arange(N), per_doc)[:N].astype(np.int32)
+    ndocs = int(v2d[-1]) + 1
+    g = fixtures.load_hip(case)
+    g.vid2docid_append(v2d[:N // 3])
+    g.vid2docid_append(v2d[N // 3:])                           # grows
+    assert g.vid2docid_count() == N
+    price = rng.integers(0, 1000, size=ndocs).astype(np.int64)   # one value per DOC
+    g.field_append(1, price)
+    dead_docs = rng.choice(ndocs, ndocs // 6, replace=False)
+    bm = np.zeros((ndocs >> 3) + 1, dtype=np.uint8)
+    np.bitwise_or.at(bm, dead_docs >> 3, (1 << (dead_docs & 7)).astype(np.uint8))
+    g.bitmap_upload(bm, ndocs)
+    docs = rng.choice(ndocs, ndocs // 2, replace=False)
+    try:
+        o = case["oracle"]
+        for has_rank in (True, False):
+            ctx = B.make_ctx(docids_bitmap=bm, range_filters=[B.make_range_filter(docs)], vid2docid=v2d, **WIDE)
+            D, I, st = o.search(q, 10, 8, recall_num=100, has_rank=has_rank, metric=B.METRIC_L2, ctx=ctx, coarse_mode=0,
+                                want_stages=True)
+            args = api.SearchArgs(metric=api.METRIC_L2, nprobe=8, recall_num=100, has_rank=has_rank, coarse_mode=0,
+                                  range_filters=[api.make_range_filter(docs)], **WIDE)
+            Dg, Ig = g.ivfpq_search(q, 10, args)
+            compare_topk(D, I, Dg, Ig)
+            assert not np.isin(v2d[Ig[Ig >= 0]], dead_docs).any()
+        # a device column clause on the doc's value
+        mask = (price[v2d] >= 200) & (price[v2d] < 700)
+        ctx = B.make_ctx(docids_bitmap=bm, range_filters=[B.make_range_filter(np.unique(v2d[mask]))], vid2docid=v2d, **WIDE)
+        D, I = o.search(q, 10, 8, recall_num=100, has_rank=True, metric=B.METRIC_L2, ctx=ctx, coarse_mode=0)
+        Dg, Ig = g.ivfpq_search(q, 10, api.SearchArgs(metric=api.METRIC_L2, nprobe=8, recall_num=100, coarse_mode=0,
+                                                      field_filters=[(1, 200, 700, True, False)], **WIDE))
+        compare_topk(D, I, Dg, Ig)
+        # flat search
+        ctx = B.make_ctx(docids_bitmap=bm, range_filters=[B.make_range_filter(docs)], vid2docid=v2d, **WIDE)
+        Df, If = B.flat_search(case["base"], q[:8], 10, B.METRIC_L2, ctx)
+        Dg, Ig = g.flat_search(q[:8], 10, api.SearchArgs(metric=api.METRIC_L2, range_filters=[api.make_range_filter(docs)],
+                                                         **WIDE))
+        compare_topk(Df, If, Dg, Ig)
+    finally:
+        g.close()

@@ -464,3 +464,57 @@ def test_ivfflat_plugin_matches_oracle(case, tmp_path):
     hit = np.mean([len(set(a) & set(b)) / 10.0 for a, b in zip(If, Ig)])
     assert hit > 0.9, hit
     m3.close()
+
+
+@pytest.mark.parametrize("model", ["HIPIVFPQ", "HIPFLAT", "HIPIVFFLAT"])
+def test_plugin_multi_vector_documents(case, model):
+    """A table whose documents carry several vectors: the plugins read the engine's VIDMgr (RawVector::VidMgr) and
+    the device tests the delete bitmap and the request's range bitmaps on the DOC id of each scanned vector;
+    Delete(vids) marks the DOCUMENT (search/gamma_engine.cc:802-824)."""
+    from gamma_amd import plugin
+    base, q, d, nlist = case["base"], case["q"], case["d"], case["nlist"]
+    N = len(base)
+    rng = np.random.default_rng(9)
+    v2d = np.repeat(np.arange(N), rng.integers(1, 4, size=N))[:N].astype(np.int32)
+    ndocs = int(v2d[-1]) + 1
+    params = {"HIPIVFPQ": '{"ncentroids": %d, "nsubvector": %d, "nprobe": 8, "metric_type": "L2"}' % (nlist, case["M"]),
+              "HIPFLAT": '{"metric_type": "L2"}',
+              "HIPIVFFLAT": '{"ncentroids": %d, "nprobe": 8, "metric_type": "L2"}' % nlist}[model]
+    m = plugin.PluginModel(model, d, params, indexing_size=5000)
+    m.set_vid2docid(0, v2d)
+    m.store(base)
+    if model != "HIPFLAT":
+        assert m.set_trained(case["cc"], case["pq"]) == 0
+    o = B.OracleIVFPQ(d, nlist, case["M"], 8, B.METRIC_L2)
+    o.set_trained(case["cc"], case["pq"], None)
+    B.lib().go_set_assign_mode(1)
+    try:
+        for i0 in range(0, N, 5000):
+            assert m.add(base[i0:i0 + 5000])
+            assert o.add(base[i0:i0 + 5000])
+        o.set_raw(base)
+        # delete whole documents: the engine sets the doc bit and hands the doc's vids to the model
+        dead_docs = rng.choice(ndocs, ndocs // 8, replace=False)
+        dead_vids = np.nonzero(np.isin(v2d, dead_docs))[0]
+        assert m.delete(dead_vids) == 0
+        bm = np.zeros((ndocs >> 3) + 1, np.uint8)
+        np.bitwise_or.at(bm, dead_docs >> 3, (1 << (dead_docs & 7)).astype(np.uint8))
+        docs = rng.choice(ndocs, ndocs // 2, replace=False)
+        for cl in ([], [(docs, False)]):
+            rfs = [B.make_range_filter(dd, b_not_in=ni) for dd, ni in cl] if cl else None
+            ctx = B.make_ctx(docids_bitmap=bm, range_filters=rfs, vid2docid=v2d)
+            kw = dict(range_filters=cl) if cl else {}
+            if model == "HIPIVFPQ":
+                B.lib().go_set_assign_mode(0)
+                D, I = o.search(q, 10, 8, recall_num=100, has_rank=True, metric=B.METRIC_L2, ctx=ctx, coarse_mode=-1)
+                B.lib().go_set_assign_mode(1)
+            elif model == "HIPIVFFLAT":
+                D, I = B.ivfflat_search(o, q, 10, 8, B.METRIC_L2, ctx)
+            else:
+                D, I = B.flat_search(base, q, 10, B.METRIC_L2, ctx)
+            Dg, Ig = m.search(q, 10, "", **kw)
+            compare_topk(D, I, Dg, Ig)
+            assert not np.isin(v2d[Ig[Ig >= 0]], dead_docs).any()
+    finally:
+        B.lib().go_set_assign_mode(0)
+        m.close()
