@@ -341,7 +341,8 @@ class GammaHip:
         self._ck(self.L.gamma_hip_set_coarse_fused(self.h, 1 if on else 0, list_cap), "set_coarse_fused")
 
     def set_small_path(self, on=True):
-        self._ck(self.L.gamma_hip_set_small_path(self.h, 1 if on else 0), "set_small_path")
+        """True / False, or an int >= 2: on, with the two-level selection of long candidate rows forced (that many slices)."""
+        self._ck(self.L.gamma_hip_set_small_path(self.h, int(on)), "set_small_path")
 
     def set_list_major(self, on=True):
         self._ck(self.L.gamma_hip_set_list_major(self.h, 1 if on else 0), "set_list_major")

@@ -171,6 +171,7 @@ struct gamma_hip_index {
     bool list_major = false;   // gamma_hip_set_list_major
     bool coarse_fused = true;  // gamma_hip_set_coarse_fused
     bool small_path = true;    // gamma_hip_set_small_path
+    int small_presel = 0;      // 0: pre-selection by estimate, > 0: always, that many slices (tests)
     // multi-vector documents (VIDMgr::VID2DocID, vector/raw_vector_common.h:90-95): docid of every vid, host + device;
     // empty = single-vector documents, docid == vid.  Every delete-bitmap / filter test goes through it.
     std::vector<int32_t> h_v2d;
@@ -1059,14 +1060,12 @@ int ivfpq_stage_b(H* h, const gamma_hip_search_params* p, int nq, const float* d
 // chain costs ~4 us of launch + drain at this size, whatever it computes.
 bool ivfpq_small_ok(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int nq, int R) {
     static const bool off = getenv("GAMMA_HIP_NO_SMALL_PATH") != nullptr;
-    const int d = h->d;
     static const int max_nq = getenv("GAMMA_HIP_SMALL_MAX") ? atoi(getenv("GAMMA_HIP_SMALL_MAX")) : 512;
     // exact coarse distances (faiss below 20 queries) come from the fused first kernel, which covers 16 queries; the
     // GEMM form (20 queries and more) from the regular matrix kernel
     return !off && h->small_path && nq >= 1 && nq <= max_nq && (p->coarse_mode == 1 || nq <= 16) &&
-           p->metric == GAMMA_HIP_METRIC_L2 &&
            p->nprobe <= 64 && R <= 1024 && !h->exact_ties && !h->profile && !fc.d_qf && !h->d_list_mask &&
-           (d == 16 || d == 32 || d == 64 || d == 96 || d == 128) && h->nlist <= 16384 &&
+           h->nlist <= 16384 &&
            (int64_t)p->nprobe * std::max(1, h->max_list_len) <= (1 << 22) && (!p->has_rank || (h->d_raw && h->raw_d == h->d));
 }
 
@@ -1091,27 +1090,64 @@ int ivfpq_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int n
     // (folding the selection into the first launch -- last workgroup done selects -- was tried: the device-scope
     // release / acquire it needs costs more than the launch it saves, 24 us against 4 + 8: the XCDs' L2s are
     // written back and invalidated either way)
+    // long lists: the scan walks a work list of (query, probe, chunk of the list) units written by the selection kernel,
+    // pieces of even size for a grid that fills the chip, instead of one workgroup per pair that runs for as long as its
+    // list is (small_presel: tests force the path on short lists)
+    static const int chunk_env = getenv("GAMMA_HIP_SMALL_CHUNK") ? atoi(getenv("GAMMA_HIP_SMALL_CHUNK")) : 512;
+    int chunk_len = 0, max_units = 0;
+    uint32_t* d_units = nullptr;
+    int* d_nunits = nullptr;
+    if (h->ntotal / std::max(1, nlist) > 1024 || h->max_list_len > 8192 || h->small_presel > 0) {
+        chunk_len = h->small_presel > 0 ? 512 : std::max(512, (chunk_env + 511) & ~511);
+        const int64_t mu = (int64_t)nq * P * (1 + (int64_t)h->max_list_len / chunk_len);
+        max_units = (int)std::min<int64_t>(mu, INT32_MAX);
+        GH_CHECK(h, h->w_lm_units.ensure((size_t)mu * sizeof(uint32_t)));
+        GH_CHECK(h, h->w_lm_cnt.ensure(64));
+        d_units = h->w_lm_units.as<uint32_t>();
+        d_nunits = h->w_lm_cnt.as<int>();
+    }
     if (p->coarse_mode == 1) {
+        if (d_nunits) GH_CHECK(h, hipMemsetAsync(d_nunits, 0, sizeof(int), s));
         gh::launch_l2_gemmform(s, d_x, nq, d, h->d_cc, nlist, nullptr, h->d_cc_norms, h->w_mat.as<float>(), nlist, true);
         gh::launch_pq_ip_table(s, d_x, nq, d, M, h->d_pqc, h->w_st2.as<float>());
     } else if (!gh::launch_small_coarse_ip(s, d_x, nq, d, h->d_cc, nlist, h->w_mat.as<float>(), M, h->d_pqc,
-                                           h->w_st2.as<float>())) {
+                                           h->w_st2.as<float>(), d_nunits)) {
         return fail(h, GAMMA_HIP_EINVAL, "small path: shape not covered");   // ivfpq_small_ok gates on the same shapes
     }
+    const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
+    if (!l2) GH_CHECK(h, h->w_pair_ip.ensure((size_t)nq * P * sizeof(float)));
     gh::launch_small_coarse_select(s, h->w_mat.as<float>(), nlist, nq, P, h->w_coarse_dis.as<float>(), h->w_probe.as<int>(),
                                    h->d_list_len, h->d_list_mask, h->d_list_off, h->w_pair_off.as<int>(),
-                                   h->w_qtotal.as<int>(), h->w_pair_base.as<int64_t>());
+                                   h->w_qtotal.as<int>(), h->w_pair_base.as<int64_t>(), d_x, h->d_cc, d,
+                                   l2 ? nullptr : h->w_pair_ip.as<float>(), d_units, d_nunits, chunk_len);
     h->scan_pairs += (int64_t)nq * P;
     const int need_ids = (fc.any_clause || (h->d_bitmap && h->bitmap_any) || h->n_moved > 0) ? 1 : 0;
-    gh::launch_ivfpq_scan_pair(s, true, d_x, nq, d, M, P, h->w_probe.as<int>(), h->w_coarse_dis.as<float>(), h->d_cc,
+    gh::launch_ivfpq_scan_pair(s, l2, d_x, nq, d, M, P, h->w_probe.as<int>(),
+                               l2 ? h->w_coarse_dis.as<float>() : h->w_pair_ip.as<float>(), h->d_cc,
                                h->w_st2.as<float>(), h->d_T2, h->d_list_off, h->d_list_len, h->d_list_mask, nlist,
                                h->d_codes, h->d_ids, h->w_pair_off.as<int>(), q_stride, h->w_dist.as<float>(), fc.d_tab,
-                               fc.d_qf, need_ids, nullptr, 1, 0, P, 0, nullptr, nullptr);
-    const float neutral = 3.402823466e+38f;
-    gh::launch_small_tail(s, true, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), nq, R, P, h->w_probe.as<int>(),
+                               fc.d_qf, need_ids, nullptr, 1, 0, P, 0, nullptr, nullptr, reinterpret_cast<const int*>(d_units), d_nunits,
+                               chunk_len, max_units);
+    const float neutral = l2 ? 3.402823466e+38f : -3.402823466e+38f;
+    // long candidate rows (expected nprobe x 1.5 mean list lengths beyond what one workgroup keeps in registers): a first
+    // selection over slices of the row by several workgroups per query, then the tail among their survivors
+    int smax = 0;
+    {
+        const int64_t slice = 16384;   // select.hip SM_SLICE
+        const int64_t est = (int64_t)P * (h->ntotal / std::max(1, nlist)) * 3 / 2;
+        const int64_t bound = (int64_t)P * std::max(1, h->max_list_len);
+        if (h->small_presel > 0) smax = h->small_presel;
+        else if (est > slice) smax = (int)std::min<int64_t>(std::min<int64_t>(64, (bound + slice - 1) / slice), std::max(2, 4096 / nq));
+        if (smax > 0) {
+            GH_CHECK(h, h->w_selv.ensure((size_t)nq * smax * R * sizeof(float)));
+            GH_CHECK(h, h->w_selp.ensure((size_t)nq * smax * R * sizeof(int)));
+        }
+    }
+    gh::launch_small_tail(s, l2, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), nq, R, P, h->w_probe.as<int>(),
                           h->w_pair_off.as<int>(), h->d_list_off, h->d_ids, h->w_cand_dis.as<float>(),
                           h->w_cand_pos.as<int>(), h->w_cand_ids.as<int64_t>(), p->has_rank ? 1 : 0, d_x, d, h->d_raw,
-                          h->nraw, k, p->min_score, p->max_score, neutral, d_distances, d_labels);
+                          h->nraw, k, p->min_score, p->max_score, neutral, d_distances, d_labels, smax,
+                          smax ? h->w_selv.as<float>() : nullptr, smax ? h->w_selp.as<int>() : nullptr);
     h->tie = H::TieCtx();
     h->tie.G = 1;
     h->tie.q_stride = q_stride;
@@ -1561,6 +1597,7 @@ int gamma_hip_set_small_path(gamma_hip_index* h, int on) {
     if (!h) return GAMMA_HIP_EINVAL;
     SearchLock lk(h);
     h->small_path = on != 0;
+    h->small_presel = on >= 2 ? on : 0;
     return GAMMA_HIP_OK;
 }
 

@@ -143,7 +143,8 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
                             int need_ids,
                             const int* qperm, int G, int pg_lo, int pg_cnt, int sparse, const ScanBound* bound,
                             const float* pqc_fused = nullptr,   // != nullptr: query table computed in the kernel
-                            const int* rq_list = nullptr, const int* rq_count = nullptr);   // repair launch (kernels.hip)
+                            const int* rq_list = nullptr, const int* rq_count = nullptr,   // repair launch (kernels.hip)
+                            int chunk_len = 0, int max_units = 0);   // > 0: rq_list is a work list of list chunks (kernels.hip)
 int query_order_bins();
 // bins: query_order_bins() ints of scratch (large batches sort over the whole grid); may be null
 void launch_query_order(hipStream_t s, const int* probe_list, int nq, int P, const int* list_rank,
@@ -163,19 +164,22 @@ CoarseFusedPlan coarse_fused_plan(int nq, int nlist, int P, int cap);
 void launch_coarse_fused(hipStream_t s, const CoarseFusedPlan& pl, void* ws, const float* x, int nq, int d,
                          const float* y, int nlist, const float* yn, int P, float* out_dis, int* out_idx);
 // small batches: exact coarse distances [nq][nlist] + inner-product tables [nq][M][256] in one launch; false = shape
-// not covered (d not in {16, 32, 64, 96, 128} or nq > 16), nothing launched
+// not covered (nq > 16), nothing launched
 bool launch_small_coarse_ip(hipStream_t s, const float* x, int nq, int d, const float* cc, int nlist, float* mat, int M,
-                            const float* pqc, float* st2);
+                            const float* pqc, float* st2, int* zero_me = nullptr);
 // small batches (select.hip): coarse top-nprobe + slab offsets in one kernel; ADC top-recall_num + ids + exact
 // re-rank + top-k + output in one kernel.  P <= 64, R <= 1024.
+// pair_ip != nullptr (inner-product metric): also dis0 = <x_q, centroid> of every probe in fvec_inner_product order
 void launch_small_coarse_select(hipStream_t s, const float* mat, int nlist, int nq, int P, float* out_vals, int* out_pos,
                                 const int* list_len, const uint8_t* list_mask, const int64_t* list_off, int* pair_off,
-                                int* q_total, int64_t* pair_base);
+                                int* q_total, int64_t* pair_base, const float* x = nullptr, const float* cc = nullptr,
+                                int d = 0, float* pair_ip = nullptr, uint32_t* units = nullptr, int* unit_count = nullptr,
+                                int chunk_len = 0);
 void launch_small_tail(hipStream_t s, bool l2, const float* slab, int64_t q_stride, const int* q_total, int nq, int R, int P,
                        const int* probe_list, const int* pair_off, const int64_t* list_off, const int64_t* ids,
                        float* cand_dis, int* cand_pos, int64_t* cand_ids, int has_rank, const float* x, int d,
                        const float* raw, int64_t nraw, int k, float min_score, float max_score, float neutral,
-                       float* distances, int64_t* labels);
+                       float* distances, int64_t* labels, int smax = 0, float* pre_val = nullptr, int* pre_pos = nullptr);
 // IVFFLAT: exact distances of every entry of the probed lists (rows from the raw store) into the query's slab
 void launch_ivfflat_scan(hipStream_t s, bool l2, const float* x, int nq, int d, int P, const int* pair_off,
                          const int64_t* pair_base, const int64_t* ids, const float* raw, int64_t nraw, int64_t q_stride,

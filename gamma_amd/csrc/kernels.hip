@@ -700,10 +700,11 @@ __global__ __launch_bounds__(256) void k_pq_ip_table(const float* __restrict__ x
 }
 // Small batches (nq <= 16): the exact coarse distances (k_pairwise_rowreg, one query range) and the queries'
 // inner-product tables are independent of each other and each is a dozen workgroups: one launch, roles by block.
-template <int D>
-__global__ __launch_bounds__(256) void k_small_coarse_ip(const float* __restrict__ x, int nq, const float* __restrict__ cc,
+__global__ __launch_bounds__(256) void k_small_coarse_ip(const float* __restrict__ x, int nq, int D, const float* __restrict__ cc,
                                                          int nlist, float* __restrict__ mat, int row_blocks, int M,
-                                                         const float* __restrict__ pqc, float* __restrict__ st2) {
+                                                         const float* __restrict__ pqc, float* __restrict__ st2,
+                                                         int* __restrict__ zero_me) {
+    if (zero_me && blockIdx.x == 0 && threadIdx.x == 0) *zero_me = 0;   // the next launch's work-list counter
     if ((int)blockIdx.x < row_blocks) {
         // eight threads per centroid = the eight AVX lane accumulators of fvec_L2sqr (rerank_dev.h): 32 centroids per
         // workgroup, coalesced 32-byte pieces, 128 workgroups at nlist 4096 instead of 16 threads-per-row ones
@@ -719,20 +720,10 @@ __global__ __launch_bounds__(256) void k_small_coarse_ip(const float* __restrict
     }
 }
 bool launch_small_coarse_ip(hipStream_t s, const float* x, int nq, int d, const float* cc, int nlist, float* mat, int M,
-                            const float* pqc, float* st2) {
-    if (nq <= 0 || nq > 2 * IPT_QB) return false;
+                            const float* pqc, float* st2, int* zero_me) {
+    if (nq <= 0 || nq > 2 * IPT_QB || d % M) return false;
     const int rb = (nlist + 31) / 32;
-#define GH_SC(DD)                                                                                                 \
-    hipLaunchKernelGGL((k_small_coarse_ip<DD>), dim3(rb + M), dim3(256), 0, s, x, nq, cc, nlist, mat, rb, M, pqc, st2)
-    switch (d) {
-        case 128: GH_SC(128); break;
-        case 96: GH_SC(96); break;
-        case 64: GH_SC(64); break;
-        case 32: GH_SC(32); break;
-        case 16: GH_SC(16); break;
-        default: return false;
-    }
-#undef GH_SC
+    hipLaunchKernelGGL(k_small_coarse_ip, dim3(rb + M), dim3(256), 0, s, x, nq, d, cc, nlist, mat, rb, M, pqc, st2, zero_me);
     return true;
 }
 void launch_pq_ip_table(hipStream_t s, const float* x, int nq, int d, int M, const float* pqc,
@@ -1080,7 +1071,7 @@ constexpr int SCAN_BATCH = 64;                   // queries per XCD by which pro
 // computed here from the PQ codebook (128 KB, L2 resident; `st2` then points at it) instead of being
 // written to HBM by k_pq_ip_table and read back -- with W shards that table is W x 16 KB per query of
 // traffic that does not shrink with the shard, and each of its entries would be read exactly once.
-template <bool L2, int MT, bool FILT, bool IPF = false>
+template <bool L2, int MT, bool FILT, bool IPF = false, bool UNITS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_ivfpq_scan_pair(
         const float* __restrict__ x, int nq, int d, int M, int P, int G, const int* __restrict__ probe_list,
         const float* __restrict__ coarse_dis, const float* __restrict__ cc,
@@ -1090,7 +1081,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
         const int64_t* __restrict__ ids, const int* __restrict__ pair_off, int64_t q_stride,
         float* __restrict__ out, const FilterDesc* __restrict__ ftab, const int* __restrict__ qfil, int need_ids,
         float sentinel, const int* __restrict__ qperm, int pg_lo, int pg_cnt, int sparse, ScanBound sb,
-        const int* __restrict__ rq_list, const int* __restrict__ rq_count) {
+        const int* __restrict__ rq_list, const int* __restrict__ rq_count, int chunk_len) {
+    // UNITS (small batches over long lists, G = 1, no bound; a variant of its own so that the bulk kernel carries
+    // none of its state): rq_list is a work list of
+    // (query << 20 | probe << 13 | chunk) units written by k_small_coarse_select, one per chunk_len codes of a
+    // (query, probe) pair, walked by a fixed grid -- one query's 64 long lists are then a few hundred pieces of
+    // even size instead of 64 workgroups that run for as long as the longest list takes.
     // This launch covers probe groups [pg_lo, pg_lo + pg_cnt) of every query.
     // FILT (pg_lo = 0, pg_cnt >= 2): threshold pre-filter.  The workgroup of a query's FIRST probe
     // group (its nearest lists) ends by bounding the query's recall_num-th best distance from above
@@ -1160,6 +1156,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
     int& s_nstage = *reinterpret_cast<int*>(s_stage + SCAN_STAGE);
     uint32_t& s_tau = *(reinterpret_cast<uint32_t*>(s_stage + SCAN_STAGE) + 1);
     uint32_t* s_red = reinterpret_cast<uint32_t*>(s_stage + SCAN_STAGE) + 2;                  // [12]
+    int cbase = 0;     // unit mode: first code of the unit within its list
+    int lut_q = -1;    // unit mode, inner product: the query whose table is in LDS
+    int lut_pair = -1; // unit mode, L2: the (query, probe) pair whose table is in LDS
     auto body = [&](const int q, const int pg) {
     // validity predicates of THIS query: entry qfil[q] of the call's filter table (one entry unless the
     // call is a combined batch of requests with their own filters); only read when need_ids
@@ -1228,11 +1227,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
         const float* xq = x + (int64_t)q * d;
 #pragma unroll
         for (int i = 0; i < MT; i++) s2r[i] = fvec_ny_row<false>(xq + i * dsub, st2 + ((int64_t)i * 256 + tid) * dsub, dsub);
-    } else if (MT > 0) {
+    } else if (MT > 0 && (!UNITS || (L2 ? q * P + pg != lut_pair : q != lut_q))) {
 #pragma unroll
         for (int i = 0; i < MT; i++) s2r[i] = st2q[tid + 256 * i];
     }
-    if (!L2) {   // inner product: the LUT is the query table itself, list independent
+    if (!L2 && (!UNITS || q != lut_q)) {   // inner product: the LUT is the query table itself, list independent
+        if (UNITS) lut_q = q;
         if (MT > 0) {
             lut_store_begin(lut_m0);
             lut_store_rows<MT>([&](int i) { return s2r[i]; }, std::make_integer_sequence<int, (MT > 0 ? MT : 1)>{});
@@ -1276,9 +1276,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
         const int l = probe_list[pair];
         if (l < 0 || l >= nlist) continue;            // uniform
         if (list_mask && !list_mask[l]) continue;
-        const int len = list_len[l];
-        if (len == 0) continue;
-        const int64_t off = list_off[l];
+        int len = list_len[l];
+        int64_t off = list_off[l];
+        if (UNITS) {
+            len = min(len - cbase, chunk_len);
+            off += cbase;
+        }
+        if (len <= 0) continue;
         const uint8_t* lc = codes + off * M;
         // the first 256 codes are requested BEFORE the T2 row: both latencies overlap, and lists of
         // up to 256 codes (most of them) never wait for their codes after the LUT is ready
@@ -1298,7 +1302,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
                 else asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(cfirst[u]) : "v"(a) : "memory");
             }
         }
-        if (L2) {
+        if (L2 && (!UNITS || pair != lut_pair)) {   // (uniform)
+            if (UNITS) lut_pair = pair;
             __syncthreads();   // the previous list's gathers are finished
             const float* t2 = T2 + (int64_t)l * msz;
             if (MT > 0) {
@@ -1318,7 +1323,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
         // dependent fmas per AVX lane has no place inside this loop)
         const float dis0 = coarse_dis[pair];
         const int64_t* lid = ids + off;
-        const int pbase = pair_off[(int64_t)q * (P + 1) + p];
+        const int pbase = pair_off[(int64_t)q * (P + 1) + p] + (UNITS ? cbase : 0);
         float* o = out + (int64_t)q * q_stride + pbase;
         // store + what the pre-filter tracks about a scored code
         // Distances are stored where something reads them: the first group's (its producer's histogram, the
@@ -1553,6 +1558,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
     };   // body
     if (!repair) {
         body(q, pg);
+    } else if (UNITS) {
+        // a workgroup takes a contiguous run of units: consecutive chunks of one list share its LUT
+        const int nu = *rq_count, per = (nu + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int w0 = (int)blockIdx.x * per, w1 = min(nu, w0 + per);
+        for (int w = w0; w < w1; w++) {
+            const uint32_t u = (uint32_t)rq_list[w];
+            cbase = (int)(u & 8191u) * chunk_len;
+            body((int)(u >> 20), (int)((u >> 13) & 127u));
+            __syncthreads();   // the LUT of this unit has been consumed
+        }
     } else {
         const int nrq = *rq_count;
         for (int w = blockIdx.x; w / pg_cnt < nrq; w += gridDim.x) {
@@ -1579,8 +1594,9 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
                             const uint8_t* codes, const int64_t* ids, const int* pair_off,
                             int64_t q_stride, float* out, const FilterDesc* ftab, const int* qfil, int need_ids,
                             const int* qperm, int G, int pg_lo, int pg_cnt, int sparse, const ScanBound* bound,
-                            const float* pqc_fused, const int* rq_list, const int* rq_count) {
+                            const float* pqc_fused, const int* rq_list, const int* rq_count, int chunk_len, int max_units) {
     if (nq <= 0 || pg_cnt <= 0) return;
+    if (chunk_len > 0 && (bound || pqc_fused || !rq_list || G != 1 || pg_lo != 0 || pg_cnt != P || max_units < 1)) abort();
     if (pqc_fused) {   // the table is computed inside the kernel (IPF): one workgroup per query, M 16 / 32
         if (!bound || pg_cnt != 1 || (M != 16 && M != 32)) abort();
         st2 = pqc_fused;
@@ -1598,13 +1614,18 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
         if (bound || pqc_fused) abort();
         grid.x = (unsigned)std::min<int64_t>((int64_t)nq * pg_cnt, 2048);
     }
+    if (chunk_len > 0) {   // as many workgroups as are resident at once (LDS: the LUT), no more than there can be units
+        const int per_cu = std::max(1, std::min(8, (int)(160 * 1024 / (lds + 1024))));
+        grid.x = (unsigned)std::min<int64_t>(max_units, 256 * per_cu);
+    }
 #define GH_SCAN(LL, MT, FF)                                                                       \
     GH_SCAN4(LL, MT, FF, false)
-#define GH_SCAN4(LL, MT, FF, II)                                                                       \
-    hipLaunchKernelGGL((k_ivfpq_scan_pair<LL, MT, FF, II>), grid, dim3(256), lds, s, x, nq, d, M, P, G,     \
+#define GH_SCAN4(LL, MT, FF, II) GH_SCAN5(LL, MT, FF, II, false)
+#define GH_SCAN5(LL, MT, FF, II, UU)                                                                       \
+    hipLaunchKernelGGL((k_ivfpq_scan_pair<LL, MT, FF, II, UU>), grid, dim3(256), lds, s, x, nq, d, M, P, G,     \
                        probe_list, coarse_dis, cc, st2, T2, list_off, list_len, list_mask, nlist, codes, \
                        ids, pair_off, q_stride, out, ftab, qfil, need_ids, LL ? INFINITY : -INFINITY, qperm,   \
-                       pg_lo, pg_cnt, sparse, sb, rq_list, rq_count)
+                       pg_lo, pg_cnt, sparse, sb, rq_list, rq_count, chunk_len)
 #define GH_SCAN_M(LL, FF)                       \
     do {                                        \
         if (M == 16) GH_SCAN(LL, 16, FF);       \
@@ -1615,7 +1636,19 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
         else if (M == 48) GH_SCAN(LL, 48, FF);  \
         else GH_SCAN(LL, 0, FF);                \
     } while (0)
-    if (pqc_fused) {
+    if (chunk_len > 0) {
+#define GH_SCAN_U(LL)                                           \
+    do {                                                        \
+        if (M == 16) GH_SCAN5(LL, 16, false, false, true);      \
+        else if (M == 32) GH_SCAN5(LL, 32, false, false, true); \
+        else if (M == 64) GH_SCAN5(LL, 64, false, false, true); \
+        else if (M == 8) GH_SCAN5(LL, 8, false, false, true);   \
+        else GH_SCAN5(LL, 0, false, false, true);               \
+    } while (0)
+        if (l2) GH_SCAN_U(true);
+        else GH_SCAN_U(false);
+#undef GH_SCAN_U
+    } else if (pqc_fused) {
         if (l2 && M == 16) GH_SCAN4(true, 16, true, true);
         else if (l2) GH_SCAN4(true, 32, true, true);
         else if (M == 16) GH_SCAN4(false, 16, true, true);
@@ -1630,6 +1663,7 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
 #undef GH_SCAN_M
 #undef GH_SCAN
 #undef GH_SCAN4
+#undef GH_SCAN5
 }
 
 // ------------------------------------------------------------------------------------

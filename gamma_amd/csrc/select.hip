@@ -1442,6 +1442,8 @@ void launch_select_final(hipStream_t s, bool smallest, const unsigned long long*
 namespace gh {
 namespace {
 constexpr int SM_NT = 1024, SM_NW = SM_NT / 64, SM_BINS = 2048;
+constexpr uint32_t SM_KEYSENT = 0xff800000u;   // key of the filtered-entry marker: +inf (smallest first) / -inf (largest first)
+constexpr int SM_SLICE = 16 * SM_NT;          // a row slice whose keys one workgroup keeps in registers
 
 // exclusive scan of one int per thread over the 1024-thread block; s_w: SM_NW ints.  Two barriers.
 __device__ __forceinline__ int block_excl_scan_sm(int v, int* s_w, int& total) {
@@ -1621,16 +1623,14 @@ __device__ __forceinline__ int block_select_sorted(const float* __restrict__ v, 
         for (int u = 0; u < NREG; u++) {
             const int i = tid + SM_NT * u;
             kreg[u] = i < n ? sel_key<SMALLEST>(v[i]) : 0xffffffffu;
-            if (i < n) {
-                kmin = kreg[u] < kmin ? kreg[u] : kmin;
-                kmax = kreg[u] > kmax ? kreg[u] : kmax;
-            }
+            if (i < n) kmin = kreg[u] < kmin ? kreg[u] : kmin;
+            if (kreg[u] < SM_KEYSENT) kmax = kreg[u] > kmax ? kreg[u] : kmax;
         }
-    } else {
+    } else {   // (batching these loads by hand, NREG in flight per thread, measured slower than the plain loops)
         for (int i = tid; i < n; i += SM_NT) {
             const uint32_t key = sel_key<SMALLEST>(v[i]);
             kmin = key < kmin ? key : kmin;
-            kmax = key > kmax ? key : kmax;
+            if (key < SM_KEYSENT) kmax = key > kmax ? key : kmax;
         }
     }
     kmin = __reduce_min_sync(~0ull, kmin);   // DPP row operations, not LDS shuffles
@@ -1648,15 +1648,22 @@ __device__ __forceinline__ int block_select_sorted(const float* __restrict__ v, 
         kmin = a < kmin ? a : kmin;
         kmax = b > kmax ? b : kmax;
     }
+    // the range is that of the VALID keys: the marker of filtered entries (+-inf, deleted or filtered documents) is
+    // far from any distance and would leave the histogram a handful of useful bins; it lands in the last bin
+    if (kmax < kmin) kmax = kmin;
     const uint32_t range = kmax - kmin;
     const int nbits = range == 0 ? 0 : 32 - __clz((int)range);
     const int shift = nbits > 11 ? nbits - 11 : 0;
+    auto bin_of = [&](uint32_t key) -> uint32_t {
+        const uint32_t b = (key - kmin) >> shift;
+        return b < (uint32_t)(SM_BINS - 1) ? b : (uint32_t)(SM_BINS - 1);
+    };
     if (inreg) {
 #pragma unroll
         for (int u = 0; u < NREG; u++)
-            if (tid + SM_NT * u < n) atomicAdd(&s_hist[(kreg[u] - kmin) >> shift], 1);
+            if (tid + SM_NT * u < n) atomicAdd(&s_hist[bin_of(kreg[u])], 1);
     } else {
-        for (int i = tid; i < n; i += SM_NT) atomicAdd(&s_hist[(sel_key<SMALLEST>(v[i]) - kmin) >> shift], 1);
+        for (int i = tid; i < n; i += SM_NT) atomicAdd(&s_hist[bin_of(sel_key<SMALLEST>(v[i]))], 1);
     }
     __syncthreads();
     constexpr int PER = SM_BINS / SM_NT;
@@ -1687,7 +1694,7 @@ __device__ __forceinline__ int block_select_sorted(const float* __restrict__ v, 
         return K;
     }
     auto append = [&](uint32_t key, int i, bool live) {
-        const bool take = live && ((key - kmin) >> shift) <= b;
+        const bool take = live && bin_of(key) <= b;
         const unsigned long long mask = __ballot(take);
         if (mask) {   // uniform
             uint32_t base = 0;
@@ -1721,6 +1728,13 @@ struct SmallSelectArgs {
     int* pair_off;
     int* q_total;
     int64_t* pair_base;
+    const float* x;    // inner-product metric: dis0 of the pairs
+    const float* cc;
+    int d;
+    float* pair_ip;
+    uint32_t* units;   // long lists: the scan's work list, (q << 20 | probe << 13 | chunk) per chunk_len codes of a pair
+    int* unit_count;   // zeroed by the launch before
+    int chunk_len;
 };
 __device__ __forceinline__ void small_coarse_select_body(int q, const SmallSelectArgs& A) {
     const float* __restrict__ mat = A.mat;
@@ -1782,6 +1796,26 @@ __device__ __forceinline__ void small_coarse_select_body(int q, const SmallSelec
             pair_off[(int64_t)q * (K + 1) + K] = tot;
             q_total[q] = tot;
         }
+        if (A.units) {   // uniform
+            const int nch = (len + A.chunk_len - 1) / A.chunk_len;
+            const int uincl = wave_incl_scan(nch);
+            const int utot = __shfl(uincl, 63, 64);
+            int ub = 0;
+            if (lane == 0 && utot) ub = atomicAdd(A.unit_count, utot);
+            ub = __shfl(ub, 0, 64) + uincl - nch;
+            for (int c = 0; c < nch; c++) A.units[ub + c] = ((uint32_t)q << 20) | ((uint32_t)lane << 13) | (uint32_t)c;
+        }
+    }
+    if (A.pair_ip) {   // k_pair_ip for this query: eight threads per probe (rerank_dev.h: fvec_inner_product's lane order)
+        __syncthreads();
+        const int g = tid >> 3, l8 = tid & 7;
+        for (int p0 = 0; p0 < K; p0 += SM_NT / 8) {
+            const int p = p0 + g;
+            const int l = p < K ? s_probe[p] : -1;
+            const bool live = l >= 0 && l < nlist;
+            const float ip = rerank_dist8<false>(A.x + (int64_t)q * A.d, A.cc + (int64_t)(live ? l : 0) * A.d, A.d, l8, live);
+            if (l8 == 0 && p < K) A.pair_ip[(int64_t)q * K + p] = live ? ip : 0.f;
+        }
     }
 }
 
@@ -1789,11 +1823,51 @@ __global__ __launch_bounds__(SM_NT) void k_small_coarse_select(SmallSelectArgs A
 
 void launch_small_coarse_select(hipStream_t s, const float* mat, int nlist, int nq, int P, float* out_vals, int* out_pos,
                                 const int* list_len, const uint8_t* list_mask, const int64_t* list_off, int* pair_off,
-                                int* q_total, int64_t* pair_base) {
+                                int* q_total, int64_t* pair_base, const float* x, const float* cc, int d, float* pair_ip,
+                                uint32_t* units, int* unit_count, int chunk_len) {
     if (nq <= 0) return;
     if (P > 64) abort();   // callers gate on this
-    const SmallSelectArgs A{mat, nlist, P, out_vals, out_pos, list_len, list_mask, list_off, pair_off, q_total, pair_base};
+    if (units && (nq > 4096 || chunk_len < 1)) abort();
+    const SmallSelectArgs A{mat, nlist, P, out_vals, out_pos, list_len, list_mask, list_off, pair_off, q_total, pair_base,
+                            x, cc, d, pair_ip, units, unit_count, chunk_len};
     hipLaunchKernelGGL(k_small_coarse_select, dim3(nq), dim3(SM_NT), 0, s, A);
+}
+
+// Long candidate rows (big indexes: nprobe x list length in the 10^5s) are too much for the one workgroup of
+// k_small_tail: the row is cut into S = min(smax, ceil(n / SM_SLICE)) slices, workgroup (q, s) leaves the
+// min(recall_num, slice) best of slice s -- value and slab position, best first -- and the tail selects among S x R.
+// Equal keys keep their slab order through both levels (slices are in slab order, a slice's survivors in
+// (key, position) order), so the result is the one-level selection's, ties included.
+template <bool L2>
+__global__ __launch_bounds__(SM_NT) void k_small_presel(const float* __restrict__ slab, int64_t q_stride,
+                                                        const int* __restrict__ q_total, int R, int smax,
+                                                        float* __restrict__ pre_val, int* __restrict__ pre_pos) {
+    __shared__ int s_hist[SM_BINS];
+    __shared__ unsigned long long s_it[2 * SM_NT];
+    __shared__ int s_w[2 * SM_NW];
+    __shared__ uint32_t s_pick[3];
+    const int q = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
+    const int n = q_total[q];
+    const int S = min(smax, (n + SM_SLICE - 1) / SM_SLICE);
+    if (sl >= S) return;   // uniform
+    const int per = (((n + S - 1) / S) + 3) & ~3;
+    const int i0 = min(n, sl * per), m = min(n, i0 + per) - i0;
+    const float* v = slab + (int64_t)q * q_stride + i0;
+    const int cnt = m > 0 ? block_select_sorted<L2, 16, 2>(v, m, R, s_it, s_hist, s_w, s_pick) : 0;   // barriers inside
+    if (m <= 0) __syncthreads();
+    const int64_t o = ((int64_t)q * smax + sl) * R;
+    for (int r = tid; r < R; r += SM_NT) {
+        float val = L2 ? INFINITY : -INFINITY;
+        int pos = -1;
+        if (r < cnt) {
+            const unsigned long long it = s_it[r];
+            const uint32_t key = (uint32_t)(it >> 32);
+            val = key2f(L2 ? key : ~key);
+            pos = i0 + (int)(uint32_t)it;
+        }
+        pre_val[o + r] = val;
+        pre_pos[o + r] = pos;
+    }
 }
 
 template <bool L2>
@@ -1808,7 +1882,8 @@ __global__ __launch_bounds__(SM_NT) void k_small_tail(const float* __restrict__ 
                                                       const float* __restrict__ raw, int64_t nraw, int k,
                                                       float min_score, float max_score, float neutral,
                                                       float* __restrict__ distances, int64_t* __restrict__ labels,
-                                                      unsigned long long* __restrict__ dbg) {
+                                                      const float* __restrict__ pre_val, const int* __restrict__ pre_pos,
+                                                      int smax, unsigned long long* __restrict__ dbg) {
 #define GH_T(i) do { if (dbg && threadIdx.x == 0 && blockIdx.x == 0) dbg[i] = wall_clock64(); } while (0)
     __shared__ int s_hist[SM_BINS];
     __shared__ unsigned long long s_it[2 * SM_NT];
@@ -1820,7 +1895,13 @@ __global__ __launch_bounds__(SM_NT) void k_small_tail(const float* __restrict__ 
     __shared__ int64_t s_lbase[64];
     const int q = blockIdx.x, tid = threadIdx.x;
     const float* v = slab + (int64_t)q * q_stride;
-    const int n = q_total[q];
+    int n = q_total[q];
+    const int* ppos = nullptr;
+    if (smax > 0) {   // long rows: k_small_presel has left min(R, slice) candidates of each of the row's slices
+        v = pre_val + (int64_t)q * smax * R;
+        ppos = pre_pos + (int64_t)q * smax * R;
+        n = min(smax, (n + SM_SLICE - 1) / SM_SLICE) * R;
+    }
     const float sentinel = L2 ? INFINITY : -INFINITY;
     // the pairs' slab offsets and list bases: loaded while the selection runs, read from LDS by the id look-up
     GH_T(0);
@@ -1831,6 +1912,10 @@ __global__ __launch_bounds__(SM_NT) void k_small_tail(const float* __restrict__ 
     }
     const int cnt = block_select_sorted<L2, 16, 2>(v, n, R, s_it, s_hist, s_w, s_pick);   // barriers inside
     GH_T(1);
+    if (dbg && tid == 0 && q == 0) {
+        dbg[6] = (unsigned long long)n;
+        dbg[7] = (unsigned long long)s_pick[1];
+    }
     // top-R table of the query: ADC distance, slab position, vector id (k_map_candidates)
     const int* off = s_off;
     for (int r = tid; r < R; r += SM_NT) {
@@ -1841,6 +1926,7 @@ __global__ __launch_bounds__(SM_NT) void k_small_tail(const float* __restrict__ 
             pos = (int)(uint32_t)s_it[r];
             val = v[pos];
             if (val == sentinel) pos = -1;
+            else if (ppos) pos = ppos[pos];
         }
         if (pos >= 0) {
             int lo = 0, hi = P - 1;
@@ -1923,29 +2009,37 @@ void launch_small_tail(hipStream_t s, bool l2, const float* slab, int64_t q_stri
                        const int* probe_list, const int* pair_off, const int64_t* list_off, const int64_t* ids,
                        float* cand_dis, int* cand_pos, int64_t* cand_ids, int has_rank, const float* x, int d,
                        const float* raw, int64_t nraw, int k, float min_score, float max_score, float neutral,
-                       float* distances, int64_t* labels) {
+                       float* distances, int64_t* labels, int smax, float* pre_val, int* pre_pos) {
     if (nq <= 0) return;
     if (R > 1024) abort();   // callers gate on this
+    if (smax > 0) {
+        if (l2)
+            hipLaunchKernelGGL((k_small_presel<true>), dim3(nq, smax), dim3(SM_NT), 0, s, slab, q_stride, q_total, R, smax,
+                               pre_val, pre_pos);
+        else
+            hipLaunchKernelGGL((k_small_presel<false>), dim3(nq, smax), dim3(SM_NT), 0, s, slab, q_stride, q_total, R, smax,
+                               pre_val, pre_pos);
+    }
     static unsigned long long* dbg = nullptr;
     static int shown = 0;
     if (getenv("GAMMA_HIP_SM_DBG")) {
         if (!dbg) (void)hipMalloc((void**)&dbg, 64);
         if (shown++ % 10 == 9) {
-            unsigned long long h[6];
+            unsigned long long h[8];
             (void)hipStreamSynchronize(s);
             (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
-            fprintf(stderr, "small tail (10 ns ticks): select %llu map %llu rerank %llu sort %llu out %llu\n", h[1] - h[0], h[2] - h[1],
-                    h[3] - h[2], h[4] - h[3], h[5] - h[4]);
+            fprintf(stderr, "small tail (10 ns ticks): select %llu map %llu rerank %llu sort %llu out %llu (n %llu, taken %llu)\n",
+                    h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6], h[7]);
         }
     }
     if (l2)
         hipLaunchKernelGGL((k_small_tail<true>), dim3(nq), dim3(SM_NT), 0, s, slab, q_stride, q_total, R, P, probe_list,
                            pair_off, list_off, ids, cand_dis, cand_pos, cand_ids, has_rank, x, d, raw, nraw, k, min_score,
-                           max_score, neutral, distances, labels, dbg);
+                           max_score, neutral, distances, labels, pre_val, pre_pos, smax, dbg);
     else
         hipLaunchKernelGGL((k_small_tail<false>), dim3(nq), dim3(SM_NT), 0, s, slab, q_stride, q_total, R, P, probe_list,
                            pair_off, list_off, ids, cand_dis, cand_pos, cand_ids, has_rank, x, d, raw, nraw, k, min_score,
-                           max_score, neutral, distances, labels, dbg);
+                           max_score, neutral, distances, labels, pre_val, pre_pos, smax, dbg);
 }
 
 }  // namespace gh

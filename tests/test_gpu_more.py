@@ -1064,14 +1064,18 @@ def test_fused_coarse_matches_matrix_path_and_oracle(d, nlist, P, nq):
         g.close()
 
 
-@pytest.mark.parametrize("d,M,nlist", [(32, 8, 64), (128, 16, 256), (64, 32, 64)])
-def test_small_batch_path_is_the_regular_chain(d, M, nlist):
+@pytest.mark.parametrize("d,M,nlist,metric", [(32, 8, 64, B.METRIC_L2), (128, 16, 256, B.METRIC_L2),
+                                              (64, 32, 64, B.METRIC_L2), (32, 8, 64, B.METRIC_IP),
+                                              (100, 20, 64, B.METRIC_L2), (100, 25, 96, B.METRIC_IP),
+                                              (768, 64, 64, B.METRIC_IP)])
+def test_small_batch_path_is_the_regular_chain(d, M, nlist, metric):
     """Calls of up to 512 queries run as four or five fused kernels (gamma_hip.cpp ivfpq_small); every output and every stage
     table must equal the regular chain's, byte for byte: with / without re-rank, recall_num above and below the
     candidate count, k > candidates, deleted docs, a score window, and the oracle for good measure."""
-    case = fixtures.trained_case(d=d, nlist=nlist, M=M, N=20000, nq=64, metric=B.METRIC_L2)
+    case = fixtures.trained_case(d=d, nlist=nlist, M=M, N=20000 if d < 512 else 6000, nq=64, metric=metric)
     g = fixtures.load_hip(case)
     rng = np.random.default_rng(d + M)
+    hip_metric = api.METRIC_L2 if metric == B.METRIC_L2 else api.METRIC_IP
     N = case["N"]
     dead = rng.choice(N, N // 10, replace=False)
     try:
@@ -1085,23 +1089,28 @@ def test_small_batch_path_is_the_regular_chain(d, M, nlist):
                 q = case["q"][:nq] if nq <= 64 else big
                 for has_rank in (True, False):
                     for P, R, k, win in ((8, 100, 10, None), (1, 50, 10, None), (32, 1000, 100, None),
-                                         (4, 20, 30, None), (16, 200, 10, (2e4, 9e4))):
+                                         (4, 20, 30, None), (16, 200, 10, True), (64, 300, 10, None)):
                         kw = dict(WIDE)
-                        if win:
-                            kw = dict(min_score=win[0], max_score=win[1])
-                        args = api.SearchArgs(metric=api.METRIC_L2, nprobe=P, recall_num=R, has_rank=has_rank, **kw)
+                        if win:   # a window that cuts on both sides, whatever the metric and the scale of the data
+                            Dw, _ = g.ivfpq_search(q, k, api.SearchArgs(metric=hip_metric, nprobe=P, recall_num=R,
+                                                                        has_rank=has_rank, **WIDE))
+                            fin = Dw[np.isfinite(Dw) & (np.abs(Dw) < 1e37)]
+                            kw = dict(min_score=float(np.quantile(fin, 0.2)), max_score=float(np.quantile(fin, 0.8)))
+                        args = api.SearchArgs(metric=hip_metric, nprobe=P, recall_num=R, has_rank=has_rank, **kw)
                         g.set_small_path(False)
                         D0, I0 = g.ivfpq_search(q, k, args)
                         s0 = g.last_stages(nq, P, max(R, k))
-                        g.set_small_path(True)
-                        D1, I1 = g.ivfpq_search(q, k, args)
-                        s1 = g.last_stages(nq, P, max(R, k))
-                        tag = (step, nq, has_rank, P, R, k)
-                        assert D0.tobytes() == D1.tobytes() and np.array_equal(I0, I1), tag
-                        for key in s0:
-                            assert s0[key].tobytes() == s1[key].tobytes(), (tag, key)
+                        # 1: automatic; 3: long-row selection in two levels forced (three slices at most)
+                        for mode in ((1, 3) if nq in (1, 5, 37, 300) else (1,)):
+                            g.set_small_path(mode)
+                            D1, I1 = g.ivfpq_search(q, k, args)
+                            s1 = g.last_stages(nq, P, max(R, k))
+                            tag = (step, nq, has_rank, P, R, k, mode)
+                            assert D0.tobytes() == D1.tobytes() and np.array_equal(I0, I1), tag
+                            for key in s0:
+                                assert s0[key].tobytes() == s1[key].tobytes(), (tag, key)
             if step == 0:
-                (D, I, st), (Dg, Ig) = run_both(case, g, case["q"][:3], 10, 8, 100, B.METRIC_L2, True)
+                (D, I, st), (Dg, Ig) = run_both(case, g, case["q"][:3], 10, 8, 100, metric, True)
                 compare_topk(D, I, Dg, Ig)
     finally:
         g.close()
