@@ -25,6 +25,7 @@
 // MFMAs of the next, so the matrix pipe does not wait for the VALU work.  LDS: 2 x 64 x (d+1) floats = 66 KB at d = 128 -> two workgroups per CU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <math.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -425,17 +426,41 @@ __global__ __launch_bounds__(256) void k_coarse_repair(const float* __restrict__
     }
 }
 
+// (sample, strips) for a shape, or false.  tau is the P-th smallest of 64 lane minima over NPL = sample / 64 values
+// each (k_coarse_bound): it sits at the row quantile F = 1 - (1 - P/64)^(1/NPL) -- 0.69 / NPL at P = 32 -- and a strip
+// then keeps about F (nlist - sample) / strips entries per query, sd ~17 %.  The strip lists hold 127: the plan keeps
+// the mean at 48 or less (ten sigma of margin at C3's 37), first with 16 strips instead of 8, then with a larger
+// sample.  P > 32 is left to the matrix path: the P-th of 64 lane minima is no bound worth having up there (at
+// P = 64 it is the LARGEST lane minimum, a quarter of the row), and every query would go through the repair kernel.
+static bool coarse_fused_shape(int nlist, int P, int* sample, int* nseg) {
+    if (P < 1 || P > 32) return false;
+    for (int sm = 512; sm <= 2048; sm *= 2) {
+        if (nlist < 4 * sm) break;
+        const double F = 1.0 - pow(1.0 - P / 64.0, 64.0 / sm);
+        for (int sg = 8; sg <= 16; sg *= 2) {
+            if (F * (nlist - sm) / sg <= 48.0) {
+                *sample = sm;
+                *nseg = sg;
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
 bool coarse_fused_supported(int nq, int d, int nlist, int P) {
-    return nq >= 4096 && nlist >= 4 * (P <= 32 ? 512 : 1024) && (d == 32 || d == 64 || d == 96 || d == 128) && P >= 1 && P <= 64;
+    int sm, sg;
+    if (!(nq >= 4096 && (d == 32 || d == 64 || d == 96 || d == 128) && coarse_fused_shape(nlist, P, &sm, &sg))) return false;
+    // the strip lists and the sample matrix are addressed through 32-bit buffer offsets (k_coarse_fused)
+    return (int64_t)nq * sg * kCoarseCap * 8 < 0x7fffffffLL && (int64_t)nq * sm * 4 < 0x7fffffffLL;
 }
 
 CoarseFusedPlan coarse_fused_plan(int nq, int nlist, int P, int cap) {
     CoarseFusedPlan pl;
-    // tau sits at quantile ~1.3 P / sample = 1/12 of a row (k_coarse_bound), sd ~17 %: a strip of 448 columns keeps
-    // 37 +- 9 entries per query at P = 32; kCoarseCap = 128 is ten sigma away, the rest goes to k_coarse_repair
-    pl.sample = P <= 32 ? 512 : 1024;
+    // C3 (nlist 4096, P 32): sample 512, 8 strips of 448 columns that keep 37 +- 9 entries per query; kCoarseCap = 128
+    // is ten sigma away, the rest goes to k_coarse_repair
+    if (!coarse_fused_shape(nlist, P, &pl.sample, &pl.nseg)) abort();   // callers ask coarse_fused_supported first
     const int ntiles = (nlist - pl.sample + 63) / 64;
-    pl.nseg = 8;
     pl.tiles_per_strip = (ntiles + pl.nseg - 1) / pl.nseg;
     pl.nseg = (ntiles + pl.tiles_per_strip - 1) / pl.tiles_per_strip;
     pl.cap_stride = kCoarseCap;
@@ -490,7 +515,8 @@ void launch_coarse_fused(hipStream_t s, const CoarseFusedPlan& pl, void* ws, con
 #undef GH_CS
     }
     if (pl.sample == 512) hipLaunchKernelGGL(k_coarse_bound<8>, dim3((nq + 3) / 4), dim3(256), 0, s, mat, nq, P, tau, ovf);
-    else hipLaunchKernelGGL(k_coarse_bound<16>, dim3((nq + 3) / 4), dim3(256), 0, s, mat, nq, P, tau, ovf);
+    else if (pl.sample == 1024) hipLaunchKernelGGL(k_coarse_bound<16>, dim3((nq + 3) / 4), dim3(256), 0, s, mat, nq, P, tau, ovf);
+    else hipLaunchKernelGGL(k_coarse_bound<32>, dim3((nq + 3) / 4), dim3(256), 0, s, mat, nq, P, tau, ovf);
     // B: the other columns, filtered
     dim3 grid((unsigned)pl.nseg, (unsigned)((nq + 127) / 128));
 #define GH_CF(NCH)                                                                                                      \
@@ -517,10 +543,14 @@ void launch_coarse_fused(hipStream_t s, const CoarseFusedPlan& pl, void* ws, con
                        pl.cap_stride, nq, P, out_dis, out_idx, ovf)
     if (pl.sample == 512) {
         if (pl.nseg <= 4) GH_FIN(8, 4);
-        else GH_FIN(8, 8);
+        else if (pl.nseg <= 8) GH_FIN(8, 8);
+        else GH_FIN(8, 16);
+    } else if (pl.sample == 1024) {
+        if (pl.nseg <= 8) GH_FIN(16, 8);
+        else GH_FIN(16, 16);
     } else {
-        if (pl.nseg <= 4) GH_FIN(16, 4);
-        else GH_FIN(16, 8);
+        if (pl.nseg <= 8) GH_FIN(32, 8);
+        else GH_FIN(32, 16);
     }
 #undef GH_FIN
     hipLaunchKernelGGL(k_coarse_repair, dim3(kCoarseRepairGrid), dim3(256), (size_t)d * sizeof(float), s, x, d, y, nlist, yn,

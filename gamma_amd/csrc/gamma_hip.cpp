@@ -673,6 +673,14 @@ int ivfpq_coarse(H* h, const gamma_hip_search_params* p, int nq, const float* d_
     StageScope t(h, GAMMA_HIP_STAGE_COARSE);
     if (fused) {
         gh::launch_coarse_fused(s, plan, h->w_mat.p, d_x, nq, d, h->d_cc, nlist, h->d_cc_norms, P, out_dis, out_probe);
+        static const bool dbg = getenv("GAMMA_HIP_COARSE_DBG") != nullptr;
+        if (dbg) {   // how many queries the strip lists could not hold (they went through the repair kernel)
+            int n_ovf = 0;
+            GH_CHECK(h, hipStreamSynchronize(s));
+            GH_CHECK(h, hipMemcpy(&n_ovf, static_cast<char*>(h->w_mat.p) + plan.off_ovf, sizeof(int), hipMemcpyDeviceToHost));
+            fprintf(stderr, "coarse fused: nlist %d nprobe %d sample %d strips %d: %d of %d queries repaired\n", nlist, P,
+                    plan.sample, plan.nseg, n_ovf, nq);
+        }
         return GAMMA_HIP_OK;
     }
     if (mode == 0) {
@@ -1066,7 +1074,10 @@ bool ivfpq_small_ok(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, i
     return !off && h->small_path && nq >= 1 && nq <= max_nq && (p->coarse_mode == 1 || nq <= 16) &&
            p->nprobe <= 64 && R <= 1024 && !h->exact_ties && !h->profile && !fc.d_qf && !h->d_list_mask &&
            h->nlist <= 16384 &&
-           (int64_t)p->nprobe * std::max(1, h->max_list_len) <= (1 << 22) && (!p->has_rank || (h->d_raw && h->raw_d == h->d));
+           (int64_t)p->nprobe * std::max(1, h->max_list_len) <= (1 << 22) &&
+           // long lists: beyond ~5e7 codes per call the regular chain's bound filter wins (full-size C4, 390 k codes per
+           // query: 64 queries 0.46 ms against 1.04, 256 queries 1.63 against 1.33)
+           (int64_t)nq * p->nprobe * (h->ntotal / std::max(1, h->nlist)) <= 48000000LL && (!p->has_rank || (h->d_raw && h->raw_d == h->d));
 }
 
 int ivfpq_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int nq, const float* d_x, int R, int k,

@@ -1475,14 +1475,15 @@ __device__ __forceinline__ void block_rank_sort_sm(unsigned long long* a, int n,
     const int ngroups = (n + 63) >> 6;
     int lg = 0;
     while ((1 << lg) < ngroups) lg++;
-    const int slices = SM_NW >> lg;
+    static_assert(SM_NW == 16, "the j range is cut into SM_NW >> lg = 2^(4 - lg) slices");
     for (int i = tid; i < n; i += SM_NT) s_rank[i] = 0;
     __syncthreads();
     const int g = w & ((1 << lg) - 1), sl = w >> lg;
     const int i = g * 64 + lane;
     const unsigned long long item = i < n ? a[i] : ~0ull;
     if (g < ngroups) {   // uniform per wave
-        const int j0 = (int)((int64_t)sl * n / slices), j1 = (int)((int64_t)(sl + 1) * n / slices);
+        // (slices is the power of two SM_NW >> lg and sl * n < 2^14: shifts, not the 64-bit division the general form costs)
+        const int j0 = (sl * n) >> (4 - lg), j1 = ((sl + 1) * n) >> (4 - lg);
         int rk = 0, j = j0;
         for (; j + 8 <= j1; j += 8) {
             unsigned long long x[8];

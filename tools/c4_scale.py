@@ -45,3 +45,19 @@ Ih = I[:64].cpu().numpy()
 Df, If = g.flat_search(q[(steps - 1) % 2 * nq:][:64], k, api.SearchArgs(metric=api.METRIC_L2, min_score=0.0, max_score=1e30))
 rec = np.mean([len(set(Ih[i].tolist()) & set(If[i].tolist())) / float(k) for i in range(64)])
 print("recall@10 vs flat on 64 queries: %.3f" % rec)
+# small calls (serving latency): device-buffer entry point, synchronised per call; the small-batch chain against the
+# regular one
+g.profile_enable(False)
+for nqs in (1, 16, 64, 256):
+    for small in (1, 0):
+        g.set_small_path(small)
+        ts = []
+        for i in range(120):
+            off = (i * nqs) % (nq - nqs)
+            t0 = time.perf_counter()
+            g.ivfpq_search_device(dq[off:].data_ptr(), nqs, k, args, D.data_ptr(), I.data_ptr())
+            g.synchronize()
+            ts.append(time.perf_counter() - t0)
+        ts = np.sort(np.array(ts[20:])) * 1e6
+        print("latency nq=%-4d %s median %.1f us  p99 %.1f us" % (nqs, "small-batch chain" if small else "regular chain    ", np.median(ts), ts[98]))
+g.set_small_path(1)
