@@ -686,8 +686,16 @@ int ivfpq_coarse(H* h, const gamma_hip_search_params* p, int nq, const float* d_
     if (mode == 0) {
         gh::launch_pairwise(s, true, d_x, nq, d, h->d_cc, nlist, h->w_mat.as<float>(), nlist);
     } else {
-        // query norms are fused into the MFMA kernel (xn = nullptr)
-        gh::launch_l2_gemmform(s, d_x, nq, d, h->d_cc, nlist, nullptr, h->d_cc_norms,
+        // query norms: fused into the MFMA kernel (xn = nullptr) when a tile holds whole rows (d <= 128); longer rows
+        // get them from their own pass -- inside the K-slab loop they cost a fifth of the kernel (d = 768: 3.46 -> 2.72 ms
+        // per 8192 x 16384 with the conflict-free staging)
+        const float* xn = nullptr;
+        if (d > 128) {
+            GH_CHECK(h, h->w_xn.ensure((size_t)nq * sizeof(float)));
+            gh::launch_row_norms(s, d_x, nq, d, h->w_xn.as<float>());
+            xn = h->w_xn.as<float>();
+        }
+        gh::launch_l2_gemmform(s, d_x, nq, d, h->d_cc, nlist, xn, h->d_cc_norms,
                                h->w_mat.as<float>(), nlist, true);
     }
     if (h->exact_ties) GH_CHECK(h, h->w_tieflag.ensure((size_t)nq));

@@ -369,6 +369,7 @@ __global__ __launch_bounds__(256) void k_l2_gemmform_valu(const float* __restric
 // row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+template <int KS>
 __global__ __launch_bounds__(256) void k_l2_gemmform_mfma(const float* __restrict__ x, int nq, int d,
                                                           const float* __restrict__ y, int ny,
                                                           const float* __restrict__ xn,
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(256) void k_l2_gemmform_mfma(const float* __restric
     // loads of a slab are issued back to back (float4, 16 per thread and operand), then each
     // wave runs 64 dependent MFMAs uninterrupted.  Row stride 129 dwords: the fragment reads
     // (row = lane & 31, fixed k) hit 32 distinct banks.
-    constexpr int KS = 128, LD = KS + 1;
+    constexpr int LD = KS + 1, NIT = KS / 16, SEG = KS / 32;   // float4 slots per thread and operand; 32-float segments per row
     extern __shared__ float s_gemm[];
     float* sA = s_gemm;            // [64][LD]
     float* sB = s_gemm + 64 * LD;  // [64][LD]
@@ -396,13 +397,17 @@ __global__ __launch_bounds__(256) void k_l2_gemmform_mfma(const float* __restric
     // addresses (a branch per load would make hipcc wait for each one); out-of-range lanes are zeroed
     // when the slab is written to LDS.  The NEXT slab is requested before the MFMAs of the current one
     // (d = 768: six slabs per tile, their global latency used to be exposed once per slab).
-    float4 va[8], vb[8];
+    // slot (it) of a thread: one wave instruction covers 8 rows x 32 floats (8 lanes per 128-byte row segment,
+    // coalesced); with row stride 129 the four scalar LDS stores of such an instruction hit 32 distinct banks per
+    // half wave (a whole row per instruction would be 4-way conflicted)
+    auto slot_r = [&](int it) { return (((w * NIT + it) / SEG) << 3) + (lane >> 3); };
+    auto slot_c = [&](int it) { return (((w * NIT + it) % SEG) << 5) + ((lane & 7) << 2); };
+    float4 va[NIT], vb[NIT];
     auto gload = [&](int k0) {
         const int kw = min(KS, d - k0);
 #pragma unroll
-        for (int it = 0; it < 8; it++) {
-            const int e = it * 256 + tid;
-            const int r = e >> 5, c4 = (e & 31) * 4;
+        for (int it = 0; it < NIT; it++) {
+            const int r = slot_r(it), c4 = slot_c(it);
             const int q = min(q_base + r, nq - 1), cc = min(c_base + r, ny - 1);
             const int c4c = min(c4, kw - 4);
             va[it] = *reinterpret_cast<const float4*>(x + (int64_t)q * d + k0 + c4c);
@@ -414,9 +419,8 @@ __global__ __launch_bounds__(256) void k_l2_gemmform_mfma(const float* __restric
         const int kw = min(KS, d - k0);
         if (vec4) {
 #pragma unroll
-            for (int it = 0; it < 8; it++) {
-                const int e = it * 256 + tid;
-                const int r = e >> 5, c4 = (e & 31) * 4;
+            for (int it = 0; it < NIT; it++) {
+                const int r = slot_r(it), c4 = slot_c(it);
                 const bool oka = c4 < kw && q_base + r < nq, okb = c4 < kw && c_base + r < ny;
                 float* pa = sA + r * LD + c4;
                 float* pb = sB + r * LD + c4;
@@ -426,9 +430,9 @@ __global__ __launch_bounds__(256) void k_l2_gemmform_mfma(const float* __restric
                 pb[2] = okb ? vb[it].z : 0.f; pb[3] = okb ? vb[it].w : 0.f;
             }
         } else {
-            for (int it = 0; it < 32; it++) {
+            for (int it = 0; it < KS / 4; it++) {
                 const int e = it * 256 + tid;
-                const int r = e >> 7, c = e & 127;
+                const int r = e / KS, c = e % KS;
                 const int q = q_base + r, cc = c_base + r;
                 sA[r * LD + c] = (q < nq && c < kw) ? x[(int64_t)q * d + k0 + c] : 0.f;
                 sB[r * LD + c] = (cc < ny && c < kw) ? y[(int64_t)cc * d + k0 + c] : 0.f;
@@ -484,6 +488,100 @@ __global__ __launch_bounds__(256) void k_l2_gemmform_mfma(const float* __restric
             float dis = (xnr + yn[col]) - 2.f * acc[r];
             if (dis < 0.f) dis = 0.f;
             out[(int64_t)row * ld_out + col] = dis;
+        }
+    }
+}
+
+// Long rows (d > 128, e.g. 768-dimensional embeddings): a 128 x 128 tile per workgroup, 64 x 64 per wave as four
+// 32 x 32 accumulators, K slabs of 32 staged in LDS.  Per MFMA half as many floats are staged and half as many
+// fragments read as with the 64 x 64 tile above, and four workgroups fit a CU (34 KB of LDS), so one's staging
+// overlaps the others' MFMAs.  Every accumulator still receives its k in ascending order: the same chain.
+// Query norms come from their own pass (xn != nullptr), d % 4 == 0.
+__global__ __launch_bounds__(256) void k_l2_gemmform_big(const float* __restrict__ x, int nq, int d,
+                                                         const float* __restrict__ y, int ny,
+                                                         const float* __restrict__ xn,
+                                                         const float* __restrict__ yn,
+                                                         float* __restrict__ out, int64_t ld_out) {
+    constexpr int KS = 32, LD = KS + 1, NIT = 4;   // 128 rows x 8 float4 per operand = 4 per thread
+    __shared__ float sA[128 * LD];
+    __shared__ float sB[128 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wq = w >> 1, wc = w & 1;
+    const int q_base = blockIdx.y * 128, c_base = blockIdx.x * 128;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    // a wave instruction covers 8 rows x 32 floats: coalesced 128-byte segments, conflict-free scalar LDS stores
+    auto slot_r = [&](int it) { return ((w * NIT + it) << 3) + (lane >> 3); };
+    const int c4 = (lane & 7) << 2;
+    float4 va[NIT], vb[NIT];
+    auto gload = [&](int k0) {
+        const int c4c = min(c4, d - k0 - 4);   // clamped address; out-of-range lanes are zeroed when written to LDS
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int r = slot_r(it);
+            va[it] = *reinterpret_cast<const float4*>(x + (int64_t)min(q_base + r, nq - 1) * d + k0 + c4c);
+            vb[it] = *reinterpret_cast<const float4*>(y + (int64_t)min(c_base + r, ny - 1) * d + k0 + c4c);
+        }
+    };
+    gload(0);
+    const float* fa = sA + (wq * 64 + (lane & 31)) * LD + (lane >> 5);
+    const float* fb = sB + (wc * 64 + (lane & 31)) * LD + (lane >> 5);
+    for (int k0 = 0; k0 < d; k0 += KS) {
+        const int kw = min(KS, d - k0);
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int r = slot_r(it);
+            const bool oka = c4 < kw && q_base + r < nq, okb = c4 < kw && c_base + r < ny;
+            float* pa = sA + r * LD + c4;
+            float* pb = sB + r * LD + c4;
+            pa[0] = oka ? va[it].x : 0.f; pa[1] = oka ? va[it].y : 0.f;
+            pa[2] = oka ? va[it].z : 0.f; pa[3] = oka ? va[it].w : 0.f;
+            pb[0] = okb ? vb[it].x : 0.f; pb[1] = okb ? vb[it].y : 0.f;
+            pb[2] = okb ? vb[it].z : 0.f; pb[3] = okb ? vb[it].w : 0.f;
+        }
+        __syncthreads();
+        if (k0 + KS < d) gload(k0 + KS);   // uniform; lands while the 64 MFMAs below run
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++) {   // 8 k pairs per chunk: fragment reads first, then 32 MFMAs
+            float a0[8], a1[8], b0[8], b1[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                a0[u] = fa[ch * 16 + 2 * u];
+                a1[u] = fa[32 * LD + ch * 16 + 2 * u];
+                b0[u] = fb[ch * 16 + 2 * u];
+                b1[u] = fb[32 * LD + ch * 16 + 2 * u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b1[u], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b0[u], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc[1][1], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // epilogue: dis = (xn + yn) - 2*ip, clamp
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int col = c_base + wc * 64 + j * 32 + (lane & 31);
+            const float ync = yn[min(col, ny - 1)];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = q_base + wq * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < nq && col < ny) {
+                    float dis = (xn[row] + ync) - 2.f * acc[i][j][r];
+                    if (dis < 0.f) dis = 0.f;
+                    out[(int64_t)row * ld_out + col] = dis;
+                }
+            }
         }
     }
 }
@@ -641,7 +739,7 @@ void launch_l2_gemmform(hipStream_t s, const float* x, int nq, int d, const floa
         constexpr size_t lds = 2 * 64 * 129 * sizeof(float);  // 66 KB > the 64 KB default cap
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_l2_gemmform_mfma),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_l2_gemmform_mfma<128>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
         }
@@ -663,8 +761,22 @@ void launch_l2_gemmform(hipStream_t s, const float* x, int nq, int d, const floa
             return;
         }
         // xn == nullptr: query norms are computed inside the kernel from the staged tile
-        hipLaunchKernelGGL(k_l2_gemmform_mfma, grid, dim3(256), lds, s, x, nq, d, y, (int)ny, xn, yn,
-                           out, ld_out);
+        static const bool no_big = getenv("GAMMA_HIP_NO_GEMM_BIG") != nullptr;
+        if (xn && d > 128 && (d & 3) == 0 && nq >= 256 && !no_big) {
+            hipLaunchKernelGGL(k_l2_gemmform_big, dim3((unsigned)((ny + 127) / 128), (unsigned)((nq + 127) / 128)), dim3(256), 0, s,
+                               x, nq, d, y, (int)ny, xn, yn, out, ld_out);
+            return;
+        }
+        static const int ks_env = getenv("GAMMA_HIP_GEMM_KS") ? atoi(getenv("GAMMA_HIP_GEMM_KS")) : 128;
+        if (ks_env == 64)
+            hipLaunchKernelGGL(k_l2_gemmform_mfma<64>, grid, dim3(256), 2 * 64 * 65 * sizeof(float), s, x, nq, d, y, (int)ny, xn, yn,
+                               out, ld_out);
+        else if (ks_env == 32)
+            hipLaunchKernelGGL(k_l2_gemmform_mfma<32>, grid, dim3(256), 2 * 64 * 33 * sizeof(float), s, x, nq, d, y, (int)ny, xn, yn,
+                               out, ld_out);
+        else
+            hipLaunchKernelGGL(k_l2_gemmform_mfma<128>, grid, dim3(256), lds, s, x, nq, d, y, (int)ny, xn, yn,
+                               out, ld_out);
     } else {
         const int64_t row_blocks = (ny + 255) / 256;
         int q_per_block = 8;

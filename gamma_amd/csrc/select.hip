@@ -537,18 +537,41 @@ __global__ __launch_bounds__(256) void k_select_wave(const float* __restrict__ v
                     key[j0 + u] = (j0 + u) * 64 < nrem ? sel_key<SMALLEST>(t[u]) : 0xffffffffu;
             }
         }
-        uint32_t m = key[0];
+        uint32_t tau;
+        if (K <= 32 || NPL < 2) {   // uniform
+            uint32_t m = key[0];
 #pragma unroll
-        for (int j = 1; j < NPL; j++) m = key[j] < m ? key[j] : m;
-        // rank of this lane's minimum among the 64 (ties by lane): K-th smallest = tau
-        int rk = 0;
+            for (int j = 1; j < NPL; j++) m = key[j] < m ? key[j] : m;
+            // rank of this lane's minimum among the 64 (ties by lane): K-th smallest = tau
+            int rk = 0;
 #pragma unroll
-        for (int l = 0; l < 64; l++) {
-            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)m, l);
-            rk += (o < m || (o == m && l < lane)) ? 1 : 0;
+            for (int l = 0; l < 64; l++) {
+                const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)m, l);
+                rk += (o < m || (o == m && l < lane)) ? 1 : 0;
+            }
+            const unsigned long long who = __ballot(rk == K - 1);
+            tau = (uint32_t)__shfl((int)m, (int)__ffsll((long long)who) - 1, 64);
+        } else {
+            // K in (32, 64]: the K-th of 64 lane minima is no bound (at K = 64 it is the LARGEST of them, a quarter of
+            // the chunk passes and the exact extraction below runs for every chunk).  Two minima per lane, over the
+            // even and the odd slots: the K-th smallest of the 128 sits where the K/2-th of 64 would -- ~1.4 K items pass.
+            uint32_t m0 = key[0], m1 = key[1];
+#pragma unroll
+            for (int j = 2; j < NPL; j += 2) m0 = key[j] < m0 ? key[j] : m0;
+#pragma unroll
+            for (int j = 3; j < NPL; j += 2) m1 = key[j] < m1 ? key[j] : m1;
+            int rk0 = 0, rk1 = 0;   // ranks among the 128, ties by (group, lane)
+#pragma unroll
+            for (int l = 0; l < 64; l++) {
+                const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)m0, l);
+                const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)m1, l);
+                rk0 += ((o0 < m0 || (o0 == m0 && l < lane)) ? 1 : 0) + (o1 < m0 ? 1 : 0);
+                rk1 += (o0 <= m1 ? 1 : 0) + ((o1 < m1 || (o1 == m1 && l < lane)) ? 1 : 0);
+            }
+            const unsigned long long who0 = __ballot(rk0 == K - 1), who1 = __ballot(rk1 == K - 1);
+            tau = who0 ? (uint32_t)__shfl((int)m0, (int)__ffsll((long long)who0) - 1, 64)
+                       : (uint32_t)__shfl((int)m1, (int)__ffsll((long long)who1) - 1, 64);
         }
-        const unsigned long long who = __ballot(rk == K - 1);
-        uint32_t tau = (uint32_t)__shfl((int)m, (int)__ffsll((long long)who) - 1, 64);
         if (run == K) {
             const uint32_t kth = (uint32_t)(buf[K - 1] >> 32);
             tau = kth < tau ? kth : tau;

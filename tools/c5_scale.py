@@ -66,3 +66,19 @@ for name, ff in (("no filter", None), ("10% range filter", [(0, 0, 99999, True, 
     Df, If = g.flat_search(q[(steps - 1) % 2 * nq:][:64], k, api.SearchArgs(metric=api.METRIC_IP, min_score=-1e30, max_score=1e30, field_filters=ff))
     rec = np.mean([len(set(Ih[i].tolist()) & set(If[i].tolist()) - {-1}) / float(max(1, (If[i] >= 0).sum())) for i in range(64)])
     print("   recall@10 vs flat on 64 queries: %.3f" % rec)
+# small calls (serving latency): device-buffer entry point, synchronised per call; small-batch chain / regular chain
+g.profile_enable(False)
+args = api.SearchArgs(metric=api.METRIC_IP, nprobe=P, recall_num=R, has_rank=True, min_score=-1e30, max_score=1e30)
+for nqs in (1, 16, 64):
+    for small in (1, 0):
+        g.set_small_path(small)
+        ts = []
+        for i in range(120):
+            off = (i * nqs) % (nq - nqs)
+            t0 = time.perf_counter()
+            g.ivfpq_search_device(dq[off:].data_ptr(), nqs, k, args, D.data_ptr(), I.data_ptr())
+            g.synchronize()
+            ts.append(time.perf_counter() - t0)
+        ts = np.sort(np.array(ts[20:])) * 1e6
+        print("latency nq=%-4d %s median %.1f us  p99 %.1f us" % (nqs, "small-batch chain" if small else "regular chain    ", np.median(ts), ts[98]))
+g.set_small_path(1)
