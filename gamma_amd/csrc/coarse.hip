@@ -243,6 +243,23 @@ __device__ __forceinline__ uint32_t wave_kth_smallest(uint32_t m, int K) {
     return (uint32_t)__shfl((int)m, (int)__ffsll((long long)who) - 1, 64);
 }
 
+// K-th smallest of the 128 values (m0, m1) of the 64 lanes, K <= 128
+__device__ __forceinline__ uint32_t wave_kth_smallest2(uint32_t m0, uint32_t m1, int K) {
+    int lt0 = 0, le0 = 0, lt1 = 0, le1 = 0;
+#pragma unroll
+    for (int l = 0; l < 64; l++) {
+        const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)m0, l);
+        const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)m1, l);
+        lt0 += (o0 < m0 ? 1 : 0) + (o1 < m0 ? 1 : 0);
+        le0 += (o0 <= m0 ? 1 : 0) + (o1 <= m0 ? 1 : 0);
+        lt1 += (o0 < m1 ? 1 : 0) + (o1 < m1 ? 1 : 0);
+        le1 += (o0 <= m1 ? 1 : 0) + (o1 <= m1 ? 1 : 0);
+    }
+    const unsigned long long who0 = __ballot(lt0 < K && K <= le0), who1 = __ballot(lt1 < K && K <= le1);
+    return who0 ? (uint32_t)__shfl((int)m0, (int)__ffsll((long long)who0) - 1, 64)
+                : (uint32_t)__shfl((int)m1, (int)__ffsll((long long)who1) - 1, 64);
+}
+
 // One wave per query: tau_q = the P-th smallest of the 64 lane minima of the query's sample row.  P lanes hold a
 // value <= tau_q, so tau_q bounds the P-th smallest distance of the row from above, and with 8 values per lane it
 // sits at the same quantile (about 1.3 P / sample) a full selection would reach -- at a tenth of its cost.
@@ -253,13 +270,16 @@ __global__ __launch_bounds__(256) void k_coarse_bound(const float* __restrict__ 
     const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= nq) return;
     const float* v = mat + (int64_t)q * (64 * NPL) + lane;
-    uint32_t m = 0xffffffffu;
+    // P > 32: two minima per lane, over the even and the odd columns of the lane -- the P-th smallest of the 128 sits
+    // where the P/2-th of 64 would (the P-th of 64 lane minima is no bound up there: at P = 64 it is the largest)
+    uint32_t m0 = 0xffffffffu, m1 = 0xffffffffu;
 #pragma unroll
     for (int j = 0; j < NPL; j++) {
         const uint32_t k = f2key(v[64 * j]);
-        m = k < m ? k : m;
+        if (j & 1) m1 = k < m1 ? k : m1;
+        else m0 = k < m0 ? k : m0;
     }
-    const uint32_t kb = wave_kth_smallest(m, P);
+    const uint32_t kb = P <= 32 ? wave_kth_smallest(m0 < m1 ? m0 : m1, P) : wave_kth_smallest2(m0, m1, P);
     if (lane == 0) tau[q] = key2f(kb);
 }
 
@@ -300,16 +320,22 @@ __global__ __launch_bounds__(256) void k_coarse_final(const float* __restrict__ 
     for (int sg = 0; sg < MAXSEG; sg++) {
         const int c = __shfl(cnt, sg, 64);   // 0 beyond nseg
         const unsigned long long* p = cand + ((int64_t)q * nseg + min(sg, nseg - 1)) * cap_stride;
-        it[SNPL + 2 * sg] = lane < c ? p[lane] : ~0ull;
-        it[SNPL + 2 * sg + 1] = lane + 64 < c ? p[lane + 64] : ~0ull;
+        // entry e of strip sg goes to lane (e + 4 sg) mod 64: the ~40 entries of every strip would otherwise all sit in
+        // the low lanes, the high lanes would hold nothing, and a bound taken from lane minima would be no bound
+        const int e0 = (lane - 4 * sg) & 63;
+        it[SNPL + 2 * sg] = e0 < c ? p[e0] : ~0ull;
+        it[SNPL + 2 * sg + 1] = e0 + 64 < c ? p[e0 + 64] : ~0ull;
     }
-    uint32_t m = 0xffffffffu;   // empty slots carry the largest key
+    uint32_t m0 = 0xffffffffu, m1 = 0xffffffffu;   // empty slots carry the largest key
 #pragma unroll
-    for (int j = 0; j < NPL; j++) {
+    for (int j = 0; j < NPL; j++) {   // two groups of slots: sample columns by parity, strips by parity
         const uint32_t k = (uint32_t)(it[j] >> 32);
-        m = k < m ? k : m;
+        const bool g1 = j < SNPL ? (j & 1) != 0 : ((j >> 1) & 1) != 0;
+        if (g1) m1 = k < m1 ? k : m1;
+        else m0 = k < m0 ? k : m0;
     }
-    const uint32_t kb = wave_kth_smallest(m, P);   // 0xffffffff when fewer than P lanes hold entries: keep all
+    // 0xffffffff when fewer than P lanes (P > 32: lane halves) hold entries: keep all
+    const uint32_t kb = P <= 32 ? wave_kth_smallest(m0 < m1 ? m0 : m1, P) : wave_kth_smallest2(m0, m1, P);
     int c = 0;
 #pragma unroll
     for (int j = 0; j < NPL; j++) c += ((uint32_t)(it[j] >> 32) <= kb && it[j] != ~0ull) ? 1 : 0;
@@ -430,13 +456,13 @@ __global__ __launch_bounds__(256) void k_coarse_repair(const float* __restrict__
 // each (k_coarse_bound): it sits at the row quantile F = 1 - (1 - P/64)^(1/NPL) -- 0.69 / NPL at P = 32 -- and a strip
 // then keeps about F (nlist - sample) / strips entries per query, sd ~17 %.  The strip lists hold 127: the plan keeps
 // the mean at 48 or less (ten sigma of margin at C3's 37), first with 16 strips instead of 8, then with a larger
-// sample.  P > 32 is left to the matrix path: the P-th of 64 lane minima is no bound worth having up there (at
-// P = 64 it is the LARGEST lane minimum, a quarter of the row), and every query would go through the repair kernel.
+// sample.  P > 32: two minima per lane, the P-th of 128 (the P-th of 64 would be no bound: at P = 64 the LARGEST lane
+// minimum, a quarter of the row), F = 1 - (1 - P/128)^(2/NPL).
 static bool coarse_fused_shape(int nlist, int P, int* sample, int* nseg) {
-    if (P < 1 || P > 32) return false;
-    for (int sm = 512; sm <= 2048; sm *= 2) {
+    if (P < 1 || P > 64) return false;
+    for (int sm = P <= 32 ? 512 : 1024; sm <= 2048; sm *= 2) {
         if (nlist < 4 * sm) break;
-        const double F = 1.0 - pow(1.0 - P / 64.0, 64.0 / sm);
+        const double F = P <= 32 ? 1.0 - pow(1.0 - P / 64.0, 64.0 / sm) : 1.0 - pow(1.0 - P / 128.0, 128.0 / sm);
         for (int sg = 8; sg <= 16; sg *= 2) {
             if (F * (nlist - sm) / sg <= 48.0) {
                 *sample = sm;

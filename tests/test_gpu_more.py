@@ -1023,12 +1023,12 @@ def test_term_filters_on_device(case):
 
 @pytest.mark.parametrize("d,nlist,P,nq", [(128, 4096, 32, 4500), (32, 2048, 8, 4100), (64, 4100, 64, 4200),
                                           (96, 2304, 20, 8200), (128, 4096, 1, 4096), (32, 8192, 32, 4100),
-                                          (32, 16384, 32, 4100), (32, 32768, 24, 4100)])
+                                          (32, 16384, 32, 4100), (32, 32768, 24, 4100), (32, 16384, 64, 4100), (64, 8192, 40, 4100)])
 def test_fused_coarse_matches_matrix_path_and_oracle(d, nlist, P, nq):
     """csrc/coarse.hip (sample -> bound -> filtered GEMM epilogue -> merge) == the distance-matrix path, bit for
     bit, also when survivor lists overflow and queries go through the repair kernel (list_cap 1: every query;
     40: some), and == the oracle's GEMM-form knn_L2sqr (faiss:utils/distances.cpp:215-296) up to ties.  The larger
-    nlist take 16 strips and a 1024 / 2048-column sample (coarse_fused_shape); nprobe 64 is the matrix path's."""
+    nlist take 16 strips and a 1024 / 2048-column sample (coarse_fused_shape); nprobe > 32 bounds with two minima per lane."""
     import torch
     rng = np.random.default_rng(d + nlist + P)
     cc = (rng.standard_normal((nlist, d)) * 20).astype(np.float32)
