@@ -62,7 +62,10 @@ def test_random_configuration(seed):
             g.delete(dead)
             o.set_docids_bitmap(bm)
             o.delete(dead)
+        rng_mode = np.random.default_rng(77000 + seed)   # (its own stream: the configurations of old seeds stay as they were)
         for nq in (1, 23, int(rng.choice([300, 700]))):
+            # regular chain / small-batch chain / the latter with its long-row selection and unit work list forced
+            g.set_small_path(int(rng_mode.choice([0, 1, 1, 3])))
             q = synth.sift_like(nq, d=d, seed=900 + seed)
             if metric == B.METRIC_IP:
                 q = (q / np.maximum(np.linalg.norm(q, axis=1, keepdims=True), 1e-9)).astype(np.float32)
