@@ -1260,6 +1260,64 @@ int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, c
 // coarse quantizer (the IVFPQ one) -> slab offsets -> exact distance of every entry of the probed lists
 // (k_ivfflat_scan) -> top-k of the slab in (distance, scan position) order -> ids.  The reference's k-heap keeps
 // the same k entries (up to its order inside exact ties).
+// IVFFLAT, small batches: the chain of ivfpq_small without tables and re-rank -- exact coarse distances | top-nprobe +
+// slab offsets | exact distances of the probed lists' rows, one workgroup per pair | top-k + ids + score window
+int ivfflat_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int nq, const float* d_x, int k,
+                  float* d_distances, int64_t* d_labels) {
+    const int P = p->nprobe, d = h->d, nlist = h->nlist;
+    const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
+    hipStream_t s = h->stream;
+    const int ver = h->cur_ver;
+    GH_CHECK(h, hipStreamWaitEvent(s, h->ver_ev[ver], 0));
+    GH_CHECK(h, h->w_mat.ensure((size_t)nq * nlist * sizeof(float)));
+    GH_CHECK(h, h->w_coarse_dis.ensure((size_t)nq * P * sizeof(float)));
+    GH_CHECK(h, h->w_probe.ensure((size_t)nq * P * sizeof(int)));
+    GH_CHECK(h, h->w_pair_off.ensure((size_t)nq * (P + 1) * sizeof(int)));
+    GH_CHECK(h, h->w_pair_base.ensure((size_t)nq * P * sizeof(int64_t)));
+    GH_CHECK(h, h->w_qtotal.ensure((size_t)nq * sizeof(int)));
+    GH_CHECK(h, h->w_cand_pos.ensure((size_t)nq * k * sizeof(int)));
+    GH_CHECK(h, h->w_cand_dis.ensure((size_t)nq * k * sizeof(float)));
+    GH_CHECK(h, h->w_cand_ids.ensure((size_t)nq * k * sizeof(int64_t)));
+    const int64_t q_stride = (std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len)) + 3) & ~(int64_t)3;
+    GH_CHECK(h, h->w_dist.ensure((size_t)nq * q_stride * sizeof(float)));
+    if (p->coarse_mode == 1) {
+        gh::launch_l2_gemmform(s, d_x, nq, d, h->d_cc, nlist, nullptr, h->d_cc_norms, h->w_mat.as<float>(), nlist, true);
+    } else if (!gh::launch_small_coarse_ip(s, d_x, nq, d, h->d_cc, nlist, h->w_mat.as<float>(), 0, nullptr, nullptr)) {
+        return fail(h, GAMMA_HIP_EINVAL, "small path: shape not covered");
+    }
+    gh::launch_small_coarse_select(s, h->w_mat.as<float>(), nlist, nq, P, h->w_coarse_dis.as<float>(), h->w_probe.as<int>(),
+                                   h->d_list_len, h->d_list_mask, h->d_list_off, h->w_pair_off.as<int>(),
+                                   h->w_qtotal.as<int>(), h->w_pair_base.as<int64_t>());
+    const int need_filter = (fc.any_clause || (h->d_bitmap && h->bitmap_any)) ? 1 : 0;
+    gh::launch_ivfflat_scan(s, l2, d_x, nq, d, P, h->w_pair_off.as<int>(), h->w_pair_base.as<int64_t>(), h->d_ids, h->d_raw,
+                            h->nraw, q_stride, h->w_dist.as<float>(), fc.d_tab, need_filter, p->min_score, p->max_score);
+    int smax = 0;   // long candidate rows: two-level selection (ivfpq_small)
+    {
+        const int64_t slice = 16384;
+        const int64_t est = (int64_t)P * (h->ntotal / std::max(1, nlist)) * 3 / 2;
+        const int64_t bound = (int64_t)P * std::max(1, h->max_list_len);
+        if (h->small_presel > 0) smax = h->small_presel;
+        else if (est > slice) smax = (int)std::min<int64_t>(std::min<int64_t>(64, (bound + slice - 1) / slice), std::max(2, 4096 / nq));
+        if (smax > 0) {
+            GH_CHECK(h, h->w_selv.ensure((size_t)nq * smax * k * sizeof(float)));
+            GH_CHECK(h, h->w_selp.ensure((size_t)nq * smax * k * sizeof(int)));
+        }
+    }
+    const float neutral = l2 ? 3.402823466e+38f : -3.402823466e+38f;
+    gh::launch_small_tail(s, l2, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), nq, k, P, h->w_probe.as<int>(),
+                          h->w_pair_off.as<int>(), h->d_list_off, h->d_ids, h->w_cand_dis.as<float>(),
+                          h->w_cand_pos.as<int>(), h->w_cand_ids.as<int64_t>(), 0, d_x, d, h->d_raw, h->nraw, k, p->min_score,
+                          p->max_score, neutral, d_distances, d_labels, smax, smax ? h->w_selv.as<float>() : nullptr,
+                          smax ? h->w_selp.as<int>() : nullptr);
+    GH_CHECK(h, hipEventRecord(h->rd_ev[ver], s));
+    h->rd_set[ver] = true;
+    h->last_nq = nq;
+    h->last_P = P;
+    h->last_R = k;
+    GH_CHECK(h, hipGetLastError());
+    return GAMMA_HIP_OK;
+}
+
 int ivfflat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, int k,
                                  float* d_distances, int64_t* d_labels) {
     GH_TRY(check_params(h, p, nq, k));
@@ -1279,6 +1337,13 @@ int ivfflat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq,
     if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;   // faiss:utils/distances.cpp:303,346, whole call
     const int P = pp.nprobe, nlist = h->nlist;
     hipStream_t s = h->stream;
+    {   // small batches, as long as the pair-per-workgroup scan is the one that would run anyway (below 2 nlist pairs)
+        static const bool off = getenv("GAMMA_HIP_NO_SMALL_PATH") != nullptr;
+        if (!off && h->small_path && nq <= 512 && (pp.coarse_mode == 1 || nq <= 16) && P <= 64 && k <= 1024 && !h->profile &&
+            !fc.d_qf && !h->d_list_mask && nlist <= 16384 && (int64_t)nq * P < 2 * (int64_t)nlist &&
+            (int64_t)P * std::max(1, h->max_list_len) <= (1 << 22))
+            return ivfflat_small(h, &pp, fc, nq, d_x, k, d_distances, d_labels);
+    }
     const int chunk = scan_chunk(h, nq, P);
     const int need_filter = (fc.any_clause || (h->d_bitmap && h->bitmap_any)) ? 1 : 0;
     for (int q0 = 0; q0 < nq; q0 += chunk) {

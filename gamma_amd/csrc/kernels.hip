@@ -833,7 +833,7 @@ __global__ __launch_bounds__(256) void k_small_coarse_ip(const float* __restrict
 }
 bool launch_small_coarse_ip(hipStream_t s, const float* x, int nq, int d, const float* cc, int nlist, float* mat, int M,
                             const float* pqc, float* st2, int* zero_me) {
-    if (nq <= 0 || nq > 2 * IPT_QB || d % M) return false;
+    if (nq <= 0 || nq > 2 * IPT_QB || M < 0 || (M > 0 && d % M)) return false;   // M = 0 (IVFFLAT): no query tables
     const int rb = (nlist + 31) / 32;
     hipLaunchKernelGGL(k_small_coarse_ip, dim3(rb + M), dim3(256), 0, s, x, nq, d, cc, nlist, mat, rb, M, pqc, st2, zero_me);
     return true;

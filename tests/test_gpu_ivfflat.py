@@ -119,3 +119,52 @@ def test_ivfflat_add_update_delete_follow_the_reference_lists():
     finally:
         B.lib().go_set_assign_mode(0)
         g.close()
+
+
+@pytest.mark.parametrize("metric,d,nlist", [(B.METRIC_L2, 32, 256), (B.METRIC_IP, 100, 256), (B.METRIC_L2, 128, 1024)])
+def test_ivfflat_small_batch_chain_is_the_regular_chain(metric, d, nlist):
+    """Small calls (fewer (query, probe) pairs than 2 nlist) run as four launches (gamma_hip.cpp ivfflat_small): results
+    byte for byte those of the regular chain -- deletes, a range filter, a score window, k beyond the candidates, the
+    two-level selection forced -- and the oracle's."""
+    case = fixtures.trained_case(d=d, nlist=nlist, M=d // 4, N=20000, nq=64, metric=B.METRIC_L2)
+    o = case["oracle"]
+    g = _load(case, metric)
+    rng = np.random.default_rng(d + nlist)
+    N = case["N"]
+    try:
+        for step in range(2):
+            kw_f = {}
+            ctx_kw = {}
+            if step == 1:
+                dead = rng.choice(N, N // 7, replace=False)
+                bm = np.zeros((N >> 3) + 1, dtype=np.uint8)
+                np.bitwise_or.at(bm, dead >> 3, (1 << (dead & 7)).astype(np.uint8))
+                g.bitmap_upload(bm, N)
+                docs = rng.choice(N, N // 2, replace=False)
+                kw_f = dict(range_filters=[api.make_range_filter(docs)])
+                ctx_kw = dict(docids_bitmap=bm, range_filters=[B.make_range_filter(docs)])
+            for nq in (1, 3, 16, 17, 40, 64):
+                q = case["q"][:nq]
+                for P, k in ((1, 10), (8, 10), (4, 300), (min(64, 2 * nlist // nq - 1), 50)):
+                    if nq * P >= 2 * nlist:
+                        continue
+                    wins = [WIDE]
+                    g.set_small_path(0)
+                    Dw, _ = g.ivfflat_search(q, k, api.SearchArgs(metric=metric, nprobe=P, **WIDE, **kw_f))
+                    fin = Dw[np.isfinite(Dw) & (np.abs(Dw) < 1e37)]
+                    if len(fin) > 4:
+                        wins.append(dict(min_score=float(np.quantile(fin, 0.2)), max_score=float(np.quantile(fin, 0.8))))
+                    for kw in wins:
+                        args = api.SearchArgs(metric=metric, nprobe=P, **kw, **kw_f)
+                        g.set_small_path(0)
+                        D0, I0 = g.ivfflat_search(q, k, args)
+                        for mode in (1, 3):
+                            g.set_small_path(mode)
+                            D1, I1 = g.ivfflat_search(q, k, args)
+                            assert D0.tobytes() == D1.tobytes() and np.array_equal(I0, I1), (step, nq, P, k, mode)
+                    D, I = B.ivfflat_search(o, q, k, P, metric, B.make_ctx(**WIDE, **ctx_kw))
+                    g.set_small_path(1)
+                    Dg, Ig = g.ivfflat_search(q, k, api.SearchArgs(metric=metric, nprobe=P, **WIDE, **kw_f))
+                    compare_topk(D, I, Dg, Ig)
+    finally:
+        g.close()
