@@ -218,6 +218,9 @@ struct gamma_hip_index {
     // pinned staging of the combined batches, two sets (only the worker touches them)
     void* comb_pin[2] = {nullptr, nullptr};
     size_t comb_pin_bytes[2] = {0, 0};
+    // pinned staging of small direct calls (host_search; the search lock serialises its users)
+    void* dir_pin = nullptr;
+    size_t dir_pin_bytes = 0;
 
     // profiling
     bool profile = false;
@@ -1527,6 +1530,42 @@ int host_search(H* h, int nq, int d, const float* x, int k, float* distances, in
     GH_CHECK(h, h->w_x.ensure((size_t)nq * d * sizeof(float)));
     GH_CHECK(h, h->w_outd.ensure((size_t)nq * k * sizeof(float)));
     GH_CHECK(h, h->w_outl.ensure((size_t)nq * k * sizeof(int64_t)));
+    // Small synchronous calls (a client thread's single query): the caller's buffers are pageable, and a pageable
+    // copy is a blocking staged transfer -- three of them cost more than the search chain.  Queries and results go
+    // through a pinned staging area instead: the copies are true asynchronous transfers in stream order, the thread
+    // blocks once, and the results are copied out by the CPU.
+    const size_t bx = (size_t)nq * d * sizeof(float), bd = (size_t)nq * k * sizeof(float), bi = (size_t)nq * k * sizeof(int64_t);
+    const size_t off_i = (bx + 63) & ~(size_t)63, off_d = off_i + ((bi + 63) & ~(size_t)63), need = off_d + bd;
+    static const bool no_pin = getenv("GAMMA_HIP_NO_PINNED_CALLS") != nullptr;
+    if (sync && !no_pin && need <= ((size_t)1 << 20)) {
+        if (need > h->dir_pin_bytes) {
+            if (h->dir_pin) (void)hipHostFree(h->dir_pin);
+            h->dir_pin = nullptr;
+            h->dir_pin_bytes = 0;
+            GH_CHECK(h, hipHostMalloc(&h->dir_pin, std::max<size_t>(need * 2, 65536), hipHostMallocDefault));
+            h->dir_pin_bytes = std::max<size_t>(need * 2, 65536);
+        }
+        char* base = static_cast<char*>(h->dir_pin);
+        std::memcpy(base, x, bx);
+        GH_CHECK(h, hipMemcpyAsync(h->w_x.p, base, bx, hipMemcpyHostToDevice, h->stream));
+        // results: the last kernel of the chain stores them straight into the staging area (pinned host memory is
+        // mapped into the device's address space; a few KB of posted writes) -- no copy back at all
+        static const bool no_map = getenv("GAMMA_HIP_NO_MAPPED_RESULTS") != nullptr;
+        void* dbase = nullptr;
+        if (!no_map && hipHostGetDevicePointer(&dbase, base, 0) == hipSuccess && dbase) {
+            char* db = static_cast<char*>(dbase);
+            GH_TRY(f(h->w_x.as<float>(), reinterpret_cast<float*>(db + off_d), reinterpret_cast<int64_t*>(db + off_i)));
+        } else {
+            GH_TRY(f(h->w_x.as<float>(), h->w_outd.as<float>(), h->w_outl.as<int64_t>()));
+            GH_CHECK(h, hipMemcpyAsync(base + off_d, h->w_outd.p, bd, hipMemcpyDeviceToHost, h->stream));
+            GH_CHECK(h, hipMemcpyAsync(base + off_i, h->w_outl.p, bi, hipMemcpyDeviceToHost, h->stream));
+        }
+        if (lk) lk->enqueued();
+        GH_CHECK(h, hipStreamSynchronize(h->stream));
+        std::memcpy(distances, base + off_d, bd);
+        std::memcpy(labels, base + off_i, bi);
+        return GAMMA_HIP_OK;
+    }
     GH_CHECK(h, hipMemcpyAsync(h->w_x.p, x, (size_t)nq * d * sizeof(float), hipMemcpyHostToDevice, h->stream));
     GH_TRY(f(h->w_x.as<float>(), h->w_outd.as<float>(), h->w_outl.as<int64_t>()));
     GH_CHECK(h, hipMemcpyAsync(distances, h->w_outd.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -1628,6 +1667,7 @@ int gamma_hip_destroy(gamma_hip_index* h) {
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
     for (void* pp : h->comb_pin)
         if (pp) (void)hipHostFree(pp);
+    if (h->dir_pin) (void)hipHostFree(h->dir_pin);
     DevBuf* bufs[] = {&h->w_mat, &h->w_coarse_dis, &h->w_probe, &h->w_xn, &h->w_st2, &h->w_pair_off,
                       &h->w_qtotal, &h->w_dist, &h->w_cand_dis, &h->w_cand_pos, &h->w_cand_ids,
                       &h->w_exact, &h->w_selv, &h->w_selp, &h->w_x, &h->w_outd, &h->w_outl, &h->w_stage,
