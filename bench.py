@@ -269,6 +269,15 @@ def main():
                         200 if nqb < 1024 else 100, 10)
             byb[str(nqb)] = {"qps": round(nqb / sec, 1), "us_per_call": round(sec * 1e6, 1)}
         extra["qps_by_batch"] = byb
+        # (b') the same single query through the host-buffer entry point (what the plugin calls): pageable numpy
+        #      buffers in and out, the call returns when the results are there
+        hq = np.ascontiguousarray(queries[:1])
+        ts = []
+        for i in range(220):
+            t0 = time.perf_counter()
+            g.ivfpq_search(hq, k, args)
+            ts.append(time.perf_counter() - t0)
+        extra["single_query_host_call_us"] = round(float(np.median(ts[20:])) * 1e6, 1)
         # (c) the coarse path that is bit-identical to the compiled reference at every batch size (exact
         #     fvec_L2sqr per pair instead of the GEMM form; faiss itself switches to sgemm at 20 queries)
         args0 = api.SearchArgs(metric=api.METRIC_L2, nprobe=a.nprobe, recall_num=a.recall_num,
