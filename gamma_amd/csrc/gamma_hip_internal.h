@@ -1,0 +1,369 @@
+// gamma_hip_internal.h -- the handle of libgamma_hip.so (HBM-resident state, workspaces, locks) and the helpers its
+// translation units share: gamma_hip.cpp (life cycle, switches, accounting), gamma_hip_store.cpp (realtime lists,
+// raw store, columns, bitmap: the writers), gamma_hip_search.cpp (the search pipelines and their entry points).
+#pragma once
+#include "../../include/gamma_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <map>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "kernels.h"
+
+namespace ghi {
+
+constexpr double kPI = 3.14159265;  // realtime/realtime_mem_data.h:24
+constexpr int64_t kDelMask = (int64_t)(1ULL << 63);
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) {
+            hipError_t e = hipFree(p);
+            if (e != hipSuccess) return e;
+            p = nullptr;
+            cap = 0;
+        }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return e;
+        }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T>
+    T* as() const {
+        return reinterpret_cast<T*>(p);
+    }
+};
+
+struct StageEvent {
+    int stage;
+    hipEvent_t a, b;
+    bool count;
+};
+
+}  // namespace ghi
+using ghi::DevBuf;
+using ghi::StageEvent;
+
+struct WriteLock;
+
+struct gamma_hip_index {
+    int device = 0;
+    // Concurrency (SURVEY 8b "Threading": Search from any number of client threads while ONE indexing thread adds
+    // and API threads delete; the reference's lists are lock-free for readers, realtime_mem_data.cc:279-300):
+    //   stream / search_mu : searches.  One at a time (they share the workspaces); search_mu is held for a whole
+    //                        call, mu only while the call reads the handle's state and enqueues its kernels.
+    //   wstream / writer_mu: writers (list appends, encode, raw / bitmap / column updates) on their own stream, so
+    //                        they neither wait for the searches in flight nor hold them up; mu while they work.
+    //   list meta versions : a search's kernels read the (offset, length) table of the VERSION that was current
+    //                        when it was enqueued; a writer publishes a new version after its copies (the
+    //                        reference publishes retrieve_idx_pos_ after the copy, realtime_mem_data.cc:299-300).
+    //                        Old extents stay intact inside the arena, so a search in flight keeps reading a
+    //                        consistent prefix of the insert log.
+    //   reallocation       : growing the arena / raw store / bitmap frees memory a search in flight may read --
+    //                        the writer then takes search_mu too and drains both streams first (WriteLock::exclusive).
+    // Lock order: writer_mu -> search_mu -> mu.
+    hipStream_t stream = nullptr, wstream = nullptr;
+    std::mutex mu, search_mu, writer_mu;
+    WriteLock* wl = nullptr;   // the writer holding mu (for exclusive() deep inside the arena code)
+    static constexpr int NVER = 4;
+    int64_t* d_ver_off[NVER] = {nullptr, nullptr, nullptr, nullptr};
+    int* d_ver_len[NVER] = {nullptr, nullptr, nullptr, nullptr};
+    void* pin_ver[NVER] = {nullptr, nullptr, nullptr, nullptr};   // pinned staging of a version's tables
+    hipEvent_t ver_ev[NVER] = {nullptr, nullptr, nullptr, nullptr};   // wstream: the version's tables are in place
+    hipEvent_t rd_ev[NVER] = {nullptr, nullptr, nullptr, nullptr};    // stream: the last search reading it is past its list kernels
+    bool rd_set[NVER] = {false, false, false, false};
+    int cur_ver = 0;
+    std::string err;
+
+    // raw vector store
+    int raw_d = 0;
+    float* d_raw = nullptr;
+    int64_t nraw = 0, raw_cap = 0;
+
+    // numeric scalar columns (on-device range filters)
+    struct Column {
+        int dtype = 0;
+        uint8_t* d = nullptr;
+        int64_t n = 0, cap = 0;
+    };
+    std::map<int, Column> fields;
+    // STRING columns as dictionary-encoded item lists (on-device term filters): doc i = tok[off[i] .. off[i + 1])
+    struct TermColumn {
+        int64_t* d_off = nullptr;
+        int32_t* d_tok = nullptr;
+        int64_t ndocs = 0, cap_docs = 0, ntok = 0, cap_tok = 0;
+    };
+    std::map<int, TermColumn> terms;
+
+    // delete bitmap
+    uint8_t* d_bitmap = nullptr;
+    int64_t bitmap_bits = 0;
+    size_t bitmap_cap_bytes = 0;
+    std::vector<uint8_t> h_bitmap;
+    bool bitmap_any = false;   // any delete bit set
+    int64_t n_moved = 0;       // inverted-list slots marked superseded (bit 63) since creation
+
+    // IVFPQ model
+    bool ivf_init = false, trained = false;
+    int d = 0, nlist = 0, M = 0, ksub = 256, dsub = 0, code_size = 0, metric = GAMMA_HIP_METRIC_L2;
+    int bucket_init = 1000, bucket_max = 1280000;
+    float *d_cc = nullptr, *d_cc_norms = nullptr, *d_pqc = nullptr, *d_T2 = nullptr;
+    int* d_list_rank = nullptr;   // spatial order of the coarse centroids (scan locality only)
+    bool sort_queries = getenv("GAMMA_HIP_NO_QUERY_SORT") == nullptr;
+    bool scan_bound = getenv("GAMMA_HIP_NO_SCAN_BOUND") == nullptr;
+
+    // inverted-list arena
+    uint8_t* d_codes = nullptr;
+    int64_t* d_ids = nullptr;
+    int64_t arena_cap = 0, arena_used = 0, arena_waste = 0;   // entries; waste = abandoned extents inside used
+    int64_t repack_min_entries = 1 << 16;                     // no repack for less waste than this
+    int64_t n_repacks = 0;
+    std::vector<int64_t> h_list_off;
+    std::vector<int> h_list_len, h_list_cap, h_deleted;
+    std::vector<uint8_t> h_extend_time;
+    int64_t* d_list_off = nullptr;
+    int* d_list_len = nullptr;
+    uint8_t* d_list_mask = nullptr;
+    std::vector<uint8_t> h_list_mask;
+    std::vector<int64_t> vid_pos;
+    int max_list_len = 0;
+    int64_t ntotal = 0;
+
+    // workspace
+    DevBuf w_mat, w_coarse_dis, w_probe, w_xn, w_st2, w_pair_off, w_qtotal, w_dist, w_cand_dis,
+            w_cand_pos, w_cand_ids, w_exact, w_selv, w_selp, w_x, w_outd, w_outl, w_stage, w_filter,
+            w_m_dis, w_m_ids, w_part_v, w_part_i, w_assign, w_codes_tmp, w_qperm, w_scnt, w_sflag, w_surv, w_pair_base,
+            w_pair_ip, w_flat_cand, w_flat_meta, w_full_cdis, w_full_probe, w_ftab, w_qfil, w_tieflag, w_tcut, w_tlist, w_survc, w_lm_units, w_lm_cnt,
+            we_mat, we_cdis, we_x, we_assign, we_codes, we_stage;   // writer side (encode, bitmap_set): never shared with a search
+    unsigned long long* d_scan_codes = nullptr;
+    size_t dist_budget_bytes = (size_t)8 << 30;   // per-chunk ADC distance buffer (288 GB of HBM per GPU)
+
+    // device copy of the filter table of the running call (entry 0 = the call's own descriptor) and the
+    // host image of what entry 0 holds, so an unchanged descriptor is not uploaded again
+    gh::FilterDesc ftab_shadow;
+    bool ftab_valid = false;
+
+    bool exact_ties = false;   // gamma_hip_set_exact_ties
+    bool list_major = false;   // gamma_hip_set_list_major
+    bool coarse_fused = true;  // gamma_hip_set_coarse_fused
+    bool small_path = true;    // gamma_hip_set_small_path
+    int small_presel = 0;      // 0: pre-selection by estimate, > 0: always, that many slices (tests)
+    // multi-vector documents (VIDMgr::VID2DocID, vector/raw_vector_common.h:90-95): docid of every vid, host + device;
+    // empty = single-vector documents, docid == vid.  Every delete-bitmap / filter test goes through it.
+    std::vector<int32_t> h_v2d;
+    int32_t* d_v2d = nullptr;
+    int64_t v2d_cap = 0;
+    int64_t doc_of(int64_t v) const { return (v >= 0 && (size_t)v < h_v2d.size()) ? (int64_t)h_v2d[v] : v; }
+    bool doc_deleted(int64_t v) const {
+        const int64_t dd = doc_of(v);
+        return dd >= 0 && dd < bitmap_bits && !h_bitmap.empty() && ((h_bitmap[dd >> 3] >> (dd & 7)) & 1);
+    }
+    bool ivfflat = false;      // gamma_hip_ivfflat_init: lists of vector ids (1 dummy code byte), rows from the raw store
+    int coarse_cap = gh::kCoarseCap;
+    unsigned long long* d_tie_stats = nullptr;   // {coarse rows redone, top-R cuts through a tie, queries replayed}
+    // what stage A leaves for the tie replay of stage B (ties.hip)
+    struct TieCtx {
+        bool on = false, bounded = false;
+        int G = 0, nsl = 0, cap = 0;
+        int64_t q_stride = 0;
+    } tie;
+
+    // last-search stage info
+    int last_nq = 0, last_P = 0, last_R = 0;
+    const int* last_qperm = nullptr;   // query order of the last stage A (null: arrival order)
+
+    // request combining of small concurrent host-buffer searches (gamma_hip_ivfpq_search)
+    struct Waiter {
+        const gamma_hip_search_params* p;
+        int nq, k, mode;   // mode: coarse path resolved from THIS request's size
+        int kind = 0;      // 0: IVFPQ search, 1: flat search
+        const float* x;
+        float* D;
+        int64_t* I;
+        int rc = 0;
+        bool done = false;
+        std::condition_variable cv;   // woken when done
+    };
+    std::mutex comb_mu;
+    std::condition_variable comb_wcv;   // the worker waits here
+    std::deque<Waiter*> comb_q;
+    bool comb_busy = false;             // a batch (or a direct call) is in flight
+    bool comb_stop = false;
+    std::thread comb_thread;
+    bool combine = getenv("GAMMA_HIP_NO_COMBINE") == nullptr;
+    // pinned staging of the combined batches, two sets (only the worker touches them)
+    void* comb_pin[2] = {nullptr, nullptr};
+    size_t comb_pin_bytes[2] = {0, 0};
+    // pinned staging of small direct calls (host_search; the search lock serialises its users)
+    void* dir_pin = nullptr;
+    size_t dir_pin_bytes = 0;
+
+    // profiling
+    bool profile = false;
+    std::vector<StageEvent> events;
+    std::vector<hipEvent_t> event_pool;
+    double stage_ms[GAMMA_HIP_NUM_STAGES] = {0};
+    int64_t stage_n[GAMMA_HIP_NUM_STAGES] = {0};
+    int64_t scan_pairs = 0;
+};
+
+// a writer call: writer_mu (one writer at a time) + mu; exclusive() before memory that a search in flight may be
+// reading is freed or moved: search_mu as well (no search can start), both streams drained
+struct WriteLock {
+    gamma_hip_index* h;
+    std::unique_lock<std::mutex> w, s, m;
+    explicit WriteLock(gamma_hip_index* h_) : h(h_), w(h_->writer_mu), s(h_->search_mu, std::defer_lock), m(h_->mu) { h->wl = this; }
+    ~WriteLock() { h->wl = nullptr; }
+    hipError_t exclusive() {
+        if (!s.owns_lock()) {
+            m.unlock();
+            s.lock();
+            m.lock();
+        }
+        hipError_t e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->wstream);
+        return e;
+    }
+};
+
+namespace ghi {
+
+using H = gamma_hip_index;
+
+// a search-type call: search_mu for the whole call, mu while it reads the handle and enqueues
+struct SearchLock {
+    std::unique_lock<std::mutex> s, m;
+    explicit SearchLock(H* h) : s(h->search_mu), m(h->mu) {}
+    void enqueued() {   // everything is on the stream: writers may go on while the call waits for the GPU
+        if (m.owns_lock()) m.unlock();
+    }
+};
+
+#define GH_CHECK(h, expr)                                                                  \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                  \
+            return e_ == hipErrorOutOfMemory ? GAMMA_HIP_ENOMEM : GAMMA_HIP_EDEVICE;       \
+        }                                                                                  \
+    } while (0)
+
+#define GH_TRY(expr)                   \
+    do {                               \
+        int rc_ = (expr);              \
+        if (rc_ != GAMMA_HIP_OK) return rc_; \
+    } while (0)
+
+inline int fail(H* h, int code, const char* msg) {
+    h->err = msg;
+    return code;
+}
+
+struct StageScope {
+    H* h;
+    int stage;
+    bool count;   // false: add the time to the stage but do not count a new invocation
+    hipEvent_t a = nullptr, b = nullptr;
+    StageScope(H* h_, int st, bool count_ = true) : h(h_), stage(st), count(count_) {
+        if (h->profile) {
+            // events are recycled: creating / destroying two per stage and step costs the host
+            // more than the stages' launches
+            auto take = [&]() -> hipEvent_t {
+                if (!h->event_pool.empty()) {
+                    hipEvent_t e = h->event_pool.back();
+                    h->event_pool.pop_back();
+                    return e;
+                }
+                hipEvent_t e = nullptr;
+                return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+            };
+            a = take();
+            b = take();
+            if (!a || !b) {
+                a = b = nullptr;
+                return;
+            }
+            (void)hipEventRecord(a, h->stream);
+        }
+    }
+    ~StageScope() {
+        if (a && b) {
+            (void)hipEventRecord(b, h->stream);
+            h->events.push_back({stage, a, b, count});
+        }
+    }
+};
+
+inline int drain_events(H* h) {
+    if (h->events.empty()) return GAMMA_HIP_OK;
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    for (auto& e : h->events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            h->stage_ms[e.stage] += ms;
+            h->stage_n[e.stage] += e.count ? 1 : 0;
+        }
+        h->event_pool.push_back(e.a);
+        h->event_pool.push_back(e.b);
+    }
+    h->events.clear();
+    return GAMMA_HIP_OK;
+}
+
+inline double extend_coefficient(uint8_t t) { return 1.1 + kPI / 2 - atan((double)t); }
+
+// A new version of the lists' (offset, length) tables: what the host mirror holds, copied through the
+// version's pinned staging on the writer stream -- behind the data copies of the writer that calls this, so a
+// search that uses the version finds the entries in place (publish after write, realtime_mem_data.cc:299-300).
+// The slot that is overwritten was current NVER - 1 versions ago; the last search that read it is awaited first.
+inline int publish_meta(H* h) {
+    const int v = (h->cur_ver + 1) % H::NVER;
+    if (h->rd_set[v]) GH_CHECK(h, hipStreamWaitEvent(h->wstream, h->rd_ev[v], 0));
+    // the staging itself: free once the copies of the version's previous use are done (the writer stream is
+    // drained at the end of every writer call, so they are)
+    int64_t* po = reinterpret_cast<int64_t*>(h->pin_ver[v]);
+    int* pl = reinterpret_cast<int*>(po + h->nlist);
+    memcpy(po, h->h_list_off.data(), (size_t)h->nlist * sizeof(int64_t));
+    memcpy(pl, h->h_list_len.data(), (size_t)h->nlist * sizeof(int));
+    GH_CHECK(h, hipMemcpyAsync(h->d_ver_off[v], po, (size_t)h->nlist * sizeof(int64_t), hipMemcpyHostToDevice, h->wstream));
+    GH_CHECK(h, hipMemcpyAsync(h->d_ver_len[v], pl, (size_t)h->nlist * sizeof(int), hipMemcpyHostToDevice, h->wstream));
+    GH_CHECK(h, hipEventRecord(h->ver_ev[v], h->wstream));
+    h->cur_ver = v;
+    h->d_list_off = h->d_ver_off[v];
+    h->d_list_len = h->d_ver_len[v];
+    int mx = 0;
+    for (int l = 0; l < h->nlist; l++) mx = std::max(mx, h->h_list_len[l]);
+    h->max_list_len = mx;
+    return GAMMA_HIP_OK;
+}
+
+inline size_t field_elem_size(int dtype) {
+    return dtype == GAMMA_HIP_FIELD_INT || dtype == GAMMA_HIP_FIELD_FLOAT ? 4 : 8;
+}
+
+}  // namespace ghi

@@ -1,0 +1,1519 @@
+// gamma_hip_search.cpp -- the search pipelines of libgamma_hip.so (IVFPQ stages A and B, the small-batch chains, IVFFLAT,
+// flat), validity filters, the combining queue of small concurrent calls and the search entry points of the C ABI
+// (include/gamma_hip.h).  No CPU fallback: every entry point runs the HIP kernels or returns an error.
+#include "gamma_hip_internal.h"
+
+namespace ghi {
+
+
+// off != nullptr: the range bitmaps go to w_filter at *off (advanced; the caller has sized w_filter for all
+// the requests of a combined batch); nullptr: a call of its own, bitmaps from offset 0
+int build_filter(H* h, const gamma_hip_search_params* p, gh::FilterDesc* f, size_t* off_io = nullptr) {
+    memset(f, 0, sizeof(*f));
+    f->del_bitmap = h->d_bitmap;
+    f->del_bits = h->d_bitmap ? h->bitmap_bits : 0;
+    f->vid2doc = h->h_v2d.empty() ? nullptr : h->d_v2d;
+    f->n_vid2doc = (int64_t)h->h_v2d.size();
+    f->has_range = p->has_range ? 1 : 0;
+    f->n_range = p->has_range ? p->n_range : 0;
+    if (f->n_range > gh::kMaxRange) return fail(h, GAMMA_HIP_EINVAL, "too many range filters");
+    if (f->n_range > 0) {
+        size_t tot = 0;
+        for (int i = 0; i < f->n_range; i++) tot += ((size_t)p->range[i].bitmap_bytes + 15) & ~(size_t)15;
+        if (!off_io) GH_CHECK(h, h->w_filter.ensure(tot));
+        size_t off = off_io ? *off_io : 0;
+        for (int i = 0; i < f->n_range; i++) {
+            const gamma_hip_range_filter& r = p->range[i];
+            uint8_t* dst = h->w_filter.as<uint8_t>() + off;
+            GH_CHECK(h, hipMemcpyAsync(dst, r.bitmap, (size_t)r.bitmap_bytes, hipMemcpyHostToDevice,
+                                       h->stream));
+            f->range[i].bitmap = dst;
+            f->range[i].min_doc = r.min_doc;
+            f->range[i].max_doc = r.max_doc;
+            f->range[i].min_aligned = r.min_aligned;
+            f->range[i].b_not_in = r.b_not_in;
+            off += ((size_t)r.bitmap_bytes + 15) & ~(size_t)15;
+        }
+        if (off_io) *off_io = off;
+    }
+    f->n_field = p->n_field;
+    if (p->n_field < 0 || p->n_field > gh::kMaxField || (p->n_field > 0 && !p->field))
+        return fail(h, GAMMA_HIP_EINVAL, "bad field filters");
+    for (int i = 0; i < p->n_field; i++) {
+        const gamma_hip_field_filter& ff = p->field[i];
+        auto it = h->fields.find(ff.field_id);
+        if (it == h->fields.end()) return fail(h, GAMMA_HIP_EINVAL, "field filter on an unknown column");
+        gh::FieldDesc& fd = f->field[i];
+        fd.col = it->second.d;
+        fd.n = it->second.n;
+        fd.dtype = it->second.dtype;
+        fd.incl = (ff.include_lower ? 1 : 0) | (ff.include_upper ? 2 : 0);
+        fd.lo_i = ff.lower_i;
+        fd.hi_i = ff.upper_i;
+        fd.lo_f = ff.lower_f;
+        fd.hi_f = ff.upper_f;
+    }
+    f->n_term = p->n_term;
+    if (p->n_term < 0 || p->n_term > gh::kMaxTerm || (p->n_term > 0 && !p->term))
+        return fail(h, GAMMA_HIP_EINVAL, "bad term filters");
+    for (int i = 0; i < p->n_term; i++) {
+        const gamma_hip_term_filter& tf = p->term[i];
+        auto it = h->terms.find(tf.field_id);
+        if (it == h->terms.end()) return fail(h, GAMMA_HIP_EINVAL, "term filter on an unknown column");
+        if (tf.n_items < 0 || tf.n_items > gh::kMaxTermItems || tf.op < 0 || tf.op > 2)
+            return fail(h, GAMMA_HIP_EINVAL, "bad term filter");
+        gh::TermDesc& td = f->term[i];
+        td.off = it->second.d_off;
+        td.tok = it->second.d_tok;
+        td.n = it->second.ndocs;
+        td.op = tf.op;
+        td.n_items = tf.n_items;
+        for (int k = 0; k < tf.n_items; k++) td.items[k] = tf.items[k];
+    }
+    return GAMMA_HIP_OK;
+}
+
+// What the scan needs to know about the validity predicates of a call: the device filter table, the
+// optional query -> entry map (combined batches of requests with their own filters), and whether
+// anything but the delete bitmap can reject an entry.
+struct FiltCtx {
+    const gh::FilterDesc* d_tab = nullptr;
+    const int* d_qf = nullptr;
+    bool any_clause = false;
+    FiltCtx at(int q0) const {   // the same context for the queries from q0 on
+        FiltCtx c = *this;
+        if (c.d_qf) c.d_qf += q0;
+        return c;
+    }
+};
+
+int filt_ctx_single(H* h, const gh::FilterDesc& f, FiltCtx* c) {
+    GH_CHECK(h, h->w_ftab.ensure(sizeof(gh::FilterDesc)));
+    if (!h->ftab_valid || memcmp(&h->ftab_shadow, &f, sizeof(f)) != 0) {
+        // the stream may still be reading the previous image: the copy is ordered behind it
+        h->ftab_shadow = f;
+        h->ftab_valid = true;
+        GH_CHECK(h, hipMemcpyAsync(h->w_ftab.p, &h->ftab_shadow, sizeof(f), hipMemcpyHostToDevice, h->stream));
+    }
+    c->d_tab = h->w_ftab.as<gh::FilterDesc>();
+    c->d_qf = nullptr;
+    c->any_clause = f.has_range || f.n_field > 0 || f.n_term > 0;
+    return GAMMA_HIP_OK;
+}
+
+int check_params(H* h, const gamma_hip_search_params* p, int nq, int k) {
+    if (!p) return fail(h, GAMMA_HIP_EINVAL, "null params");
+    if (nq < 0) return fail(h, GAMMA_HIP_EINVAL, "nq < 0");
+    if (p->metric != GAMMA_HIP_METRIC_IP && p->metric != GAMMA_HIP_METRIC_L2)
+        return fail(h, GAMMA_HIP_EINVAL, "bad metric");
+    if (k > 4096) return fail(h, GAMMA_HIP_EINVAL, "k > 4096 unsupported");
+    return GAMMA_HIP_OK;
+}
+
+// ---- IVFPQ stage A: coarse + tables + scan + top-R + ids ------------------------------
+// results: w_cand_dis [nq*R] (ADC distance, best first, sentinel pad), w_cand_ids [nq*R]
+int ivfpq_coarse(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, float* out_dis = nullptr,
+                 int* out_probe = nullptr) {
+    const int P = p->nprobe, d = h->d, nlist = h->nlist;
+    hipStream_t s = h->stream;
+    int mode = p->coarse_mode;
+    if (mode < 0) mode = nq < 20 ? 0 : 1;  // faiss:utils/distances.cpp:303,346
+    // large batches: no distance matrix (coarse.hip); exact ties replay rows of the matrix, so they keep it
+    const bool fused = mode == 1 && h->coarse_fused && !h->exact_ties && gh::coarse_fused_supported(nq, d, nlist, P);
+    gh::CoarseFusedPlan plan;
+    if (fused) {
+        plan = gh::coarse_fused_plan(nq, nlist, P, h->coarse_cap);
+        GH_CHECK(h, h->w_mat.ensure(plan.bytes));
+    } else {
+        GH_CHECK(h, h->w_mat.ensure((size_t)nq * nlist * sizeof(float)));
+    }
+    if (!out_dis || !out_probe) {   // the workspace the scan reads
+        GH_CHECK(h, h->w_coarse_dis.ensure((size_t)nq * P * sizeof(float)));
+        GH_CHECK(h, h->w_probe.ensure((size_t)nq * P * sizeof(int)));
+        out_dis = h->w_coarse_dis.as<float>();
+        out_probe = h->w_probe.as<int>();
+    }
+    StageScope t(h, GAMMA_HIP_STAGE_COARSE);
+    if (fused) {
+        gh::launch_coarse_fused(s, plan, h->w_mat.p, d_x, nq, d, h->d_cc, nlist, h->d_cc_norms, P, out_dis, out_probe);
+        static const bool dbg = getenv("GAMMA_HIP_COARSE_DBG") != nullptr;
+        if (dbg) {   // how many queries the strip lists could not hold (they went through the repair kernel)
+            int n_ovf = 0;
+            GH_CHECK(h, hipStreamSynchronize(s));
+            GH_CHECK(h, hipMemcpy(&n_ovf, static_cast<char*>(h->w_mat.p) + plan.off_ovf, sizeof(int), hipMemcpyDeviceToHost));
+            fprintf(stderr, "coarse fused: nlist %d nprobe %d sample %d strips %d: %d of %d queries repaired\n", nlist, P,
+                    plan.sample, plan.nseg, n_ovf, nq);
+        }
+        return GAMMA_HIP_OK;
+    }
+    if (mode == 0) {
+        gh::launch_pairwise(s, true, d_x, nq, d, h->d_cc, nlist, h->w_mat.as<float>(), nlist);
+    } else {
+        // query norms: fused into the MFMA kernel (xn = nullptr) when a tile holds whole rows (d <= 128); longer rows
+        // get them from their own pass -- inside the K-slab loop they cost a fifth of the kernel (d = 768: 3.46 -> 2.72 ms
+        // per 8192 x 16384 with the conflict-free staging)
+        const float* xn = nullptr;
+        if (d > 128) {
+            GH_CHECK(h, h->w_xn.ensure((size_t)nq * sizeof(float)));
+            gh::launch_row_norms(s, d_x, nq, d, h->w_xn.as<float>());
+            xn = h->w_xn.as<float>();
+        }
+        gh::launch_l2_gemmform(s, d_x, nq, d, h->d_cc, nlist, xn, h->d_cc_norms,
+                               h->w_mat.as<float>(), nlist, true);
+    }
+    if (h->exact_ties) GH_CHECK(h, h->w_tieflag.ensure((size_t)nq));
+    gh::launch_coarse_select(s, h->w_mat.as<float>(), nlist, nq, P, out_dis, out_probe,
+                             h->exact_ties ? h->w_tieflag.as<uint8_t>() : nullptr, h->d_tie_stats);
+    return GAMMA_HIP_OK;
+}
+
+// pre_dis / pre_probe: coarse assignment computed elsewhere (sharded search: the rank owning the
+// query slice), device pointers [nq*nprobe]; nullptr = run the coarse quantizer here
+int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int nq,
+                  const float* d_x, int R, const float* pre_dis = nullptr, const int* pre_probe = nullptr,
+                  bool shard = false, float* out_dis = nullptr, int64_t* out_ids = nullptr) {
+    const int P = p->nprobe, d = h->d, M = h->M, nlist = h->nlist;
+    const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
+    hipStream_t s = h->stream;
+    // this call reads the lists through the version of their (offset, length) tables that is current now:
+    // behind the writer's copies (ver_ev), and the version is not reused before the kernels below are done (rd_ev)
+    const int ver = h->cur_ver;
+    GH_CHECK(h, hipStreamWaitEvent(s, h->ver_ev[ver], 0));
+    GH_CHECK(h, h->w_coarse_dis.ensure((size_t)nq * P * sizeof(float)));
+    GH_CHECK(h, h->w_probe.ensure((size_t)nq * P * sizeof(int)));
+    GH_CHECK(h, h->w_pair_off.ensure((size_t)nq * (P + 1) * sizeof(int)));
+    GH_CHECK(h, h->w_pair_base.ensure((size_t)nq * P * sizeof(int64_t)));
+    GH_CHECK(h, h->w_qtotal.ensure((size_t)nq * sizeof(int)));
+    GH_CHECK(h, h->w_cand_pos.ensure((size_t)nq * R * sizeof(int)));
+    // the top-R table goes to the workspace (stage B reads it there) or straight into the caller's
+    // buffers (sharded search: 12 B x R per query would otherwise be copied once more)
+    if (!out_dis) {
+        GH_CHECK(h, h->w_cand_dis.ensure((size_t)nq * R * sizeof(float)));
+        out_dis = h->w_cand_dis.as<float>();
+    }
+    if (!out_ids) {
+        GH_CHECK(h, h->w_cand_ids.ensure((size_t)nq * R * sizeof(int64_t)));
+        out_ids = h->w_cand_ids.as<int64_t>();
+    }
+    if (pre_dis && pre_probe) {
+        if (shard) {
+            // dense probe groups for the owned lists (kernels.hip, k_compact_probes)
+            gh::launch_compact_probes(s, pre_probe, pre_dis, nq, P, h->d_list_len, h->d_list_mask, nlist,
+                                      h->w_probe.as<int>(), h->w_coarse_dis.as<float>());
+        } else {
+            GH_CHECK(h, hipMemcpyAsync(h->w_coarse_dis.p, pre_dis, (size_t)nq * P * sizeof(float),
+                                       hipMemcpyDeviceToDevice, s));
+            GH_CHECK(h, hipMemcpyAsync(h->w_probe.p, pre_probe, (size_t)nq * P * sizeof(int),
+                                       hipMemcpyDeviceToDevice, s));
+        }
+    } else {
+        GH_TRY(ivfpq_coarse(h, p, nq, d_x));
+    }
+    h->scan_pairs += (int64_t)nq * P;
+    // ids are only read during the scan when something can reject an entry: a delete bit,
+    // a range filter, or a superseded (bit 63) slot left behind by Update
+    const int need_ids =
+            (fc.any_clause || (h->d_bitmap && h->bitmap_any) || h->n_moved > 0) ? 1 : 0;
+    const int* qperm = nullptr;
+    // Probes per workgroup.  Sharded search with a compacted assignment: a query keeps ~P/W probes on
+    // this shard, all in its first group(s) -- the other P/G - 1 workgroups of the query would start only
+    // to find nothing to do (at W = 8 that was half of the scan time).  When the expected candidate
+    // count per query is small, ONE workgroup takes all of a query's probes (G = P): it bounds the
+    // R-th best itself (producer path of the pre-filter, no consumers), and computes the query's PQ
+    // table on the fly instead of reading it back from HBM (IPF, kernels.hip).
+    // 8 probes per workgroup pay off with short lists (half the query-table re-reads, a tighter bound from a
+    // first group of 8 lists); long lists or many probes balance better with 4 (tools/shape_sweep.py)
+    int G0 = ((double)h->ntotal / std::max(1, nlist) <= 700.0 && P <= 64) ? 8 : 4;
+    int64_t t2_bytes = (int64_t)nlist * M * 256 * sizeof(float);
+    const bool compacted = shard && pre_dis && pre_probe;
+    if (compacted && h->scan_bound && R <= 256) {
+        int64_t owned = 0;
+        for (int l = 0; l < nlist; l++)
+            owned += h->h_list_len[l] > 0 && (h->h_list_mask.empty() || h->h_list_mask[l]);
+        t2_bytes = owned * M * 256 * (int64_t)sizeof(float);
+        const double exp_probes = (double)P * (double)owned / std::max(1, nlist);
+        const double exp_cand = exp_probes * (owned ? (double)h->ntotal / (double)owned : 0.0);
+        if (exp_cand <= 16384.0) {
+            G0 = 1;
+            while (G0 < P) G0 <<= 1;
+        }
+    }
+    const int G = gh::scan_group_size(nq, P, G0), PGN = (P + G - 1) / G;
+    // exact ties (ties.hip): queries whose top-R cut goes through a group of equal ADC distances are marked here
+    // and redone by the replay at the end of stage B
+    h->tie = H::TieCtx();
+    h->tie.on = h->exact_ties && !shard && R <= gh::tie_replay_max_k() && P <= gh::tie_replay_max_probes();
+    if (h->tie.on) {
+        GH_CHECK(h, h->w_tcut.ensure((size_t)nq));
+        GH_CHECK(h, h->w_tlist.ensure(((size_t)nq + 1) * sizeof(int)));   // count | list[nq]
+        GH_CHECK(h, hipMemsetAsync(h->w_tcut.p, 0, (size_t)nq, s));
+        GH_CHECK(h, hipMemsetAsync(h->w_tlist.p, 0, sizeof(int), s));
+    }
+    // Threshold pre-filter: scan the nearest probe group first, bound each query's R-th best
+    // distance from it, and let the scan of the remaining groups keep a short survivor list per
+    // query; the exact top-R then comes from a few hundred survivors instead of ~10^4 candidates
+    // (select.hip).  Queries without a usable bound fall back to the unfiltered selection.
+    // (sharded without a supplied assignment: probe groups are sparse, nothing to bound from)
+    // small batches: one probe per workgroup, a single list rarely holds R candidates, and the
+    // unfiltered selection is latency-bound anyway
+    // (one group per query -- few probes, or a shard -- is fine: the producer bounds and compacts its own candidates)
+    const bool bounded = (!shard || compacted) && h->scan_bound && R <= 256 && P <= 128 && G >= 4;
+    const bool fuse_ip = bounded && PGN == 1 && (M == 16 || M == 32) && !getenv("GAMMA_HIP_NO_FUSED_IP");
+    {
+        StageScope t(h, GAMMA_HIP_STAGE_TABLES);
+        if (!fuse_ip) {
+            GH_CHECK(h, h->w_st2.ensure((size_t)nq * M * 256 * sizeof(float)));
+            gh::launch_pq_ip_table(s, d_x, nq, d, M, h->d_pqc, h->w_st2.as<float>());
+        }
+        gh::launch_pair_offsets(s, h->w_probe.as<int>(), nq, P, h->d_list_len, h->d_list_mask, nlist,
+                                h->w_pair_off.as<int>(), h->w_qtotal.as<int>(),
+                                h->profile ? h->d_scan_codes : nullptr, h->d_list_off,
+                                h->w_pair_base.as<int64_t>());
+        // enough queries that L2 capacity matters: run them in spatial order (kernels.hip)
+        // (not when the T2 rows of the lists scanned here fit the L2s anyway: a shard of a small index)
+        if (h->sort_queries && h->d_list_rank && nq >= 256 && t2_bytes > ((int64_t)8 << 20)) {
+            GH_CHECK(h, h->w_qperm.ensure(((size_t)2 * nq + gh::query_order_bins()) * sizeof(int)));   // qperm | qkey | bins
+            gh::launch_query_order(s, h->w_probe.as<int>(), nq, P, h->d_list_rank, nlist,
+                                   h->w_qperm.as<int>() + nq, h->w_qperm.as<int>(), h->w_qperm.as<int>() + 2 * (size_t)nq);
+            qperm = h->w_qperm.as<int>();
+        }
+        h->last_qperm = qperm;   // stage B runs the re-rank in the same order
+    }
+    // per-query slab of the distance buffer; multiple of 4 floats so rows are 16-byte aligned
+    const int64_t q_stride = (std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len)) + 3) & ~(int64_t)3;
+    GH_CHECK(h, h->w_dist.ensure((size_t)nq * q_stride * sizeof(float)));
+    // dis0 of every (query, probe) pair: the coarse distance (L2) or <x_q, centroid> (inner product)
+    const float* dis0 = h->w_coarse_dis.as<float>();
+    if (!l2) {
+        StageScope t(h, GAMMA_HIP_STAGE_TABLES, false);
+        GH_CHECK(h, h->w_pair_ip.ensure((size_t)nq * P * sizeof(float)));
+        gh::launch_pair_ip(s, d_x, h->d_cc, h->w_probe.as<int>(), nq, P, d, nlist, h->w_pair_ip.as<float>());
+        dis0 = h->w_pair_ip.as<float>();
+    }
+    auto scan = [&](int gsz, int pg_lo, int pg_cnt, const gh::ScanBound* bound, bool count) {
+        StageScope t(h, GAMMA_HIP_STAGE_SCAN, count);
+        gh::launch_ivfpq_scan_pair(s, l2, d_x, nq, d, M, P, h->w_probe.as<int>(),
+                                   dis0, h->d_cc, h->w_st2.as<float>(), h->d_T2,
+                                   h->d_list_off, h->d_list_len, h->d_list_mask, nlist, h->d_codes,
+                                   h->d_ids, h->w_pair_off.as<int>(), q_stride, h->w_dist.as<float>(),
+                                   fc.d_tab, fc.d_qf, need_ids, qperm, gsz, pg_lo, pg_cnt, shard ? 1 : 0, bound,
+                                   fuse_ip ? h->d_pqc : nullptr);
+    };
+    if (!bounded) {
+        scan(G, 0, PGN, nullptr, true);
+        StageScope t(h, GAMMA_HIP_STAGE_SELECT);
+        gh::launch_select_topk(s, l2, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), 0,
+                               (int)std::min<int64_t>(q_stride, 1 << 30), nq, R,
+                               out_dis, h->w_cand_pos.as<int>());
+        gh::launch_map_candidates(s, h->w_cand_pos.as<int>(), nq, R, P, h->w_probe.as<int>(),
+                                  h->w_pair_off.as<int>(), h->d_list_off, h->d_ids,
+                                  out_ids);
+        if (h->tie.on)
+            gh::launch_flag_cut_ties(s, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), nq, R, out_dis,
+                                     h->w_cand_pos.as<int>(), nullptr, h->w_tcut.as<uint8_t>());
+    } else {
+        // List-major consumer scan (scan_lm.hip) for large batches: the producers run alone, then every other probe
+        // is scored two queries per list pass.  Gated on what k_scan_lm covers; results are the same either way.
+        // Measured at C3 (16384 queries): 233 k units for 393 k consumer pairs, 58 % of the query-major kernel's
+        // vector instructions and 84 % of its LDS cycles -- but 1069 us against ~700 us for the same pairs: two
+        // 16 KB query-table rows per unit instead of one per eight pairs (11 GB through the L2 per launch), four
+        // workgroups per CU behind a 32 KB LUT2, and ds_read_b64 gathers that conflict more than ds_read_b32.
+        // Lists of a few hundred codes are too short to pay for it; it stays OFF unless asked for
+        // (gamma_hip_set_list_major, GAMMA_HIP_LM=1), kept for long-list shapes and covered by a parity test.
+        static const bool env_lm = getenv("GAMMA_HIP_LM") != nullptr;
+        const bool lm = (env_lm || h->list_major) && !shard && PGN > 1 && M == 16 && nq >= 2048 && 1 + (P - G) <= 64 &&
+                        !fc.d_qf && h->d_list_mask == nullptr;
+        const int cap = gh::scan_slice_cap();
+        // one survivor slice per probe group (slice 0: the producer's own) -- or, list-major, per consumer PAIR
+        const int nsl = lm ? 1 + (P - G) : PGN;
+        // rq | ready[nq] | gcnt[nq][nsl]   (rq: count + list of the queries that need the repair launch, 8-byte aligned)
+        const size_t rq_bytes = (((size_t)nq + 1) * sizeof(int) + 7) & ~(size_t)7;
+        GH_CHECK(h, h->w_scnt.ensure(rq_bytes + (size_t)nq * (sizeof(unsigned long long) + (size_t)nsl * sizeof(int))));
+        GH_CHECK(h, h->w_sflag.ensure((size_t)nq));
+        GH_CHECK(h, h->w_surv.ensure((size_t)nq * (lm ? 1 : nsl) * cap * sizeof(unsigned long long)));
+        unsigned long long* ready = reinterpret_cast<unsigned long long*>(h->w_scnt.as<char>() + rq_bytes);
+        GH_CHECK(h, hipMemsetAsync(h->w_scnt.p, 0, sizeof(int), s));
+        GH_CHECK(h, hipMemsetAsync(ready, 0, (size_t)nq * sizeof(unsigned long long), s));
+        gh::ScanBound sb;
+        sb.ready = ready;
+        sb.surv = h->w_surv.as<unsigned long long>();
+        sb.gcnt = reinterpret_cast<int*>(ready + nq);
+        sb.K = R;
+        sb.cnt_stride = nsl;
+        // exact ties: the replay reads a bounded query's candidates from slab group 0 + the survivor slices, and an
+        // unbounded one's from the slab the repair launch below fills -- nothing else needs the consumers' distances
+        // (the list-major variant has no repair launch: it stores everything)
+        sb.store_all = (h->tie.on && lm) ? 1 : 0;
+        sb.rq_count = h->w_scnt.as<int>();
+        sb.rq_list = h->w_scnt.as<int>() + 1;
+        const unsigned long long* surv_c = nullptr;
+        if (!lm) {
+            scan(G, 0, PGN, &sb, true);
+        } else {
+            const int PC = P - G, B = gh::lm_block_queries(P, G), nblk = (nq + B - 1) / B;
+            GH_CHECK(h, h->w_survc.ensure((size_t)nq * PC * gh::lm_pair_cap() * sizeof(unsigned long long)));
+            GH_CHECK(h, h->w_lm_units.ensure((size_t)nblk * gh::lm_units_per_block() * 16 * sizeof(int)));
+            GH_CHECK(h, h->w_lm_cnt.ensure((size_t)nblk * sizeof(int)));
+            GH_CHECK(h, hipMemsetAsync(sb.gcnt, 0, (size_t)nq * nsl * sizeof(int), s));   // pairs never scored: 0 survivors
+            scan(G, 0, 1, &sb, true);   // producers: first probe group, bound, own survivors (slice 0)
+            StageScope t2(h, GAMMA_HIP_STAGE_SCAN, false);
+            gh::launch_lm_units(s, h->w_probe.as<int>(), dis0, h->w_pair_off.as<int>(), h->d_list_off, h->d_list_len,
+                                h->d_list_mask, nlist, qperm, ready, nq, P, G, B, h->w_lm_units.as<int>(),
+                                h->w_lm_cnt.as<int>());
+            gh::LmScanArgs la;
+            la.units = h->w_lm_units.as<int>();
+            la.ucount = h->w_lm_cnt.as<int>();
+            la.nq = nq;
+            la.B = B;
+            la.st2 = h->w_st2.as<float>();
+            la.T2 = h->d_T2;
+            la.codes = h->d_codes;
+            la.ids = h->d_ids;
+            la.out = h->w_dist.as<float>();
+            la.q_stride = q_stride;
+            la.surv = h->w_survc.as<unsigned long long>();
+            la.cnt = sb.gcnt;
+            la.nslc = PC;
+            la.cnt_stride = nsl;
+            la.store_all = sb.store_all;
+            la.need_ids = need_ids;
+            la.ftab = fc.d_tab;
+            gh::launch_scan_lm(s, l2, M, la);
+            surv_c = h->w_survc.as<unsigned long long>();
+            static const bool lm_dbg = getenv("GAMMA_HIP_LM_DBG") != nullptr;
+            static int lm_shown = 0;
+            if (lm_dbg && lm_shown++ < 2) {
+                std::vector<int> uc(nblk);
+                (void)hipStreamSynchronize(s);
+                (void)hipMemcpy(uc.data(), h->w_lm_cnt.p, (size_t)nblk * sizeof(int), hipMemcpyDeviceToHost);
+                int64_t tot = 0;
+                for (int v : uc) tot += v;
+                fprintf(stderr, "list-major scan: %d blocks of %d queries, %lld units for %lld consumer pairs\n", nblk, B,
+                        (long long)tot, (long long)nq * PC);
+            }
+        }
+        static const bool dbg = getenv("GAMMA_HIP_BOUND_DBG") != nullptr;
+        static int shown = 0;
+        StageScope t(h, GAMMA_HIP_STAGE_SELECT);
+        gh::launch_select_final(s, l2, sb.surv, sb.gcnt, nsl, cap, sb.ready, h->w_pair_off.as<int>(), P, nq, R,
+                                h->w_pair_base.as<int64_t>(), h->d_ids,
+                                h->w_sflag.as<uint8_t>(), out_dis,
+                                h->w_cand_pos.as<int>(), out_ids, h->tie.on ? h->w_tcut.as<uint8_t>() : nullptr,
+                                h->d_tie_stats, sb.rq_list, sb.rq_count, surv_c, gh::lm_pair_cap());
+        if (PGN > 1 && !sb.store_all) {
+            // queries the slices could not answer: their consumer groups are scored again, distances stored
+            StageScope t2(h, GAMMA_HIP_STAGE_SCAN, false);
+            gh::launch_ivfpq_scan_pair(s, l2, d_x, nq, d, M, P, h->w_probe.as<int>(), dis0, h->d_cc,
+                                       h->w_st2.as<float>(), h->d_T2, h->d_list_off, h->d_list_len, h->d_list_mask,
+                                       nlist, h->d_codes, h->d_ids, h->w_pair_off.as<int>(), q_stride,
+                                       h->w_dist.as<float>(), fc.d_tab, fc.d_qf, need_ids, nullptr, G, 1, PGN - 1,
+                                       shard ? 1 : 0, nullptr, nullptr, sb.rq_list, sb.rq_count);
+        }
+        gh::launch_select_topk(s, l2, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), 0,
+                               (int)std::min<int64_t>(q_stride, 1 << 30), nq, R,
+                               out_dis, h->w_cand_pos.as<int>(), h->w_sflag.as<uint8_t>());
+        if (h->tie.on) {
+            gh::launch_flag_cut_ties(s, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), nq, R, out_dis,
+                                     h->w_cand_pos.as<int>(), h->w_sflag.as<uint8_t>(), h->w_tcut.as<uint8_t>());
+            h->tie.bounded = !lm;   // list-major: the replay walks the whole slab (everything is stored with exact ties on)
+            h->tie.nsl = nsl;
+            h->tie.cap = cap;
+        }
+        if (dbg && shown++ >= 8 && shown <= 13) {
+            std::vector<uint8_t> hf(nq);
+            std::vector<int> hc((size_t)nq * nsl);
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(hf.data(), h->w_sflag.p, nq, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(hc.data(), sb.gcnt, hc.size() * sizeof(int), hipMemcpyDeviceToHost);
+            std::vector<unsigned long long> hr(nq);
+            (void)hipMemcpy(hr.data(), sb.ready, (size_t)nq * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            int64_t nf = 0, tot = 0, mx = 0, nobound = 0;
+            for (int i = 0; i < nq; i++) {
+                nf += hf[i];
+                nobound += (hr[i] >> 32) != 1ull;
+            }
+            for (size_t i = 0; i < hc.size(); i++) {
+                tot += hc[i];
+                mx = std::max<int64_t>(mx, hc[i]);
+            }
+            fprintf(stderr, "scan bound: %lld of %d queries unfiltered (%lld without a bound), survivors per query mean %.1f, "
+                    "per slice max %lld\n",
+                    (long long)nf, nq, (long long)nobound, (double)tot / nq, (long long)mx);
+        }
+        gh::launch_map_candidates(s, h->w_cand_pos.as<int>(), nq, R, P, h->w_probe.as<int>(),
+                                  h->w_pair_off.as<int>(), h->d_list_off, h->d_ids,
+                                  out_ids, h->w_sflag.as<uint8_t>());
+    }
+    h->tie.G = G;
+    h->tie.q_stride = q_stride;
+    GH_CHECK(h, hipEventRecord(h->rd_ev[ver], s));
+    h->rd_set[ver] = true;
+    GH_CHECK(h, hipGetLastError());
+    return GAMMA_HIP_OK;
+}
+
+// ---- stage B: compute_dis (gamma_index_ivfpq.cc:642-697) ------------------------------
+int ivfpq_stage_b(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, int R, int k,
+                  const float* cand_dis, const int64_t* cand_ids, float* d_distances,
+                  int64_t* d_labels, const int* qperm = nullptr, bool tie_replay = false) {
+    const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
+    const float neutral = l2 ? 3.402823466e+38f : -3.402823466e+38f;
+    hipStream_t s = h->stream;
+    StageScope t(h, GAMMA_HIP_STAGE_RERANK);
+    // exact ties: the final-stage kernel lists the queries with a tie among their first k+1 distances (or with a
+    // tied top-R cut, stage A) and k_tie_replay redoes those the way the reference's heaps do (ties.hip)
+    const bool ties = tie_replay && h->tie.on;
+    gh::TieFlags tf;
+    if (ties) {
+        tf.cut = h->w_tcut.as<uint8_t>();
+        tf.count = h->w_tlist.as<int>();
+        tf.list = h->w_tlist.as<int>() + 1;
+        tf.stats = h->d_tie_stats;
+    }
+    auto replay = [&]() {
+        gh::TieReplayArgs a;
+        a.list = tf.list;
+        a.count = tf.count;
+        a.nq = nq;
+        a.slab = h->w_dist.as<float>();
+        a.q_stride = h->tie.q_stride;
+        a.pair_off = h->w_pair_off.as<int>();
+        a.pair_base = h->w_pair_base.as<int64_t>();
+        a.ids = h->d_ids;
+        a.P = p->nprobe;
+        a.G = h->tie.G;
+        const size_t rq_bytes = (((size_t)nq + 1) * sizeof(int) + 7) & ~(size_t)7;
+        unsigned long long* ready = reinterpret_cast<unsigned long long*>(h->w_scnt.as<char>() + rq_bytes);
+        a.ready = h->tie.bounded ? ready : nullptr;
+        a.surv = h->w_surv.as<unsigned long long>();
+        a.gcnt = reinterpret_cast<int*>(ready + nq);
+        a.nsl = h->tie.nsl;
+        a.slice_cap = h->tie.cap;
+        a.x = d_x;
+        a.d = h->d;
+        a.raw = h->d_raw;
+        a.nraw = h->nraw;
+        a.R = R;
+        a.k = k;
+        a.has_rank = p->has_rank ? 1 : 0;
+        a.min_score = p->min_score;
+        a.max_score = p->max_score;
+        a.neutral = neutral;
+        a.cand_dis = const_cast<float*>(cand_dis);
+        a.cand_ids = const_cast<int64_t*>(cand_ids);
+        a.distances = d_distances;
+        a.labels = d_labels;
+        gh::launch_tie_replay(s, l2, a);
+    };
+    if (p->has_rank) {
+        if (!h->d_raw || h->raw_d != h->d) return fail(h, GAMMA_HIP_EINVAL, "has_rank needs the raw store");
+        if (R <= 1024 && (nq >= 256 || ties)) {
+            // one fused kernel: exact distances + top-k + output
+            gh::launch_rerank_topk(s, l2, d_x, nq, h->d, h->d_raw, h->nraw, cand_ids, R, k, p->min_score,
+                                   p->max_score, neutral, d_distances, d_labels, qperm, ties ? &tf : nullptr);
+            if (ties) replay();
+            GH_CHECK(h, hipGetLastError());
+            return GAMMA_HIP_OK;
+        }
+        GH_CHECK(h, h->w_exact.ensure((size_t)nq * R * sizeof(float)));
+        GH_CHECK(h, h->w_selv.ensure((size_t)nq * k * sizeof(float)));
+        GH_CHECK(h, h->w_selp.ensure((size_t)nq * k * sizeof(int)));
+        gh::launch_rerank_dist(s, l2, d_x, nq, h->d, h->d_raw, h->nraw, cand_ids, R, p->min_score,
+                               p->max_score, h->w_exact.as<float>());
+        gh::launch_select_topk(s, l2, h->w_exact.as<float>(), R, nullptr, R, R, nq, k,
+                               h->w_selv.as<float>(), h->w_selp.as<int>());
+        gh::launch_finalize_topk(s, h->w_selv.as<float>(), h->w_selp.as<int>(), nq, k, cand_ids, R, 0,
+                                 neutral, d_distances, d_labels);
+    } else {
+        gh::launch_finalize_norank(s, cand_dis, cand_ids, nq, R, k, p->min_score, p->max_score, neutral,
+                                   d_distances, d_labels, ties ? &tf : nullptr);
+        if (ties) replay();
+    }
+    GH_CHECK(h, hipGetLastError());
+    return GAMMA_HIP_OK;
+}
+
+// ---- small batches (nq <= 512; measured cross-over with the regular chain ~1000): four or five launches instead of eleven ---------------------------------
+// exact coarse distances + query tables | top-nprobe + slab offsets | scan | top-recall_num + ids + re-rank + top-k
+// (kernels.hip k_small_coarse_ip, select.hip k_small_coarse_select / k_small_tail).  Each launch of the regular
+// chain costs ~4 us of launch + drain at this size, whatever it computes.
+bool ivfpq_small_ok(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int nq, int R) {
+    static const bool off = getenv("GAMMA_HIP_NO_SMALL_PATH") != nullptr;
+    static const int max_nq = getenv("GAMMA_HIP_SMALL_MAX") ? atoi(getenv("GAMMA_HIP_SMALL_MAX")) : 512;
+    // exact coarse distances (faiss below 20 queries) come from the fused first kernel, which covers 16 queries; the
+    // GEMM form (20 queries and more) from the regular matrix kernel
+    return !off && h->small_path && nq >= 1 && nq <= max_nq && (p->coarse_mode == 1 || nq <= 16) &&
+           p->nprobe <= 64 && R <= 1024 && !h->exact_ties && !h->profile && !fc.d_qf && !h->d_list_mask &&
+           h->nlist <= 16384 &&
+           (int64_t)p->nprobe * std::max(1, h->max_list_len) <= (1 << 22) &&
+           // long lists: beyond ~5e7 codes per call the regular chain's bound filter wins (full-size C4, 390 k codes per
+           // query: 64 queries 0.46 ms against 1.04, 256 queries 1.63 against 1.33)
+           (int64_t)nq * p->nprobe * (h->ntotal / std::max(1, h->nlist)) <= 48000000LL && (!p->has_rank || (h->d_raw && h->raw_d == h->d));
+}
+
+int ivfpq_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int nq, const float* d_x, int R, int k,
+                float* d_distances, int64_t* d_labels) {
+    const int P = p->nprobe, d = h->d, M = h->M, nlist = h->nlist;
+    hipStream_t s = h->stream;
+    const int ver = h->cur_ver;
+    GH_CHECK(h, hipStreamWaitEvent(s, h->ver_ev[ver], 0));
+    GH_CHECK(h, h->w_mat.ensure((size_t)nq * nlist * sizeof(float)));
+    GH_CHECK(h, h->w_st2.ensure((size_t)nq * M * 256 * sizeof(float)));
+    GH_CHECK(h, h->w_coarse_dis.ensure((size_t)nq * P * sizeof(float)));
+    GH_CHECK(h, h->w_probe.ensure((size_t)nq * P * sizeof(int)));
+    GH_CHECK(h, h->w_pair_off.ensure((size_t)nq * (P + 1) * sizeof(int)));
+    GH_CHECK(h, h->w_pair_base.ensure((size_t)nq * P * sizeof(int64_t)));
+    GH_CHECK(h, h->w_qtotal.ensure((size_t)nq * sizeof(int)));
+    GH_CHECK(h, h->w_cand_pos.ensure((size_t)nq * R * sizeof(int)));
+    GH_CHECK(h, h->w_cand_dis.ensure((size_t)nq * R * sizeof(float)));
+    GH_CHECK(h, h->w_cand_ids.ensure((size_t)nq * R * sizeof(int64_t)));
+    const int64_t q_stride = (std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len)) + 3) & ~(int64_t)3;
+    GH_CHECK(h, h->w_dist.ensure((size_t)nq * q_stride * sizeof(float)));
+    // (folding the selection into the first launch -- last workgroup done selects -- was tried: the device-scope
+    // release / acquire it needs costs more than the launch it saves, 24 us against 4 + 8: the XCDs' L2s are
+    // written back and invalidated either way)
+    // long lists: the scan walks a work list of (query, probe, chunk of the list) units written by the selection kernel,
+    // pieces of even size for a grid that fills the chip, instead of one workgroup per pair that runs for as long as its
+    // list is (small_presel: tests force the path on short lists)
+    static const int chunk_env = getenv("GAMMA_HIP_SMALL_CHUNK") ? atoi(getenv("GAMMA_HIP_SMALL_CHUNK")) : 512;
+    int chunk_len = 0, max_units = 0;
+    uint32_t* d_units = nullptr;
+    int* d_nunits = nullptr;
+    if (h->ntotal / std::max(1, nlist) > 1024 || h->max_list_len > 8192 || h->small_presel > 0) {
+        chunk_len = h->small_presel > 0 ? 512 : std::max(512, (chunk_env + 511) & ~511);
+        const int64_t mu = (int64_t)nq * P * (1 + (int64_t)h->max_list_len / chunk_len);
+        max_units = (int)std::min<int64_t>(mu, INT32_MAX);
+        GH_CHECK(h, h->w_lm_units.ensure((size_t)mu * sizeof(uint32_t)));
+        GH_CHECK(h, h->w_lm_cnt.ensure(64));
+        d_units = h->w_lm_units.as<uint32_t>();
+        d_nunits = h->w_lm_cnt.as<int>();
+    }
+    if (p->coarse_mode == 1) {
+        if (d_nunits) GH_CHECK(h, hipMemsetAsync(d_nunits, 0, sizeof(int), s));
+        gh::launch_l2_gemmform(s, d_x, nq, d, h->d_cc, nlist, nullptr, h->d_cc_norms, h->w_mat.as<float>(), nlist, true);
+        gh::launch_pq_ip_table(s, d_x, nq, d, M, h->d_pqc, h->w_st2.as<float>());
+    } else if (!gh::launch_small_coarse_ip(s, d_x, nq, d, h->d_cc, nlist, h->w_mat.as<float>(), M, h->d_pqc,
+                                           h->w_st2.as<float>(), d_nunits)) {
+        return fail(h, GAMMA_HIP_EINVAL, "small path: shape not covered");   // ivfpq_small_ok gates on the same shapes
+    }
+    const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
+    if (!l2) GH_CHECK(h, h->w_pair_ip.ensure((size_t)nq * P * sizeof(float)));
+    gh::launch_small_coarse_select(s, h->w_mat.as<float>(), nlist, nq, P, h->w_coarse_dis.as<float>(), h->w_probe.as<int>(),
+                                   h->d_list_len, h->d_list_mask, h->d_list_off, h->w_pair_off.as<int>(),
+                                   h->w_qtotal.as<int>(), h->w_pair_base.as<int64_t>(), d_x, h->d_cc, d,
+                                   l2 ? nullptr : h->w_pair_ip.as<float>(), d_units, d_nunits, chunk_len);
+    h->scan_pairs += (int64_t)nq * P;
+    const int need_ids = (fc.any_clause || (h->d_bitmap && h->bitmap_any) || h->n_moved > 0) ? 1 : 0;
+    gh::launch_ivfpq_scan_pair(s, l2, d_x, nq, d, M, P, h->w_probe.as<int>(),
+                               l2 ? h->w_coarse_dis.as<float>() : h->w_pair_ip.as<float>(), h->d_cc,
+                               h->w_st2.as<float>(), h->d_T2, h->d_list_off, h->d_list_len, h->d_list_mask, nlist,
+                               h->d_codes, h->d_ids, h->w_pair_off.as<int>(), q_stride, h->w_dist.as<float>(), fc.d_tab,
+                               fc.d_qf, need_ids, nullptr, 1, 0, P, 0, nullptr, nullptr, reinterpret_cast<const int*>(d_units), d_nunits,
+                               chunk_len, max_units);
+    const float neutral = l2 ? 3.402823466e+38f : -3.402823466e+38f;
+    // long candidate rows (expected nprobe x 1.5 mean list lengths beyond what one workgroup keeps in registers): a first
+    // selection over slices of the row by several workgroups per query, then the tail among their survivors
+    int smax = 0;
+    {
+        const int64_t slice = 16384;   // select.hip SM_SLICE
+        const int64_t est = (int64_t)P * (h->ntotal / std::max(1, nlist)) * 3 / 2;
+        const int64_t bound = (int64_t)P * std::max(1, h->max_list_len);
+        if (h->small_presel > 0) smax = h->small_presel;
+        else if (est > slice) smax = (int)std::min<int64_t>(std::min<int64_t>(64, (bound + slice - 1) / slice), std::max(2, 4096 / nq));
+        if (smax > 0) {
+            GH_CHECK(h, h->w_selv.ensure((size_t)nq * smax * R * sizeof(float)));
+            GH_CHECK(h, h->w_selp.ensure((size_t)nq * smax * R * sizeof(int)));
+        }
+    }
+    gh::launch_small_tail(s, l2, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), nq, R, P, h->w_probe.as<int>(),
+                          h->w_pair_off.as<int>(), h->d_list_off, h->d_ids, h->w_cand_dis.as<float>(),
+                          h->w_cand_pos.as<int>(), h->w_cand_ids.as<int64_t>(), p->has_rank ? 1 : 0, d_x, d, h->d_raw,
+                          h->nraw, k, p->min_score, p->max_score, neutral, d_distances, d_labels, smax,
+                          smax ? h->w_selv.as<float>() : nullptr, smax ? h->w_selp.as<int>() : nullptr);
+    h->tie = H::TieCtx();
+    h->tie.G = 1;
+    h->tie.q_stride = q_stride;
+    h->last_qperm = nullptr;
+    GH_CHECK(h, hipEventRecord(h->rd_ev[ver], s));
+    h->rd_set[ver] = true;
+    GH_CHECK(h, hipGetLastError());
+    return GAMMA_HIP_OK;
+}
+
+int ivfpq_check(H* h, const gamma_hip_search_params* p, int nq, int k) {
+    GH_TRY(check_params(h, p, nq, k));
+    if (!h->ivf_init || h->ivfflat) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
+    if (!h->trained) return fail(h, GAMMA_HIP_ENOTTRAINED, "ivfpq not trained");
+    if (p->nprobe <= 0 || p->nprobe > h->nlist) return fail(h, GAMMA_HIP_EINVAL, "nprobe out of range");
+    if (std::max(p->recall_num, k) > 4096) return fail(h, GAMMA_HIP_EINVAL, "recall_num > 4096 unsupported");
+    return GAMMA_HIP_OK;
+}
+
+// queries per internal chunk: the coarse distance matrix (nlist floats per query) and the ADC distance
+// slab (nprobe x longest list floats per query) each stay inside the workspace budget
+int coarse_chunk(H* h, int nq) {
+    const int64_t by_mat = (int64_t)(h->dist_budget_bytes / ((size_t)h->nlist * sizeof(float)));
+    return (int)std::max<int64_t>(1, std::min<int64_t>(by_mat, nq));
+}
+int scan_chunk(H* h, int nq, int P) {
+    const int64_t q_stride = std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len));
+    const int64_t by_dist = (int64_t)(h->dist_budget_bytes / (q_stride * sizeof(float)));
+    return (int)std::max<int64_t>(1, std::min<int64_t>(by_dist, nq));
+}
+int query_chunk(H* h, int nq, int P) { return std::min(coarse_chunk(h, nq), scan_chunk(h, nq, P)); }
+
+// given != nullptr: the filter context of a combined batch (p's own filter clauses are ignored)
+int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, int k,
+                               float* d_distances, int64_t* d_labels, const FiltCtx* given = nullptr) {
+    GH_TRY(ivfpq_check(h, p, nq, k));
+    if (k <= 0 || nq == 0) return GAMMA_HIP_OK;  // gamma_index_ivfpq.cc:753-756
+    GH_CHECK(h, hipSetDevice(h->device));
+    const int R = std::max(p->recall_num, k);
+    FiltCtx fc;
+    if (given) {
+        fc = *given;
+    } else {
+        gh::FilterDesc filt;
+        GH_TRY(build_filter(h, p, &filt));
+        GH_TRY(filt_ctx_single(h, filt, &fc));
+    }
+    // faiss picks the coarse path from the size of the WHOLE call (faiss:utils/distances.cpp:346);
+    // the internal chunks must not re-decide it
+    gamma_hip_search_params pp = *p;
+    if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;
+    p = &pp;
+    if (ivfpq_small_ok(h, p, fc, nq, R)) {
+        GH_TRY(ivfpq_small(h, p, fc, nq, d_x, R, k, d_distances, d_labels));
+        h->last_nq = nq;
+        h->last_P = p->nprobe;
+        h->last_R = R;
+        return GAMMA_HIP_OK;
+    }
+    const int chunk = scan_chunk(h, nq, p->nprobe), P = p->nprobe;
+    // long lists (C4: 64 probes x lists of tens of thousands) make the ADC slab the limit: the coarse
+    // quantizer then still runs over the whole call (one GEMM instead of one per slab chunk)
+    const bool coarse_first = chunk < nq;
+    if (coarse_first) {
+        GH_CHECK(h, h->w_full_cdis.ensure((size_t)nq * P * sizeof(float)));
+        GH_CHECK(h, h->w_full_probe.ensure((size_t)nq * P * sizeof(int)));
+        const int cc = coarse_chunk(h, nq);
+        for (int q0 = 0; q0 < nq; q0 += cc)
+            GH_TRY(ivfpq_coarse(h, p, std::min(cc, nq - q0), d_x + (size_t)q0 * h->d,
+                                h->w_full_cdis.as<float>() + (size_t)q0 * P, h->w_full_probe.as<int>() + (size_t)q0 * P));
+    }
+    for (int q0 = 0; q0 < nq; q0 += chunk) {
+        const int nc = std::min(chunk, nq - q0);
+        if (coarse_first)
+            GH_TRY(ivfpq_stage_a(h, p, fc.at(q0), nc, d_x + (size_t)q0 * h->d, R,
+                                 h->w_full_cdis.as<float>() + (size_t)q0 * P, h->w_full_probe.as<int>() + (size_t)q0 * P));
+        else
+            GH_TRY(ivfpq_stage_a(h, p, fc.at(q0), nc, d_x + (size_t)q0 * h->d, R));
+        GH_TRY(ivfpq_stage_b(h, p, nc, d_x + (size_t)q0 * h->d, R, k, h->w_cand_dis.as<float>(),
+                             h->w_cand_ids.as<int64_t>(), d_distances + (size_t)q0 * k,
+                             d_labels + (size_t)q0 * k, getenv("GAMMA_HIP_NO_RERANK_ORDER") ? nullptr : h->last_qperm,
+                             /*tie_replay=*/true));
+        h->last_nq = nc;
+    }
+    h->last_P = p->nprobe;
+    h->last_R = R;
+    return GAMMA_HIP_OK;
+}
+
+// ---- IVFFLAT (index/impl/gamma_index_ivfflat.cc:392-567) ------------------------------------------------------
+// coarse quantizer (the IVFPQ one) -> slab offsets -> exact distance of every entry of the probed lists
+// (k_ivfflat_scan) -> top-k of the slab in (distance, scan position) order -> ids.  The reference's k-heap keeps
+// the same k entries (up to its order inside exact ties).
+// IVFFLAT, small batches: the chain of ivfpq_small without tables and re-rank -- exact coarse distances | top-nprobe +
+// slab offsets | exact distances of the probed lists' rows, one workgroup per pair | top-k + ids + score window
+int ivfflat_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int nq, const float* d_x, int k,
+                  float* d_distances, int64_t* d_labels) {
+    const int P = p->nprobe, d = h->d, nlist = h->nlist;
+    const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
+    hipStream_t s = h->stream;
+    const int ver = h->cur_ver;
+    GH_CHECK(h, hipStreamWaitEvent(s, h->ver_ev[ver], 0));
+    GH_CHECK(h, h->w_mat.ensure((size_t)nq * nlist * sizeof(float)));
+    GH_CHECK(h, h->w_coarse_dis.ensure((size_t)nq * P * sizeof(float)));
+    GH_CHECK(h, h->w_probe.ensure((size_t)nq * P * sizeof(int)));
+    GH_CHECK(h, h->w_pair_off.ensure((size_t)nq * (P + 1) * sizeof(int)));
+    GH_CHECK(h, h->w_pair_base.ensure((size_t)nq * P * sizeof(int64_t)));
+    GH_CHECK(h, h->w_qtotal.ensure((size_t)nq * sizeof(int)));
+    GH_CHECK(h, h->w_cand_pos.ensure((size_t)nq * k * sizeof(int)));
+    GH_CHECK(h, h->w_cand_dis.ensure((size_t)nq * k * sizeof(float)));
+    GH_CHECK(h, h->w_cand_ids.ensure((size_t)nq * k * sizeof(int64_t)));
+    const int64_t q_stride = (std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len)) + 3) & ~(int64_t)3;
+    GH_CHECK(h, h->w_dist.ensure((size_t)nq * q_stride * sizeof(float)));
+    if (p->coarse_mode == 1) {
+        gh::launch_l2_gemmform(s, d_x, nq, d, h->d_cc, nlist, nullptr, h->d_cc_norms, h->w_mat.as<float>(), nlist, true);
+    } else if (!gh::launch_small_coarse_ip(s, d_x, nq, d, h->d_cc, nlist, h->w_mat.as<float>(), 0, nullptr, nullptr)) {
+        return fail(h, GAMMA_HIP_EINVAL, "small path: shape not covered");
+    }
+    gh::launch_small_coarse_select(s, h->w_mat.as<float>(), nlist, nq, P, h->w_coarse_dis.as<float>(), h->w_probe.as<int>(),
+                                   h->d_list_len, h->d_list_mask, h->d_list_off, h->w_pair_off.as<int>(),
+                                   h->w_qtotal.as<int>(), h->w_pair_base.as<int64_t>());
+    const int need_filter = (fc.any_clause || (h->d_bitmap && h->bitmap_any)) ? 1 : 0;
+    gh::launch_ivfflat_scan(s, l2, d_x, nq, d, P, h->w_pair_off.as<int>(), h->w_pair_base.as<int64_t>(), h->d_ids, h->d_raw,
+                            h->nraw, q_stride, h->w_dist.as<float>(), fc.d_tab, need_filter, p->min_score, p->max_score);
+    int smax = 0;   // long candidate rows: two-level selection (ivfpq_small)
+    {
+        const int64_t slice = 16384;
+        const int64_t est = (int64_t)P * (h->ntotal / std::max(1, nlist)) * 3 / 2;
+        const int64_t bound = (int64_t)P * std::max(1, h->max_list_len);
+        if (h->small_presel > 0) smax = h->small_presel;
+        else if (est > slice) smax = (int)std::min<int64_t>(std::min<int64_t>(64, (bound + slice - 1) / slice), std::max(2, 4096 / nq));
+        if (smax > 0) {
+            GH_CHECK(h, h->w_selv.ensure((size_t)nq * smax * k * sizeof(float)));
+            GH_CHECK(h, h->w_selp.ensure((size_t)nq * smax * k * sizeof(int)));
+        }
+    }
+    const float neutral = l2 ? 3.402823466e+38f : -3.402823466e+38f;
+    gh::launch_small_tail(s, l2, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), nq, k, P, h->w_probe.as<int>(),
+                          h->w_pair_off.as<int>(), h->d_list_off, h->d_ids, h->w_cand_dis.as<float>(),
+                          h->w_cand_pos.as<int>(), h->w_cand_ids.as<int64_t>(), 0, d_x, d, h->d_raw, h->nraw, k, p->min_score,
+                          p->max_score, neutral, d_distances, d_labels, smax, smax ? h->w_selv.as<float>() : nullptr,
+                          smax ? h->w_selp.as<int>() : nullptr);
+    GH_CHECK(h, hipEventRecord(h->rd_ev[ver], s));
+    h->rd_set[ver] = true;
+    h->last_nq = nq;
+    h->last_P = P;
+    h->last_R = k;
+    GH_CHECK(h, hipGetLastError());
+    return GAMMA_HIP_OK;
+}
+
+int ivfflat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, int k,
+                                 float* d_distances, int64_t* d_labels) {
+    GH_TRY(check_params(h, p, nq, k));
+    if (!h->ivf_init || !h->ivfflat) return fail(h, GAMMA_HIP_EINVAL, "ivfflat not initialised");
+    if (!h->trained) return fail(h, GAMMA_HIP_ENOTTRAINED, "ivfflat not trained");
+    if (p->nprobe <= 0 || p->nprobe > h->nlist) return fail(h, GAMMA_HIP_EINVAL, "nprobe out of range");
+    if (!h->d_raw || h->raw_d != h->d) return fail(h, GAMMA_HIP_EINVAL, "ivfflat needs the raw store");
+    if (k <= 0 || nq == 0) return GAMMA_HIP_OK;
+    GH_CHECK(h, hipSetDevice(h->device));
+    const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
+    const float neutral = l2 ? 3.402823466e+38f : -3.402823466e+38f;
+    gh::FilterDesc filt;
+    GH_TRY(build_filter(h, p, &filt));
+    FiltCtx fc;
+    GH_TRY(filt_ctx_single(h, filt, &fc));
+    gamma_hip_search_params pp = *p;
+    if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;   // faiss:utils/distances.cpp:303,346, whole call
+    const int P = pp.nprobe, nlist = h->nlist;
+    hipStream_t s = h->stream;
+    {   // small batches, as long as the pair-per-workgroup scan is the one that would run anyway (below 2 nlist pairs)
+        static const bool off = getenv("GAMMA_HIP_NO_SMALL_PATH") != nullptr;
+        if (!off && h->small_path && nq <= 512 && (pp.coarse_mode == 1 || nq <= 16) && P <= 64 && k <= 1024 && !h->profile &&
+            !fc.d_qf && !h->d_list_mask && nlist <= 16384 && (int64_t)nq * P < 2 * (int64_t)nlist &&
+            (int64_t)P * std::max(1, h->max_list_len) <= (1 << 22))
+            return ivfflat_small(h, &pp, fc, nq, d_x, k, d_distances, d_labels);
+    }
+    const int chunk = scan_chunk(h, nq, P);
+    const int need_filter = (fc.any_clause || (h->d_bitmap && h->bitmap_any)) ? 1 : 0;
+    for (int q0 = 0; q0 < nq; q0 += chunk) {
+        const int nc = std::min(chunk, nq - q0);
+        const float* xq = d_x + (size_t)q0 * h->d;
+        const int ver = h->cur_ver;
+        GH_CHECK(h, hipStreamWaitEvent(s, h->ver_ev[ver], 0));
+        GH_CHECK(h, h->w_pair_off.ensure((size_t)nc * (P + 1) * sizeof(int)));
+        GH_CHECK(h, h->w_pair_base.ensure((size_t)nc * P * sizeof(int64_t)));
+        GH_CHECK(h, h->w_qtotal.ensure((size_t)nc * sizeof(int)));
+        GH_CHECK(h, h->w_cand_pos.ensure((size_t)nc * k * sizeof(int)));
+        GH_CHECK(h, h->w_cand_dis.ensure((size_t)nc * k * sizeof(float)));
+        GH_CHECK(h, h->w_cand_ids.ensure((size_t)nc * k * sizeof(int64_t)));
+        GH_TRY(ivfpq_coarse(h, &pp, nc, xq));
+        gh::launch_pair_offsets(s, h->w_probe.as<int>(), nc, P, h->d_list_len, h->d_list_mask, nlist,
+                                h->w_pair_off.as<int>(), h->w_qtotal.as<int>(), nullptr, h->d_list_off,
+                                h->w_pair_base.as<int64_t>());
+        const int64_t q_stride = (std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len)) + 3) & ~(int64_t)3;
+        GH_CHECK(h, h->w_dist.ensure((size_t)nc * q_stride * sizeof(float)));
+        {
+            StageScope t(h, GAMMA_HIP_STAGE_SCAN);
+            // enough (query, probe) pairs that lists are shared: list-major (ivfflat.hip), a list's rows are read once
+            // for all the queries probing it; else one workgroup per pair
+            static const bool no_lm = getenv("GAMMA_HIP_NO_IVFFLAT_LM") != nullptr;
+            if (!no_lm && gh::ivfflat_lm_supported(h->d) && (int64_t)nc * P >= 2 * (int64_t)nlist && !h->d_list_mask) {
+                GH_CHECK(h, h->w_lm_units.ensure(gh::ivfflat_lm_scratch_bytes(nc, P, nlist)));
+                gh::launch_ivfflat_lm(s, l2, xq, nc, h->d, P, h->w_probe.as<int>(), h->w_pair_off.as<int>(), h->d_list_off,
+                                      h->d_list_len, nlist, h->d_ids, h->d_raw, h->nraw, q_stride, h->w_dist.as<float>(),
+                                      fc.d_tab, need_filter, p->min_score, p->max_score, h->w_lm_units.p);
+            } else {
+                gh::launch_ivfflat_scan(s, l2, xq, nc, h->d, P, h->w_pair_off.as<int>(), h->w_pair_base.as<int64_t>(),
+                                        h->d_ids, h->d_raw, h->nraw, q_stride, h->w_dist.as<float>(), fc.d_tab, need_filter,
+                                        p->min_score, p->max_score);
+            }
+        }
+        {
+            StageScope t(h, GAMMA_HIP_STAGE_SELECT);
+            gh::launch_select_topk(s, l2, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), 0,
+                                   (int)std::min<int64_t>(q_stride, 1 << 30), nc, k, h->w_cand_dis.as<float>(),
+                                   h->w_cand_pos.as<int>());
+            gh::launch_map_candidates(s, h->w_cand_pos.as<int>(), nc, k, P, h->w_probe.as<int>(), h->w_pair_off.as<int>(),
+                                      h->d_list_off, h->d_ids, h->w_cand_ids.as<int64_t>());
+            gh::launch_finalize_norank(s, h->w_cand_dis.as<float>(), h->w_cand_ids.as<int64_t>(), nc, k, k, p->min_score,
+                                       p->max_score, neutral, d_distances + (size_t)q0 * k, d_labels + (size_t)q0 * k,
+                                       nullptr);
+        }
+        GH_CHECK(h, hipEventRecord(h->rd_ev[ver], s));
+        h->rd_set[ver] = true;
+        h->last_nq = nc;
+    }
+    h->last_P = P;
+    h->last_R = k;
+    GH_CHECK(h, hipGetLastError());
+    return GAMMA_HIP_OK;
+}
+
+// ---- flat ------------------------------------------------------------------------------
+int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, int k,
+                              float* d_distances, int64_t* d_labels) {
+    GH_TRY(check_params(h, p, nq, k));
+    if (!h->d_raw && h->nraw > 0) return fail(h, GAMMA_HIP_EINVAL, "raw store not initialised");
+    if (h->raw_d <= 0) return fail(h, GAMMA_HIP_EINVAL, "raw store not initialised");
+    if (k <= 0 || nq == 0) return GAMMA_HIP_OK;
+    GH_CHECK(h, hipSetDevice(h->device));
+    const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
+    const float neutral = l2 ? 3.402823466e+38f : -3.402823466e+38f;
+    const float sentinel = l2 ? INFINITY : -INFINITY;
+    const int d = h->raw_d;
+    const int64_t N = h->nraw;
+    hipStream_t s = h->stream;
+    gh::FilterDesc filt;
+    GH_TRY(build_filter(h, p, &filt));
+    // query chunks x row chunks so the distance slab stays inside the budget
+    int64_t rows_chunk = std::max<int64_t>(256, std::min<int64_t>(N, (int64_t)1 << 16));
+    rows_chunk = (rows_chunk + 255) / 256 * 256;
+    int qc = (int)std::max<int64_t>(1, std::min<int64_t>(nq, (int64_t)(h->dist_budget_bytes / (rows_chunk * sizeof(float)))));
+    const int nchunks = (int)std::max<int64_t>(1, (N + rows_chunk - 1) / rows_chunk);
+    GH_CHECK(h, h->w_dist.ensure((size_t)qc * rows_chunk * sizeof(float)));
+    GH_CHECK(h, h->w_part_v.ensure((size_t)qc * nchunks * k * sizeof(float)));
+    GH_CHECK(h, h->w_part_i.ensure((size_t)qc * nchunks * k * sizeof(int64_t)));
+    GH_CHECK(h, h->w_selv.ensure((size_t)qc * k * sizeof(float)));
+    GH_CHECK(h, h->w_selp.ensure((size_t)qc * k * sizeof(int)));
+    GH_CHECK(h, h->w_cand_pos.ensure((size_t)qc * k * sizeof(int)));
+    GH_CHECK(h, h->w_cand_dis.ensure((size_t)qc * k * sizeof(float)));
+    StageScope t(h, GAMMA_HIP_STAGE_FLAT);
+    // the reference's loop: every row, one query at a time, a k-heap (gamma_index_flat.cc:118-300).
+    // Here: distance slab of one row chunk -> per-chunk top-k -> merge of the chunks' tables.
+    auto unbounded = [&](int q0, int nc) -> int {
+        const float* xq = d_x + (size_t)q0 * d;
+        for (int c = 0; c < nchunks; c++) {
+            const int64_t r0 = (int64_t)c * rows_chunk;
+            const int64_t nr = std::min<int64_t>(rows_chunk, N - r0);
+            gh::launch_pairwise_filtered(s, l2, xq, nc, d, h->d_raw + r0 * d, nr, h->w_dist.as<float>(),
+                                         rows_chunk, filt, p->min_score, p->max_score, r0);
+            // per-chunk top-k: values + positions relative to the chunk
+            gh::launch_select_topk(s, l2, h->w_dist.as<float>(), rows_chunk, nullptr, (int)nr, (int)nr, nc, k,
+                                   h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>());
+            // scatter into the partial table [q][chunk][k] with global ids
+            // (reuse finalize_topk: labels = pos, then offset by r0 on the fly below)
+            gh::launch_finalize_topk(s, h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>(), nc, k, nullptr,
+                                     0, r0, sentinel, h->w_selv.as<float>(),
+                                     h->w_part_i.as<int64_t>() + (size_t)c * nc * k);
+            GH_CHECK(h, hipMemcpyAsync(h->w_part_v.as<float>() + (size_t)c * nc * k, h->w_selv.p,
+                                       (size_t)nc * k * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
+        // merge: layout [chunk][q][k] == the sharded layout [shard][nq][R]
+        GH_CHECK(h, h->w_m_dis.ensure((size_t)nc * nchunks * k * sizeof(float)));
+        GH_CHECK(h, h->w_m_ids.ensure((size_t)nc * nchunks * k * sizeof(int64_t)));
+        gh::launch_gather_shards(s, h->w_part_v.as<float>(), h->w_part_i.as<int64_t>(), nchunks, nc, k,
+                                 h->w_m_dis.as<float>(), h->w_m_ids.as<int64_t>(), sentinel);
+        gh::launch_select_topk(s, l2, h->w_m_dis.as<float>(), (int64_t)nchunks * k, nullptr, nchunks * k,
+                               nchunks * k, nc, k, h->w_selv.as<float>(), h->w_selp.as<int>());
+        gh::launch_finalize_topk(s, h->w_selv.as<float>(), h->w_selp.as<int>(), nc, k,
+                                 h->w_m_ids.as<int64_t>(), (int64_t)nchunks * k, 0, neutral,
+                                 d_distances + (size_t)q0 * k, d_labels + (size_t)q0 * k);
+        return GAMMA_HIP_OK;
+    };
+    // Running bound: only the first chunk goes through a distance slab.  Its k-th best bounds the
+    // answer; the remaining rows are scored in passes that double the rows seen so far, each pass
+    // appending only the distances within the current bound to the query's candidate list (about k
+    // per pass and query) and ending with a compaction that tightens the bound.  The k smallest
+    // (distance, row id) items are the same either way.  A list that overflows (rows arriving in
+    // improving order) is detected and the call redone without a bound.
+    const int cap = gh::flat_list_cap();
+    auto bounded = [&](int q0, int nc, bool* redo) -> int {
+        const float* xq = d_x + (size_t)q0 * d;
+        GH_CHECK(h, h->w_flat_cand.ensure((size_t)nc * cap * sizeof(unsigned long long)));
+        GH_CHECK(h, h->w_flat_meta.ensure((size_t)(2 * nc + 1) * sizeof(int)));   // tau[nc] | cnt[nc] | overflow
+        uint32_t* tau = h->w_flat_meta.as<uint32_t>();
+        int* cnt = h->w_flat_meta.as<int>() + nc;
+        int* over = cnt + nc;
+        gh::FlatEmit em{tau, h->w_flat_cand.as<unsigned long long>(), cnt, cap};
+        GH_CHECK(h, hipMemsetAsync(over, 0, sizeof(int), s));
+        gh::launch_pairwise_filtered(s, l2, xq, nc, d, h->d_raw, rows_chunk, h->w_dist.as<float>(), rows_chunk, filt,
+                                     p->min_score, p->max_score, 0);
+        gh::launch_select_topk(s, l2, h->w_dist.as<float>(), rows_chunk, nullptr, (int)rows_chunk, (int)rows_chunk,
+                               nc, k, h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>());
+        gh::launch_flat_init(s, l2, h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>(), nc, k, 0, em, tau);
+        for (int64_t r = rows_chunk; r < N;) {
+            const int64_t nr = std::min<int64_t>(r, N - r);
+            gh::launch_pairwise_emit(s, l2, xq, nc, d, h->d_raw + r * d, nr, filt, p->min_score, p->max_score, r, em);
+            gh::launch_flat_compact(s, nc, k, em, tau, over);
+            r += nr;
+        }
+        gh::launch_flat_final(s, l2, nc, k, em, neutral, d_distances + (size_t)q0 * k, d_labels + (size_t)q0 * k);
+        GH_CHECK(h, hipGetLastError());
+        int h_over = 0;
+        GH_CHECK(h, hipMemcpyAsync(&h_over, over, sizeof(int), hipMemcpyDeviceToHost, s));
+        GH_CHECK(h, hipStreamSynchronize(s));
+        *redo = h_over != 0;
+        return GAMMA_HIP_OK;
+    };
+    for (int q0 = 0; q0 < nq; q0 += qc) {
+        const int nc = std::min(qc, nq - q0);
+        if (N == 0) {
+            // nothing to scan: all-empty result
+            GH_CHECK(h, hipMemsetAsync(h->w_selp.p, 0xff, (size_t)nc * k * sizeof(int), s));
+            gh::launch_finalize_topk(s, h->w_selv.as<float>(), h->w_selp.as<int>(), nc, k, nullptr, 0, 0,
+                                     neutral, d_distances + (size_t)q0 * k, d_labels + (size_t)q0 * k);
+            continue;
+        }
+        bool redo = true;
+        if (k <= 256 && N > rows_chunk && N < ((int64_t)1 << 32) &&
+            gh::pairwise_can_emit(nc, d, N - rows_chunk))
+            GH_TRY(bounded(q0, nc, &redo));
+        if (redo) GH_TRY(unbounded(q0, nc));
+    }
+    GH_CHECK(h, hipGetLastError());
+    return GAMMA_HIP_OK;
+}
+
+// host-pointer wrapper shared by ivfpq / flat
+// sync = false: everything is only enqueued (pinned host buffers); the caller synchronises the stream
+// lk != nullptr: the caller's SearchLock; its mu is released once everything is enqueued, so writers go on while
+// this call waits for the GPU (search_mu stays: the workspaces are in use)
+template <typename F>
+int host_search(H* h, int nq, int d, const float* x, int k, float* distances, int64_t* labels, F&& f,
+                bool sync = true, SearchLock* lk = nullptr) {
+    if (nq <= 0 || k <= 0) return f(nullptr, nullptr, nullptr);
+    GH_CHECK(h, hipSetDevice(h->device));
+    GH_CHECK(h, h->w_x.ensure((size_t)nq * d * sizeof(float)));
+    GH_CHECK(h, h->w_outd.ensure((size_t)nq * k * sizeof(float)));
+    GH_CHECK(h, h->w_outl.ensure((size_t)nq * k * sizeof(int64_t)));
+    // Small synchronous calls (a client thread's single query): the caller's buffers are pageable, and a pageable
+    // copy is a blocking staged transfer -- three of them cost more than the search chain.  Queries and results go
+    // through a pinned staging area instead: the copies are true asynchronous transfers in stream order, the thread
+    // blocks once, and the results are copied out by the CPU.
+    const size_t bx = (size_t)nq * d * sizeof(float), bd = (size_t)nq * k * sizeof(float), bi = (size_t)nq * k * sizeof(int64_t);
+    const size_t off_i = (bx + 63) & ~(size_t)63, off_d = off_i + ((bi + 63) & ~(size_t)63), need = off_d + bd;
+    static const bool no_pin = getenv("GAMMA_HIP_NO_PINNED_CALLS") != nullptr;
+    if (sync && !no_pin && need <= ((size_t)1 << 20)) {
+        if (need > h->dir_pin_bytes) {
+            if (h->dir_pin) (void)hipHostFree(h->dir_pin);
+            h->dir_pin = nullptr;
+            h->dir_pin_bytes = 0;
+            GH_CHECK(h, hipHostMalloc(&h->dir_pin, std::max<size_t>(need * 2, 65536), hipHostMallocDefault));
+            h->dir_pin_bytes = std::max<size_t>(need * 2, 65536);
+        }
+        char* base = static_cast<char*>(h->dir_pin);
+        std::memcpy(base, x, bx);
+        GH_CHECK(h, hipMemcpyAsync(h->w_x.p, base, bx, hipMemcpyHostToDevice, h->stream));
+        // results: the last kernel of the chain stores them straight into the staging area (pinned host memory is
+        // mapped into the device's address space; a few KB of posted writes) -- no copy back at all
+        static const bool no_map = getenv("GAMMA_HIP_NO_MAPPED_RESULTS") != nullptr;
+        void* dbase = nullptr;
+        if (!no_map && hipHostGetDevicePointer(&dbase, base, 0) == hipSuccess && dbase) {
+            char* db = static_cast<char*>(dbase);
+            GH_TRY(f(h->w_x.as<float>(), reinterpret_cast<float*>(db + off_d), reinterpret_cast<int64_t*>(db + off_i)));
+        } else {
+            GH_TRY(f(h->w_x.as<float>(), h->w_outd.as<float>(), h->w_outl.as<int64_t>()));
+            GH_CHECK(h, hipMemcpyAsync(base + off_d, h->w_outd.p, bd, hipMemcpyDeviceToHost, h->stream));
+            GH_CHECK(h, hipMemcpyAsync(base + off_i, h->w_outl.p, bi, hipMemcpyDeviceToHost, h->stream));
+        }
+        if (lk) lk->enqueued();
+        GH_CHECK(h, hipStreamSynchronize(h->stream));
+        std::memcpy(distances, base + off_d, bd);
+        std::memcpy(labels, base + off_i, bi);
+        return GAMMA_HIP_OK;
+    }
+    GH_CHECK(h, hipMemcpyAsync(h->w_x.p, x, (size_t)nq * d * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    GH_TRY(f(h->w_x.as<float>(), h->w_outd.as<float>(), h->w_outl.as<int64_t>()));
+    GH_CHECK(h, hipMemcpyAsync(distances, h->w_outd.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    GH_CHECK(h, hipMemcpyAsync(labels, h->w_outl.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    if (lk) lk->enqueued();
+    if (sync) GH_CHECK(h, hipStreamSynchronize(h->stream));
+    return GAMMA_HIP_OK;
+}
+}  // namespace ghi
+
+using namespace ghi;
+
+extern "C" {
+
+/* ---- search ----------------------------------------------------------------------------- */
+int gamma_hip_ivfpq_search_device(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
+                                  const float* d_x, int k, float* d_distances, int64_t* d_labels) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    return ivfpq_search_device_locked(h, p, nq, d_x, k, d_distances, d_labels);
+}
+
+int gamma_hip_ivfflat_search_device(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* d_x,
+                                    int k, float* d_distances, int64_t* d_labels) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    return ivfflat_search_device_locked(h, p, nq, d_x, k, d_distances, d_labels);
+}
+
+int gamma_hip_ivfflat_search(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x, int k,
+                             float* distances, int64_t* labels) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    GH_TRY(check_params(h, p, nq, k));
+    if (!h->ivf_init || !h->ivfflat) return fail(h, GAMMA_HIP_EINVAL, "ivfflat not initialised");
+    if (nq > 0 && k > 0 && (!x || !distances || !labels)) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
+    return host_search(h, nq, h->d, x, k, distances, labels, [&](const float* dx, float* dd, int64_t* dl) {
+        return ivfflat_search_device_locked(h, p, nq, dx, k, dd, dl);
+    }, true, &lk);
+}
+
+static int flat_search_host_locked(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x, int k,
+                                  float* distances, int64_t* labels) {
+    SearchLock lk(h);
+    GH_TRY(check_params(h, p, nq, k));
+    if (h->raw_d <= 0) return fail(h, GAMMA_HIP_EINVAL, "raw store not initialised");
+    if (nq > 0 && k > 0 && (!x || !distances || !labels)) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
+    return host_search(h, nq, h->raw_d, x, k, distances, labels, [&](const float* dx, float* dd, int64_t* dl) {
+        return flat_search_device_locked(h, p, nq, dx, k, dd, dl);
+    }, true, &lk);
+}
+
+static int ivfpq_search_host_locked(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x,
+                                   int k, float* distances, int64_t* labels) {
+    SearchLock lk(h);
+    GH_TRY(ivfpq_check(h, p, nq, k));
+    if (nq > 0 && k > 0 && (!x || !distances || !labels)) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
+    return host_search(h, nq, h->d, x, k, distances, labels, [&](const float* dx, float* dd, int64_t* dl) {
+        return ivfpq_search_device_locked(h, p, nq, dx, k, dd, dl);
+    }, true, &lk);
+}
+
+// Search is re-entrant in the reference and is called from many client threads at once, typically with
+// one query each (tools/perf.cc).  One GPU stream serves one call at a time, so small calls
+// that arrive while another is in flight are COMBINED: they queue, and a worker thread of the handle
+// (the reference's GPU model funnels its searches through one thread as well) takes every queued
+// request with the same parameters, runs them as one batch and hands the results back.  A call that
+// finds the handle idle runs directly on the caller's thread.
+// Results are those of the separate calls: rows are independent, and the coarse path (exact below 20
+// queries, GEMM form from 20 on, faiss:utils/distances.cpp:346) is the one each request's OWN size
+// selects -- requests only share a batch with requests that resolve to the same path.
+constexpr int COMB_MAX_NQ = 256, COMB_MAX_TOTAL = 4096;
+
+// filter table of a combined batch (h->mu held): entry i = request i's clauses + the delete bitmap
+static int build_group_filters(gamma_hip_index* h, const std::vector<gamma_hip_index::Waiter*>& grp, int total,
+                               std::vector<gh::FilterDesc>& tab, std::vector<int>& qf, FiltCtx* fc) {
+    GH_CHECK(h, hipSetDevice(h->device));
+    size_t tot = 0;
+    for (auto* g : grp)
+        if (g->p->has_range)
+            for (int i = 0; i < g->p->n_range; i++) tot += ((size_t)g->p->range[i].bitmap_bytes + 15) & ~(size_t)15;
+    GH_CHECK(h, h->w_filter.ensure(std::max<size_t>(tot, 16)));
+    tab.resize(grp.size());
+    qf.resize(total);
+    size_t off = 0;
+    int at = 0;
+    for (size_t i = 0; i < grp.size(); i++) {
+        GH_TRY(build_filter(h, grp[i]->p, &tab[i], &off));
+        for (int j = 0; j < grp[i]->nq; j++) qf[at++] = (int)i;
+    }
+    GH_CHECK(h, h->w_ftab.ensure(tab.size() * sizeof(gh::FilterDesc)));
+    GH_CHECK(h, h->w_qfil.ensure(qf.size() * sizeof(int)));
+    h->ftab_valid = false;   // entry 0 no longer holds a single call's descriptor
+    GH_CHECK(h, hipMemcpyAsync(h->w_ftab.p, tab.data(), tab.size() * sizeof(gh::FilterDesc), hipMemcpyHostToDevice, h->stream));
+    GH_CHECK(h, hipMemcpyAsync(h->w_qfil.p, qf.data(), qf.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    fc->d_tab = h->w_ftab.as<gh::FilterDesc>();
+    fc->d_qf = h->w_qfil.as<int>();
+    fc->any_clause = true;
+    return GAMMA_HIP_OK;
+}
+
+static void combine_worker(gamma_hip_index* h) {
+    using W = gamma_hip_index::Waiter;
+    auto same = [](const W* a, const W* b) {
+        return a->kind == b->kind && a->k == b->k && a->mode == b->mode && a->p->metric == b->p->metric &&
+               a->p->nprobe == b->p->nprobe &&
+               a->p->recall_num == b->p->recall_num && a->p->has_rank == b->p->has_rank &&
+               a->p->min_score == b->p->min_score && a->p->max_score == b->p->max_score;
+    };
+    // a batch in flight: its requests, where its results land, whether the stream still has to be awaited
+    struct Batch {
+        std::vector<W*> grp;
+        int rc = GAMMA_HIP_OK, total = 0, kk = 0;
+        float* sd = nullptr;
+        int64_t* si = nullptr;
+        bool enqueued = false;
+        int set = -1;                       // pinned staging set holding its inputs / results
+        std::vector<gh::FilterDesc> ftab;   // host images of the uploads, alive until the batch is awaited
+        std::vector<int> qf;
+        std::vector<int> rcs;               // per-request codes when the batch had to be redone one by one
+    };
+    // Results -> callers: a helper thread copies them out of the pinned staging set and wakes the callers
+    // (one futex wake per request costs the worker more than launching the next batch), so the worker only
+    // forms, launches and awaits batches.  A staging set is reused once its batch has been delivered.
+    std::mutex n_mu;
+    std::condition_variable n_cv;
+    std::deque<Batch> n_q;
+    bool n_stop = false;
+    std::atomic<bool> set_busy[2];
+    set_busy[0] = false;
+    set_busy[1] = false;
+    std::thread notifier([&]() {
+        std::unique_lock<std::mutex> nl(n_mu);
+        for (;;) {
+            n_cv.wait(nl, [&] { return n_stop || !n_q.empty(); });
+            if (n_q.empty()) break;   // stop requested and nothing left
+            Batch b = std::move(n_q.front());
+            n_q.pop_front();
+            nl.unlock();
+            if (b.rc == GAMMA_HIP_OK && b.sd) {   // no lock needed for the copies: the callers are blocked
+                size_t at = 0;
+                for (W* g : b.grp) {
+                    std::memcpy(g->D, b.sd + at * b.kk, (size_t)g->nq * b.kk * sizeof(float));
+                    std::memcpy(g->I, b.si + at * b.kk, (size_t)g->nq * b.kk * sizeof(int64_t));
+                    at += g->nq;
+                }
+            }
+            if (b.set >= 0) set_busy[b.set].store(false, std::memory_order_release);
+            {
+                std::lock_guard<std::mutex> cl(h->comb_mu);
+                for (size_t i = 0; i < b.grp.size(); i++) {
+                    W* g = b.grp[i];
+                    g->rc = b.rcs.empty() ? b.rc : b.rcs[i];
+                    g->done = true;
+                    g->cv.notify_one();
+                }
+            }
+            nl.lock();
+        }
+    });
+    auto post = [&](Batch&& b) {
+        if (b.grp.empty()) return;
+        {
+            std::lock_guard<std::mutex> nl(n_mu);
+            n_q.push_back(std::move(b));
+        }
+        n_cv.notify_one();
+    };
+    Batch cur;
+    int set = 0;
+    static const bool dbg = getenv("GAMMA_HIP_COMB_DBG") != nullptr;   // phase times of the worker, printed at exit
+    double us_stage = 0, us_deliver = 0, us_sync = 0;
+    long n_batches = 0, n_reqs = 0;
+    std::unique_lock<std::mutex> lk(h->comb_mu);
+    for (;;) {
+        h->comb_wcv.wait(lk, [&] { return h->comb_stop || (!h->comb_busy && !h->comb_q.empty()); });
+        if (h->comb_stop) break;
+        h->comb_busy = true;
+        // the handle stays busy until the queue is drained; delivery of batch N overlaps with forming and
+        // launching batch N+1
+        for (;;) {
+            cur = Batch();
+            const auto t_a = std::chrono::steady_clock::now();
+            if (!h->comb_q.empty()) {   // one group: the oldest request and everything compatible with it
+                W* first = h->comb_q.front();
+                for (auto it = h->comb_q.begin(); it != h->comb_q.end();) {
+                    if (same(first, *it) && (cur.grp.empty() || cur.total + (*it)->nq <= COMB_MAX_TOTAL)) {
+                        cur.total += (*it)->nq;
+                        cur.grp.push_back(*it);
+                        it = h->comb_q.erase(it);
+                    } else {
+                        ++it;
+                    }
+                }
+            }
+            lk.unlock();
+            if (!cur.grp.empty()) {
+                W* first = cur.grp.front();
+                gamma_hip_search_params pp = *first->p;
+                pp.coarse_mode = first->mode;
+                const bool flat = first->kind == 1;
+                const int d = flat ? h->raw_d : h->d, kk = first->k, total = cur.total;
+                cur.kk = kk;
+                const size_t bx = (size_t)total * d * sizeof(float), bd = (size_t)total * kk * sizeof(float),
+                             bi = (size_t)total * kk * sizeof(int64_t);
+                const size_t off_i = (bx + 15) & ~(size_t)15, off_d = off_i + ((bi + 15) & ~(size_t)15),
+                             need = off_d + bd;
+                while (set_busy[set].load(std::memory_order_acquire)) std::this_thread::yield();   // its last batch is being delivered
+                if (need > h->comb_pin_bytes[set]) {
+                    if (h->comb_pin[set]) (void)hipHostFree(h->comb_pin[set]);
+                    h->comb_pin[set] = nullptr;
+                    h->comb_pin_bytes[set] = 0;
+                    if (hipSetDevice(h->device) == hipSuccess &&
+                        hipHostMalloc(&h->comb_pin[set], need * 2, hipHostMallocDefault) == hipSuccess)
+                        h->comb_pin_bytes[set] = need * 2;
+                    else
+                        cur.rc = GAMMA_HIP_ENOMEM;
+                }
+                if (cur.rc == GAMMA_HIP_OK) {
+                    char* base = static_cast<char*>(h->comb_pin[set]);
+                    float* sx = reinterpret_cast<float*>(base);
+                    cur.si = reinterpret_cast<int64_t*>(base + off_i);
+                    cur.sd = reinterpret_cast<float*>(base + off_d);
+                    size_t at = 0;
+                    for (W* g : cur.grp) {
+                        std::memcpy(sx + at * d, g->x, (size_t)g->nq * d * sizeof(float));
+                        at += g->nq;
+                    }
+                    cur.set = set;
+                    set_busy[set].store(true, std::memory_order_release);
+                    h->search_mu.lock();   // held until the batch has been awaited (below)
+                    h->mu.lock();          // while the batch reads the handle and is enqueued
+                    cur.rc = flat ? check_params(h, &pp, total, kk) : ivfpq_check(h, &pp, total, kk);
+                    // requests with their own filter clauses: one table entry per request, a query -> entry map
+                    // (IVFPQ only: filtered flat requests are not combined)
+                    FiltCtx fc;
+                    bool any_filter = false;
+                    for (W* g : cur.grp) any_filter |= g->p->has_range || g->p->n_field > 0 || g->p->n_term > 0;
+                    const bool multi = !flat && any_filter && cur.grp.size() > 1;
+                    if (cur.rc == GAMMA_HIP_OK && multi) cur.rc = build_group_filters(h, cur.grp, total, cur.ftab, cur.qf, &fc);
+                    if (cur.rc == GAMMA_HIP_OK)
+                        cur.rc = host_search(h, total, d, sx, kk, cur.sd, cur.si,
+                                             [&](const float* dx, float* dd, int64_t* dl) {
+                                                 if (flat) return flat_search_device_locked(h, &pp, total, dx, kk, dd, dl);
+                                                 return ivfpq_search_device_locked(h, &pp, total, dx, kk, dd, dl,
+                                                                                   multi ? &fc : nullptr);
+                                             },
+                                             /*sync=*/false);
+                    h->mu.unlock();
+                    cur.enqueued = true;
+                }
+                set ^= 1;
+            }
+            const auto t_b = std::chrono::steady_clock::now();
+            const auto t_c = t_b;
+            if (cur.enqueued) {
+                if (hipStreamSynchronize(h->stream) != hipSuccess && cur.rc == GAMMA_HIP_OK) cur.rc = GAMMA_HIP_EDEVICE;
+                h->search_mu.unlock();
+                cur.enqueued = false;
+                if (cur.rc != GAMMA_HIP_OK && cur.grp.size() > 1) {
+                    // one request's parameters may be at fault (a filter on an unknown column, ...): every
+                    // request gets the outcome of its own call
+                    for (W* g : cur.grp) {
+                        gamma_hip_search_params pg = *g->p;
+                        pg.coarse_mode = g->mode;
+                        cur.rcs.push_back(g->kind == 1 ? flat_search_host_locked(h, &pg, g->nq, g->x, g->k, g->D, g->I)
+                                                       : ivfpq_search_host_locked(h, &pg, g->nq, g->x, g->k, g->D, g->I));
+                    }
+                    cur.sd = nullptr;   // results are already in the callers' buffers
+                    cur.rc = GAMMA_HIP_OK;
+                }
+            }
+            if (dbg) {
+                const auto t_d = std::chrono::steady_clock::now();
+                us_stage += std::chrono::duration<double, std::micro>(t_b - t_a).count();
+                us_deliver += std::chrono::duration<double, std::micro>(t_c - t_b).count();
+                us_sync += std::chrono::duration<double, std::micro>(t_d - t_c).count();
+                n_batches++;
+                n_reqs += (long)cur.grp.size();
+            }
+            post(std::move(cur));
+            lk.lock();
+            if (h->comb_q.empty()) break;
+        }
+        h->comb_busy = false;
+    }
+    lk.unlock();
+    {
+        std::lock_guard<std::mutex> nl(n_mu);
+        n_stop = true;
+    }
+    n_cv.notify_one();
+    notifier.join();
+    if (dbg && n_batches)
+        fprintf(stderr, "combine worker: %ld batches, %.1f requests each; per batch: group+stage+enqueue %.1f us, deliver previous %.1f us, "
+                "wait for the GPU %.1f us\n", n_batches, (double)n_reqs / n_batches, us_stage / n_batches, us_deliver / n_batches,
+                us_sync / n_batches);
+}
+
+static int combined_search(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x, int k,
+                           float* distances, int64_t* labels, int kind = 0) {
+    gamma_hip_index::Waiter w;
+    w.p = p; w.nq = nq; w.k = k; w.x = x; w.D = distances; w.I = labels;
+    w.kind = kind;
+    w.mode = kind == 1 ? 0 : (p->coarse_mode < 0 ? (nq < 20 ? 0 : 1) : p->coarse_mode);
+    std::unique_lock<std::mutex> lk(h->comb_mu);
+    if (!h->comb_busy && h->comb_q.empty()) {   // idle handle: run on this thread, no hop
+        h->comb_busy = true;
+        lk.unlock();
+        gamma_hip_search_params pp = *p;
+        pp.coarse_mode = w.mode;
+        const int rc = kind == 1 ? flat_search_host_locked(h, &pp, nq, x, k, distances, labels)
+                                 : ivfpq_search_host_locked(h, &pp, nq, x, k, distances, labels);
+        lk.lock();
+        h->comb_busy = false;
+        if (!h->comb_q.empty()) h->comb_wcv.notify_one();
+        return rc;
+    }
+    if (!h->comb_thread.joinable()) h->comb_thread = std::thread(combine_worker, h);
+    h->comb_q.push_back(&w);
+    h->comb_wcv.notify_one();
+    w.cv.wait(lk, [&] { return w.done; });
+    return w.rc;
+}
+
+int gamma_hip_ivfpq_search(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x,
+                           int k, float* distances, int64_t* labels) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    if (h->combine && p && nq > 0 && nq <= COMB_MAX_NQ && k > 0 && x && distances && labels && h->ivf_init && h->d > 0 &&
+        (!p->has_range || (p->n_range >= 0 && p->n_range <= gh::kMaxRange && (p->n_range == 0 || p->range))) &&
+        p->n_field >= 0 && p->n_field <= gh::kMaxField && (p->n_field == 0 || p->field) &&
+        p->n_term >= 0 && p->n_term <= gh::kMaxTerm && (p->n_term == 0 || p->term))
+        return combined_search(h, p, nq, x, k, distances, labels);
+    return ivfpq_search_host_locked(h, p, nq, x, k, distances, labels);
+}
+
+int gamma_hip_ivfpq_last_stages(gamma_hip_index* h, float* coarse_dis, int64_t* coarse_idx,
+                                float* recall_dis, int64_t* recall_ids) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    const int nq = h->last_nq, P = h->last_P, R = h->last_R;
+    if (nq <= 0) return fail(h, GAMMA_HIP_EINVAL, "no previous search");
+    GH_CHECK(h, hipSetDevice(h->device));
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    if (coarse_dis) GH_CHECK(h, hipMemcpy(coarse_dis, h->w_coarse_dis.p, (size_t)nq * P * sizeof(float), hipMemcpyDeviceToHost));
+    if (coarse_idx) {
+        std::vector<int> tmp((size_t)nq * P);
+        GH_CHECK(h, hipMemcpy(tmp.data(), h->w_probe.p, tmp.size() * sizeof(int), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < tmp.size(); i++) coarse_idx[i] = tmp[i];
+    }
+    if (recall_dis) GH_CHECK(h, hipMemcpy(recall_dis, h->w_cand_dis.p, (size_t)nq * R * sizeof(float), hipMemcpyDeviceToHost));
+    if (recall_ids) GH_CHECK(h, hipMemcpy(recall_ids, h->w_cand_ids.p, (size_t)nq * R * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_search_shard(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
+                                 const float* d_x, int k, float* d_recall_dis, int64_t* d_recall_ids) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    GH_TRY(ivfpq_check(h, p, nq, k));
+    if (k <= 0 || nq == 0) return GAMMA_HIP_OK;
+    if (!d_x || !d_recall_dis || !d_recall_ids) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
+    GH_CHECK(h, hipSetDevice(h->device));
+    const int R = std::max(p->recall_num, k);
+    gh::FilterDesc filt;
+    GH_TRY(build_filter(h, p, &filt));
+    FiltCtx fc;
+    GH_TRY(filt_ctx_single(h, filt, &fc));
+    gamma_hip_search_params pp = *p;
+    if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;   // decided on the whole call, not per chunk
+    p = &pp;
+    const int chunk = query_chunk(h, nq, p->nprobe);
+    for (int q0 = 0; q0 < nq; q0 += chunk) {
+        const int nc = std::min(chunk, nq - q0);
+        GH_TRY(ivfpq_stage_a(h, p, fc.at(q0), nc, d_x + (size_t)q0 * h->d, R, nullptr, nullptr, /*shard=*/true,
+                             d_recall_dis + (size_t)q0 * R, d_recall_ids + (size_t)q0 * R));
+        h->last_nq = nc;
+    }
+    h->last_P = p->nprobe;
+    h->last_R = R;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_coarse_device(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
+                                  const float* d_x, float* d_coarse_dis, int32_t* d_probe) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    GH_TRY(ivfpq_check(h, p, nq, 1));
+    if (nq == 0) return GAMMA_HIP_OK;
+    if (!d_x || !d_coarse_dis || !d_probe) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
+    GH_CHECK(h, hipSetDevice(h->device));
+    const int P = p->nprobe;
+    gamma_hip_search_params pp = *p;   // the caller resolves -1 on the size of the whole batch; a slice
+    if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;   // that arrives unresolved decides by itself
+    p = &pp;
+    const int chunk = coarse_chunk(h, nq);
+    for (int q0 = 0; q0 < nq; q0 += chunk)
+        GH_TRY(ivfpq_coarse(h, p, std::min(chunk, nq - q0), d_x + (size_t)q0 * h->d, d_coarse_dis + (size_t)q0 * P,
+                            d_probe + (size_t)q0 * P));
+    GH_CHECK(h, hipGetLastError());
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_search_shard_preassigned(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
+                                             const float* d_x, const float* d_coarse_dis,
+                                             const int32_t* d_probe, int k, float* d_recall_dis,
+                                             int64_t* d_recall_ids) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    GH_TRY(ivfpq_check(h, p, nq, k));
+    if (k <= 0 || nq == 0) return GAMMA_HIP_OK;
+    if (!d_coarse_dis || !d_probe) return fail(h, GAMMA_HIP_EINVAL, "null coarse assignment");
+    if (!d_x || !d_recall_dis || !d_recall_ids) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
+    GH_CHECK(h, hipSetDevice(h->device));
+    const int R = std::max(p->recall_num, k), P = p->nprobe;
+    gh::FilterDesc filt;
+    GH_TRY(build_filter(h, p, &filt));
+    FiltCtx fc;
+    GH_TRY(filt_ctx_single(h, filt, &fc));
+    const int chunk = query_chunk(h, nq, P);
+    for (int q0 = 0; q0 < nq; q0 += chunk) {
+        const int nc = std::min(chunk, nq - q0);
+        GH_TRY(ivfpq_stage_a(h, p, fc.at(q0), nc, d_x + (size_t)q0 * h->d, R, d_coarse_dis + (size_t)q0 * P,
+                             d_probe + (size_t)q0 * P, /*shard=*/true, d_recall_dis + (size_t)q0 * R,
+                             d_recall_ids + (size_t)q0 * R));
+        h->last_nq = nc;
+    }
+    h->last_P = P;
+    h->last_R = R;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_merge_rerank(gamma_hip_index* h, const gamma_hip_search_params* p, int nshards, int nq,
+                                 const float* d_x, int k, const float* d_all_dis, const int64_t* d_all_ids,
+                                 int q0, int nq_local, float* d_distances, int64_t* d_labels) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    GH_TRY(ivfpq_check(h, p, nq, k));
+    if (nshards <= 0 || q0 < 0 || nq_local < 0 || q0 + nq_local > nq) return fail(h, GAMMA_HIP_EINVAL, "bad shard/query range");
+    if (k <= 0 || nq_local == 0) return GAMMA_HIP_OK;
+    GH_CHECK(h, hipSetDevice(h->device));
+    const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
+    const int R = std::max(p->recall_num, k);
+    if ((int64_t)nshards * R > (int64_t)1 << 24) return fail(h, GAMMA_HIP_EINVAL, "too many candidates");
+    hipStream_t s = h->stream;
+    GH_CHECK(h, h->w_cand_dis.ensure((size_t)nq_local * R * sizeof(float)));
+    GH_CHECK(h, h->w_cand_ids.ensure((size_t)nq_local * R * sizeof(int64_t)));
+    {
+        StageScope t(h, GAMMA_HIP_STAGE_SELECT);
+        static const bool no_merge_kernel = getenv("GAMMA_HIP_NO_MERGE_KERNEL") != nullptr;
+        if (no_merge_kernel ||
+            !gh::launch_merge_shards(s, l2, d_all_dis, d_all_ids, nshards, nq, R, q0, nq_local,
+                                     h->w_cand_dis.as<float>(), h->w_cand_ids.as<int64_t>())) {
+            // general shapes: transpose to [nq][W * R], select, translate positions to ids
+            GH_CHECK(h, h->w_m_dis.ensure((size_t)nq * nshards * R * sizeof(float)));
+            GH_CHECK(h, h->w_m_ids.ensure((size_t)nq * nshards * R * sizeof(int64_t)));
+            GH_CHECK(h, h->w_cand_pos.ensure((size_t)nq_local * R * sizeof(int)));
+            gh::launch_gather_shards(s, d_all_dis, d_all_ids, nshards, nq, R, h->w_m_dis.as<float>(),
+                                     h->w_m_ids.as<int64_t>(), l2 ? INFINITY : -INFINITY);
+            const int64_t stride = (int64_t)nshards * R;
+            gh::launch_select_topk(s, l2, h->w_m_dis.as<float>() + (size_t)q0 * stride, stride, nullptr,
+                                   (int)stride, (int)stride, nq_local, R, h->w_cand_dis.as<float>(),
+                                   h->w_cand_pos.as<int>());
+            gh::launch_take_ids(s, h->w_cand_pos.as<int>(), h->w_m_ids.as<int64_t>() + (size_t)q0 * stride, stride,
+                                nq_local, R, h->w_cand_ids.as<int64_t>());
+        }
+        GH_CHECK(h, hipGetLastError());
+    }
+    return ivfpq_stage_b(h, p, nq_local, d_x + (size_t)q0 * h->d, R, k, h->w_cand_dis.as<float>(),
+                         h->w_cand_ids.as<int64_t>(), d_distances, d_labels);
+}
+
+int gamma_hip_flat_search_device(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
+                                 const float* d_x, int k, float* d_distances, int64_t* d_labels) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    return flat_search_device_locked(h, p, nq, d_x, k, d_distances, d_labels);
+}
+
+int gamma_hip_flat_search(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x,
+                          int k, float* distances, int64_t* labels) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    // small unfiltered calls from concurrent client threads share device batches (see gamma_hip_ivfpq_search)
+    if (h->combine && p && nq > 0 && nq <= COMB_MAX_NQ && k > 0 && x && distances && labels && h->raw_d > 0 &&
+        !p->has_range && p->n_range == 0 && p->n_field == 0 && p->n_term == 0)
+        return combined_search(h, p, nq, x, k, distances, labels, /*kind=*/1);
+    return flat_search_host_locked(h, p, nq, x, k, distances, labels);
+}
+
+
+}  // extern "C"

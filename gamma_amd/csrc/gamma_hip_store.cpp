@@ -1,0 +1,934 @@
+// gamma_hip_store.cpp -- the writers of libgamma_hip.so: the realtime inverted-list arena (growth law, repack,
+// versioned (offset, length) tables), training state, Add / Update / Delete / compaction, device-side encoding, the raw
+// vector store, scalar columns and the delete bitmap.  C ABI: include/gamma_hip.h.
+#include "gamma_hip_internal.h"
+
+namespace ghi {
+
+
+// ---- arena ---------------------------------------------------------------------------
+int arena_reserve(H* h, int64_t need_entries) {
+    if (h->arena_used + need_entries <= h->arena_cap) return GAMMA_HIP_OK;
+    int64_t ncap = std::max<int64_t>(h->arena_cap * 2, h->arena_used + need_entries);
+    ncap += ncap / 8;
+    uint8_t* nc = nullptr;
+    int64_t* ni = nullptr;
+    if (h->wl) GH_CHECK(h, h->wl->exclusive());   // the old arrays are freed below: no search may be reading them
+    GH_CHECK(h, hipMalloc((void**)&nc, (size_t)ncap * h->code_size));
+    GH_CHECK(h, hipMalloc((void**)&ni, (size_t)ncap * sizeof(int64_t)));
+    if (h->arena_used > 0) {
+        GH_CHECK(h, hipMemcpyAsync(nc, h->d_codes, (size_t)h->arena_used * h->code_size,
+                                   hipMemcpyDeviceToDevice, h->wstream));
+        GH_CHECK(h, hipMemcpyAsync(ni, h->d_ids, (size_t)h->arena_used * sizeof(int64_t),
+                                   hipMemcpyDeviceToDevice, h->wstream));
+    }
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    if (h->d_codes) GH_CHECK(h, hipFree(h->d_codes));
+    if (h->d_ids) GH_CHECK(h, hipFree(h->d_ids));
+    h->d_codes = nc;
+    h->d_ids = ni;
+    h->arena_cap = ncap;
+    return GAMMA_HIP_OK;
+}
+
+// The reference frees a bucket's old memory after a grow / compact swap (delayed by 1 s,
+// realtime_mem_data.cc:457-466).  Here grown and compacted extents are abandoned inside the arena
+// (arena_waste); once they are more than half of what is in use -- and worth at least a megabyte of codes --
+// every list moves into a fresh, tight arena: one kernel, offsets re-published in stream order.
+int arena_repack(H* h) {
+    int64_t total = 0;
+    std::vector<int64_t> noff(h->nlist);
+    for (int l = 0; l < h->nlist; l++) {
+        noff[l] = total;
+        total += h->h_list_cap[l];
+    }
+    const int64_t ncap = total + total / 8 + 1024;
+    uint8_t* nc = nullptr;
+    int64_t* ni = nullptr;
+    if (h->wl) GH_CHECK(h, h->wl->exclusive());   // every list moves and the old arrays are freed
+    GH_TRY(publish_meta(h));                      // the device tables the kernel below reads = the host mirror
+    GH_CHECK(h, hipMalloc((void**)&nc, (size_t)ncap * h->code_size));
+    if (hipMalloc((void**)&ni, (size_t)ncap * sizeof(int64_t)) != hipSuccess) {
+        (void)hipFree(nc);
+        return fail(h, GAMMA_HIP_ENOMEM, "arena repack: out of memory");
+    }
+    GH_CHECK(h, h->we_stage.ensure((size_t)h->nlist * sizeof(int64_t)));
+    GH_CHECK(h, hipMemcpyAsync(h->we_stage.p, noff.data(), (size_t)h->nlist * sizeof(int64_t), hipMemcpyHostToDevice, h->wstream));
+    gh::launch_repack_lists(h->wstream, h->d_codes, h->d_ids, nc, ni, h->d_list_off, h->we_stage.as<int64_t>(),
+                            h->d_list_len, h->nlist, h->code_size, h->max_list_len);
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));   // noff is a local; the old arrays are free to go
+    GH_CHECK(h, hipFree(h->d_codes));
+    GH_CHECK(h, hipFree(h->d_ids));
+    h->d_codes = nc;
+    h->d_ids = ni;
+    h->arena_cap = ncap;
+    h->arena_used = total;
+    h->arena_waste = 0;
+    h->h_list_off = noff;
+    h->n_repacks++;
+    return publish_meta(h);
+}
+int arena_repack_if_need(H* h) {
+    const int64_t min_waste = std::max<int64_t>(h->repack_min_entries, 1);
+    if (h->arena_waste < min_waste || h->arena_waste * 2 < h->arena_used) return GAMMA_HIP_OK;
+    return arena_repack(h);
+}
+
+// RealTimeMemData::ExtendBucketIfNeed + RTInvertBucketData::ExtendBucketMem
+// (realtime_mem_data.cc:383-421,152-188): same growth law, region moved inside the arena.
+int list_ensure(H* h, int l, int add) {
+    const int len = h->h_list_len[l], cap = h->h_list_cap[l];
+    if ((int64_t)len + add <= cap) return GAMMA_HIP_OK;
+    if ((int64_t)cap * 2 >= h->bucket_max) return fail(h, GAMMA_HIP_EFULL, "exceed the max bucket keys");
+    const int least = len + add;
+    double coef = extend_coefficient(++h->h_extend_time[l]);
+    int ext = (int)(cap * coef);
+    while (ext < least) {
+        coef = extend_coefficient(++h->h_extend_time[l]);
+        ext = (int)(ext * coef);
+    }
+    GH_TRY(arena_reserve(h, ext));
+    const int64_t noff = h->arena_used;
+    if (len > 0) {
+        GH_CHECK(h, hipMemcpyAsync(h->d_codes + noff * h->code_size,
+                                   h->d_codes + h->h_list_off[l] * h->code_size,
+                                   (size_t)len * h->code_size, hipMemcpyDeviceToDevice, h->wstream));
+        GH_CHECK(h, hipMemcpyAsync(h->d_ids + noff, h->d_ids + h->h_list_off[l],
+                                   (size_t)len * sizeof(int64_t), hipMemcpyDeviceToDevice, h->wstream));
+    }
+    h->arena_waste += cap;
+    h->arena_used += ext;
+    h->h_list_off[l] = noff;   // the old extent stays intact: searches in flight read it through their version
+    h->h_list_cap[l] = ext;
+    return GAMMA_HIP_OK;
+}
+
+int add_keys_locked(H* h, int l, int n, const int64_t* vids, const uint8_t* codes) {
+    if (l < 0 || l >= h->nlist || n < 0) return fail(h, GAMMA_HIP_EINVAL, "bad list_no");
+    if (n == 0) return GAMMA_HIP_OK;
+    GH_TRY(list_ensure(h, l, n));
+    const int64_t pos = h->h_list_off[l] + h->h_list_len[l];
+    GH_CHECK(h, hipMemcpyAsync(h->d_ids + pos, vids, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice,
+                               h->wstream));
+    GH_CHECK(h, hipMemcpyAsync(h->d_codes + pos * h->code_size, codes, (size_t)n * h->code_size,
+                               hipMemcpyHostToDevice, h->wstream));
+    for (int i = 0; i < n; i++) {
+        const int64_t v = vids[i];
+        if (v < 0) {   // superseded slot restored from a dump (ReadInvertedLists, gamma_index_io.cc:186-189)
+            h->h_deleted[l]++;
+            h->n_moved++;
+            continue;
+        }
+        if ((size_t)v >= h->vid_pos.size()) h->vid_pos.resize(std::max<size_t>(h->vid_pos.size() * 2, v + 1), -1);
+        h->vid_pos[v] = ((int64_t)l << 32) | (int64_t)(h->h_list_len[l] + i);
+        if (h->doc_deleted(v)) h->h_deleted[l]++;  // realtime_mem_data.cc:293-296
+    }
+    h->h_list_len[l] += n;  // publish after the copies (realtime_mem_data.cc:299-300)
+    h->ntotal += n;
+    GH_TRY(publish_meta(h));
+    // the host buffers may be reused by the caller as soon as we return
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    return arena_repack_if_need(h);
+}
+// Spatial order of the coarse centroids by recursive principal-axis bisection: split the set at
+// the median of its projection on the dominant direction (a few power iterations), recurse.
+// Neighbouring ranks = neighbouring centroids.  Used only to order queries for cache locality.
+void centroid_order_rec(const float* cc, int d, std::vector<int>& idx, int lo, int hi, std::vector<float>& proj,
+                        std::vector<double>& mean, std::vector<double>& dir, std::vector<double>& tmp) {
+    const int n = hi - lo;
+    if (n <= 2) return;
+    for (int t = 0; t < d; t++) mean[t] = 0;
+    for (int i = lo; i < hi; i++) {
+        const float* c = cc + (size_t)idx[i] * d;
+        for (int t = 0; t < d; t++) mean[t] += c[t];
+    }
+    for (int t = 0; t < d; t++) mean[t] /= n;
+    // start from the direction to the point farthest from the mean (never orthogonal to the data)
+    double best = -1;
+    int far = lo;
+    for (int i = lo; i < hi; i++) {
+        const float* c = cc + (size_t)idx[i] * d;
+        double s = 0;
+        for (int t = 0; t < d; t++) s += (c[t] - mean[t]) * (c[t] - mean[t]);
+        if (s > best) { best = s; far = i; }
+    }
+    for (int t = 0; t < d; t++) dir[t] = cc[(size_t)idx[far] * d + t] - mean[t];
+    for (int it = 0; it < 6; it++) {
+        for (int t = 0; t < d; t++) tmp[t] = 0;
+        for (int i = lo; i < hi; i++) {
+            const float* c = cc + (size_t)idx[i] * d;
+            double pr = 0;
+            for (int t = 0; t < d; t++) pr += (c[t] - mean[t]) * dir[t];
+            for (int t = 0; t < d; t++) tmp[t] += pr * (c[t] - mean[t]);
+        }
+        double nrm = 0;
+        for (int t = 0; t < d; t++) nrm += tmp[t] * tmp[t];
+        if (nrm <= 0) break;
+        nrm = std::sqrt(nrm);
+        for (int t = 0; t < d; t++) dir[t] = tmp[t] / nrm;
+    }
+    for (int i = lo; i < hi; i++) {
+        const float* c = cc + (size_t)idx[i] * d;
+        double pr = 0;
+        for (int t = 0; t < d; t++) pr += (c[t] - mean[t]) * dir[t];
+        proj[idx[i]] = (float)pr;
+    }
+    const int mid = lo + n / 2;
+    std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi,
+                     [&](int a, int b) { return proj[a] < proj[b] || (proj[a] == proj[b] && a < b); });
+    centroid_order_rec(cc, d, idx, lo, mid, proj, mean, dir, tmp);
+    centroid_order_rec(cc, d, idx, mid, hi, proj, mean, dir, tmp);
+}
+
+std::vector<int> centroid_rank(const float* cc, int nlist, int d) {
+    std::vector<int> idx(nlist), rank(nlist);
+    for (int i = 0; i < nlist; i++) idx[i] = i;
+    std::vector<float> proj(nlist);
+    std::vector<double> mean(d), dir(d), tmp(d);
+    centroid_order_rec(cc, d, idx, 0, nlist, proj, mean, dir, tmp);
+    for (int i = 0; i < nlist; i++) rank[idx[i]] = i;
+    return rank;
+}
+
+}  // namespace ghi
+
+using namespace ghi;
+
+extern "C" {
+
+
+int gamma_hip_field_append(gamma_hip_index* h, int field_id, int dtype, int64_t n, const void* values) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    if (dtype < GAMMA_HIP_FIELD_INT || dtype > GAMMA_HIP_FIELD_DOUBLE || n < 0 || (n > 0 && !values))
+        return fail(h, GAMMA_HIP_EINVAL, "bad column append");
+    GH_CHECK(h, hipSetDevice(h->device));
+    auto& c = h->fields[field_id];
+    if (c.n == 0 && c.cap == 0) c.dtype = dtype;
+    if (c.dtype != dtype) return fail(h, GAMMA_HIP_EINVAL, "column dtype mismatch");
+    const size_t es = field_elem_size(dtype);
+    if (c.n + n > c.cap) {
+        const int64_t ncap = std::max<int64_t>(c.n + n, std::max<int64_t>(1 << 16, c.cap * 2));
+        uint8_t* nd = nullptr;
+        GH_CHECK(h, lk.exclusive());   // the old column is freed below
+        GH_CHECK(h, hipMalloc((void**)&nd, (size_t)ncap * es));
+        if (c.n) GH_CHECK(h, hipMemcpyAsync(nd, c.d, (size_t)c.n * es, hipMemcpyDeviceToDevice, h->wstream));
+        GH_CHECK(h, hipStreamSynchronize(h->wstream));
+        if (c.d) (void)hipFree(c.d);
+        c.d = nd;
+        c.cap = ncap;
+    }
+    if (n) {
+        GH_CHECK(h, hipMemcpyAsync(c.d + (size_t)c.n * es, values, (size_t)n * es, hipMemcpyHostToDevice, h->wstream));
+        GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    }
+    c.n += n;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_field_update(gamma_hip_index* h, int field_id, int64_t docid, const void* value) {
+    if (!h || !value) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    auto it = h->fields.find(field_id);
+    if (it == h->fields.end() || docid < 0 || docid >= it->second.n) return fail(h, GAMMA_HIP_EINVAL, "bad column update");
+    GH_CHECK(h, hipSetDevice(h->device));
+    const size_t es = field_elem_size(it->second.dtype);
+    GH_CHECK(h, hipMemcpyAsync(it->second.d + (size_t)docid * es, value, es, hipMemcpyHostToDevice, h->wstream));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_vid2docid_append(gamma_hip_index* h, int64_t n, const int32_t* docids) {
+    if (!h || n < 0 || (n > 0 && !docids)) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    GH_CHECK(h, hipSetDevice(h->device));
+    const int64_t have = (int64_t)h->h_v2d.size();
+    if (have + n > h->v2d_cap) {
+        const int64_t ncap = std::max<int64_t>(have + n, std::max<int64_t>(1 << 16, h->v2d_cap * 2));
+        int32_t* nd = nullptr;
+        GH_CHECK(h, lk.exclusive());   // the old array is freed below
+        GH_CHECK(h, hipMalloc((void**)&nd, (size_t)ncap * sizeof(int32_t)));
+        if (have) GH_CHECK(h, hipMemcpyAsync(nd, h->d_v2d, (size_t)have * sizeof(int32_t), hipMemcpyDeviceToDevice, h->wstream));
+        GH_CHECK(h, hipStreamSynchronize(h->wstream));
+        if (h->d_v2d) (void)hipFree(h->d_v2d);
+        h->d_v2d = nd;
+        h->v2d_cap = ncap;
+    }
+    if (n) {
+        GH_CHECK(h, hipMemcpyAsync(h->d_v2d + have, docids, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, h->wstream));
+        GH_CHECK(h, hipStreamSynchronize(h->wstream));
+        h->h_v2d.insert(h->h_v2d.end(), docids, docids + n);   // published last: searches enqueued before see the shorter map
+    }
+    return GAMMA_HIP_OK;
+}
+
+int64_t gamma_hip_vid2docid_count(gamma_hip_index* h) {
+    if (!h) return -1;
+    std::lock_guard<std::mutex> g(h->mu);
+    return (int64_t)h->h_v2d.size();
+}
+
+int64_t gamma_hip_field_count(gamma_hip_index* h, int field_id) {
+    if (!h) return -1;
+    std::lock_guard<std::mutex> g(h->mu);
+    auto it = h->fields.find(field_id);
+    return it == h->fields.end() ? 0 : it->second.n;
+}
+
+int gamma_hip_term_append(gamma_hip_index* h, int field_id, int64_t n_docs, const int32_t* counts,
+                          const int32_t* items) {
+    if (!h || n_docs < 0 || (n_docs > 0 && !counts)) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    GH_CHECK(h, hipSetDevice(h->device));
+    auto& c = h->terms[field_id];
+    int64_t add_tok = 0;
+    for (int64_t i = 0; i < n_docs; i++) {
+        if (counts[i] < 0) return fail(h, GAMMA_HIP_EINVAL, "negative item count");
+        add_tok += counts[i];
+    }
+    if (add_tok > 0 && !items) return fail(h, GAMMA_HIP_EINVAL, "null items");
+    if (c.ndocs + n_docs + 1 > c.cap_docs || c.ntok + add_tok > c.cap_tok || !c.d_off) {
+        // growth frees the old arrays: no search may be reading them
+        GH_CHECK(h, lk.exclusive());
+        const int64_t nd = std::max<int64_t>(c.ndocs + n_docs + 1, std::max<int64_t>(1 << 16, c.cap_docs * 2));
+        const int64_t nt = std::max<int64_t>(c.ntok + add_tok, std::max<int64_t>(1 << 16, c.cap_tok * 2));
+        int64_t* no = nullptr;
+        int32_t* ntk = nullptr;
+        GH_CHECK(h, hipMalloc((void**)&no, (size_t)nd * sizeof(int64_t)));
+        GH_CHECK(h, hipMalloc((void**)&ntk, (size_t)nt * sizeof(int32_t)));
+        if (c.d_off) {
+            GH_CHECK(h, hipMemcpyAsync(no, c.d_off, (size_t)(c.ndocs + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, h->wstream));
+            if (c.ntok) GH_CHECK(h, hipMemcpyAsync(ntk, c.d_tok, (size_t)c.ntok * sizeof(int32_t), hipMemcpyDeviceToDevice, h->wstream));
+        } else {
+            GH_CHECK(h, hipMemsetAsync(no, 0, sizeof(int64_t), h->wstream));   // off[0] = 0
+        }
+        GH_CHECK(h, hipStreamSynchronize(h->wstream));
+        if (c.d_off) (void)hipFree(c.d_off);
+        if (c.d_tok) (void)hipFree(c.d_tok);
+        c.d_off = no;
+        c.d_tok = ntk;
+        c.cap_docs = nd;
+        c.cap_tok = nt;
+    }
+    if (n_docs > 0) {
+        std::vector<int64_t> off(n_docs);
+        int64_t run = c.ntok;
+        for (int64_t i = 0; i < n_docs; i++) {
+            run += counts[i];
+            off[i] = run;
+        }
+        if (add_tok) GH_CHECK(h, hipMemcpyAsync(c.d_tok + c.ntok, items, (size_t)add_tok * sizeof(int32_t), hipMemcpyHostToDevice, h->wstream));
+        GH_CHECK(h, hipMemcpyAsync(c.d_off + c.ndocs + 1, off.data(), (size_t)n_docs * sizeof(int64_t), hipMemcpyHostToDevice, h->wstream));
+        GH_CHECK(h, hipStreamSynchronize(h->wstream));
+        c.ntok += add_tok;
+        c.ndocs += n_docs;   // published last: a search enqueued before sees the shorter column
+    }
+    return GAMMA_HIP_OK;
+}
+
+int64_t gamma_hip_term_count(gamma_hip_index* h, int field_id) {
+    if (!h) return -1;
+    std::lock_guard<std::mutex> g(h->mu);
+    auto it = h->terms.find(field_id);
+    return it == h->terms.end() ? 0 : it->second.ndocs;
+}
+
+int gamma_hip_raw_init(gamma_hip_index* h, int d) {
+    if (!h || d <= 0) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    if (h->raw_d != 0 && h->raw_d != d) return fail(h, GAMMA_HIP_EINVAL, "raw store dimension mismatch");
+    h->raw_d = d;
+    return GAMMA_HIP_OK;
+}
+
+static int raw_reserve(H* h, int64_t need) {
+    if (need <= h->raw_cap) return GAMMA_HIP_OK;
+    int64_t ncap = std::max<int64_t>(need, h->raw_cap + h->raw_cap / 2);
+    ncap = std::max<int64_t>(ncap, 1024);
+    float* np = nullptr;
+    if (h->wl) GH_CHECK(h, h->wl->exclusive());   // the old store is freed below
+    GH_CHECK(h, hipMalloc((void**)&np, (size_t)ncap * h->raw_d * sizeof(float)));
+    if (h->nraw > 0)
+        GH_CHECK(h, hipMemcpyAsync(np, h->d_raw, (size_t)h->nraw * h->raw_d * sizeof(float),
+                                   hipMemcpyDeviceToDevice, h->wstream));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    if (h->d_raw) GH_CHECK(h, hipFree(h->d_raw));
+    h->d_raw = np;
+    h->raw_cap = ncap;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_raw_append(gamma_hip_index* h, int64_t n, const float* vecs) {
+    if (!h || n < 0 || (n > 0 && !vecs)) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    if (h->raw_d <= 0) return fail(h, GAMMA_HIP_EINVAL, "raw store not initialised");
+    if (n == 0) return GAMMA_HIP_OK;
+    GH_CHECK(h, hipSetDevice(h->device));
+    GH_TRY(raw_reserve(h, h->nraw + n));
+    GH_CHECK(h, hipMemcpyAsync(h->d_raw + h->nraw * h->raw_d, vecs, (size_t)n * h->raw_d * sizeof(float),
+                               hipMemcpyHostToDevice, h->wstream));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    h->nraw += n;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_raw_write(gamma_hip_index* h, int64_t first_vid, int64_t n, const float* vecs) {
+    if (!h || n < 0 || first_vid < 0 || (n > 0 && !vecs)) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    if (h->raw_d <= 0) return fail(h, GAMMA_HIP_EINVAL, "raw store not initialised");
+    if (first_vid > h->nraw) return fail(h, GAMMA_HIP_EINVAL, "raw write would leave a gap");
+    if (n == 0) return GAMMA_HIP_OK;
+    GH_CHECK(h, hipSetDevice(h->device));
+    GH_TRY(raw_reserve(h, first_vid + n));
+    GH_CHECK(h, hipMemcpyAsync(h->d_raw + first_vid * h->raw_d, vecs, (size_t)n * h->raw_d * sizeof(float),
+                               hipMemcpyHostToDevice, h->wstream));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    h->nraw = std::max(h->nraw, first_vid + n);
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_raw_update(gamma_hip_index* h, int64_t vid, const float* vec) {
+    if (!h || !vec) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    if (vid < 0 || vid >= h->nraw) return fail(h, GAMMA_HIP_EINVAL, "vid out of range");
+    GH_CHECK(h, hipSetDevice(h->device));
+    GH_CHECK(h, hipMemcpyAsync(h->d_raw + vid * h->raw_d, vec, (size_t)h->raw_d * sizeof(float),
+                               hipMemcpyHostToDevice, h->wstream));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    return GAMMA_HIP_OK;
+}
+
+int64_t gamma_hip_raw_count(gamma_hip_index* h) { return h ? h->nraw : -1; }
+
+/* ---- delete bitmap ------------------------------------------------------------------- */
+static int bitmap_reserve(H* h, int64_t nbits) {
+    size_t bytes = (((size_t)nbits >> 3) + 1 + 3) & ~(size_t)3;
+    if (bytes <= h->bitmap_cap_bytes) return GAMMA_HIP_OK;
+    size_t ncap = std::max(bytes, h->bitmap_cap_bytes * 2);
+    uint8_t* np = nullptr;
+    if (h->wl) GH_CHECK(h, h->wl->exclusive());   // the old bitmap is freed below
+    GH_CHECK(h, hipMalloc((void**)&np, ncap));
+    GH_CHECK(h, hipMemsetAsync(np, 0, ncap, h->wstream));
+    if (h->d_bitmap)
+        GH_CHECK(h, hipMemcpyAsync(np, h->d_bitmap, h->bitmap_cap_bytes, hipMemcpyDeviceToDevice, h->wstream));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    if (h->d_bitmap) GH_CHECK(h, hipFree(h->d_bitmap));
+    h->d_bitmap = np;
+    h->bitmap_cap_bytes = ncap;
+    h->h_bitmap.resize(ncap, 0);
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_bitmap_upload(gamma_hip_index* h, const uint8_t* bitmap, int64_t nbits) {
+    if (!h || nbits < 0 || (nbits > 0 && !bitmap)) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    GH_CHECK(h, hipSetDevice(h->device));
+    GH_TRY(bitmap_reserve(h, nbits));
+    size_t bytes = ((size_t)nbits >> 3) + 1;  // bitmap::create, util/bitmap.cc:15-23
+    GH_CHECK(h, hipMemsetAsync(h->d_bitmap, 0, h->bitmap_cap_bytes, h->wstream));
+    GH_CHECK(h, hipMemcpyAsync(h->d_bitmap, bitmap, bytes, hipMemcpyHostToDevice, h->wstream));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    std::fill(h->h_bitmap.begin(), h->h_bitmap.end(), 0);
+    memcpy(h->h_bitmap.data(), bitmap, bytes);
+    h->bitmap_bits = nbits;
+    h->bitmap_any = false;
+    for (size_t i = 0; i < bytes && !h->bitmap_any; i++) h->bitmap_any = bitmap[i] != 0;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_bitmap_set(gamma_hip_index* h, const int64_t* docids, int64_t n, int value) {
+    if (!h || n < 0 || (n > 0 && !docids)) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    if (n == 0) return GAMMA_HIP_OK;
+    GH_CHECK(h, hipSetDevice(h->device));
+    int64_t mx = 0;
+    for (int64_t i = 0; i < n; i++) mx = std::max(mx, docids[i]);
+    if (mx >= h->bitmap_bits) {
+        GH_TRY(bitmap_reserve(h, mx + 1));
+        h->bitmap_bits = std::max<int64_t>(h->bitmap_bits, mx + 1);
+    }
+    GH_CHECK(h, h->we_stage.ensure((size_t)n * sizeof(int64_t)));
+    GH_CHECK(h, hipMemcpyAsync(h->we_stage.p, docids, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, h->wstream));
+    gh::launch_bitmap_set(h->wstream, h->d_bitmap, h->we_stage.as<int64_t>(), n, h->bitmap_bits, value);
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    for (int64_t i = 0; i < n; i++) {
+        int64_t id = docids[i];
+        if (id < 0) continue;
+        if (value) h->bitmap_any = true;
+        if (value) h->h_bitmap[id >> 3] |= (uint8_t)(1u << (id & 7));
+        else h->h_bitmap[id >> 3] &= (uint8_t)~(1u << (id & 7));
+    }
+    return GAMMA_HIP_OK;
+}
+
+/* ---- IVFPQ / IVFFLAT models ----------------------------------------------------------- */
+static int ivf_init_locked(gamma_hip_index* h, int d, int nlist, int M, int metric, int bucket_init_size,
+                           int bucket_max_size, bool flat);
+int gamma_hip_ivfpq_init(gamma_hip_index* h, int d, int nlist, int M, int nbits, int metric,
+                         int bucket_init_size, int bucket_max_size) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    if (h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "already initialised");
+    if (d <= 0 || nlist <= 0 || M <= 0) return fail(h, GAMMA_HIP_EINVAL, "bad d/nlist/M");
+    if (nbits != 8) return fail(h, GAMMA_HIP_EINVAL, "only nbits_per_idx == 8 is supported on device");
+    if (d % M != 0) return fail(h, GAMMA_HIP_EINVAL, "d must be divisible by nsubvector");
+    if (d / M > 64) return fail(h, GAMMA_HIP_EINVAL, "dsub > 64 unsupported");
+    if (M > 64) return fail(h, GAMMA_HIP_EINVAL, "nsubvector > 64 unsupported (LUT must fit 64 KiB LDS)");
+    return ivf_init_locked(h, d, nlist, M, metric, bucket_init_size, bucket_max_size, false);
+}
+
+static int ivf_init_locked(gamma_hip_index* h, int d, int nlist, int M, int metric, int bucket_init_size,
+                           int bucket_max_size, bool flat) {
+    if (metric != GAMMA_HIP_METRIC_IP && metric != GAMMA_HIP_METRIC_L2) return fail(h, GAMMA_HIP_EINVAL, "bad metric");
+    GH_CHECK(h, hipSetDevice(h->device));
+    h->ivfflat = flat;
+    h->d = d;
+    h->nlist = nlist;
+    h->M = M;
+    h->dsub = d / M;
+    h->code_size = M;   // IVFFLAT: M = 1, one dummy byte per entry (the arena code keeps its shape)
+    h->metric = metric;
+    h->bucket_init = bucket_init_size > 0 ? bucket_init_size : 1000;
+    h->bucket_max = bucket_max_size > 0 ? bucket_max_size : 1280000;
+    GH_CHECK(h, hipMalloc((void**)&h->d_cc, (size_t)nlist * d * sizeof(float)));
+    GH_CHECK(h, hipMalloc((void**)&h->d_cc_norms, (size_t)nlist * sizeof(float)));
+    GH_CHECK(h, hipMalloc((void**)&h->d_pqc, flat ? 256 : (size_t)M * 256 * h->dsub * sizeof(float)));
+    GH_CHECK(h, hipMalloc((void**)&h->d_T2, flat ? 256 : (size_t)nlist * M * 256 * sizeof(float)));
+    for (int v = 0; v < H::NVER; v++) {
+        GH_CHECK(h, hipMalloc((void**)&h->d_ver_off[v], (size_t)nlist * sizeof(int64_t)));
+        GH_CHECK(h, hipMalloc((void**)&h->d_ver_len[v], (size_t)nlist * sizeof(int)));
+        GH_CHECK(h, hipHostMalloc(&h->pin_ver[v], (size_t)nlist * (sizeof(int64_t) + sizeof(int)), hipHostMallocDefault));
+    }
+    h->d_list_off = h->d_ver_off[0];
+    h->d_list_len = h->d_ver_len[0];
+    // RTInvertBucketData::Init (realtime_mem_data.cc:57-96): bucket_init entries per list
+    h->h_list_off.resize(nlist);
+    h->h_list_len.assign(nlist, 0);
+    h->h_list_cap.assign(nlist, h->bucket_init);
+    h->h_deleted.assign(nlist, 0);
+    h->h_extend_time.assign(nlist, 0);
+    for (int l = 0; l < nlist; l++) h->h_list_off[l] = (int64_t)l * h->bucket_init;
+    h->arena_used = 0;
+    GH_TRY(arena_reserve(h, (int64_t)nlist * h->bucket_init));
+    h->arena_used = (int64_t)nlist * h->bucket_init;
+    GH_TRY(publish_meta(h));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    h->vid_pos.assign((size_t)nlist * h->bucket_init, -1);
+    h->ivf_init = true;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfflat_init(gamma_hip_index* h, int d, int nlist, int metric, int bucket_init_size, int bucket_max_size) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    if (h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "already initialised");
+    if (d <= 0 || nlist <= 0) return fail(h, GAMMA_HIP_EINVAL, "bad d/nlist");
+    return ivf_init_locked(h, d, nlist, 1, metric, bucket_init_size, bucket_max_size, true);
+}
+
+int gamma_hip_ivfflat_set_trained(gamma_hip_index* h, const float* cc) {
+    if (!h || !cc) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    if (!h->ivf_init || !h->ivfflat) return fail(h, GAMMA_HIP_EINVAL, "ivfflat not initialised");
+    GH_CHECK(h, hipSetDevice(h->device));
+    GH_CHECK(h, hipMemcpyAsync(h->d_cc, cc, (size_t)h->nlist * h->d * sizeof(float), hipMemcpyHostToDevice, h->wstream));
+    gh::launch_row_norms(h->wstream, h->d_cc, h->nlist, h->d, h->d_cc_norms);
+    GH_CHECK(h, hipGetLastError());
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    h->trained = true;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_set_trained(gamma_hip_index* h, const float* cc, const float* pqc, const float* table) {
+    if (!h || !cc || !pqc) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    if (!h->ivf_init || h->ivfflat) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
+    GH_CHECK(h, hipSetDevice(h->device));
+    const size_t ncc = (size_t)h->nlist * h->d, npq = (size_t)h->M * 256 * h->dsub;
+    const size_t nt = (size_t)h->nlist * h->M * 256;
+    GH_CHECK(h, hipMemcpyAsync(h->d_cc, cc, ncc * sizeof(float), hipMemcpyHostToDevice, h->wstream));
+    GH_CHECK(h, hipMemcpyAsync(h->d_pqc, pqc, npq * sizeof(float), hipMemcpyHostToDevice, h->wstream));
+    gh::launch_row_norms(h->wstream, h->d_cc, h->nlist, h->d, h->d_cc_norms);
+    if (table)
+        GH_CHECK(h, hipMemcpyAsync(h->d_T2, table, nt * sizeof(float), hipMemcpyHostToDevice, h->wstream));
+    else
+        gh::launch_precompute_table(h->wstream, h->d_cc, h->nlist, h->d, h->M, h->d_pqc, h->d_T2);
+    {
+        std::vector<int> rank = centroid_rank(cc, h->nlist, h->d);
+        if (!h->d_list_rank) GH_CHECK(h, hipMalloc((void**)&h->d_list_rank, (size_t)h->nlist * sizeof(int)));
+        GH_CHECK(h, hipMemcpyAsync(h->d_list_rank, rank.data(), (size_t)h->nlist * sizeof(int),
+                                   hipMemcpyHostToDevice, h->wstream));
+        GH_CHECK(h, hipStreamSynchronize(h->wstream));   // rank is a local
+    }
+    GH_CHECK(h, hipGetLastError());
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    h->trained = true;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_get_precomputed_table(gamma_hip_index* h, float* out) {
+    if (!h || !out) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    if (!h->trained) return fail(h, GAMMA_HIP_ENOTTRAINED, "not trained");
+    GH_CHECK(h, hipSetDevice(h->device));
+    GH_CHECK(h, hipMemcpyAsync(out, h->d_T2, (size_t)h->nlist * h->M * 256 * sizeof(float),
+                               hipMemcpyDeviceToHost, h->wstream));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    return GAMMA_HIP_OK;
+}
+
+/* ---- realtime lists ------------------------------------------------------------------- */
+int gamma_hip_ivfpq_add_keys(gamma_hip_index* h, int list_no, int n, const int64_t* vids, const uint8_t* codes) {
+    if (!h || (n > 0 && (!vids || !codes))) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    if (!h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
+    GH_CHECK(h, hipSetDevice(h->device));
+    return add_keys_locked(h, list_no, n, vids, codes);
+}
+
+int gamma_hip_ivfpq_add_keys_batch(gamma_hip_index* h, int nlists, const int32_t* list_nos,
+                                   const int32_t* counts, const int64_t* vids, const uint8_t* codes) {
+    if (!h || nlists < 0 || (nlists > 0 && (!list_nos || !counts || !vids || !codes))) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    if (!h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
+    GH_CHECK(h, hipSetDevice(h->device));
+    int64_t off = 0;
+    // grow first so that no copy below races with an arena move; a list named twice reserves for the sum
+    {
+        std::map<int, int64_t> per_list;
+        for (int i = 0; i < nlists; i++) {
+            if (list_nos[i] < 0 || list_nos[i] >= h->nlist || counts[i] < 0) return fail(h, GAMMA_HIP_EINVAL, "bad list_no");
+            per_list[list_nos[i]] += counts[i];
+        }
+        for (auto& kv : per_list) {
+            if (kv.second > h->bucket_max) return fail(h, GAMMA_HIP_EFULL, "exceed the max bucket keys");
+            GH_TRY(list_ensure(h, kv.first, (int)kv.second));
+        }
+    }
+    for (int i = 0; i < nlists; i++) {
+        const int l = list_nos[i], n = counts[i];
+        if (n == 0) continue;
+        const int64_t pos = h->h_list_off[l] + h->h_list_len[l];
+        GH_CHECK(h, hipMemcpyAsync(h->d_ids + pos, vids + off, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, h->wstream));
+        GH_CHECK(h, hipMemcpyAsync(h->d_codes + pos * h->code_size, codes + off * h->code_size,
+                                   (size_t)n * h->code_size, hipMemcpyHostToDevice, h->wstream));
+        for (int j = 0; j < n; j++) {
+            const int64_t v = vids[off + j];
+            if (v < 0) {   // superseded slot restored from a dump: same accounting as add_keys_locked, so that
+                h->h_deleted[l]++;   // the scan reads the ids (n_moved) and never returns the slot
+                h->n_moved++;
+                continue;
+            }
+            if ((size_t)v >= h->vid_pos.size()) h->vid_pos.resize(std::max<size_t>(h->vid_pos.size() * 2, v + 1), -1);
+            h->vid_pos[v] = ((int64_t)l << 32) | (int64_t)(h->h_list_len[l] + j);
+            if (h->doc_deleted(v)) h->h_deleted[l]++;
+        }
+        h->h_list_len[l] += n;
+        h->ntotal += n;
+        if (h->h_list_len[l] > h->max_list_len) h->max_list_len = h->h_list_len[l];
+        off += n;
+    }
+    // publish the new lengths (and moved extents) after the copies, in stream order
+    GH_TRY(publish_meta(h));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    return arena_repack_if_need(h);
+}
+
+int gamma_hip_ivfpq_update(gamma_hip_index* h, int list_no, int64_t vid, const uint8_t* code) {
+    if (!h || !code) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    if (!h->ivf_init || list_no < 0 || list_no >= h->nlist) return fail(h, GAMMA_HIP_EINVAL, "bad list_no");
+    if (vid < 0 || (size_t)vid >= h->vid_pos.size()) return GAMMA_HIP_OK;  // realtime_mem_data.cc:307
+    const int64_t bp = h->vid_pos[vid];
+    if (bp == -1) return GAMMA_HIP_OK;
+    GH_CHECK(h, hipSetDevice(h->device));
+    const int ob = (int)(bp >> 32), op = (int)(bp & 0xffffffff);
+    if (ob == list_no) {
+        GH_CHECK(h, hipMemcpyAsync(h->d_codes + (h->h_list_off[ob] + op) * h->code_size, code, h->code_size,
+                                   hipMemcpyHostToDevice, h->wstream));
+        GH_CHECK(h, hipStreamSynchronize(h->wstream));
+        return GAMMA_HIP_OK;
+    }
+    gh::launch_mark_moved(h->wstream, h->d_ids, h->h_list_off[ob] + op);
+    h->h_deleted[ob]++;
+    h->n_moved++;
+    h->ntotal -= 1;  // add_keys_locked re-counts it
+    return add_keys_locked(h, list_no, 1, &vid, code);
+}
+
+int gamma_hip_ivfpq_has_vid(gamma_hip_index* h, const int64_t* vids, int n, uint8_t* out) {
+    if (!h || n < 0 || (n > 0 && (!vids || !out))) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    for (int i = 0; i < n; i++)
+        out[i] = vids[i] >= 0 && (size_t)vids[i] < h->vid_pos.size() && h->vid_pos[vids[i]] != -1;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_remove(gamma_hip_index* h, int64_t vid) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    if (!h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
+    if (vid < 0 || (size_t)vid >= h->vid_pos.size()) return GAMMA_HIP_OK;
+    const int64_t bp = h->vid_pos[vid];
+    if (bp == -1) return GAMMA_HIP_OK;
+    GH_CHECK(h, hipSetDevice(h->device));
+    const int ob = (int)(bp >> 32), op = (int)(bp & 0xffffffff);
+    gh::launch_mark_moved(h->wstream, h->d_ids, h->h_list_off[ob] + op);
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    h->h_deleted[ob]++;
+    h->n_moved++;
+    h->ntotal -= 1;
+    h->vid_pos[vid] = -1;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_delete(gamma_hip_index* h, const int64_t* vids, int n) {
+    if (!h || (n > 0 && !vids)) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    for (int i = 0; i < n; i++) {
+        if (vids[i] < 0 || (size_t)vids[i] >= h->vid_pos.size()) continue;
+        const int64_t bp = h->vid_pos[vids[i]];
+        if (bp == -1) continue;
+        h->h_deleted[bp >> 32]++;
+    }
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_compact_if_need(gamma_hip_index* h) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    if (!h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
+    GH_CHECK(h, hipSetDevice(h->device));
+    std::vector<int64_t> ids;
+    std::vector<uint8_t> codes;
+    bool changed = false;
+    for (int l = 0; l < h->nlist; l++) {
+        const int len = h->h_list_len[l];
+        if (!((float)h->h_deleted[l] / len >= 0.3f)) continue;  // Compactable, :373-377
+        ids.resize(len);
+        codes.resize((size_t)len * h->code_size);
+        GH_CHECK(h, hipMemcpyAsync(ids.data(), h->d_ids + h->h_list_off[l], (size_t)len * sizeof(int64_t), hipMemcpyDeviceToHost, h->wstream));
+        GH_CHECK(h, hipMemcpyAsync(codes.data(), h->d_codes + h->h_list_off[l] * h->code_size, (size_t)len * h->code_size, hipMemcpyDeviceToHost, h->wstream));
+        GH_CHECK(h, hipStreamSynchronize(h->wstream));
+        int pos = 0;
+        for (int i = 0; i < len; i++) {  // CompactOne, :98-112
+            const int64_t id = ids[i];
+            const int64_t v = id & ~kDelMask;
+            const bool deleted = h->doc_deleted(v);
+            if (!(id & kDelMask) && !deleted) {
+                ids[pos] = id;
+                memmove(codes.data() + (size_t)pos * h->code_size, codes.data() + (size_t)i * h->code_size, h->code_size);
+                h->vid_pos[id] = ((int64_t)l << 32) | pos;
+                pos++;
+            }
+        }
+        // new region of the same capacity (copy-on-write swap, :426-474)
+        GH_TRY(arena_reserve(h, h->h_list_cap[l]));
+        const int64_t noff = h->arena_used;
+        h->arena_used += h->h_list_cap[l];
+        h->arena_waste += h->h_list_cap[l];
+        if (pos > 0) {
+            GH_CHECK(h, hipMemcpyAsync(h->d_ids + noff, ids.data(), (size_t)pos * sizeof(int64_t), hipMemcpyHostToDevice, h->wstream));
+            GH_CHECK(h, hipMemcpyAsync(h->d_codes + noff * h->code_size, codes.data(), (size_t)pos * h->code_size, hipMemcpyHostToDevice, h->wstream));
+        }
+        h->h_list_off[l] = noff;
+        h->ntotal -= (len - pos);
+        h->h_list_len[l] = pos;
+        h->h_deleted[l] = 0;
+        GH_CHECK(h, hipStreamSynchronize(h->wstream));   // ids / codes are locals of this loop
+        changed = true;
+    }
+    if (changed) {
+        GH_TRY(publish_meta(h));
+        GH_CHECK(h, hipStreamSynchronize(h->wstream));
+        GH_TRY(arena_repack_if_need(h));
+    }
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_arena_stats(gamma_hip_index* h, int64_t* out4) {
+    if (!h || !out4) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    out4[0] = h->arena_cap;
+    out4[1] = h->arena_used;
+    out4[2] = h->arena_waste;
+    out4[3] = h->n_repacks;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_set_repack_threshold(gamma_hip_index* h, int64_t min_waste_entries) {
+    if (!h || min_waste_entries < 0) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    if (!h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
+    GH_CHECK(h, hipSetDevice(h->device));
+    h->repack_min_entries = min_waste_entries;
+    return arena_repack_if_need(h);
+}
+
+int64_t gamma_hip_ivfpq_list_size(gamma_hip_index* h, int l) {
+    if (!h || !h->ivf_init || l < 0 || l >= h->nlist) return -1;
+    return h->h_list_len[l];
+}
+int64_t gamma_hip_ivfpq_list_capacity(gamma_hip_index* h, int l) {
+    if (!h || !h->ivf_init || l < 0 || l >= h->nlist) return -1;
+    return h->h_list_cap[l];
+}
+
+int gamma_hip_ivfpq_get_list(gamma_hip_index* h, int l, int64_t* vids, uint8_t* codes) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    if (!h->ivf_init || l < 0 || l >= h->nlist) return fail(h, GAMMA_HIP_EINVAL, "bad list_no");
+    const int len = h->h_list_len[l];
+    if (len == 0) return GAMMA_HIP_OK;
+    GH_CHECK(h, hipSetDevice(h->device));
+    if (vids) GH_CHECK(h, hipMemcpyAsync(vids, h->d_ids + h->h_list_off[l], (size_t)len * sizeof(int64_t), hipMemcpyDeviceToHost, h->wstream));
+    if (codes) GH_CHECK(h, hipMemcpyAsync(codes, h->d_codes + h->h_list_off[l] * h->code_size, (size_t)len * h->code_size, hipMemcpyDeviceToHost, h->wstream));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_set_list_mask(gamma_hip_index* h, const uint8_t* owned) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    if (!h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
+    GH_CHECK(h, hipSetDevice(h->device));
+    GH_CHECK(h, lk.exclusive());
+    if (!owned) {
+        if (h->d_list_mask) GH_CHECK(h, hipFree(h->d_list_mask));
+        h->d_list_mask = nullptr;
+        h->h_list_mask.clear();
+        return GAMMA_HIP_OK;
+    }
+    if (!h->d_list_mask) GH_CHECK(h, hipMalloc((void**)&h->d_list_mask, (size_t)h->nlist));
+    h->h_list_mask.assign(owned, owned + h->nlist);
+    GH_CHECK(h, hipMemcpyAsync(h->d_list_mask, owned, (size_t)h->nlist, hipMemcpyHostToDevice, h->wstream));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    return GAMMA_HIP_OK;
+}
+
+/* ---- device-side encode / add ----------------------------------------------------------- */
+// exact: the arithmetic form faiss picks from the size of the WHOLE assign() call (n < 20), not of a chunk
+static int encode_locked(H* h, int64_t n, const float* d_vecs, int* d_assign, uint8_t* d_codes_out, bool exact) {
+    // quantizer->assign == search with k = 1 (faiss rule for the arithmetic form)
+    hipStream_t s = h->wstream;   // own stream and own workspace: runs beside the searches
+    const int d = h->d, nlist = h->nlist;
+    GH_CHECK(h, h->we_mat.ensure((size_t)n * nlist * sizeof(float)));
+    GH_CHECK(h, h->we_cdis.ensure((size_t)n * sizeof(float)));
+    if (exact) {
+        gh::launch_pairwise(s, true, d_vecs, (int)n, d, h->d_cc, nlist, h->we_mat.as<float>(), nlist);
+    } else {
+        gh::launch_l2_gemmform(s, d_vecs, (int)n, d, h->d_cc, nlist, nullptr, h->d_cc_norms,
+                               h->we_mat.as<float>(), nlist, true);
+    }
+    gh::launch_select_topk(s, true, h->we_mat.as<float>(), nlist, nullptr, nlist, nlist, (int)n, 1,
+                           h->we_cdis.as<float>(), d_assign);
+    if (h->ivfflat) GH_CHECK(h, hipMemsetAsync(d_codes_out, 0, (size_t)n, s));   // the dummy byte of every entry
+    else gh::launch_pq_encode(s, d_vecs, n, d, h->M, d_assign, h->d_cc, h->d_pqc, d_codes_out);
+    GH_CHECK(h, hipGetLastError());
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_encode(gamma_hip_index* h, int64_t n, const float* vecs, int64_t* list_nos, uint8_t* codes) {
+    if (!h || n < 0 || (n > 0 && (!vecs || !list_nos || !codes))) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    if (!h->trained) return fail(h, GAMMA_HIP_ENOTTRAINED, "not trained");
+    if (n == 0) return GAMMA_HIP_OK;
+    GH_CHECK(h, hipSetDevice(h->device));
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n, 65536), (int64_t)(h->dist_budget_bytes / ((size_t)h->nlist * sizeof(float)))));
+    std::vector<int> assign(chunk);
+    for (int64_t i0 = 0; i0 < n; i0 += chunk) {
+        const int64_t nc = std::min(chunk, n - i0);
+        GH_CHECK(h, h->we_x.ensure((size_t)nc * h->d * sizeof(float)));
+        GH_CHECK(h, h->we_assign.ensure((size_t)nc * sizeof(int)));
+        GH_CHECK(h, h->we_codes.ensure((size_t)nc * h->code_size));
+        GH_CHECK(h, hipMemcpyAsync(h->we_x.p, vecs + i0 * h->d, (size_t)nc * h->d * sizeof(float), hipMemcpyHostToDevice, h->wstream));
+        GH_TRY(encode_locked(h, nc, h->we_x.as<float>(), h->we_assign.as<int>(), h->we_codes.as<uint8_t>(), n < 20));
+        GH_CHECK(h, hipMemcpyAsync(assign.data(), h->we_assign.p, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, h->wstream));
+        GH_CHECK(h, hipMemcpyAsync(codes + i0 * h->code_size, h->we_codes.p, (size_t)nc * h->code_size, hipMemcpyDeviceToHost, h->wstream));
+        GH_CHECK(h, hipStreamSynchronize(h->wstream));
+        for (int64_t i = 0; i < nc; i++) list_nos[i0 + i] = assign[i];
+    }
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_assign(gamma_hip_index* h, int d, int64_t n, const float* x, int k, const float* centroids,
+                     int32_t* assign, float* dis) {
+    if (!h || d <= 0 || n < 0 || k <= 0 || (n > 0 && (!x || !centroids || !assign))) return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    if (n == 0) return GAMMA_HIP_OK;
+    GH_CHECK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    // centroids + their norms live in the (otherwise unused here) partial-result buffers
+    GH_CHECK(h, h->w_part_v.ensure((size_t)k * d * sizeof(float)));
+    GH_CHECK(h, h->w_xn.ensure((size_t)k * sizeof(float)));
+    GH_CHECK(h, hipMemcpyAsync(h->w_part_v.p, centroids, (size_t)k * d * sizeof(float), hipMemcpyHostToDevice, s));
+    gh::launch_row_norms(s, h->w_part_v.as<float>(), k, d, h->w_xn.as<float>());
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(h->dist_budget_bytes / ((size_t)k * sizeof(float)))));
+    for (int64_t i0 = 0; i0 < n; i0 += chunk) {
+        const int64_t nc = std::min(chunk, n - i0);
+        GH_CHECK(h, h->w_x.ensure((size_t)nc * d * sizeof(float)));
+        GH_CHECK(h, h->w_mat.ensure((size_t)nc * k * sizeof(float)));
+        GH_CHECK(h, h->w_assign.ensure((size_t)nc * sizeof(int)));
+        GH_CHECK(h, h->w_coarse_dis.ensure((size_t)nc * sizeof(float)));
+        GH_CHECK(h, hipMemcpyAsync(h->w_x.p, x + i0 * d, (size_t)nc * d * sizeof(float), hipMemcpyHostToDevice, s));
+        gh::launch_l2_gemmform(s, h->w_x.as<float>(), (int)nc, d, h->w_part_v.as<float>(), k, nullptr,
+                               h->w_xn.as<float>(), h->w_mat.as<float>(), k, true);
+        gh::launch_select_topk(s, true, h->w_mat.as<float>(), k, nullptr, k, k, (int)nc, 1,
+                               h->w_coarse_dis.as<float>(), h->w_assign.as<int>());
+        GH_CHECK(h, hipGetLastError());
+        GH_CHECK(h, hipMemcpyAsync(assign + i0, h->w_assign.p, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, s));
+        if (dis) GH_CHECK(h, hipMemcpyAsync(dis + i0, h->w_coarse_dis.p, (size_t)nc * sizeof(float), hipMemcpyDeviceToHost, s));
+        GH_CHECK(h, hipStreamSynchronize(s));
+    }
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_add(gamma_hip_index* h, int64_t n, const float* vecs, int64_t first_vid) {
+    if (!h || n < 0 || (n > 0 && !vecs)) return GAMMA_HIP_EINVAL;
+    if (n == 0) return GAMMA_HIP_OK;
+    std::vector<int64_t> lno(n);
+    std::vector<uint8_t> codes;
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        if (!h->trained) return fail(h, GAMMA_HIP_ENOTTRAINED, "not trained");
+        codes.resize((size_t)n * h->code_size);
+    }
+    GH_TRY(gamma_hip_ivfpq_encode(h, n, vecs, lno.data(), codes.data()));
+    // group by list in ascending list order (std::map in gamma_index_ivfpq.cc:428-494)
+    const int cs = h->code_size;
+    std::vector<int64_t> order(n);
+    for (int64_t i = 0; i < n; i++) {
+        if (lno[i] < 0) lno[i] = (first_vid + i) % h->nlist;
+        order[i] = i;
+    }
+    // list-sharded index: every shard is handed the same batch and keeps the vectors whose list it owns
+    // (realtime inserts route to the owner of the assigned list) -- no exchange needed
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        if (!h->h_list_mask.empty()) {
+            int64_t m = 0;
+            for (int64_t i = 0; i < n; i++)
+                if (h->h_list_mask[lno[i]]) order[m++] = i;
+            order.resize(m);
+        }
+    }
+    const int64_t nkeep = (int64_t)order.size();
+    if (nkeep == 0) return GAMMA_HIP_OK;
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return lno[a] < lno[b]; });
+    std::vector<int32_t> lists, counts;
+    std::vector<int64_t> vids(nkeep);
+    std::vector<uint8_t> gcodes((size_t)nkeep * cs);
+    for (int64_t i = 0; i < nkeep; i++) {
+        const int64_t src = order[i];
+        vids[i] = first_vid + src;
+        memcpy(gcodes.data() + (size_t)i * cs, codes.data() + (size_t)src * cs, cs);
+        if (lists.empty() || lists.back() != (int32_t)lno[src]) {
+            lists.push_back((int32_t)lno[src]);
+            counts.push_back(0);
+        }
+        counts.back()++;
+    }
+    return gamma_hip_ivfpq_add_keys_batch(h, (int)lists.size(), lists.data(), counts.data(), vids.data(), gcodes.data());
+}
+
+}  // extern "C"

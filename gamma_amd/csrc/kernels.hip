@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void k_pairwise_rowreg(const float* __restrict
 // v_pk_fma_f32 on two of the eight lane accumulators at a time (IEEE per component: same bits).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int PW_QT = 32;
-// EMIT (flat search with a running bound, gamma_hip.cpp flat_search_device_locked): instead of writing
+// EMIT (flat search with a running bound, gamma_hip_search.cpp flat_search_device_locked): instead of writing
 // the nq x ny distance slab, append (key << 32 | row id) of every distance within the query's current
 // bound tau[q] to the query's candidate list (cand[q][cap], cnt[q]; an atomic per survivor, and there
 // are about k per query and chunk).  Keys order like the distances ("smaller is better").
@@ -2170,7 +2170,7 @@ void launch_mark_moved(hipStream_t s, int64_t* ids, int64_t pos) {
     hipLaunchKernelGGL(k_mark_moved, dim3(1), dim3(64), 0, s, ids, pos);
 }
 
-// Arena repack (gamma_hip.cpp, arena_repack): every list's live entries move from (old arrays, old offset)
+// Arena repack (gamma_hip_store.cpp, arena_repack): every list's live entries move from (old arrays, old offset)
 // to (new arrays, new offset).  grid = (nlist, chunks); the code bytes move as dwords when M % 4 == 0.
 __global__ __launch_bounds__(256) void k_repack_lists(const uint8_t* __restrict__ oc, const int64_t* __restrict__ oi,
                                                       uint8_t* __restrict__ nc, int64_t* __restrict__ ni,

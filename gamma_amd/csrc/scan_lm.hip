@@ -12,7 +12,7 @@
 // inside a block of queries the rows hit in the XCD's L2 (the query-major kernel streams ~1.6 x the code bytes
 // in T2 rows from the fabric).
 //
-// Shape of the stage (gamma_hip.cpp, ivfpq_stage_a):
+// Shape of the stage (gamma_hip_search.cpp, ivfpq_stage_a):
 //   1. k_ivfpq_scan_pair, producers only: every query's FIRST probe group, bound tau[q], its own survivors
 //   2. k_lm_units: per block of LM_B queries (in the scan's spatial query order) the consumer pairs are
 //      sorted by list and cut into units of two pairs (one when a list is probed an odd number of times);

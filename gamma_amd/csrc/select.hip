@@ -1117,7 +1117,7 @@ bool launch_merge_shards(hipStream_t s, bool smallest, const float* all_dis, con
 }
 
 // ------------------------------------------------------------------------------------
-// Flat search with a running bound (gamma_hip.cpp, flat_search_device_locked; the emitting
+// Flat search with a running bound (gamma_hip_search.cpp, flat_search_device_locked; the emitting
 // distance kernel is k_pairwise_lds<.., EMIT> in kernels.hip).  A query's candidate list holds
 // (key << 32 | row id) items: ascending 64-bit order = (distance, row id) order, the order the
 // reference's scan + heap leaves behind up to the membership inside exact ties.
@@ -1436,7 +1436,7 @@ void launch_select_final(hipStream_t s, bool smallest, const unsigned long long*
                          int* out_pos, int64_t* out_ids, uint8_t* cut_tie, unsigned long long* tie_stats,
                          int* rq_list, int* rq_count, const unsigned long long* surv_c, int cap_c) {
     if (nq <= 0) return;
-    if (P > 128 || nslices > 64) abort();   // callers gate on this (gamma_hip.cpp, ivfpq_stage_a)
+    if (P > 128 || nslices > 64) abort();   // callers gate on this (gamma_hip_search.cpp, ivfpq_stage_a)
 #define GH_SF(SM, PM)                                                                                        \
     hipLaunchKernelGGL((k_select_final<SM, PM>), dim3((nq + 3) / 4), dim3(256), 0, s, surv, gcnt, nslices,   \
                        slice_cap, ready, pair_off, P, nq, K, pair_base, ids, flag,                           \

@@ -123,7 +123,7 @@ def test_ivfflat_add_update_delete_follow_the_reference_lists():
 
 @pytest.mark.parametrize("metric,d,nlist", [(B.METRIC_L2, 32, 256), (B.METRIC_IP, 100, 256), (B.METRIC_L2, 128, 1024)])
 def test_ivfflat_small_batch_chain_is_the_regular_chain(metric, d, nlist):
-    """Small calls (fewer (query, probe) pairs than 2 nlist) run as four launches (gamma_hip.cpp ivfflat_small): results
+    """Small calls (fewer (query, probe) pairs than 2 nlist) run as four launches (gamma_hip_search.cpp ivfflat_small): results
     byte for byte those of the regular chain -- deletes, a range filter, a score window, k beyond the candidates, the
     two-level selection forced -- and the oracle's."""
     case = fixtures.trained_case(d=d, nlist=nlist, M=d // 4, N=20000, nq=64, metric=B.METRIC_L2)

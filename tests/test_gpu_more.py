@@ -1071,7 +1071,7 @@ def test_fused_coarse_matches_matrix_path_and_oracle(d, nlist, P, nq):
                                               (100, 20, 64, B.METRIC_L2), (100, 25, 96, B.METRIC_IP),
                                               (768, 64, 64, B.METRIC_IP)])
 def test_small_batch_path_is_the_regular_chain(d, M, nlist, metric):
-    """Calls of up to 512 queries run as four or five fused kernels (gamma_hip.cpp ivfpq_small); every output and every stage
+    """Calls of up to 512 queries run as four or five fused kernels (gamma_hip_search.cpp ivfpq_small); every output and every stage
     table must equal the regular chain's, byte for byte: with / without re-rank, recall_num above and below the
     candidate count, k > candidates, deleted docs, a score window, and the oracle for good measure."""
     case = fixtures.trained_case(d=d, nlist=nlist, M=M, N=20000 if d < 512 else 6000, nq=64, metric=metric)
