@@ -221,6 +221,7 @@ struct gamma_hip_index {
     size_t comb_pin_bytes[2] = {0, 0};
     // pinned staging of small direct calls (host_search; the search lock serialises its users)
     void* dir_pin = nullptr;
+    void* dir_pin_dev = nullptr;   // its address on the device (hipHostGetDevicePointer), nullptr: not mapped
     size_t dir_pin_bytes = 0;
 
     // profiling

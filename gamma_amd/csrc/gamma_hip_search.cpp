@@ -1004,6 +1004,8 @@ int host_search(H* h, int nq, int d, const float* x, int k, float* distances, in
             h->dir_pin_bytes = 0;
             GH_CHECK(h, hipHostMalloc(&h->dir_pin, std::max<size_t>(need * 2, 65536), hipHostMallocDefault));
             h->dir_pin_bytes = std::max<size_t>(need * 2, 65536);
+            h->dir_pin_dev = nullptr;
+            if (hipHostGetDevicePointer(&h->dir_pin_dev, h->dir_pin, 0) != hipSuccess) h->dir_pin_dev = nullptr;
         }
         char* base = static_cast<char*>(h->dir_pin);
         std::memcpy(base, x, bx);
@@ -1011,9 +1013,8 @@ int host_search(H* h, int nq, int d, const float* x, int k, float* distances, in
         // results: the last kernel of the chain stores them straight into the staging area (pinned host memory is
         // mapped into the device's address space; a few KB of posted writes) -- no copy back at all
         static const bool no_map = getenv("GAMMA_HIP_NO_MAPPED_RESULTS") != nullptr;
-        void* dbase = nullptr;
-        if (!no_map && hipHostGetDevicePointer(&dbase, base, 0) == hipSuccess && dbase) {
-            char* db = static_cast<char*>(dbase);
+        if (!no_map && h->dir_pin_dev) {
+            char* db = static_cast<char*>(h->dir_pin_dev);
             GH_TRY(f(h->w_x.as<float>(), reinterpret_cast<float*>(db + off_d), reinterpret_cast<int64_t*>(db + off_i)));
         } else {
             GH_TRY(f(h->w_x.as<float>(), h->w_outd.as<float>(), h->w_outl.as<int64_t>()));
