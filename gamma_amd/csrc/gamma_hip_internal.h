@@ -206,8 +206,15 @@ struct gamma_hip_index {
         float* D;
         int64_t* I;
         int rc = 0;
+        // delivery (gamma_hip_search.cpp, combine_worker): every waiter sleeps on its OWN mutex + condition variable; the
+        // worker's helper copies a batch's rows into the callers' buffers, links the waiters into a forest, wakes the
+        // first FAN, and every woken waiter wakes FAN more on its way out -- a batch of 128 is awake after three hops
+        // instead of 128 wake-ups issued by one thread through one mutex
+        static constexpr int FAN = 4;
         bool done = false;
-        std::condition_variable cv;   // woken when done
+        std::mutex wm;
+        std::condition_variable cv;
+        Waiter* child[FAN] = {nullptr, nullptr, nullptr, nullptr};
     };
     std::mutex comb_mu;
     std::condition_variable comb_wcv;   // the worker waits here
@@ -216,9 +223,12 @@ struct gamma_hip_index {
     bool comb_stop = false;
     std::thread comb_thread;
     bool combine = getenv("GAMMA_HIP_NO_COMBINE") == nullptr;
-    // pinned staging of the combined batches, two sets (only the worker touches them)
-    void* comb_pin[2] = {nullptr, nullptr};
-    size_t comb_pin_bytes[2] = {0, 0};
+    // pinned staging of the combined batches: one set per batch from formation until its last caller has copied its
+    // rows out (only the worker allocates them); four, so that forming a batch never waits for a delivery
+    static constexpr int NSET = 4;
+    void* comb_pin[NSET] = {nullptr, nullptr, nullptr, nullptr};
+    void* comb_pin_dev[NSET] = {nullptr, nullptr, nullptr, nullptr};   // their addresses on the device (results are stored in place)
+    size_t comb_pin_bytes[NSET] = {0, 0, 0, 0};
     // pinned staging of small direct calls (host_search; the search lock serialises its users)
     void* dir_pin = nullptr;
     void* dir_pin_dev = nullptr;   // its address on the device (hipHostGetDevicePointer), nullptr: not mapped

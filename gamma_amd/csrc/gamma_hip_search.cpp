@@ -984,7 +984,7 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
 // this call waits for the GPU (search_mu stays: the workspaces are in use)
 template <typename F>
 int host_search(H* h, int nq, int d, const float* x, int k, float* distances, int64_t* labels, F&& f,
-                bool sync = true, SearchLock* lk = nullptr) {
+                bool sync = true, SearchLock* lk = nullptr, float* mapped_d = nullptr, int64_t* mapped_i = nullptr) {
     if (nq <= 0 || k <= 0) return f(nullptr, nullptr, nullptr);
     GH_CHECK(h, hipSetDevice(h->device));
     GH_CHECK(h, h->w_x.ensure((size_t)nq * d * sizeof(float)));
@@ -1028,6 +1028,12 @@ int host_search(H* h, int nq, int d, const float* x, int k, float* distances, in
         return GAMMA_HIP_OK;
     }
     GH_CHECK(h, hipMemcpyAsync(h->w_x.p, x, (size_t)nq * d * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (mapped_d && mapped_i) {   // distances / labels are pinned and mapped (the combining queue's staging set): stored in place
+        GH_TRY(f(h->w_x.as<float>(), mapped_d, mapped_i));
+        if (lk) lk->enqueued();
+        if (sync) GH_CHECK(h, hipStreamSynchronize(h->stream));
+        return GAMMA_HIP_OK;
+    }
     GH_TRY(f(h->w_x.as<float>(), h->w_outd.as<float>(), h->w_outl.as<int64_t>()));
     GH_CHECK(h, hipMemcpyAsync(distances, h->w_outd.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     GH_CHECK(h, hipMemcpyAsync(labels, h->w_outl.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
@@ -1128,6 +1134,14 @@ static int build_group_filters(gamma_hip_index* h, const std::vector<gamma_hip_i
     return GAMMA_HIP_OK;
 }
 
+// wake one waiter of the combining queue.  Notified under ITS mutex: it cannot leave combined_search (and destroy the
+// condition variable, which lives on its stack) before this thread is done with it.
+static void comb_wake(gamma_hip_index::Waiter* w) {
+    std::lock_guard<std::mutex> l(w->wm);
+    w->done = true;
+    w->cv.notify_one();
+}
+
 static void combine_worker(gamma_hip_index* h) {
     using W = gamma_hip_index::Waiter;
     auto same = [](const W* a, const W* b) {
@@ -1155,9 +1169,9 @@ static void combine_worker(gamma_hip_index* h) {
     std::condition_variable n_cv;
     std::deque<Batch> n_q;
     bool n_stop = false;
-    std::atomic<bool> set_busy[2];
-    set_busy[0] = false;
-    set_busy[1] = false;
+    constexpr int NSET = gamma_hip_index::NSET;
+    std::atomic<bool> set_busy[NSET];
+    for (int i = 0; i < NSET; i++) set_busy[i] = false;
     std::thread notifier([&]() {
         std::unique_lock<std::mutex> nl(n_mu);
         for (;;) {
@@ -1166,7 +1180,13 @@ static void combine_worker(gamma_hip_index* h) {
             Batch b = std::move(n_q.front());
             n_q.pop_front();
             nl.unlock();
-            if (b.rc == GAMMA_HIP_OK && b.sd) {   // no lock needed for the copies: the callers are blocked
+            // rows -> the callers' buffers (they are blocked; a batch of 128 is 15 KB), the staging set is free again --
+            // NOT left to the callers: one of them descheduled for a time slice would hold its set, and with more
+            // client threads than cores every set was soon held by a straggler -- then the waiters are linked and the
+            // roots woken (comb_wake); the forest unfolds on the callers' own threads
+            const size_t n = b.grp.size();
+            constexpr size_t ROOTS = 16;   // woken by this thread (batches up to 16: all of them); 16 + 64 + 256 in two hops
+            if (b.rc == GAMMA_HIP_OK && b.sd) {
                 size_t at = 0;
                 for (W* g : b.grp) {
                     std::memcpy(g->D, b.sd + at * b.kk, (size_t)g->nq * b.kk * sizeof(float));
@@ -1175,15 +1195,15 @@ static void combine_worker(gamma_hip_index* h) {
                 }
             }
             if (b.set >= 0) set_busy[b.set].store(false, std::memory_order_release);
-            {
-                std::lock_guard<std::mutex> cl(h->comb_mu);
-                for (size_t i = 0; i < b.grp.size(); i++) {
-                    W* g = b.grp[i];
-                    g->rc = b.rcs.empty() ? b.rc : b.rcs[i];
-                    g->done = true;
-                    g->cv.notify_one();
+            for (size_t i = 0; i < n; i++) {
+                W* g = b.grp[i];
+                g->rc = b.rcs.empty() ? b.rc : b.rcs[i];
+                for (size_t j = 0; j < (size_t)W::FAN; j++) {   // waiter i wakes ROOTS + FAN i .. ROOTS + FAN i + FAN - 1
+                    const size_t c = ROOTS + W::FAN * i + j;
+                    g->child[j] = c < n ? b.grp[c] : nullptr;
                 }
             }
+            for (size_t i = 0; i < std::min<size_t>(n, ROOTS); i++) comb_wake(b.grp[i]);   // the roots, from here
             nl.lock();
         }
     });
@@ -1197,6 +1217,11 @@ static void combine_worker(gamma_hip_index* h) {
     };
     Batch cur;
     int set = 0;
+    bool holding = false;          // this thread holds h->search_mu
+    hipEvent_t done_ev[NSET] = {nullptr, nullptr, nullptr, nullptr};   // end of the batch staged in set i
+    (void)hipSetDevice(h->device);
+    for (auto& e : done_ev)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
     static const bool dbg = getenv("GAMMA_HIP_COMB_DBG") != nullptr;   // phase times of the worker, printed at exit
     double us_stage = 0, us_deliver = 0, us_sync = 0;
     long n_batches = 0, n_reqs = 0;
@@ -1205,8 +1230,49 @@ static void combine_worker(gamma_hip_index* h) {
         h->comb_wcv.wait(lk, [&] { return h->comb_stop || (!h->comb_busy && !h->comb_q.empty()); });
         if (h->comb_stop) break;
         h->comb_busy = true;
-        // the handle stays busy until the queue is drained; delivery of batch N overlaps with forming and
-        // launching batch N+1
+        // The handle stays busy until the queue is drained.  One batch at a time: formed, staged, enqueued, awaited
+        // through its event, handed to the notifier.  GAMMA_HIP_COMB_PIPELINE=1 keeps TWO in flight (batch N+1 is
+        // formed and enqueued while the GPU runs batch N; the stream orders them, so workspaces are reused safely and
+        // results land in different staging sets; search_mu is then held across batches and given up at least every
+        // 32).  Measured with closed-loop single-query clients (tools/plugin_clients.py): no gain -- 8 threads 67 k
+        // against 67 k queries/s, 32 threads 190 k against 196 k, 128 threads 440 k against 470 k with a worse p99: the
+        // batches get smaller by what the overlap saves, each still pays its fixed 20 us of enqueue and ~45 us of GPU.
+        Batch prev;
+        bool have_prev = false;
+        int streak = 0;
+        // await and deliver a batch; its per-request redo when the batch failed as a whole
+        auto finish = [&](Batch& b) {
+            if (b.enqueued) {
+                if (b.rc == GAMMA_HIP_OK) {
+                    if (hipEventSynchronize(done_ev[b.set]) != hipSuccess) b.rc = GAMMA_HIP_EDEVICE;
+                } else if (hipStreamSynchronize(h->stream) != hipSuccess) {
+                    b.rc = GAMMA_HIP_EDEVICE;
+                }
+                b.enqueued = false;
+                if (b.rc != GAMMA_HIP_OK && b.grp.size() > 1) {
+                    // one request's parameters may be at fault (a filter on an unknown column, ...): every request gets
+                    // the outcome of its own call -- with the stream drained and the handle released
+                    (void)hipStreamSynchronize(h->stream);
+                    if (holding) {
+                        h->search_mu.unlock();
+                        holding = false;
+                    }
+                    for (W* g : b.grp) {
+                        gamma_hip_search_params pg = *g->p;
+                        pg.coarse_mode = g->mode;
+                        b.rcs.push_back(g->kind == 1 ? flat_search_host_locked(h, &pg, g->nq, g->x, g->k, g->D, g->I)
+                                                     : ivfpq_search_host_locked(h, &pg, g->nq, g->x, g->k, g->D, g->I));
+                    }
+                    b.sd = nullptr;   // results are already in the callers' buffers
+                    b.rc = GAMMA_HIP_OK;
+                }
+            }
+            if (dbg) {
+                n_batches++;
+                n_reqs += (long)b.grp.size();
+            }
+            post(std::move(b));
+        };
         for (;;) {
             cur = Batch();
             const auto t_a = std::chrono::steady_clock::now();
@@ -1239,11 +1305,15 @@ static void combine_worker(gamma_hip_index* h) {
                     if (h->comb_pin[set]) (void)hipHostFree(h->comb_pin[set]);
                     h->comb_pin[set] = nullptr;
                     h->comb_pin_bytes[set] = 0;
+                    h->comb_pin_dev[set] = nullptr;
                     if (hipSetDevice(h->device) == hipSuccess &&
-                        hipHostMalloc(&h->comb_pin[set], need * 2, hipHostMallocDefault) == hipSuccess)
+                        hipHostMalloc(&h->comb_pin[set], need * 2, hipHostMallocDefault) == hipSuccess) {
                         h->comb_pin_bytes[set] = need * 2;
-                    else
+                        if (hipHostGetDevicePointer(&h->comb_pin_dev[set], h->comb_pin[set], 0) != hipSuccess)
+                            h->comb_pin_dev[set] = nullptr;
+                    } else {
                         cur.rc = GAMMA_HIP_ENOMEM;
+                    }
                 }
                 if (cur.rc == GAMMA_HIP_OK) {
                     char* base = static_cast<char*>(h->comb_pin[set]);
@@ -1256,8 +1326,13 @@ static void combine_worker(gamma_hip_index* h) {
                         at += g->nq;
                     }
                     cur.set = set;
+                    static const bool no_map = getenv("GAMMA_HIP_NO_MAPPED_RESULTS") != nullptr;
+                    const bool map_ok = !no_map && h->comb_pin_dev[set] != nullptr;
                     set_busy[set].store(true, std::memory_order_release);
-                    h->search_mu.lock();   // held until the batch has been awaited (below)
+                    if (!holding) {        // held while batches are in flight (the workspaces are in use), see below
+                        h->search_mu.lock();
+                        holding = true;
+                    }
                     h->mu.lock();          // while the batch reads the handle and is enqueued
                     cur.rc = flat ? check_params(h, &pp, total, kk) : ivfpq_check(h, &pp, total, kk);
                     // requests with their own filter clauses: one table entry per request, a query -> entry map
@@ -1274,43 +1349,57 @@ static void combine_worker(gamma_hip_index* h) {
                                                  return ivfpq_search_device_locked(h, &pp, total, dx, kk, dd, dl,
                                                                                    multi ? &fc : nullptr);
                                              },
-                                             /*sync=*/false);
+                                             /*sync=*/false, nullptr,
+                                             map_ok ? reinterpret_cast<float*>(static_cast<char*>(h->comb_pin_dev[set]) + off_d) : nullptr,
+                                             map_ok ? reinterpret_cast<int64_t*>(static_cast<char*>(h->comb_pin_dev[set]) + off_i) : nullptr);
+                    if (cur.rc == GAMMA_HIP_OK && hipEventRecord(done_ev[set], h->stream) != hipSuccess) cur.rc = GAMMA_HIP_EDEVICE;
                     h->mu.unlock();
                     cur.enqueued = true;
                 }
-                set ^= 1;
+                set = (set + 1) % NSET;
             }
             const auto t_b = std::chrono::steady_clock::now();
-            const auto t_c = t_b;
-            if (cur.enqueued) {
-                if (hipStreamSynchronize(h->stream) != hipSuccess && cur.rc == GAMMA_HIP_OK) cur.rc = GAMMA_HIP_EDEVICE;
-                h->search_mu.unlock();
-                cur.enqueued = false;
-                if (cur.rc != GAMMA_HIP_OK && cur.grp.size() > 1) {
-                    // one request's parameters may be at fault (a filter on an unknown column, ...): every
-                    // request gets the outcome of its own call
-                    for (W* g : cur.grp) {
-                        gamma_hip_search_params pg = *g->p;
-                        pg.coarse_mode = g->mode;
-                        cur.rcs.push_back(g->kind == 1 ? flat_search_host_locked(h, &pg, g->nq, g->x, g->k, g->D, g->I)
-                                                       : ivfpq_search_host_locked(h, &pg, g->nq, g->x, g->k, g->D, g->I));
-                    }
-                    cur.sd = nullptr;   // results are already in the callers' buffers
-                    cur.rc = GAMMA_HIP_OK;
+            // the batch before this one: await, deliver.  A failed batch is finished before anything else goes on.
+            if (have_prev) {
+                finish(prev);
+                have_prev = false;
+            }
+            const auto t_c = std::chrono::steady_clock::now();
+            static const bool pipeline = getenv("GAMMA_HIP_COMB_PIPELINE") != nullptr;   // off: measured, see above
+            if (pipeline && cur.enqueued && cur.rc == GAMMA_HIP_OK && ++streak < 32) {
+                prev = std::move(cur);
+                have_prev = true;
+            } else if (!cur.grp.empty()) {
+                finish(cur);
+                streak = 32;
+            }
+            if (streak >= 32 && !have_prev) {   // nothing in flight: let others at the handle
+                if (holding) {
+                    h->search_mu.unlock();
+                    holding = false;
                 }
+                streak = 0;
             }
             if (dbg) {
-                const auto t_d = std::chrono::steady_clock::now();
                 us_stage += std::chrono::duration<double, std::micro>(t_b - t_a).count();
-                us_deliver += std::chrono::duration<double, std::micro>(t_c - t_b).count();
-                us_sync += std::chrono::duration<double, std::micro>(t_d - t_c).count();
-                n_batches++;
-                n_reqs += (long)cur.grp.size();
+                us_sync += std::chrono::duration<double, std::micro>(t_c - t_b).count();
             }
-            post(std::move(cur));
             lk.lock();
-            if (h->comb_q.empty()) break;
+            if (h->comb_q.empty()) {
+                if (have_prev) {   // drain the pipeline; requests may arrive meanwhile
+                    lk.unlock();
+                    finish(prev);
+                    have_prev = false;
+                    lk.lock();
+                }
+                if (h->comb_q.empty()) break;
+            }
         }
+        if (holding) {
+            h->search_mu.unlock();
+            holding = false;
+        }
+        streak = 0;
         h->comb_busy = false;
     }
     lk.unlock();
@@ -1320,9 +1409,11 @@ static void combine_worker(gamma_hip_index* h) {
     }
     n_cv.notify_one();
     notifier.join();
+    for (auto& e : done_ev)
+        if (e) (void)hipEventDestroy(e);
     if (dbg && n_batches)
-        fprintf(stderr, "combine worker: %ld batches, %.1f requests each; per batch: group+stage+enqueue %.1f us, deliver previous %.1f us, "
-                "wait for the GPU %.1f us\n", n_batches, (double)n_reqs / n_batches, us_stage / n_batches, us_deliver / n_batches,
+        fprintf(stderr, "combine worker: %ld batches, %.1f requests each; per batch: group+stage+enqueue %.1f us (the batch before it on the GPU meanwhile), "
+                "(unused %.1f) then waiting for that batch %.1f us\n", n_batches, (double)n_reqs / n_batches, us_stage / n_batches, us_deliver / n_batches,
                 us_sync / n_batches);
 }
 
@@ -1348,7 +1439,14 @@ static int combined_search(gamma_hip_index* h, const gamma_hip_search_params* p,
     if (!h->comb_thread.joinable()) h->comb_thread = std::thread(combine_worker, h);
     h->comb_q.push_back(&w);
     h->comb_wcv.notify_one();
-    w.cv.wait(lk, [&] { return w.done; });
+    lk.unlock();
+    {
+        std::unique_lock<std::mutex> wl(w.wm);
+        w.cv.wait(wl, [&] { return w.done; });
+    }
+    // (every field of w was written before done; the children are still blocked, their Waiters alive)
+    for (gamma_hip_index::Waiter* c : w.child)
+        if (c) comb_wake(c);
     return w.rc;
 }
 

@@ -16,14 +16,15 @@ for i0 in range(0, N, 10000):
     assert m.add(base[i0:i0 + 10000])
 params = '{"metric_type": "L2", "recall_num": 200, "nprobe": 32}'
 m.search(q[:4], 10, params)
-for T in (1, 8, 32, 128, 512):
-    calls = max(100, 20000 // T)
+TS = [int(v) for v in os.environ['PC_THREADS'].split(',')] if os.environ.get('PC_THREADS') else (1, 8, 32, 128, 512)
+for T in TS:
+    calls = max(100, int(os.environ.get('PC_CALLS', 20000)) // T)
     dt, lat = m.concurrent_clients(q, params, T, calls)
     lat = np.sort(lat)
     print("%3d client threads x 1 query per call: %8.0f queries/s, latency median %.0f us, p99 %.0f us" % (
         T, T * calls / dt, np.median(lat), lat[int(0.99 * len(lat))]), flush=True)
 N0 = N
-for T in (8, 32, 128):
+for T in (() if os.environ.get('PC_THREADS') else (8, 32, 128)):
     bad, sec = m.concurrent_filtered_check(q, params, T, max(50, 4000 // T), N0 // (T + 4), N0 // 4)
     print("%3d client threads x 1 query, each with its own range filter: %8.0f queries/s (%d results differ from the call made alone)" % (
         T, T * max(50, 4000 // T) / sec, bad), flush=True)
