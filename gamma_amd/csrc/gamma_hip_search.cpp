@@ -542,7 +542,7 @@ bool ivfpq_small_ok(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, i
     static const int max_nq = getenv("GAMMA_HIP_SMALL_MAX") ? atoi(getenv("GAMMA_HIP_SMALL_MAX")) : 512;
     // exact coarse distances (faiss below 20 queries) come from the fused first kernel, which covers 16 queries; the
     // GEMM form (20 queries and more) from the regular matrix kernel
-    return !off && h->small_path && nq >= 1 && nq <= max_nq && (p->coarse_mode == 1 || nq <= 16) &&
+    return !off && h->small_path && nq >= 1 && nq <= max_nq &&
            p->nprobe <= 64 && R <= 1024 && !h->exact_ties && !h->profile && !fc.d_qf && !h->d_list_mask &&
            h->nlist <= 16384 &&
            (int64_t)p->nprobe * std::max(1, h->max_list_len) <= (1 << 22) &&
@@ -594,7 +594,11 @@ int ivfpq_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int n
         gh::launch_pq_ip_table(s, d_x, nq, d, M, h->d_pqc, h->w_st2.as<float>());
     } else if (!gh::launch_small_coarse_ip(s, d_x, nq, d, h->d_cc, nlist, h->w_mat.as<float>(), M, h->d_pqc,
                                            h->w_st2.as<float>(), d_nunits)) {
-        return fail(h, GAMMA_HIP_EINVAL, "small path: shape not covered");   // ivfpq_small_ok gates on the same shapes
+        // exact coarse distances for more than 16 queries (an explicit coarse_mode 0, or a combined batch of requests
+        // that are each below faiss's 20-query switch): the regular chain's kernel, then the small chain
+        if (d_nunits) GH_CHECK(h, hipMemsetAsync(d_nunits, 0, sizeof(int), s));
+        gh::launch_pairwise(s, true, d_x, nq, d, h->d_cc, nlist, h->w_mat.as<float>(), nlist);
+        gh::launch_pq_ip_table(s, d_x, nq, d, M, h->d_pqc, h->w_st2.as<float>());
     }
     const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
     if (!l2) GH_CHECK(h, h->w_pair_ip.ensure((size_t)nq * P * sizeof(float)));
@@ -746,7 +750,7 @@ int ivfflat_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     if (p->coarse_mode == 1) {
         gh::launch_l2_gemmform(s, d_x, nq, d, h->d_cc, nlist, nullptr, h->d_cc_norms, h->w_mat.as<float>(), nlist, true);
     } else if (!gh::launch_small_coarse_ip(s, d_x, nq, d, h->d_cc, nlist, h->w_mat.as<float>(), 0, nullptr, nullptr)) {
-        return fail(h, GAMMA_HIP_EINVAL, "small path: shape not covered");
+        gh::launch_pairwise(s, true, d_x, nq, d, h->d_cc, nlist, h->w_mat.as<float>(), nlist);   // exact, more than 16 queries
     }
     gh::launch_small_coarse_select(s, h->w_mat.as<float>(), nlist, nq, P, h->w_coarse_dis.as<float>(), h->w_probe.as<int>(),
                                    h->d_list_len, h->d_list_mask, h->d_list_off, h->w_pair_off.as<int>(),
@@ -802,7 +806,7 @@ int ivfflat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq,
     hipStream_t s = h->stream;
     {   // small batches, as long as the pair-per-workgroup scan is the one that would run anyway (below 2 nlist pairs)
         static const bool off = getenv("GAMMA_HIP_NO_SMALL_PATH") != nullptr;
-        if (!off && h->small_path && nq <= 512 && (pp.coarse_mode == 1 || nq <= 16) && P <= 64 && k <= 1024 && !h->profile &&
+        if (!off && h->small_path && nq <= 512 && P <= 64 && k <= 1024 && !h->profile &&
             !fc.d_qf && !h->d_list_mask && nlist <= 16384 && (int64_t)nq * P < 2 * (int64_t)nlist &&
             (int64_t)P * std::max(1, h->max_list_len) <= (1 << 22))
             return ivfflat_small(h, &pp, fc, nq, d_x, k, d_distances, d_labels);

@@ -1098,19 +1098,23 @@ def test_small_batch_path_is_the_regular_chain(d, M, nlist, metric):
                                                                         has_rank=has_rank, **WIDE))
                             fin = Dw[np.isfinite(Dw) & (np.abs(Dw) < 1e37)]
                             kw = dict(min_score=float(np.quantile(fin, 0.2)), max_score=float(np.quantile(fin, 0.8)))
-                        args = api.SearchArgs(metric=hip_metric, nprobe=P, recall_num=R, has_rank=has_rank, **kw)
-                        g.set_small_path(False)
-                        D0, I0 = g.ivfpq_search(q, k, args)
-                        s0 = g.last_stages(nq, P, max(R, k))
-                        # 1: automatic; 3: long-row selection in two levels forced (three slices at most)
-                        for mode in ((1, 3) if nq in (1, 5, 37, 300) else (1,)):
-                            g.set_small_path(mode)
-                            D1, I1 = g.ivfpq_search(q, k, args)
-                            s1 = g.last_stages(nq, P, max(R, k))
-                            tag = (step, nq, has_rank, P, R, k, mode)
-                            assert D0.tobytes() == D1.tobytes() and np.array_equal(I0, I1), tag
-                            for key in s0:
-                                assert s0[key].tobytes() == s1[key].tobytes(), (tag, key)
+                        # coarse_mode 0 = exact coarse distances whatever the batch (what a combined batch of
+                        # single-query requests asks for): beyond 16 queries the regular chain's kernel feeds the chain
+                        for cm in ((-1, 0) if (has_rank and nq in (20, 37, 300)) else (-1,)):
+                            args = api.SearchArgs(metric=hip_metric, nprobe=P, recall_num=R, has_rank=has_rank,
+                                                  coarse_mode=cm, **kw)
+                            g.set_small_path(False)
+                            D0, I0 = g.ivfpq_search(q, k, args)
+                            s0 = g.last_stages(nq, P, max(R, k))
+                            # 1: automatic; 3: long-row selection in two levels forced (three slices at most)
+                            for mode in ((1, 3) if nq in (1, 5, 37, 300) else (1,)):
+                                g.set_small_path(mode)
+                                D1, I1 = g.ivfpq_search(q, k, args)
+                                s1 = g.last_stages(nq, P, max(R, k))
+                                tag = (step, nq, has_rank, P, R, k, mode, cm)
+                                assert D0.tobytes() == D1.tobytes() and np.array_equal(I0, I1), tag
+                                for key in s0:
+                                    assert s0[key].tobytes() == s1[key].tobytes(), (tag, key)
             if step == 0:
                 (D, I, st), (Dg, Ig) = run_both(case, g, case["q"][:3], 10, 8, 100, metric, True)
                 compare_topk(D, I, Dg, Ig)

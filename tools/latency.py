@@ -20,7 +20,8 @@ for i0 in range(0, N, 200000):
     g.raw_append(base[i0:i0 + 200000])
     g.add(base[i0:i0 + 200000], i0)
 q = synth.sift_like(4096, d=d, seed=4321)
-args = api.SearchArgs(metric=metric, nprobe=P, recall_num=R, has_rank=True, min_score=-1e30, max_score=1e30)
+args = api.SearchArgs(metric=metric, nprobe=P, recall_num=R, has_rank=True, min_score=-1e30, max_score=1e30,
+                      coarse_mode=E('LAT_CM', -1))
 dq = torch.from_numpy(q).to(dev)
 for nq in ([E("LAT_NQ", 0)] if E("LAT_NQ", 0) else (1, 4, 16, 64)):
     D = torch.empty((nq, k), dtype=torch.float32, device=dev)

@@ -21,8 +21,8 @@ for T in TS:
     calls = max(100, int(os.environ.get('PC_CALLS', 20000)) // T)
     dt, lat = m.concurrent_clients(q, params, T, calls)
     lat = np.sort(lat)
-    print("%3d client threads x 1 query per call: %8.0f queries/s, latency median %.0f us, p99 %.0f us" % (
-        T, T * calls / dt, np.median(lat), lat[int(0.99 * len(lat))]), flush=True)
+    print("%3d client threads x 1 query per call: %8.0f queries/s, latency median %.0f us, p99 %.0f us (mean %.0f, p99.9 %.0f, max %.0f; %d calls in %.2f s)" % (
+        T, T * calls / dt, np.median(lat), lat[int(0.99 * len(lat))], lat.mean(), lat[int(0.999 * len(lat))], lat[-1], len(lat), dt), flush=True)
 N0 = N
 for T in (() if os.environ.get('PC_THREADS') else (8, 32, 128)):
     bad, sec = m.concurrent_filtered_check(q, params, T, max(50, 4000 // T), N0 // (T + 4), N0 // 4)
