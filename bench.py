@@ -454,6 +454,24 @@ def cpu_baseline(a, base, queries, cc, pq, g, lno, codes, list_sizes):
     budget = max(2.0, a.cpu_seconds)
     nb = queries.shape[0] // a.nq
     cores = B.lib().go_num_threads()
+    # a container CPU quota (cgroup v2 cpu.max "quota period"): with more OpenMP threads than the quota carries, every
+    # thread runs for a fraction of each period and is then throttled.  The baseline is then ALSO timed with as many
+    # threads as the quota is worth, and the better of the two is reported, with the quota next to it.
+    quota_cores = None
+    try:
+        qv, pv = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if qv != "max":
+            quota_cores = max(1, int(round(float(qv) / float(pv))))
+    except Exception:
+        pass
+
+    def set_threads(n):
+        try:
+            import ctypes
+            ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+            return True
+        except Exception:
+            return False
 
     def timed(fn, seconds):
         fn(0)   # warm-up
@@ -479,6 +497,9 @@ def cpu_baseline(a, base, queries, cc, pq, g, lno, codes, list_sizes):
     o.set_raw(base)
     ctx = B.make_ctx(min_score=0.0, max_score=1e30)
     log("cpu baseline: oracle index built in %.1fs, %d threads" % (time.time() - t0, cores))
+    all_threads = cores
+    if quota_cores and quota_cores < cores and set_threads(quota_cores):
+        cores = quota_cores   # the port's legs and the first reference leg run with what the quota carries
     port = {}
     for mode, name in ((1, "gemm_form_coarse"), (0, "exact_coarse")):
         qps, n, el = timed(lambda b: o.search(queries[b * a.nq:(b + 1) * a.nq], a.k, a.nprobe, recall_num=a.recall_num,
@@ -494,13 +515,27 @@ def cpu_baseline(a, base, queries, cc, pq, g, lno, codes, list_sizes):
             r.train(base[:min(len(base), a.nlist * 64)])
             r.add(base)
             log("cpu baseline: faiss trained + filled in %.1fs" % (time.time() - t0))
-            qps, n, el = timed(lambda b: r.search_rerank(queries[b * a.nq:(b + 1) * a.nq], a.k, a.recall_num, a.nprobe,
-                                                         base), budget / 3)
-            out = {"value": round(qps, 1), "unit": "queries/s", "cores": cores, "kind": "reference",
-                   "per_thread": round(qps / cores, 1),
+            fn = lambda b: r.search_rerank(queries[b * a.nq:(b + 1) * a.nq], a.k, a.recall_num, a.nprobe, base)
+            qps, n, el = timed(fn, budget / 3)
+            used = cores
+            alt = None
+            if cores != all_threads and set_threads(all_threads):   # and with every hardware thread, throttled by the quota
+                q2, n2, el2 = timed(fn, budget / 3)
+                alt = {"threads": all_threads, "value": round(q2, 1)}
+                set_threads(cores)
+                if q2 > qps:
+                    alt = {"threads": cores, "value": round(qps, 1)}
+                    qps, n, el, used = q2, n2, el2, all_threads
+            out = {"value": round(qps, 1), "unit": "queries/s", "cores": used, "kind": "reference",
+                   "per_thread": round(qps / used, 1),
                    "sample": "faiss 1.7.1 (oracle/_ref) IndexIVFPQ::search k=%d + compute_dis re-rank, its own training "
                              "on the same vectors: %d Search calls of %d queries in %.1fs" % (a.recall_num, n, a.nq, el),
                    "port": port}
+            if quota_cores:
+                out["cpu_quota_cores"] = quota_cores
+                out["sample"] += "; the container's CPU quota is %d cores (cgroup cpu.max)" % quota_cores
+            if alt:
+                out["other_thread_count"] = alt
         except Exception as e:   # a prebuilt _ref that does not load here: fall back to the port
             log("cpu baseline: reference library unusable (%s), using the port" % e)
     if out is None:
