@@ -543,7 +543,7 @@ bool ivfpq_small_ok(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, i
     // exact coarse distances (faiss below 20 queries) come from the fused first kernel, which covers 16 queries; the
     // GEMM form (20 queries and more) from the regular matrix kernel
     return !off && h->small_path && nq >= 1 && nq <= max_nq &&
-           p->nprobe <= 64 && R <= 1024 && !h->exact_ties && !h->profile && !fc.d_qf && !h->d_list_mask &&
+           p->nprobe <= 128 && R <= 1024 && !h->exact_ties && !h->profile && !fc.d_qf && !h->d_list_mask &&
            h->nlist <= 16384 &&
            (int64_t)p->nprobe * std::max(1, h->max_list_len) <= (1 << 22) &&
            // long lists: beyond ~5e7 codes per call the regular chain's bound filter wins (full-size C4, 390 k codes per
@@ -806,7 +806,7 @@ int ivfflat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq,
     hipStream_t s = h->stream;
     {   // small batches, as long as the pair-per-workgroup scan is the one that would run anyway (below 2 nlist pairs)
         static const bool off = getenv("GAMMA_HIP_NO_SMALL_PATH") != nullptr;
-        if (!off && h->small_path && nq <= 512 && P <= 64 && k <= 1024 && !h->profile &&
+        if (!off && h->small_path && nq <= 512 && P <= 128 && k <= 1024 && !h->profile &&
             !fc.d_qf && !h->d_list_mask && nlist <= 16384 && (int64_t)nq * P < 2 * (int64_t)nlist &&
             (int64_t)P * std::max(1, h->max_list_len) <= (1 << 22))
             return ivfflat_small(h, &pp, fc, nq, d_x, k, d_distances, d_labels);

@@ -1775,59 +1775,52 @@ __device__ __forceinline__ void small_coarse_select_body(int q, const SmallSelec
     __shared__ unsigned long long s_it[SM_NT];
     __shared__ int s_w[2 * SM_NW];
     __shared__ uint32_t s_pick[3];
-    __shared__ int s_probe[64];
+    __shared__ int s_probe[128];
     const int tid = threadIdx.x, lane = tid & 63;
     const float* v = mat + (int64_t)q * nlist;
     const int cnt = block_select_sorted<true, 4, 1>(v, nlist, K, s_it, s_hist, s_w, s_pick);   // trailing barrier inside
-    if (tid < 64) {   // cnt <= K <= 64
-        const unsigned long long mine = tid < cnt ? s_it[tid] : ~0ull;
-        const int rk = tid;
-        int pos = -1;
-        float val = INFINITY;
-        if (tid < cnt) {
-            pos = (int)(uint32_t)mine;
-            val = v[pos];
-            if (val == INFINITY) pos = -1;
-        }
-        s_probe[tid] = -1;
-        __builtin_amdgcn_wave_barrier();
-        if (tid < cnt) {
-            out_vals[(int64_t)q * K + rk] = val;
-            out_pos[(int64_t)q * K + rk] = pos;
-            s_probe[rk] = pos;
-        } else if (tid < K) {
-            out_vals[(int64_t)q * K + tid] = INFINITY;
-            out_pos[(int64_t)q * K + tid] = -1;
-        }
-        __builtin_amdgcn_wave_barrier();
-        // k_pair_offsets for this query (K <= 64 probes: one pass)
-        int len = 0;
-        int64_t lbase = 0;
-        if (lane < K) {
-            const int l = s_probe[lane];
-            if (l >= 0 && l < nlist && (!list_mask || list_mask[l])) {
-                len = list_len[l];
-                lbase = list_off[l];
+    if (tid < 64) {   // cnt <= K <= 128: the first wave, 64 probes per round
+        int run_off = 0;   // slab offset of the round's first probe
+        for (int b0 = 0; b0 < K; b0 += 64) {   // uniform
+            const int i = b0 + lane;
+            int pos = -1;
+            float val = INFINITY;
+            if (i < cnt) {
+                pos = (int)(uint32_t)s_it[i];
+                val = v[pos];
+                if (val == INFINITY) pos = -1;
             }
+            // k_pair_offsets for this query
+            int len = 0;
+            int64_t lbase = 0;
+            if (i < K) {
+                out_vals[(int64_t)q * K + i] = val;
+                out_pos[(int64_t)q * K + i] = pos;
+                s_probe[i] = pos;
+                if (pos >= 0 && pos < nlist && (!list_mask || list_mask[pos])) {
+                    len = list_len[pos];
+                    lbase = list_off[pos];
+                }
+            }
+            const int incl = wave_incl_scan(len);
+            if (i < K) {
+                pair_off[(int64_t)q * (K + 1) + i] = run_off + incl - len;
+                if (pair_base) pair_base[(int64_t)q * K + i] = lbase;
+            }
+            if (A.units) {   // uniform
+                const int nch = (len + A.chunk_len - 1) / A.chunk_len;
+                const int uincl = wave_incl_scan(nch);
+                const int utot = __shfl(uincl, 63, 64);
+                int ub = 0;
+                if (lane == 0 && utot) ub = atomicAdd(A.unit_count, utot);
+                ub = __shfl(ub, 0, 64) + uincl - nch;
+                for (int c = 0; c < nch; c++) A.units[ub + c] = ((uint32_t)q << 20) | ((uint32_t)i << 13) | (uint32_t)c;
+            }
+            run_off += __shfl(incl, 63, 64);
         }
-        const int incl = wave_incl_scan(len);
-        if (lane < K) {
-            pair_off[(int64_t)q * (K + 1) + lane] = incl - len;
-            if (pair_base) pair_base[(int64_t)q * K + lane] = lbase;
-        }
-        const int tot = __shfl(incl, 63, 64);
         if (lane == 0) {
-            pair_off[(int64_t)q * (K + 1) + K] = tot;
-            q_total[q] = tot;
-        }
-        if (A.units) {   // uniform
-            const int nch = (len + A.chunk_len - 1) / A.chunk_len;
-            const int uincl = wave_incl_scan(nch);
-            const int utot = __shfl(uincl, 63, 64);
-            int ub = 0;
-            if (lane == 0 && utot) ub = atomicAdd(A.unit_count, utot);
-            ub = __shfl(ub, 0, 64) + uincl - nch;
-            for (int c = 0; c < nch; c++) A.units[ub + c] = ((uint32_t)q << 20) | ((uint32_t)lane << 13) | (uint32_t)c;
+            pair_off[(int64_t)q * (K + 1) + K] = run_off;
+            q_total[q] = run_off;
         }
     }
     if (A.pair_ip) {   // k_pair_ip for this query: eight threads per probe (rerank_dev.h: fvec_inner_product's lane order)
@@ -1850,7 +1843,7 @@ void launch_small_coarse_select(hipStream_t s, const float* mat, int nlist, int 
                                 int* q_total, int64_t* pair_base, const float* x, const float* cc, int d, float* pair_ip,
                                 uint32_t* units, int* unit_count, int chunk_len) {
     if (nq <= 0) return;
-    if (P > 64) abort();   // callers gate on this
+    if (P > 128) abort();   // callers gate on this
     if (units && (nq > 4096 || chunk_len < 1)) abort();
     const SmallSelectArgs A{mat, nlist, P, out_vals, out_pos, list_len, list_mask, list_off, pair_off, q_total, pair_base,
                             x, cc, d, pair_ip, units, unit_count, chunk_len};
@@ -1915,8 +1908,8 @@ __global__ __launch_bounds__(SM_NT) void k_small_tail(const float* __restrict__ 
     __shared__ float s_val[1024];
     __shared__ int s_w[2 * SM_NW];
     __shared__ uint32_t s_pick[3];
-    __shared__ int s_off[65];
-    __shared__ int64_t s_lbase[64];
+    __shared__ int s_off[129];
+    __shared__ int64_t s_lbase[128];
     const int q = blockIdx.x, tid = threadIdx.x;
     const float* v = slab + (int64_t)q * q_stride;
     int n = q_total[q];

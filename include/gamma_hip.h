@@ -142,7 +142,7 @@ int gamma_hip_set_list_major(gamma_hip_index* h, int on);
  * list_cap: capacity of a query's per-strip survivor list, 1..128 (default 128); a query that overflows it is redone
  * by the repair kernel -- tests shrink it to force that path.  Results are identical either way. */
 int gamma_hip_set_coarse_fused(gamma_hip_index* h, int on, int list_cap);
-/* Calls of up to 512 queries (nprobe <= 64, recall_num <= 1024) run as a chain of
+/* Calls of up to 512 queries (nprobe <= 128, recall_num <= 1024) run as a chain of
  * four or five fused kernels instead of eleven (DESIGN.md "small batches").  on: 1 = automatic (default), 0 = always
  * the regular chain, n >= 2 = automatic with the two-level selection of long candidate rows forced on with n slices
  * (tests; by default it is used when nprobe x 1.5 mean list lengths exceed 16384).  Results are identical either way. */

@@ -70,6 +70,8 @@ def test_random_configuration(seed):
             if metric == B.METRIC_IP:
                 q = (q / np.maximum(np.linalg.norm(q, axis=1, keepdims=True), 1e-9)).astype(np.float32)
             P = int(rng.choice([1, 4, min(32, nlist), min(64, nlist)]))
+            if rng_mode.random() < 0.2:
+                P = min(96, nlist)   # beyond 64 probes (the reference's default is 80)
             R = int(rng.choice([10, 64, 100, 200, 300]))
             k = int(rng.choice([1, 10, 50]))
             has_rank = bool(rng.random() < 0.6)

@@ -1091,7 +1091,8 @@ def test_small_batch_path_is_the_regular_chain(d, M, nlist, metric):
                 q = case["q"][:nq] if nq <= 64 else big
                 for has_rank in (True, False):
                     for P, R, k, win in ((8, 100, 10, None), (1, 50, 10, None), (32, 1000, 100, None),
-                                         (4, 20, 30, None), (16, 200, 10, True), (64, 300, 10, None)):
+                                         (4, 20, 30, None), (16, 200, 10, True), (64, 300, 10, None),
+                                         (min(100, nlist), 250, 10, None)):   # the reference's default nprobe is 80
                         kw = dict(WIDE)
                         if win:   # a window that cuts on both sides, whatever the metric and the scale of the data
                             Dw, _ = g.ivfpq_search(q, k, api.SearchArgs(metric=hip_metric, nprobe=P, recall_num=R,
