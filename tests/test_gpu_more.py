@@ -1203,3 +1203,31 @@ def test_multi_vector_documents(case):
         compare_topk(Df, If, Dg, Ig)
     finally:
         g.close()
+
+
+def test_small_batch_path_parameter_corners():
+    """The small-batch chain at the edges of its gate (512 queries, 128 probes, recall_num 1024, k up to recall_num, one
+    list, nprobe = nlist, empty probed lists) against the regular chain, byte for byte."""
+    rng = np.random.default_rng(99)
+    for (d, M, nlist, N, metric) in ((16, 4, 128, 6000, B.METRIC_L2), (24, 8, 1, 3000, B.METRIC_IP),
+                                     (40, 8, 200, 1500, B.METRIC_L2)):   # 200 lists for 1500 vectors: many are empty
+        case = fixtures.trained_case(d=d, nlist=nlist, M=M, N=N, nq=64, metric=metric)
+        g = fixtures.load_hip(case)
+        hip_metric = api.METRIC_L2 if metric == B.METRIC_L2 else api.METRIC_IP
+        try:
+            big = synth.sift_like(512, d=d, seed=777)
+            for nq, P, R, k, has_rank in ((512, min(128, nlist), 1024, 1024, True), (512, min(128, nlist), 1000, 7, False),
+                                          (1, nlist if nlist <= 128 else 128, 1024, 1024, True), (19, 1, 1, 1, True),
+                                          (16, min(65, nlist), 64, 64, False), (17, min(127, nlist), 300, 300, True),
+                                          (255, min(3, nlist), 5, 50, True)):
+                q = big[:nq]
+                for cm in (-1, 0, 1):
+                    args = api.SearchArgs(metric=hip_metric, nprobe=P, recall_num=R, has_rank=has_rank, coarse_mode=cm, **WIDE)
+                    g.set_small_path(0)
+                    D0, I0 = g.ivfpq_search(q, k, args)
+                    for mode in (1, 2):
+                        g.set_small_path(mode)
+                        D1, I1 = g.ivfpq_search(q, k, args)
+                        assert D0.tobytes() == D1.tobytes() and np.array_equal(I0, I1), (d, nq, P, R, k, has_rank, cm, mode)
+        finally:
+            g.close()
