@@ -179,7 +179,8 @@ void launch_small_tail(hipStream_t s, bool l2, const float* slab, int64_t q_stri
                        const int* probe_list, const int* pair_off, const int64_t* list_off, const int64_t* ids,
                        float* cand_dis, int* cand_pos, int64_t* cand_ids, int has_rank, const float* x, int d,
                        const float* raw, int64_t nraw, int k, float min_score, float max_score, float neutral,
-                       float* distances, int64_t* labels, int smax = 0, float* pre_val = nullptr, int* pre_pos = nullptr);
+                       float* distances, int64_t* labels, int smax = 0, float* pre_val = nullptr, int* pre_pos = nullptr,
+                       int fixed_n = 0);   // q_total == nullptr (flat search): every row has fixed_n entries, position = vector id
 // IVFFLAT: exact distances of every entry of the probed lists (rows from the raw store) into the query's slab
 void launch_ivfflat_scan(hipStream_t s, bool l2, const float* x, int nq, int d, int P, const int* pair_off,
                          const int64_t* pair_base, const int64_t* ids, const float* raw, int64_t nraw, int64_t q_stride,

@@ -1858,13 +1858,13 @@ void launch_small_coarse_select(hipStream_t s, const float* mat, int nlist, int 
 template <bool L2>
 __global__ __launch_bounds__(SM_NT) void k_small_presel(const float* __restrict__ slab, int64_t q_stride,
                                                         const int* __restrict__ q_total, int R, int smax,
-                                                        float* __restrict__ pre_val, int* __restrict__ pre_pos) {
+                                                        float* __restrict__ pre_val, int* __restrict__ pre_pos, int fixed_n) {
     __shared__ int s_hist[SM_BINS];
     __shared__ unsigned long long s_it[2 * SM_NT];
     __shared__ int s_w[2 * SM_NW];
     __shared__ uint32_t s_pick[3];
     const int q = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
-    const int n = q_total[q];
+    const int n = q_total ? q_total[q] : fixed_n;   // (flat search: every query's row is the whole store)
     const int S = min(smax, (n + SM_SLICE - 1) / SM_SLICE);
     if (sl >= S) return;   // uniform
     const int per = (((n + S - 1) / S) + 3) & ~3;
@@ -1900,7 +1900,7 @@ __global__ __launch_bounds__(SM_NT) void k_small_tail(const float* __restrict__ 
                                                       float min_score, float max_score, float neutral,
                                                       float* __restrict__ distances, int64_t* __restrict__ labels,
                                                       const float* __restrict__ pre_val, const int* __restrict__ pre_pos,
-                                                      int smax, unsigned long long* __restrict__ dbg) {
+                                                      int smax, int fixed_n, unsigned long long* __restrict__ dbg) {
 #define GH_T(i) do { if (dbg && threadIdx.x == 0 && blockIdx.x == 0) dbg[i] = wall_clock64(); } while (0)
     __shared__ int s_hist[SM_BINS];
     __shared__ unsigned long long s_it[2 * SM_NT];
@@ -1912,7 +1912,7 @@ __global__ __launch_bounds__(SM_NT) void k_small_tail(const float* __restrict__ 
     __shared__ int64_t s_lbase[128];
     const int q = blockIdx.x, tid = threadIdx.x;
     const float* v = slab + (int64_t)q * q_stride;
-    int n = q_total[q];
+    int n = q_total ? q_total[q] : fixed_n;   // flat search (no lists: pair_off == nullptr, a position IS the vector id)
     const int* ppos = nullptr;
     if (smax > 0) {   // long rows: k_small_presel has left min(R, slice) candidates of each of the row's slices
         v = pre_val + (int64_t)q * smax * R;
@@ -1922,8 +1922,8 @@ __global__ __launch_bounds__(SM_NT) void k_small_tail(const float* __restrict__ 
     const float sentinel = L2 ? INFINITY : -INFINITY;
     // the pairs' slab offsets and list bases: loaded while the selection runs, read from LDS by the id look-up
     GH_T(0);
-    if (tid <= P) s_off[tid] = pair_off[(int64_t)q * (P + 1) + tid];
-    if (tid < P) {
+    if (pair_off && tid <= P) s_off[tid] = pair_off[(int64_t)q * (P + 1) + tid];
+    if (pair_off && tid < P) {
         const int l = probe_list[(int64_t)q * P + tid];
         s_lbase[tid] = l >= 0 ? list_off[l] : 0;
     }
@@ -1945,7 +1945,9 @@ __global__ __launch_bounds__(SM_NT) void k_small_tail(const float* __restrict__ 
             if (val == sentinel) pos = -1;
             else if (ppos) pos = ppos[pos];
         }
-        if (pos >= 0) {
+        if (pos >= 0 && !pair_off) {
+            id = pos;
+        } else if (pos >= 0) {
             int lo = 0, hi = P - 1;
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
@@ -2026,16 +2028,16 @@ void launch_small_tail(hipStream_t s, bool l2, const float* slab, int64_t q_stri
                        const int* probe_list, const int* pair_off, const int64_t* list_off, const int64_t* ids,
                        float* cand_dis, int* cand_pos, int64_t* cand_ids, int has_rank, const float* x, int d,
                        const float* raw, int64_t nraw, int k, float min_score, float max_score, float neutral,
-                       float* distances, int64_t* labels, int smax, float* pre_val, int* pre_pos) {
+                       float* distances, int64_t* labels, int smax, float* pre_val, int* pre_pos, int fixed_n) {
     if (nq <= 0) return;
     if (R > 1024) abort();   // callers gate on this
     if (smax > 0) {
         if (l2)
             hipLaunchKernelGGL((k_small_presel<true>), dim3(nq, smax), dim3(SM_NT), 0, s, slab, q_stride, q_total, R, smax,
-                               pre_val, pre_pos);
+                               pre_val, pre_pos, fixed_n);
         else
             hipLaunchKernelGGL((k_small_presel<false>), dim3(nq, smax), dim3(SM_NT), 0, s, slab, q_stride, q_total, R, smax,
-                               pre_val, pre_pos);
+                               pre_val, pre_pos, fixed_n);
     }
     static unsigned long long* dbg = nullptr;
     static int shown = 0;
@@ -2052,11 +2054,11 @@ void launch_small_tail(hipStream_t s, bool l2, const float* slab, int64_t q_stri
     if (l2)
         hipLaunchKernelGGL((k_small_tail<true>), dim3(nq), dim3(SM_NT), 0, s, slab, q_stride, q_total, R, P, probe_list,
                            pair_off, list_off, ids, cand_dis, cand_pos, cand_ids, has_rank, x, d, raw, nraw, k, min_score,
-                           max_score, neutral, distances, labels, pre_val, pre_pos, smax, dbg);
+                           max_score, neutral, distances, labels, pre_val, pre_pos, smax, fixed_n, dbg);
     else
         hipLaunchKernelGGL((k_small_tail<false>), dim3(nq), dim3(SM_NT), 0, s, slab, q_stride, q_total, R, P, probe_list,
                            pair_off, list_off, ids, cand_dis, cand_pos, cand_ids, has_rank, x, d, raw, nraw, k, min_score,
-                           max_score, neutral, distances, labels, pre_val, pre_pos, smax, dbg);
+                           max_score, neutral, distances, labels, pre_val, pre_pos, smax, fixed_n, dbg);
 }
 
 }  // namespace gh

@@ -163,8 +163,67 @@ def test_flat_parity(metric, d):
             rf_g = [api.make_range_filter(r) for r in ranges] if ranges else None
             ctx = B.make_ctx(docids_bitmap=bm, range_filters=rf_o, **WIDE)
             D, I = B.flat_search(base, q, k, metric, ctx)
-            Dg, Ig = g.flat_search(q, k, api.SearchArgs(metric=metric, range_filters=rf_g, **WIDE))
-            compare_topk(D, I, Dg, Ig)
+            # calls of up to 64 queries take the whole store as one chunk and the small-batch chains' selection
+            # (gamma_hip_search.cpp, flat_search_device_locked); without it: row chunks + merge.  3: the two-level
+            # selection with three slices only (slices longer than the registers hold)
+            res = []
+            for mode in (0, 1, 3):
+                g.set_small_path(mode)
+                Dg, Ig = g.flat_search(q, k, api.SearchArgs(metric=metric, range_filters=rf_g, **WIDE))
+                compare_topk(D, I, Dg, Ig)
+                res.append((Dg, Ig))
+            for Dg, Ig in res[1:]:
+                assert res[0][0].tobytes() == Dg.tobytes()
+    finally:
+        g.close()
+
+
+def test_flat_small_calls_are_the_chunked_search():
+    """Flat search of 1 .. 64 queries: one row chunk + block selection against the chunked path, byte for byte -- duplicate
+    rows (equal distances: ids in row order), deleted rows, a score window, k from 1 to more than the valid rows."""
+    d, N = 24, 40000
+    rng = np.random.default_rng(5)
+    base = synth.sift_like(N, d=d, seed=31)
+    base[1000:3000] = base[5000:7000]          # 2000 exact duplicates
+    base[20000:20050] = base[0]
+    q = np.concatenate([synth.sift_like(60, d=d, seed=32), base[[0, 5000, 1000, 39999]]])
+    deleted = rng.choice(N, size=N // 5, replace=False)
+    bm = np.zeros((N >> 3) + 1, dtype=np.uint8)
+    np.bitwise_or.at(bm, deleted >> 3, (1 << (deleted & 7)).astype(np.uint8))
+    g = api.GammaHip(0)
+    try:
+        g.raw_init(d)
+        g.raw_append(base)
+        for step in range(2):
+            if step == 1:
+                g.bitmap_upload(bm, N)
+            for metric in (api.METRIC_L2, api.METRIC_IP):
+                for nq, k in ((1, 1), (1, 1000), (3, 10), (64, 100), (17, 33)):
+                    qq = q[-nq:]
+                    g.set_small_path(0)
+                    Dw, _ = g.flat_search(qq, k, api.SearchArgs(metric=metric, **WIDE))
+                    fin = Dw[np.abs(Dw) < 1e37]
+                    wins = [WIDE, dict(min_score=float(np.quantile(fin, 0.3)), max_score=float(np.quantile(fin, 0.9)))]
+                    for kw in wins:
+                        args = api.SearchArgs(metric=metric, **kw)
+                        g.set_small_path(0)
+                        D0, I0 = g.flat_search(qq, k, args)
+                        for mode in (1, 2):
+                            g.set_small_path(mode)
+                            D1, I1 = g.flat_search(qq, k, args)
+                            assert D0.tobytes() == D1.tobytes() and np.array_equal(I0, I1), (step, metric, nq, k, mode)
+        # every valid row asked for and more (k > what is left after the deletes would need k > 1024: a small store)
+        g2 = api.GammaHip(0)
+        g2.raw_init(d)
+        g2.raw_append(base[:300])
+        for mode in (0, 1):
+            g2.set_small_path(mode)
+            r = g2.flat_search(q[:2], 400, api.SearchArgs(metric=api.METRIC_L2, **WIDE))
+            if mode == 0:
+                r0 = r
+            else:
+                assert r0[0].tobytes() == r[0].tobytes() and np.array_equal(r0[1], r[1])
+        g2.close()
     finally:
         g.close()
 
