@@ -60,6 +60,7 @@ def main():
                     help="experiment: every batch repeats its first N queries (the lists they probe stay cache "
                          "resident: what the scan costs without its table traffic)")
     ap.add_argument("--batches", default="1,32,1024", help="batch sizes of the qps_by_batch leg (BASELINE.md protocol)")
+    ap.add_argument("--no-shapes", action="store_true", help="skip the reduced C4 / C5 shape legs (child processes, ~1 min)")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the extra legs (exact ties, batch sizes 1/32/1024, coarse_mode 0, C2 flat)")
     ap.add_argument("--pmc-traffic", type=float, default=None,
@@ -345,6 +346,43 @@ def main():
         wt.join()
         extra["search_during_inserts"] = {"qps": round(gnq * nsteps / el, 1), "insert_rate_vectors_per_s": round(20000 / done["t"], 1),
                                           "inserted": 20000, "batch": gnq, "steps": nsteps}
+
+    # (g) the other BASELINE shapes at a size that builds in seconds, so that the driver's line carries a timing of
+    #     them too (full size -- 100 M x 128 and 10 M x 768 -- takes minutes to generate: tools/c4_scale.py 1e8,
+    #     tools/c5_scale.py 1e7 16384).  Child processes: each tool builds its own index.
+    if world == 1 and not a.no_extra and not a.no_shapes:
+        import re
+        import subprocess
+        here = os.path.dirname(os.path.abspath(__file__))
+
+        def run_tool(argv, seconds):
+            try:
+                r = subprocess.run([sys.executable] + argv, cwd=here, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                   timeout=seconds, universal_newlines=True)
+                return r.stdout
+            except Exception as e:   # a shape leg never fails the bench
+                return "failed: %s" % e
+
+        def first(pattern, text, cast=float):
+            m = re.search(pattern, text)
+            return cast(m.group(1)) if m else None
+
+        t0 = time.time()
+        out = run_tool([os.path.join("tools", "c4_scale.py"), "8e6"], 240)
+        extra["c4_shape_8m"] = {
+            "workload": "C4 shape at 8 M vectors: 8000000x128, nlist 16384, M 32, nprobe 64, recall_num 100, 8192 queries/call",
+            "qps": first(r"= (\d+) queries/s", out), "ms_per_call": first(r"search: ([0-9.]+) ms", out),
+            "scan_gb_per_call": first(r"scan GB/step ([0-9.]+)", out), "recall_at_10_vs_flat": first(r"recall@10 vs flat on 64 queries: ([0-9.]+)", out),
+            "single_query_us": first(r"latency nq=1\s+small-batch chain median ([0-9.]+)", out), "seconds": round(time.time() - t0, 1)}
+        t0 = time.time()
+        out = run_tool([os.path.join("tools", "c5_scale.py"), "2e6"], 240)
+        extra["c5_shape_2m"] = {
+            "workload": "C5 shape at 2 M vectors: 2000000x768 inner product, nlist 4096, M 64, nprobe 64, recall_num 100, 4096 queries/call",
+            "qps": first(r"no filter: [0-9.]+ ms per \d+ queries = (\d+) queries/s", out),
+            "qps_with_10pct_range_filter": first(r"10% range filter: [0-9.]+ ms per \d+ queries = (\d+) queries/s", out),
+            "scan_tb_per_s": first(r"-> ([0-9.]+) TB/s", out),
+            "single_query_us": first(r"latency nq=1\s+small-batch chain median ([0-9.]+)", out), "seconds": round(time.time() - t0, 1)}
+        log("shape legs: %s" % json.dumps({k2: extra[k2] for k2 in ("c4_shape_8m", "c5_shape_2m")}))
 
     cpu = None
     if world == 1 and a.cpu_seconds > 0:
