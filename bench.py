@@ -368,14 +368,14 @@ def main():
             return cast(m.group(1)) if m else None
 
         t0 = time.time()
-        out = run_tool([os.path.join("tools", "c4_scale.py"), "8e6"], 240)
+        out = run_tool([os.path.join("tools", "c4_scale.py"), "8e6"], 150)
         extra["c4_shape_8m"] = {
             "workload": "C4 shape at 8 M vectors: 8000000x128, nlist 16384, M 32, nprobe 64, recall_num 100, 8192 queries/call",
             "qps": first(r"= (\d+) queries/s", out), "ms_per_call": first(r"search: ([0-9.]+) ms", out),
             "scan_gb_per_call": first(r"scan GB/step ([0-9.]+)", out), "recall_at_10_vs_flat": first(r"recall@10 vs flat on 64 queries: ([0-9.]+)", out),
             "single_query_us": first(r"latency nq=1\s+small-batch chain median ([0-9.]+)", out), "seconds": round(time.time() - t0, 1)}
         t0 = time.time()
-        out = run_tool([os.path.join("tools", "c5_scale.py"), "2e6"], 240)
+        out = run_tool([os.path.join("tools", "c5_scale.py"), "2e6"], 150)
         extra["c5_shape_2m"] = {
             "workload": "C5 shape at 2 M vectors: 2000000x768 inner product, nlist 4096, M 64, nprobe 64, recall_num 100, 4096 queries/call",
             "qps": first(r"no filter: [0-9.]+ ms per \d+ queries = (\d+) queries/s", out),
