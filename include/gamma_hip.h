@@ -270,7 +270,11 @@ int gamma_hip_ivfflat_search_device(gamma_hip_index* h, const gamma_hip_search_p
 /* ---- search ------------------------------------------------------------------------ */
 /* replaces GammaIVFPQIndex::Search (gamma_index_ivfpq.cc:514-566 + search_preassigned
  * :701-890).  x: nq*d fp32 host; distances/labels: nq*k host, best first, unused slots
- * label -1 / distance = heap neutral (FLT_MAX for L2, -FLT_MAX for IP). */
+ * label -1 / distance = heap neutral (FLT_MAX for L2, -FLT_MAX for IP).
+ * Re-entrant like the reference's Search: any number of threads may call it on one handle.  Calls of up to 256 queries
+ * that find the handle busy are queued and run as ONE device batch per set of equal parameters (each caller gets the
+ * result of its own call, bit for bit); a call that finds it idle runs on the caller's thread, its queries and results
+ * staged in pinned memory (no pageable copies).  The buffers need not be pinned. */
 int gamma_hip_ivfpq_search(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
                            const float* x, int k, float* distances, int64_t* labels);
 /* same, all pointers in device memory, enqueued on the handle's stream, no sync */
