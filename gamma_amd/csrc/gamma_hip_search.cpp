@@ -8,7 +8,11 @@ namespace ghi {
 
 // off != nullptr: the range bitmaps go to w_filter at *off (advanced; the caller has sized w_filter for all
 // the requests of a combined batch); nullptr: a call of its own, bitmaps from offset 0
-int build_filter(H* h, const gamma_hip_search_params* p, gh::FilterDesc* f, size_t* off_io = nullptr) {
+// est_codes > 0: about how many list entries (rows, for the flat search) the call will test against the filter; when
+// that is several times the number of documents, the field / term clauses are evaluated once per document into a
+// bitmap (k_filter_bitmap) and join the request's range bitmaps -- the scan then tests a bit instead of reading column
+// values (C5 shape, 10 % range filter on an int64 column: scan 9.6 -> 7.5 ms per 4096 queries)
+int build_filter(H* h, const gamma_hip_search_params* p, gh::FilterDesc* f, size_t* off_io = nullptr, int64_t est_codes = 0) {
     memset(f, 0, sizeof(*f));
     f->del_bitmap = h->d_bitmap;
     f->del_bits = h->d_bitmap ? h->bitmap_bits : 0;
@@ -69,6 +73,33 @@ int build_filter(H* h, const gamma_hip_search_params* p, gh::FilterDesc* f, size
         td.op = tf.op;
         td.n_items = tf.n_items;
         for (int k = 0; k < tf.n_items; k++) td.items[k] = tf.items[k];
+    }
+    if (!off_io && est_codes > 0 && f->n_field + f->n_term > 0 && f->n_range < gh::kMaxRange) {
+        int64_t nbits = 0;   // beyond every column no clause matches (filter_dev.h), as beyond a range bitmap's max_doc
+        for (int i = 0; i < f->n_field; i++) nbits = std::max<int64_t>(nbits, f->field[i].n);
+        for (int i = 0; i < f->n_term; i++) nbits = std::max<int64_t>(nbits, f->term[i].n);
+        const char* env = getenv("GAMMA_HIP_FILTER_BITMAP");   // 0: never, 1: always (tests), unset: by the estimate
+        const bool want = env ? atoi(env) != 0 : est_codes >= 4 * nbits;
+        if (want && nbits > 0 && nbits < ((int64_t)1 << 31)) {
+            gh::FilterDesc g = *f;   // the clauses alone, on document ids
+            g.has_range = 0;
+            g.n_range = 0;
+            g.del_bitmap = nullptr;
+            g.del_bits = 0;
+            g.vid2doc = nullptr;
+            g.n_vid2doc = 0;
+            GH_CHECK(h, h->w_fbits.ensure((size_t)((nbits + 63) / 64) * 8));
+            gh::launch_filter_bitmap(h->stream, g, nbits, h->w_fbits.as<uint8_t>());
+            gh::RangeDesc& r = f->range[f->n_range++];
+            r.bitmap = h->w_fbits.as<uint8_t>();
+            r.min_doc = 0;
+            r.max_doc = (int32_t)(nbits - 1);
+            r.min_aligned = 0;
+            r.b_not_in = 0;
+            f->has_range = 1;
+            f->n_field = 0;
+            f->n_term = 0;
+        }
     }
     return GAMMA_HIP_OK;
 }
@@ -678,7 +709,7 @@ int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, c
         fc = *given;
     } else {
         gh::FilterDesc filt;
-        GH_TRY(build_filter(h, p, &filt));
+        GH_TRY(build_filter(h, p, &filt, nullptr, (int64_t)nq * p->nprobe * (h->ntotal / std::max(1, h->nlist))));
         GH_TRY(filt_ctx_single(h, filt, &fc));
     }
     // faiss picks the coarse path from the size of the WHOLE call (faiss:utils/distances.cpp:346);
@@ -797,7 +828,7 @@ int ivfflat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq,
     const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
     const float neutral = l2 ? 3.402823466e+38f : -3.402823466e+38f;
     gh::FilterDesc filt;
-    GH_TRY(build_filter(h, p, &filt));
+    GH_TRY(build_filter(h, p, &filt, nullptr, (int64_t)nq * p->nprobe * (h->ntotal / std::max(1, h->nlist))));
     FiltCtx fc;
     GH_TRY(filt_ctx_single(h, filt, &fc));
     gamma_hip_search_params pp = *p;
@@ -882,7 +913,7 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
     const int64_t N = h->nraw;
     hipStream_t s = h->stream;
     gh::FilterDesc filt;
-    GH_TRY(build_filter(h, p, &filt));
+    GH_TRY(build_filter(h, p, &filt, nullptr, (int64_t)nq * N));
     {   // small calls: the whole store as ONE row chunk, then the small-batch chains' selection -- three or four launches
         // instead of three per 65536 rows (1 M x 128, one query: 49 launches, 1.1 ms)
         static const bool off = getenv("GAMMA_HIP_NO_SMALL_PATH") != nullptr;

@@ -50,6 +50,9 @@ struct FilterDesc {
 
 void launch_pairwise(hipStream_t s, bool l2, const float* x, int nq, int d, const float* y,
                      int64_t ny, float* out, int64_t ld_out);
+// field / term clauses of f -> one bit per document id in [0, nbits) (out: ceil(nbits / 64) * 8 bytes); f must carry no
+// range bitmaps, no delete bitmap and no vid -> doc map (it is evaluated on document ids)
+void launch_filter_bitmap(hipStream_t s, const FilterDesc& f, int64_t nbits, uint8_t* out);
 void launch_pairwise_filtered(hipStream_t s, bool l2, const float* x, int nq, int d,
                               const float* y, int64_t ny, float* out, int64_t ld_out,
                               const FilterDesc& filt, float min_score, float max_score,

@@ -310,6 +310,22 @@ void launch_pairwise(hipStream_t s, bool l2, const float* x, int nq, int d, cons
         launch_pairwise_t<false, false>(s, x, nq, d, y, ny, out, ld_out, f, 0, 0, 0, 0);
 }
 
+// The numeric-column and term clauses of a request, evaluated once per DOCUMENT into one bit each -- the form in
+// which range filters arrive (table/range_query_result.h).  A large batch tests a document's clauses once per scored
+// code of that document; with the bit in hand the scan reads one bit of an L2-resident map instead of a column value
+// (and a term list) at a random address.  Same predicate code (filter_dev.h), so the same answer by construction.
+__global__ __launch_bounds__(256) void k_filter_bitmap(FilterDesc f, int64_t nbits, unsigned long long* __restrict__ out) {
+    const int64_t doc = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = doc < nbits && is_valid_doc(f, doc);
+    const unsigned long long m = __ballot(ok);
+    if ((threadIdx.x & 63) == 0 && (doc >> 6) < ((nbits + 63) >> 6)) out[doc >> 6] = m;
+}
+void launch_filter_bitmap(hipStream_t s, const FilterDesc& f, int64_t nbits, uint8_t* out) {
+    if (nbits <= 0) return;
+    hipLaunchKernelGGL(k_filter_bitmap, dim3((unsigned)((nbits + 255) / 256)), dim3(256), 0, s, f, nbits,
+                       reinterpret_cast<unsigned long long*>(out));
+}
+
 void launch_pairwise_filtered(hipStream_t s, bool l2, const float* x, int nq, int d,
                               const float* y, int64_t ny, float* out, int64_t ld_out,
                               const FilterDesc& filt, float min_score, float max_score,

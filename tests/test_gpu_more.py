@@ -770,6 +770,32 @@ def test_concurrent_small_searches_are_combined_and_exact(case, hip):
     assert not errors, errors[:3]
 
 
+_FILTER_BITMAP_MODES = ("0", "1", None)
+
+
+class _filter_bitmap:
+    """GAMMA_HIP_FILTER_BITMAP for the calls inside: "0" clauses evaluated per scored code, "1" once per document into a
+    bitmap (k_filter_bitmap), None: the library's own estimate decides."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        import os
+        self.old = os.environ.get("GAMMA_HIP_FILTER_BITMAP")
+        if self.mode is None:
+            os.environ.pop("GAMMA_HIP_FILTER_BITMAP", None)
+        else:
+            os.environ["GAMMA_HIP_FILTER_BITMAP"] = self.mode
+
+    def __exit__(self, *a):
+        import os
+        if self.old is None:
+            os.environ.pop("GAMMA_HIP_FILTER_BITMAP", None)
+        else:
+            os.environ["GAMMA_HIP_FILTER_BITMAP"] = self.old
+
+
 def test_field_filters_on_device(case):
     """Scalar range filters evaluated on device columns == the same selection handed over as a
     host-built RangeQueryResult bitmap (reference semantics: IsInRange<T>, AND of the clauses,
@@ -807,12 +833,16 @@ def test_field_filters_on_device(case):
             (D, I, st), _ = run_both(case, g, q, 10, 8, 100, B.METRIC_L2, has_rank, range_docs=[docs])
             args = api.SearchArgs(metric=api.METRIC_L2, nprobe=8, recall_num=100, has_rank=has_rank,
                                   coarse_mode=0, field_filters=filters, **WIDE)
-            Dg, Ig = g.ivfpq_search(q, 10, args)
-            compare_topk(D, I, Dg, Ig)
+            for fb in _FILTER_BITMAP_MODES:   # clauses per scored code / once per document into a bitmap / by estimate
+                with _filter_bitmap(fb):
+                    Dg, Ig = g.ivfpq_search(q, 10, args)
+                compare_topk(D, I, Dg, Ig)
         Df, If = B.flat_search(case["base"], q[:8], 10, B.METRIC_L2,
                                B.make_ctx(range_filters=[B.make_range_filter(docs)], **WIDE))
-        Dg, Ig = g.flat_search(q[:8], 10, api.SearchArgs(metric=api.METRIC_L2, field_filters=filters, **WIDE))
-        compare_topk(Df, If, Dg, Ig)
+        for fb in _FILTER_BITMAP_MODES:
+            with _filter_bitmap(fb):
+                Dg, Ig = g.flat_search(q[:8], 10, api.SearchArgs(metric=api.METRIC_L2, field_filters=filters, **WIDE))
+            compare_topk(Df, If, Dg, Ig)
     with pytest.raises(api.GammaHipError):      # unknown column
         g.ivfpq_search(q, 10, api.SearchArgs(metric=api.METRIC_L2, nprobe=8, field_filters=[(99, 0, 1, True, True)],
                                              **WIDE))
@@ -1068,13 +1098,17 @@ def test_term_filters_on_device(case):
             (D, I, st), _ = run_both(case, g, q, 10, 8, 100, B.METRIC_L2, has_rank, range_docs=[docs])
             args = api.SearchArgs(metric=api.METRIC_L2, nprobe=8, recall_num=100, has_rank=has_rank, coarse_mode=0,
                                   term_filters=terms, field_filters=fields or None, **WIDE)
-            Dg, Ig = g.ivfpq_search(q, 10, args)
-            compare_topk(D, I, Dg, Ig)
+            for fb in _FILTER_BITMAP_MODES:
+                with _filter_bitmap(fb):
+                    Dg, Ig = g.ivfpq_search(q, 10, args)
+                compare_topk(D, I, Dg, Ig)
         Df, If = B.flat_search(case["base"], q[:8], 10, B.METRIC_L2,
                                B.make_ctx(range_filters=[B.make_range_filter(docs)], **WIDE))
-        Dg, Ig = g.flat_search(q[:8], 10, api.SearchArgs(metric=api.METRIC_L2, term_filters=terms,
-                                                         field_filters=fields or None, **WIDE))
-        compare_topk(Df, If, Dg, Ig)
+        for fb in _FILTER_BITMAP_MODES:
+            with _filter_bitmap(fb):
+                Dg, Ig = g.flat_search(q[:8], 10, api.SearchArgs(metric=api.METRIC_L2, term_filters=terms,
+                                                                 field_filters=fields or None, **WIDE))
+            compare_topk(Df, If, Dg, Ig)
     with pytest.raises(api.GammaHipError):      # unknown column
         g.ivfpq_search(q, 10, api.SearchArgs(metric=api.METRIC_L2, nprobe=8, term_filters=[(77, 1, [1])], **WIDE))
     g.close()

@@ -32,22 +32,28 @@ g.raw_init(d)
 rng = np.random.default_rng(3)
 done = 0
 c = 0
+col = []
 while done < N:
     n = min(CH, N - done)
     xb = chunk(n, 2000 + c)
     g.raw_append(xb)
     g.add(xb, done)
-    g.field_append(0, rng.integers(0, 1000000, size=n).astype(np.int64))
+    col.append(rng.integers(0, 1000000, size=n).astype(np.int64))
+    g.field_append(0, col[-1])
     done += n
     c += 1
+col = np.concatenate(col)
 print("generate + add %d vectors %.1fs, device bytes %.1f GB" % (N, time.time() - t0, g.total_mem_bytes() / 1e9))
 q = chunk(nq * 2, 777)
 dq = torch.from_numpy(q).to(dev)
 D = torch.empty((nq, k), dtype=torch.float32, device=dev)
 I = torch.empty((nq, k), dtype=torch.int64, device=dev)
-for name, ff in (("no filter", None), ("10% range filter", [(0, 0, 99999, True, True)])):
+legs = [("no filter", None, None), ("10% range filter", [(0, 0, 99999, True, True)], None)]
+if os.environ.get("C5_BITMAP_LEG"):   # the same documents as a request bitmap (what the engine's range index hands over)
+    legs.append(("10% range filter as a bitmap", None, [api.make_range_filter(np.nonzero(col <= 99999)[0])]))
+for name, ff, rf in legs:
     args = api.SearchArgs(metric=api.METRIC_IP, nprobe=P, recall_num=R, has_rank=True, min_score=-1e30, max_score=1e30,
-                          field_filters=ff)
+                          field_filters=ff, range_filters=rf)
     for i in range(3):
         g.ivfpq_search_device(dq[(i % 2) * nq:].data_ptr(), nq, k, args, D.data_ptr(), I.data_ptr())
     g.synchronize()
