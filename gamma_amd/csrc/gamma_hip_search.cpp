@@ -244,7 +244,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     // ids are only read during the scan when something can reject an entry: a delete bit,
     // a range filter, or a superseded (bit 63) slot left behind by Update
     const int need_ids =
-            (fc.any_clause || (h->d_bitmap && h->bitmap_any) || h->n_moved > 0) ? 1 : 0;
+            (!h->prefiltered && (fc.any_clause || (h->d_bitmap && h->bitmap_any) || h->n_moved > 0)) ? 1 : 0;
     const int* qperm = nullptr;
     // Probes per workgroup.  Sharded search with a compacted assignment: a query keeps ~P/W probes on
     // this shard, all in its first group(s) -- the other P/G - 1 workgroups of the query would start only
@@ -638,7 +638,7 @@ int ivfpq_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int n
                                    h->w_qtotal.as<int>(), h->w_pair_base.as<int64_t>(), d_x, h->d_cc, d,
                                    l2 ? nullptr : h->w_pair_ip.as<float>(), d_units, d_nunits, chunk_len);
     h->scan_pairs += (int64_t)nq * P;
-    const int need_ids = (fc.any_clause || (h->d_bitmap && h->bitmap_any) || h->n_moved > 0) ? 1 : 0;
+    const int need_ids = (!h->prefiltered && (fc.any_clause || (h->d_bitmap && h->bitmap_any) || h->n_moved > 0)) ? 1 : 0;
     gh::launch_ivfpq_scan_pair(s, l2, d_x, nq, d, M, P, h->w_probe.as<int>(),
                                l2 ? h->w_coarse_dis.as<float>() : h->w_pair_ip.as<float>(), h->d_cc,
                                h->w_st2.as<float>(), h->d_T2, h->d_list_off, h->d_list_len, h->d_list_mask, nlist,
@@ -723,6 +723,45 @@ int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, c
         h->last_P = p->nprobe;
         h->last_R = R;
         return GAMMA_HIP_OK;
+    }
+    // Large filtered batches: the lists are cut down to the entries that pass -- once per call, the predicate does not
+    // depend on the query (kernels.hip k_compact_lists) -- and the call runs unfiltered over the shadow lists.  Worth it
+    // when the call tests several times as many entries as the index holds; GAMMA_HIP_LIST_COMPACT=0/1 never / always.
+    struct Restore {
+        H* h;
+        uint8_t* codes;
+        int64_t* ids;
+        int* len;
+        bool on = false;
+        ~Restore() {
+            if (on) {
+                h->d_codes = codes;
+                h->d_ids = ids;
+                h->d_list_len = len;
+                h->prefiltered = false;
+            }
+        }
+    } restore{h, h->d_codes, h->d_ids, h->d_list_len};
+    {
+        const bool need = fc.any_clause || (h->d_bitmap && h->bitmap_any) || h->n_moved > 0;
+        const char* env = getenv("GAMMA_HIP_LIST_COMPACT");
+        const int64_t est = (int64_t)nq * p->nprobe * (h->ntotal / std::max(1, h->nlist));
+        const bool want = env ? atoi(env) != 0 : est >= 4 * std::max<int64_t>(1, h->ntotal);
+        if (need && want && !given && !h->exact_ties && !h->d_list_mask && !h->list_major && h->arena_cap > 0) {
+            GH_CHECK(h, h->w_cmp_codes.ensure((size_t)h->arena_cap * h->code_size));
+            GH_CHECK(h, h->w_cmp_ids.ensure((size_t)h->arena_cap * sizeof(int64_t)));
+            GH_CHECK(h, h->w_cmp_len.ensure((size_t)h->nlist * sizeof(int)));
+            GH_CHECK(h, hipStreamWaitEvent(h->stream, h->ver_ev[h->cur_ver], 0));   // the version's lists are in place
+            gh::launch_compact_lists(h->stream, h->d_list_off, h->d_list_len, h->nlist, h->d_codes, h->d_ids, h->code_size,
+                                     fc.d_tab, h->w_cmp_codes.as<uint8_t>(), h->w_cmp_ids.as<int64_t>(),
+                                     h->w_cmp_len.as<int>());
+            h->d_codes = h->w_cmp_codes.as<uint8_t>();
+            h->d_ids = h->w_cmp_ids.as<int64_t>();
+            h->d_list_len = h->w_cmp_len.as<int>();
+            h->prefiltered = true;
+            restore.on = true;
+            fc.any_clause = false;
+        }
     }
     const int chunk = scan_chunk(h, nq, p->nprobe), P = p->nprobe;
     // long lists (C4: 64 probes x lists of tens of thousands) make the ADC slab the limit: the coarse

@@ -53,6 +53,11 @@ void launch_pairwise(hipStream_t s, bool l2, const float* x, int nq, int d, cons
 // field / term clauses of f -> one bit per document id in [0, nbits) (out: ceil(nbits / 64) * 8 bytes); f must carry no
 // range bitmaps, no delete bitmap and no vid -> doc map (it is evaluated on document ids)
 void launch_filter_bitmap(hipStream_t s, const FilterDesc& f, int64_t nbits, uint8_t* out);
+// every list cut down to the entries that pass ftab[0] (delete bitmap, superseded slots, every clause), in order,
+// at the same offsets of (out_codes, out_ids); out_len: the new lengths
+void launch_compact_lists(hipStream_t s, const int64_t* list_off, const int* list_len, int nlist, const uint8_t* codes,
+                          const int64_t* ids, int code_size, const FilterDesc* ftab /* device */, uint8_t* out_codes,
+                          int64_t* out_ids, int* out_len);
 void launch_pairwise_filtered(hipStream_t s, bool l2, const float* x, int nq, int d,
                               const float* y, int64_t ny, float* out, int64_t ld_out,
                               const FilterDesc& filt, float min_score, float max_score,

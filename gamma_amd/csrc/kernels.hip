@@ -326,6 +326,66 @@ void launch_filter_bitmap(hipStream_t s, const FilterDesc& f, int64_t nbits, uin
                        reinterpret_cast<unsigned long long*>(out));
 }
 
+// Per-call compaction of the inverted lists under the call's validity predicate (large filtered batches): a
+// document passes or fails whatever the query, so every list is cut down ONCE to the entries that pass -- same
+// region of a shadow arena, same order, new length -- and the batch then runs the UNFILTERED pipeline over the
+// shadow lists: no id reads, no predicate and no ADC work for entries that could never be returned (at 10 %
+// selectivity nine tenths of the scan).  One workgroup per list; positions by ballot + prefix, stable.
+__global__ __launch_bounds__(256) void k_compact_lists(const int64_t* __restrict__ list_off, const int* __restrict__ list_len,
+                                                       const uint8_t* __restrict__ codes, const int64_t* __restrict__ ids,
+                                                       int code_size, const FilterDesc* __restrict__ ftab,
+                                                       uint8_t* __restrict__ out_codes, int64_t* __restrict__ out_ids,
+                                                       int* __restrict__ out_len) {
+    __shared__ int s_wtot[4];
+    const int l = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t off = list_off[l];
+    const int len = list_len[l];
+    const FilterDesc& filt = ftab[0];
+    int run = 0;
+    for (int j0 = 0; j0 < len; j0 += 256) {   // uniform
+        const int j = j0 + tid;
+        int64_t id = -1;
+        bool ok = false;
+        if (j < len) {
+            id = ids[off + j];
+            ok = id >= 0 && is_valid_doc(filt, id);   // bit 63: superseded slot (realtime_mem_data.h:26)
+        }
+        const unsigned long long m = __ballot(ok);
+        if (lane == 0) s_wtot[w] = __popcll(m);
+        __syncthreads();
+        int base = run, tot = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int t = s_wtot[i];
+            if (i < w) base += t;
+            tot += t;
+        }
+        if (ok) {
+            const int64_t dst = off + base + __popcll(m & ((1ull << lane) - 1ull));
+            out_ids[dst] = id;
+            const uint8_t* src = codes + (off + j) * code_size;
+            uint8_t* d8 = out_codes + dst * code_size;
+            if ((code_size & 15) == 0) {
+                for (int b = 0; b < code_size; b += 16) *reinterpret_cast<uint4*>(d8 + b) = *reinterpret_cast<const uint4*>(src + b);
+            } else if ((code_size & 7) == 0) {
+                for (int b = 0; b < code_size; b += 8) *reinterpret_cast<uint2*>(d8 + b) = *reinterpret_cast<const uint2*>(src + b);
+            } else {
+                for (int b = 0; b < code_size; b++) d8[b] = src[b];
+            }
+        }
+        run += tot;
+        __syncthreads();   // s_wtot is rewritten by the next round
+    }
+    if (tid == 0) out_len[l] = run;
+}
+void launch_compact_lists(hipStream_t s, const int64_t* list_off, const int* list_len, int nlist, const uint8_t* codes,
+                          const int64_t* ids, int code_size, const FilterDesc* ftab, uint8_t* out_codes, int64_t* out_ids,
+                          int* out_len) {
+    if (nlist <= 0) return;
+    hipLaunchKernelGGL(k_compact_lists, dim3(nlist), dim3(256), 0, s, list_off, list_len, codes, ids, code_size, ftab,
+                       out_codes, out_ids, out_len);
+}
+
 void launch_pairwise_filtered(hipStream_t s, bool l2, const float* x, int nq, int d,
                               const float* y, int64_t ny, float* out, int64_t ld_out,
                               const FilterDesc& filt, float min_score, float max_score,
