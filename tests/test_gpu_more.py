@@ -1324,3 +1324,63 @@ def test_small_batch_path_parameter_corners():
                         assert D0.tobytes() == D1.tobytes() and np.array_equal(I0, I1), (d, nq, P, R, k, has_rank, cm, mode)
         finally:
             g.close()
+
+
+class _env:
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        import os
+        self.old = os.environ.get(self.name)
+        if self.value is None:
+            os.environ.pop(self.name, None)
+        else:
+            os.environ[self.name] = self.value
+
+    def __exit__(self, *a):
+        import os
+        if self.old is None:
+            os.environ.pop(self.name, None)
+        else:
+            os.environ[self.name] = self.old
+
+
+@pytest.mark.parametrize("metric", [B.METRIC_L2, B.METRIC_IP])
+def test_large_filtered_batches_run_over_compacted_lists(metric):
+    """Batches that test several times as many entries as the index holds have the lists cut down once per call to the
+    entries that pass (delete bitmap, superseded slots of updated vectors, range / field clauses; kernels.hip
+    k_compact_lists) and then run unfiltered: results byte for byte those of the per-code predicate, and the oracle's."""
+    case = fixtures.trained_case(d=32, nlist=64, M=8, N=20000, nq=64, metric=metric)
+    hip_metric = api.METRIC_L2 if metric == B.METRIC_L2 else api.METRIC_IP
+    g = fixtures.load_hip(case)
+    N = case["N"]
+    rng = np.random.default_rng(11)
+    try:
+        dead = rng.choice(N, N // 6, replace=False)
+        bm = np.zeros((N >> 3) + 1, dtype=np.uint8)
+        np.bitwise_or.at(bm, dead >> 3, (1 << (dead & 7)).astype(np.uint8))
+        g.bitmap_upload(bm, N)
+        g.delete(dead)
+        price = rng.integers(0, 1000, size=N).astype(np.int64)
+        g.field_append(1, price)
+        q = synth.sift_like(700, d=32, seed=4242)
+        keep = rng.choice(N, N // 10, replace=False)
+        for kw_g, kw_o in ((dict(), dict()),
+                           (dict(range_filters=[api.make_range_filter(keep)]), dict(range_filters=[B.make_range_filter(keep)])),
+                           (dict(field_filters=[(1, 100, 200, True, False)]),
+                            dict(range_filters=[B.make_range_filter(np.nonzero((price >= 100) & (price < 200))[0])]))):
+            for has_rank in (True, False):
+                args = api.SearchArgs(metric=hip_metric, nprobe=16, recall_num=120, has_rank=has_rank, **WIDE, **kw_g)
+                res = []
+                for mode in ("0", "1", None):   # None: the library's estimate (700 x 16 x 312 >= 4 x 20000: compacted)
+                    with _env("GAMMA_HIP_LIST_COMPACT", mode):
+                        res.append(g.ivfpq_search(q, 10, args))
+                for D1, I1 in res[1:]:
+                    assert res[0][0].tobytes() == D1.tobytes() and np.array_equal(res[0][1], I1)
+                ctx = B.make_ctx(docids_bitmap=bm, **WIDE, **kw_o)
+                o = case["oracle"]   # (the shared fixture's oracle: validity comes from the context's bitmap only)
+                Do, Io = o.search(q[:200], 10, 16, recall_num=120, has_rank=has_rank, metric=metric, ctx=ctx)[:2]
+                compare_topk(Do, Io, res[1][0][:200], res[1][1][:200])
+    finally:
+        g.close()
