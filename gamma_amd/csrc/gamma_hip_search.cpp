@@ -752,6 +752,7 @@ int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, c
             GH_CHECK(h, h->w_cmp_ids.ensure((size_t)h->arena_cap * sizeof(int64_t)));
             GH_CHECK(h, h->w_cmp_len.ensure((size_t)h->nlist * sizeof(int)));
             GH_CHECK(h, hipStreamWaitEvent(h->stream, h->ver_ev[h->cur_ver], 0));   // the version's lists are in place
+            StageScope t(h, GAMMA_HIP_STAGE_SCAN, false);   // profiled as part of the scan it shortens
             gh::launch_compact_lists(h->stream, h->d_list_off, h->d_list_len, h->nlist, h->d_codes, h->d_ids, h->code_size,
                                      fc.d_tab, h->w_cmp_codes.as<uint8_t>(), h->w_cmp_ids.as<int64_t>(),
                                      h->w_cmp_len.as<int>());
