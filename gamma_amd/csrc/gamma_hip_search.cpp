@@ -697,6 +697,49 @@ int scan_chunk(H* h, int nq, int P) {
 }
 int query_chunk(H* h, int nq, int P) { return std::min(coarse_chunk(h, nq), scan_chunk(h, nq, P)); }
 
+// Large filtered batches: the lists are cut down to the entries that pass -- once per call, the predicate does not
+// depend on the query (kernels.hip k_compact_lists) -- and the call runs unfiltered over the shadow lists.  Worth it
+// when the call tests several times as many entries as the index holds; GAMMA_HIP_LIST_COMPACT=0/1 never / always.
+// The handle's list pointers are swapped until the ListCompaction object goes out of scope (the caller holds the
+// search lock and h->mu for the whole enqueue).
+struct ListCompaction {
+    H* h;
+    uint8_t* codes;
+    int64_t* ids;
+    int* len;
+    bool on = false;
+    explicit ListCompaction(H* h_) : h(h_), codes(h_->d_codes), ids(h_->d_ids), len(h_->d_list_len) {}
+    ~ListCompaction() {
+        if (on) {
+            h->d_codes = codes;
+            h->d_ids = ids;
+            h->d_list_len = len;
+            h->prefiltered = false;
+        }
+    }
+};
+
+int compact_lists_for_call(H* h, FiltCtx* fc, int64_t est, bool allowed, ListCompaction* lc) {
+    const bool need = fc->any_clause || (h->d_bitmap && h->bitmap_any) || h->n_moved > 0;
+    const char* env = getenv("GAMMA_HIP_LIST_COMPACT");
+    const bool want = env ? atoi(env) != 0 : est >= 4 * std::max<int64_t>(1, h->ntotal);
+    if (!(need && want && allowed && !fc->d_qf && !h->d_list_mask && h->arena_cap > 0)) return GAMMA_HIP_OK;
+    GH_CHECK(h, h->w_cmp_codes.ensure((size_t)h->arena_cap * h->code_size));
+    GH_CHECK(h, h->w_cmp_ids.ensure((size_t)h->arena_cap * sizeof(int64_t)));
+    GH_CHECK(h, h->w_cmp_len.ensure((size_t)h->nlist * sizeof(int)));
+    GH_CHECK(h, hipStreamWaitEvent(h->stream, h->ver_ev[h->cur_ver], 0));   // the version's lists are in place
+    StageScope t(h, GAMMA_HIP_STAGE_SCAN, false);   // profiled as part of the scan it shortens
+    gh::launch_compact_lists(h->stream, h->d_list_off, h->d_list_len, h->nlist, h->d_codes, h->d_ids, h->code_size,
+                             fc->d_tab, h->w_cmp_codes.as<uint8_t>(), h->w_cmp_ids.as<int64_t>(), h->w_cmp_len.as<int>());
+    h->d_codes = h->w_cmp_codes.as<uint8_t>();
+    h->d_ids = h->w_cmp_ids.as<int64_t>();
+    h->d_list_len = h->w_cmp_len.as<int>();
+    h->prefiltered = true;
+    lc->on = true;
+    fc->any_clause = false;
+    return GAMMA_HIP_OK;
+}
+
 // given != nullptr: the filter context of a combined batch (p's own filter clauses are ignored)
 int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, int k,
                                float* d_distances, int64_t* d_labels, const FiltCtx* given = nullptr) {
@@ -724,46 +767,9 @@ int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, c
         h->last_R = R;
         return GAMMA_HIP_OK;
     }
-    // Large filtered batches: the lists are cut down to the entries that pass -- once per call, the predicate does not
-    // depend on the query (kernels.hip k_compact_lists) -- and the call runs unfiltered over the shadow lists.  Worth it
-    // when the call tests several times as many entries as the index holds; GAMMA_HIP_LIST_COMPACT=0/1 never / always.
-    struct Restore {
-        H* h;
-        uint8_t* codes;
-        int64_t* ids;
-        int* len;
-        bool on = false;
-        ~Restore() {
-            if (on) {
-                h->d_codes = codes;
-                h->d_ids = ids;
-                h->d_list_len = len;
-                h->prefiltered = false;
-            }
-        }
-    } restore{h, h->d_codes, h->d_ids, h->d_list_len};
-    {
-        const bool need = fc.any_clause || (h->d_bitmap && h->bitmap_any) || h->n_moved > 0;
-        const char* env = getenv("GAMMA_HIP_LIST_COMPACT");
-        const int64_t est = (int64_t)nq * p->nprobe * (h->ntotal / std::max(1, h->nlist));
-        const bool want = env ? atoi(env) != 0 : est >= 4 * std::max<int64_t>(1, h->ntotal);
-        if (need && want && !given && !h->exact_ties && !h->d_list_mask && !h->list_major && h->arena_cap > 0) {
-            GH_CHECK(h, h->w_cmp_codes.ensure((size_t)h->arena_cap * h->code_size));
-            GH_CHECK(h, h->w_cmp_ids.ensure((size_t)h->arena_cap * sizeof(int64_t)));
-            GH_CHECK(h, h->w_cmp_len.ensure((size_t)h->nlist * sizeof(int)));
-            GH_CHECK(h, hipStreamWaitEvent(h->stream, h->ver_ev[h->cur_ver], 0));   // the version's lists are in place
-            StageScope t(h, GAMMA_HIP_STAGE_SCAN, false);   // profiled as part of the scan it shortens
-            gh::launch_compact_lists(h->stream, h->d_list_off, h->d_list_len, h->nlist, h->d_codes, h->d_ids, h->code_size,
-                                     fc.d_tab, h->w_cmp_codes.as<uint8_t>(), h->w_cmp_ids.as<int64_t>(),
-                                     h->w_cmp_len.as<int>());
-            h->d_codes = h->w_cmp_codes.as<uint8_t>();
-            h->d_ids = h->w_cmp_ids.as<int64_t>();
-            h->d_list_len = h->w_cmp_len.as<int>();
-            h->prefiltered = true;
-            restore.on = true;
-            fc.any_clause = false;
-        }
-    }
+    ListCompaction restore(h);
+    GH_TRY(compact_lists_for_call(h, &fc, (int64_t)nq * p->nprobe * (h->ntotal / std::max(1, h->nlist)),
+                                  !given && !h->exact_ties && !h->list_major, &restore));
     const int chunk = scan_chunk(h, nq, p->nprobe), P = p->nprobe;
     // long lists (C4: 64 probes x lists of tens of thousands) make the ADC slab the limit: the coarse
     // quantizer then still runs over the whole call (one GEMM instead of one per slab chunk)
@@ -882,8 +888,10 @@ int ivfflat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq,
             (int64_t)P * std::max(1, h->max_list_len) <= (1 << 22))
             return ivfflat_small(h, &pp, fc, nq, d_x, k, d_distances, d_labels);
     }
+    ListCompaction restore(h);
+    GH_TRY(compact_lists_for_call(h, &fc, (int64_t)nq * P * (h->ntotal / std::max(1, nlist)), true, &restore));
     const int chunk = scan_chunk(h, nq, P);
-    const int need_filter = (fc.any_clause || (h->d_bitmap && h->bitmap_any)) ? 1 : 0;
+    const int need_filter = (!h->prefiltered && (fc.any_clause || (h->d_bitmap && h->bitmap_any))) ? 1 : 0;
     for (int q0 = 0; q0 < nq; q0 += chunk) {
         const int nc = std::min(chunk, nq - q0);
         const float* xq = d_x + (size_t)q0 * h->d;
