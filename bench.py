@@ -347,6 +347,19 @@ def main():
         extra["search_during_inserts"] = {"qps": round(gnq * nsteps / el, 1), "insert_rate_vectors_per_s": round(20000 / done["t"], 1),
                                           "inserted": 20000, "batch": gnq, "steps": nsteps}
 
+    # (f') the same index with 5 % of its documents deleted (the last leg that touches it): large batches run over lists
+    #      cut down to the live entries once per call (csrc/kernels.hip k_compact_lists) instead of testing the delete
+    #      bitmap for every scored code
+    if world == 1 and not a.no_extra:
+        rng_d = np.random.default_rng(5)
+        dead = rng_d.choice(N, N // 20, replace=False)
+        bmd = np.zeros((N >> 3) + 1, dtype=np.uint8)
+        np.bitwise_or.at(bmd, dead >> 3, (1 << (dead & 7)).astype(np.uint8))
+        g.bitmap_upload(bmd, N)
+        g.delete(dead)
+        sec = timed(lambda: g.ivfpq_search_device(d_q.data_ptr(), gnq, k, args, d_D.data_ptr(), d_I.data_ptr()), 10, 3)
+        extra["deleted_5pct"] = {"qps": round(gnq / sec, 1), "ms_per_step": round(sec * 1e3, 4), "batch": gnq}
+
     # (g) the other BASELINE shapes at a size that builds in seconds, so that the driver's line carries a timing of
     #     them too (full size -- 100 M x 128 and 10 M x 768 -- takes minutes to generate: tools/c4_scale.py 1e8,
     #     tools/c5_scale.py 1e7 16384).  Child processes: each tool builds its own index.
