@@ -45,6 +45,24 @@ Ih = I[:64].cpu().numpy()
 Df, If = g.flat_search(q[(steps - 1) % 2 * nq:][:64], k, api.SearchArgs(metric=api.METRIC_L2, min_score=0.0, max_score=1e30))
 rec = np.mean([len(set(Ih[i].tolist()) & set(If[i].tolist())) / float(k) for i in range(64)])
 print("recall@10 vs flat on 64 queries: %.3f" % rec)
+if os.environ.get("C4_FILTER"):   # a request bitmap that keeps every tenth document (what the engine's range index hands over)
+    keep = np.arange(0, N, 10, dtype=np.int64)
+    fargs = api.SearchArgs(metric=api.METRIC_L2, nprobe=P, recall_num=R, has_rank=True, min_score=0.0, max_score=1e30,
+                           range_filters=[api.make_range_filter(keep)])
+    for mode, name in (("0", "predicate per scored code"), (None, "lists compacted per call")):
+        if mode is None:
+            os.environ.pop("GAMMA_HIP_LIST_COMPACT", None)
+        else:
+            os.environ["GAMMA_HIP_LIST_COMPACT"] = mode
+        for i in range(2):
+            g.ivfpq_search_device(dq[(i % 2) * nq:].data_ptr(), nq, k, fargs, D.data_ptr(), I.data_ptr())
+        g.synchronize()
+        t0 = time.perf_counter()
+        for i in range(5):
+            g.ivfpq_search_device(dq[(i % 2) * nq:].data_ptr(), nq, k, fargs, D.data_ptr(), I.data_ptr())
+        g.synchronize()
+        dt = (time.perf_counter() - t0) / 5
+        print("10 %% range filter, %s: %.2f ms per %d queries = %.0f queries/s" % (name, dt * 1e3, nq, nq / dt))
 # small calls (serving latency): device-buffer entry point, synchronised per call; the small-batch chain against the
 # regular one
 g.profile_enable(False)
