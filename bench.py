@@ -371,7 +371,7 @@ def main():
         def run_tool(argv, seconds):
             try:
                 r = subprocess.run([sys.executable] + argv, cwd=here, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                                   timeout=seconds, universal_newlines=True)
+                                   timeout=seconds, universal_newlines=True, env=dict(os.environ, C4_FILTER="1"))
                 return r.stdout
             except Exception as e:   # a shape leg never fails the bench
                 return "failed: %s" % e
@@ -386,6 +386,7 @@ def main():
             "workload": "C4 shape at 8 M vectors: 8000000x128, nlist 16384, M 32, nprobe 64, recall_num 100, 8192 queries/call",
             "qps": first(r"= (\d+) queries/s", out), "ms_per_call": first(r"search: ([0-9.]+) ms", out),
             "scan_gb_per_call": first(r"scan GB/step ([0-9.]+)", out), "recall_at_10_vs_flat": first(r"recall@10 vs flat on 64 queries: ([0-9.]+)", out),
+            "qps_with_10pct_filter": first(r"lists compacted per call: [0-9.]+ ms per \d+ queries = (\d+) queries/s", out),
             "single_query_us": first(r"latency nq=1\s+small-batch chain median ([0-9.]+)", out), "seconds": round(time.time() - t0, 1)}
         t0 = time.time()
         out = run_tool([os.path.join("tools", "c5_scale.py"), "2e6"], 150)
