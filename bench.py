@@ -54,8 +54,9 @@ def main():
                     help="torch.distributed backend; 'gloo' with --one-gpu runs all ranks on GPU 0 (functional "
                          "check of the multi-rank path on a single-GPU box, not a measurement)")
     ap.add_argument("--one-gpu", action="store_true", help="every rank uses cuda:0")
-    ap.add_argument("--exact-ties", action="store_true",
-                    help="run the timed region with gamma_hip_set_exact_ties on (reference heap order inside ties)")
+    ap.add_argument("--no-exact-ties", action="store_true",
+                    help="run the timed region WITHOUT the reference's heap order inside exact ties (the library default "
+                         "is on: labels identical to the reference at every rank)")
     ap.add_argument("--dup-queries", type=int, default=0,
                     help="experiment: every batch repeats its first N queries (the lists they probe stay cache "
                          "resident: what the scan costs without its table traffic)")
@@ -163,8 +164,7 @@ def main():
     d_D = torch.empty((gnq, k), dtype=torch.float32, device=dev)
     d_I = torch.empty((gnq, k), dtype=torch.int64, device=dev)
     backend = gdist.HipShardBackend(g, local_rank) if use_dist else None
-    if a.exact_ties:
-        g.set_exact_ties(True)
+    g.set_exact_ties(not a.no_exact_ties)
 
     def step(i):
         xb = d_q[(i % nbatches) * gnq:(i % nbatches + 1) * gnq]
@@ -250,15 +250,20 @@ def main():
             torch.cuda.synchronize()
             return (time.perf_counter() - t1) / n
 
-        # (a) exact ties on: the queries whose result a tie can change are replayed with the reference's heaps
+        # (a) exact ties (the default: the queries whose result a tie can change are replayed through the reference's
+        #     heaps, csrc/ties.hip): how many are flagged per batch, and what the step costs with the mode off
         g.set_exact_ties(True)
         sec = timed(lambda: g.ivfpq_search_device(d_q.data_ptr(), gnq, k, args, d_D.data_ptr(), d_I.data_ptr()), 2, 3)
         g.tie_stats(reset=True)
         nst = 10
         sec = timed(lambda: g.ivfpq_search_device(d_q.data_ptr(), gnq, k, args, d_D.data_ptr(), d_I.data_ptr()), nst, 0)
         ts = g.tie_stats()
-        g.set_exact_ties(a.exact_ties)
+        g.set_exact_ties(False)
+        sec_off = timed(lambda: g.ivfpq_search_device(d_q.data_ptr(), gnq, k, args, d_D.data_ptr(), d_I.data_ptr()), nst, 3)
+        g.set_exact_ties(True)
         extra["exact_ties"] = {"qps": round(gnq / sec, 1), "ms_per_step": round(sec * 1e3, 4),
+                               "qps_with_ties_off": round(gnq / sec_off, 1),
+                               "ms_per_step_with_ties_off": round(sec_off * 1e3, 4),
                                "flagged_per_batch": {"coarse_rows_redone": round(ts["coarse_rows"] / nst, 1),
                                                      "recall_num_cut_ties": round(ts["cut_ties"] / nst, 1),
                                                      "queries_replayed": round(ts["replayed"] / nst, 1)},
@@ -284,7 +289,9 @@ def main():
         args0 = api.SearchArgs(metric=api.METRIC_L2, nprobe=a.nprobe, recall_num=a.recall_num,
                                has_rank=not a.no_rank, min_score=0.0, max_score=1e30, coarse_mode=0)
         sec = timed(lambda: g.ivfpq_search_device(d_q.data_ptr(), gnq, k, args0, d_D.data_ptr(), d_I.data_ptr()), 10, 3)
-        extra["coarse_mode_0"] = {"qps": round(gnq / sec, 1), "ms_per_step": round(sec * 1e3, 4)}
+        extra["exact_ties_coarse_mode_0"] = {"qps": round(gnq / sec, 1), "ms_per_step": round(sec * 1e3, 4),
+                                             "note": "exact ties on + the coarse path that is bit-identical to compiled faiss"}
+        g.set_exact_ties(not a.no_exact_ties)
         # (d) C2: flat L2 over the same 1M x 128 raw vectors, 1024 queries per call, k = 100, exact
         #     fvec_L2sqr operation order (1 sub + 1 fma per element pair = 3 flops): bound by the fp32 vector rate
         if N * d * 4 <= (2 << 30):

@@ -32,6 +32,7 @@
 #include <type_traits>
 
 #include "device_math.h"
+#include "heap_dev.h"
 #include "kernels.h"
 
 namespace gh {
@@ -60,13 +61,23 @@ __global__ __launch_bounds__(256, 2) void k_coarse_fused(const float* __restrict
                                                          const float* __restrict__ tau,
                                                          int tiles_per_strip, int cap, int cap_stride,
                                                          unsigned long long* __restrict__ cand,
-                                                         int* __restrict__ cand_cnt, int nseg) {
+                                                         int* __restrict__ cand_cnt, int nseg,
+                                                         const int* __restrict__ rowmap) {
+    // rowmap (STORE only): rowmap[0] rows to compute, row i of the output = query rowmap[1 + i] (the rows k_coarse_final
+    // flagged for the heap replay); a workgroup beyond the count has nothing to do
     constexpr int D = 16 * NCH, LD = D + 1, SEGS = D / 32;   // 32-float segments per row
     extern __shared__ float s_co[];                          // 2 x [64][LD]; first used as the query tile [128][LD]
     __shared__ float s_xn[128];
     __shared__ float2 s_xt[128];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int seg = blockIdx.x, q_base = blockIdx.y * 128;
+    int nrows = nq;
+    if constexpr (STORE) {
+        if (rowmap) {
+            nrows = min(rowmap[0], nq);
+            if (q_base >= nrows) return;   // uniform
+        }
+    }
     const int ntiles = (ny - col0 + 63) >> 6;
     const int t0 = seg * tiles_per_strip, t1 = min(ntiles, t0 + tiles_per_strip);
     // a wave instruction covers 8 rows x 32 floats (8 lanes per 128-byte row segment, coalesced); with the odd
@@ -82,8 +93,13 @@ __global__ __launch_bounds__(256, 2) void k_coarse_fused(const float* __restrict
 #pragma unroll
     for (int half = 0; half < 2; half++) {
 #pragma unroll
-        for (int it = 0; it < NCH; it++)
-            vb[it] = *reinterpret_cast<const float4*>(x + (int64_t)min(q_base + half * 64 + slot_r(it), nq - 1) * D + slot_c(it));
+        for (int it = 0; it < NCH; it++) {
+            int row = min(q_base + half * 64 + slot_r(it), nrows - 1);
+            if constexpr (STORE) {
+                if (rowmap) row = rowmap[1 + row];
+            }
+            vb[it] = *reinterpret_cast<const float4*>(x + (int64_t)row * D + slot_c(it));
+        }
 #pragma unroll
         for (int it = 0; it < NCH; it++) put(s_co + half * 64 * LD, it);
     }
@@ -294,7 +310,7 @@ __global__ __launch_bounds__(256) void k_coarse_final(const float* __restrict__ 
                                                       const unsigned long long* __restrict__ cand,
                                                       const int* __restrict__ cand_cnt, int nseg, int cap,
                                                       int cap_stride, int nq, int P, float* __restrict__ out_dis,
-                                                      int* __restrict__ out_idx, int* __restrict__ ovf) {
+                                                      int* __restrict__ out_idx, int* __restrict__ ovf, int flag_ties) {
     constexpr int NPL = SNPL + 2 * MAXSEG;
     __shared__ unsigned long long s_buf[4][CF_BUF];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -377,6 +393,20 @@ __global__ __launch_bounds__(256) void k_coarse_final(const float* __restrict__ 
     for (int r = tot + lane; r < P; r += 64) {   // fewer than P centroids in all
         out_dis[(int64_t)q * P + r] = INFINITY;
         out_idx[(int64_t)q * P + r] = -1;
+    }
+    if (flag_ties) {
+        // exact ties: two equal keys among the P + 1 smallest (every entry at the P-th key is <= kb, hence here) --
+        // which of them is probed, and in which order equal ones are scanned, is the doing of the reference's heap:
+        // the row goes to k_coarse_repair, which then replays that heap
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < CF_BUF / 64; u++)
+            if (lane + 64 * u < tot) buf[rr[u]] = mine[u];
+        __builtin_amdgcn_wave_barrier();
+        const int have = min(tot, P + 1);
+        bool eq = false;
+        for (int i = lane; i + 1 < have; i += 64) eq |= (uint32_t)(buf[i] >> 32) == (uint32_t)(buf[i + 1] >> 32);
+        if (__ballot(eq) && lane == 0) ovf[1 + atomicAdd(ovf, 1)] = q;
     }
 }
 
@@ -474,14 +504,16 @@ static bool coarse_fused_shape(int nlist, int P, int* sample, int* nseg) {
     return false;
 }
 
-bool coarse_fused_supported(int nq, int d, int nlist, int P) {
+bool coarse_fused_supported(int nq, int d, int nlist, int P, bool exact_ties) {
     int sm, sg;
     if (!(nq >= 4096 && (d == 32 || d == 64 || d == 96 || d == 128) && coarse_fused_shape(nlist, P, &sm, &sg))) return false;
-    // the strip lists and the sample matrix are addressed through 32-bit buffer offsets (k_coarse_fused)
+    // the strip lists and the sample matrix are addressed through 32-bit buffer offsets (k_coarse_fused); with exact
+    // ties also the full rows of the flagged queries
+    if (exact_ties && (int64_t)nq * nlist * 4 >= 0x7fffffffLL) return false;
     return (int64_t)nq * sg * kCoarseCap * 8 < 0x7fffffffLL && (int64_t)nq * sm * 4 < 0x7fffffffLL;
 }
 
-CoarseFusedPlan coarse_fused_plan(int nq, int nlist, int P, int cap) {
+CoarseFusedPlan coarse_fused_plan(int nq, int nlist, int P, int cap, bool exact_ties) {
     CoarseFusedPlan pl;
     // C3 (nlist 4096, P 32): sample 512, 8 strips of 448 columns that keep 37 +- 9 entries per query; kCoarseCap = 128
     // is ten sigma away, the rest goes to k_coarse_repair
@@ -503,12 +535,15 @@ CoarseFusedPlan coarse_fused_plan(int nq, int nlist, int P, int cap) {
     pl.off_cnt = take((size_t)nq * pl.nseg * sizeof(int));
     pl.off_ovf = take((size_t)(nq + 1) * sizeof(int));
     pl.off_scratch = take((size_t)kCoarseRepairGrid * nlist * sizeof(uint32_t));
+    // exact ties: full distance rows of the flagged queries (row i = the i-th flagged query; sized for all of them)
+    pl.off_full = exact_ties ? take((size_t)nq * nlist * sizeof(float)) : 0;
     pl.bytes = o;
     return pl;
 }
 
 void launch_coarse_fused(hipStream_t s, const CoarseFusedPlan& pl, void* ws, const float* x, int nq, int d,
-                         const float* y, int nlist, const float* yn, int P, float* out_dis, int* out_idx) {
+                         const float* y, int nlist, const float* yn, int P, float* out_dis, int* out_idx, bool exact_ties,
+                         unsigned long long* tie_stats, hipStream_t side, hipEvent_t fork, hipEvent_t join) {
     char* b = static_cast<char*>(ws);
     float* mat = reinterpret_cast<float*>(b + pl.off_mat);
     float* tau = reinterpret_cast<float*>(b + pl.off_tau);
@@ -523,14 +558,13 @@ void launch_coarse_fused(hipStream_t s, const CoarseFusedPlan& pl, void* ws, con
         dim3 sgrid((unsigned)sstrips, (unsigned)((nq + 127) / 128));
 #define GH_CS(NCH)                                                                                                      \
     do {                                                                                                                \
-        static bool attr = false;                                                                                       \
-        if (!attr) {                                                                                                    \
+        static std::atomic<uint64_t> attr{0};   /* per device */                                                        \
+        if (first_call_on_device(attr)) {                                                                               \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_coarse_fused<NCH, true>),                         \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (16 * NCH + 1) * 4);         \
-            attr = true;                                                                                                \
         }                                                                                                               \
         hipLaunchKernelGGL((k_coarse_fused<NCH, true>), sgrid, dim3(256), lds, s, x, nq, y, pl.sample, 0, yn, nullptr, \
-                           tps, 0, pl.sample, reinterpret_cast<unsigned long long*>(mat), nullptr, sstrips);           \
+                           tps, 0, pl.sample, reinterpret_cast<unsigned long long*>(mat), nullptr, sstrips, nullptr);  \
     } while (0)
         switch (d) {
             case 32: GH_CS(2); break;
@@ -547,14 +581,13 @@ void launch_coarse_fused(hipStream_t s, const CoarseFusedPlan& pl, void* ws, con
     dim3 grid((unsigned)pl.nseg, (unsigned)((nq + 127) / 128));
 #define GH_CF(NCH)                                                                                                      \
     do {                                                                                                                \
-        static bool attr = false;                                                                                       \
-        if (!attr) {                                                                                                    \
+        static std::atomic<uint64_t> attr{0};   /* per device */                                                        \
+        if (first_call_on_device(attr)) {                                                                               \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_coarse_fused<NCH>),                               \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (16 * NCH + 1) * 4);         \
-            attr = true;                                                                                                \
         }                                                                                                               \
         hipLaunchKernelGGL((k_coarse_fused<NCH>), grid, dim3(256), lds, s, x, nq, y, nlist, pl.sample, yn, tau,         \
-                           pl.tiles_per_strip, pl.cap, pl.cap_stride, cand, cnt, pl.nseg);                                   \
+                           pl.tiles_per_strip, pl.cap, pl.cap_stride, cand, cnt, pl.nseg, nullptr);                          \
     } while (0)
     switch (d) {
         case 32: GH_CF(2); break;
@@ -566,7 +599,7 @@ void launch_coarse_fused(hipStream_t s, const CoarseFusedPlan& pl, void* ws, con
     // C + D
 #define GH_FIN(SN, MS)                                                                                                  \
     hipLaunchKernelGGL((k_coarse_final<SN, MS>), dim3((nq + 3) / 4), dim3(256), 0, s, mat, tau, cand, cnt, pl.nseg, pl.cap, \
-                       pl.cap_stride, nq, P, out_dis, out_idx, ovf)
+                       pl.cap_stride, nq, P, out_dis, out_idx, ovf, exact_ties ? 1 : 0)
     if (pl.sample == 512) {
         if (pl.nseg <= 4) GH_FIN(8, 4);
         else if (pl.nseg <= 8) GH_FIN(8, 8);
@@ -579,8 +612,39 @@ void launch_coarse_fused(hipStream_t s, const CoarseFusedPlan& pl, void* ws, con
         else GH_FIN(32, 16);
     }
 #undef GH_FIN
-    hipLaunchKernelGGL(k_coarse_repair, dim3(kCoarseRepairGrid), dim3(256), (size_t)d * sizeof(float), s, x, d, y, nlist, yn,
-                       ovf, scratch, P, out_dis, out_idx);
+    if (!exact_ties) {
+        hipLaunchKernelGGL(k_coarse_repair, dim3(kCoarseRepairGrid), dim3(256), (size_t)d * sizeof(float), s, x, d, y, nlist, yn,
+                           ovf, scratch, P, out_dis, out_idx);
+        return;
+    }
+    // Exact ties: every row on the list (overflowed, or two equal keys among its P + 1 smallest -- a few in a thousand)
+    // is recomputed in full by the same MFMA chain (store-all mode of the strip kernel, row i = the i-th listed
+    // query) and walked the way faiss's HeapResultHandler walks it (k_coarse_heap_fix).  The two kernels may run on a
+    // side stream beside the caller's next kernels that do not read the assignment; the caller waits for `join`
+    // before the first one that does.
+    hipStream_t rs = s;
+    if (side && fork && join) {
+        (void)hipEventRecord(fork, s);
+        (void)hipStreamWaitEvent(side, fork, 0);
+        rs = side;
+    }
+    float* full = reinterpret_cast<float*>(b + pl.off_full);
+    {
+        const int ntiles = (nlist + 63) / 64, fstrips = std::min(ntiles, 32), tps = (ntiles + fstrips - 1) / fstrips;
+        dim3 fgrid((unsigned)fstrips, (unsigned)((nq + 127) / 128));
+#define GH_CR(NCH)                                                                                                      \
+    hipLaunchKernelGGL((k_coarse_fused<NCH, true>), fgrid, dim3(256), lds, rs, x, nq, y, nlist, 0, yn, nullptr, tps, 0,  \
+                       nlist, reinterpret_cast<unsigned long long*>(full), nullptr, fstrips, ovf)
+        switch (d) {   // (the attribute of this instantiation was set by the sample launch above)
+            case 32: GH_CR(2); break;
+            case 64: GH_CR(4); break;
+            case 96: GH_CR(6); break;
+            default: GH_CR(8); break;
+        }
+#undef GH_CR
+    }
+    launch_coarse_heap_rows(rs, full, nlist, nq, P, ovf, out_dis, out_idx, tie_stats);
+    if (rs != s) (void)hipEventRecord(join, rs);
 }
 
 }  // namespace gh

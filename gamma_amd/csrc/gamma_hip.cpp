@@ -34,7 +34,10 @@ int gamma_hip_create(int device, gamma_hip_index** out) {
     if (!h) return GAMMA_HIP_ENOMEM;
     h->device = device;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&h->wstream, hipStreamNonBlocking) != hipSuccess) {
+        hipStreamCreateWithFlags(&h->wstream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
         delete h;
         return GAMMA_HIP_EDEVICE;
     }
@@ -72,6 +75,9 @@ int gamma_hip_destroy(gamma_hip_index* h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     (void)hipStreamSynchronize(h->wstream);
+    if (h->side) (void)hipStreamSynchronize(h->side);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (int v = 0; v < H::NVER; v++) {
         if (h->ver_ev[v]) (void)hipEventDestroy(h->ver_ev[v]);
         if (h->rd_ev[v]) (void)hipEventDestroy(h->rd_ev[v]);
@@ -108,6 +114,7 @@ int gamma_hip_destroy(gamma_hip_index* h) {
     for (DevBuf* b : bufs) b->release();
     (void)hipStreamDestroy(h->stream);
     (void)hipStreamDestroy(h->wstream);
+    if (h->side) (void)hipStreamDestroy(h->side);
     delete h;
     return GAMMA_HIP_OK;
 }

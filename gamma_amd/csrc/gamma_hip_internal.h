@@ -88,6 +88,11 @@ struct gamma_hip_index {
     //                        the writer then takes search_mu too and drains both streams first (WriteLock::exclusive).
     // Lock order: writer_mu -> search_mu -> mu.
     hipStream_t stream = nullptr, wstream = nullptr;
+    // side stream of the searches: kernels of a call that may overlap its main chain (the heap replay of the coarse
+    // rows with a tie, beside the query tables); forked from and joined into `stream` by events, never used alone
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool coarse_join_pending = false;
     std::mutex mu, search_mu, writer_mu;
     WriteLock* wl = nullptr;   // the writer holding mu (for exclusive() deep inside the arena code)
     static constexpr int NVER = 4;
@@ -168,7 +173,7 @@ struct gamma_hip_index {
     gh::FilterDesc ftab_shadow;
     bool ftab_valid = false;
 
-    bool exact_ties = false;   // gamma_hip_set_exact_ties
+    bool exact_ties = true;    // gamma_hip_set_exact_ties
     bool list_major = false;   // gamma_hip_set_list_major
     bool coarse_fused = true;  // gamma_hip_set_coarse_fused
     bool small_path = true;    // gamma_hip_set_small_path

@@ -143,17 +143,28 @@ int check_params(H* h, const gamma_hip_search_params* p, int nq, int k) {
 
 // ---- IVFPQ stage A: coarse + tables + scan + top-R + ids ------------------------------
 // results: w_cand_dis [nq*R] (ADC distance, best first, sentinel pad), w_cand_ids [nq*R]
+// the assignment is complete on the stream (the heap replay of tied rows may still be running on the side stream)
+int coarse_join(H* h) {
+    if (h->coarse_join_pending) {
+        GH_CHECK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+        h->coarse_join_pending = false;
+    }
+    return GAMMA_HIP_OK;
+}
+
+// defer_join: the caller has kernels to launch that do not read the assignment and calls coarse_join itself
 int ivfpq_coarse(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, float* out_dis = nullptr,
-                 int* out_probe = nullptr) {
+                 int* out_probe = nullptr, bool defer_join = false) {
     const int P = p->nprobe, d = h->d, nlist = h->nlist;
     hipStream_t s = h->stream;
     int mode = p->coarse_mode;
     if (mode < 0) mode = nq < 20 ? 0 : 1;  // faiss:utils/distances.cpp:303,346
-    // large batches: no distance matrix (coarse.hip); exact ties replay rows of the matrix, so they keep it
-    const bool fused = mode == 1 && h->coarse_fused && !h->exact_ties && gh::coarse_fused_supported(nq, d, nlist, P);
+    // large batches: no distance matrix (coarse.hip); with exact ties its rows with a tie near the cut are recomputed
+    // and replayed through the reference's heap by the repair kernel
+    const bool fused = mode == 1 && h->coarse_fused && gh::coarse_fused_supported(nq, d, nlist, P, h->exact_ties);
     gh::CoarseFusedPlan plan;
     if (fused) {
-        plan = gh::coarse_fused_plan(nq, nlist, P, h->coarse_cap);
+        plan = gh::coarse_fused_plan(nq, nlist, P, h->coarse_cap, h->exact_ties);
         GH_CHECK(h, h->w_mat.ensure(plan.bytes));
     } else {
         GH_CHECK(h, h->w_mat.ensure((size_t)nq * nlist * sizeof(float)));
@@ -166,7 +177,11 @@ int ivfpq_coarse(H* h, const gamma_hip_search_params* p, int nq, const float* d_
     }
     StageScope t(h, GAMMA_HIP_STAGE_COARSE);
     if (fused) {
-        gh::launch_coarse_fused(s, plan, h->w_mat.p, d_x, nq, d, h->d_cc, nlist, h->d_cc_norms, P, out_dis, out_probe);
+        static const bool no_side = getenv("GAMMA_HIP_NO_SIDE_STREAM") != nullptr;
+        const bool side = h->exact_ties && defer_join && !no_side;
+        gh::launch_coarse_fused(s, plan, h->w_mat.p, d_x, nq, d, h->d_cc, nlist, h->d_cc_norms, P, out_dis, out_probe,
+                                h->exact_ties, h->d_tie_stats, side ? h->side : nullptr, h->ev_fork, h->ev_join);
+        h->coarse_join_pending = side;
         static const bool dbg = getenv("GAMMA_HIP_COARSE_DBG") != nullptr;
         if (dbg) {   // how many queries the strip lists could not hold (they went through the repair kernel)
             int n_ovf = 0;
@@ -238,7 +253,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
                                        hipMemcpyDeviceToDevice, s));
         }
     } else {
-        GH_TRY(ivfpq_coarse(h, p, nq, d_x));
+        GH_TRY(ivfpq_coarse(h, p, nq, d_x, nullptr, nullptr, /*defer_join=*/true));
     }
     h->scan_pairs += (int64_t)nq * P;
     // ids are only read during the scan when something can reject an entry: a delete bit,
@@ -296,6 +311,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
             GH_CHECK(h, h->w_st2.ensure((size_t)nq * M * 256 * sizeof(float)));
             gh::launch_pq_ip_table(s, d_x, nq, d, M, h->d_pqc, h->w_st2.as<float>());
         }
+        GH_TRY(coarse_join(h));
         gh::launch_pair_offsets(s, h->w_probe.as<int>(), nq, P, h->d_list_len, h->d_list_mask, nlist,
                                 h->w_pair_off.as<int>(), h->w_qtotal.as<int>(),
                                 h->profile ? h->d_scan_codes : nullptr, h->d_list_off,
@@ -574,7 +590,7 @@ bool ivfpq_small_ok(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, i
     // exact coarse distances (faiss below 20 queries) come from the fused first kernel, which covers 16 queries; the
     // GEMM form (20 queries and more) from the regular matrix kernel
     return !off && h->small_path && nq >= 1 && nq <= max_nq &&
-           p->nprobe <= 128 && R <= 1024 && !h->exact_ties && !h->profile && !fc.d_qf && !h->d_list_mask &&
+           p->nprobe <= 128 && R <= 1024 && !h->profile && !fc.d_qf && !h->d_list_mask &&
            h->nlist <= 16384 &&
            (int64_t)p->nprobe * std::max(1, h->max_list_len) <= (1 << 22) &&
            // long lists: beyond ~5e7 codes per call the regular chain's bound filter wins (full-size C4, 390 k codes per
@@ -636,7 +652,8 @@ int ivfpq_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int n
     gh::launch_small_coarse_select(s, h->w_mat.as<float>(), nlist, nq, P, h->w_coarse_dis.as<float>(), h->w_probe.as<int>(),
                                    h->d_list_len, h->d_list_mask, h->d_list_off, h->w_pair_off.as<int>(),
                                    h->w_qtotal.as<int>(), h->w_pair_base.as<int64_t>(), d_x, h->d_cc, d,
-                                   l2 ? nullptr : h->w_pair_ip.as<float>(), d_units, d_nunits, chunk_len);
+                                   l2 ? nullptr : h->w_pair_ip.as<float>(), d_units, d_nunits, chunk_len,
+                                   h->exact_ties ? 1 : 0, h->d_tie_stats);
     h->scan_pairs += (int64_t)nq * P;
     const int need_ids = (!h->prefiltered && (fc.any_clause || (h->d_bitmap && h->bitmap_any) || h->n_moved > 0)) ? 1 : 0;
     gh::launch_ivfpq_scan_pair(s, l2, d_x, nq, d, M, P, h->w_probe.as<int>(),
@@ -660,11 +677,47 @@ int ivfpq_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int n
             GH_CHECK(h, h->w_selp.ensure((size_t)nq * smax * R * sizeof(int)));
         }
     }
+    // exact ties: a query with a tie at the recall_num or k cut is replayed through the reference's heaps inside the
+    // tail kernel (tie_dev.h), from the whole slab row
+    gh::TieReplayArgs tr;
+    const bool ties = h->exact_ties && R <= gh::tie_replay_max_k() && P <= gh::tie_replay_max_probes();
+    if (ties) {
+        tr.list = nullptr;
+        tr.count = nullptr;
+        tr.nq = nq;
+        tr.slab = h->w_dist.as<float>();
+        tr.q_stride = q_stride;
+        tr.pair_off = h->w_pair_off.as<int>();
+        tr.pair_base = h->w_pair_base.as<int64_t>();
+        tr.ids = h->d_ids;
+        tr.P = P;
+        tr.G = 1;
+        tr.ready = nullptr;
+        tr.surv = nullptr;
+        tr.gcnt = nullptr;
+        tr.nsl = 0;
+        tr.slice_cap = 0;
+        tr.x = d_x;
+        tr.d = d;
+        tr.raw = h->d_raw;
+        tr.nraw = h->nraw;
+        tr.R = R;
+        tr.k = k;
+        tr.has_rank = p->has_rank ? 1 : 0;
+        tr.min_score = p->min_score;
+        tr.max_score = p->max_score;
+        tr.neutral = neutral;
+        tr.cand_dis = h->w_cand_dis.as<float>();
+        tr.cand_ids = h->w_cand_ids.as<int64_t>();
+        tr.distances = d_distances;
+        tr.labels = d_labels;
+    }
     gh::launch_small_tail(s, l2, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), nq, R, P, h->w_probe.as<int>(),
                           h->w_pair_off.as<int>(), h->d_list_off, h->d_ids, h->w_cand_dis.as<float>(),
                           h->w_cand_pos.as<int>(), h->w_cand_ids.as<int64_t>(), p->has_rank ? 1 : 0, d_x, d, h->d_raw,
                           h->nraw, k, p->min_score, p->max_score, neutral, d_distances, d_labels, smax,
-                          smax ? h->w_selv.as<float>() : nullptr, smax ? h->w_selp.as<int>() : nullptr);
+                          smax ? h->w_selv.as<float>() : nullptr, smax ? h->w_selp.as<int>() : nullptr, 0,
+                          ties ? &tr : nullptr, h->d_tie_stats);
     h->tie = H::TieCtx();
     h->tie.G = 1;
     h->tie.q_stride = q_stride;

@@ -1,0 +1,172 @@
+// heap_dev.h -- faiss's binary heaps (faiss:utils/Heap.h:46-131,300-330) replayed on the device, CMax form
+// (cmp(a, b) = a > b: the heap of the k SMALLEST values, its largest at the root; the inner-product CMin heap on
+// v is this heap on -v, negation is exact).
+//
+// The array a heap ends with depends on its whole history, so reproducing the reference inside exact ties means
+// replaying every accepted candidate -- a chain of dependent sifts that no amount of lanes shortens by itself.
+// What the 64 lanes CAN do:
+//   * skip: `if (top > dis)` of 64 candidates at a time is one ballot (HeapWalk::accept);
+//   * pipeline: heap_replace_top of candidate n+1 may start as soon as candidate n has left the two levels
+//     below the root.  Lanes 0..7 are operation slots; every tick() moves all operations in flight one level
+//     down (one 16-byte LDS read of the two children, one 8-byte write), a new operation enters every second
+//     tick.  An operation two levels behind its predecessor reads nodes the predecessor wrote one tick earlier,
+//     never nodes it is about to write, so the heap array goes through exactly the states of the sequential
+//     code.  One candidate costs two LDS round trips instead of one per level (8 for recall_num = 200).
+// The heap lives in LDS as h[i] = (value bits, payload), node i 1-based as in faiss after its `bh_val--`;
+// h[0] is a dump slot for idle lanes; the array needs K + 2 entries and 16-byte alignment.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gh {
+
+constexpr float kHeapFltMax = 3.402823466e+38f;
+
+// heap_heapify on an empty heap: (neutral, -1) everywhere (Heap.h:195-217)
+__device__ __forceinline__ void heap_fill(uint2* h, int K, int tid, int nthreads) {
+    for (int i = tid; i < K + 2; i += nthreads) h[i] = make_uint2(__float_as_uint(kHeapFltMax), 0xffffffffu);
+}
+
+__device__ __forceinline__ float hw_readlane_f(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_amdgcn_readfirstlane(l)));
+}
+__device__ __forceinline__ int hw_readlane_i(int v, int l) {
+    return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l));
+}
+
+// One wave.  All 64 lanes call every member together.
+struct HeapWalk {
+    char* hb;    // the heap array as bytes: node i at hb + 8 i
+    int K8, KR;  // 8 K; byte offset of the last aligned child pair that may be read (clamp of the read address)
+    float top;   // value at the root (wave-uniform)
+    int nin;     // operations started (wave-uniform); slot of the next one = nin & 7
+    // the operation slot of this lane (lanes 0..7; the other lanes stay idle): byte offset of its node (0 = idle),
+    // the value / payload it carries, the value it wrote last
+    int nb, pay;
+    float val, wv;
+
+    __device__ __forceinline__ void begin(uint2* h_, int K_) {
+        hb = reinterpret_cast<char*>(h_);
+        K8 = K_ * 8;
+        KR = (K_ & ~1) * 8;
+        top = __uint_as_float(h_[1].x);
+        nin = 0;
+        nb = 0;
+        pay = 0;
+        val = 0.f;
+        wv = 0.f;
+    }
+    // every operation in flight goes one level down (heap_replace_top's loop body, Heap.h:110-127); an idle lane
+    // reads the pair (h[0], h[1]) and writes the dump slot h[0]
+    __device__ __forceinline__ void tick() {
+        const int cb = nb << 1;                               // byte offset of the children pair (i1 = 2 i)
+        const uint4 c = *reinterpret_cast<const uint4*>(hb + min(cb, KR));
+        const float v1 = __uint_as_float(c.x), v2 = __uint_as_float(c.z);
+        const bool pick1 = !(cb < K8) || v1 > v2;             // i2 == k + 1 || cmp(val[i1], val[i2])
+        const float cv = pick1 ? v1 : v2;
+        const unsigned cp = pick1 ? c.y : c.w;
+        const bool stop = !(cb <= K8) || val > cv || nb == 0; // i1 > k, or cmp(val, child): the value stays here
+        wv = stop ? val : cv;
+        *reinterpret_cast<uint2*>(hb + nb) = make_uint2(__float_as_uint(wv), stop ? (unsigned)pay : cp);
+        nb = stop ? 0 : (pick1 ? cb : cb + 8);
+    }
+    // heap_replace_top(val, payload)
+    __device__ __forceinline__ void replace_top(float v, int p) {
+        const int slot = nin & 7;
+        const bool me = (int)(threadIdx.x & 63) == slot;
+        nb = me ? 8 : nb;
+        val = me ? v : val;
+        pay = me ? p : pay;
+        nin++;
+        tick();
+        top = hw_readlane_f(wv, slot);   // what the root holds now
+        tick();
+    }
+    // one block of <= 64 candidates in stream order, one per lane: `if (cmp(top, dis)) heap_replace_top`
+    // (dv: smaller is better; filtered entries carry +inf and never beat the top).  The top only ever decreases, so a
+    // candidate that has lost against it once need not be looked at again.
+    __device__ __forceinline__ void accept(bool ok, float dv, int p) {
+        unsigned long long m = __ballot(ok && top > dv);
+        while (m) {
+            const int l = (int)__ffsll((long long)m) - 1;
+            replace_top(hw_readlane_f(dv, l), hw_readlane_i(p, l));
+            m &= m - 1ull;
+            m &= __ballot(top > dv);
+        }
+    }
+    // let the operations in flight finish (a heap of K nodes has at most 32 - clz(K) levels)
+    __device__ __forceinline__ void drain() {
+        const int levels = 32 - __clz(K8 > 8 ? K8 >> 3 : 1);
+        for (int t = 0; t < levels; t++) tick();
+        __builtin_amdgcn_wave_barrier();
+    }
+};
+
+// ---- sequential forms, for the short phases (k-heap of compute_dis, heap_reorder).  Every lane of the calling
+//      wave executes the same accesses (LDS broadcast); values are pulled into SGPRs so that the branches are
+//      scalar. ----
+__device__ __forceinline__ float hs_f(unsigned x) { return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)x)); }
+__device__ __forceinline__ unsigned hs_u(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }
+
+// the sift of heap_pop / heap_replace_top over k nodes
+__device__ __forceinline__ void heap_sift_down_seq(uint2* h, int k, float val, unsigned pay) {
+    int i = 1;
+    for (;;) {
+        const int i1 = i << 1;
+        if (i1 > k) break;
+        const uint4 c = *reinterpret_cast<const uint4*>(h + i1);
+        const float v1 = hs_f(c.x), v2 = hs_f(c.z);
+        const bool pick1 = i1 == k || v1 > v2;
+        const float cv = pick1 ? v1 : v2;
+        if (val > cv) break;
+        h[i] = make_uint2(__float_as_uint(cv), pick1 ? hs_u(c.y) : hs_u(c.w));
+        i = pick1 ? i1 : i1 + 1;
+    }
+    h[i] = make_uint2(__float_as_uint(val), pay);
+}
+// heap_pop (Heap.h:46-72): the last element sifts down from the root; slot k keeps its stale copy
+__device__ __forceinline__ void heap_pop_seq(uint2* h, int k) {
+    const uint2 last = h[k];
+    heap_sift_down_seq(h, k, hs_f(last.x), hs_u(last.y));
+}
+// heap_push into slot k (Heap.h:77-100)
+__device__ __forceinline__ void heap_push_seq(uint2* h, int k, float val, unsigned pay) {
+    int i = k;
+    while (i > 1) {
+        const int f = i >> 1;
+        const uint2 pf = h[f];
+        if (!(val > hs_f(pf.x))) break;
+        h[i] = make_uint2(hs_u(pf.x), hs_u(pf.y));
+        i = f;
+    }
+    h[i] = make_uint2(__float_as_uint(val), pay);
+}
+// heap_reorder (Heap.h:300-330): sorted best first into h[1..k], (FLT_MAX, -1) padded; returns the number of real
+// entries (payload != -1)
+__device__ __forceinline__ int heap_reorder_seq(uint2* h, int k) {
+    int ii = 0;
+    for (int i = 0; i < k; i++) {
+        const uint2 r = h[1];
+        const float val = hs_f(r.x);
+        const unsigned idv = hs_u(r.y);
+        heap_pop_seq(h, k - i);
+        h[k - ii] = make_uint2(__float_as_uint(val), idv);   // 0-based slot k - ii - 1
+        if (idv != 0xffffffffu) ii++;
+    }
+    // memmove to the front, 64 entries per step (a step reads before it writes, and writes below what the next
+    // step reads: dst <= src), then the padding
+    const int lane = threadIdx.x & 63;
+    if (ii < k) {
+        for (int i0 = 0; i0 < ii; i0 += 64) {
+            const int i = i0 + lane;
+            uint2 t = make_uint2(0u, 0u);
+            if (i < ii) t = h[1 + k - ii + i];
+            if (i < ii) h[1 + i] = t;
+        }
+        for (int i = ii + lane; i < k; i += 64) h[1 + i] = make_uint2(__float_as_uint(kHeapFltMax), 0xffffffffu);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return ii;
+}
+
+}  // namespace gh

@@ -1,10 +1,20 @@
 // kernels.h -- launch wrappers of the gfx950 kernels in kernels.hip (internal to
 // libgamma_hip.so; the public surface is include/gamma_hip.h).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace gh {
+
+// once-per-device initialisation of a kernel attribute (hipFuncSetAttribute is per device; a process may hold handles
+// on several): true the first time the calling thread's current device comes by
+inline bool first_call_on_device(std::atomic<uint64_t>& done) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    return (done.fetch_or(bit) & bit) == 0;
+}
 
 constexpr int kMaxRange = 8;
 
@@ -162,15 +172,21 @@ int select_kpad(int K);
 // coarse quantizer selection (ties at the K-th distance resolved like the reference's heap); tie_flag: nq bytes
 // coarse.hip: coarse quantizer of a large batch without the distance matrix (sample -> bound -> filtered GEMM
 // epilogue -> merge; see the file header).  ws: pl.bytes of scratch.
-constexpr int kCoarseCap = 128, kCoarseRepairGrid = 64;
+constexpr int kCoarseCap = 128, kCoarseRepairGrid = 256;
 struct CoarseFusedPlan {
     int sample, nseg, tiles_per_strip, cap, cap_stride;
-    size_t off_mat, off_tau, off_cand, off_cnt, off_ovf, off_scratch, bytes;
+    size_t off_mat, off_tau, off_cand, off_cnt, off_ovf, off_scratch, off_full, bytes;
 };
-bool coarse_fused_supported(int nq, int d, int nlist, int P);
-CoarseFusedPlan coarse_fused_plan(int nq, int nlist, int P, int cap);
+bool coarse_fused_supported(int nq, int d, int nlist, int P, bool exact_ties = false);
+CoarseFusedPlan coarse_fused_plan(int nq, int nlist, int P, int cap, bool exact_ties = false);
+// rows[0] distance rows mat[i][0..nlist) of the queries rows[1 + i], each walked through faiss's result heap
+// (select.hip k_coarse_heap_fix): the K nearest in the reference's order, ties included
+void launch_coarse_heap_rows(hipStream_t s, const float* mat, int nlist, int nq, int K, const int* rows, float* out_vals,
+                             int* out_pos, unsigned long long* tie_stats);
 void launch_coarse_fused(hipStream_t s, const CoarseFusedPlan& pl, void* ws, const float* x, int nq, int d,
-                         const float* y, int nlist, const float* yn, int P, float* out_dis, int* out_idx);
+                         const float* y, int nlist, const float* yn, int P, float* out_dis, int* out_idx,
+                         bool exact_ties = false, unsigned long long* tie_stats = nullptr,
+                         hipStream_t side = nullptr, hipEvent_t fork = nullptr, hipEvent_t join = nullptr);
 // small batches: exact coarse distances [nq][nlist] + inner-product tables [nq][M][256] in one launch; false = shape
 // not covered (nq > 16), nothing launched
 bool launch_small_coarse_ip(hipStream_t s, const float* x, int nq, int d, const float* cc, int nlist, float* mat, int M,
@@ -182,13 +198,16 @@ void launch_small_coarse_select(hipStream_t s, const float* mat, int nlist, int 
                                 const int* list_len, const uint8_t* list_mask, const int64_t* list_off, int* pair_off,
                                 int* q_total, int64_t* pair_base, const float* x = nullptr, const float* cc = nullptr,
                                 int d = 0, float* pair_ip = nullptr, uint32_t* units = nullptr, int* unit_count = nullptr,
-                                int chunk_len = 0);
+                                int chunk_len = 0, int exact_ties = 0, unsigned long long* tie_stats = nullptr);
+struct TieReplayArgs;   // below
 void launch_small_tail(hipStream_t s, bool l2, const float* slab, int64_t q_stride, const int* q_total, int nq, int R, int P,
                        const int* probe_list, const int* pair_off, const int64_t* list_off, const int64_t* ids,
                        float* cand_dis, int* cand_pos, int64_t* cand_ids, int has_rank, const float* x, int d,
                        const float* raw, int64_t nraw, int k, float min_score, float max_score, float neutral,
                        float* distances, int64_t* labels, int smax = 0, float* pre_val = nullptr, int* pre_pos = nullptr,
-                       int fixed_n = 0);   // q_total == nullptr (flat search): every row has fixed_n entries, position = vector id
+                       int fixed_n = 0,    // q_total == nullptr (flat search): every row has fixed_n entries, position = vector id
+                       const TieReplayArgs* tr = nullptr,   // exact ties: a query with a tie at a cut is replayed in the kernel
+                       unsigned long long* tie_stats = nullptr);
 // IVFFLAT: exact distances of every entry of the probed lists (rows from the raw store) into the query's slab
 void launch_ivfflat_scan(hipStream_t s, bool l2, const float* x, int nq, int d, int P, const int* pair_off,
                          const int64_t* pair_base, const int64_t* ids, const float* raw, int64_t nraw, int64_t q_stride,
@@ -261,12 +280,17 @@ struct TieReplayArgs {
     int64_t* cand_ids;
     float* distances;             // [nq][k]
     int64_t* labels;
+    unsigned long long* dbg = nullptr;   // phase clocks of the first replayed query (GAMMA_HIP_TIE_DBG)
 };
 int tie_replay_max_k();
 int tie_replay_max_probes();
 void launch_tie_replay(hipStream_t s, bool l2, const TieReplayArgs& a);
 void launch_flag_cut_ties(hipStream_t s, const float* slab, int64_t q_stride, const int* q_total, int nq, int K,
-                          const float* sel_vals, const int* sel_pos, const uint8_t* only, uint8_t* tflag);
+                          const float* sel_vals, const int* sel_pos, const uint8_t* only, uint8_t* tflag,
+                          int fixed_n = 0, int inside = 0);   // q_total == nullptr: rows of fixed_n entries; inside: also
+                                                              // equal values among the selected K
+int coarse_heap_max_k();
+size_t tie_replay_lds_bytes(int R, int k, int P);
 void launch_finalize_topk(hipStream_t s, const float* sel_vals, const int* sel_pos, int nq, int k,
                           const int64_t* src_ids, int64_t src_stride, int64_t id_base,
                           float neutral, float* distances, int64_t* labels);

@@ -17,6 +17,7 @@
 // SMALLEST=true: K smallest (CMax heap, L2); false: K largest (CMin heap, IP).
 // Sentinels (+inf / -inf) mark filtered entries and come back as pos = -1.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -24,6 +25,8 @@
 #include <vector>
 
 #include "block_utils.h"
+#include "heap_dev.h"
+#include "tie_dev.h"
 #include "device_math.h"
 #include "kernels.h"
 
@@ -1274,118 +1277,88 @@ void launch_flat_final(hipStream_t s, bool l2, int nq, int k, const FlatEmit& em
 // heap_reorder -- so that the SAME tied lists are probed.  One wave per flagged row: the 64 lanes find
 // the next entry that beats the heap's top, lane 0 sifts it in.  ~1e-5 of the rows on fp32 data.
 // ------------------------------------------------------------------------------------
-// The heap lives in registers, node i (1-based) in lane i - 1: every index of the sift is wave-uniform, so
-// nodes are read with v_readlane and written with a lane-select move (a few cycles) instead of LDS round trips.
-// (the lane index is forced into an SGPR: with an index the compiler cannot prove uniform it would wrap every
-//  v_readlane in a waterfall loop, ~100 cycles each)
-__device__ __forceinline__ float rl_f(float v, int l) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_amdgcn_readfirstlane(l)));
-}
-__device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l)); }
-__device__ __forceinline__ void wl_f(float& v, int l, float x) { v = (int)(threadIdx.x & 63) == l ? x : v; }
-__device__ __forceinline__ void wl_i(int& v, int l, int x) { v = (int)(threadIdx.x & 63) == l ? x : v; }
+// The walk itself is heap_dev.h's HeapWalk: 64 candidates per ballot, accepted ones pipelined through an LDS heap.
+constexpr int CH_MAXK = 256;   // nprobe the coarse replay covers
 
-// 1-based sift of faiss's heap_pop / heap_replace_top (CMax: cmp(a, b) = a > b), heap of k nodes
-__device__ __forceinline__ void heap_sift_down(int k, float& hv, int& hi, float val, int id) {
-    int i = 1;
-    for (;;) {
-        const int i1 = i << 1, i2 = i1 + 1;
-        if (i1 > k) break;
-        const float v1 = rl_f(hv, i1 - 1);
-        const float v2 = i2 <= k ? rl_f(hv, i2 - 1) : 0.f;
-        if (i2 == k + 1 || v1 > v2) {
-            if (val > v1) break;
-            wl_f(hv, i - 1, v1);
-            wl_i(hi, i - 1, rl_i(hi, i1 - 1));
-            i = i1;
-        } else {
-            if (val > v2) break;
-            wl_f(hv, i - 1, v2);
-            wl_i(hi, i - 1, rl_i(hi, i2 - 1));
-            i = i2;
-        }
-    }
-    wl_f(hv, i - 1, val);
-    wl_i(hi, i - 1, id);
-}
+int coarse_heap_max_k() { return CH_MAXK; }
 
 __global__ __launch_bounds__(256) void k_coarse_heap_fix(const float* __restrict__ mat, int64_t ld, int n, int K,
                                                          int nq, const uint8_t* __restrict__ flag,
                                                          float* __restrict__ out_vals, int* __restrict__ out_pos,
-                                                         unsigned long long* __restrict__ tie_stats) {
+                                                         unsigned long long* __restrict__ tie_stats,
+                                                         const int* __restrict__ rows) {
+    // flag: row q of the matrix is query q, walked if flag[q]; rows: row i of the matrix is query rows[1 + i], rows[0] rows
+    __shared__ __attribute__((aligned(16))) uint2 s_h[4][CH_MAXK + 2];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int q = blockIdx.x * 4 + w;
-    if (q >= nq || !flag[q]) return;   // whole wave
+    const int ri = blockIdx.x * 4 + w;
+    if (ri >= nq) return;              // whole wave; no workgroup barrier below
+    int q = ri;
+    if (rows) {
+        if (ri >= rows[0]) return;
+        q = rows[1 + ri];
+    } else if (!flag[q]) {
+        return;
+    }
     if (tie_stats && lane == 0) atomicAdd(tie_stats, 1ull);
-    float hv = 3.402823466e+38f;       // heap_heapify: (FLT_MAX, -1) everywhere
-    int hi = -1;
-    const float* v = mat + (int64_t)q * ld;
-    // the whole row (n <= 4096) goes to LDS first, 16 loads in flight per lane: one global round trip per
-    // 64-entry block of the sequential walk below would cost more than the walk itself
-    __shared__ float s_row[4][64 * SW_NPL];
-    float* row = s_row[w];
-    for (int i0 = 0; i0 < n; i0 += 64 * 16) {
-        float t[16];
-#pragma unroll
-        for (int u = 0; u < 16; u++) t[u] = v[min(i0 + u * 64 + lane, n - 1)];
-#pragma unroll
-        for (int u = 0; u < 16; u++)
-            if (i0 + u * 64 + lane < n) row[i0 + u * 64 + lane] = t[u];
-    }
+    uint2* h = s_h[w];
+    heap_fill(h, K, lane, 64);         // heap_heapify: (FLT_MAX, -1) everywhere
     __builtin_amdgcn_wave_barrier();
-    float top = 3.402823466e+38f;
-    for (int j0 = 0; j0 < n; j0 += 64) {
-        const int j = j0 + lane;
-        const float dv = j < n ? row[j] : 3.402823466e+38f;
-        int from = 0;
-        for (;;) {
-            unsigned long long m = __ballot(j < n && top > dv);
-            m &= from >= 64 ? 0ull : (~0ull << from);
-            if (m == 0ull) break;
-            const int l = (int)__ffsll((long long)m) - 1;
-            heap_sift_down(K, hv, hi, rl_f(dv, l), j0 + l);
-            top = rl_f(hv, 0);
-            from = l + 1;
+    HeapWalk hw;
+    hw.begin(h, K);
+    const float* v = mat + (int64_t)ri * ld;
+    // sixteen 64-entry blocks of the row in flight ahead of the walk
+    float t[16], tn[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) t[u] = v[min(u * 64 + lane, n - 1)];
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) tn[u] = v[min(i0 + 1024 + u * 64 + lane, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int j = i0 + u * 64 + lane;
+            if (i0 + u * 64 < n) hw.accept(j < n, t[u], j);
         }
+#pragma unroll
+        for (int u = 0; u < 16; u++) t[u] = tn[u];
     }
-    // heap_reorder (faiss:utils/Heap.h:300-330), as written: K pops, real entries packed from the back
-    float ov = INFINITY;
-    int oi = -1;
-    int ii = 0;
-    for (int i = 0; i < K; i++) {
-        const float val = rl_f(hv, 0);
-        const int id = rl_i(hi, 0);
-        const int kk = K - i;
-        heap_sift_down(kk, hv, hi, rl_f(hv, kk - 1), rl_i(hi, kk - 1));   // heap_pop
-        wl_f(ov, K - ii - 1, val);
-        wl_i(oi, K - ii - 1, id);
-        if (id != -1) ii++;
-    }
-    // real entries sit in lanes [K - ii, K): move to the front, pad with (+inf, -1)
-    const float rv = __shfl(ov, min(lane + K - ii, 63), 64);
-    const int ri = __shfl(oi, min(lane + K - ii, 63), 64);
-    if (lane < K) {
-        out_vals[(int64_t)q * K + lane] = lane < ii ? rv : INFINITY;
-        out_pos[(int64_t)q * K + lane] = lane < ii ? ri : -1;
+    hw.drain();
+    heap_reorder_seq(h, K);            // faiss:impl/ResultHandler.h:112-117
+    for (int r = lane; r < K; r += 64) {
+        const uint2 e = h[1 + r];
+        out_vals[(int64_t)q * K + r] = (int)e.y < 0 ? INFINITY : __uint_as_float(e.x);
+        out_pos[(int64_t)q * K + r] = (int)e.y;
     }
 }
 
 // top-K nearest centroids of every row of the coarse distance matrix.  tie_flag != nullptr (nq bytes of
-// scratch; gamma_hip_set_exact_ties): with the reference's choice among entries tied at the K-th distance
-// (K <= 64, rows of <= 4096 entries; other shapes keep the (distance, index) order).  A flagged row is a
-// sequential walk of one wave, ~0.17 ms, and about 3 rows in 10^4 are flagged on fp32 data -- hence opt-in.
+// scratch; exact ties): a row with two equal keys among its K + 1 smallest -- which of them is probed, or in which
+// order their lists are scanned, is the doing of the reference's heap -- is redone by k_coarse_heap_fix
+// (K <= 256; beyond that faiss itself switches to its reservoir, faiss:utils/distances.cpp:341-358).
 void launch_coarse_select(hipStream_t s, const float* mat, int nlist, int nq, int K, float* out_vals, int* out_pos,
                           uint8_t* tie_flag, unsigned long long* tie_stats) {
     static const bool off = getenv("GAMMA_HIP_NO_WAVE_SELECT") != nullptr;
     if (nq <= 0) return;
-    if (off || !tie_flag || K > 64 || nlist > 64 * SW_NPL) {
+    if (!tie_flag || K > CH_MAXK) {
         launch_select_topk(s, true, mat, nlist, nullptr, nlist, nlist, nq, K, out_vals, out_pos);
         return;
     }
-    hipLaunchKernelGGL((k_select_wave<true, SW_NPL>), dim3((nq + 3) / 4), dim3(256), 0, s, mat, (int64_t)nlist, nullptr, nlist, nq,
-                       K, out_vals, out_pos, tie_flag);
+    if (!off && K <= 64 && nlist <= 64 * SW_NPL) {
+        hipLaunchKernelGGL((k_select_wave<true, SW_NPL>), dim3((nq + 3) / 4), dim3(256), 0, s, mat, (int64_t)nlist, nullptr, nlist,
+                           nq, K, out_vals, out_pos, tie_flag);
+    } else {
+        launch_select_topk(s, true, mat, nlist, nullptr, nlist, nlist, nq, K, out_vals, out_pos);
+        (void)hipMemsetAsync(tie_flag, 0, (size_t)nq, s);
+        launch_flag_cut_ties(s, mat, nlist, nullptr, nq, K, out_vals, out_pos, nullptr, tie_flag, nlist, 1);
+    }
     hipLaunchKernelGGL(k_coarse_heap_fix, dim3((nq + 3) / 4), dim3(256), 0, s, mat, (int64_t)nlist, nlist, K, nq, tie_flag,
-                       out_vals, out_pos, tie_stats);
+                       out_vals, out_pos, tie_stats, nullptr);
+}
+
+void launch_coarse_heap_rows(hipStream_t s, const float* mat, int nlist, int nq, int K, const int* rows, float* out_vals,
+                             int* out_pos, unsigned long long* tie_stats) {
+    if (nq <= 0 || K > CH_MAXK) return;
+    hipLaunchKernelGGL(k_coarse_heap_fix, dim3((nq + 3) / 4), dim3(256), 0, s, mat, (int64_t)nlist, nlist, K, nq, nullptr,
+                       out_vals, out_pos, tie_stats, rows);
 }
 
 int select_kpad(int K) {
@@ -1759,6 +1732,8 @@ struct SmallSelectArgs {
     uint32_t* units;   // long lists: the scan's work list, (q << 20 | probe << 13 | chunk) per chunk_len codes of a pair
     int* unit_count;   // zeroed by the launch before
     int chunk_len;
+    int exact_ties;    // rows with equal keys among the K + 1 smallest are redone through the reference's heap
+    unsigned long long* tie_stats;
 };
 __device__ __forceinline__ void small_coarse_select_body(int q, const SmallSelectArgs& A) {
     const float* __restrict__ mat = A.mat;
@@ -1778,7 +1753,56 @@ __device__ __forceinline__ void small_coarse_select_body(int q, const SmallSelec
     __shared__ int s_probe[128];
     const int tid = threadIdx.x, lane = tid & 63;
     const float* v = mat + (int64_t)q * nlist;
-    const int cnt = block_select_sorted<true, 4, 1>(v, nlist, K, s_it, s_hist, s_w, s_pick);   // trailing barrier inside
+    int cnt = block_select_sorted<true, 4, 1>(v, nlist, K, s_it, s_hist, s_w, s_pick);   // trailing barrier inside
+    if (A.exact_ties) {   // uniform
+        // two equal keys among the K + 1 smallest: which of them is probed, and in which order equal ones are scanned,
+        // is the doing of faiss's HeapResultHandler -- the row is walked the way it walks it (k_coarse_heap_fix)
+        __shared__ __attribute__((aligned(16))) uint2 s_heap[128 + 2];
+        __shared__ int s_nreal;
+        bool eq = false;
+        for (int r = tid; r + 1 < cnt; r += SM_NT) eq |= (uint32_t)(s_it[r] >> 32) == (uint32_t)(s_it[r + 1] >> 32);
+        int tie = __syncthreads_or(eq ? 1 : 0);
+        if (!tie && cnt == K && K < nlist) {
+            const uint32_t vk = (uint32_t)(s_it[K - 1] >> 32);
+            const int in_sel = __syncthreads_count(tid < cnt && (uint32_t)(s_it[min(tid, cnt - 1)] >> 32) == vk);
+            int in_all = 0;
+            for (int i0 = 0; i0 < nlist; i0 += SM_NT)
+                in_all += __syncthreads_count(i0 + tid < nlist && sel_key<true>(v[min(i0 + tid, nlist - 1)]) == vk);
+            tie = in_all > in_sel;
+        }
+        if (tie) {
+            heap_fill(s_heap, K, tid, SM_NT);
+            __syncthreads();
+            if (tid < 64) {
+                if (A.tie_stats && tid == 0) atomicAdd(A.tie_stats, 1ull);
+                HeapWalk hw;
+                hw.begin(s_heap, K);
+                float t[16], tn[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) t[u] = v[min(u * 64 + lane, nlist - 1)];
+                for (int i0 = 0; i0 < nlist; i0 += 1024) {
+#pragma unroll
+                    for (int u = 0; u < 16; u++) tn[u] = v[min(i0 + 1024 + u * 64 + lane, nlist - 1)];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) {
+                        const int j = i0 + u * 64 + lane;
+                        if (i0 + u * 64 < nlist) hw.accept(j < nlist, t[u], j);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; u++) t[u] = tn[u];
+                }
+                hw.drain();
+                const int nreal = heap_reorder_seq(s_heap, K);
+                for (int r = lane; r < K; r += 64) {
+                    const uint2 e = s_heap[1 + r];
+                    s_it[r] = (int)e.y < 0 ? ~0ull : (((unsigned long long)f2key(__uint_as_float(e.x)) << 32) | e.y);
+                }
+                if (lane == 0) s_nreal = nreal;
+            }
+            __syncthreads();
+            cnt = s_nreal;
+        }
+    }
     if (tid < 64) {   // cnt <= K <= 128: the first wave, 64 probes per round
         int run_off = 0;   // slab offset of the round's first probe
         for (int b0 = 0; b0 < K; b0 += 64) {   // uniform
@@ -1841,12 +1865,13 @@ __global__ __launch_bounds__(SM_NT) void k_small_coarse_select(SmallSelectArgs A
 void launch_small_coarse_select(hipStream_t s, const float* mat, int nlist, int nq, int P, float* out_vals, int* out_pos,
                                 const int* list_len, const uint8_t* list_mask, const int64_t* list_off, int* pair_off,
                                 int* q_total, int64_t* pair_base, const float* x, const float* cc, int d, float* pair_ip,
-                                uint32_t* units, int* unit_count, int chunk_len) {
+                                uint32_t* units, int* unit_count, int chunk_len, int exact_ties,
+                                unsigned long long* tie_stats) {
     if (nq <= 0) return;
     if (P > 128) abort();   // callers gate on this
     if (units && (nq > 4096 || chunk_len < 1)) abort();
     const SmallSelectArgs A{mat, nlist, P, out_vals, out_pos, list_len, list_mask, list_off, pair_off, q_total, pair_base,
-                            x, cc, d, pair_ip, units, unit_count, chunk_len};
+                            x, cc, d, pair_ip, units, unit_count, chunk_len, exact_ties, tie_stats};
     hipLaunchKernelGGL(k_small_coarse_select, dim3(nq), dim3(SM_NT), 0, s, A);
 }
 
@@ -1900,7 +1925,9 @@ __global__ __launch_bounds__(SM_NT) void k_small_tail(const float* __restrict__ 
                                                       float min_score, float max_score, float neutral,
                                                       float* __restrict__ distances, int64_t* __restrict__ labels,
                                                       const float* __restrict__ pre_val, const int* __restrict__ pre_pos,
-                                                      int smax, int fixed_n, unsigned long long* __restrict__ dbg) {
+                                                      int smax, int fixed_n, unsigned long long* __restrict__ dbg,
+                                                      int exact_ties, TieReplayArgs tr, unsigned long long* tie_stats) {
+    extern __shared__ __attribute__((aligned(16))) char s_tie_lds[];   // the replay's workspace (exact ties)
 #define GH_T(i) do { if (dbg && threadIdx.x == 0 && blockIdx.x == 0) dbg[i] = wall_clock64(); } while (0)
     __shared__ int s_hist[SM_BINS];
     __shared__ unsigned long long s_it[2 * SM_NT];
@@ -1929,6 +1956,23 @@ __global__ __launch_bounds__(SM_NT) void k_small_tail(const float* __restrict__ 
     }
     const int cnt = block_select_sorted<L2, 16, 2>(v, n, R, s_it, s_hist, s_w, s_pick);   // barriers inside
     GH_T(1);
+    // exact ties (ties.hip): does the top-R cut go through a group of equal ADC distances?  Counted over the whole
+    // slab row (a pre-selected slice may have dropped members of the group)
+    int tie = 0;
+    if (exact_ties && cnt == R) {   // uniform
+        const uint32_t vk = (uint32_t)(s_it[R - 1] >> 32);
+        if (vk != (L2 ? f2key(INFINITY) : ~f2key(-INFINITY))) {
+            int in_sel = 0;
+            for (int r0 = 0; r0 < R; r0 += SM_NT)
+                in_sel += __syncthreads_count(r0 + tid < R && (uint32_t)(s_it[min(r0 + tid, R - 1)] >> 32) == vk);
+            const float* v0 = slab + (int64_t)q * q_stride;
+            const int n0 = q_total[q];
+            int in_all = 0;
+            for (int i0 = 0; i0 < n0 && in_all <= in_sel; i0 += SM_NT)
+                in_all += __syncthreads_count(i0 + tid < n0 && sel_key<L2>(v0[min(i0 + tid, n0 - 1)]) == vk);
+            tie = in_all > in_sel;
+        }
+    }
     if (dbg && tid == 0 && q == 0) {
         dbg[6] = (unsigned long long)n;
         dbg[7] = (unsigned long long)s_pick[1];
@@ -1981,6 +2025,14 @@ __global__ __launch_bounds__(SM_NT) void k_small_tail(const float* __restrict__ 
         GH_T(3);
         block_rank_sort_sm(s_it, R, s_hist);
         GH_T(4);
+        if (exact_ties) {   // two of the first k + 1 exact distances equal (k_rerank_topk)
+            bool eq = false;
+            for (int i = tid; i < k && i + 1 < R; i += SM_NT) {
+                const uint32_t ka = (uint32_t)(s_it[i] >> 32), kb = (uint32_t)(s_it[i + 1] >> 32);
+                eq |= ka == kb && ka != (L2 ? f2key(sentinel) : ~f2key(sentinel));
+            }
+            tie |= __syncthreads_or(eq ? 1 : 0);
+        }
         for (int i = tid; i < k; i += SM_NT) {
             float val = neutral;
             int64_t id = -1;
@@ -2011,10 +2063,14 @@ __global__ __launch_bounds__(SM_NT) void k_small_tail(const float* __restrict__ 
             int tot;
             const int ex = block_excl_scan_sm(flag, s_w, tot);
             const int slot = running + ex;
+            bool eq = false;
             if (flag && slot < k) {
                 distances[(int64_t)q * k + slot] = dis;
                 labels[(int64_t)q * k + slot] = id;
+                // an entry that is taken and its successor at the same ADC distance (k_finalize_norank)
+                eq = r + 1 < R && s_id[r + 1] != -1 && s_val[r + 1] == dis;
             }
+            if (exact_ties) tie |= __syncthreads_or(eq ? 1 : 0);
             running += tot;
         }
         for (int i = min(running, k) + tid; i < k; i += SM_NT) {
@@ -2022,15 +2078,30 @@ __global__ __launch_bounds__(SM_NT) void k_small_tail(const float* __restrict__ 
             labels[(int64_t)q * k + i] = -1;
         }
     }
+    if (tie) {   // uniform: the query is redone the way the reference's heaps run it
+        if (tie_stats && tid == 0) atomicAdd(tie_stats + 2, 1ull);
+        tie_replay_query<L2, SM_NT, 2048>(tr, q, s_tie_lds, nullptr);
+    }
 }
 
 void launch_small_tail(hipStream_t s, bool l2, const float* slab, int64_t q_stride, const int* q_total, int nq, int R, int P,
                        const int* probe_list, const int* pair_off, const int64_t* list_off, const int64_t* ids,
                        float* cand_dis, int* cand_pos, int64_t* cand_ids, int has_rank, const float* x, int d,
                        const float* raw, int64_t nraw, int k, float min_score, float max_score, float neutral,
-                       float* distances, int64_t* labels, int smax, float* pre_val, int* pre_pos, int fixed_n) {
+                       float* distances, int64_t* labels, int smax, float* pre_val, int* pre_pos, int fixed_n,
+                       const TieReplayArgs* tr, unsigned long long* tie_stats) {
     if (nq <= 0) return;
     if (R > 1024) abort();   // callers gate on this
+    const int exact_ties = tr != nullptr && pair_off != nullptr ? 1 : 0;
+    const TieReplayArgs tra = exact_ties ? *tr : TieReplayArgs{};
+    const size_t lds = exact_ties ? tie_replay_lds_bytes_(R, k, P, 2048) : 0;
+    if (exact_ties) {   // static + dynamic LDS go beyond the default 64 KB for large recall_num
+        static std::atomic<uint64_t> done{0};
+        if (first_call_on_device(done)) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_tail<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_tail<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10);
+        }
+    }
     if (smax > 0) {
         if (l2)
             hipLaunchKernelGGL((k_small_presel<true>), dim3(nq, smax), dim3(SM_NT), 0, s, slab, q_stride, q_total, R, smax,
@@ -2052,13 +2123,15 @@ void launch_small_tail(hipStream_t s, bool l2, const float* slab, int64_t q_stri
         }
     }
     if (l2)
-        hipLaunchKernelGGL((k_small_tail<true>), dim3(nq), dim3(SM_NT), 0, s, slab, q_stride, q_total, R, P, probe_list,
+        hipLaunchKernelGGL((k_small_tail<true>), dim3(nq), dim3(SM_NT), lds, s, slab, q_stride, q_total, R, P, probe_list,
                            pair_off, list_off, ids, cand_dis, cand_pos, cand_ids, has_rank, x, d, raw, nraw, k, min_score,
-                           max_score, neutral, distances, labels, pre_val, pre_pos, smax, fixed_n, dbg);
+                           max_score, neutral, distances, labels, pre_val, pre_pos, smax, fixed_n, dbg, exact_ties, tra,
+                           tie_stats);
     else
-        hipLaunchKernelGGL((k_small_tail<false>), dim3(nq), dim3(SM_NT), 0, s, slab, q_stride, q_total, R, P, probe_list,
+        hipLaunchKernelGGL((k_small_tail<false>), dim3(nq), dim3(SM_NT), lds, s, slab, q_stride, q_total, R, P, probe_list,
                            pair_off, list_off, ids, cand_dis, cand_pos, cand_ids, has_rank, x, d, raw, nraw, k, min_score,
-                           max_score, neutral, distances, labels, pre_val, pre_pos, smax, fixed_n, dbg);
+                           max_score, neutral, distances, labels, pre_val, pre_pos, smax, fixed_n, dbg, exact_ties, tra,
+                           tie_stats);
 }
 
 }  // namespace gh

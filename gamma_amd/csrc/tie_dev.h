@@ -1,0 +1,268 @@
+// tie_dev.h -- one query replayed through the reference's heaps (device code shared by k_tie_replay, ties.hip, and the
+// small-batch chain's tail kernel, select.hip).  See ties.hip for what is replayed and why.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "block_utils.h"
+#include "device_math.h"
+#include "heap_dev.h"
+#include "kernels.h"
+#include "rerank_dev.h"
+
+namespace gh {
+
+constexpr int TR_MAXK = 1024;    // heap sizes the replay covers (recall_num and k)
+constexpr int TR_MAXP = 256;     // probes per query
+constexpr int TR_STAGE = 1024;   // survivor items sorted per round (= the scan's slice capacity)
+constexpr int TR_SLAB = 4096;    // candidates of the first probe group staged in LDS before the walk
+
+
+// dynamic LDS of one replayed query
+struct TieLds {
+    uint2* hR;                  // R-heap: (value, position in the query's slab), array order
+    uint2* hK;                  // k-heap: (exact distance, slot of the R-heap array)
+    int64_t* id;                // vector id of R-heap slot j
+    float* ex;                  // exact distance of slot j
+    float* slab;                // staged candidates
+    unsigned long long* it;     // sort buffer
+    int* off;                   // [P + 1]
+    int64_t* base;              // [P]
+};
+__host__ __device__ inline size_t tie_align16(size_t x) { return (x + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t tie_replay_lds_bytes_(int R, int k, int P, int slab = TR_SLAB) {
+    return tie_align16((size_t)(R + 2) * 8) + tie_align16((size_t)(k + 2) * 8) + tie_align16((size_t)R * 8) +
+           tie_align16((size_t)R * 4) + (size_t)slab * 4 + (size_t)TR_STAGE * 8 + tie_align16((size_t)(P + 1) * 4) +
+           tie_align16((size_t)P * 8);
+}
+__device__ __forceinline__ TieLds tie_carve(char* p, int R, int k, int P, int slab) {
+    TieLds L;
+    L.hR = reinterpret_cast<uint2*>(p);
+    p += tie_align16((size_t)(R + 2) * 8);
+    L.hK = reinterpret_cast<uint2*>(p);
+    p += tie_align16((size_t)(k + 2) * 8);
+    L.id = reinterpret_cast<int64_t*>(p);
+    p += tie_align16((size_t)R * 8);
+    L.ex = reinterpret_cast<float*>(p);
+    p += tie_align16((size_t)R * 4);
+    L.slab = reinterpret_cast<float*>(p);
+    p += (size_t)slab * 4;
+    L.it = reinterpret_cast<unsigned long long*>(p);
+    p += (size_t)TR_STAGE * 8;
+    L.off = reinterpret_cast<int*>(p);
+    p += tie_align16((size_t)(P + 1) * 4);
+    L.base = reinterpret_cast<int64_t*>(p);
+    return L;
+}
+
+// One query, replayed the way the reference runs it.  Called by all NT threads of a workgroup (NT a multiple
+// of 64, <= 1024); `lds` = tie_replay_lds_bytes_(R, k, P, SLAB) bytes, 16-byte aligned, free for this call.
+template <bool L2, int NT, int SLAB = TR_SLAB>
+__device__ __forceinline__ void tie_replay_query(const TieReplayArgs& a, int q, char* lds, unsigned long long* dbg) {
+#define GH_TT(i) do { if (dbg && threadIdx.x == 0) dbg[i] = wall_clock64(); } while (0)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int R = a.R, k = a.k, P = a.P;
+    const TieLds L = tie_carve(lds, R, k, P, SLAB);
+    __syncthreads();   // the LDS is free
+    GH_TT(0);
+    for (int i = tid; i <= P; i += NT) L.off[i] = a.pair_off[(int64_t)q * (P + 1) + i];
+    for (int i = tid; i < P; i += NT) L.base[i] = a.pair_base[(int64_t)q * P + i];
+    heap_fill(L.hR, R, tid, NT);   // heap_heapify: (neutral, -1)
+    if (a.has_rank) heap_fill(L.hK, k, tid, NT);
+    __syncthreads();
+    // ---- the candidate stream, in scan order ----
+    // bounded query (the scan published a bound and no slice overflowed): first probe group from the
+    // slab, the other groups from their survivor slices; otherwise the whole slab
+    bool sliced = false;
+    if (a.ready) {
+        sliced = (a.ready[q] >> 32) == 1ull;
+        for (int s = 0; s < a.nsl && sliced; s++)
+            if (a.gcnt[(int64_t)q * a.nsl + s] > a.slice_cap) sliced = false;   // uniform
+    }
+    const int ntot = L.off[P];
+    const int n_slab = sliced ? L.off[min(a.G, P)] : ntot;
+    const float* slab = a.slab + (int64_t)q * a.q_stride;
+    const bool staged = n_slab <= SLAB;
+    if (staged) {
+        for (int j = tid; j < n_slab; j += NT) L.slab[j] = L2 ? slab[j] : -slab[j];   // filtered entries: +inf
+        __syncthreads();
+    }
+    GH_TT(1);
+    HeapWalk w;
+    w.begin(L.hR, R);
+    if (wv == 0) {
+        if (staged) {
+            for (int j0 = 0; j0 < n_slab; j0 += 64) {
+                const int j = j0 + lane;
+                w.accept(j < n_slab, L.slab[min(j, n_slab - 1)], j);
+            }
+        } else {
+            // eight blocks of the slab in flight ahead of the walk
+            float t[8], tn[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) t[u] = slab[min(u * 64 + lane, n_slab - 1)];
+            for (int j0 = 0; j0 < n_slab; j0 += 512) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) tn[u] = slab[min(j0 + 512 + u * 64 + lane, n_slab - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int j = j0 + u * 64 + lane;
+                    if (j0 + u * 64 < n_slab) w.accept(j < n_slab, L2 ? t[u] : -t[u], j);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) t[u] = tn[u];
+            }
+        }
+    }
+    GH_TT(2);
+    if (sliced) {
+        // slices 1.. in order (slice s holds positions of probe group s only, so slices are ordered among
+        // themselves); several short slices share one sorting round
+        int s = 1;
+        while (s < a.nsl) {
+            __syncthreads();   // the sort buffer is free again
+            int n = 0, s_end = s;
+            while (s_end < a.nsl) {
+                const int c = a.gcnt[(int64_t)q * a.nsl + s_end];
+                if (n + c > TR_STAGE) break;
+                const unsigned long long* src = a.surv + ((int64_t)q * a.nsl + s_end) * a.slice_cap;
+                for (int i = tid; i < c; i += NT) {
+                    const unsigned long long it = src[i];   // (key << 32 | position)
+                    L.it[n + i] = (it << 32) | (it >> 32);  // -> (position << 32 | key)
+                }
+                n += c;
+                s_end++;
+            }
+            block_rank_sort<NT, TR_STAGE / NT>(L.it, n);   // positions are distinct
+            if (wv == 0) {
+                for (int j0 = 0; j0 < n; j0 += 64) {
+                    const unsigned long long it = L.it[min(j0 + lane, n - 1)];
+                    const uint32_t key = (uint32_t)it;
+                    const float val = key2f(L2 ? key : ~key);
+                    w.accept(j0 + lane < n, L2 ? val : -val, (int)(uint32_t)(it >> 32));
+                }
+            }
+            s = s_end;
+        }
+    }
+    if (wv == 0) w.drain();
+    __syncthreads();
+    GH_TT(3);
+    // ---- the R-heap is final: array order in hR[1..R].  Positions -> vector ids. ----
+    auto pos_to_id = [&](int ps) -> int64_t {
+        if (ps < 0) return -1;
+        int lo = 0, hi = P - 1;
+        while (lo < hi) {   // last p with off[p] <= ps
+            const int mid = (lo + hi + 1) >> 1;
+            if (L.off[mid] <= ps) lo = mid; else hi = mid - 1;
+        }
+        return a.ids[L.base[lo] + (ps - L.off[lo])] & 0x7fffffffffffffffLL;
+    };
+    for (int j = tid; j < R; j += NT) L.id[j] = pos_to_id((int)L.hR[1 + j].y);
+    __syncthreads();
+    float* od = a.distances + (int64_t)q * k;
+    int64_t* ol = a.labels + (int64_t)q * k;
+    if (a.has_rank) {
+        // exact distances in array order: 8 threads per candidate = the 8 AVX lane accumulators
+        // (same arithmetic as k_rerank_topk)
+        const int l8 = tid & 7, g = tid >> 3;
+        const float* xq = a.x + (int64_t)q * a.d;
+        for (int j0 = 0; j0 < R; j0 += NT / 8) {
+            const int j = j0 + g;
+            const int64_t id = j < R ? L.id[j] : -1;
+            const bool live = id >= 0 && id < a.nraw;
+            const float dis = rerank_dist8<L2>(xq, a.raw + (live ? id : 0) * a.d, a.d, l8, live);
+            if (l8 == 0 && j < R) {
+                const bool ok = live && dis <= a.max_score && dis >= a.min_score;   // IsSimilarScoreValid
+                L.ex[j] = ok ? (L2 ? dis : -dis) : INFINITY;   // +inf never beats the heap's top
+            }
+        }
+        __syncthreads();
+        GH_TT(4);
+        if (wv == 0) {
+            float top = kHeapFltMax;
+            for (int j0 = 0; j0 < R; j0 += 64) {
+                const int j = j0 + lane;
+                const float dv = j < R ? L.ex[j] : INFINITY;
+                unsigned long long m = __ballot(top > dv);
+                while (m) {
+                    const int l = (int)__ffsll((long long)m) - 1;
+                    const float val = hw_readlane_f(dv, l);
+                    heap_pop_seq(L.hK, k);   // heap_pop + heap_push (gamma_index_ivfpq.cc:664-676)
+                    heap_push_seq(L.hK, k, val, (unsigned)(j0 + l));
+                    top = hs_f(L.hK[1].x);
+                    const unsigned long long above = l >= 63 ? 0ull : (~0ull << (l + 1));
+                    m = __ballot(top > dv) & above;
+                }
+            }
+            heap_reorder_seq(L.hK, k);
+        }
+        __syncthreads();
+        GH_TT(5);
+        for (int i = tid; i < k; i += NT) {
+            const uint2 e = L.hK[1 + i];
+            const int j = (int)e.y;
+            const float v = __uint_as_float(e.x);
+            od[i] = j < 0 ? a.neutral : (L2 ? v : -v);
+            ol[i] = j < 0 ? -1 : L.id[j];
+        }
+        // the recall-stage table: the heap's entries, best first; equal distances in scan order (the order of the
+        // regular kernels' table -- the reference never sorts its R-heap on this path)
+        __syncthreads();
+        for (int j = tid; j < R; j += NT) {
+            const uint2 e = L.hR[1 + j];
+            // (empty slots: distinct items that sort last -- block_rank_sort needs pairwise distinct items)
+            L.it[j] = (int)e.y < 0 ? (0xffffffff80000000ull | (unsigned)j)
+                                   : (((unsigned long long)f2key(__uint_as_float(e.x)) << 32) | e.y);
+        }
+        block_rank_sort<NT, TR_MAXK / NT>(L.it, R);
+        for (int j = tid; j < R; j += NT) {
+            const unsigned long long it = L.it[j];
+            const bool empty = (uint32_t)(it >> 32) == 0xffffffffu;
+            const float v = key2f((uint32_t)(it >> 32));
+            a.cand_dis[(int64_t)q * R + j] = empty ? (L2 ? INFINITY : -INFINITY) : (L2 ? v : -v);
+            a.cand_ids[(int64_t)q * R + j] = empty ? -1 : pos_to_id((int)(uint32_t)it);
+        }
+        GH_TT(6);
+    } else {
+        // without rank: heap_reorder of the R-heap is the result (gamma_index_ivfpq.cc:681-696)
+        if (wv == 0) heap_reorder_seq(L.hR, R);
+        __syncthreads();
+        GH_TT(4);
+        for (int j = tid; j < R; j += NT) {
+            const uint2 e = L.hR[1 + j];
+            const int ps = (int)e.y;
+            const int64_t id = pos_to_id(ps);
+            const float v = __uint_as_float(e.x);
+            L.id[j] = id;
+            L.ex[j] = L2 ? v : -v;
+            a.cand_dis[(int64_t)q * R + j] = ps < 0 ? (L2 ? INFINITY : -INFINITY) : (L2 ? v : -v);
+            a.cand_ids[(int64_t)q * R + j] = id;
+        }
+        __syncthreads();
+        if (wv == 0) {
+            // first k entries inside the score window
+            int taken = 0;
+            for (int j0 = 0; j0 < R && taken < k; j0 += 64) {
+                const int j = j0 + lane;
+                const float dis = j < R ? L.ex[j] : 0.f;
+                const bool ok = j < R && L.id[j] >= 0 && dis <= a.max_score && dis >= a.min_score;
+                const unsigned long long bal = __ballot(ok);
+                const int slot = taken + __popcll(bal & ((1ull << lane) - 1ull));
+                if (ok && slot < k) {
+                    od[slot] = dis;
+                    ol[slot] = L.id[j];
+                }
+                taken += __popcll(bal);
+            }
+            for (int i = min(taken, k) + lane; i < k; i += 64) {
+                od[i] = a.neutral;
+                ol[i] = -1;
+            }
+        }
+        GH_TT(5);
+    }
+#undef GH_TT
+}
+
+}  // namespace gh
