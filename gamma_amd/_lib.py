@@ -38,7 +38,7 @@ class SearchParams(C.Structure):
                 ("has_rank", C.c_int32), ("min_score", C.c_float), ("max_score", C.c_float),
                 ("coarse_mode", C.c_int32), ("has_range", C.c_int32), ("n_range", C.c_int32),
                 ("range", C.POINTER(RangeFilter)), ("n_field", C.c_int32), ("n_term", C.c_int32),
-                ("field", C.POINTER(FieldFilter)), ("term", C.POINTER(TermFilter))]
+                ("field", C.POINTER(FieldFilter)), ("term", C.POINTER(TermFilter)), ("exact_ties", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/gamma_hip.h declares

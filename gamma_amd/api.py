@@ -42,7 +42,8 @@ class SearchArgs:
     """Builds a gamma_hip_search_params; keeps the filter buffers alive."""
 
     def __init__(self, metric=METRIC_L2, nprobe=1, recall_num=100, has_rank=True, min_score=None,
-                 max_score=None, coarse_mode=-1, range_filters=None, field_filters=None, term_filters=None):
+                 max_score=None, coarse_mode=-1, range_filters=None, field_filters=None, term_filters=None,
+                 exact_ties=0):
         """field_filters: list of (field_id, lower, upper, include_lower, include_upper) evaluated on
         the device against columns loaded with GammaHip.field_append.
         term_filters: list of (field_id, op, item ids) -- op 0 And / 1 Or / 2 Not -- against columns loaded with
@@ -56,6 +57,7 @@ class SearchArgs:
         p.min_score = FLT_TINY if min_score is None else min_score
         p.max_score = FLT_MAX if max_score is None else max_score
         p.coarse_mode = coarse_mode
+        p.exact_ties = exact_ties   # 0: the handle's setting (default on), 1: on, -1: off
         self._keep = []
         if range_filters is not None:
             p.has_range = 1

@@ -793,10 +793,22 @@ int compact_lists_for_call(H* h, FiltCtx* fc, int64_t est, bool allowed, ListCom
     return GAMMA_HIP_OK;
 }
 
+// a request's own exact-ties choice (gamma_hip_search_params.exact_ties) for the duration of its enqueue; the caller
+// holds the search lock
+struct TiesScope {
+    H* h;
+    bool saved;
+    TiesScope(H* h_, const gamma_hip_search_params* p) : h(h_), saved(h_->exact_ties) {
+        if (p && p->exact_ties != 0) h->exact_ties = p->exact_ties > 0;
+    }
+    ~TiesScope() { h->exact_ties = saved; }
+};
+
 // given != nullptr: the filter context of a combined batch (p's own filter clauses are ignored)
 int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, int k,
                                float* d_distances, int64_t* d_labels, const FiltCtx* given = nullptr) {
     GH_TRY(ivfpq_check(h, p, nq, k));
+    TiesScope ties_scope(h, p);
     if (k <= 0 || nq == 0) return GAMMA_HIP_OK;  // gamma_index_ivfpq.cc:753-756
     GH_CHECK(h, hipSetDevice(h->device));
     const int R = std::max(p->recall_num, k);
@@ -822,7 +834,7 @@ int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, c
     }
     ListCompaction restore(h);
     GH_TRY(compact_lists_for_call(h, &fc, (int64_t)nq * p->nprobe * (h->ntotal / std::max(1, h->nlist)),
-                                  !given && !h->exact_ties && !h->list_major, &restore));
+                                  !given && !h->list_major, &restore));
     const int chunk = scan_chunk(h, nq, p->nprobe), P = p->nprobe;
     // long lists (C4: 64 probes x lists of tens of thousands) make the ADC slab the limit: the coarse
     // quantizer then still runs over the whole call (one GEMM instead of one per slab chunk)
@@ -1310,7 +1322,8 @@ static void combine_worker(gamma_hip_index* h) {
         return a->kind == b->kind && a->k == b->k && a->mode == b->mode && a->p->metric == b->p->metric &&
                a->p->nprobe == b->p->nprobe &&
                a->p->recall_num == b->p->recall_num && a->p->has_rank == b->p->has_rank &&
-               a->p->min_score == b->p->min_score && a->p->max_score == b->p->max_score;
+               a->p->min_score == b->p->min_score && a->p->max_score == b->p->max_score &&
+               a->p->exact_ties == b->p->exact_ties;
     };
     // a batch in flight: its requests, where its results land, whether the stream still has to be awaited
     struct Batch {

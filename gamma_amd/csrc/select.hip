@@ -1605,11 +1605,15 @@ __device__ __forceinline__ int block_select_items(const float* __restrict__ v, i
 // and rank-sorted.  Only when that bin is crowded (mass ties) does block_select_items refine it pass by pass.
 template <bool SMALLEST, int NREG, int MAXI>
 __device__ __forceinline__ int block_select_sorted(const float* __restrict__ v, int n, int K, unsigned long long* s_it,
-                                                   int* s_hist, int* s_w, uint32_t* s_pick) {
+                                                   int* s_hist, int* s_w, uint32_t* s_pick, int* n_sorted = nullptr) {
+    // n_sorted: how many sorted items s_it holds -- K plus whatever else shared the K-th item's bin (so s_it[K], if
+    // there, is the (K+1)-th smallest: exact ties look at it); -1: only K, and whether the cut went through a group of
+    // equal keys is not known here (crowded bin)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (n <= K) {
         for (int i = tid; i < n; i += SM_NT) s_it[i] = ((unsigned long long)sel_key<SMALLEST>(v[i]) << 32) | (unsigned)i;
         block_rank_sort_sm(s_it, n, s_hist);
+        if (n_sorted) *n_sorted = n;
         return n;
     }
     const bool inreg = n <= NREG * SM_NT;   // uniform
@@ -1688,8 +1692,10 @@ __device__ __forceinline__ int block_select_sorted(const float* __restrict__ v, 
         __syncthreads();
         block_select_items<SMALLEST>(v, n, K, s_it, s_hist, s_w, s_pick);
         block_rank_sort_sm(s_it, K, s_hist);
+        if (n_sorted) *n_sorted = -1;
         return K;
     }
+    if (n_sorted) *n_sorted = T;
     auto append = [&](uint32_t key, int i, bool live) {
         const bool take = live && bin_of(key) <= b;
         const unsigned long long mask = __ballot(take);
@@ -1753,23 +1759,19 @@ __device__ __forceinline__ void small_coarse_select_body(int q, const SmallSelec
     __shared__ int s_probe[128];
     const int tid = threadIdx.x, lane = tid & 63;
     const float* v = mat + (int64_t)q * nlist;
-    int cnt = block_select_sorted<true, 4, 1>(v, nlist, K, s_it, s_hist, s_w, s_pick);   // trailing barrier inside
+    int nsorted = 0;
+    int cnt = block_select_sorted<true, 4, 1>(v, nlist, K, s_it, s_hist, s_w, s_pick, &nsorted);   // trailing barrier inside
     if (A.exact_ties) {   // uniform
         // two equal keys among the K + 1 smallest: which of them is probed, and in which order equal ones are scanned,
         // is the doing of faiss's HeapResultHandler -- the row is walked the way it walks it (k_coarse_heap_fix)
         __shared__ __attribute__((aligned(16))) uint2 s_heap[128 + 2];
         __shared__ int s_nreal;
+        // (the selection leaves the (K+1)-th smallest item behind the K-th whenever it shares its histogram bin; from
+        //  another bin it cannot carry the same key)
         bool eq = false;
-        for (int r = tid; r + 1 < cnt; r += SM_NT) eq |= (uint32_t)(s_it[r] >> 32) == (uint32_t)(s_it[r + 1] >> 32);
-        int tie = __syncthreads_or(eq ? 1 : 0);
-        if (!tie && cnt == K && K < nlist) {
-            const uint32_t vk = (uint32_t)(s_it[K - 1] >> 32);
-            const int in_sel = __syncthreads_count(tid < cnt && (uint32_t)(s_it[min(tid, cnt - 1)] >> 32) == vk);
-            int in_all = 0;
-            for (int i0 = 0; i0 < nlist; i0 += SM_NT)
-                in_all += __syncthreads_count(i0 + tid < nlist && sel_key<true>(v[min(i0 + tid, nlist - 1)]) == vk);
-            tie = in_all > in_sel;
-        }
+        const int have = nsorted < 0 ? cnt : min(nsorted, K + 1);
+        for (int r = tid; r + 1 < have; r += SM_NT) eq |= (uint32_t)(s_it[r] >> 32) == (uint32_t)(s_it[r + 1] >> 32);
+        int tie = __syncthreads_or((eq || nsorted < 0) ? 1 : 0);
         if (tie) {
             heap_fill(s_heap, K, tid, SM_NT);
             __syncthreads();
@@ -1954,7 +1956,8 @@ __global__ __launch_bounds__(SM_NT) void k_small_tail(const float* __restrict__ 
         const int l = probe_list[(int64_t)q * P + tid];
         s_lbase[tid] = l >= 0 ? list_off[l] : 0;
     }
-    const int cnt = block_select_sorted<L2, 16, 2>(v, n, R, s_it, s_hist, s_w, s_pick);   // barriers inside
+    int nsorted = 0;
+    const int cnt = block_select_sorted<L2, 16, 2>(v, n, R, s_it, s_hist, s_w, s_pick, &nsorted);   // barriers inside
     GH_T(1);
     // exact ties (ties.hip): does the top-R cut go through a group of equal ADC distances?  Counted over the whole
     // slab row (a pre-selected slice may have dropped members of the group)
@@ -1962,15 +1965,23 @@ __global__ __launch_bounds__(SM_NT) void k_small_tail(const float* __restrict__ 
     if (exact_ties && cnt == R) {   // uniform
         const uint32_t vk = (uint32_t)(s_it[R - 1] >> 32);
         if (vk != (L2 ? f2key(INFINITY) : ~f2key(-INFINITY))) {
-            int in_sel = 0;
-            for (int r0 = 0; r0 < R; r0 += SM_NT)
-                in_sel += __syncthreads_count(r0 + tid < R && (uint32_t)(s_it[min(r0 + tid, R - 1)] >> 32) == vk);
-            const float* v0 = slab + (int64_t)q * q_stride;
-            const int n0 = q_total[q];
-            int in_all = 0;
-            for (int i0 = 0; i0 < n0 && in_all <= in_sel; i0 += SM_NT)
-                in_all += __syncthreads_count(i0 + tid < n0 && sel_key<L2>(v0[min(i0 + tid, n0 - 1)]) == vk);
-            tie = in_all > in_sel;
+            if (smax == 0 && nsorted >= 0) {
+                // the (R+1)-th smallest item is behind the R-th whenever it shares its histogram bin; from another bin it
+                // cannot carry the same key
+                tie = nsorted > R && (uint32_t)(s_it[R] >> 32) == vk;
+            } else {
+                // crowded bin, or a pre-selected row (a slice may have dropped members of the group): count the key
+                // over the whole slab row
+                int in_sel = 0;
+                for (int r0 = 0; r0 < R; r0 += SM_NT)
+                    in_sel += __syncthreads_count(r0 + tid < R && (uint32_t)(s_it[min(r0 + tid, R - 1)] >> 32) == vk);
+                const float* v0 = slab + (int64_t)q * q_stride;
+                const int n0 = q_total[q];
+                int loc = 0, in_all;
+                for (int i = tid; i < n0; i += SM_NT) loc += sel_key<L2>(v0[i]) == vk ? 1 : 0;
+                (void)block_excl_scan_sm(min(loc, 2048), s_w, in_all);
+                tie = in_all > in_sel;
+            }
         }
     }
     if (dbg && tid == 0 && q == 0) {

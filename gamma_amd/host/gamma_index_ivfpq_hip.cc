@@ -60,6 +60,7 @@ int HIPIVFPQModelParams::Parse(const char *str) {
   }
   if (!jp.GetInt("support_indivisible_nsubvector", v)) support_indivisible_nsubvector = v != 0;
   if (!jp.GetInt("device_filters", v)) device_filters = v != 0;
+  if (!jp.GetInt("exact_ties", v)) exact_ties = v != 0;
   if (!jp.GetInt("bucket_init_size", v)) {
     if (v < -1) return -1;
     if (v > 0) bucket_init_size = v;
@@ -123,6 +124,7 @@ int GammaIVFPQHIPIndex::Init(const std::string &model_parameters, int indexing_s
                             metric_type_ == DistanceComputeType::L2 ? GAMMA_HIP_METRIC_L2 : GAMMA_HIP_METRIC_IP,
                             pa.bucket_init_size, pa.bucket_max_size);
   if (!rc) rc = gamma_hip_raw_init(h_, d_);
+  if (!rc) rc = gamma_hip_set_exact_ties(h_, pa.exact_ties ? 1 : 0);
   if (rc) {
     HLOG("device init failed: %s (%s)", gamma_hip_strerror(rc), gamma_hip_last_error(h_));
     return -1;
@@ -149,6 +151,7 @@ RetrievalParameters *GammaIVFPQHIPIndex::Parse(const std::string &parameters) {
   if (!jp.GetInt("recall_num", v) && v > 0) rp->SetRecallNum(v);
   if (!jp.GetInt("nprobe", v) && v > 0) rp->SetNprobe(v);
   if (!jp.GetInt("parallel_on_queries", v)) rp->SetParallelOnQueries(v != 0);
+  if (!jp.GetInt("exact_ties", v)) rp->SetExactTies(v != 0 ? 1 : -1);   // HIP only: this request's choice
   return rp;
 }
 
@@ -324,6 +327,7 @@ int GammaIVFPQHIPIndex::Search(RetrievalContext *retrieval_context, int n, const
   p.min_score = cond ? cond->min_score : std::numeric_limits<float>::min();
   p.max_score = cond ? cond->max_score : std::numeric_limits<float>::max();
   p.coarse_mode = -1;
+  p.exact_ties = rp->ExactTies();
   std::vector<gamma_hip_range_filter> rf;
   std::vector<gamma_hip_field_filter> ff;
   std::vector<gamma_hip_term_filter> tf;

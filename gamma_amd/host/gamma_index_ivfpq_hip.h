@@ -21,20 +21,24 @@ namespace tig_gamma {
 
 class HIPIVFPQRetrievalParameters : public RetrievalParameters {
  public:
-  HIPIVFPQRetrievalParameters() : RetrievalParameters(), parallel_on_queries_(true), recall_num_(100), nprobe_(-1) {}
+  HIPIVFPQRetrievalParameters() : RetrievalParameters(), parallel_on_queries_(true), recall_num_(100), nprobe_(-1), exact_ties_(0) {}
   HIPIVFPQRetrievalParameters(enum DistanceComputeType type)
-      : RetrievalParameters(type), parallel_on_queries_(true), recall_num_(100), nprobe_(-1) {}
+      : RetrievalParameters(type), parallel_on_queries_(true), recall_num_(100), nprobe_(-1), exact_ties_(0) {}
   int RecallNum() { return recall_num_; }
   void SetRecallNum(int recall_num) { recall_num_ = recall_num; }
   int Nprobe() { return nprobe_; }
   void SetNprobe(int nprobe) { nprobe_ = nprobe; }
   bool ParallelOnQueries() { return parallel_on_queries_; }
   void SetParallelOnQueries(bool p) { parallel_on_queries_ = p; }
+  // HIP only ("exact_ties" in the request's retrieval parameters): 0 = the model's setting, 1 = on, -1 = off
+  int ExactTies() { return exact_ties_; }
+  void SetExactTies(int v) { exact_ties_ = v; }
 
  protected:
   bool parallel_on_queries_;   // accepted for compatibility; the device path is always batched
   int recall_num_;
   int nprobe_;
+  int exact_ties_;
 };
 
 struct HIPIVFPQModelParams {
@@ -49,6 +53,7 @@ struct HIPIVFPQModelParams {
   int bucket_init_size = 1000;
   int bucket_max_size = 1280000;
   bool device_filters = false;   // HIP only: evaluate range / term filters on device-resident columns (filter_bridge.h)
+  bool exact_ties = true;        // HIP only: the reference's heap order inside exact distance ties (gamma_hip_set_exact_ties)
   int Parse(const char *str);   // 0 ok, -1 bad (same rules as gamma_index_ivfpq.h:708-851)
 };
 

@@ -105,6 +105,8 @@ typedef struct {
     int32_t n_term;       /* GammaSearchCondition::term_filters evaluated on device columns */
     const gamma_hip_field_filter* field;
     const gamma_hip_term_filter* term;
+    int32_t exact_ties;   /* the reference's heap order inside exact distance ties (gamma_hip_set_exact_ties) for this
+                             request: 0 = the handle's setting (default on), 1 = on, -1 = off */
 } gamma_hip_search_params;
 
 /* ---- lifecycle ------------------------------------------------------------------- */
@@ -121,17 +123,20 @@ int gamma_hip_synchronize(gamma_hip_index* h);
 /* Upper bound in bytes of the per-chunk workspaces (coarse distance matrix, ADC distance buffer);
  * larger calls are processed in chunks of queries.  Default: an eighth of the device memory, 1 to 32 GiB. */
 int gamma_hip_set_workspace_budget(gamma_hip_index* h, int64_t bytes);
-/* Exact distance ties.  By default a top-k here is "the k smallest (distance, scan position) pairs".  The
- * reference keeps candidates in faiss binary heaps (faiss:utils/Heap.h:46-131): WHICH of several candidates at
- * exactly the same fp32 distance survive a cut, and the order equal distances come out in, is what the heap's
- * sift order leaves -- at the nprobe cut of the coarse quantizer (HeapResultHandler,
+/* Exact distance ties.  The reference keeps candidates in faiss binary heaps (faiss:utils/Heap.h:46-131): WHICH of
+ * several candidates at exactly the same fp32 distance survive a cut, and the order equal distances come out in,
+ * is what the heap's sift order leaves -- at the nprobe cut of the coarse quantizer (HeapResultHandler,
  * faiss:impl/ResultHandler.h:112-117), at the recall_num cut of the list scan (KnnSearchResults::add,
  * index/impl/gamma_index_ivfpq.h:363-369) and in compute_dis, which feeds the k-heap in the ARRAY order of the
- * unsorted recall heap (index/impl/gamma_index_ivfpq.cc:646-680).  on != 0: rows / queries in which such a tie
- * can change the result are detected by the regular kernels and redone by replaying the reference's heaps
- * (csrc/ties.hip), so labels and ranks are the reference's, ties included.  Covers single-GPU IVFPQ search with
- * nprobe <= 64 on <= 4096 lists for the coarse cut, recall_num <= 256 and nprobe <= 256 otherwise; other shapes
- * and the sharded search keep the (distance, position) order. */
+ * unsorted recall heap (index/impl/gamma_index_ivfpq.cc:646-680).  on != 0 (the DEFAULT): rows / queries in which
+ * such a tie can change the result are detected by the regular kernels and redone by replaying the reference's heaps
+ * (csrc/ties.hip, csrc/heap_dev.h), so labels and ranks are the reference's, ties included.  on == 0: a top-k is "the
+ * k smallest (distance, scan position) pairs" -- the same distances at every rank, the same ids up to the order /
+ * membership inside groups of exactly equal distances, and no replay cost (a few queries in a thousand on integer
+ * data, none to speak of on real-valued data).  Per request: gamma_hip_search_params.exact_ties.
+ * Covers IVFPQ search on one handle, every batch size: nprobe <= 256 (beyond 100 probes faiss itself selects
+ * through its reservoir, whose order inside ties is not reproduced), recall_num <= 1024; other shapes, IVFFLAT /
+ * flat search and the sharded merge keep the (distance, position) order inside ties. */
 int gamma_hip_set_exact_ties(gamma_hip_index* h, int on);
 /* Experimental scan schedule for large batches (csrc/scan_lm.hip): the probes behind a query's first group are
  * scored list-major, two queries per pass over a list.  Same results; slower than the default at C3-sized

@@ -323,6 +323,11 @@ def main():
         R.ref_set_blas_threshold(1 << 30)
         gen_ivfpq_ties(R, "ivfpq_ties_d32", 32, 16, 8, 1500, 6000, 48, 6, 60, 10)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "ties_c4":   # the C4 shape's cuts: > 4096 lists, 64 probes, recall_num 100
+        R = B.ref()
+        R.ref_set_blas_threshold(1 << 30)
+        gen_ivfpq_ties(R, "ivfpq_ties_c4shape", 32, 4160, 8, 12000, 24000, 32, 64, 100, 10)
+        return
     if not B.have_ref():
         raise SystemExit("oracle/_ref/libgamma_ref.so missing: run make -f oracle/Makefile.ref")
     os.makedirs(OUT, exist_ok=True)
@@ -334,6 +339,7 @@ def main():
     gen_ivfpq(R, "ivfpq_l2_d64", 64, 32, 8, 6000, 40, B.METRIC_L2, 8, 100)       # dsub 8
     gen_ivfpq(R, "ivfpq_ip_d48", 48, 16, 4, 4000, 30, B.METRIC_IP, 4, 50, True)  # dsub 12
     gen_ivfpq_ties(R, "ivfpq_ties_d32", 32, 16, 8, 1500, 6000, 48, 6, 60, 10)
+    gen_ivfpq_ties(R, "ivfpq_ties_c4shape", 32, 4160, 8, 12000, 24000, 32, 64, 100, 10)
     gen_realtime()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -476,7 +476,8 @@ def test_c3_properties(c3):
     assert rec >= 0.95, rec
 
 
-def test_c3_sampled_oracle_parity(c3):
+@pytest.fixture(scope="module")
+def c3_oracle(c3):
     g = c3["g"]
     o = B.OracleIVFPQ(c3["d"], c3["nlist"], c3["M"], 8, B.METRIC_L2, bucket_init_size=4000)
     o.set_trained(c3["cc"], c3["pq"], g.ivfpq_table())
@@ -485,6 +486,11 @@ def test_c3_sampled_oracle_parity(c3):
         if len(ids):
             o.add_keys(l, ids, codes)
     o.set_raw(c3["base"])
+    return o
+
+
+def test_c3_sampled_oracle_parity(c3, c3_oracle):
+    g, o = c3["g"], c3_oracle
     q = synth.sift_like(96, d=128, seed=999)
     case = dict(oracle=o)
     for has_rank, cm in ((True, 1), (False, 1), (True, 0)):
@@ -493,6 +499,39 @@ def test_c3_sampled_oracle_parity(c3):
         sg = g.last_stages(len(q), 32, 200)
         assert sg["coarse_dis"].tobytes() == st["coarse_dis"].tobytes()
         compare_topk(D, I, Dg, Ig)
+
+
+def test_c3_headline_call_matches_oracle(c3, c3_oracle):
+    """The call bench.py times, pinned: ONE 16384-query Search on the C3 index (nprobe 32, recall_num 200, k 10), i.e.
+    the matrix-free GEMM-form coarse quantizer (k_coarse_fused + the heap replay of its tied rows), the bounded scan
+    with eight probes per workgroup, k_select_final, k_rerank_topk and the tie replay.  A sample of the batch --
+    every 67th query plus queries whose result holds equal distances -- against the oracle: coarse assignment byte
+    for byte, recall-stage tables, and the final labels at EVERY rank (exact ties are the default; the oracle's
+    heaps are pinned against the compiled faiss, tests/test_oracle_golden.py)."""
+    from tests.parity import compare_exact
+    g, o = c3["g"], c3_oracle
+    nq, P, R, k = 16384, 32, 200, 10
+    q = synth.sift_like(nq, d=128, seed=4321)
+    ctx = B.make_ctx(min_score=0.0, max_score=1e30)
+    for has_rank in (True, False):
+        args = api.SearchArgs(metric=api.METRIC_L2, nprobe=P, recall_num=R, has_rank=has_rank, min_score=0.0,
+                              max_score=1e30, coarse_mode=-1)
+        g.tie_stats(reset=True)
+        Dg, Ig = g.ivfpq_search(q, k, args)
+        ts = g.tie_stats()
+        sg = g.last_stages(nq, P, R)
+        tied = np.nonzero((np.diff(Dg, axis=1) == 0).any(axis=1))[0]
+        rows = np.unique(np.concatenate([np.arange(0, nq, 67), tied[:80]]))
+        D, I, st = o.search(q[rows], k, P, recall_num=R, has_rank=has_rank, metric=B.METRIC_L2, ctx=ctx, coarse_mode=1,
+                            want_stages=True)
+        assert sg["coarse_dis"][rows].tobytes() == st["coarse_dis"].tobytes()
+        assert np.array_equal(sg["coarse_idx"][rows], st["coarse_idx"])
+        sub = dict(recall_dis=sg["recall_dis"][rows], recall_ids=sg["recall_ids"][rows])
+        assert compare_search(D, I, st, Dg[rows], Ig[rows], sub) == 0
+        compare_exact(D, I, Dg[rows], Ig[rows])
+        assert ts["coarse_rows"] > 0 and ts["replayed"] > 0   # the sample really went through the replays
+        if has_rank:
+            assert len(tied) > 0
 
 
 def test_c2_flat_full_size(c3):

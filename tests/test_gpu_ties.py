@@ -31,11 +31,14 @@ def _device_for(z, tag, base, metric):
     return g
 
 
+@pytest.mark.parametrize("name", ["ivfpq_ties_d32", "ivfpq_ties_c4shape"])
 @pytest.mark.parametrize("tag", ["l2", "ip"])
-def test_tie_heavy_golden_on_device(tag):
+def test_tie_heavy_golden_on_device(tag, name):
     """tests/golden/ivfpq_ties_d32.npz: most queries have equal ADC distances across the recall_num cut and
-    equal exact distances across the k cut.  Small call: the unfiltered selection path flags, the replay redoes."""
-    z, o, base, metric = load_ties(tag)
+    equal exact distances across the k cut.  Small call: the small-batch chain flags and replays inside its
+    kernels.  ivfpq_ties_c4shape.npz: the same with the cuts of the C4 configuration -- 4160 lists (rows of the
+    coarse matrix longer than the wave selection's chunk: the generic tie flags), 64 probes, recall_num 100."""
+    z, o, base, metric = load_ties(tag, name)
     nprobe, R, k = int(z["nprobe"]), int(z["R"]), int(z["k"])
     g = _device_for(z, tag, base, metric)
     try:
@@ -49,6 +52,10 @@ def test_tie_heavy_golden_on_device(tag):
             compare_exact(z["D_%s_%s" % (nm, tag)], z["I_%s_%s" % (nm, tag)], Dg, Ig)
             st = g.tie_stats()
             assert st["replayed"] >= int(z["ncut_" + tag][0])
+            g.set_small_path(0)   # the same call through the regular chain (matrix coarse path, k_tie_replay)
+            Dg2, Ig2 = g.ivfpq_search(z["q"], k, args)
+            g.set_small_path(1)
+            compare_exact(z["D_%s_%s" % (nm, tag)], z["I_%s_%s" % (nm, tag)], Dg2, Ig2)
             if not has_rank:     # the replay leaves the recall-stage table in heap_reorder order
                 rows = np.array([i for i in range(len(z["q"]))])
                 compare_exact(z["rdis_" + tag][rows], z["rids_" + tag][rows], sg["recall_dis"][rows],
@@ -114,5 +121,70 @@ def test_ties_with_filters_and_score_window():
                 for qq, rep in ((z["q"], 1), (q, 12)):
                     Dg, Ig = g.ivfpq_search(qq, k, args)
                     compare_exact(np.tile(D, (rep, 1)), np.tile(I, (rep, 1)), Dg, Ig)
+    finally:
+        g.close()
+
+
+def test_plugin_exact_ties_keys():
+    """Through the RetrievalModel boundary: exact ties are the model's default, `"exact_ties": 0` in the model's
+    retrieval_param or in a request's retrieval parameters (Parse) turns them off for the index / that request."""
+    from gamma_amd import plugin
+    z, _, base, metric = load_ties("l2")
+    d, nlist, M = int(z["d"]), int(z["nlist"]), int(z["M"])
+    nprobe, R, k = int(z["nprobe"]), int(z["R"]), int(z["k"])
+    q = np.tile(z["q"], (3, 1))                       # 3 x the golden queries: >= 20 -> GEMM-form coarse on both sides
+    o = B.OracleIVFPQ(d, nlist, M, 8, metric)
+    o.set_trained(z["cc_l2"], z["pq_l2"], None)
+    B.lib().go_set_assign_mode(1)                     # GammaIVFPQIndex::Add of >= 20 vectors: faiss's BLAS assign rule
+    try:
+        assert o.add(base)
+    finally:
+        B.lib().go_set_assign_mode(0)
+    o.set_raw(base)
+    D, I = o.search(q, k, nprobe, recall_num=R, has_rank=True, metric=metric, ctx=B.make_ctx(), coarse_mode=-1)
+    req = '{"metric_type": "L2", "recall_num": %d, "nprobe": %d%s}'
+    model = '{"ncentroids": %d, "nsubvector": %d, "nprobe": %d, "metric_type": "L2"%s}'
+    for model_extra, req_extra, exact in (("", "", True), ("", ', "exact_ties": 0', False),
+                                          (', "exact_ties": 0', "", False), (', "exact_ties": 0', ', "exact_ties": 1', True)):
+        m = plugin.PluginModel("HIPIVFPQ", d, model % (nlist, M, nprobe, model_extra), indexing_size=len(base))
+        try:
+            m.store(base)
+            assert m.set_trained(z["cc_l2"], z["pq_l2"]) == 0
+            assert m.add(base)
+            Dg, Ig = m.search(q, k, req % (R, nprobe, req_extra), has_rank=True)
+            if exact:
+                compare_exact(D, I, Dg, Ig)
+            else:
+                # (distances agree up to the members of cut ties; the labels of this tie-heavy data do not)
+                assert not np.array_equal(Ig, I)
+        finally:
+            m.close()
+
+
+@pytest.mark.parametrize("tag", ["l2", "ip"])
+def test_c4_shape_ties_at_batch_size(tag):
+    """The C4-shaped tie-heavy index at a batch size that takes the matrix-free coarse quantizer (>= 4096 queries,
+    GEMM form, 4160 lists, 64 probes: k_coarse_fused -> k_coarse_final flags rows with equal keys near the cut -> their
+    rows recomputed by the MFMA chain and walked through faiss's result heap) and the bounded scan + k_tie_replay.
+    Expected: the pinned oracle with the GEMM-form coarse distances, labels strictly."""
+    z, o, base, metric = load_ties(tag, "ivfpq_ties_c4shape")
+    nprobe, R, k = int(z["nprobe"]), int(z["R"]), int(z["k"])
+    reps = 4096 // len(z["q"]) + 1
+    q = np.tile(z["q"], (reps, 1))
+    g = _device_for(z, tag, base, metric)
+    try:
+        ctx = B.make_ctx(**WIDE)
+        for has_rank in (True, False):
+            D, I, st = o.search(z["q"], k, nprobe, recall_num=R, has_rank=has_rank, metric=metric, ctx=ctx,
+                                coarse_mode=1, want_stages=True)
+            args = api.SearchArgs(metric=metric, nprobe=nprobe, recall_num=R, has_rank=has_rank, coarse_mode=-1, **WIDE)
+            g.tie_stats(reset=True)
+            Dg, Ig = g.ivfpq_search(q, k, args)
+            sg = g.last_stages(len(q), nprobe, R)
+            assert sg["coarse_dis"].tobytes() == np.tile(st["coarse_dis"], (reps, 1)).tobytes()
+            assert np.array_equal(sg["coarse_idx"], np.tile(st["coarse_idx"], (reps, 1)))
+            compare_exact(np.tile(D, (reps, 1)), np.tile(I, (reps, 1)), Dg, Ig)
+            ts = g.tie_stats()
+            assert ts["coarse_rows"] > 0 and ts["replayed"] > 0
     finally:
         g.close()

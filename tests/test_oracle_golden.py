@@ -167,10 +167,11 @@ def test_flat_matches_knn():
     compare_topk(Dk, Ik, D, I)
 
 
-def load_ties(tag):
-    """tests/golden/ivfpq_ties_d32.npz (gen_golden.gen_ivfpq_ties): duplicated integer base vectors, every
-    expected table built with the real faiss primitives and heaps."""
-    z = np.load(os.path.join(G, "ivfpq_ties_d32.npz"))
+def load_ties(tag, name="ivfpq_ties_d32"):
+    """tests/golden/ivfpq_ties_d32.npz, ivfpq_ties_c4shape.npz (gen_golden.gen_ivfpq_ties): duplicated integer base
+    vectors, every expected table built with the real faiss primitives and heaps.  The second file has the cuts of
+    the C4 configuration: more than 4096 lists, 64 probes, recall_num 100."""
+    z = np.load(os.path.join(G, name + ".npz"))
     d, nlist, M = int(z["d"]), int(z["nlist"]), int(z["M"])
     b0 = synth.sift_like(int(z["N0"]), d=d, seed=1234)
     base = np.ascontiguousarray(b0[z["pick"]])
@@ -188,12 +189,13 @@ def load_ties(tag):
     return z, o, base, metric
 
 
+@pytest.mark.parametrize("name", ["ivfpq_ties_d32", "ivfpq_ties_c4shape"])
 @pytest.mark.parametrize("tag", ["l2", "ip"])
-def test_tie_heavy_golden_labels_and_ranks_exact(tag):
+def test_tie_heavy_golden_labels_and_ranks_exact(tag, name):
     """Equal ADC distances straddle the recall_num cut in most queries, equal exact distances the k cut: the
     oracle's heaps must leave exactly what the real library's heaps leave -- labels at every rank."""
     from tests.parity import compare_exact
-    z, o, base, metric = load_ties(tag)
+    z, o, base, metric = load_ties(tag, name)
     nprobe, R, k = int(z["nprobe"]), int(z["R"]), int(z["k"])
     assert int(z["ncut_" + tag][0]) > 10
     ctx = B.make_ctx(min_score=-3e38, max_score=3e38)
