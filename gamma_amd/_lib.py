@@ -112,6 +112,29 @@ SYMBOLS = {
                                         f32p, i64p]),
     "gamma_hip_flat_search_device": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int,
                                                C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "gamma_hip_raw_update_batch": (C.c_int, [C.c_void_p, C.c_int64, i64p, f32p]),
+    "gamma_hip_ivfpq_dim": (C.c_int, [C.c_void_p]),
+    "gamma_hip_ivfpq_nlist": (C.c_int, [C.c_void_p]),
+    "gamma_hip_ivfpq_code_size": (C.c_int, [C.c_void_p]),
+    "gamma_hip_ivfpq_update_batch": (C.c_int, [C.c_void_p, C.c_int, i64p, f32p]),
+    "gamma_hip_ivfpq_encode_each": (C.c_int, [C.c_void_p, C.c_int64, f32p, i64p, u8p]),
+    "gamma_hip_ivfpq_apply_updates": (C.c_int, [C.c_void_p, C.c_int, i32p, i64p, u8p, u8p]),
+    "gamma_hip_group_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "gamma_hip_group_destroy": (C.c_int, [C.c_void_p]),
+    "gamma_hip_group_size": (C.c_int, [C.c_void_p]),
+    "gamma_hip_group_member": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "gamma_hip_group_last_error": (C.c_char_p, [C.c_void_p]),
+    "gamma_hip_group_set_owners": (C.c_int, [C.c_void_p, i64p]),
+    "gamma_hip_group_owner": (C.c_int, [C.c_void_p, C.c_int]),
+    "gamma_hip_group_ivfpq_add": (C.c_int, [C.c_void_p, C.c_int64, f32p, C.c_int64]),
+    "gamma_hip_group_ivfpq_add_keys": (C.c_int, [C.c_void_p, C.c_int, C.c_int, i64p, u8p]),
+    "gamma_hip_group_ivfpq_list_size": (C.c_int64, [C.c_void_p, C.c_int]),
+    "gamma_hip_group_ivfpq_get_list": (C.c_int, [C.c_void_p, C.c_int, i64p, u8p]),
+    "gamma_hip_group_ivfpq_update": (C.c_int, [C.c_void_p, C.c_int, i64p, f32p]),
+    "gamma_hip_group_ivfpq_delete": (C.c_int, [C.c_void_p, i64p, C.c_int]),
+    "gamma_hip_group_ivfpq_compact_if_need": (C.c_int, [C.c_void_p]),
+    "gamma_hip_group_ivfpq_search": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int, f32p, C.c_int, f32p, i64p]),
+    "gamma_hip_group_total_mem_bytes": (C.c_int64, [C.c_void_p]),
     "gamma_hip_total_mem_bytes": (C.c_int64, [C.c_void_p]),
     "gamma_hip_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "gamma_hip_profile_reset": (C.c_int, [C.c_void_p]),

@@ -244,6 +244,14 @@ class GammaHip:
         vecs = _f32(vecs)
         self._ck(self.L.gamma_hip_ivfpq_add(self.h, vecs.shape[0], _p(vecs, _lib.f32p), first_vid), "add")
 
+    def update_batch(self, vids, vecs):
+        """GammaIVFPQIndex::Update for a batch: one encode (each vector assigned as a call of its own), list updates in
+        order, one publish"""
+        vids = np.ascontiguousarray(vids, dtype=np.int64)
+        vecs = _f32(vecs)
+        self._ck(self.L.gamma_hip_ivfpq_update_batch(self.h, len(vids), _p(vids, _lib.i64p), _p(vecs, _lib.f32p)),
+                 "update_batch")
+
     def encode(self, vecs):
         vecs = _f32(vecs)
         n = vecs.shape[0]
@@ -412,3 +420,100 @@ class GammaHip:
         out["scan_bytes"] = b.value
         out["scan_pairs"] = pr.value
         return out
+
+
+class GammaHipGroup:
+    """Several GPUs behind one index object in ONE process (include/gamma_hip.h, gamma_hip_group_*): member i is an
+    ordinary handle on devices[i] owning the lists owner(l) == i; replicated state (centroids, codebooks, raw vectors,
+    bitmap) is broadcast through `members`.  The multi-process form of the same search is gamma_amd.dist."""
+
+    def __init__(self, devices):
+        self.L = _lib.load()
+        devs = (C.c_int * len(devices))(*devices)
+        g = C.c_void_p()
+        rc = self.L.gamma_hip_group_create(devs, len(devices), C.byref(g))
+        if rc != 0:
+            raise GammaHipError("gamma_hip_group_create(%s): %s" % (list(devices), self.L.gamma_hip_strerror(rc).decode()))
+        self.g = g
+        self.members = []
+        for i in range(len(devices)):
+            m = GammaHip.__new__(GammaHip)       # borrowed handle: the group owns it
+            m.L = self.L
+            m.h = C.c_void_p(self.L.gamma_hip_group_member(g, i))
+            m.d = m.M = None
+            m.close = lambda: None
+            self.members.append(m)
+
+    def close(self):
+        if getattr(self, "g", None):
+            for m in self.members:
+                m.h = None
+            self.L.gamma_hip_group_destroy(self.g)
+            self.g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise GammaHipError("%s: %s (%s)" % (what, self.L.gamma_hip_strerror(rc).decode(),
+                                                 self.L.gamma_hip_group_last_error(self.g).decode()))
+
+    def each(self, fn):
+        """replicated state: the same call on every member"""
+        return [fn(m) for m in self.members]
+
+    def set_owners(self, weights=None):
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.int64)
+        self._ck(self.L.gamma_hip_group_set_owners(self.g, None if w is None else _p(w, _lib.i64p)), "group_set_owners")
+
+    def owner(self, l):
+        return self.L.gamma_hip_group_owner(self.g, l)
+
+    def add(self, vecs, first_vid):
+        vecs = _f32(vecs)
+        self._ck(self.L.gamma_hip_group_ivfpq_add(self.g, vecs.shape[0], _p(vecs, _lib.f32p), first_vid), "group_add")
+
+    def add_keys(self, l, vids, codes):
+        vids = np.ascontiguousarray(vids, dtype=np.int64)
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        self._ck(self.L.gamma_hip_group_ivfpq_add_keys(self.g, l, len(vids), _p(vids, _lib.i64p), _p(codes, _lib.u8p)),
+                 "group_add_keys")
+
+    def update(self, vids, vecs):
+        vids = np.ascontiguousarray(vids, dtype=np.int64)
+        vecs = _f32(vecs)
+        self._ck(self.L.gamma_hip_group_ivfpq_update(self.g, len(vids), _p(vids, _lib.i64p), _p(vecs, _lib.f32p)), "group_update")
+
+    def delete(self, vids):
+        vids = np.ascontiguousarray(vids, dtype=np.int64)
+        self._ck(self.L.gamma_hip_group_ivfpq_delete(self.g, _p(vids, _lib.i64p), len(vids)), "group_delete")
+
+    def compact_if_need(self):
+        self._ck(self.L.gamma_hip_group_ivfpq_compact_if_need(self.g), "group_compact_if_need")
+
+    def list_size(self, l):
+        return self.L.gamma_hip_group_ivfpq_list_size(self.g, l)
+
+    def get_list(self, l, code_size):
+        n = self.list_size(l)
+        ids = np.empty(n, dtype=np.int64)
+        codes = np.empty((n, code_size), dtype=np.uint8)
+        if n:
+            self._ck(self.L.gamma_hip_group_ivfpq_get_list(self.g, l, _p(ids, _lib.i64p), _p(codes, _lib.u8p)), "group_get_list")
+        return ids, codes
+
+    def ivfpq_search(self, x, k, args):
+        x = _f32(x)
+        nq = x.shape[0]
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        self._ck(self.L.gamma_hip_group_ivfpq_search(self.g, C.byref(args.p), nq, _p(x, _lib.f32p), k, _p(D, _lib.f32p),
+                                                     _p(I, _lib.i64p)), "group_search")
+        return D, I
+
+    def total_mem_bytes(self):
+        return self.L.gamma_hip_group_total_mem_bytes(self.g)

@@ -131,6 +131,10 @@ int gamma_hip_synchronize(gamma_hip_index* h) {
     return GAMMA_HIP_OK;
 }
 
+int gamma_hip_ivfpq_dim(gamma_hip_index* h) { return (h && h->ivf_init) ? h->d : 0; }
+int gamma_hip_ivfpq_nlist(gamma_hip_index* h) { return (h && h->ivf_init) ? h->nlist : 0; }
+int gamma_hip_ivfpq_code_size(gamma_hip_index* h) { return (h && h->ivf_init) ? h->code_size : 0; }
+
 int gamma_hip_set_exact_ties(gamma_hip_index* h, int on) {
     if (!h) return GAMMA_HIP_EINVAL;
     SearchLock lk(h);

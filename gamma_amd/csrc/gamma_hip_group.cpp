@@ -1,0 +1,524 @@
+// gamma_hip_group.cpp -- several GPUs behind ONE index object in one process: a group of handles, the index sharded by
+// IVF list (include/gamma_hip.h, "several GPUs in ONE process").  The reference's GPU model does this with faiss's
+// IndexShards (index/impl/gpu/gamma_gpu_cloner.cpp:200-269, index/impl/gpu/gamma_index_ivfpq_gpu.cc:356-436,
+// faiss:IndexShards.cpp:283-345: a host thread per GPU, results merged on the host); here the split is by list (SURVEY
+// 8e), the exchange is device-to-device and the merge runs on the GPU that owns the query.
+//
+// Built on the public C ABI of the members only (plus the HIP runtime for the peer copies and events): a member is an
+// ordinary handle with a list mask.  One host thread per member enqueues that member's share of a call on the member's
+// own stream; the threads meet at two barriers (assignment exchanged, candidates exchanged) and cross-device ordering
+// is by events.  gamma_amd/dist.py is the same sequence of steps with one PROCESS per GPU and RCCL collectives.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/gamma_hip.h"
+
+namespace {
+
+struct GBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        else p = nullptr;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// all members' threads meet here; reusable
+struct Barrier {
+    std::mutex mu;
+    std::condition_variable cv;
+    int n = 0, waiting = 0;
+    uint64_t gen = 0;
+    void arrive() {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t g = gen;
+        if (++waiting == n) {
+            waiting = 0;
+            gen++;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return gen != g; });
+        }
+    }
+};
+
+}  // namespace
+
+struct gamma_hip_group {
+    std::vector<gamma_hip_index*> m;
+    std::vector<int> dev;
+    std::vector<int> owner;   // list -> member; empty until gamma_hip_group_set_owners
+    std::string err;
+    std::mutex mu;            // one group-level call at a time
+    int next_enc = 0;         // members take turns encoding Add / Update batches
+
+    struct Member {
+        GBuf x, cdis, probe, rdis, rids, all_dis, all_ids, D, I;
+        hipEvent_t ev_coarse = nullptr, ev_scan = nullptr;
+    };
+    std::vector<Member> mb;
+
+    // one persistent thread per member: run(job) executes job(i) on thread i and returns when all are done
+    std::vector<std::thread> th;
+    std::mutex pmu;
+    std::condition_variable pcv, dcv;
+    std::function<void(int)> job;
+    uint64_t job_gen = 0;
+    int job_left = 0;
+    bool stop = false;
+    Barrier bar;
+
+    void worker(int i) {
+        (void)hipSetDevice(dev[i]);
+        uint64_t seen = 0;
+        for (;;) {
+            std::function<void(int)> f;
+            {
+                std::unique_lock<std::mutex> lk(pmu);
+                pcv.wait(lk, [&] { return stop || job_gen != seen; });
+                if (stop) return;
+                seen = job_gen;
+                f = job;
+            }
+            f(i);
+            {
+                std::lock_guard<std::mutex> lk(pmu);
+                if (--job_left == 0) dcv.notify_all();
+            }
+        }
+    }
+    void run(const std::function<void(int)>& f) {
+        std::unique_lock<std::mutex> lk(pmu);
+        job = f;
+        job_left = (int)m.size();
+        job_gen++;
+        pcv.notify_all();
+        dcv.wait(lk, [&] { return job_left == 0; });
+    }
+};
+
+namespace {
+
+int gfail(gamma_hip_group* g, int code, const std::string& msg) {
+    g->err = msg;
+    return code;
+}
+int member_fail(gamma_hip_group* g, int i, int rc) {
+    g->err = "member " + std::to_string(i) + ": " + gamma_hip_strerror(rc) + " (" + gamma_hip_last_error(g->m[i]) + ")";
+    return rc;
+}
+
+// src on device sd -> dst on device dd, ordered on stream s (a stream of device dd)
+hipError_t copy_between(void* dst, int dd, const void* src, int sd, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    if (dd == sd) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
+    return hipMemcpyPeerAsync(dst, dd, src, sd, bytes, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int gamma_hip_group_create(const int* devices, int n, gamma_hip_group** out) {
+    if (!out || !devices || n <= 0 || n > 64) return GAMMA_HIP_EINVAL;
+    *out = nullptr;
+    gamma_hip_group* g = new (std::nothrow) gamma_hip_group();
+    if (!g) return GAMMA_HIP_ENOMEM;
+    g->dev.assign(devices, devices + n);
+    g->mb.resize(n);
+    for (int i = 0; i < n; i++) {
+        gamma_hip_index* h = nullptr;
+        const int rc = gamma_hip_create(devices[i], &h);
+        if (rc != GAMMA_HIP_OK) {
+            for (auto* mh : g->m) gamma_hip_destroy(mh);
+            delete g;
+            return rc;
+        }
+        g->m.push_back(h);
+    }
+    // direct copies between the members' devices where the fabric allows it (xGMI); failure is not an error, the
+    // runtime then stages peer copies itself
+    for (int i = 0; i < n; i++) {
+        (void)hipSetDevice(devices[i]);
+        for (int j = 0; j < n; j++) {
+            if (devices[j] == devices[i]) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) == hipSuccess && can) {
+                const hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
+                if (e != hipSuccess) (void)hipGetLastError();   // already enabled, or refused: both fine
+            }
+        }
+        if (hipEventCreateWithFlags(&g->mb[i].ev_coarse, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&g->mb[i].ev_scan, hipEventDisableTiming) != hipSuccess) {
+            for (auto* mh : g->m) gamma_hip_destroy(mh);
+            delete g;
+            return GAMMA_HIP_EDEVICE;
+        }
+    }
+    g->bar.n = n;
+    for (int i = 0; i < n; i++) g->th.emplace_back([g, i] { g->worker(i); });
+    *out = g;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_group_destroy(gamma_hip_group* g) {
+    if (!g) return GAMMA_HIP_OK;
+    {
+        std::lock_guard<std::mutex> lk(g->pmu);
+        g->stop = true;
+        g->pcv.notify_all();
+    }
+    for (auto& t : g->th)
+        if (t.joinable()) t.join();
+    for (size_t i = 0; i < g->m.size(); i++) {
+        (void)hipSetDevice(g->dev[i]);
+        (void)gamma_hip_synchronize(g->m[i]);
+        gamma_hip_group::Member& b = g->mb[i];
+        for (GBuf* p : {&b.x, &b.cdis, &b.probe, &b.rdis, &b.rids, &b.all_dis, &b.all_ids, &b.D, &b.I}) p->release();
+        if (b.ev_coarse) (void)hipEventDestroy(b.ev_coarse);
+        if (b.ev_scan) (void)hipEventDestroy(b.ev_scan);
+    }
+    for (auto* h : g->m) gamma_hip_destroy(h);
+    delete g;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_group_size(const gamma_hip_group* g) { return g ? (int)g->m.size() : 0; }
+gamma_hip_index* gamma_hip_group_member(gamma_hip_group* g, int i) {
+    return (g && i >= 0 && i < (int)g->m.size()) ? g->m[i] : nullptr;
+}
+const char* gamma_hip_group_last_error(gamma_hip_group* g) { return g ? g->err.c_str() : "null group"; }
+
+int gamma_hip_group_set_owners(gamma_hip_group* g, const int64_t* weights) {
+    if (!g) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> lk(g->mu);
+    const int W = (int)g->m.size();
+    const int nlist = gamma_hip_ivfpq_nlist(g->m[0]);
+    if (nlist <= 0) return gfail(g, GAMMA_HIP_EINVAL, "set_owners: members not initialised");
+    for (int i = 1; i < W; i++)
+        if (gamma_hip_ivfpq_nlist(g->m[i]) != nlist) return gfail(g, GAMMA_HIP_EINVAL, "set_owners: members differ in nlist");
+    g->owner.assign(nlist, 0);
+    if (!weights) {
+        for (int l = 0; l < nlist; l++) g->owner[l] = l % W;
+    } else {
+        // greedy longest-processing-time on the weights (gamma_amd/dist.py balance_lists): heaviest list first onto the
+        // lightest member; the +1 spreads empty lists as well
+        std::vector<int> order(nlist);
+        for (int l = 0; l < nlist; l++) order[l] = l;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return weights[a] > weights[b]; });
+        std::vector<int64_t> load(W, 0);
+        for (int l : order) {
+            int best = 0;
+            for (int i = 1; i < W; i++)
+                if (load[i] < load[best]) best = i;
+            g->owner[l] = best;
+            load[best] += std::max<int64_t>(0, weights[l]) + 1;
+        }
+    }
+    std::vector<uint8_t> mask(nlist);
+    for (int i = 0; i < W; i++) {
+        for (int l = 0; l < nlist; l++) mask[l] = g->owner[l] == i ? 1 : 0;
+        const int rc = gamma_hip_ivfpq_set_list_mask(g->m[i], mask.data());
+        if (rc) return member_fail(g, i, rc);
+    }
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_group_owner(const gamma_hip_group* g, int l) {
+    return (g && l >= 0 && l < (int)g->owner.size()) ? g->owner[l] : -1;
+}
+
+int gamma_hip_group_ivfpq_add(gamma_hip_group* g, int64_t n, const float* vecs, int64_t first_vid) {
+    if (!g || n < 0 || (n > 0 && !vecs)) return GAMMA_HIP_EINVAL;
+    if (n == 0) return GAMMA_HIP_OK;
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (g->owner.empty()) return gfail(g, GAMMA_HIP_EINVAL, "add: gamma_hip_group_set_owners first");
+    const int W = (int)g->m.size(), nlist = (int)g->owner.size();
+    // one encode for the batch (quantizer->assign + residual + pq.compute_codes, gamma_index_ivfpq.cc:424-512)
+    const int e = g->next_enc++ % W;
+    const int cs = gamma_hip_ivfpq_code_size(g->m[e]);
+    if (cs <= 0) return gfail(g, GAMMA_HIP_EINVAL, "add: members not initialised");
+    std::vector<int64_t> lno(n);
+    std::vector<uint8_t> codes((size_t)n * cs);
+    int rc = gamma_hip_ivfpq_encode(g->m[e], n, vecs, lno.data(), codes.data());
+    if (rc) return member_fail(g, e, rc);
+    // AddKeys at the owner, lists in ascending order, entries in batch order (the std::map of gamma_index_ivfpq.cc:428-494)
+    std::vector<int64_t> order(n);
+    for (int64_t i = 0; i < n; i++) {
+        if (lno[i] < 0 || lno[i] >= nlist) lno[i] = (first_vid + i) % nlist;
+        order[i] = i;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return lno[a] < lno[b]; });
+    for (int o = 0; o < W; o++) {
+        std::vector<int32_t> lists, counts;
+        std::vector<int64_t> vids;
+        std::vector<uint8_t> gcodes;
+        for (int64_t i = 0; i < n; i++) {
+            const int64_t src = order[i];
+            if (g->owner[lno[src]] != o) continue;
+            if (lists.empty() || lists.back() != (int32_t)lno[src]) {
+                lists.push_back((int32_t)lno[src]);
+                counts.push_back(0);
+            }
+            counts.back()++;
+            vids.push_back(first_vid + src);
+            gcodes.insert(gcodes.end(), codes.begin() + (size_t)src * cs, codes.begin() + (size_t)(src + 1) * cs);
+        }
+        if (lists.empty()) continue;
+        rc = gamma_hip_ivfpq_add_keys_batch(g->m[o], (int)lists.size(), lists.data(), counts.data(), vids.data(), gcodes.data());
+        if (rc) return member_fail(g, o, rc);
+    }
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_group_ivfpq_add_keys(gamma_hip_group* g, int l, int n, const int64_t* vids, const uint8_t* codes) {
+    if (!g) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (l < 0 || l >= (int)g->owner.size()) return gfail(g, GAMMA_HIP_EINVAL, "add_keys: bad list (or no owners yet)");
+    const int o = g->owner[l];
+    const int rc = gamma_hip_ivfpq_add_keys(g->m[o], l, n, vids, codes);
+    return rc ? member_fail(g, o, rc) : GAMMA_HIP_OK;
+}
+
+int64_t gamma_hip_group_ivfpq_list_size(gamma_hip_group* g, int l) {
+    if (!g || l < 0 || l >= (int)g->owner.size()) return -1;
+    return gamma_hip_ivfpq_list_size(g->m[g->owner[l]], l);
+}
+
+int gamma_hip_group_ivfpq_get_list(gamma_hip_group* g, int l, int64_t* vids, uint8_t* codes) {
+    if (!g) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (l < 0 || l >= (int)g->owner.size()) return gfail(g, GAMMA_HIP_EINVAL, "get_list: bad list (or no owners yet)");
+    const int o = g->owner[l];
+    const int rc = gamma_hip_ivfpq_get_list(g->m[o], l, vids, codes);
+    return rc ? member_fail(g, o, rc) : GAMMA_HIP_OK;
+}
+
+int gamma_hip_group_ivfpq_update(gamma_hip_group* g, int n, const int64_t* vids, const float* vecs) {
+    if (!g || n < 0 || (n > 0 && (!vids || !vecs))) return GAMMA_HIP_EINVAL;
+    if (n == 0) return GAMMA_HIP_OK;
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (g->owner.empty()) return gfail(g, GAMMA_HIP_EINVAL, "update: gamma_hip_group_set_owners first");
+    const int W = (int)g->m.size(), nlist = (int)g->owner.size();
+    const int e = g->next_enc++ % W;
+    const int cs = gamma_hip_ivfpq_code_size(g->m[e]);
+    if (cs <= 0) return gfail(g, GAMMA_HIP_EINVAL, "update: bad code size");
+    std::vector<int64_t> lno(n);
+    std::vector<uint8_t> codes((size_t)n * cs);
+    int rc = gamma_hip_ivfpq_encode_each(g->m[e], n, vecs, lno.data(), codes.data());
+    if (rc) return member_fail(g, e, rc);
+    // who holds each vid now (at most one member); kept current while the batch is routed, so that a vid named
+    // twice is followed through its first move
+    std::unordered_map<int64_t, int> holder;
+    {
+        std::vector<uint8_t> has(n);
+        for (int i = 0; i < W; i++) {
+            rc = gamma_hip_ivfpq_has_vid(g->m[i], vids, n, has.data());
+            if (rc) return member_fail(g, i, rc);
+            for (int j = 0; j < n; j++)
+                if (has[j]) holder[vids[j]] = i;
+        }
+    }
+    // RealTimeMemData::Update (realtime_mem_data.cc:305-327) when the list a vector leaves and the list it joins may
+    // belong to different members: per member the entries that concern it, in batch order
+    std::vector<std::vector<int>> idx(W);
+    std::vector<std::vector<uint8_t>> ops(W);
+    for (int j = 0; j < n; j++) {
+        auto it = holder.find(vids[j]);
+        if (it == holder.end()) continue;   // never added: Update ignores it (:307-311)
+        if (lno[j] < 0 || lno[j] >= nlist) continue;
+        const int from = it->second, to = g->owner[lno[j]];
+        if (from == to) {
+            idx[to].push_back(j);
+            ops[to].push_back(0);
+        } else {
+            idx[from].push_back(j);
+            ops[from].push_back(2);   // leaves: flag the old entry
+            idx[to].push_back(j);
+            ops[to].push_back(1);     // the owner of the new list appends
+            it->second = to;
+        }
+    }
+    for (int i = 0; i < W; i++) {
+        const int ni = (int)idx[i].size();
+        if (ni == 0) continue;
+        std::vector<int32_t> l32(ni);
+        std::vector<int64_t> v(ni);
+        std::vector<uint8_t> c((size_t)ni * cs);
+        for (int t = 0; t < ni; t++) {
+            const int j = idx[i][t];
+            l32[t] = (int32_t)lno[j];
+            v[t] = vids[j];
+            memcpy(c.data() + (size_t)t * cs, codes.data() + (size_t)j * cs, cs);
+        }
+        rc = gamma_hip_ivfpq_apply_updates(g->m[i], ni, l32.data(), v.data(), c.data(), ops[i].data());
+        if (rc) return member_fail(g, i, rc);
+    }
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_group_ivfpq_delete(gamma_hip_group* g, const int64_t* vids, int n) {
+    if (!g || (n > 0 && !vids)) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> lk(g->mu);
+    for (size_t i = 0; i < g->m.size(); i++) {   // a member counts the vids it holds and ignores the others
+        const int rc = gamma_hip_ivfpq_delete(g->m[i], vids, n);
+        if (rc) return member_fail(g, (int)i, rc);
+    }
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_group_ivfpq_compact_if_need(gamma_hip_group* g) {
+    if (!g) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> lk(g->mu);
+    for (size_t i = 0; i < g->m.size(); i++) {
+        const int rc = gamma_hip_ivfpq_compact_if_need(g->m[i]);
+        if (rc) return member_fail(g, (int)i, rc);
+    }
+    return GAMMA_HIP_OK;
+}
+
+int64_t gamma_hip_group_total_mem_bytes(gamma_hip_group* g) {
+    if (!g) return 0;
+    int64_t t = 0;
+    for (auto* h : g->m) t += gamma_hip_total_mem_bytes(h);
+    return t;
+}
+
+int gamma_hip_group_ivfpq_search(gamma_hip_group* g, const gamma_hip_search_params* p, int nq, const float* x, int k,
+                                 float* distances, int64_t* labels) {
+    if (!g || !p) return GAMMA_HIP_EINVAL;
+    if (nq < 0) return GAMMA_HIP_EINVAL;
+    if (k <= 0 || nq == 0) return GAMMA_HIP_OK;   // gamma_index_ivfpq.cc:753-756
+    if (!x || !distances || !labels) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (g->owner.empty()) return gfail(g, GAMMA_HIP_EINVAL, "search: gamma_hip_group_set_owners first");
+    const int W = (int)g->m.size();
+    const int d = gamma_hip_ivfpq_dim(g->m[0]);
+    if (d <= 0) return gfail(g, GAMMA_HIP_EINVAL, "search: members not initialised");
+    const int P = p->nprobe, R = std::max(p->recall_num, k);
+    if (P <= 0) return gfail(g, GAMMA_HIP_EINVAL, "search: nprobe out of range");
+    // faiss chooses the coarse path from the size of the WHOLE call (faiss:utils/distances.cpp:346): the slices must agree
+    gamma_hip_search_params pp = *p;
+    if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;
+    const int per = (nq + W - 1) / W;
+    std::vector<int> rcs(W, GAMMA_HIP_OK);
+    std::vector<std::string> errs(W);
+    auto slice = [&](int i, int* q0, int* q1) {
+        *q0 = std::min(nq, i * per);
+        *q1 = std::min(nq, *q0 + per);
+    };
+    g->run([&](int i) {
+        gamma_hip_group::Member& b = g->mb[i];
+        gamma_hip_index* h = g->m[i];
+        hipStream_t s = (hipStream_t)gamma_hip_stream(h);
+        int q0, q1;
+        slice(i, &q0, &q1);
+        const int nql = q1 - q0;
+        int& rc = rcs[i];
+        auto hip = [&](hipError_t e, const char* what) {
+            if (e != hipSuccess && rc == GAMMA_HIP_OK) {
+                rc = e == hipErrorOutOfMemory ? GAMMA_HIP_ENOMEM : GAMMA_HIP_EDEVICE;
+                errs[i] = std::string(what) + ": " + hipGetErrorString(e);
+            }
+        };
+        auto abi = [&](int r) {
+            if (r != GAMMA_HIP_OK && rc == GAMMA_HIP_OK) {
+                rc = r;
+                errs[i] = std::string(gamma_hip_strerror(r)) + " (" + gamma_hip_last_error(h) + ")";
+            }
+        };
+        hip(hipSetDevice(g->dev[i]), "hipSetDevice");
+        hip(b.x.ensure((size_t)nq * d * sizeof(float)), "alloc");
+        hip(b.cdis.ensure((size_t)nq * P * sizeof(float)), "alloc");
+        hip(b.probe.ensure((size_t)nq * P * sizeof(int32_t)), "alloc");
+        hip(b.rdis.ensure((size_t)nq * R * sizeof(float)), "alloc");
+        hip(b.rids.ensure((size_t)nq * R * sizeof(int64_t)), "alloc");
+        hip(b.all_dis.ensure((size_t)W * per * R * sizeof(float)), "alloc");
+        hip(b.all_ids.ensure((size_t)W * per * R * sizeof(int64_t)), "alloc");
+        hip(b.D.ensure((size_t)per * k * sizeof(float)), "alloc");
+        hip(b.I.ensure((size_t)per * k * sizeof(int64_t)), "alloc");
+        // 0. the whole batch to every member (each scans its lists for all queries); coarse quantizer for the own slice
+        if (rc == GAMMA_HIP_OK) {
+            hip(hipMemcpyAsync(b.x.p, x, (size_t)nq * d * sizeof(float), hipMemcpyHostToDevice, s), "H2D queries");
+            if (nql > 0)
+                abi(gamma_hip_ivfpq_coarse_device(h, &pp, nql, b.x.as<float>() + (size_t)q0 * d, b.cdis.as<float>() + (size_t)q0 * P,
+                                                  b.probe.as<int32_t>() + (size_t)q0 * P));
+            hip(hipEventRecord(b.ev_coarse, s), "record");
+        }
+        g->bar.arrive();   // every member's assignment is on its stream
+        bool all_ok = true;
+        for (int j = 0; j < W; j++) all_ok = all_ok && rcs[j] == GAMMA_HIP_OK;
+        // 1. pull the other slices of the assignment; scan of the owned probed lists, local top-R of every query
+        if (all_ok) {
+            for (int j = 0; j < W; j++) {
+                if (j == i) continue;
+                int a0, a1;
+                slice(j, &a0, &a1);
+                if (a1 <= a0) continue;
+                hip(hipStreamWaitEvent(s, g->mb[j].ev_coarse, 0), "wait");
+                hip(copy_between(b.cdis.as<float>() + (size_t)a0 * P, g->dev[i], g->mb[j].cdis.as<float>() + (size_t)a0 * P, g->dev[j],
+                                 (size_t)(a1 - a0) * P * sizeof(float), s), "assignment exchange");
+                hip(copy_between(b.probe.as<int32_t>() + (size_t)a0 * P, g->dev[i], g->mb[j].probe.as<int32_t>() + (size_t)a0 * P,
+                                 g->dev[j], (size_t)(a1 - a0) * P * sizeof(int32_t), s), "assignment exchange");
+            }
+            if (rc == GAMMA_HIP_OK)
+                abi(gamma_hip_ivfpq_search_shard_preassigned(h, &pp, nq, b.x.as<float>(), b.cdis.as<float>(), b.probe.as<int32_t>(), k,
+                                                             b.rdis.as<float>(), b.rids.as<int64_t>()));
+            hip(hipEventRecord(b.ev_scan, s), "record");
+        }
+        g->bar.arrive();   // every member's candidate tables are on its stream
+        all_ok = true;
+        for (int j = 0; j < W; j++) all_ok = all_ok && rcs[j] == GAMMA_HIP_OK;
+        // 2. the exchange of the path: the candidates of the own query slice from every member ([W][per][R]);
+        // 3. merge to the global top-R, compute_dis, results to the caller
+        if (all_ok && nql > 0) {
+            for (int j = 0; j < W; j++) {
+                if (j != i) hip(hipStreamWaitEvent(s, g->mb[j].ev_scan, 0), "wait");
+                hip(copy_between(b.all_dis.as<float>() + (size_t)j * per * R, g->dev[i], g->mb[j].rdis.as<float>() + (size_t)q0 * R,
+                                 g->dev[j], (size_t)nql * R * sizeof(float), s), "candidate exchange");
+                hip(copy_between(b.all_ids.as<int64_t>() + (size_t)j * per * R, g->dev[i], g->mb[j].rids.as<int64_t>() + (size_t)q0 * R,
+                                 g->dev[j], (size_t)nql * R * sizeof(int64_t), s), "candidate exchange");
+            }
+            if (rc == GAMMA_HIP_OK)
+                abi(gamma_hip_ivfpq_merge_rerank(h, &pp, W, per, b.x.as<float>() + (size_t)q0 * d, k, b.all_dis.as<float>(),
+                                                 b.all_ids.as<int64_t>(), 0, nql, b.D.as<float>(), b.I.as<int64_t>()));
+            if (rc == GAMMA_HIP_OK) {
+                hip(hipMemcpyAsync(distances + (size_t)q0 * k, b.D.p, (size_t)nql * k * sizeof(float), hipMemcpyDeviceToHost, s), "D2H");
+                hip(hipMemcpyAsync(labels + (size_t)q0 * k, b.I.p, (size_t)nql * k * sizeof(int64_t), hipMemcpyDeviceToHost, s), "D2H");
+            }
+        }
+        hip(hipStreamSynchronize(s), "sync");
+        g->bar.arrive();   // nobody is reading this member's tables any more
+    });
+    for (int i = 0; i < W; i++)
+        if (rcs[i] != GAMMA_HIP_OK) return gfail(g, rcs[i], "member " + std::to_string(i) + ": " + errs[i]);
+    return GAMMA_HIP_OK;
+}
+
+}  // extern "C"

@@ -15,7 +15,10 @@ int arena_reserve(H* h, int64_t need_entries) {
     int64_t* ni = nullptr;
     if (h->wl) GH_CHECK(h, h->wl->exclusive());   // the old arrays are freed below: no search may be reading them
     GH_CHECK(h, hipMalloc((void**)&nc, (size_t)ncap * h->code_size));
-    GH_CHECK(h, hipMalloc((void**)&ni, (size_t)ncap * sizeof(int64_t)));
+    if (hipMalloc((void**)&ni, (size_t)ncap * sizeof(int64_t)) != hipSuccess) {
+        (void)hipFree(nc);
+        return fail(h, GAMMA_HIP_ENOMEM, "arena growth: out of memory");
+    }
     if (h->arena_used > 0) {
         GH_CHECK(h, hipMemcpyAsync(nc, h->d_codes, (size_t)h->arena_used * h->code_size,
                                    hipMemcpyDeviceToDevice, h->wstream));
@@ -81,13 +84,17 @@ int list_ensure(H* h, int l, int add) {
     if ((int64_t)len + add <= cap) return GAMMA_HIP_OK;
     if ((int64_t)cap * 2 >= h->bucket_max) return fail(h, GAMMA_HIP_EFULL, "exceed the max bucket keys");
     const int least = len + add;
-    double coef = extend_coefficient(++h->h_extend_time[l]);
+    // the growth step is worked out on a copy of the list's extend counter and committed only once the arena holds
+    // the new extent (a failed reservation leaves the list as it was)
+    uint8_t et = h->h_extend_time[l];
+    double coef = extend_coefficient(++et);
     int ext = (int)(cap * coef);
     while (ext < least) {
-        coef = extend_coefficient(++h->h_extend_time[l]);
+        coef = extend_coefficient(++et);
         ext = (int)(ext * coef);
     }
     GH_TRY(arena_reserve(h, ext));
+    h->h_extend_time[l] = et;
     const int64_t noff = h->arena_used;
     if (len > 0) {
         GH_CHECK(h, hipMemcpyAsync(h->d_codes + noff * h->code_size,
@@ -398,6 +405,21 @@ int gamma_hip_raw_update(gamma_hip_index* h, int64_t vid, const float* vec) {
     return GAMMA_HIP_OK;
 }
 
+// n rows rewritten (vids below the row count; others are skipped: the mirror has not reached them yet), one wait
+int gamma_hip_raw_update_batch(gamma_hip_index* h, int64_t n, const int64_t* vids, const float* vecs) {
+    if (!h || n < 0 || (n > 0 && (!vids || !vecs))) return GAMMA_HIP_EINVAL;
+    if (n == 0) return GAMMA_HIP_OK;
+    WriteLock lk(h);
+    GH_CHECK(h, hipSetDevice(h->device));
+    for (int64_t i = 0; i < n; i++) {
+        if (vids[i] < 0 || vids[i] >= h->nraw) continue;
+        GH_CHECK(h, hipMemcpyAsync(h->d_raw + vids[i] * h->raw_d, vecs + i * h->raw_d, (size_t)h->raw_d * sizeof(float),
+                                   hipMemcpyHostToDevice, h->wstream));
+    }
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    return GAMMA_HIP_OK;
+}
+
 int64_t gamma_hip_raw_count(gamma_hip_index* h) { return h ? h->nraw : -1; }
 
 /* ---- delete bitmap ------------------------------------------------------------------- */
@@ -649,11 +671,85 @@ int gamma_hip_ivfpq_update(gamma_hip_index* h, int list_no, int64_t vid, const u
         GH_CHECK(h, hipStreamSynchronize(h->wstream));
         return GAMMA_HIP_OK;
     }
+    GH_TRY(list_ensure(h, list_no, 1));   // before the old entry is given up: a full list must not lose the vector
     gh::launch_mark_moved(h->wstream, h->d_ids, h->h_list_off[ob] + op);
     h->h_deleted[ob]++;
     h->n_moved++;
     h->ntotal -= 1;  // add_keys_locked re-counts it
     return add_keys_locked(h, list_no, 1, &vid, code);
+}
+
+// n list updates with the codes already computed: what RTInvertIndex::Update (realtime_mem_data.cc:305-327) does for
+// each entry in order, with ONE publish of the lists' tables and ONE wait for the device at the end.
+//   ops[i] (nullptr = all 0)   0: Update -- a vid this handle does not hold is ignored (:307-311)
+//                              1: the vid is held by ANOTHER shard of a list-sharded index and joins list_nos[i] here: AddKeys
+//                              2: the vid leaves this shard: the first half of Update alone (gamma_hip_ivfpq_remove)
+int gamma_hip_ivfpq_apply_updates(gamma_hip_index* h, int n, const int32_t* list_nos, const int64_t* vids,
+                                  const uint8_t* codes, const uint8_t* ops) {
+    if (!h || n < 0 || (n > 0 && (!list_nos || !vids || !codes))) return GAMMA_HIP_EINVAL;
+    if (n == 0) return GAMMA_HIP_OK;
+    WriteLock lk(h);
+    if (!h->ivf_init) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
+    GH_CHECK(h, hipSetDevice(h->device));
+    const int cs = h->code_size;
+    // room first: an upper bound of the entries every list may receive (an entry that stays in its list needs none,
+    // but a vid named twice may have moved in between -- counted as a move), so that no extent moves while the copies
+    // below are in flight
+    {
+        std::map<int, int64_t> per_list;
+        for (int i = 0; i < n; i++) {
+            const int op = ops ? ops[i] : 0;
+            if (op == 2) continue;
+            if (list_nos[i] < 0 || list_nos[i] >= h->nlist) return fail(h, GAMMA_HIP_EINVAL, "bad list_no");
+            if (op == 0) {
+                const int64_t v = vids[i];
+                if (v < 0 || (size_t)v >= h->vid_pos.size() || h->vid_pos[v] == -1) continue;
+            }
+            per_list[list_nos[i]]++;
+        }
+        for (auto& kv : per_list) {
+            if (h->h_list_len[kv.first] + kv.second > h->bucket_max) return fail(h, GAMMA_HIP_EFULL, "exceed the max bucket keys");
+            GH_TRY(list_ensure(h, kv.first, (int)kv.second));
+        }
+    }
+    bool changed = false;
+    for (int i = 0; i < n; i++) {
+        const int op = ops ? ops[i] : 0;
+        const int64_t vid = vids[i];
+        const int l = list_nos[i];
+        const uint8_t* code = codes + (size_t)i * cs;
+        int64_t bp = -1;
+        if (vid >= 0 && (size_t)vid < h->vid_pos.size()) bp = h->vid_pos[vid];
+        if (op != 1) {
+            if (bp == -1) continue;   // not held here
+            const int ob = (int)(bp >> 32), opos = (int)(bp & 0xffffffff);
+            if (op == 0 && ob == l) {   // same list: the code is rewritten in place
+                GH_CHECK(h, hipMemcpyAsync(h->d_codes + (h->h_list_off[ob] + opos) * cs, code, cs, hipMemcpyHostToDevice, h->wstream));
+                continue;
+            }
+            gh::launch_mark_moved(h->wstream, h->d_ids, h->h_list_off[ob] + opos);
+            h->h_deleted[ob]++;
+            h->n_moved++;
+            h->ntotal -= 1;
+            h->vid_pos[vid] = -1;
+            if (op == 2) continue;
+        }
+        // AddKeys of one entry (add_keys_locked without its publish)
+        const int64_t pos = h->h_list_off[l] + h->h_list_len[l];
+        GH_CHECK(h, hipMemcpyAsync(h->d_ids + pos, vids + i, sizeof(int64_t), hipMemcpyHostToDevice, h->wstream));
+        GH_CHECK(h, hipMemcpyAsync(h->d_codes + pos * cs, code, cs, hipMemcpyHostToDevice, h->wstream));
+        if ((size_t)vid >= h->vid_pos.size()) h->vid_pos.resize(std::max<size_t>(h->vid_pos.size() * 2, vid + 1), -1);
+        h->vid_pos[vid] = ((int64_t)l << 32) | (int64_t)h->h_list_len[l];
+        if (h->doc_deleted(vid)) h->h_deleted[l]++;
+        h->h_list_len[l] += 1;
+        h->ntotal += 1;
+        if (h->h_list_len[l] > h->max_list_len) h->max_list_len = h->h_list_len[l];
+        changed = true;
+    }
+    if (changed) GH_TRY(publish_meta(h));
+    GH_CHECK(h, hipGetLastError());
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));   // the caller's buffers are free again
+    return changed ? arena_repack_if_need(h) : GAMMA_HIP_OK;
 }
 
 int gamma_hip_ivfpq_has_vid(gamma_hip_index* h, const int64_t* vids, int n, uint8_t* out) {
@@ -828,7 +924,19 @@ static int encode_locked(H* h, int64_t n, const float* d_vecs, int* d_assign, ui
     return GAMMA_HIP_OK;
 }
 
+static int encode_host(gamma_hip_index* h, int64_t n, const float* vecs, int64_t* list_nos, uint8_t* codes, bool exact);
+
 int gamma_hip_ivfpq_encode(gamma_hip_index* h, int64_t n, const float* vecs, int64_t* list_nos, uint8_t* codes) {
+    return encode_host(h, n, vecs, list_nos, codes, n < 20);
+}
+
+// every vector assigned as a call of its own would assign it (quantizer->assign(1, ..): the exact form, what
+// GammaIVFPQIndex::Update runs per vector, gamma_index_ivfpq.cc:398), in one device pass
+int gamma_hip_ivfpq_encode_each(gamma_hip_index* h, int64_t n, const float* vecs, int64_t* list_nos, uint8_t* codes) {
+    return encode_host(h, n, vecs, list_nos, codes, true);
+}
+
+static int encode_host(gamma_hip_index* h, int64_t n, const float* vecs, int64_t* list_nos, uint8_t* codes, bool exact) {
     if (!h || n < 0 || (n > 0 && (!vecs || !list_nos || !codes))) return GAMMA_HIP_EINVAL;
     WriteLock lk(h);
     if (!h->trained) return fail(h, GAMMA_HIP_ENOTTRAINED, "not trained");
@@ -842,13 +950,32 @@ int gamma_hip_ivfpq_encode(gamma_hip_index* h, int64_t n, const float* vecs, int
         GH_CHECK(h, h->we_assign.ensure((size_t)nc * sizeof(int)));
         GH_CHECK(h, h->we_codes.ensure((size_t)nc * h->code_size));
         GH_CHECK(h, hipMemcpyAsync(h->we_x.p, vecs + i0 * h->d, (size_t)nc * h->d * sizeof(float), hipMemcpyHostToDevice, h->wstream));
-        GH_TRY(encode_locked(h, nc, h->we_x.as<float>(), h->we_assign.as<int>(), h->we_codes.as<uint8_t>(), n < 20));
+        GH_TRY(encode_locked(h, nc, h->we_x.as<float>(), h->we_assign.as<int>(), h->we_codes.as<uint8_t>(), exact));
         GH_CHECK(h, hipMemcpyAsync(assign.data(), h->we_assign.p, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, h->wstream));
         GH_CHECK(h, hipMemcpyAsync(codes + i0 * h->code_size, h->we_codes.p, (size_t)nc * h->code_size, hipMemcpyDeviceToHost, h->wstream));
         GH_CHECK(h, hipStreamSynchronize(h->wstream));
         for (int64_t i = 0; i < nc; i++) list_nos[i0 + i] = assign[i];
     }
     return GAMMA_HIP_OK;
+}
+
+// GammaIVFPQIndex::Update for a batch (gamma_index_ivfpq.cc:375-422; the engine drains up to 20 000 updated vids per
+// pass, vector/vector_manager.cc:355-380): one encode, the list updates in order, one publish
+int gamma_hip_ivfpq_update_batch(gamma_hip_index* h, int n, const int64_t* vids, const float* vecs) {
+    if (!h || n < 0 || (n > 0 && (!vids || !vecs))) return GAMMA_HIP_EINVAL;
+    if (n == 0) return GAMMA_HIP_OK;
+    int cs = 0;
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        if (!h->trained) return fail(h, GAMMA_HIP_ENOTTRAINED, "not trained");
+        cs = h->code_size;
+    }
+    std::vector<int64_t> lno(n);
+    std::vector<uint8_t> codes((size_t)n * cs);
+    GH_TRY(encode_host(h, n, vecs, lno.data(), codes.data(), true));
+    std::vector<int32_t> l32(n);
+    for (int i = 0; i < n; i++) l32[i] = (int32_t)lno[i];
+    return gamma_hip_ivfpq_apply_updates(h, n, l32.data(), vids, codes.data(), nullptr);
 }
 
 int gamma_hip_assign(gamma_hip_index* h, int d, int64_t n, const float* x, int k, const float* centroids,

@@ -61,6 +61,27 @@ int HIPIVFPQModelParams::Parse(const char *str) {
   if (!jp.GetInt("support_indivisible_nsubvector", v)) support_indivisible_nsubvector = v != 0;
   if (!jp.GetInt("device_filters", v)) device_filters = v != 0;
   if (!jp.GetInt("exact_ties", v)) exact_ties = v != 0;
+  std::string devs;
+  if (!jp.GetString("devices", devs)) {   // "0,1,2,3" (the engine's JsonParser has no arrays)
+    devices.clear();
+    size_t at = 0;
+    while (at < devs.size()) {
+      size_t end = devs.find(',', at);
+      if (end == std::string::npos) end = devs.size();
+      const std::string tok = devs.substr(at, end - at);
+      char *rest = nullptr;
+      const long dv = strtol(tok.c_str(), &rest, 10);
+      if (tok.empty() || (rest && *rest != '\0' && *rest != ' ') || dv < 0) {
+        HLOG("invalid devices = %s", devs.c_str());
+        return -1;
+      }
+      devices.push_back((int)dv);
+      at = end + 1;
+    }
+  } else if (!jp.GetInt("devices", v)) {   // a single ordinal
+    if (v < 0) return -1;
+    devices.assign(1, v);
+  }
   if (!jp.GetInt("bucket_init_size", v)) {
     if (v < -1) return -1;
     if (v > 0) bucket_init_size = v;
@@ -87,8 +108,33 @@ int HIPIVFPQModelParams::Parse(const char *str) {
 GammaIVFPQHIPIndex::GammaIVFPQHIPIndex() {}
 
 GammaIVFPQHIPIndex::~GammaIVFPQHIPIndex() {
-  if (h_) gamma_hip_destroy(h_);
+  if (grp_) gamma_hip_group_destroy(grp_);   // owns its members, h_ among them
+  else if (h_) gamma_hip_destroy(h_);
   delete model_param_;
+}
+
+// one handle, or a group of handles with the lists sharded by owner (gamma_hip_group_*; what the reference's GPU model
+// does with IndexShards, index/impl/gpu/gamma_gpu_cloner.cpp:200-269)
+int GammaIVFPQHIPIndex::OpenDevices(const std::vector<int> &devices) {
+  if (devices.size() > 1) {
+    int rc = gamma_hip_group_create(devices.data(), (int)devices.size(), &grp_);
+    if (rc) {
+      HLOG("gamma_hip_group_create failed: %s", gamma_hip_strerror(rc));
+      return -1;
+    }
+    for (int i = 0; i < gamma_hip_group_size(grp_); i++) members_.push_back(gamma_hip_group_member(grp_, i));
+    h_ = members_[0];
+    return 0;
+  }
+  const char *dev = getenv("GAMMA_HIP_DEVICE");
+  const int ordinal = devices.size() == 1 ? devices[0] : (dev ? atoi(dev) : 0);
+  int rc = gamma_hip_create(ordinal, &h_);
+  if (rc) {
+    HLOG("gamma_hip_create failed: %s", gamma_hip_strerror(rc));
+    return -1;
+  }
+  members_.assign(1, h_);
+  return 0;
 }
 
 int GammaIVFPQHIPIndex::Init(const std::string &model_parameters, int indexing_size) {
@@ -114,17 +160,19 @@ int GammaIVFPQHIPIndex::Init(const std::string &model_parameters, int indexing_s
   M_ = pa.nsubvector;
   metric_type_ = pa.metric_type;
   nprobe_ = pa.nprobe;
-  const char *dev = getenv("GAMMA_HIP_DEVICE");
-  int rc = gamma_hip_create(dev ? atoi(dev) : 0, &h_);
-  if (rc) {
-    HLOG("gamma_hip_create failed: %s", gamma_hip_strerror(rc));
-    return -1;
+  if (pa.devices.size() > 1 && pa.device_filters) {
+    HLOG("device_filters with several devices is not supported (the columns live on one handle)");
+    return -2;
   }
-  rc = gamma_hip_ivfpq_init(h_, d_, nlist_, M_, 8,
-                            metric_type_ == DistanceComputeType::L2 ? GAMMA_HIP_METRIC_L2 : GAMMA_HIP_METRIC_IP,
-                            pa.bucket_init_size, pa.bucket_max_size);
-  if (!rc) rc = gamma_hip_raw_init(h_, d_);
-  if (!rc) rc = gamma_hip_set_exact_ties(h_, pa.exact_ties ? 1 : 0);
+  if (OpenDevices(pa.devices)) return -1;
+  int rc = ForAll([&](gamma_hip_index *m) {
+    int r = gamma_hip_ivfpq_init(m, d_, nlist_, M_, 8,
+                                 metric_type_ == DistanceComputeType::L2 ? GAMMA_HIP_METRIC_L2 : GAMMA_HIP_METRIC_IP,
+                                 pa.bucket_init_size, pa.bucket_max_size);
+    if (!r) r = gamma_hip_raw_init(m, d_);
+    if (!r) r = gamma_hip_set_exact_ties(m, pa.exact_ties ? 1 : 0);
+    return r;
+  });
   if (rc) {
     HLOG("device init failed: %s (%s)", gamma_hip_strerror(rc), gamma_hip_last_error(h_));
     return -1;
@@ -234,7 +282,18 @@ int GammaIVFPQHIPIndex::Indexing() {
   size_t num = 0;
   if (TrainingSet(xt, num)) return -1;
   int rc = TrainOnHost(num, xt.data());
-  if (!rc) rc = gamma_hip_ivfpq_set_trained(h_, coarse_centroids_.data(), pq_centroids_.data(), nullptr);
+  if (!rc) rc = ForAll([&](gamma_hip_index *m) {
+    return gamma_hip_ivfpq_set_trained(m, coarse_centroids_.data(), pq_centroids_.data(), nullptr);
+  });
+  if (!rc && grp_) {
+    // list -> GPU by the training set's list sizes, balanced greedily: the lists never move afterwards
+    std::vector<int32_t> assign(num);
+    rc = gamma_hip_assign(h_, d_, (int64_t)num, xt.data(), nlist_, coarse_centroids_.data(), assign.data(), nullptr);
+    std::vector<int64_t> weight(nlist_, 0);
+    for (size_t i = 0; i < num && !rc; i++)
+      if (assign[i] >= 0 && assign[i] < nlist_) weight[assign[i]]++;
+    if (!rc) rc = gamma_hip_group_set_owners(grp_, weight.data());
+  }
   if (rc) {
     HLOG("training failed: %s (%s)", gamma_hip_strerror(rc), gamma_hip_last_error(h_));
     return -1;
@@ -272,13 +331,13 @@ bool GammaIVFPQHIPIndex::Add(int n, const uint8_t *vec) {
   if (EnsureRaw(indexed_vec_count_)) return false;
   {
     std::lock_guard<std::mutex> g(raw_mu_);
-    if (gamma_hip_raw_write(h_, indexed_vec_count_, n, v)) return false;
+    if (ForAll([&](gamma_hip_index *m) { return gamma_hip_raw_write(m, indexed_vec_count_, n, v); })) return false;
     raw_uploaded_ = std::max(raw_uploaded_, end);
   }
   if (SyncVid2DocID(end)) return false;   // before AddKeys: it counts vectors of deleted DOCS (realtime_mem_data.cc:294)
-  int rc = gamma_hip_ivfpq_add(h_, n, v, indexed_vec_count_);
+  int rc = grp_ ? gamma_hip_group_ivfpq_add(grp_, n, v, indexed_vec_count_) : gamma_hip_ivfpq_add(h_, n, v, indexed_vec_count_);
   if (rc) {
-    HLOG("add failed: %s (%s)", gamma_hip_strerror(rc), gamma_hip_last_error(h_));
+    HLOG("add failed: %s (%s)", gamma_hip_strerror(rc), grp_ ? gamma_hip_group_last_error(grp_) : gamma_hip_last_error(h_));
     return false;
   }
   indexed_vec_count_ += n;
@@ -286,16 +345,26 @@ bool GammaIVFPQHIPIndex::Add(int n, const uint8_t *vec) {
 }
 
 int GammaIVFPQHIPIndex::Update(const std::vector<int64_t> &ids, const std::vector<const uint8_t *> &vecs) {
-  for (size_t i = 0; i < ids.size(); i++) {
-    const float *v = reinterpret_cast<const float *>(vecs[i]);
-    int64_t lno = -1;
-    std::vector<uint8_t> code(M_);
-    if (gamma_hip_ivfpq_encode(h_, 1, v, &lno, code.data())) return -1;
-    if (gamma_hip_ivfpq_update(h_, (int)lno, ids[i], code.data())) return -1;
-    std::lock_guard<std::mutex> g(raw_mu_);
-    if (ids[i] < raw_uploaded_ && gamma_hip_raw_update(h_, ids[i], v)) return -1;
+  // the engine drains up to 20 000 updated vids per pass (vector/vector_manager.cc:355-380): ONE encode of the batch
+  // (each vector assigned as quantizer->assign(1, ..) assigns it, gamma_index_ivfpq.cc:398), the list updates in
+  // order, one publish -- instead of two device round trips per vid
+  const size_t n = ids.size();
+  if (n == 0) return 0;
+  if (vecs.size() != n) return -1;
+  std::vector<float> x(n * (size_t)d_);
+  for (size_t i = 0; i < n; i++) memcpy(&x[i * d_], vecs[i], sizeof(float) * d_);
+  int rc = grp_ ? gamma_hip_group_ivfpq_update(grp_, (int)n, ids.data(), x.data())
+                : gamma_hip_ivfpq_update_batch(h_, (int)n, ids.data(), x.data());
+  if (rc) {
+    HLOG("update failed: %s (%s)", gamma_hip_strerror(rc), grp_ ? gamma_hip_group_last_error(grp_) : gamma_hip_last_error(h_));
+    return -1;
   }
-  gamma_hip_ivfpq_compact_if_need(h_);   // gamma_index_ivfpq.cc:420
+  {
+    std::lock_guard<std::mutex> g(raw_mu_);   // rows the mirror has not reached yet are skipped: EnsureRaw brings them
+    if (ForAll([&](gamma_hip_index *m) { return gamma_hip_raw_update_batch(m, (int64_t)n, ids.data(), x.data()); })) return -1;
+  }
+  if (grp_) gamma_hip_group_ivfpq_compact_if_need(grp_);
+  else gamma_hip_ivfpq_compact_if_need(h_);   // gamma_index_ivfpq.cc:420
   return 0;
 }
 
@@ -308,7 +377,8 @@ int GammaIVFPQHIPIndex::Delete(const std::vector<int64_t> &ids) {
   RawVector *rv = dynamic_cast<RawVector *>(vector_);
   if (rv && rv->VidMgr() && rv->VidMgr()->MultiVids())
     for (size_t i = 0; i < docs.size(); i++) docs[i] = rv->VidMgr()->VID2DocID((int)ids[i]);
-  if (gamma_hip_bitmap_set(h_, docs.data(), (int64_t)docs.size(), 1)) return -1;
+  if (ForAll([&](gamma_hip_index *m) { return gamma_hip_bitmap_set(m, docs.data(), (int64_t)docs.size(), 1); })) return -1;
+  if (grp_) return gamma_hip_group_ivfpq_delete(grp_, ids.data(), (int)ids.size()) ? -1 : 0;
   return gamma_hip_ivfpq_delete(h_, ids.data(), (int)ids.size()) ? -1 : 0;
 }
 
@@ -344,10 +414,11 @@ int GammaIVFPQHIPIndex::Search(RetrievalContext *retrieval_context, int n, const
   } else {
     // nprobe rule of gamma_index_ivfpq.cc:539-545
     p.nprobe = (rp->Nprobe() > 0 && rp->Nprobe() <= nlist_) ? rp->Nprobe() : nprobe_;
-    rc = gamma_hip_ivfpq_search(h_, &p, n, xq, k, distances, ids);
+    rc = grp_ ? gamma_hip_group_ivfpq_search(grp_, &p, n, xq, k, distances, ids)
+              : gamma_hip_ivfpq_search(h_, &p, n, xq, k, distances, ids);
   }
   if (rc) {
-    HLOG("search failed: %s (%s)", gamma_hip_strerror(rc), gamma_hip_last_error(h_));
+    HLOG("search failed: %s (%s)", gamma_hip_strerror(rc), grp_ ? gamma_hip_group_last_error(grp_) : gamma_hip_last_error(h_));
     return rc;
   }
   return 0;
@@ -367,7 +438,7 @@ int GammaIVFPQHIPIndex::EnsureRaw(int64_t upto) {
     if (vector_->Gets(vids, sv)) return -1;
     std::vector<float> buf((size_t)nb * d_);
     for (int64_t i = 0; i < nb; i++) memcpy(&buf[(size_t)i * d_], sv.Get((int)i), sizeof(float) * d_);
-    if (gamma_hip_raw_write(h_, i0, nb, buf.data())) return -1;
+    if (ForAll([&](gamma_hip_index *m) { return gamma_hip_raw_write(m, i0, nb, buf.data()); })) return -1;
     raw_uploaded_ = i0 + nb;
   }
   return 0;
@@ -385,25 +456,35 @@ int GammaIVFPQHIPIndex::SyncVid2DocID(int64_t upto) {
   if (upto <= have) return 0;
   std::vector<int32_t> m((size_t)(upto - have));
   for (int64_t v = have; v < upto; v++) m[(size_t)(v - have)] = rv->VidMgr()->VID2DocID((int)v);
-  return gamma_hip_vid2docid_append(h_, (int64_t)m.size(), m.data());
+  return ForAll([&](gamma_hip_index *mm) { return gamma_hip_vid2docid_append(mm, (int64_t)m.size(), m.data()); });
 }
 
 int GammaIVFPQHIPIndex::UploadEngineBitmap() {
   RawVector *rv = dynamic_cast<RawVector *>(vector_);
   if (!rv || !rv->Bitmap() || rv->Bitmap()->BitSize() == 0) return 0;
-  return gamma_hip_bitmap_upload(h_, reinterpret_cast<const uint8_t *>(rv->Bitmap()->Bitmap()),
-                                 (int64_t)rv->Bitmap()->BitSize());
+  return ForAll([&](gamma_hip_index *m) {
+    return gamma_hip_bitmap_upload(m, reinterpret_cast<const uint8_t *>(rv->Bitmap()->Bitmap()), (int64_t)rv->Bitmap()->BitSize());
+  });
 }
 
 int GammaIVFPQHIPIndex::SetTrained(const float *coarse, const float *pq) {
   coarse_centroids_.assign(coarse, coarse + (size_t)nlist_ * d_);
   pq_centroids_.assign(pq, pq + (size_t)M_ * 256 * (d_ / M_));
-  if (gamma_hip_ivfpq_set_trained(h_, coarse_centroids_.data(), pq_centroids_.data(), nullptr)) return -1;
+  if (ForAll([&](gamma_hip_index *m) {
+        return gamma_hip_ivfpq_set_trained(m, coarse_centroids_.data(), pq_centroids_.data(), nullptr);
+      }))
+    return -1;
+  // several GPUs: no list sizes to balance yet -- lists are dealt round robin (Indexing balances by the training
+  // set's assignment, Load by the dumped sizes)
+  if (grp_ && gamma_hip_group_owner(grp_, 0) < 0 && gamma_hip_group_set_owners(grp_, nullptr)) return -1;
   is_trained_ = true;
   return 0;
 }
 
-long GammaIVFPQHIPIndex::GetTotalMemBytes() { return h_ ? (long)gamma_hip_total_mem_bytes(h_) : 0; }
+long GammaIVFPQHIPIndex::GetTotalMemBytes() {
+  if (grp_) return (long)gamma_hip_group_total_mem_bytes(grp_);
+  return h_ ? (long)gamma_hip_total_mem_bytes(h_) : 0;
+}
 
 // Dump / Load in the reference's own file format (gamma_index_ivfpq.cc:958-1048): an index dumped by
 // the CPU "IVFPQ" model loads here and the other way round (iwpq_io.h for the record layout).
@@ -433,13 +514,15 @@ int GammaIVFPQHIPIndex::Dump(const std::string &dir) {
   f.codes.resize(nlist_);
   f.ids.resize(nlist_);
   for (int l = 0; l < nlist_; l++) {
-    const int64_t len = gamma_hip_ivfpq_list_size(h_, l);
+    const int64_t len = grp_ ? gamma_hip_group_ivfpq_list_size(grp_, l) : gamma_hip_ivfpq_list_size(h_, l);
     if (len < 0) return -1;
     f.sizes[l] = (size_t)len;
     if (len == 0) continue;
     f.ids[l].resize(len);
     f.codes[l].resize((size_t)len * M_);
-    if (gamma_hip_ivfpq_get_list(h_, l, f.ids[l].data(), f.codes[l].data())) return -1;
+    if (grp_ ? gamma_hip_group_ivfpq_get_list(grp_, l, f.ids[l].data(), f.codes[l].data())
+             : gamma_hip_ivfpq_get_list(h_, l, f.ids[l].data(), f.codes[l].data()))
+      return -1;
   }
   if (WriteIwPQ(index_dir + "/ivfpq.index", f)) {
     HLOG("write error, index dir=%s", index_dir.c_str());
@@ -467,6 +550,11 @@ int GammaIVFPQHIPIndex::Load(const std::string &dir) {
     HLOG("index file does not match the table's retrieval_param");
     return -1;
   }
+  if (grp_) {   // several GPUs: list -> GPU balanced by the dumped list sizes, before the lists come back
+    std::vector<int64_t> weight(nlist_);
+    for (int l = 0; l < nlist_; l++) weight[l] = (int64_t)f.sizes[l];
+    if (gamma_hip_group_set_owners(grp_, weight.data())) return -1;
+  }
   if (SetTrained(f.coarse.data(), f.pq.data())) return -1;   // T2 is recomputed, as in the reference
   // deletes that happened before the restart: the bitmap must be in place BEFORE the lists come back, so that
   // AddKeys counts the deleted entries per list as the reference does (realtime_mem_data.cc:293-296)
@@ -477,7 +565,9 @@ int GammaIVFPQHIPIndex::Load(const std::string &dir) {
   for (int l = 0; l < nlist_; l++) {
     const size_t n = f.sizes[l];
     if (n == 0) continue;
-    if (gamma_hip_ivfpq_add_keys(h_, l, (int)n, f.ids[l].data(), f.codes[l].data())) return -1;
+    if (grp_ ? gamma_hip_group_ivfpq_add_keys(grp_, l, (int)n, f.ids[l].data(), f.codes[l].data())
+             : gamma_hip_ivfpq_add_keys(h_, l, (int)n, f.ids[l].data(), f.codes[l].data()))
+      return -1;
     for (size_t i = 0; i < n; i++)
       if (f.ids[l][i] >= 0) count++;   // bit 63 = superseded by an Update (gamma_index_io.cc:186-189)
   }

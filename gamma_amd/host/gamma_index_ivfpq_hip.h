@@ -54,6 +54,8 @@ struct HIPIVFPQModelParams {
   int bucket_max_size = 1280000;
   bool device_filters = false;   // HIP only: evaluate range / term filters on device-resident columns (filter_bridge.h)
   bool exact_ties = true;        // HIP only: the reference's heap order inside exact distance ties (gamma_hip_set_exact_ties)
+  std::vector<int> devices;      // HIP only: "devices": "0,1,2,3" -- the index sharded by IVF list over these GPUs in this
+                                 // process (gamma_hip_group_*); empty: one GPU, GAMMA_HIP_DEVICE or 0
   int Parse(const char *str);   // 0 ok, -1 bad (same rules as gamma_index_ivfpq.h:708-851)
 };
 
@@ -92,6 +94,19 @@ class GammaIVFPQHIPIndex : public RetrievalModel {
   int SyncVid2DocID(int64_t upto);   // multi-vector documents: docids of vids [0, upto) to the device (VIDMgr)
   std::mutex raw_mu_;   // raw_uploaded_ + the mirror writes (Search threads, the indexing thread, Load)
   DeviceColumns columns_;
+  // one GPU: h_ alone.  "devices" with several entries: a group of handles, lists sharded by owner; h_ is member 0 and
+  // serves what needs no lists (training's assignment step, brute-force search over the replicated raw vectors)
+  gamma_hip_group *grp_ = nullptr;
+  std::vector<gamma_hip_index *> members_;   // where replicated state goes: {h_} or every member of the group
+  template <typename F>
+  int ForAll(F f) {
+    for (gamma_hip_index *m : members_) {
+      const int rc = f(m);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  int OpenDevices(const std::vector<int> &devices);
   gamma_hip_index *h_ = nullptr;
   HIPIVFPQModelParams *model_param_ = nullptr;
   int64_t raw_uploaded_ = 0;

@@ -100,6 +100,18 @@ int gh_host_update(void *hp, int64_t vid, const float *x) {
   std::vector<const uint8_t *> vecs{reinterpret_cast<const uint8_t *>(x)};
   return h->model->Update(ids, vecs);
 }
+// the engine's update pass (vector/vector_manager.cc:355-380): a batch of updated vids handed to the model at once
+int gh_host_update_batch(void *hp, int n, const int64_t *vids, const float *x) {
+  Host *h = (Host *)hp;
+  const int d = h->store->d_;
+  std::vector<int64_t> ids(vids, vids + n);
+  std::vector<const uint8_t *> vecs(n);
+  for (int i = 0; i < n; i++) {
+    memcpy(&h->store->data_[(size_t)vids[i] * d], x + (size_t)i * d, sizeof(float) * d);
+    vecs[i] = reinterpret_cast<const uint8_t *>(x + (size_t)i * d);
+  }
+  return h->model->Update(ids, vecs);
+}
 // GammaEngine::Delete (search/gamma_engine.cc:802-824): the doc bit in the engine's bitmap, then the models
 int gh_host_delete(void *hp, const int64_t *vids, int n) {
   Host *h = (Host *)hp;

@@ -22,6 +22,7 @@ HOST_SYMBOLS = {
     "gh_host_indexing": (C.c_int, [C.c_void_p]),
     "gh_host_add": (C.c_int, [C.c_void_p, C.c_int, f32p]),
     "gh_host_update": (C.c_int, [C.c_void_p, C.c_int64, f32p]),
+    "gh_host_update_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), f32p]),
     "gh_host_delete": (C.c_int, [C.c_void_p, i64p, C.c_int]),
     "gh_host_engine_bitmap_set": (None, [C.c_void_p, i64p, C.c_int]),
     "gh_host_search_during_add": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p,
@@ -166,6 +167,11 @@ class PluginModel:
     def update(self, vid, x):
         x = np.ascontiguousarray(x, np.float32)
         return self.L.gh_host_update(self.h, vid, _f(x))
+
+    def update_batch(self, vids, x):
+        vids = np.ascontiguousarray(vids, np.int64)
+        x = np.ascontiguousarray(x, np.float32)
+        return self.L.gh_host_update_batch(self.h, len(vids), vids.ctypes.data_as(C.POINTER(C.c_int64)), _f(x))
 
     def delete(self, vids):
         v = np.ascontiguousarray(vids, np.int64)

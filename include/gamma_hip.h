@@ -172,6 +172,8 @@ int64_t gamma_hip_term_count(gamma_hip_index* h, int field_id);
 int gamma_hip_raw_init(gamma_hip_index* h, int d);
 int gamma_hip_raw_append(gamma_hip_index* h, int64_t n, const float* vecs);
 int gamma_hip_raw_update(gamma_hip_index* h, int64_t vid, const float* vec);
+/* n rows rewritten with one wait for the device (vids the mirror has not reached yet are skipped) */
+int gamma_hip_raw_update_batch(gamma_hip_index* h, int64_t n, const int64_t* vids, const float* vecs);
 /* rows [first_vid, first_vid + n) written at their own position: idempotent (a repeated or overlapping
  * call rewrites the same rows with the same bytes), the row count only ever grows to first_vid + n.
  * first_vid may not leave a gap (first_vid <= gamma_hip_raw_count).  This is what a mirror of the engine's
@@ -194,6 +196,10 @@ int gamma_hip_ivfpq_init(gamma_hip_index* h, int d, int nlist, int M, int nbits,
 int gamma_hip_ivfpq_set_trained(gamma_hip_index* h, const float* coarse_centroids,
                                 const float* pq_centroids, const float* precomputed_table);
 int gamma_hip_ivfpq_get_precomputed_table(gamma_hip_index* h, float* out);
+/* shape of an initialised model: dimension, number of lists, bytes per code (nsubvector; 1 for IVFFLAT); 0 before Init */
+int gamma_hip_ivfpq_dim(gamma_hip_index* h);
+int gamma_hip_ivfpq_nlist(gamma_hip_index* h);
+int gamma_hip_ivfpq_code_size(gamma_hip_index* h);
 
 /* ---- realtime inverted lists (realtime::RTInvertIndex, realtime/realtime_invert_index.h)
  *      resident in HBM ----------------------------------------------------------------- */
@@ -211,6 +217,18 @@ int gamma_hip_ivfpq_update(gamma_hip_index* h, int list_no, int64_t vid, const u
  * entry of vids[i]; _remove: the first half of RealTimeMemData::Update (:318-321) alone -- the entry is flagged
  * as moved away and counted as deleted; unknown vids are ignored like Update ignores them (:307-311). */
 int gamma_hip_ivfpq_has_vid(gamma_hip_index* h, const int64_t* vids, int n, uint8_t* out);
+/* GammaIVFPQIndex::Update for a batch of n vectors (gamma_index_ivfpq.cc:375-422; the engine drains up to 20 000
+ * updated vids per pass, vector/vector_manager.cc:355-380): every vector is assigned and encoded the way a call of
+ * its own assigns it (quantizer->assign(1, ..), the exact form), in ONE device pass; then RTInvertIndex::Update for
+ * each (vid, list, code) in order, one publish of the lists' tables, one wait for the device.  vecs: n*d fp32. */
+int gamma_hip_ivfpq_update_batch(gamma_hip_index* h, int n, const int64_t* vids, const float* vecs);
+/* the encode half alone (list_nos[n], codes[n*code_size] to host), and the list half alone with the codes supplied:
+ * ops[i] = 0 Update (a vid this handle does not hold is ignored, realtime_mem_data.cc:307-311), 1 = the vid is held by
+ * ANOTHER shard of a list-sharded index and joins list_nos[i] here (AddKeys), 2 = the vid leaves this shard (the first
+ * half of Update: flagged as moved, counted as deleted); ops == NULL: all 0.  (gamma_hip_group_ivfpq_update) */
+int gamma_hip_ivfpq_encode_each(gamma_hip_index* h, int64_t n, const float* vecs, int64_t* list_nos, uint8_t* codes);
+int gamma_hip_ivfpq_apply_updates(gamma_hip_index* h, int n, const int32_t* list_nos, const int64_t* vids,
+                                  const uint8_t* codes, const uint8_t* ops);
 int gamma_hip_ivfpq_remove(gamma_hip_index* h, int64_t vid);
 /* RTInvertIndex::Delete (realtime_mem_data.cc:329-335,190-199): counter only */
 int gamma_hip_ivfpq_delete(gamma_hip_index* h, const int64_t* vids, int n);
@@ -318,6 +336,43 @@ int gamma_hip_flat_search(gamma_hip_index* h, const gamma_hip_search_params* p, 
                           const float* x, int k, float* distances, int64_t* labels);
 int gamma_hip_flat_search_device(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
                                  const float* d_x, int k, float* d_distances, int64_t* d_labels);
+
+/* ---- several GPUs in ONE process: a group of handles, the index sharded by IVF list ----------------------------
+ * What the reference's GPU model does with faiss's IndexShards / GpuClonerOptions (index/impl/gpu/gamma_gpu_cloner.cpp:200-269,
+ * index/impl/gpu/gamma_index_ivfpq_gpu.cc:356-436, faiss:IndexShards.cpp:283-345): one index object, a host thread per
+ * GPU, every search fanned out and merged.  Here member i is an ordinary handle on devices[i] (several members may
+ * share a device: tests) that owns the lists owner(l) == i; centroids, codebooks, T2, the delete bitmap and the raw
+ * vectors are replicated (broadcast the replicated state yourself through gamma_hip_group_member, as the plugins do).
+ * A search: every member runs the coarse quantizer for its slice of the queries, the assignment is exchanged
+ * (device-to-device copies), every member scans the probed lists it owns for the whole batch and keeps a local
+ * top-recall_num, each member pulls the candidates of ITS query slice from all members, merges them (k_merge_shards) and
+ * runs compute_dis.  Results equal those of one handle holding every list: same distances at every rank, same ids
+ * up to the order inside exact ties.  The multi-process form of the same steps over RCCL is gamma_amd/dist.py. */
+typedef struct gamma_hip_group gamma_hip_group;
+int gamma_hip_group_create(const int* devices, int n, gamma_hip_group** out);
+int gamma_hip_group_destroy(gamma_hip_group* g);
+int gamma_hip_group_size(const gamma_hip_group* g);
+gamma_hip_index* gamma_hip_group_member(gamma_hip_group* g, int i);
+const char* gamma_hip_group_last_error(gamma_hip_group* g);
+/* list -> member.  weights[nlist] (expected or actual list sizes: the training set's assignment counts, the sizes in a
+ * dump) are balanced greedily, heaviest list first -- probe popularity follows list size, so this balances scan
+ * bytes; NULL: l mod n.  Call once, after gamma_hip_ivfpq_init on every member and before the first Add. */
+int gamma_hip_group_set_owners(gamma_hip_group* g, const int64_t* weights);
+int gamma_hip_group_owner(const gamma_hip_group* g, int list_no);
+/* GammaIVFPQIndex::Add: ONE encode (members take turns), then AddKeys at the owner of every assigned list */
+int gamma_hip_group_ivfpq_add(gamma_hip_group* g, int64_t n, const float* vecs, int64_t first_vid);
+/* AddKeys / list read-back at the owner (Load / Dump) */
+int gamma_hip_group_ivfpq_add_keys(gamma_hip_group* g, int list_no, int n, const int64_t* vids, const uint8_t* codes);
+int64_t gamma_hip_group_ivfpq_list_size(gamma_hip_group* g, int list_no);
+int gamma_hip_group_ivfpq_get_list(gamma_hip_group* g, int list_no, int64_t* vids, uint8_t* codes);
+/* GammaIVFPQIndex::Update: one encode; the member holding the old entry flags it, the owner of the new list appends */
+int gamma_hip_group_ivfpq_update(gamma_hip_group* g, int n, const int64_t* vids, const float* vecs);
+int gamma_hip_group_ivfpq_delete(gamma_hip_group* g, const int64_t* vids, int n);
+int gamma_hip_group_ivfpq_compact_if_need(gamma_hip_group* g);
+/* GammaIVFPQIndex::Search over all members; host buffers as gamma_hip_ivfpq_search */
+int gamma_hip_group_ivfpq_search(gamma_hip_group* g, const gamma_hip_search_params* p, int nq, const float* x, int k,
+                                 float* distances, int64_t* labels);
+int64_t gamma_hip_group_total_mem_bytes(gamma_hip_group* g);
 
 /* ---- accounting (GetTotalMemBytes, index/retrieval_model.h:287; PerfTool :23-50) ------ */
 int64_t gamma_hip_total_mem_bytes(gamma_hip_index* h);
