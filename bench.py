@@ -54,6 +54,9 @@ def main():
                     help="torch.distributed backend; 'gloo' with --one-gpu runs all ranks on GPU 0 (functional "
                          "check of the multi-rank path on a single-GPU box, not a measurement)")
     ap.add_argument("--one-gpu", action="store_true", help="every rank uses cuda:0")
+    ap.add_argument("--in-process", action="store_true",
+                    help="--gpus N through ONE process: the in-process group of handles (gamma_hip_group_*, what the "
+                         "plugins run with \"devices\"), tools/group_bench.py")
     ap.add_argument("--no-exact-ties", action="store_true",
                     help="run the timed region WITHOUT the reference's heap order inside exact ties (the library default "
                          "is on: labels identical to the reference at every rank)")
@@ -71,6 +74,13 @@ def main():
     # `python bench.py --gpus N` without a launcher: this process only starts the N ranks (one fresh process per
     # GPU, RCCL rendezvous on 127.0.0.1) -- BEFORE anything here touches the GPU -- and waits for them; rank 0
     # prints the line.  Under torchrun (WORLD_SIZE set) the world size must BE --gpus.
+    if a.in_process:   # one process, N handles: a child of its own (this process has not touched the GPU yet)
+        import subprocess
+        cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "group_bench.py"),
+               "--gpus", str(a.gpus), "--steps", str(a.steps), "--warmup", str(a.warmup), "--nq", str(a.nq)]
+        if a.one_gpu:
+            cmd.append("--one-gpu")
+        sys.exit(subprocess.call(cmd))
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(spawn_ranks(a.gpus))
     if int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:

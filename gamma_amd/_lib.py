@@ -134,6 +134,8 @@ SYMBOLS = {
     "gamma_hip_group_ivfpq_delete": (C.c_int, [C.c_void_p, i64p, C.c_int]),
     "gamma_hip_group_ivfpq_compact_if_need": (C.c_int, [C.c_void_p]),
     "gamma_hip_group_ivfpq_search": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int, f32p, C.c_int, f32p, i64p]),
+    "gamma_hip_group_ivfpq_search_device": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int, C.c_void_p, C.c_int,
+                                                      C.c_void_p, C.c_void_p]),
     "gamma_hip_group_total_mem_bytes": (C.c_int64, [C.c_void_p]),
     "gamma_hip_total_mem_bytes": (C.c_int64, [C.c_void_p]),
     "gamma_hip_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),

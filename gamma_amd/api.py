@@ -515,5 +515,10 @@ class GammaHipGroup:
                                                      _p(I, _lib.i64p)), "group_search")
         return D, I
 
+    def ivfpq_search_device(self, d_x, nq, k, args, d_D, d_I):
+        """queries / results in the memory of member 0's device (raw pointers); synchronous"""
+        self._ck(self.L.gamma_hip_group_ivfpq_search_device(self.g, C.byref(args.p), nq, C.c_void_p(d_x), k, C.c_void_p(d_D),
+                                                            C.c_void_p(d_I)), "group_search_device")
+
     def total_mem_bytes(self):
         return self.L.gamma_hip_group_total_mem_bytes(self.g)

@@ -90,7 +90,7 @@ int gamma_hip_destroy(gamma_hip_index* h) {
         (void)hipEventDestroy(e.b);
     }
     void* ptrs[] = {h->d_list_rank, h->d_raw, h->d_bitmap, h->d_cc, h->d_cc_norms, h->d_pqc, h->d_T2, h->d_codes,
-                    h->d_ids, h->d_list_mask, h->d_scan_codes, h->d_tie_stats, h->d_v2d};
+                    h->d_ids, h->d_list_mask, h->d_scan_codes, h->d_tie_stats, h->d_v2d, h->d_sums, h->d_t2max};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& kv : h->fields)
@@ -197,7 +197,10 @@ int64_t gamma_hip_total_mem_bytes(gamma_hip_index* h) {
         b += (int64_t)h->nlist * h->d * 4 + (int64_t)h->nlist * 4 + (int64_t)h->M * 256 * h->dsub * 4;
         b += (int64_t)h->nlist * h->M * 256 * 4;
         b += h->arena_cap * (h->code_size + (int64_t)sizeof(int64_t));
+        if (h->d_sums) b += h->arena_cap * (int64_t)sizeof(float) + (int64_t)h->nlist * 4;
         b += (int64_t)h->nlist * 12;
+        // the shadow arena of calls that run over lists compacted under their filter (kept between calls)
+        b += (int64_t)(h->w_cmp_codes.cap + h->w_cmp_ids.cap + h->w_cmp_len.cap);
     }
     return b;
 }

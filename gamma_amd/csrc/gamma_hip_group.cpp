@@ -410,8 +410,23 @@ int64_t gamma_hip_group_total_mem_bytes(gamma_hip_group* g) {
     return t;
 }
 
+static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, int nq, const float* x, int k,
+                        float* distances, int64_t* labels, bool on_device);
+
 int gamma_hip_group_ivfpq_search(gamma_hip_group* g, const gamma_hip_search_params* p, int nq, const float* x, int k,
                                  float* distances, int64_t* labels) {
+    return group_search(g, p, nq, x, k, distances, labels, false);
+}
+
+int gamma_hip_group_ivfpq_search_device(gamma_hip_group* g, const gamma_hip_search_params* p, int nq, const float* d_x, int k,
+                                        float* d_distances, int64_t* d_labels) {
+    return group_search(g, p, nq, d_x, k, d_distances, d_labels, true);
+}
+
+// on_device: x / distances / labels live on member 0's device (the other members pull the batch over the fabric and
+// push their slice of the results back); the call still returns when the results are in place
+static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, int nq, const float* x, int k,
+                        float* distances, int64_t* labels, bool on_device) {
     if (!g || !p) return GAMMA_HIP_EINVAL;
     if (nq < 0) return GAMMA_HIP_EINVAL;
     if (k <= 0 || nq == 0) return GAMMA_HIP_OK;   // gamma_index_ivfpq.cc:753-756
@@ -465,7 +480,8 @@ int gamma_hip_group_ivfpq_search(gamma_hip_group* g, const gamma_hip_search_para
         hip(b.I.ensure((size_t)per * k * sizeof(int64_t)), "alloc");
         // 0. the whole batch to every member (each scans its lists for all queries); coarse quantizer for the own slice
         if (rc == GAMMA_HIP_OK) {
-            hip(hipMemcpyAsync(b.x.p, x, (size_t)nq * d * sizeof(float), hipMemcpyHostToDevice, s), "H2D queries");
+            if (on_device) hip(copy_between(b.x.p, g->dev[i], x, g->dev[0], (size_t)nq * d * sizeof(float), s), "queries to the member");
+            else hip(hipMemcpyAsync(b.x.p, x, (size_t)nq * d * sizeof(float), hipMemcpyHostToDevice, s), "H2D queries");
             if (nql > 0)
                 abi(gamma_hip_ivfpq_coarse_device(h, &pp, nql, b.x.as<float>() + (size_t)q0 * d, b.cdis.as<float>() + (size_t)q0 * P,
                                                   b.probe.as<int32_t>() + (size_t)q0 * P));
@@ -508,7 +524,10 @@ int gamma_hip_group_ivfpq_search(gamma_hip_group* g, const gamma_hip_search_para
             if (rc == GAMMA_HIP_OK)
                 abi(gamma_hip_ivfpq_merge_rerank(h, &pp, W, per, b.x.as<float>() + (size_t)q0 * d, k, b.all_dis.as<float>(),
                                                  b.all_ids.as<int64_t>(), 0, nql, b.D.as<float>(), b.I.as<int64_t>()));
-            if (rc == GAMMA_HIP_OK) {
+            if (rc == GAMMA_HIP_OK && on_device) {
+                hip(copy_between(distances + (size_t)q0 * k, g->dev[0], b.D.p, g->dev[i], (size_t)nql * k * sizeof(float), s), "results");
+                hip(copy_between(labels + (size_t)q0 * k, g->dev[0], b.I.p, g->dev[i], (size_t)nql * k * sizeof(int64_t), s), "results");
+            } else if (rc == GAMMA_HIP_OK) {
                 hip(hipMemcpyAsync(distances + (size_t)q0 * k, b.D.p, (size_t)nql * k * sizeof(float), hipMemcpyDeviceToHost, s), "D2H");
                 hip(hipMemcpyAsync(labels + (size_t)q0 * k, b.I.p, (size_t)nql * k * sizeof(int64_t), hipMemcpyDeviceToHost, s), "D2H");
             }

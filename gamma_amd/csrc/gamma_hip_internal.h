@@ -145,6 +145,12 @@ struct gamma_hip_index {
     // inverted-list arena
     uint8_t* d_codes = nullptr;
     int64_t* d_ids = nullptr;
+    // L2 scan filter pass (k_ivfpq_scan_pair<.., CF>): per arena entry sum_m T2[list][m][code[m]], kept beside the codes
+    // by every writer; per list sum_m max_c |T2[l][m][c]| (the margin of the filter).  Null for IVFFLAT / inner-product
+    // indexes (the inner-product scan has no per-list table to avoid).
+    float* d_sums = nullptr;
+    float* d_t2max = nullptr;
+    bool keep_sums = false;   // set by Init: IVFPQ handles (GAMMA_HIP_NO_CODE_SUMS=1 turns the filter pass off)
     int64_t arena_cap = 0, arena_used = 0, arena_waste = 0;   // entries; waste = abandoned extents inside used
     int64_t repack_min_entries = 1 << 16;                     // no repack for less waste than this
     int64_t n_repacks = 0;

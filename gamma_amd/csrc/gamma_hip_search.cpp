@@ -393,6 +393,12 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         sb.store_all = (h->tie.on && lm) ? 1 : 0;
         sb.rq_count = h->w_scnt.as<int>();
         sb.rq_list = h->w_scnt.as<int>() + 1;
+        // filter pass of the consumers (kernels.hip, CF): needs the sums beside the arena the scan reads -- not the
+        // shadow arena of a call running over lists compacted under its filter
+        static const bool no_cf = getenv("GAMMA_HIP_NO_SCAN_CF") != nullptr;
+        const bool cf_ok = !no_cf && l2 && h->d_sums && h->d_t2max && !h->prefiltered && !lm;
+        sb.sums = cf_ok ? h->d_sums : nullptr;
+        sb.t2max = cf_ok ? h->d_t2max : nullptr;
         const unsigned long long* surv_c = nullptr;
         if (!lm) {
             scan(G, 0, PGN, &sb, true);

@@ -19,6 +19,14 @@ int arena_reserve(H* h, int64_t need_entries) {
         (void)hipFree(nc);
         return fail(h, GAMMA_HIP_ENOMEM, "arena growth: out of memory");
     }
+    float* ns = nullptr;
+    if (h->keep_sums && hipMalloc((void**)&ns, (size_t)ncap * sizeof(float)) != hipSuccess) {
+        (void)hipFree(nc);
+        (void)hipFree(ni);
+        return fail(h, GAMMA_HIP_ENOMEM, "arena growth: out of memory");
+    }
+    if (ns && h->d_sums && h->arena_used > 0)
+        GH_CHECK(h, hipMemcpyAsync(ns, h->d_sums, (size_t)h->arena_used * sizeof(float), hipMemcpyDeviceToDevice, h->wstream));
     if (h->arena_used > 0) {
         GH_CHECK(h, hipMemcpyAsync(nc, h->d_codes, (size_t)h->arena_used * h->code_size,
                                    hipMemcpyDeviceToDevice, h->wstream));
@@ -28,9 +36,26 @@ int arena_reserve(H* h, int64_t need_entries) {
     GH_CHECK(h, hipStreamSynchronize(h->wstream));
     if (h->d_codes) GH_CHECK(h, hipFree(h->d_codes));
     if (h->d_ids) GH_CHECK(h, hipFree(h->d_ids));
+    if (h->d_sums) GH_CHECK(h, hipFree(h->d_sums));
     h->d_codes = nc;
     h->d_ids = ni;
+    h->d_sums = ns;
     h->arena_cap = ncap;
+    return GAMMA_HIP_OK;
+}
+
+// sums of arena entries [pos, pos + n) of list l, behind the copy of their codes on the writer stream
+static int sums_range(H* h, int l, int64_t pos, int n) {
+    if (!h->d_sums || !h->trained || n <= 0) return GAMMA_HIP_OK;
+    gh::launch_code_sums_one(h->wstream, h->d_T2, h->d_codes, h->code_size, l, pos, n, h->d_sums);
+    return GAMMA_HIP_OK;
+}
+// every list at its current extent (after a repack, a compaction, a new table): the device tables of the current
+// version must be the host mirror's (publish_meta before)
+static int sums_all_lists(H* h) {
+    if (!h->d_sums || !h->trained) return GAMMA_HIP_OK;
+    gh::launch_code_sums_lists(h->wstream, h->d_T2, h->d_codes, h->code_size, h->d_list_off, h->d_list_len, h->nlist,
+                               std::max(1, h->max_list_len), h->d_sums);
     return GAMMA_HIP_OK;
 }
 
@@ -55,6 +80,12 @@ int arena_repack(H* h) {
         (void)hipFree(nc);
         return fail(h, GAMMA_HIP_ENOMEM, "arena repack: out of memory");
     }
+    float* ns = nullptr;
+    if (h->keep_sums && hipMalloc((void**)&ns, (size_t)ncap * sizeof(float)) != hipSuccess) {
+        (void)hipFree(nc);
+        (void)hipFree(ni);
+        return fail(h, GAMMA_HIP_ENOMEM, "arena repack: out of memory");
+    }
     GH_CHECK(h, h->we_stage.ensure((size_t)h->nlist * sizeof(int64_t)));
     GH_CHECK(h, hipMemcpyAsync(h->we_stage.p, noff.data(), (size_t)h->nlist * sizeof(int64_t), hipMemcpyHostToDevice, h->wstream));
     gh::launch_repack_lists(h->wstream, h->d_codes, h->d_ids, nc, ni, h->d_list_off, h->we_stage.as<int64_t>(),
@@ -62,14 +93,17 @@ int arena_repack(H* h) {
     GH_CHECK(h, hipStreamSynchronize(h->wstream));   // noff is a local; the old arrays are free to go
     GH_CHECK(h, hipFree(h->d_codes));
     GH_CHECK(h, hipFree(h->d_ids));
+    if (h->d_sums) GH_CHECK(h, hipFree(h->d_sums));
     h->d_codes = nc;
     h->d_ids = ni;
+    h->d_sums = ns;
     h->arena_cap = ncap;
     h->arena_used = total;
     h->arena_waste = 0;
     h->h_list_off = noff;
     h->n_repacks++;
-    return publish_meta(h);
+    GH_TRY(publish_meta(h));
+    return sums_all_lists(h);   // the sums follow their codes: recomputed at the new offsets (the caller drains the stream)
 }
 int arena_repack_if_need(H* h) {
     const int64_t min_waste = std::max<int64_t>(h->repack_min_entries, 1);
@@ -102,6 +136,9 @@ int list_ensure(H* h, int l, int add) {
                                    (size_t)len * h->code_size, hipMemcpyDeviceToDevice, h->wstream));
         GH_CHECK(h, hipMemcpyAsync(h->d_ids + noff, h->d_ids + h->h_list_off[l],
                                    (size_t)len * sizeof(int64_t), hipMemcpyDeviceToDevice, h->wstream));
+        if (h->d_sums)
+            GH_CHECK(h, hipMemcpyAsync(h->d_sums + noff, h->d_sums + h->h_list_off[l], (size_t)len * sizeof(float),
+                                       hipMemcpyDeviceToDevice, h->wstream));
     }
     h->arena_waste += cap;
     h->arena_used += ext;
@@ -119,6 +156,7 @@ int add_keys_locked(H* h, int l, int n, const int64_t* vids, const uint8_t* code
                                h->wstream));
     GH_CHECK(h, hipMemcpyAsync(h->d_codes + pos * h->code_size, codes, (size_t)n * h->code_size,
                                hipMemcpyHostToDevice, h->wstream));
+    GH_TRY(sums_range(h, l, pos, n));
     for (int i = 0; i < n; i++) {
         const int64_t v = vids[i];
         if (v < 0) {   // superseded slot restored from a dump (ReadInvertedLists, gamma_index_io.cc:186-189)
@@ -504,6 +542,7 @@ static int ivf_init_locked(gamma_hip_index* h, int d, int nlist, int M, int metr
     if (metric != GAMMA_HIP_METRIC_IP && metric != GAMMA_HIP_METRIC_L2) return fail(h, GAMMA_HIP_EINVAL, "bad metric");
     GH_CHECK(h, hipSetDevice(h->device));
     h->ivfflat = flat;
+    h->keep_sums = !flat && getenv("GAMMA_HIP_NO_CODE_SUMS") == nullptr;
     h->d = d;
     h->nlist = nlist;
     h->M = M;
@@ -582,9 +621,17 @@ int gamma_hip_ivfpq_set_trained(gamma_hip_index* h, const float* cc, const float
                                    hipMemcpyHostToDevice, h->wstream));
         GH_CHECK(h, hipStreamSynchronize(h->wstream));   // rank is a local
     }
+    if (h->keep_sums) {
+        if (!h->d_t2max) GH_CHECK(h, hipMalloc((void**)&h->d_t2max, (size_t)h->nlist * sizeof(float)));
+        gh::launch_t2_rowmax(h->wstream, h->d_T2, h->nlist, h->M, h->d_t2max);
+    }
     GH_CHECK(h, hipGetLastError());
     GH_CHECK(h, hipStreamSynchronize(h->wstream));
     h->trained = true;
+    if (h->ntotal > 0) {   // a new table under existing lists: their sums follow it
+        GH_TRY(sums_all_lists(h));
+        GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    }
     return GAMMA_HIP_OK;
 }
 
@@ -627,10 +674,17 @@ int gamma_hip_ivfpq_add_keys_batch(gamma_hip_index* h, int nlists, const int32_t
             GH_TRY(list_ensure(h, kv.first, (int)kv.second));
         }
     }
+    std::vector<int> r_list, r_n;      // the appended ranges, for the code sums (alive until the wait below)
+    std::vector<int64_t> r_pos;
+    int r_max = 0;
     for (int i = 0; i < nlists; i++) {
         const int l = list_nos[i], n = counts[i];
         if (n == 0) continue;
         const int64_t pos = h->h_list_off[l] + h->h_list_len[l];
+        r_list.push_back(l);
+        r_n.push_back(n);
+        r_pos.push_back(pos);
+        r_max = std::max(r_max, n);
         GH_CHECK(h, hipMemcpyAsync(h->d_ids + pos, vids + off, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, h->wstream));
         GH_CHECK(h, hipMemcpyAsync(h->d_codes + pos * h->code_size, codes + off * h->code_size,
                                    (size_t)n * h->code_size, hipMemcpyHostToDevice, h->wstream));
@@ -650,6 +704,17 @@ int gamma_hip_ivfpq_add_keys_batch(gamma_hip_index* h, int nlists, const int32_t
         if (h->h_list_len[l] > h->max_list_len) h->max_list_len = h->h_list_len[l];
         off += n;
     }
+    if (h->d_sums && h->trained && !r_list.empty()) {
+        const size_t nr = r_list.size(), o_n = nr * sizeof(int), o_pos = (2 * nr * sizeof(int) + 7) & ~(size_t)7;
+        GH_CHECK(h, h->we_stage.ensure(o_pos + nr * sizeof(int64_t)));
+        char* b = h->we_stage.as<char>();
+        GH_CHECK(h, hipMemcpyAsync(b, r_list.data(), nr * sizeof(int), hipMemcpyHostToDevice, h->wstream));
+        GH_CHECK(h, hipMemcpyAsync(b + o_n, r_n.data(), nr * sizeof(int), hipMemcpyHostToDevice, h->wstream));
+        GH_CHECK(h, hipMemcpyAsync(b + o_pos, r_pos.data(), nr * sizeof(int64_t), hipMemcpyHostToDevice, h->wstream));
+        gh::launch_code_sums_ranges(h->wstream, h->d_T2, h->d_codes, h->code_size, reinterpret_cast<int*>(b),
+                                    reinterpret_cast<int64_t*>(b + o_pos), reinterpret_cast<int*>(b + o_n), (int)nr, r_max,
+                                    h->d_sums);
+    }
     // publish the new lengths (and moved extents) after the copies, in stream order
     GH_TRY(publish_meta(h));
     GH_CHECK(h, hipStreamSynchronize(h->wstream));
@@ -668,6 +733,7 @@ int gamma_hip_ivfpq_update(gamma_hip_index* h, int list_no, int64_t vid, const u
     if (ob == list_no) {
         GH_CHECK(h, hipMemcpyAsync(h->d_codes + (h->h_list_off[ob] + op) * h->code_size, code, h->code_size,
                                    hipMemcpyHostToDevice, h->wstream));
+        GH_TRY(sums_range(h, ob, h->h_list_off[ob] + op, 1));
         GH_CHECK(h, hipStreamSynchronize(h->wstream));
         return GAMMA_HIP_OK;
     }
@@ -725,6 +791,7 @@ int gamma_hip_ivfpq_apply_updates(gamma_hip_index* h, int n, const int32_t* list
             const int ob = (int)(bp >> 32), opos = (int)(bp & 0xffffffff);
             if (op == 0 && ob == l) {   // same list: the code is rewritten in place
                 GH_CHECK(h, hipMemcpyAsync(h->d_codes + (h->h_list_off[ob] + opos) * cs, code, cs, hipMemcpyHostToDevice, h->wstream));
+                GH_TRY(sums_range(h, ob, h->h_list_off[ob] + opos, 1));
                 continue;
             }
             gh::launch_mark_moved(h->wstream, h->d_ids, h->h_list_off[ob] + opos);
@@ -738,6 +805,7 @@ int gamma_hip_ivfpq_apply_updates(gamma_hip_index* h, int n, const int32_t* list
         const int64_t pos = h->h_list_off[l] + h->h_list_len[l];
         GH_CHECK(h, hipMemcpyAsync(h->d_ids + pos, vids + i, sizeof(int64_t), hipMemcpyHostToDevice, h->wstream));
         GH_CHECK(h, hipMemcpyAsync(h->d_codes + pos * cs, code, cs, hipMemcpyHostToDevice, h->wstream));
+        GH_TRY(sums_range(h, l, pos, 1));
         if ((size_t)vid >= h->vid_pos.size()) h->vid_pos.resize(std::max<size_t>(h->vid_pos.size() * 2, vid + 1), -1);
         h->vid_pos[vid] = ((int64_t)l << 32) | (int64_t)h->h_list_len[l];
         if (h->doc_deleted(vid)) h->h_deleted[l]++;
@@ -826,6 +894,7 @@ int gamma_hip_ivfpq_compact_if_need(gamma_hip_index* h) {
         if (pos > 0) {
             GH_CHECK(h, hipMemcpyAsync(h->d_ids + noff, ids.data(), (size_t)pos * sizeof(int64_t), hipMemcpyHostToDevice, h->wstream));
             GH_CHECK(h, hipMemcpyAsync(h->d_codes + noff * h->code_size, codes.data(), (size_t)pos * h->code_size, hipMemcpyHostToDevice, h->wstream));
+            GH_TRY(sums_range(h, l, noff, pos));
         }
         h->h_list_off[l] = noff;
         h->ntotal -= (len - pos);

@@ -123,6 +123,9 @@ struct ScanBound {
     int store_all;              // != 0: consumer groups store their distances even with a bound (exact-ties replay)
     int* rq_list;               // queries k_select_final could not finish from the slices (launch_ivfpq_scan_repair)
     int* rq_count;
+    const float* sums;          // filter pass of the L2 consumers (k_ivfpq_scan_pair<.., CF>): per arena entry
+                                // sum_m T2[list][m][code[m]]; per list sum_m max_c |T2[l][m][c]|.  nullptr: regular loop
+    const float* t2max;
 };
 // list-major consumer scan (scan_lm.hip)
 constexpr int LM_PAIR_CAP = 64;   // survivors one (query, probe) pair may leave in its own mini-slice
@@ -311,6 +314,14 @@ void launch_mark_moved(hipStream_t s, int64_t* ids, int64_t pos);
 void launch_repack_lists(hipStream_t s, const uint8_t* oc, const int64_t* oi, uint8_t* nc, int64_t* ni,
                          const int64_t* old_off, const int64_t* new_off, const int* len, int nlist, int M,
                          int max_len);
+// per-code table sums of the L2 scan's filter pass and the per-list bound of their magnitude (kernels.hip)
+void launch_code_sums_ranges(hipStream_t s, const float* T2, const uint8_t* codes, int M, const int* list_no, const int64_t* pos,
+                             const int* n, int nranges, int max_n, float* sums);
+void launch_code_sums_one(hipStream_t s, const float* T2, const uint8_t* codes, int M, int list_no, int64_t pos, int n,
+                          float* sums);
+void launch_code_sums_lists(hipStream_t s, const float* T2, const uint8_t* codes, int M, const int64_t* list_off,
+                            const int* list_len, int nlist, int max_len, float* sums);
+void launch_t2_rowmax(hipStream_t s, const float* T2, int nlist, int M, float* t2max);
 void launch_pq_encode(hipStream_t s, const float* x, int64_t n, int d, int M, const int* assign,
                       const float* cc, const float* pqc, uint8_t* codes);
 

@@ -1259,7 +1259,10 @@ constexpr int SCAN_BATCH = 64;                   // queries per XCD by which pro
 // computed here from the PQ codebook (128 KB, L2 resident; `st2` then points at it) instead of being
 // written to HBM by k_pq_ip_table and read back -- with W shards that table is W x 16 KB per query of
 // traffic that does not shrink with the shard, and each of its entries would be read exactly once.
-template <bool L2, int MT, bool FILT, bool IPF = false, bool UNITS = false>
+// CF (L2, FILT, MT 16 / 32, large batches): the consumer groups of a query with a bound run a FILTER pass without the
+// per-list table -- see "filter pass" in the body.
+constexpr int SCAN_CF_CAP = 512;   // filter-pass candidates staged per workgroup (8 bytes each)
+template <bool L2, int MT, bool FILT, bool IPF = false, bool UNITS = false, bool CF = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_ivfpq_scan_pair(
         const float* __restrict__ x, int nq, int d, int M, int P, int G, const int* __restrict__ probe_list,
         const float* __restrict__ coarse_dis, const float* __restrict__ cc,
@@ -1344,6 +1347,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
     int& s_nstage = *reinterpret_cast<int*>(s_stage + SCAN_STAGE);
     uint32_t& s_tau = *(reinterpret_cast<uint32_t*>(s_stage + SCAN_STAGE) + 1);
     uint32_t* s_red = reinterpret_cast<uint32_t*>(s_stage + SCAN_STAGE) + 2;                  // [12]
+    int& s_ncand = *(reinterpret_cast<int*>(s_stage + SCAN_STAGE) + 14);                       // CF: staged candidates
+    uint2* s_cand = reinterpret_cast<uint2*>(reinterpret_cast<int*>(s_stage + SCAN_STAGE) + 16);  // CF: [SCAN_CF_CAP]
     int cbase = 0;     // unit mode: first code of the unit within its list
     int lut_q = -1;    // unit mode, inner product: the query whose table is in LDS
     int lut_pair = -1; // unit mode, L2: the (query, probe) pair whose table is in LDS
@@ -1429,9 +1434,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
             for (int e = tid; e < msz; e += 256) s_lut[e] = st2q[e];
         }
     }
+    if constexpr (CF) {
+        if (pg > 0) {   // (uniform) largest |entry| of the query's table: one word per wave, read behind the barrier below
+            float mxv = 0.f;
+#pragma unroll
+            for (int i = 0; i < MT; i++) mxv = fmaxf(mxv, fabsf(s2r[i]));
+            const uint32_t wmx = __reduce_max_sync(~0ull, __float_as_uint(mxv));   // non-negative floats order as integers
+            if (lane == 0) s_red[tid >> 6] = wmx;
+        }
+    }
     if (FILT) {   // placed after the table loads were issued: their latency and this one overlap
         if (threadIdx.x == 0) {
             s_nstage = 0;
+            if (CF) s_ncand = 0;
             if (pg > 0) {   // wait for this query's bound (published by its group-0 workgroup)
                 // ONE relaxed 64-bit word carries (state << 32 | bound): no acquire/release fence is
                 // needed (nothing else the producer wrote is read here), and agent-scope fences
@@ -1456,6 +1471,146 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
             tauq = s_tau;
             bound_on = tauq < KEY_SENTINEL;   // otherwise the query takes the unfiltered selection
             tau_f = key2f(L2 ? tauq : ~tauq);
+        }
+    }
+    if constexpr (CF) {
+        if (pg > 0 && bound_on) {   // (uniform)
+            // ---- filter pass (L2 consumers with a bound) ----------------------------------------------------------
+            // Half of the regular loop's instructions build the per-list table T2[l] - 2 ip[q] (4096 entries for
+            // lists of a few hundred codes).  Here the LUT is the QUERY's table ip[q] alone, written once per
+            // workgroup -- no per-list build, no barriers in the probe loop -- and a code is tested on
+            //     f = (dis0 + s_j) - 2 sum_m ip[q][m][c_m],     s_j = sum_m T2[l][m][c_m]  (kept beside the code, 4 bytes),
+            // which differs from the reference's value  dis0 + sum_m fma(-2, ip, T2)  (sequential) only by rounding:
+            // every one of the < 50 roundings of either evaluation is at most 2^-24 times a partial sum, and every
+            // partial sum is bounded by S = |dis0| + sum_m max_c |T2[l][m][c]| + 2 sum_m max_c |ip[q][m][c]|, so
+            // |f - exact| <= 50 * 2^-24 * S.  A code passes when f <= tau + 2^-17 S (a margin 2.5 times that, the
+            // second term of S taken as 32 times the largest |entry| of the query's table).  The few that pass
+            // (about as many as end up in the slice) get the EXACT value afterwards -- table entries fetched from
+            // the L2-resident T2 row, fma and adds in the reference's order -- and the slice receives what the
+            // regular loop would have put there: same keys, same positions.
+            lut_store_begin(lut_m0);
+            lut_store_rows<MT>([&](int i) { return s2r[i]; }, std::make_integer_sequence<int, (MT > 0 ? MT : 1)>{});
+            lut_store_done();
+            const float qmax = __uint_as_float(max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3])));
+            // The table does not depend on the list, so nothing in this loop needs the workgroup in step: every WAVE
+            // takes whole lists of the group (next one from a counter in LDS), 64 codes per step, the next step's codes
+            // and sums requested before the current step's gathers -- four independent latency chains per workgroup
+            // instead of one, and no barrier until the candidates are complete.
+            int& s_next = *reinterpret_cast<int*>(s_cand + SCAN_CF_CAP);
+            if (tid == 0) s_next = 0;
+            __syncthreads();   // the LUT and the list counter are in place
+            const int ng = p_end - p_begin;
+            for (;;) {
+                int r = 0;
+                if (lane == 0) r = atomicAdd(&s_next, 1);
+                r = __builtin_amdgcn_readfirstlane(r);
+                if (r >= ng) break;
+                const int p = p_begin + r, pair = q * P + p;
+                const int l = probe_list[pair];
+                if (l < 0 || l >= nlist) continue;            // uniform per wave
+                if (list_mask && !list_mask[l]) continue;
+                const int len = list_len[l];
+                if (len <= 0) continue;
+                const int64_t off = list_off[l];
+                const uint8_t* lc = codes + off * MT;
+                const float* ls = sb.sums + off;
+                const int64_t* lid = ids + off;
+                const float dis0 = coarse_dis[pair];
+                const int pbase = pair_off[(int64_t)q * (P + 1) + p];
+                const float S = fabsf(dis0) + sb.t2max[l] + 32.f * qmax;
+                float thr = __builtin_fmaf(S, 1.f / 131072.f, tau_f);
+                thr += fabsf(thr) * 1.2e-7f;   // the threshold's own rounding
+                uint4 cn[MT / 16];
+                float sn;
+                {
+                    const int jc = min(lane, len - 1);
+                    const uint4* cp = reinterpret_cast<const uint4*>(lc + (int64_t)jc * MT);
+#pragma unroll
+                    for (int u = 0; u < MT / 16; u++) cn[u] = cp[u];
+                    sn = ls[jc];
+                }
+                for (int j0 = 0; j0 < len; j0 += 64) {
+                    const int j = j0 + lane;
+                    uint32_t cw[MT / 4];
+#pragma unroll
+                    for (int u = 0; u < MT / 16; u++) {
+                        cw[4 * u] = cn[u].x; cw[4 * u + 1] = cn[u].y; cw[4 * u + 2] = cn[u].z; cw[4 * u + 3] = cn[u].w;
+                    }
+                    const float sj = sn;
+                    if (j0 + 64 < len) {   // (uniform) the next step's codes and sums, in flight during this step's gathers
+                        const int jc = min(j + 64, len - 1);
+                        const uint4* cp = reinterpret_cast<const uint4*>(lc + (int64_t)jc * MT);
+#pragma unroll
+                        for (int u = 0; u < MT / 16; u++) cn[u] = cp[u];
+                        sn = ls[jc];
+                    }
+                    bool ok = j < len;
+                    if (need_ids) {
+                        const int64_t id = lid[min(j, len - 1)];
+                        ok = ok && id >= 0;
+                        if (ok) ok = is_valid_doc(filt, id);
+                    }
+                    float t[MT];
+#pragma unroll
+                    for (int m = 0; m < MT; m++) t[m] = lut_gather(cw[m >> 2], m & 3, m);
+                    __builtin_amdgcn_sched_barrier(0);   // all gathers in flight before the adds
+                    float g4[4] = {t[0], t[1], t[2], t[3]};   // four independent chains: the order is free here
+#pragma unroll
+                    for (int m = 4; m < MT; m++) g4[m & 3] += t[m];
+                    const float g = (g4[0] + g4[1]) + (g4[2] + g4[3]);
+                    const float f = __builtin_fmaf(-2.f, g, dis0 + sj);
+                    const bool cand = ok && f <= thr;
+                    const unsigned long long bal = __ballot(cand);
+                    if (bal) {   // uniform per wave
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(&s_ncand, __popcll(bal));
+                        base = __shfl(base, 0, 64);
+                        const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+                        if (cand && slot < SCAN_CF_CAP) s_cand[slot] = make_uint2((uint32_t)(pbase + j), (uint32_t)p);
+                    }
+                }
+            }
+            __syncthreads();
+            const int nc = s_ncand;
+            if (nc > SCAN_CF_CAP) {   // (uniform) more candidates than the stage holds: the query takes the unfiltered path
+                if (tid == 0) s_nstage = SCAN_SLICE + 1;
+            } else {
+                for (int c0 = 0; c0 < nc; c0 += 256) {   // uniform trip count: append() ballots
+                    const int c = c0 + tid;
+                    bool keep = false;
+                    float dis = 0.f;
+                    int pos = 0;
+                    if (c < nc) {
+                        const uint2 cd = s_cand[c];
+                        pos = (int)cd.x;
+                        const int p = (int)cd.y, pair = q * P + p;
+                        const int l = probe_list[pair];
+                        const int j = pos - pair_off[(int64_t)q * (P + 1) + p];
+                        const uint8_t* cj = codes + (list_off[l] + j) * MT;
+                        const float* t2 = T2 + (int64_t)l * msz;
+                        uint32_t cw[MT / 4];
+#pragma unroll
+                        for (int u = 0; u < MT / 16; u++) {
+                            const uint4 cv = reinterpret_cast<const uint4*>(cj)[u];
+                            cw[4 * u] = cv.x; cw[4 * u + 1] = cv.y; cw[4 * u + 2] = cv.z; cw[4 * u + 3] = cv.w;
+                        }
+                        dis = coarse_dis[pair];
+#pragma unroll
+                        for (int m0 = 0; m0 < MT; m0 += 8) {   // eight table entries in flight at a time
+                            float a[8];
+#pragma unroll
+                            for (int m = 0; m < 8; m++) a[m] = t2[(m0 + m) * 256 + ((cw[(m0 + m) >> 2] >> (8 * (m & 3))) & 255u)];
+#pragma unroll
+                            for (int m = 0; m < 8; m++)   // the regular loop's table entry and its adds, in the reference's order
+                                dis += __builtin_fmaf(-2.0f, s_lut[(m0 + m) * 256 + ((cw[(m0 + m) >> 2] >> (8 * (m & 3))) & 255u)], a[m]);
+                        }
+                        keep = dis <= tau_f;
+                    }
+                    append(keep, dis, pos);
+                }
+            }
+            flush();
+            return;
         }
     }
     if (!L2) __syncthreads();   // the LUT (written once per query) is complete; L2 rebuilds it per list
@@ -1790,14 +1945,16 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
         st2 = pqc_fused;
     }
     // LUT | survivor staging | a few words (see the kernel)
-    const size_t lds = (size_t)M * 256 * sizeof(float) + SCAN_STAGE * sizeof(unsigned long long) + 16 * sizeof(int);
+    size_t lds = (size_t)M * 256 * sizeof(float) + SCAN_STAGE * sizeof(unsigned long long) + 16 * sizeof(int);
     dim3 grid((unsigned)(8 * (int64_t)((nq + 7) / 8) * pg_cnt));
     if (bound) {   // P(0) | P(t+1) C(t) ...: whole batches, see the kernel
         const int64_t nq8 = (nq + 7) / 8, nb = (nq8 + SCAN_BATCH - 1) / SCAN_BATCH;
         grid.x = (unsigned)(8 * (SCAN_BATCH + nb * SCAN_BATCH * pg_cnt));
     }
-    ScanBound sb = {nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr};
+    ScanBound sb = {nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
     if (bound) sb = *bound;
+    // filter pass for the consumers of a bounded L2 scan: needs the per-code sums (sb.sums) and survivor-only consumers
+    const bool cf = bound && l2 && !pqc_fused && pg_cnt > 1 && sb.sums && sb.t2max && !sb.store_all && (M == 16 || M == 32);
     if (rq_list) {   // repair launch: a fixed grid loops over the flagged (query, group) items
         if (bound || pqc_fused) abort();
         grid.x = (unsigned)std::min<int64_t>((int64_t)nq * pg_cnt, 2048);
@@ -1806,6 +1963,7 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
         const int per_cu = std::max(1, std::min(8, (int)(160 * 1024 / (lds + 1024))));
         grid.x = (unsigned)std::min<int64_t>(max_units, 256 * per_cu);
     }
+    if (cf) lds += SCAN_CF_CAP * sizeof(uint2) + 16;
 #define GH_SCAN(LL, MT, FF)                                                                       \
     GH_SCAN4(LL, MT, FF, false)
 #define GH_SCAN4(LL, MT, FF, II) GH_SCAN5(LL, MT, FF, II, false)
@@ -1841,6 +1999,15 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
         else if (l2) GH_SCAN4(true, 32, true, true);
         else if (M == 16) GH_SCAN4(false, 16, true, true);
         else GH_SCAN4(false, 32, true, true);
+    } else if (cf) {
+#define GH_SCAN_CF(MT)                                                                                                  \
+    hipLaunchKernelGGL((k_ivfpq_scan_pair<true, MT, true, false, false, true>), grid, dim3(256), lds, s, x, nq, d, M, P, G, \
+                       probe_list, coarse_dis, cc, st2, T2, list_off, list_len, list_mask, nlist, codes, ids, pair_off,  \
+                       q_stride, out, ftab, qfil, need_ids, INFINITY, qperm, pg_lo, pg_cnt, sparse, sb, rq_list,         \
+                       rq_count, chunk_len)
+        if (M == 16) GH_SCAN_CF(16);
+        else GH_SCAN_CF(32);
+#undef GH_SCAN_CF
     } else if (bound) {
         if (l2) GH_SCAN_M(true, true);
         else GH_SCAN_M(false, true);
@@ -2273,6 +2440,77 @@ void launch_repack_lists(hipStream_t s, const uint8_t* oc, const int64_t* oi, ui
     if (nlist <= 0) return;
     const int chunks = std::max(1, std::min(64, (max_len + 1023) / 1024));
     hipLaunchKernelGGL(k_repack_lists, dim3(nlist, chunks), dim3(256), 0, s, oc, oi, nc, ni, old_off, new_off, len, M);
+}
+
+// ------------------------------------------------------------------------------------
+// Per-code table sums of the L2 scan's filter pass (k_ivfpq_scan_pair<.., CF>): sums[pos] = sum_m T2[list][m][code[m]]
+// (sequential fp32 adds from 0).  The value is only ever used inside a bound with a margin that covers its rounding,
+// so any fixed order would do.
+//   ranges: range r = n[r] entries of list list_no[r] from arena position pos[r]  (grid = (ranges, chunks))
+//   lists : every entry of every list at its current extent                      (grid = (nlist, chunks))
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void code_sums_span(const float* __restrict__ t2l, const uint8_t* __restrict__ codes, int M,
+                                               int64_t pos, int n, float* __restrict__ sums) {
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) {
+        const uint8_t* c = codes + (pos + i) * M;
+        float acc = 0.f;
+        for (int m = 0; m < M; m++) acc += t2l[m * 256 + c[m]];
+        sums[pos + i] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void k_code_sums_ranges(const float* __restrict__ T2, const uint8_t* __restrict__ codes, int M,
+                                                          const int* __restrict__ list_no, const int64_t* __restrict__ pos,
+                                                          const int* __restrict__ n, float* __restrict__ sums) {
+    const int r = blockIdx.x;
+    code_sums_span(T2 + (int64_t)list_no[r] * M * 256, codes, M, pos[r], n[r], sums);
+}
+__global__ __launch_bounds__(256) void k_code_sums_lists(const float* __restrict__ T2, const uint8_t* __restrict__ codes, int M,
+                                                         const int64_t* __restrict__ list_off, const int* __restrict__ list_len,
+                                                         float* __restrict__ sums) {
+    const int l = blockIdx.x;
+    code_sums_span(T2 + (int64_t)l * M * 256, codes, M, list_off[l], list_len[l], sums);
+}
+__global__ __launch_bounds__(256) void k_code_sums_one(const float* __restrict__ t2l, const uint8_t* __restrict__ codes, int M,
+                                                       int64_t pos, int n, float* __restrict__ sums) {
+    code_sums_span(t2l, codes, M, pos, n, sums);
+}
+void launch_code_sums_one(hipStream_t s, const float* T2, const uint8_t* codes, int M, int list_no, int64_t pos, int n,
+                          float* sums) {
+    if (n <= 0) return;
+    const int chunks = std::max(1, std::min(64, (n + 1023) / 1024));
+    hipLaunchKernelGGL(k_code_sums_one, dim3(1, chunks), dim3(256), 0, s, T2 + (int64_t)list_no * M * 256, codes, M, pos, n, sums);
+}
+void launch_code_sums_ranges(hipStream_t s, const float* T2, const uint8_t* codes, int M, const int* list_no, const int64_t* pos,
+                             const int* n, int nranges, int max_n, float* sums) {
+    if (nranges <= 0) return;
+    const int chunks = std::max(1, std::min(64, (max_n + 1023) / 1024));
+    hipLaunchKernelGGL(k_code_sums_ranges, dim3(nranges, chunks), dim3(256), 0, s, T2, codes, M, list_no, pos, n, sums);
+}
+void launch_code_sums_lists(hipStream_t s, const float* T2, const uint8_t* codes, int M, const int64_t* list_off,
+                            const int* list_len, int nlist, int max_len, float* sums) {
+    if (nlist <= 0) return;
+    const int chunks = std::max(1, std::min(64, (max_len + 1023) / 1024));
+    hipLaunchKernelGGL(k_code_sums_lists, dim3(nlist, chunks), dim3(256), 0, s, T2, codes, M, list_off, list_len, sums);
+}
+// t2max[l] = sum_m max_c |T2[l][m][c]|: bounds every partial sum of a code's table entries (the filter's margin)
+__global__ __launch_bounds__(256) void k_t2_rowmax(const float* __restrict__ T2, int M, float* __restrict__ t2max) {
+    __shared__ float s_w[4];
+    const int l = blockIdx.x, tid = threadIdx.x;
+    const float* t = T2 + (int64_t)l * M * 256;
+    float tot = 0.f;
+    for (int m = 0; m < M; m++) {
+        float v = fabsf(t[m * 256 + tid]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+        __syncthreads();
+        if ((tid & 63) == 0) s_w[tid >> 6] = v;
+        __syncthreads();
+        tot += fmaxf(fmaxf(s_w[0], s_w[1]), fmaxf(s_w[2], s_w[3]));
+    }
+    if (tid == 0) t2max[l] = tot;
+}
+void launch_t2_rowmax(hipStream_t s, const float* T2, int nlist, int M, float* t2max) {
+    if (nlist > 0) hipLaunchKernelGGL(k_t2_rowmax, dim3(nlist), dim3(256), 0, s, T2, M, t2max);
 }
 
 // ------------------------------------------------------------------------------------

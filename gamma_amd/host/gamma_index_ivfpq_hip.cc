@@ -621,6 +621,7 @@ int GammaIVFFlatHIPIndex::Init(const std::string &model_parameters, int indexing
   const char *dev = getenv("GAMMA_HIP_DEVICE");
   int rc = gamma_hip_create(dev ? atoi(dev) : 0, &h_);
   if (rc) return -1;
+  members_.assign(1, h_);   // one GPU (the sharded group serves HIPIVFPQ)
   rc = gamma_hip_ivfflat_init(h_, d_, nlist_, metric_type_ == DistanceComputeType::L2 ? GAMMA_HIP_METRIC_L2 : GAMMA_HIP_METRIC_IP,
                               pa.bucket_init_size, pa.bucket_max_size);
   if (!rc) rc = gamma_hip_raw_init(h_, d_);

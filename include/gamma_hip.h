@@ -372,6 +372,9 @@ int gamma_hip_group_ivfpq_compact_if_need(gamma_hip_group* g);
 /* GammaIVFPQIndex::Search over all members; host buffers as gamma_hip_ivfpq_search */
 int gamma_hip_group_ivfpq_search(gamma_hip_group* g, const gamma_hip_search_params* p, int nq, const float* x, int k,
                                  float* distances, int64_t* labels);
+/* the same with the queries and the result buffers in the memory of member 0's device; returns when the results are there */
+int gamma_hip_group_ivfpq_search_device(gamma_hip_group* g, const gamma_hip_search_params* p, int nq, const float* d_x,
+                                        int k, float* d_distances, int64_t* d_labels);
 int64_t gamma_hip_group_total_mem_bytes(gamma_hip_group* g);
 
 /* ---- accounting (GetTotalMemBytes, index/retrieval_model.h:287; PerfTool :23-50) ------ */
