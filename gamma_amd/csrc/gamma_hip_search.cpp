@@ -371,8 +371,15 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         const bool lm = (env_lm || h->list_major) && !shard && PGN > 1 && M == 16 && nq >= 2048 && 1 + (P - G) <= 64 &&
                         !fc.d_qf && h->d_list_mask == nullptr;
         const int cap = gh::scan_slice_cap();
+        // filter pass of the consumers (kernels.hip, CF): needs the sums beside the arena the scan reads -- not the
+        // shadow arena of a call running over lists compacted under its filter.  With it ONE consumer workgroup per
+        // query takes every probe behind the producer's: two groups, two slices per query.
+        static const bool no_cf = getenv("GAMMA_HIP_NO_SCAN_CF") != nullptr;
+        const bool cf_ok = !no_cf && !h->prefiltered && !lm && PGN > 1 &&
+                           gh::scan_cf_applies(l2, M, P, G, h->d_sums && h->d_t2max, h->tie.on && lm);
+        const int PGM = cf_ok ? 2 : PGN;   // probe groups of the main launch
         // one survivor slice per probe group (slice 0: the producer's own) -- or, list-major, per consumer PAIR
-        const int nsl = lm ? 1 + (P - G) : PGN;
+        const int nsl = lm ? 1 + (P - G) : PGM;
         // rq | ready[nq] | gcnt[nq][nsl]   (rq: count + list of the queries that need the repair launch, 8-byte aligned)
         const size_t rq_bytes = (((size_t)nq + 1) * sizeof(int) + 7) & ~(size_t)7;
         GH_CHECK(h, h->w_scnt.ensure(rq_bytes + (size_t)nq * (sizeof(unsigned long long) + (size_t)nsl * sizeof(int))));
@@ -393,15 +400,11 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         sb.store_all = (h->tie.on && lm) ? 1 : 0;
         sb.rq_count = h->w_scnt.as<int>();
         sb.rq_list = h->w_scnt.as<int>() + 1;
-        // filter pass of the consumers (kernels.hip, CF): needs the sums beside the arena the scan reads -- not the
-        // shadow arena of a call running over lists compacted under its filter
-        static const bool no_cf = getenv("GAMMA_HIP_NO_SCAN_CF") != nullptr;
-        const bool cf_ok = !no_cf && l2 && h->d_sums && h->d_t2max && !h->prefiltered && !lm;
         sb.sums = cf_ok ? h->d_sums : nullptr;
         sb.t2max = cf_ok ? h->d_t2max : nullptr;
         const unsigned long long* surv_c = nullptr;
         if (!lm) {
-            scan(G, 0, PGN, &sb, true);
+            scan(G, 0, PGM, &sb, true);
         } else {
             const int PC = P - G, B = gh::lm_block_queries(P, G), nblk = (nq + B - 1) / B;
             GH_CHECK(h, h->w_survc.ensure((size_t)nq * PC * gh::lm_pair_cap() * sizeof(unsigned long long)));

@@ -154,6 +154,9 @@ void launch_lm_units(hipStream_t s, const int* probe, const float* dis0, const i
                      int* ucount);
 void launch_scan_lm(hipStream_t s, bool l2, int M, const LmScanArgs& a);
 int scan_slice_cap();
+// true when launch_ivfpq_scan_pair would run the filter pass (CF) for a bounded scan with these arguments; the caller
+// then launches TWO groups per query -- the producer's G probes and one consumer group with all the others
+bool scan_cf_applies(bool l2, int M, int P, int G, bool have_sums, bool store_all);
 int scan_group_size(int nq, int P, int G0 = 8);   // G0: probes per workgroup to start from (power of two)
 void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int d, int M, int P,
                             const int* probe_list, const float* coarse_dis, const float* cc,

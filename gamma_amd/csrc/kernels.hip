@@ -1261,7 +1261,7 @@ constexpr int SCAN_BATCH = 64;                   // queries per XCD by which pro
 // traffic that does not shrink with the shard, and each of its entries would be read exactly once.
 // CF (L2, FILT, MT 16 / 32, large batches): the consumer groups of a query with a bound run a FILTER pass without the
 // per-list table -- see "filter pass" in the body.
-constexpr int SCAN_CF_CAP = 512;   // filter-pass candidates staged per workgroup (8 bytes each)
+constexpr int SCAN_CF_CAP = 768;   // filter-pass candidates staged per workgroup (8 bytes each)
 template <bool L2, int MT, bool FILT, bool IPF = false, bool UNITS = false, bool CF = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_ivfpq_scan_pair(
         const float* __restrict__ x, int nq, int d, int M, int P, int G, const int* __restrict__ probe_list,
@@ -1392,7 +1392,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
         if (threadIdx.x == 0) sb.gcnt[(int64_t)q * sb.cnt_stride + pg] = n;
         for (int i = threadIdx.x; i < min(n, SCAN_STAGE); i += 256) sb.surv[slice * SCAN_SLICE + i] = s_stage[i];
     };
-    const int p_begin = pg * G, p_end = min(P, p_begin + G);
+    // (CF: the LAST group takes every probe behind the ones before it -- its table is the query's, not a list's, so
+    //  one workgroup per query serves all consumer probes: one table write, one slice)
+    const int p_begin = pg * G, p_end = (CF && pg == pg_cnt - 1) ? P : min(P, p_begin + G);
     const int tid = threadIdx.x;
     const int msz = M * 256;
     // LDS byte address of this wave's 256-byte segment of a LUT row (lut_store)
@@ -1921,6 +1923,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
 }
 
 int scan_slice_cap() { return SCAN_SLICE; }
+bool scan_cf_applies(bool l2, int M, int P, int G, bool have_sums, bool store_all) {
+    return l2 && have_sums && !store_all && (M == 16 || M == 32) && P > G;
+}
 
 int scan_group_size(int nq, int P, int G0) {
     // probes per workgroup: amortise the query table, but keep >= ~4096 workgroups in flight
