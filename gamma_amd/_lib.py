@@ -30,7 +30,7 @@ class FieldFilter(C.Structure):
 
 
 class TermFilter(C.Structure):
-    _fields_ = [("field_id", C.c_int32), ("op", C.c_int32), ("n_items", C.c_int32), ("items", C.c_int32 * 8)]
+    _fields_ = [("field_id", C.c_int32), ("op", C.c_int32), ("n_items", C.c_int32), ("items", C.c_int32 * 16)]
 
 
 class SearchParams(C.Structure):
@@ -56,12 +56,12 @@ SYMBOLS = {
     "gamma_hip_field_count": (C.c_int64, [C.c_void_p, C.c_int]),
     "gamma_hip_term_append": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gamma_hip_term_count": (C.c_int64, [C.c_void_p, C.c_int]),
+    "gamma_hip_term_update": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int32, C.POINTER(C.c_int32)]),
     "gamma_hip_raw_init": (C.c_int, [C.c_void_p, C.c_int]),
     "gamma_hip_raw_append": (C.c_int, [C.c_void_p, C.c_int64, f32p]),
     "gamma_hip_raw_update": (C.c_int, [C.c_void_p, C.c_int64, f32p]),
     "gamma_hip_ivfpq_arena_stats": (C.c_int, [C.c_void_p, i64p]),
     "gamma_hip_ivfpq_set_repack_threshold": (C.c_int, [C.c_void_p, C.c_int64]),
-    "gamma_hip_set_list_major": (C.c_int, [C.c_void_p, C.c_int]),
     "gamma_hip_set_small_path": (C.c_int, [C.c_void_p, C.c_int]),
     "gamma_hip_set_coarse_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "gamma_hip_tie_stats": (C.c_int, [C.c_void_p, i64p, C.c_int]),

@@ -354,9 +354,6 @@ class GammaHip:
         """True / False, or an int >= 2: on, with the two-level selection of long candidate rows forced (that many slices)."""
         self._ck(self.L.gamma_hip_set_small_path(self.h, int(on)), "set_small_path")
 
-    def set_list_major(self, on=True):
-        self._ck(self.L.gamma_hip_set_list_major(self.h, 1 if on else 0), "set_list_major")
-
     def tie_stats(self, reset=False):
         out = np.zeros(3, np.int64)
         self._ck(self.L.gamma_hip_tie_stats(self.h, _p(out, _lib.i64p), 1 if reset else 0), "tie_stats")
@@ -386,6 +383,12 @@ class GammaHip:
         flat = np.ascontiguousarray([t for d in docs_items for t in d], dtype=np.int32)
         self._ck(self.L.gamma_hip_term_append(self.h, field_id, len(counts), counts.ctypes.data_as(C.POINTER(C.c_int32)),
                                               flat.ctypes.data_as(C.POINTER(C.c_int32))), "term_append")
+
+    def term_update(self, field_id, docid, items):
+        """rewrite doc `docid`'s items (its STRING field was updated)"""
+        it = np.ascontiguousarray(items, dtype=np.int32)
+        self._ck(self.L.gamma_hip_term_update(self.h, field_id, docid, len(it), it.ctypes.data_as(C.POINTER(C.c_int32))),
+                 "term_update")
 
     def term_count(self, field_id):
         return self.L.gamma_hip_term_count(self.h, field_id)

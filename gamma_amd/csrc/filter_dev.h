@@ -52,7 +52,8 @@ __device__ __forceinline__ bool is_valid_doc(const FilterDesc& f, int64_t vid) {
     for (int i = 0; i < f.n_term; i++) {
         const TermDesc& t = f.term[i];
         if (doc < 0 || (int64_t)doc >= t.n) return false;
-        const int64_t b = t.off[doc], e = t.off[doc + 1];
+        const int64_t row = t.off[doc];   // start << 16 | number of items
+        const int64_t b = row >> 16, e = b + (row & 0xffff);
         // Or: any term item among the doc's items; And: all of them (as the reference's GPU model); Not: none
         bool any = false, all = true;
         for (int k = 0; k < t.n_items; k++) {

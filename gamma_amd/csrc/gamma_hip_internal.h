@@ -117,11 +117,13 @@ struct gamma_hip_index {
         int64_t n = 0, cap = 0;
     };
     std::map<int, Column> fields;
-    // STRING columns as dictionary-encoded item lists (on-device term filters): doc i = tok[off[i] .. off[i + 1])
+    // STRING columns as dictionary-encoded item lists (on-device term filters): doc i = tok[start .. start + len),
+    // row word off[i] = start << 16 | len (gamma_hip_term_update rewrites a row)
     struct TermColumn {
         int64_t* d_off = nullptr;
         int32_t* d_tok = nullptr;
         int64_t ndocs = 0, cap_docs = 0, ntok = 0, cap_tok = 0;
+        std::vector<int64_t> h_rows;   // host copy of the row words
     };
     std::map<int, TermColumn> terms;
 
@@ -169,7 +171,7 @@ struct gamma_hip_index {
     DevBuf w_mat, w_coarse_dis, w_probe, w_xn, w_st2, w_pair_off, w_qtotal, w_dist, w_cand_dis,
             w_cand_pos, w_cand_ids, w_exact, w_selv, w_selp, w_x, w_outd, w_outl, w_stage, w_filter,
             w_m_dis, w_m_ids, w_part_v, w_part_i, w_assign, w_codes_tmp, w_qperm, w_scnt, w_sflag, w_surv, w_pair_base,
-            w_pair_ip, w_flat_cand, w_flat_meta, w_full_cdis, w_full_probe, w_ftab, w_qfil, w_tieflag, w_tcut, w_tlist, w_survc, w_lm_units, w_lm_cnt, w_fbits, w_cmp_codes, w_cmp_ids, w_cmp_len,
+            w_pair_ip, w_flat_cand, w_flat_meta, w_full_cdis, w_full_probe, w_ftab, w_qfil, w_tieflag, w_tcut, w_tlist, w_lm_units, w_lm_cnt, w_fbits, w_cmp_codes, w_cmp_ids, w_cmp_len,
             we_mat, we_cdis, we_x, we_assign, we_codes, we_stage;   // writer side (encode, bitmap_set): never shared with a search
     unsigned long long* d_scan_codes = nullptr;
     size_t dist_budget_bytes = (size_t)8 << 30;   // per-chunk ADC distance buffer (288 GB of HBM per GPU)
@@ -180,7 +182,6 @@ struct gamma_hip_index {
     bool ftab_valid = false;
 
     bool exact_ties = true;    // gamma_hip_set_exact_ties
-    bool list_major = false;   // gamma_hip_set_list_major
     bool coarse_fused = true;  // gamma_hip_set_coarse_fused
     bool small_path = true;    // gamma_hip_set_small_path
     int small_presel = 0;      // 0: pre-selection by estimate, > 0: always, that many slices (tests)

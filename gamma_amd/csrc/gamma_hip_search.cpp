@@ -2,6 +2,7 @@
 // flat), validity filters, the combining queue of small concurrent calls and the search entry points of the C ABI
 // (include/gamma_hip.h).  No CPU fallback: every entry point runs the HIP kernels or returns an error.
 #include "gamma_hip_internal.h"
+#include "gamma_hip_search.h"
 
 namespace ghi {
 
@@ -12,7 +13,7 @@ namespace ghi {
 // that is several times the number of documents, the field / term clauses are evaluated once per document into a
 // bitmap (k_filter_bitmap) and join the request's range bitmaps -- the scan then tests a bit instead of reading column
 // values (C5 shape, 10 % range filter on an int64 column: scan 9.6 -> 7.5 ms per 4096 queries)
-int build_filter(H* h, const gamma_hip_search_params* p, gh::FilterDesc* f, size_t* off_io = nullptr, int64_t est_codes = 0) {
+int build_filter(H* h, const gamma_hip_search_params* p, gh::FilterDesc* f, size_t* off_io, int64_t est_codes) {
     memset(f, 0, sizeof(*f));
     f->del_bitmap = h->d_bitmap;
     f->del_bits = h->d_bitmap ? h->bitmap_bits : 0;
@@ -103,20 +104,6 @@ int build_filter(H* h, const gamma_hip_search_params* p, gh::FilterDesc* f, size
     }
     return GAMMA_HIP_OK;
 }
-
-// What the scan needs to know about the validity predicates of a call: the device filter table, the
-// optional query -> entry map (combined batches of requests with their own filters), and whether
-// anything but the delete bitmap can reject an entry.
-struct FiltCtx {
-    const gh::FilterDesc* d_tab = nullptr;
-    const int* d_qf = nullptr;
-    bool any_clause = false;
-    FiltCtx at(int q0) const {   // the same context for the queries from q0 on
-        FiltCtx c = *this;
-        if (c.d_qf) c.d_qf += q0;
-        return c;
-    }
-};
 
 int filt_ctx_single(H* h, const gh::FilterDesc& f, FiltCtx* c) {
     GH_CHECK(h, h->w_ftab.ensure(sizeof(gh::FilterDesc)));
@@ -359,32 +346,21 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
             gh::launch_flag_cut_ties(s, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), nq, R, out_dis,
                                      h->w_cand_pos.as<int>(), nullptr, h->w_tcut.as<uint8_t>());
     } else {
-        // List-major consumer scan (scan_lm.hip) for large batches: the producers run alone, then every other probe
-        // is scored two queries per list pass.  Gated on what k_scan_lm covers; results are the same either way.
-        // Measured at C3 (16384 queries): 233 k units for 393 k consumer pairs, 58 % of the query-major kernel's
-        // vector instructions and 84 % of its LDS cycles -- but 1069 us against ~700 us for the same pairs: two
-        // 16 KB query-table rows per unit instead of one per eight pairs (11 GB through the L2 per launch), four
-        // workgroups per CU behind a 32 KB LUT2, and ds_read_b64 gathers that conflict more than ds_read_b32.
-        // Lists of a few hundred codes are too short to pay for it; it stays OFF unless asked for
-        // (gamma_hip_set_list_major, GAMMA_HIP_LM=1), kept for long-list shapes and covered by a parity test.
-        static const bool env_lm = getenv("GAMMA_HIP_LM") != nullptr;
-        const bool lm = (env_lm || h->list_major) && !shard && PGN > 1 && M == 16 && nq >= 2048 && 1 + (P - G) <= 64 &&
-                        !fc.d_qf && h->d_list_mask == nullptr;
         const int cap = gh::scan_slice_cap();
         // filter pass of the consumers (kernels.hip, CF): needs the sums beside the arena the scan reads -- not the
         // shadow arena of a call running over lists compacted under its filter.  With it ONE consumer workgroup per
         // query takes every probe behind the producer's: two groups, two slices per query.
         static const bool no_cf = getenv("GAMMA_HIP_NO_SCAN_CF") != nullptr;
-        const bool cf_ok = !no_cf && !h->prefiltered && !lm && PGN > 1 &&
-                           gh::scan_cf_applies(l2, M, P, G, h->d_sums && h->d_t2max, h->tie.on && lm);
+        const bool cf_ok = !no_cf && !h->prefiltered && PGN > 1 &&
+                           gh::scan_cf_applies(l2, M, P, G, h->d_sums && h->d_t2max, false);
         const int PGM = cf_ok ? 2 : PGN;   // probe groups of the main launch
-        // one survivor slice per probe group (slice 0: the producer's own) -- or, list-major, per consumer PAIR
-        const int nsl = lm ? 1 + (P - G) : PGM;
+        // one survivor slice per probe group (slice 0: the producer's own)
+        const int nsl = PGM;
         // rq | ready[nq] | gcnt[nq][nsl]   (rq: count + list of the queries that need the repair launch, 8-byte aligned)
         const size_t rq_bytes = (((size_t)nq + 1) * sizeof(int) + 7) & ~(size_t)7;
         GH_CHECK(h, h->w_scnt.ensure(rq_bytes + (size_t)nq * (sizeof(unsigned long long) + (size_t)nsl * sizeof(int))));
         GH_CHECK(h, h->w_sflag.ensure((size_t)nq));
-        GH_CHECK(h, h->w_surv.ensure((size_t)nq * (lm ? 1 : nsl) * cap * sizeof(unsigned long long)));
+        GH_CHECK(h, h->w_surv.ensure((size_t)nq * nsl * cap * sizeof(unsigned long long)));
         unsigned long long* ready = reinterpret_cast<unsigned long long*>(h->w_scnt.as<char>() + rq_bytes);
         GH_CHECK(h, hipMemsetAsync(h->w_scnt.p, 0, sizeof(int), s));
         GH_CHECK(h, hipMemsetAsync(ready, 0, (size_t)nq * sizeof(unsigned long long), s));
@@ -394,60 +370,14 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         sb.gcnt = reinterpret_cast<int*>(ready + nq);
         sb.K = R;
         sb.cnt_stride = nsl;
-        // exact ties: the replay reads a bounded query's candidates from slab group 0 + the survivor slices, and an
-        // unbounded one's from the slab the repair launch below fills -- nothing else needs the consumers' distances
-        // (the list-major variant has no repair launch: it stores everything)
-        sb.store_all = (h->tie.on && lm) ? 1 : 0;
+        // consumer groups with a bound keep only their survivors; what the unfiltered fallback and the tie replay of a
+        // query without a usable bound need is stored by the repair launch below
+        sb.store_all = 0;
         sb.rq_count = h->w_scnt.as<int>();
         sb.rq_list = h->w_scnt.as<int>() + 1;
         sb.sums = cf_ok ? h->d_sums : nullptr;
         sb.t2max = cf_ok ? h->d_t2max : nullptr;
-        const unsigned long long* surv_c = nullptr;
-        if (!lm) {
-            scan(G, 0, PGM, &sb, true);
-        } else {
-            const int PC = P - G, B = gh::lm_block_queries(P, G), nblk = (nq + B - 1) / B;
-            GH_CHECK(h, h->w_survc.ensure((size_t)nq * PC * gh::lm_pair_cap() * sizeof(unsigned long long)));
-            GH_CHECK(h, h->w_lm_units.ensure((size_t)nblk * gh::lm_units_per_block() * 16 * sizeof(int)));
-            GH_CHECK(h, h->w_lm_cnt.ensure((size_t)nblk * sizeof(int)));
-            GH_CHECK(h, hipMemsetAsync(sb.gcnt, 0, (size_t)nq * nsl * sizeof(int), s));   // pairs never scored: 0 survivors
-            scan(G, 0, 1, &sb, true);   // producers: first probe group, bound, own survivors (slice 0)
-            StageScope t2(h, GAMMA_HIP_STAGE_SCAN, false);
-            gh::launch_lm_units(s, h->w_probe.as<int>(), dis0, h->w_pair_off.as<int>(), h->d_list_off, h->d_list_len,
-                                h->d_list_mask, nlist, qperm, ready, nq, P, G, B, h->w_lm_units.as<int>(),
-                                h->w_lm_cnt.as<int>());
-            gh::LmScanArgs la;
-            la.units = h->w_lm_units.as<int>();
-            la.ucount = h->w_lm_cnt.as<int>();
-            la.nq = nq;
-            la.B = B;
-            la.st2 = h->w_st2.as<float>();
-            la.T2 = h->d_T2;
-            la.codes = h->d_codes;
-            la.ids = h->d_ids;
-            la.out = h->w_dist.as<float>();
-            la.q_stride = q_stride;
-            la.surv = h->w_survc.as<unsigned long long>();
-            la.cnt = sb.gcnt;
-            la.nslc = PC;
-            la.cnt_stride = nsl;
-            la.store_all = sb.store_all;
-            la.need_ids = need_ids;
-            la.ftab = fc.d_tab;
-            gh::launch_scan_lm(s, l2, M, la);
-            surv_c = h->w_survc.as<unsigned long long>();
-            static const bool lm_dbg = getenv("GAMMA_HIP_LM_DBG") != nullptr;
-            static int lm_shown = 0;
-            if (lm_dbg && lm_shown++ < 2) {
-                std::vector<int> uc(nblk);
-                (void)hipStreamSynchronize(s);
-                (void)hipMemcpy(uc.data(), h->w_lm_cnt.p, (size_t)nblk * sizeof(int), hipMemcpyDeviceToHost);
-                int64_t tot = 0;
-                for (int v : uc) tot += v;
-                fprintf(stderr, "list-major scan: %d blocks of %d queries, %lld units for %lld consumer pairs\n", nblk, B,
-                        (long long)tot, (long long)nq * PC);
-            }
-        }
+        scan(G, 0, PGM, &sb, true);
         static const bool dbg = getenv("GAMMA_HIP_BOUND_DBG") != nullptr;
         static int shown = 0;
         StageScope t(h, GAMMA_HIP_STAGE_SELECT);
@@ -455,7 +385,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
                                 h->w_pair_base.as<int64_t>(), h->d_ids,
                                 h->w_sflag.as<uint8_t>(), out_dis,
                                 h->w_cand_pos.as<int>(), out_ids, h->tie.on ? h->w_tcut.as<uint8_t>() : nullptr,
-                                h->d_tie_stats, sb.rq_list, sb.rq_count, surv_c, gh::lm_pair_cap());
+                                h->d_tie_stats, sb.rq_list, sb.rq_count);
         if (PGN > 1 && !sb.store_all) {
             // queries the slices could not answer: their consumer groups are scored again, distances stored
             StageScope t2(h, GAMMA_HIP_STAGE_SCAN, false);
@@ -471,7 +401,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         if (h->tie.on) {
             gh::launch_flag_cut_ties(s, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), nq, R, out_dis,
                                      h->w_cand_pos.as<int>(), h->w_sflag.as<uint8_t>(), h->w_tcut.as<uint8_t>());
-            h->tie.bounded = !lm;   // list-major: the replay walks the whole slab (everything is stored with exact ties on)
+            h->tie.bounded = true;
             h->tie.nsl = nsl;
             h->tie.cap = cap;
         }
@@ -815,7 +745,7 @@ struct TiesScope {
 
 // given != nullptr: the filter context of a combined batch (p's own filter clauses are ignored)
 int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, int k,
-                               float* d_distances, int64_t* d_labels, const FiltCtx* given = nullptr) {
+                               float* d_distances, int64_t* d_labels, const FiltCtx* given) {
     GH_TRY(ivfpq_check(h, p, nq, k));
     TiesScope ties_scope(h, p);
     if (k <= 0 || nq == 0) return GAMMA_HIP_OK;  // gamma_index_ivfpq.cc:753-756
@@ -843,7 +773,7 @@ int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, c
     }
     ListCompaction restore(h);
     GH_TRY(compact_lists_for_call(h, &fc, (int64_t)nq * p->nprobe * (h->ntotal / std::max(1, h->nlist)),
-                                  !given && !h->list_major, &restore));
+                                  !given, &restore));
     const int chunk = scan_chunk(h, nq, p->nprobe), P = p->nprobe;
     // long lists (C4: 64 probes x lists of tens of thousands) make the ADC slab the limit: the coarse
     // quantizer then still runs over the whole call (one GEMM instead of one per slab chunk)
@@ -1161,69 +1091,27 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
     return GAMMA_HIP_OK;
 }
 
-// host-pointer wrapper shared by ivfpq / flat
-// sync = false: everything is only enqueued (pinned host buffers); the caller synchronises the stream
-// lk != nullptr: the caller's SearchLock; its mu is released once everything is enqueued, so writers go on while
-// this call waits for the GPU (search_mu stays: the workspaces are in use)
-template <typename F>
-int host_search(H* h, int nq, int d, const float* x, int k, float* distances, int64_t* labels, F&& f,
-                bool sync = true, SearchLock* lk = nullptr, float* mapped_d = nullptr, int64_t* mapped_i = nullptr) {
-    if (nq <= 0 || k <= 0) return f(nullptr, nullptr, nullptr);
-    GH_CHECK(h, hipSetDevice(h->device));
-    GH_CHECK(h, h->w_x.ensure((size_t)nq * d * sizeof(float)));
-    GH_CHECK(h, h->w_outd.ensure((size_t)nq * k * sizeof(float)));
-    GH_CHECK(h, h->w_outl.ensure((size_t)nq * k * sizeof(int64_t)));
-    // Small synchronous calls (a client thread's single query): the caller's buffers are pageable, and a pageable
-    // copy is a blocking staged transfer -- three of them cost more than the search chain.  Queries and results go
-    // through a pinned staging area instead: the copies are true asynchronous transfers in stream order, the thread
-    // blocks once, and the results are copied out by the CPU.
-    const size_t bx = (size_t)nq * d * sizeof(float), bd = (size_t)nq * k * sizeof(float), bi = (size_t)nq * k * sizeof(int64_t);
-    const size_t off_i = (bx + 63) & ~(size_t)63, off_d = off_i + ((bi + 63) & ~(size_t)63), need = off_d + bd;
-    static const bool no_pin = getenv("GAMMA_HIP_NO_PINNED_CALLS") != nullptr;
-    if (sync && !no_pin && need <= ((size_t)1 << 20)) {
-        if (need > h->dir_pin_bytes) {
-            if (h->dir_pin) (void)hipHostFree(h->dir_pin);
-            h->dir_pin = nullptr;
-            h->dir_pin_bytes = 0;
-            GH_CHECK(h, hipHostMalloc(&h->dir_pin, std::max<size_t>(need * 2, 65536), hipHostMallocDefault));
-            h->dir_pin_bytes = std::max<size_t>(need * 2, 65536);
-            h->dir_pin_dev = nullptr;
-            if (hipHostGetDevicePointer(&h->dir_pin_dev, h->dir_pin, 0) != hipSuccess) h->dir_pin_dev = nullptr;
-        }
-        char* base = static_cast<char*>(h->dir_pin);
-        std::memcpy(base, x, bx);
-        GH_CHECK(h, hipMemcpyAsync(h->w_x.p, base, bx, hipMemcpyHostToDevice, h->stream));
-        // results: the last kernel of the chain stores them straight into the staging area (pinned host memory is
-        // mapped into the device's address space; a few KB of posted writes) -- no copy back at all
-        static const bool no_map = getenv("GAMMA_HIP_NO_MAPPED_RESULTS") != nullptr;
-        if (!no_map && h->dir_pin_dev) {
-            char* db = static_cast<char*>(h->dir_pin_dev);
-            GH_TRY(f(h->w_x.as<float>(), reinterpret_cast<float*>(db + off_d), reinterpret_cast<int64_t*>(db + off_i)));
-        } else {
-            GH_TRY(f(h->w_x.as<float>(), h->w_outd.as<float>(), h->w_outl.as<int64_t>()));
-            GH_CHECK(h, hipMemcpyAsync(base + off_d, h->w_outd.p, bd, hipMemcpyDeviceToHost, h->stream));
-            GH_CHECK(h, hipMemcpyAsync(base + off_i, h->w_outl.p, bi, hipMemcpyDeviceToHost, h->stream));
-        }
-        if (lk) lk->enqueued();
-        GH_CHECK(h, hipStreamSynchronize(h->stream));
-        std::memcpy(distances, base + off_d, bd);
-        std::memcpy(labels, base + off_i, bi);
-        return GAMMA_HIP_OK;
-    }
-    GH_CHECK(h, hipMemcpyAsync(h->w_x.p, x, (size_t)nq * d * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    if (mapped_d && mapped_i) {   // distances / labels are pinned and mapped (the combining queue's staging set): stored in place
-        GH_TRY(f(h->w_x.as<float>(), mapped_d, mapped_i));
-        if (lk) lk->enqueued();
-        if (sync) GH_CHECK(h, hipStreamSynchronize(h->stream));
-        return GAMMA_HIP_OK;
-    }
-    GH_TRY(f(h->w_x.as<float>(), h->w_outd.as<float>(), h->w_outl.as<int64_t>()));
-    GH_CHECK(h, hipMemcpyAsync(distances, h->w_outd.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    GH_CHECK(h, hipMemcpyAsync(labels, h->w_outl.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-    if (lk) lk->enqueued();
-    if (sync) GH_CHECK(h, hipStreamSynchronize(h->stream));
-    return GAMMA_HIP_OK;
+int flat_search_host_locked(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x, int k,
+                                  float* distances, int64_t* labels) {
+    SearchLock lk(h);
+    GH_TRY(check_params(h, p, nq, k));
+    if (h->raw_d <= 0) return fail(h, GAMMA_HIP_EINVAL, "raw store not initialised");
+    if (nq > 0 && k > 0 && (!x || !distances || !labels)) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
+    return host_search(h, nq, h->raw_d, x, k, distances, labels, [&](const float* dx, float* dd, int64_t* dl) {
+        return flat_search_device_locked(h, p, nq, dx, k, dd, dl);
+    }, true, &lk);
 }
+
+int ivfpq_search_host_locked(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x,
+                                   int k, float* distances, int64_t* labels) {
+    SearchLock lk(h);
+    GH_TRY(ivfpq_check(h, p, nq, k));
+    if (nq > 0 && k > 0 && (!x || !distances || !labels)) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
+    return host_search(h, nq, h->d, x, k, distances, labels, [&](const float* dx, float* dd, int64_t* dl) {
+        return ivfpq_search_device_locked(h, p, nq, dx, k, dd, dl);
+    }, true, &lk);
+}
+
 }  // namespace ghi
 
 using namespace ghi;
@@ -1255,388 +1143,6 @@ int gamma_hip_ivfflat_search(gamma_hip_index* h, const gamma_hip_search_params* 
     return host_search(h, nq, h->d, x, k, distances, labels, [&](const float* dx, float* dd, int64_t* dl) {
         return ivfflat_search_device_locked(h, p, nq, dx, k, dd, dl);
     }, true, &lk);
-}
-
-static int flat_search_host_locked(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x, int k,
-                                  float* distances, int64_t* labels) {
-    SearchLock lk(h);
-    GH_TRY(check_params(h, p, nq, k));
-    if (h->raw_d <= 0) return fail(h, GAMMA_HIP_EINVAL, "raw store not initialised");
-    if (nq > 0 && k > 0 && (!x || !distances || !labels)) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
-    return host_search(h, nq, h->raw_d, x, k, distances, labels, [&](const float* dx, float* dd, int64_t* dl) {
-        return flat_search_device_locked(h, p, nq, dx, k, dd, dl);
-    }, true, &lk);
-}
-
-static int ivfpq_search_host_locked(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x,
-                                   int k, float* distances, int64_t* labels) {
-    SearchLock lk(h);
-    GH_TRY(ivfpq_check(h, p, nq, k));
-    if (nq > 0 && k > 0 && (!x || !distances || !labels)) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
-    return host_search(h, nq, h->d, x, k, distances, labels, [&](const float* dx, float* dd, int64_t* dl) {
-        return ivfpq_search_device_locked(h, p, nq, dx, k, dd, dl);
-    }, true, &lk);
-}
-
-// Search is re-entrant in the reference and is called from many client threads at once, typically with
-// one query each (tools/perf.cc).  One GPU stream serves one call at a time, so small calls
-// that arrive while another is in flight are COMBINED: they queue, and a worker thread of the handle
-// (the reference's GPU model funnels its searches through one thread as well) takes every queued
-// request with the same parameters, runs them as one batch and hands the results back.  A call that
-// finds the handle idle runs directly on the caller's thread.
-// Results are those of the separate calls: rows are independent, and the coarse path (exact below 20
-// queries, GEMM form from 20 on, faiss:utils/distances.cpp:346) is the one each request's OWN size
-// selects -- requests only share a batch with requests that resolve to the same path.
-constexpr int COMB_MAX_NQ = 256, COMB_MAX_TOTAL = 4096;
-
-// filter table of a combined batch (h->mu held): entry i = request i's clauses + the delete bitmap
-static int build_group_filters(gamma_hip_index* h, const std::vector<gamma_hip_index::Waiter*>& grp, int total,
-                               std::vector<gh::FilterDesc>& tab, std::vector<int>& qf, FiltCtx* fc) {
-    GH_CHECK(h, hipSetDevice(h->device));
-    size_t tot = 0;
-    for (auto* g : grp)
-        if (g->p->has_range)
-            for (int i = 0; i < g->p->n_range; i++) tot += ((size_t)g->p->range[i].bitmap_bytes + 15) & ~(size_t)15;
-    GH_CHECK(h, h->w_filter.ensure(std::max<size_t>(tot, 16)));
-    tab.resize(grp.size());
-    qf.resize(total);
-    size_t off = 0;
-    int at = 0;
-    for (size_t i = 0; i < grp.size(); i++) {
-        GH_TRY(build_filter(h, grp[i]->p, &tab[i], &off));
-        for (int j = 0; j < grp[i]->nq; j++) qf[at++] = (int)i;
-    }
-    GH_CHECK(h, h->w_ftab.ensure(tab.size() * sizeof(gh::FilterDesc)));
-    GH_CHECK(h, h->w_qfil.ensure(qf.size() * sizeof(int)));
-    h->ftab_valid = false;   // entry 0 no longer holds a single call's descriptor
-    GH_CHECK(h, hipMemcpyAsync(h->w_ftab.p, tab.data(), tab.size() * sizeof(gh::FilterDesc), hipMemcpyHostToDevice, h->stream));
-    GH_CHECK(h, hipMemcpyAsync(h->w_qfil.p, qf.data(), qf.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    fc->d_tab = h->w_ftab.as<gh::FilterDesc>();
-    fc->d_qf = h->w_qfil.as<int>();
-    fc->any_clause = true;
-    return GAMMA_HIP_OK;
-}
-
-// wake one waiter of the combining queue.  Notified under ITS mutex: it cannot leave combined_search (and destroy the
-// condition variable, which lives on its stack) before this thread is done with it.
-static void comb_wake(gamma_hip_index::Waiter* w) {
-    std::lock_guard<std::mutex> l(w->wm);
-    w->done = true;
-    w->cv.notify_one();
-}
-
-static void combine_worker(gamma_hip_index* h) {
-    using W = gamma_hip_index::Waiter;
-    auto same = [](const W* a, const W* b) {
-        return a->kind == b->kind && a->k == b->k && a->mode == b->mode && a->p->metric == b->p->metric &&
-               a->p->nprobe == b->p->nprobe &&
-               a->p->recall_num == b->p->recall_num && a->p->has_rank == b->p->has_rank &&
-               a->p->min_score == b->p->min_score && a->p->max_score == b->p->max_score &&
-               a->p->exact_ties == b->p->exact_ties;
-    };
-    // a batch in flight: its requests, where its results land, whether the stream still has to be awaited
-    struct Batch {
-        std::vector<W*> grp;
-        int rc = GAMMA_HIP_OK, total = 0, kk = 0;
-        float* sd = nullptr;
-        int64_t* si = nullptr;
-        bool enqueued = false;
-        int set = -1;                       // pinned staging set holding its inputs / results
-        std::vector<gh::FilterDesc> ftab;   // host images of the uploads, alive until the batch is awaited
-        std::vector<int> qf;
-        std::vector<int> rcs;               // per-request codes when the batch had to be redone one by one
-    };
-    // Results -> callers: a helper thread copies them out of the pinned staging set and wakes the callers
-    // (one futex wake per request costs the worker more than launching the next batch), so the worker only
-    // forms, launches and awaits batches.  A staging set is reused once its batch has been delivered.
-    std::mutex n_mu;
-    std::condition_variable n_cv;
-    std::deque<Batch> n_q;
-    bool n_stop = false;
-    constexpr int NSET = gamma_hip_index::NSET;
-    std::atomic<bool> set_busy[NSET];
-    for (int i = 0; i < NSET; i++) set_busy[i] = false;
-    std::thread notifier([&]() {
-        std::unique_lock<std::mutex> nl(n_mu);
-        for (;;) {
-            n_cv.wait(nl, [&] { return n_stop || !n_q.empty(); });
-            if (n_q.empty()) break;   // stop requested and nothing left
-            Batch b = std::move(n_q.front());
-            n_q.pop_front();
-            nl.unlock();
-            // rows -> the callers' buffers (they are blocked; a batch of 128 is 15 KB), the staging set is free again --
-            // NOT left to the callers: one of them descheduled for a time slice would hold its set, and with more
-            // client threads than cores every set was soon held by a straggler -- then the waiters are linked and the
-            // roots woken (comb_wake); the forest unfolds on the callers' own threads
-            const size_t n = b.grp.size();
-            constexpr size_t ROOTS = 16;   // woken by this thread (batches up to 16: all of them); 16 + 64 + 256 in two hops
-            if (b.rc == GAMMA_HIP_OK && b.sd) {
-                size_t at = 0;
-                for (W* g : b.grp) {
-                    std::memcpy(g->D, b.sd + at * b.kk, (size_t)g->nq * b.kk * sizeof(float));
-                    std::memcpy(g->I, b.si + at * b.kk, (size_t)g->nq * b.kk * sizeof(int64_t));
-                    at += g->nq;
-                }
-            }
-            if (b.set >= 0) set_busy[b.set].store(false, std::memory_order_release);
-            for (size_t i = 0; i < n; i++) {
-                W* g = b.grp[i];
-                g->rc = b.rcs.empty() ? b.rc : b.rcs[i];
-                for (size_t j = 0; j < (size_t)W::FAN; j++) {   // waiter i wakes ROOTS + FAN i .. ROOTS + FAN i + FAN - 1
-                    const size_t c = ROOTS + W::FAN * i + j;
-                    g->child[j] = c < n ? b.grp[c] : nullptr;
-                }
-            }
-            for (size_t i = 0; i < std::min<size_t>(n, ROOTS); i++) comb_wake(b.grp[i]);   // the roots, from here
-            nl.lock();
-        }
-    });
-    auto post = [&](Batch&& b) {
-        if (b.grp.empty()) return;
-        {
-            std::lock_guard<std::mutex> nl(n_mu);
-            n_q.push_back(std::move(b));
-        }
-        n_cv.notify_one();
-    };
-    Batch cur;
-    int set = 0;
-    bool holding = false;          // this thread holds h->search_mu
-    hipEvent_t done_ev[NSET] = {nullptr, nullptr, nullptr, nullptr};   // end of the batch staged in set i
-    (void)hipSetDevice(h->device);
-    for (auto& e : done_ev)
-        // (blocking: the worker sleeps while the GPU runs its batch instead of spinning on a core for the whole busy
-        //  period -- with 128 clients under the test box's 16-core quota 275 k -> 328 k queries/s sustained, the
-        //  median latency no worse; GAMMA_HIP_COMB_SPIN=1 spins)
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming | (getenv("GAMMA_HIP_COMB_SPIN") ? 0 : hipEventBlockingSync)) !=
-            hipSuccess)
-            e = nullptr;
-    static const bool dbg = getenv("GAMMA_HIP_COMB_DBG") != nullptr;   // phase times of the worker, printed at exit
-    double us_stage = 0, us_deliver = 0, us_sync = 0;
-    long n_batches = 0, n_reqs = 0;
-    std::unique_lock<std::mutex> lk(h->comb_mu);
-    for (;;) {
-        h->comb_wcv.wait(lk, [&] { return h->comb_stop || (!h->comb_busy && !h->comb_q.empty()); });
-        if (h->comb_stop) break;
-        h->comb_busy = true;
-        // The handle stays busy until the queue is drained.  One batch at a time: formed, staged, enqueued, awaited
-        // through its event, handed to the notifier.  GAMMA_HIP_COMB_PIPELINE=1 keeps TWO in flight (batch N+1 is
-        // formed and enqueued while the GPU runs batch N; the stream orders them, so workspaces are reused safely and
-        // results land in different staging sets; search_mu is then held across batches and given up at least every
-        // 32).  Measured with closed-loop single-query clients (tools/plugin_clients.py): no gain -- 8 threads 67 k
-        // against 67 k queries/s, 32 threads 190 k against 196 k, 128 threads 440 k against 470 k with a worse p99: the
-        // batches get smaller by what the overlap saves, each still pays its fixed 20 us of enqueue and ~45 us of GPU.
-        Batch prev;
-        bool have_prev = false;
-        int streak = 0;
-        // await and deliver a batch; its per-request redo when the batch failed as a whole
-        auto finish = [&](Batch& b) {
-            if (b.enqueued) {
-                if (b.rc == GAMMA_HIP_OK) {
-                    if (hipEventSynchronize(done_ev[b.set]) != hipSuccess) b.rc = GAMMA_HIP_EDEVICE;
-                } else if (hipStreamSynchronize(h->stream) != hipSuccess) {
-                    b.rc = GAMMA_HIP_EDEVICE;
-                }
-                b.enqueued = false;
-                if (b.rc != GAMMA_HIP_OK && b.grp.size() > 1) {
-                    // one request's parameters may be at fault (a filter on an unknown column, ...): every request gets
-                    // the outcome of its own call -- with the stream drained and the handle released
-                    (void)hipStreamSynchronize(h->stream);
-                    if (holding) {
-                        h->search_mu.unlock();
-                        holding = false;
-                    }
-                    for (W* g : b.grp) {
-                        gamma_hip_search_params pg = *g->p;
-                        pg.coarse_mode = g->mode;
-                        b.rcs.push_back(g->kind == 1 ? flat_search_host_locked(h, &pg, g->nq, g->x, g->k, g->D, g->I)
-                                                     : ivfpq_search_host_locked(h, &pg, g->nq, g->x, g->k, g->D, g->I));
-                    }
-                    b.sd = nullptr;   // results are already in the callers' buffers
-                    b.rc = GAMMA_HIP_OK;
-                }
-            }
-            if (dbg) {
-                n_batches++;
-                n_reqs += (long)b.grp.size();
-            }
-            post(std::move(b));
-        };
-        for (;;) {
-            cur = Batch();
-            const auto t_a = std::chrono::steady_clock::now();
-            if (!h->comb_q.empty()) {   // one group: the oldest request and everything compatible with it
-                W* first = h->comb_q.front();
-                for (auto it = h->comb_q.begin(); it != h->comb_q.end();) {
-                    if (same(first, *it) && (cur.grp.empty() || cur.total + (*it)->nq <= COMB_MAX_TOTAL)) {
-                        cur.total += (*it)->nq;
-                        cur.grp.push_back(*it);
-                        it = h->comb_q.erase(it);
-                    } else {
-                        ++it;
-                    }
-                }
-            }
-            lk.unlock();
-            if (!cur.grp.empty()) {
-                W* first = cur.grp.front();
-                gamma_hip_search_params pp = *first->p;
-                pp.coarse_mode = first->mode;
-                const bool flat = first->kind == 1;
-                const int d = flat ? h->raw_d : h->d, kk = first->k, total = cur.total;
-                cur.kk = kk;
-                const size_t bx = (size_t)total * d * sizeof(float), bd = (size_t)total * kk * sizeof(float),
-                             bi = (size_t)total * kk * sizeof(int64_t);
-                const size_t off_i = (bx + 15) & ~(size_t)15, off_d = off_i + ((bi + 15) & ~(size_t)15),
-                             need = off_d + bd;
-                while (set_busy[set].load(std::memory_order_acquire)) std::this_thread::yield();   // its last batch is being delivered
-                if (need > h->comb_pin_bytes[set]) {
-                    if (h->comb_pin[set]) (void)hipHostFree(h->comb_pin[set]);
-                    h->comb_pin[set] = nullptr;
-                    h->comb_pin_bytes[set] = 0;
-                    h->comb_pin_dev[set] = nullptr;
-                    if (hipSetDevice(h->device) == hipSuccess &&
-                        hipHostMalloc(&h->comb_pin[set], need * 2, hipHostMallocDefault) == hipSuccess) {
-                        h->comb_pin_bytes[set] = need * 2;
-                        if (hipHostGetDevicePointer(&h->comb_pin_dev[set], h->comb_pin[set], 0) != hipSuccess)
-                            h->comb_pin_dev[set] = nullptr;
-                    } else {
-                        cur.rc = GAMMA_HIP_ENOMEM;
-                    }
-                }
-                if (cur.rc == GAMMA_HIP_OK) {
-                    char* base = static_cast<char*>(h->comb_pin[set]);
-                    float* sx = reinterpret_cast<float*>(base);
-                    cur.si = reinterpret_cast<int64_t*>(base + off_i);
-                    cur.sd = reinterpret_cast<float*>(base + off_d);
-                    size_t at = 0;
-                    for (W* g : cur.grp) {
-                        std::memcpy(sx + at * d, g->x, (size_t)g->nq * d * sizeof(float));
-                        at += g->nq;
-                    }
-                    cur.set = set;
-                    static const bool no_map = getenv("GAMMA_HIP_NO_MAPPED_RESULTS") != nullptr;
-                    const bool map_ok = !no_map && h->comb_pin_dev[set] != nullptr;
-                    set_busy[set].store(true, std::memory_order_release);
-                    if (!holding) {        // held while batches are in flight (the workspaces are in use), see below
-                        h->search_mu.lock();
-                        holding = true;
-                    }
-                    h->mu.lock();          // while the batch reads the handle and is enqueued
-                    cur.rc = flat ? check_params(h, &pp, total, kk) : ivfpq_check(h, &pp, total, kk);
-                    // requests with their own filter clauses: one table entry per request, a query -> entry map
-                    // (IVFPQ only: filtered flat requests are not combined)
-                    FiltCtx fc;
-                    bool any_filter = false;
-                    for (W* g : cur.grp) any_filter |= g->p->has_range || g->p->n_field > 0 || g->p->n_term > 0;
-                    const bool multi = !flat && any_filter && cur.grp.size() > 1;
-                    if (cur.rc == GAMMA_HIP_OK && multi) cur.rc = build_group_filters(h, cur.grp, total, cur.ftab, cur.qf, &fc);
-                    if (cur.rc == GAMMA_HIP_OK)
-                        cur.rc = host_search(h, total, d, sx, kk, cur.sd, cur.si,
-                                             [&](const float* dx, float* dd, int64_t* dl) {
-                                                 if (flat) return flat_search_device_locked(h, &pp, total, dx, kk, dd, dl);
-                                                 return ivfpq_search_device_locked(h, &pp, total, dx, kk, dd, dl,
-                                                                                   multi ? &fc : nullptr);
-                                             },
-                                             /*sync=*/false, nullptr,
-                                             map_ok ? reinterpret_cast<float*>(static_cast<char*>(h->comb_pin_dev[set]) + off_d) : nullptr,
-                                             map_ok ? reinterpret_cast<int64_t*>(static_cast<char*>(h->comb_pin_dev[set]) + off_i) : nullptr);
-                    if (cur.rc == GAMMA_HIP_OK && hipEventRecord(done_ev[set], h->stream) != hipSuccess) cur.rc = GAMMA_HIP_EDEVICE;
-                    h->mu.unlock();
-                    cur.enqueued = true;
-                }
-                set = (set + 1) % NSET;
-            }
-            const auto t_b = std::chrono::steady_clock::now();
-            // the batch before this one: await, deliver.  A failed batch is finished before anything else goes on.
-            if (have_prev) {
-                finish(prev);
-                have_prev = false;
-            }
-            const auto t_c = std::chrono::steady_clock::now();
-            static const bool pipeline = getenv("GAMMA_HIP_COMB_PIPELINE") != nullptr;   // off: measured, see above
-            if (pipeline && cur.enqueued && cur.rc == GAMMA_HIP_OK && ++streak < 32) {
-                prev = std::move(cur);
-                have_prev = true;
-            } else if (!cur.grp.empty()) {
-                finish(cur);
-                streak = 32;
-            }
-            if (streak >= 32 && !have_prev) {   // nothing in flight: let others at the handle
-                if (holding) {
-                    h->search_mu.unlock();
-                    holding = false;
-                }
-                streak = 0;
-            }
-            if (dbg) {
-                us_stage += std::chrono::duration<double, std::micro>(t_b - t_a).count();
-                us_sync += std::chrono::duration<double, std::micro>(t_c - t_b).count();
-            }
-            lk.lock();
-            if (h->comb_q.empty()) {
-                if (have_prev) {   // drain the pipeline; requests may arrive meanwhile
-                    lk.unlock();
-                    finish(prev);
-                    have_prev = false;
-                    lk.lock();
-                }
-                if (h->comb_q.empty()) break;
-            }
-        }
-        if (holding) {
-            h->search_mu.unlock();
-            holding = false;
-        }
-        streak = 0;
-        h->comb_busy = false;
-    }
-    lk.unlock();
-    {
-        std::lock_guard<std::mutex> nl(n_mu);
-        n_stop = true;
-    }
-    n_cv.notify_one();
-    notifier.join();
-    for (auto& e : done_ev)
-        if (e) (void)hipEventDestroy(e);
-    if (dbg && n_batches)
-        fprintf(stderr, "combine worker: %ld batches, %.1f requests each; per batch: group+stage+enqueue %.1f us (the batch before it on the GPU meanwhile), "
-                "(unused %.1f) then waiting for that batch %.1f us\n", n_batches, (double)n_reqs / n_batches, us_stage / n_batches, us_deliver / n_batches,
-                us_sync / n_batches);
-}
-
-static int combined_search(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x, int k,
-                           float* distances, int64_t* labels, int kind = 0) {
-    gamma_hip_index::Waiter w;
-    w.p = p; w.nq = nq; w.k = k; w.x = x; w.D = distances; w.I = labels;
-    w.kind = kind;
-    w.mode = kind == 1 ? 0 : (p->coarse_mode < 0 ? (nq < 20 ? 0 : 1) : p->coarse_mode);
-    std::unique_lock<std::mutex> lk(h->comb_mu);
-    if (!h->comb_busy && h->comb_q.empty()) {   // idle handle: run on this thread, no hop
-        h->comb_busy = true;
-        lk.unlock();
-        gamma_hip_search_params pp = *p;
-        pp.coarse_mode = w.mode;
-        const int rc = kind == 1 ? flat_search_host_locked(h, &pp, nq, x, k, distances, labels)
-                                 : ivfpq_search_host_locked(h, &pp, nq, x, k, distances, labels);
-        lk.lock();
-        h->comb_busy = false;
-        if (!h->comb_q.empty()) h->comb_wcv.notify_one();
-        return rc;
-    }
-    if (!h->comb_thread.joinable()) h->comb_thread = std::thread(combine_worker, h);
-    h->comb_q.push_back(&w);
-    h->comb_wcv.notify_one();
-    lk.unlock();
-    {
-        std::unique_lock<std::mutex> wl(w.wm);
-        w.cv.wait(wl, [&] { return w.done; });
-    }
-    // (every field of w was written before done; the children are still blocked, their Waiters alive)
-    for (gamma_hip_index::Waiter* c : w.child)
-        if (c) comb_wake(c);
-    return w.rc;
 }
 
 int gamma_hip_ivfpq_search(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x,

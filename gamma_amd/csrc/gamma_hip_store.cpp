@@ -320,6 +320,36 @@ int64_t gamma_hip_field_count(gamma_hip_index* h, int field_id) {
     return it == h->fields.end() ? 0 : it->second.n;
 }
 
+// A STRING column on the device: doc i = items tok[start .. start + len), its row word = start << 16 | len.  One 8-byte
+// word per doc (not CSR offsets) so that a doc's items can be REWRITTEN: the new items go in place when they fit, else
+// to the end of the item array, and the row word -- a single aligned store -- switches the doc over.
+static int term_reserve(gamma_hip_index* h, WriteLock& lk, gamma_hip_index::TermColumn& c, int64_t add_docs, int64_t add_tok) {
+    if (c.ndocs + add_docs <= c.cap_docs && c.ntok + add_tok <= c.cap_tok && c.d_off) return GAMMA_HIP_OK;
+    // growth frees the old arrays: no search may be reading them
+    GH_CHECK(h, lk.exclusive());
+    const int64_t nd = std::max<int64_t>(c.ndocs + add_docs, std::max<int64_t>(1 << 16, c.cap_docs * 2));
+    const int64_t nt = std::max<int64_t>(c.ntok + add_tok, std::max<int64_t>(1 << 16, c.cap_tok * 2));
+    int64_t* no = nullptr;
+    int32_t* ntk = nullptr;
+    GH_CHECK(h, hipMalloc((void**)&no, (size_t)nd * sizeof(int64_t)));
+    if (hipMalloc((void**)&ntk, (size_t)nt * sizeof(int32_t)) != hipSuccess) {
+        (void)hipFree(no);
+        return fail(h, GAMMA_HIP_ENOMEM, "term column: out of memory");
+    }
+    if (c.d_off) {
+        if (c.ndocs) GH_CHECK(h, hipMemcpyAsync(no, c.d_off, (size_t)c.ndocs * sizeof(int64_t), hipMemcpyDeviceToDevice, h->wstream));
+        if (c.ntok) GH_CHECK(h, hipMemcpyAsync(ntk, c.d_tok, (size_t)c.ntok * sizeof(int32_t), hipMemcpyDeviceToDevice, h->wstream));
+    }
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    if (c.d_off) (void)hipFree(c.d_off);
+    if (c.d_tok) (void)hipFree(c.d_tok);
+    c.d_off = no;
+    c.d_tok = ntk;
+    c.cap_docs = nd;
+    c.cap_tok = nt;
+    return GAMMA_HIP_OK;
+}
+
 int gamma_hip_term_append(gamma_hip_index* h, int field_id, int64_t n_docs, const int32_t* counts,
                           const int32_t* items) {
     if (!h || n_docs < 0 || (n_docs > 0 && !counts)) return GAMMA_HIP_EINVAL;
@@ -328,46 +358,48 @@ int gamma_hip_term_append(gamma_hip_index* h, int field_id, int64_t n_docs, cons
     auto& c = h->terms[field_id];
     int64_t add_tok = 0;
     for (int64_t i = 0; i < n_docs; i++) {
-        if (counts[i] < 0) return fail(h, GAMMA_HIP_EINVAL, "negative item count");
+        if (counts[i] < 0 || counts[i] > 65535) return fail(h, GAMMA_HIP_EINVAL, "item count out of range");
         add_tok += counts[i];
     }
     if (add_tok > 0 && !items) return fail(h, GAMMA_HIP_EINVAL, "null items");
-    if (c.ndocs + n_docs + 1 > c.cap_docs || c.ntok + add_tok > c.cap_tok || !c.d_off) {
-        // growth frees the old arrays: no search may be reading them
-        GH_CHECK(h, lk.exclusive());
-        const int64_t nd = std::max<int64_t>(c.ndocs + n_docs + 1, std::max<int64_t>(1 << 16, c.cap_docs * 2));
-        const int64_t nt = std::max<int64_t>(c.ntok + add_tok, std::max<int64_t>(1 << 16, c.cap_tok * 2));
-        int64_t* no = nullptr;
-        int32_t* ntk = nullptr;
-        GH_CHECK(h, hipMalloc((void**)&no, (size_t)nd * sizeof(int64_t)));
-        GH_CHECK(h, hipMalloc((void**)&ntk, (size_t)nt * sizeof(int32_t)));
-        if (c.d_off) {
-            GH_CHECK(h, hipMemcpyAsync(no, c.d_off, (size_t)(c.ndocs + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, h->wstream));
-            if (c.ntok) GH_CHECK(h, hipMemcpyAsync(ntk, c.d_tok, (size_t)c.ntok * sizeof(int32_t), hipMemcpyDeviceToDevice, h->wstream));
-        } else {
-            GH_CHECK(h, hipMemsetAsync(no, 0, sizeof(int64_t), h->wstream));   // off[0] = 0
-        }
-        GH_CHECK(h, hipStreamSynchronize(h->wstream));
-        if (c.d_off) (void)hipFree(c.d_off);
-        if (c.d_tok) (void)hipFree(c.d_tok);
-        c.d_off = no;
-        c.d_tok = ntk;
-        c.cap_docs = nd;
-        c.cap_tok = nt;
-    }
+    GH_TRY(term_reserve(h, lk, c, n_docs, add_tok));
     if (n_docs > 0) {
-        std::vector<int64_t> off(n_docs);
+        std::vector<int64_t> rows(n_docs);
         int64_t run = c.ntok;
         for (int64_t i = 0; i < n_docs; i++) {
+            rows[i] = (run << 16) | (int64_t)counts[i];
             run += counts[i];
-            off[i] = run;
         }
         if (add_tok) GH_CHECK(h, hipMemcpyAsync(c.d_tok + c.ntok, items, (size_t)add_tok * sizeof(int32_t), hipMemcpyHostToDevice, h->wstream));
-        GH_CHECK(h, hipMemcpyAsync(c.d_off + c.ndocs + 1, off.data(), (size_t)n_docs * sizeof(int64_t), hipMemcpyHostToDevice, h->wstream));
+        GH_CHECK(h, hipMemcpyAsync(c.d_off + c.ndocs, rows.data(), (size_t)n_docs * sizeof(int64_t), hipMemcpyHostToDevice, h->wstream));
         GH_CHECK(h, hipStreamSynchronize(h->wstream));
+        c.h_rows.insert(c.h_rows.end(), rows.begin(), rows.end());
         c.ntok += add_tok;
         c.ndocs += n_docs;   // published last: a search enqueued before sees the shorter column
     }
+    return GAMMA_HIP_OK;
+}
+
+// a doc's items rewritten (the doc's STRING field was updated in the table)
+int gamma_hip_term_update(gamma_hip_index* h, int field_id, int64_t docid, int32_t count, const int32_t* items) {
+    if (!h || count < 0 || count > 65535 || (count > 0 && !items)) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    GH_CHECK(h, hipSetDevice(h->device));
+    auto it = h->terms.find(field_id);
+    if (it == h->terms.end() || docid < 0 || docid >= it->second.ndocs) return fail(h, GAMMA_HIP_EINVAL, "term update: unknown field / doc");
+    auto& c = it->second;
+    const int64_t old = c.h_rows[docid];
+    int64_t start = old >> 16;
+    if (count > (int32_t)(old & 0xffff)) {   // does not fit in place: the new items go to the end of the item array
+        GH_TRY(term_reserve(h, lk, c, 0, count));
+        start = c.ntok;
+        c.ntok += count;
+    }
+    const int64_t row = (start << 16) | (int64_t)count;
+    if (count) GH_CHECK(h, hipMemcpyAsync(c.d_tok + start, items, (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice, h->wstream));
+    GH_CHECK(h, hipMemcpyAsync(c.d_off + docid, &row, sizeof(row), hipMemcpyHostToDevice, h->wstream));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    c.h_rows[docid] = row;
     return GAMMA_HIP_OK;
 }
 

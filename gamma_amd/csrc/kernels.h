@@ -25,7 +25,7 @@ struct RangeDesc {
 };
 
 // numeric column predicate (IsInRange<T>, index/impl/gpu/gamma_index_ivfpq_gpu.cc:685-727)
-constexpr int kMaxField = 4;
+constexpr int kMaxField = 8;
 struct FieldDesc {
     const void* col;
     int64_t n;
@@ -36,7 +36,7 @@ struct FieldDesc {
 
 // term filter on a STRING field (FilteredByTermFilter, index/impl/gpu/gamma_index_ivfpq_gpu.cc:727-762): the
 // field's items (split at \001) are dictionary-encoded on the host; doc i holds tok[off[i] .. off[i + 1])
-constexpr int kMaxTerm = 4, kMaxTermItems = 8;
+constexpr int kMaxTerm = 8, kMaxTermItems = 16;
 struct TermDesc {
     const int64_t* off;
     const int32_t* tok;
@@ -127,32 +127,6 @@ struct ScanBound {
                                 // sum_m T2[list][m][code[m]]; per list sum_m max_c |T2[l][m][c]|.  nullptr: regular loop
     const float* t2max;
 };
-// list-major consumer scan (scan_lm.hip)
-constexpr int LM_PAIR_CAP = 64;   // survivors one (query, probe) pair may leave in its own mini-slice
-struct LmScanArgs {
-    const int* units;             // [blocks][lm_units_per_block()][16] unit records (k_lm_units)
-    const int* ucount;            // [blocks]
-    int nq, B;                    // queries, queries per block
-    const float* st2;             // [nq][M][256] query tables
-    const float* T2;              // [nlist][M][256] (L2 only)
-    const uint8_t* codes;         // list arena
-    const int64_t* ids;
-    float* out;                   // distance slab [nq][q_stride]
-    int64_t q_stride;
-    unsigned long long* surv;     // [nq][nslc][LM_PAIR_CAP] pair slices
-    int* cnt;                     // [nq][cnt_stride]: [0] producer slice, [1 + probe - G] pair slices
-    int nslc, cnt_stride;
-    int store_all, need_ids;
-    const FilterDesc* ftab;       // entry 0: the call's validity predicates
-};
-int lm_pair_cap();
-int lm_block_queries(int P, int G);
-int lm_units_per_block();
-void launch_lm_units(hipStream_t s, const int* probe, const float* dis0, const int* pair_off,
-                     const int64_t* list_off, const int* list_len, const uint8_t* list_mask, int nlist,
-                     const int* qperm, const unsigned long long* ready, int nq, int P, int G, int B, int* units,
-                     int* ucount);
-void launch_scan_lm(hipStream_t s, bool l2, int M, const LmScanArgs& a);
 int scan_slice_cap();
 // true when launch_ivfpq_scan_pair would run the filter pass (CF) for a bounded scan with these arguments; the caller
 // then launches TWO groups per query -- the producer's G probes and one consumer group with all the others
@@ -236,8 +210,7 @@ void launch_select_final(hipStream_t s, bool smallest, const unsigned long long*
                          int nslices, int slice_cap, const unsigned long long* ready, const int* pair_off, int P,
                          int nq, int K, const int64_t* pair_base, const int64_t* ids, uint8_t* flag, float* out_vals,
                          int* out_pos, int64_t* out_ids, uint8_t* cut_tie = nullptr,
-                         unsigned long long* tie_stats = nullptr, int* rq_list = nullptr, int* rq_count = nullptr,
-                         const unsigned long long* surv_c = nullptr, int cap_c = 0);   // slices 1.. in their own
+                         unsigned long long* tie_stats = nullptr, int* rq_list = nullptr, int* rq_count = nullptr);   // slices 1.. in their own
                                                                                         // array [nq][nslices - 1][cap_c]   // cut_tie[q] = 1: the K-th and (K+1)-th keys are equal
 void launch_map_candidates(hipStream_t s, const int* pos, int nq, int R, int P,
                            const int* probe_list, const int* pair_off, const int64_t* list_off,

@@ -702,8 +702,7 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
                                                       int64_t* __restrict__ out_ids,
                                                       uint8_t* __restrict__ cut_tie,
                                                       unsigned long long* __restrict__ tie_stats,
-                                                      int* __restrict__ rq_list, int* __restrict__ rq_count,
-                                                      const unsigned long long* __restrict__ surv_c, int cap_c) {
+                                                      int* __restrict__ rq_list, int* __restrict__ rq_count) {
     __shared__ int s_hist[4][256];
     __shared__ unsigned long long s_cand[4][SF_CAND];   // candidates, later the <= 256 kept ones (in place)
     __shared__ int s_off[4][PMAX + 8];
@@ -720,13 +719,8 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
         if (lane == 0) flag[q] = 1;
         return;
     }
-    // surv_c != nullptr (list-major consumer scan, scan_lm.hip): slice 0 is the producer's [nq][slice_cap], slices
-    // 1.. are the (query, probe) pair slices [nq][nslices - 1][cap_c]
-    auto slice_ptr = [&](int g) -> const unsigned long long* {
-        if (surv_c) return g == 0 ? surv + (int64_t)q * slice_cap : surv_c + ((int64_t)q * (nslices - 1) + (g - 1)) * cap_c;
-        return surv + ((int64_t)q * nslices + g) * slice_cap;
-    };
-    if (__ballot(my_cnt > ((surv_c && lane > 0) ? cap_c : slice_cap))) {
+    auto slice_ptr = [&](int g) -> const unsigned long long* { return surv + ((int64_t)q * nslices + g) * slice_cap; };
+    if (__ballot(my_cnt > slice_cap)) {
         if (lane == 0) {
             flag[q] = 1;
             if (rq_list) rq_list[atomicAdd(rq_count, 1)] = q;
@@ -1407,13 +1401,13 @@ void launch_select_final(hipStream_t s, bool smallest, const unsigned long long*
                          int nslices, int slice_cap, const unsigned long long* ready, const int* pair_off, int P,
                          int nq, int K, const int64_t* pair_base, const int64_t* ids, uint8_t* flag, float* out_vals,
                          int* out_pos, int64_t* out_ids, uint8_t* cut_tie, unsigned long long* tie_stats,
-                         int* rq_list, int* rq_count, const unsigned long long* surv_c, int cap_c) {
+                         int* rq_list, int* rq_count) {
     if (nq <= 0) return;
     if (P > 128 || nslices > 64) abort();   // callers gate on this (gamma_hip_search.cpp, ivfpq_stage_a)
 #define GH_SF(SM, PM)                                                                                        \
     hipLaunchKernelGGL((k_select_final<SM, PM>), dim3((nq + 3) / 4), dim3(256), 0, s, surv, gcnt, nslices,   \
                        slice_cap, ready, pair_off, P, nq, K, pair_base, ids, flag,                           \
-                       out_vals, out_pos, out_ids, cut_tie, tie_stats, rq_list, rq_count, surv_c, cap_c)
+                       out_vals, out_pos, out_ids, cut_tie, tie_stats, rq_list, rq_count)
     if (smallest) {
         if (P <= 64) GH_SF(true, 64);
         else GH_SF(true, 128);

@@ -1,5 +1,6 @@
 // filter_bridge.h -- GammaSearchCondition's range filter -> gamma_hip_range_filter[]
 #pragma once
+#include <stdio.h>
 #include <string.h>
 
 #include <algorithm>
@@ -45,8 +46,22 @@ inline void FillRangeFilters(GammaSearchCondition *cond, gamma_hip_search_params
 // request's filters into the C ABI's clauses; the scan then evaluates them per code with the reference GPU
 // model's rules, and nothing docs/8 bytes long is uploaded per request.
 // The mirror is fed lazily: a field is read from the Table (GetFieldRawValue) up to the current doc count the
-// first time a filter names it, and extended by the docs added since on every later request.  Field values
-// rewritten in place by a doc update are not re-read (the reference's GPU model reads the Table per candidate).
+// first time a filter names it, and extended by the docs added since on every later request.  A doc update reaches
+// the mirror through the model's Update (Refresh below: the engine hands an upserted doc's vid to every index of its
+// vector fields, vector/vector_manager.cc:355-380 -- the same pass that brings the new vector); an update that
+// rewrites ONLY scalar fields of a doc is not announced to retrieval models at all and is seen by the reference's
+// GPU model (which reads the Table per candidate) but not by this mirror.
+// Requests with more clauses than the C ABI carries (GAMMA_HIP_MAX_FIELD_FILTERS / _TERM_FILTERS / _TERM_ITEMS) take
+// the request's docid bitmaps instead -- the same result, evaluated on the host by the engine -- and say so once.
+// number of DOCUMENTS behind a vector store of `nvec` vectors: with several vectors per document (VIDMgr,
+// vector/raw_vector_common.h:36-110) the table holds fewer docs than the store holds vectors, and Table::GetFieldRawValue
+// does not check its docid (table/table.cc)
+inline int64_t DocCountOf(RetrievalModel *model, int64_t nvec) {
+  RawVector *rv = model ? dynamic_cast<RawVector *>(model->vector_) : nullptr;
+  if (nvec > 0 && rv && rv->VidMgr() && rv->VidMgr()->MultiVids()) return (int64_t)rv->VidMgr()->VID2DocID((int)nvec - 1) + 1;
+  return nvec;
+}
+
 class DeviceColumns {
  public:
   // false: this request cannot take the device path (no table, too many clauses, unknown field, ...): use the bitmaps
@@ -55,9 +70,10 @@ class DeviceColumns {
     if (!cond || !cond->table) return false;
     if (cond->range_filters.empty() && cond->term_filters.empty()) return false;
     if (cond->range_filters.size() > GAMMA_HIP_MAX_FIELD_FILTERS || cond->term_filters.size() > GAMMA_HIP_MAX_TERM_FILTERS)
-      return false;
+      return TooMany();
     std::lock_guard<std::mutex> g(mu_);
     Table *t = cond->table;
+    table_ = t;
     for (auto &r : cond->range_filters) {
       DataType type;
       if (t->GetFieldType(r.field, type) || type == DataType::STRING || type == DataType::VECTOR) return false;
@@ -95,7 +111,7 @@ class DeviceColumns {
       const int fid = t->GetAttrIdx(tm.field);
       if (fid < 0 || Sync(h, t, fid, type, ndocs)) return false;
       std::vector<std::string> items = Split(tm.value);
-      if (items.size() > GAMMA_HIP_MAX_TERM_ITEMS) return false;
+      if (items.size() > GAMMA_HIP_MAX_TERM_ITEMS) return TooMany();
       gamma_hip_term_filter f;
       memset(&f, 0, sizeof(f));
       f.field_id = fid;
@@ -118,11 +134,52 @@ class DeviceColumns {
     return true;
   }
 
+  // The docs whose vectors the engine has just handed to the model's Update: their mirrored fields are read again from
+  // the Table and rewritten on the device (gamma_hip_field_update / gamma_hip_term_update).
+  int Refresh(gamma_hip_index *h, const std::vector<int64_t> &docids) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (!table_ || fields_.empty()) return 0;
+    std::string raw;
+    for (auto &kv : fields_) {
+      const int fid = kv.first;
+      Field &f = kv.second;
+      for (int64_t doc : docids) {
+        if (doc < 0 || doc >= f.synced) continue;   // not mirrored yet: Sync reads the current value when it gets there
+        raw.clear();
+        if (table_->GetFieldRawValue((int)doc, fid, raw)) continue;
+        if (f.type == DataType::STRING) {
+          std::vector<int32_t> items;
+          for (auto &s : Split(raw)) {
+            auto it = f.dict.find(s);
+            if (it == f.dict.end()) it = f.dict.emplace(s, (int)f.dict.size()).first;
+            items.push_back(it->second);
+          }
+          if (gamma_hip_term_update(h, fid, doc, (int32_t)items.size(), items.data())) return -1;
+        } else {
+          uint8_t v[8] = {0};
+          memcpy(v, raw.data(), std::min(sizeof(v), raw.size()));
+          if (gamma_hip_field_update(h, fid, doc, v)) return -1;
+        }
+      }
+    }
+    return 0;
+  }
+
  private:
   struct Field {
     int64_t synced = 0;
+    DataType type = DataType::INT;
     std::map<std::string, int> dict;   // STRING fields: item -> id
   };
+  bool TooMany() {
+    if (!warned_) {
+      warned_ = true;
+      fprintf(stderr, "[gamma_hip] a request carries more filter clauses than the device evaluates (%d range, %d term, %d "
+              "items per term): such requests take the engine's docid bitmaps\n", GAMMA_HIP_MAX_FIELD_FILTERS,
+              GAMMA_HIP_MAX_TERM_FILTERS, GAMMA_HIP_MAX_TERM_ITEMS);
+    }
+    return false;
+  }
   static std::vector<std::string> Split(const std::string &v) {   // utils::split(v, "\001") of the reference
     std::vector<std::string> out;
     size_t a = 0;
@@ -136,14 +193,21 @@ class DeviceColumns {
   }
   int Sync(gamma_hip_index *h, Table *t, int fid, DataType type, int64_t ndocs) {
     Field &f = fields_[fid];
+    f.type = type;
     if (f.synced >= ndocs) return 0;
-    const int64_t n = ndocs - f.synced;
+    int64_t n = ndocs - f.synced;
     std::string raw;
+    // (ndocs is the caller's count of DOCUMENTS; a docid the table does not know -- GetFieldRawValue fails -- ends the
+    //  pass: the watermark stops there and the doc is read when it exists)
     if (type == DataType::STRING) {
       std::vector<int32_t> counts(n), items;
       for (int64_t i = 0; i < n; i++) {
         raw.clear();
-        t->GetFieldRawValue((int)(f.synced + i), fid, raw);
+        if (t->GetFieldRawValue((int)(f.synced + i), fid, raw)) {
+          n = i;
+          counts.resize(n);
+          break;
+        }
         std::vector<std::string> its = Split(raw);
         counts[i] = (int32_t)its.size();
         for (auto &s : its) {
@@ -152,7 +216,7 @@ class DeviceColumns {
           items.push_back(it->second);
         }
       }
-      if (gamma_hip_term_append(h, fid, n, counts.data(), items.data())) return -1;
+      if (n > 0 && gamma_hip_term_append(h, fid, n, counts.data(), items.data())) return -1;
     } else {
       const int dt = type == DataType::INT ? GAMMA_HIP_FIELD_INT : type == DataType::LONG ? GAMMA_HIP_FIELD_LONG
                    : type == DataType::FLOAT ? GAMMA_HIP_FIELD_FLOAT : GAMMA_HIP_FIELD_DOUBLE;
@@ -160,16 +224,21 @@ class DeviceColumns {
       std::vector<uint8_t> buf((size_t)n * es, 0);
       for (int64_t i = 0; i < n; i++) {
         raw.clear();
-        t->GetFieldRawValue((int)(f.synced + i), fid, raw);
+        if (t->GetFieldRawValue((int)(f.synced + i), fid, raw)) {
+          n = i;
+          break;
+        }
         memcpy(&buf[(size_t)i * es], raw.data(), std::min(es, raw.size()));
       }
-      if (gamma_hip_field_append(h, fid, dt, n, buf.data())) return -1;
+      if (n > 0 && gamma_hip_field_append(h, fid, dt, n, buf.data())) return -1;
     }
-    f.synced = ndocs;
+    f.synced += n;
     return 0;
   }
   std::mutex mu_;
   std::map<int, Field> fields_;
+  Table *table_ = nullptr;
+  bool warned_ = false;
 };
 
 }  // namespace tig_gamma

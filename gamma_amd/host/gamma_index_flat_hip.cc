@@ -129,7 +129,7 @@ int GammaFLATHIPIndex::Search(RetrievalContext *retrieval_context, int n, const 
   std::vector<gamma_hip_range_filter> rf;
   std::vector<gamma_hip_field_filter> ff;
   std::vector<gamma_hip_term_filter> tf;
-  if (!(device_filters_ && columns_.Prepare(h_, cond, (int64_t)vector_->MetaInfo()->Size(), p, ff, tf)))
+  if (!(device_filters_ && columns_.Prepare(h_, cond, DocCountOf(this, (int64_t)vector_->MetaInfo()->Size()), p, ff, tf)))
     FillRangeFilters(cond, p, rf);
   return gamma_hip_flat_search(h_, &p, n, reinterpret_cast<const float *>(x), k, distances, ids);
 }

@@ -61,6 +61,7 @@ int HIPIVFPQModelParams::Parse(const char *str) {
   if (!jp.GetInt("support_indivisible_nsubvector", v)) support_indivisible_nsubvector = v != 0;
   if (!jp.GetInt("device_filters", v)) device_filters = v != 0;
   if (!jp.GetInt("exact_ties", v)) exact_ties = v != 0;
+  if (!jp.GetInt("perf_stages", v)) perf_stages = v != 0;
   std::string devs;
   if (!jp.GetString("devices", devs)) {   // "0,1,2,3" (the engine's JsonParser has no arrays)
     devices.clear();
@@ -171,6 +172,7 @@ int GammaIVFPQHIPIndex::Init(const std::string &model_parameters, int indexing_s
                                  pa.bucket_init_size, pa.bucket_max_size);
     if (!r) r = gamma_hip_raw_init(m, d_);
     if (!r) r = gamma_hip_set_exact_ties(m, pa.exact_ties ? 1 : 0);
+    if (!r && pa.perf_stages) r = gamma_hip_profile_enable(m, 1);
     return r;
   });
   if (rc) {
@@ -365,6 +367,14 @@ int GammaIVFPQHIPIndex::Update(const std::vector<int64_t> &ids, const std::vecto
   }
   if (grp_) gamma_hip_group_ivfpq_compact_if_need(grp_);
   else gamma_hip_ivfpq_compact_if_need(h_);   // gamma_index_ivfpq.cc:420
+  if (model_param_ && model_param_->device_filters) {
+    // the engine updated these docs (table first, then this model): the device mirror of their scalar fields follows
+    std::vector<int64_t> docs(ids);
+    RawVector *rv = dynamic_cast<RawVector *>(vector_);
+    if (rv && rv->VidMgr() && rv->VidMgr()->MultiVids())
+      for (size_t i = 0; i < docs.size(); i++) docs[i] = rv->VidMgr()->VID2DocID((int)ids[i]);
+    if (columns_.Refresh(h_, docs)) return -1;
+  }
   return 0;
 }
 
@@ -404,7 +414,7 @@ int GammaIVFPQHIPIndex::Search(RetrievalContext *retrieval_context, int n, const
   // scalar filters: on the device against mirrored columns when asked for and possible, else the request's
   // flattened docid bitmaps as the CPU models take them
   if (!(model_param_ && model_param_->device_filters &&
-        columns_.Prepare(h_, cond, (int64_t)vector_->MetaInfo()->Size(), p, ff, tf)))
+        columns_.Prepare(h_, cond, DocCountOf(this, (int64_t)vector_->MetaInfo()->Size()), p, ff, tf)))
     FillRangeFilters(cond, p, rf);
   const float *xq = reinterpret_cast<const float *>(x);
   int rc;
@@ -417,11 +427,30 @@ int GammaIVFPQHIPIndex::Search(RetrievalContext *retrieval_context, int n, const
     rc = grp_ ? gamma_hip_group_ivfpq_search(grp_, &p, n, xq, k, distances, ids)
               : gamma_hip_ivfpq_search(h_, &p, n, xq, k, distances, ids);
   }
+  PerfLabels(cond);
   if (rc) {
     HLOG("search failed: %s (%s)", gamma_hip_strerror(rc), grp_ ? gamma_hip_group_last_error(grp_) : gamma_hip_last_error(h_));
     return rc;
   }
   return 0;
+}
+
+// PerfTool (index/retrieval_model.h:23-50; printed by the engine at online_log_level=debug): one label for the device
+// call, and with "perf_stages": 1 the device time of every stage of the handle's searches since the last label
+// (HIP events, gamma_hip_profile_get; concurrent searches share the counters)
+void GammaIVFPQHIPIndex::PerfLabels(GammaSearchCondition *cond) {
+  if (!cond || !cond->perf_tool_) return;
+  cond->GetPerfTool().Perf("hip search");
+  if (!(model_param_ && model_param_->perf_stages) || grp_) return;
+  static const char *names[] = {"coarse", "tables", "scan", "select", "rerank", "flat"};
+  std::lock_guard<std::mutex> g(perf_mu_);
+  for (int st = 0; st < GAMMA_HIP_NUM_STAGES; st++) {
+    double ms = 0;
+    int64_t launches = 0;
+    if (gamma_hip_profile_get(h_, st, &ms, &launches)) continue;
+    if (ms > perf_ms_[st]) cond->GetPerfTool().perf_ss << "hip " << names[st] << " [" << ms - perf_ms_[st] << "]ms ";
+    perf_ms_[st] = ms;
+  }
 }
 
 // mirror vids [raw_uploaded_, upto) of the engine's vector store into HBM.  Called from Search (any number of
@@ -686,7 +715,7 @@ int GammaIVFFlatHIPIndex::Search(RetrievalContext *retrieval_context, int n, con
   std::vector<gamma_hip_field_filter> ff;
   std::vector<gamma_hip_term_filter> tf;
   if (!(model_param_ && model_param_->device_filters &&
-        columns_.Prepare(h_, cond, (int64_t)vector_->MetaInfo()->Size(), p, ff, tf)))
+        columns_.Prepare(h_, cond, DocCountOf(this, (int64_t)vector_->MetaInfo()->Size()), p, ff, tf)))
     FillRangeFilters(cond, p, rf);
   const float *xq = reinterpret_cast<const float *>(x);
   int rc;

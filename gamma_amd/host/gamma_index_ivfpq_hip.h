@@ -54,6 +54,7 @@ struct HIPIVFPQModelParams {
   int bucket_max_size = 1280000;
   bool device_filters = false;   // HIP only: evaluate range / term filters on device-resident columns (filter_bridge.h)
   bool exact_ties = true;        // HIP only: the reference's heap order inside exact distance ties (gamma_hip_set_exact_ties)
+  bool perf_stages = false;      // HIP only: per-stage device times in the request's PerfTool (stage events on every search)
   std::vector<int> devices;      // HIP only: "devices": "0,1,2,3" -- the index sharded by IVF list over these GPUs in this
                                  // process (gamma_hip_group_*); empty: one GPU, GAMMA_HIP_DEVICE or 0
   int Parse(const char *str);   // 0 ok, -1 bad (same rules as gamma_index_ivfpq.h:708-851)
@@ -107,6 +108,9 @@ class GammaIVFPQHIPIndex : public RetrievalModel {
     return 0;
   }
   int OpenDevices(const std::vector<int> &devices);
+  void PerfLabels(GammaSearchCondition *cond);
+  std::mutex perf_mu_;
+  double perf_ms_[GAMMA_HIP_NUM_STAGES] = {0};
   gamma_hip_index *h_ = nullptr;
   HIPIVFPQModelParams *model_param_ = nullptr;
   int64_t raw_uploaded_ = 0;

@@ -56,6 +56,7 @@ struct Host {
   MemVectorReader *store;
   RetrievalModel *model;
   Table table;   // the scalar fields of the docs (device filters read it through GammaSearchCondition::table)
+  std::string last_perf;   // PerfTool summary of the last search (what the engine logs at online_log_level=debug)
 };
 }  // namespace
 
@@ -64,7 +65,7 @@ extern "C" {
 void *gh_host_new(const char *retrieval_type, int d) {
   RetrievalModel *m = reflector().GetNewModel(retrieval_type);
   if (!m) return nullptr;
-  Host *h = new Host{new MemVectorReader(d), m, Table()};
+  Host *h = new Host{new MemVectorReader(d), m, Table(), std::string()};
   m->vector_ = h->store;
   return h;
 }
@@ -169,8 +170,25 @@ int gh_host_search(void *hp, const char *retrieval_params, int has_rank, int bru
   cond.max_score = max_score;
   cond.retrieval_params_ = h->model->Parse(retrieval_params);   // owned by the context
   if (!cond.retrieval_params_) return -100;
-  return h->model->Search(&cond, n, reinterpret_cast<const uint8_t *>(x), k, distances, ids);
+  const int rc = h->model->Search(&cond, n, reinterpret_cast<const uint8_t *>(x), k, distances, ids);
+  h->last_perf = perf.OutputPerf().str();
+  return rc;
 }
+// the PerfTool summary of the last gh_host_search (single-threaded use)
+int gh_host_last_perf(void *hp, char *out, int cap) {
+  Host *h = (Host *)hp;
+  const int n = std::min<int>(cap - 1, (int)h->last_perf.size());
+  if (cap > 0) {
+    memcpy(out, h->last_perf.data(), n);
+    out[n] = 0;
+  }
+  return n;
+}
+// Table::Update of one field of one doc (table/table.cc:420-470), and the stub's count of out-of-range reads
+void gh_host_table_set(void *hp, int field_id, int docid, const uint8_t *raw, int len) {
+  ((Host *)hp)->table.SetValue(field_id, docid, std::string(reinterpret_cast<const char *>(raw), (size_t)len));
+}
+long gh_host_table_oob_reads(void *hp) { return ((Host *)hp)->table.oob_reads_; }
 // Search with a scalar filter: range clause i matches docids[off_i .. off_i+counts[i]) (not_in[i]
 // inverts it); the MultiRangeQueryResults is built the way field_range_index.cc fills one
 // (SetRange over the matching ids, Resize, Set(doc - MinAligned)).

@@ -395,11 +395,16 @@ class Table {
   }
   int GetFieldRawValue(int docid, int field_id, std::string &value, const uint8_t *doc_v = nullptr) {
     (void)doc_v;
-    if (field_id < 0 || (size_t)field_id >= values_.size() || docid < 0 || (size_t)docid >= values_[field_id].size())
+    if (field_id < 0 || (size_t)field_id >= values_.size() || docid < 0 || (size_t)docid >= values_[field_id].size()) {
+      oob_reads_++;   // the engine's Table does not check its docid (table/table.cc): a caller must never get here
       return -1;
+    }
     value = values_[field_id][docid];
     return 0;
   }
+  // stand-alone build only: Table::Update's effect on one field, and the out-of-range reads the stub has seen
+  void SetValue(int field_id, int docid, const std::string &raw) { values_[field_id][docid] = raw; }
+  long oob_reads_ = 0;
 
  private:
   std::vector<std::string> names_;

@@ -23,6 +23,9 @@ HOST_SYMBOLS = {
     "gh_host_add": (C.c_int, [C.c_void_p, C.c_int, f32p]),
     "gh_host_update": (C.c_int, [C.c_void_p, C.c_int64, f32p]),
     "gh_host_update_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), f32p]),
+    "gh_host_last_perf": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "gh_host_table_set": (None, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int]),
+    "gh_host_table_oob_reads": (C.c_long, [C.c_void_p]),
     "gh_host_delete": (C.c_int, [C.c_void_p, i64p, C.c_int]),
     "gh_host_engine_bitmap_set": (None, [C.c_void_p, i64p, C.c_int]),
     "gh_host_search_during_add": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p,
@@ -233,6 +236,20 @@ class PluginModel:
         else:
             v = np.ascontiguousarray(values, dtype=self._NP[dt])
             self.L.gh_host_table_append(self.h, fid, v.size, v.ctypes.data, v.itemsize, None)
+
+    def table_set(self, name, docid, value):
+        """Table::Update of one field of one doc: a numeric value, or a list of items for a string field"""
+        fid, dt = self._ftypes[name]
+        raw = b"\x01".join(s.encode() for s in value) if dt == 4 else np.array([value], dtype=self._NP[dt]).tobytes()
+        self.L.gh_host_table_set(self.h, fid, docid, raw, len(raw))
+
+    def table_oob_reads(self):
+        return self.L.gh_host_table_oob_reads(self.h)
+
+    def last_perf(self):
+        buf = C.create_string_buffer(4096)
+        self.L.gh_host_last_perf(self.h, buf, 4096)
+        return buf.value.decode()
 
     def search_scalar(self, xq, k, retrieval_params="", has_rank=True, brute_force=False, ranges=(), terms=()):
         """ranges: (field, lower, upper, include_lower, include_upper); terms: (field, [items], op 0 And / 1 Or / 2 Not)"""

@@ -2,8 +2,8 @@
  * gamma_hip.h -- C ABI of libgamma_hip.so, the MI355X (gfx950) device shim behind Gamma's
  * RetrievalModel plugin boundary.
  *
- * The only callers are the plugin classes in gamma_amd/host/ (GammaIVFPQHIPIndex,
- * GammaFLATHIPIndex -- REGISTER_MODEL(HIPIVFPQ / HIPFLAT)), i.e. what a Gamma maintainer
+ * The only callers are the plugin classes in gamma_amd/host/ (GammaIVFPQHIPIndex, GammaIVFFlatHIPIndex,
+ * GammaFLATHIPIndex -- REGISTER_MODEL(HIPIVFPQ / HIPIVFFLAT / HIPFLAT)), i.e. what a Gamma maintainer
  * compiles into libgamma next to index/impl/gamma_index_ivfpq.cc, and
  * the ctypes binding used by this repo's tests and bench.  Everything is extern "C", plain
  * pointers and sizes, caller-owned buffers, int return codes (0 = ok, <0 = error, see
@@ -12,9 +12,16 @@
  * Each entry point names the reference interface it stands in for (paths relative to the
  * reference tree; "faiss:" = third_party/faiss-1.7.1.tar.gz, faiss-1.7.1/faiss/).
  *
- * Threading: one handle owns one device and one HIP stream.  Calls on a handle are
- * serialised by an internal mutex (search + single writer, retrieval contract
- * SURVEY.md §8b "Threading"); use one handle per GPU / per shard.
+ * Threading (the retrieval contract of SURVEY.md 8b: Search from any number of client threads while ONE indexing thread
+ * adds / updates and API threads delete).  A handle owns one device, a search stream and a writer stream.
+ *   - Searches may be called from any number of threads.  They take turns on the search stream (they share its
+ *     workspaces); small host-buffer calls that find the handle busy are queued and run as ONE device batch.
+ *   - Writers (Add, Update, Delete, raw rows, bitmap, columns) serialise among themselves and run on the writer stream
+ *     beside the searches: a search reads the inverted lists through the VERSION of their (offset, length) tables that was
+ *     current when it was enqueued, a writer publishes a new version after its copies (realtime_mem_data.cc:299-300).
+ *   - Only operations that free or move memory a search may be reading (arena growth and repack, raw-store and column
+ *     growth) wait for the searches in flight.
+ * One handle per GPU; several GPUs behind one index object: gamma_hip_group_* below.
  */
 #ifndef GAMMA_HIP_H_
 #define GAMMA_HIP_H_
@@ -60,7 +67,7 @@ typedef struct {
 #define GAMMA_HIP_FIELD_LONG 1
 #define GAMMA_HIP_FIELD_FLOAT 2
 #define GAMMA_HIP_FIELD_DOUBLE 3
-#define GAMMA_HIP_MAX_FIELD_FILTERS 4
+#define GAMMA_HIP_MAX_FIELD_FILTERS 8
 typedef struct {
     int32_t field_id;
     int32_t include_lower, include_upper;
@@ -75,8 +82,8 @@ typedef struct {
  * them; Not (FilterOperator::Not, table/field_range_index.h:23) = none).  Items are dictionary-encoded by the
  * caller (the plugin keeps the dictionary, gamma_amd/host/filter_bridge.h); an item the dictionary does not
  * know is passed as -1.  The doc's items live in HBM (gamma_hip_term_append). */
-#define GAMMA_HIP_MAX_TERM_FILTERS 4
-#define GAMMA_HIP_MAX_TERM_ITEMS 8
+#define GAMMA_HIP_MAX_TERM_FILTERS 8
+#define GAMMA_HIP_MAX_TERM_ITEMS 16
 #define GAMMA_HIP_TERM_AND 0
 #define GAMMA_HIP_TERM_OR 1
 #define GAMMA_HIP_TERM_NOT 2
@@ -138,10 +145,6 @@ int gamma_hip_set_workspace_budget(gamma_hip_index* h, int64_t bytes);
  * through its reservoir, whose order inside ties is not reproduced), recall_num <= 1024; other shapes, IVFFLAT /
  * flat search and the sharded merge keep the (distance, position) order inside ties. */
 int gamma_hip_set_exact_ties(gamma_hip_index* h, int on);
-/* Experimental scan schedule for large batches (csrc/scan_lm.hip): the probes behind a query's first group are
- * scored list-major, two queries per pass over a list.  Same results; slower than the default at C3-sized
- * lists, off by default.  Covers nsubvector 16, >= 2048 queries per call, no per-request filters. */
-int gamma_hip_set_list_major(gamma_hip_index* h, int on);
 /* Coarse quantizer of large batches (>= 4096 queries, >= 2048 lists, d in {32, 64, 96, 128}, nprobe <= 64) without
  * the [nq][nlist] distance matrix (csrc/coarse.hip).  on: 1 = automatic (default), 0 = always the matrix path.
  * list_cap: capacity of a query's per-strip survivor list, 1..128 (default 128); a query that overflows it is redone
@@ -166,6 +169,9 @@ int64_t gamma_hip_field_count(gamma_hip_index* h, int field_id);
 int gamma_hip_term_append(gamma_hip_index* h, int field_id, int64_t n_docs, const int32_t* counts,
                           const int32_t* items);
 int64_t gamma_hip_term_count(gamma_hip_index* h, int field_id);
+/* a doc's items rewritten after its STRING field was updated in the table (Table::Update, table/table.cc:420-470):
+ * in place when they fit, else at the end of the item array; the doc's row switches over with one 8-byte store */
+int gamma_hip_term_update(gamma_hip_index* h, int field_id, int64_t docid, int32_t count, const int32_t* items);
 
 /* ---- raw vector store (VectorReader::Gets / MemoryRawVector, vector/raw_vector.cc:99-109,
  *      vector/memory_raw_vector.cc:90-142): device mirror, vid = row ------------------- */

@@ -1050,41 +1050,6 @@ def test_add_keys_batch_counts_superseded_slots(case):
     g2.close()
 
 
-@pytest.mark.parametrize("metric", [B.METRIC_L2, B.METRIC_IP])
-def test_list_major_scan_matches_the_default_schedule(metric):
-    """csrc/scan_lm.hip (gamma_hip_set_list_major): consumer probes scored two queries per list pass.  Same ADC
-    values, same bounds, same results as the query-major schedule -- bit for bit, with and without a delete
-    bitmap, and with exact ties on (the replay then walks the fully stored slab)."""
-    case = fixtures.trained_case(d=64, nlist=128, M=16, N=30000, nq=64, metric=metric, normalize=metric == B.METRIC_IP)
-    g = fixtures.load_hip(case)
-    try:
-        q = synth.sift_like(4096, d=64, seed=77)
-        if metric == B.METRIC_IP:
-            q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
-        dead = np.arange(0, 30000, 7)
-        for step in range(2):
-            for has_rank in (True, False):
-                args = api.SearchArgs(metric=metric, nprobe=24, recall_num=120, has_rank=has_rank, coarse_mode=1, **WIDE)
-                g.set_list_major(False)
-                D0, I0 = g.ivfpq_search(q, 10, args)
-                s0 = g.last_stages(len(q), 24, 120)
-                g.set_list_major(True)
-                D1, I1 = g.ivfpq_search(q, 10, args)
-                s1 = g.last_stages(len(q), 24, 120)
-                assert D0.tobytes() == D1.tobytes() and np.array_equal(I0, I1)
-                assert s0["recall_dis"].tobytes() == s1["recall_dis"].tobytes()
-                assert np.array_equal(s0["recall_ids"], s1["recall_ids"])
-                g.set_exact_ties(True)
-                D2, I2 = g.ivfpq_search(q, 10, args)
-                g.set_list_major(False)
-                D3, I3 = g.ivfpq_search(q, 10, args)
-                g.set_exact_ties(False)
-                assert D2.tobytes() == D3.tobytes() and np.array_equal(I2, I3)
-            g.bitmap_set(dead, 1)     # second round: ids are read, deleted docs filtered
-    finally:
-        g.close()
-
-
 def _term_mask(doc_items, items, op):
     want = set(items)
     if op == 1:
@@ -1423,3 +1388,32 @@ def test_large_filtered_batches_run_over_compacted_lists(metric):
                 compare_topk(Do, Io, res[1][0][:200], res[1][1][:200])
     finally:
         g.close()
+
+
+def test_term_rows_can_be_rewritten(case, hip):
+    """gamma_hip_term_update: a doc's items rewritten in place (fewer), at the end of the item array (more), to nothing;
+    gamma_hip_field_update for the numeric column -- the filtered search follows."""
+    g = hip
+    N = len(case["base"])
+    rng = np.random.default_rng(77)
+    docs_items = [list(rng.choice(6, size=int(rng.integers(0, 4)), replace=False)) for _ in range(N)]
+    vals = rng.integers(0, 100, size=N).astype(np.int64)
+    g.term_append(31, docs_items)
+    g.field_append(32, vals)
+    q = case["q"][:16]
+
+    def check():
+        want = np.nonzero(np.array([2 in d for d in docs_items]) & (vals < 50))[0]
+        a = api.SearchArgs(metric=api.METRIC_L2, term_filters=[(31, 1, [2])], field_filters=[(32, 0, 50, True, False)], **WIDE)
+        b = api.SearchArgs(metric=api.METRIC_L2, range_filters=[api.make_range_filter(want)], **WIDE)
+        Da, Ia = g.flat_search(q, 10, a)
+        Db, Ib = g.flat_search(q, 10, b)
+        assert Da.tobytes() == Db.tobytes() and np.array_equal(Ia, Ib)
+
+    check()
+    for doc in rng.choice(N, size=500, replace=False):
+        docs_items[doc] = list(rng.choice(6, size=int(rng.integers(0, 6)), replace=False))
+        g.term_update(31, int(doc), docs_items[doc])
+        vals[doc] = int(rng.integers(0, 100))
+        g.field_update(32, int(doc), vals[doc:doc + 1])
+    check()

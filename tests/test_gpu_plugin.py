@@ -518,3 +518,110 @@ def test_plugin_multi_vector_documents(case, model):
     finally:
         B.lib().go_set_assign_mode(0)
         m.close()
+
+
+def _filtered_plugin(case, extra=""):
+    from gamma_amd import plugin
+    m = plugin.PluginModel("HIPIVFPQ", case["d"],
+                           '{"ncentroids": %d, "nsubvector": %d, "nprobe": 8, "metric_type": "L2", "device_filters": 1%s}'
+                           % (case["nlist"], case["M"], extra), indexing_size=5000)
+    m.table_add_field("price", "int")
+    m.table_add_field("tags", "string")
+    assert m.set_trained(case["cc"], case["pq"]) == 0
+    return m
+
+
+def test_device_filter_mirror_follows_doc_updates(case):
+    """A doc update after the mirror was built (VERDICT r2 missing #5): the engine rewrites the doc's
+    fields in the Table and hands its vid to the model's Update (vector/vector_manager.cc:355-380); the device columns
+    of that doc are read again from the Table -- numeric value and string items (longer, shorter, empty)."""
+    base, q = case["base"], case["q"]
+    N = 6000
+    rng = np.random.default_rng(12)
+    price = rng.integers(0, 1000, size=N).astype(np.int32)
+    tags = ["red", "green", "blue", "cyan"]
+    doc_tags = [list(rng.choice(tags, size=int(rng.integers(0, 3)), replace=False)) for _ in range(N)]
+    m = _filtered_plugin(case)
+    try:
+        m.store(base[:N])
+        m.table_append("price", price)
+        m.table_append("tags", doc_tags)
+        assert m.add(base[:N])
+
+        def check():
+            for rg, tm, mask in (
+                    ([("price", 200, 500, True, True)], [], (price >= 200) & (price <= 500)),
+                    ([], [("tags", ["red", "cyan"], 1)], np.array([bool({"red", "cyan"} & set(d)) for d in doc_tags])),
+                    ([("price", 0, 900, True, False)], [("tags", ["blue"], 0)],
+                     (price < 900) & np.array(["blue" in d for d in doc_tags]))):
+                docs = np.nonzero(mask)[0]
+                ctx = B.make_ctx(range_filters=[B.make_range_filter(docs)])
+                Df, If = B.flat_search(base[:N], q[:24], 10, B.METRIC_L2, ctx)
+                Dg, Ig = m.search_scalar(q[:24], 10, '{"metric_type": "L2"}', brute_force=True, ranges=rg, terms=tm)
+                compare_topk(Df, If, Dg, Ig)
+                Dg, Ig = m.search_scalar(q, 10, '{"metric_type": "L2", "nprobe": 16, "recall_num": 200}', ranges=rg, terms=tm)
+                assert np.isin(Ig[Ig >= 0], docs).all()
+
+        check()                                     # builds the mirror
+        upd = rng.choice(N, size=400, replace=False)
+        for v in upd:                               # Table::Update of both fields of 400 docs
+            price[v] = int(rng.integers(0, 1000))
+            doc_tags[v] = list(rng.choice(tags, size=int(rng.integers(0, 5)), replace=False))
+            m.table_set("price", int(v), int(price[v]))
+            m.table_set("tags", int(v), doc_tags[v])
+        assert m.update_batch(upd.astype(np.int64), base[upd]) == 0   # ... and the engine's update pass reaches the model
+        check()
+        assert m.table_oob_reads() == 0
+    finally:
+        m.close()
+
+
+def test_device_filters_with_multi_vector_documents(case):
+    """ADVICE r2 (medium): with several vectors per document the table holds fewer docs than the store holds vectors;
+    the mirror must be fed by DOC count -- the engine's Table does not check the docid it is asked for."""
+    base, q = case["base"], case["q"]
+    N = 6000
+    rng = np.random.default_rng(13)
+    v2d = np.repeat(np.arange(N), rng.integers(1, 4, size=N))[:N].astype(np.int32)
+    ndocs = int(v2d[-1]) + 1
+    price = rng.integers(0, 1000, size=ndocs).astype(np.int32)
+    doc_tags = [list(rng.choice(["a", "b", "c"], size=int(rng.integers(0, 3)), replace=False)) for _ in range(ndocs)]
+    m = _filtered_plugin(case)
+    try:
+        m.set_vid2docid(0, v2d)
+        m.store(base[:N])
+        m.table_append("price", price)
+        m.table_append("tags", doc_tags)
+        assert m.add(base[:N])
+        mask = (price >= 100) & (price < 700) & np.array(["a" in d for d in doc_tags])
+        docs = np.nonzero(mask)[0]
+        ctx = B.make_ctx(range_filters=[B.make_range_filter(docs)], vid2docid=v2d)
+        Df, If = B.flat_search(base[:N], q[:24], 10, B.METRIC_L2, ctx)
+        Dg, Ig = m.search_scalar(q[:24], 10, '{"metric_type": "L2"}', brute_force=True,
+                                 ranges=[("price", 100, 700, True, False)], terms=[("tags", ["a"], 0)])
+        compare_topk(Df, If, Dg, Ig)
+        assert np.isin(v2d[Ig[Ig >= 0]], docs).all()
+        assert m.table_oob_reads() == 0             # never asked the table for a doc it does not have
+    finally:
+        m.close()
+
+
+def test_perf_tool_labels(case):
+    """index/retrieval_model.h:23-50: the request's PerfTool gets a label for the device call, and with
+    "perf_stages": 1 the device time of the stages (what online_log_level=debug prints)."""
+    from gamma_amd import plugin
+    base, q = case["base"], case["q"]
+    for extra, want in (("", ["hip search"]), (', "perf_stages": 1', ["hip search", "hip coarse", "hip scan", "hip rerank"])):
+        m = plugin.PluginModel("HIPIVFPQ", case["d"],
+                               '{"ncentroids": %d, "nsubvector": %d, "nprobe": 8, "metric_type": "L2"%s}'
+                               % (case["nlist"], case["M"], extra), indexing_size=5000)
+        try:
+            m.store(base)
+            assert m.set_trained(case["cc"], case["pq"]) == 0
+            assert m.add(base)
+            m.search(q, 10, '{"metric_type": "L2", "recall_num": 100, "nprobe": 8}')
+            perf = m.last_perf()
+            for w in want:
+                assert w in perf, perf
+        finally:
+            m.close()
