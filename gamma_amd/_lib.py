@@ -93,6 +93,9 @@ SYMBOLS = {
     "gamma_hip_ivfpq_add": (C.c_int, [C.c_void_p, C.c_int64, f32p, C.c_int64]),
     "gamma_hip_ivfpq_encode": (C.c_int, [C.c_void_p, C.c_int64, f32p, i64p, u8p]),
     "gamma_hip_assign": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, f32p, C.c_int, f32p, i32p, f32p]),
+    "gamma_hip_kmeans": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, f32p, C.c_int, C.c_int, C.c_int64, C.c_int, f32p,
+                                   C.POINTER(C.c_float)]),
+    "gamma_hip_rand_perm": (None, [i32p, C.c_int64, C.c_int64]),
     "gamma_hip_ivfpq_search": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int, f32p, C.c_int,
                                          f32p, i64p]),
     "gamma_hip_ivfpq_search_device": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int,

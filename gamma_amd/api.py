@@ -244,6 +244,15 @@ class GammaHip:
         vecs = _f32(vecs)
         self._ck(self.L.gamma_hip_ivfpq_add(self.h, vecs.shape[0], _p(vecs, _lib.f32p), first_vid), "add")
 
+    def kmeans(self, x, k, niter, seed=1234, max_points_per_centroid=256):
+        """faiss::Clustering::train on the device: (centroids [k, d], objective of the last assignment)"""
+        x = _f32(x)
+        cen = np.empty((k, x.shape[1]), dtype=np.float32)
+        obj = C.c_float(0)
+        self._ck(self.L.gamma_hip_kmeans(self.h, x.shape[1], x.shape[0], _p(x, _lib.f32p), k, niter, seed,
+                                         max_points_per_centroid, _p(cen, _lib.f32p), C.byref(obj)), "kmeans")
+        return cen, float(obj.value)
+
     def update_batch(self, vids, vecs):
         """GammaIVFPQIndex::Update for a batch: one encode (each vector assigned as a call of its own), list updates in
         order, one publish"""

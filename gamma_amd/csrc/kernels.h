@@ -298,6 +298,8 @@ void launch_code_sums_one(hipStream_t s, const float* T2, const uint8_t* codes, 
 void launch_code_sums_lists(hipStream_t s, const float* T2, const uint8_t* codes, int M, const int64_t* list_off,
                             const int* list_len, int nlist, int max_len, float* sums);
 void launch_t2_rowmax(hipStream_t s, const float* T2, int nlist, int M, float* t2max);
+void launch_centroid_update(hipStream_t s, const float* x, int d, const int* order, const int* seg, int k, float* centroids,
+                            float* hassign);
 void launch_pq_encode(hipStream_t s, const float* x, int64_t n, int d, int M, const int* assign,
                       const float* cc, const float* pqc, uint8_t* codes);
 

@@ -2519,6 +2519,33 @@ void launch_t2_rowmax(hipStream_t s, const float* T2, int nlist, int M, float* t
 }
 
 // ------------------------------------------------------------------------------------
+// k-means update (gamma_hip_train.cpp; compute_centroids, faiss:Clustering.cpp:138-208): cluster c = the points
+// order[seg[c] .. seg[c + 1]) in ascending point order; one float accumulator per (cluster, dimension) adds them in that
+// order, then c[j] *= 1 / count.  An empty cluster's centroid is zero (the host re-seeds it, split_clusters).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_centroid_update(const float* __restrict__ x, int d, const int* __restrict__ order,
+                                                         const int* __restrict__ seg, float* __restrict__ centroids,
+                                                         float* __restrict__ hassign) {
+    const int c = blockIdx.x;
+    const int b = seg[c], e = seg[c + 1];
+    const float cnt = (float)(e - b);
+    for (int j = threadIdx.x; j < d; j += 128) {
+        float acc = 0.f;
+        for (int m = b; m < e; m++) acc += x[(int64_t)order[m] * d + j];
+        if (e > b) {
+            const float norm = 1 / cnt;
+            acc *= norm;
+        }
+        centroids[(int64_t)c * d + j] = acc;
+    }
+    if (threadIdx.x == 0) hassign[c] = cnt;
+}
+void launch_centroid_update(hipStream_t s, const float* x, int d, const int* order, const int* seg, int k, float* centroids,
+                            float* hassign) {
+    if (k > 0) hipLaunchKernelGGL(k_centroid_update, dim3(k), dim3(128), 0, s, x, d, order, seg, centroids, hassign);
+}
+
+// ------------------------------------------------------------------------------------
 // a12 (Add path): residual + PQ encode.  assign comes from the coarse kernels + select.
 //   code[m] = argmin_j fvec_L2sqr_ny(residual_m, c_mj)   (strict <, first minimum,
 //   faiss:impl/ProductQuantizer.cpp:321-348).  grid = (M, n), block = 256 = ksub.

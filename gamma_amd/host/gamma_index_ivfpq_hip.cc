@@ -205,72 +205,47 @@ RetrievalParameters *GammaIVFPQHIPIndex::Parse(const std::string &parameters) {
   return rp;
 }
 
-// Lloyd k-means; the assignment step runs on the device (gamma_hip_assign), the centroid
-// update on the host.  Deterministic for a given seed.
-static int kmeans_device(gamma_hip_index *h, int d, size_t n, const float *x, int k, int niter,
-                         unsigned seed, std::vector<float> &centroids) {
-  centroids.resize((size_t)k * d);
-  std::mt19937_64 rng(seed);
-  std::vector<size_t> perm(n);
-  for (size_t i = 0; i < n; i++) perm[i] = i;
-  for (size_t i = 0; i < (size_t)k && i < n; i++) {
-    size_t j = i + rng() % (n - i);
-    std::swap(perm[i], perm[j]);
-    memcpy(&centroids[i * d], x + perm[i] * d, sizeof(float) * d);
-  }
-  std::vector<int32_t> assign(n);
-  std::vector<double> sums((size_t)k * d);
-  std::vector<int64_t> cnt(k);
-  for (int it = 0; it < niter; it++) {
-    int rc = gamma_hip_assign(h, d, (int64_t)n, x, k, centroids.data(), assign.data(), nullptr);
-    if (rc) return rc;
-    std::fill(sums.begin(), sums.end(), 0.0);
-    std::fill(cnt.begin(), cnt.end(), 0);
-    for (size_t i = 0; i < n; i++) {
-      const int a = assign[i];
-      if (a < 0 || a >= k) continue;
-      cnt[a]++;
-      double *s = &sums[(size_t)a * d];
-      const float *xi = x + i * d;
-      for (int t = 0; t < d; t++) s[t] += xi[t];
-    }
-    for (int c = 0; c < k; c++) {
-      if (cnt[c] == 0) {  // re-seed an empty cluster from a random point
-        memcpy(&centroids[(size_t)c * d], x + (rng() % n) * d, sizeof(float) * d);
-        continue;
-      }
-      for (int t = 0; t < d; t++) centroids[(size_t)c * d + t] = (float)(sums[(size_t)c * d + t] / cnt[c]);
-    }
-  }
-  return 0;
-}
-
+// Training = faiss's, on the device (gamma_hip_kmeans: faiss::Clustering::train -- subsampling, rand_perm seeds,
+// centroid sums, empty-cluster splits -- with the assignment and the sums on the GPU, the training set resident).
 int GammaIVFPQHIPIndex::TrainCoarse(size_t num, const float *xt) {
-  // coarse quantizer: cp.niter = 10 (gamma_index_ivfpq.cc:175; faiss's default for IndexIVFFlat::train as well)
-  return kmeans_device(h_, d_, num, xt, nlist_, 10, 1234, coarse_centroids_);
+  // IndexIVF::train_q1: Clustering(d, nlist, cp) with cp.niter = 10 (gamma_index_ivfpq.cc:175), seed 1234,
+  // max_points_per_centroid 256
+  coarse_centroids_.resize((size_t)nlist_ * d_);
+  return gamma_hip_kmeans(h_, d_, (int64_t)num, xt, nlist_, 10, 1234, 256, coarse_centroids_.data(), nullptr);
 }
 
 int GammaIVFPQHIPIndex::TrainOnHost(size_t num, const float *xt) {
   int rc = TrainCoarse(num, xt);
   if (rc) return rc;
-  // residuals of the training set (by_residual = true, :179)
-  std::vector<int32_t> assign(num);
-  rc = gamma_hip_assign(h_, d_, (int64_t)num, xt, nlist_, coarse_centroids_.data(), assign.data(), nullptr);
+  // IndexIVFPQ::train_residual_o (faiss:IndexIVFPQ.cpp:67-106): at most max_points_per_centroid * ksub = 65536
+  // points (fvecs_maybe_subsample with pq.cp.seed = 1234), their residuals to the nearest coarse centroid
+  // (by_residual = true, :179), then ProductQuantizer::train: one Clustering(dsub, 256, niter 25) per sub-quantizer
+  const size_t nmax = 256 * 256;
+  std::vector<float> subset;
+  const float *xs = xt;
+  size_t ns = num;
+  if (num > nmax) {
+    std::vector<int32_t> perm(num);
+    gamma_hip_rand_perm(perm.data(), (int64_t)num, 1234);
+    subset.resize(nmax * (size_t)d_);
+    for (size_t i = 0; i < nmax; i++) memcpy(&subset[i * d_], xt + (size_t)perm[i] * d_, sizeof(float) * d_);
+    xs = subset.data();
+    ns = nmax;
+  }
+  std::vector<int32_t> assign(ns);
+  rc = gamma_hip_assign(h_, d_, (int64_t)ns, xs, nlist_, coarse_centroids_.data(), assign.data(), nullptr);
   if (rc) return rc;
-  const size_t nsub = std::min<size_t>(num, 256 * 256);  // max_points_per_centroid * ksub
   const int dsub = d_ / M_;
-  std::vector<float> sub(nsub * dsub);
+  std::vector<float> slice(ns * (size_t)dsub);
   pq_centroids_.resize((size_t)M_ * 256 * dsub);
   for (int m = 0; m < M_; m++) {
-    for (size_t i = 0; i < nsub; i++) {
-      const float *xi = xt + i * d_ + m * dsub;
+    for (size_t i = 0; i < ns; i++) {
+      const float *xi = xs + i * d_ + m * dsub;
       const float *c = &coarse_centroids_[(size_t)assign[i] * d_ + m * dsub];
-      for (int t = 0; t < dsub; t++) sub[i * dsub + t] = xi[t] - c[t];
+      for (int t = 0; t < dsub; t++) slice[i * dsub + t] = xi[t] - c[t];
     }
-    std::vector<float> cm;
-    rc = kmeans_device(h_, dsub, nsub, sub.data(), 256, 25, 1235 + m, cm);
+    rc = gamma_hip_kmeans(h_, dsub, (int64_t)ns, slice.data(), 256, 25, 1234, 256, &pq_centroids_[(size_t)m * 256 * dsub], nullptr);
     if (rc) return rc;
-    memcpy(&pq_centroids_[(size_t)m * 256 * dsub], cm.data(), sizeof(float) * 256 * dsub);
   }
   return 0;
 }

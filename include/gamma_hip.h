@@ -268,6 +268,18 @@ int gamma_hip_ivfpq_encode(gamma_hip_index* h, int64_t n, const float* vecs, int
 int gamma_hip_assign(gamma_hip_index* h, int d, int64_t n, const float* x, int k,
                      const float* centroids, int32_t* assign, float* dis);
 
+/* Training on the device: faiss::Clustering::train (faiss:Clustering.cpp:255-560; nredo 1, L2, no weights) as
+ * GammaIVFPQIndex::Indexing runs it through IndexIVFPQ::train (gamma_index_ivfpq.cc:272-354) -- subsample_training_set
+ * to k * max_points_per_centroid with rand_perm(seed), centroids initialised from rand_perm(seed + 1), niter times
+ * { assign (the coarse quantizer's kernels), compute_centroids (float sums in point order), split_clusters }.  The
+ * training set is uploaded once; x: n*d fp32 host, centroids: k*d fp32 host out, objective (may be NULL): sum of the
+ * distances of the last assignment.  Bit-identical to the oracle's go_kmeans, which is pinned against compiled faiss. */
+int gamma_hip_kmeans(gamma_hip_index* h, int d, int64_t n, const float* x, int k, int niter, int64_t seed,
+                     int max_points_per_centroid, float* centroids, float* objective);
+/* faiss::rand_perm (faiss:utils/random.cpp:136-146; std::mt19937): the permutation IndexIVFPQ::train_residual_o
+ * subsamples its training set with (host only) */
+void gamma_hip_rand_perm(int32_t* perm, int64_t n, int64_t seed);
+
 /* ---- multi-vector documents (VIDMgr, vector/raw_vector_common.h:36-110) -------------------------
  * A table whose documents carry several vectors per field has vid != docid; every validity test of the path --
  * the delete bitmap, the per-request range bitmaps, the device columns (GammaSearchCondition::IsValid,

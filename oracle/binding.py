@@ -71,6 +71,13 @@ def lib():
         L.go_knn_L2sqr.restype = None
         L.go_knn_L2sqr.argtypes = [C.c_int, _f32p, _f32p, C.c_size_t, C.c_size_t, C.c_size_t,
                                    C.c_size_t, _f32p, _i64p]
+        L.go_rand_perm.restype = None
+        L.go_rand_perm.argtypes = [C.POINTER(C.c_int), C.c_size_t, C.c_int64]
+        L.go_set_kmeans_assign_mode.argtypes = [C.c_int]
+        L.go_kmeans.restype = C.c_float
+        L.go_kmeans.argtypes = [C.c_int, C.c_int64, _f32p, C.c_int, C.c_int, C.c_int64, C.c_int, _f32p]
+        L.go_ivfpq_train.restype = None
+        L.go_ivfpq_train.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, _f32p, _f32p, _f32p]
         L.go_knn_inner_product.restype = None
         L.go_knn_inner_product.argtypes = [_f32p, _f32p, C.c_size_t, C.c_size_t, C.c_size_t,
                                            C.c_size_t, _f32p, _i64p]
@@ -359,6 +366,28 @@ def flat_search(raw, x, k, metric=METRIC_L2, ctx=None):
     return D, I
 
 
+def kmeans(x, k, niter, seed=1234, max_points_per_centroid=256, assign_mode=-1):
+    """faiss::Clustering::train restated (gamma_oracle.c): (centroids [k, d], objective of the last assignment)"""
+    x = _f32(x)
+    cen = np.empty((k, x.shape[1]), dtype=np.float32)
+    lib().go_set_kmeans_assign_mode(assign_mode)
+    try:
+        obj = lib().go_kmeans(x.shape[1], x.shape[0], _fp(x), k, niter, seed, max_points_per_centroid, _fp(cen))
+    finally:
+        lib().go_set_kmeans_assign_mode(-1)
+    return cen, float(obj)
+
+
+def ivfpq_train(x, nlist, M):
+    """IndexIVFPQ::train as GammaIVFPQIndex::Indexing configures it: (coarse centroids, PQ codebooks)"""
+    x = _f32(x)
+    d = x.shape[1]
+    cc = np.empty((nlist, d), dtype=np.float32)
+    pq = np.empty((M, 256, d // M), dtype=np.float32)
+    lib().go_ivfpq_train(d, nlist, M, x.shape[0], _fp(x), _fp(cc), _fp(pq))
+    return cc, pq
+
+
 def knn_L2sqr(x, y, k, mode=0):
     x, y = _f32(x), _f32(y)
     D = np.empty((x.shape[0], k), dtype=np.float32)
@@ -395,6 +424,10 @@ def ref():
         R.ref_fvec_madd.restype = None
         R.ref_fvec_madd.argtypes = [C.c_size_t, _f32p, C.c_float, _f32p, _f32p]
         R.ref_set_blas_threshold.argtypes = [C.c_int]
+        R.ref_rand_perm.restype = None
+        R.ref_rand_perm.argtypes = [C.POINTER(C.c_int), C.c_size_t, C.c_int64]
+        R.ref_kmeans.restype = C.c_float
+        R.ref_kmeans.argtypes = [C.c_int, C.c_int64, _f32p, C.c_int, C.c_int, C.c_int64, _f32p]
         R.ref_get_blas_threshold.restype = C.c_int
         for n in ("ref_flat_l2_search", "ref_flat_ip_search"):
             getattr(R, n).restype = None

@@ -1040,3 +1040,187 @@ int go_num_threads(void) {
     return 1;
 #endif
 }
+
+/* ===================================================================================
+ * Training: faiss::Clustering::train (faiss:Clustering.cpp:255-560) as GammaIVFPQIndex::Indexing drives it
+ * (index/impl/gamma_index_ivfpq.cc:272-354 -> IndexIVFPQ::train: train_q1 with cp.niter = 10, then
+ * train_residual_o, faiss:IndexIVFPQ.cpp:67-131, and ProductQuantizer::train, faiss:impl/ProductQuantizer.cpp:249-302).
+ * nredo 1, no weights, no codec, no frozen centroids, L2.  The random numbers are std::mt19937's
+ * (faiss:utils/random.cpp:18-38,136-146); the assignment step is go_knn_L2sqr (mode 1 from 20 points on: the
+ * stand-in for sgemm_), so the result is a DETERMINISTIC function of the input -- the device trainer
+ * is compared with it bit for bit; against the compiled faiss (MKL sgemm_ order, its own thread count) the
+ * comparison is on the quantisation error (tests/test_training_cpu.py).
+ * =================================================================================== */
+typedef struct {
+    uint32_t mt[624];
+    int idx;
+} go_mt19937;
+
+static void mt_seed(go_mt19937* g, uint32_t seed) {
+    g->mt[0] = seed;
+    for (int i = 1; i < 624; i++) g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+    g->idx = 624;
+}
+static uint32_t mt_next(go_mt19937* g) {
+    if (g->idx >= 624) {
+        for (int i = 0; i < 624; i++) {
+            const uint32_t y = (g->mt[i] & 0x80000000u) | (g->mt[(i + 1) % 624] & 0x7fffffffu);
+            g->mt[i] = g->mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        g->idx = 0;
+    }
+    uint32_t y = g->mt[g->idx++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+/* rand_perm, faiss:utils/random.cpp:136-146 */
+void go_rand_perm(int* perm, size_t n, int64_t seed) {
+    for (size_t i = 0; i < n; i++) perm[i] = (int)i;
+    go_mt19937 g;
+    mt_seed(&g, (uint32_t)seed);
+    for (size_t i = 0; i + 1 < n; i++) {
+        const int i2 = (int)(i + (size_t)(mt_next(&g) % (uint64_t)(int)(n - i)));
+        const int t = perm[i];
+        perm[i] = perm[i2];
+        perm[i2] = t;
+    }
+}
+
+/* compute_centroids + the normalisation, faiss:Clustering.cpp:138-208: per centroid a float sum over its points in
+ * ascending point order, then c[j] *= 1 / hassign */
+void go_kmeans_update(int d, int k, int64_t n, const float* x, const int64_t* assign, float* hassign, float* centroids) {
+    memset(centroids, 0, sizeof(float) * (size_t)d * k);
+    memset(hassign, 0, sizeof(float) * (size_t)k);
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t ci = assign[i];
+        float* c = centroids + ci * d;
+        const float* xi = x + i * d;
+        hassign[ci] += 1.0f;
+        for (int j = 0; j < d; j++) c[j] += xi[j];
+    }
+    for (int ci = 0; ci < k; ci++) {
+        if (hassign[ci] == 0) continue;
+        const float norm = 1 / hassign[ci];
+        float* c = centroids + (size_t)ci * d;
+        for (int j = 0; j < d; j++) c[j] *= norm;
+    }
+}
+
+/* split_clusters, faiss:Clustering.cpp:220-268 */
+int go_kmeans_split(int d, int k, int64_t n, float* hassign, float* centroids) {
+    int nsplit = 0;
+    go_mt19937 g;
+    mt_seed(&g, 1234u);
+    for (int ci = 0; ci < k; ci++) {
+        if (hassign[ci] != 0) continue;
+        int cj;
+        for (cj = 0; 1; cj = (cj + 1) % k) {
+            const float p = (float)(((double)hassign[cj] - 1.0) / (double)(float)(n - k));
+            const float r = (float)mt_next(&g) / 4294967296.0f;   /* mt() / float(mt.max()) */
+            if (r < p) break;
+        }
+        memcpy(centroids + (size_t)ci * d, centroids + (size_t)cj * d, sizeof(float) * d);
+        for (int j = 0; j < d; j++) {
+            float* a = &centroids[(size_t)ci * d + j];
+            float* b = &centroids[(size_t)cj * d + j];
+            if (j % 2 == 0) {
+                *a = (float)((double)*a * (1 + 1 / 1024.));
+                *b = (float)((double)*b * (1 - 1 / 1024.));
+            } else {
+                *a = (float)((double)*a * (1 - 1 / 1024.));
+                *b = (float)((double)*b * (1 + 1 / 1024.));
+            }
+        }
+        hassign[ci] = hassign[cj] / 2;
+        hassign[cj] -= hassign[ci];
+        nsplit++;
+    }
+    return nsplit;
+}
+
+/* Clustering::train.  centroids: k*d out.  Returns the objective of the last assignment (sum of the distances,
+ * accumulated in float in point order, :478-481). */
+static int g_kmeans_assign_mode = -1; /* -1: faiss's rule (exact below 20 points); 0 / 1 force a form (tests) */
+void go_set_kmeans_assign_mode(int mode) { g_kmeans_assign_mode = mode; }
+
+float go_kmeans(int d, int64_t n, const float* x_in, int k, int niter, int64_t seed, int max_points_per_centroid,
+                float* centroids) {
+    const float* x = x_in;
+    float* x_new = NULL;
+    if (n > (int64_t)k * max_points_per_centroid) { /* subsample_training_set, :92-120 */
+        int* perm = (int*)malloc(sizeof(int) * (size_t)n);
+        go_rand_perm(perm, (size_t)n, seed);
+        const int64_t n2 = (int64_t)k * max_points_per_centroid;
+        x_new = (float*)malloc(sizeof(float) * (size_t)n2 * d);
+        for (int64_t i = 0; i < n2; i++) memcpy(x_new + i * d, x_in + (size_t)perm[i] * d, sizeof(float) * d);
+        free(perm);
+        n = n2;
+        x = x_new;
+    }
+    if (n == k) { /* :334-355 */
+        memcpy(centroids, x, sizeof(float) * (size_t)d * k);
+        free(x_new);
+        return 0.f;
+    }
+    {
+        int* perm = (int*)malloc(sizeof(int) * (size_t)n);
+        go_rand_perm(perm, (size_t)n, seed + 1); /* :412 */
+        for (int i = 0; i < k; i++) memcpy(centroids + (size_t)i * d, x + (size_t)perm[i] * d, sizeof(float) * d);
+        free(perm);
+    }
+    int64_t* assign = (int64_t*)malloc(sizeof(int64_t) * (size_t)n);
+    float* dis = (float*)malloc(sizeof(float) * (size_t)n);
+    float* hassign = (float*)malloc(sizeof(float) * (size_t)k);
+    float obj = 0;
+    for (int it = 0; it < niter; it++) {
+        go_knn_L2sqr(g_kmeans_assign_mode >= 0 ? g_kmeans_assign_mode : (n < 20 ? 0 : 1), x, centroids, (size_t)d, (size_t)n,
+                     (size_t)k, 1, dis, assign);
+        obj = 0;
+        for (int64_t j = 0; j < n; j++) obj += dis[j];
+        go_kmeans_update(d, k, n, x, assign, hassign, centroids);
+        go_kmeans_split(d, k, n, hassign, centroids);
+    }
+    free(assign);
+    free(dis);
+    free(hassign);
+    free(x_new);
+    return obj;
+}
+
+/* IndexIVFPQ::train as Gamma configures it: coarse k-means (niter 10, seed 1234), then the product quantizer on the
+ * residuals of at most 256 * 256 points (fvecs_maybe_subsample with pq.cp.seed = 1234; niter 25 per sub-quantizer) */
+void go_ivfpq_train(int d, int nlist, int M, int64_t n, const float* x, float* cc, float* pq) {
+    go_kmeans(d, n, x, nlist, 10, 1234, 256, cc);
+    const int64_t nmax = 256 * 256;
+    const float* xs = x;
+    float* sub = NULL;
+    int64_t ns = n;
+    if (n > nmax) {
+        int* perm = (int*)malloc(sizeof(int) * (size_t)n);
+        go_rand_perm(perm, (size_t)n, 1234);
+        sub = (float*)malloc(sizeof(float) * (size_t)nmax * d);
+        for (int64_t i = 0; i < nmax; i++) memcpy(sub + i * d, x + (size_t)perm[i] * d, sizeof(float) * d);
+        free(perm);
+        xs = sub;
+        ns = nmax;
+    }
+    int64_t* assign = (int64_t*)malloc(sizeof(int64_t) * (size_t)ns);
+    float* dis = (float*)malloc(sizeof(float) * (size_t)ns);
+    go_knn_L2sqr(ns < 20 ? 0 : 1, xs, cc, (size_t)d, (size_t)ns, (size_t)nlist, 1, dis, assign);
+    const int dsub = d / M;
+    float* slice = (float*)malloc(sizeof(float) * (size_t)ns * dsub);
+    for (int m = 0; m < M; m++) {
+        for (int64_t i = 0; i < ns; i++)
+            for (int t = 0; t < dsub; t++) /* compute_residual: x - centroid */
+                slice[i * dsub + t] = xs[i * d + m * dsub + t] - cc[(size_t)assign[i] * d + m * dsub + t];
+        go_kmeans(dsub, ns, slice, 256, 25, 1234, 256, pq + (size_t)m * 256 * dsub);
+    }
+    free(slice);
+    free(assign);
+    free(dis);
+    free(sub);
+}

@@ -152,6 +152,14 @@ void go_ivfflat_assign(go_ivfpq* ix, int64_t n, const float* x, int64_t* list_no
 int go_flat_search(const float* raw, int64_t n, int d, const go_search_ctx* ctx, int metric,
                    int nq, const float* x, int k, float* distances, int64_t* labels);
 
+/* training: faiss::Clustering::train and IndexIVFPQ::train restated (gamma_oracle.c, "Training") */
+void go_rand_perm(int* perm, size_t n, int64_t seed);
+void go_set_kmeans_assign_mode(int mode);
+void go_kmeans_update(int d, int k, int64_t n, const float* x, const int64_t* assign, float* hassign, float* centroids);
+int go_kmeans_split(int d, int k, int64_t n, float* hassign, float* centroids);
+float go_kmeans(int d, int64_t n, const float* x, int k, int niter, int64_t seed, int max_points_per_centroid,
+                float* centroids);
+void go_ivfpq_train(int d, int nlist, int M, int64_t n, const float* x, float* cc, float* pq);
 int go_num_threads(void);
 
 #ifdef __cplusplus

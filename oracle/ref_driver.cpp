@@ -6,6 +6,7 @@
 // that oracle/gamma_oracle.c (the CPU restatement) can be pinned bit-for-bit against the
 // real arithmetic, and so tests/gen_golden.py can emit golden vectors.  Nothing in the
 // product path may link or load it.
+#include <faiss/Clustering.h>
 #include <faiss/IndexFlat.h>
 #include <faiss/IndexIVFPQ.h>
 #include <faiss/impl/ProductQuantizer.h>
@@ -13,6 +14,7 @@
 #include <faiss/invlists/InvertedLists.h>
 #include <faiss/utils/Heap.h>
 #include <faiss/utils/distances.h>
+#include <faiss/utils/random.h>
 #include <faiss/utils/utils.h>
 
 #include <cstdint>
@@ -85,6 +87,21 @@ void ref_fvec_madd(size_t n, const float* a, float bf, const float* b, float* c)
 }
 
 void ref_set_blas_threshold(int t) { faiss::distance_compute_blas_threshold = t; }
+
+/* ---------------- training: the real rand_perm and the real Clustering ---------------- */
+void ref_rand_perm(int* perm, size_t n, int64_t seed) { faiss::rand_perm(perm, n, seed); }
+/* faiss::Clustering over an IndexFlatL2, the way IndexIVF::train_q1 / ProductQuantizer::train run it; returns the
+ * objective of the last iteration */
+float ref_kmeans(int d, int64_t n, const float* x, int k, int niter, int64_t seed, float* centroids) {
+    faiss::ClusteringParameters cp;
+    cp.niter = niter;
+    cp.seed = (int)seed;
+    faiss::Clustering clus(d, k, cp);
+    faiss::IndexFlatL2 index(d);
+    clus.train(n, x, index);
+    memcpy(centroids, clus.centroids.data(), sizeof(float) * (size_t)d * k);
+    return clus.iteration_stats.empty() ? 0.f : clus.iteration_stats.back().obj;
+}
 int ref_get_blas_threshold() { return faiss::distance_compute_blas_threshold; }
 
 /* ---------------- brute-force kNN as the coarse quantizer runs it ---------------- */
