@@ -313,6 +313,11 @@ def main():
             flops = 3.0 * fnq * N * d
             extra["c2_flat"] = {"workload": "C2: flat L2, %dx%d, %d queries/call, k=%d" % (N, d, fnq, fk),
                                 "ms_per_call": round(sec * 1e3, 3), "qps": round(fnq / sec, 1),
+                                # SURVEY 8d counts the GEMM form's 2 nq N d flops; the exact (x - y)^2 order the kernel
+                                # computes (bit-identical to fvec_L2sqr) costs a sub and an fma per element pair = 3
+                                "roofline_gemm_form_flops": {"bound": "valu_fp32", "achieved": round(2.0 * fnq * N * d / sec / 1e12, 2),
+                                                             "peak": 157.3, "unit": "TFLOP/s",
+                                                             "frac": round(2.0 * fnq * N * d / sec / 1e12 / 157.3, 4)},
                                 "roofline": {"bound": "valu_fp32", "achieved": round(flops / sec / 1e12, 2),
                                              "peak": 157.3, "unit": "TFLOP/s",
                                              "frac": round(flops / sec / 157.3e12, 4)}}
@@ -404,6 +409,10 @@ def main():
             "qps": first(r"= (\d+) queries/s", out), "ms_per_call": first(r"search: ([0-9.]+) ms", out),
             "scan_gb_per_call": first(r"scan GB/step ([0-9.]+)", out), "recall_at_10_vs_flat": first(r"recall@10 vs flat on 64 queries: ([0-9.]+)", out),
             "qps_with_10pct_filter": first(r"lists compacted per call: [0-9.]+ ms per \d+ queries = (\d+) queries/s", out),
+            "roofline": {"bound": "hbm", "kernel": "k_ivfpq_scan_pair (MT 32)", "unit": "GB/s", "peak": 8000.0,
+                         "achieved": (first(r"-> ([0-9.]+) TB/s = [0-9.]+ of 8 TB/s", out) or 0) * 1000.0,
+                         "frac": first(r"TB/s = ([0-9.]+) of 8 TB/s", out)},
+            "recall_num_sweep": re.findall(r"recall_num (\d+): recall@10 ([0-9.]+), ([0-9.]+) ms per \d+ queries = (\d+) queries/s", out),
             "single_query_us": first(r"latency nq=1\s+small-batch chain median ([0-9.]+)", out), "seconds": round(time.time() - t0, 1)}
         t0 = time.time()
         out = run_tool([os.path.join("tools", "c5_scale.py"), "2e6"], 150)
@@ -412,6 +421,9 @@ def main():
             "qps": first(r"no filter: [0-9.]+ ms per \d+ queries = (\d+) queries/s", out),
             "qps_with_10pct_range_filter": first(r"10% range filter: [0-9.]+ ms per \d+ queries = (\d+) queries/s", out),
             "scan_tb_per_s": first(r"-> ([0-9.]+) TB/s", out),
+            "roofline": {"bound": "hbm", "kernel": "k_ivfpq_scan_pair (MT 64, inner product)", "unit": "GB/s", "peak": 8000.0,
+                         "achieved": (first(r"-> ([0-9.]+) TB/s", out) or 0) * 1000.0,
+                         "frac": round((first(r"-> ([0-9.]+) TB/s", out) or 0) / 8.0, 4)},
             "single_query_us": first(r"latency nq=1\s+small-batch chain median ([0-9.]+)", out), "seconds": round(time.time() - t0, 1)}
         log("shape legs: %s" % json.dumps({k2: extra[k2] for k2 in ("c4_shape_8m", "c5_shape_2m")}))
 

@@ -137,6 +137,11 @@ class GammaHip:
         vecs = _f32(vecs)
         self._ck(self.L.gamma_hip_raw_write(self.h, first_vid, vecs.shape[0], _p(vecs, _lib.f32p)), "raw_write")
 
+    def raw_stats(self):
+        out = np.zeros(4, dtype=np.int64)
+        self._ck(self.L.gamma_hip_raw_stats(self.h, _p(out, _lib.i64p)), "raw_stats")
+        return dict(rows=int(out[0]), capacity=int(out[1]), moves=int(out[2]), in_place=bool(out[3]))
+
     def raw_update(self, vid, vec):
         vec = _f32(vec)
         self._ck(self.L.gamma_hip_raw_update(self.h, vid, _p(vec, _lib.f32p)), "raw_update")

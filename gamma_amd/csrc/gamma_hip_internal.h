@@ -110,6 +110,16 @@ struct gamma_hip_index {
     int raw_d = 0;
     float* d_raw = nullptr;
     int64_t nraw = 0, raw_cap = 0;
+    // The store grows IN PLACE where the runtime offers virtual memory management: one address range reserved up
+    // front, physical chunks mapped behind the rows as they come -- no copy, no second allocation, no wait for the
+    // searches in flight (the reference keeps 500 000-vector segments for the same reason, vector/memory_raw_vector.cc:
+    // 90-142; a segment table would cost every gather an indirection, a mapped range costs nothing).  Fallback: a
+    // geometric reallocation under the exclusive lock.
+    bool raw_vmm = false;
+    size_t raw_va_bytes = 0, raw_mapped = 0, raw_gran = 0;
+    std::vector<hipMemGenericAllocationHandle_t> raw_chunks;
+    std::vector<size_t> raw_chunk_bytes;
+    int64_t raw_regrows = 0;   // reallocations that moved the store (0 with virtual memory management)
 
     // numeric scalar columns (on-device range filters)
     struct Column {

@@ -414,12 +414,70 @@ int gamma_hip_raw_init(gamma_hip_index* h, int d) {
     if (!h || d <= 0) return GAMMA_HIP_EINVAL;
     WriteLock lk(h);
     if (h->raw_d != 0 && h->raw_d != d) return fail(h, GAMMA_HIP_EINVAL, "raw store dimension mismatch");
+    if (h->raw_d == 0 && !getenv("GAMMA_HIP_NO_RAW_VMM")) {
+        // reserve the address range the store may ever need (the device's memory): physical chunks are mapped into it
+        // as rows arrive (raw_reserve).  Any failure leaves the reallocating store.
+        GH_CHECK(h, hipSetDevice(h->device));
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = h->device;
+        size_t gran = 0, free_b = 0, total_b = 0;
+        void* va = nullptr;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran > 0 &&
+            hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) {
+            const size_t want = (total_b + gran - 1) / gran * gran;
+            if (hipMemAddressReserve(&va, want, 0, nullptr, 0) == hipSuccess && va) {
+                h->raw_vmm = true;
+                h->raw_gran = gran;
+                h->raw_va_bytes = want;
+                h->d_raw = static_cast<float*>(va);
+            }
+        }
+        if (!h->raw_vmm) (void)hipGetLastError();
+    }
     h->raw_d = d;
     return GAMMA_HIP_OK;
 }
 
 static int raw_reserve(H* h, int64_t need) {
     if (need <= h->raw_cap) return GAMMA_HIP_OK;
+    if (h->raw_vmm) {
+        // map more physical memory behind the rows in place: nothing moves, searches in flight go on reading
+        const size_t row = (size_t)h->raw_d * sizeof(float);
+        const size_t need_b = (size_t)need * row;
+        // at least 1/8 more than what is mapped (fewer, larger chunks), in whole granules
+        size_t add = std::max(need_b - h->raw_mapped, h->raw_mapped / 8);
+        add = std::max<size_t>(add, (size_t)64 << 20);
+        add = (add + h->raw_gran - 1) / h->raw_gran * h->raw_gran;
+        if (h->raw_mapped + add > h->raw_va_bytes) add = h->raw_va_bytes - h->raw_mapped;
+        if (h->raw_mapped + add < need_b) return fail(h, GAMMA_HIP_ENOMEM, "raw store: beyond the reserved address range");
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = h->device;
+        hipMemGenericAllocationHandle_t hnd;
+        if (hipMemCreate(&hnd, add, &prop, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(h, GAMMA_HIP_ENOMEM, "raw store: out of device memory");
+        }
+        char* at = reinterpret_cast<char*>(h->d_raw) + h->raw_mapped;
+        hipMemAccessDesc acc = {};
+        acc.location.type = hipMemLocationTypeDevice;
+        acc.location.id = h->device;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        if (hipMemMap(at, add, 0, hnd, 0) != hipSuccess || hipMemSetAccess(at, add, &acc, 1) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipMemRelease(hnd);
+            return fail(h, GAMMA_HIP_EDEVICE, "raw store: mapping failed");
+        }
+        h->raw_chunks.push_back(hnd);
+        h->raw_chunk_bytes.push_back(add);
+        h->raw_mapped += add;
+        h->raw_cap = (int64_t)(h->raw_mapped / row);
+        return GAMMA_HIP_OK;
+    }
+    h->raw_regrows++;
     int64_t ncap = std::max<int64_t>(need, h->raw_cap + h->raw_cap / 2);
     ncap = std::max<int64_t>(ncap, 1024);
     float* np = nullptr;
@@ -491,6 +549,16 @@ int gamma_hip_raw_update_batch(gamma_hip_index* h, int64_t n, const int64_t* vid
 }
 
 int64_t gamma_hip_raw_count(gamma_hip_index* h) { return h ? h->nraw : -1; }
+
+int gamma_hip_raw_stats(gamma_hip_index* h, int64_t* out4) {
+    if (!h || !out4) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    out4[0] = h->nraw;
+    out4[1] = h->raw_cap;
+    out4[2] = h->raw_regrows;
+    out4[3] = h->raw_vmm ? 1 : 0;
+    return GAMMA_HIP_OK;
+}
 
 /* ---- delete bitmap ------------------------------------------------------------------- */
 static int bitmap_reserve(H* h, int64_t nbits) {

@@ -186,6 +186,10 @@ int gamma_hip_raw_update_batch(gamma_hip_index* h, int64_t n, const int64_t* vid
  * vector store needs when Search (brute force before training) and the indexing thread's Add race. */
 int gamma_hip_raw_write(gamma_hip_index* h, int64_t first_vid, int64_t n, const float* vecs);
 int64_t gamma_hip_raw_count(gamma_hip_index* h);
+/* out4 = {rows, rows the mapped / allocated memory holds, reallocations that MOVED the store so far, 1 when the store
+ * grows in place (virtual memory management: physical chunks mapped behind the rows, nothing ever moves or waits for
+ * the searches in flight -- what the reference gets from its 500 000-vector segments, vector/memory_raw_vector.cc:90-142)} */
+int gamma_hip_raw_stats(gamma_hip_index* h, int64_t* out4);
 
 /* ---- delete bitmap (bitmap::BitmapManager, util/bitmap_manager.cc:171-192): bit = docid,
  *      byte docid>>3, mask 1<<(docid&7) --------------------------------------------------- */

@@ -103,3 +103,42 @@ def test_search_during_inserts_sees_a_prefix_of_the_log():
         compare_topk(expect[nb][0], expect[nb][1], D, I)
     finally:
         g.close()
+
+
+def test_raw_store_grows_in_place_under_search():
+    """The raw store (re-rank rows, flat search) grows by mapping physical memory behind its rows (virtual memory
+    management): no reallocation, no copy, no wait for the searches in flight -- a searcher thread keeps getting exact
+    answers over a prefix of the rows while 600 MB arrive in 40 appends."""
+    import threading
+    d, rows_per, nb = 128, 30000, 40
+    rng = np.random.default_rng(5)
+    blocks = [rng.integers(0, 255, size=(rows_per, d)).astype(np.float32) for _ in range(4)]
+    g = api.GammaHip(0)
+    try:
+        g.raw_init(d)
+        g.raw_append(blocks[0])
+        st0 = g.raw_stats()
+        q = blocks[0][:8] + 1.0
+        args = api.SearchArgs(metric=api.METRIC_L2, min_score=-3e38, max_score=3e38)
+        stop, bad, calls = threading.Event(), [], [0]
+
+        def searcher():
+            while not stop.is_set():
+                D, I = g.flat_search(q, 1, args)
+                calls[0] += 1
+                # row i of block 0 is the nearest of q[i] (distance d) whatever has been appended since
+                if not (np.array_equal(I[:, 0], np.arange(8)) and (D[:, 0] == float(d)).all()):
+                    bad.append((I[:, 0].copy(), D[:, 0].copy()))
+
+        t = threading.Thread(target=searcher)
+        t.start()
+        for b in range(1, nb):
+            g.raw_append(blocks[b % 4] + np.float32(1000.0 * b))   # far from the queries
+        stop.set()
+        t.join()
+        st = g.raw_stats()
+        assert st["rows"] == rows_per * nb and not bad and calls[0] > 0
+        if st["in_place"]:
+            assert st["moves"] == 0 and st0["moves"] == 0
+    finally:
+        g.close()
