@@ -54,6 +54,12 @@ def main():
                     help="torch.distributed backend; 'gloo' with --one-gpu runs all ranks on GPU 0 (functional "
                          "check of the multi-rank path on a single-GPU box, not a measurement)")
     ap.add_argument("--one-gpu", action="store_true", help="every rank uses cuda:0")
+    ap.add_argument("--placement", default="auto", choices=["auto", "shard", "replicate"],
+                    help="--gpus N > 1: 'shard' = the lists split over the ranks (greedy sum(len)), candidates exchanged "
+                         "(gamma_amd.dist.sharded_search); 'replicate' = every rank holds the whole index and answers its "
+                         "slice of the batch (replicated_search: one all-gather of the results); 'auto' = replicate while "
+                         "the lists are under 2 GiB per GPU -- list sharding is for indexes that need it (C4), at C3 size "
+                         "it multiplies the per-query fixed work by N (DESIGN.md, multi-GPU)")
     ap.add_argument("--in-process", action="store_true",
                     help="--gpus N through ONE process: the in-process group of handles (gamma_hip_group_*, what the "
                          "plugins run with \"devices\"), tools/group_bench.py")
@@ -154,8 +160,9 @@ def main():
     lno, codes = enc[0].cpu().numpy(), enc[1].cpu().numpy()
     del enc, state
     list_sizes = np.bincount(lno, minlength=nlist)
-    owner = gdist.balance_lists(list_sizes, world)
-    mine = owner[lno] == rank
+    replicate = use_dist and (a.placement == "replicate" or (a.placement == "auto" and N * (M + 12) <= (2 << 30)))
+    owner = gdist.balance_lists(list_sizes, 1 if replicate else world)
+    mine = owner[lno] == (0 if replicate else rank)
     vids = np.nonzero(mine)[0].astype(np.int64)
     order = np.argsort(lno[vids], kind="stable")
     lists, counts = np.unique(lno[vids], return_counts=True)
@@ -181,6 +188,8 @@ def main():
         if not use_dist:
             g.ivfpq_search_device(xb.data_ptr(), gnq, k, args, d_D.data_ptr(), d_I.data_ptr())
             return d_D, d_I
+        if replicate:
+            return gdist.replicated_search(backend, xb, k, args)
         return gdist.sharded_search(backend, xb, k, args)
 
     # ---- recall@10 against exact flat search on the GPU (rank 0 data is complete: raw replicated)
@@ -466,9 +475,13 @@ def main():
                         "recall_num=%d, has_rank=%s, k=%d, L2, batch=%d queries/step (%d per GPU)" % (
                             nlist, M, N, d, a.nprobe, a.recall_num, str(not a.no_rank).lower(), k, gnq, a.nq),
             "recall_at_10": None if recall is None else round(recall, 4),
-            "parallelism": ("IVF lists sharded x%d (greedy by size), queries sliced x%d; RCCL all-gather of "
-                            "the coarse assignment, all-to-all of per-shard top-recall_num, all-gather of "
-                            "top-k" % (world, world)) if world > 1 else "single GPU",
+            "parallelism": "single GPU" if world == 1 else (
+                ("query-parallel x%d over REPLICATED lists (%.0f MB of lists per GPU: --placement %s), every rank answers "
+                 "its slice of the batch; RCCL all-gather of the top-k" % (world, N * (M + 12) / 1e6, a.placement))
+                if replicate else
+                ("IVF lists sharded x%d (greedy by size), queries sliced x%d; RCCL all-gather of "
+                 "the coarse assignment, all-to-all of per-shard top-recall_num, all-gather of "
+                 "top-k" % (world, world))),
             "stage_us": stages,
             "pcie_inclusive_qps": None if host_qps is None else round(host_qps, 1),
             **extra,

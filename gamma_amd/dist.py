@@ -83,6 +83,10 @@ class HipShardBackend:
     def compact_if_need(self):
         self.g.compact_if_need()
 
+    def search_all(self, x, k, args, D, I):
+        """the whole search for the rows of x on this rank's (complete) index: replicated_search"""
+        self.g.ivfpq_search_device(x.data_ptr(), x.shape[0], k, args, D.data_ptr(), I.data_ptr())
+
     def coarse(self, x, args, cdis, probe):
         """coarse assignment of the rows of x into the preallocated cdis/probe [n, nprobe]"""
         if x.shape[0]:
@@ -276,6 +280,48 @@ def _sharded_search(backend, x, k, args, group, pipeline):
             Iall[rows].view(world, per, k).copy_(b["res"][:, :nres * 8].view(torch.int64).view(world, per, k))
             Dall[rows].view(world, per, k).copy_(b["res"][:, nres * 8:nres * 12].view(torch.float32).view(world, per, k))
     return Dall[:nq], Iall[:nq]
+
+
+def replicated_search(backend, x, k, args, group=None):
+    """Query-parallel search over REPLICATED lists: every rank holds the whole index (no list mask) and answers its slice
+    of the batch with the ordinary single-handle search -- exact ties and all -- and the [nq/W, k] results are
+    all-gathered (the one collective of the path: nq*k*12 bytes in total).  This is what a deployment does with an index
+    that is small next to a GPU's memory: at C3 size (24 MB of codes) list sharding leaves every shard ~1000 codes per
+    query and the per-query fixed work (table, bound, selection) times W (multi-GPU); replicas scale with no
+    exchange on the search path at all.  Inserts / updates / deletes go to every rank.  x: [nq, d] on the device, the
+    same on every rank.  Returns (D, I) for all nq queries on every rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    nq = x.shape[0]
+    q0, q1, per = query_slice(nq, rank, world)
+    stream_ctx = torch.cuda.stream(backend.stream) if hasattr(backend, "stream") else _Null()
+    with stream_ctx:
+        cache = backend.__dict__.setdefault("_rbuf", {})
+        key = (world, per, k)
+        b = cache.get(key)
+        if b is None:
+            nres = per * k
+            res_bytes = (nres * 12 + 7) // 8 * 8
+            res_l = backend.empty((res_bytes,), torch.uint8)
+            b = dict(res_l=res_l, I=res_l[:nres * 8].view(torch.int64).view(per, k),
+                     D=res_l[nres * 8:nres * 12].view(torch.float32).view(per, k),
+                     res=backend.empty((world, res_bytes), torch.uint8),
+                     Dall=backend.empty((world * per, k), torch.float32), Iall=backend.empty((world * per, k), torch.int64))
+            cache.clear()
+            cache[key] = b
+        if q1 - q0 < per:
+            b["D"].zero_()
+            b["I"].fill_(-1)
+        if q1 > q0:
+            backend.search_all(x[q0:q1], k, args, b["D"][:q1 - q0], b["I"][:q1 - q0])
+        if world > 1:
+            dist.all_gather_into_tensor(b["res"].view(-1), b["res_l"], group=group)
+        else:
+            b["res"][0].copy_(b["res_l"])
+        nres = per * k
+        b["Iall"].view(world, per, k).copy_(b["res"][:, :nres * 8].view(torch.int64).view(world, per, k))
+        b["Dall"].view(world, per, k).copy_(b["res"][:, nres * 8:nres * 12].view(torch.float32).view(world, per, k))
+    return b["Dall"][:nq], b["Iall"][:nq]
 
 
 class _Null:

@@ -62,6 +62,11 @@ def main():
         D, I = gdist.sharded_search(be, x, k, args, pipeline=pipeline)
         torch.cuda.synchronize()
         compare_topk(Dref.cpu().numpy(), Iref.cpu().numpy(), D.cpu().numpy(), I.cpu().numpy())
+    # query-parallel over replicated lists: every rank answers its slice on the whole index (the single-handle path,
+    # exact ties included), one all-gather of the results
+    D, I = gdist.replicated_search(gdist.HipShardBackend(full, local), x, k, args)
+    torch.cuda.synchronize()
+    assert D.cpu().numpy().tobytes() == Dref.cpu().numpy().tobytes() and np.array_equal(I.cpu().numpy(), Iref.cpu().numpy())
     dist.destroy_process_group()
     print("rank %d ok" % rank)
 

@@ -119,6 +119,18 @@ def main():
     for pipeline in (2, 3, None):
         D, I = gdist.sharded_search(be, x, k, args, pipeline=pipeline)
         compare_topk(Dr, Ir, D.numpy(), I.numpy())
+    # query-parallel over replicated lists: every rank answers its slice on the whole index, one all-gather
+    class Full:
+        def empty(self, shape, dtype):
+            return torch.empty(shape, dtype=dtype)
+
+        def search_all(self, xs, kk, a, Dd, Ii):
+            Ds, Is = case["oracle"].search(xs.numpy(), kk, nprobe, recall_num=R, has_rank=True, metric=B.METRIC_L2, ctx=ctx,
+                                           coarse_mode=0)
+            Dd.copy_(torch.from_numpy(Ds))
+            Ii.copy_(torch.from_numpy(Is))
+    Dp, Ip = gdist.replicated_search(Full(), x, k, args)
+    assert Dp.numpy().tobytes() == Dr.tobytes() and np.array_equal(Ip.numpy(), Ir)
     # every rank holds the full, identical result
     gathered = [torch.empty_like(I) for _ in range(world)]
     dist.all_gather(gathered, I)
