@@ -83,7 +83,7 @@ def main():
     if a.in_process:   # one process, N handles: a child of its own (this process has not touched the GPU yet)
         import subprocess
         cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "group_bench.py"),
-               "--gpus", str(a.gpus), "--steps", str(a.steps), "--warmup", str(a.warmup), "--nq", str(a.nq)]
+               "--gpus", str(a.gpus), "--steps", str(a.steps), "--warmup", str(a.warmup), "--nq", str(a.nq), "--placement", a.placement]
         if a.one_gpu:
             cmd.append("--one-gpu")
         sys.exit(subprocess.call(cmd))

@@ -490,6 +490,10 @@ class GammaHipGroup:
     def owner(self, l):
         return self.L.gamma_hip_group_owner(self.g, l)
 
+    def set_placement(self, replicate):
+        """before set_owners: True = every member holds every list and a search splits the queries"""
+        self._ck(self.L.gamma_hip_group_set_placement(self.g, 1 if replicate else 0), "group_set_placement")
+
     def add(self, vecs, first_vid):
         vecs = _f32(vecs)
         self._ck(self.L.gamma_hip_group_ivfpq_add(self.g, vecs.shape[0], _p(vecs, _lib.f32p), first_vid), "group_add")

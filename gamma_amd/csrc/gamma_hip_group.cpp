@@ -77,6 +77,7 @@ struct gamma_hip_group {
     std::string err;
     std::mutex mu;            // one group-level call at a time
     int next_enc = 0;         // members take turns encoding Add / Update batches
+    bool replicate = false;   // gamma_hip_group_set_placement: every member holds every list, queries are split
 
     struct Member {
         GBuf x, cdis, probe, rdis, rids, all_dis, all_ids, D, I;
@@ -224,6 +225,14 @@ int gamma_hip_group_set_owners(gamma_hip_group* g, const int64_t* weights) {
     for (int i = 1; i < W; i++)
         if (gamma_hip_ivfpq_nlist(g->m[i]) != nlist) return gfail(g, GAMMA_HIP_EINVAL, "set_owners: members differ in nlist");
     g->owner.assign(nlist, 0);
+    if (g->replicate) {
+        // every member holds every list (member 0 answers the per-list getters); no mask
+        for (int i = 0; i < W; i++) {
+            const int rc = gamma_hip_ivfpq_set_list_mask(g->m[i], nullptr);
+            if (rc) return member_fail(g, i, rc);
+        }
+        return GAMMA_HIP_OK;
+    }
     if (!weights) {
         for (int l = 0; l < nlist; l++) g->owner[l] = l % W;
     } else {
@@ -249,6 +258,16 @@ int gamma_hip_group_set_owners(gamma_hip_group* g, const int64_t* weights) {
     }
     return GAMMA_HIP_OK;
 }
+
+int gamma_hip_group_set_placement(gamma_hip_group* g, int replicate) {
+    if (!g) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (!g->owner.empty() && g->replicate != (replicate != 0))
+        return gfail(g, GAMMA_HIP_EINVAL, "set_placement: before gamma_hip_group_set_owners");
+    g->replicate = replicate != 0;
+    return GAMMA_HIP_OK;
+}
+int gamma_hip_group_placement(const gamma_hip_group* g) { return g && g->replicate ? 1 : 0; }
 
 int gamma_hip_group_owner(const gamma_hip_group* g, int l) {
     return (g && l >= 0 && l < (int)g->owner.size()) ? g->owner[l] : -1;
@@ -281,7 +300,7 @@ int gamma_hip_group_ivfpq_add(gamma_hip_group* g, int64_t n, const float* vecs, 
         std::vector<uint8_t> gcodes;
         for (int64_t i = 0; i < n; i++) {
             const int64_t src = order[i];
-            if (g->owner[lno[src]] != o) continue;
+            if (!g->replicate && g->owner[lno[src]] != o) continue;
             if (lists.empty() || lists.back() != (int32_t)lno[src]) {
                 lists.push_back((int32_t)lno[src]);
                 counts.push_back(0);
@@ -291,6 +310,13 @@ int gamma_hip_group_ivfpq_add(gamma_hip_group* g, int64_t n, const float* vecs, 
             gcodes.insert(gcodes.end(), codes.begin() + (size_t)src * cs, codes.begin() + (size_t)(src + 1) * cs);
         }
         if (lists.empty()) continue;
+        if (g->replicate) {   // the same grouped batch to every member
+            for (int i = 0; i < W; i++) {
+                rc = gamma_hip_ivfpq_add_keys_batch(g->m[i], (int)lists.size(), lists.data(), counts.data(), vids.data(), gcodes.data());
+                if (rc) return member_fail(g, i, rc);
+            }
+            break;
+        }
         rc = gamma_hip_ivfpq_add_keys_batch(g->m[o], (int)lists.size(), lists.data(), counts.data(), vids.data(), gcodes.data());
         if (rc) return member_fail(g, o, rc);
     }
@@ -302,6 +328,13 @@ int gamma_hip_group_ivfpq_add_keys(gamma_hip_group* g, int l, int n, const int64
     std::lock_guard<std::mutex> lk(g->mu);
     if (l < 0 || l >= (int)g->owner.size()) return gfail(g, GAMMA_HIP_EINVAL, "add_keys: bad list (or no owners yet)");
     const int o = g->owner[l];
+    if (g->replicate) {
+        for (size_t i = 0; i < g->m.size(); i++) {
+            const int rc = gamma_hip_ivfpq_add_keys(g->m[i], l, n, vids, codes);
+            if (rc) return member_fail(g, (int)i, rc);
+        }
+        return GAMMA_HIP_OK;
+    }
     const int rc = gamma_hip_ivfpq_add_keys(g->m[o], l, n, vids, codes);
     return rc ? member_fail(g, o, rc) : GAMMA_HIP_OK;
 }
@@ -333,6 +366,15 @@ int gamma_hip_group_ivfpq_update(gamma_hip_group* g, int n, const int64_t* vids,
     std::vector<uint8_t> codes((size_t)n * cs);
     int rc = gamma_hip_ivfpq_encode_each(g->m[e], n, vecs, lno.data(), codes.data());
     if (rc) return member_fail(g, e, rc);
+    if (g->replicate) {   // one encode, the same in-place Update at every member (a member ignores vids it never held)
+        std::vector<int32_t> l32(n);
+        for (int j = 0; j < n; j++) l32[j] = (int32_t)lno[j];
+        for (int i = 0; i < W; i++) {
+            rc = gamma_hip_ivfpq_apply_updates(g->m[i], n, l32.data(), vids, codes.data(), nullptr);
+            if (rc) return member_fail(g, i, rc);
+        }
+        return GAMMA_HIP_OK;
+    }
     // who holds each vid now (at most one member); kept current while the batch is routed, so that a vid named
     // twice is followed through its first move
     std::unordered_map<int64_t, int> holder;
@@ -456,6 +498,49 @@ static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, in
         slice(i, &q0, &q1);
         const int nql = q1 - q0;
         int& rc = rcs[i];
+        if (g->replicate) {
+            // query-parallel over replicated lists: the member answers its slice with the ordinary single-handle search
+            // (exact ties and all); nothing is exchanged but the slice and its k results
+            auto hipr = [&](hipError_t e, const char* what) {
+                if (e != hipSuccess && rc == GAMMA_HIP_OK) {
+                    rc = e == hipErrorOutOfMemory ? GAMMA_HIP_ENOMEM : GAMMA_HIP_EDEVICE;
+                    errs[i] = std::string(what) + ": " + hipGetErrorString(e);
+                }
+            };
+            hipr(hipSetDevice(g->dev[i]), "hipSetDevice");
+            if (nql <= 0 || rc != GAMMA_HIP_OK) return;
+            const bool local = on_device && g->dev[i] == g->dev[0];
+            const float* xs = x + (size_t)q0 * d;
+            float* Ds = distances + (size_t)q0 * k;
+            int64_t* Is = labels + (size_t)q0 * k;
+            if (!local) {
+                hipr(b.x.ensure((size_t)nql * d * sizeof(float)), "alloc");
+                hipr(b.D.ensure((size_t)nql * k * sizeof(float)), "alloc");
+                hipr(b.I.ensure((size_t)nql * k * sizeof(int64_t)), "alloc");
+                if (rc != GAMMA_HIP_OK) return;
+                if (on_device) hipr(copy_between(b.x.p, g->dev[i], xs, g->dev[0], (size_t)nql * d * sizeof(float), s), "queries to the member");
+                else hipr(hipMemcpyAsync(b.x.p, xs, (size_t)nql * d * sizeof(float), hipMemcpyHostToDevice, s), "H2D queries");
+            }
+            if (rc == GAMMA_HIP_OK) {
+                const int r = gamma_hip_ivfpq_search_device(h, &pp, nql, local ? xs : b.x.as<float>(), k, local ? Ds : b.D.as<float>(),
+                                                           local ? Is : b.I.as<int64_t>());
+                if (r != GAMMA_HIP_OK) {
+                    rc = r;
+                    errs[i] = std::string(gamma_hip_strerror(r)) + " (" + gamma_hip_last_error(h) + ")";
+                }
+            }
+            if (rc == GAMMA_HIP_OK && !local) {
+                if (on_device) {
+                    hipr(copy_between(Ds, g->dev[0], b.D.p, g->dev[i], (size_t)nql * k * sizeof(float), s), "results");
+                    hipr(copy_between(Is, g->dev[0], b.I.p, g->dev[i], (size_t)nql * k * sizeof(int64_t), s), "results");
+                } else {
+                    hipr(hipMemcpyAsync(Ds, b.D.p, (size_t)nql * k * sizeof(float), hipMemcpyDeviceToHost, s), "D2H");
+                    hipr(hipMemcpyAsync(Is, b.I.p, (size_t)nql * k * sizeof(int64_t), hipMemcpyDeviceToHost, s), "D2H");
+                }
+            }
+            hipr(hipStreamSynchronize(s), "sync");
+            return;
+        }
         auto hip = [&](hipError_t e, const char* what) {
             if (e != hipSuccess && rc == GAMMA_HIP_OK) {
                 rc = e == hipErrorOutOfMemory ? GAMMA_HIP_ENOMEM : GAMMA_HIP_EDEVICE;

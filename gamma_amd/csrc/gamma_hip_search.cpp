@@ -810,6 +810,43 @@ int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, c
 // the same k entries (up to its order inside exact ties).
 // IVFFLAT, small batches: the chain of ivfpq_small without tables and re-rank -- exact coarse distances | top-nprobe +
 // slab offsets | exact distances of the probed lists' rows, one workgroup per pair | top-k + ids + score window
+// the replay of a query of the exact scanners (IVFFLAT: P > 0, the slab in probe order; flat: P == 0, fixed_n rows in
+// vid order): the k-heap IS the result heap, score window and filters are already in the slab (sentinels)
+void flat_tie_args(H* h, gh::TieReplayArgs* tr, bool l2, int nq, int64_t q_stride, int P, int k, const float* d_x, float* cand_dis,
+                   int64_t* cand_ids, float* d_distances, int64_t* d_labels, int fixed_n = 0) {
+    tr->list = nullptr;
+    tr->count = nullptr;
+    tr->nq = nq;
+    tr->slab = h->w_dist.as<float>();
+    tr->q_stride = q_stride;
+    tr->pair_off = P > 0 ? h->w_pair_off.as<int>() : nullptr;
+    tr->pair_base = P > 0 ? h->w_pair_base.as<int64_t>() : nullptr;
+    tr->ids = h->d_ids;
+    tr->P = P;
+    tr->G = 1;
+    tr->ready = nullptr;
+    tr->surv = nullptr;
+    tr->gcnt = nullptr;
+    tr->nsl = 0;
+    tr->slice_cap = 0;
+    tr->x = d_x;
+    tr->d = h->d;
+    tr->raw = h->d_raw;
+    tr->nraw = h->nraw;
+    tr->R = k;
+    tr->k = k;
+    tr->has_rank = 0;
+    tr->min_score = -INFINITY;
+    tr->max_score = INFINITY;
+    tr->neutral = l2 ? 3.402823466e+38f : -3.402823466e+38f;
+    tr->cand_dis = cand_dis;
+    tr->cand_ids = cand_ids;
+    tr->distances = d_distances;
+    tr->labels = d_labels;
+    tr->pop_push = 1;
+    tr->fixed_n = fixed_n;
+}
+
 int ivfflat_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int nq, const float* d_x, int k,
                   float* d_distances, int64_t* d_labels) {
     const int P = p->nprobe, d = h->d, nlist = h->nlist;
@@ -835,7 +872,8 @@ int ivfflat_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     }
     gh::launch_small_coarse_select(s, h->w_mat.as<float>(), nlist, nq, P, h->w_coarse_dis.as<float>(), h->w_probe.as<int>(),
                                    h->d_list_len, h->d_list_mask, h->d_list_off, h->w_pair_off.as<int>(),
-                                   h->w_qtotal.as<int>(), h->w_pair_base.as<int64_t>());
+                                   h->w_qtotal.as<int>(), h->w_pair_base.as<int64_t>(), nullptr, nullptr, 0, nullptr, nullptr,
+                                   nullptr, 0, h->exact_ties ? 1 : 0, h->d_tie_stats);
     const int need_filter = (fc.any_clause || (h->d_bitmap && h->bitmap_any)) ? 1 : 0;
     gh::launch_ivfflat_scan(s, l2, d_x, nq, d, P, h->w_pair_off.as<int>(), h->w_pair_base.as<int64_t>(), h->d_ids, h->d_raw,
                             h->nraw, q_stride, h->w_dist.as<float>(), fc.d_tab, need_filter, p->min_score, p->max_score);
@@ -852,11 +890,17 @@ int ivfflat_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         }
     }
     const float neutral = l2 ? 3.402823466e+38f : -3.402823466e+38f;
+    // exact ties: a query with equal distances at the k cut or among its k results is replayed through the scanner's
+    // heap (heap_pop + heap_push per accepted entry, heap_reorder: gamma_index_ivfflat.h:52-75) inside the tail kernel
+    gh::TieReplayArgs tr;
+    const bool ties = h->exact_ties && k <= gh::tie_replay_max_k() && P <= gh::tie_replay_max_probes();
+    if (ties) flat_tie_args(h, &tr, l2, nq, q_stride, P, k, d_x, h->w_cand_dis.as<float>(), h->w_cand_ids.as<int64_t>(), d_distances,
+                            d_labels);
     gh::launch_small_tail(s, l2, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), nq, k, P, h->w_probe.as<int>(),
                           h->w_pair_off.as<int>(), h->d_list_off, h->d_ids, h->w_cand_dis.as<float>(),
                           h->w_cand_pos.as<int>(), h->w_cand_ids.as<int64_t>(), 0, d_x, d, h->d_raw, h->nraw, k, p->min_score,
                           p->max_score, neutral, d_distances, d_labels, smax, smax ? h->w_selv.as<float>() : nullptr,
-                          smax ? h->w_selp.as<int>() : nullptr);
+                          smax ? h->w_selp.as<int>() : nullptr, 0, ties ? &tr : nullptr, h->d_tie_stats);
     GH_CHECK(h, hipEventRecord(h->rd_ev[ver], s));
     h->rd_set[ver] = true;
     h->last_nq = nq;
@@ -869,6 +913,7 @@ int ivfflat_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
 int ivfflat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, int k,
                                  float* d_distances, int64_t* d_labels) {
     GH_TRY(check_params(h, p, nq, k));
+    TiesScope ties_scope(h, p);
     if (!h->ivf_init || !h->ivfflat) return fail(h, GAMMA_HIP_EINVAL, "ivfflat not initialised");
     if (!h->trained) return fail(h, GAMMA_HIP_ENOTTRAINED, "ivfflat not trained");
     if (p->nprobe <= 0 || p->nprobe > h->nlist) return fail(h, GAMMA_HIP_EINVAL, "nprobe out of range");
@@ -936,9 +981,32 @@ int ivfflat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq,
                                    h->w_cand_pos.as<int>());
             gh::launch_map_candidates(s, h->w_cand_pos.as<int>(), nc, k, P, h->w_probe.as<int>(), h->w_pair_off.as<int>(),
                                       h->d_list_off, h->d_ids, h->w_cand_ids.as<int64_t>());
+            const bool ties = h->exact_ties && k <= gh::tie_replay_max_k() && P <= gh::tie_replay_max_probes();
+            gh::TieFlags tf;
+            if (ties) {
+                // equal distances at the k cut or among the k selected: the scanner's heap decides (ties.hip)
+                GH_CHECK(h, h->w_tcut.ensure((size_t)nc));
+                GH_CHECK(h, h->w_tlist.ensure(((size_t)nc + 1) * sizeof(int)));
+                GH_CHECK(h, hipMemsetAsync(h->w_tlist.p, 0, sizeof(int), s));
+                GH_CHECK(h, hipMemsetAsync(h->w_tcut.p, 0, (size_t)nc, s));
+                gh::launch_flag_cut_ties(s, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), nc, k, h->w_cand_dis.as<float>(),
+                                         h->w_cand_pos.as<int>(), nullptr, h->w_tcut.as<uint8_t>(), 0, 1);
+                tf.cut = h->w_tcut.as<uint8_t>();
+                tf.count = h->w_tlist.as<int>();
+                tf.list = h->w_tlist.as<int>() + 1;
+                tf.stats = h->d_tie_stats;
+            }
             gh::launch_finalize_norank(s, h->w_cand_dis.as<float>(), h->w_cand_ids.as<int64_t>(), nc, k, k, p->min_score,
                                        p->max_score, neutral, d_distances + (size_t)q0 * k, d_labels + (size_t)q0 * k,
-                                       nullptr);
+                                       ties ? &tf : nullptr);
+            if (ties) {
+                gh::TieReplayArgs tr;
+                flat_tie_args(h, &tr, l2, nc, q_stride, P, k, xq, h->w_cand_dis.as<float>(), h->w_cand_ids.as<int64_t>(),
+                              d_distances + (size_t)q0 * k, d_labels + (size_t)q0 * k);
+                tr.list = tf.list;
+                tr.count = tf.count;
+                gh::launch_tie_replay(s, l2, tr);
+            }
         }
         GH_CHECK(h, hipEventRecord(h->rd_ev[ver], s));
         h->rd_set[ver] = true;
@@ -954,6 +1022,7 @@ int ivfflat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq,
 int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, int k,
                               float* d_distances, int64_t* d_labels) {
     GH_TRY(check_params(h, p, nq, k));
+    TiesScope ties_scope(h, p);
     if (!h->d_raw && h->nraw > 0) return fail(h, GAMMA_HIP_EINVAL, "raw store not initialised");
     if (h->raw_d <= 0) return fail(h, GAMMA_HIP_EINVAL, "raw store not initialised");
     if (k <= 0 || nq == 0) return GAMMA_HIP_OK;
@@ -984,10 +1053,20 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
                 GH_CHECK(h, h->w_selv.ensure((size_t)nq * smax * k * sizeof(float)));
                 GH_CHECK(h, h->w_selp.ensure((size_t)nq * smax * k * sizeof(int)));
             }
+            // exact ties: a query with equal distances at the k cut or among its k results is replayed through the
+            // reference's heap over the whole row (gamma_index_flat.cc:118-300: heap_pop + heap_push in vid order)
+            gh::TieReplayArgs tr;
+            const bool ties = h->exact_ties && k <= gh::tie_replay_max_k();
+            if (ties) {
+                flat_tie_args(h, &tr, l2, nq, stride, 0, k, d_x, h->w_cand_dis.as<float>(), h->w_cand_ids.as<int64_t>(), d_distances,
+                              d_labels, (int)N);
+                tr.d = d;
+            }
             gh::launch_small_tail(s, l2, h->w_dist.as<float>(), stride, nullptr, nq, k, 0, nullptr, nullptr, nullptr, nullptr,
                                   h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>(), h->w_cand_ids.as<int64_t>(), 0, d_x, d,
                                   h->d_raw, N, k, p->min_score, p->max_score, neutral, d_distances, d_labels, smax,
-                                  smax ? h->w_selv.as<float>() : nullptr, smax ? h->w_selp.as<int>() : nullptr, (int)N);
+                                  smax ? h->w_selv.as<float>() : nullptr, smax ? h->w_selp.as<int>() : nullptr, (int)N,
+                                  ties ? &tr : nullptr, h->d_tie_stats);
             GH_CHECK(h, hipGetLastError());
             return GAMMA_HIP_OK;
         }
@@ -997,6 +1076,13 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
     rows_chunk = (rows_chunk + 255) / 256 * 256;
     int qc = (int)std::max<int64_t>(1, std::min<int64_t>(nq, (int64_t)(h->dist_budget_bytes / (rows_chunk * sizeof(float)))));
     const int nchunks = (int)std::max<int64_t>(1, (N + rows_chunk - 1) / rows_chunk);
+    // exact ties: the paths below order results on (distance, row id); the reference's heap (heap_pop + heap_push in
+    // vid order, heap_reorder: gamma_index_flat.cc:118-300) orders equal distances its own way and decides which members
+    // of a tie at the cut stay.  Run for k + 1 results, list the queries with two equal distances among them and replay
+    // those through the heap over a freshly computed distance row (k_tie_replay).
+    const int k_out = k;
+    const bool ties = h->exact_ties && k + 1 <= gh::tie_replay_max_k() && N > 0 && N < ((int64_t)1 << 31);
+    if (ties) k = k + 1;
     GH_CHECK(h, h->w_dist.ensure((size_t)qc * rows_chunk * sizeof(float)));
     GH_CHECK(h, h->w_part_v.ensure((size_t)qc * nchunks * k * sizeof(float)));
     GH_CHECK(h, h->w_part_i.ensure((size_t)qc * nchunks * k * sizeof(int64_t)));
@@ -1004,6 +1090,15 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
     GH_CHECK(h, h->w_selp.ensure((size_t)qc * k * sizeof(int)));
     GH_CHECK(h, h->w_cand_pos.ensure((size_t)qc * k * sizeof(int)));
     GH_CHECK(h, h->w_cand_dis.ensure((size_t)qc * k * sizeof(float)));
+    if (ties) {
+        GH_CHECK(h, h->w_fD.ensure((size_t)qc * k * sizeof(float)));
+        GH_CHECK(h, h->w_fI.ensure((size_t)qc * k * sizeof(int64_t)));
+        GH_CHECK(h, h->w_tlist.ensure(((size_t)qc + 1) * sizeof(int)));
+        GH_CHECK(h, h->w_cand_ids.ensure((size_t)qc * k * sizeof(int64_t)));
+    }
+    // where the paths write their [nc][k] result of query chunk q0
+    auto outD = [&](int q0) { return ties ? h->w_fD.as<float>() : d_distances + (size_t)q0 * k; };
+    auto outI = [&](int q0) { return ties ? h->w_fI.as<int64_t>() : d_labels + (size_t)q0 * k; };
     StageScope t(h, GAMMA_HIP_STAGE_FLAT);
     // the reference's loop: every row, one query at a time, a k-heap (gamma_index_flat.cc:118-300).
     // Here: distance slab of one row chunk -> per-chunk top-k -> merge of the chunks' tables.
@@ -1034,7 +1129,7 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
                                nchunks * k, nc, k, h->w_selv.as<float>(), h->w_selp.as<int>());
         gh::launch_finalize_topk(s, h->w_selv.as<float>(), h->w_selp.as<int>(), nc, k,
                                  h->w_m_ids.as<int64_t>(), (int64_t)nchunks * k, 0, neutral,
-                                 d_distances + (size_t)q0 * k, d_labels + (size_t)q0 * k);
+                                 outD(q0), outI(q0));
         return GAMMA_HIP_OK;
     };
     // Running bound: only the first chunk goes through a distance slab.  Its k-th best bounds the
@@ -1064,7 +1159,7 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
             gh::launch_flat_compact(s, nc, k, em, tau, over);
             r += nr;
         }
-        gh::launch_flat_final(s, l2, nc, k, em, neutral, d_distances + (size_t)q0 * k, d_labels + (size_t)q0 * k);
+        gh::launch_flat_final(s, l2, nc, k, em, neutral, outD(q0), outI(q0));
         GH_CHECK(h, hipGetLastError());
         int h_over = 0;
         GH_CHECK(h, hipMemcpyAsync(&h_over, over, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1078,7 +1173,7 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
             // nothing to scan: all-empty result
             GH_CHECK(h, hipMemsetAsync(h->w_selp.p, 0xff, (size_t)nc * k * sizeof(int), s));
             gh::launch_finalize_topk(s, h->w_selv.as<float>(), h->w_selp.as<int>(), nc, k, nullptr, 0, 0,
-                                     neutral, d_distances + (size_t)q0 * k, d_labels + (size_t)q0 * k);
+                                     neutral, outD(q0), outI(q0));
             continue;
         }
         bool redo = true;
@@ -1086,6 +1181,35 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
             gh::pairwise_can_emit(nc, d, N - rows_chunk))
             GH_TRY(bounded(q0, nc, &redo));
         if (redo) GH_TRY(unbounded(q0, nc));
+        if (ties) {
+            int* count = h->w_tlist.as<int>();
+            int* list = count + 1;
+            GH_CHECK(h, hipMemsetAsync(count, 0, sizeof(int), s));
+            gh::launch_flat_take_flag(s, h->w_fD.as<float>(), h->w_fI.as<int64_t>(), nc, k_out, d_distances + (size_t)q0 * k_out,
+                                      d_labels + (size_t)q0 * k_out, list, count, h->d_tie_stats);
+            int nflag = 0;
+            GH_CHECK(h, hipMemcpyAsync(&nflag, count, sizeof(int), hipMemcpyDeviceToHost, s));
+            GH_CHECK(h, hipStreamSynchronize(s));
+            const int64_t stride = (N + 3) & ~(int64_t)3;
+            const int fcap = (int)std::max<int64_t>(1, std::min<int64_t>(64, (int64_t)(h->dist_budget_bytes / ((size_t)stride * sizeof(float)))));
+            for (int f0 = 0; f0 < nflag; f0 += fcap) {
+                const int nf = std::min(fcap, nflag - f0);
+                GH_CHECK(h, h->w_fx.ensure((size_t)nf * d * sizeof(float)));
+                GH_CHECK(h, h->w_fslab.ensure((size_t)nf * stride * sizeof(float)));
+                gh::launch_gather_rows(s, d_x + (size_t)q0 * d, list + f0, nf, d, h->w_fx.as<float>());
+                gh::launch_pairwise_filtered(s, l2, h->w_fx.as<float>(), nf, d, h->d_raw, N, h->w_fslab.as<float>(), stride, filt,
+                                             p->min_score, p->max_score, 0);
+                gh::TieReplayArgs tr;
+                flat_tie_args(h, &tr, l2, nf, stride, 0, k_out, d_x + (size_t)q0 * d, h->w_cand_dis.as<float>(),
+                              h->w_cand_ids.as<int64_t>(), d_distances + (size_t)q0 * k_out, d_labels + (size_t)q0 * k_out, (int)N);
+                tr.slab = h->w_fslab.as<float>();
+                tr.d = d;
+                tr.list = list + f0;
+                tr.count = count;       // >= f0 + nf
+                tr.compact_rows = 1;
+                gh::launch_tie_replay(s, l2, tr);
+            }
+        }
     }
     GH_CHECK(h, hipGetLastError());
     return GAMMA_HIP_OK;

@@ -426,10 +426,13 @@ int gamma_hip_raw_init(gamma_hip_index* h, int d) {
         void* va = nullptr;
         if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran > 0 &&
             hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) {
-            const size_t want = (total_b + gran - 1) / gran * gran;
+            const size_t chunk = std::max<size_t>(gran, (size_t)64 << 20) / gran * gran;
+            const size_t want = (total_b + chunk - 1) / chunk * chunk;
             if (hipMemAddressReserve(&va, want, 0, nullptr, 0) == hipSuccess && va) {
                 h->raw_vmm = true;
-                h->raw_gran = gran;
+                // chunks of whole 64 MB: hipMemSetAccess refuses chunk sizes that are only a multiple of the reported
+                // 4 KB granularity (tools/exp/vmm_probe.cpp)
+                h->raw_gran = chunk;
                 h->raw_va_bytes = want;
                 h->d_raw = static_cast<float*>(va);
             }
@@ -443,13 +446,12 @@ int gamma_hip_raw_init(gamma_hip_index* h, int d) {
 static int raw_reserve(H* h, int64_t need) {
     if (need <= h->raw_cap) return GAMMA_HIP_OK;
     if (h->raw_vmm) {
-        // map more physical memory behind the rows in place: nothing moves, searches in flight go on reading
+        // map more physical memory behind the rows in place: nothing moves
         const size_t row = (size_t)h->raw_d * sizeof(float);
         const size_t need_b = (size_t)need * row;
         // at least 1/8 more than what is mapped (fewer, larger chunks), in whole granules
         size_t add = std::max(need_b - h->raw_mapped, h->raw_mapped / 8);
-        add = std::max<size_t>(add, (size_t)64 << 20);
-        add = (add + h->raw_gran - 1) / h->raw_gran * h->raw_gran;
+        add = (add + h->raw_gran - 1) / h->raw_gran * h->raw_gran;   // whole 64 MB chunks (raw_init)
         if (h->raw_mapped + add > h->raw_va_bytes) add = h->raw_va_bytes - h->raw_mapped;
         if (h->raw_mapped + add < need_b) return fail(h, GAMMA_HIP_ENOMEM, "raw store: beyond the reserved address range");
         hipMemAllocationProp prop = {};
@@ -466,10 +468,24 @@ static int raw_reserve(H* h, int64_t need) {
         acc.location.type = hipMemLocationTypeDevice;
         acc.location.id = h->device;
         acc.flags = hipMemAccessFlagsProtReadWrite;
-        if (hipMemMap(at, add, 0, hnd, 0) != hipSuccess || hipMemSetAccess(at, add, &acc, 1) != hipSuccess) {
+        // beside the kernels of the searches in flight: page-table updates of a range they do not read yet
+        // (tools/exp/vmm_probe.cpp: mapping beside kernels on the range and beside a thread allocating and launching)
+        hipError_t e = hipMemMap(at, add, 0, hnd, 0);
+        const char* what = "hipMemMap";
+        if (e == hipSuccess) {
+            e = hipMemSetAccess(at, add, &acc, 1);
+            what = "hipMemSetAccess";
+            if (e != hipSuccess) {   // seen for chunks that are not a multiple of 2 MB: the whole mapped range is accepted
+                (void)hipGetLastError();
+                e = hipMemSetAccess(h->d_raw, h->raw_mapped + add, &acc, 1);
+            }
+            if (e != hipSuccess) (void)hipMemUnmap(at, add);
+        }
+        if (e != hipSuccess) {
             (void)hipGetLastError();
             (void)hipMemRelease(hnd);
-            return fail(h, GAMMA_HIP_EDEVICE, "raw store: mapping failed");
+            h->err = std::string("raw store: ") + what + " failed: " + hipGetErrorString(e);
+            return GAMMA_HIP_EDEVICE;
         }
         h->raw_chunks.push_back(hnd);
         h->raw_chunk_bytes.push_back(add);

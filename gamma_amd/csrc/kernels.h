@@ -260,6 +260,10 @@ struct TieReplayArgs {
     float* distances;             // [nq][k]
     int64_t* labels;
     unsigned long long* dbg = nullptr;   // phase clocks of the first replayed query (GAMMA_HIP_TIE_DBG)
+    int pop_push = 0;             // the heap takes a candidate with heap_pop + heap_push (IVFFLAT / flat scanners) instead
+                                  // of heap_replace_top (the IVFPQ scanner)
+    int fixed_n = 0;              // pair_off == nullptr (flat): every row has fixed_n entries, a position IS the vector id
+    int compact_rows = 0;         // slab row i belongs to the i-th flagged query (list[i]) instead of query i
 };
 int tie_replay_max_k();
 int tie_replay_max_probes();
@@ -270,6 +274,12 @@ void launch_flag_cut_ties(hipStream_t s, const float* slab, int64_t q_stride, co
                                                               // equal values among the selected K
 int coarse_heap_max_k();
 size_t tie_replay_lds_bytes(int R, int k, int P);
+// flat search under exact ties: the chunked paths run for k + 1 results; this copies the first k to the caller's rows and
+// lists the queries with two equal distances among the k + 1 (their order, or which of them stays, is the heap's)
+void launch_flat_take_flag(hipStream_t s, const float* D1, const int64_t* I1, int nq, int k, float* distances, int64_t* labels,
+                           int* list, int* count, unsigned long long* tie_stats);
+// out[i] = x[list[i]] for i < n (rows of d floats)
+void launch_gather_rows(hipStream_t s, const float* x, const int* list, int n, int d, float* out);
 void launch_finalize_topk(hipStream_t s, const float* sel_vals, const int* sel_pos, int nq, int k,
                           const int64_t* src_ids, int64_t src_stride, int64_t id_base,
                           float neutral, float* distances, int64_t* labels);

@@ -1970,7 +1970,7 @@ __global__ __launch_bounds__(SM_NT) void k_small_tail(const float* __restrict__ 
                 for (int r0 = 0; r0 < R; r0 += SM_NT)
                     in_sel += __syncthreads_count(r0 + tid < R && (uint32_t)(s_it[min(r0 + tid, R - 1)] >> 32) == vk);
                 const float* v0 = slab + (int64_t)q * q_stride;
-                const int n0 = q_total[q];
+                const int n0 = q_total ? q_total[q] : fixed_n;
                 int loc = 0, in_all;
                 for (int i = tid; i < n0; i += SM_NT) loc += sel_key<L2>(v0[i]) == vk ? 1 : 0;
                 (void)block_excl_scan_sm(min(loc, 2048), s_w, in_all);
@@ -2097,7 +2097,7 @@ void launch_small_tail(hipStream_t s, bool l2, const float* slab, int64_t q_stri
                        const TieReplayArgs* tr, unsigned long long* tie_stats) {
     if (nq <= 0) return;
     if (R > 1024) abort();   // callers gate on this
-    const int exact_ties = tr != nullptr && pair_off != nullptr ? 1 : 0;
+    const int exact_ties = tr != nullptr ? 1 : 0;
     const TieReplayArgs tra = exact_ties ? *tr : TieReplayArgs{};
     const size_t lds = exact_ties ? tie_replay_lds_bytes_(R, k, P, 2048) : 0;
     if (exact_ties) {   // static + dynamic LDS go beyond the default 64 KB for large recall_num

@@ -58,15 +58,18 @@ __device__ __forceinline__ TieLds tie_carve(char* p, int R, int k, int P, int sl
 // One query, replayed the way the reference runs it.  Called by all NT threads of a workgroup (NT a multiple
 // of 64, <= 1024); `lds` = tie_replay_lds_bytes_(R, k, P, SLAB) bytes, 16-byte aligned, free for this call.
 template <bool L2, int NT, int SLAB = TR_SLAB>
-__device__ __forceinline__ void tie_replay_query(const TieReplayArgs& a, int q, char* lds, unsigned long long* dbg) {
+__device__ __forceinline__ void tie_replay_query(const TieReplayArgs& a, int q, char* lds, unsigned long long* dbg,
+                                                 int slab_row = -1) {
 #define GH_TT(i) do { if (dbg && threadIdx.x == 0) dbg[i] = wall_clock64(); } while (0)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int R = a.R, k = a.k, P = a.P;
     const TieLds L = tie_carve(lds, R, k, P, SLAB);
     __syncthreads();   // the LDS is free
     GH_TT(0);
-    for (int i = tid; i <= P; i += NT) L.off[i] = a.pair_off[(int64_t)q * (P + 1) + i];
-    for (int i = tid; i < P; i += NT) L.base[i] = a.pair_base[(int64_t)q * P + i];
+    if (a.pair_off) {
+        for (int i = tid; i <= P; i += NT) L.off[i] = a.pair_off[(int64_t)q * (P + 1) + i];
+        for (int i = tid; i < P; i += NT) L.base[i] = a.pair_base[(int64_t)q * P + i];
+    }
     heap_fill(L.hR, R, tid, NT);   // heap_heapify: (neutral, -1)
     if (a.has_rank) heap_fill(L.hK, k, tid, NT);
     __syncthreads();
@@ -79,9 +82,9 @@ __device__ __forceinline__ void tie_replay_query(const TieReplayArgs& a, int q, 
         for (int s = 0; s < a.nsl && sliced; s++)
             if (a.gcnt[(int64_t)q * a.nsl + s] > a.slice_cap) sliced = false;   // uniform
     }
-    const int ntot = L.off[P];
+    const int ntot = a.pair_off ? L.off[P] : a.fixed_n;
     const int n_slab = sliced ? L.off[min(a.G, P)] : ntot;
-    const float* slab = a.slab + (int64_t)q * a.q_stride;
+    const float* slab = a.slab + (int64_t)(slab_row >= 0 ? slab_row : q) * a.q_stride;
     const bool staged = n_slab <= SLAB;
     if (staged) {
         for (int j = tid; j < n_slab; j += NT) L.slab[j] = L2 ? slab[j] : -slab[j];   // filtered entries: +inf
@@ -90,7 +93,40 @@ __device__ __forceinline__ void tie_replay_query(const TieReplayArgs& a, int q, 
     GH_TT(1);
     HeapWalk w;
     w.begin(L.hR, R);
-    if (wv == 0) {
+    if (wv == 0 && a.pop_push) {
+        // IVFFLAT / flat scanners: `if (C::cmp(simi[0], dis)) { heap_pop; heap_push }` (gamma_index_ivfflat.h:52-75,
+        // gamma_index_flat.cc:118-300) -- one candidate at a time, 64 compared with the top per step
+        float top = kHeapFltMax;
+        auto feed = [&](bool valid, float dv, int j0) {
+            if (!valid) dv = INFINITY;
+            unsigned long long m = __ballot(top > dv);
+            while (m) {
+                const int l = (int)__ffsll((long long)m) - 1;
+                const float val = hw_readlane_f(dv, l);
+                heap_pop_seq(L.hR, R);
+                heap_push_seq(L.hR, R, val, (unsigned)(j0 + l));
+                top = hs_f(L.hR[1].x);
+                const unsigned long long above = l >= 63 ? 0ull : (~0ull << (l + 1));
+                m = __ballot(top > dv) & above;
+            }
+        };
+        if (staged) {
+            for (int j0 = 0; j0 < n_slab; j0 += 64) feed(j0 + lane < n_slab, L.slab[min(j0 + lane, n_slab - 1)], j0);
+        } else {
+            float t[8], tn[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) t[u] = slab[min(u * 64 + lane, n_slab - 1)];
+            for (int j0 = 0; j0 < n_slab; j0 += 512) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) tn[u] = slab[min(j0 + 512 + u * 64 + lane, n_slab - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (j0 + u * 64 < n_slab) feed(j0 + u * 64 + lane < n_slab, L2 ? t[u] : -t[u], j0 + u * 64);
+#pragma unroll
+                for (int u = 0; u < 8; u++) t[u] = tn[u];
+            }
+        }
+    } else if (wv == 0) {
         if (staged) {
             for (int j0 = 0; j0 < n_slab; j0 += 64) {
                 const int j = j0 + lane;
@@ -145,12 +181,13 @@ __device__ __forceinline__ void tie_replay_query(const TieReplayArgs& a, int q, 
             s = s_end;
         }
     }
-    if (wv == 0) w.drain();
+    if (wv == 0 && !a.pop_push) w.drain();
     __syncthreads();
     GH_TT(3);
     // ---- the R-heap is final: array order in hR[1..R].  Positions -> vector ids. ----
     auto pos_to_id = [&](int ps) -> int64_t {
         if (ps < 0) return -1;
+        if (!a.pair_off) return ps;
         int lo = 0, hi = P - 1;
         while (lo < hi) {   // last p with off[p] <= ps
             const int mid = (lo + hi + 1) >> 1;

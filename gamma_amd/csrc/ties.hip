@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_tie_replay(TieReplayArgs a) {
     extern __shared__ __attribute__((aligned(16))) char s_tie_lds[];
     const int nflag = min(*a.count, a.nq);
     for (int fi = blockIdx.x; fi < nflag; fi += gridDim.x)
-        tie_replay_query<L2, 256>(a, a.list[fi], s_tie_lds, (a.dbg && fi == 0) ? a.dbg : nullptr);
+        tie_replay_query<L2, 256>(a, a.list[fi], s_tie_lds, (a.dbg && fi == 0) ? a.dbg : nullptr, a.compact_rows ? fi : -1);
 }
 
 void launch_tie_replay(hipStream_t s, bool l2, const TieReplayArgs& a0) {
@@ -126,6 +126,45 @@ void launch_flag_cut_ties(hipStream_t s, const float* slab, int64_t q_stride, co
     if (nq <= 0) return;
     hipLaunchKernelGGL(k_flag_cut_ties, dim3((nq + 3) / 4), dim3(256), 0, s, slab, q_stride, q_total, nq, K,
                        sel_vals, sel_pos, only, tflag, fixed_n, inside);
+}
+
+// ------------------------------------------------------------------------------------
+// flat search, chunked paths under exact ties (gamma_hip_search.cpp): D1/I1 [nq][k + 1] sorted on (distance, row id).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_flat_take_flag(const float* __restrict__ D1, const int64_t* __restrict__ I1, int nq,
+                                                        int k, float* __restrict__ distances, int64_t* __restrict__ labels,
+                                                        int* __restrict__ list, int* __restrict__ count,
+                                                        unsigned long long* __restrict__ tie_stats) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const float* dv = D1 + (int64_t)q * (k + 1);
+    const int64_t* iv = I1 + (int64_t)q * (k + 1);
+    bool eq = false;
+    for (int i = lane; i < k; i += 64) {
+        distances[(int64_t)q * k + i] = dv[i];
+        labels[(int64_t)q * k + i] = iv[i];
+        eq |= iv[i] >= 0 && iv[i + 1] >= 0 && dv[i] == dv[i + 1];
+    }
+    if (__ballot(eq) && lane == 0) {
+        list[atomicAdd(count, 1)] = q;
+        if (tie_stats) atomicAdd(tie_stats + 2, 1ull);
+    }
+}
+void launch_flat_take_flag(hipStream_t s, const float* D1, const int64_t* I1, int nq, int k, float* distances, int64_t* labels,
+                           int* list, int* count, unsigned long long* tie_stats) {
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(k_flat_take_flag, dim3((nq + 3) / 4), dim3(256), 0, s, D1, I1, nq, k, distances, labels, list, count,
+                       tie_stats);
+}
+
+__global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ x, const int* __restrict__ list, int d,
+                                                     float* __restrict__ out) {
+    const int64_t src = list[blockIdx.x];
+    for (int j = threadIdx.x; j < d; j += 256) out[(int64_t)blockIdx.x * d + j] = x[src * d + j];
+}
+void launch_gather_rows(hipStream_t s, const float* x, const int* list, int n, int d, float* out) {
+    if (n > 0) hipLaunchKernelGGL(k_gather_rows, dim3(n), dim3(256), 0, s, x, list, d, out);
 }
 
 }  // namespace gh

@@ -83,6 +83,14 @@ int HIPIVFPQModelParams::Parse(const char *str) {
     if (v < 0) return -1;
     devices.assign(1, v);
   }
+  std::string plc;
+  if (!jp.GetString("placement", plc)) {   // several devices: "shard" (by IVF list, the default) | "replicate"
+    if (strcasecmp("shard", plc.c_str()) && strcasecmp("replicate", plc.c_str())) {
+      HLOG("invalid placement = %s", plc.c_str());
+      return -1;
+    }
+    replicate = !strcasecmp("replicate", plc.c_str());
+  }
   if (!jp.GetInt("bucket_init_size", v)) {
     if (v < -1) return -1;
     if (v > 0) bucket_init_size = v;
@@ -116,9 +124,10 @@ GammaIVFPQHIPIndex::~GammaIVFPQHIPIndex() {
 
 // one handle, or a group of handles with the lists sharded by owner (gamma_hip_group_*; what the reference's GPU model
 // does with IndexShards, index/impl/gpu/gamma_gpu_cloner.cpp:200-269)
-int GammaIVFPQHIPIndex::OpenDevices(const std::vector<int> &devices) {
+int GammaIVFPQHIPIndex::OpenDevices(const std::vector<int> &devices, bool replicate) {
   if (devices.size() > 1) {
     int rc = gamma_hip_group_create(devices.data(), (int)devices.size(), &grp_);
+    if (!rc) rc = gamma_hip_group_set_placement(grp_, replicate ? 1 : 0);
     if (rc) {
       HLOG("gamma_hip_group_create failed: %s", gamma_hip_strerror(rc));
       return -1;
@@ -165,7 +174,7 @@ int GammaIVFPQHIPIndex::Init(const std::string &model_parameters, int indexing_s
     HLOG("device_filters with several devices is not supported (the columns live on one handle)");
     return -2;
   }
-  if (OpenDevices(pa.devices)) return -1;
+  if (OpenDevices(pa.devices, pa.replicate)) return -1;
   int rc = ForAll([&](gamma_hip_index *m) {
     int r = gamma_hip_ivfpq_init(m, d_, nlist_, M_, 8,
                                  metric_type_ == DistanceComputeType::L2 ? GAMMA_HIP_METRIC_L2 : GAMMA_HIP_METRIC_IP,

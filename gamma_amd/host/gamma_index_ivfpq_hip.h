@@ -57,6 +57,8 @@ struct HIPIVFPQModelParams {
   bool perf_stages = false;      // HIP only: per-stage device times in the request's PerfTool (stage events on every search)
   std::vector<int> devices;      // HIP only: "devices": "0,1,2,3" -- the index sharded by IVF list over these GPUs in this
                                  // process (gamma_hip_group_*); empty: one GPU, GAMMA_HIP_DEVICE or 0
+  bool replicate = false;        // HIP only: "placement": "replicate" -- every device holds every list, a search splits
+                                 // the queries (results of one GPU bit for bit); "shard" (default): by IVF list
   int Parse(const char *str);   // 0 ok, -1 bad (same rules as gamma_index_ivfpq.h:708-851)
 };
 
@@ -107,7 +109,7 @@ class GammaIVFPQHIPIndex : public RetrievalModel {
     }
     return 0;
   }
-  int OpenDevices(const std::vector<int> &devices);
+  int OpenDevices(const std::vector<int> &devices, bool replicate = false);
   void PerfLabels(GammaSearchCondition *cond);
   std::mutex perf_mu_;
   double perf_ms_[GAMMA_HIP_NUM_STAGES] = {0};

@@ -380,6 +380,14 @@ const char* gamma_hip_group_last_error(gamma_hip_group* g);
  * dump) are balanced greedily, heaviest list first -- probe popularity follows list size, so this balances scan
  * bytes; NULL: l mod n.  Call once, after gamma_hip_ivfpq_init on every member and before the first Add. */
 int gamma_hip_group_set_owners(gamma_hip_group* g, const int64_t* weights);
+/* Placement, before gamma_hip_group_set_owners.  0 (default): sharded by list as above.  1: REPLICATED -- every member
+ * holds every list (Add / AddKeys / Update / Delete go to all members, one encode), a search splits the QUERIES: member
+ * i answers its slice with the ordinary single-handle search, so results are those of one handle bit for bit (exact
+ * ties included) and nothing is exchanged but the slice and its k results.  The choice for an index that is small next
+ * to one GPU's memory: list sharding leaves the per-query fixed work (table, bound, selection) on every member for
+ * every query, replicas divide it (multi-GPU).  The per-list getters read member 0. */
+int gamma_hip_group_set_placement(gamma_hip_group* g, int replicate);
+int gamma_hip_group_placement(const gamma_hip_group* g);
 int gamma_hip_group_owner(const gamma_hip_group* g, int list_no);
 /* GammaIVFPQIndex::Add: ONE encode (members take turns), then AddKeys at the owner of every assigned list */
 int gamma_hip_group_ivfpq_add(gamma_hip_group* g, int64_t n, const float* vecs, int64_t first_vid);

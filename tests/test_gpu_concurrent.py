@@ -132,10 +132,12 @@ def test_raw_store_grows_in_place_under_search():
 
         t = threading.Thread(target=searcher)
         t.start()
-        for b in range(1, nb):
-            g.raw_append(blocks[b % 4] + np.float32(1000.0 * b))   # far from the queries
-        stop.set()
-        t.join()
+        try:
+            for b in range(1, nb):
+                g.raw_append(blocks[b % 4] + np.float32(1000.0 * b))   # far from the queries
+        finally:
+            stop.set()
+            t.join()
         st = g.raw_stats()
         assert st["rows"] == rows_per * nb and not bad and calls[0] > 0
         if st["in_place"]:

@@ -204,3 +204,77 @@ def test_plugin_devices_key(case):
     finally:
         for m in ms:
             m.close()
+
+
+def test_replicated_group_is_the_single_handle_bit_for_bit(case):
+    """gamma_hip_group_set_placement(1): every member holds every list, a search splits the queries -- labels and
+    distances are those of ONE handle strictly (compare_exact: no tie tolerance), before and after batched Update and
+    Delete; the plugin's `"placement": "replicate"` key is the same thing behind the RetrievalModel boundary."""
+    from gamma_amd import plugin
+    from tests.parity import compare_exact
+    full = _single(case)
+    grp = api.GammaHipGroup([0] * 3)
+    try:
+        grp.set_placement(True)
+        for m in grp.members:
+            m.ivfpq_init(case["d"], case["nlist"], case["M"], 8, api.METRIC_L2, 1000)
+            m.ivfpq_set_trained(case["cc"], case["pq"], None)
+            m.raw_init(case["d"])
+            m.raw_append(case["base"])
+        grp.set_owners(None)
+        for i0 in range(0, len(case["base"]), 5000):
+            grp.add(case["base"][i0:i0 + 5000], i0)
+        _same_lists(case, grp, full)
+        for m in grp.members:
+            for l in (0, 17, case["nlist"] - 1):
+                assert m.list_size(l) == full.list_size(l)
+
+        def check():
+            for nq in (1, 2, 7, 64, 700):
+                q = synth.sift_like(nq, d=case["d"], seed=177 + nq)
+                for metric, has_rank, P, R, k in ((api.METRIC_L2, True, 8, 100, 10), (api.METRIC_IP, True, 16, 64, 5),
+                                                  (api.METRIC_L2, False, 12, 50, 10)):
+                    a = api.SearchArgs(metric=metric, nprobe=P, recall_num=R, has_rank=has_rank, **WIDE)
+                    D, I = full.ivfpq_search(q, k, a)
+                    Dg, Ig = grp.ivfpq_search(q, k, a)
+                    compare_exact(D, I, Dg, Ig)
+        check()
+        rng = np.random.default_rng(12)
+        vids = rng.choice(len(case["base"]), size=300, replace=False).astype(np.int64)
+        vecs = case["base"][rng.integers(0, len(case["base"]), size=300)].copy()
+        dead = rng.choice(len(case["base"]), size=1500, replace=False).astype(np.int64)
+        full.update_batch(vids, vecs)
+        grp.update(vids, vecs)
+        full.delete(dead)
+        grp.delete(dead)
+        b2 = case["base"].copy()
+        b2[vids] = vecs
+        for g in [full] + grp.members:
+            for v, x in zip(vids, vecs):
+                g.raw_update(int(v), x)
+        _same_lists(case, grp, full)
+        check()
+    finally:
+        grp.close()
+        full.close()
+    model = '{"ncentroids": %d, "nsubvector": %d, "nprobe": 8, "metric_type": "L2"%s}'
+    ms = [plugin.PluginModel("HIPIVFPQ", case["d"], model % (case["nlist"], case["M"], extra), indexing_size=5000)
+          for extra in ("", ', "devices": "0,0,0", "placement": "replicate"')]
+    try:
+        for m in ms:
+            m.store(case["base"])
+            assert m.indexing() == 0
+            for i0 in range(0, len(case["base"]), 5000):
+                assert m.add(case["base"][i0:i0 + 5000])
+        req = '{"metric_type": "L2", "recall_num": 100, "nprobe": 8}'
+        for n in (len(case["q"]), 5, 1):
+            D, I = ms[0].search(case["q"][:n], 10, req)
+            Dg, Ig = ms[1].search(case["q"][:n], 10, req)
+            compare_exact(D, I, Dg, Ig)
+    finally:
+        for m in ms:
+            m.close()
+    # Parse rejects an unknown placement
+    with pytest.raises(Exception):
+        plugin.PluginModel("HIPIVFPQ", case["d"], model % (case["nlist"], case["M"], ', "devices": "0,0", "placement": "x"'),
+                           indexing_size=5000)

@@ -188,3 +188,111 @@ def test_c4_shape_ties_at_batch_size(tag):
             assert ts["coarse_rows"] > 0 and ts["replayed"] > 0
     finally:
         g.close()
+
+
+def _ivfflat_for(z, tag, base, metric):
+    g = api.GammaHip(0)
+    g.ivfflat_init(int(z["d"]), int(z["nlist"]), metric, 1000)
+    g.ivfflat_set_trained(z["cc_" + tag])
+    sizes = z["list_sizes_" + tag]
+    nz = np.nonzero(sizes)[0]
+    g.add_keys_batch(nz, sizes[nz], z["list_ids_" + tag], np.zeros((len(z["list_ids_" + tag]), 1), np.uint8))
+    g.raw_init(int(z["d"]))
+    g.raw_append(base)
+    return g
+
+
+@pytest.mark.parametrize("tag", ["l2", "ip"])
+def test_ivfflat_exact_ties(tag):
+    """IVFFLAT on the tie-heavy data (every base vector four times): the scanner's k-heap takes an entry with
+    heap_pop + heap_push (gamma_index_ivfflat.h:52-75) and heap_reorder orders the result -- labels strictly the
+    oracle's at every rank, through the small-batch chain (replay inside k_small_tail), the pair kernel and the
+    list-major kernel (k_flag_cut_ties + k_tie_replay), with deletes, a range filter and a score window."""
+    z, o, base, metric = load_ties(tag)
+    g = _ivfflat_for(z, tag, base, metric)
+    N = len(base)
+    rng = np.random.default_rng(5)
+    try:
+        for step in range(2):
+            ctx_kw, kw_f = {}, {}
+            if step == 1:
+                dead = rng.choice(N, N // 9, replace=False)
+                bm = np.zeros((N >> 3) + 1, dtype=np.uint8)
+                np.bitwise_or.at(bm, dead >> 3, (1 << (dead & 7)).astype(np.uint8))
+                g.bitmap_upload(bm, N)
+                docs = rng.choice(N, 2 * N // 3, replace=False)
+                ctx_kw = dict(docids_bitmap=bm, range_filters=[B.make_range_filter(docs)])
+                kw_f = dict(range_filters=[api.make_range_filter(docs)])
+            for q, reps in ((z["q"][:4], 1), (z["q"][:5], 1), (z["q"], 1), (z["q"], 30)):
+                for P, k in ((6, 10), (3, 40), (16, 100), (1, 3)):
+                    wins = [WIDE]
+                    Dw, _ = B.ivfflat_search(o, q, k, P, metric, B.make_ctx(**WIDE, **ctx_kw), coarse_mode=0)
+                    fin = Dw[np.abs(Dw) < 1e37]
+                    if len(fin) > 4 and reps == 1:
+                        wins.append(dict(min_score=float(np.quantile(fin, 0.3)), max_score=float(np.quantile(fin, 0.9))))
+                    for win in wins:
+                        D, I = B.ivfflat_search(o, q, k, P, metric, B.make_ctx(**win, **ctx_kw), coarse_mode=0)
+                        args = api.SearchArgs(metric=metric, nprobe=P, coarse_mode=0, **win, **kw_f)
+                        g.tie_stats(reset=True)
+                        Dg, Ig = g.ivfflat_search(np.tile(q, (reps, 1)), k, args)
+                        compare_exact(np.tile(D, (reps, 1)), np.tile(I, (reps, 1)), Dg, Ig)
+                        if k > 3:
+                            assert g.tie_stats()["replayed"] > 0
+        # the data needs it: with the mode off for the request only the distances agree
+        args = api.SearchArgs(metric=metric, nprobe=6, coarse_mode=0, exact_ties=-1, **WIDE, **kw_f)
+        D, I = B.ivfflat_search(o, z["q"], 10, 6, metric, B.make_ctx(**WIDE, **ctx_kw), coarse_mode=0)
+        Dg, Ig = g.ivfflat_search(z["q"], 10, args)
+        assert Dg.tobytes() == D.tobytes() and not np.array_equal(Ig, I)
+    finally:
+        g.close()
+
+
+@pytest.mark.parametrize("tag", ["l2", "ip"])
+def test_flat_exact_ties(tag):
+    """GammaFLATIndex::Search on tie-heavy data (gamma_index_flat.cc:118-300: rows in vid order through heap_pop +
+    heap_push, heap_reorder): labels strictly the oracle's -- the small-batch chain (replay inside k_small_tail), the
+    slab path (one row chunk) and the running-bound path over several row chunks (both run for k + 1 results, queries
+    with equal distances among them replayed over a recomputed distance row)."""
+    z, _, base, metric = load_ties(tag)
+    d = int(z["d"])
+    rng = np.random.default_rng(11)
+    for mult in (1, 12):     # 6 000 rows: one chunk; 72 000 rows: the running bound, two row chunks
+        b = np.ascontiguousarray(np.tile(base, (mult, 1)))
+        if mult > 1:
+            b = np.ascontiguousarray(b[rng.permutation(len(b))])
+        N = len(b)
+        g = api.GammaHip(0)
+        g.raw_init(d)
+        g.raw_append(b)
+        try:
+            for step in range(2):
+                ctx_kw, kw_f = {}, {}
+                if step == 1:
+                    dead = rng.choice(N, N // 9, replace=False)
+                    bm = np.zeros((N >> 3) + 1, dtype=np.uint8)
+                    np.bitwise_or.at(bm, dead >> 3, (1 << (dead & 7)).astype(np.uint8))
+                    g.bitmap_upload(bm, N)
+                    docs = rng.choice(N, 2 * N // 3, replace=False)
+                    ctx_kw = dict(docids_bitmap=bm, range_filters=[B.make_range_filter(docs)])
+                    kw_f = dict(range_filters=[api.make_range_filter(docs)])
+                for q, reps in ((z["q"][:3], 1), (z["q"], 1), (z["q"], 3)):     # 144 queries: past the small-batch chain
+                    for k in (10, 1, 100):
+                        wins = [WIDE]
+                        Dw, _ = B.flat_search(b, q, k, metric, B.make_ctx(**WIDE, **ctx_kw))
+                        fin = Dw[np.abs(Dw) < 1e37]
+                        if len(fin) > 4 and k == 10:
+                            wins.append(dict(min_score=float(np.quantile(fin, 0.3)), max_score=float(np.quantile(fin, 0.9))))
+                        for win in wins:
+                            D, I = B.flat_search(b, q, k, metric, B.make_ctx(**win, **ctx_kw))
+                            args = api.SearchArgs(metric=metric, **win, **kw_f)
+                            g.tie_stats(reset=True)
+                            Dg, Ig = g.flat_search(np.tile(q, (reps, 1)), k, args)
+                            compare_exact(np.tile(D, (reps, 1)), np.tile(I, (reps, 1)), Dg, Ig)
+                            if k > 1:
+                                assert g.tie_stats()["replayed"] > 0
+            args = api.SearchArgs(metric=metric, exact_ties=-1, **WIDE, **kw_f)
+            D, I = B.flat_search(b, z["q"], 10, metric, B.make_ctx(**WIDE, **ctx_kw))
+            Dg, Ig = g.flat_search(np.tile(z["q"], (3, 1)), 10, args)
+            assert Dg[:len(D)].tobytes() == D.tobytes() and not np.array_equal(Ig[:len(I)], I)
+        finally:
+            g.close()

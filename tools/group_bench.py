@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--nprobe", type=int, default=32)
     ap.add_argument("--recall-num", type=int, default=200)
     ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--placement", default="auto", choices=["auto", "shard", "replicate"])
     a = ap.parse_args()
     import torch
     from gamma_amd import api, synth, train
@@ -39,9 +40,11 @@ def main():
     nb = 2
     queries = synth.sift_like(gnq * nb, d=d, seed=4321)
     cc, pq = train.train_ivfpq(base[:min(a.n, a.nlist * 64)], a.nlist, a.m, niter=10, pq_niter=25, seed=1234, device="cuda:0")
+    replicate = a.placement == "replicate" or (a.placement == "auto" and a.n * (a.m + 12) <= (2 << 30))
     grp = api.GammaHipGroup(devices)
+    grp.set_placement(replicate)
     for m in grp.members:
-        m.ivfpq_init(d, a.nlist, a.m, 8, api.METRIC_L2, bucket_init_size=max(1000, int(2.5 * a.n / a.nlist / W)))
+        m.ivfpq_init(d, a.nlist, a.m, 8, api.METRIC_L2, bucket_init_size=max(1000, int(2.5 * a.n / a.nlist / (1 if replicate else W))))
         m.ivfpq_set_trained(cc, pq, None)
         m.raw_init(d)
         for i0 in range(0, a.n, 1 << 18):
@@ -83,8 +86,10 @@ def main():
            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": "C3 through the in-process group: %d members%s, %d queries per member and step, lists sharded "
-                                  "by greedy sum(len)" % (W, " on ONE GPU (functional check)" if a.one_gpu else "", a.nq),
-                      "parallelism": "in-process, list-sharded x%d" % W, "recall_at_10": round(recall, 4),
+                                  "by greedy sum(len)" % (W, " on ONE GPU (functional check)" if a.one_gpu else "", a.nq)
+                      if not replicate else "C3 through the in-process group: %d members%s, %d queries per member and step, lists "
+                      "REPLICATED, queries split" % (W, " on ONE GPU (functional check)" if a.one_gpu else "", a.nq),
+                      "parallelism": "in-process, %s x%d" % ("query-parallel over replicas" if replicate else "list-sharded", W), "recall_at_10": round(recall, 4),
                       "build_s": round(build_s, 1), "device_bytes": grp.total_mem_bytes()}}
     print(json.dumps(out), flush=True)
     grp.close()
