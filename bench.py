@@ -54,6 +54,9 @@ def main():
                     help="torch.distributed backend; 'gloo' with --one-gpu runs all ranks on GPU 0 (functional "
                          "check of the multi-rank path on a single-GPU box, not a measurement)")
     ap.add_argument("--one-gpu", action="store_true", help="every rank uses cuda:0")
+    ap.add_argument("--no-deferred-replay", action="store_true",
+                    help="exact ties: replay the flagged queries of a step at its end on the search stream instead of beside "
+                         "the next step's coarse quantizer (gamma_hip_set_deferred_replay; single-GPU steps only)")
     ap.add_argument("--placement", default="auto", choices=["auto", "shard", "replicate"],
                     help="--gpus N > 1: 'shard' = the lists split over the ranks (greedy sum(len)), candidates exchanged "
                          "(gamma_amd.dist.sharded_search); 'replicate' = every rank holds the whole index and answers its "
@@ -182,6 +185,11 @@ def main():
     d_I = torch.empty((gnq, k), dtype=torch.int64, device=dev)
     backend = gdist.HipShardBackend(g, local_rank) if use_dist else None
     g.set_exact_ties(not a.no_exact_ties)
+    # the steps of the timed loop are back-to-back device-pointer calls: the handful of queries a step flags for the heap
+    # replay are redone beside the NEXT step's coarse quantizer / query tables; everything is complete at the
+    # synchronize that ends the timed region (include/gamma_hip.h, gamma_hip_set_deferred_replay)
+    deferred = (not use_dist) and (not a.no_exact_ties) and (not a.no_deferred_replay)
+    g.set_deferred_replay(deferred)
 
     def step(i):
         xb = d_q[(i % nbatches) * gnq:(i % nbatches + 1) * gnq]
@@ -277,10 +285,15 @@ def main():
         nst = 10
         sec = timed(lambda: g.ivfpq_search_device(d_q.data_ptr(), gnq, k, args, d_D.data_ptr(), d_I.data_ptr()), nst, 0)
         ts = g.tie_stats()
+        g.set_deferred_replay(False)
+        sec_inline = timed(lambda: g.ivfpq_search_device(d_q.data_ptr(), gnq, k, args, d_D.data_ptr(), d_I.data_ptr()), nst, 3)
+        g.set_deferred_replay(deferred)
         g.set_exact_ties(False)
         sec_off = timed(lambda: g.ivfpq_search_device(d_q.data_ptr(), gnq, k, args, d_D.data_ptr(), d_I.data_ptr()), nst, 3)
         g.set_exact_ties(True)
         extra["exact_ties"] = {"qps": round(gnq / sec, 1), "ms_per_step": round(sec * 1e3, 4),
+                               "deferred_replay": bool(deferred),
+                               "qps_replay_at_the_end_of_each_call": round(gnq / sec_inline, 1),
                                "qps_with_ties_off": round(gnq / sec_off, 1),
                                "ms_per_step_with_ties_off": round(sec_off * 1e3, 4),
                                "flagged_per_batch": {"coarse_rows_redone": round(ts["coarse_rows"] / nst, 1),
@@ -483,6 +496,10 @@ def main():
                  "the coarse assignment, all-to-all of per-shard top-recall_num, all-gather of "
                  "top-k" % (world, world))),
             "stage_us": stages,
+            "tie_replay": ("exact ties on; the replay of a step's flagged queries runs on a side stream beside the next "
+                           "step's coarse quantizer and query tables (gamma_hip_set_deferred_replay); every step's results "
+                           "are complete inside the timed region (it ends with a device-wide synchronize)") if deferred else
+                          ("exact ties on; replay at the end of every call" if not a.no_exact_ties else "exact ties off"),
             "pcie_inclusive_qps": None if host_qps is None else round(host_qps, 1),
             **extra,
         },

@@ -130,6 +130,8 @@ SYMBOLS = {
     "gamma_hip_group_last_error": (C.c_char_p, [C.c_void_p]),
     "gamma_hip_group_set_owners": (C.c_int, [C.c_void_p, i64p]),
     "gamma_hip_group_owner": (C.c_int, [C.c_void_p, C.c_int]),
+    "gamma_hip_set_deferred_replay": (C.c_int, [C.c_void_p, C.c_int]),
+    "gamma_hip_join": (C.c_int, [C.c_void_p]),
     "gamma_hip_group_set_placement": (C.c_int, [C.c_void_p, C.c_int]),
     "gamma_hip_group_placement": (C.c_int, [C.c_void_p]),
     "gamma_hip_group_ivfpq_add": (C.c_int, [C.c_void_p, C.c_int64, f32p, C.c_int64]),

@@ -137,6 +137,14 @@ class GammaHip:
         vecs = _f32(vecs)
         self._ck(self.L.gamma_hip_raw_write(self.h, first_vid, vecs.shape[0], _p(vecs, _lib.f32p)), "raw_write")
 
+    def set_deferred_replay(self, on):
+        """streaming device-pointer searches: the tie replay of a call runs beside the next call's first stages; results
+        of a call are complete after the next search, join() or synchronize() (include/gamma_hip.h)"""
+        self._ck(self.L.gamma_hip_set_deferred_replay(self.h, 1 if on else 0), "set_deferred_replay")
+
+    def join(self):
+        self._ck(self.L.gamma_hip_join(self.h), "join")
+
     def raw_stats(self):
         out = np.zeros(4, dtype=np.int64)
         self._ck(self.L.gamma_hip_raw_stats(self.h, _p(out, _lib.i64p)), "raw_stats")

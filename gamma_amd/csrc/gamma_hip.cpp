@@ -36,8 +36,11 @@ int gamma_hip_create(int device, gamma_hip_index** out) {
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&h->wstream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_rfork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_rdone, hipEventDisableTiming) != hipSuccess) {
         delete h;
         return GAMMA_HIP_EDEVICE;
     }
@@ -78,6 +81,8 @@ int gamma_hip_destroy(gamma_hip_index* h) {
     if (h->side) (void)hipStreamSynchronize(h->side);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->ev_rfork) (void)hipEventDestroy(h->ev_rfork);
+    if (h->ev_rdone) (void)hipEventDestroy(h->ev_rdone);
     for (int v = 0; v < H::NVER; v++) {
         if (h->ver_ev[v]) (void)hipEventDestroy(h->ver_ev[v]);
         if (h->rd_ev[v]) (void)hipEventDestroy(h->rd_ev[v]);
@@ -119,12 +124,13 @@ int gamma_hip_destroy(gamma_hip_index* h) {
                       &h->w_filter, &h->w_m_dis, &h->w_m_ids, &h->w_part_v, &h->w_part_i, &h->w_assign,
                       &h->w_codes_tmp, &h->w_qperm, &h->w_scnt, &h->w_sflag, &h->w_surv, &h->w_pair_base,
                       &h->w_pair_ip, &h->w_flat_cand, &h->w_flat_meta, &h->w_full_cdis,
-                      &h->w_full_probe, &h->w_ftab, &h->w_qfil, &h->w_tieflag, &h->w_tcut, &h->w_tlist, &h->w_lm_units, &h->w_lm_cnt, &h->w_fbits, &h->w_cmp_codes, &h->w_cmp_ids, &h->w_cmp_len, &h->w_fD, &h->w_fI, &h->w_fx, &h->w_fslab,
+                      &h->w_full_probe, &h->w_ftab, &h->w_qfil, &h->w_tieflag, &h->w_tcut, &h->w_tlist, &h->w_lm_units, &h->w_lm_cnt, &h->w_fbits, &h->w_cmp_codes, &h->w_cmp_ids, &h->w_cmp_len, &h->w_fD, &h->w_fI, &h->w_fx, &h->w_fslab, &h->w_flog,
                       &h->we_mat, &h->we_cdis, &h->we_x, &h->we_assign, &h->we_codes, &h->we_stage};
     for (DevBuf* b : bufs) b->release();
     (void)hipStreamDestroy(h->stream);
     (void)hipStreamDestroy(h->wstream);
     if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->side2) (void)hipStreamDestroy(h->side2);
     delete h;
     return GAMMA_HIP_OK;
 }
@@ -138,6 +144,32 @@ int gamma_hip_synchronize(gamma_hip_index* h) {
     GH_CHECK(h, hipSetDevice(h->device));
     GH_CHECK(h, hipStreamSynchronize(h->stream));
     GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    if (h->side) GH_CHECK(h, hipStreamSynchronize(h->side));
+    if (h->side2) GH_CHECK(h, hipStreamSynchronize(h->side2));
+    h->replay_pending = false;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_set_deferred_replay(gamma_hip_index* h, int on) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    if (!on && h->replay_pending) {
+        GH_CHECK(h, hipSetDevice(h->device));
+        GH_CHECK(h, hipStreamWaitEvent(h->stream, h->ev_rdone, 0));
+        h->replay_pending = false;
+    }
+    h->defer_replay = on != 0;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_join(gamma_hip_index* h) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    if (h->replay_pending) {
+        GH_CHECK(h, hipSetDevice(h->device));
+        GH_CHECK(h, hipStreamWaitEvent(h->stream, h->ev_rdone, 0));
+        h->replay_pending = false;
+    }
     return GAMMA_HIP_OK;
 }
 

@@ -92,8 +92,14 @@ struct gamma_hip_index {
     // side stream of the searches: kernels of a call that may overlap its main chain (the heap replay of the coarse
     // rows with a tie, beside the query tables); forked from and joined into `stream` by events, never used alone
     hipStream_t side = nullptr;
+    hipStream_t side2 = nullptr;   // the deferred tie replay (its own stream: the coarse heap fix must not queue behind it)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool coarse_join_pending = false;
+    // deferred tie replay (gamma_hip_set_deferred_replay): the replay of a device-pointer call's flagged queries runs on
+    // the side stream and the search stream waits for it only before the next kernel that touches what it reads (the
+    // next call's or chunk's pair offsets) -- its latency hides behind the next coarse quantizer and query tables
+    hipEvent_t ev_rfork = nullptr, ev_rdone = nullptr;
+    bool defer_replay = false, defer_now = false, replay_pending = false;
     std::mutex mu, search_mu, writer_mu;
     WriteLock* wl = nullptr;   // the writer holding mu (for exclusive() deep inside the arena code)
     static constexpr int NVER = 4;
@@ -182,7 +188,7 @@ struct gamma_hip_index {
     DevBuf w_mat, w_coarse_dis, w_probe, w_xn, w_st2, w_pair_off, w_qtotal, w_dist, w_cand_dis,
             w_cand_pos, w_cand_ids, w_exact, w_selv, w_selp, w_x, w_outd, w_outl, w_stage, w_filter,
             w_m_dis, w_m_ids, w_part_v, w_part_i, w_assign, w_codes_tmp, w_qperm, w_scnt, w_sflag, w_surv, w_pair_base,
-            w_pair_ip, w_flat_cand, w_flat_meta, w_full_cdis, w_full_probe, w_ftab, w_qfil, w_tieflag, w_tcut, w_tlist, w_lm_units, w_lm_cnt, w_fbits, w_cmp_codes, w_cmp_ids, w_cmp_len, w_fD, w_fI, w_fx, w_fslab,
+            w_pair_ip, w_flat_cand, w_flat_meta, w_full_cdis, w_full_probe, w_ftab, w_qfil, w_tieflag, w_tcut, w_tlist, w_lm_units, w_lm_cnt, w_fbits, w_cmp_codes, w_cmp_ids, w_cmp_len, w_fD, w_fI, w_fx, w_fslab, w_flog,
             we_mat, we_cdis, we_x, we_assign, we_codes, we_stage;   // writer side (encode, bitmap_set): never shared with a search
     unsigned long long* d_scan_codes = nullptr;
     size_t dist_budget_bytes = (size_t)8 << 30;   // per-chunk ADC distance buffer (288 GB of HBM per GPU)
@@ -282,6 +288,8 @@ struct WriteLock {
         }
         hipError_t e = hipStreamSynchronize(h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->wstream);
+        if (e == hipSuccess && h->side) e = hipStreamSynchronize(h->side);
+        if (e == hipSuccess && h->side2) e = hipStreamSynchronize(h->side2);   // a deferred tie replay reads lists and rows
         return e;
     }
     // searches may start again (the writer keeps writer_mu + mu): after a step that only needed the device idle

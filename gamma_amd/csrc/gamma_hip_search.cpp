@@ -276,12 +276,6 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     // and redone by the replay at the end of stage B
     h->tie = H::TieCtx();
     h->tie.on = h->exact_ties && !shard && R <= gh::tie_replay_max_k() && P <= gh::tie_replay_max_probes();
-    if (h->tie.on) {
-        GH_CHECK(h, h->w_tcut.ensure((size_t)nq));
-        GH_CHECK(h, h->w_tlist.ensure(((size_t)nq + 1) * sizeof(int)));   // count | list[nq]
-        GH_CHECK(h, hipMemsetAsync(h->w_tcut.p, 0, (size_t)nq, s));
-        GH_CHECK(h, hipMemsetAsync(h->w_tlist.p, 0, sizeof(int), s));
-    }
     // Threshold pre-filter: scan the nearest probe group first, bound each query's R-th best
     // distance from it, and let the scan of the remaining groups keep a short survivor list per
     // query; the exact top-R then comes from a few hundred survivors instead of ~10^4 candidates
@@ -299,6 +293,15 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
             gh::launch_pq_ip_table(s, d_x, nq, d, M, h->d_pqc, h->w_st2.as<float>());
         }
         GH_TRY(coarse_join(h));
+        // a deferred replay of the previous call / chunk reads what is written from here on (flag lists, pair offsets,
+        // slab, survivor slices, candidate tables): it has had the coarse quantizer and the tables to finish behind
+        GH_TRY(replay_join(h));
+        if (h->tie.on) {
+            GH_CHECK(h, h->w_tcut.ensure((size_t)nq));
+            GH_CHECK(h, h->w_tlist.ensure(((size_t)nq + 1) * sizeof(int)));   // count | list[nq]
+            GH_CHECK(h, hipMemsetAsync(h->w_tcut.p, 0, (size_t)nq, s));
+            GH_CHECK(h, hipMemsetAsync(h->w_tlist.p, 0, sizeof(int), s));
+        }
         gh::launch_pair_offsets(s, h->w_probe.as<int>(), nq, P, h->d_list_len, h->d_list_mask, nlist,
                                 h->w_pair_off.as<int>(), h->w_qtotal.as<int>(),
                                 h->profile ? h->d_scan_codes : nullptr, h->d_list_off,
@@ -489,7 +492,17 @@ int ivfpq_stage_b(H* h, const gamma_hip_search_params* p, int nq, const float* d
         a.cand_ids = const_cast<int64_t*>(cand_ids);
         a.distances = d_distances;
         a.labels = d_labels;
-        gh::launch_tie_replay(s, l2, a);
+        static const bool no_side = getenv("GAMMA_HIP_NO_SIDE_STREAM") != nullptr;
+        if (h->defer_now && h->side2 && !no_side) {
+            // beside whatever the search stream does next that does not touch the replay's inputs (replay_join)
+            (void)hipEventRecord(h->ev_rfork, s);
+            (void)hipStreamWaitEvent(h->side2, h->ev_rfork, 0);
+            gh::launch_tie_replay(h->side2, l2, a);
+            (void)hipEventRecord(h->ev_rdone, h->side2);
+            h->replay_pending = true;
+        } else {
+            gh::launch_tie_replay(s, l2, a);
+        }
     };
     if (p->has_rank) {
         if (!h->d_raw || h->raw_d != h->d) return fail(h, GAMMA_HIP_EINVAL, "has_rank needs the raw store");
@@ -716,6 +729,7 @@ int compact_lists_for_call(H* h, FiltCtx* fc, int64_t est, bool allowed, ListCom
     const char* env = getenv("GAMMA_HIP_LIST_COMPACT");
     const bool want = env ? atoi(env) != 0 : est >= 4 * std::max<int64_t>(1, h->ntotal);
     if (!(need && want && allowed && !fc->d_qf && !h->d_list_mask && h->arena_cap > 0)) return GAMMA_HIP_OK;
+    GH_TRY(replay_join(h));   // a deferred replay may still read the shadow lists of the previous call
     GH_CHECK(h, h->w_cmp_codes.ensure((size_t)h->arena_cap * h->code_size));
     GH_CHECK(h, h->w_cmp_ids.ensure((size_t)h->arena_cap * sizeof(int64_t)));
     GH_CHECK(h, h->w_cmp_len.ensure((size_t)h->nlist * sizeof(int)));
@@ -765,6 +779,7 @@ int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, c
     if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;
     p = &pp;
     if (ivfpq_small_ok(h, p, fc, nq, R)) {
+        GH_TRY(replay_join(h));
         GH_TRY(ivfpq_small(h, p, fc, nq, d_x, R, k, d_distances, d_labels));
         h->last_nq = nq;
         h->last_P = p->nprobe;
@@ -1139,6 +1154,8 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
     // (distance, row id) items are the same either way.  A list that overflows (rows arriving in
     // improving order) is detected and the call redone without a bound.
     const int cap = gh::flat_list_cap();
+    int log_nsl = 1;   // slices of the log: one per pass of the running bound (+ slice 0, the first chunk's slab)
+    for (int64_t r = rows_chunk; r < N; r += std::min<int64_t>(r, N - r)) log_nsl++;
     auto bounded = [&](int q0, int nc, bool* redo) -> int {
         const float* xq = d_x + (size_t)q0 * d;
         GH_CHECK(h, h->w_flat_cand.ensure((size_t)nc * cap * sizeof(unsigned long long)));
@@ -1148,15 +1165,26 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
         int* over = cnt + nc;
         gh::FlatEmit em{tau, h->w_flat_cand.as<unsigned long long>(), cnt, cap};
         GH_CHECK(h, hipMemsetAsync(over, 0, sizeof(int), s));
+        gh::FlatLog lg;
+        if (ties) {   // what every pass appends is kept for the replay (slice `pass` of the query)
+            GH_CHECK(h, h->w_flog.ensure((size_t)nc * log_nsl * cap * sizeof(unsigned long long) +
+                                         (size_t)nc * (log_nsl + 1) * sizeof(int)));
+            lg.items = h->w_flog.as<unsigned long long>();
+            lg.cnt = reinterpret_cast<int*>(lg.items + (size_t)nc * log_nsl * cap);
+            lg.kept = lg.cnt + (size_t)nc * log_nsl;
+            lg.nsl = log_nsl;
+            GH_CHECK(h, hipMemsetAsync(lg.cnt, 0, (size_t)nc * log_nsl * sizeof(int), s));
+        }
         gh::launch_pairwise_filtered(s, l2, xq, nc, d, h->d_raw, rows_chunk, h->w_dist.as<float>(), rows_chunk, filt,
                                      p->min_score, p->max_score, 0);
         gh::launch_select_topk(s, l2, h->w_dist.as<float>(), rows_chunk, nullptr, (int)rows_chunk, (int)rows_chunk,
                                nc, k, h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>());
-        gh::launch_flat_init(s, l2, h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>(), nc, k, 0, em, tau);
+        gh::launch_flat_init(s, l2, h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>(), nc, k, 0, em, tau, lg.kept);
         for (int64_t r = rows_chunk; r < N;) {
             const int64_t nr = std::min<int64_t>(r, N - r);
             gh::launch_pairwise_emit(s, l2, xq, nc, d, h->d_raw + r * d, nr, filt, p->min_score, p->max_score, r, em);
-            gh::launch_flat_compact(s, nc, k, em, tau, over);
+            lg.pass++;
+            gh::launch_flat_compact(s, nc, k, em, tau, over, ties ? &lg : nullptr);
             r += nr;
         }
         gh::launch_flat_final(s, l2, nc, k, em, neutral, outD(q0), outI(q0));
@@ -1187,27 +1215,46 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
             GH_CHECK(h, hipMemsetAsync(count, 0, sizeof(int), s));
             gh::launch_flat_take_flag(s, h->w_fD.as<float>(), h->w_fI.as<int64_t>(), nc, k_out, d_distances + (size_t)q0 * k_out,
                                       d_labels + (size_t)q0 * k_out, list, count, h->d_tie_stats);
-            int nflag = 0;
-            GH_CHECK(h, hipMemcpyAsync(&nflag, count, sizeof(int), hipMemcpyDeviceToHost, s));
-            GH_CHECK(h, hipStreamSynchronize(s));
-            const int64_t stride = (N + 3) & ~(int64_t)3;
-            const int fcap = (int)std::max<int64_t>(1, std::min<int64_t>(64, (int64_t)(h->dist_budget_bytes / ((size_t)stride * sizeof(float)))));
-            for (int f0 = 0; f0 < nflag; f0 += fcap) {
-                const int nf = std::min(fcap, nflag - f0);
-                GH_CHECK(h, h->w_fx.ensure((size_t)nf * d * sizeof(float)));
-                GH_CHECK(h, h->w_fslab.ensure((size_t)nf * stride * sizeof(float)));
-                gh::launch_gather_rows(s, d_x + (size_t)q0 * d, list + f0, nf, d, h->w_fx.as<float>());
-                gh::launch_pairwise_filtered(s, l2, h->w_fx.as<float>(), nf, d, h->d_raw, N, h->w_fslab.as<float>(), stride, filt,
-                                             p->min_score, p->max_score, 0);
-                gh::TieReplayArgs tr;
-                flat_tie_args(h, &tr, l2, nf, stride, 0, k_out, d_x + (size_t)q0 * d, h->w_cand_dis.as<float>(),
-                              h->w_cand_ids.as<int64_t>(), d_distances + (size_t)q0 * k_out, d_labels + (size_t)q0 * k_out, (int)N);
-                tr.slab = h->w_fslab.as<float>();
-                tr.d = d;
-                tr.list = list + f0;
-                tr.count = count;       // >= f0 + nf
-                tr.compact_rows = 1;
+            gh::TieReplayArgs tr;
+            flat_tie_args(h, &tr, l2, nc, rows_chunk, 0, k_out, d_x + (size_t)q0 * d, h->w_cand_dis.as<float>(),
+                          h->w_cand_ids.as<int64_t>(), d_distances + (size_t)q0 * k_out, d_labels + (size_t)q0 * k_out, (int)N);
+            tr.d = d;
+            tr.list = list;
+            tr.count = count;
+            if (!redo) {
+                // the running bound: the stream the heap saw = the first row chunk (its slab is intact) + what every
+                // later pass appended to the query's list, in row order
+                tr.G = (int)rows_chunk;
+                tr.always_sliced = 1;
+                tr.surv = h->w_flog.as<unsigned long long>();
+                tr.gcnt = reinterpret_cast<const int*>(tr.surv + (size_t)nc * log_nsl * cap);
+                tr.nsl = log_nsl;
+                tr.slice_cap = cap;
                 gh::launch_tie_replay(s, l2, tr);
+            } else if (nchunks == 1) {
+                gh::launch_tie_replay(s, l2, tr);   // the one slab holds every row
+            } else {
+                // several row chunks through one slab: the rows of the flagged queries are computed again
+                int nflag = 0;
+                GH_CHECK(h, hipMemcpyAsync(&nflag, count, sizeof(int), hipMemcpyDeviceToHost, s));
+                GH_CHECK(h, hipStreamSynchronize(s));
+                const int64_t stride = (N + 3) & ~(int64_t)3;
+                const int fcap = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (int64_t)(h->dist_budget_bytes / ((size_t)stride * sizeof(float)))));
+                for (int f0 = 0; f0 < nflag; f0 += fcap) {
+                    const int nf = std::min(fcap, nflag - f0);
+                    GH_CHECK(h, h->w_fx.ensure((size_t)nf * d * sizeof(float)));
+                    GH_CHECK(h, h->w_fslab.ensure((size_t)nf * stride * sizeof(float)));
+                    gh::launch_gather_rows(s, d_x + (size_t)q0 * d, list + f0, nf, d, h->w_fx.as<float>());
+                    gh::launch_pairwise_filtered(s, l2, h->w_fx.as<float>(), nf, d, h->d_raw, N, h->w_fslab.as<float>(), stride, filt,
+                                                 p->min_score, p->max_score, 0);
+                    gh::TieReplayArgs t2 = tr;
+                    t2.nq = nf;
+                    t2.slab = h->w_fslab.as<float>();
+                    t2.q_stride = stride;
+                    t2.list = list + f0;
+                    t2.compact_rows = 1;
+                    gh::launch_tie_replay(s, l2, t2);
+                }
             }
         }
     }
@@ -1247,13 +1294,17 @@ int gamma_hip_ivfpq_search_device(gamma_hip_index* h, const gamma_hip_search_par
                                   const float* d_x, int k, float* d_distances, int64_t* d_labels) {
     if (!h) return GAMMA_HIP_EINVAL;
     SearchLock lk(h);
-    return ivfpq_search_device_locked(h, p, nq, d_x, k, d_distances, d_labels);
+    h->defer_now = h->defer_replay;
+    const int rc = ivfpq_search_device_locked(h, p, nq, d_x, k, d_distances, d_labels);
+    h->defer_now = false;
+    return rc;
 }
 
 int gamma_hip_ivfflat_search_device(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* d_x,
                                     int k, float* d_distances, int64_t* d_labels) {
     if (!h) return GAMMA_HIP_EINVAL;
     SearchLock lk(h);
+    GH_TRY(replay_join(h));
     return ivfflat_search_device_locked(h, p, nq, d_x, k, d_distances, d_labels);
 }
 
@@ -1284,6 +1335,7 @@ int gamma_hip_ivfpq_last_stages(gamma_hip_index* h, float* coarse_dis, int64_t* 
                                 float* recall_dis, int64_t* recall_ids) {
     if (!h) return GAMMA_HIP_EINVAL;
     SearchLock lk(h);
+    GH_TRY(replay_join(h));
     const int nq = h->last_nq, P = h->last_P, R = h->last_R;
     if (nq <= 0) return fail(h, GAMMA_HIP_EINVAL, "no previous search");
     GH_CHECK(h, hipSetDevice(h->device));
@@ -1303,6 +1355,7 @@ int gamma_hip_ivfpq_search_shard(gamma_hip_index* h, const gamma_hip_search_para
                                  const float* d_x, int k, float* d_recall_dis, int64_t* d_recall_ids) {
     if (!h) return GAMMA_HIP_EINVAL;
     SearchLock lk(h);
+    GH_TRY(replay_join(h));
     GH_TRY(ivfpq_check(h, p, nq, k));
     if (k <= 0 || nq == 0) return GAMMA_HIP_OK;
     if (!d_x || !d_recall_dis || !d_recall_ids) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
@@ -1331,6 +1384,7 @@ int gamma_hip_ivfpq_coarse_device(gamma_hip_index* h, const gamma_hip_search_par
                                   const float* d_x, float* d_coarse_dis, int32_t* d_probe) {
     if (!h) return GAMMA_HIP_EINVAL;
     SearchLock lk(h);
+    GH_TRY(replay_join(h));
     GH_TRY(ivfpq_check(h, p, nq, 1));
     if (nq == 0) return GAMMA_HIP_OK;
     if (!d_x || !d_coarse_dis || !d_probe) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
@@ -1353,6 +1407,7 @@ int gamma_hip_ivfpq_search_shard_preassigned(gamma_hip_index* h, const gamma_hip
                                              int64_t* d_recall_ids) {
     if (!h) return GAMMA_HIP_EINVAL;
     SearchLock lk(h);
+    GH_TRY(replay_join(h));
     GH_TRY(ivfpq_check(h, p, nq, k));
     if (k <= 0 || nq == 0) return GAMMA_HIP_OK;
     if (!d_coarse_dis || !d_probe) return fail(h, GAMMA_HIP_EINVAL, "null coarse assignment");
@@ -1381,6 +1436,7 @@ int gamma_hip_ivfpq_merge_rerank(gamma_hip_index* h, const gamma_hip_search_para
                                  int q0, int nq_local, float* d_distances, int64_t* d_labels) {
     if (!h) return GAMMA_HIP_EINVAL;
     SearchLock lk(h);
+    GH_TRY(replay_join(h));
     GH_TRY(ivfpq_check(h, p, nq, k));
     if (nshards <= 0 || q0 < 0 || nq_local < 0 || q0 + nq_local > nq) return fail(h, GAMMA_HIP_EINVAL, "bad shard/query range");
     if (k <= 0 || nq_local == 0) return GAMMA_HIP_OK;
@@ -1420,6 +1476,7 @@ int gamma_hip_flat_search_device(gamma_hip_index* h, const gamma_hip_search_para
                                  const float* d_x, int k, float* d_distances, int64_t* d_labels) {
     if (!h) return GAMMA_HIP_EINVAL;
     SearchLock lk(h);
+    GH_TRY(replay_join(h));
     return flat_search_device_locked(h, p, nq, d_x, k, d_distances, d_labels);
 }
 

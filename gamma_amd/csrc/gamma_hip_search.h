@@ -42,11 +42,21 @@ int combined_search(gamma_hip_index* h, const gamma_hip_search_params* p, int nq
 // sync = false: everything is only enqueued (pinned host buffers); the caller synchronises the stream
 // lk != nullptr: the caller's SearchLock; its mu is released once everything is enqueued, so writers go on while
 // this call waits for the GPU (search_mu stays: the workspaces are in use)
+// a deferred tie replay (gamma_hip_set_deferred_replay) is complete on the search stream
+inline int replay_join(H* h) {
+    if (h->replay_pending) {
+        GH_CHECK(h, hipStreamWaitEvent(h->stream, h->ev_rdone, 0));
+        h->replay_pending = false;
+    }
+    return GAMMA_HIP_OK;
+}
+
 template <typename F>
 int host_search(H* h, int nq, int d, const float* x, int k, float* distances, int64_t* labels, F&& f,
                 bool sync = true, SearchLock* lk = nullptr, float* mapped_d = nullptr, int64_t* mapped_i = nullptr) {
     if (nq <= 0 || k <= 0) return f(nullptr, nullptr, nullptr);
     GH_CHECK(h, hipSetDevice(h->device));
+    GH_TRY(replay_join(h));
     GH_CHECK(h, h->w_x.ensure((size_t)nq * d * sizeof(float)));
     GH_CHECK(h, h->w_outd.ensure((size_t)nq * k * sizeof(float)));
     GH_CHECK(h, h->w_outl.ensure((size_t)nq * k * sizeof(int64_t)));

@@ -1167,6 +1167,10 @@ int gamma_hip_assign(gamma_hip_index* h, int d, int64_t n, const float* x, int k
                      int32_t* assign, float* dis) {
     if (!h || d <= 0 || n < 0 || k <= 0 || (n > 0 && (!x || !centroids || !assign))) return GAMMA_HIP_EINVAL;
     SearchLock lk(h);
+    if (h->replay_pending) {
+        GH_CHECK(h, hipStreamWaitEvent(h->stream, h->ev_rdone, 0));
+        h->replay_pending = false;
+    }
     if (n == 0) return GAMMA_HIP_OK;
     GH_CHECK(h, hipSetDevice(h->device));
     hipStream_t s = h->stream;

@@ -143,18 +143,9 @@ __device__ __forceinline__ void heap_push_seq(uint2* h, int k, float val, unsign
 }
 // heap_reorder (Heap.h:300-330): sorted best first into h[1..k], (FLT_MAX, -1) padded; returns the number of real
 // entries (payload != -1)
-__device__ __forceinline__ int heap_reorder_seq(uint2* h, int k) {
-    int ii = 0;
-    for (int i = 0; i < k; i++) {
-        const uint2 r = h[1];
-        const float val = hs_f(r.x);
-        const unsigned idv = hs_u(r.y);
-        heap_pop_seq(h, k - i);
-        h[k - ii] = make_uint2(__float_as_uint(val), idv);   // 0-based slot k - ii - 1
-        if (idv != 0xffffffffu) ii++;
-    }
-    // memmove to the front, 64 entries per step (a step reads before it writes, and writes below what the next
-    // step reads: dst <= src), then the padding
+// heap_reorder, second half: the ii real entries sit at the end of h[1..k]; memmove to the front, 64 entries per step (a
+// step reads before it writes, and writes below what the next step reads: dst <= src), then the padding
+__device__ __forceinline__ int heap_reorder_tail(uint2* h, int k, int ii) {
     const int lane = threadIdx.x & 63;
     if (ii < k) {
         for (int i0 = 0; i0 < ii; i0 += 64) {
@@ -168,5 +159,112 @@ __device__ __forceinline__ int heap_reorder_seq(uint2* h, int k) {
     __builtin_amdgcn_wave_barrier();
     return ii;
 }
+__device__ __forceinline__ int heap_reorder_seq(uint2* h, int k) {
+    int ii = 0;
+    for (int i = 0; i < k; i++) {
+        const uint2 r = h[1];
+        const float val = hs_f(r.x);
+        const unsigned idv = hs_u(r.y);
+        heap_pop_seq(h, k - i);
+        h[k - ii] = make_uint2(__float_as_uint(val), idv);   // 0-based slot k - ii - 1
+        if (idv != 0xffffffffu) ii++;
+    }
+    return heap_reorder_tail(h, k, ii);
+}
+
+// ---- the same sequential forms with the heap in REGISTERS: node i (1-based) in lane i & 63 of register i >> 6, read
+//      with v_readlane and written by the owning lane -- a level of a sift costs a few scalar instructions instead of an
+//      LDS round trip.  For the heaps that take their candidates one at a time (heap_pop + heap_push: the k-heap of
+//      compute_dis, the IVFFLAT / flat scanners' heap).  K <= 64 NREG - 1.  All lanes of the wave call every member.
+template <int NREG>
+struct RegHeap {
+    unsigned kv[NREG], pv[NREG];
+    __device__ __forceinline__ void fill() {
+#pragma unroll
+        for (int r = 0; r < NREG; r++) {
+            kv[r] = __float_as_uint(kHeapFltMax);
+            pv[r] = 0xffffffffu;
+        }
+    }
+    __device__ __forceinline__ unsigned getk(int i) const {
+        const int l = __builtin_amdgcn_readfirstlane(i & 63), rr = __builtin_amdgcn_readfirstlane(i >> 6);
+        unsigned v = (unsigned)__builtin_amdgcn_readlane((int)kv[0], l);
+#pragma unroll
+        for (int r = 1; r < NREG; r++) {
+            const unsigned t = (unsigned)__builtin_amdgcn_readlane((int)kv[r], l);
+            v = rr == r ? t : v;
+        }
+        return v;
+    }
+    __device__ __forceinline__ unsigned getp(int i) const {
+        const int l = __builtin_amdgcn_readfirstlane(i & 63), rr = __builtin_amdgcn_readfirstlane(i >> 6);
+        unsigned v = (unsigned)__builtin_amdgcn_readlane((int)pv[0], l);
+#pragma unroll
+        for (int r = 1; r < NREG; r++) {
+            const unsigned t = (unsigned)__builtin_amdgcn_readlane((int)pv[r], l);
+            v = rr == r ? t : v;
+        }
+        return v;
+    }
+    __device__ __forceinline__ void set(int i, unsigned kb, unsigned pb) {
+        const int l = __builtin_amdgcn_readfirstlane(i & 63), rr = __builtin_amdgcn_readfirstlane(i >> 6);
+#pragma unroll
+        for (int r = 0; r < NREG; r++) {
+            const bool me = rr == r && (int)(threadIdx.x & 63) == l;
+            kv[r] = me ? kb : kv[r];
+            pv[r] = me ? pb : pv[r];
+        }
+    }
+    __device__ __forceinline__ float top() const { return __uint_as_float(getk(1)); }
+    // heap_sift_down_seq over the first n nodes
+    __device__ __forceinline__ void sift_down(int n, float val, unsigned pay) {
+        int i = 1;
+        for (;;) {
+            const int i1 = i << 1;
+            if (i1 > n) break;
+            const float v1 = __uint_as_float(getk(i1)), v2 = __uint_as_float(getk(i1 + 1));   // i1 + 1 <= 64 NREG - 1
+            const bool pick1 = i1 == n || v1 > v2;
+            const float cv = pick1 ? v1 : v2;
+            if (val > cv) break;
+            const int c = pick1 ? i1 : i1 + 1;
+            set(i, __float_as_uint(cv), getp(c));
+            i = c;
+        }
+        set(i, __float_as_uint(val), pay);
+    }
+    __device__ __forceinline__ void pop(int n) { sift_down(n, __uint_as_float(getk(n)), getp(n)); }
+    __device__ __forceinline__ void push(int n, float val, unsigned pay) {
+        int i = n;
+        while (i > 1) {
+            const int f = i >> 1;
+            const unsigned fk = getk(f);
+            if (!(val > __uint_as_float(fk))) break;
+            set(i, fk, getp(f));
+            i = f;
+        }
+        set(i, __float_as_uint(val), pay);
+    }
+    // heap_reorder's pops (the array then goes to LDS for heap_reorder_tail); returns the number of real entries
+    __device__ __forceinline__ int reorder_pops(int k) {
+        int ii = 0;
+        for (int i = 0; i < k; i++) {
+            const unsigned rk = getk(1), rp = getp(1);
+            pop(k - i);
+            set(k - ii, rk, rp);
+            if (rp != 0xffffffffu) ii++;
+        }
+        return ii;
+    }
+    // node i -> h[i], i = 1..k
+    __device__ __forceinline__ void dump(uint2* h, int k) const {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int r = 0; r < NREG; r++) {
+            const int i = r * 64 + lane;
+            if (i >= 1 && i <= k) h[i] = make_uint2(kv[r], pv[r]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+};
 
 }  // namespace gh

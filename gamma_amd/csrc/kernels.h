@@ -86,9 +86,18 @@ void launch_pairwise_emit(hipStream_t s, bool l2, const float* x, int nq, int d,
                           const FlatEmit& em);
 // candidate lists from the first chunk's top-k (vals / positions inside the chunk starting at row r0)
 void launch_flat_init(hipStream_t s, bool l2, const float* vals, const int* pos, int nq, int k, int64_t r0,
-                      const FlatEmit& em, uint32_t* tau);
+                      const FlatEmit& em, uint32_t* tau, int* kept = nullptr);   // kept: FlatLog::kept
 // per query: keep the k best of its list (sorted), set the new bound; lists that overflowed set *overflow
-void launch_flat_compact(hipStream_t s, int nq, int k, const FlatEmit& em, uint32_t* tau, int* overflow);
+// log (exact ties): what pass `pass` (1..) appended to a query's list, kept for the replay -- items [nq][nsl][cap] in the
+// layout of the scan's survivor slices, counts [nq][nsl]; kept[nq]: list entries that are older than the pass
+struct FlatLog {
+    unsigned long long* items = nullptr;
+    int* cnt = nullptr;
+    int* kept = nullptr;
+    int nsl = 0, pass = 0;
+};
+void launch_flat_compact(hipStream_t s, int nq, int k, const FlatEmit& em, uint32_t* tau, int* overflow,
+                         const FlatLog* log = nullptr);
 // sorted lists -> distances / labels (neutral / -1 padded)
 void launch_flat_final(hipStream_t s, bool l2, int nq, int k, const FlatEmit& em, float neutral, float* distances,
                        int64_t* labels);
@@ -264,6 +273,8 @@ struct TieReplayArgs {
                                   // of heap_replace_top (the IVFPQ scanner)
     int fixed_n = 0;              // pair_off == nullptr (flat): every row has fixed_n entries, a position IS the vector id
     int compact_rows = 0;         // slab row i belongs to the i-th flagged query (list[i]) instead of query i
+    int always_sliced = 0;        // ready == nullptr: every query is first G slab entries + slices 1.. (flat search with the
+                                  // running bound: first row chunk + the candidates each later pass emitted)
 };
 int tie_replay_max_k();
 int tie_replay_max_probes();

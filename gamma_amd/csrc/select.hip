@@ -1124,7 +1124,7 @@ constexpr int FLAT_CAP = 2048;               // items per query list (k_flat_com
 
 __global__ __launch_bounds__(256) void k_flat_init(const float* __restrict__ vals, const int* __restrict__ pos,
                                                    int k, int64_t r0, bool smallest, FlatEmit em,
-                                                   uint32_t* __restrict__ tau) {
+                                                   uint32_t* __restrict__ tau, int* __restrict__ kept) {
     // first chunk's top-k (sorted on (value, position), invalid entries behind with pos = -1)
     const int q = blockIdx.x;
     __shared__ int s_n;
@@ -1144,13 +1144,14 @@ __global__ __launch_bounds__(256) void k_flat_init(const float* __restrict__ val
     if (threadIdx.x == 0) {
         const int n = s_n;
         em.cnt[q] = n;
+        if (kept) kept[q] = n;
         tau[q] = n == k ? (uint32_t)(em.cand[(int64_t)q * em.cap + k - 1] >> 32) : FLAT_ANY;
     }
 }
 
 // one wave per query: keep the k smallest items of the list, sorted; new bound = key of the k-th
 __global__ __launch_bounds__(256) void k_flat_compact(int nq, int k, FlatEmit em, uint32_t* __restrict__ tau,
-                                                      int* __restrict__ overflow) {
+                                                      int* __restrict__ overflow, FlatLog lg) {
     constexpr int NPL = FLAT_CAP / 64;
     __shared__ unsigned long long s_run[4][256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1161,12 +1162,28 @@ __global__ __launch_bounds__(256) void k_flat_compact(int nq, int k, FlatEmit em
         if (lane == 0) *overflow = 1;
         return;
     }
+    if (lg.items && lane == 0 && cnt == 0) lg.cnt[(int64_t)q * lg.nsl + lg.pass] = 0;
     if (cnt == 0) return;
     unsigned long long* list = em.cand + (int64_t)q * em.cap;
     unsigned long long it[NPL];
 #pragma unroll
     for (int j = 0; j < NPL; j++) it[j] = j * 64 + lane < cnt ? list[j * 64 + lane] : ~0ull;
     const int m = min(cnt, k);
+    if (lg.items) {
+        // exact ties: what this pass appended (entries behind the `kept` older ones) is the pass's part of the stream
+        // the reference's heap saw -- a superset of what it took: the bound was its root or looser
+        const int old = min(lg.kept[q], cnt);
+        unsigned long long* dst = lg.items + ((int64_t)q * lg.nsl + lg.pass) * em.cap;
+#pragma unroll
+        for (int j = 0; j < NPL; j++) {
+            const int idx = j * 64 + lane;
+            if (idx >= old && idx < cnt) dst[idx - old] = it[j];
+        }
+        if (lane == 0) {
+            lg.cnt[(int64_t)q * lg.nsl + lg.pass] = cnt - old;
+            lg.kept[q] = m;
+        }
+    }
     // smallest V with #(item <= V) >= m; items are distinct, so exactly m items are <= V
     unsigned long long lo = 0ull, hi = ~0ull - 1ull;
     while (lo < hi) {
@@ -1251,12 +1268,14 @@ __global__ __launch_bounds__(256) void k_flat_final(int k, bool smallest, FlatEm
 int flat_list_cap() { return FLAT_CAP; }
 
 void launch_flat_init(hipStream_t s, bool l2, const float* vals, const int* pos, int nq, int k, int64_t r0,
-                      const FlatEmit& em, uint32_t* tau) {
-    if (nq > 0) hipLaunchKernelGGL(k_flat_init, dim3(nq), dim3(256), 0, s, vals, pos, k, r0, l2, em, tau);
+                      const FlatEmit& em, uint32_t* tau, int* kept) {
+    if (nq > 0) hipLaunchKernelGGL(k_flat_init, dim3(nq), dim3(256), 0, s, vals, pos, k, r0, l2, em, tau, kept);
 }
-void launch_flat_compact(hipStream_t s, int nq, int k, const FlatEmit& em, uint32_t* tau, int* overflow) {
+void launch_flat_compact(hipStream_t s, int nq, int k, const FlatEmit& em, uint32_t* tau, int* overflow, const FlatLog* log) {
     if (k > 256 || em.cap != FLAT_CAP) abort();   // callers gate on this
-    if (nq > 0) hipLaunchKernelGGL(k_flat_compact, dim3((nq + 3) / 4), dim3(256), 0, s, nq, k, em, tau, overflow);
+    if (nq > 0)
+        hipLaunchKernelGGL(k_flat_compact, dim3((nq + 3) / 4), dim3(256), 0, s, nq, k, em, tau, overflow,
+                           log ? *log : FlatLog{});
 }
 void launch_flat_final(hipStream_t s, bool l2, int nq, int k, const FlatEmit& em, float neutral, float* distances,
                        int64_t* labels) {

@@ -15,7 +15,8 @@ namespace gh {
 constexpr int TR_MAXK = 1024;    // heap sizes the replay covers (recall_num and k)
 constexpr int TR_MAXP = 256;     // probes per query
 constexpr int TR_STAGE = 1024;   // survivor items sorted per round (= the scan's slice capacity)
-constexpr int TR_SLAB = 4096;    // candidates of the first probe group staged in LDS before the walk
+constexpr int TR_SLAB = 2048;    // candidates of the slab part brought into LDS per round (with it a C3 replay needs 21 KB of LDS: a
+                                 // workgroup fits a CU beside two of the coarse kernel, whose stage a deferred replay runs behind)
 
 
 // dynamic LDS of one replayed query
@@ -30,12 +31,12 @@ struct TieLds {
     int64_t* base;              // [P]
 };
 __host__ __device__ inline size_t tie_align16(size_t x) { return (x + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t tie_replay_lds_bytes_(int R, int k, int P, int slab = TR_SLAB) {
+__host__ __device__ inline size_t tie_replay_lds_bytes_(int R, int k, int P, int slab = TR_SLAB, int stage = TR_STAGE) {
     return tie_align16((size_t)(R + 2) * 8) + tie_align16((size_t)(k + 2) * 8) + tie_align16((size_t)R * 8) +
-           tie_align16((size_t)R * 4) + (size_t)slab * 4 + (size_t)TR_STAGE * 8 + tie_align16((size_t)(P + 1) * 4) +
+           tie_align16((size_t)R * 4) + (size_t)slab * 4 + (size_t)stage * 8 + tie_align16((size_t)(P + 1) * 4) +
            tie_align16((size_t)P * 8);
 }
-__device__ __forceinline__ TieLds tie_carve(char* p, int R, int k, int P, int slab) {
+__device__ __forceinline__ TieLds tie_carve(char* p, int R, int k, int P, int slab, int stage = TR_STAGE) {
     TieLds L;
     L.hR = reinterpret_cast<uint2*>(p);
     p += tie_align16((size_t)(R + 2) * 8);
@@ -48,7 +49,7 @@ __device__ __forceinline__ TieLds tie_carve(char* p, int R, int k, int P, int sl
     L.slab = reinterpret_cast<float*>(p);
     p += (size_t)slab * 4;
     L.it = reinterpret_cast<unsigned long long*>(p);
-    p += (size_t)TR_STAGE * 8;
+    p += (size_t)stage * 8;
     L.off = reinterpret_cast<int*>(p);
     p += tie_align16((size_t)(P + 1) * 4);
     L.base = reinterpret_cast<int64_t*>(p);
@@ -57,13 +58,13 @@ __device__ __forceinline__ TieLds tie_carve(char* p, int R, int k, int P, int sl
 
 // One query, replayed the way the reference runs it.  Called by all NT threads of a workgroup (NT a multiple
 // of 64, <= 1024); `lds` = tie_replay_lds_bytes_(R, k, P, SLAB) bytes, 16-byte aligned, free for this call.
-template <bool L2, int NT, int SLAB = TR_SLAB>
+template <bool L2, int NT, int SLAB = TR_SLAB, int STG = TR_STAGE>
 __device__ __forceinline__ void tie_replay_query(const TieReplayArgs& a, int q, char* lds, unsigned long long* dbg,
                                                  int slab_row = -1) {
 #define GH_TT(i) do { if (dbg && threadIdx.x == 0) dbg[i] = wall_clock64(); } while (0)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int R = a.R, k = a.k, P = a.P;
-    const TieLds L = tie_carve(lds, R, k, P, SLAB);
+    const TieLds L = tie_carve(lds, R, k, P, SLAB, STG);
     __syncthreads();   // the LDS is free
     GH_TT(0);
     if (a.pair_off) {
@@ -76,81 +77,88 @@ __device__ __forceinline__ void tie_replay_query(const TieReplayArgs& a, int q, 
     // ---- the candidate stream, in scan order ----
     // bounded query (the scan published a bound and no slice overflowed): first probe group from the
     // slab, the other groups from their survivor slices; otherwise the whole slab
-    bool sliced = false;
+    bool sliced = a.always_sliced != 0;
     if (a.ready) {
         sliced = (a.ready[q] >> 32) == 1ull;
         for (int s = 0; s < a.nsl && sliced; s++)
             if (a.gcnt[(int64_t)q * a.nsl + s] > a.slice_cap) sliced = false;   // uniform
     }
     const int ntot = a.pair_off ? L.off[P] : a.fixed_n;
-    const int n_slab = sliced ? L.off[min(a.G, P)] : ntot;
+    const int n_slab = sliced ? (a.pair_off ? L.off[min(a.G, P)] : min(a.G, ntot)) : ntot;
     const float* slab = a.slab + (int64_t)(slab_row >= 0 ? slab_row : q) * a.q_stride;
-    const bool staged = n_slab <= SLAB;
-    if (staged) {
-        for (int j = tid; j < n_slab; j += NT) L.slab[j] = L2 ? slab[j] : -slab[j];   // filtered entries: +inf
-        __syncthreads();
-    }
     GH_TT(1);
     HeapWalk w;
     w.begin(L.hR, R);
-    if (wv == 0 && a.pop_push) {
-        // IVFFLAT / flat scanners: `if (C::cmp(simi[0], dis)) { heap_pop; heap_push }` (gamma_index_ivfflat.h:52-75,
-        // gamma_index_flat.cc:118-300) -- one candidate at a time, 64 compared with the top per step
-        float top = kHeapFltMax;
-        auto feed = [&](bool valid, float dv, int j0) {
-            if (!valid) dv = INFINITY;
-            unsigned long long m = __ballot(top > dv);
-            while (m) {
-                const int l = (int)__ffsll((long long)m) - 1;
-                const float val = hw_readlane_f(dv, l);
-                heap_pop_seq(L.hR, R);
-                heap_push_seq(L.hR, R, val, (unsigned)(j0 + l));
-                top = hs_f(L.hR[1].x);
-                const unsigned long long above = l >= 63 ? 0ull : (~0ull << (l + 1));
-                m = __ballot(top > dv) & above;
+    // IVFFLAT / flat scanners: `if (C::cmp(simi[0], dis)) { heap_pop; heap_push }` (gamma_index_ivfflat.h:52-75,
+    // gamma_index_flat.cc:118-300) -- one candidate at a time, 64 compared with the top per step.  The IVFPQ scanner:
+    // heap_replace_top, pipelined (HeapWalk).  take(): one block of <= 64 candidates in stream order, wave 0.
+    float ptop = kHeapFltMax;
+    auto take = [&](bool valid, float dv, int pay) {
+        if (!a.pop_push) {
+            w.accept(valid, dv, pay);
+            return;
+        }
+        if (!valid) dv = INFINITY;
+        unsigned long long m = __ballot(ptop > dv);
+        while (m) {
+            const int l = (int)__ffsll((long long)m) - 1;
+            const float val = hw_readlane_f(dv, l);
+            heap_pop_seq(L.hR, R);
+            heap_push_seq(L.hR, R, val, (unsigned)hw_readlane_i(pay, l));
+            ptop = hs_f(L.hR[1].x);
+            const unsigned long long above = l >= 63 ? 0ull : (~0ull << (l + 1));
+            m = __ballot(ptop > dv) & above;
+        }
+    };
+    {
+        // The slab part of the stream, SLAB candidates at a time: all threads bring a chunk into LDS (the next one is in
+        // flight in registers meanwhile), every wave compares its share of the chunk's 64-candidate groups with the root
+        // value the heap had when the chunk began -- the root only ever decreases, so a group without a candidate below
+        // it holds nothing the heap would take -- and wave 0 walks the groups that are left, in order.
+        static_assert(SLAB % NT == 0 && SLAB / 64 <= 64, "chunk = whole rounds of the workgroup, at most 64 groups");
+        constexpr int PER = SLAB / NT;
+        unsigned long long* gmask = L.it;                        // [SLAB / 64], the sort buffer is idle here
+        float* s_top = reinterpret_cast<float*>(L.it + SLAB / 64);
+        const float far = L2 ? INFINITY : -INFINITY;
+        float pre[PER];
+        auto issue = [&](int c0) {
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const int j = c0 + u * NT + tid;
+                pre[u] = j < n_slab ? slab[j] : far;
             }
         };
-        if (staged) {
-            for (int j0 = 0; j0 < n_slab; j0 += 64) feed(j0 + lane < n_slab, L.slab[min(j0 + lane, n_slab - 1)], j0);
-        } else {
-            float t[8], tn[8];
+        if (n_slab > 0) issue(0);
+        if (tid == 0) *s_top = kHeapFltMax;
+        for (int c0 = 0; c0 < n_slab; c0 += SLAB) {
+            const int cn = min(SLAB, n_slab - c0);
+            __syncthreads();   // wave 0 is through the previous chunk
 #pragma unroll
-            for (int u = 0; u < 8; u++) t[u] = slab[min(u * 64 + lane, n_slab - 1)];
-            for (int j0 = 0; j0 < n_slab; j0 += 512) {
-#pragma unroll
-                for (int u = 0; u < 8; u++) tn[u] = slab[min(j0 + 512 + u * 64 + lane, n_slab - 1)];
-#pragma unroll
-                for (int u = 0; u < 8; u++)
-                    if (j0 + u * 64 < n_slab) feed(j0 + u * 64 + lane < n_slab, L2 ? t[u] : -t[u], j0 + u * 64);
-#pragma unroll
-                for (int u = 0; u < 8; u++) t[u] = tn[u];
+            for (int u = 0; u < PER; u++) L.slab[u * NT + tid] = L2 ? pre[u] : -pre[u];   // filtered entries: +inf
+            if (c0 + SLAB < n_slab) issue(c0 + SLAB);
+            __syncthreads();
+            const float t0 = *s_top;
+            for (int g = wv; g * 64 < cn; g += NT / 64) {
+                const unsigned long long m = __ballot(t0 > L.slab[g * 64 + lane]);   // beyond cn: +inf
+                if (lane == 0) gmask[g] = m;
             }
-        }
-    } else if (wv == 0) {
-        if (staged) {
-            for (int j0 = 0; j0 < n_slab; j0 += 64) {
-                const int j = j0 + lane;
-                w.accept(j < n_slab, L.slab[min(j, n_slab - 1)], j);
-            }
-        } else {
-            // eight blocks of the slab in flight ahead of the walk
-            float t[8], tn[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) t[u] = slab[min(u * 64 + lane, n_slab - 1)];
-            for (int j0 = 0; j0 < n_slab; j0 += 512) {
-#pragma unroll
-                for (int u = 0; u < 8; u++) tn[u] = slab[min(j0 + 512 + u * 64 + lane, n_slab - 1)];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int j = j0 + u * 64 + lane;
-                    if (j0 + u * 64 < n_slab) w.accept(j < n_slab, L2 ? t[u] : -t[u], j);
+            __syncthreads();
+            if (wv == 0) {
+                const int ng = (cn + 63) >> 6;
+                unsigned long long gm = __ballot(lane < ng && gmask[min(lane, ng - 1)] != 0ull);
+                while (gm) {
+                    const int g = (int)__ffsll((long long)gm) - 1;
+                    gm &= gm - 1ull;
+                    const int j = g * 64 + lane;
+                    take(j < cn, L.slab[j], c0 + j);
                 }
-#pragma unroll
-                for (int u = 0; u < 8; u++) t[u] = tn[u];
+                if (lane == 0) *s_top = a.pop_push ? ptop : w.top;
             }
         }
+        __syncthreads();
     }
     GH_TT(2);
+    if (dbg && threadIdx.x == 0) dbg[7] = (unsigned long long)(unsigned)w.nin | ((unsigned long long)(unsigned)n_slab << 32);
     if (sliced) {
         // slices 1.. in order (slice s holds positions of probe group s only, so slices are ordered among
         // themselves); several short slices share one sorting round
@@ -159,8 +167,8 @@ __device__ __forceinline__ void tie_replay_query(const TieReplayArgs& a, int q, 
             __syncthreads();   // the sort buffer is free again
             int n = 0, s_end = s;
             while (s_end < a.nsl) {
-                const int c = a.gcnt[(int64_t)q * a.nsl + s_end];
-                if (n + c > TR_STAGE) break;
+                const int c = min(a.gcnt[(int64_t)q * a.nsl + s_end], STG);
+                if (n + c > STG) break;
                 const unsigned long long* src = a.surv + ((int64_t)q * a.nsl + s_end) * a.slice_cap;
                 for (int i = tid; i < c; i += NT) {
                     const unsigned long long it = src[i];   // (key << 32 | position)
@@ -169,13 +177,13 @@ __device__ __forceinline__ void tie_replay_query(const TieReplayArgs& a, int q, 
                 n += c;
                 s_end++;
             }
-            block_rank_sort<NT, TR_STAGE / NT>(L.it, n);   // positions are distinct
+            block_rank_sort<NT, STG / NT>(L.it, n);   // positions are distinct
             if (wv == 0) {
                 for (int j0 = 0; j0 < n; j0 += 64) {
                     const unsigned long long it = L.it[min(j0 + lane, n - 1)];
                     const uint32_t key = (uint32_t)it;
                     const float val = key2f(L2 ? key : ~key);
-                    w.accept(j0 + lane < n, L2 ? val : -val, (int)(uint32_t)(it >> 32));
+                    take(j0 + lane < n, L2 ? val : -val, (int)(uint32_t)(it >> 32));
                 }
             }
             s = s_end;
@@ -216,7 +224,28 @@ __device__ __forceinline__ void tie_replay_query(const TieReplayArgs& a, int q, 
         }
         __syncthreads();
         GH_TT(4);
-        if (wv == 0) {
+        if (wv == 0 && k <= 63) {
+            // the k-heap in registers: heap_pop + heap_push per accepted candidate (gamma_index_ivfpq.cc:664-676)
+            RegHeap<1> kh;
+            kh.fill();
+            float top = kHeapFltMax;
+            for (int j0 = 0; j0 < R; j0 += 64) {
+                const int j = j0 + lane;
+                const float dv = j < R ? L.ex[j] : INFINITY;
+                unsigned long long m = __ballot(top > dv);
+                while (m) {
+                    const int l = (int)__ffsll((long long)m) - 1;
+                    kh.pop(k);
+                    kh.push(k, hw_readlane_f(dv, l), (unsigned)(j0 + l));
+                    top = kh.top();
+                    const unsigned long long above = l >= 63 ? 0ull : (~0ull << (l + 1));
+                    m = __ballot(top > dv) & above;
+                }
+            }
+            const int real = kh.reorder_pops(k);
+            kh.dump(L.hK, k);
+            heap_reorder_tail(L.hK, k, real);
+        } else if (wv == 0) {
             float top = kHeapFltMax;
             for (int j0 = 0; j0 < R; j0 += 64) {
                 const int j = j0 + lane;

@@ -44,12 +44,13 @@ int tie_replay_max_k() { return TR_MAXK; }
 int tie_replay_max_probes() { return TR_MAXP; }
 size_t tie_replay_lds_bytes(int R, int k, int P) { return tie_replay_lds_bytes_(R, k, P); }
 
-template <bool L2>
+template <bool L2, int STG>
 __global__ __launch_bounds__(256) void k_tie_replay(TieReplayArgs a) {
     extern __shared__ __attribute__((aligned(16))) char s_tie_lds[];
     const int nflag = min(*a.count, a.nq);
     for (int fi = blockIdx.x; fi < nflag; fi += gridDim.x)
-        tie_replay_query<L2, 256>(a, a.list[fi], s_tie_lds, (a.dbg && fi == 0) ? a.dbg : nullptr, a.compact_rows ? fi : -1);
+        tie_replay_query<L2, 256, TR_SLAB, STG>(a, a.list[fi], s_tie_lds, (a.dbg && fi == 0) ? a.dbg : nullptr,
+                                                 a.compact_rows ? fi : -1);
 }
 
 void launch_tie_replay(hipStream_t s, bool l2, const TieReplayArgs& a0) {
@@ -66,15 +67,22 @@ void launch_tie_replay(hipStream_t s, bool l2, const TieReplayArgs& a0) {
             (void)hipStreamSynchronize(s);
             (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
             (void)hipMemcpy(&n, a.count, sizeof(int), hipMemcpyDeviceToHost);
-            fprintf(stderr, "tie replay (10 ns ticks, previous call): stage %llu slab walk %llu slices %llu ids+exact %llu k-heap %llu out %llu; %d queries flagged now\n",
-                    h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], n);
+            fprintf(stderr, "tie replay (10 ns ticks, previous call): stage %llu slab walk %llu slices %llu ids+exact %llu k-heap %llu out %llu; slab %llu candidates, %llu taken; %d queries flagged now\n",
+                    h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] >> 32, h[7] & 0xffffffffull, n);
         }
         a.dbg = dbg;
     }
     const int grid = std::min(a.nq, 1024);
+    if (a.slice_cap > 2048) abort();   // callers gate on this
+    if (a.slice_cap > TR_STAGE) {      // long slices (flat search: the candidate lists of the running bound)
+        const size_t lds = tie_replay_lds_bytes_(a.R, a.k, a.P, TR_SLAB, 2048);
+        if (l2) hipLaunchKernelGGL((k_tie_replay<true, 2048>), dim3(grid), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((k_tie_replay<false, 2048>), dim3(grid), dim3(256), lds, s, a);
+        return;
+    }
     const size_t lds = tie_replay_lds_bytes(a.R, a.k, a.P);
-    if (l2) hipLaunchKernelGGL((k_tie_replay<true>), dim3(grid), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((k_tie_replay<false>), dim3(grid), dim3(256), lds, s, a);
+    if (l2) hipLaunchKernelGGL((k_tie_replay<true, TR_STAGE>), dim3(grid), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((k_tie_replay<false, TR_STAGE>), dim3(grid), dim3(256), lds, s, a);
 }
 
 // ------------------------------------------------------------------------------------

