@@ -130,6 +130,13 @@ SYMBOLS = {
     "gamma_hip_group_last_error": (C.c_char_p, [C.c_void_p]),
     "gamma_hip_group_set_owners": (C.c_int, [C.c_void_p, i64p]),
     "gamma_hip_group_owner": (C.c_int, [C.c_void_p, C.c_int]),
+    "gamma_hip_ivfpq_merge_flagged": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
+    "gamma_hip_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "gamma_hip_ivfpq_max_list_len": (C.c_int, [C.c_void_p]),
+    "gamma_hip_ivfpq_shard_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                               C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gamma_hip_ivfpq_merge_replay": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gamma_hip_set_deferred_replay": (C.c_int, [C.c_void_p, C.c_int]),
     "gamma_hip_join": (C.c_int, [C.c_void_p]),
     "gamma_hip_coarse_bf_check": (C.c_int, [C.c_void_p, C.c_int, i64p]),

@@ -372,6 +372,29 @@ class GammaHip:
         self._ck(self.L.gamma_hip_ivfpq_merge_rerank(self.h, args.ref(), nshards, nq, d_x, k, d_all_dis,
                                                      d_all_ids, q0, nq_local, d_D, d_I), "merge_rerank")
 
+    # exact ties across list shards (include/gamma_hip.h): all pointers are device addresses (ints)
+    def ivfpq_merge_flagged(self):
+        """(n_flagged, device address of the int32 list of flagged slice-local queries) after ivfpq_merge_rerank"""
+        import ctypes as C
+        n = C.c_int(0)
+        ptr = C.c_void_p(0)
+        self._ck(self.L.gamma_hip_ivfpq_merge_flagged(self.h, C.byref(n), C.byref(ptr)), "merge_flagged")
+        return int(n.value), (ptr.value or 0)
+
+    def gather_rows(self, d_src, row_words, d_list, n, d_dst):
+        self._ck(self.L.gamma_hip_gather_rows(self.h, d_src, row_words, d_list, n, d_dst), "gather_rows")
+
+    def max_list_len(self):
+        return self.L.gamma_hip_ivfpq_max_list_len(self.h)
+
+    def ivfpq_shard_export(self, nf, d_xf, d_cdis_f, d_probe_f, stride, args, d_vals, d_ids, d_off):
+        self._ck(self.L.gamma_hip_ivfpq_shard_export(self.h, args.ref(), nf, d_xf, d_cdis_f, d_probe_f, stride, d_vals, d_ids,
+                                                     d_off), "shard_export")
+
+    def ivfpq_merge_replay(self, nshards, nf, d_x_slice, stride, d_vals_all, d_ids_all, d_off_all, k, args, d_list, d_D, d_I):
+        self._ck(self.L.gamma_hip_ivfpq_merge_replay(self.h, args.ref(), nshards, nf, d_x_slice, stride, d_vals_all, d_ids_all,
+                                                     d_off_all, k, d_list, d_D, d_I), "merge_replay")
+
     def set_dist_budget(self, nbytes):
         self._ck(self.L.gamma_hip_set_workspace_budget(self.h, int(nbytes)), "set_workspace_budget")
 

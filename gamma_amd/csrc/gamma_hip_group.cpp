@@ -81,7 +81,9 @@ struct gamma_hip_group {
 
     struct Member {
         GBuf x, cdis, probe, rdis, rids, all_dis, all_ids, D, I;
-        hipEvent_t ev_coarse = nullptr, ev_scan = nullptr;
+        // exact ties across members: flagged queries' inputs (owner side / shard side), exports, the owner's copy of all exports
+        GBuf fx, fcd, fpr, sx, scd, spr, ex_vals, ex_ids, ex_off, av, ai, ao;
+        hipEvent_t ev_coarse = nullptr, ev_scan = nullptr, ev_tie = nullptr;
     };
     std::vector<Member> mb;
 
@@ -176,6 +178,7 @@ int gamma_hip_group_create(const int* devices, int n, gamma_hip_group** out) {
             }
         }
         if (hipEventCreateWithFlags(&g->mb[i].ev_coarse, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&g->mb[i].ev_tie, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&g->mb[i].ev_scan, hipEventDisableTiming) != hipSuccess) {
             for (auto* mh : g->m) gamma_hip_destroy(mh);
             delete g;
@@ -201,7 +204,10 @@ int gamma_hip_group_destroy(gamma_hip_group* g) {
         (void)hipSetDevice(g->dev[i]);
         (void)gamma_hip_synchronize(g->m[i]);
         gamma_hip_group::Member& b = g->mb[i];
-        for (GBuf* p : {&b.x, &b.cdis, &b.probe, &b.rdis, &b.rids, &b.all_dis, &b.all_ids, &b.D, &b.I}) p->release();
+        for (GBuf* p : {&b.x, &b.cdis, &b.probe, &b.rdis, &b.rids, &b.all_dis, &b.all_ids, &b.D, &b.I, &b.fx, &b.fcd, &b.fpr, &b.sx,
+                        &b.scd, &b.spr, &b.ex_vals, &b.ex_ids, &b.ex_off, &b.av, &b.ai, &b.ao})
+            p->release();
+        if (b.ev_tie) (void)hipEventDestroy(b.ev_tie);
         if (b.ev_coarse) (void)hipEventDestroy(b.ev_coarse);
         if (b.ev_scan) (void)hipEventDestroy(b.ev_scan);
     }
@@ -486,6 +492,8 @@ static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, in
     const int per = (nq + W - 1) / W;
     std::vector<int> rcs(W, GAMMA_HIP_OK);
     std::vector<std::string> errs(W);
+    std::vector<int> nfl(W, 0);                        // flagged queries of every member's slice
+    std::vector<const int32_t*> lists(W, nullptr);     // and the device lists of their slice-local indices
     auto slice = [&](int i, int* q0, int* q1) {
         *q0 = std::min(nq, i * per);
         *q1 = std::min(nq, *q0 + per);
@@ -609,6 +617,91 @@ static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, in
             if (rc == GAMMA_HIP_OK)
                 abi(gamma_hip_ivfpq_merge_rerank(h, &pp, W, per, b.x.as<float>() + (size_t)q0 * d, k, b.all_dis.as<float>(),
                                                  b.all_ids.as<int64_t>(), 0, nql, b.D.as<float>(), b.I.as<int64_t>()));
+        }
+        // 4. exact ties across members (include/gamma_hip.h): the queries a tie can change, listed by their owner, get their
+        //    candidate streams exported by every member and replayed at the owner
+        {
+            int nf_i = 0;
+            const int32_t* list_i = nullptr;
+            if (all_ok && nql > 0 && rc == GAMMA_HIP_OK) abi(gamma_hip_ivfpq_merge_flagged(h, &nf_i, &list_i));
+            nfl[i] = rc == GAMMA_HIP_OK ? nf_i : 0;
+            lists[i] = list_i;
+            g->bar.arrive();
+            all_ok = true;
+            for (int j = 0; j < W; j++) all_ok = all_ok && rcs[j] == GAMMA_HIP_OK;
+            int total = 0;
+            for (int j = 0; j < W; j++) total += nfl[j];
+            if (all_ok && total > 0) {
+                int64_t maxlen = 1;
+                for (int j = 0; j < W; j++) maxlen = std::max<int64_t>(maxlen, gamma_hip_ivfpq_max_list_len(g->m[j]));
+                const int64_t stride = (int64_t)P * maxlen;
+                // flagged queries per round: the owner holds W exports of `stride` entries (12 bytes) per query
+                const int fcap = (int)std::max<int64_t>(1, std::min<int64_t>(1 << 16, ((int64_t)1 << 30) / (12 * stride * W)));
+                for (int o = 0; o < W; o++) {
+                    for (int f0 = 0; f0 < nfl[o]; f0 += fcap) {
+                        const int nf = std::min(fcap, nfl[o] - f0);
+                        int oq0, oq1;
+                        slice(o, &oq0, &oq1);
+                        if (i == o) {   // the flagged queries' vectors and assignment rows, compact
+                            hip(b.fx.ensure((size_t)nf * d * sizeof(float)), "alloc");
+                            hip(b.fcd.ensure((size_t)nf * P * sizeof(float)), "alloc");
+                            hip(b.fpr.ensure((size_t)nf * P * sizeof(int32_t)), "alloc");
+                            if (rc == GAMMA_HIP_OK) {
+                                abi(gamma_hip_gather_rows(h, b.x.as<float>() + (size_t)q0 * d, d, lists[o] + f0, nf, b.fx.p));
+                                abi(gamma_hip_gather_rows(h, b.cdis.as<float>() + (size_t)q0 * P, P, lists[o] + f0, nf, b.fcd.p));
+                                abi(gamma_hip_gather_rows(h, b.probe.as<int32_t>() + (size_t)q0 * P, P, lists[o] + f0, nf, b.fpr.p));
+                            }
+                            hip(hipEventRecord(b.ev_tie, s), "record");
+                        }
+                        g->bar.arrive();   // the owner's compact inputs are on its stream
+                        gamma_hip_group::Member& ob = g->mb[o];
+                        hip(b.sx.ensure((size_t)nf * d * sizeof(float)), "alloc");
+                        hip(b.scd.ensure((size_t)nf * P * sizeof(float)), "alloc");
+                        hip(b.spr.ensure((size_t)nf * P * sizeof(int32_t)), "alloc");
+                        hip(b.ex_vals.ensure((size_t)nf * stride * sizeof(float)), "alloc");
+                        hip(b.ex_ids.ensure((size_t)nf * stride * sizeof(int64_t)), "alloc");
+                        hip(b.ex_off.ensure((size_t)nf * (P + 1) * sizeof(int32_t)), "alloc");
+                        bool ok2 = true;
+                        for (int j = 0; j < W; j++) ok2 = ok2 && rcs[j] == GAMMA_HIP_OK;
+                        if (ok2 && rc == GAMMA_HIP_OK) {
+                            if (i != o) hip(hipStreamWaitEvent(s, ob.ev_tie, 0), "wait");
+                            hip(copy_between(b.sx.p, g->dev[i], ob.fx.p, g->dev[o], (size_t)nf * d * sizeof(float), s), "tie inputs");
+                            hip(copy_between(b.scd.p, g->dev[i], ob.fcd.p, g->dev[o], (size_t)nf * P * sizeof(float), s), "tie inputs");
+                            hip(copy_between(b.spr.p, g->dev[i], ob.fpr.p, g->dev[o], (size_t)nf * P * sizeof(int32_t), s), "tie inputs");
+                            if (rc == GAMMA_HIP_OK)
+                                abi(gamma_hip_ivfpq_shard_export(h, &pp, nf, b.sx.as<float>(), b.scd.as<float>(), b.spr.as<int32_t>(), stride,
+                                                                 b.ex_vals.as<float>(), b.ex_ids.as<int64_t>(), b.ex_off.as<int32_t>()));
+                        }
+                        hip(hipStreamSynchronize(s), "sync");
+                        g->bar.arrive();   // every member's export is complete
+                        ok2 = true;
+                        for (int j = 0; j < W; j++) ok2 = ok2 && rcs[j] == GAMMA_HIP_OK;
+                        if (i == o && ok2) {
+                            hip(b.av.ensure((size_t)W * nf * stride * sizeof(float)), "alloc");
+                            hip(b.ai.ensure((size_t)W * nf * stride * sizeof(int64_t)), "alloc");
+                            hip(b.ao.ensure((size_t)W * nf * (P + 1) * sizeof(int32_t)), "alloc");
+                            for (int j = 0; j < W && rc == GAMMA_HIP_OK; j++) {
+                                hip(copy_between(b.av.as<float>() + (size_t)j * nf * stride, g->dev[i], g->mb[j].ex_vals.p, g->dev[j],
+                                                 (size_t)nf * stride * sizeof(float), s), "exports");
+                                hip(copy_between(b.ai.as<int64_t>() + (size_t)j * nf * stride, g->dev[i], g->mb[j].ex_ids.p, g->dev[j],
+                                                 (size_t)nf * stride * sizeof(int64_t), s), "exports");
+                                hip(copy_between(b.ao.as<int32_t>() + (size_t)j * nf * (P + 1), g->dev[i], g->mb[j].ex_off.p, g->dev[j],
+                                                 (size_t)nf * (P + 1) * sizeof(int32_t), s), "exports");
+                            }
+                            if (rc == GAMMA_HIP_OK)
+                                abi(gamma_hip_ivfpq_merge_replay(h, &pp, W, nf, b.x.as<float>() + (size_t)q0 * d, stride, b.av.as<float>(),
+                                                                 b.ai.as<int64_t>(), b.ao.as<int32_t>(), k, lists[o] + f0, b.D.as<float>(),
+                                                                 b.I.as<int64_t>()));
+                            hip(hipStreamSynchronize(s), "sync");
+                        }
+                        g->bar.arrive();   // the exports may be overwritten
+                    }
+                }
+            }
+        }
+        all_ok = true;
+        for (int j = 0; j < W; j++) all_ok = all_ok && rcs[j] == GAMMA_HIP_OK;
+        if (all_ok && nql > 0) {   // the slice's rows to the caller
             if (rc == GAMMA_HIP_OK && on_device) {
                 hip(copy_between(distances + (size_t)q0 * k, g->dev[0], b.D.p, g->dev[i], (size_t)nql * k * sizeof(float), s), "results");
                 hip(copy_between(labels + (size_t)q0 * k, g->dev[0], b.I.p, g->dev[i], (size_t)nql * k * sizeof(int64_t), s), "results");

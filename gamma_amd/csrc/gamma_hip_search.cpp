@@ -456,14 +456,15 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
 // ---- stage B: compute_dis (gamma_index_ivfpq.cc:642-697) ------------------------------
 int ivfpq_stage_b(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, int R, int k,
                   const float* cand_dis, const int64_t* cand_ids, float* d_distances,
-                  int64_t* d_labels, const int* qperm = nullptr, bool tie_replay = false) {
+                  int64_t* d_labels, const int* qperm = nullptr, int tie_mode = 0) {   // 1: flag + replay; 2: flag only
+                                                                                         // (merge of shards: w_tcut / w_tlist set up by the caller)
     const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
     const float neutral = l2 ? 3.402823466e+38f : -3.402823466e+38f;
     hipStream_t s = h->stream;
     StageScope t(h, GAMMA_HIP_STAGE_RERANK);
     // exact ties: the final-stage kernel lists the queries with a tie among their first k+1 distances (or with a
     // tied top-R cut, stage A) and k_tie_replay redoes those the way the reference's heaps do (ties.hip)
-    const bool ties = tie_replay && h->tie.on;
+    const bool ties = (tie_mode == 1 && h->tie.on) || tie_mode == 2;
     gh::TieFlags tf;
     if (ties) {
         tf.cut = h->w_tcut.as<uint8_t>();
@@ -522,7 +523,7 @@ int ivfpq_stage_b(H* h, const gamma_hip_search_params* p, int nq, const float* d
             // one fused kernel: exact distances + top-k + output
             gh::launch_rerank_topk(s, l2, d_x, nq, h->d, h->d_raw, h->nraw, cand_ids, R, k, p->min_score,
                                    p->max_score, neutral, d_distances, d_labels, qperm, ties ? &tf : nullptr);
-            if (ties) replay();
+            if (ties && tie_mode == 1) replay();
             GH_CHECK(h, hipGetLastError());
             return GAMMA_HIP_OK;
         }
@@ -538,7 +539,7 @@ int ivfpq_stage_b(H* h, const gamma_hip_search_params* p, int nq, const float* d
     } else {
         gh::launch_finalize_norank(s, cand_dis, cand_ids, nq, R, k, p->min_score, p->max_score, neutral,
                                    d_distances, d_labels, ties ? &tf : nullptr);
-        if (ties) replay();
+        if (ties && tie_mode == 1) replay();
     }
     GH_CHECK(h, hipGetLastError());
     return GAMMA_HIP_OK;
@@ -823,7 +824,7 @@ int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, c
         GH_TRY(ivfpq_stage_b(h, p, nc, d_x + (size_t)q0 * h->d, R, k, h->w_cand_dis.as<float>(),
                              h->w_cand_ids.as<int64_t>(), d_distances + (size_t)q0 * k,
                              d_labels + (size_t)q0 * k, getenv("GAMMA_HIP_NO_RERANK_ORDER") ? nullptr : h->last_qperm,
-                             /*tie_replay=*/true));
+                             /*tie_mode=*/1));
         h->last_nq = nc;
     }
     h->last_P = p->nprobe;
@@ -1480,8 +1481,152 @@ int gamma_hip_ivfpq_merge_rerank(gamma_hip_index* h, const gamma_hip_search_para
         }
         GH_CHECK(h, hipGetLastError());
     }
+    // exact ties: the slice's queries whose result a tie can change are listed (gamma_hip_ivfpq_merge_flagged); the
+    // caller gathers their candidate streams from the shards and has them replayed (gamma_hip_ivfpq_merge_replay)
+    TiesScope ties_scope(h, p);
+    const bool ties = h->exact_ties && R <= gh::tie_replay_max_k() && p->nprobe <= gh::tie_replay_max_probes();
+    h->merge_flags = ties;
+    h->merge_nql = nq_local;
+    if (ties) {
+        GH_CHECK(h, h->w_tcut.ensure((size_t)nq_local));
+        GH_CHECK(h, h->w_tlist.ensure(((size_t)nq_local + 1) * sizeof(int)));
+        GH_CHECK(h, hipMemsetAsync(h->w_tlist.p, 0, sizeof(int), s));
+        gh::launch_flag_merge_cut(s, d_all_dis, nshards, nq, R, q0, nq_local, h->w_cand_dis.as<float>(), h->w_cand_ids.as<int64_t>(),
+                                  h->w_tcut.as<uint8_t>());
+    }
     return ivfpq_stage_b(h, p, nq_local, d_x + (size_t)q0 * h->d, R, k, h->w_cand_dis.as<float>(),
-                         h->w_cand_ids.as<int64_t>(), d_distances, d_labels);
+                         h->w_cand_ids.as<int64_t>(), d_distances, d_labels, nullptr, ties ? 2 : 0);
+}
+
+int gamma_hip_ivfpq_merge_flagged(gamma_hip_index* h, int* n_flagged, const int32_t** d_list) {
+    if (!h || !n_flagged) return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    *n_flagged = 0;
+    if (d_list) *d_list = nullptr;
+    if (!h->merge_flags) return GAMMA_HIP_OK;
+    GH_CHECK(h, hipSetDevice(h->device));
+    int n = 0;
+    GH_CHECK(h, hipMemcpyAsync(&n, h->w_tlist.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    *n_flagged = std::min(n, h->merge_nql);
+    if (d_list) *d_list = h->w_tlist.as<int32_t>() + 1;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_max_list_len(gamma_hip_index* h) { return (h && h->ivf_init) ? h->max_list_len : 0; }
+
+int gamma_hip_gather_rows(gamma_hip_index* h, const void* d_src, int row_words, const int32_t* d_list, int n, void* d_dst) {
+    if (!h || row_words <= 0 || n < 0) return GAMMA_HIP_EINVAL;
+    if (n == 0) return GAMMA_HIP_OK;
+    if (!d_src || !d_list || !d_dst) return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    GH_CHECK(h, hipSetDevice(h->device));
+    gh::launch_gather_words(h->stream, d_src, d_list, n, row_words, d_dst);
+    GH_CHECK(h, hipGetLastError());
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_shard_export(gamma_hip_index* h, const gamma_hip_search_params* p, int nf, const float* d_xf,
+                                 const float* d_cdis_f, const int32_t* d_probe_f, int64_t stride, float* d_vals, int64_t* d_ids,
+                                 int32_t* d_off) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    GH_TRY(replay_join(h));
+    GH_TRY(ivfpq_check(h, p, nf, 1));
+    if (nf == 0) return GAMMA_HIP_OK;
+    if (!d_xf || !d_cdis_f || !d_probe_f || !d_vals || !d_ids || !d_off) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
+    if (p->nprobe > gh::tie_replay_max_probes()) return fail(h, GAMMA_HIP_EINVAL, "nprobe beyond the replay's range");
+    GH_CHECK(h, hipSetDevice(h->device));
+    const int P = p->nprobe, R = std::max(p->recall_num, 1);
+    if (stride < (int64_t)P * std::max(1, h->max_list_len)) return fail(h, GAMMA_HIP_EINVAL, "stride below nprobe x longest list");
+    gh::FilterDesc filt;
+    GH_TRY(build_filter(h, p, &filt));
+    FiltCtx fc;
+    GH_TRY(filt_ctx_single(h, filt, &fc));
+    // the plain scan (every distance of the owned probed lists in the slab, scan order); its top-R goes to scratch
+    const bool saved_bound = h->scan_bound;
+    h->scan_bound = false;
+    const int chunk = query_chunk(h, nf, P);
+    int rc = GAMMA_HIP_OK;
+    for (int f0 = 0; f0 < nf && rc == GAMMA_HIP_OK; f0 += chunk) {
+        const int nc = std::min(chunk, nf - f0);
+        rc = h->w_m_dis.ensure((size_t)nc * R * sizeof(float)) == hipSuccess &&
+                     h->w_m_ids.ensure((size_t)nc * R * sizeof(int64_t)) == hipSuccess
+                 ? GAMMA_HIP_OK
+                 : fail(h, GAMMA_HIP_ENOMEM, "export scratch");
+        if (rc == GAMMA_HIP_OK)
+            rc = ivfpq_stage_a(h, p, fc.at(f0), nc, d_xf + (size_t)f0 * h->d, R, d_cdis_f + (size_t)f0 * P,
+                               d_probe_f + (size_t)f0 * P, /*shard=*/true, h->w_m_dis.as<float>(), h->w_m_ids.as<int64_t>());
+        if (rc == GAMMA_HIP_OK)
+            gh::launch_shard_export(h->stream, d_probe_f + (size_t)f0 * P, nc, P, h->d_list_len, h->d_list_off, h->d_list_mask,
+                                    h->nlist, h->d_ids, h->w_dist.as<float>(), h->tie.q_stride, stride,
+                                    d_vals + (size_t)f0 * stride, d_ids + (size_t)f0 * stride, d_off + (size_t)f0 * (P + 1));
+    }
+    h->scan_bound = saved_bound;
+    if (rc != GAMMA_HIP_OK) return rc;
+    GH_CHECK(h, hipGetLastError());
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_merge_replay(gamma_hip_index* h, const gamma_hip_search_params* p, int nshards, int nf, const float* d_x_slice,
+                                 int64_t stride, const float* d_vals_all, const int64_t* d_ids_all, const int32_t* d_off_all, int k,
+                                 const int32_t* d_list, float* d_distances, int64_t* d_labels) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    GH_TRY(ivfpq_check(h, p, nf, k));
+    if (nf == 0 || k <= 0) return GAMMA_HIP_OK;
+    if (!d_x_slice || !d_vals_all || !d_ids_all || !d_off_all || !d_list || !d_distances || !d_labels)
+        return fail(h, GAMMA_HIP_EINVAL, "null buffer");
+    if (!h->merge_flags) return fail(h, GAMMA_HIP_EINVAL, "no merge with tie flags before the replay");
+    GH_CHECK(h, hipSetDevice(h->device));
+    const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
+    const int P = p->nprobe, R = std::max(p->recall_num, k);
+    if (R > gh::tie_replay_max_k() || P > gh::tie_replay_max_probes()) return fail(h, GAMMA_HIP_EINVAL, "beyond the replay's range");
+    if (p->has_rank && (!h->d_raw || h->raw_d != h->d)) return fail(h, GAMMA_HIP_EINVAL, "has_rank needs the raw store");
+    hipStream_t s = h->stream;
+    GH_CHECK(h, h->w_mr_vals.ensure((size_t)nf * stride * sizeof(float)));
+    GH_CHECK(h, h->w_mr_ids.ensure((size_t)nf * stride * sizeof(int64_t)));
+    GH_CHECK(h, h->w_mr_meta.ensure((size_t)nf * (P + 1) * sizeof(int32_t) + (size_t)nf * P * sizeof(int64_t) + 64));
+    int64_t* m_base = h->w_mr_meta.as<int64_t>();
+    int* count = reinterpret_cast<int*>(m_base + (size_t)nf * P);
+    int32_t* m_off = count + 16;
+    GH_CHECK(h, hipMemcpyAsync(count, &nf, sizeof(int), hipMemcpyHostToDevice, s));
+    gh::launch_merge_streams(s, nshards, nf, P, stride, d_vals_all, d_ids_all, d_off_all, h->w_mr_vals.as<float>(),
+                             h->w_mr_ids.as<int64_t>(), m_off, m_base, l2 ? INFINITY : -INFINITY);
+    gh::TieReplayArgs a;
+    a.list = d_list;
+    a.count = count;
+    a.nq = nf;
+    a.slab = h->w_mr_vals.as<float>();
+    a.q_stride = stride;
+    a.pair_off = m_off;
+    a.pair_base = m_base;
+    a.ids = h->w_mr_ids.as<int64_t>();
+    a.P = P;
+    a.G = P;
+    a.ready = nullptr;
+    a.surv = nullptr;
+    a.gcnt = nullptr;
+    a.nsl = 0;
+    a.slice_cap = 0;
+    a.x = d_x_slice;
+    a.d = h->d;
+    a.raw = h->d_raw;
+    a.nraw = h->nraw;
+    a.R = R;
+    a.k = k;
+    a.has_rank = p->has_rank ? 1 : 0;
+    a.min_score = p->min_score;
+    a.max_score = p->max_score;
+    a.neutral = l2 ? 3.402823466e+38f : -3.402823466e+38f;
+    a.cand_dis = h->w_cand_dis.as<float>();     // the merged tables of the slice (gamma_hip_ivfpq_merge_rerank)
+    a.cand_ids = h->w_cand_ids.as<int64_t>();
+    a.distances = d_distances;
+    a.labels = d_labels;
+    a.compact_rows = 1;
+    gh::launch_tie_replay(s, l2, a);
+    GH_CHECK(h, hipGetLastError());
+    return GAMMA_HIP_OK;
 }
 
 int gamma_hip_flat_search_device(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,

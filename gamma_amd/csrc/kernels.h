@@ -299,6 +299,16 @@ size_t tie_replay_lds_bytes(int R, int k, int P);
 // lists the queries with two equal distances among the k + 1 (their order, or which of them stays, is the heap's)
 void launch_flat_take_flag(hipStream_t s, const float* D1, const int64_t* I1, int nq, int k, float* distances, int64_t* labels,
                            int* list, int* count, unsigned long long* tie_stats);
+// exact ties across list shards (ties.hip): cut-tie flags of the merged tables, a shard's export of the flagged queries'
+// candidate streams, the owner's assembly of the exports
+void launch_flag_merge_cut(hipStream_t s, const float* all_dis, int W, int nq, int R, int q0, int nql, const float* merged,
+                           const int64_t* merged_ids, uint8_t* tcut);
+void launch_shard_export(hipStream_t s, const int32_t* probe, int nf, int P, const int* list_len, const int64_t* list_off,
+                         const uint8_t* list_mask, int nlist, const int64_t* ids, const float* slab, int64_t q_stride,
+                         int64_t stride, float* vals, int64_t* out_ids, int32_t* off);
+void launch_merge_streams(hipStream_t s, int W, int nf, int P, int64_t stride, const float* vals, const int64_t* ids,
+                          const int32_t* off, float* m_vals, int64_t* m_ids, int32_t* m_off, int64_t* m_base, float sentinel);
+void launch_gather_words(hipStream_t s, const void* src, const int* list, int n, int words, void* out);
 // out[i] = x[list[i]] for i < n (rows of d floats)
 void launch_gather_rows(hipStream_t s, const float* x, const int* list, int n, int d, float* out);
 void launch_finalize_topk(hipStream_t s, const float* sel_vals, const int* sel_pos, int nq, int k,

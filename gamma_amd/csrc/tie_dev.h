@@ -67,9 +67,10 @@ __device__ __forceinline__ void tie_replay_query(const TieReplayArgs& a, int q, 
     const TieLds L = tie_carve(lds, R, k, P, SLAB, STG);
     __syncthreads();   // the LDS is free
     GH_TT(0);
-    if (a.pair_off) {
-        for (int i = tid; i <= P; i += NT) L.off[i] = a.pair_off[(int64_t)q * (P + 1) + i];
-        for (int i = tid; i < P; i += NT) L.base[i] = a.pair_base[(int64_t)q * P + i];
+    if (a.pair_off) {   // (compact rows: the tables of the slab_row-th flagged query)
+        const int64_t qr = slab_row >= 0 ? slab_row : q;
+        for (int i = tid; i <= P; i += NT) L.off[i] = a.pair_off[qr * (P + 1) + i];
+        for (int i = tid; i < P; i += NT) L.base[i] = a.pair_base[qr * P + i];
     }
     heap_fill(L.hR, R, tid, NT);   // heap_heapify: (neutral, -1)
     if (a.has_rank) heap_fill(L.hK, k, tid, NT);

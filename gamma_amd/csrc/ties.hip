@@ -175,4 +175,155 @@ void launch_gather_rows(hipStream_t s, const float* x, const int* list, int n, i
     if (n > 0) hipLaunchKernelGGL(k_gather_rows, dim3(n), dim3(256), 0, s, x, list, d, out);
 }
 
+// ------------------------------------------------------------------------------------
+// Exact ties across list shards (several GPUs, gamma_hip_group.cpp / DESIGN.md 7).  The owner of a query slice merges
+// the shards' top-R tables; a query whose result a tie can change is replayed over the stream the reference's scanner
+// saw -- which is spread over the shards: every shard EXPORTS, for the flagged queries, the distances and ids of the
+// probed lists it owns in list order (k_shard_export, from the slab of an unbounded scan), the owner assembles the
+// exports probe by probe (k_merge_streams) and runs the ordinary replay over the assembled rows.
+// ------------------------------------------------------------------------------------
+// does the merged top-R cut of a slice query go through a group of equal distances?  One wave per query: entries equal
+// to the R-th merged value in all W tables against those that made it into the merged table.  A shard's own cut may
+// have dropped members of the group (its table is full and ends at that value): counted as a tie as well.
+__global__ __launch_bounds__(256) void k_flag_merge_cut(const float* __restrict__ all_dis, int W, int nq, int R, int q0, int nql,
+                                                        const float* __restrict__ merged, const int64_t* __restrict__ merged_ids,
+                                                        uint8_t* __restrict__ tcut) {
+    const int lane = threadIdx.x & 63;
+    const int ql = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ql >= nql) return;
+    if (lane == 0) tcut[ql] = 0;
+    if (merged_ids[(int64_t)ql * R + R - 1] < 0) return;   // fewer than R candidates in all: nothing was cut
+    const float vk = merged[(int64_t)ql * R + R - 1];
+    int in_m = 0, in_all = 0, shard_cut = 0;
+    for (int r = lane; r < R; r += 64) in_m += merged[(int64_t)ql * R + r] == vk ? 1 : 0;
+    for (int w = 0; w < W; w++) {
+        const float* row = all_dis + ((int64_t)w * nq + q0 + ql) * R;
+        for (int r = lane; r < R; r += 64) in_all += row[r] == vk ? 1 : 0;
+        if (lane == 0 && row[R - 1] == vk) shard_cut = 1;   // (an empty slot holds +-inf, never a real value)
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        in_m += __shfl_xor(in_m, off, 64);
+        in_all += __shfl_xor(in_all, off, 64);
+    }
+    shard_cut = __shfl(shard_cut, 0, 64);
+    if (lane == 0 && (in_all > in_m || shard_cut)) tcut[ql] = 1;
+}
+void launch_flag_merge_cut(hipStream_t s, const float* all_dis, int W, int nq, int R, int q0, int nql, const float* merged,
+                           const int64_t* merged_ids, uint8_t* tcut) {
+    if (nql > 0)
+        hipLaunchKernelGGL(k_flag_merge_cut, dim3((nql + 3) / 4), dim3(256), 0, s, all_dis, W, nq, R, q0, nql, merged,
+                           merged_ids, tcut);
+}
+
+// one workgroup per exported query f: off[f][p] = start of probe p's entries in the row (probes of lists this shard
+// does not own are empty); vals = the slab row of the unbounded scan (same order: the shard's compacted probe list keeps
+// the order of the original one), ids = the vector ids of those entries
+__global__ __launch_bounds__(256) void k_shard_export(const int32_t* __restrict__ probe, int P, const int* __restrict__ list_len,
+                                                      const int64_t* __restrict__ list_off, const uint8_t* __restrict__ list_mask,
+                                                      int nlist, const int64_t* __restrict__ ids, const float* __restrict__ slab,
+                                                      int64_t q_stride, int64_t stride, float* __restrict__ vals,
+                                                      int64_t* __restrict__ out_ids, int32_t* __restrict__ off) {
+    __shared__ int s_off[TR_MAXP + 1];
+    __shared__ int64_t s_base[TR_MAXP];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        int at = 0;
+        for (int pi = 0; pi < P; pi++) {
+            const int l = probe[(int64_t)f * P + pi];
+            const bool mine = l >= 0 && l < nlist && (!list_mask || list_mask[l]);
+            s_off[pi] = at;
+            s_base[pi] = mine ? list_off[l] : 0;
+            at += mine ? list_len[l] : 0;
+        }
+        s_off[P] = at;
+    }
+    __syncthreads();
+    for (int pi = tid; pi <= P; pi += 256) off[(int64_t)f * (P + 1) + pi] = s_off[pi];
+    const int n = (int)min((int64_t)s_off[P], stride);
+    const float* row = slab + (int64_t)f * q_stride;
+    for (int j = tid; j < n; j += 256) {
+        int lo = 0, hi = P - 1;
+        while (lo < hi) {   // last p with off[p] <= j
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_off[mid] <= j) lo = mid; else hi = mid - 1;
+        }
+        vals[(int64_t)f * stride + j] = row[j];
+        out_ids[(int64_t)f * stride + j] = ids[s_base[lo] + (j - s_off[lo])] & 0x7fffffffffffffffLL;
+    }
+}
+void launch_shard_export(hipStream_t s, const int32_t* probe, int nf, int P, const int* list_len, const int64_t* list_off,
+                         const uint8_t* list_mask, int nlist, const int64_t* ids, const float* slab, int64_t q_stride,
+                         int64_t stride, float* vals, int64_t* out_ids, int32_t* off) {
+    if (nf > 0)
+        hipLaunchKernelGGL(k_shard_export, dim3(nf), dim3(256), 0, s, probe, P, list_len, list_off, list_mask, nlist, ids, slab,
+                           q_stride, stride, vals, out_ids, off);
+}
+
+// one workgroup per flagged query f: the W exports [W][nf][stride] / [W][nf][P + 1] -> ONE row in probe order
+// (m_off[f][P + 1], m_base[f][p] = f * stride + m_off[f][p]: the replay's pair_off / pair_base over m_ids as its id arena)
+__global__ __launch_bounds__(256) void k_merge_streams(int W, int nf, int P, int64_t stride, const float* __restrict__ vals,
+                                                       const int64_t* __restrict__ ids, const int32_t* __restrict__ off,
+                                                       float* __restrict__ m_vals, int64_t* __restrict__ m_ids,
+                                                       int32_t* __restrict__ m_off, int64_t* __restrict__ m_base, float sentinel) {
+    __shared__ int s_moff[TR_MAXP + 1];
+    __shared__ int s_src[TR_MAXP];    // the shard that holds probe p's list (or -1)
+    __shared__ int s_soff[TR_MAXP];   // where its entries start in that shard's row
+    const int f = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        int at = 0;
+        for (int pi = 0; pi < P; pi++) {
+            int src = -1, so = 0, len = 0;
+            for (int w = 0; w < W; w++) {
+                const int32_t* o = off + ((int64_t)w * nf + f) * (P + 1);
+                const int lw = o[pi + 1] - o[pi];
+                if (lw > 0) {
+                    src = w;
+                    so = o[pi];
+                    len = lw;
+                }
+            }
+            if ((int64_t)at + len > stride) len = (int)max((int64_t)0, stride - at);   // cannot happen with the stride the callers size
+            s_moff[pi] = at;
+            s_src[pi] = src;
+            s_soff[pi] = so;
+            at += len;
+        }
+        s_moff[P] = at;
+    }
+    __syncthreads();
+    for (int pi = tid; pi <= P; pi += 256) m_off[(int64_t)f * (P + 1) + pi] = s_moff[pi];
+    for (int pi = tid; pi < P; pi += 256) m_base[(int64_t)f * P + pi] = (int64_t)f * stride + s_moff[pi];
+    const int n = s_moff[P];
+    for (int j = tid; j < n; j += 256) {
+        int lo = 0, hi = P - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_moff[mid] <= j) lo = mid; else hi = mid - 1;
+        }
+        const int w = s_src[lo];
+        const int64_t at = ((int64_t)w * nf + f) * stride + s_soff[lo] + (j - s_moff[lo]);
+        m_vals[(int64_t)f * stride + j] = w >= 0 ? vals[at] : sentinel;
+        m_ids[(int64_t)f * stride + j] = w >= 0 ? ids[at] : -1;
+    }
+}
+void launch_merge_streams(hipStream_t s, int W, int nf, int P, int64_t stride, const float* vals, const int64_t* ids,
+                          const int32_t* off, float* m_vals, int64_t* m_ids, int32_t* m_off, int64_t* m_base, float sentinel) {
+    if (nf > 0)
+        hipLaunchKernelGGL(k_merge_streams, dim3(nf), dim3(256), 0, s, W, nf, P, stride, vals, ids, off, m_vals, m_ids, m_off,
+                           m_base, sentinel);
+}
+
+// rows of `words` 32-bit words: out[i] = src[list[i]]
+__global__ __launch_bounds__(256) void k_gather_words(const uint32_t* __restrict__ src, const int* __restrict__ list, int words,
+                                                      uint32_t* __restrict__ out) {
+    const int64_t r = list[blockIdx.x];
+    for (int j = threadIdx.x; j < words; j += 256) out[(int64_t)blockIdx.x * words + j] = src[r * words + j];
+}
+void launch_gather_words(hipStream_t s, const void* src, const int* list, int n, int words, void* out) {
+    if (n > 0)
+        hipLaunchKernelGGL(k_gather_words, dim3(n), dim3(256), 0, s, static_cast<const uint32_t*>(src), list, words,
+                           static_cast<uint32_t*>(out));
+}
+
 }  // namespace gh

@@ -373,6 +373,34 @@ int gamma_hip_flat_search(gamma_hip_index* h, const gamma_hip_search_params* p, 
 int gamma_hip_flat_search_device(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
                                  const float* d_x, int k, float* d_distances, int64_t* d_labels);
 
+/* Exact ties across list shards.  gamma_hip_ivfpq_merge_rerank (exact ties on) leaves a list of the slice's queries whose
+ * result a tie can change: two equal exact distances among the first k + 1 (or equal ADC distances among the taken ones
+ * without re-rank), or the cut of the merged top-recall_num going through a group of equal distances (also when a shard's
+ * own cut may have dropped members of the group).  Those are replayed through the reference's heaps over the stream its
+ * scanner saw (faiss:utils/Heap.h:103-131, gamma_index_ivfpq.h:363-369, gamma_index_ivfpq.cc:664-696) -- which is
+ * spread over the shards:
+ *   merge_flagged   n_flagged (host; waits for the handle's stream) and the device list of flagged slice-local query
+ *                   indices (valid until the next search-type call on the handle);
+ *   gather_rows     d_dst[i] = row d_list[i] of d_src (rows of row_words 32-bit words): the flagged queries' vectors and
+ *                   assignment rows for the shards;
+ *   shard_export    on EVERY shard: for the nf flagged queries (vectors d_xf, assignment d_cdis_f / d_probe_f [nf][nprobe])
+ *                   the ADC distances (+-inf = filtered entry) and vector ids of the probed lists this shard owns, in list
+ *                   order: rows of `stride` entries, d_off[f][p .. p + 1) = the entries of probe p (empty for a list of
+ *                   another shard).  stride >= nprobe x the longest list of any shard (gamma_hip_ivfpq_max_list_len);
+ *   merge_replay    on the slice's owner: the exports of all shards ([nshards][nf][stride], [nshards][nf][nprobe + 1])
+ *                   are assembled probe by probe into the streams and replayed; rows d_list[f] of d_distances /
+ *                   d_labels (the slice's result rows) are rewritten.  d_x_slice: the slice's query vectors. */
+int gamma_hip_ivfpq_merge_flagged(gamma_hip_index* h, int* n_flagged, const int32_t** d_list);
+int gamma_hip_gather_rows(gamma_hip_index* h, const void* d_src, int row_words, const int32_t* d_list, int n, void* d_dst);
+int gamma_hip_ivfpq_max_list_len(gamma_hip_index* h);
+int gamma_hip_ivfpq_shard_export(gamma_hip_index* h, const gamma_hip_search_params* p, int nf, const float* d_xf,
+                                 const float* d_cdis_f, const int32_t* d_probe_f, int64_t stride, float* d_vals,
+                                 int64_t* d_ids, int32_t* d_off);
+int gamma_hip_ivfpq_merge_replay(gamma_hip_index* h, const gamma_hip_search_params* p, int nshards, int nf,
+                                 const float* d_x_slice, int64_t stride, const float* d_vals_all, const int64_t* d_ids_all,
+                                 const int32_t* d_off_all, int k, const int32_t* d_list, float* d_distances,
+                                 int64_t* d_labels);
+
 /* ---- several GPUs in ONE process: a group of handles, the index sharded by IVF list ----------------------------
  * What the reference's GPU model does with faiss's IndexShards / GpuClonerOptions (index/impl/gpu/gamma_gpu_cloner.cpp:200-269,
  * index/impl/gpu/gamma_index_ivfpq_gpu.cc:356-436, faiss:IndexShards.cpp:283-345): one index object, a host thread per

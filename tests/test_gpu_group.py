@@ -278,3 +278,41 @@ def test_replicated_group_is_the_single_handle_bit_for_bit(case):
     with pytest.raises(Exception):
         plugin.PluginModel("HIPIVFPQ", case["d"], model % (case["nlist"], case["M"], ', "devices": "0,0", "placement": "x"'),
                            indexing_size=5000)
+
+
+@pytest.mark.parametrize("tag,W", [("l2", 2), ("ip", 3), ("l2", 4)])
+def test_sharded_group_keeps_the_reference_order_inside_ties(tag, W):
+    """List-sharded members and tie-heavy data (every base vector four times): the owner of a query slice lists the
+    queries a tie can change, every member exports their candidate streams over the lists it owns, the owner replays
+    them -- labels strictly the pinned oracle's on the unsharded index."""
+    from tests.parity import compare_exact
+    from tests.test_oracle_golden import load_ties
+    z, o, base, metric = load_ties(tag)
+    d, nlist, M = int(z["d"]), int(z["nlist"]), int(z["M"])
+    sizes = z["list_sizes_" + tag]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    grp = api.GammaHipGroup([0] * W)
+    try:
+        for m in grp.members:
+            m.ivfpq_init(d, nlist, M, 8, metric)
+            m.ivfpq_set_trained(z["cc_" + tag], z["pq_" + tag], None)
+            m.raw_init(d)
+            m.raw_append(base)
+        grp.set_owners(sizes)
+        for l in range(nlist):
+            if sizes[l]:
+                grp.add_keys(l, z["list_ids_" + tag][offs[l]:offs[l + 1]], z["list_codes_" + tag][offs[l]:offs[l + 1]])
+        ctx = B.make_ctx(**WIDE)
+        for nprobe, R, k, has_rank in ((12, 60, 10, True), (6, 40, 10, False), (16, 100, 20, True)):
+            D1, I1 = o.search(z["q"], k, nprobe, recall_num=R, has_rank=has_rank, metric=metric, ctx=ctx, coarse_mode=0)
+            a = api.SearchArgs(metric=metric, nprobe=nprobe, recall_num=R, has_rank=has_rank, coarse_mode=0, **WIDE)
+            for reps in (1, 15):
+                q = np.tile(z["q"], (reps, 1))[:len(z["q"]) * reps - (reps > 1)]
+                Dg, Ig = grp.ivfpq_search(q, k, a)
+                compare_exact(np.tile(D1, (reps, 1))[:len(q)], np.tile(I1, (reps, 1))[:len(q)], Dg, Ig)
+            # with the mode off for the request only the distances agree on this data
+            a0 = api.SearchArgs(metric=metric, nprobe=nprobe, recall_num=R, has_rank=has_rank, coarse_mode=0, exact_ties=-1, **WIDE)
+            Dg, Ig = grp.ivfpq_search(z["q"], k, a0)
+            assert Dg.tobytes() == D1.tobytes() or not has_rank
+    finally:
+        grp.close()

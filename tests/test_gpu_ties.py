@@ -350,3 +350,115 @@ def test_deferred_replay_streams_of_device_calls():
         g.set_deferred_replay(False)
     finally:
         g.close()
+
+
+def _shard_of(z, tag, base, metric, owner, s):
+    g = api.GammaHip(0)
+    g.ivfpq_init(int(z["d"]), int(z["nlist"]), int(z["M"]), 8, metric)
+    g.ivfpq_set_trained(z["cc_" + tag], z["pq_" + tag], None)
+    sizes = z["list_sizes_" + tag]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    lists, counts, vids, codes = [], [], [], []
+    for l in range(int(z["nlist"])):
+        if owner[l] == s and sizes[l]:
+            lists.append(l)
+            counts.append(int(sizes[l]))
+            vids.append(z["list_ids_" + tag][offs[l]:offs[l + 1]])
+            codes.append(z["list_codes_" + tag][offs[l]:offs[l + 1]])
+    g.add_keys_batch(lists, counts, np.concatenate(vids), np.concatenate(codes))
+    mask = (np.asarray(owner) == s).astype(np.uint8)
+    g.set_list_mask(mask)
+    g.raw_init(int(z["d"]))
+    g.raw_append(base)
+    return g
+
+
+@pytest.mark.parametrize("tag,W,reps,has_rank", [("l2", 2, 1, True), ("l2", 3, 13, True), ("ip", 2, 13, True), ("l2", 2, 13, False),
+                                                 ("l2", 4, 90, True)])
+def test_exact_ties_across_list_shards(tag, W, reps, has_rank):
+    """W shards emulated on one GPU through the C ABI (what gamma_hip_group / dist.py drive): coarse per slice, shard scans,
+    merge + re-rank at the slice's owner -- then the tie phase: the owner lists the queries a tie can change
+    (gamma_hip_ivfpq_merge_flagged), every shard exports their candidate streams over the lists it owns
+    (gamma_hip_ivfpq_shard_export), the owner assembles and replays them (gamma_hip_ivfpq_merge_replay).  Expected: the
+    pinned oracle on the unsharded index, labels strictly."""
+    import torch
+    from gamma_amd import dist as gdist
+    z, o, base, metric = load_ties(tag)
+    nprobe, R, k = 12, 60, 10
+    sizes = z["list_sizes_" + tag]
+    owner = gdist.balance_lists(sizes, W)
+    shards = [_shard_of(z, tag, base, metric, owner, s) for s in range(W)]
+    try:
+        q1 = z["q"]
+        D1, I1 = o.search(q1, k, nprobe, recall_num=R, has_rank=has_rank, metric=metric, ctx=B.make_ctx(**WIDE), coarse_mode=0)
+        qh = np.tile(q1, (reps, 1))[:len(q1) * reps - (1 if reps > 1 else 0)]     # not a multiple of W
+        nq = len(qh)
+        Dexp = np.tile(D1, (reps, 1))[:nq]
+        Iexp = np.tile(I1, (reps, 1))[:nq]
+        dev = torch.device("cuda", 0)
+        x = torch.from_numpy(qh).to(dev)
+        args = api.SearchArgs(metric=metric, nprobe=nprobe, recall_num=R, has_rank=has_rank, coarse_mode=0, **WIDE)
+        per = (nq + W - 1) // W
+        backs = [gdist.HipShardBackend(g, 0) for g in shards]
+        cdis = torch.zeros((W * per, nprobe), dtype=torch.float32, device=dev)
+        probe = torch.full((W * per, nprobe), -1, dtype=torch.int32, device=dev)
+        for s in range(W):
+            q0, q1_, _ = gdist.query_slice(nq, s, W)
+            backs[s].coarse(x[q0:q1_], args, cdis[s * per:s * per + (q1_ - q0)], probe[s * per:s * per + (q1_ - q0)])
+            shards[s].synchronize()
+        # the assignment in query order for the shard scans
+        cd_all = torch.cat([cdis[s * per:s * per + (gdist.query_slice(nq, s, W)[1] - gdist.query_slice(nq, s, W)[0])] for s in range(W)])
+        pr_all = torch.cat([probe[s * per:s * per + (gdist.query_slice(nq, s, W)[1] - gdist.query_slice(nq, s, W)[0])] for s in range(W)])
+        rd, ri = [], []
+        for s in range(W):
+            rdis = torch.zeros((nq, R), dtype=torch.float32, device=dev)
+            rids = torch.full((nq, R), -1, dtype=torch.int64, device=dev)
+            backs[s].search_shard(x, cd_all, pr_all, k, args, rdis, rids)
+            shards[s].synchronize()
+            rd.append(rdis)
+            ri.append(rids)
+        D = torch.zeros((nq, k), dtype=torch.float32, device=dev)
+        I = torch.full((nq, k), -1, dtype=torch.int64, device=dev)
+        stride = nprobe * max(g.max_list_len() for g in shards)
+        flagged = 0
+        for r in range(W):
+            q0, q1_, _ = gdist.query_slice(nq, r, W)
+            nql = q1_ - q0
+            if nql == 0:
+                continue
+            all_dis = torch.stack([rd[s][q0:q1_] for s in range(W)]).contiguous()
+            all_ids = torch.stack([ri[s][q0:q1_] for s in range(W)]).contiguous()
+            xs = x[q0:q1_].contiguous()
+            Dr = torch.zeros((nql, k), dtype=torch.float32, device=dev)
+            Ir = torch.full((nql, k), -1, dtype=torch.int64, device=dev)
+            shards[r].ivfpq_merge_rerank(W, nql, xs.data_ptr(), k, args, all_dis.data_ptr(), all_ids.data_ptr(), 0, nql,
+                                         Dr.data_ptr(), Ir.data_ptr())
+            nf, d_list = shards[r].ivfpq_merge_flagged()
+            flagged += nf
+            if nf:
+                xf = torch.empty((nf, int(z["d"])), dtype=torch.float32, device=dev)
+                cf = torch.empty((nf, nprobe), dtype=torch.float32, device=dev)
+                pf = torch.empty((nf, nprobe), dtype=torch.int32, device=dev)
+                cds = cd_all[q0:q1_].contiguous()
+                prs = pr_all[q0:q1_].contiguous()
+                shards[r].gather_rows(xs.data_ptr(), int(z["d"]), d_list, nf, xf.data_ptr())
+                shards[r].gather_rows(cds.data_ptr(), nprobe, d_list, nf, cf.data_ptr())
+                shards[r].gather_rows(prs.data_ptr(), nprobe, d_list, nf, pf.data_ptr())
+                shards[r].synchronize()
+                vals = torch.empty((W, nf, stride), dtype=torch.float32, device=dev)
+                ids = torch.empty((W, nf, stride), dtype=torch.int64, device=dev)
+                off = torch.empty((W, nf, nprobe + 1), dtype=torch.int32, device=dev)
+                for s in range(W):
+                    shards[s].ivfpq_shard_export(nf, xf.data_ptr(), cf.data_ptr(), pf.data_ptr(), stride, args, vals[s].data_ptr(),
+                                                 ids[s].data_ptr(), off[s].data_ptr())
+                    shards[s].synchronize()
+                shards[r].ivfpq_merge_replay(W, nf, xs.data_ptr(), stride, vals.data_ptr(), ids.data_ptr(), off.data_ptr(), k, args,
+                                             d_list, Dr.data_ptr(), Ir.data_ptr())
+            shards[r].synchronize()
+            D[q0:q1_] = Dr
+            I[q0:q1_] = Ir
+        assert flagged > 0
+        compare_exact(Dexp, Iexp, D.cpu().numpy(), I.cpu().numpy())
+    finally:
+        for g in shards:
+            g.close()
