@@ -104,6 +104,27 @@ class HipShardBackend:
             self.g.ivfpq_merge_rerank(W, per, x.data_ptr(), k, args, all_dis.data_ptr(),
                                       all_ids.data_ptr(), 0, nql, D.data_ptr(), I.data_ptr())
 
+    # ---- exact ties across shards (include/gamma_hip.h; tie_phase below) ----
+    def merge_flagged(self):
+        """(number of the slice's queries a tie can change, device address of their slice-local indices); waits for the
+        handle's stream"""
+        return self.g.ivfpq_merge_flagged()
+
+    def max_list_len(self):
+        return self.g.max_list_len()
+
+    def gather_rows(self, src, d_list, n, dst):
+        self.g.gather_rows(src.data_ptr(), src.shape[1], d_list, n, dst.data_ptr())
+
+    def shard_export(self, xf, cf, pf, stride, args, vals, ids, off):
+        self.g.ivfpq_shard_export(xf.shape[0], xf.data_ptr(), cf.data_ptr(), pf.data_ptr(), stride, args, vals.data_ptr(),
+                                  ids.data_ptr(), off.data_ptr())
+
+    def merge_replay(self, vals_all, ids_all, off_all, x_slice, stride, k, args, d_list, D, I):
+        W, nf = vals_all.shape[0], vals_all.shape[1]
+        self.g.ivfpq_merge_replay(W, nf, x_slice.data_ptr(), stride, vals_all.data_ptr(), ids_all.data_ptr(), off_all.data_ptr(), k,
+                                  args, d_list, D.data_ptr(), I.data_ptr())
+
 
 def route_update(store, lno, vid, code, owned, held_somewhere):
     """RealTimeMemData::Update (realtime_mem_data.cc:305-327) when the list the vector leaves and the list it joins
@@ -194,6 +215,58 @@ def plan_sub_batches(nq, world, nsub):
     return [(bounds[j], bounds[j + 1]) for j in range(len(bounds) - 1) if bounds[j + 1] > bounds[j] or j == 0]
 
 
+def tie_phase(backend, x_slice, cdis_slice, probe_slice, nql, k, args, D, I, group=None):
+    """Exact ties across shards, after merge_rerank of a (sub-)batch: the slice's owner lists the queries whose result
+    a tie can change; their vectors and assignment rows go to every rank (broadcast), every rank exports the candidate
+    streams over the lists it owns (gamma_hip_ivfpq_shard_export), the exports are gathered and the owner replays the
+    assembled streams through the reference's heaps (gamma_hip_ivfpq_merge_replay): rows of D / I rewritten.  Collective:
+    every rank calls it.  A batch without a flagged query costs one all-gather of a counter (and a wait for the merge)."""
+    if not hasattr(backend, "merge_flagged"):
+        return
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    P = args.p.nprobe
+    nf, d_list = backend.merge_flagged() if nql > 0 else (0, 0)
+    meta = backend.empty((2,), torch.int64)
+    meta[0] = nf
+    meta[1] = backend.max_list_len()
+    allm = backend.empty((world, 2), torch.int64)
+    dist.all_gather_into_tensor(allm.view(-1), meta, group=group)
+    allm = allm.cpu()
+    counts = [int(v) for v in allm[:, 0]]
+    if sum(counts) == 0:
+        return
+    stride = P * max(1, int(allm[:, 1].max()))
+    d = x_slice.shape[1]
+    fcap = max(1, min(1 << 16, (1 << 28) // (12 * stride * world)))
+    for o in range(world):
+        src = dist.get_global_rank(group, o) if group is not None else o
+        for f0 in range(0, counts[o], fcap):
+            n = min(fcap, counts[o] - f0)
+            xf = backend.empty((n, d), torch.float32)
+            cf = backend.empty((n, P), torch.float32)
+            pf = backend.empty((n, P), torch.int32)
+            if rank == o:
+                lst = d_list + 4 * f0
+                backend.gather_rows(x_slice, lst, n, xf)
+                backend.gather_rows(cdis_slice.view(torch.float32), lst, n, cf)
+                backend.gather_rows(probe_slice, lst, n, pf)
+            for t in (xf, cf, pf):
+                dist.broadcast(t, src=src, group=group)
+            vals = backend.empty((n, stride), torch.float32)
+            ids = backend.empty((n, stride), torch.int64)
+            off = backend.empty((n, P + 1), torch.int32)
+            backend.shard_export(xf, cf, pf, stride, args, vals, ids, off)
+            av = backend.empty((world, n, stride), torch.float32)
+            ai = backend.empty((world, n, stride), torch.int64)
+            ao = backend.empty((world, n, P + 1), torch.int32)
+            dist.all_gather_into_tensor(av.view(-1), vals.view(-1), group=group)
+            dist.all_gather_into_tensor(ai.view(-1), ids.view(-1), group=group)
+            dist.all_gather_into_tensor(ao.view(-1), off.view(-1), group=group)
+            if rank == o:
+                backend.merge_replay(av, ai, ao, x_slice, stride, k, args, d_list + 4 * f0, D, I)
+
+
 def sharded_search(backend, x, k, args, group=None, pipeline=None):
     """x: [nq, d] tensor on the backend's device (same on every rank).  Returns (D, I) for all nq
     queries on every rank.  The returned tensors are views of buffers that the next call with the
@@ -271,6 +344,10 @@ def _sharded_search(backend, x, k, args, group, pipeline):
                 I.fill_(-1)
             backend.merge_rerank(b["all_dis"].view(world, per, R), b["all_ids"].view(world, per, R),
                                  sb["x"][sb["q0"]:sb["q1"]], k, args, nql, D, I)
+            if args.p.exact_ties >= 0:   # (the handle's default is on; -1 = off for this request)
+                o0 = rank * per
+                tie_phase(backend, sb["x"][sb["q0"]:sb["q1"]], b["cdis"][o0:o0 + nql], b["probe"][o0:o0 + nql], nql, k, args, D, I,
+                          group)
             pending.append((sb, dist.all_gather_into_tensor(b["res"].view(-1), b["res_l"], group=group, async_op=True)))
         for sb, w in pending:
             w.wait()

@@ -410,8 +410,8 @@ int gamma_hip_ivfpq_merge_replay(gamma_hip_index* h, const gamma_hip_search_para
  * A search: every member runs the coarse quantizer for its slice of the queries, the assignment is exchanged
  * (device-to-device copies), every member scans the probed lists it owns for the whole batch and keeps a local
  * top-recall_num, each member pulls the candidates of ITS query slice from all members, merges them (k_merge_shards) and
- * runs compute_dis.  Results equal those of one handle holding every list: same distances at every rank, same ids
- * up to the order inside exact ties.  The multi-process form of the same steps over RCCL is gamma_amd/dist.py. */
+ * runs compute_dis, then the tie phase above (flagged queries' streams exported by every member, replayed at the owner).
+ * Results equal those of one handle holding every list.  The multi-process form of the same steps over RCCL is gamma_amd/dist.py. */
 typedef struct gamma_hip_group gamma_hip_group;
 int gamma_hip_group_create(const int* devices, int n, gamma_hip_group** out);
 int gamma_hip_group_destroy(gamma_hip_group* g);

@@ -67,6 +67,36 @@ def main():
     D, I = gdist.replicated_search(gdist.HipShardBackend(full, local), x, k, args)
     torch.cuda.synchronize()
     assert D.cpu().numpy().tobytes() == Dref.cpu().numpy().tobytes() and np.array_equal(I.cpu().numpy(), Iref.cpu().numpy())
+    # exact ties across the ranks' shards: tie-heavy data (every base vector four times), labels strictly the pinned
+    # oracle's on the unsharded index (gamma_amd.dist.tie_phase: flagged queries broadcast, candidate streams exported by
+    # every rank, gathered, replayed by the slice's owner)
+    from tests.parity import compare_exact
+    from tests.test_oracle_golden import load_ties
+    z, o, base, metric = load_ties("l2")
+    sizes = z["list_sizes_l2"]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    own = gdist.balance_lists(sizes, world)
+    gt = api.GammaHip(local)
+    gt.ivfpq_init(int(z["d"]), int(z["nlist"]), int(z["M"]), 8, metric)
+    gt.ivfpq_set_trained(z["cc_l2"], z["pq_l2"], None)
+    ls = [l for l in range(int(z["nlist"])) if own[l] == rank and sizes[l]]
+    gt.add_keys_batch(ls, [int(sizes[l]) for l in ls], np.concatenate([z["list_ids_l2"][offs[l]:offs[l + 1]] for l in ls]),
+                      np.concatenate([z["list_codes_l2"][offs[l]:offs[l + 1]] for l in ls]))
+    gt.set_list_mask((np.asarray(own) == rank).astype(np.uint8))
+    gt.raw_init(int(z["d"]))
+    gt.raw_append(base)
+    bt = gdist.HipShardBackend(gt, local)
+    wide = dict(min_score=-3e38, max_score=3e38)
+    for has_rank, reps in ((True, 1), (True, 9), (False, 9)):
+        nprobe, R, kk = 12, 60, 10
+        D1, I1 = o.search(z["q"], kk, nprobe, recall_num=R, has_rank=has_rank, metric=metric, ctx=B.make_ctx(**wide), coarse_mode=0)
+        qh = np.tile(z["q"], (reps, 1))[:len(z["q"]) * reps - (reps > 1)]
+        at = api.SearchArgs(metric=metric, nprobe=nprobe, recall_num=R, has_rank=has_rank, coarse_mode=0, **wide)
+        xt = torch.from_numpy(qh).to(dev)
+        for pipeline in (None, 2):
+            Dt, It = gdist.sharded_search(bt, xt, kk, at, pipeline=pipeline)
+            torch.cuda.synchronize()
+            compare_exact(np.tile(D1, (reps, 1))[:len(qh)], np.tile(I1, (reps, 1))[:len(qh)], Dt.cpu().numpy(), It.cpu().numpy())
     dist.destroy_process_group()
     print("rank %d ok" % rank)
 
