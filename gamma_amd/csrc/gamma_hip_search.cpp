@@ -743,9 +743,16 @@ int compact_lists_for_call(H* h, FiltCtx* fc, int64_t est, bool allowed, ListCom
     const bool want = env ? atoi(env) != 0 : est >= 4 * std::max<int64_t>(1, h->ntotal);
     if (!(need && want && allowed && !fc->d_qf && !h->d_list_mask && h->arena_cap > 0)) return GAMMA_HIP_OK;
     GH_TRY(replay_join(h));   // a deferred replay may still read the shadow lists of the previous call
-    GH_CHECK(h, h->w_cmp_codes.ensure((size_t)h->arena_cap * h->code_size));
-    GH_CHECK(h, h->w_cmp_ids.ensure((size_t)h->arena_cap * sizeof(int64_t)));
-    GH_CHECK(h, h->w_cmp_len.ensure((size_t)h->nlist * sizeof(int)));
+    // the shadow arena is an optimisation: without the memory for it the call runs over the lists as they are, testing
+    // the predicate per scored code (same results)
+    if (h->w_cmp_codes.ensure((size_t)h->arena_cap * h->code_size) != hipSuccess ||
+        h->w_cmp_ids.ensure((size_t)h->arena_cap * sizeof(int64_t)) != hipSuccess ||
+        h->w_cmp_len.ensure((size_t)h->nlist * sizeof(int)) != hipSuccess) {
+        (void)hipGetLastError();
+        h->w_cmp_codes.release();
+        h->w_cmp_ids.release();
+        return GAMMA_HIP_OK;
+    }
     GH_CHECK(h, hipStreamWaitEvent(h->stream, h->ver_ev[h->cur_ver], 0));   // the version's lists are in place
     StageScope t(h, GAMMA_HIP_STAGE_SCAN, false);   // profiled as part of the scan it shortens
     gh::launch_compact_lists(h->stream, h->d_list_off, h->d_list_len, h->nlist, h->d_codes, h->d_ids, h->code_size,

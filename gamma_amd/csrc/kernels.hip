@@ -914,9 +914,47 @@ bool launch_small_coarse_ip(hipStream_t s, const float* x, int nq, int d, const 
     hipLaunchKernelGGL(k_small_coarse_ip, dim3(rb + M), dim3(256), 0, s, x, nq, d, cc, nlist, mat, rb, M, pqc, st2, zero_me);
     return true;
 }
+// Large batches: the kernel is all stores (16 KB of table per query).  A thread keeps FOUR consecutive centroids of its
+// sub-quantizer in registers and writes their four products as one 16-byte store; a workgroup (4 sub-quantizers x 64
+// lanes) covers 4 KB of consecutive table per query, for IPT4_QB queries.  Same fvec_inner_products_ny arithmetic.
+constexpr int IPT4_QB = 32;
+template <int DSUB>
+__global__ __launch_bounds__(256) void k_pq_ip_table4(const float* __restrict__ x, int nq, int d, int M,
+                                                      const float* __restrict__ pqc, float* __restrict__ out) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    float c[4][DSUB];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int t = 0; t < DSUB; t++) c[r][t] = pqc[((int64_t)m * 256 + 4 * lane + r) * DSUB + t];
+    const int q0 = blockIdx.y * IPT4_QB;
+    for (int u = 0; u < IPT4_QB; u++) {
+        const int q = q0 + u;
+        if (q >= nq) break;                                          // uniform
+        const float* xs = x + (int64_t)q * d + m * DSUB;             // wave-uniform
+        float xv[DSUB];
+#pragma unroll
+        for (int t = 0; t < DSUB; t++) xv[t] = xs[t];
+        float4 o;
+        o.x = fvec_ny_row<false>(xv, c[0], DSUB);
+        o.y = fvec_ny_row<false>(xv, c[1], DSUB);
+        o.z = fvec_ny_row<false>(xv, c[2], DSUB);
+        o.w = fvec_ny_row<false>(xv, c[3], DSUB);
+        *reinterpret_cast<float4*>(out + ((int64_t)q * M + m) * 256 + 4 * lane) = o;
+    }
+}
 void launch_pq_ip_table(hipStream_t s, const float* x, int nq, int d, int M, const float* pqc,
                         float* out) {
     if (nq <= 0) return;
+    static const bool no4 = getenv("GAMMA_HIP_NO_IP_TABLE4") != nullptr;
+    const int dsub = d / M;
+    if (!no4 && nq >= 256 && (M & 3) == 0 && (dsub == 4 || dsub == 8 || dsub == 12)) {
+        const dim3 grid(M / 4, (nq + IPT4_QB - 1) / IPT4_QB);
+        if (dsub == 4) hipLaunchKernelGGL(k_pq_ip_table4<4>, grid, dim3(256), 0, s, x, nq, d, M, pqc, out);
+        else if (dsub == 8) hipLaunchKernelGGL(k_pq_ip_table4<8>, grid, dim3(256), 0, s, x, nq, d, M, pqc, out);
+        else hipLaunchKernelGGL(k_pq_ip_table4<12>, grid, dim3(256), 0, s, x, nq, d, M, pqc, out);
+        return;
+    }
     hipLaunchKernelGGL(k_pq_ip_table, dim3(M, (nq + IPT_QB - 1) / IPT_QB), dim3(256), 0, s, x, nq, d, M,
                        d / M, pqc, out);
 }
