@@ -130,9 +130,12 @@ SYMBOLS = {
     "gamma_hip_group_last_error": (C.c_char_p, [C.c_void_p]),
     "gamma_hip_group_set_owners": (C.c_int, [C.c_void_p, i64p]),
     "gamma_hip_group_owner": (C.c_int, [C.c_void_p, C.c_int]),
+    "gamma_hip_ivfpq_shard_cut_flags": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "gamma_hip_ivfpq_merge_set_shard_flags": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gamma_hip_ivfpq_merge_flagged": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
     "gamma_hip_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "gamma_hip_ivfpq_max_list_len": (C.c_int, [C.c_void_p]),
+    "gamma_hip_ivfpq_shard_export_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, i64p]),
     "gamma_hip_ivfpq_shard_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "gamma_hip_ivfpq_merge_replay": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,

@@ -373,6 +373,12 @@ class GammaHip:
                                                      d_all_ids, q0, nq_local, d_D, d_I), "merge_rerank")
 
     # exact ties across list shards (include/gamma_hip.h): all pointers are device addresses (ints)
+    def ivfpq_shard_cut_flags(self, nq, d_flags):
+        self._ck(self.L.gamma_hip_ivfpq_shard_cut_flags(self.h, nq, d_flags), "shard_cut_flags")
+
+    def ivfpq_merge_set_shard_flags(self, d_flags):
+        self._ck(self.L.gamma_hip_ivfpq_merge_set_shard_flags(self.h, d_flags), "merge_set_shard_flags")
+
     def ivfpq_merge_flagged(self):
         """(n_flagged, device address of the int32 list of flagged slice-local queries) after ivfpq_merge_rerank"""
         import ctypes as C
@@ -386,6 +392,11 @@ class GammaHip:
 
     def max_list_len(self):
         return self.L.gamma_hip_ivfpq_max_list_len(self.h)
+
+    def ivfpq_shard_export_rows(self, nf, d_probe_f, args):
+        out = np.zeros(1, dtype=np.int64)
+        self._ck(self.L.gamma_hip_ivfpq_shard_export_rows(self.h, args.ref(), nf, d_probe_f, _p(out, _lib.i64p)), "shard_export_rows")
+        return int(out[0])
 
     def ivfpq_shard_export(self, nf, d_xf, d_cdis_f, d_probe_f, stride, args, d_vals, d_ids, d_off):
         self._ck(self.L.gamma_hip_ivfpq_shard_export(self.h, args.ref(), nf, d_xf, d_cdis_f, d_probe_f, stride, d_vals, d_ids,

@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <map>
@@ -82,7 +83,7 @@ struct gamma_hip_group {
     struct Member {
         GBuf x, cdis, probe, rdis, rids, all_dis, all_ids, D, I;
         // exact ties across members: flagged queries' inputs (owner side / shard side), exports, the owner's copy of all exports
-        GBuf fx, fcd, fpr, sx, scd, spr, ex_vals, ex_ids, ex_off, av, ai, ao;
+        GBuf fx, fcd, fpr, sx, scd, spr, ex_vals, ex_ids, ex_off, av, ai, ao, cutf, cutall;
         hipEvent_t ev_coarse = nullptr, ev_scan = nullptr, ev_tie = nullptr;
     };
     std::vector<Member> mb;
@@ -205,7 +206,7 @@ int gamma_hip_group_destroy(gamma_hip_group* g) {
         (void)gamma_hip_synchronize(g->m[i]);
         gamma_hip_group::Member& b = g->mb[i];
         for (GBuf* p : {&b.x, &b.cdis, &b.probe, &b.rdis, &b.rids, &b.all_dis, &b.all_ids, &b.D, &b.I, &b.fx, &b.fcd, &b.fpr, &b.sx,
-                        &b.scd, &b.spr, &b.ex_vals, &b.ex_ids, &b.ex_off, &b.av, &b.ai, &b.ao})
+                        &b.scd, &b.spr, &b.ex_vals, &b.ex_ids, &b.ex_off, &b.av, &b.ai, &b.ao, &b.cutf, &b.cutall})
             p->release();
         if (b.ev_tie) (void)hipEventDestroy(b.ev_tie);
         if (b.ev_coarse) (void)hipEventDestroy(b.ev_coarse);
@@ -492,6 +493,7 @@ static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, in
     const int per = (nq + W - 1) / W;
     std::vector<int> rcs(W, GAMMA_HIP_OK);
     std::vector<std::string> errs(W);
+    std::vector<int64_t> rowmax(W, 0);                 // tie phase: every member's longest export row of the round
     std::vector<int> nfl(W, 0);                        // flagged queries of every member's slice
     std::vector<const int32_t*> lists(W, nullptr);     // and the device lists of their slice-local indices
     auto slice = [&](int i, int* q0, int* q1) {
@@ -599,6 +601,9 @@ static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, in
             if (rc == GAMMA_HIP_OK)
                 abi(gamma_hip_ivfpq_search_shard_preassigned(h, &pp, nq, b.x.as<float>(), b.cdis.as<float>(), b.probe.as<int32_t>(), k,
                                                              b.rdis.as<float>(), b.rids.as<int64_t>()));
+            // did this member's own top-R cut of a query go through a tie?  (the merge at the query's owner asks)
+            hip(b.cutf.ensure((size_t)nq), "alloc");
+            if (rc == GAMMA_HIP_OK) abi(gamma_hip_ivfpq_shard_cut_flags(h, nq, b.cutf.as<uint8_t>()));
             hip(hipEventRecord(b.ev_scan, s), "record");
         }
         g->bar.arrive();   // every member's candidate tables are on its stream
@@ -614,34 +619,39 @@ static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, in
                 hip(copy_between(b.all_ids.as<int64_t>() + (size_t)j * per * R, g->dev[i], g->mb[j].rids.as<int64_t>() + (size_t)q0 * R,
                                  g->dev[j], (size_t)nql * R * sizeof(int64_t), s), "candidate exchange");
             }
+            hip(b.cutall.ensure((size_t)W * per), "alloc");
+            for (int j = 0; j < W && rc == GAMMA_HIP_OK; j++)
+                hip(copy_between(b.cutall.as<uint8_t>() + (size_t)j * per, g->dev[i], g->mb[j].cutf.as<uint8_t>() + q0, g->dev[j], (size_t)nql, s),
+                    "cut flags");
+            if (rc == GAMMA_HIP_OK) abi(gamma_hip_ivfpq_merge_set_shard_flags(h, b.cutall.as<uint8_t>()));
             if (rc == GAMMA_HIP_OK)
                 abi(gamma_hip_ivfpq_merge_rerank(h, &pp, W, per, b.x.as<float>() + (size_t)q0 * d, k, b.all_dis.as<float>(),
                                                  b.all_ids.as<int64_t>(), 0, nql, b.D.as<float>(), b.I.as<int64_t>()));
         }
         // 4. exact ties across members (include/gamma_hip.h): the queries a tie can change, listed by their owner, get their
         //    candidate streams exported by every member and replayed at the owner
+        static const bool gdbg = getenv("GAMMA_HIP_GROUP_DBG") != nullptr;
+        const auto tp0 = std::chrono::steady_clock::now();
+        auto since = [&](std::chrono::steady_clock::time_point t) {
+            return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+        };
         {
             int nf_i = 0;
             const int32_t* list_i = nullptr;
             if (all_ok && nql > 0 && rc == GAMMA_HIP_OK) abi(gamma_hip_ivfpq_merge_flagged(h, &nf_i, &list_i));
             nfl[i] = rc == GAMMA_HIP_OK ? nf_i : 0;
             lists[i] = list_i;
+            if (gdbg && i == 0) fprintf(stderr, "group: member 0 waited %.3f ms for its merge, %d flagged\n", since(tp0), nf_i);
             g->bar.arrive();
             all_ok = true;
             for (int j = 0; j < W; j++) all_ok = all_ok && rcs[j] == GAMMA_HIP_OK;
             int total = 0;
             for (int j = 0; j < W; j++) total += nfl[j];
             if (all_ok && total > 0) {
-                int64_t maxlen = 1;
-                for (int j = 0; j < W; j++) maxlen = std::max<int64_t>(maxlen, gamma_hip_ivfpq_max_list_len(g->m[j]));
-                const int64_t stride = (int64_t)P * maxlen;
-                // flagged queries per round: the owner holds W exports of `stride` entries (12 bytes) per query
-                const int fcap = (int)std::max<int64_t>(1, std::min<int64_t>(1 << 16, ((int64_t)1 << 30) / (12 * stride * W)));
+                const int fcap = 256;   // flagged queries per round
                 for (int o = 0; o < W; o++) {
                     for (int f0 = 0; f0 < nfl[o]; f0 += fcap) {
                         const int nf = std::min(fcap, nfl[o] - f0);
-                        int oq0, oq1;
-                        slice(o, &oq0, &oq1);
                         if (i == o) {   // the flagged queries' vectors and assignment rows, compact
                             hip(b.fx.ensure((size_t)nf * d * sizeof(float)), "alloc");
                             hip(b.fcd.ensure((size_t)nf * P * sizeof(float)), "alloc");
@@ -658,20 +668,30 @@ static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, in
                         hip(b.sx.ensure((size_t)nf * d * sizeof(float)), "alloc");
                         hip(b.scd.ensure((size_t)nf * P * sizeof(float)), "alloc");
                         hip(b.spr.ensure((size_t)nf * P * sizeof(int32_t)), "alloc");
-                        hip(b.ex_vals.ensure((size_t)nf * stride * sizeof(float)), "alloc");
-                        hip(b.ex_ids.ensure((size_t)nf * stride * sizeof(int64_t)), "alloc");
                         hip(b.ex_off.ensure((size_t)nf * (P + 1) * sizeof(int32_t)), "alloc");
                         bool ok2 = true;
                         for (int j = 0; j < W; j++) ok2 = ok2 && rcs[j] == GAMMA_HIP_OK;
+                        rowmax[i] = 0;
                         if (ok2 && rc == GAMMA_HIP_OK) {
                             if (i != o) hip(hipStreamWaitEvent(s, ob.ev_tie, 0), "wait");
                             hip(copy_between(b.sx.p, g->dev[i], ob.fx.p, g->dev[o], (size_t)nf * d * sizeof(float), s), "tie inputs");
                             hip(copy_between(b.scd.p, g->dev[i], ob.fcd.p, g->dev[o], (size_t)nf * P * sizeof(float), s), "tie inputs");
                             hip(copy_between(b.spr.p, g->dev[i], ob.fpr.p, g->dev[o], (size_t)nf * P * sizeof(int32_t), s), "tie inputs");
-                            if (rc == GAMMA_HIP_OK)
-                                abi(gamma_hip_ivfpq_shard_export(h, &pp, nf, b.sx.as<float>(), b.scd.as<float>(), b.spr.as<int32_t>(), stride,
-                                                                 b.ex_vals.as<float>(), b.ex_ids.as<int64_t>(), b.ex_off.as<int32_t>()));
+                            // how long this member's export rows get: the exports of all members share one row stride
+                            int64_t mine = 0;
+                            if (rc == GAMMA_HIP_OK) abi(gamma_hip_ivfpq_shard_export_rows(h, &pp, nf, b.spr.as<int32_t>(), &mine));
+                            rowmax[i] = mine;
                         }
+                        g->bar.arrive();   // every member's longest row is known
+                        int64_t stride = 4;
+                        for (int j = 0; j < W; j++) stride = std::max<int64_t>(stride, (rowmax[j] + 3) & ~(int64_t)3);
+                        ok2 = true;
+                        for (int j = 0; j < W; j++) ok2 = ok2 && rcs[j] == GAMMA_HIP_OK;
+                        hip(b.ex_vals.ensure((size_t)nf * stride * sizeof(float)), "alloc");
+                        hip(b.ex_ids.ensure((size_t)nf * stride * sizeof(int64_t)), "alloc");
+                        if (ok2 && rc == GAMMA_HIP_OK)
+                            abi(gamma_hip_ivfpq_shard_export(h, &pp, nf, b.sx.as<float>(), b.scd.as<float>(), b.spr.as<int32_t>(), stride,
+                                                             b.ex_vals.as<float>(), b.ex_ids.as<int64_t>(), b.ex_off.as<int32_t>()));
                         hip(hipStreamSynchronize(s), "sync");
                         g->bar.arrive();   // every member's export is complete
                         ok2 = true;
@@ -699,6 +719,7 @@ static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, in
                 }
             }
         }
+        if (gdbg && i == 0) fprintf(stderr, "group: tie phase done %.3f ms after the merge was enqueued\n", since(tp0));
         all_ok = true;
         for (int j = 0; j < W; j++) all_ok = all_ok && rcs[j] == GAMMA_HIP_OK;
         if (all_ok && nql > 0) {   // the slice's rows to the caller

@@ -101,6 +101,8 @@ struct gamma_hip_index {
     hipEvent_t ev_rfork = nullptr, ev_rdone = nullptr;
     bool defer_replay = false, defer_now = false, replay_pending = false;
     bool merge_flags = false;   // the last gamma_hip_ivfpq_merge_rerank left tie flags of its slice in w_tlist
+    int shard_cut_nq = 0;       // the last shard search left the cut-tie flags of its nq queries in w_tcut
+    const uint8_t* merge_shard_flags = nullptr;   // [nshards][nq] for the next merge (gamma_hip_ivfpq_merge_set_shard_flags)
     int merge_nql = 0;
     std::mutex mu, search_mu, writer_mu;
     WriteLock* wl = nullptr;   // the writer holding mu (for exclusive() deep inside the arena code)

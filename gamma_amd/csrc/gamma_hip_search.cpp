@@ -287,7 +287,10 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     // exact ties (ties.hip): queries whose top-R cut goes through a group of equal ADC distances are marked here
     // and redone by the replay at the end of stage B
     h->tie = H::TieCtx();
-    h->tie.on = h->exact_ties && !shard && R <= gh::tie_replay_max_k() && P <= gh::tie_replay_max_probes();
+    // (a shard marks the cut ties of its own top-R too: the merge at the slice's owner asks for them,
+    //  gamma_hip_ivfpq_shard_cut_flags)
+    h->tie.on = h->exact_ties && R <= gh::tie_replay_max_k() && P <= gh::tie_replay_max_probes();
+    h->shard_cut_nq = (shard && h->tie.on) ? nq : 0;
     // Threshold pre-filter: scan the nearest probe group first, bound each query's R-th best
     // distance from it, and let the scan of the remaining groups keep a short survivor list per
     // query; the exact top-R then comes from a few hundred survivors instead of ~10^4 candidates
@@ -1499,10 +1502,32 @@ int gamma_hip_ivfpq_merge_rerank(gamma_hip_index* h, const gamma_hip_search_para
         GH_CHECK(h, h->w_tlist.ensure(((size_t)nq_local + 1) * sizeof(int)));
         GH_CHECK(h, hipMemsetAsync(h->w_tlist.p, 0, sizeof(int), s));
         gh::launch_flag_merge_cut(s, d_all_dis, nshards, nq, R, q0, nq_local, h->w_cand_dis.as<float>(), h->w_cand_ids.as<int64_t>(),
-                                  h->w_tcut.as<uint8_t>());
+                                  h->w_tcut.as<uint8_t>(), h->merge_shard_flags);
+        h->merge_shard_flags = nullptr;   // one merge
     }
     return ivfpq_stage_b(h, p, nq_local, d_x + (size_t)q0 * h->d, R, k, h->w_cand_dis.as<float>(),
                          h->w_cand_ids.as<int64_t>(), d_distances, d_labels, nullptr, ties ? 2 : 0);
+}
+
+int gamma_hip_ivfpq_shard_cut_flags(gamma_hip_index* h, int nq, uint8_t* d_flags) {
+    if (!h || nq < 0 || (nq > 0 && !d_flags)) return GAMMA_HIP_EINVAL;
+    if (nq == 0) return GAMMA_HIP_OK;
+    SearchLock lk(h);
+    GH_CHECK(h, hipSetDevice(h->device));
+    if (h->shard_cut_nq == nq) {
+        GH_CHECK(h, hipMemcpyAsync(d_flags, h->w_tcut.p, (size_t)nq, hipMemcpyDeviceToDevice, h->stream));
+    } else {
+        // no flags from the last shard search (exact ties off, or beyond the replay's range): "may have cut a tie"
+        GH_CHECK(h, hipMemsetAsync(d_flags, 1, (size_t)nq, h->stream));
+    }
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_merge_set_shard_flags(gamma_hip_index* h, const uint8_t* d_flags) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    h->merge_shard_flags = d_flags;
+    return GAMMA_HIP_OK;
 }
 
 int gamma_hip_ivfpq_merge_flagged(gamma_hip_index* h, int* n_flagged, const int32_t** d_list) {
@@ -1533,6 +1558,27 @@ int gamma_hip_gather_rows(gamma_hip_index* h, const void* d_src, int row_words, 
     return GAMMA_HIP_OK;
 }
 
+int gamma_hip_ivfpq_shard_export_rows(gamma_hip_index* h, const gamma_hip_search_params* p, int nf, const int32_t* d_probe_f,
+                                      int64_t* max_entries) {
+    if (!h || !p || !max_entries) return GAMMA_HIP_EINVAL;
+    *max_entries = 0;
+    if (nf <= 0) return GAMMA_HIP_OK;
+    if (!d_probe_f) return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    GH_TRY(replay_join(h));
+    if (!h->ivf_init || h->ivfflat) return fail(h, GAMMA_HIP_EINVAL, "ivfpq not initialised");
+    GH_CHECK(h, hipSetDevice(h->device));
+    GH_CHECK(h, h->w_qtotal.ensure(sizeof(int)));
+    GH_CHECK(h, hipMemsetAsync(h->w_qtotal.p, 0, sizeof(int), h->stream));
+    GH_CHECK(h, hipStreamWaitEvent(h->stream, h->ver_ev[h->cur_ver], 0));
+    gh::launch_shard_export_rows(h->stream, d_probe_f, nf, p->nprobe, h->d_list_len, h->d_list_mask, h->nlist, h->w_qtotal.as<int>());
+    int mx = 0;
+    GH_CHECK(h, hipMemcpyAsync(&mx, h->w_qtotal.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    *max_entries = mx;
+    return GAMMA_HIP_OK;
+}
+
 int gamma_hip_ivfpq_shard_export(gamma_hip_index* h, const gamma_hip_search_params* p, int nf, const float* d_xf,
                                  const float* d_cdis_f, const int32_t* d_probe_f, int64_t stride, float* d_vals, int64_t* d_ids,
                                  int32_t* d_off) {
@@ -1545,7 +1591,7 @@ int gamma_hip_ivfpq_shard_export(gamma_hip_index* h, const gamma_hip_search_para
     if (p->nprobe > gh::tie_replay_max_probes()) return fail(h, GAMMA_HIP_EINVAL, "nprobe beyond the replay's range");
     GH_CHECK(h, hipSetDevice(h->device));
     const int P = p->nprobe, R = std::max(p->recall_num, 1);
-    if (stride < (int64_t)P * std::max(1, h->max_list_len)) return fail(h, GAMMA_HIP_EINVAL, "stride below nprobe x longest list");
+    if (stride < 1) return fail(h, GAMMA_HIP_EINVAL, "stride");
     gh::FilterDesc filt;
     GH_TRY(build_filter(h, p, &filt));
     FiltCtx fc;
@@ -1591,21 +1637,22 @@ int gamma_hip_ivfpq_merge_replay(gamma_hip_index* h, const gamma_hip_search_para
     if (R > gh::tie_replay_max_k() || P > gh::tie_replay_max_probes()) return fail(h, GAMMA_HIP_EINVAL, "beyond the replay's range");
     if (p->has_rank && (!h->d_raw || h->raw_d != h->d)) return fail(h, GAMMA_HIP_EINVAL, "has_rank needs the raw store");
     hipStream_t s = h->stream;
-    GH_CHECK(h, h->w_mr_vals.ensure((size_t)nf * stride * sizeof(float)));
-    GH_CHECK(h, h->w_mr_ids.ensure((size_t)nf * stride * sizeof(int64_t)));
+    const int64_t mstride = ((int64_t)nshards * stride + 3) & ~(int64_t)3;   // a row assembled from every shard's export
+    GH_CHECK(h, h->w_mr_vals.ensure((size_t)nf * mstride * sizeof(float)));
+    GH_CHECK(h, h->w_mr_ids.ensure((size_t)nf * mstride * sizeof(int64_t)));
     GH_CHECK(h, h->w_mr_meta.ensure((size_t)nf * (P + 1) * sizeof(int32_t) + (size_t)nf * P * sizeof(int64_t) + 64));
     int64_t* m_base = h->w_mr_meta.as<int64_t>();
     int* count = reinterpret_cast<int*>(m_base + (size_t)nf * P);
     int32_t* m_off = count + 16;
     GH_CHECK(h, hipMemcpyAsync(count, &nf, sizeof(int), hipMemcpyHostToDevice, s));
-    gh::launch_merge_streams(s, nshards, nf, P, stride, d_vals_all, d_ids_all, d_off_all, h->w_mr_vals.as<float>(),
+    gh::launch_merge_streams(s, nshards, nf, P, stride, mstride, d_vals_all, d_ids_all, d_off_all, h->w_mr_vals.as<float>(),
                              h->w_mr_ids.as<int64_t>(), m_off, m_base, l2 ? INFINITY : -INFINITY);
     gh::TieReplayArgs a;
     a.list = d_list;
     a.count = count;
     a.nq = nf;
     a.slab = h->w_mr_vals.as<float>();
-    a.q_stride = stride;
+    a.q_stride = mstride;
     a.pair_off = m_off;
     a.pair_base = m_base;
     a.ids = h->w_mr_ids.as<int64_t>();

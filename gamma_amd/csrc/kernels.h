@@ -302,11 +302,13 @@ void launch_flat_take_flag(hipStream_t s, const float* D1, const int64_t* I1, in
 // exact ties across list shards (ties.hip): cut-tie flags of the merged tables, a shard's export of the flagged queries'
 // candidate streams, the owner's assembly of the exports
 void launch_flag_merge_cut(hipStream_t s, const float* all_dis, int W, int nq, int R, int q0, int nql, const float* merged,
-                           const int64_t* merged_ids, uint8_t* tcut);
+                           const int64_t* merged_ids, uint8_t* tcut, const uint8_t* shard_flags = nullptr);
 void launch_shard_export(hipStream_t s, const int32_t* probe, int nf, int P, const int* list_len, const int64_t* list_off,
                          const uint8_t* list_mask, int nlist, const int64_t* ids, const float* slab, int64_t q_stride,
                          int64_t stride, float* vals, int64_t* out_ids, int32_t* off);
-void launch_merge_streams(hipStream_t s, int W, int nf, int P, int64_t stride, const float* vals, const int64_t* ids,
+void launch_shard_export_rows(hipStream_t s, const int32_t* probe, int nf, int P, const int* list_len, const uint8_t* list_mask,
+                              int nlist, int* max_entries);
+void launch_merge_streams(hipStream_t s, int W, int nf, int P, int64_t stride, int64_t mstride, const float* vals, const int64_t* ids,
                           const int32_t* off, float* m_vals, int64_t* m_ids, int32_t* m_off, int64_t* m_base, float sentinel);
 void launch_gather_words(hipStream_t s, const void* src, const int* list, int n, int words, void* out);
 // out[i] = x[list[i]] for i < n (rows of d floats)

@@ -184,10 +184,11 @@ void launch_gather_rows(hipStream_t s, const float* x, const int* list, int n, i
 // ------------------------------------------------------------------------------------
 // does the merged top-R cut of a slice query go through a group of equal distances?  One wave per query: entries equal
 // to the R-th merged value in all W tables against those that made it into the merged table.  A shard's own cut may
-// have dropped members of the group (its table is full and ends at that value): counted as a tie as well.
+// have dropped members of the group: its table ends at that value and its own selection says the cut went through a tie
+// (shard_flags [W][nq], gamma_hip_ivfpq_shard_cut_flags; without them every such table counts).
 __global__ __launch_bounds__(256) void k_flag_merge_cut(const float* __restrict__ all_dis, int W, int nq, int R, int q0, int nql,
                                                         const float* __restrict__ merged, const int64_t* __restrict__ merged_ids,
-                                                        uint8_t* __restrict__ tcut) {
+                                                        uint8_t* __restrict__ tcut, const uint8_t* __restrict__ shard_flags) {
     const int lane = threadIdx.x & 63;
     const int ql = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ql >= nql) return;
@@ -199,7 +200,8 @@ __global__ __launch_bounds__(256) void k_flag_merge_cut(const float* __restrict_
     for (int w = 0; w < W; w++) {
         const float* row = all_dis + ((int64_t)w * nq + q0 + ql) * R;
         for (int r = lane; r < R; r += 64) in_all += row[r] == vk ? 1 : 0;
-        if (lane == 0 && row[R - 1] == vk) shard_cut = 1;   // (an empty slot holds +-inf, never a real value)
+        // the shard's own cut went through a tie (its flag; without flags: assumed) and ended at this very value
+        if (lane == 0 && row[R - 1] == vk && (!shard_flags || shard_flags[(int64_t)w * nq + q0 + ql])) shard_cut = 1;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -210,10 +212,10 @@ __global__ __launch_bounds__(256) void k_flag_merge_cut(const float* __restrict_
     if (lane == 0 && (in_all > in_m || shard_cut)) tcut[ql] = 1;
 }
 void launch_flag_merge_cut(hipStream_t s, const float* all_dis, int W, int nq, int R, int q0, int nql, const float* merged,
-                           const int64_t* merged_ids, uint8_t* tcut) {
+                           const int64_t* merged_ids, uint8_t* tcut, const uint8_t* shard_flags) {
     if (nql > 0)
         hipLaunchKernelGGL(k_flag_merge_cut, dim3((nql + 3) / 4), dim3(256), 0, s, all_dis, W, nq, R, q0, nql, merged,
-                           merged_ids, tcut);
+                           merged_ids, tcut, shard_flags);
 }
 
 // one workgroup per exported query f: off[f][p] = start of probe p's entries in the row (probes of lists this shard
@@ -252,6 +254,25 @@ __global__ __launch_bounds__(256) void k_shard_export(const int32_t* __restrict_
         out_ids[(int64_t)f * stride + j] = ids[s_base[lo] + (j - s_off[lo])] & 0x7fffffffffffffffLL;
     }
 }
+// the longest export row of nf queries on this shard: sum of the lengths of the probed lists it owns
+__global__ __launch_bounds__(256) void k_shard_export_rows(const int32_t* __restrict__ probe, int nf, int P,
+                                                           const int* __restrict__ list_len, const uint8_t* __restrict__ list_mask,
+                                                           int nlist, int* __restrict__ max_entries) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= nf) return;
+    int tot = 0;
+    for (int pi = 0; pi < P; pi++) {
+        const int l = probe[(int64_t)f * P + pi];
+        if (l >= 0 && l < nlist && (!list_mask || list_mask[l])) tot += list_len[l];
+    }
+    atomicMax(max_entries, tot);
+}
+void launch_shard_export_rows(hipStream_t s, const int32_t* probe, int nf, int P, const int* list_len, const uint8_t* list_mask,
+                              int nlist, int* max_entries) {
+    if (nf > 0)
+        hipLaunchKernelGGL(k_shard_export_rows, dim3((nf + 255) / 256), dim3(256), 0, s, probe, nf, P, list_len, list_mask, nlist,
+                           max_entries);
+}
 void launch_shard_export(hipStream_t s, const int32_t* probe, int nf, int P, const int* list_len, const int64_t* list_off,
                          const uint8_t* list_mask, int nlist, const int64_t* ids, const float* slab, int64_t q_stride,
                          int64_t stride, float* vals, int64_t* out_ids, int32_t* off) {
@@ -261,8 +282,8 @@ void launch_shard_export(hipStream_t s, const int32_t* probe, int nf, int P, con
 }
 
 // one workgroup per flagged query f: the W exports [W][nf][stride] / [W][nf][P + 1] -> ONE row in probe order
-// (m_off[f][P + 1], m_base[f][p] = f * stride + m_off[f][p]: the replay's pair_off / pair_base over m_ids as its id arena)
-__global__ __launch_bounds__(256) void k_merge_streams(int W, int nf, int P, int64_t stride, const float* __restrict__ vals,
+// of mstride entries (m_off[f][P + 1], m_base[f][p] = f * mstride + m_off[f][p]: the replay's pair_off / pair_base over m_ids)
+__global__ __launch_bounds__(256) void k_merge_streams(int W, int nf, int P, int64_t stride, int64_t mstride, const float* __restrict__ vals,
                                                        const int64_t* __restrict__ ids, const int32_t* __restrict__ off,
                                                        float* __restrict__ m_vals, int64_t* __restrict__ m_ids,
                                                        int32_t* __restrict__ m_off, int64_t* __restrict__ m_base, float sentinel) {
@@ -283,7 +304,7 @@ __global__ __launch_bounds__(256) void k_merge_streams(int W, int nf, int P, int
                     len = lw;
                 }
             }
-            if ((int64_t)at + len > stride) len = (int)max((int64_t)0, stride - at);   // cannot happen with the stride the callers size
+            if ((int64_t)at + len > mstride) len = (int)max((int64_t)0, mstride - at);   // cannot happen: mstride = W x stride
             s_moff[pi] = at;
             s_src[pi] = src;
             s_soff[pi] = so;
@@ -293,7 +314,7 @@ __global__ __launch_bounds__(256) void k_merge_streams(int W, int nf, int P, int
     }
     __syncthreads();
     for (int pi = tid; pi <= P; pi += 256) m_off[(int64_t)f * (P + 1) + pi] = s_moff[pi];
-    for (int pi = tid; pi < P; pi += 256) m_base[(int64_t)f * P + pi] = (int64_t)f * stride + s_moff[pi];
+    for (int pi = tid; pi < P; pi += 256) m_base[(int64_t)f * P + pi] = (int64_t)f * mstride + s_moff[pi];
     const int n = s_moff[P];
     for (int j = tid; j < n; j += 256) {
         int lo = 0, hi = P - 1;
@@ -303,15 +324,15 @@ __global__ __launch_bounds__(256) void k_merge_streams(int W, int nf, int P, int
         }
         const int w = s_src[lo];
         const int64_t at = ((int64_t)w * nf + f) * stride + s_soff[lo] + (j - s_moff[lo]);
-        m_vals[(int64_t)f * stride + j] = w >= 0 ? vals[at] : sentinel;
-        m_ids[(int64_t)f * stride + j] = w >= 0 ? ids[at] : -1;
+        m_vals[(int64_t)f * mstride + j] = w >= 0 ? vals[at] : sentinel;
+        m_ids[(int64_t)f * mstride + j] = w >= 0 ? ids[at] : -1;
     }
 }
-void launch_merge_streams(hipStream_t s, int W, int nf, int P, int64_t stride, const float* vals, const int64_t* ids,
+void launch_merge_streams(hipStream_t s, int W, int nf, int P, int64_t stride, int64_t mstride, const float* vals, const int64_t* ids,
                           const int32_t* off, float* m_vals, int64_t* m_ids, int32_t* m_off, int64_t* m_base, float sentinel) {
     if (nf > 0)
-        hipLaunchKernelGGL(k_merge_streams, dim3(nf), dim3(256), 0, s, W, nf, P, stride, vals, ids, off, m_vals, m_ids, m_off,
-                           m_base, sentinel);
+        hipLaunchKernelGGL(k_merge_streams, dim3(nf), dim3(256), 0, s, W, nf, P, stride, mstride, vals, ids, off, m_vals, m_ids,
+                           m_off, m_base, sentinel);
 }
 
 // rows of `words` 32-bit words: out[i] = src[list[i]]

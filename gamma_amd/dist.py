@@ -105,6 +105,14 @@ class HipShardBackend:
                                       all_ids.data_ptr(), 0, nql, D.data_ptr(), I.data_ptr())
 
     # ---- exact ties across shards (include/gamma_hip.h; tie_phase below) ----
+    def shard_cut_flags(self, n, flags):
+        """flags[q] != 0: this shard's own top-R cut of query q went through a group of equal distances"""
+        if n > 0:
+            self.g.ivfpq_shard_cut_flags(n, flags.data_ptr())
+
+    def merge_set_shard_flags(self, flags):
+        self.g.ivfpq_merge_set_shard_flags(flags.data_ptr())
+
     def merge_flagged(self):
         """(number of the slice's queries a tie can change, device address of their slice-local indices); waits for the
         handle's stream"""
@@ -115,6 +123,10 @@ class HipShardBackend:
 
     def gather_rows(self, src, d_list, n, dst):
         self.g.gather_rows(src.data_ptr(), src.shape[1], d_list, n, dst.data_ptr())
+
+    def shard_export_rows(self, pf, args):
+        """the longest export row of these queries on this shard (entries of the probed lists it owns)"""
+        return self.g.ivfpq_shard_export_rows(pf.shape[0], pf.data_ptr(), args)
 
     def shard_export(self, xf, cf, pf, stride, args, vals, ids, off):
         self.g.ivfpq_shard_export(xf.shape[0], xf.data_ptr(), cf.data_ptr(), pf.data_ptr(), stride, args, vals.data_ptr(),
@@ -185,6 +197,7 @@ def _buffers(backend, world, pers, P, R, k):
                 cdis=backend.empty((world * per, P), f32), probe=backend.empty((world * per, P), i32),
                 rdis=backend.empty((world * per, R), f32), rids=backend.empty((world * per, R), i64),
                 all_dis=backend.empty((world * per, R), f32), all_ids=backend.empty((world * per, R), i64),
+                cutf=backend.empty((world * per,), u8), cutall=backend.empty((world * per,), u8),
                 res_l=res_l, I=res_l[:nres * 8].view(i64).view(per, k),
                 D=res_l[nres * 8:nres * 12].view(f32).view(per, k),
                 res=backend.empty((world, res_bytes), u8)))
@@ -227,18 +240,15 @@ def tie_phase(backend, x_slice, cdis_slice, probe_slice, nql, k, args, D, I, gro
     rank = dist.get_rank(group)
     P = args.p.nprobe
     nf, d_list = backend.merge_flagged() if nql > 0 else (0, 0)
-    meta = backend.empty((2,), torch.int64)
+    meta = backend.empty((1,), torch.int64)
     meta[0] = nf
-    meta[1] = backend.max_list_len()
-    allm = backend.empty((world, 2), torch.int64)
-    dist.all_gather_into_tensor(allm.view(-1), meta, group=group)
-    allm = allm.cpu()
-    counts = [int(v) for v in allm[:, 0]]
+    allm = backend.empty((world,), torch.int64)
+    dist.all_gather_into_tensor(allm, meta, group=group)
+    counts = [int(v) for v in allm.cpu()]
     if sum(counts) == 0:
         return
-    stride = P * max(1, int(allm[:, 1].max()))
     d = x_slice.shape[1]
-    fcap = max(1, min(1 << 16, (1 << 28) // (12 * stride * world)))
+    fcap = 256
     for o in range(world):
         src = dist.get_global_rank(group, o) if group is not None else o
         for f0 in range(0, counts[o], fcap):
@@ -253,6 +263,10 @@ def tie_phase(backend, x_slice, cdis_slice, probe_slice, nql, k, args, D, I, gro
                 backend.gather_rows(probe_slice, lst, n, pf)
             for t in (xf, cf, pf):
                 dist.broadcast(t, src=src, group=group)
+            # one row stride for the exports of all ranks: the longest row any of them has for these queries
+            meta[0] = backend.shard_export_rows(pf, args)
+            dist.all_reduce(meta, op=dist.ReduceOp.MAX, group=group)
+            stride = max(4, (int(meta.item()) + 3) // 4 * 4)
             vals = backend.empty((n, stride), torch.float32)
             ids = backend.empty((n, stride), torch.int64)
             off = backend.empty((n, P + 1), torch.int32)
@@ -332,6 +346,12 @@ def _sharded_search(backend, x, k, args, group, pipeline):
                 rids[n:].fill_(-1)
             backend.search_shard(sb["x"], b["cdis"][:n], b["probe"][:n], k, args, rdis[:n], rids[:n])
             sb["w"] = _exchange(rdis, rids, b["all_dis"], b["all_ids"], group)
+            if hasattr(backend, "shard_cut_flags") and args.p.exact_ties >= 0:
+                # did this shard's own top-R cut of a query go through a tie?  One byte per query to the query's owner
+                if n < world * per:
+                    b["cutf"][n:].zero_()
+                backend.shard_cut_flags(n, b["cutf"])
+                sb["w"].append(dist.all_to_all_single(b["cutall"], b["cutf"], group=group, async_op=True))
         # 3. merge + compute_dis for the own slice, results all-gathered into the common table
         pending = []
         for sb in subs:
@@ -342,6 +362,8 @@ def _sharded_search(backend, x, k, args, group, pipeline):
             if nql < per:
                 D.zero_()
                 I.fill_(-1)
+            if hasattr(backend, "shard_cut_flags") and args.p.exact_ties >= 0 and nql > 0:
+                backend.merge_set_shard_flags(b["cutall"])
             backend.merge_rerank(b["all_dis"].view(world, per, R), b["all_ids"].view(world, per, R),
                                  sb["x"][sb["q0"]:sb["q1"]], k, args, nql, D, I)
             if args.p.exact_ties >= 0:   # (the handle's default is on; -1 = off for this request)

@@ -379,20 +379,31 @@ int gamma_hip_flat_search_device(gamma_hip_index* h, const gamma_hip_search_para
  * own cut may have dropped members of the group).  Those are replayed through the reference's heaps over the stream its
  * scanner saw (faiss:utils/Heap.h:103-131, gamma_index_ivfpq.h:363-369, gamma_index_ivfpq.cc:664-696) -- which is
  * spread over the shards:
+ *   shard_cut_flags after a shard search of nq queries: d_flags[q] != 0 = the shard's own top-recall_num cut went through
+ *                   a group of equal distances (it may have dropped members of the group);
+ *   merge_set_shard_flags  before merge_rerank: those flags of every shard for the merge's queries, [nshards][nq] (the
+ *                   layout of d_all_dis without the recall_num axis); without them a shard table that ends at the merged
+ *                   cut value is assumed to have cut a tie (more queries replayed, same results);
  *   merge_flagged   n_flagged (host; waits for the handle's stream) and the device list of flagged slice-local query
  *                   indices (valid until the next search-type call on the handle);
  *   gather_rows     d_dst[i] = row d_list[i] of d_src (rows of row_words 32-bit words): the flagged queries' vectors and
  *                   assignment rows for the shards;
+ *   shard_export_rows  on every shard: the longest export row of the nf flagged queries (entries of the probed lists this
+ *                   shard owns; host value, waits for the stream): the callers take `stride` = the maximum over the shards;
  *   shard_export    on EVERY shard: for the nf flagged queries (vectors d_xf, assignment d_cdis_f / d_probe_f [nf][nprobe])
  *                   the ADC distances (+-inf = filtered entry) and vector ids of the probed lists this shard owns, in list
  *                   order: rows of `stride` entries, d_off[f][p .. p + 1) = the entries of probe p (empty for a list of
- *                   another shard).  stride >= nprobe x the longest list of any shard (gamma_hip_ivfpq_max_list_len);
+ *                   another shard);
  *   merge_replay    on the slice's owner: the exports of all shards ([nshards][nf][stride], [nshards][nf][nprobe + 1])
  *                   are assembled probe by probe into the streams and replayed; rows d_list[f] of d_distances /
  *                   d_labels (the slice's result rows) are rewritten.  d_x_slice: the slice's query vectors. */
+int gamma_hip_ivfpq_shard_cut_flags(gamma_hip_index* h, int nq, uint8_t* d_flags);
+int gamma_hip_ivfpq_merge_set_shard_flags(gamma_hip_index* h, const uint8_t* d_flags);
 int gamma_hip_ivfpq_merge_flagged(gamma_hip_index* h, int* n_flagged, const int32_t** d_list);
 int gamma_hip_gather_rows(gamma_hip_index* h, const void* d_src, int row_words, const int32_t* d_list, int n, void* d_dst);
 int gamma_hip_ivfpq_max_list_len(gamma_hip_index* h);
+int gamma_hip_ivfpq_shard_export_rows(gamma_hip_index* h, const gamma_hip_search_params* p, int nf, const int32_t* d_probe_f,
+                                      int64_t* max_entries);
 int gamma_hip_ivfpq_shard_export(gamma_hip_index* h, const gamma_hip_search_params* p, int nf, const float* d_xf,
                                  const float* d_cdis_f, const int32_t* d_probe_f, int64_t stride, float* d_vals,
                                  int64_t* d_ids, int32_t* d_off);

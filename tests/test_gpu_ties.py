@@ -409,17 +409,19 @@ def test_exact_ties_across_list_shards(tag, W, reps, has_rank):
         # the assignment in query order for the shard scans
         cd_all = torch.cat([cdis[s * per:s * per + (gdist.query_slice(nq, s, W)[1] - gdist.query_slice(nq, s, W)[0])] for s in range(W)])
         pr_all = torch.cat([probe[s * per:s * per + (gdist.query_slice(nq, s, W)[1] - gdist.query_slice(nq, s, W)[0])] for s in range(W)])
-        rd, ri = [], []
+        rd, ri, cf_ = [], [], []
         for s in range(W):
             rdis = torch.zeros((nq, R), dtype=torch.float32, device=dev)
             rids = torch.full((nq, R), -1, dtype=torch.int64, device=dev)
+            cutf = torch.zeros((nq,), dtype=torch.uint8, device=dev)
             backs[s].search_shard(x, cd_all, pr_all, k, args, rdis, rids)
+            backs[s].shard_cut_flags(nq, cutf)
             shards[s].synchronize()
             rd.append(rdis)
             ri.append(rids)
+            cf_.append(cutf)
         D = torch.zeros((nq, k), dtype=torch.float32, device=dev)
         I = torch.full((nq, k), -1, dtype=torch.int64, device=dev)
-        stride = nprobe * max(g.max_list_len() for g in shards)
         flagged = 0
         for r in range(W):
             q0, q1_, _ = gdist.query_slice(nq, r, W)
@@ -431,6 +433,9 @@ def test_exact_ties_across_list_shards(tag, W, reps, has_rank):
             xs = x[q0:q1_].contiguous()
             Dr = torch.zeros((nql, k), dtype=torch.float32, device=dev)
             Ir = torch.full((nql, k), -1, dtype=torch.int64, device=dev)
+            if W != 3:   # (W == 3 runs without the shards' flags: every table that ends at the cut value counts as a tie)
+                cut_all = torch.stack([cf_[s][q0:q1_] for s in range(W)]).contiguous()
+                shards[r].ivfpq_merge_set_shard_flags(cut_all.data_ptr())
             shards[r].ivfpq_merge_rerank(W, nql, xs.data_ptr(), k, args, all_dis.data_ptr(), all_ids.data_ptr(), 0, nql,
                                          Dr.data_ptr(), Ir.data_ptr())
             nf, d_list = shards[r].ivfpq_merge_flagged()
@@ -445,6 +450,7 @@ def test_exact_ties_across_list_shards(tag, W, reps, has_rank):
                 shards[r].gather_rows(cds.data_ptr(), nprobe, d_list, nf, cf.data_ptr())
                 shards[r].gather_rows(prs.data_ptr(), nprobe, d_list, nf, pf.data_ptr())
                 shards[r].synchronize()
+                stride = max(4, (max(g.ivfpq_shard_export_rows(nf, pf.data_ptr(), args) for g in shards) + 3) // 4 * 4)
                 vals = torch.empty((W, nf, stride), dtype=torch.float32, device=dev)
                 ids = torch.empty((W, nf, stride), dtype=torch.int64, device=dev)
                 off = torch.empty((W, nf, nprobe + 1), dtype=torch.int32, device=dev)
