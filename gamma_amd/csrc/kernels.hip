@@ -813,19 +813,17 @@ void launch_l2_gemmform(hipStream_t s, const float* x, int nq, int d, const floa
     if (use_mfma) {
         dim3 grid((unsigned)((ny + 63) / 64), (unsigned)((nq + 63) / 64));
         constexpr size_t lds = 2 * 64 * 129 * sizeof(float);  // 66 KB > the 64 KB default cap
-        static bool attr_set = false;
-        if (!attr_set) {
+        static std::atomic<uint64_t> attr_set{0};   // the attribute is per device (several handles / a group in one process)
+        if (first_call_on_device(attr_set)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_l2_gemmform_mfma<128>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
         }
         static const bool no_strip = getenv("GAMMA_HIP_NO_GEMM_STRIP") != nullptr;
         if (d <= 128 && (d & 3) == 0 && !no_strip) {
-            static bool attr2 = false;
-            if (!attr2) {
+            static std::atomic<uint64_t> attr2{0};
+            if (first_call_on_device(attr2)) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_l2_gemmform_strip),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                attr2 = true;
             }
             // tiles per strip: amortise the query tile, but keep >= 512 workgroups
             const int ntiles = (int)((ny + 63) / 64);

@@ -76,10 +76,12 @@ typedef struct {
     double lower_f, upper_f;
 } gamma_hip_field_filter;
 
-/* Term filter on a STRING field evaluated on the device (GammaSearchCondition::term_filters; semantics of
- * FilteredByTermFilter, index/impl/gpu/gamma_index_ivfpq_gpu.cc:727-762: the field value and the filter value
- * are lists of items separated by \001; is_union Or = any filter item among the doc's items, And = all of
- * them; Not (FilterOperator::Not, table/field_range_index.h:23) = none).  Items are dictionary-encoded by the
+/* Term filter on a STRING field evaluated on the device (GammaSearchCondition::term_filters).  The field value and the
+ * filter value are lists of items separated by \001; is_union Or = any filter item among the doc's items, And = all of
+ * them, as in FilteredByTermFilter (index/impl/gpu/gamma_index_ivfpq_gpu.cc:727-762).  Not (FilterOperator::Not,
+ * table/field_range_index.h:23) = NONE of the filter items, which is what the engine's CPU bitmap path computes
+ * (the reference's GPU-side FilteredByTermFilter treats Not like And; the device filter follows the bitmap path so that
+ * "device_filters": 1 and 0 return the same documents).  Items are dictionary-encoded by the
  * caller (the plugin keeps the dictionary, gamma_amd/host/filter_bridge.h); an item the dictionary does not
  * know is passed as -1.  The doc's items live in HBM (gamma_hip_term_append). */
 #define GAMMA_HIP_MAX_TERM_FILTERS 8
