@@ -100,6 +100,10 @@ struct gamma_hip_index {
     // next call's or chunk's pair offsets) -- its latency hides behind the next coarse quantizer and query tables
     hipEvent_t ev_rfork = nullptr, ev_rdone = nullptr;
     bool defer_replay = false, defer_now = false, replay_pending = false;
+    // the shadow lists of compact_lists_for_call stay valid while nothing was written and the call has no clauses of its own
+    // (standing deletes): write_gen counts writer calls (WriteLock), cmp_gen = the count the shadow lists were built at
+    uint64_t write_gen = 1, cmp_gen = 0;
+    bool cmp_has_sums = false, cmp_sums_built = false;
     bool merge_flags = false;   // the last gamma_hip_ivfpq_merge_rerank left tie flags of its slice in w_tlist
     int shard_cut_nq = 0;       // the last shard search left the cut-tie flags of its nq queries in w_tcut
     const uint8_t* merge_shard_flags = nullptr;   // [nshards][nq] for the next merge (gamma_hip_ivfpq_merge_set_shard_flags)
@@ -197,7 +201,7 @@ struct gamma_hip_index {
     DevBuf w_mat, w_coarse_dis, w_probe, w_xn, w_st2, w_pair_off, w_qtotal, w_dist, w_cand_dis,
             w_cand_pos, w_cand_ids, w_exact, w_selv, w_selp, w_x, w_outd, w_outl, w_stage, w_filter,
             w_m_dis, w_m_ids, w_part_v, w_part_i, w_assign, w_codes_tmp, w_qperm, w_scnt, w_sflag, w_surv, w_pair_base,
-            w_pair_ip, w_flat_cand, w_flat_meta, w_full_cdis, w_full_probe, w_ftab, w_qfil, w_tieflag, w_tcut, w_tlist, w_lm_units, w_lm_cnt, w_fbits, w_cmp_codes, w_cmp_ids, w_cmp_len, w_fD, w_fI, w_fx, w_fslab, w_flog, w_mr_vals, w_mr_ids, w_mr_meta,
+            w_pair_ip, w_flat_cand, w_flat_meta, w_full_cdis, w_full_probe, w_ftab, w_qfil, w_tieflag, w_tcut, w_tlist, w_lm_units, w_lm_cnt, w_fbits, w_cmp_codes, w_cmp_ids, w_cmp_len, w_cmp_sums, w_fD, w_fI, w_fx, w_fslab, w_flog, w_mr_vals, w_mr_ids, w_mr_meta,
             we_mat, we_cdis, we_x, we_assign, we_codes, we_stage;   // writer side (encode, bitmap_set): never shared with a search
     unsigned long long* d_scan_codes = nullptr;
     size_t dist_budget_bytes = (size_t)8 << 30;   // per-chunk ADC distance buffer (288 GB of HBM per GPU)
@@ -287,7 +291,10 @@ struct gamma_hip_index {
 struct WriteLock {
     gamma_hip_index* h;
     std::unique_lock<std::mutex> w, s, m;
-    explicit WriteLock(gamma_hip_index* h_) : h(h_), w(h_->writer_mu), s(h_->search_mu, std::defer_lock), m(h_->mu) { h->wl = this; }
+    explicit WriteLock(gamma_hip_index* h_) : h(h_), w(h_->writer_mu), s(h_->search_mu, std::defer_lock), m(h_->mu) {
+        h->wl = this;
+        h->write_gen++;   // (under mu: searches read it under mu)
+    }
     ~WriteLock() { h->wl = nullptr; }
     hipError_t exclusive() {
         if (!s.owns_lock()) {

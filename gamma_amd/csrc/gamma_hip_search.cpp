@@ -369,7 +369,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         // shadow arena of a call running over lists compacted under its filter.  With it ONE consumer workgroup per
         // query takes every probe behind the producer's: two groups, two slices per query.
         static const bool no_cf = getenv("GAMMA_HIP_NO_SCAN_CF") != nullptr;
-        const bool cf_ok = !no_cf && !h->prefiltered && PGN > 1 &&
+        const bool cf_ok = !no_cf && (!h->prefiltered || h->cmp_has_sums) && PGN > 1 &&
                            gh::scan_cf_applies(l2, M, P, G, h->d_sums && h->d_t2max, false);
         const int PGM = cf_ok ? 2 : PGN;   // probe groups of the main launch
         // one survivor slice per probe group (slice 0: the producer's own)
@@ -728,14 +728,17 @@ struct ListCompaction {
     uint8_t* codes;
     int64_t* ids;
     int* len;
+    float* sums;
     bool on = false;
-    explicit ListCompaction(H* h_) : h(h_), codes(h_->d_codes), ids(h_->d_ids), len(h_->d_list_len) {}
+    explicit ListCompaction(H* h_) : h(h_), codes(h_->d_codes), ids(h_->d_ids), len(h_->d_list_len), sums(h_->d_sums) {}
     ~ListCompaction() {
         if (on) {
             h->d_codes = codes;
             h->d_ids = ids;
             h->d_list_len = len;
+            h->d_sums = sums;
             h->prefiltered = false;
+            h->cmp_has_sums = false;
         }
     }
 };
@@ -745,7 +748,6 @@ int compact_lists_for_call(H* h, FiltCtx* fc, int64_t est, bool allowed, ListCom
     const char* env = getenv("GAMMA_HIP_LIST_COMPACT");
     const bool want = env ? atoi(env) != 0 : est >= 4 * std::max<int64_t>(1, h->ntotal);
     if (!(need && want && allowed && !fc->d_qf && !h->d_list_mask && h->arena_cap > 0)) return GAMMA_HIP_OK;
-    GH_TRY(replay_join(h));   // a deferred replay may still read the shadow lists of the previous call
     // the shadow arena is an optimisation: without the memory for it the call runs over the lists as they are, testing
     // the predicate per scored code (same results)
     if (h->w_cmp_codes.ensure((size_t)h->arena_cap * h->code_size) != hipSuccess ||
@@ -756,10 +758,25 @@ int compact_lists_for_call(H* h, FiltCtx* fc, int64_t est, bool allowed, ListCom
         h->w_cmp_ids.release();
         return GAMMA_HIP_OK;
     }
+    // the per-code sums of the scan's filter pass go along (same offsets), so the pass stays on over the shadow lists
+    const bool with_sums = h->d_sums && h->w_cmp_sums.ensure((size_t)h->arena_cap * sizeof(float)) == hipSuccess;
+    if (!with_sums) (void)hipGetLastError();
+    // standing deletes (no clause of the call's own): the shadow lists of the last call are still right unless a writer
+    // has run since -- Add / Update / Delete / bitmap / compaction all count in write_gen
+    static const bool no_cache = getenv("GAMMA_HIP_NO_COMPACT_CACHE") != nullptr;
+    const bool reuse = !no_cache && !fc->any_clause && h->cmp_gen == h->write_gen && h->cmp_sums_built == with_sums;
     GH_CHECK(h, hipStreamWaitEvent(h->stream, h->ver_ev[h->cur_ver], 0));   // the version's lists are in place
-    StageScope t(h, GAMMA_HIP_STAGE_SCAN, false);   // profiled as part of the scan it shortens
-    gh::launch_compact_lists(h->stream, h->d_list_off, h->d_list_len, h->nlist, h->d_codes, h->d_ids, h->code_size,
-                             fc->d_tab, h->w_cmp_codes.as<uint8_t>(), h->w_cmp_ids.as<int64_t>(), h->w_cmp_len.as<int>());
+    if (!reuse) {
+        GH_TRY(replay_join(h));   // a deferred replay may still read the shadow lists of the previous call
+        StageScope t(h, GAMMA_HIP_STAGE_SCAN, false);   // profiled as part of the scan it shortens
+        gh::launch_compact_lists(h->stream, h->d_list_off, h->d_list_len, h->nlist, h->d_codes, h->d_ids, h->code_size,
+                                 fc->d_tab, h->w_cmp_codes.as<uint8_t>(), h->w_cmp_ids.as<int64_t>(), h->w_cmp_len.as<int>(),
+                                 with_sums ? h->d_sums : nullptr, with_sums ? h->w_cmp_sums.as<float>() : nullptr);
+        h->cmp_gen = fc->any_clause ? 0 : h->write_gen;   // shadow lists under a request's own clauses serve that request only
+        h->cmp_sums_built = with_sums;
+    }
+    if (with_sums) h->d_sums = h->w_cmp_sums.as<float>();
+    h->cmp_has_sums = with_sums;
     h->d_codes = h->w_cmp_codes.as<uint8_t>();
     h->d_ids = h->w_cmp_ids.as<int64_t>();
     h->d_list_len = h->w_cmp_len.as<int>();

@@ -67,7 +67,7 @@ void launch_filter_bitmap(hipStream_t s, const FilterDesc& f, int64_t nbits, uin
 // at the same offsets of (out_codes, out_ids); out_len: the new lengths
 void launch_compact_lists(hipStream_t s, const int64_t* list_off, const int* list_len, int nlist, const uint8_t* codes,
                           const int64_t* ids, int code_size, const FilterDesc* ftab /* device */, uint8_t* out_codes,
-                          int64_t* out_ids, int* out_len);
+                          int64_t* out_ids, int* out_len, const float* sums = nullptr, float* out_sums = nullptr);
 void launch_pairwise_filtered(hipStream_t s, bool l2, const float* x, int nq, int d,
                               const float* y, int64_t ny, float* out, int64_t ld_out,
                               const FilterDesc& filt, float min_score, float max_score,

@@ -335,7 +335,8 @@ __global__ __launch_bounds__(256) void k_compact_lists(const int64_t* __restrict
                                                        const uint8_t* __restrict__ codes, const int64_t* __restrict__ ids,
                                                        int code_size, const FilterDesc* __restrict__ ftab,
                                                        uint8_t* __restrict__ out_codes, int64_t* __restrict__ out_ids,
-                                                       int* __restrict__ out_len) {
+                                                       int* __restrict__ out_len, const float* __restrict__ sums,
+                                                       float* __restrict__ out_sums) {
     __shared__ int s_wtot[4];
     const int l = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t off = list_off[l];
@@ -363,6 +364,7 @@ __global__ __launch_bounds__(256) void k_compact_lists(const int64_t* __restrict
         if (ok) {
             const int64_t dst = off + base + __popcll(m & ((1ull << lane) - 1ull));
             out_ids[dst] = id;
+            if (out_sums) out_sums[dst] = sums[off + j];   // the filter pass of the scan reads them beside the codes
             const uint8_t* src = codes + (off + j) * code_size;
             uint8_t* d8 = out_codes + dst * code_size;
             if ((code_size & 15) == 0) {
@@ -380,10 +382,10 @@ __global__ __launch_bounds__(256) void k_compact_lists(const int64_t* __restrict
 }
 void launch_compact_lists(hipStream_t s, const int64_t* list_off, const int* list_len, int nlist, const uint8_t* codes,
                           const int64_t* ids, int code_size, const FilterDesc* ftab, uint8_t* out_codes, int64_t* out_ids,
-                          int* out_len) {
+                          int* out_len, const float* sums, float* out_sums) {
     if (nlist <= 0) return;
     hipLaunchKernelGGL(k_compact_lists, dim3(nlist), dim3(256), 0, s, list_off, list_len, codes, ids, code_size, ftab,
-                       out_codes, out_ids, out_len);
+                       out_codes, out_ids, out_len, sums, out_sums);
 }
 
 void launch_pairwise_filtered(hipStream_t s, bool l2, const float* x, int nq, int d,

@@ -1421,3 +1421,46 @@ def test_term_rows_can_be_rewritten(case, hip):
         vals[doc] = int(rng.integers(0, 100))
         g.field_update(32, int(doc), vals[doc:doc + 1])
     check()
+
+
+def test_shadow_lists_are_reused_until_a_writer_runs():
+    """Large batches over an index with deleted documents run over shadow lists cut down to the live entries
+    (compact_lists_for_call); without a clause of the call's own the shadow lists are kept for the next call and rebuilt
+    only after a writer (Delete, Add, Update, bitmap) has run.  Every call == the oracle with the same deletes."""
+    import os
+    case = fixtures.trained_case(d=32, nlist=64, M=8, N=20000, nq=64, metric=B.METRIC_L2)
+    o = case["oracle"]
+    g = fixtures.load_hip(case)
+    q = synth.sift_like(700, d=32, seed=5)
+    N = case["N"]
+    rng = np.random.default_rng(8)
+    bm = np.zeros((N >> 3) + 1, dtype=np.uint8)
+    old = os.environ.get("GAMMA_HIP_LIST_COMPACT")
+    os.environ["GAMMA_HIP_LIST_COMPACT"] = "1"
+    try:
+        args = api.SearchArgs(metric=api.METRIC_L2, nprobe=8, recall_num=100, has_rank=True, **WIDE)
+        for step in range(4):
+            dead = rng.choice(N, 800, replace=False)
+            np.bitwise_or.at(bm, dead >> 3, (1 << (dead & 7)).astype(np.uint8))
+            g.bitmap_upload(bm, N)
+            ctx = B.make_ctx(docids_bitmap=bm, **WIDE)
+            D, I = o.search(q, 10, 8, recall_num=100, has_rank=True, metric=B.METRIC_L2, ctx=ctx)
+            for rep in range(3):        # the first call builds the shadow lists, the others reuse them
+                Dg, Ig = g.ivfpq_search(q, 10, args)
+                compare_topk(D, I, Dg, Ig)
+            # a call with a clause of its own in between must not leave ITS shadow lists behind
+            docs = rng.choice(N, N // 2, replace=False)
+            a2 = api.SearchArgs(metric=api.METRIC_L2, nprobe=8, recall_num=100, has_rank=True,
+                                range_filters=[api.make_range_filter(docs)], **WIDE)
+            D2, I2 = o.search(q, 10, 8, recall_num=100, has_rank=True, metric=B.METRIC_L2,
+                              ctx=B.make_ctx(docids_bitmap=bm, range_filters=[B.make_range_filter(docs)], **WIDE))
+            Dg2, Ig2 = g.ivfpq_search(q, 10, a2)
+            compare_topk(D2, I2, Dg2, Ig2)
+            Dg, Ig = g.ivfpq_search(q, 10, args)
+            compare_topk(D, I, Dg, Ig)
+    finally:
+        if old is None:
+            os.environ.pop("GAMMA_HIP_LIST_COMPACT", None)
+        else:
+            os.environ["GAMMA_HIP_LIST_COMPACT"] = old
+        g.close()
