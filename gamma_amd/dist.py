@@ -20,8 +20,11 @@ Large batches run as two interleaved sub-batches with every collective asynchron
 all-to-all of one overlaps the scan / merge of the other (sharded_search).
 
 The global top-recall_num of the union equals the single-GPU top-recall_num (same ADC
-distances, disjoint lists), so results are identical to one GPU up to the order inside exact
-ties.  The orchestration is backend-agnostic so the world_size-2 gloo test on CPU exercises
+distances, disjoint lists); the queries in which the order inside a group of exactly equal
+distances can change the answer are replayed by their slice's owner over the candidate
+streams every rank exports for them (tie_phase), so with exact ties on the results are those
+of one GPU at every rank.  replicated_search is the other placement: every rank holds every
+list and answers a slice of the queries.  The orchestration is backend-agnostic so the world_size-2 gloo test on CPU exercises
 the same code with an oracle-based backend (tests/test_dist_cpu.py).
 """
 import os

@@ -32,10 +32,12 @@ int GammaFLATHIPIndex::Init(const std::string &model_parameters, int indexing_si
     }
     int v = 0;
     if (!jp.GetInt("device_filters", v)) device_filters_ = v != 0;   // HIP only, see filter_bridge.h
+    if (!jp.GetInt("exact_ties", v)) exact_ties_ = v != 0;           // HIP only: the reference's heap order inside ties (default on)
   }
   d_ = vector_->MetaInfo()->Dimension();
   const char *dev = getenv("GAMMA_HIP_DEVICE");
   if (gamma_hip_create(dev ? atoi(dev) : 0, &h_)) return -1;
+  if (gamma_hip_set_exact_ties(h_, exact_ties_ ? 1 : 0)) return -1;
   return gamma_hip_raw_init(h_, d_) ? -1 : 0;
 }
 
@@ -49,7 +51,10 @@ RetrievalParameters *GammaFLATHIPIndex::Parse(const std::string &parameters) {
     type = !strcasecmp("L2", mt.c_str()) ? DistanceComputeType::L2 : DistanceComputeType::INNER_PRODUCT;
   int poq = 1;
   jp.GetInt("parallel_on_queries", poq);
-  return new HIPFlatRetrievalParameters(poq != 0, type);
+  HIPFlatRetrievalParameters *rp = new HIPFlatRetrievalParameters(poq != 0, type);
+  int et = 0;
+  if (!jp.GetInt("exact_ties", et)) rp->SetExactTies(et != 0 ? 1 : -1);
+  return rp;
 }
 
 bool GammaFLATHIPIndex::Add(int n, const uint8_t *vec) {
@@ -126,6 +131,7 @@ int GammaFLATHIPIndex::Search(RetrievalContext *retrieval_context, int n, const 
                                                                                 : GAMMA_HIP_METRIC_L2;
   p.min_score = cond ? cond->min_score : std::numeric_limits<float>::min();
   p.max_score = cond ? cond->max_score : std::numeric_limits<float>::max();
+  p.exact_ties = rp->ExactTies();
   std::vector<gamma_hip_range_filter> rf;
   std::vector<gamma_hip_field_filter> ff;
   std::vector<gamma_hip_term_filter> tf;

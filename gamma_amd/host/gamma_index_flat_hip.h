@@ -14,14 +14,18 @@ namespace tig_gamma {
 
 class HIPFlatRetrievalParameters : public RetrievalParameters {
  public:
-  HIPFlatRetrievalParameters() : RetrievalParameters(), parallel_on_queries_(true) {}
+  HIPFlatRetrievalParameters() : RetrievalParameters(), parallel_on_queries_(true), exact_ties_(0) {}
   HIPFlatRetrievalParameters(bool parallel_on_queries, enum DistanceComputeType type)
-      : RetrievalParameters(type), parallel_on_queries_(parallel_on_queries) {}
-  HIPFlatRetrievalParameters(enum DistanceComputeType type) : RetrievalParameters(type), parallel_on_queries_(true) {}
+      : RetrievalParameters(type), parallel_on_queries_(parallel_on_queries), exact_ties_(0) {}
+  HIPFlatRetrievalParameters(enum DistanceComputeType type) : RetrievalParameters(type), parallel_on_queries_(true), exact_ties_(0) {}
   bool ParallelOnQueries() { return parallel_on_queries_; }
+  // HIP only ("exact_ties" in the request's retrieval parameters): 0 = the model's setting, 1 = on, -1 = off
+  int ExactTies() { return exact_ties_; }
+  void SetExactTies(int v) { exact_ties_ = v; }
 
  private:
   bool parallel_on_queries_;   // accepted for compatibility; the device path is always batched
+  int exact_ties_;
 };
 
 class GammaFLATHIPIndex : public RetrievalModel {
@@ -48,6 +52,7 @@ class GammaFLATHIPIndex : public RetrievalModel {
   int SyncVid2DocID(int64_t upto);
   std::mutex raw_mu_;   // uploaded_ + the mirror writes
   bool device_filters_ = false;
+  bool exact_ties_ = true;      // "exact_ties" of the model parameters (HIP only, default on)
   DeviceColumns columns_;
 };
 

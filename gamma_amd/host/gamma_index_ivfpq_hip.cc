@@ -620,6 +620,7 @@ int GammaIVFFlatHIPIndex::Init(const std::string &model_parameters, int indexing
     pa.metric_type = !strcasecmp("L2", mt.c_str()) ? DistanceComputeType::L2 : DistanceComputeType::INNER_PRODUCT;
   }
   if (!jp.GetInt("device_filters", v)) pa.device_filters = v != 0;
+  if (!jp.GetInt("exact_ties", v)) pa.exact_ties = v != 0;
   if (!jp.GetInt("bucket_init_size", v) && v > 0) pa.bucket_init_size = v;
   if (!jp.GetInt("bucket_max_size", v) && v > 0) pa.bucket_max_size = v;
   if (!vector_) {
@@ -638,6 +639,7 @@ int GammaIVFFlatHIPIndex::Init(const std::string &model_parameters, int indexing
   rc = gamma_hip_ivfflat_init(h_, d_, nlist_, metric_type_ == DistanceComputeType::L2 ? GAMMA_HIP_METRIC_L2 : GAMMA_HIP_METRIC_IP,
                               pa.bucket_init_size, pa.bucket_max_size);
   if (!rc) rc = gamma_hip_raw_init(h_, d_);
+  if (!rc) rc = gamma_hip_set_exact_ties(h_, pa.exact_ties ? 1 : 0);
   if (rc) {
     HLOG("device init failed: %s (%s)", gamma_hip_strerror(rc), gamma_hip_last_error(h_));
     return -1;
@@ -664,6 +666,7 @@ RetrievalParameters *GammaIVFFlatHIPIndex::Parse(const std::string &parameters) 
   int v;
   if (!jp.GetInt("nprobe", v) && v > 0) rp->SetNprobe(v);
   if (!jp.GetInt("parallel_on_queries", v)) rp->SetParallelOnQueries(v != 0);
+  if (!jp.GetInt("exact_ties", v)) rp->SetExactTies(v != 0 ? 1 : -1);
   return rp;
 }
 
@@ -695,6 +698,7 @@ int GammaIVFFlatHIPIndex::Search(RetrievalContext *retrieval_context, int n, con
   p.min_score = cond ? cond->min_score : std::numeric_limits<float>::min();
   p.max_score = cond ? cond->max_score : std::numeric_limits<float>::max();
   p.coarse_mode = -1;
+  p.exact_ties = rp->ExactTies();
   std::vector<gamma_hip_range_filter> rf;
   std::vector<gamma_hip_field_filter> ff;
   std::vector<gamma_hip_term_filter> tf;

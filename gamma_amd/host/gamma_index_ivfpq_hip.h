@@ -126,10 +126,13 @@ class GammaIVFPQHIPIndex : public RetrievalModel {
 // iwpq_io.h) differ.
 class HIPIVFFlatRetrievalParameters : public RetrievalParameters {
  public:
-  HIPIVFFlatRetrievalParameters() : RetrievalParameters(), parallel_on_queries_(true), nprobe_(-1) {}
+  HIPIVFFlatRetrievalParameters() : RetrievalParameters(), parallel_on_queries_(true), nprobe_(-1), exact_ties_(0) {}
   HIPIVFFlatRetrievalParameters(enum DistanceComputeType type)
-      : RetrievalParameters(type), parallel_on_queries_(true), nprobe_(-1) {}
+      : RetrievalParameters(type), parallel_on_queries_(true), nprobe_(-1), exact_ties_(0) {}
   int Nprobe() { return nprobe_; }
+  // HIP only ("exact_ties" in the request's retrieval parameters): 0 = the model's setting, 1 = on, -1 = off
+  int ExactTies() { return exact_ties_; }
+  void SetExactTies(int v) { exact_ties_ = v; }
   void SetNprobe(int nprobe) { nprobe_ = nprobe; }
   bool ParallelOnQueries() { return parallel_on_queries_; }
   void SetParallelOnQueries(bool p) { parallel_on_queries_ = p; }
@@ -137,6 +140,7 @@ class HIPIVFFlatRetrievalParameters : public RetrievalParameters {
  protected:
   bool parallel_on_queries_;   // accepted for compatibility; the device path is always batched
   int nprobe_;
+  int exact_ties_;
 };
 
 class GammaIVFFlatHIPIndex : public GammaIVFPQHIPIndex {
