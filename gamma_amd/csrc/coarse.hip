@@ -1030,7 +1030,8 @@ void launch_coarse_fused(hipStream_t s, const CoarseFusedPlan& pl, void* ws, con
     }
     float* full = reinterpret_cast<float*>(b + pl.off_full);
     {
-        const int ntiles = (nlist + 63) / 64, fstrips = std::min(ntiles, 32), tps = (ntiles + fstrips - 1) / fstrips;
+        // (64 strips: the few workgroups that have rows to do take one tile each at nlist 4096 -- the launch is the latency of one)
+        const int ntiles = (nlist + 63) / 64, fstrips = std::min(ntiles, 64), tps = (ntiles + fstrips - 1) / fstrips;
         dim3 fgrid((unsigned)fstrips, (unsigned)((nq + 127) / 128));
 #define GH_CR(NCH)                                                                                                      \
     hipLaunchKernelGGL((k_coarse_fused<NCH, true>), fgrid, dim3(256), lds, rs, x, nq, y, nlist, 0, yn, nullptr, tps, 0,  \

@@ -255,6 +255,17 @@ struct RegHeap {
         }
         return ii;
     }
+    // h[i] -> node i, i = 1..k (an LDS heap taken over, e.g. for heap_reorder's pops)
+    __device__ __forceinline__ void load(const uint2* h, int k) {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int r = 0; r < NREG; r++) {
+            const int i = r * 64 + lane;
+            const uint2 e = (i >= 1 && i <= k) ? h[i] : make_uint2(__float_as_uint(kHeapFltMax), 0xffffffffu);
+            kv[r] = e.x;
+            pv[r] = e.y;
+        }
+    }
     // node i -> h[i], i = 1..k
     __device__ __forceinline__ void dump(uint2* h, int k) const {
         const int lane = threadIdx.x & 63;

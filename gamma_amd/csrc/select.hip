@@ -1335,7 +1335,17 @@ __global__ __launch_bounds__(256) void k_coarse_heap_fix(const float* __restrict
         for (int u = 0; u < 16; u++) t[u] = tn[u];
     }
     hw.drain();
-    heap_reorder_seq(h, K);            // faiss:impl/ResultHandler.h:112-117
+    // heap_reorder (faiss:impl/ResultHandler.h:112-117): K pops; with the heap in registers a level of a sift is a few
+    // scalar instructions instead of an LDS round trip
+    if (K <= 63) {
+        RegHeap<1> rh;
+        rh.load(h, K);
+        const int real = rh.reorder_pops(K);
+        rh.dump(h, K);
+        heap_reorder_tail(h, K, real);
+    } else {
+        heap_reorder_seq(h, K);
+    }
     for (int r = lane; r < K; r += 64) {
         const uint2 e = h[1 + r];
         out_vals[(int64_t)q * K + r] = (int)e.y < 0 ? INFINITY : __uint_as_float(e.x);
