@@ -642,7 +642,7 @@ int ivfpq_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int n
         else if (est > slice) smax = (int)std::min<int64_t>(std::min<int64_t>(64, (bound + slice - 1) / slice), std::max(2, 4096 / nq));
         if (smax > 0) {
             GH_CHECK(h, h->w_selv.ensure((size_t)nq * smax * R * sizeof(float)));
-            GH_CHECK(h, h->w_selp.ensure((size_t)nq * smax * R * sizeof(int)));
+            GH_CHECK(h, h->w_selp.ensure(((size_t)nq * smax * R + (size_t)nq * smax) * sizeof(int)));   // + a cut flag per slice
         }
     }
     // exact ties: a query with a tie at the recall_num or k cut is replayed through the reference's heaps inside the
@@ -941,7 +941,7 @@ int ivfflat_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         else if (est > slice) smax = (int)std::min<int64_t>(std::min<int64_t>(64, (bound + slice - 1) / slice), std::max(2, 4096 / nq));
         if (smax > 0) {
             GH_CHECK(h, h->w_selv.ensure((size_t)nq * smax * k * sizeof(float)));
-            GH_CHECK(h, h->w_selp.ensure((size_t)nq * smax * k * sizeof(int)));
+            GH_CHECK(h, h->w_selp.ensure(((size_t)nq * smax * k + (size_t)nq * smax) * sizeof(int)));   // + a cut flag per slice
         }
     }
     const float neutral = l2 ? 3.402823466e+38f : -3.402823466e+38f;
@@ -1106,7 +1106,7 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
             int smax = h->small_presel > 0 ? h->small_presel : (N > 16384 ? (int)std::min<int64_t>(64, (N + 16383) / 16384) : 0);
             if (smax > 0) {
                 GH_CHECK(h, h->w_selv.ensure((size_t)nq * smax * k * sizeof(float)));
-                GH_CHECK(h, h->w_selp.ensure((size_t)nq * smax * k * sizeof(int)));
+                GH_CHECK(h, h->w_selp.ensure(((size_t)nq * smax * k + (size_t)nq * smax) * sizeof(int)));   // + a cut flag per slice
             }
             // exact ties: a query with equal distances at the k cut or among its k results is replayed through the
             // reference's heap over the whole row (gamma_index_flat.cc:118-300: heap_pop + heap_push in vid order)

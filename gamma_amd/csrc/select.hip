@@ -1908,7 +1908,9 @@ void launch_small_coarse_select(hipStream_t s, const float* mat, int nlist, int 
 template <bool L2>
 __global__ __launch_bounds__(SM_NT) void k_small_presel(const float* __restrict__ slab, int64_t q_stride,
                                                         const int* __restrict__ q_total, int R, int smax,
-                                                        float* __restrict__ pre_val, int* __restrict__ pre_pos, int fixed_n) {
+                                                        float* __restrict__ pre_val, int* __restrict__ pre_pos, int fixed_n,
+                                                        int* __restrict__ pre_cut) {
+    // pre_cut[q][slice] (exact ties; may be null): the slice's own top-R cut went through a group of equal values
     __shared__ int s_hist[SM_BINS];
     __shared__ unsigned long long s_it[2 * SM_NT];
     __shared__ int s_w[2 * SM_NW];
@@ -1920,8 +1922,26 @@ __global__ __launch_bounds__(SM_NT) void k_small_presel(const float* __restrict_
     const int per = (((n + S - 1) / S) + 3) & ~3;
     const int i0 = min(n, sl * per), m = min(n, i0 + per) - i0;
     const float* v = slab + (int64_t)q * q_stride + i0;
-    const int cnt = m > 0 ? block_select_sorted<L2, 16, 2>(v, m, R, s_it, s_hist, s_w, s_pick) : 0;   // barriers inside
+    int nsorted = 0;
+    const int cnt = m > 0 ? block_select_sorted<L2, 16, 2>(v, m, R, s_it, s_hist, s_w, s_pick, &nsorted) : 0;   // barriers inside
     if (m <= 0) __syncthreads();
+    if (pre_cut) {
+        int cut = 0;
+        if (cnt == R && m > R) {   // uniform
+            const uint32_t vk = (uint32_t)(s_it[R - 1] >> 32);
+            if (nsorted >= 0) {
+                cut = nsorted > R && (uint32_t)(s_it[R] >> 32) == vk;
+            } else {   // crowded bin: count the value over the slice
+                int in_sel = 0, loc = 0, in_all;
+                for (int r0 = 0; r0 < R; r0 += SM_NT)
+                    in_sel += __syncthreads_count(r0 + tid < R && (uint32_t)(s_it[min(r0 + tid, R - 1)] >> 32) == vk);
+                for (int i = tid; i < m; i += SM_NT) loc += sel_key<L2>(v[i]) == vk ? 1 : 0;
+                (void)block_excl_scan_sm(min(loc, 2048), s_w, in_all);
+                cut = in_all > in_sel;
+            }
+        }
+        if (tid == 0) pre_cut[(int64_t)q * smax + sl] = cut;
+    }
     const int64_t o = ((int64_t)q * smax + sl) * R;
     for (int r = tid; r < R; r += SM_NT) {
         float val = L2 ? INFINITY : -INFINITY;
@@ -1993,17 +2013,29 @@ __global__ __launch_bounds__(SM_NT) void k_small_tail(const float* __restrict__ 
                 // cannot carry the same key
                 tie = nsorted > R && (uint32_t)(s_it[R] >> 32) == vk;
             } else {
-                // crowded bin, or a pre-selected row (a slice may have dropped members of the group): count the key
-                // over the whole slab row
+                // crowded bin: count the key over the whole slab row
                 int in_sel = 0;
                 for (int r0 = 0; r0 < R; r0 += SM_NT)
                     in_sel += __syncthreads_count(r0 + tid < R && (uint32_t)(s_it[min(r0 + tid, R - 1)] >> 32) == vk);
-                const float* v0 = slab + (int64_t)q * q_stride;
-                const int n0 = q_total ? q_total[q] : fixed_n;
                 int loc = 0, in_all;
-                for (int i = tid; i < n0; i += SM_NT) loc += sel_key<L2>(v0[i]) == vk ? 1 : 0;
+                bool slice_cut = false;
+                if (smax > 0) {
+                    // pre-selected row: the slices' tables hold every entry at the cut value unless a slice's own cut
+                    // dropped some -- its table ends at that value and its own cut went through a tie (k_small_presel's
+                    // flag).  n entries to look at instead of the row's hundreds of thousands.
+                    const int* pcut = pre_pos + (int64_t)gridDim.x * smax * R + (int64_t)q * smax;
+                    for (int i = tid; i < n; i += SM_NT) {
+                        const bool eq = sel_key<L2>(v[i]) == vk;
+                        loc += eq ? 1 : 0;
+                        slice_cut |= eq && (i % R) == R - 1 && ppos[i] >= 0 && pcut[i / R] != 0;
+                    }
+                } else {
+                    const float* v0 = slab + (int64_t)q * q_stride;
+                    const int n0 = q_total ? q_total[q] : fixed_n;
+                    for (int i = tid; i < n0; i += SM_NT) loc += sel_key<L2>(v0[i]) == vk ? 1 : 0;
+                }
                 (void)block_excl_scan_sm(min(loc, 2048), s_w, in_all);
-                tie = in_all > in_sel;
+                tie = in_all > in_sel || __syncthreads_or(slice_cut ? 1 : 0);
             }
         }
     }
@@ -2139,10 +2171,10 @@ void launch_small_tail(hipStream_t s, bool l2, const float* slab, int64_t q_stri
     if (smax > 0) {
         if (l2)
             hipLaunchKernelGGL((k_small_presel<true>), dim3(nq, smax), dim3(SM_NT), 0, s, slab, q_stride, q_total, R, smax,
-                               pre_val, pre_pos, fixed_n);
+                               pre_val, pre_pos, fixed_n, exact_ties ? pre_pos + (int64_t)nq * smax * R : nullptr);
         else
             hipLaunchKernelGGL((k_small_presel<false>), dim3(nq, smax), dim3(SM_NT), 0, s, slab, q_stride, q_total, R, smax,
-                               pre_val, pre_pos, fixed_n);
+                               pre_val, pre_pos, fixed_n, exact_ties ? pre_pos + (int64_t)nq * smax * R : nullptr);
     }
     static unsigned long long* dbg = nullptr;
     static int shown = 0;
