@@ -369,7 +369,12 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         // shadow arena of a call running over lists compacted under its filter.  With it ONE consumer workgroup per
         // query takes every probe behind the producer's: two groups, two slices per query.
         static const bool no_cf = getenv("GAMMA_HIP_NO_SCAN_CF") != nullptr;
+        // (short lists only: with thousands of codes per list the per-pair table costs next to nothing, while ONE consumer
+        //  workgroup per query overruns its candidate stage and sends the query to the unfiltered path -- full-size C4, 6100
+        //  codes per list: 38.6 ms per 8192 queries with the filter pass, 27.6 without)
+        static const double cf_maxlen = getenv("GAMMA_HIP_SCAN_CF_MAXLEN") ? atof(getenv("GAMMA_HIP_SCAN_CF_MAXLEN")) : 2000.0;
         const bool cf_ok = !no_cf && (!h->prefiltered || h->cmp_has_sums) && PGN > 1 &&
+                           (double)h->ntotal / std::max(1, nlist) <= cf_maxlen &&
                            gh::scan_cf_applies(l2, M, P, G, h->d_sums && h->d_t2max, false);
         const int PGM = cf_ok ? 2 : PGN;   // probe groups of the main launch
         // one survivor slice per probe group (slice 0: the producer's own)
