@@ -347,6 +347,13 @@ def test_deferred_replay_streams_of_device_calls():
             e = exp[seq[i]]
             compare_exact(np.tile(e[0], (reps, 1)), np.tile(e[1], (reps, 1)), D.cpu().numpy(), I.cpu().numpy())
         assert g.tie_stats()["replayed"] > 0
+        # a call cut into many chunks (small slab budget): the replay of chunk i runs beside chunk i + 1
+        g.set_dist_budget(4 << 20)
+        for nm in ("a", "b"):
+            D, I = outs[0]
+            g.ivfpq_search_device(d_q[nm].data_ptr(), nq, k, args, D.data_ptr(), I.data_ptr())
+            g.synchronize()
+            compare_exact(np.tile(exp[nm][0], (reps, 1)), np.tile(exp[nm][1], (reps, 1)), D.cpu().numpy(), I.cpu().numpy())
         g.set_deferred_replay(False)
     finally:
         g.close()
