@@ -846,6 +846,15 @@ int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, c
             GH_TRY(ivfpq_coarse(h, p, std::min(cc, nq - q0), d_x + (size_t)q0 * h->d,
                                 h->w_full_cdis.as<float>() + (size_t)q0 * P, h->w_full_probe.as<int>() + (size_t)q0 * P));
     }
+    // a call of several chunks: the tie replay of chunk i runs on its own stream beside chunk i + 1 (what
+    // gamma_hip_set_deferred_replay does across calls); a caller that has not asked for that gets the join at the end
+    struct DeferScope {
+        H* h;
+        bool saved;
+        ~DeferScope() { h->defer_now = saved; }
+    } defer_scope{h, h->defer_now};
+    const bool defer_inside = chunk < nq && !h->defer_now && h->side2 != nullptr;
+    if (defer_inside) h->defer_now = true;
     for (int q0 = 0; q0 < nq; q0 += chunk) {
         const int nc = std::min(chunk, nq - q0);
         if (coarse_first)
@@ -859,6 +868,7 @@ int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, c
                              /*tie_mode=*/1));
         h->last_nq = nc;
     }
+    if (defer_inside) GH_TRY(replay_join(h));
     h->last_P = p->nprobe;
     h->last_R = R;
     return GAMMA_HIP_OK;
