@@ -280,6 +280,9 @@ class GammaHip:
         self._ck(self.L.gamma_hip_ivfpq_update_batch(self.h, len(vids), _p(vids, _lib.i64p), _p(vecs, _lib.f32p)),
                  "update_batch")
 
+    def code_size(self):
+        return self.L.gamma_hip_ivfpq_code_size(self.h)
+
     def encode(self, vecs):
         vecs = _f32(vecs)
         n = vecs.shape[0]

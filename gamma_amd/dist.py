@@ -74,6 +74,19 @@ class HipShardBackend:
         self.g.raw_append(vecs)
         self.g.add(vecs, first_vid)
 
+    # sharded_add
+    def code_size(self):
+        return self.g.code_size()
+
+    def encode(self, vecs):
+        return self.g.encode(vecs)
+
+    def append_raw(self, vecs):
+        self.g.raw_append(vecs)
+
+    def add_keys_batch(self, lists, counts, vids, codes):
+        self.g.add_keys_batch(lists, counts, np.ascontiguousarray(vids, dtype=np.int64), codes)
+
     def has_vid(self, vids):
         return torch.from_numpy(self.g.has_vid(vids)).to(self.device)
 
@@ -152,6 +165,38 @@ def route_update(store, lno, vid, code, owned, held_somewhere):
     elif owned[lno] and held_somewhere:
         store.add_keys(lno, np.array([vid], dtype=np.int64), np.asarray(code, dtype=np.uint8)[None])
     # a vid no shard holds is ignored (:307-311)
+
+
+def sharded_add(backend, vecs, first_vid, owned, group=None, turn=0):
+    """GammaIVFPQIndex::Add (gamma_index_ivfpq.cc:424-512) on a list-sharded index with ONE encode per batch: every rank
+    calls this with the same host batch [n, d] and its list mask `owned`; rank `turn % W` runs the encode (coarse
+    assignment + PQ codes) and broadcasts n x (8 + code_size) bytes, every rank appends the vectors to its replica of the
+    raw store and the entries of the lists it owns -- lists in ascending order, entries in batch order, as the reference's
+    std::map does.  (HipShardBackend.add is the exchange-free form: every rank encodes the batch itself.)"""
+    vecs = np.ascontiguousarray(vecs, dtype=np.float32)
+    n = vecs.shape[0]
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    cs = backend.code_size()
+    src_local = turn % world
+    if rank == src_local:
+        lno, codes = backend.encode(vecs)
+        pack = torch.from_numpy(np.concatenate([lno.astype(np.int64).view(np.uint8).reshape(n, 8),
+                                                np.ascontiguousarray(codes, dtype=np.uint8).reshape(n, cs)], axis=1))
+    else:
+        pack = torch.empty((n, 8 + cs), dtype=torch.uint8)
+    pack = pack.to(backend.device) if hasattr(backend, "device") else pack
+    if world > 1:
+        dist.broadcast(pack, src=dist.get_global_rank(group, src_local) if group is not None else src_local, group=group)
+    pack = pack.cpu().numpy()
+    lno = np.ascontiguousarray(pack[:, :8]).view(np.int64).reshape(n)
+    codes = np.ascontiguousarray(pack[:, 8:])
+    backend.append_raw(vecs)
+    mine = np.nonzero(np.asarray(owned)[lno] != 0)[0]
+    if len(mine):
+        order = mine[np.argsort(lno[mine], kind="stable")]
+        lists, counts = np.unique(lno[order], return_counts=True)
+        backend.add_keys_batch(lists, counts, first_vid + order, codes[order])
 
 
 def sharded_update(backend, vids, vecs, owned, group=None):

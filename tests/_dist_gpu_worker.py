@@ -67,6 +67,20 @@ def main():
     D, I = gdist.replicated_search(gdist.HipShardBackend(full, local), x, k, args)
     torch.cuda.synchronize()
     assert D.cpu().numpy().tobytes() == Dref.cpu().numpy().tobytes() and np.array_equal(I.cpu().numpy(), Iref.cpu().numpy())
+    # Add with ONE encode per batch (sharded_add: the encoding rank broadcasts list numbers + codes): the shards' lists are
+    # those of the unsharded handle after the same Add, entry by entry
+    from gamma_amd import synth
+    extra = synth.sift_like(3000, d=case["d"], seed=77)
+    v0 = len(case["base"])
+    for t, i0 in enumerate(range(0, len(extra), 1000)):
+        gdist.sharded_add(be, extra[i0:i0 + 1000], v0 + i0, (np.asarray(owner) == rank).astype(np.uint8), turn=t)
+        full.raw_append(extra[i0:i0 + 1000])
+        full.add(extra[i0:i0 + 1000], v0 + i0)
+    for l in range(case["nlist"]):
+        if owner[l] == rank:
+            ia, ca = g.get_list(l)
+            ib, cb = full.get_list(l)
+            assert np.array_equal(ia, ib) and np.array_equal(ca, cb), l
     # exact ties across the ranks' shards: tie-heavy data (every base vector four times), labels strictly the pinned
     # oracle's on the unsharded index (gamma_amd.dist.tie_phase: flagged queries broadcast, candidate streams exported by
     # every rank, gathered, replayed by the slice's owner)
