@@ -142,7 +142,6 @@ SYMBOLS = {
                                                C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gamma_hip_set_deferred_replay": (C.c_int, [C.c_void_p, C.c_int]),
     "gamma_hip_join": (C.c_int, [C.c_void_p]),
-    "gamma_hip_coarse_bf_check": (C.c_int, [C.c_void_p, C.c_int, i64p]),
     "gamma_hip_group_set_placement": (C.c_int, [C.c_void_p, C.c_int]),
     "gamma_hip_group_placement": (C.c_int, [C.c_void_p]),
     "gamma_hip_group_ivfpq_add": (C.c_int, [C.c_void_p, C.c_int64, f32p, C.c_int64]),

@@ -142,12 +142,6 @@ class GammaHip:
         of a call are complete after the next search, join() or synchronize() (include/gamma_hip.h)"""
         self._ck(self.L.gamma_hip_set_deferred_replay(self.h, 1 if on else 0), "set_deferred_replay")
 
-    def coarse_bf_check(self, on=True):
-        """debug counter of the bf16 coarse filter (include/gamma_hip.h): returns the violations counted so far"""
-        out = np.zeros(1, dtype=np.int64)
-        self._ck(self.L.gamma_hip_coarse_bf_check(self.h, 1 if on else 0, _p(out, _lib.i64p)), "coarse_bf_check")
-        return int(out[0])
-
     def join(self):
         self._ck(self.L.gamma_hip_join(self.h), "join")
 

@@ -247,269 +247,6 @@ __global__ __launch_bounds__(256, 2) void k_coarse_fused(const float* __restrict
 }
 
 
-// ------------------------------------------------------------------------------------
-// The FILTER with bf16 matrix instructions.  A filter does not need the reference's fp32 inner products, only values
-// within a known distance of them: with x = xh + xl + ex, y = yh + yl + ey (xh = bf16(x), xl = bf16(x - xh), both round
-// to nearest: |ex| <= 2^-16 |x| elementwise) the three products xh.yh + xh.yl + xl.yh are exact in fp32 term by term
-// and miss <x, y> by sum(xl yl + ex y + (x - ex) ey) <= 3 * 2^-16 sum|x_i||y_i|; accumulating 3 d terms in fp32 adds at
-// most 3 d 2^-24 of the same sum, the reference's own fma chain d 2^-24.  So the approximate distance
-//      a(q, c) = fma(-2, ip_bf16, |x|^2 + |y|^2)      (the exact norms)
-// differs from the reference's d(q, c) by at most
-//      m_q = C_d * |x_q| * max_c |y_c| + 2^-22 (|x_q|^2 + max_c |y_c|^2),    C_d = coarse_bf_margin_c(d)
-// (Cauchy-Schwarz on the sums; the second term covers the final fma and the clamp).  v_mfma_f32_32x32x16_bf16 runs at
-// 16 x the rate of the fp32 instruction, so the three products cost a fifth of the fp32 chain and, unlike f32 MFMAs,
-// overlap with the epilogue's VALU work.  Selection on approximate values, decision on exact ones:
-//   * sample columns: a(q, c) stored, k_coarse_bound takes tau_a from them as before: P columns have a <= tau_a, hence
-//     d <= tau_a + m: the P-th smallest d is <= tau_a + m, and every column at or below it has a <= tau_a + 2 m;
-//   * the other columns: entries with a <= tau_a + 2 m are kept (lists as before);
-//   * k_coarse_final<BF>: tightens the bound the same way on the approximate values (+ 2 m), recomputes the ~40 entries
-//     that pass with the reference's chain (one lane per entry: k-ascending fmaf from 0, norms as fvec_norm_L2sqr --
-//     the arithmetic of k_coarse_repair) and ranks THOSE.  coarse_dis / coarse_idx are bit-identical to the fp32 path.
-// Rows with two equal exact keys among the P + 1 smallest, and overflowed rows, go the way they went: full fp32 rows by
-// k_coarse_fused<.., STORE> + the heap walk, or k_coarse_repair.
-// ------------------------------------------------------------------------------------
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-__host__ __device__ inline float coarse_bf_margin_c(int d) {
-    // 2 x (representation 3 * 2^-16 + accumulation of 3 d products + the reference's own chain of d), with a factor 2 on
-    // the accumulation terms (the matrix unit's internal rounding is not documented)
-    return 2.0f * (3.0f / 65536.0f + 2.0f * 4.0f * (float)d / 16777216.0f);
-}
-__device__ __forceinline__ uint32_t bf16_rn_bits(float x) {   // round to nearest even; finite inputs
-    const uint32_t u = __float_as_uint(x);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ void bf16_split(float x, uint32_t& hi, uint32_t& lo) {
-    hi = bf16_rn_bits(x);
-    lo = bf16_rn_bits(x - __uint_as_float(hi << 16));   // the difference is exact
-}
-// centroids -> hi / lo bf16 rows (set_trained)
-__global__ __launch_bounds__(256) void k_split_bf16(const float* __restrict__ y, int64_t n, uint16_t* __restrict__ hi,
-                                                    uint16_t* __restrict__ lo) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    uint32_t h, l;
-    bf16_split(y[i], h, l);
-    hi[i] = (uint16_t)h;
-    lo[i] = (uint16_t)l;
-}
-void launch_split_bf16(hipStream_t s, const float* y, int64_t n, uint16_t* hi, uint16_t* lo) {
-    if (n > 0) hipLaunchKernelGGL(k_split_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, n, hi, lo);
-}
-
-// per query: threshold slack 2 m_q (see above) from |x_q|^2
-__device__ __forceinline__ float coarse_bf_slack(float xn, float mc_ymax, float ynmax) {
-    return 2.0f * (mc_ymax * sqrtf(xn) + (xn + ynmax) * (1.0f / 4194304.0f));
-}
-
-template <int NCH, bool STORE>   // d = 16 * NCH, NCH even
-__global__ __launch_bounds__(256, 2) void k_coarse_fused_bf(const float* __restrict__ x, int nq,
-                                                            const uint16_t* __restrict__ yh, const uint16_t* __restrict__ yl,
-                                                            int ny, int col0, const float* __restrict__ yn,
-                                                            const float* __restrict__ tau, float mc_ymax, float ynmax,
-                                                            int tiles_per_strip, int cap, int cap_stride,
-                                                            unsigned long long* __restrict__ cand,
-                                                            int* __restrict__ cand_cnt, int nseg,
-                                                            unsigned long long* __restrict__ dbg) {
-#define GH_CT(i) do { if (dbg && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) dbg[i] = (i) >= 12 ? (unsigned long long)clock64() : wall_clock64(); } while (0)
-    GH_CT(0);
-    constexpr int D = 16 * NCH, LD = D + 1, SEGS = D / 32;
-    constexpr int NKK = D / 16;                 // MFMA k-steps
-    constexpr int RB = (D + 8) * 2;             // bytes of a centroid row in a bf16 tile: 16 bytes of padding
-    constexpr int TILE_B = 64 * RB;             // one array (hi or lo) of a 64-centroid tile
-    constexpr int CPR = D / 8;                  // 16-byte chunks per row
-    constexpr int NPASS = NCH / 2;              // passes of 256 threads x 16 bytes over one array of a tile
-    extern __shared__ float s_co[];             // the query tile [128][LD] fp32 first, then 2 x (hi, lo) bf16 tiles
-    __shared__ float s_xn[128];
-    __shared__ float2 s_xt[128];
-    char* s_tb = reinterpret_cast<char*>(s_co);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int seg = blockIdx.x, q_base = blockIdx.y * 128;
-    const int ntiles = (ny - col0 + 63) >> 6;
-    const int t0 = seg * tiles_per_strip, t1 = min(ntiles, t0 + tiles_per_strip);
-    auto slot_r = [&](int it) { return (((w * NCH + it) / SEGS) << 3) + (lane >> 3); };
-    auto slot_c = [&](int it) { return (((w * NCH + it) % SEGS) << 5) + ((lane & 7) << 2); };
-    // ---- the 128 queries: LDS once, then norms and bf16 hi / lo MFMA fragments into registers ----
-    {
-        float4 vq[NCH];
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-#pragma unroll
-            for (int it = 0; it < NCH; it++) {
-                const int row = min(q_base + half * 64 + slot_r(it), nq - 1);
-                vq[it] = *reinterpret_cast<const float4*>(x + (int64_t)row * D + slot_c(it));
-            }
-#pragma unroll
-            for (int it = 0; it < NCH; it++) {
-                float* p = s_co + half * 64 * LD + slot_r(it) * LD + slot_c(it);
-                p[0] = vq[it].x; p[1] = vq[it].y; p[2] = vq[it].z; p[3] = vq[it].w;
-            }
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int half = 0; half < 2; half++) {   // fvec_norm_L2sqr order: 4 lanes per row, (a0 + a1) + (a2 + a3)
-        const float* row = s_co + (half * 64 + (tid >> 2)) * LD;
-        const int l4 = tid & 3;
-        float nacc = 0.f;
-        for (int i = 0; i < D; i += 4) {
-            const float xv = row[i + l4];
-            nacc = __builtin_fmaf(xv, xv, nacc);
-        }
-        const float t01 = nacc + __shfl_down(nacc, 1, 4);
-        const float nn = t01 + __shfl_down(t01, 2, 4);
-        if (l4 == 0) s_xn[half * 64 + (tid >> 2)] = nn;
-    }
-    // A operand of v_mfma_f32_32x32x16_bf16: lane holds row (lane & 31), k = 16 kk + 8 (lane >> 5) + 0..7
-    bf16x8_t ah[NKK], al[NKK];
-    {
-        const float* fa = s_co + (w * 32 + (lane & 31)) * LD + 8 * (lane >> 5);
-#pragma unroll
-        for (int kk = 0; kk < NKK; kk++) {
-            uint32_t ph[4], pl[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                uint32_t h0, l0, h1, l1;
-                bf16_split(fa[16 * kk + 2 * j], h0, l0);
-                bf16_split(fa[16 * kk + 2 * j + 1], h1, l1);
-                ph[j] = h0 | (h1 << 16);
-                pl[j] = l0 | (l1 << 16);
-            }
-            ah[kk] = __builtin_bit_cast(bf16x8_t, make_uint4(ph[0], ph[1], ph[2], ph[3]));
-            al[kk] = __builtin_bit_cast(bf16x8_t, make_uint4(pl[0], pl[1], pl[2], pl[3]));
-        }
-    }
-    __syncthreads();
-    // (|x|^2, threshold) of the 128 rows stay in LDS
-    if (tid < 128) {
-        const float xn = s_xn[tid];
-        s_xt[tid] = make_float2(xn, (!STORE && q_base + tid < nq) ? tau[q_base + tid] + coarse_bf_slack(xn, mc_ymax, ynmax) : -INFINITY);
-    }
-    // ---- centroid tiles: hi and lo rows, 16-byte chunks, coalesced ----
-    uint4 vb[NCH];
-    auto gload = [&](int t) {
-#pragma unroll
-        for (int it = 0; it < NPASS; it++) {
-            const int idx = it * 256 + tid, row = idx / CPR, ch = idx % CPR;
-            const int64_t g = (int64_t)min(col0 + t * 64 + row, ny - 1) * D + ch * 8;
-            vb[it] = *reinterpret_cast<const uint4*>(yh + g);
-            vb[NPASS + it] = *reinterpret_cast<const uint4*>(yl + g);
-        }
-    };
-    auto stage = [&](int t) {
-        char* base = s_tb + ((t - t0) & 1) * 2 * TILE_B;
-#pragma unroll
-        for (int it = 0; it < NPASS; it++) {
-            const int idx = it * 256 + tid, row = idx / CPR, ch = idx % CPR;
-            *reinterpret_cast<uint4*>(base + row * RB + ch * 16) = vb[it];
-            *reinterpret_cast<uint4*>(base + TILE_B + row * RB + ch * 16) = vb[NPASS + it];
-        }
-    };
-    GH_CT(1);
-    if (t0 < t1) {
-        gload(t0);
-        stage(t0);
-    }
-    __syncthreads();
-    GH_CT(2);
-    int cnt[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) cnt[r] = 0;
-    const uint32_t lt_mask = (1u << (lane & 31)) - 1u;
-    const unsigned row_stride = STORE ? (unsigned)cap_stride : (unsigned)nseg * (unsigned)cap_stride;
-    const unsigned lane_row = STORE ? (unsigned)(q_base + w * 32 + 4 * (lane >> 5)) * (unsigned)cap_stride
-                                    : ((unsigned)((q_base + w * 32 + 4 * (lane >> 5)) * nseg + seg)) * (unsigned)cap_stride;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        cand, 0,
-        (int)min(STORE ? (int64_t)nq * cap_stride * 4 : (int64_t)nq * nseg * cap_stride * 8, (int64_t)0x7fffffff),
-        0x00020000);
-    constexpr unsigned OOB = 0x80000000u;
-    const int sh = lane & 32;
-    int rs[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) rs[r] = ((r & 3) + 8 * (r >> 2)) * (int)row_stride * (STORE ? 4 : 8);
-    const float2* xt_row = s_xt + w * 32 + 4 * (lane >> 5);
-    auto epi = [&](const f32x16& o, int r, unsigned colv, float ync, int rsoff) {
-        const float2 xt = xt_row[(r & 3) + 8 * (r >> 2)];
-        const float dis = __builtin_fmaf(-2.f, o[r], xt.x + ync);
-        if constexpr (STORE) {
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dis < 0.f ? 0.f : dis), rsrc,
-                                                  (int)colv < ny ? (lane_row + (colv - (unsigned)col0)) * 4u : OOB, rsoff, 0);
-            return;
-        }
-        const bool pass = dis <= xt.y;
-        const unsigned long long mask = __ballot(pass);
-        const uint32_t mh = (uint32_t)(mask >> sh);
-        const unsigned slot = min((unsigned)cnt[r] + (unsigned)__popc(mh & lt_mask), (unsigned)cap);
-        u32x2 item;
-        item.x = colv;
-        item.y = (uint32_t)max((int)__float_as_uint(dis), 0) | 0x80000000u;
-        // lanes that fail are masked out (not steered out of range as in the fp32 kernel: the address unit works through
-        // every enabled lane of a store, and with the matrix work a fifth of what it was the stores are what is left)
-        if (pass) __builtin_amdgcn_raw_buffer_store_b64(item, rsrc, (lane_row + slot) * 8u, rsoff, 0);
-        cnt[r] += __popc(mh);
-    };
-    // one 32-column block: 3 NKK bf16 MFMAs into n with the 16 epilogue elements of the PREVIOUS block spread between them
-    auto step = [&](auto do_mfma, auto do_epi, f32x16& n, const char* pb, const f32x16& o, int colo) {
-        constexpr bool MF = decltype(do_mfma)::value, EP = decltype(do_epi)::value;
-        float ync = 0.f;
-        const unsigned colv = (unsigned)(colo + (lane & 31));
-        if constexpr (EP) ync = (int)colv < ny ? yn[min((int)colv, ny - 1)] : INFINITY;
-        if constexpr (MF) {
-#pragma unroll
-            for (int i = 0; i < 16; i++) n[i] = 0.f;
-#pragma unroll
-            for (int kk = 0; kk < NKK; kk++) {
-                const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(pb + kk * 32));
-                const bf16x8_t bl = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(pb + TILE_B + kk * 32));
-                n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk], bh, n, 0, 0, 0);
-                n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk], bl, n, 0, 0, 0);
-                n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kk], bh, n, 0, 0, 0);
-                if constexpr (EP) {
-#pragma unroll
-                    for (int e = 0; e < 16; e++)
-                        if (e * NKK / 16 == kk) epi(o, e, colv, ync, rs[e]);
-                }
-            }
-        } else if constexpr (EP) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) epi(o, r, colv, ync, rs[r]);
-        }
-    };
-    const std::true_type yes;
-    const std::false_type no;
-    f32x16 acc0, acc1;
-    for (int t = t0; t < t1; t++) {
-        // B operand: lane holds column (lane & 31) of the block, k = 16 kk + 8 (lane >> 5) + 0..7: 16 bytes of its row
-        const char* pb0 = s_tb + ((t - t0) & 1) * 2 * TILE_B + (lane & 31) * RB + (lane >> 5) * 16;
-        const int colb = col0 + t * 64;
-        const bool tm = dbg && t == t0 + 1;
-        if (tm) GH_CT(12);
-        if (t > t0) step(yes, yes, acc0, pb0, acc1, colb - 32);
-        else step(yes, no, acc0, pb0, acc1, 0);
-        if (tm) GH_CT(13);
-        const bool more = t + 1 < t1;   // uniform
-        if (more) gload(t + 1);
-        if (tm) GH_CT(14);
-        step(yes, yes, acc1, pb0 + 32 * RB, acc0, colb);
-        if (tm) GH_CT(15);
-        if (more) stage(t + 1);
-        if (tm) GH_CT(16);
-        __syncthreads();
-        if (tm) GH_CT(17);
-        if (t - t0 < 8) GH_CT(3 + (t - t0));
-    }
-    if (t0 < t1) step(no, yes, acc0, s_tb, acc1, col0 + (t1 - 1) * 64 + 32);
-    GH_CT(11);
-    if (!STORE && (lane & 31) == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = q_base + w * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (row < nq) cand_cnt[row * nseg + seg] = cnt[r];
-        }
-    }
-#undef GH_CT
-}
-
 // K-th smallest (with multiplicity) of the 64 lane values: the value v with #(m < v) < K <= #(m <= v)
 __device__ __forceinline__ uint32_t wave_kth_smallest(uint32_t m, int K) {
     int lt = 0, le = 0;
@@ -569,22 +306,12 @@ __global__ __launch_bounds__(256) void k_coarse_bound(const float* __restrict__ 
 // rank-sorted in LDS.  A query with an overflowed strip list, or too many entries at the bound, goes to
 // k_coarse_repair.
 constexpr int CF_BUF = 256;
-// BF: mat / cand hold approximate distances (k_coarse_fused_bf); the entries that pass are recomputed exactly
-struct CoarseBfArgs {
-    const float* x = nullptr;    // queries [nq][d]
-    const float* y = nullptr;    // centroids [ny][d] (fp32)
-    const float* yn = nullptr;   // their norms
-    int d = 0;
-    float mc_ymax = 0.f, ynmax = 0.f;
-    unsigned long long* viol = nullptr;   // debug: entries whose approximate distance is further than m_q from the exact one
-};
-template <int SNPL, int MAXSEG, bool BF = false>
+template <int SNPL, int MAXSEG>
 __global__ __launch_bounds__(256) void k_coarse_final(const float* __restrict__ mat, const float* __restrict__ tau,
                                                       const unsigned long long* __restrict__ cand,
                                                       const int* __restrict__ cand_cnt, int nseg, int cap,
                                                       int cap_stride, int nq, int P, float* __restrict__ out_dis,
-                                                      int* __restrict__ out_idx, int* __restrict__ ovf, int flag_ties,
-                                                      CoarseBfArgs bf) {
+                                                      int* __restrict__ out_idx, int* __restrict__ ovf, int flag_ties) {
     constexpr int NPL = SNPL + 2 * MAXSEG;
     __shared__ unsigned long long s_buf[4][CF_BUF];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -597,22 +324,8 @@ __global__ __launch_bounds__(256) void k_coarse_final(const float* __restrict__ 
         return;
     }
     unsigned long long it[NPL];
-    float slack = 0.f, xn = 0.f;
-    if constexpr (BF) {
-        // |x_q|^2 as every kernel of the chain computes it (fvec_norm_L2sqr order: 4 lanes, (a0 + a1) + (a2 + a3))
-        const float* xq = bf.x + (int64_t)q * bf.d;
-        const int l4 = lane & 3;
-        float nacc = 0.f;
-        for (int i = 0; i < bf.d; i += 4) {
-            const float xv = xq[i + l4];
-            nacc = __builtin_fmaf(xv, xv, nacc);
-        }
-        const float t01 = nacc + __shfl_down(nacc, 1, 4);
-        xn = __shfl(t01 + __shfl_down(t01, 2, 4), 0, 64);
-        slack = coarse_bf_slack(xn, bf.mc_ymax, bf.ynmax);
-    }
     {
-        const float t = tau[q] + slack;
+        const float t = tau[q];
         const float* v = mat + (int64_t)q * (64 * SNPL) + lane;
 #pragma unroll
         for (int j = 0; j < SNPL; j++) {
@@ -639,12 +352,7 @@ __global__ __launch_bounds__(256) void k_coarse_final(const float* __restrict__ 
         else m0 = k < m0 ? k : m0;
     }
     // 0xffffffff when fewer than P lanes (P > 32: lane halves) hold entries: keep all
-    uint32_t kb = P <= 32 ? wave_kth_smallest(m0 < m1 ? m0 : m1, P) : wave_kth_smallest2(m0, m1, P);
-    if constexpr (BF) {
-        // P entries have an approximate distance <= kb, so the exact P-th smallest is <= kb + m and whatever is at or
-        // below it has an approximate distance <= kb + 2 m
-        if (kb != 0xffffffffu) kb = f2key(key2f(kb) + slack);
-    }
+    const uint32_t kb = P <= 32 ? wave_kth_smallest(m0 < m1 ? m0 : m1, P) : wave_kth_smallest2(m0, m1, P);
     int c = 0;
 #pragma unroll
     for (int j = 0; j < NPL; j++) c += ((uint32_t)(it[j] >> 32) <= kb && it[j] != ~0ull) ? 1 : 0;
@@ -659,33 +367,6 @@ __global__ __launch_bounds__(256) void k_coarse_final(const float* __restrict__ 
     for (int j = 0; j < NPL; j++)
         if ((uint32_t)(it[j] >> 32) <= kb && it[j] != ~0ull) buf[off++] = it[j];
     __builtin_amdgcn_wave_barrier();
-    if constexpr (BF) {
-        // the entries that are left: exact distances, one lane per entry -- the k-ascending fma chain from 0 and the final
-        // fma + clamp of k_coarse_fused / k_coarse_repair
-        const float* xq = bf.x + (int64_t)q * bf.d;
-        for (int e = lane; e < tot; e += 64) {
-            const unsigned long long item = buf[e];
-            const unsigned col = (unsigned)item;
-            const float4* yr = reinterpret_cast<const float4*>(bf.y + (int64_t)col * bf.d);
-            const float4* xr = reinterpret_cast<const float4*>(xq);
-            float ip = 0.f;
-            for (int t = 0; t < bf.d / 4; t++) {
-                const float4 xv = xr[t], yv = yr[t];
-                ip = __builtin_fmaf(xv.x, yv.x, ip);
-                ip = __builtin_fmaf(xv.y, yv.y, ip);
-                ip = __builtin_fmaf(xv.z, yv.z, ip);
-                ip = __builtin_fmaf(xv.w, yv.w, ip);
-            }
-            float dis = __builtin_fmaf(-2.f, ip, xn + bf.yn[col]);
-            if (dis < 0.f) dis = 0.f;
-            if (bf.viol) {
-                const float approx = key2f((uint32_t)(item >> 32));
-                if (fabsf(approx - dis) > 0.5f * slack) atomicAdd(bf.viol, 1ull);
-            }
-            buf[e] = ((unsigned long long)f2key(dis) << 32) | col;
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
     // rank sort of the tot (<= 256) distinct items: lane holds items lane, lane + 64, ..
     unsigned long long mine[CF_BUF / 64];
     int rr[CF_BUF / 64];
@@ -863,8 +544,7 @@ CoarseFusedPlan coarse_fused_plan(int nq, int nlist, int P, int cap, bool exact_
 
 void launch_coarse_fused(hipStream_t s, const CoarseFusedPlan& pl, void* ws, const float* x, int nq, int d,
                          const float* y, int nlist, const float* yn, int P, float* out_dis, int* out_idx, bool exact_ties,
-                         unsigned long long* tie_stats, hipStream_t side, hipEvent_t fork, hipEvent_t join,
-                         const CoarseBf* bfp) {
+                         unsigned long long* tie_stats, hipStream_t side, hipEvent_t fork, hipEvent_t join) {
     char* b = static_cast<char*>(ws);
     float* mat = reinterpret_cast<float*>(b + pl.off_mat);
     float* tau = reinterpret_cast<float*>(b + pl.off_tau);
@@ -872,9 +552,6 @@ void launch_coarse_fused(hipStream_t s, const CoarseFusedPlan& pl, void* ws, con
     int* cnt = reinterpret_cast<int*>(b + pl.off_cnt);
     int* ovf = reinterpret_cast<int*>(b + pl.off_ovf);
     uint32_t* scratch = reinterpret_cast<uint32_t*>(b + pl.off_scratch);
-    const bool use_bf = bfp && bfp->yh && bfp->yl && (d % 32) == 0;
-    const float mc_ymax = use_bf ? coarse_bf_margin_c(d) * sqrtf(bfp->ynmax) : 0.f;
-    const size_t lds_bf = std::max((size_t)128 * (d + 1) * sizeof(float), (size_t)4 * 64 * (d + 8) * 2);
     // A: the sample columns, every distance stored (two strips: the 128 queries' fragments are loaded once per strip)
     const size_t lds = (size_t)2 * 64 * (d + 1) * sizeof(float);
     {
@@ -890,33 +567,12 @@ void launch_coarse_fused(hipStream_t s, const CoarseFusedPlan& pl, void* ws, con
         hipLaunchKernelGGL((k_coarse_fused<NCH, true>), sgrid, dim3(256), lds, s, x, nq, y, pl.sample, 0, yn, nullptr, \
                            tps, 0, pl.sample, reinterpret_cast<unsigned long long*>(mat), nullptr, sstrips, nullptr);  \
     } while (0)
-#define GH_CSB(NCH)                                                                                                     \
-    do {                                                                                                                \
-        static std::atomic<uint64_t> attr{0};   /* per device */                                                        \
-        if (first_call_on_device(attr)) {                                                                               \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_coarse_fused_bf<NCH, true>),                      \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bf);                         \
-        }                                                                                                               \
-        hipLaunchKernelGGL((k_coarse_fused_bf<NCH, true>), sgrid, dim3(256), lds_bf, s, x, nq, bfp->yh, bfp->yl, pl.sample, \
-                           0, yn, nullptr, mc_ymax, bfp->ynmax, tps, 0, pl.sample,                                      \
-                           reinterpret_cast<unsigned long long*>(mat), nullptr, sstrips, nullptr);                     \
-    } while (0)
-        if (use_bf) {
-            switch (d) {
-                case 32: GH_CSB(2); break;
-                case 64: GH_CSB(4); break;
-                case 96: GH_CSB(6); break;
-                default: GH_CSB(8); break;
-            }
-        } else {
-            switch (d) {
-                case 32: GH_CS(2); break;
-                case 64: GH_CS(4); break;
-                case 96: GH_CS(6); break;
-                default: GH_CS(8); break;
-            }
+        switch (d) {
+            case 32: GH_CS(2); break;
+            case 64: GH_CS(4); break;
+            case 96: GH_CS(6); break;
+            default: GH_CS(8); break;
         }
-#undef GH_CSB
 #undef GH_CS
     }
     if (pl.sample == 512) hipLaunchKernelGGL(k_coarse_bound<8>, dim3((nq + 3) / 4), dim3(256), 0, s, mat, nq, P, tau, ovf);
@@ -934,72 +590,17 @@ void launch_coarse_fused(hipStream_t s, const CoarseFusedPlan& pl, void* ws, con
         hipLaunchKernelGGL((k_coarse_fused<NCH>), grid, dim3(256), lds, s, x, nq, y, nlist, pl.sample, yn, tau,         \
                            pl.tiles_per_strip, pl.cap, pl.cap_stride, cand, cnt, pl.nseg, nullptr);                          \
     } while (0)
-#define GH_CFB(NCH)                                                                                                     \
-    do {                                                                                                                \
-        static std::atomic<uint64_t> attr{0};   /* per device */                                                        \
-        if (first_call_on_device(attr)) {                                                                               \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_coarse_fused_bf<NCH, false>),                     \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bf);                         \
-        }                                                                                                               \
-        hipLaunchKernelGGL((k_coarse_fused_bf<NCH, false>), grid, dim3(256), lds_bf, s, x, nq, bfp->yh, bfp->yl, nlist,  \
-                           pl.sample, yn, tau, mc_ymax, bfp->ynmax, pl.tiles_per_strip, pl.cap, pl.cap_stride, cand, cnt, \
-                           pl.nseg, cdbg);                                                                              \
-    } while (0)
-    static unsigned long long* cdbg = nullptr;
-    static const bool want_cdbg = getenv("GAMMA_HIP_COARSE_CLK") != nullptr;
-    static int cshown = 0;
-    if (want_cdbg) {
-        if (!cdbg) {
-            (void)hipMalloc((void**)&cdbg, 24 * sizeof(unsigned long long));
-            (void)hipMemset(cdbg, 0, 24 * sizeof(unsigned long long));
-        }
-        if (cshown++ % 10 == 9) {
-            unsigned long long hh[24];
-            (void)hipStreamSynchronize(s);
-            (void)hipMemcpy(hh, cdbg, sizeof(hh), hipMemcpyDeviceToHost);
-            fprintf(stderr, "coarse bf workgroup 0 (10 ns ticks): prologue %llu first tile %llu tiles", hh[1] - hh[0], hh[2] - hh[1]);
-            for (int i = 3; i < 10 && hh[i]; i++) fprintf(stderr, " %llu", hh[i] - hh[i - 1]);
-            fprintf(stderr, " total %llu; second tile (shader clocks): step %llu gload %llu step %llu stage %llu barrier %llu\n", hh[11] - hh[0],
-                    hh[13] - hh[12], hh[14] - hh[13], hh[15] - hh[14], hh[16] - hh[15], hh[17] - hh[16]);
-        }
+    switch (d) {
+        case 32: GH_CF(2); break;
+        case 64: GH_CF(4); break;
+        case 96: GH_CF(6); break;
+        default: GH_CF(8); break;
     }
-    if (use_bf) {
-        switch (d) {
-            case 32: GH_CFB(2); break;
-            case 64: GH_CFB(4); break;
-            case 96: GH_CFB(6); break;
-            default: GH_CFB(8); break;
-        }
-    } else {
-        switch (d) {
-            case 32: GH_CF(2); break;
-            case 64: GH_CF(4); break;
-            case 96: GH_CF(6); break;
-            default: GH_CF(8); break;
-        }
-    }
-#undef GH_CFB
 #undef GH_CF
     // C + D
-    CoarseBfArgs bfa;
-    if (use_bf) {
-        bfa.x = x;
-        bfa.y = y;
-        bfa.yn = yn;
-        bfa.d = d;
-        bfa.mc_ymax = mc_ymax;
-        bfa.ynmax = bfp->ynmax;
-        bfa.viol = bfp->viol;
-    }
 #define GH_FIN(SN, MS)                                                                                                  \
-    do {                                                                                                                \
-        if (use_bf)                                                                                                     \
-            hipLaunchKernelGGL((k_coarse_final<SN, MS, true>), dim3((nq + 3) / 4), dim3(256), 0, s, mat, tau, cand, cnt, pl.nseg, \
-                               pl.cap, pl.cap_stride, nq, P, out_dis, out_idx, ovf, exact_ties ? 1 : 0, bfa);            \
-        else                                                                                                            \
-            hipLaunchKernelGGL((k_coarse_final<SN, MS, false>), dim3((nq + 3) / 4), dim3(256), 0, s, mat, tau, cand, cnt, pl.nseg, \
-                               pl.cap, pl.cap_stride, nq, P, out_dis, out_idx, ovf, exact_ties ? 1 : 0, bfa);            \
-    } while (0)
+    hipLaunchKernelGGL((k_coarse_final<SN, MS>), dim3((nq + 3) / 4), dim3(256), 0, s, mat, tau, cand, cnt, pl.nseg, pl.cap, \
+                       pl.cap_stride, nq, P, out_dis, out_idx, ovf, exact_ties ? 1 : 0)
     if (pl.sample == 512) {
         if (pl.nseg <= 4) GH_FIN(8, 4);
         else if (pl.nseg <= 8) GH_FIN(8, 8);

@@ -104,7 +104,7 @@ int gamma_hip_destroy(gamma_hip_index* h) {
         (void)hipMemAddressFree(h->d_raw, h->raw_va_bytes);
         h->d_raw = nullptr;
     }
-    void* ptrs[] = {h->d_cc_hi, h->d_cc_lo, h->d_bf_viol, h->d_list_rank, h->d_raw, h->d_bitmap, h->d_cc, h->d_cc_norms, h->d_pqc, h->d_T2, h->d_codes,
+    void* ptrs[] = {h->d_list_rank, h->d_raw, h->d_bitmap, h->d_cc, h->d_cc_norms, h->d_pqc, h->d_T2, h->d_codes,
                     h->d_ids, h->d_list_mask, h->d_scan_codes, h->d_tie_stats, h->d_v2d, h->d_sums, h->d_t2max};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -159,24 +159,6 @@ int gamma_hip_set_deferred_replay(gamma_hip_index* h, int on) {
         h->replay_pending = false;
     }
     h->defer_replay = on != 0;
-    return GAMMA_HIP_OK;
-}
-
-int gamma_hip_coarse_bf_check(gamma_hip_index* h, int on, int64_t* violations) {
-    if (!h) return GAMMA_HIP_EINVAL;
-    SearchLock lk(h);
-    GH_CHECK(h, hipSetDevice(h->device));
-    if (!h->d_bf_viol) {
-        GH_CHECK(h, hipMalloc((void**)&h->d_bf_viol, sizeof(unsigned long long)));
-        GH_CHECK(h, hipMemset(h->d_bf_viol, 0, sizeof(unsigned long long)));
-    }
-    GH_CHECK(h, hipStreamSynchronize(h->stream));
-    if (violations) {
-        unsigned long long v = 0;
-        GH_CHECK(h, hipMemcpy(&v, h->d_bf_viol, sizeof(v), hipMemcpyDeviceToHost));
-        *violations = (int64_t)v;
-    }
-    h->bf_check = on != 0;
     return GAMMA_HIP_OK;
 }
 

@@ -165,11 +165,6 @@ struct gamma_hip_index {
     int d = 0, nlist = 0, M = 0, ksub = 256, dsub = 0, code_size = 0, metric = GAMMA_HIP_METRIC_L2;
     int bucket_init = 1000, bucket_max = 1280000;
     float *d_cc = nullptr, *d_cc_norms = nullptr, *d_pqc = nullptr, *d_T2 = nullptr;
-    // the centroids as bf16 hi / lo rows + their largest norm: the filter of the matrix-free coarse quantizer (coarse.hip)
-    uint16_t *d_cc_hi = nullptr, *d_cc_lo = nullptr;
-    float cc_ynmax = 0.f;
-    unsigned long long* d_bf_viol = nullptr;   // debug counter (gamma_hip_coarse_bf_check)
-    bool bf_check = false;
     int* d_list_rank = nullptr;   // spatial order of the coarse centroids (scan locality only)
     bool sort_queries = getenv("GAMMA_HIP_NO_QUERY_SORT") == nullptr;
     bool scan_bound = getenv("GAMMA_HIP_NO_SCAN_BOUND") == nullptr;

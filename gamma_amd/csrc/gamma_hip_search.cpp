@@ -166,20 +166,8 @@ int ivfpq_coarse(H* h, const gamma_hip_search_params* p, int nq, const float* d_
     if (fused) {
         static const bool no_side = getenv("GAMMA_HIP_NO_SIDE_STREAM") != nullptr;
         const bool side = h->exact_ties && defer_join && !no_side;
-        // experimental (coarse.hip): the filter on bf16 matrix instructions, the decision on exact fp32 values.
-        // Bit-identical output, but not faster yet -- the survivor stores bound both kernels -- so it is opt-in:
-        // GAMMA_HIP_COARSE_BF=1 or gamma_hip_coarse_bf_check(h, 1, ..)
-        static const bool env_bf = getenv("GAMMA_HIP_COARSE_BF") != nullptr;
-        gh::CoarseBf bf;
-        if ((env_bf || h->bf_check) && h->d_cc_hi && h->d_cc_lo && (d % 32) == 0) {
-            bf.yh = h->d_cc_hi;
-            bf.yl = h->d_cc_lo;
-            bf.ynmax = h->cc_ynmax;
-            bf.viol = h->bf_check ? h->d_bf_viol : nullptr;
-        }
         gh::launch_coarse_fused(s, plan, h->w_mat.p, d_x, nq, d, h->d_cc, nlist, h->d_cc_norms, P, out_dis, out_probe,
-                                h->exact_ties, h->d_tie_stats, side ? h->side : nullptr, h->ev_fork, h->ev_join,
-                                bf.yh ? &bf : nullptr);
+                                h->exact_ties, h->d_tie_stats, side ? h->side : nullptr, h->ev_fork, h->ev_join);
         h->coarse_join_pending = side;
         static const bool dbg = getenv("GAMMA_HIP_COARSE_DBG") != nullptr;
         if (dbg) {   // how many queries the strip lists could not hold (they went through the repair kernel)

@@ -703,21 +703,6 @@ int gamma_hip_ivfflat_init(gamma_hip_index* h, int d, int nlist, int metric, int
     return ivf_init_locked(h, d, nlist, 1, metric, bucket_init_size, bucket_max_size, true);
 }
 
-// the coarse centroids changed: their bf16 hi / lo rows and largest norm for the matrix-free coarse filter
-static int centroids_bf16(H* h) {
-    const size_t n = (size_t)h->nlist * h->d;
-    if (!h->d_cc_hi) GH_CHECK(h, hipMalloc((void**)&h->d_cc_hi, n * sizeof(uint16_t)));
-    if (!h->d_cc_lo) GH_CHECK(h, hipMalloc((void**)&h->d_cc_lo, n * sizeof(uint16_t)));
-    gh::launch_split_bf16(h->wstream, h->d_cc, (int64_t)n, h->d_cc_hi, h->d_cc_lo);
-    std::vector<float> norms(h->nlist);
-    GH_CHECK(h, hipMemcpyAsync(norms.data(), h->d_cc_norms, (size_t)h->nlist * sizeof(float), hipMemcpyDeviceToHost, h->wstream));
-    GH_CHECK(h, hipStreamSynchronize(h->wstream));
-    float mx = 0.f;
-    for (float v : norms) mx = std::max(mx, v);
-    h->cc_ynmax = mx;
-    return GAMMA_HIP_OK;
-}
-
 int gamma_hip_ivfflat_set_trained(gamma_hip_index* h, const float* cc) {
     if (!h || !cc) return GAMMA_HIP_EINVAL;
     WriteLock lk(h);
@@ -727,7 +712,6 @@ int gamma_hip_ivfflat_set_trained(gamma_hip_index* h, const float* cc) {
     gh::launch_row_norms(h->wstream, h->d_cc, h->nlist, h->d, h->d_cc_norms);
     GH_CHECK(h, hipGetLastError());
     GH_CHECK(h, hipStreamSynchronize(h->wstream));
-    GH_TRY(centroids_bf16(h));
     h->trained = true;
     return GAMMA_HIP_OK;
 }
@@ -742,7 +726,6 @@ int gamma_hip_ivfpq_set_trained(gamma_hip_index* h, const float* cc, const float
     GH_CHECK(h, hipMemcpyAsync(h->d_cc, cc, ncc * sizeof(float), hipMemcpyHostToDevice, h->wstream));
     GH_CHECK(h, hipMemcpyAsync(h->d_pqc, pqc, npq * sizeof(float), hipMemcpyHostToDevice, h->wstream));
     gh::launch_row_norms(h->wstream, h->d_cc, h->nlist, h->d, h->d_cc_norms);
-    GH_TRY(centroids_bf16(h));
     if (table)
         GH_CHECK(h, hipMemcpyAsync(h->d_T2, table, nt * sizeof(float), hipMemcpyHostToDevice, h->wstream));
     else

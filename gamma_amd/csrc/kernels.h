@@ -172,20 +172,10 @@ CoarseFusedPlan coarse_fused_plan(int nq, int nlist, int P, int cap, bool exact_
 // (select.hip k_coarse_heap_fix): the K nearest in the reference's order, ties included
 void launch_coarse_heap_rows(hipStream_t s, const float* mat, int nlist, int nq, int K, const int* rows, float* out_vals,
                              int* out_pos, unsigned long long* tie_stats);
-// the centroids as bf16 hi / lo rows (launch_split_bf16) and the largest centroid norm: the filter of the matrix-free
-// coarse quantizer then runs on bf16 matrix instructions, the decision on exact fp32 values (coarse.hip)
-struct CoarseBf {
-    const uint16_t* yh = nullptr;
-    const uint16_t* yl = nullptr;
-    float ynmax = 0.f;
-    unsigned long long* viol = nullptr;   // debug counter (GAMMA_HIP_COARSE_BF_CHECK)
-};
-void launch_split_bf16(hipStream_t s, const float* y, int64_t n, uint16_t* hi, uint16_t* lo);
 void launch_coarse_fused(hipStream_t s, const CoarseFusedPlan& pl, void* ws, const float* x, int nq, int d,
                          const float* y, int nlist, const float* yn, int P, float* out_dis, int* out_idx,
                          bool exact_ties = false, unsigned long long* tie_stats = nullptr,
-                         hipStream_t side = nullptr, hipEvent_t fork = nullptr, hipEvent_t join = nullptr,
-                         const CoarseBf* bf = nullptr);
+                         hipStream_t side = nullptr, hipEvent_t fork = nullptr, hipEvent_t join = nullptr);
 // small batches: exact coarse distances [nq][nlist] + inner-product tables [nq][M][256] in one launch; false = shape
 // not covered (nq > 16), nothing launched
 bool launch_small_coarse_ip(hipStream_t s, const float* x, int nq, int d, const float* cc, int nlist, float* mat, int M,

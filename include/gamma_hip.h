@@ -335,11 +335,6 @@ int gamma_hip_ivfpq_search_device(gamma_hip_index* h, const gamma_hip_search_par
  * next search call on the handle, gamma_hip_join (the handle's stream waits for the pending replay; no host wait) or
  * gamma_hip_synchronize.  Host-buffer calls are not affected.  Default: off. */
 int gamma_hip_set_deferred_replay(gamma_hip_index* h, int on);
-/* experimental: on = 1 runs the FILTER of the matrix-free coarse quantizer on bf16 matrix products (three products of hi / lo
- * halves) and the decision on exact fp32 distances -- same coarse_dis / coarse_idx bytes -- and counts filter values that
- * are further from the exact distance than the margin the filter allows for (must stay 0).  violations (may be NULL):
- * the count so far.  Off by default: the kernel is not faster than the fp32 one yet. */
-int gamma_hip_coarse_bf_check(gamma_hip_index* h, int on, int64_t* violations);
 int gamma_hip_join(gamma_hip_index* h);
 /* stage outputs of the LAST search for parity tests / sharded merge (device->host):
  * coarse_dis/idx [nq*nprobe], recall_dis/ids [nq*recall_num] (sorted best first, -1 pad) */
