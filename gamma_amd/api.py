@@ -466,7 +466,8 @@ class GammaHip:
         return self.L.gamma_hip_total_mem_bytes(self.h)
 
     def profile_enable(self, on=True):
-        self._ck(self.L.gamma_hip_profile_enable(self.h, 1 if on else 0), "profile_enable")
+        # on: False / 0 off, True / 1 every stage + scanned-code counter, 2 the scan stage alone (include/gamma_hip.h)
+        self._ck(self.L.gamma_hip_profile_enable(self.h, int(on)), "profile_enable")
 
     def profile_reset(self):
         self._ck(self.L.gamma_hip_profile_reset(self.h), "profile_reset")

@@ -243,7 +243,7 @@ int64_t gamma_hip_total_mem_bytes(gamma_hip_index* h) {
 int gamma_hip_profile_enable(gamma_hip_index* h, int on) {
     if (!h) return GAMMA_HIP_EINVAL;
     SearchLock lk(h);
-    h->profile = on != 0;
+    h->profile = on == 2 ? 2 : (on != 0 ? 1 : 0);
     return GAMMA_HIP_OK;
 }
 

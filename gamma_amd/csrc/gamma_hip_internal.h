@@ -273,7 +273,7 @@ struct gamma_hip_index {
     size_t dir_pin_bytes = 0;
 
     // profiling
-    bool profile = false;
+    int profile = 0;   // 0 off, 1 every stage + the scanned-code counter, 2 the scan stage alone (gamma_hip_profile_enable)
     std::vector<StageEvent> events;
     std::vector<hipEvent_t> event_pool;
     double stage_ms[GAMMA_HIP_NUM_STAGES] = {0};
@@ -348,7 +348,7 @@ struct StageScope {
     bool count;   // false: add the time to the stage but do not count a new invocation
     hipEvent_t a = nullptr, b = nullptr;
     StageScope(H* h_, int st, bool count_ = true) : h(h_), stage(st), count(count_) {
-        if (h->profile) {
+        if (h->profile == 1 || (h->profile == 2 && st == GAMMA_HIP_STAGE_SCAN && count_)) {
             // events are recycled: creating / destroying two per stage and step costs the host
             // more than the stages' launches
             auto take = [&]() -> hipEvent_t {

@@ -289,6 +289,33 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     // (one group per query -- few probes, or a shard -- is fine: the producer bounds and compacts its own candidates)
     const bool bounded = (!shard || compacted) && h->scan_bound && R <= 256 && P <= 128 && G >= 4;
     const bool fuse_ip = bounded && PGN == 1 && (M == 16 || M == 32) && !getenv("GAMMA_HIP_NO_FUSED_IP");
+    // the bounded scan's per-call state (repair list, ready words, survivor counts) is sized here, before the pair offsets,
+    // whose kernel clears it together with the tie flags -- one launch instead of four fills in front of the scan
+    const int cap = gh::scan_slice_cap();
+    bool cf_ok = false;
+    int PGM = PGN, nsl = PGN;
+    unsigned long long* ready = nullptr;
+    if (bounded) {
+        // filter pass of the consumers (kernels.hip, CF): needs the sums beside the arena the scan reads -- not the
+        // shadow arena of a call running over lists compacted under its filter.  With it ONE consumer workgroup per
+        // query takes every probe behind the producer's: two groups, two slices per query.
+        static const bool no_cf = getenv("GAMMA_HIP_NO_SCAN_CF") != nullptr;
+        // (short lists only: with thousands of codes per list the per-pair table costs next to nothing, while ONE consumer
+        //  workgroup per query overruns its candidate stage and sends the query to the unfiltered path -- full-size C4, 6100
+        //  codes per list: 38.6 ms per 8192 queries with the filter pass, 27.6 without)
+        static const double cf_maxlen = getenv("GAMMA_HIP_SCAN_CF_MAXLEN") ? atof(getenv("GAMMA_HIP_SCAN_CF_MAXLEN")) : 2000.0;
+        cf_ok = !no_cf && (!h->prefiltered || h->cmp_has_sums) && PGN > 1 &&
+                (double)h->ntotal / std::max(1, nlist) <= cf_maxlen &&
+                gh::scan_cf_applies(l2, M, P, G, h->d_sums && h->d_t2max, false);
+        PGM = cf_ok ? 2 : PGN;   // probe groups of the main launch
+        nsl = PGM;               // one survivor slice per probe group (slice 0: the producer's own)
+        // rq | ready[nq] | gcnt[nq][nsl]   (rq: count + list of the queries that need the repair launch, 8-byte aligned)
+        const size_t rq_bytes = (((size_t)nq + 1) * sizeof(int) + 7) & ~(size_t)7;
+        GH_CHECK(h, h->w_scnt.ensure(rq_bytes + (size_t)nq * (sizeof(unsigned long long) + (size_t)nsl * sizeof(int))));
+        GH_CHECK(h, h->w_sflag.ensure((size_t)nq));
+        GH_CHECK(h, h->w_surv.ensure((size_t)nq * nsl * cap * sizeof(unsigned long long)));
+        ready = reinterpret_cast<unsigned long long*>(h->w_scnt.as<char>() + rq_bytes);
+    }
     {
         StageScope t(h, GAMMA_HIP_STAGE_TABLES);
         if (!fuse_ip) {
@@ -302,13 +329,20 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         if (h->tie.on) {
             GH_CHECK(h, h->w_tcut.ensure((size_t)nq));
             GH_CHECK(h, h->w_tlist.ensure(((size_t)nq + 1) * sizeof(int)));   // count | list[nq]
-            GH_CHECK(h, hipMemsetAsync(h->w_tcut.p, 0, (size_t)nq, s));
-            GH_CHECK(h, hipMemsetAsync(h->w_tlist.p, 0, sizeof(int), s));
+        }
+        gh::PairZero pz;
+        if (h->tie.on) {
+            pz.bytes = h->w_tcut.as<uint8_t>();
+            pz.count_a = h->w_tlist.as<int>();
+        }
+        if (bounded) {
+            pz.words = ready;
+            pz.count_b = h->w_scnt.as<int>();
         }
         gh::launch_pair_offsets(s, h->w_probe.as<int>(), nq, P, h->d_list_len, h->d_list_mask, nlist,
                                 h->w_pair_off.as<int>(), h->w_qtotal.as<int>(),
-                                h->profile ? h->d_scan_codes : nullptr, h->d_list_off,
-                                h->w_pair_base.as<int64_t>());
+                                h->profile == 1 ? h->d_scan_codes : nullptr, h->d_list_off,
+                                h->w_pair_base.as<int64_t>(), &pz);
         // enough queries that L2 capacity matters: run them in spatial order (kernels.hip)
         // (not when the T2 rows of the lists scanned here fit the L2s anyway: a shard of a small index)
         if (h->sort_queries && h->d_list_rank && nq >= 256 && t2_bytes > ((int64_t)8 << 20)) {
@@ -352,29 +386,6 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
             gh::launch_flag_cut_ties(s, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), nq, R, out_dis,
                                      h->w_cand_pos.as<int>(), nullptr, h->w_tcut.as<uint8_t>());
     } else {
-        const int cap = gh::scan_slice_cap();
-        // filter pass of the consumers (kernels.hip, CF): needs the sums beside the arena the scan reads -- not the
-        // shadow arena of a call running over lists compacted under its filter.  With it ONE consumer workgroup per
-        // query takes every probe behind the producer's: two groups, two slices per query.
-        static const bool no_cf = getenv("GAMMA_HIP_NO_SCAN_CF") != nullptr;
-        // (short lists only: with thousands of codes per list the per-pair table costs next to nothing, while ONE consumer
-        //  workgroup per query overruns its candidate stage and sends the query to the unfiltered path -- full-size C4, 6100
-        //  codes per list: 38.6 ms per 8192 queries with the filter pass, 27.6 without)
-        static const double cf_maxlen = getenv("GAMMA_HIP_SCAN_CF_MAXLEN") ? atof(getenv("GAMMA_HIP_SCAN_CF_MAXLEN")) : 2000.0;
-        const bool cf_ok = !no_cf && (!h->prefiltered || h->cmp_has_sums) && PGN > 1 &&
-                           (double)h->ntotal / std::max(1, nlist) <= cf_maxlen &&
-                           gh::scan_cf_applies(l2, M, P, G, h->d_sums && h->d_t2max, false);
-        const int PGM = cf_ok ? 2 : PGN;   // probe groups of the main launch
-        // one survivor slice per probe group (slice 0: the producer's own)
-        const int nsl = PGM;
-        // rq | ready[nq] | gcnt[nq][nsl]   (rq: count + list of the queries that need the repair launch, 8-byte aligned)
-        const size_t rq_bytes = (((size_t)nq + 1) * sizeof(int) + 7) & ~(size_t)7;
-        GH_CHECK(h, h->w_scnt.ensure(rq_bytes + (size_t)nq * (sizeof(unsigned long long) + (size_t)nsl * sizeof(int))));
-        GH_CHECK(h, h->w_sflag.ensure((size_t)nq));
-        GH_CHECK(h, h->w_surv.ensure((size_t)nq * nsl * cap * sizeof(unsigned long long)));
-        unsigned long long* ready = reinterpret_cast<unsigned long long*>(h->w_scnt.as<char>() + rq_bytes);
-        GH_CHECK(h, hipMemsetAsync(h->w_scnt.p, 0, sizeof(int), s));
-        GH_CHECK(h, hipMemsetAsync(ready, 0, (size_t)nq * sizeof(unsigned long long), s));
         gh::ScanBound sb;
         sb.ready = ready;
         sb.surv = h->w_surv.as<unsigned long long>();

@@ -109,10 +109,17 @@ void launch_pq_ip_table(hipStream_t s, const float* x, int nq, int d, int M, con
                         float* out);
 void launch_precompute_table(hipStream_t s, const float* cc, int nlist, int d, int M,
                              const float* pqc, float* out);
+// per-call state cleared by the pair-offset kernel (one byte and one 8-byte word per query, two counters); null = skip
+struct PairZero {
+    uint8_t* bytes = nullptr;
+    unsigned long long* words = nullptr;
+    int* count_a = nullptr;
+    int* count_b = nullptr;
+};
 void launch_pair_offsets(hipStream_t s, const int* probe_list, int nq, int P, const int* list_len,
                          const uint8_t* list_mask, int nlist, int* pair_off, int* q_total,
                          unsigned long long* scan_codes, const int64_t* list_off = nullptr,
-                         int64_t* pair_base = nullptr);
+                         int64_t* pair_base = nullptr, const PairZero* zero = nullptr);
 void launch_compact_probes(hipStream_t s, const int* probe_in, const float* cdis_in, int nq, int P,
                            const int* list_len, const uint8_t* list_mask, int nlist, int* probe_out,
                            float* cdis_out);

@@ -988,11 +988,20 @@ __global__ __launch_bounds__(256) void k_pair_offsets(const int* __restrict__ pr
                                                       int* __restrict__ q_total,
                                                       unsigned long long* __restrict__ scan_codes,
                                                       const int64_t* __restrict__ list_off,
-                                                      int64_t* __restrict__ pair_base) {
+                                                      int64_t* __restrict__ pair_base, PairZero z) {
     // one wave per query: the scan is a wave-shuffle prefix sum, no barriers
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (q >= nq) return;
+    // the per-call state the scan / selection / tie flags start from zero, cleared here instead of by four fills
+    if (lane == 0) {
+        if (z.bytes) z.bytes[q] = 0;
+        if (z.words) z.words[q] = 0ull;
+        if (q == 0) {
+            if (z.count_a) *z.count_a = 0;
+            if (z.count_b) *z.count_b = 0;
+        }
+    }
     int running = 0;
     for (int p0 = 0; p0 < P; p0 += 64) {
         const int p = p0 + lane;
@@ -1076,10 +1085,11 @@ __global__ __launch_bounds__(256) void k_sum_totals(const int* __restrict__ q_to
 }
 void launch_pair_offsets(hipStream_t s, const int* probe_list, int nq, int P, const int* list_len,
                          const uint8_t* list_mask, int nlist, int* pair_off, int* q_total,
-                         unsigned long long* scan_codes, const int64_t* list_off, int64_t* pair_base) {
+                         unsigned long long* scan_codes, const int64_t* list_off, int64_t* pair_base,
+                         const PairZero* zero) {
     if (nq <= 0) return;
     hipLaunchKernelGGL(k_pair_offsets, dim3((nq + 3) / 4), dim3(256), 0, s, probe_list, nq, P, list_len,
-                       list_mask, nlist, pair_off, q_total, scan_codes, list_off, pair_base);
+                       list_mask, nlist, pair_off, q_total, scan_codes, list_off, pair_base, zero ? *zero : PairZero());
     if (scan_codes)
         hipLaunchKernelGGL(k_sum_totals, dim3(std::min(64, (nq + 255) / 256)), dim3(256), 0, s, q_total, nq,
                            scan_codes);

@@ -467,6 +467,10 @@ int64_t gamma_hip_total_mem_bytes(gamma_hip_index* h);
 #define GAMMA_HIP_STAGE_RERANK 4
 #define GAMMA_HIP_STAGE_FLAT 5
 #define GAMMA_HIP_NUM_STAGES 6
+/* on: 0 off; 1 every stage, plus the counter of scanned codes behind gamma_hip_profile_scan_bytes; 2 the scan stage alone --
+ * two events around the scan launch and nothing else.  (Under rocprofv3's kernel trace an event pair between two kernels
+ * shows as a 10-16 us gap; without the tracer the call rate is the same with 0, 1 and 2 -- bench.py --timed-events, 60
+ * steps of 16384 queries each: 1.635 / 1.629 / 1.642 ms.) */
 int gamma_hip_profile_enable(gamma_hip_index* h, int on);
 int gamma_hip_profile_reset(gamma_hip_index* h);
 /* total milliseconds and number of timed launches of a stage since the last reset;
