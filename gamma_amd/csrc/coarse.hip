@@ -623,8 +623,13 @@ void launch_coarse_fused(hipStream_t s, const CoarseFusedPlan& pl, void* ws, con
     // query) and walked the way faiss's HeapResultHandler walks it (k_coarse_heap_fix).  The two kernels may run on a
     // side stream beside the caller's next kernels that do not read the assignment; the caller waits for `join`
     // before the first one that does.
+    // (the recompute stays on the caller's stream: beside the caller's next kernel -- the query tables, which fill the
+    //  chip -- its few workgroups wait for slots and the launch takes 65 us instead of 25; the walk, one wave per row and
+    //  all latency, is what runs beside it)
+    static const bool store_side = getenv("GAMMA_HIP_COARSE_STORE_SIDE") != nullptr;
     hipStream_t rs = s;
-    if (side && fork && join) {
+    const bool forked = side && fork && join;
+    if (forked && store_side) {
         (void)hipEventRecord(fork, s);
         (void)hipStreamWaitEvent(side, fork, 0);
         rs = side;
@@ -644,6 +649,11 @@ void launch_coarse_fused(hipStream_t s, const CoarseFusedPlan& pl, void* ws, con
             default: GH_CR(8); break;
         }
 #undef GH_CR
+    }
+    if (forked && !store_side) {
+        (void)hipEventRecord(fork, s);
+        (void)hipStreamWaitEvent(side, fork, 0);
+        rs = side;
     }
     launch_coarse_heap_rows(rs, full, nlist, nq, P, ovf, out_dis, out_idx, tie_stats);
     if (rs != s) (void)hipEventRecord(join, rs);

@@ -122,7 +122,7 @@ int gamma_hip_destroy(gamma_hip_index* h) {
                       &h->w_qtotal, &h->w_dist, &h->w_cand_dis, &h->w_cand_pos, &h->w_cand_ids,
                       &h->w_exact, &h->w_selv, &h->w_selp, &h->w_x, &h->w_outd, &h->w_outl, &h->w_stage,
                       &h->w_filter, &h->w_m_dis, &h->w_m_ids, &h->w_part_v, &h->w_part_i, &h->w_assign,
-                      &h->w_codes_tmp, &h->w_qperm, &h->w_scnt, &h->w_sflag, &h->w_surv, &h->w_pair_base,
+                      &h->w_codes_tmp, &h->w_qperm, &h->w_qbins, &h->w_scnt, &h->w_sflag, &h->w_surv, &h->w_pair_base,
                       &h->w_pair_ip, &h->w_flat_cand, &h->w_flat_meta, &h->w_full_cdis,
                       &h->w_full_probe, &h->w_ftab, &h->w_qfil, &h->w_tieflag, &h->w_tcut, &h->w_tlist, &h->w_lm_units, &h->w_lm_cnt, &h->w_fbits, &h->w_cmp_codes, &h->w_cmp_ids, &h->w_cmp_len, &h->w_cmp_sums, &h->w_fD, &h->w_fI, &h->w_fx, &h->w_fslab, &h->w_flog, &h->w_mr_vals, &h->w_mr_ids, &h->w_mr_meta,
                       &h->we_mat, &h->we_cdis, &h->we_x, &h->we_assign, &h->we_codes, &h->we_stage};

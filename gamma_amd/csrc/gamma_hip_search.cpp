@@ -331,6 +331,23 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
             GH_CHECK(h, h->w_tlist.ensure(((size_t)nq + 1) * sizeof(int)));   // count | list[nq]
         }
         gh::PairZero pz;
+        // enough queries that L2 capacity matters: run them in spatial order (kernels.hip)
+        // (not when the T2 rows of the lists scanned here fit the L2s anyway: a shard of a small index)
+        const bool order = h->sort_queries && h->d_list_rank && nq >= 256 && t2_bytes > ((int64_t)8 << 20);
+        int* qo_bins = nullptr;
+        if (order) {
+            GH_CHECK(h, h->w_qperm.ensure((size_t)2 * nq * sizeof(int)));   // qperm | qkey
+            if (gh::query_order_grid(nq)) {
+                if (!h->w_qbins.p) {   // histogram | cursors; every call leaves the histogram zero
+                    GH_CHECK(h, h->w_qbins.ensure((size_t)2 * gh::query_order_bins() * sizeof(int)));
+                    GH_CHECK(h, hipMemsetAsync(h->w_qbins.p, 0, (size_t)2 * gh::query_order_bins() * sizeof(int), s));
+                }
+                qo_bins = h->w_qbins.as<int>();
+                pz.qo_rank = h->d_list_rank;
+                pz.qo_key = h->w_qperm.as<int>() + nq;
+                pz.qo_bins = qo_bins;
+            }
+        }
         if (h->tie.on) {
             pz.bytes = h->w_tcut.as<uint8_t>();
             pz.count_a = h->w_tlist.as<int>();
@@ -343,12 +360,9 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
                                 h->w_pair_off.as<int>(), h->w_qtotal.as<int>(),
                                 h->profile == 1 ? h->d_scan_codes : nullptr, h->d_list_off,
                                 h->w_pair_base.as<int64_t>(), &pz);
-        // enough queries that L2 capacity matters: run them in spatial order (kernels.hip)
-        // (not when the T2 rows of the lists scanned here fit the L2s anyway: a shard of a small index)
-        if (h->sort_queries && h->d_list_rank && nq >= 256 && t2_bytes > ((int64_t)8 << 20)) {
-            GH_CHECK(h, h->w_qperm.ensure(((size_t)2 * nq + gh::query_order_bins()) * sizeof(int)));   // qperm | qkey | bins
+        if (order) {
             gh::launch_query_order(s, h->w_probe.as<int>(), nq, P, h->d_list_rank, nlist,
-                                   h->w_qperm.as<int>() + nq, h->w_qperm.as<int>(), h->w_qperm.as<int>() + 2 * (size_t)nq);
+                                   h->w_qperm.as<int>() + nq, h->w_qperm.as<int>(), qo_bins, qo_bins != nullptr);
             qperm = h->w_qperm.as<int>();
         }
         h->last_qperm = qperm;   // stage B runs the re-rank in the same order

@@ -115,6 +115,10 @@ struct PairZero {
     unsigned long long* words = nullptr;
     int* count_a = nullptr;
     int* count_b = nullptr;
+    // histogram pass of the grid-wide query order (launch_query_order with hist_done): list_rank, qkey[nq], bins
+    const int* qo_rank = nullptr;
+    int* qo_key = nullptr;
+    int* qo_bins = nullptr;
 };
 void launch_pair_offsets(hipStream_t s, const int* probe_list, int nq, int P, const int* list_len,
                          const uint8_t* list_mask, int nlist, int* pair_off, int* q_total,
@@ -160,9 +164,11 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
                             const int* rq_list = nullptr, const int* rq_count = nullptr,   // repair launch (kernels.hip)
                             int chunk_len = 0, int max_units = 0);   // > 0: rq_list is a work list of list chunks (kernels.hip)
 int query_order_bins();
-// bins: query_order_bins() ints of scratch (large batches sort over the whole grid); may be null
+bool query_order_grid(int nq);   // the batch is sorted over the whole grid (needs bins)
+// bins: 2 * query_order_bins() ints (histogram | cursors) for the grid-wide sort of large batches; the histogram half is
+// zero on entry and left zero.  hist_done: qkey and the histogram were filled by the pair-offset kernel (PairZero::qo_*)
 void launch_query_order(hipStream_t s, const int* probe_list, int nq, int P, const int* list_rank,
-                        int nlist, int* qkey, int* qperm, int* bins = nullptr);
+                        int nlist, int* qkey, int* qperm, int* bins = nullptr, bool hist_done = false);
 void launch_sum_totals(hipStream_t s, const int* q_total, int nq, unsigned long long* acc);
 int select_kpad(int K);
 // coarse quantizer selection (ties at the K-th distance resolved like the reference's heap); tie_flag: nq bytes

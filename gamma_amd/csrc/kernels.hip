@@ -981,6 +981,7 @@ void launch_precompute_table(hipStream_t s, const float* cc, int nlist, int d, i
 // writes its distances.  grid = nq, block = 256.  Also masks lists not owned by this
 // shard (length 0) and accumulates the algorithmic scan-byte counter.
 // ------------------------------------------------------------------------------------
+constexpr int QO_BINS = 4096, QO_BATCH = 8;   // query order (below)
 __global__ __launch_bounds__(256) void k_pair_offsets(const int* __restrict__ probe_list, int nq, int P,
                                                       const int* __restrict__ list_len,
                                                       const uint8_t* __restrict__ list_mask,
@@ -1000,6 +1001,14 @@ __global__ __launch_bounds__(256) void k_pair_offsets(const int* __restrict__ pr
         if (q == 0) {
             if (z.count_a) *z.count_a = 0;
             if (z.count_b) *z.count_b = 0;
+        }
+        // the histogram pass of the grid-wide query order (k_qo_scan / k_qo_scatter below): key of the query's nearest list
+        if (z.qo_bins) {
+            const int l0 = probe_list[(int64_t)q * P];
+            const int r = (l0 >= 0 && l0 < nlist) ? z.qo_rank[l0] : 0;
+            const int key = (int)((int64_t)r * QO_BINS / nlist);
+            z.qo_key[q] = key;
+            atomicAdd(&z.qo_bins[key], 1);
         }
     }
     int running = 0;
@@ -1105,7 +1114,6 @@ void launch_sum_totals(hipStream_t s, const int* q_total, int nq, unsigned long 
 // of the coarse centroids (recursive principal-axis bisection, host side).  One workgroup;
 // keys are fetched QO_BATCH at a time so the strided loads overlap.
 // ------------------------------------------------------------------------------------
-constexpr int QO_BINS = 4096, QO_BATCH = 8;
 __global__ __launch_bounds__(1024) void k_query_order(const int* __restrict__ probe_list, int nq, int P,
                                                       const int* __restrict__ list_rank, int nlist,
                                                       int* __restrict__ qkey, int* __restrict__ qperm) {
@@ -1186,13 +1194,15 @@ __global__ __launch_bounds__(256) void k_qo_hist(const int* __restrict__ probe_l
     qkey[q] = key;
     atomicAdd(&bins[key], 1);
 }
-__global__ __launch_bounds__(1024) void k_qo_scan(int* __restrict__ bins) {
+// bins -> cursor (exclusive prefix); the bins are left zero for the next call's histogram
+__global__ __launch_bounds__(1024) void k_qo_scan(int* __restrict__ bins, int* __restrict__ cursor) {
     __shared__ int s_part[32];
     const int tid = threadIdx.x;
     int v[QO_BINS / 1024], sum = 0;
 #pragma unroll
     for (int u = 0; u < QO_BINS / 1024; u++) {
         v[u] = bins[tid * (QO_BINS / 1024) + u];
+        bins[tid * (QO_BINS / 1024) + u] = 0;
         sum += v[u];
     }
     const int incl = wave_incl_scan(sum);
@@ -1207,7 +1217,7 @@ __global__ __launch_bounds__(1024) void k_qo_scan(int* __restrict__ bins) {
     int run = s_part[16 + (tid >> 6)] + incl - sum;
 #pragma unroll
     for (int u = 0; u < QO_BINS / 1024; u++) {
-        bins[tid * (QO_BINS / 1024) + u] = run;
+        cursor[tid * (QO_BINS / 1024) + u] = run;
         run += v[u];
     }
 }
@@ -1217,14 +1227,17 @@ __global__ __launch_bounds__(256) void k_qo_scatter(const int* __restrict__ qkey
     if (q < nq) qperm[atomicAdd(&bins[qkey[q]], 1)] = q;
 }
 int query_order_bins() { return QO_BINS; }
+bool query_order_grid(int nq) { return nq > 8192; }   // one workgroup takes 20 us for 8192 queries and grows linearly
+// bins: 2 * QO_BINS ints (histogram | cursors), the histogram zero on entry and left zero; hist_done: the pair-offset
+// kernel has filled qkey and the histogram (PairZero::qo_*)
 void launch_query_order(hipStream_t s, const int* probe_list, int nq, int P, const int* list_rank,
-                        int nlist, int* qkey, int* qperm, int* bins) {
+                        int nlist, int* qkey, int* qperm, int* bins, bool hist_done) {
     if (nq <= 0) return;
-    if (nq > 8192 && bins) {   // one workgroup takes 20 us for 8192 queries and grows linearly
-        (void)hipMemsetAsync(bins, 0, QO_BINS * sizeof(int), s);
-        hipLaunchKernelGGL(k_qo_hist, dim3((nq + 255) / 256), dim3(256), 0, s, probe_list, nq, P, list_rank, nlist, qkey, bins);
-        hipLaunchKernelGGL(k_qo_scan, dim3(1), dim3(1024), 0, s, bins);
-        hipLaunchKernelGGL(k_qo_scatter, dim3((nq + 255) / 256), dim3(256), 0, s, qkey, nq, bins, qperm);
+    if (query_order_grid(nq) && bins) {
+        if (!hist_done)
+            hipLaunchKernelGGL(k_qo_hist, dim3((nq + 255) / 256), dim3(256), 0, s, probe_list, nq, P, list_rank, nlist, qkey, bins);
+        hipLaunchKernelGGL(k_qo_scan, dim3(1), dim3(1024), 0, s, bins, bins + QO_BINS);
+        hipLaunchKernelGGL(k_qo_scatter, dim3((nq + 255) / 256), dim3(256), 0, s, qkey, nq, bins + QO_BINS, qperm);
         return;
     }
     hipLaunchKernelGGL(k_query_order, dim3(1), dim3(1024), 0, s, probe_list, nq, P, list_rank, nlist, qkey,
