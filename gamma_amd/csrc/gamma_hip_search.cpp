@@ -195,8 +195,11 @@ int ivfpq_coarse(H* h, const gamma_hip_search_params* p, int nq, const float* d_
                                h->w_mat.as<float>(), nlist, true);
     }
     if (h->exact_ties) GH_CHECK(h, h->w_tieflag.ensure((size_t)nq));
-    gh::launch_coarse_select(s, h->w_mat.as<float>(), nlist, nq, P, out_dis, out_probe,
-                             h->exact_ties ? h->w_tieflag.as<uint8_t>() : nullptr, h->d_tie_stats);
+    static const bool no_side = getenv("GAMMA_HIP_NO_SIDE_STREAM") != nullptr;
+    const bool side = h->exact_ties && defer_join && !no_side;
+    h->coarse_join_pending = gh::launch_coarse_select(s, h->w_mat.as<float>(), nlist, nq, P, out_dis, out_probe,
+                                                      h->exact_ties ? h->w_tieflag.as<uint8_t>() : nullptr, h->d_tie_stats,
+                                                      side ? h->side : nullptr, h->ev_fork, h->ev_join);
     return GAMMA_HIP_OK;
 }
 

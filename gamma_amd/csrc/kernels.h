@@ -221,8 +221,10 @@ void launch_ivfflat_lm(hipStream_t s, bool l2, const float* x, int nq, int d, in
                        const int64_t* list_off, const int* list_len, int nlist, const int64_t* ids, const float* raw,
                        int64_t nraw, int64_t q_stride, float* out, const FilterDesc* ftab, int need_filter, float min_score,
                        float max_score, void* scratch);
-void launch_coarse_select(hipStream_t s, const float* mat, int nlist, int nq, int K, float* out_vals, int* out_pos,
-                          uint8_t* tie_flag, unsigned long long* tie_stats = nullptr);
+// returns true when the walk of the tied rows went to `side` (the caller then waits for `join` before reading the result)
+bool launch_coarse_select(hipStream_t s, const float* mat, int nlist, int nq, int K, float* out_vals, int* out_pos,
+                          uint8_t* tie_flag, unsigned long long* tie_stats = nullptr, hipStream_t side = nullptr,
+                          hipEvent_t fork = nullptr, hipEvent_t join = nullptr);
 void launch_select_topk(hipStream_t s, bool smallest, const float* vals, int64_t seg_stride,
                         const int* seg_len, int fixed_len, int max_len, int nseg, int K,
                         float* out_vals, int* out_pos, const uint8_t* only = nullptr);

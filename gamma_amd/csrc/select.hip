@@ -1357,13 +1357,16 @@ __global__ __launch_bounds__(256) void k_coarse_heap_fix(const float* __restrict
 // scratch; exact ties): a row with two equal keys among its K + 1 smallest -- which of them is probed, or in which
 // order their lists are scanned, is the doing of the reference's heap -- is redone by k_coarse_heap_fix
 // (K <= 256; beyond that faiss itself switches to its reservoir, faiss:utils/distances.cpp:341-358).
-void launch_coarse_select(hipStream_t s, const float* mat, int nlist, int nq, int K, float* out_vals, int* out_pos,
-                          uint8_t* tie_flag, unsigned long long* tie_stats) {
+// side / fork / join: the walk of the flagged rows (one wave per row, all latency) may run on a side stream beside the
+// caller's next kernels that do not read the assignment; the caller waits for `join` before the first one that does
+bool launch_coarse_select(hipStream_t s, const float* mat, int nlist, int nq, int K, float* out_vals, int* out_pos,
+                          uint8_t* tie_flag, unsigned long long* tie_stats, hipStream_t side, hipEvent_t fork,
+                          hipEvent_t join) {
     static const bool off = getenv("GAMMA_HIP_NO_WAVE_SELECT") != nullptr;
-    if (nq <= 0) return;
+    if (nq <= 0) return false;
     if (!tie_flag || K > CH_MAXK) {
         launch_select_topk(s, true, mat, nlist, nullptr, nlist, nlist, nq, K, out_vals, out_pos);
-        return;
+        return false;
     }
     if (!off && K <= 64 && nlist <= 64 * SW_NPL) {
         hipLaunchKernelGGL((k_select_wave<true, SW_NPL>), dim3((nq + 3) / 4), dim3(256), 0, s, mat, (int64_t)nlist, nullptr, nlist,
@@ -1373,8 +1376,16 @@ void launch_coarse_select(hipStream_t s, const float* mat, int nlist, int nq, in
         (void)hipMemsetAsync(tie_flag, 0, (size_t)nq, s);
         launch_flag_cut_ties(s, mat, nlist, nullptr, nq, K, out_vals, out_pos, nullptr, tie_flag, nlist, 1);
     }
-    hipLaunchKernelGGL(k_coarse_heap_fix, dim3((nq + 3) / 4), dim3(256), 0, s, mat, (int64_t)nlist, nlist, K, nq, tie_flag,
+    hipStream_t rs = s;
+    if (side && fork && join) {
+        (void)hipEventRecord(fork, s);
+        (void)hipStreamWaitEvent(side, fork, 0);
+        rs = side;
+    }
+    hipLaunchKernelGGL(k_coarse_heap_fix, dim3((nq + 3) / 4), dim3(256), 0, rs, mat, (int64_t)nlist, nlist, K, nq, tie_flag,
                        out_vals, out_pos, tie_stats, nullptr);
+    if (rs != s) (void)hipEventRecord(join, rs);
+    return rs != s;
 }
 
 void launch_coarse_heap_rows(hipStream_t s, const float* mat, int nlist, int nq, int K, const int* rows, float* out_vals,
