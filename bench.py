@@ -191,15 +191,23 @@ def main():
     # the steps of the timed loop are back-to-back device-pointer calls: the handful of queries a step flags for the heap
     # replay are redone beside the NEXT step's coarse quantizer / query tables; everything is complete at the
     # synchronize that ends the timed region (include/gamma_hip.h, gamma_hip_set_deferred_replay)
-    deferred = (not use_dist) and (not a.no_exact_ties) and (not a.no_deferred_replay)
-    g.set_deferred_replay(deferred)
+    # (replicated ranks do the same: gamma_amd.dist.ReplicatedStream gathers a step's results one step behind, after the
+    #  next step's search has been enqueued, and flush() -- inside the timed region -- gathers the last step's)
+    deferred = (not use_dist or replicate) and (not a.no_exact_ties) and (not a.no_deferred_replay)
+    rstream = gdist.ReplicatedStream(backend, k, args) if (use_dist and replicate and deferred) else None
+    if rstream is None:
+        g.set_deferred_replay(deferred)
 
-    def step(i):
+    def step(i, stream=True):
         xb = d_q[(i % nbatches) * gnq:(i % nbatches + 1) * gnq]
         if not use_dist:
             g.ivfpq_search_device(xb.data_ptr(), gnq, k, args, d_D.data_ptr(), d_I.data_ptr())
             return d_D, d_I
         if replicate:
+            if rstream is not None and stream:
+                return rstream.submit(xb)      # the PREVIOUS step's results (None for the first)
+            if rstream is not None:
+                rstream.flush()
             return gdist.replicated_search(backend, xb, k, args)
         return gdist.sharded_search(backend, xb, k, args)
 
@@ -207,7 +215,7 @@ def main():
     recall = None
     nrq = min(a.recall_queries, gnq)
     if nrq > 0:
-        Dg, Ig = step(0)
+        Dg, Ig = step(0, stream=False)
         torch.cuda.synchronize()
         Ig = Ig[:nrq].cpu().numpy()
         fargs = api.SearchArgs(metric=api.METRIC_L2, min_score=0.0, max_score=1e30)
@@ -230,6 +238,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(a.warmup + i)
+    if rstream is not None:
+        rstream.flush()                  # the last step's results: gathered inside the timed region
     t_enq = time.perf_counter() - t0     # host time to enqueue the steps (log only)
     torch.cuda.synchronize()
     if world > 1:
@@ -247,6 +257,8 @@ def main():
         g.profile_reset()
         for i in range(a.steps):
             step(a.warmup + i)
+        if rstream is not None:
+            rstream.flush()
         torch.cuda.synchronize()
         prof = g.profile()
         if prof_timed["scan"][1]:
@@ -515,7 +527,9 @@ def main():
             "stage_timing": "HIP events in the timed region: " + a.timed_events,
             "tie_replay": ("exact ties on; the replay of a step's flagged queries runs on a side stream beside the next "
                            "step's coarse quantizer and query tables (gamma_hip_set_deferred_replay); every step's results "
-                           "are complete inside the timed region (it ends with a device-wide synchronize)") if deferred else
+                           "are complete inside the timed region (it ends with a device-wide synchronize)"
+                           + ("; replicated ranks: a step's results are all-gathered one step behind, the last step's before "
+                              "the timed region ends (gamma_amd.dist.ReplicatedStream)" if rstream is not None else "")) if deferred else
                           ("exact ties on; replay at the end of every call" if not a.no_exact_ties else "exact ties off"),
             "pcie_inclusive_qps": None if host_qps is None else round(host_qps, 1),
             **extra,

@@ -823,7 +823,14 @@ int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, c
                                float* d_distances, int64_t* d_labels, const FiltCtx* given) {
     GH_TRY(ivfpq_check(h, p, nq, k));
     TiesScope ties_scope(h, p);
-    if (k <= 0 || nq == 0) return GAMMA_HIP_OK;  // gamma_index_ivfpq.cc:753-756
+    if (k <= 0 || nq == 0) {   // gamma_index_ivfpq.cc:753-756
+        // (the deferred-replay contract: the previous call is complete after ANY next search call, an empty one too)
+        if (h->replay_pending) {
+            GH_CHECK(h, hipSetDevice(h->device));
+            GH_TRY(replay_join(h));
+        }
+        return GAMMA_HIP_OK;
+    }
     GH_CHECK(h, hipSetDevice(h->device));
     const int R = std::max(p->recall_num, k);
     FiltCtx fc;

@@ -103,6 +103,12 @@ class HipShardBackend:
         """the whole search for the rows of x on this rank's (complete) index: replicated_search"""
         self.g.ivfpq_search_device(x.data_ptr(), x.shape[0], k, args, D.data_ptr(), I.data_ptr())
 
+    def set_deferred_replay(self, on):
+        self.g.set_deferred_replay(on)
+
+    def join(self):
+        self.g.join()
+
     def coarse(self, x, args, cdis, probe):
         """coarse assignment of the rows of x into the preallocated cdis/probe [n, nprobe]"""
         if x.shape[0]:
@@ -469,6 +475,94 @@ def replicated_search(backend, x, k, args, group=None):
         b["Iall"].view(world, per, k).copy_(b["res"][:, :nres * 8].view(torch.int64).view(world, per, k))
         b["Dall"].view(world, per, k).copy_(b["res"][:, nres * 8:nres * 12].view(torch.float32).view(world, per, k))
     return b["Dall"][:nq], b["Iall"][:nq]
+
+
+class ReplicatedStream:
+    """replicated_search for a STREAM of batches of one shape, with the deferred tie replay (include/gamma_hip.h,
+    gamma_hip_set_deferred_replay): the few queries of a batch that go through the reference's heaps again are replayed
+    on the handle's side stream beside the NEXT batch's coarse quantizer and query tables instead of at the end of
+    their own call, where the replay is the latency of one query's chain with the chip idle.  The results
+    of a batch are therefore complete only once the next search has been enqueued, so the all-gather runs one batch
+    behind:
+
+        submit(x)  enqueues the search of this rank's slice of x and returns the gathered (D, I) of the PREVIOUS batch
+                   (None for the first one);
+        flush()    returns those of the last batch (joins its replay first).
+
+    Every batch is searched once and gathered once; the buffers alternate between two sets.  x must stay untouched until
+    its results have been returned.  A backend without deferred replay (the CPU backends of the tests) runs the same
+    schedule, one batch behind."""
+
+    def __init__(self, backend, k, args, group=None):
+        self.backend, self.k, self.args, self.group = backend, k, args, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.bufs = {}
+        self.pending = None      # (slot, nq) of the batch searched but not gathered yet
+        self.n = 0
+        self.deferred = hasattr(backend, "set_deferred_replay")
+        if self.deferred:
+            backend.set_deferred_replay(True)
+
+    def close(self):
+        if self.deferred:
+            self.backend.set_deferred_replay(False)
+
+    def _ctx(self):
+        return torch.cuda.stream(self.backend.stream) if hasattr(self.backend, "stream") else _Null()
+
+    def _buf(self, slot, per):
+        b = self.bufs.get(slot)
+        if b is None or b["per"] != per:
+            be, k, world = self.backend, self.k, self.world
+            nres = per * k
+            res_bytes = (nres * 12 + 7) // 8 * 8
+            res_l = be.empty((res_bytes,), torch.uint8)
+            b = dict(per=per, res_l=res_l, I=res_l[:nres * 8].view(torch.int64).view(per, k),
+                     D=res_l[nres * 8:nres * 12].view(torch.float32).view(per, k),
+                     res=be.empty((world, res_bytes), torch.uint8),
+                     Dall=be.empty((world * per, k), torch.float32), Iall=be.empty((world * per, k), torch.int64))
+            self.bufs[slot] = b
+        return b
+
+    def _gather(self, slot, nq):
+        b, world, k = self.bufs[slot], self.world, self.k
+        per, nres = b["per"], b["per"] * self.k
+        if world > 1:
+            dist.all_gather_into_tensor(b["res"].view(-1), b["res_l"], group=self.group)
+        else:
+            b["res"][0].copy_(b["res_l"])
+        b["Iall"].view(world, per, k).copy_(b["res"][:, :nres * 8].view(torch.int64).view(world, per, k))
+        b["Dall"].view(world, per, k).copy_(b["res"][:, nres * 8:nres * 12].view(torch.float32).view(world, per, k))
+        return b["Dall"][:nq], b["Iall"][:nq]
+
+    def submit(self, x):
+        nq = x.shape[0]
+        q0, q1, per = query_slice(nq, self.rank, self.world)
+        slot = self.n & 1
+        self.n += 1
+        out = None
+        with self._ctx():
+            b = self._buf(slot, per)
+            if q1 - q0 < per:
+                b["D"].zero_()
+                b["I"].fill_(-1)
+            # (an empty slice still makes the call: a search call is what completes the previous one)
+            self.backend.search_all(x[q0:q1], self.k, self.args, b["D"][:q1 - q0], b["I"][:q1 - q0])
+            if self.pending is not None:
+                out = self._gather(*self.pending)
+            self.pending = (slot, nq)
+        return out
+
+    def flush(self):
+        if self.pending is None:
+            return None
+        with self._ctx():
+            if self.deferred:
+                self.backend.join()
+            out = self._gather(*self.pending)
+            self.pending = None
+        return out
 
 
 class _Null:

@@ -67,6 +67,29 @@ def main():
     D, I = gdist.replicated_search(gdist.HipShardBackend(full, local), x, k, args)
     torch.cuda.synchronize()
     assert D.cpu().numpy().tobytes() == Dref.cpu().numpy().tobytes() and np.array_equal(I.cpu().numpy(), Iref.cpu().numpy())
+    # a stream of batches with the deferred tie replay: gathered one batch behind, every batch bit for bit the unsharded
+    # handle's answer (tie-heavy queries included: x holds base vectors, whose nearest neighbours are at distance 0 ...)
+    rs = gdist.ReplicatedStream(gdist.HipShardBackend(full, local), k, args)
+    batches = [x, x[:7].contiguous(), x[3:].contiguous(), x]
+    refs = []
+    for xb in batches:
+        Dx = torch.empty((xb.shape[0], k), dtype=torch.float32, device=x.device)
+        Ix = torch.empty((xb.shape[0], k), dtype=torch.int64, device=x.device)
+        full.ivfpq_search_device(xb.data_ptr(), xb.shape[0], k, args, Dx.data_ptr(), Ix.data_ptr())
+        full.synchronize()
+        refs.append((Dx.cpu().numpy(), Ix.cpu().numpy()))
+    outs = []
+    def keep(o):   # results are ready in the order of the backend's stream (as replicated_search's): wait, then copy
+        torch.cuda.synchronize()
+        return None if o is None else (o[0].clone(), o[1].clone())
+    for xb in batches:
+        outs.append(keep(rs.submit(xb)))
+    outs.append(keep(rs.flush()))
+    torch.cuda.synchronize()
+    assert outs[0] is None
+    for (Dx, Ix), (Ds, Is) in zip(refs, outs[1:]):
+        assert Ds.cpu().numpy().tobytes() == Dx.tobytes() and np.array_equal(Is.cpu().numpy(), Ix)
+    rs.close()
     # Add with ONE encode per batch (sharded_add: the encoding rank broadcasts list numbers + codes): the shards' lists are
     # those of the unsharded handle after the same Add, entry by entry
     from gamma_amd import synth

@@ -131,6 +131,17 @@ def main():
             Ii.copy_(torch.from_numpy(Is))
     Dp, Ip = gdist.replicated_search(Full(), x, k, args)
     assert Dp.numpy().tobytes() == Dr.tobytes() and np.array_equal(Ip.numpy(), Ir)
+    # the same for a stream of batches, gathered one batch behind (ReplicatedStream: what runs with the deferred tie
+    # replay on the device); batch sizes that do and do not divide by the world size
+    rs = gdist.ReplicatedStream(Full(), k, args)
+    batches = [x, x[:5], x[3:], x]
+    outs = [rs.submit(xb) for xb in batches] + [rs.flush()]
+    assert outs[0] is None and rs.flush() is None
+    for xb, (Ds, Is) in zip(batches, outs[1:]):
+        De, Ie = case["oracle"].search(xb.numpy(), k, nprobe, recall_num=R, has_rank=True, metric=B.METRIC_L2, ctx=ctx,
+                                       coarse_mode=0)
+        assert Ds.numpy().tobytes() == De.tobytes() and np.array_equal(Is.numpy(), Ie)
+    rs.close()
     # every rank holds the full, identical result
     gathered = [torch.empty_like(I) for _ in range(world)]
     dist.all_gather(gathered, I)
