@@ -268,6 +268,7 @@ def main():
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
+        _flush_c_stdio()      # (this rank's RCCL banner: out now, long before rank 0 prints the line)
         return
 
     qps = gnq * a.steps / dt
@@ -548,9 +549,21 @@ def main():
         },
         "cpu_baseline": cpu,
     }
-    print(json.dumps(out), flush=True)
+    # the JSON line is the LAST thing on stdout: RCCL writes a version banner to the C stdout of every process that
+    # created a communicator, buffered until something flushes it
     if use_dist:
         dist.destroy_process_group()
+    _flush_c_stdio()
+    print(json.dumps(out), flush=True)
+
+
+def _flush_c_stdio():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:     # noqa: BLE001
+        pass
+    sys.stdout.flush()
 
 
 def spawn_ranks(n):
