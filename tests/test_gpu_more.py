@@ -1460,3 +1460,37 @@ def test_shadow_lists_are_reused_until_a_writer_runs():
         else:
             os.environ["GAMMA_HIP_LIST_COMPACT"] = old
         g.close()
+
+
+def test_profile_levels_and_the_state_the_pair_offset_kernel_clears(case):
+    """gamma_hip_profile_enable: 1 = an event pair around every stage + the scanned-code counter, 2 = around the scan launch
+    alone (what a throughput measurement that wants the scan's duration live can afford), 0 = none.  The results do not
+    depend on the level, and neither on what the previous call left in the per-call state that k_pair_offsets clears
+    (tie flags, repair list, ready words, query-order histogram): calls of different sizes alternate on one handle."""
+    g = fixtures.load_hip(case)
+    try:
+        args = api.SearchArgs(metric=api.METRIC_L2, nprobe=16, recall_num=60, has_rank=True, coarse_mode=1, **WIDE)
+        qa = synth.sift_like(9000, d=case["d"], seed=77)    # > 8192 queries: the grid-wide query order
+        qb = synth.sift_like(700, d=case["d"], seed=78)
+        ref = {}
+        for name, q in (("a", qa), ("b", qb)):
+            ref[name] = g.ivfpq_search(q, 10, args)
+        for level in (1, 2, 0, 2, 1):
+            g.profile_enable(level)
+            g.profile_reset()
+            for name, q in (("a", qa), ("b", qb), ("b", qb), ("a", qa)):
+                D, I = g.ivfpq_search(q, 10, args)
+                assert D.tobytes() == ref[name][0].tobytes() and np.array_equal(I, ref[name][1]), (level, name)
+            prof = g.profile()
+            launches = {n: prof[n][1] for n in ("coarse", "tables", "scan", "select", "rerank")}
+            if level == 0:
+                assert not any(launches.values()) and prof["scan_bytes"] == 0
+            elif level == 2:
+                assert launches["scan"] == 4 and prof["scan"][0] > 0.0
+                assert not any(v for n, v in launches.items() if n != "scan") and prof["scan_bytes"] == 0
+            else:
+                assert all(v >= 4 for v in launches.values()), launches
+                assert prof["scan_bytes"] > 0
+        g.profile_enable(0)
+    finally:
+        g.close()
