@@ -126,6 +126,22 @@ __device__ __forceinline__ float fvec_ny_row(PX x, PY y, int d) {
     }
 }
 
+// s[i] = a[i] of lane ^ 1 + a[i]: four v_add_f32 with a DPP operand (quad_perm [1, 0, 3, 2]).  __shfl_xor goes through the
+// LDS crossbar (ds_bpermute + a wait); a DPP move + add written in C++ becomes moves and PACKED adds, which cannot take a
+// DPP operand (4 moves + 3 copies + 2 packed adds where 4 instructions do).  The
+// leading s_nop covers the VALU-write -> DPP-read hazard for inputs written just before (the assembler text is opaque to
+// the hazard recognizer).  Every lane of the wave must be active.
+__device__ __forceinline__ void add_xor1_x4(float a0, float a1, float a2, float a3, float& s0, float& s1, float& s2,
+                                            float& s3) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+}
+
 // float <-> order-preserving uint32 key.  ascending key == ascending float (-0 < +0).
 __device__ __forceinline__ uint32_t f2key(float f) {
     uint32_t u = __float_as_uint(f);

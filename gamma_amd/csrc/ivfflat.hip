@@ -179,10 +179,8 @@ __global__ __launch_bounds__(256) void k_ivfflat_lm(const float* __restrict__ x,
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // even thread: AVX lanes 0..3, odd thread: lanes 4..7;  s[l] = acc[l+4] + acc[l]
-                const float s0 = __shfl_xor(acc[0].x, 1, 64) + acc[0].x;
-                const float s1 = __shfl_xor(acc[0].y, 1, 64) + acc[0].y;
-                const float s2 = __shfl_xor(acc[1].x, 1, 64) + acc[1].x;
-                const float s3 = __shfl_xor(acc[1].y, 1, 64) + acc[1].y;
+                float s0, s1, s2, s3;
+                add_xor1_x4(acc[0].x, acc[0].y, acc[1].x, acc[1].y, s0, s1, s2, s3);
                 float dis = hsum4(s0, s1, s2, s3);
                 if (!live || !(dis <= max_score && dis >= min_score)) dis = sentinel;
                 if (inrow && half == 0) out[(int64_t)s_q[qi] * q_stride + s_off[qi] + j] = dis;

@@ -112,7 +112,10 @@ __global__ __launch_bounds__(256) void k_pairwise_lds(const float* __restrict__ 
     // several waves fit per SIMD.  Per lane the accumulation order is untouched; the pair's sums
     // meet in s[l] = acc[l+4] + acc[l] through one shuffle.
     __shared__ float4 s_x[PW_QT * D / 4];
-    __shared__ uint32_t s_tau[PW_QT];
+    // EMIT: the queries' bounds AS DISTANCES.  key <= tau (keys order like the distances; neither side is ever -0 or NaN
+    // here) is dis <= key2f(tau) for L2 and dis >= key2f(~tau) for the inner product; a bound at or beyond the sentinel's
+    // key (none yet) becomes the largest finite value, so the one comparison also keeps the sentinel (+-inf) out
+    __shared__ float s_tau[PW_QT];
     const int half = threadIdx.x & 1;
     const int64_t row = (int64_t)blockIdx.x * 128 + (threadIdx.x >> 1);
     const int q0 = blockIdx.y * q_per_block;
@@ -135,10 +138,14 @@ __global__ __launch_bounds__(256) void k_pairwise_lds(const float* __restrict__ 
         __syncthreads();   // the previous tile has been consumed
         for (int e = threadIdx.x; e < nqt * (D / 4); e += 256)
             s_x[e] = reinterpret_cast<const float4*>(x + (int64_t)qt * D)[e];
-        if (EMIT && threadIdx.x < nqt) s_tau[threadIdx.x] = em.tau[qt + threadIdx.x];
+        if (EMIT && threadIdx.x < nqt) {
+            const uint32_t t = em.tau[qt + threadIdx.x];
+            s_tau[threadIdx.x] = t >= 0xff800000u ? (L2 ? 3.402823466e+38f : -3.402823466e+38f) : key2f(L2 ? t : ~t);
+        }
         __syncthreads();
         for (int qi = 0; qi < nqt; qi++) {
             const float4* xq = s_x + qi * (D / 4) + half;
+            const float tau_q = EMIT ? s_tau[qi] : 0.f;   // requested before the row's math, used behind it
             f32x2 acc[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
 #pragma unroll
             for (int i0 = 0; i0 < D / 8; i0 += 8) {
@@ -163,22 +170,22 @@ __global__ __launch_bounds__(256) void k_pairwise_lds(const float* __restrict__ 
                         }
                     }
                 }
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // the chunk's 8 LDS reads back to back ...
+                __builtin_amdgcn_sched_group_barrier(0x002, 64, 0);  // ... then its packed math
                 __builtin_amdgcn_sched_barrier(0);
             }
             // even thread: lanes 0..3, odd thread: lanes 4..7;  s[l] = acc[l+4] + acc[l]
-            const float s0 = __shfl_xor(acc[0].x, 1, 64) + acc[0].x;
-            const float s1 = __shfl_xor(acc[0].y, 1, 64) + acc[0].y;
-            const float s2 = __shfl_xor(acc[1].x, 1, 64) + acc[1].x;
-            const float s3 = __shfl_xor(acc[1].y, 1, 64) + acc[1].y;
+            float s0, s1, s2, s3;
+            add_xor1_x4(acc[0].x, acc[0].y, acc[1].x, acc[1].y, s0, s1, s2, s3);
             float dis = hsum4(s0, s1, s2, s3);
             if (FILTER) {
                 if (!valid || !(dis <= max_score && dis >= min_score)) dis = sentinel;
             }
             if (EMIT) {
                 if (live && half == 0) {
-                    const uint32_t kk = f2key(dis);
-                    const uint32_t key = L2 ? kk : ~kk;
-                    if (key <= s_tau[qi] && key < 0xff800000u) {   // 0xff800000: key of the sentinel
+                    if (L2 ? dis <= tau_q : dis >= tau_q) {
+                        const uint32_t kk = f2key(dis);
+                        const uint32_t key = L2 ? kk : ~kk;
                         const int slot = atomicAdd(&em.cnt[qt + qi], 1);
                         if (slot < em.cap)
                             em.cand[(int64_t)(qt + qi) * em.cap + slot] =
