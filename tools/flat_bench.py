@@ -18,7 +18,7 @@ for _ in range(2):
     g.flat_search_device(dq.data_ptr(), nq, k, args, D.data_ptr(), I.data_ptr())
 g.synchronize()
 t0 = time.perf_counter()
-n = 5
+n = int(os.environ.get("FLAT_BENCH_CALLS", "5"))
 for _ in range(n):
     g.flat_search_device(dq.data_ptr(), nq, k, args, D.data_ptr(), I.data_ptr())
 g.synchronize()
