@@ -206,9 +206,13 @@ def main():
         if replicate:
             if rstream is not None and stream:
                 return rstream.submit(xb)      # the PREVIOUS step's results (None for the first)
-            if rstream is not None:
-                rstream.flush()
-            return gdist.replicated_search(backend, xb, k, args)
+            if rstream is None:
+                return gdist.replicated_search(backend, xb, k, args)
+            rstream.flush()
+            g.set_deferred_replay(False)       # a call on its own: complete when it returns
+            out = gdist.replicated_search(backend, xb, k, args)
+            g.set_deferred_replay(True)
+            return out
         return gdist.sharded_search(backend, xb, k, args)
 
     # ---- recall@10 against exact flat search on the GPU (rank 0 data is complete: raw replicated)
