@@ -8,6 +8,8 @@ base = synth.sift_like(N, d=d, seed=1234)
 q = synth.sift_like(nq, d=d, seed=4321)
 g = api.GammaHip(0)
 g.raw_init(d)
+if os.environ.get("FLAT_BENCH_NO_TIES"):
+    g.set_exact_ties(False)
 g.raw_append(base)
 dev = torch.device("cuda", 0)
 dq = torch.from_numpy(q).to(dev)
