@@ -228,6 +228,24 @@ def main():
         recall = hits / float(nrq * k)
         log("[rank %d] recall@%d = %.4f over %d queries" % (rank, k, recall, nrq))
 
+    # the streamed schedule of the replicated ranks against a plain call on the same batch, once, before anything is
+    # timed: a mismatch on ANY rank sends every rank back to the plain schedule (replay at the end of each call)
+    if rstream is not None:
+        Dp, Ip = step(0, stream=False)
+        Dp, Ip = Dp.clone(), Ip.clone()
+        rstream.submit(d_q[:gnq])
+        Ds, Is = rstream.flush()
+        torch.cuda.synchronize()
+        same = torch.tensor([1 if (torch.equal(Ds, Dp) and torch.equal(Is, Ip)) else 0], dtype=torch.int32, device=dev)
+        if world > 1:
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        if int(same.item()) != 1:
+            log("[rank %d] ReplicatedStream disagrees with replicated_search: falling back to the plain schedule" % rank)
+            rstream.close()
+            rstream = None
+            deferred = False
+            g.set_deferred_replay(False)
+
     # ---- timed region ----
     for i in range(a.warmup):
         step(i)
