@@ -489,8 +489,9 @@ class ReplicatedStream:
                    (None for the first one);
         flush()    returns those of the last batch (joins its replay first).
 
-    Every batch is searched once and gathered once; the buffers alternate between two sets.  x must stay untouched until
-    its results have been returned.  A backend without deferred replay (the CPU backends of the tests) runs the same
+    Every batch is searched once and gathered once; the buffers alternate between two sets: the (D, I) a call returns are
+    views that stay valid until the second next submit, and are ready in the order of the backend's stream (as
+    replicated_search's).  x must stay untouched until its results have been returned.  A backend without deferred replay (the CPU backends of the tests) runs the same
     schedule, one batch behind."""
 
     def __init__(self, backend, k, args, group=None):
