@@ -65,6 +65,7 @@ SYMBOLS = {
     "gamma_hip_set_small_path": (C.c_int, [C.c_void_p, C.c_int]),
     "gamma_hip_set_coarse_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "gamma_hip_tie_stats": (C.c_int, [C.c_void_p, i64p, C.c_int]),
+    "gamma_hip_ties_not_honoured": (C.c_int, [C.c_void_p, i64p, C.c_int]),
     "gamma_hip_raw_write": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, f32p]),
     "gamma_hip_raw_count": (C.c_int64, [C.c_void_p]),
     "gamma_hip_raw_stats": (C.c_int, [C.c_void_p, i64p]),

@@ -418,6 +418,13 @@ class GammaHip:
         self._ck(self.L.gamma_hip_tie_stats(self.h, _p(out, _lib.i64p), 1 if reset else 0), "tie_stats")
         return dict(coarse_rows=int(out[0]), cut_ties=int(out[1]), replayed=int(out[2]))
 
+    def ties_not_honoured(self, reset=False):
+        """search calls that ran without the exact-ties mode although the handle's default asked for it (shape beyond the
+        replay's range: nprobe > 256, flat k = 4096)"""
+        out = np.zeros(1, dtype=np.int64)
+        self._ck(self.L.gamma_hip_ties_not_honoured(self.h, _p(out, _lib.i64p), 1 if reset else 0), "ties_not_honoured")
+        return int(out[0])
+
     def set_exact_ties(self, on=True):
         """probe exactly the lists the reference's heap keeps when coarse distances tie at the nprobe boundary"""
         self._ck(self.L.gamma_hip_set_exact_ties(self.h, 1 if on else 0), "set_exact_ties")

@@ -19,6 +19,7 @@ const char* gamma_hip_strerror(int code) {
         case GAMMA_HIP_EDEVICE: return "HIP runtime error";
         case GAMMA_HIP_ENOMEM: return "out of memory";
         case GAMMA_HIP_EFULL: return "inverted list full";
+        case GAMMA_HIP_EUNSUPPORTED: return "exact ties requested beyond the replay's range";
         default: return "unknown error";
     }
 }
@@ -209,6 +210,12 @@ int gamma_hip_tie_stats(gamma_hip_index* h, int64_t* out3, int reset) {
     GH_CHECK(h, hipMemcpy(v, h->d_tie_stats, sizeof(v), hipMemcpyDeviceToHost));
     for (int i = 0; i < 3; i++) out3[i] = (int64_t)v[i];
     if (reset) GH_CHECK(h, hipMemset(h->d_tie_stats, 0, sizeof(v)));
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ties_not_honoured(gamma_hip_index* h, int64_t* out_calls, int reset) {
+    if (!h || !out_calls) return GAMMA_HIP_EINVAL;
+    *out_calls = reset ? h->ties_unhonoured.exchange(0) : h->ties_unhonoured.load();
     return GAMMA_HIP_OK;
 }
 

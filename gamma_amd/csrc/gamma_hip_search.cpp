@@ -128,6 +128,25 @@ int check_params(H* h, const gamma_hip_search_params* p, int nq, int k) {
     return GAMMA_HIP_OK;
 }
 
+// A request's exact-ties choice (gamma_hip_search_params.exact_ties: 0 = the handle's setting, 1 on, -1 off) is resolved
+// ONCE per call, at the entry point, into the call's own copy of the parameter block (exact_ties = 1 / -1); everything
+// below reads tie_on(p) -- the handle is not touched.  in_range: the shape is one the replay covers (every recall_num / k
+// the ABI accepts; nprobe <= 256).  Beyond it a request that asked for the mode explicitly gets GAMMA_HIP_EUNSUPPORTED;
+// one that relies on the handle's default runs with the (distance, position) order inside ties and is COUNTED
+// (gamma_hip_ties_not_honoured) -- never silently.
+static inline bool tie_on(const gamma_hip_search_params* p) { return p->exact_ties > 0; }
+int resolve_ties(H* h, const gamma_hip_search_params* p, gamma_hip_search_params* pp, bool in_range, const char* what) {
+    *pp = *p;
+    bool want = p->exact_ties != 0 ? p->exact_ties > 0 : h->exact_ties;
+    if (want && !in_range) {
+        if (p->exact_ties > 0) return fail(h, GAMMA_HIP_EUNSUPPORTED, what);
+        h->ties_unhonoured.fetch_add(1, std::memory_order_relaxed);
+        want = false;
+    }
+    pp->exact_ties = want ? 1 : -1;
+    return GAMMA_HIP_OK;
+}
+
 // ---- IVFPQ stage A: coarse + tables + scan + top-R + ids ------------------------------
 // results: w_cand_dis [nq*R] (ADC distance, best first, sentinel pad), w_cand_ids [nq*R]
 // the assignment is complete on the stream (the heap replay of tied rows may still be running on the side stream)
@@ -148,10 +167,10 @@ int ivfpq_coarse(H* h, const gamma_hip_search_params* p, int nq, const float* d_
     if (mode < 0) mode = nq < 20 ? 0 : 1;  // faiss:utils/distances.cpp:303,346
     // large batches: no distance matrix (coarse.hip); with exact ties its rows with a tie near the cut are recomputed
     // and replayed through the reference's heap by the repair kernel
-    const bool fused = mode == 1 && h->coarse_fused && gh::coarse_fused_supported(nq, d, nlist, P, h->exact_ties);
+    const bool fused = mode == 1 && h->coarse_fused && gh::coarse_fused_supported(nq, d, nlist, P, tie_on(p));
     gh::CoarseFusedPlan plan;
     if (fused) {
-        plan = gh::coarse_fused_plan(nq, nlist, P, h->coarse_cap, h->exact_ties);
+        plan = gh::coarse_fused_plan(nq, nlist, P, h->coarse_cap, tie_on(p));
         GH_CHECK(h, h->w_mat.ensure(plan.bytes));
     } else {
         GH_CHECK(h, h->w_mat.ensure((size_t)nq * nlist * sizeof(float)));
@@ -165,9 +184,9 @@ int ivfpq_coarse(H* h, const gamma_hip_search_params* p, int nq, const float* d_
     StageScope t(h, GAMMA_HIP_STAGE_COARSE);
     if (fused) {
         static const bool no_side = getenv("GAMMA_HIP_NO_SIDE_STREAM") != nullptr;
-        const bool side = h->exact_ties && defer_join && !no_side;
+        const bool side = tie_on(p) && defer_join && !no_side;
         gh::launch_coarse_fused(s, plan, h->w_mat.p, d_x, nq, d, h->d_cc, nlist, h->d_cc_norms, P, out_dis, out_probe,
-                                h->exact_ties, h->d_tie_stats, side ? h->side : nullptr, h->ev_fork, h->ev_join);
+                                tie_on(p), h->d_tie_stats, side ? h->side : nullptr, h->ev_fork, h->ev_join);
         h->coarse_join_pending = side;
         static const bool dbg = getenv("GAMMA_HIP_COARSE_DBG") != nullptr;
         if (dbg) {   // how many queries the strip lists could not hold (they went through the repair kernel)
@@ -194,11 +213,11 @@ int ivfpq_coarse(H* h, const gamma_hip_search_params* p, int nq, const float* d_
         gh::launch_l2_gemmform(s, d_x, nq, d, h->d_cc, nlist, xn, h->d_cc_norms,
                                h->w_mat.as<float>(), nlist, true);
     }
-    if (h->exact_ties) GH_CHECK(h, h->w_tieflag.ensure((size_t)nq));
+    if (tie_on(p)) GH_CHECK(h, h->w_tieflag.ensure((size_t)nq));
     static const bool no_side = getenv("GAMMA_HIP_NO_SIDE_STREAM") != nullptr;
-    const bool side = h->exact_ties && defer_join && !no_side;
+    const bool side = tie_on(p) && defer_join && !no_side;
     h->coarse_join_pending = gh::launch_coarse_select(s, h->w_mat.as<float>(), nlist, nq, P, out_dis, out_probe,
-                                                      h->exact_ties ? h->w_tieflag.as<uint8_t>() : nullptr, h->d_tie_stats,
+                                                      tie_on(p) ? h->w_tieflag.as<uint8_t>() : nullptr, h->d_tie_stats,
                                                       side ? h->side : nullptr, h->ev_fork, h->ev_join);
     return GAMMA_HIP_OK;
 }
@@ -280,7 +299,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     h->tie = H::TieCtx();
     // (a shard marks the cut ties of its own top-R too: the merge at the slice's owner asks for them,
     //  gamma_hip_ivfpq_shard_cut_flags)
-    h->tie.on = h->exact_ties && R <= gh::tie_replay_max_k() && P <= gh::tie_replay_max_probes();
+    h->tie.on = tie_on(p);
     h->shard_cut_nq = (shard && h->tie.on) ? nq : 0;
     // Threshold pre-filter: scan the nearest probe group first, bound each query's R-th best
     // distance from it, and let the scan of the remaining groups keep a short survivor list per
@@ -560,6 +579,16 @@ int ivfpq_stage_b(H* h, const gamma_hip_search_params* p, int nq, const float* d
                                h->w_selv.as<float>(), h->w_selp.as<int>());
         gh::launch_finalize_topk(s, h->w_selv.as<float>(), h->w_selp.as<int>(), nq, k, cand_ids, R, 0,
                                  neutral, d_distances, d_labels);
+        if (ties) {
+            // recall_num beyond 1024: the flags of the fused kernel, made here -- equal exact distances among the k selected
+            // or at the k cut (the row of exact distances against the selection), or a tied top-R cut (stage A)
+            GH_CHECK(h, h->w_textra.ensure((size_t)nq));
+            GH_CHECK(h, hipMemsetAsync(h->w_textra.p, 0, (size_t)nq, s));
+            gh::launch_flag_cut_ties(s, h->w_exact.as<float>(), R, nullptr, nq, k, h->w_selv.as<float>(), h->w_selp.as<int>(),
+                                     nullptr, h->w_textra.as<uint8_t>(), R, 1);
+            gh::launch_tie_list(s, tf.cut, h->w_textra.as<uint8_t>(), nq, tf.list, tf.count, tf.stats);
+            if (tie_mode == 1) replay();
+        }
     } else {
         gh::launch_finalize_norank(s, cand_dis, cand_ids, nq, R, k, p->min_score, p->max_score, neutral,
                                    d_distances, d_labels, ties ? &tf : nullptr);
@@ -642,7 +671,7 @@ int ivfpq_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int n
                                    h->d_list_len, h->d_list_mask, h->d_list_off, h->w_pair_off.as<int>(),
                                    h->w_qtotal.as<int>(), h->w_pair_base.as<int64_t>(), d_x, h->d_cc, d,
                                    l2 ? nullptr : h->w_pair_ip.as<float>(), d_units, d_nunits, chunk_len,
-                                   h->exact_ties ? 1 : 0, h->d_tie_stats);
+                                   tie_on(p) ? 1 : 0, h->d_tie_stats);
     h->scan_pairs += (int64_t)nq * P;
     const int need_ids = (!h->prefiltered && (fc.any_clause || (h->d_bitmap && h->bitmap_any) || h->n_moved > 0)) ? 1 : 0;
     gh::launch_ivfpq_scan_pair(s, l2, d_x, nq, d, M, P, h->w_probe.as<int>(),
@@ -669,7 +698,7 @@ int ivfpq_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int n
     // exact ties: a query with a tie at the recall_num or k cut is replayed through the reference's heaps inside the
     // tail kernel (tie_dev.h), from the whole slab row
     gh::TieReplayArgs tr;
-    const bool ties = h->exact_ties && R <= gh::tie_replay_max_k() && P <= gh::tie_replay_max_probes();
+    const bool ties = tie_on(p) && R <= gh::tie_small_max_k();   // (ivfpq_small_ok: recall_num <= 1024)
     if (ties) {
         tr.list = nullptr;
         tr.count = nullptr;
@@ -807,22 +836,13 @@ int compact_lists_for_call(H* h, FiltCtx* fc, int64_t est, bool allowed, ListCom
     return GAMMA_HIP_OK;
 }
 
-// a request's own exact-ties choice (gamma_hip_search_params.exact_ties) for the duration of its enqueue; the caller
-// holds the search lock
-struct TiesScope {
-    H* h;
-    bool saved;
-    TiesScope(H* h_, const gamma_hip_search_params* p) : h(h_), saved(h_->exact_ties) {
-        if (p && p->exact_ties != 0) h->exact_ties = p->exact_ties > 0;
-    }
-    ~TiesScope() { h->exact_ties = saved; }
-};
-
 // given != nullptr: the filter context of a combined batch (p's own filter clauses are ignored)
 int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, int k,
                                float* d_distances, int64_t* d_labels, const FiltCtx* given) {
     GH_TRY(ivfpq_check(h, p, nq, k));
-    TiesScope ties_scope(h, p);
+    gamma_hip_search_params pp;
+    GH_TRY(resolve_ties(h, p, &pp, p->nprobe <= gh::tie_replay_max_probes(), "exact_ties = 1 with nprobe > 256"));
+    p = &pp;
     if (k <= 0 || nq == 0) {   // gamma_index_ivfpq.cc:753-756
         // (the deferred-replay contract: the previous call is complete after ANY next search call, an empty one too)
         if (h->replay_pending) {
@@ -843,9 +863,7 @@ int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, c
     }
     // faiss picks the coarse path from the size of the WHOLE call (faiss:utils/distances.cpp:346);
     // the internal chunks must not re-decide it
-    gamma_hip_search_params pp = *p;
     if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;
-    p = &pp;
     if (ivfpq_small_ok(h, p, fc, nq, R)) {
         GH_TRY(replay_join(h));
         GH_TRY(ivfpq_small(h, p, fc, nq, d_x, R, k, d_distances, d_labels));
@@ -966,7 +984,7 @@ int ivfflat_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     gh::launch_small_coarse_select(s, h->w_mat.as<float>(), nlist, nq, P, h->w_coarse_dis.as<float>(), h->w_probe.as<int>(),
                                    h->d_list_len, h->d_list_mask, h->d_list_off, h->w_pair_off.as<int>(),
                                    h->w_qtotal.as<int>(), h->w_pair_base.as<int64_t>(), nullptr, nullptr, 0, nullptr, nullptr,
-                                   nullptr, 0, h->exact_ties ? 1 : 0, h->d_tie_stats);
+                                   nullptr, 0, tie_on(p) ? 1 : 0, h->d_tie_stats);
     const int need_filter = (fc.any_clause || (h->d_bitmap && h->bitmap_any)) ? 1 : 0;
     gh::launch_ivfflat_scan(s, l2, d_x, nq, d, P, h->w_pair_off.as<int>(), h->w_pair_base.as<int64_t>(), h->d_ids, h->d_raw,
                             h->nraw, q_stride, h->w_dist.as<float>(), fc.d_tab, need_filter, p->min_score, p->max_score);
@@ -986,7 +1004,7 @@ int ivfflat_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     // exact ties: a query with equal distances at the k cut or among its k results is replayed through the scanner's
     // heap (heap_pop + heap_push per accepted entry, heap_reorder: gamma_index_ivfflat.h:52-75) inside the tail kernel
     gh::TieReplayArgs tr;
-    const bool ties = h->exact_ties && k <= gh::tie_replay_max_k() && P <= gh::tie_replay_max_probes();
+    const bool ties = tie_on(p) && k <= gh::tie_small_max_k();   // (the caller's gate: k <= 1024)
     if (ties) flat_tie_args(h, &tr, l2, nq, q_stride, P, k, d_x, h->w_cand_dis.as<float>(), h->w_cand_ids.as<int64_t>(), d_distances,
                             d_labels);
     gh::launch_small_tail(s, l2, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), nq, k, P, h->w_probe.as<int>(),
@@ -1006,7 +1024,9 @@ int ivfflat_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
 int ivfflat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, int k,
                                  float* d_distances, int64_t* d_labels) {
     GH_TRY(check_params(h, p, nq, k));
-    TiesScope ties_scope(h, p);
+    gamma_hip_search_params pp;
+    GH_TRY(resolve_ties(h, p, &pp, p->nprobe <= gh::tie_replay_max_probes(), "exact_ties = 1 with nprobe > 256"));
+    p = &pp;
     if (!h->ivf_init || !h->ivfflat) return fail(h, GAMMA_HIP_EINVAL, "ivfflat not initialised");
     if (!h->trained) return fail(h, GAMMA_HIP_ENOTTRAINED, "ivfflat not trained");
     if (p->nprobe <= 0 || p->nprobe > h->nlist) return fail(h, GAMMA_HIP_EINVAL, "nprobe out of range");
@@ -1019,7 +1039,6 @@ int ivfflat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq,
     GH_TRY(build_filter(h, p, &filt, nullptr, (int64_t)nq * p->nprobe * (h->ntotal / std::max(1, h->nlist))));
     FiltCtx fc;
     GH_TRY(filt_ctx_single(h, filt, &fc));
-    gamma_hip_search_params pp = *p;
     if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;   // faiss:utils/distances.cpp:303,346, whole call
     const int P = pp.nprobe, nlist = h->nlist;
     hipStream_t s = h->stream;
@@ -1074,7 +1093,7 @@ int ivfflat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq,
                                    h->w_cand_pos.as<int>());
             gh::launch_map_candidates(s, h->w_cand_pos.as<int>(), nc, k, P, h->w_probe.as<int>(), h->w_pair_off.as<int>(),
                                       h->d_list_off, h->d_ids, h->w_cand_ids.as<int64_t>());
-            const bool ties = h->exact_ties && k <= gh::tie_replay_max_k() && P <= gh::tie_replay_max_probes();
+            const bool ties = tie_on(p);
             gh::TieFlags tf;
             if (ties) {
                 // equal distances at the k cut or among the k selected: the scanner's heap decides (ties.hip)
@@ -1115,7 +1134,10 @@ int ivfflat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq,
 int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, int k,
                               float* d_distances, int64_t* d_labels) {
     GH_TRY(check_params(h, p, nq, k));
-    TiesScope ties_scope(h, p);
+    gamma_hip_search_params pp;   // (the chunked paths run for k + 1 results: k = 4096, the ABI's largest, is beyond the mode)
+    GH_TRY(resolve_ties(h, p, &pp, k + 1 <= gh::tie_replay_max_k() && h->nraw < ((int64_t)1 << 31),
+                        "exact_ties = 1 with k = 4096 or 2^31 rows (flat search)"));
+    p = &pp;
     if (!h->d_raw && h->nraw > 0) return fail(h, GAMMA_HIP_EINVAL, "raw store not initialised");
     if (h->raw_d <= 0) return fail(h, GAMMA_HIP_EINVAL, "raw store not initialised");
     if (k <= 0 || nq == 0) return GAMMA_HIP_OK;
@@ -1149,7 +1171,7 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
             // exact ties: a query with equal distances at the k cut or among its k results is replayed through the
             // reference's heap over the whole row (gamma_index_flat.cc:118-300: heap_pop + heap_push in vid order)
             gh::TieReplayArgs tr;
-            const bool ties = h->exact_ties && k <= gh::tie_replay_max_k();
+            const bool ties = tie_on(p) && k <= gh::tie_small_max_k();   // (this path's gate: k <= 1024)
             if (ties) {
                 flat_tie_args(h, &tr, l2, nq, stride, 0, k, d_x, h->w_cand_dis.as<float>(), h->w_cand_ids.as<int64_t>(), d_distances,
                               d_labels, (int)N);
@@ -1174,7 +1196,7 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
     // of a tie at the cut stay.  Run for k + 1 results, list the queries with two equal distances among them and replay
     // those through the heap over a freshly computed distance row (k_tie_replay).
     const int k_out = k;
-    const bool ties = h->exact_ties && k + 1 <= gh::tie_replay_max_k() && N > 0 && N < ((int64_t)1 << 31);
+    const bool ties = tie_on(p) && N > 0;
     if (ties) k = k + 1;
     GH_CHECK(h, h->w_dist.ensure((size_t)qc * rows_chunk * sizeof(float)));
     GH_CHECK(h, h->w_part_v.ensure((size_t)qc * nchunks * k * sizeof(float)));
@@ -1443,7 +1465,8 @@ int gamma_hip_ivfpq_search_shard(gamma_hip_index* h, const gamma_hip_search_para
     GH_TRY(build_filter(h, p, &filt));
     FiltCtx fc;
     GH_TRY(filt_ctx_single(h, filt, &fc));
-    gamma_hip_search_params pp = *p;
+    gamma_hip_search_params pp;
+    GH_TRY(resolve_ties(h, p, &pp, p->nprobe <= gh::tie_replay_max_probes(), "exact_ties = 1 with nprobe > 256"));
     if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;   // decided on the whole call, not per chunk
     p = &pp;
     const int chunk = query_chunk(h, nq, p->nprobe);
@@ -1468,8 +1491,10 @@ int gamma_hip_ivfpq_coarse_device(gamma_hip_index* h, const gamma_hip_search_par
     if (!d_x || !d_coarse_dis || !d_probe) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
     GH_CHECK(h, hipSetDevice(h->device));
     const int P = p->nprobe;
-    gamma_hip_search_params pp = *p;   // the caller resolves -1 on the size of the whole batch; a slice
-    if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;   // that arrives unresolved decides by itself
+    gamma_hip_search_params pp;
+    GH_TRY(resolve_ties(h, p, &pp, p->nprobe <= gh::tie_replay_max_probes(), "exact_ties = 1 with nprobe > 256"));
+    // the caller resolves coarse_mode -1 on the size of the whole batch; a slice that arrives unresolved decides by itself
+    if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;
     p = &pp;
     const int chunk = coarse_chunk(h, nq);
     for (int q0 = 0; q0 < nq; q0 += chunk)
@@ -1492,6 +1517,9 @@ int gamma_hip_ivfpq_search_shard_preassigned(gamma_hip_index* h, const gamma_hip
     if (!d_x || !d_recall_dis || !d_recall_ids) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
     GH_CHECK(h, hipSetDevice(h->device));
     const int R = std::max(p->recall_num, k), P = p->nprobe;
+    gamma_hip_search_params pp;
+    GH_TRY(resolve_ties(h, p, &pp, P <= gh::tie_replay_max_probes(), "exact_ties = 1 with nprobe > 256"));
+    p = &pp;
     gh::FilterDesc filt;
     GH_TRY(build_filter(h, p, &filt));
     FiltCtx fc;
@@ -1548,8 +1576,10 @@ int gamma_hip_ivfpq_merge_rerank(gamma_hip_index* h, const gamma_hip_search_para
     }
     // exact ties: the slice's queries whose result a tie can change are listed (gamma_hip_ivfpq_merge_flagged); the
     // caller gathers their candidate streams from the shards and has them replayed (gamma_hip_ivfpq_merge_replay)
-    TiesScope ties_scope(h, p);
-    const bool ties = h->exact_ties && R <= gh::tie_replay_max_k() && p->nprobe <= gh::tie_replay_max_probes();
+    gamma_hip_search_params pp;
+    GH_TRY(resolve_ties(h, p, &pp, p->nprobe <= gh::tie_replay_max_probes(), "exact_ties = 1 with nprobe > 256"));
+    p = &pp;
+    const bool ties = tie_on(p);
     h->merge_flags = ties;
     h->merge_nql = nq_local;
     if (ties) {
@@ -1558,8 +1588,8 @@ int gamma_hip_ivfpq_merge_rerank(gamma_hip_index* h, const gamma_hip_search_para
         GH_CHECK(h, hipMemsetAsync(h->w_tlist.p, 0, sizeof(int), s));
         gh::launch_flag_merge_cut(s, d_all_dis, nshards, nq, R, q0, nq_local, h->w_cand_dis.as<float>(), h->w_cand_ids.as<int64_t>(),
                                   h->w_tcut.as<uint8_t>(), h->merge_shard_flags);
-        h->merge_shard_flags = nullptr;   // one merge
     }
+    h->merge_shard_flags = nullptr;   // one merge, with ties or without
     return ivfpq_stage_b(h, p, nq_local, d_x + (size_t)q0 * h->d, R, k, h->w_cand_dis.as<float>(),
                          h->w_cand_ids.as<int64_t>(), d_distances, d_labels, nullptr, ties ? 2 : 0);
 }
@@ -1647,6 +1677,9 @@ int gamma_hip_ivfpq_shard_export(gamma_hip_index* h, const gamma_hip_search_para
     GH_CHECK(h, hipSetDevice(h->device));
     const int P = p->nprobe, R = std::max(p->recall_num, 1);
     if (stride < 1) return fail(h, GAMMA_HIP_EINVAL, "stride");
+    gamma_hip_search_params pp = *p;   // the scan behind an export flags nothing: its top-R goes to scratch
+    pp.exact_ties = -1;
+    p = &pp;
     gh::FilterDesc filt;
     GH_TRY(build_filter(h, p, &filt));
     FiltCtx fc;

@@ -292,6 +292,9 @@ struct TieReplayArgs {
                                   // running bound: first row chunk + the candidates each later pass emitted)
 };
 int tie_replay_max_k();
+int tie_small_max_k();
+void launch_tie_list(hipStream_t s, const uint8_t* cut, const uint8_t* extra, int nq, int* list, int* count,
+                     unsigned long long* tie_stats);
 int tie_replay_max_probes();
 void launch_tie_replay(hipStream_t s, bool l2, const TieReplayArgs& a);
 void launch_flag_cut_ties(hipStream_t s, const float* slab, int64_t q_stride, const int* q_total, int nq, int K,

@@ -12,7 +12,8 @@
 
 namespace gh {
 
-constexpr int TR_MAXK = 1024;    // heap sizes the replay covers (recall_num and k)
+constexpr int TR_MAXK = 1024;    // heap sizes the in-kernel replays of the small-batch chains cover (recall_num and k)
+constexpr int TR_MAXK_BIG = 4096;   // k_tie_replay: every recall_num / k the ABI accepts (its <.., 4096, 4096> variant beyond 1024)
 constexpr int TR_MAXP = 256;     // probes per query
 constexpr int TR_STAGE = 1024;   // survivor items sorted per round (= the scan's slice capacity)
 constexpr int TR_SLAB = 2048;    // candidates of the slab part brought into LDS per round (with it a C3 replay needs 21 KB of LDS: a
@@ -58,7 +59,7 @@ __device__ __forceinline__ TieLds tie_carve(char* p, int R, int k, int P, int sl
 
 // One query, replayed the way the reference runs it.  Called by all NT threads of a workgroup (NT a multiple
 // of 64, <= 1024); `lds` = tie_replay_lds_bytes_(R, k, P, SLAB) bytes, 16-byte aligned, free for this call.
-template <bool L2, int NT, int SLAB = TR_SLAB, int STG = TR_STAGE>
+template <bool L2, int NT, int SLAB = TR_SLAB, int STG = TR_STAGE, int MAXK = TR_MAXK>
 __device__ __forceinline__ void tie_replay_query(const TieReplayArgs& a, int q, char* lds, unsigned long long* dbg,
                                                  int slab_row = -1) {
 #define GH_TT(i) do { if (dbg && threadIdx.x == 0) dbg[i] = wall_clock64(); } while (0)
@@ -282,7 +283,7 @@ __device__ __forceinline__ void tie_replay_query(const TieReplayArgs& a, int q, 
             L.it[j] = (int)e.y < 0 ? (0xffffffff80000000ull | (unsigned)j)
                                    : (((unsigned long long)f2key(__uint_as_float(e.x)) << 32) | e.y);
         }
-        block_rank_sort<NT, TR_MAXK / NT>(L.it, R);
+        block_rank_sort<NT, (MAXK + NT - 1) / NT>(L.it, R);   // (L.it holds max(STG, MAXK) items: tie_replay_lds_bytes_)
         for (int j = tid; j < R; j += NT) {
             const unsigned long long it = L.it[j];
             const bool empty = (uint32_t)(it >> 32) == 0xffffffffu;

@@ -40,17 +40,18 @@
 
 namespace gh {
 
-int tie_replay_max_k() { return TR_MAXK; }
+int tie_replay_max_k() { return TR_MAXK_BIG; }
+int tie_small_max_k() { return TR_MAXK; }
 int tie_replay_max_probes() { return TR_MAXP; }
 size_t tie_replay_lds_bytes(int R, int k, int P) { return tie_replay_lds_bytes_(R, k, P); }
 
-template <bool L2, int STG>
+template <bool L2, int STG, int MAXK = TR_MAXK>
 __global__ __launch_bounds__(256) void k_tie_replay(TieReplayArgs a) {
     extern __shared__ __attribute__((aligned(16))) char s_tie_lds[];
     const int nflag = min(*a.count, a.nq);
     for (int fi = blockIdx.x; fi < nflag; fi += gridDim.x)
-        tie_replay_query<L2, 256, TR_SLAB, STG>(a, a.list[fi], s_tie_lds, (a.dbg && fi == 0) ? a.dbg : nullptr,
-                                                 a.compact_rows ? fi : -1);
+        tie_replay_query<L2, 256, TR_SLAB, STG, MAXK>(a, a.list[fi], s_tie_lds, (a.dbg && fi == 0) ? a.dbg : nullptr,
+                                                       a.compact_rows ? fi : -1);
 }
 
 void launch_tie_replay(hipStream_t s, bool l2, const TieReplayArgs& a0) {
@@ -74,6 +75,22 @@ void launch_tie_replay(hipStream_t s, bool l2, const TieReplayArgs& a0) {
     }
     const int grid = std::min(a.nq, 1024);
     if (a.slice_cap > 2048) abort();   // callers gate on this
+    if (a.R > TR_MAXK || a.k > TR_MAXK) {
+        // heaps beyond 1024 entries (up to the 4096 the ABI accepts): the same replay with a sort buffer of 4096 items --
+        // up to 155 KB of LDS, one workgroup per CU; a sequential heap_reorder of 4096 entries takes milliseconds, which
+        // is what a request for thousands of results with a tie at its cut costs
+        const size_t lds = tie_replay_lds_bytes_(a.R, a.k, a.P, TR_SLAB, TR_MAXK_BIG);
+        static std::atomic<uint64_t> attr{0};   // per device
+        if (first_call_on_device(attr)) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tie_replay<true, TR_MAXK_BIG, TR_MAXK_BIG>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tie_replay<false, TR_MAXK_BIG, TR_MAXK_BIG>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+        }
+        if (l2) hipLaunchKernelGGL((k_tie_replay<true, TR_MAXK_BIG, TR_MAXK_BIG>), dim3(grid), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((k_tie_replay<false, TR_MAXK_BIG, TR_MAXK_BIG>), dim3(grid), dim3(256), lds, s, a);
+        return;
+    }
     if (a.slice_cap > TR_STAGE) {      // long slices (flat search: the candidate lists of the running bound)
         const size_t lds = tie_replay_lds_bytes_(a.R, a.k, a.P, TR_SLAB, 2048);
         if (l2) hipLaunchKernelGGL((k_tie_replay<true, 2048>), dim3(grid), dim3(256), lds, s, a);
@@ -164,6 +181,23 @@ void launch_flat_take_flag(hipStream_t s, const float* D1, const int64_t* I1, in
     if (nq <= 0) return;
     hipLaunchKernelGGL(k_flat_take_flag, dim3((nq + 3) / 4), dim3(256), 0, s, D1, I1, nq, k, distances, labels, list, count,
                        tie_stats);
+}
+
+// flagged[q] = cut[q] | extra[q] -> list / count (the paths whose final kernels do not list the flagged queries themselves:
+// recall_num beyond 1024)
+__global__ __launch_bounds__(256) void k_tie_list(const uint8_t* __restrict__ cut, const uint8_t* __restrict__ extra, int nq,
+                                                  int* __restrict__ list, int* __restrict__ count,
+                                                  unsigned long long* __restrict__ tie_stats) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    if ((cut && cut[q]) || (extra && extra[q])) {
+        list[atomicAdd(count, 1)] = q;
+        if (tie_stats) atomicAdd(tie_stats + 2, 1ull);
+    }
+}
+void launch_tie_list(hipStream_t s, const uint8_t* cut, const uint8_t* extra, int nq, int* list, int* count,
+                     unsigned long long* tie_stats) {
+    if (nq > 0) hipLaunchKernelGGL(k_tie_list, dim3((nq + 255) / 256), dim3(256), 0, s, cut, extra, nq, list, count, tie_stats);
 }
 
 __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ x, const int* __restrict__ list, int d,

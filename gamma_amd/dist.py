@@ -198,6 +198,13 @@ def sharded_add(backend, vecs, first_vid, owned, group=None, turn=0):
     lno = np.ascontiguousarray(pack[:, :8]).view(np.int64).reshape(n)
     codes = np.ascontiguousarray(pack[:, 8:])
     backend.append_raw(vecs)
+    # a key the quantizer could not assign goes to list vid % nlist (gamma_index_ivfpq.cc:475-481) -- the same rule on
+    # every rank, before the owner mask is consulted
+    nlist = len(owned)
+    bad = (lno < 0) | (lno >= nlist)
+    if bad.any():
+        lno = lno.copy()
+        lno[bad] = (first_vid + np.nonzero(bad)[0]) % nlist
     mine = np.nonzero(np.asarray(owned)[lno] != 0)[0]
     if len(mine):
         order = mine[np.argsort(lno[mine], kind="stable")]
@@ -347,13 +354,8 @@ def sharded_search(backend, x, k, args, group=None, pipeline=None):
     # faiss chooses the coarse path from the size of the whole batch: slices and sub-batches must agree.  The
     # resolved mode lives in the caller's parameter block only for the duration of this call -- a SearchArgs
     # reused for a batch on the other side of the 20-query rule must resolve again.
-    saved_mode = args.p.coarse_mode
-    if saved_mode < 0:
-        args.p.coarse_mode = 0 if x.shape[0] < 20 else 1
-    try:
+    with _whole_call_coarse_mode(args, x.shape[0]):
         return _sharded_search(backend, x, k, args, group, pipeline)
-    finally:
-        args.p.coarse_mode = saved_mode
 
 
 def _sharded_search(backend, x, k, args, group, pipeline):
@@ -435,6 +437,25 @@ def _sharded_search(backend, x, k, args, group, pipeline):
     return Dall[:nq], Iall[:nq]
 
 
+class _whole_call_coarse_mode:
+    """faiss picks the coarse path (exact below 20 queries, GEMM form from 20 on, faiss:utils/distances.cpp:303,346) from
+    the size of the WHOLE call.  A rank that searches a slice must not let the slice's size decide: the mode is resolved
+    here on the batch size and lives in the caller's parameter block only for the duration of the call (a SearchArgs
+    reused for a batch on the other side of the rule resolves again)."""
+
+    def __init__(self, args, nq):
+        self.args, self.nq = args, nq
+
+    def __enter__(self):
+        self.saved = self.args.p.coarse_mode
+        if self.saved < 0:
+            self.args.p.coarse_mode = 0 if self.nq < 20 else 1
+
+    def __exit__(self, *a):
+        self.args.p.coarse_mode = self.saved
+        return False
+
+
 def replicated_search(backend, x, k, args, group=None):
     """Query-parallel search over REPLICATED lists: every rank holds the whole index (no list mask) and answers its slice
     of the batch with the ordinary single-handle search -- exact ties and all -- and the [nq/W, k] results are
@@ -466,7 +487,8 @@ def replicated_search(backend, x, k, args, group=None):
             b["D"].zero_()
             b["I"].fill_(-1)
         if q1 > q0:
-            backend.search_all(x[q0:q1], k, args, b["D"][:q1 - q0], b["I"][:q1 - q0])
+            with _whole_call_coarse_mode(args, nq):
+                backend.search_all(x[q0:q1], k, args, b["D"][:q1 - q0], b["I"][:q1 - q0])
         if world > 1:
             dist.all_gather_into_tensor(b["res"].view(-1), b["res_l"], group=group)
         else:
@@ -549,7 +571,8 @@ class ReplicatedStream:
                 b["D"].zero_()
                 b["I"].fill_(-1)
             # (an empty slice still makes the call: a search call is what completes the previous one)
-            self.backend.search_all(x[q0:q1], self.k, self.args, b["D"][:q1 - q0], b["I"][:q1 - q0])
+            with _whole_call_coarse_mode(self.args, nq):
+                self.backend.search_all(x[q0:q1], self.k, self.args, b["D"][:q1 - q0], b["I"][:q1 - q0])
             if self.pending is not None:
                 out = self._gather(*self.pending)
             self.pending = (slot, nq)

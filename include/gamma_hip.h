@@ -43,6 +43,7 @@ extern "C" {
 #define GAMMA_HIP_EDEVICE (-3)    /* a HIP runtime call failed (hipGetLastError text kept) */
 #define GAMMA_HIP_ENOMEM (-4)     /* device or host allocation failed */
 #define GAMMA_HIP_EFULL (-5)      /* list would exceed bucket_max_size (AddKeys returns false) */
+#define GAMMA_HIP_EUNSUPPORTED (-6) /* the request asked for exact_ties = 1 on a shape the replay does not cover */
 
 typedef struct gamma_hip_index gamma_hip_index;
 
@@ -143,9 +144,12 @@ int gamma_hip_set_workspace_budget(gamma_hip_index* h, int64_t bytes);
  * k smallest (distance, scan position) pairs" -- the same distances at every rank, the same ids up to the order /
  * membership inside groups of exactly equal distances, and no replay cost (a few queries in a thousand on integer
  * data, none to speak of on real-valued data).  Per request: gamma_hip_search_params.exact_ties.
- * Covers IVFPQ search on one handle, every batch size: nprobe <= 256 (beyond 100 probes faiss itself selects
- * through its reservoir, whose order inside ties is not reproduced), recall_num <= 1024; other shapes, IVFFLAT /
- * flat search and the sharded merge keep the (distance, position) order inside ties. */
+ * Covers IVFPQ / IVFFLAT / flat search, every batch size, every recall_num and k the ABI accepts (<= 4096), the
+ * list-sharded merge and the group.  NOT covered: nprobe > 256 (from 100 probes on faiss itself selects through its
+ * reservoir, faiss:utils/distances.cpp:341-358), a flat search for k = 4096 or over 2^31 rows.  Such a call never
+ * degrades silently: with exact_ties = 1 in the request it fails with GAMMA_HIP_EUNSUPPORTED; when it merely inherits the
+ * handle's default it runs with the (distance, position) order inside ties and is counted
+ * (gamma_hip_ties_not_honoured). */
 int gamma_hip_set_exact_ties(gamma_hip_index* h, int on);
 /* Coarse quantizer of large batches (>= 4096 queries, >= 2048 lists, d in {32, 64, 96, 128}, nprobe <= 64) without
  * the [nq][nlist] distance matrix (csrc/coarse.hip).  on: 1 = automatic (default), 0 = always the matrix path.
@@ -160,6 +164,10 @@ int gamma_hip_set_small_path(gamma_hip_index* h, int on);
 /* out3 = {coarse rows redone, queries whose recall_num cut went through a tie, queries replayed} since creation
  * or the last reset; meaningful with exact ties on */
 int gamma_hip_tie_stats(gamma_hip_index* h, int64_t* out3, int reset);
+/* search calls since creation (or the last reset) that ran WITHOUT the exact-ties mode although the handle's default asked
+ * for it, because their shape is beyond the replay's range (see gamma_hip_set_exact_ties); the reference has no such
+ * limit (faiss:utils/Heap.h:103-131, index/impl/gamma_index_ivfpq.cc:762-770) */
+int gamma_hip_ties_not_honoured(gamma_hip_index* h, int64_t* out_calls, int reset);
 
 /* ---- numeric scalar columns for on-device range filters (docid = row).  The engine side
  *      appends a doc's value when the doc is added (Table::Add, table/table.cc) ----------- */

@@ -14,7 +14,7 @@ from gamma_amd import api  # noqa: E402
 from gamma_amd import dist as gdist  # noqa: E402
 from oracle import binding as B  # noqa: E402
 from tests import fixtures  # noqa: E402
-from tests.parity import compare_topk  # noqa: E402
+from tests.parity import compare_exact  # noqa: E402
 
 
 def main():
@@ -61,12 +61,32 @@ def main():
     for pipeline in (None, None, 2, 3, 2):
         D, I = gdist.sharded_search(be, x, k, args, pipeline=pipeline)
         torch.cuda.synchronize()
-        compare_topk(Dref.cpu().numpy(), Iref.cpu().numpy(), D.cpu().numpy(), I.cpu().numpy())
+        compare_exact(Dref.cpu().numpy(), Iref.cpu().numpy(), D.cpu().numpy(), I.cpu().numpy())
     # query-parallel over replicated lists: every rank answers its slice on the whole index (the single-handle path,
     # exact ties included), one all-gather of the results
     D, I = gdist.replicated_search(gdist.HipShardBackend(full, local), x, k, args)
     torch.cuda.synchronize()
     assert D.cpu().numpy().tobytes() == Dref.cpu().numpy().tobytes() and np.array_equal(I.cpu().numpy(), Iref.cpu().numpy())
+    # the DEFAULT coarse_mode with 20 <= nq < 20 * world: faiss decides on the size of the whole call (GEMM form here), so
+    # the slices -- each below 20 queries -- must not fall back to the exact form by themselves
+    args_def = api.SearchArgs(metric=api.METRIC_L2, nprobe=P, recall_num=R, has_rank=True, min_score=-3e38, max_score=3e38,
+                              coarse_mode=-1)
+    nd = min(nq, 20 + 9 * (world - 1))
+    xd = x[:nd].contiguous()
+    Dd = torch.empty((nd, k), dtype=torch.float32, device=dev)
+    Id = torch.empty((nd, k), dtype=torch.int64, device=dev)
+    full.ivfpq_search_device(xd.data_ptr(), nd, k, args_def, Dd.data_ptr(), Id.data_ptr())
+    full.synchronize()
+    D, I = gdist.replicated_search(gdist.HipShardBackend(full, local), xd, k, args_def)
+    torch.cuda.synchronize()
+    assert args_def.p.coarse_mode == -1
+    assert D.cpu().numpy().tobytes() == Dd.cpu().numpy().tobytes() and np.array_equal(I.cpu().numpy(), Id.cpu().numpy())
+    rs_d = gdist.ReplicatedStream(gdist.HipShardBackend(full, local), k, args_def)
+    rs_d.submit(xd)
+    Ds, Is = rs_d.flush()
+    torch.cuda.synchronize()
+    assert Ds.cpu().numpy().tobytes() == Dd.cpu().numpy().tobytes() and np.array_equal(Is.cpu().numpy(), Id.cpu().numpy())
+    rs_d.close()
     # a stream of batches with the deferred tie replay: gathered one batch behind, every batch bit for bit the unsharded
     # handle's answer (tie-heavy queries included: x holds base vectors, whose nearest neighbours are at distance 0 ...)
     rs = gdist.ReplicatedStream(gdist.HipShardBackend(full, local), k, args)
@@ -107,7 +127,6 @@ def main():
     # exact ties across the ranks' shards: tie-heavy data (every base vector four times), labels strictly the pinned
     # oracle's on the unsharded index (gamma_amd.dist.tie_phase: flagged queries broadcast, candidate streams exported by
     # every rank, gathered, replayed by the slice's owner)
-    from tests.parity import compare_exact
     from tests.test_oracle_golden import load_ties
     z, o, base, metric = load_ties("l2")
     sizes = z["list_sizes_l2"]

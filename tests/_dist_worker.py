@@ -142,6 +142,26 @@ def main():
                                        coarse_mode=0)
         assert Ds.numpy().tobytes() == De.tobytes() and np.array_equal(Is.numpy(), Ie)
     rs.close()
+    # the default coarse_mode (-1) is resolved on the size of the WHOLE batch before the slices are searched (faiss's
+    # 20-query rule, faiss:utils/distances.cpp:303,346) and restored afterwards: 20 <= nq < 20 * world
+    seen = []
+
+    class Spy(Full):
+        def search_all(self, xs, kk, a, Dd, Ii):
+            seen.append((xs.shape[0], a.p.coarse_mode))
+            Full.search_all(self, xs, kk, a, Dd, Ii)
+    a_def = api.SearchArgs(metric=api.METRIC_L2, nprobe=nprobe, recall_num=R, has_rank=True, min_score=-3e38, max_score=3e38,
+                           coarse_mode=-1)
+    nd = 20 + 4 * (world - 1)
+    assert nd <= x.shape[0]
+    gdist.replicated_search(Spy(), x[:nd], k, a_def)
+    rs2 = gdist.ReplicatedStream(Spy(), k, a_def)
+    rs2.submit(x[:nd])
+    rs2.submit(x[:7])
+    rs2.flush()
+    rs2.close()
+    assert a_def.p.coarse_mode == -1
+    assert [m for n_, m in seen] == [1, 1, 0] and all(n_ < 20 for n_, m in seen), seen
     # every rank holds the full, identical result
     gathered = [torch.empty_like(I) for _ in range(world)]
     dist.all_gather(gathered, I)

@@ -89,3 +89,32 @@ def compare_exact(D_ref, I_ref, D_got, I_got):
         q, r = bad[0]
         raise AssertionError("labels differ at %d entries (%d queries), first (q=%d, rank=%d): ref=%s got=%s"
                              % (len(bad), len(set(bad[:, 0].tolist())), q, r, I_ref[q].tolist(), I_got[q].tolist()))
+
+
+def _stage_rows(dis, ids):
+    """Recall-stage rows as canonically ordered (distance bits, id) pairs; padding (-1) normalised."""
+    dis = np.ascontiguousarray(dis, dtype=np.float32).copy()
+    ids = np.ascontiguousarray(ids, dtype=np.int64)
+    dis[ids == -1] = 0
+    order = np.lexsort((ids, dis.view(np.uint32)), axis=1)
+    return np.take_along_axis(dis.view(np.uint32), order, axis=1), np.take_along_axis(ids, order, axis=1)
+
+
+def compare_search_exact(D, I, st, Dg, Ig, sg):
+    """Strict form of compare_search (exact ties on, the default): NO query is excluded.  The probed lists must
+    be the reference's in the reference's order (coarse distances bit-identical), the recall stage must hold
+    the same (distance, id) pairs -- which members of a tie group cut by recall_num survive is the reference
+    heap's choice and the device has to make the same one -- and the final table must pass compare_exact."""
+    if "coarse_idx" in st and "coarse_idx" in sg and st["coarse_idx"].shape == sg["coarse_idx"].shape:
+        if not np.array_equal(st["coarse_idx"], sg["coarse_idx"]):
+            bad = np.argwhere((st["coarse_idx"] != sg["coarse_idx"]).any(axis=1)).ravel()
+            raise AssertionError("probed lists differ for %d queries, first q=%d: ref=%s got=%s"
+                                 % (len(bad), bad[0], st["coarse_idx"][bad[0]].tolist(), sg["coarse_idx"][bad[0]].tolist()))
+        assert st["coarse_dis"].tobytes() == sg["coarse_dis"].tobytes(), "coarse distances differ"
+    a_d, a_i = _stage_rows(st["recall_dis"], st["recall_ids"])
+    b_d, b_i = _stage_rows(sg["recall_dis"], sg["recall_ids"])
+    if not (np.array_equal(a_i, b_i) and np.array_equal(a_d, b_d)):
+        bad = np.argwhere((a_i != b_i).any(axis=1) | (a_d != b_d).any(axis=1)).ravel()
+        raise AssertionError("recall-stage (distance, id) sets differ for %d queries, first q=%d" % (len(bad), bad[0]))
+    compare_exact(D, I, Dg, Ig)
+    return 0

@@ -1,0 +1,89 @@
+"""W list shards emulated on ONE GPU through the C ABI -- the steps gamma_hip_group / gamma_amd.dist drive, with the
+exchanges done by tensor indexing: coarse per query slice, shard scans, merge + re-rank at the slice's owner, then the
+tie phase (include/gamma_hip.h, "exact ties across list shards"): the owner lists the queries a tie can change
+(gamma_hip_ivfpq_merge_flagged), every shard exports their candidate streams over the lists it owns
+(gamma_hip_ivfpq_shard_export), the owner assembles and replays them (gamma_hip_ivfpq_merge_replay).
+Shared by tests/test_gpu_ties.py and tests/test_gpu_dist.py."""
+import torch
+
+from gamma_amd import dist as gdist
+
+
+def sharded_search_emulated(shards, x, k, args, use_shard_flags=True):
+    """shards: W api.GammaHip handles, each holding the lists it owns.  x: [nq, d] float32 tensor on cuda:0.
+    Returns (D, I, flagged): [nq, k] result tensors and the number of queries that went through the tie phase."""
+    W = len(shards)
+    nq, d = x.shape
+    P = args.p.nprobe
+    R = max(args.p.recall_num, k)
+    dev = x.device
+    per = (nq + W - 1) // W
+    backs = [gdist.HipShardBackend(g, 0) for g in shards]
+    sl = [gdist.query_slice(nq, s, W) for s in range(W)]
+    cd_parts, pr_parts = [], []
+    for s in range(W):
+        q0, q1, _ = sl[s]
+        cdis = torch.zeros((max(1, q1 - q0), P), dtype=torch.float32, device=dev)
+        probe = torch.full((max(1, q1 - q0), P), -1, dtype=torch.int32, device=dev)
+        if q1 > q0:
+            backs[s].coarse(x[q0:q1].contiguous(), args, cdis, probe)
+            shards[s].synchronize()
+        cd_parts.append(cdis[:q1 - q0])
+        pr_parts.append(probe[:q1 - q0])
+    cd_all = torch.cat(cd_parts).contiguous()      # the assignment in query order: what the all-gather delivers
+    pr_all = torch.cat(pr_parts).contiguous()
+    rd, ri, cf_ = [], [], []
+    for s in range(W):
+        rdis = torch.zeros((nq, R), dtype=torch.float32, device=dev)
+        rids = torch.full((nq, R), -1, dtype=torch.int64, device=dev)
+        cutf = torch.zeros((nq,), dtype=torch.uint8, device=dev)
+        backs[s].search_shard(x, cd_all, pr_all, k, args, rdis, rids)
+        backs[s].shard_cut_flags(nq, cutf)
+        shards[s].synchronize()
+        rd.append(rdis)
+        ri.append(rids)
+        cf_.append(cutf)
+    D = torch.zeros((nq, k), dtype=torch.float32, device=dev)
+    I = torch.full((nq, k), -1, dtype=torch.int64, device=dev)
+    flagged = 0
+    for r in range(W):       # what the all-to-all delivers to rank r: its slice of every shard's table
+        q0, q1, _ = sl[r]
+        nql = q1 - q0
+        if nql == 0:
+            continue
+        all_dis = torch.stack([rd[s][q0:q1] for s in range(W)]).contiguous()
+        all_ids = torch.stack([ri[s][q0:q1] for s in range(W)]).contiguous()
+        xs = x[q0:q1].contiguous()
+        Dr = torch.zeros((nql, k), dtype=torch.float32, device=dev)
+        Ir = torch.full((nql, k), -1, dtype=torch.int64, device=dev)
+        if use_shard_flags:   # (without: every table that ends at the cut value counts as a tie)
+            cut_all = torch.stack([cf_[s][q0:q1] for s in range(W)]).contiguous()
+            shards[r].ivfpq_merge_set_shard_flags(cut_all.data_ptr())
+        shards[r].ivfpq_merge_rerank(W, nql, xs.data_ptr(), k, args, all_dis.data_ptr(), all_ids.data_ptr(), 0, nql,
+                                     Dr.data_ptr(), Ir.data_ptr())
+        nf, d_list = shards[r].ivfpq_merge_flagged() if args.p.exact_ties >= 0 else (0, 0)
+        flagged += nf
+        if nf:
+            xf = torch.empty((nf, d), dtype=torch.float32, device=dev)
+            cf = torch.empty((nf, P), dtype=torch.float32, device=dev)
+            pf = torch.empty((nf, P), dtype=torch.int32, device=dev)
+            cds = cd_all[q0:q1].contiguous()
+            prs = pr_all[q0:q1].contiguous()
+            shards[r].gather_rows(xs.data_ptr(), d, d_list, nf, xf.data_ptr())
+            shards[r].gather_rows(cds.data_ptr(), P, d_list, nf, cf.data_ptr())
+            shards[r].gather_rows(prs.data_ptr(), P, d_list, nf, pf.data_ptr())
+            shards[r].synchronize()
+            stride = max(4, (max(g.ivfpq_shard_export_rows(nf, pf.data_ptr(), args) for g in shards) + 3) // 4 * 4)
+            vals = torch.empty((W, nf, stride), dtype=torch.float32, device=dev)
+            ids = torch.empty((W, nf, stride), dtype=torch.int64, device=dev)
+            off = torch.empty((W, nf, P + 1), dtype=torch.int32, device=dev)
+            for s in range(W):
+                shards[s].ivfpq_shard_export(nf, xf.data_ptr(), cf.data_ptr(), pf.data_ptr(), stride, args, vals[s].data_ptr(),
+                                             ids[s].data_ptr(), off[s].data_ptr())
+                shards[s].synchronize()
+            shards[r].ivfpq_merge_replay(W, nf, xs.data_ptr(), stride, vals.data_ptr(), ids.data_ptr(), off.data_ptr(), k, args,
+                                         d_list, Dr.data_ptr(), Ir.data_ptr())
+        shards[r].synchronize()
+        D[q0:q1] = Dr
+        I[q0:q1] = Ir
+    return D, I, flagged

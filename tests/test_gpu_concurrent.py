@@ -12,7 +12,7 @@ import pytest
 
 from gamma_amd import api, synth, train
 from oracle import binding as B
-from tests.parity import compare_topk
+from tests.parity import compare_exact
 
 pytestmark = pytest.mark.gpu
 WIDE = dict(min_score=-3e38, max_score=3e38)
@@ -89,7 +89,7 @@ def test_search_during_inserts_sees_a_prefix_of_the_log():
                 hit = None
                 for b in range(last, nb + 1):
                     try:
-                        compare_topk(expect[b][0], expect[b][1], D, I)
+                        compare_exact(expect[b][0], expect[b][1], D, I)
                         hit = b
                         break
                     except AssertionError:
@@ -100,7 +100,7 @@ def test_search_during_inserts_sees_a_prefix_of_the_log():
         assert len(seen) >= 2, seen            # searches really ran while the index was growing
         # and the final state is the whole log
         D, I = g.ivfpq_search(q, k, args)
-        compare_topk(expect[nb][0], expect[nb][1], D, I)
+        compare_exact(expect[nb][0], expect[nb][1], D, I)
     finally:
         g.close()
 

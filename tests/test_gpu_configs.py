@@ -7,7 +7,7 @@ import pytest
 
 from gamma_amd import api, synth, train
 from oracle import binding as B
-from tests.parity import compare_search, compare_topk
+from tests.parity import compare_search_exact, compare_exact
 
 pytestmark = pytest.mark.gpu
 WIDE = dict(min_score=-3e38, max_score=3e38)
@@ -61,8 +61,8 @@ def test_c4_shape_m32_nlist16384_nprobe64():
             Dg, Ig = g.ivfpq_search(qs, 10, a2)
             sg = g.last_stages(len(qs), P, 100)
             assert sg["coarse_dis"].tobytes() == st["coarse_dis"].tobytes()
-            compare_topk(st["coarse_dis"], st["coarse_idx"], sg["coarse_dis"], sg["coarse_idx"])   # tie-aware
-            compare_search(Do, Io, st, Dg, Ig, sg)
+            compare_exact(st["coarse_dis"], st["coarse_idx"], sg["coarse_dis"], sg["coarse_idx"])   # tie-aware
+            compare_search_exact(Do, Io, st, Dg, Ig, sg)
     finally:
         g.close()
 
@@ -124,7 +124,7 @@ def test_c5_shape_d768_ip_filters_and_realtime_inserts():
                                        coarse_mode=1, range_filters=rf_g, **WIDE)
                     Dg, Ig = g.ivfpq_search(q, 10, a)
                     sg = g.last_stages(len(q), P, 100)
-                    compare_search(Do, Io, st, Dg, Ig, sg)
+                    compare_search_exact(Do, Io, st, Dg, Ig, sg)
 
         check(N)
         # realtime inserts between searches, then deletes + updates
@@ -158,7 +158,7 @@ def test_c5_shape_d768_ip_filters_and_realtime_inserts():
                                **WIDE)
             Dg, Ig = g.ivfpq_search(qb, 10, a)
             sg = g.last_stages(len(qb), P, 100)
-            compare_search(Do, Io, st, Dg, Ig, sg)
+            compare_search_exact(Do, Io, st, Dg, Ig, sg)
     finally:
         B.lib().go_set_assign_mode(0)
         g.close()
@@ -171,7 +171,6 @@ def test_c1_flat_l2_10k_128_k10_through_the_plugin_boundary():
     restatement of GammaFLATIndex::Search.  Also the engine's default score window (tests/test.h:584-585)."""
     from gamma_amd import plugin
     from oracle import binding as B
-    from tests.parity import compare_topk
     N, d, k, nq = 10000, 128, 10, 1000
     base = synth.sift_like(N, d=d, seed=1234)
     q = synth.sift_like(nq, d=d, seed=4321)
@@ -181,14 +180,14 @@ def test_c1_flat_l2_10k_128_k10_through_the_plugin_boundary():
         assert m.add(base[i0:i0 + 1000])
     Df, If = B.flat_search(base, q, k, B.METRIC_L2, B.make_ctx())
     Dg, Ig = m.search(q, k, '{"metric_type": "L2"}')
-    compare_topk(Df, If, Dg, Ig)
+    compare_exact(Df, If, Dg, Ig)
     assert (Ig >= 0).all() and (np.diff(Dg, axis=1) >= 0).all()
     Df, If = B.flat_search(base, q, k, B.METRIC_L2, B.make_ctx(min_score=0.0, max_score=10000.0))
     Dg, Ig = m.search(q, k, '{"metric_type": "L2"}', min_score=0.0, max_score=10000.0)
-    compare_topk(Df, If, Dg, Ig)
+    compare_exact(Df, If, Dg, Ig)
     # one query at a time, as tests/test.h issues them
     for i in range(0, 40):
         D1, I1 = m.search(q[i:i + 1], k, "")
-        compare_topk(Df[i:i + 1] * 0 + B.flat_search(base, q[i:i + 1], k, B.METRIC_L2, B.make_ctx())[0],
+        compare_exact(Df[i:i + 1] * 0 + B.flat_search(base, q[i:i + 1], k, B.METRIC_L2, B.make_ctx())[0],
                      B.flat_search(base, q[i:i + 1], k, B.METRIC_L2, B.make_ctx())[1], D1, I1)
     m.close()

@@ -10,7 +10,7 @@ import pytest
 
 from oracle import binding as B
 from tests import fixtures
-from tests.parity import compare_topk
+from tests.parity import compare_exact
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -52,32 +52,9 @@ def _sharded_vs_full(case, shards, full, metric, has_rank, W, nq, P):
     Iref = torch.empty((nq, k), dtype=torch.int64, device=dev)
     full.ivfpq_search_device(x.data_ptr(), nq, k, args, Dref.data_ptr(), Iref.data_ptr())
     full.synchronize()
-    per = (nq + W - 1) // W
-    backs = [gdist.HipShardBackend(g, 0) for g in shards]
-    cdis = torch.zeros((W * per, P), dtype=torch.float32, device=dev)
-    probe = torch.full((W * per, P), -1, dtype=torch.int32, device=dev)
-    for s in range(W):
-        q0, q1, _ = gdist.query_slice(nq, s, W)
-        backs[s].coarse(x[q0:q1], args, cdis[s * per:(s + 1) * per], probe[s * per:(s + 1) * per])
-        shards[s].synchronize()
-    rd, ri = [], []
-    for s in range(W):
-        rdis = torch.zeros((W * per, R), dtype=torch.float32, device=dev)
-        rids = torch.full((W * per, R), -1, dtype=torch.int64, device=dev)
-        backs[s].search_shard(x, cdis[:nq], probe[:nq], k, args, rdis[:nq], rids[:nq])
-        shards[s].synchronize()
-        rd.append(rdis.view(W, per, R))
-        ri.append(rids.view(W, per, R))
-    D = torch.zeros((W * per, k), dtype=torch.float32, device=dev)
-    I = torch.full((W * per, k), -1, dtype=torch.int64, device=dev)
-    for r in range(W):       # what all_to_all delivers to rank r: block r of every shard
-        q0, q1, _ = gdist.query_slice(nq, r, W)
-        all_dis = torch.stack([rd[s][r] for s in range(W)]).contiguous()
-        all_ids = torch.stack([ri[s][r] for s in range(W)]).contiguous()
-        backs[r].merge_rerank(all_dis, all_ids, x[q0:q1], k, args, q1 - q0, D[r * per:(r + 1) * per],
-                              I[r * per:(r + 1) * per])
-        shards[r].synchronize()
-    compare_topk(Dref.cpu().numpy(), Iref.cpu().numpy(), D[:nq].cpu().numpy(), I[:nq].cpu().numpy())
+    from tests.shard_emul import sharded_search_emulated
+    D, I, _ = sharded_search_emulated(shards, x, k, args)      # incl. the tie phase across the shards
+    compare_exact(Dref.cpu().numpy(), Iref.cpu().numpy(), D[:nq].cpu().numpy(), I[:nq].cpu().numpy())
 
 
 @pytest.mark.parametrize("metric,has_rank,W,nq,P,d,M", [

@@ -5,7 +5,7 @@ import pytest
 
 from gamma_amd import api, synth, train
 from oracle import binding as B
-from tests.parity import compare_search
+from tests.parity import compare_search_exact
 
 pytestmark = pytest.mark.gpu
 WIDE = dict(min_score=-3e38, max_score=3e38)
@@ -88,7 +88,7 @@ def test_random_configuration(seed):
                                range_filters=rf_g, **WIDE)
             Dg, Ig = g.ivfpq_search(q, k, a)
             sg = g.last_stages(nq, P, max(R, k))
-            compare_search(Do, Io, st, Dg, Ig, sg)
+            compare_search_exact(Do, Io, st, Dg, Ig, sg)
     finally:
         B.lib().go_set_assign_mode(0)
         g.close()
@@ -121,7 +121,7 @@ def test_many_probes_and_large_batch():
                 a = api.SearchArgs(metric=api.METRIC_L2, nprobe=P, recall_num=R, has_rank=has_rank, **WIDE)
                 Dg, Ig = g.ivfpq_search(q, k, a)
                 sg = g.last_stages(len(q), P, max(R, k))
-                compare_search(Do, Io, st, Dg, Ig, sg)
+                compare_search_exact(Do, Io, st, Dg, Ig, sg)
     finally:
         B.lib().go_set_assign_mode(0)
         g.close()

@@ -8,7 +8,7 @@ import pytest
 from gamma_amd import api, synth
 from oracle import binding as B
 from tests import fixtures
-from tests.parity import compare_topk
+from tests.parity import compare_exact
 
 pytestmark = pytest.mark.gpu
 WIDE = dict(min_score=-3e38, max_score=3e38)
@@ -69,7 +69,7 @@ def test_group_is_the_single_handle(case, W, weights):
                 a = api.SearchArgs(metric=metric, nprobe=P, recall_num=R, has_rank=has_rank, **WIDE)
                 D, I = full.ivfpq_search(q, k, a)
                 Dg, Ig = grp.ivfpq_search(q, k, a)
-                compare_topk(D, I, Dg, Ig)
+                compare_exact(D, I, Dg, Ig)
         # a request's range filter reaches every member
         allowed = np.nonzero(np.random.default_rng(5).random(len(case["base"])) < 0.3)[0]
         q = synth.sift_like(40, d=case["d"], seed=3)
@@ -77,7 +77,7 @@ def test_group_is_the_single_handle(case, W, weights):
                            range_filters=[api.make_range_filter(allowed)], **WIDE)
         D, I = full.ivfpq_search(q, 10, a)
         Dg, Ig = grp.ivfpq_search(q, 10, a)
-        compare_topk(D, I, Dg, Ig)
+        compare_exact(D, I, Dg, Ig)
         assert np.isin(Ig[Ig >= 0], allowed).all()
     finally:
         grp.close()
@@ -122,7 +122,7 @@ def test_group_update_and_delete_route_to_the_owners(case):
         a = api.SearchArgs(metric=api.METRIC_L2, nprobe=16, recall_num=100, has_rank=True, **WIDE)
         D, I = full.ivfpq_search(q, 10, a)
         Dg, Ig = grp.ivfpq_search(q, 10, a)
-        compare_topk(D, I, Dg, Ig)
+        compare_exact(D, I, Dg, Ig)
         assert not np.isin(Ig, dead).any()
     finally:
         grp.close()
@@ -171,7 +171,7 @@ def test_plugin_devices_key(case):
         for n in (len(q), 5):
             D, I = ms[0].search(q[:n], 10, req)
             Dg, Ig = ms[1].search(q[:n], 10, req)
-            compare_topk(D, I, Dg, Ig)
+            compare_exact(D, I, Dg, Ig)
         rng = np.random.default_rng(2)
         vids = rng.choice(len(base), size=64, replace=False).astype(np.int64)
         vecs = base[rng.integers(0, len(base), size=64)].copy()
@@ -183,7 +183,7 @@ def test_plugin_devices_key(case):
             assert m.delete(dead) == 0
         D, I = ms[0].search(q, 10, req)
         Dg, Ig = ms[1].search(q, 10, req)
-        compare_topk(D, I, Dg, Ig)
+        compare_exact(D, I, Dg, Ig)
         assert not np.isin(Ig, dead).any()
         # Dump from the sharded model, Load into a one-GPU model and the other way round
         with tempfile.TemporaryDirectory() as td:
@@ -197,7 +197,7 @@ def test_plugin_devices_key(case):
                     m.engine_bitmap_set(dead)
                     assert m.load(td) > 0
                     Dl, Il = m.search(q, 10, req)
-                    compare_topk(Dg, Ig, Dl, Il)
+                    compare_exact(Dg, Ig, Dl, Il)
             finally:
                 m2.close()
                 m3.close()
@@ -211,7 +211,6 @@ def test_replicated_group_is_the_single_handle_bit_for_bit(case):
     distances are those of ONE handle strictly (compare_exact: no tie tolerance), before and after batched Update and
     Delete; the plugin's `"placement": "replicate"` key is the same thing behind the RetrievalModel boundary."""
     from gamma_amd import plugin
-    from tests.parity import compare_exact
     full = _single(case)
     grp = api.GammaHipGroup([0] * 3)
     try:
@@ -285,7 +284,6 @@ def test_sharded_group_keeps_the_reference_order_inside_ties(tag, W):
     """List-sharded members and tie-heavy data (every base vector four times): the owner of a query slice lists the
     queries a tie can change, every member exports their candidate streams over the lists it owns, the owner replays
     them -- labels strictly the pinned oracle's on the unsharded index."""
-    from tests.parity import compare_exact
     from tests.test_oracle_golden import load_ties
     z, o, base, metric = load_ties(tag)
     d, nlist, M = int(z["d"]), int(z["nlist"]), int(z["M"])

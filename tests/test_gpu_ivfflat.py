@@ -7,7 +7,7 @@ import pytest
 from gamma_amd import api, synth
 from oracle import binding as B
 from tests import fixtures
-from tests.parity import compare_topk
+from tests.parity import compare_exact
 
 pytestmark = pytest.mark.gpu
 WIDE = dict(min_score=-3e38, max_score=3e38)
@@ -47,7 +47,7 @@ def test_ivfflat_search_matches_oracle(metric, d):
             for P, k in ((1, 10), (8, 10), (8, 1), (64, 100), (3, 2000)):
                 D, I = B.ivfflat_search(o, q, k, P, metric, B.make_ctx(**WIDE))
                 Dg, Ig = g.ivfflat_search(q, k, api.SearchArgs(metric=metric, nprobe=P, **WIDE))
-                compare_topk(D, I, Dg, Ig)
+                compare_exact(D, I, Dg, Ig)
         # delete bitmap + range filter + score window
         rng = np.random.default_rng(3)
         N = case["N"]
@@ -65,7 +65,7 @@ def test_ivfflat_search_matches_oracle(metric, d):
             D, I = B.ivfflat_search(o, q, 10, 8, metric, ctx)
             Dg, Ig = g.ivfflat_search(q, 10, api.SearchArgs(metric=metric, nprobe=8,
                                                             range_filters=[api.make_range_filter(docs)], **kw))
-            compare_topk(D, I, Dg, Ig)
+            compare_exact(D, I, Dg, Ig)
             assert not np.isin(Ig, dead).any()
     finally:
         g.close()
@@ -115,7 +115,7 @@ def test_ivfflat_add_update_delete_follow_the_reference_lists():
         q = case["q"][:40]
         D, I = B.ivfflat_search(o, q, 10, 8, B.METRIC_L2, B.make_ctx(**WIDE))
         Dg, Ig = g.ivfflat_search(q, 10, api.SearchArgs(metric=api.METRIC_L2, nprobe=8, **WIDE))
-        compare_topk(D, I, Dg, Ig)
+        compare_exact(D, I, Dg, Ig)
     finally:
         B.lib().go_set_assign_mode(0)
         g.close()
@@ -165,6 +165,6 @@ def test_ivfflat_small_batch_chain_is_the_regular_chain(metric, d, nlist):
                     D, I = B.ivfflat_search(o, q, k, P, metric, B.make_ctx(**WIDE, **ctx_kw))
                     g.set_small_path(1)
                     Dg, Ig = g.ivfflat_search(q, k, api.SearchArgs(metric=metric, nprobe=P, **WIDE, **kw_f))
-                    compare_topk(D, I, Dg, Ig)
+                    compare_exact(D, I, Dg, Ig)
     finally:
         g.close()

@@ -6,7 +6,7 @@ import pytest
 
 from oracle import binding as B
 from tests import fixtures
-from tests.parity import compare_topk
+from tests.parity import compare_exact
 
 pytestmark = pytest.mark.gpu
 
@@ -58,5 +58,5 @@ def test_search_parity(case_l2, hip_l2, metric, has_rank, coarse_mode):
     rd_g = sg["recall_dis"].copy()
     rd_o[st["recall_ids"] == -1] = 0
     rd_g[sg["recall_ids"] == -1] = 0
-    compare_topk(rd_o, st["recall_ids"], rd_g, sg["recall_ids"])
-    compare_topk(D, I, Dg, Ig)
+    compare_exact(rd_o, st["recall_ids"], rd_g, sg["recall_ids"])
+    compare_exact(D, I, Dg, Ig)

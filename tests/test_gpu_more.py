@@ -9,7 +9,7 @@ import pytest
 from gamma_amd import api, synth
 from oracle import binding as B
 from tests import fixtures
-from tests.parity import compare_search, compare_topk
+from tests.parity import compare_search_exact, compare_exact
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
@@ -59,7 +59,7 @@ def test_delete_bitmap_and_range_filters(case, hip, has_rank):
         for ranges, not_in in (([r1], False), ([r1, r2], False), ([r2], True), ([], False)):
             (D, I, _), (Dg, Ig) = run_both(case, hip, case["q"], 10, 8, 100, B.METRIC_L2, has_rank,
                                            range_docs=ranges, del_bitmap=bm, b_not_in=not_in)
-            compare_topk(D, I, Dg, Ig)
+            compare_exact(D, I, Dg, Ig)
             live = Ig[Ig >= 0]
             assert not np.isin(live, deleted).any()
             if ranges == []:
@@ -73,12 +73,12 @@ def test_score_window(case, hip, metric):
     # default GammaSearchCondition window: min = FLT_MIN (tiny), max = FLT_MAX
     (D, I, _), (Dg, Ig) = run_both(case, hip, case["q"], 10, 8, 100, metric, True,
                                    ctx_kw=dict(min_score=None, max_score=None))
-    compare_topk(D, I, Dg, Ig)
+    compare_exact(D, I, Dg, Ig)
     lo, hi = (20000.0, 60000.0) if metric == B.METRIC_L2 else (1e5, 4e5)
     for has_rank in (True, False):
         (D, I, _), (Dg, Ig) = run_both(case, hip, case["q"], 10, 8, 100, metric, has_rank,
                                        ctx_kw=dict(min_score=lo, max_score=hi))
-        compare_topk(D, I, Dg, Ig)
+        compare_exact(D, I, Dg, Ig)
         ok = Ig >= 0
         assert (Dg[ok] >= lo).all() and (Dg[ok] <= hi).all()
 
@@ -88,7 +88,7 @@ def test_edge_shapes(case, hip):
     # nq = 1 (exact coarse rule), k = 1, recall_num < k is raised to k, nprobe = nlist
     for nq, k, nprobe, R in ((1, 1, 1, 1), (1, 10, 64, 5), (3, 200, 2, 50), (64, 10, 64, 300)):
         (D, I, _), (Dg, Ig) = run_both(case, hip, q[:nq], k, nprobe, R, B.METRIC_L2, True, coarse_mode=-1)
-        compare_topk(D, I, Dg, Ig)
+        compare_exact(D, I, Dg, Ig)
     # k <= 0 leaves the outputs alone and succeeds (gamma_index_ivfpq.cc:753-756)
     args = api.SearchArgs(metric=api.METRIC_L2, nprobe=4)
     Dg, Ig = hip.ivfpq_search(q[:2], 0, args)
@@ -135,7 +135,7 @@ def test_other_shapes(cfg, metric):
                                                 has_rank, coarse_mode=cm)
                 sg = g.last_stages(len(case["q"]), min(6, cfg["nlist"]), 40)
                 assert sg["coarse_dis"].tobytes() == st["coarse_dis"].tobytes()
-                compare_search(D, I, st, Dg, Ig, sg)
+                compare_search_exact(D, I, st, Dg, Ig, sg)
     finally:
         g.close()
 
@@ -170,7 +170,7 @@ def test_flat_parity(metric, d):
             for mode in (0, 1, 3):
                 g.set_small_path(mode)
                 Dg, Ig = g.flat_search(q, k, api.SearchArgs(metric=metric, range_filters=rf_g, **WIDE))
-                compare_topk(D, I, Dg, Ig)
+                compare_exact(D, I, Dg, Ig)
                 res.append((Dg, Ig))
             for Dg, Ig in res[1:]:
                 assert res[0][0].tobytes() == Dg.tobytes()
@@ -265,7 +265,7 @@ def test_flat_running_bound(order):
                     assert np.allclose(dd, Dg[i][ok], rtol=1e-5)
                     assert len(set(Ig[i][ok].tolist())) == ok.sum()
             else:
-                compare_topk(D, I, Dg, Ig)
+                compare_exact(D, I, Dg, Ig)
     finally:
         g.close()
 
@@ -295,7 +295,7 @@ def test_small_k_selection_paths(k, layout):
         for metric in (B.METRIC_L2, B.METRIC_IP):
             D, I = B.flat_search(base, q, k, metric, B.make_ctx(**WIDE))
             Dg, Ig = g.flat_search(q, k, api.SearchArgs(metric=metric, **WIDE))
-            compare_topk(D, I, Dg, Ig)
+            compare_exact(D, I, Dg, Ig)
             if layout == "ties":
                 assert Dg.tobytes() == D.tobytes()
     finally:
@@ -313,7 +313,7 @@ def test_flat_small_and_empty():
         g.raw_append(base)
         D, I = B.flat_search(base, q, 5, B.METRIC_L2, B.make_ctx(**WIDE))
         Dg, Ig = g.flat_search(q, 5, api.SearchArgs(metric=api.METRIC_L2, **WIDE))
-        compare_topk(D, I, Dg, Ig)      # k > N: -1 / FLT_MAX padding
+        compare_exact(D, I, Dg, Ig)      # k > N: -1 / FLT_MAX padding
     finally:
         g.close()
 
@@ -338,8 +338,16 @@ def test_golden_vectors_from_real_faiss(name):
             sg = g.last_stages(len(z["q"]), nprobe, R)
             assert sg["coarse_dis"].tobytes() == z["coarse_dis"].tobytes()
             assert np.array_equal(sg["coarse_idx"], z["coarse_idx"])
-            compare_topk(z["rdis_" + tag], z["rids_" + tag], sg["recall_dis"], sg["recall_ids"])
-            compare_topk(z["rdis_" + tag][:, :5], z["rids_" + tag][:, :5], Dg, Ig)
+            # the stage table holds the reference's top-R as a SET (its order inside ties is the scan's; only a query whose
+            # result a tie can change is replayed) ...
+            from tests.parity import _stage_rows
+            a_d, a_i = _stage_rows(z["rdis_" + tag], z["rids_" + tag])
+            b_d, b_i = _stage_rows(sg["recall_dis"], sg["recall_ids"])
+            assert np.array_equal(a_d, b_d) and np.array_equal(a_i, b_i)
+            compare_exact(z["rdis_" + tag][:, :5], z["rids_" + tag][:, :5], Dg, Ig)
+            # ... and asked for all R results, the call returns faiss's heap_reorder order rank by rank
+            DR, IR = g.ivfpq_search(z["q"], R, args)
+            compare_exact(z["rdis_" + tag], z["rids_" + tag], DR, IR)
     finally:
         g.close()
 
@@ -408,7 +416,7 @@ def test_moved_entries_are_skipped(case):
         c2 = dict(case, oracle=o)
         for has_rank in (True, False):
             (D, I, _), (Dg, Ig) = run_both(c2, g, case["q"], 10, 16, 100, B.METRIC_L2, has_rank)
-            compare_topk(D, I, Dg, Ig)
+            compare_exact(D, I, Dg, Ig)
     finally:
         g.close()
 
@@ -498,7 +506,7 @@ def test_c3_sampled_oracle_parity(c3, c3_oracle):
                                         ctx_kw=dict(min_score=0.0, max_score=1e30))
         sg = g.last_stages(len(q), 32, 200)
         assert sg["coarse_dis"].tobytes() == st["coarse_dis"].tobytes()
-        compare_topk(D, I, Dg, Ig)
+        compare_exact(D, I, Dg, Ig)
 
 
 def test_c3_headline_call_matches_oracle(c3, c3_oracle):
@@ -508,7 +516,6 @@ def test_c3_headline_call_matches_oracle(c3, c3_oracle):
     every 67th query plus queries whose result holds equal distances -- against the oracle: coarse assignment byte
     for byte, recall-stage tables, and the final labels at EVERY rank (exact ties are the default; the oracle's
     heaps are pinned against the compiled faiss, tests/test_oracle_golden.py)."""
-    from tests.parity import compare_exact
     g, o = c3["g"], c3_oracle
     nq, P, R, k = 16384, 32, 200, 10
     q = synth.sift_like(nq, d=128, seed=4321)
@@ -527,7 +534,7 @@ def test_c3_headline_call_matches_oracle(c3, c3_oracle):
         assert sg["coarse_dis"][rows].tobytes() == st["coarse_dis"].tobytes()
         assert np.array_equal(sg["coarse_idx"][rows], st["coarse_idx"])
         sub = dict(recall_dis=sg["recall_dis"][rows], recall_ids=sg["recall_ids"][rows])
-        assert compare_search(D, I, st, Dg[rows], Ig[rows], sub) == 0
+        assert compare_search_exact(D, I, st, Dg[rows], Ig[rows], sub) == 0
         compare_exact(D, I, Dg[rows], Ig[rows])
         assert ts["coarse_rows"] > 0 and ts["replayed"] > 0   # the sample really went through the replays
         if has_rank:
@@ -557,12 +564,12 @@ def test_c2_flat_full_size(c3):
         assert np.partition(dall, 99)[99] == D[i, 99]
     # the oracle (reference flat loop restated) on a few queries over the full base
     Do, Io = B.flat_search(base, q[:6], 100, B.METRIC_L2, B.make_ctx(min_score=0.0, max_score=1e30))
-    compare_topk(Do, Io, D[:6], I[:6])
+    compare_exact(Do, Io, D[:6], I[:6])
     # inner product over the same store
     argi = api.SearchArgs(metric=api.METRIC_IP, **WIDE)
     Di, Ii = g.flat_search(q[:6], 100, argi)
     Do, Io = B.flat_search(base, q[:6], 100, B.METRIC_IP, B.make_ctx(**WIDE))
-    compare_topk(Do, Io, Di, Ii)
+    compare_exact(Do, Io, Di, Ii)
 
 
 @pytest.mark.parametrize("shape", ["m8", "m64"])
@@ -591,7 +598,7 @@ def test_scan_bound_parity_at_batch_size(case, shape):
                                                     del_bitmap=del_bm, range_docs=rdocs)
                     sg = g.last_stages(len(q), 32, 100)
                     assert sg["coarse_dis"].tobytes() == st["coarse_dis"].tobytes()
-                    compare_search(D, I, st, Dg, Ig, sg)
+                    compare_search_exact(D, I, st, Dg, Ig, sg)
     finally:
         case["oracle"].set_docids_bitmap(np.zeros((case["N"] >> 3) + 1, dtype=np.uint8))
         g.close()
@@ -610,7 +617,7 @@ def test_scan_bound_with_more_than_64_probes(P):
                 (D, I, st), (Dg, Ig) = run_both(case, g, q, 10, P, 100, metric, has_rank, coarse_mode=1)
                 sg = g.last_stages(len(q), P, 100)
                 assert sg["coarse_dis"].tobytes() == st["coarse_dis"].tobytes()
-                compare_search(D, I, st, Dg, Ig, sg)
+                compare_search_exact(D, I, st, Dg, Ig, sg)
     finally:
         g.close()
 
@@ -651,7 +658,7 @@ def test_coarse_ties_at_the_nprobe_boundary_follow_the_reference_heap():
             for a, b in zip(st["coarse_idx"], sg["coarse_idx"]):
                 assert set(a.tolist()) == set(b.tolist())
                 n_split += (a[-1] ^ 1) not in a.tolist() if P < 64 else 0
-            compare_search(D, I, st, Dg, Ig, sg)
+            compare_search_exact(D, I, st, Dg, Ig, sg)
         assert n_split > 100          # the boundary really did split pairs
     finally:
         B.lib().go_set_assign_mode(0)
@@ -697,7 +704,7 @@ def test_scan_bound_fallback_paths():
                     (D, I, st), (Dg, Ig) = run_both(case, g, q, 10, 32, 120, metric, has_rank, coarse_mode=1,
                                                     del_bitmap=del_bm)
                     sg = g.last_stages(len(q), 32, 120)
-                    compare_search(D, I, st, Dg, Ig, sg)
+                    compare_search_exact(D, I, st, Dg, Ig, sg)
     finally:
         g.close()
 
@@ -746,7 +753,7 @@ def test_concurrent_search_and_add_on_one_handle(case):
         D, I = o.search(q, 10, 8, recall_num=100, has_rank=True, metric=B.METRIC_L2, ctx=B.make_ctx(**WIDE),
                         coarse_mode=0)
         Dg, Ig = g.ivfpq_search(q, 10, args)
-        compare_topk(D, I, Dg, Ig)
+        compare_exact(D, I, Dg, Ig)
     finally:
         g.close()
 
@@ -875,13 +882,13 @@ def test_field_filters_on_device(case):
             for fb in _FILTER_BITMAP_MODES:   # clauses per scored code / once per document into a bitmap / by estimate
                 with _filter_bitmap(fb):
                     Dg, Ig = g.ivfpq_search(q, 10, args)
-                compare_topk(D, I, Dg, Ig)
+                compare_exact(D, I, Dg, Ig)
         Df, If = B.flat_search(case["base"], q[:8], 10, B.METRIC_L2,
                                B.make_ctx(range_filters=[B.make_range_filter(docs)], **WIDE))
         for fb in _FILTER_BITMAP_MODES:
             with _filter_bitmap(fb):
                 Dg, Ig = g.flat_search(q[:8], 10, api.SearchArgs(metric=api.METRIC_L2, field_filters=filters, **WIDE))
-            compare_topk(Df, If, Dg, Ig)
+            compare_exact(Df, If, Dg, Ig)
     with pytest.raises(api.GammaHipError):      # unknown column
         g.ivfpq_search(q, 10, api.SearchArgs(metric=api.METRIC_L2, nprobe=8, field_filters=[(99, 0, 1, True, True)],
                                              **WIDE))
@@ -896,7 +903,7 @@ def test_internal_chunking_keeps_the_whole_call_semantics(case):
         q = synth.sift_like(45, d=case["d"], seed=31337)
         g.set_dist_budget(case["nlist"] * 4 * 20)        # room for 20 rows of the coarse matrix: chunks of 20, 20, 5
         (D, I, st), (Dg, Ig) = run_both(case, g, q, 10, 8, 100, B.METRIC_L2, True, coarse_mode=-1)
-        compare_topk(D, I, Dg, Ig)
+        compare_exact(D, I, Dg, Ig)
         # same for the Add path's quantizer->assign: 45 vectors in chunks of 20, 20, 5
         xs = case["base"][100:145]
         B.lib().go_set_assign_mode(1)
@@ -1105,14 +1112,14 @@ def test_term_filters_on_device(case):
             for fb in _FILTER_BITMAP_MODES:
                 with _filter_bitmap(fb):
                     Dg, Ig = g.ivfpq_search(q, 10, args)
-                compare_topk(D, I, Dg, Ig)
+                compare_exact(D, I, Dg, Ig)
         Df, If = B.flat_search(case["base"], q[:8], 10, B.METRIC_L2,
                                B.make_ctx(range_filters=[B.make_range_filter(docs)], **WIDE))
         for fb in _FILTER_BITMAP_MODES:
             with _filter_bitmap(fb):
                 Dg, Ig = g.flat_search(q[:8], 10, api.SearchArgs(metric=api.METRIC_L2, term_filters=terms,
                                                                  field_filters=fields or None, **WIDE))
-            compare_topk(Df, If, Dg, Ig)
+            compare_exact(Df, If, Dg, Ig)
     with pytest.raises(api.GammaHipError):      # unknown column
         g.ivfpq_search(q, 10, api.SearchArgs(metric=api.METRIC_L2, nprobe=8, term_filters=[(77, 1, [1])], **WIDE))
     g.close()
@@ -1158,7 +1165,7 @@ def test_fused_coarse_matches_matrix_path_and_oracle(d, nlist, P, nq):
             assert D0.tobytes() == D1.tobytes(), cap
             assert np.array_equal(I0, I1), cap
         Do, Io = B.knn_L2sqr(x[:600], cc, P, mode=1)
-        compare_topk(Do, Io, D0[:600], I0[:600].astype(np.int64))
+        compare_exact(Do, Io, D0[:600], I0[:600].astype(np.int64))
     finally:
         g.close()
 
@@ -1215,7 +1222,7 @@ def test_small_batch_path_is_the_regular_chain(d, M, nlist, metric):
                                     assert s0[key].tobytes() == s1[key].tobytes(), (tag, key)
             if step == 0:
                 (D, I, st), (Dg, Ig) = run_both(case, g, case["q"][:3], 10, 8, 100, metric, True)
-                compare_topk(D, I, Dg, Ig)
+                compare_exact(D, I, Dg, Ig)
     finally:
         g.close()
 
@@ -1242,7 +1249,7 @@ def test_large_batch_search_with_fused_coarse_matches_oracle():
             (D, I, st), (Dg, Ig) = run_both(case, g, q, 10, 16, 100, B.METRIC_L2, has_rank, coarse_mode=1)
             sg = g.last_stages(nq, 16, 100)
             assert st["coarse_dis"].tobytes() == sg["coarse_dis"].tobytes()
-            excluded = compare_search(D, I, st, Dg, Ig, sg)
+            excluded = compare_search_exact(D, I, st, Dg, Ig, sg)
             assert excluded <= nq // 100
         g.set_coarse_fused(False)      # and the matrix path gives the same bytes
         args = api.SearchArgs(metric=api.METRIC_L2, nprobe=16, recall_num=100, has_rank=True, coarse_mode=1, **WIDE)
@@ -1283,7 +1290,7 @@ def test_multi_vector_documents(case):
             args = api.SearchArgs(metric=api.METRIC_L2, nprobe=8, recall_num=100, has_rank=has_rank, coarse_mode=0,
                                   range_filters=[api.make_range_filter(docs)], **WIDE)
             Dg, Ig = g.ivfpq_search(q, 10, args)
-            compare_topk(D, I, Dg, Ig)
+            compare_exact(D, I, Dg, Ig)
             assert not np.isin(v2d[Ig[Ig >= 0]], dead_docs).any()
         # a device column clause on the doc's value
         mask = (price[v2d] >= 200) & (price[v2d] < 700)
@@ -1291,13 +1298,13 @@ def test_multi_vector_documents(case):
         D, I = o.search(q, 10, 8, recall_num=100, has_rank=True, metric=B.METRIC_L2, ctx=ctx, coarse_mode=0)
         Dg, Ig = g.ivfpq_search(q, 10, api.SearchArgs(metric=api.METRIC_L2, nprobe=8, recall_num=100, coarse_mode=0,
                                                       field_filters=[(1, 200, 700, True, False)], **WIDE))
-        compare_topk(D, I, Dg, Ig)
+        compare_exact(D, I, Dg, Ig)
         # flat search
         ctx = B.make_ctx(docids_bitmap=bm, range_filters=[B.make_range_filter(docs)], vid2docid=v2d, **WIDE)
         Df, If = B.flat_search(case["base"], q[:8], 10, B.METRIC_L2, ctx)
         Dg, Ig = g.flat_search(q[:8], 10, api.SearchArgs(metric=api.METRIC_L2, range_filters=[api.make_range_filter(docs)],
                                                          **WIDE))
-        compare_topk(Df, If, Dg, Ig)
+        compare_exact(Df, If, Dg, Ig)
     finally:
         g.close()
 
@@ -1385,7 +1392,7 @@ def test_large_filtered_batches_run_over_compacted_lists(metric):
                 ctx = B.make_ctx(docids_bitmap=bm, **WIDE, **kw_o)
                 o = case["oracle"]   # (the shared fixture's oracle: validity comes from the context's bitmap only)
                 Do, Io = o.search(q[:200], 10, 16, recall_num=120, has_rank=has_rank, metric=metric, ctx=ctx)[:2]
-                compare_topk(Do, Io, res[1][0][:200], res[1][1][:200])
+                compare_exact(Do, Io, res[1][0][:200], res[1][1][:200])
     finally:
         g.close()
 
@@ -1443,7 +1450,7 @@ def test_shadow_lists_are_reused_until_a_writer_runs():
             D, I = o.search(q, 10, 8, recall_num=100, has_rank=True, metric=B.METRIC_L2, ctx=ctx)
             for rep in range(3):        # the first call builds the shadow lists, the others reuse them
                 Dg, Ig = g.ivfpq_search(q, 10, args)
-                compare_topk(D, I, Dg, Ig)
+                compare_exact(D, I, Dg, Ig)
             # a call with a clause of its own in between must not leave ITS shadow lists behind
             docs = rng.choice(N, N // 2, replace=False)
             a2 = api.SearchArgs(metric=api.METRIC_L2, nprobe=8, recall_num=100, has_rank=True,
@@ -1451,9 +1458,9 @@ def test_shadow_lists_are_reused_until_a_writer_runs():
             D2, I2 = o.search(q, 10, 8, recall_num=100, has_rank=True, metric=B.METRIC_L2,
                               ctx=B.make_ctx(docids_bitmap=bm, range_filters=[B.make_range_filter(docs)], **WIDE))
             Dg2, Ig2 = g.ivfpq_search(q, 10, a2)
-            compare_topk(D2, I2, Dg2, Ig2)
+            compare_exact(D2, I2, Dg2, Ig2)
             Dg, Ig = g.ivfpq_search(q, 10, args)
-            compare_topk(D, I, Dg, Ig)
+            compare_exact(D, I, Dg, Ig)
     finally:
         if old is None:
             os.environ.pop("GAMMA_HIP_LIST_COMPACT", None)

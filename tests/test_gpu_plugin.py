@@ -7,7 +7,7 @@ import pytest
 
 from oracle import binding as B
 from tests import fixtures
-from tests.parity import compare_topk
+from tests.parity import compare_exact
 from gamma_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -46,16 +46,16 @@ def test_ivfpq_plugin_matches_oracle(case):
                              ctx=B.make_ctx(), coarse_mode=-1)
             Dg, Ig = m.search(q[:n], 10, '{"metric_type": "L2", "recall_num": 100, "nprobe": 8}',
                               has_rank=has_rank)
-            compare_topk(D, I, Dg, Ig)
+            compare_exact(D, I, Dg, Ig)
     # retrieval_params "" -> model defaults (nprobe from Init, recall_num 100)
     D, I = o2.search(q, 10, 8, recall_num=100, has_rank=True, metric=B.METRIC_L2, ctx=B.make_ctx(),
                      coarse_mode=-1)
     Dg, Ig = m.search(q, 10, "")
-    compare_topk(D, I, Dg, Ig)
+    compare_exact(D, I, Dg, Ig)
     # brute_force_search -> flat scan over the raw vectors
     Df, If = B.flat_search(base, q, 10, B.METRIC_L2, B.make_ctx())
     Dg, Ig = m.search(q, 10, '{"metric_type": "L2"}', brute_force=True)
-    compare_topk(Df, If, Dg, Ig)
+    compare_exact(Df, If, Dg, Ig)
     # Delete: doc bits set + list entries flagged
     dead = np.unique(I[:, 0])
     dead = dead[dead >= 0]
@@ -68,7 +68,7 @@ def test_ivfpq_plugin_matches_oracle(case):
     D, I = o2.search(q, 10, 8, recall_num=100, has_rank=True, metric=B.METRIC_L2,
                      ctx=B.make_ctx(docids_bitmap=bm), coarse_mode=-1)
     Dg, Ig = m.search(q, 10, "")
-    compare_topk(D, I, Dg, Ig)
+    compare_exact(D, I, Dg, Ig)
     assert not np.isin(Ig, dead).any()
     # Update: re-encode + move
     vid = int(I[0, 0])
@@ -82,7 +82,7 @@ def test_ivfpq_plugin_matches_oracle(case):
     D, I = o2.search(q, 10, 8, recall_num=100, has_rank=True, metric=B.METRIC_L2,
                      ctx=B.make_ctx(docids_bitmap=bm), coarse_mode=-1)
     Dg, Ig = m.search(q, 10, "")
-    compare_topk(D, I, Dg, Ig)
+    compare_exact(D, I, Dg, Ig)
     assert m.mem_bytes() > 0
     m.close()
 
@@ -96,7 +96,7 @@ def test_ivfpq_plugin_trains_and_recalls(case, tmp_path):
     # untrained model: Search falls back to brute force (gamma_index_ivfpq.cc:529-537)
     Df, If = B.flat_search(base, q, 10, B.METRIC_L2, B.make_ctx())
     Dg, Ig = m.search(q, 10, '{"metric_type": "L2"}')
-    compare_topk(Df, If, Dg, Ig)
+    compare_exact(Df, If, Dg, Ig)
     assert m.indexing() == 0
     assert m.indexing() == 0          # second call is a no-op
     assert m.add(base)
@@ -142,7 +142,7 @@ def test_flat_plugin_matches_oracle(case, metric):
         assert m.add(base[i0:i0 + 3000])
     Df, If = B.flat_search(base, q, 10, mt, B.make_ctx())
     Dg, Ig = m.search(q, 10, "")
-    compare_topk(Df, If, Dg, Ig)
+    compare_exact(Df, If, Dg, Ig)
     dead = np.unique(If[:, :2])
     assert m.delete(dead) == 0
     bm = np.zeros((len(base) + 7) // 8, np.uint8)
@@ -150,13 +150,13 @@ def test_flat_plugin_matches_oracle(case, metric):
         bm[v >> 3] |= 1 << (v & 7)
     Df, If = B.flat_search(base, q, 10, mt, B.make_ctx(docids_bitmap=bm))
     Dg, Ig = m.search(q, 10, '{"metric_type": "%s"}' % metric)
-    compare_topk(Df, If, Dg, Ig)
+    compare_exact(Df, If, Dg, Ig)
     # score window (GammaSearchCondition::IsSimilarScoreValid)
     lo, hi = float(np.median(Df[:, 2])), float(np.median(Df[:, 8]))
     lo, hi = min(lo, hi), max(lo, hi)
     Df, If = B.flat_search(base, q, 10, mt, B.make_ctx(docids_bitmap=bm, min_score=lo, max_score=hi))
     Dg, Ig = m.search(q, 10, "", min_score=lo, max_score=hi)
-    compare_topk(Df, If, Dg, Ig)
+    compare_exact(Df, If, Dg, Ig)
     m.close()
 
 
@@ -185,10 +185,10 @@ def test_plugin_range_filters(case):
         ctx = B.make_ctx(range_filters=rfs)
         D, I = o2.search(q, 10, 8, recall_num=100, has_rank=True, metric=B.METRIC_L2, ctx=ctx, coarse_mode=-1)
         Dg, Ig = m.search(q, 10, "", range_filters=cl)
-        compare_topk(D, I, Dg, Ig)
+        compare_exact(D, I, Dg, Ig)
         Df, If = B.flat_search(base, q[:16], 10, B.METRIC_L2, ctx)
         Dg, Ig = m.search(q[:16], 10, "", brute_force=True, range_filters=cl)
-        compare_topk(Df, If, Dg, Ig)
+        compare_exact(Df, If, Dg, Ig)
     m.close()
 
 
@@ -221,7 +221,7 @@ def test_plugin_loads_an_index_dumped_by_the_reference(tmp_path):
         D, I = o.search(q, 10, 5, recall_num=50, has_rank=has_rank, metric=B.METRIC_L2, ctx=B.make_ctx(),
                         coarse_mode=-1)
         Dg, Ig = m.search(q, 10, '{"metric_type": "L2", "recall_num": 50}', has_rank=has_rank)
-        compare_topk(D, I, Dg, Ig)
+        compare_exact(D, I, Dg, Ig)
     out = tmp_path / "redump"
     os.makedirs(out)
     assert m.dump(str(out)) == 0
@@ -262,7 +262,7 @@ def test_bruteforce_search_during_add_keeps_the_mirror_exact(case):
     assert failed == 0
     Df, If = B.flat_search(base, q, 10, B.METRIC_L2, B.make_ctx())
     Dg, Ig = m.search(q, 10, '{"metric_type": "L2"}', brute_force=True)
-    compare_topk(Df, If, Dg, Ig)
+    compare_exact(Df, If, Dg, Ig)
     # the re-rank reads the same mirror
     D1, I1 = m.search(q, 10, '{"metric_type": "L2", "recall_num": 100, "nprobe": 8}')
     for i in range(0, len(q), 7):
@@ -385,11 +385,11 @@ def test_plugin_device_filters_from_the_table(case, model):
                 D, I = o2.search(q, 10, 8, recall_num=100, has_rank=True, metric=B.METRIC_L2, ctx=ctx, coarse_mode=-1)
                 B.lib().go_set_assign_mode(1)
                 Dg, Ig = m.search_scalar(q, 10, "", ranges=s["ranges"], terms=s["terms"])
-                compare_topk(D, I, Dg, Ig)
+                compare_exact(D, I, Dg, Ig)
             Df, If = B.flat_search(base[:b], q[:16], 10, B.METRIC_L2, ctx)
             Dg, Ig = m.search_scalar(q[:16], 10, '{"metric_type": "L2"}', brute_force=(model == "HIPIVFPQ"),
                                      ranges=s["ranges"], terms=s["terms"])
-            compare_topk(Df, If, Dg, Ig)
+            compare_exact(Df, If, Dg, Ig)
     B.lib().go_set_assign_mode(0)
     m.close()
 
@@ -421,10 +421,10 @@ def test_ivfflat_plugin_matches_oracle(case, tmp_path):
         for n in (len(q), 5):
             D, I = B.ivfflat_search(o, q[:n], 10, 8, B.METRIC_L2, B.make_ctx())
             Dg, Ig = m.search(q[:n], 10, '{"metric_type": "L2", "nprobe": 8}')
-            compare_topk(D, I, Dg, Ig)
+            compare_exact(D, I, Dg, Ig)
         D, I = B.ivfflat_search(o, q, 10, 8, B.METRIC_L2, B.make_ctx())
         Dg, Ig = m.search(q, 10, "")                      # nprobe from Init
-        compare_topk(D, I, Dg, Ig)
+        compare_exact(D, I, Dg, Ig)
         # Delete + Update
         dead = np.unique(I[:, 0])
         assert m.delete(dead) == 0
@@ -439,7 +439,7 @@ def test_ivfflat_plugin_matches_oracle(case, tmp_path):
         o.update_code(int(B.ivfflat_assign(o, newv[None])[0]), vid, np.zeros(case["M"], np.uint8))
         D, I = B.ivfflat_search(o, q, 10, 8, B.METRIC_L2, B.make_ctx(docids_bitmap=bm))
         Dg, Ig = m.search(q, 10, "")
-        compare_topk(D, I, Dg, Ig)
+        compare_exact(D, I, Dg, Ig)
         # Dump -> a fresh model loads the reference-format file and answers the same
         assert m.dump(str(tmp_path)) == 0
         m2 = plugin.PluginModel("HIPIVFFLAT", d, '{"ncentroids": %d, "nprobe": 8, "metric_type": "L2"}' % nlist,
@@ -513,7 +513,7 @@ def test_plugin_multi_vector_documents(case, model):
             else:
                 D, I = B.flat_search(base, q, 10, B.METRIC_L2, ctx)
             Dg, Ig = m.search(q, 10, "", **kw)
-            compare_topk(D, I, Dg, Ig)
+            compare_exact(D, I, Dg, Ig)
             assert not np.isin(v2d[Ig[Ig >= 0]], dead_docs).any()
     finally:
         B.lib().go_set_assign_mode(0)
@@ -558,7 +558,7 @@ def test_device_filter_mirror_follows_doc_updates(case):
                 ctx = B.make_ctx(range_filters=[B.make_range_filter(docs)])
                 Df, If = B.flat_search(base[:N], q[:24], 10, B.METRIC_L2, ctx)
                 Dg, Ig = m.search_scalar(q[:24], 10, '{"metric_type": "L2"}', brute_force=True, ranges=rg, terms=tm)
-                compare_topk(Df, If, Dg, Ig)
+                compare_exact(Df, If, Dg, Ig)
                 Dg, Ig = m.search_scalar(q, 10, '{"metric_type": "L2", "nprobe": 16, "recall_num": 200}', ranges=rg, terms=tm)
                 assert np.isin(Ig[Ig >= 0], docs).all()
 
@@ -599,7 +599,7 @@ def test_device_filters_with_multi_vector_documents(case):
         Df, If = B.flat_search(base[:N], q[:24], 10, B.METRIC_L2, ctx)
         Dg, Ig = m.search_scalar(q[:24], 10, '{"metric_type": "L2"}', brute_force=True,
                                  ranges=[("price", 100, 700, True, False)], terms=[("tags", ["a"], 0)])
-        compare_topk(Df, If, Dg, Ig)
+        compare_exact(Df, If, Dg, Ig)
         assert np.isin(v2d[Ig[Ig >= 0]], docs).all()
         assert m.table_oob_reads() == 0             # never asked the table for a doc it does not have
     finally:

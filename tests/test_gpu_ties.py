@@ -405,71 +405,9 @@ def test_exact_ties_across_list_shards(tag, W, reps, has_rank):
         dev = torch.device("cuda", 0)
         x = torch.from_numpy(qh).to(dev)
         args = api.SearchArgs(metric=metric, nprobe=nprobe, recall_num=R, has_rank=has_rank, coarse_mode=0, **WIDE)
-        per = (nq + W - 1) // W
-        backs = [gdist.HipShardBackend(g, 0) for g in shards]
-        cdis = torch.zeros((W * per, nprobe), dtype=torch.float32, device=dev)
-        probe = torch.full((W * per, nprobe), -1, dtype=torch.int32, device=dev)
-        for s in range(W):
-            q0, q1_, _ = gdist.query_slice(nq, s, W)
-            backs[s].coarse(x[q0:q1_], args, cdis[s * per:s * per + (q1_ - q0)], probe[s * per:s * per + (q1_ - q0)])
-            shards[s].synchronize()
-        # the assignment in query order for the shard scans
-        cd_all = torch.cat([cdis[s * per:s * per + (gdist.query_slice(nq, s, W)[1] - gdist.query_slice(nq, s, W)[0])] for s in range(W)])
-        pr_all = torch.cat([probe[s * per:s * per + (gdist.query_slice(nq, s, W)[1] - gdist.query_slice(nq, s, W)[0])] for s in range(W)])
-        rd, ri, cf_ = [], [], []
-        for s in range(W):
-            rdis = torch.zeros((nq, R), dtype=torch.float32, device=dev)
-            rids = torch.full((nq, R), -1, dtype=torch.int64, device=dev)
-            cutf = torch.zeros((nq,), dtype=torch.uint8, device=dev)
-            backs[s].search_shard(x, cd_all, pr_all, k, args, rdis, rids)
-            backs[s].shard_cut_flags(nq, cutf)
-            shards[s].synchronize()
-            rd.append(rdis)
-            ri.append(rids)
-            cf_.append(cutf)
-        D = torch.zeros((nq, k), dtype=torch.float32, device=dev)
-        I = torch.full((nq, k), -1, dtype=torch.int64, device=dev)
-        flagged = 0
-        for r in range(W):
-            q0, q1_, _ = gdist.query_slice(nq, r, W)
-            nql = q1_ - q0
-            if nql == 0:
-                continue
-            all_dis = torch.stack([rd[s][q0:q1_] for s in range(W)]).contiguous()
-            all_ids = torch.stack([ri[s][q0:q1_] for s in range(W)]).contiguous()
-            xs = x[q0:q1_].contiguous()
-            Dr = torch.zeros((nql, k), dtype=torch.float32, device=dev)
-            Ir = torch.full((nql, k), -1, dtype=torch.int64, device=dev)
-            if W != 3:   # (W == 3 runs without the shards' flags: every table that ends at the cut value counts as a tie)
-                cut_all = torch.stack([cf_[s][q0:q1_] for s in range(W)]).contiguous()
-                shards[r].ivfpq_merge_set_shard_flags(cut_all.data_ptr())
-            shards[r].ivfpq_merge_rerank(W, nql, xs.data_ptr(), k, args, all_dis.data_ptr(), all_ids.data_ptr(), 0, nql,
-                                         Dr.data_ptr(), Ir.data_ptr())
-            nf, d_list = shards[r].ivfpq_merge_flagged()
-            flagged += nf
-            if nf:
-                xf = torch.empty((nf, int(z["d"])), dtype=torch.float32, device=dev)
-                cf = torch.empty((nf, nprobe), dtype=torch.float32, device=dev)
-                pf = torch.empty((nf, nprobe), dtype=torch.int32, device=dev)
-                cds = cd_all[q0:q1_].contiguous()
-                prs = pr_all[q0:q1_].contiguous()
-                shards[r].gather_rows(xs.data_ptr(), int(z["d"]), d_list, nf, xf.data_ptr())
-                shards[r].gather_rows(cds.data_ptr(), nprobe, d_list, nf, cf.data_ptr())
-                shards[r].gather_rows(prs.data_ptr(), nprobe, d_list, nf, pf.data_ptr())
-                shards[r].synchronize()
-                stride = max(4, (max(g.ivfpq_shard_export_rows(nf, pf.data_ptr(), args) for g in shards) + 3) // 4 * 4)
-                vals = torch.empty((W, nf, stride), dtype=torch.float32, device=dev)
-                ids = torch.empty((W, nf, stride), dtype=torch.int64, device=dev)
-                off = torch.empty((W, nf, nprobe + 1), dtype=torch.int32, device=dev)
-                for s in range(W):
-                    shards[s].ivfpq_shard_export(nf, xf.data_ptr(), cf.data_ptr(), pf.data_ptr(), stride, args, vals[s].data_ptr(),
-                                                 ids[s].data_ptr(), off[s].data_ptr())
-                    shards[s].synchronize()
-                shards[r].ivfpq_merge_replay(W, nf, xs.data_ptr(), stride, vals.data_ptr(), ids.data_ptr(), off.data_ptr(), k, args,
-                                             d_list, Dr.data_ptr(), Ir.data_ptr())
-            shards[r].synchronize()
-            D[q0:q1_] = Dr
-            I[q0:q1_] = Ir
+        from tests.shard_emul import sharded_search_emulated
+        # (W == 3 runs without the shards' flags: every table that ends at the cut value counts as a tie)
+        D, I, flagged = sharded_search_emulated(shards, x, k, args, use_shard_flags=(W != 3))
         assert flagged > 0
         compare_exact(Dexp, Iexp, D.cpu().numpy(), I.cpu().numpy())
     finally:
@@ -515,3 +453,78 @@ def test_plugin_flat_and_ivfflat_exact_ties_keys():
     finally:
         for m in ms:
             m.close()
+
+
+@pytest.mark.parametrize("tag", ["l2", "ip"])
+def test_heaps_beyond_1024_entries(tag):
+    """recall_num and k above 1024 (up to the 4096 the ABI accepts; the reference has no limit, faiss:utils/Heap.h:103-131,
+    gamma_index_ivfpq.cc:762-770): the regular chain + k_tie_replay's <.., 4096, 4096> variant (sort buffer of 4096 items,
+    heaps in > 64 KB of LDS).  Tie-heavy data, labels strictly the oracle's: IVFPQ with and without rank, IVFFLAT, flat."""
+    z, o, base, metric = load_ties(tag)
+    q = z["q"][:12]
+    g = _device_for(z, tag, base, metric)
+    try:
+        ctx = B.make_ctx(**WIDE)
+        for nprobe, R, k, has_rank in ((16, 1500, 1100, True), (16, 2000, 10, True), (12, 1030, 1030, False),
+                                       (16, 4096, 4096, True), (12, 3000, 200, False)):
+            D, I = o.search(q, k, nprobe, recall_num=R, has_rank=has_rank, metric=metric, ctx=ctx, coarse_mode=0)
+            args = api.SearchArgs(metric=metric, nprobe=nprobe, recall_num=R, has_rank=has_rank, coarse_mode=0, **WIDE)
+            g.tie_stats(reset=True)
+            Dg, Ig = g.ivfpq_search(q, k, args)
+            compare_exact(D, I, Dg, Ig)
+            assert g.tie_stats()["replayed"] > 0
+        assert g.ties_not_honoured() == 0
+    finally:
+        g.close()
+    gf = _ivfflat_for(z, tag, base, metric)
+    try:
+        for P, k in ((3, 2000), (16, 1100), (16, 4096)):
+            D, I = B.ivfflat_search(o, q, k, P, metric, B.make_ctx(**WIDE), coarse_mode=0)
+            Dg, Ig = gf.ivfflat_search(q, k, api.SearchArgs(metric=metric, nprobe=P, coarse_mode=0, **WIDE))
+            compare_exact(D, I, Dg, Ig)
+        assert gf.ties_not_honoured() == 0
+    finally:
+        gf.close()
+    g2 = api.GammaHip(0)
+    try:
+        g2.raw_init(int(z["d"]))
+        g2.raw_append(base)
+        for k in (1100, 2500, 4095):
+            D, I = B.flat_search(base, q[:5], k, metric, B.make_ctx(**WIDE))
+            Dg, Ig = g2.flat_search(q[:5], k, api.SearchArgs(metric=metric, **WIDE))
+            compare_exact(D, I, Dg, Ig)
+        assert g2.ties_not_honoured() == 0
+    finally:
+        g2.close()
+
+
+def test_a_shape_beyond_the_replay_is_never_silent():
+    """nprobe > 256 (and a flat search for k = 4096) are outside the exact-ties mode.  A request that asks for the mode
+    explicitly fails with GAMMA_HIP_EUNSUPPORTED; one that inherits the handle's default runs with the (distance, position)
+    order inside ties -- still the reference's distances at every rank -- and is counted (gamma_hip_ties_not_honoured)."""
+    from tests.parity import compare_topk
+    case = fixtures.trained_case(d=32, nlist=320, M=8, N=20000, nq=64, metric=B.METRIC_L2)
+    g = fixtures.load_hip(case)
+    try:
+        q = case["q"][:9]
+        P, R, k = 300, 100, 10
+        ctx = B.make_ctx(**WIDE)
+        D, I = case["oracle"].search(q, k, P, recall_num=R, has_rank=True, metric=B.METRIC_L2, ctx=ctx, coarse_mode=0)
+        assert g.ties_not_honoured() == 0
+        Dg, Ig = g.ivfpq_search(q, k, api.SearchArgs(metric=api.METRIC_L2, nprobe=P, recall_num=R, coarse_mode=0, **WIDE))
+        compare_topk(D, I, Dg, Ig)                 # ties off on purpose: the tie-tolerant comparison
+        assert g.ties_not_honoured() == 1
+        with pytest.raises(RuntimeError, match="ties"):
+            g.ivfpq_search(q, k, api.SearchArgs(metric=api.METRIC_L2, nprobe=P, recall_num=R, coarse_mode=0, exact_ties=1, **WIDE))
+        g.ivfpq_search(q, k, api.SearchArgs(metric=api.METRIC_L2, nprobe=P, recall_num=R, coarse_mode=0, exact_ties=-1, **WIDE))
+        assert g.ties_not_honoured() == 1          # asked to be off: nothing to report
+        g.ivfpq_search(q, k, api.SearchArgs(metric=api.METRIC_L2, nprobe=256, recall_num=R, coarse_mode=0, exact_ties=1, **WIDE))
+        assert g.ties_not_honoured(reset=True) == 1 and g.ties_not_honoured() == 0
+        Df, If = B.flat_search(case["base"], q[:2], 4096, B.METRIC_L2, ctx)
+        Dg, Ig = g.flat_search(q[:2], 4096, api.SearchArgs(metric=api.METRIC_L2, **WIDE))
+        compare_topk(Df, If, Dg, Ig)
+        assert g.ties_not_honoured() == 1
+        with pytest.raises(RuntimeError, match="ties"):
+            g.flat_search(q[:2], 4096, api.SearchArgs(metric=api.METRIC_L2, exact_ties=1, **WIDE))
+    finally:
+        g.close()
