@@ -102,6 +102,13 @@ void launch_flat_compact(hipStream_t s, int nq, int k, const FlatEmit& em, uint3
 void launch_flat_final(hipStream_t s, bool l2, int nq, int k, const FlatEmit& em, float neutral, float* distances,
                        int64_t* labels);
 void launch_row_norms(hipStream_t s, const float* y, int64_t n, int d, float* out);
+// How the compiled reference's sgemm_ (MKL, the BLAS faiss links in the reference's build) sums the K dimension of
+// exhaustive_L2sqr_blas's x . y^T (faiss:utils/distances.cpp:215-296), measured against the compiled library
+// (oracle/gamma_oracle.c go_gemm_k_split, tests/test_oracle_vs_ref.py): K <= 384 -- one k-ascending fma chain per
+// element, which is what v_mfma_f32_32x32x2_f32 computes; 384 < K <= 768 with K % 8 == 0 -- two chains, [0, K/2) and
+// [K/2, K), each from zero, added once; beyond that MKL's blocking is not restated (one chain).  Returns the split
+// point, 0 = none.  With it the GEMM-form coarse distances are the library's, bit for bit.
+inline int gemm_k_split(int d) { return (d > 384 && d <= 768 && d % 8 == 0) ? d / 2 : 0; }
 void launch_l2_gemmform(hipStream_t s, const float* x, int nq, int d, const float* y, int64_t ny,
                         const float* xn, const float* yn, float* out, int64_t ld_out,
                         bool use_mfma);

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void k_l2_gemmform_valu(const float* __restric
                                                           const float* __restrict__ xn,
                                                           const float* __restrict__ yn,
                                                           float* __restrict__ out, int64_t ld_out,
-                                                          int q_per_block) {
+                                                          int q_per_block, int ksplit) {
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (row >= ny) return;
     const int q0 = blockIdx.y * q_per_block;
@@ -439,7 +439,12 @@ __global__ __launch_bounds__(256) void k_l2_gemmform_valu(const float* __restric
     for (int q = q0; q < q1; q++) {
         const float* xq = x + (int64_t)q * d;
         float ip = 0.f;
-        for (int t = 0; t < d; t++) ip = __builtin_fmaf(xq[t], yr[t], ip);
+        for (int t = 0; t < (ksplit ? ksplit : d); t++) ip = __builtin_fmaf(xq[t], yr[t], ip);
+        if (ksplit) {   // the compiled sgemm_'s second K block (gemm_k_split): its own chain, added once
+            float ip2 = 0.f;
+            for (int t = ksplit; t < d; t++) ip2 = __builtin_fmaf(xq[t], yr[t], ip2);
+            ip = ip + ip2;
+        }
         float dis = (xn[q] + ynr) - 2.f * ip;
         if (dis < 0.f) dis = 0.f;
         out[(int64_t)q * ld_out + row] = dis;
@@ -454,12 +459,14 @@ __global__ __launch_bounds__(256) void k_l2_gemmform_valu(const float* __restric
 // row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// ksplit > 0 (gemm_k_split: 384 < d <= 768): the K dimension in the two blocks the compiled reference's sgemm_ sums it
+// in -- [0, ksplit) and [ksplit, d), each chain from zero, added once.
 template <int KS>
 __global__ __launch_bounds__(256) void k_l2_gemmform_mfma(const float* __restrict__ x, int nq, int d,
                                                           const float* __restrict__ y, int ny,
                                                           const float* __restrict__ xn,
                                                           const float* __restrict__ yn,
-                                                          float* __restrict__ out, int64_t ld_out) {
+                                                          float* __restrict__ out, int64_t ld_out, int ksplit) {
     // Whole-K slabs of 128 in LDS (2 x 64 x 129 floats = 66 KB, 2 blocks / CU): all global
     // loads of a slab are issued back to back (float4, 16 per thread and operand), then each
     // wave runs 64 dependent MFMAs uninterrupted.  Row stride 129 dwords: the fragment reads
@@ -488,8 +495,8 @@ __global__ __launch_bounds__(256) void k_l2_gemmform_mfma(const float* __restric
     auto slot_r = [&](int it) { return (((w * NIT + it) / SEG) << 3) + (lane >> 3); };
     auto slot_c = [&](int it) { return (((w * NIT + it) % SEG) << 5) + ((lane & 7) << 2); };
     float4 va[NIT], vb[NIT];
-    auto gload = [&](int k0) {
-        const int kw = min(KS, d - k0);
+    auto gload = [&](int k0, int ke) {
+        const int kw = min(KS, ke - k0);
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
             const int r = slot_r(it), c4 = slot_c(it);
@@ -499,9 +506,13 @@ __global__ __launch_bounds__(256) void k_l2_gemmform_mfma(const float* __restric
             vb[it] = *reinterpret_cast<const float4*>(y + (int64_t)cc * d + k0 + c4c);
         }
     };
-    if (vec4) gload(0);
-    for (int k0 = 0; k0 < d; k0 += KS) {
-        const int kw = min(KS, d - k0);
+    f32x16 tot;
+    const int nseg = ksplit > 0 ? 2 : 1;
+    if (vec4) gload(0, ksplit > 0 ? ksplit : d);
+    for (int seg = 0; seg < nseg; seg++) {
+    const int kb = seg ? ksplit : 0, ke = (seg == 0 && ksplit > 0) ? ksplit : d;
+    for (int k0 = kb; k0 < ke; k0 += KS) {
+        const int kw = min(KS, ke - k0);
         if (vec4) {
 #pragma unroll
             for (int it = 0; it < NIT; it++) {
@@ -524,7 +535,10 @@ __global__ __launch_bounds__(256) void k_l2_gemmform_mfma(const float* __restric
             }
         }
         __syncthreads();
-        if (vec4 && k0 + KS < d) gload(k0 + KS);   // uniform
+        if (vec4) {   // uniform: the next slab of this K block, or the first of the second block
+            if (k0 + KS < ke) gload(k0 + KS, ke);
+            else if (seg + 1 < nseg) gload(ksplit, d);
+        }
         if (!xn) {
             const float* row = sA + (tid >> 2) * LD;
             const int l4 = tid & 3;
@@ -555,6 +569,16 @@ __global__ __launch_bounds__(256) void k_l2_gemmform_mfma(const float* __restric
         }
         __syncthreads();
     }
+    if (seg + 1 < nseg) {   // C = P1; the second block accumulates from zero
+        tot = acc;
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[i] = 0.f;
+    }
+    }
+    if (nseg == 2) {        // C += P2
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[i] = tot[i] + acc[i];
+    }
     if (!xn) {
         // (a0 + a1) + (a2 + a3) inside each 4-lane group
         const float t01 = nacc + __shfl_down(nacc, 1, 4);
@@ -582,11 +606,14 @@ __global__ __launch_bounds__(256) void k_l2_gemmform_mfma(const float* __restric
 // fragments read as with the 64 x 64 tile above, and four workgroups fit a CU (34 KB of LDS), so one's staging
 // overlaps the others' MFMAs.  Every accumulator still receives its k in ascending order: the same chain.
 // Query norms come from their own pass (xn != nullptr), d % 4 == 0.
+// SPLIT (gemm_k_split: 384 < d <= 768): K in the two blocks of the compiled sgemm_, [0, ksplit) and [ksplit, d) -- the
+// first block's sums wait in a second accumulator set while the second block runs, then the two are added once.
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void k_l2_gemmform_big(const float* __restrict__ x, int nq, int d,
                                                          const float* __restrict__ y, int ny,
                                                          const float* __restrict__ xn,
                                                          const float* __restrict__ yn,
-                                                         float* __restrict__ out, int64_t ld_out) {
+                                                         float* __restrict__ out, int64_t ld_out, int ksplit) {
     constexpr int KS = 32, LD = KS + 1, NIT = 4;   // 128 rows x 8 float4 per operand = 4 per thread
     __shared__ float sA[128 * LD];
     __shared__ float sB[128 * LD];
@@ -604,8 +631,8 @@ __global__ __launch_bounds__(256) void k_l2_gemmform_big(const float* __restrict
     auto slot_r = [&](int it) { return ((w * NIT + it) << 3) + (lane >> 3); };
     const int c4 = (lane & 7) << 2;
     float4 va[NIT], vb[NIT];
-    auto gload = [&](int k0) {
-        const int c4c = min(c4, d - k0 - 4);   // clamped address; out-of-range lanes are zeroed when written to LDS
+    auto gload = [&](int k0, int ke) {
+        const int c4c = min(c4, ke - k0 - 4);   // clamped address; out-of-range lanes are zeroed when written to LDS
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
             const int r = slot_r(it);
@@ -613,11 +640,16 @@ __global__ __launch_bounds__(256) void k_l2_gemmform_big(const float* __restrict
             vb[it] = *reinterpret_cast<const float4*>(y + (int64_t)min(c_base + r, ny - 1) * d + k0 + c4c);
         }
     };
-    gload(0);
+    f32x16 tot[2][2];
+    constexpr int NSEG = SPLIT ? 2 : 1;
+    gload(0, SPLIT ? ksplit : d);
     const float* fa = sA + (wq * 64 + (lane & 31)) * LD + (lane >> 5);
     const float* fb = sB + (wc * 64 + (lane & 31)) * LD + (lane >> 5);
-    for (int k0 = 0; k0 < d; k0 += KS) {
-        const int kw = min(KS, d - k0);
+#pragma unroll
+    for (int seg = 0; seg < NSEG; seg++) {
+    const int kb = seg ? ksplit : 0, ke = (SPLIT && seg == 0) ? ksplit : d;
+    for (int k0 = kb; k0 < ke; k0 += KS) {
+        const int kw = min(KS, ke - k0);
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
             const int r = slot_r(it);
@@ -630,7 +662,9 @@ __global__ __launch_bounds__(256) void k_l2_gemmform_big(const float* __restrict
             pb[2] = okb ? vb[it].z : 0.f; pb[3] = okb ? vb[it].w : 0.f;
         }
         __syncthreads();
-        if (k0 + KS < d) gload(k0 + KS);   // uniform; lands while the 64 MFMAs below run
+        // uniform; lands while the 64 MFMAs below run (the next slab of this K block, or the first of the second block)
+        if (k0 + KS < ke) gload(k0 + KS, ke);
+        else if (SPLIT && seg == 0) gload(ksplit, d);
 #pragma unroll
         for (int ch = 0; ch < 2; ch++) {   // 8 k pairs per chunk: fragment reads first, then 32 MFMAs
             float a0[8], a1[8], b0[8], b1[8];
@@ -650,6 +684,25 @@ __global__ __launch_bounds__(256) void k_l2_gemmform_big(const float* __restrict
             }
         }
         __syncthreads();
+    }
+    if (SPLIT && seg == 0) {   // C = P1; the second block accumulates from zero
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                tot[i][j] = acc[i][j];
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+            }
+    }
+    }
+    if (SPLIT) {               // C += P2
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = tot[i][j][r] + acc[i][j][r];
     }
     // epilogue: dis = (xn + yn) - 2*ip, clamp
 #pragma unroll
@@ -817,6 +870,7 @@ void launch_l2_gemmform(hipStream_t s, const float* x, int nq, int d, const floa
                         const float* xn, const float* yn, float* out, int64_t ld_out,
                         bool use_mfma) {
     if (nq <= 0 || ny <= 0) return;
+    const int ksplit = gemm_k_split(d);   // the K blocks of the compiled reference's sgemm_ (kernels.h)
     // the 32x32x2 MFMA consumes k in pairs with a zero pad for odd d: fma(0,0,acc) == acc
     // exactly, so any d is bit-safe
     if (use_mfma) {
@@ -846,26 +900,27 @@ void launch_l2_gemmform(hipStream_t s, const float* x, int nq, int d, const floa
         // xn == nullptr: query norms are computed inside the kernel from the staged tile
         static const bool no_big = getenv("GAMMA_HIP_NO_GEMM_BIG") != nullptr;
         if (xn && d > 128 && (d & 3) == 0 && nq >= 256 && !no_big) {
-            hipLaunchKernelGGL(k_l2_gemmform_big, dim3((unsigned)((ny + 127) / 128), (unsigned)((nq + 127) / 128)), dim3(256), 0, s,
-                               x, nq, d, y, (int)ny, xn, yn, out, ld_out);
+            const dim3 gb((unsigned)((ny + 127) / 128), (unsigned)((nq + 127) / 128));
+            if (ksplit) hipLaunchKernelGGL(k_l2_gemmform_big<true>, gb, dim3(256), 0, s, x, nq, d, y, (int)ny, xn, yn, out, ld_out, ksplit);
+            else hipLaunchKernelGGL(k_l2_gemmform_big<false>, gb, dim3(256), 0, s, x, nq, d, y, (int)ny, xn, yn, out, ld_out, 0);
             return;
         }
         static const int ks_env = getenv("GAMMA_HIP_GEMM_KS") ? atoi(getenv("GAMMA_HIP_GEMM_KS")) : 128;
         if (ks_env == 64)
             hipLaunchKernelGGL(k_l2_gemmform_mfma<64>, grid, dim3(256), 2 * 64 * 65 * sizeof(float), s, x, nq, d, y, (int)ny, xn, yn,
-                               out, ld_out);
+                               out, ld_out, ksplit);
         else if (ks_env == 32)
             hipLaunchKernelGGL(k_l2_gemmform_mfma<32>, grid, dim3(256), 2 * 64 * 33 * sizeof(float), s, x, nq, d, y, (int)ny, xn, yn,
-                               out, ld_out);
+                               out, ld_out, ksplit);
         else
             hipLaunchKernelGGL(k_l2_gemmform_mfma<128>, grid, dim3(256), lds, s, x, nq, d, y, (int)ny, xn, yn,
-                               out, ld_out);
+                               out, ld_out, ksplit);
     } else {
         const int64_t row_blocks = (ny + 255) / 256;
         int q_per_block = 8;
         dim3 grid((unsigned)row_blocks, (unsigned)((nq + q_per_block - 1) / q_per_block));
         hipLaunchKernelGGL(k_l2_gemmform_valu, grid, dim3(256), 0, s, x, nq, d, y, ny, xn, yn, out,
-                           ld_out, q_per_block);
+                           ld_out, q_per_block, ksplit);
     }
 }
 

@@ -306,7 +306,9 @@ class OracleIVFPQ:
         return self.L.go_ivfpq_vid_pos(self.h, vid)
 
     def search(self, x, k, nprobe, recall_num=100, has_rank=True, metric=None, ctx=None,
-               coarse_mode=-1, want_stages=False):
+               coarse_mode=-1, want_stages=False, preassigned=None):
+        """preassigned = (coarse_dis [nq, nprobe] float32, coarse_idx [nq, nprobe] int64): search_preassigned with an
+        assignment computed elsewhere (coarse_mode is ignored)"""
         x = _f32(x)
         nq = x.shape[0]
         metric = self.metric if metric is None else metric
@@ -314,11 +316,15 @@ class OracleIVFPQ:
         D = np.empty((nq, k), dtype=np.float32)
         I = np.empty((nq, k), dtype=np.int64)
         cd = ci = rd = ri = None
-        if want_stages:
+        if want_stages or preassigned is not None:
             cd = np.empty((nq, nprobe), dtype=np.float32)
             ci = np.empty((nq, nprobe), dtype=np.int64)
             rd = np.empty((nq, R), dtype=np.float32)
             ri = np.empty((nq, R), dtype=np.int64)
+        if preassigned is not None:
+            cd[:] = np.asarray(preassigned[0], dtype=np.float32).reshape(nq, nprobe)
+            ci[:] = np.asarray(preassigned[1], dtype=np.int64).reshape(nq, nprobe)
+            coarse_mode = 2
         rc = self.L.go_ivfpq_search(self.h, C.byref(ctx) if ctx is not None else None, metric,
                                     nprobe, recall_num, 1 if has_rank else 0, coarse_mode, nq,
                                     _fp(x), k, _fp(D), _ip(I), _fp(cd), _ip(ci), _fp(rd), _ip(ri))

@@ -306,6 +306,18 @@ void go_heap_pop_push_stream(int ks, size_t k, size_t n, const float* vals, cons
  * mode 0 = exhaustive_L2sqr_seq (:130-155); mode 1 = exhaustive_L2sqr_blas (:215-296)
  * with sgemm_ restated as a k-sequential single-accumulator fmaf chain.
  * =================================================================================== */
+/* How the compiled reference's sgemm_ (MKL, /opt/conda/lib/libmkl_rt.so: the BLAS oracle/Makefile.ref links, as the
+ * survey's build does) sums the K dimension of exhaustive_L2sqr_blas's ip_block = x . y^T, measured in this container
+ * (tests/test_oracle_vs_ref.py::test_gemm_form_is_the_compiled_sgemm pins it):
+ *   K <= 384:                   ONE k-ascending fma chain per output element;
+ *   384 < K <= 768, K % 8 == 0: TWO chains, [0, K/2) and [K/2, K), each from zero, added once (C = P1; C += P2);
+ *   otherwise (K > 768, or an odd split): MKL's blocking is not restated -- one chain, 1-ulp-level differences.
+ * Shape-dependent corners that are NOT restated either: K = 384 exactly with a database block (ny mod 1024) of 9..512
+ * rows is already split in two; remainder blocks of a few rows (nx mod 4096 or ny mod 1024 below 8) take a
+ * different kernel.
+ * Returns the split point, 0 = none.  The device's GEMM-form kernels use the same rule (kernels.hip gemm_k_split). */
+size_t go_gemm_k_split(size_t d) { return (d > 384 && d <= 768 && d % 8 == 0) ? d / 2 : 0; }
+
 __attribute__((unused)) static float dot_seq(const float* x, const float* y, size_t d) {
     float ip = 0.f;
     for (size_t t = 0; t < d; t++) ip = fmaf(x[t], y[t], ip);
@@ -349,8 +361,15 @@ void go_knn_L2sqr(int mode, const float* x, const float* y, size_t d, size_t nx,
             for (size_t b = 0; b < nb; b++) {
                 const float* yb = yT + b * d * 8;
                 __m256 acc = _mm256_setzero_ps();
-                for (size_t t = 0; t < d; t++)
+                const size_t ksp = go_gemm_k_split(d);
+                for (size_t t = 0; t < (ksp ? ksp : d); t++)
                     acc = _mm256_fmadd_ps(_mm256_broadcast_ss(xi + t), _mm256_load_ps(yb + t * 8), acc);
+                if (ksp) { /* second K block: its own chain from zero, added to the first (sgemm_'s C += A2 B2) */
+                    __m256 acc2 = _mm256_setzero_ps();
+                    for (size_t t = ksp; t < d; t++)
+                        acc2 = _mm256_fmadd_ps(_mm256_broadcast_ss(xi + t), _mm256_load_ps(yb + t * 8), acc2);
+                    acc = _mm256_add_ps(acc, acc2);
+                }
                 float ip[8];
                 _mm256_storeu_ps(ip, acc);
                 for (int l = 0; l < 8 && b * 8 + l < ny; l++) {
@@ -838,9 +857,17 @@ int go_ivfpq_search(go_ivfpq* ix, const go_search_ctx* ctx, int metric, int npro
     float* coarse_dis = (float*)malloc(sizeof(float) * (size_t)nq * nprobe);
     int64_t* idx = (int64_t*)malloc(sizeof(int64_t) * (size_t)nq * nprobe);
     int mode = coarse_mode < 0 ? (nq < 20 ? 0 : 1) : coarse_mode; /* distances.cpp:303,346 */
-    go_knn_L2sqr(mode, x, ix->cc, d, nq, ix->nlist, nprobe, coarse_dis, idx);
-    if (coarse_dis_out) memcpy(coarse_dis_out, coarse_dis, sizeof(float) * (size_t)nq * nprobe);
-    if (coarse_idx_out) memcpy(coarse_idx_out, idx, sizeof(int64_t) * (size_t)nq * nprobe);
+    if (mode == 2) {
+        /* search_preassigned with an assignment computed elsewhere (:563,701): coarse_dis_out / coarse_idx_out are INPUTS
+         * -- e.g. the compiled library's own quantizer->search with its BLAS path (tests/gen_golden.py, blas leg) */
+        if (!coarse_dis_out || !coarse_idx_out) return -1;
+        memcpy(coarse_dis, coarse_dis_out, sizeof(float) * (size_t)nq * nprobe);
+        memcpy(idx, coarse_idx_out, sizeof(int64_t) * (size_t)nq * nprobe);
+    } else {
+        go_knn_L2sqr(mode, x, ix->cc, d, nq, ix->nlist, nprobe, coarse_dis, idx);
+        if (coarse_dis_out) memcpy(coarse_dis_out, coarse_dis, sizeof(float) * (size_t)nq * nprobe);
+        if (coarse_idx_out) memcpy(coarse_idx_out, idx, sizeof(int64_t) * (size_t)nq * nprobe);
+    }
 
 #pragma omp parallel
     {

@@ -200,6 +200,77 @@ def gen_ivfpq_ties(R, name, d, nlist, M, N0, N, nq, nprobe, Rk, k):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
 
 
+def gen_blas_coarse(R, name="ivfpq_blas_c3shape", N=200000, d=128, nlist=1024, M=16, nq=2048, nprobe=32, Rk=200, k=10):
+    """What "the faiss-CPU path" returns for a BATCH at the C3 shape, with the library's DEFAULT
+    distance_compute_blas_threshold (20): the coarse quantizer then runs exhaustive_L2sqr_blas -- norms + MKL sgemm_
+    (faiss:utils/distances.cpp:215-296,303-305) -- whose summation order no restatement can reproduce bit for bit.
+    The fixture pins how far the device's default path (the k-ascending fma chain of the fp32 MFMA, = the oracle's
+    mode 1) is from it: the library's coarse assignment (idx + distances), the final labels / distances of Gamma's
+    search on that assignment (search_preassigned + compute_dis with has_rank: the pinned oracle run on the LIBRARY's
+    assignment, cross-checked against the library's own search_preassigned table), and for comparison the same with the
+    BLAS switch disabled (bit-exact territory).  Trained by the real library; base and queries come from the portable
+    generator and are not stored; the lists are rebuilt by the Add path under test and checked against the stored
+    sizes and checksums."""
+    base = synth.sift_like(N, d=d, seed=1234)
+    q = synth.sift_like(nq, d=d, seed=4321)
+    r = B.RefIVFPQ(d, nlist, M, 8, B.METRIC_L2)
+    R.ref_set_blas_threshold(20)                 # the library default: training, Add and search as a deployment runs them
+    r.train(base[:nlist * 64])
+    r.add(base)
+    assert r.use_precomputed_table() == 1
+    cc, pq = r.coarse_centroids(), r.pq_centroids()
+    sizes = np.zeros(nlist, np.int64)
+    idsum = np.zeros(nlist, np.int64)
+    codesum = np.zeros(nlist, np.int64)
+    o = B.OracleIVFPQ(d, nlist, M, 8, B.METRIC_L2)
+    o.set_trained(cc, pq, None)
+    for l in range(nlist):
+        i, c = r.get_list(l)
+        sizes[l] = len(i)
+        idsum[l] = int(i.sum())
+        codesum[l] = int((c.astype(np.int64) * (1 + np.arange(M))).sum())
+        if len(i):
+            assert o.add_keys(l, i, c)
+    o.set_raw(base)
+    ctx = B.make_ctx(min_score=-3e38, max_score=3e38)
+    out = dict(N=N, d=d, nlist=nlist, M=M, nq=nq, nprobe=nprobe, R=Rk, k=k, cc=cc, pq=pq, list_sizes=sizes.astype(np.int32),
+               list_idsum=idsum, list_codesum=codesum, base_sum=np.array([base.astype(np.float64).sum()]),
+               q_sum=np.array([q.astype(np.float64).sum()]))
+    for tag, thr in (("blas", 20), ("exact", 1 << 30)):
+        R.ref_set_blas_threshold(thr)
+        cd, ci = r.coarse(q, nprobe)
+        D, I, st = o.search(q, k, nprobe, recall_num=Rk, has_rank=True, metric=B.METRIC_L2, ctx=ctx, want_stages=True,
+                            preassigned=(cd, ci))
+        # the library's own scan on the same assignment: its sorted top-R table holds the same (distance, id) pairs
+        Dp, Ip = r.search_preassigned(q, Rk, ci, cd)
+        from tests.parity import _stage_rows
+        a_d, a_i = _stage_rows(Dp, Ip)
+        b_d, b_i = _stage_rows(st["recall_dis"], st["recall_ids"])
+        same = (a_d == b_d).all(axis=1) & (a_i == b_i).all(axis=1)
+        print(name, tag, "recall-stage tables equal to the library's search_preassigned:", int(same.sum()), "of", nq,
+              "(the rest: ties at the recall_num cut, where faiss's own scanner and Gamma's differ)")
+        assert (a_d == b_d).all()
+        out["coarse_dis_" + tag] = cd
+        out["coarse_idx_" + tag] = ci.astype(np.int16)
+        out["D_" + tag] = D
+        out["I_" + tag] = I.astype(np.int32)
+    R.ref_set_blas_threshold(1 << 30)
+    # how far the canonical GEMM form (oracle mode 1 = the device's default path for >= 20 queries) is from the library
+    Dg, Ig, sg = o.search(q, k, nprobe, recall_num=Rk, has_rank=True, metric=B.METRIC_L2, ctx=ctx, coarse_mode=1,
+                          want_stages=True)
+    cib = out["coarse_idx_blas"].astype(np.int64)
+    set_diff = np.array([set(a.tolist()) != set(b.tolist()) for a, b in zip(cib, sg["coarse_idx"])])
+    order_diff = (cib != sg["coarse_idx"]).any(axis=1)
+    lab_diff = (out["I_blas"].astype(np.int64) != Ig).any(axis=1)
+    dis_bits = (out["coarse_dis_blas"].view(np.uint32) != sg["coarse_dis"].view(np.uint32)).any(axis=1)
+    print(name, "canonical GEMM form vs MKL: probe sets differ in", int(set_diff.sum()), "rows, probe order in",
+          int(order_diff.sum()), ", coarse distance bits in", int(dis_bits.sum()), ", final labels in", int(lab_diff.sum()),
+          "of", nq, "; label mismatches outside rows whose probe set differs:", int((lab_diff & ~set_diff).sum()))
+    out["n_label_diff_canonical"] = np.array([int(lab_diff.sum())])
+    out["n_set_diff_canonical"] = np.array([int(set_diff.sum())])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+
+
 def gen_realtime():
     """Drive the reference's real RTInvertIndex through a scripted sequence of AddKeys /
     Update / Delete / CompactIfNeed and record the observable state after each phase."""
@@ -318,6 +389,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "iwpq":     # add one fixture, leave the others alone
         gen_iwpq(B.ref())
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "blas":      # the library's default BLAS coarse path at the C3 shape
+        gen_blas_coarse(B.ref())
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "ties":
         R = B.ref()
         R.ref_set_blas_threshold(1 << 30)
@@ -341,6 +415,7 @@ def main():
     gen_ivfpq_ties(R, "ivfpq_ties_d32", 32, 16, 8, 1500, 6000, 48, 6, 60, 10)
     gen_ivfpq_ties(R, "ivfpq_ties_c4shape", 32, 4160, 8, 12000, 24000, 32, 64, 100, 10)
     gen_realtime()
+    gen_blas_coarse(R)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

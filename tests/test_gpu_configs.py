@@ -191,3 +191,73 @@ def test_c1_flat_l2_10k_128_k10_through_the_plugin_boundary():
         compare_exact(Df[i:i + 1] * 0 + B.flat_search(base, q[i:i + 1], k, B.METRIC_L2, B.make_ctx())[0],
                      B.flat_search(base, q[i:i + 1], k, B.METRIC_L2, B.make_ctx())[1], D1, I1)
     m.close()
+
+
+def test_default_path_is_the_librarys_default_blas_path_at_the_c3_shape():
+    """tests/golden/ivfpq_blas_c3shape.npz: a C3-shaped index (200 k x 128, 1024 lists, M 16) trained, filled and searched
+    by the COMPILED library at its default distance_compute_blas_threshold -- coarse quantizer through MKL sgemm_
+    (faiss:utils/distances.cpp:215-296,303-305).  The device's DEFAULT path (coarse_mode -1, exact ties on, Add through the
+    device encode with faiss's assign rule) must return exactly that for a 2048-query batch: lists, coarse distances bit
+    for bit, probe order, final labels at every rank, distances bit for bit.  Mismatch bound: zero queries."""
+    from tests.test_oracle_golden import check_blas_c3shape_lists, load_blas_c3shape
+    z, base, q = load_blas_c3shape()
+    d, nlist, M = int(z["d"]), int(z["nlist"]), int(z["M"])
+    nprobe, R, k = int(z["nprobe"]), int(z["R"]), int(z["k"])
+    g = api.GammaHip(0)
+    try:
+        g.ivfpq_init(d, nlist, M, 8, api.METRIC_L2, 1000)
+        g.ivfpq_set_trained(z["cc"], z["pq"], None)
+        g.raw_init(d)
+        for i0 in range(0, len(base), 50000):
+            g.raw_append(base[i0:i0 + 50000])
+            g.add(base[i0:i0 + 50000], i0)
+        check_blas_c3shape_lists(z, g.get_list)
+        args = api.SearchArgs(metric=api.METRIC_L2, nprobe=nprobe, recall_num=R, has_rank=True, coarse_mode=-1, **WIDE)
+        for nq in (len(q), 700, 40):           # matrix-free coarse path from 4096 queries on is covered by the bench leg
+            D, I = g.ivfpq_search(q[:nq], k, args)
+            sg = g.last_stages(nq, nprobe, R)
+            assert sg["coarse_dis"].tobytes() == z["coarse_dis_blas"][:nq].tobytes()
+            assert np.array_equal(sg["coarse_idx"], z["coarse_idx_blas"][:nq].astype(np.int64))
+            compare_exact(z["D_blas"][:nq], z["I_blas"][:nq].astype(np.int64), D, I)
+        # below 20 queries the library itself takes the exact form
+        D, I = g.ivfpq_search(q[:19], k, args)
+        compare_exact(z["D_exact"][:19], z["I_exact"][:19].astype(np.int64), D, I)
+        # a large batch (the matrix-free coarse kernels, the bounded scan): the fixture's queries tiled
+        reps = 3
+        D, I = g.ivfpq_search(np.tile(q, (reps, 1)), k, args)
+        compare_exact(np.tile(z["D_blas"], (reps, 1)), np.tile(z["I_blas"].astype(np.int64), (reps, 1)), D, I)
+        assert g.ties_not_honoured() == 0
+    finally:
+        g.close()
+
+
+@pytest.mark.parametrize("d,nlist", [(768, 256), (512, 200), (448, 130), (392, 64)])
+def test_gemm_form_k_split_matches_the_oracle(d, nlist):
+    """384 < d <= 768: the compiled sgemm_ sums K in two blocks (kernels.h gemm_k_split, oracle go_gemm_k_split, pinned
+    against the library in tests/test_oracle_vs_ref.py).  The three device kernels that compute the GEMM form for long
+    rows -- k_l2_gemmform_big<true> (batches from 256 queries) and k_l2_gemmform_mfma (smaller ones; d = 392 splits inside a
+    K slab) -- against the oracle's mode 1, bit for bit, through the coarse entry point."""
+    import torch
+    rng = np.random.default_rng(d)
+    cc = (rng.standard_normal((nlist, d)) * 2).astype(np.float32)
+    M = min(64, d // 8)
+    pq = (rng.standard_normal((M, 256, d // M)) * 0.1).astype(np.float32)
+    g = api.GammaHip(0)
+    try:
+        g.ivfpq_init(d, nlist, M, 8, api.METRIC_L2, 100)
+        g.ivfpq_set_trained(cc, pq, None)
+        P = 16
+        args = api.SearchArgs(metric=api.METRIC_L2, nprobe=P, coarse_mode=1, **WIDE)
+        for nq in (24, 300, 1000):
+            x = rng.standard_normal((nq, d)).astype(np.float32)
+            Do, Io = B.knn_L2sqr(x, cc, P, mode=1)
+            dev = torch.device("cuda", 0)
+            dx = torch.from_numpy(x).to(dev)
+            cd = torch.empty((nq, P), dtype=torch.float32, device=dev)
+            pr = torch.empty((nq, P), dtype=torch.int32, device=dev)
+            g.ivfpq_coarse_device(dx.data_ptr(), nq, args, cd.data_ptr(), pr.data_ptr())
+            g.synchronize()
+            assert cd.cpu().numpy().tobytes() == Do.tobytes(), (d, nq)
+            assert np.array_equal(pr.cpu().numpy().astype(np.int64), Io), (d, nq)
+    finally:
+        g.close()

@@ -206,3 +206,55 @@ def test_tie_heavy_golden_labels_and_ranks_exact(tag, name):
         assert np.array_equal(st["coarse_idx"], z["coarse_idx_" + tag])
         compare_exact(z["rdis_" + tag], z["rids_" + tag], st["recall_dis"], st["recall_ids"])
         compare_exact(z["D_%s_%s" % (nm, tag)], z["I_%s_%s" % (nm, tag)], D, I)
+
+
+def load_blas_c3shape():
+    """tests/golden/ivfpq_blas_c3shape.npz (tests/gen_golden.py gen_blas_coarse): a C3-shaped index trained, filled and
+    searched by the compiled library at its DEFAULT blas threshold.  Base and queries come from the portable generator."""
+    z = np.load(os.path.join(G, "ivfpq_blas_c3shape.npz"))
+    N, d, nq = int(z["N"]), int(z["d"]), int(z["nq"])
+    base = synth.sift_like(N, d=d, seed=1234)
+    q = synth.sift_like(nq, d=d, seed=4321)
+    assert float(base.astype(np.float64).sum()) == float(z["base_sum"][0]) and float(q.astype(np.float64).sum()) == float(z["q_sum"][0])
+    return z, base, q
+
+
+def check_blas_c3shape_lists(z, get_list):
+    """the lists an Add path built == the library's: sizes and checksums of ids and codes per list"""
+    M = int(z["M"])
+    w = 1 + np.arange(M)
+    for l in range(int(z["nlist"])):
+        ids, codes = get_list(l)
+        assert len(ids) == int(z["list_sizes"][l]), l
+        assert int(ids.sum()) == int(z["list_idsum"][l]) and int((codes.astype(np.int64) * w).sum()) == int(z["list_codesum"][l]), l
+
+
+def test_default_blas_path_of_the_library_at_the_c3_shape():
+    """The oracle's DEFAULT path (coarse_mode -1: GEMM form from 20 queries on, Add with the library's assign rule) on a
+    2048-query batch == the compiled library with its default BLAS threshold: lists, coarse assignment (distance bits and
+    list order), final labels and distances -- all strictly.  "Bit-exact vs the faiss-CPU path" therefore holds for
+    batched calls as the library actually runs them, not only with its BLAS switch disabled."""
+    z, base, q = load_blas_c3shape()
+    d, nlist, M = int(z["d"]), int(z["nlist"]), int(z["M"])
+    o = B.OracleIVFPQ(d, nlist, M, 8, B.METRIC_L2)
+    o.set_trained(z["cc"], z["pq"], None)
+    B.lib().go_set_assign_mode(-1)
+    try:
+        for i0 in range(0, len(base), 50000):
+            assert o.add(base[i0:i0 + 50000])
+    finally:
+        B.lib().go_set_assign_mode(0)
+    check_blas_c3shape_lists(z, o.get_list)
+    o.set_raw(base)
+    ctx = B.make_ctx(min_score=-3e38, max_score=3e38)
+    nprobe, R, k = int(z["nprobe"]), int(z["R"]), int(z["k"])
+    D, I, st = o.search(q, k, nprobe, recall_num=R, has_rank=True, metric=B.METRIC_L2, ctx=ctx, coarse_mode=-1, want_stages=True)
+    assert st["coarse_dis"].tobytes() == z["coarse_dis_blas"].tobytes()
+    assert np.array_equal(st["coarse_idx"], z["coarse_idx_blas"].astype(np.int64))
+    assert D.tobytes() == z["D_blas"].tobytes() and np.array_equal(I, z["I_blas"].astype(np.int64))
+    # the switch disabled (what the other goldens pin): a different, equally exact, answer
+    D0, I0, st0 = o.search(q, k, nprobe, recall_num=R, has_rank=True, metric=B.METRIC_L2, ctx=ctx, coarse_mode=0, want_stages=True)
+    assert st0["coarse_dis"].tobytes() == z["coarse_dis_exact"].tobytes()
+    assert np.array_equal(st0["coarse_idx"], z["coarse_idx_exact"].astype(np.int64))
+    assert D0.tobytes() == z["D_exact"].tobytes() and np.array_equal(I0, z["I_exact"].astype(np.int64))
+    assert not np.array_equal(z["coarse_idx_blas"], z["coarse_idx_exact"])

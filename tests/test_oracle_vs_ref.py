@@ -86,17 +86,45 @@ def test_ivfpq_end_to_end(cfg):
     R.ref_set_blas_threshold(20)
 
 
-def test_default_blas_coarse_path_close_to_gemm_form():
-    """With faiss's default threshold (nq >= 20 -> MKL sgemm) the reference's own coarse
-    distances depend on the BLAS; our restated GEMM form must agree to rounding."""
+@pytest.mark.parametrize("kind", ["sift", "gauss"])
+def test_gemm_form_is_the_compiled_sgemm(kind):
+    """With faiss's default threshold (nq >= 20) the coarse distances come from exhaustive_L2sqr_blas: norms + MKL's
+    sgemm_ (faiss:utils/distances.cpp:215-296,303-305).  The restated GEMM form (oracle mode 1 = the device's default
+    path) is that computation BIT FOR BIT: one k-ascending fma chain per element up to K = 384, two half chains added
+    once for 384 < K <= 768 with K % 8 == 0 (go_gemm_k_split) -- every BASELINE shape (d = 128, 768).  Beyond that MKL's
+    blocking is not restated (K = 1024 below: ulp-level differences, documented).  Not covered either: remainder blocks
+    of a few rows (nq mod 4096 or nlist mod 1024 below 8), where MKL switches kernels, and K = 384
+    exactly with a database block of 9..512 rows (nlist mod 1024 in that range), which MKL already splits in two."""
     R = B.ref()
     R.ref_set_blas_threshold(20)
-    rng = np.random.default_rng(9)
-    y = synth.sift_like(512, d=64, seed=3)
-    x = synth.sift_like(64, d=64, seed=4)
-    D = np.empty((64, 8), np.float32)
-    I = np.empty((64, 8), np.int64)
-    R.ref_flat_l2_search(64, 512, B._fp(y), 64, B._fp(x), 8, B._fp(D), B._ip(I))
-    D1, I1 = B.knn_L2sqr(x, y, 8, mode=1)
-    assert np.allclose(D, D1, rtol=1e-5, atol=1e-2)
-    assert (I == I1).mean() > 0.99
+    try:
+        for d, nx, ny in ((32, 64, 512), (64, 100, 1000), (96, 40, 300), (128, 512, 2048), (128, 20, 4160), (200, 33, 700),
+                          (256, 64, 1024), (376, 64, 1500), (384, 64, 2048), (392, 64, 512), (512, 50, 1024), (640, 64, 512), (768, 256, 2048),
+                          (768, 21, 333), (128, 4160, 1024)):
+            rng = np.random.default_rng(d + nx)
+            if kind == "sift":
+                y = (synth.sift_like(ny, d=d, seed=3) + rng.random((ny, d))).astype(np.float32)   # centroid-like
+                x = synth.sift_like(nx, d=d, seed=4)
+            else:
+                y = (rng.standard_normal((ny, d)) * 3).astype(np.float32)
+                x = rng.standard_normal((nx, d)).astype(np.float32)
+            k = 32
+            D = np.empty((nx, k), np.float32)
+            I = np.empty((nx, k), np.int64)
+            R.ref_flat_l2_search(d, ny, B._fp(y), nx, B._fp(x), k, B._fp(D), B._ip(I))
+            D1, I1 = B.knn_L2sqr(x, y, k, mode=1)
+            assert D.tobytes() == D1.tobytes() and np.array_equal(I, I1), (d, nx, ny)
+            D0, _ = B.knn_L2sqr(x, y, k, mode=0)
+            assert D.tobytes() != D0.tobytes()          # (the library really took its BLAS path)
+        # beyond the restated range: close, not identical
+        d, nx, ny = 1024, 64, 512
+        rng = np.random.default_rng(1)
+        y = (rng.standard_normal((ny, d)) * 3).astype(np.float32)
+        x = rng.standard_normal((nx, d)).astype(np.float32)
+        D = np.empty((nx, 8), np.float32)
+        I = np.empty((nx, 8), np.int64)
+        R.ref_flat_l2_search(d, ny, B._fp(y), nx, B._fp(x), 8, B._fp(D), B._ip(I))
+        D1, I1 = B.knn_L2sqr(x, y, 8, mode=1)
+        assert np.allclose(D, D1, rtol=1e-5) and (I == I1).mean() > 0.99
+    finally:
+        R.ref_set_blas_threshold(20)
