@@ -57,9 +57,11 @@ def main():
     ap.add_argument("--timed-events", default="all", choices=["scan", "all", "none"],
                     help="HIP events inside the timed region: around every stage (default; roofline.achieved is the scan launch "
                          "measured live), around the scan launch only, or none (everything from an untimed pass over the same steps)")
-    ap.add_argument("--no-deferred-replay", action="store_true",
-                    help="exact ties: replay the flagged queries of a step at its end on the search stream instead of beside "
-                         "the next step's coarse quantizer (gamma_hip_set_deferred_replay; single-GPU steps only)")
+    ap.add_argument("--deferred-replay", action="store_true",
+                    help="exact ties: replay the flagged queries of a step beside the NEXT step's coarse quantizer "
+                         "(gamma_hip_set_deferred_replay: a streamed schedule of device-pointer calls whose flagged rows "
+                         "complete one call later).  Default: every call is complete when it returns -- what the plugin "
+                         "boundary hands back -- and `value` is that figure; the streamed figure is config.exact_ties.qps")
     ap.add_argument("--placement", default="auto", choices=["auto", "shard", "replicate"],
                     help="--gpus N > 1: 'shard' = the lists split over the ranks (greedy sum(len)), candidates exchanged "
                          "(gamma_amd.dist.sharded_search); 'replicate' = every rank holds the whole index and answers its "
@@ -76,6 +78,7 @@ def main():
                     help="experiment: every batch repeats its first N queries (the lists they probe stay cache "
                          "resident: what the scan costs without its table traffic)")
     ap.add_argument("--batches", default="1,32,1024", help="batch sizes of the qps_by_batch leg (BASELINE.md protocol)")
+    ap.add_argument("--no-plugin", action="store_true", help="skip the leg that drives the HIPIVFPQ plugin (Indexing, Add, Search with host buffers)")
     ap.add_argument("--no-shapes", action="store_true", help="skip the reduced C4 / C5 shape legs (child processes, ~1 min)")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the extra legs (exact ties, batch sizes 1/32/1024, coarse_mode 0, C2 flat)")
@@ -102,7 +105,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from gamma_amd import api, synth, train
+    from gamma_amd import api, synth
     from gamma_amd import dist as gdist
 
     rank = int(os.environ.get("RANK", "0"))
@@ -142,9 +145,14 @@ def main():
     # ---- training + encoding (setup, untimed): rank 0 trains, everyone gets the same state ----
     t0 = time.time()
     ntrain = min(N, nlist * 64)
+    train_s = None
     if rank == 0:
-        cc, pq = train.train_ivfpq(base[:ntrain], nlist, M, niter=10, pq_niter=25, seed=1234,
-                                   device=str(dev))
+        # trained the way a Gamma table's Indexing() trains it: faiss's IndexIVFPQ::train on the first nlist * 64 vectors, on
+        # the device (gamma_hip_ivfpq_train; bit-identical to the compiled library's training, tests/test_training_cpu.py)
+        t1 = time.time()
+        cc, pq = g.ivfpq_train(base[:ntrain], nlist, M)
+        train_s = time.time() - t1
+        log("[rank 0] IndexIVFPQ::train on the device: %.2fs for %d x %d vectors" % (train_s, ntrain, d))
         state = [torch.from_numpy(cc).to(dev), torch.from_numpy(pq).to(dev)]
     else:
         state = [torch.empty((nlist, d), dtype=torch.float32, device=dev),
@@ -193,7 +201,7 @@ def main():
     # synchronize that ends the timed region (include/gamma_hip.h, gamma_hip_set_deferred_replay)
     # (replicated ranks do the same: gamma_amd.dist.ReplicatedStream gathers a step's results one step behind, after the
     #  next step's search has been enqueued, and flush() -- inside the timed region -- gathers the last step's)
-    deferred = (not use_dist or replicate) and (not a.no_exact_ties) and (not a.no_deferred_replay)
+    deferred = (not use_dist or replicate) and (not a.no_exact_ties) and a.deferred_replay
     rstream = gdist.ReplicatedStream(backend, k, args) if (use_dist and replicate and deferred) else None
     if rstream is None:
         g.set_deferred_replay(deferred)
@@ -314,6 +322,29 @@ def main():
             g.ivfpq_search(qh, k, args)
         host_qps = 5 * a.nq / (time.perf_counter() - t1)
 
+    # batch 0 through the device's default path, every call complete -- kept for the label-by-label comparison with the CPU
+    # baseline (the compiled library at its default BLAS threshold) -- and the plugin leg: both BEFORE the legs below
+    # insert into and delete from the index
+    gpu_res = None
+    if world == 1:
+        g.set_exact_ties(True)
+        g.set_deferred_replay(False)
+        g.ivfpq_search_device(d_q.data_ptr(), a.nq, k, args, d_D.data_ptr(), d_I.data_ptr())
+        torch.cuda.synchronize()
+        gpu_res = (d_D[:a.nq].cpu().numpy().copy(), d_I[:a.nq].cpu().numpy().copy())
+        g.set_exact_ties(not a.no_exact_ties)
+        g.set_deferred_replay(deferred)
+    # ---- what the RetrievalModel boundary delivers: the HIPIVFPQ plugin driven the way VectorManager drives a model
+    #      (gamma_amd/host/harness_c_api.cc): vectors stored, Indexing(), Add() in the engine's batches of 10 000, then
+    #      Search() with HOST buffers in and out -- 16384-query and 1024-query calls.  Never `value` (PCIe inclusive).
+    plugin_leg = None
+    if world == 1 and not a.no_extra and not a.no_plugin:
+        try:
+            plugin_leg = plugin_bench(a, base, queries, cc, pq, g, d_q, d_D, d_I, k, args)
+        except Exception as e:      # noqa: BLE001 -- a leg never fails the bench
+            plugin_leg = {"error": str(e)}
+        log("plugin leg: %s" % json.dumps(plugin_leg))
+
     # ---- the other operating points BASELINE.md / SURVEY 8d name, each a short bounded leg on the same index
     #      (single GPU only; none of them is `value`) ----
     extra = {}
@@ -339,13 +370,14 @@ def main():
             g.ivfpq_search_device(xb.data_ptr(), gnq, k, args, d_D.data_ptr(), d_I.data_ptr())
 
         g.set_exact_ties(True)
+        g.set_deferred_replay(True)      # the streamed schedule: a step's flagged rows complete beside the next step
         sec = timed(one_step, 2, 3)
         g.tie_stats(reset=True)
         nst = 4 * nbatches
         turn[0] = 0
         sec = timed(one_step, nst, 0)
         ts = g.tie_stats()
-        g.set_deferred_replay(False)
+        g.set_deferred_replay(False)     # every call complete on return (the timed region's default)
         turn[0] = 0
         sec_inline = timed(one_step, nst, 3)
         g.set_deferred_replay(deferred)
@@ -353,9 +385,8 @@ def main():
         turn[0] = 0
         sec_off = timed(one_step, nst, 3)
         g.set_exact_ties(True)
-        extra["exact_ties"] = {"qps": round(gnq / sec, 1), "ms_per_step": round(sec * 1e3, 4),
-                               "deferred_replay": bool(deferred),
-                               "qps_replay_at_the_end_of_each_call": round(gnq / sec_inline, 1),
+        extra["exact_ties"] = {"qps_streamed_deferred_replay": round(gnq / sec, 1), "ms_per_step_streamed": round(sec * 1e3, 4),
+                               "qps_call_complete": round(gnq / sec_inline, 1),
                                "qps_with_ties_off": round(gnq / sec_off, 1),
                                "ms_per_step_with_ties_off": round(sec_off * 1e3, 4),
                                "flagged_per_batch": {"coarse_rows_redone": round(ts["coarse_rows"] / nst, 1),
@@ -453,19 +484,6 @@ def main():
         extra["search_during_inserts"] = {"qps": round(gnq * nsteps / el, 1), "insert_rate_vectors_per_s": round(20000 / done["t"], 1),
                                           "inserted": 20000, "batch": gnq, "steps": nsteps}
 
-    # (f') the same index with 5 % of its documents deleted (the last leg that touches it): large batches run over lists
-    #      cut down to the live entries once per call (csrc/kernels.hip k_compact_lists) instead of testing the delete
-    #      bitmap for every scored code
-    if world == 1 and not a.no_extra:
-        rng_d = np.random.default_rng(5)
-        dead = rng_d.choice(N, N // 20, replace=False)
-        bmd = np.zeros((N >> 3) + 1, dtype=np.uint8)
-        np.bitwise_or.at(bmd, dead >> 3, (1 << (dead & 7)).astype(np.uint8))
-        g.bitmap_upload(bmd, N)
-        g.delete(dead)
-        sec = timed(lambda: g.ivfpq_search_device(d_q.data_ptr(), gnq, k, args, d_D.data_ptr(), d_I.data_ptr()), 10, 3)
-        extra["deleted_5pct"] = {"qps": round(gnq / sec, 1), "ms_per_step": round(sec * 1e3, 4), "batch": gnq}
-
     # (g) the other BASELINE shapes at a size that builds in seconds, so that the driver's line carries a timing of
     #     them too (full size -- 100 M x 128 and 10 M x 768 -- takes minutes to generate: tools/c4_scale.py 1e8,
     #     tools/c5_scale.py 1e7 16384).  Child processes: each tool builds its own index.
@@ -512,8 +530,24 @@ def main():
         log("shape legs: %s" % json.dumps({k2: extra[k2] for k2 in ("c4_shape_8m", "c5_shape_2m")}))
 
     cpu = None
+    labels_vs_cpu = None
     if world == 1 and a.cpu_seconds > 0:
-        cpu = cpu_baseline(a, base, queries, cc, pq, g, lno, codes, list_sizes)
+        # (gpu_res: batch 0 through the device's default path, taken before the legs that change the index)
+        cpu = cpu_baseline(a, base, queries, cc, pq, g, lno, codes, list_sizes, gpu_res)
+        labels_vs_cpu = cpu.pop("labels_equal_to_cpu_baseline", None) if cpu else None
+
+    # (f') the same index with 5 % of its documents deleted (the LAST leg: it changes the index): large batches run over lists
+    #      cut down to the live entries once per call (csrc/kernels.hip k_compact_lists) instead of testing the delete
+    #      bitmap for every scored code
+    if world == 1 and not a.no_extra:
+        rng_d = np.random.default_rng(5)
+        dead = rng_d.choice(N, N // 20, replace=False)
+        bmd = np.zeros((N >> 3) + 1, dtype=np.uint8)
+        np.bitwise_or.at(bmd, dead >> 3, (1 << (dead & 7)).astype(np.uint8))
+        g.bitmap_upload(bmd, N)
+        g.delete(dead)
+        sec = timed(lambda: g.ivfpq_search_device(d_q.data_ptr(), gnq, k, args, d_D.data_ptr(), d_I.data_ptr()), 10, 3)
+        extra["deleted_5pct"] = {"qps": round(gnq / sec, 1), "ms_per_step": round(sec * 1e3, 4), "batch": gnq}
 
     # HBM-side traffic of the scan kernel cannot be read from inside the process: it comes from
     # the separate rocprofv3 --pmc passes (tools/pmc_traffic.sh) committed under profiles/, and is
@@ -559,6 +593,9 @@ def main():
                  "top-k" % (world, world))),
             "stage_us": stages,
             "stage_timing": "HIP events in the timed region: " + a.timed_events,
+            "value_is": "device-pointer Search calls, each COMPLETE when it returns (exact ties on, replay inside the call)" if not deferred else
+                        "a STREAM of device-pointer calls with the deferred tie replay (--deferred-replay): flagged rows complete one call later",
+            "indexing_seconds": None if train_s is None else round(train_s, 2),
             "tie_replay": ("exact ties on; the replay of a step's flagged queries runs on a side stream beside the next "
                            "step's coarse quantizer and query tables (gamma_hip_set_deferred_replay); every step's results "
                            "are complete inside the timed region (it ends with a device-wide synchronize)"
@@ -566,6 +603,8 @@ def main():
                               "the timed region ends (gamma_amd.dist.ReplicatedStream)" if rstream is not None else "")) if deferred else
                           ("exact ties on; replay at the end of every call" if not a.no_exact_ties else "exact ties off"),
             "pcie_inclusive_qps": None if host_qps is None else round(host_qps, 1),
+            "labels_equal_to_cpu_baseline": labels_vs_cpu,
+            "plugin": plugin_leg,
             **extra,
         },
         "roofline": {
@@ -628,7 +667,50 @@ def spawn_ranks(n):
     return rc
 
 
-def cpu_baseline(a, base, queries, cc, pq, g, lno, codes, list_sizes):
+def plugin_bench(a, base, queries, cc, pq, g, d_q, d_D, d_I, k, args):
+    """HIPIVFPQ behind the reference's plugin interface (index/retrieval_model.h:218-310; vector/vector_manager.cc:161-349,
+    433-617): Init -> (store) -> Indexing -> Add in batches of 10 000 -> Search with the caller's host buffers."""
+    import torch
+    from gamma_amd import plugin
+    N, d = base.shape
+    params = ('{"ncentroids": %d, "nsubvector": %d, "nprobe": %d, "metric_type": "L2", "bucket_init_size": %d}'
+              % (a.nlist, a.m, a.nprobe, max(1000, int(2.5 * N / a.nlist))))
+    m = plugin.PluginModel("HIPIVFPQ", d, params, indexing_size=min(N, a.nlist * 64))
+    out = {}
+    try:
+        t0 = time.time()
+        m.store(base)
+        out["store_seconds"] = round(time.time() - t0, 2)
+        t0 = time.time()
+        if m.indexing() != 0:
+            raise RuntimeError("Indexing() failed")
+        out["indexing_seconds"] = round(time.time() - t0, 2)      # the reference: 11.3 s on 8 cores (BASELINE.md 2)
+        st = m.trained_state(a.nlist, a.m)
+        out["same_trained_state_as_the_handle"] = bool(st is not None and st[0].tobytes() == cc.tobytes() and st[1].tobytes() == pq.tobytes())
+        t0 = time.time()
+        for i0 in range(0, N, 10000):
+            if not m.add(base[i0:i0 + 10000]):
+                raise RuntimeError("Add() failed")
+        out["add_vectors_per_s"] = round(N / (time.time() - t0), 1)
+        rp = '{"nprobe": %d, "recall_num": %d, "metric_type": "L2"}' % (a.nprobe, a.recall_num)
+        for nqb, reps in ((a.nq, 8), (1024, 40)):
+            qh = np.ascontiguousarray(queries[:nqb])
+            Dp, Ip = m.search(qh, k, rp, has_rank=not a.no_rank, min_score=0.0, max_score=1e30)
+            g.ivfpq_search_device(d_q.data_ptr(), nqb, k, args, d_D.data_ptr(), d_I.data_ptr())
+            torch.cuda.synchronize()
+            same = bool(np.array_equal(Ip, d_I[:nqb].cpu().numpy()) and Dp.tobytes() == d_D[:nqb].cpu().numpy().tobytes())
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                m.search(qh, k, rp, has_rank=not a.no_rank, min_score=0.0, max_score=1e30)
+            sec = (time.perf_counter() - t0) / reps
+            out["search_%d" % nqb] = {"qps": round(nqb / sec, 1), "ms_per_call": round(sec * 1e3, 4),
+                                      "identical_to_the_device_pointer_call": same}
+    finally:
+        m.close()
+    return out
+
+
+def cpu_baseline(a, base, queries, cc, pq, g, lno, codes, list_sizes, gpu_res=None):
     """The reference's CPU path on the host cores of this box, on a bounded sample of the same workload.
 
     kind "reference" (when oracle/_ref is there -- it is built from /root/reference and travels with the
@@ -704,6 +786,28 @@ def cpu_baseline(a, base, queries, cc, pq, g, lno, codes, list_sizes):
             r.add(base)
             log("cpu baseline: faiss trained + filled in %.1fs" % (time.time() - t0))
             fn = lambda b: r.search_rerank(queries[b * a.nq:(b + 1) * a.nq], a.k, a.recall_num, a.nprobe, base)
+            agree = None
+            if gpu_res is not None:
+                # The library trained itself on the same vectors -- and the device's training is the library's bit for
+                # bit -- so the two indexes are the same index, and the library's answer to batch 0 (MKL coarse path at
+                # this batch size) can be compared with the device's label by label.  (ref_ivfpq_search_rerank feeds the
+                # k-heap from the SORTED recall table, Gamma from the heap's array: inside exact ties the order can
+                # differ, hence the set figure beside the strict one; the oracle run on the library's own coarse
+                # assignment is Gamma's order exactly.)
+                same_index = (r.coarse_centroids().tobytes() == np.ascontiguousarray(cc, np.float32).tobytes() and
+                              r.pq_centroids().tobytes() == np.ascontiguousarray(pq, np.float32).tobytes())
+                Dc, Ic = fn(0)
+                Dg, Ig = gpu_res
+                strict = float((Ic == Ig).all(axis=1).mean())
+                sets = float(np.mean([set(x_.tolist()) == set(y_.tolist()) for x_, y_ in zip(Ic, Ig)]))
+                cdl, cil = r.coarse(queries[:a.nq], a.nprobe)
+                Do, Io = o.search(queries[:a.nq], a.k, a.nprobe, recall_num=a.recall_num, has_rank=True, metric=B.METRIC_L2,
+                                  ctx=ctx, preassigned=(cdl, cil))
+                agree = {"queries": int(a.nq), "same_trained_state_as_the_library": bool(same_index),
+                         "identical_to_faiss_search_rerank": round(strict, 6), "identical_as_sets": round(sets, 6),
+                         "identical_to_gamma_order_on_the_librarys_coarse_assignment": round(float((Io == Ig).all(axis=1).mean()), 6),
+                         "distance_bits_identical": round(float((Do.view(np.uint32) == Dg.view(np.uint32)).all(axis=1).mean()), 6)}
+                log("cpu baseline: label agreement with the device on batch 0: %s" % json.dumps(agree))
             qps, n, el = timed(fn, budget / 3)
             used = cores
             alt = None
@@ -724,6 +828,8 @@ def cpu_baseline(a, base, queries, cc, pq, g, lno, codes, list_sizes):
                 out["sample"] += "; the container's CPU quota is %d cores (cgroup cpu.max)" % quota_cores
             if alt:
                 out["other_thread_count"] = alt
+            if agree:
+                out["labels_equal_to_cpu_baseline"] = agree
         except Exception as e:   # a prebuilt _ref that does not load here: fall back to the port
             log("cpu baseline: reference library unusable (%s), using the port" % e)
     if out is None:

@@ -6,7 +6,7 @@ Layout:
   host/      C++ RetrievalModel plugin (HIPIVFPQ / HIPFLAT) that calls the C ABI
   api.py     ctypes face of the C ABI for tests / bench
   dist.py    list-sharded multi-GPU search (RCCL all-gather of per-shard top-k)
-  synth.py   portable synthetic data;  train.py  k-means / PQ training for bench setup
+  synth.py   portable synthetic data (bench / tests)
 
 Importing the package does not load the HIP library; gamma_amd.api.GammaHip() does and raises
 if it is missing (there is no CPU fallback).

@@ -98,6 +98,7 @@ SYMBOLS = {
     "gamma_hip_kmeans": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, f32p, C.c_int, C.c_int, C.c_int64, C.c_int, f32p,
                                    C.POINTER(C.c_float)]),
     "gamma_hip_rand_perm": (None, [i32p, C.c_int64, C.c_int64]),
+    "gamma_hip_ivfpq_train": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, f32p, C.c_int, C.c_int, f32p, f32p]),
     "gamma_hip_ivfpq_search": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int, f32p, C.c_int,
                                          f32p, i64p]),
     "gamma_hip_ivfpq_search_device": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int,
@@ -181,6 +182,13 @@ def load():
                 "libgamma_hip.so not found at %s -- build it with `python -c 'import "
                 "__graft_entry__ as g; g.build()'` or `make -C gamma_amd/csrc` (no CPU fallback)"
                 % LIB_PATH)
+        # ONE HIP runtime per process: PyTorch ships its own libamdhip64 and the tests / bench / dist.py hand torch tensors'
+        # device pointers to this library.  Whichever runtime is loaded first serves both (same SONAME), and a torch
+        # imported AFTER this library has initialised the ROCm install's runtime finds no device -- so torch goes first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the library does not export it

@@ -266,6 +266,17 @@ class GammaHip:
                                          max_points_per_centroid, _p(cen, _lib.f32p), C.byref(obj)), "kmeans")
         return cen, float(obj.value)
 
+    def ivfpq_train(self, x, nlist, M):
+        """IndexIVFPQ::train as GammaIVFPQIndex::Indexing runs it, on the device: (coarse centroids [nlist, d], PQ codebooks
+        [M, 256, d / M]) -- the library's own training, bit for bit (gamma_hip_ivfpq_train)"""
+        x = _f32(x)
+        d = x.shape[1]
+        cc = np.empty((nlist, d), dtype=np.float32)
+        pq = np.empty((M, 256, d // M), dtype=np.float32)
+        self._ck(self.L.gamma_hip_ivfpq_train(self.h, d, x.shape[0], _p(x, _lib.f32p), nlist, M, _p(cc, _lib.f32p),
+                                              _p(pq, _lib.f32p)), "ivfpq_train")
+        return cc, pq
+
     def update_batch(self, vids, vecs):
         """GammaIVFPQIndex::Update for a batch: one encode (each vector assigned as a call of its own), list updates in
         order, one publish"""
@@ -596,3 +607,14 @@ class GammaHipGroup:
 
     def total_mem_bytes(self):
         return self.L.gamma_hip_group_total_mem_bytes(self.g)
+
+
+def train_ivfpq(x, nlist, M, device=0):
+    """Coarse centroids + PQ codebooks the way GammaIVFPQIndex::Indexing trains them (IndexIVFPQ::train, bit for bit), on
+    the device, through a handle of its own: what bench.py and the tools build their indexes with."""
+    g = GammaHip(device)
+    try:
+        return g.ivfpq_train(x, nlist, M)
+    finally:
+        g.close()
+

@@ -179,4 +179,43 @@ int gamma_hip_kmeans(gamma_hip_index* h, int d, int64_t n, const float* x_in, in
     return GAMMA_HIP_OK;
 }
 
+// IndexIVFPQ::train as GammaIVFPQIndex::Indexing configures it (index/impl/gamma_index_ivfpq.cc:172-185,272-354):
+// train_q1 -- Clustering(d, nlist) with cp.niter = 10, seed 1234, max_points_per_centroid 256 -- then
+// train_residual_o (faiss:IndexIVFPQ.cpp:67-106): at most 256 * 256 points (fvecs_maybe_subsample with pq.cp.seed =
+// 1234), their residuals to the nearest coarse centroid (by_residual), and ProductQuantizer::train: one
+// Clustering(dsub, 256, niter 25) per sub-quantizer.  coarse: nlist*d, pq: M*256*(d/M) fp32 host out.
+int gamma_hip_ivfpq_train(gamma_hip_index* h, int d, int64_t n, const float* x, int nlist, int M, float* coarse, float* pq) {
+    if (!h || d <= 0 || nlist <= 0 || M <= 0 || d % M != 0 || !x || !coarse || !pq) return GAMMA_HIP_EINVAL;
+    int rc = gamma_hip_kmeans(h, d, n, x, nlist, 10, 1234, 256, coarse, nullptr);
+    if (rc) return rc;
+    const int64_t nmax = 256 * 256;
+    std::vector<float> subset;
+    const float* xs = x;
+    int64_t ns = n;
+    if (n > nmax) {
+        std::vector<int> perm;
+        rand_perm(perm, (size_t)n, 1234);
+        subset.resize((size_t)nmax * d);
+        for (int64_t i = 0; i < nmax; i++) memcpy(&subset[(size_t)i * d], x + (size_t)perm[i] * d, sizeof(float) * d);
+        xs = subset.data();
+        ns = nmax;
+    }
+    std::vector<int32_t> assign((size_t)ns);
+    rc = gamma_hip_assign(h, d, ns, xs, nlist, coarse, assign.data(), nullptr);
+    if (rc) return rc;
+    const int dsub = d / M;
+    std::vector<float> slice((size_t)ns * dsub);
+    for (int m = 0; m < M; m++) {
+        for (int64_t i = 0; i < ns; i++) {
+            if (assign[i] < 0 || assign[i] >= nlist) return fail(h, GAMMA_HIP_EDEVICE, "training: bad assignment");
+            const float* xi = xs + (size_t)i * d + m * dsub;
+            const float* c = coarse + (size_t)assign[i] * d + m * dsub;
+            for (int t = 0; t < dsub; t++) slice[(size_t)i * dsub + t] = xi[t] - c[t];
+        }
+        rc = gamma_hip_kmeans(h, dsub, ns, slice.data(), 256, 25, 1234, 256, pq + (size_t)m * 256 * dsub, nullptr);
+        if (rc) return rc;
+    }
+    return GAMMA_HIP_OK;
+}
+
 }  // extern "C"

@@ -224,39 +224,10 @@ int GammaIVFPQHIPIndex::TrainCoarse(size_t num, const float *xt) {
 }
 
 int GammaIVFPQHIPIndex::TrainOnHost(size_t num, const float *xt) {
-  int rc = TrainCoarse(num, xt);
-  if (rc) return rc;
-  // IndexIVFPQ::train_residual_o (faiss:IndexIVFPQ.cpp:67-106): at most max_points_per_centroid * ksub = 65536
-  // points (fvecs_maybe_subsample with pq.cp.seed = 1234), their residuals to the nearest coarse centroid
-  // (by_residual = true, :179), then ProductQuantizer::train: one Clustering(dsub, 256, niter 25) per sub-quantizer
-  const size_t nmax = 256 * 256;
-  std::vector<float> subset;
-  const float *xs = xt;
-  size_t ns = num;
-  if (num > nmax) {
-    std::vector<int32_t> perm(num);
-    gamma_hip_rand_perm(perm.data(), (int64_t)num, 1234);
-    subset.resize(nmax * (size_t)d_);
-    for (size_t i = 0; i < nmax; i++) memcpy(&subset[i * d_], xt + (size_t)perm[i] * d_, sizeof(float) * d_);
-    xs = subset.data();
-    ns = nmax;
-  }
-  std::vector<int32_t> assign(ns);
-  rc = gamma_hip_assign(h_, d_, (int64_t)ns, xs, nlist_, coarse_centroids_.data(), assign.data(), nullptr);
-  if (rc) return rc;
-  const int dsub = d_ / M_;
-  std::vector<float> slice(ns * (size_t)dsub);
-  pq_centroids_.resize((size_t)M_ * 256 * dsub);
-  for (int m = 0; m < M_; m++) {
-    for (size_t i = 0; i < ns; i++) {
-      const float *xi = xs + i * d_ + m * dsub;
-      const float *c = &coarse_centroids_[(size_t)assign[i] * d_ + m * dsub];
-      for (int t = 0; t < dsub; t++) slice[i * dsub + t] = xi[t] - c[t];
-    }
-    rc = gamma_hip_kmeans(h_, dsub, (int64_t)ns, slice.data(), 256, 25, 1234, 256, &pq_centroids_[(size_t)m * 256 * dsub], nullptr);
-    if (rc) return rc;
-  }
-  return 0;
+  // IndexIVFPQ::train (train_q1 + train_residual_o + ProductQuantizer::train) on the device: gamma_hip_ivfpq_train
+  coarse_centroids_.resize((size_t)nlist_ * d_);
+  pq_centroids_.resize((size_t)M_ * 256 * (d_ / M_));
+  return gamma_hip_ivfpq_train(h_, d_, (int64_t)num, xt, nlist_, M_, coarse_centroids_.data(), pq_centroids_.data());
 }
 
 int GammaIVFPQHIPIndex::Indexing() {

@@ -290,6 +290,12 @@ int gamma_hip_assign(gamma_hip_index* h, int d, int64_t n, const float* x, int k
  * distances of the last assignment.  Bit-identical to the oracle's go_kmeans, which is pinned against compiled faiss. */
 int gamma_hip_kmeans(gamma_hip_index* h, int d, int64_t n, const float* x, int k, int niter, int64_t seed,
                      int max_points_per_centroid, float* centroids, float* objective);
+/* IndexIVFPQ::train as GammaIVFPQIndex::Indexing runs it (index/impl/gamma_index_ivfpq.cc:272-354, faiss:IndexIVFPQ.cpp:
+ * 67-131): coarse k-means (niter 10), residuals of at most 65536 subsampled points, one 256-centroid k-means (niter 25)
+ * per sub-quantizer -- every k-means the gamma_hip_kmeans above.  x: n*d fp32 host; coarse: nlist*d, pq: M*256*(d/M) fp32
+ * host out.  Bit-identical to the oracle's go_ivfpq_train, which is bit-identical to the compiled library's
+ * IndexIVFPQ::train at its default BLAS threshold (tests/test_training_cpu.py). */
+int gamma_hip_ivfpq_train(gamma_hip_index* h, int d, int64_t n, const float* x, int nlist, int M, float* coarse, float* pq);
 /* faiss::rand_perm (faiss:utils/random.cpp:136-146; std::mt19937): the permutation IndexIVFPQ::train_residual_o
  * subsamples its training set with (host only) */
 void gamma_hip_rand_perm(int32_t* perm, int64_t n, int64_t seed);

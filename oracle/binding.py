@@ -45,12 +45,39 @@ def build_oracle():
 _lib = None
 
 
+def usable_cpus():
+    """Threads worth starting: the hardware threads this process may run on, capped by a container CPU quota (cgroup v2
+    cpu.max).  The GPU boxes show 256 hardware threads under a 16-core quota; OpenMP's default of one thread per
+    hardware thread then turns every barrier of the k-means loops into a spin against the throttle."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    try:
+        qv, pv = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if qv != "max":
+            n = min(n, max(1, int(round(float(qv) / float(pv)))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def _cap_openmp_threads():
+    if "OMP_NUM_THREADS" in os.environ:
+        return
+    try:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(usable_cpus())
+    except OSError:
+        pass
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(ORACLE_SO):
             build_oracle()
         L = C.CDLL(ORACLE_SO)
+        _cap_openmp_threads()
         L.go_fvec_L2sqr.restype = C.c_float
         L.go_fvec_L2sqr.argtypes = [_f32p, _f32p, C.c_size_t]
         L.go_fvec_inner_product.restype = C.c_float

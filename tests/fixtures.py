@@ -2,7 +2,7 @@
 into the CPU oracle and (on a GPU box) into libgamma_hip.so."""
 import numpy as np
 
-from gamma_amd import synth, train
+from gamma_amd import synth
 from oracle import binding as B
 
 _cache = {}
@@ -10,8 +10,9 @@ _cache = {}
 
 def trained_case(d=32, nlist=64, M=8, N=20000, nq=64, metric=B.METRIC_L2, seed=1234, normalize=False,
                  bucket_init_size=1000):
-    """Synthetic base/queries, k-means coarse centroids + PQ codebooks (CPU torch, tiny), and
-    an oracle index with everything added through the oracle's own Add path."""
+    """Synthetic base/queries, coarse centroids + PQ codebooks trained the way GammaIVFPQIndex::Indexing trains them
+    (IndexIVFPQ::train: the oracle's go_ivfpq_train, bit-identical to the compiled library, tests/test_training_cpu.py),
+    and an oracle index with everything added through the oracle's own Add path."""
     key = (d, nlist, M, N, nq, metric, seed, normalize, bucket_init_size)
     if key in _cache:
         return _cache[key]
@@ -21,7 +22,7 @@ def trained_case(d=32, nlist=64, M=8, N=20000, nq=64, metric=B.METRIC_L2, seed=1
         base = (base / np.maximum(np.linalg.norm(base, axis=1, keepdims=True), 1e-9)).astype(np.float32)
         q = (q / np.maximum(np.linalg.norm(q, axis=1, keepdims=True), 1e-9)).astype(np.float32)
     ntrain = min(N, max(nlist * 40, 5000))
-    cc, pq = train.train_ivfpq(base[:ntrain], nlist, M, niter=6, pq_niter=8, seed=seed, device="cpu")
+    cc, pq = B.ivfpq_train(base[:ntrain], nlist, M)
     o = B.OracleIVFPQ(d, nlist, M, 8, metric, bucket_init_size=bucket_init_size)
     o.set_trained(cc, pq, None)
     B.lib().go_set_assign_mode(0)

@@ -1,8 +1,8 @@
-"""Index training for bench / test setup (NOT on the search hot path):
-plain Lloyd k-means for the coarse quantizer and the PQ codebooks, in torch (GPU when
-available).  The reference trains with faiss::Clustering (BLAS + its own RNG), which cannot
-be reproduced bit for bit; search parity is defined GIVEN the trained centroids/codebooks,
-so any reasonable trainer serves.  Deterministic for a given seed/device."""
+"""TEST HELPER (not part of the package): a quick Lloyd k-means in torch for tests that only need SOME trained
+centroids / codebooks in a hurry (the differential fuzz trains hundreds of small indexes).  The product trains with
+faiss's own procedure on the device (gamma_hip_ivfpq_train / the plugins' Indexing()); bench.py, the C3 fixture and the
+tools use that.  Search parity is defined GIVEN the trained state, so either trainer serves a parity test.
+Deterministic for a given seed / device."""
 import numpy as np
 import torch
 

@@ -10,7 +10,8 @@ import time
 import numpy as np
 import pytest
 
-from gamma_amd import api, synth, train
+from gamma_amd import api, synth
+from tests import lloyd as train
 from oracle import binding as B
 from tests.parity import compare_exact
 

@@ -5,7 +5,8 @@ updates interleaved with searches), checked against the CPU oracle on the same i
 import numpy as np
 import pytest
 
-from gamma_amd import api, synth, train
+from gamma_amd import api, synth
+from tests import lloyd as train
 from oracle import binding as B
 from tests.parity import compare_search_exact, compare_exact
 

@@ -3,7 +3,8 @@ Fixed seeds; every configuration goes through training, the Add path and several
 import numpy as np
 import pytest
 
-from gamma_amd import api, synth, train
+from gamma_amd import api, synth
+from tests import lloyd as train
 from oracle import binding as B
 from tests.parity import compare_search_exact
 

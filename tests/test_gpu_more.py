@@ -435,15 +435,13 @@ def test_device_encode_matches_oracle(case, hip):
 # --------------------------------------------------------------------------- full size (C3)
 @pytest.fixture(scope="module")
 def c3():
-    """BASELINE.json configs[2]: 1M x 128, nlist 4096, M 16; trained on the GPU, encoded on the
-    GPU; the oracle is loaded with the same lists for sampled parity."""
-    import torch
-    from gamma_amd import train
+    """BASELINE.json configs[2]: 1M x 128, nlist 4096, M 16; trained (faiss's IndexIVFPQ::train, gamma_hip_ivfpq_train) and
+    encoded on the GPU; the oracle is loaded with the same lists for sampled parity."""
     N, d, nlist, M = 1000000, 128, 4096, 16
     base = synth.sift_like(N, d=d, seed=1234)
-    cc, pq = train.train_ivfpq(base[:nlist * 64], nlist, M, niter=10, pq_niter=25, seed=1234,
-                               device="cuda" if torch.cuda.is_available() else "cpu")
     g = api.GammaHip(0)
+    # trained the way a Gamma table's Indexing() trains it: IndexIVFPQ::train on the first nlist * 64 vectors, on the device
+    cc, pq = g.ivfpq_train(base[:nlist * 64], nlist, M)
     g.ivfpq_init(d, nlist, M, 8, api.METRIC_L2, bucket_init_size=1000)
     g.ivfpq_set_trained(cc, pq, None)
     for i0 in range(0, N, 250000):          # Add path in batches: exercises list growth
@@ -676,7 +674,7 @@ def test_scan_bound_fallback_paths():
     base[:2000] = synth.sift_like(2000, d=d, seed=78)            # plus some ordinary ones
     # 520 queries x 32 probes: enough workgroups for 4 probes per group, i.e. the pre-filter is on
     q = np.concatenate([distinct[:60], synth.sift_like(460, d=d, seed=79)])
-    from gamma_amd import train
+    from tests import lloyd as train
     cc, pq = train.train_ivfpq(base[:6000], nlist, M, niter=6, pq_niter=8, seed=9, device="cpu")
     o = B.OracleIVFPQ(d, nlist, M, 8, B.METRIC_L2, bucket_init_size=4000)
     o.set_trained(cc, pq, None)

@@ -4,14 +4,14 @@ QPS at 8192-query steps, recall@10 against the exact flat search on the GPU, sta
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from gamma_amd import api, synth, train
+from gamma_amd import api, synth
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20000000
 d, nlist, M, P, R, k, nq = 128, 16384, 32, 64, 100, 10, 8192
 dev = torch.device("cuda", 0)
 CH = 1000000
 t0 = time.time()
 first = synth.sift_like(CH, d=d, seed=1234)      # synth blocks are position-keyed: chunk c = rows [c*CH, (c+1)*CH)
-cc, pq = train.train_ivfpq(first[:nlist * 40], nlist, M, niter=8, pq_niter=15, seed=1234, device=str(dev))
+cc, pq = api.train_ivfpq(first[:nlist * 40], nlist, M)
 print("train %.1fs" % (time.time() - t0)); t0 = time.time()
 g = api.GammaHip(0)
 g.ivfpq_init(d, nlist, M, 8, api.METRIC_L2, bucket_init_size=max(200, int(1.3 * N / nlist)))

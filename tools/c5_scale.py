@@ -5,7 +5,7 @@ recall@10 against the exact flat search, stage times."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from gamma_amd import api, train
+from gamma_amd import api
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 2000000
 d, nlist, M, P, R, k, nq = 768, (int(sys.argv[2]) if len(sys.argv) > 2 else 4096), 64, 64, 100, 10, 4096
 dev = torch.device("cuda", 0)
@@ -23,7 +23,7 @@ def chunk(n, seed):
 
 t0 = time.time()
 first = chunk(max(CH, nlist * 40), 1000)
-cc, pq = train.train_ivfpq(first[:nlist * 40], nlist, M, niter=8, pq_niter=12, seed=5, device=str(dev))
+cc, pq = api.train_ivfpq(first[:nlist * 40], nlist, M)
 print("train %.1fs" % (time.time() - t0)); t0 = time.time()
 g = api.GammaHip(0)
 g.ivfpq_init(d, nlist, M, 8, api.METRIC_IP, bucket_init_size=max(200, int(1.5 * N / nlist)))

@@ -3,13 +3,13 @@ and -- GAMMA_HIP_COARSE_DBG=1 -- how many queries the fused path had to repair."
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from gamma_amd import api, synth, train
+from gamma_amd import api, synth
 dev = torch.device("cuda", 0)
 nq = 8192
 SH = os.environ.get('CS_SHAPES')
 for d, nlist, P in [tuple(int(v) for v in t.split(',')) for t in SH.split(';')] if SH else ((128, 4096, 32), (128, 8192, 32), (128, 16384, 32), (128, 16384, 16), (128, 16384, 64), (128, 32768, 32), (64, 16384, 32), (768, 16384, 64), (256, 4096, 32)):
     base = synth.sift_like(max(200000, nlist * 20), d=d, seed=1234)
-    cc, pq = train.train_ivfpq(base[:nlist * 20], nlist, 16 if d % 16 == 0 else 8, niter=4, pq_niter=2, seed=1, device=str(dev))
+    cc, pq = api.train_ivfpq(base[:nlist * 20], nlist, 16 if d % 16 == 0 else 8)
     g = api.GammaHip(0)
     g.ivfpq_init(d, nlist, 16, 8, api.METRIC_L2, 100)
     g.ivfpq_set_trained(cc, pq, None)

@@ -4,11 +4,11 @@ with request combining on (default) and off (GAMMA_HIP_NO_COMBINE=1 in the envir
 import sys, os, time, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from gamma_amd import api, synth, train
+from gamma_amd import api, synth
 dev = torch.device("cuda", 0)
 N, d, nlist, M, P, R, k = 1000000, 128, 4096, 16, 32, 200, 10
 base = synth.sift_like(N, d=d, seed=1234)
-cc, pq = train.train_ivfpq(base[:nlist * 40], nlist, M, niter=5, pq_niter=6, seed=1, device=str(dev))
+cc, pq = api.train_ivfpq(base[:nlist * 40], nlist, M)
 g = api.GammaHip(0)
 g.ivfpq_init(d, nlist, M, 8, api.METRIC_L2, bucket_init_size=700)
 g.ivfpq_set_trained(cc, pq, None)

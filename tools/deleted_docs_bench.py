@@ -3,11 +3,11 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from gamma_amd import api, synth, train
+from gamma_amd import api, synth
 dev = torch.device("cuda", 0)
 N, d, nlist, M, P, R, k, nq = 1000000, 128, 4096, 16, 32, 200, 10, 16384
 base = synth.sift_like(N, d=d, seed=1234)
-cc, pq = train.train_ivfpq(base[:nlist * 64], nlist, M, niter=10, pq_niter=10, seed=1234, device=str(dev))
+cc, pq = api.train_ivfpq(base[:nlist * 64], nlist, M)
 g = api.GammaHip(0)
 g.ivfpq_init(d, nlist, M, 8, api.METRIC_L2, bucket_init_size=700)
 g.ivfpq_set_trained(cc, pq, None)

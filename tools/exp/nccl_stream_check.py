@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from gamma_amd import api, synth, train   # noqa: E402
+from gamma_amd import api, synth   # noqa: E402
 from gamma_amd import dist as gdist      # noqa: E402
 
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -19,7 +19,7 @@ dist.init_process_group("nccl", rank=0, world_size=1)
 d, nlist, M, N, nq, k = 64, 64, 8, 20000, 4096, 10
 base = synth.sift_like(N, d=d, seed=1)
 q = synth.sift_like(nq, d=d, seed=2)
-cc, pq = train.train_ivfpq(base[:8000], nlist, M, niter=4, pq_niter=4, seed=3, device="cpu")
+cc, pq = api.train_ivfpq(base[:8000], nlist, M)
 g = api.GammaHip(0)
 g.ivfpq_init(d, nlist, M, 8, api.METRIC_L2, 1000)
 g.ivfpq_set_trained(cc, pq, None)

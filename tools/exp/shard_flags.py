@@ -2,12 +2,12 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
-from gamma_amd import api, synth, train
+from gamma_amd import api, synth
 from gamma_amd import dist as gdist
 W, nq, N, d, nlist, M, P, R, k = 2, 4096, 200000, 128, 1024, 16, 32, 200, 10
 base = synth.sift_like(N, d=d, seed=1234)
 q = synth.sift_like(nq, d=d, seed=4321)
-cc, pq = train.train_ivfpq(base[:nlist * 64], nlist, M, niter=10, pq_niter=25, seed=1234, device="cuda:0")
+cc, pq = api.train_ivfpq(base[:nlist * 64], nlist, M)
 grp = api.GammaHipGroup([0] * W)
 for m in grp.members:
     m.ivfpq_init(d, nlist, M, 8, api.METRIC_L2, 1000)

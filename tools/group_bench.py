@@ -32,14 +32,14 @@ def main():
     ap.add_argument("--placement", default="auto", choices=["auto", "shard", "replicate"])
     a = ap.parse_args()
     import torch
-    from gamma_amd import api, synth, train
+    from gamma_amd import api, synth
     W, d = a.gpus, 128
     devices = [0] * W if a.one_gpu else list(range(W))
     base = synth.sift_like(a.n, d=d, seed=1234)
     gnq = a.nq * W
     nb = 2
     queries = synth.sift_like(gnq * nb, d=d, seed=4321)
-    cc, pq = train.train_ivfpq(base[:min(a.n, a.nlist * 64)], a.nlist, a.m, niter=10, pq_niter=25, seed=1234, device="cuda:0")
+    cc, pq = api.train_ivfpq(base[:min(a.n, a.nlist * 64)], a.nlist, a.m)
     replicate = a.placement == "replicate" or (a.placement == "auto" and a.n * (a.m + 12) <= (2 << 30))
     grp = api.GammaHipGroup(devices)
     grp.set_placement(replicate)

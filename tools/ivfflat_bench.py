@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gamma_amd import api, synth, train  # noqa: E402
+from gamma_amd import api, synth  # noqa: E402
 
 
 def main():
@@ -18,7 +18,7 @@ def main():
     dev = torch.device("cuda", 0)
     base = synth.sift_like(N, d=d, seed=1234)
     q = synth.sift_like(nq, d=d, seed=4321)
-    cc, _ = train.train_ivfpq(base[:nlist * 64], nlist, 16, niter=10, pq_niter=1, seed=1234, device=str(dev))
+    cc, _ = api.train_ivfpq(base[:nlist * 64], nlist, 16)
     g = api.GammaHip(0)
     g.ivfflat_init(d, nlist, api.METRIC_L2, bucket_init_size=max(1000, int(2.5 * N / nlist)))
     g.ivfflat_set_trained(cc)

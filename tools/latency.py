@@ -4,13 +4,13 @@ nq in {1, 4, 16, 64}, median / p99 over 300 calls each, and the device-buffer en
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from gamma_amd import api, synth, train
+from gamma_amd import api, synth
 dev = torch.device("cuda", 0)
 E = lambda n, v: int(os.environ.get(n, v))
 N, d, nlist, M, P, R, k = E("LAT_N", 1000000), E("LAT_D", 128), E("LAT_NLIST", 4096), E("LAT_M", 16), E("LAT_NPROBE", 32), 200, 10
 metric = api.METRIC_IP if os.environ.get("LAT_METRIC", "l2") == "ip" else api.METRIC_L2
 base = synth.sift_like(N, d=d, seed=1234)
-cc, pq = train.train_ivfpq(base[:nlist * 40], nlist, M, niter=5, pq_niter=6, seed=1, device=str(dev))
+cc, pq = api.train_ivfpq(base[:nlist * 40], nlist, M)
 g = api.GammaHip(0)
 g.ivfpq_init(d, nlist, M, 8, metric, bucket_init_size=700)
 g.set_small_path(E("LAT_SMALL", 1) != 0)

@@ -6,7 +6,7 @@ usage: python tools/rank_emul.py [W=8] [nq=8192]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from gamma_amd import api, synth, train
+from gamma_amd import api, synth
 from gamma_amd import dist as gdist
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 nq = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
@@ -17,7 +17,7 @@ gnq = nq * W
 queries = synth.sift_like(gnq * 2, d=d, seed=4321)
 g = api.GammaHip(0)
 g.ivfpq_init(d, nlist, M, 8, api.METRIC_L2, bucket_init_size=max(1000, int(2.5 * N / nlist)))
-cc, pq = train.train_ivfpq(base[:nlist * 64], nlist, M, niter=10, pq_niter=25, seed=1234, device=str(dev))
+cc, pq = api.train_ivfpq(base[:nlist * 64], nlist, M)
 g.ivfpq_set_trained(cc, pq, None)
 lno, codes = g.encode(base)
 list_sizes = np.bincount(lno, minlength=nlist)

@@ -3,7 +3,7 @@ GPU: looks for shape-dependent cliffs away from the benchmarked C3 point.  1M ve
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from gamma_amd import api, synth, train
+from gamma_amd import api, synth
 dev = torch.device("cuda", 0)
 N = 1000000
 SHAPES = [
@@ -30,7 +30,7 @@ for metric, d, M, nlist, P, R, k, nq in SHAPES:
         base = synth.sift_like(n, d=d, seed=1234)
         if metric == "IP":
             base = (base / np.maximum(np.linalg.norm(base, axis=1, keepdims=True), 1e-9)).astype(np.float32)
-        cc, pq = train.train_ivfpq(base[:nlist * 40], nlist, M, niter=5, pq_niter=6, seed=1, device=str(dev))
+        cc, pq = api.train_ivfpq(base[:nlist * 40], nlist, M)
         g = api.GammaHip(0)
         mt = api.METRIC_L2 if metric == "L2" else api.METRIC_IP
         g.ivfpq_init(d, nlist, M, 8, mt, bucket_init_size=max(200, int(2.5 * n / nlist)))
