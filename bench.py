@@ -425,17 +425,23 @@ def main():
             fI = torch.empty((fnq, fk), dtype=torch.int64, device=dev)
             fargs = api.SearchArgs(metric=api.METRIC_L2, min_score=0.0, max_score=1e30)
             sec = timed(lambda: g.flat_search_device(d_q.data_ptr(), fnq, fk, fargs, fD.data_ptr(), fI.data_ptr()), 5, 2)
-            flops = 3.0 * fnq * N * d
+            g.set_exact_ties(False)
+            sec_off = timed(lambda: g.flat_search_device(d_q.data_ptr(), fnq, fk, fargs, fD.data_ptr(), fI.data_ptr()), 5, 2)
+            g.set_exact_ties(not a.no_exact_ties)
             extra["c2_flat"] = {"workload": "C2: flat L2, %dx%d, %d queries/call, k=%d" % (N, d, fnq, fk),
                                 "ms_per_call": round(sec * 1e3, 3), "qps": round(fnq / sec, 1),
-                                # SURVEY 8d counts the GEMM form's 2 nq N d flops; the exact (x - y)^2 order the kernel
-                                # computes (bit-identical to fvec_L2sqr) costs a sub and an fma per element pair = 3
-                                "roofline_gemm_form_flops": {"bound": "valu_fp32", "achieved": round(2.0 * fnq * N * d / sec / 1e12, 2),
+                                "ms_per_call_with_ties_off": round(sec_off * 1e3, 3),
+                                "how": "first 16384 rows exactly for every query; the rest through a bf16 hi/lo filter on the matrix "
+                                       "pipe (3 products, proven margin, csrc/flat_mfma.hip) + the reference's exact arithmetic for "
+                                       "the ~k survivors per query and pass; queries with equal distances among their k + 1 best "
+                                       "replayed through the reference's heap",
+                                # SURVEY 8d counts the GEMM form's 2 nq N d flops against the fp32 matrix / vector peak
+                                "roofline_gemm_form_flops": {"bound": "mfma", "achieved": round(2.0 * fnq * N * d / sec / 1e12, 2),
                                                              "peak": 157.3, "unit": "TFLOP/s",
                                                              "frac": round(2.0 * fnq * N * d / sec / 1e12 / 157.3, 4)},
-                                "roofline": {"bound": "valu_fp32", "achieved": round(flops / sec / 1e12, 2),
-                                             "peak": 157.3, "unit": "TFLOP/s",
-                                             "frac": round(flops / sec / 157.3e12, 4)}}
+                                # the filter kernel's own work: 3 bf16 products per element pair of the rows behind the
+                                # first chunk, against the dense bf16 MFMA peak; its launch times are in profiles/ (rocprofv3)
+                                "filter_bf16_flops_per_call": 6.0 * fnq * max(0, N - 16384) * d}
 
         # (d2) the IVFFLAT model (f4) on the same vectors, centroids and nprobe: exact distances of every entry of the
         #      probed lists, rows gathered from the raw store

@@ -1187,7 +1187,11 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
         }
     }
     // query chunks x row chunks so the distance slab stays inside the budget
-    int64_t rows_chunk = std::max<int64_t>(256, std::min<int64_t>(N, (int64_t)1 << 16));
+    // The matrix-pipe filter (flat_mfma.hip: bf16 hi / lo products with a proven margin, exact distances of the ~k survivors
+    // per query and pass) takes the passes behind the first row chunk when the shape has a variant; the first chunk -- scored
+    // exactly for every query, the only part still on the vector ALU -- is then 16384 rows instead of 65536.
+    const bool mfma_filter = k <= 256 && N < ((int64_t)1 << 32) && gh::flat_filter_supported(nq, d, N);
+    int64_t rows_chunk = std::max<int64_t>(256, std::min<int64_t>(N, (int64_t)1 << (mfma_filter ? 14 : 16)));
     rows_chunk = (rows_chunk + 255) / 256 * 256;
     int qc = (int)std::max<int64_t>(1, std::min<int64_t>(nq, (int64_t)(h->dist_budget_bytes / (rows_chunk * sizeof(float)))));
     const int nchunks = (int)std::max<int64_t>(1, (N + rows_chunk - 1) / rows_chunk);
@@ -1280,9 +1284,31 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
         gh::launch_select_topk(s, l2, h->w_dist.as<float>(), rows_chunk, nullptr, (int)rows_chunk, (int)rows_chunk,
                                nc, k, h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>());
         gh::launch_flat_init(s, l2, h->w_cand_dis.as<float>(), h->w_cand_pos.as<int>(), nc, k, 0, em, tau, lg.kept);
+        const bool mf = mfma_filter && gh::flat_filter_supported(nc, d, N);
+        const int64_t pcap = gh::flat_filter_pair_cap(nc);
+        float* bnd = nullptr;
+        int* npairs = nullptr;
+        if (mf) {   // once per query chunk: norms and the queries' bf16 hi / lo image
+            GH_CHECK(h, h->w_xn.ensure((size_t)nc * sizeof(float)));
+            GH_CHECK(h, h->w_fq.ensure(gh::flat_filter_query_image_bytes(nc, d)));
+            GH_CHECK(h, h->w_fraw.ensure((size_t)pcap * 8));
+            GH_CHECK(h, h->w_frcnt.ensure(64 + gh::flat_filter_bounds_bytes(nc)));   // pair count | bounds
+            npairs = h->w_frcnt.as<int>();
+            bnd = reinterpret_cast<float*>(h->w_frcnt.as<char>() + 64);
+            gh::launch_row_norms(s, xq, nc, d, h->w_xn.as<float>());
+            gh::launch_flat_prep_queries(s, xq, nc, d, h->w_fq.p);
+        }
         for (int64_t r = rows_chunk; r < N;) {
             const int64_t nr = std::min<int64_t>(r, N - r);
-            gh::launch_pairwise_emit(s, l2, xq, nc, d, h->d_raw + r * d, nr, filt, p->min_score, p->max_score, r, em);
+            if (mf) {
+                GH_CHECK(h, hipMemsetAsync(npairs, 0, sizeof(int), s));
+                gh::launch_flat_filter(s, l2, d, h->w_fq.p, h->w_xn.as<float>(), tau, bnd, nc, h->d_raw + r * d, nr, r,
+                                       h->w_fraw.p, npairs, pcap);
+                gh::launch_flat_exact(s, l2, h->w_fraw.p, npairs, pcap, xq, nc, d, h->d_raw, filt, p->min_score, p->max_score,
+                                      em, over);
+            } else {
+                gh::launch_pairwise_emit(s, l2, xq, nc, d, h->d_raw + r * d, nr, filt, p->min_score, p->max_score, r, em);
+            }
             lg.pass++;
             gh::launch_flat_compact(s, nc, k, em, tau, over, ties ? &lg : nullptr);
             r += nr;
@@ -1306,7 +1332,7 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
         }
         bool redo = true;
         if (k <= 256 && N > rows_chunk && N < ((int64_t)1 << 32) &&
-            gh::pairwise_can_emit(nc, d, N - rows_chunk))
+            (gh::pairwise_can_emit(nc, d, N - rows_chunk) || (mfma_filter && gh::flat_filter_supported(nc, d, N))))
             GH_TRY(bounded(q0, nc, &redo));
         if (redo) GH_TRY(unbounded(q0, nc));
         if (ties) {

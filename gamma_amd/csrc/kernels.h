@@ -102,6 +102,19 @@ void launch_flat_compact(hipStream_t s, int nq, int k, const FlatEmit& em, uint3
 void launch_flat_final(hipStream_t s, bool l2, int nq, int k, const FlatEmit& em, float neutral, float* distances,
                        int64_t* labels);
 void launch_row_norms(hipStream_t s, const float* y, int64_t n, int d, float* out);
+// Flat search on the matrix pipe (flat_mfma.hip): a bf16 hi / lo filter with a proven margin + the survivors' exact
+// distances -- appends to the FlatEmit lists exactly the items launch_pairwise_emit would append.
+bool flat_filter_supported(int nq, int d, int64_t ny);
+int64_t flat_filter_pair_cap(int nq);
+size_t flat_filter_query_image_bytes(int nq, int d);
+void launch_flat_prep_queries(hipStream_t s, const float* x, int nq, int d, void* image);
+size_t flat_filter_bounds_bytes(int nq);
+// survivors of the pass as (query, store row) pairs in any order: pairs [cap] of 8 bytes, *npairs appended (zeroed by the caller)
+void launch_flat_filter(hipStream_t s, bool l2, int d, const void* qimage, const float* xn, const uint32_t* tau, float* bounds,
+                        int nq, const float* y, int64_t ny, int64_t row_base, void* pairs, int* npairs, int64_t cap);
+void launch_flat_exact(hipStream_t s, bool l2, const void* pairs, const int* npairs, int64_t cap, const float* x, int nq, int d,
+                       const float* store, const FilterDesc& filt, float min_score, float max_score, const FlatEmit& em,
+                       int* overflow);
 // How the compiled reference's sgemm_ (MKL, the BLAS faiss links in the reference's build) sums the K dimension of
 // exhaustive_L2sqr_blas's x . y^T (faiss:utils/distances.cpp:215-296), measured against the compiled library
 // (oracle/gamma_oracle.c go_gemm_k_split, tests/test_oracle_vs_ref.py): K <= 384 -- one k-ascending fma chain per

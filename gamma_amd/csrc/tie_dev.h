@@ -95,6 +95,14 @@ __device__ __forceinline__ void tie_replay_query(const TieReplayArgs& a, int q, 
     // gamma_index_flat.cc:118-300) -- one candidate at a time, 64 compared with the top per step.  The IVFPQ scanner:
     // heap_replace_top, pipelined (HeapWalk).  take(): one block of <= 64 candidates in stream order, wave 0.
     float ptop = kHeapFltMax;
+    // (heap_pop + heap_push cannot be pipelined the way heap_replace_top is: the next pop starts from slot k, where this
+    //  push ended.  What can be cut is the cost of a level: up to 63 entries the heap lives in ONE register -- node i in
+    //  lane i, a level is two readlanes instead of an LDS round trip (~135 ns per accepted candidate at k = 10); the array
+    //  goes to LDS once, when the stream is through.  With two registers (k <= 127) the lane / register selects cost what the
+    //  LDS round trip does: measured at k = 100, 0.80 ms for a 16384-row slab against 0.74 -- not used.)
+    const bool reg_heap = a.pop_push && R <= 63;
+    RegHeap<1> rh;
+    rh.fill();
     auto take = [&](bool valid, float dv, int pay) {
         if (!a.pop_push) {
             w.accept(valid, dv, pay);
@@ -105,9 +113,15 @@ __device__ __forceinline__ void tie_replay_query(const TieReplayArgs& a, int q, 
         while (m) {
             const int l = (int)__ffsll((long long)m) - 1;
             const float val = hw_readlane_f(dv, l);
-            heap_pop_seq(L.hR, R);
-            heap_push_seq(L.hR, R, val, (unsigned)hw_readlane_i(pay, l));
-            ptop = hs_f(L.hR[1].x);
+            if (reg_heap) {
+                rh.pop(R);
+                rh.push(R, val, (unsigned)hw_readlane_i(pay, l));
+                ptop = rh.top();
+            } else {
+                heap_pop_seq(L.hR, R);
+                heap_push_seq(L.hR, R, val, (unsigned)hw_readlane_i(pay, l));
+                ptop = hs_f(L.hR[1].x);
+            }
             const unsigned long long above = l >= 63 ? 0ull : (~0ull << (l + 1));
             m = __ballot(ptop > dv) & above;
         }
@@ -192,6 +206,7 @@ __device__ __forceinline__ void tie_replay_query(const TieReplayArgs& a, int q, 
         }
     }
     if (wv == 0 && !a.pop_push) w.drain();
+    if (wv == 0 && reg_heap) rh.dump(L.hR, R);
     __syncthreads();
     GH_TT(3);
     // ---- the R-heap is final: array order in hR[1..R].  Positions -> vector ids. ----

@@ -256,16 +256,61 @@ def test_flat_running_bound(order):
             ctx = B.make_ctx(docids_bitmap=bm, **win)
             D, I = B.flat_search(base, q, k, metric, ctx)
             Dg, Ig = g.flat_search(q, k, api.SearchArgs(metric=metric, **win))
-            if order == "ties":
-                # same distances; ids may differ inside exact ties only (heap vs (distance, row id) order)
-                assert np.array_equal(D, Dg)
-                for i in range(nq):
-                    ok = Ig[i] >= 0
-                    dd = ((base[Ig[i][ok]] - q[i]) ** 2).sum(1) if metric == B.METRIC_L2 else (base[Ig[i][ok]] * q[i]).sum(1)
-                    assert np.allclose(dd, Dg[i][ok], rtol=1e-5)
-                    assert len(set(Ig[i][ok].tolist())) == ok.sum()
-            else:
-                compare_exact(D, I, Dg, Ig)
+            compare_exact(D, I, Dg, Ig)      # "ties" too: membership and order inside the ties are the reference heap's
+    finally:
+        g.close()
+
+
+@pytest.mark.parametrize("d,kind", [(128, "near_duplicates"), (64, "wide_range"), (96, "sift"), (32, "near_duplicates"), (128, "unit")])
+def test_flat_matrix_filter_never_drops_a_neighbour(d, kind):
+    """flat_mfma.hip: from 64 queries on the passes behind the first row chunk run a bf16 hi / lo filter on the matrix pipe
+    (three products, a proven error margin) and only the survivors get the reference's exact arithmetic.  The filter must
+    be a SUPERSET test: results identical to the oracle's exhaustive exact search, labels strictly -- on data built to sit
+    on the margin: rows that are tiny perturbations of a few prototypes (thousands of distances within 1e-4 of the k-th),
+    columns spanning six orders of magnitude, unit-norm embeddings; L2 and inner product; deletes, a range filter and a
+    score window; batch sizes with padded tiles."""
+    rng = np.random.default_rng(d)
+    N = 90000
+    if kind == "near_duplicates":
+        proto = (rng.standard_normal((50, d)) * 40).astype(np.float32)
+        base = (proto[rng.integers(0, 50, N)] + rng.standard_normal((N, d)).astype(np.float32) * np.float32(2e-3)).astype(np.float32)
+        q = (proto[rng.integers(0, 50, 200)] + rng.standard_normal((200, d)).astype(np.float32) * np.float32(1e-3)).astype(np.float32)
+    elif kind == "wide_range":
+        scale = (10.0 ** rng.uniform(-3, 3, d)).astype(np.float32)
+        base = (rng.standard_normal((N, d)).astype(np.float32) * scale).astype(np.float32)
+        q = (rng.standard_normal((200, d)).astype(np.float32) * scale).astype(np.float32)
+    elif kind == "unit":
+        base = rng.standard_normal((N, d)).astype(np.float32)
+        base /= np.linalg.norm(base, axis=1, keepdims=True)
+        q = rng.standard_normal((200, d)).astype(np.float32)
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+    else:
+        base = synth.sift_like(N, d=d, seed=7)
+        q = synth.sift_like(200, d=d, seed=8)
+    dead = rng.choice(N, N // 11, replace=False)
+    bm = np.zeros((N >> 3) + 1, dtype=np.uint8)
+    np.bitwise_or.at(bm, dead >> 3, (1 << (dead & 7)).astype(np.uint8))
+    docs = rng.choice(N, 3 * N // 4, replace=False)
+    g = api.GammaHip(0)
+    try:
+        g.raw_init(d)
+        g.raw_append(base)
+        for step in range(2):
+            ctx_kw, kw_f = {}, {}
+            if step == 1:
+                g.bitmap_upload(bm, N)
+                ctx_kw = dict(docids_bitmap=bm, range_filters=[B.make_range_filter(docs)])
+                kw_f = dict(range_filters=[api.make_range_filter(docs)])
+            for metric in (B.METRIC_L2, B.METRIC_IP):
+                for nq, k in ((64, 10), (200, 100), (130, 1)):
+                    wins = [WIDE]
+                    if step == 1 and k == 10:
+                        Dw, _ = B.flat_search(base, q[:nq], k, metric, B.make_ctx(**WIDE, **ctx_kw))
+                        wins.append(dict(min_score=float(np.quantile(Dw, 0.2)), max_score=float(np.quantile(Dw, 0.9))))
+                    for win in wins:
+                        D, I = B.flat_search(base, q[:nq], k, metric, B.make_ctx(**win, **ctx_kw))
+                        Dg, Ig = g.flat_search(q[:nq], k, api.SearchArgs(metric=metric, **win, **kw_f))
+                        compare_exact(D, I, Dg, Ig)
     finally:
         g.close()
 

@@ -3,7 +3,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from gamma_amd import api, synth
-N, d, nq, k = 1000000, 128, 1024, int(sys.argv[1]) if len(sys.argv) > 1 else 100
+N, d, nq, k = int(os.environ.get("FLAT_BENCH_N", "1000000")), 128, int(os.environ.get("FLAT_BENCH_NQ", "1024")), int(sys.argv[1]) if len(sys.argv) > 1 else 100
 base = synth.sift_like(N, d=d, seed=1234)
 q = synth.sift_like(nq, d=d, seed=4321)
 g = api.GammaHip(0)
@@ -25,4 +25,4 @@ for _ in range(n):
     g.flat_search_device(dq.data_ptr(), nq, k, args, D.data_ptr(), I.data_ptr())
 g.synchronize()
 dt = (time.perf_counter() - t0) / n
-print("flat 1M x 128, %d queries, k=%d: %.2f ms per call = %.0f queries/s" % (nq, k, dt * 1e3, nq / dt))
+print("flat %d x 128, %d queries, k=%d: %.2f ms per call = %.0f queries/s" % (N, nq, k, dt * 1e3, nq / dt))
