@@ -174,7 +174,16 @@ def main():
     lno, codes = enc[0].cpu().numpy(), enc[1].cpu().numpy()
     del enc, state
     list_sizes = np.bincount(lno, minlength=nlist)
-    replicate = use_dist and (a.placement == "replicate" or (a.placement == "auto" and N * (M + 12) <= (2 << 30)))
+    # Several GPUs: an index whose lists fit one GPU (<= 2 GiB of codes + ids: C3) is loaded WHOLE on every rank and BOTH
+    # placements are timed in this run -- "shard" (the north star's design: lists split by greedy sum(len), every rank scans
+    # its lists for the whole batch, all-to-all of per-shard top-recall_num, merge + re-rank at the query's owner; the
+    # handle then works under the list mask of its shard) and "replicate" (every rank answers its slice of the batch on the
+    # whole index, one all-gather of the top-k).  `value` is the one --placement names (auto: the faster of the two, named
+    # in config.placement); both figures are in the line.  An index beyond that size is list-sharded, period.
+    fits = N * (M + 12) <= (2 << 30)
+    both = use_dist and fits and a.placement == "auto"
+    replicate = use_dist and (a.placement == "replicate" or both)
+    shard_owner = gdist.balance_lists(list_sizes, world) if use_dist else None
     owner = gdist.balance_lists(list_sizes, 1 if replicate else world)
     mine = owner[lno] == (0 if replicate else rank)
     vids = np.nonzero(mine)[0].astype(np.int64)
@@ -206,12 +215,19 @@ def main():
     if rstream is None:
         g.set_deferred_replay(deferred)
 
+    mode = {"replicate": replicate}     # the placement the steps run (both: switched between the two timed regions)
+
+    def set_placement(rep):
+        mode["replicate"] = rep
+        if both:   # a shard = the whole index under the list mask of this rank
+            g.set_list_mask(None if rep else (shard_owner == rank).astype(np.uint8))
+
     def step(i, stream=True):
         xb = d_q[(i % nbatches) * gnq:(i % nbatches + 1) * gnq]
         if not use_dist:
             g.ivfpq_search_device(xb.data_ptr(), gnq, k, args, d_D.data_ptr(), d_I.data_ptr())
             return d_D, d_I
-        if replicate:
+        if mode["replicate"]:
             if rstream is not None and stream:
                 return rstream.submit(xb)      # the PREVIOUS step's results (None for the first)
             if rstream is None:
@@ -255,32 +271,55 @@ def main():
             g.set_deferred_replay(False)
 
     # ---- timed region ----
-    for i in range(a.warmup):
-        step(i)
-    # stage events inside the timed region (roofline.achieved is the scan kernel's launch duration measured live there).
-    # --timed-events scan / none: fewer / no events in the timed region, the rest from an untimed pass over the same
-    # batches -- the step time is the same within run-to-run noise (all 1.629, scan 1.642, none 1.635 ms, 60 steps each)
-    g.profile_enable({"scan": 2, "all": 1, "none": 0}[a.timed_events])
-    g.profile_reset()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(a.warmup + i)
-    if rstream is not None:
-        rstream.flush()                  # the last step's results: gathered inside the timed region
-    t_enq = time.perf_counter() - t0     # host time to enqueue the steps (log only)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    log("[rank %d] host enqueue %.3f ms/step of %.3f ms/step" % (rank, t_enq / a.steps * 1e3, dt / a.steps * 1e3))
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    prof = prof_timed = g.profile()
+    def timed_region():
+        """W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides; max over the ranks"""
+        for i in range(a.warmup):
+            step(i)
+        # stage events inside the timed region (roofline.achieved is the scan kernel's launch duration measured live there).
+        # --timed-events scan / none: fewer / no events in the timed region, the rest from an untimed pass over the same
+        # batches -- the step time is the same within run-to-run noise (all 1.629, scan 1.642, none 1.635 ms, 60 steps each)
+        g.profile_enable({"scan": 2, "all": 1, "none": 0}[a.timed_events])
+        g.profile_reset()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            step(a.warmup + i)
+        if rstream is not None and mode["replicate"]:
+            rstream.flush()                  # the last step's results: gathered inside the timed region
+        t_enq = time.perf_counter() - t0     # host time to enqueue the steps (log only)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt_ = time.perf_counter() - t0
+        log("[rank %d] %s: host enqueue %.3f ms/step of %.3f ms/step" % (
+            rank, "single GPU" if not use_dist else ("replicate" if mode["replicate"] else "shard"), t_enq / a.steps * 1e3,
+            dt_ / a.steps * 1e3))
+        if world > 1:
+            tt = torch.tensor([dt_], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_ = float(tt.item())
+        return dt_, g.profile()
+
+    placement_qps = {}
+    if both:
+        set_placement(False)
+        dt_s, prof_s = timed_region()
+        set_placement(True)
+        dt_r, prof_r = timed_region()
+        placement_qps = {"shard": gnq * a.steps / dt_s, "replicate": gnq * a.steps / dt_r}
+        if dt_s <= dt_r:          # `value` = the faster placement, named in config.placement
+            set_placement(False)
+            dt, prof_first = dt_s, prof_s
+        else:
+            dt, prof_first = dt_r, prof_r
+        replicate = mode["replicate"]
+    else:
+        dt, prof_first = timed_region()
+        if use_dist:
+            placement_qps = {("replicate" if replicate else "shard"): gnq * a.steps / dt}
+    prof = prof_timed = prof_first
     if a.timed_events != "all":
         # every stage + the algorithmic bytes of the same launches: the same steps again, untimed
         g.profile_enable(True)
@@ -590,9 +629,13 @@ def main():
                         "recall_num=%d, has_rank=%s, k=%d, L2, batch=%d queries/step (%d per GPU)" % (
                             nlist, M, N, d, a.nprobe, a.recall_num, str(not a.no_rank).lower(), k, gnq, a.nq),
             "recall_at_10": None if recall is None else round(recall, 4),
+            "placement": None if not use_dist else ("replicate" if replicate else "shard"),
+            "sharded_qps": None if "shard" not in placement_qps else round(placement_qps["shard"], 1),
+            "replicated_qps": None if "replicate" not in placement_qps else round(placement_qps["replicate"], 1),
             "parallelism": "single GPU" if world == 1 else (
                 ("query-parallel x%d over REPLICATED lists (%.0f MB of lists per GPU: --placement %s), every rank answers "
-                 "its slice of the batch; RCCL all-gather of the top-k" % (world, N * (M + 12) / 1e6, a.placement))
+                 "its slice of the batch; RCCL all-gather of the top-k; the list-sharded placement timed in the same run: "
+                 "config.sharded_qps" % (world, N * (M + 12) / 1e6, a.placement))
                 if replicate else
                 ("IVF lists sharded x%d (greedy by size), queries sliced x%d; RCCL all-gather of "
                  "the coarse assignment, all-to-all of per-shard top-recall_num, all-gather of "
@@ -699,17 +742,22 @@ def plugin_bench(a, base, queries, cc, pq, g, d_q, d_D, d_I, k, args):
                 raise RuntimeError("Add() failed")
         out["add_vectors_per_s"] = round(N / (time.time() - t0), 1)
         rp = '{"nprobe": %d, "recall_num": %d, "metric_type": "L2"}' % (a.nprobe, a.recall_num)
-        for nqb, reps in ((a.nq, 8), (1024, 40)):
+        for nqb, reps in ((a.nq, 20), (1024, 60)):
             qh = np.ascontiguousarray(queries[:nqb])
             Dp, Ip = m.search(qh, k, rp, has_rank=not a.no_rank, min_score=0.0, max_score=1e30)
             g.ivfpq_search_device(d_q.data_ptr(), nqb, k, args, d_D.data_ptr(), d_I.data_ptr())
             torch.cuda.synchronize()
             same = bool(np.array_equal(Ip, d_I[:nqb].cpu().numpy()) and Dp.tobytes() == d_D[:nqb].cpu().numpy().tobytes())
-            t0 = time.perf_counter()
+            ts = []
             for _ in range(reps):
+                t0 = time.perf_counter()
                 m.search(qh, k, rp, has_rank=not a.no_rank, min_score=0.0, max_score=1e30)
-            sec = (time.perf_counter() - t0) / reps
+                ts.append(time.perf_counter() - t0)
+            # median: the host side of a call is CPU work (8 MB in, 2 MB out), and this process runs under a CPU quota --
+            # a throttled period inside a short loop would otherwise be the figure
+            sec = float(np.median(ts))
             out["search_%d" % nqb] = {"qps": round(nqb / sec, 1), "ms_per_call": round(sec * 1e3, 4),
+                                      "ms_per_call_mean": round(float(np.mean(ts)) * 1e3, 4),
                                       "identical_to_the_device_pointer_call": same}
     finally:
         m.close()

@@ -315,7 +315,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     // whose kernel clears it together with the tie flags -- one launch instead of four fills in front of the scan
     const int cap = gh::scan_slice_cap();
     bool cf_ok = false;
-    int PGM = PGN, nsl = PGN;
+    int PGM = PGN, nsl = PGN, cf_span = 0;
     unsigned long long* ready = nullptr;
     if (bounded) {
         // filter pass of the consumers (kernels.hip, CF): needs the sums beside the arena the scan reads -- not the
@@ -325,11 +325,27 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         // (short lists only: with thousands of codes per list the per-pair table costs next to nothing, while ONE consumer
         //  workgroup per query overruns its candidate stage and sends the query to the unfiltered path -- full-size C4, 6100
         //  codes per list: 38.6 ms per 8192 queries with the filter pass, 27.6 without)
+        // Short lists only (mean <= 2000 codes).  With thousands of codes per list the per-pair table costs next to
+        // nothing and the pass loses: full-size C4 (6100 codes per list, 8192 queries) 27.7 ms without it; 38.6 ms with ONE
+        // consumer workgroup per query (it stages more candidates than its 768 slots hold and the query goes to the
+        // unfiltered path); 32.5 ms with the probes behind the producer's cut into consumer groups of ~48 k codes, each
+        // with its own stage and slice (round 4, profiles/r04_scale_runs.txt) -- the margin candidates' exact recompute
+        // and the second look at the codes cost more than the table build they save.  The split (cf_span) stays for the
+        // lists in between: a consumer group takes at most ~64 k codes.
         static const double cf_maxlen = getenv("GAMMA_HIP_SCAN_CF_MAXLEN") ? atof(getenv("GAMMA_HIP_SCAN_CF_MAXLEN")) : 2000.0;
-        cf_ok = !no_cf && (!h->prefiltered || h->cmp_has_sums) && PGN > 1 &&
-                (double)h->ntotal / std::max(1, nlist) <= cf_maxlen &&
+        static const double cf_codes = getenv("GAMMA_HIP_SCAN_CF_CODES") ? atof(getenv("GAMMA_HIP_SCAN_CF_CODES")) : 65536.0;
+        const double mean_len = (double)h->ntotal / std::max(1, nlist);
+        cf_ok = !no_cf && (!h->prefiltered || h->cmp_has_sums) && PGN > 1 && mean_len <= cf_maxlen &&
                 gh::scan_cf_applies(l2, M, P, G, h->d_sums && h->d_t2max, false);
-        PGM = cf_ok ? 2 : PGN;   // probe groups of the main launch
+        if (cf_ok) {
+            const int rest = P - G;
+            int nc = (int)std::ceil(rest * mean_len / cf_codes);
+            nc = std::max(1, std::min(nc, std::max(1, PGN - 1)));
+            cf_span = nc > 1 ? (rest + nc - 1) / nc : 0;
+            PGM = 1 + (nc > 1 ? (rest + cf_span - 1) / cf_span : 1);
+        } else {
+            PGM = PGN;   // probe groups of the main launch
+        }
         nsl = PGM;               // one survivor slice per probe group (slice 0: the producer's own)
         // rq | ready[nq] | gcnt[nq][nsl]   (rq: count + list of the queries that need the repair launch, 8-byte aligned)
         const size_t rq_bytes = (((size_t)nq + 1) * sizeof(int) + 7) & ~(size_t)7;
@@ -435,6 +451,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         sb.rq_list = h->w_scnt.as<int>() + 1;
         sb.sums = cf_ok ? h->d_sums : nullptr;
         sb.t2max = cf_ok ? h->d_t2max : nullptr;
+        sb.cf_span = cf_ok ? cf_span : 0;
         scan(G, 0, PGM, &sb, true);
         static const bool dbg = getenv("GAMMA_HIP_BOUND_DBG") != nullptr;
         static int shown = 0;

@@ -166,6 +166,7 @@ struct ScanBound {
     const float* sums;          // filter pass of the L2 consumers (k_ivfpq_scan_pair<.., CF>): per arena entry
                                 // sum_m T2[list][m][code[m]]; per list sum_m max_c |T2[l][m][c]|.  nullptr: regular loop
     const float* t2max;
+    int cf_span;                // filter pass: probes per consumer group behind the producer's G (0: one consumer takes them all)
 };
 int scan_slice_cap();
 // true when launch_ivfpq_scan_pair would run the filter pass (CF) for a bounded scan with these arguments; the caller

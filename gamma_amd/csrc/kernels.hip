@@ -1517,7 +1517,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
     };
     // (CF: the LAST group takes every probe behind the ones before it -- its table is the query's, not a list's, so
     //  one workgroup per query serves all consumer probes: one table write, one slice)
-    const int p_begin = pg * G, p_end = (CF && pg == pg_cnt - 1) ? P : min(P, p_begin + G);
+    // (long lists: several consumer groups of sb.cf_span probes each, so that no group's candidates outgrow its stage)
+    const int cfs = CF ? sb.cf_span : 0;
+    const int p_begin = (CF && cfs > 0 && pg > 0) ? G + (pg - 1) * cfs : pg * G;
+    const int p_end = CF ? (pg == 0 ? min(P, G) : (cfs > 0 ? min(P, p_begin + cfs) : P)) : min(P, p_begin + G);
     const int tid = threadIdx.x;
     const int msz = M * 256;
     // LDS byte address of this wave's 256-byte segment of a LUT row (lut_store)
@@ -2079,7 +2082,7 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
         const int64_t nq8 = (nq + 7) / 8, nb = (nq8 + SCAN_BATCH - 1) / SCAN_BATCH;
         grid.x = (unsigned)(8 * (SCAN_BATCH + nb * SCAN_BATCH * pg_cnt));
     }
-    ScanBound sb = {nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
+    ScanBound sb = {nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, 0};
     if (bound) sb = *bound;
     // filter pass for the consumers of a bounded L2 scan: needs the per-code sums (sb.sums) and survivor-only consumers
     const bool cf = bound && l2 && !pqc_fused && pg_cnt > 1 && sb.sums && sb.t2max && !sb.store_all && (M == 16 || M == 32);

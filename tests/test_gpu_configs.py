@@ -262,3 +262,20 @@ def test_gemm_form_k_split_matches_the_oracle(d, nlist):
             assert np.array_equal(pr.cpu().numpy().astype(np.int64), Io), (d, nq)
     finally:
         g.close()
+
+
+def test_filter_pass_with_several_consumer_groups():
+    """Long lists: the scan's filter pass cuts the probes behind the producer's into several consumer groups
+    (gamma_hip_search.cpp, cf_span).  The shapes of this suite have short lists, so the split is forced here through
+    GAMMA_HIP_SCAN_CF_CODES (read once per process: a child process) on the bounded-scan parity tests and the C3 headline
+    test -- strict comparisons, as in the parent."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GAMMA_HIP_SCAN_CF_CODES="1500")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_more.py", "tests/test_gpu_ties.py",
+                        "-k", "scan_bound_parity_at_batch_size or c3_headline or bounded_scan or large_batch_search"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
