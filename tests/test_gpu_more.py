@@ -1544,3 +1544,40 @@ def test_profile_levels_and_the_state_the_pair_offset_kernel_clears(case):
         g.profile_enable(0)
     finally:
         g.close()
+
+
+def test_large_host_buffer_calls_are_the_device_pointer_call(c3):
+    """A large host-buffer call (what RetrievalModel::Search hands over) == the device-pointer call, bit for bit: several
+    sizes, with and without re-rank, ties on and off, several scan chunks (a small workspace budget).  (Round 4 built a
+    pipelined form of this call -- queries uploaded in chunks behind which the coarse quantizer ran, results fetched beside
+    the tie replay -- and measured it SLOWER than upload / search / download: tools/host_call_bench.py, DESIGN.md.)"""
+    import torch
+    g = c3["g"]
+    q = synth.sift_like(16384 + 777, d=128, seed=4321)
+    dev = torch.device("cuda", 0)
+    dq = torch.from_numpy(q).to(dev)
+    try:
+        for nq, k, R, has_rank, ties in ((16384, 10, 200, True, 0), (4096, 10, 200, True, 0), (16384 + 777, 10, 200, True, 0),
+                                         (5000, 10, 100, False, 0), (8192, 50, 200, True, -1), (4100, 1, 100, True, 0)):
+            args = api.SearchArgs(metric=api.METRIC_L2, nprobe=32, recall_num=R, has_rank=has_rank, min_score=0.0, max_score=1e30,
+                                  exact_ties=ties)
+            D = torch.empty((nq, k), dtype=torch.float32, device=dev)
+            I = torch.empty((nq, k), dtype=torch.int64, device=dev)
+            g.ivfpq_search_device(dq.data_ptr(), nq, k, args, D.data_ptr(), I.data_ptr())
+            g.synchronize()
+            g.tie_stats(reset=True)
+            Dh, Ih = g.ivfpq_search(q[:nq], k, args)
+            assert Dh.tobytes() == D.cpu().numpy().tobytes() and np.array_equal(Ih, I.cpu().numpy()), (nq, k, R, has_rank, ties)
+            if ties == 0 and has_rank and nq >= 8192:
+                assert g.tie_stats()["replayed"] > 0       # (integer data: some rows did go through the replay and the patch)
+        g.set_dist_budget(64 << 20)      # several scan chunks per call
+        args = api.SearchArgs(metric=api.METRIC_L2, nprobe=32, recall_num=200, has_rank=True, min_score=0.0, max_score=1e30)
+        nq, k = 16384, 10
+        D = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        I = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        g.ivfpq_search_device(dq.data_ptr(), nq, k, args, D.data_ptr(), I.data_ptr())
+        g.synchronize()
+        Dh, Ih = g.ivfpq_search(q[:nq], k, args)
+        assert Dh.tobytes() == D.cpu().numpy().tobytes() and np.array_equal(Ih, I.cpu().numpy())
+    finally:
+        g.set_dist_budget(32 << 30)
