@@ -1,0 +1,325 @@
+// rerank.hip -- a9: candidate positions -> ids, exact re-rank (compute_dis), the IVFFLAT pair scan, result finalisation.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <utility>
+
+#include "block_utils.h"
+#include "device_math.h"
+#include "filter_dev.h"
+#include "kernels.h"
+#include "rerank_dev.h"
+#include "scan_dev.h"
+
+namespace gh {
+
+// ------------------------------------------------------------------------------------
+// positions in a query's candidate segment -> vector ids (KnnSearchResults::add stores
+// ids[j], gamma_index_ivfpq.h:363-369).  grid = nq.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_map_candidates(const int* __restrict__ pos, int R, int P,
+                                                        const int* __restrict__ probe_list,
+                                                        const int* __restrict__ pair_off,
+                                                        const int64_t* __restrict__ list_off,
+                                                        const int64_t* __restrict__ ids,
+                                                        int64_t* __restrict__ cand_ids,
+                                                        const uint8_t* __restrict__ only) {
+    const int q = blockIdx.x;
+    if (only && !only[q]) return;   // rows k_select_final has already mapped
+    const int* off = pair_off + (int64_t)q * (P + 1);
+    for (int r = threadIdx.x; r < R; r += 256) {
+        const int ps = pos[(int64_t)q * R + r];
+        int64_t id = -1;
+        if (ps >= 0) {
+            // last p with off[p] <= ps
+            int lo = 0, hi = P - 1;
+            while (lo < hi) {
+                int mid = (lo + hi + 1) >> 1;
+                if (off[mid] <= ps) lo = mid; else hi = mid - 1;
+            }
+            const int l = probe_list[(int64_t)q * P + lo];
+            id = ids[list_off[l] + (ps - off[lo])] & 0x7fffffffffffffffLL;
+        }
+        cand_ids[(int64_t)q * R + r] = id;
+    }
+}
+void launch_map_candidates(hipStream_t s, const int* pos, int nq, int R, int P,
+                           const int* probe_list, const int* pair_off, const int64_t* list_off,
+                           const int64_t* ids, int64_t* cand_ids, const uint8_t* only) {
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(k_map_candidates, dim3(nq), dim3(256), 0, s, pos, R, P, probe_list, pair_off,
+                       list_off, ids, cand_ids, only);
+}
+
+// ------------------------------------------------------------------------------------
+// a9: exact re-rank distances (compute_dis, gamma_index_ivfpq.cc:642-680).  8 threads
+// per candidate = the 8 lane accumulators of fvec_L2sqr / fvec_inner_product; the
+// cross-lane reduction mirrors extractf128 + add + 2x haddps.  grid = nq, block = 256
+// (32 candidates in flight).  Out-of-window scores and empty slots get the sentinel.
+// ------------------------------------------------------------------------------------
+template <bool L2>
+__global__ __launch_bounds__(256) void k_rerank_dist(const float* __restrict__ x, int d,
+                                                     const float* __restrict__ raw, int64_t nraw,
+                                                     const int64_t* __restrict__ cand_ids, int R,
+                                                     float min_score, float max_score,
+                                                     float* __restrict__ out) {
+    const int q = blockIdx.x;
+    const int l = threadIdx.x & 7, g = threadIdx.x >> 3;
+    const float* xq = x + (int64_t)q * d;
+    const float sentinel = L2 ? INFINITY : -INFINITY;
+    for (int r0 = blockIdx.y * 32; r0 < R; r0 += gridDim.y * 32) {
+        const int r = r0 + g;
+        int64_t id = -1;
+        if (r < R) id = cand_ids[(int64_t)q * R + r];
+        const bool live = id >= 0 && id < nraw;
+        float dis = rerank_dist8<L2>(xq, raw + (live ? id : 0) * d, d, l, live);
+        if (l == 0 && r < R) {
+            if (!live || !(dis <= max_score && dis >= min_score)) dis = sentinel;
+            out[(int64_t)q * R + r] = dis;
+        }
+    }
+}
+void launch_rerank_dist(hipStream_t s, bool l2, const float* x, int nq, int d, const float* raw,
+                        int64_t nraw, const int64_t* cand_ids, int R, float min_score,
+                        float max_score, float* out) {
+    if (nq <= 0) return;
+    const int gy = (R + 31) / 32;   // 32 candidates (8 lanes each) per workgroup
+    if (l2)
+        hipLaunchKernelGGL((k_rerank_dist<true>), dim3(nq, gy), dim3(256), 0, s, x, d, raw, nraw, cand_ids,
+                           R, min_score, max_score, out);
+    else
+        hipLaunchKernelGGL((k_rerank_dist<false>), dim3(nq, gy), dim3(256), 0, s, x, d, raw, nraw,
+                           cand_ids, R, min_score, max_score, out);
+}
+
+// ------------------------------------------------------------------------------------
+// a9, fused: exact re-rank distances + top-k + output in ONE kernel (compute_dis with
+// has_rank, gamma_index_ivfpq.cc:646-680).  One workgroup per query: the R exact distances
+// become (key, candidate rank) items in LDS, a block rank sort orders them -- equal exact
+// distances keep the ADC order of the candidates -- and the first k go out with their ids
+// (empty slots: -1 / heap neutral).  R <= 1024.
+// ------------------------------------------------------------------------------------
+template <bool L2>
+__global__ __launch_bounds__(256) void k_rerank_topk(const float* __restrict__ x, int d,
+                                                     const float* __restrict__ raw, int64_t nraw,
+                                                     const int64_t* __restrict__ cand_ids, int R, int k,
+                                                     float min_score, float max_score, float neutral,
+                                                     float* __restrict__ distances,
+                                                     int64_t* __restrict__ labels, int nq,
+                                                     const int* __restrict__ qperm, TieFlags tf) {
+    __shared__ unsigned long long s_it[1024];
+    __shared__ int64_t s_id[1024];
+    __shared__ int s_tie;
+    // With the scan's query order (qperm: queries sorted by the spatial rank of their nearest list) XCD x takes
+    // the x-th eighth of that order: queries running together share candidates (a batch references every raw
+    // row ~3 times), so their rows are served by that XCD's L2 instead of HBM.  Results do not depend on it.
+    int q = blockIdx.x;
+    if (qperm) {
+        const int qi = (blockIdx.x & 7) * ((nq + 7) >> 3) + (blockIdx.x >> 3);
+        if (qi >= nq) return;
+        q = qperm[qi];
+    } else if (q >= nq) {
+        return;
+    }
+    const int l = threadIdx.x & 7, g = threadIdx.x >> 3;
+    const float* xq = x + (int64_t)q * d;
+    const float sentinel = L2 ? INFINITY : -INFINITY;
+    // all candidate ids first (one coalesced pass): the row gathers below then start without a
+    // dependent id load in front of each of them
+    for (int r = threadIdx.x; r < R; r += 256) s_id[r] = cand_ids[(int64_t)q * R + r];
+    __syncthreads();
+    for (int r0 = 0; r0 < R; r0 += 32) {
+        const int r = r0 + g;
+        int64_t id = -1;
+        if (r < R) id = s_id[r];
+        const bool live = id >= 0 && id < nraw;
+        float dis = rerank_dist8<L2>(xq, raw + (live ? id : 0) * d, d, l, live);
+        if (l == 0 && r < R) {
+            if (!live || !(dis <= max_score && dis >= min_score)) dis = sentinel;
+            const uint32_t key = L2 ? f2key(dis) : ~f2key(dis);
+            s_it[r] = ((unsigned long long)key << 32) | (unsigned)r;
+        }
+    }
+    if (tf.list && threadIdx.x == 0) s_tie = tf.cut ? tf.cut[q] : 0;
+    block_rank_sort<256, 4>(s_it, R);   // R distinct items (the rank field differs)
+    if (tf.list) {
+        // exact ties (ties.hip): two of the first k+1 exact distances equal -- their order, or which of them
+        // stays inside the k, is decided by the reference's heaps -- or the top-R cut went through a tie
+        for (int i = threadIdx.x; i < k && i + 1 < R; i += 256) {
+            const uint32_t ka = (uint32_t)(s_it[i] >> 32), kb = (uint32_t)(s_it[i + 1] >> 32);
+            if (ka == kb && ka != (L2 ? f2key(sentinel) : ~f2key(sentinel))) s_tie = 1;   // benign race: same value
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && s_tie) {
+            tf.list[atomicAdd(tf.count, 1)] = q;
+            if (tf.stats) atomicAdd(tf.stats + 2, 1ull);
+        }
+    }
+    for (int i = threadIdx.x; i < k; i += 256) {
+        float val = neutral;
+        int64_t id = -1;
+        if (i < R) {
+            const unsigned long long it = s_it[i];
+            const uint32_t key = (uint32_t)(it >> 32);
+            const float dv = key2f(L2 ? key : ~key);
+            if (dv != sentinel) {
+                val = dv;
+                id = s_id[(uint32_t)it];
+            }
+        }
+        distances[(int64_t)q * k + i] = val;
+        labels[(int64_t)q * k + i] = id;
+    }
+}
+void launch_rerank_topk(hipStream_t s, bool l2, const float* x, int nq, int d, const float* raw,
+                        int64_t nraw, const int64_t* cand_ids, int R, int k, float min_score,
+                        float max_score, float neutral, float* distances, int64_t* labels, const int* qperm,
+                        const TieFlags* ties) {
+    if (nq <= 0) return;
+    const dim3 grid((unsigned)(8 * ((nq + 7) / 8)));
+    const TieFlags tf = ties ? *ties : TieFlags{};
+    if (l2)
+        hipLaunchKernelGGL((k_rerank_topk<true>), grid, dim3(256), 0, s, x, d, raw, nraw, cand_ids,
+                           R, k, min_score, max_score, neutral, distances, labels, nq, qperm, tf);
+    else
+        hipLaunchKernelGGL((k_rerank_topk<false>), grid, dim3(256), 0, s, x, d, raw, nraw, cand_ids,
+                           R, k, min_score, max_score, neutral, distances, labels, nq, qperm, tf);
+}
+
+// ------------------------------------------------------------------------------------
+// IVFFLAT list scan (GammaIVFFlatScanner1::scan_codes, index/impl/gamma_index_ivfflat.h:52-75): the reference's
+// lists hold the vectors themselves; here a list holds vector ids and the rows come from the raw store (the same
+// floats).  One workgroup per (query, probe) pair, eight threads per list entry = the eight AVX lane accumulators
+// of fvec_L2sqr / fvec_inner_product (rerank_dev.h).  Entries with bit 63, filtered docs and scores outside the
+// window get the sentinel; one fp32 per entry into the query's slab at the pair's offset.
+// ------------------------------------------------------------------------------------
+template <bool L2>
+__global__ __launch_bounds__(256) void k_ivfflat_scan(const float* __restrict__ x, int d, int P,
+                                                      const int* __restrict__ pair_off,
+                                                      const int64_t* __restrict__ pair_base,
+                                                      const int64_t* __restrict__ ids,
+                                                      const float* __restrict__ raw, int64_t nraw, int64_t q_stride,
+                                                      float* __restrict__ out, const FilterDesc* __restrict__ ftab,
+                                                      int need_filter, float min_score, float max_score) {
+    const int q = blockIdx.x / P, p = blockIdx.x - q * P;
+    const int off = pair_off[(int64_t)q * (P + 1) + p], len = pair_off[(int64_t)q * (P + 1) + p + 1] - off;
+    if (len <= 0) return;   // uniform
+    const int64_t base = pair_base[(int64_t)q * P + p];
+    const float* xq = x + (int64_t)q * d;
+    const int l8 = threadIdx.x & 7, g = threadIdx.x >> 3;
+    const float sentinel = L2 ? INFINITY : -INFINITY;
+    for (int j0 = 0; j0 < len; j0 += 32) {
+        const int j = j0 + g;
+        int64_t id = -1;
+        if (j < len) id = ids[base + j];
+        const int64_t vid = id & 0x7fffffffffffffffLL;
+        bool live = j < len && id >= 0 && vid < nraw;   // id < 0: bit 63, superseded by an Update
+        if (need_filter && live) live = is_valid_doc(ftab[0], vid);
+        float dis = rerank_dist8<L2>(xq, raw + (live ? vid : 0) * d, d, l8, live);
+        if (l8 == 0 && j < len) {
+            if (!live || !(dis <= max_score && dis >= min_score)) dis = sentinel;
+            out[(int64_t)q * q_stride + off + j] = dis;
+        }
+    }
+}
+void launch_ivfflat_scan(hipStream_t s, bool l2, const float* x, int nq, int d, int P, const int* pair_off,
+                         const int64_t* pair_base, const int64_t* ids, const float* raw, int64_t nraw, int64_t q_stride,
+                         float* out, const FilterDesc* ftab, int need_filter, float min_score, float max_score) {
+    if (nq <= 0 || P <= 0) return;
+    const dim3 grid((unsigned)((int64_t)nq * P));
+    if (l2)
+        hipLaunchKernelGGL((k_ivfflat_scan<true>), grid, dim3(256), 0, s, x, d, P, pair_off, pair_base, ids, raw, nraw,
+                           q_stride, out, ftab, need_filter, min_score, max_score);
+    else
+        hipLaunchKernelGGL((k_ivfflat_scan<false>), grid, dim3(256), 0, s, x, d, P, pair_off, pair_base, ids, raw, nraw,
+                           q_stride, out, ftab, need_filter, min_score, max_score);
+}
+
+// final outputs from a top-k selection over re-ranked (or flat) candidates:
+//   labels = src_ids ? src_ids[q][pos] : id_base + pos ; empty -> -1 / heap neutral
+__global__ __launch_bounds__(256) void k_finalize_topk(const float* __restrict__ sel_vals,
+                                                       const int* __restrict__ sel_pos, int k,
+                                                       const int64_t* __restrict__ src_ids,
+                                                       int64_t src_stride, int64_t id_base,
+                                                       float neutral,
+                                                       float* __restrict__ distances,
+                                                       int64_t* __restrict__ labels, int n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)n * k) return;
+    const int q = (int)(i / k);
+    const int ps = sel_pos[i];
+    if (ps < 0) {
+        distances[i] = neutral;
+        labels[i] = -1;
+    } else {
+        distances[i] = sel_vals[i];
+        labels[i] = src_ids ? src_ids[(int64_t)q * src_stride + ps] : id_base + (int64_t)ps;
+    }
+}
+void launch_finalize_topk(hipStream_t s, const float* sel_vals, const int* sel_pos, int nq, int k,
+                          const int64_t* src_ids, int64_t src_stride, int64_t id_base,
+                          float neutral, float* distances, int64_t* labels) {
+    if (nq <= 0 || k <= 0) return;
+    int64_t tot = (int64_t)nq * k;
+    hipLaunchKernelGGL(k_finalize_topk, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, sel_vals,
+                       sel_pos, k, src_ids, src_stride, id_base, neutral, distances, labels, nq);
+}
+
+// has_rank == false (gamma_index_ivfpq.cc:681-696): candidates are already sorted by ADC
+// distance; copy the first k whose score is inside the window.  grid = nq.
+__global__ __launch_bounds__(256) void k_finalize_norank(const float* __restrict__ cand_dis,
+                                                         const int64_t* __restrict__ cand_ids, int R,
+                                                         int k, float min_score, float max_score,
+                                                         float neutral, float* __restrict__ distances,
+                                                         int64_t* __restrict__ labels, TieFlags tf) {
+    __shared__ int s_w[4];
+    __shared__ int s_tie;
+    const int q = blockIdx.x;
+    int running = 0;
+    if (tf.list && threadIdx.x == 0) s_tie = tf.cut ? tf.cut[q] : 0;
+    for (int r0 = 0; r0 < R && running < k; r0 += 256) {
+        const int r = r0 + threadIdx.x;
+        float dis = 0.f;
+        int64_t id = -1;
+        if (r < R) {
+            dis = cand_dis[(int64_t)q * R + r];
+            id = cand_ids[(int64_t)q * R + r];
+        }
+        const int flag = (id != -1 && dis <= max_score && dis >= min_score) ? 1 : 0;
+        int tot;
+        const int ex = block_excl_scan256(flag, s_w, tot);
+        const int slot = running + ex;
+        if (flag && slot < k) {
+            distances[(int64_t)q * k + slot] = dis;
+            labels[(int64_t)q * k + slot] = id;
+            // exact ties (ties.hip): an entry that is taken and its successor at the same ADC distance -- their
+            // order, or which of them is the k-th, is whatever heap_reorder of the reference's R-heap leaves
+            if (tf.list && r + 1 < R && cand_ids[(int64_t)q * R + r + 1] != -1 &&
+                cand_dis[(int64_t)q * R + r + 1] == dis)
+                s_tie = 1;
+        }
+        running += tot;
+    }
+    if (tf.list) {
+        __syncthreads();
+        if (threadIdx.x == 0 && s_tie) {
+            tf.list[atomicAdd(tf.count, 1)] = q;
+            if (tf.stats) atomicAdd(tf.stats + 2, 1ull);
+        }
+    }
+    for (int i = min(running, k) + threadIdx.x; i < k; i += 256) {
+        distances[(int64_t)q * k + i] = neutral;
+        labels[(int64_t)q * k + i] = -1;
+    }
+}
+void launch_finalize_norank(hipStream_t s, const float* cand_dis, const int64_t* cand_ids, int nq,
+                            int R, int k, float min_score, float max_score, float neutral,
+                            float* distances, int64_t* labels, const TieFlags* ties) {
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(k_finalize_norank, dim3(nq), dim3(256), 0, s, cand_dis, cand_ids, R, k,
+                       min_score, max_score, neutral, distances, labels, ties ? *ties : TieFlags{});
+}
+
+}  // namespace gh

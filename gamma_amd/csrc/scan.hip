@@ -1,0 +1,811 @@
+// scan.hip -- a4 + a5 + a6 + a8: the IVFPQ inverted-list scan (the roofline kernel), its threshold pre-filter and the
+// filter pass of the L2 consumers.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <utility>
+
+#include "block_utils.h"
+#include "device_math.h"
+#include "filter_dev.h"
+#include "kernels.h"
+#include "rerank_dev.h"
+#include "scan_dev.h"
+
+namespace gh {
+
+// ------------------------------------------------------------------------------------
+// a4+a5+a6+a8: IVFPQ list scan, one workgroup per (query, probe) pair.
+//   LUT (M x 256 fp32) built in LDS:  L2: lut = T2[list] + (-2) * st2[q]  (fvec_madd)
+//                                     IP: lut = st2[q]
+//   dis0: L2 = coarse distance; IP = <x_q, centroid> in fvec_inner_product order.
+//   per code j:  skip if ids[j] bit 63 / !IsValid;  dis = dis0; for m: dis += lut[m][code[m]]
+//   (sequential fp32 adds, gamma_index_ivfpq.h:591-597).  Distances go to the pair's slot
+//   range in out; filtered entries get the sentinel.
+// Codes are AoS [len][M] exactly as the reference stores them; a 16-byte code is one
+// dwordx4 load per lane, so a wave reads 1 KiB contiguous.
+// ------------------------------------------------------------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int SCAN_STAGE = 256;                  // survivors staged in LDS per workgroup
+constexpr int SCAN_SLICE = 1024;                 // candidate slice of one workgroup (global); a producer needs recall_num + one histogram bin
+constexpr int SCAN_BATCH = 64;                   // queries per XCD by which producers run ahead
+
+// amdgpu_num_sgpr(96): 8 waves per SIMD need <= 96 SGPRs each (800 per SIMD); the FILT variant
+// would otherwise take 100 and lose one of the eight resident workgroups per CU
+// IPF (sharded search with every probe of a query in ONE workgroup): the query's table <x_q,m , c_mj> is
+// computed here from the PQ codebook (128 KB, L2 resident; `st2` then points at it) instead of being
+// written to HBM by k_pq_ip_table and read back -- with W shards that table is W x 16 KB per query of
+// traffic that does not shrink with the shard, and each of its entries would be read exactly once.
+// CF (L2, FILT, MT 16 / 32, large batches): the consumer groups of a query with a bound run a FILTER pass without the
+// per-list table -- see "filter pass" in the body.
+constexpr int SCAN_CF_CAP = 768;   // filter-pass candidates staged per workgroup (8 bytes each)
+template <bool L2, int MT, bool FILT, bool IPF = false, bool UNITS = false, bool CF = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_ivfpq_scan_pair(
+        const float* __restrict__ x, int nq, int d, int M, int P, int G, const int* __restrict__ probe_list,
+        const float* __restrict__ coarse_dis, const float* __restrict__ cc,
+        const float* __restrict__ st2, const float* __restrict__ T2,
+        const int64_t* __restrict__ list_off, const int* __restrict__ list_len,
+        const uint8_t* __restrict__ list_mask, int nlist, const uint8_t* __restrict__ codes,
+        const int64_t* __restrict__ ids, const int* __restrict__ pair_off, int64_t q_stride,
+        float* __restrict__ out, const FilterDesc* __restrict__ ftab, const int* __restrict__ qfil, int need_ids,
+        float sentinel, const int* __restrict__ qperm, int pg_lo, int pg_cnt, int sparse, ScanBound sb,
+        const int* __restrict__ rq_list, const int* __restrict__ rq_count, int chunk_len) {
+    // UNITS (small batches over long lists, G = 1, no bound; a variant of its own so that the bulk kernel carries
+    // none of its state): rq_list is a work list of
+    // (query << 20 | probe << 13 | chunk) units written by k_small_coarse_select, one per chunk_len codes of a
+    // (query, probe) pair, walked by a fixed grid -- one query's 64 long lists are then a few hundred pieces of
+    // even size instead of 64 workgroups that run for as long as the longest list takes.
+    // This launch covers probe groups [pg_lo, pg_lo + pg_cnt) of every query.
+    // FILT (pg_lo = 0, pg_cnt >= 2): threshold pre-filter.  The workgroup of a query's FIRST probe
+    // group (its nearest lists) ends by bounding the query's recall_num-th best distance from above
+    // with the candidates it has just scored, and publishes that bound; the workgroups of the other
+    // groups append every candidate within the bound, as a (key, position) item, to the query's
+    // short survivor list.  The exact top-recall_num is then selected from the first group's
+    // candidates within the bound plus a few hundred survivors, instead of all ~10^4 candidates
+    // (select.hip, k_select_final).
+    // One workgroup scans G consecutive probes of one query: the query's 16 KB table st2 is
+    // read ONCE into registers (MT per thread) and reused for the G list-specific LUTs, so
+    // the per-pair table traffic drops from 2 x M KB to (1 + 1/G) x M KB.
+    extern __shared__ float s_lut[];  // M*256
+    // XCD-aware placement (speed only): block b runs on XCD b % 8 with its own L2, so all PGN
+    // workgroups of one query are given block ids with the same residue -- the query's table
+    // st2[q] is then fetched from HBM/MALL once per XCD and served from that L2 afterwards.
+    // With qperm (queries sorted by the spatial rank of their nearest list, k_query_order) XCD x
+    // takes the x-th contiguous eighth of that order, in order: concurrently running queries
+    // probe overlapping lists, so the 16 KB T2 rows they stream are mostly L2 hits as well.
+    const int xcd = blockIdx.x & 7;
+    int slot = blockIdx.x >> 3, pg, qslot;
+    if (FILT) {
+        // Block order inside an XCD (slot = XCD-local index): producers (group 0, they publish
+        // the bounds) run one batch of SCAN_BATCH queries AHEAD of the consumers (other groups):
+        //   P(0) | P(1) C(0) | P(2) C(1) | ...
+        // Workgroups are dispatched in id order, so a consumer only ever waits for a producer that
+        // is already resident or finished -- and it starts >= SCAN_BATCH * pg_cnt dispatches after
+        // its producer, by when the bound is normally there.  The query's table st2[q] is still in
+        // this XCD's L2 when its consumers arrive.
+        const int nq8 = (nq + 7) >> 3;
+        if (slot < SCAN_BATCH) {
+            pg = 0;
+            qslot = slot;
+        } else {
+            const int s2 = slot - SCAN_BATCH, period = SCAN_BATCH * pg_cnt;
+            const int t = s2 / period, r = s2 % period;
+            if (r < SCAN_BATCH) {
+                pg = 0;
+                qslot = (t + 1) * SCAN_BATCH + r;
+            } else {
+                const int i = r - SCAN_BATCH;
+                pg = 1 + i % (pg_cnt - 1);
+                qslot = t * SCAN_BATCH + i / (pg_cnt - 1);
+            }
+        }
+        if (qslot >= nq8) return;
+    } else {
+        pg = pg_lo + slot % pg_cnt;
+        qslot = slot / pg_cnt;
+    }
+    const bool repair = !FILT && rq_list != nullptr;
+    int q = 0;
+    if (repair) {
+        // repair launch (launch_ivfpq_scan_repair): a fixed grid walks the (query, probe group) items of the
+        // queries k_select_final could not finish from their survivor slices -- consumer groups with a bound
+        // do not store distances (finish() below) -- and scores those groups again, storing everything
+    } else if (qperm) {
+        const int qi = xcd * ((nq + 7) >> 3) + qslot;
+        if (qi >= nq) return;
+        q = qperm[qi];
+    } else {
+        q = qslot * 8 + xcd;
+        if (q >= nq) return;
+    }
+    // ALL of the kernel's LDS is the dynamic buffer, the LUT first: its LDS address is then the constant 0 and a
+    // gather address is just (code byte << 2) + an immediate offset (one VALU op per look-up instead of two)
+    unsigned long long* s_stage = reinterpret_cast<unsigned long long*>(s_lut + M * 256);   // [SCAN_STAGE]
+    int& s_nstage = *reinterpret_cast<int*>(s_stage + SCAN_STAGE);
+    uint32_t& s_tau = *(reinterpret_cast<uint32_t*>(s_stage + SCAN_STAGE) + 1);
+    uint32_t* s_red = reinterpret_cast<uint32_t*>(s_stage + SCAN_STAGE) + 2;                  // [12]
+    int& s_ncand = *(reinterpret_cast<int*>(s_stage + SCAN_STAGE) + 14);                       // CF: staged candidates
+    uint2* s_cand = reinterpret_cast<uint2*>(reinterpret_cast<int*>(s_stage + SCAN_STAGE) + 16);  // CF: [SCAN_CF_CAP]
+    int cbase = 0;     // unit mode: first code of the unit within its list
+    int lut_q = -1;    // unit mode, inner product: the query whose table is in LDS
+    int lut_pair = -1; // unit mode, L2: the (query, probe) pair whose table is in LDS
+    auto body = [&](const int q, const int pg) {
+    // validity predicates of THIS query: entry qfil[q] of the call's filter table (one entry unless the
+    // call is a combined batch of requests with their own filters); only read when need_ids
+    const FilterDesc& filt = ftab[(need_ids && qfil) ? qfil[q] : 0];
+    const int lane = threadIdx.x & 63;
+    // Survivors are staged in LDS (one LDS atomic per wave and iteration) and flushed to the
+    // query's list with ONE global atomic per workgroup; a returning global atomic per wave
+    // iteration would put ~1 us of latency into the scan loop.  All lanes of a wave call append().
+    uint32_t tauq = 0xffffffffu;
+    float tau_f = sentinel;   // the bound as a distance: a candidate survives iff it is not worse than tau_f
+    bool bound_on = false;
+    // producer (pg == 0): range and count of its valid distances.  Kept as floats (one min, one max per code
+    // instead of a key conversion and two compare-selects), turned into keys once at the end.
+    float g_fmn = INFINITY, g_fmx = -INFINITY;
+    int g_nv = 0;
+    auto within = [&](float val) -> bool { return L2 ? val <= tau_f : val >= tau_f; };
+    auto append = [&](bool keep, float val, int pos) {
+        const unsigned long long bal = __ballot(keep);
+        if (bal) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_nstage, __popcll(bal));
+            base = __shfl(base, 0, 64);
+            if (keep) {
+                const int at = base + __popcll(bal & ((1ull << lane) - 1ull));
+                const unsigned long long item = ((unsigned long long)dis_key<L2>(val) << 32) | (unsigned)pos;
+                if (at < SCAN_STAGE) s_stage[at] = item;
+                else if (at < SCAN_SLICE)   // staging full (rare): the slot number is already unique
+                    sb.surv[((int64_t)q * pg_cnt + pg) * SCAN_SLICE + at] = item;
+            }
+        }
+    };
+    // every consumer workgroup owns one fixed slice of its query's survivor list: no global
+    // atomics, the count (> SCAN_SLICE = overflowed) is a plain store
+    auto flush = [&]() {   // whole workgroup
+        __syncthreads();
+        const int n = s_nstage;
+        const int64_t slice = (int64_t)q * pg_cnt + pg;
+        if (threadIdx.x == 0) sb.gcnt[(int64_t)q * sb.cnt_stride + pg] = n;
+        for (int i = threadIdx.x; i < min(n, SCAN_STAGE); i += 256) sb.surv[slice * SCAN_SLICE + i] = s_stage[i];
+    };
+    // (CF: the LAST group takes every probe behind the ones before it -- its table is the query's, not a list's, so
+    //  one workgroup per query serves all consumer probes: one table write, one slice)
+    // (long lists: several consumer groups of sb.cf_span probes each, so that no group's candidates outgrow its stage)
+    const int cfs = CF ? sb.cf_span : 0;
+    const int p_begin = (CF && cfs > 0 && pg > 0) ? G + (pg - 1) * cfs : pg * G;
+    const int p_end = CF ? (pg == 0 ? min(P, G) : (cfs > 0 ? min(P, p_begin + cfs) : P)) : min(P, p_begin + G);
+    const int tid = threadIdx.x;
+    const int msz = M * 256;
+    // LDS byte address of this wave's 256-byte segment of a LUT row (lut_store)
+    const uint32_t lut_m0 = __builtin_amdgcn_readfirstlane(
+            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)s_lut + 256u * (uint32_t)(tid >> 6));
+    // nothing to scan in this group (a shard owns ~1/W of the probed lists): leave before the
+    // 16 KB query table is fetched (sparse = sharded search only: the check costs two dependent
+    // scalar loads per probe).  Producers always go on: they must publish.
+    if (sparse && (!FILT || pg > 0)) {
+        bool any = false;
+        for (int p = p_begin; p < p_end; p++) {
+            const int l = probe_list[q * P + p];
+            if (l >= 0 && l < nlist && (!list_mask || list_mask[l]) && list_len[l] > 0) any = true;
+        }
+        if (!any) {   // uniform
+            if (FILT && threadIdx.x == 0) sb.gcnt[(int64_t)q * sb.cnt_stride + pg] = 0;
+            return;
+        }
+    }
+    const float* st2q = st2 + (int64_t)q * msz;
+    float s2r[MT > 0 ? MT : 1];
+    if (IPF && MT > 0) {
+        // same arithmetic as k_pq_ip_table: one fvec_inner_products_ny row per (m, code word)
+        const int dsub = d / M;
+        const float* xq = x + (int64_t)q * d;
+#pragma unroll
+        for (int i = 0; i < MT; i++) s2r[i] = fvec_ny_row<false>(xq + i * dsub, st2 + ((int64_t)i * 256 + tid) * dsub, dsub);
+    } else if (MT > 0 && (!UNITS || (L2 ? q * P + pg != lut_pair : q != lut_q))) {
+#pragma unroll
+        for (int i = 0; i < MT; i++) s2r[i] = st2q[tid + 256 * i];
+    }
+    if (!L2 && (!UNITS || q != lut_q)) {   // inner product: the LUT is the query table itself, list independent
+        if (UNITS) lut_q = q;
+        if (MT > 0) {
+            lut_store_begin(lut_m0);
+            lut_store_rows<MT>([&](int i) { return s2r[i]; }, std::make_integer_sequence<int, (MT > 0 ? MT : 1)>{});
+            lut_store_done();
+        } else {
+            for (int e = tid; e < msz; e += 256) s_lut[e] = st2q[e];
+        }
+    }
+    if constexpr (CF) {
+        if (pg > 0) {   // (uniform) largest |entry| of the query's table: one word per wave, read behind the barrier below
+            float mxv = 0.f;
+#pragma unroll
+            for (int i = 0; i < MT; i++) mxv = fmaxf(mxv, fabsf(s2r[i]));
+            const uint32_t wmx = __reduce_max_sync(~0ull, __float_as_uint(mxv));   // non-negative floats order as integers
+            if (lane == 0) s_red[tid >> 6] = wmx;
+        }
+    }
+    if (FILT) {   // placed after the table loads were issued: their latency and this one overlap
+        if (threadIdx.x == 0) {
+            s_nstage = 0;
+            if (CF) s_ncand = 0;
+            if (pg > 0) {   // wait for this query's bound (published by its group-0 workgroup)
+                // ONE relaxed 64-bit word carries (state << 32 | bound): no acquire/release fence is
+                // needed (nothing else the producer wrote is read here), and agent-scope fences
+                // would write back / invalidate the L2 this kernel lives on
+                int spins = 0;
+                unsigned long long word;
+                // (bounded: dispatch order is not a contract -- if the producer has not published within ~2e6
+                //  cycles the group goes on without a bound and the query takes the unfiltered selection)
+                while ((word = __hip_atomic_load(&sb.ready[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0ull &&
+                       ++spins < (1 << 11))
+                    __builtin_amdgcn_s_sleep(16);
+                if (word != 0ull) {
+                    s_tau = (word >> 32) == 1ull ? (uint32_t)word : 0xffffffffu;
+                } else {   // never expected: give the query to the unfiltered selection instead of hanging
+                    s_tau = 0xffffffffu;
+                    s_nstage = SCAN_SLICE + 1;
+                }
+            }
+        }
+        __syncthreads();
+        if (pg > 0) {
+            tauq = s_tau;
+            bound_on = tauq < KEY_SENTINEL;   // otherwise the query takes the unfiltered selection
+            tau_f = key2f(L2 ? tauq : ~tauq);
+        }
+    }
+    if constexpr (CF) {
+        if (pg > 0 && bound_on) {   // (uniform)
+            // ---- filter pass (L2 consumers with a bound) ----------------------------------------------------------
+            // Half of the regular loop's instructions build the per-list table T2[l] - 2 ip[q] (4096 entries for
+            // lists of a few hundred codes).  Here the LUT is the QUERY's table ip[q] alone, written once per
+            // workgroup -- no per-list build, no barriers in the probe loop -- and a code is tested on
+            //     f = (dis0 + s_j) - 2 sum_m ip[q][m][c_m],     s_j = sum_m T2[l][m][c_m]  (kept beside the code, 4 bytes),
+            // which differs from the reference's value  dis0 + sum_m fma(-2, ip, T2)  (sequential) only by rounding:
+            // every one of the < 50 roundings of either evaluation is at most 2^-24 times a partial sum, and every
+            // partial sum is bounded by S = |dis0| + sum_m max_c |T2[l][m][c]| + 2 sum_m max_c |ip[q][m][c]|, so
+            // |f - exact| <= 50 * 2^-24 * S.  A code passes when f <= tau + 2^-17 S (a margin 2.5 times that, the
+            // second term of S taken as 32 times the largest |entry| of the query's table).  The few that pass
+            // (about as many as end up in the slice) get the EXACT value afterwards -- table entries fetched from
+            // the L2-resident T2 row, fma and adds in the reference's order -- and the slice receives what the
+            // regular loop would have put there: same keys, same positions.
+            lut_store_begin(lut_m0);
+            lut_store_rows<MT>([&](int i) { return s2r[i]; }, std::make_integer_sequence<int, (MT > 0 ? MT : 1)>{});
+            lut_store_done();
+            const float qmax = __uint_as_float(max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3])));
+            // The table does not depend on the list, so nothing in this loop needs the workgroup in step: every WAVE
+            // takes whole lists of the group (next one from a counter in LDS), 64 codes per step, the next step's codes
+            // and sums requested before the current step's gathers -- four independent latency chains per workgroup
+            // instead of one, and no barrier until the candidates are complete.
+            int& s_next = *reinterpret_cast<int*>(s_cand + SCAN_CF_CAP);
+            if (tid == 0) s_next = 0;
+            __syncthreads();   // the LUT and the list counter are in place
+            const int ng = p_end - p_begin;
+            for (;;) {
+                int r = 0;
+                if (lane == 0) r = atomicAdd(&s_next, 1);
+                r = __builtin_amdgcn_readfirstlane(r);
+                if (r >= ng) break;
+                const int p = p_begin + r, pair = q * P + p;
+                const int l = probe_list[pair];
+                if (l < 0 || l >= nlist) continue;            // uniform per wave
+                if (list_mask && !list_mask[l]) continue;
+                const int len = list_len[l];
+                if (len <= 0) continue;
+                const int64_t off = list_off[l];
+                const uint8_t* lc = codes + off * MT;
+                const float* ls = sb.sums + off;
+                const int64_t* lid = ids + off;
+                const float dis0 = coarse_dis[pair];
+                const int pbase = pair_off[(int64_t)q * (P + 1) + p];
+                const float S = fabsf(dis0) + sb.t2max[l] + 32.f * qmax;
+                float thr = __builtin_fmaf(S, 1.f / 131072.f, tau_f);
+                thr += fabsf(thr) * 1.2e-7f;   // the threshold's own rounding
+                uint4 cn[MT / 16];
+                float sn;
+                {
+                    const int jc = min(lane, len - 1);
+                    const uint4* cp = reinterpret_cast<const uint4*>(lc + (int64_t)jc * MT);
+#pragma unroll
+                    for (int u = 0; u < MT / 16; u++) cn[u] = cp[u];
+                    sn = ls[jc];
+                }
+                for (int j0 = 0; j0 < len; j0 += 64) {
+                    const int j = j0 + lane;
+                    uint32_t cw[MT / 4];
+#pragma unroll
+                    for (int u = 0; u < MT / 16; u++) {
+                        cw[4 * u] = cn[u].x; cw[4 * u + 1] = cn[u].y; cw[4 * u + 2] = cn[u].z; cw[4 * u + 3] = cn[u].w;
+                    }
+                    const float sj = sn;
+                    if (j0 + 64 < len) {   // (uniform) the next step's codes and sums, in flight during this step's gathers
+                        const int jc = min(j + 64, len - 1);
+                        const uint4* cp = reinterpret_cast<const uint4*>(lc + (int64_t)jc * MT);
+#pragma unroll
+                        for (int u = 0; u < MT / 16; u++) cn[u] = cp[u];
+                        sn = ls[jc];
+                    }
+                    bool ok = j < len;
+                    if (need_ids) {
+                        const int64_t id = lid[min(j, len - 1)];
+                        ok = ok && id >= 0;
+                        if (ok) ok = is_valid_doc(filt, id);
+                    }
+                    float t[MT];
+#pragma unroll
+                    for (int m = 0; m < MT; m++) t[m] = lut_gather(cw[m >> 2], m & 3, m);
+                    __builtin_amdgcn_sched_barrier(0);   // all gathers in flight before the adds
+                    float g4[4] = {t[0], t[1], t[2], t[3]};   // four independent chains: the order is free here
+#pragma unroll
+                    for (int m = 4; m < MT; m++) g4[m & 3] += t[m];
+                    const float g = (g4[0] + g4[1]) + (g4[2] + g4[3]);
+                    const float f = __builtin_fmaf(-2.f, g, dis0 + sj);
+                    const bool cand = ok && f <= thr;
+                    const unsigned long long bal = __ballot(cand);
+                    if (bal) {   // uniform per wave
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(&s_ncand, __popcll(bal));
+                        base = __shfl(base, 0, 64);
+                        const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+                        if (cand && slot < SCAN_CF_CAP) s_cand[slot] = make_uint2((uint32_t)(pbase + j), (uint32_t)p);
+                    }
+                }
+            }
+            __syncthreads();
+            const int nc = s_ncand;
+            if (nc > SCAN_CF_CAP) {   // (uniform) more candidates than the stage holds: the query takes the unfiltered path
+                if (tid == 0) s_nstage = SCAN_SLICE + 1;
+            } else {
+                for (int c0 = 0; c0 < nc; c0 += 256) {   // uniform trip count: append() ballots
+                    const int c = c0 + tid;
+                    bool keep = false;
+                    float dis = 0.f;
+                    int pos = 0;
+                    if (c < nc) {
+                        const uint2 cd = s_cand[c];
+                        pos = (int)cd.x;
+                        const int p = (int)cd.y, pair = q * P + p;
+                        const int l = probe_list[pair];
+                        const int j = pos - pair_off[(int64_t)q * (P + 1) + p];
+                        const uint8_t* cj = codes + (list_off[l] + j) * MT;
+                        const float* t2 = T2 + (int64_t)l * msz;
+                        uint32_t cw[MT / 4];
+#pragma unroll
+                        for (int u = 0; u < MT / 16; u++) {
+                            const uint4 cv = reinterpret_cast<const uint4*>(cj)[u];
+                            cw[4 * u] = cv.x; cw[4 * u + 1] = cv.y; cw[4 * u + 2] = cv.z; cw[4 * u + 3] = cv.w;
+                        }
+                        dis = coarse_dis[pair];
+#pragma unroll
+                        for (int m0 = 0; m0 < MT; m0 += 8) {   // eight table entries in flight at a time
+                            float a[8];
+#pragma unroll
+                            for (int m = 0; m < 8; m++) a[m] = t2[(m0 + m) * 256 + ((cw[(m0 + m) >> 2] >> (8 * (m & 3))) & 255u)];
+#pragma unroll
+                            for (int m = 0; m < 8; m++)   // the regular loop's table entry and its adds, in the reference's order
+                                dis += __builtin_fmaf(-2.0f, s_lut[(m0 + m) * 256 + ((cw[(m0 + m) >> 2] >> (8 * (m & 3))) & 255u)], a[m]);
+                        }
+                        keep = dis <= tau_f;
+                    }
+                    append(keep, dis, pos);
+                }
+            }
+            flush();
+            return;
+        }
+    }
+    if (!L2) __syncthreads();   // the LUT (written once per query) is complete; L2 rebuilds it per list
+    for (int p = p_begin; p < p_end; p++) {
+        const int pair = q * P + p;
+        const int l = probe_list[pair];
+        if (l < 0 || l >= nlist) continue;            // uniform
+        if (list_mask && !list_mask[l]) continue;
+        int len = list_len[l];
+        int64_t off = list_off[l];
+        if (UNITS) {
+            len = min(len - cbase, chunk_len);
+            off += cbase;
+        }
+        if (len <= 0) continue;
+        const uint8_t* lc = codes + off * M;
+        // the first 256 codes are requested BEFORE the T2 row: both latencies overlap, and lists of
+        // up to 256 codes (most of them) never wait for their codes after the LUT is ready
+        // compiled code widths: any multiple of 8 bytes up to 64; a code is NLD loads of LW dwords
+        constexpr bool PRE = MT > 0 && MT % 8 == 0 && MT <= 64;
+        constexpr int LW = (MT % 16 == 0) ? 4 : 2, NLD = PRE ? MT / (4 * LW) : 1;
+        typedef uint32_t cvec_t __attribute__((ext_vector_type(LW)));
+        // (issued as inline asm: hipcc sinks an ordinary load down to its first use, behind both
+        // barriers; the matching s_waitcnt is placed by hand where the codes are consumed)
+        cvec_t cfirst[NLD];
+        if (PRE) {
+            const uint8_t* cp0 = lc + (int64_t)min(tid, len - 1) * (PRE ? MT : 16);
+#pragma unroll
+            for (int u = 0; u < NLD; u++) {
+                const uint8_t* a = cp0 + 4 * LW * u;
+                if constexpr (LW == 4) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(cfirst[u]) : "v"(a) : "memory");
+                else asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(cfirst[u]) : "v"(a) : "memory");
+            }
+        }
+        if (L2 && (!UNITS || pair != lut_pair)) {   // (uniform)
+            if (UNITS) lut_pair = pair;
+            __syncthreads();   // the previous list's gathers are finished
+            const float* t2 = T2 + (int64_t)l * msz;
+            if (MT > 0) {
+                float tv[MT > 0 ? MT : 1];
+#pragma unroll
+                for (int i = 0; i < MT; i++) tv[i] = t2[tid + 256 * i];   // MT loads in flight
+                lut_store_begin(lut_m0);
+                lut_store_rows<MT>([&](int i) { return __builtin_fmaf(-2.0f, s2r[i], tv[i]); },
+                                   std::make_integer_sequence<int, (MT > 0 ? MT : 1)>{});
+                lut_store_done();
+            } else {
+                for (int e = tid; e < msz; e += 256) s_lut[e] = __builtin_fmaf(-2.0f, st2q[e], t2[e]);
+            }
+            __syncthreads();
+        }
+        // L2: the coarse distance; IP: <x_q, centroid_l>, computed per pair by k_pair_ip (a chain of d/8
+        // dependent fmas per AVX lane has no place inside this loop)
+        const float dis0 = coarse_dis[pair];
+        const int64_t* lid = ids + off;
+        const int pbase = pair_off[(int64_t)q * (P + 1) + p] + (UNITS ? cbase : 0);
+        float* o = out + (int64_t)q * q_stride + pbase;
+        // store + what the pre-filter tracks about a scored code
+        // Distances are stored where something reads them: the first group's (its producer's histogram, the
+        // unfiltered selection, the tie replay) and those of a group without a bound.  A consumer with a bound
+        // keeps only its survivors; if k_select_final cannot finish the query from the slices (a slice
+        // overflowed, > 256 equal keys at the cut) the repair launch scores the group again with stores.
+        const bool store = !FILT || pg == 0 || !bound_on || sb.store_all;
+        auto finish = [&](int j, bool ok, float dis) -> float {
+            const float val = ok ? dis : sentinel;
+            if (store) o[j] = val;
+            if (FILT && pg == 0) {
+                const bool valid = val != sentinel;
+                g_fmn = fminf(g_fmn, valid ? val : INFINITY);
+                g_fmx = fmaxf(g_fmx, valid ? val : -INFINITY);
+                g_nv += valid ? 1 : 0;
+            }
+            return val;
+        };
+        // one code: validity, ADC (gathers issued together, adds in reference order), store
+        auto do_code = [&](int j, const uint32_t* cw) -> float {
+            // ids are read only when something can reject an entry (delete bit, range filter,
+            // superseded slot); otherwise 8 of the 28 bytes per candidate stay in HBM
+            bool ok = true;
+            if (need_ids) {
+                const int64_t id = lid[j];
+                ok = id >= 0;  // bit 63 = kDelIdxMask (realtime_mem_data.h:26)
+                if (ok) ok = is_valid_doc(filt, id);
+            }
+            float dis = dis0;
+            if (PRE) {
+                float t[PRE ? MT : 1];
+#pragma unroll
+                for (int m = 0; m < (PRE ? MT : 1); m++) t[m] = lut_gather(cw[m >> 2], m & 3, m);
+                __builtin_amdgcn_sched_barrier(0);   // all gathers in flight before the add chain
+#pragma unroll
+                for (int m = 0; m < (PRE ? MT : 1); m++) dis += t[m];   // sequential, reference order
+            } else {
+                const uint8_t* cj = lc + (int64_t)j * M;
+                for (int m = 0; m < M; m++) dis += s_lut[m * 256 + cj[m]];
+            }
+            return finish(j, ok, dis);
+        };
+        // uniform trip counts: append() ballots.  First 256 codes: already in registers.
+        if (PRE) {
+#pragma unroll
+            for (int u = 0; u < NLD; u++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(cfirst[u]) : : "memory");
+        }
+        {
+            float val = sentinel;
+            if (tid < len) {
+                uint32_t cw[PRE ? MT / 4 : 1];
+                if (PRE) {
+#pragma unroll
+                    for (int u = 0; u < NLD; u++)
+#pragma unroll
+                        for (int i = 0; i < LW; i++) cw[LW * u + i] = cfirst[u][i];
+                }
+                val = do_code(tid, cw);
+            }
+            if (FILT && bound_on) append(within(val), val, pbase + tid);
+        }
+        if constexpr (MT == 64) {
+            // 64-byte codes: the 64 KB LUT leaves two workgroups per CU (2 waves per SIMD), so each
+            // thread scores TWO codes per iteration -- 128 LDS gathers in flight, two independent
+            // add chains -- instead of relying on other waves to cover its latency
+            int j0 = 256;
+            for (; j0 + 256 < len; j0 += 512) {   // both halves hold codes (uniform)
+                const int ja = j0 + tid, jb = ja + 256;
+                const bool ina = true, inb = jb < len;
+                uint32_t cwa[16], cwb[16];
+                {
+                    const uint4* pa = reinterpret_cast<const uint4*>(lc + (int64_t)min(ja, len - 1) * 64);
+                    const uint4* pb = reinterpret_cast<const uint4*>(lc + (int64_t)min(jb, len - 1) * 64);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint4 a = pa[u], b = pb[u];
+                        cwa[4 * u] = a.x; cwa[4 * u + 1] = a.y; cwa[4 * u + 2] = a.z; cwa[4 * u + 3] = a.w;
+                        cwb[4 * u] = b.x; cwb[4 * u + 1] = b.y; cwb[4 * u + 2] = b.z; cwb[4 * u + 3] = b.w;
+                    }
+                }
+                bool oka = true, okb = true;
+                if (need_ids) {
+                    const int64_t ida = lid[min(ja, len - 1)], idb = lid[min(jb, len - 1)];
+                    oka = ida >= 0;
+                    if (oka) oka = is_valid_doc(filt, ida);
+                    okb = idb >= 0;
+                    if (okb) okb = is_valid_doc(filt, idb);
+                }
+                float ta[64], tb[64];
+#pragma unroll
+                for (int m = 0; m < 64; m++) ta[m] = lut_gather(cwa[m >> 2], m & 3, m);
+#pragma unroll
+                for (int m = 0; m < 64; m++) tb[m] = lut_gather(cwb[m >> 2], m & 3, m);
+                __builtin_amdgcn_sched_barrier(0);   // all gathers in flight before the add chains
+                float da = dis0, db = dis0;
+#pragma unroll
+                for (int m = 0; m < 64; m++) {       // each chain sequential, reference order
+                    da += ta[m];
+                    db += tb[m];
+                }
+                const float vala = ina ? finish(ja, oka, da) : sentinel;
+                const float valb = inb ? finish(jb, okb, db) : sentinel;
+                if (FILT && bound_on) {
+                    append(within(vala), vala, pbase + ja);
+                    append(within(valb), valb, pbase + jb);
+                }
+            }
+            if (j0 < len) {   // at most 256 codes left: one per thread
+                const int j = j0 + tid;
+                float val = sentinel;
+                if (j < len) {
+                    uint32_t cw[16];
+                    const uint4* cp = reinterpret_cast<const uint4*>(lc + (int64_t)j * 64);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint4 cv = cp[u];
+                        cw[4 * u] = cv.x; cw[4 * u + 1] = cv.y; cw[4 * u + 2] = cv.z; cw[4 * u + 3] = cv.w;
+                    }
+                    val = do_code(j, cw);
+                }
+                if (FILT && bound_on) append(within(val), val, pbase + j);
+            }
+        } else {
+            for (int j0 = 256; j0 < len; j0 += 256) {
+                const int j = j0 + tid;
+                float val = sentinel;
+                if (j < len) {
+                    uint32_t cw[PRE ? MT / 4 : 1];
+                    if (PRE) {
+                        const cvec_t* cp = reinterpret_cast<const cvec_t*>(lc + (int64_t)j * (PRE ? MT : 16));
+#pragma unroll
+                        for (int u = 0; u < NLD; u++) {
+                            const cvec_t cv = cp[u];
+#pragma unroll
+                            for (int i = 0; i < LW; i++) cw[LW * u + i] = cv[i];
+                        }
+                    }
+                    val = do_code(j, cw);
+                }
+                if (FILT && bound_on) append(within(val), val, pbase + j);
+            }
+        }
+    }
+    if (FILT && pg > 0) flush();   // also without a bound: the slice count must be written (0)
+    if (FILT && pg == 0) {
+        // ---- producer: bound of this query's K-th best from its first probe group ----
+        // 256-bin histogram of the group's valid keys over [min, max]; tau = upper edge of the bin
+        // holding the K-th smallest.  At least K candidates are <= tau, hence the whole final top-K.
+        __syncthreads();   // this workgroup's distance stores are visible to all its threads
+        int* hist = reinterpret_cast<int*>(s_stage);   // staging has not been used yet
+        const int n0 = pair_off[(int64_t)q * (P + 1) + min(G, P)];
+        const float* o0 = out + (int64_t)q * q_stride;
+        // float range -> key range (a zero may carry either sign: take the widest pair of keys)
+        const float fmn = g_fmn == 0.f ? -0.f : g_fmn, fmx = g_fmx == 0.f ? 0.f : g_fmx;
+        uint32_t mn = g_nv ? (L2 ? dis_key<L2>(fmn) : dis_key<L2>(fmx)) : 0xffffffffu;
+        uint32_t mx = g_nv ? (L2 ? dis_key<L2>(fmx) : dis_key<L2>(fmn)) : 0u;
+        int nv = g_nv;
+        mn = wave_min_u32(mn);
+        mx = wave_max_u32(mx);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nv += __shfl_xor(nv, off, 64);
+        if (lane == 0) {
+            s_red[threadIdx.x >> 6] = mn;
+            s_red[4 + (threadIdx.x >> 6)] = mx;
+            s_red[8 + (threadIdx.x >> 6)] = (uint32_t)nv;
+        }
+        hist[threadIdx.x] = 0;
+        __syncthreads();
+        mn = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+        mx = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+        nv = (int)(s_red[8] + s_red[9] + s_red[10] + s_red[11]);
+        uint32_t tau = 0xffffffffu;
+        if (nv >= sb.K) {   // uniform
+            const uint32_t range = mx - mn;
+            const int sh = range >= 256u ? (32 - __clz((int)range)) - 8 : 0;   // (range >> sh) < 256
+            for (int i0 = 0; i0 < n0; i0 += 256 * 8) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) t[u] = o0[min(i0 + u * 256 + (int)threadIdx.x, n0 - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t key = dis_key<L2>(t[u]);
+                    if (i0 + u * 256 + (int)threadIdx.x < n0 && key < KEY_SENTINEL)
+                        atomicAdd(&hist[(key - mn) >> sh], 1);
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < 64) {   // wave 0: scan of the 256 bins, 4 per lane
+                int c[4], c4 = 0;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    c[u] = hist[lane * 4 + u];
+                    c4 += c[u];
+                }
+                const int incl = wave_incl_scan(c4);
+                int run = incl - c4;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (run < sb.K && sb.K <= run + c[u]) {
+                        unsigned long long edge = (unsigned long long)mn +
+                                                  (((unsigned long long)(lane * 4 + u) + 1ull) << sh) - 1ull;
+                        if (edge > (unsigned long long)mx) edge = mx;
+                        s_tau = (uint32_t)edge;
+                    }
+                    run += c[u];
+                }
+            }
+            __syncthreads();
+            tau = s_tau;
+        }
+        if (threadIdx.x == 0)
+            __hip_atomic_store(&sb.ready[q], tau < KEY_SENTINEL ? ((1ull << 32) | tau) : (2ull << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the group's own candidates within the bound become its survivor slice (slice 0), like a
+        // consumer's: k_select_final then reads a few hundred items per query and never the distance
+        // buffer (one wave walking a long first group -- 24 k candidates at C4 -- was the slow part)
+        if (tau < KEY_SENTINEL) {   // uniform
+            __syncthreads();        // the histogram (aliasing the staging area) has been read
+            for (int i0 = 0; i0 < n0; i0 += 256 * 8) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) t[u] = o0[min(i0 + u * 256 + (int)threadIdx.x, n0 - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int idx = i0 + u * 256 + (int)threadIdx.x;
+                    append(idx < n0 && dis_key<L2>(t[u]) <= tau, t[u], idx);
+                }
+            }
+        }
+        flush();   // without a bound: count 0
+    }
+    };   // body
+    if (!repair) {
+        body(q, pg);
+    } else if (UNITS) {
+        // a workgroup takes a contiguous run of units: consecutive chunks of one list share its LUT
+        const int nu = *rq_count, per = (nu + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int w0 = (int)blockIdx.x * per, w1 = min(nu, w0 + per);
+        for (int w = w0; w < w1; w++) {
+            const uint32_t u = (uint32_t)rq_list[w];
+            cbase = (int)(u & 8191u) * chunk_len;
+            body((int)(u >> 20), (int)((u >> 13) & 127u));
+            __syncthreads();   // the LUT of this unit has been consumed
+        }
+    } else {
+        const int nrq = *rq_count;
+        for (int w = blockIdx.x; w / pg_cnt < nrq; w += gridDim.x) {
+            body(rq_list[w / pg_cnt], pg_lo + w % pg_cnt);
+            __syncthreads();   // the LUT of this item has been consumed
+        }
+    }
+}
+
+int scan_slice_cap() { return SCAN_SLICE; }
+bool scan_cf_applies(bool l2, int M, int P, int G, bool have_sums, bool store_all) {
+    return l2 && have_sums && !store_all && (M == 16 || M == 32) && P > G;
+}
+
+int scan_group_size(int nq, int P, int G0) {
+    // probes per workgroup: amortise the query table, but keep >= ~4096 workgroups in flight
+    static const int g_env = getenv("GAMMA_HIP_SCAN_G") ? atoi(getenv("GAMMA_HIP_SCAN_G")) : 0;
+    int G = g_env > 0 ? g_env : G0;
+    while (G > 1 && (int64_t)nq * ((P + G - 1) / G) < 4096) G >>= 1;
+    return std::max(1, std::min(G, P));
+}
+
+void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int d, int M, int P,
+                            const int* probe_list, const float* coarse_dis, const float* cc,
+                            const float* st2, const float* T2, const int64_t* list_off,
+                            const int* list_len, const uint8_t* list_mask, int nlist,
+                            const uint8_t* codes, const int64_t* ids, const int* pair_off,
+                            int64_t q_stride, float* out, const FilterDesc* ftab, const int* qfil, int need_ids,
+                            const int* qperm, int G, int pg_lo, int pg_cnt, int sparse, const ScanBound* bound,
+                            const float* pqc_fused, const int* rq_list, const int* rq_count, int chunk_len, int max_units) {
+    if (nq <= 0 || pg_cnt <= 0) return;
+    if (chunk_len > 0 && (bound || pqc_fused || !rq_list || G != 1 || pg_lo != 0 || pg_cnt != P || max_units < 1)) abort();
+    if (pqc_fused) {   // the table is computed inside the kernel (IPF): one workgroup per query, M 16 / 32
+        if (!bound || pg_cnt != 1 || (M != 16 && M != 32)) abort();
+        st2 = pqc_fused;
+    }
+    // LUT | survivor staging | a few words (see the kernel)
+    size_t lds = (size_t)M * 256 * sizeof(float) + SCAN_STAGE * sizeof(unsigned long long) + 16 * sizeof(int);
+    dim3 grid((unsigned)(8 * (int64_t)((nq + 7) / 8) * pg_cnt));
+    if (bound) {   // P(0) | P(t+1) C(t) ...: whole batches, see the kernel
+        const int64_t nq8 = (nq + 7) / 8, nb = (nq8 + SCAN_BATCH - 1) / SCAN_BATCH;
+        grid.x = (unsigned)(8 * (SCAN_BATCH + nb * SCAN_BATCH * pg_cnt));
+    }
+    ScanBound sb = {nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, 0};
+    if (bound) sb = *bound;
+    // filter pass for the consumers of a bounded L2 scan: needs the per-code sums (sb.sums) and survivor-only consumers
+    const bool cf = bound && l2 && !pqc_fused && pg_cnt > 1 && sb.sums && sb.t2max && !sb.store_all && (M == 16 || M == 32);
+    if (rq_list) {   // repair launch: a fixed grid loops over the flagged (query, group) items
+        if (bound || pqc_fused) abort();
+        grid.x = (unsigned)std::min<int64_t>((int64_t)nq * pg_cnt, 2048);
+    }
+    if (chunk_len > 0) {   // as many workgroups as are resident at once (LDS: the LUT), no more than there can be units
+        const int per_cu = std::max(1, std::min(8, (int)(160 * 1024 / (lds + 1024))));
+        grid.x = (unsigned)std::min<int64_t>(max_units, 256 * per_cu);
+    }
+    if (cf) lds += SCAN_CF_CAP * sizeof(uint2) + 16;
+#define GH_SCAN(LL, MT, FF)                                                                       \
+    GH_SCAN4(LL, MT, FF, false)
+#define GH_SCAN4(LL, MT, FF, II) GH_SCAN5(LL, MT, FF, II, false)
+#define GH_SCAN5(LL, MT, FF, II, UU)                                                                       \
+    hipLaunchKernelGGL((k_ivfpq_scan_pair<LL, MT, FF, II, UU>), grid, dim3(256), lds, s, x, nq, d, M, P, G,     \
+                       probe_list, coarse_dis, cc, st2, T2, list_off, list_len, list_mask, nlist, codes, \
+                       ids, pair_off, q_stride, out, ftab, qfil, need_ids, LL ? INFINITY : -INFINITY, qperm,   \
+                       pg_lo, pg_cnt, sparse, sb, rq_list, rq_count, chunk_len)
+#define GH_SCAN_M(LL, FF)                       \
+    do {                                        \
+        if (M == 16) GH_SCAN(LL, 16, FF);       \
+        else if (M == 32) GH_SCAN(LL, 32, FF);  \
+        else if (M == 64) GH_SCAN(LL, 64, FF);  \
+        else if (M == 8) GH_SCAN(LL, 8, FF);    \
+        else if (M == 24) GH_SCAN(LL, 24, FF);  \
+        else if (M == 48) GH_SCAN(LL, 48, FF);  \
+        else GH_SCAN(LL, 0, FF);                \
+    } while (0)
+    if (chunk_len > 0) {
+#define GH_SCAN_U(LL)                                           \
+    do {                                                        \
+        if (M == 16) GH_SCAN5(LL, 16, false, false, true);      \
+        else if (M == 32) GH_SCAN5(LL, 32, false, false, true); \
+        else if (M == 64) GH_SCAN5(LL, 64, false, false, true); \
+        else if (M == 8) GH_SCAN5(LL, 8, false, false, true);   \
+        else GH_SCAN5(LL, 0, false, false, true);               \
+    } while (0)
+        if (l2) GH_SCAN_U(true);
+        else GH_SCAN_U(false);
+#undef GH_SCAN_U
+    } else if (pqc_fused) {
+        if (l2 && M == 16) GH_SCAN4(true, 16, true, true);
+        else if (l2) GH_SCAN4(true, 32, true, true);
+        else if (M == 16) GH_SCAN4(false, 16, true, true);
+        else GH_SCAN4(false, 32, true, true);
+    } else if (cf) {
+#define GH_SCAN_CF(MT)                                                                                                  \
+    hipLaunchKernelGGL((k_ivfpq_scan_pair<true, MT, true, false, false, true>), grid, dim3(256), lds, s, x, nq, d, M, P, G, \
+                       probe_list, coarse_dis, cc, st2, T2, list_off, list_len, list_mask, nlist, codes, ids, pair_off,  \
+                       q_stride, out, ftab, qfil, need_ids, INFINITY, qperm, pg_lo, pg_cnt, sparse, sb, rq_list,         \
+                       rq_count, chunk_len)
+        if (M == 16) GH_SCAN_CF(16);
+        else GH_SCAN_CF(32);
+#undef GH_SCAN_CF
+    } else if (bound) {
+        if (l2) GH_SCAN_M(true, true);
+        else GH_SCAN_M(false, true);
+    } else {
+        if (l2) GH_SCAN_M(true, false);
+        else GH_SCAN_M(false, false);
+    }
+#undef GH_SCAN_M
+#undef GH_SCAN
+#undef GH_SCAN4
+#undef GH_SCAN5
+}
+
+}  // namespace gh

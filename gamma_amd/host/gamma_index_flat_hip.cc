@@ -1,5 +1,6 @@
 // GammaFLATHIPIndex -- see gamma_index_flat_hip.h
 #include "gamma_index_flat_hip.h"
+#include "gamma_index_ivfpq_hip.h"   // WarnTiesNotHonoured
 
 #include "filter_bridge.h"
 
@@ -137,7 +138,9 @@ int GammaFLATHIPIndex::Search(RetrievalContext *retrieval_context, int n, const 
   std::vector<gamma_hip_term_filter> tf;
   if (!(device_filters_ && columns_.Prepare(h_, cond, DocCountOf(this, (int64_t)vector_->MetaInfo()->Size()), p, ff, tf)))
     FillRangeFilters(cond, p, rf);
-  return gamma_hip_flat_search(h_, &p, n, reinterpret_cast<const float *>(x), k, distances, ids);
+  const int rc = gamma_hip_flat_search(h_, &p, n, reinterpret_cast<const float *>(x), k, distances, ids);
+  if (!rc) WarnTiesNotHonoured(h_);
+  return rc;
 }
 
 }  // namespace tig_gamma

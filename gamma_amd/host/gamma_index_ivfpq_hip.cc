@@ -387,7 +387,21 @@ int GammaIVFPQHIPIndex::Search(RetrievalContext *retrieval_context, int n, const
     HLOG("search failed: %s (%s)", gamma_hip_strerror(rc), grp_ ? gamma_hip_group_last_error(grp_) : gamma_hip_last_error(h_));
     return rc;
   }
+  WarnTiesNotHonoured(h_);
   return 0;
+}
+
+// A search beyond the exact-ties mode's range (nprobe > 256, a flat search for k = 4096) that merely inherited the model's
+// default ran with the (distance, position) order inside ties: said once per occurrence count, never silently
+// (gamma_hip_ties_not_honoured; a request that sets "exact_ties": 1 itself fails instead)
+void WarnTiesNotHonoured(gamma_hip_index *h) {
+  static std::atomic<int64_t> said{0};
+  int64_t n = 0;
+  if (!h || gamma_hip_ties_not_honoured(h, &n, 0) || n <= 0) return;
+  int64_t prev = said.load();
+  if (n > prev && said.compare_exchange_strong(prev, n))
+    HLOG("%lld search call(s) ran without the reference's heap order inside exact ties: shape beyond the mode's range "
+         "(nprobe > 256 or flat k = 4096)", (long long)n);
 }
 
 // PerfTool (index/retrieval_model.h:23-50; printed by the engine at online_log_level=debug): one label for the device
@@ -692,6 +706,7 @@ int GammaIVFFlatHIPIndex::Search(RetrievalContext *retrieval_context, int n, con
     HLOG("search failed: %s (%s)", gamma_hip_strerror(rc), gamma_hip_last_error(h_));
     return rc;
   }
+  WarnTiesNotHonoured(h_);
   return 0;
 }
 

@@ -9,6 +9,7 @@
 // tig_gamma::IVFPQModelParams with another layout would be an ODR violation.  Unsupported on device and rejected in Init like any bad parameter:
 // hnsw quantizer, opq, support_indivisible_nsubvector, nbits_per_idx != 8.
 #pragma once
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -18,6 +19,8 @@
 #include "filter_bridge.h"
 
 namespace tig_gamma {
+
+void WarnTiesNotHonoured(gamma_hip_index *h);   // gamma_index_ivfpq_hip.cc
 
 class HIPIVFPQRetrievalParameters : public RetrievalParameters {
  public:

@@ -67,6 +67,55 @@ for R2 in (150, 200, 300, 400):
     Df2, If2 = g.flat_search(q[nq:][:NR], k, api.SearchArgs(metric=api.METRIC_L2, min_score=0.0, max_score=1e30))
     rec2 = np.mean([len(set(Ih[i].tolist()) & set(If2[i].tolist())) / float(k) for i in range(NR)])
     print("recall_num %d: recall@10 %.3f, %.2f ms per %d queries = %.0f queries/s" % (R2, rec2, dt2 * 1e3, nq, nq / dt2))
+if os.environ.get("C4_EMUL"):
+    # One rank of a W-GPU LIST-SHARDED job on this index, emulated on one GPU (no communication; tools/rank_emul.py is
+    # the C3 version): the handle works under the list mask of shard 0 of gamma_amd.dist.balance_lists(sizes, W) -- it
+    # scans only the lists that rank would own -- and a step is what dist.sharded_search has one rank compute for a batch
+    # of W x nq queries: the coarse quantizer for its own slice of nq queries, the shard scan + local top-recall_num of
+    # ALL W x nq queries over its lists, the merge + re-rank of its slice (stand-in candidate tables of the right shape).
+    # Weak scaling: per-rank compute efficiency = (one GPU, nq queries, whole index) / (this step).
+    from gamma_amd import dist as gdist
+    f32, i32, i64 = torch.float32, torch.int32, torch.int64
+    sizes = np.array([g.list_size(l) for l in range(nlist)], dtype=np.int64)
+    base_ms = dt * 1e3
+    for W in [int(v) for v in os.environ["C4_EMUL"].split(",")]:
+        owner = gdist.balance_lists(sizes, W)
+        g.set_list_mask((owner == 0).astype(np.uint8))
+        gnq = nq * W
+        qq = synth.sift_like(gnq, d=d, seed=4321)
+        dqq = torch.from_numpy(qq).to(dev)
+        cdis = torch.empty((gnq, P), dtype=f32, device=dev)
+        probe = torch.empty((gnq, P), dtype=i32, device=dev)
+        g.set_list_mask(None)
+        for s_ in range(W):      # the assignment of the whole batch (the other ranks' coarse results, all-gathered)
+            g.ivfpq_coarse_device(dqq[s_ * nq:].data_ptr(), nq, args, cdis[s_ * nq:].data_ptr(), probe[s_ * nq:].data_ptr())
+        g.set_list_mask((owner == 0).astype(np.uint8))
+        rdis = torch.empty((gnq, R), dtype=f32, device=dev)
+        rids = torch.empty((gnq, R), dtype=i64, device=dev)
+        D2 = torch.empty((nq, k), dtype=f32, device=dev)
+        I2 = torch.empty((nq, k), dtype=i64, device=dev)
+
+        def estep():
+            g.ivfpq_coarse_device(dqq.data_ptr(), nq, args, cdis.data_ptr(), probe.data_ptr())
+            g.ivfpq_search_shard_preassigned(dqq.data_ptr(), gnq, cdis.data_ptr(), probe.data_ptr(), k, args, rdis.data_ptr(),
+                                             rids.data_ptr())
+            g.ivfpq_merge_rerank(W, nq, dqq.data_ptr(), k, args, rdis.data_ptr(), rids.data_ptr(), 0, nq, D2.data_ptr(), I2.data_ptr())
+        for _ in range(2):
+            estep()
+        g.synchronize()
+        g.profile_enable(True); g.profile_reset()
+        t0 = time.perf_counter()
+        for _ in range(4):
+            estep()
+        g.synchronize()
+        de = (time.perf_counter() - t0) / 4
+        pr = g.profile()
+        print("emulated rank of W=%d (lists of shard 0: %.1f M of %.1f M vectors): %.2f ms per step of %d queries (%d per rank) "
+              "against %.2f ms for %d queries on one GPU -> per-rank compute efficiency %.0f %%; stage ms/step %s" % (
+                  W, sizes[owner == 0].sum() / 1e6, sizes.sum() / 1e6, de * 1e3, gnq, nq, base_ms, nq, 100.0 * base_ms / (de * 1e3),
+                  {n: round(pr[n][0] / 4, 3) for n in pr if isinstance(pr[n], tuple) and pr[n][1]}))
+        g.profile_enable(False)
+    g.set_list_mask(None)
 g.profile_enable(True)
 if os.environ.get("C4_FILTER"):   # a request bitmap that keeps every tenth document (what the engine's range index hands over)
     keep = np.arange(0, N, 10, dtype=np.int64)

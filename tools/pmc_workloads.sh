@@ -7,11 +7,12 @@ root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/pmc_wl
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-run() {   # name kernel-substring script args...
-  local name=$1 kern=$2; shift 2
+run() {   # name kernel-substring kernel-regex script args...
+  local name=$1 kern=$2 kre=$3; shift 3
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rm -rf $out/${name}_$ctr
-    timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/${name}_$ctr -o pmc -- python3 "$@" > $out/${name}_$ctr.log 2>&1
+    # counters only for the kernel of interest: with every kernel of the build phase counted the pass does not finish
+    timeout 900 rocprofv3 --pmc $ctr --kernel-trace --kernel-include-regex "$kre" --output-format csv -d $out/${name}_$ctr -o pmc -- python3 "$@" > $out/${name}_$ctr.log 2>&1
   done
   python3 - "$out" "$name" "$kern" <<'PY'
 import csv, glob, json, sys
@@ -32,8 +33,7 @@ print(json.dumps(res))
 PY
   rm -rf $out/${name}_FETCH_SIZE $out/${name}_WRITE_SIZE
 }
-run c2_flat "k_pairwise_lds<true, 128, true, true>" $root/tools/flat_bench.py
-run c4_shape_8m "k_ivfpq_scan_pair<true, 32, true" $root/tools/c4_scale.py 8e6
-run c5_shape_2m "k_ivfpq_scan_pair<false, 64, true" $root/tools/c5_scale.py 2e6
-run ivfflat "k_ivfflat_lm" $root/tools/ivfflat_bench.py
-run single_query "k_small_tail" $root/tools/latency.py
+run c2_flat "k_flat_filter<true, 128>" "k_flat_filter" $root/tools/flat_bench.py
+run c4_shape_8m "k_ivfpq_scan_pair<true, 32, true" "k_ivfpq_scan_pair" $root/tools/c4_scale.py 8e6
+run c5_shape_2m "k_ivfpq_scan_pair<false, 64, true" "k_ivfpq_scan_pair" $root/tools/c5_scale.py 2e6
+run ivfflat "k_ivfflat_lm" "k_ivfflat_lm" $root/tools/ivfflat_bench.py

@@ -30,6 +30,22 @@ with open(dst, "w") as o:
                 o.write("%-96s %7s %12.1f %12.3f %7.2f\n" % (r["Name"][:96], r["Calls"], float(r["AverageNs"]) / 1e3,
                                                           float(r["TotalDurationNs"]) / 1e6, 100.0 * float(r["TotalDurationNs"]) / tot))
 PY
+  # what the workload itself printed about its launches (bytes per launch, launches per call, stage times): with these
+  # lines every roofline fraction quoted for the workload can be recomputed from this one file
+  {
+    echo "# from the workload's own output (per-launch bytes from the device-side counters of gamma_hip_profile_*; calls = kernel launches in the whole run):"
+    grep -a "scan roofline\|search: \|stage ms per step\|stage avg us\|ms per call\|queries/s\|no filter:\|range filter" $out/${name}.log | grep -av "^\[rank\|latency nq" | cut -c1-400 | sed 's/^/#   /' | head -24
+    tail -1 $out/${name}.log | python3 -c "
+import json, sys
+try:
+    d = json.loads(sys.stdin.read())
+    r = d['roofline']
+    print('#   bench line: value %s %s, %s steps, ms_per_step %s; roofline kernel %s: algorithmic_bytes_per_launch %s, avg_launch_us %s, achieved %s GB/s, frac %s' % (
+        d['value'], d['unit'], d['steps'], d['ms_per_step'], r['kernel'], r['algorithmic_bytes_per_launch'], r['avg_launch_us'], r['achieved'], r['frac']))
+except Exception:
+    pass
+"
+  } >> $out/${name}_kernel_stats.txt
   tail -2 $out/${name}.log | cut -c1-300
   rm -rf $out/raw_$name
 }
