@@ -145,3 +145,74 @@ def test_raw_store_grows_in_place_under_search():
             assert st["moves"] == 0 and st0["moves"] == 0
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("mapped", [True, False])
+def test_list_arena_grows_in_place_under_search(mapped, monkeypatch):
+    """The inverted-list arena (codes, ids, code sums) grows by mapping physical memory behind its three arrays: no
+    reallocation, no copy, no exclusive lock (the reference grows bucket by bucket,
+    realtime/realtime_mem_data.cc:152-188,426-474).  A searcher thread keeps getting the answer of a prefix state while
+    400 000 entries arrive in lists that start with 16 slots; the final state is the oracle's.  mapped = False: the
+    reallocating fallback (GAMMA_HIP_NO_ARENA_VMM) gives the same results and reports its moves."""
+    import threading
+    if not mapped:
+        monkeypatch.setenv("GAMMA_HIP_NO_ARENA_VMM", "1")
+    d, nlist, M, nb, per = 32, 64, 8, 40, 10000
+    rng = np.random.default_rng(11)
+    base = rng.integers(0, 255, size=(nb * per, d)).astype(np.float32)
+    cc, pq = api.train_ivfpq(base[:8000], nlist, M)
+    g = api.GammaHip(0)
+    try:
+        g.ivfpq_init(d, nlist, M, 8, api.METRIC_L2, 16)
+        g.ivfpq_set_trained(cc, pq, None)
+        g.raw_init(d)
+        g.raw_append(base[:per])
+        g.add(base[:per], 0)
+        g0 = g.arena_growth()
+        q = base[:16] + 0.25     # row i of the first block is the nearest of q[i], whatever arrives later
+        args = api.SearchArgs(metric=api.METRIC_L2, nprobe=nlist, recall_num=50, has_rank=True, min_score=-3e38,
+                              max_score=3e38)
+        stop, bad, calls = threading.Event(), [], [0]
+
+        def searcher():
+            while not stop.is_set():
+                D, I = g.ivfpq_search(q, 1, args)
+                calls[0] += 1
+                if not np.array_equal(I[:, 0], np.arange(16)):
+                    bad.append(I[:, 0].copy())
+
+        t = threading.Thread(target=searcher)
+        t.start()
+        try:
+            for b in range(1, nb):
+                xb = base[b * per:(b + 1) * per] + np.float32(4000.0)    # far from the queries
+                g.raw_append(xb)
+                g.add(xb, b * per)
+        finally:
+            stop.set()
+            t.join()
+        assert not bad and calls[0] > 0
+        st, gr = g.arena_stats(), g.arena_growth()
+        assert st["used"] >= nb * per
+        assert gr["mapped"] == (mapped and g0["mapped"])
+        if gr["mapped"]:
+            assert gr["moves"] == 0
+        else:
+            assert gr["moves"] > 0
+        # final state against the oracle built the same way
+        allx = np.concatenate([base[:per]] + [base[b * per:(b + 1) * per] + np.float32(4000.0) for b in range(1, nb)])
+        B.lib().go_set_assign_mode(1)     # Add in the engine's batches: n >= 20 -> GEMM-form assignment
+        o = B.OracleIVFPQ(d, nlist, M, 8, B.METRIC_L2, bucket_init_size=16)
+        o.set_trained(cc, pq, None)
+        for b in range(nb):
+            assert o.add(allx[b * per:(b + 1) * per])
+        B.lib().go_set_assign_mode(0)
+        o.set_raw(allx)
+        qq = np.concatenate([q, allx[5 * per:5 * per + 16] + np.float32(0.25)])
+        a2 = api.SearchArgs(metric=api.METRIC_L2, nprobe=8, recall_num=50, has_rank=True, min_score=-3e38, max_score=3e38,
+                            coarse_mode=0)
+        D, I = g.ivfpq_search(qq, 10, a2)
+        Do, Io = o.search(qq, 10, 8, recall_num=50, has_rank=True, metric=B.METRIC_L2, ctx=B.make_ctx(**WIDE), coarse_mode=0)
+        compare_exact(Do, Io, D, I)
+    finally:
+        g.close()

@@ -2,7 +2,7 @@
 # usage (GPU box): tools/pmc_workloads.sh > gpurun_out/pmc_workloads.json
 # One FETCH_SIZE and one WRITE_SIZE pass (rocprofv3 --pmc, counters only, separate passes) of the other BASELINE workloads:
 # per-launch averages of the kernel that dominates each of them.  HBM-side bytes = FETCH_SIZE (KB) x 1024 x 2 (gfx950,
-# MI355X_MICROARCH.md) + WRITE_SIZE (KB) x 1024; this box's own calibration of FETCH_SIZE is in profiles/r03_pmc_scan_summary.json.
+# MI355X_MICROARCH.md) + WRITE_SIZE (KB) x 1024; this box's own calibration of FETCH_SIZE is in profiles/r04_pmc_scan_summary.json.
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/pmc_wl
 mkdir -p $out
