@@ -61,6 +61,7 @@ SYMBOLS = {
     "gamma_hip_raw_append": (C.c_int, [C.c_void_p, C.c_int64, f32p]),
     "gamma_hip_raw_update": (C.c_int, [C.c_void_p, C.c_int64, f32p]),
     "gamma_hip_ivfpq_arena_stats": (C.c_int, [C.c_void_p, i64p]),
+    "gamma_hip_ivfpq_arena_growth": (C.c_int, [C.c_void_p, i64p]),
     "gamma_hip_ivfpq_set_repack_threshold": (C.c_int, [C.c_void_p, C.c_int64]),
     "gamma_hip_set_small_path": (C.c_int, [C.c_void_p, C.c_int]),
     "gamma_hip_set_coarse_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

@@ -232,6 +232,12 @@ class GammaHip:
         self._ck(self.L.gamma_hip_ivfpq_arena_stats(self.h, _p(out, _lib.i64p)), "arena_stats")
         return dict(zip(["cap", "used", "waste", "repacks"], [int(v) for v in out]))
 
+    def arena_growth(self):
+        """{moves: growths that reallocated and copied the arena, mapped: it grows in place (mapped ranges)}"""
+        out = np.zeros(2, np.int64)
+        self._ck(self.L.gamma_hip_ivfpq_arena_growth(self.h, _p(out, _lib.i64p)), "arena_growth")
+        return {"moves": int(out[0]), "mapped": bool(out[1])}
+
     def set_repack_threshold(self, min_waste_entries):
         self._ck(self.L.gamma_hip_ivfpq_set_repack_threshold(self.h, min_waste_entries), "set_repack_threshold")
 

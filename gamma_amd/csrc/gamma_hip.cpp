@@ -96,14 +96,16 @@ int gamma_hip_destroy(gamma_hip_index* h) {
         (void)hipEventDestroy(e.b);
     }
     if (h->raw_vmm) {   // the mapped store: unmap the chunks, release them, free the range
-        size_t off = 0;
-        for (size_t i = 0; i < h->raw_chunks.size(); i++) {
-            (void)hipMemUnmap(reinterpret_cast<char*>(h->d_raw) + off, h->raw_chunk_bytes[i]);
-            (void)hipMemRelease(h->raw_chunks[i]);
-            off += h->raw_chunk_bytes[i];
-        }
-        (void)hipMemAddressFree(h->d_raw, h->raw_va_bytes);
+        h->raw_vm.release();
         h->d_raw = nullptr;
+    }
+    if (h->arena_vmm) {
+        h->vm_codes.release();
+        h->vm_ids.release();
+        h->vm_sums.release();
+        h->d_codes = nullptr;
+        h->d_ids = nullptr;
+        h->d_sums = nullptr;
     }
     void* ptrs[] = {h->d_list_rank, h->d_raw, h->d_bitmap, h->d_cc, h->d_cc_norms, h->d_pqc, h->d_T2, h->d_codes,
                     h->d_ids, h->d_list_mask, h->d_scan_codes, h->d_tie_stats, h->d_v2d, h->d_sums, h->d_t2max};

@@ -72,6 +72,23 @@ using ghi::StageEvent;
 
 struct WriteLock;
 
+// A device array that grows in place: an address range reserved once (the device's whole memory -- addresses are free),
+// physical chunks mapped behind what is in use.  Nothing moves, so readers of the mapped part go on while it grows.
+struct VmRange {
+    char* base = nullptr;
+    size_t va_bytes = 0, mapped = 0, gran = 0;
+    int device = 0;
+    std::vector<hipMemGenericAllocationHandle_t> chunks;
+    std::vector<size_t> chunk_bytes;
+    bool on() const { return base != nullptr; }
+    // false: the runtime does not offer it (nothing is left behind)
+    bool reserve(int device_, size_t chunk_min);
+    // mapped >= bytes afterwards; grows by at least 1/8 of what is mapped, in whole chunks.  On failure *what names the
+    // step and nothing of the failed step stays mapped.
+    hipError_t map_to(size_t bytes, const char** what);
+    void release();
+};
+
 struct gamma_hip_index {
     int device = 0;
     // Concurrency (SURVEY 8b "Threading": Search from any number of client threads while ONE indexing thread adds
@@ -130,9 +147,7 @@ struct gamma_hip_index {
     // 90-142; a segment table would cost every gather an indirection, a mapped range costs nothing).  Fallback: a
     // geometric reallocation under the exclusive lock.
     bool raw_vmm = false;
-    size_t raw_va_bytes = 0, raw_mapped = 0, raw_gran = 0;
-    std::vector<hipMemGenericAllocationHandle_t> raw_chunks;
-    std::vector<size_t> raw_chunk_bytes;
+    VmRange raw_vm;
     int64_t raw_regrows = 0;   // reallocations that moved the store (0 with virtual memory management)
 
     // numeric scalar columns (on-device range filters)
@@ -179,6 +194,12 @@ struct gamma_hip_index {
     float* d_t2max = nullptr;
     bool keep_sums = false;   // set by Init: IVFPQ handles (GAMMA_HIP_NO_CODE_SUMS=1 turns the filter pass off)
     int64_t arena_cap = 0, arena_used = 0, arena_waste = 0;   // entries; waste = abandoned extents inside used
+    // the three arena arrays (codes, ids, code sums) are mapped ranges like the raw store where the runtime allows:
+    // growth maps chunks behind them -- no copy, no second arena, no exclusive lock (the reference grows per bucket for
+    // the same reason, realtime/realtime_mem_data.cc:152-188,426-474).  Fallback: reallocation under the exclusive lock.
+    bool arena_vmm = false;
+    VmRange vm_codes, vm_ids, vm_sums;
+    int64_t arena_regrows = 0;   // growths that moved the arena (0 with virtual memory management)
     int64_t repack_min_entries = 1 << 16;                     // no repack for less waste than this
     int64_t n_repacks = 0;
     std::vector<int64_t> h_list_off;

@@ -6,9 +6,160 @@
 namespace ghi {
 
 
+// ---- mapped ranges ------------------------------------------------------------------------
+}  // namespace ghi
+bool VmRange::reserve(int device_, size_t chunk_min) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device_;
+    size_t g = 0, free_b = 0, total_b = 0;
+    void* va = nullptr;
+    if (hipMemGetAllocationGranularity(&g, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || g == 0 ||
+        hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) {
+        (void)hipGetLastError();
+        return false;
+    }
+    // whole chunks of at least 2 MB: hipMemSetAccess refuses chunk sizes that are only a multiple of the reported 4 KB
+    // granularity (tools/exp/vmm_probe.cpp)
+    const size_t chunk = std::max<size_t>(std::max<size_t>(g, chunk_min), (size_t)2 << 20) / g * g;
+    const size_t want = (total_b + chunk - 1) / chunk * chunk;
+    if (hipMemAddressReserve(&va, want, 0, nullptr, 0) != hipSuccess || !va) {
+        (void)hipGetLastError();
+        return false;
+    }
+    base = static_cast<char*>(va);
+    va_bytes = want;
+    mapped = 0;
+    gran = chunk;
+    device = device_;
+    return true;
+}
+hipError_t VmRange::map_to(size_t bytes, const char** what) {
+    *what = "";
+    if (bytes <= mapped) return hipSuccess;
+    size_t add = std::max(bytes - mapped, mapped / 8);   // fewer, larger chunks
+    add = (add + gran - 1) / gran * gran;
+    if (mapped + add > va_bytes) add = va_bytes - mapped;
+    if (mapped + add < bytes) {
+        *what = "beyond the reserved address range";
+        return hipErrorOutOfMemory;
+    }
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    hipMemGenericAllocationHandle_t hnd;
+    hipError_t e = hipMemCreate(&hnd, add, &prop, 0);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *what = "hipMemCreate";
+        return e;
+    }
+    char* at = base + mapped;
+    hipMemAccessDesc acc = {};
+    acc.location.type = hipMemLocationTypeDevice;
+    acc.location.id = device;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    // beside the kernels of the searches in flight: page-table updates of a range they do not read yet
+    // (tools/exp/vmm_probe.cpp: mapping beside kernels on the range and beside a thread allocating and launching)
+    e = hipMemMap(at, add, 0, hnd, 0);
+    *what = "hipMemMap";
+    if (e == hipSuccess) {
+        e = hipMemSetAccess(at, add, &acc, 1);
+        *what = "hipMemSetAccess";
+        if (e != hipSuccess) {   // seen for chunks that are not a multiple of 2 MB: the whole mapped range is accepted
+            (void)hipGetLastError();
+            e = hipMemSetAccess(base, mapped + add, &acc, 1);
+        }
+        if (e != hipSuccess) (void)hipMemUnmap(at, add);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipMemRelease(hnd);
+        return e;
+    }
+    chunks.push_back(hnd);
+    chunk_bytes.push_back(add);
+    mapped += add;
+    *what = "";
+    return hipSuccess;
+}
+void VmRange::release() {
+    if (!base) return;
+    size_t off = 0;
+    for (size_t i = 0; i < chunks.size(); i++) {
+        (void)hipMemUnmap(base + off, chunk_bytes[i]);
+        (void)hipMemRelease(chunks[i]);
+        off += chunk_bytes[i];
+    }
+    (void)hipMemAddressFree(base, va_bytes);
+    chunks.clear();
+    chunk_bytes.clear();
+    base = nullptr;
+    va_bytes = mapped = 0;
+}
+namespace ghi {
+
+static int vm_fail(H* h, const char* who, hipError_t e, const char* what) {
+    if (e == hipErrorOutOfMemory) return fail(h, GAMMA_HIP_ENOMEM, (std::string(who) + ": out of device memory (" + what + ")").c_str());
+    h->err = std::string(who) + ": " + what + " failed: " + hipGetErrorString(e);
+    return GAMMA_HIP_EDEVICE;
+}
+
 // ---- arena ---------------------------------------------------------------------------
+// entries the three mapped arrays hold
+static int64_t arena_vm_cap(const H* h) {
+    int64_t c = std::min<int64_t>((int64_t)(h->vm_codes.mapped / (size_t)h->code_size), (int64_t)(h->vm_ids.mapped / sizeof(int64_t)));
+    if (h->keep_sums) c = std::min<int64_t>(c, (int64_t)(h->vm_sums.mapped / sizeof(float)));
+    return c;
+}
+// the first reservation of an index: mapped ranges when the runtime offers them AND the first chunks map (a failure
+// here leaves the reallocating arena, nothing behind)
+static bool arena_vm_start(H* h, int64_t entries) {
+    if (getenv("GAMMA_HIP_NO_ARENA_VMM")) return false;
+    const size_t chunk = (size_t)8 << 20;
+    const char* what = "";
+    bool ok = h->vm_codes.reserve(h->device, chunk) && h->vm_ids.reserve(h->device, chunk) &&
+              (!h->keep_sums || h->vm_sums.reserve(h->device, chunk));
+    ok = ok && h->vm_codes.map_to((size_t)entries * h->code_size, &what) == hipSuccess &&
+         h->vm_ids.map_to((size_t)entries * sizeof(int64_t), &what) == hipSuccess &&
+         (!h->keep_sums || h->vm_sums.map_to((size_t)entries * sizeof(float), &what) == hipSuccess);
+    if (!ok) {
+        h->vm_codes.release();
+        h->vm_ids.release();
+        h->vm_sums.release();
+        (void)hipGetLastError();
+        return false;
+    }
+    return true;
+}
+static void arena_vm_adopt(H* h) {
+    h->d_codes = reinterpret_cast<uint8_t*>(h->vm_codes.base);
+    h->d_ids = reinterpret_cast<int64_t*>(h->vm_ids.base);
+    h->d_sums = h->keep_sums ? reinterpret_cast<float*>(h->vm_sums.base) : nullptr;
+    h->arena_cap = arena_vm_cap(h);
+}
+
 int arena_reserve(H* h, int64_t need_entries) {
     if (h->arena_used + need_entries <= h->arena_cap) return GAMMA_HIP_OK;
+    if (!h->d_codes && h->arena_cap == 0 && !h->arena_vmm && arena_vm_start(h, h->arena_used + need_entries)) {
+        h->arena_vmm = true;
+        arena_vm_adopt(h);
+        return GAMMA_HIP_OK;
+    }
+    if (h->arena_vmm) {
+        // map more physical memory behind the three arrays in place: nothing moves, the searches in flight go on
+        const int64_t need = h->arena_used + need_entries;
+        const char* what = "";
+        hipError_t e = h->vm_codes.map_to((size_t)need * h->code_size, &what);
+        if (e == hipSuccess) e = h->vm_ids.map_to((size_t)need * sizeof(int64_t), &what);
+        if (e == hipSuccess && h->keep_sums) e = h->vm_sums.map_to((size_t)need * sizeof(float), &what);
+        h->arena_cap = arena_vm_cap(h);
+        if (e != hipSuccess) return vm_fail(h, "arena growth", e, what);
+        return GAMMA_HIP_OK;
+    }
+    h->arena_regrows++;
     int64_t ncap = std::max<int64_t>(h->arena_cap * 2, h->arena_used + need_entries);
     ncap += ncap / 8;
     uint8_t* nc = nullptr;
@@ -70,34 +221,67 @@ int arena_repack(H* h) {
         noff[l] = total;
         total += h->h_list_cap[l];
     }
-    const int64_t ncap = total + total / 8 + 1024;
+    int64_t ncap = total + total / 8 + 1024;
     uint8_t* nc = nullptr;
     int64_t* ni = nullptr;
+    float* ns = nullptr;
     if (h->wl) GH_CHECK(h, h->wl->exclusive());   // every list moves and the old arrays are freed
     GH_TRY(publish_meta(h));                      // the device tables the kernel below reads = the host mirror
-    GH_CHECK(h, hipMalloc((void**)&nc, (size_t)ncap * h->code_size));
-    if (hipMalloc((void**)&ni, (size_t)ncap * sizeof(int64_t)) != hipSuccess) {
-        (void)hipFree(nc);
-        return fail(h, GAMMA_HIP_ENOMEM, "arena repack: out of memory");
-    }
-    float* ns = nullptr;
-    if (h->keep_sums && hipMalloc((void**)&ns, (size_t)ncap * sizeof(float)) != hipSuccess) {
-        (void)hipFree(nc);
-        (void)hipFree(ni);
-        return fail(h, GAMMA_HIP_ENOMEM, "arena repack: out of memory");
+    VmRange vc, vi, vs;
+    if (h->arena_vmm) {   // a fresh set of mapped ranges, tight
+        const size_t chunk = (size_t)8 << 20;
+        const char* what = "";
+        hipError_t e = hipSuccess;
+        if (!vc.reserve(h->device, chunk) || !vi.reserve(h->device, chunk) || (h->keep_sums && !vs.reserve(h->device, chunk))) {
+            e = hipErrorOutOfMemory;
+            what = "address range";
+        }
+        if (e == hipSuccess) e = vc.map_to((size_t)ncap * h->code_size, &what);
+        if (e == hipSuccess) e = vi.map_to((size_t)ncap * sizeof(int64_t), &what);
+        if (e == hipSuccess && h->keep_sums) e = vs.map_to((size_t)ncap * sizeof(float), &what);
+        if (e != hipSuccess) {
+            vc.release();
+            vi.release();
+            vs.release();
+            return vm_fail(h, "arena repack", e, what);
+        }
+        nc = reinterpret_cast<uint8_t*>(vc.base);
+        ni = reinterpret_cast<int64_t*>(vi.base);
+        ns = h->keep_sums ? reinterpret_cast<float*>(vs.base) : nullptr;
+    } else {
+        GH_CHECK(h, hipMalloc((void**)&nc, (size_t)ncap * h->code_size));
+        if (hipMalloc((void**)&ni, (size_t)ncap * sizeof(int64_t)) != hipSuccess) {
+            (void)hipFree(nc);
+            return fail(h, GAMMA_HIP_ENOMEM, "arena repack: out of memory");
+        }
+        if (h->keep_sums && hipMalloc((void**)&ns, (size_t)ncap * sizeof(float)) != hipSuccess) {
+            (void)hipFree(nc);
+            (void)hipFree(ni);
+            return fail(h, GAMMA_HIP_ENOMEM, "arena repack: out of memory");
+        }
     }
     GH_CHECK(h, h->we_stage.ensure((size_t)h->nlist * sizeof(int64_t)));
     GH_CHECK(h, hipMemcpyAsync(h->we_stage.p, noff.data(), (size_t)h->nlist * sizeof(int64_t), hipMemcpyHostToDevice, h->wstream));
     gh::launch_repack_lists(h->wstream, h->d_codes, h->d_ids, nc, ni, h->d_list_off, h->we_stage.as<int64_t>(),
                             h->d_list_len, h->nlist, h->code_size, h->max_list_len);
     GH_CHECK(h, hipStreamSynchronize(h->wstream));   // noff is a local; the old arrays are free to go
-    GH_CHECK(h, hipFree(h->d_codes));
-    GH_CHECK(h, hipFree(h->d_ids));
-    if (h->d_sums) GH_CHECK(h, hipFree(h->d_sums));
-    h->d_codes = nc;
-    h->d_ids = ni;
-    h->d_sums = ns;
-    h->arena_cap = ncap;
+    if (h->arena_vmm) {
+        h->vm_codes.release();
+        h->vm_ids.release();
+        h->vm_sums.release();
+        h->vm_codes = std::move(vc);
+        h->vm_ids = std::move(vi);
+        h->vm_sums = std::move(vs);
+        arena_vm_adopt(h);
+    } else {
+        GH_CHECK(h, hipFree(h->d_codes));
+        GH_CHECK(h, hipFree(h->d_ids));
+        if (h->d_sums) GH_CHECK(h, hipFree(h->d_sums));
+        h->d_codes = nc;
+        h->d_ids = ni;
+        h->d_sums = ns;
+        h->arena_cap = ncap;
+    }
     h->arena_used = total;
     h->arena_waste = 0;
     h->h_list_off = noff;
@@ -416,28 +600,12 @@ int gamma_hip_raw_init(gamma_hip_index* h, int d) {
     if (h->raw_d != 0 && h->raw_d != d) return fail(h, GAMMA_HIP_EINVAL, "raw store dimension mismatch");
     if (h->raw_d == 0 && !getenv("GAMMA_HIP_NO_RAW_VMM")) {
         // reserve the address range the store may ever need (the device's memory): physical chunks are mapped into it
-        // as rows arrive (raw_reserve).  Any failure leaves the reallocating store.
+        // as rows arrive (raw_reserve).  Any failure -- here or of the FIRST chunk -- leaves the reallocating store.
         GH_CHECK(h, hipSetDevice(h->device));
-        hipMemAllocationProp prop = {};
-        prop.type = hipMemAllocationTypePinned;
-        prop.location.type = hipMemLocationTypeDevice;
-        prop.location.id = h->device;
-        size_t gran = 0, free_b = 0, total_b = 0;
-        void* va = nullptr;
-        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran > 0 &&
-            hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) {
-            const size_t chunk = std::max<size_t>(gran, (size_t)64 << 20) / gran * gran;
-            const size_t want = (total_b + chunk - 1) / chunk * chunk;
-            if (hipMemAddressReserve(&va, want, 0, nullptr, 0) == hipSuccess && va) {
-                h->raw_vmm = true;
-                // chunks of whole 64 MB: hipMemSetAccess refuses chunk sizes that are only a multiple of the reported
-                // 4 KB granularity (tools/exp/vmm_probe.cpp)
-                h->raw_gran = chunk;
-                h->raw_va_bytes = want;
-                h->d_raw = static_cast<float*>(va);
-            }
+        if (h->raw_vm.reserve(h->device, (size_t)64 << 20)) {   // chunks of whole 64 MB
+            h->raw_vmm = true;
+            h->d_raw = reinterpret_cast<float*>(h->raw_vm.base);
         }
-        if (!h->raw_vmm) (void)hipGetLastError();
     }
     h->raw_d = d;
     return GAMMA_HIP_OK;
@@ -448,50 +616,17 @@ static int raw_reserve(H* h, int64_t need) {
     if (h->raw_vmm) {
         // map more physical memory behind the rows in place: nothing moves
         const size_t row = (size_t)h->raw_d * sizeof(float);
-        const size_t need_b = (size_t)need * row;
-        // at least 1/8 more than what is mapped (fewer, larger chunks), in whole granules
-        size_t add = std::max(need_b - h->raw_mapped, h->raw_mapped / 8);
-        add = (add + h->raw_gran - 1) / h->raw_gran * h->raw_gran;   // whole 64 MB chunks (raw_init)
-        if (h->raw_mapped + add > h->raw_va_bytes) add = h->raw_va_bytes - h->raw_mapped;
-        if (h->raw_mapped + add < need_b) return fail(h, GAMMA_HIP_ENOMEM, "raw store: beyond the reserved address range");
-        hipMemAllocationProp prop = {};
-        prop.type = hipMemAllocationTypePinned;
-        prop.location.type = hipMemLocationTypeDevice;
-        prop.location.id = h->device;
-        hipMemGenericAllocationHandle_t hnd;
-        if (hipMemCreate(&hnd, add, &prop, 0) != hipSuccess) {
-            (void)hipGetLastError();
-            return fail(h, GAMMA_HIP_ENOMEM, "raw store: out of device memory");
-        }
-        char* at = reinterpret_cast<char*>(h->d_raw) + h->raw_mapped;
-        hipMemAccessDesc acc = {};
-        acc.location.type = hipMemLocationTypeDevice;
-        acc.location.id = h->device;
-        acc.flags = hipMemAccessFlagsProtReadWrite;
-        // beside the kernels of the searches in flight: page-table updates of a range they do not read yet
-        // (tools/exp/vmm_probe.cpp: mapping beside kernels on the range and beside a thread allocating and launching)
-        hipError_t e = hipMemMap(at, add, 0, hnd, 0);
-        const char* what = "hipMemMap";
+        const char* what = "";
+        hipError_t e = h->raw_vm.map_to((size_t)need * row, &what);
         if (e == hipSuccess) {
-            e = hipMemSetAccess(at, add, &acc, 1);
-            what = "hipMemSetAccess";
-            if (e != hipSuccess) {   // seen for chunks that are not a multiple of 2 MB: the whole mapped range is accepted
-                (void)hipGetLastError();
-                e = hipMemSetAccess(h->d_raw, h->raw_mapped + add, &acc, 1);
-            }
-            if (e != hipSuccess) (void)hipMemUnmap(at, add);
+            h->raw_cap = (int64_t)(h->raw_vm.mapped / row);
+            return GAMMA_HIP_OK;
         }
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            (void)hipMemRelease(hnd);
-            h->err = std::string("raw store: ") + what + " failed: " + hipGetErrorString(e);
-            return GAMMA_HIP_EDEVICE;
-        }
-        h->raw_chunks.push_back(hnd);
-        h->raw_chunk_bytes.push_back(add);
-        h->raw_mapped += add;
-        h->raw_cap = (int64_t)(h->raw_mapped / row);
-        return GAMMA_HIP_OK;
+        if (h->raw_vm.mapped > 0 || h->nraw > 0) return vm_fail(h, "raw store", e, what);
+        // nothing is mapped yet: the range is given back and the store reallocates from here on
+        h->raw_vm.release();
+        h->raw_vmm = false;
+        h->d_raw = nullptr;
     }
     h->raw_regrows++;
     int64_t ncap = std::max<int64_t>(need, h->raw_cap + h->raw_cap / 2);
@@ -1034,6 +1169,14 @@ int gamma_hip_ivfpq_arena_stats(gamma_hip_index* h, int64_t* out4) {
     out4[1] = h->arena_used;
     out4[2] = h->arena_waste;
     out4[3] = h->n_repacks;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_arena_growth(gamma_hip_index* h, int64_t* out2) {
+    if (!h || !out2) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    out2[0] = h->arena_regrows;
+    out2[1] = h->arena_vmm ? 1 : 0;
     return GAMMA_HIP_OK;
 }
 

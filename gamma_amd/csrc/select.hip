@@ -26,6 +26,7 @@
 
 #include "block_utils.h"
 #include "heap_dev.h"
+#include "reservoir_dev.h"
 #include "tie_dev.h"
 #include "device_math.h"
 #include "kernels.h"
@@ -1353,10 +1354,49 @@ __global__ __launch_bounds__(256) void k_coarse_heap_fix(const float* __restrict
     }
 }
 
+// The same rows from 100 probes on: faiss collects those through ReservoirTopN (faiss:utils/distances.cpp:341-358),
+// whose choice among tied centroids and their order is not the heap's -- reservoir_dev.h replays it.  One wave per row.
+__global__ __launch_bounds__(256) void k_coarse_reservoir_fix(const float* __restrict__ mat, int64_t ld, int n, int K,
+                                                              int nq, const uint8_t* __restrict__ flag,
+                                                              float* __restrict__ out_vals, int* __restrict__ out_pos,
+                                                              unsigned long long* __restrict__ tie_stats,
+                                                              const int* __restrict__ rows) {
+    __shared__ __attribute__((aligned(16))) uint2 s_h[4][CH_MAXK + 2];
+    __shared__ float s_v[4][reservoir_capacity(CH_MAXK)];
+    __shared__ int s_i[4][reservoir_capacity(CH_MAXK)];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int ri = blockIdx.x * 4 + w;
+    if (ri >= nq) return;              // whole wave; no workgroup barrier below
+    int q = ri;
+    if (rows) {
+        if (ri >= rows[0]) return;
+        q = rows[1 + ri];
+    } else if (!flag[q]) {
+        return;
+    }
+    if (tie_stats && lane == 0) atomicAdd(tie_stats, 1ull);
+    uint2* h = s_h[w];
+    (void)reservoir_row(mat + (int64_t)ri * ld, n, K, s_v[w], s_i[w], h);
+    for (int r = lane; r < K; r += 64) {
+        const uint2 e = h[1 + r];
+        out_vals[(int64_t)q * K + r] = (int)e.y < 0 ? INFINITY : __uint_as_float(e.x);
+        out_pos[(int64_t)q * K + r] = (int)e.y;
+    }
+}
+static void launch_coarse_tie_rows(hipStream_t s, const float* mat, int nlist, int K, int nq, const uint8_t* flag,
+                                   float* out_vals, int* out_pos, unsigned long long* tie_stats, const int* rows) {
+    if (K >= RV_MIN_K)
+        hipLaunchKernelGGL(k_coarse_reservoir_fix, dim3((nq + 3) / 4), dim3(256), 0, s, mat, (int64_t)nlist, nlist, K, nq, flag,
+                           out_vals, out_pos, tie_stats, rows);
+    else
+        hipLaunchKernelGGL(k_coarse_heap_fix, dim3((nq + 3) / 4), dim3(256), 0, s, mat, (int64_t)nlist, nlist, K, nq, flag,
+                           out_vals, out_pos, tie_stats, rows);
+}
+
 // top-K nearest centroids of every row of the coarse distance matrix.  tie_flag != nullptr (nq bytes of
 // scratch; exact ties): a row with two equal keys among its K + 1 smallest -- which of them is probed, or in which
 // order their lists are scanned, is the doing of the reference's heap -- is redone by k_coarse_heap_fix
-// (K <= 256; beyond that faiss itself switches to its reservoir, faiss:utils/distances.cpp:341-358).
+// (K <= 256; from 100 probes on the walk is faiss's reservoir, k_coarse_reservoir_fix).
 // side / fork / join: the walk of the flagged rows (one wave per row, all latency) may run on a side stream beside the
 // caller's next kernels that do not read the assignment; the caller waits for `join` before the first one that does
 bool launch_coarse_select(hipStream_t s, const float* mat, int nlist, int nq, int K, float* out_vals, int* out_pos,
@@ -1382,8 +1422,7 @@ bool launch_coarse_select(hipStream_t s, const float* mat, int nlist, int nq, in
         (void)hipStreamWaitEvent(side, fork, 0);
         rs = side;
     }
-    hipLaunchKernelGGL(k_coarse_heap_fix, dim3((nq + 3) / 4), dim3(256), 0, rs, mat, (int64_t)nlist, nlist, K, nq, tie_flag,
-                       out_vals, out_pos, tie_stats, nullptr);
+    launch_coarse_tie_rows(rs, mat, nlist, K, nq, tie_flag, out_vals, out_pos, tie_stats, nullptr);
     if (rs != s) (void)hipEventRecord(join, rs);
     return rs != s;
 }
@@ -1391,8 +1430,7 @@ bool launch_coarse_select(hipStream_t s, const float* mat, int nlist, int nq, in
 void launch_coarse_heap_rows(hipStream_t s, const float* mat, int nlist, int nq, int K, const int* rows, float* out_vals,
                              int* out_pos, unsigned long long* tie_stats) {
     if (nq <= 0 || K > CH_MAXK) return;
-    hipLaunchKernelGGL(k_coarse_heap_fix, dim3((nq + 3) / 4), dim3(256), 0, s, mat, (int64_t)nlist, nlist, K, nq, nullptr,
-                       out_vals, out_pos, tie_stats, rows);
+    launch_coarse_tie_rows(s, mat, nlist, K, nq, nullptr, out_vals, out_pos, tie_stats, rows);
 }
 
 int select_kpad(int K) {
@@ -1806,7 +1844,21 @@ __device__ __forceinline__ void small_coarse_select_body(int q, const SmallSelec
         const int have = nsorted < 0 ? cnt : min(nsorted, K + 1);
         for (int r = tid; r + 1 < have; r += SM_NT) eq |= (uint32_t)(s_it[r] >> 32) == (uint32_t)(s_it[r + 1] >> 32);
         int tie = __syncthreads_or((eq || nsorted < 0) ? 1 : 0);
-        if (tie) {
+        if (tie && K >= RV_MIN_K) {   // from 100 probes on the reference collects through its reservoir (reservoir_dev.h)
+            __shared__ float s_rv[reservoir_capacity(128)];
+            __shared__ int s_ri[reservoir_capacity(128)];
+            if (tid < 64) {
+                if (A.tie_stats && tid == 0) atomicAdd(A.tie_stats, 1ull);
+                const int nreal = reservoir_row(v, nlist, K, s_rv, s_ri, s_heap);
+                for (int r = lane; r < K; r += 64) {
+                    const uint2 e = s_heap[1 + r];
+                    s_it[r] = (int)e.y < 0 ? ~0ull : (((unsigned long long)f2key(__uint_as_float(e.x)) << 32) | e.y);
+                }
+                if (lane == 0) s_nreal = nreal;
+            }
+            __syncthreads();
+            cnt = s_nreal;
+        } else if (tie) {
             heap_fill(s_heap, K, tid, SM_NT);
             __syncthreads();
             if (tid < 64) {

@@ -19,8 +19,9 @@
  *   - Writers (Add, Update, Delete, raw rows, bitmap, columns) serialise among themselves and run on the writer stream
  *     beside the searches: a search reads the inverted lists through the VERSION of their (offset, length) tables that was
  *     current when it was enqueued, a writer publishes a new version after its copies (realtime_mem_data.cc:299-300).
- *   - Only operations that free or move memory a search may be reading (arena growth and repack, raw-store and column
- *     growth) wait for the searches in flight.
+ *   - The list arena and the raw store grow IN PLACE (mapped address ranges, gamma_hip_ivfpq_arena_growth /
+ *     gamma_hip_raw_stats): growth waits for nobody.  Only operations that free or move memory a search may be reading
+ *     (the arena repack after compactions, column growth, the reallocating fallbacks) wait for the searches in flight.
  * One handle per GPU; several GPUs behind one index object: gamma_hip_group_* below.
  */
 #ifndef GAMMA_HIP_H_
@@ -145,8 +146,9 @@ int gamma_hip_set_workspace_budget(gamma_hip_index* h, int64_t bytes);
  * membership inside groups of exactly equal distances, and no replay cost (a few queries in a thousand on integer
  * data, none to speak of on real-valued data).  Per request: gamma_hip_search_params.exact_ties.
  * Covers IVFPQ / IVFFLAT / flat search, every batch size, every recall_num and k the ABI accepts (<= 4096), the
- * list-sharded merge and the group.  NOT covered: nprobe > 256 (from 100 probes on faiss itself selects through its
- * reservoir, faiss:utils/distances.cpp:341-358), a flat search for k = 4096 or over 2^31 rows.  Such a call never
+ * list-sharded merge and the group.  From 100 probes on the coarse assignment is replayed through faiss's ReservoirTopN
+ * (what knn_L2sqr collects through there, faiss:utils/distances.cpp:341-358; csrc/reservoir_dev.h), below through its
+ * result heap.  NOT covered: nprobe > 256, a flat search for k = 4096 or over 2^31 rows.  Such a call never
  * degrades silently: with exact_ties = 1 in the request it fails with GAMMA_HIP_EUNSUPPORTED; when it merely inherits the
  * handle's default it runs with the (distance, position) order inside ties and is counted
  * (gamma_hip_ties_not_honoured). */
@@ -261,6 +263,11 @@ int gamma_hip_ivfpq_compact_if_need(gamma_hip_index* h);
  * abandoned, repacks so far}, in list entries (code_size + 8 bytes each).  Setting the threshold re-checks at once. */
 int gamma_hip_ivfpq_arena_stats(gamma_hip_index* h, int64_t* out4);
 int gamma_hip_ivfpq_set_repack_threshold(gamma_hip_index* h, int64_t min_waste_entries);
+/* How the arena grows: out2 = {growths that MOVED the arena (reallocation + copy under the exclusive lock), 1 when the
+ * arena's arrays are mapped address ranges that grow in place (chunks mapped behind them: no copy, no second arena, no
+ * wait for the searches in flight -- the reference grows bucket by bucket for the same reason,
+ * realtime/realtime_mem_data.cc:152-188,426-474)}.  GAMMA_HIP_NO_ARENA_VMM=1 in the environment forces the fallback. */
+int gamma_hip_ivfpq_arena_growth(gamma_hip_index* h, int64_t* out2);
 int64_t gamma_hip_ivfpq_list_size(gamma_hip_index* h, int list_no);
 int64_t gamma_hip_ivfpq_list_capacity(gamma_hip_index* h, int list_no);
 /* RealTimeMemData::RetrieveCodes ("for unit test", realtime_mem_data.h:95-96) */

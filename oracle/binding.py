@@ -95,6 +95,10 @@ def lib():
         L.go_heap_pop_push_stream.restype = None
         L.go_heap_pop_push_stream.argtypes = [C.c_int, C.c_size_t, C.c_size_t, _f32p, _i64p,
                                               _f32p, _i64p]
+        L.go_reservoir_capacity.restype = C.c_size_t
+        L.go_reservoir_capacity.argtypes = [C.c_size_t]
+        L.go_reservoir_stream.restype = None
+        L.go_reservoir_stream.argtypes = [C.c_int, C.c_size_t, C.c_size_t, _f32p, _i64p, _f32p, _i64p]
         L.go_knn_L2sqr.restype = None
         L.go_knn_L2sqr.argtypes = [C.c_int, _f32p, _f32p, C.c_size_t, C.c_size_t, C.c_size_t,
                                    C.c_size_t, _f32p, _i64p]

@@ -195,6 +195,7 @@ void go_fvec_madd(size_t n, const float* a, float bf, const float* b, float* c) 
  * Binary heap, 1-based sift exactly as faiss:utils/Heap.h.  keep_smallest=1 is CMax
  * (cmp(a,b) = a > b, neutral FLT_MAX), 0 is CMin (a < b, neutral -FLT_MAX).
  * =================================================================================== */
+#define GO_MIN_K_RESERVOIR 100 /* faiss:utils/distances.cpp:305 distance_compute_min_k_reservoir */
 static inline int hcmp(int ks, float a, float b) { return ks ? (a > b) : (a < b); }
 static inline float hneutral(int ks) { return ks ? FLT_MAX : -FLT_MAX; }
 
@@ -300,9 +301,149 @@ void go_heap_pop_push_stream(int ks, size_t k, size_t n, const float* vals, cons
 }
 
 /* ===================================================================================
+ * ReservoirTopN (faiss:impl/ResultHandler.h:131-187) and the partition it shrinks with
+ * (partition_fuzzy_median3, faiss:utils/partitioning.cpp:29-215; float keys never take the
+ * SIMD branch, :746-764).  knn_L2sqr / knn_inner_product collect through it from k = 100 on
+ * (distance_compute_min_k_reservoir, faiss:utils/distances.cpp:341-358): same k best as the heap
+ * wherever the keys are distinct; inside exact ties WHICH entries stay and in what order they come
+ * out is this structure's doing.  ks = 1: keep the smallest (CMax), 0: the largest (CMin).
+ * =================================================================================== */
+typedef struct {
+    float* vals;
+    int64_t* ids;
+    size_t i, n, capacity;
+    float threshold;
+} go_reservoir;
+
+size_t go_reservoir_capacity(size_t k) { return (2 * k + 15) & ~(size_t)15; } /* :211 */
+
+static float res_median3(float a, float b, float c) { /* partitioning.cpp:29-40: plain >, whatever the order kept */
+    if (a > b) {
+        float t = a;
+        a = b;
+        b = t;
+    }
+    if (c > b) return b;
+    if (c > a) return c;
+    return a;
+}
+
+static float res_sample_threshold_median3(int ks, const float* vals, size_t n, float thresh_inf, float thresh_sup) {
+    const size_t big_prime = 6700417; /* :49 */
+    float val3[3];
+    int vi = 0;
+    for (size_t i = 0; i < n; i++) {
+        float v = vals[(i * big_prime) % n];
+        if (hcmp(ks, v, thresh_inf) && hcmp(ks, thresh_sup, v)) {
+            val3[vi++] = v;
+            if (vi == 3) break;
+        }
+    }
+    if (vi == 3) return res_median3(val3[0], val3[1], val3[2]);
+    if (vi != 0) return val3[0];
+    return thresh_inf;
+}
+
+static float res_partition_fuzzy(int ks, float* vals, int64_t* ids, size_t n, size_t q_min, size_t q_max, size_t* q_out) {
+    /* (q_min == 0 and q_max >= n cannot happen for a reservoir: k >= 100, q_max = (capacity + k) / 2 < capacity) */
+    float thresh_inf = hneutral(!ks), thresh_sup = hneutral(ks);
+    float thresh = res_median3(vals[0], vals[n / 2], vals[n - 1]);
+    size_t n_eq = 0, n_lt = 0, q = 0;
+    for (int it = 0; it < 200; it++) {
+        n_lt = n_eq = 0; /* count_lt_and_eq :75-92 */
+        for (size_t i = 0; i < n; i++) {
+            if (hcmp(ks, thresh, vals[i])) n_lt++;
+            else if (vals[i] == thresh) n_eq++;
+        }
+        if (n_lt <= q_min) {
+            if (n_lt + n_eq >= q_min) {
+                q = q_min;
+                break;
+            }
+            thresh_inf = thresh;
+        } else if (n_lt <= q_max) {
+            q = n_lt;
+            break;
+        } else {
+            thresh_sup = thresh;
+        }
+        float new_thresh = res_sample_threshold_median3(ks, vals, n, thresh_inf, thresh_sup);
+        if (new_thresh == thresh_inf) break; /* nothing between the bounds */
+        thresh = new_thresh;
+    }
+    int64_t n_eq_1 = (int64_t)q - (int64_t)n_lt;
+    if (n_eq_1 < 0) { /* more than q entries at the lower bound (:196-200) */
+        q = q_min;
+        thresh = nextafterf(thresh, ks ? -HUGE_VALF : HUGE_VALF); /* C::Crev::nextafter */
+        n_eq_1 = (int64_t)q;
+    }
+    size_t wp = 0; /* compress_array :94-116: stable, the first n_eq_1 entries equal to thresh stay */
+    size_t left = (size_t)n_eq_1;
+    for (size_t i = 0; i < n; i++) {
+        if (hcmp(ks, thresh, vals[i])) {
+            vals[wp] = vals[i];
+            ids[wp] = ids[i];
+            wp++;
+        } else if (left > 0 && vals[i] == thresh) {
+            vals[wp] = vals[i];
+            ids[wp] = ids[i];
+            wp++;
+            left--;
+        }
+    }
+    *q_out = q;
+    (void)wp;
+    return thresh;
+}
+
+static void res_begin(go_reservoir* r, int ks, size_t n, size_t capacity, float* vals, int64_t* ids) {
+    r->vals = vals;
+    r->ids = ids;
+    r->i = 0;
+    r->n = n;
+    r->capacity = capacity;
+    r->threshold = hneutral(ks);
+}
+static inline void res_add(go_reservoir* r, int ks, float val, int64_t id) { /* :152-161 */
+    if (hcmp(ks, r->threshold, val)) {
+        if (r->i == r->capacity) /* shrink_fuzzy :165-170 */
+            r->threshold = res_partition_fuzzy(ks, r->vals, r->ids, r->capacity, r->n, (r->capacity + r->n) / 2, &r->i);
+        r->vals[r->i] = val;
+        r->ids[r->i] = id;
+        r->i++;
+    }
+}
+static void res_to_result(const go_reservoir* r, int ks, float* heap_dis, int64_t* heap_ids) { /* :172-186 */
+    const size_t m = r->i < r->n ? r->i : r->n;
+    for (size_t j = 0; j < m; j++) go_heap_push(ks, j + 1, heap_dis, heap_ids, r->vals[j], r->ids[j]);
+    if (r->i < r->n) {
+        go_heap_reorder(ks, r->i, heap_dis, heap_ids);
+        go_heap_heapify(ks, r->n - r->i, heap_dis + r->i, heap_ids + r->i);
+    } else {
+        for (size_t j = r->n; j < r->i; j++) /* heap_addn, faiss:utils/Heap.h:247-260 */
+            if (hcmp(ks, heap_dis[0], r->vals[j])) go_heap_replace_top(ks, r->n, heap_dis, heap_ids, r->vals[j], r->ids[j]);
+        go_heap_reorder(ks, r->n, heap_dis, heap_ids);
+    }
+}
+
+/* a stream of (value, id) through the reservoir: what the device's replay of a tied row is checked against */
+void go_reservoir_stream(int ks, size_t k, size_t n, const float* vals, const int64_t* ids, float* sorted_vals,
+                         int64_t* sorted_ids) {
+    const size_t cap = go_reservoir_capacity(k);
+    float* rv = (float*)malloc(sizeof(float) * cap);
+    int64_t* ri = (int64_t*)malloc(sizeof(int64_t) * cap);
+    go_reservoir r;
+    res_begin(&r, ks, k, cap, rv, ri);
+    for (size_t i = 0; i < n; i++) res_add(&r, ks, vals[i], ids ? ids[i] : (int64_t)i);
+    res_to_result(&r, ks, sorted_vals, sorted_ids);
+    free(rv);
+    free(ri);
+}
+
+/* ===================================================================================
  * Brute-force kNN: IndexFlatL2::search -> knn_L2sqr (faiss:IndexFlat.cpp:35-55,
- * faiss:utils/distances.cpp:334-360).  HeapResultHandler for every k (the reservoir
- * used for k>=100 returns the same set/order except inside exact ties).
+ * faiss:utils/distances.cpp:334-360).  HeapResultHandler below 100 results, ReservoirResultHandler
+ * from there on (:341-358; the restatement above).
  * mode 0 = exhaustive_L2sqr_seq (:130-155); mode 1 = exhaustive_L2sqr_blas (:215-296)
  * with sgemm_ restated as a k-sequential single-accumulator fmaf chain.
  * =================================================================================== */
@@ -350,11 +491,27 @@ void go_knn_L2sqr(int mode, const float* x, const float* y, size_t d, size_t nx,
         const float* xi = x + i * d;
         float* hd = D + i * k;
         int64_t* hi = I + i * k;
-        go_heap_heapify(1, k, hd, hi);
+        const int use_res = k >= GO_MIN_K_RESERVOIR;
+        go_reservoir rs;
+        float* rv = NULL;
+        int64_t* ri = NULL;
+        if (use_res) {
+            const size_t cap = go_reservoir_capacity(k);
+            rv = (float*)malloc(sizeof(float) * cap);
+            ri = (int64_t*)malloc(sizeof(int64_t) * cap);
+            res_begin(&rs, 1, k, cap, rv, ri);
+        } else {
+            go_heap_heapify(1, k, hd, hi);
+        }
+#define GO_KNN_ADD(dis, j)                                                         \
+    do {                                                                           \
+        if (use_res) res_add(&rs, 1, (dis), (int64_t)(j));                         \
+        else if (hd[0] > (dis)) go_heap_replace_top(1, k, hd, hi, (dis), (int64_t)(j)); \
+    } while (0)
         if (mode == 0) {
             for (size_t j = 0; j < ny; j++) {
                 float dis = go_fvec_L2sqr(xi, y + j * d, d);
-                if (hd[0] > dis) go_heap_replace_top(1, k, hd, hi, dis, (int64_t)j);
+                GO_KNN_ADD(dis, j);
             }
         } else {
             float xn = go_fvec_norm_L2sqr(xi, d);
@@ -376,11 +533,18 @@ void go_knn_L2sqr(int mode, const float* x, const float* y, size_t d, size_t nx,
                     size_t j = b * 8 + l;
                     float dis = (xn + yn[j]) - 2 * ip[l];
                     if (dis < 0) dis = 0;
-                    if (hd[0] > dis) go_heap_replace_top(1, k, hd, hi, dis, (int64_t)j);
+                    GO_KNN_ADD(dis, j);
                 }
             }
         }
-        go_heap_reorder(1, k, hd, hi);
+#undef GO_KNN_ADD
+        if (use_res) {
+            res_to_result(&rs, 1, hd, hi);
+            free(rv);
+            free(ri);
+        } else {
+            go_heap_reorder(1, k, hd, hi);
+        }
     }
     free(yn);
     free(yT);
@@ -393,6 +557,18 @@ void go_knn_inner_product(const float* x, const float* y, size_t d, size_t nx, s
         const float* xi = x + i * d;
         float* hd = D + i * k;
         int64_t* hi = I + i * k;
+        if (k >= GO_MIN_K_RESERVOIR) { /* knn_inner_product, faiss:utils/distances.cpp:307-332 */
+            const size_t cap = go_reservoir_capacity(k);
+            float* rv = (float*)malloc(sizeof(float) * cap);
+            int64_t* ri = (int64_t*)malloc(sizeof(int64_t) * cap);
+            go_reservoir rs;
+            res_begin(&rs, 0, k, cap, rv, ri);
+            for (size_t j = 0; j < ny; j++) res_add(&rs, 0, go_fvec_inner_product(xi, y + j * d, d), (int64_t)j);
+            res_to_result(&rs, 0, hd, hi);
+            free(rv);
+            free(ri);
+            continue;
+        }
         go_heap_heapify(0, k, hd, hi);
         for (size_t j = 0; j < ny; j++) {
             float ip = go_fvec_inner_product(xi, y + j * d, d);

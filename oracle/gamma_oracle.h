@@ -64,6 +64,13 @@ void go_heap_stream(int keep_smallest, size_t k, size_t n, const float* vals, co
 void go_heap_pop_push_stream(int keep_smallest, size_t k, size_t n, const float* vals,
                              const int64_t* ids, float* sorted_vals, int64_t* sorted_ids);
 
+/* ReservoirTopN (faiss:impl/ResultHandler.h:131-187; shrink = partition_fuzzy_median3, faiss:utils/partitioning.cpp:
+ * 119-215): what knn_L2sqr / knn_inner_product collect through from k = 100 on.  A stream of (value, id; ids == NULL:
+ * the position) through a reservoir of capacity go_reservoir_capacity(k), then to_result: k sorted entries. */
+size_t go_reservoir_capacity(size_t k);
+void go_reservoir_stream(int keep_smallest, size_t k, size_t n, const float* vals, const int64_t* ids,
+                         float* sorted_vals, int64_t* sorted_ids);
+
 /* ---- brute-force kNN (coarse quantizer / flat) ---------------------------------- */
 /* mode 0: sequential fvec_L2sqr per pair (faiss nx<20 path); mode 1: norms + k-ordered
  * fmaf inner product (the "BLAS" form, with the GEMM restated as a k-sequential fma chain,

@@ -79,6 +79,38 @@ def gen_heap(R):
     np.savez_compressed(os.path.join(OUT, "heap.npz"), **out)
 
 
+def gen_reservoir(R):
+    """Streams of tied keys through the compiled library's ReservoirTopN: IndexFlatL2 / IndexFlatIP over one-dimensional
+    integer rows, one query -- the distance of row j is vals[j] exactly (L2: (0 - v)^2 with v = sqrt-free small integers
+    squared by the library itself; IP: 1 * v), k >= 100 takes the reservoir (faiss:utils/distances.cpp:307-358)."""
+    rng = np.random.default_rng(23)
+    out = {}
+    cases = []
+    R.ref_set_blas_threshold(1 << 30)
+    for ks in (1, 0):
+        for k in (100, 128, 200, 256):
+            for n, hi in ((k, 3), (300, 2), (1000, 6), (4096, 12), (5000, 40)):
+                if n >= k:
+                    cases.append((ks, k, n, hi))
+    out["cases"] = np.array(cases)
+    for ci, (ks, k, n, hi) in enumerate(cases):
+        v = rng.integers(0, hi, size=(n, 1)).astype(np.float32)
+        D = np.empty((1, k), np.float32)
+        I = np.empty((1, k), np.int64)
+        if ks:
+            x = np.zeros((1, 1), np.float32)
+            R.ref_flat_l2_search(1, n, B._fp(v), 1, B._fp(x), k, B._fp(D), B._ip(I))
+            keys = (v * v).ravel()
+        else:
+            x = np.ones((1, 1), np.float32)
+            R.ref_flat_ip_search(1, n, B._fp(v), 1, B._fp(x), k, B._fp(D), B._ip(I))
+            keys = v.ravel().copy()
+        out["keys_%d" % ci] = keys
+        out["D_%d" % ci] = D[0]
+        out["I_%d" % ci] = I[0]
+    np.savez_compressed(os.path.join(OUT, "reservoir_ties.npz"), **out)
+
+
 def gen_ivfpq(R, name, d, nlist, M, N, nq, metric, nprobe, Rk, normalize=False):
     base = synth.sift_like(N, d=d, seed=1234)
     q = synth.sift_like(nq, d=d, seed=4321)
@@ -389,6 +421,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "iwpq":     # add one fixture, leave the others alone
         gen_iwpq(B.ref())
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "reservoir":  # tied key streams through the library's ReservoirTopN
+        gen_reservoir(B.ref())
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "blas":      # the library's default BLAS coarse path at the C3 shape
         gen_blas_coarse(B.ref())
         return
@@ -409,6 +444,7 @@ def main():
     R.ref_set_blas_threshold(1 << 30)
     gen_prims(R)
     gen_heap(R)
+    gen_reservoir(R)
     gen_ivfpq(R, "ivfpq_l2_d32", 32, 32, 8, 6000, 40, B.METRIC_L2, 6, 64)        # dsub 4
     gen_ivfpq(R, "ivfpq_l2_d64", 64, 32, 8, 6000, 40, B.METRIC_L2, 8, 100)       # dsub 8
     gen_ivfpq(R, "ivfpq_ip_d48", 48, 16, 4, 4000, 30, B.METRIC_IP, 4, 50, True)  # dsub 12

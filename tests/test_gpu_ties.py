@@ -528,3 +528,50 @@ def test_a_shape_beyond_the_replay_is_never_silent():
             g.flat_search(q[:2], 4096, api.SearchArgs(metric=api.METRIC_L2, exact_ties=1, **WIDE))
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("nprobe,nq,coarse_mode", [(100, 24, 0), (128, 24, 1), (128, 700, 0), (200, 24, 0), (200, 700, 1),
+                                                     (256, 300, 0), (100, 4200, -1), (256, 4200, -1), (99, 700, 0)])
+def test_coarse_ties_from_100_probes_on_are_the_reservoirs(nprobe, nq, coarse_mode):
+    """From 100 probes on faiss's knn_L2sqr collects the coarse assignment through ReservoirTopN instead of the result
+    heap (faiss:utils/distances.cpp:341-358): which of the centroids at the same distance are probed, and in which order
+    their lists are scanned, is the reservoir's doing (oracle: go_reservoir_stream, pinned against the compiled library
+    in tests/test_oracle_vs_ref.py and tests/golden/reservoir_ties.npz).  Integer centroids and queries on a small
+    grid: nearly every row has equal keys around the nprobe cut.  Small calls (the small-batch chain walks in-kernel up
+    to 128 probes), matrix-path calls and the matrix-free coarse quantizer (>= 4096 queries); 99 probes: the heap."""
+    d, nlist, M, N, R, k = 16, 640, 4, 30000, 120, 10
+    rng = np.random.default_rng(nprobe * 7 + nq)
+    cc = rng.integers(0, 4, size=(nlist, d)).astype(np.float32)
+    base = rng.integers(0, 4, size=(N, d)).astype(np.float32) + rng.standard_normal((N, d)).astype(np.float32) * 0.05
+    pq = rng.standard_normal((M, 256, d // M)).astype(np.float32) * 0.3
+    q = rng.integers(0, 4, size=(nq, d)).astype(np.float32)
+    B.lib().go_set_assign_mode(1)
+    o = B.OracleIVFPQ(d, nlist, M, 8, B.METRIC_L2)
+    o.set_trained(cc, pq, None)
+    assert o.add(base)
+    B.lib().go_set_assign_mode(0)
+    o.set_raw(base)
+    g = api.GammaHip(0)
+    try:
+        g.ivfpq_init(d, nlist, M, 8, api.METRIC_L2)
+        g.ivfpq_set_trained(cc, pq, None)
+        g.raw_init(d)
+        g.raw_append(base)
+        g.add(base, 0)
+        g.set_exact_ties(True)
+        omode = coarse_mode if coarse_mode >= 0 else (1 if nq >= 20 else 0)
+        D, I, st = o.search(q, k, nprobe, recall_num=R, has_rank=True, metric=B.METRIC_L2, ctx=B.make_ctx(**WIDE),
+                            coarse_mode=omode, want_stages=True)
+        # the data does what the test is for: rows with equal keys across the nprobe cut or among the probed
+        full, _ = B.knn_L2sqr(q[:64], cc, nprobe + 1, mode=omode)
+        assert (full[:, 1:] == full[:, :-1]).any(axis=1).mean() > 0.9
+        args = api.SearchArgs(metric=api.METRIC_L2, nprobe=nprobe, recall_num=R, has_rank=True, coarse_mode=coarse_mode, **WIDE)
+        g.tie_stats(reset=True)
+        Dg, Ig = g.ivfpq_search(q, k, args)
+        sg = g.last_stages(nq, nprobe, R)
+        from tests.parity import compare_search_exact
+        compare_search_exact(D, I, st, Dg, Ig, sg)
+        assert g.tie_stats()["coarse_rows"] > 0
+        assert g.ties_not_honoured() == 0
+    finally:
+        g.close()

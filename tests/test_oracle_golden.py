@@ -55,6 +55,27 @@ def test_heap_mechanics_with_ties():
             assert arr.tobytes() == z["%s_%d" % (nm, ci)].tobytes(), (nm, ks, k, n)
 
 
+def test_reservoir_mechanics_with_ties():
+    """tests/golden/reservoir_ties.npz: streams of tied keys through the compiled library's ReservoirTopN (what
+    knn_L2sqr / knn_inner_product collect through from k = 100 on) -- the restatement leaves the same labels at every
+    rank, and the result heap would NOT (the fixture tells the two apart)."""
+    z = np.load(os.path.join(G, "reservoir_ties.npz"))
+    L = B.lib()
+    heap_differs = 0
+    for ci, (ks, k, n, hi) in enumerate(z["cases"]):
+        keys = np.ascontiguousarray(z["keys_%d" % ci])
+        sv, si = np.empty(k, np.float32), np.empty(k, np.int64)
+        L.go_reservoir_stream(int(ks), int(k), int(n), B._fp(keys), None, B._fp(sv), B._ip(si))
+        assert sv.tobytes() == z["D_%d" % ci].tobytes() and np.array_equal(si, z["I_%d" % ci]), (ks, k, n, hi)
+        hv, hi_ = np.empty(k, np.float32), np.empty(k, np.int64)
+        tv, ti = np.empty(k, np.float32), np.empty(k, np.int64)
+        L.go_heap_stream(int(ks), int(k), int(n), B._fp(keys), B._ip(np.arange(n, dtype=np.int64)), B._fp(hv), B._ip(hi_),
+                         B._fp(tv), B._ip(ti))
+        assert tv.tobytes() == sv.tobytes()          # same keys
+        heap_differs += int(not np.array_equal(ti, si))
+    assert heap_differs > len(z["cases"]) // 2
+
+
 def load_ivfpq(name):
     z = np.load(os.path.join(G, name + ".npz"))
     d, nlist, M, N = int(z["d"]), int(z["nlist"]), int(z["M"]), int(z["N"])

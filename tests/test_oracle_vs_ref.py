@@ -128,3 +128,44 @@ def test_gemm_form_is_the_compiled_sgemm(kind):
         assert np.allclose(D, D1, rtol=1e-5) and (I == I1).mean() > 0.99
     finally:
         R.ref_set_blas_threshold(20)
+
+
+def _ref_flat(fn, x, y, k):
+    D = np.empty((len(x), k), np.float32)
+    I = np.empty((len(x), k), np.int64)
+    fn(x.shape[1], len(y), B._fp(y), len(x), B._fp(x), k, B._fp(D), B._ip(I))
+    return D, I
+
+
+def test_reservoir_selection_is_the_compiled_librarys_inside_ties():
+    """From k = 100 on knn_L2sqr / knn_inner_product collect through ReservoirTopN (faiss:utils/distances.cpp:307-358):
+    the restatement (go_reservoir_*, partition_fuzzy_median3) returns the compiled library's labels at every rank on data
+    where most keys tie -- both the sequential and the BLAS form -- and k = 99 still takes the heap."""
+    R = B.ref()
+    try:
+        for seed in range(24):
+            rng = np.random.default_rng(seed)
+            d = int(rng.choice([4, 8, 16, 32]))
+            ny = int(rng.choice([150, 600, 1024, 3000, 4096]))
+            hi = int(rng.choice([2, 3, 5, 16]))     # few distinct values: many exact ties
+            y = rng.integers(0, hi, size=(ny, d)).astype(np.float32)
+            nx = int(rng.choice([5, 19, 25]))
+            x = rng.integers(0, hi, size=(nx, d)).astype(np.float32)
+            for k in (99, 100, 128, 200, 256):
+                if k > ny:
+                    continue
+                for mode, thr in ((0, 1000000), (1, 1)):
+                    if mode == 1 and (ny % 1024) and (ny % 1024) < 8:   # sgemm_'s remainder kernel is not restated
+                        continue
+                    R.ref_set_blas_threshold(thr)
+                    Dr, Ir = _ref_flat(R.ref_flat_l2_search, x, y, k)
+                    Do, Io = B.knn_L2sqr(x, y, k, mode=mode)
+                    assert Dr.tobytes() == Do.tobytes() and np.array_equal(Ir, Io), (seed, d, ny, k, mode)
+                R.ref_set_blas_threshold(1000000)
+                Dr, Ir = _ref_flat(R.ref_flat_ip_search, x, y, k)
+                Do = np.empty((nx, k), np.float32)
+                Io = np.empty((nx, k), np.int64)
+                B.lib().go_knn_inner_product(B._fp(x), B._fp(y), d, nx, ny, k, B._fp(Do), B._ip(Io))
+                assert Dr.tobytes() == Do.tobytes() and np.array_equal(Ir, Io), (seed, d, ny, k, "ip")
+    finally:
+        R.ref_set_blas_threshold(20)
