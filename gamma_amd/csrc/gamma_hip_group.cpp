@@ -56,16 +56,24 @@ struct Barrier {
     std::condition_variable cv;
     int n = 0, waiting = 0;
     uint64_t gen = 0;
-    void arrive() {
+    bool acc_ok = true, phase_ok[2] = {true, true};
+    // Every member passes its own status; all of them get the SAME answer for the phase: whether every member was fine
+    // when it arrived.  The go / no-go decisions of a multi-phase call are taken from this snapshot only -- a member that
+    // fails after the barrier cannot make the others disagree about which barriers are still to come.
+    bool arrive(bool my_ok = true) {
         std::unique_lock<std::mutex> lk(mu);
         const uint64_t g = gen;
+        acc_ok = acc_ok && my_ok;
         if (++waiting == n) {
             waiting = 0;
+            phase_ok[g & 1] = acc_ok;   // (a member can be at most one generation ahead of the slowest reader)
+            acc_ok = true;
             gen++;
             cv.notify_all();
         } else {
             cv.wait(lk, [&] { return gen != g; });
         }
+        return phase_ok[g & 1];
     }
 };
 
@@ -347,7 +355,9 @@ int gamma_hip_group_ivfpq_add_keys(gamma_hip_group* g, int l, int n, const int64
 }
 
 int64_t gamma_hip_group_ivfpq_list_size(gamma_hip_group* g, int l) {
-    if (!g || l < 0 || l >= (int)g->owner.size()) return -1;
+    if (!g) return -1;
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (l < 0 || l >= (int)g->owner.size()) return -1;
     return gamma_hip_ivfpq_list_size(g->m[g->owner[l]], l);
 }
 
@@ -582,9 +592,7 @@ static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, in
                                                   b.probe.as<int32_t>() + (size_t)q0 * P));
             hip(hipEventRecord(b.ev_coarse, s), "record");
         }
-        g->bar.arrive();   // every member's assignment is on its stream
-        bool all_ok = true;
-        for (int j = 0; j < W; j++) all_ok = all_ok && rcs[j] == GAMMA_HIP_OK;
+        bool all_ok = g->bar.arrive(rc == GAMMA_HIP_OK);   // every member's assignment is on its stream
         // 1. pull the other slices of the assignment; scan of the owned probed lists, local top-R of every query
         if (all_ok) {
             for (int j = 0; j < W; j++) {
@@ -606,9 +614,7 @@ static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, in
             if (rc == GAMMA_HIP_OK) abi(gamma_hip_ivfpq_shard_cut_flags(h, nq, b.cutf.as<uint8_t>()));
             hip(hipEventRecord(b.ev_scan, s), "record");
         }
-        g->bar.arrive();   // every member's candidate tables are on its stream
-        all_ok = true;
-        for (int j = 0; j < W; j++) all_ok = all_ok && rcs[j] == GAMMA_HIP_OK;
+        all_ok = g->bar.arrive(rc == GAMMA_HIP_OK);   // every member's candidate tables are on its stream
         // 2. the exchange of the path: the candidates of the own query slice from every member ([W][per][R]);
         // 3. merge to the global top-R, compute_dis, results to the caller
         if (all_ok && nql > 0) {
@@ -642,9 +648,7 @@ static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, in
             nfl[i] = rc == GAMMA_HIP_OK ? nf_i : 0;
             lists[i] = list_i;
             if (gdbg && i == 0) fprintf(stderr, "group: member 0 waited %.3f ms for its merge, %d flagged\n", since(tp0), nf_i);
-            g->bar.arrive();
-            all_ok = true;
-            for (int j = 0; j < W; j++) all_ok = all_ok && rcs[j] == GAMMA_HIP_OK;
+            all_ok = g->bar.arrive(rc == GAMMA_HIP_OK);
             int total = 0;
             for (int j = 0; j < W; j++) total += nfl[j];
             if (all_ok && total > 0) {
@@ -663,14 +667,12 @@ static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, in
                             }
                             hip(hipEventRecord(b.ev_tie, s), "record");
                         }
-                        g->bar.arrive();   // the owner's compact inputs are on its stream
+                        bool ok2 = g->bar.arrive(rc == GAMMA_HIP_OK);   // the owner's compact inputs are on its stream
                         gamma_hip_group::Member& ob = g->mb[o];
                         hip(b.sx.ensure((size_t)nf * d * sizeof(float)), "alloc");
                         hip(b.scd.ensure((size_t)nf * P * sizeof(float)), "alloc");
                         hip(b.spr.ensure((size_t)nf * P * sizeof(int32_t)), "alloc");
                         hip(b.ex_off.ensure((size_t)nf * (P + 1) * sizeof(int32_t)), "alloc");
-                        bool ok2 = true;
-                        for (int j = 0; j < W; j++) ok2 = ok2 && rcs[j] == GAMMA_HIP_OK;
                         rowmax[i] = 0;
                         if (ok2 && rc == GAMMA_HIP_OK) {
                             if (i != o) hip(hipStreamWaitEvent(s, ob.ev_tie, 0), "wait");
@@ -682,20 +684,16 @@ static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, in
                             if (rc == GAMMA_HIP_OK) abi(gamma_hip_ivfpq_shard_export_rows(h, &pp, nf, b.spr.as<int32_t>(), &mine));
                             rowmax[i] = mine;
                         }
-                        g->bar.arrive();   // every member's longest row is known
+                        ok2 = g->bar.arrive(rc == GAMMA_HIP_OK);   // every member's longest row is known
                         int64_t stride = 4;
                         for (int j = 0; j < W; j++) stride = std::max<int64_t>(stride, (rowmax[j] + 3) & ~(int64_t)3);
-                        ok2 = true;
-                        for (int j = 0; j < W; j++) ok2 = ok2 && rcs[j] == GAMMA_HIP_OK;
                         hip(b.ex_vals.ensure((size_t)nf * stride * sizeof(float)), "alloc");
                         hip(b.ex_ids.ensure((size_t)nf * stride * sizeof(int64_t)), "alloc");
                         if (ok2 && rc == GAMMA_HIP_OK)
                             abi(gamma_hip_ivfpq_shard_export(h, &pp, nf, b.sx.as<float>(), b.scd.as<float>(), b.spr.as<int32_t>(), stride,
                                                              b.ex_vals.as<float>(), b.ex_ids.as<int64_t>(), b.ex_off.as<int32_t>()));
                         hip(hipStreamSynchronize(s), "sync");
-                        g->bar.arrive();   // every member's export is complete
-                        ok2 = true;
-                        for (int j = 0; j < W; j++) ok2 = ok2 && rcs[j] == GAMMA_HIP_OK;
+                        ok2 = g->bar.arrive(rc == GAMMA_HIP_OK);   // every member's export is complete
                         if (i == o && ok2) {
                             hip(b.av.ensure((size_t)W * nf * stride * sizeof(float)), "alloc");
                             hip(b.ai.ensure((size_t)W * nf * stride * sizeof(int64_t)), "alloc");
@@ -714,14 +712,13 @@ static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, in
                                                                  b.I.as<int64_t>()));
                             hip(hipStreamSynchronize(s), "sync");
                         }
-                        g->bar.arrive();   // the exports may be overwritten
+                        (void)g->bar.arrive(rc == GAMMA_HIP_OK);   // the exports may be overwritten
                     }
                 }
             }
         }
         if (gdbg && i == 0) fprintf(stderr, "group: tie phase done %.3f ms after the merge was enqueued\n", since(tp0));
-        all_ok = true;
-        for (int j = 0; j < W; j++) all_ok = all_ok && rcs[j] == GAMMA_HIP_OK;
+        // (all_ok: the snapshot of the last barrier every member passed -- the tie phase's own failures show in rc)
         if (all_ok && nql > 0) {   // the slice's rows to the caller
             if (rc == GAMMA_HIP_OK && on_device) {
                 hip(copy_between(distances + (size_t)q0 * k, g->dev[0], b.D.p, g->dev[i], (size_t)nql * k * sizeof(float), s), "results");
@@ -732,7 +729,7 @@ static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, in
             }
         }
         hip(hipStreamSynchronize(s), "sync");
-        g->bar.arrive();   // nobody is reading this member's tables any more
+        (void)g->bar.arrive(rc == GAMMA_HIP_OK);   // nobody is reading this member's tables any more
     });
     for (int i = 0; i < W; i++)
         if (rcs[i] != GAMMA_HIP_OK) return gfail(g, rcs[i], "member " + std::to_string(i) + ": " + errs[i]);

@@ -440,7 +440,12 @@ int gamma_hip_ivfpq_merge_replay(gamma_hip_index* h, const gamma_hip_search_para
  * (device-to-device copies), every member scans the probed lists it owns for the whole batch and keeps a local
  * top-recall_num, each member pulls the candidates of ITS query slice from all members, merges them (k_merge_shards) and
  * runs compute_dis, then the tie phase above (flagged queries' streams exported by every member, replayed at the owner).
- * Results equal those of one handle holding every list.  The multi-process form of the same steps over RCCL is gamma_amd/dist.py. */
+ * Results equal those of one handle holding every list.  The multi-process form of the same steps over RCCL is gamma_amd/dist.py.
+ * Threading: group-level calls (search, add, update, delete, compaction) may come from any thread but run ONE AT A TIME
+ * (a call occupies every member's worker thread and their barriers): concurrent client threads queue behind each other
+ * and behind the indexing thread, and small calls are not combined -- batch queries above the group, as the reference's
+ * GPU model does (its GPUItem queue, index/impl/gpu/gamma_index_ivfpq_gpu.cc:356-436).  A member that fails in any phase
+ * ends the call with that member's error on every thread (the go / no-go of each phase is one snapshot all members share). */
 typedef struct gamma_hip_group gamma_hip_group;
 int gamma_hip_group_create(const int* devices, int n, gamma_hip_group** out);
 int gamma_hip_group_destroy(gamma_hip_group* g);

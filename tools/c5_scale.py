@@ -1,7 +1,10 @@
 """C5-shaped run on one GPU: d=768 unit-normalised embedding-shaped vectors, inner product, nlist 4096, M 64
 (dsub 12), nprobe 64, recall_num 100, N vectors (default 2M) added in 100k chunks, with and without a 10 %
 range filter on an int column (device-side field filter).  Reports build time, QPS at 4096-query steps,
-recall@10 against the exact flat search, stage times."""
+recall@10 against the exact flat search, stage times.
+C5_NOISE=<sigma> (default 0.7): the per-coordinate noise of the mixture before normalisation -- at 0.7 a vector is two
+thirds noise by energy and 64 x 8-bit codes of a 768-d unit vector keep little of a neighbour ranking; C5_SWEEP=1: the
+recall_num / nprobe sweep towards the metric's recall@10 >= 0.95 with the QPS at each point."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -10,6 +13,7 @@ N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 2000000
 d, nlist, M, P, R, k, nq = 768, (int(sys.argv[2]) if len(sys.argv) > 2 else 4096), 64, 64, 100, 10, 4096
 dev = torch.device("cuda", 0)
 CH = 100000
+NOISE = float(os.environ.get("C5_NOISE", "0.7"))
 gen = torch.Generator(device=dev); gen.manual_seed(99)
 centres = torch.randn((4096, d), device=dev, generator=gen)
 
@@ -17,7 +21,7 @@ centres = torch.randn((4096, d), device=dev, generator=gen)
 def chunk(n, seed):
     g2 = torch.Generator(device=dev); g2.manual_seed(seed)
     lab = torch.randint(0, 4096, (n,), device=dev, generator=g2)
-    v = centres[lab] + 0.7 * torch.randn((n, d), device=dev, generator=g2)
+    v = centres[lab] + NOISE * torch.randn((n, d), device=dev, generator=g2)
     return torch.nn.functional.normalize(v, dim=1).cpu().numpy()
 
 
@@ -72,6 +76,28 @@ for name, ff, rf in legs:
     Df, If = g.flat_search(q[(steps - 1) % 2 * nq:][:64], k, api.SearchArgs(metric=api.METRIC_IP, min_score=-1e30, max_score=1e30, field_filters=ff))
     rec = np.mean([len(set(Ih[i].tolist()) & set(If[i].tolist()) - {-1}) / float(max(1, (If[i] >= 0).sum())) for i in range(64)])
     print("   recall@10 vs flat on 64 queries: %.3f" % rec)
+if os.environ.get("C5_SWEEP"):
+    g.profile_enable(False)
+    NR = 256
+    fl = api.SearchArgs(metric=api.METRIC_IP, min_score=-1e30, max_score=1e30)
+    Df, If = g.flat_search(q[:NR], k, fl)
+    print("sweep (noise %.2f, %d vectors): recall@10 vs flat on %d queries" % (NOISE, N, NR))
+    for P2, R2 in ((64, 100), (64, 200), (64, 400), (64, 1000), (64, 2000), (64, 4000), (128, 1000), (128, 4000), (256, 4000)):
+        if P2 > nlist:
+            continue
+        a2 = api.SearchArgs(metric=api.METRIC_IP, nprobe=P2, recall_num=R2, has_rank=True, min_score=-1e30, max_score=1e30)
+        for i in range(2):
+            g.ivfpq_search_device(dq.data_ptr(), nq, k, a2, D.data_ptr(), I.data_ptr())
+        g.synchronize()
+        t0 = time.perf_counter()
+        for i in range(4):
+            g.ivfpq_search_device(dq.data_ptr(), nq, k, a2, D.data_ptr(), I.data_ptr())
+        g.synchronize()
+        dt2 = (time.perf_counter() - t0) / 4
+        Ih = I[:NR].cpu().numpy()
+        rec2 = np.mean([len(set(Ih[i].tolist()) & set(If[i].tolist())) / float(k) for i in range(NR)])
+        print("   nprobe %3d recall_num %4d: recall@10 %.3f, %.2f ms per %d queries = %.0f queries/s" % (P2, R2, rec2, dt2 * 1e3, nq, nq / dt2))
+    g.profile_enable(True)
 # small calls (serving latency): device-buffer entry point, synchronised per call; small-batch chain / regular chain
 g.profile_enable(False)
 args = api.SearchArgs(metric=api.METRIC_IP, nprobe=P, recall_num=R, has_rank=True, min_score=-1e30, max_score=1e30)
