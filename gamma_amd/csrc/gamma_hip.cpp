@@ -123,7 +123,7 @@ int gamma_hip_destroy(gamma_hip_index* h) {
     if (h->dir_pin) (void)hipHostFree(h->dir_pin);
     DevBuf* bufs[] = {&h->w_mat, &h->w_coarse_dis, &h->w_probe, &h->w_xn, &h->w_st2, &h->w_pair_off,
                       &h->w_qtotal, &h->w_dist, &h->w_cand_dis, &h->w_cand_pos, &h->w_cand_ids,
-                      &h->w_exact, &h->w_selv, &h->w_selp, &h->w_x, &h->w_outd, &h->w_outl, &h->w_stage,
+                      &h->w_exact, &h->w_selv, &h->w_selp, &h->w_x, &h->w_outd, &h->w_outl, &h->w_stage, &h->w_shard_cut,
                       &h->w_filter, &h->w_m_dis, &h->w_m_ids, &h->w_part_v, &h->w_part_i, &h->w_assign,
                       &h->w_codes_tmp, &h->w_qperm, &h->w_qbins, &h->w_scnt, &h->w_sflag, &h->w_surv, &h->w_pair_base,
                       &h->w_pair_ip, &h->w_flat_cand, &h->w_flat_meta, &h->w_full_cdis,

@@ -123,6 +123,7 @@ struct gamma_hip_index {
     bool cmp_has_sums = false, cmp_sums_built = false;
     bool merge_flags = false;   // the last gamma_hip_ivfpq_merge_rerank left tie flags of its slice in w_tlist
     int shard_cut_nq = 0;       // the last shard search left the cut-tie flags of its nq queries in w_tcut
+    bool shard_cut_chunked = false;   // ... of a call of several chunks: gathered in w_shard_cut
     const uint8_t* merge_shard_flags = nullptr;   // [nshards][nq] for the next merge (gamma_hip_ivfpq_merge_set_shard_flags)
     int merge_nql = 0;
     std::mutex mu, search_mu, writer_mu;
@@ -193,6 +194,9 @@ struct gamma_hip_index {
     float* d_sums = nullptr;
     float* d_t2max = nullptr;
     bool keep_sums = false;   // set by Init: IVFPQ handles (GAMMA_HIP_NO_CODE_SUMS=1 turns the filter pass off)
+    // list shard over a supplied assignment (gamma_hip_ivfpq_search_shard_preassigned): the longest candidate row of the
+    // call, measured on the device -- the slab stride of its chunks (0: nprobe x the longest list)
+    int64_t q_stride_cap = 0;
     int64_t arena_cap = 0, arena_used = 0, arena_waste = 0;   // entries; waste = abandoned extents inside used
     // the three arena arrays (codes, ids, code sums) are mapped ranges like the raw store where the runtime allows:
     // growth maps chunks behind them -- no copy, no second arena, no exclusive lock (the reference grows per bucket for
@@ -215,7 +219,7 @@ struct gamma_hip_index {
 
     // workspace
     DevBuf w_mat, w_coarse_dis, w_probe, w_xn, w_st2, w_pair_off, w_qtotal, w_dist, w_cand_dis,
-            w_cand_pos, w_cand_ids, w_exact, w_selv, w_selp, w_x, w_outd, w_outl, w_stage, w_filter,
+            w_cand_pos, w_cand_ids, w_exact, w_selv, w_selp, w_x, w_outd, w_outl, w_stage, w_shard_cut, w_filter,
             w_m_dis, w_m_ids, w_part_v, w_part_i, w_assign, w_codes_tmp, w_qperm, w_qbins, w_scnt, w_sflag, w_surv, w_pair_base,
             w_pair_ip, w_flat_cand, w_flat_meta, w_full_cdis, w_full_probe, w_ftab, w_qfil, w_tieflag, w_tcut, w_tlist, w_textra, w_fq, w_fraw, w_frcnt, w_lm_units, w_lm_cnt, w_fbits, w_cmp_codes, w_cmp_ids, w_cmp_len, w_cmp_sums, w_fD, w_fI, w_fx, w_fslab, w_flog, w_mr_vals, w_mr_ids, w_mr_meta,
             we_mat, we_cdis, we_x, we_assign, we_codes, we_stage;   // writer side (encode, bitmap_set): never shared with a search

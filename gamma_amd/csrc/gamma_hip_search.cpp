@@ -288,6 +288,9 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         t2_bytes = owned * M * 256 * (int64_t)sizeof(float);
         const double exp_probes = (double)P * (double)owned / std::max(1, nlist);
         const double exp_cand = exp_probes * (owned ? (double)h->ntotal / (double)owned : 0.0);
+        // (not beyond that: one workgroup walking 50 k - 200 k codes of a query is the long pole of the launch -- full-size
+        //  C4 emulated, profiles/r04_scaling_emul.txt: W = 2 25.4 ms per step with 4 or 8 probes per workgroup, 27.9 with
+        //  16, 31.4 with 32 or 64; W = 4 27.0 / 27.1 / 30.1 / 30.3 / 30.2)
         if (exp_cand <= 16384.0) {
             G0 = 1;
             while (G0 < P) G0 <<= 1;
@@ -301,6 +304,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     //  gamma_hip_ivfpq_shard_cut_flags)
     h->tie.on = tie_on(p);
     h->shard_cut_nq = (shard && h->tie.on) ? nq : 0;
+    h->shard_cut_chunked = false;
     // Threshold pre-filter: scan the nearest probe group first, bound each query's R-th best
     // distance from it, and let the scan of the remaining groups keep a short survivor list per
     // query; the exact top-R then comes from a few hundred survivors instead of ~10^4 candidates
@@ -406,7 +410,8 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         h->last_qperm = qperm;   // stage B runs the re-rank in the same order
     }
     // per-query slab of the distance buffer; multiple of 4 floats so rows are 16-byte aligned
-    const int64_t q_stride = (std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len)) + 3) & ~(int64_t)3;
+    int64_t q_stride = (std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len)) + 3) & ~(int64_t)3;
+    if (shard && h->q_stride_cap > 0) q_stride = std::min(q_stride, h->q_stride_cap);
     GH_CHECK(h, h->w_dist.ensure((size_t)nq * q_stride * sizeof(float)));
     // dis0 of every (query, probe) pair: the coarse distance (L2) or <x_q, centroid> (inner product)
     const float* dis0 = h->w_coarse_dis.as<float>();
@@ -453,7 +458,11 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         sb.t2max = cf_ok ? h->d_t2max : nullptr;
         sb.cf_span = cf_ok ? cf_span : 0;
         scan(G, 0, PGM, &sb, true);
-        static const bool dbg = getenv("GAMMA_HIP_BOUND_DBG") != nullptr;
+        // GAMMA_HIP_BOUND_DBG=1: the bounded scan's statistics of the 9th .. 14th call; =shard: of list-shard calls only
+        static const bool dbg_any = getenv("GAMMA_HIP_BOUND_DBG") != nullptr;
+        static const bool dbg_shard = dbg_any && getenv("GAMMA_HIP_BOUND_DBG")[0] == 's';
+        const bool dbg = dbg_any && (!dbg_shard || shard);
+        static const int dbg_from = 8;
         static int shown = 0;
         StageScope t(h, GAMMA_HIP_STAGE_SELECT);
         gh::launch_select_final(s, l2, sb.surv, sb.gcnt, nsl, cap, sb.ready, h->w_pair_off.as<int>(), P, nq, R,
@@ -480,7 +489,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
             h->tie.nsl = nsl;
             h->tie.cap = cap;
         }
-        if (dbg && shown++ >= 8 && shown <= 13) {
+        if (dbg && shown++ >= dbg_from && shown <= dbg_from + 5) {
             std::vector<uint8_t> hf(nq);
             std::vector<int> hc((size_t)nq * nsl);
             (void)hipStreamSynchronize(s);
@@ -498,8 +507,8 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
                 mx = std::max<int64_t>(mx, hc[i]);
             }
             fprintf(stderr, "scan bound: %lld of %d queries unfiltered (%lld without a bound), survivors per query mean %.1f, "
-                    "per slice max %lld\n",
-                    (long long)nf, nq, (long long)nobound, (double)tot / nq, (long long)mx);
+                    "per slice max %lld; G %d, %d groups, %d slices, q_stride %lld\n",
+                    (long long)nf, nq, (long long)nobound, (double)tot / nq, (long long)mx, G, PGN, nsl, (long long)q_stride);
         }
         gh::launch_map_candidates(s, h->w_cand_pos.as<int>(), nq, R, P, h->w_probe.as<int>(),
                                   h->w_pair_off.as<int>(), h->d_list_off, h->d_ids,
@@ -1567,14 +1576,43 @@ int gamma_hip_ivfpq_search_shard_preassigned(gamma_hip_index* h, const gamma_hip
     GH_TRY(build_filter(h, p, &filt));
     FiltCtx fc;
     GH_TRY(filt_ctx_single(h, filt, &fc));
-    const int chunk = query_chunk(h, nq, P);
+    int chunk = query_chunk(h, nq, P);
+    struct StrideScope {   // the measured stride holds for this call only
+        H* h;
+        ~StrideScope() { h->q_stride_cap = 0; }
+    } stride_scope{h};
+    if (chunk < nq) {
+        // A shard scans ~P / W of a query's probes, but the slab stride of the general path is P x the longest list:
+        // the budget then cuts the batch (W times the queries of one rank) into many chunks, each with its own launches
+        // and its own handful of fallback queries (full-size C4, W = 8: 20 chunks, 5.7 ms of a 37 ms step).  The
+        // assignment is on the device: one small kernel measures the longest candidate row of THIS batch over THIS
+        // shard's lists, the host reads the one word back (the call is tens of milliseconds long) and sizes the chunks
+        // by it.
+        GH_CHECK(h, h->w_shard_cut.ensure(std::max<size_t>((size_t)nq, 16)));   // (its first word; the flags come later)
+        gh::launch_max_local_total(h->stream, d_probe, nq, P, h->d_list_len, h->d_list_mask, h->nlist, h->w_shard_cut.as<int>());
+        int mx = 0;
+        GH_CHECK(h, hipMemcpyAsync(&mx, h->w_shard_cut.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        GH_CHECK(h, hipStreamSynchronize(h->stream));
+        h->q_stride_cap = (std::max<int64_t>(mx, 1) + 3) & ~(int64_t)3;
+        const int64_t by_dist = (int64_t)(h->dist_budget_bytes / ((size_t)h->q_stride_cap * sizeof(float)));
+        chunk = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(by_dist, coarse_chunk(h, nq)), nq));
+    }
+    bool all_cut = true;
     for (int q0 = 0; q0 < nq; q0 += chunk) {
         const int nc = std::min(chunk, nq - q0);
         GH_TRY(ivfpq_stage_a(h, p, fc.at(q0), nc, d_x + (size_t)q0 * h->d, R, d_coarse_dis + (size_t)q0 * P,
                              d_probe + (size_t)q0 * P, /*shard=*/true, d_recall_dis + (size_t)q0 * R,
                              d_recall_ids + (size_t)q0 * R));
         h->last_nq = nc;
+        if (chunk < nq && h->shard_cut_nq == nc) {   // a call of several chunks: the cut-tie flags of all of them
+            GH_CHECK(h, h->w_shard_cut.ensure((size_t)nq));
+            GH_CHECK(h, hipMemcpyAsync(h->w_shard_cut.as<uint8_t>() + q0, h->w_tcut.p, (size_t)nc, hipMemcpyDeviceToDevice, h->stream));
+        } else if (chunk < nq) {
+            all_cut = false;
+        }
     }
+    h->shard_cut_chunked = chunk < nq && all_cut;
+    if (h->shard_cut_chunked) h->shard_cut_nq = nq;
     h->last_P = P;
     h->last_R = R;
     return GAMMA_HIP_OK;
@@ -1643,7 +1681,8 @@ int gamma_hip_ivfpq_shard_cut_flags(gamma_hip_index* h, int nq, uint8_t* d_flags
     SearchLock lk(h);
     GH_CHECK(h, hipSetDevice(h->device));
     if (h->shard_cut_nq == nq) {
-        GH_CHECK(h, hipMemcpyAsync(d_flags, h->w_tcut.p, (size_t)nq, hipMemcpyDeviceToDevice, h->stream));
+        GH_CHECK(h, hipMemcpyAsync(d_flags, h->shard_cut_chunked ? h->w_shard_cut.p : h->w_tcut.p, (size_t)nq,
+                                   hipMemcpyDeviceToDevice, h->stream));
     } else {
         // no flags from the last shard search (exact ties off, or beyond the replay's range): "may have cut a tie"
         GH_CHECK(h, hipMemsetAsync(d_flags, 1, (size_t)nq, h->stream));

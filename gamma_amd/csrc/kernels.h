@@ -191,6 +191,9 @@ bool query_order_grid(int nq);   // the batch is sorted over the whole grid (nee
 void launch_query_order(hipStream_t s, const int* probe_list, int nq, int P, const int* list_rank,
                         int nlist, int* qkey, int* qperm, int* bins = nullptr, bool hist_done = false);
 void launch_sum_totals(hipStream_t s, const int* q_total, int nq, unsigned long long* acc);
+// list shard over a supplied assignment: *out_max = the longest candidate row of the batch over the lists scanned here
+void launch_max_local_total(hipStream_t s, const int* probe_list, int nq, int P, const int* list_len,
+                            const uint8_t* list_mask, int nlist, int* out_max);
 int select_kpad(int K);
 // coarse quantizer selection (ties at the K-th distance resolved like the reference's heap); tie_flag: nq bytes
 // coarse.hip: coarse quantizer of a large batch without the distance matrix (sample -> bound -> filtered GEMM

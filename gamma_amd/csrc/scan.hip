@@ -660,6 +660,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
             }
             __syncthreads();
             tau = s_tau;
+        } else {
+            // fewer than K candidates in the first group (a shard that holds one short list of the query, the tail of
+            // a filter): everything valid is a survivor -- the widest bound there is.  The group's own < K candidates
+            // fit its slice; consumers append all of theirs (a slice that overflows sends the query to the unfiltered
+            // selection, as ever).  Without this such a query had no bound and went there always: a handful per chunk of a
+            // list shard, each a latency-bound pass over its slab behind the chunk's scan.
+            tau = KEY_SENTINEL - 1u;
         }
         if (threadIdx.x == 0)
             __hip_atomic_store(&sb.ready[q], tau < KEY_SENTINEL ? ((1ull << 32) | tau) : (2ull << 32),
@@ -711,7 +718,8 @@ bool scan_cf_applies(bool l2, int M, int P, int G, bool have_sums, bool store_al
 
 int scan_group_size(int nq, int P, int G0) {
     // probes per workgroup: amortise the query table, but keep >= ~4096 workgroups in flight
-    static const int g_env = getenv("GAMMA_HIP_SCAN_G") ? atoi(getenv("GAMMA_HIP_SCAN_G")) : 0;
+    const char* ge = getenv("GAMMA_HIP_SCAN_G");   // (read per call: tools sweep it inside one process)
+    const int g_env = ge ? atoi(ge) : 0;
     int G = g_env > 0 ? g_env : G0;
     while (G > 1 && (int64_t)nq * ((P + G - 1) / G) < 4096) G >>= 1;
     return std::max(1, std::min(G, P));

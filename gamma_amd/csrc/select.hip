@@ -922,8 +922,9 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
         }
         pp[r] = lo;
     }
+    // (no survivor at all -- a shard that holds none of the query's probed lists: nothing to look up)
 #pragma unroll
-    for (int r = 0; r < 4; r++) idv[r] = ids[lbase[pp[r]] + (ps[r] - off[pp[r]])];
+    for (int r = 0; r < 4; r++) idv[r] = nres > 0 ? ids[lbase[pp[r]] + (ps[r] - off[pp[r]])] : -1;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int rank = lane + 64 * r;
@@ -934,7 +935,7 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
             out_ids[(int64_t)q * K + rank] = idv[r] & 0x7fffffffffffffffLL;
         }
     }
-    for (int r = m + lane; r < K; r += 64) {   // fewer than K survivors cannot happen with a bound; be safe
+    for (int r = m + lane; r < K; r += 64) {   // fewer than K candidates in all (the widest bound, scan.hip)
         out_vals[(int64_t)q * K + r] = sentinel;
         out_pos[(int64_t)q * K + r] = -1;
         out_ids[(int64_t)q * K + r] = -1;

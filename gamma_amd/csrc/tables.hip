@@ -258,6 +258,33 @@ void launch_pair_offsets(hipStream_t s, const int* probe_list, int nq, int P, co
         hipLaunchKernelGGL(k_sum_totals, dim3(std::min(64, (nq + 255) / 256)), dim3(256), 0, s, q_total, nq,
                            scan_codes);
 }
+// list shard over a supplied assignment: the longest candidate row any query of the batch gets from the lists this
+// handle scans (its slab stride; the host reads it back before it sizes the chunks of the call)
+__global__ __launch_bounds__(256) void k_max_local_total(const int* __restrict__ probe_list, int nq, int P,
+                                                         const int* __restrict__ list_len,
+                                                         const uint8_t* __restrict__ list_mask, int nlist,
+                                                         int* __restrict__ out_max) {
+    const int lane = threadIdx.x & 63;
+    int best = 0;
+    for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < nq; q += gridDim.x * 4) {
+        int t = 0;
+        for (int p = lane; p < P; p += 64) {
+            const int l = probe_list[(int64_t)q * P + p];
+            if (l >= 0 && l < nlist && (!list_mask || list_mask[l])) t += max(list_len[l], 0);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+        best = max(best, t);
+    }
+    if (lane == 0 && best > 0) atomicMax(out_max, best);
+}
+void launch_max_local_total(hipStream_t s, const int* probe_list, int nq, int P, const int* list_len,
+                            const uint8_t* list_mask, int nlist, int* out_max) {
+    (void)hipMemsetAsync(out_max, 0, sizeof(int), s);
+    if (nq > 0)
+        hipLaunchKernelGGL(k_max_local_total, dim3(std::min(2048, (nq + 3) / 4)), dim3(256), 0, s, probe_list, nq, P, list_len,
+                           list_mask, nlist, out_max);
+}
 void launch_sum_totals(hipStream_t s, const int* q_total, int nq, unsigned long long* acc) {
     if (nq > 0 && acc)
         hipLaunchKernelGGL(k_sum_totals, dim3(std::min(64, (nq + 255) / 256)), dim3(256), 0, s, q_total, nq, acc);

@@ -380,14 +380,18 @@ def _shard_of(z, tag, base, metric, owner, s):
     return g
 
 
-@pytest.mark.parametrize("tag,W,reps,has_rank", [("l2", 2, 1, True), ("l2", 3, 13, True), ("ip", 2, 13, True), ("l2", 2, 13, False),
-                                                 ("l2", 4, 90, True)])
-def test_exact_ties_across_list_shards(tag, W, reps, has_rank):
+@pytest.mark.parametrize("tag,W,reps,has_rank,small_budget", [
+    ("l2", 2, 1, True, False), ("l2", 3, 13, True, False), ("ip", 2, 13, True, False), ("l2", 2, 13, False, False),
+    ("l2", 4, 90, True, False), ("l2", 2, 13, True, True), ("ip", 4, 90, True, True)])
+def test_exact_ties_across_list_shards(tag, W, reps, has_rank, small_budget):
     """W shards emulated on one GPU through the C ABI (what gamma_hip_group / dist.py drive): coarse per slice, shard scans,
     merge + re-rank at the slice's owner -- then the tie phase: the owner lists the queries a tie can change
     (gamma_hip_ivfpq_merge_flagged), every shard exports their candidate streams over the lists it owns
     (gamma_hip_ivfpq_shard_export), the owner assembles and replays them (gamma_hip_ivfpq_merge_replay).  Expected: the
-    pinned oracle on the unsharded index, labels strictly."""
+    pinned oracle on the unsharded index, labels strictly.  90 repetitions: >= 4096 queries per shard call (one workgroup per
+    query whatever the lists' length).  small_budget: the workspace budget holds the slab of ~40 queries at the general
+    stride (nprobe x the longest list), so the shard call measures the longest candidate row of the batch on the device,
+    sizes its chunks by that, and gathers the chunks' cut-tie flags."""
     import torch
     from gamma_amd import dist as gdist
     z, o, base, metric = load_ties(tag)
@@ -410,6 +414,12 @@ def test_exact_ties_across_list_shards(tag, W, reps, has_rank):
         D, I, flagged = sharded_search_emulated(shards, x, k, args, use_shard_flags=(W != 3))
         assert flagged > 0
         compare_exact(Dexp, Iexp, D.cpu().numpy(), I.cpu().numpy())
+        if small_budget:
+            for g in shards:
+                g.set_dist_budget(40 * nprobe * max(1, g.max_list_len()) * 4)
+            D2, I2, flagged2 = sharded_search_emulated(shards, x, k, args, use_shard_flags=True)
+            assert flagged2 == flagged   # the chunks' own flags reached the merge (not "every query may have cut a tie")
+            compare_exact(Dexp, Iexp, D2.cpu().numpy(), I2.cpu().numpy())
     finally:
         for g in shards:
             g.close()

@@ -100,21 +100,26 @@ if os.environ.get("C4_EMUL"):
             g.ivfpq_search_shard_preassigned(dqq.data_ptr(), gnq, cdis.data_ptr(), probe.data_ptr(), k, args, rdis.data_ptr(),
                                              rids.data_ptr())
             g.ivfpq_merge_rerank(W, nq, dqq.data_ptr(), k, args, rdis.data_ptr(), rids.data_ptr(), 0, nq, D2.data_ptr(), I2.data_ptr())
-        for _ in range(2):
-            estep()
-        g.synchronize()
-        g.profile_enable(True); g.profile_reset()
-        t0 = time.perf_counter()
-        for _ in range(4):
-            estep()
-        g.synchronize()
-        de = (time.perf_counter() - t0) / 4
-        pr = g.profile()
-        print("emulated rank of W=%d (lists of shard 0: %.1f M of %.1f M vectors): %.2f ms per step of %d queries (%d per rank) "
-              "against %.2f ms for %d queries on one GPU -> per-rank compute efficiency %.0f %%; stage ms/step %s" % (
-                  W, sizes[owner == 0].sum() / 1e6, sizes.sum() / 1e6, de * 1e3, gnq, nq, base_ms, nq, 100.0 * base_ms / (de * 1e3),
-                  {n: round(pr[n][0] / 4, 3) for n in pr if isinstance(pr[n], tuple) and pr[n][1]}))
-        g.profile_enable(False)
+        for Genv in os.environ.get("C4_EMUL_G", "0").split(","):
+            if Genv != "0":
+                os.environ["GAMMA_HIP_SCAN_G"] = Genv     # probes per workgroup forced (the library reads it per call)
+                print("GAMMA_HIP_SCAN_G=%s:" % Genv, end=" ")
+            for _ in range(2):
+                estep()
+            g.synchronize()
+            g.profile_enable(True); g.profile_reset()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                estep()
+            g.synchronize()
+            de = (time.perf_counter() - t0) / 4
+            pr = g.profile()
+            os.environ.pop("GAMMA_HIP_SCAN_G", None)
+            print("emulated rank of W=%d (lists of shard 0: %.1f M of %.1f M vectors): %.2f ms per step of %d queries (%d per rank) "
+                  "against %.2f ms for %d queries on one GPU -> per-rank compute efficiency %.0f %%; stage ms/step %s" % (
+                      W, sizes[owner == 0].sum() / 1e6, sizes.sum() / 1e6, de * 1e3, gnq, nq, base_ms, nq, 100.0 * base_ms / (de * 1e3),
+                      {n: round(pr[n][0] / 4, 3) for n in pr if isinstance(pr[n], tuple) and pr[n][1]}))
+            g.profile_enable(False)
     g.set_list_mask(None)
 g.profile_enable(True)
 if os.environ.get("C4_FILTER"):   # a request bitmap that keeps every tenth document (what the engine's range index hands over)
