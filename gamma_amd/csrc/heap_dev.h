@@ -278,4 +278,113 @@ struct RegHeap {
     }
 };
 
+// ---- the sifts with all 64 lanes (LDS heap, k <= 128 NPL nodes).  A sift cannot be cut short -- but which way it goes
+//      does not depend on what is sifted: from every internal node the walk continues to its LARGER child (Heap.h:56-70),
+//      and the sifted value only decides where it stops.  So one step does every node at once: each lane reads the two
+//      children of its node(s) (one 16-byte LDS read), two ballots say for every node which child is larger and whether
+//      the sifted value would go on below it, the path from the root is a scalar walk over those two bit masks (no
+//      memory), and the lanes of the nodes on it write their larger child's entry into their own node in one store.
+//      heap_push: the ancestors of slot k are k >> 1, k >> 2, ..: lane j reads the j-th, one ballot says how far the
+//      new value rises, the lanes below that store their ancestor one level down.
+//      One pop + push costs three LDS round trips instead of one per level of each -- 14 at k = 100.  The heap array
+//      goes through exactly the states of the sequential code (same moves, same final slot).  All lanes of ONE wave
+//      call every member together.
+template <int NPL>
+struct ParHeap {
+    // the sift of heap_pop / heap_replace_top over nodes 1..k with (val, pay) entering at the root; returns the root's value
+    static __device__ __forceinline__ float sift_down(uint2* h, int k, float val, unsigned pay) {
+        const int lane = threadIdx.x & 63;
+        unsigned cv[NPL], cp[NPL];
+        unsigned long long pick1[NPL], le[NPL], mv[NPL];   // bit b of mask t: node 64 t + b + 1
+#pragma unroll
+        for (int t = 0; t < NPL; t++) {
+            const int i = lane + 64 * t + 1;
+            const bool in = 2 * i <= k;
+            const uint4 c = in ? *reinterpret_cast<const uint4*>(h + 2 * i) : make_uint4(0u, 0u, 0u, 0u);
+            const float v1 = __uint_as_float(c.x), v2 = __uint_as_float(c.z);
+            const bool p1 = 2 * i == k || v1 > v2;
+            const float v = p1 ? v1 : v2;
+            cv[t] = __float_as_uint(v);
+            cp[t] = p1 ? c.y : c.w;
+            pick1[t] = __ballot(in && p1);
+            le[t] = __ballot(in && !(val > v));   // the sifted value goes on below this node
+            mv[t] = 0ull;
+        }
+        int cur = 1;
+        while (2 * cur <= k) {
+            const int u = (cur - 1) >> 6;
+            const unsigned long long bit = 1ull << ((cur - 1) & 63);
+            unsigned long long le_u = le[0], p1_u = pick1[0];
+#pragma unroll
+            for (int t = 1; t < NPL; t++) {
+                le_u = u == t ? le[t] : le_u;
+                p1_u = u == t ? pick1[t] : p1_u;
+            }
+            if (!(le_u & bit)) break;
+#pragma unroll
+            for (int t = 0; t < NPL; t++) mv[t] |= u == t ? bit : 0ull;
+            cur = 2 * cur + ((p1_u & bit) ? 0 : 1);
+        }
+        const float root = (mv[0] & 1ull) ? __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)cv[0], 0)) : val;
+#pragma unroll
+        for (int t = 0; t < NPL; t++)
+            if ((mv[t] >> lane) & 1ull) h[lane + 64 * t + 1] = make_uint2(cv[t], cp[t]);
+        if (lane == 0) h[cur] = make_uint2(__float_as_uint(val), pay);
+        __builtin_amdgcn_wave_barrier();
+        return root;
+    }
+    // heap_pop over k nodes (Heap.h:46-72); returns the root's value afterwards
+    static __device__ __forceinline__ float pop(uint2* h, int k) {
+        const uint2 last = h[k];
+        return sift_down(h, k, hs_f(last.x), hs_u(last.y));
+    }
+    // heap_push into slot k (Heap.h:77-100); true when the new entry became the root
+    static __device__ __forceinline__ bool push(uint2* h, int k, float val, unsigned pay) {
+        const int lane = threadIdx.x & 63;
+        const int a = lane < 31 ? k >> (lane + 1) : 0;   // the (lane + 1)-th ancestor of slot k
+        const uint2 e = a >= 1 ? h[a] : make_uint2(0u, 0u);
+        const unsigned long long up = __ballot(a >= 1 && val > __uint_as_float(e.x));
+        const int t = (int)__ffsll((long long)~up) - 1;   // ancestors the value passes: 0 .. t - 1
+        if (lane < t) h[k >> lane] = e;
+        const int slot = k >> t;
+        if (lane == 0) h[slot] = make_uint2(__float_as_uint(val), pay);
+        __builtin_amdgcn_wave_barrier();
+        return slot == 1;
+    }
+    // heap_reorder (Heap.h:300-330) with parallel pops
+    static __device__ __forceinline__ int reorder(uint2* h, int k) {
+        int ii = 0;
+        for (int i = 0; i < k; i++) {
+            const uint2 r = h[1];
+            const float val = hs_f(r.x);
+            const unsigned idv = hs_u(r.y);
+            (void)pop(h, k - i);
+            h[k - ii] = make_uint2(__float_as_uint(val), idv);   // 0-based slot k - ii - 1
+            __builtin_amdgcn_wave_barrier();
+            if (idv != 0xffffffffu) ii++;
+        }
+        return heap_reorder_tail(h, k, ii);
+    }
+};
+// by heap size (k <= 1024; beyond: the sequential forms)
+__device__ __forceinline__ float par_heap_pop(uint2* h, int k) {
+    if (k <= 128) return ParHeap<1>::pop(h, k);
+    if (k <= 256) return ParHeap<2>::pop(h, k);
+    return ParHeap<8>::pop(h, k);
+}
+__device__ __forceinline__ int par_heap_reorder(uint2* h, int k) {
+    if (k <= 128) return ParHeap<1>::reorder(h, k);
+    if (k <= 256) return ParHeap<2>::reorder(h, k);
+    if (k <= 1024) return ParHeap<8>::reorder(h, k);
+    return heap_reorder_seq(h, k);
+}
+constexpr int kParHeapMaxK = 1024;
+__device__ __forceinline__ bool par_heap_push(uint2* h, int k, float val, unsigned pay) { return ParHeap<1>::push(h, k, val, pay); }
+// the sift of heap_replace_top over k nodes
+__device__ __forceinline__ float par_heap_replace_top(uint2* h, int k, float val, unsigned pay) {
+    if (k <= 128) return ParHeap<1>::sift_down(h, k, val, pay);
+    if (k <= 256) return ParHeap<2>::sift_down(h, k, val, pay);
+    return ParHeap<8>::sift_down(h, k, val, pay);
+}
+
 }  // namespace gh

@@ -7,7 +7,7 @@
 // threshold) to between K and (capacity + K) / 2 entries; to_result pushes the first K entries into a heap,
 // heap_addn's the rest and reorders.  The array a reservoir ends with depends on its whole history, so a row whose
 // selection can be changed by ties is replayed in full, one wave per row: the 64 lanes test 64 candidates per ballot,
-// count / sample / compact 64 slots per step; the heap phases are the sequential forms of heap_dev.h.
+// count / sample / compact 64 slots per step; the heap phases are heap_dev.h's ParHeap (all lanes per sift).
 // oracle/gamma_oracle.c (go_reservoir_stream) is the CPU restatement, pinned against the compiled library.
 #pragma once
 #include "heap_dev.h"
@@ -153,18 +153,18 @@ __device__ __forceinline__ int reservoir_row(const float* __restrict__ v, int n,
     }
     // to_result (ResultHandler.h:172-186)
     const int m0 = min(cnt, K);
-    for (int j = 0; j < m0; j++) heap_push_seq(h, j + 1, hs_f(__float_as_uint(sv[j])), hs_u((unsigned)si[j]));
+    for (int j = 0; j < m0; j++) (void)par_heap_push(h, j + 1, hs_f(__float_as_uint(sv[j])), hs_u((unsigned)si[j]));
     if (cnt < K) {
-        const int real = heap_reorder_seq(h, cnt);
+        const int real = cnt > 0 ? par_heap_reorder(h, cnt) : 0;
         for (int i = cnt + lane; i < K; i += 64) h[1 + i] = make_uint2(__float_as_uint(kHeapFltMax), 0xffffffffu);
         __builtin_amdgcn_wave_barrier();
         return real;
     }
     for (int j = K; j < cnt; j++) {   // heap_addn (Heap.h:247-260)
         const float x = hs_f(__float_as_uint(sv[j]));
-        if (hs_f(h[1].x) > x) heap_sift_down_seq(h, K, x, hs_u((unsigned)si[j]));
+        if (hs_f(h[1].x) > x) (void)par_heap_replace_top(h, K, x, hs_u((unsigned)si[j]));
     }
-    return heap_reorder_seq(h, K);
+    return par_heap_reorder(h, K);
 }
 
 }  // namespace gh

@@ -1346,7 +1346,7 @@ __global__ __launch_bounds__(256) void k_coarse_heap_fix(const float* __restrict
         rh.dump(h, K);
         heap_reorder_tail(h, K, real);
     } else {
-        heap_reorder_seq(h, K);
+        par_heap_reorder(h, K);
     }
     for (int r = lane; r < K; r += 64) {
         const uint2 e = h[1 + r];
@@ -1881,7 +1881,7 @@ __device__ __forceinline__ void small_coarse_select_body(int q, const SmallSelec
                     for (int u = 0; u < 16; u++) t[u] = tn[u];
                 }
                 hw.drain();
-                const int nreal = heap_reorder_seq(s_heap, K);
+                const int nreal = par_heap_reorder(s_heap, K);
                 for (int r = lane; r < K; r += 64) {
                     const uint2 e = s_heap[1 + r];
                     s_it[r] = (int)e.y < 0 ? ~0ull : (((unsigned long long)f2key(__uint_as_float(e.x)) << 32) | e.y);

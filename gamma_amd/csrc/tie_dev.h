@@ -100,7 +100,10 @@ __device__ __forceinline__ void tie_replay_query(const TieReplayArgs& a, int q, 
     //  lane i, a level is two readlanes instead of an LDS round trip (~135 ns per accepted candidate at k = 10); the array
     //  goes to LDS once, when the stream is through.  With two registers (k <= 127) the lane / register selects cost what the
     //  LDS round trip does: measured at k = 100, 0.80 ms for a 16384-row slab against 0.74 -- not used.)
+    // Beyond 63 entries (flat search at k = 100): the sifts run with all 64 lanes (ParHeap, heap_dev.h) -- three LDS round
+    // trips per accepted candidate instead of one per level of the pop and of the push.
     const bool reg_heap = a.pop_push && R <= 63;
+    const bool par_heap = a.pop_push && !reg_heap && R <= kParHeapMaxK;
     RegHeap<1> rh;
     rh.fill();
     auto take = [&](bool valid, float dv, int pay) {
@@ -117,6 +120,9 @@ __device__ __forceinline__ void tie_replay_query(const TieReplayArgs& a, int q, 
                 rh.pop(R);
                 rh.push(R, val, (unsigned)hw_readlane_i(pay, l));
                 ptop = rh.top();
+            } else if (par_heap) {
+                const float root = par_heap_pop(L.hR, R);
+                ptop = par_heap_push(L.hR, R, val, (unsigned)hw_readlane_i(pay, l)) ? val : root;
             } else {
                 heap_pop_seq(L.hR, R);
                 heap_push_seq(L.hR, R, val, (unsigned)hw_readlane_i(pay, l));
@@ -271,14 +277,19 @@ __device__ __forceinline__ void tie_replay_query(const TieReplayArgs& a, int q, 
                 while (m) {
                     const int l = (int)__ffsll((long long)m) - 1;
                     const float val = hw_readlane_f(dv, l);
-                    heap_pop_seq(L.hK, k);   // heap_pop + heap_push (gamma_index_ivfpq.cc:664-676)
-                    heap_push_seq(L.hK, k, val, (unsigned)(j0 + l));
-                    top = hs_f(L.hK[1].x);
+                    if (k <= kParHeapMaxK) {   // heap_pop + heap_push (gamma_index_ivfpq.cc:664-676), all lanes per sift
+                        const float root = par_heap_pop(L.hK, k);
+                        top = par_heap_push(L.hK, k, val, (unsigned)(j0 + l)) ? val : root;
+                    } else {
+                        heap_pop_seq(L.hK, k);
+                        heap_push_seq(L.hK, k, val, (unsigned)(j0 + l));
+                        top = hs_f(L.hK[1].x);
+                    }
                     const unsigned long long above = l >= 63 ? 0ull : (~0ull << (l + 1));
                     m = __ballot(top > dv) & above;
                 }
             }
-            heap_reorder_seq(L.hK, k);
+            par_heap_reorder(L.hK, k);
         }
         __syncthreads();
         GH_TT(5);
@@ -309,7 +320,7 @@ __device__ __forceinline__ void tie_replay_query(const TieReplayArgs& a, int q, 
         GH_TT(6);
     } else {
         // without rank: heap_reorder of the R-heap is the result (gamma_index_ivfpq.cc:681-696)
-        if (wv == 0) heap_reorder_seq(L.hR, R);
+        if (wv == 0) par_heap_reorder(L.hR, R);
         __syncthreads();
         GH_TT(4);
         for (int j = tid; j < R; j += NT) {
