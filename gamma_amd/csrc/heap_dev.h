@@ -278,57 +278,86 @@ struct RegHeap {
     }
 };
 
-// ---- the sifts with all 64 lanes (LDS heap, k <= 128 NPL nodes).  A sift cannot be cut short -- but which way it goes
-//      does not depend on what is sifted: from every internal node the walk continues to its LARGER child (Heap.h:56-70),
-//      and the sifted value only decides where it stops.  So one step does every node at once: each lane reads the two
-//      children of its node(s) (one 16-byte LDS read), two ballots say for every node which child is larger and whether
-//      the sifted value would go on below it, the path from the root is a scalar walk over those two bit masks (no
-//      memory), and the lanes of the nodes on it write their larger child's entry into their own node in one store.
-//      heap_push: the ancestors of slot k are k >> 1, k >> 2, ..: lane j reads the j-th, one ballot says how far the
-//      new value rises, the lanes below that store their ancestor one level down.
-//      One pop + push costs three LDS round trips instead of one per level of each -- 14 at k = 100.  The heap array
-//      goes through exactly the states of the sequential code (same moves, same final slot).  All lanes of ONE wave
-//      call every member together.
-template <int NPL>
+// ---- the sifts with all 64 lanes (LDS heap of k <= 128 NPL entries: lane l holds the internal nodes l + 1 + 64 t).
+//      A sift cannot be cut short -- but which way it goes does not depend on what is sifted: from every internal node
+//      the walk continues to its LARGER child (Heap.h:56-70), and the sifted value only decides where it stops.  So one
+//      step does every node at once: each lane reads the two children of its node(s) (one 16-byte LDS read); two ballots
+//      say for every node which child is larger and whether the sifted value would go on below it; "the walk reaches
+//      node i" = every step from the root towards i is the one the walk takes, an AND along i's ancestors, evaluated for
+//      all nodes in three doubling rounds (ballot + shift, no memory, no loop over levels -- a scalar walk over the masks
+//      costs ~100 cycles a level on this chip); the lanes of the nodes the walk passes write their larger child's entry
+//      into their own node in one store.  heap_push: the ancestors of slot k are k >> 1, k >> 2, ..: lane j reads the
+//      j-th, one ballot says how far the new value rises, the lanes below that store their ancestor one level down.
+//      Measured (tools/exp/heap_bench.hip, one wave, k = 100): pop + push 1018 ns sequential, 768 with a scalar walk,
+//      450 with the doubling rounds (590 at k = 200 against 1150).  The heap array goes through exactly the states of the sequential code (same
+//      moves, same final slot).  All lanes of ONE wave call every member together.
+template <int NPL>   // 1 or 2
 struct ParHeap {
+    static_assert(NPL == 1 || NPL == 2, "masks of 64 NPL nodes");
+    struct Mask {
+        unsigned long long w[NPL];
+        // bit of node n (1-based); node 0 = "above the root": true
+        __device__ __forceinline__ bool at(int n) const {
+            if (n < 1) return true;
+            const unsigned long long m = (NPL == 2 && n > 64) ? w[NPL - 1] : w[0];
+            return ((m >> ((n - 1) & 63)) & 1ull) != 0ull;
+        }
+    };
+    static __device__ __forceinline__ Mask vote(const bool (&b)[NPL]) {
+        Mask m;
+#pragma unroll
+        for (int t = 0; t < NPL; t++) m.w[t] = __ballot(b[t]);
+        return m;
+    }
     // the sift of heap_pop / heap_replace_top over nodes 1..k with (val, pay) entering at the root; returns the root's value
     static __device__ __forceinline__ float sift_down(uint2* h, int k, float val, unsigned pay) {
         const int lane = threadIdx.x & 63;
         unsigned cv[NPL], cp[NPL];
-        unsigned long long pick1[NPL], le[NPL], mv[NPL];   // bit b of mask t: node 64 t + b + 1
+        bool in[NPL], p1[NPL], le[NPL], g[NPL];
 #pragma unroll
         for (int t = 0; t < NPL; t++) {
             const int i = lane + 64 * t + 1;
-            const bool in = 2 * i <= k;
-            const uint4 c = in ? *reinterpret_cast<const uint4*>(h + 2 * i) : make_uint4(0u, 0u, 0u, 0u);
+            in[t] = 2 * i <= k;
+            const uint4 c = in[t] ? *reinterpret_cast<const uint4*>(h + 2 * i) : make_uint4(0u, 0u, 0u, 0u);
             const float v1 = __uint_as_float(c.x), v2 = __uint_as_float(c.z);
-            const bool p1 = 2 * i == k || v1 > v2;
-            const float v = p1 ? v1 : v2;
+            p1[t] = in[t] && (2 * i == k || v1 > v2);
+            const float v = p1[t] ? v1 : v2;
             cv[t] = __float_as_uint(v);
-            cp[t] = p1 ? c.y : c.w;
-            pick1[t] = __ballot(in && p1);
-            le[t] = __ballot(in && !(val > v));   // the sifted value goes on below this node
-            mv[t] = 0ull;
+            cp[t] = p1[t] ? c.y : c.w;
+            le[t] = in[t] && !(val > v);   // the sifted value goes on below this node
         }
+        const Mask P1 = vote(p1), LE = vote(le);
+        // g(i): the walk, IF it reaches i's parent, steps to i
+#pragma unroll
+        for (int t = 0; t < NPL; t++) {
+            const int i = lane + 64 * t + 1, p = i >> 1;
+            g[t] = i == 1 || (LE.at(p) && P1.at(p) == ((i & 1) == 0));
+        }
+        // reaches(i) = g(i) & g(i >> 1) & g(i >> 2) & ..: three doubling rounds cover 8 levels (i <= 255)
+        Mask G = vote(g);
+#pragma unroll
+        for (int t = 0; t < NPL; t++) g[t] = g[t] && G.at((lane + 64 * t + 1) >> 1);
+        G = vote(g);
+#pragma unroll
+        for (int t = 0; t < NPL; t++) g[t] = g[t] && G.at((lane + 64 * t + 1) >> 2);
+        G = vote(g);
+        bool mv[NPL];
+#pragma unroll
+        for (int t = 0; t < NPL; t++) mv[t] = g[t] && G.at((lane + 64 * t + 1) >> 4) && le[t];   // passed: the child moves up
+        const Mask MV = vote(mv);
+        // where the value lands: below the deepest node passed (nodes on the walk grow with depth), or at the root
         int cur = 1;
-        while (2 * cur <= k) {
-            const int u = (cur - 1) >> 6;
-            const unsigned long long bit = 1ull << ((cur - 1) & 63);
-            unsigned long long le_u = le[0], p1_u = pick1[0];
-#pragma unroll
-            for (int t = 1; t < NPL; t++) {
-                le_u = u == t ? le[t] : le_u;
-                p1_u = u == t ? pick1[t] : p1_u;
-            }
-            if (!(le_u & bit)) break;
-#pragma unroll
-            for (int t = 0; t < NPL; t++) mv[t] |= u == t ? bit : 0ull;
-            cur = 2 * cur + ((p1_u & bit) ? 0 : 1);
+        if (NPL == 2 && MV.w[NPL - 1] != 0ull) {
+            const int m = 128 - __builtin_clzll(MV.w[NPL - 1]);
+            cur = 2 * m + (P1.at(m) ? 0 : 1);
+        } else if (MV.w[0] != 0ull) {
+            const int m = 64 - __builtin_clzll(MV.w[0]);
+            cur = 2 * m + (P1.at(m) ? 0 : 1);
         }
-        const float root = (mv[0] & 1ull) ? __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)cv[0], 0)) : val;
+        const float root = (MV.w[0] & 1ull) ? __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)cv[0], 0)) : val;
 #pragma unroll
         for (int t = 0; t < NPL; t++)
-            if ((mv[t] >> lane) & 1ull) h[lane + 64 * t + 1] = make_uint2(cv[t], cp[t]);
+            if (mv[t]) h[lane + 64 * t + 1] = make_uint2(cv[t], cp[t]);
         if (lane == 0) h[cur] = make_uint2(__float_as_uint(val), pay);
         __builtin_amdgcn_wave_barrier();
         return root;
@@ -366,25 +395,22 @@ struct ParHeap {
         return heap_reorder_tail(h, k, ii);
     }
 };
-// by heap size (k <= 1024; beyond: the sequential forms)
+// by heap size (k <= 256; beyond: the sequential forms -- eight nodes per lane lose to them)
+constexpr int kParHeapMaxK = 256;
 __device__ __forceinline__ float par_heap_pop(uint2* h, int k) {
     if (k <= 128) return ParHeap<1>::pop(h, k);
-    if (k <= 256) return ParHeap<2>::pop(h, k);
-    return ParHeap<8>::pop(h, k);
+    return ParHeap<2>::pop(h, k);
 }
 __device__ __forceinline__ int par_heap_reorder(uint2* h, int k) {
     if (k <= 128) return ParHeap<1>::reorder(h, k);
     if (k <= 256) return ParHeap<2>::reorder(h, k);
-    if (k <= 1024) return ParHeap<8>::reorder(h, k);
     return heap_reorder_seq(h, k);
 }
-constexpr int kParHeapMaxK = 1024;
 __device__ __forceinline__ bool par_heap_push(uint2* h, int k, float val, unsigned pay) { return ParHeap<1>::push(h, k, val, pay); }
-// the sift of heap_replace_top over k nodes
+// the sift of heap_replace_top over k <= 256 nodes
 __device__ __forceinline__ float par_heap_replace_top(uint2* h, int k, float val, unsigned pay) {
     if (k <= 128) return ParHeap<1>::sift_down(h, k, val, pay);
-    if (k <= 256) return ParHeap<2>::sift_down(h, k, val, pay);
-    return ParHeap<8>::sift_down(h, k, val, pay);
+    return ParHeap<2>::sift_down(h, k, val, pay);
 }
 
 }  // namespace gh

@@ -1339,7 +1339,7 @@ __global__ __launch_bounds__(256) void k_coarse_heap_fix(const float* __restrict
     hw.drain();
     // heap_reorder (faiss:impl/ResultHandler.h:112-117): K pops; with the heap in registers a level of a sift is a few
     // scalar instructions instead of an LDS round trip
-    if (K <= 63) {
+    if (K <= 15) {
         RegHeap<1> rh;
         rh.load(h, K);
         const int real = rh.reorder_pops(K);

@@ -100,9 +100,10 @@ __device__ __forceinline__ void tie_replay_query(const TieReplayArgs& a, int q, 
     //  lane i, a level is two readlanes instead of an LDS round trip (~135 ns per accepted candidate at k = 10); the array
     //  goes to LDS once, when the stream is through.  With two registers (k <= 127) the lane / register selects cost what the
     //  LDS round trip does: measured at k = 100, 0.80 ms for a 16384-row slab against 0.74 -- not used.)
-    // Beyond 63 entries (flat search at k = 100): the sifts run with all 64 lanes (ParHeap, heap_dev.h) -- three LDS round
-    // trips per accepted candidate instead of one per level of the pop and of the push.
-    const bool reg_heap = a.pop_push && R <= 63;
+    // From 16 entries on (flat search at k = 100): the sifts run with all 64 lanes (ParHeap, heap_dev.h) -- three LDS round
+    // trips and no loop over levels per accepted candidate: 450 ns per pop + push up to 128 entries, 590 up to 256, against
+    // 450 / 590 / 680 ns in one register at 10 / 32 / 63 entries and 1020 ns sequentially at 100 (tools/exp/heap_bench.hip).
+    const bool reg_heap = a.pop_push && R <= 15;
     const bool par_heap = a.pop_push && !reg_heap && R <= kParHeapMaxK;
     RegHeap<1> rh;
     rh.fill();
@@ -247,7 +248,7 @@ __device__ __forceinline__ void tie_replay_query(const TieReplayArgs& a, int q, 
         }
         __syncthreads();
         GH_TT(4);
-        if (wv == 0 && k <= 63) {
+        if (wv == 0 && k <= 15) {
             // the k-heap in registers: heap_pop + heap_push per accepted candidate (gamma_index_ivfpq.cc:664-676)
             RegHeap<1> kh;
             kh.fill();
