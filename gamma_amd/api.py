@@ -420,6 +420,14 @@ class GammaHip:
         self._ck(self.L.gamma_hip_ivfpq_merge_replay(self.h, args.ref(), nshards, nf, d_x_slice, stride, d_vals_all, d_ids_all,
                                                      d_off_all, k, d_list, d_D, d_I), "merge_replay")
 
+    def set_scan_bound_feedback(self, on):
+        self._ck(self.L.gamma_hip_set_scan_bound_feedback(self.h, 1 if on else 0), "set_scan_bound_feedback")
+
+    def scan_bound_stats(self):
+        out = np.zeros(4, np.int64)
+        self._ck(self.L.gamma_hip_scan_bound_stats(self.h, _p(out, _lib.i64p)), "scan_bound_stats")
+        return dict(zip(["fell_through", "queries", "backoffs", "gave_up_waiting"], [int(v) for v in out]))
+
     def set_dist_budget(self, nbytes):
         self._ck(self.L.gamma_hip_set_workspace_budget(self.h, int(nbytes)), "set_workspace_budget")
 

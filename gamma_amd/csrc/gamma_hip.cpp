@@ -54,11 +54,15 @@ int gamma_hip_create(int device, gamma_hip_index** out) {
     if (hipMalloc((void**)&h->d_scan_codes, sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(h->d_scan_codes, 0, sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void**)&h->d_tie_stats, 3 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(h->d_tie_stats, 0, 3 * sizeof(unsigned long long)) != hipSuccess) {
+        hipMemset(h->d_tie_stats, 0, 3 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void**)&h->d_bound_stat, 5 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(h->d_bound_stat, 0, 5 * sizeof(unsigned long long)) != hipSuccess ||
+        hipHostMalloc((void**)&h->pin_bound_stat, 4 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
         (void)hipStreamDestroy(h->stream);
         delete h;
         return GAMMA_HIP_EDEVICE;
     }
+    memset(h->pin_bound_stat, 0, 4 * sizeof(unsigned long long));
     // workspace budget of the chunked buffers: an eighth of the device memory, 1..32 GiB (36 GB -> 32 GiB
     // on a 288 GB MI355X); gamma_hip_set_workspace_budget overrides
     size_t free_b = 0, total_b = 0;
@@ -108,7 +112,7 @@ int gamma_hip_destroy(gamma_hip_index* h) {
         h->d_sums = nullptr;
     }
     void* ptrs[] = {h->d_list_rank, h->d_raw, h->d_bitmap, h->d_cc, h->d_cc_norms, h->d_pqc, h->d_T2, h->d_codes,
-                    h->d_ids, h->d_list_mask, h->d_scan_codes, h->d_tie_stats, h->d_v2d, h->d_sums, h->d_t2max};
+                    h->d_ids, h->d_list_mask, h->d_scan_codes, h->d_tie_stats, h->d_v2d, h->d_sums, h->d_t2max, h->d_bound_stat};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& kv : h->fields)
@@ -121,6 +125,7 @@ int gamma_hip_destroy(gamma_hip_index* h) {
     for (void* pp : h->comb_pin)
         if (pp) (void)hipHostFree(pp);
     if (h->dir_pin) (void)hipHostFree(h->dir_pin);
+    if (h->pin_bound_stat) (void)hipHostFree(h->pin_bound_stat);
     DevBuf* bufs[] = {&h->w_mat, &h->w_coarse_dis, &h->w_probe, &h->w_xn, &h->w_st2, &h->w_pair_off,
                       &h->w_qtotal, &h->w_dist, &h->w_cand_dis, &h->w_cand_pos, &h->w_cand_ids,
                       &h->w_exact, &h->w_selv, &h->w_selp, &h->w_x, &h->w_outd, &h->w_outl, &h->w_stage, &h->w_shard_cut,
@@ -218,6 +223,29 @@ int gamma_hip_tie_stats(gamma_hip_index* h, int64_t* out3, int reset) {
 int gamma_hip_ties_not_honoured(gamma_hip_index* h, int64_t* out_calls, int reset) {
     if (!h || !out_calls) return GAMMA_HIP_EINVAL;
     *out_calls = reset ? h->ties_unhonoured.exchange(0) : h->ties_unhonoured.load();
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_set_scan_bound_feedback(gamma_hip_index* h, int on) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    h->bound_feedback_off = on == 0;
+    h->bound_off_calls = 0;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_scan_bound_stats(gamma_hip_index* h, int64_t* out4) {
+    if (!h || !out4) return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    GH_CHECK(h, hipSetDevice(h->device));
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    unsigned long long v[5] = {0, 0, 0, 0, 0};
+    GH_CHECK(h, hipMemcpy(v, h->d_bound_stat, sizeof(v), hipMemcpyDeviceToHost));
+    const int slot = h->bound_epoch & 1;   // the counts of the current kind of call
+    out4[0] = (int64_t)v[2 * slot];
+    out4[1] = (int64_t)v[2 * slot + 1];
+    out4[2] = h->bound_backoffs;
+    out4[3] = (int64_t)v[4];
     return GAMMA_HIP_OK;
 }
 

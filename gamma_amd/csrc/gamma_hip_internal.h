@@ -184,6 +184,20 @@ struct gamma_hip_index {
     int* d_list_rank = nullptr;   // spatial order of the coarse centroids (scan locality only)
     bool sort_queries = getenv("GAMMA_HIP_NO_QUERY_SORT") == nullptr;
     bool scan_bound = getenv("GAMMA_HIP_NO_SCAN_BOUND") == nullptr;
+    // Feedback for the bounded scan (results are the same either way): the pre-filter pays when the first probe group
+    // bounds well.  On data where it does not (full-size C5: noise-dominated inner-product vectors, 2460 survivors per
+    // query instead of ~100, every query sent to the unfiltered selection AFTER the filtered scan) the path costs more
+    // than it saves.  k_select_final counts the queries it gives up on; the totals come back through a pinned word every
+    // few calls, and while more than half of the recent queries fell through the handle scans unbounded, re-probing now
+    // and then.
+    unsigned long long* d_bound_stat = nullptr;    // 2 slots x {queries given to the unfiltered selection, queries}, then: consumer groups that gave up waiting
+    unsigned long long* pin_bound_stat = nullptr;  // the two slots as of some recent call (pinned host memory)
+    unsigned long long bound_seen[2] = {0, 0};     // what the last decision had read
+    uint64_t bound_sig = 0;                        // (nprobe, recall_num, metric, filter, shard) of the calls the counts are of
+    int bound_epoch = 0;                           // kinds of call seen; its low bit selects the counter slot
+    bool bound_feedback_off = false;               // gamma_hip_set_scan_bound_feedback(h, 0): the pre-filter whenever it applies
+    int bound_calls = 0, bound_off_calls = 0;      // calls since the last copy; unbounded calls left before the re-probe
+    int64_t bound_backoffs = 0;                    // times the handle turned the pre-filter off
 
     // inverted-list arena
     uint8_t* d_codes = nullptr;

@@ -313,7 +313,42 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     // small batches: one probe per workgroup, a single list rarely holds R candidates, and the
     // unfiltered selection is latency-bound anyway
     // (one group per query -- few probes, or a shard -- is fine: the producer bounds and compacts its own candidates)
-    const bool bounded = (!shard || compacted) && h->scan_bound && R <= 256 && P <= 128 && G >= 4;
+    bool bounded = (!shard || compacted) && h->scan_bound && R <= 256 && P <= 128 && G >= 4;
+    if (bounded) {
+        // feedback (gamma_hip_internal.h, bound_*): the counts of some recent call are in the pinned words
+        static const bool no_fb = getenv("GAMMA_HIP_NO_BOUND_FEEDBACK") != nullptr;
+        // (what was learnt holds for one kind of call: other cuts or a filter bound differently -- start over, with
+        //  counters of its own: the two slots alternate, so counts of the previous kind still on their way land elsewhere)
+        const uint64_t sig = ((uint64_t)P << 40) ^ ((uint64_t)R << 20) ^ ((uint64_t)(l2 ? 1 : 0) << 1) ^ (fc.any_clause ? 1u : 0u) ^
+                             ((uint64_t)(shard ? 1 : 0) << 2) ^ (1ull << 63);
+        if (sig != h->bound_sig) {
+            h->bound_sig = sig;
+            h->bound_epoch++;
+            h->bound_off_calls = 0;
+            h->bound_calls = 0;
+            h->bound_seen[0] = h->bound_seen[1] = 0;
+            const int slot = h->bound_epoch & 1;
+            h->pin_bound_stat[2 * slot] = h->pin_bound_stat[2 * slot + 1] = 0;
+            GH_CHECK(h, hipMemsetAsync(h->d_bound_stat + 2 * slot, 0, 2 * sizeof(unsigned long long), s));
+        }
+        const int slot = h->bound_epoch & 1;
+        if (no_fb || h->bound_feedback_off) {
+        } else if (h->bound_off_calls > 0) {
+            if (--h->bound_off_calls > 0) bounded = false;   // (0: this call re-probes)
+        } else {
+            const unsigned long long u = h->pin_bound_stat[2 * slot], n = h->pin_bound_stat[2 * slot + 1];
+            const unsigned long long du = u - h->bound_seen[0], dn = n - h->bound_seen[1];
+            if (n >= h->bound_seen[1] && dn >= 2048) {
+                h->bound_seen[0] = u;
+                h->bound_seen[1] = n;
+                if (2 * du > dn) {   // more than half of the recent queries went to the unfiltered selection anyway
+                    h->bound_off_calls = 256;
+                    h->bound_backoffs++;
+                    bounded = false;
+                }
+            }
+        }
+    }
     const bool fuse_ip = bounded && PGN == 1 && (M == 16 || M == 32) && !getenv("GAMMA_HIP_NO_FUSED_IP");
     // the bounded scan's per-call state (repair list, ready words, survivor counts) is sized here, before the pair offsets,
     // whose kernel clears it together with the tie flags -- one launch instead of four fills in front of the scan
@@ -457,6 +492,9 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         sb.sums = cf_ok ? h->d_sums : nullptr;
         sb.t2max = cf_ok ? h->d_t2max : nullptr;
         sb.cf_span = cf_ok ? cf_span : 0;
+        static const int spins_env = getenv("GAMMA_HIP_SCAN_SPINS") ? atoi(getenv("GAMMA_HIP_SCAN_SPINS")) : 0;
+        sb.spins = spins_env;
+        sb.timeouts = h->d_bound_stat + 4;
         scan(G, 0, PGM, &sb, true);
         // GAMMA_HIP_BOUND_DBG=1: the bounded scan's statistics of the 9th .. 14th call; =shard: of list-shard calls only
         static const bool dbg_any = getenv("GAMMA_HIP_BOUND_DBG") != nullptr;
@@ -469,7 +507,12 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
                                 h->w_pair_base.as<int64_t>(), h->d_ids,
                                 h->w_sflag.as<uint8_t>(), out_dis,
                                 h->w_cand_pos.as<int>(), out_ids, h->tie.on ? h->w_tcut.as<uint8_t>() : nullptr,
-                                h->d_tie_stats, sb.rq_list, sb.rq_count);
+                                h->d_tie_stats, sb.rq_list, sb.rq_count, h->d_bound_stat + 2 * (h->bound_epoch & 1));
+        // the counts as of this call, for a later call's decision (16 bytes: the first calls of a kind, then every 4th)
+        if (h->bound_calls < 8 || (h->bound_calls & 3) == 0)
+            GH_CHECK(h, hipMemcpyAsync(h->pin_bound_stat + 2 * (h->bound_epoch & 1), h->d_bound_stat + 2 * (h->bound_epoch & 1),
+                                       2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        h->bound_calls++;
         if (PGN > 1 && !sb.store_all) {
             // queries the slices could not answer: their consumer groups are scored again, distances stored
             StageScope t2(h, GAMMA_HIP_STAGE_SCAN, false);
@@ -507,8 +550,9 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
                 mx = std::max<int64_t>(mx, hc[i]);
             }
             fprintf(stderr, "scan bound: %lld of %d queries unfiltered (%lld without a bound), survivors per query mean %.1f, "
-                    "per slice max %lld; G %d, %d groups, %d slices, q_stride %lld\n",
-                    (long long)nf, nq, (long long)nobound, (double)tot / nq, (long long)mx, G, PGN, nsl, (long long)q_stride);
+                    "per slice max %lld; G %d, %d groups, %d slices, q_stride %lld; consumers that gave up waiting so far %llu\n",
+                    (long long)nf, nq, (long long)nobound, (double)tot / nq, (long long)mx, G, PGN, nsl, (long long)q_stride,
+                    [&] { unsigned long long t = 0; (void)hipMemcpy(&t, h->d_bound_stat + 4, sizeof(t), hipMemcpyDeviceToHost); return t; }());
         }
         gh::launch_map_candidates(s, h->w_cand_pos.as<int>(), nq, R, P, h->w_probe.as<int>(),
                                   h->w_pair_off.as<int>(), h->d_list_off, h->d_ids,

@@ -167,6 +167,8 @@ struct ScanBound {
                                 // sum_m T2[list][m][code[m]]; per list sum_m max_c |T2[l][m][c]|.  nullptr: regular loop
     const float* t2max;
     int cf_span;                // filter pass: probes per consumer group behind the producer's G (0: one consumer takes them all)
+    int spins;                  // sleeps a consumer waits for its producer's bound before it goes on without one (0: 2048)
+    unsigned long long* timeouts;   // consumers that gave up waiting (diagnostics; may be nullptr)
 };
 int scan_slice_cap();
 // true when launch_ivfpq_scan_pair would run the filter pass (CF) for a bounded scan with these arguments; the caller
@@ -258,7 +260,7 @@ void launch_select_final(hipStream_t s, bool smallest, const unsigned long long*
                          int nslices, int slice_cap, const unsigned long long* ready, const int* pair_off, int P,
                          int nq, int K, const int64_t* pair_base, const int64_t* ids, uint8_t* flag, float* out_vals,
                          int* out_pos, int64_t* out_ids, uint8_t* cut_tie = nullptr,
-                         unsigned long long* tie_stats = nullptr, int* rq_list = nullptr, int* rq_count = nullptr);   // slices 1.. in their own
+                         unsigned long long* tie_stats = nullptr, int* rq_list = nullptr, int* rq_count = nullptr, unsigned long long* bound_stat = nullptr);   // slices 1.. in their own
                                                                                         // array [nq][nslices - 1][cap_c]   // cut_tie[q] = 1: the K-th and (K+1)-th keys are equal
 void launch_map_candidates(hipStream_t s, const int* pos, int nq, int R, int P,
                            const int* probe_list, const int* pair_off, const int64_t* list_off,

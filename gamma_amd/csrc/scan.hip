@@ -239,14 +239,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
                 unsigned long long word;
                 // (bounded: dispatch order is not a contract -- if the producer has not published within ~2e6
                 //  cycles the group goes on without a bound and the query takes the unfiltered selection)
+                const int spin_max = sb.spins > 0 ? sb.spins : (1 << 11);
                 while ((word = __hip_atomic_load(&sb.ready[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0ull &&
-                       ++spins < (1 << 11))
+                       ++spins < spin_max)
                     __builtin_amdgcn_s_sleep(16);
                 if (word != 0ull) {
                     s_tau = (word >> 32) == 1ull ? (uint32_t)word : 0xffffffffu;
-                } else {   // never expected: give the query to the unfiltered selection instead of hanging
+                } else {   // give the query to the unfiltered selection instead of hanging
                     s_tau = 0xffffffffu;
                     s_nstage = SCAN_SLICE + 1;
+                    if (sb.timeouts) atomicAdd(sb.timeouts, 1ull);
                 }
             }
         }

@@ -703,13 +703,15 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
                                                       int64_t* __restrict__ out_ids,
                                                       uint8_t* __restrict__ cut_tie,
                                                       unsigned long long* __restrict__ tie_stats,
-                                                      int* __restrict__ rq_list, int* __restrict__ rq_count) {
+                                                      int* __restrict__ rq_list, int* __restrict__ rq_count,
+                                                      unsigned long long* __restrict__ bound_stat) {
     __shared__ int s_hist[4][256];
     __shared__ unsigned long long s_cand[4][SF_CAND];   // candidates, later the <= 256 kept ones (in place)
     __shared__ int s_off[4][PMAX + 8];
     __shared__ int64_t s_base[4][PMAX];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + w;
+    if (bound_stat && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(bound_stat + 1, (unsigned long long)nq);
     if (q >= nq) return;
     const unsigned long long word = ready[q];
     // slice counts of the consumer workgroups (nslices <= 64: one per lane)
@@ -717,7 +719,10 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
     // left to the unfiltered selection kernel: no bound (every group stored its distances), or a slice overflowed
     // (groups with a bound did not store: the repair launch scores them again first, rq_list)
     if ((word >> 32) != 1ull) {
-        if (lane == 0) flag[q] = 1;
+        if (lane == 0) {
+            flag[q] = 1;
+            if (bound_stat) atomicAdd(bound_stat, 1ull);
+        }
         return;
     }
     auto slice_ptr = [&](int g) -> const unsigned long long* { return surv + ((int64_t)q * nslices + g) * slice_cap; };
@@ -725,6 +730,7 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
         if (lane == 0) {
             flag[q] = 1;
             if (rq_list) rq_list[atomicAdd(rq_count, 1)] = q;
+            if (bound_stat) atomicAdd(bound_stat, 1ull);
         }
         return;
     }
@@ -829,6 +835,7 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
                     if (lane == 0) {
                         flag[q] = 1;
                         if (rq_list) rq_list[atomicAdd(rq_count, 1)] = q;
+                        if (bound_stat) atomicAdd(bound_stat, 1ull);
                     }
                     return;
                 }
@@ -1480,13 +1487,13 @@ void launch_select_final(hipStream_t s, bool smallest, const unsigned long long*
                          int nslices, int slice_cap, const unsigned long long* ready, const int* pair_off, int P,
                          int nq, int K, const int64_t* pair_base, const int64_t* ids, uint8_t* flag, float* out_vals,
                          int* out_pos, int64_t* out_ids, uint8_t* cut_tie, unsigned long long* tie_stats,
-                         int* rq_list, int* rq_count) {
+                         int* rq_list, int* rq_count, unsigned long long* bound_stat) {
     if (nq <= 0) return;
     if (P > 128 || nslices > 64) abort();   // callers gate on this (gamma_hip_search.cpp, ivfpq_stage_a)
 #define GH_SF(SM, PM)                                                                                        \
     hipLaunchKernelGGL((k_select_final<SM, PM>), dim3((nq + 3) / 4), dim3(256), 0, s, surv, gcnt, nslices,   \
                        slice_cap, ready, pair_off, P, nq, K, pair_base, ids, flag,                           \
-                       out_vals, out_pos, out_ids, cut_tie, tie_stats, rq_list, rq_count)
+                       out_vals, out_pos, out_ids, cut_tie, tie_stats, rq_list, rq_count, bound_stat)
     if (smallest) {
         if (P <= 64) GH_SF(true, 64);
         else GH_SF(true, 128);

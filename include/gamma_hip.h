@@ -131,6 +131,18 @@ const char* gamma_hip_last_error(gamma_hip_index* h);
 void* gamma_hip_stream(gamma_hip_index* h);
 int gamma_hip_synchronize(gamma_hip_index* h);
 
+/* The IVFPQ scan of large batches bounds each query's recall_num-th best distance from its nearest probe group and keeps
+ * only the candidates within the bound of the other groups (csrc/scan.hip); queries whose bound turns out too loose (a
+ * survivor slice overflows) are scored again and selected from the full candidate row.  Results do not depend on it.  On
+ * data where the nearest lists do not hold the best candidates (full-size C5: noise-dominated inner-product vectors) nearly
+ * every query falls through and the pre-filter costs more than it saves (41 ms per 4096 queries against 24 without it):
+ * the handle counts the queries that fall through and, while they are more than half of the recent ones, scans unbounded,
+ * on = 0: no feedback, the pre-filter whenever the shape allows it.
+ * re-probing every 256 calls; what it learnt holds for one kind of call (nprobe, recall_num, metric, filter or not).
+ * stats: out4 = {queries that fell through, queries that went through the bounded scan -- both of the current kind of call --,
+ * times the handle backed off, consumer workgroups that ever gave up waiting for their bound}. */
+int gamma_hip_set_scan_bound_feedback(gamma_hip_index* h, int on);
+int gamma_hip_scan_bound_stats(gamma_hip_index* h, int64_t* out4);
 /* Upper bound in bytes of the per-chunk workspaces (coarse distance matrix, ADC distance buffer);
  * larger calls are processed in chunks of queries.  Default: an eighth of the device memory, 1 to 32 GiB. */
 int gamma_hip_set_workspace_budget(gamma_hip_index* h, int64_t bytes);

@@ -279,3 +279,61 @@ def test_filter_pass_with_several_consumer_groups():
                        cwd=root, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_bounded_scan_backs_off_where_the_bound_is_loose():
+    """The scan's pre-filter bounds a query's recall_num-th best from its NEAREST probe group.  Inner-product data whose
+    best candidates sit in lists far from the query in L2 (centroids s_l * u with scales 0.5 .. 2: the quantizer probes
+    the lists at s ~ 1 first, the scores grow with s): the bound is loose, the survivor slices of the far groups overflow,
+    every query falls through to the unfiltered selection -- after the filtered scan.  The handle counts that
+    (gamma_hip_scan_bound_stats) and turns the pre-filter off for such calls (full-size C5: 41 -> 24 ms per 4096 queries).
+    Results are the oracle's before and after, and with the feedback off."""
+    rng = np.random.default_rng(77)
+    d, nlist, M, N, P, R, k = 32, 64, 8, 64000, 64, 100, 10
+    u = rng.standard_normal(d).astype(np.float32)
+    u /= np.linalg.norm(u)
+    scales = np.linspace(0.5, 2.0, nlist).astype(np.float32)
+    cc = (scales[:, None] * u[None, :] + 0.01 * rng.standard_normal((nlist, d))).astype(np.float32)
+    lab = rng.integers(0, nlist, size=N)
+    base = (scales[lab, None] * (u[None, :] + 0.05 * rng.standard_normal((N, d)))).astype(np.float32)
+    _, pq = api.train_ivfpq(base[:20000], nlist, M)
+    q1 = (u[None, :] + 0.05 * rng.standard_normal((64, d))).astype(np.float32)
+    q = np.tile(q1, (64, 1))                       # 4096 queries per call
+    B.lib().go_set_assign_mode(1)
+    o = B.OracleIVFPQ(d, nlist, M, 8, B.METRIC_IP)
+    o.set_trained(cc, pq, None)
+    assert o.add(base)
+    B.lib().go_set_assign_mode(0)
+    o.set_raw(base)
+    D1, I1 = o.search(q1, k, P, recall_num=R, has_rank=True, metric=B.METRIC_IP, ctx=B.make_ctx(**WIDE), coarse_mode=1)
+    De, Ie = np.tile(D1, (64, 1)), np.tile(I1, (64, 1))
+    g = api.GammaHip(0)
+    try:
+        g.ivfpq_init(d, nlist, M, 8, api.METRIC_IP)
+        g.ivfpq_set_trained(cc, pq, None)
+        g.raw_init(d)
+        g.raw_append(base)
+        g.add(base, 0)
+        args = api.SearchArgs(metric=api.METRIC_IP, nprobe=P, recall_num=R, has_rank=True, **WIDE)
+        g.set_scan_bound_feedback(False)
+        for _ in range(8):
+            D, I = g.ivfpq_search(q, k, args)
+            compare_exact(De, Ie, D, I)
+        st0 = g.scan_bound_stats()
+        assert st0["queries"] == 8 * len(q) and st0["fell_through"] > st0["queries"] // 2, st0   # the data does its job
+        assert st0["backoffs"] == 0
+        g.set_scan_bound_feedback(True)
+        for _ in range(12):
+            D, I = g.ivfpq_search(q, k, args)
+            compare_exact(De, Ie, D, I)
+        st1 = g.scan_bound_stats()
+        assert st1["backoffs"] >= 1, st1
+        assert st1["queries"] - st0["queries"] < 12 * len(q)      # some of the 12 calls ran without the pre-filter
+        # another kind of call starts over: a narrow bound (few probes of the nearest lists) stays filtered
+        a2 = api.SearchArgs(metric=api.METRIC_IP, nprobe=16, recall_num=R, has_rank=True, **WIDE)
+        D2o, I2o = o.search(q1, k, 16, recall_num=R, has_rank=True, metric=B.METRIC_IP, ctx=B.make_ctx(**WIDE), coarse_mode=1)
+        for _ in range(3):
+            D, I = g.ivfpq_search(q, k, a2)
+            compare_exact(np.tile(D2o, (64, 1)), np.tile(I2o, (64, 1)), D, I)
+    finally:
+        g.close()
