@@ -131,7 +131,7 @@ int check_params(H* h, const gamma_hip_search_params* p, int nq, int k) {
 // A request's exact-ties choice (gamma_hip_search_params.exact_ties: 0 = the handle's setting, 1 on, -1 off) is resolved
 // ONCE per call, at the entry point, into the call's own copy of the parameter block (exact_ties = 1 / -1); everything
 // below reads tie_on(p) -- the handle is not touched.  in_range: the shape is one the replay covers (every recall_num / k
-// the ABI accepts; nprobe <= 256).  Beyond it a request that asked for the mode explicitly gets GAMMA_HIP_EUNSUPPORTED;
+// the ABI accepts; nprobe <= 1024).  Beyond it a request that asked for the mode explicitly gets GAMMA_HIP_EUNSUPPORTED;
 // one that relies on the handle's default runs with the (distance, position) order inside ties and is COUNTED
 // (gamma_hip_ties_not_honoured) -- never silently.
 static inline bool tie_on(const gamma_hip_search_params* p) { return p->exact_ties > 0; }
@@ -911,7 +911,7 @@ int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, c
                                float* d_distances, int64_t* d_labels, const FiltCtx* given) {
     GH_TRY(ivfpq_check(h, p, nq, k));
     gamma_hip_search_params pp;
-    GH_TRY(resolve_ties(h, p, &pp, p->nprobe <= gh::tie_replay_max_probes(), "exact_ties = 1 with nprobe > 256"));
+    GH_TRY(resolve_ties(h, p, &pp, p->nprobe <= gh::tie_replay_max_probes(), "exact_ties = 1 with nprobe > 1024"));
     p = &pp;
     if (k <= 0 || nq == 0) {   // gamma_index_ivfpq.cc:753-756
         // (the deferred-replay contract: the previous call is complete after ANY next search call, an empty one too)
@@ -1095,7 +1095,7 @@ int ivfflat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq,
                                  float* d_distances, int64_t* d_labels) {
     GH_TRY(check_params(h, p, nq, k));
     gamma_hip_search_params pp;
-    GH_TRY(resolve_ties(h, p, &pp, p->nprobe <= gh::tie_replay_max_probes(), "exact_ties = 1 with nprobe > 256"));
+    GH_TRY(resolve_ties(h, p, &pp, p->nprobe <= gh::tie_replay_max_probes(), "exact_ties = 1 with nprobe > 1024"));
     p = &pp;
     if (!h->ivf_init || !h->ivfflat) return fail(h, GAMMA_HIP_EINVAL, "ivfflat not initialised");
     if (!h->trained) return fail(h, GAMMA_HIP_ENOTTRAINED, "ivfflat not trained");
@@ -1562,7 +1562,7 @@ int gamma_hip_ivfpq_search_shard(gamma_hip_index* h, const gamma_hip_search_para
     FiltCtx fc;
     GH_TRY(filt_ctx_single(h, filt, &fc));
     gamma_hip_search_params pp;
-    GH_TRY(resolve_ties(h, p, &pp, p->nprobe <= gh::tie_replay_max_probes(), "exact_ties = 1 with nprobe > 256"));
+    GH_TRY(resolve_ties(h, p, &pp, p->nprobe <= gh::tie_replay_max_probes(), "exact_ties = 1 with nprobe > 1024"));
     if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;   // decided on the whole call, not per chunk
     p = &pp;
     const int chunk = query_chunk(h, nq, p->nprobe);
@@ -1588,7 +1588,7 @@ int gamma_hip_ivfpq_coarse_device(gamma_hip_index* h, const gamma_hip_search_par
     GH_CHECK(h, hipSetDevice(h->device));
     const int P = p->nprobe;
     gamma_hip_search_params pp;
-    GH_TRY(resolve_ties(h, p, &pp, p->nprobe <= gh::tie_replay_max_probes(), "exact_ties = 1 with nprobe > 256"));
+    GH_TRY(resolve_ties(h, p, &pp, p->nprobe <= gh::tie_replay_max_probes(), "exact_ties = 1 with nprobe > 1024"));
     // the caller resolves coarse_mode -1 on the size of the whole batch; a slice that arrives unresolved decides by itself
     if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;
     p = &pp;
@@ -1614,7 +1614,7 @@ int gamma_hip_ivfpq_search_shard_preassigned(gamma_hip_index* h, const gamma_hip
     GH_CHECK(h, hipSetDevice(h->device));
     const int R = std::max(p->recall_num, k), P = p->nprobe;
     gamma_hip_search_params pp;
-    GH_TRY(resolve_ties(h, p, &pp, P <= gh::tie_replay_max_probes(), "exact_ties = 1 with nprobe > 256"));
+    GH_TRY(resolve_ties(h, p, &pp, P <= gh::tie_replay_max_probes(), "exact_ties = 1 with nprobe > 1024"));
     p = &pp;
     gh::FilterDesc filt;
     GH_TRY(build_filter(h, p, &filt));
@@ -1702,7 +1702,7 @@ int gamma_hip_ivfpq_merge_rerank(gamma_hip_index* h, const gamma_hip_search_para
     // exact ties: the slice's queries whose result a tie can change are listed (gamma_hip_ivfpq_merge_flagged); the
     // caller gathers their candidate streams from the shards and has them replayed (gamma_hip_ivfpq_merge_replay)
     gamma_hip_search_params pp;
-    GH_TRY(resolve_ties(h, p, &pp, p->nprobe <= gh::tie_replay_max_probes(), "exact_ties = 1 with nprobe > 256"));
+    GH_TRY(resolve_ties(h, p, &pp, p->nprobe <= gh::tie_replay_max_probes(), "exact_ties = 1 with nprobe > 1024"));
     p = &pp;
     const bool ties = tie_on(p);
     h->merge_flags = ties;

@@ -399,7 +399,9 @@ struct ParHeap {
 constexpr int kParHeapMaxK = 256;
 __device__ __forceinline__ float par_heap_pop(uint2* h, int k) {
     if (k <= 128) return ParHeap<1>::pop(h, k);
-    return ParHeap<2>::pop(h, k);
+    if (k <= 256) return ParHeap<2>::pop(h, k);
+    heap_pop_seq(h, k);
+    return hs_f(h[1].x);
 }
 __device__ __forceinline__ int par_heap_reorder(uint2* h, int k) {
     if (k <= 128) return ParHeap<1>::reorder(h, k);
@@ -407,10 +409,12 @@ __device__ __forceinline__ int par_heap_reorder(uint2* h, int k) {
     return heap_reorder_seq(h, k);
 }
 __device__ __forceinline__ bool par_heap_push(uint2* h, int k, float val, unsigned pay) { return ParHeap<1>::push(h, k, val, pay); }
-// the sift of heap_replace_top over k <= 256 nodes
+// the sift of heap_replace_top over k nodes
 __device__ __forceinline__ float par_heap_replace_top(uint2* h, int k, float val, unsigned pay) {
     if (k <= 128) return ParHeap<1>::sift_down(h, k, val, pay);
-    return ParHeap<2>::sift_down(h, k, val, pay);
+    if (k <= 256) return ParHeap<2>::sift_down(h, k, val, pay);
+    heap_sift_down_seq(h, k, val, pay);
+    return hs_f(h[1].x);
 }
 
 }  // namespace gh

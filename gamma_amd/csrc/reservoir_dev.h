@@ -62,7 +62,7 @@ __device__ __forceinline__ float rv_partition_fuzzy(float* sv, int* si, int n, i
         for (int i0 = 0; i0 < n && vi < 3; i0 += 64) {
             const unsigned i = (unsigned)(i0 + lane);
             const bool in = (int)i < n;
-            const float v = in ? sv[(i * 6700417u) % (unsigned)n] : 0.f;   // n <= 528: the product stays below 2^32
+            const float v = in ? sv[(unsigned)(((unsigned long long)i * 6700417ull) % (unsigned long long)n)] : 0.f;
             unsigned long long m = __ballot(in && v > thresh_inf && thresh_sup > v);
             while (m && vi < 3) {
                 const int l = __ffsll((long long)m) - 1;

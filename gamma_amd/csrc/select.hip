@@ -1300,7 +1300,8 @@ void launch_flat_final(hipStream_t s, bool l2, int nq, int k, const FlatEmit& em
 // the next entry that beats the heap's top, lane 0 sifts it in.  ~1e-5 of the rows on fp32 data.
 // ------------------------------------------------------------------------------------
 // The walk itself is heap_dev.h's HeapWalk: 64 candidates per ballot, accepted ones pipelined through an LDS heap.
-constexpr int CH_MAXK = 256;   // nprobe the coarse replay covers
+constexpr int CH_MAXK = 1024;   // nprobe the coarse replay covers
+constexpr int CH_HEAPK = 128;   // ... through the result heap (below RV_MIN_K = 100 probes; from there on the reservoir)
 
 int coarse_heap_max_k() { return CH_MAXK; }
 
@@ -1310,7 +1311,7 @@ __global__ __launch_bounds__(256) void k_coarse_heap_fix(const float* __restrict
                                                          unsigned long long* __restrict__ tie_stats,
                                                          const int* __restrict__ rows) {
     // flag: row q of the matrix is query q, walked if flag[q]; rows: row i of the matrix is query rows[1 + i], rows[0] rows
-    __shared__ __attribute__((aligned(16))) uint2 s_h[4][CH_MAXK + 2];
+    __shared__ __attribute__((aligned(16))) uint2 s_h[4][CH_HEAPK + 2];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int ri = blockIdx.x * 4 + w;
     if (ri >= nq) return;              // whole wave; no workgroup barrier below
@@ -1364,16 +1365,17 @@ __global__ __launch_bounds__(256) void k_coarse_heap_fix(const float* __restrict
 
 // The same rows from 100 probes on: faiss collects those through ReservoirTopN (faiss:utils/distances.cpp:341-358),
 // whose choice among tied centroids and their order is not the heap's -- reservoir_dev.h replays it.  One wave per row.
-__global__ __launch_bounds__(256) void k_coarse_reservoir_fix(const float* __restrict__ mat, int64_t ld, int n, int K,
-                                                              int nq, const uint8_t* __restrict__ flag,
-                                                              float* __restrict__ out_vals, int* __restrict__ out_pos,
-                                                              unsigned long long* __restrict__ tie_stats,
-                                                              const int* __restrict__ rows) {
-    __shared__ __attribute__((aligned(16))) uint2 s_h[4][CH_MAXK + 2];
-    __shared__ float s_v[4][reservoir_capacity(CH_MAXK)];
-    __shared__ int s_i[4][reservoir_capacity(CH_MAXK)];
+template <int MAXK, int WAVES>   // <256, 4>: four rows per workgroup; <1024, 1>: one (25 KB of LDS per row)
+__global__ __launch_bounds__(64 * WAVES) void k_coarse_reservoir_fix(const float* __restrict__ mat, int64_t ld, int n, int K,
+                                                                     int nq, const uint8_t* __restrict__ flag,
+                                                                     float* __restrict__ out_vals, int* __restrict__ out_pos,
+                                                                     unsigned long long* __restrict__ tie_stats,
+                                                                     const int* __restrict__ rows) {
+    __shared__ __attribute__((aligned(16))) uint2 s_h[WAVES][MAXK + 2];
+    __shared__ float s_v[WAVES][reservoir_capacity(MAXK)];
+    __shared__ int s_i[WAVES][reservoir_capacity(MAXK)];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int ri = blockIdx.x * 4 + w;
+    const int ri = blockIdx.x * WAVES + w;
     if (ri >= nq) return;              // whole wave; no workgroup barrier below
     int q = ri;
     if (rows) {
@@ -1393,8 +1395,11 @@ __global__ __launch_bounds__(256) void k_coarse_reservoir_fix(const float* __res
 }
 static void launch_coarse_tie_rows(hipStream_t s, const float* mat, int nlist, int K, int nq, const uint8_t* flag,
                                    float* out_vals, int* out_pos, unsigned long long* tie_stats, const int* rows) {
-    if (K >= RV_MIN_K)
-        hipLaunchKernelGGL(k_coarse_reservoir_fix, dim3((nq + 3) / 4), dim3(256), 0, s, mat, (int64_t)nlist, nlist, K, nq, flag,
+    if (K > 256)
+        hipLaunchKernelGGL((k_coarse_reservoir_fix<CH_MAXK, 1>), dim3(nq), dim3(64), 0, s, mat, (int64_t)nlist, nlist, K, nq, flag,
+                           out_vals, out_pos, tie_stats, rows);
+    else if (K >= RV_MIN_K)
+        hipLaunchKernelGGL((k_coarse_reservoir_fix<256, 4>), dim3((nq + 3) / 4), dim3(256), 0, s, mat, (int64_t)nlist, nlist, K, nq, flag,
                            out_vals, out_pos, tie_stats, rows);
     else
         hipLaunchKernelGGL(k_coarse_heap_fix, dim3((nq + 3) / 4), dim3(256), 0, s, mat, (int64_t)nlist, nlist, K, nq, flag,
@@ -1404,7 +1409,7 @@ static void launch_coarse_tie_rows(hipStream_t s, const float* mat, int nlist, i
 // top-K nearest centroids of every row of the coarse distance matrix.  tie_flag != nullptr (nq bytes of
 // scratch; exact ties): a row with two equal keys among its K + 1 smallest -- which of them is probed, or in which
 // order their lists are scanned, is the doing of the reference's heap -- is redone by k_coarse_heap_fix
-// (K <= 256; from 100 probes on the walk is faiss's reservoir, k_coarse_reservoir_fix).
+// (K <= 1024; from 100 probes on the walk is faiss's reservoir, k_coarse_reservoir_fix).
 // side / fork / join: the walk of the flagged rows (one wave per row, all latency) may run on a side stream beside the
 // caller's next kernels that do not read the assignment; the caller waits for `join` before the first one that does
 bool launch_coarse_select(hipStream_t s, const float* mat, int nlist, int nq, int K, float* out_vals, int* out_pos,

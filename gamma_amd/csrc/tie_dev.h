@@ -14,7 +14,7 @@ namespace gh {
 
 constexpr int TR_MAXK = 1024;    // heap sizes the in-kernel replays of the small-batch chains cover (recall_num and k)
 constexpr int TR_MAXK_BIG = 4096;   // k_tie_replay: every recall_num / k the ABI accepts (its <.., 4096, 4096> variant beyond 1024)
-constexpr int TR_MAXP = 256;     // probes per query
+constexpr int TR_MAXP = 1024;    // probes per query
 constexpr int TR_STAGE = 1024;   // survivor items sorted per round (= the scan's slice capacity)
 constexpr int TR_SLAB = 2048;    // candidates of the slab part brought into LDS per round (with it a C3 replay needs 21 KB of LDS: a
                                  // workgroup fits a CU beside two of the coarse kernel, whose stage a deferred replay runs behind)

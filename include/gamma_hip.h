@@ -160,7 +160,7 @@ int gamma_hip_set_workspace_budget(gamma_hip_index* h, int64_t bytes);
  * Covers IVFPQ / IVFFLAT / flat search, every batch size, every recall_num and k the ABI accepts (<= 4096), the
  * list-sharded merge and the group.  From 100 probes on the coarse assignment is replayed through faiss's ReservoirTopN
  * (what knn_L2sqr collects through there, faiss:utils/distances.cpp:341-358; csrc/reservoir_dev.h), below through its
- * result heap.  NOT covered: nprobe > 256, a flat search for k = 4096 or over 2^31 rows.  Such a call never
+ * result heap.  NOT covered: nprobe > 1024, a flat search for k = 4096 or over 2^31 rows.  Such a call never
  * degrades silently: with exact_ties = 1 in the request it fails with GAMMA_HIP_EUNSUPPORTED; when it merely inherits the
  * handle's default it runs with the (distance, position) order inside ties and is counted
  * (gamma_hip_ties_not_honoured). */

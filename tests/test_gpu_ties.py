@@ -509,15 +509,15 @@ def test_heaps_beyond_1024_entries(tag):
 
 
 def test_a_shape_beyond_the_replay_is_never_silent():
-    """nprobe > 256 (and a flat search for k = 4096) are outside the exact-ties mode.  A request that asks for the mode
+    """nprobe > 1024 (and a flat search for k = 4096) are outside the exact-ties mode.  A request that asks for the mode
     explicitly fails with GAMMA_HIP_EUNSUPPORTED; one that inherits the handle's default runs with the (distance, position)
     order inside ties -- still the reference's distances at every rank -- and is counted (gamma_hip_ties_not_honoured)."""
     from tests.parity import compare_topk
-    case = fixtures.trained_case(d=32, nlist=320, M=8, N=20000, nq=64, metric=B.METRIC_L2)
+    case = fixtures.trained_case(d=32, nlist=1056, M=8, N=45000, nq=64, metric=B.METRIC_L2)
     g = fixtures.load_hip(case)
     try:
         q = case["q"][:9]
-        P, R, k = 300, 100, 10
+        P, R, k = 1030, 100, 10
         ctx = B.make_ctx(**WIDE)
         D, I = case["oracle"].search(q, k, P, recall_num=R, has_rank=True, metric=B.METRIC_L2, ctx=ctx, coarse_mode=0)
         assert g.ties_not_honoured() == 0
@@ -528,7 +528,7 @@ def test_a_shape_beyond_the_replay_is_never_silent():
             g.ivfpq_search(q, k, api.SearchArgs(metric=api.METRIC_L2, nprobe=P, recall_num=R, coarse_mode=0, exact_ties=1, **WIDE))
         g.ivfpq_search(q, k, api.SearchArgs(metric=api.METRIC_L2, nprobe=P, recall_num=R, coarse_mode=0, exact_ties=-1, **WIDE))
         assert g.ties_not_honoured() == 1          # asked to be off: nothing to report
-        g.ivfpq_search(q, k, api.SearchArgs(metric=api.METRIC_L2, nprobe=256, recall_num=R, coarse_mode=0, exact_ties=1, **WIDE))
+        g.ivfpq_search(q, k, api.SearchArgs(metric=api.METRIC_L2, nprobe=1024, recall_num=R, coarse_mode=0, exact_ties=1, **WIDE))
         assert g.ties_not_honoured(reset=True) == 1 and g.ties_not_honoured() == 0
         Df, If = B.flat_search(case["base"], q[:2], 4096, B.METRIC_L2, ctx)
         Dg, Ig = g.flat_search(q[:2], 4096, api.SearchArgs(metric=api.METRIC_L2, **WIDE))
@@ -541,14 +541,16 @@ def test_a_shape_beyond_the_replay_is_never_silent():
 
 
 @pytest.mark.parametrize("nprobe,nq,coarse_mode", [(100, 24, 0), (128, 24, 1), (128, 700, 0), (200, 24, 0), (200, 700, 1),
-                                                     (256, 300, 0), (100, 4200, -1), (256, 4200, -1), (99, 700, 0)])
+                                                     (256, 300, 0), (100, 4200, -1), (256, 4200, -1), (99, 700, 0),
+                                                     (300, 300, 0), (512, 24, 0), (600, 700, 1), (640, 4200, -1)])
 def test_coarse_ties_from_100_probes_on_are_the_reservoirs(nprobe, nq, coarse_mode):
     """From 100 probes on faiss's knn_L2sqr collects the coarse assignment through ReservoirTopN instead of the result
     heap (faiss:utils/distances.cpp:341-358): which of the centroids at the same distance are probed, and in which order
     their lists are scanned, is the reservoir's doing (oracle: go_reservoir_stream, pinned against the compiled library
     in tests/test_oracle_vs_ref.py and tests/golden/reservoir_ties.npz).  Integer centroids and queries on a small
     grid: nearly every row has equal keys around the nprobe cut.  Small calls (the small-batch chain walks in-kernel up
-    to 128 probes), matrix-path calls and the matrix-free coarse quantizer (>= 4096 queries); 99 probes: the heap."""
+    to 128 probes), matrix-path calls and the matrix-free coarse quantizer (>= 4096 queries); 99 probes: the heap; beyond
+    256 probes (one row per workgroup, up to 1024)."""
     d, nlist, M, N, R, k = 16, 640, 4, 30000, 120, 10
     rng = np.random.default_rng(nprobe * 7 + nq)
     cc = rng.integers(0, 4, size=(nlist, d)).astype(np.float32)
