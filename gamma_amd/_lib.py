@@ -152,6 +152,9 @@ SYMBOLS = {
     "gamma_hip_group_ivfpq_add": (C.c_int, [C.c_void_p, C.c_int64, f32p, C.c_int64]),
     "gamma_hip_group_ivfpq_add_keys": (C.c_int, [C.c_void_p, C.c_int, C.c_int, i64p, u8p]),
     "gamma_hip_group_ivfpq_list_size": (C.c_int64, [C.c_void_p, C.c_int]),
+    "gamma_hip_group_set_transport": (C.c_int, [C.c_void_p, C.c_int]),
+    "gamma_hip_group_transport": (C.c_int, [C.c_void_p, i64p]),
+    "gamma_hip_group_transport_note": (C.c_char_p, [C.c_void_p]),
     "gamma_hip_group_ivfpq_get_list": (C.c_int, [C.c_void_p, C.c_int, i64p, u8p]),
     "gamma_hip_group_ivfpq_update": (C.c_int, [C.c_void_p, C.c_int, i64p, f32p]),
     "gamma_hip_group_ivfpq_delete": (C.c_int, [C.c_void_p, i64p, C.c_int]),

@@ -597,6 +597,16 @@ class GammaHipGroup:
     def list_size(self, l):
         return self.L.gamma_hip_group_ivfpq_list_size(self.g, l)
 
+    def set_transport(self, rccl):
+        self._ck(self.L.gamma_hip_group_set_transport(self.g, 1 if rccl else 0), "group_set_transport")
+
+    def transport(self):
+        """{rccl: a communicator is in use, rccl_searches: searches exchanged through it, note: why (not)}"""
+        out = np.zeros(2, np.int64)
+        self._ck(self.L.gamma_hip_group_transport(self.g, _p(out, _lib.i64p)), "group_transport")
+        note = self.L.gamma_hip_group_transport_note(self.g)
+        return {"rccl": bool(out[0]), "rccl_searches": int(out[1]), "note": (note or b"").decode()}
+
     def get_list(self, l, code_size):
         n = self.list_size(l)
         ids = np.empty(n, dtype=np.int64)

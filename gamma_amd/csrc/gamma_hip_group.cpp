@@ -8,6 +8,7 @@
 // ordinary handle with a list mask.  One host thread per member enqueues that member's share of a call on the member's
 // own stream; the threads meet at two barriers (assignment exchanged, candidates exchanged) and cross-device ordering
 // is by events.  gamma_amd/dist.py is the same sequence of steps with one PROCESS per GPU and RCCL collectives.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -79,6 +80,49 @@ struct Barrier {
 
 }  // namespace
 
+// ---- optional transport: RCCL over xGMI (the north star's wording: an all-gather of the assignment, the per-shard
+//      top-recall_num tables exchanged before the final merge).  Resolved at run time (dlopen: no link-time dependency on
+//      the library, whose copy inside the process may be the one a host framework already loaded); one communicator per
+//      member from ncclCommInitAll, every member's thread issues its own calls on its own stream.  Off by default
+//      (GAMMA_HIP_GROUP_RCCL=1 or gamma_hip_group_set_transport): peer copies and the barriers below do the same job, and a
+//      group whose members share a device (tests) cannot form a communicator. ----
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    int (*CommInitAll)(void**, int, const int*) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok() const { return CommInitAll && CommDestroy && AllGather && Send && Recv && GroupStart && GroupEnd; }
+};
+constexpr int kNcclChar = 0;   // ncclInt8: the exchanges are counted in bytes
+RcclApi* rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* l = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);   // a copy already in the process first
+        if (!l) l = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+        if (!l) l = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!l) l = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!l) return;
+        api.lib = l;
+        api.CommInitAll = reinterpret_cast<int (*)(void**, int, const int*)>(dlsym(l, "ncclCommInitAll"));
+        api.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(l, "ncclCommDestroy"));
+        api.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(l, "ncclAllGather"));
+        api.Send = reinterpret_cast<int (*)(const void*, size_t, int, int, void*, hipStream_t)>(dlsym(l, "ncclSend"));
+        api.Recv = reinterpret_cast<int (*)(void*, size_t, int, int, void*, hipStream_t)>(dlsym(l, "ncclRecv"));
+        api.GroupStart = reinterpret_cast<int (*)()>(dlsym(l, "ncclGroupStart"));
+        api.GroupEnd = reinterpret_cast<int (*)()>(dlsym(l, "ncclGroupEnd"));
+        api.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(l, "ncclGetErrorString"));
+    });
+    return &api;
+}
+}  // namespace
+
 struct gamma_hip_group {
     std::vector<gamma_hip_index*> m;
     std::vector<int> dev;
@@ -87,6 +131,11 @@ struct gamma_hip_group {
     std::mutex mu;            // one group-level call at a time
     int next_enc = 0;         // members take turns encoding Add / Update batches
     bool replicate = false;   // gamma_hip_group_set_placement: every member holds every list, queries are split
+    int transport = getenv("GAMMA_HIP_GROUP_RCCL") ? 1 : 0;   // 0: peer copies; 1: RCCL where a communicator can be formed
+    std::vector<void*> comm;  // one per member once formed
+    bool comm_tried = false;
+    std::string transport_note;
+    int64_t rccl_calls = 0;   // searches whose exchanges went through RCCL
 
     struct Member {
         GBuf x, cdis, probe, rdis, rids, all_dis, all_ids, D, I;
@@ -220,10 +269,31 @@ int gamma_hip_group_destroy(gamma_hip_group* g) {
         if (b.ev_coarse) (void)hipEventDestroy(b.ev_coarse);
         if (b.ev_scan) (void)hipEventDestroy(b.ev_scan);
     }
+    if (!g->comm.empty() && rccl_api()->CommDestroy)
+        for (void* c : g->comm)
+            if (c) (void)rccl_api()->CommDestroy(c);
     for (auto* h : g->m) gamma_hip_destroy(h);
     delete g;
     return GAMMA_HIP_OK;
 }
+
+int gamma_hip_group_set_transport(gamma_hip_group* g, int rccl) {
+    if (!g || (rccl != 0 && rccl != 1)) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->transport = rccl;
+    if (rccl == 1 && g->comm.empty()) g->comm_tried = false;   // (formed at the next sharded search)
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_group_transport(gamma_hip_group* g, int64_t* out2) {
+    if (!g || !out2) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> lk(g->mu);
+    out2[0] = (g->transport == 1 && !g->comm.empty()) ? 1 : 0;
+    out2[1] = g->rccl_calls;
+    return GAMMA_HIP_OK;
+}
+
+const char* gamma_hip_group_transport_note(gamma_hip_group* g) { return g ? g->transport_note.c_str() : ""; }
 
 int gamma_hip_group_size(const gamma_hip_group* g) { return g ? (int)g->m.size() : 0; }
 gamma_hip_index* gamma_hip_group_member(gamma_hip_group* g, int i) {
@@ -501,6 +571,31 @@ static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, in
     gamma_hip_search_params pp = *p;
     if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;
     const int per = (nq + W - 1) / W;
+    // transport of the two exchanges of the path: RCCL when asked for and a communicator can be formed
+    if (g->transport == 1 && !g->replicate && !g->comm_tried) {
+        g->comm_tried = true;
+        bool distinct = true;
+        for (int i = 0; i < W; i++)
+            for (int j = 0; j < i; j++) distinct = distinct && g->dev[i] != g->dev[j];
+        RcclApi* api = rccl_api();
+        if (!distinct) {
+            g->transport_note = "RCCL asked for, but members share a device: peer copies";
+        } else if (!api->ok()) {
+            g->transport_note = "RCCL asked for, but librccl.so could not be loaded: peer copies";
+        } else {
+            g->comm.assign(W, nullptr);
+            const int e = api->CommInitAll(g->comm.data(), W, g->dev.data());
+            if (e != 0) {
+                g->comm.clear();
+                g->transport_note = std::string("ncclCommInitAll failed (") + (api->GetErrorString ? api->GetErrorString(e) : "?") + "): peer copies";
+            } else {
+                g->transport_note = "RCCL";
+            }
+        }
+    }
+    const bool use_rccl = g->transport == 1 && !g->replicate && (int)g->comm.size() == W;
+    if (use_rccl) g->rccl_calls++;
+    RcclApi* const nccl = use_rccl ? rccl_api() : nullptr;
     std::vector<int> rcs(W, GAMMA_HIP_OK);
     std::vector<std::string> errs(W);
     std::vector<int64_t> rowmax(W, 0);                 // tie phase: every member's longest export row of the round
@@ -575,8 +670,9 @@ static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, in
         };
         hip(hipSetDevice(g->dev[i]), "hipSetDevice");
         hip(b.x.ensure((size_t)nq * d * sizeof(float)), "alloc");
-        hip(b.cdis.ensure((size_t)nq * P * sizeof(float)), "alloc");
-        hip(b.probe.ensure((size_t)nq * P * sizeof(int32_t)), "alloc");
+        // (W * per rows: the in-place all-gather moves whole slices, the last one's tail rows are never read)
+        hip(b.cdis.ensure((size_t)W * per * P * sizeof(float)), "alloc");
+        hip(b.probe.ensure((size_t)W * per * P * sizeof(int32_t)), "alloc");
         hip(b.rdis.ensure((size_t)nq * R * sizeof(float)), "alloc");
         hip(b.rids.ensure((size_t)nq * R * sizeof(int64_t)), "alloc");
         hip(b.all_dis.ensure((size_t)W * per * R * sizeof(float)), "alloc");
@@ -593,9 +689,24 @@ static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, in
             hip(hipEventRecord(b.ev_coarse, s), "record");
         }
         bool all_ok = g->bar.arrive(rc == GAMMA_HIP_OK);   // every member's assignment is on its stream
+        auto ncc = [&](int e, const char* what) {
+            if (e != 0 && rc == GAMMA_HIP_OK) {
+                rc = GAMMA_HIP_EDEVICE;
+                errs[i] = std::string(what) + ": " + (nccl && nccl->GetErrorString ? nccl->GetErrorString(e) : "RCCL error");
+            }
+        };
         // 1. pull the other slices of the assignment; scan of the owned probed lists, local top-R of every query
+        if (all_ok && nccl) {
+            // RCCL: ONE all-gather of the assignment over xGMI (in place: this member's slice sits at its offset already)
+            ncc(nccl->GroupStart(), "ncclGroupStart");
+            ncc(nccl->AllGather(b.cdis.as<float>() + (size_t)i * per * P, b.cdis.p, (size_t)per * P * sizeof(float), kNcclChar,
+                                g->comm[i], s), "ncclAllGather");
+            ncc(nccl->AllGather(b.probe.as<int32_t>() + (size_t)i * per * P, b.probe.p, (size_t)per * P * sizeof(int32_t), kNcclChar,
+                                g->comm[i], s), "ncclAllGather");
+            ncc(nccl->GroupEnd(), "ncclGroupEnd");
+        }
         if (all_ok) {
-            for (int j = 0; j < W; j++) {
+            for (int j = 0; j < W && !nccl; j++) {
                 if (j == i) continue;
                 int a0, a1;
                 slice(j, &a0, &a1);
@@ -617,8 +728,30 @@ static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, in
         all_ok = g->bar.arrive(rc == GAMMA_HIP_OK);   // every member's candidate tables are on its stream
         // 2. the exchange of the path: the candidates of the own query slice from every member ([W][per][R]);
         // 3. merge to the global top-R, compute_dis, results to the caller
+        if (all_ok && nccl) {
+            // RCCL: the per-shard tables of every owner's slice in one grouped exchange (every member sends slice j of its
+            // tables to member j and receives its own slice of theirs -- an all-to-all over xGMI); members with an empty
+            // slice still take part
+            hip(b.cutall.ensure((size_t)W * per), "alloc");
+            ncc(nccl->GroupStart(), "ncclGroupStart");
+            for (int j = 0; j < W; j++) {   // (never cut short: the other members' halves of the exchange are under way)
+                int a0, a1;
+                slice(j, &a0, &a1);
+                if (a1 > a0) {
+                    ncc(nccl->Send(b.rdis.as<float>() + (size_t)a0 * R, (size_t)(a1 - a0) * R * sizeof(float), kNcclChar, j, g->comm[i], s), "ncclSend");
+                    ncc(nccl->Send(b.rids.as<int64_t>() + (size_t)a0 * R, (size_t)(a1 - a0) * R * sizeof(int64_t), kNcclChar, j, g->comm[i], s), "ncclSend");
+                    ncc(nccl->Send(b.cutf.as<uint8_t>() + a0, (size_t)(a1 - a0), kNcclChar, j, g->comm[i], s), "ncclSend");
+                }
+                if (nql > 0) {
+                    ncc(nccl->Recv(b.all_dis.as<float>() + (size_t)j * per * R, (size_t)nql * R * sizeof(float), kNcclChar, j, g->comm[i], s), "ncclRecv");
+                    ncc(nccl->Recv(b.all_ids.as<int64_t>() + (size_t)j * per * R, (size_t)nql * R * sizeof(int64_t), kNcclChar, j, g->comm[i], s), "ncclRecv");
+                    ncc(nccl->Recv(b.cutall.as<uint8_t>() + (size_t)j * per, (size_t)nql, kNcclChar, j, g->comm[i], s), "ncclRecv");
+                }
+            }
+            ncc(nccl->GroupEnd(), "ncclGroupEnd");
+        }
         if (all_ok && nql > 0) {
-            for (int j = 0; j < W; j++) {
+            for (int j = 0; j < W && !nccl; j++) {
                 if (j != i) hip(hipStreamWaitEvent(s, g->mb[j].ev_scan, 0), "wait");
                 hip(copy_between(b.all_dis.as<float>() + (size_t)j * per * R, g->dev[i], g->mb[j].rdis.as<float>() + (size_t)q0 * R,
                                  g->dev[j], (size_t)nql * R * sizeof(float), s), "candidate exchange");
@@ -626,7 +759,7 @@ static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, in
                                  g->dev[j], (size_t)nql * R * sizeof(int64_t), s), "candidate exchange");
             }
             hip(b.cutall.ensure((size_t)W * per), "alloc");
-            for (int j = 0; j < W && rc == GAMMA_HIP_OK; j++)
+            for (int j = 0; j < W && rc == GAMMA_HIP_OK && !nccl; j++)
                 hip(copy_between(b.cutall.as<uint8_t>() + (size_t)j * per, g->dev[i], g->mb[j].cutf.as<uint8_t>() + q0, g->dev[j], (size_t)nql, s),
                     "cut flags");
             if (rc == GAMMA_HIP_OK) abi(gamma_hip_ivfpq_merge_set_shard_flags(h, b.cutall.as<uint8_t>()));

@@ -464,6 +464,17 @@ int gamma_hip_group_destroy(gamma_hip_group* g);
 int gamma_hip_group_size(const gamma_hip_group* g);
 gamma_hip_index* gamma_hip_group_member(gamma_hip_group* g, int i);
 const char* gamma_hip_group_last_error(gamma_hip_group* g);
+/* Transport of the two exchanges of a sharded search (the assignment, the per-shard top-recall_num tables of every owner's
+ * slice).  0 (default): device-to-device copies ordered by events and host barriers.  1: RCCL over xGMI -- ONE in-place
+ * ncclAllGather of the assignment and one grouped ncclSend / ncclRecv exchange of the tables, one communicator per member
+ * (ncclCommInitAll), resolved from librccl.so at run time; formed at the next sharded search, and only when every member
+ * has a device of its own (otherwise, or when the library cannot be loaded, the group stays on copies and says why in
+ * gamma_hip_group_transport_note).  The environment variable GAMMA_HIP_GROUP_RCCL=1 selects 1 for every new group.
+ * gamma_hip_group_transport: out2 = {1 when a communicator is in use, searches whose exchanges went through RCCL}.
+ * The rare tie-phase exports stay on copies.  Results do not depend on the transport. */
+int gamma_hip_group_set_transport(gamma_hip_group* g, int rccl);
+int gamma_hip_group_transport(gamma_hip_group* g, int64_t* out2);
+const char* gamma_hip_group_transport_note(gamma_hip_group* g);
 /* list -> member.  weights[nlist] (expected or actual list sizes: the training set's assignment counts, the sizes in a
  * dump) are balanced greedily, heaviest list first -- probe popularity follows list size, so this balances scan
  * bytes; NULL: l mod n.  Call once, after gamma_hip_ivfpq_init on every member and before the first Add. */

@@ -314,3 +314,34 @@ def test_sharded_group_keeps_the_reference_order_inside_ties(tag, W):
             assert Dg.tobytes() == D1.tobytes() or not has_rank
     finally:
         grp.close()
+
+
+def test_group_exchanges_through_rccl_where_a_communicator_forms(case):
+    """gamma_hip_group_set_transport(g, 1): the assignment goes through ONE in-place ncclAllGather and the per-shard tables
+    through one grouped ncclSend / ncclRecv exchange (the north star's RCCL over xGMI), one communicator per member.  The test
+    box has one GPU: a group of ONE member forms a (one-rank) communicator and runs every RCCL call of the path; members that
+    share a device cannot, stay on copies and say so.  Results are the single handle's either way."""
+    full = _single(case)
+    q = case["q"]
+    args = api.SearchArgs(metric=api.METRIC_L2, nprobe=8, recall_num=60, has_rank=True, **WIDE)
+    D0, I0 = full.ivfpq_search(q, 10, args)
+    one = _group(case, 1)
+    two = _group(case, 2)
+    try:
+        one.set_transport(True)
+        D1, I1 = one.ivfpq_search(q, 10, args)
+        t1 = one.transport()
+        assert t1["rccl"] and t1["rccl_searches"] == 1 and t1["note"] == "RCCL", t1
+        compare_exact(D0, I0, D1, I1)
+        D1b, I1b = one.ivfpq_search(q[:7], 10, args)        # another batch size through the same communicator
+        compare_exact(D0[:7], I0[:7], D1b, I1b)
+        assert one.transport()["rccl_searches"] == 2
+        two.set_transport(True)
+        D2, I2 = two.ivfpq_search(q, 10, args)
+        t2 = two.transport()
+        assert not t2["rccl"] and t2["rccl_searches"] == 0 and "share a device" in t2["note"], t2
+        compare_exact(D0, I0, D2, I2)
+    finally:
+        one.close()
+        two.close()
+        full.close()
