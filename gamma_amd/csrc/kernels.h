@@ -95,6 +95,7 @@ struct FlatLog {
     int* cnt = nullptr;
     int* kept = nullptr;
     int nsl = 0, pass = 0;
+    unsigned long long* dbg = nullptr;   // GAMMA_HIP_COMPACT_DBG: phase clocks of query 0
 };
 void launch_flat_compact(hipStream_t s, int nq, int k, const FlatEmit& em, uint32_t* tau, int* overflow,
                          const FlatLog* log = nullptr);

@@ -22,6 +22,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "block_utils.h"
@@ -1166,6 +1167,8 @@ __global__ __launch_bounds__(256) void k_flat_compact(int nq, int k, FlatEmit em
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + w;
     if (q >= nq) return;
+#define GH_CT(i) do { if (lg.dbg && q == 0 && lane == 0) lg.dbg[i] = wall_clock64(); } while (0)
+    GH_CT(0);
     const int cnt = em.cnt[q];
     if (cnt > em.cap) {   // more survivors than the list holds: the caller redoes the call without a bound
         if (lane == 0) *overflow = 1;
@@ -1174,10 +1177,18 @@ __global__ __launch_bounds__(256) void k_flat_compact(int nq, int k, FlatEmit em
     if (lg.items && lane == 0 && cnt == 0) lg.cnt[(int64_t)q * lg.nsl + lg.pass] = 0;
     if (cnt == 0) return;
     unsigned long long* list = em.cand + (int64_t)q * em.cap;
+    // (a list rarely holds more than a few hundred of its 2048 slots: every loop below stops at the last slot in use)
+    const int nj = (cnt + 63) >> 6;   // uniform
     unsigned long long it[NPL];
 #pragma unroll
-    for (int j = 0; j < NPL; j++) it[j] = j * 64 + lane < cnt ? list[j * 64 + lane] : ~0ull;
+    for (int j = 0; j < NPL; j++) it[j] = ~0ull;
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+        if (j >= nj) continue;
+        if (j * 64 + lane < cnt) it[j] = list[j * 64 + lane];
+    }
     const int m = min(cnt, k);
+    GH_CT(1);
     if (lg.items) {
         // exact ties: what this pass appended (entries behind the `kept` older ones) is the pass's part of the stream
         // the reference's heap saw -- a superset of what it took: the bound was its root or looser
@@ -1185,6 +1196,7 @@ __global__ __launch_bounds__(256) void k_flat_compact(int nq, int k, FlatEmit em
         unsigned long long* dst = lg.items + ((int64_t)q * lg.nsl + lg.pass) * em.cap;
 #pragma unroll
         for (int j = 0; j < NPL; j++) {
+            if (j >= nj) continue;
             const int idx = j * 64 + lane;
             if (idx >= old && idx < cnt) dst[idx - old] = it[j];
         }
@@ -1193,24 +1205,75 @@ __global__ __launch_bounds__(256) void k_flat_compact(int nq, int k, FlatEmit em
             lg.kept[q] = m;
         }
     }
-    // smallest V with #(item <= V) >= m; items are distinct, so exactly m items are <= V
-    unsigned long long lo = 0ull, hi = ~0ull - 1ull;
-    while (lo < hi) {
-        const unsigned long long mid = lo + ((hi - lo) >> 1);
-        int c = 0;
+    // V with exactly m items <= V (items are distinct).  Bisection on the 32-bit KEYS between the smallest and the largest
+    // one present (about twenty steps of 32-bit compares; the 64-step bisection on whole items was most of this kernel);
+    // only when the m-th key is shared does a second bisection over the positions of the items that carry it decide.
+    auto wave_sum = [&](int c) { return __reduce_add_sync(~0ull, c); };
+    uint32_t kmin = 0xffffffffu, kmax = 0u;
+    GH_CT(2);
 #pragma unroll
-        for (int j = 0; j < NPL; j++) c += it[j] <= mid ? 1 : 0;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
-        if (c >= m) hi = mid;
-        else lo = mid + 1ull;
+    for (int j = 0; j < NPL; j++) {
+        if (j >= nj) continue;
+        const uint32_t kj = (uint32_t)(it[j] >> 32);   // (an empty slot carries 0xffffffff: never <= a bound below kmax)
+        if (it[j] != ~0ull) {
+            kmin = min(kmin, kj);
+            kmax = max(kmax, kj);
+        }
     }
-    const unsigned long long V = lo;
+    uint32_t klo = wave_min_u32(kmin), khi = wave_max_u32(kmax);
+    // one step = a ballot and a scalar popcount per 64 slots in use: no cross-lane reduction, the count is wave-uniform
+    // (mid < khi <= kmax < the empty slots' key, so those never count)
+    auto bisect = [&](auto nj_c) {
+        constexpr int NJ = decltype(nj_c)::value;
+        while (klo < khi) {
+            const uint32_t mid = klo + ((khi - klo) >> 1);
+            int c = 0;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) c += __popcll(__ballot((uint32_t)(it[j] >> 32) <= mid));
+            if (c >= m) khi = mid;
+            else klo = mid + 1u;
+        }
+    };
+    if (nj <= 4) bisect(std::integral_constant<int, 4>{});
+    else if (nj <= 8) bisect(std::integral_constant<int, 8>{});
+    else bisect(std::integral_constant<int, NPL>{});
+    const uint32_t K = klo;
+    GH_CT(3);
+    int c_le = 0, c_lt = 0;
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+        if (j >= nj) continue;
+        const uint32_t kj = (uint32_t)(it[j] >> 32);
+        c_le += (it[j] != ~0ull && kj <= K) ? 1 : 0;
+        c_lt += (it[j] != ~0ull && kj < K) ? 1 : 0;
+    }
+    c_le = wave_sum(c_le);
+    c_lt = wave_sum(c_lt);
+    unsigned long long V = ((unsigned long long)K << 32) | 0xffffffffull;
+    if (c_le > m) {   // (uniform) the cut goes through the items with key K: the (m - c_lt) lowest positions among them
+        const int need = m - c_lt;
+        uint32_t plo = 0u, phi = 0xffffffffu;
+        while (plo < phi) {
+            const uint32_t mid = plo + ((phi - plo) >> 1);
+            int c = 0;
+#pragma unroll
+            for (int j = 0; j < NPL; j++) {
+                if (j >= nj) continue;
+                c += (it[j] != ~0ull && (uint32_t)(it[j] >> 32) == K && (uint32_t)it[j] <= mid) ? 1 : 0;
+            }
+            c = wave_sum(c);
+            if (c >= need) phi = mid;
+            else plo = mid + 1u;
+        }
+        V = ((unsigned long long)K << 32) | plo;
+    }
     unsigned long long* runs = s_run[w];
+    GH_CT(4);
     int at = 0;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
     for (int j = 0; j < NPL; j++) {
+        if (j >= nj) continue;
         const bool take = it[j] <= V;
         const unsigned long long tb = __ballot(take);
         if (take) runs[at + __popcll(tb & lt_mask)] = it[j];
@@ -1220,18 +1283,23 @@ __global__ __launch_bounds__(256) void k_flat_compact(int nq, int k, FlatEmit em
     unsigned long long x[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) x[r] = (r * 64 + lane < m) ? runs[r * 64 + lane] : ~0ull;
+    GH_CT(5);
     __builtin_amdgcn_wave_barrier();
+    const int nr = (m + 63) >> 6;   // runs in use (uniform): k = 100 sorts and merges two, not four
 #pragma unroll
-    for (int r = 0; r < 4; r++) x[r] = wave_sort64(x[r]);
+    for (int r = 0; r < 4; r++)
+        if (r < nr) x[r] = wave_sort64(x[r]);
 #pragma unroll
     for (int r = 0; r < 4; r++) runs[r * 64 + lane] = x[r];
     __builtin_amdgcn_wave_barrier();
+    GH_CT(6);
 #pragma unroll
     for (int r = 0; r < 4; r++) {
+        if (r >= nr) continue;
         int rank = lane;
 #pragma unroll
         for (int o = 0; o < 4; o++) {
-            if (o == r) continue;
+            if (o == r || o >= nr) continue;
             const unsigned long long* ro = runs + o * 64;
             int lo2 = 0, n2 = 64;
 #pragma unroll
@@ -1250,6 +1318,8 @@ __global__ __launch_bounds__(256) void k_flat_compact(int nq, int k, FlatEmit em
         }
         if (x[r] != ~0ull) list[rank] = x[r];   // ranks are a permutation of 0..m-1
     }
+    GH_CT(7);
+#undef GH_CT
     if (lane == 0) {
         em.cnt[q] = m;
         tau[q] = m == k ? (uint32_t)(V >> 32) : FLAT_ANY;
@@ -1282,9 +1352,22 @@ void launch_flat_init(hipStream_t s, bool l2, const float* vals, const int* pos,
 }
 void launch_flat_compact(hipStream_t s, int nq, int k, const FlatEmit& em, uint32_t* tau, int* overflow, const FlatLog* log) {
     if (k > 256 || em.cap != FLAT_CAP) abort();   // callers gate on this
-    if (nq > 0)
-        hipLaunchKernelGGL(k_flat_compact, dim3((nq + 3) / 4), dim3(256), 0, s, nq, k, em, tau, overflow,
-                           log ? *log : FlatLog{});
+    FlatLog lg = log ? *log : FlatLog{};
+    static const bool want_dbg = getenv("GAMMA_HIP_COMPACT_DBG") != nullptr;
+    static unsigned long long* dbg = nullptr;
+    static int shown = 0;
+    if (want_dbg) {
+        if (!dbg) (void)hipMalloc((void**)&dbg, 64);
+        if (shown++ % 16 == 15) {
+            unsigned long long t[8];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(t, dbg, sizeof(t), hipMemcpyDeviceToHost);
+            fprintf(stderr, "flat compact (10 ns ticks, previous launch, query 0): load %llu log %llu minmax %llu bisect %llu tail-count %llu compact %llu sort %llu merge %llu\n",
+                    t[1] - t[0], t[2] - t[1], 0ull, t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], t[7] - t[6]);
+        }
+        lg.dbg = dbg;
+    }
+    if (nq > 0) hipLaunchKernelGGL(k_flat_compact, dim3((nq + 3) / 4), dim3(256), 0, s, nq, k, em, tau, overflow, lg);
 }
 void launch_flat_final(hipStream_t s, bool l2, int nq, int k, const FlatEmit& em, float neutral, float* distances,
                        int64_t* labels) {
