@@ -228,6 +228,17 @@ int arena_repack(H* h) {
     if (h->wl) GH_CHECK(h, h->wl->exclusive());   // every list moves and the old arrays are freed
     GH_TRY(publish_meta(h));                      // the device tables the kernel below reads = the host mirror
     VmRange vc, vi, vs;
+    struct VmGuard {   // an error below gives the fresh ranges back
+        VmRange *a, *b, *c;
+        bool armed = true;
+        ~VmGuard() {
+            if (armed) {
+                a->release();
+                b->release();
+                c->release();
+            }
+        }
+    } vm_guard{&vc, &vi, &vs};
     if (h->arena_vmm) {   // a fresh set of mapped ranges, tight
         const size_t chunk = (size_t)8 << 20;
         const char* what = "";
@@ -239,12 +250,7 @@ int arena_repack(H* h) {
         if (e == hipSuccess) e = vc.map_to((size_t)ncap * h->code_size, &what);
         if (e == hipSuccess) e = vi.map_to((size_t)ncap * sizeof(int64_t), &what);
         if (e == hipSuccess && h->keep_sums) e = vs.map_to((size_t)ncap * sizeof(float), &what);
-        if (e != hipSuccess) {
-            vc.release();
-            vi.release();
-            vs.release();
-            return vm_fail(h, "arena repack", e, what);
-        }
+        if (e != hipSuccess) return vm_fail(h, "arena repack", e, what);
         nc = reinterpret_cast<uint8_t*>(vc.base);
         ni = reinterpret_cast<int64_t*>(vi.base);
         ns = h->keep_sums ? reinterpret_cast<float*>(vs.base) : nullptr;
@@ -269,6 +275,7 @@ int arena_repack(H* h) {
         h->vm_codes.release();
         h->vm_ids.release();
         h->vm_sums.release();
+        vm_guard.armed = false;   // the handle owns them from here
         h->vm_codes = std::move(vc);
         h->vm_ids = std::move(vi);
         h->vm_sums = std::move(vs);
