@@ -508,8 +508,9 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
                                 h->w_sflag.as<uint8_t>(), out_dis,
                                 h->w_cand_pos.as<int>(), out_ids, h->tie.on ? h->w_tcut.as<uint8_t>() : nullptr,
                                 h->d_tie_stats, sb.rq_list, sb.rq_count, h->d_bound_stat + 2 * (h->bound_epoch & 1));
-        // the counts as of this call, for a later call's decision (16 bytes: the first calls of a kind, then every 4th)
-        if (h->bound_calls < 8 || (h->bound_calls & 3) == 0)
+        // the counts as of this call, for a later call's decision (16 bytes; ~5 us on the call's critical path, so: the
+        // first calls of a kind, then every 16th)
+        if (h->bound_calls < 4 || (h->bound_calls & 15) == 0)
             GH_CHECK(h, hipMemcpyAsync(h->pin_bound_stat + 2 * (h->bound_epoch & 1), h->d_bound_stat + 2 * (h->bound_epoch & 1),
                                        2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         h->bound_calls++;
