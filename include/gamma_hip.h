@@ -384,7 +384,11 @@ int gamma_hip_ivfpq_search_shard(gamma_hip_index* h, const gamma_hip_search_para
 int gamma_hip_ivfpq_coarse_device(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
                                   const float* d_x, float* d_coarse_dis, int32_t* d_probe);
 /* stage 1 with the coarse assignment supplied = search_preassigned restricted to the owned lists
- * (gamma_index_ivfpq.cc:701-890): tables + scan + local top-recall_num */
+ * (gamma_index_ivfpq.cc:701-890): tables + scan + local top-recall_num.  Enqueued like every device-pointer call, except
+ * when the batch does not fit the workspace budget at the general slab stride (nprobe x the longest list; a W-rank job hands
+ * every rank W x the queries but ~nprobe / W of their probes): then the longest candidate row of THIS batch over THIS shard's
+ * lists is measured on the device and read back (one word; the call waits for the work enqueued before it) and stride and
+ * chunks are sized by it -- full-size C4, 8 shards: 1-2 chunks instead of 20. */
 int gamma_hip_ivfpq_search_shard_preassigned(gamma_hip_index* h, const gamma_hip_search_params* p,
                                              int nq, const float* d_x, const float* d_coarse_dis,
                                              const int32_t* d_probe, int k, float* d_recall_dis,
