@@ -50,6 +50,7 @@ SYMBOLS = {
     "gamma_hip_stream": (C.c_void_p, [C.c_void_p]),
     "gamma_hip_synchronize": (C.c_int, [C.c_void_p]),
     "gamma_hip_set_workspace_budget": (C.c_int, [C.c_void_p, C.c_int64]),
+    "gamma_hip_debug_heap_stream": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, f32p, f32p, i32p, f32p, i32p]),
     "gamma_hip_set_scan_bound_feedback": (C.c_int, [C.c_void_p, C.c_int]),
     "gamma_hip_scan_bound_stats": (C.c_int, [C.c_void_p, i64p]),
     "gamma_hip_set_exact_ties": (C.c_int, [C.c_void_p, C.c_int]),

@@ -420,6 +420,15 @@ class GammaHip:
         self._ck(self.L.gamma_hip_ivfpq_merge_replay(self.h, args.ref(), nshards, nf, d_x_slice, stride, d_vals_all, d_ids_all,
                                                      d_off_all, k, d_list, d_D, d_I), "merge_replay")
 
+    def debug_heap_stream(self, op, k, vals):
+        """test hook: (array values, array ids, sorted values, sorted ids) of one heap fed with vals (gamma_hip.h)"""
+        vals = _f32(vals).ravel()
+        av, ai = np.empty(k, np.float32), np.empty(k, np.int32)
+        sv, si = np.empty(k, np.float32), np.empty(k, np.int32)
+        self._ck(self.L.gamma_hip_debug_heap_stream(self.h, op, k, len(vals), _p(vals, _lib.f32p), _p(av, _lib.f32p),
+                                                    _p(ai, _lib.i32p), _p(sv, _lib.f32p), _p(si, _lib.i32p)), "debug_heap_stream")
+        return av, ai, sv, si
+
     def set_scan_bound_feedback(self, on):
         self._ck(self.L.gamma_hip_set_scan_bound_feedback(self.h, 1 if on else 0), "set_scan_bound_feedback")
 

@@ -1777,6 +1777,31 @@ int gamma_hip_ivfpq_merge_flagged(gamma_hip_index* h, int* n_flagged, const int3
 
 int gamma_hip_ivfpq_max_list_len(gamma_hip_index* h) { return (h && h->ivf_init) ? h->max_list_len : 0; }
 
+int gamma_hip_debug_heap_stream(gamma_hip_index* h, int op, int k, int n, const float* vals, float* arr_vals, int32_t* arr_ids,
+                                float* sorted_vals, int32_t* sorted_ids) {
+    if (!h || op < 0 || op > 3 || k < 1 || k > gh::tie_small_max_k() || n < 0 || (n > 0 && !vals) || !arr_vals || !arr_ids ||
+        !sorted_vals || !sorted_ids)
+        return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    GH_CHECK(h, hipSetDevice(h->device));
+    GH_CHECK(h, h->w_stage.ensure((size_t)std::max(n, 1) * sizeof(float) + (size_t)2 * k * sizeof(uint2) + 16));
+    float* d_vals = h->w_stage.as<float>();
+    uint2* d_arr = reinterpret_cast<uint2*>(h->w_stage.as<char>() + (((size_t)std::max(n, 1) * sizeof(float) + 15) & ~(size_t)15));
+    uint2* d_sorted = d_arr + k;
+    if (n > 0) GH_CHECK(h, hipMemcpyAsync(d_vals, vals, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    gh::launch_debug_heap_stream(h->stream, op, k, n, d_vals, d_arr, d_sorted);
+    std::vector<uint2> out((size_t)2 * k);
+    GH_CHECK(h, hipMemcpyAsync(out.data(), d_arr, (size_t)2 * k * sizeof(uint2), hipMemcpyDeviceToHost, h->stream));
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < k; i++) {
+        memcpy(&arr_vals[i], &out[i].x, 4);
+        arr_ids[i] = (int32_t)out[i].y;
+        memcpy(&sorted_vals[i], &out[k + i].x, 4);
+        sorted_ids[i] = (int32_t)out[k + i].y;
+    }
+    return GAMMA_HIP_OK;
+}
+
 int gamma_hip_gather_rows(gamma_hip_index* h, const void* d_src, int row_words, const int32_t* d_list, int n, void* d_dst) {
     if (!h || row_words <= 0 || n < 0) return GAMMA_HIP_EINVAL;
     if (n == 0) return GAMMA_HIP_OK;

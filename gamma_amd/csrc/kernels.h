@@ -322,6 +322,8 @@ int tie_replay_max_k();
 int tie_small_max_k();
 void launch_tie_list(hipStream_t s, const uint8_t* cut, const uint8_t* extra, int nq, int* list, int* count,
                      unsigned long long* tie_stats);
+// test hook: one stream through one heap with each form of the sifts (ties.hip)
+void launch_debug_heap_stream(hipStream_t s, int op, int k, int n, const float* vals, uint2* out_arr, uint2* out_sorted);
 int tie_replay_max_probes();
 void launch_tie_replay(hipStream_t s, bool l2, const TieReplayArgs& a);
 void launch_flag_cut_ties(hipStream_t s, const float* slab, int64_t q_stride, const int* q_total, int nq, int K,

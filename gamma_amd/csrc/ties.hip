@@ -381,4 +381,60 @@ void launch_gather_words(hipStream_t s, const void* src, const int* list, int n,
                            static_cast<uint32_t*>(out));
 }
 
+
+// ------------------------------------------------------------------------------------
+// Test hook (gamma_hip_debug_heap_stream): one stream of keys through ONE heap with each form of the sifts, so that the
+// device's heaps can be compared with the oracle's (= the compiled library's) entry for entry.
+//   op 0: heap_replace_top stream through the pipelined HeapWalk          -> the heap ARRAY, then heap_reorder
+//   op 1: heap_pop + heap_push stream through ParHeap (all lanes per sift) -> likewise
+//   op 2: heap_pop + heap_push stream through the sequential forms
+//   op 3: heap_replace_top stream through ParHeap's sift
+// out_arr: the array when the stream is through (k entries: value, payload); out_sorted: after heap_reorder.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_debug_heap_stream(int op, int k, int n, const float* __restrict__ vals,
+                                                          uint2* __restrict__ out_arr, uint2* __restrict__ out_sorted) {
+    __shared__ __attribute__((aligned(16))) uint2 h[TR_MAXK + 2];
+    const int lane = threadIdx.x;
+    heap_fill(h, k, lane, 64);
+    __builtin_amdgcn_wave_barrier();
+    HeapWalk w;
+    w.begin(h, k);
+    float top = kHeapFltMax;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + lane;
+        const float dv = j < n ? vals[j] : INFINITY;
+        if (op == 0) {
+            w.accept(j < n, dv, j);
+            continue;
+        }
+        unsigned long long m = __ballot(top > dv);
+        while (m) {
+            const int l = (int)__ffsll((long long)m) - 1;
+            const float val = hw_readlane_f(dv, l);
+            if (op == 1) {
+                const float root = par_heap_pop(h, k);
+                top = par_heap_push(h, k, val, (unsigned)(j0 + l)) ? val : root;
+            } else if (op == 2) {
+                heap_pop_seq(h, k);
+                heap_push_seq(h, k, val, (unsigned)(j0 + l));
+                top = hs_f(h[1].x);
+            } else {
+                top = par_heap_replace_top(h, k, val, (unsigned)(j0 + l));
+            }
+            const unsigned long long above = l >= 63 ? 0ull : (~0ull << (l + 1));
+            m = __ballot(top > dv) & above;
+        }
+    }
+    if (op == 0) w.drain();
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < k; i += 64) out_arr[i] = h[1 + i];
+    __builtin_amdgcn_wave_barrier();
+    if (op == 2) heap_reorder_seq(h, k);
+    else par_heap_reorder(h, k);
+    for (int i = lane; i < k; i += 64) out_sorted[i] = h[1 + i];
+}
+void launch_debug_heap_stream(hipStream_t s, int op, int k, int n, const float* vals, uint2* out_arr, uint2* out_sorted) {
+    hipLaunchKernelGGL(k_debug_heap_stream, dim3(1), dim3(64), 0, s, op, k, n, vals, out_arr, out_sorted);
+}
+
 }  // namespace gh

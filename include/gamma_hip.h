@@ -407,6 +407,13 @@ int gamma_hip_flat_search(gamma_hip_index* h, const gamma_hip_search_params* p, 
 int gamma_hip_flat_search_device(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
                                  const float* d_x, int k, float* d_distances, int64_t* d_labels);
 
+/* Test hook: n keys (smaller is better; payload = position) through ONE heap of k <= 1024 entries with one form of the
+ * device's sifts -- op 0: heap_replace_top stream through the pipelined walk (csrc/heap_dev.h HeapWalk), 1: heap_pop +
+ * heap_push through ParHeap (all lanes per sift), 2: the same through the sequential forms, 3: heap_replace_top through
+ * ParHeap's sift.  arr_*: the heap ARRAY when the stream is through ((FLT_MAX, -1) = empty); sorted_*: after heap_reorder.
+ * tests/test_gpu_heaps.py compares them with the oracle's heaps (= the compiled library's, faiss:utils/Heap.h). */
+int gamma_hip_debug_heap_stream(gamma_hip_index* h, int op, int k, int n, const float* vals, float* arr_vals, int32_t* arr_ids,
+                                float* sorted_vals, int32_t* sorted_ids);
 /* Exact ties across list shards.  gamma_hip_ivfpq_merge_rerank (exact ties on) leaves a list of the slice's queries whose
  * result a tie can change: two equal exact distances among the first k + 1 (or equal ADC distances among the taken ones
  * without re-rank), or the cut of the merged top-recall_num going through a group of equal distances (also when a shard's
