@@ -1779,7 +1779,7 @@ int gamma_hip_ivfpq_max_list_len(gamma_hip_index* h) { return (h && h->ivf_init)
 
 int gamma_hip_debug_heap_stream(gamma_hip_index* h, int op, int k, int n, const float* vals, float* arr_vals, int32_t* arr_ids,
                                 float* sorted_vals, int32_t* sorted_ids) {
-    if (!h || op < 0 || op > 3 || k < 1 || k > gh::tie_small_max_k() || n < 0 || (n > 0 && !vals) || !arr_vals || !arr_ids ||
+    if (!h || op < 0 || op > 4 || (op == 4 && n < 1) || k < 1 || k > gh::tie_small_max_k() || n < 0 || (n > 0 && !vals) || !arr_vals || !arr_ids ||
         !sorted_vals || !sorted_ids)
         return GAMMA_HIP_EINVAL;
     SearchLock lk(h);

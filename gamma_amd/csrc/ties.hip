@@ -36,6 +36,7 @@
 #include "device_math.h"
 #include "kernels.h"
 #include "rerank_dev.h"
+#include "reservoir_dev.h"
 #include "tie_dev.h"
 
 namespace gh {
@@ -389,12 +390,23 @@ void launch_gather_words(hipStream_t s, const void* src, const int* list, int n,
 //   op 1: heap_pop + heap_push stream through ParHeap (all lanes per sift) -> likewise
 //   op 2: heap_pop + heap_push stream through the sequential forms
 //   op 3: heap_replace_top stream through ParHeap's sift
+//   op 4: the stream through faiss's ReservoirTopN (n >= 1; out_arr = out_sorted = to_result's output)
 // out_arr: the array when the stream is through (k entries: value, payload); out_sorted: after heap_reorder.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_debug_heap_stream(int op, int k, int n, const float* __restrict__ vals,
                                                           uint2* __restrict__ out_arr, uint2* __restrict__ out_sorted) {
     __shared__ __attribute__((aligned(16))) uint2 h[TR_MAXK + 2];
     const int lane = threadIdx.x;
+    if (op == 4) {   // faiss's ReservoirTopN (reservoir_dev.h): there is no array to show, only to_result's output
+        __shared__ float s_v[reservoir_capacity(TR_MAXK)];
+        __shared__ int s_i[reservoir_capacity(TR_MAXK)];
+        (void)reservoir_row(vals, n, k, s_v, s_i, h);
+        for (int i = lane; i < k; i += 64) {
+            out_arr[i] = h[1 + i];
+            out_sorted[i] = h[1 + i];
+        }
+        return;
+    }
     heap_fill(h, k, lane, 64);
     __builtin_amdgcn_wave_barrier();
     HeapWalk w;

@@ -410,7 +410,8 @@ int gamma_hip_flat_search_device(gamma_hip_index* h, const gamma_hip_search_para
 /* Test hook: n keys (smaller is better; payload = position) through ONE heap of k <= 1024 entries with one form of the
  * device's sifts -- op 0: heap_replace_top stream through the pipelined walk (csrc/heap_dev.h HeapWalk), 1: heap_pop +
  * heap_push through ParHeap (all lanes per sift), 2: the same through the sequential forms, 3: heap_replace_top through
- * ParHeap's sift.  arr_*: the heap ARRAY when the stream is through ((FLT_MAX, -1) = empty); sorted_*: after heap_reorder.
+ * ParHeap's sift, 4: faiss's ReservoirTopN (what knn_L2sqr collects through from 100 results on; arr = sorted = its
+ * to_result output, n >= 1).  arr_*: the heap ARRAY when the stream is through ((FLT_MAX, -1) = empty); sorted_*: after heap_reorder.
  * tests/test_gpu_heaps.py compares them with the oracle's heaps (= the compiled library's, faiss:utils/Heap.h). */
 int gamma_hip_debug_heap_stream(gamma_hip_index* h, int op, int k, int n, const float* vals, float* arr_vals, int32_t* arr_ids,
                                 float* sorted_vals, int32_t* sorted_ids);

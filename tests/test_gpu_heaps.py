@@ -54,3 +54,33 @@ def test_every_form_of_the_sifts_leaves_the_reference_heaps(k):
                     assert av.tobytes() == ref_arr[0].tobytes() and np.array_equal(ai, ref_arr[1]), (op, k, n)
     finally:
         g.close()
+
+
+def test_reservoir_streams_of_the_compiled_library_on_the_device():
+    """tests/golden/reservoir_ties.npz: streams of tied keys through the COMPILED library's ReservoirTopN (k = 100 .. 256, what
+    knn_L2sqr collects the coarse assignment through from 100 probes on).  The device's replay (reservoir_dev.h: append,
+    partition_fuzzy_median3 shrinks, to_result) returns the library's labels at every rank -- keep-smallest streams; and the
+    oracle's restatement agrees with the device on longer streams and larger k (up to the 1024 probes the mode covers)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reservoir_ties.npz"))
+    g = api.GammaHip(0)
+    try:
+        seen = 0
+        for ci, (ks, k, n, hi) in enumerate(z["cases"]):
+            if not ks:
+                continue                                  # (the device replays the L2 coarse quantizer: keep-smallest)
+            keys = np.ascontiguousarray(z["keys_%d" % ci])
+            _, _, sv, si = g.debug_heap_stream(4, int(k), keys)
+            assert sv.tobytes() == z["D_%d" % ci].tobytes() and np.array_equal(si.astype(np.int64), z["I_%d" % ci]), (k, n, hi)
+            seen += 1
+        assert seen >= 10
+        for seed, (k, n, hi) in enumerate([(300, 5000, 7), (512, 20000, 3), (1000, 3000, 2), (1024, 16384, 50), (100, 100, 2),
+                                           (640, 641, 4)]):
+            rng = np.random.default_rng(seed)
+            keys = rng.integers(0, hi, size=n).astype(np.float32)
+            ov, oi = np.empty(k, np.float32), np.empty(k, np.int64)
+            B.lib().go_reservoir_stream(1, k, n, B._fp(keys), None, B._fp(ov), B._ip(oi))
+            _, _, sv, si = g.debug_heap_stream(4, k, keys)
+            assert sv.tobytes() == ov.tobytes() and np.array_equal(si.astype(np.int64), oi), (k, n, hi)
+    finally:
+        g.close()
