@@ -6,7 +6,7 @@ import pytest
 from gamma_amd import api, synth
 from tests import lloyd as train
 from oracle import binding as B
-from tests.parity import compare_search_exact
+from tests.parity import compare_search_exact, compare_exact
 
 pytestmark = pytest.mark.gpu
 WIDE = dict(min_score=-3e38, max_score=3e38)
@@ -125,4 +125,56 @@ def test_many_probes_and_large_batch():
                 compare_search_exact(Do, Io, st, Dg, Ig, sg)
     finally:
         B.lib().go_set_assign_mode(0)
+        g.close()
+
+
+_FLAT_SEEDS = list(range(12))
+if os.environ.get("GAMMA_FLAT_FUZZ_SEEDS"):     # e.g. "100:400": an extended one-off run
+    _a, _b = os.environ["GAMMA_FLAT_FUZZ_SEEDS"].split(":")
+    _FLAT_SEEDS = list(range(int(_a), int(_b)))
+
+
+@pytest.mark.parametrize("seed", _FLAT_SEEDS)
+def test_random_flat_configuration(seed):
+    """GammaFLATIndex::Search on random shapes: dimension, row count (one slab chunk .. several passes of the running bound
+    behind the bf16 matrix-pipe filter), k from 1 to 300 (the heaps in one register, in LDS with all lanes per sift, beyond
+    256 sequential), small-grid integer data (most queries tie at the k cut) or SIFT-shaped data, both metrics, delete
+    bitmap + range filter + score window now and then.  Labels at every rank are the oracle's."""
+    rng = np.random.default_rng(31000 + seed)
+    d = int(rng.choice([16, 32, 64, 96, 128]))
+    N = int(rng.choice([3000, 17000, 40000, 70000, 150000]))
+    nq = int(rng.choice([1, 9, 64, 130, 300]))
+    k = int(rng.choice([1, 5, 10, 16, 63, 64, 100, 128, 200, 256, 300]))
+    metric = int(rng.choice([B.METRIC_L2, B.METRIC_IP]))
+    if rng.random() < 0.6:
+        hi = int(rng.choice([2, 4, 16]))
+        base = rng.integers(0, hi, size=(N, d)).astype(np.float32)
+        q = rng.integers(0, hi, size=(nq, d)).astype(np.float32)
+    else:
+        base = synth.sift_like(N, d=d, seed=700 + seed)
+        q = synth.sift_like(nq, d=d, seed=800 + seed)
+    ctx_kw, kw_f = {}, {}
+    g = api.GammaHip(0)
+    try:
+        g.raw_init(d)
+        g.raw_append(base)
+        if rng.random() < 0.4:
+            dead = rng.choice(N, N // 7, replace=False)
+            bm = np.zeros((N >> 3) + 1, dtype=np.uint8)
+            np.bitwise_or.at(bm, dead >> 3, (1 << (dead & 7)).astype(np.uint8))
+            g.bitmap_upload(bm, N)
+            docs = rng.choice(N, 3 * N // 4, replace=False)
+            ctx_kw = dict(docids_bitmap=bm, range_filters=[B.make_range_filter(docs)])
+            kw_f = dict(range_filters=[api.make_range_filter(docs)])
+        win = WIDE
+        if rng.random() < 0.3:
+            Dw, _ = B.flat_search(base, q, k, metric, B.make_ctx(**WIDE, **ctx_kw))
+            fin = Dw[np.abs(Dw) < 1e37]
+            if len(fin) > 4:
+                win = dict(min_score=float(np.quantile(fin, 0.2)), max_score=float(np.quantile(fin, 0.95)))
+        D, I = B.flat_search(base, q, k, metric, B.make_ctx(**win, **ctx_kw))
+        Dg, Ig = g.flat_search(q, k, api.SearchArgs(metric=metric, **win, **kw_f))
+        compare_exact(D, I, Dg, Ig)
+        assert g.ties_not_honoured() == 0
+    finally:
         g.close()
