@@ -178,3 +178,60 @@ def test_random_flat_configuration(seed):
         assert g.ties_not_honoured() == 0
     finally:
         g.close()
+
+
+_IVFFLAT_SEEDS = list(range(8))
+if os.environ.get("GAMMA_IVFFLAT_FUZZ_SEEDS"):
+    _a, _b = os.environ["GAMMA_IVFFLAT_FUZZ_SEEDS"].split(":")
+    _IVFFLAT_SEEDS = list(range(int(_a), int(_b)))
+
+
+@pytest.mark.parametrize("seed", _IVFFLAT_SEEDS)
+def test_random_ivfflat_configuration(seed):
+    """The IVFFLAT model on random shapes (gamma_index_ivfflat.h:52-75: exact distances over the probed lists into a k-heap
+    fed with heap_pop + heap_push): list count, probes (up to the reservoir's range), k 1..200, tie-heavy or SIFT-shaped data,
+    both metrics, small calls / pair kernel / list-major kernel by batch size.  Labels at every rank are the oracle's."""
+    rng = np.random.default_rng(52000 + seed)
+    d = int(rng.choice([16, 32, 64, 128]))
+    nlist = int(rng.choice([16, 64, 200]))
+    N = int(rng.choice([4000, 20000, 60000]))
+    nq = int(rng.choice([1, 7, 64, 300, 1500]))
+    P = int(min(nlist, rng.choice([1, 4, 16, 40, 120])))
+    k = int(rng.choice([1, 3, 10, 40, 100, 200]))
+    metric = int(rng.choice([B.METRIC_L2, B.METRIC_IP]))
+    if rng.random() < 0.6:
+        hi = int(rng.choice([3, 6, 20]))
+        base = rng.integers(0, hi, size=(N, d)).astype(np.float32)
+        q = rng.integers(0, hi, size=(nq, d)).astype(np.float32)
+        cc = rng.integers(0, hi, size=(nlist, d)).astype(np.float32) + (rng.random((nlist, d)) < 0.1).astype(np.float32) * 0.5
+    else:
+        base = synth.sift_like(N, d=d, seed=300 + seed)
+        q = synth.sift_like(nq, d=d, seed=400 + seed)
+        cc = base[rng.choice(N, nlist, replace=False)].copy()
+    M = 4
+    pq = np.zeros((M, 256, d // M), np.float32)
+    B.lib().go_set_assign_mode(1)
+    o = B.OracleIVFPQ(d, nlist, M, 8, metric)
+    o.set_trained(cc, pq, None)
+    assert o.add(base)
+    B.lib().go_set_assign_mode(0)
+    o.set_raw(base)
+    g = api.GammaHip(0)
+    try:
+        g.ivfflat_init(d, nlist, metric, 1000)
+        g.ivfflat_set_trained(cc)
+        lists = [o.get_list(l) for l in range(nlist)]
+        sizes = np.array([len(ids) for ids, _ in lists], dtype=np.int64)
+        nz = np.nonzero(sizes)[0]
+        allids = np.concatenate([lists[l][0] for l in nz]) if len(nz) else np.zeros(0, np.int64)
+        g.add_keys_batch(nz, sizes[nz], allids, np.zeros((len(allids), 1), np.uint8))
+        g.raw_init(d)
+        g.raw_append(base)
+        cm = int(rng.choice([0, 1, -1]))
+        om = cm if cm >= 0 else (1 if nq >= 20 else 0)
+        D, I = B.ivfflat_search(o, q, k, P, metric, B.make_ctx(**WIDE), coarse_mode=om)
+        Dg, Ig = g.ivfflat_search(q, k, api.SearchArgs(metric=metric, nprobe=P, coarse_mode=cm, **WIDE))
+        compare_exact(D, I, Dg, Ig)
+        assert g.ties_not_honoured() == 0
+    finally:
+        g.close()
