@@ -76,8 +76,9 @@ void launch_pairwise_filtered(hipStream_t s, bool l2, const float* x, int nq, in
 struct FlatEmit {
     const uint32_t* tau;        // [nq] key bound per query (0xff7fffff = anything valid)
     unsigned long long* cand;   // [nq][cap] (key << 32 | row id)
-    int* cnt;                   // [nq] items appended (may exceed cap: overflow)
+    int* cnt;                   // [nq * cstride] items appended (may exceed cap: overflow); query q's counter at q * cstride
     int cap;
+    int cstride = 1;            // counters one 128-byte line apart (32): appends of different queries do not serialise on a line
 };
 bool pairwise_can_emit(int nq, int d, int64_t ny);
 int flat_list_cap();

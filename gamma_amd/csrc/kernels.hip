@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void k_pairwise_lds(const float* __restrict__ 
                     if (L2 ? dis <= tau_q : dis >= tau_q) {
                         const uint32_t kk = f2key(dis);
                         const uint32_t key = L2 ? kk : ~kk;
-                        const int slot = atomicAdd(&em.cnt[qt + qi], 1);
+                        const int slot = atomicAdd(&em.cnt[(int64_t)(qt + qi) * em.cstride], 1);
                         if (slot < em.cap)
                             em.cand[(int64_t)(qt + qi) * em.cap + slot] =
                                     ((unsigned long long)key << 32) | (unsigned)(row_base + row);

@@ -1153,7 +1153,7 @@ __global__ __launch_bounds__(256) void k_flat_init(const float* __restrict__ val
     __syncthreads();
     if (threadIdx.x == 0) {
         const int n = s_n;
-        em.cnt[q] = n;
+        em.cnt[(int64_t)q * em.cstride] = n;
         if (kept) kept[q] = n;
         tau[q] = n == k ? (uint32_t)(em.cand[(int64_t)q * em.cap + k - 1] >> 32) : FLAT_ANY;
     }
@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(256) void k_flat_compact(int nq, int k, FlatEmit em
     if (q >= nq) return;
 #define GH_CT(i) do { if (lg.dbg && q == 0 && lane == 0) lg.dbg[i] = wall_clock64(); } while (0)
     GH_CT(0);
-    const int cnt = em.cnt[q];
+    const int cnt = em.cnt[(int64_t)q * em.cstride];
     if (cnt > em.cap) {   // more survivors than the list holds: the caller redoes the call without a bound
         if (lane == 0) *overflow = 1;
         return;
@@ -1321,7 +1321,7 @@ __global__ __launch_bounds__(256) void k_flat_compact(int nq, int k, FlatEmit em
     GH_CT(7);
 #undef GH_CT
     if (lane == 0) {
-        em.cnt[q] = m;
+        em.cnt[(int64_t)q * em.cstride] = m;
         tau[q] = m == k ? (uint32_t)(V >> 32) : FLAT_ANY;
     }
 }
@@ -1329,7 +1329,7 @@ __global__ __launch_bounds__(256) void k_flat_compact(int nq, int k, FlatEmit em
 __global__ __launch_bounds__(256) void k_flat_final(int k, bool smallest, FlatEmit em, float neutral,
                                                     float* __restrict__ distances, int64_t* __restrict__ labels) {
     const int q = blockIdx.x;
-    const int m = min(em.cnt[q], k);
+    const int m = min(em.cnt[(int64_t)q * em.cstride], k);
     for (int i = threadIdx.x; i < k; i += 256) {
         float dv = neutral;
         int64_t id = -1;
