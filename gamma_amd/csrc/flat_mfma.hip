@@ -45,6 +45,7 @@
 
 #include "device_math.h"
 #include "filter_dev.h"
+#include "block_utils.h"
 #include "kernels.h"
 #include "rerank_dev.h"
 
@@ -135,6 +136,9 @@ struct FlatFilterArgs {
     int cap;
 };
 constexpr int FM_WLIST = 256;   // survivors a wave collects in LDS before it reserves room in the global list
+constexpr int FM_NSUB = 32;     // the global pair list is FM_NSUB segments, each with a counter on a cache line of its own
+                                // (workgroup b appends to segment b % FM_NSUB): reservations do not queue on ONE address
+constexpr int FM_CTR_STRIDE = 32;   // ints between the segments' counters
 
 template <bool L2, int D>
 __global__ __launch_bounds__(FM_NT) void k_flat_filter(FlatFilterArgs a) {
@@ -197,14 +201,17 @@ __global__ __launch_bounds__(FM_NT) void k_flat_filter(FlatFilterArgs a) {
     };
     uint2* wl = s_list + w * FM_WLIST;
     int wcnt = 0;   // wave-uniform
+    const int sub = (int)(blockIdx.x & (FM_NSUB - 1));
+    int* seg_ctr = a.npairs + sub * FM_CTR_STRIDE;
+    uint2* seg = a.pairs + (int64_t)sub * a.cap;   // a.cap: capacity of ONE segment
     auto flush = [&]() {
         // the wave's list -> the global pair list: one atomic per flush
         int base = 0;
-        if (lane == 0) base = atomicAdd(a.npairs, wcnt);
+        if (lane == 0) base = atomicAdd(seg_ctr, wcnt);
         base = __builtin_amdgcn_readfirstlane(base);
         __builtin_amdgcn_wave_barrier();
         for (int i = lane; i < wcnt; i += 64)
-            if (base + i < a.cap) a.pairs[base + i] = wl[i];
+            if (base + i < a.cap) seg[base + i] = wl[i];
         __builtin_amdgcn_wave_barrier();
         wcnt = 0;
     };
@@ -277,7 +284,23 @@ __global__ __launch_bounds__(FM_NT) void k_flat_filter(FlatFilterArgs a) {
         }
         __syncthreads();   // every wave is through buffer b; the next tile's LDS-DMA and bounds have landed
     }
-    if (wcnt > 0) flush();
+    // what the waves still hold goes out with ONE reservation per workgroup: the counter is a single address, a returning
+    // atomic per wave (31 k per pass at C2) queued the finishing workgroups behind each other
+    __shared__ int s_wcnt[FM_NT / 64];
+    __shared__ int s_wbase;
+    if (lane == 0) s_wcnt[w] = wcnt;
+    __syncthreads();
+    if (tid == 0) {
+        int total = 0;
+#pragma unroll
+        for (int i = 0; i < FM_NT / 64; i++) total += s_wcnt[i];
+        s_wbase = total > 0 ? atomicAdd(seg_ctr, total) : 0;
+    }
+    __syncthreads();
+    int base = s_wbase;
+    for (int i = 0; i < w; i++) base += s_wcnt[i];
+    for (int i = lane; i < wcnt; i += 64)
+        if (base + i < a.cap) seg[base + i] = wl[i];
 }
 
 // the survivors' exact distances, 8 threads per survivor (the 8 AVX lane accumulators of the reference's kernels)
@@ -287,16 +310,33 @@ __global__ __launch_bounds__(256) void k_flat_exact(const uint2* __restrict__ pa
                                                     FilterDesc filt, int use_filter, float min_score, float max_score,
                                                     FlatEmit em, int* __restrict__ overflow) {
     const int l8 = threadIdx.x & 7, g = threadIdx.x >> 3;
-    const int n_all = *npairs;
-    if (n_all > cap) {   // more survivors than the list holds (no bound yet, or adversarial data): the caller redoes the call
+    // the list is FM_NSUB segments of `cap` slots (k_flat_filter): their counts, prefix-summed, index the survivors
+    __shared__ int s_off[FM_NSUB + 1];
+    __shared__ int s_over;
+    if (threadIdx.x == 0) s_over = 0;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int c = threadIdx.x < FM_NSUB ? npairs[threadIdx.x * FM_CTR_STRIDE] : 0;
+        if (c > cap) s_over = 1;   // more survivors than a segment holds (no bound yet, or adversarial data)
+        const int incl = wave_incl_scan(c);
+        if (threadIdx.x < FM_NSUB) s_off[threadIdx.x + 1] = incl;
+        if (threadIdx.x == 0) s_off[0] = 0;
+    }
+    __syncthreads();
+    if (s_over) {   // the caller redoes the call
         if (threadIdx.x == 0 && blockIdx.x == 0) *overflow = 1;
         return;
     }
+    const int n_all = s_off[FM_NSUB];
     const float sentinel = L2 ? INFINITY : -INFINITY;
     for (int s0 = blockIdx.x * 32; s0 < n_all; s0 += gridDim.x * 32) {
         const int s = s0 + g;
         const bool live = s < n_all;
-        const uint2 pr = live ? pairs[s] : make_uint2(0u, 0u);
+        int sg = 0;   // last segment with s_off[sg] <= s
+#pragma unroll
+        for (int step = FM_NSUB / 2; step >= 1; step >>= 1)
+            if (s_off[sg + step] <= s) sg += step;
+        const uint2 pr = live ? pairs[(int64_t)sg * cap + (s - s_off[sg])] : make_uint2(0u, 0u);
         const int q = (int)pr.x;
         const int64_t row = (int64_t)pr.y;
         float dis = rerank_dist8<L2>(x + (int64_t)q * d, store + row * d, d, l8, live);
@@ -319,7 +359,8 @@ bool flat_filter_supported(int nq, int d, int64_t ny) {
     static const bool off = getenv("GAMMA_HIP_NO_FLAT_MFMA") != nullptr;
     return !off && (d == 128 || d == 96 || d == 64 || d == 32) && nq >= 64 && ny >= 4096;
 }
-int64_t flat_filter_pair_cap(int nq) { return (int64_t)nq * 1024; }   // ~k survivors per query and pass are expected
+int64_t flat_filter_pair_cap(int nq) { return (int64_t)nq * 1024; }   // ~k survivors per query and pass are expected (all segments)
+int flat_filter_counter_bytes() { return FM_NSUB * FM_CTR_STRIDE * (int)sizeof(int); }
 size_t flat_filter_query_image_bytes(int nq, int d) {
     const int nq_pad = (nq + FM_QT - 1) / FM_QT * FM_QT;
     return (size_t)(nq_pad / 32) * fm_mt_bytes(d);
@@ -368,7 +409,7 @@ void launch_flat_filter(hipStream_t s, bool l2, int d, const void* qimage, const
     a.row_base = row_base;
     a.pairs = static_cast<uint2*>(pairs);
     a.npairs = npairs;
-    a.cap = (int)std::min<int64_t>(cap, INT32_MAX);
+    a.cap = (int)std::min<int64_t>(cap / FM_NSUB, INT32_MAX);   // per segment
 #define GH_FILT(DD)                                   \
     do {                                              \
         if (l2) launch_filter_t<true, DD>(s, a);      \
@@ -391,7 +432,7 @@ void launch_flat_exact(hipStream_t s, bool l2, const void* pairs, const int* npa
     const int use_filter = (filt.del_bitmap || filt.has_range || filt.n_field > 0 || filt.n_term > 0 || filt.vid2doc) ? 1 : 0;
     const dim3 grid(1024);
     const uint2* pp = static_cast<const uint2*>(pairs);
-    const int icap = (int)std::min<int64_t>(cap, INT32_MAX);
+    const int icap = (int)std::min<int64_t>(cap / FM_NSUB, INT32_MAX);   // per segment
     if (l2)
         hipLaunchKernelGGL((k_flat_exact<true>), grid, dim3(256), 0, s, pp, npairs, icap, x, d, store, filt, use_filter, min_score,
                            max_score, em, overflow);

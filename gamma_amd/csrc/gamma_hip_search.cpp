@@ -1372,16 +1372,16 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
             GH_CHECK(h, h->w_xn.ensure((size_t)nc * sizeof(float)));
             GH_CHECK(h, h->w_fq.ensure(gh::flat_filter_query_image_bytes(nc, d)));
             GH_CHECK(h, h->w_fraw.ensure((size_t)pcap * 8));
-            GH_CHECK(h, h->w_frcnt.ensure(64 + gh::flat_filter_bounds_bytes(nc)));   // pair count | bounds
+            GH_CHECK(h, h->w_frcnt.ensure(gh::flat_filter_counter_bytes() + gh::flat_filter_bounds_bytes(nc)));   // pair counters | bounds
             npairs = h->w_frcnt.as<int>();
-            bnd = reinterpret_cast<float*>(h->w_frcnt.as<char>() + 64);
+            bnd = reinterpret_cast<float*>(h->w_frcnt.as<char>() + gh::flat_filter_counter_bytes());
             gh::launch_row_norms(s, xq, nc, d, h->w_xn.as<float>());
             gh::launch_flat_prep_queries(s, xq, nc, d, h->w_fq.p);
         }
         for (int64_t r = rows_chunk; r < N;) {
             const int64_t nr = pass_rows(r);
             if (mf) {
-                GH_CHECK(h, hipMemsetAsync(npairs, 0, sizeof(int), s));
+                GH_CHECK(h, hipMemsetAsync(npairs, 0, (size_t)gh::flat_filter_counter_bytes(), s));
                 gh::launch_flat_filter(s, l2, d, h->w_fq.p, h->w_xn.as<float>(), tau, bnd, nc, h->d_raw + r * d, nr, r,
                                        h->w_fraw.p, npairs, pcap);
                 gh::launch_flat_exact(s, l2, h->w_fraw.p, npairs, pcap, xq, nc, d, h->d_raw, filt, p->min_score, p->max_score,

@@ -108,6 +108,7 @@ void launch_row_norms(hipStream_t s, const float* y, int64_t n, int d, float* ou
 // distances -- appends to the FlatEmit lists exactly the items launch_pairwise_emit would append.
 bool flat_filter_supported(int nq, int d, int64_t ny);
 int64_t flat_filter_pair_cap(int nq);
+int flat_filter_counter_bytes();   // the pair list's counters (one per segment, a cache line apart): zeroed before a pass
 size_t flat_filter_query_image_bytes(int nq, int d);
 void launch_flat_prep_queries(hipStream_t s, const float* x, int nq, int d, void* image);
 size_t flat_filter_bounds_bytes(int nq);
