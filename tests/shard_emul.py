@@ -3,7 +3,11 @@ exchanges done by tensor indexing: coarse per query slice, shard scans, merge + 
 tie phase (include/gamma_hip.h, "exact ties across list shards"): the owner lists the queries a tie can change
 (gamma_hip_ivfpq_merge_flagged), every shard exports their candidate streams over the lists it owns
 (gamma_hip_ivfpq_shard_export), the owner assembles and replays them (gamma_hip_ivfpq_merge_replay).
-Shared by tests/test_gpu_ties.py and tests/test_gpu_dist.py."""
+Shared by tests/test_gpu_ties.py, tests/test_gpu_dist.py and the shard fuzz.
+Several handles = several streams, and torch's own: every tensor torch fills or copies is complete (torch.cuda.synchronize)
+before a handle's kernels are enqueued on it, every handle call is synchronised before torch or another handle reads its
+output -- without the first half a zero fill could land AFTER the shard scan it was meant to precede (seen under load:
+six test processes on one GPU)."""
 import torch
 
 from gamma_amd import dist as gdist
@@ -25,6 +29,7 @@ def sharded_search_emulated(shards, x, k, args, use_shard_flags=True):
         q0, q1, _ = sl[s]
         cdis = torch.zeros((max(1, q1 - q0), P), dtype=torch.float32, device=dev)
         probe = torch.full((max(1, q1 - q0), P), -1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
         if q1 > q0:
             backs[s].coarse(x[q0:q1].contiguous(), args, cdis, probe)
             shards[s].synchronize()
@@ -32,11 +37,13 @@ def sharded_search_emulated(shards, x, k, args, use_shard_flags=True):
         pr_parts.append(probe[:q1 - q0])
     cd_all = torch.cat(cd_parts).contiguous()      # the assignment in query order: what the all-gather delivers
     pr_all = torch.cat(pr_parts).contiguous()
+    torch.cuda.synchronize()
     rd, ri, cf_ = [], [], []
     for s in range(W):
         rdis = torch.zeros((nq, R), dtype=torch.float32, device=dev)
         rids = torch.full((nq, R), -1, dtype=torch.int64, device=dev)
         cutf = torch.zeros((nq,), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
         backs[s].search_shard(x, cd_all, pr_all, k, args, rdis, rids)
         backs[s].shard_cut_flags(nq, cutf)
         shards[s].synchronize()
@@ -56,8 +63,9 @@ def sharded_search_emulated(shards, x, k, args, use_shard_flags=True):
         xs = x[q0:q1].contiguous()
         Dr = torch.zeros((nql, k), dtype=torch.float32, device=dev)
         Ir = torch.full((nql, k), -1, dtype=torch.int64, device=dev)
+        cut_all = torch.stack([cf_[s][q0:q1] for s in range(W)]).contiguous() if use_shard_flags else None
+        torch.cuda.synchronize()
         if use_shard_flags:   # (without: every table that ends at the cut value counts as a tie)
-            cut_all = torch.stack([cf_[s][q0:q1] for s in range(W)]).contiguous()
             shards[r].ivfpq_merge_set_shard_flags(cut_all.data_ptr())
         shards[r].ivfpq_merge_rerank(W, nql, xs.data_ptr(), k, args, all_dis.data_ptr(), all_ids.data_ptr(), 0, nql,
                                      Dr.data_ptr(), Ir.data_ptr())
@@ -69,6 +77,7 @@ def sharded_search_emulated(shards, x, k, args, use_shard_flags=True):
             pf = torch.empty((nf, P), dtype=torch.int32, device=dev)
             cds = cd_all[q0:q1].contiguous()
             prs = pr_all[q0:q1].contiguous()
+            torch.cuda.synchronize()
             shards[r].gather_rows(xs.data_ptr(), d, d_list, nf, xf.data_ptr())
             shards[r].gather_rows(cds.data_ptr(), P, d_list, nf, cf.data_ptr())
             shards[r].gather_rows(prs.data_ptr(), P, d_list, nf, pf.data_ptr())

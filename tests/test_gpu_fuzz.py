@@ -235,3 +235,78 @@ def test_random_ivfflat_configuration(seed):
         assert g.ties_not_honoured() == 0
     finally:
         g.close()
+
+
+_SHARD_SEEDS = list(range(8))
+if os.environ.get("GAMMA_SHARD_FUZZ_SEEDS"):
+    _a, _b = os.environ["GAMMA_SHARD_FUZZ_SEEDS"].split(":")
+    _SHARD_SEEDS = list(range(int(_a), int(_b)))
+
+
+@pytest.mark.parametrize("seed", _SHARD_SEEDS)
+def test_random_list_shard_configuration(seed):
+    """The list-sharded search (what gamma_amd.dist / gamma_hip_group drive across GPUs) emulated on one GPU through the C ABI
+    (tests/shard_emul.py: coarse per query slice, shard scans over the compacted assignment, merge + re-rank at the owner,
+    the tie phase): random list counts, shard counts 2..8, probes, short-lists, batch sizes on both sides of the 4096-query
+    paths, tie-heavy or SIFT-shaped data, now and then a workspace budget that cuts the shard call into chunks (stride
+    measured on the device, cut flags gathered).  Results are the single-index oracle's, labels at every rank."""
+    import torch
+    from gamma_amd import dist as gdist
+    from tests.shard_emul import sharded_search_emulated
+    rng = np.random.default_rng(88000 + seed)
+    d = int(rng.choice([16, 32, 64]))
+    M = int(rng.choice([4, 8]))
+    nlist = int(rng.choice([16, 64, 200]))
+    N = int(rng.choice([4000, 20000, 50000]))
+    W = int(rng.choice([2, 3, 4, 8]))
+    nq = int(rng.choice([5, 60, 700, 4300]))
+    P = int(min(nlist, rng.choice([1, 4, 16, 48])))
+    R = int(rng.choice([20, 60, 150]))
+    k = int(rng.choice([1, 10, 20]))
+    metric = int(rng.choice([B.METRIC_L2, B.METRIC_IP]))
+    has_rank = bool(rng.random() < 0.8)
+    if rng.random() < 0.5:
+        hi = int(rng.choice([3, 8]))
+        base = rng.integers(0, hi, size=(N, d)).astype(np.float32)
+        q1 = rng.integers(0, hi, size=(min(nq, 64), d)).astype(np.float32)
+    else:
+        base = synth.sift_like(N, d=d, seed=500 + seed)
+        q1 = synth.sift_like(min(nq, 64), d=d, seed=600 + seed)
+    cc, pq = train.train_ivfpq(base[:max(nlist * 40, 3000)], nlist, M, niter=3, pq_niter=3, seed=seed, device="cpu")
+    B.lib().go_set_assign_mode(1)
+    o = B.OracleIVFPQ(d, nlist, M, 8, metric)
+    o.set_trained(cc, pq, None)
+    assert o.add(base)
+    B.lib().go_set_assign_mode(0)
+    o.set_raw(base)
+    reps = (nq + len(q1) - 1) // len(q1)
+    q = np.tile(q1, (reps, 1))[:nq]
+    omode = 1 if nq >= 20 else 0
+    D1, I1 = o.search(q1, k, P, recall_num=R, has_rank=has_rank, metric=metric, ctx=B.make_ctx(**WIDE), coarse_mode=omode)
+    De, Ie = np.tile(D1, (reps, 1))[:nq], np.tile(I1, (reps, 1))[:nq]
+    lists = [o.get_list(l) for l in range(nlist)]
+    sizes = np.array([len(ids) for ids, _ in lists], dtype=np.int64)
+    owner = gdist.balance_lists(sizes, W)
+    shards = []
+    try:
+        for s in range(W):
+            g = api.GammaHip(0)
+            shards.append(g)
+            g.ivfpq_init(d, nlist, M, 8, metric)
+            g.ivfpq_set_trained(cc, pq, None)
+            own = [l for l in range(nlist) if owner[l] == s and sizes[l]]
+            if own:
+                g.add_keys_batch(own, [int(sizes[l]) for l in own], np.concatenate([lists[l][0] for l in own]),
+                                 np.concatenate([lists[l][1] for l in own]))
+            g.set_list_mask((np.asarray(owner) == s).astype(np.uint8))
+            g.raw_init(d)
+            g.raw_append(base)
+            if rng.random() < 0.4:
+                g.set_dist_budget(max(1 << 16, 50 * P * max(1, g.max_list_len()) * 4))
+        x = torch.from_numpy(q).to(torch.device("cuda", 0))
+        args = api.SearchArgs(metric=metric, nprobe=P, recall_num=R, has_rank=has_rank, coarse_mode=omode, **WIDE)
+        D, I, _ = sharded_search_emulated(shards, x, k, args, use_shard_flags=bool(rng.random() < 0.8))
+        compare_exact(De, Ie, D.cpu().numpy(), I.cpu().numpy())
+    finally:
+        for g in shards:
+            g.close()
