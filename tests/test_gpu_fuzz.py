@@ -310,3 +310,66 @@ def test_random_list_shard_configuration(seed):
     finally:
         for g in shards:
             g.close()
+
+
+_GROUP_SEEDS = list(range(6))
+if os.environ.get("GAMMA_GROUP_FUZZ_SEEDS"):
+    _a, _b = os.environ["GAMMA_GROUP_FUZZ_SEEDS"].split(":")
+    _GROUP_SEEDS = list(range(int(_a), int(_b)))
+
+
+@pytest.mark.parametrize("seed", _GROUP_SEEDS)
+def test_random_group_configuration(seed):
+    """gamma_hip_group_* (several handles behind one index object in ONE process: what the plugins' "devices" key builds) on
+    random shapes: 1..5 members (all on the test box's one GPU), sharded or replicated placement, Add through the group, a
+    few searches per configuration (host buffers), tie-heavy or SIFT-shaped data.  Results are the single-index oracle's."""
+    rng = np.random.default_rng(99000 + seed)
+    d = int(rng.choice([16, 32, 64]))
+    M = int(rng.choice([4, 8]))
+    nlist = int(rng.choice([16, 64, 150]))
+    N = int(rng.choice([3000, 12000, 30000]))
+    W = int(rng.choice([1, 2, 3, 5]))
+    replicate = bool(rng.random() < 0.3)
+    metric = int(rng.choice([B.METRIC_L2, B.METRIC_IP]))
+    if rng.random() < 0.5:
+        hi = int(rng.choice([3, 8]))
+        base = rng.integers(0, hi, size=(N, d)).astype(np.float32)
+        qpool = rng.integers(0, hi, size=(64, d)).astype(np.float32)
+    else:
+        base = synth.sift_like(N, d=d, seed=520 + seed)
+        qpool = synth.sift_like(64, d=d, seed=620 + seed)
+    cc, pq = train.train_ivfpq(base[:max(nlist * 40, 3000)], nlist, M, niter=3, pq_niter=3, seed=seed, device="cpu")
+    B.lib().go_set_assign_mode(1)
+    o = B.OracleIVFPQ(d, nlist, M, 8, metric)
+    o.set_trained(cc, pq, None)
+    assert o.add(base)
+    B.lib().go_set_assign_mode(0)
+    o.set_raw(base)
+    grp = api.GammaHipGroup([0] * W)
+    try:
+        if replicate:
+            grp.set_placement(True)
+        for m in grp.members:
+            m.ivfpq_init(d, nlist, M, 8, metric, 1000)
+            m.ivfpq_set_trained(cc, pq, None)
+            m.raw_init(d)
+            m.raw_append(base)
+        grp.set_owners(None)
+        step = int(rng.choice([2500, 7000, 40000]))
+        for i0 in range(0, N, step):
+            grp.add(base[i0:i0 + step], i0)
+        for _ in range(3):
+            nq = int(rng.choice([1, 6, 40, 300]))
+            P = int(min(nlist, rng.choice([1, 4, 16, 40])))
+            R = int(rng.choice([20, 60, 150]))
+            k = int(rng.choice([1, 10, 20]))
+            has_rank = bool(rng.random() < 0.8)
+            reps = (nq + 63) // 64
+            q = np.tile(qpool, (reps, 1))[:nq]
+            om = 1 if nq >= 20 else 0
+            D, I = o.search(q, k, P, recall_num=R, has_rank=has_rank, metric=metric, ctx=B.make_ctx(**WIDE), coarse_mode=om)
+            a = api.SearchArgs(metric=metric, nprobe=P, recall_num=R, has_rank=has_rank, **WIDE)
+            Dg, Ig = grp.ivfpq_search(q, k, a)
+            compare_exact(D, I, Dg, Ig)
+    finally:
+        grp.close()
