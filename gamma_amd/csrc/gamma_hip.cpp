@@ -107,6 +107,9 @@ int gamma_hip_destroy(gamma_hip_index* h) {
         h->vm_codes.release();
         h->vm_ids.release();
         h->vm_sums.release();
+        h->alt_codes.release();
+        h->alt_ids.release();
+        h->alt_sums.release();
         h->d_codes = nullptr;
         h->d_ids = nullptr;
         h->d_sums = nullptr;

@@ -87,6 +87,8 @@ struct VmRange {
     // step and nothing of the failed step stays mapped.
     hipError_t map_to(size_t bytes, const char** what);
     void release();
+    // the physical memory goes back, the address range stays reserved (mapped = 0)
+    void unmap_all();
 };
 
 struct gamma_hip_index {
@@ -217,6 +219,7 @@ struct gamma_hip_index {
     // the same reason, realtime/realtime_mem_data.cc:152-188,426-474).  Fallback: reallocation under the exclusive lock.
     bool arena_vmm = false;
     VmRange vm_codes, vm_ids, vm_sums;
+    VmRange alt_codes, alt_ids, alt_sums;   // the repack's target set (the two sets swap roles; see arena_repack)
     int64_t arena_regrows = 0;   // growths that moved the arena (0 with virtual memory management)
     int64_t repack_min_entries = 1 << 16;                     // no repack for less waste than this
     int64_t n_repacks = 0;

@@ -85,6 +85,29 @@ hipError_t VmRange::map_to(size_t bytes, const char** what) {
     *what = "";
     return hipSuccess;
 }
+// An address that was unmapped and is mapped again (to other physical memory) read back stale contents -- zeros -- now and then
+// on this runtime when the GPU was shared with other processes (tests/test_gpu_fuzz.py::test_random_realtime_script under six
+// processes: 10-18 % of the scripts, whether the range was freed and reserved again or merely unmapped and remapped;
+// hipDeviceSynchronize does not help).  An ordinary allocation and release by the runtime in between does (0 of 400): it goes
+// through the driver's page-table path and leaves no stale translation behind.  Every unmap ends with one.
+static void vm_unmap_fence() {
+    void* t = nullptr;
+    if (hipMalloc(&t, (size_t)64 << 20) == hipSuccess) (void)hipFree(t);
+    else (void)hipGetLastError();
+}
+void VmRange::unmap_all() {
+    if (!base) return;
+    size_t off = 0;
+    for (size_t i = 0; i < chunks.size(); i++) {
+        (void)hipMemUnmap(base + off, chunk_bytes[i]);
+        (void)hipMemRelease(chunks[i]);
+        off += chunk_bytes[i];
+    }
+    if (!chunks.empty()) vm_unmap_fence();
+    chunks.clear();
+    chunk_bytes.clear();
+    mapped = 0;
+}
 void VmRange::release() {
     if (!base) return;
     size_t off = 0;
@@ -93,6 +116,7 @@ void VmRange::release() {
         (void)hipMemRelease(chunks[i]);
         off += chunk_bytes[i];
     }
+    if (!chunks.empty()) vm_unmap_fence();
     (void)hipMemAddressFree(base, va_bytes);
     chunks.clear();
     chunk_bytes.clear();
@@ -227,33 +251,37 @@ int arena_repack(H* h) {
     float* ns = nullptr;
     if (h->wl) GH_CHECK(h, h->wl->exclusive());   // every list moves and the old arrays are freed
     GH_TRY(publish_meta(h));                      // the device tables the kernel below reads = the host mirror
-    VmRange vc, vi, vs;
-    struct VmGuard {   // an error below gives the fresh ranges back
-        VmRange *a, *b, *c;
+    // Mapped arena: the handle keeps TWO sets of address ranges and the repack moves the lists from the set in use into the
+    // other one (physical chunks mapped there for the occasion), gives the old set's physical memory back and swaps the roles.
+    // (two persistent sets: address space stays bounded; what makes the re-mapping of the idle set's addresses safe is the
+    //  fence every unmap ends with -- VmRange::unmap_all)
+    struct AltGuard {   // an error below gives the target set's physical memory back
+        H* h;
         bool armed = true;
-        ~VmGuard() {
+        ~AltGuard() {
             if (armed) {
-                a->release();
-                b->release();
-                c->release();
+                h->alt_codes.unmap_all();
+                h->alt_ids.unmap_all();
+                h->alt_sums.unmap_all();
             }
         }
-    } vm_guard{&vc, &vi, &vs};
-    if (h->arena_vmm) {   // a fresh set of mapped ranges, tight
+    } alt_guard{h, h->arena_vmm};
+    if (h->arena_vmm) {
         const size_t chunk = (size_t)8 << 20;
         const char* what = "";
         hipError_t e = hipSuccess;
-        if (!vc.reserve(h->device, chunk) || !vi.reserve(h->device, chunk) || (h->keep_sums && !vs.reserve(h->device, chunk))) {
+        if ((!h->alt_codes.on() && !h->alt_codes.reserve(h->device, chunk)) || (!h->alt_ids.on() && !h->alt_ids.reserve(h->device, chunk)) ||
+            (h->keep_sums && !h->alt_sums.on() && !h->alt_sums.reserve(h->device, chunk))) {
             e = hipErrorOutOfMemory;
             what = "address range";
         }
-        if (e == hipSuccess) e = vc.map_to((size_t)ncap * h->code_size, &what);
-        if (e == hipSuccess) e = vi.map_to((size_t)ncap * sizeof(int64_t), &what);
-        if (e == hipSuccess && h->keep_sums) e = vs.map_to((size_t)ncap * sizeof(float), &what);
+        if (e == hipSuccess) e = h->alt_codes.map_to((size_t)ncap * h->code_size, &what);
+        if (e == hipSuccess) e = h->alt_ids.map_to((size_t)ncap * sizeof(int64_t), &what);
+        if (e == hipSuccess && h->keep_sums) e = h->alt_sums.map_to((size_t)ncap * sizeof(float), &what);
         if (e != hipSuccess) return vm_fail(h, "arena repack", e, what);
-        nc = reinterpret_cast<uint8_t*>(vc.base);
-        ni = reinterpret_cast<int64_t*>(vi.base);
-        ns = h->keep_sums ? reinterpret_cast<float*>(vs.base) : nullptr;
+        nc = reinterpret_cast<uint8_t*>(h->alt_codes.base);
+        ni = reinterpret_cast<int64_t*>(h->alt_ids.base);
+        ns = h->keep_sums ? reinterpret_cast<float*>(h->alt_sums.base) : nullptr;
     } else {
         GH_CHECK(h, hipMalloc((void**)&nc, (size_t)ncap * h->code_size));
         if (hipMalloc((void**)&ni, (size_t)ncap * sizeof(int64_t)) != hipSuccess) {
@@ -272,13 +300,13 @@ int arena_repack(H* h) {
                             h->d_list_len, h->nlist, h->code_size, h->max_list_len);
     GH_CHECK(h, hipStreamSynchronize(h->wstream));   // noff is a local; the old arrays are free to go
     if (h->arena_vmm) {
-        h->vm_codes.release();
-        h->vm_ids.release();
-        h->vm_sums.release();
-        vm_guard.armed = false;   // the handle owns them from here
-        h->vm_codes = std::move(vc);
-        h->vm_ids = std::move(vi);
-        h->vm_sums = std::move(vs);
+        alt_guard.armed = false;   // the target set is the arena from here
+        h->vm_codes.unmap_all();
+        h->vm_ids.unmap_all();
+        h->vm_sums.unmap_all();
+        std::swap(h->vm_codes, h->alt_codes);
+        std::swap(h->vm_ids, h->alt_ids);
+        std::swap(h->vm_sums, h->alt_sums);
         arena_vm_adopt(h);
     } else {
         GH_CHECK(h, hipFree(h->d_codes));

@@ -373,3 +373,90 @@ def test_random_group_configuration(seed):
             compare_exact(D, I, Dg, Ig)
     finally:
         grp.close()
+
+
+_RT_SEEDS = list(range(6))
+if os.environ.get("GAMMA_RT_FUZZ_SEEDS"):
+    _a, _b = os.environ["GAMMA_RT_FUZZ_SEEDS"].split(":")
+    _RT_SEEDS = list(range(int(_a), int(_b)))
+
+
+@pytest.mark.parametrize("seed", _RT_SEEDS)
+def test_random_realtime_script(seed):
+    """The realtime inverted lists (realtime/realtime_mem_data.cc: AddKeys, Update = mark + append, Delete, ExtendBucket's growth
+    law, CompactIfNeed) under random scripts on tiny buckets -- lists grow many times (extents abandoned inside the mapped
+    arena, repacks when half of it is waste), entries move between lists, deleted ones are compacted away.  After every few
+    operations the lists' contents and capacities equal the oracle's (itself pinned on the compiled reference:
+    tests/golden/realtime.npz) and a search returns the oracle's labels."""
+    rng = np.random.default_rng(123000 + seed)
+    d, M = 16, 4
+    nlist = int(rng.choice([4, 16, 40]))
+    binit = int(rng.choice([4, 16, 100]))
+    nvec = int(rng.choice([2000, 8000]))
+    base = rng.integers(0, 6, size=(nvec, d)).astype(np.float32)
+    cc, pq = train.train_ivfpq(base[:max(nlist * 40, 1000)], nlist, M, niter=3, pq_niter=3, seed=seed, device="cpu")
+    o = B.OracleIVFPQ(d, nlist, M, 8, B.METRIC_L2, bucket_init_size=binit)
+    o.set_trained(cc, pq, None)
+    o.set_raw(base)
+    nbits = nvec + 64
+    bm = np.zeros(nbits // 8 + 1, dtype=np.uint8)
+    o.set_docids_bitmap(bm)
+    g = api.GammaHip(0)
+    try:
+        g.ivfpq_init(d, nlist, M, 8, api.METRIC_L2, binit)
+        g.ivfpq_set_trained(cc, pq, None)
+        g.raw_init(d)
+        g.raw_append(base)
+        g.bitmap_upload(bm, nbits)
+        thr = int(rng.choice([1, 64, 1 << 30]))
+        if os.environ.get("GAMMA_RT_FUZZ_REPACK"):      # (debugging aid: force the threshold)
+            thr = int(os.environ["GAMMA_RT_FUZZ_REPACK"])
+        g.set_repack_threshold(thr)
+        lno, codes = o.encode(base)
+        lno = np.where((lno < 0) | (lno >= nlist), np.arange(nvec) % nlist, lno)
+        next_vid, live = 0, []
+        q = base[rng.choice(nvec, 16, replace=False)] + 0.25
+        for step in range(int(rng.choice([30, 80]))):
+            op = rng.random()
+            if op < 0.5 and next_vid < nvec:           # AddKeys: a run of consecutive vids that share a list
+                l = int(lno[next_vid])
+                n = 1
+                while next_vid + n < nvec and n < 200 and lno[next_vid + n] == l:
+                    n += 1
+                n = int(min(n, rng.integers(1, 60)))
+                keys = np.arange(next_vid, next_vid + n, dtype=np.int64)
+                assert o.add_keys(l, keys, codes[next_vid:next_vid + n])
+                g.add_keys(l, keys, codes[next_vid:next_vid + n])
+                live.extend(range(next_vid, next_vid + n))
+                next_vid += n
+            elif op < 0.7 and live:                    # Update: the entry moves (or stays) with a new code
+                vid = int(rng.choice(live))
+                newl = int(rng.integers(0, nlist))
+                code = rng.integers(0, 256, size=M).astype(np.uint8)
+                o.update_code(newl, vid, code)
+                g.update(newl, vid, code)
+            elif op < 0.9 and live:                    # Delete a few documents
+                dead = rng.choice(live, size=min(len(live), int(rng.integers(1, 40))), replace=False).astype(np.int64)
+                np.bitwise_or.at(bm, dead >> 3, (1 << (dead & 7)).astype(np.uint8))
+                g.bitmap_set(dead, 1)
+                o.delete(dead)
+                g.delete(dead)
+                dead_set = set(int(v) for v in dead)
+                live = [v for v in live if v not in dead_set]
+            else:
+                o.compact_if_need(bm)
+                g.compact_if_need()
+            if step % 7 == 6:
+                for l in range(nlist):
+                    io, co = o.get_list(l)
+                    ig, cg = g.get_list(l)
+                    assert np.array_equal(io, ig) and np.array_equal(co, cg), (step, l)
+                    assert o.list_capacity(l) == g.list_capacity(l), (step, l)
+                P = int(min(nlist, 4))
+                ctx = B.make_ctx(docids_bitmap=bm, **WIDE)
+                D, I = o.search(q, 5, P, recall_num=30, has_rank=True, metric=B.METRIC_L2, ctx=ctx, coarse_mode=0)
+                Dg, Ig = g.ivfpq_search(q, 5, api.SearchArgs(metric=api.METRIC_L2, nprobe=P, recall_num=30, has_rank=True,
+                                                              coarse_mode=0, **WIDE))
+                compare_exact(D, I, Dg, Ig)
+    finally:
+        g.close()
