@@ -216,3 +216,92 @@ def test_list_arena_grows_in_place_under_search(mapped, monkeypatch):
         compare_exact(Do, Io, D, I)
     finally:
         g.close()
+
+
+def test_searches_stay_exact_while_everything_else_moves():
+    """The retrieval contract under stress (Search from any number of threads beside ONE indexing thread): three
+    searcher threads (single queries, small and large batches, device chains of every kind) keep getting the oracle's answer
+    over a fixed set of vectors while the writer thread adds far-away vectors (lists grow: extents move, the mapped arena
+    grows), moves them between lists (Update), deletes them, compacts, and -- repack threshold 1 -- has the whole arena moved
+    to the other set of address ranges again and again under the exclusive lock.  The searches carry a range filter that
+    admits exactly the fixed set (tie-free data), so nothing the writer does may change an answer."""
+    import threading
+    d, nlist, M, nbase, nnoise = 32, 32, 8, 6000, 30000
+    rng = np.random.default_rng(2024)
+    base = rng.standard_normal((nbase, d)).astype(np.float32)
+    noise = (rng.standard_normal((nnoise, d)) * 0.5 + 60.0).astype(np.float32)          # far from every query
+    cc, pq = train.train_ivfpq(base[:4000], nlist, M, niter=4, pq_niter=4, seed=3, device="cpu")
+    B.lib().go_set_assign_mode(1)
+    o = B.OracleIVFPQ(d, nlist, M, 8, B.METRIC_L2, bucket_init_size=16)
+    o.set_trained(cc, pq, None)
+    assert o.add(base)
+    B.lib().go_set_assign_mode(0)
+    o.set_raw(base)
+    allx = np.concatenate([base, noise])
+    g = api.GammaHip(0)
+    try:
+        g.ivfpq_init(d, nlist, M, 8, api.METRIC_L2, 16)                 # tiny buckets: constant growth
+        g.ivfpq_set_trained(cc, pq, None)
+        g.raw_init(d)
+        g.raw_append(allx)
+        g.add(base, 0)
+        nbits = nbase + nnoise + 64
+        g.bitmap_upload(np.zeros(nbits // 8 + 1, np.uint8), nbits)
+        g.set_repack_threshold(1)
+        ctx = B.make_ctx(**WIDE)
+        jobs = []
+        for nq, P, R, k in ((1, nlist, 50, 10), (7, nlist, 64, 5), (300, nlist, 100, 10), (4200, nlist, 40, 3)):
+            q = rng.standard_normal((nq, d)).astype(np.float32)
+            mode = 1 if nq >= 20 else 0
+            D, I = o.search(q, k, P, recall_num=R, has_rank=True, metric=B.METRIC_L2, ctx=ctx, coarse_mode=mode)
+            # (a range filter that admits exactly the fixed set: the far-away entries' PQ codes decode to ordinary points --
+            #  a product quantizer cannot represent an outlier -- and would crowd the short-list otherwise)
+            jobs.append((q, k, api.SearchArgs(metric=api.METRIC_L2, nprobe=P, recall_num=R, has_rank=True,
+                                              range_filters=[api.make_range_filter(np.arange(nbase, dtype=np.int64))], **WIDE), D, I))
+        stop, bad, calls = threading.Event(), [], [0, 0, 0]
+
+        def searcher(slot):
+            i = slot
+            while not stop.is_set():
+                q, k, a, D, I = jobs[i % len(jobs)]
+                Dg, Ig = g.ivfpq_search(q, k, a)
+                if Dg.tobytes() != D.tobytes() or not np.array_equal(Ig, I):
+                    rows = np.nonzero((Ig != I).any(axis=1) | (Dg != D).any(axis=1))[0]
+                    r0 = int(rows[0]) if len(rows) else -1
+                    bad.append((slot, i % len(jobs), len(rows), r0, I[r0].tolist(), Ig[r0].tolist(), D[r0].tolist(), Dg[r0].tolist()))
+                    stop.set()
+                calls[slot] += 1
+                i += 1
+
+        th = [threading.Thread(target=searcher, args=(s,)) for s in range(3)]
+        for t in th:
+            t.start()
+        try:
+            lno, codes = g.encode(noise)
+            lno = np.where((lno < 0) | (lno >= nlist), np.arange(nnoise) % nlist, lno)
+            added = 0
+            t_end = time.time() + 4.0
+            wr = np.random.default_rng(7)
+            while time.time() < t_end and not stop.is_set():
+                op = wr.random()
+                if op < 0.45 and added < nnoise:
+                    n = int(min(nnoise - added, wr.integers(50, 1500)))
+                    g.add(noise[added:added + n], nbase + added)
+                    added += n
+                elif op < 0.65 and added:
+                    j = int(wr.integers(0, added))     # (its own code: far in every list -- a random code could decode near a query)
+                    g.update(int(wr.integers(0, nlist)), nbase + j, codes[j])
+                elif op < 0.85 and added:
+                    dead = (nbase + wr.integers(0, added, size=int(wr.integers(1, 200)))).astype(np.int64)
+                    g.bitmap_set(dead, 1)
+                    g.delete(dead)
+                else:
+                    g.compact_if_need()
+        finally:
+            stop.set()
+            for t in th:
+                t.join()
+        assert not bad, bad
+        assert min(calls) > 3 and g.arena_stats()["repacks"] > 0, (calls, g.arena_stats())
+    finally:
+        g.close()
