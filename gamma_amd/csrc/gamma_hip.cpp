@@ -110,6 +110,7 @@ int gamma_hip_destroy(gamma_hip_index* h) {
         h->alt_codes.release();
         h->alt_ids.release();
         h->alt_sums.release();
+        for (auto& r : h->vm_retired) r.release();
         h->d_codes = nullptr;
         h->d_ids = nullptr;
         h->d_sums = nullptr;

@@ -80,6 +80,7 @@ struct VmRange {
     int device = 0;
     std::vector<hipMemGenericAllocationHandle_t> chunks;
     std::vector<size_t> chunk_bytes;
+    bool tainted = false;   // unmapped without the fence (unmap_all): must not be mapped again
     bool on() const { return base != nullptr; }
     // false: the runtime does not offer it (nothing is left behind)
     bool reserve(int device_, size_t chunk_min);
@@ -220,6 +221,7 @@ struct gamma_hip_index {
     bool arena_vmm = false;
     VmRange vm_codes, vm_ids, vm_sums;
     VmRange alt_codes, alt_ids, alt_sums;   // the repack's target set (the two sets swap roles; see arena_repack)
+    std::vector<VmRange> vm_retired;        // ranges that may not be mapped again (address space only; freed with the handle)
     int64_t arena_regrows = 0;   // growths that moved the arena (0 with virtual memory management)
     int64_t repack_min_entries = 1 << 16;                     // no repack for less waste than this
     int64_t n_repacks = 0;

@@ -90,10 +90,18 @@ hipError_t VmRange::map_to(size_t bytes, const char** what) {
 // processes: 10-18 % of the scripts, whether the range was freed and reserved again or merely unmapped and remapped;
 // hipDeviceSynchronize does not help).  An ordinary allocation and release by the runtime in between does (0 of 400): it goes
 // through the driver's page-table path and leaves no stale translation behind.  Every unmap ends with one.
-static void vm_unmap_fence() {
+static bool vm_unmap_fence() {
+    // (the runtime serves allocations below 2 MB from blocks it keeps: 1 MB and 4 KB fences changed nothing, 2 / 4 / 16 / 64 MB
+    //  all cured it -- 0 of 600 scripts each)
     void* t = nullptr;
-    if (hipMalloc(&t, (size_t)64 << 20) == hipSuccess) (void)hipFree(t);
-    else (void)hipGetLastError();
+    for (size_t bytes : {(size_t)16 << 20, (size_t)2 << 20}) {
+        if (hipMalloc(&t, bytes) == hipSuccess) {
+            (void)hipFree(t);
+            return true;
+        }
+        (void)hipGetLastError();
+    }
+    return false;   // the device is out of memory: the caller must not map these addresses again
 }
 void VmRange::unmap_all() {
     if (!base) return;
@@ -103,7 +111,7 @@ void VmRange::unmap_all() {
         (void)hipMemRelease(chunks[i]);
         off += chunk_bytes[i];
     }
-    if (!chunks.empty()) vm_unmap_fence();
+    if (!chunks.empty() && !vm_unmap_fence()) tainted = true;
     chunks.clear();
     chunk_bytes.clear();
     mapped = 0;
@@ -116,7 +124,7 @@ void VmRange::release() {
         (void)hipMemRelease(chunks[i]);
         off += chunk_bytes[i];
     }
-    if (!chunks.empty()) vm_unmap_fence();
+    if (!chunks.empty()) (void)vm_unmap_fence();
     (void)hipMemAddressFree(base, va_bytes);
     chunks.clear();
     chunk_bytes.clear();
@@ -267,6 +275,11 @@ int arena_repack(H* h) {
         }
     } alt_guard{h, h->arena_vmm};
     if (h->arena_vmm) {
+        for (VmRange* r : {&h->alt_codes, &h->alt_ids, &h->alt_sums})
+            if (r->tainted) {   // unmapped without a fence (the device was out of memory): these addresses are not mapped again
+                h->vm_retired.push_back(std::move(*r));
+                *r = VmRange();
+            }
         const size_t chunk = (size_t)8 << 20;
         const char* what = "";
         hipError_t e = hipSuccess;
