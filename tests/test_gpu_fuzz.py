@@ -460,3 +460,86 @@ def test_random_realtime_script(seed):
                 compare_exact(D, I, Dg, Ig)
     finally:
         g.close()
+
+
+_PLUGIN_SEEDS = list(range(5))
+if os.environ.get("GAMMA_PLUGIN_FUZZ_SEEDS"):
+    _a, _b = os.environ["GAMMA_PLUGIN_FUZZ_SEEDS"].split(":")
+    _PLUGIN_SEEDS = list(range(int(_a), int(_b)))
+
+
+@pytest.mark.parametrize("seed", _PLUGIN_SEEDS)
+def test_random_plugin_script(seed):
+    """The HIPIVFPQ RetrievalModel behind the reference's plugin boundary (host/gamma_index_ivfpq_hip.cc through the ctypes
+    harness): random model parameters, Add in engine-sized batches, a random script of Search (model defaults / request
+    parameters / brute force), Delete and Update; every Search equals the oracle's on the same state -- labels at every rank."""
+    from gamma_amd import plugin
+    rng = np.random.default_rng(140000 + seed)
+    d = int(rng.choice([16, 32, 64]))
+    M = int(rng.choice([4, 8]))
+    nlist = int(rng.choice([16, 64, 128]))
+    N = int(rng.choice([4000, 15000]))
+    mname, metric = [("L2", B.METRIC_L2), ("InnerProduct", B.METRIC_IP)][int(rng.integers(0, 2))]
+    P0 = int(min(nlist, rng.choice([4, 16, 40])))
+    if rng.random() < 0.5:
+        hi = int(rng.choice([3, 8]))
+        base = rng.integers(0, hi, size=(N, d)).astype(np.float32)
+        qpool = rng.integers(0, hi, size=(64, d)).astype(np.float32)
+    else:
+        base = synth.sift_like(N, d=d, seed=900 + seed)
+        qpool = synth.sift_like(64, d=d, seed=950 + seed)
+    cc, pq = train.train_ivfpq(base[:max(nlist * 40, 3000)], nlist, M, niter=3, pq_niter=3, seed=seed, device="cpu")
+    m = plugin.PluginModel("HIPIVFPQ", d, '{"ncentroids": %d, "nsubvector": %d, "nprobe": %d, "metric_type": "%s"}' % (nlist, M, P0, mname),
+                           indexing_size=5000)
+    o = B.OracleIVFPQ(d, nlist, M, 8, metric)
+    o.set_trained(cc, pq, None)
+    try:
+        m.store(base)
+        assert m.set_trained(cc, pq) == 0
+        B.lib().go_set_assign_mode(1)
+        step = int(rng.choice([1000, 5000]))
+        for i0 in range(0, N, step):
+            assert m.add(base[i0:i0 + step])
+            assert o.add(base[i0:i0 + step])
+        B.lib().go_set_assign_mode(0)
+        raw = base.copy()
+        o.set_raw(raw)
+        bm = np.zeros((N + 7) // 8, np.uint8)
+        o.set_docids_bitmap(bm)
+        for _ in range(int(rng.integers(4, 9))):
+            op = rng.random()
+            if op < 0.6:
+                nq = int(rng.choice([1, 7, 40, 300]))
+                q = np.tile(qpool, ((nq + 63) // 64, 1))[:nq]
+                k = int(rng.choice([1, 10, 20]))
+                has_rank = bool(rng.random() < 0.8)
+                ctx = B.make_ctx(docids_bitmap=bm)
+                if rng.random() < 0.25:
+                    D, I = B.flat_search(raw, q, k, metric, ctx)
+                    Dg, Ig = m.search(q, k, '{"metric_type": "%s"}' % mname, brute_force=True)
+                elif rng.random() < 0.3:
+                    D, I = o.search(q, k, P0, recall_num=100, has_rank=has_rank, metric=metric, ctx=ctx, coarse_mode=-1)
+                    Dg, Ig = m.search(q, k, "", has_rank=has_rank)
+                else:
+                    P = int(min(nlist, rng.choice([1, 8, 30])))
+                    R = int(rng.choice([20, 100, 300]))
+                    D, I = o.search(q, k, P, recall_num=R, has_rank=has_rank, metric=metric, ctx=ctx, coarse_mode=-1)
+                    Dg, Ig = m.search(q, k, '{"metric_type": "%s", "recall_num": %d, "nprobe": %d}' % (mname, R, P), has_rank=has_rank)
+                compare_exact(D, I, Dg, Ig)
+            elif op < 0.8:
+                dead = np.unique(rng.integers(0, N, size=int(rng.integers(1, 60)))).astype(np.int64)
+                assert m.delete(dead) == 0
+                np.bitwise_or.at(bm, dead >> 3, (1 << (dead & 7)).astype(np.uint8))
+                o.delete(dead)
+            else:
+                vid = int(rng.integers(0, N))
+                if (bm[vid >> 3] >> (vid & 7)) & 1:
+                    continue
+                newv = base[int(rng.integers(0, N))].copy()
+                assert m.update(vid, newv) == 0
+                raw[vid] = newv
+                o.set_raw(raw)
+                o.update(vid, newv)
+    finally:
+        B.lib().go_set_assign_mode(0)
+        m.close()
