@@ -543,3 +543,83 @@ def test_random_plugin_script(seed):
     finally:
         B.lib().go_set_assign_mode(0)
         m.close()
+
+
+_LARGE_SEEDS = list(range(4))
+if os.environ.get("GAMMA_LARGE_FUZZ_SEEDS"):
+    _a, _b = os.environ["GAMMA_LARGE_FUZZ_SEEDS"].split(":")
+    _LARGE_SEEDS = list(range(int(_a), int(_b)))
+
+
+@pytest.mark.parametrize("seed", _LARGE_SEEDS)
+def test_random_large_batch_configuration(seed):
+    """IVFPQ at the batch sizes the throughput path runs at (>= 4096 queries: the matrix-free coarse quantizer from 2048 lists
+    on, the bounded scan with its filter pass and feedback, the fused re-rank) on random shapes: 256 .. 4096 lists, up to 300
+    probes (from 100 on the coarse ties go through the reservoir), short-lists up to 3000, k up to 700, tie-heavy or
+    SIFT-shaped data, deletes, a range filter, a score window now and then.  Labels at every rank are the oracle's."""
+    rng = np.random.default_rng(170000 + seed)
+    d = int(rng.choice([32, 64, 128]))
+    M = int(rng.choice([8, 16]))
+    nlist = int(rng.choice([256, 2048, 4096]))
+    N = int(rng.choice([60000, 200000]))
+    metric = B.METRIC_L2 if rng.random() < 0.7 else B.METRIC_IP
+    if rng.random() < 0.4:
+        hi = int(rng.choice([4, 16]))
+        base = rng.integers(0, hi, size=(N, d)).astype(np.float32)
+        qpool = rng.integers(0, hi, size=(384, d)).astype(np.float32)
+    else:
+        base = synth.sift_like(N, d=d, seed=1500 + seed)
+        qpool = synth.sift_like(384, d=d, seed=1600 + seed)
+    cc = base[rng.choice(N, nlist, replace=False)] + (rng.random((nlist, d)) < 0.05).astype(np.float32) * 0.25
+    _, pq = train.train_ivfpq(base[:3000], 16, M, niter=2, pq_niter=3, seed=seed, device="cpu")
+    o = B.OracleIVFPQ(d, nlist, M, 8, metric)
+    o.set_trained(cc, pq, None)
+    g = api.GammaHip(0)
+    try:
+        g.ivfpq_init(d, nlist, M, 8, metric)
+        g.ivfpq_set_trained(cc, pq, None)
+        g.raw_init(d)
+        g.raw_append(base)
+        B.lib().go_set_assign_mode(1)
+        for i0 in range(0, N, 50000):
+            g.add(base[i0:i0 + 50000], i0)
+            assert o.add(base[i0:i0 + 50000])
+        B.lib().go_set_assign_mode(0)
+        o.set_raw(base)
+        ctx_kw, kw_f = {}, {}
+        if rng.random() < 0.4:
+            dead = rng.choice(N, N // 10, replace=False)
+            bm = np.zeros((N >> 3) + 1, dtype=np.uint8)
+            np.bitwise_or.at(bm, dead >> 3, (1 << (dead & 7)).astype(np.uint8))
+            g.bitmap_upload(bm, N)
+            g.delete(dead)
+            o.set_docids_bitmap(bm)
+            o.delete(dead)
+            ctx_kw["docids_bitmap"] = bm
+        if rng.random() < 0.3:
+            docs = rng.choice(N, size=int(N * rng.choice([0.1, 0.6])), replace=False)
+            ctx_kw["range_filters"] = [B.make_range_filter(docs)]
+            kw_f["range_filters"] = [api.make_range_filter(docs)]
+        for _ in range(2):
+            nq = int(rng.choice([4096, 5000, 9000]))
+            P = int(min(nlist, rng.choice([8, 32, 64, 120, 300])))
+            R = int(rng.choice([20, 200, 256, 1024, 3000]))
+            k = int(min(R, rng.choice([1, 10, 100, 700])))
+            has_rank = bool(rng.random() < 0.75)
+            win = WIDE
+            D1, I1, st1 = o.search(qpool, k, P, recall_num=R, has_rank=has_rank, metric=metric, ctx=B.make_ctx(**win, **ctx_kw),
+                                   coarse_mode=1, want_stages=True)
+            if has_rank and rng.random() < 0.25:
+                fin = D1[np.abs(D1) < 1e37]
+                if len(fin) > 10:
+                    win = dict(min_score=float(np.quantile(fin, 0.1)), max_score=float(np.quantile(fin, 0.9)))
+                    D1, I1, st1 = o.search(qpool, k, P, recall_num=R, has_rank=has_rank, metric=metric,
+                                           ctx=B.make_ctx(**win, **ctx_kw), coarse_mode=1, want_stages=True)
+            reps = (nq + len(qpool) - 1) // len(qpool)
+            q = np.tile(qpool, (reps, 1))[:nq]
+            Dg, Ig = g.ivfpq_search(q, k, api.SearchArgs(metric=metric, nprobe=P, recall_num=R, has_rank=has_rank, **win, **kw_f))
+            compare_exact(np.tile(D1, (reps, 1))[:nq], np.tile(I1, (reps, 1))[:nq], Dg, Ig)
+            assert g.ties_not_honoured() == 0
+    finally:
+        B.lib().go_set_assign_mode(0)
+        g.close()
