@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/prof_all.sh <tag> [section ...]   sections: c3 c3nocf c2 c4 c5 ivfflat single pmc (default: all)
+# usage (GPU box, repo root): tools/prof_all.sh <tag> [section ...]   sections: c3 c3default c3nocf c2 c4 c5 ivfflat single pmc (default: all but c3default)
 # rocprofv3 --kernel-trace --stats of EVERY workload a BASELINE configuration times, one summary per workload under
 # gpurun_out/prof_<tag>/ (copy what is to be judged to profiles/): C3 (bench.py, the headline), C2 flat, the C4 shape,
 # the C5 shape, IVFFLAT, the single-query chain; then PMC passes of the C3 scan with and without the filter pass
@@ -50,6 +50,7 @@ except Exception:
   rm -rf $out/raw_$name
 }
 want c3 && stats c3_bench $root/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --recall-queries 0 --no-extra --no-shapes
+want c3default && stats c3_bench_default_command $root/bench.py   # the driver's exact command (every leg of the default run)
 want c3nocf && stats c3_bench_no_filter_pass $root/tools/run_env.py GAMMA_HIP_NO_SCAN_CF=1 $root/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --recall-queries 0 --no-extra --no-shapes
 want c2 && stats c2_flat $root/tools/flat_bench.py
 want c4 && stats c4_shape_8m $root/tools/c4_scale.py 8e6
