@@ -154,6 +154,13 @@ class GammaHip:
         vec = _f32(vec)
         self._ck(self.L.gamma_hip_raw_update(self.h, vid, _p(vec, _lib.f32p)), "raw_update")
 
+    def raw_gets(self, vids):
+        """VectorReader::Gets: rows of the device store by vector id"""
+        vids = np.ascontiguousarray(vids, dtype=np.int64).ravel()
+        out = np.empty((len(vids), self.raw_d), dtype=np.float32)
+        self._ck(self.L.gamma_hip_raw_gets(self.h, len(vids), _p(vids, _lib.i64p), _p(out, _lib.f32p)), "raw_gets")
+        return out
+
     def raw_count(self):
         return self.L.gamma_hip_raw_count(self.h)
 

@@ -747,6 +747,23 @@ int gamma_hip_raw_update_batch(gamma_hip_index* h, int64_t n, const int64_t* vid
     return GAMMA_HIP_OK;
 }
 
+// VectorReader::Gets (vector/raw_vector.cc:99-109 -> MemoryRawVector::GetVector, vector/memory_raw_vector.cc:136-142): rows
+// by vector id, read back from the device store (what compute_dis hands to the exact distance); one wait for n rows
+int gamma_hip_raw_gets(gamma_hip_index* h, int64_t n, const int64_t* vids, float* out) {
+    if (!h || n < 0 || (n > 0 && (!vids || !out))) return GAMMA_HIP_EINVAL;
+    if (n == 0) return GAMMA_HIP_OK;
+    WriteLock lk(h);   // no row is read half written
+    if (h->raw_d <= 0) return fail(h, GAMMA_HIP_EINVAL, "raw store not initialised");
+    for (int64_t i = 0; i < n; i++)
+        if (vids[i] < 0 || vids[i] >= h->nraw) return fail(h, GAMMA_HIP_EINVAL, "vid out of range");
+    GH_CHECK(h, hipSetDevice(h->device));
+    for (int64_t i = 0; i < n; i++)
+        GH_CHECK(h, hipMemcpyAsync(out + i * h->raw_d, h->d_raw + vids[i] * h->raw_d, (size_t)h->raw_d * sizeof(float),
+                                   hipMemcpyDeviceToHost, h->wstream));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    return GAMMA_HIP_OK;
+}
+
 int64_t gamma_hip_raw_count(gamma_hip_index* h) { return h ? h->nraw : -1; }
 
 int gamma_hip_raw_stats(gamma_hip_index* h, int64_t* out4) {

@@ -209,6 +209,9 @@ int gamma_hip_raw_update_batch(gamma_hip_index* h, int64_t n, const int64_t* vid
  * first_vid may not leave a gap (first_vid <= gamma_hip_raw_count).  This is what a mirror of the engine's
  * vector store needs when Search (brute force before training) and the indexing thread's Add race. */
 int gamma_hip_raw_write(gamma_hip_index* h, int64_t first_vid, int64_t n, const float* vecs);
+/* VectorReader::Gets (vector/raw_vector.cc:99-109, vector/memory_raw_vector.cc:136-142): rows vids[0..n) of the device
+ * store copied to out [n][d] (the rows compute_dis reads); GAMMA_HIP_EINVAL for a vid outside [0, gamma_hip_raw_count) */
+int gamma_hip_raw_gets(gamma_hip_index* h, int64_t n, const int64_t* vids, float* out);
 int64_t gamma_hip_raw_count(gamma_hip_index* h);
 /* out4 = {rows, rows the mapped / allocated memory holds, reallocations that MOVED the store so far, 1 when the store
  * grows in place (virtual memory management: physical chunks mapped behind the rows, nothing ever moves or waits for

@@ -337,3 +337,113 @@ def test_bounded_scan_backs_off_where_the_bound_is_loose():
             compare_exact(np.tile(D2o, (64, 1)), np.tile(I2o, (64, 1)), D, I)
     finally:
         g.close()
+
+
+# ---- the list-length regimes of the full-size 8-GPU configurations -----------------------------------
+# Full-size C4 has 6100 codes per list, C5 2440: the regime in which the scan's filter pass is OFF (mean list length above
+# GAMMA_HIP_SCAN_CF_MAXLEN), consumer groups are split, the bounded-scan feedback acts, and MT = 32 / 64 run at batch size.
+# The tests above keep nlist at the configurations' values and therefore have 60-90 codes per list.  Here nlist is cut
+# instead, so that the oracle affords lists as long as the real ones; >= 4096 queries per call (the oracle's 512 tiled).
+
+
+def _tile_stages(st, reps):
+    return {k: np.tile(v, (reps, 1)) for k, v in st.items()}
+
+
+def _check_regime(g, o, q1, reps, metric, P, R, k, has_rank, ctx_kw=None, args_kw=None, win=WIDE):
+    bm = B.METRIC_L2 if metric == api.METRIC_L2 else B.METRIC_IP
+    D1, I1, st1 = o.search(q1, k, P, recall_num=R, has_rank=has_rank, metric=bm, ctx=B.make_ctx(**win, **(ctx_kw or {})),
+                           coarse_mode=1, want_stages=True)
+    q = np.tile(q1, (reps, 1))
+    Dg, Ig = g.ivfpq_search(q, k, api.SearchArgs(metric=metric, nprobe=P, recall_num=R, has_rank=has_rank, coarse_mode=1,
+                                                 **win, **(args_kw or {})))
+    sg = g.last_stages(len(q), P, max(R, k))
+    compare_search_exact(np.tile(D1, (reps, 1)), np.tile(I1, (reps, 1)), _tile_stages(st1, reps), Dg, Ig, sg)
+    assert g.ties_not_honoured() == 0
+    return D1, I1
+
+
+def test_c4_list_length_regime_m32_5900_codes_per_list():
+    """C4's regime: 1.5 M x 128, M 32, nprobe 64 over 256 lists (5 900 codes per list; full-size C4: 6 100), 4096 queries
+    per call, recall_num 100 / 150 / 300 (the configuration's recall bar sits at 150; 300 is beyond the bounded scan's old
+    gate), has_rank both, then a delete bitmap and a 10 % range filter -- every call against the oracle holding the
+    same lists: probe order, recall-stage (distance, id) sets, labels at every rank (gamma_index_ivfpq.cc:701-890)."""
+    N, d, nlist, M, P, k = 1500000, 128, 256, 32, 64, 10
+    base = synth.sift_like(N, d=d, seed=1234)
+    cc, pq = api.train_ivfpq(base[:nlist * 64], nlist, M)
+    g = api.GammaHip(0)
+    try:
+        g.ivfpq_init(d, nlist, M, 8, api.METRIC_L2, bucket_init_size=8000)
+        g.ivfpq_set_trained(cc, pq, None)
+        g.raw_init(d)
+        for i0 in range(0, N, 500000):
+            g.raw_append(base[i0:i0 + 500000])
+            g.add(base[i0:i0 + 500000], i0)
+        sizes = np.array([g.list_size(l) for l in range(nlist)])
+        assert sizes.sum() == N and sizes.mean() > 5000
+        o = _oracle_from_device(g, d, nlist, M, B.METRIC_L2, cc, pq, base, bucket=8000)
+        q1 = synth.sift_like(512, d=d, seed=4321)
+        for R in (100, 150, 300):
+            for has_rank in (True, False):
+                _check_regime(g, o, q1, 8, api.METRIC_L2, P, R, k, has_rank)
+        # the engine's default score window on a has_rank call
+        _check_regime(g, o, q1, 8, api.METRIC_L2, P, 150, k, True, win=dict(min_score=0.0, max_score=1e30))
+        rng = np.random.default_rng(5)
+        dead = rng.choice(N, N // 20, replace=False)
+        bm = np.zeros((N >> 3) + 1, dtype=np.uint8)
+        np.bitwise_or.at(bm, dead >> 3, (1 << (dead & 7)).astype(np.uint8))
+        g.bitmap_upload(bm, N)
+        g.delete(dead)
+        o.set_docids_bitmap(bm)
+        o.delete(dead)
+        docs = np.nonzero(rng.random(N) < 0.10)[0]
+        for R, has_rank in ((100, True), (300, True), (150, False)):
+            _check_regime(g, o, q1, 8, api.METRIC_L2, P, R, k, has_rank, ctx_kw=dict(docids_bitmap=bm))
+            _check_regime(g, o, q1, 8, api.METRIC_L2, P, R, k, has_rank,
+                          ctx_kw=dict(docids_bitmap=bm, range_filters=[B.make_range_filter(docs)]),
+                          args_kw=dict(range_filters=[api.make_range_filter(docs)]))
+        # fewer queries than a full batch (other probe-group sizes, the small-batch chain's long-list units)
+        for nq1 in (1, 7, 64, 300):
+            _check_regime(g, o, q1[:nq1], 1, api.METRIC_L2, P, 150, k, True, ctx_kw=dict(docids_bitmap=bm))
+    finally:
+        g.close()
+
+
+def test_c5_list_length_regime_d768_ip_m64_2300_codes_per_list():
+    """C5's regime: 300 k x 768 inner product, M 64 (dsub 12), nprobe 64 over 128 lists (2 300 codes per list; full-size C5:
+    2 440), 4096 queries per call, recall_num 100 and 1000 (the short-list at which full-size C5 reaches recall@10 0.95),
+    the bounded scan's feedback on and off, then range filters of 1 % / 10 % / 50 % -- against the oracle, strict."""
+    N, d, nlist, M, P, k = 300000, 768, 128, 64, 64, 10
+    base = synth.embedding_like(N, d=d, seed=1234)
+    cc, pq = api.train_ivfpq(base[:nlist * 64], nlist, M)
+    g = api.GammaHip(0)
+    try:
+        g.ivfpq_init(d, nlist, M, 8, api.METRIC_IP, bucket_init_size=3000)
+        g.ivfpq_set_trained(cc, pq, None)
+        g.raw_init(d)
+        for i0 in range(0, N, 100000):
+            g.raw_append(base[i0:i0 + 100000])
+            g.add(base[i0:i0 + 100000], i0)
+        sizes = np.array([g.list_size(l) for l in range(nlist)])
+        assert sizes.sum() == N and sizes.mean() > 2000
+        o = _oracle_from_device(g, d, nlist, M, B.METRIC_IP, cc, pq, base, bucket=3000)
+        q1 = synth.embedding_like(512, d=d, seed=4321)
+        for fb in (True, False):
+            g.set_scan_bound_feedback(fb)
+            for R in (100, 1000):
+                for has_rank in (True, False):
+                    for _ in range(3 if fb else 1):      # the feedback acts from the second call of a kind on
+                        _check_regime(g, o, q1, 8, api.METRIC_IP, P, R, k, has_rank)
+        g.set_scan_bound_feedback(True)
+        rng = np.random.default_rng(9)
+        scalar = rng.integers(0, 1000000, size=N)
+        for sel in (0.01, 0.10, 0.50):
+            docs = np.nonzero(scalar < int(sel * 1000000))[0]
+            for R in (100, 1000):
+                _check_regime(g, o, q1, 8, api.METRIC_IP, P, R, k, True,
+                              ctx_kw=dict(range_filters=[B.make_range_filter(docs)]),
+                              args_kw=dict(range_filters=[api.make_range_filter(docs)]))
+        for nq1 in (1, 16, 200):
+            _check_regime(g, o, q1[:nq1], 1, api.METRIC_IP, P, 1000, k, True)
+    finally:
+        g.close()

@@ -1,0 +1,246 @@
+"""BASELINE.json configs[3] and configs[4] at FULL size on ONE MI355X (the 8-GPU node the configurations name does not
+exist for this build; 288 GB of HBM hold either index whole): 100 M x 128 IVFPQ nlist 16384 / M 32 / nprobe 64, and
+10 M x 768 inner product nlist 4096 / M 64 / nprobe 64 with range filters.  Vectors are generated on the device in chunks
+(gamma_amd/synth.py, *_device streams) and added through the product's Add -- no host ever holds the base.
+
+Checked at full size:
+  * the size-independent properties of the C3 headline test: sorted rows, ids in range and distinct, idempotence, batch-split
+    invariance, every returned distance equal to the exact distance of the returned row (bit for bit), recall@10 against the
+    device's flat search at the configuration's operating point;
+  * a SAMPLED ORACLE: for a few dozen queries of the timed batch, an oracle index holding ONLY the inverted lists those
+    queries probe (read back from the device) -- exact, not approximate: ADC touches no other list, and the coarse quantizer
+    sees all centroids.  The rows of the big batch that belong to the sampled queries must equal the oracle's: probe order,
+    recall-stage (distance, id) sets, labels at every rank, distance bits (gamma_index_ivfpq.cc:701-890,
+    gamma_index_ivfpq.h:575-601).  Raw rows for the oracle's re-rank are fetched with gamma_hip_raw_gets into a sparse
+    file-backed array (only the candidates' rows are ever touched).
+GAMMA_FULLSIZE=0 skips the file (a box with less memory); GAMMA_FULLSIZE_N4 / _N5 shrink N for a quick look."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from gamma_amd import api, synth
+from oracle import binding as B
+from tests.parity import compare_exact, compare_search_exact
+
+pytestmark = pytest.mark.gpu
+WIDE = dict(min_score=-3e38, max_score=3e38)
+
+
+def _skip_unless(gb):
+    import torch
+    if os.environ.get("GAMMA_FULLSIZE", "1") == "0":
+        pytest.skip("GAMMA_FULLSIZE=0")
+    free, total = torch.cuda.mem_get_info(0)
+    if free < gb * (1 << 30):
+        pytest.skip("needs %d GB of free device memory, %.0f free" % (gb, free / 2 ** 30))
+
+
+class _SparseRaw:
+    """[N][d] float32 backed by a sparse temporary file: the oracle's raw store, of which only the re-rank candidates' rows
+    are ever written or read."""
+
+    def __init__(self, N, d):
+        self.f = tempfile.NamedTemporaryFile(prefix="gamma_raw_", dir=os.environ.get("TMPDIR", "/tmp"))
+        self.f.truncate(N * d * 4)       # a hole: no block is allocated before a row is written
+        self.a = np.memmap(self.f.name, dtype=np.float32, mode="r+", shape=(N, d))
+        self.have = set()
+
+    def fill(self, g, vids):
+        vids = np.unique(vids[vids >= 0])
+        new = np.array([v for v in vids.tolist() if v not in self.have], dtype=np.int64)
+        if len(new):
+            self.a[new] = g.raw_gets(new)
+            self.have.update(new.tolist())
+
+    def close(self):
+        del self.a
+        self.f.close()
+
+
+def _sub_oracle(g, d, nlist, M, metric, cc, pq, lists, bucket):
+    o = B.OracleIVFPQ(d, nlist, M, 8, metric, bucket_init_size=bucket)
+    o.set_trained(cc, pq, g.ivfpq_table() if metric == B.METRIC_L2 else None)
+    for l in lists:
+        ids, codes = g.get_list(int(l))
+        if len(ids):
+            o.add_keys(int(l), ids, codes)
+    return o
+
+
+def _rows(st, idx):
+    return {k: v[idx] for k, v in st.items()}
+
+
+def _properties(g, q, k, args, N, exact_fn, recall_min, flat_args, nrec=256):
+    """the C3 headline test's property set on one big batch; returns (D, I, stages)"""
+    nq = len(q)
+    D, I = g.ivfpq_search(q, k, args)
+    st = g.last_stages(nq, args.nprobe, max(args.recall_num, k))
+    l2 = args.metric == api.METRIC_L2
+    assert ((np.diff(D, axis=1) >= 0) if l2 else (np.diff(D, axis=1) <= 0)).all(), "rows not sorted best-first"
+    assert (I >= 0).all() and (I < N).all()
+    assert all(len(set(r.tolist())) == k for r in I[::37]), "duplicate labels in a row"
+    D2, I2 = g.ivfpq_search(q, k, args)
+    assert D2.tobytes() == D.tobytes() and np.array_equal(I2, I), "not idempotent"
+    # batch-split invariance: the same rows whatever the call they arrive in (other chunking, other probe grouping, the
+    # small-batch chain for the short pieces)
+    for lo, hi in ((0, 1), (1, 17), (17, 400), (400, 2100), (nq - 1500, nq)):
+        Ds, Is = g.ivfpq_search(q[lo:hi], k, args)
+        assert Ds.tobytes() == D[lo:hi].tobytes() and np.array_equal(Is, I[lo:hi]), "batch split %d:%d changes results" % (lo, hi)
+    # exact re-rank values: the returned distance IS the exact distance of the returned row, in the reference's arithmetic
+    if args.has_rank:
+        sel = np.arange(0, nq, max(1, nq // 64))[:64]
+        rows = g.raw_gets(I[sel].ravel()).reshape(len(sel), k, -1)
+        for t, qi in enumerate(sel):
+            assert exact_fn(q[qi], rows[t]).tobytes() == D[qi].tobytes(), "distance of query %d is not the exact one" % qi
+    Df, If = g.flat_search(q[:nrec], k, flat_args)
+    rec = float(np.mean([len(set(I[i].tolist()) & set(If[i].tolist())) / float(k) for i in range(nrec)]))
+    assert rec >= recall_min, "recall@%d %.4f below %.2f" % (k, rec, recall_min)
+    return D, I, st, rec
+
+
+def _sampled_parity(g, o, raw, q, sel, D, I, st, k, P, R, has_rank, metric, ctx_kw=None):
+    """rows `sel` of the big batch's result against the sub-index oracle"""
+    bm = B.METRIC_L2 if metric == api.METRIC_L2 else B.METRIC_IP
+    qs = np.ascontiguousarray(q[sel])
+    _, _, st0 = o.search(qs, k, P, recall_num=R, has_rank=False, metric=bm, ctx=B.make_ctx(**WIDE, **(ctx_kw or {})),
+                         coarse_mode=1, want_stages=True)
+    raw.fill(g, st0["recall_ids"].ravel())
+    o.set_raw(raw.a)
+    Do, Io, sto = o.search(qs, k, P, recall_num=R, has_rank=has_rank, metric=bm, ctx=B.make_ctx(**WIDE, **(ctx_kw or {})),
+                           coarse_mode=1, want_stages=True)
+    compare_search_exact(Do, Io, sto, D[sel], I[sel], _rows(st, sel))
+
+
+def _l2_exact(qv, rows):
+    # integer-valued coordinates below 256, d = 128: every partial sum is an integer below 2^24, exact in any order
+    return ((rows - qv[None, :]) ** 2).sum(1).astype(np.float32)
+
+
+def _ip_exact(qv, rows):
+    ctx = B.make_ctx(**WIDE)
+    Dv, Iv = B.flat_search(np.ascontiguousarray(rows), qv[None, :], len(rows), B.METRIC_IP, ctx)
+    return Dv[0]
+
+
+def test_c4_full_size_100m_x_128_one_gpu():
+    _skip_unless(110)
+    import torch
+    N = int(float(os.environ.get("GAMMA_FULLSIZE_N4", "1e8")))
+    d, nlist, M, P, k, nq, CH = 128, 16384, 32, 64, 10, 8192, 2000000
+    dev = "cuda:0"
+    first = synth.sift_like_device(nlist * 40, d=d, seed=1234, device=dev).cpu().numpy()
+    cc, pq = api.train_ivfpq(first, nlist, M)
+    del first
+    g = api.GammaHip(0)
+    raw = _SparseRaw(N, d)
+    try:
+        g.ivfpq_init(d, nlist, M, 8, api.METRIC_L2, bucket_init_size=max(200, int(1.3 * N / nlist)))
+        g.ivfpq_set_trained(cc, pq, None)
+        g.raw_init(d)
+        for c in range(0, N, CH):
+            xb = synth.sift_like_device(min(CH, N - c), d=d, seed=1234, start=c, device=dev).cpu().numpy()
+            g.raw_append(xb)
+            g.add(xb, c)
+        del xb
+        torch.cuda.empty_cache()
+        sizes = np.array([g.list_size(l) for l in range(nlist)])
+        assert sizes.sum() == N
+        q = synth.sift_like_device(nq, d=d, seed=4321, device=dev).cpu().numpy()
+        flat_args = api.SearchArgs(metric=api.METRIC_L2, **WIDE)
+        sel = np.arange(5, nq, nq // 40)[:40]
+        o = None
+        # the configuration's operating point (recall_num 150: recall@10 0.96), then the reference's default short-list and
+        # one beyond the bounded scan's old gate; has_rank both
+        for R, has_rank, rmin in ((150, True, 0.95 if N >= 10 ** 8 else 0.0), (100, False, 0.0), (300, True, 0.0)):
+            args = api.SearchArgs(metric=api.METRIC_L2, nprobe=P, recall_num=R, has_rank=has_rank, coarse_mode=1, **WIDE)
+            D, I, st, rec = _properties(g, q, k, args, N, _l2_exact, rmin, flat_args)
+            if o is None:
+                lists = np.unique(st["coarse_idx"][sel])
+                o = _sub_oracle(g, d, nlist, M, B.METRIC_L2, cc, pq, lists, bucket=100)
+            _sampled_parity(g, o, raw, q, sel, D, I, st, k, P, R, has_rank, api.METRIC_L2)
+        # deletes + a 10 % range filter (bitmap handed over by the engine's range index)
+        rng = np.random.default_rng(5)
+        dead = rng.choice(N, N // 50, replace=False)
+        bm = np.zeros((N >> 3) + 1, dtype=np.uint8)
+        np.bitwise_or.at(bm, dead >> 3, (1 << (dead & 7)).astype(np.uint8))
+        g.bitmap_upload(bm, N)
+        g.delete(dead)
+        o.set_docids_bitmap(bm)
+        # (the oracle holds a subset of the lists: Delete's per-list bookkeeping is skipped there, the bitmap does the filtering)
+        docs = np.arange(0, N, 10, dtype=np.int64)
+        for rf in (None, docs):
+            args = api.SearchArgs(metric=api.METRIC_L2, nprobe=P, recall_num=150, has_rank=True, coarse_mode=1,
+                                  range_filters=None if rf is None else [api.make_range_filter(rf)], **WIDE)
+            D, I = g.ivfpq_search(q, k, args)
+            st = g.last_stages(nq, P, 150)
+            alive = I >= 0
+            assert not ((bm[I[alive] >> 3] >> (I[alive] & 7)) & 1).any(), "a deleted document was returned"
+            if rf is not None:
+                assert (I[alive] % 10 == 0).all(), "a document outside the range filter was returned"
+            ck = dict(docids_bitmap=bm)
+            if rf is not None:
+                ck["range_filters"] = [B.make_range_filter(rf)]
+            _sampled_parity(g, o, raw, q, sel, D, I, st, k, P, 150, True, api.METRIC_L2, ctx_kw=ck)
+    finally:
+        raw.close()
+        g.close()
+
+
+def test_c5_full_size_10m_x_768_ip_one_gpu():
+    _skip_unless(60)
+    import torch
+    N = int(float(os.environ.get("GAMMA_FULLSIZE_N5", "1e7")))
+    d, nlist, M, P, k, nq, CH = 768, 4096, 64, 64, 10, 4096, 250000
+    dev = "cuda:0"
+    first = synth.embedding_like_device(nlist * 40, d=d, seed=1234, device=dev).cpu().numpy()
+    cc, pq = api.train_ivfpq(first, nlist, M)
+    del first
+    g = api.GammaHip(0)
+    raw = _SparseRaw(N, d)
+    try:
+        g.ivfpq_init(d, nlist, M, 8, api.METRIC_IP, bucket_init_size=max(200, int(1.5 * N / nlist)))
+        g.ivfpq_set_trained(cc, pq, None)
+        g.raw_init(d)
+        rng = np.random.default_rng(3)
+        col = rng.integers(0, 1000000, size=N).astype(np.int64)   # the int column range filters select on
+        for c in range(0, N, CH):
+            xb = synth.embedding_like_device(min(CH, N - c), d=d, seed=1234, start=c, device=dev).cpu().numpy()
+            g.raw_append(xb)
+            g.add(xb, c)
+            g.field_append(0, col[c:c + len(xb)])
+        del xb
+        torch.cuda.empty_cache()
+        assert sum(g.list_size(l) for l in range(nlist)) == N
+        q = synth.embedding_like_device(nq, d=d, seed=4321, device=dev).cpu().numpy()
+        flat_args = api.SearchArgs(metric=api.METRIC_IP, **WIDE)
+        sel = np.arange(3, nq, nq // 32)[:32]
+        o = None
+        # recall_num 1000 is where this configuration reaches recall@10 0.95 (profiles/r04_scale_runs.txt); 100 = the default
+        for R, has_rank, rmin in ((1000, True, 0.95 if N >= 10 ** 7 else 0.0), (100, True, 0.0), (1000, False, 0.0)):
+            args = api.SearchArgs(metric=api.METRIC_IP, nprobe=P, recall_num=R, has_rank=has_rank, coarse_mode=1, **WIDE)
+            for rep in range(2):     # the bounded scan's feedback switches the pre-filter from the second call of a kind on
+                D, I, st, rec = _properties(g, q, k, args, N, _ip_exact, rmin if rep == 0 else 0.0, flat_args, nrec=128)
+            if o is None:
+                lists = np.unique(st["coarse_idx"][sel])
+                o = _sub_oracle(g, d, nlist, M, B.METRIC_IP, cc, pq, lists, bucket=100)
+            _sampled_parity(g, o, raw, q, sel, D, I, st, k, P, R, has_rank, api.METRIC_IP)
+        # range filters of 1 % / 10 % / 50 %: as a device-side column filter (f2) and as the engine's bitmap
+        for sel_frac in (0.01, 0.10, 0.50):
+            hi = int(sel_frac * 1000000) - 1
+            docs = np.nonzero(col <= hi)[0]
+            for form in ("column", "bitmap"):
+                kw = dict(field_filters=[(0, 0, hi, True, True)]) if form == "column" else \
+                    dict(range_filters=[api.make_range_filter(docs)])
+                args = api.SearchArgs(metric=api.METRIC_IP, nprobe=P, recall_num=1000, has_rank=True, coarse_mode=1, **WIDE, **kw)
+                D, I = g.ivfpq_search(q, k, args)
+                st = g.last_stages(nq, P, 1000)
+                alive = I >= 0
+                assert (col[I[alive]] <= hi).all(), "a document outside the %s filter was returned" % form
+                _sampled_parity(g, o, raw, q, sel, D, I, st, k, P, 1000, True, api.METRIC_IP,
+                                ctx_kw=dict(range_filters=[B.make_range_filter(docs)]))
+    finally:
+        raw.close()
+        g.close()
