@@ -84,6 +84,17 @@ def main():
                     help="skip the extra legs (exact ties, batch sizes 1/32/1024, coarse_mode 0, C2 flat)")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per scan launch from a separate rocprofv3 --pmc pass")
+    ap.add_argument("--workload", default="c3", choices=["c3", "c4", "c5"],
+                    help="c3 (default): the metric's configuration, this file.  c4 / c5: BASELINE.json configs[3] / configs[4] as a "
+                         "streamed list-sharded job over --gpus ranks (bench_scale.py): vectors drawn on the device in chunks, every "
+                         "rank encodes each chunk under its list mask, no host holds the base")
+    ap.add_argument("--scale-n", type=float, default=0, help="--workload c4 / c5: vectors (default 1e8 / 1e7)")
+    ap.add_argument("--scale-nq", type=int, default=0, help="--workload c4 / c5: queries per GPU and step (default 8192 / 4096)")
+    ap.add_argument("--scale-nlist", type=int, default=0, help="--workload c4 / c5: lists (default 16384 / 4096)")
+    ap.add_argument("--scale-recall-num", type=int, default=0, help="--workload c4 / c5: short-list (default 150 / 1000: recall@10 >= 0.95)")
+    ap.add_argument("--scale-dump", default="", help="--workload c4 / c5: rank 0 writes step 0's (D, I), the trained state and the queries here (.npz)")
+    ap.add_argument("--insert-rate", type=float, default=10000.0, help="--workload c5: vectors per second of the realtime insert leg")
+    ap.add_argument("--insert-seconds", type=float, default=12.0, help="--workload c5: length of the insert leg")
     a = ap.parse_args()
 
     # `python bench.py --gpus N` without a launcher: this process only starts the N ranks (one fresh process per
@@ -101,6 +112,12 @@ def main():
     if int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:
         log("error: --gpus %d but WORLD_SIZE=%s" % (a.gpus, os.environ.get("WORLD_SIZE")))
         sys.exit(2)
+
+    if a.workload != "c3":
+        import bench_scale
+        if a.steps == 50 and a.warmup == 10:     # the defaults are C3's: a step here is 26 ms .. seconds
+            a.steps, a.warmup = 10, 3
+        return bench_scale.run(a)
 
     import torch
     import torch.distributed as dist

@@ -248,3 +248,56 @@ def test_update_across_shards():
     finally:
         for g in shards + [full]:
             g.close()
+
+
+@pytest.mark.parametrize("workload,extra", [
+    ("c4", ["--scale-n", "400000", "--scale-nlist", "1024", "--scale-nq", "1500", "--scale-recall-num", "150"]),
+    ("c5", ["--scale-n", "120000", "--scale-nlist", "256", "--scale-nq", "700", "--scale-recall-num", "300", "--insert-seconds", "5",
+            "--insert-rate", "4000"]),
+])
+def test_bench_workload_c4_c5_streamed_two_ranks_on_one_gpu(workload, extra, tmp_path):
+    """`bench.py --workload c4|c5 --gpus 2` (bench_scale.py), the entry point of the two 8-GPU configurations, at reduced N
+    with both ranks on cuda:0 over gloo: the streamed Add under the ranks' list masks must leave every vector in exactly one
+    shard (the job asserts it), the line must carry the placement / exchange / per-rank blocks, and step 0's result table
+    must equal, at every rank, what ONE unsharded handle returns for the same device streams (exact ties on: identical
+    labels) -- gamma_gpu_cloner.cpp:200-269, faiss:IndexShards.cpp:283-345."""
+    import json
+    from gamma_amd import api, synth
+    dump = str(tmp_path / "step0.npz")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--gpus", "2", "--one-gpu", "--backend",
+                        "gloo", "--steps", "2", "--warmup", "1", "--scale-dump", dump] + extra,
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    cfg = line["config"]
+    assert len(cfg["per_rank"]) == 2 and sum(p["shard_vectors"] for p in cfg["per_rank"]) == int(float(extra[1]))
+    assert "no RCCL communicator" in cfg["communicator"] and "replicated" in cfg["raw_placement"]
+    if workload == "c5":
+        ins = cfg["search_during_inserts"]
+        assert ins["inserted"] > 0 and "writer_error" not in ins, ins
+        assert ins["vectors_in_the_shards_after"] == int(float(extra[1])) + ins["inserted"]
+        assert all(v["results_inside_the_filter"] for v in cfg["range_filter"].values())
+    # the same index in ONE handle
+    z = np.load(dump)
+    N = int(float(extra[1]))
+    l2 = workload == "c4"
+    d, M = (128, 32) if l2 else (768, 64)
+    nlist, R = int(extra[3]), int(extra[7])
+    g = api.GammaHip(0)
+    try:
+        g.ivfpq_init(d, nlist, M, 8, api.METRIC_L2 if l2 else api.METRIC_IP, bucket_init_size=1000)
+        g.ivfpq_set_trained(z["cc"], z["pq"], None)
+        g.raw_init(d)
+        gen = synth.sift_like_device if l2 else synth.embedding_like_device
+        for c in range(0, N, 100000):
+            xb = gen(min(100000, N - c), d=d, seed=1234, start=c, device="cuda:0").cpu().numpy()
+            g.raw_append(xb)
+            g.add(xb, c)
+        win = dict(min_score=0.0, max_score=1e30) if l2 else dict(min_score=-1e30, max_score=1e30)
+        D, I = g.ivfpq_search(z["q"], 10, api.SearchArgs(metric=api.METRIC_L2 if l2 else api.METRIC_IP, nprobe=64, recall_num=R,
+                                                         has_rank=True, **win))
+        compare_exact(D, I, z["D"], z["I"])
+    finally:
+        g.close()
