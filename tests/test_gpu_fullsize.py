@@ -77,8 +77,8 @@ def _properties(g, q, k, args, N, exact_fn, recall_min, flat_args, nrec=256):
     """the C3 headline test's property set on one big batch; returns (D, I, stages)"""
     nq = len(q)
     D, I = g.ivfpq_search(q, k, args)
-    st = g.last_stages(nq, args.nprobe, max(args.recall_num, k))
-    l2 = args.metric == api.METRIC_L2
+    st = g.last_stages(nq, args.p.nprobe, max(args.p.recall_num, k))
+    l2 = args.p.metric == api.METRIC_L2
     assert ((np.diff(D, axis=1) >= 0) if l2 else (np.diff(D, axis=1) <= 0)).all(), "rows not sorted best-first"
     assert (I >= 0).all() and (I < N).all()
     assert all(len(set(r.tolist())) == k for r in I[::37]), "duplicate labels in a row"
@@ -90,7 +90,7 @@ def _properties(g, q, k, args, N, exact_fn, recall_min, flat_args, nrec=256):
         Ds, Is = g.ivfpq_search(q[lo:hi], k, args)
         assert Ds.tobytes() == D[lo:hi].tobytes() and np.array_equal(Is, I[lo:hi]), "batch split %d:%d changes results" % (lo, hi)
     # exact re-rank values: the returned distance IS the exact distance of the returned row, in the reference's arithmetic
-    if args.has_rank:
+    if args.p.has_rank:
         sel = np.arange(0, nq, max(1, nq // 64))[:64]
         rows = g.raw_gets(I[sel].ravel()).reshape(len(sel), k, -1)
         for t, qi in enumerate(sel):
