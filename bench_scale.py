@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 SPEC = {
     "c4": dict(d=128, nlist=16384, M=32, P=64, R=150, k=10, nq=8192, n=100000000, metric="L2", chunk=2000000,
                name="C4: IVFPQ nlist=16384 m=32, %dx128 synthetic (SIFT-shaped device stream), nprobe=64"),
-    "c5": dict(d=768, nlist=4096, M=64, P=64, R=1000, k=10, nq=4096, n=10000000, metric="IP", chunk=250000,
+    "c5": dict(d=768, nlist=4096, M=64, P=64, R=1200, k=10, nq=4096, n=10000000, metric="IP", chunk=250000,
                name="C5: IVFPQ %dx768 inner product (embedding-shaped device stream), nlist=4096 m=64 nprobe=64, range filter "
                     "on an int column, realtime inserts during search"),
 }
@@ -142,8 +142,15 @@ def run(a):
     args = api.SearchArgs(metric=metric, nprobe=P, recall_num=R, has_rank=True, **win)
     g.set_exact_ties(not a.no_exact_ties)
 
+    d_D = torch.empty((gnq, k), dtype=torch.float32, device=dev)
+    d_I = torch.empty((gnq, k), dtype=torch.int64, device=dev)
+    plain = world == 1 and not a.force_dist     # one GPU: the ordinary Search (the sharded orchestration with --force-dist)
+
     def step(i, sargs=args):
         xb = d_q[(i % nbatches) * gnq:(i % nbatches + 1) * gnq]
+        if plain:
+            g.ivfpq_search_device(xb.data_ptr(), gnq, k, sargs, d_D.data_ptr(), d_I.data_ptr())
+            return d_D, d_I
         return gdist.sharded_search(backend, xb, k, sargs)
 
     def timed(sargs, steps, warmup, profile=True):
@@ -291,7 +298,7 @@ def run(a):
         "dtype": "f32", "data": "synthetic",
         "config": dict({
             "workload": (sp["name"] % N) + ", recall_num=%d has_rank=true k=%d, %d queries per step (%d per GPU)" % (R, k, gnq, nq),
-            "placement": "shard: lists by greedy sum(len) over sizes estimated from %d sample rows; per-shard top-recall_num "
+            "placement": "one GPU: the whole index, plain Search" if plain else "shard: lists by greedy sum(len) over sizes estimated from %d sample rows; per-shard top-recall_num "
                          "exchanged all-to-all; merge + re-rank at the query slice's owner" % ns,
             "raw_placement": "replicated: %.1f GB of raw vectors on EVERY rank (re-rank at the slice's owner reads rows of every "
                              "shard's candidates); codes + ids + sums sharded" % (N * d * 4 / 1e9),

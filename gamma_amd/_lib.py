@@ -72,6 +72,7 @@ SYMBOLS = {
     "gamma_hip_ties_not_honoured": (C.c_int, [C.c_void_p, i64p, C.c_int]),
     "gamma_hip_raw_write": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, f32p]),
     "gamma_hip_raw_gets": (C.c_int, [C.c_void_p, C.c_int64, i64p, f32p]),
+    "gamma_hip_ivfpq_repack_verify_stats": (C.c_int, [C.c_void_p, i64p]),
     "gamma_hip_raw_count": (C.c_int64, [C.c_void_p]),
     "gamma_hip_raw_stats": (C.c_int, [C.c_void_p, i64p]),
     "gamma_hip_bitmap_upload": (C.c_int, [C.c_void_p, u8p, C.c_int64]),

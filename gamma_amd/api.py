@@ -239,6 +239,11 @@ class GammaHip:
         self._ck(self.L.gamma_hip_ivfpq_arena_stats(self.h, _p(out, _lib.i64p)), "arena_stats")
         return dict(zip(["cap", "used", "waste", "repacks"], [int(v) for v in out]))
 
+    def repack_verify_stats(self):
+        out = np.zeros(2, dtype=np.int64)
+        self._ck(self.L.gamma_hip_ivfpq_repack_verify_stats(self.h, _p(out, _lib.i64p)), "repack_verify_stats")
+        return dict(verified=int(out[0]), failures=int(out[1]))
+
     def arena_growth(self):
         """{moves: growths that reallocated and copied the arena, mapped: it grows in place (mapped ranges)}"""
         out = np.zeros(2, np.int64)

@@ -103,14 +103,16 @@ int gamma_hip_destroy(gamma_hip_index* h) {
         h->raw_vm.release();
         h->d_raw = nullptr;
     }
+    // (release() of a range that was never reserved does nothing; an arena that left virtual memory management after a
+    //  failed repack read-back still owns its reserved ranges)
+    h->vm_codes.release();
+    h->vm_ids.release();
+    h->vm_sums.release();
+    h->alt_codes.release();
+    h->alt_ids.release();
+    h->alt_sums.release();
+    for (auto& r : h->vm_retired) r.release();
     if (h->arena_vmm) {
-        h->vm_codes.release();
-        h->vm_ids.release();
-        h->vm_sums.release();
-        h->alt_codes.release();
-        h->alt_ids.release();
-        h->alt_sums.release();
-        for (auto& r : h->vm_retired) r.release();
         h->d_codes = nullptr;
         h->d_ids = nullptr;
         h->d_sums = nullptr;

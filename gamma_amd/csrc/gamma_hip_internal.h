@@ -225,6 +225,7 @@ struct gamma_hip_index {
     int64_t arena_regrows = 0;   // growths that moved the arena (0 with virtual memory management)
     int64_t repack_min_entries = 1 << 16;                     // no repack for less waste than this
     int64_t n_repacks = 0;
+    int64_t repack_verified = 0, repack_verify_failures = 0;   // read-backs of a repack target / those that differed from the source
     std::vector<int64_t> h_list_off;
     std::vector<int> h_list_len, h_list_cap, h_deleted;
     std::vector<uint8_t> h_extend_time;
@@ -241,7 +242,7 @@ struct gamma_hip_index {
             w_cand_pos, w_cand_ids, w_exact, w_selv, w_selp, w_x, w_outd, w_outl, w_stage, w_shard_cut, w_filter,
             w_m_dis, w_m_ids, w_part_v, w_part_i, w_assign, w_codes_tmp, w_qperm, w_qbins, w_scnt, w_sflag, w_surv, w_pair_base,
             w_pair_ip, w_flat_cand, w_flat_meta, w_full_cdis, w_full_probe, w_ftab, w_qfil, w_tieflag, w_tcut, w_tlist, w_textra, w_fq, w_fraw, w_frcnt, w_lm_units, w_lm_cnt, w_fbits, w_cmp_codes, w_cmp_ids, w_cmp_len, w_cmp_sums, w_fD, w_fI, w_fx, w_fslab, w_flog, w_mr_vals, w_mr_ids, w_mr_meta,
-            we_mat, we_cdis, we_x, we_assign, we_codes, we_stage;   // writer side (encode, bitmap_set): never shared with a search
+            we_mat, we_cdis, we_x, we_assign, we_codes, we_stage, we_chk;   // writer side (encode, bitmap_set): never shared with a search
     unsigned long long* d_scan_codes = nullptr;
     size_t dist_budget_bytes = (size_t)8 << 30;   // per-chunk ADC distance buffer (288 GB of HBM per GPU)
 

@@ -35,6 +35,7 @@ bool VmRange::reserve(int device_, size_t chunk_min) {
     device = device_;
     return true;
 }
+static bool vm_unmap_fence();
 hipError_t VmRange::map_to(size_t bytes, const char** what) {
     *what = "";
     if (bytes <= mapped) return hipSuccess;
@@ -72,7 +73,10 @@ hipError_t VmRange::map_to(size_t bytes, const char** what) {
             (void)hipGetLastError();
             e = hipMemSetAccess(base, mapped + add, &acc, 1);
         }
-        if (e != hipSuccess) (void)hipMemUnmap(at, add);
+        if (e != hipSuccess) {
+            (void)hipMemUnmap(at, add);
+            if (!vm_unmap_fence()) tainted = true;   // (the next map_to would hand out the same address)
+        }
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -124,8 +128,9 @@ void VmRange::release() {
         (void)hipMemRelease(chunks[i]);
         off += chunk_bytes[i];
     }
-    if (!chunks.empty()) (void)vm_unmap_fence();
-    (void)hipMemAddressFree(base, va_bytes);
+    // (no fence: the address range is NOT given back -- whoever reserved it next would map addresses with stale
+    //  translations; it stays reserved for the life of the process, address space only)
+    if (chunks.empty() || vm_unmap_fence()) (void)hipMemAddressFree(base, va_bytes);
     chunks.clear();
     chunk_bytes.clear();
     base = nullptr;
@@ -246,23 +251,34 @@ static int sums_all_lists(H* h) {
 // realtime_mem_data.cc:457-466).  Here grown and compacted extents are abandoned inside the arena
 // (arena_waste); once they are more than half of what is in use -- and worth at least a megabyte of codes --
 // every list moves into a fresh, tight arena: one kernel, offsets re-published in stream order.
-int arena_repack(H* h) {
-    int64_t total = 0;
-    std::vector<int64_t> noff(h->nlist);
-    for (int l = 0; l < h->nlist; l++) {
-        noff[l] = total;
-        total += h->h_list_cap[l];
-    }
-    int64_t ncap = total + total / 8 + 1024;
+// Safe by construction (round 5): the version of the list tables that points at the new extents is published only after
+// the target has been READ BACK through its new mapping and found equal to the source -- per-list checksums of ids + codes
+// (k_list_checksum) taken at the source before the move and at the target in a launch of its own, behind a translation
+// fence (the stale-translation failure seen on this runtime lets a kernel read back what it wrote itself; a later launch
+// over fresh translations is what a search would see).  A mismatch keeps the old version (nothing has been freed), retires
+// the target's address ranges, counts (gamma_hip_ivfpq_repack_verify_stats, logged by the plugins) and repeats the move
+// into ordinary hipMalloc'd arrays -- the handle's arena then stays outside virtual memory management.  The fence after
+// every unmap stays as belt and braces.
+static int repack_checksums(H* h, const uint8_t* codes, const int64_t* ids, const int64_t* d_off, std::vector<unsigned long long>* out) {
+    GH_CHECK(h, h->we_chk.ensure((size_t)h->nlist * sizeof(unsigned long long)));
+    gh::launch_list_checksum(h->wstream, codes, ids, d_off, h->d_list_len, h->nlist, h->code_size, std::max(1, h->max_list_len),
+                             h->we_chk.as<unsigned long long>());
+    out->resize(h->nlist);
+    GH_CHECK(h, hipMemcpyAsync(out->data(), h->we_chk.p, (size_t)h->nlist * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->wstream));
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    return GAMMA_HIP_OK;
+}
+
+// one attempt: GAMMA_HIP_OK = moved, verified, committed; kRepackMismatch = the target did not read back as written (old
+// version intact, target given back / retired); anything else = error (old version intact)
+static const int kRepackMismatch = 1;
+static int arena_repack_once(H* h, bool vmm, const std::vector<int64_t>& noff, int64_t total, int64_t ncap,
+                             const std::vector<unsigned long long>& src_sum) {
     uint8_t* nc = nullptr;
     int64_t* ni = nullptr;
     float* ns = nullptr;
-    if (h->wl) GH_CHECK(h, h->wl->exclusive());   // every list moves and the old arrays are freed
-    GH_TRY(publish_meta(h));                      // the device tables the kernel below reads = the host mirror
     // Mapped arena: the handle keeps TWO sets of address ranges and the repack moves the lists from the set in use into the
     // other one (physical chunks mapped there for the occasion), gives the old set's physical memory back and swaps the roles.
-    // (two persistent sets: address space stays bounded; what makes the re-mapping of the idle set's addresses safe is the
-    //  fence every unmap ends with -- VmRange::unmap_all)
     struct AltGuard {   // an error below gives the target set's physical memory back
         H* h;
         bool armed = true;
@@ -273,10 +289,19 @@ int arena_repack(H* h) {
                 h->alt_sums.unmap_all();
             }
         }
-    } alt_guard{h, h->arena_vmm};
-    if (h->arena_vmm) {
+    } alt_guard{h, vmm};
+    struct MallocGuard {
+        void* p[3] = {nullptr, nullptr, nullptr};
+        bool armed = true;
+        ~MallocGuard() {
+            if (armed)
+                for (void* q : p)
+                    if (q) (void)hipFree(q);
+        }
+    } mg;
+    if (vmm) {
         for (VmRange* r : {&h->alt_codes, &h->alt_ids, &h->alt_sums})
-            if (r->tainted) {   // unmapped without a fence (the device was out of memory): these addresses are not mapped again
+            if (r->tainted) {   // unmapped without a fence, or failed a read-back: these addresses are not mapped again
                 h->vm_retired.push_back(std::move(*r));
                 *r = VmRange();
             }
@@ -296,23 +321,44 @@ int arena_repack(H* h) {
         ni = reinterpret_cast<int64_t*>(h->alt_ids.base);
         ns = h->keep_sums ? reinterpret_cast<float*>(h->alt_sums.base) : nullptr;
     } else {
-        GH_CHECK(h, hipMalloc((void**)&nc, (size_t)ncap * h->code_size));
-        if (hipMalloc((void**)&ni, (size_t)ncap * sizeof(int64_t)) != hipSuccess) {
-            (void)hipFree(nc);
+        if (hipMalloc((void**)&nc, (size_t)ncap * h->code_size) != hipSuccess) return fail(h, GAMMA_HIP_ENOMEM, "arena repack: out of memory");
+        mg.p[0] = nc;
+        if (hipMalloc((void**)&ni, (size_t)ncap * sizeof(int64_t)) != hipSuccess) return fail(h, GAMMA_HIP_ENOMEM, "arena repack: out of memory");
+        mg.p[1] = ni;
+        if (h->keep_sums && hipMalloc((void**)&ns, (size_t)ncap * sizeof(float)) != hipSuccess)
             return fail(h, GAMMA_HIP_ENOMEM, "arena repack: out of memory");
-        }
-        if (h->keep_sums && hipMalloc((void**)&ns, (size_t)ncap * sizeof(float)) != hipSuccess) {
-            (void)hipFree(nc);
-            (void)hipFree(ni);
-            return fail(h, GAMMA_HIP_ENOMEM, "arena repack: out of memory");
-        }
+        mg.p[2] = ns;
     }
     GH_CHECK(h, h->we_stage.ensure((size_t)h->nlist * sizeof(int64_t)));
     GH_CHECK(h, hipMemcpyAsync(h->we_stage.p, noff.data(), (size_t)h->nlist * sizeof(int64_t), hipMemcpyHostToDevice, h->wstream));
     gh::launch_repack_lists(h->wstream, h->d_codes, h->d_ids, nc, ni, h->d_list_off, h->we_stage.as<int64_t>(),
                             h->d_list_len, h->nlist, h->code_size, h->max_list_len);
-    GH_CHECK(h, hipStreamSynchronize(h->wstream));   // noff is a local; the old arrays are free to go
-    if (h->arena_vmm) {
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    static const bool no_verify = getenv("GAMMA_HIP_NO_REPACK_VERIFY") != nullptr;
+    if (!no_verify) {
+        if (vmm) (void)vm_unmap_fence();   // translations the move may have cached are gone before the read-back
+        // fault injection for the tests (GAMMA_HIP_FAULT_REPACK=<n>: the first n read-backs see a zeroed entry)
+        static int fault_left = getenv("GAMMA_HIP_FAULT_REPACK") ? atoi(getenv("GAMMA_HIP_FAULT_REPACK")) : 0;
+        if (fault_left > 0 && total > 0) {
+            fault_left--;
+            int l0 = 0;
+            while (l0 < h->nlist - 1 && h->h_list_len[l0] == 0) l0++;
+            GH_CHECK(h, hipMemsetAsync(ni + noff[l0], 0, sizeof(int64_t), h->wstream));
+            GH_CHECK(h, hipMemsetAsync(nc + noff[l0] * h->code_size, 0xa5, (size_t)h->code_size, h->wstream));
+        }
+        std::vector<unsigned long long> dst_sum;
+        GH_TRY(repack_checksums(h, nc, ni, h->we_stage.as<int64_t>(), &dst_sum));
+        h->repack_verified++;
+        if (dst_sum != src_sum) {
+            h->repack_verify_failures++;
+            if (vmm) {   // the guard unmaps the target (with its fence); its addresses are never mapped again
+                h->alt_codes.tainted = h->alt_ids.tainted = true;
+                if (h->keep_sums) h->alt_sums.tainted = true;
+            }
+            return kRepackMismatch;
+        }
+    }
+    if (vmm) {
         alt_guard.armed = false;   // the target set is the arena from here
         h->vm_codes.unmap_all();
         h->vm_ids.unmap_all();
@@ -322,9 +368,17 @@ int arena_repack(H* h) {
         std::swap(h->vm_sums, h->alt_sums);
         arena_vm_adopt(h);
     } else {
-        GH_CHECK(h, hipFree(h->d_codes));
-        GH_CHECK(h, hipFree(h->d_ids));
-        if (h->d_sums) GH_CHECK(h, hipFree(h->d_sums));
+        mg.armed = false;
+        if (h->arena_vmm) {   // leaving virtual memory management after a failed read-back: the mapped sets go
+            h->vm_codes.unmap_all();
+            h->vm_ids.unmap_all();
+            h->vm_sums.unmap_all();
+            h->arena_vmm = false;
+        } else {
+            GH_CHECK(h, hipFree(h->d_codes));
+            GH_CHECK(h, hipFree(h->d_ids));
+            if (h->d_sums) GH_CHECK(h, hipFree(h->d_sums));
+        }
         h->d_codes = nc;
         h->d_ids = ni;
         h->d_sums = ns;
@@ -336,6 +390,25 @@ int arena_repack(H* h) {
     h->n_repacks++;
     GH_TRY(publish_meta(h));
     return sums_all_lists(h);   // the sums follow their codes: recomputed at the new offsets (the caller drains the stream)
+}
+
+int arena_repack(H* h) {
+    int64_t total = 0;
+    std::vector<int64_t> noff(h->nlist);
+    for (int l = 0; l < h->nlist; l++) {
+        noff[l] = total;
+        total += h->h_list_cap[l];
+    }
+    const int64_t ncap = total + total / 8 + 1024;
+    if (h->wl) GH_CHECK(h, h->wl->exclusive());   // every list moves and the old arrays are freed
+    GH_TRY(publish_meta(h));                      // the device tables the kernels below read = the host mirror
+    std::vector<unsigned long long> src_sum;
+    GH_TRY(repack_checksums(h, h->d_codes, h->d_ids, h->d_list_off, &src_sum));
+    int rc = arena_repack_once(h, h->arena_vmm, noff, total, ncap, src_sum);
+    if (rc == kRepackMismatch && h->arena_vmm) rc = arena_repack_once(h, false, noff, total, ncap, src_sum);
+    if (rc == kRepackMismatch)
+        return fail(h, GAMMA_HIP_EDEVICE, "arena repack: the moved lists did not read back as written (the previous arena stays in use)");
+    return rc;
 }
 int arena_repack_if_need(H* h) {
     const int64_t min_waste = std::max<int64_t>(h->repack_min_entries, 1);
@@ -1234,6 +1307,14 @@ int gamma_hip_ivfpq_arena_stats(gamma_hip_index* h, int64_t* out4) {
     out4[1] = h->arena_used;
     out4[2] = h->arena_waste;
     out4[3] = h->n_repacks;
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_repack_verify_stats(gamma_hip_index* h, int64_t* out2) {
+    if (!h || !out2) return GAMMA_HIP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    out2[0] = h->repack_verified;
+    out2[1] = h->repack_verify_failures;
     return GAMMA_HIP_OK;
 }
 

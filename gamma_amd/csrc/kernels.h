@@ -369,6 +369,8 @@ void launch_take_ids(hipStream_t s, const int* pos, const int64_t* src_ids, int6
 void launch_bitmap_set(hipStream_t s, uint8_t* bm, const int64_t* docids, int64_t n, int64_t nbits,
                        int value);
 void launch_mark_moved(hipStream_t s, int64_t* ids, int64_t pos);
+void launch_list_checksum(hipStream_t s, const uint8_t* codes, const int64_t* ids, const int64_t* off, const int* len, int nlist,
+                          int M, int max_len, unsigned long long* out);
 void launch_repack_lists(hipStream_t s, const uint8_t* oc, const int64_t* oi, uint8_t* nc, int64_t* ni,
                          const int64_t* old_off, const int64_t* new_off, const int* len, int nlist, int M,
                          int max_len);

@@ -130,6 +130,41 @@ void launch_repack_lists(hipStream_t s, const uint8_t* oc, const int64_t* oi, ui
     hipLaunchKernelGGL(k_repack_lists, dim3(nlist, chunks), dim3(256), 0, s, oc, oi, nc, ni, old_off, new_off, len, M);
 }
 
+// Per-list checksum of (ids, codes) at given extents: what arena_repack compares between the source and -- read back
+// through the NEW mapping, in a launch of its own behind a translation fence -- the target before the new version of the
+// list tables is published (realtime/realtime_mem_data.cc:426-474 swaps a bucket's pointer only after the copy).
+// sum over entries of mix(position in the list, word): a moved, dropped, zeroed or permuted entry changes it.
+__device__ __forceinline__ unsigned long long chk_mix(unsigned long long x) {   // splitmix64 finaliser
+    x += 0x9e3779b97f4a7c15ull;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(256) void k_list_checksum(const uint8_t* __restrict__ codes, const int64_t* __restrict__ ids,
+                                                       const int64_t* __restrict__ off, const int* __restrict__ len, int M,
+                                                       unsigned long long* __restrict__ out) {
+    const int l = blockIdx.x;
+    const int n = len[l];
+    const int64_t a = off[l];
+    unsigned long long acc = 0;
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256)
+        acc += chk_mix(((unsigned long long)i << 1) ^ chk_mix((unsigned long long)ids[a + i]));
+    const int64_t nb = (int64_t)n * M;
+    const uint8_t* c = codes + a * M;
+    for (int64_t i = blockIdx.y * 256 + threadIdx.x; i < nb; i += gridDim.y * 256)
+        acc += chk_mix((((unsigned long long)i << 9) | 0x100ull | c[i]) * 0x2545f4914f6cdd1dull);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out + l, acc);
+}
+void launch_list_checksum(hipStream_t s, const uint8_t* codes, const int64_t* ids, const int64_t* off, const int* len, int nlist,
+                          int M, int max_len, unsigned long long* out) {
+    if (nlist <= 0) return;
+    (void)hipMemsetAsync(out, 0, (size_t)nlist * sizeof(unsigned long long), s);
+    const int chunks = std::max(1, std::min(64, (max_len + 1023) / 1024));
+    hipLaunchKernelGGL(k_list_checksum, dim3(nlist, chunks), dim3(256), 0, s, codes, ids, off, len, M, out);
+}
+
 // ------------------------------------------------------------------------------------
 // Per-code table sums of the L2 scan's filter pass (k_ivfpq_scan_pair<.., CF>): sums[pos] = sum_m T2[list][m][code[m]]
 // (sequential fp32 adds from 0).  The value is only ever used inside a bound with a margin that covers its rounding,

@@ -278,6 +278,12 @@ int gamma_hip_ivfpq_compact_if_need(gamma_hip_index* h);
  * abandoned, repacks so far}, in list entries (code_size + 8 bytes each).  Setting the threshold re-checks at once. */
 int gamma_hip_ivfpq_arena_stats(gamma_hip_index* h, int64_t* out4);
 int gamma_hip_ivfpq_set_repack_threshold(gamma_hip_index* h, int64_t min_waste_entries);
+/* out2 = {repack targets read back before their version of the list tables was published, read-backs that DIFFERED from
+ * the source}.  A repack moves every list (realtime/realtime_mem_data.cc:426-474 swaps a bucket's pointer only after the
+ * copy); the new version is published only after per-list checksums of ids + codes, recomputed through the new mapping in
+ * a launch of their own, equal those of the source.  A difference keeps the old version, retires the target's address
+ * ranges and repeats the move into ordinary allocations; the plugins log a non-zero second value. */
+int gamma_hip_ivfpq_repack_verify_stats(gamma_hip_index* h, int64_t* out2);
 /* How the arena grows: out2 = {growths that MOVED the arena (reallocation + copy under the exclusive lock), 1 when the
  * arena's arrays are mapped address ranges that grow in place (chunks mapped behind them: no copy, no second arena, no
  * wait for the searches in flight -- the reference grows bucket by bucket for the same reason,
