@@ -313,7 +313,10 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     // small batches: one probe per workgroup, a single list rarely holds R candidates, and the
     // unfiltered selection is latency-bound anyway
     // (one group per query -- few probes, or a shard -- is fine: the producer bounds and compacts its own candidates)
-    bool bounded = (!shard || compacted) && h->scan_bound && R <= 256 && P <= 128 && G >= 4;
+    // (recall_num up to 1024 since round 5: slices of 2048 items and k_select_final_wg beyond 256 -- the configurations that need
+    //  a long short-list, full-size C5 at ~1000, keep the pre-filter; GAMMA_HIP_BOUND_MAXR: the old gate for A/B runs)
+    static const int bound_maxr = getenv("GAMMA_HIP_BOUND_MAXR") ? atoi(getenv("GAMMA_HIP_BOUND_MAXR")) : 1024;
+    bool bounded = (!shard || compacted) && h->scan_bound && R <= std::min(1024, bound_maxr) && P <= 128 && G >= 4;
     if (bounded) {
         // feedback (gamma_hip_internal.h, bound_*): the counts of some recent call are in the pinned words
         static const bool no_fb = getenv("GAMMA_HIP_NO_BOUND_FEEDBACK") != nullptr;
@@ -352,7 +355,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     const bool fuse_ip = bounded && PGN == 1 && (M == 16 || M == 32) && !getenv("GAMMA_HIP_NO_FUSED_IP");
     // the bounded scan's per-call state (repair list, ready words, survivor counts) is sized here, before the pair offsets,
     // whose kernel clears it together with the tie flags -- one launch instead of four fills in front of the scan
-    const int cap = gh::scan_slice_cap();
+    const int cap = gh::scan_slice_cap(R);
     bool cf_ok = false;
     int PGM = PGN, nsl = PGN, cf_span = 0;
     unsigned long long* ready = nullptr;
@@ -374,7 +377,8 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         static const double cf_maxlen = getenv("GAMMA_HIP_SCAN_CF_MAXLEN") ? atof(getenv("GAMMA_HIP_SCAN_CF_MAXLEN")) : 2000.0;
         static const double cf_codes = getenv("GAMMA_HIP_SCAN_CF_CODES") ? atof(getenv("GAMMA_HIP_SCAN_CF_CODES")) : 65536.0;
         const double mean_len = (double)h->ntotal / std::max(1, nlist);
-        cf_ok = !no_cf && (!h->prefiltered || h->cmp_has_sums) && PGN > 1 && mean_len <= cf_maxlen &&
+        // (and short-lists only: the pass stages SCAN_CF_CAP = 768 candidates per consumer workgroup)
+        cf_ok = !no_cf && R <= 256 && (!h->prefiltered || h->cmp_has_sums) && PGN > 1 && mean_len <= cf_maxlen &&
                 gh::scan_cf_applies(l2, M, P, G, h->d_sums && h->d_t2max, false);
         if (cf_ok) {
             const int rest = P - G;
@@ -495,6 +499,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         static const int spins_env = getenv("GAMMA_HIP_SCAN_SPINS") ? atoi(getenv("GAMMA_HIP_SCAN_SPINS")) : 0;
         sb.spins = spins_env;
         sb.timeouts = h->d_bound_stat + 4;
+        sb.slice_cap = cap;
         scan(G, 0, PGM, &sb, true);
         // GAMMA_HIP_BOUND_DBG=1: the bounded scan's statistics of the 9th .. 14th call; =shard: of list-shard calls only
         static const bool dbg_any = getenv("GAMMA_HIP_BOUND_DBG") != nullptr;

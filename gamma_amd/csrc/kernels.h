@@ -172,8 +172,9 @@ struct ScanBound {
     int cf_span;                // filter pass: probes per consumer group behind the producer's G (0: one consumer takes them all)
     int spins;                  // sleeps a consumer waits for its producer's bound before it goes on without one (0: 2048)
     unsigned long long* timeouts;   // consumers that gave up waiting (diagnostics; may be nullptr)
+    int slice_cap;              // items a slice holds: scan_slice_cap(K)
 };
-int scan_slice_cap();
+int scan_slice_cap(int K);   // 1024 up to recall_num 256, 2048 up to 1024
 // true when launch_ivfpq_scan_pair would run the filter pass (CF) for a bounded scan with these arguments; the caller
 // then launches TWO groups per query -- the producer's G probes and one consumer group with all the others
 bool scan_cf_applies(bool l2, int M, int P, int G, bool have_sums, bool store_all);

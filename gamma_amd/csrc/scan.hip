@@ -29,7 +29,8 @@ namespace gh {
 // ------------------------------------------------------------------------------------
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int SCAN_STAGE = 256;                  // survivors staged in LDS per workgroup
-constexpr int SCAN_SLICE = 1024;                 // candidate slice of one workgroup (global); a producer needs recall_num + one histogram bin
+constexpr int SCAN_SLICE = 1024;                 // candidate slice of one workgroup (global) up to recall_num 256; a producer needs recall_num +
+                                                 // one histogram bin: 2048 beyond (ScanBound::slice_cap, scan_slice_cap)
 constexpr int SCAN_BATCH = 64;                   // queries per XCD by which producers run ahead
 
 // amdgpu_num_sgpr(96): 8 waves per SIMD need <= 96 SGPRs each (800 per SIMD); the FILT variant
@@ -157,8 +158,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
                 const int at = base + __popcll(bal & ((1ull << lane) - 1ull));
                 const unsigned long long item = ((unsigned long long)dis_key<L2>(val) << 32) | (unsigned)pos;
                 if (at < SCAN_STAGE) s_stage[at] = item;
-                else if (at < SCAN_SLICE)   // staging full (rare): the slot number is already unique
-                    sb.surv[((int64_t)q * pg_cnt + pg) * SCAN_SLICE + at] = item;
+                else if (at < sb.slice_cap)   // staging full (rare): the slot number is already unique
+                    sb.surv[((int64_t)q * pg_cnt + pg) * sb.slice_cap + at] = item;
             }
         }
     };
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
         const int n = s_nstage;
         const int64_t slice = (int64_t)q * pg_cnt + pg;
         if (threadIdx.x == 0) sb.gcnt[(int64_t)q * sb.cnt_stride + pg] = n;
-        for (int i = threadIdx.x; i < min(n, SCAN_STAGE); i += 256) sb.surv[slice * SCAN_SLICE + i] = s_stage[i];
+        for (int i = threadIdx.x; i < min(n, SCAN_STAGE); i += 256) sb.surv[slice * sb.slice_cap + i] = s_stage[i];
     };
     // (CF: the LAST group takes every probe behind the ones before it -- its table is the query's, not a list's, so
     //  one workgroup per query serves all consumer probes: one table write, one slice)
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
                     s_tau = (word >> 32) == 1ull ? (uint32_t)word : 0xffffffffu;
                 } else {   // give the query to the unfiltered selection instead of hanging
                     s_tau = 0xffffffffu;
-                    s_nstage = SCAN_SLICE + 1;
+                    s_nstage = sb.slice_cap + 1;
                     if (sb.timeouts) atomicAdd(sb.timeouts, 1ull);
                 }
             }
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
             __syncthreads();
             const int nc = s_ncand;
             if (nc > SCAN_CF_CAP) {   // (uniform) more candidates than the stage holds: the query takes the unfiltered path
-                if (tid == 0) s_nstage = SCAN_SLICE + 1;
+                if (tid == 0) s_nstage = sb.slice_cap + 1;
             } else {
                 for (int c0 = 0; c0 < nc; c0 += 256) {   // uniform trip count: append() ballots
                     const int c = c0 + tid;
@@ -713,7 +714,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
     }
 }
 
-int scan_slice_cap() { return SCAN_SLICE; }
+int scan_slice_cap(int K) { return K <= 256 ? SCAN_SLICE : 2 * SCAN_SLICE; }
 bool scan_cf_applies(bool l2, int M, int P, int G, bool have_sums, bool store_all) {
     return l2 && have_sums && !store_all && (M == 16 || M == 32) && P > G;
 }
@@ -748,7 +749,8 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
         const int64_t nq8 = (nq + 7) / 8, nb = (nq8 + SCAN_BATCH - 1) / SCAN_BATCH;
         grid.x = (unsigned)(8 * (SCAN_BATCH + nb * SCAN_BATCH * pg_cnt));
     }
-    ScanBound sb = {nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, 0};
+    ScanBound sb = {};
+    sb.slice_cap = SCAN_SLICE;
     if (bound) sb = *bound;
     // filter pass for the consumers of a bounded L2 scan: needs the per-code sums (sb.sums) and survivor-only consumers
     const bool cf = bound && l2 && !pqc_fused && pg_cnt > 1 && sb.sums && sb.t2max && !sb.store_all && (M == 16 || M == 32);

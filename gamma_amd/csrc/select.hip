@@ -951,6 +951,193 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
 }
 
 // ------------------------------------------------------------------------------------
+// k_select_final_wg: the same selection for 256 < K <= 1024 (round 5: the bounded scan's gate was recall_num <= 256, and the
+// configurations that need a long short-list -- full-size C5 reaches recall@10 0.95 at recall_num ~1000 -- ran on the
+// unfiltered path).  One WORKGROUP per query: the survivor slices (slice_cap up to 2048 items each, a few thousand items in
+// all) are streamed from memory for nested 256-bin histograms of the keys until the cut keeps <= SFW_KEEP items, those are
+// compacted into LDS, rank-sorted on the whole (key, position) item, and the first K go out.  Same results, flags, repair
+// list and counters as k_select_final.
+// ------------------------------------------------------------------------------------
+namespace {
+constexpr int SFW_KEEP = 2048;
+}
+template <bool SMALLEST>
+__global__ __launch_bounds__(256) void k_select_final_wg(const unsigned long long* __restrict__ surv, const int* __restrict__ gcnt,
+                                                         int nslices, int slice_cap, const unsigned long long* __restrict__ ready,
+                                                         const int* __restrict__ pair_off, int P, int nq, int K,
+                                                         const int64_t* __restrict__ pair_base, const int64_t* __restrict__ ids,
+                                                         uint8_t* __restrict__ flag, float* __restrict__ out_vals,
+                                                         int* __restrict__ out_pos, int64_t* __restrict__ out_ids,
+                                                         uint8_t* __restrict__ cut_tie, unsigned long long* __restrict__ tie_stats,
+                                                         int* __restrict__ rq_list, int* __restrict__ rq_count,
+                                                         unsigned long long* __restrict__ bound_stat) {
+    __shared__ unsigned long long s_it[SFW_KEEP];
+    __shared__ int s_hist[256];
+    __shared__ int s_off[128 + 8];
+    __shared__ int64_t s_base[128];
+    __shared__ int s_w[8];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int q = blockIdx.x;
+    if (bound_stat && q == 0 && tid == 0) atomicAdd(bound_stat + 1, (unsigned long long)nq);
+    const unsigned long long word = ready[q];
+    if ((word >> 32) != 1ull) {   // no bound: every group stored its distances, the unfiltered selection takes the query
+        if (tid == 0) {
+            flag[q] = 1;
+            if (bound_stat) atomicAdd(bound_stat, 1ull);
+        }
+        return;
+    }
+    auto give_up = [&]() {   // a slice overflowed / a mass tie: the repair launch scores the consumer groups again, with stores
+        if (tid == 0) {
+            flag[q] = 1;
+            if (rq_list) rq_list[atomicAdd(rq_count, 1)] = q;
+            if (bound_stat) atomicAdd(bound_stat, 1ull);
+        }
+    };
+    const int* cnt = gcnt + (int64_t)q * nslices;
+    int c = 0;
+    bool over = false;
+    for (int g = 0; g < nslices; g++) {   // uniform
+        const int n = cnt[g];
+        over |= n > slice_cap;
+        c += n;
+    }
+    if (over) {
+        give_up();
+        return;
+    }
+    const int* goff = pair_off + (int64_t)q * (P + 1);
+    for (int i = tid; i <= P; i += 256) s_off[i] = goff[i];
+    for (int i = tid; i < P; i += 256) s_base[i] = pair_base[(int64_t)q * P + i];
+    // body(valid, item) for every survivor, uniform trip counts per slice
+    auto for_each = [&](auto&& body) {
+        for (int g = 0; g < nslices; g++) {
+            const int n = cnt[g];
+            const unsigned long long* sg = surv + ((int64_t)q * nslices + g) * slice_cap;
+            for (int i0 = 0; i0 < n; i0 += 256) {
+                const int i = i0 + tid;
+                body(i < n, sg[min(i, n - 1)]);
+            }
+        }
+    };
+    // ---- the range of the keys ----
+    uint32_t mn = 0xffffffffu, mx = 0u;
+    for_each([&](bool ok, unsigned long long item) {
+        const uint32_t key = (uint32_t)(item >> 32);
+        if (ok) {
+            mn = key < mn ? key : mn;
+            mx = key > mx ? key : mx;
+        }
+    });
+    mn = wave_min_u32(mn);
+    mx = wave_max_u32(mx);
+    if (lane == 0) {
+        s_w[wv] = (int)mn;
+        s_w[4 + wv] = (int)mx;
+    }
+    __syncthreads();
+    mn = min(min((uint32_t)s_w[0], (uint32_t)s_w[1]), min((uint32_t)s_w[2], (uint32_t)s_w[3]));
+    mx = max(max((uint32_t)s_w[4], (uint32_t)s_w[5]), max((uint32_t)s_w[6], (uint32_t)s_w[7]));
+    __syncthreads();
+    // ---- cut to <= SFW_KEEP items: keep keys <= cutoff, cutoff from (nested) 256-bin histograms ----
+    uint32_t cutoff = 0xffffffffu;
+    if (c > SFW_KEEP) {
+        uint32_t lo = mn;
+        const uint32_t range = mx - mn;
+        int sh = range >= 256u ? (32 - __clz((int)range)) - 8 : 0;
+        int below = 0;   // items with key < lo (all kept)
+        for (;;) {
+            s_hist[tid] = 0;
+            __syncthreads();
+            for_each([&](bool ok, unsigned long long item) {
+                const uint32_t key = (uint32_t)(item >> 32);
+                if (ok && key >= lo && ((key - lo) >> sh) < 256u) atomicAdd(&s_hist[(key - lo) >> sh], 1);
+            });
+            __syncthreads();
+            if (tid < 64) {   // wave 0: the bin in which the running count passes K
+                int cc[4], c4 = 0;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    cc[u] = s_hist[lane * 4 + u];
+                    c4 += cc[u];
+                }
+                const int incl = wave_incl_scan(c4);
+                int run = below + incl - c4;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (run < K && K <= run + cc[u]) {
+                        s_w[0] = lane * 4 + u;
+                        s_w[1] = run;
+                        s_w[2] = run + cc[u];
+                    }
+                    run += cc[u];
+                }
+            }
+            __syncthreads();
+            const int b = s_w[0], before = s_w[1], kept = s_w[2];
+            __syncthreads();
+            if (kept <= SFW_KEEP || sh == 0) {
+                if (kept > SFW_KEEP) {   // more than SFW_KEEP copies of one key around the K-th
+                    give_up();
+                    return;
+                }
+                const unsigned long long edge = (unsigned long long)lo + (((unsigned long long)b + 1ull) << sh) - 1ull;
+                cutoff = edge > 0xffffffffull ? 0xffffffffu : (uint32_t)edge;
+                break;
+            }
+            below = before;
+            lo += (uint32_t)b << sh;
+            sh = sh > 8 ? sh - 8 : 0;
+        }
+    }
+    if (tid == 0) {
+        flag[q] = 0;
+        s_w[3] = 0;
+    }
+    __syncthreads();
+    // ---- the kept items into LDS (any order: sorted next) ----
+    for_each([&](bool ok, unsigned long long item) {
+        const bool keep = ok && (uint32_t)(item >> 32) <= cutoff;
+        const unsigned long long bal = __ballot(keep);
+        if (bal) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_w[3], __popcll(bal));
+            base = __shfl(base, 0, 64);
+            if (keep) s_it[base + __popcll(bal & ((1ull << lane) - 1ull))] = item;
+        }
+    });
+    __syncthreads();
+    const int m = s_w[3];
+    block_rank_sort<256, SFW_KEEP / 256>(s_it, m);   // (key, position) items are distinct
+    if (cut_tie && tid == 0) {   // every candidate at the K-th key is among the kept items
+        const bool tie = m > K && (uint32_t)(s_it[K] >> 32) == (uint32_t)(s_it[K - 1] >> 32);
+        cut_tie[q] = tie ? 1 : 0;
+        if (tie && tie_stats) atomicAdd(tie_stats + 1, 1ull);
+    }
+    const float sentinel = SMALLEST ? INFINITY : -INFINITY;
+    const int nres = min(m, K);
+    for (int r = tid; r < K; r += 256) {
+        if (r < nres) {
+            const unsigned long long it = s_it[r];
+            const int ps = (int)(uint32_t)it;
+            int lo2 = 0, hi2 = P - 1;
+            while (lo2 < hi2) {   // last p with off[p] <= ps
+                const int mid = (lo2 + hi2 + 1) >> 1;
+                if (s_off[mid] <= ps) lo2 = mid; else hi2 = mid - 1;
+            }
+            const uint32_t key = (uint32_t)(it >> 32);
+            out_vals[(int64_t)q * K + r] = key2f(SMALLEST ? key : ~key);
+            out_pos[(int64_t)q * K + r] = ps;
+            out_ids[(int64_t)q * K + r] = ids[s_base[lo2] + (ps - s_off[lo2])] & 0x7fffffffffffffffLL;
+        } else {
+            out_vals[(int64_t)q * K + r] = sentinel;
+            out_pos[(int64_t)q * K + r] = -1;
+            out_ids[(int64_t)q * K + r] = -1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Merge of the per-shard candidate tables (list-sharded search, gamma_hip_ivfpq_merge_rerank):
 // all_dis / all_ids [W][nq][R] -> the K = R best of each query's W*R candidates, ordered by
 // (distance, shard, rank inside the shard) -- what selecting from the gathered [nq][W*R] row gives.
@@ -1577,7 +1764,18 @@ void launch_select_final(hipStream_t s, bool smallest, const unsigned long long*
                          int* out_pos, int64_t* out_ids, uint8_t* cut_tie, unsigned long long* tie_stats,
                          int* rq_list, int* rq_count, unsigned long long* bound_stat) {
     if (nq <= 0) return;
-    if (P > 128 || nslices > 64) abort();   // callers gate on this (gamma_hip_search.cpp, ivfpq_stage_a)
+    if (P > 128) abort();   // callers gate on this (gamma_hip_search.cpp, ivfpq_stage_a)
+    if (K > 256) {          // one workgroup per query (recall_num up to 1024: the callers' gate)
+        if (K > 1024) abort();
+        if (smallest)
+            hipLaunchKernelGGL((k_select_final_wg<true>), dim3(nq), dim3(256), 0, s, surv, gcnt, nslices, slice_cap, ready, pair_off, P, nq,
+                               K, pair_base, ids, flag, out_vals, out_pos, out_ids, cut_tie, tie_stats, rq_list, rq_count, bound_stat);
+        else
+            hipLaunchKernelGGL((k_select_final_wg<false>), dim3(nq), dim3(256), 0, s, surv, gcnt, nslices, slice_cap, ready, pair_off, P,
+                               nq, K, pair_base, ids, flag, out_vals, out_pos, out_ids, cut_tie, tie_stats, rq_list, rq_count, bound_stat);
+        return;
+    }
+    if (nslices > 64) abort();
 #define GH_SF(SM, PM)                                                                                        \
     hipLaunchKernelGGL((k_select_final<SM, PM>), dim3((nq + 3) / 4), dim3(256), 0, s, surv, gcnt, nslices,   \
                        slice_cap, ready, pair_off, P, nq, K, pair_base, ids, flag,                           \
