@@ -466,7 +466,7 @@ class GammaHip:
 
     def ties_not_honoured(self, reset=False):
         """search calls that ran without the exact-ties mode although the handle's default asked for it (shape beyond the
-        replay's range: nprobe > 256, flat k = 4096)"""
+        replay's range: nprobe > 1024, flat k = 4096)"""
         out = np.zeros(1, dtype=np.int64)
         self._ck(self.L.gamma_hip_ties_not_honoured(self.h, _p(out, _lib.i64p), 1 if reset else 0), "ties_not_honoured")
         return int(out[0])

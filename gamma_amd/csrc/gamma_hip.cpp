@@ -131,6 +131,7 @@ int gamma_hip_destroy(gamma_hip_index* h) {
     for (void* pp : h->comb_pin)
         if (pp) (void)hipHostFree(pp);
     if (h->dir_pin) (void)hipHostFree(h->dir_pin);
+    if (h->bound_copy_ev) (void)hipEventDestroy(h->bound_copy_ev);
     if (h->pin_bound_stat) (void)hipHostFree(h->pin_bound_stat);
     DevBuf* bufs[] = {&h->w_mat, &h->w_coarse_dis, &h->w_probe, &h->w_xn, &h->w_st2, &h->w_pair_off,
                       &h->w_qtotal, &h->w_dist, &h->w_cand_dis, &h->w_cand_pos, &h->w_cand_ids,

@@ -196,6 +196,8 @@ struct gamma_hip_index {
     unsigned long long* d_bound_stat = nullptr;    // 2 slots x {queries given to the unfiltered selection, queries}, then: consumer groups that gave up waiting
     unsigned long long* pin_bound_stat = nullptr;  // the two slots as of some recent call (pinned host memory)
     unsigned long long bound_seen[2] = {0, 0};     // what the last decision had read
+    hipEvent_t bound_copy_ev = nullptr;            // behind the last copy into pin_bound_stat
+    bool bound_copy_pending = false;
     uint64_t bound_sig = 0;                        // (nprobe, recall_num, metric, filter, shard) of the calls the counts are of
     int bound_epoch = 0;                           // kinds of call seen; its low bit selects the counter slot
     bool bound_feedback_off = false;               // gamma_hip_set_scan_bound_feedback(h, 0): the pre-filter whenever it applies

@@ -331,6 +331,10 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
             h->bound_calls = 0;
             h->bound_seen[0] = h->bound_seen[1] = 0;
             const int slot = h->bound_epoch & 1;
+            if (h->bound_copy_pending) {   // a copy of the previous kind's counts still on its way: it lands before the words are reused
+                (void)hipEventSynchronize(h->bound_copy_ev);
+                h->bound_copy_pending = false;
+            }
             h->pin_bound_stat[2 * slot] = h->pin_bound_stat[2 * slot + 1] = 0;
             GH_CHECK(h, hipMemsetAsync(h->d_bound_stat + 2 * slot, 0, 2 * sizeof(unsigned long long), s));
         }
@@ -339,9 +343,16 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         } else if (h->bound_off_calls > 0) {
             if (--h->bound_off_calls > 0) bounded = false;   // (0: this call re-probes)
         } else {
+            // (the pair is consulted only once the copy that writes it has completed -- bound_copy_ev -- so the two
+            //  words belong to one state of the counters; a sample that runs backwards, e.g. a late copy landing on words
+            //  zeroed for a new kind of call, is ignored, and the fell-through count can never exceed the queries)
+            const bool landed = !h->bound_copy_pending || hipEventQuery(h->bound_copy_ev) == hipSuccess;
+            if (landed) h->bound_copy_pending = false;
+            else (void)hipGetLastError();
             const unsigned long long u = h->pin_bound_stat[2 * slot], n = h->pin_bound_stat[2 * slot + 1];
-            const unsigned long long du = u - h->bound_seen[0], dn = n - h->bound_seen[1];
-            if (n >= h->bound_seen[1] && dn >= 2048) {
+            const unsigned long long dn = n - h->bound_seen[1];
+            const unsigned long long du = std::min(u >= h->bound_seen[0] ? u - h->bound_seen[0] : 0ull, dn);
+            if (landed && n >= h->bound_seen[1] && u >= h->bound_seen[0] && dn >= 2048) {
                 h->bound_seen[0] = u;
                 h->bound_seen[1] = n;
                 if (2 * du > dn) {   // more than half of the recent queries went to the unfiltered selection anyway
@@ -515,9 +526,13 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
                                 h->d_tie_stats, sb.rq_list, sb.rq_count, h->d_bound_stat + 2 * (h->bound_epoch & 1));
         // the counts as of this call, for a later call's decision (16 bytes; ~5 us on the call's critical path, so: the
         // first calls of a kind, then every 16th)
-        if (h->bound_calls < 4 || (h->bound_calls & 15) == 0)
+        if ((h->bound_calls < 4 || (h->bound_calls & 15) == 0) && !h->bound_copy_pending) {
             GH_CHECK(h, hipMemcpyAsync(h->pin_bound_stat + 2 * (h->bound_epoch & 1), h->d_bound_stat + 2 * (h->bound_epoch & 1),
                                        2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            if (!h->bound_copy_ev) GH_CHECK(h, hipEventCreateWithFlags(&h->bound_copy_ev, hipEventDisableTiming));
+            GH_CHECK(h, hipEventRecord(h->bound_copy_ev, s));
+            h->bound_copy_pending = true;
+        }
         h->bound_calls++;
         if (PGN > 1 && !sb.store_all) {
             // queries the slices could not answer: their consumer groups are scored again, distances stored

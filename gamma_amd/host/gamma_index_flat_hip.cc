@@ -139,7 +139,7 @@ int GammaFLATHIPIndex::Search(RetrievalContext *retrieval_context, int n, const 
   if (!(device_filters_ && columns_.Prepare(h_, cond, DocCountOf(this, (int64_t)vector_->MetaInfo()->Size()), p, ff, tf)))
     FillRangeFilters(cond, p, rf);
   const int rc = gamma_hip_flat_search(h_, &p, n, reinterpret_cast<const float *>(x), k, distances, ids);
-  if (!rc) WarnTiesNotHonoured(h_);
+  if (!rc) WarnTiesNotHonoured(h_, nullptr, &ties_said_);
   return rc;
 }
 

@@ -2,6 +2,7 @@
 // (reference index/impl/gamma_index_flat.{h,cc}) on an MI355X.  Same JSON keys
 // (metric_type, parallel_on_queries), same Search contract.
 #pragma once
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -47,6 +48,7 @@ class GammaFLATHIPIndex : public RetrievalModel {
 
  private:
   gamma_hip_index *h_ = nullptr;
+  std::atomic<int64_t> ties_said_{0};   // WarnTiesNotHonoured: what this model has reported so far
   int d_ = 0;
   int64_t uploaded_ = 0;
   int SyncVid2DocID(int64_t upto);

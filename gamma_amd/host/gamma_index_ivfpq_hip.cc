@@ -387,21 +387,35 @@ int GammaIVFPQHIPIndex::Search(RetrievalContext *retrieval_context, int n, const
     HLOG("search failed: %s (%s)", gamma_hip_strerror(rc), grp_ ? gamma_hip_group_last_error(grp_) : gamma_hip_last_error(h_));
     return rc;
   }
-  WarnTiesNotHonoured(h_);
+  WarnTiesNotHonoured(h_, grp_, &ties_said_);
   return 0;
 }
 
-// A search beyond the exact-ties mode's range (nprobe > 256, a flat search for k = 4096) that merely inherited the model's
-// default ran with the (distance, position) order inside ties: said once per occurrence count, never silently
-// (gamma_hip_ties_not_honoured; a request that sets "exact_ties": 1 itself fails instead)
-void WarnTiesNotHonoured(gamma_hip_index *h) {
-  static std::atomic<int64_t> said{0};
-  int64_t n = 0;
-  if (!h || gamma_hip_ties_not_honoured(h, &n, 0) || n <= 0) return;
-  int64_t prev = said.load();
-  if (n > prev && said.compare_exchange_strong(prev, n))
-    HLOG("%lld search call(s) ran without the reference's heap order inside exact ties: shape beyond the mode's range "
-         "(nprobe > 256 or flat k = 4096)", (long long)n);
+// A search beyond the exact-ties mode's range (nprobe > 1024, a flat search for k = 4096) that merely inherited the model's
+// default ran with the (distance, position) order inside ties: said once per new occurrence count of THIS model (the
+// high-water mark is a member of the index object; a group's count is the sum over its members), never silently
+// (gamma_hip_ties_not_honoured; a request that sets "exact_ties": 1 itself fails instead).  The same line reports repack
+// read-backs that differed from their source (gamma_hip_ivfpq_repack_verify_stats).
+void WarnTiesNotHonoured(gamma_hip_index *h, gamma_hip_group *grp, std::atomic<int64_t> *said) {
+  int64_t n = 0, bad_repacks = 0;
+  const int members = grp ? gamma_hip_group_size(grp) : 1;
+  for (int i = 0; i < members; i++) {
+    gamma_hip_index *m = grp ? gamma_hip_group_member(grp, i) : h;
+    int64_t c = 0, rv[2] = {0, 0};
+    if (m && !gamma_hip_ties_not_honoured(m, &c, 0)) n += c;
+    if (m && !gamma_hip_ivfpq_repack_verify_stats(m, rv)) bad_repacks += rv[1];
+  }
+  const int64_t mark = n + (bad_repacks << 40);
+  if (mark <= 0 || !said) return;
+  int64_t prev = said->load();
+  if (mark > prev && said->compare_exchange_strong(prev, mark)) {
+    if (n > 0)
+      HLOG("%lld search call(s) ran without the reference's heap order inside exact ties: shape beyond the mode's range "
+           "(nprobe > 1024 or flat k = 4096)", (long long)n);
+    if (bad_repacks > 0)
+      HLOG("%lld list-arena repack(s) did not read back as written: the previous arena was kept and the move repeated into "
+           "ordinary allocations", (long long)bad_repacks);
+  }
 }
 
 // PerfTool (index/retrieval_model.h:23-50; printed by the engine at online_log_level=debug): one label for the device
@@ -706,7 +720,7 @@ int GammaIVFFlatHIPIndex::Search(RetrievalContext *retrieval_context, int n, con
     HLOG("search failed: %s (%s)", gamma_hip_strerror(rc), gamma_hip_last_error(h_));
     return rc;
   }
-  WarnTiesNotHonoured(h_);
+  WarnTiesNotHonoured(h_, nullptr, &ties_said_);
   return 0;
 }
 
