@@ -165,7 +165,8 @@ def test_c4_full_size_100m_x_128_one_gpu():
             args = api.SearchArgs(metric=api.METRIC_L2, nprobe=P, recall_num=R, has_rank=has_rank, coarse_mode=1, **WIDE)
             D, I, st, rec = _properties(g, q, k, args, N, _l2_exact, rmin, flat_args)
             if o is None:
-                lists = np.unique(st["coarse_idx"][sel])
+                g.ivfpq_search(np.ascontiguousarray(q[sel]), k, args)       # the lists the sampled queries probe
+                lists = np.unique(g.last_stages(len(sel), P, max(R, k))["coarse_idx"])
                 o = _sub_oracle(g, d, nlist, M, B.METRIC_L2, cc, pq, lists, bucket=100)
             _sampled_parity(g, o, raw, q, sel, D, I, st, k, P, R, has_rank, api.METRIC_L2)
         # deletes + a 10 % range filter (bitmap handed over by the engine's range index)
@@ -233,7 +234,8 @@ def test_c5_full_size_10m_x_768_ip_one_gpu():
             for rep in range(2):     # the bounded scan's feedback switches the pre-filter from the second call of a kind on
                 D, I, st, rec = _properties(g, q, k, args, N, _ip_exact, rmin if rep == 0 else 0.0, flat_args, nrec=128)
             if o is None:
-                lists = np.unique(st["coarse_idx"][sel])
+                g.ivfpq_search(np.ascontiguousarray(q[sel]), k, args)       # the lists the sampled queries probe
+                lists = np.unique(g.last_stages(len(sel), P, max(R, k))["coarse_idx"])
                 o = _sub_oracle(g, d, nlist, M, B.METRIC_IP, cc, pq, lists, bucket=100)
             _sampled_parity(g, o, raw, q, sel, D, I, st, k, P, R, has_rank, api.METRIC_IP)
         # range filters of 1 % / 10 % / 50 %: as a device-side column filter (f2) and as the engine's bitmap
