@@ -70,6 +70,7 @@ SYMBOLS = {
     "gamma_hip_set_coarse_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "gamma_hip_tie_stats": (C.c_int, [C.c_void_p, i64p, C.c_int]),
     "gamma_hip_ties_not_honoured": (C.c_int, [C.c_void_p, i64p, C.c_int]),
+    "gamma_hip_blas_form_not_restated": (C.c_int, [C.c_void_p, i64p, C.c_int]),
     "gamma_hip_raw_write": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, f32p]),
     "gamma_hip_raw_gets": (C.c_int, [C.c_void_p, C.c_int64, i64p, f32p]),
     "gamma_hip_ivfpq_repack_verify_stats": (C.c_int, [C.c_void_p, i64p]),

@@ -471,6 +471,12 @@ class GammaHip:
         self._ck(self.L.gamma_hip_ties_not_honoured(self.h, _p(out, _lib.i64p), 1 if reset else 0), "ties_not_honoured")
         return int(out[0])
 
+    def blas_form_not_restated(self, reset=False):
+        """calls whose GEMM-form coarse distances fell into a shape whose MKL kernel is not restated (ulp-level differences)"""
+        out = np.zeros(1, dtype=np.int64)
+        self._ck(self.L.gamma_hip_blas_form_not_restated(self.h, _p(out, _lib.i64p), 1 if reset else 0), "blas_form_not_restated")
+        return int(out[0])
+
     def set_exact_ties(self, on=True):
         """probe exactly the lists the reference's heap keeps when coarse distances tie at the nprobe boundary"""
         self._ck(self.L.gamma_hip_set_exact_ties(self.h, 1 if on else 0), "set_exact_ties")

@@ -233,6 +233,12 @@ int gamma_hip_ties_not_honoured(gamma_hip_index* h, int64_t* out_calls, int rese
     return GAMMA_HIP_OK;
 }
 
+int gamma_hip_blas_form_not_restated(gamma_hip_index* h, int64_t* out_calls, int reset) {
+    if (!h || !out_calls) return GAMMA_HIP_EINVAL;
+    *out_calls = reset ? h->blas_unrestated.exchange(0) : h->blas_unrestated.load();
+    return GAMMA_HIP_OK;
+}
+
 int gamma_hip_set_scan_bound_feedback(gamma_hip_index* h, int on) {
     if (!h) return GAMMA_HIP_EINVAL;
     SearchLock lk(h);

@@ -570,6 +570,8 @@ static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, in
     // faiss chooses the coarse path from the size of the WHOLE call (faiss:utils/distances.cpp:346): the slices must agree
     gamma_hip_search_params pp = *p;
     if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;
+    // (gamma_hip_blas_form_not_restated: every member counts the shape of ITS slice -- a remainder block of the whole call
+    //  that a slice boundary hides is not counted here)
     const int per = (nq + W - 1) / W;
     // transport of the two exchanges of the path: RCCL when asked for and a communicator can be formed
     if (g->transport == 1 && !g->replicate && !g->comm_tried) {

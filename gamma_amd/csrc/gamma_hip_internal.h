@@ -92,6 +92,18 @@ struct VmRange {
     void unmap_all();
 };
 
+// GEMM-form distance calls (coarse quantizer, assign, k-means: faiss's exhaustive_L2sqr_blas, faiss:utils/distances.cpp:215-296)
+// whose sgemm_ kernel is NOT restated (oracle/gamma_oracle.c, go_gemm_k_split): K beyond 768 or an odd split, K = 384 with
+// a database remainder block of 9..512 rows, remainder blocks of a few rows (nx mod 4096 / ny mod 1024 in 1..7: MKL takes
+// another kernel there -- measured: the rows of a 1..3-row query remainder differ in ~10 % of their entries by an ulp).
+// Such calls are COUNTED (gamma_hip_blas_form_not_restated), never silent.
+inline bool blas_form_not_restated(int64_t nx, int64_t ny, int d) {
+    if (d > 768 || (d > 384 && (d & 7))) return true;
+    const int64_t rx = nx % 4096, ry = ny % 1024;
+    if ((rx >= 1 && rx <= 7) || (ry >= 1 && ry <= 7)) return true;
+    return d == 384 && ry >= 9 && ry <= 512;
+}
+
 struct gamma_hip_index {
     int device = 0;
     // Concurrency (SURVEY 8b "Threading": Search from any number of client threads while ONE indexing thread adds
@@ -255,6 +267,7 @@ struct gamma_hip_index {
 
     bool exact_ties = true;    // gamma_hip_set_exact_ties
     std::atomic<int64_t> ties_unhonoured{0};   // gamma_hip_ties_not_honoured
+    std::atomic<int64_t> blas_unrestated{0};   // gamma_hip_blas_form_not_restated
     bool coarse_fused = true;  // gamma_hip_set_coarse_fused
     bool small_path = true;    // gamma_hip_set_small_path
     int small_presel = 0;      // 0: pre-selection by estimate, > 0: always, that many slices (tests)

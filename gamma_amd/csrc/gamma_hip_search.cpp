@@ -955,6 +955,7 @@ int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, c
     // faiss picks the coarse path from the size of the WHOLE call (faiss:utils/distances.cpp:346);
     // the internal chunks must not re-decide it
     if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;
+    if (pp.coarse_mode == 1 && blas_form_not_restated(nq, h->nlist, h->d)) h->blas_unrestated++;
     if (ivfpq_small_ok(h, p, fc, nq, R)) {
         GH_TRY(replay_join(h));
         GH_TRY(ivfpq_small(h, p, fc, nq, d_x, R, k, d_distances, d_labels));
@@ -1131,6 +1132,7 @@ int ivfflat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq,
     FiltCtx fc;
     GH_TRY(filt_ctx_single(h, filt, &fc));
     if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;   // faiss:utils/distances.cpp:303,346, whole call
+    if (pp.coarse_mode == 1 && blas_form_not_restated(nq, h->nlist, h->d)) h->blas_unrestated++;
     const int P = pp.nprobe, nlist = h->nlist;
     hipStream_t s = h->stream;
     {   // small batches, as long as the pair-per-workgroup scan is the one that would run anyway (below 2 nlist pairs)
@@ -1606,6 +1608,7 @@ int gamma_hip_ivfpq_search_shard(gamma_hip_index* h, const gamma_hip_search_para
     gamma_hip_search_params pp;
     GH_TRY(resolve_ties(h, p, &pp, p->nprobe <= gh::tie_replay_max_probes(), "exact_ties = 1 with nprobe > 1024"));
     if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;   // decided on the whole call, not per chunk
+    if (pp.coarse_mode == 1 && blas_form_not_restated(nq, h->nlist, h->d)) h->blas_unrestated++;
     p = &pp;
     const int chunk = query_chunk(h, nq, p->nprobe);
     for (int q0 = 0; q0 < nq; q0 += chunk) {
@@ -1633,6 +1636,7 @@ int gamma_hip_ivfpq_coarse_device(gamma_hip_index* h, const gamma_hip_search_par
     GH_TRY(resolve_ties(h, p, &pp, p->nprobe <= gh::tie_replay_max_probes(), "exact_ties = 1 with nprobe > 1024"));
     // the caller resolves coarse_mode -1 on the size of the whole batch; a slice that arrives unresolved decides by itself
     if (pp.coarse_mode < 0) pp.coarse_mode = nq < 20 ? 0 : 1;
+    if (pp.coarse_mode == 1 && blas_form_not_restated(nq, h->nlist, h->d)) h->blas_unrestated++;
     p = &pp;
     const int chunk = coarse_chunk(h, nq);
     for (int q0 = 0; q0 < nq; q0 += chunk)

@@ -1415,6 +1415,7 @@ static int encode_host(gamma_hip_index* h, int64_t n, const float* vecs, int64_t
     WriteLock lk(h);
     if (!h->trained) return fail(h, GAMMA_HIP_ENOTTRAINED, "not trained");
     if (n == 0) return GAMMA_HIP_OK;
+    if (!exact && blas_form_not_restated(n, h->nlist, h->d)) h->blas_unrestated++;
     GH_CHECK(h, hipSetDevice(h->device));
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n, 65536), (int64_t)(h->dist_budget_bytes / ((size_t)h->nlist * sizeof(float)))));
     std::vector<int> assign(chunk);
@@ -1461,6 +1462,7 @@ int gamma_hip_assign(gamma_hip_index* h, int d, int64_t n, const float* x, int k
         h->replay_pending = false;
     }
     if (n == 0) return GAMMA_HIP_OK;
+    if (blas_form_not_restated(n, k, d)) h->blas_unrestated++;
     GH_CHECK(h, hipSetDevice(h->device));
     hipStream_t s = h->stream;
     // centroids + their norms live in the (otherwise unused here) partial-result buffers

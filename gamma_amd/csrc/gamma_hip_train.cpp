@@ -122,6 +122,7 @@ int gamma_hip_kmeans(gamma_hip_index* h, int d, int64_t n, const float* x_in, in
     std::vector<int> assign(n), order(n), seg(k + 1);
     std::vector<float> hassign(k), dis;
     const bool exact = n < 20;   // IndexFlatL2::search: the exact form below 20 queries (faiss:utils/distances.cpp:346)
+    if (!exact && blas_form_not_restated(n, k, d)) h->blas_unrestated++;
     for (int it = 0; it < niter; it++) {
         // index.search(nx, x, 1, dis, assign)
         if (!exact) gh::launch_row_norms(s, d_cen.as<float>(), k, d, d_cn.as<float>());

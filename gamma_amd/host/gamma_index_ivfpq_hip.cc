@@ -388,6 +388,7 @@ int GammaIVFPQHIPIndex::Search(RetrievalContext *retrieval_context, int n, const
     return rc;
   }
   WarnTiesNotHonoured(h_, grp_, &ties_said_);
+  WarnBlasCorners(h_, grp_, &blas_said_);
   return 0;
 }
 
@@ -416,6 +417,25 @@ void WarnTiesNotHonoured(gamma_hip_index *h, gamma_hip_group *grp, std::atomic<i
       HLOG("%lld list-arena repack(s) did not read back as written: the previous arena was kept and the move repeated into "
            "ordinary allocations", (long long)bad_repacks);
   }
+}
+
+// Calls whose GEMM-form coarse distances fell into a shape for which the library's sgemm_ kernel is not restated
+// (gamma_hip_blas_form_not_restated: ulp-level differences in a few coarse distances): logged when the count first
+// becomes non-zero and at every doubling -- an Add stream of odd batch sizes would otherwise fill the log.
+void WarnBlasCorners(gamma_hip_index *h, gamma_hip_group *grp, std::atomic<int64_t> *said) {
+  int64_t n = 0;
+  const int members = grp ? gamma_hip_group_size(grp) : 1;
+  for (int i = 0; i < members; i++) {
+    gamma_hip_index *m = grp ? gamma_hip_group_member(grp, i) : h;
+    int64_t c = 0;
+    if (m && !gamma_hip_blas_form_not_restated(m, &c, 0)) n += c;
+  }
+  if (n <= 0 || !said) return;
+  int64_t prev = said->load();
+  if (n >= 2 * prev && n > prev && said->compare_exchange_strong(prev, n))
+    HLOG("%lld call(s) computed coarse distances in a GEMM shape whose MKL kernel is not restated (K > 768, K = 384 with a "
+         "9..512-row remainder, remainder blocks of 1..7 rows): a few coarse distances may differ from faiss's by an ulp",
+         (long long)n);
 }
 
 // PerfTool (index/retrieval_model.h:23-50; printed by the engine at online_log_level=debug): one label for the device
@@ -721,6 +741,7 @@ int GammaIVFFlatHIPIndex::Search(RetrievalContext *retrieval_context, int n, con
     return rc;
   }
   WarnTiesNotHonoured(h_, nullptr, &ties_said_);
+  WarnBlasCorners(h_, nullptr, &blas_said_);
   return 0;
 }
 

@@ -20,7 +20,8 @@
 
 namespace tig_gamma {
 
-void WarnTiesNotHonoured(gamma_hip_index *h, gamma_hip_group *grp, std::atomic<int64_t> *said);   // gamma_index_ivfpq_hip.cc
+void WarnTiesNotHonoured(gamma_hip_index *h, gamma_hip_group *grp, std::atomic<int64_t> *said);
+void WarnBlasCorners(gamma_hip_index *h, gamma_hip_group *grp, std::atomic<int64_t> *said);   // gamma_index_ivfpq_hip.cc
 
 class HIPIVFPQRetrievalParameters : public RetrievalParameters {
  public:
@@ -117,6 +118,7 @@ class GammaIVFPQHIPIndex : public RetrievalModel {
   std::mutex perf_mu_;
   double perf_ms_[GAMMA_HIP_NUM_STAGES] = {0};
   gamma_hip_index *h_ = nullptr;
+  std::atomic<int64_t> blas_said_{0};   // WarnBlasCorners
   std::atomic<int64_t> ties_said_{0};   // WarnTiesNotHonoured: what this model has reported so far
   HIPIVFPQModelParams *model_param_ = nullptr;
   int64_t raw_uploaded_ = 0;

@@ -182,6 +182,13 @@ int gamma_hip_tie_stats(gamma_hip_index* h, int64_t* out3, int reset);
  * for it, because their shape is beyond the replay's range (see gamma_hip_set_exact_ties); the reference has no such
  * limit (faiss:utils/Heap.h:103-131, index/impl/gamma_index_ivfpq.cc:762-770) */
 int gamma_hip_ties_not_honoured(gamma_hip_index* h, int64_t* out_calls, int reset);
+/* Calls (searches, Add / assign, k-means iterations' assignments) whose GEMM-form coarse distances fell into a shape for
+ * which the compiled library's sgemm_ kernel is NOT restated (faiss:utils/distances.cpp:215-296 through MKL: K > 768 or an
+ * odd split, K = 384 with a database remainder block of 9..512 rows, remainder blocks of 1..7 rows -- nq mod 4096 or
+ * nlist mod 1024).  There the coarse distances of a few entries can differ from the library's by an ulp (measured:
+ * tests/test_oracle_vs_ref.py::test_unrestated_blas_corners_differ_by_ulps); every other shape is the library's bit for
+ * bit.  Counted, never silent; the plugins log a new count. */
+int gamma_hip_blas_form_not_restated(gamma_hip_index* h, int64_t* out_calls, int reset);
 
 /* ---- numeric scalar columns for on-device range filters (docid = row).  The engine side
  *      appends a doc's value when the doc is added (Table::Add, table/table.cc) ----------- */

@@ -1061,6 +1061,28 @@ def test_arena_repack_reclaims_abandoned_extents(case):
     g.close()
 
 
+def test_blas_corner_shapes_are_counted(case):
+    """gamma_hip_blas_form_not_restated: a search / Add whose GEMM-form coarse call has a shape the restatement of MKL's
+    sgemm_ does not cover is counted (never silent); the BASELINE shapes are not."""
+    from gamma_amd import api
+    g = fixtures.load_hip(case)
+    try:
+        args = api.SearchArgs(metric=case["metric"], nprobe=4, recall_num=20, has_rank=True, min_score=-1e30, max_score=1e30)
+        q = synth.sift_like(4099, d=case["d"], seed=9)
+        assert g.blas_form_not_restated(reset=True) == 0
+        g.ivfpq_search(q[:4096], 5, args)
+        g.ivfpq_search(q[:64], 5, args)
+        g.ivfpq_search(q[:10], 5, args)          # below 20 queries: the exact form, no BLAS at all
+        assert g.blas_form_not_restated() == 0
+        g.ivfpq_search(q, 5, args)               # 4099 = 4096 + a 3-row remainder block
+        assert g.blas_form_not_restated() == 1
+        g.encode(q[:4097])
+        assert g.blas_form_not_restated(reset=True) == 2
+        assert g.blas_form_not_restated() == 0
+    finally:
+        g.close()
+
+
 def _repack_script():
     """forced repacks between searches on a small index; prints the verify statistics and whether every state equalled the
     oracle's (run in-process and, with the fault injection, in a child process: the variable is read once per process)"""

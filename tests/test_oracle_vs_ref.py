@@ -130,6 +130,40 @@ def test_gemm_form_is_the_compiled_sgemm(kind):
         R.ref_set_blas_threshold(20)
 
 
+def test_unrestated_blas_corners_differ_by_ulps():
+    """What the shapes counted by gamma_hip_blas_form_not_restated cost: exhaustive_L2sqr_blas against the
+    restated GEMM form (oracle mode 1 = the device's default path) at a query remainder block of 1 / 3 rows (nq = 4097,
+    4099), a 3-row database remainder (nlist = 1027) and K = 384 with a 76-row database remainder.  Outside the remainder
+    rows / columns every distance is the library's bit for bit; inside, some entries differ -- by a few ulps of the
+    distance -- and a probe list can change only where two centroids are that close.  A shape right next to the corner
+    (nq = 4103: an 7-row remainder here happens to agree) is not required to differ."""
+    R = B.ref()
+    R.ref_set_blas_threshold(20)
+    rng = np.random.default_rng(0)
+    seen_diff = 0
+    for d, nx, ny, rows, cols in ((128, 4097, 256, slice(4096, None), slice(None)), (128, 4099, 1027, slice(4096, None), slice(None)),
+                                  (384, 40, 1100, slice(None), slice(1024, None))):
+        y = (rng.standard_normal((ny, d)) * 3).astype(np.float32)
+        x = rng.standard_normal((nx, d)).astype(np.float32)
+        D, I = _ref_flat(R.ref_flat_l2_search, x, y, ny)
+        D1, I1 = B.knn_L2sqr(x, y, ny, mode=1)
+        M = np.empty((nx, ny), np.float32)
+        M1 = np.empty((nx, ny), np.float32)
+        np.put_along_axis(M, I, D, axis=1)
+        np.put_along_axis(M1, I1, D1, axis=1)
+        diff = M.view(np.uint32) != M1.view(np.uint32)
+        inside = np.zeros_like(diff)
+        inside[rows, cols] = True
+        assert not (diff & ~inside).any(), (d, nx, ny)          # everything outside the remainder block: the library's bits
+        nd = int(diff.sum())
+        seen_diff += nd
+        if nd:
+            rel = np.abs(M[diff].astype(np.float64) - M1[diff]) / np.maximum(np.abs(M[diff]), 1e-30)
+            assert rel.max() < 4e-6, (d, nx, ny, rel.max())       # a few ulps of fp32
+            assert nd < 0.5 * inside.sum()
+    assert seen_diff > 0      # (if MKL on this machine ever agrees everywhere the corners can be dropped from the count)
+
+
 def _ref_flat(fn, x, y, k):
     D = np.empty((len(x), k), np.float32)
     I = np.empty((len(x), k), np.int64)
