@@ -1113,7 +1113,7 @@ def _repack_script():
                     g.add_keys(l, ids[lo:hi], cds[lo:hi])
             g.set_repack_threshold(1)          # repack now
             g.set_repack_threshold(1 << 40)
-            modes.append(bool(g.arena_growth()["in_place"]))
+            modes.append(bool(g.arena_growth()["mapped"]))
             for l in range(0, nlist, 7):
                 gi, gc = g.get_list(l)
                 hi = len(lists[l][0]) * (rnd + 1) // 4
