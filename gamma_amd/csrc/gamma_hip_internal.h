@@ -254,7 +254,7 @@ struct gamma_hip_index {
     // workspace
     DevBuf w_mat, w_coarse_dis, w_probe, w_xn, w_st2, w_pair_off, w_qtotal, w_dist, w_cand_dis,
             w_cand_pos, w_cand_ids, w_exact, w_selv, w_selp, w_x, w_outd, w_outl, w_stage, w_shard_cut, w_filter,
-            w_m_dis, w_m_ids, w_part_v, w_part_i, w_assign, w_codes_tmp, w_qperm, w_qbins, w_scnt, w_sflag, w_surv, w_pair_base,
+            w_m_dis, w_m_ids, w_part_v, w_part_i, w_assign, w_codes_tmp, w_qperm, w_qbins, w_scnt, w_sflag, w_surv, w_pair_base, w_q8, w_q8meta, w_q8cand, w_q8int,
             w_pair_ip, w_flat_cand, w_flat_meta, w_full_cdis, w_full_probe, w_ftab, w_qfil, w_tieflag, w_tcut, w_tlist, w_textra, w_fq, w_fraw, w_frcnt, w_lm_units, w_lm_cnt, w_fbits, w_cmp_codes, w_cmp_ids, w_cmp_len, w_cmp_sums, w_fD, w_fI, w_fx, w_fslab, w_flog, w_mr_vals, w_mr_ids, w_mr_meta,
             we_mat, we_cdis, we_x, we_assign, we_codes, we_stage, we_chk;   // writer side (encode, bitmap_set): never shared with a search
     unsigned long long* d_scan_codes = nullptr;

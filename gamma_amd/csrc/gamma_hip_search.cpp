@@ -367,7 +367,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     // the bounded scan's per-call state (repair list, ready words, survivor counts) is sized here, before the pair offsets,
     // whose kernel clears it together with the tie flags -- one launch instead of four fills in front of the scan
     const int cap = gh::scan_slice_cap(R);
-    bool cf_ok = false;
+    bool cf_ok = false, q8_ok = false;
     int PGM = PGN, nsl = PGN, cf_span = 0;
     unsigned long long* ready = nullptr;
     if (bounded) {
@@ -391,7 +391,18 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         // (and short-lists only: the pass stages SCAN_CF_CAP = 768 candidates per consumer workgroup)
         cf_ok = !no_cf && R <= 256 && (!h->prefiltered || h->cmp_has_sums) && PGN > 1 && mean_len <= cf_maxlen &&
                 gh::scan_cf_applies(l2, M, P, G, h->d_sums && h->d_t2max, false);
-        if (cf_ok) {
+        // list-major byte-table pass for the consumer probes (q8scan.hip, round 5): same conditions as the filter pass it
+        // replaces, one validity predicate for the whole call, not a shard (GAMMA_HIP_NO_Q8: the query-major pass, for A/B)
+        static const bool no_q8 = getenv("GAMMA_HIP_NO_Q8") != nullptr;
+        static const double q8_maxlen = getenv("GAMMA_HIP_Q8_MAXLEN") ? atof(getenv("GAMMA_HIP_Q8_MAXLEN")) : 1e12;
+        const int64_t q_stride0 = (std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len)) + 3) & ~(int64_t)3;
+        q8_ok = !no_q8 && !no_cf && R <= 256 && !shard && !h->prefiltered && !fc.d_qf && PGN > 1 && mean_len <= q8_maxlen &&
+                gh::scan_cf_applies(l2, M, P, G, h->d_sums && h->d_t2max, false) && gh::q8_supported(M, P, q_stride0);
+        if (q8_ok) cf_ok = false;
+        if (q8_ok) {
+            PGM = 1;   // the main launch: producers only
+            nsl = 2;   // slice 0: the producer's, slice 1: the consumers' (k_q8_exact)
+        } else if (cf_ok) {
             const int rest = P - G;
             int nc = (int)std::ceil(rest * mean_len / cf_codes);
             nc = std::max(1, std::min(nc, std::max(1, PGN - 1)));
@@ -400,7 +411,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         } else {
             PGM = PGN;   // probe groups of the main launch
         }
-        nsl = PGM;               // one survivor slice per probe group (slice 0: the producer's own)
+        if (!q8_ok) nsl = PGM;   // one survivor slice per probe group (slice 0: the producer's own)
         // rq | ready[nq] | gcnt[nq][nsl]   (rq: count + list of the queries that need the repair launch, 8-byte aligned)
         const size_t rq_bytes = (((size_t)nq + 1) * sizeof(int) + 7) & ~(size_t)7;
         GH_CHECK(h, h->w_scnt.ensure(rq_bytes + (size_t)nq * (sizeof(unsigned long long) + (size_t)nsl * sizeof(int))));
@@ -511,7 +522,49 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         sb.spins = spins_env;
         sb.timeouts = h->d_bound_stat + 4;
         sb.slice_cap = cap;
-        scan(G, 0, PGM, &sb, true);
+        if (!q8_ok) {
+            scan(G, 0, PGM, &sb, true);
+        } else {
+            // producers (the first G probes: exact, they publish the bounds), then the other probes list-major over byte
+            // tables -- all of it one "scan launch" for the stage clock and the roofline figure
+            StageScope t(h, GAMMA_HIP_STAGE_SCAN, true);
+            gh::launch_ivfpq_scan_pair(s, l2, d_x, nq, d, M, P, h->w_probe.as<int>(), dis0, h->d_cc, h->w_st2.as<float>(), h->d_T2,
+                                       h->d_list_off, h->d_list_len, h->d_list_mask, nlist, h->d_codes, h->d_ids,
+                                       h->w_pair_off.as<int>(), q_stride, h->w_dist.as<float>(), fc.d_tab, fc.d_qf, need_ids, qperm, G, 0,
+                                       1, 0, &sb, nullptr);
+            GH_CHECK(h, h->w_q8.ensure((size_t)nq * M * 256));
+            GH_CHECK(h, h->w_q8meta.ensure((size_t)nq * 4 * sizeof(float)));
+            GH_CHECK(h, h->w_q8cand.ensure((size_t)nq * gh::q8_cand_cap() * sizeof(uint32_t)));
+            GH_CHECK(h, h->w_q8int.ensure(gh::q8_int_words(nq, P, G, nlist) * sizeof(int)));
+            gh::Q8Args qa;
+            qa.nq = nq; qa.P = P; qa.G = G; qa.M = M; qa.nlist = nlist;
+            qa.probe_list = h->w_probe.as<int>();
+            qa.coarse_dis = dis0;
+            qa.st2 = h->w_st2.as<float>();
+            qa.T2 = h->d_T2;
+            qa.t2max = h->d_t2max;
+            qa.sums = h->d_sums;
+            qa.codes = h->d_codes;
+            qa.ids = h->d_ids;
+            qa.list_off = h->d_list_off;
+            qa.list_len = h->d_list_len;
+            qa.list_mask = h->d_list_mask;
+            qa.pair_off = h->w_pair_off.as<int>();
+            qa.ready = sb.ready;
+            qa.ftab = fc.d_tab;
+            qa.need_ids = need_ids;
+            qa.surv = sb.surv;
+            qa.gcnt = sb.gcnt;
+            qa.cnt_stride = nsl;
+            qa.slice_cap = cap;
+            qa.rq_list = sb.rq_list;
+            qa.rq_count = sb.rq_count;
+            qa.q8 = h->w_q8.as<uint8_t>();
+            qa.meta = reinterpret_cast<float4*>(h->w_q8meta.p);
+            qa.cand = h->w_q8cand.as<uint32_t>();
+            qa.iwork = h->w_q8int.as<int>();
+            gh::launch_q8_consumers(s, qa);
+        }
         // GAMMA_HIP_BOUND_DBG=1: the bounded scan's statistics of the 9th .. 14th call; =shard: of list-shard calls only
         static const bool dbg_any = getenv("GAMMA_HIP_BOUND_DBG") != nullptr;
         static const bool dbg_shard = dbg_any && getenv("GAMMA_HIP_BOUND_DBG")[0] == 's';

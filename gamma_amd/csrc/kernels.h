@@ -174,6 +174,38 @@ struct ScanBound {
     unsigned long long* timeouts;   // consumers that gave up waiting (diagnostics; may be nullptr)
     int slice_cap;              // items a slice holds: scan_slice_cap(K)
 };
+// ---- q8scan.hip: the consumer probes of a bounded L2 scan, list-major over byte tables (one list x 8 queries per tile) ----
+struct Q8Args {
+    int nq, P, G, M, nlist;
+    const int* probe_list;            // [nq][P]
+    const float* coarse_dis;          // [nq][P] dis0
+    const float* st2;                 // [nq][M][256] fp32 inner-product tables (k_pq_ip_table)
+    const float* T2;                  // [nlist][M][256]
+    const float* t2max;               // [nlist]
+    const float* sums;                // per arena entry: sum_m T2[list][m][code[m]]
+    const uint8_t* codes;
+    const int64_t* ids;
+    const int64_t* list_off;
+    const int* list_len;
+    const uint8_t* list_mask;
+    const int* pair_off;              // [nq][P + 1]
+    const unsigned long long* ready;  // [nq] the producers' bounds
+    const FilterDesc* ftab;           // entry 0: the call's validity predicate (need_ids)
+    int need_ids;
+    unsigned long long* surv;         // survivor slices [nq][cnt_stride][slice_cap]; slice 1 is written here
+    int* gcnt;
+    int cnt_stride, slice_cap;
+    int* rq_list;                     // queries without a bound are appended (their consumer groups are scored by the repair launch)
+    int* rq_count;
+    uint8_t* q8;                      // workspace [nq][M][256]
+    float4* meta;                     // workspace [nq]
+    uint32_t* cand;                   // workspace [nq][q8_cand_cap()]
+    int* iwork;                       // workspace q8_int_words(..) ints
+};
+bool q8_supported(int M, int P, int64_t q_stride);
+int q8_cand_cap();
+size_t q8_int_words(int nq, int P, int G, int nlist);
+void launch_q8_consumers(hipStream_t s, const Q8Args& a);
 int scan_slice_cap(int K);   // 1024 up to recall_num 256, 2048 up to 1024
 // true when launch_ivfpq_scan_pair would run the filter pass (CF) for a bounded scan with these arguments; the caller
 // then launches TWO groups per query -- the producer's G probes and one consumer group with all the others

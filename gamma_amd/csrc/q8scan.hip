@@ -1,0 +1,476 @@
+// q8scan.hip -- a6, list-major: the consumer side of the bounded L2 list scan re-mapped from "one query per workgroup"
+// to "one inverted list x a tile of 8 of the queries that probe it" (VERDICT r4 #3).
+//
+// Why the mapping had to change, and why with BYTE tables.  The query-major filter pass (scan.hip, CF) issues one
+// ds_read_b32 gather per (query, code, sub-quantizer): 64 random addresses in one 256-entry table row, ~3.5-way bank
+// conflicts, 57 % of the LDS cycles (profiles/r04_pmc_scan_summary.json), and every one of the ~128 queries that probe a
+// list in a 16384-query batch reads the list's codes again.  A gather can only serve several queries if their table
+// entries for the same code byte sit side by side in LDS, i.e. if the workgroup's queries all want the SAME code: list-major.
+// Round 2 tried that with the fp32 tables (scan_lm.hip: two queries per pass, 58 % of the vector instructions, but 1.07 ms
+// against 0.70 ms -- a 16 KB table per (query, list) pair through the L2 costs more than the 4 KB of codes it is used on).
+// The filter pass, however, does not need the table's exact values -- it only has to PROVE a code outside the bound, and
+// the few codes it cannot prove outside are recomputed exactly afterwards (as in CF).  So the table travels as BYTES:
+//     ip[q][m][c]  ~  lo[q][m] + delta[q] * u8[q][m][c],   |error| <= 0.5001 delta per entry,
+// 4 KB per (query, list) pair instead of 16, eight queries' bytes in one 8-byte LDS entry:
+//     LDS  lut[m][c + (c >> 3)] = { u8 of the tile's 8 queries }      (one pad entry per 8: conflict-free staging stores)
+// and ONE ds_read_b64 per (code, m) serves eight queries; the per-query sums are integers (v_dot4_u32_u8 with a one-hot
+// selector), exact.  With  U = sum_m u8[q][m][c_m]  the true value of the reference's ADC
+//     v = dis0 + sum_m fma(-2, ip[q][m][c_m], T2[l][m][c_m])         (gamma_index_ivfpq.h:575-601, sequential fp32)
+// satisfies  v >= (dis0 - 2 sum_m lo - 1.02 M delta) + s_j - 2 delta U - 50 * 2^-24 S   with the per-code table sum s_j and
+// the magnitude bound S of the CF pass (scan.hip), so a code is kept as a CANDIDATE iff
+//     (A_q + s_j) - 2 delta_q U  <=  tau_q + 2^-16 S ,   A_q = dis0 - cq_q,  cq_q = 2 sum_m lo + 1.02 M delta .
+// Candidates (a few % of the codes; ~20 % more than the fp32 filter lets through) go to a per-query list; k_q8_exact -- one
+// workgroup per query, the query's fp32 table in LDS -- gives them the reference's exact value in the reference's order of
+// operations and appends those within the bound to the query's consumer slice: the same (key, position) items the CF pass
+// and the regular loop would have put there, so k_select_final, the repair launch and the tie replay are unchanged.
+//
+// Launches (launch_q8_consumers): tables -> bytes | pairs counted per list | offsets, tiles | pairs filled | filter | exact.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "block_utils.h"
+#include "device_math.h"
+#include "filter_dev.h"
+#include "kernels.h"
+#include "scan_dev.h"
+
+namespace gh {
+
+namespace {
+constexpr int Q8_T = 8;          // queries per tile
+constexpr int Q8_ROW = 288;      // LUT entries per sub-quantizer row: 256 + one pad per 8
+constexpr int Q8_STG = 64;       // candidates staged per (tile, query); more = the query takes the unfiltered path
+constexpr int Q8_POS_BITS = 25;  // candidate = position in the query's segment | probe << 25
+}  // namespace
+
+int q8_cand_cap() { return 768; }
+
+// ------------------------------------------------------------------------------------
+// u8 image of every query's inner-product table (k_pq_ip_table's st2): one workgroup per query, thread = code word c.
+// meta[q] = { cq = 2 sum_m lo_m + 1.02 M delta,  -2 delta,  max |entry|,  0 }
+// ------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256) void k_q8_quant(const float* __restrict__ st2, uint8_t* __restrict__ q8,
+                                                  float4* __restrict__ meta) {
+    __shared__ float s_mn[MT][4], s_mx[MT][4];
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float v[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) v[m] = st2[((int64_t)q * MT + m) * 256 + tid];
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        float mn = v[m], mx = v[m];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn = fminf(mn, __shfl_xor(mn, o, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        }
+        if (lane == 0) {
+            s_mn[m][wv] = mn;
+            s_mx[m][wv] = mx;
+        }
+    }
+    __syncthreads();
+    float lo[MT], range = 0.f, L = 0.f, amax = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        lo[m] = fminf(fminf(s_mn[m][0], s_mn[m][1]), fminf(s_mn[m][2], s_mn[m][3]));
+        const float hi = fmaxf(fmaxf(s_mx[m][0], s_mx[m][1]), fmaxf(s_mx[m][2], s_mx[m][3]));
+        range = fmaxf(range, hi - lo[m]);
+        L += lo[m];
+        amax = fmaxf(amax, fmaxf(fabsf(lo[m]), fabsf(hi)));
+    }
+    // delta a few ulps above range / 255: (hi - lo) / delta stays below 255.5 whatever the roundings
+    const float delta = (range / 255.f) * 1.000001f;
+    const float inv = delta > 0.f ? 1.f / delta : 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        int u = (int)rintf((v[m] - lo[m]) * inv);
+        u = min(255, max(0, u));
+        q8[((int64_t)q * MT + m) * 256 + tid] = (uint8_t)u;
+    }
+    if (tid == 0) meta[q] = make_float4(2.f * L + 1.02f * (float)MT * delta, -2.f * delta, amax, 0.f);
+}
+
+// ------------------------------------------------------------------------------------
+// The consumer pairs (query, probe >= G) of the queries WITH a bound, grouped by list: count | fill.
+// A query WITHOUT a bound goes to the repair list (its consumer groups are scored with stores by the repair launch:
+// the unfiltered selection reads the slab).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_q8_pairs(const int* __restrict__ probe_list, int nq, int P, int G,
+                                                  const unsigned long long* __restrict__ ready, const int* __restrict__ list_len,
+                                                  const uint8_t* __restrict__ list_mask, int nlist, int* __restrict__ cnt,
+                                                  int* __restrict__ cur, const int* __restrict__ off, int* __restrict__ items,
+                                                  int* __restrict__ rq_list, int* __restrict__ rq_count) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int per = P - G;
+    const int q = (int)(idx / per), p = G + (int)(idx % per);
+    if (q >= nq) return;
+    if ((ready[q] >> 32) != 1ull) {
+        if (!cur && p == G) rq_list[atomicAdd(rq_count, 1)] = q;
+        return;
+    }
+    const int l = probe_list[(int64_t)q * P + p];
+    if (l < 0 || l >= nlist || (list_mask && !list_mask[l]) || list_len[l] <= 0) return;
+    if (!cur) atomicAdd(&cnt[l], 1);
+    else items[off[l] + atomicAdd(&cur[l], 1)] = q * P + p;
+}
+
+// offsets of the lists' pair runs, the tiles of 8 pairs, the tile -> list table; one workgroup
+__global__ __launch_bounds__(1024) void k_q8_offsets(const int* __restrict__ cnt, int nlist, int* __restrict__ off,
+                                                     int* __restrict__ tile_first, int* __restrict__ tile_list,
+                                                     int* __restrict__ n_tiles) {
+    __shared__ int s_c[1024], s_t[1024];
+    const int tid = threadIdx.x;
+    const int per = (nlist + 1023) / 1024, a = min(nlist, tid * per), b = min(nlist, a + per);
+    int c = 0, t = 0;
+    for (int l = a; l < b; l++) {
+        c += cnt[l];
+        t += (cnt[l] + Q8_T - 1) / Q8_T;
+    }
+    s_c[tid] = c;
+    s_t[tid] = t;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {   // inclusive scans
+        const int ac = tid >= o ? s_c[tid - o] : 0, at = tid >= o ? s_t[tid - o] : 0;
+        __syncthreads();
+        s_c[tid] += ac;
+        s_t[tid] += at;
+        __syncthreads();
+    }
+    int oc = s_c[tid] - c, ot = s_t[tid] - t;
+    for (int l = a; l < b; l++) {
+        off[l] = oc;
+        tile_first[l] = ot;
+        const int nt = (cnt[l] + Q8_T - 1) / Q8_T;
+        for (int i = 0; i < nt; i++) tile_list[ot + i] = l;
+        oc += cnt[l];
+        ot += nt;
+    }
+    if (tid == 1023) {
+        off[nlist] = s_c[1023];
+        tile_first[nlist] = s_t[1023];
+        *n_tiles = s_t[1023];
+    }
+}
+
+// 4x4 byte transpose of the dwords a0..a3: t_j byte i = a_i byte j
+__device__ __forceinline__ void tr4x4(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t& t0, uint32_t& t1,
+                                      uint32_t& t2, uint32_t& t3) {
+    const uint32_t p0 = __builtin_amdgcn_perm(a1, a0, 0x05010400u), p1 = __builtin_amdgcn_perm(a1, a0, 0x07030602u);
+    const uint32_t p2 = __builtin_amdgcn_perm(a3, a2, 0x05010400u), p3 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
+    t0 = __builtin_amdgcn_perm(p2, p0, 0x05040100u);
+    t1 = __builtin_amdgcn_perm(p2, p0, 0x07060302u);
+    t2 = __builtin_amdgcn_perm(p3, p1, 0x05040100u);
+    t3 = __builtin_amdgcn_perm(p3, p1, 0x07060302u);
+}
+
+// sum += byte k of w (exact integer)
+template <int K>
+__device__ __forceinline__ uint32_t add_byte(uint32_t acc, uint32_t w) {
+    return __builtin_amdgcn_udot4(w, 1u << (8 * K), acc, false);
+}
+
+// ------------------------------------------------------------------------------------
+// The filter: a persistent grid walks the tiles.  256 threads; a wave takes 64 codes of the list per step.
+// ------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256) void k_q8_filter(
+        const int* __restrict__ tile_list, const int* __restrict__ tile_first, const int* __restrict__ n_tiles,
+        const int* __restrict__ pair_run, const int* __restrict__ items, const unsigned long long* __restrict__ ready,
+        const float* __restrict__ coarse_dis, const float* __restrict__ t2max, const float4* __restrict__ meta,
+        const uint8_t* __restrict__ q8, const uint8_t* __restrict__ codes, const float* __restrict__ sums,
+        const int64_t* __restrict__ ids, const int64_t* __restrict__ list_off, const int* __restrict__ list_len,
+        const int* __restrict__ pair_off, int P, const FilterDesc* __restrict__ ftab, int need_ids,
+        uint32_t* __restrict__ cand, int* __restrict__ ccnt, int cand_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_q8[];
+    unsigned char* lut = s_q8;                                                              // [MT][Q8_ROW][8]
+    float* s_A = reinterpret_cast<float*>(s_q8 + (size_t)MT * Q8_ROW * 8);                  // [8] dis0 - cq
+    float* s_nd = s_A + 8;                                                                  // [8] -2 delta
+    float* s_thr = s_nd + 8;                                                                // [8]
+    int* s_q = reinterpret_cast<int*>(s_thr + 8);                                           // [8] query (-1: empty slot)
+    int* s_pb = s_q + 8;                                                                    // [8] segment position of the pair's list
+    int* s_pp = s_pb + 8;                                                                   // [8] probe
+    int* s_n = s_pp + 8;                                                                    // [8] candidates
+    int* s_g = s_n + 8;                                                                     // [8] base in the query's list
+    int* s_cj = s_g + 8;                                                                    // [8][Q8_STG]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ntile = *n_tiles;
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int l = tile_list[tile];
+        const int first = pair_run[l] + Q8_T * (tile - tile_first[l]);
+        const int nit = min(Q8_T, pair_run[l + 1] - first);
+        if (tid < Q8_T) {
+            int q = -1, pb = 0, pp = 0;
+            float A = 0.f, nd = 0.f, thr = -INFINITY;
+            if (tid < nit) {
+                const int pair = items[first + tid];
+                q = pair / P;
+                pp = pair - q * P;
+                pb = pair_off[(int64_t)q * (P + 1) + pp];
+                const float4 mq = meta[q];
+                const float dis0 = coarse_dis[pair];
+                const uint32_t tk = (uint32_t)ready[q];
+                const float tau = key2f(tk);
+                const float S = fabsf(dis0) + t2max[l] + 32.f * mq.z;
+                thr = __builtin_fmaf(S, 1.f / 65536.f, tau);
+                thr += fabsf(thr) * 2.4e-7f;   // the threshold's own roundings
+                A = dis0 - mq.x;
+                nd = mq.y;
+            }
+            s_q[tid] = q;
+            s_pb[tid] = pb;
+            s_pp[tid] = pp;
+            s_A[tid] = A;
+            s_nd[tid] = nd;
+            s_thr[tid] = thr;
+            s_n[tid] = 0;
+        }
+        __syncthreads();
+        // ---- the tile's table: 8 queries' bytes side by side.  A thread takes (m, 8 consecutive code words) blocks ----
+        for (int bi = tid; bi < MT * 32; bi += 256) {
+            const int m = bi >> 5, cb = bi & 31;
+            uint2 r[Q8_T];
+#pragma unroll
+            for (int i = 0; i < Q8_T; i++) {
+                const int q = s_q[i];
+                r[i] = q >= 0 ? *reinterpret_cast<const uint2*>(q8 + ((int64_t)q * MT + m) * 256 + cb * 8) : make_uint2(0u, 0u);
+            }
+            uint32_t xl[4], xh[4], yl[4], yh[4];
+            tr4x4(r[0].x, r[1].x, r[2].x, r[3].x, xl[0], xl[1], xl[2], xl[3]);   // code words 0..3, queries 0..3
+            tr4x4(r[4].x, r[5].x, r[6].x, r[7].x, xh[0], xh[1], xh[2], xh[3]);   //                 queries 4..7
+            tr4x4(r[0].y, r[1].y, r[2].y, r[3].y, yl[0], yl[1], yl[2], yl[3]);   // code words 4..7
+            tr4x4(r[4].y, r[5].y, r[6].y, r[7].y, yh[0], yh[1], yh[2], yh[3]);
+            uint2* dst = reinterpret_cast<uint2*>(lut + ((size_t)m * Q8_ROW + cb * 9) * 8);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                dst[j] = make_uint2(xl[j], xh[j]);
+                dst[4 + j] = make_uint2(yl[j], yh[j]);
+            }
+        }
+        __syncthreads();
+        // ---- the list's codes ----
+        const int len = list_len[l];
+        const int64_t off = list_off[l];
+        const uint8_t* lc = codes + off * MT;
+        const float* ls = sums + off;
+        const int64_t* lid = ids + off;
+        for (int j0 = wv * 64; j0 < len; j0 += 256) {
+            const int j = j0 + lane, jc = min(j, len - 1);
+            uint32_t cw[MT / 4];
+            {
+                const uint4* cp = reinterpret_cast<const uint4*>(lc + (int64_t)jc * MT);
+#pragma unroll
+                for (int u = 0; u < MT / 16; u++) {
+                    const uint4 cv = cp[u];
+                    cw[4 * u] = cv.x; cw[4 * u + 1] = cv.y; cw[4 * u + 2] = cv.z; cw[4 * u + 3] = cv.w;
+                }
+            }
+            const float sj = ls[jc];
+            bool ok = j < len;
+            if (need_ids) {
+                const int64_t id = lid[jc];
+                ok = ok && id >= 0;
+                if (ok) ok = is_valid_doc(ftab[0], id);
+            }
+            uint2 t[MT];
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                const uint32_t c = (cw[m >> 2] >> (8 * (m & 3))) & 255u;
+                const uint32_t e = c + (c >> 3);
+                t[m] = *reinterpret_cast<const uint2*>(lut + (size_t)m * Q8_ROW * 8 + e * 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // all gathers in flight before the sums
+            uint32_t acc[Q8_T] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                acc[0] = add_byte<0>(acc[0], t[m].x);
+                acc[1] = add_byte<1>(acc[1], t[m].x);
+                acc[2] = add_byte<2>(acc[2], t[m].x);
+                acc[3] = add_byte<3>(acc[3], t[m].x);
+                acc[4] = add_byte<0>(acc[4], t[m].y);
+                acc[5] = add_byte<1>(acc[5], t[m].y);
+                acc[6] = add_byte<2>(acc[6], t[m].y);
+                acc[7] = add_byte<3>(acc[7], t[m].y);
+            }
+#pragma unroll
+            for (int i = 0; i < Q8_T; i++) {
+                const float lhs = __builtin_fmaf(s_nd[i], (float)acc[i], s_A[i] + sj);
+                const bool pass = ok && lhs <= s_thr[i];
+                const unsigned long long bal = __ballot(pass);
+                if (bal) {   // uniform per wave
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&s_n[i], __popcll(bal));
+                    base = __shfl(base, 0, 64);
+                    const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (pass && slot < Q8_STG) s_cj[i * Q8_STG + slot] = j;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- the candidates of each of the tile's queries into its list (one returning atomic per pair) ----
+        if (tid < nit) {
+            const int n = s_n[tid];
+            int g = 0;
+            if (n > Q8_STG) g = atomicAdd(&ccnt[s_q[tid]], cand_cap + 1);   // more than the stage holds: the query takes the unfiltered path
+            else if (n > 0) g = atomicAdd(&ccnt[s_q[tid]], n);
+            s_g[tid] = g;
+        }
+        __syncthreads();
+        {
+            const int i = tid >> 5, k0 = tid & 31;
+            if (i < nit) {
+                const int n = s_n[i], g = s_g[i];
+                if (n <= Q8_STG)
+                    for (int k = k0; k < n; k += 32)
+                        if (g + k < cand_cap)
+                            cand[(int64_t)s_q[i] * cand_cap + g + k] = (uint32_t)(s_pb[i] + s_cj[i * Q8_STG + k]) | ((uint32_t)s_pp[i] << Q8_POS_BITS);
+            }
+        }
+        __syncthreads();   // the tile's LDS is free
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// The candidates' exact values, one workgroup per query (the query's fp32 table in LDS): what the regular loop computes
+// for these codes -- fma and adds in the reference's order -- and the query's consumer slice (slice 1 of 2) as the CF
+// pass would have written it.
+// ------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256) void k_q8_exact(const float* __restrict__ st2, const float* __restrict__ T2, int nq, int P,
+                                                  const int* __restrict__ probe_list, const float* __restrict__ coarse_dis,
+                                                  const int64_t* __restrict__ list_off, const uint8_t* __restrict__ codes,
+                                                  const int* __restrict__ pair_off, const unsigned long long* __restrict__ ready,
+                                                  const uint32_t* __restrict__ cand, const int* __restrict__ ccnt, int cand_cap,
+                                                  unsigned long long* __restrict__ surv, int* __restrict__ gcnt, int cnt_stride,
+                                                  int slice_cap) {
+    __shared__ float s_lut[MT * 256];
+    __shared__ unsigned long long s_stage[256];
+    __shared__ int s_nstage;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const unsigned long long word = ready[q];
+    if ((word >> 32) != 1ull) {   // no bound: repair list (k_q8_pairs)
+        if (tid == 0) gcnt[(int64_t)q * cnt_stride + 1] = 0;
+        return;
+    }
+    const int n = ccnt[q];
+    if (n > cand_cap) {   // more candidates than the list holds: the slice reads as overflowed, k_select_final sends the
+        if (tid == 0) gcnt[(int64_t)q * cnt_stride + 1] = slice_cap + 1;   // query to the repair launch
+        return;
+    }
+    if (tid == 0) s_nstage = 0;
+    if (n > 0)
+        for (int e = tid; e < MT * 256; e += 256) s_lut[e] = st2[(int64_t)q * MT * 256 + e];
+    __syncthreads();
+    const float tau_f = key2f((uint32_t)word);
+    const int64_t slice = (int64_t)q * cnt_stride + 1;
+    for (int c0 = 0; c0 < n; c0 += 256) {   // uniform trip count: ballots below
+        const int c = c0 + tid;
+        bool keep = false;
+        float dis = 0.f;
+        int pos = 0;
+        if (c < n) {
+            const uint32_t cd = cand[(int64_t)q * cand_cap + c];
+            pos = (int)(cd & ((1u << Q8_POS_BITS) - 1u));
+            const int p = (int)(cd >> Q8_POS_BITS), pair = q * P + p;
+            const int l = probe_list[pair];
+            const int j = pos - pair_off[(int64_t)q * (P + 1) + p];
+            const uint8_t* cj = codes + (list_off[l] + j) * MT;
+            const float* t2 = T2 + (int64_t)l * MT * 256;
+            uint32_t cw[MT / 4];
+#pragma unroll
+            for (int u = 0; u < MT / 16; u++) {
+                const uint4 cv = reinterpret_cast<const uint4*>(cj)[u];
+                cw[4 * u] = cv.x; cw[4 * u + 1] = cv.y; cw[4 * u + 2] = cv.z; cw[4 * u + 3] = cv.w;
+            }
+            dis = coarse_dis[pair];
+#pragma unroll
+            for (int m0 = 0; m0 < MT; m0 += 8) {   // eight table entries in flight at a time
+                float a[8];
+#pragma unroll
+                for (int m = 0; m < 8; m++) a[m] = t2[(m0 + m) * 256 + ((cw[(m0 + m) >> 2] >> (8 * (m & 3))) & 255u)];
+#pragma unroll
+                for (int m = 0; m < 8; m++)   // the regular loop's table entry and its adds, in the reference's order
+                    dis += __builtin_fmaf(-2.0f, s_lut[(m0 + m) * 256 + ((cw[(m0 + m) >> 2] >> (8 * (m & 3))) & 255u)], a[m]);
+            }
+            keep = dis <= tau_f;
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (bal) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_nstage, __popcll(bal));
+            base = __shfl(base, 0, 64);
+            if (keep) {
+                const int at = base + __popcll(bal & ((1ull << lane) - 1ull));
+                const unsigned long long item = ((unsigned long long)dis_key<true>(dis) << 32) | (unsigned)pos;
+                if (at < 256) s_stage[at] = item;
+                else if (at < slice_cap) surv[slice * slice_cap + at] = item;
+            }
+        }
+    }
+    __syncthreads();
+    const int ns = s_nstage;
+    if (tid == 0) gcnt[slice] = ns;
+    for (int i = tid; i < min(ns, 256); i += 256) surv[slice * slice_cap + i] = s_stage[i];
+}
+
+bool q8_supported(int M, int P, int64_t q_stride) { return (M == 16 || M == 32) && P <= 128 && q_stride < ((int64_t)1 << Q8_POS_BITS); }
+
+// workspace: [cnt nlist | cur nlist | ccnt nq] (zeroed here) | off nlist+1 | tile_first nlist+1 | n_tiles 1 | tile_list | items
+size_t q8_int_words(int nq, int P, int G, int nlist) {
+    const int64_t pairs = (int64_t)nq * (P - G);
+    return (size_t)(2 * (int64_t)nlist + nq + 2 * ((int64_t)nlist + 1) + 1 + (pairs / Q8_T + nlist + 1) + pairs + 16);
+}
+
+void launch_q8_consumers(hipStream_t s, const Q8Args& a) {
+    if (a.nq <= 0 || a.P <= a.G) return;
+    const int nq = a.nq, P = a.P, G = a.G, nlist = a.nlist, M = a.M;
+    int* w = a.iwork;
+    int* cnt = w;
+    int* cur = cnt + nlist;
+    int* ccnt = cur + nlist;
+    int* off = ccnt + nq;
+    int* tile_first = off + nlist + 1;
+    int* n_tiles = tile_first + nlist + 1;
+    int* tile_list = n_tiles + 1;
+    const int64_t pairs = (int64_t)nq * (P - G);
+    int* items = tile_list + (pairs / Q8_T + nlist + 1);
+    (void)hipMemsetAsync(cnt, 0, (size_t)(2 * (int64_t)nlist + nq) * sizeof(int), s);
+    const unsigned pg = (unsigned)((pairs + 255) / 256);
+    const int cap = q8_cand_cap();
+    if (M == 16) hipLaunchKernelGGL((k_q8_quant<16>), dim3(nq), dim3(256), 0, s, a.st2, a.q8, a.meta);
+    else hipLaunchKernelGGL((k_q8_quant<32>), dim3(nq), dim3(256), 0, s, a.st2, a.q8, a.meta);
+    hipLaunchKernelGGL(k_q8_pairs, dim3(pg), dim3(256), 0, s, a.probe_list, nq, P, G, a.ready, a.list_len, a.list_mask, nlist, cnt,
+                       (int*)nullptr, (const int*)nullptr, (int*)nullptr, a.rq_list, a.rq_count);
+    hipLaunchKernelGGL(k_q8_offsets, dim3(1), dim3(1024), 0, s, cnt, nlist, off, tile_first, tile_list, n_tiles);
+    hipLaunchKernelGGL(k_q8_pairs, dim3(pg), dim3(256), 0, s, a.probe_list, nq, P, G, a.ready, a.list_len, a.list_mask, nlist, cnt,
+                       cur, off, items, a.rq_list, a.rq_count);
+    // LUT | per-slot words | candidate stage
+    const size_t lds = (size_t)M * Q8_ROW * 8 + 9 * 8 * sizeof(int) + (size_t)Q8_T * Q8_STG * sizeof(int);
+    const int per_cu = std::max(1, std::min(8, (int)((160 * 1024) / (lds + 512))));
+    static const int grid_env = getenv("GAMMA_HIP_Q8_GRID") ? atoi(getenv("GAMMA_HIP_Q8_GRID")) : 0;
+    const unsigned grid = grid_env > 0 ? (unsigned)grid_env : (unsigned)(256 * per_cu);
+    if (M == 16) {
+        hipLaunchKernelGGL((k_q8_filter<16>), dim3(grid), dim3(256), lds, s, tile_list, tile_first, n_tiles, off, items, a.ready,
+                           a.coarse_dis, a.t2max, a.meta, a.q8, a.codes, a.sums, a.ids, a.list_off, a.list_len, a.pair_off, P,
+                           a.ftab, a.need_ids, a.cand, ccnt, cap);
+        hipLaunchKernelGGL((k_q8_exact<16>), dim3(nq), dim3(256), 0, s, a.st2, a.T2, nq, P, a.probe_list, a.coarse_dis, a.list_off,
+                           a.codes, a.pair_off, a.ready, a.cand, ccnt, cap, a.surv, a.gcnt, a.cnt_stride, a.slice_cap);
+    } else {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_q8_filter<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+            attr = true;
+        }
+        hipLaunchKernelGGL((k_q8_filter<32>), dim3(grid), dim3(256), lds, s, tile_list, tile_first, n_tiles, off, items, a.ready,
+                           a.coarse_dis, a.t2max, a.meta, a.q8, a.codes, a.sums, a.ids, a.list_off, a.list_len, a.pair_off, P,
+                           a.ftab, a.need_ids, a.cand, ccnt, cap);
+        hipLaunchKernelGGL((k_q8_exact<32>), dim3(nq), dim3(256), 0, s, a.st2, a.T2, nq, P, a.probe_list, a.coarse_dis, a.list_off,
+                           a.codes, a.pair_off, a.ready, a.cand, ccnt, cap, a.surv, a.gcnt, a.cnt_stride, a.slice_cap);
+    }
+}
+
+}  // namespace gh

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
                 const unsigned long long item = ((unsigned long long)dis_key<L2>(val) << 32) | (unsigned)pos;
                 if (at < SCAN_STAGE) s_stage[at] = item;
                 else if (at < sb.slice_cap)   // staging full (rare): the slot number is already unique
-                    sb.surv[((int64_t)q * pg_cnt + pg) * sb.slice_cap + at] = item;
+                    sb.surv[((int64_t)q * sb.cnt_stride + pg) * sb.slice_cap + at] = item;
             }
         }
     };
@@ -168,8 +168,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
     auto flush = [&]() {   // whole workgroup
         __syncthreads();
         const int n = s_nstage;
-        const int64_t slice = (int64_t)q * pg_cnt + pg;
-        if (threadIdx.x == 0) sb.gcnt[(int64_t)q * sb.cnt_stride + pg] = n;
+        const int64_t slice = (int64_t)q * sb.cnt_stride + pg;   // (cnt_stride = slices per query: the groups of this launch, or more)
+        if (threadIdx.x == 0) sb.gcnt[slice] = n;
         for (int i = threadIdx.x; i < min(n, SCAN_STAGE); i += 256) sb.surv[slice * sb.slice_cap + i] = s_stage[i];
     };
     // (CF: the LAST group takes every probe behind the ones before it -- its table is the query's, not a list's, so
