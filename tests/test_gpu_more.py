@@ -1143,8 +1143,8 @@ def test_arena_repack_publishes_only_what_reads_back():
     assert c.returncode == 0, c.stdout[-2000:] + c.stderr[-3000:]
     rf = json.loads([l for l in c.stdout.splitlines() if l.startswith("RES ")][-1][4:])
     assert rf["ok"] and rf["stats"]["failures"] == 1 and rf["stats"]["verified"] == rf["repacks"] + 1, rf
-    if r["in_place"][0]:                       # (a runtime without virtual memory management starts outside it)
-        assert rf["in_place"] == [False] * len(rf["in_place"]), rf
+    if r["in_place"][-1]:                      # (a runtime without virtual memory management starts outside it)
+        assert not rf["in_place"][-1], rf      # the arena left virtual memory management at the failed read-back
 
 
 def test_add_keys_batch_counts_superseded_slots(case):
