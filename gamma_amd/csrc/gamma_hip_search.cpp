@@ -395,13 +395,17 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         // replaces, one validity predicate for the whole call, not a shard (GAMMA_HIP_NO_Q8: the query-major pass, for A/B)
         static const bool no_q8 = getenv("GAMMA_HIP_NO_Q8") != nullptr;
         static const double q8_maxlen = getenv("GAMMA_HIP_Q8_MAXLEN") ? atof(getenv("GAMMA_HIP_Q8_MAXLEN")) : 1e12;
+        // (long lists: a tile's table staging and its chain of dependent loads are amortised over thousands of codes; at C3's
+        //  244 codes per list a tile is one step of 64 codes per wave and the pass is latency-bound -- measured slower than the
+        //  query-major pass there, profiles/r05_q8_*.txt -- so short lists keep the query-major filter pass)
+        static const double q8_minlen = getenv("GAMMA_HIP_Q8_MINLEN") ? atof(getenv("GAMMA_HIP_Q8_MINLEN")) : 1000.0;
         const int64_t q_stride0 = (std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len)) + 3) & ~(int64_t)3;
         q8_ok = !no_q8 && !no_cf && R <= 256 && !shard && !h->prefiltered && !fc.d_qf && PGN > 1 && mean_len <= q8_maxlen &&
-                gh::scan_cf_applies(l2, M, P, G, h->d_sums && h->d_t2max, false) && gh::q8_supported(M, P, q_stride0);
+                gh::scan_cf_applies(l2, M, P, G, h->d_sums && h->d_t2max, false) && gh::q8_supported(M, P, G, q_stride0) && mean_len >= q8_minlen;
         if (q8_ok) cf_ok = false;
         if (q8_ok) {
-            PGM = 1;   // the main launch: producers only
-            nsl = 2;   // slice 0: the producer's, slice 1: the consumers' (k_q8_exact)
+            PGM = 1;     // the main launch: producers only
+            nsl = PGN;   // slice 0: the producer's, slices 1 ..: the consumer probe groups' (k_q8_exact)
         } else if (cf_ok) {
             const int rest = P - G;
             int nc = (int)std::ceil(rest * mean_len / cf_codes);
@@ -534,7 +538,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
                                        1, 0, &sb, nullptr);
             GH_CHECK(h, h->w_q8.ensure((size_t)nq * M * 256));
             GH_CHECK(h, h->w_q8meta.ensure((size_t)nq * 4 * sizeof(float)));
-            GH_CHECK(h, h->w_q8cand.ensure((size_t)nq * gh::q8_cand_cap() * sizeof(uint32_t)));
+            GH_CHECK(h, h->w_q8cand.ensure((size_t)nq * gh::q8_cand_cap(nq) * sizeof(uint32_t)));
             GH_CHECK(h, h->w_q8int.ensure(gh::q8_int_words(nq, P, G, nlist) * sizeof(int)));
             gh::Q8Args qa;
             qa.nq = nq; qa.P = P; qa.G = G; qa.M = M; qa.nlist = nlist;

@@ -192,18 +192,18 @@ struct Q8Args {
     const unsigned long long* ready;  // [nq] the producers' bounds
     const FilterDesc* ftab;           // entry 0: the call's validity predicate (need_ids)
     int need_ids;
-    unsigned long long* surv;         // survivor slices [nq][cnt_stride][slice_cap]; slice 1 is written here
+    unsigned long long* surv;         // survivor slices [nq][cnt_stride][slice_cap]; slices 1 .. of the consumer probe groups are written here
     int* gcnt;
     int cnt_stride, slice_cap;
     int* rq_list;                     // queries without a bound are appended (their consumer groups are scored by the repair launch)
     int* rq_count;
     uint8_t* q8;                      // workspace [nq][M][256]
     float4* meta;                     // workspace [nq]
-    uint32_t* cand;                   // workspace [nq][q8_cand_cap()]
+    uint32_t* cand;                   // workspace [nq][q8_cand_cap(nq)]
     int* iwork;                       // workspace q8_int_words(..) ints
 };
-bool q8_supported(int M, int P, int64_t q_stride);
-int q8_cand_cap();
+bool q8_supported(int M, int P, int G, int64_t q_stride);
+int q8_cand_cap(int nq);
 size_t q8_int_words(int nq, int P, int G, int nlist);
 void launch_q8_consumers(hipStream_t s, const Q8Args& a);
 int scan_slice_cap(int K);   // 1024 up to recall_num 256, 2048 up to 1024

@@ -42,11 +42,12 @@ namespace gh {
 namespace {
 constexpr int Q8_T = 8;          // queries per tile
 constexpr int Q8_ROW = 288;      // LUT entries per sub-quantizer row: 256 + one pad per 8
-constexpr int Q8_STG = 64;       // candidates staged per (tile, query); more = the query takes the unfiltered path
+constexpr int Q8_STG = 128;      // candidates staged per (tile, query); more = the query takes the unfiltered path
 constexpr int Q8_POS_BITS = 25;  // candidate = position in the query's segment | probe << 25
 }  // namespace
 
-int q8_cand_cap() { return 768; }
+// candidates a query's list holds (beyond: the query takes the unfiltered path): 128 MB of workspace spread over the batch
+int q8_cand_cap(int nq) { return (int)std::max<int64_t>(768, std::min<int64_t>(8192, ((int64_t)32 << 20) / std::max(1, nq))); }
 
 // ------------------------------------------------------------------------------------
 // u8 image of every query's inner-product table (k_pq_ip_table's st2): one workgroup per query, thread = code word c.
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(256) void k_q8_filter(
 // pass would have written it.
 // ------------------------------------------------------------------------------------
 template <int MT>
-__global__ __launch_bounds__(256) void k_q8_exact(const float* __restrict__ st2, const float* __restrict__ T2, int nq, int P,
+__global__ __launch_bounds__(256) void k_q8_exact(const float* __restrict__ st2, const float* __restrict__ T2, int nq, int P, int G,
                                                   const int* __restrict__ probe_list, const float* __restrict__ coarse_dis,
                                                   const int64_t* __restrict__ list_off, const uint8_t* __restrict__ codes,
                                                   const int* __restrict__ pair_off, const unsigned long long* __restrict__ ready,
@@ -348,76 +349,61 @@ __global__ __launch_bounds__(256) void k_q8_exact(const float* __restrict__ st2,
                                                   unsigned long long* __restrict__ surv, int* __restrict__ gcnt, int cnt_stride,
                                                   int slice_cap) {
     __shared__ float s_lut[MT * 256];
-    __shared__ unsigned long long s_stage[256];
-    __shared__ int s_nstage;
-    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    __shared__ int s_cnt[64];   // survivors per probe group (slice pg holds the positions of probe group pg: the order the tie
+                                // replay walks the slices in, tie_dev.h)
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int ngroups = (P + G - 1) / G;   // == cnt_stride
     const unsigned long long word = ready[q];
     if ((word >> 32) != 1ull) {   // no bound: repair list (k_q8_pairs)
-        if (tid == 0) gcnt[(int64_t)q * cnt_stride + 1] = 0;
+        for (int g = 1 + tid; g < ngroups; g += 256) gcnt[(int64_t)q * cnt_stride + g] = 0;
         return;
     }
     const int n = ccnt[q];
-    if (n > cand_cap) {   // more candidates than the list holds: the slice reads as overflowed, k_select_final sends the
-        if (tid == 0) gcnt[(int64_t)q * cnt_stride + 1] = slice_cap + 1;   // query to the repair launch
+    if (n > cand_cap) {   // more candidates than the list holds: a slice reads as overflowed, k_select_final sends the query
+        for (int g = 1 + tid; g < ngroups; g += 256) gcnt[(int64_t)q * cnt_stride + g] = g == 1 ? slice_cap + 1 : 0;   // to the repair launch
         return;
     }
-    if (tid == 0) s_nstage = 0;
+    if (tid < 64) s_cnt[tid] = 0;
     if (n > 0)
         for (int e = tid; e < MT * 256; e += 256) s_lut[e] = st2[(int64_t)q * MT * 256 + e];
     __syncthreads();
     const float tau_f = key2f((uint32_t)word);
-    const int64_t slice = (int64_t)q * cnt_stride + 1;
-    for (int c0 = 0; c0 < n; c0 += 256) {   // uniform trip count: ballots below
-        const int c = c0 + tid;
-        bool keep = false;
-        float dis = 0.f;
-        int pos = 0;
-        if (c < n) {
-            const uint32_t cd = cand[(int64_t)q * cand_cap + c];
-            pos = (int)(cd & ((1u << Q8_POS_BITS) - 1u));
-            const int p = (int)(cd >> Q8_POS_BITS), pair = q * P + p;
-            const int l = probe_list[pair];
-            const int j = pos - pair_off[(int64_t)q * (P + 1) + p];
-            const uint8_t* cj = codes + (list_off[l] + j) * MT;
-            const float* t2 = T2 + (int64_t)l * MT * 256;
-            uint32_t cw[MT / 4];
+    for (int c = tid; c < n; c += 256) {
+        const uint32_t cd = cand[(int64_t)q * cand_cap + c];
+        const int pos = (int)(cd & ((1u << Q8_POS_BITS) - 1u));
+        const int p = (int)(cd >> Q8_POS_BITS), pair = q * P + p;
+        const int l = probe_list[pair];
+        const int j = pos - pair_off[(int64_t)q * (P + 1) + p];
+        const uint8_t* cj = codes + (list_off[l] + j) * MT;
+        const float* t2 = T2 + (int64_t)l * MT * 256;
+        uint32_t cw[MT / 4];
 #pragma unroll
-            for (int u = 0; u < MT / 16; u++) {
-                const uint4 cv = reinterpret_cast<const uint4*>(cj)[u];
-                cw[4 * u] = cv.x; cw[4 * u + 1] = cv.y; cw[4 * u + 2] = cv.z; cw[4 * u + 3] = cv.w;
-            }
-            dis = coarse_dis[pair];
-#pragma unroll
-            for (int m0 = 0; m0 < MT; m0 += 8) {   // eight table entries in flight at a time
-                float a[8];
-#pragma unroll
-                for (int m = 0; m < 8; m++) a[m] = t2[(m0 + m) * 256 + ((cw[(m0 + m) >> 2] >> (8 * (m & 3))) & 255u)];
-#pragma unroll
-                for (int m = 0; m < 8; m++)   // the regular loop's table entry and its adds, in the reference's order
-                    dis += __builtin_fmaf(-2.0f, s_lut[(m0 + m) * 256 + ((cw[(m0 + m) >> 2] >> (8 * (m & 3))) & 255u)], a[m]);
-            }
-            keep = dis <= tau_f;
+        for (int u = 0; u < MT / 16; u++) {
+            const uint4 cv = reinterpret_cast<const uint4*>(cj)[u];
+            cw[4 * u] = cv.x; cw[4 * u + 1] = cv.y; cw[4 * u + 2] = cv.z; cw[4 * u + 3] = cv.w;
         }
-        const unsigned long long bal = __ballot(keep);
-        if (bal) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&s_nstage, __popcll(bal));
-            base = __shfl(base, 0, 64);
-            if (keep) {
-                const int at = base + __popcll(bal & ((1ull << lane) - 1ull));
-                const unsigned long long item = ((unsigned long long)dis_key<true>(dis) << 32) | (unsigned)pos;
-                if (at < 256) s_stage[at] = item;
-                else if (at < slice_cap) surv[slice * slice_cap + at] = item;
-            }
+        float dis = coarse_dis[pair];
+#pragma unroll
+        for (int m0 = 0; m0 < MT; m0 += 8) {   // eight table entries in flight at a time
+            float a[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++) a[m] = t2[(m0 + m) * 256 + ((cw[(m0 + m) >> 2] >> (8 * (m & 3))) & 255u)];
+#pragma unroll
+            for (int m = 0; m < 8; m++)   // the regular loop's table entry and its adds, in the reference's order
+                dis += __builtin_fmaf(-2.0f, s_lut[(m0 + m) * 256 + ((cw[(m0 + m) >> 2] >> (8 * (m & 3))) & 255u)], a[m]);
+        }
+        if (dis <= tau_f) {
+            const int g = p / G;
+            const int at = atomicAdd(&s_cnt[g], 1);
+            if (at < slice_cap)
+                surv[((int64_t)q * cnt_stride + g) * slice_cap + at] = ((unsigned long long)dis_key<true>(dis) << 32) | (unsigned)pos;
         }
     }
     __syncthreads();
-    const int ns = s_nstage;
-    if (tid == 0) gcnt[slice] = ns;
-    for (int i = tid; i < min(ns, 256); i += 256) surv[slice * slice_cap + i] = s_stage[i];
+    for (int g = 1 + tid; g < ngroups; g += 256) gcnt[(int64_t)q * cnt_stride + g] = s_cnt[g];
 }
 
-bool q8_supported(int M, int P, int64_t q_stride) { return (M == 16 || M == 32) && P <= 128 && q_stride < ((int64_t)1 << Q8_POS_BITS); }
+bool q8_supported(int M, int P, int G, int64_t q_stride) { return (M == 16 || M == 32) && P <= 128 && G >= 2 && (P + G - 1) / G <= 64 && q_stride < ((int64_t)1 << Q8_POS_BITS); }
 
 // workspace: [cnt nlist | cur nlist | ccnt nq] (zeroed here) | off nlist+1 | tile_first nlist+1 | n_tiles 1 | tile_list | items
 size_t q8_int_words(int nq, int P, int G, int nlist) {
@@ -440,7 +426,7 @@ void launch_q8_consumers(hipStream_t s, const Q8Args& a) {
     int* items = tile_list + (pairs / Q8_T + nlist + 1);
     (void)hipMemsetAsync(cnt, 0, (size_t)(2 * (int64_t)nlist + nq) * sizeof(int), s);
     const unsigned pg = (unsigned)((pairs + 255) / 256);
-    const int cap = q8_cand_cap();
+    const int cap = q8_cand_cap(nq);
     if (M == 16) hipLaunchKernelGGL((k_q8_quant<16>), dim3(nq), dim3(256), 0, s, a.st2, a.q8, a.meta);
     else hipLaunchKernelGGL((k_q8_quant<32>), dim3(nq), dim3(256), 0, s, a.st2, a.q8, a.meta);
     hipLaunchKernelGGL(k_q8_pairs, dim3(pg), dim3(256), 0, s, a.probe_list, nq, P, G, a.ready, a.list_len, a.list_mask, nlist, cnt,
@@ -457,7 +443,7 @@ void launch_q8_consumers(hipStream_t s, const Q8Args& a) {
         hipLaunchKernelGGL((k_q8_filter<16>), dim3(grid), dim3(256), lds, s, tile_list, tile_first, n_tiles, off, items, a.ready,
                            a.coarse_dis, a.t2max, a.meta, a.q8, a.codes, a.sums, a.ids, a.list_off, a.list_len, a.pair_off, P,
                            a.ftab, a.need_ids, a.cand, ccnt, cap);
-        hipLaunchKernelGGL((k_q8_exact<16>), dim3(nq), dim3(256), 0, s, a.st2, a.T2, nq, P, a.probe_list, a.coarse_dis, a.list_off,
+        hipLaunchKernelGGL((k_q8_exact<16>), dim3(nq), dim3(256), 0, s, a.st2, a.T2, nq, P, G, a.probe_list, a.coarse_dis, a.list_off,
                            a.codes, a.pair_off, a.ready, a.cand, ccnt, cap, a.surv, a.gcnt, a.cnt_stride, a.slice_cap);
     } else {
         static bool attr = false;
@@ -468,7 +454,7 @@ void launch_q8_consumers(hipStream_t s, const Q8Args& a) {
         hipLaunchKernelGGL((k_q8_filter<32>), dim3(grid), dim3(256), lds, s, tile_list, tile_first, n_tiles, off, items, a.ready,
                            a.coarse_dis, a.t2max, a.meta, a.q8, a.codes, a.sums, a.ids, a.list_off, a.list_len, a.pair_off, P,
                            a.ftab, a.need_ids, a.cand, ccnt, cap);
-        hipLaunchKernelGGL((k_q8_exact<32>), dim3(nq), dim3(256), 0, s, a.st2, a.T2, nq, P, a.probe_list, a.coarse_dis, a.list_off,
+        hipLaunchKernelGGL((k_q8_exact<32>), dim3(nq), dim3(256), 0, s, a.st2, a.T2, nq, P, G, a.probe_list, a.coarse_dis, a.list_off,
                            a.codes, a.pair_off, a.ready, a.cand, ccnt, cap, a.surv, a.gcnt, a.cnt_stride, a.slice_cap);
     }
 }

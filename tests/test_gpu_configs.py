@@ -281,6 +281,24 @@ def test_filter_pass_with_several_consumer_groups():
     assert " passed" in r.stdout
 
 
+def test_list_major_byte_table_pass_on_short_lists():
+    """The list-major consumer pass over byte tables (csrc/q8scan.hip: one list x 8 queries per tile, candidates recomputed
+    exactly per query) is the default from 1000 codes per list on -- the C4 / C5 list-length regimes above run it.  Here it is
+    forced on the short-list suites (GAMMA_HIP_Q8_MINLEN=0, read once per process: a child process): the bounded-scan
+    parity tests, the C3 headline test and the large-batch fuzz -- strict comparisons, as in the parent."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GAMMA_HIP_Q8_MINLEN="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_more.py", "tests/test_gpu_ties.py",
+                        "tests/test_gpu_fuzz.py", "-k",
+                        "scan_bound_parity_at_batch_size or c3_headline or bounded_scan or large_batch"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def test_bounded_scan_backs_off_where_the_bound_is_loose():
     """The scan's pre-filter bounds a query's recall_num-th best from its NEAREST probe group.  Inner-product data whose
     best candidates sit in lists far from the query in L2 (centroids s_l * u with scales 0.5 .. 2: the quantizer probes
