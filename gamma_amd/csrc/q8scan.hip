@@ -41,8 +41,15 @@ namespace gh {
 
 namespace {
 constexpr int Q8_T = 8;          // queries per tile
-constexpr int Q8_ROW = 288;      // LUT entries per sub-quantizer row: 256 + one pad per 8
-constexpr int Q8_STG = 128;      // candidates staged per (tile, query); more = the query takes the unfiltered path
+// LUT entries per sub-quantizer row: 256 + one pad per 8 at M = 16 (conflict-free staging stores; 36 KB, four workgroups
+// per CU).  M = 32 goes without the pad (64 KB + the pool = two workgroups per CU; its lists are long, the staging amortised)
+template <int MT> struct Q8Lut {
+    static constexpr bool PAD = MT <= 16;
+    static constexpr int ROW = PAD ? 288 : 256;
+    __device__ static __forceinline__ uint32_t entry(uint32_t c) { return PAD ? c + (c >> 3) : c; }
+    __device__ static __forceinline__ int block(int cb) { return PAD ? cb * 9 : cb * 8; }
+};
+constexpr int Q8_POOL = 2048;    // candidates staged per tile (all of its queries); more = the tile's queries take the unfiltered path
 constexpr int Q8_POS_BITS = 25;  // candidate = position in the query's segment | probe << 25
 }  // namespace
 
@@ -56,42 +63,51 @@ int q8_cand_cap(int nq) { return (int)std::max<int64_t>(768, std::min<int64_t>(8
 template <int MT>
 __global__ __launch_bounds__(256) void k_q8_quant(const float* __restrict__ st2, uint8_t* __restrict__ q8,
                                                   float4* __restrict__ meta) {
-    __shared__ float s_mn[MT][4], s_mx[MT][4];
+    // wave w takes table rows w, w + 4, ..: a row is one 1 KB read of the wave (four code words per lane), its minimum and
+    // maximum one wave reduction, its bytes one 256-byte store
+    constexpr int NR = MT / 4;
+    __shared__ float s_part[4][3];
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    float v[MT];
+    float4 v[NR];
+    float lo[NR], range = 0.f, L = 0.f, amax = 0.f;
 #pragma unroll
-    for (int m = 0; m < MT; m++) v[m] = st2[((int64_t)q * MT + m) * 256 + tid];
+    for (int k = 0; k < NR; k++) v[k] = *reinterpret_cast<const float4*>(st2 + ((int64_t)q * MT + wv + 4 * k) * 256 + 4 * lane);
 #pragma unroll
-    for (int m = 0; m < MT; m++) {
-        float mn = v[m], mx = v[m];
+    for (int k = 0; k < NR; k++) {
+        float mn = fminf(fminf(v[k].x, v[k].y), fminf(v[k].z, v[k].w)), mx = fmaxf(fmaxf(v[k].x, v[k].y), fmaxf(v[k].z, v[k].w));
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             mn = fminf(mn, __shfl_xor(mn, o, 64));
             mx = fmaxf(mx, __shfl_xor(mx, o, 64));
         }
-        if (lane == 0) {
-            s_mn[m][wv] = mn;
-            s_mx[m][wv] = mx;
-        }
+        lo[k] = mn;
+        range = fmaxf(range, mx - mn);
+        L += mn;
+        amax = fmaxf(amax, fmaxf(fabsf(mn), fabsf(mx)));
+    }
+    if (lane == 0) {
+        s_part[wv][0] = range;
+        s_part[wv][1] = L;
+        s_part[wv][2] = amax;
     }
     __syncthreads();
-    float lo[MT], range = 0.f, L = 0.f, amax = 0.f;
-#pragma unroll
-    for (int m = 0; m < MT; m++) {
-        lo[m] = fminf(fminf(s_mn[m][0], s_mn[m][1]), fminf(s_mn[m][2], s_mn[m][3]));
-        const float hi = fmaxf(fmaxf(s_mx[m][0], s_mx[m][1]), fmaxf(s_mx[m][2], s_mx[m][3]));
-        range = fmaxf(range, hi - lo[m]);
-        L += lo[m];
-        amax = fmaxf(amax, fmaxf(fabsf(lo[m]), fabsf(hi)));
-    }
+    range = fmaxf(fmaxf(s_part[0][0], s_part[1][0]), fmaxf(s_part[2][0], s_part[3][0]));
+    L = (s_part[0][1] + s_part[1][1]) + (s_part[2][1] + s_part[3][1]);
+    amax = fmaxf(fmaxf(s_part[0][2], s_part[1][2]), fmaxf(s_part[2][2], s_part[3][2]));
     // delta a few ulps above range / 255: (hi - lo) / delta stays below 255.5 whatever the roundings
     const float delta = (range / 255.f) * 1.000001f;
     const float inv = delta > 0.f ? 1.f / delta : 0.f;
 #pragma unroll
-    for (int m = 0; m < MT; m++) {
-        int u = (int)rintf((v[m] - lo[m]) * inv);
-        u = min(255, max(0, u));
-        q8[((int64_t)q * MT + m) * 256 + tid] = (uint8_t)u;
+    for (int k = 0; k < NR; k++) {
+        const float f[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+        uint32_t w = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            int u = (int)rintf((f[e] - lo[k]) * inv);
+            u = min(255, max(0, u));
+            w |= (uint32_t)u << (8 * e);
+        }
+        *reinterpret_cast<uint32_t*>(q8 + ((int64_t)q * MT + wv + 4 * k) * 256 + 4 * lane) = w;
     }
     if (tid == 0) meta[q] = make_float4(2.f * L + 1.02f * (float)MT * delta, -2.f * delta, amax, 0.f);
 }
@@ -188,8 +204,9 @@ __global__ __launch_bounds__(256) void k_q8_filter(
         const int* __restrict__ pair_off, int P, const FilterDesc* __restrict__ ftab, int need_ids,
         uint32_t* __restrict__ cand, int* __restrict__ ccnt, int cand_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_q8[];
-    unsigned char* lut = s_q8;                                                              // [MT][Q8_ROW][8]
-    float* s_A = reinterpret_cast<float*>(s_q8 + (size_t)MT * Q8_ROW * 8);                  // [8] dis0 - cq
+    constexpr int ROW = Q8Lut<MT>::ROW;
+    unsigned char* lut = s_q8;                                                              // [MT][ROW][8]
+    float* s_A = reinterpret_cast<float*>(s_q8 + (size_t)MT * ROW * 8);                     // [8] dis0 - cq
     float* s_nd = s_A + 8;                                                                  // [8] -2 delta
     float* s_thr = s_nd + 8;                                                                // [8]
     int* s_q = reinterpret_cast<int*>(s_thr + 8);                                           // [8] query (-1: empty slot)
@@ -197,7 +214,8 @@ __global__ __launch_bounds__(256) void k_q8_filter(
     int* s_pp = s_pb + 8;                                                                   // [8] probe
     int* s_n = s_pp + 8;                                                                    // [8] candidates
     int* s_g = s_n + 8;                                                                     // [8] base in the query's list
-    int* s_cj = s_g + 8;                                                                    // [8][Q8_STG]
+    int* s_cur = s_g + 8;                                                                   // [8] copied so far | [8]: pool counter
+    uint32_t* s_pool = reinterpret_cast<uint32_t*>(s_cur + 16);                             // [Q8_POOL] query slot << 28 | code
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ntile = *n_tiles;
     for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
@@ -229,6 +247,8 @@ __global__ __launch_bounds__(256) void k_q8_filter(
             s_nd[tid] = nd;
             s_thr[tid] = thr;
             s_n[tid] = 0;
+            s_cur[tid] = 0;
+            if (tid == 0) s_cur[8] = 0;
         }
         __syncthreads();
         // ---- the tile's table: 8 queries' bytes side by side.  A thread takes (m, 8 consecutive code words) blocks ----
@@ -245,7 +265,7 @@ __global__ __launch_bounds__(256) void k_q8_filter(
             tr4x4(r[4].x, r[5].x, r[6].x, r[7].x, xh[0], xh[1], xh[2], xh[3]);   //                 queries 4..7
             tr4x4(r[0].y, r[1].y, r[2].y, r[3].y, yl[0], yl[1], yl[2], yl[3]);   // code words 4..7
             tr4x4(r[4].y, r[5].y, r[6].y, r[7].y, yh[0], yh[1], yh[2], yh[3]);
-            uint2* dst = reinterpret_cast<uint2*>(lut + ((size_t)m * Q8_ROW + cb * 9) * 8);
+            uint2* dst = reinterpret_cast<uint2*>(lut + ((size_t)m * ROW + Q8Lut<MT>::block(cb)) * 8);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 dst[j] = make_uint2(xl[j], xh[j]);
@@ -281,8 +301,8 @@ __global__ __launch_bounds__(256) void k_q8_filter(
 #pragma unroll
             for (int m = 0; m < MT; m++) {
                 const uint32_t c = (cw[m >> 2] >> (8 * (m & 3))) & 255u;
-                const uint32_t e = c + (c >> 3);
-                t[m] = *reinterpret_cast<const uint2*>(lut + (size_t)m * Q8_ROW * 8 + e * 8);
+                const uint32_t e = Q8Lut<MT>::entry(c);
+                t[m] = *reinterpret_cast<const uint2*>(lut + (size_t)m * ROW * 8 + e * 8);
             }
             __builtin_amdgcn_sched_barrier(0);   // all gathers in flight before the sums
             uint32_t acc[Q8_T] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -304,33 +324,35 @@ __global__ __launch_bounds__(256) void k_q8_filter(
                 const unsigned long long bal = __ballot(pass);
                 if (bal) {   // uniform per wave
                     int base = 0;
-                    if (lane == 0) base = atomicAdd(&s_n[i], __popcll(bal));
+                    if (lane == 0) {
+                        base = atomicAdd(&s_cur[8], __popcll(bal));
+                        atomicAdd(&s_n[i], __popcll(bal));
+                    }
                     base = __shfl(base, 0, 64);
                     const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
-                    if (pass && slot < Q8_STG) s_cj[i * Q8_STG + slot] = j;
+                    if (pass && slot < Q8_POOL) s_pool[slot] = ((uint32_t)i << 28) | (uint32_t)j;
                 }
             }
         }
         __syncthreads();
         // ---- the candidates of each of the tile's queries into its list (one returning atomic per pair) ----
+        const int np = s_cur[8];
         if (tid < nit) {
             const int n = s_n[tid];
             int g = 0;
-            if (n > Q8_STG) g = atomicAdd(&ccnt[s_q[tid]], cand_cap + 1);   // more than the stage holds: the query takes the unfiltered path
+            if (np > Q8_POOL) g = atomicAdd(&ccnt[s_q[tid]], cand_cap + 1);   // more than the pool holds: the tile's queries take the unfiltered path
             else if (n > 0) g = atomicAdd(&ccnt[s_q[tid]], n);
             s_g[tid] = g;
         }
         __syncthreads();
-        {
-            const int i = tid >> 5, k0 = tid & 31;
-            if (i < nit) {
-                const int n = s_n[i], g = s_g[i];
-                if (n <= Q8_STG)
-                    for (int k = k0; k < n; k += 32)
-                        if (g + k < cand_cap)
-                            cand[(int64_t)s_q[i] * cand_cap + g + k] = (uint32_t)(s_pb[i] + s_cj[i * Q8_STG + k]) | ((uint32_t)s_pp[i] << Q8_POS_BITS);
+        if (np <= Q8_POOL)
+            for (int k = tid; k < np; k += 256) {
+                const uint32_t e = s_pool[k];
+                const int i = (int)(e >> 28);
+                const int slot = s_g[i] + atomicAdd(&s_cur[i], 1);   // (the order inside a query's list is free)
+                if (slot < cand_cap)
+                    cand[(int64_t)s_q[i] * cand_cap + slot] = (uint32_t)(s_pb[i] + (int)(e & 0x0fffffffu)) | ((uint32_t)s_pp[i] << Q8_POS_BITS);
             }
-        }
         __syncthreads();   // the tile's LDS is free
     }
 }
@@ -435,7 +457,7 @@ void launch_q8_consumers(hipStream_t s, const Q8Args& a) {
     hipLaunchKernelGGL(k_q8_pairs, dim3(pg), dim3(256), 0, s, a.probe_list, nq, P, G, a.ready, a.list_len, a.list_mask, nlist, cnt,
                        cur, off, items, a.rq_list, a.rq_count);
     // LUT | per-slot words | candidate stage
-    const size_t lds = (size_t)M * Q8_ROW * 8 + 9 * 8 * sizeof(int) + (size_t)Q8_T * Q8_STG * sizeof(int);
+    const size_t lds = (size_t)M * (M <= 16 ? 288 : 256) * 8 + 11 * 8 * sizeof(int) + (size_t)Q8_POOL * sizeof(uint32_t);
     const int per_cu = std::max(1, std::min(8, (int)((160 * 1024) / (lds + 512))));
     static const int grid_env = getenv("GAMMA_HIP_Q8_GRID") ? atoi(getenv("GAMMA_HIP_Q8_GRID")) : 0;
     const unsigned grid = grid_env > 0 ? (unsigned)grid_env : (unsigned)(256 * per_cu);
