@@ -49,7 +49,9 @@ template <int MT> struct Q8Lut {
     __device__ static __forceinline__ uint32_t entry(uint32_t c) { return PAD ? c + (c >> 3) : c; }
     __device__ static __forceinline__ int block(int cb) { return PAD ? cb * 9 : cb * 8; }
 };
-constexpr int Q8_POOL = 2048;    // candidates staged per tile (all of its queries); more = the tile's queries take the unfiltered path
+// candidates staged per tile (all of its queries; more = the tile's queries take the unfiltered path): what the LDS beside
+// the table leaves at four (M = 16) / two (M = 32: long lists, hundreds of candidates from the nearest lists) workgroups per CU
+template <int MT> struct Q8Pool { static constexpr int N = MT <= 16 ? 640 : 3584; };
 constexpr int Q8_POS_BITS = 25;  // candidate = position in the query's segment | probe << 25
 }  // namespace
 
@@ -113,31 +115,45 @@ __global__ __launch_bounds__(256) void k_q8_quant(const float* __restrict__ st2,
 }
 
 // ------------------------------------------------------------------------------------
-// The consumer pairs (query, probe >= G) of the queries WITH a bound, grouped by list: count | fill.
+// The consumer pairs (query, probe >= G) of the queries WITH a bound, grouped by list -- a counting sort without global
+// atomics (393 k device-scope atomics on 4096 counters cost 85 us a pass): Q8_NW workgroups each take a contiguous run of
+// the pairs, count them per list in LDS (k_q8_hist -> hist[w][l]), k_q8_offsets turns the columns into exclusive offsets
+// (hist[w][l] = first position of workgroup w's pairs of list l) and k_q8_fill places the pairs with LDS cursors.
 // A query WITHOUT a bound goes to the repair list (its consumer groups are scored with stores by the repair launch:
 // the unfiltered selection reads the slab).
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_q8_pairs(const int* __restrict__ probe_list, int nq, int P, int G,
+constexpr int Q8_NW = 64;
+template <bool FILL>
+__global__ __launch_bounds__(1024) void k_q8_hist(const int* __restrict__ probe_list, int nq, int P, int G,
                                                   const unsigned long long* __restrict__ ready, const int* __restrict__ list_len,
-                                                  const uint8_t* __restrict__ list_mask, int nlist, int* __restrict__ cnt,
-                                                  int* __restrict__ cur, const int* __restrict__ off, int* __restrict__ items,
-                                                  int* __restrict__ rq_list, int* __restrict__ rq_count) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+                                                  const uint8_t* __restrict__ list_mask, int nlist, int* __restrict__ hist,
+                                                  int* __restrict__ items, int* __restrict__ rq_list, int* __restrict__ rq_count) {
+    extern __shared__ int s_h[];   // [nlist]
+    const int tid = threadIdx.x, w = blockIdx.x;
     const int per = P - G;
-    const int q = (int)(idx / per), p = G + (int)(idx % per);
-    if (q >= nq) return;
-    if ((ready[q] >> 32) != 1ull) {
-        if (!cur && p == G) rq_list[atomicAdd(rq_count, 1)] = q;
-        return;
+    const int64_t pairs = (int64_t)nq * per, chunk = (pairs + Q8_NW - 1) / Q8_NW;
+    const int64_t a = (int64_t)w * chunk, b = min(pairs, a + chunk);
+    for (int l = tid; l < nlist; l += 1024) s_h[l] = FILL ? hist[(int64_t)w * nlist + l] : 0;
+    __syncthreads();
+    for (int64_t idx = a + tid; idx < b; idx += 1024) {
+        const int q = (int)(idx / per), p = G + (int)(idx - (int64_t)q * per);
+        if ((ready[q] >> 32) != 1ull) {
+            if (!FILL && p == G) rq_list[atomicAdd(rq_count, 1)] = q;
+            continue;
+        }
+        const int l = probe_list[(int64_t)q * P + p];
+        if (l < 0 || l >= nlist || (list_mask && !list_mask[l]) || list_len[l] <= 0) continue;
+        const int at = atomicAdd(&s_h[l], 1);
+        if (FILL) items[at] = q * P + p;
     }
-    const int l = probe_list[(int64_t)q * P + p];
-    if (l < 0 || l >= nlist || (list_mask && !list_mask[l]) || list_len[l] <= 0) return;
-    if (!cur) atomicAdd(&cnt[l], 1);
-    else items[off[l] + atomicAdd(&cur[l], 1)] = q * P + p;
+    if (!FILL) {
+        __syncthreads();
+        for (int l = tid; l < nlist; l += 1024) hist[(int64_t)w * nlist + l] = s_h[l];
+    }
 }
 
-// offsets of the lists' pair runs, the tiles of 8 pairs, the tile -> list table; one workgroup
-__global__ __launch_bounds__(1024) void k_q8_offsets(const int* __restrict__ cnt, int nlist, int* __restrict__ off,
+// offsets of the lists' pair runs, the tiles of 8 pairs, the tile -> list table, the workgroups' first positions; one workgroup
+__global__ __launch_bounds__(1024) void k_q8_offsets(int* __restrict__ hist, int nlist, int* __restrict__ off,
                                                      int* __restrict__ tile_first, int* __restrict__ tile_list,
                                                      int* __restrict__ n_tiles) {
     __shared__ int s_c[1024], s_t[1024];
@@ -145,8 +161,10 @@ __global__ __launch_bounds__(1024) void k_q8_offsets(const int* __restrict__ cnt
     const int per = (nlist + 1023) / 1024, a = min(nlist, tid * per), b = min(nlist, a + per);
     int c = 0, t = 0;
     for (int l = a; l < b; l++) {
-        c += cnt[l];
-        t += (cnt[l] + Q8_T - 1) / Q8_T;
+        int n = 0;
+        for (int w = 0; w < Q8_NW; w++) n += hist[(int64_t)w * nlist + l];
+        c += n;
+        t += (n + Q8_T - 1) / Q8_T;
     }
     s_c[tid] = c;
     s_t[tid] = t;
@@ -162,9 +180,15 @@ __global__ __launch_bounds__(1024) void k_q8_offsets(const int* __restrict__ cnt
     for (int l = a; l < b; l++) {
         off[l] = oc;
         tile_first[l] = ot;
-        const int nt = (cnt[l] + Q8_T - 1) / Q8_T;
+        int n = 0;
+        for (int w = 0; w < Q8_NW; w++) {   // the column becomes the workgroups' first positions
+            const int hv = hist[(int64_t)w * nlist + l];
+            hist[(int64_t)w * nlist + l] = oc + n;
+            n += hv;
+        }
+        const int nt = (n + Q8_T - 1) / Q8_T;
         for (int i = 0; i < nt; i++) tile_list[ot + i] = l;
-        oc += cnt[l];
+        oc += n;
         ot += nt;
     }
     if (tid == 1023) {
@@ -215,7 +239,8 @@ __global__ __launch_bounds__(256) void k_q8_filter(
     int* s_n = s_pp + 8;                                                                    // [8] candidates
     int* s_g = s_n + 8;                                                                     // [8] base in the query's list
     int* s_cur = s_g + 8;                                                                   // [8] copied so far | [8]: pool counter
-    uint32_t* s_pool = reinterpret_cast<uint32_t*>(s_cur + 16);                             // [Q8_POOL] query slot << 28 | code
+    uint32_t* s_pool = reinterpret_cast<uint32_t*>(s_cur + 16);                             // [POOL] query slot << 28 | code
+    constexpr int POOL = Q8Pool<MT>::N;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ntile = *n_tiles;
     for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
@@ -279,18 +304,30 @@ __global__ __launch_bounds__(256) void k_q8_filter(
         const uint8_t* lc = codes + off * MT;
         const float* ls = sums + off;
         const int64_t* lid = ids + off;
+        uint4 cn[MT / 16];   // the next step's codes and sums are requested before this step's gathers
+        float sn = 0.f;
+        if (wv * 64 < len) {
+            const int jc = min(wv * 64 + lane, len - 1);
+            const uint4* cp = reinterpret_cast<const uint4*>(lc + (int64_t)jc * MT);
+#pragma unroll
+            for (int u = 0; u < MT / 16; u++) cn[u] = cp[u];
+            sn = ls[jc];
+        }
         for (int j0 = wv * 64; j0 < len; j0 += 256) {
             const int j = j0 + lane, jc = min(j, len - 1);
             uint32_t cw[MT / 4];
-            {
-                const uint4* cp = reinterpret_cast<const uint4*>(lc + (int64_t)jc * MT);
 #pragma unroll
-                for (int u = 0; u < MT / 16; u++) {
-                    const uint4 cv = cp[u];
-                    cw[4 * u] = cv.x; cw[4 * u + 1] = cv.y; cw[4 * u + 2] = cv.z; cw[4 * u + 3] = cv.w;
-                }
+            for (int u = 0; u < MT / 16; u++) {
+                cw[4 * u] = cn[u].x; cw[4 * u + 1] = cn[u].y; cw[4 * u + 2] = cn[u].z; cw[4 * u + 3] = cn[u].w;
             }
-            const float sj = ls[jc];
+            const float sj = sn;
+            if (j0 + 256 < len) {   // (uniform)
+                const int jn = min(j + 256, len - 1);
+                const uint4* cp = reinterpret_cast<const uint4*>(lc + (int64_t)jn * MT);
+#pragma unroll
+                for (int u = 0; u < MT / 16; u++) cn[u] = cp[u];
+                sn = ls[jn];
+            }
             bool ok = j < len;
             if (need_ids) {
                 const int64_t id = lid[jc];
@@ -330,7 +367,7 @@ __global__ __launch_bounds__(256) void k_q8_filter(
                     }
                     base = __shfl(base, 0, 64);
                     const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
-                    if (pass && slot < Q8_POOL) s_pool[slot] = ((uint32_t)i << 28) | (uint32_t)j;
+                    if (pass && slot < POOL) s_pool[slot] = ((uint32_t)i << 28) | (uint32_t)j;
                 }
             }
         }
@@ -340,12 +377,12 @@ __global__ __launch_bounds__(256) void k_q8_filter(
         if (tid < nit) {
             const int n = s_n[tid];
             int g = 0;
-            if (np > Q8_POOL) g = atomicAdd(&ccnt[s_q[tid]], cand_cap + 1);   // more than the pool holds: the tile's queries take the unfiltered path
+            if (np > POOL) g = atomicAdd(&ccnt[s_q[tid]], cand_cap + 1);   // more than the pool holds: the tile's queries take the unfiltered path
             else if (n > 0) g = atomicAdd(&ccnt[s_q[tid]], n);
             s_g[tid] = g;
         }
         __syncthreads();
-        if (np <= Q8_POOL)
+        if (np <= POOL)
             for (int k = tid; k < np; k += 256) {
                 const uint32_t e = s_pool[k];
                 const int i = (int)(e >> 28);
@@ -425,39 +462,37 @@ __global__ __launch_bounds__(256) void k_q8_exact(const float* __restrict__ st2,
     for (int g = 1 + tid; g < ngroups; g += 256) gcnt[(int64_t)q * cnt_stride + g] = s_cnt[g];
 }
 
-bool q8_supported(int M, int P, int G, int64_t q_stride) { return (M == 16 || M == 32) && P <= 128 && G >= 2 && (P + G - 1) / G <= 64 && q_stride < ((int64_t)1 << Q8_POS_BITS); }
+bool q8_supported(int M, int P, int G, int64_t q_stride) { return (M == 16 || M == 32) && P <= 128 && G >= 2 && /* (the caller checks nlist <= 16384: the per-list counters live in LDS) */ (P + G - 1) / G <= 64 && q_stride < ((int64_t)1 << Q8_POS_BITS); }
 
-// workspace: [cnt nlist | cur nlist | ccnt nq] (zeroed here) | off nlist+1 | tile_first nlist+1 | n_tiles 1 | tile_list | items
+// workspace: ccnt nq (zeroed here) | hist Q8_NW x nlist | off nlist+1 | tile_first nlist+1 | n_tiles 1 | tile_list | items
 size_t q8_int_words(int nq, int P, int G, int nlist) {
     const int64_t pairs = (int64_t)nq * (P - G);
-    return (size_t)(2 * (int64_t)nlist + nq + 2 * ((int64_t)nlist + 1) + 1 + (pairs / Q8_T + nlist + 1) + pairs + 16);
+    return (size_t)(nq + (int64_t)Q8_NW * nlist + 2 * ((int64_t)nlist + 1) + 1 + (pairs / Q8_T + nlist + 1) + pairs + 16);
 }
 
 void launch_q8_consumers(hipStream_t s, const Q8Args& a) {
     if (a.nq <= 0 || a.P <= a.G) return;
     const int nq = a.nq, P = a.P, G = a.G, nlist = a.nlist, M = a.M;
-    int* w = a.iwork;
-    int* cnt = w;
-    int* cur = cnt + nlist;
-    int* ccnt = cur + nlist;
-    int* off = ccnt + nq;
+    int* ccnt = a.iwork;
+    int* hist = ccnt + nq;
+    int* off = hist + (int64_t)Q8_NW * nlist;
     int* tile_first = off + nlist + 1;
     int* n_tiles = tile_first + nlist + 1;
     int* tile_list = n_tiles + 1;
     const int64_t pairs = (int64_t)nq * (P - G);
     int* items = tile_list + (pairs / Q8_T + nlist + 1);
-    (void)hipMemsetAsync(cnt, 0, (size_t)(2 * (int64_t)nlist + nq) * sizeof(int), s);
-    const unsigned pg = (unsigned)((pairs + 255) / 256);
+    (void)hipMemsetAsync(ccnt, 0, (size_t)nq * sizeof(int), s);
     const int cap = q8_cand_cap(nq);
     if (M == 16) hipLaunchKernelGGL((k_q8_quant<16>), dim3(nq), dim3(256), 0, s, a.st2, a.q8, a.meta);
     else hipLaunchKernelGGL((k_q8_quant<32>), dim3(nq), dim3(256), 0, s, a.st2, a.q8, a.meta);
-    hipLaunchKernelGGL(k_q8_pairs, dim3(pg), dim3(256), 0, s, a.probe_list, nq, P, G, a.ready, a.list_len, a.list_mask, nlist, cnt,
-                       (int*)nullptr, (const int*)nullptr, (int*)nullptr, a.rq_list, a.rq_count);
-    hipLaunchKernelGGL(k_q8_offsets, dim3(1), dim3(1024), 0, s, cnt, nlist, off, tile_first, tile_list, n_tiles);
-    hipLaunchKernelGGL(k_q8_pairs, dim3(pg), dim3(256), 0, s, a.probe_list, nq, P, G, a.ready, a.list_len, a.list_mask, nlist, cnt,
-                       cur, off, items, a.rq_list, a.rq_count);
+    const size_t hl = (size_t)nlist * sizeof(int);
+    hipLaunchKernelGGL((k_q8_hist<false>), dim3(Q8_NW), dim3(1024), hl, s, a.probe_list, nq, P, G, a.ready, a.list_len, a.list_mask,
+                       nlist, hist, (int*)nullptr, a.rq_list, a.rq_count);
+    hipLaunchKernelGGL(k_q8_offsets, dim3(1), dim3(1024), 0, s, hist, nlist, off, tile_first, tile_list, n_tiles);
+    hipLaunchKernelGGL((k_q8_hist<true>), dim3(Q8_NW), dim3(1024), hl, s, a.probe_list, nq, P, G, a.ready, a.list_len, a.list_mask,
+                       nlist, hist, items, a.rq_list, a.rq_count);
     // LUT | per-slot words | candidate stage
-    const size_t lds = (size_t)M * (M <= 16 ? 288 : 256) * 8 + 11 * 8 * sizeof(int) + (size_t)Q8_POOL * sizeof(uint32_t);
+    const size_t lds = (size_t)M * (M <= 16 ? 288 : 256) * 8 + 11 * 8 * sizeof(int) + (size_t)(M <= 16 ? Q8Pool<16>::N : Q8Pool<32>::N) * sizeof(uint32_t);
     const int per_cu = std::max(1, std::min(8, (int)((160 * 1024) / (lds + 512))));
     static const int grid_env = getenv("GAMMA_HIP_Q8_GRID") ? atoi(getenv("GAMMA_HIP_Q8_GRID")) : 0;
     const unsigned grid = grid_env > 0 ? (unsigned)grid_env : (unsigned)(256 * per_cu);
