@@ -57,6 +57,7 @@ struct Host {
   RetrievalModel *model;
   Table table;   // the scalar fields of the docs (device filters read it through GammaSearchCondition::table)
   std::string last_perf;   // PerfTool summary of the last search (what the engine logs at online_log_level=debug)
+  std::mutex perf_mu;      // gh_host_search runs on any number of client threads
 };
 }  // namespace
 
@@ -65,7 +66,9 @@ extern "C" {
 void *gh_host_new(const char *retrieval_type, int d) {
   RetrievalModel *m = reflector().GetNewModel(retrieval_type);
   if (!m) return nullptr;
-  Host *h = new Host{new MemVectorReader(d), m, Table(), std::string()};
+  Host *h = new Host();
+  h->store = new MemVectorReader(d);
+  h->model = m;
   m->vector_ = h->store;
   return h;
 }
@@ -171,7 +174,10 @@ int gh_host_search(void *hp, const char *retrieval_params, int has_rank, int bru
   cond.retrieval_params_ = h->model->Parse(retrieval_params);   // owned by the context
   if (!cond.retrieval_params_) return -100;
   const int rc = h->model->Search(&cond, n, reinterpret_cast<const uint8_t *>(x), k, distances, ids);
-  h->last_perf = perf.OutputPerf().str();
+  {
+    std::lock_guard<std::mutex> g(h->perf_mu);
+    h->last_perf = perf.OutputPerf().str();
+  }
   return rc;
 }
 // the PerfTool summary of the last gh_host_search (single-threaded use)

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <deque>
 #include <iostream>
 #include <limits>
@@ -132,7 +133,9 @@ class VectorMetaInfo {
   std::string name_;
   int dimension_;
   VectorValueType data_type_;
-  size_t size_;
+  // (the engine publishes the store size with a plain store and the models read it unlocked, vector/raw_vector_common.h;
+  //  the stand-in makes that hand-over explicit so that a ThreadSanitizer run of the plugins sees the protocol, not a race)
+  std::atomic<size_t> size_;
   long mem_bytes_;
   int data_size_;
   int version_;
