@@ -152,8 +152,27 @@ __global__ __launch_bounds__(1024) void k_q8_hist(const int* __restrict__ probe_
     }
 }
 
-// offsets of the lists' pair runs, the tiles of 8 pairs, the tile -> list table, the workgroups' first positions; one workgroup
-__global__ __launch_bounds__(1024) void k_q8_offsets(int* __restrict__ hist, int nlist, int* __restrict__ off,
+// pairs per list = the sum of its column of the workgroups' histograms (thread = list: coalesced rows)
+__global__ __launch_bounds__(256) void k_q8_colsum(const int* __restrict__ hist, int nlist, int* __restrict__ cnt) {
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= nlist) return;
+    int n = 0;
+    for (int w = 0; w < Q8_NW; w++) n += hist[(int64_t)w * nlist + l];
+    cnt[l] = n;
+}
+// the column becomes the workgroups' first positions inside the list's run
+__global__ __launch_bounds__(256) void k_q8_colfix(int* __restrict__ hist, int nlist, const int* __restrict__ off) {
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= nlist) return;
+    int run = off[l];
+    for (int w = 0; w < Q8_NW; w++) {
+        const int hv = hist[(int64_t)w * nlist + l];
+        hist[(int64_t)w * nlist + l] = run;
+        run += hv;
+    }
+}
+// offsets of the lists' pair runs, the tiles of 8 pairs, the tile -> list table; one workgroup
+__global__ __launch_bounds__(1024) void k_q8_offsets(const int* __restrict__ cnt, int nlist, int* __restrict__ off,
                                                      int* __restrict__ tile_first, int* __restrict__ tile_list,
                                                      int* __restrict__ n_tiles) {
     __shared__ int s_c[1024], s_t[1024];
@@ -161,10 +180,8 @@ __global__ __launch_bounds__(1024) void k_q8_offsets(int* __restrict__ hist, int
     const int per = (nlist + 1023) / 1024, a = min(nlist, tid * per), b = min(nlist, a + per);
     int c = 0, t = 0;
     for (int l = a; l < b; l++) {
-        int n = 0;
-        for (int w = 0; w < Q8_NW; w++) n += hist[(int64_t)w * nlist + l];
-        c += n;
-        t += (n + Q8_T - 1) / Q8_T;
+        c += cnt[l];
+        t += (cnt[l] + Q8_T - 1) / Q8_T;
     }
     s_c[tid] = c;
     s_t[tid] = t;
@@ -178,14 +195,9 @@ __global__ __launch_bounds__(1024) void k_q8_offsets(int* __restrict__ hist, int
     }
     int oc = s_c[tid] - c, ot = s_t[tid] - t;
     for (int l = a; l < b; l++) {
+        const int n = cnt[l];
         off[l] = oc;
         tile_first[l] = ot;
-        int n = 0;
-        for (int w = 0; w < Q8_NW; w++) {   // the column becomes the workgroups' first positions
-            const int hv = hist[(int64_t)w * nlist + l];
-            hist[(int64_t)w * nlist + l] = oc + n;
-            n += hv;
-        }
         const int nt = (n + Q8_T - 1) / Q8_T;
         for (int i = 0; i < nt; i++) tile_list[ot + i] = l;
         oc += n;
@@ -216,10 +228,13 @@ __device__ __forceinline__ uint32_t add_byte(uint32_t acc, uint32_t w) {
 }
 
 // ------------------------------------------------------------------------------------
-// The filter: a persistent grid walks the tiles.  256 threads; a wave takes 64 codes of the list per step.
+// The filter: a persistent grid walks the tiles.  Q8_NT threads; a wave takes 64 codes of the list per step.
+// (512 threads: the table limits a CU to two (M = 32) / four (M = 16) workgroups, and with four waves each the code loads
+//  in flight -- one 2 KB step per wave -- left the pass waiting for memory: 5.4 ms per 3216 queries at full-size C4)
 // ------------------------------------------------------------------------------------
+constexpr int Q8_NT = 512;
 template <int MT>
-__global__ __launch_bounds__(256) void k_q8_filter(
+__global__ __launch_bounds__(Q8_NT) void k_q8_filter(
         const int* __restrict__ tile_list, const int* __restrict__ tile_first, const int* __restrict__ n_tiles,
         const int* __restrict__ pair_run, const int* __restrict__ items, const unsigned long long* __restrict__ ready,
         const float* __restrict__ coarse_dis, const float* __restrict__ t2max, const float4* __restrict__ meta,
@@ -238,7 +253,7 @@ __global__ __launch_bounds__(256) void k_q8_filter(
     int* s_pp = s_pb + 8;                                                                   // [8] probe
     int* s_n = s_pp + 8;                                                                    // [8] candidates
     int* s_g = s_n + 8;                                                                     // [8] base in the query's list
-    int* s_cur = s_g + 8;                                                                   // [8] copied so far | [8]: pool counter
+    int* s_cur = s_g + 8;                                                                   // [8] copied so far | [8]: pool counter | [9]: valid pool entries
     uint32_t* s_pool = reinterpret_cast<uint32_t*>(s_cur + 16);                             // [POOL] query slot << 28 | code
     constexpr int POOL = Q8Pool<MT>::N;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -273,11 +288,11 @@ __global__ __launch_bounds__(256) void k_q8_filter(
             s_thr[tid] = thr;
             s_n[tid] = 0;
             s_cur[tid] = 0;
-            if (tid == 0) s_cur[8] = 0;
+            if (tid == 0) s_cur[8] = s_cur[9] = 0;
         }
         __syncthreads();
         // ---- the tile's table: 8 queries' bytes side by side.  A thread takes (m, 8 consecutive code words) blocks ----
-        for (int bi = tid; bi < MT * 32; bi += 256) {
+        for (int bi = tid; bi < MT * 32; bi += Q8_NT) {
             const int m = bi >> 5, cb = bi & 31;
             uint2 r[Q8_T];
 #pragma unroll
@@ -304,29 +319,34 @@ __global__ __launch_bounds__(256) void k_q8_filter(
         const uint8_t* lc = codes + off * MT;
         const float* ls = sums + off;
         const int64_t* lid = ids + off;
-        uint4 cn[MT / 16];   // the next step's codes and sums are requested before this step's gathers
-        float sn = 0.f;
-        if (wv * 64 < len) {
-            const int jc = min(wv * 64 + lane, len - 1);
-            const uint4* cp = reinterpret_cast<const uint4*>(lc + (int64_t)jc * MT);
+        // the codes and sums of the next TWO steps are in flight during this step's gathers
+        uint4 cn[2][MT / 16];
+        float sn[2] = {0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < MT / 16; u++) cn[u] = cp[u];
-            sn = ls[jc];
-        }
-        for (int j0 = wv * 64; j0 < len; j0 += 256) {
+        for (int a = 0; a < 2; a++)
+            if (wv * 64 + a * Q8_NT < len) {
+                const int jc = min(wv * 64 + a * Q8_NT + lane, len - 1);
+                const uint4* cp = reinterpret_cast<const uint4*>(lc + (int64_t)jc * MT);
+#pragma unroll
+                for (int u = 0; u < MT / 16; u++) cn[a][u] = cp[u];
+                sn[a] = ls[jc];
+            }
+        for (int j0 = wv * 64; j0 < len; j0 += Q8_NT) {
             const int j = j0 + lane, jc = min(j, len - 1);
             uint32_t cw[MT / 4];
 #pragma unroll
             for (int u = 0; u < MT / 16; u++) {
-                cw[4 * u] = cn[u].x; cw[4 * u + 1] = cn[u].y; cw[4 * u + 2] = cn[u].z; cw[4 * u + 3] = cn[u].w;
+                cw[4 * u] = cn[0][u].x; cw[4 * u + 1] = cn[0][u].y; cw[4 * u + 2] = cn[0][u].z; cw[4 * u + 3] = cn[0][u].w;
+                cn[0][u] = cn[1][u];
             }
-            const float sj = sn;
-            if (j0 + 256 < len) {   // (uniform)
-                const int jn = min(j + 256, len - 1);
+            const float sj = sn[0];
+            sn[0] = sn[1];
+            if (j0 + 2 * Q8_NT < len) {   // (uniform)
+                const int jn = min(j + 2 * Q8_NT, len - 1);
                 const uint4* cp = reinterpret_cast<const uint4*>(lc + (int64_t)jn * MT);
 #pragma unroll
-                for (int u = 0; u < MT / 16; u++) cn[u] = cp[u];
-                sn = ls[jn];
+                for (int u = 0; u < MT / 16; u++) cn[1][u] = cp[u];
+                sn[1] = ls[jn];
             }
             bool ok = j < len;
             if (need_ids) {
@@ -360,36 +380,42 @@ __global__ __launch_bounds__(256) void k_q8_filter(
                 const bool pass = ok && lhs <= s_thr[i];
                 const unsigned long long bal = __ballot(pass);
                 if (bal) {   // uniform per wave
+                    const int nb = __popcll(bal);
                     int base = 0;
                     if (lane == 0) {
-                        base = atomicAdd(&s_cur[8], __popcll(bal));
-                        atomicAdd(&s_n[i], __popcll(bal));
+                        base = atomicAdd(&s_cur[8], nb);
+                        if (base + nb <= POOL) {
+                            atomicAdd(&s_n[i], nb);
+                            atomicMax(&s_cur[9], base + nb);
+                        }
                     }
                     base = __shfl(base, 0, 64);
-                    const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
-                    if (pass && slot < POOL) s_pool[slot] = ((uint32_t)i << 28) | (uint32_t)j;
+                    if (base + nb <= POOL) {
+                        if (pass) s_pool[base + __popcll(bal & ((1ull << lane) - 1ull))] = ((uint32_t)i << 28) | (uint32_t)j;
+                    } else if (pass) {
+                        // the pool is full (eight queries next to one long list): straight into the query's list, one
+                        // returning atomic per candidate -- rare, and the query keeps its pre-filter
+                        const int g = atomicAdd(&ccnt[s_q[i]], 1);
+                        if (g < cand_cap) cand[(int64_t)s_q[i] * cand_cap + g] = (uint32_t)(s_pb[i] + j) | ((uint32_t)s_pp[i] << Q8_POS_BITS);
+                    }
                 }
             }
         }
         __syncthreads();
         // ---- the candidates of each of the tile's queries into its list (one returning atomic per pair) ----
-        const int np = s_cur[8];
+        const int np = s_cur[9];   // pool entries [0, np) are valid (reservations past the end went straight to memory)
         if (tid < nit) {
             const int n = s_n[tid];
-            int g = 0;
-            if (np > POOL) g = atomicAdd(&ccnt[s_q[tid]], cand_cap + 1);   // more than the pool holds: the tile's queries take the unfiltered path
-            else if (n > 0) g = atomicAdd(&ccnt[s_q[tid]], n);
-            s_g[tid] = g;
+            s_g[tid] = n > 0 ? atomicAdd(&ccnt[s_q[tid]], n) : 0;
         }
         __syncthreads();
-        if (np <= POOL)
-            for (int k = tid; k < np; k += 256) {
-                const uint32_t e = s_pool[k];
-                const int i = (int)(e >> 28);
-                const int slot = s_g[i] + atomicAdd(&s_cur[i], 1);   // (the order inside a query's list is free)
-                if (slot < cand_cap)
-                    cand[(int64_t)s_q[i] * cand_cap + slot] = (uint32_t)(s_pb[i] + (int)(e & 0x0fffffffu)) | ((uint32_t)s_pp[i] << Q8_POS_BITS);
-            }
+        for (int k = tid; k < np; k += Q8_NT) {
+            const uint32_t e = s_pool[k];
+            const int i = (int)(e >> 28);
+            const int slot = s_g[i] + atomicAdd(&s_cur[i], 1);   // (the order inside a query's list is free)
+            if (slot < cand_cap)
+                cand[(int64_t)s_q[i] * cand_cap + slot] = (uint32_t)(s_pb[i] + (int)(e & 0x0fffffffu)) | ((uint32_t)s_pp[i] << Q8_POS_BITS);
+        }
         __syncthreads();   // the tile's LDS is free
     }
 }
@@ -464,10 +490,10 @@ __global__ __launch_bounds__(256) void k_q8_exact(const float* __restrict__ st2,
 
 bool q8_supported(int M, int P, int G, int64_t q_stride) { return (M == 16 || M == 32) && P <= 128 && G >= 2 && /* (the caller checks nlist <= 16384: the per-list counters live in LDS) */ (P + G - 1) / G <= 64 && q_stride < ((int64_t)1 << Q8_POS_BITS); }
 
-// workspace: ccnt nq (zeroed here) | hist Q8_NW x nlist | off nlist+1 | tile_first nlist+1 | n_tiles 1 | tile_list | items
+// workspace: ccnt nq (zeroed here) | hist Q8_NW x nlist | cnt nlist | off nlist+1 | tile_first nlist+1 | n_tiles 1 | tile_list | items
 size_t q8_int_words(int nq, int P, int G, int nlist) {
     const int64_t pairs = (int64_t)nq * (P - G);
-    return (size_t)(nq + (int64_t)Q8_NW * nlist + 2 * ((int64_t)nlist + 1) + 1 + (pairs / Q8_T + nlist + 1) + pairs + 16);
+    return (size_t)(nq + (int64_t)(Q8_NW + 1) * nlist + 2 * ((int64_t)nlist + 1) + 1 + (pairs / Q8_T + nlist + 1) + pairs + 16);
 }
 
 void launch_q8_consumers(hipStream_t s, const Q8Args& a) {
@@ -475,7 +501,8 @@ void launch_q8_consumers(hipStream_t s, const Q8Args& a) {
     const int nq = a.nq, P = a.P, G = a.G, nlist = a.nlist, M = a.M;
     int* ccnt = a.iwork;
     int* hist = ccnt + nq;
-    int* off = hist + (int64_t)Q8_NW * nlist;
+    int* cnt = hist + (int64_t)Q8_NW * nlist;
+    int* off = cnt + nlist;
     int* tile_first = off + nlist + 1;
     int* n_tiles = tile_first + nlist + 1;
     int* tile_list = n_tiles + 1;
@@ -488,7 +515,9 @@ void launch_q8_consumers(hipStream_t s, const Q8Args& a) {
     const size_t hl = (size_t)nlist * sizeof(int);
     hipLaunchKernelGGL((k_q8_hist<false>), dim3(Q8_NW), dim3(1024), hl, s, a.probe_list, nq, P, G, a.ready, a.list_len, a.list_mask,
                        nlist, hist, (int*)nullptr, a.rq_list, a.rq_count);
-    hipLaunchKernelGGL(k_q8_offsets, dim3(1), dim3(1024), 0, s, hist, nlist, off, tile_first, tile_list, n_tiles);
+    hipLaunchKernelGGL(k_q8_colsum, dim3((nlist + 255) / 256), dim3(256), 0, s, hist, nlist, cnt);
+    hipLaunchKernelGGL(k_q8_offsets, dim3(1), dim3(1024), 0, s, cnt, nlist, off, tile_first, tile_list, n_tiles);
+    hipLaunchKernelGGL(k_q8_colfix, dim3((nlist + 255) / 256), dim3(256), 0, s, hist, nlist, off);
     hipLaunchKernelGGL((k_q8_hist<true>), dim3(Q8_NW), dim3(1024), hl, s, a.probe_list, nq, P, G, a.ready, a.list_len, a.list_mask,
                        nlist, hist, items, a.rq_list, a.rq_count);
     // LUT | per-slot words | candidate stage
@@ -497,7 +526,7 @@ void launch_q8_consumers(hipStream_t s, const Q8Args& a) {
     static const int grid_env = getenv("GAMMA_HIP_Q8_GRID") ? atoi(getenv("GAMMA_HIP_Q8_GRID")) : 0;
     const unsigned grid = grid_env > 0 ? (unsigned)grid_env : (unsigned)(256 * per_cu);
     if (M == 16) {
-        hipLaunchKernelGGL((k_q8_filter<16>), dim3(grid), dim3(256), lds, s, tile_list, tile_first, n_tiles, off, items, a.ready,
+        hipLaunchKernelGGL((k_q8_filter<16>), dim3(grid), dim3(Q8_NT), lds, s, tile_list, tile_first, n_tiles, off, items, a.ready,
                            a.coarse_dis, a.t2max, a.meta, a.q8, a.codes, a.sums, a.ids, a.list_off, a.list_len, a.pair_off, P,
                            a.ftab, a.need_ids, a.cand, ccnt, cap);
         hipLaunchKernelGGL((k_q8_exact<16>), dim3(nq), dim3(256), 0, s, a.st2, a.T2, nq, P, G, a.probe_list, a.coarse_dis, a.list_off,
@@ -508,7 +537,7 @@ void launch_q8_consumers(hipStream_t s, const Q8Args& a) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_q8_filter<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
             attr = true;
         }
-        hipLaunchKernelGGL((k_q8_filter<32>), dim3(grid), dim3(256), lds, s, tile_list, tile_first, n_tiles, off, items, a.ready,
+        hipLaunchKernelGGL((k_q8_filter<32>), dim3(grid), dim3(Q8_NT), lds, s, tile_list, tile_first, n_tiles, off, items, a.ready,
                            a.coarse_dis, a.t2max, a.meta, a.q8, a.codes, a.sums, a.ids, a.list_off, a.list_len, a.pair_off, P,
                            a.ftab, a.need_ids, a.cand, ccnt, cap);
         hipLaunchKernelGGL((k_q8_exact<32>), dim3(nq), dim3(256), 0, s, a.st2, a.T2, nq, P, G, a.probe_list, a.coarse_dis, a.list_off,
