@@ -55,8 +55,12 @@ template <int MT> struct Q8Pool { static constexpr int N = MT <= 16 ? 640 : 3584
 constexpr int Q8_POS_BITS = 25;  // candidate = position in the query's segment | probe << 25
 }  // namespace
 
-// candidates a query's list holds (beyond: the query takes the unfiltered path): 128 MB of workspace spread over the batch
-int q8_cand_cap(int nq) { return (int)std::max<int64_t>(768, std::min<int64_t>(8192, ((int64_t)32 << 20) / std::max(1, nq))); }
+// candidates a query's list holds (beyond: the query takes the unfiltered path): GAMMA_HIP_Q8_CAND_MB (default 512) MB of
+// workspace spread over the batch, 768 .. 32768 entries per query
+int q8_cand_cap(int nq) {
+    static const int64_t mb = getenv("GAMMA_HIP_Q8_CAND_MB") ? atoll(getenv("GAMMA_HIP_Q8_CAND_MB")) : 512;
+    return (int)std::max<int64_t>(768, std::min<int64_t>(32768, ((mb << 20) / 4) / std::max(1, nq)));
+}
 
 // ------------------------------------------------------------------------------------
 // u8 image of every query's inner-product table (k_pq_ip_table's st2): one workgroup per query, thread = code word c.
