@@ -605,9 +605,16 @@ def test_c2_flat_full_size(c3):
     for i in range(0, 40, 8):
         dall = ((base - q[i]) ** 2).sum(1)
         assert np.partition(dall, 99)[99] == D[i, 99]
-    # the oracle (reference flat loop restated) on a few queries over the full base
-    Do, Io = B.flat_search(base, q[:6], 100, B.METRIC_L2, B.make_ctx(min_score=0.0, max_score=1e30))
-    compare_exact(Do, Io, D[:6], I[:6])
+    # the oracle (reference flat loop restated) over the full base: every query of the batch with an exact-distance tie among
+    # its first k + 1 results (the rows the tie replay rewrites: integer-valued data has many) up to 48 of them, plus queries
+    # spread over the batch -- at least 64 in all (6 of 1024 was the whole oracle sample)
+    D101, _ = g.flat_search(q, 101, args)
+    tied = np.nonzero((np.diff(D101, axis=1) == 0).any(axis=1))[0]
+    sel = np.unique(np.concatenate([tied[:48], np.arange(0, 1024, 16)]))
+    assert len(sel) >= 64
+    Do, Io = B.flat_search(base, np.ascontiguousarray(q[sel]), 100, B.METRIC_L2, B.make_ctx(min_score=0.0, max_score=1e30))
+    compare_exact(Do, Io, D[sel], I[sel])
+    print("C2 oracle sample: %d queries, %d of them with a tie among the first 101 distances (%d in the batch)" % (len(sel), min(len(tied), 48), len(tied)))
     # inner product over the same store
     argi = api.SearchArgs(metric=api.METRIC_IP, **WIDE)
     Di, Ii = g.flat_search(q[:6], 100, argi)
