@@ -542,6 +542,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
             GH_CHECK(h, h->w_q8int.ensure(gh::q8_int_words(nq, P, G, nlist) * sizeof(int)));
             gh::Q8Args qa;
             qa.nq = nq; qa.P = P; qa.G = G; qa.M = M; qa.nlist = nlist;
+            qa.mean_len = (double)h->ntotal / std::max(1, nlist);
             qa.probe_list = h->w_probe.as<int>();
             qa.coarse_dis = dis0;
             qa.st2 = h->w_st2.as<float>();

@@ -177,6 +177,7 @@ struct ScanBound {
 // ---- q8scan.hip: the consumer probes of a bounded L2 scan, list-major over byte tables (one list x 8 queries per tile) ----
 struct Q8Args {
     int nq, P, G, M, nlist;
+    double mean_len;                  // codes per list (short lists take the pipelined filter kernel)
     const int* probe_list;            // [nq][P]
     const float* coarse_dis;          // [nq][P] dis0
     const float* st2;                 // [nq][M][256] fp32 inner-product tables (k_pq_ip_table)

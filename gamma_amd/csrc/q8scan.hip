@@ -127,11 +127,19 @@ __global__ __launch_bounds__(256) void k_q8_quant(const float* __restrict__ st2,
 // the unfiltered selection reads the slab).
 // ------------------------------------------------------------------------------------
 constexpr int Q8_NW = 64;
+// what a tile needs to know about one of its (query, probe) pairs, computed once when the pair is placed (k_q8_hist<true>):
+// the filter kernels read ONE 32-byte record per slot instead of walking pair -> pair_off / meta / coarse_dis / ready
+struct Q8Rec {
+    int q, pp, pb, pad;      // query, probe, position of the pair's list in the query's segment
+    float A, nd, thr, pad2;  // dis0 - cq, -2 delta, tau + 2^-16 S
+};
 template <bool FILL>
 __global__ __launch_bounds__(1024) void k_q8_hist(const int* __restrict__ probe_list, int nq, int P, int G,
                                                   const unsigned long long* __restrict__ ready, const int* __restrict__ list_len,
                                                   const uint8_t* __restrict__ list_mask, int nlist, int* __restrict__ hist,
-                                                  int* __restrict__ items, int* __restrict__ rq_list, int* __restrict__ rq_count) {
+                                                  Q8Rec* __restrict__ recs, int* __restrict__ rq_list, int* __restrict__ rq_count,
+                                                  const float* __restrict__ coarse_dis, const float* __restrict__ t2max,
+                                                  const float4* __restrict__ meta, const int* __restrict__ pair_off) {
     extern __shared__ int s_h[];   // [nlist]
     const int tid = threadIdx.x, w = blockIdx.x;
     const int per = P - G;
@@ -141,14 +149,27 @@ __global__ __launch_bounds__(1024) void k_q8_hist(const int* __restrict__ probe_
     __syncthreads();
     for (int64_t idx = a + tid; idx < b; idx += 1024) {
         const int q = (int)(idx / per), p = G + (int)(idx - (int64_t)q * per);
-        if ((ready[q] >> 32) != 1ull) {
+        const unsigned long long word = ready[q];
+        if ((word >> 32) != 1ull) {
             if (!FILL && p == G) rq_list[atomicAdd(rq_count, 1)] = q;
             continue;
         }
-        const int l = probe_list[(int64_t)q * P + p];
+        const int pair = q * P + p;
+        const int l = probe_list[pair];
         if (l < 0 || l >= nlist || (list_mask && !list_mask[l]) || list_len[l] <= 0) continue;
         const int at = atomicAdd(&s_h[l], 1);
-        if (FILL) items[at] = q * P + p;
+        if (FILL) {
+            const float4 mq = meta[q];
+            const float dis0 = coarse_dis[pair];
+            const float tau = key2f((uint32_t)word);
+            const float S = fabsf(dis0) + t2max[l] + 32.f * mq.z;
+            float thr = __builtin_fmaf(S, 1.f / 65536.f, tau);
+            thr += fabsf(thr) * 2.4e-7f;   // the threshold's own roundings
+            Q8Rec r;
+            r.q = q; r.pp = p; r.pb = pair_off[(int64_t)q * (P + 1) + p]; r.pad = 0;
+            r.A = dis0 - mq.x; r.nd = mq.y; r.thr = thr; r.pad2 = 0.f;
+            recs[at] = r;
+        }
     }
     if (!FILL) {
         __syncthreads();
@@ -177,8 +198,9 @@ __global__ __launch_bounds__(256) void k_q8_colfix(int* __restrict__ hist, int n
 }
 // offsets of the lists' pair runs, the tiles of 8 pairs, the tile -> list table; one workgroup
 __global__ __launch_bounds__(1024) void k_q8_offsets(const int* __restrict__ cnt, int nlist, int* __restrict__ off,
-                                                     int* __restrict__ tile_first, int* __restrict__ tile_list,
-                                                     int* __restrict__ n_tiles) {
+                                                     int* __restrict__ tile_first, int4* __restrict__ tile_list,
+                                                     int* __restrict__ n_tiles, const int* __restrict__ list_len,
+                                                     const int64_t* __restrict__ list_off) {
     __shared__ int s_c[1024], s_t[1024];
     const int tid = threadIdx.x;
     const int per = (nlist + 1023) / 1024, a = min(nlist, tid * per), b = min(nlist, a + per);
@@ -203,7 +225,11 @@ __global__ __launch_bounds__(1024) void k_q8_offsets(const int* __restrict__ cnt
         off[l] = oc;
         tile_first[l] = ot;
         const int nt = (n + Q8_T - 1) / Q8_T;
-        for (int i = 0; i < nt; i++) tile_list[ot + i] = l;
+        if (nt > 0) {   // (list, length, arena offset): a tile starts on its codes without walking the list tables
+            const int64_t lo = list_off[l];
+            const int4 ti = make_int4(l, list_len[l], (int)(uint32_t)lo, (int)(lo >> 32));
+            for (int i = 0; i < nt; i++) tile_list[ot + i] = ti;
+        }
         oc += n;
         ot += nt;
     }
@@ -239,13 +265,10 @@ __device__ __forceinline__ uint32_t add_byte(uint32_t acc, uint32_t w) {
 constexpr int Q8_NT = 512;
 template <int MT>
 __global__ __launch_bounds__(Q8_NT) void k_q8_filter(
-        const int* __restrict__ tile_list, const int* __restrict__ tile_first, const int* __restrict__ n_tiles,
-        const int* __restrict__ pair_run, const int* __restrict__ items, const unsigned long long* __restrict__ ready,
-        const float* __restrict__ coarse_dis, const float* __restrict__ t2max, const float4* __restrict__ meta,
-        const uint8_t* __restrict__ q8, const uint8_t* __restrict__ codes, const float* __restrict__ sums,
-        const int64_t* __restrict__ ids, const int64_t* __restrict__ list_off, const int* __restrict__ list_len,
-        const int* __restrict__ pair_off, int P, const FilterDesc* __restrict__ ftab, int need_ids,
-        uint32_t* __restrict__ cand, int* __restrict__ ccnt, int cand_cap) {
+        const int4* __restrict__ tile_list, const int* __restrict__ tile_first, const int* __restrict__ n_tiles,
+        const int* __restrict__ pair_run, const Q8Rec* __restrict__ recs, const uint8_t* __restrict__ q8,
+        const uint8_t* __restrict__ codes, const float* __restrict__ sums, const int64_t* __restrict__ ids,
+        const FilterDesc* __restrict__ ftab, int need_ids, uint32_t* __restrict__ cand, int* __restrict__ ccnt, int cand_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_q8[];
     constexpr int ROW = Q8Lut<MT>::ROW;
     unsigned char* lut = s_q8;                                                              // [MT][ROW][8]
@@ -263,33 +286,20 @@ __global__ __launch_bounds__(Q8_NT) void k_q8_filter(
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ntile = *n_tiles;
     for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-        const int l = tile_list[tile];
+        const int4 ti = tile_list[tile];
+        const int l = ti.x;
         const int first = pair_run[l] + Q8_T * (tile - tile_first[l]);
         const int nit = min(Q8_T, pair_run[l + 1] - first);
         if (tid < Q8_T) {
-            int q = -1, pb = 0, pp = 0;
-            float A = 0.f, nd = 0.f, thr = -INFINITY;
-            if (tid < nit) {
-                const int pair = items[first + tid];
-                q = pair / P;
-                pp = pair - q * P;
-                pb = pair_off[(int64_t)q * (P + 1) + pp];
-                const float4 mq = meta[q];
-                const float dis0 = coarse_dis[pair];
-                const uint32_t tk = (uint32_t)ready[q];
-                const float tau = key2f(tk);
-                const float S = fabsf(dis0) + t2max[l] + 32.f * mq.z;
-                thr = __builtin_fmaf(S, 1.f / 65536.f, tau);
-                thr += fabsf(thr) * 2.4e-7f;   // the threshold's own roundings
-                A = dis0 - mq.x;
-                nd = mq.y;
-            }
-            s_q[tid] = q;
-            s_pb[tid] = pb;
-            s_pp[tid] = pp;
-            s_A[tid] = A;
-            s_nd[tid] = nd;
-            s_thr[tid] = thr;
+            Q8Rec r;
+            r.q = -1; r.pp = 0; r.pb = 0; r.A = 0.f; r.nd = 0.f; r.thr = -INFINITY;
+            if (tid < nit) r = recs[first + tid];
+            s_q[tid] = r.q;
+            s_pb[tid] = r.pb;
+            s_pp[tid] = r.pp;
+            s_A[tid] = r.A;
+            s_nd[tid] = r.nd;
+            s_thr[tid] = r.thr;
             s_n[tid] = 0;
             s_cur[tid] = 0;
             if (tid == 0) s_cur[8] = s_cur[9] = 0;
@@ -318,8 +328,8 @@ __global__ __launch_bounds__(Q8_NT) void k_q8_filter(
         }
         __syncthreads();
         // ---- the list's codes ----
-        const int len = list_len[l];
-        const int64_t off = list_off[l];
+        const int len = ti.y;
+        const int64_t off = (int64_t)(((uint64_t)(uint32_t)ti.w << 32) | (uint32_t)ti.z);
         const uint8_t* lc = codes + off * MT;
         const float* ls = sums + off;
         const int64_t* lid = ids + off;
@@ -425,6 +435,229 @@ __global__ __launch_bounds__(Q8_NT) void k_q8_filter(
 }
 
 // ------------------------------------------------------------------------------------
+// The same filter for SHORT lists (a tile = a few hundred codes: one step of 64 per wave), software-pipelined across tiles:
+// while tile t is scanned, the bytes of tile t + 1 are on their way into registers, the records of tile t + 2 and the first
+// codes of tile t + 1 are requested, the atomic that reserves room for tile t's candidates is issued after the scan and
+// its result is only used one tile later (copy-out of tile t - 1 beside the table stores of tile t + 1).  Two barriers per
+// tile, no load waited for where it is issued.  Records 4-way, pools and counters 3-way rotated.
+// ------------------------------------------------------------------------------------
+constexpr int Q8_SL_POOL = 1024;
+template <int MT>
+__global__ __launch_bounds__(Q8_NT) void k_q8_filter_sl(
+        const int4* __restrict__ tile_list, const int* __restrict__ tile_first, const int* __restrict__ n_tiles,
+        const int* __restrict__ pair_run, const Q8Rec* __restrict__ recs, const uint8_t* __restrict__ q8,
+        const uint8_t* __restrict__ codes, const float* __restrict__ sums, const int64_t* __restrict__ ids,
+        const FilterDesc* __restrict__ ftab, int need_ids, uint32_t* __restrict__ cand, int* __restrict__ ccnt, int cand_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_q8[];
+    constexpr int ROW = Q8Lut<MT>::ROW;
+    constexpr int NB = (MT * 32 + Q8_NT - 1) / Q8_NT;   // table blocks per thread
+    unsigned char* lut = s_q8;                                                        // [MT][ROW][8]
+    Q8Rec* s_m = reinterpret_cast<Q8Rec*>(s_q8 + (size_t)MT * ROW * 8);               // [4][8]
+    int* s_n = reinterpret_cast<int*>(s_m + 4 * Q8_T);                                // [3][8] candidates per query
+    int* s_g = s_n + 3 * Q8_T;                                                        // [3][8] base in the query's list
+    int* s_cp = s_g + 3 * Q8_T;                                                       // [3][8] copied so far
+    int* s_np = s_cp + 3 * Q8_T;                                                      // [3] pool counter | [3] valid entries
+    uint32_t* s_pool = reinterpret_cast<uint32_t*>(s_np + 8);                         // [3][Q8_SL_POOL]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ntile = *n_tiles, G = (int)gridDim.x;
+    int tile = blockIdx.x;
+    if (tile >= ntile) return;
+    auto load_rec = [&](int t) -> Q8Rec {   // threads 0..7
+        Q8Rec r;
+        r.q = -1; r.pp = 0; r.pb = 0; r.pad = 0; r.A = 0.f; r.nd = 0.f; r.thr = -INFINITY; r.pad2 = 0.f;
+        if (t < ntile) {
+            const int l = tile_list[t].x;
+            const int first = pair_run[l] + Q8_T * (t - tile_first[l]);
+            if (tid < min(Q8_T, pair_run[l + 1] - first)) r = recs[first + tid];
+        }
+        return r;
+    };
+    struct Tab { uint2 r[NB][Q8_T]; };
+    auto issue_tables = [&](int ms, Tab& tb) {
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const int bi = tid + b * Q8_NT;
+            const int m = bi >> 5, cb = bi & 31;
+#pragma unroll
+            for (int i = 0; i < Q8_T; i++) {
+                const int q = s_m[ms * Q8_T + i].q;
+                tb.r[b][i] = (q >= 0 && bi < MT * 32) ? *reinterpret_cast<const uint2*>(q8 + ((int64_t)q * MT + m) * 256 + cb * 8) : make_uint2(0u, 0u);
+            }
+        }
+    };
+    auto write_lut = [&](const Tab& tb) {
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const int bi = tid + b * Q8_NT;
+            if (bi >= MT * 32) continue;
+            const int m = bi >> 5, cb = bi & 31;
+            uint32_t xl[4], xh[4], yl[4], yh[4];
+            tr4x4(tb.r[b][0].x, tb.r[b][1].x, tb.r[b][2].x, tb.r[b][3].x, xl[0], xl[1], xl[2], xl[3]);
+            tr4x4(tb.r[b][4].x, tb.r[b][5].x, tb.r[b][6].x, tb.r[b][7].x, xh[0], xh[1], xh[2], xh[3]);
+            tr4x4(tb.r[b][0].y, tb.r[b][1].y, tb.r[b][2].y, tb.r[b][3].y, yl[0], yl[1], yl[2], yl[3]);
+            tr4x4(tb.r[b][4].y, tb.r[b][5].y, tb.r[b][6].y, tb.r[b][7].y, yh[0], yh[1], yh[2], yh[3]);
+            uint2* dst = reinterpret_cast<uint2*>(lut + ((size_t)m * ROW + Q8Lut<MT>::block(cb)) * 8);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                dst[j] = make_uint2(xl[j], xh[j]);
+                dst[4 + j] = make_uint2(yl[j], yh[j]);
+            }
+        }
+    };
+    struct Codes { uint4 c[MT / 16]; float s; int len; int64_t off; };
+    auto issue_codes = [&](int t, Codes& cd) {
+        const int4 ti = tile_list[t];
+        cd.len = ti.y;
+        cd.off = (int64_t)(((uint64_t)(uint32_t)ti.w << 32) | (uint32_t)ti.z);
+        cd.s = 0.f;
+        if (wv * 64 < cd.len) {
+            const int jc = min(wv * 64 + lane, cd.len - 1);
+            const uint4* cp = reinterpret_cast<const uint4*>(codes + (cd.off + jc) * MT);
+#pragma unroll
+            for (int u = 0; u < MT / 16; u++) cd.c[u] = cp[u];
+            cd.s = sums[cd.off + jc];
+        }
+    };
+    auto copy_out = [&](int ps, int ms) {   // the pooled candidates of a finished tile into their queries' lists
+        const int np = s_np[3 + ps];
+        for (int k = tid; k < np; k += Q8_NT) {
+            const uint32_t e = s_pool[ps * Q8_SL_POOL + k];
+            const int i = (int)(e >> 28);
+            const Q8Rec& r = s_m[ms * Q8_T + i];
+            const int slot = s_g[ps * Q8_T + i] + atomicAdd(&s_cp[ps * Q8_T + i], 1);   // (the order inside a query's list is free)
+            if (slot < cand_cap) cand[(int64_t)r.q * cand_cap + slot] = (uint32_t)(r.pb + (int)(e & 0x0fffffffu)) | ((uint32_t)r.pp << Q8_POS_BITS);
+        }
+    };
+    // ---- prologue: tile 0's records, bytes and codes; tile 1's records ----
+    if (tid < Q8_T) s_m[tid] = load_rec(tile);
+    if (tid < 3 * Q8_T) s_n[tid] = s_cp[tid] = 0;
+    if (tid < 8) s_np[tid] = 0;
+    __syncthreads();
+    Tab tb;
+    Codes cd;
+    {
+        issue_tables(0, tb);
+        Q8Rec r1 = load_rec(tile + G);
+        issue_codes(tile, cd);
+        write_lut(tb);
+        if (tid < Q8_T) s_m[Q8_T + tid] = r1;
+    }
+    __syncthreads();
+    int g_reg = 0;
+    int it = 0;
+    for (;; it++) {
+        const int ms = it & 3, pc = it % 3, pprev = (it + 2) % 3, pres = (it + 1) % 3;
+        const int nxt = tile + G;
+        const bool has_n = nxt < ntile;
+        Codes cn;
+        Q8Rec r2;
+        if (has_n) {
+            issue_tables((it + 1) & 3, tb);
+            issue_codes(nxt, cn);
+        }
+        if (tid < Q8_T) r2 = load_rec(nxt + G);
+        // ---- scan tile `it` ----
+        {
+            const int len = cd.len;
+            const uint8_t* lc = codes + cd.off * MT;
+            const float* ls = sums + cd.off;
+            const int64_t* lid = ids + cd.off;
+            const Q8Rec* mr = s_m + ms * Q8_T;
+            for (int j0 = wv * 64; j0 < len; j0 += Q8_NT) {
+                const int j = j0 + lane, jc = min(j, len - 1);
+                uint32_t cw[MT / 4];
+#pragma unroll
+                for (int u = 0; u < MT / 16; u++) {
+                    cw[4 * u] = cd.c[u].x; cw[4 * u + 1] = cd.c[u].y; cw[4 * u + 2] = cd.c[u].z; cw[4 * u + 3] = cd.c[u].w;
+                }
+                const float sj = cd.s;
+                if (j0 + Q8_NT < len) {   // (uniform) lists beyond 512 codes: the next step's codes
+                    const int jn = min(j + Q8_NT, len - 1);
+                    const uint4* cp = reinterpret_cast<const uint4*>(lc + (int64_t)jn * MT);
+#pragma unroll
+                    for (int u = 0; u < MT / 16; u++) cd.c[u] = cp[u];
+                    cd.s = ls[jn];
+                }
+                bool ok = j < len;
+                if (need_ids) {
+                    const int64_t id = lid[jc];
+                    ok = ok && id >= 0;
+                    if (ok) ok = is_valid_doc(ftab[0], id);
+                }
+                uint2 t[MT];
+#pragma unroll
+                for (int m = 0; m < MT; m++) {
+                    const uint32_t c = (cw[m >> 2] >> (8 * (m & 3))) & 255u;
+                    const uint32_t e = Q8Lut<MT>::entry(c);
+                    t[m] = *reinterpret_cast<const uint2*>(lut + (size_t)m * ROW * 8 + e * 8);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // all gathers in flight before the sums
+                uint32_t acc[Q8_T] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int m = 0; m < MT; m++) {
+                    acc[0] = add_byte<0>(acc[0], t[m].x);
+                    acc[1] = add_byte<1>(acc[1], t[m].x);
+                    acc[2] = add_byte<2>(acc[2], t[m].x);
+                    acc[3] = add_byte<3>(acc[3], t[m].x);
+                    acc[4] = add_byte<0>(acc[4], t[m].y);
+                    acc[5] = add_byte<1>(acc[5], t[m].y);
+                    acc[6] = add_byte<2>(acc[6], t[m].y);
+                    acc[7] = add_byte<3>(acc[7], t[m].y);
+                }
+#pragma unroll
+                for (int i = 0; i < Q8_T; i++) {
+                    const float lhs = __builtin_fmaf(mr[i].nd, (float)acc[i], mr[i].A + sj);
+                    const bool pass = ok && lhs <= mr[i].thr;
+                    const unsigned long long bal = __ballot(pass);
+                    if (bal) {   // uniform per wave
+                        const int nb = __popcll(bal);
+                        int base = 0;
+                        if (lane == 0) {
+                            base = atomicAdd(&s_np[pc], nb);
+                            if (base + nb <= Q8_SL_POOL) {
+                                atomicAdd(&s_n[pc * Q8_T + i], nb);
+                                atomicMax(&s_np[3 + pc], base + nb);
+                            }
+                        }
+                        base = __shfl(base, 0, 64);
+                        if (base + nb <= Q8_SL_POOL) {
+                            if (pass) s_pool[pc * Q8_SL_POOL + base + __popcll(bal & ((1ull << lane) - 1ull))] = ((uint32_t)i << 28) | (uint32_t)j;
+                        } else if (pass) {   // the pool is full: straight into the query's list
+                            const int g = atomicAdd(&ccnt[mr[i].q], 1);
+                            if (g < cand_cap) cand[(int64_t)mr[i].q * cand_cap + g] = (uint32_t)(mr[i].pb + j) | ((uint32_t)mr[i].pp << Q8_POS_BITS);
+                        }
+                    }
+                }
+            }
+        }
+        if (it > 0 && tid < Q8_T) s_g[pprev * Q8_T + tid] = g_reg;   // the reservation issued one tile ago has returned long since
+        __syncthreads();   // #1: the table and this tile's pool are complete
+        if (tid < Q8_T) {
+            const int n = s_n[pc * Q8_T + tid], q = s_m[ms * Q8_T + tid].q;
+            g_reg = (n > 0 && q >= 0) ? atomicAdd(&ccnt[q], n) : 0;
+        }
+        if (tid >= 32 && tid < 32 + 3 * Q8_T) {   // the slot tile it + 1 will fill: its previous user (tile it - 2) was copied out
+            const int k = tid - 32;               // before the last barrier
+            if (k < Q8_T) s_n[pres * Q8_T + k] = 0;
+            else if (k < 2 * Q8_T) s_cp[pres * Q8_T + k - Q8_T] = 0;
+            else if (k == 2 * Q8_T) s_np[pres] = 0;
+            else if (k == 2 * Q8_T + 1) s_np[3 + pres] = 0;
+        }
+        if (it > 0) copy_out(pprev, (it + 3) & 3);
+        if (!has_n) break;
+        write_lut(tb);
+        if (tid < Q8_T) s_m[((it + 2) & 3) * Q8_T + tid] = r2;
+        __syncthreads();   // #2: the next tile's table and records are in place
+        tile = nxt;
+        cd = cn;
+    }
+    // ---- epilogue: the last tile's candidates ----
+    if (tid < Q8_T) s_g[(it % 3) * Q8_T + tid] = g_reg;
+    __syncthreads();
+    copy_out(it % 3, it & 3);
+}
+
+// ------------------------------------------------------------------------------------
 // The candidates' exact values, one workgroup per query (the query's fp32 table in LDS): what the regular loop computes
 // for these codes -- fma and adds in the reference's order -- and the query's consumer slice (slice 1 of 2) as the CF
 // pass would have written it.
@@ -494,10 +727,11 @@ __global__ __launch_bounds__(256) void k_q8_exact(const float* __restrict__ st2,
 
 bool q8_supported(int M, int P, int G, int64_t q_stride) { return (M == 16 || M == 32) && P <= 128 && G >= 2 && /* (the caller checks nlist <= 16384: the per-list counters live in LDS) */ (P + G - 1) / G <= 64 && q_stride < ((int64_t)1 << Q8_POS_BITS); }
 
-// workspace: ccnt nq (zeroed here) | hist Q8_NW x nlist | cnt nlist | off nlist+1 | tile_first nlist+1 | n_tiles 1 | tile_list | items
+// workspace: ccnt nq (zeroed here) | hist Q8_NW x nlist | cnt nlist | off nlist+1 | tile_first nlist+1 | n_tiles 1 | pad |
+//            tile_list (int4) | recs (Q8Rec, 32 B)
 size_t q8_int_words(int nq, int P, int G, int nlist) {
     const int64_t pairs = (int64_t)nq * (P - G);
-    return (size_t)(nq + (int64_t)(Q8_NW + 1) * nlist + 2 * ((int64_t)nlist + 1) + 1 + (pairs / Q8_T + nlist + 1) + pairs + 16);
+    return (size_t)(nq + (int64_t)(Q8_NW + 1) * nlist + 2 * ((int64_t)nlist + 1) + 1 + 8 + 4 * (pairs / Q8_T + nlist + 1) + 8 * pairs + 16);
 }
 
 void launch_q8_consumers(hipStream_t s, const Q8Args& a) {
@@ -509,44 +743,52 @@ void launch_q8_consumers(hipStream_t s, const Q8Args& a) {
     int* off = cnt + nlist;
     int* tile_first = off + nlist + 1;
     int* n_tiles = tile_first + nlist + 1;
-    int* tile_list = n_tiles + 1;
     const int64_t pairs = (int64_t)nq * (P - G);
-    int* items = tile_list + (pairs / Q8_T + nlist + 1);
+    uintptr_t pa = (reinterpret_cast<uintptr_t>(n_tiles + 1) + 31) & ~(uintptr_t)31;
+    int4* tile_list = reinterpret_cast<int4*>(pa);
+    Q8Rec* recs = reinterpret_cast<Q8Rec*>(tile_list + (pairs / Q8_T + nlist + 1));
     (void)hipMemsetAsync(ccnt, 0, (size_t)nq * sizeof(int), s);
     const int cap = q8_cand_cap(nq);
     if (M == 16) hipLaunchKernelGGL((k_q8_quant<16>), dim3(nq), dim3(256), 0, s, a.st2, a.q8, a.meta);
     else hipLaunchKernelGGL((k_q8_quant<32>), dim3(nq), dim3(256), 0, s, a.st2, a.q8, a.meta);
     const size_t hl = (size_t)nlist * sizeof(int);
     hipLaunchKernelGGL((k_q8_hist<false>), dim3(Q8_NW), dim3(1024), hl, s, a.probe_list, nq, P, G, a.ready, a.list_len, a.list_mask,
-                       nlist, hist, (int*)nullptr, a.rq_list, a.rq_count);
+                       nlist, hist, (Q8Rec*)nullptr, a.rq_list, a.rq_count, a.coarse_dis, a.t2max, a.meta, a.pair_off);
     hipLaunchKernelGGL(k_q8_colsum, dim3((nlist + 255) / 256), dim3(256), 0, s, hist, nlist, cnt);
-    hipLaunchKernelGGL(k_q8_offsets, dim3(1), dim3(1024), 0, s, cnt, nlist, off, tile_first, tile_list, n_tiles);
+    hipLaunchKernelGGL(k_q8_offsets, dim3(1), dim3(1024), 0, s, cnt, nlist, off, tile_first, tile_list, n_tiles, a.list_len, a.list_off);
     hipLaunchKernelGGL(k_q8_colfix, dim3((nlist + 255) / 256), dim3(256), 0, s, hist, nlist, off);
     hipLaunchKernelGGL((k_q8_hist<true>), dim3(Q8_NW), dim3(1024), hl, s, a.probe_list, nq, P, G, a.ready, a.list_len, a.list_mask,
-                       nlist, hist, items, a.rq_list, a.rq_count);
-    // LUT | per-slot words | candidate stage
-    const size_t lds = (size_t)M * (M <= 16 ? 288 : 256) * 8 + 11 * 8 * sizeof(int) + (size_t)(M <= 16 ? Q8Pool<16>::N : Q8Pool<32>::N) * sizeof(uint32_t);
+                       nlist, hist, recs, a.rq_list, a.rq_count, a.coarse_dis, a.t2max, a.meta, a.pair_off);
+    // short lists: the pipelined kernel (a tile is a step or two per wave: everything is latency); long lists: the plain loop
+    static const double sl_len = getenv("GAMMA_HIP_Q8_SL_LEN") ? atof(getenv("GAMMA_HIP_Q8_SL_LEN")) : 1000.0;
+    const bool sl = a.mean_len < sl_len;
+    const size_t lut_bytes = (size_t)M * (M <= 16 ? 288 : 256) * 8;
+    const size_t lds = sl ? lut_bytes + 4 * Q8_T * sizeof(Q8Rec) + (9 * Q8_T + 8) * sizeof(int) + 3 * (size_t)Q8_SL_POOL * sizeof(uint32_t)
+                          : lut_bytes + 11 * 8 * sizeof(int) + (size_t)(M <= 16 ? Q8Pool<16>::N : Q8Pool<32>::N) * sizeof(uint32_t);
     const int per_cu = std::max(1, std::min(8, (int)((160 * 1024) / (lds + 512))));
     static const int grid_env = getenv("GAMMA_HIP_Q8_GRID") ? atoi(getenv("GAMMA_HIP_Q8_GRID")) : 0;
     const unsigned grid = grid_env > 0 ? (unsigned)grid_env : (unsigned)(256 * per_cu);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_q8_filter<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_q8_filter_sl<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+        attr = true;
+    }
+#define GH_Q8F(KERN, MM)                                                                                                      \
+    hipLaunchKernelGGL((KERN<MM>), dim3(grid), dim3(Q8_NT), lds, s, tile_list, tile_first, n_tiles, off, recs, a.q8, a.codes, \
+                       a.sums, a.ids, a.ftab, a.need_ids, a.cand, ccnt, cap)
     if (M == 16) {
-        hipLaunchKernelGGL((k_q8_filter<16>), dim3(grid), dim3(Q8_NT), lds, s, tile_list, tile_first, n_tiles, off, items, a.ready,
-                           a.coarse_dis, a.t2max, a.meta, a.q8, a.codes, a.sums, a.ids, a.list_off, a.list_len, a.pair_off, P,
-                           a.ftab, a.need_ids, a.cand, ccnt, cap);
+        if (sl) GH_Q8F(k_q8_filter_sl, 16);
+        else GH_Q8F(k_q8_filter, 16);
         hipLaunchKernelGGL((k_q8_exact<16>), dim3(nq), dim3(256), 0, s, a.st2, a.T2, nq, P, G, a.probe_list, a.coarse_dis, a.list_off,
                            a.codes, a.pair_off, a.ready, a.cand, ccnt, cap, a.surv, a.gcnt, a.cnt_stride, a.slice_cap);
     } else {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_q8_filter<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
-            attr = true;
-        }
-        hipLaunchKernelGGL((k_q8_filter<32>), dim3(grid), dim3(Q8_NT), lds, s, tile_list, tile_first, n_tiles, off, items, a.ready,
-                           a.coarse_dis, a.t2max, a.meta, a.q8, a.codes, a.sums, a.ids, a.list_off, a.list_len, a.pair_off, P,
-                           a.ftab, a.need_ids, a.cand, ccnt, cap);
+        if (sl) GH_Q8F(k_q8_filter_sl, 32);
+        else GH_Q8F(k_q8_filter, 32);
         hipLaunchKernelGGL((k_q8_exact<32>), dim3(nq), dim3(256), 0, s, a.st2, a.T2, nq, P, G, a.probe_list, a.coarse_dis, a.list_off,
                            a.codes, a.pair_off, a.ready, a.cand, ccnt, cap, a.surv, a.gcnt, a.cnt_stride, a.slice_cap);
     }
+#undef GH_Q8F
 }
 
 }  // namespace gh
