@@ -139,7 +139,8 @@ __global__ __launch_bounds__(1024) void k_q8_hist(const int* __restrict__ probe_
                                                   const uint8_t* __restrict__ list_mask, int nlist, int* __restrict__ hist,
                                                   Q8Rec* __restrict__ recs, int* __restrict__ rq_list, int* __restrict__ rq_count,
                                                   const float* __restrict__ coarse_dis, const float* __restrict__ t2max,
-                                                  const float4* __restrict__ meta, const int* __restrict__ pair_off) {
+                                                  const float4* __restrict__ meta, const int* __restrict__ pair_off,
+                                                  const int* __restrict__ off, const int* __restrict__ tile_first) {
     extern __shared__ int s_h[];   // [nlist]
     const int tid = threadIdx.x, w = blockIdx.x;
     const int per = P - G;
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(1024) void k_q8_hist(const int* __restrict__ probe_
             Q8Rec r;
             r.q = q; r.pp = p; r.pb = pair_off[(int64_t)q * (P + 1) + p]; r.pad = 0;
             r.A = dis0 - mq.x; r.nd = mq.y; r.thr = thr; r.pad2 = 0.f;
-            recs[at] = r;
+            recs[(int64_t)tile_first[l] * Q8_T + (at - off[l])] = r;   // slot (at - off) % 8 of tile tile_first + (at - off) / 8
         }
     }
     if (!FILL) {
@@ -186,7 +187,11 @@ __global__ __launch_bounds__(256) void k_q8_colsum(const int* __restrict__ hist,
     cnt[l] = n;
 }
 // the column becomes the workgroups' first positions inside the list's run
-__global__ __launch_bounds__(256) void k_q8_colfix(int* __restrict__ hist, int nlist, const int* __restrict__ off) {
+// ... and the list's tiles get their (list, length, arena offset) entries: a tile starts on its codes without walking the
+// list tables
+__global__ __launch_bounds__(256) void k_q8_colfix(int* __restrict__ hist, int nlist, const int* __restrict__ off,
+                                                   const int* __restrict__ tile_first, int4* __restrict__ tile_list,
+                                                   const int* __restrict__ list_len, const int64_t* __restrict__ list_off) {
     const int l = blockIdx.x * 256 + threadIdx.x;
     if (l >= nlist) return;
     int run = off[l];
@@ -195,12 +200,16 @@ __global__ __launch_bounds__(256) void k_q8_colfix(int* __restrict__ hist, int n
         hist[(int64_t)w * nlist + l] = run;
         run += hv;
     }
+    const int t0 = tile_first[l], t1 = tile_first[l + 1];
+    if (t1 > t0) {
+        const int64_t lo = list_off[l];
+        const int4 ti = make_int4(l, list_len[l], (int)(uint32_t)lo, (int)(lo >> 32));
+        for (int t = t0; t < t1; t++) tile_list[t] = ti;
+    }
 }
 // offsets of the lists' pair runs, the tiles of 8 pairs, the tile -> list table; one workgroup
 __global__ __launch_bounds__(1024) void k_q8_offsets(const int* __restrict__ cnt, int nlist, int* __restrict__ off,
-                                                     int* __restrict__ tile_first, int4* __restrict__ tile_list,
-                                                     int* __restrict__ n_tiles, const int* __restrict__ list_len,
-                                                     const int64_t* __restrict__ list_off) {
+                                                     int* __restrict__ tile_first, int* __restrict__ n_tiles) {
     __shared__ int s_c[1024], s_t[1024];
     const int tid = threadIdx.x;
     const int per = (nlist + 1023) / 1024, a = min(nlist, tid * per), b = min(nlist, a + per);
@@ -225,11 +234,6 @@ __global__ __launch_bounds__(1024) void k_q8_offsets(const int* __restrict__ cnt
         off[l] = oc;
         tile_first[l] = ot;
         const int nt = (n + Q8_T - 1) / Q8_T;
-        if (nt > 0) {   // (list, length, arena offset): a tile starts on its codes without walking the list tables
-            const int64_t lo = list_off[l];
-            const int4 ti = make_int4(l, list_len[l], (int)(uint32_t)lo, (int)(lo >> 32));
-            for (int i = 0; i < nt; i++) tile_list[ot + i] = ti;
-        }
         oc += n;
         ot += nt;
     }
@@ -287,13 +291,10 @@ __global__ __launch_bounds__(Q8_NT) void k_q8_filter(
     const int ntile = *n_tiles;
     for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
         const int4 ti = tile_list[tile];
-        const int l = ti.x;
-        const int first = pair_run[l] + Q8_T * (tile - tile_first[l]);
-        const int nit = min(Q8_T, pair_run[l + 1] - first);
+        const int nit = Q8_T;   // (slots past the tile's pairs hold q = -1 records: the launcher's fill)
         if (tid < Q8_T) {
-            Q8Rec r;
-            r.q = -1; r.pp = 0; r.pb = 0; r.A = 0.f; r.nd = 0.f; r.thr = -INFINITY;
-            if (tid < nit) r = recs[first + tid];
+            Q8Rec r = recs[(int64_t)tile * Q8_T + tid];
+            if (r.q < 0) { r.pp = 0; r.pb = 0; r.A = 0.f; r.nd = 0.f; r.thr = -INFINITY; }
             s_q[tid] = r.q;
             s_pb[tid] = r.pb;
             s_pp[tid] = r.pp;
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(Q8_NT) void k_q8_filter(
         const int np = s_cur[9];   // pool entries [0, np) are valid (reservations past the end went straight to memory)
         if (tid < nit) {
             const int n = s_n[tid];
-            s_g[tid] = n > 0 ? atomicAdd(&ccnt[s_q[tid]], n) : 0;
+            s_g[tid] = (n > 0 && s_q[tid] >= 0) ? atomicAdd(&ccnt[s_q[tid]], n) : 0;
         }
         __syncthreads();
         for (int k = tid; k < np; k += Q8_NT) {
@@ -462,14 +463,11 @@ __global__ __launch_bounds__(Q8_NT) void k_q8_filter_sl(
     const int ntile = *n_tiles, G = (int)gridDim.x;
     int tile = blockIdx.x;
     if (tile >= ntile) return;
-    auto load_rec = [&](int t) -> Q8Rec {   // threads 0..7
+    auto load_rec = [&](int t) -> Q8Rec {   // threads 0..7: ONE load (records are stored per tile, 8 slots, q = -1 in the unused ones)
         Q8Rec r;
-        r.q = -1; r.pp = 0; r.pb = 0; r.pad = 0; r.A = 0.f; r.nd = 0.f; r.thr = -INFINITY; r.pad2 = 0.f;
-        if (t < ntile) {
-            const int l = tile_list[t].x;
-            const int first = pair_run[l] + Q8_T * (t - tile_first[l]);
-            if (tid < min(Q8_T, pair_run[l + 1] - first)) r = recs[first + tid];
-        }
+        r.q = -1;
+        if (t < ntile && tid < Q8_T) r = recs[(int64_t)t * Q8_T + tid];
+        if (r.q < 0) { r.pp = 0; r.pb = 0; r.pad = 0; r.A = 0.f; r.nd = 0.f; r.thr = -INFINITY; r.pad2 = 0.f; }
         return r;
     };
     struct Tab { uint2 r[NB][Q8_T]; };
@@ -731,7 +729,7 @@ bool q8_supported(int M, int P, int G, int64_t q_stride) { return (M == 16 || M 
 //            tile_list (int4) | recs (Q8Rec, 32 B)
 size_t q8_int_words(int nq, int P, int G, int nlist) {
     const int64_t pairs = (int64_t)nq * (P - G);
-    return (size_t)(nq + (int64_t)(Q8_NW + 1) * nlist + 2 * ((int64_t)nlist + 1) + 1 + 8 + 4 * (pairs / Q8_T + nlist + 1) + 8 * pairs + 16);
+    return (size_t)(nq + (int64_t)(Q8_NW + 1) * nlist + 2 * ((int64_t)nlist + 1) + 1 + 8 + 4 * (pairs / Q8_T + nlist + 1) + 8 * Q8_T * (pairs / Q8_T + nlist + 1) + 16);
 }
 
 void launch_q8_consumers(hipStream_t s, const Q8Args& a) {
@@ -748,17 +746,19 @@ void launch_q8_consumers(hipStream_t s, const Q8Args& a) {
     int4* tile_list = reinterpret_cast<int4*>(pa);
     Q8Rec* recs = reinterpret_cast<Q8Rec*>(tile_list + (pairs / Q8_T + nlist + 1));
     (void)hipMemsetAsync(ccnt, 0, (size_t)nq * sizeof(int), s);
+    // (records are stored per tile, 8 slots each: the slots past a tile's pairs read q = -1)
+    (void)hipMemsetAsync(recs, 0xff, (size_t)(pairs / Q8_T + nlist + 1) * Q8_T * sizeof(Q8Rec), s);
     const int cap = q8_cand_cap(nq);
     if (M == 16) hipLaunchKernelGGL((k_q8_quant<16>), dim3(nq), dim3(256), 0, s, a.st2, a.q8, a.meta);
     else hipLaunchKernelGGL((k_q8_quant<32>), dim3(nq), dim3(256), 0, s, a.st2, a.q8, a.meta);
     const size_t hl = (size_t)nlist * sizeof(int);
     hipLaunchKernelGGL((k_q8_hist<false>), dim3(Q8_NW), dim3(1024), hl, s, a.probe_list, nq, P, G, a.ready, a.list_len, a.list_mask,
-                       nlist, hist, (Q8Rec*)nullptr, a.rq_list, a.rq_count, a.coarse_dis, a.t2max, a.meta, a.pair_off);
+                       nlist, hist, (Q8Rec*)nullptr, a.rq_list, a.rq_count, a.coarse_dis, a.t2max, a.meta, a.pair_off, off, tile_first);
     hipLaunchKernelGGL(k_q8_colsum, dim3((nlist + 255) / 256), dim3(256), 0, s, hist, nlist, cnt);
-    hipLaunchKernelGGL(k_q8_offsets, dim3(1), dim3(1024), 0, s, cnt, nlist, off, tile_first, tile_list, n_tiles, a.list_len, a.list_off);
-    hipLaunchKernelGGL(k_q8_colfix, dim3((nlist + 255) / 256), dim3(256), 0, s, hist, nlist, off);
+    hipLaunchKernelGGL(k_q8_offsets, dim3(1), dim3(1024), 0, s, cnt, nlist, off, tile_first, n_tiles);
+    hipLaunchKernelGGL(k_q8_colfix, dim3((nlist + 255) / 256), dim3(256), 0, s, hist, nlist, off, tile_first, tile_list, a.list_len, a.list_off);
     hipLaunchKernelGGL((k_q8_hist<true>), dim3(Q8_NW), dim3(1024), hl, s, a.probe_list, nq, P, G, a.ready, a.list_len, a.list_mask,
-                       nlist, hist, recs, a.rq_list, a.rq_count, a.coarse_dis, a.t2max, a.meta, a.pair_off);
+                       nlist, hist, recs, a.rq_list, a.rq_count, a.coarse_dis, a.t2max, a.meta, a.pair_off, off, tile_first);
     // short lists: the pipelined kernel (a tile is a step or two per wave: everything is latency); long lists: the plain loop
     static const double sl_len = getenv("GAMMA_HIP_Q8_SL_LEN") ? atof(getenv("GAMMA_HIP_Q8_SL_LEN")) : 1000.0;
     const bool sl = a.mean_len < sl_len;
