@@ -400,7 +400,8 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         //  query-major pass there, profiles/r05_q8_*.txt -- so short lists keep the query-major filter pass)
         static const double q8_minlen = getenv("GAMMA_HIP_Q8_MINLEN") ? atof(getenv("GAMMA_HIP_Q8_MINLEN")) : 1000.0;
         const int64_t q_stride0 = (std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len)) + 3) & ~(int64_t)3;
-        q8_ok = !no_q8 && !no_cf && R <= 1024 && !shard && !h->prefiltered && !fc.d_qf && PGN > 1 && mean_len <= q8_maxlen &&
+        // (a list shard with a supplied, compacted assignment runs it too: pairs of lists of other shards are simply not placed)
+        q8_ok = !no_q8 && !no_cf && R <= 1024 && (!shard || compacted) && !h->prefiltered && !fc.d_qf && PGN > 1 && mean_len <= q8_maxlen &&
                 gh::scan_cf_applies(l2, M, P, G, h->d_sums && h->d_t2max, false) && gh::q8_supported(M, P, G, q_stride0) && mean_len >= q8_minlen && nlist <= 16384;
         if (q8_ok) cf_ok = false;
         if (q8_ok) {
