@@ -499,6 +499,31 @@ def main():
                                 # first chunk, against the dense bf16 MFMA peak; its launch times are in profiles/ (rocprofv3)
                                 "filter_bf16_flops_per_call": 6.0 * fnq * max(0, N - 16384) * d}
 
+        # (d') C5's flat fallback / HIPFLAT on embedding-shaped rows: inner product over 1 M x 768 unit vectors, 1024 queries,
+        #      k = 100 (GammaFLATIndex::Search is dimension-agnostic, gamma_index_flat.cc:183-291): the long-row variant of the
+        #      matrix-pipe filter (flat_mfma.hip, k_flat_filter_big: a block of 32 queries' bf16 hi / lo image in LDS, rows streamed)
+        try:
+            fN, fd, fk, fnq = 1000000, 768, 100, 1024
+            gf5 = api.GammaHip(local_rank)
+            gf5.raw_init(fd)
+            for c0 in range(0, fN, 250000):
+                gf5.raw_append(synth.embedding_like_device(250000, d=fd, seed=1234, start=c0, device=dev).cpu().numpy())
+            fq5 = synth.embedding_like_device(fnq, d=fd, seed=4321, device=dev)
+            fD5 = torch.empty((fnq, fk), dtype=torch.float32, device=dev)
+            fI5 = torch.empty((fnq, fk), dtype=torch.int64, device=dev)
+            fa5 = api.SearchArgs(metric=api.METRIC_IP, min_score=-1e30, max_score=1e30)
+            sec5 = timed(lambda: gf5.flat_search_device(fq5.data_ptr(), fnq, fk, fa5, fD5.data_ptr(), fI5.data_ptr()), 3, 1)
+            extra["c5_flat"] = {"workload": "C5 flat: inner product, %dx%d unit-norm embedding-shaped rows, %d queries/call, k=%d" % (fN, fd, fnq, fk),
+                                "ms_per_call": round(sec5 * 1e3, 3), "qps": round(fnq / sec5, 1),
+                                "roofline_gemm_form_flops": {"bound": "mfma", "achieved": round(2.0 * fnq * fN * fd / sec5 / 1e12, 2),
+                                                             "peak": 157.3, "unit": "TFLOP/s",
+                                                             "frac": round(2.0 * fnq * fN * fd / sec5 / 1e12 / 157.3, 4)},
+                                "filter_bf16_flops_per_call": 6.0 * fnq * max(0, fN - 4096) * fd,
+                                "exact_vector_kernel_ms_per_call_round4": "~1200 (k_pairwise_generic at ~1.3 TFLOP/s, profiles/r04_c5_shape_2m_kernel_stats.txt)"}
+            gf5.close()
+        except Exception as e:      # noqa: BLE001 -- a leg never fails the bench
+            extra["c5_flat"] = {"error": str(e)}
+
         # (d2) the IVFFLAT model (f4) on the same vectors, centroids and nprobe: exact distances of every entry of the
         #      probed lists, rows gathered from the raw store
         if N * d * 4 <= (2 << 30):

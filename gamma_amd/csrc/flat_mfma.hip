@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_flat_prep_queries(const float* __restri
 // per pass: the queries' thresholds a_q (and g_q for the inner product), padded to whole tiles -- bnd[2][nq_pad]
 template <bool L2>
 __global__ __launch_bounds__(256) void k_flat_bounds(const float* __restrict__ xn, const uint32_t* __restrict__ tau, int nq,
-                                                     int nq_pad, float* __restrict__ bnd) {
+                                                     int nq_pad, float* __restrict__ bnd, float cm) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= nq_pad) return;
     float av = INFINITY, gv = 0.f;   // a padding query never passes
@@ -114,10 +114,10 @@ __global__ __launch_bounds__(256) void k_flat_bounds(const float* __restrict__ x
         const float tq = t >= 0xff800000u ? (L2 ? 3.402823466e+38f : -3.402823466e+38f) : key2f(L2 ? t : ~t);
         const float x2 = xn[q];
         if (L2) {
-            av = 0.5f * ((1.f - FM_C) * x2 - tq);
+            av = 0.5f * ((1.f - cm) * x2 - tq);
         } else {
             av = tq;
-            gv = -FM_C * __builtin_sqrtf(x2);
+            gv = -cm * __builtin_sqrtf(x2);
         }
     }
     bnd[q] = av;
@@ -355,9 +355,173 @@ __global__ __launch_bounds__(256) void k_flat_exact(const uint2* __restrict__ pa
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Long rows (128 < d <= 1024, d % 32 == 0; round 5: C5's d = 768 ran the exact vector kernel at ~1.3 TFLOP/s).  The rows'
+// fragments no longer fit the registers for a whole launch, so the roles are swapped: a workgroup keeps ONE block of 32
+// QUERIES -- its bf16 hi / lo image, d x 128 bytes of LDS -- for the whole launch and streams rows: 256 rows per step (64
+// per wave), K in steps of 16 with the lane's 8 floats of each of its two rows loaded, split into hi / lo and fed to the same
+// three products; the row's norm falls out of the same loads.  Rows are re-read once per query block (L2 / Infinity Cache:
+// the query blocks walk the same row slice together).  Same survivors' list, same exact stage as the short-row kernel.
+// Margin: |dropped products| <= 3.1 * 2^-18 |x||y|, fp32 accumulation of 3 d exact products <= 3 d 2^-24 |x||y| (1.83e-4 at
+// d = 1024), the fp32 norms <= d 2^-24 (xn + yn), the exact path's own roundings <= (d / 8 + 4) 2^-24 (2 (xn + yn)):
+//   d <= 512:  |d~ - d_exact| <= 1.4e-4 (xn + yn)   margin 2^-12 = 2.44e-4
+//   d <= 1024: |d~ - d_exact| <= 2.7e-4 (xn + yn)   margin 2^-11 = 4.88e-4       (inner product: the same constants on |x||y|)
+// ------------------------------------------------------------------------------------
+float flat_filter_margin(int d) { return d <= 128 ? FM_C : (d <= 512 ? 2.44140625e-4f : 4.8828125e-4f); }
+
+__global__ __launch_bounds__(256) void k_flat_prep_queries_rt(const float* __restrict__ x, int nq, int nq_pad, int D,
+                                                              char* __restrict__ out) {
+    const int KK = D / 16;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nq_pad * (D / 8)) return;
+    const int q = idx / (D / 8), kg = idx % (D / 8);
+    float f[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) f[t] = q < nq ? x[(int64_t)q * D + kg * 8 + t] : 0.f;
+    uint4 hi, lo;
+    split_bf16x8(f, hi, lo);
+    const int mt = q >> 5, i = q & 31, kh = kg / KK, kk = kg % KK;
+    char* base = out + (int64_t)mt * fm_mt_bytes(D);
+    *reinterpret_cast<uint4*>(base + ((((0 * KK + kk) * 2 + kh) * 32 + i) * 16)) = hi;
+    *reinterpret_cast<uint4*>(base + ((((1 * KK + kk) * 2 + kh) * 32 + i) * 16)) = lo;
+}
+
+template <bool L2>
+__global__ __launch_bounds__(FM_NT) void k_flat_filter_big(FlatFilterArgs a, int D, float c_margin) {
+    const int KK = D / 16;
+    const int IMG = fm_mt_bytes(D);
+    extern __shared__ __attribute__((aligned(16))) char s_fm[];
+    char* s_img = s_fm;                                                   // [IMG] the block's 32 queries
+    uint2* s_list = reinterpret_cast<uint2*>(s_fm + IMG);                 // [4 waves][FM_WLIST]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int kh = lane >> 5, j = lane & 31;
+    const int mt = blockIdx.x;
+    // the image: plain copy, once
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(a.qimg + (int64_t)mt * IMG);
+        uint4* dst = reinterpret_cast<uint4*>(s_img);
+        for (int i = tid; i < IMG / 16; i += FM_NT) dst[i] = src[i];
+    }
+    // this lane's 16 queries: i = (reg & 3) + 8 (reg >> 2) + 4 kh
+    float av[16], gv[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int qi = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        av[r] = a.bnd[qi];
+        gv[r] = L2 ? 1.f : a.bnd[a.nq_pad + qi];
+    }
+    __syncthreads();
+    uint2* wl = s_list + w * FM_WLIST;
+    int wcnt = 0;   // wave-uniform
+    const int sub = (int)((blockIdx.x + blockIdx.y * gridDim.x) & (FM_NSUB - 1));
+    int* seg_ctr = a.npairs + sub * FM_CTR_STRIDE;
+    uint2* seg = a.pairs + (int64_t)sub * a.cap;
+    auto flush = [&]() {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(seg_ctr, wcnt);
+        base = __builtin_amdgcn_readfirstlane(base);
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < wcnt; i += 64)
+            if (base + i < a.cap) seg[base + i] = wl[i];
+        __builtin_amdgcn_wave_barrier();
+        wcnt = 0;
+    };
+    // row slice of this workgroup: whole steps of 256 rows
+    const int64_t steps = (a.ny + 255) / 256, per = (steps + gridDim.y - 1) / gridDim.y;
+    const int64_t s_lo = (int64_t)blockIdx.y * per, s_hi = min(steps, s_lo + per);
+    const char* tb = s_img + (kh * 32 + j) * 16;
+    for (int64_t st = s_lo; st < s_hi; st++) {
+        const int64_t r0 = st * 256 + w * 64;
+        const float* yp[2];
+        bool live[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) {
+            const int64_t r = r0 + nt * 32 + j;
+            live[nt] = r < a.ny;
+            yp[nt] = a.y + (live[nt] ? r : 0) * D + (D / 2) * kh;
+        }
+        ff32x16 acc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[nt][r] = 0.f;
+        float ss[2] = {0.f, 0.f};
+        float4 v[2][2];
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) {
+            v[nt][0] = *reinterpret_cast<const float4*>(yp[nt]);
+            v[nt][1] = *reinterpret_cast<const float4*>(yp[nt] + 4);
+        }
+        for (int kk = 0; kk < KK; kk++) {
+            bf16x8 bh[2], bl[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) {
+                const float f[8] = {v[nt][0].x, v[nt][0].y, v[nt][0].z, v[nt][0].w, v[nt][1].x, v[nt][1].y, v[nt][1].z, v[nt][1].w};
+#pragma unroll
+                for (int t = 0; t < 8; t++) ss[nt] = __builtin_fmaf(f[t], f[t], ss[nt]);
+                uint4 hi, lo;
+                split_bf16x8(f, hi, lo);
+                bh[nt] = __builtin_bit_cast(bf16x8, hi);
+                bl[nt] = __builtin_bit_cast(bf16x8, lo);
+            }
+            if (kk + 1 < KK) {   // the next step's floats, in flight during this step's products
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++) {
+                    v[nt][0] = *reinterpret_cast<const float4*>(yp[nt] + 8 * (kk + 1));
+                    v[nt][1] = *reinterpret_cast<const float4*>(yp[nt] + 8 * (kk + 1) + 4);
+                }
+            }
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(tb + ((0 * KK + kk) * 2) * 512);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(tb + ((1 * KK + kk) * 2) * 512);
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) {
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[nt], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[nt], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[nt], acc[nt], 0, 0, 0);
+            }
+        }
+        float hrow[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) {
+            const float yn = ss[nt] + __shfl_xor(ss[nt], 32, 64);
+            hrow[nt] = !live[nt] ? (L2 ? INFINITY : -INFINITY) : (L2 ? 0.5f * (1.f - c_margin) * yn : __builtin_sqrtf(yn));
+        }
+        unsigned long long m[2][16], any = 0ull;
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float t = L2 ? av[r] + hrow[nt] : __builtin_fmaf(gv[r], hrow[nt], av[r]);
+                m[nt][r] = __ballot(acc[nt][r] >= t);
+                any |= m[nt][r];
+            }
+        if (any) {
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const unsigned long long mm = m[nt][r];
+                    if (mm) {   // scalar branch
+                        const int n = __popcll(mm);
+                        if (wcnt + n > FM_WLIST) flush();
+                        if ((mm >> lane) & 1ull) {
+                            const uint32_t q = (uint32_t)(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh);
+                            wl[wcnt + __popcll(mm & ((1ull << lane) - 1ull))] = make_uint2(q, (uint32_t)(a.row_base + r0 + nt * 32 + j));
+                        }
+                        wcnt += n;
+                    }
+                }
+        }
+    }
+    if (wcnt > 0) flush();
+}
+
 bool flat_filter_supported(int nq, int d, int64_t ny) {
     static const bool off = getenv("GAMMA_HIP_NO_FLAT_MFMA") != nullptr;
-    return !off && (d == 128 || d == 96 || d == 64 || d == 32) && nq >= 64 && ny >= 4096;
+    static const bool off_big = getenv("GAMMA_HIP_NO_FLAT_MFMA_BIG") != nullptr;
+    const bool small = d == 128 || d == 96 || d == 64 || d == 32;
+    const bool big = !off_big && d > 128 && d <= 1024 && d % 32 == 0;   // k_flat_filter_big: the query block's image is d x 128 bytes of LDS
+    return !off && (small || big) && nq >= 64 && ny >= 4096;
 }
 int64_t flat_filter_pair_cap(int nq) { return (int64_t)nq * 1024; }   // ~k survivors per query and pass are expected (all segments)
 int flat_filter_counter_bytes() { return FM_NSUB * FM_CTR_STRIDE * (int)sizeof(int); }
@@ -377,7 +541,9 @@ void launch_flat_prep_queries(hipStream_t s, const float* x, int nq, int d, void
         case 96: GH_PREP(96); break;
         case 64: GH_PREP(64); break;
         case 32: GH_PREP(32); break;
-        default: abort();   // flat_filter_supported
+        default:   // long rows (flat_filter_supported: d % 32 == 0)
+            hipLaunchKernelGGL(k_flat_prep_queries_rt, dim3((n + 255) / 256), dim3(256), 0, s, x, nq, nq_pad, d, out);
+            break;
     }
 #undef GH_PREP
 }
@@ -401,8 +567,9 @@ void launch_flat_filter(hipStream_t s, bool l2, int d, const void* qimage, const
     a.qimg = static_cast<const char*>(qimage);
     a.nq = nq;
     a.nq_pad = (nq + FM_QT - 1) / FM_QT * FM_QT;
-    if (l2) hipLaunchKernelGGL((k_flat_bounds<true>), dim3((a.nq_pad + 255) / 256), dim3(256), 0, s, xn, tau, nq, a.nq_pad, bounds);
-    else hipLaunchKernelGGL((k_flat_bounds<false>), dim3((a.nq_pad + 255) / 256), dim3(256), 0, s, xn, tau, nq, a.nq_pad, bounds);
+    const float cm = flat_filter_margin(d);
+    if (l2) hipLaunchKernelGGL((k_flat_bounds<true>), dim3((a.nq_pad + 255) / 256), dim3(256), 0, s, xn, tau, nq, a.nq_pad, bounds, cm);
+    else hipLaunchKernelGGL((k_flat_bounds<false>), dim3((a.nq_pad + 255) / 256), dim3(256), 0, s, xn, tau, nq, a.nq_pad, bounds, cm);
     a.bnd = bounds;
     a.y = y;
     a.ny = ny;
@@ -420,7 +587,20 @@ void launch_flat_filter(hipStream_t s, bool l2, int d, const void* qimage, const
         case 96: GH_FILT(96); break;
         case 64: GH_FILT(64); break;
         case 32: GH_FILT(32); break;
-        default: abort();   // flat_filter_supported
+        default: {   // long rows: one workgroup per (block of 32 queries, slice of the rows)
+            const size_t lds = (size_t)fm_mt_bytes(d) + (FM_NT / 64) * FM_WLIST * sizeof(uint2);
+            static std::atomic<uint64_t> attr{0};   // per device
+            if (first_call_on_device(attr)) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_flat_filter_big<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_flat_filter_big<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+            }
+            const int qb = a.nq_pad / 32;
+            const int64_t steps = (a.ny + 255) / 256;
+            const int slices = (int)std::max<int64_t>(1, std::min<int64_t>(steps, (2048 + qb - 1) / qb));
+            if (l2) hipLaunchKernelGGL((k_flat_filter_big<true>), dim3(qb, slices), dim3(FM_NT), lds, s, a, d, cm);
+            else hipLaunchKernelGGL((k_flat_filter_big<false>), dim3(qb, slices), dim3(FM_NT), lds, s, a, d, cm);
+            break;
+        }
     }
 #undef GH_FILT
 }

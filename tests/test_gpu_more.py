@@ -261,7 +261,9 @@ def test_flat_running_bound(order):
         g.close()
 
 
-@pytest.mark.parametrize("d,kind", [(128, "near_duplicates"), (64, "wide_range"), (96, "sift"), (32, "near_duplicates"), (128, "unit")])
+@pytest.mark.parametrize("d,kind", [(128, "near_duplicates"), (64, "wide_range"), (96, "sift"), (32, "near_duplicates"), (128, "unit"),
+                                    # long rows (round 5, k_flat_filter_big): C5's d = 768 and the variant's range, margins 2^-12 / 2^-11
+                                    (768, "near_duplicates"), (768, "unit"), (256, "wide_range"), (512, "sift"), (1024, "unit"), (160, "unit")])
 def test_flat_matrix_filter_never_drops_a_neighbour(d, kind):
     """flat_mfma.hip: from 64 queries on the passes behind the first row chunk run a bf16 hi / lo filter on the matrix pipe
     (three products, a proven error margin) and only the survivors get the reference's exact arithmetic.  The filter must
@@ -270,7 +272,7 @@ def test_flat_matrix_filter_never_drops_a_neighbour(d, kind):
     columns spanning six orders of magnitude, unit-norm embeddings; L2 and inner product; deletes, a range filter and a
     score window; batch sizes with padded tiles."""
     rng = np.random.default_rng(d)
-    N = 90000
+    N = 90000 if d <= 128 else 40000
     if kind == "near_duplicates":
         proto = (rng.standard_normal((50, d)) * 40).astype(np.float32)
         base = (proto[rng.integers(0, 50, N)] + rng.standard_normal((N, d)).astype(np.float32) * np.float32(2e-3)).astype(np.float32)
