@@ -518,7 +518,7 @@ def main():
                                 "roofline_gemm_form_flops": {"bound": "mfma", "achieved": round(2.0 * fnq * fN * fd / sec5 / 1e12, 2),
                                                              "peak": 157.3, "unit": "TFLOP/s",
                                                              "frac": round(2.0 * fnq * fN * fd / sec5 / 1e12 / 157.3, 4)},
-                                "filter_bf16_flops_per_call": 6.0 * fnq * max(0, fN - 4096) * fd,
+                                "filter_bf16_flops_per_call": 6.0 * fnq * max(0, fN - 1024) * fd,
                                 "exact_vector_kernel_ms_per_call_round4": "~1200 (k_pairwise_generic at ~1.3 TFLOP/s, profiles/r04_c5_shape_2m_kernel_stats.txt)"}
             gf5.close()
         except Exception as e:      # noqa: BLE001 -- a leg never fails the bench

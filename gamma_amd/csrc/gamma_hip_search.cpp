@@ -1343,8 +1343,11 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
     // per query and pass) takes the passes behind the first row chunk when the shape has a variant; the first chunk -- scored
     // exactly for every query, the only part still on the vector ALU -- is then 16384 rows instead of 65536.
     const bool mfma_filter = k <= 256 && N < ((int64_t)1 << 32) && gh::flat_filter_supported(nq, d, N);
-    // (long rows: the first chunk's exact kernel runs at ~1.3 TFLOP/s -- 4096 rows of d = 768 instead of 16384)
-    int64_t rows_chunk = std::max<int64_t>(256, std::min<int64_t>(N, (int64_t)1 << (mfma_filter ? (d > 128 ? 12 : 14) : 16)));
+    // (long rows: the first chunk's exact kernel runs at ~1.3 TFLOP/s -- 1024 rows of d = 768 instead of 16384: C5 flat, 1 M x 768,
+    //  1024 queries: 15.6 / 16.1 / 16.8 / 18.4 ms per call with a first chunk of 2^10 / 2^11 / 2^12 / 2^13 rows)
+    static const int first_log2 = getenv("GAMMA_HIP_FLAT_FIRST_LOG2") ? atoi(getenv("GAMMA_HIP_FLAT_FIRST_LOG2")) : 0;
+    const int fl2 = (first_log2 >= 8 && first_log2 <= 16 && mfma_filter) ? first_log2 : (mfma_filter ? (d > 128 ? 10 : 14) : 16);
+    int64_t rows_chunk = std::max<int64_t>(256, std::min<int64_t>(N, (int64_t)1 << fl2));
     rows_chunk = (rows_chunk + 255) / 256 * 256;
     int qc = (int)std::max<int64_t>(1, std::min<int64_t>(nq, (int64_t)(h->dist_budget_bytes / (rows_chunk * sizeof(float)))));
     const int nchunks = (int)std::max<int64_t>(1, (N + rows_chunk - 1) / rows_chunk);
