@@ -261,6 +261,28 @@ __device__ __forceinline__ uint32_t add_byte(uint32_t acc, uint32_t w) {
     return __builtin_amdgcn_udot4(w, 1u << (8 * K), acc, false);
 }
 
+// LDS byte address of table entry (m, code byte k of w) in the UNPADDED layout (M = 32): (byte << 3) + 2048 m with the table
+// at LDS address 0 (the kernels' only LDS is the dynamic block) -- one SDWA shift per look-up, the row offset in the ds_read's
+// immediate (as lut_gather, scan_dev.h); the padded layout (M = 16) pays the extra c + (c >> 3)
+template <int MT>
+__device__ __forceinline__ uint2 q8_gather(const unsigned char* lut, uint32_t w, int k, int m) {
+    if constexpr (!Q8Lut<MT>::PAD) {
+        uint32_t a;
+        switch (k) {   // constant after unrolling
+            case 0: asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(a) : "v"(w)); break;
+            case 1: asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(a) : "v"(w)); break;
+            case 2: asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(a) : "v"(w)); break;
+            default: asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(a) : "v"(w)); break;
+        }
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 v = *reinterpret_cast<const __attribute__((address_space(3))) u32x2*>((uintptr_t)(a + 2048u * (uint32_t)m));
+        return make_uint2(v.x, v.y);
+    } else {
+        const uint32_t c = (w >> (8 * k)) & 255u;
+        return *reinterpret_cast<const uint2*>(lut + (size_t)m * Q8Lut<MT>::ROW * 8 + Q8Lut<MT>::entry(c) * 8);
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // The filter: a persistent grid walks the tiles.  Q8_NT threads; a wave takes 64 codes of the list per step.
 // (512 threads: the table limits a CU to two (M = 32) / four (M = 16) workgroups, and with four waves each the code loads
@@ -371,11 +393,7 @@ __global__ __launch_bounds__(Q8_NT) void k_q8_filter(
             }
             uint2 t[MT];
 #pragma unroll
-            for (int m = 0; m < MT; m++) {
-                const uint32_t c = (cw[m >> 2] >> (8 * (m & 3))) & 255u;
-                const uint32_t e = Q8Lut<MT>::entry(c);
-                t[m] = *reinterpret_cast<const uint2*>(lut + (size_t)m * ROW * 8 + e * 8);
-            }
+            for (int m = 0; m < MT; m++) t[m] = q8_gather<MT>(lut, cw[m >> 2], m & 3, m);
             __builtin_amdgcn_sched_barrier(0);   // all gathers in flight before the sums
             uint32_t acc[Q8_T] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -584,11 +602,7 @@ __global__ __launch_bounds__(Q8_NT) void k_q8_filter_sl(
                 }
                 uint2 t[MT];
 #pragma unroll
-                for (int m = 0; m < MT; m++) {
-                    const uint32_t c = (cw[m >> 2] >> (8 * (m & 3))) & 255u;
-                    const uint32_t e = Q8Lut<MT>::entry(c);
-                    t[m] = *reinterpret_cast<const uint2*>(lut + (size_t)m * ROW * 8 + e * 8);
-                }
+                for (int m = 0; m < MT; m++) t[m] = q8_gather<MT>(lut, cw[m >> 2], m & 3, m);
                 __builtin_amdgcn_sched_barrier(0);   // all gathers in flight before the sums
                 uint32_t acc[Q8_T] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
