@@ -86,7 +86,14 @@ static int run(const char* type, const char* params, bool ivf) {
 }
 
 int main() {
+#ifdef GAMMA_STRESS_GROUP
+    // the REAL gamma_hip_group.cpp (member threads, barriers, go / no-go snapshots) behind the plugin's "devices" key, on three
+    // stub handles: replicate placement (every member holds every list, queries split)
+    return run("HIPIVFPQ", "{\"ncentroids\": 32, \"nsubvector\": 8, \"nprobe\": 8, \"metric_type\": \"L2\", \"devices\": \"0,1,2\", "
+                           "\"placement\": \"replicate\"}", true);
+#else
     int rc = run("HIPIVFPQ", "{\"ncentroids\": 32, \"nsubvector\": 8, \"nprobe\": 8, \"metric_type\": \"L2\"}", true);
     if (rc) return rc;
     return run("HIPFLAT", "{\"metric_type\": \"L2\"}", false);
+#endif
 }

@@ -26,7 +26,9 @@ struct gamma_hip_index {
     bool trained = false;
     std::string err;
 };
+#ifndef GAMMA_STUB_REAL_GROUP
 struct gamma_hip_group { int dummy; };
+#endif
 
 extern "C" {
 int gamma_hip_create(int, gamma_hip_index** out) { *out = new gamma_hip_index(); return GAMMA_HIP_OK; }
@@ -196,7 +198,17 @@ int gamma_hip_term_append(gamma_hip_index*, int, int64_t, const int32_t*, const 
 int gamma_hip_field_update(gamma_hip_index*, int, int64_t, const void*) { return GAMMA_HIP_EUNSUPPORTED; }
 int gamma_hip_field_append(gamma_hip_index*, int, int, int64_t, const void*) { return GAMMA_HIP_EUNSUPPORTED; }
 int gamma_hip_kmeans(gamma_hip_index*, int, int64_t, const float*, int, int, int64_t, int, float*, float*) { return GAMMA_HIP_EUNSUPPORTED; }
-int gamma_hip_assign(gamma_hip_index*, int, int64_t, const float*, int, const float*, int32_t*, float*) { return GAMMA_HIP_EUNSUPPORTED; }
+int gamma_hip_assign(gamma_hip_index*, int d, int64_t n, const float* x, int k, const float* centroids, int32_t* assign, float* dis) {
+    std::vector<float> D((size_t)n);
+    std::vector<int64_t> I((size_t)n);
+    go_knn_L2sqr(n < 20 ? 0 : 1, x, centroids, (size_t)d, (size_t)n, (size_t)k, 1, D.data(), I.data());
+    for (int64_t i = 0; i < n; i++) {
+        assign[i] = (int32_t)I[i];
+        if (dis) dis[i] = D[i];
+    }
+    return GAMMA_HIP_OK;
+}
+#ifndef GAMMA_STUB_REAL_GROUP   /* the group build links the REAL gamma_hip_group.cpp instead (Makefile: stress_group_tsan) */
 int gamma_hip_group_create(const int*, int, gamma_hip_group**) { return GAMMA_HIP_EUNSUPPORTED; }
 int gamma_hip_group_destroy(gamma_hip_group*) { return GAMMA_HIP_EUNSUPPORTED; }
 int gamma_hip_group_size(const gamma_hip_group*) { return 0; }
@@ -214,4 +226,66 @@ int gamma_hip_group_ivfpq_delete(gamma_hip_group*, const int64_t*, int) { return
 int gamma_hip_group_ivfpq_compact_if_need(gamma_hip_group*) { return GAMMA_HIP_EUNSUPPORTED; }
 int gamma_hip_group_ivfpq_add_keys(gamma_hip_group*, int, int, const int64_t*, const uint8_t*) { return GAMMA_HIP_EUNSUPPORTED; }
 int gamma_hip_group_ivfpq_add(gamma_hip_group*, int64_t, const float*, int64_t) { return GAMMA_HIP_EUNSUPPORTED; }
+#endif
+
+/* ---- what gamma_hip_group.cpp calls on its members (replicate placement: every member holds every list) ---- */
+void* gamma_hip_stream(gamma_hip_index*) { return nullptr; }
+int gamma_hip_synchronize(gamma_hip_index*) { return GAMMA_HIP_OK; }
+int gamma_hip_ivfpq_dim(gamma_hip_index* h) { return h ? h->d : -1; }
+int gamma_hip_ivfpq_nlist(gamma_hip_index* h) { return h ? h->nlist : -1; }
+int gamma_hip_ivfpq_code_size(gamma_hip_index* h) { return h ? h->M : -1; }
+int gamma_hip_ivfpq_set_list_mask(gamma_hip_index*, const uint8_t*) { return GAMMA_HIP_OK; }
+int gamma_hip_ivfpq_encode(gamma_hip_index* h, int64_t n, const float* v, int64_t* lno, uint8_t* codes) {
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!h->trained) return GAMMA_HIP_ENOTTRAINED;
+    go_ivfpq_encode(h->ix, n, v, lno, codes);
+    return GAMMA_HIP_OK;
+}
+int gamma_hip_ivfpq_encode_each(gamma_hip_index* h, int64_t n, const float* v, int64_t* lno, uint8_t* codes) {
+    return gamma_hip_ivfpq_encode(h, n, v, lno, codes);
+}
+int gamma_hip_ivfpq_add_keys_batch(gamma_hip_index* h, int nl, const int32_t* lists, const int32_t* counts, const int64_t* vids,
+                                   const uint8_t* codes) {
+    std::lock_guard<std::mutex> g(h->mu);
+    size_t at = 0;
+    for (int i = 0; i < nl; i++) {
+        if (!go_ivfpq_add_keys(h->ix, lists[i], counts[i], vids + at, codes + at * h->M)) return GAMMA_HIP_EFULL;
+        at += counts[i];
+    }
+    return GAMMA_HIP_OK;
+}
+int gamma_hip_ivfpq_has_vid(gamma_hip_index* h, const int64_t* vids, int n, uint8_t* out) {
+    std::lock_guard<std::mutex> g(h->mu);
+    for (int i = 0; i < n; i++) out[i] = go_ivfpq_has_vid(h->ix, vids[i]) ? 1 : 0;
+    return GAMMA_HIP_OK;
+}
+int gamma_hip_ivfpq_apply_updates(gamma_hip_index* h, int n, const int32_t* lists, const int64_t* vids, const uint8_t* codes,
+                                  const uint8_t* ops) {
+    std::lock_guard<std::mutex> g(h->mu);
+    for (int i = 0; i < n; i++) {
+        const int op = ops ? ops[i] : 0;
+        if (op == 2) go_ivfpq_remove(h->ix, vids[i]);
+        else if (op == 1) go_ivfpq_add_keys(h->ix, lists[i], 1, vids + i, codes + (size_t)i * h->M);
+        else go_ivfpq_update_code(h->ix, lists[i], vids[i], codes + (size_t)i * h->M);
+    }
+    return GAMMA_HIP_OK;
+}
+int gamma_hip_ivfpq_search_device(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x, int k, float* D, int64_t* I) {
+    return gamma_hip_ivfpq_search(h, p, nq, x, k, D, I);   // "device" memory is host memory here (fakehip)
+}
+/* list-shard entry points: not reached in replicate placement */
+int gamma_hip_gather_rows(gamma_hip_index*, const void*, int, const int32_t*, int, void*) { return GAMMA_HIP_EUNSUPPORTED; }
+int gamma_hip_ivfpq_coarse_device(gamma_hip_index*, const gamma_hip_search_params*, int, const float*, float*, int32_t*) { return GAMMA_HIP_EUNSUPPORTED; }
+int gamma_hip_ivfpq_search_shard_preassigned(gamma_hip_index*, const gamma_hip_search_params*, int, const float*, const float*, const int32_t*,
+                                             int, float*, int64_t*) { return GAMMA_HIP_EUNSUPPORTED; }
+int gamma_hip_ivfpq_merge_rerank(gamma_hip_index*, const gamma_hip_search_params*, int, int, const float*, int, const float*, const int64_t*,
+                                 int, int, float*, int64_t*) { return GAMMA_HIP_EUNSUPPORTED; }
+int gamma_hip_ivfpq_shard_cut_flags(gamma_hip_index*, int, uint8_t*) { return GAMMA_HIP_EUNSUPPORTED; }
+int gamma_hip_ivfpq_merge_set_shard_flags(gamma_hip_index*, const uint8_t*) { return GAMMA_HIP_EUNSUPPORTED; }
+int gamma_hip_ivfpq_merge_flagged(gamma_hip_index*, int*, const int32_t**) { return GAMMA_HIP_EUNSUPPORTED; }
+int gamma_hip_ivfpq_shard_export_rows(gamma_hip_index*, const gamma_hip_search_params*, int, const int32_t*, int64_t*) { return GAMMA_HIP_EUNSUPPORTED; }
+int gamma_hip_ivfpq_shard_export(gamma_hip_index*, const gamma_hip_search_params*, int, const float*, const float*, const int32_t*, int64_t,
+                                 float*, int64_t*, int32_t*) { return GAMMA_HIP_EUNSUPPORTED; }
+int gamma_hip_ivfpq_merge_replay(gamma_hip_index*, const gamma_hip_search_params*, int, int, const float*, int64_t, const float*, const int64_t*,
+                                 const int32_t*, int, const int32_t*, float*, int64_t*) { return GAMMA_HIP_EUNSUPPORTED; }
 }
