@@ -289,6 +289,13 @@ struct gamma_hip_index {
         bool on = false, bounded = false;
         int G = 0, nsl = 0, cap = 0;
         int64_t q_stride = 0;
+        // ScanBound::prod_cf: the slab segment of a query's first probe group holds approximate values; a query whose slab is
+        // read (tie replay) gets it re-scored first -- what that launch needs of stage A's arguments
+        bool prod_cf = false;
+        int need_ids = 0;
+        const void* d_ftab = nullptr;
+        const int* d_qf = nullptr;
+        const float* dis0 = nullptr;
     } tie;
 
     // last-search stage info

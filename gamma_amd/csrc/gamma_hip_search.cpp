@@ -527,6 +527,9 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         sb.spins = spins_env;
         sb.timeouts = h->d_bound_stat + 4;
         sb.slice_cap = cap;
+        // the producer on the filter pass's arithmetic too (scan.hip, prod_cf): with the query-major filter pass, not for shards
+        static const bool no_prod_cf = getenv("GAMMA_HIP_NO_PROD_CF") != nullptr;
+        sb.prod_cf = (cf_ok && !shard && !no_prod_cf) ? 1 : 0;
         if (!q8_ok) {
             scan(G, 0, PGM, &sb, true);
         } else {
@@ -595,13 +598,20 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         h->bound_calls++;
         if (PGN > 1 && !sb.store_all) {
             // queries the slices could not answer: their consumer groups are scored again, distances stored
+            // (prod_cf: group 0 too -- its slab segment holds approximate values -- and for the queries without a bound as well)
             StageScope t2(h, GAMMA_HIP_STAGE_SCAN, false);
+            if (sb.prod_cf) gh::launch_rq_nobound(s, sb.ready, nq, sb.rq_list, sb.rq_count);
             gh::launch_ivfpq_scan_pair(s, l2, d_x, nq, d, M, P, h->w_probe.as<int>(), dis0, h->d_cc,
                                        h->w_st2.as<float>(), h->d_T2, h->d_list_off, h->d_list_len, h->d_list_mask,
                                        nlist, h->d_codes, h->d_ids, h->w_pair_off.as<int>(), q_stride,
-                                       h->w_dist.as<float>(), fc.d_tab, fc.d_qf, need_ids, nullptr, G, 1, PGN - 1,
-                                       shard ? 1 : 0, nullptr, nullptr, sb.rq_list, sb.rq_count);
+                                       h->w_dist.as<float>(), fc.d_tab, fc.d_qf, need_ids, nullptr, G, sb.prod_cf ? 0 : 1,
+                                       sb.prod_cf ? PGN : PGN - 1, shard ? 1 : 0, nullptr, nullptr, sb.rq_list, sb.rq_count);
         }
+        h->tie.prod_cf = sb.prod_cf != 0;
+        h->tie.need_ids = need_ids;
+        h->tie.d_ftab = fc.d_tab;
+        h->tie.d_qf = fc.d_qf;
+        h->tie.dis0 = dis0;
         gh::launch_select_topk(s, l2, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), 0,
                                (int)std::min<int64_t>(q_stride, 1 << 30), nq, R,
                                out_dis, h->w_cand_pos.as<int>(), h->w_sflag.as<uint8_t>());
@@ -698,6 +708,16 @@ int ivfpq_stage_b(H* h, const gamma_hip_search_params* p, int nq, const float* d
         a.cand_ids = const_cast<int64_t*>(cand_ids);
         a.distances = d_distances;
         a.labels = d_labels;
+        if (h->tie.prod_cf) {
+            // the flagged queries' first probe group: the slab holds the producer's approximate values (ScanBound::prod_cf), the
+            // replay walks the reference's -- re-scored here, on the search stream, in front of the replay (the tables and the
+            // assignment of this call are still in place)
+            gh::launch_ivfpq_scan_pair(s, l2, d_x, nq, h->d, h->M, p->nprobe, h->w_probe.as<int>(), h->tie.dis0, h->d_cc,
+                                       h->w_st2.as<float>(), h->d_T2, h->d_list_off, h->d_list_len, h->d_list_mask, h->nlist,
+                                       h->d_codes, h->d_ids, h->w_pair_off.as<int>(), h->tie.q_stride, h->w_dist.as<float>(),
+                                       static_cast<const gh::FilterDesc*>(h->tie.d_ftab), h->tie.d_qf, h->tie.need_ids, nullptr,
+                                       h->tie.G, 0, 1, 0, nullptr, nullptr, tf.list, tf.count);
+        }
         static const bool no_side = getenv("GAMMA_HIP_NO_SIDE_STREAM") != nullptr;
         if (h->defer_now && h->side2 && !no_side) {
             // beside whatever the search stream does next that does not touch the replay's inputs (replay_join)

@@ -173,6 +173,10 @@ struct ScanBound {
     int spins;                  // sleeps a consumer waits for its producer's bound before it goes on without one (0: 2048)
     unsigned long long* timeouts;   // consumers that gave up waiting (diagnostics; may be nullptr)
     int slice_cap;              // items a slice holds: scan_slice_cap(K)
+    int prod_cf;                // != 0 (filter-pass launches only): the PRODUCER scores its probes with the query's table + the per-code
+                                // sums too -- no per-list table -- bounds from those values plus their error margin, and gives only its
+                                // candidates the exact arithmetic.  Its slab segment then holds APPROXIMATE values: the callers re-score
+                                // group 0 (repair launch) for every query whose slab is read (unfiltered selection, tie replay)
 };
 // ---- q8scan.hip: the consumer probes of a bounded L2 scan, list-major over byte tables (one list x 8 queries per tile) ----
 struct Q8Args {
@@ -208,6 +212,7 @@ int q8_cand_cap(int nq);
 size_t q8_int_words(int nq, int P, int G, int nlist);
 void launch_q8_consumers(hipStream_t s, const Q8Args& a);
 int scan_slice_cap(int K);   // 1024 up to recall_num 256, 2048 up to 1024
+void launch_rq_nobound(hipStream_t s, const unsigned long long* ready, int nq, int* rq_list, int* rq_count);
 // true when launch_ivfpq_scan_pair would run the filter pass (CF) for a bounded scan with these arguments; the caller
 // then launches TWO groups per query -- the producer's G probes and one consumer group with all the others
 bool scan_cf_applies(bool l2, int M, int P, int G, bool have_sums, bool store_all);

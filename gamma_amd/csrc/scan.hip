@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
         }
     }
     if constexpr (CF) {
-        if (pg > 0) {   // (uniform) largest |entry| of the query's table: one word per wave, read behind the barrier below
+        if (pg > 0 || sb.prod_cf) {   // (uniform) largest |entry| of the query's table: one word per wave, read behind the barrier below
             float mxv = 0.f;
 #pragma unroll
             for (int i = 0; i < MT; i++) mxv = fmaxf(mxv, fabsf(s2r[i]));
@@ -400,8 +400,102 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
             return;
         }
     }
+    // ---- producer with the filter pass's arithmetic (sb.prod_cf, round 5) ---------------------------------------------------
+    // The producer was the expensive quarter of the launch: a per-list table (16 KB of T2 through the L2, 4096 fma + LDS stores,
+    // two barriers) for lists of a few hundred codes -- 1635 cycles per (query, list) pair against 675 for a consumer pair.
+    // It needs exact values for nothing but its own ~K + one-bin candidates: the bound only has to be an UPPER bound of the
+    // K-th best.  With f_j = (dis0 + s_j) - 2 sum_m ip[c_m] (the consumers' test value, |f_j - v_j| <= 50 * 2^-24 S) the K-th
+    // smallest f plus the margin 2^-17 S_max bounds the K-th smallest exact value, so: score the group with the query's table
+    // alone, histogram the f's, publish tau' = edge + margin, recompute exactly the codes with f <= tau' + margin and keep
+    // those with v <= tau'.  The slab segment of group 0 holds the f's, NOT the reference's values (see ScanBound::prod_cf).
+    float prod_smax = 0.f;
+    bool prod_done = false;
+    if constexpr (CF) {
+        if (pg == 0 && sb.prod_cf) {   // (uniform)
+            prod_done = true;
+            lut_store_begin(lut_m0);
+            lut_store_rows<MT>([&](int i) { return s2r[i]; }, std::make_integer_sequence<int, (MT > 0 ? MT : 1)>{});
+            lut_store_done();
+            int& s_next = *reinterpret_cast<int*>(s_cand + SCAN_CF_CAP);
+            uint32_t& s_smax = *(reinterpret_cast<uint32_t*>(s_cand + SCAN_CF_CAP) + 1);
+            if (tid == 0) {
+                s_next = 0;
+                s_smax = 0u;
+            }
+            __syncthreads();   // the LUT, the list counter and the per-wave maxima are in place
+            const float qmax = __uint_as_float(max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3])));
+            const int ng = p_end - p_begin;
+            for (;;) {
+                int r = 0;
+                if (lane == 0) r = atomicAdd(&s_next, 1);
+                r = __builtin_amdgcn_readfirstlane(r);
+                if (r >= ng) break;
+                const int p = p_begin + r, pair = q * P + p;
+                const int l = probe_list[pair];
+                if (l < 0 || l >= nlist) continue;            // uniform per wave
+                if (list_mask && !list_mask[l]) continue;
+                const int len = list_len[l];
+                if (len <= 0) continue;
+                const int64_t off = list_off[l];
+                const uint8_t* lc = codes + off * MT;
+                const float* ls = sb.sums + off;
+                const int64_t* lid = ids + off;
+                const float dis0 = coarse_dis[pair];
+                float* o = out + (int64_t)q * q_stride + pair_off[(int64_t)q * (P + 1) + p];
+                prod_smax = fmaxf(prod_smax, fabsf(dis0) + sb.t2max[l] + 32.f * qmax);
+                uint4 cn[MT / 16];
+                float sn;
+                {
+                    const int jc = min(lane, len - 1);
+                    const uint4* cp = reinterpret_cast<const uint4*>(lc + (int64_t)jc * MT);
+#pragma unroll
+                    for (int u = 0; u < MT / 16; u++) cn[u] = cp[u];
+                    sn = ls[jc];
+                }
+                for (int j0 = 0; j0 < len; j0 += 64) {
+                    const int j = j0 + lane;
+                    uint32_t cw[MT / 4];
+#pragma unroll
+                    for (int u = 0; u < MT / 16; u++) {
+                        cw[4 * u] = cn[u].x; cw[4 * u + 1] = cn[u].y; cw[4 * u + 2] = cn[u].z; cw[4 * u + 3] = cn[u].w;
+                    }
+                    const float sj = sn;
+                    if (j0 + 64 < len) {   // (uniform)
+                        const int jc = min(j + 64, len - 1);
+                        const uint4* cp = reinterpret_cast<const uint4*>(lc + (int64_t)jc * MT);
+#pragma unroll
+                        for (int u = 0; u < MT / 16; u++) cn[u] = cp[u];
+                        sn = ls[jc];
+                    }
+                    bool ok = j < len;
+                    if (need_ids && ok) {
+                        const int64_t id = lid[j];
+                        ok = id >= 0;
+                        if (ok) ok = is_valid_doc(filt, id);
+                    }
+                    float t[MT];
+#pragma unroll
+                    for (int m = 0; m < MT; m++) t[m] = lut_gather(cw[m >> 2], m & 3, m);
+                    __builtin_amdgcn_sched_barrier(0);
+                    float g4[4] = {t[0], t[1], t[2], t[3]};
+#pragma unroll
+                    for (int m = 4; m < MT; m++) g4[m & 3] += t[m];
+                    const float g = (g4[0] + g4[1]) + (g4[2] + g4[3]);
+                    const float f = __builtin_fmaf(-2.f, g, dis0 + sj);
+                    if (j < len) {
+                        const float val = ok ? f : sentinel;
+                        o[j] = val;
+                        g_fmn = fminf(g_fmn, ok ? val : INFINITY);
+                        g_fmx = fmaxf(g_fmx, ok ? val : -INFINITY);
+                        g_nv += ok ? 1 : 0;
+                    }
+                }
+            }
+            if (lane == 0) atomicMax(&s_smax, __float_as_uint(prod_smax));   // non-negative floats order as integers
+        }
+    }
     if (!L2) __syncthreads();   // the LUT (written once per query) is complete; L2 rebuilds it per list
-    for (int p = p_begin; p < p_end; p++) {
+    for (int p = p_begin; p < (prod_done ? p_begin : p_end); p++) {
         const int pair = q * P + p;
         const int l = probe_list[pair];
         if (l < 0 || l >= nlist) continue;            // uniform
@@ -671,13 +765,90 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
             // list shard, each a latency-bound pass over its slab behind the chunk's scan.
             tau = KEY_SENTINEL - 1u;
         }
+        float prod_m = 0.f;
+        if constexpr (CF) {
+            if (prod_done && tau < KEY_SENTINEL) {   // (uniform) the bound of the EXACT values: the f's edge + their error margin
+                const uint32_t smax = *(reinterpret_cast<const uint32_t*>(s_cand + SCAN_CF_CAP) + 1);
+                prod_m = __uint_as_float(smax) * (1.f / 131072.f);
+                if (tau < KEY_SENTINEL - 1u) {
+                    float tp = key2f(tau) + prod_m;
+                    tp += fabsf(tp) * 1.2e-7f;   // the sum's own rounding
+                    tau = min(dis_key<L2>(tp), KEY_SENTINEL - 1u);
+                }
+            }
+        }
         if (threadIdx.x == 0)
             __hip_atomic_store(&sb.ready[q], tau < KEY_SENTINEL ? ((1ull << 32) | tau) : (2ull << 32),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // the group's own candidates within the bound become its survivor slice (slice 0), like a
         // consumer's: k_select_final then reads a few hundred items per query and never the distance
         // buffer (one wave walking a long first group -- 24 k candidates at C4 -- was the slow part)
-        if (tau < KEY_SENTINEL) {   // uniform
+        bool prod_exact = false;
+        if constexpr (CF) prod_exact = prod_done;
+        if (tau < KEY_SENTINEL && prod_exact) {   // uniform
+            if constexpr (CF) {
+                // candidates: f <= tau' + margin (every code whose exact value is within tau' is among them), then the exact
+                // value in the reference's order of operations -- the list's T2 row from the L2, the query's table in LDS
+                __syncthreads();        // the histogram (aliasing the staging area) has been read
+                const float taup = key2f(tau);
+                float thr = taup + prod_m;
+                thr += fabsf(thr) * 1.2e-7f;
+                for (int i0 = 0; i0 < n0; i0 += 256) {
+                    const int idx = i0 + (int)threadIdx.x;
+                    const float fv = o0[min(idx, n0 - 1)];
+                    const bool cand = idx < n0 && fv <= thr;   // (the sentinel is +inf)
+                    const unsigned long long bal = __ballot(cand);
+                    if (bal) {
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(&s_ncand, __popcll(bal));
+                        base = __shfl(base, 0, 64);
+                        const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+                        if (cand && slot < SCAN_CF_CAP) s_cand[slot] = make_uint2((uint32_t)idx, 0u);
+                    }
+                }
+                __syncthreads();
+                const int nc = s_ncand;
+                if (nc > SCAN_CF_CAP) {   // (uniform) more candidates than the stage holds: the query takes the unfiltered path
+                    if (tid == 0) s_nstage = sb.slice_cap + 1;
+                } else {
+                    const int* poff = pair_off + (int64_t)q * (P + 1);
+                    for (int c0 = 0; c0 < nc; c0 += 256) {   // uniform trip count: append() ballots
+                        const int c = c0 + tid;
+                        bool keep = false;
+                        float dis = 0.f;
+                        int pos = 0;
+                        if (c < nc) {
+                            pos = (int)s_cand[c].x;
+                            int p = p_begin;
+                            for (int pp = p_begin + 1; pp < p_end; pp++) p = poff[pp] <= pos ? pp : p;   // last probe with off <= pos
+                            const int pair = q * P + p;
+                            const int l = probe_list[pair];
+                            const int j = pos - poff[p];
+                            const uint8_t* cj = codes + (list_off[l] + j) * MT;
+                            const float* t2 = T2 + (int64_t)l * msz;
+                            uint32_t cw[MT / 4];
+#pragma unroll
+                            for (int u = 0; u < MT / 16; u++) {
+                                const uint4 cv = reinterpret_cast<const uint4*>(cj)[u];
+                                cw[4 * u] = cv.x; cw[4 * u + 1] = cv.y; cw[4 * u + 2] = cv.z; cw[4 * u + 3] = cv.w;
+                            }
+                            dis = coarse_dis[pair];
+#pragma unroll
+                            for (int m0 = 0; m0 < MT; m0 += 8) {
+                                float a[8];
+#pragma unroll
+                                for (int m = 0; m < 8; m++) a[m] = t2[(m0 + m) * 256 + ((cw[(m0 + m) >> 2] >> (8 * (m & 3))) & 255u)];
+#pragma unroll
+                                for (int m = 0; m < 8; m++)
+                                    dis += __builtin_fmaf(-2.0f, s_lut[(m0 + m) * 256 + ((cw[(m0 + m) >> 2] >> (8 * (m & 3))) & 255u)], a[m]);
+                            }
+                            keep = dis <= taup;
+                        }
+                        append(keep, dis, pos);
+                    }
+                }
+            }
+        } else if (tau < KEY_SENTINEL) {   // uniform
             __syncthreads();        // the histogram (aliasing the staging area) has been read
             for (int i0 = 0; i0 < n0; i0 += 256 * 8) {
                 float t[8];
@@ -712,6 +883,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
             __syncthreads();   // the LUT of this item has been consumed
         }
     }
+}
+
+// queries WITHOUT a bound join the repair list (ScanBound::prod_cf launches: their first group's slab segment holds the
+// producer's approximate values, and the unfiltered selection reads the slab)
+__global__ __launch_bounds__(256) void k_rq_nobound(const unsigned long long* __restrict__ ready, int nq, int* __restrict__ rq_list,
+                                                    int* __restrict__ rq_count) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q < nq && (ready[q] >> 32) != 1ull) rq_list[atomicAdd(rq_count, 1)] = q;
+}
+void launch_rq_nobound(hipStream_t s, const unsigned long long* ready, int nq, int* rq_list, int* rq_count) {
+    if (nq > 0) hipLaunchKernelGGL(k_rq_nobound, dim3((nq + 255) / 256), dim3(256), 0, s, ready, nq, rq_list, rq_count);
 }
 
 int scan_slice_cap(int K) { return K <= 256 ? SCAN_SLICE : 2 * SCAN_SLICE; }
