@@ -42,7 +42,9 @@ constexpr int SCAN_BATCH = 64;                   // queries per XCD by which pro
 // CF (L2, FILT, MT 16 / 32, large batches): the consumer groups of a query with a bound run a FILTER pass without the
 // per-list table -- see "filter pass" in the body.
 constexpr int SCAN_CF_CAP = 768;   // filter-pass candidates staged per workgroup (8 bytes each)
-template <bool L2, int MT, bool FILT, bool IPF = false, bool UNITS = false, bool CF = false>
+// PCF (with CF): the producer runs on the filter pass's arithmetic too (ScanBound::prod_cf) -- a variant of its own: the extra
+// path costs the plain filter-pass kernel 16 VGPRs (73 -> 89: six -> five waves per SIMD) even when it is not taken
+template <bool L2, int MT, bool FILT, bool IPF = false, bool UNITS = false, bool CF = false, bool PCF = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_ivfpq_scan_pair(
         const float* __restrict__ x, int nq, int d, int M, int P, int G, const int* __restrict__ probe_list,
         const float* __restrict__ coarse_dis, const float* __restrict__ cc,
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
         }
     }
     if constexpr (CF) {
-        if (pg > 0 || sb.prod_cf) {   // (uniform) largest |entry| of the query's table: one word per wave, read behind the barrier below
+        if (pg > 0 || PCF) {   // (uniform) largest |entry| of the query's table: one word per wave, read behind the barrier below
             float mxv = 0.f;
 #pragma unroll
             for (int i = 0; i < MT; i++) mxv = fmaxf(mxv, fabsf(s2r[i]));
@@ -410,8 +412,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
     // those with v <= tau'.  The slab segment of group 0 holds the f's, NOT the reference's values (see ScanBound::prod_cf).
     float prod_smax = 0.f;
     bool prod_done = false;
-    if constexpr (CF) {
-        if (pg == 0 && sb.prod_cf) {   // (uniform)
+    if constexpr (CF && PCF) {
+        if (pg == 0) {   // (uniform)
             prod_done = true;
             lut_store_begin(lut_m0);
             lut_store_rows<MT>([&](int i) { return s2r[i]; }, std::make_integer_sequence<int, (MT > 0 ? MT : 1)>{});
@@ -766,7 +768,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
             tau = KEY_SENTINEL - 1u;
         }
         float prod_m = 0.f;
-        if constexpr (CF) {
+        if constexpr (CF && PCF) {
             if (prod_done && tau < KEY_SENTINEL) {   // (uniform) the bound of the EXACT values: the f's edge + their error margin
                 const uint32_t smax = *(reinterpret_cast<const uint32_t*>(s_cand + SCAN_CF_CAP) + 1);
                 prod_m = __uint_as_float(smax) * (1.f / 131072.f);
@@ -784,9 +786,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
         // consumer's: k_select_final then reads a few hundred items per query and never the distance
         // buffer (one wave walking a long first group -- 24 k candidates at C4 -- was the slow part)
         bool prod_exact = false;
-        if constexpr (CF) prod_exact = prod_done;
+        if constexpr (CF && PCF) prod_exact = prod_done;
         if (tau < KEY_SENTINEL && prod_exact) {   // uniform
-            if constexpr (CF) {
+            if constexpr (CF && PCF) {
                 // candidates: f <= tau' + margin (every code whose exact value is within tau' is among them), then the exact
                 // value in the reference's order of operations -- the list's T2 row from the L2, the query's table in LDS
                 __syncthreads();        // the histogram (aliasing the staging area) has been read
@@ -981,13 +983,18 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
         else if (M == 16) GH_SCAN4(false, 16, true, true);
         else GH_SCAN4(false, 32, true, true);
     } else if (cf) {
-#define GH_SCAN_CF(MT)                                                                                                  \
-    hipLaunchKernelGGL((k_ivfpq_scan_pair<true, MT, true, false, false, true>), grid, dim3(256), lds, s, x, nq, d, M, P, G, \
+#define GH_SCAN_CF(MT, PP)                                                                                              \
+    hipLaunchKernelGGL((k_ivfpq_scan_pair<true, MT, true, false, false, true, PP>), grid, dim3(256), lds, s, x, nq, d, M, P, G, \
                        probe_list, coarse_dis, cc, st2, T2, list_off, list_len, list_mask, nlist, codes, ids, pair_off,  \
                        q_stride, out, ftab, qfil, need_ids, INFINITY, qperm, pg_lo, pg_cnt, sparse, sb, rq_list,         \
                        rq_count, chunk_len)
-        if (M == 16) GH_SCAN_CF(16);
-        else GH_SCAN_CF(32);
+        if (sb.prod_cf) {
+            if (M == 16) GH_SCAN_CF(16, true);
+            else GH_SCAN_CF(32, true);
+        } else {
+            if (M == 16) GH_SCAN_CF(16, false);
+            else GH_SCAN_CF(32, false);
+        }
 #undef GH_SCAN_CF
     } else if (bound) {
         if (l2) GH_SCAN_M(true, true);
