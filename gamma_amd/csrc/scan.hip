@@ -44,8 +44,9 @@ constexpr int SCAN_BATCH = 64;                   // queries per XCD by which pro
 constexpr int SCAN_CF_CAP = 768;   // filter-pass candidates staged per workgroup (8 bytes each)
 // PCF (with CF): the producer runs on the filter pass's arithmetic too (ScanBound::prod_cf) -- a variant of its own: the extra
 // path costs the plain filter-pass kernel 16 VGPRs (73 -> 89: six -> five waves per SIMD) even when it is not taken
-template <bool L2, int MT, bool FILT, bool IPF = false, bool UNITS = false, bool CF = false, bool PCF = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_ivfpq_scan_pair(
+template <bool L2, int MT, bool FILT, bool IPF, bool UNITS, bool CF, bool PCF>
+__device__ __forceinline__ void scan_pair_body(
+
         const float* __restrict__ x, int nq, int d, int M, int P, int G, const int* __restrict__ probe_list,
         const float* __restrict__ coarse_dis, const float* __restrict__ cc,
         const float* __restrict__ st2, const float* __restrict__ T2,
@@ -887,6 +888,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
     }
 }
 
+// the kernels: the body above under its register budgets
+template <bool L2, int MT, bool FILT, bool IPF = false, bool UNITS = false, bool CF = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_ivfpq_scan_pair(
+
+        const float* __restrict__ x, int nq, int d, int M, int P, int G, const int* __restrict__ probe_list,
+        const float* __restrict__ coarse_dis, const float* __restrict__ cc,
+        const float* __restrict__ st2, const float* __restrict__ T2,
+        const int64_t* __restrict__ list_off, const int* __restrict__ list_len,
+        const uint8_t* __restrict__ list_mask, int nlist, const uint8_t* __restrict__ codes,
+        const int64_t* __restrict__ ids, const int* __restrict__ pair_off, int64_t q_stride,
+        float* __restrict__ out, const FilterDesc* __restrict__ ftab, const int* __restrict__ qfil, int need_ids,
+        float sentinel, const int* __restrict__ qperm, int pg_lo, int pg_cnt, int sparse, ScanBound sb,
+        const int* __restrict__ rq_list, const int* __restrict__ rq_count, int chunk_len) {
+    scan_pair_body<L2, MT, FILT, IPF, UNITS, CF, false>(x, nq, d, M, P, G, probe_list, coarse_dis, cc, st2, T2, list_off, list_len, list_mask, nlist, codes, ids, pair_off, q_stride, out, ftab, qfil, need_ids, sentinel, qperm, pg_lo, pg_cnt, sparse, sb, rq_list, rq_count, chunk_len);
+}
+// filter pass + the producer on its arithmetic (ScanBound::prod_cf): held to six waves per SIMD like the plain filter-pass kernel
+template <int MT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96), amdgpu_waves_per_eu(6, 8))) void k_ivfpq_scan_pair_pcf(
+
+        const float* __restrict__ x, int nq, int d, int M, int P, int G, const int* __restrict__ probe_list,
+        const float* __restrict__ coarse_dis, const float* __restrict__ cc,
+        const float* __restrict__ st2, const float* __restrict__ T2,
+        const int64_t* __restrict__ list_off, const int* __restrict__ list_len,
+        const uint8_t* __restrict__ list_mask, int nlist, const uint8_t* __restrict__ codes,
+        const int64_t* __restrict__ ids, const int* __restrict__ pair_off, int64_t q_stride,
+        float* __restrict__ out, const FilterDesc* __restrict__ ftab, const int* __restrict__ qfil, int need_ids,
+        float sentinel, const int* __restrict__ qperm, int pg_lo, int pg_cnt, int sparse, ScanBound sb,
+        const int* __restrict__ rq_list, const int* __restrict__ rq_count, int chunk_len) {
+    scan_pair_body<true, MT, true, false, false, true, true>(x, nq, d, M, P, G, probe_list, coarse_dis, cc, st2, T2, list_off, list_len, list_mask, nlist, codes, ids, pair_off, q_stride, out, ftab, qfil, need_ids, sentinel, qperm, pg_lo, pg_cnt, sparse, sb, rq_list, rq_count, chunk_len);
+}
+
 // queries WITHOUT a bound join the repair list (ScanBound::prod_cf launches: their first group's slab segment holds the
 // producer's approximate values, and the unfiltered selection reads the slab)
 __global__ __launch_bounds__(256) void k_rq_nobound(const unsigned long long* __restrict__ ready, int nq, int* __restrict__ rq_list,
@@ -983,17 +1015,17 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
         else if (M == 16) GH_SCAN4(false, 16, true, true);
         else GH_SCAN4(false, 32, true, true);
     } else if (cf) {
-#define GH_SCAN_CF(MT, PP)                                                                                              \
-    hipLaunchKernelGGL((k_ivfpq_scan_pair<true, MT, true, false, false, true, PP>), grid, dim3(256), lds, s, x, nq, d, M, P, G, \
+#define GH_SCAN_CF(KERN)                                                                                                \
+    hipLaunchKernelGGL((KERN), grid, dim3(256), lds, s, x, nq, d, M, P, G,                                              \
                        probe_list, coarse_dis, cc, st2, T2, list_off, list_len, list_mask, nlist, codes, ids, pair_off,  \
                        q_stride, out, ftab, qfil, need_ids, INFINITY, qperm, pg_lo, pg_cnt, sparse, sb, rq_list,         \
                        rq_count, chunk_len)
         if (sb.prod_cf) {
-            if (M == 16) GH_SCAN_CF(16, true);
-            else GH_SCAN_CF(32, true);
+            if (M == 16) GH_SCAN_CF(k_ivfpq_scan_pair_pcf<16>);
+            else GH_SCAN_CF(k_ivfpq_scan_pair_pcf<32>);
         } else {
-            if (M == 16) GH_SCAN_CF(16, false);
-            else GH_SCAN_CF(32, false);
+            if (M == 16) GH_SCAN_CF((k_ivfpq_scan_pair<true, 16, true, false, false, true>));
+            else GH_SCAN_CF((k_ivfpq_scan_pair<true, 32, true, false, false, true>));
         }
 #undef GH_SCAN_CF
     } else if (bound) {
