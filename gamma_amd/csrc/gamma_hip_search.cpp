@@ -527,9 +527,13 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         sb.spins = spins_env;
         sb.timeouts = h->d_bound_stat + 4;
         sb.slice_cap = cap;
-        // the producer on the filter pass's arithmetic too (scan.hip, prod_cf): with the query-major filter pass, not for shards
-        static const bool no_prod_cf = getenv("GAMMA_HIP_NO_PROD_CF") != nullptr;
-        sb.prod_cf = (cf_ok && !shard && !no_prod_cf) ? 1 : 0;
+        // the producer on the filter pass's arithmetic too (scan.hip, prod_cf; with the query-major filter pass, not for shards).
+        // OFF by default: measured slower at C3 -- scan 828 us against 784 (878 before the variant was held to six waves per
+        // SIMD: 89 VGPRs), + 25 us for re-scoring the first group of the tie-flagged queries in front of the replay: the
+        // producer's chain (table, per-wave list walk, histogram, candidate pass, exact recompute, flush) is no shorter than
+        // eight per-list tables, and its bound is looser by the margin.  GAMMA_HIP_PROD_CF=1 turns it on (parity-tested).
+        static const bool prod_cf_on = getenv("GAMMA_HIP_PROD_CF") != nullptr;
+        sb.prod_cf = (cf_ok && !shard && prod_cf_on) ? 1 : 0;
         if (!q8_ok) {
             scan(G, 0, PGM, &sb, true);
         } else {

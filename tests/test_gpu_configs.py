@@ -299,6 +299,25 @@ def test_list_major_byte_table_pass_on_short_lists():
     assert " passed" in r.stdout
 
 
+def test_producer_on_the_filter_pass_arithmetic():
+    """GAMMA_HIP_PROD_CF=1 (scan.hip, ScanBound::prod_cf; off by default -- it measured slower): the producer workgroup scores
+    its probes with the query's table + the per-code sums, bounds from those approximate values plus their error margin,
+    recomputes only its candidates exactly, and the first group's slab segment is re-scored for every query whose slab is read
+    (unfiltered selection, tie replay).  The bounded-scan parity tests, the C3 headline test, the tie suites and the large-batch
+    fuzz in a child process with the variable set: strict comparisons, as in the parent."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GAMMA_HIP_PROD_CF="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_more.py", "tests/test_gpu_ties.py",
+                        "tests/test_gpu_fuzz.py", "-k",
+                        "scan_bound_parity_at_batch_size or c3_headline or bounded_scan or large_batch or ivfpq_exact_ties or cut_ties"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def test_bounded_scan_backs_off_where_the_bound_is_loose():
     """The scan's pre-filter bounds a query's recall_num-th best from its NEAREST probe group.  Inner-product data whose
     best candidates sit in lists far from the query in L2 (centroids s_l * u with scales 0.5 .. 2: the quantizer probes
