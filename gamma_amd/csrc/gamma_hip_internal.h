@@ -267,6 +267,7 @@ struct gamma_hip_index {
 
     bool exact_ties = true;    // gamma_hip_set_exact_ties
     std::atomic<int64_t> ties_unhonoured{0};   // gamma_hip_ties_not_honoured
+    int scan_dbg_now = 0;   // GAMMA_HIP_SCAN_PART (timing experiments)
     std::atomic<int64_t> blas_unrestated{0};   // gamma_hip_blas_form_not_restated
     bool coarse_fused = true;  // gamma_hip_set_coarse_fused
     bool small_path = true;    // gamma_hip_set_small_path

@@ -279,6 +279,11 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     // 8 probes per workgroup pay off with short lists (half the query-table re-reads, a tighter bound from a
     // first group of 8 lists); long lists or many probes balance better with 4 (tools/shape_sweep.py)
     int G0 = ((double)h->ntotal / std::max(1, nlist) <= 700.0 && P <= 64) ? 8 : 4;
+    // (with the byte-table filter pass a consumer probe costs a third of a producer's: five probes bound nearly as well as
+    //  eight -- C3: scan 729 us at 8, 691 at 6, 676 at 5, 671 at 4 but with queries whose slices overflow; GAMMA_HIP_SCAN_G to sweep)
+    static const bool no_c8 = getenv("GAMMA_HIP_NO_C8") != nullptr;
+    const bool c8_shape = !no_c8 && l2 && M == 16 && R <= 256 && h->d_sums && h->d_t2max;
+    if (G0 == 8 && c8_shape && P > 8) G0 = 5;
     int64_t t2_bytes = (int64_t)nlist * M * 256 * sizeof(float);
     const bool compacted = shard && pre_dis && pre_probe;
     if (compacted && h->scan_bound && R <= 256) {
@@ -461,7 +466,11 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
             pz.count_a = h->w_tlist.as<int>();
         }
         if (bounded) {
-            pz.words = ready;
+            static const int scan_dbg_part = getenv("GAMMA_HIP_SCAN_PART") ? atoi(getenv("GAMMA_HIP_SCAN_PART")) : 0;
+            // (timing experiment 3: every other call runs the consumers alone, on the bounds of the call before)
+            static int scan_dbg_calls = 0;
+            h->scan_dbg_now = scan_dbg_part == 3 ? ((scan_dbg_calls++ & 1) ? 2 : 0) : scan_dbg_part;
+            pz.words = h->scan_dbg_now == 2 ? nullptr : ready;
             pz.count_b = h->w_scnt.as<int>();
         }
         gh::launch_pair_offsets(s, h->w_probe.as<int>(), nq, P, h->d_list_len, h->d_list_mask, nlist,
@@ -534,6 +543,14 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         // eight per-list tables, and its bound is looser by the margin.  GAMMA_HIP_PROD_CF=1 turns it on (parity-tested).
         static const bool prod_cf_on = getenv("GAMMA_HIP_PROD_CF") != nullptr;
         sb.prod_cf = (cf_ok && !shard && prod_cf_on) ? 1 : 0;
+        // the consumers' filter pass on a byte image of the query's table (scan.hip, "byte table")
+        const bool c8_on = c8_shape;
+        const int c8_mode = 1;
+        // (timing experiments, results invalid: 1 = only the producers run, 2 = only the consumers, on the bounds of the call before)
+        static const int scan_part = getenv("GAMMA_HIP_SCAN_PART") ? atoi(getenv("GAMMA_HIP_SCAN_PART")) : 0;
+        (void)scan_part;
+        sb.dbg_part = h->scan_dbg_now;
+        sb.c8 = (cf_ok && !sb.prod_cf && c8_on && M == 16 && (cf_span > 0 ? cf_span : P - G) <= 64) ? c8_mode : 0;
         if (!q8_ok) {
             scan(G, 0, PGM, &sb, true);
         } else {

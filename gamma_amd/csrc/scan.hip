@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <utility>
 
 #include "block_utils.h"
@@ -42,9 +43,11 @@ constexpr int SCAN_BATCH = 64;                   // queries per XCD by which pro
 // CF (L2, FILT, MT 16 / 32, large batches): the consumer groups of a query with a bound run a FILTER pass without the
 // per-list table -- see "filter pass" in the body.
 constexpr int SCAN_CF_CAP = 768;   // filter-pass candidates staged per workgroup (8 bytes each)
+constexpr int C8_CAND = 1536;      // byte-table pass: its candidates sit in the 12 KB of the fp32 table's place that the bytes leave free (M = 16)
 // PCF (with CF): the producer runs on the filter pass's arithmetic too (ScanBound::prod_cf) -- a variant of its own: the extra
 // path costs the plain filter-pass kernel 16 VGPRs (73 -> 89: six -> five waves per SIMD) even when it is not taken
-template <bool L2, int MT, bool FILT, bool IPF, bool UNITS, bool CF, bool PCF>
+// C8 (with CF): the filter pass gathers BYTES (ScanBound::c8; "byte table" in the body).
+template <bool L2, int MT, bool FILT, bool IPF, bool UNITS, bool CF, bool PCF, bool C8 = false>
 __device__ __forceinline__ void scan_pair_body(
 
         const float* __restrict__ x, int nq, int d, int M, int P, int G, const int* __restrict__ probe_list,
@@ -109,6 +112,9 @@ __device__ __forceinline__ void scan_pair_body(
     } else {
         pg = pg_lo + slot % pg_cnt;
         qslot = slot / pg_cnt;
+    }
+    if constexpr (CF) {
+        if (sb.dbg_part && (sb.dbg_part == 1) == (pg > 0)) return;   // timing experiments (ScanBound::dbg_part)
     }
     const bool repair = !FILT && rq_list != nullptr;
     int q = 0;
@@ -208,9 +214,19 @@ __device__ __forceinline__ void scan_pair_body(
         const float* xq = x + (int64_t)q * d;
 #pragma unroll
         for (int i = 0; i < MT; i++) s2r[i] = fvec_ny_row<false>(xq + i * dsub, st2 + ((int64_t)i * 256 + tid) * dsub, dsub);
+    } else if (C8 && pg > 0) {
+        // byte table: wave w reads table rows w, w + 4, .. (four code words per lane), see below; s2r is loaded later
     } else if (MT > 0 && (!UNITS || (L2 ? q * P + pg != lut_pair : q != lut_q))) {
 #pragma unroll
         for (int i = 0; i < MT; i++) s2r[i] = st2q[tid + 256 * i];
+    }
+    float4 v8[C8 ? MT / 4 : 1];
+    if constexpr (C8) {
+        if (pg > 0) {
+#pragma unroll
+            for (int k = 0; k < MT / 4; k++)
+                v8[k] = *reinterpret_cast<const float4*>(st2q + ((tid >> 6) + 4 * k) * 256 + 4 * lane);
+        }
     }
     if (!L2 && (!UNITS || q != lut_q)) {   // inner product: the LUT is the query table itself, list independent
         if (UNITS) lut_q = q;
@@ -222,7 +238,7 @@ __device__ __forceinline__ void scan_pair_body(
             for (int e = tid; e < msz; e += 256) s_lut[e] = st2q[e];
         }
     }
-    if constexpr (CF) {
+    if constexpr (CF && !C8) {
         if (pg > 0 || PCF) {   // (uniform) largest |entry| of the query's table: one word per wave, read behind the barrier below
             float mxv = 0.f;
 #pragma unroll
@@ -278,15 +294,72 @@ __device__ __forceinline__ void scan_pair_body(
             // (about as many as end up in the slice) get the EXACT value afterwards -- table entries fetched from
             // the L2-resident T2 row, fma and adds in the reference's order -- and the slice receives what the
             // regular loop would have put there: same keys, same positions.
-            lut_store_begin(lut_m0);
-            lut_store_rows<MT>([&](int i) { return s2r[i]; }, std::make_integer_sequence<int, (MT > 0 ? MT : 1)>{});
-            lut_store_done();
-            const float qmax = __uint_as_float(max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3])));
+            float qmax, c8_cq = 0.f, c8_nd = 0.f;
+            if constexpr (C8) {
+                // ---- byte table (round 5) --------------------------------------------------------------------------
+                // 64 lanes gathering random fp32 entries of one 256-entry row hit the 32 banks ~3.5 deep (a half wave's 32
+                // requests over 32 banks, 8 entries per bank): 57 % of this kernel's LDS cycles were conflicts.  A row of
+                // BYTES is 64 words, two per bank: a gather is at most 2 deep.  The pass only has to prove a code OUTSIDE
+                // the bound, so it may run on the u8 image of the query's table that the list-major pass uses
+                // (q8scan.hip: ip ~ lo_m + delta * u8, |error| <= 0.5001 delta, one delta per query), same proof:
+                //     v >= (dis0 - 2 sum_m lo - 1.02 M delta) + s_j - 2 delta U - 50 * 2^-24 S,   U = sum_m u8[m][c_m] (exact),
+                // a code is a candidate iff (A + s_j) - 2 delta U <= tau + 2^-16 S.  The image is made HERE (the arithmetic
+                // of k_q8_quant: wave w owns rows w, w + 4, ..; minimum and maximum of a row are one wave reduction) and
+                // lives where the fp32 table will be written for the exact recompute of the candidates.
+                float lo[MT / 4], range = 0.f, Lsum = 0.f, amax = 0.f;
+#pragma unroll
+                for (int k = 0; k < MT / 4; k++) {
+                    float mn = fminf(fminf(v8[k].x, v8[k].y), fminf(v8[k].z, v8[k].w));
+                    float mx = fmaxf(fmaxf(v8[k].x, v8[k].y), fmaxf(v8[k].z, v8[k].w));
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        mn = fminf(mn, __shfl_xor(mn, o, 64));
+                        mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                    }
+                    lo[k] = mn;
+                    range = fmaxf(range, mx - mn);
+                    Lsum += mn;
+                    amax = fmaxf(amax, fmaxf(fabsf(mn), fabsf(mx)));
+                }
+                float* s_part = reinterpret_cast<float*>(s_red);   // [4 waves][3]
+                if (lane == 0) {
+                    s_part[3 * (tid >> 6)] = range;
+                    s_part[3 * (tid >> 6) + 1] = Lsum;
+                    s_part[3 * (tid >> 6) + 2] = amax;
+                }
+                __syncthreads();
+                range = fmaxf(fmaxf(s_part[0], s_part[3]), fmaxf(s_part[6], s_part[9]));
+                Lsum = (s_part[1] + s_part[4]) + (s_part[7] + s_part[10]);
+                amax = fmaxf(fmaxf(s_part[2], s_part[5]), fmaxf(s_part[8], s_part[11]));
+                const float delta = (range / 255.f) * 1.000001f;   // (hi - lo) / delta stays below 255.5 whatever the roundings
+                const float inv = delta > 0.f ? 1.f / delta : 0.f;
+                uint32_t* s_b8 = reinterpret_cast<uint32_t*>(s_lut);
+#pragma unroll
+                for (int k = 0; k < MT / 4; k++) {
+                    const float f[4] = {v8[k].x, v8[k].y, v8[k].z, v8[k].w};
+                    uint32_t w = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        int u = (int)rintf((f[e] - lo[k]) * inv);
+                        u = min(255, max(0, u));
+                        w |= (uint32_t)u << (8 * e);
+                    }
+                    s_b8[((tid >> 6) + 4 * k) * 64 + lane] = w;
+                }
+                qmax = amax;
+                c8_cq = 2.f * Lsum + 1.02f * (float)MT * delta;
+                c8_nd = -2.f * delta;
+            } else {
+                lut_store_begin(lut_m0);
+                lut_store_rows<MT>([&](int i) { return s2r[i]; }, std::make_integer_sequence<int, (MT > 0 ? MT : 1)>{});
+                lut_store_done();
+                qmax = __uint_as_float(max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3])));
+            }
             // The table does not depend on the list, so nothing in this loop needs the workgroup in step: every WAVE
             // takes whole lists of the group (next one from a counter in LDS), 64 codes per step, the next step's codes
             // and sums requested before the current step's gathers -- four independent latency chains per workgroup
             // instead of one, and no barrier until the candidates are complete.
-            int& s_next = *reinterpret_cast<int*>(s_cand + SCAN_CF_CAP);
+            int& s_next = *reinterpret_cast<int*>(s_cand + (C8 ? 0 : SCAN_CF_CAP));   // (the byte pass has no stage of its own)
             if (tid == 0) s_next = 0;
             __syncthreads();   // the LUT and the list counter are in place
             const int ng = p_end - p_begin;
@@ -308,8 +381,9 @@ __device__ __forceinline__ void scan_pair_body(
                 const float dis0 = coarse_dis[pair];
                 const int pbase = pair_off[(int64_t)q * (P + 1) + p];
                 const float S = fabsf(dis0) + sb.t2max[l] + 32.f * qmax;
-                float thr = __builtin_fmaf(S, 1.f / 131072.f, tau_f);
-                thr += fabsf(thr) * 1.2e-7f;   // the threshold's own rounding
+                float thr = __builtin_fmaf(S, C8 ? 1.f / 65536.f : 1.f / 131072.f, tau_f);
+                thr += fabsf(thr) * (C8 ? 2.4e-7f : 1.2e-7f);   // the threshold's own rounding(s)
+                const float c8_A = dis0 - c8_cq;
                 uint4 cn[MT / 16];
                 float sn;
                 {
@@ -340,15 +414,28 @@ __device__ __forceinline__ void scan_pair_body(
                         ok = ok && id >= 0;
                         if (ok) ok = is_valid_doc(filt, id);
                     }
-                    float t[MT];
+                    float f;
+                    if constexpr (C8) {
+                        uint32_t t[MT];
 #pragma unroll
-                    for (int m = 0; m < MT; m++) t[m] = lut_gather(cw[m >> 2], m & 3, m);
-                    __builtin_amdgcn_sched_barrier(0);   // all gathers in flight before the adds
-                    float g4[4] = {t[0], t[1], t[2], t[3]};   // four independent chains: the order is free here
+                        for (int m = 0; m < MT; m++) t[m] = lut_gather_u8(cw[m >> 2], m & 3, m);
+                        __builtin_amdgcn_sched_barrier(0);   // all gathers in flight before the adds
+                        uint32_t u4[4] = {t[0], t[1], t[2], t[3]};
 #pragma unroll
-                    for (int m = 4; m < MT; m++) g4[m & 3] += t[m];
-                    const float g = (g4[0] + g4[1]) + (g4[2] + g4[3]);
-                    const float f = __builtin_fmaf(-2.f, g, dis0 + sj);
+                        for (int m = 4; m < MT; m++) u4[m & 3] += t[m];
+                        const uint32_t U = (u4[0] + u4[1]) + (u4[2] + u4[3]);
+                        f = __builtin_fmaf(c8_nd, (float)U, c8_A + sj);
+                    } else {
+                        float t[MT];
+#pragma unroll
+                        for (int m = 0; m < MT; m++) t[m] = lut_gather(cw[m >> 2], m & 3, m);
+                        __builtin_amdgcn_sched_barrier(0);   // all gathers in flight before the adds
+                        float g4[4] = {t[0], t[1], t[2], t[3]};   // four independent chains: the order is free here
+#pragma unroll
+                        for (int m = 4; m < MT; m++) g4[m & 3] += t[m];
+                        const float g = (g4[0] + g4[1]) + (g4[2] + g4[3]);
+                        f = __builtin_fmaf(-2.f, g, dis0 + sj);
+                    }
                     const bool cand = ok && f <= thr;
                     const unsigned long long bal = __ballot(cand);
                     if (bal) {   // uniform per wave
@@ -356,22 +443,27 @@ __device__ __forceinline__ void scan_pair_body(
                         if (lane == 0) base = atomicAdd(&s_ncand, __popcll(bal));
                         base = __shfl(base, 0, 64);
                         const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
-                        if (cand && slot < SCAN_CF_CAP) s_cand[slot] = make_uint2((uint32_t)(pbase + j), (uint32_t)p);
+                        if constexpr (C8) {   // the candidates sit in the part of the fp32 table's place the bytes leave free
+                            if (cand && slot < C8_CAND)
+                                reinterpret_cast<uint2*>(s_lut + MT * 64)[slot] = make_uint2((uint32_t)(pbase + j), (uint32_t)p);
+                        } else {
+                            if (cand && slot < SCAN_CF_CAP) s_cand[slot] = make_uint2((uint32_t)(pbase + j), (uint32_t)p);
+                        }
                     }
                 }
             }
             __syncthreads();
             const int nc = s_ncand;
-            if (nc > SCAN_CF_CAP) {   // (uniform) more candidates than the stage holds: the query takes the unfiltered path
+            if (nc > (C8 ? C8_CAND : SCAN_CF_CAP)) {   // (uniform) more candidates than the stage holds: the query takes the unfiltered path
                 if (tid == 0) s_nstage = sb.slice_cap + 1;
             } else {
-                for (int c0 = 0; c0 < nc; c0 += 256) {   // uniform trip count: append() ballots
-                    const int c = c0 + tid;
+                // the exact value of a candidate: the regular loop's table entries and its adds, in the reference's order (the
+                // list's T2 row from the L2, the query's table entries from LDS)
+                auto exact_one = [&](bool have, const uint2 cd) {   // whole workgroup: append() ballots
                     bool keep = false;
                     float dis = 0.f;
                     int pos = 0;
-                    if (c < nc) {
-                        const uint2 cd = s_cand[c];
+                    if (have) {
                         pos = (int)cd.x;
                         const int p = (int)cd.y, pair = q * P + p;
                         const int l = probe_list[pair];
@@ -391,16 +483,46 @@ __device__ __forceinline__ void scan_pair_body(
 #pragma unroll
                             for (int m = 0; m < 8; m++) a[m] = t2[(m0 + m) * 256 + ((cw[(m0 + m) >> 2] >> (8 * (m & 3))) & 255u)];
 #pragma unroll
-                            for (int m = 0; m < 8; m++)   // the regular loop's table entry and its adds, in the reference's order
+                            for (int m = 0; m < 8; m++)
                                 dis += __builtin_fmaf(-2.0f, s_lut[(m0 + m) * 256 + ((cw[(m0 + m) >> 2] >> (8 * (m & 3))) & 255u)], a[m]);
                         }
                         keep = dis <= tau_f;
                     }
                     append(keep, dis, pos);
+                };
+                if constexpr (C8) {
+                    // into registers (C8_CAND / 256 per thread), then the fp32 table over the bytes and the candidates' place
+                    uint2 mine[C8_CAND / 256];
+#pragma unroll
+                    for (int i = 0; i < C8_CAND / 256; i++) {
+                        const int c = tid + 256 * i;
+                        mine[i] = c < nc ? reinterpret_cast<const uint2*>(s_lut + MT * 64)[c] : make_uint2(0u, 0u);
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int i = 0; i < MT; i++) s2r[i] = st2q[tid + 256 * i];
+                    lut_store_begin(lut_m0);
+                    lut_store_rows<MT>([&](int i) { return s2r[i]; }, std::make_integer_sequence<int, (MT > 0 ? MT : 1)>{});
+                    lut_store_done();
+                    __syncthreads();
+#pragma unroll
+                    for (int i = 0; i < C8_CAND / 256; i++)
+                        if (256 * i < nc) exact_one(tid + 256 * i < nc, mine[i]);   // (uniform)
+                } else {
+                    for (int c0 = 0; c0 < nc; c0 += 256) {   // uniform trip count
+                        const int c = c0 + tid;
+                        exact_one(c < nc, c < nc ? s_cand[c] : make_uint2(0u, 0u));
+                    }
                 }
             }
             flush();
             return;
+        }
+    }
+    if constexpr (C8) {
+        if (pg > 0) {   // (uniform) a consumer without a bound takes the regular loop: its table entries, the regular way
+#pragma unroll
+            for (int i = 0; i < MT; i++) s2r[i] = st2q[tid + 256 * i];
         }
     }
     // ---- producer with the filter pass's arithmetic (sb.prod_cf, round 5) ---------------------------------------------------
@@ -919,6 +1041,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96), amdgpu_wav
     scan_pair_body<true, MT, true, false, false, true, true>(x, nq, d, M, P, G, probe_list, coarse_dis, cc, st2, T2, list_off, list_len, list_mask, nlist, codes, ids, pair_off, q_stride, out, ftab, qfil, need_ids, sentinel, qperm, pg_lo, pg_cnt, sparse, sb, rq_list, rq_count, chunk_len);
 }
 
+// filter pass on the byte table (ScanBound::c8)
+template <int MT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(112), amdgpu_waves_per_eu(7, 8))) void k_ivfpq_scan_pair_c8(
+
+        const float* __restrict__ x, int nq, int d, int M, int P, int G, const int* __restrict__ probe_list,
+        const float* __restrict__ coarse_dis, const float* __restrict__ cc,
+        const float* __restrict__ st2, const float* __restrict__ T2,
+        const int64_t* __restrict__ list_off, const int* __restrict__ list_len,
+        const uint8_t* __restrict__ list_mask, int nlist, const uint8_t* __restrict__ codes,
+        const int64_t* __restrict__ ids, const int* __restrict__ pair_off, int64_t q_stride,
+        float* __restrict__ out, const FilterDesc* __restrict__ ftab, const int* __restrict__ qfil, int need_ids,
+        float sentinel, const int* __restrict__ qperm, int pg_lo, int pg_cnt, int sparse, ScanBound sb,
+        const int* __restrict__ rq_list, const int* __restrict__ rq_count, int chunk_len) {
+    scan_pair_body<true, MT, true, false, false, true, false, true>(x, nq, d, M, P, G, probe_list, coarse_dis, cc, st2, T2, list_off, list_len, list_mask, nlist, codes, ids, pair_off, q_stride, out, ftab, qfil, need_ids, sentinel, qperm, pg_lo, pg_cnt, sparse, sb, rq_list, rq_count, chunk_len);
+}
+
 // queries WITHOUT a bound join the repair list (ScanBound::prod_cf launches: their first group's slab segment holds the
 // producer's approximate values, and the unfiltered selection reads the slab)
 __global__ __launch_bounds__(256) void k_rq_nobound(const unsigned long long* __restrict__ ready, int nq, int* __restrict__ rq_list,
@@ -978,7 +1116,7 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
         const int per_cu = std::max(1, std::min(8, (int)(160 * 1024 / (lds + 1024))));
         grid.x = (unsigned)std::min<int64_t>(max_units, 256 * per_cu);
     }
-    if (cf) lds += SCAN_CF_CAP * sizeof(uint2) + 16;
+    if (cf) lds += ((sb.c8 && M == 16) ? 0 : SCAN_CF_CAP * sizeof(uint2)) + 16;
 #define GH_SCAN(LL, MT, FF)                                                                       \
     GH_SCAN4(LL, MT, FF, false)
 #define GH_SCAN4(LL, MT, FF, II) GH_SCAN5(LL, MT, FF, II, false)
@@ -1023,6 +1161,8 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
         if (sb.prod_cf) {
             if (M == 16) GH_SCAN_CF(k_ivfpq_scan_pair_pcf<16>);
             else GH_SCAN_CF(k_ivfpq_scan_pair_pcf<32>);
+        } else if (sb.c8 && M == 16) {
+            GH_SCAN_CF(k_ivfpq_scan_pair_c8<16>);
         } else {
             if (M == 16) GH_SCAN_CF((k_ivfpq_scan_pair<true, 16, true, false, false, true>));
             else GH_SCAN_CF((k_ivfpq_scan_pair<true, 32, true, false, false, true>));

@@ -299,6 +299,24 @@ def test_list_major_byte_table_pass_on_short_lists():
     assert " passed" in r.stdout
 
 
+def test_filter_pass_on_the_fp32_table():
+    """GAMMA_HIP_NO_C8=1: the consumers' filter pass gathers from the fp32 table (rounds 3-4) instead of its byte image, and
+    the first probe group goes back to eight lists.  The default is the byte image (scan.hip, ScanBound::c8) -- the bounded-scan
+    parity tests, the C3 headline test, the tie suites and the large-batch fuzz run it in the parent; here the same tests in a
+    child process with the variable set, strict comparisons."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GAMMA_HIP_NO_C8="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_more.py", "tests/test_gpu_ties.py",
+                        "tests/test_gpu_fuzz.py", "-k",
+                        "scan_bound_parity_at_batch_size or c3_headline or bounded_scan or large_batch or ivfpq_exact_ties or cut_ties"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def test_producer_on_the_filter_pass_arithmetic():
     """GAMMA_HIP_PROD_CF=1 (scan.hip, ScanBound::prod_cf; off by default -- it measured slower): the producer workgroup scores
     its probes with the query's table + the per-code sums, bounds from those approximate values plus their error margin,
