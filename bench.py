@@ -700,7 +700,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_ivfpq_scan_pair",
+            "kernel": "k_ivfpq_scan_pair_c8",
             "achieved": round(achieved, 1),
             "peak": peak,
             "unit": "GB/s",

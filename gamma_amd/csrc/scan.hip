@@ -311,11 +311,9 @@ __device__ __forceinline__ void scan_pair_body(
                 for (int k = 0; k < MT / 4; k++) {
                     float mn = fminf(fminf(v8[k].x, v8[k].y), fminf(v8[k].z, v8[k].w));
                     float mx = fmaxf(fmaxf(v8[k].x, v8[k].y), fmaxf(v8[k].z, v8[k].w));
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        mn = fminf(mn, __shfl_xor(mn, o, 64));
-                        mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-                    }
+                    // (wave reductions on the order-preserving keys: DPP, not 12 LDS permutes per row)
+                    mn = key2f(__reduce_min_sync(~0ull, f2key(mn)));
+                    mx = key2f(__reduce_max_sync(~0ull, f2key(mx)));
                     lo[k] = mn;
                     range = fmaxf(range, mx - mn);
                     Lsum += mn;

@@ -62,8 +62,9 @@ pmc() {   # name, counter, script, args...
   timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${name}_$ctr -o pmc -- python3 "$@" > $out/pmc_${name}_$ctr.log 2>&1
 }
 if ! want pmc; then ls $out; exit 0; fi
-for ctr in FETCH_SIZE WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE; do
-  pmc cf $ctr $root/bench.py --steps 6 --warmup 2 --cpu-seconds 0 --recall-queries 0 --no-extra --no-shapes
+for ctr in FETCH_SIZE WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_BUSY_CYCLES; do
+  pmc c8 $ctr $root/bench.py --steps 6 --warmup 2 --cpu-seconds 0 --recall-queries 0 --no-extra --no-shapes
+  pmc cf $ctr $root/tools/run_env.py GAMMA_HIP_NO_C8=1 $root/bench.py --steps 6 --warmup 2 --cpu-seconds 0 --recall-queries 0 --no-extra --no-shapes
   pmc nocf $ctr $root/tools/run_env.py GAMMA_HIP_NO_SCAN_CF=1 $root/bench.py --steps 6 --warmup 2 --cpu-seconds 0 --recall-queries 0 --no-extra --no-shapes
 done
 for ctr in FETCH_SIZE WRITE_SIZE; do
@@ -81,12 +82,15 @@ def per_dispatch(sub, kern, ctr):
         if kern in r["Kernel_Name"] and r["Counter_Name"] == ctr:
             tot += float(r["Counter_Value"]); n += 1
     return (tot / n if n else None), n
-res = {"note": "per launch of the scan kernel k_ivfpq_scan_pair<true, 16, true, ..>, C3, 16384 queries; FETCH_SIZE / WRITE_SIZE in KB, "
-               "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md); cf = with the filter pass, nocf = GAMMA_HIP_NO_SCAN_CF=1"}
-for mode in ("cf", "nocf"):
+res = {"note": "per launch of the bounded-scan kernel, C3, 16384 queries; FETCH_SIZE / WRITE_SIZE in KB, FETCH_SIZE x2 on gfx950 "
+               "(MI355X_MICROARCH.md); c8 = the default (k_ivfpq_scan_pair_c8<16>: filter pass on the byte image of the query's table, "
+               "first probe group of 5), cf = GAMMA_HIP_NO_C8=1 (k_ivfpq_scan_pair<true, 16, true, ..>: filter pass on the fp32 table, "
+               "first group of 8: rounds 3-4), nocf = GAMMA_HIP_NO_SCAN_CF=1 (per-list tables for every probe)"}
+for mode in ("c8", "cf", "nocf"):
     m = {}
-    for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
-        v, n = per_dispatch("pmc_%s_%s" % (mode, ctr), "k_ivfpq_scan_pair<true, 16, true", ctr)
+    kern = "k_ivfpq_scan_pair_c8<16>" if mode == "c8" else "k_ivfpq_scan_pair<true, 16, true"
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS", "SQ_INSTS_VALU", "SQ_BUSY_CYCLES"):
+        v, n = per_dispatch("pmc_%s_%s" % (mode, ctr), kern, ctr)
         m[ctr] = {"per_launch": v, "launches": n}
     f, w = m["FETCH_SIZE"]["per_launch"], m["WRITE_SIZE"]["per_launch"]
     if f is not None and w is not None:
@@ -97,5 +101,5 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     res["calib_" + ctr] = {"per_launch_of_a_kernel_moving_2^30_bytes": v, "launches": n}
 print(json.dumps(res, indent=1))
 PY
-rm -rf $out/pmc_*_FETCH_SIZE $out/pmc_*_WRITE_SIZE $out/pmc_*_SQ_LDS_BANK_CONFLICT $out/pmc_*_SQ_LDS_IDX_ACTIVE
+rm -rf $out/pmc_*_FETCH_SIZE $out/pmc_*_WRITE_SIZE $out/pmc_*_SQ_LDS_BANK_CONFLICT $out/pmc_*_SQ_LDS_IDX_ACTIVE $out/pmc_*_SQ_INSTS_LDS $out/pmc_*_SQ_INSTS_VALU $out/pmc_*_SQ_BUSY_CYCLES
 ls $out
