@@ -549,6 +549,8 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         // (timing experiments, results invalid: 1 = only the producers run, 2 = only the consumers, on the bounds of the call before)
         static const int scan_part = getenv("GAMMA_HIP_SCAN_PART") ? atoi(getenv("GAMMA_HIP_SCAN_PART")) : 0;
         (void)scan_part;
+        static const int scan_batch = getenv("GAMMA_HIP_SCAN_BATCH") ? atoi(getenv("GAMMA_HIP_SCAN_BATCH")) : 0;
+        sb.batch = scan_batch;
         sb.dbg_part = h->scan_dbg_now;
         sb.c8 = (cf_ok && !sb.prod_cf && c8_on && M == 16 && (cf_span > 0 ? cf_span : P - G) <= 64) ? c8_mode : 0;
         if (!q8_ok) {

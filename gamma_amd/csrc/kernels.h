@@ -177,6 +177,7 @@ struct ScanBound {
                                 // sums too -- no per-list table -- bounds from those values plus their error margin, and gives only its
                                 // candidates the exact arithmetic.  Its slab segment then holds APPROXIMATE values: the callers re-score
                                 // group 0 (repair launch) for every query whose slab is read (unfiltered selection, tie replay)
+    int batch;                  // queries per XCD by which the producers run ahead of the consumers (0: 64)
     int dbg_part;               // timing experiments only (GAMMA_HIP_SCAN_PART): 1 = consumers leave at once, 2 = producers do
     int c8;                     // != 0 (filter-pass launches only): the consumers' filter pass gathers from a BYTE image of the query's
                                 // table made in the workgroup (2-way bank conflicts at most instead of ~3.5); candidates as ever

@@ -93,19 +93,20 @@ __device__ __forceinline__ void scan_pair_body(
         // its producer, by when the bound is normally there.  The query's table st2[q] is still in
         // this XCD's L2 when its consumers arrive.
         const int nq8 = (nq + 7) >> 3;
-        if (slot < SCAN_BATCH) {
+        const int SB = sb.batch > 0 ? sb.batch : SCAN_BATCH;
+        if (slot < SB) {
             pg = 0;
             qslot = slot;
         } else {
-            const int s2 = slot - SCAN_BATCH, period = SCAN_BATCH * pg_cnt;
+            const int s2 = slot - SB, period = SB * pg_cnt;
             const int t = s2 / period, r = s2 % period;
-            if (r < SCAN_BATCH) {
+            if (r < SB) {
                 pg = 0;
-                qslot = (t + 1) * SCAN_BATCH + r;
+                qslot = (t + 1) * SB + r;
             } else {
-                const int i = r - SCAN_BATCH;
+                const int i = r - SB;
                 pg = 1 + i % (pg_cnt - 1);
-                qslot = t * SCAN_BATCH + i / (pg_cnt - 1);
+                qslot = t * SB + i / (pg_cnt - 1);
             }
         }
         if (qslot >= nq8) return;
@@ -162,7 +163,7 @@ __device__ __forceinline__ void scan_pair_body(
         if (bal) {
             int base = 0;
             if (lane == 0) base = atomicAdd(&s_nstage, __popcll(bal));
-            base = __shfl(base, 0, 64);
+            base = __builtin_amdgcn_readfirstlane(base);   // (lane 0 holds it: no LDS permute)
             if (keep) {
                 const int at = base + __popcll(bal & ((1ull << lane) - 1ull));
                 const unsigned long long item = ((unsigned long long)dis_key<L2>(val) << 32) | (unsigned)pos;
@@ -439,7 +440,7 @@ __device__ __forceinline__ void scan_pair_body(
                     if (bal) {   // uniform per wave
                         int base = 0;
                         if (lane == 0) base = atomicAdd(&s_ncand, __popcll(bal));
-                        base = __shfl(base, 0, 64);
+                        base = __builtin_amdgcn_readfirstlane(base);   // (lane 0 holds it: no LDS permute)
                         const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
                         if constexpr (C8) {   // the candidates sit in the part of the fp32 table's place the bytes leave free
                             if (cand && slot < C8_CAND)
@@ -924,7 +925,7 @@ __device__ __forceinline__ void scan_pair_body(
                     if (bal) {
                         int base = 0;
                         if (lane == 0) base = atomicAdd(&s_ncand, __popcll(bal));
-                        base = __shfl(base, 0, 64);
+                        base = __builtin_amdgcn_readfirstlane(base);   // (lane 0 holds it: no LDS permute)
                         const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
                         if (cand && slot < SCAN_CF_CAP) s_cand[slot] = make_uint2((uint32_t)idx, 0u);
                     }
@@ -1098,8 +1099,9 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
     size_t lds = (size_t)M * 256 * sizeof(float) + SCAN_STAGE * sizeof(unsigned long long) + 16 * sizeof(int);
     dim3 grid((unsigned)(8 * (int64_t)((nq + 7) / 8) * pg_cnt));
     if (bound) {   // P(0) | P(t+1) C(t) ...: whole batches, see the kernel
-        const int64_t nq8 = (nq + 7) / 8, nb = (nq8 + SCAN_BATCH - 1) / SCAN_BATCH;
-        grid.x = (unsigned)(8 * (SCAN_BATCH + nb * SCAN_BATCH * pg_cnt));
+        const int SB = bound->batch > 0 ? bound->batch : SCAN_BATCH;
+        const int64_t nq8 = (nq + 7) / 8, nb = (nq8 + SB - 1) / SB;
+        grid.x = (unsigned)(8 * (SB + nb * SB * pg_cnt));
     }
     ScanBound sb = {};
     sb.slice_cap = SCAN_SLICE;
