@@ -282,7 +282,8 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     // (with the byte-table filter pass a consumer probe costs a third of a producer's: five probes bound nearly as well as
     //  eight -- C3: scan 729 us at 8, 691 at 6, 676 at 5, 671 at 4 but with queries whose slices overflow; GAMMA_HIP_SCAN_G to sweep)
     static const bool no_c8 = getenv("GAMMA_HIP_NO_C8") != nullptr;
-    const bool c8_shape = !no_c8 && l2 && M == 16 && R <= 256 && h->d_sums && h->d_t2max;
+    static const bool c8_m32 = getenv("GAMMA_HIP_C8_M32") != nullptr;
+    const bool c8_shape = !no_c8 && l2 && (M == 16 || (M == 32 && c8_m32)) && R <= 256 && h->d_sums && h->d_t2max;
     if (G0 == 8 && c8_shape && P > 8) G0 = 5;
     int64_t t2_bytes = (int64_t)nlist * M * 256 * sizeof(float);
     const bool compacted = shard && pre_dis && pre_probe;
@@ -552,7 +553,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         static const int scan_batch = getenv("GAMMA_HIP_SCAN_BATCH") ? atoi(getenv("GAMMA_HIP_SCAN_BATCH")) : 0;
         sb.batch = scan_batch;
         sb.dbg_part = h->scan_dbg_now;
-        sb.c8 = (cf_ok && !sb.prod_cf && c8_on && M == 16 && (cf_span > 0 ? cf_span : P - G) <= 64) ? c8_mode : 0;
+        sb.c8 = (cf_ok && !sb.prod_cf && c8_on && (cf_span > 0 ? cf_span : P - G) <= 64) ? c8_mode : 0;
         if (!q8_ok) {
             scan(G, 0, PGM, &sb, true);
         } else {

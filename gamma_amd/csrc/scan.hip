@@ -1056,6 +1056,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(112), amdgpu_wa
     scan_pair_body<true, MT, true, false, false, true, false, true>(x, nq, d, M, P, G, probe_list, coarse_dis, cc, st2, T2, list_off, list_len, list_mask, nlist, codes, ids, pair_off, q_stride, out, ftab, qfil, need_ids, sentinel, qperm, pg_lo, pg_cnt, sparse, sb, rq_list, rq_count, chunk_len);
 }
 
+// (M = 32: the 32 KB table leaves four workgroups per CU whatever the registers)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_ivfpq_scan_pair_c8m32(
+
+        const float* __restrict__ x, int nq, int d, int M, int P, int G, const int* __restrict__ probe_list,
+        const float* __restrict__ coarse_dis, const float* __restrict__ cc,
+        const float* __restrict__ st2, const float* __restrict__ T2,
+        const int64_t* __restrict__ list_off, const int* __restrict__ list_len,
+        const uint8_t* __restrict__ list_mask, int nlist, const uint8_t* __restrict__ codes,
+        const int64_t* __restrict__ ids, const int* __restrict__ pair_off, int64_t q_stride,
+        float* __restrict__ out, const FilterDesc* __restrict__ ftab, const int* __restrict__ qfil, int need_ids,
+        float sentinel, const int* __restrict__ qperm, int pg_lo, int pg_cnt, int sparse, ScanBound sb,
+        const int* __restrict__ rq_list, const int* __restrict__ rq_count, int chunk_len) {
+    scan_pair_body<true, 32, true, false, false, true, false, true>(x, nq, d, M, P, G, probe_list, coarse_dis, cc, st2, T2, list_off, list_len, list_mask, nlist, codes, ids, pair_off, q_stride, out, ftab, qfil, need_ids, sentinel, qperm, pg_lo, pg_cnt, sparse, sb, rq_list, rq_count, chunk_len);
+}
+
 // queries WITHOUT a bound join the repair list (ScanBound::prod_cf launches: their first group's slab segment holds the
 // producer's approximate values, and the unfiltered selection reads the slab)
 __global__ __launch_bounds__(256) void k_rq_nobound(const unsigned long long* __restrict__ ready, int nq, int* __restrict__ rq_list,
@@ -1116,7 +1131,7 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
         const int per_cu = std::max(1, std::min(8, (int)(160 * 1024 / (lds + 1024))));
         grid.x = (unsigned)std::min<int64_t>(max_units, 256 * per_cu);
     }
-    if (cf) lds += ((sb.c8 && M == 16) ? 0 : SCAN_CF_CAP * sizeof(uint2)) + 16;
+    if (cf) lds += (sb.c8 ? 0 : SCAN_CF_CAP * sizeof(uint2)) + 16;
 #define GH_SCAN(LL, MT, FF)                                                                       \
     GH_SCAN4(LL, MT, FF, false)
 #define GH_SCAN4(LL, MT, FF, II) GH_SCAN5(LL, MT, FF, II, false)
@@ -1163,6 +1178,8 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
             else GH_SCAN_CF(k_ivfpq_scan_pair_pcf<32>);
         } else if (sb.c8 && M == 16) {
             GH_SCAN_CF(k_ivfpq_scan_pair_c8<16>);
+        } else if (sb.c8) {
+            GH_SCAN_CF(k_ivfpq_scan_pair_c8m32);
         } else {
             if (M == 16) GH_SCAN_CF((k_ivfpq_scan_pair<true, 16, true, false, false, true>));
             else GH_SCAN_CF((k_ivfpq_scan_pair<true, 32, true, false, false, true>));
