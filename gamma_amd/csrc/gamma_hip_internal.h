@@ -136,6 +136,7 @@ struct gamma_hip_index {
     // (standing deletes): write_gen counts writer calls (WriteLock), cmp_gen = the count the shadow lists were built at
     uint64_t write_gen = 1, cmp_gen = 0;
     bool cmp_has_sums = false, cmp_sums_built = false;
+    bool cmp_by_clause = false;   // the shadow lists were cut under a request's own clauses (as short as those make them)
     bool merge_flags = false;   // the last gamma_hip_ivfpq_merge_rerank left tie flags of its slice in w_tlist
     int shard_cut_nq = 0;       // the last shard search left the cut-tie flags of its nq queries in w_tcut
     bool shard_cut_chunked = false;   // ... of a call of several chunks: gathered in w_shard_cut

@@ -122,6 +122,27 @@ if os.environ.get("C4_EMUL"):
             g.profile_enable(False)
     g.set_list_mask(None)
 g.profile_enable(True)
+if os.environ.get("C4_DELETE"):   # 5 % of the documents deleted (the engine's delete bitmap): every search after it tests the bit
+    rng = np.random.default_rng(5)
+    dead = np.sort(rng.choice(N, N // 20, replace=False)).astype(np.int64)
+    bm = np.zeros((N + 7) // 8, dtype=np.uint8)
+    np.bitwise_or.at(bm, dead >> 3, (1 << (dead & 7)).astype(np.uint8))
+    g.bitmap_upload(bm, N)
+    for mode, name in (("0", "bit tested per scored code"), (None, "lists compacted (kept until the next write)")):
+        if mode is None:
+            os.environ.pop("GAMMA_HIP_LIST_COMPACT", None)
+        else:
+            os.environ["GAMMA_HIP_LIST_COMPACT"] = mode
+        for i in range(3):
+            g.ivfpq_search_device(dq[(i % 2) * nq:].data_ptr(), nq, k, args, D.data_ptr(), I.data_ptr())
+        g.synchronize()
+        t0 = time.perf_counter()
+        for i in range(5):
+            g.ivfpq_search_device(dq[(i % 2) * nq:].data_ptr(), nq, k, args, D.data_ptr(), I.data_ptr())
+        g.synchronize()
+        dt = (time.perf_counter() - t0) / 5
+        print("5 %% deleted, %s: %.2f ms per %d queries = %.0f queries/s" % (name, dt * 1e3, nq, nq / dt))
+    g.bitmap_upload(np.zeros((N + 7) // 8, dtype=np.uint8), N)
 if os.environ.get("C4_FILTER"):   # a request bitmap that keeps every tenth document (what the engine's range index hands over)
     keep = np.arange(0, N, 10, dtype=np.int64)
     fargs = api.SearchArgs(metric=api.METRIC_L2, nprobe=P, recall_num=R, has_rank=True, min_score=0.0, max_score=1e30,
