@@ -322,7 +322,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     // (recall_num up to 1024 since round 5: slices of 2048 items and k_select_final_wg beyond 256 -- the configurations that need
     //  a long short-list, full-size C5 at ~1000, keep the pre-filter; GAMMA_HIP_BOUND_MAXR: the old gate for A/B runs)
     static const int bound_maxr = getenv("GAMMA_HIP_BOUND_MAXR") ? atoi(getenv("GAMMA_HIP_BOUND_MAXR")) : 1024;
-    bool bounded = (!shard || compacted) && h->scan_bound && R <= std::min(1024, bound_maxr) && P <= 128 && G >= 4;
+    bool bounded = (!shard || compacted) && h->scan_bound && R <= std::min(1024, bound_maxr) && P <= 128 && G >= (getenv("GAMMA_HIP_SCAN_GMIN") ? atoi(getenv("GAMMA_HIP_SCAN_GMIN")) : 4);
     if (bounded) {
         // feedback (gamma_hip_internal.h, bound_*): the counts of some recent call are in the pinned words
         static const bool no_fb = getenv("GAMMA_HIP_NO_BOUND_FEEDBACK") != nullptr;
@@ -372,7 +372,10 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     const bool fuse_ip = bounded && PGN == 1 && (M == 16 || M == 32) && !getenv("GAMMA_HIP_NO_FUSED_IP");
     // the bounded scan's per-call state (repair list, ready words, survivor counts) is sized here, before the pair offsets,
     // whose kernel clears it together with the tie flags -- one launch instead of four fills in front of the scan
-    const int cap = gh::scan_slice_cap(R);
+    // (byte-table filter pass: a first group of a few probes bounds loosely for some queries -- slices of 2048 keep them out of the
+    //  unfiltered path; GAMMA_HIP_SLICE_CAP to sweep)
+    static const int cap_env = getenv("GAMMA_HIP_SLICE_CAP") ? atoi(getenv("GAMMA_HIP_SLICE_CAP")) : 0;
+    const int cap = cap_env > 0 ? std::max(cap_env, gh::scan_slice_cap(R)) : gh::scan_slice_cap(R);
     bool cf_ok = false, q8_ok = false;
     int PGM = PGN, nsl = PGN, cf_span = 0;
     unsigned long long* ready = nullptr;
