@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <type_traits>
 #include <utility>
 
@@ -16,6 +17,18 @@
 #include "scan_dev.h"
 
 namespace gh {
+
+// phase clocks of the bounded-scan kernel (build with -DGH_SCAN_TIMING; the launcher prints the sums every 16th launch)
+#ifdef GH_SCAN_TIMING
+__device__ unsigned long long g_scan_t[32];
+#define GH_ST(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define GH_ST_ADD(i, a, b) do { if (threadIdx.x == 0 && (blockIdx.x & 127) < 8) atomicAdd(&g_scan_t[i], (b) - (a)); } while (0)
+#define GH_ST_CNT(i) do { if (threadIdx.x == 0 && (blockIdx.x & 127) < 8) atomicAdd(&g_scan_t[i], 1ull); } while (0)
+#else
+#define GH_ST(var)
+#define GH_ST_ADD(i, a, b)
+#define GH_ST_CNT(i)
+#endif
 
 // ------------------------------------------------------------------------------------
 // a4+a5+a6+a8: IVFPQ list scan, one workgroup per (query, probe) pair.
@@ -143,6 +156,7 @@ __device__ __forceinline__ void scan_pair_body(
     int lut_q = -1;    // unit mode, inner product: the query whose table is in LDS
     int lut_pair = -1; // unit mode, L2: the (query, probe) pair whose table is in LDS
     auto body = [&](const int q, const int pg) {
+    GH_ST(t_start);
     // validity predicates of THIS query: entry qfil[q] of the call's filter table (one entry unless the
     // call is a combined batch of requests with their own filters); only read when need_ids
     const FilterDesc& filt = ftab[(need_ids && qfil) ? qfil[q] : 0];
@@ -280,8 +294,11 @@ __device__ __forceinline__ void scan_pair_body(
             tau_f = key2f(L2 ? tauq : ~tauq);
         }
     }
+    GH_ST(t_bound);
     if constexpr (CF) {
         if (pg > 0 && bound_on) {   // (uniform)
+            GH_ST_CNT(8);
+            GH_ST_ADD(9, t_start, t_bound);
             // ---- filter pass (L2 consumers with a bound) ----------------------------------------------------------
             // Half of the regular loop's instructions build the per-list table T2[l] - 2 ip[q] (4096 entries for
             // lists of a few hundred codes).  Here the LUT is the QUERY's table ip[q] alone, written once per
@@ -361,6 +378,8 @@ __device__ __forceinline__ void scan_pair_body(
             int& s_next = *reinterpret_cast<int*>(s_cand + (C8 ? 0 : SCAN_CF_CAP));   // (the byte pass has no stage of its own)
             if (tid == 0) s_next = 0;
             __syncthreads();   // the LUT and the list counter are in place
+            GH_ST(t_quant);
+            GH_ST_ADD(10, t_bound, t_quant);
             const int ng = p_end - p_begin;
             for (;;) {
                 int r = 0;
@@ -452,6 +471,8 @@ __device__ __forceinline__ void scan_pair_body(
                 }
             }
             __syncthreads();
+            GH_ST(t_loop);
+            GH_ST_ADD(11, t_quant, t_loop);
             const int nc = s_ncand;
             if (nc > (C8 ? C8_CAND : SCAN_CF_CAP)) {   // (uniform) more candidates than the stage holds: the query takes the unfiltered path
                 if (tid == 0) s_nstage = sb.slice_cap + 1;
@@ -515,6 +536,8 @@ __device__ __forceinline__ void scan_pair_body(
                 }
             }
             flush();
+            GH_ST(t_cend);
+            GH_ST_ADD(12, t_loop, t_cend);
             return;
         }
     }
@@ -619,7 +642,10 @@ __device__ __forceinline__ void scan_pair_body(
         }
     }
     if (!L2) __syncthreads();   // the LUT (written once per query) is complete; L2 rebuilds it per list
+    GH_ST(t_lists);
+    if (FILT && pg == 0) { GH_ST_CNT(0); GH_ST_ADD(1, t_start, t_lists); }
     for (int p = p_begin; p < (prod_done ? p_begin : p_end); p++) {
+        GH_ST(t_l0);
         const int pair = q * P + p;
         const int l = probe_list[pair];
         if (l < 0 || l >= nlist) continue;            // uniform
@@ -667,6 +693,8 @@ __device__ __forceinline__ void scan_pair_body(
             }
             __syncthreads();
         }
+        GH_ST(t_l1);
+        if (FILT && pg == 0) GH_ST_ADD(2, t_l0, t_l1);
         // L2: the coarse distance; IP: <x_q, centroid_l>, computed per pair by k_pair_ip (a chain of d/8
         // dependent fmas per AVX lane has no place inside this loop)
         const float dis0 = coarse_dis[pair];
@@ -816,6 +844,8 @@ __device__ __forceinline__ void scan_pair_body(
         }
     }
     if (FILT && pg > 0) flush();   // also without a bound: the slice count must be written (0)
+    GH_ST(t_lend);
+    if (FILT && pg == 0) GH_ST_ADD(3, t_lists, t_lend);
     if (FILT && pg == 0) {
         // ---- producer: bound of this query's K-th best from its first probe group ----
         // 256-bin histogram of the group's valid keys over [min, max]; tau = upper edge of the bin
@@ -904,6 +934,8 @@ __device__ __forceinline__ void scan_pair_body(
         if (threadIdx.x == 0)
             __hip_atomic_store(&sb.ready[q], tau < KEY_SENTINEL ? ((1ull << 32) | tau) : (2ull << 32),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        GH_ST(t_pub);
+        GH_ST_ADD(4, t_lend, t_pub);
         // the group's own candidates within the bound become its survivor slice (slice 0), like a
         // consumer's: k_select_final then reads a few hundred items per query and never the distance
         // buffer (one wave walking a long first group -- 24 k candidates at C4 -- was the slow part)
@@ -986,6 +1018,8 @@ __device__ __forceinline__ void scan_pair_body(
             }
         }
         flush();   // without a bound: count 0
+        GH_ST(t_pend);
+        GH_ST_ADD(5, t_pub, t_pend);
     }
     };   // body
     if (!repair) {
@@ -1105,6 +1139,22 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
                             const int* qperm, int G, int pg_lo, int pg_cnt, int sparse, const ScanBound* bound,
                             const float* pqc_fused, const int* rq_list, const int* rq_count, int chunk_len, int max_units) {
     if (nq <= 0 || pg_cnt <= 0) return;
+#ifdef GH_SCAN_TIMING
+    {
+        static int calls = 0;
+        if (bound && (++calls & 15) == 0) {
+            unsigned long long t[32];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_scan_t), sizeof(t));
+            const double np = (double)std::max<unsigned long long>(1, t[0]), nc = (double)std::max<unsigned long long>(1, t[8]);
+            fprintf(stderr, "scan phases, shader cycles per workgroup -- producers (%llu): start %.0f, lists total %.0f (of which table builds incl. "
+                    "their waits %.0f), bound %.0f, own slice %.0f; consumers (%llu): to the bound %.0f, byte image %.0f, filter loop %.0f, exact + flush %.0f\n",
+                    t[0], t[1] / np, t[3] / np, t[2] / np, t[4] / np, t[5] / np, t[8], t[9] / nc, t[10] / nc, t[11] / nc, t[12] / nc);
+            unsigned long long z[32] = {};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_scan_t), z, sizeof(z));
+        }
+    }
+#endif
     if (chunk_len > 0 && (bound || pqc_fused || !rq_list || G != 1 || pg_lo != 0 || pg_cnt != P || max_units < 1)) abort();
     if (pqc_fused) {   // the table is computed inside the kernel (IPF): one workgroup per query, M 16 / 32
         if (!bound || pg_cnt != 1 || (M != 16 && M != 32)) abort();
