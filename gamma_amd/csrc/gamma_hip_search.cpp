@@ -407,7 +407,10 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         // (long lists: a tile's table staging and its chain of dependent loads are amortised over thousands of codes; at C3's
         //  244 codes per list a tile is one step of 64 codes per wave and the pass is latency-bound -- measured slower than the
         //  query-major pass there, profiles/r05_q8_*.txt -- so short lists keep the query-major filter pass)
-        static const double q8_minlen = getenv("GAMMA_HIP_Q8_MINLEN") ? atof(getenv("GAMMA_HIP_Q8_MINLEN")) : 1000.0;
+        // (the switch, measured after the byte image went into the query-major pass: nlist 4096 / M 16 / nprobe 32 -- 732 codes per
+        //  list 2.81 ms query-major, 2.84 list-major; 976: 3.31 / 3.20; 1465: 4.49 / 3.57 -- nlist 16384 / M 32 / nprobe 64 -- 732: 4.35 /
+        //  4.38; 976: 5.36 / 4.87)
+        static const double q8_minlen = getenv("GAMMA_HIP_Q8_MINLEN") ? atof(getenv("GAMMA_HIP_Q8_MINLEN")) : 800.0;
         const int64_t q_stride0 = (std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len)) + 3) & ~(int64_t)3;
         // (a list shard with a supplied, compacted assignment runs it too: pairs of lists of other shards are simply not placed)
         q8_ok = !no_q8 && !no_cf && R <= 1024 && (!shard || compacted) &&

@@ -283,7 +283,7 @@ def test_filter_pass_with_several_consumer_groups():
 
 def test_list_major_byte_table_pass_on_short_lists():
     """The list-major consumer pass over byte tables (csrc/q8scan.hip: one list x 8 queries per tile, candidates recomputed
-    exactly per query) is the default from 1000 codes per list on -- the C4 / C5 list-length regimes above run it.  Here it is
+    exactly per query) is the default from 800 codes per list on -- the C4 / C5 list-length regimes above run it.  Here it is
     forced on the short-list suites (GAMMA_HIP_Q8_MINLEN=0, read once per process: a child process): the bounded-scan
     parity tests, the C3 headline test and the large-batch fuzz -- strict comparisons, as in the parent."""
     import os
@@ -416,6 +416,47 @@ def _check_regime(g, o, q1, reps, metric, P, R, k, has_rank, ctx_kw=None, args_k
     compare_search_exact(np.tile(D1, (reps, 1)), np.tile(I1, (reps, 1)), _tile_stages(st1, reps), Dg, Ig, sg)
     assert g.ties_not_honoured() == 0
     return D1, I1
+
+
+@pytest.mark.parametrize("M,nlist,N", [(16, 256, 230000), (32, 192, 180000)])
+def test_lists_around_the_switch_between_the_two_consumer_passes(M, nlist, N):
+    """~900 codes per list: the region where the list-major byte-table pass takes over from the query-major one (800 codes per
+    list, csrc/gamma_hip_search.cpp: the lists of the large-batch fuzz stop at ~780) -- its short-list kernel (k_q8_filter_sl) at
+    batch size, M 16 and 32, has_rank both, deletes + a 10 % range filter; then the SAME calls with the switch moved out of the way
+    (GAMMA_HIP_Q8_MINLEN is read once per process, so the other side runs in the fuzz and the short-list suites), all against the
+    oracle: probe order, recall-stage sets, labels at every rank."""
+    d, P, k = 128, 32, 10
+    base = synth.sift_like(N, d=d, seed=99)
+    cc, pq = api.train_ivfpq(base[:nlist * 64], nlist, M)
+    g = api.GammaHip(0)
+    try:
+        g.ivfpq_init(d, nlist, M, 8, api.METRIC_L2, bucket_init_size=2000)
+        g.ivfpq_set_trained(cc, pq, None)
+        g.raw_init(d)
+        g.raw_append(base)
+        g.add(base, 0)
+        sizes = np.array([g.list_size(l) for l in range(nlist)])
+        assert sizes.sum() == N and 800 < sizes.mean() < 1000
+        o = _oracle_from_device(g, d, nlist, M, B.METRIC_L2, cc, pq, base, bucket=2000)
+        q1 = synth.sift_like(512, d=d, seed=4321)
+        for R in (100, 200):
+            for has_rank in (True, False):
+                _check_regime(g, o, q1, 8, api.METRIC_L2, P, R, k, has_rank)
+        rng = np.random.default_rng(5)
+        dead = rng.choice(N, N // 20, replace=False)
+        bm = np.zeros((N >> 3) + 1, dtype=np.uint8)
+        np.bitwise_or.at(bm, dead >> 3, (1 << (dead & 7)).astype(np.uint8))
+        g.bitmap_upload(bm, N)
+        g.delete(dead)
+        o.set_docids_bitmap(bm)
+        o.delete(dead)
+        docs = np.nonzero(rng.random(N) < 0.10)[0]
+        _check_regime(g, o, q1, 8, api.METRIC_L2, P, 200, k, True, ctx_kw=dict(docids_bitmap=bm))
+        _check_regime(g, o, q1, 8, api.METRIC_L2, P, 200, k, True,
+                      ctx_kw=dict(docids_bitmap=bm, range_filters=[B.make_range_filter(docs)]),
+                      args_kw=dict(range_filters=[api.make_range_filter(docs)]))
+    finally:
+        g.close()
 
 
 def test_c4_list_length_regime_m32_5900_codes_per_list():
