@@ -725,6 +725,10 @@ static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, in
             // did this member's own top-R cut of a query go through a tie?  (the merge at the query's owner asks)
             hip(b.cutf.ensure((size_t)nq), "alloc");
             if (rc == GAMMA_HIP_OK) abi(gamma_hip_ivfpq_shard_cut_flags(h, nq, b.cutf.as<uint8_t>()));
+            // (what the exchange below receives into is allocated on THIS side of the barrier: a member that cannot get it says so
+            //  in the go / no-go snapshot instead of leaving its peers inside a collective -- ADVICE r4.  An RCCL error AFTER the
+            //  barrier is fatal for the group: nothing can call a member back out of ncclGroupEnd)
+            hip(b.cutall.ensure((size_t)W * per), "alloc");
             hip(hipEventRecord(b.ev_scan, s), "record");
         }
         all_ok = g->bar.arrive(rc == GAMMA_HIP_OK);   // every member's candidate tables are on its stream
@@ -734,7 +738,6 @@ static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, in
             // RCCL: the per-shard tables of every owner's slice in one grouped exchange (every member sends slice j of its
             // tables to member j and receives its own slice of theirs -- an all-to-all over xGMI); members with an empty
             // slice still take part
-            hip(b.cutall.ensure((size_t)W * per), "alloc");
             ncc(nccl->GroupStart(), "ncclGroupStart");
             for (int j = 0; j < W; j++) {   // (never cut short: the other members' halves of the exchange are under way)
                 int a0, a1;
@@ -760,7 +763,6 @@ static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, in
                 hip(copy_between(b.all_ids.as<int64_t>() + (size_t)j * per * R, g->dev[i], g->mb[j].rids.as<int64_t>() + (size_t)q0 * R,
                                  g->dev[j], (size_t)nql * R * sizeof(int64_t), s), "candidate exchange");
             }
-            hip(b.cutall.ensure((size_t)W * per), "alloc");
             for (int j = 0; j < W && rc == GAMMA_HIP_OK && !nccl; j++)
                 hip(copy_between(b.cutall.as<uint8_t>() + (size_t)j * per, g->dev[i], g->mb[j].cutf.as<uint8_t>() + q0, g->dev[j], (size_t)nql, s),
                     "cut flags");
