@@ -518,7 +518,11 @@ CoarseFusedPlan coarse_fused_plan(int nq, int nlist, int P, int cap, bool exact_
     CoarseFusedPlan pl;
     // C3 (nlist 4096, P 32): sample 512, 8 strips of 448 columns that keep 37 +- 9 entries per query; kCoarseCap = 128
     // is ten sigma away, the rest goes to k_coarse_repair
-    if (!coarse_fused_shape(nlist, P, &pl.sample, &pl.nseg)) abort();   // callers ask coarse_fused_supported first
+    if (!coarse_fused_shape(nlist, P, &pl.sample, &pl.nseg)) {   // callers ask coarse_fused_supported first
+        launch_refused("coarse_fused_plan: shape outside the matrix-free coarse path (coarse_fused_supported)");
+        pl.sample = 512;
+        pl.nseg = 1;
+    }
     const int ntiles = (nlist - pl.sample + 63) / 64;
     pl.tiles_per_strip = (ntiles + pl.nseg - 1) / pl.nseg;
     pl.nseg = (ntiles + pl.tiles_per_strip - 1) / pl.tiles_per_strip;

@@ -399,6 +399,10 @@ struct SearchLock {
             (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                  \
             return e_ == hipErrorOutOfMemory ? GAMMA_HIP_ENOMEM : GAMMA_HIP_EDEVICE;       \
         }                                                                                  \
+        if (const char* r_ = gh::launch_refused_take()) {   /* kernels.h: a launcher was handed a shape its callers rule out */ \
+            (h)->err = std::string("internal: ") + r_;                                     \
+            return GAMMA_HIP_EDEVICE;                                                      \
+        }                                                                                  \
     } while (0)
 
 #define GH_TRY(expr)                   \

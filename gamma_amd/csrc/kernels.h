@@ -7,6 +7,13 @@
 
 namespace gh {
 
+// A launcher that is handed a shape its callers are supposed to rule out does not abort the process (a database server's): it
+// records what it refused, launches nothing, and the C-ABI entry point under way fails with GAMMA_HIP_EDEVICE and that text at
+// its next GH_CHECK (gamma_hip_internal.h).  Thread-local: a call enqueues from one thread.
+void launch_refused(const char* what);
+const char* launch_refused_take();   // what was refused since the last take (nullptr: nothing), cleared
+
+
 // once-per-device initialisation of a kernel attribute (hipFuncSetAttribute is per device; a process may hold handles
 // on several): true the first time the calling thread's current device comes by
 inline bool first_call_on_device(std::atomic<uint64_t>& done) {

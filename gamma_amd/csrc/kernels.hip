@@ -19,6 +19,19 @@
 
 namespace gh {
 
+namespace {
+thread_local const char* g_launch_refused = nullptr;
+}
+void launch_refused(const char* what) {
+    if (!g_launch_refused) g_launch_refused = what;
+}
+const char* launch_refused_take() {
+    const char* w = g_launch_refused;
+    g_launch_refused = nullptr;
+    return w;
+}
+
+
 // ------------------------------------------------------------------------------------
 // a2/a10: exact pairwise distances, one database row per thread held in registers.
 //   out[q][row] = fvec_L2sqr / fvec_inner_product (x_q, y_row), reference op order.
@@ -257,7 +270,7 @@ static void launch_pairwise_emit_t(hipStream_t s, const float* x, int nq, int d,
         case 64: GH_EMIT(64); break;
         case 32: GH_EMIT(32); break;
         case 16: GH_EMIT(16); break;
-        default: abort();   // pairwise_can_emit
+        default: launch_refused("launch_pairwise_emit: row length without an emitting kernel (pairwise_can_emit)"); return;
     }
 #undef GH_EMIT
 }

@@ -1155,9 +1155,15 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
         }
     }
 #endif
-    if (chunk_len > 0 && (bound || pqc_fused || !rq_list || G != 1 || pg_lo != 0 || pg_cnt != P || max_units < 1)) abort();
+    if (chunk_len > 0 && (bound || pqc_fused || !rq_list || G != 1 || pg_lo != 0 || pg_cnt != P || max_units < 1)) {
+        launch_refused("launch_ivfpq_scan_pair: unit mode with a bound, a fused table, grouped probes or no work list");
+        return;
+    }
     if (pqc_fused) {   // the table is computed inside the kernel (IPF): one workgroup per query, M 16 / 32
-        if (!bound || pg_cnt != 1 || (M != 16 && M != 32)) abort();
+        if (!bound || pg_cnt != 1 || (M != 16 && M != 32)) {
+            launch_refused("launch_ivfpq_scan_pair: fused query tables need a bound, one group per query and M 16 / 32");
+            return;
+        }
         st2 = pqc_fused;
     }
     // LUT | survivor staging | a few words (see the kernel)
@@ -1174,7 +1180,10 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
     // filter pass for the consumers of a bounded L2 scan: needs the per-code sums (sb.sums) and survivor-only consumers
     const bool cf = bound && l2 && !pqc_fused && pg_cnt > 1 && sb.sums && sb.t2max && !sb.store_all && (M == 16 || M == 32);
     if (rq_list) {   // repair launch: a fixed grid loops over the flagged (query, group) items
-        if (bound || pqc_fused) abort();
+        if (bound || pqc_fused) {
+            launch_refused("launch_ivfpq_scan_pair: a repair launch takes neither a bound nor fused tables");
+            return;
+        }
         grid.x = (unsigned)std::min<int64_t>((int64_t)nq * pg_cnt, 2048);
     }
     if (chunk_len > 0) {   // as many workgroups as are resident at once (LDS: the LUT), no more than there can be units

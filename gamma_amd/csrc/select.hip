@@ -1538,7 +1538,10 @@ void launch_flat_init(hipStream_t s, bool l2, const float* vals, const int* pos,
     if (nq > 0) hipLaunchKernelGGL(k_flat_init, dim3(nq), dim3(256), 0, s, vals, pos, k, r0, l2, em, tau, kept);
 }
 void launch_flat_compact(hipStream_t s, int nq, int k, const FlatEmit& em, uint32_t* tau, int* overflow, const FlatLog* log) {
-    if (k > 256 || em.cap != FLAT_CAP) abort();   // callers gate on this
+    if (k > 256 || em.cap != FLAT_CAP) {   // callers gate on this
+        launch_refused("launch_flat_compact: k > 256 or a candidate list of another capacity");
+        return;
+    }
     FlatLog lg = log ? *log : FlatLog{};
     static const bool want_dbg = getenv("GAMMA_HIP_COMPACT_DBG") != nullptr;
     static unsigned long long* dbg = nullptr;
@@ -1764,9 +1767,11 @@ void launch_select_final(hipStream_t s, bool smallest, const unsigned long long*
                          int* out_pos, int64_t* out_ids, uint8_t* cut_tie, unsigned long long* tie_stats,
                          int* rq_list, int* rq_count, unsigned long long* bound_stat) {
     if (nq <= 0) return;
-    if (P > 128) abort();   // callers gate on this (gamma_hip_search.cpp, ivfpq_stage_a)
+    if (P > 128 || K > 1024 || (K <= 256 && nslices > 64)) {   // callers gate on this (gamma_hip_search.cpp, ivfpq_stage_a)
+        launch_refused("launch_select_final: nprobe > 128, recall_num > 1024 or more than 64 survivor slices");
+        return;
+    }
     if (K > 256) {          // one workgroup per query (recall_num up to 1024: the callers' gate)
-        if (K > 1024) abort();
         if (smallest)
             hipLaunchKernelGGL((k_select_final_wg<true>), dim3(nq), dim3(256), 0, s, surv, gcnt, nslices, slice_cap, ready, pair_off, P, nq,
                                K, pair_base, ids, flag, out_vals, out_pos, out_ids, cut_tie, tie_stats, rq_list, rq_count, bound_stat);
@@ -1775,7 +1780,6 @@ void launch_select_final(hipStream_t s, bool smallest, const unsigned long long*
                                nq, K, pair_base, ids, flag, out_vals, out_pos, out_ids, cut_tie, tie_stats, rq_list, rq_count, bound_stat);
         return;
     }
-    if (nslices > 64) abort();
 #define GH_SF(SM, PM)                                                                                        \
     hipLaunchKernelGGL((k_select_final<SM, PM>), dim3((nq + 3) / 4), dim3(256), 0, s, surv, gcnt, nslices,   \
                        slice_cap, ready, pair_off, P, nq, K, pair_base, ids, flag,                           \
@@ -2250,8 +2254,10 @@ void launch_small_coarse_select(hipStream_t s, const float* mat, int nlist, int 
                                 uint32_t* units, int* unit_count, int chunk_len, int exact_ties,
                                 unsigned long long* tie_stats) {
     if (nq <= 0) return;
-    if (P > 128) abort();   // callers gate on this
-    if (units && (nq > 4096 || chunk_len < 1)) abort();
+    if (P > 128 || (units && (nq > 4096 || chunk_len < 1))) {   // callers gate on this
+        launch_refused("launch_small_coarse_select: nprobe > 128, or a unit list for more than 4096 queries");
+        return;
+    }
     const SmallSelectArgs A{mat, nlist, P, out_vals, out_pos, list_len, list_mask, list_off, pair_off, q_total, pair_base,
                             x, cc, d, pair_ip, units, unit_count, chunk_len, exact_ties, tie_stats};
     hipLaunchKernelGGL(k_small_coarse_select, dim3(nq), dim3(SM_NT), 0, s, A);
@@ -2514,7 +2520,10 @@ void launch_small_tail(hipStream_t s, bool l2, const float* slab, int64_t q_stri
                        float* distances, int64_t* labels, int smax, float* pre_val, int* pre_pos, int fixed_n,
                        const TieReplayArgs* tr, unsigned long long* tie_stats) {
     if (nq <= 0) return;
-    if (R > 1024) abort();   // callers gate on this
+    if (R > 1024) {   // callers gate on this
+        launch_refused("launch_small_tail: recall_num > 1024");
+        return;
+    }
     const int exact_ties = tr != nullptr ? 1 : 0;
     const TieReplayArgs tra = exact_ties ? *tr : TieReplayArgs{};
     const size_t lds = exact_ties ? tie_replay_lds_bytes_(R, k, P, 2048) : 0;

@@ -75,7 +75,10 @@ void launch_tie_replay(hipStream_t s, bool l2, const TieReplayArgs& a0) {
         a.dbg = dbg;
     }
     const int grid = std::min(a.nq, 1024);
-    if (a.slice_cap > 2048) abort();   // callers gate on this
+    if (a.slice_cap > 2048) {   // callers gate on this
+        launch_refused("launch_tie_replay: survivor slices of more than 2048 items");
+        return;
+    }
     if (a.R > TR_MAXK || a.k > TR_MAXK) {
         // heaps beyond 1024 entries (up to the 4096 the ABI accepts): the same replay with a sort buffer of 4096 items --
         // up to 155 KB of LDS, one workgroup per CU; a sequential heap_reorder of 4096 entries takes milliseconds, which
