@@ -458,6 +458,11 @@ def test_random_realtime_script(seed):
                 Dg, Ig = g.ivfpq_search(q, 5, api.SearchArgs(metric=api.METRIC_L2, nprobe=P, recall_num=30, has_rank=True,
                                                               coarse_mode=0, **WIDE))
                 compare_exact(D, I, Dg, Ig)
+        st = g.repack_verify_stats()
+        assert st["failures"] == 0, st     # a repack whose target did not read back equal is caught and redone -- and worth knowing about
+        if os.environ.get("GAMMA_RT_FUZZ_LOG"):   # one line per script: seed, repacks verified before publication, read-back failures
+            with open(os.environ["GAMMA_RT_FUZZ_LOG"], "a") as f:
+                f.write("%d %d %d\n" % (seed, st["verified"], st["failures"]))
     finally:
         g.close()
 
