@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void k_flat_exact(const uint2* __restrict__ pa
 }
 
 // ------------------------------------------------------------------------------------
-// Long rows (128 < d <= 1024, d % 32 == 0; round 5: C5's d = 768 ran the exact vector kernel at ~1.3 TFLOP/s).  The rows'
+// Long rows (128 < d <= 1536, d % 32 == 0; round 5: C5's d = 768 ran the exact vector kernel at ~1.3 TFLOP/s).  The rows'
 // fragments no longer fit the registers for a whole launch, so the roles are swapped: a workgroup keeps ONE block of 32
 // QUERIES -- its bf16 hi / lo image, d x 128 bytes of LDS -- for the whole launch and streams rows: 256 rows per step (64
 // per wave), K in steps of 16 with the lane's 8 floats of each of its two rows loaded, split into hi / lo and fed to the same
@@ -366,8 +366,11 @@ __global__ __launch_bounds__(256) void k_flat_exact(const uint2* __restrict__ pa
 // d = 1024), the fp32 norms <= d 2^-24 (xn + yn), the exact path's own roundings <= (d / 8 + 4) 2^-24 (2 (xn + yn)):
 //   d <= 512:  |d~ - d_exact| <= 1.4e-4 (xn + yn)   margin 2^-12 = 2.44e-4
 //   d <= 1024: |d~ - d_exact| <= 2.7e-4 (xn + yn)   margin 2^-11 = 4.88e-4       (inner product: the same constants on |x||y|)
+//   d <= 1536: |d~ - d_exact| <= 4.0e-4 (xn + yn)   margin 2^-10 = 9.77e-4
+// Beyond 1024 the image of a query block (d x 128 bytes) no longer fits the LDS: its hi half stays there (d x 64 bytes, 96 KB
+// at d = 1536), the lo fragments -- one of the three products' operands -- are read from the L2 beside the rows.
 // ------------------------------------------------------------------------------------
-float flat_filter_margin(int d) { return d <= 128 ? FM_C : (d <= 512 ? 2.44140625e-4f : 4.8828125e-4f); }
+float flat_filter_margin(int d) { return d <= 128 ? FM_C : (d <= 512 ? 2.44140625e-4f : (d <= 1024 ? 4.8828125e-4f : 9.765625e-4f)); }
 
 __global__ __launch_bounds__(256) void k_flat_prep_queries_rt(const float* __restrict__ x, int nq, int nq_pad, int D,
                                                               char* __restrict__ out) {
@@ -391,8 +394,10 @@ __global__ __launch_bounds__(FM_NT) void k_flat_filter_big(FlatFilterArgs a, int
     const int KK = D / 16;
     const int IMG = fm_mt_bytes(D);
     extern __shared__ __attribute__((aligned(16))) char s_fm[];
-    char* s_img = s_fm;                                                   // [IMG] the block's 32 queries
-    uint2* s_list = reinterpret_cast<uint2*>(s_fm + IMG);                 // [4 waves][FM_WLIST]
+    const bool lo_in_l2 = D > 1024;                                       // (uniform) only the hi half of the image fits the LDS
+    const int IMG_LDS = lo_in_l2 ? IMG / 2 : IMG;
+    char* s_img = s_fm;                                                   // [IMG_LDS] the block's 32 queries
+    uint2* s_list = reinterpret_cast<uint2*>(s_fm + IMG_LDS);             // [4 waves][FM_WLIST]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int kh = lane >> 5, j = lane & 31;
     const int mt = blockIdx.x;
@@ -400,7 +405,7 @@ __global__ __launch_bounds__(FM_NT) void k_flat_filter_big(FlatFilterArgs a, int
     {
         const uint4* src = reinterpret_cast<const uint4*>(a.qimg + (int64_t)mt * IMG);
         uint4* dst = reinterpret_cast<uint4*>(s_img);
-        for (int i = tid; i < IMG / 16; i += FM_NT) dst[i] = src[i];
+        for (int i = tid; i < IMG_LDS / 16; i += FM_NT) dst[i] = src[i];
     }
     // this lane's 16 queries: i = (reg & 3) + 8 (reg >> 2) + 4 kh
     float av[16], gv[16];
@@ -430,6 +435,7 @@ __global__ __launch_bounds__(FM_NT) void k_flat_filter_big(FlatFilterArgs a, int
     const int64_t steps = (a.ny + 255) / 256, per = (steps + gridDim.y - 1) / gridDim.y;
     const int64_t s_lo = (int64_t)blockIdx.y * per, s_hi = min(steps, s_lo + per);
     const char* tb = s_img + (kh * 32 + j) * 16;
+    const char* tg = a.qimg + (int64_t)mt * IMG + (kh * 32 + j) * 16;    // the same fragment in the image in memory
     for (int64_t st = s_lo; st < s_hi; st++) {
         const int64_t r0 = st * 256 + w * 64;
         const float* yp[2];
@@ -472,7 +478,7 @@ __global__ __launch_bounds__(FM_NT) void k_flat_filter_big(FlatFilterArgs a, int
                 }
             }
             const bf16x8 ah = *reinterpret_cast<const bf16x8*>(tb + ((0 * KK + kk) * 2) * 512);
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(tb + ((1 * KK + kk) * 2) * 512);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>((lo_in_l2 ? tg : tb) + ((1 * KK + kk) * 2) * 512);
 #pragma unroll
             for (int nt = 0; nt < 2; nt++) {
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[nt], acc[nt], 0, 0, 0);
@@ -520,7 +526,7 @@ bool flat_filter_supported(int nq, int d, int64_t ny) {
     static const bool off = getenv("GAMMA_HIP_NO_FLAT_MFMA") != nullptr;
     static const bool off_big = getenv("GAMMA_HIP_NO_FLAT_MFMA_BIG") != nullptr;
     const bool small = d == 128 || d == 96 || d == 64 || d == 32;
-    const bool big = !off_big && d > 128 && d <= 1024 && d % 32 == 0;   // k_flat_filter_big: the query block's image is d x 128 bytes of LDS
+    const bool big = !off_big && d > 128 && d <= 1536 && d % 32 == 0;   // k_flat_filter_big: the query block's image is d x 128 bytes (LDS; beyond 1024 half of it)
     return !off && (small || big) && nq >= 64 && ny >= 4096;
 }
 int64_t flat_filter_pair_cap(int nq) { return (int64_t)nq * 1024; }   // ~k survivors per query and pass are expected (all segments)
@@ -588,7 +594,7 @@ void launch_flat_filter(hipStream_t s, bool l2, int d, const void* qimage, const
         case 64: GH_FILT(64); break;
         case 32: GH_FILT(32); break;
         default: {   // long rows: one workgroup per (block of 32 queries, slice of the rows)
-            const size_t lds = (size_t)fm_mt_bytes(d) + (FM_NT / 64) * FM_WLIST * sizeof(uint2);
+            const size_t lds = (size_t)fm_mt_bytes(d) / (d > 1024 ? 2 : 1) + (FM_NT / 64) * FM_WLIST * sizeof(uint2);
             static std::atomic<uint64_t> attr{0};   // per device
             if (first_call_on_device(attr)) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_flat_filter_big<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);

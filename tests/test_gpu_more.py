@@ -263,7 +263,8 @@ def test_flat_running_bound(order):
 
 @pytest.mark.parametrize("d,kind", [(128, "near_duplicates"), (64, "wide_range"), (96, "sift"), (32, "near_duplicates"), (128, "unit"),
                                     # long rows (round 5, k_flat_filter_big): C5's d = 768 and the variant's range, margins 2^-12 / 2^-11
-                                    (768, "near_duplicates"), (768, "unit"), (256, "wide_range"), (512, "sift"), (1024, "unit"), (160, "unit")])
+                                    (768, "near_duplicates"), (768, "unit"), (256, "wide_range"), (512, "sift"), (1024, "unit"), (160, "unit"),
+                                    (1536, "unit"), (1536, "near_duplicates"), (1280, "wide_range")])
 def test_flat_matrix_filter_never_drops_a_neighbour(d, kind):
     """flat_mfma.hip: from 64 queries on the passes behind the first row chunk run a bf16 hi / lo filter on the matrix pipe
     (three products, a proven error margin) and only the survivors get the reference's exact arithmetic.  The filter must

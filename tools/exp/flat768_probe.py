@@ -5,13 +5,13 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gamma_amd import api, synth
 dev=torch.device("cuda",0)
-g=api.GammaHip(0); g.raw_init(768)
-for c0 in range(0,1000000,250000): g.raw_append(synth.embedding_like_device(250000,d=768,seed=1234,start=c0,device=dev).cpu().numpy())
-q=synth.embedding_like_device(1024,d=768,seed=4321,device=dev)
+DD=int(os.environ.get("FLAT_D","768")); NN=int(float(os.environ.get("FLAT_N","1e6"))); g=api.GammaHip(0); g.raw_init(DD)
+for c0 in range(0,NN,125000): g.raw_append(synth.embedding_like_device(125000,d=DD,seed=1234,start=c0,device=dev).cpu().numpy())
+q=synth.embedding_like_device(1024,d=DD,seed=4321,device=dev)
 D=torch.empty((1024,100),dtype=torch.float32,device=dev); I=torch.empty((1024,100),dtype=torch.int64,device=dev)
 a=api.SearchArgs(metric=api.METRIC_IP,min_score=-1e30,max_score=1e30)
 for _ in range(2): g.flat_search_device(q.data_ptr(),1024,100,a,D.data_ptr(),I.data_ptr())
 g.synchronize(); t=time.perf_counter()
 for _ in range(3): g.flat_search_device(q.data_ptr(),1024,100,a,D.data_ptr(),I.data_ptr())
 g.synchronize(); dt=(time.perf_counter()-t)/3
-print("c5 flat 1Mx768 IP 1024q k100: %.2f ms, gemm-form %.1f TF/s" % (dt*1e3, 2*1024*1e6*768/dt/1e12))
+print("flat %d x %d IP 1024q k100: %.2f ms, gemm-form %.1f TF/s" % (NN, DD, dt*1e3, 2*1024*NN*DD/dt/1e12))
