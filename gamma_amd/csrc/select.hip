@@ -261,13 +261,15 @@ __global__ __launch_bounds__(256) void k_select2(const float* __restrict__ vals,
 // the K smallest (key, position) pairs, sorted.
 // ------------------------------------------------------------------------------------
 namespace {
-constexpr int ST_CAPS = 2048;          // survivor buffer entries (16 KB -> 6 workgroups / CU)
+// survivor buffer entries: CAPS = 2048 (16 KB -> 6 workgroups / CU) up to K = 1024, 4096 up to K = 2048 (round 5: full-size C5 needs
+// recall_num 1200 for the metric's recall bar, and k_select2 took 5.4 ms of its 31 ms step)
 constexpr int ST_CHUNK = 1024;         // elements per threshold check
-constexpr int ST_IPT = ST_CAPS / 256;  // buffer items per thread during compaction
 
 // keep the K smallest items of buf[0..n) in buf[0..K); returns the largest kept key
+template <int ST_CAPS>
 __device__ uint32_t st_compact(unsigned long long* buf, int n, int K, int* s_hist, int* s_w,
                                uint32_t* s_red, int* s_misc) {
+    constexpr int ST_IPT = ST_CAPS / 256;  // buffer items per thread during compaction
     const int tid = threadIdx.x;
     unsigned long long it[ST_IPT];
     uint32_t mn = 0xffffffffu, mx = 0u;
@@ -329,7 +331,7 @@ __device__ uint32_t st_compact(unsigned long long* buf, int n, int K, int* s_his
     } else if (cnt <= 1024) {
         int cpad = 2;
         while (cpad < cnt) cpad <<= 1;
-        unsigned long long* cand = buf + (ST_CAPS - cpad);   // disjoint from [0, below): K <= 1024
+        unsigned long long* cand = buf + (ST_CAPS - cpad);   // disjoint from [0, below): K <= ST_CAPS / 2, cpad <= 1024
 #pragma unroll
         for (int j = 0; j < ST_IPT; j++) {
             if (tid + 256 * j < n) {
@@ -359,7 +361,7 @@ __device__ uint32_t st_compact(unsigned long long* buf, int n, int K, int* s_his
 }
 }  // namespace
 
-template <bool SMALLEST>
+template <bool SMALLEST, int ST_CAPS = 2048>
 __global__ __launch_bounds__(256) void k_select_stream(const float* __restrict__ vals, int64_t seg_stride,
                                                        const int* __restrict__ seg_len, int fixed_len,
                                                        int K, int Kpad, float* __restrict__ out_vals,
@@ -422,18 +424,18 @@ __global__ __launch_bounds__(256) void k_select_stream(const float* __restrict__
         const int cnt = s_cnt;
         __syncthreads();
         if (cnt > ST_CAPS - ST_CHUNK && cnt > K) {     // uniform
-            tau = st_compact(s_buf, cnt, K, s_hist, s_w, s_red, s_misc);
+            tau = st_compact<ST_CAPS>(s_buf, cnt, K, s_hist, s_w, s_red, s_misc);
             if (tid == 0) s_cnt = K;
             __syncthreads();
         }
     }
     int cnt = s_cnt;
     if (cnt > K) {
-        (void)st_compact(s_buf, cnt, K, s_hist, s_w, s_red, s_misc);
+        (void)st_compact<ST_CAPS>(s_buf, cnt, K, s_hist, s_w, s_red, s_misc);
         cnt = K;
     }
     __syncthreads();
-    block_rank_sort<256, 4>(s_buf, cnt);           // cnt <= K <= 1024 distinct items
+    block_rank_sort<256, ST_CAPS / 512>(s_buf, cnt);   // cnt <= K <= ST_CAPS / 2 distinct items
     for (int i = cnt + tid; i < K; i += 256) s_buf[i] = ~0ull;
     __syncthreads();
     const float sentinel = SMALLEST ? INFINITY : -INFINITY;
@@ -1746,6 +1748,10 @@ static void launch_sel(hipStream_t s, const float* vals, int64_t seg_stride, con
     else if (K <= 1024 && (seg_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(vals) & 15) == 0 &&
              !getenv("GAMMA_HIP_NO_STREAM_SELECT"))
         hipLaunchKernelGGL((k_select_stream<SMALLEST>), dim3(nseg), dim3(256), 0, s, vals, seg_stride,
+                           seg_len, fixed_len, K, Kpad, out_vals, out_pos, only);
+    else if (K <= 2048 && (seg_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(vals) & 15) == 0 &&
+             !getenv("GAMMA_HIP_NO_STREAM_SELECT") && !getenv("GAMMA_HIP_NO_STREAM_SELECT_2K"))
+        hipLaunchKernelGGL((k_select_stream<SMALLEST, 4096>), dim3(nseg), dim3(256), 0, s, vals, seg_stride,
                            seg_len, fixed_len, K, Kpad, out_vals, out_pos, only);
     else GH_SEL(0);
 #undef GH_SEL
