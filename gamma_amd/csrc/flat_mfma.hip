@@ -389,12 +389,12 @@ __global__ __launch_bounds__(256) void k_flat_prep_queries_rt(const float* __res
     *reinterpret_cast<uint4*>(base + ((((1 * KK + kk) * 2 + kh) * 32 + i) * 16)) = lo;
 }
 
-template <bool L2>
+template <bool L2, bool LO_L2>   // LO_L2: d > 1024, only the hi half of the image fits the LDS (a kernel of its own: the choice costs the others nothing)
 __global__ __launch_bounds__(FM_NT) void k_flat_filter_big(FlatFilterArgs a, int D, float c_margin) {
     const int KK = D / 16;
     const int IMG = fm_mt_bytes(D);
     extern __shared__ __attribute__((aligned(16))) char s_fm[];
-    const bool lo_in_l2 = D > 1024;                                       // (uniform) only the hi half of the image fits the LDS
+    constexpr bool lo_in_l2 = LO_L2;
     const int IMG_LDS = lo_in_l2 ? IMG / 2 : IMG;
     char* s_img = s_fm;                                                   // [IMG_LDS] the block's 32 queries
     uint2* s_list = reinterpret_cast<uint2*>(s_fm + IMG_LDS);             // [4 waves][FM_WLIST]
@@ -597,14 +597,21 @@ void launch_flat_filter(hipStream_t s, bool l2, int d, const void* qimage, const
             const size_t lds = (size_t)fm_mt_bytes(d) / (d > 1024 ? 2 : 1) + (FM_NT / 64) * FM_WLIST * sizeof(uint2);
             static std::atomic<uint64_t> attr{0};   // per device
             if (first_call_on_device(attr)) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_flat_filter_big<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_flat_filter_big<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_flat_filter_big<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_flat_filter_big<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_flat_filter_big<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_flat_filter_big<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
             }
             const int qb = a.nq_pad / 32;
             const int64_t steps = (a.ny + 255) / 256;
             const int slices = (int)std::max<int64_t>(1, std::min<int64_t>(steps, (2048 + qb - 1) / qb));
-            if (l2) hipLaunchKernelGGL((k_flat_filter_big<true>), dim3(qb, slices), dim3(FM_NT), lds, s, a, d, cm);
-            else hipLaunchKernelGGL((k_flat_filter_big<false>), dim3(qb, slices), dim3(FM_NT), lds, s, a, d, cm);
+            if (d > 1024) {
+                if (l2) hipLaunchKernelGGL((k_flat_filter_big<true, true>), dim3(qb, slices), dim3(FM_NT), lds, s, a, d, cm);
+                else hipLaunchKernelGGL((k_flat_filter_big<false, true>), dim3(qb, slices), dim3(FM_NT), lds, s, a, d, cm);
+            } else {
+                if (l2) hipLaunchKernelGGL((k_flat_filter_big<true, false>), dim3(qb, slices), dim3(FM_NT), lds, s, a, d, cm);
+                else hipLaunchKernelGGL((k_flat_filter_big<false, false>), dim3(qb, slices), dim3(FM_NT), lds, s, a, d, cm);
+            }
             break;
         }
     }
