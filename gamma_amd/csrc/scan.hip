@@ -479,7 +479,8 @@ __device__ __forceinline__ void scan_pair_body(
             } else {
                 // the exact value of a candidate: the regular loop's table entries and its adds, in the reference's order (the
                 // list's T2 row from the L2, the query's table entries from LDS)
-                auto exact_one = [&](bool have, const uint2 cd) {   // whole workgroup: append() ballots
+                auto exact_one = [&](bool have, const uint2 cd, auto glob) {   // whole workgroup: append() ballots
+                    constexpr bool GLOB = decltype(glob)::value;   // the query's table entries from memory (L2), not from LDS
                     bool keep = false;
                     float dis = 0.f;
                     int pos = 0;
@@ -502,36 +503,32 @@ __device__ __forceinline__ void scan_pair_body(
                             float a[8];
 #pragma unroll
                             for (int m = 0; m < 8; m++) a[m] = t2[(m0 + m) * 256 + ((cw[(m0 + m) >> 2] >> (8 * (m & 3))) & 255u)];
+                            float b[8];
 #pragma unroll
-                            for (int m = 0; m < 8; m++)
-                                dis += __builtin_fmaf(-2.0f, s_lut[(m0 + m) * 256 + ((cw[(m0 + m) >> 2] >> (8 * (m & 3))) & 255u)], a[m]);
+                            for (int m = 0; m < 8; m++) {
+                                const int e = (m0 + m) * 256 + ((cw[(m0 + m) >> 2] >> (8 * (m & 3))) & 255u);
+                                b[m] = GLOB ? st2q[e] : s_lut[e];
+                            }
+#pragma unroll
+                            for (int m = 0; m < 8; m++) dis += __builtin_fmaf(-2.0f, b[m], a[m]);
                         }
                         keep = dis <= tau_f;
                     }
                     append(keep, dis, pos);
                 };
                 if constexpr (C8) {
-                    // into registers (C8_CAND / 256 per thread), then the fp32 table over the bytes and the candidates' place
-                    uint2 mine[C8_CAND / 256];
-#pragma unroll
-                    for (int i = 0; i < C8_CAND / 256; i++) {
-                        const int c = tid + 256 * i;
-                        mine[i] = c < nc ? reinterpret_cast<const uint2*>(s_lut + MT * 64)[c] : make_uint2(0u, 0u);
+                    // The ~260 candidates' table entries come from the query's fp32 table in memory (16 KB, L2-hot: this workgroup
+                    // read it a moment ago) -- 16 more gathers per candidate on the otherwise idle vector-memory path instead of
+                    // writing the table into LDS (64 stores, two barriers) and gathering there: the LDS array is what this kernel
+                    // is short of (profiles/r05_scan_parts.txt).  The candidates stay where the filter loop put them.
+                    for (int c0 = 0; c0 < nc; c0 += 256) {   // uniform trip count
+                        const int c = c0 + tid;
+                        exact_one(c < nc, c < nc ? reinterpret_cast<const uint2*>(s_lut + MT * 64)[c] : make_uint2(0u, 0u), std::true_type{});
                     }
-                    __syncthreads();
-#pragma unroll
-                    for (int i = 0; i < MT; i++) s2r[i] = st2q[tid + 256 * i];
-                    lut_store_begin(lut_m0);
-                    lut_store_rows<MT>([&](int i) { return s2r[i]; }, std::make_integer_sequence<int, (MT > 0 ? MT : 1)>{});
-                    lut_store_done();
-                    __syncthreads();
-#pragma unroll
-                    for (int i = 0; i < C8_CAND / 256; i++)
-                        if (256 * i < nc) exact_one(tid + 256 * i < nc, mine[i]);   // (uniform)
                 } else {
                     for (int c0 = 0; c0 < nc; c0 += 256) {   // uniform trip count
                         const int c = c0 + tid;
-                        exact_one(c < nc, c < nc ? s_cand[c] : make_uint2(0u, 0u));
+                        exact_one(c < nc, c < nc ? s_cand[c] : make_uint2(0u, 0u), std::false_type{});
                     }
                 }
             }
