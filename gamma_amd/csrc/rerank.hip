@@ -130,16 +130,58 @@ __global__ __launch_bounds__(256) void k_rerank_topk(const float* __restrict__ x
     // dependent id load in front of each of them
     for (int r = threadIdx.x; r < R; r += 256) s_id[r] = cand_ids[(int64_t)q * R + r];
     __syncthreads();
-    for (int r0 = 0; r0 < R; r0 += 32) {
-        const int r = r0 + g;
-        int64_t id = -1;
-        if (r < R) id = s_id[r];
-        const bool live = id >= 0 && id < nraw;
-        float dis = rerank_dist8<L2>(xq, raw + (live ? id : 0) * d, d, l, live);
+    auto put = [&](int r, bool live, float dis) {
         if (l == 0 && r < R) {
             if (!live || !(dis <= max_score && dis >= min_score)) dis = sentinel;
             const uint32_t key = L2 ? f2key(dis) : ~f2key(dis);
             s_it[r] = ((unsigned long long)key << 32) | (unsigned)r;
+        }
+    };
+    if (d == 128) {
+        // d = 128 (C3, C4): the lane's 16 query elements stay in registers for all candidates (they were half of the loads), and TWO
+        // candidates per group of 8 lanes are in flight -- the rows are 512 bytes from all over the raw store, the workgroup's seven
+        // rounds of dependent row loads were what it waited for.  Same arithmetic as rerank_dist8 (rerank_dev.h): the lane's fma chain
+        // over its elements l, l + 8, .., then (a[l] + a[l + 4]), (s0 + s1) + (s2 + s3).
+        float xx[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) xx[u] = xq[l + 8 * u];
+        for (int r0 = 0; r0 < R; r0 += 64) {
+            const int ra = r0 + g, rb = r0 + 32 + g;
+            const int64_t ida = ra < R ? s_id[ra] : -1, idb = rb < R ? s_id[rb] : -1;
+            const bool la = ida >= 0 && ida < nraw, lb = idb >= 0 && idb < nraw;
+            const float* va = raw + (la ? ida : 0) * 128 + l;
+            const float* vb = raw + (lb ? idb : 0) * 128 + l;
+            float fa[16], fb[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) fa[u] = va[8 * u];
+#pragma unroll
+            for (int u = 0; u < 16; u++) fb[u] = vb[8 * u];
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                if (L2) {
+                    const float ta = xx[u] - fa[u], tb = xx[u] - fb[u];
+                    a = __builtin_fmaf(ta, ta, a);
+                    b = __builtin_fmaf(tb, tb, b);
+                } else {
+                    a = __builtin_fmaf(xx[u], fa[u], a);
+                    b = __builtin_fmaf(xx[u], fb[u], b);
+                }
+            }
+            if (!la) a = 0.f;
+            if (!lb) b = 0.f;
+            const float sa = __shfl_down(a, 4, 8) + a, sb_ = __shfl_down(b, 4, 8) + b;
+            const float ta = sa + __shfl_down(sa, 1, 8), tb = sb_ + __shfl_down(sb_, 1, 8);
+            put(ra, la, ta + __shfl_down(ta, 2, 8));
+            put(rb, lb, tb + __shfl_down(tb, 2, 8));
+        }
+    } else {
+        for (int r0 = 0; r0 < R; r0 += 32) {
+            const int r = r0 + g;
+            int64_t id = -1;
+            if (r < R) id = s_id[r];
+            const bool live = id >= 0 && id < nraw;
+            put(r, live, rerank_dist8<L2>(xq, raw + (live ? id : 0) * d, d, l, live));
         }
     }
     if (tf.list && threadIdx.x == 0) s_tie = tf.cut ? tf.cut[q] : 0;
