@@ -749,6 +749,34 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
     //      candidates within the bound, appended by its producer workgroup) ----
     int c = 0;
     uint32_t mn = 0xffffffffu, mx = 0u;
+    if (nslices == 2) {
+        // two slices (the filter-pass launches: the producer's own candidates + ONE consumer's): the first four 64-item blocks of
+        // both requested together -- a consumer's slice holds ~230 items, and each further block used to be a load of its own
+        // behind the previous one's use
+        const int c0 = __shfl(my_cnt, 0, 64), c1 = __shfl(my_cnt, 1, 64);
+        const unsigned long long* s0 = slice_ptr(0);
+        const unsigned long long* s1 = slice_ptr(1);
+        unsigned long long t0[4], t1[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            t0[u] = s0[min(64 * u + lane, max(c0 - 1, 0))];
+            t1[u] = s1[min(64 * u + lane, max(c1 - 1, 0))];
+        }
+        auto take = [&](const unsigned long long* sg, const unsigned long long (&t)[4], int cg) {
+            for (int i0 = 0; i0 < cg; i0 += 64) {
+                if (i0 + lane < cg) {
+                    const unsigned long long item = i0 < 256 ? t[(i0 >> 6) & 3] : sg[i0 + lane];
+                    const uint32_t key = (uint32_t)(item >> 32);
+                    if (c + i0 + lane < SF_CAND) cand[c + i0 + lane] = item;
+                    mn = key < mn ? key : mn;
+                    mx = key > mx ? key : mx;
+                }
+            }
+            c += cg;
+        };
+        take(s0, t0, c0);
+        take(s1, t1, c1);
+    } else
     for (int g0 = 0; g0 < nslices; g0 += 8) {   // the first 64 items of 8 slices in flight at once
         int cg[8];
         unsigned long long t[8];
