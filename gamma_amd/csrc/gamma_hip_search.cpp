@@ -321,8 +321,9 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     // (one group per query -- few probes, or a shard -- is fine: the producer bounds and compacts its own candidates)
     // (recall_num up to 1024 since round 5: slices of 2048 items and k_select_final_wg beyond 256 -- the configurations that need
     //  a long short-list, full-size C5 at ~1000, keep the pre-filter; GAMMA_HIP_BOUND_MAXR: the old gate for A/B runs)
+    static const int scan_gmin = getenv("GAMMA_HIP_SCAN_GMIN") ? atoi(getenv("GAMMA_HIP_SCAN_GMIN")) : 4;
     static const int bound_maxr = getenv("GAMMA_HIP_BOUND_MAXR") ? atoi(getenv("GAMMA_HIP_BOUND_MAXR")) : 1024;
-    bool bounded = (!shard || compacted) && h->scan_bound && R <= std::min(1024, bound_maxr) && P <= 128 && G >= (getenv("GAMMA_HIP_SCAN_GMIN") ? atoi(getenv("GAMMA_HIP_SCAN_GMIN")) : 4);
+    bool bounded = (!shard || compacted) && h->scan_bound && R <= std::min(1024, bound_maxr) && P <= 128 && G >= scan_gmin;
     if (bounded) {
         // feedback (gamma_hip_internal.h, bound_*): the counts of some recent call are in the pinned words
         static const bool no_fb = getenv("GAMMA_HIP_NO_BOUND_FEEDBACK") != nullptr;
@@ -375,7 +376,8 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     // (byte-table filter pass: a first group of a few probes bounds loosely for some queries -- slices of 2048 keep them out of the
     //  unfiltered path; GAMMA_HIP_SLICE_CAP to sweep)
     static const int cap_env = getenv("GAMMA_HIP_SLICE_CAP") ? atoi(getenv("GAMMA_HIP_SLICE_CAP")) : 0;
-    const int cap = cap_env > 0 ? std::max(cap_env, gh::scan_slice_cap(R)) : gh::scan_slice_cap(R);
+    // (clamped to 2048: the selection and the tie replay hold one slice in LDS)
+    const int cap = cap_env > 0 ? std::min(2048, std::max(cap_env, gh::scan_slice_cap(R))) : gh::scan_slice_cap(R);
     bool cf_ok = false, q8_ok = false;
     int PGM = PGN, nsl = PGN, cf_span = 0;
     unsigned long long* ready = nullptr;
@@ -477,10 +479,12 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
             pz.count_a = h->w_tlist.as<int>();
         }
         if (bounded) {
+#ifdef GH_SCAN_TIMING   // timing experiments with INVALID results: only in a library built for them (-DGH_SCAN_TIMING)
             static const int scan_dbg_part = getenv("GAMMA_HIP_SCAN_PART") ? atoi(getenv("GAMMA_HIP_SCAN_PART")) : 0;
             // (timing experiment 3: every other call runs the consumers alone, on the bounds of the call before)
-            static int scan_dbg_calls = 0;
-            h->scan_dbg_now = scan_dbg_part == 3 ? ((scan_dbg_calls++ & 1) ? 2 : 0) : scan_dbg_part;
+            static std::atomic<int> scan_dbg_calls{0};
+            h->scan_dbg_now = scan_dbg_part == 3 ? ((scan_dbg_calls.fetch_add(1) & 1) ? 2 : 0) : scan_dbg_part;
+#endif
             pz.words = h->scan_dbg_now == 2 ? nullptr : ready;
             pz.count_b = h->w_scnt.as<int>();
         }
@@ -557,9 +561,6 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         // the consumers' filter pass on a byte image of the query's table (scan.hip, "byte table")
         const bool c8_on = c8_shape;
         const int c8_mode = 1;
-        // (timing experiments, results invalid: 1 = only the producers run, 2 = only the consumers, on the bounds of the call before)
-        static const int scan_part = getenv("GAMMA_HIP_SCAN_PART") ? atoi(getenv("GAMMA_HIP_SCAN_PART")) : 0;
-        (void)scan_part;
         static const int scan_batch = getenv("GAMMA_HIP_SCAN_BATCH") ? atoi(getenv("GAMMA_HIP_SCAN_BATCH")) : 0;
         sb.batch = scan_batch;
         sb.dbg_part = h->scan_dbg_now;

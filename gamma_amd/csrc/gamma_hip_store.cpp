@@ -338,9 +338,8 @@ static int arena_repack_once(H* h, bool vmm, const std::vector<int64_t>& noff, i
     if (!no_verify) {
         if (vmm) (void)vm_unmap_fence();   // translations the move may have cached are gone before the read-back
         // fault injection for the tests (GAMMA_HIP_FAULT_REPACK=<n>: the first n read-backs see a zeroed entry)
-        static int fault_left = getenv("GAMMA_HIP_FAULT_REPACK") ? atoi(getenv("GAMMA_HIP_FAULT_REPACK")) : 0;
-        if (fault_left > 0 && total > 0) {
-            fault_left--;
+        static std::atomic<int> fault_left{getenv("GAMMA_HIP_FAULT_REPACK") ? atoi(getenv("GAMMA_HIP_FAULT_REPACK")) : 0};
+        if (total > 0 && fault_left.load() > 0 && fault_left.fetch_sub(1) > 0) {
             int l0 = 0;
             while (l0 < h->nlist - 1 && h->h_list_len[l0] == 0) l0++;
             GH_CHECK(h, hipMemsetAsync(ni + noff[l0], 0, sizeof(int64_t), h->wstream));

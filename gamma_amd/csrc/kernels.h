@@ -227,7 +227,7 @@ void launch_rq_nobound(hipStream_t s, const unsigned long long* ready, int nq, i
 // true when launch_ivfpq_scan_pair would run the filter pass (CF) for a bounded scan with these arguments; the caller
 // then launches TWO groups per query -- the producer's G probes and one consumer group with all the others
 bool scan_cf_applies(bool l2, int M, int P, int G, bool have_sums, bool store_all);
-int scan_group_size(int nq, int P, int G0 = 8);   // G0: probes per workgroup to start from (power of two)
+int scan_group_size(int nq, int P, int G0 = 8);   // G0: probes per workgroup to start from; shrinks through the powers of two below it
 void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int d, int M, int P,
                             const int* probe_list, const float* coarse_dis, const float* cc,
                             const float* st2, const float* T2, const int64_t* list_off,

@@ -782,12 +782,12 @@ void launch_q8_consumers(hipStream_t s, const Q8Args& a) {
     const int per_cu = std::max(1, std::min(8, (int)((160 * 1024) / (lds + 512))));
     static const int grid_env = getenv("GAMMA_HIP_Q8_GRID") ? atoi(getenv("GAMMA_HIP_Q8_GRID")) : 0;
     const unsigned grid = grid_env > 0 ? (unsigned)grid_env : (unsigned)(256 * per_cu);
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<uint64_t> attr{0};   // the attribute is per DEVICE (an in-process group launches this on every member's device)
+    if (first_call_on_device(attr)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_q8_filter<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_q8_filter_sl<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
-        attr = true;
     }
+    (void)hipGetLastError();   // (a stale error of an earlier call is not this pass's)
 #define GH_Q8F(KERN, MM)                                                                                                      \
     hipLaunchKernelGGL((KERN<MM>), dim3(grid), dim3(Q8_NT), lds, s, tile_list, tile_first, n_tiles, off, recs, a.q8, a.codes, \
                        a.sums, a.ids, a.ftab, a.need_ids, a.cand, ccnt, cap)
@@ -803,6 +803,8 @@ void launch_q8_consumers(hipStream_t s, const Q8Args& a) {
                            a.codes, a.pair_off, a.ready, a.cand, ccnt, cap, a.surv, a.gcnt, a.cnt_stride, a.slice_cap);
     }
 #undef GH_Q8F
+    // a launch of this pass that did not start leaves ccnt at 0 and k_q8_exact would publish EMPTY consumer groups: never silent
+    if (hipGetLastError() != hipSuccess) launch_refused("launch_q8_consumers: a kernel of the byte-table pass failed to launch");
 }
 
 }  // namespace gh

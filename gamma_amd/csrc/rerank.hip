@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k_rerank_topk(const float* __restrict__ x
             s_it[r] = ((unsigned long long)key << 32) | (unsigned)r;
         }
     };
-    if (d == 128) {
+    if (d == 128 && nraw > 0) {   // (nraw == 0: row 0 of the reserved range may not be mapped yet -- the predicated path below never touches it)
         // d = 128 (C3, C4): the lane's 16 query elements stay in registers for all candidates (they were half of the loads), and TWO
         // candidates per group of 8 lanes are in flight -- the rows are 512 bytes from all over the raw store, the workgroup's seven
         // rounds of dependent row loads were what it waited for.  Same arithmetic as rerank_dist8 (rerank_dev.h): the lane's fma chain

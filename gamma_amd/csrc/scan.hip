@@ -127,9 +127,11 @@ __device__ __forceinline__ void scan_pair_body(
         pg = pg_lo + slot % pg_cnt;
         qslot = slot / pg_cnt;
     }
+#ifdef GH_SCAN_TIMING
     if constexpr (CF) {
         if (sb.dbg_part && (sb.dbg_part == 1) == (pg > 0)) return;   // timing experiments (ScanBound::dbg_part)
     }
+#endif
     const bool repair = !FILT && rq_list != nullptr;
     int q = 0;
     if (repair) {
@@ -1123,7 +1125,9 @@ int scan_group_size(int nq, int P, int G0) {
     const char* ge = getenv("GAMMA_HIP_SCAN_G");   // (read per call: tools sweep it inside one process)
     const int g_env = ge ? atoi(ge) : 0;
     int G = g_env > 0 ? g_env : G0;
-    while (G > 1 && (int64_t)nq * ((P + G - 1) / G) < 4096) G >>= 1;
+    // (a start that is not a power of two -- 5 with the byte-image pass -- steps to the power of two below it: 5 -> 4 -> 2, not
+    //  5 -> 2, which skipped the G >= 4 the bounded scan needs for batches of 512 .. 585 queries at 32 probes)
+    while (G > 1 && (int64_t)nq * ((P + G - 1) / G) < 4096) G = (G & (G - 1)) ? (1 << (31 - __builtin_clz((unsigned)G))) : G >> 1;
     return std::max(1, std::min(G, P));
 }
 

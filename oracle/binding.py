@@ -127,6 +127,11 @@ def lib():
         L.go_ivfpq_set_trained.argtypes = [C.c_void_p, _f32p, _f32p, _f32p]
         L.go_ivfpq_table.restype = _f32p
         L.go_ivfpq_table.argtypes = [C.c_void_p]
+        L.go_set_precomputed_table_max_bytes.restype = None
+        L.go_set_precomputed_table_max_bytes.argtypes = [C.c_size_t]
+        L.go_get_precomputed_table_max_bytes.restype = C.c_size_t
+        L.go_ivfpq_use_precomputed_table.restype = C.c_int
+        L.go_ivfpq_use_precomputed_table.argtypes = [C.c_void_p]
         L.go_ivfpq_set_docids_bitmap.restype = None
         L.go_ivfpq_set_docids_bitmap.argtypes = [C.c_void_p, _u8p, C.c_int64]
         L.go_ivfpq_set_raw.restype = None
@@ -262,9 +267,15 @@ class OracleIVFPQ:
         t = _f32(table) if table is not None else None
         self.L.go_ivfpq_set_trained(self.h, _fp(cc), _fp(pq), _fp(t))
 
+    def use_precomputed_table(self):
+        """1 after set_trained unless the table would exceed precomputed_table_max_bytes (then 0: residual tables)."""
+        return self.L.go_ivfpq_use_precomputed_table(self.h)
+
     def table(self):
         n = self.nlist * self.M * self.ksub
         p = self.L.go_ivfpq_table(self.h)
+        if not p:   # table mode 0
+            return None
         return np.ctypeslib.as_array(p, shape=(n,)).reshape(self.nlist, self.M, self.ksub).copy()
 
     def set_docids_bitmap(self, bm):
@@ -484,6 +495,10 @@ def ref():
         R.ref_ivfpq_use_precomputed_table.restype = C.c_int
         R.ref_ivfpq_use_precomputed_table.argtypes = [C.c_void_p]
         R.ref_ivfpq_set_metric.argtypes = [C.c_void_p, C.c_int]
+        if hasattr(R, "ref_set_precomputed_table_max_bytes"):   # (a prebuilt oracle/_ref from before round 6 lacks it)
+            R.ref_set_precomputed_table_max_bytes.restype = None
+            R.ref_set_precomputed_table_max_bytes.argtypes = [C.c_size_t]
+            R.ref_get_precomputed_table_max_bytes.restype = C.c_size_t
         R.ref_ivfpq_get_coarse_centroids.argtypes = [C.c_void_p, _f32p]
         R.ref_ivfpq_get_pq_centroids.argtypes = [C.c_void_p, _f32p]
         R.ref_ivfpq_precomputed_table_size.restype = C.c_int64
@@ -547,6 +562,8 @@ class RefIVFPQ:
         n = self.R.ref_ivfpq_precomputed_table_size(self.h)
         out = np.empty(n, dtype=np.float32)
         self.R.ref_ivfpq_get_precomputed_table(self.h, _fp(out))
+        if n == 0:   # table mode 0: the library built none
+            return out
         return out.reshape(self.nlist, self.M, self.ksub)
 
     def get_list(self, l):

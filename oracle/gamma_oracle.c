@@ -752,25 +752,42 @@ void go_ivfpq_free(go_ivfpq* ix) {
     free(ix);
 }
 
+/* faiss's process-wide limit `precomputed_table_max_bytes` (faiss:IndexIVFPQ.cpp:379, 2 GiB): a table
+ * nlist * M * ksub * 4 bytes above it is NOT built and the index stays in table mode 0
+ * (faiss:IndexIVFPQ.cpp:441-449).  Settable like the library's extern so a test can reach the branch at a small shape. */
+static size_t g_precomputed_table_max_bytes = ((size_t)1) << 31;
+void go_set_precomputed_table_max_bytes(size_t bytes) { g_precomputed_table_max_bytes = bytes; }
+size_t go_get_precomputed_table_max_bytes(void) { return g_precomputed_table_max_bytes; }
+
 void go_ivfpq_set_trained(go_ivfpq* ix, const float* cc, const float* pqc, const float* table) {
     size_t ncc = (size_t)ix->nlist * ix->d, npq = (size_t)ix->M * ix->ksub * ix->dsub;
     size_t nt = (size_t)ix->nlist * ix->M * ix->ksub;
     free(ix->cc);
     free(ix->pqc);
     free(ix->table);
+    ix->table = NULL;
     ix->cc = (float*)malloc(ncc * sizeof(float));
     ix->pqc = (float*)malloc(npq * sizeof(float));
-    ix->table = (float*)malloc(nt * sizeof(float));
     memcpy(ix->cc, cc, ncc * sizeof(float));
     memcpy(ix->pqc, pqc, npq * sizeof(float));
+    /* train_residual_o -> precompute_table (faiss:IndexIVFPQ.cpp:132-135) and Load
+     * (gamma_index_ivfpq.cc:1033-1034) start from use_precomputed_table == 0 and let
+     * initialize_IVFPQ_precomputed_table choose (faiss:IndexIVFPQ.cpp:426-452; Gamma's quantizer is always an
+     * IndexFlatL2, gamma_index_ivfpq.cc:147, so the inner-product exit at :427-434 is never taken):
+     * table_size > precomputed_table_max_bytes -> no table, the mode stays 0; otherwise mode 1. */
+    if (nt * sizeof(float) > g_precomputed_table_max_bytes) {
+        ix->use_precomputed_table = 0;
+        return;
+    }
+    ix->table = (float*)malloc(nt * sizeof(float));
     if (table)
         memcpy(ix->table, table, nt * sizeof(float));
     else
         go_ivfpq_precompute_table(ix->cc, ix->nlist, ix->d, ix->pqc, ix->M, ix->ksub, ix->table);
-    /* train_residual_o -> precompute_table flips the mode to 1 for an L2 quantizer
-     * (faiss:IndexIVFPQ.cpp:132-135,426-452) */
     ix->use_precomputed_table = 1;
 }
+
+int go_ivfpq_use_precomputed_table(const go_ivfpq* ix) { return ix->use_precomputed_table; }
 
 const float* go_ivfpq_table(go_ivfpq* ix) { return ix->table; }
 

@@ -116,7 +116,12 @@ void go_ivfpq_free(go_ivfpq* ix);
 /* trained state: copies the arrays; computes the precomputed table when `table` is NULL */
 void go_ivfpq_set_trained(go_ivfpq* ix, const float* coarse_centroids, const float* pq_centroids,
                           const float* table);
-const float* go_ivfpq_table(go_ivfpq* ix);
+const float* go_ivfpq_table(go_ivfpq* ix); /* NULL in table mode 0 */
+/* faiss::precomputed_table_max_bytes (faiss:IndexIVFPQ.cpp:379): above it set_trained builds no table and the
+ * search scores with per-(query, list) residual tables (index/impl/gamma_index_ivfpq.h:239-245) */
+void go_set_precomputed_table_max_bytes(size_t bytes);
+size_t go_get_precomputed_table_max_bytes(void);
+int go_ivfpq_use_precomputed_table(const go_ivfpq* ix);
 /* delete bitmap the list writer consults (AddKeys, CompactBucket); borrowed pointer */
 void go_ivfpq_set_docids_bitmap(go_ivfpq* ix, const uint8_t* bm, int64_t nbits);
 /* vid -> docid of multi-vector documents for the list writer's delete tests (realtime_mem_data.cc:102,294); borrowed */

@@ -170,6 +170,10 @@ void ref_ivfpq_train(void* h, int64_t n, const float* x) {
 void ref_ivfpq_add(void* h, int64_t n, const float* x) {
     ((RefIVFPQ*)h)->index->add(n, x);
 }
+// the library's process-wide limit above which no precomputed table is built and the index stays in table mode 0
+// (faiss:IndexIVFPQ.cpp:379,441-449); lowered by the tests to reach that branch at a small shape
+void ref_set_precomputed_table_max_bytes(size_t bytes) { faiss::precomputed_table_max_bytes = bytes; }
+size_t ref_get_precomputed_table_max_bytes() { return faiss::precomputed_table_max_bytes; }
 int ref_ivfpq_use_precomputed_table(void* h) {
     return ((RefIVFPQ*)h)->index->use_precomputed_table;
 }

@@ -111,7 +111,22 @@ def gen_reservoir(R):
     np.savez_compressed(os.path.join(OUT, "reservoir_ties.npz"), **out)
 
 
-def gen_ivfpq(R, name, d, nlist, M, N, nq, metric, nprobe, Rk, normalize=False):
+def gen_ivfpq(R, name, d, nlist, M, N, nq, metric, nprobe, Rk, normalize=False, table_max_bytes=None):
+    """table_max_bytes: the library's extern faiss::precomputed_table_max_bytes lowered for this index (restored
+    afterwards) -- below nlist * M * 1 KiB the trained index stays in table mode 0 (faiss:IndexIVFPQ.cpp:441-449) and
+    the L2 search scores with per-(query, list) residual tables (index/impl/gamma_index_ivfpq.h:239-245)."""
+    saved = None
+    if table_max_bytes is not None:
+        saved = R.ref_get_precomputed_table_max_bytes()
+        R.ref_set_precomputed_table_max_bytes(table_max_bytes)
+    try:
+        _gen_ivfpq(R, name, d, nlist, M, N, nq, metric, nprobe, Rk, normalize, table_max_bytes)
+    finally:
+        if saved is not None:
+            R.ref_set_precomputed_table_max_bytes(saved)
+
+
+def _gen_ivfpq(R, name, d, nlist, M, N, nq, metric, nprobe, Rk, normalize, table_max_bytes):
     base = synth.sift_like(N, d=d, seed=1234)
     q = synth.sift_like(nq, d=d, seed=4321)
     if normalize:
@@ -120,9 +135,11 @@ def gen_ivfpq(R, name, d, nlist, M, N, nq, metric, nprobe, Rk, normalize=False):
     r = B.RefIVFPQ(d, nlist, M, 8, metric)
     r.train(base[:min(N, nlist * 64)])
     r.add(base)
-    assert r.use_precomputed_table() == 1
+    mode = r.use_precomputed_table()
+    assert mode == (1 if table_max_bytes is None or nlist * M * 1024 <= table_max_bytes else 0)
     out = dict(d=d, nlist=nlist, M=M, N=N, nq=nq, metric=metric, nprobe=nprobe, R=Rk,
-               normalize=int(normalize), q=q,
+               normalize=int(normalize), q=q, table_mode=mode,
+               table_max_bytes=-1 if table_max_bytes is None else table_max_bytes,
                cc=r.coarse_centroids(), pq=r.pq_centroids(), table=r.precomputed_table())
     # base is regenerated from the portable generator (not stored): only its checksum
     out["base_sum"] = np.array([base.astype(np.float64).sum()])
@@ -145,6 +162,14 @@ def gen_ivfpq(R, name, d, nlist, M, N, nq, metric, nprobe, Rk, normalize=False):
         out["rdis_" + tag], out["rids_" + tag] = D, I
     r.set_metric(metric)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+
+
+def gen_mode0(R):
+    """L2 table mode 0: the table of each shape would be nlist * M KiB; the limit sits just below it."""
+    gen_ivfpq(R, "ivfpq_l2_mode0_d32", 32, 32, 8, 6000, 40, B.METRIC_L2, 6, 64, table_max_bytes=32 * 8 * 1024 - 1)    # dsub 4
+    gen_ivfpq(R, "ivfpq_l2_mode0_d64", 64, 32, 8, 6000, 40, B.METRIC_L2, 8, 100, table_max_bytes=1 << 16)             # dsub 8
+    gen_ivfpq(R, "ivfpq_l2_mode0_d96", 96, 16, 8, 4000, 30, B.METRIC_L2, 4, 50, table_max_bytes=0)                    # dsub 12
+    gen_ivfpq(R, "ivfpq_l2_mode0_d128m8", 128, 16, 8, 4000, 30, B.METRIC_L2, 4, 50, table_max_bytes=4096)             # dsub 16: the AVX fvec_L2sqr row
 
 
 def gen_ivfpq_ties(R, name, d, nlist, M, N0, N, nq, nprobe, Rk, k):
@@ -427,6 +452,11 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "blas":      # the library's default BLAS coarse path at the C3 shape
         gen_blas_coarse(B.ref())
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "mode0":     # table mode 0 (no precomputed table): the library's limit lowered
+        R = B.ref()
+        R.ref_set_blas_threshold(1 << 30)
+        gen_mode0(R)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "ties":
         R = B.ref()
         R.ref_set_blas_threshold(1 << 30)
@@ -448,6 +478,7 @@ def main():
     gen_ivfpq(R, "ivfpq_l2_d32", 32, 32, 8, 6000, 40, B.METRIC_L2, 6, 64)        # dsub 4
     gen_ivfpq(R, "ivfpq_l2_d64", 64, 32, 8, 6000, 40, B.METRIC_L2, 8, 100)       # dsub 8
     gen_ivfpq(R, "ivfpq_ip_d48", 48, 16, 4, 4000, 30, B.METRIC_IP, 4, 50, True)  # dsub 12
+    gen_mode0(R)
     gen_ivfpq_ties(R, "ivfpq_ties_d32", 32, 16, 8, 1500, 6000, 48, 6, 60, 10)
     gen_ivfpq_ties(R, "ivfpq_ties_c4shape", 32, 4160, 8, 12000, 24000, 32, 64, 100, 10)
     gen_realtime()

@@ -122,6 +122,57 @@ def test_ivfpq_pipeline(name):
         assert np.array_equal(I, z["rids_" + tag][:, :5])
 
 
+@pytest.mark.parametrize("name", ["ivfpq_l2_mode0_d32", "ivfpq_l2_mode0_d64", "ivfpq_l2_mode0_d96", "ivfpq_l2_mode0_d128m8"])
+def test_ivfpq_table_mode_0_pipeline(name):
+    """L2 table mode 0 (faiss:IndexIVFPQ.cpp:441-449: the table would exceed precomputed_table_max_bytes, none is built;
+    index/impl/gamma_index_ivfpq.h:239-245: residual q - centroid, compute_distance_table on it, dis0 = 0).  The fixtures
+    come from the compiled library with its extern limit lowered (tests/gen_golden.py mode0)."""
+    z, base = load_ivfpq(name)
+    d, nlist, M = int(z["d"]), int(z["nlist"]), int(z["M"])
+    nprobe, R = int(z["nprobe"]), int(z["R"])
+    assert int(z["table_mode"]) == 0 and z["table"].size == 0
+    L = B.lib()
+    saved = L.go_get_precomputed_table_max_bytes()
+    L.go_set_precomputed_table_max_bytes(int(z["table_max_bytes"]))
+    try:
+        o = B.OracleIVFPQ(d, nlist, M, 8, B.METRIC_L2)
+        o.set_trained(z["cc"], z["pq"], None)
+        assert o.use_precomputed_table() == 0 and o.table() is None
+        # one byte more and the table is built: the rule is `>` (faiss:IndexIVFPQ.cpp:442)
+        L.go_set_precomputed_table_max_bytes(nlist * M * 1024)
+        o1 = B.OracleIVFPQ(d, nlist, M, 8, B.METRIC_L2)
+        o1.set_trained(z["cc"], z["pq"], None)
+        assert o1.use_precomputed_table() == 1 and o1.table() is not None
+    finally:
+        L.go_set_precomputed_table_max_bytes(saved)
+    L.go_set_assign_mode(0)
+    assert o.add(base)
+    off = 0
+    for l in range(nlist):
+        n = int(z["list_sizes"][l])
+        ids, cds = o.get_list(l)
+        assert np.array_equal(ids, z["list_ids"][off:off + n])
+        assert np.array_equal(cds, z["list_codes"][off:off + n])
+        off += n
+    o.set_raw(base)
+    ctx = B.make_ctx(min_score=-3e38, max_score=3e38)
+    differs_from_mode1 = 0
+    for m, tag in ((B.METRIC_L2, "l2"), (B.METRIC_IP, "ip")):
+        D, I, st = o.search(z["q"], 5, nprobe, recall_num=R, has_rank=False, metric=m, ctx=ctx,
+                            coarse_mode=0, want_stages=True)
+        assert np.array_equal(st["coarse_idx"], z["coarse_idx"])
+        assert st["recall_dis"].tobytes() == z["rdis_" + tag].tobytes()
+        assert np.array_equal(st["recall_ids"], z["rids_" + tag])
+        assert D.tobytes() == z["rdis_" + tag][:, :5].tobytes() and np.array_equal(I, z["rids_" + tag][:, :5])
+        if m == B.METRIC_L2:   # the branch is not a no-op: table mode 1 rounds differently
+            o1.add(base)
+            o1.set_raw(base)
+            _, _, st1 = o1.search(z["q"], 5, nprobe, recall_num=R, has_rank=False, metric=m, ctx=ctx,
+                                  coarse_mode=0, want_stages=True)
+            differs_from_mode1 = int((st1["recall_dis"].view(np.uint32) != st["recall_dis"].view(np.uint32)).sum())
+    assert differs_from_mode1 > 0
+
+
 def test_gemm_form_coarse_agrees_with_exact():
     """The 'BLAS form' coarse distances (restated GEMM) differ from the exact ones only by
     rounding: same probe sets except near-ties, distances within 1e-4 relative."""

@@ -86,6 +86,45 @@ def test_ivfpq_end_to_end(cfg):
     R.ref_set_blas_threshold(20)
 
 
+@pytest.mark.parametrize("cfg", [(32, 48, 8, 9000, 40, 8, 100), (128, 32, 16, 8000, 32, 16, 200), (96, 24, 8, 6000, 24, 6, 80),
+                                 (64, 32, 32, 8000, 30, 8, 60), (48, 16, 2, 4000, 20, 4, 50)])
+def test_ivfpq_table_mode_0_end_to_end(cfg):
+    """Live: faiss::precomputed_table_max_bytes lowered below the index's table -> the compiled library trains into table
+    mode 0 (faiss:IndexIVFPQ.cpp:441-449) and scores with residual tables; the oracle under the same limit agrees bit for
+    bit (dsub 4, 8, 12, 2 and the generic AVX row at dsub 24)."""
+    d, nlist, M, N, nq, nprobe, Rk = cfg
+    R = B.ref()
+    L = B.lib()
+    R.ref_set_blas_threshold(1 << 30)
+    L.go_set_assign_mode(0)
+    saved_r, saved_o = R.ref_get_precomputed_table_max_bytes(), L.go_get_precomputed_table_max_bytes()
+    limit = nlist * M * 1024 - 1
+    R.ref_set_precomputed_table_max_bytes(limit)
+    L.go_set_precomputed_table_max_bytes(limit)
+    try:
+        base = synth.sift_like(N, d=d, seed=177)
+        q = synth.sift_like(nq, d=d, seed=178)
+        r = B.RefIVFPQ(d, nlist, M, 8, B.METRIC_L2)
+        r.train(base[:nlist * 64])
+        r.add(base)
+        assert r.use_precomputed_table() == 0 and r.precomputed_table().size == 0
+        o = B.OracleIVFPQ(d, nlist, M, 8, B.METRIC_L2)
+        o.set_trained(r.coarse_centroids(), r.pq_centroids(), None)
+        assert o.use_precomputed_table() == 0 and o.table() is None
+        assert o.add(base)
+        o.set_raw(base)
+        ctx = B.make_ctx(min_score=-3e38, max_score=3e38)
+        Dr, Ir = r.search(q, Rk, nprobe)
+        _, _, st = o.search(q, 10, nprobe, recall_num=Rk, has_rank=False, metric=B.METRIC_L2, ctx=ctx,
+                            coarse_mode=0, want_stages=True)
+        assert st["recall_dis"].tobytes() == Dr.tobytes()
+        assert np.array_equal(st["recall_ids"], Ir)
+    finally:
+        R.ref_set_precomputed_table_max_bytes(saved_r)
+        L.go_set_precomputed_table_max_bytes(saved_o)
+        R.ref_set_blas_threshold(20)
+
+
 @pytest.mark.parametrize("kind", ["sift", "gauss"])
 def test_gemm_form_is_the_compiled_sgemm(kind):
     """With faiss's default threshold (nq >= 20) the coarse distances come from exhaustive_L2sqr_blas: norms + MKL's
