@@ -81,6 +81,9 @@ SYMBOLS = {
     "gamma_hip_ivfpq_init": (C.c_int, [C.c_void_p] + [C.c_int] * 7),
     "gamma_hip_ivfpq_set_trained": (C.c_int, [C.c_void_p, f32p, f32p, f32p]),
     "gamma_hip_ivfpq_get_precomputed_table": (C.c_int, [C.c_void_p, f32p]),
+    "gamma_hip_set_precomputed_table_max_bytes": (C.c_int, [C.c_int64]),
+    "gamma_hip_get_precomputed_table_max_bytes": (C.c_int64, []),
+    "gamma_hip_ivfpq_use_precomputed_table": (C.c_int, [C.c_void_p]),
     "gamma_hip_ivfpq_add_keys": (C.c_int, [C.c_void_p, C.c_int, C.c_int, i64p, u8p]),
     "gamma_hip_ivfpq_add_keys_batch": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p, i64p, u8p]),
     "gamma_hip_ivfpq_update": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, u8p]),

@@ -186,6 +186,14 @@ class GammaHip:
         self._ck(self.L.gamma_hip_ivfpq_set_trained(self.h, _p(cc, _lib.f32p), _p(pq, _lib.f32p),
                                                     _p(t, _lib.f32p)), "ivfpq_set_trained")
 
+    def use_precomputed_table(self):
+        """L2 table mode of the initialised index: 1 = precomputed table resident, 0 = it would exceed
+        precomputed_table_max_bytes and searches score with residual tables (include/gamma_hip.h)."""
+        m = self.L.gamma_hip_ivfpq_use_precomputed_table(self.h)
+        if m < 0:
+            self._ck(m, "use_precomputed_table")
+        return m
+
     def ivfpq_table(self):
         out = np.empty((self.nlist, self.M, 256), dtype=np.float32)
         self._ck(self.L.gamma_hip_ivfpq_get_precomputed_table(self.h, _p(out, _lib.f32p)), "get_table")
@@ -658,6 +666,17 @@ class GammaHipGroup:
 
     def total_mem_bytes(self):
         return self.L.gamma_hip_group_total_mem_bytes(self.g)
+
+
+def set_precomputed_table_max_bytes(nbytes):
+    """Process-wide, like faiss::precomputed_table_max_bytes (faiss:IndexIVFPQ.cpp:379); read by ivfpq_init."""
+    rc = _lib.load().gamma_hip_set_precomputed_table_max_bytes(int(nbytes))
+    if rc != 0:
+        raise ValueError("precomputed_table_max_bytes must be >= 0")
+
+
+def get_precomputed_table_max_bytes():
+    return int(_lib.load().gamma_hip_get_precomputed_table_max_bytes())
 
 
 def train_ivfpq(x, nlist, M, device=0):

@@ -280,7 +280,7 @@ int64_t gamma_hip_total_mem_bytes(gamma_hip_index* h) {
     for (auto& kv : h->terms) b += kv.second.cap_docs * 8 + kv.second.cap_tok * 4;
     if (h->ivf_init) {
         b += (int64_t)h->nlist * h->d * 4 + (int64_t)h->nlist * 4 + (int64_t)h->M * 256 * h->dsub * 4;
-        b += (int64_t)h->nlist * h->M * 256 * 4;
+        if (h->d_T2) b += h->ivfflat ? 256 : (int64_t)h->nlist * h->M * 256 * 4;
         b += h->arena_cap * (h->code_size + (int64_t)sizeof(int64_t));
         if (h->d_sums) b += h->arena_cap * (int64_t)sizeof(float) + (int64_t)h->nlist * 4;
         b += (int64_t)h->nlist * 12;

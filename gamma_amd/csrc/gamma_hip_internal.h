@@ -225,6 +225,12 @@ struct gamma_hip_index {
     // indexes (the inner-product scan has no per-list table to avoid).
     float* d_sums = nullptr;
     float* d_t2max = nullptr;
+    // L2 table mode (faiss::IndexIVFPQ::use_precomputed_table after train / Load): 1 = the precomputed table T2 is resident,
+    // 0 = it would exceed precomputed_table_max_bytes (faiss:IndexIVFPQ.cpp:441-449) -- none is built, L2 searches score with
+    // per-(query, list) residual tables (gamma_index_ivfpq.h:239-245).  Decided by Init from nlist * M and the limit.
+    int table_mode = 1;
+    // what the scan launcher takes as (st2, T2): mode 0 -> (the PQ codebook, nullptr), see scan.hip RES
+    const float* scan_st2(bool l2) const { return (l2 && table_mode == 0) ? d_pqc : w_st2.as<float>(); }
     bool keep_sums = false;   // set by Init: IVFPQ handles (GAMMA_HIP_NO_CODE_SUMS=1 turns the filter pass off)
     // list shard over a supplied assignment (gamma_hip_ivfpq_search_shard_preassigned): the longest candidate row of the
     // call, measured on the device -- the slab stride of its chunks (0: nprobe x the longest list)

@@ -370,7 +370,10 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
             }
         }
     }
-    const bool fuse_ip = bounded && PGN == 1 && (M == 16 || M == 32) && !getenv("GAMMA_HIP_NO_FUSED_IP");
+    // L2 table mode 0 (no precomputed table, H::table_mode): per-list tables from the residual (scan.hip RES) -- the plain and
+    // the bounded loop; no query table, none of the passes built on T2 sums (d_sums is null: cf / c8 / q8 are off by their own gates)
+    const bool res = l2 && h->table_mode == 0;
+    const bool fuse_ip = bounded && !res && PGN == 1 && (M == 16 || M == 32) && !getenv("GAMMA_HIP_NO_FUSED_IP");
     // the bounded scan's per-call state (repair list, ready words, survivor counts) is sized here, before the pair offsets,
     // whose kernel clears it together with the tie flags -- one launch instead of four fills in front of the scan
     // (byte-table filter pass: a first group of a few probes bounds loosely for some queries -- slices of 2048 keep them out of the
@@ -444,7 +447,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     }
     {
         StageScope t(h, GAMMA_HIP_STAGE_TABLES);
-        if (!fuse_ip) {
+        if (!fuse_ip && !res) {
             GH_CHECK(h, h->w_st2.ensure((size_t)nq * M * 256 * sizeof(float)));
             gh::launch_pq_ip_table(s, d_x, nq, d, M, h->d_pqc, h->w_st2.as<float>());
         }
@@ -514,7 +517,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     auto scan = [&](int gsz, int pg_lo, int pg_cnt, const gh::ScanBound* bound, bool count) {
         StageScope t(h, GAMMA_HIP_STAGE_SCAN, count);
         gh::launch_ivfpq_scan_pair(s, l2, d_x, nq, d, M, P, h->w_probe.as<int>(),
-                                   dis0, h->d_cc, h->w_st2.as<float>(), h->d_T2,
+                                   dis0, h->d_cc, h->scan_st2(l2), h->d_T2,
                                    h->d_list_off, h->d_list_len, h->d_list_mask, nlist, h->d_codes,
                                    h->d_ids, h->w_pair_off.as<int>(), q_stride, h->w_dist.as<float>(),
                                    fc.d_tab, fc.d_qf, need_ids, qperm, gsz, pg_lo, pg_cnt, shard ? 1 : 0, bound,
@@ -571,7 +574,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
             // producers (the first G probes: exact, they publish the bounds), then the other probes list-major over byte
             // tables -- all of it one "scan launch" for the stage clock and the roofline figure
             StageScope t(h, GAMMA_HIP_STAGE_SCAN, true);
-            gh::launch_ivfpq_scan_pair(s, l2, d_x, nq, d, M, P, h->w_probe.as<int>(), dis0, h->d_cc, h->w_st2.as<float>(), h->d_T2,
+            gh::launch_ivfpq_scan_pair(s, l2, d_x, nq, d, M, P, h->w_probe.as<int>(), dis0, h->d_cc, h->scan_st2(l2), h->d_T2,
                                        h->d_list_off, h->d_list_len, h->d_list_mask, nlist, h->d_codes, h->d_ids,
                                        h->w_pair_off.as<int>(), q_stride, h->w_dist.as<float>(), fc.d_tab, fc.d_qf, need_ids, qperm, G, 0,
                                        1, 0, &sb, nullptr);
@@ -637,7 +640,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
             StageScope t2(h, GAMMA_HIP_STAGE_SCAN, false);
             if (sb.prod_cf) gh::launch_rq_nobound(s, sb.ready, nq, sb.rq_list, sb.rq_count);
             gh::launch_ivfpq_scan_pair(s, l2, d_x, nq, d, M, P, h->w_probe.as<int>(), dis0, h->d_cc,
-                                       h->w_st2.as<float>(), h->d_T2, h->d_list_off, h->d_list_len, h->d_list_mask,
+                                       h->scan_st2(l2), h->d_T2, h->d_list_off, h->d_list_len, h->d_list_mask,
                                        nlist, h->d_codes, h->d_ids, h->w_pair_off.as<int>(), q_stride,
                                        h->w_dist.as<float>(), fc.d_tab, fc.d_qf, need_ids, nullptr, G, sb.prod_cf ? 0 : 1,
                                        sb.prod_cf ? PGN : PGN - 1, shard ? 1 : 0, nullptr, nullptr, sb.rq_list, sb.rq_count);
@@ -748,7 +751,7 @@ int ivfpq_stage_b(H* h, const gamma_hip_search_params* p, int nq, const float* d
             // replay walks the reference's -- re-scored here, on the search stream, in front of the replay (the tables and the
             // assignment of this call are still in place)
             gh::launch_ivfpq_scan_pair(s, l2, d_x, nq, h->d, h->M, p->nprobe, h->w_probe.as<int>(), h->tie.dis0, h->d_cc,
-                                       h->w_st2.as<float>(), h->d_T2, h->d_list_off, h->d_list_len, h->d_list_mask, h->nlist,
+                                       h->scan_st2(l2), h->d_T2, h->d_list_off, h->d_list_len, h->d_list_mask, h->nlist,
                                        h->d_codes, h->d_ids, h->w_pair_off.as<int>(), h->tie.q_stride, h->w_dist.as<float>(),
                                        static_cast<const gh::FilterDesc*>(h->tie.d_ftab), h->tie.d_qf, h->tie.need_ids, nullptr,
                                        h->tie.G, 0, 1, 0, nullptr, nullptr, tf.list, tf.count);
@@ -881,7 +884,7 @@ int ivfpq_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int n
     const int need_ids = (!h->prefiltered && (fc.any_clause || (h->d_bitmap && h->bitmap_any) || h->n_moved > 0)) ? 1 : 0;
     gh::launch_ivfpq_scan_pair(s, l2, d_x, nq, d, M, P, h->w_probe.as<int>(),
                                l2 ? h->w_coarse_dis.as<float>() : h->w_pair_ip.as<float>(), h->d_cc,
-                               h->w_st2.as<float>(), h->d_T2, h->d_list_off, h->d_list_len, h->d_list_mask, nlist,
+                               h->scan_st2(l2), h->d_T2, h->d_list_off, h->d_list_len, h->d_list_mask, nlist,
                                h->d_codes, h->d_ids, h->w_pair_off.as<int>(), q_stride, h->w_dist.as<float>(), fc.d_tab,
                                fc.d_qf, need_ids, nullptr, 1, 0, P, 0, nullptr, nullptr, reinterpret_cast<const int*>(d_units), d_nunits,
                                chunk_len, max_units);

@@ -925,12 +925,29 @@ int gamma_hip_ivfpq_init(gamma_hip_index* h, int d, int nlist, int M, int nbits,
     return ivf_init_locked(h, d, nlist, M, metric, bucket_init_size, bucket_max_size, false);
 }
 
+// faiss::precomputed_table_max_bytes (faiss:IndexIVFPQ.cpp:379): process-wide like the library's extern
+static std::atomic<int64_t> g_table_max_bytes{(int64_t)1 << 31};
+int gamma_hip_set_precomputed_table_max_bytes(int64_t bytes) {
+    if (bytes < 0) return GAMMA_HIP_EINVAL;
+    g_table_max_bytes.store(bytes);
+    return GAMMA_HIP_OK;
+}
+int64_t gamma_hip_get_precomputed_table_max_bytes(void) { return g_table_max_bytes.load(); }
+int gamma_hip_ivfpq_use_precomputed_table(gamma_hip_index* h) {
+    if (!h || !h->ivf_init || h->ivfflat) return GAMMA_HIP_EINVAL;
+    return h->table_mode;
+}
+
 static int ivf_init_locked(gamma_hip_index* h, int d, int nlist, int M, int metric, int bucket_init_size,
                            int bucket_max_size, bool flat) {
     if (metric != GAMMA_HIP_METRIC_IP && metric != GAMMA_HIP_METRIC_L2) return fail(h, GAMMA_HIP_EINVAL, "bad metric");
     GH_CHECK(h, hipSetDevice(h->device));
     h->ivfflat = flat;
-    h->keep_sums = !flat && getenv("GAMMA_HIP_NO_CODE_SUMS") == nullptr;
+    // initialize_IVFPQ_precomputed_table's rule (faiss:IndexIVFPQ.cpp:441-449): `table_size > max` keeps mode 0.  faiss
+    // applies it at train / Load; the outcome depends on nlist, M and the process-wide limit only, so it is fixed here,
+    // where the arena decides whether it keeps the per-code table sums (they are sums of T2 entries: none in mode 0).
+    h->table_mode = (!flat && (int64_t)nlist * M * 256 * (int64_t)sizeof(float) > g_table_max_bytes.load()) ? 0 : 1;
+    h->keep_sums = !flat && h->table_mode == 1 && getenv("GAMMA_HIP_NO_CODE_SUMS") == nullptr;
     h->d = d;
     h->nlist = nlist;
     h->M = M;
@@ -942,7 +959,7 @@ static int ivf_init_locked(gamma_hip_index* h, int d, int nlist, int M, int metr
     GH_CHECK(h, hipMalloc((void**)&h->d_cc, (size_t)nlist * d * sizeof(float)));
     GH_CHECK(h, hipMalloc((void**)&h->d_cc_norms, (size_t)nlist * sizeof(float)));
     GH_CHECK(h, hipMalloc((void**)&h->d_pqc, flat ? 256 : (size_t)M * 256 * h->dsub * sizeof(float)));
-    GH_CHECK(h, hipMalloc((void**)&h->d_T2, flat ? 256 : (size_t)nlist * M * 256 * sizeof(float)));
+    if (flat || h->table_mode == 1) GH_CHECK(h, hipMalloc((void**)&h->d_T2, flat ? 256 : (size_t)nlist * M * 256 * sizeof(float)));
     for (int v = 0; v < H::NVER; v++) {
         GH_CHECK(h, hipMalloc((void**)&h->d_ver_off[v], (size_t)nlist * sizeof(int64_t)));
         GH_CHECK(h, hipMalloc((void**)&h->d_ver_len[v], (size_t)nlist * sizeof(int)));
@@ -998,7 +1015,9 @@ int gamma_hip_ivfpq_set_trained(gamma_hip_index* h, const float* cc, const float
     GH_CHECK(h, hipMemcpyAsync(h->d_cc, cc, ncc * sizeof(float), hipMemcpyHostToDevice, h->wstream));
     GH_CHECK(h, hipMemcpyAsync(h->d_pqc, pqc, npq * sizeof(float), hipMemcpyHostToDevice, h->wstream));
     gh::launch_row_norms(h->wstream, h->d_cc, h->nlist, h->d, h->d_cc_norms);
-    if (table)
+    if (h->table_mode == 0) {
+        // no table (a supplied one is not taken either: the reference would not have built it)
+    } else if (table)
         GH_CHECK(h, hipMemcpyAsync(h->d_T2, table, nt * sizeof(float), hipMemcpyHostToDevice, h->wstream));
     else
         gh::launch_precompute_table(h->wstream, h->d_cc, h->nlist, h->d, h->M, h->d_pqc, h->d_T2);
@@ -1027,6 +1046,7 @@ int gamma_hip_ivfpq_get_precomputed_table(gamma_hip_index* h, float* out) {
     if (!h || !out) return GAMMA_HIP_EINVAL;
     WriteLock lk(h);
     if (!h->trained) return fail(h, GAMMA_HIP_ENOTTRAINED, "not trained");
+    if (h->table_mode == 0) return fail(h, GAMMA_HIP_EUNSUPPORTED, "table mode 0: no precomputed table (it would exceed precomputed_table_max_bytes)");
     GH_CHECK(h, hipSetDevice(h->device));
     GH_CHECK(h, hipMemcpyAsync(out, h->d_T2, (size_t)h->nlist * h->M * 256 * sizeof(float),
                                hipMemcpyDeviceToHost, h->wstream));

@@ -60,7 +60,11 @@ constexpr int C8_CAND = 1536;      // byte-table pass: its candidates sit in the
 // PCF (with CF): the producer runs on the filter pass's arithmetic too (ScanBound::prod_cf) -- a variant of its own: the extra
 // path costs the plain filter-pass kernel 16 VGPRs (73 -> 89: six -> five waves per SIMD) even when it is not taken
 // C8 (with CF): the filter pass gathers BYTES (ScanBound::c8; "byte table" in the body).
-template <bool L2, int MT, bool FILT, bool IPF, bool UNITS, bool CF, bool PCF, bool C8 = false>
+// RES (L2 table mode 0, round 6): the index has NO precomputed table -- it would exceed faiss's precomputed_table_max_bytes
+// (faiss:IndexIVFPQ.cpp:441-449) -- and the reference scores every (query, list) pair with the distance table of the RESIDUAL:
+// r = x_q - centroid_l, lut[m][j] = fvec_L2sqr_ny(r_m, c_mj), dis0 = 0 (index/impl/gamma_index_ivfpq.h:239-245).  Here `st2`
+// points at the PQ codebook and `T2` is null; the residual sits in LDS behind the staging words.
+template <bool L2, int MT, bool FILT, bool IPF, bool UNITS, bool CF, bool PCF, bool C8 = false, bool RES = false>
 __device__ __forceinline__ void scan_pair_body(
 
         const float* __restrict__ x, int nq, int d, int M, int P, int G, const int* __restrict__ probe_list,
@@ -154,6 +158,8 @@ __device__ __forceinline__ void scan_pair_body(
     uint32_t* s_red = reinterpret_cast<uint32_t*>(s_stage + SCAN_STAGE) + 2;                  // [12]
     int& s_ncand = *(reinterpret_cast<int*>(s_stage + SCAN_STAGE) + 14);                       // CF: staged candidates
     uint2* s_cand = reinterpret_cast<uint2*>(reinterpret_cast<int*>(s_stage + SCAN_STAGE) + 16);  // CF: [SCAN_CF_CAP]
+    float* s_res = reinterpret_cast<float*>(reinterpret_cast<int*>(s_stage + SCAN_STAGE) + 16);   // RES (never with CF): [d]
+    static_assert(!RES || (L2 && !CF && !IPF && !PCF && !C8), "residual tables: the plain L2 loop only");
     int cbase = 0;     // unit mode: first code of the unit within its list
     int lut_q = -1;    // unit mode, inner product: the query whose table is in LDS
     int lut_pair = -1; // unit mode, L2: the (query, probe) pair whose table is in LDS
@@ -233,6 +239,8 @@ __device__ __forceinline__ void scan_pair_body(
         for (int i = 0; i < MT; i++) s2r[i] = fvec_ny_row<false>(xq + i * dsub, st2 + ((int64_t)i * 256 + tid) * dsub, dsub);
     } else if (C8 && pg > 0) {
         // byte table: wave w reads table rows w, w + 4, .. (four code words per lane), see below; s2r is loaded later
+    } else if (RES) {
+        // no query table: the per-list table comes from the residual and the codebook
     } else if (MT > 0 && (!UNITS || (L2 ? q * P + pg != lut_pair : q != lut_q))) {
 #pragma unroll
         for (int i = 0; i < MT; i++) s2r[i] = st2q[tid + 256 * i];
@@ -679,7 +687,23 @@ __device__ __forceinline__ void scan_pair_body(
             if (UNITS) lut_pair = pair;
             __syncthreads();   // the previous list's gathers are finished
             const float* t2 = T2 + (int64_t)l * msz;
-            if (MT > 0) {
+            if constexpr (RES) {
+                // compute_residual (faiss:Index.cpp:95-102: x - reconstruct(key)) + ProductQuantizer::compute_distance_table
+                // (faiss:impl/ProductQuantizer.cpp:505-516: one fvec_L2sqr_ny row per sub-quantizer)
+                const int dsub = d / M;
+                const float* xq = x + (int64_t)q * d;
+                const float* cl = cc + (int64_t)l * d;
+                for (int t = tid; t < d; t += 256) s_res[t] = xq[t] - cl[t];
+                __syncthreads();
+                if (MT > 0) {
+                    lut_store_begin(lut_m0);
+                    lut_store_rows<MT>([&](int i) { return fvec_ny_row<true>(s_res + i * dsub, st2 + ((int64_t)i * 256 + tid) * dsub, dsub); },
+                                       std::make_integer_sequence<int, (MT > 0 ? MT : 1)>{});
+                    lut_store_done();
+                } else {
+                    for (int e = tid; e < msz; e += 256) s_lut[e] = fvec_ny_row<true>(s_res + (e >> 8) * dsub, st2 + (int64_t)e * dsub, dsub);
+                }
+            } else if (MT > 0) {
                 float tv[MT > 0 ? MT : 1];
 #pragma unroll
                 for (int i = 0; i < MT; i++) tv[i] = t2[tid + 256 * i];   // MT loads in flight
@@ -696,7 +720,7 @@ __device__ __forceinline__ void scan_pair_body(
         if (FILT && pg == 0) GH_ST_ADD(2, t_l0, t_l1);
         // L2: the coarse distance; IP: <x_q, centroid_l>, computed per pair by k_pair_ip (a chain of d/8
         // dependent fmas per AVX lane has no place inside this loop)
-        const float dis0 = coarse_dis[pair];
+        const float dis0 = RES ? 0.f : coarse_dis[pair];   // (table mode 0: `float dis0 = 0`, gamma_index_ivfpq.h:236)
         const int64_t* lid = ids + off;
         const int pbase = pair_off[(int64_t)q * (P + 1) + p] + (UNITS ? cbase : 0);
         float* o = out + (int64_t)q * q_stride + pbase;
@@ -1057,6 +1081,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_iv
         const int* __restrict__ rq_list, const int* __restrict__ rq_count, int chunk_len) {
     scan_pair_body<L2, MT, FILT, IPF, UNITS, CF, false>(x, nq, d, M, P, G, probe_list, coarse_dis, cc, st2, T2, list_off, list_len, list_mask, nlist, codes, ids, pair_off, q_stride, out, ftab, qfil, need_ids, sentinel, qperm, pg_lo, pg_cnt, sparse, sb, rq_list, rq_count, chunk_len);
 }
+// L2 table mode 0: per-list tables from the residual (RES in the body)
+template <int MT, bool FILT, bool UNITS>
+__global__ __launch_bounds__(256) void k_ivfpq_scan_pair_res(
+
+        const float* __restrict__ x, int nq, int d, int M, int P, int G, const int* __restrict__ probe_list,
+        const float* __restrict__ coarse_dis, const float* __restrict__ cc,
+        const float* __restrict__ pqc, const float* __restrict__ T2,
+        const int64_t* __restrict__ list_off, const int* __restrict__ list_len,
+        const uint8_t* __restrict__ list_mask, int nlist, const uint8_t* __restrict__ codes,
+        const int64_t* __restrict__ ids, const int* __restrict__ pair_off, int64_t q_stride,
+        float* __restrict__ out, const FilterDesc* __restrict__ ftab, const int* __restrict__ qfil, int need_ids,
+        float sentinel, const int* __restrict__ qperm, int pg_lo, int pg_cnt, int sparse, ScanBound sb,
+        const int* __restrict__ rq_list, const int* __restrict__ rq_count, int chunk_len) {
+    scan_pair_body<true, MT, FILT, false, UNITS, false, false, false, true>(x, nq, d, M, P, G, probe_list, coarse_dis, cc, pqc, T2, list_off, list_len, list_mask, nlist, codes, ids, pair_off, q_stride, out, ftab, qfil, need_ids, sentinel, qperm, pg_lo, pg_cnt, sparse, sb, rq_list, rq_count, chunk_len);
+}
+
 // filter pass + the producer on its arithmetic (ScanBound::prod_cf): held to six waves per SIMD like the plain filter-pass kernel
 template <int MT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96), amdgpu_waves_per_eu(6, 8))) void k_ivfpq_scan_pair_pcf(
@@ -1160,6 +1200,12 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
         launch_refused("launch_ivfpq_scan_pair: unit mode with a bound, a fused table, grouped probes or no work list");
         return;
     }
+    // L2 table mode 0 (no precomputed table on the handle): `st2` is the PQ codebook, the per-list tables come from the residual
+    const bool res = l2 && T2 == nullptr;
+    if (res && (pqc_fused || (bound && bound->sums))) {
+        launch_refused("launch_ivfpq_scan_pair: table mode 0 takes neither fused query tables nor the filter pass");
+        return;
+    }
     if (pqc_fused) {   // the table is computed inside the kernel (IPF): one workgroup per query, M 16 / 32
         if (!bound || pg_cnt != 1 || (M != 16 && M != 32)) {
             launch_refused("launch_ivfpq_scan_pair: fused query tables need a bound, one group per query and M 16 / 32");
@@ -1169,6 +1215,7 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
     }
     // LUT | survivor staging | a few words (see the kernel)
     size_t lds = (size_t)M * 256 * sizeof(float) + SCAN_STAGE * sizeof(unsigned long long) + 16 * sizeof(int);
+    if (res) lds += (size_t)d * sizeof(float);   // the residual
     dim3 grid((unsigned)(8 * (int64_t)((nq + 7) / 8) * pg_cnt));
     if (bound) {   // P(0) | P(t+1) C(t) ...: whole batches, see the kernel
         const int SB = bound->batch > 0 ? bound->batch : SCAN_BATCH;
@@ -1210,7 +1257,34 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
         else if (M == 48) GH_SCAN(LL, 48, FF);  \
         else GH_SCAN(LL, 0, FF);                \
     } while (0)
-    if (chunk_len > 0) {
+#define GH_SCAN_RES(FF, UU)                                                                                                  \
+    do {                                                                                                                    \
+        if (M == 16) GH_SCAN_RES1(16, FF, UU);                                                                              \
+        else if (M == 32) GH_SCAN_RES1(32, FF, UU);                                                                         \
+        else if (M == 64) GH_SCAN_RES1(64, FF, UU);                                                                         \
+        else if (M == 8) GH_SCAN_RES1(8, FF, UU);                                                                           \
+        else GH_SCAN_RES1(0, FF, UU);                                                                                       \
+    } while (0)
+#define GH_SCAN_RES1(MT, FF, UU)                                                                                            \
+    hipLaunchKernelGGL((k_ivfpq_scan_pair_res<MT, FF, UU>), grid, dim3(256), lds, s, x, nq, d, M, P, G, probe_list, coarse_dis, \
+                       cc, st2, T2, list_off, list_len, list_mask, nlist, codes, ids, pair_off, q_stride, out, ftab, qfil,      \
+                       need_ids, INFINITY, qperm, pg_lo, pg_cnt, sparse, sb, rq_list, rq_count, chunk_len)
+    if (res) {
+        if (lds > (64u << 10)) {   // M = 64: 64 KB of table + the staging words
+            static std::atomic<uint64_t> attr{0};
+            if (first_call_on_device(attr)) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ivfpq_scan_pair_res<64, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ivfpq_scan_pair_res<64, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ivfpq_scan_pair_res<64, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ivfpq_scan_pair_res<0, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ivfpq_scan_pair_res<0, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ivfpq_scan_pair_res<0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+            }
+        }
+        if (chunk_len > 0) GH_SCAN_RES(false, true);
+        else if (bound) GH_SCAN_RES(true, false);
+        else GH_SCAN_RES(false, false);
+    } else if (chunk_len > 0) {
 #define GH_SCAN_U(LL)                                           \
     do {                                                        \
         if (M == 16) GH_SCAN5(LL, 16, false, false, true);      \
@@ -1253,6 +1327,8 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
         else GH_SCAN_M(false, false);
     }
 #undef GH_SCAN_M
+#undef GH_SCAN_RES
+#undef GH_SCAN_RES1
 #undef GH_SCAN
 #undef GH_SCAN4
 #undef GH_SCAN5

@@ -188,6 +188,10 @@ int GammaIVFPQHIPIndex::Init(const std::string &model_parameters, int indexing_s
     HLOG("device init failed: %s (%s)", gamma_hip_strerror(rc), gamma_hip_last_error(h_));
     return -1;
   }
+  // what IndexIVFPQ::precompute_table prints in verbose mode (faiss:IndexIVFPQ.cpp:443-448): never silent
+  if (gamma_hip_ivfpq_use_precomputed_table(h_) == 0)
+    HLOG("not precomputing table, it would be too big: %lld bytes (max %lld) -- L2 searches score with residual tables "
+         "(use_precomputed_table = 0)", (long long)nlist_ * M_ * 1024, (long long)gamma_hip_get_precomputed_table_max_bytes());
   return 0;
 }
 

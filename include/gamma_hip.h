@@ -240,6 +240,17 @@ int gamma_hip_ivfpq_init(gamma_hip_index* h, int d, int nlist, int M, int nbits,
 int gamma_hip_ivfpq_set_trained(gamma_hip_index* h, const float* coarse_centroids,
                                 const float* pq_centroids, const float* precomputed_table);
 int gamma_hip_ivfpq_get_precomputed_table(gamma_hip_index* h, float* out);
+/* L2 table mode (faiss::IndexIVFPQ::use_precomputed_table as train / Load leave it, faiss:IndexIVFPQ.cpp:132-135,
+ * index/impl/gamma_index_ivfpq.cc:1033-1034).  Replaces the extern `faiss::precomputed_table_max_bytes`
+ * (faiss:IndexIVFPQ.cpp:379, 2 GiB; process-wide here too): an index whose table nlist * nsubvector * 1 KiB would be
+ * LARGER keeps mode 0 (faiss:IndexIVFPQ.cpp:441-449) -- no table is built or held, gamma_hip_ivfpq_get_precomputed_table
+ * returns GAMMA_HIP_EUNSUPPORTED, and L2 searches score every (query, list) pair with the distance table of the residual
+ * x - centroid (index/impl/gamma_index_ivfpq.h:239-245: compute_residual + pq.compute_distance_table, dis0 = 0), whose
+ * fp32 values differ from mode 1's by rounding.  The rule is applied by gamma_hip_ivfpq_init (it depends on nlist, M and
+ * the limit only): set the limit before Init.  _use_precomputed_table: 0 / 1, GAMMA_HIP_EINVAL before Init. */
+int gamma_hip_set_precomputed_table_max_bytes(int64_t bytes);
+int64_t gamma_hip_get_precomputed_table_max_bytes(void);
+int gamma_hip_ivfpq_use_precomputed_table(gamma_hip_index* h);
 /* shape of an initialised model: dimension, number of lists, bytes per code (nsubvector; 1 for IVFFLAT); 0 before Init */
 int gamma_hip_ivfpq_dim(gamma_hip_index* h);
 int gamma_hip_ivfpq_nlist(gamma_hip_index* h);

@@ -99,6 +99,17 @@ int gamma_hip_ivfpq_set_trained(gamma_hip_index* h, const float* cc, const float
     h->trained = true;
     return GAMMA_HIP_OK;
 }
+int gamma_hip_ivfpq_use_precomputed_table(gamma_hip_index* h) {
+    std::lock_guard<std::mutex> g(h->mu);
+    // (the product decides at Init from nlist * M and the limit; so does this)
+    return h->ix ? ((size_t)h->nlist * h->M * 1024 > go_get_precomputed_table_max_bytes() ? 0 : 1) : GAMMA_HIP_EINVAL;
+}
+int64_t gamma_hip_get_precomputed_table_max_bytes(void) { return (int64_t)go_get_precomputed_table_max_bytes(); }
+int gamma_hip_set_precomputed_table_max_bytes(int64_t b) {
+    if (b < 0) return GAMMA_HIP_EINVAL;
+    go_set_precomputed_table_max_bytes((size_t)b);
+    return GAMMA_HIP_OK;
+}
 int gamma_hip_ivfpq_train(gamma_hip_index*, int d, int64_t n, const float* x, int nlist, int M, float* cc, float* pq) {
     go_ivfpq_train(d, nlist, M, n, x, cc, pq);
     return GAMMA_HIP_OK;
