@@ -121,6 +121,9 @@ SYMBOLS = {
     "gamma_hip_ivfpq_search_shard_preassigned": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int,
                                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                            C.c_void_p, C.c_void_p]),
+    "gamma_hip_ivfpq_search_shard_bounded": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int,
+                                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gamma_hip_ivfpq_merge_rerank": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int, C.c_int,
                                                C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                                C.c_int, C.c_void_p, C.c_void_p]),
@@ -180,6 +183,10 @@ SYMBOLS = {
 }
 
 _lib = None
+
+
+# gamma_hip_bound_reduce_fn (include/gamma_hip.h): (user, d_bound, nq, take_max, stream) -> 0 on success
+BOUND_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
 
 
 class GammaHipError(RuntimeError):

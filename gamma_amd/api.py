@@ -402,6 +402,26 @@ class GammaHip:
                                                                   d_probe, k, d_rdis, d_rids),
                  "ivfpq_search_shard_preassigned")
 
+    def ivfpq_search_shard_bounded(self, d_x, nq, d_cdis, d_probe, k, args, d_rdis, d_rids, d_bound, reduce=None):
+        """two-phase shard search (include/gamma_hip.h): reduce(nq, take_max) is called ONCE from inside the call, after the
+        shard's own bounds were written to d_bound [nq] floats and before its consumers read them back -- the caller's
+        collective over d_bound (min / max across the shards), enqueued on the handle's stream; None = a single shard"""
+        err = []
+
+        def _cb(user, ptr, n, take_max, stream):
+            try:
+                reduce(n, bool(take_max))
+                return 0
+            except BaseException as e:   # an exception cannot cross the C frames: the call fails with EDEVICE, the error is re-raised
+                err.append(e)
+                return 1
+        cb = _lib.BOUND_REDUCE_FN(_cb) if reduce is not None else None
+        rc = self.L.gamma_hip_ivfpq_search_shard_bounded(self.h, args.ref(), nq, d_x, d_cdis, d_probe, k, d_rdis, d_rids,
+                                                         d_bound, C.cast(cb, C.c_void_p) if cb is not None else None, None)
+        if err:
+            raise err[0]
+        self._ck(rc, "ivfpq_search_shard_bounded")
+
     def ivfpq_merge_rerank(self, nshards, nq, d_x, k, args, d_all_dis, d_all_ids, q0, nq_local, d_D, d_I):
         self._ck(self.L.gamma_hip_ivfpq_merge_rerank(self.h, args.ref(), nshards, nq, d_x, k, d_all_dis,
                                                      d_all_ids, q0, nq_local, d_D, d_I), "merge_rerank")

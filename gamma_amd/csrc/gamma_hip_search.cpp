@@ -224,10 +224,32 @@ int ivfpq_coarse(H* h, const gamma_hip_search_params* p, int nq, const float* d_
 
 // pre_dis / pre_probe: coarse assignment computed elsewhere (sharded search: the rank owning the
 // query slice), device pointers [nq*nprobe]; nullptr = run the coarse quantizer here
+// Two-phase list-shard search (round 6): between the producers (the query's nearest probes OWNED BY THIS SHARD: they
+// bound the shard's recall_num-th best) and the consumers (all its other probes) the bounds of all shards are reduced
+// -- min for L2, max for inner product: one float per query -- so that every shard filters against a bound of the GLOBAL
+// recall_num-th best instead of its own, W times looser one.  `reduce` is the caller's collective (RCCL all-reduce in
+// gamma_amd/dist.py, peer reads in the in-process group); it is called exactly ONCE per shard call, with neutral values
+// when this call cannot run in two phases.
+struct BoundXchg {
+    float* d_bound = nullptr;                  // [nq of the whole call] the caller's buffer; holds the reduced bounds afterwards
+    gamma_hip_bound_reduce_fn fn = nullptr;
+    void* user = nullptr;
+    bool called = false;
+    bool two_phase = false;                    // this call runs in two phases (one chunk, bounded scan possible)
+    int P_in = 0;                              // row length of the supplied assignment (p->nprobe is the compacted rows')
+    int G1 = 2;                                // probes of the producers' group
+    int reduce(H* h, int nq, bool l2) {
+        called = true;
+        const int rc = fn ? fn(user, d_bound, nq, l2 ? 0 : 1, (void*)h->stream) : 0;
+        return rc ? fail(h, GAMMA_HIP_EDEVICE, "bound reduction callback failed") : GAMMA_HIP_OK;
+    }
+};
+
 int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int nq,
                   const float* d_x, int R, const float* pre_dis = nullptr, const int* pre_probe = nullptr,
-                  bool shard = false, float* out_dis = nullptr, int64_t* out_ids = nullptr) {
+                  bool shard = false, float* out_dis = nullptr, int64_t* out_ids = nullptr, BoundXchg* bx = nullptr) {
     const int P = p->nprobe, d = h->d, M = h->M, nlist = h->nlist;
+    const bool two = bx && bx->two_phase;
     const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
     hipStream_t s = h->stream;
     // this call reads the lists through the version of their (offset, length) tables that is current now:
@@ -253,8 +275,8 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     if (pre_dis && pre_probe) {
         if (shard) {
             // dense probe groups for the owned lists (kernels.hip, k_compact_probes)
-            gh::launch_compact_probes(s, pre_probe, pre_dis, nq, P, h->d_list_len, h->d_list_mask, nlist,
-                                      h->w_probe.as<int>(), h->w_coarse_dis.as<float>());
+            gh::launch_compact_probes(s, pre_probe, pre_dis, nq, two ? bx->P_in : P, h->d_list_len, h->d_list_mask, nlist,
+                                      h->w_probe.as<int>(), h->w_coarse_dis.as<float>(), P);
         } else {
             GH_CHECK(h, hipMemcpyAsync(h->w_coarse_dis.p, pre_dis, (size_t)nq * P * sizeof(float),
                                        hipMemcpyDeviceToDevice, s));
@@ -278,7 +300,20 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     // table on the fly instead of reading it back from HBM (IPF, kernels.hip).
     // 8 probes per workgroup pay off with short lists (half the query-table re-reads, a tighter bound from a
     // first group of 8 lists); long lists or many probes balance better with 4 (tools/shape_sweep.py)
-    int G0 = ((double)h->ntotal / std::max(1, nlist) <= 700.0 && P <= 64) ? 8 : 4;
+    // codes per list of the lists THIS handle scans: a list shard holds (or, under a mask, scans) 1 / W of the lists
+    double mean_len = (double)h->ntotal / std::max(1, nlist);
+    int64_t owned = nlist;
+    if (shard && !h->h_list_mask.empty()) {
+        int64_t tot = 0;
+        owned = 0;
+        for (int l = 0; l < nlist; l++)
+            if (h->h_list_len[l] > 0 && h->h_list_mask[l]) {
+                owned++;
+                tot += h->h_list_len[l];
+            }
+        mean_len = owned ? (double)tot / (double)owned : 0.0;
+    }
+    int G0 = (mean_len <= 700.0 && P <= 64) ? 8 : 4;
     // (with the byte-table filter pass a consumer probe costs a third of a producer's: five probes bound nearly as well as
     //  eight -- C3: scan 729 us at 8, 691 at 6, 676 at 5, 671 at 4 but with queries whose slices overflow; GAMMA_HIP_SCAN_G to sweep)
     static const bool no_c8 = getenv("GAMMA_HIP_NO_C8") != nullptr;
@@ -287,13 +322,18 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     if (G0 == 8 && c8_shape && P > 8) G0 = 5;
     int64_t t2_bytes = (int64_t)nlist * M * 256 * sizeof(float);
     const bool compacted = shard && pre_dis && pre_probe;
-    if (compacted && h->scan_bound && R <= 256) {
-        int64_t owned = 0;
-        for (int l = 0; l < nlist; l++)
-            owned += h->h_list_len[l] > 0 && (h->h_list_mask.empty() || h->h_list_mask[l]);
+    if (two) {
+        // the producers take the query's nearest G1 owned probes only: everything else waits for the GLOBAL bound
+        G0 = std::max(1, std::min(bx->G1, P));
+        t2_bytes = owned * M * 256 * (int64_t)sizeof(float);
+    } else if (compacted && h->scan_bound && R <= 256) {
+        if (h->h_list_mask.empty()) {
+            owned = 0;
+            for (int l = 0; l < nlist; l++) owned += h->h_list_len[l] > 0;
+        }
         t2_bytes = owned * M * 256 * (int64_t)sizeof(float);
         const double exp_probes = (double)P * (double)owned / std::max(1, nlist);
-        const double exp_cand = exp_probes * (owned ? (double)h->ntotal / (double)owned : 0.0);
+        const double exp_cand = exp_probes * mean_len;
         // (not beyond that: one workgroup walking 50 k - 200 k codes of a query is the long pole of the launch -- full-size
         //  C4 emulated, profiles/r04_scaling_emul.txt: W = 2 25.4 ms per step with 4 or 8 probes per workgroup, 27.9 with
         //  16, 31.4 with 32 or 64; W = 4 27.0 / 27.1 / 30.1 / 30.3 / 30.2)
@@ -323,7 +363,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     //  a long short-list, full-size C5 at ~1000, keep the pre-filter; GAMMA_HIP_BOUND_MAXR: the old gate for A/B runs)
     static const int scan_gmin = getenv("GAMMA_HIP_SCAN_GMIN") ? atoi(getenv("GAMMA_HIP_SCAN_GMIN")) : 4;
     static const int bound_maxr = getenv("GAMMA_HIP_BOUND_MAXR") ? atoi(getenv("GAMMA_HIP_BOUND_MAXR")) : 1024;
-    bool bounded = (!shard || compacted) && h->scan_bound && R <= std::min(1024, bound_maxr) && P <= 128 && G >= scan_gmin;
+    bool bounded = (!shard || compacted) && h->scan_bound && R <= std::min(1024, bound_maxr) && P <= 128 && G >= (two ? 1 : scan_gmin);
     if (bounded) {
         // feedback (gamma_hip_internal.h, bound_*): the counts of some recent call are in the pinned words
         static const bool no_fb = getenv("GAMMA_HIP_NO_BOUND_FEEDBACK") != nullptr;
@@ -401,7 +441,6 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         // lists in between: a consumer group takes at most ~64 k codes.
         static const double cf_maxlen = getenv("GAMMA_HIP_SCAN_CF_MAXLEN") ? atof(getenv("GAMMA_HIP_SCAN_CF_MAXLEN")) : 2000.0;
         static const double cf_codes = getenv("GAMMA_HIP_SCAN_CF_CODES") ? atof(getenv("GAMMA_HIP_SCAN_CF_CODES")) : 65536.0;
-        const double mean_len = (double)h->ntotal / std::max(1, nlist);
         // (and short-lists only: the pass stages SCAN_CF_CAP = 768 candidates per consumer workgroup)
         cf_ok = !no_cf && R <= 256 && (!h->prefiltered || h->cmp_has_sums) && PGN > 1 && mean_len <= cf_maxlen &&
                 gh::scan_cf_applies(l2, M, P, G, h->d_sums && h->d_t2max, false);
@@ -536,7 +575,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
             gh::launch_flag_cut_ties(s, h->w_dist.as<float>(), q_stride, h->w_qtotal.as<int>(), nq, R, out_dis,
                                      h->w_cand_pos.as<int>(), nullptr, h->w_tcut.as<uint8_t>());
     } else {
-        gh::ScanBound sb;
+        gh::ScanBound sb = {};   // (every field starts at 0: part, dbg_part, c8 ...)
         sb.ready = ready;
         sb.surv = h->w_surv.as<unsigned long long>();
         sb.gcnt = reinterpret_cast<int*>(ready + nq);
@@ -568,7 +607,28 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         sb.batch = scan_batch;
         sb.dbg_part = h->scan_dbg_now;
         sb.c8 = (cf_ok && !sb.prod_cf && c8_on && (cf_span > 0 ? cf_span : P - G) <= 64) ? c8_mode : 0;
-        if (!q8_ok) {
+        // two-phase shard search: the producers' bounds out, the reduced (global) bounds back into the ready words
+        auto exchange = [&]() -> int {
+            gh::launch_bound_export(s, l2, sb.ready, nq, bx->d_bound);
+            GH_TRY(bx->reduce(h, nq, l2));
+            gh::launch_bound_import(s, l2, bx->d_bound, nq, sb.ready);
+            return GAMMA_HIP_OK;
+        };
+        if (!q8_ok && two) {
+            {   // phase 1: the producers alone (one group per query; the plain bounded kernel)
+                StageScope t(h, GAMMA_HIP_STAGE_SCAN, true);
+                gh::launch_ivfpq_scan_pair(s, l2, d_x, nq, d, M, P, h->w_probe.as<int>(), dis0, h->d_cc, h->scan_st2(l2), h->d_T2,
+                                           h->d_list_off, h->d_list_len, h->d_list_mask, nlist, h->d_codes, h->d_ids,
+                                           h->w_pair_off.as<int>(), q_stride, h->w_dist.as<float>(), fc.d_tab, fc.d_qf, need_ids, qperm, G, 0,
+                                           1, 1, &sb, fuse_ip ? h->d_pqc : nullptr);
+            }
+            GH_TRY(exchange());
+            if (PGM > 1) {   // phase 2: the consumers alone, against the global bounds
+                sb.part = 2;
+                scan(G, 0, PGM, &sb, false);
+                sb.part = 0;
+            }
+        } else if (!q8_ok) {
             scan(G, 0, PGM, &sb, true);
         } else {
             // producers (the first G probes: exact, they publish the bounds), then the other probes list-major over byte
@@ -578,13 +638,14 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
                                        h->d_list_off, h->d_list_len, h->d_list_mask, nlist, h->d_codes, h->d_ids,
                                        h->w_pair_off.as<int>(), q_stride, h->w_dist.as<float>(), fc.d_tab, fc.d_qf, need_ids, qperm, G, 0,
                                        1, 0, &sb, nullptr);
+            if (two) GH_TRY(exchange());   // (the list-major pass below reads the ready words: now the global bounds)
             GH_CHECK(h, h->w_q8.ensure((size_t)nq * M * 256));
             GH_CHECK(h, h->w_q8meta.ensure((size_t)nq * 4 * sizeof(float)));
             GH_CHECK(h, h->w_q8cand.ensure((size_t)nq * gh::q8_cand_cap(nq) * sizeof(uint32_t)));
             GH_CHECK(h, h->w_q8int.ensure(gh::q8_int_words(nq, P, G, nlist) * sizeof(int)));
             gh::Q8Args qa;
             qa.nq = nq; qa.P = P; qa.G = G; qa.M = M; qa.nlist = nlist;
-            qa.mean_len = (double)h->ntotal / std::max(1, nlist);
+            qa.mean_len = mean_len;
             qa.probe_list = h->w_probe.as<int>();
             qa.coarse_dis = dis0;
             qa.st2 = h->w_st2.as<float>();
@@ -1768,17 +1829,28 @@ int gamma_hip_ivfpq_coarse_device(gamma_hip_index* h, const gamma_hip_search_par
     return GAMMA_HIP_OK;
 }
 
-int gamma_hip_ivfpq_search_shard_preassigned(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
-                                             const float* d_x, const float* d_coarse_dis,
-                                             const int32_t* d_probe, int k, float* d_recall_dis,
-                                             int64_t* d_recall_ids) {
+static int shard_preassigned(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
+                             const float* d_x, const float* d_coarse_dis,
+                             const int32_t* d_probe, int k, float* d_recall_dis,
+                             int64_t* d_recall_ids, ghi::BoundXchg* bx) {
     if (!h) return GAMMA_HIP_EINVAL;
     SearchLock lk(h);
+    // (a call with a reduction makes it exactly once, whatever happens: the other shards are waiting in theirs)
+    struct ReduceOnce {
+        H* h; ghi::BoundXchg* bx; int nq; bool l2;
+        ~ReduceOnce() {
+            if (bx && !bx->called && bx->d_bound && nq > 0) {
+                gh::launch_fill_f32(h->stream, bx->d_bound, nq, l2 ? INFINITY : -INFINITY);
+                (void)bx->reduce(h, nq, l2);
+            }
+        }
+    } reduce_once{h, bx, nq, p && p->metric == GAMMA_HIP_METRIC_L2};
     GH_TRY(replay_join(h));
     GH_TRY(ivfpq_check(h, p, nq, k));
     if (k <= 0 || nq == 0) return GAMMA_HIP_OK;
     if (!d_coarse_dis || !d_probe) return fail(h, GAMMA_HIP_EINVAL, "null coarse assignment");
     if (!d_x || !d_recall_dis || !d_recall_ids) return fail(h, GAMMA_HIP_EINVAL, "null buffer");
+    if (bx && !bx->d_bound) return fail(h, GAMMA_HIP_EINVAL, "null bound buffer");
     GH_CHECK(h, hipSetDevice(h->device));
     const int R = std::max(p->recall_num, k), P = p->nprobe;
     gamma_hip_search_params pp;
@@ -1793,7 +1865,8 @@ int gamma_hip_ivfpq_search_shard_preassigned(gamma_hip_index* h, const gamma_hip
         H* h;
         ~StrideScope() { h->q_stride_cap = 0; }
     } stride_scope{h};
-    if (chunk < nq) {
+    static const bool no_two = getenv("GAMMA_HIP_NO_TWO_PHASE") != nullptr;
+    if (chunk < nq || (bx && !no_two)) {
         // A shard scans ~P / W of a query's probes, but the slab stride of the general path is P x the longest list:
         // the budget then cuts the batch (W times the queries of one rank) into many chunks, each with its own launches
         // and its own handful of fallback queries (full-size C4, W = 8: 20 chunks, 5.7 ms of a 37 ms step).  The
@@ -1802,19 +1875,32 @@ int gamma_hip_ivfpq_search_shard_preassigned(gamma_hip_index* h, const gamma_hip
         // by it.
         GH_CHECK(h, h->w_shard_cut.ensure(std::max<size_t>((size_t)nq, 16)));   // (its first word; the flags come later)
         gh::launch_max_local_total(h->stream, d_probe, nq, P, h->d_list_len, h->d_list_mask, h->nlist, h->w_shard_cut.as<int>());
-        int mx = 0;
-        GH_CHECK(h, hipMemcpyAsync(&mx, h->w_shard_cut.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        int mx[2] = {0, 0};
+        GH_CHECK(h, hipMemcpyAsync(mx, h->w_shard_cut.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         GH_CHECK(h, hipStreamSynchronize(h->stream));
-        h->q_stride_cap = (std::max<int64_t>(mx, 1) + 3) & ~(int64_t)3;
+        h->q_stride_cap = (std::max<int64_t>(mx[0], 1) + 3) & ~(int64_t)3;
         const int64_t by_dist = (int64_t)(h->dist_budget_bytes / ((size_t)h->q_stride_cap * sizeof(float)));
         chunk = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(by_dist, coarse_chunk(h, nq)), nq));
+        if (bx && !no_two && chunk >= nq) {
+            // two phases (ivfpq_stage_a, BoundXchg): the batch runs as ONE chunk, so the reduction is one collective; the scan
+            // behind sees a search of P' probes -- the most owned probes any query of the batch has -- all of them dense
+            const char* g1e = getenv("GAMMA_HIP_SHARD_G1");   // (read per call: tools sweep it inside one process)
+            const int g1_env = g1e ? atoi(g1e) : 2;
+            bx->two_phase = true;
+            bx->P_in = P;
+            bx->G1 = std::max(1, g1_env);
+            const int g = bx->G1;
+            pp.nprobe = std::max(1, std::min(P, ((std::max(mx[1], 1) + g - 1) / g) * g));
+        }
     }
+    const int P_in = P;
+    const int Pe = pp.nprobe;   // rows of the compacted assignment the scan sees (P unless two phases)
     bool all_cut = true;
     for (int q0 = 0; q0 < nq; q0 += chunk) {
         const int nc = std::min(chunk, nq - q0);
-        GH_TRY(ivfpq_stage_a(h, p, fc.at(q0), nc, d_x + (size_t)q0 * h->d, R, d_coarse_dis + (size_t)q0 * P,
-                             d_probe + (size_t)q0 * P, /*shard=*/true, d_recall_dis + (size_t)q0 * R,
-                             d_recall_ids + (size_t)q0 * R));
+        GH_TRY(ivfpq_stage_a(h, p, fc.at(q0), nc, d_x + (size_t)q0 * h->d, R, d_coarse_dis + (size_t)q0 * P_in,
+                             d_probe + (size_t)q0 * P_in, /*shard=*/true, d_recall_dis + (size_t)q0 * R,
+                             d_recall_ids + (size_t)q0 * R, (bx && bx->two_phase) ? bx : nullptr));
         h->last_nq = nc;
         if (chunk < nq && h->shard_cut_nq == nc) {   // a call of several chunks: the cut-tie flags of all of them
             GH_CHECK(h, h->w_shard_cut.ensure((size_t)nq));
@@ -1825,9 +1911,27 @@ int gamma_hip_ivfpq_search_shard_preassigned(gamma_hip_index* h, const gamma_hip
     }
     h->shard_cut_chunked = chunk < nq && all_cut;
     if (h->shard_cut_chunked) h->shard_cut_nq = nq;
-    h->last_P = P;
+    h->last_P = Pe;
     h->last_R = R;
     return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_search_shard_preassigned(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
+                                             const float* d_x, const float* d_coarse_dis,
+                                             const int32_t* d_probe, int k, float* d_recall_dis,
+                                             int64_t* d_recall_ids) {
+    return shard_preassigned(h, p, nq, d_x, d_coarse_dis, d_probe, k, d_recall_dis, d_recall_ids, nullptr);
+}
+
+int gamma_hip_ivfpq_search_shard_bounded(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
+                                         const float* d_x, const float* d_coarse_dis, const int32_t* d_probe, int k,
+                                         float* d_recall_dis, int64_t* d_recall_ids, float* d_bound,
+                                         gamma_hip_bound_reduce_fn reduce, void* user) {
+    ghi::BoundXchg bx;
+    bx.d_bound = d_bound;
+    bx.fn = reduce;
+    bx.user = user;
+    return shard_preassigned(h, p, nq, d_x, d_coarse_dis, d_probe, k, d_recall_dis, d_recall_ids, &bx);
 }
 
 int gamma_hip_ivfpq_merge_rerank(gamma_hip_index* h, const gamma_hip_search_params* p, int nshards, int nq,

@@ -156,7 +156,11 @@ void launch_pair_offsets(hipStream_t s, const int* probe_list, int nq, int P, co
                          int64_t* pair_base = nullptr, const PairZero* zero = nullptr);
 void launch_compact_probes(hipStream_t s, const int* probe_in, const float* cdis_in, int nq, int P,
                            const int* list_len, const uint8_t* list_mask, int nlist, int* probe_out,
-                           float* cdis_out);
+                           float* cdis_out, int P_out = 0);   // P_out: row length of the output (0: P)
+// two-phase shard search: the producers' bounds as floats (+-inf: none) for the reduction across shards, and back
+void launch_bound_export(hipStream_t s, bool l2, const unsigned long long* ready, int nq, float* out);
+void launch_bound_import(hipStream_t s, bool l2, const float* in, int nq, unsigned long long* ready);
+void launch_fill_f32(hipStream_t s, float* p, int n, float v);
 // inner-product scan: dis0[q][p] = <x_q, centroid of probe p> (fvec_inner_product order); the scan takes it
 // through its coarse_dis argument
 void launch_pair_ip(hipStream_t s, const float* x, const float* cc, const int* probe_list, int nq, int P, int d,
@@ -185,6 +189,8 @@ struct ScanBound {
                                 // candidates the exact arithmetic.  Its slab segment then holds APPROXIMATE values: the callers re-score
                                 // group 0 (repair launch) for every query whose slab is read (unfiltered selection, tie replay)
     int batch;                  // queries per XCD by which the producers run ahead of the consumers (0: 64)
+    int part;                   // two-phase shard search: 1 = only the producers of this launch work (the consumers leave at once),
+                                // 2 = only the consumers (the bounds are in `ready` already: imported after the reduction across shards)
     int dbg_part;               // timing experiments only (GAMMA_HIP_SCAN_PART): 1 = consumers leave at once, 2 = producers do
     int c8;                     // != 0 (filter-pass launches only): the consumers' filter pass gathers from a BYTE image of the query's
                                 // table made in the workgroup (2-way bank conflicts at most instead of ~3.5); candidates as ever
@@ -246,7 +252,8 @@ bool query_order_grid(int nq);   // the batch is sorted over the whole grid (nee
 void launch_query_order(hipStream_t s, const int* probe_list, int nq, int P, const int* list_rank,
                         int nlist, int* qkey, int* qperm, int* bins = nullptr, bool hist_done = false);
 void launch_sum_totals(hipStream_t s, const int* q_total, int nq, unsigned long long* acc);
-// list shard over a supplied assignment: *out_max = the longest candidate row of the batch over the lists scanned here
+// list shard over a supplied assignment: out_max[0] = the longest candidate row of the batch over the lists scanned here,
+// out_max[1] = the most owned, non-empty probes of any query (TWO words)
 void launch_max_local_total(hipStream_t s, const int* probe_list, int nq, int P, const int* list_len,
                             const uint8_t* list_mask, int nlist, int* out_max);
 int select_kpad(int K);

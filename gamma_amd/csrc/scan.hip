@@ -136,6 +136,9 @@ __device__ __forceinline__ void scan_pair_body(
         if (sb.dbg_part && (sb.dbg_part == 1) == (pg > 0)) return;   // timing experiments (ScanBound::dbg_part)
     }
 #endif
+    if constexpr (FILT) {
+        if (sb.part && (sb.part == 1) == (pg > 0)) return;   // two-phase shard search (ScanBound::part)
+    }
     const bool repair = !FILT && rq_list != nullptr;
     int q = 0;
     if (repair) {

@@ -212,7 +212,9 @@ __global__ __launch_bounds__(256) void k_compact_probes(const int* __restrict__ 
                                                         const int* __restrict__ list_len,
                                                         const uint8_t* __restrict__ list_mask, int nlist,
                                                         int* __restrict__ probe_out,
-                                                        float* __restrict__ cdis_out) {
+                                                        float* __restrict__ cdis_out, int P_out) {
+    // P_out <= P: rows of the OUTPUT (two-phase shard search: the longest run of owned probes any query of the batch has,
+    // measured first -- k_max_local_total -- so that the scan behind sees a search of P_out probes, all of them dense)
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (q >= nq) return;
@@ -229,22 +231,24 @@ __global__ __launch_bounds__(256) void k_compact_probes(const int* __restrict__ 
         const unsigned long long bal = __ballot(own);
         if (own) {
             const int at = nown + __popcll(bal & ((1ull << lane) - 1ull));
-            probe_out[(int64_t)q * P + at] = l;
-            cdis_out[(int64_t)q * P + at] = cd;
+            if (at < P_out) {   // (never false when P_out came from k_max_local_total of this batch)
+                probe_out[(int64_t)q * P_out + at] = l;
+                cdis_out[(int64_t)q * P_out + at] = cd;
+            }
         }
         nown += __popcll(bal);
     }
-    for (int p = nown + lane; p < P; p += 64) {
-        probe_out[(int64_t)q * P + p] = -1;
-        cdis_out[(int64_t)q * P + p] = 0.f;
+    for (int p = nown + lane; p < P_out; p += 64) {
+        probe_out[(int64_t)q * P_out + p] = -1;
+        cdis_out[(int64_t)q * P_out + p] = 0.f;
     }
 }
 void launch_compact_probes(hipStream_t s, const int* probe_in, const float* cdis_in, int nq, int P,
                            const int* list_len, const uint8_t* list_mask, int nlist, int* probe_out,
-                           float* cdis_out) {
+                           float* cdis_out, int P_out) {
     if (nq <= 0) return;
     hipLaunchKernelGGL(k_compact_probes, dim3((nq + 3) / 4), dim3(256), 0, s, probe_in, cdis_in, nq, P, list_len,
-                       list_mask, nlist, probe_out, cdis_out);
+                       list_mask, nlist, probe_out, cdis_out, P_out > 0 ? std::min(P_out, P) : P);
 }
 
 // profiling only: algorithmic scan volume of a batch = sum of the per-query candidate counts
@@ -276,23 +280,72 @@ __global__ __launch_bounds__(256) void k_max_local_total(const int* __restrict__
                                                          const int* __restrict__ list_len,
                                                          const uint8_t* __restrict__ list_mask, int nlist,
                                                          int* __restrict__ out_max) {
+    // out_max[0]: the longest candidate row; out_max[1]: the most owned, non-empty probes any query has (the rows'
+    // length after k_compact_probes)
     const int lane = threadIdx.x & 63;
-    int best = 0;
+    int best = 0, bestn = 0;
     for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < nq; q += gridDim.x * 4) {
-        int t = 0;
+        int t = 0, n = 0;
         for (int p = lane; p < P; p += 64) {
             const int l = probe_list[(int64_t)q * P + p];
-            if (l >= 0 && l < nlist && (!list_mask || list_mask[l])) t += max(list_len[l], 0);
+            if (l >= 0 && l < nlist && (!list_mask || list_mask[l])) {
+                t += max(list_len[l], 0);
+                n += list_len[l] > 0 ? 1 : 0;
+            }
         }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+        for (int off = 32; off > 0; off >>= 1) {
+            t += __shfl_xor(t, off, 64);
+            n += __shfl_xor(n, off, 64);
+        }
         best = max(best, t);
+        bestn = max(bestn, n);
     }
     if (lane == 0 && best > 0) atomicMax(out_max, best);
+    if (lane == 0 && bestn > 0) atomicMax(out_max + 1, bestn);
+}
+
+// Two-phase shard search (round 6): the bound a shard's producers published per query, as a float the caller reduces
+// across the shards (min for L2, max for inner product: every shard's value bounds the GLOBAL recall_num-th best from
+// the wrong side at worst, so the tightest of them does too), and the reduced value back into the ready words the
+// consumers read.  A query without a bound travels as +inf / -inf.
+template <bool L2>
+__global__ __launch_bounds__(256) void k_bound_export(const unsigned long long* __restrict__ ready, int nq, float* __restrict__ out) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const unsigned long long w = ready[q];
+    const uint32_t key = (uint32_t)w;
+    out[q] = (w >> 32) == 1ull ? key2f(L2 ? key : ~key) : (L2 ? INFINITY : -INFINITY);
+}
+template <bool L2>
+__global__ __launch_bounds__(256) void k_bound_import(const float* __restrict__ in, int nq, unsigned long long* __restrict__ ready) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const float v = in[q];
+    const uint32_t key = L2 ? f2key(v) : ~f2key(v);
+    // (never looser than the shard's own bound: the reduction included it)
+    ready[q] = (v == v && key < KEY_SENTINEL) ? ((1ull << 32) | key) : (2ull << 32);
+}
+void launch_bound_export(hipStream_t s, bool l2, const unsigned long long* ready, int nq, float* out) {
+    if (nq <= 0) return;
+    if (l2) hipLaunchKernelGGL(k_bound_export<true>, dim3((nq + 255) / 256), dim3(256), 0, s, ready, nq, out);
+    else hipLaunchKernelGGL(k_bound_export<false>, dim3((nq + 255) / 256), dim3(256), 0, s, ready, nq, out);
+}
+void launch_bound_import(hipStream_t s, bool l2, const float* in, int nq, unsigned long long* ready) {
+    if (nq <= 0) return;
+    if (l2) hipLaunchKernelGGL(k_bound_import<true>, dim3((nq + 255) / 256), dim3(256), 0, s, in, nq, ready);
+    else hipLaunchKernelGGL(k_bound_import<false>, dim3((nq + 255) / 256), dim3(256), 0, s, in, nq, ready);
+}
+__global__ __launch_bounds__(256) void k_fill_f32(float* __restrict__ p, int n, float v) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+void launch_fill_f32(hipStream_t s, float* p, int n, float v) {
+    if (n > 0) hipLaunchKernelGGL(k_fill_f32, dim3((n + 255) / 256), dim3(256), 0, s, p, n, v);
 }
 void launch_max_local_total(hipStream_t s, const int* probe_list, int nq, int P, const int* list_len,
                             const uint8_t* list_mask, int nlist, int* out_max) {
-    (void)hipMemsetAsync(out_max, 0, sizeof(int), s);
+    (void)hipMemsetAsync(out_max, 0, 2 * sizeof(int), s);
     if (nq > 0)
         hipLaunchKernelGGL(k_max_local_total, dim3(std::min(2048, (nq + 3) / 4)), dim3(256), 0, s, probe_list, nq, P, list_len,
                            list_mask, nlist, out_max);

@@ -119,6 +119,14 @@ class HipShardBackend:
         self.g.ivfpq_search_shard_preassigned(x.data_ptr(), x.shape[0], cdis.data_ptr(), probe.data_ptr(),
                                               k, args, rdis.data_ptr(), rids.data_ptr())
 
+    def search_shard_bounded(self, x, cdis, probe, k, args, rdis, rids, bound, reduce):
+        """search_shard in two phases (gamma_hip_ivfpq_search_shard_bounded): the shard's own bound per query lands in
+        `bound` [n] float32, reduce(take_max) -- the caller's collective over `bound` -- runs once in between, the consumers
+        then filter against the reduced, global bound"""
+        self.g.ivfpq_search_shard_bounded(x.data_ptr(), x.shape[0], cdis.data_ptr(), probe.data_ptr(), k, args,
+                                          rdis.data_ptr(), rids.data_ptr(), bound.data_ptr(),
+                                          (lambda n, take_max: reduce(take_max)) if reduce is not None else None)
+
     def merge_rerank(self, all_dis, all_ids, x, k, args, nql, D, I):
         """all_dis/all_ids [W, per, R]: candidates of this rank's slice from every shard"""
         W, per = all_dis.shape[0], all_dis.shape[1]

@@ -420,6 +420,29 @@ int gamma_hip_ivfpq_search_shard_preassigned(gamma_hip_index* h, const gamma_hip
                                              int nq, const float* d_x, const float* d_coarse_dis,
                                              const int32_t* d_probe, int k, float* d_recall_dis,
                                              int64_t* d_recall_ids);
+/* Stage 1 in TWO PHASES with a bound of the GLOBAL recall_num-th best (round 6).  A list shard on its own can only
+ * bound its LOCAL recall_num-th best -- with W shards about W times looser than what one GPU holding every list gets from
+ * the query's nearest probes -- so all its probes take the expensive exact path and it exports recall_num candidates per
+ * query of which the merge keeps ~1 / W.  Here the shard first scores only the query's nearest `GAMMA_HIP_SHARD_G1`
+ * (default 2) probes it OWNS, which bound its local recall_num-th best exactly as the single-GPU producers do
+ * (gamma_index_ivfpq.h:351-370: anything worse than the recall_num-th best seen can never enter the R-heap), writes that
+ * bound per query to d_bound [nq] (+inf / -inf: none), and calls `reduce` ONCE: the caller's collective replaces d_bound[q]
+ * by the minimum (L2; take_max = 0) or maximum (inner product; take_max = 1) over all shards -- every shard's value is an
+ * upper bound of the global recall_num-th best, so the tightest one is too -- enqueued on `stream` (the handle's).
+ * The shard's other probes then run as consumers of that bound (byte-table filter pass, list-major for long lists) and
+ * the shard's table holds its candidates within the bound, best first, padded with (sentinel, -1): a SUPERSET of the
+ * shard's part of the global top-recall_num, so the merge (gamma_hip_ivfpq_merge_rerank) and the tie machinery are
+ * unchanged.  Results are identical to _search_shard_preassigned's after the merge.  `reduce` is called exactly once per
+ * call -- with neutral values when the call cannot run in two phases (several chunks) -- so the shards' collectives
+ * always pair up; NULL reduce = a single shard (the bounds stay local).  d_bound holds the reduced bounds on return
+ * (stream order).  Replaces the per-shard scan of faiss:IndexShards.cpp:283-345 /
+ * index/impl/gpu/gamma_gpu_cloner.cpp:200-253, where every shard scans with its own heap threshold. */
+typedef int (*gamma_hip_bound_reduce_fn)(void* user, float* d_bound, int nq, int take_max, void* stream);
+int gamma_hip_ivfpq_search_shard_bounded(gamma_hip_index* h, const gamma_hip_search_params* p,
+                                         int nq, const float* d_x, const float* d_coarse_dis,
+                                         const int32_t* d_probe, int k, float* d_recall_dis,
+                                         int64_t* d_recall_ids, float* d_bound,
+                                         gamma_hip_bound_reduce_fn reduce, void* user);
 /* sharded search, stage 2: merge nshards*recall_num candidates per query (layout
  * [shard][nq][recall_num]) into the global top-recall_num, then compute_dis (re-rank or
  * truncate, gamma_index_ivfpq.cc:642-697) for queries [q0, q0+nq_local) */

@@ -8,14 +8,23 @@ Several handles = several streams, and torch's own: every tensor torch fills or 
 before a handle's kernels are enqueued on it, every handle call is synchronised before torch or another handle reads its
 output -- without the first half a zero fill could land AFTER the shard scan it was meant to precede (seen under load:
 six test processes on one GPU)."""
+import os
+
 import torch
 
+from gamma_amd import api
 from gamma_amd import dist as gdist
 
 
-def sharded_search_emulated(shards, x, k, args, use_shard_flags=True):
+def sharded_search_emulated(shards, x, k, args, use_shard_flags=True, two_phase=None):
     """shards: W api.GammaHip handles, each holding the lists it owns.  x: [nq, d] float32 tensor on cuda:0.
-    Returns (D, I, flagged): [nq, k] result tensors and the number of queries that went through the tie phase."""
+    Returns (D, I, flagged): [nq, k] result tensors and the number of queries that went through the tie phase.
+    two_phase (default: on, GAMMA_TEST_TWO_PHASE=0 turns it off): the shard scans run through
+    gamma_hip_ivfpq_search_shard_bounded with the reduction of the bounds across the shards emulated in two passes -- every
+    shard once with its own bounds only (they are what its first phase exports), then again with a reduction that hands
+    it the minimum (L2) / maximum (inner product) over all shards."""
+    if two_phase is None:
+        two_phase = os.environ.get("GAMMA_TEST_TWO_PHASE", "1") != "0"
     W = len(shards)
     nq, d = x.shape
     P = args.p.nprobe
@@ -39,12 +48,40 @@ def sharded_search_emulated(shards, x, k, args, use_shard_flags=True):
     pr_all = torch.cat(pr_parts).contiguous()
     torch.cuda.synchronize()
     rd, ri, cf_ = [], [], []
+    glob = None
+    if two_phase:
+        own = []
+        for s in range(W):
+            rdis = torch.zeros((nq, R), dtype=torch.float32, device=dev)
+            rids = torch.full((nq, R), -1, dtype=torch.int64, device=dev)
+            b = torch.zeros((nq,), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+            backs[s].search_shard_bounded(x, cd_all, pr_all, k, args, rdis, rids, b, None)
+            shards[s].synchronize()
+            own.append(b)
+        st = torch.stack(own)
+        glob = (st.max(dim=0).values if args.p.metric == api.METRIC_IP else st.min(dim=0).values).contiguous()
+        torch.cuda.synchronize()
     for s in range(W):
         rdis = torch.zeros((nq, R), dtype=torch.float32, device=dev)
         rids = torch.full((nq, R), -1, dtype=torch.int64, device=dev)
         cutf = torch.zeros((nq,), dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
-        backs[s].search_shard(x, cd_all, pr_all, k, args, rdis, rids)
+        if two_phase:
+            b = torch.zeros((nq,), dtype=torch.float32, device=dev)
+
+            def reduce(take_max, b=b, s=s):
+                # what the all-reduce leaves in the buffer; the shard's own value must be one of the inputs
+                # (no call back into the handle from here: the search holds its lock)
+                torch.cuda.synchronize()
+                assert torch.equal(b, own[s]), "phase 1 is not deterministic"
+                assert take_max == (args.p.metric == api.METRIC_IP)
+                b.copy_(glob)
+                torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            backs[s].search_shard_bounded(x, cd_all, pr_all, k, args, rdis, rids, b, reduce)
+        else:
+            backs[s].search_shard(x, cd_all, pr_all, k, args, rdis, rids)
         backs[s].shard_cut_flags(nq, cutf)
         shards[s].synchronize()
         rd.append(rdis)

@@ -227,3 +227,46 @@ def test_mode0_long_lists_unit_mode_and_add_path():
     finally:
         B.lib().go_set_assign_mode(0)
         g.close()
+
+
+def test_mode0_behind_the_plugin_boundary(tmp_path):
+    """HIPIVFPQ created while the limit is below its table: Init logs what faiss prints, Indexing / Add / Search / Dump / Load
+    run as ever, results are the oracle's in table mode 0 -- and differ in their bits from the same index in mode 1"""
+    from gamma_amd import plugin
+    d, nlist, M, N = 32, 64, 8, 20000
+    case = fixtures.trained_case(d=d, nlist=nlist, M=M, N=N, nq=64, metric=B.METRIC_L2)
+    base, q = case["base"], case["q"]
+    js = '{"ncentroids": %d, "nsubvector": %d, "nprobe": 8, "metric_type": "L2"}' % (nlist, M)
+    with table_limit(nlist * M * 1024 - 1):
+        m = plugin.PluginModel("HIPIVFPQ", d, js, indexing_size=5000)
+        o = B.OracleIVFPQ(d, nlist, M, 8, B.METRIC_L2)
+        o.set_trained(case["cc"], case["pq"], None)
+        assert o.use_precomputed_table() == 0
+    m.store(base)
+    assert m.set_trained(case["cc"], case["pq"]) == 0
+    B.lib().go_set_assign_mode(1)
+    for i0 in range(0, N, 5000):
+        assert m.add(base[i0:i0 + 5000])
+        assert o.add(base[i0:i0 + 5000])
+    B.lib().go_set_assign_mode(0)
+    o.set_raw(base)
+    rp = '{"metric_type": "L2", "recall_num": 100, "nprobe": 8}'
+    for has_rank in (True, False):
+        for n in (len(q), 7):
+            D, I = o.search(q[:n], 10, 8, recall_num=100, has_rank=has_rank, metric=B.METRIC_L2, ctx=B.make_ctx(), coarse_mode=-1)
+            Dg, Ig = m.search(q[:n], 10, rp, has_rank=has_rank)
+            compare_exact(D, I, Dg, Ig)
+    # the same index in table mode 1 (the cached case's oracle): other bits in the ADC stage
+    D1, _ = case["oracle"].search(q, 10, 8, recall_num=100, has_rank=False, metric=B.METRIC_L2, ctx=B.make_ctx(), coarse_mode=-1)
+    D0, I0 = m.search(q, 10, rp, has_rank=False)
+    assert (D1.view(np.uint32) != D0.view(np.uint32)).any()
+    # Dump / Load: the table is not stored (gamma_index_ivfpq.cc:1032-1034 recomputes -- or not -- under the limit in force)
+    assert m.dump(str(tmp_path)) == 0
+    with table_limit(nlist * M * 1024 - 1):
+        m2 = plugin.PluginModel("HIPIVFPQ", d, js, indexing_size=5000)
+    m2.store(base)
+    assert m2.load(str(tmp_path)) == N
+    D2, I2 = m2.search(q, 10, rp, has_rank=False)
+    assert D0.tobytes() == D2.tobytes() and np.array_equal(I0, I2)
+    m.close()
+    m2.close()

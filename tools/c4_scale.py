@@ -67,6 +67,29 @@ for R2 in (150, 200, 300, 400):
     Df2, If2 = g.flat_search(q[nq:][:NR], k, api.SearchArgs(metric=api.METRIC_L2, min_score=0.0, max_score=1e30))
     rec2 = np.mean([len(set(Ih[i].tolist()) & set(If2[i].tolist())) / float(k) for i in range(NR)])
     print("recall_num %d: recall@10 %.3f, %.2f ms per %d queries = %.0f queries/s" % (R2, rec2, dt2 * 1e3, nq, nq / dt2))
+def _emul_measure(g, step_fn, two, Genv, W, sizes, owner, gnq, nq, base_ms):
+    if not two and Genv != "0":
+        os.environ["GAMMA_HIP_SCAN_G"] = Genv     # probes per workgroup forced (the library reads it per call)
+        print("GAMMA_HIP_SCAN_G=%s:" % Genv, end=" ")
+    for _ in range(2):
+        step_fn()
+    g.synchronize()
+    g.profile_enable(True); g.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        step_fn()
+    g.synchronize()
+    de = (time.perf_counter() - t0) / 4
+    pr = g.profile()
+    os.environ.pop("GAMMA_HIP_SCAN_G", None)
+    print("emulated rank of W=%d%s (lists of shard 0: %.1f M of %.1f M vectors): %.2f ms per step of %d queries (%d per rank) "
+          "against %.2f ms for %d queries on one GPU -> per-rank compute efficiency %.0f %%; stage ms/step %s" % (
+              W, ", TWO-PHASE (global bound)" if two else "", sizes[owner == 0].sum() / 1e6, sizes.sum() / 1e6, de * 1e3, gnq, nq,
+              base_ms, nq, 100.0 * base_ms / (de * 1e3),
+              {n: round(pr[n][0] / 4, 3) for n in pr if isinstance(pr[n], tuple) and pr[n][1]}))
+    g.profile_enable(False)
+
+
 if os.environ.get("C4_EMUL"):
     # One rank of a W-GPU LIST-SHARDED job on this index, emulated on one GPU (no communication; tools/rank_emul.py is
     # the C3 version): the handle works under the list mask of shard 0 of gamma_amd.dist.balance_lists(sizes, W) -- it
@@ -100,26 +123,51 @@ if os.environ.get("C4_EMUL"):
             g.ivfpq_search_shard_preassigned(dqq.data_ptr(), gnq, cdis.data_ptr(), probe.data_ptr(), k, args, rdis.data_ptr(),
                                              rids.data_ptr())
             g.ivfpq_merge_rerank(W, nq, dqq.data_ptr(), k, args, rdis.data_ptr(), rids.data_ptr(), 0, nq, D2.data_ptr(), I2.data_ptr())
-        for Genv in os.environ.get("C4_EMUL_G", "0").split(","):
-            if Genv != "0":
-                os.environ["GAMMA_HIP_SCAN_G"] = Genv     # probes per workgroup forced (the library reads it per call)
-                print("GAMMA_HIP_SCAN_G=%s:" % Genv, end=" ")
-            for _ in range(2):
-                estep()
-            g.synchronize()
-            g.profile_enable(True); g.profile_reset()
-            t0 = time.perf_counter()
-            for _ in range(4):
-                estep()
-            g.synchronize()
-            de = (time.perf_counter() - t0) / 4
-            pr = g.profile()
-            os.environ.pop("GAMMA_HIP_SCAN_G", None)
-            print("emulated rank of W=%d (lists of shard 0: %.1f M of %.1f M vectors): %.2f ms per step of %d queries (%d per rank) "
-                  "against %.2f ms for %d queries on one GPU -> per-rank compute efficiency %.0f %%; stage ms/step %s" % (
-                      W, sizes[owner == 0].sum() / 1e6, sizes.sum() / 1e6, de * 1e3, gnq, nq, base_ms, nq, 100.0 * base_ms / (de * 1e3),
-                      {n: round(pr[n][0] / 4, 3) for n in pr if isinstance(pr[n], tuple) and pr[n][1]}))
-            g.profile_enable(False)
+        # two-phase shard search (gamma_hip_ivfpq_search_shard_bounded): the reduction across the W shards is emulated -- the
+        # bounds every shard's first phase exports are computed once, outside the timed region, under each shard's list mask;
+        # the timed step's reduce callback hands shard 0 their minimum (what the all-reduce would leave in its buffer)
+        two_modes = [False]
+        if os.environ.get("C4_EMUL_TWO"):
+            two_modes = [False, True]
+            bound = torch.empty((gnq,), dtype=f32, device=dev)
+            stream = torch.cuda.ExternalStream(g.stream(), device=dev)
+            glob_box = [None]
+
+            def compute_glob():
+                own = []
+                for s_ in range(W):
+                    g.set_list_mask((owner == s_).astype(np.uint8))
+                    b_ = torch.empty((gnq,), dtype=f32, device=dev)
+                    g.ivfpq_search_shard_bounded(dqq.data_ptr(), gnq, cdis.data_ptr(), probe.data_ptr(), k, args, rdis.data_ptr(),
+                                                 rids.data_ptr(), b_.data_ptr(), None)
+                    g.synchronize()
+                    own.append(b_)
+                glob_box[0] = torch.stack(own).min(dim=0).values.contiguous()
+                g.set_list_mask((owner == 0).astype(np.uint8))
+                print("two-phase: shard 0's own bound is the global one for %.1f %% of the queries; mean ratio global / own %.3f" % (
+                    100.0 * (own[0] == glob_box[0]).float().mean().item(),
+                    (glob_box[0] / own[0].clamp(min=1e-9)).clamp(max=1.0).mean().item()))
+
+            def reduce_cb(n, take_max):
+                with torch.cuda.stream(stream):
+                    bound.copy_(glob_box[0], non_blocking=True)
+
+            def estep2():
+                g.ivfpq_coarse_device(dqq.data_ptr(), nq, args, cdis.data_ptr(), probe.data_ptr())
+                g.ivfpq_search_shard_bounded(dqq.data_ptr(), gnq, cdis.data_ptr(), probe.data_ptr(), k, args, rdis.data_ptr(),
+                                             rids.data_ptr(), bound.data_ptr(), reduce_cb)
+                g.ivfpq_merge_rerank(W, nq, dqq.data_ptr(), k, args, rdis.data_ptr(), rids.data_ptr(), 0, nq, D2.data_ptr(), I2.data_ptr())
+            # the coarse call above overwrote rows [0, nq) of the assignment with shard 0's own slice: the same values
+        for two in two_modes:
+          step_fn = estep2 if two else estep
+          for Genv in os.environ.get("C4_EMUL_G1" if two else "C4_EMUL_G", "0").split(","):
+            if two and Genv != "0":
+                os.environ["GAMMA_HIP_SHARD_G1"] = Genv
+                print("GAMMA_HIP_SHARD_G1=%s:" % Genv, end=" ")
+            if two:
+                compute_glob()
+            _emul_measure(g, step_fn, two, Genv, W, sizes, owner, gnq, nq, base_ms)
+            os.environ.pop("GAMMA_HIP_SHARD_G1", None)
     g.set_list_mask(None)
 g.profile_enable(True)
 if os.environ.get("C4_DELETE"):   # 5 % of the documents deleted (the engine's delete bitmap): every search after it tests the bit
