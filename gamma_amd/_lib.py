@@ -124,6 +124,7 @@ SYMBOLS = {
     "gamma_hip_ivfpq_search_shard_bounded": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int,
                                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gamma_hip_bound_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "gamma_hip_ivfpq_merge_rerank": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int, C.c_int,
                                                C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                                C.c_int, C.c_void_p, C.c_void_p]),

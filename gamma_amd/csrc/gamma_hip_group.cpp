@@ -92,14 +92,16 @@ struct RcclApi {
     int (*CommInitAll)(void**, int, const int*) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
-    bool ok() const { return CommInitAll && CommDestroy && AllGather && Send && Recv && GroupStart && GroupEnd; }
+    bool ok() const { return CommInitAll && CommDestroy && AllGather && AllReduce && Send && Recv && GroupStart && GroupEnd; }
 };
 constexpr int kNcclChar = 0;   // ncclInt8: the exchanges are counted in bytes
+constexpr int kNcclFloat = 7, kNcclMax = 2, kNcclMin = 3;   // ncclFloat32, ncclMax, ncclMin (nccl.h)
 RcclApi* rccl_api() {
     static RcclApi api;
     static std::once_flag once;
@@ -113,6 +115,7 @@ RcclApi* rccl_api() {
         api.CommInitAll = reinterpret_cast<int (*)(void**, int, const int*)>(dlsym(l, "ncclCommInitAll"));
         api.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(l, "ncclCommDestroy"));
         api.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(l, "ncclAllGather"));
+        api.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(l, "ncclAllReduce"));
         api.Send = reinterpret_cast<int (*)(const void*, size_t, int, int, void*, hipStream_t)>(dlsym(l, "ncclSend"));
         api.Recv = reinterpret_cast<int (*)(void*, size_t, int, int, void*, hipStream_t)>(dlsym(l, "ncclRecv"));
         api.GroupStart = reinterpret_cast<int (*)()>(dlsym(l, "ncclGroupStart"));
@@ -131,7 +134,10 @@ struct gamma_hip_group {
     std::mutex mu;            // one group-level call at a time
     int next_enc = 0;         // members take turns encoding Add / Update batches
     bool replicate = false;   // gamma_hip_group_set_placement: every member holds every list, queries are split
-    int transport = getenv("GAMMA_HIP_GROUP_RCCL") ? 1 : 0;   // 0: peer copies; 1: RCCL where a communicator can be formed
+    // 0: peer copies; 1 (default since round 6; GAMMA_HIP_GROUP_RCCL=0 turns it off): RCCL wherever a communicator of the
+    // members' DISTINCT devices can be formed -- members sharing a device, a missing librccl.so or a failing
+    // ncclCommInitAll fall back to peer copies and say so (gamma_hip_group_transport)
+    int transport = (getenv("GAMMA_HIP_GROUP_RCCL") && atoi(getenv("GAMMA_HIP_GROUP_RCCL")) == 0) ? 0 : 1;
     std::vector<void*> comm;  // one per member once formed
     bool comm_tried = false;
     std::string transport_note;
@@ -141,7 +147,9 @@ struct gamma_hip_group {
         GBuf x, cdis, probe, rdis, rids, all_dis, all_ids, D, I;
         // exact ties across members: flagged queries' inputs (owner side / shard side), exports, the owner's copy of all exports
         GBuf fx, fcd, fpr, sx, scd, spr, ex_vals, ex_ids, ex_off, av, ai, ao, cutf, cutall;
-        hipEvent_t ev_coarse = nullptr, ev_scan = nullptr, ev_tie = nullptr;
+        // two-phase shard search: the bounds this member's scan exports (what its peers read), its working copy, a peer's
+        GBuf bound, bound_pub, bound_peer;
+        hipEvent_t ev_coarse = nullptr, ev_scan = nullptr, ev_tie = nullptr, ev_bound = nullptr;
     };
     std::vector<Member> mb;
 
@@ -237,6 +245,7 @@ int gamma_hip_group_create(const int* devices, int n, gamma_hip_group** out) {
         }
         if (hipEventCreateWithFlags(&g->mb[i].ev_coarse, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&g->mb[i].ev_tie, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&g->mb[i].ev_bound, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&g->mb[i].ev_scan, hipEventDisableTiming) != hipSuccess) {
             for (auto* mh : g->m) gamma_hip_destroy(mh);
             delete g;
@@ -266,6 +275,7 @@ int gamma_hip_group_destroy(gamma_hip_group* g) {
                         &b.scd, &b.spr, &b.ex_vals, &b.ex_ids, &b.ex_off, &b.av, &b.ai, &b.ao, &b.cutf, &b.cutall})
             p->release();
         if (b.ev_tie) (void)hipEventDestroy(b.ev_tie);
+        if (b.ev_bound) (void)hipEventDestroy(b.ev_bound);
         if (b.ev_coarse) (void)hipEventDestroy(b.ev_coarse);
         if (b.ev_scan) (void)hipEventDestroy(b.ev_scan);
     }
@@ -719,9 +729,51 @@ static int group_search(gamma_hip_group* g, const gamma_hip_search_params* p, in
                 hip(copy_between(b.probe.as<int32_t>() + (size_t)a0 * P, g->dev[i], g->mb[j].probe.as<int32_t>() + (size_t)a0 * P,
                                  g->dev[j], (size_t)(a1 - a0) * P * sizeof(int32_t), s), "assignment exchange");
             }
+            // The scan in TWO PHASES around a reduction of one float per query (gamma_hip_ivfpq_search_shard_bounded): every
+            // member bounds its own recall_num-th best from the query's nearest probes it owns, the minimum (L2) / maximum (IP)
+            // over the members bounds the GLOBAL one, and the members' other probes only keep what is within it.  The
+            // reduction: ncclAllReduce over xGMI, or -- peer copies -- every member publishes its bounds, the members meet at a
+            // barrier, pull each other's and combine.  It is one more meeting point of the call: a member that does not get
+            // as far as its scan arrives there all the same.
+            struct Red {
+                gamma_hip_group* g; int i, W; RcclApi* nccl; bool* ok_in; bool arrived; std::string* err;
+            } red{g, i, W, nccl, nullptr, false, &errs[i]};
+            bool my_ok = rc == GAMMA_HIP_OK;
+            red.ok_in = &my_ok;
+            auto reduce = [](void* user, float* d_bound, int n, int take_max, void* stream) -> int {
+                Red& r = *static_cast<Red*>(user);
+                gamma_hip_group* g = r.g;
+                auto& b = g->mb[r.i];
+                hipStream_t s = static_cast<hipStream_t>(stream);
+                r.arrived = true;
+                if (r.nccl) {
+                    const bool all = g->bar.arrive(*r.ok_in);   // (every member is about to enter the collective, or none does)
+                    if (!all) return 0;
+                    const int e = r.nccl->AllReduce(d_bound, d_bound, (size_t)n, kNcclFloat, take_max ? kNcclMax : kNcclMin, g->comm[r.i], s);
+                    if (e != 0) *r.err = std::string("ncclAllReduce: ") + (r.nccl->GetErrorString ? r.nccl->GetErrorString(e) : "RCCL error");
+                    return e != 0;
+                }
+                bool ok = *r.ok_in && b.bound_pub.ensure((size_t)n * sizeof(float)) == hipSuccess &&
+                          b.bound_peer.ensure((size_t)n * sizeof(float)) == hipSuccess;
+                ok = ok && hipMemcpyAsync(b.bound_pub.p, d_bound, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s) == hipSuccess &&
+                     hipEventRecord(b.ev_bound, s) == hipSuccess;
+                const bool all = g->bar.arrive(ok);   // every member's bounds are on its stream
+                if (!all) return ok ? 0 : 1;        // (the bounds stay this member's own: still valid)
+                for (int j = 0; j < r.W && ok; j++) {
+                    if (j == r.i) continue;
+                    ok = hipStreamWaitEvent(s, g->mb[j].ev_bound, 0) == hipSuccess &&
+                         copy_between(b.bound_peer.p, g->dev[r.i], g->mb[j].bound_pub.p, g->dev[j], (size_t)n * sizeof(float), s) == hipSuccess &&
+                         gamma_hip_bound_combine(stream, d_bound, b.bound_peer.as<float>(), n, take_max) == GAMMA_HIP_OK;
+                }
+                if (!ok) *r.err = "bound reduction: peer copy failed";
+                return ok ? 0 : 1;
+            };
+            hip(b.bound.ensure((size_t)nq * sizeof(float)), "alloc");
+            my_ok = rc == GAMMA_HIP_OK;
             if (rc == GAMMA_HIP_OK)
-                abi(gamma_hip_ivfpq_search_shard_preassigned(h, &pp, nq, b.x.as<float>(), b.cdis.as<float>(), b.probe.as<int32_t>(), k,
-                                                             b.rdis.as<float>(), b.rids.as<int64_t>()));
+                abi(gamma_hip_ivfpq_search_shard_bounded(h, &pp, nq, b.x.as<float>(), b.cdis.as<float>(), b.probe.as<int32_t>(), k,
+                                                         b.rdis.as<float>(), b.rids.as<int64_t>(), b.bound.as<float>(), reduce, &red));
+            if (!red.arrived) (void)g->bar.arrive(false);   // (this member never got to the reduction: its peers are waiting there)
             // did this member's own top-R cut of a query go through a tie?  (the merge at the query's owner asks)
             hip(b.cutf.ensure((size_t)nq), "alloc");
             if (rc == GAMMA_HIP_OK) abi(gamma_hip_ivfpq_shard_cut_flags(h, nq, b.cutf.as<uint8_t>()));

@@ -421,7 +421,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     static const int cap_env = getenv("GAMMA_HIP_SLICE_CAP") ? atoi(getenv("GAMMA_HIP_SLICE_CAP")) : 0;
     // (clamped to 2048: the selection and the tie replay hold one slice in LDS)
     const int cap = cap_env > 0 ? std::min(2048, std::max(cap_env, gh::scan_slice_cap(R))) : gh::scan_slice_cap(R);
-    bool cf_ok = false, q8_ok = false;
+    bool cf_ok = false, q8_ok = false, q8_fused = false;
     int PGM = PGN, nsl = PGN, cf_span = 0;
     unsigned long long* ready = nullptr;
     if (bounded) {
@@ -486,9 +486,14 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     }
     {
         StageScope t(h, GAMMA_HIP_STAGE_TABLES);
+        // two-phase list shard on the list-major pass: every consumer of the query tables computes them on the fly (the
+        // producers: IPF; k_q8_quant / k_q8_exact: fx) -- W x 32 KB per query through HBM otherwise; only the rows of the
+        // queries the repair launch re-scores are written (launch_pq_ip_table_rows below)
+        static const bool no_q8_fused = getenv("GAMMA_HIP_NO_Q8_FUSED_IP") != nullptr;
+        q8_fused = two && q8_ok && !no_q8_fused && (M == 16 || M == 32);
         if (!fuse_ip && !res) {
             GH_CHECK(h, h->w_st2.ensure((size_t)nq * M * 256 * sizeof(float)));
-            gh::launch_pq_ip_table(s, d_x, nq, d, M, h->d_pqc, h->w_st2.as<float>());
+            if (!q8_fused) gh::launch_pq_ip_table(s, d_x, nq, d, M, h->d_pqc, h->w_st2.as<float>());
         }
         GH_TRY(coarse_join(h));
         // a deferred replay of the previous call / chunk reads what is written from here on (flag lists, pair offsets,
@@ -637,7 +642,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
             gh::launch_ivfpq_scan_pair(s, l2, d_x, nq, d, M, P, h->w_probe.as<int>(), dis0, h->d_cc, h->scan_st2(l2), h->d_T2,
                                        h->d_list_off, h->d_list_len, h->d_list_mask, nlist, h->d_codes, h->d_ids,
                                        h->w_pair_off.as<int>(), q_stride, h->w_dist.as<float>(), fc.d_tab, fc.d_qf, need_ids, qperm, G, 0,
-                                       1, 0, &sb, nullptr);
+                                       1, 0, &sb, q8_fused ? h->d_pqc : nullptr);
             if (two) GH_TRY(exchange());   // (the list-major pass below reads the ready words: now the global bounds)
             GH_CHECK(h, h->w_q8.ensure((size_t)nq * M * 256));
             GH_CHECK(h, h->w_q8meta.ensure((size_t)nq * 4 * sizeof(float)));
@@ -649,6 +654,11 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
             qa.probe_list = h->w_probe.as<int>();
             qa.coarse_dis = dis0;
             qa.st2 = h->w_st2.as<float>();
+            if (q8_fused) {
+                qa.fx = d_x;
+                qa.pqc = h->d_pqc;
+                qa.d = d;
+            }
             qa.T2 = h->d_T2;
             qa.t2max = h->d_t2max;
             qa.sums = h->d_sums;
@@ -700,6 +710,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
             // (prod_cf: group 0 too -- its slab segment holds approximate values -- and for the queries without a bound as well)
             StageScope t2(h, GAMMA_HIP_STAGE_SCAN, false);
             if (sb.prod_cf) gh::launch_rq_nobound(s, sb.ready, nq, sb.rq_list, sb.rq_count);
+            if (q8_fused) gh::launch_pq_ip_table_rows(s, d_x, d, M, h->d_pqc, h->w_st2.as<float>(), sb.rq_list, sb.rq_count);
             gh::launch_ivfpq_scan_pair(s, l2, d_x, nq, d, M, P, h->w_probe.as<int>(), dis0, h->d_cc,
                                        h->scan_st2(l2), h->d_T2, h->d_list_off, h->d_list_len, h->d_list_mask,
                                        nlist, h->d_codes, h->d_ids, h->w_pair_off.as<int>(), q_stride,
@@ -1921,6 +1932,12 @@ int gamma_hip_ivfpq_search_shard_preassigned(gamma_hip_index* h, const gamma_hip
                                              const int32_t* d_probe, int k, float* d_recall_dis,
                                              int64_t* d_recall_ids) {
     return shard_preassigned(h, p, nq, d_x, d_coarse_dis, d_probe, k, d_recall_dis, d_recall_ids, nullptr);
+}
+
+int gamma_hip_bound_combine(void* stream, float* d_acc, const float* d_in, int n, int take_max) {
+    if (n < 0 || (n > 0 && (!d_acc || !d_in))) return GAMMA_HIP_EINVAL;
+    gh::launch_bound_combine(static_cast<hipStream_t>(stream), d_acc, d_in, n, take_max);
+    return hipGetLastError() == hipSuccess ? GAMMA_HIP_OK : GAMMA_HIP_EDEVICE;
 }
 
 int gamma_hip_ivfpq_search_shard_bounded(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,

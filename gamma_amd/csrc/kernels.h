@@ -161,6 +161,9 @@ void launch_compact_probes(hipStream_t s, const int* probe_in, const float* cdis
 void launch_bound_export(hipStream_t s, bool l2, const unsigned long long* ready, int nq, float* out);
 void launch_bound_import(hipStream_t s, bool l2, const float* in, int nq, unsigned long long* ready);
 void launch_fill_f32(hipStream_t s, float* p, int n, float v);
+void launch_bound_combine(hipStream_t s, float* acc, const float* in, int n, int take_max);
+void launch_pq_ip_table_rows(hipStream_t s, const float* x, int d, int M, const float* pqc, float* out, const int* rq_list,
+                             const int* rq_count);
 // inner-product scan: dis0[q][p] = <x_q, centroid of probe p> (fvec_inner_product order); the scan takes it
 // through its coarse_dis argument
 void launch_pair_ip(hipStream_t s, const float* x, const float* cc, const int* probe_list, int nq, int P, int d,
@@ -202,6 +205,9 @@ struct Q8Args {
     const int* probe_list;            // [nq][P]
     const float* coarse_dis;          // [nq][P] dis0
     const float* st2;                 // [nq][M][256] fp32 inner-product tables (k_pq_ip_table)
+    const float* fx = nullptr;        // != nullptr: no st2 -- the tables are computed from the queries [nq][d] and the codebook
+    const float* pqc = nullptr;
+    int d = 0;
     const float* T2;                  // [nlist][M][256]
     const float* t2max;               // [nlist]
     const float* sums;                // per arena entry: sum_m T2[list][m][code[m]]

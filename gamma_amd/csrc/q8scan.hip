@@ -66,9 +66,13 @@ int q8_cand_cap(int nq) {
 // u8 image of every query's inner-product table (k_pq_ip_table's st2): one workgroup per query, thread = code word c.
 // meta[q] = { cq = 2 sum_m lo_m + 1.02 M delta,  -2 delta,  max |entry|,  0 }
 // ------------------------------------------------------------------------------------
+// fx != nullptr (two-phase list shards, round 6): the table is not in memory -- a shard sees W times the queries of a rank, and
+// W x 32 KB per query written by k_pq_ip_table and read back here and by k_q8_exact was a tenth of its step -- the entries are
+// computed here from the query and the PQ codebook (128 KB, L2-resident), the arithmetic of k_pq_ip_table: identical values.
 template <int MT>
 __global__ __launch_bounds__(256) void k_q8_quant(const float* __restrict__ st2, uint8_t* __restrict__ q8,
-                                                  float4* __restrict__ meta) {
+                                                  float4* __restrict__ meta, const float* __restrict__ fx,
+                                                  const float* __restrict__ pqc, int d) {
     // wave w takes table rows w, w + 4, ..: a row is one 1 KB read of the wave (four code words per lane), its minimum and
     // maximum one wave reduction, its bytes one 256-byte store
     constexpr int NR = MT / 4;
@@ -76,8 +80,22 @@ __global__ __launch_bounds__(256) void k_q8_quant(const float* __restrict__ st2,
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     float4 v[NR];
     float lo[NR], range = 0.f, L = 0.f, amax = 0.f;
+    if (fx) {   // (uniform)
+        const int dsub = d / MT;
+        const float* xq = fx + (int64_t)q * d;
 #pragma unroll
-    for (int k = 0; k < NR; k++) v[k] = *reinterpret_cast<const float4*>(st2 + ((int64_t)q * MT + wv + 4 * k) * 256 + 4 * lane);
+        for (int k = 0; k < NR; k++) {
+            const int m = wv + 4 * k;
+            const float* c = pqc + ((int64_t)m * 256 + 4 * lane) * dsub;
+            v[k].x = fvec_ny_row<false>(xq + m * dsub, c, dsub);
+            v[k].y = fvec_ny_row<false>(xq + m * dsub, c + dsub, dsub);
+            v[k].z = fvec_ny_row<false>(xq + m * dsub, c + 2 * dsub, dsub);
+            v[k].w = fvec_ny_row<false>(xq + m * dsub, c + 3 * dsub, dsub);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NR; k++) v[k] = *reinterpret_cast<const float4*>(st2 + ((int64_t)q * MT + wv + 4 * k) * 256 + 4 * lane);
+    }
 #pragma unroll
     for (int k = 0; k < NR; k++) {
         float mn = fminf(fminf(v[k].x, v[k].y), fminf(v[k].z, v[k].w)), mx = fmaxf(fmaxf(v[k].x, v[k].y), fmaxf(v[k].z, v[k].w));
@@ -681,7 +699,7 @@ __global__ __launch_bounds__(256) void k_q8_exact(const float* __restrict__ st2,
                                                   const int* __restrict__ pair_off, const unsigned long long* __restrict__ ready,
                                                   const uint32_t* __restrict__ cand, const int* __restrict__ ccnt, int cand_cap,
                                                   unsigned long long* __restrict__ surv, int* __restrict__ gcnt, int cnt_stride,
-                                                  int slice_cap) {
+                                                  int slice_cap, const float* __restrict__ fx, const float* __restrict__ pqc, int d) {
     __shared__ float s_lut[MT * 256];
     __shared__ int s_cnt[64];   // survivors per probe group (slice pg holds the positions of probe group pg: the order the tie
                                 // replay walks the slices in, tie_dev.h)
@@ -698,7 +716,12 @@ __global__ __launch_bounds__(256) void k_q8_exact(const float* __restrict__ st2,
         return;
     }
     if (tid < 64) s_cnt[tid] = 0;
-    if (n > 0)
+    if (n > 0 && fx) {   // (the query's table computed here: k_q8_quant's note)
+        const int dsub = d / MT;
+        const float* xq = fx + (int64_t)q * d;
+#pragma unroll 4
+        for (int i = 0; i < MT; i++) s_lut[i * 256 + tid] = fvec_ny_row<false>(xq + i * dsub, pqc + ((int64_t)i * 256 + tid) * dsub, dsub);
+    } else if (n > 0)
         for (int e = tid; e < MT * 256; e += 256) s_lut[e] = st2[(int64_t)q * MT * 256 + e];
     __syncthreads();
     const float tau_f = key2f((uint32_t)word);
@@ -737,7 +760,7 @@ __global__ __launch_bounds__(256) void k_q8_exact(const float* __restrict__ st2,
     for (int g = 1 + tid; g < ngroups; g += 256) gcnt[(int64_t)q * cnt_stride + g] = s_cnt[g];
 }
 
-bool q8_supported(int M, int P, int G, int64_t q_stride) { return (M == 16 || M == 32) && P <= 128 && G >= 2 && /* (the caller checks nlist <= 16384: the per-list counters live in LDS) */ (P + G - 1) / G <= 64 && q_stride < ((int64_t)1 << Q8_POS_BITS); }
+bool q8_supported(int M, int P, int G, int64_t q_stride) { return (M == 16 || M == 32) && P <= 128 && G >= 1 && /* (the caller checks nlist <= 16384: the per-list counters live in LDS) */ (P + G - 1) / G <= 64 && q_stride < ((int64_t)1 << Q8_POS_BITS); }
 
 // workspace: ccnt nq (zeroed here) | hist Q8_NW x nlist | cnt nlist | off nlist+1 | tile_first nlist+1 | n_tiles 1 | pad |
 //            tile_list (int4) | recs (Q8Rec, 32 B)
@@ -763,8 +786,8 @@ void launch_q8_consumers(hipStream_t s, const Q8Args& a) {
     // (records are stored per tile, 8 slots each: the slots past a tile's pairs read q = -1)
     (void)hipMemsetAsync(recs, 0xff, (size_t)(pairs / Q8_T + nlist + 1) * Q8_T * sizeof(Q8Rec), s);
     const int cap = q8_cand_cap(nq);
-    if (M == 16) hipLaunchKernelGGL((k_q8_quant<16>), dim3(nq), dim3(256), 0, s, a.st2, a.q8, a.meta);
-    else hipLaunchKernelGGL((k_q8_quant<32>), dim3(nq), dim3(256), 0, s, a.st2, a.q8, a.meta);
+    if (M == 16) hipLaunchKernelGGL((k_q8_quant<16>), dim3(nq), dim3(256), 0, s, a.st2, a.q8, a.meta, a.fx, a.pqc, a.d);
+    else hipLaunchKernelGGL((k_q8_quant<32>), dim3(nq), dim3(256), 0, s, a.st2, a.q8, a.meta, a.fx, a.pqc, a.d);
     const size_t hl = (size_t)nlist * sizeof(int);
     hipLaunchKernelGGL((k_q8_hist<false>), dim3(Q8_NW), dim3(1024), hl, s, a.probe_list, nq, P, G, a.ready, a.list_len, a.list_mask,
                        nlist, hist, (Q8Rec*)nullptr, a.rq_list, a.rq_count, a.coarse_dis, a.t2max, a.meta, a.pair_off, off, tile_first);
@@ -795,12 +818,12 @@ void launch_q8_consumers(hipStream_t s, const Q8Args& a) {
         if (sl) GH_Q8F(k_q8_filter_sl, 16);
         else GH_Q8F(k_q8_filter, 16);
         hipLaunchKernelGGL((k_q8_exact<16>), dim3(nq), dim3(256), 0, s, a.st2, a.T2, nq, P, G, a.probe_list, a.coarse_dis, a.list_off,
-                           a.codes, a.pair_off, a.ready, a.cand, ccnt, cap, a.surv, a.gcnt, a.cnt_stride, a.slice_cap);
+                           a.codes, a.pair_off, a.ready, a.cand, ccnt, cap, a.surv, a.gcnt, a.cnt_stride, a.slice_cap, a.fx, a.pqc, a.d);
     } else {
         if (sl) GH_Q8F(k_q8_filter_sl, 32);
         else GH_Q8F(k_q8_filter, 32);
         hipLaunchKernelGGL((k_q8_exact<32>), dim3(nq), dim3(256), 0, s, a.st2, a.T2, nq, P, G, a.probe_list, a.coarse_dis, a.list_off,
-                           a.codes, a.pair_off, a.ready, a.cand, ccnt, cap, a.surv, a.gcnt, a.cnt_stride, a.slice_cap);
+                           a.codes, a.pair_off, a.ready, a.cand, ccnt, cap, a.surv, a.gcnt, a.cnt_stride, a.slice_cap, a.fx, a.pqc, a.d);
     }
 #undef GH_Q8F
     // a launch of this pass that did not start leaves ccnt at 0 and k_q8_exact would publish EMPTY consumer groups: never silent

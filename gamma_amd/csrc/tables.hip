@@ -281,16 +281,19 @@ __global__ __launch_bounds__(256) void k_max_local_total(const int* __restrict__
                                                          const uint8_t* __restrict__ list_mask, int nlist,
                                                          int* __restrict__ out_max) {
     // out_max[0]: the longest candidate row; out_max[1]: the most owned, non-empty probes any query has (the rows'
-    // length after k_compact_probes)
-    const int lane = threadIdx.x & 63;
+    // length after k_compact_probes).  One wave per query, the workgroup's four results combined in LDS: ONE pair of
+    // atomics per workgroup (a wave looping over eight queries behind dependent loads took 200 us per 65536 queries)
+    __shared__ int s_t[4], s_n[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int best = 0, bestn = 0;
-    for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < nq; q += gridDim.x * 4) {
+    for (int q = blockIdx.x * 4 + wv; q < nq; q += gridDim.x * 4) {
         int t = 0, n = 0;
         for (int p = lane; p < P; p += 64) {
             const int l = probe_list[(int64_t)q * P + p];
             if (l >= 0 && l < nlist && (!list_mask || list_mask[l])) {
-                t += max(list_len[l], 0);
-                n += list_len[l] > 0 ? 1 : 0;
+                const int len = list_len[l];
+                t += max(len, 0);
+                n += len > 0 ? 1 : 0;
             }
         }
 #pragma unroll
@@ -301,8 +304,17 @@ __global__ __launch_bounds__(256) void k_max_local_total(const int* __restrict__
         best = max(best, t);
         bestn = max(bestn, n);
     }
-    if (lane == 0 && best > 0) atomicMax(out_max, best);
-    if (lane == 0 && bestn > 0) atomicMax(out_max + 1, bestn);
+    if (lane == 0) {
+        s_t[wv] = best;
+        s_n[wv] = bestn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        best = max(max(s_t[0], s_t[1]), max(s_t[2], s_t[3]));
+        bestn = max(max(s_n[0], s_n[1]), max(s_n[2], s_n[3]));
+        if (best > 0) atomicMax(out_max, best);
+        if (bestn > 0) atomicMax(out_max + 1, bestn);
+    }
 }
 
 // Two-phase shard search (round 6): the bound a shard's producers published per query, as a float the caller reduces
@@ -336,6 +348,28 @@ void launch_bound_import(hipStream_t s, bool l2, const float* in, int nq, unsign
     if (l2) hipLaunchKernelGGL(k_bound_import<true>, dim3((nq + 255) / 256), dim3(256), 0, s, in, nq, ready);
     else hipLaunchKernelGGL(k_bound_import<false>, dim3((nq + 255) / 256), dim3(256), 0, s, in, nq, ready);
 }
+// st2 rows of the queries in a device list (the repair launch of a call whose tables were computed on the fly)
+__global__ __launch_bounds__(256) void k_pq_ip_table_rows(const float* __restrict__ x, int d, int M, const float* __restrict__ pqc,
+                                                          float* __restrict__ out, const int* __restrict__ rq_list,
+                                                          const int* __restrict__ rq_count) {
+    const int n = *rq_count, dsub = d / M, j = threadIdx.x;
+    for (int w = blockIdx.x; w < n; w += gridDim.x) {
+        const int q = rq_list[w];
+        for (int m = 0; m < M; m++)
+            out[((int64_t)q * M + m) * 256 + j] = fvec_ny_row<false>(x + (int64_t)q * d + m * dsub, pqc + ((int64_t)m * 256 + j) * dsub, dsub);
+    }
+}
+void launch_pq_ip_table_rows(hipStream_t s, const float* x, int d, int M, const float* pqc, float* out, const int* rq_list,
+                             const int* rq_count) {
+    hipLaunchKernelGGL(k_pq_ip_table_rows, dim3(1024), dim3(256), 0, s, x, d, M, pqc, out, rq_list, rq_count);
+}
+__global__ __launch_bounds__(256) void k_bound_combine(float* __restrict__ acc, const float* __restrict__ in, int n, int take_max) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) acc[i] = take_max ? fmaxf(acc[i], in[i]) : fminf(acc[i], in[i]);
+}
+void launch_bound_combine(hipStream_t s, float* acc, const float* in, int n, int take_max) {
+    if (n > 0) hipLaunchKernelGGL(k_bound_combine, dim3((n + 255) / 256), dim3(256), 0, s, acc, in, n, take_max);
+}
 __global__ __launch_bounds__(256) void k_fill_f32(float* __restrict__ p, int n, float v) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;
@@ -347,7 +381,7 @@ void launch_max_local_total(hipStream_t s, const int* probe_list, int nq, int P,
                             const uint8_t* list_mask, int nlist, int* out_max) {
     (void)hipMemsetAsync(out_max, 0, 2 * sizeof(int), s);
     if (nq > 0)
-        hipLaunchKernelGGL(k_max_local_total, dim3(std::min(2048, (nq + 3) / 4)), dim3(256), 0, s, probe_list, nq, P, list_len,
+        hipLaunchKernelGGL(k_max_local_total, dim3(std::min(16384, (nq + 3) / 4)), dim3(256), 0, s, probe_list, nq, P, list_len,
                            list_mask, nlist, out_max);
 }
 void launch_sum_totals(hipStream_t s, const int* q_total, int nq, unsigned long long* acc) {

@@ -7,8 +7,12 @@ runs in four steps:
 
   0. every rank: coarse quantizer for ITS query slice                (gamma_hip_ivfpq_coarse_device)
      + all-gather of the (distance, list) assignment, nq*nprobe*8 bytes in total
-  1. every rank: query tables for the whole batch, scan of the owned probed lists only, local
-     top-recall_num per query                            (gamma_hip_ivfpq_search_shard_preassigned)
+  1. every rank: scan of the owned probed lists only, in TWO PHASES around a min-all-reduce of one float per query
+     (gamma_hip_ivfpq_search_shard_bounded): the query's nearest owned probes bound the shard's recall_num-th best, the
+     bounds are reduced across the ranks -- every shard's bound is an upper bound of the GLOBAL recall_num-th best, so
+     the smallest one is too -- and the shard's other probes only keep what is within the global bound; local
+     top-recall_num per query from that            (GAMMA_DIST_TWO_PHASE=0: gamma_hip_ivfpq_search_shard_preassigned,
+     every shard against its own, W times looser bound)
   2. the one real exchange of the path: every rank sends each peer the candidates of the PEER'S
      query slice -- an RCCL all-to-all over xGMI, (nq/W)*R*(4+8) bytes per pair of GPUs, each
      pair on its own direct link (an all-gather of everything would move W times as much)
@@ -267,6 +271,7 @@ def _buffers(backend, world, pers, P, R, k):
                 rdis=backend.empty((world * per, R), f32), rids=backend.empty((world * per, R), i64),
                 all_dis=backend.empty((world * per, R), f32), all_ids=backend.empty((world * per, R), i64),
                 cutf=backend.empty((world * per,), u8), cutall=backend.empty((world * per,), u8),
+                bound=backend.empty((world * per,), f32),
                 res_l=res_l, I=res_l[:nres * 8].view(i64).view(per, k),
                 D=res_l[nres * 8:nres * 12].view(f32).view(per, k),
                 res=backend.empty((world, res_bytes), u8)))
@@ -375,6 +380,7 @@ def _sharded_search(backend, x, k, args, group, pipeline):
     nsub = pipeline or int(os.environ.get("GAMMA_DIST_PIPELINE", "0")) or (2 if world > 1 and nq >= 2 * world * MIN_SUB else 1)
     plan = plan_sub_batches(nq, world, nsub)
     pers = [max(1, -(-(e - s) // world)) for s, e in plan]
+    two_phase = hasattr(backend, "search_shard_bounded") and os.environ.get("GAMMA_DIST_TWO_PHASE", "1") != "0"
     stream_ctx = torch.cuda.stream(backend.stream) if hasattr(backend, "stream") else _Null()
     with stream_ctx:
         bufs = _buffers(backend, world, pers, P, R, k)
@@ -408,7 +414,15 @@ def _sharded_search(backend, x, k, args, group, pipeline):
             if n < world * per:     # padding rows carry no candidates
                 rdis[n:].zero_()
                 rids[n:].fill_(-1)
-            backend.search_shard(sb["x"], b["cdis"][:n], b["probe"][:n], k, args, rdis[:n], rids[:n])
+            if two_phase:
+                bound = b["bound"][:n]
+
+                def reduce(take_max, bound=bound):
+                    # (called once from inside the shard call, between its two phases, on the backend's stream)
+                    dist.all_reduce(bound, op=dist.ReduceOp.MAX if take_max else dist.ReduceOp.MIN, group=group)
+                backend.search_shard_bounded(sb["x"], b["cdis"][:n], b["probe"][:n], k, args, rdis[:n], rids[:n], bound, reduce)
+            else:
+                backend.search_shard(sb["x"], b["cdis"][:n], b["probe"][:n], k, args, rdis[:n], rids[:n])
             sb["w"] = _exchange(rdis, rids, b["all_dis"], b["all_ids"], group)
             if hasattr(backend, "shard_cut_flags") and args.p.exact_ties >= 0:
                 # did this shard's own top-R cut of a query go through a tie?  One byte per query to the query's owner

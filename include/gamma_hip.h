@@ -443,6 +443,10 @@ int gamma_hip_ivfpq_search_shard_bounded(gamma_hip_index* h, const gamma_hip_sea
                                          const int32_t* d_probe, int k, float* d_recall_dis,
                                          int64_t* d_recall_ids, float* d_bound,
                                          gamma_hip_bound_reduce_fn reduce, void* user);
+/* building block of a reduce callback without a collective library (the in-process group's peer-copy transport):
+ * d_acc[i] = min (take_max = 0) / max (1) of d_acc[i] and d_in[i], i < n, enqueued on `stream` of the calling thread's
+ * current device.  Takes no handle and no lock: it is called from inside _search_shard_bounded's callback. */
+int gamma_hip_bound_combine(void* stream, float* d_acc, const float* d_in, int n, int take_max);
 /* sharded search, stage 2: merge nshards*recall_num candidates per query (layout
  * [shard][nq][recall_num]) into the global top-recall_num, then compute_dis (re-rank or
  * truncate, gamma_index_ivfpq.cc:642-697) for queries [q0, q0+nq_local) */

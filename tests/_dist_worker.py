@@ -74,6 +74,43 @@ class OracleShardBackend:
         rdis[:] = torch.from_numpy(st["recall_dis"])
         rids[:] = torch.from_numpy(st["recall_ids"])
 
+    G1 = 2
+    n_tightened = 0
+
+    def search_shard_bounded(self, x, cdis, probe, k, args, rdis, rids, bound, reduce):
+        """the two phases of gamma_hip_ivfpq_search_shard_bounded restated on the oracle: the bound of this shard's
+        recall_num-th best from the query's nearest G1 probes it owns, the caller's reduction, the local candidates
+        within the reduced bound (best first, padded)"""
+        p = args.p
+        R = max(p.recall_num, k)
+        l2 = p.metric == B.METRIC_L2
+        ctx = B.make_ctx(min_score=p.min_score, max_score=p.max_score)
+        xs, pr, cd = x.numpy(), probe.numpy().astype(np.int64), cdis.numpy()
+        nq, P = pr.shape
+        own = np.array([self.o.list_size(l) > 0 for l in range(self.case["nlist"])])
+        p1, c1 = np.full((nq, P), -1, np.int64), np.zeros((nq, P), np.float32)
+        for qi in range(nq):
+            mine = [j for j in range(P) if pr[qi, j] >= 0 and own[pr[qi, j]]][:self.G1]
+            p1[qi, :len(mine)] = pr[qi, mine]
+            c1[qi, :len(mine)] = cd[qi, mine]
+        _, _, s1 = self.o.search(xs, k, P, recall_num=R, has_rank=False, metric=p.metric, ctx=ctx, want_stages=True,
+                                 preassigned=(c1, p1))
+        full = s1["recall_ids"][:, R - 1] >= 0
+        none = np.float32(np.inf if l2 else -np.inf)
+        bound[:] = torch.from_numpy(np.where(full, s1["recall_dis"][:, R - 1], none).astype(np.float32))
+        own_bound = bound.numpy().copy()
+        reduce(not l2)
+        _, _, st = self.o.search(xs, k, P, recall_num=R, has_rank=False, metric=p.metric, ctx=ctx, want_stages=True,
+                                 preassigned=(cd, pr))
+        self.n_tightened += int((bound.numpy() != own_bound).sum())
+        b = bound.numpy()[:, None]
+        rd, ri = st["recall_dis"].copy(), st["recall_ids"].copy()
+        drop = (ri < 0) | ((rd > b) if l2 else (rd < b))
+        rd[drop] = np.float32(3.4028235e38 if l2 else -3.4028235e38)
+        ri[drop] = -1
+        rdis[:] = torch.from_numpy(rd)
+        rids[:] = torch.from_numpy(ri)
+
     def merge_rerank(self, all_dis, all_ids, x, k, args, nql, D, I):
         p = args.p
         R = max(p.recall_num, k)
@@ -119,6 +156,13 @@ def main():
     for pipeline in (2, 3, None):
         D, I = gdist.sharded_search(be, x, k, args, pipeline=pipeline)
         compare_topk(Dr, Ir, D.numpy(), I.numpy())
+    # the single-phase shard scan (every shard against its own bound) gives the same table
+    os.environ["GAMMA_DIST_TWO_PHASE"] = "0"
+    D, I = gdist.sharded_search(be, x, k, args)
+    compare_topk(Dr, Ir, D.numpy(), I.numpy())
+    os.environ.pop("GAMMA_DIST_TWO_PHASE")
+    # the reduction did something: some query's global bound is tighter than this shard's own
+    assert be.n_tightened > 0 or world == 1
     # query-parallel over replicated lists: every rank answers its slice on the whole index, one all-gather
     class Full:
         def empty(self, shape, dtype):

@@ -285,6 +285,7 @@ int gamma_hip_ivfpq_search_device(gamma_hip_index* h, const gamma_hip_search_par
     return gamma_hip_ivfpq_search(h, p, nq, x, k, D, I);   // "device" memory is host memory here (fakehip)
 }
 /* list-shard entry points: not reached in replicate placement */
+int gamma_hip_bound_combine(void*, float*, const float*, int, int) { return GAMMA_HIP_EUNSUPPORTED; }
 int gamma_hip_ivfpq_search_shard_bounded(gamma_hip_index*, const gamma_hip_search_params*, int, const float*, const float*, const int32_t*,
                                          int, float*, int64_t*, float*, gamma_hip_bound_reduce_fn, void*) { return GAMMA_HIP_EUNSUPPORTED; }
 int gamma_hip_gather_rows(gamma_hip_index*, const void*, int, const int32_t*, int, void*) { return GAMMA_HIP_EUNSUPPORTED; }
