@@ -269,6 +269,37 @@ def main():
         recall = hits / float(nrq * k)
         log("[rank %d] recall@%d = %.4f over %d queries" % (rank, k, recall, nrq))
 
+    # both placements answer step 0: the list-sharded result table (two-phase scan, packed exchange, merge at the owners)
+    # must be the replicated one -- labels and distance bits -- so that a scaling run carries its own correctness bit
+    sharded_equals_replicated = None
+    exchange_per_step = None
+    if both:
+        set_placement(False)
+        backend.exchange_stats = {}
+        Ds0, Is0 = step(0, stream=False)
+        Ds0, Is0 = Ds0.clone(), Is0.clone()
+        es = backend.exchange_stats
+        backend.exchange_stats = None
+        set_placement(True)
+        Dr0, Ir0 = step(0, stream=False)
+        torch.cuda.synchronize()
+        same = torch.tensor([1 if (torch.equal(Is0, Ir0) and torch.equal(Ds0, Dr0)) else 0], dtype=torch.int32, device=dev)
+        if world > 1:
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        sharded_equals_replicated = bool(int(same.item()) == 1)
+        exchange_per_step = {"candidates_sent_by_rank_0_bytes": es.get("exchange_bytes"),
+                             "candidates_sent_by_rank_0_entries_per_query": None if not es.get("queries") else round(es["exchange_entries"] / es["queries"], 1),
+                             "whole_tables_would_be_bytes": (gnq // world) * R * 12 * (world - 1)}
+        log("[rank %d] sharded == replicated on step 0: %s" % (rank, sharded_equals_replicated))
+    elif use_dist and not replicate:
+        backend.exchange_stats = {}
+        step(0, stream=False)
+        es = backend.exchange_stats
+        backend.exchange_stats = None
+        exchange_per_step = {"candidates_sent_by_rank_0_bytes": es.get("exchange_bytes"),
+                             "candidates_sent_by_rank_0_entries_per_query": None if not es.get("queries") else round(es["exchange_entries"] / es["queries"], 1),
+                             "whole_tables_would_be_bytes": (gnq // world) * R * 12 * (world - 1)}
+
     # the streamed schedule of the replicated ranks against a plain call on the same batch, once, before anything is
     # timed: a mismatch on ANY rank sends every rank back to the plain schedule (replay at the end of each call)
     if rstream is not None:
@@ -672,6 +703,10 @@ def main():
                             nlist, M, N, d, a.nprobe, a.recall_num, str(not a.no_rank).lower(), k, gnq, a.nq),
             "recall_at_10": None if recall is None else round(recall, 4),
             "placement": None if not use_dist else ("replicate" if replicate else "shard"),
+            "sharded_equals_replicated": sharded_equals_replicated,
+            "communicator": None if not use_dist else {"backend": a.backend + (" (RCCL)" if a.backend == "nccl" else ""), "ranks": dist.get_world_size(),
+                                                       "devices": 1 if a.one_gpu else world},
+            "exchange_per_step": exchange_per_step,
             "sharded_qps": None if "shard" not in placement_qps else round(placement_qps["shard"], 1),
             "replicated_qps": None if "replicate" not in placement_qps else round(placement_qps["replicate"], 1),
             "parallelism": "single GPU" if world == 1 else (

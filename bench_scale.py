@@ -189,6 +189,13 @@ def run(a):
         recall = float(np.mean([len(set(Ih[i].tolist()) & set(If[i].tolist())) / float(k) for i in range(nrq)]))
         log("[rank 0] recall@%d = %.4f over %d queries at recall_num %d" % (k, recall, nrq, R))
 
+    # what this rank's candidate exchange carries in one step (two-phase scan + packed exchange: gamma_amd/dist.py)
+    backend.exchange_stats = {}
+    if not plain:
+        step(1)
+        torch.cuda.synchronize()
+    xst = backend.exchange_stats
+    backend.exchange_stats = None
     dt, prof = timed(args, a.steps, a.warmup)
     stages = {n: round(prof[n][0] / max(1, prof[n][1]) * 1e3, 1) for n in ("coarse", "tables", "scan", "select", "rerank") if prof[n][1]}
     scan_ms, scan_n = prof["scan"]
@@ -303,8 +310,14 @@ def run(a):
             "raw_placement": "replicated: %.1f GB of raw vectors on EVERY rank (re-rank at the slice's owner reads rows of every "
                              "shard's candidates); codes + ids + sums sharded" % (N * d * 4 / 1e9),
             "communicator": comm,
-            "exchange_bytes_per_step": {"assignment_all_gather": gnq * P * 8, "candidates_all_to_all_per_rank": (gnq // world) * R * 12 * (world - 1),
+            "exchange_bytes_per_step": {"assignment_all_gather": gnq * P * 8,
+                                        "candidates_all_to_all_per_rank": xst.get("exchange_bytes", (gnq // world) * R * 12 * (world - 1)),
+                                        "candidates_per_query_sent_by_rank_0": None if not xst.get("queries") else round(xst["exchange_entries"] / xst["queries"], 1),
+                                        "whole_tables_would_be_per_rank": (gnq // world) * R * 12 * (world - 1),
+                                        "bounds_all_reduce": gnq * 4, "tightening_all_reduce": gnq * 32 * 4 if l2 else 0,
                                         "results_all_gather": gnq * k * 12},
+            "shard_scan": "two phases around a min-all-reduce of one float per query (gamma_hip_ivfpq_search_shard_bounded); "
+                          "GAMMA_DIST_TWO_PHASE=0 / GAMMA_DIST_PACKED=0 for the round-5 path",
             "build": {"train_s": round(train_s, 2), "streamed_add_s": round(add_s, 1), "add_vec_per_s_per_rank": round(N / add_s, 0)},
             "recall_at_10": recall, "recall_queries": nrq,
             "per_rank": [json.loads(s) for s in per_rank],

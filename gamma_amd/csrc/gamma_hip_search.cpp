@@ -489,8 +489,12 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         // two-phase list shard on the list-major pass: every consumer of the query tables computes them on the fly (the
         // producers: IPF; k_q8_quant / k_q8_exact: fx) -- W x 32 KB per query through HBM otherwise; only the rows of the
         // queries the repair launch re-scores are written (launch_pq_ip_table_rows below)
-        static const bool no_q8_fused = getenv("GAMMA_HIP_NO_Q8_FUSED_IP") != nullptr;
-        q8_fused = two && q8_ok && !no_q8_fused && (M == 16 || M == 32);
+        // MEASURED SLOWER and off by default (GAMMA_HIP_Q8_FUSED_IP=1): an entry of the table is 4 bytes, the dsub = 4 codebook
+        // row it is made from 16 -- every workgroup pulling the 128 KB codebook through the L2 costs more than the 32 KB table
+        // from HBM (one emulated rank of 8, C4 shape 20 M: tables 0.49 -> 0.05 ms but scan 4.35 -> 5.5).  What does pay is
+        // k_q8_exact computing only its candidates' entries (Q8Args::xd).
+        static const bool q8_fused_on = getenv("GAMMA_HIP_Q8_FUSED_IP") != nullptr;
+        q8_fused = two && q8_ok && q8_fused_on && (M == 16 || M == 32);
         if (!fuse_ip && !res) {
             GH_CHECK(h, h->w_st2.ensure((size_t)nq * M * 256 * sizeof(float)));
             if (!q8_fused) gh::launch_pq_ip_table(s, d_x, nq, d, M, h->d_pqc, h->w_st2.as<float>());
@@ -654,11 +658,11 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
             qa.probe_list = h->w_probe.as<int>();
             qa.coarse_dis = dis0;
             qa.st2 = h->w_st2.as<float>();
-            if (q8_fused) {
-                qa.fx = d_x;
-                qa.pqc = h->d_pqc;
-                qa.d = d;
-            }
+            if (q8_fused) qa.fx = d_x;
+            static const bool no_demand = getenv("GAMMA_HIP_NO_Q8_DEMAND") != nullptr;
+            if (shard && !no_demand) qa.xd = d_x;
+            qa.pqc = h->d_pqc;
+            qa.d = d;
             qa.T2 = h->d_T2;
             qa.t2max = h->d_t2max;
             qa.sums = h->d_sums;
@@ -1892,6 +1896,16 @@ static int shard_preassigned(gamma_hip_index* h, const gamma_hip_search_params* 
         h->q_stride_cap = (std::max<int64_t>(mx[0], 1) + 3) & ~(int64_t)3;
         const int64_t by_dist = (int64_t)(h->dist_budget_bytes / ((size_t)h->q_stride_cap * sizeof(float)));
         chunk = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(by_dist, coarse_chunk(h, nq)), nq));
+        if (bx && !no_two && chunk < nq && (int64_t)nq <= coarse_chunk(h, nq)) {
+            // Two phases need the batch in ONE chunk (one reduction per call).  The slab of a W-rank job's batch -- W x the
+            // queries of a rank, each with its longest-case row -- can exceed the general workspace budget (full-size C4, 8
+            // shards: ~40 GB against 32); a list shard holds 1 / W of the index, so the memory is there: up to half of what
+            // is free now (the workspace stays allocated for the calls that follow).
+            size_t free_b = 0, total_b = 0;
+            const size_t need = (size_t)nq * (size_t)h->q_stride_cap * sizeof(float);
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= h->w_dist.cap + free_b / 2) chunk = nq;
+            else (void)hipGetLastError();
+        }
         if (bx && !no_two && chunk >= nq) {
             // two phases (ivfpq_stage_a, BoundXchg): the batch runs as ONE chunk, so the reduction is one collective; the scan
             // behind sees a search of P' probes -- the most owned probes any query of the batch has -- all of them dense

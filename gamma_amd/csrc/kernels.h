@@ -208,6 +208,8 @@ struct Q8Args {
     const float* fx = nullptr;        // != nullptr: no st2 -- the tables are computed from the queries [nq][d] and the codebook
     const float* pqc = nullptr;
     int d = 0;
+    const float* xd = nullptr;        // != nullptr (with pqc, d): k_q8_exact computes the table entries of a query's candidates on
+                                      // demand when they are few -- the queries [nq][d]
     const float* T2;                  // [nlist][M][256]
     const float* t2max;               // [nlist]
     const float* sums;                // per arena entry: sum_m T2[list][m][code[m]]

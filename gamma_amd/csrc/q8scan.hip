@@ -41,6 +41,7 @@ namespace gh {
 
 namespace {
 constexpr int Q8_T = 8;          // queries per tile
+constexpr int Q8_DEMAND_MAX = 40;   // k_q8_exact: candidates of a query up to which their table entries are computed on demand
 // LUT entries per sub-quantizer row: 256 + one pad per 8 at M = 16 (conflict-free staging stores; 36 KB, four workgroups
 // per CU).  M = 32 goes without the pad (64 KB + the pool = two workgroups per CU; its lists are long, the staging amortised)
 template <int MT> struct Q8Lut {
@@ -699,7 +700,8 @@ __global__ __launch_bounds__(256) void k_q8_exact(const float* __restrict__ st2,
                                                   const int* __restrict__ pair_off, const unsigned long long* __restrict__ ready,
                                                   const uint32_t* __restrict__ cand, const int* __restrict__ ccnt, int cand_cap,
                                                   unsigned long long* __restrict__ surv, int* __restrict__ gcnt, int cnt_stride,
-                                                  int slice_cap, const float* __restrict__ fx, const float* __restrict__ pqc, int d) {
+                                                  int slice_cap, const float* __restrict__ fx, const float* __restrict__ pqc, int d,
+                                                  const float* __restrict__ xd) {
     __shared__ float s_lut[MT * 256];
     __shared__ int s_cnt[64];   // survivors per probe group (slice pg holds the positions of probe group pg: the order the tie
                                 // replay walks the slices in, tie_dev.h)
@@ -716,14 +718,20 @@ __global__ __launch_bounds__(256) void k_q8_exact(const float* __restrict__ st2,
         return;
     }
     if (tid < 64) s_cnt[tid] = 0;
-    if (n > 0 && fx) {   // (the query's table computed here: k_q8_quant's note)
-        const int dsub = d / MT;
+    // Few candidates (a list shard sees W times the queries with ~1 / W of their candidates each): the M table entries of a
+    // candidate are computed ON DEMAND from the query and the codebook -- n x M x dsub floats from the L2-resident codebook
+    // instead of the query's whole 4 M KB table from HBM (k_pq_ip_table's arithmetic: the identical value)
+    const bool demand = xd != nullptr && n > 0 && n <= Q8_DEMAND_MAX;
+    const bool fused = !demand && n > 0 && fx != nullptr;
+    const int dsub = d > 0 ? d / MT : 1;
+    if (fused) {   // (opt-in: the query's whole table computed here, k_q8_quant's note)
         const float* xq = fx + (int64_t)q * d;
 #pragma unroll 4
         for (int i = 0; i < MT; i++) s_lut[i * 256 + tid] = fvec_ny_row<false>(xq + i * dsub, pqc + ((int64_t)i * 256 + tid) * dsub, dsub);
-    } else if (n > 0)
+    } else if (n > 0 && !demand)
         for (int e = tid; e < MT * 256; e += 256) s_lut[e] = st2[(int64_t)q * MT * 256 + e];
     __syncthreads();
+    const float* xq = (demand ? xd : fx) ? (demand ? xd : fx) + (int64_t)q * d : nullptr;
     const float tau_f = key2f((uint32_t)word);
     for (int c = tid; c < n; c += 256) {
         const uint32_t cd = cand[(int64_t)q * cand_cap + c];
@@ -746,8 +754,12 @@ __global__ __launch_bounds__(256) void k_q8_exact(const float* __restrict__ st2,
 #pragma unroll
             for (int m = 0; m < 8; m++) a[m] = t2[(m0 + m) * 256 + ((cw[(m0 + m) >> 2] >> (8 * (m & 3))) & 255u)];
 #pragma unroll
-            for (int m = 0; m < 8; m++)   // the regular loop's table entry and its adds, in the reference's order
-                dis += __builtin_fmaf(-2.0f, s_lut[(m0 + m) * 256 + ((cw[(m0 + m) >> 2] >> (8 * (m & 3))) & 255u)], a[m]);
+            for (int m = 0; m < 8; m++) {   // the regular loop's table entry and its adds, in the reference's order
+                const uint32_t cb = (cw[(m0 + m) >> 2] >> (8 * (m & 3))) & 255u;
+                const float ip = demand ? fvec_ny_row<false>(xq + (m0 + m) * dsub, pqc + ((int64_t)(m0 + m) * 256 + cb) * dsub, dsub)
+                                        : s_lut[(m0 + m) * 256 + cb];
+                dis += __builtin_fmaf(-2.0f, ip, a[m]);
+            }
         }
         if (dis <= tau_f) {
             const int g = p / G;
@@ -818,12 +830,12 @@ void launch_q8_consumers(hipStream_t s, const Q8Args& a) {
         if (sl) GH_Q8F(k_q8_filter_sl, 16);
         else GH_Q8F(k_q8_filter, 16);
         hipLaunchKernelGGL((k_q8_exact<16>), dim3(nq), dim3(256), 0, s, a.st2, a.T2, nq, P, G, a.probe_list, a.coarse_dis, a.list_off,
-                           a.codes, a.pair_off, a.ready, a.cand, ccnt, cap, a.surv, a.gcnt, a.cnt_stride, a.slice_cap, a.fx, a.pqc, a.d);
+                           a.codes, a.pair_off, a.ready, a.cand, ccnt, cap, a.surv, a.gcnt, a.cnt_stride, a.slice_cap, a.fx, a.pqc, a.d, a.xd);
     } else {
         if (sl) GH_Q8F(k_q8_filter_sl, 32);
         else GH_Q8F(k_q8_filter, 32);
         hipLaunchKernelGGL((k_q8_exact<32>), dim3(nq), dim3(256), 0, s, a.st2, a.T2, nq, P, G, a.probe_list, a.coarse_dis, a.list_off,
-                           a.codes, a.pair_off, a.ready, a.cand, ccnt, cap, a.surv, a.gcnt, a.cnt_stride, a.slice_cap, a.fx, a.pqc, a.d);
+                           a.codes, a.pair_off, a.ready, a.cand, ccnt, cap, a.surv, a.gcnt, a.cnt_stride, a.slice_cap, a.fx, a.pqc, a.d, a.xd);
     }
 #undef GH_Q8F
     // a launch of this pass that did not start leaves ccnt at 0 and k_q8_exact would publish EMPTY consumer groups: never silent

@@ -37,6 +37,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+METRIC_IP, METRIC_L2 = 0, 1   # gamma_hip_search_params.metric (include/gamma_hip.h)
+
 
 def balance_lists(list_sizes, nshards):
     """owner[l] by greedy longest-processing-time on list size: probe popularity follows list
@@ -287,6 +289,85 @@ def _exchange(rdis, rids, all_dis, all_ids, group):
             dist.all_to_all_single(all_ids, rids, group=group, async_op=True)]
 
 
+NB_TIGHTEN = 32   # edges per query of the second, tightening reduction (L2)
+
+
+def _packed_exchange(backend, rdis, rids, bound, n, world, per, R, l2, all_dis, all_ids, group, stats):
+    """The exchange of a two-phase step, PACKED: what a shard holds beyond the global bound cannot be in the global
+    top-recall_num, so only the entries within it travel -- about recall_num per query over ALL shards instead of W x
+    recall_num.  (1) L2: the bound is tightened first -- every shard counts its entries under 32 edges between 0 and
+    the bound, the counts are sum-all-reduced (nq x 32 ints) and the lowest edge under which at least recall_num
+    entries lie is the new bound: it still bounds the global recall_num-th best, now from all W shards' candidates
+    instead of the best shard's producers'.  (2) every shard packs its entries within the bound, query by query; the
+    W x W table of block sizes is all-gathered and read by the host (the one synchronisation of the path) and the blocks
+    go out in one all-to-all with exact split sizes, next to the per-query counts (fixed size).  (3) the receiver
+    unpacks into the [W, per, R] layout the merge takes, padding with (sentinel, -1): the merge, the cut flags and the
+    tie phase are unchanged.  rdis / rids: [W * per, R] (rows >= n are padding), bound: [W * per] floats (n valid)."""
+    dev_long = torch.int64
+    rows = world * per
+    tau = bound
+    valid = rids >= 0
+    if rows > n:
+        valid[n:] = False
+    if l2:
+        # tightening: edges tau * j / NB, j = 1 .. NB (the last one is tau itself); rows are sorted ascending
+        pos = torch.isfinite(tau) & (tau > 0)
+        frac = torch.arange(1, NB_TIGHTEN + 1, device=tau.device, dtype=torch.float32) / NB_TIGHTEN
+        edges = torch.where(pos, tau, torch.zeros_like(tau))[:, None] * frac[None, :]
+        cnt_e = torch.searchsorted(rdis, edges, right=True).to(torch.int32)
+        if rows > n:
+            cnt_e[n:] = 0
+        if world > 1:
+            dist.all_reduce(cnt_e, op=dist.ReduceOp.SUM, group=group)
+        ok = cnt_e >= R
+        j = ok.to(torch.int32).argmax(dim=1, keepdim=True)
+        tight = torch.where(ok.any(dim=1) & pos, edges.gather(1, j.to(dev_long)).squeeze(1), tau)
+        within = valid & (rdis <= tight[:, None])
+    else:
+        within = valid & (rdis >= tau[:, None])
+    cnt = within.sum(dim=1, dtype=torch.int32)                      # [rows] entries of every query that travel
+    blk = cnt.view(world, per).sum(dim=1, dtype=dev_long)            # [W] block sizes: what goes to each owner
+    table = torch.empty((world, world), dtype=dev_long, device=blk.device)
+    if world > 1:
+        dist.all_gather_into_tensor(table.view(-1), blk, group=group)
+    else:
+        table[0] = blk
+    rank = dist.get_rank(group) if world > 1 else 0
+    th = table.cpu()                                                 # the host needs the split sizes
+    send = [int(v) for v in th[rank]]
+    recv = [int(v) for v in th[:, rank]]
+    pk_dis = rdis[within]                                            # row-major: by owner, query, rank
+    pk_ids = rids[within]
+    rc_dis = torch.empty((sum(recv),), dtype=rdis.dtype, device=rdis.device)
+    rc_ids = torch.empty((sum(recv),), dtype=rids.dtype, device=rids.device)
+    rc_cnt = torch.empty((world, per), dtype=torch.int32, device=cnt.device)
+    if world > 1:
+        w = [dist.all_to_all_single(rc_cnt.view(-1), cnt, group=group, async_op=True),
+             dist.all_to_all_single(rc_dis, pk_dis, output_split_sizes=recv, input_split_sizes=send, group=group, async_op=True),
+             dist.all_to_all_single(rc_ids, pk_ids, output_split_sizes=recv, input_split_sizes=send, group=group, async_op=True)]
+        for x in w:
+            x.wait()
+    else:
+        rc_cnt.view(-1).copy_(cnt)
+        rc_dis, rc_ids = pk_dis, pk_ids
+    # unpack: entry e of the received stream belongs to row rowid[e] (shard-major, then query) at column e - start[row]
+    flat_cnt = rc_cnt.view(-1).to(dev_long)
+    start = torch.cumsum(flat_cnt, 0) - flat_cnt
+    total = sum(recv)
+    all_dis.fill_(3.4028234663852886e38 if l2 else -3.4028234663852886e38)
+    all_ids.fill_(-1)
+    if total > 0:
+        rowid = torch.repeat_interleave(torch.arange(world * per, device=flat_cnt.device), flat_cnt, output_size=total)
+        col = torch.arange(total, device=flat_cnt.device) - start[rowid]
+        all_dis.view(world * per, R)[rowid, col] = rc_dis
+        all_ids.view(world * per, R)[rowid, col] = rc_ids
+    if stats is not None:
+        stats["exchange_entries"] = stats.get("exchange_entries", 0) + sum(send) - send[rank]
+        stats["exchange_bytes"] = stats.get("exchange_bytes", 0) + (sum(send) - send[rank]) * 12 + (world - 1) * per * 4 + \
+            (rows * NB_TIGHTEN * 4 if l2 else 0)
+        stats["queries"] = stats.get("queries", 0) + n
+
+
 def plan_sub_batches(nq, world, nsub):
     """[(first query, end query)] of the contiguous sub-batches.  All but the last hold a multiple of
     `world` queries, so their gathered result rows carry no padding and the whole result stays one
@@ -381,6 +462,8 @@ def _sharded_search(backend, x, k, args, group, pipeline):
     plan = plan_sub_batches(nq, world, nsub)
     pers = [max(1, -(-(e - s) // world)) for s, e in plan]
     two_phase = hasattr(backend, "search_shard_bounded") and os.environ.get("GAMMA_DIST_TWO_PHASE", "1") != "0"
+    packed = two_phase and os.environ.get("GAMMA_DIST_PACKED", "1") != "0"
+    stats = getattr(backend, "exchange_stats", None)   # a dict the caller hangs on the backend: entries / bytes this rank sent
     stream_ctx = torch.cuda.stream(backend.stream) if hasattr(backend, "stream") else _Null()
     with stream_ctx:
         bufs = _buffers(backend, world, pers, P, R, k)
@@ -423,7 +506,16 @@ def _sharded_search(backend, x, k, args, group, pipeline):
                 backend.search_shard_bounded(sb["x"], b["cdis"][:n], b["probe"][:n], k, args, rdis[:n], rids[:n], bound, reduce)
             else:
                 backend.search_shard(sb["x"], b["cdis"][:n], b["probe"][:n], k, args, rdis[:n], rids[:n])
-            sb["w"] = _exchange(rdis, rids, b["all_dis"], b["all_ids"], group)
+            if two_phase and packed:
+                _packed_exchange(backend, rdis, rids, b["bound"], n, world, per, R, args.p.metric == METRIC_L2,
+                                 b["all_dis"], b["all_ids"], group, stats)
+                sb["w"] = []
+            else:
+                sb["w"] = _exchange(rdis, rids, b["all_dis"], b["all_ids"], group)
+                if stats is not None:
+                    stats["exchange_entries"] = stats.get("exchange_entries", 0) + (world - 1) * per * R
+                    stats["exchange_bytes"] = stats.get("exchange_bytes", 0) + (world - 1) * per * R * 12
+                    stats["queries"] = stats.get("queries", 0) + n
             if hasattr(backend, "shard_cut_flags") and args.p.exact_ties >= 0:
                 # did this shard's own top-R cut of a query go through a tie?  One byte per query to the query's owner
                 if n < world * per:

@@ -156,6 +156,21 @@ def main():
     for pipeline in (2, 3, None):
         D, I = gdist.sharded_search(be, x, k, args, pipeline=pipeline)
         compare_topk(Dr, Ir, D.numpy(), I.numpy())
+    # the packed exchange carries what lies within the (tightened) global bound: about recall_num entries per query over
+    # ALL shards, not world x recall_num; the plain all-to-all of whole tables gives the same result
+    be.exchange_stats = {}
+    D, I = gdist.sharded_search(be, x, k, args, pipeline=1)
+    compare_topk(Dr, Ir, D.numpy(), I.numpy())
+    st = be.exchange_stats
+    per_q = st["exchange_entries"] / float(st["queries"])
+    assert per_q < 1.3 * R * (world - 1) / world, (per_q, R, world)     # this rank's share of ~ R (+ one edge's worth) per query
+    os.environ["GAMMA_DIST_PACKED"] = "0"
+    be.exchange_stats = {}
+    D, I = gdist.sharded_search(be, x, k, args, pipeline=1)
+    compare_topk(Dr, Ir, D.numpy(), I.numpy())
+    assert be.exchange_stats["exchange_entries"] >= (world - 1) * R * (len(x) // world)
+    os.environ.pop("GAMMA_DIST_PACKED")
+    be.exchange_stats = None
     # the single-phase shard scan (every shard against its own bound) gives the same table
     os.environ["GAMMA_DIST_TWO_PHASE"] = "0"
     D, I = gdist.sharded_search(be, x, k, args)
