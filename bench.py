@@ -480,6 +480,36 @@ def main():
                                                      "recall_num_cut_ties": round(ts["cut_ties"] / nst, 1),
                                                      "queries_replayed": round(ts["replayed"] / nst, 1)},
                                "batch": gnq}
+        # (a'') TWO (and three) caller threads on the one handle, every call COMPLETE when it returns to its caller
+        #       (gamma_hip_ivfpq_search_device_wait): one caller's tie replay runs beside the other's coarse quantizer, query
+        #       tables and scan -- the reference's own calling pattern (re-entrant Search, tests/test.h:1033-1062)
+        import threading
+        callers = {}
+        for T in (1, 2, 3):
+            per_t = max(8, 48 // T)
+            bufs = [(torch.empty((gnq, k), dtype=torch.float32, device=dev), torch.empty((gnq, k), dtype=torch.int64, device=dev)) for _ in range(T)]
+
+            def caller(t, n):
+                for i in range(n):
+                    xb = d_q[((t + i) % nbatches) * gnq:((t + i) % nbatches + 1) * gnq]
+                    g.ivfpq_search_device_wait(xb.data_ptr(), gnq, k, args, bufs[t][0].data_ptr(), bufs[t][1].data_ptr())
+            for t in range(T):
+                caller(t, 2)
+            th = [threading.Thread(target=caller, args=(t, per_t)) for t in range(T)]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for x_ in th:
+                x_.start()
+            for x_ in th:
+                x_.join()
+            el = time.perf_counter() - t0
+            callers[str(T)] = {"qps": round(T * per_t * gnq / el, 1), "ms_per_call_per_caller": round(el / per_t * 1e3, 4)}
+        # the last call of caller 0 against the plain call on the same batch
+        xb = d_q[((0 + per_t - 1) % nbatches) * gnq:((0 + per_t - 1) % nbatches + 1) * gnq]
+        g.ivfpq_search_device(xb.data_ptr(), gnq, k, args, d_D.data_ptr(), d_I.data_ptr())
+        torch.cuda.synchronize()
+        callers["identical_to_the_plain_call"] = bool(torch.equal(bufs[0][1], d_I) and torch.equal(bufs[0][0], d_D))
+        extra["exact_ties"]["caller_threads_each_call_complete_on_return"] = callers
         # (b) batch sizes of the BASELINE.md protocol: one Search call of nq queries, device buffers
         byb = {}
         for nqb in [int(v) for v in a.batches.split(",")]:
@@ -731,6 +761,11 @@ def main():
             "pcie_inclusive_qps": None if host_qps is None else round(host_qps, 1),
             "labels_equal_to_cpu_baseline": labels_vs_cpu,
             "plugin": plugin_leg,
+            # T closed-loop client threads x ONE query per Search call -- the HIPIVFPQ plugin (host buffers,
+            # through RetrievalModel::Search) beside the compiled faiss 1.7.1 + re-rank under the same T on this box's host cores
+            "closed_loop": {"pattern": "T client threads x 1 query per call (tools/perf.cc:364-395)",
+                            "plugin_HIPIVFPQ": (plugin_leg or {}).get("closed_loop_threads_x_1_query") if isinstance(plugin_leg, dict) else None,
+                            "cpu_reference_faiss": (cpu or {}).get("closed_loop_threads_x_1_query") if isinstance(cpu, dict) else None},
             **extra,
         },
         "roofline": {
@@ -793,6 +828,18 @@ def spawn_ranks(n):
     return rc
 
 
+def _closed_loop_threads():
+    """T of the closed-loop legs: 1, 8 and as many client threads as this process has cores (CPU quota respected)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+    try:
+        qv, pv = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if qv != "max":
+            n = min(n, max(1, int(round(float(qv) / float(pv)))))
+    except Exception:
+        pass
+    return sorted({1, 8, max(1, n)})
+
+
 def plugin_bench(a, base, queries, cc, pq, g, d_q, d_D, d_I, k, args):
     """HIPIVFPQ behind the reference's plugin interface (index/retrieval_model.h:218-310; vector/vector_manager.cc:161-349,
     433-617): Init -> (store) -> Indexing -> Add in batches of 10 000 -> Search with the caller's host buffers."""
@@ -836,6 +883,18 @@ def plugin_bench(a, base, queries, cc, pq, g, d_q, d_D, d_I, k, args):
             out["search_%d" % nqb] = {"qps": round(nqb / sec, 1), "ms_per_call": round(sec * 1e3, 4),
                                       "ms_per_call_mean": round(float(np.mean(ts)) * 1e3, 4),
                                       "identical_to_the_device_pointer_call": same}
+        # the reference's own load pattern (tools/perf.cc:364-395): T closed-loop client threads, ONE query
+        # per Search call, through the plugin boundary (C++ threads in the harness: no GIL).  Concurrent small calls share
+        # device batches (gamma_hip_combine.cpp).
+        cl = {}
+        pool = np.ascontiguousarray(queries[:4096])
+        for T in _closed_loop_threads():
+            calls = max(150, 6000 // T)
+            dtc, lat = m.concurrent_clients(pool, rp, T, calls, k=k, has_rank=not a.no_rank)
+            lat = np.sort(lat)
+            cl[str(T)] = {"qps": round(T * calls / dtc, 1), "p50_us": round(float(np.median(lat)), 1),
+                          "p99_us": round(float(lat[int(0.99 * (len(lat) - 1))]), 1), "calls": int(len(lat))}
+        out["closed_loop_threads_x_1_query"] = cl
     finally:
         m.close()
     return out
@@ -939,6 +998,40 @@ def cpu_baseline(a, base, queries, cc, pq, g, lno, codes, list_sizes, gpu_res=No
                          "identical_to_gamma_order_on_the_librarys_coarse_assignment": round(float((Io == Ig).all(axis=1).mean()), 6),
                          "distance_bits_identical": round(float((Do.view(np.uint32) == Dg.view(np.uint32)).all(axis=1).mean()), 6)}
                 log("cpu baseline: label agreement with the device on batch 0: %s" % json.dumps(agree))
+            # the same library under the reference's closed-loop pattern (T client threads x 1 query per call: ctypes drops the
+            # GIL for the call; OpenMP to one thread per call -- a one-query call has one iteration to hand out) and at the
+            # 1024-query batch of BASELINE.md 3
+            closed = {}
+            try:
+                import threading
+                set_threads(1)
+                for T in _closed_loop_threads():
+                    lats = [[] for _ in range(T)]
+                    stop_at = time.perf_counter() + 1.5
+
+                    def client(t):
+                        set_threads(1)   # (the OpenMP thread-count setting is per calling thread: a new thread starts from the default)
+                        i = t * 977
+                        while time.perf_counter() < stop_at:
+                            t1 = time.perf_counter()
+                            r.search_rerank(queries[i % a.nq:i % a.nq + 1], a.k, a.recall_num, a.nprobe, base)
+                            lats[t].append(time.perf_counter() - t1)
+                            i += 1
+                    th = [threading.Thread(target=client, args=(t,)) for t in range(T)]
+                    t1 = time.perf_counter()
+                    for x_ in th:
+                        x_.start()
+                    for x_ in th:
+                        x_.join()
+                    el_c = time.perf_counter() - t1
+                    lat = np.sort(np.concatenate([np.asarray(v) for v in lats])) * 1e6
+                    closed[str(T)] = {"qps": round(len(lat) / el_c, 1), "p50_us": round(float(np.median(lat)), 1),
+                                      "p99_us": round(float(lat[int(0.99 * (len(lat) - 1))]), 1), "calls": int(len(lat))}
+            finally:
+                set_threads(cores)
+            q1024 = timed(lambda b: r.search_rerank(queries[(b * 1024) % (a.nq - 1024):(b * 1024) % (a.nq - 1024) + 1024], a.k,
+                                                    a.recall_num, a.nprobe, base), 1.5)
+            nq1024 = {"qps": round(q1024[0] * 1024.0 / a.nq, 1), "calls": q1024[1]}
             qps, n, el = timed(fn, budget / 3)
             used = cores
             alt = None
@@ -961,6 +1054,8 @@ def cpu_baseline(a, base, queries, cc, pq, g, lno, codes, list_sizes, gpu_res=No
                 out["other_thread_count"] = alt
             if agree:
                 out["labels_equal_to_cpu_baseline"] = agree
+            out["closed_loop_threads_x_1_query"] = closed
+            out["search_1024"] = nq1024
         except Exception as e:   # a prebuilt _ref that does not load here: fall back to the port
             log("cpu baseline: reference library unusable (%s), using the port" % e)
     if out is None:

@@ -86,6 +86,8 @@ int gamma_hip_destroy(gamma_hip_index* h) {
     if (h->side) (void)hipStreamSynchronize(h->side);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    for (hipEvent_t& e : h->ev_call)
+        if (e) (void)hipEventDestroy(e);
     if (h->ev_rfork) (void)hipEventDestroy(h->ev_rfork);
     if (h->ev_rdone) (void)hipEventDestroy(h->ev_rdone);
     for (int v = 0; v < H::NVER; v++) {

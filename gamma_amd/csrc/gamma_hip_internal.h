@@ -132,6 +132,10 @@ struct gamma_hip_index {
     // next call's or chunk's pair offsets) -- its latency hides behind the next coarse quantizer and query tables
     hipEvent_t ev_rfork = nullptr, ev_rdone = nullptr;
     bool defer_replay = false, defer_now = false, replay_pending = false;
+    // gamma_hip_ivfpq_search_device_wait: completion events of the calls in flight (rotating; a waiter that finds its slot
+    // re-recorded by a later call waits for that one -- later implies earlier on in-order streams)
+    hipEvent_t ev_call[4] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned call_seq = 0;
     // the shadow lists of compact_lists_for_call stay valid while nothing was written and the call has no clauses of its own
     // (standing deletes): write_gen counts writer calls (WriteLock), cmp_gen = the count the shadow lists were built at
     uint64_t write_gen = 1, cmp_gen = 0;

@@ -1738,6 +1738,31 @@ int gamma_hip_ivfpq_search_device(gamma_hip_index* h, const gamma_hip_search_par
     return rc;
 }
 
+int gamma_hip_ivfpq_search_device_wait(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
+                                       const float* d_x, int k, float* d_distances, int64_t* d_labels) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    hipEvent_t ev = nullptr;
+    int dev = 0;
+    {
+        SearchLock lk(h);
+        dev = h->device;
+        GH_CHECK(h, hipSetDevice(h->device));
+        const unsigned slot = h->call_seq++ & 3u;
+        if (!h->ev_call[slot]) GH_CHECK(h, hipEventCreateWithFlags(&h->ev_call[slot], hipEventDisableTiming));
+        ev = h->ev_call[slot];
+        h->defer_now = h->side2 != nullptr;   // the replay of this call's flagged queries: side stream, beside the next caller's head
+        const int rc = ivfpq_search_device_locked(h, p, nq, d_x, k, d_distances, d_labels);
+        h->defer_now = false;
+        if (rc != GAMMA_HIP_OK) return rc;
+        // everything of the call precedes the replay's fork; the replay (if one is pending: this call's) ends the call
+        GH_CHECK(h, hipEventRecord(ev, h->replay_pending ? h->side2 : h->stream));
+    }
+    // the handle is free from here on: the next caller enqueues while this one waits for its own call
+    (void)dev;
+    const hipError_t e = hipEventSynchronize(ev);
+    return e == hipSuccess ? GAMMA_HIP_OK : GAMMA_HIP_EDEVICE;
+}
+
 int gamma_hip_ivfflat_search_device(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* d_x,
                                     int k, float* d_distances, int64_t* d_labels) {
     if (!h) return GAMMA_HIP_EINVAL;

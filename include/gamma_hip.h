@@ -395,6 +395,16 @@ int gamma_hip_ivfpq_search_device(gamma_hip_index* h, const gamma_hip_search_par
  * next search call on the handle, gamma_hip_join (the handle's stream waits for the pending replay; no host wait) or
  * gamma_hip_synchronize.  Host-buffer calls are not affected.  Default: off. */
 int gamma_hip_set_deferred_replay(gamma_hip_index* h, int on);
+/* The reference's Search is re-entrant and returns a COMPLETE result to each of its client threads (tests/test.h:1033-1062,
+ * tools/perf.cc:364-395).  _search_device_wait is that contract for device buffers: it returns when THIS call's
+ * d_distances / d_labels are complete (it waits on the host for the call's own completion event) -- and while it waits
+ * the handle is free: the tie replay of this call (serial by nature, ~200 waves on the whole device) runs on the side
+ * stream and the NEXT caller's coarse quantizer, query tables and scan run beside it, exactly as under
+ * gamma_hip_set_deferred_replay, with no contract on the callers but "wait for your own call".  Two client threads
+ * alternating on one handle thus hide each other's replay tail; one thread alone gets what _search_device +
+ * gamma_hip_synchronize gives.  d_x must stay untouched until the call returns. */
+int gamma_hip_ivfpq_search_device_wait(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
+                                       const float* d_x, int k, float* d_distances, int64_t* d_labels);
 int gamma_hip_join(gamma_hip_index* h);
 /* stage outputs of the LAST search for parity tests / sharded merge (device->host):
  * coarse_dis/idx [nq*nprobe], recall_dis/ids [nq*recall_num] (sorted best first, -1 pad) */

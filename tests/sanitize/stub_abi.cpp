@@ -284,6 +284,9 @@ int gamma_hip_ivfpq_apply_updates(gamma_hip_index* h, int n, const int32_t* list
 int gamma_hip_ivfpq_search_device(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x, int k, float* D, int64_t* I) {
     return gamma_hip_ivfpq_search(h, p, nq, x, k, D, I);   // "device" memory is host memory here (fakehip)
 }
+int gamma_hip_ivfpq_search_device_wait(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x, int k, float* D, int64_t* I) {
+    return gamma_hip_ivfpq_search(h, p, nq, x, k, D, I);
+}
 /* list-shard entry points: not reached in replicate placement */
 int gamma_hip_bound_combine(void*, float*, const float*, int, int) { return GAMMA_HIP_EUNSUPPORTED; }
 int gamma_hip_ivfpq_search_shard_bounded(gamma_hip_index*, const gamma_hip_search_params*, int, const float*, const float*, const int32_t*,

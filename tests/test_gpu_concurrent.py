@@ -305,3 +305,72 @@ def test_searches_stay_exact_while_everything_else_moves():
         assert min(calls) > 3 and g.arena_stats()["repacks"] > 0, (calls, g.arena_stats())
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("nthreads", [2, 3])
+def test_concurrent_callers_each_get_a_complete_result(nthreads):
+    """gamma_hip_ivfpq_search_device_wait (round 6): every call is complete when it returns to ITS caller, while the tie
+    replay of one caller's call runs beside the next caller's coarse quantizer / tables / scan.  Tie-heavy data (duplicated
+    vectors: equal ADC values at the recall_num cut, equal exact distances at the k cut) so that every call has flagged
+    queries to replay; each thread's batches differ, every result is compared -- labels and distance bits at every rank --
+    with the same batch through the plain call made alone."""
+    import torch
+    d, nlist, M, N = 32, 64, 8, 40000
+    base = synth.sift_like(N, d=d, seed=31)
+    base[N // 2:] = base[:N // 2]            # every vector twice
+    cc, pq = B.ivfpq_train(base[:6000], nlist, M)
+    g = api.GammaHip(0)
+    try:
+        g.ivfpq_init(d, nlist, M, 8, api.METRIC_L2)
+        g.ivfpq_set_trained(cc, pq, None)
+        g.raw_init(d)
+        g.raw_append(base)
+        g.add(base, 0)
+        dev = torch.device("cuda", 0)
+        nq, k, nb = 4200, 10, 3
+        args = api.SearchArgs(metric=api.METRIC_L2, nprobe=16, recall_num=100, has_rank=True, coarse_mode=1, **WIDE)
+        qs = [[torch.from_numpy(synth.sift_like(nq, d=d, seed=1000 + 17 * t + b)).to(dev) for b in range(nb)] for t in range(nthreads)]
+        want = [[None] * nb for _ in range(nthreads)]
+        D0 = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        I0 = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        before = g.tie_stats()
+        for t in range(nthreads):
+            for b in range(nb):
+                g.ivfpq_search_device(qs[t][b].data_ptr(), nq, k, args, D0.data_ptr(), I0.data_ptr())
+                g.synchronize()
+                want[t][b] = (D0.cpu().numpy().copy(), I0.cpu().numpy().copy())
+        after = g.tie_stats()
+        assert after["replayed"] > before["replayed"], "the data was meant to flag queries for the replay"
+        errors = []
+
+        def client(t):
+            try:
+                Dt = torch.empty((nq, k), dtype=torch.float32, device=dev)
+                It = torch.empty((nq, k), dtype=torch.int64, device=dev)
+                for rep in range(12):
+                    b = rep % nb
+                    g.ivfpq_search_device_wait(qs[t][b].data_ptr(), nq, k, args, Dt.data_ptr(), It.data_ptr())
+                    # complete on return: read back WITHOUT any further synchronisation of the handle
+                    Dh = torch.empty((nq, k), dtype=torch.float32).pin_memory()
+                    Ih = torch.empty((nq, k), dtype=torch.int64).pin_memory()
+                    st = torch.cuda.Stream(device=dev)
+                    with torch.cuda.stream(st):
+                        Dh.copy_(Dt, non_blocking=True)
+                        Ih.copy_(It, non_blocking=True)
+                    st.synchronize()
+                    compare_exact(want[t][b][0], want[t][b][1], Dh.numpy(), Ih.numpy())
+            except BaseException as e:   # noqa: B902 (reported by the main thread)
+                errors.append((t, repr(e)))
+
+        th = [threading.Thread(target=client, args=(t,)) for t in range(nthreads)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not errors, errors[:3]
+        # and a plain call afterwards still joins whatever replay is pending
+        g.ivfpq_search_device(qs[0][0].data_ptr(), nq, k, args, D0.data_ptr(), I0.data_ptr())
+        g.synchronize()
+        compare_exact(want[0][0][0], want[0][0][1], D0.cpu().numpy(), I0.cpu().numpy())
+    finally:
+        g.close()
