@@ -895,6 +895,17 @@ def plugin_bench(a, base, queries, cc, pq, g, d_q, d_D, d_I, k, args):
             cl[str(T)] = {"qps": round(T * calls / dtc, 1), "p50_us": round(float(np.median(lat)), 1),
                           "p99_us": round(float(lat[int(0.99 * (len(lat) - 1))]), 1), "calls": int(len(lat))}
         out["closed_loop_threads_x_1_query"] = cl
+        # T client threads x one LARGE call each (the batch of `value`, host buffers in and out, every call complete on
+        # return): the queries of one caller go up and its results come down beside the other caller's kernels, and one
+        # caller's tie replay runs beside the other's coarse quantizer / tables (ivfpq_search_host_overlap)
+        big = {}
+        poolb = np.ascontiguousarray(queries)
+        for T in (1, 2, 3):
+            calls = max(10, 48 // T)
+            m.concurrent_clients(poolb, rp, T, 3, nq_call=a.nq, k=k, has_rank=not a.no_rank)   # warm-up (staging slots)
+            dtc, lat = m.concurrent_clients(poolb, rp, T, calls, nq_call=a.nq, k=k, has_rank=not a.no_rank)
+            big[str(T)] = {"qps": round(T * calls * a.nq / dtc, 1), "ms_per_call_p50": round(float(np.median(lat)) / 1e3, 4)}
+        out["client_threads_x_%d_queries" % a.nq] = big
     finally:
         m.close()
     return out

@@ -88,6 +88,15 @@ int gamma_hip_destroy(gamma_hip_index* h) {
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (hipEvent_t& e : h->ev_call)
         if (e) (void)hipEventDestroy(e);
+    for (auto& sl : h->hslot) {
+        sl.x.release();
+        sl.D.release();
+        sl.I.release();
+        if (sl.pin) (void)hipHostFree(sl.pin);
+        if (sl.ev_up) (void)hipEventDestroy(sl.ev_up);
+        if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+    }
+    if (h->up_stream) (void)hipStreamDestroy(h->up_stream);
     if (h->ev_rfork) (void)hipEventDestroy(h->ev_rfork);
     if (h->ev_rdone) (void)hipEventDestroy(h->ev_rdone);
     for (int v = 0; v < H::NVER; v++) {

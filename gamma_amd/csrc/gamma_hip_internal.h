@@ -136,6 +136,22 @@ struct gamma_hip_index {
     // re-recorded by a later call waits for that one -- later implies earlier on in-order streams)
     hipEvent_t ev_call[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned call_seq = 0;
+    // large host-buffer IVFPQ calls from several client threads (ivfpq_search_host_overlap): a call's queries go up on
+    // `up_stream` into its own staging slot BEFORE it takes the search lock, its results come down behind its tie replay
+    // on the side stream into pinned memory, and the caller waits for its own event with the handle already free
+    struct HostSlot {
+        DevBuf x, D, I;
+        void* pin = nullptr;
+        size_t pin_bytes = 0;
+        hipEvent_t ev_up = nullptr, ev_done = nullptr;
+        bool busy = false;
+    };
+    HostSlot hslot[2];
+    std::mutex hs_mu;
+    std::condition_variable hs_cv;
+    hipStream_t up_stream = nullptr;
+    std::atomic<int> big_calls_in_flight{0};
+    std::atomic<int64_t> big_calls_overlap_seen_ns{INT64_MIN / 2};
     // the shadow lists of compact_lists_for_call stay valid while nothing was written and the call has no clauses of its own
     // (standing deletes): write_gen counts writer calls (WriteLock), cmp_gen = the count the shadow lists were built at
     uint64_t write_gen = 1, cmp_gen = 0;

@@ -374,3 +374,47 @@ def test_concurrent_callers_each_get_a_complete_result(nthreads):
         compare_exact(want[0][0][0], want[0][0][1], D0.cpu().numpy(), I0.cpu().numpy())
     finally:
         g.close()
+
+
+def test_large_host_buffer_calls_from_several_threads_overlap_and_stay_exact():
+    """gamma_hip_ivfpq_search with more than 1 MB of queries (the plugin's large Search): staged through two slots so that
+    concurrent callers overlap (ivfpq_search_host_overlap) -- every caller gets the result of ITS call, bit for bit what the
+    call gives when made alone; tie-heavy data, so that every call has a replay pending when the next one starts"""
+    d, nlist, M, N = 32, 64, 8, 40000
+    base = synth.sift_like(N, d=d, seed=32)
+    base[N // 2:] = base[:N // 2]
+    cc, pq = B.ivfpq_train(base[:6000], nlist, M)
+    g = api.GammaHip(0)
+    try:
+        g.ivfpq_init(d, nlist, M, 8, api.METRIC_L2)
+        g.ivfpq_set_trained(cc, pq, None)
+        g.raw_init(d)
+        g.raw_append(base)
+        g.add(base, 0)
+        nq, k, nthreads, nb = 8400, 10, 3, 2          # 8400 x 32 x 4 B > 1 MB: the staged path
+        args = api.SearchArgs(metric=api.METRIC_L2, nprobe=16, recall_num=100, has_rank=True, coarse_mode=1, **WIDE)
+        qs = [[synth.sift_like(nq, d=d, seed=2000 + 13 * t + b) for b in range(nb)] for t in range(nthreads)]
+        want = [[g.ivfpq_search(qs[t][b], k, args) for b in range(nb)] for t in range(nthreads)]
+        assert g.tie_stats()["replayed"] > 0
+        errors = []
+
+        def client(t):
+            try:
+                for rep in range(8):
+                    b = rep % nb
+                    D, I = g.ivfpq_search(qs[t][b], k, args)
+                    compare_exact(want[t][b][0], want[t][b][1], D, I)
+            except BaseException as e:   # noqa: B902
+                errors.append((t, repr(e)))
+        th = [threading.Thread(target=client, args=(t,)) for t in range(nthreads)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not errors, errors[:3]
+        # a writer between the calls: the pending replay of the last call is joined before the lists change
+        g.add(base[:100] + 1.0, N)
+        D, I = g.ivfpq_search(qs[0][0], k, args)
+        assert D.shape == (nq, k)
+    finally:
+        g.close()
