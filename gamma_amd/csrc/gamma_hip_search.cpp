@@ -552,7 +552,9 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     }
     // per-query slab of the distance buffer; multiple of 4 floats so rows are 16-byte aligned
     int64_t q_stride = (std::max<int64_t>(1, (int64_t)P * std::max(1, h->max_list_len)) + 3) & ~(int64_t)3;
-    if (shard && h->q_stride_cap > 0) q_stride = std::min(q_stride, h->q_stride_cap);
+    // (the longest candidate row of THIS batch, measured on its assignment: list shards, and whole-index calls whose general
+    //  stride -- nprobe x the longest list -- would cut the batch into chunks)
+    if (h->q_stride_cap > 0) q_stride = std::min(q_stride, h->q_stride_cap);
     GH_CHECK(h, h->w_dist.ensure((size_t)nq * q_stride * sizeof(float)));
     // dis0 of every (query, probe) pair: the coarse distance (L2) or <x_q, centroid> (inner product)
     const float* dis0 = h->w_coarse_dis.as<float>();
@@ -1161,10 +1163,15 @@ int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, c
     ListCompaction restore(h);
     GH_TRY(compact_lists_for_call(h, &fc, (int64_t)nq * p->nprobe * (h->ntotal / std::max(1, h->nlist)),
                                   !given, &restore));
-    const int chunk = scan_chunk(h, nq, p->nprobe), P = p->nprobe;
+    int chunk = scan_chunk(h, nq, p->nprobe);
+    const int P = p->nprobe;
     // long lists (C4: 64 probes x lists of tens of thousands) make the ADC slab the limit: the coarse
     // quantizer then still runs over the whole call (one GEMM instead of one per slab chunk)
     const bool coarse_first = chunk < nq;
+    struct StrideScope {   // the measured stride holds for this call only
+        H* h;
+        ~StrideScope() { h->q_stride_cap = 0; }
+    } stride_scope{h};
     if (coarse_first) {
         GH_CHECK(h, h->w_full_cdis.ensure((size_t)nq * P * sizeof(float)));
         GH_CHECK(h, h->w_full_probe.ensure((size_t)nq * P * sizeof(int)));
@@ -1172,6 +1179,24 @@ int ivfpq_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, c
         for (int q0 = 0; q0 < nq; q0 += cc)
             GH_TRY(ivfpq_coarse(h, p, std::min(cc, nq - q0), d_x + (size_t)q0 * h->d,
                                 h->w_full_cdis.as<float>() + (size_t)q0 * P, h->w_full_probe.as<int>() + (size_t)q0 * P));
+        // The general slab stride is nprobe x the LONGEST list; the batch's longest candidate row is what it needs (full-size
+        // C4: the longest list is ~5 x the mean, so the budget cut 8192 queries into three chunks -- and the list-major pass
+        // of a third of the batch finds 11 queries per list where the whole batch has 32: half-empty tiles of 8).  The
+        // assignment is on the device: measure, read one word back (the call is tens of milliseconds long), size the
+        // chunks by it -- what the list shards do (gamma_hip_ivfpq_search_shard_preassigned).
+        static const bool no_measure = getenv("GAMMA_HIP_NO_ROW_MEASURE") != nullptr;
+        if (!no_measure && !given) {
+            GH_TRY(coarse_join(h));
+            GH_CHECK(h, h->w_shard_cut.ensure(std::max<size_t>((size_t)nq, 16)));
+            gh::launch_max_local_total(h->stream, h->w_full_probe.as<int>(), nq, P, h->d_list_len, h->d_list_mask, h->nlist,
+                                       h->w_shard_cut.as<int>());
+            int mx[2] = {0, 0};
+            GH_CHECK(h, hipMemcpyAsync(mx, h->w_shard_cut.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            GH_CHECK(h, hipStreamSynchronize(h->stream));
+            h->q_stride_cap = (std::max<int64_t>(mx[0], 1) + 3) & ~(int64_t)3;
+            const int64_t by_dist = (int64_t)(h->dist_budget_bytes / ((size_t)h->q_stride_cap * sizeof(float)));
+            chunk = (int)std::max<int64_t>(chunk, std::min<int64_t>(by_dist, nq));
+        }
     }
     // a call of several chunks: the tie replay of chunk i runs on its own stream beside chunk i + 1 (what
     // gamma_hip_set_deferred_replay does across calls); a caller that has not asked for that gets the join at the end
