@@ -230,11 +230,15 @@ int gamma_hip_tie_stats(gamma_hip_index* h, int64_t* out3, int reset) {
     if (!h || !out3) return GAMMA_HIP_EINVAL;
     SearchLock lk(h);
     GH_CHECK(h, hipSetDevice(h->device));
-    GH_CHECK(h, hipStreamSynchronize(h->stream));
+    // (everything on the handle's own streams: a null-stream hipMemset is asynchronous and NOT ordered against the
+    //  non-blocking search stream -- a reset could land after the next search's first increments)
+    if (h->side) GH_CHECK(h, hipStreamSynchronize(h->side));
+    if (h->side2) GH_CHECK(h, hipStreamSynchronize(h->side2));
     unsigned long long v[3];
-    GH_CHECK(h, hipMemcpy(v, h->d_tie_stats, sizeof(v), hipMemcpyDeviceToHost));
+    GH_CHECK(h, hipMemcpyAsync(v, h->d_tie_stats, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    if (reset) GH_CHECK(h, hipMemsetAsync(h->d_tie_stats, 0, sizeof(v), h->stream));
+    GH_CHECK(h, hipStreamSynchronize(h->stream));
     for (int i = 0; i < 3; i++) out3[i] = (int64_t)v[i];
-    if (reset) GH_CHECK(h, hipMemset(h->d_tie_stats, 0, sizeof(v)));
     return GAMMA_HIP_OK;
 }
 

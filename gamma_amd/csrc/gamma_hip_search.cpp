@@ -318,7 +318,11 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     //  eight -- C3: scan 729 us at 8, 691 at 6, 676 at 5, 671 at 4 but with queries whose slices overflow; GAMMA_HIP_SCAN_G to sweep)
     static const bool no_c8 = getenv("GAMMA_HIP_NO_C8") != nullptr;
     static const bool c8_m32 = getenv("GAMMA_HIP_C8_M32") != nullptr;
-    const bool c8_shape = !no_c8 && l2 && (M == 16 || (M == 32 && c8_m32)) && R <= 256 && h->d_sums && h->d_t2max;
+    // (recall_num up to 512 since round 6 -- with the wave-per-query selection of eight sorted runs, select.hip: C3 at
+    //  recall_num 300 3.00 -> 2.07 ms per 16384 queries (scan 0.475 -> 0.675 of the roofline, select 910 -> 277 us), the C4 shape
+    //  at 8 M 5.19 -> 3.96 ms per 8192; the candidate stages (1536 / 768 slots) overflow into the unfiltered path as ever)
+    static const int cf_maxr = getenv("GAMMA_HIP_CF_MAXR") ? atoi(getenv("GAMMA_HIP_CF_MAXR")) : 512;
+    const bool c8_shape = !no_c8 && l2 && (M == 16 || (M == 32 && c8_m32)) && R <= cf_maxr && h->d_sums && h->d_t2max;
     if (G0 == 8 && c8_shape && P > 8) G0 = 5;
     int64_t t2_bytes = (int64_t)nlist * M * 256 * sizeof(float);
     const bool compacted = shard && pre_dis && pre_probe;
@@ -442,7 +446,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         static const double cf_maxlen = getenv("GAMMA_HIP_SCAN_CF_MAXLEN") ? atof(getenv("GAMMA_HIP_SCAN_CF_MAXLEN")) : 2000.0;
         static const double cf_codes = getenv("GAMMA_HIP_SCAN_CF_CODES") ? atof(getenv("GAMMA_HIP_SCAN_CF_CODES")) : 65536.0;
         // (and short-lists only: the pass stages SCAN_CF_CAP = 768 candidates per consumer workgroup)
-        cf_ok = !no_cf && R <= 256 && (!h->prefiltered || h->cmp_has_sums) && PGN > 1 && mean_len <= cf_maxlen &&
+        cf_ok = !no_cf && R <= cf_maxr && (!h->prefiltered || h->cmp_has_sums) && PGN > 1 && mean_len <= cf_maxlen &&
                 gh::scan_cf_applies(l2, M, P, G, h->d_sums && h->d_t2max, false);
         // list-major byte-table pass for the consumer probes (q8scan.hip, round 5): same conditions as the filter pass it
         // replaces, one validity predicate for the whole call, not a shard (GAMMA_HIP_NO_Q8: the query-major pass, for A/B)

@@ -692,7 +692,8 @@ constexpr int SF_CAND = 384;   // candidates of one query held in LDS (first gro
                                // sized so that 8 workgroups (= all 2048 of an 8192-query batch) are resident per CU
 }
 
-template <bool SMALLEST, int PMAX>   // PMAX: 64 or 128 probes per query
+template <bool SMALLEST, int PMAX, int NR = 4>   // PMAX: 64 or 128 probes per query; NR: sorted runs of 64 (K <= 64 NR: 4, or 8 for
+                                                  // recall_num 257 ... 512, round 6 -- the workgroup-per-query kernel took 0.9 ms there against 0.1)
 __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* __restrict__ surv,
                                                       const int* __restrict__ gcnt, int nslices,
                                                       int slice_cap,
@@ -709,7 +710,8 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
                                                       int* __restrict__ rq_list, int* __restrict__ rq_count,
                                                       unsigned long long* __restrict__ bound_stat) {
     __shared__ int s_hist[4][256];
-    __shared__ unsigned long long s_cand[4][SF_CAND];   // candidates, later the <= 256 kept ones (in place)
+    constexpr int KEEP = 64 * NR, SFC = NR == 4 ? SF_CAND : 96 * NR;
+    __shared__ unsigned long long s_cand[4][SFC];   // candidates, later the <= KEEP kept ones (in place)
     __shared__ int s_off[4][PMAX + 8];
     __shared__ int64_t s_base[4][PMAX];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -767,7 +769,7 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
                 if (i0 + lane < cg) {
                     const unsigned long long item = i0 < 256 ? t[(i0 >> 6) & 3] : sg[i0 + lane];
                     const uint32_t key = (uint32_t)(item >> 32);
-                    if (c + i0 + lane < SF_CAND) cand[c + i0 + lane] = item;
+                    if (c + i0 + lane < SFC) cand[c + i0 + lane] = item;
                     mn = key < mn ? key : mn;
                     mx = key > mx ? key : mx;
                 }
@@ -793,7 +795,7 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
                 if (i0 + lane < cg[u]) {
                     const unsigned long long item = i0 == 0 ? t[u] : sg[i0 + lane];
                     const uint32_t key = (uint32_t)(item >> 32);
-                    if (c + i0 + lane < SF_CAND) cand[c + i0 + lane] = item;
+                    if (c + i0 + lane < SFC) cand[c + i0 + lane] = item;
                     mn = key < mn ? key : mn;
                     mx = key > mx ? key : mx;
                 }
@@ -807,7 +809,7 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
     // later passes visit the candidates in LDS, or -- when they did not fit (loose bound, rare) --
     // stream them again from memory; body(valid, key, item) is called with a uniform trip count
     auto for_each = [&](auto&& body) {
-        if (c <= SF_CAND) {
+        if (c <= SFC) {
             for (int i0 = 0; i0 < c; i0 += 64) {
                 const unsigned long long item = i0 + lane < c ? cand[i0 + lane] : ~0ull;
                 body(i0 + lane < c, (uint32_t)(item >> 32), item);
@@ -825,7 +827,7 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
     };
     // ---- cut to <= 256 items: keep keys <= cutoff, cutoff from (nested) 256-bin histograms ----
     uint32_t cutoff = 0xffffffffu;
-    if (c > 256) {
+    if (c > KEEP) {
         uint32_t lo = mn;
         const uint32_t range = mx - mn;
         int s = range >= 256u ? (32 - __clz((int)range)) - 8 : 0;
@@ -861,8 +863,8 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
             kept = __shfl(kept, src_lane, 64);
             before = __shfl(before, src_lane, 64);
             __builtin_amdgcn_wave_barrier();
-            if (kept <= 256 || s == 0) {
-                if (kept > 256) {        // > 256 copies of one key around the K-th: rare, unfiltered path
+            if (kept <= KEEP || s == 0) {
+                if (kept > KEEP) {        // > 256 copies of one key around the K-th: rare, unfiltered path
                     if (lane == 0) {
                         flag[q] = 1;
                         if (rq_list) rq_list[atomicAdd(rq_count, 1)] = q;
@@ -893,22 +895,22 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
     });
     __builtin_amdgcn_wave_barrier();
     // ---- four sorted runs of 64, then rank merge ----
-    unsigned long long x[4];
+    unsigned long long x[NR];
 #pragma unroll
-    for (int r = 0; r < 4; r++) x[r] = (r * 64 + lane < m) ? runs[r * 64 + lane] : ~0ull;
+    for (int r = 0; r < NR; r++) x[r] = (r * 64 + lane < m) ? runs[r * 64 + lane] : ~0ull;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int r = 0; r < 4; r++) x[r] = wave_sort64(x[r]);
+    for (int r = 0; r < NR; r++) x[r] = wave_sort64(x[r]);
 #pragma unroll
-    for (int r = 0; r < 4; r++) runs[r * 64 + lane] = x[r];
+    for (int r = 0; r < NR; r++) runs[r * 64 + lane] = x[r];
     __builtin_amdgcn_wave_barrier();
     const float sentinel = SMALLEST ? INFINITY : -INFINITY;
-    int rk[4];
+    int rk[NR];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < NR; r++) {
         int rank = lane;
 #pragma unroll
-        for (int o = 0; o < 4; o++) {
+        for (int o = 0; o < NR; o++) {
             if (o == r) continue;
             // number of items of run o smaller than x[r]
             const unsigned long long* ro = runs + o * 64;
@@ -932,8 +934,8 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
     // the K winners in rank order (LDS), then one coalesced pass: rank r = lane + 64 i
     __builtin_amdgcn_wave_barrier();   // all binary searches have read the runs
 #pragma unroll
-    for (int r = 0; r < 4; r++)
-        if (x[r] != ~0ull && rk[r] < 256) runs[rk[r]] = x[r];   // ranks are a permutation of 0..m-1
+    for (int r = 0; r < NR; r++)
+        if (x[r] != ~0ull && rk[r] < KEEP) runs[rk[r]] = x[r];   // ranks are a permutation of 0..m-1
     __builtin_amdgcn_wave_barrier();
     // exact ties: every candidate at the K-th key is among the m kept items (key <= cutoff), so the cut went
     // through a tie group iff the item of rank K carries the key of rank K - 1
@@ -945,11 +947,11 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
     // position in the query's segment -> vector id (as k_map_candidates): last p with off[p] <= ps.
     // Branch-free on clamped values so the four dependent load chains run side by side.
     const int nres = min(m, K);
-    unsigned long long it[4];
-    int ps[4], pp[4];
-    int64_t idv[4];
+    unsigned long long it[NR];
+    int ps[NR], pp[NR];
+    int64_t idv[NR];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < NR; r++) {
         it[r] = runs[min(lane + 64 * r, max(nres - 1, 0))];
         ps[r] = (int)(uint32_t)it[r];
         int lo = 0;
@@ -962,9 +964,9 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
     }
     // (no survivor at all -- a shard that holds none of the query's probed lists: nothing to look up)
 #pragma unroll
-    for (int r = 0; r < 4; r++) idv[r] = nres > 0 ? ids[lbase[pp[r]] + (ps[r] - off[pp[r]])] : -1;
+    for (int r = 0; r < NR; r++) idv[r] = nres > 0 ? ids[lbase[pp[r]] + (ps[r] - off[pp[r]])] : -1;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < NR; r++) {
         const int rank = lane + 64 * r;
         if (rank < nres) {
             const uint32_t key = (uint32_t)(it[r] >> 32);
@@ -1803,6 +1805,22 @@ void launch_select_final(hipStream_t s, bool smallest, const unsigned long long*
     if (nq <= 0) return;
     if (P > 128 || K > 1024 || (K <= 256 && nslices > 64)) {   // callers gate on this (gamma_hip_search.cpp, ivfpq_stage_a)
         launch_refused("launch_select_final: nprobe > 128, recall_num > 1024 or more than 64 survivor slices");
+        return;
+    }
+    static const bool no_wave8 = getenv("GAMMA_HIP_NO_SELECT_WAVE8") != nullptr;
+    if (K > 256 && K <= 512 && nslices <= 64 && !no_wave8) {   // a wave per query with eight sorted runs
+#define GH_SF8(SM, PM)                                                                                           \
+    hipLaunchKernelGGL((k_select_final<SM, PM, 8>), dim3((nq + 3) / 4), dim3(256), 0, s, surv, gcnt, nslices,   \
+                       slice_cap, ready, pair_off, P, nq, K, pair_base, ids, flag,                               \
+                       out_vals, out_pos, out_ids, cut_tie, tie_stats, rq_list, rq_count, bound_stat)
+        if (smallest) {
+            if (P <= 64) GH_SF8(true, 64);
+            else GH_SF8(true, 128);
+        } else {
+            if (P <= 64) GH_SF8(false, 64);
+            else GH_SF8(false, 128);
+        }
+#undef GH_SF8
         return;
     }
     if (K > 256) {          // one workgroup per query (recall_num up to 1024: the callers' gate)
