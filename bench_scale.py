@@ -325,7 +325,9 @@ def run(a):
         }, **extra),
         "cpu_baseline": None,     # the CPU leg belongs to the default (C3) line; this line is the sharded job's
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s", "frac": round(achieved / peak, 4),
-                     "traffic": None, "note": "rank 0's scan launches: device-counted sum(len) x %d B / HIP-event duration" % M},
+                     "traffic": None, "note": "rank 0's scan launches: device-counted sum(len) x %d B / HIP-event duration -- ALGORITHMIC bytes by the "
+                     "contract (every (query, list) pair counts the list's codes); the list-major byte-table pass reads a list's codes once "
+                     "per tile of 8 queries, so with enough queries per list the figure exceeds the HBM peak" % M},
     }
     print(json.dumps(line), flush=True)
     dist.destroy_process_group()

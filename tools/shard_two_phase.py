@@ -21,24 +21,34 @@ from gamma_amd import dist as gdist
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20000000
 WS = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "2,4,8").split(",")]
 R = int(sys.argv[3]) if len(sys.argv) > 3 else 100
-d, nlist, M, P, k, nq = 128, 16384, 32, 64, 10, 8192
+C5 = os.environ.get("SHAPE", "c4") == "c5"     # SHAPE=c5: d 768 inner product, nlist 4096, M 64, nprobe 64, 4096 queries per rank
+d, nlist, M, P, k, nq = (768, 4096, 64, 64, 10, 4096) if C5 else (128, 16384, 32, 64, 10, 8192)
+METRIC = api.METRIC_IP if C5 else api.METRIC_L2
 STEPS = int(os.environ.get("STEPS", "6"))
 dev = torch.device("cuda", 0)
-CH = 1000000
+CH = 200000 if C5 else 1000000
 f32, i32, i64 = torch.float32, torch.int32, torch.int64
 t0 = time.time()
-first = synth.sift_like(CH, d=d, seed=1234)
+
+
+def rows(n, start, seed):
+    if C5:
+        return synth.embedding_like_device(n, d=d, seed=seed, start=start, device=dev).cpu().numpy()
+    return synth.sift_like(n, d=d, seed=seed, start=start)
+
+
+first = rows(CH, 0, 1234)
 cc, pq = api.train_ivfpq(first[:nlist * 40], nlist, M)
 g = api.GammaHip(0)
-g.ivfpq_init(d, nlist, M, 8, api.METRIC_L2, bucket_init_size=max(200, int(1.3 * N / nlist)))
+g.ivfpq_init(d, nlist, M, 8, METRIC, bucket_init_size=max(200, int((1.5 if C5 else 1.3) * N / nlist)))
 g.ivfpq_set_trained(cc, pq, None)
 g.raw_init(d)
 for c in range(0, N, CH):
-    xb = first if c == 0 else synth.sift_like(min(CH, N - c), d=d, seed=1234, start=c)
+    xb = first[:min(CH, N)] if c == 0 else rows(min(CH, N - c), c, 1234)
     g.raw_append(xb)
     g.add(xb, c)
-print("# C4 shape, %d vectors (%d codes per list), recall_num %d: train + add %.1f s" % (N, N // nlist, R, time.time() - t0), flush=True)
-args = api.SearchArgs(metric=api.METRIC_L2, nprobe=P, recall_num=R, has_rank=True, min_score=0.0, max_score=1e30)
+print("# %s shape, %d vectors (%d codes per list), recall_num %d: train + add %.1f s" % ("C5" if C5 else "C4", N, N // nlist, R, time.time() - t0), flush=True)
+args = api.SearchArgs(metric=METRIC, nprobe=P, recall_num=R, has_rank=True, min_score=-1e30 if C5 else 0.0, max_score=1e30)
 sizes = np.array([g.list_size(l) for l in range(nlist)], dtype=np.int64)
 stream = torch.cuda.ExternalStream(g.stream(), device=dev)
 
@@ -60,7 +70,7 @@ def timed(fn, tag):
     return dt * 1e3, st
 
 
-q1 = torch.from_numpy(synth.sift_like(nq, d=d, seed=4321)).to(dev)
+q1 = torch.from_numpy(rows(nq, 0, 4321)).to(dev)
 D = torch.empty((nq, k), dtype=f32, device=dev)
 I = torch.empty((nq, k), dtype=i64, device=dev)
 ONLY_TWO = os.environ.get("ONLY_TWO") is not None   # (kernel profiles of the two-phase step alone)
@@ -69,7 +79,7 @@ print("one GPU, whole index: %.2f ms per %d queries; stage ms/step %s" % (base_m
 for W in WS:
     owner = gdist.balance_lists(sizes, W)
     gnq = nq * W
-    dqq = torch.from_numpy(synth.sift_like(gnq, d=d, seed=4321)).to(dev)
+    dqq = torch.from_numpy(rows(gnq, 0, 4321)).to(dev)
     cdis = torch.empty((gnq, P), dtype=f32, device=dev)
     probe = torch.empty((gnq, P), dtype=i32, device=dev)
     g.set_list_mask(None)
@@ -111,13 +121,13 @@ for W in WS:
                                          rids.data_ptr(), b_.data_ptr(), None)
             g.synchronize()
             own.append(b_)
-        glob[0] = torch.stack(own).min(dim=0).values.contiguous()
+        glob[0] = (torch.stack(own).max(dim=0).values if C5 else torch.stack(own).min(dim=0).values).contiguous()
         for s_ in range(W):      # what the exchange would have to carry: every shard's candidates within the global bound
             g.set_list_mask((owner == s_).astype(np.uint8))
             g.ivfpq_search_shard_bounded(dqq.data_ptr(), gnq, cdis.data_ptr(), probe.data_ptr(), k, args, rdis.data_ptr(),
                                          rids.data_ptr(), bound.data_ptr(), reduce_cb)
             g.synchronize()
-            cnt += ((rids >= 0) & (rdis <= glob[0][:, None])).sum().double()
+            cnt += ((rids >= 0) & ((rdis >= glob[0][:, None]) if C5 else (rdis <= glob[0][:, None]))).sum().double()
         g.set_list_mask((owner == 0).astype(np.uint8))
         ms, st = timed(lambda: estep(True), "two")
         print("W=%d TWO-PHASE (G1 %s): %.2f ms per step -> per-rank compute efficiency %.0f %%; stage ms/step %s; shard 0's own bound is "
