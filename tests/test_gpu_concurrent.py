@@ -372,6 +372,16 @@ def test_concurrent_callers_each_get_a_complete_result(nthreads):
         g.ivfpq_search_device(qs[0][0].data_ptr(), nq, k, args, D0.data_ptr(), I0.data_ptr())
         g.synchronize()
         compare_exact(want[0][0][0], want[0][0][1], D0.cpu().numpy(), I0.cpu().numpy())
+        # small batches (the small-batch chain replays inside its tail kernel) and an empty call through the same entry point
+        for n in (1, 7, 300):
+            g.ivfpq_search_device_wait(qs[1][1].data_ptr(), n, k, args, D0.data_ptr(), I0.data_ptr())
+            a_small = api.SearchArgs(metric=api.METRIC_L2, nprobe=16, recall_num=100, has_rank=True, coarse_mode=1, **WIDE)
+            Dp = torch.empty((n, k), dtype=torch.float32, device=dev)
+            Ip = torch.empty((n, k), dtype=torch.int64, device=dev)
+            g.ivfpq_search_device(qs[1][1].data_ptr(), n, k, a_small, Dp.data_ptr(), Ip.data_ptr())
+            g.synchronize()
+            compare_exact(Dp.cpu().numpy(), Ip.cpu().numpy(), D0[:n].cpu().numpy(), I0[:n].cpu().numpy())
+        g.ivfpq_search_device_wait(qs[1][1].data_ptr(), 0, k, args, D0.data_ptr(), I0.data_ptr())
     finally:
         g.close()
 

@@ -31,7 +31,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     # reports half of the bytes of a wide coalesced read -> x2; WRITE_SIZE as is.  The box's own calibration
     # (a kernel that moves exactly 2^30 bytes each way) is kept next to it.
     guide = 2.0 if c == "FETCH_SIZE" else 1.0
-    for kern in ("k_ivfpq_scan_pair<true, 16, true", "k_ivfpq_scan_pair<true, 16, false", "k_select_final", "k_rerank_topk",
+    for kern in ("k_ivfpq_scan_pair_c8", "k_ivfpq_scan_pair<true, 16, true", "k_ivfpq_scan_pair<true, 16, false", "k_select_final", "k_rerank_topk",
                  "k_l2_gemmform_strip", "k_pq_ip_table"):
         v, n = per_dispatch("bench_" + c, kern, c)
         res[c][kern] = {"counter_per_launch": v, "launches": n,
