@@ -92,6 +92,10 @@ def main():
     ap.add_argument("--scale-nq", type=int, default=0, help="--workload c4 / c5: queries per GPU and step (default 8192 / 4096)")
     ap.add_argument("--scale-nlist", type=int, default=0, help="--workload c4 / c5: lists (default 16384 / 4096)")
     ap.add_argument("--scale-recall-num", type=int, default=0, help="--workload c4 / c5: short-list (default 150 / 1000: recall@10 >= 0.95)")
+    ap.add_argument("--raw-placement", default="replicated", choices=["replicated", "sharded"],
+                    help="--workload c4 / c5 with several ranks: 'sharded' = every rank keeps the raw rows of the vectors in ITS lists "
+                         "only (gamma_hip_raw_put) and the exact re-rank distances travel with the candidates (C4 on 8 GPUs: 6.4 GB of "
+                         "rows per GPU instead of 51.2); 'replicated' = every rank holds every row")
     ap.add_argument("--scale-dump", default="", help="--workload c4 / c5: rank 0 writes step 0's (D, I), the trained state and the queries here (.npz)")
     ap.add_argument("--insert-rate", type=float, default=10000.0, help="--workload c5: vectors per second of the realtime insert leg")
     ap.add_argument("--insert-seconds", type=float, default=12.0, help="--workload c5: length of the insert leg")

@@ -107,7 +107,8 @@ def run(a):
     owned = (owner == rank).astype(np.uint8)
     if world > 1:
         g.set_list_mask(owned)
-    backend = gdist.HipShardBackend(g, local_rank)
+    raw_sharded = world > 1 and getattr(a, "raw_placement", "replicated") == "sharded"
+    backend = gdist.HipShardBackend(g, local_rank, raw_sharded=raw_sharded, owned=owned)
     g.raw_init(d)
 
     # ---- streamed Add: every rank draws the same chunk on its GPU and keeps the entries of its own lists ----------------
@@ -183,7 +184,7 @@ def run(a):
     torch.cuda.synchronize()
     if rank == 0 and a.scale_dump:     # step 0's result table, for a comparison with an unsharded index (tests/test_gpu_dist.py)
         np.savez(a.scale_dump, D=Dg.cpu().numpy(), I=Ig.cpu().numpy(), cc=cc, pq=pq, q=d_q[:gnq].cpu().numpy())
-    if rank == 0 and nrq > 0:
+    if rank == 0 and nrq > 0 and not raw_sharded:   # (the exact flat search needs every row on this rank)
         Ih = Ig[:nrq].cpu().numpy()
         Df, If = g.flat_search(d_q[:nrq].cpu().numpy(), k, api.SearchArgs(metric=metric, **win))
         recall = float(np.mean([len(set(Ih[i].tolist()) & set(If[i].tolist())) / float(k) for i in range(nrq)]))
@@ -307,8 +308,14 @@ def run(a):
             "workload": (sp["name"] % N) + ", recall_num=%d has_rank=true k=%d, %d queries per step (%d per GPU)" % (R, k, gnq, nq),
             "placement": "one GPU: the whole index, plain Search" if plain else "shard: lists by greedy sum(len) over sizes estimated from %d sample rows; per-shard top-recall_num "
                          "exchanged all-to-all; merge + re-rank at the query slice's owner" % ns,
-            "raw_placement": "replicated: %.1f GB of raw vectors on EVERY rank (re-rank at the slice's owner reads rows of every "
-                             "shard's candidates); codes + ids + sums sharded" % (N * d * 4 / 1e9),
+            "raw_placement": ("sharded: every rank keeps the raw rows of the vectors in ITS lists only (%.1f GB of rows + a 4-byte vid -> row "
+                              "table on rank 0; replicated it would be %.1f GB per rank); the exact re-rank distances are computed by the "
+                              "shard that holds the row and travel with the packed candidates (16 instead of 12 bytes per entry); recall is "
+                              "not computed in this mode (the exact flat search needs every row on one rank)"
+                              % (g.raw_stats()["rows"] * d * 4 / 1e9, N * d * 4 / 1e9)) if raw_sharded else
+                             ("replicated: %.1f GB of raw vectors on EVERY rank (re-rank at the slice's owner reads rows of every "
+                              "shard's candidates); codes + ids + sums sharded; --raw-placement sharded keeps a rank's own rows only"
+                              % (N * d * 4 / 1e9)),
             "communicator": comm,
             "exchange_bytes_per_step": {"assignment_all_gather": gnq * P * 8,
                                         "candidates_all_to_all_per_rank": xst.get("exchange_bytes", (gnq // world) * R * 12 * (world - 1)),

@@ -126,6 +126,15 @@ SYMBOLS = {
     "gamma_hip_ivfpq_search_shard_bounded": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int,
                                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gamma_hip_raw_put": (C.c_int, [C.c_void_p, C.c_int64, i64p, f32p]),
+    "gamma_hip_ivfpq_shard_exact": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "gamma_hip_ivfpq_merge_rerank_exact": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "gamma_hip_ivfpq_shard_export_exact": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "gamma_hip_ivfpq_merge_replay_exact": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p]),
     "gamma_hip_bound_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "gamma_hip_ivfpq_merge_rerank": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int, C.c_int,
                                                C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,

@@ -133,6 +133,12 @@ class GammaHip:
         vecs = _f32(vecs)
         self._ck(self.L.gamma_hip_raw_append(self.h, vecs.shape[0], _p(vecs, _lib.f32p)), "raw_append")
 
+    def raw_put(self, vids, vecs):
+        """raw vectors sharded with their lists: the rows of THIS shard's vectors (include/gamma_hip.h)"""
+        vids = np.ascontiguousarray(vids, dtype=np.int64)
+        vecs = _f32(vecs)
+        self._ck(self.L.gamma_hip_raw_put(self.h, len(vids), _p(vids, _lib.i64p), _p(vecs, _lib.f32p)), "raw_put")
+
     def raw_write(self, first_vid, vecs):
         vecs = _f32(vecs)
         self._ck(self.L.gamma_hip_raw_write(self.h, first_vid, vecs.shape[0], _p(vecs, _lib.f32p)), "raw_write")
@@ -460,6 +466,22 @@ class GammaHip:
     def ivfpq_shard_export(self, nf, d_xf, d_cdis_f, d_probe_f, stride, args, d_vals, d_ids, d_off):
         self._ck(self.L.gamma_hip_ivfpq_shard_export(self.h, args.ref(), nf, d_xf, d_cdis_f, d_probe_f, stride, d_vals, d_ids,
                                                      d_off), "shard_export")
+
+    def ivfpq_shard_exact(self, d_x, nq, d_ids, R, args, d_exact):
+        self._ck(self.L.gamma_hip_ivfpq_shard_exact(self.h, args.ref(), nq, d_x, d_ids, R, d_exact), "shard_exact")
+
+    def ivfpq_merge_rerank_exact(self, nshards, nq, d_x, k, args, d_all_dis, d_all_ids, d_all_exact, q0, nq_local, d_D, d_I):
+        self._ck(self.L.gamma_hip_ivfpq_merge_rerank_exact(self.h, args.ref(), nshards, nq, d_x, k, d_all_dis, d_all_ids, d_all_exact,
+                                                           q0, nq_local, d_D, d_I), "merge_rerank_exact")
+
+    def ivfpq_shard_export_exact(self, nf, d_xf, d_vals, d_ids, d_off, stride, d_bound_f, args, d_ex):
+        self._ck(self.L.gamma_hip_ivfpq_shard_export_exact(self.h, args.ref(), nf, d_xf, d_vals, d_ids, d_off, stride, d_bound_f, d_ex),
+                 "shard_export_exact")
+
+    def ivfpq_merge_replay_exact(self, nshards, nf, d_x_slice, stride, d_vals_all, d_ids_all, d_off_all, d_ex_all, k, args, d_list,
+                                 d_D, d_I):
+        self._ck(self.L.gamma_hip_ivfpq_merge_replay_exact(self.h, args.ref(), nshards, nf, d_x_slice, stride, d_vals_all, d_ids_all,
+                                                           d_off_all, d_ex_all, k, d_list, d_D, d_I), "merge_replay_exact")
 
     def ivfpq_merge_replay(self, nshards, nf, d_x_slice, stride, d_vals_all, d_ids_all, d_off_all, k, args, d_list, d_D, d_I):
         self._ck(self.L.gamma_hip_ivfpq_merge_replay(self.h, args.ref(), nshards, nf, d_x_slice, stride, d_vals_all, d_ids_all,

@@ -128,6 +128,7 @@ int gamma_hip_destroy(gamma_hip_index* h) {
         h->d_ids = nullptr;
         h->d_sums = nullptr;
     }
+    if (h->d_raw_slot) (void)hipFree(h->d_raw_slot);
     void* ptrs[] = {h->d_list_rank, h->d_raw, h->d_bitmap, h->d_cc, h->d_cc_norms, h->d_pqc, h->d_T2, h->d_codes,
                     h->d_ids, h->d_list_mask, h->d_scan_codes, h->d_tie_stats, h->d_v2d, h->d_sums, h->d_t2max, h->d_bound_stat};
     for (void* p : ptrs)
@@ -289,7 +290,7 @@ int64_t gamma_hip_total_mem_bytes(gamma_hip_index* h) {
     if (!h) return -1;
     std::lock_guard<std::mutex> g(h->mu);
     int64_t b = 0;
-    b += h->raw_cap * h->raw_d * (int64_t)sizeof(float);
+    b += h->raw_cap * h->raw_d * (int64_t)sizeof(float) + h->raw_slot_cap * (int64_t)sizeof(int32_t);
     b += (int64_t)h->bitmap_cap_bytes;
     for (auto& kv : h->fields) b += kv.second.cap * (int64_t)field_elem_size(kv.second.dtype);
     for (auto& kv : h->terms) b += kv.second.cap_docs * 8 + kv.second.cap_tok * 4;

@@ -178,6 +178,13 @@ struct gamma_hip_index {
     int raw_d = 0;
     float* d_raw = nullptr;
     int64_t nraw = 0, raw_cap = 0;
+    // raw vectors SHARDED with their lists (gamma_hip_raw_put, round 6): the store holds the rows of the vectors in this shard's
+    // lists only, in arrival order; raw_slot[vid] = row (-1: held by another shard).  Such a handle re-ranks nothing by itself --
+    // has_rank searches, flat search and raw_gets refuse -- it serves _shard_exact / _shard_export_exact.
+    bool raw_sparse = false;
+    std::vector<int32_t> h_raw_slot;
+    int32_t* d_raw_slot = nullptr;
+    int64_t raw_slot_cap = 0;
     // The store grows IN PLACE where the runtime offers virtual memory management: one address range reserved up
     // front, physical chunks mapped behind the rows as they come -- no copy, no second allocation, no wait for the
     // searches in flight (the reference keeps 500 000-vector segments for the same reason, vector/memory_raw_vector.cc:

@@ -852,6 +852,7 @@ int ivfpq_stage_b(H* h, const gamma_hip_search_params* p, int nq, const float* d
     };
     if (p->has_rank) {
         if (!h->d_raw || h->raw_d != h->d) return fail(h, GAMMA_HIP_EINVAL, "has_rank needs the raw store");
+        if (h->raw_sparse) return fail(h, GAMMA_HIP_EUNSUPPORTED, "has_rank on a handle that holds its shard's raw rows only: the exact distances travel with the candidates (gamma_hip_ivfpq_shard_exact / _merge_rerank_exact)");
         if (R <= 1024 && (nq >= 256 || ties)) {
             // one fused kernel: exact distances + top-k + output
             gh::launch_rerank_topk(s, l2, d_x, nq, h->d, h->d_raw, h->nraw, cand_ids, R, k, p->min_score,
@@ -903,7 +904,7 @@ bool ivfpq_small_ok(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, i
            (int64_t)p->nprobe * std::max(1, h->max_list_len) <= (1 << 22) &&
            // long lists: beyond ~5e7 codes per call the regular chain's bound filter wins (full-size C4, 390 k codes per
            // query: 64 queries 0.46 ms against 1.04, 256 queries 1.63 against 1.33)
-           (int64_t)nq * p->nprobe * (h->ntotal / std::max(1, h->nlist)) <= 48000000LL && (!p->has_rank || (h->d_raw && h->raw_d == h->d));
+           (int64_t)nq * p->nprobe * (h->ntotal / std::max(1, h->nlist)) <= 48000000LL && (!p->has_rank || (h->d_raw && h->raw_d == h->d && !h->raw_sparse));
 }
 
 int ivfpq_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int nq, const float* d_x, int R, int k,
@@ -1338,6 +1339,7 @@ int ivfflat_small(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
 
 int ivfflat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, int k,
                                  float* d_distances, int64_t* d_labels) {
+    if (h->raw_sparse) return fail(h, GAMMA_HIP_EUNSUPPORTED, "the raw store holds this shard's rows only (gamma_hip_raw_put)");
     GH_TRY(check_params(h, p, nq, k));
     gamma_hip_search_params pp;
     GH_TRY(resolve_ties(h, p, &pp, p->nprobe <= gh::tie_replay_max_probes(), "exact_ties = 1 with nprobe > 1024"));
@@ -1449,6 +1451,7 @@ int ivfflat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq,
 // ---- flat ------------------------------------------------------------------------------
 int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, const float* d_x, int k,
                               float* d_distances, int64_t* d_labels) {
+    if (h->raw_sparse) return fail(h, GAMMA_HIP_EUNSUPPORTED, "the raw store holds this shard's rows only (gamma_hip_raw_put)");
     GH_TRY(check_params(h, p, nq, k));
     gamma_hip_search_params pp;   // (the chunked paths run for k + 1 results: k = 4096, the ABI's largest, is beyond the mode)
     GH_TRY(resolve_ties(h, p, &pp, k + 1 <= gh::tie_replay_max_k() && h->nraw < ((int64_t)1 << 31),
@@ -2107,9 +2110,23 @@ int gamma_hip_ivfpq_search_shard_bounded(gamma_hip_index* h, const gamma_hip_sea
     return shard_preassigned(h, p, nq, d_x, d_coarse_dis, d_probe, k, d_recall_dis, d_recall_ids, &bx);
 }
 
+static int merge_rerank_impl(gamma_hip_index* h, const gamma_hip_search_params* p, int nshards, int nq,
+                             const float* d_x, int k, const float* d_all_dis, const int64_t* d_all_ids, const float* d_all_exact,
+                             int q0, int nq_local, float* d_distances, int64_t* d_labels);
 int gamma_hip_ivfpq_merge_rerank(gamma_hip_index* h, const gamma_hip_search_params* p, int nshards, int nq,
                                  const float* d_x, int k, const float* d_all_dis, const int64_t* d_all_ids,
                                  int q0, int nq_local, float* d_distances, int64_t* d_labels) {
+    return merge_rerank_impl(h, p, nshards, nq, d_x, k, d_all_dis, d_all_ids, nullptr, q0, nq_local, d_distances, d_labels);
+}
+int gamma_hip_ivfpq_merge_rerank_exact(gamma_hip_index* h, const gamma_hip_search_params* p, int nshards, int nq,
+                                       const float* d_x, int k, const float* d_all_dis, const int64_t* d_all_ids,
+                                       const float* d_all_exact, int q0, int nq_local, float* d_distances, int64_t* d_labels) {
+    if (!d_all_exact) return GAMMA_HIP_EINVAL;
+    return merge_rerank_impl(h, p, nshards, nq, d_x, k, d_all_dis, d_all_ids, d_all_exact, q0, nq_local, d_distances, d_labels);
+}
+static int merge_rerank_impl(gamma_hip_index* h, const gamma_hip_search_params* p, int nshards, int nq,
+                             const float* d_x, int k, const float* d_all_dis, const int64_t* d_all_ids, const float* d_all_exact,
+                             int q0, int nq_local, float* d_distances, int64_t* d_labels) {
     if (!h) return GAMMA_HIP_EINVAL;
     SearchLock lk(h);
     GH_TRY(replay_join(h));
@@ -2160,8 +2177,69 @@ int gamma_hip_ivfpq_merge_rerank(gamma_hip_index* h, const gamma_hip_search_para
                                   h->w_tcut.as<uint8_t>(), h->merge_shard_flags);
     }
     h->merge_shard_flags = nullptr;   // one merge, with ties or without
+    if (d_all_exact && p->has_rank) {
+        // raw vectors sharded with their lists: the exact distance of every candidate travelled with it (computed by the shard
+        // that holds the row, score window applied there).  compute_dis (gamma_index_ivfpq.cc:646-680) from those: the merged
+        // candidates' distances are looked up in the shard tables, then the non-fused finish of stage B -- top-k of the row of
+        // exact distances (equal distances keep the ADC order), output, tie flags.
+        const float neutral = l2 ? 3.402823466e+38f : -3.402823466e+38f;
+        StageScope t(h, GAMMA_HIP_STAGE_RERANK);
+        GH_CHECK(h, h->w_exact.ensure((size_t)nq_local * R * sizeof(float)));
+        GH_CHECK(h, h->w_selv.ensure((size_t)nq_local * k * sizeof(float)));
+        GH_CHECK(h, h->w_selp.ensure((size_t)nq_local * k * sizeof(int)));
+        gh::launch_lookup_exact(s, l2, d_all_dis, d_all_ids, d_all_exact, nshards, nq, R, q0, nq_local, h->w_cand_dis.as<float>(),
+                                h->w_cand_ids.as<int64_t>(), h->w_exact.as<float>());
+        gh::launch_select_topk(s, l2, h->w_exact.as<float>(), R, nullptr, R, R, nq_local, k, h->w_selv.as<float>(), h->w_selp.as<int>());
+        gh::launch_finalize_topk(s, h->w_selv.as<float>(), h->w_selp.as<int>(), nq_local, k, h->w_cand_ids.as<int64_t>(), R, 0, neutral,
+                                 d_distances, d_labels);
+        if (ties) {
+            gh::TieFlags tf;
+            tf.cut = h->w_tcut.as<uint8_t>();
+            tf.count = h->w_tlist.as<int>();
+            tf.list = h->w_tlist.as<int>() + 1;
+            tf.stats = h->d_tie_stats;
+            GH_CHECK(h, h->w_textra.ensure((size_t)nq_local));
+            GH_CHECK(h, hipMemsetAsync(h->w_textra.p, 0, (size_t)nq_local, s));
+            gh::launch_flag_cut_ties(s, h->w_exact.as<float>(), R, nullptr, nq_local, k, h->w_selv.as<float>(), h->w_selp.as<int>(),
+                                     nullptr, h->w_textra.as<uint8_t>(), R, 1);
+            gh::launch_tie_list(s, tf.cut, h->w_textra.as<uint8_t>(), nq_local, tf.list, tf.count, tf.stats);
+        }
+        GH_CHECK(h, hipGetLastError());
+        return GAMMA_HIP_OK;
+    }
     return ivfpq_stage_b(h, p, nq_local, d_x + (size_t)q0 * h->d, R, k, h->w_cand_dis.as<float>(),
                          h->w_cand_ids.as<int64_t>(), d_distances, d_labels, nullptr, ties ? 2 : 0);
+}
+
+int gamma_hip_ivfpq_shard_exact(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* d_x,
+                                const int64_t* d_ids, int R, float* d_exact) {
+    if (!h || !p) return GAMMA_HIP_EINVAL;
+    if (nq <= 0 || R <= 0) return GAMMA_HIP_OK;
+    if (!d_x || !d_ids || !d_exact) return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    GH_TRY(replay_join(h));
+    if (!h->d_raw || h->raw_d != h->d) return fail(h, GAMMA_HIP_EINVAL, "no raw store");
+    GH_CHECK(h, hipSetDevice(h->device));
+    // (a dense store answers for every id; a sharded one for the vectors it holds, the sentinel elsewhere)
+    gh::launch_rerank_dist(h->stream, p->metric == GAMMA_HIP_METRIC_L2, d_x, nq, h->d, h->d_raw, h->nraw, d_ids, R, p->min_score,
+                           p->max_score, d_exact, h->raw_sparse ? h->d_raw_slot : nullptr, h->raw_sparse ? h->raw_slot_cap : 0);
+    GH_CHECK(h, hipGetLastError());
+    return GAMMA_HIP_OK;
+}
+
+int gamma_hip_ivfpq_shard_export_exact(gamma_hip_index* h, const gamma_hip_search_params* p, int nf, const float* d_xf,
+                                       const float* d_vals, const int64_t* d_ids, const int32_t* d_off, int64_t stride,
+                                       const float* d_bound_f, float* d_ex) {
+    if (!h || !p) return GAMMA_HIP_EINVAL;
+    if (nf <= 0) return GAMMA_HIP_OK;
+    if (!d_xf || !d_vals || !d_ids || !d_off || !d_bound_f || !d_ex || stride < 1) return GAMMA_HIP_EINVAL;
+    SearchLock lk(h);
+    if (!h->d_raw || h->raw_d != h->d || !h->raw_sparse) return fail(h, GAMMA_HIP_EINVAL, "export of exact distances: a sharded raw store (gamma_hip_raw_put)");
+    GH_CHECK(h, hipSetDevice(h->device));
+    gh::launch_export_exact(h->stream, p->metric == GAMMA_HIP_METRIC_L2, d_xf, nf, h->d, h->d_raw, h->d_raw_slot, h->raw_slot_cap,
+                            d_vals, d_ids, stride, d_off, p->nprobe, d_bound_f, d_ex);
+    GH_CHECK(h, hipGetLastError());
+    return GAMMA_HIP_OK;
 }
 
 int gamma_hip_ivfpq_shard_cut_flags(gamma_hip_index* h, int nq, uint8_t* d_flags) {
@@ -2305,9 +2383,23 @@ int gamma_hip_ivfpq_shard_export(gamma_hip_index* h, const gamma_hip_search_para
     return GAMMA_HIP_OK;
 }
 
+static int merge_replay_impl(gamma_hip_index* h, const gamma_hip_search_params* p, int nshards, int nf, const float* d_x_slice,
+                             int64_t stride, const float* d_vals_all, const int64_t* d_ids_all, const int32_t* d_off_all, const float* d_ex_all,
+                             int k, const int32_t* d_list, float* d_distances, int64_t* d_labels);
 int gamma_hip_ivfpq_merge_replay(gamma_hip_index* h, const gamma_hip_search_params* p, int nshards, int nf, const float* d_x_slice,
                                  int64_t stride, const float* d_vals_all, const int64_t* d_ids_all, const int32_t* d_off_all, int k,
                                  const int32_t* d_list, float* d_distances, int64_t* d_labels) {
+    return merge_replay_impl(h, p, nshards, nf, d_x_slice, stride, d_vals_all, d_ids_all, d_off_all, nullptr, k, d_list, d_distances, d_labels);
+}
+int gamma_hip_ivfpq_merge_replay_exact(gamma_hip_index* h, const gamma_hip_search_params* p, int nshards, int nf, const float* d_x_slice,
+                                       int64_t stride, const float* d_vals_all, const int64_t* d_ids_all, const int32_t* d_off_all,
+                                       const float* d_ex_all, int k, const int32_t* d_list, float* d_distances, int64_t* d_labels) {
+    if (!d_ex_all) return GAMMA_HIP_EINVAL;
+    return merge_replay_impl(h, p, nshards, nf, d_x_slice, stride, d_vals_all, d_ids_all, d_off_all, d_ex_all, k, d_list, d_distances, d_labels);
+}
+static int merge_replay_impl(gamma_hip_index* h, const gamma_hip_search_params* p, int nshards, int nf, const float* d_x_slice,
+                             int64_t stride, const float* d_vals_all, const int64_t* d_ids_all, const int32_t* d_off_all, const float* d_ex_all,
+                             int k, const int32_t* d_list, float* d_distances, int64_t* d_labels) {
     if (!h) return GAMMA_HIP_EINVAL;
     SearchLock lk(h);
     GH_TRY(ivfpq_check(h, p, nf, k));
@@ -2319,7 +2411,8 @@ int gamma_hip_ivfpq_merge_replay(gamma_hip_index* h, const gamma_hip_search_para
     const bool l2 = p->metric == GAMMA_HIP_METRIC_L2;
     const int P = p->nprobe, R = std::max(p->recall_num, k);
     if (R > gh::tie_replay_max_k() || P > gh::tie_replay_max_probes()) return fail(h, GAMMA_HIP_EINVAL, "beyond the replay's range");
-    if (p->has_rank && (!h->d_raw || h->raw_d != h->d)) return fail(h, GAMMA_HIP_EINVAL, "has_rank needs the raw store");
+    if (p->has_rank && !d_ex_all && (!h->d_raw || h->raw_d != h->d || h->raw_sparse))
+        return fail(h, GAMMA_HIP_EINVAL, "has_rank needs the raw store (or the exact distances exported with the streams)");
     hipStream_t s = h->stream;
     const int64_t mstride = ((int64_t)nshards * stride + 3) & ~(int64_t)3;   // a row assembled from every shard's export
     GH_CHECK(h, h->w_mr_vals.ensure((size_t)nf * mstride * sizeof(float)));
@@ -2332,6 +2425,18 @@ int gamma_hip_ivfpq_merge_replay(gamma_hip_index* h, const gamma_hip_search_para
     gh::launch_merge_streams(s, nshards, nf, P, stride, mstride, d_vals_all, d_ids_all, d_off_all, h->w_mr_vals.as<float>(),
                              h->w_mr_ids.as<int64_t>(), m_off, m_base, l2 ? INFINITY : -INFINITY);
     gh::TieReplayArgs a;
+    if (d_ex_all && p->has_rank) {
+        // the exported exact distances, assembled probe by probe exactly like the ADC values (same positions); the ids of this
+        // second pass go to scratch.  A member of the recall_num-heap whose distance no shard exported is COUNTED and fails the call.
+        GH_CHECK(h, h->w_fslab.ensure((size_t)nf * mstride * sizeof(float)));
+        GH_CHECK(h, h->w_m_ids.ensure((size_t)nf * mstride * sizeof(int64_t)));
+        GH_CHECK(h, h->w_lm_cnt.ensure(64));
+        GH_CHECK(h, hipMemsetAsync(h->w_lm_cnt.p, 0, sizeof(int), s));
+        gh::launch_merge_streams(s, nshards, nf, P, stride, mstride, d_ex_all, d_ids_all, d_off_all, h->w_fslab.as<float>(),
+                                 h->w_m_ids.as<int64_t>(), m_off, m_base, __builtin_nanf(""));
+        a.ex_slab = h->w_fslab.as<float>();
+        a.ex_missing = h->w_lm_cnt.as<int>();
+    }
     a.list = d_list;
     a.count = count;
     a.nq = nf;
@@ -2364,6 +2469,12 @@ int gamma_hip_ivfpq_merge_replay(gamma_hip_index* h, const gamma_hip_search_para
     a.compact_rows = 1;
     gh::launch_tie_replay(s, l2, a);
     GH_CHECK(h, hipGetLastError());
+    if (a.ex_missing) {
+        int missing = 0;
+        GH_CHECK(h, hipMemcpyAsync(&missing, a.ex_missing, sizeof(int), hipMemcpyDeviceToHost, s));
+        GH_CHECK(h, hipStreamSynchronize(s));
+        if (missing) return fail(h, GAMMA_HIP_EDEVICE, "tie replay: a member of the recall_num-heap arrived without its exact distance");
+    }
     return GAMMA_HIP_OK;
 }
 

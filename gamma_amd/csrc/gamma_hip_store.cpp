@@ -768,6 +768,7 @@ int gamma_hip_raw_append(gamma_hip_index* h, int64_t n, const float* vecs) {
     if (!h || n < 0 || (n > 0 && !vecs)) return GAMMA_HIP_EINVAL;
     WriteLock lk(h);
     if (h->raw_d <= 0) return fail(h, GAMMA_HIP_EINVAL, "raw store not initialised");
+    if (h->raw_sparse) return fail(h, GAMMA_HIP_EUNSUPPORTED, "the raw store holds this shard's rows only (gamma_hip_raw_put)");
     if (n == 0) return GAMMA_HIP_OK;
     GH_CHECK(h, hipSetDevice(h->device));
     GH_TRY(raw_reserve(h, h->nraw + n));
@@ -778,9 +779,49 @@ int gamma_hip_raw_append(gamma_hip_index* h, int64_t n, const float* vecs) {
     return GAMMA_HIP_OK;
 }
 
+int gamma_hip_raw_put(gamma_hip_index* h, int64_t n, const int64_t* vids, const float* vecs) {
+    if (!h || n < 0 || (n > 0 && (!vids || !vecs))) return GAMMA_HIP_EINVAL;
+    WriteLock lk(h);
+    if (h->raw_d <= 0) return fail(h, GAMMA_HIP_EINVAL, "raw store not initialised");
+    if (!h->raw_sparse && h->nraw > 0) return fail(h, GAMMA_HIP_EINVAL, "raw_put on a store that holds rows by vector id");
+    if (n == 0) return GAMMA_HIP_OK;
+    int64_t lo = INT64_MAX, hi = -1;
+    for (int64_t i = 0; i < n; i++) {
+        if (vids[i] < 0 || vids[i] >= ((int64_t)1 << 31)) return fail(h, GAMMA_HIP_EINVAL, "raw_put: vector id out of range");
+        lo = std::min(lo, vids[i]);
+        hi = std::max(hi, vids[i]);
+    }
+    h->raw_sparse = true;
+    GH_CHECK(h, hipSetDevice(h->device));
+    GH_TRY(raw_reserve(h, h->nraw + n));
+    GH_CHECK(h, hipMemcpyAsync(h->d_raw + h->nraw * h->raw_d, vecs, (size_t)n * h->raw_d * sizeof(float),
+                               hipMemcpyHostToDevice, h->wstream));
+    if ((int64_t)h->h_raw_slot.size() <= hi) h->h_raw_slot.resize((size_t)hi + 1, -1);
+    for (int64_t i = 0; i < n; i++) h->h_raw_slot[vids[i]] = (int32_t)(h->nraw + i);
+    if (hi >= h->raw_slot_cap) {   // the device map grows: a new array, the whole mirror (readers are drained first)
+        const int64_t ncap = std::max<int64_t>(hi + 1 + (hi + 1) / 2, 1 << 16);
+        int32_t* np = nullptr;
+        if (h->wl) GH_CHECK(h, h->wl->exclusive());
+        GH_CHECK(h, hipMalloc((void**)&np, (size_t)ncap * sizeof(int32_t)));
+        GH_CHECK(h, hipMemsetAsync(np, 0xff, (size_t)ncap * sizeof(int32_t), h->wstream));
+        GH_CHECK(h, hipMemcpyAsync(np, h->h_raw_slot.data(), h->h_raw_slot.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->wstream));
+        GH_CHECK(h, hipStreamSynchronize(h->wstream));
+        if (h->d_raw_slot) GH_CHECK(h, hipFree(h->d_raw_slot));
+        h->d_raw_slot = np;
+        h->raw_slot_cap = ncap;
+    } else {
+        GH_CHECK(h, hipMemcpyAsync(h->d_raw_slot + lo, h->h_raw_slot.data() + lo, (size_t)(hi - lo + 1) * sizeof(int32_t),
+                                   hipMemcpyHostToDevice, h->wstream));
+    }
+    GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    h->nraw += n;
+    return GAMMA_HIP_OK;
+}
+
 int gamma_hip_raw_write(gamma_hip_index* h, int64_t first_vid, int64_t n, const float* vecs) {
     if (!h || n < 0 || first_vid < 0 || (n > 0 && !vecs)) return GAMMA_HIP_EINVAL;
     WriteLock lk(h);
+    if (h->raw_sparse) return fail(h, GAMMA_HIP_EUNSUPPORTED, "the raw store holds this shard's rows only (gamma_hip_raw_put)");
     if (h->raw_d <= 0) return fail(h, GAMMA_HIP_EINVAL, "raw store not initialised");
     if (first_vid > h->nraw) return fail(h, GAMMA_HIP_EINVAL, "raw write would leave a gap");
     if (n == 0) return GAMMA_HIP_OK;
@@ -796,6 +837,7 @@ int gamma_hip_raw_write(gamma_hip_index* h, int64_t first_vid, int64_t n, const 
 int gamma_hip_raw_update(gamma_hip_index* h, int64_t vid, const float* vec) {
     if (!h || !vec) return GAMMA_HIP_EINVAL;
     WriteLock lk(h);
+    if (h->raw_sparse) return fail(h, GAMMA_HIP_EUNSUPPORTED, "the raw store holds this shard's rows only (gamma_hip_raw_put)");
     if (vid < 0 || vid >= h->nraw) return fail(h, GAMMA_HIP_EINVAL, "vid out of range");
     GH_CHECK(h, hipSetDevice(h->device));
     GH_CHECK(h, hipMemcpyAsync(h->d_raw + vid * h->raw_d, vec, (size_t)h->raw_d * sizeof(float),
@@ -809,6 +851,7 @@ int gamma_hip_raw_update_batch(gamma_hip_index* h, int64_t n, const int64_t* vid
     if (!h || n < 0 || (n > 0 && (!vids || !vecs))) return GAMMA_HIP_EINVAL;
     if (n == 0) return GAMMA_HIP_OK;
     WriteLock lk(h);
+    if (h->raw_sparse) return fail(h, GAMMA_HIP_EUNSUPPORTED, "the raw store holds this shard's rows only (gamma_hip_raw_put)");
     GH_CHECK(h, hipSetDevice(h->device));
     for (int64_t i = 0; i < n; i++) {
         if (vids[i] < 0 || vids[i] >= h->nraw) continue;
@@ -825,6 +868,7 @@ int gamma_hip_raw_gets(gamma_hip_index* h, int64_t n, const int64_t* vids, float
     if (!h || n < 0 || (n > 0 && (!vids || !out))) return GAMMA_HIP_EINVAL;
     if (n == 0) return GAMMA_HIP_OK;
     WriteLock lk(h);   // no row is read half written
+    if (h->raw_sparse) return fail(h, GAMMA_HIP_EUNSUPPORTED, "the raw store holds this shard's rows only (gamma_hip_raw_put)");
     if (h->raw_d <= 0) return fail(h, GAMMA_HIP_EINVAL, "raw store not initialised");
     for (int64_t i = 0; i < n; i++)
         if (vids[i] < 0 || vids[i] >= h->nraw) return fail(h, GAMMA_HIP_EINVAL, "vid out of range");

@@ -335,7 +335,15 @@ void launch_map_candidates(hipStream_t s, const int* pos, int nq, int R, int P,
                            const int64_t* ids, int64_t* cand_ids, const uint8_t* only = nullptr);
 void launch_rerank_dist(hipStream_t s, bool l2, const float* x, int nq, int d, const float* raw,
                         int64_t nraw, const int64_t* cand_ids, int R, float min_score,
-                        float max_score, float* out);
+                        float max_score, float* out, const int32_t* slot = nullptr, int64_t nslot = 0);
+// raw vectors sharded with their lists (round 6).  slot [nslot]: vector id -> row of `raw` on THIS shard, -1 = held elsewhere.
+// _export_exact: ex[f][j] = exact distance (no score window) of entry j of exported stream row f when its ADC value is
+// within bound[f] and its vector is held here, NaN otherwise.  _lookup_exact: cand_exact[q][r] = the exact distance that
+// travelled with candidate cand_ids[q][r] in one of the W shard tables (all_ids / all_exact [W][nq][R]), sentinel if none.
+void launch_export_exact(hipStream_t s, bool l2, const float* xf, int nf, int d, const float* raw, const int32_t* slot, int64_t nslot,
+                         const float* vals, const int64_t* ids, int64_t stride, const int32_t* off, int P, const float* bound, float* ex);
+void launch_lookup_exact(hipStream_t s, bool l2, const float* all_dis, const int64_t* all_ids, const float* all_exact, int W, int nq, int R,
+                         int q0, int nql, const float* cand_dis, const int64_t* cand_ids, float* cand_exact);
 // Exact-tie bookkeeping (ties.hip, gamma_hip_set_exact_ties).  cut[q] != 0: the top-recall_num cut of query q
 // went through a group of equal ADC distances (set by the selection kernels).  The final-stage kernels add
 // their own condition -- two of the first k+1 final distances equal -- and append every query either one
@@ -371,6 +379,10 @@ struct TieReplayArgs {
     int d;
     const float* raw;             // raw vectors (has_rank)
     int64_t nraw;
+    const float* ex_slab = nullptr;   // raw vectors sharded with their lists (round 6): the exact distance of stream entry ps
+                                      // travelled with the shards' exports -- [rows][q_stride] like the slab, NaN where a shard
+                                      // did not compute it; read instead of the raw row
+    int* ex_missing = nullptr;        // counts R-heap members whose exact distance was NOT exported (must stay 0)
     int R, k, has_rank;
     float min_score, max_score, neutral;
     float* cand_dis;              // [nq][R] recall-stage table, rewritten for the replayed queries

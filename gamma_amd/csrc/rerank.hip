@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void k_rerank_dist(const float* __restrict__ x
                                                      const float* __restrict__ raw, int64_t nraw,
                                                      const int64_t* __restrict__ cand_ids, int R,
                                                      float min_score, float max_score,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ out, const int32_t* __restrict__ slot, int64_t nslot) {
     const int q = blockIdx.x;
     const int l = threadIdx.x & 7, g = threadIdx.x >> 3;
     const float* xq = x + (int64_t)q * d;
@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256) void k_rerank_dist(const float* __restrict__ x
         const int r = r0 + g;
         int64_t id = -1;
         if (r < R) id = cand_ids[(int64_t)q * R + r];
+        if (slot) id = (id >= 0 && id < nslot) ? (int64_t)slot[id] : -1;   // sharded raw store: the row of this vector HERE
         const bool live = id >= 0 && id < nraw;
         float dis = rerank_dist8<L2>(xq, raw + (live ? id : 0) * d, d, l, live);
         if (l == 0 && r < R) {
@@ -83,15 +84,118 @@ __global__ __launch_bounds__(256) void k_rerank_dist(const float* __restrict__ x
 }
 void launch_rerank_dist(hipStream_t s, bool l2, const float* x, int nq, int d, const float* raw,
                         int64_t nraw, const int64_t* cand_ids, int R, float min_score,
-                        float max_score, float* out) {
+                        float max_score, float* out, const int32_t* slot, int64_t nslot) {
     if (nq <= 0) return;
     const int gy = (R + 31) / 32;   // 32 candidates (8 lanes each) per workgroup
     if (l2)
         hipLaunchKernelGGL((k_rerank_dist<true>), dim3(nq, gy), dim3(256), 0, s, x, d, raw, nraw, cand_ids,
-                           R, min_score, max_score, out);
+                           R, min_score, max_score, out, slot, nslot);
     else
         hipLaunchKernelGGL((k_rerank_dist<false>), dim3(nq, gy), dim3(256), 0, s, x, d, raw, nraw,
-                           cand_ids, R, min_score, max_score, out);
+                           cand_ids, R, min_score, max_score, out, slot, nslot);
+}
+
+// Exact distances of the entries of an exported candidate stream that can still be members of the recall_num-heap: ADC value
+// within the query's bound and vector held on this shard.  One workgroup per exported row: the entries that qualify are
+// compacted 256 at a time (ballot), then scored 32 at a time, 8 lanes each (rerank_dist8: the arithmetic of k_rerank_topk).
+template <bool L2>
+__global__ __launch_bounds__(256) void k_export_exact(const float* __restrict__ xf, int d, const float* __restrict__ raw,
+                                                      const int32_t* __restrict__ slot, int64_t nslot, const float* __restrict__ vals,
+                                                      const int64_t* __restrict__ ids, int64_t stride, const int32_t* __restrict__ off,
+                                                      int P, const float* __restrict__ bound, float* __restrict__ ex) {
+    __shared__ int s_pos[256];
+    __shared__ int s_row[256];
+    __shared__ int s_n;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l8 = tid & 7, g = tid >> 3;
+    const int n = (int)min((int64_t)off[(int64_t)f * (P + 1) + P], stride);
+    const float b = bound[f];
+    const float* xq = xf + (int64_t)f * d;
+    const float qnan = __uint_as_float(0x7fc00000u);
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        const int j = j0 + tid;
+        bool want = false;
+        int row = -1;
+        if (j < n) {
+            const float v = vals[(int64_t)f * stride + j];
+            const int64_t id = ids[(int64_t)f * stride + j];
+            // (a filtered entry carries the sentinel: never within a finite bound; NaN bound = every entry)
+            const bool in = (b != b) || (L2 ? v <= b : v >= b);
+            row = (id >= 0 && id < nslot) ? slot[id] : -1;
+            want = in && row >= 0 && fabsf(v) != INFINITY;
+            if (!want) ex[(int64_t)f * stride + j] = qnan;
+        }
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        const unsigned long long bal = __ballot(want);
+        int base = 0;
+        if (lane == 0 && bal) base = atomicAdd(&s_n, __popcll(bal));
+        base = __shfl(base, 0, 64);
+        if (want) {
+            const int at = base + __popcll(bal & ((1ull << lane) - 1ull));
+            s_pos[at] = j;
+            s_row[at] = row;
+        }
+        __syncthreads();
+        const int m = s_n;
+        for (int c0 = 0; c0 < m; c0 += 32) {   // uniform trip count
+            const int c = c0 + g;
+            const bool live = c < m;
+            const float dis = rerank_dist8<L2>(xq, raw + (int64_t)(live ? s_row[c] : 0) * d, d, l8, live);
+            if (l8 == 0 && live) ex[(int64_t)f * stride + s_pos[c]] = dis;
+        }
+        __syncthreads();
+        (void)wv;
+    }
+}
+void launch_export_exact(hipStream_t s, bool l2, const float* xf, int nf, int d, const float* raw, const int32_t* slot, int64_t nslot,
+                         const float* vals, const int64_t* ids, int64_t stride, const int32_t* off, int P, const float* bound, float* ex) {
+    if (nf <= 0) return;
+    if (l2) hipLaunchKernelGGL((k_export_exact<true>), dim3(nf), dim3(256), 0, s, xf, d, raw, slot, nslot, vals, ids, stride, off, P, bound, ex);
+    else hipLaunchKernelGGL((k_export_exact<false>), dim3(nf), dim3(256), 0, s, xf, d, raw, slot, nslot, vals, ids, stride, off, P, bound, ex);
+}
+
+// The exact distance that travelled with each candidate of the merged table: every shard's table row is sorted by ADC value, a
+// candidate's (ADC value, id) pair sits in exactly one of them -- lower bound on the value, then the run of equal values.
+template <bool L2>
+__global__ __launch_bounds__(256) void k_lookup_exact(const float* __restrict__ all_dis, const int64_t* __restrict__ all_ids,
+                                                      const float* __restrict__ all_exact, int W, int nq, int R, int q0, int nql,
+                                                      const float* __restrict__ cand_dis, const int64_t* __restrict__ cand_ids,
+                                                      float* __restrict__ cand_exact) {
+    const int ql = blockIdx.x;
+    if (ql >= nql) return;
+    const float sentinel = L2 ? INFINITY : -INFINITY;
+    for (int r = threadIdx.x; r < R; r += 256) {
+        const int64_t id = cand_ids[(int64_t)ql * R + r];
+        const float v = cand_dis[(int64_t)ql * R + r];
+        float out = sentinel;
+        if (id >= 0) {
+            bool found = false;
+            for (int w = 0; w < W && !found; w++) {
+                const int64_t rb = ((int64_t)w * nq + q0 + ql) * R;
+                int lo = 0, hi = R;   // first position whose value is not better than v (rows are best first)
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const float t = all_dis[rb + mid];
+                    const bool before = all_ids[rb + mid] >= 0 && (L2 ? t < v : t > v);
+                    if (before) lo = mid + 1; else hi = mid;
+                }
+                for (int j = lo; j < R && all_ids[rb + j] >= 0 && all_dis[rb + j] == v; j++)
+                    if (all_ids[rb + j] == id) {
+                        out = all_exact[rb + j];
+                        found = true;
+                        break;
+                    }
+            }
+        }
+        cand_exact[(int64_t)ql * R + r] = out;
+    }
+}
+void launch_lookup_exact(hipStream_t s, bool l2, const float* all_dis, const int64_t* all_ids, const float* all_exact, int W, int nq, int R,
+                         int q0, int nql, const float* cand_dis, const int64_t* cand_ids, float* cand_exact) {
+    if (nql <= 0) return;
+    if (l2) hipLaunchKernelGGL((k_lookup_exact<true>), dim3(nql), dim3(256), 0, s, all_dis, all_ids, all_exact, W, nq, R, q0, nql, cand_dis, cand_ids, cand_exact);
+    else hipLaunchKernelGGL((k_lookup_exact<false>), dim3(nql), dim3(256), 0, s, all_dis, all_ids, all_exact, W, nq, R, q0, nql, cand_dis, cand_ids, cand_exact);
 }
 
 // ------------------------------------------------------------------------------------

@@ -239,8 +239,18 @@ __device__ __forceinline__ void tie_replay_query(const TieReplayArgs& a, int q, 
         for (int j0 = 0; j0 < R; j0 += NT / 8) {
             const int j = j0 + g;
             const int64_t id = j < R ? L.id[j] : -1;
-            const bool live = id >= 0 && id < a.nraw;
-            const float dis = rerank_dist8<L2>(xq, a.raw + (live ? id : 0) * a.d, a.d, l8, live);
+            bool live = id >= 0 && (a.ex_slab != nullptr || id < a.nraw);
+            float dis;
+            if (a.ex_slab) {   // (uniform) raw vectors sharded with their lists: the distance travelled with the entry
+                const int ps = j < R ? (int)L.hR[1 + j].y : -1;
+                dis = (live && ps >= 0) ? a.ex_slab[(int64_t)(slab_row >= 0 ? slab_row : q) * a.q_stride + ps] : 0.f;
+                if (live && dis != dis) {   // a member whose owner did not export its distance: never silent
+                    if (l8 == 0 && a.ex_missing) atomicAdd(a.ex_missing, 1);
+                    live = false;
+                }
+            } else {
+                dis = rerank_dist8<L2>(xq, a.raw + (live ? id : 0) * a.d, a.d, l8, live);
+            }
             if (l8 == 0 && j < R) {
                 const bool ok = live && dis <= a.max_score && dis >= a.min_score;   // IsSimilarScoreValid
                 L.ex[j] = ok ? (L2 ? dis : -dis) : INFINITY;   // +inf never beats the heap's top

@@ -63,10 +63,15 @@ class HipShardBackend:
     """Device backend: tensors live on the GPU, compute goes through the C ABI on the handle's
     stream, which is made torch's current stream so RCCL orders against it."""
 
-    def __init__(self, g, device):
+    def __init__(self, g, device, raw_sharded=False, owned=None):
+        """raw_sharded (round 6): this rank keeps the raw rows of the vectors in ITS lists only (gamma_hip_raw_put; `owned` = its
+        list mask); the exact distances of compute_dis are then computed by the shard that holds the row and travel with the
+        candidates (shard_exact / merge_rerank_exact; tie phase: shard_export_exact / merge_replay_exact)."""
         self.g = g
         self.device = torch.device("cuda", device)
         self.stream = torch.cuda.ExternalStream(g.stream(), device=self.device)
+        self.raw_sharded = bool(raw_sharded)
+        self.owned = None if owned is None else np.ascontiguousarray(owned, dtype=np.uint8)
 
     def empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, device=self.device)
@@ -77,6 +82,24 @@ class HipShardBackend:
         says which lists this rank owns (GammaHip.set_list_mask), encodes the batch and keeps only
         the vectors assigned to its own lists -- the insert reaches the owner of the list without
         any exchange."""
+        if self.raw_sharded:
+            # the batch is encoded here (every rank does: no exchange); entries AND rows of the vectors assigned to this rank's
+            # lists are kept -- lists in ascending order, entries in batch order, as the reference's std::map does
+            vecs = np.ascontiguousarray(vecs, dtype=np.float32)
+            lno, codes = self.g.encode(vecs)
+            lno = np.asarray(lno, dtype=np.int64)
+            nlist = len(self.owned)
+            bad = (lno < 0) | (lno >= nlist)
+            if bad.any():
+                lno = lno.copy()
+                lno[bad] = (first_vid + np.nonzero(bad)[0]) % nlist     # gamma_index_ivfpq.cc:475-481
+            mine = np.nonzero(self.owned[lno] != 0)[0]
+            if len(mine):
+                order = mine[np.argsort(lno[mine], kind="stable")]
+                lists, counts = np.unique(lno[order], return_counts=True)
+                self.g.add_keys_batch(lists, counts, (first_vid + order).astype(np.int64), np.asarray(codes)[order])
+                self.g.raw_put((first_vid + mine).astype(np.int64), vecs[mine])
+            return
         self.g.raw_append(vecs)
         self.g.add(vecs, first_vid)
 
@@ -133,12 +156,30 @@ class HipShardBackend:
                                           rdis.data_ptr(), rids.data_ptr(), bound.data_ptr(),
                                           (lambda n, take_max: reduce(take_max)) if reduce is not None else None)
 
-    def merge_rerank(self, all_dis, all_ids, x, k, args, nql, D, I):
-        """all_dis/all_ids [W, per, R]: candidates of this rank's slice from every shard"""
+    def merge_rerank(self, all_dis, all_ids, x, k, args, nql, D, I, all_exact=None):
+        """all_dis/all_ids [W, per, R]: candidates of this rank's slice from every shard (all_exact: their exact distances, when
+        the raw vectors are sharded with the lists)"""
         W, per = all_dis.shape[0], all_dis.shape[1]
-        if nql > 0:
+        if nql > 0 and all_exact is not None:
+            self.g.ivfpq_merge_rerank_exact(W, per, x.data_ptr(), k, args, all_dis.data_ptr(), all_ids.data_ptr(),
+                                            all_exact.data_ptr(), 0, nql, D.data_ptr(), I.data_ptr())
+        elif nql > 0:
             self.g.ivfpq_merge_rerank(W, per, x.data_ptr(), k, args, all_dis.data_ptr(),
                                       all_ids.data_ptr(), 0, nql, D.data_ptr(), I.data_ptr())
+
+    def shard_exact(self, x, ids, args, exact):
+        """exact[q][r] = compute_dis's distance of candidate ids[q][r] where this shard holds the row (sentinel elsewhere)"""
+        if x.shape[0]:
+            self.g.ivfpq_shard_exact(x.data_ptr(), x.shape[0], ids.data_ptr(), ids.shape[1], args, exact.data_ptr())
+
+    def shard_export_exact(self, xf, vals, ids, off, stride, bound_f, args, ex):
+        self.g.ivfpq_shard_export_exact(xf.shape[0], xf.data_ptr(), vals.data_ptr(), ids.data_ptr(), off.data_ptr(), stride,
+                                        bound_f.data_ptr(), args, ex.data_ptr())
+
+    def merge_replay_exact(self, vals_all, ids_all, off_all, ex_all, x_slice, stride, k, args, d_list, D, I):
+        W, nf = vals_all.shape[0], vals_all.shape[1]
+        self.g.ivfpq_merge_replay_exact(W, nf, x_slice.data_ptr(), stride, vals_all.data_ptr(), ids_all.data_ptr(), off_all.data_ptr(),
+                                        ex_all.data_ptr(), k, args, d_list, D.data_ptr(), I.data_ptr())
 
     # ---- exact ties across shards (include/gamma_hip.h; tie_phase below) ----
     def shard_cut_flags(self, n, flags):
@@ -274,6 +315,7 @@ def _buffers(backend, world, pers, P, R, k):
                 all_dis=backend.empty((world * per, R), f32), all_ids=backend.empty((world * per, R), i64),
                 cutf=backend.empty((world * per,), u8), cutall=backend.empty((world * per,), u8),
                 bound=backend.empty((world * per,), f32),
+                rex=backend.empty((world * per, R), f32), all_exact=backend.empty((world * per, R), f32),
                 res_l=res_l, I=res_l[:nres * 8].view(i64).view(per, k),
                 D=res_l[nres * 8:nres * 12].view(f32).view(per, k),
                 res=backend.empty((world, res_bytes), u8)))
@@ -292,7 +334,7 @@ def _exchange(rdis, rids, all_dis, all_ids, group):
 NB_TIGHTEN = 32   # edges per query of the second, tightening reduction (L2)
 
 
-def _packed_exchange(backend, rdis, rids, bound, n, world, per, R, l2, all_dis, all_ids, group, stats):
+def _packed_exchange(backend, rdis, rids, bound, n, world, per, R, l2, all_dis, all_ids, group, stats, exact_fn=None, all_exact=None):
     """The exchange of a two-phase step, PACKED: what a shard holds beyond the global bound cannot be in the global
     top-recall_num, so only the entries within it travel -- about recall_num per query over ALL shards instead of W x
     recall_num.  (1) L2: the bound is tightened first -- every shard counts its entries under 32 edges between 0 and
@@ -338,18 +380,25 @@ def _packed_exchange(backend, rdis, rids, bound, n, world, per, R, l2, all_dis, 
     recv = [int(v) for v in th[:, rank]]
     pk_dis = rdis[within]                                            # row-major: by owner, query, rank
     pk_ids = rids[within]
+    pk_ex = None
+    if exact_fn is not None:      # raw vectors sharded with the lists: the exact distance of what travels, computed where the row is
+        rex = exact_fn(torch.where(within, rids, torch.full_like(rids, -1)))
+        pk_ex = rex[within]
     rc_dis = torch.empty((sum(recv),), dtype=rdis.dtype, device=rdis.device)
     rc_ids = torch.empty((sum(recv),), dtype=rids.dtype, device=rids.device)
     rc_cnt = torch.empty((world, per), dtype=torch.int32, device=cnt.device)
+    rc_ex = torch.empty((sum(recv),), dtype=rdis.dtype, device=rdis.device) if pk_ex is not None else None
     if world > 1:
         w = [dist.all_to_all_single(rc_cnt.view(-1), cnt, group=group, async_op=True),
              dist.all_to_all_single(rc_dis, pk_dis, output_split_sizes=recv, input_split_sizes=send, group=group, async_op=True),
              dist.all_to_all_single(rc_ids, pk_ids, output_split_sizes=recv, input_split_sizes=send, group=group, async_op=True)]
+        if pk_ex is not None:
+            w.append(dist.all_to_all_single(rc_ex, pk_ex, output_split_sizes=recv, input_split_sizes=send, group=group, async_op=True))
         for x in w:
             x.wait()
     else:
         rc_cnt.view(-1).copy_(cnt)
-        rc_dis, rc_ids = pk_dis, pk_ids
+        rc_dis, rc_ids, rc_ex = pk_dis, pk_ids, pk_ex
     # unpack: entry e of the received stream belongs to row rowid[e] (shard-major, then query) at column e - start[row]
     flat_cnt = rc_cnt.view(-1).to(dev_long)
     start = torch.cumsum(flat_cnt, 0) - flat_cnt
@@ -361,9 +410,11 @@ def _packed_exchange(backend, rdis, rids, bound, n, world, per, R, l2, all_dis, 
         col = torch.arange(total, device=flat_cnt.device) - start[rowid]
         all_dis.view(world * per, R)[rowid, col] = rc_dis
         all_ids.view(world * per, R)[rowid, col] = rc_ids
+        if rc_ex is not None:
+            all_exact.view(world * per, R)[rowid, col] = rc_ex
     if stats is not None:
         stats["exchange_entries"] = stats.get("exchange_entries", 0) + sum(send) - send[rank]
-        stats["exchange_bytes"] = stats.get("exchange_bytes", 0) + (sum(send) - send[rank]) * 12 + (world - 1) * per * 4 + \
+        stats["exchange_bytes"] = stats.get("exchange_bytes", 0) + (sum(send) - send[rank]) * (16 if pk_ex is not None else 12) + (world - 1) * per * 4 + \
             (rows * NB_TIGHTEN * 4 if l2 else 0)
         stats["queries"] = stats.get("queries", 0) + n
 
@@ -383,7 +434,7 @@ def plan_sub_batches(nq, world, nsub):
     return [(bounds[j], bounds[j + 1]) for j in range(len(bounds) - 1) if bounds[j + 1] > bounds[j] or j == 0]
 
 
-def tie_phase(backend, x_slice, cdis_slice, probe_slice, nql, k, args, D, I, group=None):
+def tie_phase(backend, x_slice, cdis_slice, probe_slice, nql, k, args, D, I, group=None, bound_slice=None, raw_sharded=False):
     """Exact ties across shards, after merge_rerank of a (sub-)batch: the slice's owner lists the queries whose result
     a tie can change; their vectors and assignment rows go to every rank (broadcast), every rank exports the candidate
     streams over the lists it owns (gamma_hip_ivfpq_shard_export), the exports are gathered and the owner replays the
@@ -411,12 +462,17 @@ def tie_phase(backend, x_slice, cdis_slice, probe_slice, nql, k, args, D, I, gro
             xf = backend.empty((n, d), torch.float32)
             cf = backend.empty((n, P), torch.float32)
             pf = backend.empty((n, P), torch.int32)
+            bf = backend.empty((n, 1), torch.float32)   # raw vectors sharded: the bound under which an entry can be a heap member
             if rank == o:
                 lst = d_list + 4 * f0
                 backend.gather_rows(x_slice, lst, n, xf)
                 backend.gather_rows(cdis_slice.view(torch.float32), lst, n, cf)
                 backend.gather_rows(probe_slice, lst, n, pf)
-            for t in (xf, cf, pf):
+                if raw_sharded and bound_slice is not None:
+                    backend.gather_rows(bound_slice.view(-1, 1), lst, n, bf)
+                else:
+                    bf.fill_(float("nan"))               # no bound: every entry
+            for t in (xf, cf, pf) + ((bf,) if raw_sharded else ()):
                 dist.broadcast(t, src=src, group=group)
             # one row stride for the exports of all ranks: the longest row any of them has for these queries
             meta[0] = backend.shard_export_rows(pf, args)
@@ -432,7 +488,14 @@ def tie_phase(backend, x_slice, cdis_slice, probe_slice, nql, k, args, D, I, gro
             dist.all_gather_into_tensor(av.view(-1), vals.view(-1), group=group)
             dist.all_gather_into_tensor(ai.view(-1), ids.view(-1), group=group)
             dist.all_gather_into_tensor(ao.view(-1), off.view(-1), group=group)
-            if rank == o:
+            if raw_sharded:
+                ex = backend.empty((n, stride), torch.float32)
+                backend.shard_export_exact(xf, vals, ids, off, stride, bf.view(-1), args, ex)
+                ae = backend.empty((world, n, stride), torch.float32)
+                dist.all_gather_into_tensor(ae.view(-1), ex.view(-1), group=group)
+                if rank == o:
+                    backend.merge_replay_exact(av, ai, ao, ae, x_slice, stride, k, args, d_list + 4 * f0, D, I)
+            elif rank == o:
                 backend.merge_replay(av, ai, ao, x_slice, stride, k, args, d_list + 4 * f0, D, I)
 
 
@@ -464,6 +527,7 @@ def _sharded_search(backend, x, k, args, group, pipeline):
     two_phase = hasattr(backend, "search_shard_bounded") and os.environ.get("GAMMA_DIST_TWO_PHASE", "1") != "0"
     packed = two_phase and os.environ.get("GAMMA_DIST_PACKED", "1") != "0"
     stats = getattr(backend, "exchange_stats", None)   # a dict the caller hangs on the backend: entries / bytes this rank sent
+    raw_sharded = bool(getattr(backend, "raw_sharded", False)) and bool(args.p.has_rank)
     stream_ctx = torch.cuda.stream(backend.stream) if hasattr(backend, "stream") else _Null()
     with stream_ctx:
         bufs = _buffers(backend, world, pers, P, R, k)
@@ -506,12 +570,20 @@ def _sharded_search(backend, x, k, args, group, pipeline):
                 backend.search_shard_bounded(sb["x"], b["cdis"][:n], b["probe"][:n], k, args, rdis[:n], rids[:n], bound, reduce)
             else:
                 backend.search_shard(sb["x"], b["cdis"][:n], b["probe"][:n], k, args, rdis[:n], rids[:n])
+            exact_fn = None
+            if raw_sharded:
+                def exact_fn(ids_m, sb=sb, b=b, n=n):
+                    b["rex"].fill_(float("inf") if args.p.metric == METRIC_L2 else float("-inf"))
+                    backend.shard_exact(sb["x"], ids_m[:n].contiguous(), args, b["rex"][:n])
+                    return b["rex"]
             if two_phase and packed:
                 _packed_exchange(backend, rdis, rids, b["bound"], n, world, per, R, args.p.metric == METRIC_L2,
-                                 b["all_dis"], b["all_ids"], group, stats)
+                                 b["all_dis"], b["all_ids"], group, stats, exact_fn, b["all_exact"])
                 sb["w"] = []
             else:
                 sb["w"] = _exchange(rdis, rids, b["all_dis"], b["all_ids"], group)
+                if raw_sharded:
+                    sb["w"].append(dist.all_to_all_single(b["all_exact"], exact_fn(rids), group=group, async_op=True))
                 if stats is not None:
                     stats["exchange_entries"] = stats.get("exchange_entries", 0) + (world - 1) * per * R
                     stats["exchange_bytes"] = stats.get("exchange_bytes", 0) + (world - 1) * per * R * 12
@@ -534,12 +606,16 @@ def _sharded_search(backend, x, k, args, group, pipeline):
                 I.fill_(-1)
             if hasattr(backend, "shard_cut_flags") and args.p.exact_ties >= 0 and nql > 0:
                 backend.merge_set_shard_flags(b["cutall"])
-            backend.merge_rerank(b["all_dis"].view(world, per, R), b["all_ids"].view(world, per, R),
-                                 sb["x"][sb["q0"]:sb["q1"]], k, args, nql, D, I)
+            if raw_sharded:
+                backend.merge_rerank(b["all_dis"].view(world, per, R), b["all_ids"].view(world, per, R),
+                                     sb["x"][sb["q0"]:sb["q1"]], k, args, nql, D, I, all_exact=b["all_exact"].view(world, per, R))
+            else:
+                backend.merge_rerank(b["all_dis"].view(world, per, R), b["all_ids"].view(world, per, R),
+                                     sb["x"][sb["q0"]:sb["q1"]], k, args, nql, D, I)
             if args.p.exact_ties >= 0:   # (the handle's default is on; -1 = off for this request)
                 o0 = rank * per
                 tie_phase(backend, sb["x"][sb["q0"]:sb["q1"]], b["cdis"][o0:o0 + nql], b["probe"][o0:o0 + nql], nql, k, args, D, I,
-                          group)
+                          group, bound_slice=(b["bound"][o0:o0 + nql] if two_phase else None), raw_sharded=raw_sharded)
             pending.append((sb, dist.all_gather_into_tensor(b["res"].view(-1), b["res_l"], group=group, async_op=True)))
         for sb, w in pending:
             w.wait()

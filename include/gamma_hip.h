@@ -219,6 +219,14 @@ int gamma_hip_raw_write(gamma_hip_index* h, int64_t first_vid, int64_t n, const 
 /* VectorReader::Gets (vector/raw_vector.cc:99-109, vector/memory_raw_vector.cc:136-142): rows vids[0..n) of the device
  * store copied to out [n][d] (the rows compute_dis reads); GAMMA_HIP_EINVAL for a vid outside [0, gamma_hip_raw_count) */
 int gamma_hip_raw_gets(gamma_hip_index* h, int64_t n, const int64_t* vids, float* out);
+/* Raw vectors SHARDED WITH THEIR LISTS (round 6; SURVEY 8(e): "shard by the same owner"): a list shard of a multi-GPU job keeps
+ * the rows of the vectors in ITS lists only -- rows vecs[i] of vector ids vids[i], in any order, appended to the store with a
+ * vid -> row table (4 bytes per vector id) beside it; C4 on 8 GPUs: 6.4 GB of rows per GPU instead of 51.2.  The first call
+ * turns the (empty) store into that form for good.  Such a handle serves gamma_hip_ivfpq_shard_exact / _shard_export_exact; what
+ * needs every row -- has_rank inside a search on this handle, flat / IVFFLAT search, raw_gets / raw_write / raw_update --
+ * answers GAMMA_HIP_EUNSUPPORTED.  Replaces MemoryRawVector::GetVector for the rows a shard owns
+ * (vector/memory_raw_vector.cc:136-142). */
+int gamma_hip_raw_put(gamma_hip_index* h, int64_t n, const int64_t* vids, const float* vecs);
 int64_t gamma_hip_raw_count(gamma_hip_index* h);
 /* out4 = {rows, rows the mapped / allocated memory holds, reallocations that MOVED the store so far, 1 when the store
  * grows in place (virtual memory management: physical chunks mapped behind the rows, nothing ever moves or waits for
@@ -457,6 +465,31 @@ int gamma_hip_ivfpq_search_shard_bounded(gamma_hip_index* h, const gamma_hip_sea
  * d_acc[i] = min (take_max = 0) / max (1) of d_acc[i] and d_in[i], i < n, enqueued on `stream` of the calling thread's
  * current device.  Takes no handle and no lock: it is called from inside _search_shard_bounded's callback. */
 int gamma_hip_bound_combine(void* stream, float* d_acc, const float* d_in, int n, int take_max);
+/* compute_dis's exact distances (gamma_index_ivfpq.cc:646-680: fvec_L2sqr / fvec_inner_product on the raw query, then
+ * IsSimilarScoreValid) where the ROWS are: d_exact[q][r] for candidate d_ids[q][r] (device, [nq][R]; -1 = none) of query
+ * d_x[q] -- the sentinel (+inf L2 / -inf inner product) for an empty slot, a score outside the request's window, or a vector
+ * this handle's sharded store does not hold.  With raw vectors sharded by list owner every shard calls this on the candidates
+ * it is about to send (after the two-phase scan: ~recall_num / W per query) and the distances travel with them. */
+int gamma_hip_ivfpq_shard_exact(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* d_x,
+                                const int64_t* d_ids, int R, float* d_exact);
+/* gamma_hip_ivfpq_merge_rerank for candidates that arrive WITH their exact distances (d_all_exact laid out like d_all_dis):
+ * the global top-recall_num by ADC value as ever, then compute_dis's k-heap fed from the travelled distances -- the owner of
+ * the query slice needs no raw row.  Same results, flags and tie list as _merge_rerank on a handle that holds every row. */
+int gamma_hip_ivfpq_merge_rerank_exact(gamma_hip_index* h, const gamma_hip_search_params* p, int nshards, int nq,
+                                       const float* d_x, int k, const float* d_all_dis, const int64_t* d_all_ids,
+                                       const float* d_all_exact, int q0, int nq_local, float* d_distances, int64_t* d_labels);
+/* the tie phase with sharded raw vectors: after gamma_hip_ivfpq_shard_export the shard computes the exact distance (no score
+ * window) of every exported entry whose ADC value lies within the query's bound d_bound_f[f] (NaN: of every entry) and whose
+ * vector it holds -- the only entries that can end up in the recall_num-heap -- into d_ex [nf][stride], NaN elsewhere;
+ * gamma_hip_ivfpq_merge_replay_exact assembles those streams beside the ADC values and the replay reads a member's distance
+ * there instead of its row.  A member without a travelled distance fails the call (never silent). */
+int gamma_hip_ivfpq_shard_export_exact(gamma_hip_index* h, const gamma_hip_search_params* p, int nf, const float* d_xf,
+                                       const float* d_vals, const int64_t* d_ids, const int32_t* d_off, int64_t stride,
+                                       const float* d_bound_f, float* d_ex);
+int gamma_hip_ivfpq_merge_replay_exact(gamma_hip_index* h, const gamma_hip_search_params* p, int nshards, int nf,
+                                       const float* d_x_slice, int64_t stride, const float* d_vals_all, const int64_t* d_ids_all,
+                                       const int32_t* d_off_all, const float* d_ex_all, int k, const int32_t* d_list,
+                                       float* d_distances, int64_t* d_labels);
 /* sharded search, stage 2: merge nshards*recall_num candidates per query (layout
  * [shard][nq][recall_num]) into the global top-recall_num, then compute_dis (re-rank or
  * truncate, gamma_index_ivfpq.cc:642-697) for queries [q0, q0+nq_local) */

@@ -153,6 +153,64 @@ def main():
             Dt, It = gdist.sharded_search(bt, xt, kk, at, pipeline=pipeline)
             torch.cuda.synchronize()
             compare_exact(np.tile(D1, (reps, 1))[:len(qh)], np.tile(I1, (reps, 1))[:len(qh)], Dt.cpu().numpy(), It.cpu().numpy())
+    # ---- raw vectors SHARDED with their lists (round 6): every rank keeps the rows of its lists only, the exact distances
+    #      travel with the candidates (packed exchange) and with the tie phase's exported streams ----
+    # (a) tie-heavy data, rows by gamma_hip_raw_put; labels strictly the pinned oracle's
+    gs = api.GammaHip(local)
+    gs.ivfpq_init(int(z["d"]), int(z["nlist"]), int(z["M"]), 8, metric)
+    gs.ivfpq_set_trained(z["cc_l2"], z["pq_l2"], None)
+    gs.add_keys_batch(ls, [int(sizes[l]) for l in ls], np.concatenate([z["list_ids_l2"][offs[l]:offs[l + 1]] for l in ls]),
+                      np.concatenate([z["list_codes_l2"][offs[l]:offs[l + 1]] for l in ls]))
+    own_mask = (np.asarray(own) == rank).astype(np.uint8)
+    gs.set_list_mask(own_mask)
+    gs.raw_init(int(z["d"]))
+    mine = np.unique(np.concatenate([z["list_ids_l2"][offs[l]:offs[l + 1]] for l in ls]) & 0x7fffffffffffffff)
+    gs.raw_put(mine, base[mine])
+    assert gs.raw_stats()["rows"] == len(mine) < len(base)
+    bs = gdist.HipShardBackend(gs, local, raw_sharded=True, owned=own_mask)
+    for has_rank, reps in ((True, 1), (True, 9), (False, 9)):
+        nprobe, R, kk = 12, 60, 10
+        D1, I1 = o.search(z["q"], kk, nprobe, recall_num=R, has_rank=has_rank, metric=metric, ctx=B.make_ctx(**wide), coarse_mode=0)
+        qh = np.tile(z["q"], (reps, 1))[:len(z["q"]) * reps - (reps > 1)]
+        at = api.SearchArgs(metric=metric, nprobe=nprobe, recall_num=R, has_rank=has_rank, coarse_mode=0, **wide)
+        xt = torch.from_numpy(qh).to(dev)
+        for pipeline, env in ((None, {}), (2, {}), (None, {"GAMMA_DIST_PACKED": "0"}), (None, {"GAMMA_DIST_TWO_PHASE": "0"})):
+            os.environ.update(env)
+            Dt, It = gdist.sharded_search(bs, xt, kk, at, pipeline=pipeline)
+            torch.cuda.synchronize()
+            for kx in env:
+                os.environ.pop(kx)
+            compare_exact(np.tile(D1, (reps, 1))[:len(qh)], np.tile(I1, (reps, 1))[:len(qh)], Dt.cpu().numpy(), It.cpu().numpy())
+    # (b) the product's Add under the rank's list mask keeps entries AND rows of its own lists (HipShardBackend.add): the
+    #     sharded result is the unsharded handle's, which holds every row
+    ga = api.GammaHip(local)
+    ga.ivfpq_init(case["d"], case["nlist"], case["M"], 8, case["metric"], 1000)
+    ga.ivfpq_set_trained(case["cc"], case["pq"], None)
+    owned_c = (np.asarray(owner) == rank).astype(np.uint8)
+    ga.set_list_mask(owned_c)
+    ga.raw_init(case["d"])
+    ba = gdist.HipShardBackend(ga, local, raw_sharded=True, owned=owned_c)
+    allv = np.concatenate([case["base"], extra])
+    fa = api.GammaHip(local)
+    fa.ivfpq_init(case["d"], case["nlist"], case["M"], 8, case["metric"], 1000)
+    fa.ivfpq_set_trained(case["cc"], case["pq"], None)
+    fa.raw_init(case["d"])
+    for i0 in range(0, len(allv), 4000):
+        ba.add(allv[i0:i0 + 4000], i0)
+        fa.raw_append(allv[i0:i0 + 4000])
+        fa.add(allv[i0:i0 + 4000], i0)
+    tot = torch.tensor([ga.raw_stats()["rows"]], dtype=torch.int64)
+    dist.all_reduce(tot)
+    assert int(tot.item()) == len(allv) and ga.raw_stats()["rows"] < len(allv)
+    xq = torch.from_numpy(synth.sift_like(700, d=case["d"], seed=78)).to(dev)
+    a2 = api.SearchArgs(metric=api.METRIC_L2, nprobe=16, recall_num=100, has_rank=True, min_score=-3e38, max_score=3e38, coarse_mode=1)
+    Dr2 = torch.empty((700, k), dtype=torch.float32, device=dev)
+    Ir2 = torch.empty((700, k), dtype=torch.int64, device=dev)
+    fa.ivfpq_search_device(xq.data_ptr(), 700, k, a2, Dr2.data_ptr(), Ir2.data_ptr())
+    fa.synchronize()
+    D, I = gdist.sharded_search(ba, xq, k, a2)
+    torch.cuda.synchronize()
+    compare_exact(Dr2.cpu().numpy(), Ir2.cpu().numpy(), D.cpu().numpy(), I.cpu().numpy())
     dist.destroy_process_group()
     print("rank %d ok" % rank)
 

@@ -289,6 +289,14 @@ int gamma_hip_ivfpq_search_device_wait(gamma_hip_index* h, const gamma_hip_searc
 }
 /* list-shard entry points: not reached in replicate placement */
 int gamma_hip_bound_combine(void*, float*, const float*, int, int) { return GAMMA_HIP_EUNSUPPORTED; }
+int gamma_hip_raw_put(gamma_hip_index*, int64_t, const int64_t*, const float*) { return GAMMA_HIP_EUNSUPPORTED; }
+int gamma_hip_ivfpq_shard_exact(gamma_hip_index*, const gamma_hip_search_params*, int, const float*, const int64_t*, int, float*) { return GAMMA_HIP_EUNSUPPORTED; }
+int gamma_hip_ivfpq_merge_rerank_exact(gamma_hip_index*, const gamma_hip_search_params*, int, int, const float*, int, const float*, const int64_t*,
+                                       const float*, int, int, float*, int64_t*) { return GAMMA_HIP_EUNSUPPORTED; }
+int gamma_hip_ivfpq_shard_export_exact(gamma_hip_index*, const gamma_hip_search_params*, int, const float*, const float*, const int64_t*,
+                                       const int32_t*, int64_t, const float*, float*) { return GAMMA_HIP_EUNSUPPORTED; }
+int gamma_hip_ivfpq_merge_replay_exact(gamma_hip_index*, const gamma_hip_search_params*, int, int, const float*, int64_t, const float*,
+                                       const int64_t*, const int32_t*, const float*, int, const int32_t*, float*, int64_t*) { return GAMMA_HIP_EUNSUPPORTED; }
 int gamma_hip_ivfpq_search_shard_bounded(gamma_hip_index*, const gamma_hip_search_params*, int, const float*, const float*, const int32_t*,
                                          int, float*, int64_t*, float*, gamma_hip_bound_reduce_fn, void*) { return GAMMA_HIP_EUNSUPPORTED; }
 int gamma_hip_gather_rows(gamma_hip_index*, const void*, int, const int32_t*, int, void*) { return GAMMA_HIP_EUNSUPPORTED; }

@@ -16,7 +16,7 @@ from gamma_amd import api
 from gamma_amd import dist as gdist
 
 
-def sharded_search_emulated(shards, x, k, args, use_shard_flags=True, two_phase=None):
+def sharded_search_emulated(shards, x, k, args, use_shard_flags=True, two_phase=None, raw_sharded=False):
     """shards: W api.GammaHip handles, each holding the lists it owns.  x: [nq, d] float32 tensor on cuda:0.
     Returns (D, I, flagged): [nq, k] result tensors and the number of queries that went through the tie phase.
     two_phase (default: on, GAMMA_TEST_TWO_PHASE=0 turns it off): the shard scans run through
@@ -25,6 +25,11 @@ def sharded_search_emulated(shards, x, k, args, use_shard_flags=True, two_phase=
     it the minimum (L2) / maximum (inner product) over all shards."""
     if two_phase is None:
         two_phase = os.environ.get("GAMMA_TEST_TWO_PHASE", "1") != "0"
+    # raw_sharded: every shard holds the raw rows of ITS lists only (gamma_hip_raw_put): the exact distances of compute_dis are
+    # computed by the shard that holds the row and travel with its candidates (shard_exact -> merge_rerank_exact), in the tie
+    # phase with the exported streams (shard_export_exact -> merge_replay_exact)
+    raw_sharded = raw_sharded and bool(args.p.has_rank)
+    rx = []
     W = len(shards)
     nq, d = x.shape
     P = args.p.nprobe
@@ -82,6 +87,11 @@ def sharded_search_emulated(shards, x, k, args, use_shard_flags=True, two_phase=
             backs[s].search_shard_bounded(x, cd_all, pr_all, k, args, rdis, rids, b, reduce)
         else:
             backs[s].search_shard(x, cd_all, pr_all, k, args, rdis, rids)
+        if raw_sharded:
+            rex = torch.empty((nq, R), dtype=torch.float32, device=dev)
+            shards[s].synchronize()
+            shards[s].ivfpq_shard_exact(x.data_ptr(), nq, rids.data_ptr(), R, args, rex.data_ptr())
+            rx.append(rex)
         backs[s].shard_cut_flags(nq, cutf)
         shards[s].synchronize()
         rd.append(rdis)
@@ -104,8 +114,14 @@ def sharded_search_emulated(shards, x, k, args, use_shard_flags=True, two_phase=
         torch.cuda.synchronize()
         if use_shard_flags:   # (without: every table that ends at the cut value counts as a tie)
             shards[r].ivfpq_merge_set_shard_flags(cut_all.data_ptr())
-        shards[r].ivfpq_merge_rerank(W, nql, xs.data_ptr(), k, args, all_dis.data_ptr(), all_ids.data_ptr(), 0, nql,
-                                     Dr.data_ptr(), Ir.data_ptr())
+        if raw_sharded:
+            all_ex = torch.stack([rx[s][q0:q1] for s in range(W)]).contiguous()
+            torch.cuda.synchronize()
+            shards[r].ivfpq_merge_rerank_exact(W, nql, xs.data_ptr(), k, args, all_dis.data_ptr(), all_ids.data_ptr(),
+                                               all_ex.data_ptr(), 0, nql, Dr.data_ptr(), Ir.data_ptr())
+        else:
+            shards[r].ivfpq_merge_rerank(W, nql, xs.data_ptr(), k, args, all_dis.data_ptr(), all_ids.data_ptr(), 0, nql,
+                                         Dr.data_ptr(), Ir.data_ptr())
         nf, d_list = shards[r].ivfpq_merge_flagged() if args.p.exact_ties >= 0 else (0, 0)
         flagged += nf
         if nf:
@@ -123,12 +139,28 @@ def sharded_search_emulated(shards, x, k, args, use_shard_flags=True, two_phase=
             vals = torch.empty((W, nf, stride), dtype=torch.float32, device=dev)
             ids = torch.empty((W, nf, stride), dtype=torch.int64, device=dev)
             off = torch.empty((W, nf, P + 1), dtype=torch.int32, device=dev)
+            exs = torch.empty((W, nf, stride), dtype=torch.float32, device=dev) if raw_sharded else None
+            bf = None
+            if raw_sharded:   # the bound under which an entry can still be a member of the recall_num-heap (NaN: every entry)
+                bf = torch.full((nf,), float("nan"), dtype=torch.float32, device=dev)
+                if glob is not None:
+                    gs = glob[q0:q1].contiguous().view(-1, 1)
+                    torch.cuda.synchronize()
+                    shards[r].gather_rows(gs.data_ptr(), 1, d_list, nf, bf.data_ptr())
+                    shards[r].synchronize()
             for s in range(W):
                 shards[s].ivfpq_shard_export(nf, xf.data_ptr(), cf.data_ptr(), pf.data_ptr(), stride, args, vals[s].data_ptr(),
                                              ids[s].data_ptr(), off[s].data_ptr())
+                if raw_sharded:
+                    shards[s].ivfpq_shard_export_exact(nf, xf.data_ptr(), vals[s].data_ptr(), ids[s].data_ptr(), off[s].data_ptr(), stride,
+                                                       bf.data_ptr(), args, exs[s].data_ptr())
                 shards[s].synchronize()
-            shards[r].ivfpq_merge_replay(W, nf, xs.data_ptr(), stride, vals.data_ptr(), ids.data_ptr(), off.data_ptr(), k, args,
-                                         d_list, Dr.data_ptr(), Ir.data_ptr())
+            if raw_sharded:
+                shards[r].ivfpq_merge_replay_exact(W, nf, xs.data_ptr(), stride, vals.data_ptr(), ids.data_ptr(), off.data_ptr(),
+                                                   exs.data_ptr(), k, args, d_list, Dr.data_ptr(), Ir.data_ptr())
+            else:
+                shards[r].ivfpq_merge_replay(W, nf, xs.data_ptr(), stride, vals.data_ptr(), ids.data_ptr(), off.data_ptr(), k, args,
+                                             d_list, Dr.data_ptr(), Ir.data_ptr())
         shards[r].synchronize()
         D[q0:q1] = Dr
         I[q0:q1] = Ir

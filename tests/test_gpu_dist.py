@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _shard_handle(case, owner, s):
+def _shard_handle(case, owner, s, raw_sharded=False):
     from gamma_amd import api
     g = api.GammaHip(0)
     g.ivfpq_init(case["d"], case["nlist"], case["M"], 8, case["metric"], 1000)
@@ -33,11 +33,16 @@ def _shard_handle(case, owner, s):
             codes.append(cds)
     g.add_keys_batch(lists, counts, np.concatenate(vids), np.concatenate(codes))
     g.raw_init(case["d"])
-    g.raw_append(case["base"])
+    if raw_sharded:   # the rows of this shard's vectors only, in list order (any order will do)
+        mine = np.concatenate(vids)
+        for i0 in range(0, len(mine), 3000):   # several puts: the vid -> row table grows and is patched
+            g.raw_put(mine[i0:i0 + 3000], case["base"][mine[i0:i0 + 3000]])
+    else:
+        g.raw_append(case["base"])
     return g
 
 
-def _sharded_vs_full(case, shards, full, metric, has_rank, W, nq, P):
+def _sharded_vs_full(case, shards, full, metric, has_rank, W, nq, P, raw_sharded=False):
     import torch
     from gamma_amd import api
     from gamma_amd import dist as gdist
@@ -53,7 +58,7 @@ def _sharded_vs_full(case, shards, full, metric, has_rank, W, nq, P):
     full.ivfpq_search_device(x.data_ptr(), nq, k, args, Dref.data_ptr(), Iref.data_ptr())
     full.synchronize()
     from tests.shard_emul import sharded_search_emulated
-    D, I, _ = sharded_search_emulated(shards, x, k, args)      # incl. the tie phase across the shards
+    D, I, _ = sharded_search_emulated(shards, x, k, args, raw_sharded=raw_sharded)      # incl. the tie phase across the shards
     compare_exact(Dref.cpu().numpy(), Iref.cpu().numpy(), D[:nq].cpu().numpy(), I[:nq].cpu().numpy())
 
 
@@ -82,6 +87,42 @@ def test_shards_on_one_gpu(metric, has_rank, W, nq, P, d, M):
     _sharded_vs_full(case, shards, full, metric, has_rank, W, nq, P)
     for g in shards + [full]:
         g.close()
+
+
+@pytest.mark.parametrize("metric,W,nq,P,d,M,two_phase", [
+    (B.METRIC_L2, 2, 61, 8, 32, 8, True), (B.METRIC_L2, 3, 603, 32, 32, 8, True), (B.METRIC_IP, 2, 603, 32, 32, 8, True),
+    (B.METRIC_L2, 4, 4200, 32, 64, 16, True), (B.METRIC_L2, 3, 4200, 16, 32, 8, False), (B.METRIC_IP, 3, 4200, 32, 64, 16, True),
+])
+def test_shards_with_their_own_raw_rows(metric, W, nq, P, d, M, two_phase, monkeypatch):
+    """Raw vectors sharded with their lists (round 6): every shard holds the rows of ITS lists only, the exact
+    distances of compute_dis are computed where the row is and travel with the candidates; results are those of ONE handle
+    that holds everything -- labels and distance bits at every rank, the tie phase included.  And what needs every row
+    refuses on such a handle."""
+    import torch
+    from gamma_amd import api
+    from gamma_amd import dist as gdist
+    monkeypatch.setenv("GAMMA_TEST_TWO_PHASE", "1" if two_phase else "0")
+    case = fixtures.trained_case(d=d, nlist=64, M=M, N=20000, nq=64, metric=B.METRIC_L2)
+    sizes = np.array([case["oracle"].list_size(l) for l in range(case["nlist"])])
+    owner = gdist.balance_lists(sizes, W)
+    full = fixtures.load_hip(case)
+    shards = [_shard_handle(case, owner, s, raw_sharded=True) for s in range(W)]
+    try:
+        rows = sum(g.raw_stats()["rows"] for g in shards)
+        assert rows == 20000 and all(g.raw_stats()["rows"] < 20000 * 0.75 for g in shards)
+        _sharded_vs_full(case, shards, full, metric, True, W, nq, P, raw_sharded=True)
+        _sharded_vs_full(case, shards, full, metric, False, W, min(nq, 603), P, raw_sharded=True)   # no re-rank: nothing travels
+        # never silent: a search that would re-rank from the handle's own store, flat search, row reads
+        a = api.SearchArgs(metric=metric, nprobe=P, recall_num=100, has_rank=True, min_score=-3e38, max_score=3e38)
+        with pytest.raises(api.GammaHipError, match="raw rows only|rows only"):
+            shards[0].ivfpq_search(case["q"][:300], 10, a)
+        with pytest.raises(api.GammaHipError, match="rows only"):
+            shards[0].flat_search(case["q"][:4], 10, a)
+        with pytest.raises(api.GammaHipError, match="rows only"):
+            shards[0].raw_append(case["base"][:2])
+    finally:
+        for g in shards + [full]:
+            g.close()
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -254,6 +295,10 @@ def test_update_across_shards():
     ("c4", ["--scale-n", "400000", "--scale-nlist", "1024", "--scale-nq", "1500", "--scale-recall-num", "150"]),
     ("c5", ["--scale-n", "120000", "--scale-nlist", "256", "--scale-nq", "700", "--scale-recall-num", "300", "--insert-seconds", "5",
             "--insert-rate", "4000"]),
+    # raw vectors sharded with their lists (round 6): every rank keeps its own rows, exact distances travel with the candidates
+    ("c4", ["--scale-n", "400000", "--scale-nlist", "1024", "--scale-nq", "1500", "--scale-recall-num", "150", "--raw-placement", "sharded"]),
+    ("c5", ["--scale-n", "120000", "--scale-nlist", "256", "--scale-nq", "700", "--scale-recall-num", "300", "--insert-seconds", "5",
+            "--insert-rate", "4000", "--raw-placement", "sharded"]),
 ])
 def test_bench_workload_c4_c5_streamed_two_ranks_on_one_gpu(workload, extra, tmp_path):
     """`bench.py --workload c4|c5 --gpus 2` (bench_scale.py), the entry point of the two 8-GPU configurations, at reduced N
@@ -273,7 +318,10 @@ def test_bench_workload_c4_c5_streamed_two_ranks_on_one_gpu(workload, extra, tmp
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
     cfg = line["config"]
     assert len(cfg["per_rank"]) == 2 and sum(p["shard_vectors"] for p in cfg["per_rank"]) == int(float(extra[1]))
-    assert "no RCCL communicator" in cfg["communicator"] and "replicated" in cfg["raw_placement"]
+    sharded_raw = "sharded" in extra
+    assert "no RCCL communicator" in cfg["communicator"] and cfg["raw_placement"].startswith("sharded" if sharded_raw else "replicated")
+    if sharded_raw:   # each rank holds about half of the rows (+ the 4-byte table): well under the replicated store
+        assert all(p["device_gb"] < 0.8 * line["config"]["per_rank"][0]["device_gb"] + 1.0 for p in cfg["per_rank"])
     if workload == "c5":
         ins = cfg["search_during_inserts"]
         assert ins["inserted"] > 0 and "writer_error" not in ins, ins

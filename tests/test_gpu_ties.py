@@ -359,7 +359,7 @@ def test_deferred_replay_streams_of_device_calls():
         g.close()
 
 
-def _shard_of(z, tag, base, metric, owner, s):
+def _shard_of(z, tag, base, metric, owner, s, raw_sharded=False):
     g = api.GammaHip(0)
     g.ivfpq_init(int(z["d"]), int(z["nlist"]), int(z["M"]), 8, metric)
     g.ivfpq_set_trained(z["cc_" + tag], z["pq_" + tag], None)
@@ -376,14 +376,21 @@ def _shard_of(z, tag, base, metric, owner, s):
     mask = (np.asarray(owner) == s).astype(np.uint8)
     g.set_list_mask(mask)
     g.raw_init(int(z["d"]))
-    g.raw_append(base)
+    if raw_sharded:   # raw vectors sharded with their lists: the rows of this shard's vectors only (duplicates in the golden's
+        mine = np.unique(np.concatenate(vids) & 0x7fffffffffffffff)   # lists -- moved entries -- are one row)
+        g.raw_put(mine, base[mine])
+    else:
+        g.raw_append(base)
     return g
 
 
-@pytest.mark.parametrize("tag,W,reps,has_rank,small_budget", [
-    ("l2", 2, 1, True, False), ("l2", 3, 13, True, False), ("ip", 2, 13, True, False), ("l2", 2, 13, False, False),
-    ("l2", 4, 90, True, False), ("l2", 2, 13, True, True), ("ip", 4, 90, True, True)])
-def test_exact_ties_across_list_shards(tag, W, reps, has_rank, small_budget):
+@pytest.mark.parametrize("tag,W,reps,has_rank,small_budget,raw_sharded", [
+    ("l2", 2, 1, True, False, False), ("l2", 3, 13, True, False, False), ("ip", 2, 13, True, False, False), ("l2", 2, 13, False, False, False),
+    ("l2", 4, 90, True, False, False), ("l2", 2, 13, True, True, False), ("ip", 4, 90, True, True, False),
+    # raw vectors sharded with their lists (round 6): the exact distances travel with the candidates and with the exported streams
+    ("l2", 2, 1, True, False, True), ("l2", 3, 13, True, False, True), ("ip", 2, 13, True, False, True), ("l2", 4, 90, True, False, True),
+    ("ip", 4, 90, True, True, True)])
+def test_exact_ties_across_list_shards(tag, W, reps, has_rank, small_budget, raw_sharded):
     """W shards emulated on one GPU through the C ABI (what gamma_hip_group / dist.py drive): coarse per slice, shard scans,
     merge + re-rank at the slice's owner -- then the tie phase: the owner lists the queries a tie can change
     (gamma_hip_ivfpq_merge_flagged), every shard exports their candidate streams over the lists it owns
@@ -398,7 +405,7 @@ def test_exact_ties_across_list_shards(tag, W, reps, has_rank, small_budget):
     nprobe, R, k = 12, 60, 10
     sizes = z["list_sizes_" + tag]
     owner = gdist.balance_lists(sizes, W)
-    shards = [_shard_of(z, tag, base, metric, owner, s) for s in range(W)]
+    shards = [_shard_of(z, tag, base, metric, owner, s, raw_sharded) for s in range(W)]
     try:
         q1 = z["q"]
         D1, I1 = o.search(q1, k, nprobe, recall_num=R, has_rank=has_rank, metric=metric, ctx=B.make_ctx(**WIDE), coarse_mode=0)
@@ -411,13 +418,13 @@ def test_exact_ties_across_list_shards(tag, W, reps, has_rank, small_budget):
         args = api.SearchArgs(metric=metric, nprobe=nprobe, recall_num=R, has_rank=has_rank, coarse_mode=0, **WIDE)
         from tests.shard_emul import sharded_search_emulated
         # (W == 3 runs without the shards' flags: every table that ends at the cut value counts as a tie)
-        D, I, flagged = sharded_search_emulated(shards, x, k, args, use_shard_flags=(W != 3))
+        D, I, flagged = sharded_search_emulated(shards, x, k, args, use_shard_flags=(W != 3), raw_sharded=raw_sharded)
         assert flagged > 0
         compare_exact(Dexp, Iexp, D.cpu().numpy(), I.cpu().numpy())
         if small_budget:
             for g in shards:
                 g.set_dist_budget(40 * nprobe * max(1, g.max_list_len()) * 4)
-            D2, I2, flagged2 = sharded_search_emulated(shards, x, k, args, use_shard_flags=True)
+            D2, I2, flagged2 = sharded_search_emulated(shards, x, k, args, use_shard_flags=True, raw_sharded=raw_sharded)
             assert flagged2 == flagged   # the chunks' own flags reached the merge (not "every query may have cut a tie")
             compare_exact(Dexp, Iexp, D2.cpu().numpy(), I2.cpu().numpy())
     finally:
