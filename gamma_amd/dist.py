@@ -20,6 +20,11 @@ runs in four steps:
      runs compute_dis (re-rank / truncate)                           (gamma_hip_ivfpq_merge_rerank)
      followed by a small all-gather of the [nq/W, k] results.
 
+Raw vectors: replicated on every rank by default; with HipShardBackend(raw_sharded=True) a rank keeps the rows of the vectors in
+ITS lists only (gamma_hip_raw_put) and the exact distances of compute_dis are computed by the shard that holds the row
+(gamma_hip_ivfpq_shard_exact) and travel with the candidates -- and, in the tie phase, with the exported streams
+(gamma_hip_ivfpq_shard_export_exact / _merge_replay_exact).
+
 Large batches run as two interleaved sub-batches with every collective asynchronous, so the
 all-to-all of one overlaps the scan / merge of the other (sharded_search).
 
