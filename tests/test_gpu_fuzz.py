@@ -287,6 +287,10 @@ def test_random_list_shard_configuration(seed):
     lists = [o.get_list(l) for l in range(nlist)]
     sizes = np.array([len(ids) for ids, _ in lists], dtype=np.int64)
     owner = gdist.balance_lists(sizes, W)
+    # (every third seed, or GAMMA_TEST_RAW_SHARDED=1 / 0 for all / none: the shards hold their own raw rows only and the exact
+    #  distances travel with the candidates and the exported streams -- round 6)
+    env_rs = os.environ.get("GAMMA_TEST_RAW_SHARDED")
+    raw_sharded = (env_rs == "1") if env_rs is not None else (seed % 3 == 1)
     shards = []
     try:
         for s in range(W):
@@ -300,12 +304,17 @@ def test_random_list_shard_configuration(seed):
                                  np.concatenate([lists[l][1] for l in own]))
             g.set_list_mask((np.asarray(owner) == s).astype(np.uint8))
             g.raw_init(d)
-            g.raw_append(base)
+            if raw_sharded:   # raw vectors sharded with their lists: the rows of this shard's vectors only
+                if own:
+                    mine = np.concatenate([lists[l][0] for l in own])
+                    g.raw_put(mine, base[mine])
+            else:
+                g.raw_append(base)
             if rng.random() < 0.4:
                 g.set_dist_budget(max(1 << 16, 50 * P * max(1, g.max_list_len()) * 4))
         x = torch.from_numpy(q).to(torch.device("cuda", 0))
         args = api.SearchArgs(metric=metric, nprobe=P, recall_num=R, has_rank=has_rank, coarse_mode=omode, **WIDE)
-        D, I, _ = sharded_search_emulated(shards, x, k, args, use_shard_flags=bool(rng.random() < 0.8))
+        D, I, _ = sharded_search_emulated(shards, x, k, args, use_shard_flags=bool(rng.random() < 0.8), raw_sharded=raw_sharded)
         compare_exact(De, Ie, D.cpu().numpy(), I.cpu().numpy())
     finally:
         for g in shards:
