@@ -549,6 +549,32 @@ def main():
             g.set_exact_ties(False)
             sec_off = timed(lambda: g.flat_search_device(d_q.data_ptr(), fnq, fk, fargs, fD.data_ptr(), fI.data_ptr()), 5, 2)
             g.set_exact_ties(not a.no_exact_ties)
+            # two caller threads, every call complete on return (gamma_hip_flat_search_device_wait: one caller's heap replay
+            # beside the other's filter passes)
+            c2_callers = {}
+            for T in (1, 2):
+                fb = [(torch.empty((fnq, fk), dtype=torch.float32, device=dev), torch.empty((fnq, fk), dtype=torch.int64, device=dev)) for _ in range(T)]
+
+                def fcaller(t, n):
+                    for i in range(n):
+                        xq_ = d_q[((t + i) % 8) * fnq:((t + i) % 8 + 1) * fnq]
+                        g.flat_search_device_wait(xq_.data_ptr(), fnq, fk, fargs, fb[t][0].data_ptr(), fb[t][1].data_ptr())
+                for t in range(T):
+                    fcaller(t, 2)
+                th_ = [threading.Thread(target=fcaller, args=(t, 16 // T)) for t in range(T)]
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                for x_ in th_:
+                    x_.start()
+                for x_ in th_:
+                    x_.join()
+                el_ = time.perf_counter() - t0_
+                c2_callers[str(T)] = {"ms_per_call": round(el_ / 16 * 1e3, 3), "qps": round(16 * fnq / el_, 1)}
+            xq_ = d_q[((0 + 16 // 2 - 1) % 8) * fnq:((0 + 16 // 2 - 1) % 8 + 1) * fnq]
+            g.flat_search_device(xq_.data_ptr(), fnq, fk, fargs, fD.data_ptr(), fI.data_ptr())
+            torch.cuda.synchronize()
+            c2_callers["identical_to_the_plain_call"] = bool(torch.equal(fb[0][1], fI) and torch.equal(fb[0][0], fD))
+            extra["c2_flat_callers"] = c2_callers
             extra["c2_flat"] = {"workload": "C2: flat L2, %dx%d, %d queries/call, k=%d" % (N, d, fnq, fk),
                                 "ms_per_call": round(sec * 1e3, 3), "qps": round(fnq / sec, 1),
                                 "ms_per_call_with_ties_off": round(sec_off * 1e3, 3),

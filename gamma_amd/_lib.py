@@ -115,6 +115,8 @@ SYMBOLS = {
                                                 C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "gamma_hip_ivfpq_search_device_wait": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int,
                                                      C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "gamma_hip_flat_search_device_wait": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int,
+                                                    C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "gamma_hip_ivfpq_last_stages": (C.c_int, [C.c_void_p, f32p, i64p, f32p, i64p]),
     "gamma_hip_ivfpq_search_shard": (C.c_int, [C.c_void_p, C.POINTER(SearchParams), C.c_int,
                                                C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

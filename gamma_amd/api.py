@@ -396,6 +396,10 @@ class GammaHip:
         self._ck(self.L.gamma_hip_ivfpq_search_device_wait(self.h, args.ref(), nq, d_x, k, d_D, d_I),
                  "ivfpq_search_device_wait")
 
+    def flat_search_device_wait(self, d_x, nq, k, args, d_D, d_I):
+        """complete when it returns; concurrent callers' calls overlap (include/gamma_hip.h)"""
+        self._ck(self.L.gamma_hip_flat_search_device_wait(self.h, args.ref(), nq, d_x, k, d_D, d_I), "flat_search_device_wait")
+
     def flat_search_device(self, d_x, nq, k, args, d_D, d_I):
         self._ck(self.L.gamma_hip_flat_search_device(self.h, args.ref(), nq, d_x, k, d_D, d_I),
                  "flat_search_device")

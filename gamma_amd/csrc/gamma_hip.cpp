@@ -97,6 +97,9 @@ int gamma_hip_destroy(gamma_hip_index* h) {
         if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
     }
     if (h->up_stream) (void)hipStreamDestroy(h->up_stream);
+    for (auto& b : h->fbank) b.release();
+    for (hipEvent_t& e : h->ev_bank)
+        if (e) (void)hipEventDestroy(e);
     if (h->ev_rfork) (void)hipEventDestroy(h->ev_rfork);
     if (h->ev_rdone) (void)hipEventDestroy(h->ev_rdone);
     for (int v = 0; v < H::NVER; v++) {
@@ -145,6 +148,7 @@ int gamma_hip_destroy(gamma_hip_index* h) {
     if (h->dir_pin) (void)hipHostFree(h->dir_pin);
     if (h->bound_copy_ev) (void)hipEventDestroy(h->bound_copy_ev);
     if (h->pin_bound_stat) (void)hipHostFree(h->pin_bound_stat);
+    if (h->pin_flat_over) (void)hipHostFree(h->pin_flat_over);
     DevBuf* bufs[] = {&h->w_mat, &h->w_coarse_dis, &h->w_probe, &h->w_xn, &h->w_st2, &h->w_pair_off,
                       &h->w_qtotal, &h->w_dist, &h->w_cand_dis, &h->w_cand_pos, &h->w_cand_ids,
                       &h->w_exact, &h->w_selv, &h->w_selp, &h->w_x, &h->w_outd, &h->w_outl, &h->w_stage, &h->w_shard_cut,

@@ -150,6 +150,20 @@ struct gamma_hip_index {
     std::mutex hs_mu;
     std::condition_variable hs_cv;
     hipStream_t up_stream = nullptr;
+    // flat search with overlapping callers (gamma_hip_flat_search_device_wait): what a flat call's tie replay reads -- the first
+    // row chunk's slab, the survivor log, the flag list, the candidate tables -- exists TWICE; a call that finds a flat replay
+    // pending switches to the other bank instead of waiting, and waits (in stream order) only for the replay that last read
+    // the bank it is about to overwrite
+    DevBuf fbank[5];
+    int flat_bank = 0;
+    hipEvent_t ev_bank[2] = {nullptr, nullptr};
+    bool bank_used[2] = {false, false};
+    bool replay_is_flat = false;
+    // (the flat call's "did a survivor list overflow" word is read by the host; a _wait call reads it AFTER its completion
+    //  event, with the handle free, from one of four pinned words, and redoes the call without a bound in the rare yes)
+    int* pin_flat_over = nullptr;
+    int* flat_over_dst = nullptr;    // set by the _wait entry for the call under way
+    bool flat_no_bound = false;
     std::atomic<int> big_calls_in_flight{0};
     std::atomic<int64_t> big_calls_overlap_seen_ns{INT64_MIN / 2};
     // the shadow lists of compact_lists_for_call stay valid while nothing was written and the call has no clauses of its own

@@ -846,6 +846,7 @@ int ivfpq_stage_b(H* h, const gamma_hip_search_params* p, int nq, const float* d
             gh::launch_tie_replay(h->side2, l2, a);
             (void)hipEventRecord(h->ev_rdone, h->side2);
             h->replay_pending = true;
+            h->replay_is_flat = false;
         } else {
             gh::launch_tie_replay(s, l2, a);
         }
@@ -1475,6 +1476,7 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
         const int64_t stride = (N + 3) & ~(int64_t)3;
         if (!off && h->small_path && nq <= 64 && k <= 1024 && N >= 1 && N <= ((int64_t)1 << 22) && !h->profile &&
             (size_t)nq * stride * sizeof(float) <= std::min<size_t>(h->dist_budget_bytes, (size_t)1 << 30)) {
+            GH_TRY(replay_join(h));
             GH_CHECK(h, h->w_dist.ensure((size_t)nq * stride * sizeof(float)));
             GH_CHECK(h, h->w_cand_pos.ensure((size_t)nq * k * sizeof(int)));
             GH_CHECK(h, h->w_cand_dis.ensure((size_t)nq * k * sizeof(float)));
@@ -1525,6 +1527,38 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
     const int k_out = k;
     const bool ties = tie_on(p) && N > 0;
     if (ties) k = k + 1;
+    // Overlapping callers (gamma_hip_flat_search_device_wait): this call's tie replay goes to the side stream when the call is one
+    // query chunk; a call that finds a FLAT replay pending does not wait for it -- it works in the other bank of the buffers the
+    // replay reads and waits, in stream order, only for the replay that last read that bank.
+    const bool defer_flat = h->defer_now && h->side2 != nullptr && ties && qc >= nq;
+    if (h->replay_pending) {
+        if (defer_flat && h->replay_is_flat) {
+            DevBuf* cur[5] = {&h->w_dist, &h->w_flog, &h->w_tlist, &h->w_cand_dis, &h->w_cand_ids};
+            for (int i = 0; i < 5; i++) std::swap(*cur[i], h->fbank[i]);
+            h->flat_bank ^= 1;
+            if (h->bank_used[h->flat_bank]) GH_CHECK(h, hipStreamWaitEvent(s, h->ev_bank[h->flat_bank], 0));
+            // (replay_pending stays: whoever comes next and cannot switch banks joins)
+        } else {
+            GH_TRY(replay_join(h));
+        }
+    }
+    auto flat_replay = [&](const gh::TieReplayArgs& tr) -> int {
+        if (!defer_flat) {
+            gh::launch_tie_replay(s, l2, tr);
+            return GAMMA_HIP_OK;
+        }
+        const int b = h->flat_bank;
+        if (!h->ev_bank[b]) GH_CHECK(h, hipEventCreateWithFlags(&h->ev_bank[b], hipEventDisableTiming));
+        GH_CHECK(h, hipEventRecord(h->ev_rfork, s));
+        GH_CHECK(h, hipStreamWaitEvent(h->side2, h->ev_rfork, 0));
+        gh::launch_tie_replay(h->side2, l2, tr);
+        GH_CHECK(h, hipEventRecord(h->ev_rdone, h->side2));
+        GH_CHECK(h, hipEventRecord(h->ev_bank[b], h->side2));
+        h->bank_used[b] = true;
+        h->replay_pending = true;
+        h->replay_is_flat = true;
+        return GAMMA_HIP_OK;
+    };
     GH_CHECK(h, h->w_dist.ensure((size_t)qc * rows_chunk * sizeof(float)));
     GH_CHECK(h, h->w_part_v.ensure((size_t)qc * nchunks * k * sizeof(float)));
     GH_CHECK(h, h->w_part_i.ensure((size_t)qc * nchunks * k * sizeof(int64_t)));
@@ -1689,10 +1723,11 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
                 tr.gcnt = reinterpret_cast<const int*>(tr.surv + (size_t)nc * log_nsl * cap);
                 tr.nsl = log_nsl;
                 tr.slice_cap = cap;
-                gh::launch_tie_replay(s, l2, tr);
+                GH_TRY(flat_replay(tr));
             } else if (nchunks == 1) {
-                gh::launch_tie_replay(s, l2, tr);   // the one slab holds every row
+                GH_TRY(flat_replay(tr));   // the one slab holds every row
             } else {
+                GH_TRY(replay_join(h));
                 // several row chunks through one slab: the rows of the flagged queries are computed again
                 int nflag = 0;
                 GH_CHECK(h, hipMemcpyAsync(&nflag, count, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1718,12 +1753,19 @@ int flat_search_device_locked(H* h, const gamma_hip_search_params* p, int nq, co
             return GAMMA_HIP_OK;
         };
         bool redo = true;
-        if (k <= 256 && N > rows_chunk && N < ((int64_t)1 << 32) &&
+        if (!h->flat_no_bound && k <= 256 && N > rows_chunk && N < ((int64_t)1 << 32) &&
             (gh::pairwise_can_emit(nc, d, N - rows_chunk) || (mfma_filter && gh::flat_filter_supported(nc, d, N)))) {
             GH_TRY(bounded(q0, nc, &redo));
             if (ties) GH_TRY(tie_phase(false));   // enqueued before the host learns whether a list overflowed
+            if (defer_flat && h->flat_over_dst) {
+                // (the caller reads the word after the call's completion event, with the handle free: no host wait under the lock)
+                GH_CHECK(h, hipMemcpyAsync(h->flat_over_dst, h->w_flat_meta.as<int>() + nc + (size_t)nc * 32, sizeof(int),
+                                           hipMemcpyDeviceToHost, s));
+                continue;
+            }
             GH_TRY(overflowed(nc, &redo));
             if (!redo) continue;
+            GH_TRY(replay_join(h));   // (a replay on the side stream writes the rows that are about to be redone)
         }
         GH_TRY(unbounded(q0, nc));
         if (ties) GH_TRY(tie_phase(true));
@@ -2484,6 +2526,49 @@ int gamma_hip_flat_search_device(gamma_hip_index* h, const gamma_hip_search_para
     SearchLock lk(h);
     GH_TRY(replay_join(h));
     return flat_search_device_locked(h, p, nq, d_x, k, d_distances, d_labels);
+}
+
+int gamma_hip_flat_search_device_wait(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
+                                      const float* d_x, int k, float* d_distances, int64_t* d_labels) {
+    if (!h) return GAMMA_HIP_EINVAL;
+    hipEvent_t ev = nullptr;
+    int* over = nullptr;
+    {
+        SearchLock lk(h);
+        GH_CHECK(h, hipSetDevice(h->device));
+        const unsigned slot = h->call_seq++ & 3u;
+        if (!h->ev_call[slot]) GH_CHECK(h, hipEventCreateWithFlags(&h->ev_call[slot], hipEventDisableTiming));
+        ev = h->ev_call[slot];
+        if (!h->pin_flat_over) {
+            GH_CHECK(h, hipHostMalloc((void**)&h->pin_flat_over, 4 * sizeof(int), hipHostMallocDefault));
+            memset(h->pin_flat_over, 0, 4 * sizeof(int));
+        }
+        over = h->pin_flat_over + slot;
+        *over = 0;
+        h->defer_now = h->side2 != nullptr;
+        h->flat_over_dst = over;
+        const int rc = flat_search_device_locked(h, p, nq, d_x, k, d_distances, d_labels);
+        h->defer_now = false;
+        h->flat_over_dst = nullptr;
+        if (rc != GAMMA_HIP_OK) return rc;
+        // (the main stream carries the copy of the overflow word; the side stream, if a replay is pending, the last writes)
+        if (h->replay_pending) {
+            GH_CHECK(h, hipEventRecord(h->ev_rfork, h->stream));
+            GH_CHECK(h, hipStreamWaitEvent(h->side2, h->ev_rfork, 0));
+        }
+        GH_CHECK(h, hipEventRecord(ev, h->replay_pending ? h->side2 : h->stream));
+    }
+    if (hipEventSynchronize(ev) != hipSuccess) return GAMMA_HIP_EDEVICE;
+    if (*over) {   // a survivor list overflowed (adversarial data): the call again without a bound, the plain way
+        SearchLock lk(h);
+        h->flat_no_bound = true;
+        int rc = replay_join(h);
+        if (rc == GAMMA_HIP_OK) rc = flat_search_device_locked(h, p, nq, d_x, k, d_distances, d_labels);
+        h->flat_no_bound = false;
+        if (rc != GAMMA_HIP_OK) return rc;
+        GH_CHECK(h, hipStreamSynchronize(h->stream));
+    }
+    return GAMMA_HIP_OK;
 }
 
 int gamma_hip_flat_search(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x,

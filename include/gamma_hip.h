@@ -413,6 +413,12 @@ int gamma_hip_set_deferred_replay(gamma_hip_index* h, int on);
  * gamma_hip_synchronize gives.  d_x must stay untouched until the call returns. */
 int gamma_hip_ivfpq_search_device_wait(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
                                        const float* d_x, int k, float* d_distances, int64_t* d_labels);
+/* the same contract for the flat search (GammaFLATIndex::Search, gamma_index_flat.cc:118-300): complete on return, and the call's
+ * heap replay -- a third of a 1024-query call over 1 M rows -- runs on the side stream beside the next caller's filter passes.
+ * What the replay reads (the first row chunk's slab, the survivor log, the flag list, the candidate tables) exists twice: a call
+ * that finds a flat replay pending works in the other bank. */
+int gamma_hip_flat_search_device_wait(gamma_hip_index* h, const gamma_hip_search_params* p, int nq,
+                                      const float* d_x, int k, float* d_distances, int64_t* d_labels);
 int gamma_hip_join(gamma_hip_index* h);
 /* stage outputs of the LAST search for parity tests / sharded merge (device->host):
  * coarse_dis/idx [nq*nprobe], recall_dis/ids [nq*recall_num] (sorted best first, -1 pad) */

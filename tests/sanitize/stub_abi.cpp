@@ -287,6 +287,9 @@ int gamma_hip_ivfpq_search_device(gamma_hip_index* h, const gamma_hip_search_par
 int gamma_hip_ivfpq_search_device_wait(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x, int k, float* D, int64_t* I) {
     return gamma_hip_ivfpq_search(h, p, nq, x, k, D, I);
 }
+int gamma_hip_flat_search_device_wait(gamma_hip_index* h, const gamma_hip_search_params* p, int nq, const float* x, int k, float* D, int64_t* I) {
+    return gamma_hip_flat_search(h, p, nq, x, k, D, I);
+}
 /* list-shard entry points: not reached in replicate placement */
 int gamma_hip_bound_combine(void*, float*, const float*, int, int) { return GAMMA_HIP_EUNSUPPORTED; }
 int gamma_hip_raw_put(gamma_hip_index*, int64_t, const int64_t*, const float*) { return GAMMA_HIP_EUNSUPPORTED; }

@@ -428,3 +428,58 @@ def test_large_host_buffer_calls_from_several_threads_overlap_and_stay_exact():
         assert D.shape == (nq, k)
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("nthreads", [2, 3])
+def test_concurrent_flat_callers_each_get_a_complete_result(nthreads):
+    """gamma_hip_flat_search_device_wait: the flat call's heap replay on the side stream, the next caller in the other bank of
+    what it reads; tie-heavy rows (every row twice) so that every call replays queries; every result compared -- labels and
+    distance bits -- with the plain call's on the same batch; an IVFPQ call in between joins whatever is pending"""
+    import torch
+    d, N = 64, 80000
+    base = synth.sift_like(N, d=d, seed=41)
+    base[N // 2:] = base[:N // 2]
+    g = api.GammaHip(0)
+    try:
+        g.raw_init(d)
+        g.raw_append(base)
+        dev = torch.device("cuda", 0)
+        nq, k, nb = 700, 20, 3
+        args = api.SearchArgs(metric=api.METRIC_L2, **WIDE)
+        qs = [[torch.from_numpy(synth.sift_like(nq, d=d, seed=3000 + 11 * t + b)).to(dev) for b in range(nb)] for t in range(nthreads)]
+        D0 = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        I0 = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        want = [[None] * nb for _ in range(nthreads)]
+        g.tie_stats(reset=True)
+        for t in range(nthreads):
+            for b in range(nb):
+                g.flat_search_device(qs[t][b].data_ptr(), nq, k, args, D0.data_ptr(), I0.data_ptr())
+                g.synchronize()
+                want[t][b] = (D0.cpu().numpy().copy(), I0.cpu().numpy().copy())
+        assert g.tie_stats()["replayed"] > 0
+        errors = []
+
+        def client(t):
+            try:
+                Dt = torch.empty((nq, k), dtype=torch.float32, device=dev)
+                It = torch.empty((nq, k), dtype=torch.int64, device=dev)
+                st = torch.cuda.Stream(device=dev)
+                for rep in range(10):
+                    b = rep % nb
+                    g.flat_search_device_wait(qs[t][b].data_ptr(), nq, k, args, Dt.data_ptr(), It.data_ptr())
+                    with torch.cuda.stream(st):
+                        Dh, Ih = Dt.to("cpu", non_blocking=False), It.to("cpu", non_blocking=False)
+                    compare_exact(want[t][b][0], want[t][b][1], Dh.numpy(), Ih.numpy())
+            except BaseException as e:   # noqa: B902
+                errors.append((t, repr(e)))
+        th = [threading.Thread(target=client, args=(t,)) for t in range(nthreads)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not errors, errors[:3]
+        g.flat_search_device(qs[0][1].data_ptr(), nq, k, args, D0.data_ptr(), I0.data_ptr())
+        g.synchronize()
+        compare_exact(want[0][1][0], want[0][1][1], D0.cpu().numpy(), I0.cpu().numpy())
+    finally:
+        g.close()
