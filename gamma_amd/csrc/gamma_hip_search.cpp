@@ -622,6 +622,10 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         sb.batch = scan_batch;
         sb.dbg_part = h->scan_dbg_now;
         sb.c8 = (cf_ok && !sb.prod_cf && c8_on && (cf_span > 0 ? cf_span : P - G) <= 64) ? c8_mode : 0;
+        // the producer on the byte image too (scan.hip, "producer on the byte image"; GAMMA_HIP_PROD_C8=1)
+        static const bool prod_c8_on = getenv("GAMMA_HIP_PROD_C8") != nullptr && atoi(getenv("GAMMA_HIP_PROD_C8")) != 0;
+        sb.prod_c8 = (sb.c8 && M == 16 && !shard && !q8_ok && prod_c8_on) ? 1 : 0;
+        const bool prod_approx = sb.prod_cf || sb.prod_c8;   // group 0's slab segment does not hold the reference's values
         // two-phase shard search: the producers' bounds out, the reduced (global) bounds back into the ready words
         auto exchange = [&]() -> int {
             gh::launch_bound_export(s, l2, sb.ready, nq, bx->d_bound);
@@ -724,10 +728,10 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
             gh::launch_ivfpq_scan_pair(s, l2, d_x, nq, d, M, P, h->w_probe.as<int>(), dis0, h->d_cc,
                                        h->scan_st2(l2), h->d_T2, h->d_list_off, h->d_list_len, h->d_list_mask,
                                        nlist, h->d_codes, h->d_ids, h->w_pair_off.as<int>(), q_stride,
-                                       h->w_dist.as<float>(), fc.d_tab, fc.d_qf, need_ids, nullptr, G, sb.prod_cf ? 0 : 1,
-                                       sb.prod_cf ? PGN : PGN - 1, shard ? 1 : 0, nullptr, nullptr, sb.rq_list, sb.rq_count);
+                                       h->w_dist.as<float>(), fc.d_tab, fc.d_qf, need_ids, nullptr, G, prod_approx ? 0 : 1,
+                                       prod_approx ? PGN : PGN - 1, shard ? 1 : 0, nullptr, nullptr, sb.rq_list, sb.rq_count);
         }
-        h->tie.prod_cf = sb.prod_cf != 0;
+        h->tie.prod_cf = prod_approx;
         h->tie.need_ids = need_ids;
         h->tie.d_ftab = fc.d_tab;
         h->tie.d_qf = fc.d_qf;

@@ -197,6 +197,11 @@ struct ScanBound {
     int dbg_part;               // timing experiments only (GAMMA_HIP_SCAN_PART): 1 = consumers leave at once, 2 = producers do
     int c8;                     // != 0 (filter-pass launches only): the consumers' filter pass gathers from a BYTE image of the query's
                                 // table made in the workgroup (2-way bank conflicts at most instead of ~3.5); candidates as ever
+    int prod_c8;                // != 0 (with c8, M = 16): the PRODUCER scores its probes on the byte image too (scan.hip, "producer on the byte
+                                // image"): lower estimates of its whole group in LDS, their recall_num-th smallest + the image's proven error
+                                // width bounds the recall_num-th best exact value, only the codes under that get the exact arithmetic.  Its
+                                // slab segment is NOT written: the callers score group 0 (repair launch) for every query whose slab is read
+                                // (unfiltered selection, tie replay), as with prod_cf
 };
 // ---- q8scan.hip: the consumer probes of a bounded L2 scan, list-major over byte tables (one list x 8 queries per tile) ----
 struct Q8Args {

@@ -64,7 +64,11 @@ constexpr int C8_CAND = 1536;      // byte-table pass: its candidates sit in the
 // (faiss:IndexIVFPQ.cpp:441-449) -- and the reference scores every (query, list) pair with the distance table of the RESIDUAL:
 // r = x_q - centroid_l, lut[m][j] = fvec_L2sqr_ny(r_m, c_mj), dis0 = 0 (index/impl/gamma_index_ivfpq.h:239-245).  Here `st2`
 // points at the PQ codebook and `T2` is null; the residual sits in LDS behind the staging words.
-template <bool L2, int MT, bool FILT, bool IPF, bool UNITS, bool CF, bool PCF, bool C8 = false, bool RES = false>
+// PC8 (with C8, round 6): the producer scores its group on the byte image as well (ScanBound::prod_c8), see "producer on the byte image"
+constexpr int PC8_MAXN = 3072;     // codes of a producer's group whose lower estimates fit the 12 KB behind the byte image (M = 16)
+constexpr int PC8_CCAP = 1024;     // its candidates for the exact arithmetic (positions, 2 bytes each)
+constexpr int PC8_MAXG = 8;        // lists of a producer's group
+template <bool L2, int MT, bool FILT, bool IPF, bool UNITS, bool CF, bool PCF, bool C8 = false, bool RES = false, bool PC8 = false>
 __device__ __forceinline__ void scan_pair_body(
 
         const float* __restrict__ x, int nq, int d, int M, int P, int G, const int* __restrict__ probe_list,
@@ -163,6 +167,7 @@ __device__ __forceinline__ void scan_pair_body(
     uint2* s_cand = reinterpret_cast<uint2*>(reinterpret_cast<int*>(s_stage + SCAN_STAGE) + 16);  // CF: [SCAN_CF_CAP]
     float* s_res = reinterpret_cast<float*>(reinterpret_cast<int*>(s_stage + SCAN_STAGE) + 16);   // RES (never with CF): [d]
     static_assert(!RES || (L2 && !CF && !IPF && !PCF && !C8), "residual tables: the plain L2 loop only");
+    static_assert(!PC8 || (C8 && MT == 16), "producer on the byte image: the M = 16 byte-image kernel");
     int cbase = 0;     // unit mode: first code of the unit within its list
     int lut_q = -1;    // unit mode, inner product: the query whose table is in LDS
     int lut_pair = -1; // unit mode, L2: the (query, probe) pair whose table is in LDS
@@ -234,13 +239,22 @@ __device__ __forceinline__ void scan_pair_body(
     }
     const float* st2q = st2 + (int64_t)q * msz;
     float s2r[MT > 0 ? MT : 1];
+    // (uniform) this workgroup is a producer that takes the byte image: its group fits the estimates' place in LDS and holds
+    // at least recall_num codes
+    bool pc8 = false;
+    if constexpr (PC8) {
+        if (pg == 0 && sb.prod_c8) {
+            const int n0 = pair_off[(int64_t)q * (P + 1) + min(G, P)];
+            pc8 = n0 <= PC8_MAXN && n0 >= sb.K && G <= PC8_MAXG;
+        }
+    }
     if (IPF && MT > 0) {
         // same arithmetic as k_pq_ip_table: one fvec_inner_products_ny row per (m, code word)
         const int dsub = d / M;
         const float* xq = x + (int64_t)q * d;
 #pragma unroll
         for (int i = 0; i < MT; i++) s2r[i] = fvec_ny_row<false>(xq + i * dsub, st2 + ((int64_t)i * 256 + tid) * dsub, dsub);
-    } else if (C8 && pg > 0) {
+    } else if (C8 && (pg > 0 || pc8)) {
         // byte table: wave w reads table rows w, w + 4, .. (four code words per lane), see below; s2r is loaded later
     } else if (RES) {
         // no query table: the per-list table comes from the residual and the codebook
@@ -250,7 +264,7 @@ __device__ __forceinline__ void scan_pair_body(
     }
     float4 v8[C8 ? MT / 4 : 1];
     if constexpr (C8) {
-        if (pg > 0) {
+        if (pg > 0 || pc8) {
 #pragma unroll
             for (int k = 0; k < MT / 4; k++)
                 v8[k] = *reinterpret_cast<const float4*>(st2q + ((tid >> 6) + 4 * k) * 256 + 4 * lane);
@@ -307,6 +321,53 @@ __device__ __forceinline__ void scan_pair_body(
             tau_f = key2f(L2 ? tauq : ~tauq);
         }
     }
+    // the byte image of the query's table ("byte table" below), made by the whole workgroup from v8 where the fp32 table would be;
+    // contains one barrier, none behind the image's stores
+    auto c8_image = [&](float& qmax, float& c8_cq, float& c8_nd) {
+        if constexpr (C8) {
+        float lo[MT / 4], range = 0.f, Lsum = 0.f, amax = 0.f;
+#pragma unroll
+        for (int k = 0; k < MT / 4; k++) {
+            float mn = fminf(fminf(v8[k].x, v8[k].y), fminf(v8[k].z, v8[k].w));
+            float mx = fmaxf(fmaxf(v8[k].x, v8[k].y), fmaxf(v8[k].z, v8[k].w));
+            // (wave reductions on the order-preserving keys: DPP, not 12 LDS permutes per row)
+            mn = key2f(__reduce_min_sync(~0ull, f2key(mn)));
+            mx = key2f(__reduce_max_sync(~0ull, f2key(mx)));
+            lo[k] = mn;
+            range = fmaxf(range, mx - mn);
+            Lsum += mn;
+            amax = fmaxf(amax, fmaxf(fabsf(mn), fabsf(mx)));
+        }
+        float* s_part = reinterpret_cast<float*>(s_red);   // [4 waves][3]
+        if (lane == 0) {
+            s_part[3 * (tid >> 6)] = range;
+            s_part[3 * (tid >> 6) + 1] = Lsum;
+            s_part[3 * (tid >> 6) + 2] = amax;
+        }
+        __syncthreads();
+        range = fmaxf(fmaxf(s_part[0], s_part[3]), fmaxf(s_part[6], s_part[9]));
+        Lsum = (s_part[1] + s_part[4]) + (s_part[7] + s_part[10]);
+        amax = fmaxf(fmaxf(s_part[2], s_part[5]), fmaxf(s_part[8], s_part[11]));
+        const float delta = (range / 255.f) * 1.000001f;   // (hi - lo) / delta stays below 255.5 whatever the roundings
+        const float inv = delta > 0.f ? 1.f / delta : 0.f;
+        uint32_t* s_b8 = reinterpret_cast<uint32_t*>(s_lut);
+#pragma unroll
+        for (int k = 0; k < MT / 4; k++) {
+            const float f[4] = {v8[k].x, v8[k].y, v8[k].z, v8[k].w};
+            uint32_t w = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                int u = (int)rintf((f[e] - lo[k]) * inv);
+                u = min(255, max(0, u));
+                w |= (uint32_t)u << (8 * e);
+            }
+            s_b8[((tid >> 6) + 4 * k) * 64 + lane] = w;
+        }
+        qmax = amax;
+        c8_cq = 2.f * Lsum + 1.02f * (float)MT * delta;
+        c8_nd = -2.f * delta;
+        }
+    };
     GH_ST(t_bound);
     if constexpr (CF) {
         if (pg > 0 && bound_on) {   // (uniform)
@@ -337,47 +398,7 @@ __device__ __forceinline__ void scan_pair_body(
                 // a code is a candidate iff (A + s_j) - 2 delta U <= tau + 2^-16 S.  The image is made HERE (the arithmetic
                 // of k_q8_quant: wave w owns rows w, w + 4, ..; minimum and maximum of a row are one wave reduction) and
                 // lives where the fp32 table will be written for the exact recompute of the candidates.
-                float lo[MT / 4], range = 0.f, Lsum = 0.f, amax = 0.f;
-#pragma unroll
-                for (int k = 0; k < MT / 4; k++) {
-                    float mn = fminf(fminf(v8[k].x, v8[k].y), fminf(v8[k].z, v8[k].w));
-                    float mx = fmaxf(fmaxf(v8[k].x, v8[k].y), fmaxf(v8[k].z, v8[k].w));
-                    // (wave reductions on the order-preserving keys: DPP, not 12 LDS permutes per row)
-                    mn = key2f(__reduce_min_sync(~0ull, f2key(mn)));
-                    mx = key2f(__reduce_max_sync(~0ull, f2key(mx)));
-                    lo[k] = mn;
-                    range = fmaxf(range, mx - mn);
-                    Lsum += mn;
-                    amax = fmaxf(amax, fmaxf(fabsf(mn), fabsf(mx)));
-                }
-                float* s_part = reinterpret_cast<float*>(s_red);   // [4 waves][3]
-                if (lane == 0) {
-                    s_part[3 * (tid >> 6)] = range;
-                    s_part[3 * (tid >> 6) + 1] = Lsum;
-                    s_part[3 * (tid >> 6) + 2] = amax;
-                }
-                __syncthreads();
-                range = fmaxf(fmaxf(s_part[0], s_part[3]), fmaxf(s_part[6], s_part[9]));
-                Lsum = (s_part[1] + s_part[4]) + (s_part[7] + s_part[10]);
-                amax = fmaxf(fmaxf(s_part[2], s_part[5]), fmaxf(s_part[8], s_part[11]));
-                const float delta = (range / 255.f) * 1.000001f;   // (hi - lo) / delta stays below 255.5 whatever the roundings
-                const float inv = delta > 0.f ? 1.f / delta : 0.f;
-                uint32_t* s_b8 = reinterpret_cast<uint32_t*>(s_lut);
-#pragma unroll
-                for (int k = 0; k < MT / 4; k++) {
-                    const float f[4] = {v8[k].x, v8[k].y, v8[k].z, v8[k].w};
-                    uint32_t w = 0;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        int u = (int)rintf((f[e] - lo[k]) * inv);
-                        u = min(255, max(0, u));
-                        w |= (uint32_t)u << (8 * e);
-                    }
-                    s_b8[((tid >> 6) + 4 * k) * 64 + lane] = w;
-                }
-                qmax = amax;
-                c8_cq = 2.f * Lsum + 1.02f * (float)MT * delta;
-                c8_nd = -2.f * delta;
+                c8_image(qmax, c8_cq, c8_nd);
             } else {
                 lut_store_begin(lut_m0);
                 lut_store_rows<MT>([&](int i) { return s2r[i]; }, std::make_integer_sequence<int, (MT > 0 ? MT : 1)>{});
@@ -394,6 +415,11 @@ __device__ __forceinline__ void scan_pair_body(
             GH_ST(t_quant);
             GH_ST_ADD(10, t_bound, t_quant);
             const int ng = p_end - p_begin;
+            // (two copies of the loop, with and without the validity predicates: with their loads -- through generic pointers of
+            //  the filter table -- anywhere in the loop body, the compiler's wait-count pass puts `s_waitcnt vmcnt(0)` in front of the
+            //  gathers at the join behind them, i.e. every step waited for the NEXT step's codes it had just requested)
+            auto filter_lists = [&](auto nid_c) {
+            constexpr bool NID = decltype(nid_c)::value;
             for (;;) {
                 int r = 0;
                 if (lane == 0) r = atomicAdd(&s_next, 1);
@@ -440,7 +466,7 @@ __device__ __forceinline__ void scan_pair_body(
                         sn = ls[jc];
                     }
                     bool ok = j < len;
-                    if (need_ids) {
+                    if constexpr (NID) {
                         const int64_t id = lid[min(j, len - 1)];
                         ok = ok && id >= 0;
                         if (ok) ok = is_valid_doc(filt, id);
@@ -483,6 +509,9 @@ __device__ __forceinline__ void scan_pair_body(
                     }
                 }
             }
+            };
+            if (need_ids) filter_lists(std::true_type{});
+            else filter_lists(std::false_type{});
             __syncthreads();
             GH_ST(t_loop);
             GH_ST_ADD(11, t_quant, t_loop);
@@ -551,8 +580,309 @@ __device__ __forceinline__ void scan_pair_body(
             return;
         }
     }
+    if constexpr (PC8) {
+        if (pc8) {   // (uniform)
+            // ---- producer on the byte image (round 6) ---------------------------------------------------------------------
+            // The regular producer builds a 16 KB table per list (the T2 row through the L2, 4096 fma + LDS stores, two barriers)
+            // to score ~250 codes, a third of the launch for a sixth of its codes (profiles/r05_scan_parts.txt).  It needs exact
+            // values for its ~recall_num + one-bin candidates only.  The byte image gives every code j of the group the consumers'
+            // test value f_j = (dis0 - 2 sum_m lo - 1.02 M delta) + s_j - 2 delta U_j with, by the image's error bound
+            // (|ip - lo - delta u8| <= 0.5001 delta per entry),
+            //       f_j - eps <= v_j <= f_j + 2.0202 M delta + eps,      eps = 50 * 2^-24 S  (the roundings, as in the filter pass),
+            // so the recall_num-th smallest f plus W = 2.03 M delta + 2^-16 S_max bounds the recall_num-th smallest EXACT value:
+            // histogram of the f's (LDS), tau1 = edge + W, exact arithmetic for the codes with f <= tau1 + 2^-16 S_max (every code
+            // whose exact value is within tau1 is among them), a second histogram over those exact values gives the bound that
+            // is published, tau = min(edge2, tau1), and the slice gets the codes with v <= tau: the same slice the regular
+            // producer writes for that bound.  The slab segment of the group is not written (ScanBound::prod_c8).
+            float* s_f = s_lut + MT * 64;   // [n0 <= PC8_MAXN]: f_j; later [nc]: v of candidate c
+            int& s_nunit = *reinterpret_cast<int*>(s_cand);
+            uint32_t& s_smax = *(reinterpret_cast<uint32_t*>(s_cand) + 1);
+            // the group's lists: (first code | codes | dis0 | position of the first code in the query's row), read once
+            int64_t* s_moff = reinterpret_cast<int64_t*>(s_cand + 2);             // [PC8_MAXG]
+            int* s_mlen = reinterpret_cast<int*>(s_moff + PC8_MAXG);               // [PC8_MAXG]
+            float* s_mdis = reinterpret_cast<float*>(s_mlen + PC8_MAXG);           // [PC8_MAXG]
+            int* s_mpos = reinterpret_cast<int*>(s_mdis + PC8_MAXG);               // [PC8_MAXG]
+            uint16_t* s_ci = reinterpret_cast<uint16_t*>(s_mpos + PC8_MAXG);       // [PC8_CCAP] positions of the candidates
+            const int* poff = pair_off + (int64_t)q * (P + 1);
+            const int n0 = poff[min(G, P)];
+            const int ng = p_end - p_begin;
+            if (tid < 64) {   // wave 0 (ng <= PC8_MAXG lanes of it)
+                float sl = 0.f;
+                if (tid < ng) {
+                    const int p = p_begin + tid, pair = q * P + p;
+                    const int l = probe_list[pair];
+                    int len = 0;
+                    int64_t off = 0;
+                    float t2m = 0.f;
+                    if (l >= 0 && l < nlist && (!list_mask || list_mask[l])) {
+                        len = max(0, list_len[l]);
+                        off = list_off[l];
+                        t2m = sb.t2max[l];
+                    }
+                    const float dis0 = coarse_dis[pair];
+                    s_moff[tid] = off;
+                    s_mlen[tid] = len;
+                    s_mdis[tid] = dis0;
+                    s_mpos[tid] = poff[p];
+                    if (len > 0) sl = fabsf(dis0) + t2m;
+                }
+                const uint32_t smx = wave_max_u32(__float_as_uint(sl));   // non-negative floats order as integers
+                if (tid == 0) s_smax = smx;
+            }
+            for (int i = tid; i < n0; i += 256) s_f[i] = INFINITY;
+            float qmax = 0.f, c8_cq = 0.f, c8_nd = 0.f;
+            c8_image(qmax, c8_cq, c8_nd);
+            __syncthreads();   // the image, the lists' data and the estimates' defaults are in place
+            GH_ST(t_pq);
+            GH_ST_CNT(0);
+            GH_ST_ADD(1, t_start, t_pq);
+            // Units of 64 codes, dealt round-robin to the four waves across ALL lists of the group (whole lists per wave leave one
+            // wave with two of five lists: the workgroup then takes as long as two lists), the next unit's codes and sums
+            // requested before the current unit's gathers.
+            auto estimate_units = [&](auto nid_c) {
+                constexpr bool NID = decltype(nid_c)::value;   // (two copies, as in the consumers' loop)
+                const int wv = tid >> 6;
+                int r = 0, ub = 0;   // cursor of the unit whose codes are being requested: list r, whose first unit is ub
+                int len = s_mlen[0], ns = (len + 63) >> 6;
+                uint4 cn[MT / 16];
+                float sn = 0.f;
+                // state of the requested unit
+                int n_len = 0, n_j0 = 0, n_pos = 0;
+                float n_dis = 0.f;
+                int64_t n_off = 0;
+                bool n_have = false;
+                auto request = [&](int u) {   // (uniform)
+                    while (r < ng && u >= ub + ns) {
+                        ub += ns;
+                        r++;
+                        len = r < ng ? s_mlen[r] : 0;
+                        ns = (len + 63) >> 6;
+                    }
+                    n_have = r < ng;
+                    if (n_have) {
+                        n_len = len;
+                        n_j0 = (u - ub) << 6;
+                        n_pos = s_mpos[r];
+                        n_dis = s_mdis[r];
+                        n_off = s_moff[r];
+                        const int jc = min(n_j0 + lane, n_len - 1);
+                        const uint4* cp = reinterpret_cast<const uint4*>(codes + (n_off + jc) * MT);
+#pragma unroll
+                        for (int u2 = 0; u2 < MT / 16; u2++) cn[u2] = cp[u2];
+                        sn = sb.sums[n_off + jc];
+                    }
+                };
+                int u = wv;
+                request(u);
+                while (n_have) {
+                    const int c_len = n_len, c_j0 = n_j0, c_pos = n_pos;
+                    const float c_dis = n_dis;
+                    const int64_t c_off = n_off;
+                    uint32_t cw[MT / 4];
+#pragma unroll
+                    for (int u2 = 0; u2 < MT / 16; u2++) {
+                        cw[4 * u2] = cn[u2].x; cw[4 * u2 + 1] = cn[u2].y; cw[4 * u2 + 2] = cn[u2].z; cw[4 * u2 + 3] = cn[u2].w;
+                    }
+                    const float sj = sn;
+                    u += 4;
+                    request(u);
+                    const int j = c_j0 + lane;
+                    bool ok = j < c_len;
+                    if constexpr (NID) {
+                        const int64_t id = ids[c_off + min(j, c_len - 1)];
+                        ok = ok && id >= 0;
+                        if (ok) ok = is_valid_doc(filt, id);
+                    }
+                    uint32_t t[MT];
+#pragma unroll
+                    for (int m = 0; m < MT; m++) t[m] = lut_gather_u8(cw[m >> 2], m & 3, m);
+                    __builtin_amdgcn_sched_barrier(0);   // all gathers in flight before the adds
+                    uint32_t u4[4] = {t[0], t[1], t[2], t[3]};
+#pragma unroll
+                    for (int m = 4; m < MT; m++) u4[m & 3] += t[m];
+                    const uint32_t U = (u4[0] + u4[1]) + (u4[2] + u4[3]);
+                    const float f = __builtin_fmaf(c8_nd, (float)U, (c_dis - c8_cq) + sj);
+                    if (ok) {
+                        s_f[c_pos + j] = f;
+                        g_fmn = fminf(g_fmn, f);
+                        g_fmx = fmaxf(g_fmx, f);
+                        g_nv++;
+                    }
+                }
+            };
+            if (need_ids) estimate_units(std::true_type{});
+            else estimate_units(std::false_type{});
+            GH_ST(t_pl);
+            GH_ST_ADD(3, t_pq, t_pl);
+            // range and count of the estimates, then the upper edge of the 256-bin histogram's bin that holds the K-th smallest
+            // (the regular producer's procedure, on LDS)
+            int* hist = reinterpret_cast<int*>(s_stage);   // staging has not been used yet
+            uint32_t rmn = 0, rmx = 0;
+            int rnv = 0;
+            {
+                const float fmn = g_fmn == 0.f ? -0.f : g_fmn, fmx = g_fmx == 0.f ? 0.f : g_fmx;
+                uint32_t mn = g_nv ? dis_key<true>(fmn) : 0xffffffffu;
+                uint32_t mx = g_nv ? dis_key<true>(fmx) : 0u;
+                int nv = g_nv;
+                mn = wave_min_u32(mn);
+                mx = wave_max_u32(mx);
+#pragma unroll
+                for (int o2 = 32; o2 > 0; o2 >>= 1) nv += __shfl_xor(nv, o2, 64);
+                if (lane == 0) {   // (s_red: last read in front of the image's barrier)
+                    s_red[tid >> 6] = mn;
+                    s_red[4 + (tid >> 6)] = mx;
+                    s_red[8 + (tid >> 6)] = (uint32_t)nv;
+                }
+                hist[tid] = 0;
+                __syncthreads();   // ... and every wave's estimates are in LDS
+                rmn = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+                rmx = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+                rnv = (int)(s_red[8] + s_red[9] + s_red[10] + s_red[11]);
+            }
+            // K-th smallest of n values of s_f with keys in [rmn, rmx] (others are skipped; hist zeroed): its bin's upper edge
+            auto kth_edge = [&](int n) -> uint32_t {   // whole workgroup
+                const uint32_t range = rmx - rmn;
+                const int sh = range >= 256u ? (32 - __clz((int)range)) - 8 : 0;   // (range >> sh) < 256
+                for (int i = tid; i < n; i += 256) {
+                    const uint32_t key = dis_key<true>(s_f[i]);
+                    if (key >= rmn && key <= rmx) atomicAdd(&hist[(key - rmn) >> sh], 1);
+                }
+                __syncthreads();
+                if (tid < 64) {   // wave 0: scan of the 256 bins, 4 per lane
+                    int c[4], c4 = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        c[u] = hist[lane * 4 + u];
+                        c4 += c[u];
+                    }
+                    const int incl = wave_incl_scan(c4);
+                    int run = incl - c4;
+                    if (lane == 63) s_tau = 0xffffffffu;   // (fewer than K in range: no edge)
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (run < sb.K && sb.K <= run + c[u]) {
+                            unsigned long long edge = (unsigned long long)rmn + (((unsigned long long)(lane * 4 + u) + 1ull) << sh) - 1ull;
+                            if (edge > (unsigned long long)rmx) edge = rmx;
+                            s_tau = (uint32_t)edge;
+                        }
+                        run += c[u];
+                    }
+                }
+                __syncthreads();
+                return s_tau;
+            };
+            GH_ST(t_p1);
+            GH_ST_ADD(16, t_pl, t_p1);
+            bool pc8_ok = rnv >= sb.K;   // (uniform) fewer valid codes than recall_num (a filter): the regular producer
+            int nc = 0;
+            float tau1 = 0.f, sm = 0.f;
+            if (pc8_ok) {
+                const uint32_t e1 = kth_edge(n0);
+                GH_ST(t_p2);
+                GH_ST_ADD(17, t_p1, t_p2);
+                sm = (__uint_as_float(s_smax) + 32.f * qmax) * (1.f / 65536.f);
+                tau1 = key2f(e1) + (2.03f * (float)MT * (-0.5f * c8_nd) + sm);
+                tau1 += fabsf(tau1) * 2.4e-7f;   // the sums' own roundings
+                float thr = tau1 + sm;
+                thr += fabsf(thr) * 2.4e-7f;
+                for (int i0 = 0; i0 < n0; i0 += 256) {   // uniform trip count (s_ncand: zeroed with s_nstage)
+                    const int idx = i0 + tid;
+                    const bool cand = idx < n0 && s_f[idx] <= thr;
+                    const unsigned long long bal = __ballot(cand);
+                    if (bal) {
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(&s_ncand, __popcll(bal));
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+                        if (cand && slot < PC8_CCAP) s_ci[slot] = (uint16_t)idx;
+                    }
+                }
+                hist[tid] = 0;     // (read by wave 0 in front of kth_edge's last barrier)
+                __syncthreads();   // the estimates have been read: their place takes the candidates' exact values
+                nc = s_ncand;
+                pc8_ok = nc <= PC8_CCAP;   // (uniform) more candidates than the list holds: the regular producer
+            }
+            if (pc8_ok) {
+                GH_ST(t_pc);
+                // the candidates' exact values, the regular loop's table entries and its adds in the reference's order: the list's
+                // T2 row and the query's table entries both from memory (L2)
+                auto locate = [&](int c, const uint8_t*& cj, const float*& t2, float& dis) {
+                    const int pos = (int)s_ci[c];
+                    int rr = 0;
+                    for (int pp = 1; pp < ng; pp++) rr = s_mpos[pp] <= pos ? pp : rr;   // last list whose first code is at or before pos
+                    const int l = probe_list[q * P + p_begin + rr];
+                    cj = codes + (s_moff[rr] + (pos - s_mpos[rr])) * MT;
+                    t2 = T2 + (int64_t)l * msz;
+                    dis = s_mdis[rr];
+                };
+                for (int c = tid; c < nc; c += 256) {
+                    const uint8_t* cj = codes;
+                    const float* t2 = T2;
+                    float dis = 0.f;
+                    locate(c, cj, t2, dis);
+                    uint32_t cw[MT / 4];
+#pragma unroll
+                    for (int u = 0; u < MT / 16; u++) {
+                        const uint4 cv = reinterpret_cast<const uint4*>(cj)[u];
+                        cw[4 * u] = cv.x; cw[4 * u + 1] = cv.y; cw[4 * u + 2] = cv.z; cw[4 * u + 3] = cv.w;
+                    }
+#pragma unroll
+                    for (int m0 = 0; m0 < MT; m0 += 8) {   // eight table entries of each kind in flight at a time
+                        float a[8], b[8];
+#pragma unroll
+                        for (int m = 0; m < 8; m++) {
+                            const int e = (m0 + m) * 256 + ((cw[(m0 + m) >> 2] >> (8 * (m & 3))) & 255u);
+                            a[m] = t2[e];
+                            b[m] = st2q[e];
+                        }
+#pragma unroll
+                        for (int m = 0; m < 8; m++) dis += __builtin_fmaf(-2.0f, b[m], a[m]);
+                    }
+                    s_f[c] = dis;
+                }
+                GH_ST(t_p3);
+                GH_ST_ADD(18, t_pc, t_p3);
+#ifdef GH_SCAN_TIMING
+                if (threadIdx.x == 0 && (blockIdx.x & 127) < 8) { atomicAdd(&g_scan_t[19], (unsigned long long)nc); atomicAdd(&g_scan_t[20], (unsigned long long)n0); }
+#endif
+                // the bound that is published: the K-th smallest exact value's bin over [smallest estimate - eps, tau1] -- at least
+                // recall_num candidates are within tau1 (the recall_num-th smallest exact value of the group is)
+                {
+                    float lo_f = key2f(rmn) - sm;
+                    lo_f -= fabsf(lo_f) * 2.4e-7f;
+                    rmn = dis_key<true>(lo_f);
+                    rmx = dis_key<true>(tau1);
+                }
+                __syncthreads();   // the exact values are in LDS
+                uint32_t tau = min(kth_edge(nc), rmx);
+                tau = min(tau, KEY_SENTINEL - 1u);
+                if (tid == 0)
+                    __hip_atomic_store(&sb.ready[q], (1ull << 32) | tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                GH_ST(t_pp);
+                GH_ST_ADD(4, t_pl, t_pp);
+                GH_ST_ADD(2, t_pc, t_pp);
+                // (kth_edge's last barrier: the histogram, which aliases the staging area, has been read)
+                for (int c0 = 0; c0 < nc; c0 += 256) {   // uniform trip count: append() ballots
+                    const int c = c0 + tid;
+                    const int pos = c < nc ? (int)s_ci[c] : 0;
+                    const float v = c < nc ? s_f[c] : INFINITY;
+                    append(c < nc && dis_key<true>(v) <= tau, v, pos);
+                }
+                flush();
+                GH_ST(t_pe);
+                GH_ST_ADD(5, t_pp, t_pe);
+                return;
+            }
+            // the regular producer after all: nothing has been published or appended
+            __syncthreads();
+            g_fmn = INFINITY;
+            g_fmx = -INFINITY;
+            g_nv = 0;
+        }
+    }
     if constexpr (C8) {
-        if (pg > 0) {   // (uniform) a consumer without a bound takes the regular loop: its table entries, the regular way
+        if (pg > 0 || pc8) {   // (uniform) a consumer without a bound / a producer that left the byte image: the regular loop, its table
+                               // entries the regular way
 #pragma unroll
             for (int i = 0; i < MT; i++) s2r[i] = st2q[tid + 256 * i];
         }
@@ -1132,6 +1462,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(112), amdgpu_wa
     scan_pair_body<true, MT, true, false, false, true, false, true>(x, nq, d, M, P, G, probe_list, coarse_dis, cc, st2, T2, list_off, list_len, list_mask, nlist, codes, ids, pair_off, q_stride, out, ftab, qfil, need_ids, sentinel, qperm, pg_lo, pg_cnt, sparse, sb, rq_list, rq_count, chunk_len);
 }
 
+// ... with the producer on the byte image as well (ScanBound::prod_c8)
+template <int MT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(112), amdgpu_waves_per_eu(7, 8))) void k_ivfpq_scan_pair_pc8(
+
+        const float* __restrict__ x, int nq, int d, int M, int P, int G, const int* __restrict__ probe_list,
+        const float* __restrict__ coarse_dis, const float* __restrict__ cc,
+        const float* __restrict__ st2, const float* __restrict__ T2,
+        const int64_t* __restrict__ list_off, const int* __restrict__ list_len,
+        const uint8_t* __restrict__ list_mask, int nlist, const uint8_t* __restrict__ codes,
+        const int64_t* __restrict__ ids, const int* __restrict__ pair_off, int64_t q_stride,
+        float* __restrict__ out, const FilterDesc* __restrict__ ftab, const int* __restrict__ qfil, int need_ids,
+        float sentinel, const int* __restrict__ qperm, int pg_lo, int pg_cnt, int sparse, ScanBound sb,
+        const int* __restrict__ rq_list, const int* __restrict__ rq_count, int chunk_len) {
+    scan_pair_body<true, MT, true, false, false, true, false, true, false, true>(x, nq, d, M, P, G, probe_list, coarse_dis, cc, st2, T2, list_off, list_len, list_mask, nlist, codes, ids, pair_off, q_stride, out, ftab, qfil, need_ids, sentinel, qperm, pg_lo, pg_cnt, sparse, sb, rq_list, rq_count, chunk_len);
+}
+
 // (M = 32: the 32 KB table leaves four workgroups per CU whatever the registers)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_ivfpq_scan_pair_c8m32(
 
@@ -1191,6 +1537,7 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
             (void)hipStreamSynchronize(s);
             (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_scan_t), sizeof(t));
             const double np = (double)std::max<unsigned long long>(1, t[0]), nc = (double)std::max<unsigned long long>(1, t[8]);
+            fprintf(stderr, "pc8: range %.0f, hist1 %.0f, exact loop %.0f, candidates %.1f of %.1f\n", t[16] / np, t[17] / np, t[18] / np, t[19] / np, t[20] / np);
             fprintf(stderr, "scan phases, shader cycles per workgroup -- producers (%llu): start %.0f, lists total %.0f (of which table builds incl. "
                     "their waits %.0f), bound %.0f, own slice %.0f; consumers (%llu): to the bound %.0f, byte image %.0f, filter loop %.0f, exact + flush %.0f\n",
                     t[0], t[1] / np, t[3] / np, t[2] / np, t[4] / np, t[5] / np, t[8], t[9] / nc, t[10] / nc, t[11] / nc, t[12] / nc);
@@ -1241,7 +1588,8 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
         const int per_cu = std::max(1, std::min(8, (int)(160 * 1024 / (lds + 1024))));
         grid.x = (unsigned)std::min<int64_t>(max_units, 256 * per_cu);
     }
-    if (cf) lds += (sb.c8 ? 0 : SCAN_CF_CAP * sizeof(uint2)) + 16;
+    if (!(cf && sb.c8 && M == 16)) sb.prod_c8 = 0;
+    if (cf) lds += (sb.c8 ? 0 : SCAN_CF_CAP * sizeof(uint2)) + 16 + (sb.prod_c8 ? PC8_CCAP * sizeof(uint16_t) + PC8_MAXG * 24 : 0);
 #define GH_SCAN(LL, MT, FF)                                                                       \
     GH_SCAN4(LL, MT, FF, false)
 #define GH_SCAN4(LL, MT, FF, II) GH_SCAN5(LL, MT, FF, II, false)
@@ -1313,6 +1661,8 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
         if (sb.prod_cf) {
             if (M == 16) GH_SCAN_CF(k_ivfpq_scan_pair_pcf<16>);
             else GH_SCAN_CF(k_ivfpq_scan_pair_pcf<32>);
+        } else if (sb.prod_c8) {
+            GH_SCAN_CF(k_ivfpq_scan_pair_pc8<16>);
         } else if (sb.c8 && M == 16) {
             GH_SCAN_CF(k_ivfpq_scan_pair_c8<16>);
         } else if (sb.c8) {

@@ -336,6 +336,30 @@ def test_producer_on_the_filter_pass_arithmetic():
     assert " passed" in r.stdout
 
 
+def test_producer_on_the_byte_image():
+    """GAMMA_HIP_PROD_C8 (scan.hip, ScanBound::prod_c8): the producer workgroup scores its probe group on the byte image of the
+    query's table as the consumers do -- lower estimates in LDS, their recall_num-th smallest plus the image's proven error width
+    bounds the recall_num-th best exact value, only the codes under it get the reference's arithmetic -- and does not write the
+    group's slab segment: that is scored by the repair launch for every query whose slab is read (unfiltered selection, tie
+    replay).  The bounded-scan parity tests, the C3 headline test, the tie suites and the large-batch fuzz in a child process
+    with the variable set to the other value than the parent's default: strict comparisons, as in the parent."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    other = "0" if os.environ.get("GAMMA_HIP_PROD_C8", PROD_C8_DEFAULT) != "0" else "1"
+    env = dict(os.environ, GAMMA_HIP_PROD_C8=other)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_more.py", "tests/test_gpu_ties.py",
+                        "tests/test_gpu_fuzz.py", "-k",
+                        "scan_bound_parity_at_batch_size or c3_headline or bounded_scan or large_batch or ivfpq_exact_ties or cut_ties"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
+PROD_C8_DEFAULT = "0"   # the library's default (csrc/gamma_hip_search.cpp, prod_c8_on)
+
+
 def test_bounded_scan_backs_off_where_the_bound_is_loose():
     """The scan's pre-filter bounds a query's recall_num-th best from its NEAREST probe group.  Inner-product data whose
     best candidates sit in lists far from the query in L2 (centroids s_l * u with scales 0.5 .. 2: the quantizer probes
