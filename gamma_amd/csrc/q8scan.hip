@@ -308,7 +308,10 @@ __device__ __forceinline__ uint2 q8_gather(const unsigned char* lut, uint32_t w,
 //  in flight -- one 2 KB step per wave -- left the pass waiting for memory: 5.4 ms per 3216 queries at full-size C4)
 // ------------------------------------------------------------------------------------
 constexpr int Q8_NT = 512;
-template <int MT>
+// NID: the validity predicates are compiled in.  (Two kernels instead of a run-time `if (need_ids)`: with the predicates' loads --
+// through generic pointers of the filter table -- in the loop body the compiler's wait-count pass puts `s_waitcnt vmcnt(0)` at
+// the join behind them, in front of the gathers: every step then waited for the codes of the next steps it had just requested.)
+template <int MT, bool NID>
 __global__ __launch_bounds__(Q8_NT) void k_q8_filter(
         const int4* __restrict__ tile_list, const int* __restrict__ tile_first, const int* __restrict__ n_tiles,
         const int* __restrict__ pair_run, const Q8Rec* __restrict__ recs, const uint8_t* __restrict__ q8,
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(Q8_NT) void k_q8_filter(
                 sn[1] = ls[jn];
             }
             bool ok = j < len;
-            if (need_ids) {
+            if constexpr (NID) {
                 const int64_t id = lid[jc];
                 ok = ok && id >= 0;
                 if (ok) ok = is_valid_doc(ftab[0], id);
@@ -480,7 +483,7 @@ __global__ __launch_bounds__(Q8_NT) void k_q8_filter(
 // tile, no load waited for where it is issued.  Records 4-way, pools and counters 3-way rotated.
 // ------------------------------------------------------------------------------------
 constexpr int Q8_SL_POOL = 1024;
-template <int MT>
+template <int MT, bool NID>
 __global__ __launch_bounds__(Q8_NT) void k_q8_filter_sl(
         const int4* __restrict__ tile_list, const int* __restrict__ tile_first, const int* __restrict__ n_tiles,
         const int* __restrict__ pair_run, const Q8Rec* __restrict__ recs, const uint8_t* __restrict__ q8,
@@ -614,7 +617,7 @@ __global__ __launch_bounds__(Q8_NT) void k_q8_filter_sl(
                     cd.s = ls[jn];
                 }
                 bool ok = j < len;
-                if (need_ids) {
+                if constexpr (NID) {
                     const int64_t id = lid[jc];
                     ok = ok && id >= 0;
                     if (ok) ok = is_valid_doc(ftab[0], id);
@@ -819,13 +822,20 @@ void launch_q8_consumers(hipStream_t s, const Q8Args& a) {
     const unsigned grid = grid_env > 0 ? (unsigned)grid_env : (unsigned)(256 * per_cu);
     static std::atomic<uint64_t> attr{0};   // the attribute is per DEVICE (an in-process group launches this on every member's device)
     if (first_call_on_device(attr)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_q8_filter<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_q8_filter_sl<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_q8_filter<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_q8_filter<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_q8_filter_sl<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_q8_filter_sl<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
     }
     (void)hipGetLastError();   // (a stale error of an earlier call is not this pass's)
-#define GH_Q8F(KERN, MM)                                                                                                      \
-    hipLaunchKernelGGL((KERN<MM>), dim3(grid), dim3(Q8_NT), lds, s, tile_list, tile_first, n_tiles, off, recs, a.q8, a.codes, \
+#define GH_Q8F1(KERN, MM, NN)                                                                                                      \
+    hipLaunchKernelGGL((KERN<MM, NN>), dim3(grid), dim3(Q8_NT), lds, s, tile_list, tile_first, n_tiles, off, recs, a.q8, a.codes, \
                        a.sums, a.ids, a.ftab, a.need_ids, a.cand, ccnt, cap)
+#define GH_Q8F(KERN, MM)                    \
+    do {                                    \
+        if (a.need_ids) GH_Q8F1(KERN, MM, true); \
+        else GH_Q8F1(KERN, MM, false);      \
+    } while (0)
     if (M == 16) {
         if (sl) GH_Q8F(k_q8_filter_sl, 16);
         else GH_Q8F(k_q8_filter, 16);
@@ -838,6 +848,7 @@ void launch_q8_consumers(hipStream_t s, const Q8Args& a) {
                            a.codes, a.pair_off, a.ready, a.cand, ccnt, cap, a.surv, a.gcnt, a.cnt_stride, a.slice_cap, a.fx, a.pqc, a.d, a.xd);
     }
 #undef GH_Q8F
+#undef GH_Q8F1
     // a launch of this pass that did not start leaves ccnt at 0 and k_q8_exact would publish EMPTY consumer groups: never silent
     if (hipGetLastError() != hipSuccess) launch_refused("launch_q8_consumers: a kernel of the byte-table pass failed to launch");
 }
