@@ -341,6 +341,7 @@ struct gamma_hip_index {
         // ScanBound::prod_cf: the slab segment of a query's first probe group holds approximate values; a query whose slab is
         // read (tie replay) gets it re-scored first -- what that launch needs of stage A's arguments
         bool prod_cf = false;
+        bool slice0_all = false;   // ScanBound::prod_c8: slice 0 holds the survivors of every probe (TieReplayArgs::slice0_all)
         int need_ids = 0;
         const void* d_ftab = nullptr;
         const int* d_qf = nullptr;

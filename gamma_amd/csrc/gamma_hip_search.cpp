@@ -425,7 +425,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
     static const int cap_env = getenv("GAMMA_HIP_SLICE_CAP") ? atoi(getenv("GAMMA_HIP_SLICE_CAP")) : 0;
     // (clamped to 2048: the selection and the tie replay hold one slice in LDS)
     const int cap = cap_env > 0 ? std::min(2048, std::max(cap_env, gh::scan_slice_cap(R))) : gh::scan_slice_cap(R);
-    bool cf_ok = false, q8_ok = false, q8_fused = false;
+    bool cf_ok = false, q8_ok = false, q8_fused = false, one_wg = false;
     int PGM = PGN, nsl = PGN, cf_span = 0;
     unsigned long long* ready = nullptr;
     if (bounded) {
@@ -477,10 +477,20 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
             nc = std::max(1, std::min(nc, std::max(1, PGN - 1)));
             cf_span = nc > 1 ? (rest + nc - 1) / nc : 0;
             PGM = 1 + (nc > 1 ? (rest + cf_span - 1) / cf_span : 1);
+            // ONE workgroup per query (scan.hip, ScanBound::prod_c8): the bound from byte-image estimates of the first group, then
+            // the filter pass over all probes in the same workgroup; slice 0 = the survivors, slice 1 = those of the second stage
+            // of a query whose first group took the regular producer
+            // OFF by default (GAMMA_HIP_PROD_C8=1, parity-tested): the image's PROVEN error width (2.03 M delta: all sixteen
+            // quantisation errors of a code aligned) is ~14 times the typical error, the bound lets 875 survivors per query through
+            // instead of 225 and most queries overflow their slice (C3: scan 958 us, select 672 us against 613 / 101)
+            static const bool prod_c8_on = getenv("GAMMA_HIP_PROD_C8") != nullptr && atoi(getenv("GAMMA_HIP_PROD_C8")) != 0;
+            // (no validity predicates on this path: under a filter the first group rarely holds recall_num valid codes)
+            one_wg = prod_c8_on && c8_shape && M == 16 && !shard && !two && cf_span == 0 && P <= 64 && !need_ids;
+            if (one_wg) PGM = 1;
         } else {
             PGM = PGN;   // probe groups of the main launch
         }
-        if (!q8_ok) nsl = PGM;   // one survivor slice per probe group (slice 0: the producer's own)
+        if (!q8_ok) nsl = one_wg ? 2 : PGM;   // one survivor slice per probe group (slice 0: the producer's own)
         // rq | ready[nq] | gcnt[nq][nsl]   (rq: count + list of the queries that need the repair launch, 8-byte aligned)
         const size_t rq_bytes = (((size_t)nq + 1) * sizeof(int) + 7) & ~(size_t)7;
         GH_CHECK(h, h->w_scnt.ensure(rq_bytes + (size_t)nq * (sizeof(unsigned long long) + (size_t)nsl * sizeof(int))));
@@ -622,9 +632,8 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         sb.batch = scan_batch;
         sb.dbg_part = h->scan_dbg_now;
         sb.c8 = (cf_ok && !sb.prod_cf && c8_on && (cf_span > 0 ? cf_span : P - G) <= 64) ? c8_mode : 0;
-        // the producer on the byte image too (scan.hip, "producer on the byte image"; GAMMA_HIP_PROD_C8=1)
-        static const bool prod_c8_on = getenv("GAMMA_HIP_PROD_C8") != nullptr && atoi(getenv("GAMMA_HIP_PROD_C8")) != 0;
-        sb.prod_c8 = (sb.c8 && M == 16 && !shard && !q8_ok && prod_c8_on) ? 1 : 0;
+        sb.prod_c8 = (one_wg && sb.c8) ? 1 : 0;
+        if (one_wg && !sb.c8) return fail(h, GAMMA_HIP_EINVAL, "one workgroup per query without the byte-image pass");
         const bool prod_approx = sb.prod_cf || sb.prod_c8;   // group 0's slab segment does not hold the reference's values
         // two-phase shard search: the producers' bounds out, the reduced (global) bounds back into the ready words
         auto exchange = [&]() -> int {
@@ -745,6 +754,7 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
             h->tie.bounded = true;
             h->tie.nsl = nsl;
             h->tie.cap = cap;
+            h->tie.slice0_all = sb.prod_c8 != 0;
         }
         if (dbg && shown++ >= dbg_from && shown <= dbg_from + 5) {
             std::vector<uint8_t> hf(nq);
@@ -818,6 +828,7 @@ int ivfpq_stage_b(H* h, const gamma_hip_search_params* p, int nq, const float* d
         a.gcnt = reinterpret_cast<int*>(ready + nq);
         a.nsl = h->tie.nsl;
         a.slice_cap = h->tie.cap;
+        a.slice0_all = h->tie.slice0_all ? 1 : 0;
         a.x = d_x;
         a.d = h->d;
         a.raw = h->d_raw;

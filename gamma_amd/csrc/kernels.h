@@ -197,11 +197,12 @@ struct ScanBound {
     int dbg_part;               // timing experiments only (GAMMA_HIP_SCAN_PART): 1 = consumers leave at once, 2 = producers do
     int c8;                     // != 0 (filter-pass launches only): the consumers' filter pass gathers from a BYTE image of the query's
                                 // table made in the workgroup (2-way bank conflicts at most instead of ~3.5); candidates as ever
-    int prod_c8;                // != 0 (with c8, M = 16): the PRODUCER scores its probes on the byte image too (scan.hip, "producer on the byte
-                                // image"): lower estimates of its whole group in LDS, their recall_num-th smallest + the image's proven error
-                                // width bounds the recall_num-th best exact value, only the codes under that get the exact arithmetic.  Its
-                                // slab segment is NOT written: the callers score group 0 (repair launch) for every query whose slab is read
-                                // (unfiltered selection, tie replay), as with prod_cf
+    int prod_c8;                // != 0 (with c8, M = 16, one group per launch, two slices per query): ONE workgroup per query -- the bound from
+                                // byte-image estimates of the first probe group (their recall_num-th smallest + the image's proven error
+                                // width), then the filter pass over ALL probes in the same workgroup (scan.hip, "one workgroup per query").
+                                // The first group's slab segment is NOT written: the callers score group 0 (repair launch) for every
+                                // query whose slab is read (unfiltered selection, tie replay), as with prod_cf; slice 0 holds the
+                                // survivors of every probe (TieReplayArgs::slice0_all)
 };
 // ---- q8scan.hip: the consumer probes of a bounded L2 scan, list-major over byte tables (one list x 8 queries per tile) ----
 struct Q8Args {
@@ -399,6 +400,8 @@ struct TieReplayArgs {
                                   // of heap_replace_top (the IVFPQ scanner)
     int fixed_n = 0;              // pair_off == nullptr (flat): every row has fixed_n entries, a position IS the vector id
     int compact_rows = 0;         // slab row i belongs to the i-th flagged query (list[i]) instead of query i
+    int slice0_all = 0;           // slice 0 holds the survivors of EVERY probe (ScanBound::prod_c8): the slices are walked from slice 0 on and
+                                  // entries of the first group (in the slab part already) are skipped
     int always_sliced = 0;        // ready == nullptr: every query is first G slab entries + slices 1.. (flat search with the
                                   // running bound: first row chunk + the candidates each later pass emitted)
 };

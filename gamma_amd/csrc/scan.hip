@@ -66,8 +66,10 @@ constexpr int C8_CAND = 1536;      // byte-table pass: its candidates sit in the
 // points at the PQ codebook and `T2` is null; the residual sits in LDS behind the staging words.
 // PC8 (with C8, round 6): the producer scores its group on the byte image as well (ScanBound::prod_c8), see "producer on the byte image"
 constexpr int PC8_MAXN = 3072;     // codes of a producer's group whose lower estimates fit the 12 KB behind the byte image (M = 16)
-constexpr int PC8_CCAP = 1024;     // its candidates for the exact arithmetic (positions, 2 bytes each)
-constexpr int PC8_MAXG = 8;        // lists of a producer's group
+constexpr int PC8_MAXG = 8;        // lists of the estimate group
+// LDS byte offset of the residual image (M = 16): behind the table's place, the survivor stage, the 16 words, the list counter's 16 bytes
+// and the estimate group's lists -- the dynamic buffer is all of the kernel's LDS and starts at address 0 (see lut_gather)
+constexpr int PC8_IMG2_OFF = 16 * 1024 + SCAN_STAGE * 8 + 64 + 16 + PC8_MAXG * 24;
 template <bool L2, int MT, bool FILT, bool IPF, bool UNITS, bool CF, bool PCF, bool C8 = false, bool RES = false, bool PC8 = false>
 __device__ __forceinline__ void scan_pair_body(
 
@@ -242,10 +244,13 @@ __device__ __forceinline__ void scan_pair_body(
     // (uniform) this workgroup is a producer that takes the byte image: its group fits the estimates' place in LDS and holds
     // at least recall_num codes
     bool pc8 = false;
+    int g_est = 0;   // lists of the estimate group: the longest prefix of the first probe group whose codes fit the estimates' place
     if constexpr (PC8) {
         if (pg == 0 && sb.prod_c8) {
-            const int n0 = pair_off[(int64_t)q * (P + 1) + min(G, P)];
-            pc8 = n0 <= PC8_MAXN && n0 >= sb.K && G <= PC8_MAXG;
+            const int* po = pair_off + (int64_t)q * (P + 1);
+            pc8 = true;
+            for (int g = 1; g <= min(min(G, P), PC8_MAXG); g++)
+                if (po[g] <= PC8_MAXN) g_est = g;
         }
     }
     if (IPF && MT > 0) {
@@ -323,7 +328,8 @@ __device__ __forceinline__ void scan_pair_body(
     }
     // the byte image of the query's table ("byte table" below), made by the whole workgroup from v8 where the fp32 table would be;
     // contains one barrier, none behind the image's stores
-    auto c8_image = [&](float& qmax, float& c8_cq, float& c8_nd) {
+    auto c8_image = [&](float& qmax, float& c8_cq, float& c8_nd, auto two_c) {
+        constexpr bool TWO = decltype(two_c)::value;   // + the image of the residuals (one workgroup per query, below)
         if constexpr (C8) {
         float lo[MT / 4], range = 0.f, Lsum = 0.f, amax = 0.f;
 #pragma unroll
@@ -351,26 +357,244 @@ __device__ __forceinline__ void scan_pair_body(
         const float delta = (range / 255.f) * 1.000001f;   // (hi - lo) / delta stays below 255.5 whatever the roundings
         const float inv = delta > 0.f ? 1.f / delta : 0.f;
         uint32_t* s_b8 = reinterpret_cast<uint32_t*>(s_lut);
+        const float delta2 = (delta / 255.f) * 1.000001f, inv2 = delta2 > 0.f ? 1.f / delta2 : 0.f;
 #pragma unroll
         for (int k = 0; k < MT / 4; k++) {
             const float f[4] = {v8[k].x, v8[k].y, v8[k].z, v8[k].w};
-            uint32_t w = 0;
+            uint32_t w = 0, w2 = 0;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 int u = (int)rintf((f[e] - lo[k]) * inv);
                 u = min(255, max(0, u));
                 w |= (uint32_t)u << (8 * e);
+                if constexpr (TWO) {
+                    // ip = (lo - delta / 2) + delta u + delta2 u2 + e2,  |e2| <= 0.55 delta2 (the residual (ip - lo) - delta u lies in
+                    // [-delta / 2, delta / 2] up to roundings of 3 * 2^-24 of the row's range = 0.004 delta2)
+                    const float r = (f[e] - lo[k]) - delta * (float)u;
+                    int u2 = (int)rintf(__builtin_fmaf(0.5f, delta, r) * inv2);
+                    u2 = min(255, max(0, u2));
+                    w2 |= (uint32_t)u2 << (8 * e);
+                }
             }
             s_b8[((tid >> 6) + 4 * k) * 64 + lane] = w;
+            if constexpr (TWO) s_b8[PC8_IMG2_OFF / 4 + ((tid >> 6) + 4 * k) * 64 + lane] = w2;
         }
         qmax = amax;
         c8_cq = 2.f * Lsum + 1.02f * (float)MT * delta;
         c8_nd = -2.f * delta;
         }
     };
+    // ---- one workgroup per query (ScanBound::prod_c8, round 6): the bound from the BYTE IMAGE, then the filter pass over ALL probes ----
+    // The regular producer builds a 16 KB table per list (the T2 row through the L2, 4096 fma + LDS stores, two barriers) to score
+    // a few hundred codes: 43 % of the launch's workgroup time for 11 % of its codes, and a second workgroup per query that
+    // waits for it, reads the query's table again and makes the byte image again.  All the bound needs is an UPPER bound of the
+    // recall_num-th best exact value.  The image gives every code j of the first group the consumers' test value
+    //       f_j = (dis0 - 2 sum_m lo - 1.02 M delta) + s_j - 2 delta U_j,        f_j - eps <= v_j <= f_j + 2.0202 M delta + eps
+    // (the image's error bound |ip - lo - delta u8| <= 0.5001 delta per entry; eps = 50 * 2^-24 S, the roundings, as in the filter
+    // pass), so the recall_num-th smallest f plus W = 2.03 M delta + 2^-16 S_max bounds the recall_num-th smallest exact value of the
+    // group, hence the query's: estimates of the group in LDS (units of 64 codes dealt round-robin to the waves across all of its
+    // lists), 256-bin histogram, tau1 = edge + W published -- and the SAME workgroup goes on with the filter pass over every probe
+    // of the query, the first group included, against tau1: candidates f <= tau1 + margin get the reference's arithmetic, those with
+    // v <= tau1 are the query's survivors (slice 0; slice 1 stays empty).  No slab segment is written: the callers score group 0
+    // (repair launch) for every query whose slab is read (unfiltered selection, tie replay).
+    // A group that does not fit (more than PC8_MAXN codes, fewer than recall_num valid ones, more than PC8_MAXG lists) takes the
+    // regular producer, and the workgroup then runs the consumers' pass for the other probes as a second stage (slice 1).
+    bool fused = false;
+    float f_qmax = 0.f, f_cq = 0.f, f_nd = 0.f;
+    if constexpr (PC8) {
+        if (pc8) {   // (uniform)
+            float* s_f = s_lut + MT * 64;   // [n0 <= PC8_MAXN]: the estimates (the filter pass's candidates take the place afterwards)
+            uint32_t& s_smax = *(reinterpret_cast<uint32_t*>(s_cand) + 1);
+            // the estimate group's lists: (first code | codes | dis0 | position of the first code in the query's row), read once
+            int64_t* s_moff = reinterpret_cast<int64_t*>(s_cand + 2);             // [PC8_MAXG]
+            int* s_mlen = reinterpret_cast<int*>(s_moff + PC8_MAXG);               // [PC8_MAXG]
+            float* s_mdis = reinterpret_cast<float*>(s_mlen + PC8_MAXG);           // [PC8_MAXG]
+            int* s_mpos = reinterpret_cast<int*>(s_mdis + PC8_MAXG);               // [PC8_MAXG]
+            const int* poff = pair_off + (int64_t)q * (P + 1);
+            const int ng = g_est, n0 = poff[g_est];
+            if (tid < 64) {   // wave 0 (ng <= PC8_MAXG lanes of it)
+                float sl = 0.f;
+                if (tid < ng) {
+                    const int pair = q * P + tid;
+                    const int l = probe_list[pair];
+                    int len = 0;
+                    int64_t off = 0;
+                    float t2m = 0.f;
+                    if (l >= 0 && l < nlist && (!list_mask || list_mask[l])) {
+                        len = max(0, list_len[l]);
+                        off = list_off[l];
+                        t2m = sb.t2max[l];
+                    }
+                    const float dis0 = coarse_dis[pair];
+                    s_moff[tid] = off;
+                    s_mlen[tid] = len;
+                    s_mdis[tid] = dis0;
+                    s_mpos[tid] = poff[tid];
+                    if (len > 0) sl = fabsf(dis0) + t2m;
+                }
+                const uint32_t smx = wave_max_u32(__float_as_uint(sl));   // non-negative floats order as integers
+                if (tid == 0) s_smax = smx;
+            }
+            float qmax = 0.f, c8_cq = 0.f, c8_nd = 0.f;
+            c8_image(qmax, c8_cq, c8_nd, std::true_type{});
+            __syncthreads();   // the images and the lists' data are in place
+            GH_ST(t_pq);
+            GH_ST_CNT(0);
+            GH_ST_ADD(1, t_start, t_pq);
+            // ---- the estimates: units of 64 codes dealt round-robin to the four waves across ALL lists of the group, the next
+            // unit's codes and sums requested before the current unit's gathers.  Both images:
+            //     f2_j = dis0 + s_j - 2 (sum_m (lo_m - delta / 2) + delta U_j + delta2 U2_j) - 1.1 M delta2,
+            //     f2_j - eps <= v_j <= f2_j + 2.2 M delta2 + eps      (|e2| <= 0.55 delta2 per entry, eps: the roundings, <= 2^-16 S)
+            const float delta = -0.5f * c8_nd, delta2 = (delta / 255.f) * 1.000001f;
+            // c8_cq = 2 sum lo + 1.02 M delta  ->  2 sum (lo - delta / 2) + 1.1 M delta2
+            const float cq2 = (c8_cq - 2.02f * (float)MT * delta) + 1.1f * (float)MT * delta2;
+            const float nd2 = -2.f * delta2;
+            {
+                const int wv = tid >> 6;
+                int r = 0, ub = 0;   // cursor of the unit whose codes are being requested: list r, whose first unit is ub
+                int len = ng > 0 ? s_mlen[0] : 0, ns = (len + 63) >> 6;
+                uint4 cn[MT / 16];
+                float sn = 0.f;
+                // state of the requested unit
+                int n_len = 0, n_j0 = 0, n_pos = 0;
+                float n_dis = 0.f;
+                int64_t n_off = 0;
+                bool n_have = false;
+                auto request = [&](int u) {   // (uniform)
+                    while (r < ng && u >= ub + ns) {
+                        ub += ns;
+                        r++;
+                        len = r < ng ? s_mlen[r] : 0;
+                        ns = (len + 63) >> 6;
+                    }
+                    n_have = r < ng;
+                    if (n_have) {
+                        n_len = len;
+                        n_j0 = (u - ub) << 6;
+                        n_pos = s_mpos[r];
+                        n_dis = s_mdis[r];
+                        n_off = s_moff[r];
+                        const int jc = min(n_j0 + lane, n_len - 1);
+                        const uint4* cp = reinterpret_cast<const uint4*>(codes + (n_off + jc) * MT);
+#pragma unroll
+                        for (int u2 = 0; u2 < MT / 16; u2++) cn[u2] = cp[u2];
+                        sn = sb.sums[n_off + jc];
+                    }
+                };
+                int u = wv;
+                request(u);
+                while (n_have) {
+                    const int c_len = n_len, c_j0 = n_j0, c_pos = n_pos;
+                    const float c_dis = n_dis;
+                    uint32_t cw[MT / 4];
+#pragma unroll
+                    for (int u2 = 0; u2 < MT / 16; u2++) {
+                        cw[4 * u2] = cn[u2].x; cw[4 * u2 + 1] = cn[u2].y; cw[4 * u2 + 2] = cn[u2].z; cw[4 * u2 + 3] = cn[u2].w;
+                    }
+                    const float sj = sn;
+                    u += 4;
+                    request(u);
+                    const int j = c_j0 + lane;
+                    uint32_t t[MT], t2[MT];
+#pragma unroll
+                    for (int m = 0; m < MT; m++) t[m] = lut_gather_u8(cw[m >> 2], m & 3, m);
+#pragma unroll
+                    for (int m = 0; m < MT; m++) t2[m] = lut_gather_u8_at<PC8_IMG2_OFF>(cw[m >> 2], m & 3, m);
+                    __builtin_amdgcn_sched_barrier(0);   // all gathers in flight before the adds
+                    uint32_t u4[4] = {t[0], t[1], t[2], t[3]}, v4[4] = {t2[0], t2[1], t2[2], t2[3]};
+#pragma unroll
+                    for (int m = 4; m < MT; m++) {
+                        u4[m & 3] += t[m];
+                        v4[m & 3] += t2[m];
+                    }
+                    const uint32_t U = (u4[0] + u4[1]) + (u4[2] + u4[3]), U2 = (v4[0] + v4[1]) + (v4[2] + v4[3]);
+                    const float f = __builtin_fmaf(nd2, (float)U2, __builtin_fmaf(c8_nd, (float)U, (c_dis - cq2) + sj));
+                    if (j < c_len) {   // (no validity predicates on this path: every code counts)
+                        s_f[c_pos + j] = f;
+                        g_fmn = fminf(g_fmn, f);
+                        g_fmx = fmaxf(g_fmx, f);
+                    }
+                }
+            }
+            GH_ST(t_pl);
+            GH_ST_ADD(3, t_pq, t_pl);
+            // range of the estimates, then the upper edge of the 256-bin histogram's bin that holds the K-th smallest (the regular
+            // producer's procedure, on LDS)
+            int* hist = reinterpret_cast<int*>(s_stage);   // staging has not been used yet
+            uint32_t rmn = 0, rmx = 0;
+            {
+                const float fmn = g_fmn == 0.f ? -0.f : g_fmn, fmx = g_fmx == 0.f ? 0.f : g_fmx;
+                uint32_t mn = g_fmn <= g_fmx ? dis_key<true>(fmn) : 0xffffffffu;
+                uint32_t mx = g_fmn <= g_fmx ? dis_key<true>(fmx) : 0u;
+                mn = wave_min_u32(mn);
+                mx = wave_max_u32(mx);
+                if (lane == 0) {   // (s_red: last read in front of the image's barrier)
+                    s_red[tid >> 6] = mn;
+                    s_red[4 + (tid >> 6)] = mx;
+                }
+                hist[tid] = 0;
+                __syncthreads();   // ... and every wave's estimates are in LDS
+                rmn = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+                rmx = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+            }
+            GH_ST(t_p1);
+            GH_ST_ADD(16, t_pl, t_p1);
+            uint32_t tk = KEY_SENTINEL - 1u;
+            if (n0 >= sb.K) {   // (uniform)
+                const uint32_t range = rmx - rmn;
+                const int sh = range >= 256u ? (32 - __clz((int)range)) - 8 : 0;   // (range >> sh) < 256
+                for (int i = tid; i < n0; i += 256) atomicAdd(&hist[(dis_key<true>(s_f[i]) - rmn) >> sh], 1);
+                __syncthreads();
+                if (tid < 64) {   // wave 0: scan of the 256 bins, 4 per lane
+                    int c[4], c4 = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        c[u] = hist[lane * 4 + u];
+                        c4 += c[u];
+                    }
+                    const int incl = wave_incl_scan(c4);
+                    int run = incl - c4;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (run < sb.K && sb.K <= run + c[u]) {
+                            unsigned long long edge = (unsigned long long)rmn + (((unsigned long long)(lane * 4 + u) + 1ull) << sh) - 1ull;
+                            if (edge > (unsigned long long)rmx) edge = rmx;
+                            s_tau = (uint32_t)edge;
+                        }
+                        run += c[u];
+                    }
+                }
+                __syncthreads();
+                const float sm = (__uint_as_float(s_smax) + 32.f * qmax) * (1.f / 65536.f);
+                float tau1 = key2f(s_tau) + (2.21f * (float)MT * delta2 + sm);
+                tau1 += fabsf(tau1) * 2.4e-7f;   // the sums' own roundings
+                tk = min(dis_key<true>(tau1), KEY_SENTINEL - 1u);
+                fused = true;
+            }
+            GH_ST(t_pp);
+            GH_ST_ADD(4, t_pl, t_pp);
+            if (tid == 0) {
+                __hip_atomic_store(&sb.ready[q], (1ull << 32) | tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sb.gcnt[(int64_t)q * sb.cnt_stride + 1] = 0;   // (slice 1: unused)
+                // a query whose nearest list alone is longer than the estimates' place, or whose first group holds fewer than
+                // recall_num codes: to the unfiltered selection, via an "overflowed" slice (the repair launch scores all its groups)
+                if (!fused) s_nstage = sb.slice_cap + 1;
+            }
+            if (!fused) {
+                flush();
+                return;
+            }
+            tauq = tk;
+            tau_f = key2f(tk);
+            bound_on = true;
+            f_qmax = qmax;
+            f_cq = c8_cq;
+            f_nd = c8_nd;
+        }
+    }
     GH_ST(t_bound);
     if constexpr (CF) {
-        if (pg > 0 && bound_on) {   // (uniform)
+        if ((pg > 0 && bound_on) || fused) {   // (uniform)
             GH_ST_CNT(8);
             GH_ST_ADD(9, t_start, t_bound);
             // ---- filter pass (L2 consumers with a bound) ----------------------------------------------------------
@@ -386,8 +610,11 @@ __device__ __forceinline__ void scan_pair_body(
             // (about as many as end up in the slice) get the EXACT value afterwards -- table entries fetched from
             // the L2-resident T2 row, fma and adds in the reference's order -- and the slice receives what the
             // regular loop would have put there: same keys, same positions.
-            float qmax, c8_cq = 0.f, c8_nd = 0.f;
-            if constexpr (C8) {
+            float qmax = f_qmax, c8_cq = f_cq, c8_nd = f_nd;
+            // (one workgroup per query: the image is in place, the pass covers every probe)
+            const int pb = fused ? 0 : p_begin, pe = fused ? P : p_end;
+            if (fused) {
+            } else if constexpr (C8) {
                 // ---- byte table (round 5) --------------------------------------------------------------------------
                 // 64 lanes gathering random fp32 entries of one 256-entry row hit the 32 banks ~3.5 deep (a half wave's 32
                 // requests over 32 banks, 8 entries per bank): 57 % of this kernel's LDS cycles were conflicts.  A row of
@@ -398,7 +625,7 @@ __device__ __forceinline__ void scan_pair_body(
                 // a code is a candidate iff (A + s_j) - 2 delta U <= tau + 2^-16 S.  The image is made HERE (the arithmetic
                 // of k_q8_quant: wave w owns rows w, w + 4, ..; minimum and maximum of a row are one wave reduction) and
                 // lives where the fp32 table will be written for the exact recompute of the candidates.
-                c8_image(qmax, c8_cq, c8_nd);
+                c8_image(qmax, c8_cq, c8_nd, std::false_type{});
             } else {
                 lut_store_begin(lut_m0);
                 lut_store_rows<MT>([&](int i) { return s2r[i]; }, std::make_integer_sequence<int, (MT > 0 ? MT : 1)>{});
@@ -414,7 +641,7 @@ __device__ __forceinline__ void scan_pair_body(
             __syncthreads();   // the LUT and the list counter are in place
             GH_ST(t_quant);
             GH_ST_ADD(10, t_bound, t_quant);
-            const int ng = p_end - p_begin;
+            const int ng = pe - pb;
             // (two copies of the loop, with and without the validity predicates: with their loads -- through generic pointers of
             //  the filter table -- anywhere in the loop body, the compiler's wait-count pass puts `s_waitcnt vmcnt(0)` in front of the
             //  gathers at the join behind them, i.e. every step waited for the NEXT step's codes it had just requested)
@@ -425,7 +652,7 @@ __device__ __forceinline__ void scan_pair_body(
                 if (lane == 0) r = atomicAdd(&s_next, 1);
                 r = __builtin_amdgcn_readfirstlane(r);
                 if (r >= ng) break;
-                const int p = p_begin + r, pair = q * P + p;
+                const int p = pb + r, pair = q * P + p;
                 const int l = probe_list[pair];
                 if (l < 0 || l >= nlist) continue;            // uniform per wave
                 if (list_mask && !list_mask[l]) continue;
@@ -578,306 +805,6 @@ __device__ __forceinline__ void scan_pair_body(
             GH_ST(t_cend);
             GH_ST_ADD(12, t_loop, t_cend);
             return;
-        }
-    }
-    if constexpr (PC8) {
-        if (pc8) {   // (uniform)
-            // ---- producer on the byte image (round 6) ---------------------------------------------------------------------
-            // The regular producer builds a 16 KB table per list (the T2 row through the L2, 4096 fma + LDS stores, two barriers)
-            // to score ~250 codes, a third of the launch for a sixth of its codes (profiles/r05_scan_parts.txt).  It needs exact
-            // values for its ~recall_num + one-bin candidates only.  The byte image gives every code j of the group the consumers'
-            // test value f_j = (dis0 - 2 sum_m lo - 1.02 M delta) + s_j - 2 delta U_j with, by the image's error bound
-            // (|ip - lo - delta u8| <= 0.5001 delta per entry),
-            //       f_j - eps <= v_j <= f_j + 2.0202 M delta + eps,      eps = 50 * 2^-24 S  (the roundings, as in the filter pass),
-            // so the recall_num-th smallest f plus W = 2.03 M delta + 2^-16 S_max bounds the recall_num-th smallest EXACT value:
-            // histogram of the f's (LDS), tau1 = edge + W, exact arithmetic for the codes with f <= tau1 + 2^-16 S_max (every code
-            // whose exact value is within tau1 is among them), a second histogram over those exact values gives the bound that
-            // is published, tau = min(edge2, tau1), and the slice gets the codes with v <= tau: the same slice the regular
-            // producer writes for that bound.  The slab segment of the group is not written (ScanBound::prod_c8).
-            float* s_f = s_lut + MT * 64;   // [n0 <= PC8_MAXN]: f_j; later [nc]: v of candidate c
-            int& s_nunit = *reinterpret_cast<int*>(s_cand);
-            uint32_t& s_smax = *(reinterpret_cast<uint32_t*>(s_cand) + 1);
-            // the group's lists: (first code | codes | dis0 | position of the first code in the query's row), read once
-            int64_t* s_moff = reinterpret_cast<int64_t*>(s_cand + 2);             // [PC8_MAXG]
-            int* s_mlen = reinterpret_cast<int*>(s_moff + PC8_MAXG);               // [PC8_MAXG]
-            float* s_mdis = reinterpret_cast<float*>(s_mlen + PC8_MAXG);           // [PC8_MAXG]
-            int* s_mpos = reinterpret_cast<int*>(s_mdis + PC8_MAXG);               // [PC8_MAXG]
-            uint16_t* s_ci = reinterpret_cast<uint16_t*>(s_mpos + PC8_MAXG);       // [PC8_CCAP] positions of the candidates
-            const int* poff = pair_off + (int64_t)q * (P + 1);
-            const int n0 = poff[min(G, P)];
-            const int ng = p_end - p_begin;
-            if (tid < 64) {   // wave 0 (ng <= PC8_MAXG lanes of it)
-                float sl = 0.f;
-                if (tid < ng) {
-                    const int p = p_begin + tid, pair = q * P + p;
-                    const int l = probe_list[pair];
-                    int len = 0;
-                    int64_t off = 0;
-                    float t2m = 0.f;
-                    if (l >= 0 && l < nlist && (!list_mask || list_mask[l])) {
-                        len = max(0, list_len[l]);
-                        off = list_off[l];
-                        t2m = sb.t2max[l];
-                    }
-                    const float dis0 = coarse_dis[pair];
-                    s_moff[tid] = off;
-                    s_mlen[tid] = len;
-                    s_mdis[tid] = dis0;
-                    s_mpos[tid] = poff[p];
-                    if (len > 0) sl = fabsf(dis0) + t2m;
-                }
-                const uint32_t smx = wave_max_u32(__float_as_uint(sl));   // non-negative floats order as integers
-                if (tid == 0) s_smax = smx;
-            }
-            for (int i = tid; i < n0; i += 256) s_f[i] = INFINITY;
-            float qmax = 0.f, c8_cq = 0.f, c8_nd = 0.f;
-            c8_image(qmax, c8_cq, c8_nd);
-            __syncthreads();   // the image, the lists' data and the estimates' defaults are in place
-            GH_ST(t_pq);
-            GH_ST_CNT(0);
-            GH_ST_ADD(1, t_start, t_pq);
-            // Units of 64 codes, dealt round-robin to the four waves across ALL lists of the group (whole lists per wave leave one
-            // wave with two of five lists: the workgroup then takes as long as two lists), the next unit's codes and sums
-            // requested before the current unit's gathers.
-            auto estimate_units = [&](auto nid_c) {
-                constexpr bool NID = decltype(nid_c)::value;   // (two copies, as in the consumers' loop)
-                const int wv = tid >> 6;
-                int r = 0, ub = 0;   // cursor of the unit whose codes are being requested: list r, whose first unit is ub
-                int len = s_mlen[0], ns = (len + 63) >> 6;
-                uint4 cn[MT / 16];
-                float sn = 0.f;
-                // state of the requested unit
-                int n_len = 0, n_j0 = 0, n_pos = 0;
-                float n_dis = 0.f;
-                int64_t n_off = 0;
-                bool n_have = false;
-                auto request = [&](int u) {   // (uniform)
-                    while (r < ng && u >= ub + ns) {
-                        ub += ns;
-                        r++;
-                        len = r < ng ? s_mlen[r] : 0;
-                        ns = (len + 63) >> 6;
-                    }
-                    n_have = r < ng;
-                    if (n_have) {
-                        n_len = len;
-                        n_j0 = (u - ub) << 6;
-                        n_pos = s_mpos[r];
-                        n_dis = s_mdis[r];
-                        n_off = s_moff[r];
-                        const int jc = min(n_j0 + lane, n_len - 1);
-                        const uint4* cp = reinterpret_cast<const uint4*>(codes + (n_off + jc) * MT);
-#pragma unroll
-                        for (int u2 = 0; u2 < MT / 16; u2++) cn[u2] = cp[u2];
-                        sn = sb.sums[n_off + jc];
-                    }
-                };
-                int u = wv;
-                request(u);
-                while (n_have) {
-                    const int c_len = n_len, c_j0 = n_j0, c_pos = n_pos;
-                    const float c_dis = n_dis;
-                    const int64_t c_off = n_off;
-                    uint32_t cw[MT / 4];
-#pragma unroll
-                    for (int u2 = 0; u2 < MT / 16; u2++) {
-                        cw[4 * u2] = cn[u2].x; cw[4 * u2 + 1] = cn[u2].y; cw[4 * u2 + 2] = cn[u2].z; cw[4 * u2 + 3] = cn[u2].w;
-                    }
-                    const float sj = sn;
-                    u += 4;
-                    request(u);
-                    const int j = c_j0 + lane;
-                    bool ok = j < c_len;
-                    if constexpr (NID) {
-                        const int64_t id = ids[c_off + min(j, c_len - 1)];
-                        ok = ok && id >= 0;
-                        if (ok) ok = is_valid_doc(filt, id);
-                    }
-                    uint32_t t[MT];
-#pragma unroll
-                    for (int m = 0; m < MT; m++) t[m] = lut_gather_u8(cw[m >> 2], m & 3, m);
-                    __builtin_amdgcn_sched_barrier(0);   // all gathers in flight before the adds
-                    uint32_t u4[4] = {t[0], t[1], t[2], t[3]};
-#pragma unroll
-                    for (int m = 4; m < MT; m++) u4[m & 3] += t[m];
-                    const uint32_t U = (u4[0] + u4[1]) + (u4[2] + u4[3]);
-                    const float f = __builtin_fmaf(c8_nd, (float)U, (c_dis - c8_cq) + sj);
-                    if (ok) {
-                        s_f[c_pos + j] = f;
-                        g_fmn = fminf(g_fmn, f);
-                        g_fmx = fmaxf(g_fmx, f);
-                        g_nv++;
-                    }
-                }
-            };
-            if (need_ids) estimate_units(std::true_type{});
-            else estimate_units(std::false_type{});
-            GH_ST(t_pl);
-            GH_ST_ADD(3, t_pq, t_pl);
-            // range and count of the estimates, then the upper edge of the 256-bin histogram's bin that holds the K-th smallest
-            // (the regular producer's procedure, on LDS)
-            int* hist = reinterpret_cast<int*>(s_stage);   // staging has not been used yet
-            uint32_t rmn = 0, rmx = 0;
-            int rnv = 0;
-            {
-                const float fmn = g_fmn == 0.f ? -0.f : g_fmn, fmx = g_fmx == 0.f ? 0.f : g_fmx;
-                uint32_t mn = g_nv ? dis_key<true>(fmn) : 0xffffffffu;
-                uint32_t mx = g_nv ? dis_key<true>(fmx) : 0u;
-                int nv = g_nv;
-                mn = wave_min_u32(mn);
-                mx = wave_max_u32(mx);
-#pragma unroll
-                for (int o2 = 32; o2 > 0; o2 >>= 1) nv += __shfl_xor(nv, o2, 64);
-                if (lane == 0) {   // (s_red: last read in front of the image's barrier)
-                    s_red[tid >> 6] = mn;
-                    s_red[4 + (tid >> 6)] = mx;
-                    s_red[8 + (tid >> 6)] = (uint32_t)nv;
-                }
-                hist[tid] = 0;
-                __syncthreads();   // ... and every wave's estimates are in LDS
-                rmn = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
-                rmx = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
-                rnv = (int)(s_red[8] + s_red[9] + s_red[10] + s_red[11]);
-            }
-            // K-th smallest of n values of s_f with keys in [rmn, rmx] (others are skipped; hist zeroed): its bin's upper edge
-            auto kth_edge = [&](int n) -> uint32_t {   // whole workgroup
-                const uint32_t range = rmx - rmn;
-                const int sh = range >= 256u ? (32 - __clz((int)range)) - 8 : 0;   // (range >> sh) < 256
-                for (int i = tid; i < n; i += 256) {
-                    const uint32_t key = dis_key<true>(s_f[i]);
-                    if (key >= rmn && key <= rmx) atomicAdd(&hist[(key - rmn) >> sh], 1);
-                }
-                __syncthreads();
-                if (tid < 64) {   // wave 0: scan of the 256 bins, 4 per lane
-                    int c[4], c4 = 0;
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        c[u] = hist[lane * 4 + u];
-                        c4 += c[u];
-                    }
-                    const int incl = wave_incl_scan(c4);
-                    int run = incl - c4;
-                    if (lane == 63) s_tau = 0xffffffffu;   // (fewer than K in range: no edge)
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (run < sb.K && sb.K <= run + c[u]) {
-                            unsigned long long edge = (unsigned long long)rmn + (((unsigned long long)(lane * 4 + u) + 1ull) << sh) - 1ull;
-                            if (edge > (unsigned long long)rmx) edge = rmx;
-                            s_tau = (uint32_t)edge;
-                        }
-                        run += c[u];
-                    }
-                }
-                __syncthreads();
-                return s_tau;
-            };
-            GH_ST(t_p1);
-            GH_ST_ADD(16, t_pl, t_p1);
-            bool pc8_ok = rnv >= sb.K;   // (uniform) fewer valid codes than recall_num (a filter): the regular producer
-            int nc = 0;
-            float tau1 = 0.f, sm = 0.f;
-            if (pc8_ok) {
-                const uint32_t e1 = kth_edge(n0);
-                GH_ST(t_p2);
-                GH_ST_ADD(17, t_p1, t_p2);
-                sm = (__uint_as_float(s_smax) + 32.f * qmax) * (1.f / 65536.f);
-                tau1 = key2f(e1) + (2.03f * (float)MT * (-0.5f * c8_nd) + sm);
-                tau1 += fabsf(tau1) * 2.4e-7f;   // the sums' own roundings
-                float thr = tau1 + sm;
-                thr += fabsf(thr) * 2.4e-7f;
-                for (int i0 = 0; i0 < n0; i0 += 256) {   // uniform trip count (s_ncand: zeroed with s_nstage)
-                    const int idx = i0 + tid;
-                    const bool cand = idx < n0 && s_f[idx] <= thr;
-                    const unsigned long long bal = __ballot(cand);
-                    if (bal) {
-                        int base = 0;
-                        if (lane == 0) base = atomicAdd(&s_ncand, __popcll(bal));
-                        base = __builtin_amdgcn_readfirstlane(base);
-                        const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
-                        if (cand && slot < PC8_CCAP) s_ci[slot] = (uint16_t)idx;
-                    }
-                }
-                hist[tid] = 0;     // (read by wave 0 in front of kth_edge's last barrier)
-                __syncthreads();   // the estimates have been read: their place takes the candidates' exact values
-                nc = s_ncand;
-                pc8_ok = nc <= PC8_CCAP;   // (uniform) more candidates than the list holds: the regular producer
-            }
-            if (pc8_ok) {
-                GH_ST(t_pc);
-                // the candidates' exact values, the regular loop's table entries and its adds in the reference's order: the list's
-                // T2 row and the query's table entries both from memory (L2)
-                auto locate = [&](int c, const uint8_t*& cj, const float*& t2, float& dis) {
-                    const int pos = (int)s_ci[c];
-                    int rr = 0;
-                    for (int pp = 1; pp < ng; pp++) rr = s_mpos[pp] <= pos ? pp : rr;   // last list whose first code is at or before pos
-                    const int l = probe_list[q * P + p_begin + rr];
-                    cj = codes + (s_moff[rr] + (pos - s_mpos[rr])) * MT;
-                    t2 = T2 + (int64_t)l * msz;
-                    dis = s_mdis[rr];
-                };
-                for (int c = tid; c < nc; c += 256) {
-                    const uint8_t* cj = codes;
-                    const float* t2 = T2;
-                    float dis = 0.f;
-                    locate(c, cj, t2, dis);
-                    uint32_t cw[MT / 4];
-#pragma unroll
-                    for (int u = 0; u < MT / 16; u++) {
-                        const uint4 cv = reinterpret_cast<const uint4*>(cj)[u];
-                        cw[4 * u] = cv.x; cw[4 * u + 1] = cv.y; cw[4 * u + 2] = cv.z; cw[4 * u + 3] = cv.w;
-                    }
-#pragma unroll
-                    for (int m0 = 0; m0 < MT; m0 += 8) {   // eight table entries of each kind in flight at a time
-                        float a[8], b[8];
-#pragma unroll
-                        for (int m = 0; m < 8; m++) {
-                            const int e = (m0 + m) * 256 + ((cw[(m0 + m) >> 2] >> (8 * (m & 3))) & 255u);
-                            a[m] = t2[e];
-                            b[m] = st2q[e];
-                        }
-#pragma unroll
-                        for (int m = 0; m < 8; m++) dis += __builtin_fmaf(-2.0f, b[m], a[m]);
-                    }
-                    s_f[c] = dis;
-                }
-                GH_ST(t_p3);
-                GH_ST_ADD(18, t_pc, t_p3);
-#ifdef GH_SCAN_TIMING
-                if (threadIdx.x == 0 && (blockIdx.x & 127) < 8) { atomicAdd(&g_scan_t[19], (unsigned long long)nc); atomicAdd(&g_scan_t[20], (unsigned long long)n0); }
-#endif
-                // the bound that is published: the K-th smallest exact value's bin over [smallest estimate - eps, tau1] -- at least
-                // recall_num candidates are within tau1 (the recall_num-th smallest exact value of the group is)
-                {
-                    float lo_f = key2f(rmn) - sm;
-                    lo_f -= fabsf(lo_f) * 2.4e-7f;
-                    rmn = dis_key<true>(lo_f);
-                    rmx = dis_key<true>(tau1);
-                }
-                __syncthreads();   // the exact values are in LDS
-                uint32_t tau = min(kth_edge(nc), rmx);
-                tau = min(tau, KEY_SENTINEL - 1u);
-                if (tid == 0)
-                    __hip_atomic_store(&sb.ready[q], (1ull << 32) | tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                GH_ST(t_pp);
-                GH_ST_ADD(4, t_pl, t_pp);
-                GH_ST_ADD(2, t_pc, t_pp);
-                // (kth_edge's last barrier: the histogram, which aliases the staging area, has been read)
-                for (int c0 = 0; c0 < nc; c0 += 256) {   // uniform trip count: append() ballots
-                    const int c = c0 + tid;
-                    const int pos = c < nc ? (int)s_ci[c] : 0;
-                    const float v = c < nc ? s_f[c] : INFINITY;
-                    append(c < nc && dis_key<true>(v) <= tau, v, pos);
-                }
-                flush();
-                GH_ST(t_pe);
-                GH_ST_ADD(5, t_pp, t_pe);
-                return;
-            }
-            // the regular producer after all: nothing has been published or appended
-            __syncthreads();
-            g_fmn = INFINITY;
-            g_fmx = -INFINITY;
-            g_nv = 0;
         }
     }
     if constexpr (C8) {
@@ -1576,7 +1503,8 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
     sb.slice_cap = SCAN_SLICE;
     if (bound) sb = *bound;
     // filter pass for the consumers of a bounded L2 scan: needs the per-code sums (sb.sums) and survivor-only consumers
-    const bool cf = bound && l2 && !pqc_fused && pg_cnt > 1 && sb.sums && sb.t2max && !sb.store_all && (M == 16 || M == 32);
+    const bool cf = bound && l2 && !pqc_fused && (pg_cnt > 1 || (sb.prod_c8 && pg_cnt == 1 && P > G)) && sb.sums && sb.t2max &&
+                    !sb.store_all && (M == 16 || M == 32);
     if (rq_list) {   // repair launch: a fixed grid loops over the flagged (query, group) items
         if (bound || pqc_fused) {
             launch_refused("launch_ivfpq_scan_pair: a repair launch takes neither a bound nor fused tables");
@@ -1588,8 +1516,11 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
         const int per_cu = std::max(1, std::min(8, (int)(160 * 1024 / (lds + 1024))));
         grid.x = (unsigned)std::min<int64_t>(max_units, 256 * per_cu);
     }
-    if (!(cf && sb.c8 && M == 16)) sb.prod_c8 = 0;
-    if (cf) lds += (sb.c8 ? 0 : SCAN_CF_CAP * sizeof(uint2)) + 16 + (sb.prod_c8 ? PC8_CCAP * sizeof(uint16_t) + PC8_MAXG * 24 : 0);
+    if (sb.prod_c8 && !(cf && sb.c8 && M == 16 && pg_cnt == 1 && sb.cnt_stride >= 2 && sb.cf_span == 0)) {
+        launch_refused("launch_ivfpq_scan_pair: one workgroup per query (prod_c8) needs the M = 16 byte-image pass, one group per launch and two slices");
+        return;
+    }
+    if (cf) lds += (sb.c8 ? 0 : SCAN_CF_CAP * sizeof(uint2)) + 16 + (sb.prod_c8 ? PC8_MAXG * 24 + 4096 : 0);
 #define GH_SCAN(LL, MT, FF)                                                                       \
     GH_SCAN4(LL, MT, FF, false)
 #define GH_SCAN4(LL, MT, FF, II) GH_SCAN5(LL, MT, FF, II, false)

@@ -44,6 +44,19 @@ __device__ __forceinline__ uint32_t lut_gather_u8(uint32_t w, int k, int m) {
     return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t*>((uintptr_t)(a + 256u * (uint32_t)m));
 }
 
+// a second byte table at LDS byte BASE
+template <int BASE>
+__device__ __forceinline__ uint32_t lut_gather_u8_at(uint32_t w, int k, int m) {
+    uint32_t a;
+    switch (k) {   // constant after unrolling
+        case 0: asm("v_mov_b32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(a) : "v"(w)); break;
+        case 1: asm("v_mov_b32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(a) : "v"(w)); break;
+        case 2: asm("v_mov_b32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(a) : "v"(w)); break;
+        default: asm("v_lshrrev_b32 %0, 24, %1" : "=v"(a) : "v"(w)); break;
+    }
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t*>((uintptr_t)(a + (uint32_t)BASE + 256u * (uint32_t)m));
+}
+
 // LUT entry e = tid + 256 * i goes to LDS with ds_write_addtid_b32: address = M0 + offset + 4 * lane, no address
 // VGPR, 2 LDS cycles per wave instruction instead of the 4 of ds_write_b32 (MI355X_MICROARCH.md, LDS table).
 // M0 = LDS address of the wave's 256-byte segment of table row 0 (lut_store_begin, once per LUT: an SALU write

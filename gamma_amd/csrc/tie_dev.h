@@ -185,7 +185,7 @@ __device__ __forceinline__ void tie_replay_query(const TieReplayArgs& a, int q, 
     if (sliced) {
         // slices 1.. in order (slice s holds positions of probe group s only, so slices are ordered among
         // themselves); several short slices share one sorting round
-        int s = 1;
+        int s = a.slice0_all ? 0 : 1;
         while (s < a.nsl) {
             __syncthreads();   // the sort buffer is free again
             int n = 0, s_end = s;
@@ -206,7 +206,8 @@ __device__ __forceinline__ void tie_replay_query(const TieReplayArgs& a, int q, 
                     const unsigned long long it = L.it[min(j0 + lane, n - 1)];
                     const uint32_t key = (uint32_t)it;
                     const float val = key2f(L2 ? key : ~key);
-                    take(j0 + lane < n, L2 ? val : -val, (int)(uint32_t)(it >> 32));
+                    // (slice0_all: the first group's survivors are in the slice too -- they went through with the slab part)
+                    take(j0 + lane < n && (int)(uint32_t)(it >> 32) >= n_slab, L2 ? val : -val, (int)(uint32_t)(it >> 32));
                 }
             }
             s = s_end;
