@@ -266,6 +266,7 @@ struct gamma_hip_index {
     // indexes (the inner-product scan has no per-list table to avoid).
     float* d_sums = nullptr;
     float* d_t2max = nullptr;
+    float t2max_all = 0.f;   // max over d_t2max (set with it)
     // L2 table mode (faiss::IndexIVFPQ::use_precomputed_table after train / Load): 1 = the precomputed table T2 is resident,
     // 0 = it would exceed precomputed_table_max_bytes (faiss:IndexIVFPQ.cpp:441-449) -- none is built, L2 searches score with
     // per-(query, list) residual tables (gamma_index_ivfpq.h:239-245).  Decided by Init from nlist * M and the limit.

@@ -613,6 +613,8 @@ int ivfpq_stage_a(H* h, const gamma_hip_search_params* p, const FiltCtx& fc, int
         sb.rq_list = h->w_scnt.as<int>() + 1;
         sb.sums = cf_ok ? h->d_sums : nullptr;
         sb.t2max = cf_ok ? h->d_t2max : nullptr;
+        sb.t2max_all = h->t2max_all;
+        sb.pair_base = h->w_pair_base.as<int64_t>();
         sb.cf_span = cf_ok ? cf_span : 0;
         static const int spins_env = getenv("GAMMA_HIP_SCAN_SPINS") ? atoi(getenv("GAMMA_HIP_SCAN_SPINS")) : 0;
         sb.spins = spins_env;

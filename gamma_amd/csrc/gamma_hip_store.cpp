@@ -1078,6 +1078,12 @@ int gamma_hip_ivfpq_set_trained(gamma_hip_index* h, const float* cc, const float
     }
     GH_CHECK(h, hipGetLastError());
     GH_CHECK(h, hipStreamSynchronize(h->wstream));
+    h->t2max_all = 0.f;
+    if (h->keep_sums && h->d_t2max) {   // the largest of the per-list bounds: the filter pass's margin without a look-up per list
+        std::vector<float> tm((size_t)h->nlist);
+        GH_CHECK(h, hipMemcpy(tm.data(), h->d_t2max, tm.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (float v : tm) h->t2max_all = std::max(h->t2max_all, v);
+    }
     h->trained = true;
     if (h->ntotal > 0) {   // a new table under existing lists: their sums follow it
         GH_TRY(sums_all_lists(h));

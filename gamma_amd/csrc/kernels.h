@@ -197,6 +197,9 @@ struct ScanBound {
     int dbg_part;               // timing experiments only (GAMMA_HIP_SCAN_PART): 1 = consumers leave at once, 2 = producers do
     int c8;                     // != 0 (filter-pass launches only): the consumers' filter pass gathers from a BYTE image of the query's
                                 // table made in the workgroup (2-way bank conflicts at most instead of ~3.5); candidates as ever
+    const int64_t* pair_base;   // filter pass: [nq][P] arena offset of the pair's list (k_pair_offsets) -- with pair_off the pass needs no
+                                // look-up through the list id in front of a list
+    float t2max_all;            // filter pass: max over t2max (the margin's bound S without a look-up per list)
     int prod_c8;                // != 0 (with c8, M = 16, one group per launch, two slices per query): ONE workgroup per query -- the bound from
                                 // byte-image estimates of the first probe group (their recall_num-th smallest + the image's proven error
                                 // width), then the filter pass over ALL probes in the same workgroup (scan.hip, "one workgroup per query").

@@ -647,36 +647,68 @@ __device__ __forceinline__ void scan_pair_body(
             //  gathers at the join behind them, i.e. every step waited for the NEXT step's codes it had just requested)
             auto filter_lists = [&](auto nid_c) {
             constexpr bool NID = decltype(nid_c)::value;
-            for (;;) {
-                int r = 0;
-                if (lane == 0) r = atomicAdd(&s_next, 1);
-                r = __builtin_amdgcn_readfirstlane(r);
-                if (r >= ng) break;
-                const int p = pb + r, pair = q * P + p;
-                const int l = probe_list[pair];
-                if (l < 0 || l >= nlist) continue;            // uniform per wave
-                if (list_mask && !list_mask[l]) continue;
-                const int len = list_len[l];
-                if (len <= 0) continue;
-                const int64_t off = list_off[l];
+            // The wave's lists are pipelined.  What the loop needs of a list -- its codes' place in the arena, its length, dis0, the
+            // position of its first code in the query's row -- is indexed by (query, probe) (pair_off, pair_base, coarse_dis), no
+            // look-up through the list id: every lane holds one list of the group (loaded before the loop), a list's data are four
+            // v_readlane, and the first 64 codes of the wave's NEXT list are requested during the current list's last step.  (Before:
+            // probe -> list id -> length / offset -> codes, three dependent loads a wave waited for at the head of each of its ~7
+            // lists.)  The margin's S takes the largest per-list bound of the index instead of the list's own.
+            constexpr int NSET = C8 ? 1 : 2;   // (the byte-image pass: at most 64 lists per group)
+            int mv_pos[NSET], mv_len[NSET], mv_olo[NSET], mv_ohi[NSET];
+            float mv_dis[NSET];
+#pragma unroll
+            for (int t = 0; t < NSET; t++) {
+                const int rr = t * 64 + lane, p = pb + min(rr, ng - 1);
+                const int* po = pair_off + (int64_t)q * (P + 1) + p;
+                const int o0 = po[0], o1 = po[1];
+                const int64_t bo = sb.pair_base[(int64_t)q * P + p];
+                mv_pos[t] = o0;
+                mv_len[t] = rr < ng ? o1 - o0 : 0;
+                mv_olo[t] = (int)(uint32_t)bo;
+                mv_ohi[t] = (int)(uint32_t)((uint64_t)bo >> 32);
+                mv_dis[t] = coarse_dis[(int64_t)q * P + p];
+            }
+            auto rl = [&](const int (&v)[NSET], int r) -> int {   // (r uniform)
+                if constexpr (NSET == 1) return __builtin_amdgcn_readlane(v[0], r);
+                else return r < 64 ? __builtin_amdgcn_readlane(v[0], r) : __builtin_amdgcn_readlane(v[1], r - 64);
+            };
+            auto grab = [&]() -> int {   // the wave's next list with codes (ng: none)
+                for (;;) {
+                    int r = 0;
+                    if (lane == 0) r = atomicAdd(&s_next, 1);
+                    r = __builtin_amdgcn_readfirstlane(r);
+                    if (r >= ng) return ng;
+                    if (rl(mv_len, r) > 0) return r;
+                }
+            };
+            uint4 cn[MT / 16];
+            float sn = 0.f;
+            auto request_first = [&](int r) {   // the first 64 codes and sums of list r
+                const int len = rl(mv_len, r);
+                const int64_t off = (int64_t)(((uint64_t)(uint32_t)rl(mv_ohi, r) << 32) | (uint32_t)rl(mv_olo, r));
+                const int jc = min(lane, len - 1);
+                const uint4* cp = reinterpret_cast<const uint4*>(codes + (off + jc) * MT);
+#pragma unroll
+                for (int u = 0; u < MT / 16; u++) cn[u] = cp[u];
+                sn = sb.sums[off + jc];
+            };
+            int r_cur = grab();
+            if (r_cur < ng) request_first(r_cur);
+            const float S_q = sb.t2max_all + 32.f * qmax;
+            while (r_cur < ng) {
+                const int p = pb + r_cur, len = rl(mv_len, r_cur), pbase = rl(mv_pos, r_cur);
+                const int64_t off = (int64_t)(((uint64_t)(uint32_t)rl(mv_ohi, r_cur) << 32) | (uint32_t)rl(mv_olo, r_cur));
+                float dis0;
+                if constexpr (NSET == 1) dis0 = __builtin_amdgcn_readlane(mv_dis[0], r_cur);
+                else dis0 = r_cur < 64 ? __builtin_amdgcn_readlane(mv_dis[0], r_cur) : __builtin_amdgcn_readlane(mv_dis[1], r_cur - 64);
                 const uint8_t* lc = codes + off * MT;
                 const float* ls = sb.sums + off;
                 const int64_t* lid = ids + off;
-                const float dis0 = coarse_dis[pair];
-                const int pbase = pair_off[(int64_t)q * (P + 1) + p];
-                const float S = fabsf(dis0) + sb.t2max[l] + 32.f * qmax;
+                const float S = fabsf(dis0) + S_q;
                 float thr = __builtin_fmaf(S, C8 ? 1.f / 65536.f : 1.f / 131072.f, tau_f);
                 thr += fabsf(thr) * (C8 ? 2.4e-7f : 1.2e-7f);   // the threshold's own rounding(s)
                 const float c8_A = dis0 - c8_cq;
-                uint4 cn[MT / 16];
-                float sn;
-                {
-                    const int jc = min(lane, len - 1);
-                    const uint4* cp = reinterpret_cast<const uint4*>(lc + (int64_t)jc * MT);
-#pragma unroll
-                    for (int u = 0; u < MT / 16; u++) cn[u] = cp[u];
-                    sn = ls[jc];
-                }
+                const int r_nxt = grab();
                 for (int j0 = 0; j0 < len; j0 += 64) {
                     const int j = j0 + lane;
                     uint32_t cw[MT / 4];
@@ -691,6 +723,8 @@ __device__ __forceinline__ void scan_pair_body(
 #pragma unroll
                         for (int u = 0; u < MT / 16; u++) cn[u] = cp[u];
                         sn = ls[jc];
+                    } else if (r_nxt < ng) {
+                        request_first(r_nxt);   // ... or the first of the wave's next list
                     }
                     bool ok = j < len;
                     if constexpr (NID) {
@@ -735,6 +769,7 @@ __device__ __forceinline__ void scan_pair_body(
                         }
                     }
                 }
+                r_cur = r_nxt;
             }
             };
             if (need_ids) filter_lists(std::true_type{});
