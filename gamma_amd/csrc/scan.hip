@@ -1551,6 +1551,11 @@ void launch_ivfpq_scan_pair(hipStream_t s, bool l2, const float* x, int nq, int 
         const int per_cu = std::max(1, std::min(8, (int)(160 * 1024 / (lds + 1024))));
         grid.x = (unsigned)std::min<int64_t>(max_units, 256 * per_cu);
     }
+    // the filter pass holds its group's lists one per lane (two registers for the fp32 pass, one for the byte image)
+    if (cf && (!sb.pair_base || (sb.cf_span > 0 ? sb.cf_span : (sb.prod_c8 ? P : P - G)) > (sb.c8 ? 64 : 128))) {
+        launch_refused("launch_ivfpq_scan_pair: the filter pass needs pair_base and at most 64 (byte image) / 128 lists per consumer group");
+        return;
+    }
     if (sb.prod_c8 && !(cf && sb.c8 && M == 16 && pg_cnt == 1 && sb.cnt_stride >= 2 && sb.cf_span == 0)) {
         launch_refused("launch_ivfpq_scan_pair: one workgroup per query (prod_c8) needs the M = 16 byte-image pass, one group per launch and two slices");
         return;
