@@ -1,0 +1,78 @@
+"""Checks on the ISA the toolchain actually produced for the kernels (CPU only: the device code objects are taken out of the
+built libgamma_hip.so and disassembled with llvm-objdump).
+
+Round 6 found, by reading the ISA, that the bounded scan's filter loop -- which requests the NEXT step's codes before the
+current step's byte gathers -- had `s_waitcnt vmcnt(0)` in front of the gathers: the validity predicates' loads in the loop body
+(flat loads through the filter table's pointers) made the compiler's wait-count pass wait for everything at the join behind
+them, so the prefetch never overlapped the gathers (scan 651 -> 613 us once the loop was compiled with and without the
+predicates, profiles/r06_scan_parts.txt).  Nothing in the results shows such a stall; this test does."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "gamma_amd", "libgamma_hip.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
+
+
+def _code_objects(tmp):
+    """every gfx950 code object of the library (one per .hip translation unit)"""
+    fat = os.path.join(tmp, "fat.bin")
+    subprocess.run([os.path.join(LLVM, "llvm-objcopy") if os.path.exists(os.path.join(LLVM, "llvm-objcopy")) else "objcopy",
+                    "--dump-section", ".hip_fatbin=" + fat, LIB], check=True, capture_output=True)
+    data = open(fat, "rb").read()
+    starts = [m.start() for m in re.finditer(re.escape(b"__CLANG_OFFLOAD_BUNDLE__"), data)]
+    out = []
+    for n, (a, b) in enumerate(zip(starts, starts[1:] + [len(data)])):
+        src, dst = os.path.join(tmp, "b%d.bin" % n), os.path.join(tmp, "b%d.co" % n)
+        open(src, "wb").write(data[a:b])
+        r = subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=" + TARGET,
+                            "--input=" + src, "--output=" + dst], capture_output=True, text=True)
+        if r.returncode == 0 and os.path.getsize(dst) > 0:
+            out.append(dst)
+    return out
+
+
+def _disassemble(co, symbol_part):
+    """instruction lines of the first function of `co` whose mangled name contains symbol_part ([] if none)"""
+    syms = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--symbols", "--wide", co], capture_output=True, text=True).stdout
+    names = [ln.split()[-1] for ln in syms.splitlines() if " FUNC " in ln and symbol_part in ln]
+    if not names:
+        return []
+    d = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", "--disassemble-symbols=" + names[0], co],
+                       capture_output=True, text=True).stdout
+    return [ln.strip() for ln in d.splitlines() if ln.startswith(" ") or ln.startswith("\t")]
+
+
+@pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(os.path.join(LLVM, "llvm-objdump")) and
+                         os.path.exists(os.path.join(LLVM, "clang-offload-bundler")) and
+                         (os.path.exists(os.path.join(LLVM, "llvm-objcopy")) or shutil.which("objcopy"))),
+                    reason="needs the built library and the ROCm LLVM tools")
+def test_filter_loop_keeps_its_prefetch_in_flight(tmp_path):
+    """k_ivfpq_scan_pair_c8<16>: in the copy of the filter loop without validity predicates, the global loads of the next step's
+    codes (global_load_dwordx4) are followed by the sixteen byte gathers (ds_read_u8) with NO `s_waitcnt vmcnt(0)` in between."""
+    insns = []
+    for co in _code_objects(str(tmp_path)):
+        insns = _disassemble(co, "k_ivfpq_scan_pair_c8ILi16")
+        if insns:
+            break
+    assert insns, "k_ivfpq_scan_pair_c8<16> not found in the library's code objects"
+    ops = [re.sub(r"\s+", " ", re.sub(r"//.*$", "", ln)).strip() for ln in insns]
+    # the gather groups: sixteen consecutive-ish ds_read_u8; their first one carries no offset
+    firsts = [i for i, o in enumerate(ops) if re.match(r"ds_read_u8 v\d+, v\d+$", o)]
+    assert len(firsts) >= 2, "expected the two copies of the filter loop (with / without predicates), found %d gather groups" % len(firsts)
+    clean = 0
+    for i in firsts:
+        window = ops[max(0, i - 48):i]
+        loads = [j for j, o in enumerate(window) if o.startswith("global_load_dwordx4")]
+        if not loads:
+            continue
+        behind = window[loads[-1]:]
+        if not any(re.match(r"s_waitcnt.*vmcnt\(0\)", o) for o in behind):
+            clean += 1
+    assert clean >= 1, ("every byte-gather group of the filter loop waits for vmcnt(0) behind its prefetch loads: the compiler's "
+                        "wait-count pass is stalling the loop again (see this file's docstring)")
