@@ -671,6 +671,51 @@ __global__ __launch_bounds__(256) void k_select_wave(const float* __restrict__ v
 namespace {
 
 
+// the value of lane ^ STRIDE.  Strides 1, 2, 4, 8 stay inside a row of 16 lanes: DPP moves on the vector ALU (quad_perm for 1 and 2;
+// for 4 and 8 a row shift left for the lanes whose partner is above and a row shift right for the others, each written under its
+// bank mask) -- 18 of a 64-item bitonic sort's 21 stages; __shfl_xor is two ds_bpermute_b32 through the LDS crossbar per 64-bit value,
+// and 168 of those per query were what k_select_final's waves queued for (round 6)
+template <int STRIDE>
+__device__ __forceinline__ uint32_t lane_xor32(uint32_t v) {
+    if constexpr (STRIDE == 1) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
+    else if constexpr (STRIDE == 2) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    else if constexpr (STRIDE == 4) {
+        const int a = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xF, 0x5, false);   // row_shl:4 -> banks 0, 2 (lanes 0-3, 8-11)
+        return (uint32_t)__builtin_amdgcn_update_dpp(a, (int)v, 0x114, 0xF, 0xA, false);     // row_shr:4 -> banks 1, 3
+    } else if constexpr (STRIDE == 8) {
+        const int a = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x108, 0xF, 0x3, false);   // row_shl:8 -> banks 0, 1
+        return (uint32_t)__builtin_amdgcn_update_dpp(a, (int)v, 0x118, 0xF, 0xC, false);     // row_shr:8 -> banks 2, 3
+    } else {
+        return (uint32_t)__shfl_xor((int)v, STRIDE, 64);
+    }
+}
+template <int STRIDE>
+__device__ __forceinline__ unsigned long long lane_xor64(unsigned long long x) {
+    const uint32_t lo = lane_xor32<STRIDE>((uint32_t)x), hi = lane_xor32<STRIDE>((uint32_t)(x >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <int SIZE, int STRIDE>
+__device__ __forceinline__ void bitonic_stage(unsigned long long& x, int lane) {
+    const unsigned long long y = lane_xor64<STRIDE>(x);
+    const bool keep_min = ((lane & STRIDE) == 0) == ((lane & SIZE) == 0);
+    x = ((x < y) == keep_min) ? x : y;
+}
+template <int SIZE, int STRIDE, int N>
+__device__ __forceinline__ void bitonic_size(unsigned long long (&x)[N], int lane) {
+    if constexpr (STRIDE > 0) {
+#pragma unroll
+        for (int r = 0; r < N; r++) bitonic_stage<SIZE, STRIDE>(x[r], lane);
+        bitonic_size<SIZE, (STRIDE >> 1), N>(x, lane);
+    }
+}
+template <int SIZE, int N>
+__device__ __forceinline__ void bitonic_all(unsigned long long (&x)[N], int lane) {
+    if constexpr (SIZE <= 64) {
+        bitonic_size<SIZE, (SIZE >> 1), N>(x, lane);
+        bitonic_all<SIZE * 2, N>(x, lane);
+    }
+}
+
 // ascending bitonic sort of 64 items, one per lane
 __device__ __forceinline__ unsigned long long wave_sort64(unsigned long long x) {
     const int lane = threadIdx.x & 63;
@@ -685,6 +730,12 @@ __device__ __forceinline__ unsigned long long wave_sort64(unsigned long long x) 
     }
     return x;
 }
+// N independent sorts, stage by stage: the 2 N cross-lane moves of a stage are in flight together (one sort after the other is a
+// chain of 21 N dependent LDS-crossbar round trips: 20 k of k_select_final's 40 k cycles per query, s_memtime, round 6)
+template <int N>
+__device__ __forceinline__ void wave_sort64_multi(unsigned long long (&x)[N]) {
+    bitonic_all<2, N>(x, (int)(threadIdx.x & 63));
+}
 }  // namespace
 
 namespace {
@@ -694,7 +745,7 @@ constexpr int SF_CAND = 384;   // candidates of one query held in LDS (first gro
 
 template <bool SMALLEST, int PMAX, int NR = 4>   // PMAX: 64 or 128 probes per query; NR: sorted runs of 64 (K <= 64 NR: 4, or 8 for
                                                   // recall_num 257 ... 512, round 6 -- the workgroup-per-query kernel took 0.9 ms there against 0.1)
-__global__ __launch_bounds__(256) void k_select_final(const unsigned long long* __restrict__ surv,
+__device__ __forceinline__ void select_final_body(const unsigned long long* __restrict__ surv,
                                                       const int* __restrict__ gcnt, int nslices,
                                                       int slice_cap,
                                                       const unsigned long long* __restrict__ ready,
@@ -899,8 +950,7 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
 #pragma unroll
     for (int r = 0; r < NR; r++) x[r] = (r * 64 + lane < m) ? runs[r * 64 + lane] : ~0ull;
     __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int r = 0; r < NR; r++) x[r] = wave_sort64(x[r]);
+    wave_sort64_multi<NR>(x);
 #pragma unroll
     for (int r = 0; r < NR; r++) runs[r * 64 + lane] = x[r];
     __builtin_amdgcn_wave_barrier();
@@ -981,6 +1031,35 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long* 
         out_ids[(int64_t)q * K + r] = -1;
     }
 }
+
+// the kernels: four runs (recall_num <= 256) under a 64-register budget -- eight waves per SIMD: the kernel is a chain of dependent
+// loads per wave (bound word + counts -> slices -> ids), what it gains from is waves in flight (93.8 against 96.5 us at C3) -- and
+// eight runs (recall_num <= 512: 99 registers) without one
+#define GH_SF_PARAMS                                                                                                          \
+    const unsigned long long *__restrict__ surv, const int *__restrict__ gcnt, int nslices, int slice_cap,                    \
+        const unsigned long long *__restrict__ ready, const int *__restrict__ pair_off, int P, int nq, int K,                 \
+        const int64_t *__restrict__ pair_base, const int64_t *__restrict__ ids, uint8_t *__restrict__ flag,                   \
+        float *__restrict__ out_vals, int *__restrict__ out_pos, int64_t *__restrict__ out_ids, uint8_t *__restrict__ cut_tie, \
+        unsigned long long *__restrict__ tie_stats, int *__restrict__ rq_list, int *__restrict__ rq_count,                    \
+        unsigned long long *__restrict__ bound_stat
+#define GH_SF_ARGS                                                                                                                   \
+    surv, gcnt, nslices, slice_cap, ready, pair_off, P, nq, K, pair_base, ids, flag, out_vals, out_pos, out_ids, cut_tie, tie_stats, \
+        rq_list, rq_count, bound_stat
+// (PMAX = 128: the pair tables in LDS leave seven waves per SIMD whatever the registers -- the budget still holds, the compiler says so)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wpass-failed"
+template <bool SMALLEST, int PMAX, int NR = 4>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_select_final(GH_SF_PARAMS) {
+    static_assert(NR == 4, "the 64-register variant");
+    select_final_body<SMALLEST, PMAX, 4>(GH_SF_ARGS);
+}
+#pragma clang diagnostic pop
+template <bool SMALLEST, int PMAX>
+__global__ __launch_bounds__(256) void k_select_final8(GH_SF_PARAMS) {
+    select_final_body<SMALLEST, PMAX, 8>(GH_SF_ARGS);
+}
+#undef GH_SF_PARAMS
+#undef GH_SF_ARGS
 
 // ------------------------------------------------------------------------------------
 // k_select_final_wg: the same selection for 256 < K <= 1024 (round 5: the bounded scan's gate was recall_num <= 256, and the
@@ -1810,7 +1889,7 @@ void launch_select_final(hipStream_t s, bool smallest, const unsigned long long*
     static const bool no_wave8 = getenv("GAMMA_HIP_NO_SELECT_WAVE8") != nullptr;
     if (K > 256 && K <= 512 && nslices <= 64 && !no_wave8) {   // a wave per query with eight sorted runs
 #define GH_SF8(SM, PM)                                                                                           \
-    hipLaunchKernelGGL((k_select_final<SM, PM, 8>), dim3((nq + 3) / 4), dim3(256), 0, s, surv, gcnt, nslices,   \
+    hipLaunchKernelGGL((k_select_final8<SM, PM>), dim3((nq + 3) / 4), dim3(256), 0, s, surv, gcnt, nslices,   \
                        slice_cap, ready, pair_off, P, nq, K, pair_base, ids, flag,                               \
                        out_vals, out_pos, out_ids, cut_tie, tie_stats, rq_list, rq_count, bound_stat)
         if (smallest) {
