@@ -718,17 +718,9 @@ __device__ __forceinline__ void bitonic_all(unsigned long long (&x)[N], int lane
 
 // ascending bitonic sort of 64 items, one per lane
 __device__ __forceinline__ unsigned long long wave_sort64(unsigned long long x) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int size = 2; size <= 64; size <<= 1) {
-#pragma unroll
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            const unsigned long long y = __shfl_xor(x, stride, 64);
-            const bool keep_min = ((lane & stride) == 0) == ((lane & size) == 0);
-            x = ((x < y) == keep_min) ? x : y;
-        }
-    }
-    return x;
+    unsigned long long a[1] = {x};
+    bitonic_all<2, 1>(a, (int)(threadIdx.x & 63));
+    return a[0];
 }
 // N independent sorts, stage by stage: the 2 N cross-lane moves of a stage are in flight together (one sort after the other is a
 // chain of 21 N dependent LDS-crossbar round trips: 20 k of k_select_final's 40 k cycles per query, s_memtime, round 6)
