@@ -98,4 +98,64 @@ __device__ __forceinline__ void block_rank_sort(unsigned long long* a, int n) {
     __syncthreads();
 }
 
+
+// ---- 64-item wave sorts ----
+// the value of lane ^ STRIDE.  Strides 1, 2, 4, 8 stay inside a row of 16 lanes: DPP moves on the vector ALU (quad_perm for 1 and 2;
+// for 4 and 8 a row shift left for the lanes whose partner is above and a row shift right for the others, each written under its
+// bank mask) -- 18 of a 64-item bitonic sort's 21 stages; __shfl_xor is two ds_bpermute_b32 through the LDS crossbar per 64-bit value,
+// and 168 of those per query were what k_select_final's waves queued for (round 6)
+template <int STRIDE>
+__device__ __forceinline__ uint32_t lane_xor32(uint32_t v) {
+    if constexpr (STRIDE == 1) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
+    else if constexpr (STRIDE == 2) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    else if constexpr (STRIDE == 4) {
+        const int a = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xF, 0x5, false);   // row_shl:4 -> banks 0, 2 (lanes 0-3, 8-11)
+        return (uint32_t)__builtin_amdgcn_update_dpp(a, (int)v, 0x114, 0xF, 0xA, false);     // row_shr:4 -> banks 1, 3
+    } else if constexpr (STRIDE == 8) {
+        const int a = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x108, 0xF, 0x3, false);   // row_shl:8 -> banks 0, 1
+        return (uint32_t)__builtin_amdgcn_update_dpp(a, (int)v, 0x118, 0xF, 0xC, false);     // row_shr:8 -> banks 2, 3
+    } else {
+        return (uint32_t)__shfl_xor((int)v, STRIDE, 64);
+    }
+}
+template <int STRIDE>
+__device__ __forceinline__ unsigned long long lane_xor64(unsigned long long x) {
+    const uint32_t lo = lane_xor32<STRIDE>((uint32_t)x), hi = lane_xor32<STRIDE>((uint32_t)(x >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <int SIZE, int STRIDE>
+__device__ __forceinline__ void bitonic_stage(unsigned long long& x, int lane) {
+    const unsigned long long y = lane_xor64<STRIDE>(x);
+    const bool keep_min = ((lane & STRIDE) == 0) == ((lane & SIZE) == 0);
+    x = ((x < y) == keep_min) ? x : y;
+}
+template <int SIZE, int STRIDE, int N>
+__device__ __forceinline__ void bitonic_size(unsigned long long (&x)[N], int lane) {
+    if constexpr (STRIDE > 0) {
+#pragma unroll
+        for (int r = 0; r < N; r++) bitonic_stage<SIZE, STRIDE>(x[r], lane);
+        bitonic_size<SIZE, (STRIDE >> 1), N>(x, lane);
+    }
+}
+template <int SIZE, int N>
+__device__ __forceinline__ void bitonic_all(unsigned long long (&x)[N], int lane) {
+    if constexpr (SIZE <= 64) {
+        bitonic_size<SIZE, (SIZE >> 1), N>(x, lane);
+        bitonic_all<SIZE * 2, N>(x, lane);
+    }
+}
+
+// ascending bitonic sort of 64 items, one per lane
+__device__ __forceinline__ unsigned long long wave_sort64(unsigned long long x) {
+    unsigned long long a[1] = {x};
+    bitonic_all<2, 1>(a, (int)(threadIdx.x & 63));
+    return a[0];
+}
+// N independent sorts, stage by stage: the 2 N cross-lane moves of a stage are in flight together (one sort after the other is a
+// chain of 21 N dependent LDS-crossbar round trips: 20 k of k_select_final's 40 k cycles per query, s_memtime, round 6)
+template <int N>
+__device__ __forceinline__ void wave_sort64_multi(unsigned long long (&x)[N]) {
+    bitonic_all<2, N>(x, (int)(threadIdx.x & 63));
+}
+
 }  // namespace gh

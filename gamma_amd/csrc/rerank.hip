@@ -289,7 +289,64 @@ __global__ __launch_bounds__(256) void k_rerank_topk(const float* __restrict__ x
         }
     }
     if (tf.list && threadIdx.x == 0) s_tie = tf.cut ? tf.cut[q] : 0;
-    block_rank_sort<256, 4>(s_it, R);   // R distinct items (the rank field differs)
+    // Only the first k + 1 items are read below (the k results; whether two of the first k + 1 exact distances are equal).  Up to
+    // k + 1 = 64: every 64-item run of the R items is sorted by a wave (DPP bitonic stages), the first k + 1 items of a run get
+    // their rank in the whole -- their index in the run + the number of smaller items in every other run (binary searches) --
+    // and the items of rank < k + 1 go to their place: the same first k + 1 entries the full rank sort leaves.  (The full sort
+    // ranks all R items against all R: 200 LDS reads and 600 vector instructions per thread, ~100 of the kernel's 283 us at C3.)
+    const int K1 = min(k + 1, R);
+    if (K1 <= 64) {   // (uniform)
+        const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int nruns = (R + 63) >> 6;   // <= 16
+        __syncthreads();   // every distance is in s_it
+        for (int run = w; run < nruns; run += 4) {
+            const int idx = run * 64 + lane;
+            s_it[idx] = wave_sort64(idx < R ? s_it[idx] : ~0ull);   // (padding sorts last; s_it holds 1024 items)
+        }
+        __syncthreads();
+        unsigned long long xr[4];
+        int rkk[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int run = w + 4 * u;
+            xr[u] = ~0ull;
+            rkk[u] = K1;
+            if (run < nruns) {   // (uniform)
+                const unsigned long long x = s_it[run * 64 + lane];
+                int rank = lane;
+                if (lane < K1 && x != ~0ull) {
+                    for (int o = 0; o < nruns; o++) {
+                        if (o == run) continue;
+                        const unsigned long long* ro = s_it + o * 64;
+                        int lo = 0, n2 = 64;
+#pragma unroll
+                        for (int st = 0; st < 7; st++) {   // number of items of run o smaller than x
+                            if (n2 > 0) {
+                                const int half = n2 >> 1;
+                                if (ro[lo + half] < x) {
+                                    lo += half + 1;
+                                    n2 -= half + 1;
+                                } else {
+                                    n2 = half;
+                                }
+                            }
+                        }
+                        rank += lo;
+                        if (rank >= K1) break;
+                    }
+                    xr[u] = x;
+                    rkk[u] = rank;
+                }
+            }
+        }
+        __syncthreads();   // every search has read the runs
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (rkk[u] < K1) s_it[rkk[u]] = xr[u];
+        __syncthreads();
+    } else {
+        block_rank_sort<256, 4>(s_it, R);   // R distinct items (the rank field differs)
+    }
     if (tf.list) {
         // exact ties (ties.hip): two of the first k+1 exact distances equal -- their order, or which of them
         // stays inside the k, is decided by the reference's heaps -- or the top-R cut went through a tie
