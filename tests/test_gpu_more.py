@@ -140,6 +140,19 @@ def test_other_shapes(cfg, metric):
         g.close()
 
 
+@pytest.mark.parametrize("R,k", [(64, 63), (65, 63), (65, 64), (130, 129), (200, 10), (200, 63), (200, 64), (257, 1), (1000, 63),
+                                 (1024, 40), (1024, 200)])
+@pytest.mark.parametrize("metric", [B.METRIC_L2, B.METRIC_IP])
+def test_rerank_reads_only_its_first_k_plus_one(case, hip, R, k, metric):
+    """k_rerank_topk (csrc/rerank.hip, round 6): up to k + 1 = 64 the recall_num exact distances are not rank-sorted in full --
+    64-item runs sorted by waves, the runs' first k + 1 items ranked against the other runs -- beyond it the full rank sort.
+    recall_num on both sides of the run boundaries (64, 65, 130, 257, 1000, 1024), k + 1 on both sides of 64; results and the
+    recall-stage tables identical to the oracle's at every rank, exact ties on."""
+    (D, I, st), (Dg, Ig) = run_both(case, hip, case["q"], k, 24, R, metric, True, coarse_mode=1)
+    sg = hip.last_stages(len(case["q"]), 24, R)
+    compare_search_exact(D, I, st, Dg, Ig, sg)
+
+
 # --------------------------------------------------------------------------- flat
 @pytest.mark.parametrize("metric", [B.METRIC_L2, B.METRIC_IP])
 @pytest.mark.parametrize("d", [128, 32, 20])
