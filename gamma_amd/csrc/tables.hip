@@ -107,7 +107,9 @@ __global__ __launch_bounds__(256) void k_pq_ip_table4(const float* __restrict__ 
         o.y = fvec_ny_row<false>(xv, c[1], DSUB);
         o.z = fvec_ny_row<false>(xv, c[2], DSUB);
         o.w = fvec_ny_row<false>(xv, c[3], DSUB);
-        *reinterpret_cast<float4*>(out + ((int64_t)q * M + m) * 256 + 4 * lane) = o;
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        f4v ov = {o.x, o.y, o.z, o.w};
+        __builtin_nontemporal_store(ov, reinterpret_cast<f4v*>(out + ((int64_t)q * M + m) * 256 + 4 * lane));
     }
 }
 void launch_pq_ip_table(hipStream_t s, const float* x, int nq, int d, int M, const float* pqc,
