@@ -76,3 +76,30 @@ def test_filter_loop_keeps_its_prefetch_in_flight(tmp_path):
             clean += 1
     assert clean >= 1, ("every byte-gather group of the filter loop waits for vmcnt(0) behind its prefetch loads: the compiler's "
                         "wait-count pass is stalling the loop again (see this file's docstring)")
+
+
+@pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(os.path.join(LLVM, "llvm-objdump")) and
+                         os.path.exists(os.path.join(LLVM, "clang-offload-bundler")) and
+                         (os.path.exists(os.path.join(LLVM, "llvm-objcopy")) or shutil.which("objcopy"))),
+                    reason="needs the built library and the ROCm LLVM tools")
+@pytest.mark.parametrize("kernel", ["k_q8_filterILi32ELb0", "k_q8_filterILi16ELb0", "k_q8_filter_slILi16ELb0"])
+def test_list_major_filter_keeps_its_prefetch_in_flight(tmp_path, kernel):
+    """q8scan.hip, the kernels compiled WITHOUT validity predicates (template parameter NID = false): the codes of the next steps are
+    requested (global_load) in front of the step's gathers (ds_read_b64) with no `s_waitcnt vmcnt(0)` in between -- the same stall
+    as in the query-major loop, the same fix."""
+    insns = []
+    for co in _code_objects(str(tmp_path)):
+        insns = _disassemble(co, kernel)
+        if insns:
+            break
+    assert insns, kernel + " not found in the library's code objects"
+    ops = [re.sub(r"\s+", " ", re.sub(r"//.*$", "", ln)).strip() for ln in insns]
+    firsts = [i for i, o in enumerate(ops) if o.startswith("ds_read_b64") and not ops[i - 1].startswith("ds_read_b64")
+              and not ops[i - 2].startswith("ds_read_b64")]
+    clean = 0
+    for i in firsts:
+        window = ops[max(0, i - 60):i]
+        loads = [j for j, o in enumerate(window) if o.startswith("global_load")]
+        if loads and not any(re.match(r"s_waitcnt.*vmcnt\(0\)", o) for o in window[loads[-1]:]):
+            clean += 1
+    assert clean >= 1, "no gather group of " + kernel + " has its prefetch loads directly ahead without a vmcnt(0) wait"
